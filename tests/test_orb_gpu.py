@@ -1,0 +1,103 @@
+"""GPU parity: HIP ORB front-end (through the C-ABI) vs the CPU oracle, bit-exact at every stage.
+Oracle = restatement of vido_slam/src/ORBextractor.cc (see oracle/orb_oracle.c)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(vido):
+    c = vido.Context(width=640, height=480, max_batch=4)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def frames(vido):
+    from vido_slam_amd import synth
+    return synth.make_batch(4, 640, 480, seed=11)
+
+
+def test_pyramid_fast_blur_bit_exact(ctx, frames, oracle):
+    p = oracle.orb_params()
+    kps, desc, cnt = ctx.orb_extract_batch(frames)
+    for f in (0, 3):
+        levels = oracle.orb_pyramid(p, frames[f])
+        for l in range(8):
+            got = ctx.orb_level(f, l)
+            assert got.shape == levels[l].shape
+            assert np.array_equal(got, levels[l]), (f, l)
+            assert np.array_equal(ctx.orb_level(f, l, blurred=True), oracle.gaussian_blur7(levels[l])), (f, l)
+            cx, cy, cr = oracle.level_candidates(p, levels[l])
+            gx, gy, gs = ctx.orb_candidates(f, l)
+            assert len(gx) == len(cx), (f, l, len(gx), len(cx))
+            assert np.array_equal(gx - 16, cx.astype(np.int32)) and np.array_equal(gy - 16, cy.astype(np.int32)), (f, l)
+            assert np.array_equal(gs, cr.astype(np.int32)), (f, l)
+
+
+def test_keypoints_and_descriptors_bit_exact(ctx, frames, oracle):
+    p = oracle.orb_params()
+    kps, desc, cnt = ctx.orb_extract_batch(frames)
+    for f in range(len(frames)):
+        rk, rd, _ = oracle.orb_extract(p, frames[f])
+        assert cnt[f] == len(rk)
+        k = kps[f, :cnt[f]]
+        for name in ("x", "y", "size", "angle", "response", "octave"):
+            assert np.array_equal(k[name], rk[name]), (f, name)
+        assert np.array_equal(desc[f, :cnt[f]], rd), f
+
+
+def test_single_frame_entry_matches_batch(ctx, frames):
+    k1, d1 = ctx.orb_extract(frames[2])
+    kps, desc, cnt = ctx.orb_extract_batch(frames)
+    assert len(k1) == cnt[2]
+    assert np.array_equal(k1, kps[2, :cnt[2]]) and np.array_equal(d1, desc[2, :cnt[2]])
+
+
+@pytest.mark.parametrize("size", [(752, 480), (320, 240), (1241, 376)])
+def test_other_frame_sizes(vido, oracle, size):
+    from vido_slam_amd import synth
+    w, h = size
+    g = synth.make_frame(w, h, seed=5)
+    c = vido.Context(width=w, height=h, max_batch=1, n_features=2500)
+    k, d = c.orb_extract(g)
+    p = oracle.orb_params(n_features=2500)
+    rk, rd, _ = oracle.orb_extract(p, g)
+    assert len(k) == len(rk)
+    for name in ("x", "y", "size", "angle", "response", "octave"):
+        assert np.array_equal(k[name], rk[name]), name
+    assert np.array_equal(d, rd)
+    c.close()
+
+
+def test_flat_and_noise_images(vido, oracle):
+    c = vido.Context(width=640, height=480, max_batch=1)
+    flat = np.full((480, 640), 77, np.uint8)
+    k, d = c.orb_extract(flat)
+    assert len(k) == 0
+    rng = np.random.RandomState(0)
+    noise = rng.randint(0, 256, size=(480, 640)).astype(np.uint8)     # worst case: corners everywhere
+    p = oracle.orb_params()
+    try:
+        k, d = c.orb_extract(noise)
+    except vido.VidoError as e:
+        assert e.code == -4      # documented capacity limit, reported loudly
+    else:
+        rk, rd, _ = oracle.orb_extract(p, noise)
+        assert len(k) == len(rk) and np.array_equal(d, rd)
+    c.close()
+
+
+def test_hamming_matches_oracle(ctx, oracle):
+    rng = np.random.RandomState(1)
+    for na, nb in ((1, 1), (7, 300), (256, 256), (2000, 2011), (33, 64)):
+        a = rng.randint(0, 256, size=(na, 32)).astype(np.uint8)
+        b = rng.randint(0, 256, size=(nb, 32)).astype(np.uint8)
+        b[nb // 2] = a[0]; 
+        if nb > 3: b[3] = b[1]                 # duplicate -> tie must resolve to the lower index
+        idx, dist = ctx.hamming_match(a, b)
+        ri, rd = oracle.hamming_match(a, b)
+        assert np.array_equal(idx, ri) and np.array_equal(dist, rd), (na, nb)
+    idx, dist = ctx.hamming_match(np.zeros((5, 32), np.uint8), np.zeros((0, 32), np.uint8))
+    assert (idx == -1).all() and (dist == -1).all()

@@ -1,0 +1,59 @@
+// common.hpp — ctx layout and error plumbing shared by the HIP translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/vido_c.h"
+
+#define VIDO_CELL_CAP 128          // FAST survivors kept per ~30x30 cell (NMS'd corners; >CAP => VIDO_E_CAPACITY)
+#define VIDO_MAX_CAND_PER_FRAME 49152
+
+struct LevelInfo {
+    int w, h, pitch;               // level size, row pitch in bytes (multiple of 64)
+    int off;                       // byte offset of the level inside one frame's pyramid slab
+    int first_cell, n_cells;       // cells of this level inside the cell table (reference order)
+    int xtab_off, ytab_off;        // offsets (elements) into the resize tables
+    int n_budget;                  // mnFeaturesPerLevel
+    float scale;                   // mvScaleFactor
+};
+
+struct PyrDev {                    // passed by value to kernels
+    int n_levels;
+    int w[VIDO_MAX_LEVELS], h[VIDO_MAX_LEVELS], pitch[VIDO_MAX_LEVELS], off[VIDO_MAX_LEVELS];
+};
+
+struct CellDesc { int level, x0, y0, sw, sh, pad0, pad1, pad2; };   // FAST sub-image of one cell (level coords)
+struct BlurTile { int level, tx, ty, pad; };
+
+struct OrbState;                   // orb.hip
+struct TrackState;                 // track.hip
+struct BaState;                    // ba.hip
+
+struct vido_ctx {
+    vido_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;
+    std::string err;
+    char dev_name[256] = {0};
+    OrbState* orb = nullptr;
+    TrackState* trk = nullptr;
+    BaState* ba = nullptr;
+};
+
+int vido_set_error(vido_ctx* ctx, int code, const char* fmt, ...);
+
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return vido_set_error((ctx), VIDO_E_HIP, "%s failed: %s (%s:%d)", #expr,       \
+                                  hipGetErrorString(_e), __FILE__, __LINE__);               \
+    } while (0)
+
+int orb_state_create(vido_ctx* ctx);
+void orb_state_destroy(vido_ctx* ctx);

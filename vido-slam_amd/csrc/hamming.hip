@@ -1,0 +1,102 @@
+// hamming.hip — brute-force 256-bit Hamming matcher on gfx950.
+// No reference call site exists (the reference associates features by optical flow only,
+// SURVEY.md fact 2); BASELINE.json north_star asks for it: for every query descriptor the closest
+// train descriptor, smallest distance, lowest index on ties.
+// Mapping: one wave64 owns QW=8 queries (wave-uniform, kept in scalar registers) and streams a slab
+// of the train set: lane j loads train descriptor j (32 B, coalesced 2 KiB per wave load), scores it
+// against the 8 queries with v_bcnt (popcount-accumulate), keeps a per-lane running minimum, then a
+// wavefront-shuffle (DPP) reduction picks the wave minimum; slabs are combined with a 64-bit
+// atomicMin on (distance<<32 | index), which also implements the lowest-index tie rule.
+#include "common.hpp"
+
+#define QW 8
+
+__global__ __launch_bounds__(256) void k_hamming(const uint32_t* __restrict__ A, int na, const uint32_t* __restrict__ Bd, int nb,
+                                                 int slab, unsigned long long* __restrict__ best)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + wave) * QW);
+    if (q0 >= na) return;
+    uint32_t Q[QW][8];
+#pragma unroll
+    for (int q = 0; q < QW; q++) {
+        const int qi = min(q0 + q, na - 1);
+#pragma unroll
+        for (int w = 0; w < 8; w++) Q[q][w] = A[(size_t)qi * 8 + w];       // wave-uniform address -> scalar loads
+    }
+    const int jbeg = blockIdx.y * slab, jend = min(jbeg + slab, nb);
+    unsigned long long loc[QW];
+#pragma unroll
+    for (int q = 0; q < QW; q++) loc[q] = ~0ull;
+    for (int j = jbeg + lane; j < jend; j += 64) {
+        const uint4 b0 = *(const uint4*)(Bd + (size_t)j * 8), b1 = *(const uint4*)(Bd + (size_t)j * 8 + 4);
+#pragma unroll
+        for (int q = 0; q < QW; q++) {
+            int d = __popc(b0.x ^ Q[q][0]) + __popc(b0.y ^ Q[q][1]) + __popc(b0.z ^ Q[q][2]) + __popc(b0.w ^ Q[q][3]) +
+                    __popc(b1.x ^ Q[q][4]) + __popc(b1.y ^ Q[q][5]) + __popc(b1.z ^ Q[q][6]) + __popc(b1.w ^ Q[q][7]);
+            const unsigned long long key = ((unsigned long long)(uint32_t)d << 32) | (uint32_t)j;
+            loc[q] = key < loc[q] ? key : loc[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QW; q++) {
+        unsigned long long v = loc[q];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned long long other = __shfl_xor(v, o, 64);
+            v = other < v ? other : v;
+        }
+        if (lane == 0 && q0 + q < na && v != ~0ull) atomicMin(&best[q0 + q], v);
+    }
+}
+
+__global__ void k_hamming_finish(const unsigned long long* __restrict__ best, int na, int* __restrict__ idx, int* __restrict__ dist)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na) return;
+    const unsigned long long v = best[i];
+    if (v == ~0ull) { idx[i] = -1; dist[i] = -1; }
+    else { idx[i] = (int)(uint32_t)v; dist[i] = (int)(v >> 32); }
+}
+
+extern "C" int vido_hamming_match(vido_ctx* ctx, const uint8_t* a, int na, const uint8_t* b, int nb,
+                                  int32_t* idx_out, int32_t* dist_out, int on_device)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (na < 0 || nb < 0 || (na > 0 && (!a || !idx_out || !dist_out)) || (nb > 0 && !b))
+        return vido_set_error(ctx, VIDO_E_INVALID, "hamming: bad arguments");
+    if (na == 0) return VIDO_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint8_t *da = a, *db = b; int *didx = idx_out, *ddist = dist_out;
+    uint8_t *ta = nullptr, *tb = nullptr; int* tidx = nullptr; int* tdist = nullptr; unsigned long long* best = nullptr;
+    HIP_TRY(ctx, hipMallocAsync((void**)&best, (size_t)na * 8, st));
+    if (!on_device) {
+        HIP_TRY(ctx, hipMallocAsync((void**)&ta, (size_t)na * 32, st));
+        HIP_TRY(ctx, hipMallocAsync((void**)&tb, (size_t)std::max(nb, 1) * 32, st));
+        HIP_TRY(ctx, hipMallocAsync((void**)&tidx, (size_t)na * 4, st));
+        HIP_TRY(ctx, hipMallocAsync((void**)&tdist, (size_t)na * 4, st));
+        HIP_TRY(ctx, hipMemcpyAsync(ta, a, (size_t)na * 32, hipMemcpyHostToDevice, st));
+        if (nb > 0) HIP_TRY(ctx, hipMemcpyAsync(tb, b, (size_t)nb * 32, hipMemcpyHostToDevice, st));
+        da = ta; db = tb; didx = tidx; ddist = tdist;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(best, 0xff, (size_t)na * 8, st));
+    if (nb > 0) {
+        const int qblocks = (na + 4 * QW - 1) / (4 * QW);
+        // enough train slabs that the grid has >= ~2048 workgroups, slabs a multiple of 64 descriptors
+        int nsl = std::max(1, std::min((nb + 63) / 64, (2048 + qblocks - 1) / qblocks));
+        int slab = ((nb + nsl - 1) / nsl + 63) & ~63;
+        nsl = (nb + slab - 1) / slab;
+        hipLaunchKernelGGL(k_hamming, dim3(qblocks, nsl), dim3(256), 0, st, (const uint32_t*)da, na, (const uint32_t*)db, nb, slab, best);
+    }
+    hipLaunchKernelGGL(k_hamming_finish, dim3((na + 255) / 256), dim3(256), 0, st, best, na, didx, ddist);
+    HIP_TRY(ctx, hipGetLastError());
+    if (!on_device) {
+        HIP_TRY(ctx, hipMemcpyAsync(idx_out, tidx, (size_t)na * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(dist_out, tdist, (size_t)na * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipFreeAsync(ta, st)); HIP_TRY(ctx, hipFreeAsync(tb, st)); HIP_TRY(ctx, hipFreeAsync(tidx, st)); HIP_TRY(ctx, hipFreeAsync(tdist, st));
+    }
+    HIP_TRY(ctx, hipFreeAsync(best, st));
+    if (!on_device) HIP_TRY(ctx, hipStreamSynchronize(st));
+    return VIDO_OK;
+}

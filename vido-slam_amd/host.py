@@ -1,0 +1,187 @@
+"""Host-side Python mirror of the reference's operator interface over the C-ABI (include/vido_c.h).
+
+The reference's host is C++ (`VIDO_SLAM::ORBextractor`, `Frame`, `Optimizer` — see the C++ facade under
+include/vido_slam/); this module is the ctypes binding the parity tests, bench.py and smoke() drive.
+Names follow the reference: `ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)` is
+called with a gray image and returns (keypoints, descriptors) like ORBextractor::operator()
+(vido_slam/include/ORBextractor.h:39-49).
+
+There is no CPU path here: if libvido_slam_hip.so is missing or no gfx950 device is visible every call
+raises VidoError.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvido_slam_hip.so")
+
+VIDO_OK = 0
+KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"), ("octave", "i4")])
+
+
+class VidoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("vido error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("max_batch", C.c_int32),
+                ("n_features", C.c_int32), ("scale_factor", C.c_float), ("n_levels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("compute_descriptors", C.c_int32),
+                ("host_threads", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VidoError(-2, "%s not built: run `python __graft_entry__.py` (build()) first; there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.vido_last_error.restype = C.c_char_p
+    lib.vido_last_error.argtypes = [C.c_void_p]
+    lib.vido_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    lib.vido_destroy.argtypes = [C.c_void_p]
+    lib.vido_stream.restype = C.c_void_p
+    lib.vido_stream.argtypes = [C.c_void_p]
+    lib.vido_synchronize.argtypes = [C.c_void_p]
+    lib.vido_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.vido_orb_extract_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.vido_orb_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.vido_orb_read_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.vido_orb_read_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    lib.vido_orb_last_timing.argtypes = [C.c_void_p, C.c_void_p]
+    lib.vido_hamming_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    lib.vido_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    _lib = lib
+    return lib
+
+
+def default_config(**kw):
+    cfg = Config()
+    load_library().vido_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One vido_ctx: one HIP stream + device arena on one GPU."""
+
+    def __init__(self, **kw):
+        self.lib = load_library()
+        self.cfg = default_config(**kw)
+        h = C.c_void_p()
+        rc = self.lib.vido_create(C.byref(self.cfg), C.byref(h))
+        if rc != VIDO_OK:
+            raise VidoError(rc, self.lib.vido_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vido_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise VidoError(rc, self.lib.vido_last_error(self.h).decode())
+        return rc
+
+    @property
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.vido_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    @property
+    def stream(self):
+        return self.lib.vido_stream(self.h)
+
+    def synchronize(self):
+        self._check(self.lib.vido_synchronize(self.h))
+
+    # ---- ORB -----------------------------------------------------------------------------------
+    @property
+    def max_kp(self):
+        return self.cfg.n_features * 2 + 256
+
+    def orb_extract(self, gray):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        kps = np.zeros(self.max_kp, KP_DTYPE); desc = np.zeros((self.max_kp, 32), np.uint8); n = C.c_int()
+        self._check(self.lib.vido_orb_extract(self.h, _ptr(gray), w, w, h, _ptr(kps), self.max_kp, C.byref(n), _ptr(desc)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def orb_extract_batch(self, imgs, want_desc=True):
+        """imgs: (n,h,w) u8 numpy array (host) or a (device_ptr, n, h, w, frame_stride, row_stride) tuple."""
+        if isinstance(imgs, tuple):
+            ptr, n, h, w, fstride, rstride = imgs
+            on_dev = 1
+        else:
+            imgs = np.ascontiguousarray(imgs, np.uint8)
+            n, h, w = imgs.shape
+            ptr, fstride, rstride, on_dev = imgs.ctypes.data, h * w, w, 0
+        kps = np.zeros((n, self.max_kp), KP_DTYPE)
+        desc = np.zeros((n, self.max_kp, 32), np.uint8) if want_desc else None
+        cnt = np.zeros(n, np.int32)
+        self._check(self.lib.vido_orb_extract_batch(self.h, C.c_void_p(ptr), on_dev, n, fstride, rstride, w, h, _ptr(kps), self.max_kp,
+                                                    _ptr(cnt), _ptr(desc) if want_desc else None))
+        return kps, desc, cnt
+
+    def orb_level(self, frame, level, blurred=False):
+        lw, lh = C.c_int(), C.c_int()
+        self._check(self.lib.vido_orb_level_size(self.h, level, C.byref(lw), C.byref(lh)))
+        out = np.empty((lh.value, lw.value), np.uint8)
+        self._check(self.lib.vido_orb_read_level(self.h, frame, level, int(blurred), _ptr(out)))
+        return out
+
+    def orb_candidates(self, frame, level):
+        n = self._check(self.lib.vido_orb_read_candidates(self.h, frame, level, None, 0))
+        out = np.empty(max(n, 1), np.uint32)
+        self._check(self.lib.vido_orb_read_candidates(self.h, frame, level, _ptr(out), n))
+        out = out[:n]
+        return (out & 0xfff).astype(np.int32), ((out >> 12) & 0xfff).astype(np.int32), (out >> 24).astype(np.int32)
+
+    def orb_timing(self):
+        t = np.zeros(6, np.float32)
+        self._check(self.lib.vido_orb_last_timing(self.h, _ptr(t)))
+        return dict(zip(["pyramid_ms", "fast_ms", "quadtree_host_ms", "blur_ms", "orient_brief_ms", "wall_ms"], t.tolist()))
+
+    # ---- Hamming ---------------------------------------------------------------------------------
+    def hamming_match(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32); b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+        idx = np.empty(len(a), np.int32); dist = np.empty(len(a), np.int32)
+        self._check(self.lib.vido_hamming_match(self.h, _ptr(a), len(a), _ptr(b), len(b), _ptr(idx), _ptr(dist), 0))
+        return idx, dist
+
+    def hamming_match_device(self, a_ptr, na, b_ptr, nb, idx_ptr, dist_ptr):
+        self._check(self.lib.vido_hamming_match(self.h, C.c_void_p(a_ptr), na, C.c_void_p(b_ptr), nb, C.c_void_p(idx_ptr), C.c_void_p(dist_ptr), 1))
+
+
+class ORBextractor:
+    """Mirror of VIDO_SLAM::ORBextractor (vido_slam/include/ORBextractor.h:39-49): construct with the five
+    ctor arguments, call with a CV_8UC1 image, get keypoints + 32-byte descriptors."""
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width=640, height=480, device=0, max_batch=1):
+        self.ctx = Context(device=device, width=width, height=height, max_batch=max_batch, n_features=nfeatures,
+                           scale_factor=scaleFactor, n_levels=nlevels, ini_th_fast=iniThFAST, min_th_fast=minThFAST)
+
+    def __call__(self, image, mask=None):
+        return self.ctx.orb_extract(image)
