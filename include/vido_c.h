@@ -12,7 +12,7 @@
  *   vido_pose_opt_*        Optimizer::PoseOptimization{New,Flow2Cam,ObjMot,Flow2}   vido_slam/include/Optimizer.h:26-29
  *   vido_local_ba          Optimizer::PartialBatchOptimization vido_slam/include/Optimizer.h:31, src/Optimizer.cc:43-1228
  *   vido_global_ba         Optimizer::FullBatchOptimization    vido_slam/include/Optimizer.h:30, src/Optimizer.cc:1235-2178
- * The C++ facade (include/vido_slam/*.h) re-exports the reference's VIDO_SLAM::System/Tracking/Optimizer
+ * The C++ facade (headers under include/vido_slam/) re-exports the reference's VIDO_SLAM::System/Tracking/Optimizer
  * class surface on top of these calls; INTEGRATION.md shows the binding a maintainer adds.
  */
 #ifndef VIDO_C_H
@@ -76,9 +76,10 @@ int vido_orb_read_level(vido_ctx* ctx, int frame, int level, int blurred, uint8_
 /* FAST candidates of the last call for (frame, level) in reference order: packed x | y<<12 | score<<24
  * (level coordinates).  Returns count (or <0). */
 int vido_orb_read_candidates(vido_ctx* ctx, int frame, int level, uint32_t* out, int cap);
-/* per-stage device time of the last batch call, ms: [0] pyramid [1] fast+compact [2] host quadtree
- * [3] blur [4] orient+brief [5] total wall */
-int vido_orb_last_timing(const vido_ctx* ctx, float ms[6]);
+/* per-stage time of the last batch call (HIP events on the ctx stream), ms: [0] pyramid (level-0 copy + resize
+ * launches) [1] k_fast_cells alone [2] host quadtree [3] blur [4] keypoint upload + orient/rBRIEF + download
+ * [5] total wall [6] scan+gather [7] number of FAST candidates in the batch */
+int vido_orb_last_timing(const vido_ctx* ctx, float ms[8]);
 
 /* ---- Hamming -------------------------------------------------------------------------------------
  * For each of the na 256-bit descriptors in a: index of the closest descriptor in b (smallest Hamming

@@ -5,14 +5,15 @@
 // Mapping: one wave64 owns QW=8 queries (wave-uniform, kept in scalar registers) and streams a slab
 // of the train set: lane j loads train descriptor j (32 B, coalesced 2 KiB per wave load), scores it
 // against the 8 queries with v_bcnt (popcount-accumulate), keeps a per-lane running minimum, then a
-// wavefront-shuffle (DPP) reduction picks the wave minimum; slabs are combined with a 64-bit
-// atomicMin on (distance<<32 | index), which also implements the lowest-index tie rule.
+// wavefront-shuffle (DPP) reduction picks the wave minimum of (distance<<32 | index) — the packed key
+// also implements the lowest-index tie rule; per-slab partial minima land in a [query][slab] table
+// that a second tiny kernel folds (deterministic, no atomics).
 #include "common.hpp"
 
 #define QW 8
 
 __global__ __launch_bounds__(256) void k_hamming(const uint32_t* __restrict__ A, int na, const uint32_t* __restrict__ Bd, int nb,
-                                                 int slab, unsigned long long* __restrict__ best)
+                                                 int slab, int nsl, unsigned long long* __restrict__ part)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int q0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + wave) * QW);
@@ -46,15 +47,16 @@ __global__ __launch_bounds__(256) void k_hamming(const uint32_t* __restrict__ A,
             const unsigned long long other = __shfl_xor(v, o, 64);
             v = other < v ? other : v;
         }
-        if (lane == 0 && q0 + q < na && v != ~0ull) atomicMin(&best[q0 + q], v);
+        if (lane == 0 && q0 + q < na) part[(size_t)(q0 + q) * nsl + blockIdx.y] = v;
     }
 }
 
-__global__ void k_hamming_finish(const unsigned long long* __restrict__ best, int na, int* __restrict__ idx, int* __restrict__ dist)
+__global__ void k_hamming_finish(const unsigned long long* __restrict__ part, int nsl, int na, int* __restrict__ idx, int* __restrict__ dist)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= na) return;
-    const unsigned long long v = best[i];
+    unsigned long long v = ~0ull;
+    for (int s = 0; s < nsl; s++) { const unsigned long long o = part[(size_t)i * nsl + s]; v = o < v ? o : v; }
     if (v == ~0ull) { idx[i] = -1; dist[i] = -1; }
     else { idx[i] = (int)(uint32_t)v; dist[i] = (int)(v >> 32); }
 }
@@ -70,7 +72,12 @@ extern "C" int vido_hamming_match(vido_ctx* ctx, const uint8_t* a, int na, const
     hipStream_t st = ctx->stream;
     const uint8_t *da = a, *db = b; int *didx = idx_out, *ddist = dist_out;
     uint8_t *ta = nullptr, *tb = nullptr; int* tidx = nullptr; int* tdist = nullptr; unsigned long long* best = nullptr;
-    HIP_TRY(ctx, hipMallocAsync((void**)&best, (size_t)na * 8, st));
+    const int qblocks = (na + 4 * QW - 1) / (4 * QW);
+    // enough train slabs that the grid has >= ~2048 workgroups, slabs a multiple of 64 descriptors
+    int nsl = std::max(1, std::min((nb + 63) / 64, (2048 + qblocks - 1) / qblocks));
+    int slab = ((std::max(nb, 1) + nsl - 1) / nsl + 63) & ~63;
+    nsl = std::max(1, (nb + slab - 1) / slab);
+    HIP_TRY(ctx, hipMallocAsync((void**)&best, (size_t)na * nsl * 8, st));
     if (!on_device) {
         HIP_TRY(ctx, hipMallocAsync((void**)&ta, (size_t)na * 32, st));
         HIP_TRY(ctx, hipMallocAsync((void**)&tb, (size_t)std::max(nb, 1) * 32, st));
@@ -80,16 +87,11 @@ extern "C" int vido_hamming_match(vido_ctx* ctx, const uint8_t* a, int na, const
         if (nb > 0) HIP_TRY(ctx, hipMemcpyAsync(tb, b, (size_t)nb * 32, hipMemcpyHostToDevice, st));
         da = ta; db = tb; didx = tidx; ddist = tdist;
     }
-    HIP_TRY(ctx, hipMemsetAsync(best, 0xff, (size_t)na * 8, st));
-    if (nb > 0) {
-        const int qblocks = (na + 4 * QW - 1) / (4 * QW);
-        // enough train slabs that the grid has >= ~2048 workgroups, slabs a multiple of 64 descriptors
-        int nsl = std::max(1, std::min((nb + 63) / 64, (2048 + qblocks - 1) / qblocks));
-        int slab = ((nb + nsl - 1) / nsl + 63) & ~63;
-        nsl = (nb + slab - 1) / slab;
-        hipLaunchKernelGGL(k_hamming, dim3(qblocks, nsl), dim3(256), 0, st, (const uint32_t*)da, na, (const uint32_t*)db, nb, slab, best);
-    }
-    hipLaunchKernelGGL(k_hamming_finish, dim3((na + 255) / 256), dim3(256), 0, st, best, na, didx, ddist);
+    if (nb > 0)
+        hipLaunchKernelGGL(k_hamming, dim3(qblocks, nsl), dim3(256), 0, st, (const uint32_t*)da, na, (const uint32_t*)db, nb, slab, nsl, best);
+    else
+        HIP_TRY(ctx, hipMemsetAsync(best, 0xff, (size_t)na * nsl * 8, st));
+    hipLaunchKernelGGL(k_hamming_finish, dim3((na + 255) / 256), dim3(256), 0, st, best, nsl, na, didx, ddist);
     HIP_TRY(ctx, hipGetLastError());
     if (!on_device) {
         HIP_TRY(ctx, hipMemcpyAsync(idx_out, tidx, (size_t)na * 4, hipMemcpyDeviceToHost, st));

@@ -342,7 +342,7 @@ struct OrbState {
     // pinned host
     int* h_lvloff = nullptr; int* h_overflow = nullptr; uint32_t* h_cand = nullptr; uint2* h_kp = nullptr; float* h_angle = nullptr; uint8_t* h_desc = nullptr;
     hipEvent_t ev[8] = {};
-    float timing[6] = {0, 0, 0, 0, 0, 0};
+    float timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int last_frames = 0;
     int n_threads = 1;
 };
@@ -377,7 +377,7 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
     for (int l = 0; l < L; l++) {
         LevelInfo& v = S->lv[l];
         v.w = cv_round_f((float)c.width * inv[l]); v.h = cv_round_f((float)c.height * inv[l]);
-        if (v.w < 38 + 30 || v.h < 38 + 30)
+        if (v.w - 2 * (EDGE_THRESHOLD - 3) < 30 || v.h - 2 * (EDGE_THRESHOLD - 3) < 30)   // nCols/nRows would be 0 (the reference divides by it)
             return vido_set_error(ctx, VIDO_E_INVALID, "pyramid level %d is %dx%d: too small for the 30-px FAST cell grid", l, v.w, v.h);
         v.pitch = (v.w + 63) & ~63; v.off = off; v.scale = scale[l];
         off += v.pitch * v.h; off = (off + 255) & ~255;
@@ -647,6 +647,7 @@ static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, si
     HIP_TRY(ctx, hipEventRecord(S->ev[1], st));
     hipLaunchKernelGGL(k_fast_cells, dim3(S->n_cells, nf), dim3(64), 0, st, S->d_pyr, S->slab, S->P, S->d_cells, S->n_cells,
                        ctx->cfg.ini_th_fast, ctx->cfg.min_th_fast, S->d_slots, S->d_counts);
+    HIP_TRY(ctx, hipEventRecord(S->ev[7], st));
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, S->d_counts, S->n_cells * nf, S->d_offsets, S->n_cells, nf, L,
                        S->d_first_cell, S->d_lvloff, S->d_overflow);
     hipLaunchKernelGGL(k_gather_cands, dim3(S->n_cells, nf), dim3(64), 0, st, S->d_slots, S->d_counts, S->d_offsets, S->n_cells, S->d_cand, (int)S->cand_cap);
@@ -736,7 +737,9 @@ static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, si
     auto t_end = std::chrono::steady_clock::now();
     float ms;
     hipEventElapsedTime(&ms, S->ev[0], S->ev[1]); S->timing[0] = ms;
-    hipEventElapsedTime(&ms, S->ev[1], S->ev[2]); S->timing[1] = ms;
+    hipEventElapsedTime(&ms, S->ev[1], S->ev[7]); S->timing[1] = ms;
+    hipEventElapsedTime(&ms, S->ev[7], S->ev[2]); S->timing[6] = ms;
+    S->timing[7] = (float)S->h_lvloff[nf * L];
     S->timing[2] = std::chrono::duration<float, std::milli>(t_q1 - t_q0).count();
     hipEventElapsedTime(&ms, S->ev[3], S->ev[4]); S->timing[3] = ms;
     hipEventElapsedTime(&ms, S->ev[5], S->ev[6]); S->timing[4] = ms;
@@ -792,10 +795,10 @@ int vido_orb_read_candidates(vido_ctx* ctx, int frame, int level, uint32_t* out,
     return n;
 }
 
-int vido_orb_last_timing(const vido_ctx* ctx, float ms[6])
+int vido_orb_last_timing(const vido_ctx* ctx, float ms[8])
 {
     if (!ctx || !ctx->orb || !ms) return VIDO_E_INVALID;
-    memcpy(ms, ctx->orb->timing, sizeof(float) * 6);
+    memcpy(ms, ctx->orb->timing, sizeof(float) * 8);
     return VIDO_OK;
 }
 
