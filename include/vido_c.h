@@ -88,6 +88,49 @@ int vido_orb_last_timing(const vido_ctx* ctx, float ms[8]);
 int vido_hamming_match(vido_ctx* ctx, const uint8_t* a, int na, const uint8_t* b, int nb,
                        int32_t* idx_out, int32_t* dist_out, int on_device);
 
+/* ---- Tracking front-end, data-parallel stages ---------------------------------------------------------
+ * Frame maps (depth f32, flow f32x2, mask i32; width*height of the ctx) live in device "slots"
+ * (vido_track_slots() of them, >= 2 so that frame k and k-1 are both resident). */
+typedef struct vido_track_params {
+    int32_t dataset;            /* YAML ChooseData: 0 OMD (d/f), 1 KITTI (bf/(d/f)), 2 KAIST (scale*bf/(d/f))  Tracking.cc:306-319 */
+    float depth_map_factor, bf, kaist_scale;
+    float th_depth_bg, th_depth_obj;     /* ThDepthBG / ThDepthOBJ (Frame::mThDepth, mThDepthObj) */
+    int32_t dense_step;         /* 4 (Frame.cc:184) */
+    float fx, fy, cx, cy;       /* Camera.fx.. (Frame.cc:229-234) */
+} vido_track_params;
+
+/* Host-side list outputs of vido_frame_features, [n_frames][max_*] each (caller-owned). */
+typedef struct vido_frame_lists {
+    int32_t max_stat, max_obj;
+    int32_t* n_stat; int32_t* stat_idx; float* stat_corr; float* stat_flow; float* stat_depth;      /* mvStatKeysTmp(idx into kps)/mvCorres/mvFlowNext/mvStatDepthTmp */
+    int32_t* n_obj; float* obj_keys; float* obj_corr; float* obj_depth; int32_t* obj_label; float* obj_flow;  /* mvObjKeys/mvObjCorres/mvObjDepth/vSemObjLabel/mvObjFlowNext */
+} vido_frame_lists;
+
+int vido_track_slots(vido_ctx* ctx);
+/* Tracking::GrabImageRGBD depth pre-scale (Tracking.cc:299-322): copies the maps of n_frames frames into
+ * slots [slot0, slot0+n_frames), rescales depth on the device and writes the rescaled depth back into the
+ * caller's `depth` buffer (the reference mutates it in place).  on_device: the three pointers are device pointers. */
+int vido_frame_upload(vido_ctx* ctx, int slot0, int n_frames, float* depth, const float* flow, const int32_t* mask,
+                      int on_device, const vido_track_params* p);
+/* Frame::Frame RGB-D ctor lists (Frame.cc:72-100, 165-177, 184-211) for the frames in the slots, from the
+ * ORB keypoints kps[n_frames][max_kp] (host). */
+int vido_frame_features(vido_ctx* ctx, int slot0, int n_frames, const vido_keypoint* kps, const int32_t* n_kps, int max_kp,
+                        const vido_track_params* p, vido_frame_lists* out);
+/* Tracking.cc:369-391 / 398-421: depth (and label) of the current frame at last frame's correspondences. */
+int vido_gather_static_depth(vido_ctx* ctx, int slot, const float* keys_xy, int n, float* depth_out);
+int vido_gather_object_depth_label(vido_ctx* ctx, int slot, const float* keys_xy, int n, float th_depth_obj,
+                                   float* depth_out, int32_t* label_out);
+/* Tracking::UpdateMask (Tracking.cc:3291-3357): mask of slot_cur is patched in place on the device. */
+int vido_update_mask(vido_ctx* ctx, int slot_last, int slot_cur, const int32_t* last_label, const float* last_corr_xy, int n,
+                     int32_t* recovered_out, int cap, int32_t* n_recovered);
+int vido_read_maps(vido_ctx* ctx, int slot, float* depth_out, float* flow_out, int32_t* mask_out);   /* any pointer may be NULL */
+/* Frame::UnprojectStereoStat/Object, addnoise=0 (Frame.cc:706-771): Tcw row-major 4x4 f32. */
+int vido_unproject_world(vido_ctx* ctx, const float* keys_xy, const float* z, int n, const vido_track_params* p,
+                         const float* Tcw, float* xyz_out);
+/* Tracking::GetSceneFlowObj (Tracking.cc:1582-1668). */
+int vido_scene_flow(vido_ctx* ctx, const float* xyz_last, const float* xyz_cur, const int32_t* sem_last, const int32_t* sem_cur,
+                    int n, float* flow3d_out, int32_t* obj_label_inout);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,3 +126,58 @@ def hamming_match(a, b):
     idx = np.empty(len(a), np.int32); dist = np.empty(len(a), np.int32)
     lib().vo_hamming_match(_p(a), len(a), _p(b), len(b), _p(idx), _p(dist))
     return idx, dist
+
+
+# ---- tracking front-end (track_oracle.c) ----------------------------------------------------------
+def depth_prescale(depth, mode, factor, bf, scale):
+    d = np.array(depth, np.float32, copy=True)
+    lib().vo_depth_prescale(_p(d), d.size, mode, C.c_float(factor), C.c_float(bf), C.c_float(scale))
+    return d
+
+def static_candidates(kps, depth, flow, mask, th_depth):
+    kps = np.ascontiguousarray(kps); n = len(kps); h, w = depth.shape
+    idx = np.empty(n, np.int32); corr = np.empty((n, 2), np.float32); fl = np.empty((n, 2), np.float32); dd = np.empty(n, np.float32)
+    depth = np.ascontiguousarray(depth, np.float32); flow = np.ascontiguousarray(flow, np.float32); mask = np.ascontiguousarray(mask, np.int32)
+    m = lib().vo_static_candidates(_p(kps), n, _p(depth), _p(flow), _p(mask), w, h, C.c_float(th_depth), _p(idx), _p(corr), _p(fl), _p(dd))
+    return idx[:m].copy(), corr[:m].copy(), fl[:m].copy(), dd[:m].copy()
+
+def dense_object_samples(depth, flow, mask, th_obj, step=4):
+    h, w = depth.shape; cap = ((w + step - 1) // step) * ((h + step - 1) // step)
+    keys = np.empty((cap, 2), np.float32); corr = np.empty((cap, 2), np.float32); od = np.empty(cap, np.float32)
+    lab = np.empty(cap, np.int32); fl = np.empty((cap, 2), np.float32)
+    depth = np.ascontiguousarray(depth, np.float32); flow = np.ascontiguousarray(flow, np.float32); mask = np.ascontiguousarray(mask, np.int32)
+    m = lib().vo_dense_object_samples(_p(depth), _p(flow), _p(mask), w, h, C.c_float(th_obj), step, _p(keys), _p(corr), _p(od), _p(lab), _p(fl), cap)
+    return keys[:m].copy(), corr[:m].copy(), od[:m].copy(), lab[:m].copy(), fl[:m].copy()
+
+def gather_static_depth(keys, depth):
+    keys = np.ascontiguousarray(keys, np.float32).reshape(-1, 2); h, w = depth.shape; out = np.empty(len(keys), np.float32)
+    depth = np.ascontiguousarray(depth, np.float32)
+    lib().vo_gather_static_depth(_p(keys), len(keys), _p(depth), w, h, _p(out))
+    return out
+
+def gather_object_depth_label(keys, depth, mask, th_obj):
+    keys = np.ascontiguousarray(keys, np.float32).reshape(-1, 2); h, w = depth.shape
+    d = np.empty(len(keys), np.float32); l = np.empty(len(keys), np.int32)
+    depth = np.ascontiguousarray(depth, np.float32); mask = np.ascontiguousarray(mask, np.int32)
+    lib().vo_gather_object_depth_label(_p(keys), len(keys), _p(depth), _p(mask), w, h, C.c_float(th_obj), _p(d), _p(l))
+    return d, l
+
+def update_mask(last_label, last_corr, mask_last, flow_last, mask_cur):
+    last_label = np.ascontiguousarray(last_label, np.int32); last_corr = np.ascontiguousarray(last_corr, np.float32)
+    mask_last = np.ascontiguousarray(mask_last, np.int32); flow_last = np.ascontiguousarray(flow_last, np.float32)
+    out = np.array(mask_cur, np.int32, copy=True); h, w = out.shape; rec = np.zeros(64, np.int32)
+    n = lib().vo_update_mask(_p(last_label), _p(last_corr), len(last_label), _p(mask_last), _p(flow_last), _p(out), w, h, _p(rec), 64)
+    return out, rec[:n].copy()
+
+def unproject_world(keys, z, fx, fy, cx, cy, Tcw):
+    keys = np.ascontiguousarray(keys, np.float32).reshape(-1, 2); z = np.ascontiguousarray(z, np.float32)
+    Tcw = np.ascontiguousarray(Tcw, np.float32); out = np.empty((len(z), 3), np.float32)
+    lib().vo_unproject_world(_p(keys), _p(z), len(z), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), _p(Tcw), _p(out))
+    return out
+
+def scene_flow(xl, xc, sl, sc, obj_label):
+    xl = np.ascontiguousarray(xl, np.float32); xc = np.ascontiguousarray(xc, np.float32)
+    sl = np.ascontiguousarray(sl, np.int32); sc = np.ascontiguousarray(sc, np.int32)
+    ol = np.array(obj_label, np.int32, copy=True); out = np.empty((len(sl), 3), np.float32)
+    lib().vo_scene_flow(_p(xl), _p(xc), _p(sl), _p(sc), len(sl), _p(out), _p(ol))
+    return out, ol

@@ -43,6 +43,7 @@ struct vido_ctx {
     OrbState* orb = nullptr;
     TrackState* trk = nullptr;
     BaState* ba = nullptr;
+    struct HamState* ham = nullptr;
 };
 
 int vido_set_error(vido_ctx* ctx, int code, const char* fmt, ...);
@@ -56,4 +57,6 @@ int vido_set_error(vido_ctx* ctx, int code, const char* fmt, ...);
     } while (0)
 
 int orb_state_create(vido_ctx* ctx);
+void track_state_destroy(vido_ctx* ctx);
+void ham_state_destroy(vido_ctx* ctx);
 void orb_state_destroy(vido_ctx* ctx);

@@ -77,6 +77,8 @@ void vido_destroy(vido_ctx* ctx)
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     orb_state_destroy(ctx);
+    track_state_destroy(ctx);
+    ham_state_destroy(ctx);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     delete ctx;

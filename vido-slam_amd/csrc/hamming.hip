@@ -61,6 +61,34 @@ __global__ void k_hamming_finish(const unsigned long long* __restrict__ part, in
     else { idx[i] = (int)(uint32_t)v; dist[i] = (int)(v >> 32); }
 }
 
+// Persistent, growable device/pinned buffers (no per-call stream-ordered allocations: inputs are staged
+// through pinned memory so every transfer is ordered on the ctx stream).
+struct HamState {
+    uint8_t *d_a = nullptr, *d_b = nullptr; int *d_idx = nullptr, *d_dist = nullptr; unsigned long long* d_part = nullptr;
+    uint8_t* h_stage = nullptr;
+    size_t cap_a = 0, cap_b = 0, cap_part = 0, cap_stage = 0;
+};
+
+template <class T>
+static int grow(vido_ctx* ctx, T** p, size_t* cap, size_t need, bool pinned = false)
+{
+    if (need <= *cap) return VIDO_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (*p) { if (pinned) HIP_TRY(ctx, hipHostFree(*p)); else HIP_TRY(ctx, hipFree(*p)); *p = nullptr; }
+    const size_t n = need + need / 2 + 64;
+    if (pinned) HIP_TRY(ctx, hipHostMalloc((void**)p, n * sizeof(T))); else HIP_TRY(ctx, hipMalloc((void**)p, n * sizeof(T)));
+    *cap = n;
+    return VIDO_OK;
+}
+
+void ham_state_destroy(vido_ctx* ctx)
+{
+    HamState* S = ctx->ham;
+    if (!S) return;
+    hipFree(S->d_a); hipFree(S->d_b); hipFree(S->d_idx); hipFree(S->d_dist); hipFree(S->d_part); hipHostFree(S->h_stage);
+    delete S; ctx->ham = nullptr;
+}
+
 extern "C" int vido_hamming_match(vido_ctx* ctx, const uint8_t* a, int na, const uint8_t* b, int nb,
                                   int32_t* idx_out, int32_t* dist_out, int on_device)
 {
@@ -69,36 +97,46 @@ extern "C" int vido_hamming_match(vido_ctx* ctx, const uint8_t* a, int na, const
         return vido_set_error(ctx, VIDO_E_INVALID, "hamming: bad arguments");
     if (na == 0) return VIDO_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->ham) ctx->ham = new HamState();
+    HamState* S = ctx->ham;
     hipStream_t st = ctx->stream;
-    const uint8_t *da = a, *db = b; int *didx = idx_out, *ddist = dist_out;
-    uint8_t *ta = nullptr, *tb = nullptr; int* tidx = nullptr; int* tdist = nullptr; unsigned long long* best = nullptr;
     const int qblocks = (na + 4 * QW - 1) / (4 * QW);
     // enough train slabs that the grid has >= ~2048 workgroups, slabs a multiple of 64 descriptors
     int nsl = std::max(1, std::min((nb + 63) / 64, (2048 + qblocks - 1) / qblocks));
     int slab = ((std::max(nb, 1) + nsl - 1) / nsl + 63) & ~63;
     nsl = std::max(1, (nb + slab - 1) / slab);
-    HIP_TRY(ctx, hipMallocAsync((void**)&best, (size_t)na * nsl * 8, st));
+    int rc;
+    if ((rc = grow(ctx, &S->d_part, &S->cap_part, (size_t)na * nsl))) return rc;
+    const uint8_t *da = a, *db = b; int *didx = idx_out, *ddist = dist_out;
     if (!on_device) {
-        HIP_TRY(ctx, hipMallocAsync((void**)&ta, (size_t)na * 32, st));
-        HIP_TRY(ctx, hipMallocAsync((void**)&tb, (size_t)std::max(nb, 1) * 32, st));
-        HIP_TRY(ctx, hipMallocAsync((void**)&tidx, (size_t)na * 4, st));
-        HIP_TRY(ctx, hipMallocAsync((void**)&tdist, (size_t)na * 4, st));
-        HIP_TRY(ctx, hipMemcpyAsync(ta, a, (size_t)na * 32, hipMemcpyHostToDevice, st));
-        if (nb > 0) HIP_TRY(ctx, hipMemcpyAsync(tb, b, (size_t)nb * 32, hipMemcpyHostToDevice, st));
-        da = ta; db = tb; didx = tidx; ddist = tdist;
+        size_t capi = S->cap_a;
+        if ((rc = grow(ctx, &S->d_a, &S->cap_a, (size_t)na * 32))) return rc;
+        if (S->cap_a != capi || !S->d_idx) {
+            if (S->d_idx) { HIP_TRY(ctx, hipFree(S->d_idx)); HIP_TRY(ctx, hipFree(S->d_dist)); }
+            HIP_TRY(ctx, hipMalloc((void**)&S->d_idx, S->cap_a / 32 * 4 + 64)); HIP_TRY(ctx, hipMalloc((void**)&S->d_dist, S->cap_a / 32 * 4 + 64));
+        }
+        if ((rc = grow(ctx, &S->d_b, &S->cap_b, (size_t)std::max(nb, 1) * 32))) return rc;
+        const size_t bytes_in = ((size_t)na + nb) * 32, bytes_out = (size_t)na * 8;
+        if ((rc = grow(ctx, &S->h_stage, &S->cap_stage, std::max(bytes_in, bytes_out), true))) return rc;
+        memcpy(S->h_stage, a, (size_t)na * 32);
+        if (nb > 0) memcpy(S->h_stage + (size_t)na * 32, b, (size_t)nb * 32);
+        HIP_TRY(ctx, hipMemcpyAsync(S->d_a, S->h_stage, (size_t)na * 32, hipMemcpyHostToDevice, st));
+        if (nb > 0) HIP_TRY(ctx, hipMemcpyAsync(S->d_b, S->h_stage + (size_t)na * 32, (size_t)nb * 32, hipMemcpyHostToDevice, st));
+        da = S->d_a; db = S->d_b; didx = S->d_idx; ddist = S->d_dist;
     }
     if (nb > 0)
-        hipLaunchKernelGGL(k_hamming, dim3(qblocks, nsl), dim3(256), 0, st, (const uint32_t*)da, na, (const uint32_t*)db, nb, slab, nsl, best);
+        hipLaunchKernelGGL(k_hamming, dim3(qblocks, nsl), dim3(256), 0, st, (const uint32_t*)da, na, (const uint32_t*)db, nb, slab, nsl, S->d_part);
     else
-        HIP_TRY(ctx, hipMemsetAsync(best, 0xff, (size_t)na * nsl * 8, st));
-    hipLaunchKernelGGL(k_hamming_finish, dim3((na + 255) / 256), dim3(256), 0, st, best, nsl, na, didx, ddist);
+        HIP_TRY(ctx, hipMemsetAsync(S->d_part, 0xff, (size_t)na * nsl * 8, st));
+    hipLaunchKernelGGL(k_hamming_finish, dim3((na + 255) / 256), dim3(256), 0, st, S->d_part, nsl, na, didx, ddist);
     HIP_TRY(ctx, hipGetLastError());
     if (!on_device) {
-        HIP_TRY(ctx, hipMemcpyAsync(idx_out, tidx, (size_t)na * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(dist_out, tdist, (size_t)na * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipFreeAsync(ta, st)); HIP_TRY(ctx, hipFreeAsync(tb, st)); HIP_TRY(ctx, hipFreeAsync(tidx, st)); HIP_TRY(ctx, hipFreeAsync(tdist, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));        // staging buffer is reused for the results
+        int* hs = (int*)S->h_stage;
+        HIP_TRY(ctx, hipMemcpyAsync(hs, S->d_idx, (size_t)na * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(hs + na, S->d_dist, (size_t)na * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        memcpy(idx_out, hs, (size_t)na * 4); memcpy(dist_out, hs + na, (size_t)na * 4);
     }
-    HIP_TRY(ctx, hipFreeAsync(best, st));
-    if (!on_device) HIP_TRY(ctx, hipStreamSynchronize(st));
     return VIDO_OK;
 }

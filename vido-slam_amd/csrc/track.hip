@@ -1,0 +1,441 @@
+// track.hip — data-parallel stages of the per-frame tracking front-end on gfx950.
+// Replaces (reference, vido_slam/src): Tracking.cc:299-322 depth pre-scale; Frame.cc:72-100,165-177
+// static-candidate filter + depth gather; Frame.cc:184-211 dense object sampling; Tracking.cc:369-421
+// cross-frame gathers; Tracking.cc:3291-3357 UpdateMask; Frame.cc:706-771 back-projection;
+// Tracking.cc:1582-1668 scene flow.
+// Layout: per frame slot, depth (f32), flow (f32x2) and mask (i32) maps stay resident in HBM between
+// the calls of one frame and across the frame k / k-1 pair; the list outputs are compacted in the
+// reference's visiting order with wave ballots + one LDS scan per 1024-thread workgroup (the lists are
+// order-sensitive: index i of frame k-1's correspondences IS feature i of frame k).
+#include "common.hpp"
+
+struct TrackState {
+    int W = 0, H = 0, B = 0, max_kp = 0, max_obj = 0;
+    float *d_depth = nullptr, *d_flow = nullptr; int32_t* d_mask = nullptr;      // [slots][H*W]
+    vido_keypoint* d_kps = nullptr;                                              // [B][max_kp]
+    int32_t *d_sidx = nullptr, *d_nstat = nullptr, *d_nobj = nullptr, *d_olabel = nullptr;
+    float *d_scorr = nullptr, *d_sflow = nullptr, *d_sdepth = nullptr;
+    float *d_okeys = nullptr, *d_ocorr = nullptr, *d_odepth = nullptr, *d_oflow = nullptr;
+    float* d_tmpf = nullptr; int32_t* d_tmpi = nullptr; size_t tmp_cap = 0;       // scratch for gathers
+    int32_t* h_cnt = nullptr;
+};
+
+// ---- kernels -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_depth_prescale(float* __restrict__ d, size_t n4, int mode, float factor, float bf, float scale)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = ((float4*)d)[i];
+        float* e = (float*)&v;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float x = e[k];
+            if (x < 0) x = 0;
+            else if (mode == 0) x = x / factor;
+            else if (mode == 1) x = bf / (x / factor);
+            else x = scale * bf / (x / factor);
+            e[k] = x;
+        }
+        ((float4*)d)[i] = v;
+    }
+}
+
+// exclusive position of a flagged element among all flagged elements of the workgroup so far, in thread
+// order; `base` carries the running total across loop iterations (uniform).
+__device__ __forceinline__ int block_ordered_slot(bool flag, int& base, int* wsum /*[17]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const unsigned long long b = __ballot(flag);
+    const int within = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(b);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < nw; w++) { const int c = wsum[w]; if (w < wave) before += c; total += c; }
+    __syncthreads();
+    const int pos = base + before + within;
+    base += total;
+    return pos;
+}
+
+// Frame.cc:72-100 + :165-177.  One workgroup per frame.
+__global__ __launch_bounds__(1024) void k_static_filter(const vido_keypoint* __restrict__ kps, const int32_t* __restrict__ n_kps, int max_kp,
+                                                        const float* __restrict__ depth, const float* __restrict__ flow, const int32_t* __restrict__ mask,
+                                                        int w, int h, float th_depth,
+                                                        int32_t* __restrict__ out_idx, float* __restrict__ out_corr, float* __restrict__ out_flow,
+                                                        float* __restrict__ out_depth, int32_t* __restrict__ n_out)
+{
+    __shared__ int wsum[17];
+    const int f = blockIdx.x;
+    const size_t px = (size_t)w * h;
+    const vido_keypoint* K = kps + (size_t)f * max_kp;
+    const float* D = depth + f * px; const float* F = flow + f * px * 2; const int32_t* M = mask + f * px;
+    const int n = n_kps[f];
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        bool keep = false; float kx = 0, ky = 0, fx = 0, fy = 0, dd = 0;
+        if (i < n) {
+            kx = K[i].x; ky = K[i].y;
+            const size_t p = (size_t)(int)ky * w + (int)kx;
+            dd = D[p];
+            if (M[p] == 0 && !(dd > th_depth || dd <= 0)) {
+                fx = F[2 * p]; fy = F[2 * p + 1];
+                keep = (fx != 0 && fy != 0) && (kx + fx < (float)w && ky + fy < (float)h && kx < (float)w && ky < (float)h);
+            }
+        }
+        const int pos = block_ordered_slot(keep, base, wsum);
+        if (keep) {
+            const size_t o = (size_t)f * max_kp + pos;
+            out_idx[o] = i; out_corr[2 * o] = kx + fx; out_corr[2 * o + 1] = ky + fy;
+            out_flow[2 * o] = fx; out_flow[2 * o + 1] = fy; out_depth[o] = dd > 0 ? dd : -1.f;
+        }
+    }
+    if (threadIdx.x == 0) n_out[f] = base;
+}
+
+// Frame.cc:184-211.  One workgroup per frame, lattice visited row-major.
+__global__ __launch_bounds__(1024) void k_dense_sample(const float* __restrict__ depth, const float* __restrict__ flow, const int32_t* __restrict__ mask,
+                                                       int w, int h, float th_obj, int step, int max_obj,
+                                                       float* __restrict__ keys, float* __restrict__ corr, float* __restrict__ odepth,
+                                                       int32_t* __restrict__ label, float* __restrict__ oflow, int32_t* __restrict__ n_out)
+{
+    __shared__ int wsum[17];
+    const int f = blockIdx.x;
+    const size_t px = (size_t)w * h;
+    const float* D = depth + f * px; const float* F = flow + f * px * 2; const int32_t* M = mask + f * px;
+    const int gw = (w + step - 1) / step, gh = (h + step - 1) / step, n = gw * gh;
+    int base = 0;
+    for (int q0 = 0; q0 < n; q0 += blockDim.x) {
+        const int q = q0 + threadIdx.x;
+        bool keep = false; int i = 0, j = 0, lab = 0; float fx = 0, fy = 0, dd = 0;
+        if (q < n) {
+            i = (q / gw) * step; j = (q % gw) * step;
+            const size_t p = (size_t)i * w + j;
+            lab = M[p]; dd = D[p];
+            if (lab != 0 && dd < th_obj && dd > 0) {
+                fx = F[2 * p]; fy = F[2 * p + 1];
+                keep = (j + fx < (float)w && j + fx > 0 && i + fy < (float)h && i + fy > 0);
+            }
+        }
+        const int pos = block_ordered_slot(keep, base, wsum);
+        if (keep && pos < max_obj) {
+            const size_t o = (size_t)f * max_obj + pos;
+            keys[2 * o] = (float)j; keys[2 * o + 1] = (float)i; corr[2 * o] = j + fx; corr[2 * o + 1] = i + fy;
+            odepth[o] = dd; label[o] = lab; oflow[2 * o] = fx; oflow[2 * o + 1] = fy;
+        }
+    }
+    if (threadIdx.x == 0) n_out[f] = base;
+}
+
+// Tracking.cc:369-391 / :398-421
+__global__ void k_gather_static(const float* __restrict__ keys, int n, const float* __restrict__ depth, int w, int h, float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int u = (int)keys[2 * i], v = (int)keys[2 * i + 1];
+    float r = -1.f;
+    if (u < (w - 1) && u > 0 && v < (h - 1) && v > 0) { const float d = depth[(size_t)v * w + u]; if (d > 0) r = d; }
+    out[i] = r;
+}
+__global__ void k_gather_object(const float* __restrict__ keys, int n, const float* __restrict__ depth, const int32_t* __restrict__ mask,
+                                int w, int h, float th_obj, float* __restrict__ out_d, int32_t* __restrict__ out_l)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int u = (int)keys[2 * i], v = (int)keys[2 * i + 1];
+    float d = 0.1f; int l = 0;
+    if (u < (w - 1) && u > 0 && v < (h - 1) && v > 0) {
+        const float dd = depth[(size_t)v * w + u];
+        if (dd < th_obj && dd > 0) { d = dd; l = mask[(size_t)v * w + u]; }
+    }
+    out_d[i] = d; out_l[i] = l;
+}
+// UpdateMask helpers: labels of the current mask at the propagated points; scatter of one lost label
+__global__ void k_mask_at(const float* __restrict__ corr, int n, const int32_t* __restrict__ mask, int w, int h, int32_t* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int u = (int)corr[2 * i], v = (int)corr[2 * i + 1];
+    out[i] = (u < w && u > 0 && v < h && v > 0) ? mask[(size_t)v * w + u] : INT32_MIN;
+}
+__global__ __launch_bounds__(256) void k_mask_scatter(const int32_t* __restrict__ mask_last, const float* __restrict__ flow_last,
+                                                      int32_t* __restrict__ mask_cur, int w, int h, int label)
+{
+    const size_t n = (size_t)w * h;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        if (mask_last[p] != label) continue;
+        const int j = (int)(p / w), k = (int)(p % w);
+        const int fx = (int)flow_last[2 * p], fy = (int)flow_last[2 * p + 1];
+        if (k + fx < w && k + fx > 0 && j + fy < h && j + fy > 0) mask_cur[(size_t)(j + fy) * w + (k + fx)] = label;   // same value from every writer
+    }
+}
+// Frame.cc:706-771 (addnoise = 0): camera -> world back-projection; cv::Mat float products accumulate in double
+__global__ void k_unproject_world(const float* __restrict__ keys, const float* __restrict__ z, int n, float cx, float cy, float invfx, float invfy,
+                                  const float* __restrict__ RT /* Rwl[9] twl[3] */, float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float zz = z[i];
+    if (!(zz > 0)) { out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = 0; return; }
+    const float x = (keys[2 * i] - cx) * zz * invfx, y = (keys[2 * i + 1] - cy) * zz * invfy;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double s = (double)RT[r * 3] * x + (double)RT[r * 3 + 1] * y + (double)RT[r * 3 + 2] * zz;
+        out[3 * i + r] = (float)s + RT[9 + r];
+    }
+}
+__global__ void k_scene_flow(const float* __restrict__ Xl, const float* __restrict__ Xc, const int32_t* __restrict__ sl, const int32_t* __restrict__ sc,
+                             int n, float* __restrict__ flow3d, int32_t* __restrict__ obj_label)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (sc[i] <= 0 || sl[i] <= 0) { obj_label[i] = -1; flow3d[3 * i] = flow3d[3 * i + 1] = flow3d[3 * i + 2] = 0; return; }
+#pragma unroll
+    for (int r = 0; r < 3; r++) flow3d[3 * i + r] = Xc[3 * i + r] - Xl[3 * i + r];
+}
+
+// ---- host ------------------------------------------------------------------------------------------
+static int track_state(vido_ctx* ctx, TrackState** out)
+{
+    if (ctx->trk) { *out = ctx->trk; return VIDO_OK; }
+    TrackState* T = new TrackState();
+    ctx->trk = T;
+    T->W = ctx->cfg.width; T->H = ctx->cfg.height; T->B = std::max(ctx->cfg.max_batch, 2);    // >= 2 slots: frame k and k-1
+    T->max_kp = ctx->cfg.n_features * 2 + 256;
+    T->max_obj = ((T->W + 3) / 4) * ((T->H + 3) / 4);
+    const size_t px = (size_t)T->W * T->H, B = T->B;
+    HIP_TRY(ctx, hipMalloc(&T->d_depth, B * px * 4)); HIP_TRY(ctx, hipMalloc(&T->d_flow, B * px * 8)); HIP_TRY(ctx, hipMalloc(&T->d_mask, B * px * 4));
+    HIP_TRY(ctx, hipMalloc(&T->d_kps, B * T->max_kp * sizeof(vido_keypoint)));
+    HIP_TRY(ctx, hipMalloc(&T->d_sidx, B * T->max_kp * 4)); HIP_TRY(ctx, hipMalloc(&T->d_scorr, B * T->max_kp * 8));
+    HIP_TRY(ctx, hipMalloc(&T->d_sflow, B * T->max_kp * 8)); HIP_TRY(ctx, hipMalloc(&T->d_sdepth, B * T->max_kp * 4));
+    HIP_TRY(ctx, hipMalloc(&T->d_nstat, B * 4)); HIP_TRY(ctx, hipMalloc(&T->d_nobj, B * 4));
+    HIP_TRY(ctx, hipMalloc(&T->d_okeys, B * T->max_obj * 8)); HIP_TRY(ctx, hipMalloc(&T->d_ocorr, B * T->max_obj * 8));
+    HIP_TRY(ctx, hipMalloc(&T->d_odepth, B * T->max_obj * 4)); HIP_TRY(ctx, hipMalloc(&T->d_olabel, B * T->max_obj * 4));
+    HIP_TRY(ctx, hipMalloc(&T->d_oflow, B * T->max_obj * 8));
+    T->tmp_cap = (size_t)std::max(T->max_obj, T->max_kp) * 8;
+    HIP_TRY(ctx, hipMalloc(&T->d_tmpf, T->tmp_cap * 4)); HIP_TRY(ctx, hipMalloc(&T->d_tmpi, T->tmp_cap * 4));
+    HIP_TRY(ctx, hipHostMalloc(&T->h_cnt, 2 * B * 4));
+    *out = T;
+    return VIDO_OK;
+}
+
+void track_state_destroy(vido_ctx* ctx)
+{
+    TrackState* T = ctx->trk;
+    if (!T) return;
+    hipFree(T->d_depth); hipFree(T->d_flow); hipFree(T->d_mask); hipFree(T->d_kps); hipFree(T->d_sidx); hipFree(T->d_scorr); hipFree(T->d_sflow);
+    hipFree(T->d_sdepth); hipFree(T->d_nstat); hipFree(T->d_nobj); hipFree(T->d_okeys); hipFree(T->d_ocorr); hipFree(T->d_odepth); hipFree(T->d_olabel);
+    hipFree(T->d_oflow); hipFree(T->d_tmpf); hipFree(T->d_tmpi); hipHostFree(T->h_cnt);
+    delete T; ctx->trk = nullptr;
+}
+
+static inline hipMemcpyKind in_kind(int on_device) { return on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice; }
+
+extern "C" {
+
+int vido_track_slots(vido_ctx* ctx)
+{
+    TrackState* T; if (!ctx) return VIDO_E_INVALID;
+    int rc = track_state(ctx, &T); if (rc) return rc;
+    return T->B;
+}
+
+int vido_frame_upload(vido_ctx* ctx, int slot0, int n_frames, float* depth, const float* flow, const int32_t* mask, int on_device,
+                      const vido_track_params* p)
+{
+    if (!ctx || !p) return VIDO_E_INVALID;
+    TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
+    if (slot0 < 0 || n_frames < 1 || slot0 + n_frames > T->B || !depth || !flow || !mask)
+        return vido_set_error(ctx, VIDO_E_INVALID, "frame_upload: slots [%d,%d) outside [0,%d) or null map", slot0, slot0 + n_frames, T->B);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t px = (size_t)T->W * T->H, n = px * n_frames;
+    float* dd = T->d_depth + slot0 * px;
+    HIP_TRY(ctx, hipMemcpyAsync(dd, depth, n * 4, in_kind(on_device), st));
+    HIP_TRY(ctx, hipMemcpyAsync(T->d_flow + slot0 * px * 2, flow, n * 8, in_kind(on_device), st));
+    HIP_TRY(ctx, hipMemcpyAsync(T->d_mask + slot0 * px, mask, n * 4, in_kind(on_device), st));
+    if ((n & 3) != 0) return vido_set_error(ctx, VIDO_E_INVALID, "frame_upload: width*height must be a multiple of 4");
+    const int grid = (int)std::min<size_t>((n / 4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_depth_prescale, dim3(grid), dim3(256), 0, st, dd, n / 4, p->dataset, p->depth_map_factor, p->bf, p->kaist_scale);
+    // the reference mutates the caller's depth buffer in place (Tracking.cc:299-322): hand the scaled map back
+    HIP_TRY(ctx, hipMemcpyAsync(depth, dd, n * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    if (!on_device) HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+int vido_frame_features(vido_ctx* ctx, int slot0, int n_frames, const vido_keypoint* kps, const int32_t* n_kps, int max_kp,
+                        const vido_track_params* p, vido_frame_lists* out)
+{
+    if (!ctx || !p || !out || !kps || !n_kps) return VIDO_E_INVALID;
+    TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
+    if (slot0 < 0 || n_frames < 1 || slot0 + n_frames > T->B || max_kp > T->max_kp || max_kp < 1)
+        return vido_set_error(ctx, VIDO_E_INVALID, "frame_features: bad slot range or max_kp (%d > %d)", max_kp, T->max_kp);
+    if (out->max_stat < max_kp || out->max_obj < 1) return vido_set_error(ctx, VIDO_E_INVALID, "frame_features: output capacity too small");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t px = (size_t)T->W * T->H;
+    for (int f = 0; f < n_frames; f++) if (n_kps[f] < 0 || n_kps[f] > max_kp) return vido_set_error(ctx, VIDO_E_INVALID, "frame_features: n_kps[%d]=%d", f, n_kps[f]);
+    // keypoints are packed to the ctx's own pitch
+    HIP_TRY(ctx, hipMemcpy2DAsync(T->d_kps, (size_t)T->max_kp * sizeof(vido_keypoint), kps, (size_t)max_kp * sizeof(vido_keypoint),
+                                  (size_t)max_kp * sizeof(vido_keypoint), n_frames, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(T->d_nstat, n_kps, n_frames * 4, hipMemcpyHostToDevice, st));     // reused as the input count, overwritten by the kernel
+    HIP_TRY(ctx, hipMemcpyAsync(T->d_nobj, n_kps, n_frames * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_static_filter, dim3(n_frames), dim3(1024), 0, st, T->d_kps, T->d_nobj, T->max_kp,
+                       T->d_depth + slot0 * px, T->d_flow + slot0 * px * 2, T->d_mask + slot0 * px, T->W, T->H, p->th_depth_bg,
+                       T->d_sidx, T->d_scorr, T->d_sflow, T->d_sdepth, T->d_nstat);
+    const int step = p->dense_step > 0 ? p->dense_step : 4;
+    const int lattice = ((T->W + step - 1) / step) * ((T->H + step - 1) / step);
+    if (lattice > T->max_obj) return vido_set_error(ctx, VIDO_E_INVALID, "frame_features: dense_step %d gives %d probes > %d", step, lattice, T->max_obj);
+    hipLaunchKernelGGL(k_dense_sample, dim3(n_frames), dim3(1024), 0, st, T->d_depth + slot0 * px, T->d_flow + slot0 * px * 2, T->d_mask + slot0 * px,
+                       T->W, T->H, p->th_depth_obj, step, T->max_obj, T->d_okeys, T->d_ocorr, T->d_odepth, T->d_olabel, T->d_oflow, T->d_nobj);
+    HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt, T->d_nstat, n_frames * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt + T->B, T->d_nobj, n_frames * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipGetLastError());
+    for (int f = 0; f < n_frames; f++) {
+        const int ns = T->h_cnt[f], no = T->h_cnt[T->B + f];
+        out->n_stat[f] = ns; out->n_obj[f] = no;
+        if (no > out->max_obj) return vido_set_error(ctx, VIDO_E_CAPACITY, "frame_features: %d object samples > max_obj %d", no, out->max_obj);
+        const size_t so = (size_t)f * out->max_stat, oo = (size_t)f * out->max_obj, ds = (size_t)f * T->max_kp, dobj = (size_t)f * T->max_obj;
+        if (ns > 0) {
+            HIP_TRY(ctx, hipMemcpyAsync(out->stat_idx + so, T->d_sidx + ds, ns * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(out->stat_corr + 2 * so, T->d_scorr + 2 * ds, ns * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(out->stat_flow + 2 * so, T->d_sflow + 2 * ds, ns * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(out->stat_depth + so, T->d_sdepth + ds, ns * 4, hipMemcpyDeviceToHost, st));
+        }
+        if (no > 0) {
+            HIP_TRY(ctx, hipMemcpyAsync(out->obj_keys + 2 * oo, T->d_okeys + 2 * dobj, no * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(out->obj_corr + 2 * oo, T->d_ocorr + 2 * dobj, no * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(out->obj_depth + oo, T->d_odepth + dobj, no * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(out->obj_label + oo, T->d_olabel + dobj, no * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(out->obj_flow + 2 * oo, T->d_oflow + 2 * dobj, no * 8, hipMemcpyDeviceToHost, st));
+        }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return VIDO_OK;
+}
+
+int vido_gather_static_depth(vido_ctx* ctx, int slot, const float* keys_xy, int n, float* depth_out)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
+    if (slot < 0 || slot >= T->B || n < 0 || (size_t)n * 2 > T->tmp_cap) return vido_set_error(ctx, VIDO_E_INVALID, "gather_static_depth: bad slot/n");
+    if (n == 0) return VIDO_OK;
+    hipStream_t st = ctx->stream; const size_t px = (size_t)T->W * T->H;
+    HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, keys_xy, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gather_static, dim3((n + 255) / 256), dim3(256), 0, st, T->d_tmpf, n, T->d_depth + slot * px, T->W, T->H, T->d_tmpf + 2 * (size_t)n);
+    HIP_TRY(ctx, hipMemcpyAsync(depth_out, T->d_tmpf + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return VIDO_OK;
+}
+
+int vido_gather_object_depth_label(vido_ctx* ctx, int slot, const float* keys_xy, int n, float th_depth_obj, float* depth_out, int32_t* label_out)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
+    if (slot < 0 || slot >= T->B || n < 0 || (size_t)n * 3 > T->tmp_cap) return vido_set_error(ctx, VIDO_E_INVALID, "gather_object: bad slot/n");
+    if (n == 0) return VIDO_OK;
+    hipStream_t st = ctx->stream; const size_t px = (size_t)T->W * T->H;
+    HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, keys_xy, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gather_object, dim3((n + 255) / 256), dim3(256), 0, st, T->d_tmpf, n, T->d_depth + slot * px, T->d_mask + slot * px,
+                       T->W, T->H, th_depth_obj, T->d_tmpf + 2 * (size_t)n, T->d_tmpi);
+    HIP_TRY(ctx, hipMemcpyAsync(depth_out, T->d_tmpf + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(label_out, T->d_tmpi, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return VIDO_OK;
+}
+
+int vido_update_mask(vido_ctx* ctx, int slot_last, int slot_cur, const int32_t* last_label, const float* last_corr_xy, int n,
+                     int32_t* recovered_out, int cap, int32_t* n_recovered)
+{
+    if (!ctx || !n_recovered) return VIDO_E_INVALID;
+    TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
+    *n_recovered = 0;
+    if (slot_last < 0 || slot_last >= T->B || slot_cur < 0 || slot_cur >= T->B || n < 0 || (size_t)n * 2 > T->tmp_cap)
+        return vido_set_error(ctx, VIDO_E_INVALID, "update_mask: bad slots/n");
+    if (n == 0) return VIDO_OK;
+    hipStream_t st = ctx->stream; const size_t px = (size_t)T->W * T->H;
+    std::vector<int> uni(last_label, last_label + n);
+    std::sort(uni.begin(), uni.end()); uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
+    std::vector<float> corr; std::vector<int32_t> labs;
+    for (int lab : uni) {
+        corr.clear();
+        for (int j = 0; j < n; j++) if (last_label[j] == lab) { corr.push_back(last_corr_xy[2 * j]); corr.push_back(last_corr_xy[2 * j + 1]); }
+        const int m = (int)corr.size() / 2;
+        if (m < 100) continue;                                   // fewer than 100 in-image samples is impossible to reach with < 100 points
+        HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, corr.data(), (size_t)m * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_mask_at, dim3((m + 255) / 256), dim3(256), 0, st, T->d_tmpf, m, T->d_mask + slot_cur * px, T->W, T->H, T->d_tmpi);
+        labs.resize(m);
+        HIP_TRY(ctx, hipMemcpyAsync(labs.data(), T->d_tmpi, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        labs.erase(std::remove(labs.begin(), labs.end(), INT32_MIN), labs.end());
+        if (labs.size() < 100) continue;
+        std::sort(labs.begin(), labs.end());
+        int best = labs[0], bc = 0, run = 0;
+        for (size_t j = 0; j < labs.size(); j++) { run = (j > 0 && labs[j] == labs[j - 1]) ? run + 1 : 1; if (run > bc) { bc = run; best = labs[j]; } }
+        if (best != 0) continue;
+        hipLaunchKernelGGL(k_mask_scatter, dim3(1024), dim3(256), 0, st, T->d_mask + slot_last * px, T->d_flow + slot_last * px * 2,
+                           T->d_mask + slot_cur * px, T->W, T->H, lab);
+        if (*n_recovered < cap && recovered_out) recovered_out[*n_recovered] = lab;
+        (*n_recovered)++;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+int vido_read_maps(vido_ctx* ctx, int slot, float* depth_out, float* flow_out, int32_t* mask_out)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
+    if (slot < 0 || slot >= T->B) return vido_set_error(ctx, VIDO_E_INVALID, "read_maps: bad slot");
+    const size_t px = (size_t)T->W * T->H;
+    if (depth_out) HIP_TRY(ctx, hipMemcpyAsync(depth_out, T->d_depth + slot * px, px * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (flow_out) HIP_TRY(ctx, hipMemcpyAsync(flow_out, T->d_flow + slot * px * 2, px * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask_out) HIP_TRY(ctx, hipMemcpyAsync(mask_out, T->d_mask + slot * px, px * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return VIDO_OK;
+}
+
+int vido_unproject_world(vido_ctx* ctx, const float* keys_xy, const float* z, int n, const vido_track_params* p, const float* Tcw, float* xyz_out)
+{
+    if (!ctx || !p || !Tcw) return VIDO_E_INVALID;
+    TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
+    if (n < 0 || (size_t)n * 6 + 16 > T->tmp_cap) return vido_set_error(ctx, VIDO_E_INVALID, "unproject_world: n too large");
+    if (n == 0) return VIDO_OK;
+    hipStream_t st = ctx->stream;
+    float RT[12];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) RT[r * 3 + c] = Tcw[c * 4 + r];
+    for (int r = 0; r < 3; r++) { double s = 0; for (int c = 0; c < 3; c++) s += (double)(-RT[r * 3 + c]) * (double)Tcw[c * 4 + 3]; RT[9 + r] = (float)s; }
+    float* dk = T->d_tmpf; float* dz = dk + 2 * (size_t)n; float* dout = dz + n; float* drt = dout + 3 * (size_t)n;
+    HIP_TRY(ctx, hipMemcpyAsync(dk, keys_xy, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dz, z, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(drt, RT, sizeof RT, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_unproject_world, dim3((n + 255) / 256), dim3(256), 0, st, dk, dz, n, p->cx, p->cy, 1.0f / p->fx, 1.0f / p->fy, drt, dout);
+    HIP_TRY(ctx, hipMemcpyAsync(xyz_out, dout, (size_t)n * 12, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return VIDO_OK;
+}
+
+int vido_scene_flow(vido_ctx* ctx, const float* xyz_last, const float* xyz_cur, const int32_t* sem_last, const int32_t* sem_cur, int n,
+                    float* flow3d_out, int32_t* obj_label_inout)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
+    if (n < 0 || (size_t)n * 9 > T->tmp_cap || (size_t)n * 3 > T->tmp_cap) return vido_set_error(ctx, VIDO_E_INVALID, "scene_flow: n too large");
+    if (n == 0) return VIDO_OK;
+    hipStream_t st = ctx->stream;
+    float *a = T->d_tmpf, *b = a + 3 * (size_t)n, *c = b + 3 * (size_t)n; int32_t *sl = T->d_tmpi, *sc = sl + n, *ol = sc + n;
+    HIP_TRY(ctx, hipMemcpyAsync(a, xyz_last, (size_t)n * 12, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(b, xyz_cur, (size_t)n * 12, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(sl, sem_last, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(sc, sem_cur, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ol, obj_label_inout, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_scene_flow, dim3((n + 255) / 256), dim3(256), 0, st, a, b, sl, sc, n, c, ol);
+    HIP_TRY(ctx, hipMemcpyAsync(flow3d_out, c, (size_t)n * 12, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(obj_label_inout, ol, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return VIDO_OK;
+}
+
+}  // extern "C"

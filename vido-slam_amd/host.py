@@ -175,6 +175,91 @@ class Context:
         self._check(self.lib.vido_hamming_match(self.h, C.c_void_p(a_ptr), na, C.c_void_p(b_ptr), nb, C.c_void_p(idx_ptr), C.c_void_p(dist_ptr), 1))
 
 
+class TrackParams(C.Structure):
+    """vido_track_params: dataset/depth/camera constants the reference parses from YAML (Tracking.cc:45-171)."""
+    _fields_ = [("dataset", C.c_int32), ("depth_map_factor", C.c_float), ("bf", C.c_float), ("kaist_scale", C.c_float),
+                ("th_depth_bg", C.c_float), ("th_depth_obj", C.c_float), ("dense_step", C.c_int32),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
+
+
+class FrameLists(C.Structure):
+    _fields_ = [("max_stat", C.c_int32), ("max_obj", C.c_int32),
+                ("n_stat", C.c_void_p), ("stat_idx", C.c_void_p), ("stat_corr", C.c_void_p), ("stat_flow", C.c_void_p), ("stat_depth", C.c_void_p),
+                ("n_obj", C.c_void_p), ("obj_keys", C.c_void_p), ("obj_corr", C.c_void_p), ("obj_depth", C.c_void_p),
+                ("obj_label", C.c_void_p), ("obj_flow", C.c_void_p)]
+
+
+def track_params(dataset=0, depth_map_factor=1.0, bf=387.57, kaist_scale=1.0, th_depth_bg=80.0, th_depth_obj=60.0,
+                 dense_step=4, fx=500.0, fy=500.0, cx=320.0, cy=240.0):
+    return TrackParams(dataset, depth_map_factor, bf, kaist_scale, th_depth_bg, th_depth_obj, dense_step, fx, fy, cx, cy)
+
+
+class FrameFeatures:
+    """Device-side Frame::Frame RGB-D ctor stages (Frame.cc:36-241) bound to a Context."""
+
+    def __init__(self, ctx, params):
+        self.ctx, self.p = ctx, params
+        self.slots = ctx._check(ctx.lib.vido_track_slots(ctx.h))
+
+    def upload(self, slot0, depth, flow, mask):
+        """depth (n,h,w) f32 is rescaled IN PLACE like the reference does to the caller's buffer."""
+        assert depth.dtype == np.float32 and depth.flags.c_contiguous
+        flow = np.ascontiguousarray(flow, np.float32); mask = np.ascontiguousarray(mask, np.int32)
+        n = depth.shape[0] if depth.ndim == 3 else 1
+        self.ctx._check(self.ctx.lib.vido_frame_upload(self.ctx.h, slot0, n, _ptr(depth), _ptr(flow), _ptr(mask), 0, C.byref(self.p)))
+
+    def features(self, slot0, kps, n_kps):
+        """kps: (n, max_kp) KP_DTYPE, n_kps: (n,) -> dict of per-frame lists."""
+        kps = np.ascontiguousarray(kps); n_kps = np.ascontiguousarray(n_kps, np.int32)
+        n, max_kp = kps.shape
+        max_obj = ((self.ctx.cfg.width + 3) // 4) * ((self.ctx.cfg.height + 3) // 4)
+        o = dict(n_stat=np.zeros(n, np.int32), stat_idx=np.zeros((n, max_kp), np.int32), stat_corr=np.zeros((n, max_kp, 2), np.float32),
+                 stat_flow=np.zeros((n, max_kp, 2), np.float32), stat_depth=np.zeros((n, max_kp), np.float32),
+                 n_obj=np.zeros(n, np.int32), obj_keys=np.zeros((n, max_obj, 2), np.float32), obj_corr=np.zeros((n, max_obj, 2), np.float32),
+                 obj_depth=np.zeros((n, max_obj), np.float32), obj_label=np.zeros((n, max_obj), np.int32), obj_flow=np.zeros((n, max_obj, 2), np.float32))
+        L = FrameLists(max_kp, max_obj, *[o[k].ctypes.data for k in ("n_stat", "stat_idx", "stat_corr", "stat_flow", "stat_depth",
+                                                                      "n_obj", "obj_keys", "obj_corr", "obj_depth", "obj_label", "obj_flow")])
+        self.ctx._check(self.ctx.lib.vido_frame_features(self.ctx.h, slot0, n, _ptr(kps), _ptr(n_kps), max_kp, C.byref(self.p), C.byref(L)))
+        return o
+
+    def gather_static_depth(self, slot, keys):
+        keys = np.ascontiguousarray(keys, np.float32).reshape(-1, 2); out = np.empty(len(keys), np.float32)
+        self.ctx._check(self.ctx.lib.vido_gather_static_depth(self.ctx.h, slot, _ptr(keys), len(keys), _ptr(out)))
+        return out
+
+    def gather_object_depth_label(self, slot, keys):
+        keys = np.ascontiguousarray(keys, np.float32).reshape(-1, 2)
+        d = np.empty(len(keys), np.float32); l = np.empty(len(keys), np.int32)
+        self.ctx._check(self.ctx.lib.vido_gather_object_depth_label(self.ctx.h, slot, _ptr(keys), len(keys), C.c_float(self.p.th_depth_obj), _ptr(d), _ptr(l)))
+        return d, l
+
+    def update_mask(self, slot_last, slot_cur, last_label, last_corr):
+        last_label = np.ascontiguousarray(last_label, np.int32); last_corr = np.ascontiguousarray(last_corr, np.float32).reshape(-1, 2)
+        rec = np.zeros(64, np.int32); nrec = C.c_int32()
+        self.ctx._check(self.ctx.lib.vido_update_mask(self.ctx.h, slot_last, slot_cur, _ptr(last_label), _ptr(last_corr), len(last_label),
+                                                      _ptr(rec), 64, C.byref(nrec)))
+        return rec[:nrec.value].copy()
+
+    def read_maps(self, slot):
+        h, w = self.ctx.cfg.height, self.ctx.cfg.width
+        d = np.empty((h, w), np.float32); f = np.empty((h, w, 2), np.float32); m = np.empty((h, w), np.int32)
+        self.ctx._check(self.ctx.lib.vido_read_maps(self.ctx.h, slot, _ptr(d), _ptr(f), _ptr(m)))
+        return d, f, m
+
+    def unproject_world(self, keys, z, Tcw):
+        keys = np.ascontiguousarray(keys, np.float32).reshape(-1, 2); z = np.ascontiguousarray(z, np.float32)
+        Tcw = np.ascontiguousarray(Tcw, np.float32); out = np.empty((len(z), 3), np.float32)
+        self.ctx._check(self.ctx.lib.vido_unproject_world(self.ctx.h, _ptr(keys), _ptr(z), len(z), C.byref(self.p), _ptr(Tcw), _ptr(out)))
+        return out
+
+    def scene_flow(self, xyz_last, xyz_cur, sem_last, sem_cur, obj_label):
+        a = np.ascontiguousarray(xyz_last, np.float32); b = np.ascontiguousarray(xyz_cur, np.float32)
+        sl = np.ascontiguousarray(sem_last, np.int32); sc = np.ascontiguousarray(sem_cur, np.int32)
+        ol = np.array(obj_label, np.int32, copy=True); out = np.empty((len(sl), 3), np.float32)
+        self.ctx._check(self.ctx.lib.vido_scene_flow(self.ctx.h, _ptr(a), _ptr(b), _ptr(sl), _ptr(sc), len(sl), _ptr(out), _ptr(ol)))
+        return out, ol
+
+
 class ORBextractor:
     """Mirror of VIDO_SLAM::ORBextractor (vido_slam/include/ORBextractor.h:39-49): construct with the five
     ctor arguments, call with a CV_8UC1 image, get keypoints + 32-byte descriptors."""
