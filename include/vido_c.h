@@ -131,6 +131,38 @@ int vido_unproject_world(vido_ctx* ctx, const float* keys_xy, const float* z, in
 int vido_scene_flow(vido_ctx* ctx, const float* xyz_last, const float* xyz_cur, const int32_t* sem_last, const int32_t* sem_cur,
                     int n, float* flow3d_out, int32_t* obj_label_inout);
 
+/* ---- Per-frame pose / object-motion optimisers (Levenberg-Marquardt on the device, FP64) -----------------
+ * One problem = one of the reference's four optimiser calls; the constants each of them hard-codes
+ * (information, Huber delta, rounds, iteration caps, chi2 thresholds) are explicit fields so the caller
+ * (C++ facade Optimizer::PoseOptimization*, or vido-slam_amd/problems.py) states them once.
+ *   mode 0  EdgeSE3ProjectXYZOnlyPose     e = obs - pi_K(T Xw)                  PoseOptimizationNew      Optimizer.cc:2180
+ *   mode 1  EdgeSE3ProjectFlow2 + prior   e = (obs+f) - pi_K(T Twl K^-1(obs,d)) PoseOptimizationFlow2Cam :2622 / Flow2 :3037
+ *   mode 2  EdgeSE3ProjectXYZOnlyObjMotion e = obs - proj(P (H Xw))             PoseOptimizationObjMot   :2826
+ * All matrices row-major double; T is updated as exp(delta) * T (VertexSE3Expmap). */
+typedef struct vido_pose_problem {
+    int32_t mode, n;
+    const double* Xw;          /* [n*3] world points (modes 0, 2) */
+    const double* obs;         /* [n*2] measurement: current keypoint (0, 2) or LAST-frame keypoint (1) */
+    const double* flow0;       /* [n*2] initial optical flow (mode 1) */
+    const double* depth;       /* [n]   depth in the last frame (mode 1) */
+    double Twl[16];            /* last camera -> world (mode 1) */
+    double P[12];              /* K [R|t]_cw, 3x4 (mode 2) */
+    double fx, fy, cx, cy;
+    double T_init[16];         /* initial estimate; every round restarts from it (Optimizer.cc:2266, 2742) */
+    double info_edge, info_prior, huber_delta;
+    int32_t use_huber, rounds, drop_kernel_after_round;
+    int32_t iters[4];
+    float chi2_th[4];
+} vido_pose_problem;
+
+typedef struct vido_pose_result { double T[16]; int32_t n_inliers, lm_iterations; double chi2_final; } vido_pose_result;
+
+/* outlier_out[n] (1 = rejected), flow_out[n*2] refined flow (mode 1; zeros otherwise); either may be NULL. */
+int vido_pose_optimize(vido_ctx* ctx, const vido_pose_problem* prob, vido_pose_result* result, uint8_t* outlier_out, double* flow_out);
+/* n_prob independent problems in one launch (one workgroup each): e.g. all dynamic objects of a frame. */
+int vido_pose_optimize_batch(vido_ctx* ctx, const vido_pose_problem* probs, int n_prob, vido_pose_result* results,
+                             uint8_t* const* outlier_out, double* const* flow_out);
+
 #ifdef __cplusplus
 }
 #endif

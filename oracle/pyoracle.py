@@ -181,3 +181,37 @@ def scene_flow(xl, xc, sl, sc, obj_label):
     ol = np.array(obj_label, np.int32, copy=True); out = np.empty((len(sl), 3), np.float32)
     lib().vo_scene_flow(_p(xl), _p(xc), _p(sl), _p(sc), len(sl), _p(out), _p(ol))
     return out, ol
+
+
+# ---- per-frame optimisers (opt_oracle.c) -----------------------------------------------------------
+class PoseProblem(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("n", C.c_int32), ("Xw", C.c_void_p), ("obs", C.c_void_p), ("flow0", C.c_void_p), ("depth", C.c_void_p),
+                ("Twl", C.c_double * 16), ("P", C.c_double * 12), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("T_init", C.c_double * 16), ("info_edge", C.c_double), ("info_prior", C.c_double), ("huber_delta", C.c_double),
+                ("use_huber", C.c_int32), ("rounds", C.c_int32), ("drop_kernel_after_round", C.c_int32), ("iters", C.c_int32 * 4),
+                ("chi2_th", C.c_float * 4)]
+
+class PoseResult(C.Structure):
+    _fields_ = [("T", C.c_double * 16), ("n_inliers", C.c_int32), ("lm_iterations", C.c_int32), ("chi2_final", C.c_double)]
+
+def pose_optimize(prob_kwargs):
+    """prob_kwargs: dict as produced by vido_slam_amd.pose_problem(...) (numpy arrays + scalars)."""
+    k = prob_kwargs; n = k["n"]; keep = []
+    def arr(name, cols):
+        a = k.get(name)
+        if a is None: return None
+        a = np.ascontiguousarray(a, np.float64).reshape(n, cols) if cols > 1 else np.ascontiguousarray(a, np.float64).reshape(n)
+        keep.append(a); return a.ctypes.data
+    p = PoseProblem()
+    p.mode, p.n = k["mode"], n
+    p.Xw, p.obs, p.flow0, p.depth = arr("Xw", 3), arr("obs", 2), arr("flow0", 2), arr("depth", 1)
+    p.Twl[:] = list(np.asarray(k.get("Twl", np.eye(4)), np.float64).reshape(16)); p.P[:] = list(np.asarray(k.get("P", np.zeros((3, 4))), np.float64).reshape(12))
+    p.fx, p.fy, p.cx, p.cy = k["fx"], k["fy"], k["cx"], k["cy"]
+    p.T_init[:] = list(np.asarray(k["T_init"], np.float64).reshape(16))
+    p.info_edge, p.info_prior, p.huber_delta = k["info_edge"], k["info_prior"], k["huber_delta"]
+    p.use_huber, p.rounds, p.drop_kernel_after_round = k["use_huber"], k["rounds"], k["drop_kernel_after_round"]
+    p.iters[:] = k["iters"]; p.chi2_th[:] = k["chi2_th"]
+    r = PoseResult(); outl = np.zeros(max(n, 1), np.uint8); fl = np.zeros((max(n, 1), 2), np.float64)
+    lib().vo_pose_optimize(C.byref(p), C.byref(r), _p(outl), _p(fl))
+    return dict(T=np.array(r.T[:]).reshape(4, 4), n_inliers=r.n_inliers, lm_iterations=r.lm_iterations, chi2_final=r.chi2_final,
+                outlier=outl[:n].astype(bool), flow=fl[:n])

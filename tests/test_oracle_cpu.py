@@ -1,0 +1,139 @@
+"""CPU: pins the oracle itself (there are no reference golden vectors for this path):
+independent numpy/scipy second implementations, analytic invariants, and the committed golden fixtures."""
+import os
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_orb_params_match_reference_constants(oracle):
+    p = oracle.orb_params()
+    assert list(p.n_per_level)[:8] == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert list(p.umax) == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    p = oracle.orb_params(n_features=2500)
+    assert list(p.n_per_level)[:8] == [543, 452, 377, 314, 262, 218, 182, 152]
+    sizes = [oracle.level_size(p, 640, 480, l) for l in range(8)]
+    assert sizes == [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
+
+
+def test_gray_and_resize_against_numpy(oracle):
+    rng = np.random.RandomState(0)
+    bgr = rng.randint(0, 256, size=(37, 53, 3)).astype(np.uint8)
+    ref = ((bgr[..., 0].astype(np.int64) * 1868 + bgr[..., 1].astype(np.int64) * 9617 + bgr[..., 2].astype(np.int64) * 4899 + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(oracle.bgr2gray(bgr), ref)
+    src = rng.randint(0, 256, size=(48, 64)).astype(np.uint8)
+    dw, dh = 53, 40
+    out = oracle.resize_linear(src, dw, dh)
+    # independent vectorised restatement of the 11-bit fixed-point bilinear rule
+    def tab(s, d):
+        sc = s / d
+        f = ((np.arange(d) + 0.5) * sc - 0.5).astype(np.float32)
+        i = np.floor(f).astype(int); fr = (f - i).astype(np.float32)
+        return i, fr
+    ix, fx = tab(64, dw); iy, fy = tab(48, dh)
+    fx = np.where((ix < 0) | (ix >= 63), 0, fx).astype(np.float32); ix = np.clip(ix, 0, 63)
+    a1 = np.rint(fx * np.float32(2048)).astype(np.int64); a0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(np.int64)
+    b1 = np.rint(fy * np.float32(2048)).astype(np.int64); b0 = np.rint((np.float32(1) - fy) * np.float32(2048)).astype(np.int64)
+    y0 = np.clip(iy, 0, 47); y1 = np.clip(iy + 1, 0, 47); x1 = np.minimum(ix + 1, 63)
+    s = src.astype(np.int64)
+    r0 = s[y0][:, ix] * a0 + s[y0][:, x1] * a1; r1 = s[y1][:, ix] * a0 + s[y1][:, x1] * a1
+    ref = ((((b0[:, None] * (r0 >> 4)) >> 16) + ((b1[:, None] * (r1 >> 4)) >> 16) + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(out, ref)
+
+
+def test_blur_against_scipy(oracle):
+    from scipy.ndimage import correlate1d
+    rng = np.random.RandomState(1)
+    img = rng.randint(0, 256, size=(40, 57)).astype(np.uint8)
+    k = np.array([18, 34, 49, 54, 49, 34, 18], np.int64)
+    t = correlate1d(img.astype(np.int64), k, axis=1, mode="mirror")
+    t = correlate1d(t, k, axis=0, mode="mirror")
+    assert np.array_equal(oracle.gaussian_blur7(img), ((t + 32768) >> 16).astype(np.uint8))
+
+
+def test_fast_literal_equals_score_map_rule(oracle):
+    """cv::FAST restated literally (threshold table, count>8, cornerScore) == threshold-free score map + NMS,
+    the reformulation the HIP kernel uses."""
+    rng = np.random.RandomState(2)
+    for trial in range(6):
+        h, w = rng.randint(20, 50), rng.randint(20, 60)
+        img = (rng.randint(0, 256, size=(h, w)) if trial % 2 else np.clip(rng.normal(120, 30, size=(h, w)), 0, 255)).astype(np.uint8)
+        S = oracle.fast_score_map(img)
+        for th in (7, 20, 40):
+            pts = oracle.fast9_16(img, th)
+            T = np.where(S >= th, S, 0).astype(int); Pd = np.pad(T, 1)
+            keep = T > 0
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    if dx or dy:
+                        keep &= T > Pd[1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
+            ys, xs = np.nonzero(keep)
+            assert np.array_equal(np.stack([xs, ys, T[ys, xs]], 1), pts), (trial, th)
+            # without NMS the corner set is exactly {S >= th}
+            assert len(oracle.fast9_16(img, th, nonmax=False)) == int((S >= th).sum())
+
+
+def test_fast_atan2_accuracy_and_quadrants(oracle):
+    rng = np.random.RandomState(3)
+    for _ in range(200):
+        y, x = rng.uniform(-1e5, 1e5, 2)
+        ref = np.degrees(np.arctan2(y, x)) % 360.0
+        got = oracle.fast_atan2(y, x)
+        assert min(abs(got - ref), 360 - abs(got - ref)) < 0.4
+    assert oracle.fast_atan2(0.0, 1.0) == 0.0 and abs(oracle.fast_atan2(1.0, 0.0) - 90.0) < 1e-4
+
+
+def test_quadtree_invariants(oracle):
+    rng = np.random.RandomState(4)
+    n = 3000
+    cx = rng.randint(0, 608, n).astype(np.float32); cy = rng.randint(0, 448, n).astype(np.float32); cr = rng.randint(7, 200, n).astype(np.float32)
+    sel = oracle.distribute_octree(cx, cy, cr, 16, 624, 16, 464, 434)
+    assert 434 <= len(sel) <= 434 + 3 and len(set(sel.tolist())) == len(sel)
+    # few candidates: every candidate with a distinct position survives
+    sel2 = oracle.distribute_octree(cx[:50], cy[:50], cr[:50], 16, 624, 16, 464, 434)
+    assert len(sel2) == len({(a, b) for a, b in zip(cx[:50], cy[:50])})
+    # determinism
+    assert np.array_equal(sel, oracle.distribute_octree(cx, cy, cr, 16, 624, 16, 464, 434))
+
+
+def test_hamming_against_numpy(oracle):
+    rng = np.random.RandomState(5)
+    a = rng.randint(0, 256, (40, 32)).astype(np.uint8); b = rng.randint(0, 256, (77, 32)).astype(np.uint8)
+    b[9] = b[3]
+    d = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
+    idx, dist = oracle.hamming_match(a, b)
+    assert np.array_equal(idx, d.argmin(1)) and np.array_equal(dist, d.min(1))
+
+
+def test_pose_oracle_jacobians_and_fixed_point(oracle, vido):
+    """Second implementation: scipy least_squares on the same robustified residuals must land on the same pose;
+    LM must leave a noise-free problem at the ground truth."""
+    from scipy.optimize import least_squares
+    P = vido.problems
+    s = P.synth_pose_scene(300, seed=7, noise_px=0.0, outlier_frac=0.0)
+    pr = P.pose_problem_new(s["Xw"], s["uv_cur"], s["K"], s["T_init"])
+    r = oracle.pose_optimize(pr)
+    assert np.abs(r["T"] - s["T_cur"]).max() < 1e-8 and r["n_inliers"] == 300
+    s = P.synth_pose_scene(300, seed=8, noise_px=0.05, outlier_frac=0.0)
+    pr = P.pose_problem_new(s["Xw"], s["uv_cur"], s["K"], s["T_init"])
+    pr["use_huber"] = 0
+    r = oracle.pose_optimize(pr)
+    fx, fy, cx, cy = s["K"]
+
+    def resid(u):
+        T = P.se3_exp(u) @ s["T_init"]
+        X = s["Xw"] @ T[:3, :3].T + T[:3, 3]
+        return np.concatenate([s["uv_cur"][:, 0] - (X[:, 0] / X[:, 2] * fx + cx), s["uv_cur"][:, 1] - (X[:, 1] / X[:, 2] * fy + cy)])
+    sol = least_squares(resid, np.zeros(6), xtol=1e-14, ftol=1e-14, gtol=1e-14)
+    T_ref = P.se3_exp(sol.x) @ s["T_init"]
+    assert np.abs(r["T"] - T_ref).max() < 1e-6
+    # objmot + flow problems converge to their generating transforms too
+    H = P.se3_exp([0.01, 0.03, -0.02, 0.4, 0.05, 0.2])
+    X2 = s["Xw"] @ H[:3, :3].T + H[:3, 3]; Xc = X2 @ s["T_cur"][:3, :3].T + s["T_cur"][:3, 3]
+    obs = np.stack([Xc[:, 0] / Xc[:, 2] * fx + cx, Xc[:, 1] / Xc[:, 2] * fy + cy], 1)
+    r = oracle.pose_optimize(P.pose_problem_objmot(s["Xw"], obs, s["K"], s["T_cur"], np.eye(4)))
+    assert np.abs(r["T"] - H).max() < 1e-7
+    s0 = P.synth_pose_scene(300, seed=9, noise_px=0.0, outlier_frac=0.0)
+    r = oracle.pose_optimize(P.pose_problem_flow2cam(s0["uv_last"], s0["flow"], s0["depth"], s0["Twl"], s0["K"], s0["T_init"]))
+    assert np.abs(r["T"] - s0["T_cur"]).max() < 1e-6 and np.abs(r["flow"] - s0["flow"]).max() < 1e-6

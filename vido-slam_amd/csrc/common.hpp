@@ -44,6 +44,7 @@ struct vido_ctx {
     TrackState* trk = nullptr;
     BaState* ba = nullptr;
     struct HamState* ham = nullptr;
+    struct PoseState* pose = nullptr;
 };
 
 int vido_set_error(vido_ctx* ctx, int code, const char* fmt, ...);
@@ -59,4 +60,5 @@ int vido_set_error(vido_ctx* ctx, int code, const char* fmt, ...);
 int orb_state_create(vido_ctx* ctx);
 void track_state_destroy(vido_ctx* ctx);
 void ham_state_destroy(vido_ctx* ctx);
+void pose_state_destroy(vido_ctx* ctx);
 void orb_state_destroy(vido_ctx* ctx);

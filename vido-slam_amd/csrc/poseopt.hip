@@ -1,0 +1,503 @@
+// poseopt.hip — the four per-frame pose / object-motion optimisers as ONE persistent gfx950 kernel.
+// Replaces Optimizer::PoseOptimizationNew / PoseOptimizationFlow2Cam / PoseOptimizationObjMot /
+// PoseOptimizationFlow2 (reference vido_slam/src/Optimizer.cc:2180-2334, 2622-2824, 2826-3035,
+// 3037-3253) and the g2o pieces they drive (LM policy core/optimization_algorithm_levenberg.cpp:61-189,
+// outer loop core/sparse_optimizer.cpp:354-427, Schur core/block_solver.hpp:354-486, Huber
+// core/robust_kernel_impl.cpp:65-91, residuals/Jacobians types/types_six_dof_expmap.{h,cpp}).
+//
+// Mapping: one workgroup (<=1024 threads, 16 waves) per problem, the WHOLE Levenberg-Marquardt run stays
+// on the device (no host round trip per iteration): every thread owns residuals i, i+T, ...; per
+// linearisation the 21+6 entries of J^T W J / J^T W e (+ chi2, + max diagonal) are summed with a
+// wavefront DPP/shuffle tree and one LDS pass across the waves; for the flow-coupled edges each
+// thread keeps its points' 2x2 (scalar*I) landmark block, 6x2 coupling block and rhs in HBM and forms
+// its Schur contribution; the reduced 6x6 system is solved redundantly by every thread in registers
+// (LDL^T), so the LM accept/reject logic is wave-uniform without broadcasts.  All FP64.
+// Several problems (e.g. the frame's dynamic objects, or a batch of frames) run as a grid.
+#include "common.hpp"
+#include <cfloat>
+
+struct PoseProbDev {
+    int mode, n;
+    const double *Xw, *obs, *flow0, *depth;
+    double Twl[16], P[12], fx, fy, cx, cy, T_init[16], info_edge, info_prior, huber_delta;
+    int use_huber, rounds, drop_kernel_after_round, iters[4];
+    float chi2_th[4];
+    double *f, *err, *fsave, *Hpl, *Hll, *bl, *xl;
+    unsigned char *outlier, *has_kernel;
+    vido_pose_result* res;
+};
+
+struct Se3 { double R[9], t[3]; };
+
+__device__ __forceinline__ void mat3_mul(const double* A, const double* B, double* C)
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) C[r * 3 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c];
+}
+
+// SE3Quat::exp (se3quat.h:221-262) followed by VertexSE3Expmap::oplusImpl: T <- exp(u) * T
+__device__ void se3_oplus_left(Se3& T, const double* u)
+{
+    const double w0 = u[0], w1 = u[1], w2 = u[2];
+    const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+    const double O[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+    double O2[9]; mat3_mul(O, O, O2);
+    double R[9], V[9];
+    if (theta < 0.00001) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
+    } else {
+        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3);
+#pragma unroll
+        for (int i = 0; i < 9; i++) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * O[i] + b * O2[i]; V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * O[i] + c * O2[i]; }
+    }
+    double et[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) et[r] = V[r * 3] * u[3] + V[r * 3 + 1] * u[4] + V[r * 3 + 2] * u[5];
+    Se3 N; mat3_mul(R, T.R, N.R);
+#pragma unroll
+    for (int r = 0; r < 3; r++) N.t[r] = R[r * 3] * T.t[0] + R[r * 3 + 1] * T.t[1] + R[r * 3 + 2] * T.t[2] + et[r];
+    T = N;
+}
+
+// residual (and 2x6 Jacobian when J != nullptr) of edge i
+template <bool WITH_J>
+__device__ __forceinline__ void edge_eval(const PoseProbDev& p, const Se3& T, int i, double f0, double f1, double* e, double* J)
+{
+    double X0, X1, X2;
+    const double o0 = p.obs[2 * i], o1 = p.obs[2 * i + 1];
+    if (p.mode == 1) {
+        const double d = p.depth[i];
+        const double c0 = (o0 - p.cx) * d / p.fx, c1 = (o1 - p.cy) * d / p.fy;
+        X0 = p.Twl[0] * c0 + p.Twl[1] * c1 + p.Twl[2] * d + p.Twl[3];
+        X1 = p.Twl[4] * c0 + p.Twl[5] * c1 + p.Twl[6] * d + p.Twl[7];
+        X2 = p.Twl[8] * c0 + p.Twl[9] * c1 + p.Twl[10] * d + p.Twl[11];
+    } else { X0 = p.Xw[3 * i]; X1 = p.Xw[3 * i + 1]; X2 = p.Xw[3 * i + 2]; }
+    const double x = T.R[0] * X0 + T.R[1] * X1 + T.R[2] * X2 + T.t[0];
+    const double y = T.R[3] * X0 + T.R[4] * X1 + T.R[5] * X2 + T.t[1];
+    const double z = T.R[6] * X0 + T.R[7] * X1 + T.R[8] * X2 + T.t[2];
+    if (p.mode == 2) {
+        const double* P = p.P;
+        const double m1 = P[0] * x + P[1] * y + P[2] * z + P[3], m2 = P[4] * x + P[5] * y + P[6] * z + P[7], m3 = P[8] * x + P[9] * y + P[10] * z + P[11];
+        const double invm3 = 1.0 / m3;
+        e[0] = o0 - m1 * invm3; e[1] = o1 - m2 * invm3;
+        if (WITH_J) {
+            const double i2 = invm3 * invm3;
+            const double t00 = i2 * (P[0] * m3 - P[8] * m1), t01 = i2 * (P[1] * m3 - P[9] * m1), t02 = i2 * (P[2] * m3 - P[10] * m1);
+            const double t10 = i2 * (P[4] * m3 - P[8] * m2), t11 = i2 * (P[5] * m3 - P[9] * m2), t12 = i2 * (P[6] * m3 - P[10] * m2);
+            J[0] = -1.0 * (y * t02 - z * t01); J[1] = -1.0 * (z * t00 - x * t02); J[2] = -1.0 * (x * t01 - y * t00); J[3] = -t00; J[4] = -t01; J[5] = -t02;
+            J[6] = -1.0 * (y * t12 - z * t11); J[7] = -1.0 * (z * t10 - x * t12); J[8] = -1.0 * (x * t11 - y * t10); J[9] = -t10; J[10] = -t11; J[11] = -t12;
+        }
+        return;
+    }
+    const double u = x / z * p.fx + p.cx, v = y / z * p.fy + p.cy;
+    if (p.mode == 1) { e[0] = (o0 + f0) - u; e[1] = (o1 + f1) - v; } else { e[0] = o0 - u; e[1] = o1 - v; }
+    if (WITH_J) {
+        if (p.mode == 0) {
+            const double invz = 1.0 / z, invz_2 = invz * invz;
+            J[0] = x * y * invz_2 * p.fx; J[1] = -(1 + (x * x * invz_2)) * p.fx; J[2] = y * invz * p.fx; J[3] = -invz * p.fx; J[4] = 0; J[5] = x * invz_2 * p.fx;
+            J[6] = (1 + y * y * invz_2) * p.fy; J[7] = -x * y * invz_2 * p.fy; J[8] = -x * invz * p.fy; J[9] = 0; J[10] = -invz * p.fy; J[11] = y * invz_2 * p.fy;
+        } else {
+            const double z_2 = z * z;
+            J[0] = x * y / z_2 * p.fx; J[1] = -(1 + (x * x / z_2)) * p.fx; J[2] = y / z * p.fx; J[3] = -1. / z * p.fx; J[4] = 0; J[5] = x / z_2 * p.fx;
+            J[6] = (1 + y * y / z_2) * p.fy; J[7] = -x * y / z_2 * p.fy; J[8] = -x / z * p.fy; J[9] = 0; J[10] = -1. / z * p.fy; J[11] = y / z_2 * p.fy;
+        }
+    }
+}
+
+__device__ __forceinline__ void huber(double e2, double delta, double& rho0, double& rho1)
+{
+    const double dsqr = delta * delta;
+    if (e2 <= dsqr) { rho0 = e2; rho1 = 1.0; }
+    else { const double s = sqrt(e2); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
+}
+
+// workgroup all-reduce of NV doubles (sum, or max for entries >= first_max): wave shuffle tree, then a
+// fixed-order pass over the per-wave partials in LDS.  Every thread returns the same totals.
+template <int NV>
+__device__ void block_allreduce(double* v, int first_max, double* lds /* [16][NV] + [NV] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        double x = v[k];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const double y = __shfl_xor(x, o, 64); x = k >= first_max ? fmax(x, y) : x + y; }
+        v[k] = x;
+    }
+    __syncthreads();
+    if (lane == 0) for (int k = 0; k < NV; k++) lds[wave * NV + k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const int k = threadIdx.x;
+        double x = lds[k];
+        for (int w = 1; w < nw; w++) x = k >= first_max ? fmax(x, lds[w * NV + k]) : x + lds[w * NV + k];
+        lds[16 * NV + k] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = lds[16 * NV + k];
+}
+
+// 6x6 LDL^T solve in registers; A = upper-triangle-expanded symmetric matrix (row-major 36)
+__device__ bool ldlt6(const double* A, const double* b, double* x)
+{
+    double L[36], D[6];
+#pragma unroll
+    for (int i = 0; i < 36; i++) L[i] = A[i];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double d = L[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k < j) d -= L[j * 6 + k] * L[j * 6 + k] * D[k];
+        if (!(d > 0) || !isfinite(d)) { ok = false; d = 1.0; }
+        D[j] = d;
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (i > j) {
+            double s = L[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < 6; k++) if (k < j) s -= L[i * 6 + k] * L[j * 6 + k] * D[k];
+            L[i * 6 + j] = s / d;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { double s = b[i];
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k < i) s -= L[i * 6 + k] * x[k];
+        x[i] = s; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] /= D[i];
+#pragma unroll
+    for (int i = 5; i >= 0; i--) { double s = x[i];
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k > i) s -= L[k * 6 + i] * x[k];
+        x[i] = s; }
+    return ok;
+}
+
+#define NRED 29      // 21 H + 6 b + chi + maxdiag
+
+__global__ __launch_bounds__(256) void k_pose_opt(const PoseProbDev* __restrict__ probs)
+{
+    __shared__ double lds[17 * NRED];
+    const PoseProbDev p = probs[blockIdx.x];
+    const int n = p.n, tid = threadIdx.x, nt = blockDim.x;
+    const bool flowm = p.mode == 1;
+    Se3 T, Tinit;
+#pragma unroll
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Tinit.R[r * 3 + c] = p.T_init[r * 4 + c]; Tinit.t[r] = p.T_init[r * 4 + 3]; }
+    T = Tinit;
+    for (int i = tid; i < n; i += nt) {
+        p.outlier[i] = 0; p.has_kernel[i] = p.use_huber ? 1 : 0;
+        if (flowm) { p.f[2 * i] = p.flow0[2 * i]; p.f[2 * i + 1] = p.flow0[2 * i + 1]; }
+    }
+    int total_iters = 0, n_inl = 0; double chi2_final = 0;
+    if (n >= 3) {
+        for (int round = 0; round < p.rounds; round++) {
+            T = Tinit;
+            double lambda = -1, ni = 2, chi2_check = 0; int nBad = 0;
+            for (int it = 0; it < p.iters[round]; it++) {
+                // ---- computeActiveErrors + buildSystem in one pass
+                double acc[NRED];
+#pragma unroll
+                for (int k = 0; k < NRED; k++) acc[k] = 0;
+                for (int i = tid; i < n; i += nt) {
+                    double f0 = 0, f1 = 0, hll = 0, bl0 = 0, bl1 = 0;
+                    if (flowm) {
+                        f0 = p.f[2 * i]; f1 = p.f[2 * i + 1];
+                        const double a = f0 - p.flow0[2 * i], b = f1 - p.flow0[2 * i + 1];
+                        acc[27] += p.info_prior * (a * a + b * b);
+                        hll = p.info_prior; bl0 = -p.info_prior * a; bl1 = -p.info_prior * b;
+                    }
+                    double wo = 0, e[2] = {0, 0}, J[12];
+                    const bool act = !p.outlier[i];
+                    if (act) {
+                        edge_eval<true>(p, T, i, f0, f1, e, J);
+                        p.err[2 * i] = e[0]; p.err[2 * i + 1] = e[1];
+                        const double c2 = p.info_edge * (e[0] * e[0] + e[1] * e[1]);
+                        double r0 = c2, w = 1; if (p.has_kernel[i]) huber(c2, p.huber_delta, r0, w);
+                        acc[27] += r0;
+                        wo = w * p.info_edge;
+                        int q = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; a++) {
+                            acc[21 + a] -= wo * (J[a] * e[0] + J[6 + a] * e[1]);
+#pragma unroll
+                            for (int c = a; c < 6; c++) acc[q++] += wo * (J[a] * J[c] + J[6 + a] * J[6 + c]);
+                        }
+                    }
+                    if (flowm) {
+                        if (act) { hll += wo; bl0 -= wo * e[0]; bl1 -= wo * e[1]; }
+                        p.Hll[i] = hll; p.bl[2 * i] = bl0; p.bl[2 * i + 1] = bl1;
+#pragma unroll
+                        for (int a = 0; a < 6; a++) { p.Hpl[12 * i + 2 * a] = act ? wo * J[a] : 0.0; p.Hpl[12 * i + 2 * a + 1] = act ? wo * J[6 + a] : 0.0; }
+                        acc[28] = fmax(acc[28], fabs(hll));
+                    }
+                }
+                block_allreduce<NRED>(acc, 28, lds);
+                double H[36], b6[6];
+                { int q = 0;
+#pragma unroll
+                  for (int a = 0; a < 6; a++)
+#pragma unroll
+                      for (int c = a; c < 6; c++) { H[a * 6 + c] = acc[q]; H[c * 6 + a] = acc[q]; q++; } }
+#pragma unroll
+                for (int a = 0; a < 6; a++) b6[a] = acc[21 + a];
+                double currentChi = acc[27]; const double iniChi = acc[27];
+                if (it == 0) {
+                    double md = acc[28];
+#pragma unroll
+                    for (int a = 0; a < 6; a++) md = fmax(md, fabs(H[a * 6 + a]));
+                    lambda = 1e-5 * md; ni = 2; nBad = 0;
+                }
+                double rho = 0; int qmax = 0;
+                do {
+                    const Se3 Tsave = T;
+                    double S[36], bs[6], xp[6];
+#pragma unroll
+                    for (int k = 0; k < 36; k++) S[k] = H[k];
+#pragma unroll
+                    for (int a = 0; a < 6; a++) { bs[a] = b6[a]; S[a * 6 + a] += lambda; }
+                    if (flowm) {
+                        double sa[27];
+#pragma unroll
+                        for (int k = 0; k < 27; k++) sa[k] = 0;
+                        for (int i = tid; i < n; i += nt) {
+                            p.fsave[2 * i] = p.f[2 * i]; p.fsave[2 * i + 1] = p.f[2 * i + 1];
+                            const double dinv = 1.0 / (p.Hll[i] + lambda); const double* B = p.Hpl + 12 * i;
+                            const double g0 = p.bl[2 * i], g1 = p.bl[2 * i + 1];
+                            double Bv[12];
+#pragma unroll
+                            for (int k = 0; k < 12; k++) Bv[k] = B[k];
+                            int q = 0;
+#pragma unroll
+                            for (int a = 0; a < 6; a++) {
+                                sa[21 + a] += dinv * (Bv[2 * a] * g0 + Bv[2 * a + 1] * g1);
+#pragma unroll
+                                for (int c = a; c < 6; c++) sa[q++] += dinv * (Bv[2 * a] * Bv[2 * c] + Bv[2 * a + 1] * Bv[2 * c + 1]);
+                            }
+                        }
+                        block_allreduce<27>(sa, 27, lds);
+                        int q = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; a++) {
+                            bs[a] -= sa[21 + a];
+#pragma unroll
+                            for (int c = a; c < 6; c++) { S[a * 6 + c] -= sa[q]; if (c != a) S[c * 6 + a] -= sa[q]; q++; }
+                        }
+                    }
+                    const bool ok2 = ldlt6(S, bs, xp);
+                    double part[2] = {0, 0};          // [0] tempChi, [1] landmark part of computeScale
+                    if (ok2) se3_oplus_left(T, xp);
+                    for (int i = tid; i < n; i += nt) {
+                        double f0 = 0, f1 = 0;
+                        if (flowm) {
+                            f0 = p.f[2 * i]; f1 = p.f[2 * i + 1];
+                            if (ok2) {
+                                const double dinv = 1.0 / (p.Hll[i] + lambda); const double* B = p.Hpl + 12 * i;
+                                double c0 = p.bl[2 * i], c1 = p.bl[2 * i + 1];
+#pragma unroll
+                                for (int a = 0; a < 6; a++) { c0 -= B[2 * a] * xp[a]; c1 -= B[2 * a + 1] * xp[a]; }
+                                const double x0 = dinv * c0, x1 = dinv * c1;
+                                part[1] += x0 * (lambda * x0 + p.bl[2 * i]) + x1 * (lambda * x1 + p.bl[2 * i + 1]);
+                                f0 += x0; f1 += x1; p.f[2 * i] = f0; p.f[2 * i + 1] = f1;
+                            }
+                            const double a = f0 - p.flow0[2 * i], b = f1 - p.flow0[2 * i + 1];
+                            part[0] += p.info_prior * (a * a + b * b);
+                        }
+                        if (!p.outlier[i]) {
+                            double e[2]; edge_eval<false>(p, T, i, f0, f1, e, nullptr);
+                            p.err[2 * i] = e[0]; p.err[2 * i + 1] = e[1];
+                            const double c2 = p.info_edge * (e[0] * e[0] + e[1] * e[1]);
+                            double r0 = c2, w = 1; if (p.has_kernel[i]) huber(c2, p.huber_delta, r0, w);
+                            part[0] += r0;
+                        }
+                    }
+                    block_allreduce<2>(part, 2, lds);
+                    double tempChi = part[0], scale = part[1];
+                    if (ok2) {
+#pragma unroll
+                        for (int a = 0; a < 6; a++) scale += xp[a] * (lambda * xp[a] + b6[a]);
+                    } else tempChi = DBL_MAX;
+                    rho = (currentChi - tempChi) / (scale + 1e-3);
+                    if (rho > 0 && isfinite(tempChi)) {
+                        double alpha = 1. - pow((2 * rho - 1), 3);
+                        alpha = fmin(alpha, 2. / 3.);
+                        lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
+                    } else {
+                        lambda *= ni; ni *= 2; T = Tsave;
+                        if (flowm) for (int i = tid; i < n; i += nt) { p.f[2 * i] = p.fsave[2 * i]; p.f[2 * i + 1] = p.fsave[2 * i + 1]; }
+                    }
+                    qmax++;
+                } while (rho < 0 && qmax < 10);
+                total_iters++;
+                bool terminate = (qmax == 10 || rho == 0);
+                if (!terminate) { if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0; if (nBad >= 3) terminate = true; }
+                // activeRobustChi2() over the errors left by the last trial (sparse_optimizer.cpp:393-396)
+                double last[1] = {0};
+                for (int i = tid; i < n; i += nt) {
+                    if (!p.outlier[i]) {
+                        const double c2 = p.info_edge * (p.err[2 * i] * p.err[2 * i] + p.err[2 * i + 1] * p.err[2 * i + 1]);
+                        double r0 = c2, w; if (p.has_kernel[i]) huber(c2, p.huber_delta, r0, w);
+                        last[0] += r0;
+                    }
+                    if (flowm) { const double a = p.f[2 * i] - p.flow0[2 * i], b = p.f[2 * i + 1] - p.flow0[2 * i + 1]; last[0] += p.info_prior * (a * a + b * b); }
+                }
+                block_allreduce<1>(last, 1, lds);
+                if (chi2_check < last[0] && it > 0) terminate = true;
+                chi2_check = last[0];
+                chi2_final = currentChi;
+                if (terminate) break;
+            }
+            // ---- inlier / outlier classification
+            double nb[1] = {0};
+            for (int i = tid; i < n; i += nt) {
+                double e0 = p.err[2 * i], e1 = p.err[2 * i + 1];
+                if (p.outlier[i]) { double e[2]; edge_eval<false>(p, T, i, flowm ? p.f[2 * i] : 0.0, flowm ? p.f[2 * i + 1] : 0.0, e, nullptr); e0 = e[0]; e1 = e[1]; p.err[2 * i] = e0; p.err[2 * i + 1] = e1; }
+                const float chi2 = (float)(p.info_edge * (e0 * e0 + e1 * e1));
+                if (chi2 > p.chi2_th[round]) { p.outlier[i] = 1; nb[0] += 1; } else p.outlier[i] = 0;
+                if (round == p.drop_kernel_after_round) p.has_kernel[i] = 0;
+            }
+            block_allreduce<1>(nb, 1, lds);
+            n_inl = n - (int)nb[0];
+        }
+    }
+    if (tid == 0) {
+        vido_pose_result* r = p.res;
+        for (int rr = 0; rr < 3; rr++) { for (int c = 0; c < 3; c++) r->T[rr * 4 + c] = T.R[rr * 3 + c]; r->T[rr * 4 + 3] = T.t[rr]; }
+        r->T[12] = r->T[13] = r->T[14] = 0; r->T[15] = 1;
+        r->n_inliers = n_inl; r->lm_iterations = total_iters; r->chi2_final = chi2_final;
+    }
+}
+
+// ---- host ------------------------------------------------------------------------------------------
+struct PoseState {
+    double* d_arena = nullptr; size_t arena_cap = 0;       // doubles
+    unsigned char* d_bytes = nullptr; size_t bytes_cap = 0;
+    PoseProbDev* d_probs = nullptr; vido_pose_result* d_res = nullptr; size_t prob_cap = 0;
+    double* h_stage = nullptr; size_t stage_cap = 0;       // pinned
+    PoseProbDev* h_probs = nullptr; vido_pose_result* h_res = nullptr; unsigned char* h_bytes = nullptr; size_t hbytes_cap = 0;
+};
+
+template <class T>
+static int grow_dev(vido_ctx* ctx, T** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return VIDO_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (*p) { HIP_TRY(ctx, hipFree(*p)); *p = nullptr; }
+    const size_t n = need + need / 2 + 64;
+    HIP_TRY(ctx, hipMalloc((void**)p, n * sizeof(T)));
+    *cap = n;
+    return VIDO_OK;
+}
+template <class T>
+static int grow_pinned(vido_ctx* ctx, T** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return VIDO_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (*p) { HIP_TRY(ctx, hipHostFree(*p)); *p = nullptr; }
+    const size_t n = need + need / 2 + 64;
+    HIP_TRY(ctx, hipHostMalloc((void**)p, n * sizeof(T)));
+    *cap = n;
+    return VIDO_OK;
+}
+
+void pose_state_destroy(vido_ctx* ctx)
+{
+    PoseState* S = ctx->pose;
+    if (!S) return;
+    hipFree(S->d_arena); hipFree(S->d_bytes); hipFree(S->d_probs); hipFree(S->d_res);
+    hipHostFree(S->h_stage); hipHostFree(S->h_probs); hipHostFree(S->h_res); hipHostFree(S->h_bytes);
+    delete S; ctx->pose = nullptr;
+}
+
+extern "C" int vido_pose_optimize_batch(vido_ctx* ctx, const vido_pose_problem* probs, int n_prob, vido_pose_result* results,
+                                        uint8_t* const* outlier_out, double* const* flow_out)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!probs || !results || n_prob < 1) return vido_set_error(ctx, VIDO_E_INVALID, "pose_optimize: null/empty problem list");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->pose) ctx->pose = new PoseState();
+    PoseState* S = ctx->pose;
+    hipStream_t st = ctx->stream;
+    size_t nd_in = 0, nd_work = 0, nb = 0; int nmax = 0;
+    for (int k = 0; k < n_prob; k++) {
+        const vido_pose_problem& p = probs[k];
+        if (p.n < 0 || p.mode < 0 || p.mode > 2 || p.rounds < 1 || p.rounds > 4 || (p.n > 0 && !p.obs) || (p.mode != 1 && p.n > 0 && !p.Xw) ||
+            (p.mode == 1 && p.n > 0 && (!p.flow0 || !p.depth)))
+            return vido_set_error(ctx, VIDO_E_INVALID, "pose_optimize: problem %d is malformed (mode %d, n %d)", k, p.mode, p.n);
+        const size_t n = (size_t)p.n;
+        nd_in += 8 * n + 8; nd_work += 23 * n + 32; nb += 2 * n + 16; nmax = std::max(nmax, p.n);
+    }
+    int rc;
+    if ((rc = grow_dev(ctx, &S->d_arena, &S->arena_cap, nd_in + nd_work))) return rc;
+    if ((rc = grow_dev(ctx, &S->d_bytes, &S->bytes_cap, nb))) return rc;
+    if ((rc = grow_pinned(ctx, &S->h_stage, &S->stage_cap, std::max(nd_in, (size_t)2 * nmax * n_prob + 16)))) return rc;
+    if ((rc = grow_pinned(ctx, &S->h_bytes, &S->hbytes_cap, nb))) return rc;
+    if ((size_t)n_prob > S->prob_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (S->d_probs) { hipFree(S->d_probs); hipFree(S->d_res); hipHostFree(S->h_probs); hipHostFree(S->h_res); }
+        S->prob_cap = (size_t)n_prob * 2 + 8;
+        HIP_TRY(ctx, hipMalloc((void**)&S->d_probs, S->prob_cap * sizeof(PoseProbDev))); HIP_TRY(ctx, hipMalloc((void**)&S->d_res, S->prob_cap * sizeof(vido_pose_result)));
+        HIP_TRY(ctx, hipHostMalloc((void**)&S->h_probs, S->prob_cap * sizeof(PoseProbDev))); HIP_TRY(ctx, hipHostMalloc((void**)&S->h_res, S->prob_cap * sizeof(vido_pose_result)));
+    }
+    // pack inputs into the pinned stage and lay out the device arena
+    size_t so = 0, wo = nd_in, bo = 0;
+    std::vector<size_t> flow_off(n_prob), byte_off(n_prob);
+    for (int k = 0; k < n_prob; k++) {
+        const vido_pose_problem& p = probs[k]; PoseProbDev& d = S->h_probs[k];
+        const size_t n = (size_t)p.n;
+        memset(&d, 0, sizeof d);
+        d.mode = p.mode; d.n = p.n;
+        auto put = [&](const double* src, size_t cnt) -> const double* {
+            const double* dev = S->d_arena + so;
+            if (src && cnt) memcpy(S->h_stage + so, src, cnt * sizeof(double)); else if (cnt) memset(S->h_stage + so, 0, cnt * sizeof(double));
+            so += cnt; return dev; };
+        d.Xw = put(p.mode != 1 ? p.Xw : nullptr, p.mode != 1 ? 3 * n : 0);
+        d.obs = put(p.obs, 2 * n);
+        d.flow0 = put(p.mode == 1 ? p.flow0 : nullptr, p.mode == 1 ? 2 * n : 0);
+        d.depth = put(p.mode == 1 ? p.depth : nullptr, p.mode == 1 ? n : 0);
+        so = (so + 1) & ~(size_t)1;
+        memcpy(d.Twl, p.Twl, sizeof d.Twl); memcpy(d.P, p.P, sizeof d.P); memcpy(d.T_init, p.T_init, sizeof d.T_init);
+        d.fx = p.fx; d.fy = p.fy; d.cx = p.cx; d.cy = p.cy; d.info_edge = p.info_edge; d.info_prior = p.info_prior; d.huber_delta = p.huber_delta;
+        d.use_huber = p.use_huber; d.rounds = p.rounds; d.drop_kernel_after_round = p.drop_kernel_after_round;
+        for (int q = 0; q < 4; q++) { d.iters[q] = p.iters[q]; d.chi2_th[q] = p.chi2_th[q]; }
+        double* w = S->d_arena + wo;
+        d.f = w; flow_off[k] = wo; w += 2 * n; d.err = w; w += 2 * n; d.fsave = w; w += 2 * n; d.Hpl = w; w += 12 * n; d.Hll = w; w += n; d.bl = w; w += 2 * n; d.xl = w; w += 2 * n;
+        wo += 23 * n + 32;
+        d.outlier = S->d_bytes + bo; byte_off[k] = bo; d.has_kernel = S->d_bytes + bo + n; bo += 2 * n + 16;
+        d.res = S->d_res + k;
+    }
+    if (so) HIP_TRY(ctx, hipMemcpyAsync(S->d_arena, S->h_stage, so * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(S->d_probs, S->h_probs, n_prob * sizeof(PoseProbDev), hipMemcpyHostToDevice, st));
+    const int threads = std::min(256, std::max(64, (nmax + 63) & ~63));
+    hipLaunchKernelGGL(k_pose_opt, dim3(n_prob), dim3(threads), 0, st, S->d_probs);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(S->h_res, S->d_res, n_prob * sizeof(vido_pose_result), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(S->h_bytes, S->d_bytes, bo, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));           // inputs consumed: the stage can now carry the refined flows back
+    size_t fo = 0;
+    std::vector<size_t> fstage(n_prob);
+    for (int k = 0; k < n_prob; k++) {
+        const size_t n = (size_t)probs[k].n;
+        fstage[k] = fo;
+        if (flow_out && flow_out[k] && probs[k].mode == 1 && n) { HIP_TRY(ctx, hipMemcpyAsync(S->h_stage + fo, S->d_arena + flow_off[k], 2 * n * sizeof(double), hipMemcpyDeviceToHost, st)); fo += 2 * n; }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int k = 0; k < n_prob; k++) {
+        const size_t n = (size_t)probs[k].n;
+        results[k] = S->h_res[k];
+        if (outlier_out && outlier_out[k] && n) memcpy(outlier_out[k], S->h_bytes + byte_off[k], n);
+        if (flow_out && flow_out[k] && n) { if (probs[k].mode == 1) memcpy(flow_out[k], S->h_stage + fstage[k], 2 * n * sizeof(double)); else memset(flow_out[k], 0, 2 * n * sizeof(double)); }
+    }
+    return VIDO_OK;
+}
+
+extern "C" int vido_pose_optimize(vido_ctx* ctx, const vido_pose_problem* prob, vido_pose_result* result, uint8_t* outlier_out, double* flow_out)
+{
+    uint8_t* o[1] = {outlier_out}; double* f[1] = {flow_out};
+    return vido_pose_optimize_batch(ctx, prob, 1, result, o, f);
+}

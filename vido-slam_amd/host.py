@@ -260,6 +260,65 @@ class FrameFeatures:
         return out, ol
 
 
+class PoseProblem(C.Structure):
+    """vido_pose_problem (include/vido_c.h)."""
+    _fields_ = [("mode", C.c_int32), ("n", C.c_int32), ("Xw", C.c_void_p), ("obs", C.c_void_p), ("flow0", C.c_void_p), ("depth", C.c_void_p),
+                ("Twl", C.c_double * 16), ("P", C.c_double * 12), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("T_init", C.c_double * 16), ("info_edge", C.c_double), ("info_prior", C.c_double), ("huber_delta", C.c_double),
+                ("use_huber", C.c_int32), ("rounds", C.c_int32), ("drop_kernel_after_round", C.c_int32), ("iters", C.c_int32 * 4),
+                ("chi2_th", C.c_float * 4)]
+
+
+class PoseResult(C.Structure):
+    _fields_ = [("T", C.c_double * 16), ("n_inliers", C.c_int32), ("lm_iterations", C.c_int32), ("chi2_final", C.c_double)]
+
+
+def _fill_pose_problem(p, k, keep):
+    n = k["n"]
+
+    def arr(name, cols):
+        a = k.get(name)
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, np.float64).reshape(n, cols) if cols > 1 else np.ascontiguousarray(a, np.float64).reshape(n)
+        keep.append(a)
+        return a.ctypes.data
+    p.mode, p.n = k["mode"], n
+    p.Xw, p.obs, p.flow0, p.depth = arr("Xw", 3), arr("obs", 2), arr("flow0", 2), arr("depth", 1)
+    p.Twl[:] = list(np.asarray(k.get("Twl", np.eye(4)), np.float64).reshape(16))
+    p.P[:] = list(np.asarray(k.get("P", np.zeros((3, 4))), np.float64).reshape(12))
+    p.fx, p.fy, p.cx, p.cy = k["fx"], k["fy"], k["cx"], k["cy"]
+    p.T_init[:] = list(np.asarray(k["T_init"], np.float64).reshape(16))
+    p.info_edge, p.info_prior, p.huber_delta = k["info_edge"], k["info_prior"], k["huber_delta"]
+    p.use_huber, p.rounds, p.drop_kernel_after_round = k["use_huber"], k["rounds"], k["drop_kernel_after_round"]
+    p.iters[:] = k["iters"]
+    p.chi2_th[:] = k["chi2_th"]
+
+
+class Optimizer:
+    """Mirror of the static VIDO_SLAM::Optimizer pose functions (vido_slam/include/Optimizer.h:26-29) over
+    vido_pose_optimize*: problems are the dicts built by vido_slam_amd.problems.pose_problem_*."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def pose_optimize_batch(self, problems):
+        m = len(problems)
+        P = (PoseProblem * m)(); R = (PoseResult * m)(); keep = []
+        outl = [np.zeros(max(k["n"], 1), np.uint8) for k in problems]
+        flows = [np.zeros((max(k["n"], 1), 2), np.float64) for k in problems]
+        for i, k in enumerate(problems):
+            _fill_pose_problem(P[i], k, keep)
+        op = (C.c_void_p * m)(*[o.ctypes.data for o in outl]); fp = (C.c_void_p * m)(*[f.ctypes.data for f in flows])
+        self.ctx._check(self.ctx.lib.vido_pose_optimize_batch(self.ctx.h, P, m, R, op, fp))
+        return [dict(T=np.array(R[i].T[:]).reshape(4, 4), n_inliers=R[i].n_inliers, lm_iterations=R[i].lm_iterations,
+                     chi2_final=R[i].chi2_final, outlier=outl[i][:problems[i]["n"]].astype(bool), flow=flows[i][:problems[i]["n"]])
+                for i in range(m)]
+
+    def pose_optimize(self, problem):
+        return self.pose_optimize_batch([problem])[0]
+
+
 class ORBextractor:
     """Mirror of VIDO_SLAM::ORBextractor (vido_slam/include/ORBextractor.h:39-49): construct with the five
     ctor arguments, call with a CV_8UC1 image, get keypoints + 32-byte descriptors."""

@@ -2,4 +2,5 @@
 Python identifier), so `import vido_slam_amd` resolves its sub-modules from there."""
 import os as _os
 __path__ = [_os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "vido-slam_amd")]
-from .host import *  # noqa: F401,F403
+from .host import *  # noqa: F401,F403,E402
+from . import problems, synth  # noqa: F401,E402
