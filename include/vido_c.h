@@ -163,6 +163,37 @@ int vido_pose_optimize(vido_ctx* ctx, const vido_pose_problem* prob, vido_pose_r
 int vido_pose_optimize_batch(vido_ctx* ctx, const vido_pose_problem* probs, int n_prob, vido_pose_result* results,
                              uint8_t* const* outlier_out, double* const* flow_out);
 
+/* ---- Bundle adjustment (windowed = PartialBatchOptimization, global = FullBatchOptimization) ---------------
+ * Flat SoA problem, all f64 / i32, caller-owned; mirrors what the reference assembles from Map
+ * (Optimizer.cc:216-350): camera-to-world poses (Map::vmCameraPose), one 3-D point per static tracklet,
+ * observations = the point in the camera frame (Get3DinCamera), odometry = Map::vmRigidMotion[k][0],
+ * optional prior on one camera.  Poses are row-major 3x4 [R|t].  cam_T and pt_xyz are updated in place.
+ * Factor set of this build: EdgeSE3PointXYZ + EdgeSE3 + EdgeSE3Prior (the STATIC_ONLY graph); the
+ * object-motion factors of FullBatchOptimization are listed under "next" in DESIGN.md.
+ * Sharding (global BA over several GPUs, one process per GPU): every rank passes the whole problem with its own
+ * landmark range [pt_lo, pt_hi) and rank/world; partial reduced systems are summed through `allreduce`. */
+typedef struct vido_ba_problem {
+    int32_t n_cam, n_pt, n_obs, n_odo, prior_cam, use_huber, max_iters, pad;
+    double* cam_T; double* pt_xyz;
+    const int32_t* obs_cam; const int32_t* obs_pt; const double* obs_meas;
+    const int32_t* odo_i; const int32_t* odo_j; const double* odo_T;
+    double prior_T[12];
+    double info_obs, info_odo, info_prior, huber_obs, huber_odo, gain_threshold;
+    int32_t pt_lo, pt_hi;      /* landmark shard of this rank; pt_hi <= pt_lo means "all" */
+    int32_t rank, world;       /* rank 0 owns the camera-camera factors (odometry, prior) */
+} vido_ba_problem;
+
+typedef struct vido_ba_result { int32_t iterations, lm_trials; double chi2_initial, chi2_final, lambda_final;
+                                double ms_setup;        /* host preprocessing + upload (wall) */
+                                double ms_solve_loop;   /* the LM loop proper, inputs resident in HBM (wall) */
+} vido_ba_result;
+
+/* In-place all-reduce of `count` doubles at DEVICE address `dev_ptr` over all ranks (op 0 = sum, 1 = max);
+ * return 0 on success.  The ctx stream is idle when it is called.  NULL = single GPU. */
+typedef int (*vido_allreduce_fn)(void* user, void* dev_ptr, size_t count, int op);
+
+int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_result* result, vido_allreduce_fn allreduce, void* user);
+
 #ifdef __cplusplus
 }
 #endif

@@ -215,3 +215,72 @@ def pose_optimize(prob_kwargs):
     lib().vo_pose_optimize(C.byref(p), C.byref(r), _p(outl), _p(fl))
     return dict(T=np.array(r.T[:]).reshape(4, 4), n_inliers=r.n_inliers, lm_iterations=r.lm_iterations, chi2_final=r.chi2_final,
                 outlier=outl[:n].astype(bool), flow=fl[:n])
+
+
+# ---- bundle adjustment (ba_oracle.c) -----------------------------------------------------------------
+class BaProblem(C.Structure):
+    _fields_ = [("n_cam", C.c_int32), ("n_pt", C.c_int32), ("n_obs", C.c_int32), ("n_odo", C.c_int32), ("prior_cam", C.c_int32),
+                ("use_huber", C.c_int32), ("max_iters", C.c_int32), ("pad", C.c_int32),
+                ("cam_T", C.c_void_p), ("pt_xyz", C.c_void_p), ("obs_cam", C.c_void_p), ("obs_pt", C.c_void_p), ("obs_meas", C.c_void_p),
+                ("odo_i", C.c_void_p), ("odo_j", C.c_void_p), ("odo_T", C.c_void_p), ("prior_T", C.c_double * 12),
+                ("info_obs", C.c_double), ("info_odo", C.c_double), ("info_prior", C.c_double), ("huber_obs", C.c_double),
+                ("huber_odo", C.c_double), ("gain_threshold", C.c_double)]
+
+class BaResult(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("lm_trials", C.c_int32), ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double)]
+
+def ba_struct(k, cls=BaProblem):
+    """dict from vido_slam_amd.problems.synth_ba_problem -> (struct, keepalive arrays); cam_T / pt_xyz are COPIES that the solver updates."""
+    a = dict(cam_T=np.array(k["cam_T"], np.float64).reshape(-1, 12).copy(), pt_xyz=np.array(k["pt_xyz"], np.float64).reshape(-1, 3).copy(),
+             obs_cam=np.ascontiguousarray(k["obs_cam"], np.int32), obs_pt=np.ascontiguousarray(k["obs_pt"], np.int32),
+             obs_meas=np.ascontiguousarray(k["obs_meas"], np.float64).reshape(-1, 3), odo_i=np.ascontiguousarray(k["odo_i"], np.int32),
+             odo_j=np.ascontiguousarray(k["odo_j"], np.int32), odo_T=np.ascontiguousarray(k["odo_T"], np.float64).reshape(-1, 12))
+    p = cls()
+    p.n_cam, p.n_pt, p.n_obs, p.n_odo = k["n_cam"], k["n_pt"], len(a["obs_cam"]), len(a["odo_i"])
+    p.prior_cam, p.use_huber, p.max_iters = k["prior_cam"], k["use_huber"], k["max_iters"]
+    for name in ("cam_T", "pt_xyz", "obs_cam", "obs_pt", "obs_meas", "odo_i", "odo_j", "odo_T"):
+        setattr(p, name, a[name].ctypes.data)
+    p.prior_T[:] = list(np.asarray(k["prior_T"], np.float64).reshape(12))
+    for name in ("info_obs", "info_odo", "info_prior", "huber_obs", "huber_odo", "gain_threshold"):
+        setattr(p, name, float(k[name]))
+    return p, a
+
+def ba_optimize(k):
+    p, a = ba_struct(k); r = BaResult()
+    lib().vo_ba_optimize(C.byref(p), C.byref(r))
+    return dict(cam_T=a["cam_T"].reshape(-1, 3, 4), pt_xyz=a["pt_xyz"], iterations=r.iterations, lm_trials=r.lm_trials,
+                chi2_initial=r.chi2_initial, chi2_final=r.chi2_final, lambda_final=r.lambda_final)
+
+def ba_chi2(k):
+    p, a = ba_struct(k); f = lib().vo_ba_chi2; f.restype = C.c_double
+    return f(C.byref(p))
+
+def ba_reduced_system(k, lam, pt_lo=0, pt_hi=None, with_cam_factors=True):
+    """(S, r, chi2) of the landmark shard [pt_lo, pt_hi) at the problem's current estimate."""
+    p, a = ba_struct(k); n6 = 6 * p.n_cam; pt_hi = p.n_pt if pt_hi is None else pt_hi
+    Hcc = np.zeros((n6, n6)); bc = np.zeros(n6); Hpp = np.zeros((p.n_pt, 9)); bp = np.zeros((p.n_pt, 3)); W = np.zeros((p.n_obs + 1, 18))
+    chi = C.c_double()
+    lib().vo_ba_linearize(C.byref(p), pt_lo, pt_hi, int(with_cam_factors), _p(Hcc), _p(bc), _p(Hpp), _p(bp), _p(W), C.byref(chi))
+    S = np.zeros((n6, n6)); r = np.zeros(n6)
+    lib().vo_ba_schur(C.byref(p), pt_lo, pt_hi, C.c_double(lam), int(with_cam_factors), _p(Hcc), _p(bc), _p(Hpp), _p(bp), _p(W), _p(S), _p(r))
+    return S, r, chi.value
+
+def ba_edge_se3(Z, Xi, Xj):
+    Z = np.ascontiguousarray(Z, np.float64); Xj = np.ascontiguousarray(Xj, np.float64)
+    e = np.zeros(6); Ji = np.zeros((6, 6)); Jj = np.zeros((6, 6))
+    if Xi is None:
+        lib().vo_ba_edge_se3(_p(Z), None, _p(Xj), _p(e), None, _p(Jj))
+    else:
+        Xi = np.ascontiguousarray(Xi, np.float64); lib().vo_ba_edge_se3(_p(Z), _p(Xi), _p(Xj), _p(e), _p(Ji), _p(Jj))
+    return e, Ji, Jj
+
+def ba_edge_obs(X, pt, m):
+    X = np.ascontiguousarray(X, np.float64); pt = np.ascontiguousarray(pt, np.float64); m = np.ascontiguousarray(m, np.float64)
+    e = np.zeros(3); Jc = np.zeros((3, 6)); Jp = np.zeros((3, 3))
+    lib().vo_ba_edge_obs(_p(X), _p(pt), _p(m), _p(e), _p(Jc), _p(Jp))
+    return e, Jc, Jp
+
+def iso_oplus(X, d):
+    X = np.array(X, np.float64).reshape(3, 4).copy(); d = np.ascontiguousarray(d, np.float64)
+    lib().vo_iso_oplus(_p(X), _p(d))
+    return X

@@ -1,0 +1,725 @@
+// ba.hip — windowed / global bundle adjustment (static landmarks + odometry + prior) on gfx950.
+// Replaces Optimizer::PartialBatchOptimization (reference vido_slam/src/Optimizer.cc:43-1228, STATIC_ONLY
+// graph) and the static/odometry/prior part of Optimizer::FullBatchOptimization (:1235-2178), i.e. the g2o
+// run they set up: LM (core/optimization_algorithm_levenberg.cpp:61-189) + gain stop
+// (core/sparse_optimizer_terminate_action.cpp:49-85) over VertexSE3 / VertexPointXYZ with EdgeSE3PointXYZ
+// (types/edge_se3_pointxyz.cpp:99-135), EdgeSE3 (types/edge_se3.cpp:77-104, isometry3d_gradients.h:85-189),
+// EdgeSE3Prior (types/edge_se3_prior.cpp:89-102), Huber (core/robust_kernel_impl.cpp:65-91).
+// g2o solves the un-eliminated pose+point system; here every LM trial eliminates the points by Schur
+// complement (the same step algebraically) and factors only the reduced camera system.
+//
+// Kernels (all FP64, flat SoA in HBM):
+//   k_ba_linearize  edge-parallel over observations sorted by camera: residual, 3x6 / 3x3 Jacobians, Huber;
+//                   per-observation coupling block W (6x3) written once (144 B, contiguous, in landmark-major
+//                   position); landmark sums by FP64 atomics (contention = track length); camera sums reduced
+//                   inside the wave with DPP shuffles first (a wave's 64 observations share one camera).
+//   k_ba_camfactors odometry / prior factors: 6x6 blocks of the camera-camera part.
+//   k_ba_schur      wave-cooperative per landmark: D=(Hpp+lambda I)^-1, W D staged in LDS, the k(k+1)/2 6x6
+//                   blocks W_i D W_j^T spread over the 64 lanes; accumulation into the reduced system either in
+//                   an LDS-resident copy of S (<=22 cameras: the local-BA window) flushed once per workgroup,
+//                   or with FP64 atomics into the dense S in HBM (global BA).
+//   k_ba_chol_small single-workgroup in-LDS Cholesky solve of the reduced system (local BA);
+//   k_chol_*        blocked right-looking Cholesky in HBM for the global reduced system.
+//   k_ba_update_cams / k_ba_backsub / k_ba_chi2   trial state, back-substitution, robust chi2.
+// Multi-GPU: landmarks are sharded by contiguous id range; every rank linearises its own observations, the
+// partial reduced system (S, r) and the LM scalars are summed through the caller's all-reduce hook (RCCL via
+// torch.distributed in bench.py), the reduced solve is replicated, back-substitution is local.
+#include "common.hpp"
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+
+#define BA_LDS_MAX_N6 120          // reduced systems up to 20 cameras (the reference WINDOW_SIZE) accumulate / factor in LDS
+
+struct BaDev {
+    int n_cam, n_pt, n_obs, n_odo, prior_cam, use_huber, n6, pt_lo;
+    double info_obs, info_odo, info_prior, huber_obs, huber_odo;
+    double *cam, *cam_new, *pt, *pt_new;                    // [n_cam*12], [n_ptl*3]  (points: local shard indices)
+    const int *obs_cam, *obs_pt, *obs_pos; const double* obs_meas;   // sorted by camera; obs_pos = landmark-major slot
+    const int *pt_start;                                    // [n_ptl+1] CSR over landmark-major slots
+    const int *slot_cam;                                    // [n_obs] camera of each landmark-major slot
+    const int *odo_i, *odo_j; const double* odo_T; double prior_T[12];
+    double *W;                                              // [n_obs*18] landmark-major
+    double *Hpp, *bp;                                       // [n_ptl*6], [n_ptl*3]
+    double *Hcd, *bc, *Hodo;                                // [n_cam*36], [n6], [n_odo*36]
+    double *S, *r, *x;                                      // [n6*n6], [n6], [n6]
+    double *scal;                                           // [8]: 0 chi2 1 maxdiag 2 tempChi 3 scale 4 ok
+};
+
+// ---- small math ------------------------------------------------------------------------------------
+__device__ __forceinline__ void huber_w(double e2, double delta, int use, double& r0, double& r1)
+{
+    if (!use || e2 <= delta * delta) { r0 = e2; r1 = 1.0; return; }
+    const double s = sqrt(e2); r0 = 2 * s * delta - delta * delta; r1 = delta / s;
+}
+__device__ __forceinline__ void iso_inv_mul(const double* A, const double* B, double* C)
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) C[r * 4 + c] = A[r] * B[c] + A[4 + r] * B[4 + c] + A[8 + r] * B[8 + c];
+        C[r * 4 + 3] = A[r] * (B[3] - A[3]) + A[4 + r] * (B[7] - A[7]) + A[8 + r] * (B[11] - A[11]);
+    }
+}
+__device__ void rot_to_quat(const double* M, double* q)      // Eigen Quaternion(R) + g2o normalize (w >= 0)
+{
+    const double mm[3][3] = {{M[0], M[1], M[2]}, {M[4], M[5], M[6]}, {M[8], M[9], M[10]}};
+    double t = mm[0][0] + mm[1][1] + mm[2][2];
+    if (t > 0) {
+        t = sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (mm[2][1] - mm[1][2]) * t; q[1] = (mm[0][2] - mm[2][0]) * t; q[2] = (mm[1][0] - mm[0][1]) * t;
+    } else {
+        int i = 0; if (mm[1][1] > mm[0][0]) i = 1; if (mm[2][2] > mm[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(mm[i][i] - mm[j][j] - mm[k][k] + 1.0);
+        double qi = 0.5 * t; t = 0.5 / t;
+        const double qw = (mm[k][j] - mm[j][k]) * t, qj = (mm[j][i] + mm[i][j]) * t, qk = (mm[k][i] + mm[i][k]) * t;
+        q[3] = qw;
+        q[0] = i == 0 ? qi : (j == 0 ? qj : qk); q[1] = i == 1 ? qi : (j == 1 ? qj : qk); q[2] = i == 2 ? qi : (j == 2 ? qj : qk);
+    }
+    const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+#pragma unroll
+    for (int a = 0; a < 4; a++) q[a] /= nrm;
+    if (q[3] < 0) {
+#pragma unroll
+        for (int a = 0; a < 4; a++) q[a] = -q[a];
+    }
+}
+// EdgeSE3 residual (and closed-form Jacobians, see oracle/ba_oracle.c ba_edge_se3)
+__device__ void edge_se3(const double* Z, const double* Xi, const double* Xj, double* e, double* Ji, double* Jj, bool jac)
+{
+    double B[12], E[12], q[4];
+    if (Xi) iso_inv_mul(Xi, Xj, B); else { for (int a = 0; a < 12; a++) B[a] = Xj[a]; }
+    iso_inv_mul(Z, B, E);
+    rot_to_quat(E, q);
+    e[0] = E[3]; e[1] = E[7]; e[2] = E[11]; e[3] = q[0]; e[4] = q[1]; e[5] = q[2];
+    if (!jac) return;
+    const double Q[9] = {q[3], -q[2], q[1], q[2], q[3], -q[0], -q[1], q[0], q[3]};
+    for (int a = 0; a < 36; a++) { Jj[a] = 0; if (Ji) Ji[a] = 0; }
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { Jj[r * 6 + c] = E[r * 4 + c]; Jj[(3 + r) * 6 + 3 + c] = Q[r * 3 + c]; }
+    if (Ji) {
+        const double S[9] = {0, -2 * B[11], 2 * B[7], 2 * B[11], 0, -2 * B[3], -2 * B[7], 2 * B[3], 0};
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
+            Ji[r * 6 + c] = -Z[c * 4 + r];
+            double s = 0, qq = 0;
+            for (int k = 0; k < 3; k++) { s += Z[k * 4 + r] * S[k * 3 + c]; qq += Q[r * 3 + k] * B[c * 4 + k]; }
+            Ji[r * 6 + 3 + c] = s; Ji[(3 + r) * 6 + 3 + c] = -qq;
+        }
+    }
+}
+__device__ __forceinline__ void inv3sym(const double* H6 /*00 01 02 11 12 22*/, double lambda, double* I)
+{
+    const double a = H6[0] + lambda, b = H6[1], c = H6[2], d = H6[3] + lambda, e = H6[4], f = H6[5] + lambda;
+    const double c0 = d * f - e * e, c1 = e * c - b * f, c2 = b * e - d * c;
+    const double det = 1.0 / (a * c0 + b * c1 + c * c2);
+    I[0] = c0 * det; I[1] = c1 * det; I[2] = c2 * det;
+    I[3] = I[1]; I[4] = (a * f - c * c) * det; I[5] = (b * c - a * e) * det;
+    I[6] = I[2]; I[7] = I[5]; I[8] = (a * d - b * b) * det;
+}
+
+// ---- linearisation -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ba_linearize(BaDev P)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool act = k < P.n_obs;
+    int c = -1, l = 0;
+    double acc[28];
+#pragma unroll
+    for (int a = 0; a < 28; a++) acc[a] = 0;
+    if (act) {
+        c = P.obs_cam[k]; l = P.obs_pt[k];
+        const double* X = P.cam + 12 * c; const double* p = P.pt + 3 * l; const double* m = P.obs_meas + 3 * (size_t)k;
+        const double R00 = X[0], R01 = X[1], R02 = X[2], R10 = X[4], R11 = X[5], R12 = X[6], R20 = X[8], R21 = X[9], R22 = X[10];
+        const double d0 = p[0] - X[3], d1 = p[1] - X[7], d2 = p[2] - X[11];
+        const double Z0 = R00 * d0 + R10 * d1 + R20 * d2, Z1 = R01 * d0 + R11 * d1 + R21 * d2, Z2 = R02 * d0 + R12 * d1 + R22 * d2;
+        const double e0 = Z0 - m[0], e1 = Z1 - m[1], e2 = Z2 - m[2];
+        double r0, w; huber_w(P.info_obs * (e0 * e0 + e1 * e1 + e2 * e2), P.huber_obs, P.use_huber, r0, w);
+        const double wo = w * P.info_obs;
+        // Jc = [-I | 2[Zc]x] (3x6), Jp = R^T
+        const double Jc[18] = {-1, 0, 0, 0, -2 * Z2, 2 * Z1,   0, -1, 0, 2 * Z2, 0, -2 * Z0,   0, 0, -1, -2 * Z1, 2 * Z0, 0};
+        const double Jp[9] = {R00, R10, R20, R01, R11, R21, R02, R12, R22};
+        const double e[3] = {e0, e1, e2};
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            acc[21 + a] = -wo * (Jc[a] * e[0] + Jc[6 + a] * e[1] + Jc[12 + a] * e[2]);
+#pragma unroll
+            for (int b = a; b < 6; b++) acc[q++] = wo * (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b] + Jc[12 + a] * Jc[12 + b]);
+        }
+        acc[27] = r0;
+        double* Wk = P.W + 18 * (size_t)P.obs_pos[k];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) Wk[a * 3 + b] = wo * (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b]);
+        double* Hp = P.Hpp + 6 * (size_t)l; double* bpp = P.bp + 3 * (size_t)l;
+        q = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            atomicAdd(bpp + a, -wo * (Jp[a] * e[0] + Jp[3 + a] * e[1] + Jp[6 + a] * e[2]));
+#pragma unroll
+            for (int b = a; b < 3; b++) atomicAdd(Hp + q++, wo * (Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b] + Jp[6 + a] * Jp[6 + b]));
+        }
+    }
+    // camera-side sums: observations are sorted by camera, so a wave normally holds one camera
+    const int c0 = __shfl(c, 0, 64);
+    const bool uniform = __all(c == c0 || !act) && c0 >= 0;
+    if (uniform) {
+#pragma unroll
+        for (int a = 0; a < 28; a++) {
+            double v = acc[a];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            acc[a] = v;
+        }
+        if (lane == 0) {
+            int q = 0;
+            for (int a = 0; a < 6; a++) { atomicAdd(P.bc + 6 * c0 + a, acc[21 + a]); for (int b = a; b < 6; b++) { atomicAdd(P.Hcd + 36 * c0 + a * 6 + b, acc[q]); if (b != a) atomicAdd(P.Hcd + 36 * c0 + b * 6 + a, acc[q]); q++; } }
+            atomicAdd(P.scal + 0, acc[27]);
+        }
+    } else if (act) {
+        int q = 0;
+        for (int a = 0; a < 6; a++) { atomicAdd(P.bc + 6 * c + a, acc[21 + a]); for (int b = a; b < 6; b++) { atomicAdd(P.Hcd + 36 * c + a * 6 + b, acc[q]); if (b != a) atomicAdd(P.Hcd + 36 * c + b * 6 + a, acc[q]); q++; } }
+        atomicAdd(P.scal + 0, acc[27]);
+    }
+}
+
+// odometry edges (k < n_odo) and the prior (k == n_odo)
+__global__ void k_ba_camfactors(BaDev P, int with_jac, const double* cam, double* chi_out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = P.n_odo + (P.prior_cam >= 0 ? 1 : 0);
+    if (k >= n) return;
+    const bool is_prior = k == P.n_odo;
+    const int i = is_prior ? -1 : P.odo_i[k], j = is_prior ? P.prior_cam : P.odo_j[k];
+    double e[6], Ji[36], Jj[36];
+    edge_se3(is_prior ? P.prior_T : P.odo_T + 12 * k, is_prior ? nullptr : cam + 12 * i, cam + 12 * j, e, is_prior ? nullptr : Ji, Jj, with_jac != 0);
+    double s2 = 0; for (int a = 0; a < 6; a++) s2 += e[a] * e[a];
+    const double info = is_prior ? P.info_prior : P.info_odo;
+    double r0 = info * s2, w = 1;
+    if (!is_prior) huber_w(info * s2, P.huber_odo, P.use_huber, r0, w);
+    atomicAdd(chi_out, r0);
+    if (!with_jac) return;
+    const double wo = w * info;
+    for (int a = 0; a < 6; a++) {
+        double sj = 0, si = 0;
+        for (int r = 0; r < 6; r++) { sj += Jj[r * 6 + a] * e[r]; if (!is_prior) si += Ji[r * 6 + a] * e[r]; }
+        atomicAdd(P.bc + 6 * j + a, -wo * sj); if (!is_prior) atomicAdd(P.bc + 6 * i + a, -wo * si);
+        for (int b = 0; b < 6; b++) {
+            double hjj = 0, hii = 0, hij = 0;
+            for (int r = 0; r < 6; r++) { hjj += Jj[r * 6 + a] * Jj[r * 6 + b]; if (!is_prior) { hii += Ji[r * 6 + a] * Ji[r * 6 + b]; hij += Ji[r * 6 + a] * Jj[r * 6 + b]; } }
+            atomicAdd(P.Hcd + 36 * j + a * 6 + b, wo * hjj);
+            if (!is_prior) { atomicAdd(P.Hcd + 36 * i + a * 6 + b, wo * hii); P.Hodo[36 * k + a * 6 + b] = wo * hij; }
+        }
+    }
+}
+
+// max |diag| over camera blocks and landmark blocks (computeLambdaInit)
+__global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev P, int n_ptl)
+{
+    double m = 0;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (int a = tid; a < P.n6; a += nt) m = fmax(m, fabs(P.Hcd[36 * (a / 6) + 7 * (a % 6)]));
+    for (int l = tid; l < n_ptl; l += nt) m = fmax(m, fmax(fabs(P.Hpp[6 * (size_t)l]), fmax(fabs(P.Hpp[6 * (size_t)l + 3]), fabs(P.Hpp[6 * (size_t)l + 5]))));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) {      // non-negative doubles order like their bit patterns
+        atomicMax((unsigned long long*)(P.scal + 1), (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+// S <- camera-camera part (+ lambda on the diagonal when add_lambda), r <- bc   (upper AND lower filled)
+__global__ __launch_bounds__(256) void k_ba_init_S(BaDev P, double lambda, int add_cam_part)
+{
+    const int n6 = P.n6;
+    const size_t tot = (size_t)n6 * n6;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(t / n6), col = (int)(t % n6);
+        double v = 0;
+        if (add_cam_part && row / 6 == col / 6) { v = P.Hcd[36 * (row / 6) + (row % 6) * 6 + col % 6]; if (row == col) v += lambda; }
+        P.S[t] = v;
+    }
+    for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < n6; a += gridDim.x * blockDim.x) P.r[a] = P.bc[a];
+}
+__global__ void k_ba_add_odo(BaDev P)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.n_odo * 36) return;
+    const int k = t / 36, a = (t % 36) / 6, b = t % 6, i = P.odo_i[k], j = P.odo_j[k];
+    const double v = P.Hodo[t];
+    atomicAdd(P.S + (size_t)(6 * i + a) * P.n6 + 6 * j + b, v);
+    atomicAdd(P.S + (size_t)(6 * j + b) * P.n6 + 6 * i + a, v);
+}
+
+// ---- Schur complement: one wave per landmark ------------------------------------------------------------
+// LDS_S: the whole reduced system lives in LDS (n6 <= BA_LDS_MAX_N6) and is flushed once per workgroup.
+template <bool LDS_S>
+__global__ __launch_bounds__(256) void k_ba_schur(BaDev P, int n_ptl, double lambda, int kcap, double* S_part /*[grid][n6*n6 + n6] when LDS_S*/)
+{
+    extern __shared__ double lds[];
+    const int n6 = P.n6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    double* Sl = lds;                                        // [n6*n6 + n6] when LDS_S
+    double* stage = lds + (LDS_S ? (size_t)n6 * n6 + n6 : 0) + (size_t)wave * (2 * kcap * 18);   // W, WD of up to kcap obs per wave
+    if (LDS_S) { for (int t = threadIdx.x; t < n6 * n6 + n6; t += blockDim.x) Sl[t] = 0; __syncthreads(); }
+    for (int l = blockIdx.x * nw + wave; l < n_ptl; l += gridDim.x * nw) {
+        const int beg = P.pt_start[l], k = min(P.pt_start[l + 1] - beg, kcap);
+        double Di[9]; inv3sym(P.Hpp + 6 * (size_t)l, lambda, Di);
+        const double b0 = P.bp[3 * (size_t)l], b1 = P.bp[3 * (size_t)l + 1], b2 = P.bp[3 * (size_t)l + 2];
+        double* Wl = stage; double* WDl = stage + kcap * 18;
+        for (int t = lane; t < k * 18; t += 64) Wl[t] = P.W[18 * (size_t)beg + t];
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < k * 6; t += 64) {              // WD = W * Di, row t of the stacked (6k x 3)
+            const double w0 = Wl[t * 3], w1 = Wl[t * 3 + 1], w2 = Wl[t * 3 + 2];
+            const double d0 = w0 * Di[0] + w1 * Di[3] + w2 * Di[6], d1 = w0 * Di[1] + w1 * Di[4] + w2 * Di[7], d2 = w0 * Di[2] + w1 * Di[5] + w2 * Di[8];
+            WDl[t * 3] = d0; WDl[t * 3 + 1] = d1; WDl[t * 3 + 2] = d2;
+            const int c = P.slot_cam[beg + t / 6];
+            const double rv = -(d0 * b0 + d1 * b1 + d2 * b2);
+            if (LDS_S) atomicAdd(Sl + (size_t)n6 * n6 + 6 * c + t % 6, rv); else atomicAdd(P.r + 6 * c + t % 6, rv);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // all ordered pairs (i, j): block (ci, cj) -= WD_i W_j^T ; one 6x6 block per lane-iteration
+        for (int pq = lane; pq < k * k; pq += 64) {
+            const int i = pq / k, j = pq - i * k;
+            const int ci = P.slot_cam[beg + i], cj = P.slot_cam[beg + j];
+            const double* A = WDl + i * 18; const double* Bm = Wl + j * 18;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = 0; b < 6; b++) {
+                    const double v = -(A[a * 3] * Bm[b * 3] + A[a * 3 + 1] * Bm[b * 3 + 1] + A[a * 3 + 2] * Bm[b * 3 + 2]);
+                    if (LDS_S) atomicAdd(Sl + (size_t)(6 * ci + a) * n6 + 6 * cj + b, v);
+                    else atomicAdd(P.S + (size_t)(6 * ci + a) * n6 + 6 * cj + b, v);
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (LDS_S) {
+        __syncthreads();
+        double* out = S_part + (size_t)blockIdx.x * ((size_t)n6 * n6 + n6);
+        for (int t = threadIdx.x; t < n6 * n6 + n6; t += blockDim.x) out[t] = Sl[t];
+    }
+}
+__global__ __launch_bounds__(256) void k_ba_fold_parts(BaDev P, const double* S_part, int nparts)
+{
+    const size_t sz = (size_t)P.n6 * P.n6 + P.n6;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < sz; t += (size_t)gridDim.x * blockDim.x) {
+        double s = 0;
+        for (int p = 0; p < nparts; p++) s += S_part[(size_t)p * sz + t];
+        if (t < (size_t)P.n6 * P.n6) P.S[t] += s; else P.r[t - (size_t)P.n6 * P.n6] += s;
+    }
+}
+
+// ---- reduced solve --------------------------------------------------------------------------------------
+// single workgroup, whole matrix in LDS: Cholesky (LL^T), forward/back substitution.  scal[4] = 1 on success.
+__global__ __launch_bounds__(256) void k_ba_chol_small(BaDev P)
+{
+    extern __shared__ double lds[];
+    const int n = P.n6, tid = threadIdx.x, nt = blockDim.x;
+    double* A = lds; double* y = lds + (size_t)n * n;
+    __shared__ int ok;
+    for (int t = tid; t < n * n; t += nt) A[t] = P.S[t];
+    for (int t = tid; t < n; t += nt) y[t] = P.r[t];
+    if (tid == 0) ok = 1;
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+        if (tid == 0) { const double d = A[j * n + j]; if (!(d > 0) || !isfinite(d)) { ok = 0; A[j * n + j] = 1.0; } else A[j * n + j] = sqrt(d); }
+        __syncthreads();
+        const double dj = A[j * n + j];
+        for (int i = j + 1 + tid; i < n; i += nt) A[i * n + j] /= dj;
+        __syncthreads();
+        // trailing update of the lower triangle: A[i][c] -= A[i][j] * A[c][j]
+        const int m = n - j - 1;
+        for (int t = tid; t < m * m; t += nt) { const int i = j + 1 + t / m, c = j + 1 + t % m; if (c <= i) A[i * n + c] -= A[i * n + j] * A[c * n + j]; }
+        __syncthreads();
+    }
+    // forward L z = y, backward L^T x = z
+    for (int j = 0; j < n; j++) {
+        if (tid == 0) y[j] /= A[j * n + j];
+        __syncthreads();
+        const double yj = y[j];
+        for (int i = j + 1 + tid; i < n; i += nt) y[i] -= A[i * n + j] * yj;
+        __syncthreads();
+    }
+    for (int j = n - 1; j >= 0; j--) {
+        if (tid == 0) y[j] /= A[j * n + j];
+        __syncthreads();
+        const double yj = y[j];
+        for (int i = tid; i < j; i += nt) y[i] -= A[j * n + i] * yj;
+        __syncthreads();
+    }
+    for (int t = tid; t < n; t += nt) P.x[t] = y[t];
+    if (tid == 0) P.scal[4] = (double)ok;
+}
+
+// blocked right-looking Cholesky in HBM, lower triangle of row-major A (n x n, n any), tile NB = 32.
+#define NB 32
+__global__ __launch_bounds__(256) void k_chol_diag(double* A, int n, int k0, double* okflag)
+{
+    __shared__ double T[NB][NB + 1];
+    const int nb = min(NB, n - k0), tid = threadIdx.x;
+    for (int t = tid; t < nb * nb; t += 256) T[t / nb][t % nb] = A[(size_t)(k0 + t / nb) * n + k0 + t % nb];
+    __syncthreads();
+    for (int j = 0; j < nb; j++) {
+        if (tid == 0) { const double d = T[j][j]; if (!(d > 0) || !isfinite(d)) { *okflag = 0; T[j][j] = 1.0; } else T[j][j] = sqrt(d); }
+        __syncthreads();
+        if (tid > j && tid < nb) T[tid][j] /= T[j][j];
+        __syncthreads();
+        for (int t = tid; t < nb * nb; t += 256) { const int i = t / nb, c = t % nb; if (i > j && c > j && c <= i) T[i][c] -= T[i][j] * T[c][j]; }
+        __syncthreads();
+    }
+    for (int t = tid; t < nb * nb; t += 256) if (t % nb <= t / nb) A[(size_t)(k0 + t / nb) * n + k0 + t % nb] = T[t / nb][t % nb];
+}
+// panel: rows below the diagonal tile: X L11^T = A21  (each workgroup: NB rows)
+__global__ __launch_bounds__(256) void k_chol_panel(double* A, int n, int k0)
+{
+    __shared__ double L[NB][NB + 1], X[NB][NB + 1];
+    const int nb = min(NB, n - k0), r0 = k0 + nb + blockIdx.x * NB, nr = min(NB, n - r0), tid = threadIdx.x;
+    if (nr <= 0) return;
+    for (int t = tid; t < nb * nb; t += 256) L[t / nb][t % nb] = A[(size_t)(k0 + t / nb) * n + k0 + t % nb];
+    for (int t = tid; t < nr * nb; t += 256) X[t / nb][t % nb] = A[(size_t)(r0 + t / nb) * n + k0 + t % nb];
+    __syncthreads();
+    if (tid < nr) {                                       // one row per thread: forward substitution against L^T
+        for (int j = 0; j < nb; j++) { double s = X[tid][j]; for (int c = 0; c < j; c++) s -= X[tid][c] * L[j][c]; X[tid][j] = s / L[j][j]; }
+    }
+    __syncthreads();
+    for (int t = tid; t < nr * nb; t += 256) A[(size_t)(r0 + t / nb) * n + k0 + t % nb] = X[t / nb][t % nb];
+}
+// trailing update: A22 -= L21 L21^T on the lower triangle, one NBxNB tile per workgroup
+__global__ __launch_bounds__(256) void k_chol_update(double* A, int n, int k0)
+{
+    __shared__ double Pa[NB][NB + 1], Pb[NB][NB + 1];
+    const int nb = min(NB, n - k0), base = k0 + nb;
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    const int r0 = base + ti * NB, c0 = base + tj * NB, nr = min(NB, n - r0), nc = min(NB, n - c0), tid = threadIdx.x;
+    if (nr <= 0 || nc <= 0) return;
+    for (int t = tid; t < nr * nb; t += 256) Pa[t / nb][t % nb] = A[(size_t)(r0 + t / nb) * n + k0 + t % nb];
+    for (int t = tid; t < nc * nb; t += 256) Pb[t / nb][t % nb] = A[(size_t)(c0 + t / nb) * n + k0 + t % nb];
+    __syncthreads();
+    for (int t = tid; t < nr * nc; t += 256) {
+        const int i = t / nc, c = t % nc;
+        if (c0 + c > r0 + i) continue;
+        double s = 0;
+        for (int q = 0; q < nb; q++) s += Pa[i][q] * Pb[c][q];
+        A[(size_t)(r0 + i) * n + c0 + c] -= s;
+    }
+}
+// triangular solves with the factor in HBM: single workgroup of 1024 threads, blocked by NB so that every
+// global access is a contiguous NB-double row segment (x in place in y, y in LDS).
+__global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ A, int n, const double* __restrict__ b, double* __restrict__ x)
+{
+    extern __shared__ double y[];                         // [n] + [NB*NB] diagonal tile + [16*NB] partials
+    double* T = y + n; double* part = T + NB * NB;
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    for (int t = tid; t < n; t += nt) y[t] = b[t];
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += NB) {                  // forward: L z = b
+        const int nb = min(NB, n - k0);
+        for (int t = tid; t < nb * nb; t += nt) T[t] = A[(size_t)(k0 + t / nb) * n + k0 + t % nb];
+        __syncthreads();
+        if (tid == 0) for (int j = 0; j < nb; j++) { double s = y[k0 + j]; for (int c = 0; c < j; c++) s -= T[j * nb + c] * y[k0 + c]; y[k0 + j] = s / T[j * nb + j]; }
+        __syncthreads();
+        for (int i = k0 + nb + tid; i < n; i += nt) {     // rows below: y[i] -= L[i][k0..k0+nb) . z_blk
+            const double* row = A + (size_t)i * n + k0; double s = 0;
+            for (int c = 0; c < nb; c++) s += row[c] * y[k0 + c];
+            y[i] -= s;
+        }
+        __syncthreads();
+    }
+    for (int k0 = ((n - 1) / NB) * NB; k0 >= 0; k0 -= NB) {   // backward: L^T x = z
+        const int nb = min(NB, n - k0);
+        double acc[NB];
+#pragma unroll
+        for (int c = 0; c < NB; c++) acc[c] = 0;
+        for (int i = k0 + nb + tid; i < n; i += nt) {     // s[c] = sum_{i below} L[i][k0+c] * x[i]
+            const double* row = A + (size_t)i * n + k0; const double xi = y[i];
+#pragma unroll
+            for (int c = 0; c < NB; c++) if (c < nb) acc[c] += row[c] * xi;
+        }
+#pragma unroll
+        for (int c = 0; c < NB; c++) { double v = acc[c];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) part[wave * NB + c] = v; }
+        for (int t = tid; t < nb * nb; t += nt) T[t] = A[(size_t)(k0 + t / nb) * n + k0 + t % nb];
+        __syncthreads();
+        if (tid < nb) { double s = 0; for (int w = 0; w < nw; w++) s += part[w * NB + tid]; y[k0 + tid] -= s; }
+        __syncthreads();
+        if (tid == 0) for (int j = nb - 1; j >= 0; j--) { double s = y[k0 + j]; for (int c = j + 1; c < nb; c++) s -= T[c * nb + j] * y[k0 + c]; y[k0 + j] = s / T[j * nb + j]; }
+        __syncthreads();
+    }
+    for (int t = tid; t < n; t += nt) x[t] = y[t];
+}
+
+// ---- trial state ------------------------------------------------------------------------------------------
+__global__ void k_ba_update_cams(BaDev P, double lambda)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    double sc = 0;
+    if (c < P.n_cam) {
+        const double* d = P.x + 6 * c; const double* X = P.cam + 12 * c; double* N = P.cam_new + 12 * c;
+        double w = 1 - (d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (!(w < 0)) {
+            w = sqrt(w);
+            const double x = d[3], y = d[4], z = d[5];
+            R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+            R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+            R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+        }
+        for (int r = 0; r < 3; r++) {
+            for (int q = 0; q < 3; q++) N[r * 4 + q] = X[r * 4] * R[q] + X[r * 4 + 1] * R[3 + q] + X[r * 4 + 2] * R[6 + q];
+            N[r * 4 + 3] = X[r * 4] * d[0] + X[r * 4 + 1] * d[1] + X[r * 4 + 2] * d[2] + X[r * 4 + 3];
+        }
+        for (int a = 0; a < 6; a++) sc += d[a] * (lambda * d[a] + P.bc[6 * c + a]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o, 64);
+    if ((threadIdx.x & 63) == 0 && sc != 0) atomicAdd(P.scal + 3, sc);
+}
+// x_l = D^-1 (b_l - sum_i W_i^T x_ci), p_new = p + x_l; landmark part of computeScale
+__global__ __launch_bounds__(256) void k_ba_backsub(BaDev P, int n_ptl, double lambda)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    double sc = 0;
+    if (l < n_ptl) {
+        double t0 = P.bp[3 * (size_t)l], t1 = P.bp[3 * (size_t)l + 1], t2 = P.bp[3 * (size_t)l + 2];
+        const double b0 = t0, b1 = t1, b2 = t2;
+        for (int s = P.pt_start[l]; s < P.pt_start[l + 1]; s++) {
+            const double* W = P.W + 18 * (size_t)s; const double* xc = P.x + 6 * P.slot_cam[s];
+#pragma unroll
+            for (int a = 0; a < 6; a++) { t0 -= W[a * 3] * xc[a]; t1 -= W[a * 3 + 1] * xc[a]; t2 -= W[a * 3 + 2] * xc[a]; }
+        }
+        double Di[9]; inv3sym(P.Hpp + 6 * (size_t)l, lambda, Di);
+        const double x0 = Di[0] * t0 + Di[1] * t1 + Di[2] * t2, x1 = Di[3] * t0 + Di[4] * t1 + Di[5] * t2, x2 = Di[6] * t0 + Di[7] * t1 + Di[8] * t2;
+        P.pt_new[3 * (size_t)l] = P.pt[3 * (size_t)l] + x0; P.pt_new[3 * (size_t)l + 1] = P.pt[3 * (size_t)l + 1] + x1; P.pt_new[3 * (size_t)l + 2] = P.pt[3 * (size_t)l + 2] + x2;
+        sc = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(P.scal + 3, sc);
+}
+__global__ __launch_bounds__(256) void k_ba_chi2(BaDev P, const double* cam, const double* pt, double* out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    double v = 0;
+    if (k < P.n_obs) {
+        const double* X = cam + 12 * P.obs_cam[k]; const double* p = pt + 3 * (size_t)P.obs_pt[k]; const double* m = P.obs_meas + 3 * (size_t)k;
+        const double d0 = p[0] - X[3], d1 = p[1] - X[7], d2 = p[2] - X[11];
+        const double e0 = X[0] * d0 + X[4] * d1 + X[8] * d2 - m[0], e1 = X[1] * d0 + X[5] * d1 + X[9] * d2 - m[1], e2 = X[2] * d0 + X[6] * d1 + X[10] * d2 - m[2];
+        double w; huber_w(P.info_obs * (e0 * e0 + e1 * e1 + e2 * e2), P.huber_obs, P.use_huber, v, w);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, v);
+}
+
+// ---- host driver ---------------------------------------------------------------------------------------------
+struct BaState {
+    std::vector<void*> allocs;
+    double* h_scal = nullptr;      // pinned [8]
+    double* d_parts = nullptr; size_t parts_cap = 0;
+};
+void ba_state_destroy(vido_ctx* ctx)
+{
+    BaState* S = ctx->ba; if (!S) return;
+    for (void* p : S->allocs) hipFree(p);
+    hipFree(S->d_parts); hipHostFree(S->h_scal);
+    delete S; ctx->ba = nullptr;
+}
+
+namespace {
+struct Arena {                       // per-call device allocations, released at the end of the call
+    vido_ctx* ctx; std::vector<void*> ptrs; bool failed = false;
+    template <class T> T* get(size_t n) { void* p = nullptr; if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) { failed = true; return nullptr; } ptrs.push_back(p); return (T*)p; }
+    template <class T> T* put(const T* src, size_t n, hipStream_t st) { T* d = get<T>(n); if (d && n) if (hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) failed = true; return d; }
+    ~Arena() { for (void* p : ptrs) hipFree(p); }
+};
+}
+
+static int chol_large(vido_ctx* ctx, double* A, int n, const double* b, double* x, double* okflag, hipStream_t st)
+{
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, A, n, k0, okflag);
+        const int rem = n - k0 - std::min(NB, n - k0);
+        if (rem > 0) {
+            const int nt = (rem + NB - 1) / NB;
+            hipLaunchKernelGGL(k_chol_panel, dim3(nt), dim3(256), 0, st, A, n, k0);
+            hipLaunchKernelGGL(k_chol_update, dim3(nt, nt), dim3(256), 0, st, A, n, k0);
+        }
+    }
+    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), ((size_t)n + NB * NB + 16 * NB) * sizeof(double), st, A, n, b, x);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_result* res, vido_allreduce_fn allreduce, void* user)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!prob || !res) return vido_set_error(ctx, VIDO_E_INVALID, "ba: null problem/result");
+    const vido_ba_problem& p = *prob;
+    if (p.n_cam < 1 || p.n_pt < 0 || p.n_obs < 0 || p.n_odo < 0 || !p.cam_T || (p.n_pt && !p.pt_xyz) ||
+        (p.n_obs && (!p.obs_cam || !p.obs_pt || !p.obs_meas)) || (p.n_odo && (!p.odo_i || !p.odo_j || !p.odo_T)) || p.prior_cam >= p.n_cam)
+        return vido_set_error(ctx, VIDO_E_INVALID, "ba: malformed problem");
+    const int pt_lo = p.pt_hi > p.pt_lo ? p.pt_lo : 0, pt_hi = p.pt_hi > p.pt_lo ? p.pt_hi : p.n_pt;
+    if (pt_lo < 0 || pt_hi > p.n_pt) return vido_set_error(ctx, VIDO_E_INVALID, "ba: landmark shard [%d,%d) outside [0,%d)", pt_lo, pt_hi, p.n_pt);
+    const bool owns_cam_factors = (p.rank == 0);
+    const auto t_begin = std::chrono::steady_clock::now();
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->ba) { ctx->ba = new BaState(); HIP_TRY(ctx, hipHostMalloc((void**)&ctx->ba->h_scal, 8 * sizeof(double))); }
+    BaState* BS = ctx->ba;
+    hipStream_t st = ctx->stream;
+    const int n6 = 6 * p.n_cam, n_ptl = pt_hi - pt_lo;
+    // ---- host preprocessing: keep this shard's observations, sort by camera, build the landmark-major slots
+    std::vector<int> keep; keep.reserve(p.n_obs);
+    for (int k = 0; k < p.n_obs; k++) {
+        if (p.obs_cam[k] < 0 || p.obs_cam[k] >= p.n_cam || p.obs_pt[k] < 0 || p.obs_pt[k] >= p.n_pt) return vido_set_error(ctx, VIDO_E_INVALID, "ba: observation %d has a bad index", k);
+        if (p.obs_pt[k] >= pt_lo && p.obs_pt[k] < pt_hi) keep.push_back(k);
+    }
+    const int no = (int)keep.size();
+    std::stable_sort(keep.begin(), keep.end(), [&](int a, int b) { return p.obs_cam[a] < p.obs_cam[b]; });
+    std::vector<int> ocam(no), opt(no), opos(no), pstart(n_ptl + 1, 0), slotcam(no);
+    std::vector<double> omeas((size_t)no * 3);
+    for (int t = 0; t < no; t++) { const int k = keep[t]; ocam[t] = p.obs_cam[k]; opt[t] = p.obs_pt[k] - pt_lo; for (int a = 0; a < 3; a++) omeas[3 * (size_t)t + a] = p.obs_meas[3 * (size_t)k + a]; pstart[opt[t] + 1]++; }
+    int maxk = 0;
+    for (int l = 0; l < n_ptl; l++) { maxk = std::max(maxk, pstart[l + 1]); pstart[l + 1] += pstart[l]; }
+    if (maxk > 64) return vido_set_error(ctx, VIDO_E_CAPACITY, "ba: a landmark has %d observations; this build handles tracks up to 64", maxk);
+    { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (int t = 0; t < no; t++) { opos[t] = fill[opt[t]]++; slotcam[opos[t]] = ocam[t]; } }
+    for (int k = 0; k < p.n_odo; k++) if (p.odo_i[k] < 0 || p.odo_i[k] >= p.n_cam || p.odo_j[k] < 0 || p.odo_j[k] >= p.n_cam) return vido_set_error(ctx, VIDO_E_INVALID, "ba: odometry edge %d has a bad index", k);
+    // ---- device buffers
+    Arena A{ctx};
+    BaDev D{};
+    D.n_cam = p.n_cam; D.n_pt = p.n_pt; D.n_obs = no; D.n_odo = owns_cam_factors ? p.n_odo : 0; D.prior_cam = owns_cam_factors ? p.prior_cam : -1;
+    D.use_huber = p.use_huber; D.n6 = n6; D.pt_lo = pt_lo;
+    D.info_obs = p.info_obs; D.info_odo = p.info_odo; D.info_prior = p.info_prior; D.huber_obs = p.huber_obs; D.huber_odo = p.huber_odo;
+    memcpy(D.prior_T, p.prior_T, sizeof D.prior_T);
+    D.cam = A.put(p.cam_T, (size_t)p.n_cam * 12, st); D.cam_new = A.get<double>((size_t)p.n_cam * 12);
+    D.pt = A.put(p.pt_xyz + 3 * (size_t)pt_lo, (size_t)n_ptl * 3, st); D.pt_new = A.get<double>((size_t)n_ptl * 3);
+    D.obs_cam = A.put(ocam.data(), no, st); D.obs_pt = A.put(opt.data(), no, st); D.obs_pos = A.put(opos.data(), no, st);
+    D.obs_meas = A.put(omeas.data(), (size_t)no * 3, st); D.pt_start = A.put(pstart.data(), n_ptl + 1, st); D.slot_cam = A.put(slotcam.data(), no, st);
+    D.odo_i = A.put(p.odo_i, p.n_odo, st); D.odo_j = A.put(p.odo_j, p.n_odo, st); D.odo_T = A.put(p.odo_T, (size_t)p.n_odo * 12, st);
+    D.W = A.get<double>((size_t)no * 18); D.Hpp = A.get<double>((size_t)n_ptl * 6); D.bp = A.get<double>((size_t)n_ptl * 3);
+    D.Hcd = A.get<double>((size_t)p.n_cam * 36); D.bc = A.get<double>(n6); D.Hodo = A.get<double>((size_t)p.n_odo * 36);
+    // S and r are contiguous so that one all-reduce covers both
+    double* Sr = A.get<double>((size_t)n6 * n6 + n6); D.S = Sr; D.r = Sr + (size_t)n6 * n6; D.x = A.get<double>(n6);
+    double* red = A.get<double>((size_t)p.n_cam * 36 + n6 + 8);      // [Hcd | bc | scal] contiguous for the linearisation all-reduce
+    D.Hcd = red; D.bc = red + (size_t)p.n_cam * 36; D.scal = D.bc + n6;
+    if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device allocation failed (n6=%d, n_obs=%d)", n6, no);
+    const bool lds_path = n6 <= BA_LDS_MAX_N6;
+    const int schur_grid = lds_path ? std::min(256, std::max(1, (n_ptl + 3) / 4)) : std::min(4096, std::max(1, (n_ptl + 3) / 4));
+    const size_t sz_sr = (size_t)n6 * n6 + n6;
+    if (lds_path && (size_t)schur_grid * sz_sr > BS->parts_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(st)); if (BS->d_parts) hipFree(BS->d_parts);
+        BS->parts_cap = (size_t)256 * sz_sr; HIP_TRY(ctx, hipMalloc((void**)&BS->d_parts, BS->parts_cap * sizeof(double)));
+    }
+    const int kcap = std::max(maxk, 1);
+    const size_t lds_schur = ((lds_path ? sz_sr : 0) + (size_t)4 * (2 * kcap * 18)) * sizeof(double);
+    if (lds_schur > 160 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "ba: LDS budget exceeded (n6=%d, max track %d)", n6, maxk);
+    if (lds_path) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
+                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sz_sr * sizeof(double)))); }
+    else { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur)); }
+    if (!lds_path) HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((n6 + NB * NB + 16 * NB) * sizeof(double))));
+
+    auto AR = [&](double* dptr, size_t cnt, int op) -> int {
+        if (!allreduce) return VIDO_OK;
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (allreduce(user, dptr, cnt, op) != 0) return vido_set_error(ctx, VIDO_E_INVALID, "ba: all-reduce hook failed");
+        return VIDO_OK;
+    };
+    auto read_scal = [&]() -> int { HIP_TRY(ctx, hipMemcpyAsync(BS->h_scal, D.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st)); HIP_TRY(ctx, hipStreamSynchronize(st)); return VIDO_OK; };
+    // robust chi2 of the whole graph at (cam, pt): shard part on the device, summed over ranks
+    auto chi2_at = [&](const double* cam, const double* pt, int slot, double* out) -> int {
+        HIP_TRY(ctx, hipMemsetAsync(D.scal + slot, 0, sizeof(double), st));
+        if (no) hipLaunchKernelGGL(k_ba_chi2, dim3((no + 255) / 256), dim3(256), 0, st, D, cam, pt, D.scal + slot);
+        const int ncf = D.n_odo + (D.prior_cam >= 0 ? 1 : 0);
+        if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3((ncf + 63) / 64), dim3(64), 0, st, D, 0, cam, D.scal + slot);
+        int rc = AR(D.scal + slot, 1, 0); if (rc) return rc;
+        rc = read_scal(); if (rc) return rc;
+        *out = BS->h_scal[slot];
+        return VIDO_OK;
+    };
+    int rc;
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    res->ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    const auto t_loop = std::chrono::steady_clock::now();
+    double lambda = -1, ni = 2, lastChi = 0, chi2_check = 0; int nBad = 0, trials = 0, it = 0;
+    if ((rc = chi2_at(D.cam, D.pt, 2, &res->chi2_initial))) return rc;
+    res->chi2_final = res->chi2_initial;
+    for (it = 0; it < p.max_iters; it++) {
+        // ---- linearise
+        HIP_TRY(ctx, hipMemsetAsync(red, 0, ((size_t)p.n_cam * 36 + n6 + 8) * sizeof(double), st));
+        HIP_TRY(ctx, hipMemsetAsync(D.Hpp, 0, (size_t)n_ptl * 6 * sizeof(double), st));
+        HIP_TRY(ctx, hipMemsetAsync(D.bp, 0, (size_t)n_ptl * 3 * sizeof(double), st));
+        if (no) hipLaunchKernelGGL(k_ba_linearize, dim3((no + 255) / 256), dim3(256), 0, st, D);
+        const int ncf = D.n_odo + (D.prior_cam >= 0 ? 1 : 0);
+        if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3((ncf + 63) / 64), dim3(64), 0, st, D, 1, D.cam, D.scal + 0);
+        if (it == 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3(64), dim3(256), 0, st, D, n_ptl);
+        HIP_TRY(ctx, hipGetLastError());
+        if (allreduce) {     // camera diagonal blocks, bc, chi2 (sum) — then the max-diagonal (max) on its own
+            if (it == 0) { HIP_TRY(ctx, hipStreamSynchronize(st)); double md; HIP_TRY(ctx, hipMemcpy(&md, D.scal + 1, 8, hipMemcpyDeviceToHost)); HIP_TRY(ctx, hipMemsetAsync(D.scal + 1, 0, 8, st));
+                           if ((rc = AR(red, (size_t)p.n_cam * 36 + n6 + 1, 0))) return rc;
+                           HIP_TRY(ctx, hipMemcpy(D.scal + 1, &md, 8, hipMemcpyHostToDevice)); if ((rc = AR(D.scal + 1, 1, 1))) return rc;
+                           // the camera part of the max must see the SUMMED camera diagonals
+                           hipLaunchKernelGGL(k_ba_maxdiag, dim3(64), dim3(256), 0, st, D, 0); if ((rc = AR(D.scal + 1, 1, 1))) return rc; }
+            else if ((rc = AR(red, (size_t)p.n_cam * 36 + n6 + 1, 0))) return rc;
+        }
+        if ((rc = read_scal())) return rc;
+        double currentChi = BS->h_scal[0]; const double iniChi = currentChi;
+        if (it == 0) { lambda = 1e-5 * BS->h_scal[1]; ni = 2; nBad = 0; }
+        double rho = 0; int qmax = 0;
+        do {
+            // ---- reduced system of this shard.  With an all-reduce every rank contributes Hcd/bc ALREADY summed,
+            // so only rank 0 adds the camera-camera part (+lambda) to S; the others start from zero.
+            const int add_cam = (!allreduce || p.rank == 0) ? 1 : 0;
+            hipLaunchKernelGGL(k_ba_init_S, dim3(std::min(2048, (int)((sz_sr + 255) / 256))), dim3(256), 0, st, D, lambda, add_cam);
+            if (!add_cam) HIP_TRY(ctx, hipMemsetAsync(D.r, 0, n6 * sizeof(double), st));
+            if (add_cam && D.n_odo) hipLaunchKernelGGL(k_ba_add_odo, dim3((D.n_odo * 36 + 255) / 256), dim3(256), 0, st, D);
+            if (n_ptl) {
+                if (lds_path) {
+                    hipLaunchKernelGGL(k_ba_schur<true>, dim3(schur_grid), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, BS->d_parts);
+                    hipLaunchKernelGGL(k_ba_fold_parts, dim3(std::min(256, (int)((sz_sr + 255) / 256))), dim3(256), 0, st, D, BS->d_parts, schur_grid);
+                } else hipLaunchKernelGGL(k_ba_schur<false>, dim3(schur_grid), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, nullptr);
+            }
+            HIP_TRY(ctx, hipGetLastError());
+            if ((rc = AR(Sr, sz_sr, 0))) return rc;
+            // ---- replicated reduced solve
+            HIP_TRY(ctx, hipMemsetAsync(D.scal + 2, 0, 2 * sizeof(double), st));
+            if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(256), sz_sr * sizeof(double), st, D);
+            else { const double one = 1.0; HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4, &one, 8, hipMemcpyHostToDevice, st)); if ((rc = chol_large(ctx, D.S, n6, D.r, D.x, D.scal + 4, st))) return rc; }
+            // ---- trial state + its chi2
+            hipLaunchKernelGGL(k_ba_update_cams, dim3((p.n_cam + 63) / 64), dim3(64), 0, st, D, (allreduce && p.rank != 0) ? 0.0 : lambda);
+            if (allreduce && p.rank != 0) HIP_TRY(ctx, hipMemsetAsync(D.scal + 3, 0, sizeof(double), st));      // camera part of computeScale counted once (rank 0)
+            if (n_ptl) hipLaunchKernelGGL(k_ba_backsub, dim3((n_ptl + 255) / 256), dim3(256), 0, st, D, n_ptl, lambda);
+            if (no) hipLaunchKernelGGL(k_ba_chi2, dim3((no + 255) / 256), dim3(256), 0, st, D, D.cam_new, D.pt_new, D.scal + 2);
+            if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3((ncf + 63) / 64), dim3(64), 0, st, D, 0, D.cam_new, D.scal + 2);
+            HIP_TRY(ctx, hipGetLastError());
+            if ((rc = AR(D.scal + 2, 2, 0))) return rc;
+            if ((rc = read_scal())) return rc;
+            const bool ok2 = BS->h_scal[4] > 0.5;
+            const double tempChi = ok2 ? BS->h_scal[2] : DBL_MAX, scale = ok2 ? BS->h_scal[3] : 0.0;
+            rho = (currentChi - tempChi) / (scale + 1e-3);
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - pow((2 * rho - 1), 3); alpha = std::min(alpha, 2. / 3.);
+                lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;
+                std::swap(D.cam, D.cam_new); std::swap(D.pt, D.pt_new);
+            } else { lambda *= ni; ni *= 2; }
+            qmax++; trials++;
+        } while (rho < 0 && qmax < 10);
+        bool terminate = (qmax == 10 || rho == 0);
+        if (!terminate) { if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0; if (nBad >= 3) terminate = true; }
+        const double chiNow = currentChi;     // chi2 at the accepted state (the trial that produced it evaluated it)
+        if (chi2_check < chiNow && it > 0) terminate = true;
+        chi2_check = chiNow;
+        if (it == 0) lastChi = chiNow;
+        else { const double gain = (lastChi - chiNow) / chiNow; lastChi = chiNow; if (gain >= 0 && gain < p.gain_threshold) terminate = true; }
+        res->chi2_final = chiNow;
+        if (terminate) { it++; break; }
+    }
+    res->iterations = it; res->lm_trials = trials; res->lambda_final = lambda;
+    res->ms_solve_loop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
+    HIP_TRY(ctx, hipMemcpyAsync(prob->cam_T, D.cam, (size_t)p.n_cam * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (n_ptl) HIP_TRY(ctx, hipMemcpyAsync(prob->pt_xyz + 3 * (size_t)pt_lo, D.pt, (size_t)n_ptl * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return VIDO_OK;
+}

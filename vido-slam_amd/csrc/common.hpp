@@ -61,4 +61,5 @@ int orb_state_create(vido_ctx* ctx);
 void track_state_destroy(vido_ctx* ctx);
 void ham_state_destroy(vido_ctx* ctx);
 void pose_state_destroy(vido_ctx* ctx);
+void ba_state_destroy(vido_ctx* ctx);
 void orb_state_destroy(vido_ctx* ctx);

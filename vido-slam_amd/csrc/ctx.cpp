@@ -80,6 +80,7 @@ void vido_destroy(vido_ctx* ctx)
     track_state_destroy(ctx);
     ham_state_destroy(ctx);
     pose_state_destroy(ctx);
+    ba_state_destroy(ctx);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     delete ctx;

@@ -84,3 +84,73 @@ def synth_pose_scene(n, seed=0, K=(520.0, 515.0, 320.0, 240.0), noise_px=0.05, o
         uv_cur_noisy[idx] += rng.uniform(-15, 15, (nout, 2))
     T_init = se3_exp(rng.normal(0, 0.01, 6)) @ T_cur
     return dict(K=K, T_last=T_last, T_cur=T_cur, Twl=Twl, uv_last=uv_last, depth=z, Xw=Xw, uv_cur=uv_cur_noisy, flow=uv_cur_noisy - uv_last, T_init=T_init)
+
+
+# ---- bundle adjustment ---------------------------------------------------------------------------------
+# Constants of the reference's two batch optimisers (sigma^2 are `const float` there, so information =
+# 1/double(float(sigma2))):
+#   PartialBatchOptimization (Optimizer.cc:191-196,214): cam 1e-4, 3d_sta 16, Huber 0.01 (deltaHuber* are float),
+#       prior I/1e-7 when N == WINDOW_SIZE, <=100 iterations, gain threshold 1e-3
+#   FullBatchOptimization    (Optimizer.cc:1333-1338,1355): cam 1e-4, 3d_sta 80, prior I*1e5 on frame 0,
+#       <=300 iterations, gain threshold 1e-4
+def ba_constants(kind="local"):
+    if kind == "local":
+        return dict(info_obs=1.0 / float(F32(16)), info_odo=1.0 / float(F32(0.0001)), info_prior=1.0 / 0.0000001,
+                    huber_obs=float(F32(0.01)), huber_odo=float(F32(0.01)), use_huber=1, max_iters=100, gain_threshold=1e-3)
+    return dict(info_obs=1.0 / float(F32(80)), info_odo=1.0 / float(F32(0.0001)), info_prior=1e5,
+                huber_obs=float(F32(0.01)), huber_odo=float(F32(0.01)), use_huber=1, max_iters=300, gain_threshold=1e-4)
+
+
+def _iso(T):
+    return np.ascontiguousarray(np.asarray(T, np.float64)[:3, :4])
+
+
+def synth_ba_problem(n_cam=20, n_pt=2000, seed=7, kind="local", track_len=None, obs_noise=0.02, pose_noise=0.05, with_prior=True,
+                     step=1.0):
+    """SURVEY.md §8d configs 4/5: cameras on a forward path with yaw jitter; landmarks in a box ahead of the path;
+    measurement = 3-D point in the camera frame + N(0,(obs_noise*z)^2); odometry = true relative pose o exp(N(0,1e-3));
+    initial poses perturbed by exp(N(0,pose_noise)).  track_len=None: every landmark is seen from every camera where
+    1 < z < 60 (local BA); track_len=k: each landmark is seen in a contiguous run of ~k frames (global BA)."""
+    rng = np.random.RandomState(seed)
+    cams = []                        # camera-to-world
+    T = np.eye(4)
+    for i in range(n_cam):
+        cams.append(T.copy())
+        yaw = np.deg2rad(rng.uniform(-2, 2))
+        d = np.eye(4); d[:3, :3] = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]]); d[2, 3] = step
+        T = T @ d
+    cams = np.stack(cams)
+    length = step * (n_cam - 1)
+    if track_len is None:
+        pts = np.stack([rng.uniform(-20, 20, n_pt), rng.uniform(-5, 5, n_pt), rng.uniform(5, length + 45, n_pt)], 1)
+    else:
+        zc = rng.uniform(0, length, n_pt)
+        pts = np.stack([rng.uniform(-15, 15, n_pt), rng.uniform(-4, 4, n_pt), zc + rng.uniform(8, 25, n_pt)], 1)
+    obs_cam, obs_pt, obs_meas = [], [], []
+    inv = np.linalg.inv(cams)
+    for c in range(n_cam):
+        Xc = pts @ inv[c][:3, :3].T + inv[c][:3, 3]
+        vis = (Xc[:, 2] > 1) & (Xc[:, 2] < 60)
+        if track_len is not None:
+            first = np.clip((pts[:, 2] - 25) / step - track_len / 2, 0, max(n_cam - track_len, 0)).astype(int)
+            vis &= (c >= first) & (c < first + track_len)
+        idx = np.nonzero(vis)[0]
+        noise = rng.normal(0, 1, (len(idx), 3)) * (obs_noise * Xc[idx, 2:3])
+        obs_cam.append(np.full(len(idx), c, np.int32)); obs_pt.append(idx.astype(np.int32)); obs_meas.append(Xc[idx] + noise)
+    obs_cam = np.concatenate(obs_cam); obs_pt = np.concatenate(obs_pt); obs_meas = np.concatenate(obs_meas)
+    # drop landmarks with < 3 observations (tracklet validity, Optimizer.cc:75,86) and re-index
+    cnt = np.bincount(obs_pt, minlength=n_pt)
+    keep = cnt >= 3
+    remap = -np.ones(n_pt, np.int64); remap[keep] = np.arange(keep.sum())
+    sel = keep[obs_pt]
+    obs_cam, obs_pt, obs_meas = obs_cam[sel], remap[obs_pt[sel]].astype(np.int32), obs_meas[sel]
+    pts = pts[keep]
+    odo_i = np.arange(n_cam - 1, dtype=np.int32); odo_j = odo_i + 1
+    odo = np.stack([_iso(np.linalg.inv(cams[i]) @ cams[i + 1] @ se3_exp(rng.normal(0, 1e-3, 6))) for i in range(n_cam - 1)]) if n_cam > 1 else np.zeros((0, 3, 4))
+    cam0 = np.stack([_iso(cams[i] @ se3_exp(rng.normal(0, pose_noise, 6))) if i > 0 or not with_prior else _iso(cams[i]) for i in range(n_cam)])
+    pts0 = pts + rng.normal(0, 0.05, pts.shape)
+    d = dict(n_cam=n_cam, n_pt=len(pts), cam_T=cam0, pt_xyz=pts0, obs_cam=obs_cam, obs_pt=obs_pt, obs_meas=obs_meas,
+             odo_i=odo_i, odo_j=odo_j, odo_T=odo, prior_cam=0 if with_prior else -1, prior_T=_iso(cams[0]),
+             cam_true=np.stack([_iso(c) for c in cams]), pt_true=pts)
+    d.update(ba_constants(kind))
+    return d
