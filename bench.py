@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
 """bench.py — driver contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.
 
-Workload (BASELINE.json configs[1]): "ORB pyramid + flow-guided tracking only, synthetic 640x480
-stream, 1 MI355X".  A step = one pass of the hot path over one batch of `--batch` synthetic frames
-that are already resident in HBM when the timed region starts.  The per-frame path does not shard
-(frame k depends on frame k-1 state): with --gpus N each rank runs an independent
-replica of the same stream on its own GPU ("replicas only"), no data-path collective; value = all
-frames processed by all ranks / max-over-ranks time.
+Workload (BASELINE.json configs[1]): "ORB pyramid + flow-guided tracking only, synthetic 640x480 stream,
+1 MI355X".  A step = one pass of the per-frame hot path over one batch of `--batch` synthetic frames whose
+gray/depth/flow/mask maps are already resident in HBM when the timed region starts:
+    ORB extraction (pyramid, per-cell FAST, quadtree, IC angle, 7x7 blur, rBRIEF)      A2-A8
+    depth pre-scale, static-candidate filter + depth gather, dense object sampling    A1, A9, A10
+The per-frame path does not shard (frame k depends on frame k-1): with --gpus N every rank runs an
+independent replica on its own GPU ("replicas only"), no data-path collective; value = frames of all ranks /
+max-over-ranks time.
 
-Extra objects on the JSON line: `roofline` (dominant kernel, algorithmic bytes / live HIP-event
-duration vs the 8 TB/s HBM peak) and `cpu_baseline` (the CPU oracle — a scalar port, 1 core — timed on
-a bounded sample of the same frames, rank 0 at N=1 only).
+Extra objects on the same JSON line:
+  roofline      dominant ORB kernel (k_fast_cells): algorithmic bytes / live HIP-event time vs the 8 TB/s HBM peak
+  roofline_ba   BA linearisation kernel (k_ba_linearize): 288 B per edge / live HIP-event time
+  cpu_baseline  the CPU oracle (scalar C restatement, 1 core) on a bounded sample of the same frames (rank 0, N=1)
+  extra         per-frame optimisers (configs[3] prerequisites), local BA (configs[3]) and, with --gpus N > 1, the
+                landmark-sharded global BA (configs[4], scaled by --gba-cams/--gba-points) over RCCL
 """
 import argparse
 import json
@@ -33,6 +38,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--no-extra", action="store_true", help="skip the optimiser / BA side measurements")
+    ap.add_argument("--gba-cams", type=int, default=500)
+    ap.add_argument("--gba-points", type=int, default=100000)
     args = ap.parse_args()
 
     import numpy as np
@@ -57,20 +65,35 @@ def main():
         ge.build()
     if dist is not None:
         dist.barrier()
+    import ctypes as C
     import vido_slam_amd as V
     from vido_slam_amd import synth
 
     B, W, H = args.batch, args.width, args.height
     ctx = V.Context(device=local_rank, width=W, height=H, max_batch=B)
-    # B distinct frames of a synthetic stream (rank-dependent seed: independent replicas), resident in HBM
+    tp = V.track_params(dataset=0, depth_map_factor=1.0, th_depth_bg=40.0, th_depth_obj=25.0)
+    ff = V.FrameFeatures(ctx, tp)
+    # a synthetic stream (rank-dependent seed: independent replicas); B frames of it are resident in HBM
     n_distinct = min(B, 16)
-    base = synth.make_batch(n_distinct, W, H, seed=1 + 100 * rank)
-    frames_host = np.ascontiguousarray(base[np.arange(B) % n_distinct])
-    frames_dev = torch.from_numpy(frames_host).cuda()
-    dev_arg = (frames_dev.data_ptr(), B, H, W, H * W, W)
+    seq = synth.Sequence(n_frames=n_distinct, w=W, h=H, seed=1 + 100 * rank)
+    fr = [seq.frame(k) for k in range(n_distinct)]
+    sel = np.arange(B) % n_distinct
+    gray_h = np.ascontiguousarray(np.stack([fr[i][0] for i in sel]))
+    depth_h = np.ascontiguousarray(np.stack([fr[i][2] for i in sel]).astype(np.float32))
+    flow_h = np.ascontiguousarray(np.stack([fr[i][3] for i in sel]))
+    mask_h = np.ascontiguousarray(np.stack([fr[i][4] for i in sel]))
+    gray_d = torch.from_numpy(gray_h).cuda(); depth_d = torch.from_numpy(depth_h).cuda()
+    flow_d = torch.from_numpy(flow_h).cuda(); mask_d = torch.from_numpy(mask_h).cuda()
+    depth_work = torch.empty_like(depth_d)
+    dev_arg = (gray_d.data_ptr(), B, H, W, H * W, W)
 
     def step():
-        return ctx.orb_extract_batch(dev_arg, want_desc=True)
+        kps, desc, cnt = ctx.orb_extract_batch(dev_arg, want_desc=True)
+        depth_work.copy_(depth_d)                          # the pre-scale mutates its input in place
+        ctx._check(ctx.lib.vido_frame_upload(ctx.h, 0, B, C.c_void_p(depth_work.data_ptr()), C.c_void_p(flow_d.data_ptr()),
+                                             C.c_void_p(mask_d.data_ptr()), 1, C.byref(tp)))
+        lists = ff.features(0, kps, cnt)
+        return kps, cnt, lists
 
     def sync_all():
         torch.cuda.synchronize()
@@ -84,7 +107,7 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        kps, desc, cnt = step()
+        kps, cnt, lists = step()
         for k, v in ctx.orb_timing().items():
             stage[k] = stage.get(k, 0.0) + v
     sync_all()
@@ -94,20 +117,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stage = {k: v / max(args.steps, 1) for k, v in stage.items()}
-
     frames_total = B * args.steps * world
     fps = frames_total / dt
-    # ---- roofline of the dominant kernel (k_fast_cells): algorithmic bytes = every pyramid pixel read
-    # once (950 532 B / 640x480 frame) + 4 B per emitted candidate, per launch of B frames.
+
+    # ---- roofline of the dominant ORB kernel: every pyramid pixel read once (950 532 B per 640x480
+    # frame) + 4 B per emitted candidate, per launch of B frames
     p_px = 0
-    lw, lh = W, H
-    import ctypes as C
     for l in range(ctx.cfg.n_levels):
         a, b = C.c_int(), C.c_int()
         ctx.lib.vido_orb_level_size(ctx.h, l, C.byref(a), C.byref(b))
         p_px += a.value * b.value
-    n_cand = stage.get("n_candidates", 0.0)
-    fast_bytes = p_px * B + 4.0 * n_cand
+    fast_bytes = p_px * B + 4.0 * stage.get("n_candidates", 0.0)
     fast_s = stage["fast_ms"] * 1e-3
     achieved = fast_bytes / fast_s / 1e9 if fast_s > 0 else 0.0
     roofline = {"kernel": "k_fast_cells", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -119,23 +139,89 @@ def main():
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "configs[1]: ORB pyramid (8 levels x1.2, 2000 features, FAST 20/7, quadtree, IC angle, 7x7 blur, rBRIEF) on a synthetic %dx%d stream; stages built so far: ORB extraction; flow-guided tracking/BA stages are added as they land" % (W, H),
+        "config": {"workload": "configs[1]: ORB pyramid (8 levels x1.2, 2000 features, FAST 20/7, quadtree, IC angle, 7x7 blur, rBRIEF) + "
+                               "flow-guided tracking front-end (depth pre-scale, static filter, dense object sampling) on a synthetic "
+                               "%dx%d stream; nets / local BA are measured separately under 'extra'" % (W, H),
                    "frames_per_step": B, "parallelism": "replicas x%d (per-frame path does not shard)" % world,
-                   "inputs": "gray u8 frames resident in HBM"},
+                   "inputs": "gray u8 + depth f32 + flow f32x2 + mask i32 resident in HBM"},
         "stage_ms_per_step": {k: round(v, 4) for k, v in stage.items() if k != "n_candidates"},
-        "keypoints_per_frame": float(cnt.mean()),
+        "keypoints_per_frame": float(cnt.mean()), "static_candidates_per_frame": float(lists["n_stat"].mean()),
+        "object_samples_per_frame": float(lists["n_obj"].mean()),
         "roofline": roofline,
     }
+
+    if not args.no_extra:
+        extra = {}
+        P = V.problems
+        opt = V.Optimizer(ctx)
+        s = P.synth_pose_scene(3000, seed=2)
+        probs = {"PoseOptimizationFlow2Cam_N3000": P.pose_problem_flow2cam(s["uv_last"], s["flow"], s["depth"], s["Twl"], s["K"], s["T_init"]),
+                 "PoseOptimizationNew_N3000": P.pose_problem_new(s["Xw"], s["uv_cur"], s["K"], s["T_init"])}
+        for name, pr in probs.items():
+            opt.pose_optimize(pr)
+            t1 = time.perf_counter(); reps = 5
+            for _ in range(reps):
+                r = opt.pose_optimize(pr)
+            d = (time.perf_counter() - t1) / reps
+            extra[name] = {"ms_per_call": round(d * 1e3, 3), "lm_iterations": r["lm_iterations"], "lm_iters_per_s": round(r["lm_iterations"] / d, 1)}
+        objs = []
+        for k in range(5):
+            so = P.synth_pose_scene(800, seed=30 + k)
+            objs.append(P.pose_problem_flow2(so["uv_last"], so["flow"], so["depth"], so["Twl"], so["K"], so["T_init"]))
+        opt.pose_optimize_batch(objs)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            rs = opt.pose_optimize_batch(objs)
+        d = (time.perf_counter() - t1) / 5
+        extra["PoseOptimizationFlow2_5objects_x800"] = {"ms_per_frame": round(d * 1e3, 3), "lm_iterations": [r["lm_iterations"] for r in rs]}
+        # configs[3] (static graph): 20 KF x 2k landmarks
+        pr = P.synth_ba_problem(n_cam=20, n_pt=2000, kind="local", seed=7)
+        V.ba_optimize(ctx, pr)
+        t1 = time.perf_counter(); reps = 5
+        for _ in range(reps):
+            r = V.ba_optimize(ctx, pr)
+        d = (time.perf_counter() - t1) / reps
+        extra["local_ba_20kf_2k"] = {"ms_per_solve": round(d * 1e3, 3), "ms_lm_loop": round(r["ms_solve_loop"], 3), "ms_setup": round(r["ms_setup"], 3),
+                                     "lm_iterations": r["iterations"], "lm_iters_per_s": round(r["iterations"] / (r["ms_solve_loop"] * 1e-3), 1),
+                                     "n_obs": int(len(pr["obs_cam"])), "ms_linearize_kernel": round(r.get("ms_linearize_kernel", 0.0), 5)}
+        if r.get("ms_linearize_kernel", 0.0) > 0:
+            nb = 288.0 * len(pr["obs_cam"])
+            ach = nb / (r["ms_linearize_kernel"] * 1e-3) / 1e9
+            out["roofline_ba"] = {"kernel": "k_ba_linearize", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(nb),
+                                  "avg_launch_ms": round(r["ms_linearize_kernel"], 5), "workload": "configs[3] static graph, 20 KF x 2k landmarks"}
+        # configs[4]: global BA, landmarks sharded over the ranks, RCCL all-reduce of the reduced camera system
+        gpr = P.synth_ba_problem(n_cam=args.gba_cams, n_pt=args.gba_points, kind="global", track_len=10, seed=11)
+        gpr["max_iters"] = 5
+        shards = V.landmark_shards(gpr["obs_pt"], gpr["n_pt"], world)
+        hook = V.torch_allreduce_hook() if world > 1 else None
+        sync_all()
+        t1 = time.perf_counter()
+        r = V.ba_optimize(ctx, gpr, rank=rank, world=world, shard=shards[rank] if world > 1 else None, allreduce=hook)
+        sync_all()
+        d = time.perf_counter() - t1
+        extra["global_ba"] = {"n_cam": args.gba_cams, "n_landmarks": int(gpr["n_pt"]), "n_obs": int(len(gpr["obs_cam"])), "n_gpus": world,
+                              "lm_iterations": r["iterations"], "lm_trials": r["lm_trials"], "ms_lm_loop": round(r["ms_solve_loop"], 2),
+                              "ms_setup": round(r["ms_setup"], 2), "lm_iters_per_s": round(r["iterations"] / (r["ms_solve_loop"] * 1e-3), 2),
+                              "chi2": [round(r["chi2_initial"], 3), round(r["chi2_final"], 3)], "wall_ms": round(d * 1e3, 1),
+                              "collective": "RCCL all-reduce (sum) of S (6n x 6n f64) + r per LM trial" if world > 1 else "none"}
+        out["extra"] = extra
+
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         from oracle import pyoracle as O
         p = O.orb_params(n_features=ctx.cfg.n_features, scale_factor=ctx.cfg.scale_factor, n_levels=ctx.cfg.n_levels,
                          ini_th=ctx.cfg.ini_th_fast, min_th=ctx.cfg.min_th_fast)
         t1 = time.perf_counter()
         for i in range(args.cpu_frames):
-            O.orb_extract(p, frames_host[i % B])
+            g = gray_h[i % B]
+            k, _, _ = O.orb_extract(p, g)
+            dpt = O.depth_prescale(depth_h[i % B], 0, 1.0, tp.bf, 1.0)
+            O.static_candidates(k, dpt, flow_h[i % B], mask_h[i % B], tp.th_depth_bg)
+            O.dense_object_samples(dpt, flow_h[i % B], mask_h[i % B], tp.th_depth_obj)
         cdt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": round(args.cpu_frames / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-                               "sample": "%d of the same 640x480 frames through oracle/orb_oracle.c (scalar C restatement of ORBextractor::operator(), descriptors on), %.1f s" % (args.cpu_frames, cdt)}
+                               "sample": "%d of the same 640x480 frames through the CPU oracle (oracle/orb_oracle.c + track_oracle.c: scalar C "
+                                         "restatement of ORBextractor::operator() with descriptors + Frame ctor lists), %.1f s" % (args.cpu_frames, cdt)}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

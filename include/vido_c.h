@@ -186,6 +186,7 @@ typedef struct vido_ba_problem {
 typedef struct vido_ba_result { int32_t iterations, lm_trials; double chi2_initial, chi2_final, lambda_final;
                                 double ms_setup;        /* host preprocessing + upload (wall) */
                                 double ms_solve_loop;   /* the LM loop proper, inputs resident in HBM (wall) */
+                                double ms_linearize_kernel;   /* mean k_ba_linearize duration (HIP events on the ctx stream) */
 } vido_ba_result;
 
 /* In-place all-reduce of `count` doubles at DEVICE address `dev_ptr` over all ranks (op 0 = sum, 1 = max);

@@ -85,7 +85,10 @@ __device__ void rot_to_quat(const double* M, double* q)      // Eigen Quaternion
         for (int a = 0; a < 4; a++) q[a] = -q[a];
     }
 }
-// EdgeSE3 residual (and closed-form Jacobians, see oracle/ba_oracle.c ba_edge_se3)
+// EdgeSE3 residual: E = Z^-1 Xi^-1 Xj, e = (t_E, q_E.xyz), and its exact Jacobians w.r.t. the right-multiplicative
+// (dt, v) increments of VertexSE3::oplusImpl (R(v) ~ I + 2[v]x):
+//   Jj = [ R_E 0 ; 0 Q ],  Ji = [ -R_A  2 R_A [t_B]x ; 0  -Q R_B^T ],  Q = w_E I + [q_E.xyz]x,  A = Z^-1, B = Xi^-1 Xj
+// (g2o reaches the same matrices through dq/dR, isometry3d_gradients.h:85-189).  Xi == nullptr: EdgeSE3Prior.
 __device__ void edge_se3(const double* Z, const double* Xi, const double* Xj, double* e, double* Ji, double* Jj, bool jac)
 {
     double B[12], E[12], q[4];
@@ -519,6 +522,7 @@ __global__ __launch_bounds__(256) void k_ba_chi2(BaDev P, const double* cam, con
 struct BaState {
     std::vector<void*> allocs;
     double* h_scal = nullptr;      // pinned [8]
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double* d_parts = nullptr; size_t parts_cap = 0;
 };
 void ba_state_destroy(vido_ctx* ctx)
@@ -526,6 +530,8 @@ void ba_state_destroy(vido_ctx* ctx)
     BaState* S = ctx->ba; if (!S) return;
     for (void* p : S->allocs) hipFree(p);
     hipFree(S->d_parts); hipHostFree(S->h_scal);
+    if (S->ev0) hipEventDestroy(S->ev0);
+    if (S->ev1) hipEventDestroy(S->ev1);
     delete S; ctx->ba = nullptr;
 }
 
@@ -567,7 +573,8 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
     const bool owns_cam_factors = (p.rank == 0);
     const auto t_begin = std::chrono::steady_clock::now();
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!ctx->ba) { ctx->ba = new BaState(); HIP_TRY(ctx, hipHostMalloc((void**)&ctx->ba->h_scal, 8 * sizeof(double))); }
+    if (!ctx->ba) { ctx->ba = new BaState(); HIP_TRY(ctx, hipHostMalloc((void**)&ctx->ba->h_scal, 8 * sizeof(double)));
+                    HIP_TRY(ctx, hipEventCreate(&ctx->ba->ev0)); HIP_TRY(ctx, hipEventCreate(&ctx->ba->ev1)); }
     BaState* BS = ctx->ba;
     hipStream_t st = ctx->stream;
     const int n6 = 6 * p.n_cam, n_ptl = pt_hi - pt_lo;
@@ -643,7 +650,7 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
     HIP_TRY(ctx, hipStreamSynchronize(st));
     res->ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     const auto t_loop = std::chrono::steady_clock::now();
-    double lambda = -1, ni = 2, lastChi = 0, chi2_check = 0; int nBad = 0, trials = 0, it = 0;
+    double lambda = -1, ni = 2, lastChi = 0, chi2_check = 0, ms_lin = 0; int nBad = 0, trials = 0, it = 0, n_lin = 0;
     if ((rc = chi2_at(D.cam, D.pt, 2, &res->chi2_initial))) return rc;
     res->chi2_final = res->chi2_initial;
     for (it = 0; it < p.max_iters; it++) {
@@ -651,7 +658,10 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
         HIP_TRY(ctx, hipMemsetAsync(red, 0, ((size_t)p.n_cam * 36 + n6 + 8) * sizeof(double), st));
         HIP_TRY(ctx, hipMemsetAsync(D.Hpp, 0, (size_t)n_ptl * 6 * sizeof(double), st));
         HIP_TRY(ctx, hipMemsetAsync(D.bp, 0, (size_t)n_ptl * 3 * sizeof(double), st));
+        HIP_TRY(ctx, hipEventRecord(BS->ev0, st));
         if (no) hipLaunchKernelGGL(k_ba_linearize, dim3((no + 255) / 256), dim3(256), 0, st, D);
+        HIP_TRY(ctx, hipEventRecord(BS->ev1, st));
+        n_lin++;
         const int ncf = D.n_odo + (D.prior_cam >= 0 ? 1 : 0);
         if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3((ncf + 63) / 64), dim3(64), 0, st, D, 1, D.cam, D.scal + 0);
         if (it == 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3(64), dim3(256), 0, st, D, n_ptl);
@@ -665,6 +675,7 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
             else if ((rc = AR(red, (size_t)p.n_cam * 36 + n6 + 1, 0))) return rc;
         }
         if ((rc = read_scal())) return rc;
+        { float ms = 0; if (hipEventElapsedTime(&ms, BS->ev0, BS->ev1) == hipSuccess) ms_lin += ms; }
         double currentChi = BS->h_scal[0]; const double iniChi = currentChi;
         if (it == 0) { lambda = 1e-5 * BS->h_scal[1]; ni = 2; nBad = 0; }
         double rho = 0; int qmax = 0;
@@ -717,6 +728,7 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
         if (terminate) { it++; break; }
     }
     res->iterations = it; res->lm_trials = trials; res->lambda_final = lambda;
+    res->ms_linearize_kernel = n_lin ? ms_lin / n_lin : 0.0;
     res->ms_solve_loop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
     HIP_TRY(ctx, hipMemcpyAsync(prob->cam_T, D.cam, (size_t)p.n_cam * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (n_ptl) HIP_TRY(ctx, hipMemcpyAsync(prob->pt_xyz + 3 * (size_t)pt_lo, D.pt, (size_t)n_ptl * 3 * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -332,7 +332,7 @@ class BaProblem(C.Structure):
 
 class BaResult(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("lm_trials", C.c_int32), ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
-                ("lambda_final", C.c_double), ("ms_setup", C.c_double), ("ms_solve_loop", C.c_double)]
+                ("lambda_final", C.c_double), ("ms_setup", C.c_double), ("ms_solve_loop", C.c_double), ("ms_linearize_kernel", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
@@ -400,7 +400,7 @@ def ba_optimize(ctx, k, rank=0, world=1, shard=None, allreduce=None):
     ctx._check(ctx.lib.vido_ba_optimize(ctx.h, C.byref(p), C.byref(r), fn, None))
     return dict(cam_T=a["cam_T"].reshape(-1, 3, 4), pt_xyz=a["pt_xyz"], iterations=r.iterations, lm_trials=r.lm_trials,
                 chi2_initial=r.chi2_initial, chi2_final=r.chi2_final, lambda_final=r.lambda_final, ms_setup=r.ms_setup,
-                ms_solve_loop=r.ms_solve_loop)
+                ms_solve_loop=r.ms_solve_loop, ms_linearize_kernel=r.ms_linearize_kernel)
 
 
 class ORBextractor:
