@@ -307,51 +307,63 @@ __global__ __launch_bounds__(256) void k_ba_fold_parts(BaDev P, const double* S_
 {
     const size_t sz = (size_t)P.n6 * P.n6 + P.n6;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < sz; t += (size_t)gridDim.x * blockDim.x) {
-        double s = 0;
-        for (int p = 0; p < nparts; p++) s += S_part[(size_t)p * sz + t];
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int p = 0;
+        for (; p + 4 <= nparts; p += 4) {      // four independent load streams in flight
+            s0 += S_part[(size_t)p * sz + t]; s1 += S_part[(size_t)(p + 1) * sz + t];
+            s2 += S_part[(size_t)(p + 2) * sz + t]; s3 += S_part[(size_t)(p + 3) * sz + t];
+        }
+        for (; p < nparts; p++) s0 += S_part[(size_t)p * sz + t];
+        const double s = (s0 + s1) + (s2 + s3);
         if (t < (size_t)P.n6 * P.n6) P.S[t] += s; else P.r[t - (size_t)P.n6 * P.n6] += s;
     }
 }
 
 // ---- reduced solve --------------------------------------------------------------------------------------
-// single workgroup, whole matrix in LDS: Cholesky (LL^T), forward/back substitution.  scal[4] = 1 on success.
-__global__ __launch_bounds__(256) void k_ba_chol_small(BaDev P)
+// single workgroup (1024 threads), whole system in LDS.  The right-hand side rides along as row n of the
+// (n+1) x n lower factor, so the forward substitution costs nothing; rows are padded to an odd pitch (column
+// walks are bank-conflict free); the scaled pivot column is mirrored into a contiguous vector so the rank-1
+// trailing update reads col[i]*col[c] (broadcast) + one row-contiguous element; the backward substitution runs
+// in a single wave without workgroup barriers.  scal[4] = 1 on success.
+__global__ __launch_bounds__(1024) void k_ba_chol_small(BaDev P)
 {
     extern __shared__ double lds[];
-    const int n = P.n6, tid = threadIdx.x, nt = blockDim.x;
-    double* A = lds; double* y = lds + (size_t)n * n;
+    const int n = P.n6, tid = threadIdx.x, nt = blockDim.x, ld = (n + 1) | 1;
+    double* A = lds;                     // [(n+1)][ld]
+    double* col = lds + (size_t)(n + 1) * ld;   // [n+1]
     __shared__ int ok;
-    for (int t = tid; t < n * n; t += nt) A[t] = P.S[t];
-    for (int t = tid; t < n; t += nt) y[t] = P.r[t];
+    for (int t = tid; t < n * n; t += nt) { const int r = t / n, c = t - r * n; if (c <= r) A[r * ld + c] = P.S[t]; }
+    for (int t = tid; t < n; t += nt) A[n * ld + t] = P.r[t];
     if (tid == 0) ok = 1;
     __syncthreads();
     for (int j = 0; j < n; j++) {
-        if (tid == 0) { const double d = A[j * n + j]; if (!(d > 0) || !isfinite(d)) { ok = 0; A[j * n + j] = 1.0; } else A[j * n + j] = sqrt(d); }
+        double d = A[j * ld + j];
+        if (!(d > 0) || !isfinite(d)) { if (tid == 0) ok = 0; d = 1.0; }
+        const double inv = 1.0 / sqrt(d);
+        for (int i = j + 1 + tid; i <= n; i += nt) { const double v = A[i * ld + j] * inv; A[i * ld + j] = v; col[i] = v; }
         __syncthreads();
-        const double dj = A[j * n + j];
-        for (int i = j + 1 + tid; i < n; i += nt) A[i * n + j] /= dj;
-        __syncthreads();
-        // trailing update of the lower triangle: A[i][c] -= A[i][j] * A[c][j]
-        const int m = n - j - 1;
-        for (int t = tid; t < m * m; t += nt) { const int i = j + 1 + t / m, c = j + 1 + t % m; if (c <= i) A[i * n + c] -= A[i * n + j] * A[c * n + j]; }
-        __syncthreads();
-    }
-    // forward L z = y, backward L^T x = z
-    for (int j = 0; j < n; j++) {
-        if (tid == 0) y[j] /= A[j * n + j];
-        __syncthreads();
-        const double yj = y[j];
-        for (int i = j + 1 + tid; i < n; i += nt) y[i] -= A[i * n + j] * yj;
+        if (tid == 0) A[j * ld + j] = sqrt(d);      // after every thread has read the pivot; not touched by the update below
+        const int m = n - j;             // rows j+1 .. n (row n = rhs), columns j+1 .. n-1
+        for (int t = tid; t < m * (m - 1); t += nt) {
+            const int i = j + 1 + t / (m - 1), c = j + 1 + t % (m - 1);
+            if (c <= i) A[i * ld + c] -= col[i] * col[c];
+        }
         __syncthreads();
     }
-    for (int j = n - 1; j >= 0; j--) {
-        if (tid == 0) y[j] /= A[j * n + j];
-        __syncthreads();
-        const double yj = y[j];
-        for (int i = tid; i < j; i += nt) y[i] -= A[j * n + i] * yj;
-        __syncthreads();
+    // row n now holds z = L^-1 r.  Backward substitution L^T x = z in wave 0 (LDS ops of one wave are ordered).
+    if (tid < 64) {
+        for (int j = n - 1; j >= 0; j--) {
+            const double xj = A[n * ld + j] / A[j * ld + j];
+            __builtin_amdgcn_wave_barrier();
+            for (int i = tid; i < j; i += 64) A[n * ld + i] -= A[j * ld + i] * xj;
+            if (tid == 0) A[n * ld + j] = xj;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     }
-    for (int t = tid; t < n; t += nt) P.x[t] = y[t];
+    __syncthreads();
+    for (int t = tid; t < n; t += nt) P.x[t] = A[n * ld + t];
     if (tid == 0) P.scal[4] = (double)ok;
 }
 
@@ -524,23 +536,27 @@ struct BaState {
     double* h_scal = nullptr;      // pinned [8]
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double* d_parts = nullptr; size_t parts_cap = 0;
+    char* pool = nullptr; char* h_pool = nullptr; size_t pool_cap = 0;
 };
 void ba_state_destroy(vido_ctx* ctx)
 {
     BaState* S = ctx->ba; if (!S) return;
     for (void* p : S->allocs) hipFree(p);
-    hipFree(S->d_parts); hipHostFree(S->h_scal);
+    hipFree(S->d_parts); hipHostFree(S->h_scal); hipFree(S->pool); hipHostFree(S->h_pool);
     if (S->ev0) hipEventDestroy(S->ev0);
     if (S->ev1) hipEventDestroy(S->ev1);
     delete S; ctx->ba = nullptr;
 }
 
 namespace {
-struct Arena {                       // per-call device allocations, released at the end of the call
-    vido_ctx* ctx; std::vector<void*> ptrs; bool failed = false;
-    template <class T> T* get(size_t n) { void* p = nullptr; if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) { failed = true; return nullptr; } ptrs.push_back(p); return (T*)p; }
-    template <class T> T* put(const T* src, size_t n, hipStream_t st) { T* d = get<T>(n); if (d && n) if (hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) failed = true; return d; }
-    ~Arena() { for (void* p : ptrs) hipFree(p); }
+struct Arena {                       // bump allocator over the ctx's persistent BA pool (no hipMalloc per call);
+    char* base; size_t cap; size_t off = 0; bool failed = false;   // host inputs go through the pinned stage of the same size
+    char* hbase;
+    template <class T> T* get(size_t n) { const size_t b = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255; if (off + b > cap) { failed = true; return nullptr; } T* p = (T*)(base + off); off += b; return p; }
+    template <class T> T* put(const T* src, size_t n, hipStream_t st) {
+        const size_t o = off; T* d = get<T>(n);
+        if (d && n) { memcpy(hbase + o, src, n * sizeof(T)); if (hipMemcpyAsync(d, hbase + o, n * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) failed = true; }
+        return d; }
 };
 }
 
@@ -595,7 +611,18 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
     { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (int t = 0; t < no; t++) { opos[t] = fill[opt[t]]++; slotcam[opos[t]] = ocam[t]; } }
     for (int k = 0; k < p.n_odo; k++) if (p.odo_i[k] < 0 || p.odo_i[k] >= p.n_cam || p.odo_j[k] < 0 || p.odo_j[k] >= p.n_cam) return vido_set_error(ctx, VIDO_E_INVALID, "ba: odometry edge %d has a bad index", k);
     // ---- device buffers
-    Arena A{ctx};
+    {   // size the persistent pool (device + pinned mirror for the uploads) for this problem
+        const size_t nd = (size_t)p.n_cam * (24 + 36 + 36) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + 18) + (size_t)p.n_odo * (12 + 36) + (size_t)n6 * n6 + 5 * (size_t)n6 + 64;
+        const size_t ni32 = 4 * (size_t)no + (size_t)n_ptl + 2 * (size_t)p.n_odo + 64;
+        const size_t need = nd * 8 + ni32 * 4 + 64 * 256;
+        if (need > BS->pool_cap) {
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (BS->pool) { hipFree(BS->pool); hipHostFree(BS->h_pool); BS->pool = nullptr; BS->h_pool = nullptr; }
+            BS->pool_cap = need + need / 4;
+            HIP_TRY(ctx, hipMalloc((void**)&BS->pool, BS->pool_cap)); HIP_TRY(ctx, hipHostMalloc((void**)&BS->h_pool, BS->pool_cap));
+        }
+    }
+    Arena A{BS->pool, BS->pool_cap, 0, false, BS->h_pool};
     BaDev D{};
     D.n_cam = p.n_cam; D.n_pt = p.n_pt; D.n_obs = no; D.n_odo = owns_cam_factors ? p.n_odo : 0; D.prior_cam = owns_cam_factors ? p.prior_cam : -1;
     D.use_huber = p.use_huber; D.n6 = n6; D.pt_lo = pt_lo;
@@ -621,10 +648,11 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
         BS->parts_cap = (size_t)256 * sz_sr; HIP_TRY(ctx, hipMalloc((void**)&BS->d_parts, BS->parts_cap * sizeof(double)));
     }
     const int kcap = std::max(maxk, 1);
+    const size_t lds_chol = ((size_t)(n6 + 1) * ((n6 + 1) | 1) + n6 + 2) * sizeof(double);
     const size_t lds_schur = ((lds_path ? sz_sr : 0) + (size_t)4 * (2 * kcap * 18)) * sizeof(double);
     if (lds_schur > 160 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "ba: LDS budget exceeded (n6=%d, max track %d)", n6, maxk);
     if (lds_path) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
-                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sz_sr * sizeof(double)))); }
+                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol)); }
     else { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur)); }
     if (!lds_path) HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((n6 + NB * NB + 16 * NB) * sizeof(double))));
 
@@ -696,7 +724,7 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
             if ((rc = AR(Sr, sz_sr, 0))) return rc;
             // ---- replicated reduced solve
             HIP_TRY(ctx, hipMemsetAsync(D.scal + 2, 0, 2 * sizeof(double), st));
-            if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(256), sz_sr * sizeof(double), st, D);
+            if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
             else { const double one = 1.0; HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4, &one, 8, hipMemcpyHostToDevice, st)); if ((rc = chol_large(ctx, D.S, n6, D.r, D.x, D.scal + 4, st))) return rc; }
             // ---- trial state + its chi2
             hipLaunchKernelGGL(k_ba_update_cams, dim3((p.n_cam + 63) / 64), dim3(64), 0, st, D, (allreduce && p.rank != 0) ? 0.0 : lambda);

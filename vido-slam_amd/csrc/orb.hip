@@ -28,6 +28,9 @@
 #include <cmath>
 #include <cfloat>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 
 #define EDGE_THRESHOLD 19
 #define HALF_PATCH 15
@@ -85,33 +88,46 @@ __device__ __forceinline__ bool has9(uint32_t m)           // 9 contiguous set b
     return (x & 0xffffu) != 0;
 }
 
-// threshold-free corner score at LDS tile position t: S = max over 16 arcs of 9 of the arc's min
-// one-signed |centre - ring|, minus 1; 0 unless p is a corner at threshold `th` (then S >= th).
+// Byte `off` (0..11) of a 12-byte window held in three aligned dwords.
+#define WIN_BYTE(W, off) ((int)(((off) < 4 ? (W)[0] >> (8 * (off)) : (off) < 8 ? (W)[1] >> (8 * ((off) - 4)) : (W)[2] >> (8 * ((off) - 8))) & 0xffu))
+
+// Phase 1a: compass pre-test.  Every arc of 9 contiguous ring pixels contains at least two of the four compass
+// pixels (ring 0, 4, 8, 12), so a corner at threshold th has >= 2 compass pixels brighter than v+th or >= 2
+// darker than v-th.  Sign bits are gathered with v_alignbit, 2 ops per compass pixel and polarity.
+template <int O>
+__device__ __forceinline__ bool fast_compass(const uint32_t* up /*w1 of row -3*/, const uint32_t* mid /*w0..w2 of row 0*/, const uint32_t* dn, int th)
+{
+    const int v = WIN_BYTE(mid, O), lo = v - th, hi = v + th;
+    const int r0 = (int)((dn[0] >> (8 * (O - 4))) & 0xffu), r8 = (int)((up[0] >> (8 * (O - 4))) & 0xffu);
+    const int r4 = WIN_BYTE(mid, O + 3), r12 = WIN_BYTE(mid, O - 3);
+    uint32_t dk = 0, br = 0;
+    dk = __builtin_amdgcn_alignbit(dk, (uint32_t)(r0 - lo), 31); br = __builtin_amdgcn_alignbit(br, (uint32_t)(hi - r0), 31);
+    dk = __builtin_amdgcn_alignbit(dk, (uint32_t)(r4 - lo), 31); br = __builtin_amdgcn_alignbit(br, (uint32_t)(hi - r4), 31);
+    dk = __builtin_amdgcn_alignbit(dk, (uint32_t)(r8 - lo), 31); br = __builtin_amdgcn_alignbit(br, (uint32_t)(hi - r8), 31);
+    dk = __builtin_amdgcn_alignbit(dk, (uint32_t)(r12 - lo), 31); br = __builtin_amdgcn_alignbit(br, (uint32_t)(hi - r12), 31);
+    return (__popc(dk) >= 2) | (__popc(br) >= 2);
+}
+
+// Phase 1b: full 9/16 segment test + threshold-free corner score for one candidate pixel at LDS tile position t.
+// S = (max over the 16 arcs of 9 of the arc's min one-signed |centre - ring|) - 1; 0 unless p is a corner at `th`
+// (then S >= th): "corner at threshold t" <=> S >= t, so one score map serves both reference thresholds.
 __device__ __forceinline__ int fast_score(const uint8_t* t, int th)
 {
-    const int v = t[0];
-    const int lo = v - th, hi = v + th;
-    // any 9-arc contains one pixel of every opposite pair: two pairs reject most pixels with 4 reads
-    const int r0 = t[3 * FT_PITCH], r8 = t[-3 * FT_PITCH], r4 = t[3], r12 = t[-3];
-    const bool c0 = (r0 < lo) | (r0 > hi) | (r8 < lo) | (r8 > hi);
-    const bool c1 = (r4 < lo) | (r4 > hi) | (r12 < lo) | (r12 > hi);
-    if (!(c0 & c1)) return 0;
+    const int v = t[0], lo = v - th, hi = v + th;
     int r[16];
-    r[0] = r0; r[4] = r4; r[8] = r8; r[12] = r12;
-    r[1] = t[3 * FT_PITCH + 1]; r[2] = t[2 * FT_PITCH + 2]; r[3] = t[FT_PITCH + 3];
-    r[5] = t[-FT_PITCH + 3]; r[6] = t[-2 * FT_PITCH + 2]; r[7] = t[-3 * FT_PITCH + 1];
-    r[9] = t[-3 * FT_PITCH - 1]; r[10] = t[-2 * FT_PITCH - 2]; r[11] = t[-FT_PITCH - 3];
-    r[13] = t[FT_PITCH - 3]; r[14] = t[2 * FT_PITCH - 2]; r[15] = t[3 * FT_PITCH - 1];
+    r[0] = t[3 * FT_PITCH]; r[1] = t[3 * FT_PITCH + 1]; r[2] = t[2 * FT_PITCH + 2]; r[3] = t[FT_PITCH + 3];
+    r[4] = t[3]; r[5] = t[-FT_PITCH + 3]; r[6] = t[-2 * FT_PITCH + 2]; r[7] = t[-3 * FT_PITCH + 1];
+    r[8] = t[-3 * FT_PITCH]; r[9] = t[-3 * FT_PITCH - 1]; r[10] = t[-2 * FT_PITCH - 2]; r[11] = t[-FT_PITCH - 3];
+    r[12] = t[-3]; r[13] = t[FT_PITCH - 3]; r[14] = t[2 * FT_PITCH - 2]; r[15] = t[3 * FT_PITCH - 1];
     uint32_t dark = 0, bright = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) { dark |= (uint32_t)(r[k] < lo) << k; bright |= (uint32_t)(r[k] > hi) << k; }
-    const bool isd = has9(dark), isb = has9(bright);
+    for (int k = 0; k < 16; k++) { dark = __builtin_amdgcn_alignbit(dark, (uint32_t)(r[k] - lo), 31); bright = __builtin_amdgcn_alignbit(bright, (uint32_t)(hi - r[k]), 31); }
+    const bool isd = has9(dark), isb = has9(bright);       // bit order reversed w.r.t. k: irrelevant for a circular run
     if (!(isd | isb)) return 0;
     int d[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) d[k] = isd ? v - r[k] : r[k] - v;     // one-signed difference of the arc family
-    // sliding window min over 9 circular neighbours by doubling: 2,4,8 then +1
-    int a2[16], a4[16], a8[16];
+    int a2[16], a4[16], a8[16];                                        // sliding min over 9 circular neighbours: 2,4,8,+1
 #pragma unroll
     for (int k = 0; k < 16; k++) a2[k] = min(d[k], d[(k + 1) & 15]);
 #pragma unroll
@@ -124,14 +140,19 @@ __device__ __forceinline__ int fast_score(const uint8_t* t, int th)
     return best - 1;
 }
 
+// dynamic LDS layout (bytes): [16 pad][tile rows*FT_PITCH][score (rows-4)*FS_PITCH][cand u16 x ncand][corner u16 x ncand][listA][listB]
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t slab, PyrDev P,
                                                    const CellDesc* __restrict__ cells, int n_cells,
-                                                   int ini_th, int min_th,
+                                                   int ini_th, int min_th, int lds_rows, int lds_ncand,
                                                    uint32_t* __restrict__ slots, int* __restrict__ counts)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[FT_ROWS * FT_PITCH];
-    __shared__ __attribute__((aligned(16))) uint8_t sc[FS_ROWS * FS_PITCH];
-    __shared__ uint32_t listA[VIDO_CELL_CAP], listB[VIDO_CELL_CAP];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint8_t* tile = lds_raw + 16;                                    // quads at column 0 peek one dword to the left
+    uint8_t* sc = tile + lds_rows * FT_PITCH;
+    uint16_t* cand = (uint16_t*)(sc + (lds_rows - 4) * FS_PITCH);
+    uint16_t* corners = cand + lds_ncand;
+    uint32_t* listA = (uint32_t*)(corners + lds_ncand);
+    uint32_t* listB = listA + VIDO_CELL_CAP;
     const int cell = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
     const CellDesc c = cells[cell];
     const int pitch = P.pitch[c.level];
@@ -142,43 +163,86 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
         const int row = i / nd, col = i - row * nd;
         *(uint32_t*)(tile + row * FT_PITCH + 4 * col) = *(const uint32_t*)(img + (size_t)(c.y0 + row) * pitch + xa + 4 * col);
     }
-    const int iw = c.sw - 6, ih = c.sh - 6, npx = iw * ih;
+    const int iw = c.sw - 6, ih = c.sh - 6;
     for (int i = lane; i < (ih + 2) * (FS_PITCH / 4); i += 64) ((uint32_t*)sc)[i] = 0;
     __syncthreads();
-    for (int q = lane; q < npx; q += 64) {
-        const int iy = q / iw, ix = q - iy * iw;
-        const int S = fast_score(tile + (iy + 3) * FT_PITCH + shift + ix + 3, min_th);
-        if (S > 0) sc[(iy + 1) * FS_PITCH + ix + 1] = (uint8_t)S;
-    }
-    __syncthreads();
-    int nA = 0, nB = 0;
+    // The reference runs cv::FAST at iniThFAST and only re-runs the cell at minThFAST when that came back empty
+    // (ORBextractor.cc:799-806).  Same control flow here (wave-uniform): pass 0 works on the far smaller
+    // candidate set of the high threshold; the score map is threshold-free, so pass 1 only adds entries.
+    const int tx0 = shift + 3;                                       // tile column of interior x = 0
+    const int qc0 = tx0 >> 2, nq = ((tx0 + iw - 1) >> 2) - qc0 + 1, ntask = ih * nq;
     const unsigned long long ltmask = (1ull << lane) - 1ull;
-    for (int q0 = 0; q0 < npx; q0 += 64) {
-        const int q = q0 + lane;
-        bool kA = false, kB = false; uint32_t packed = 0;
-        if (q < npx) {
-            const int iy = q / iw, ix = q - iy * iw;
-            const uint8_t* s = sc + (iy + 1) * FS_PITCH + ix + 1;
-            const int S = s[0];
-            if (S >= min_th) {
+    bool overflow = false;
+    int n = 0;
+    for (int pass = 0; pass < 2 && n == 0; pass++) {
+        const int th = pass == 0 ? ini_th : min_th;
+        // ---- phase a: compass pre-test, 4 horizontally adjacent pixels per lane (aligned quad), ordered compaction
+        int ncand = 0;
+        for (int t0 = 0; t0 < ntask; t0 += 64) {
+            const int t = t0 + lane;
+            uint32_t m4 = 0; int iy = 0, txq = 0;
+            if (t < ntask) {
+                iy = t / nq; const int qc = qc0 + (t - iy * nq);
+                txq = 4 * qc;
+                const uint8_t* base = tile + iy * FT_PITCH + txq;        // row iy = centre row - 3
+                const uint32_t up = *(const uint32_t*)base, dn = *(const uint32_t*)(base + 6 * FT_PITCH);
+                const uint32_t* q = (const uint32_t*)(base + 3 * FT_PITCH - 4);
+                const uint32_t mid[3] = {q[0], q[1], q[2]};
+                const int ixq = txq - tx0;                               // interior x of the quad's first pixel (may be < 0)
+                if (ixq + 0 >= 0 && ixq + 0 < iw) m4 |= (uint32_t)fast_compass<4>(&up, mid, &dn, th) << 0;
+                if (ixq + 1 >= 0 && ixq + 1 < iw) m4 |= (uint32_t)fast_compass<5>(&up, mid, &dn, th) << 1;
+                if (ixq + 2 >= 0 && ixq + 2 < iw) m4 |= (uint32_t)fast_compass<6>(&up, mid, &dn, th) << 2;
+                if (ixq + 3 >= 0 && ixq + 3 < iw) m4 |= (uint32_t)fast_compass<7>(&up, mid, &dn, th) << 3;
+            }
+            const unsigned long long b0 = __ballot(m4 & 1), b1 = __ballot(m4 & 2), b2 = __ballot(m4 & 4), b3 = __ballot(m4 & 8);
+            int pos = ncand + __popcll(b0 & ltmask) + __popcll(b1 & ltmask) + __popcll(b2 & ltmask) + __popcll(b3 & ltmask);
+#pragma unroll
+            for (int p = 0; p < 4; p++) if (m4 & (1u << p)) { if (pos < lds_ncand) cand[pos] = (uint16_t)(iy * 128 + (txq - tx0 + p)); pos++; }
+            ncand += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+        }
+        overflow |= ncand > lds_ncand;                               // reported through the count (> VIDO_CELL_CAP => VIDO_E_CAPACITY)
+        ncand = min(ncand, lds_ncand);
+        __syncthreads();
+        // ---- phase b: full segment test + score, one candidate per lane; corners keep the row-major order
+        int ncorn = 0;
+        for (int q0 = 0; q0 < ncand; q0 += 64) {
+            const int q = q0 + lane;
+            int S = 0; uint16_t code = 0;
+            if (q < ncand) {
+                code = cand[q];
+                const int iy = code >> 7, ix = code & 127;
+                S = fast_score(tile + (iy + 3) * FT_PITCH + tx0 + ix, th);
+                if (S > 0) sc[(iy + 1) * FS_PITCH + ix + 1] = (uint8_t)S;
+            }
+            const unsigned long long bc = __ballot(S > 0);
+            if (S > 0) corners[ncorn + __popcll(bc & ltmask)] = code;
+            ncorn += __popcll(bc);
+        }
+        __syncthreads();
+        // ---- phase c: per-sub-image 3x3 NMS (strictly greater than the 8 neighbours' scores at this threshold;
+        // the score tile only holds scores >= th), emission in row-major order
+        for (int q0 = 0; q0 < ncorn; q0 += 64) {
+            const int q = q0 + lane;
+            bool keep = false; uint32_t packed = 0;
+            if (q < ncorn) {
+                const int iy = corners[q] >> 7, ix = corners[q] & 127;
+                const uint8_t* s = sc + (iy + 1) * FS_PITCH + ix + 1;
+                const int S = s[0];
                 const int n0 = s[-FS_PITCH - 1], n1 = s[-FS_PITCH], n2 = s[-FS_PITCH + 1], n3 = s[-1],
                           n4 = s[1], n5 = s[FS_PITCH - 1], n6 = s[FS_PITCH], n7 = s[FS_PITCH + 1];
                 const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-                kB = S > mx;                                            // th = minThFAST: every stored score counts
-                if (S >= ini_th) kA = kB | (mx < ini_th);               // th = iniThFAST: neighbours below it score 0
+                keep = S > mx;
                 packed = (uint32_t)(c.x0 + 3 + ix) | ((uint32_t)(c.y0 + 3 + iy) << 12) | ((uint32_t)S << 24);
             }
+            const unsigned long long bk = __ballot(keep);
+            if (keep) { const int pos = n + __popcll(bk & ltmask); if (pos < VIDO_CELL_CAP) listA[pos] = packed; }
+            n += __popcll(bk);
         }
-        const unsigned long long bA = __ballot(kA), bB = __ballot(kB);
-        if (kA) { const int pos = nA + __popcll(bA & ltmask); if (pos < VIDO_CELL_CAP) listA[pos] = packed; }
-        if (kB) { const int pos = nB + __popcll(bB & ltmask); if (pos < VIDO_CELL_CAP) listB[pos] = packed; }
-        nA += __popcll(bA); nB += __popcll(bB);
+        __syncthreads();
     }
-    __syncthreads();
-    const int n = nA > 0 ? nA : nB;
-    const uint32_t* list = nA > 0 ? listA : listB;
+    const uint32_t* list = listA;
     const size_t ci = (size_t)f * n_cells + cell;
-    if (lane == 0) counts[ci] = n;
+    if (lane == 0) counts[ci] = overflow ? VIDO_CELL_CAP + 1 : n;
     for (int i = lane; i < min(n, VIDO_CELL_CAP); i += 64) slots[ci * VIDO_CELL_CAP + i] = list[i];
 }
 
@@ -324,6 +388,32 @@ __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict_
 
 // ================================================================================================
 // host side
+// Persistent worker pool for the host quadtree stage (thread creation per call would cost more than the work).
+struct WorkerPool {
+    std::vector<std::thread> th; std::mutex mu; std::condition_variable cv_go, cv_done;
+    std::function<void(int)> fn; std::atomic<int> next{0}; int n = 0, active = 0; uint64_t gen = 0; bool stop = false;
+    explicit WorkerPool(int nthreads)
+    {
+        for (int t = 0; t < nthreads; t++) th.emplace_back([this] {
+            uint64_t seen = 0;
+            for (;;) {
+                { std::unique_lock<std::mutex> lk(mu); cv_go.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
+                for (int i; (i = next.fetch_add(1)) < n;) fn(i);
+                { std::lock_guard<std::mutex> lk(mu); if (--active == 0) cv_done.notify_all(); }
+            }
+        });
+    }
+    ~WorkerPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv_go.notify_all(); for (auto& t : th) t.join(); }
+    void run(int count, std::function<void(int)> f)
+    {
+        if (th.empty() || count < 4) { for (int i = 0; i < count; i++) f(i); return; }
+        { std::lock_guard<std::mutex> lk(mu); fn = std::move(f); n = count; next = 0; active = (int)th.size(); gen++; }
+        cv_go.notify_all();
+        for (int i; (i = next.fetch_add(1)) < n;) fn(i);          // the caller works too
+        std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return active == 0; });
+    }
+};
+
 struct OrbState {
     int L = 0, W = 0, H = 0, B = 0;
     LevelInfo lv[VIDO_MAX_LEVELS];
@@ -345,6 +435,8 @@ struct OrbState {
     float timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int last_frames = 0;
     int n_threads = 1;
+    struct WorkerPool* pool = nullptr;
+    int fast_rows = 0, fast_ncand = 0; size_t fast_lds = 0;
 };
 
 static inline int cv_round_f(float v) { return (int)lrintf(v); }
@@ -439,6 +531,12 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
             for (int tx = 0; tx < (v.w + 63) / 64; tx++) btiles.push_back(BlurTile{l, tx, ty, 0});
     }
     S->n_cells = (int)cells.size(); S->n_blur_tiles = (int)btiles.size();
+    {   // dynamic LDS of k_fast_cells: sized for the largest cell of this pyramid
+        int max_sh = 8, max_px = 64;
+        for (const CellDesc& cd : cells) { max_sh = std::max(max_sh, cd.sh); max_px = std::max(max_px, (cd.sw - 6) * (cd.sh - 6)); }
+        S->fast_rows = max_sh; S->fast_ncand = (max_px + 63) & ~63;
+        S->fast_lds = 16 + (size_t)max_sh * FT_PITCH + (size_t)(max_sh - 4) * FS_PITCH + 2 * sizeof(uint16_t) * S->fast_ncand + 2 * sizeof(uint32_t) * VIDO_CELL_CAP + 16;
+    }
     HIP_TRY(ctx, hipMalloc(&S->d_cells, cells.size() * sizeof(CellDesc)));
     HIP_TRY(ctx, hipMemcpy(S->d_cells, cells.data(), cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMalloc(&S->d_btiles, btiles.size() * sizeof(BlurTile)));
@@ -490,6 +588,7 @@ int orb_state_create(vido_ctx* ctx)
     int nt = ctx->cfg.host_threads;
     if (nt <= 0) { nt = (int)std::thread::hardware_concurrency(); nt = std::max(1, std::min(nt, 32)); }
     S->n_threads = nt;
+    S->pool = new WorkerPool(nt > 1 ? nt - 1 : 0);
     return VIDO_OK;
 }
 
@@ -502,6 +601,7 @@ void orb_state_destroy(vido_ctx* ctx)
     hipFree(S->d_cand); hipFree(S->d_kp); hipFree(S->d_angle); hipFree(S->d_desc);
     hipHostFree(S->h_lvloff); hipHostFree(S->h_overflow); hipHostFree(S->h_cand); hipHostFree(S->h_kp); hipHostFree(S->h_angle); hipHostFree(S->h_desc);
     for (auto& e : S->ev) if (e) hipEventDestroy(e);
+    delete S->pool;
     delete S; ctx->orb = nullptr;
 }
 
@@ -609,17 +709,6 @@ static int quadtree_select(const float* cx, const float* cy, const float* resp, 
     return (int)out.size();
 }
 
-template <class F>
-static void parallel_for(int n, int n_threads, F&& fn)
-{
-    if (n_threads <= 1 || n < 4) { for (int i = 0; i < n; i++) fn(i); return; }
-    std::atomic<int> next{0};
-    const int nt = std::min(n_threads, n);
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; t++) th.emplace_back([&] { for (int i; (i = next.fetch_add(1)) < n;) fn(i); });
-    for (auto& t : th) t.join();
-}
-
 static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_t frame_stride, int stride, int width, int height,
                    vido_keypoint* kp_out, int max_kp, int* n_out, uint8_t* desc_out)
 {
@@ -645,8 +734,8 @@ static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, si
                            S->d_xtab + d.xtab_off, S->d_ytab + d.ytab_off);
     }
     HIP_TRY(ctx, hipEventRecord(S->ev[1], st));
-    hipLaunchKernelGGL(k_fast_cells, dim3(S->n_cells, nf), dim3(64), 0, st, S->d_pyr, S->slab, S->P, S->d_cells, S->n_cells,
-                       ctx->cfg.ini_th_fast, ctx->cfg.min_th_fast, S->d_slots, S->d_counts);
+    hipLaunchKernelGGL(k_fast_cells, dim3(S->n_cells, nf), dim3(64), S->fast_lds, st, S->d_pyr, S->slab, S->P, S->d_cells, S->n_cells,
+                       ctx->cfg.ini_th_fast, ctx->cfg.min_th_fast, S->fast_rows, S->fast_ncand, S->d_slots, S->d_counts);
     HIP_TRY(ctx, hipEventRecord(S->ev[7], st));
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, S->d_counts, S->n_cells * nf, S->d_offsets, S->n_cells, nf, L,
                        S->d_first_cell, S->d_lvloff, S->d_overflow);
@@ -669,7 +758,7 @@ static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, si
     // ---- host quadtree per (frame, level)
     std::vector<std::vector<int>> sel((size_t)nf * L);
     std::vector<std::vector<float>> fx((size_t)nf * L), fy((size_t)nf * L), fr((size_t)nf * L);
-    parallel_for(nf * L, S->n_threads, [&](int task) {
+    S->pool->run(nf * L, [&](int task) {
         const int l = task % L;
         const int beg = S->h_lvloff[task], end = S->h_lvloff[task + 1];
         const int n = end - beg;

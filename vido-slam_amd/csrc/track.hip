@@ -292,25 +292,28 @@ int vido_frame_features(vido_ctx* ctx, int slot0, int n_frames, const vido_keypo
     HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt + T->B, T->d_nobj, n_frames * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     HIP_TRY(ctx, hipGetLastError());
+    int max_ns = 0, max_no = 0;
     for (int f = 0; f < n_frames; f++) {
         const int ns = T->h_cnt[f], no = T->h_cnt[T->B + f];
         out->n_stat[f] = ns; out->n_obj[f] = no;
         if (no > out->max_obj) return vido_set_error(ctx, VIDO_E_CAPACITY, "frame_features: %d object samples > max_obj %d", no, out->max_obj);
-        const size_t so = (size_t)f * out->max_stat, oo = (size_t)f * out->max_obj, ds = (size_t)f * T->max_kp, dobj = (size_t)f * T->max_obj;
-        if (ns > 0) {
-            HIP_TRY(ctx, hipMemcpyAsync(out->stat_idx + so, T->d_sidx + ds, ns * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipMemcpyAsync(out->stat_corr + 2 * so, T->d_scorr + 2 * ds, ns * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipMemcpyAsync(out->stat_flow + 2 * so, T->d_sflow + 2 * ds, ns * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipMemcpyAsync(out->stat_depth + so, T->d_sdepth + ds, ns * 4, hipMemcpyDeviceToHost, st));
-        }
-        if (no > 0) {
-            HIP_TRY(ctx, hipMemcpyAsync(out->obj_keys + 2 * oo, T->d_okeys + 2 * dobj, no * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipMemcpyAsync(out->obj_corr + 2 * oo, T->d_ocorr + 2 * dobj, no * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipMemcpyAsync(out->obj_depth + oo, T->d_odepth + dobj, no * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipMemcpyAsync(out->obj_label + oo, T->d_olabel + dobj, no * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipMemcpyAsync(out->obj_flow + 2 * oo, T->d_oflow + 2 * dobj, no * 8, hipMemcpyDeviceToHost, st));
-        }
+        max_ns = std::max(max_ns, ns); max_no = std::max(max_no, no);
     }
+    // one strided copy per list (rows = frames, width = longest list) instead of one copy per frame and list
+    auto copy2d = [&](void* dst, size_t dpitch_el, const void* src, size_t spitch_el, size_t el, int width_el) -> int {
+        if (width_el <= 0) return VIDO_OK;
+        HIP_TRY(ctx, hipMemcpy2DAsync(dst, dpitch_el * el, src, spitch_el * el, (size_t)width_el * el, n_frames, hipMemcpyDeviceToHost, st));
+        return VIDO_OK;
+    };
+    if ((rc = copy2d(out->stat_idx, out->max_stat, T->d_sidx, T->max_kp, 4, max_ns))) return rc;
+    if ((rc = copy2d(out->stat_corr, out->max_stat, T->d_scorr, T->max_kp, 8, max_ns))) return rc;
+    if ((rc = copy2d(out->stat_flow, out->max_stat, T->d_sflow, T->max_kp, 8, max_ns))) return rc;
+    if ((rc = copy2d(out->stat_depth, out->max_stat, T->d_sdepth, T->max_kp, 4, max_ns))) return rc;
+    if ((rc = copy2d(out->obj_keys, out->max_obj, T->d_okeys, T->max_obj, 8, max_no))) return rc;
+    if ((rc = copy2d(out->obj_corr, out->max_obj, T->d_ocorr, T->max_obj, 8, max_no))) return rc;
+    if ((rc = copy2d(out->obj_depth, out->max_obj, T->d_odepth, T->max_obj, 4, max_no))) return rc;
+    if ((rc = copy2d(out->obj_label, out->max_obj, T->d_olabel, T->max_obj, 4, max_no))) return rc;
+    if ((rc = copy2d(out->obj_flow, out->max_obj, T->d_oflow, T->max_obj, 8, max_no))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return VIDO_OK;
 }
