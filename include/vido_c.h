@@ -195,6 +195,26 @@ typedef int (*vido_allreduce_fn)(void* user, void* dev_ptr, size_t count, int op
 
 int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_result* result, vido_allreduce_fn allreduce, void* user);
 
+/* ---- Native ops of the three network nodes (the nets' conv/GEMM layers run on PyTorch-ROCm) -----------------
+ * All tensors f32, NCHW contiguous.  on_device != 0: every pointer is a device pointer and the call only
+ * enqueues on the ctx stream (this is how the torch modules call them); otherwise host pointers, synchronous. */
+/* correlation.FunctionCorrelation(first, second, intStride) — flow_net/src/correlation/correlation.py:277-335.
+ * out: [B, 49, ceil(H/stride), ceil(W/stride)]. */
+int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int B, int C, int H, int W, int stride,
+                     float* out, int on_device);
+/* layers.ROIAlign forward — mask_rcnn/maskrcnn_benchmark/csrc/cuda/ROIAlign_cuda.cu:257-299.  rois [n,5] =
+ * (batch index, x1, y1, x2, y2); out [n, C, pooled_h, pooled_w]. */
+int vido_roi_align(vido_ctx* ctx, const float* feat, int B, int C, int H, int W, const float* rois, int n_rois,
+                   float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio, float* out, int on_device);
+/* layers.nms(boxes, scores, thresh) — csrc/cuda/nms.cu:70-131 (IoU with the +1 convention, suppress when > thresh).
+ * Host mode returns the kept ORIGINAL indices in ascending order like the reference.  Device mode: boxes already
+ * sorted by descending score, keep_out/n_keep are device pointers receiving kept positions (ascending). */
+int vido_nms(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, int n, float thresh, int32_t* keep_out,
+             int32_t* n_keep, int on_device);
+/* BoxCoder(weights).decode(deltas [n,4k], boxes [n,4]) — modeling/box_coder.py:52-95. */
+int vido_box_decode(vido_ctx* ctx, const float* deltas, const float* boxes, int n, int k, const float weights[4],
+                    float* out, int on_device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -284,3 +284,29 @@ def iso_oplus(X, d):
     X = np.array(X, np.float64).reshape(3, 4).copy(); d = np.ascontiguousarray(d, np.float64)
     lib().vo_iso_oplus(_p(X), _p(d))
     return X
+
+
+# ---- network ops (nets_oracle.c) ---------------------------------------------------------------------
+def correlation(f1, f2, stride):
+    f1 = np.ascontiguousarray(f1, np.float32); f2 = np.ascontiguousarray(f2, np.float32); B, Cc, H, W = f1.shape
+    out = np.empty((B, 49, (H + stride - 1) // stride, (W + stride - 1) // stride), np.float32)
+    lib().vo_correlation(_p(f1), _p(f2), B, Cc, H, W, stride, _p(out))
+    return out
+
+def roi_align(feat, rois, scale, PH, PW, sampling):
+    feat = np.ascontiguousarray(feat, np.float32); rois = np.ascontiguousarray(rois, np.float32); B, Cc, H, W = feat.shape
+    out = np.empty((len(rois), Cc, PH, PW), np.float32)
+    lib().vo_roi_align(_p(feat), B, Cc, H, W, _p(rois), len(rois), C.c_float(scale), PH, PW, sampling, _p(out))
+    return out
+
+def nms(boxes, scores, thresh):
+    boxes = np.ascontiguousarray(boxes, np.float32); scores = np.ascontiguousarray(scores, np.float32)
+    keep = np.empty(max(len(boxes), 1), np.int32)
+    m = lib().vo_nms(_p(boxes), _p(scores), len(boxes), C.c_float(thresh), _p(keep))
+    return keep[:m].copy()
+
+def box_decode(deltas, boxes, weights):
+    deltas = np.ascontiguousarray(deltas, np.float32); boxes = np.ascontiguousarray(boxes, np.float32); w = np.ascontiguousarray(weights, np.float32)
+    out = np.empty_like(deltas)
+    lib().vo_box_decode(_p(deltas), _p(boxes), len(boxes), deltas.shape[1] // 4, _p(w), _p(out))
+    return out

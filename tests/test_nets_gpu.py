@@ -1,0 +1,59 @@
+"""GPU parity of the network nodes' native ops (vido_correlation / vido_roi_align / vido_nms / vido_box_decode)
+against (i) the reference's OWN known-answer vectors — tests/golden/maskrcnn_kats.npz, extracted from
+src/thirdparty/mask_rcnn/src/tests/test_nms.py and test_box_coder.py — and (ii) the CPU oracle restating
+correlation.py:7-102, ROIAlign_cuda.cu:15-122, nms.cu:13-131, box_coder.py:52-95."""
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "maskrcnn_kats.npz")
+
+
+@pytest.fixture(scope="module")
+def ops(vido):
+    return vido.NetOps(vido.Context(width=640, height=480, max_batch=1))
+
+
+def test_nms_reference_known_answers(ops):
+    g = np.load(GOLD)
+    for k in range(6):
+        keep = ops.nms(g["nms%d_boxes" % k], g["nms%d_scores" % k], float(g["nms%d_thresh" % k]))
+        assert np.array_equal(keep, g["nms%d_keep" % k]), k
+
+
+def test_box_decode_reference_known_answer(ops):
+    g = np.load(GOLD)
+    out = ops.box_decode(g["dec0_deltas"], g["dec0_boxes"], tuple(g["dec0_weights"]))
+    np.testing.assert_allclose(out, g["dec0_expected"], atol=1e-4)          # the reference test's own tolerance
+
+
+def test_nms_random_vs_oracle(ops, oracle):
+    rng = np.random.RandomState(0)
+    for n, th in ((1, 0.5), (63, 0.7), (64, 0.5), (65, 0.3), (1000, 0.7), (2500, 0.5)):
+        xy = rng.uniform(0, 600, (n, 2)); wh = rng.uniform(5, 200, (n, 2))
+        boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32); scores = rng.uniform(0, 1, n).astype(np.float32)
+        assert np.array_equal(ops.nms(boxes, scores, th), oracle.nms(boxes, scores, th).astype(np.int64)), (n, th)
+    assert len(ops.nms(np.zeros((0, 4), np.float32), np.zeros(0, np.float32), 0.5)) == 0
+
+
+def test_roi_align_vs_oracle_bit_exact(ops, oracle):
+    rng = np.random.RandomState(1)
+    feat = rng.normal(0, 1, (2, 16, 50, 68)).astype(np.float32)
+    n = 40
+    xy = rng.uniform(-20, 250, (n, 2)); wh = rng.uniform(1, 150, (n, 2))
+    rois = np.concatenate([rng.randint(0, 2, (n, 1)), xy, xy + wh], 1).astype(np.float32)
+    for (ph, pw, sr, scale) in ((7, 7, 2, 0.25), (14, 14, 2, 0.125), (7, 7, 0, 0.25)):
+        got = ops.roi_align(feat, rois, (ph, pw), scale, sr)
+        ref = oracle.roi_align(feat, rois, scale, ph, pw, sr)
+        assert np.array_equal(got, ref), (ph, pw, sr)
+
+
+def test_correlation_vs_oracle(ops, oracle):
+    rng = np.random.RandomState(2)
+    # the five LiteFlowNet call shapes scaled down (C, stride as in layers.py:124-159)
+    for (C, H, W, s) in ((192, 8, 10, 1), (128, 15, 20, 1), (96, 30, 40, 1), (64, 31, 41, 2), (64, 60, 80, 2), (5, 3, 3, 1)):
+        a = rng.normal(0, 1, (2, C, H, W)).astype(np.float32); b = rng.normal(0, 1, (2, C, H, W)).astype(np.float32)
+        got = ops.FunctionCorrelation(a, b, s); ref = oracle.correlation(a, b, s)
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)       # float summation order differs (32-way partials in the reference)

@@ -137,3 +137,28 @@ def test_pose_oracle_jacobians_and_fixed_point(oracle, vido):
     s0 = P.synth_pose_scene(300, seed=9, noise_px=0.0, outlier_frac=0.0)
     r = oracle.pose_optimize(P.pose_problem_flow2cam(s0["uv_last"], s0["flow"], s0["depth"], s0["Twl"], s0["K"], s0["T_init"]))
     assert np.abs(r["T"] - s0["T_cur"]).max() < 1e-6 and np.abs(r["flow"] - s0["flow"]).max() < 1e-6
+
+
+def test_nets_oracle_reference_kats_and_second_implementations(oracle):
+    """The reference's own golden vectors (test_nms.py, test_box_coder.py) pin the NMS / box-decode restatement;
+    correlation and ROI-Align are checked against independent torch implementations."""
+    import torch
+    g = np.load(os.path.join(GOLD, "maskrcnn_kats.npz"))
+    for k in range(6):
+        assert np.array_equal(oracle.nms(g["nms%d_boxes" % k], g["nms%d_scores" % k], float(g["nms%d_thresh" % k])), g["nms%d_keep" % k]), k
+    np.testing.assert_allclose(oracle.box_decode(g["dec0_deltas"], g["dec0_boxes"], g["dec0_weights"]), g["dec0_expected"], atol=1e-4)
+    rng = np.random.RandomState(0)
+    a = rng.normal(0, 1, (1, 6, 9, 11)).astype(np.float32); b = rng.normal(0, 1, (1, 6, 9, 11)).astype(np.float32)
+    for s in (1, 2):
+        ta, tb = torch.from_numpy(a)[:, :, ::s, ::s], torch.from_numpy(b)[:, :, ::s, ::s]
+        pad = torch.nn.functional.pad(tb, (3, 3, 3, 3))
+        ref = torch.stack([(ta * pad[:, :, p:p + ta.shape[2], o:o + ta.shape[3]]).mean(1) for p in range(7) for o in range(7)], 1)
+        np.testing.assert_allclose(oracle.correlation(a, b, s), ref.numpy(), rtol=1e-5, atol=1e-6)
+    # ROI-Align of a constant map is that constant; of a linear ramp it is the ramp at the bin centre
+    feat = np.full((1, 2, 20, 30), 3.5, np.float32)
+    rois = np.array([[0, 2.0, 3.0, 20.0, 15.0]], np.float32)
+    assert np.allclose(oracle.roi_align(feat, rois, 1.0, 7, 7, 2), 3.5)
+    ramp = np.tile(np.arange(30, dtype=np.float32), (1, 1, 20, 1))
+    out = oracle.roi_align(ramp, rois, 1.0, 1, 6, 2)
+    centres = 2.0 + (np.arange(6) + 0.5) * (18.0 / 6)
+    assert np.allclose(out[0, 0, 0], centres, atol=1e-4)

@@ -45,6 +45,7 @@ struct vido_ctx {
     BaState* ba = nullptr;
     struct HamState* ham = nullptr;
     struct PoseState* pose = nullptr;
+    struct NetState* net = nullptr;
 };
 
 int vido_set_error(vido_ctx* ctx, int code, const char* fmt, ...);
@@ -62,4 +63,5 @@ void track_state_destroy(vido_ctx* ctx);
 void ham_state_destroy(vido_ctx* ctx);
 void pose_state_destroy(vido_ctx* ctx);
 void ba_state_destroy(vido_ctx* ctx);
+void net_state_destroy(vido_ctx* ctx);
 void orb_state_destroy(vido_ctx* ctx);

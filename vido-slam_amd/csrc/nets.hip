@@ -1,0 +1,310 @@
+// nets.hip — the native GPU ops of the three network nodes, on gfx950 (the dense conv/GEMM layers of the nets
+// themselves run on PyTorch-ROCm; these are the hand-written ops the reference ships as CUDA):
+//   vido_correlation   kernel_Correlation_rearrange + kernel_Correlation_updateOutput
+//                      (reference src/thirdparty/flow_net/src/correlation/correlation.py:7-102), fused: no padded
+//                      NHWC copies, both inputs read once per tile straight from NCHW
+//   vido_roi_align     RoIAlignForward (src/thirdparty/mask_rcnn/maskrcnn_benchmark/csrc/cuda/ROIAlign_cuda.cu:15-122)
+//   vido_nms           nms_kernel + the HOST sweep of nms.cu:13-131 — here the sweep runs on the device too
+//                      (one wave keeps the 64-bit suppression words in its lanes), no mask download
+//   vido_box_decode    BoxCoder.decode (maskrcnn_benchmark/modeling/box_coder.py:52-95)
+#include "common.hpp"
+#include <numeric>
+
+// ---- correlation ---------------------------------------------------------------------------------------
+// out[b, (p+3)*7+(o+3), y, x] = (1/C) sum_c f1[b,c,y*s,x*s] * f2[b,c,(y+p)*s,(x+o)*s]   (zero outside the image)
+// 16x16 output tile per workgroup; per channel chunk the (16+6)^2 neighbourhood of f2 is staged in LDS and every
+// thread keeps its 49 displacement sums in registers.
+#define CORR_CH 8
+__global__ __launch_bounds__(256) void k_correlation(const float* __restrict__ f1, const float* __restrict__ f2, int C, int H, int W, int s,
+                                                     int Ho, int Wo, float* __restrict__ out)
+{
+    __shared__ float t2[CORR_CH][22][23];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, b = blockIdx.z;
+    const int x = blockIdx.x * 16 + tx, y = blockIdx.y * 16 + ty;
+    const bool valid = x < Wo && y < Ho;
+    float acc[49];
+#pragma unroll
+    for (int k = 0; k < 49; k++) acc[k] = 0.f;
+    const size_t plane = (size_t)H * W;
+    for (int c0 = 0; c0 < C; c0 += CORR_CH) {
+        const int nc = min(CORR_CH, C - c0);
+        for (int i = threadIdx.x; i < nc * 22 * 22; i += 256) {
+            const int cc = i / (22 * 22), r = (i / 22) % 22, q = i % 22;
+            const int yy = (blockIdx.y * 16 + r - 3), xx = (blockIdx.x * 16 + q - 3);
+            float v = 0.f;
+            if (yy >= 0 && yy < Ho && xx >= 0 && xx < Wo) v = f2[((size_t)b * C + c0 + cc) * plane + (size_t)(yy * s) * W + xx * s];
+            t2[cc][r][q] = v;
+        }
+        float a[CORR_CH];
+#pragma unroll
+        for (int cc = 0; cc < CORR_CH; cc++) a[cc] = (valid && cc < nc) ? f1[((size_t)b * C + c0 + cc) * plane + (size_t)(y * s) * W + x * s] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < CORR_CH; cc++) {
+            if (cc < nc) {
+#pragma unroll
+                for (int p = 0; p < 7; p++)
+#pragma unroll
+                    for (int o = 0; o < 7; o++) acc[p * 7 + o] += a[cc] * t2[cc][ty + p][tx + o];
+            }
+        }
+        __syncthreads();
+    }
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 49; k++) out[(((size_t)b * 49 + k) * Ho + y) * Wo + x] = acc[k] / (float)C;
+    }
+}
+
+// ---- ROI-Align ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bilinear(const float* __restrict__ d, int h, int w, float y, float x)
+{
+    if (y < -1.0 || y > h || x < -1.0 || x > w) return 0;
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+    int yl = (int)y, xl = (int)x, yh, xh;
+    if (yl >= h - 1) { yh = yl = h - 1; y = (float)yl; } else yh = yl + 1;
+    if (xl >= w - 1) { xh = xl = w - 1; x = (float)xl; } else xh = xl + 1;
+    const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
+    const float v1 = d[yl * w + xl], v2 = d[yl * w + xh], v3 = d[yh * w + xl], v4 = d[yh * w + xh];
+    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    return (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+}
+__global__ __launch_bounds__(256) void k_roi_align(const float* __restrict__ feat, int C, int H, int W, const float* __restrict__ rois, int n,
+                                                   float scale, int PH, int PW, int sampling, float* __restrict__ out)
+{
+    const size_t total = (size_t)n * C * PH * PW;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int pw = (int)(idx % PW), ph = (int)((idx / PW) % PH), c = (int)((idx / PW / PH) % C), i = (int)(idx / PW / PH / C);
+        const float* r = rois + 5 * i;
+        const int bi = (int)r[0];
+        const float sw = r[1] * scale, sh = r[2] * scale, ew = r[3] * scale, eh = r[4] * scale;
+        const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);
+        const float bh = rh / (float)PH, bw = rw / (float)PW;
+        const int gh = sampling > 0 ? sampling : (int)ceilf(rh / PH), gw = sampling > 0 ? sampling : (int)ceilf(rw / PW);
+        const float count = (float)(gh * gw);
+        const float* d = feat + ((size_t)bi * C + c) * H * W;
+        float acc = 0;
+        for (int iy = 0; iy < gh; iy++) {
+            const float y = sh + ph * bh + (float)(iy + .5f) * bh / (float)gh;
+            for (int ix = 0; ix < gw; ix++) {
+                const float x = sw + pw * bw + (float)(ix + .5f) * bw / (float)gw;
+                acc += bilinear(d, H, W, y, x);
+            }
+        }
+        out[idx] = acc / count;
+    }
+}
+
+// ---- NMS (boxes sorted by descending score) ----------------------------------------------------------------------
+__device__ __forceinline__ float dev_iou(const float* a, const float* b)
+{
+    const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]), top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+    const float w = fmaxf(right - left + 1, 0.f), h = fmaxf(bottom - top + 1, 0.f), inter = w * h;
+    const float Sa = (a[2] - a[0] + 1) * (a[3] - a[1] + 1), Sb = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+    return inter / (Sa + Sb - inter);
+}
+// mask[i][cb] bit j: box (cb*64+j) overlaps box i by more than thresh (only j > i inside the diagonal tile)
+__global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, int n, float thresh, unsigned long long* __restrict__ mask, int col_blocks)
+{
+    const int row_start = blockIdx.y, col_start = blockIdx.x;
+    const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
+    __shared__ float bb[64 * 4];
+    if ((int)threadIdx.x < col_size) { for (int k = 0; k < 4; k++) bb[threadIdx.x * 4 + k] = boxes[(size_t)(col_start * 64 + threadIdx.x) * 4 + k]; }
+    __syncthreads();
+    if ((int)threadIdx.x < row_size) {
+        const int cur = row_start * 64 + threadIdx.x;
+        const float* cb = boxes + (size_t)cur * 4;
+        unsigned long long t = 0;
+        const int start = row_start == col_start ? threadIdx.x + 1 : 0;
+        for (int i = start; i < col_size; i++) if (dev_iou(cb, bb + i * 4) > thresh) t |= 1ULL << i;
+        mask[(size_t)cur * col_blocks + col_start] = t;
+    }
+}
+// the reference does this sweep on the host after a D2H copy; here one wave owns the `remv` words (lane w <-> word w)
+__global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long* __restrict__ mask, int n, int col_blocks, int* __restrict__ keep, int* __restrict__ n_keep)
+{
+    const int lane = threadIdx.x;
+    int cnt = 0;
+    // col_blocks suppression words spread round-robin over the lanes (word w lives in lane w%64, slot w/64)
+    unsigned long long remv[16];
+    const int wpl = (col_blocks + 63) / 64;                      // words per lane (<= 16 -> n <= 65536)
+    for (int k = 0; k < 16; k++) remv[k] = 0;
+    for (int i = 0; i < n; i++) {
+        const int nblock = i >> 6, inblock = i & 63;
+        const int owner = nblock & 63, slot = nblock >> 6;
+        unsigned long long word = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) if (k == slot) word = remv[k];
+        word = __shfl(word, owner, 64);
+        if (!(word & (1ULL << inblock))) {
+            if (lane == 0) keep[cnt] = i;
+            cnt++;
+            const unsigned long long* p = mask + (size_t)i * col_blocks;
+#pragma unroll
+            for (int k = 0; k < 16; k++) if (k < wpl) { const int w = k * 64 + lane; if (w >= nblock && w < col_blocks) remv[k] |= p[w]; }
+        }
+    }
+    if (lane == 0) *n_keep = cnt;
+}
+
+// ---- box decode ------------------------------------------------------------------------------------------------
+__global__ void k_box_decode(const float* __restrict__ deltas, const float* __restrict__ boxes, int n, int k, float wx, float wy, float ww, float wh, float* __restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * k) return;
+    const int i = t / k;
+    const float clip = (float)log(1000. / 16);
+    const float* b = boxes + 4 * (size_t)i; const float* d = deltas + 4 * (size_t)t; float* o = out + 4 * (size_t)t;
+    const float w = b[2] - b[0] + 1, h = b[3] - b[1] + 1, cx = b[0] + 0.5f * w, cy = b[1] + 0.5f * h;
+    float dx = d[0] / wx, dy = d[1] / wy, dw = d[2] / ww, dh = d[3] / wh;
+    if (dw > clip) dw = clip;
+    if (dh > clip) dh = clip;
+    const float pcx = dx * w + cx, pcy = dy * h + cy, pw = expf(dw) * w, phh = expf(dh) * h;
+    o[0] = pcx - 0.5f * pw; o[1] = pcy - 0.5f * phh; o[2] = pcx + 0.5f * pw - 1; o[3] = pcy + 0.5f * phh - 1;
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------
+struct NetState { char* d = nullptr; char* h = nullptr; size_t cap = 0; };     // device scratch + pinned mirror
+void net_state_destroy(vido_ctx* ctx)
+{
+    NetState* S = ctx->net; if (!S) return;
+    hipFree(S->d); hipHostFree(S->h); delete S; ctx->net = nullptr;
+}
+static int net_scratch(vido_ctx* ctx, size_t bytes, NetState** out)
+{
+    if (!ctx->net) ctx->net = new NetState();
+    NetState* S = ctx->net;
+    if (bytes > S->cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (S->d) { hipFree(S->d); hipHostFree(S->h); S->d = nullptr; S->h = nullptr; }
+        S->cap = bytes + bytes / 4 + 4096;
+        HIP_TRY(ctx, hipMalloc((void**)&S->d, S->cap)); HIP_TRY(ctx, hipHostMalloc((void**)&S->h, S->cap));
+    }
+    *out = S;
+    return VIDO_OK;
+}
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" {
+
+int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int B, int C, int H, int W, int stride, float* out, int on_device)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!first || !second || !out || B < 1 || C < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2)) return vido_set_error(ctx, VIDO_E_INVALID, "correlation: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+    const size_t nin = (size_t)B * C * H * W * 4, nout = (size_t)B * 49 * Ho * Wo * 4;
+    const float *d1 = first, *d2 = second; float* dout = out;
+    NetState* S = nullptr;
+    if (!on_device) {
+        int rc = net_scratch(ctx, 2 * al256(nin) + al256(nout), &S); if (rc) return rc;
+        memcpy(S->h, first, nin); memcpy(S->h + al256(nin), second, nin);
+        HIP_TRY(ctx, hipMemcpyAsync(S->d, S->h, 2 * al256(nin), hipMemcpyHostToDevice, st));
+        d1 = (float*)S->d; d2 = (float*)(S->d + al256(nin)); dout = (float*)(S->d + 2 * al256(nin));
+    }
+    hipLaunchKernelGGL(k_correlation, dim3((Wo + 15) / 16, (Ho + 15) / 16, B), dim3(256), 0, st, d1, d2, C, H, W, stride, Ho, Wo, dout);
+    HIP_TRY(ctx, hipGetLastError());
+    if (!on_device) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        HIP_TRY(ctx, hipMemcpyAsync(S->h, dout, nout, hipMemcpyDeviceToHost, st)); HIP_TRY(ctx, hipStreamSynchronize(st));
+        memcpy(out, S->h, nout);
+    }
+    return VIDO_OK;
+}
+
+int vido_roi_align(vido_ctx* ctx, const float* feat, int B, int C, int H, int W, const float* rois, int n_rois, float spatial_scale,
+                   int pooled_h, int pooled_w, int sampling_ratio, float* out, int on_device)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!feat || (n_rois && (!rois || !out)) || B < 1 || C < 1 || H < 1 || W < 1 || n_rois < 0 || pooled_h < 1 || pooled_w < 1) return vido_set_error(ctx, VIDO_E_INVALID, "roi_align: bad arguments");
+    if (n_rois == 0) return VIDO_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t nf = (size_t)B * C * H * W * 4, nr = (size_t)n_rois * 5 * 4, nout = (size_t)n_rois * C * pooled_h * pooled_w * 4;
+    const float *df = feat, *dr = rois; float* dout = out; NetState* S = nullptr;
+    if (!on_device) {
+        for (int i = 0; i < n_rois; i++) if (!(rois[5 * i] >= 0 && rois[5 * i] < B)) return vido_set_error(ctx, VIDO_E_INVALID, "roi_align: roi %d has batch index %g", i, rois[5 * i]);
+        int rc = net_scratch(ctx, al256(nf) + al256(nr) + al256(nout), &S); if (rc) return rc;
+        memcpy(S->h, feat, nf); memcpy(S->h + al256(nf), rois, nr);
+        HIP_TRY(ctx, hipMemcpyAsync(S->d, S->h, al256(nf) + al256(nr), hipMemcpyHostToDevice, st));
+        df = (float*)S->d; dr = (float*)(S->d + al256(nf)); dout = (float*)(S->d + al256(nf) + al256(nr));
+    }
+    const size_t total = (size_t)n_rois * C * pooled_h * pooled_w;
+    hipLaunchKernelGGL(k_roi_align, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, st, df, C, H, W, dr, n_rois, spatial_scale, pooled_h, pooled_w, sampling_ratio, dout);
+    HIP_TRY(ctx, hipGetLastError());
+    if (!on_device) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        HIP_TRY(ctx, hipMemcpyAsync(S->h, dout, nout, hipMemcpyDeviceToHost, st)); HIP_TRY(ctx, hipStreamSynchronize(st));
+        memcpy(out, S->h, nout);
+    }
+    return VIDO_OK;
+}
+
+/* maskrcnn_benchmark.layers.nms(boxes, scores, thresh): kept ORIGINAL indices, ascending.
+ * on_device: boxes_xyxy must already be sorted by descending score (scores ignored), keep_out/n_keep are device
+ * pointers receiving the kept POSITIONS in that order (ascending); only enqueues on the ctx stream. */
+int vido_nms(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, int n, float thresh, int32_t* keep_out, int32_t* n_keep, int on_device)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (n < 0 || !n_keep || (n && (!boxes_xyxy || !keep_out)) || (!on_device && n && !scores)) return vido_set_error(ctx, VIDO_E_INVALID, "nms: bad arguments");
+    if (n > 65536) return vido_set_error(ctx, VIDO_E_CAPACITY, "nms: %d boxes > 65536", n);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (n == 0) { if (on_device) HIP_TRY(ctx, hipMemsetAsync(n_keep, 0, 4, st)); else *n_keep = 0; return VIDO_OK; }
+    const int cb = (n + 63) / 64;
+    const size_t nb = (size_t)n * 16, nm = (size_t)n * cb * 8, nk = (size_t)n * 4 + 256;
+    NetState* S = nullptr;
+    int rc = net_scratch(ctx, al256(nb) + al256(nm) + al256(nk), &S); if (rc) return rc;
+    const float* dboxes = boxes_xyxy; unsigned long long* dmask = (unsigned long long*)(S->d + al256(nb));
+    int* dkeep = keep_out; int* dn = n_keep;
+    std::vector<int> order;
+    if (!on_device) {
+        order.resize(n); std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return scores[a] > scores[b]; });
+        float* hb = (float*)S->h;
+        for (int i = 0; i < n; i++) memcpy(hb + 4 * (size_t)i, boxes_xyxy + 4 * (size_t)order[i], 16);
+        HIP_TRY(ctx, hipMemcpyAsync(S->d, S->h, nb, hipMemcpyHostToDevice, st));
+        dboxes = (float*)S->d; dkeep = (int*)(S->d + al256(nb) + al256(nm)); dn = dkeep + n;
+    }
+    hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb), dim3(64), 0, st, dboxes, n, thresh, dmask, cb);
+    hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, st, dmask, n, cb, dkeep, dn);
+    HIP_TRY(ctx, hipGetLastError());
+    if (!on_device) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        HIP_TRY(ctx, hipMemcpyAsync(S->h, dkeep, nk, hipMemcpyDeviceToHost, st)); HIP_TRY(ctx, hipStreamSynchronize(st));
+        const int* hk = (const int*)S->h; const int m = hk[n];
+        for (int i = 0; i < m; i++) keep_out[i] = order[hk[i]];
+        std::sort(keep_out, keep_out + m);
+        *n_keep = m;
+    }
+    return VIDO_OK;
+}
+
+int vido_box_decode(vido_ctx* ctx, const float* deltas, const float* boxes, int n, int k, const float weights[4], float* out, int on_device)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (n < 0 || k < 1 || !weights || (n && (!deltas || !boxes || !out))) return vido_set_error(ctx, VIDO_E_INVALID, "box_decode: bad arguments");
+    if (n == 0) return VIDO_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t nd = (size_t)n * k * 16, nb = (size_t)n * 16;
+    const float *dd = deltas, *db = boxes; float* dout = out; NetState* S = nullptr;
+    if (!on_device) {
+        int rc = net_scratch(ctx, 2 * al256(nd) + al256(nb), &S); if (rc) return rc;
+        memcpy(S->h, deltas, nd); memcpy(S->h + al256(nd), boxes, nb);
+        HIP_TRY(ctx, hipMemcpyAsync(S->d, S->h, al256(nd) + al256(nb), hipMemcpyHostToDevice, st));
+        dd = (float*)S->d; db = (float*)(S->d + al256(nd)); dout = (float*)(S->d + al256(nd) + al256(nb));
+    }
+    hipLaunchKernelGGL(k_box_decode, dim3((n * k + 255) / 256), dim3(256), 0, st, dd, db, n, k, weights[0], weights[1], weights[2], weights[3], dout);
+    HIP_TRY(ctx, hipGetLastError());
+    if (!on_device) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        HIP_TRY(ctx, hipMemcpyAsync(S->h, dout, nd, hipMemcpyDeviceToHost, st)); HIP_TRY(ctx, hipStreamSynchronize(st));
+        memcpy(out, S->h, nd);
+    }
+    return VIDO_OK;
+}
+
+}  // extern "C"

@@ -403,6 +403,42 @@ def ba_optimize(ctx, k, rank=0, world=1, shard=None, allreduce=None):
                 ms_solve_loop=r.ms_solve_loop, ms_linearize_kernel=r.ms_linearize_kernel)
 
 
+class NetOps:
+    """The reference's native network ops, same names and argument meaning:
+    FunctionCorrelation (flow_net/src/correlation/correlation.py:339), layers.ROIAlign / layers.nms
+    (maskrcnn_benchmark/layers), BoxCoder.decode (modeling/box_coder.py:52).  numpy in / numpy out (host mode)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def FunctionCorrelation(self, tensorFirst, tensorSecond, intStride):
+        a = np.ascontiguousarray(tensorFirst, np.float32); b = np.ascontiguousarray(tensorSecond, np.float32)
+        B, Cc, H, W = a.shape
+        out = np.empty((B, 49, (H + intStride - 1) // intStride, (W + intStride - 1) // intStride), np.float32)
+        self.ctx._check(self.ctx.lib.vido_correlation(self.ctx.h, _ptr(a), _ptr(b), B, Cc, H, W, intStride, _ptr(out), 0))
+        return out
+
+    def roi_align(self, input, rois, output_size, spatial_scale, sampling_ratio):
+        f = np.ascontiguousarray(input, np.float32); r = np.ascontiguousarray(rois, np.float32).reshape(-1, 5)
+        B, Cc, H, W = f.shape; ph, pw = output_size
+        out = np.empty((len(r), Cc, ph, pw), np.float32)
+        self.ctx._check(self.ctx.lib.vido_roi_align(self.ctx.h, _ptr(f), B, Cc, H, W, _ptr(r), len(r), C.c_float(spatial_scale), ph, pw,
+                                                    sampling_ratio, _ptr(out), 0))
+        return out
+
+    def nms(self, boxes, scores, nms_thresh):
+        b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 4); s = np.ascontiguousarray(scores, np.float32)
+        keep = np.empty(max(len(b), 1), np.int32); n = C.c_int32()
+        self.ctx._check(self.ctx.lib.vido_nms(self.ctx.h, _ptr(b), _ptr(s), len(b), C.c_float(nms_thresh), _ptr(keep), C.byref(n), 0))
+        return keep[:n.value].astype(np.int64)
+
+    def box_decode(self, rel_codes, boxes, weights=(1.0, 1.0, 1.0, 1.0)):
+        d = np.ascontiguousarray(rel_codes, np.float32); b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 4)
+        w = (C.c_float * 4)(*weights); out = np.empty_like(d)
+        self.ctx._check(self.ctx.lib.vido_box_decode(self.ctx.h, _ptr(d), _ptr(b), len(b), d.shape[1] // 4, w, _ptr(out), 0))
+        return out
+
+
 class ORBextractor:
     """Mirror of VIDO_SLAM::ORBextractor (vido_slam/include/ORBextractor.h:39-49): construct with the five
     ctor arguments, call with a CV_8UC1 image, get keypoints + 32-byte descriptors."""
