@@ -18,6 +18,7 @@ struct TrackState {
     float *d_okeys = nullptr, *d_ocorr = nullptr, *d_odepth = nullptr, *d_oflow = nullptr;
     float* d_tmpf = nullptr; int32_t* d_tmpi = nullptr; size_t tmp_cap = 0;       // scratch for gathers
     int32_t* h_cnt = nullptr;
+    char* h_stage = nullptr; size_t stage_cap = 0;
 };
 
 // ---- kernels -------------------------------------------------------------------------------------
@@ -224,7 +225,7 @@ void track_state_destroy(vido_ctx* ctx)
     if (!T) return;
     hipFree(T->d_depth); hipFree(T->d_flow); hipFree(T->d_mask); hipFree(T->d_kps); hipFree(T->d_sidx); hipFree(T->d_scorr); hipFree(T->d_sflow);
     hipFree(T->d_sdepth); hipFree(T->d_nstat); hipFree(T->d_nobj); hipFree(T->d_okeys); hipFree(T->d_ocorr); hipFree(T->d_odepth); hipFree(T->d_olabel);
-    hipFree(T->d_oflow); hipFree(T->d_tmpf); hipFree(T->d_tmpi); hipHostFree(T->h_cnt);
+    hipFree(T->d_oflow); hipFree(T->d_tmpf); hipFree(T->d_tmpi); hipHostFree(T->h_cnt); hipHostFree(T->h_stage);
     delete T; ctx->trk = nullptr;
 }
 
@@ -299,10 +300,19 @@ int vido_frame_features(vido_ctx* ctx, int slot0, int n_frames, const vido_keypo
         if (no > out->max_obj) return vido_set_error(ctx, VIDO_E_CAPACITY, "frame_features: %d object samples > max_obj %d", no, out->max_obj);
         max_ns = std::max(max_ns, ns); max_no = std::max(max_no, no);
     }
-    // one strided copy per list (rows = frames, width = longest list) instead of one copy per frame and list
+    // one strided copy per list (rows = frames, width = longest list) into the pinned stage, then row memcpys
+    // into the caller's (pageable) arrays — nine device copies per call instead of nine per frame
+    const size_t need = (size_t)n_frames * ((size_t)max_ns * 24 + (size_t)max_no * 32) + 4096;
+    if (need > T->stage_cap) {
+        if (T->h_stage) HIP_TRY(ctx, hipHostFree(T->h_stage));
+        T->stage_cap = need + need / 2; HIP_TRY(ctx, hipHostMalloc((void**)&T->h_stage, T->stage_cap));
+    }
+    struct Seg { void* dst; size_t dpitch; char* stage; size_t el; int width; };
+    std::vector<Seg> segs; char* cur = T->h_stage;
     auto copy2d = [&](void* dst, size_t dpitch_el, const void* src, size_t spitch_el, size_t el, int width_el) -> int {
         if (width_el <= 0) return VIDO_OK;
-        HIP_TRY(ctx, hipMemcpy2DAsync(dst, dpitch_el * el, src, spitch_el * el, (size_t)width_el * el, n_frames, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpy2DAsync(cur, (size_t)width_el * el, src, spitch_el * el, (size_t)width_el * el, n_frames, hipMemcpyDeviceToHost, st));
+        segs.push_back(Seg{dst, dpitch_el * el, cur, el, width_el}); cur += (size_t)n_frames * width_el * el;
         return VIDO_OK;
     };
     if ((rc = copy2d(out->stat_idx, out->max_stat, T->d_sidx, T->max_kp, 4, max_ns))) return rc;
@@ -315,6 +325,11 @@ int vido_frame_features(vido_ctx* ctx, int slot0, int n_frames, const vido_keypo
     if ((rc = copy2d(out->obj_label, out->max_obj, T->d_olabel, T->max_obj, 4, max_no))) return rc;
     if ((rc = copy2d(out->obj_flow, out->max_obj, T->d_oflow, T->max_obj, 8, max_no))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (const Seg& g : segs)
+        for (int f = 0; f < n_frames; f++) {
+            const int cnt = (g.dst == out->stat_idx || g.dst == out->stat_corr || g.dst == out->stat_flow || g.dst == out->stat_depth) ? out->n_stat[f] : out->n_obj[f];
+            memcpy((char*)g.dst + (size_t)f * g.dpitch, g.stage + (size_t)f * g.width * g.el, (size_t)cnt * g.el);
+        }
     return VIDO_OK;
 }
 

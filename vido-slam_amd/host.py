@@ -129,8 +129,9 @@ class Context:
         self._check(self.lib.vido_orb_extract(self.h, _ptr(gray), w, w, h, _ptr(kps), self.max_kp, C.byref(n), _ptr(desc)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
-    def orb_extract_batch(self, imgs, want_desc=True):
-        """imgs: (n,h,w) u8 numpy array (host) or a (device_ptr, n, h, w, frame_stride, row_stride) tuple."""
+    def orb_extract_batch(self, imgs, want_desc=True, reuse=False):
+        """imgs: (n,h,w) u8 numpy array (host) or a (device_ptr, n, h, w, frame_stride, row_stride) tuple.
+        reuse=True hands back the same output arrays on every call (no 15 MB allocation per batch)."""
         if isinstance(imgs, tuple):
             ptr, n, h, w, fstride, rstride = imgs
             on_dev = 1
@@ -138,9 +139,15 @@ class Context:
             imgs = np.ascontiguousarray(imgs, np.uint8)
             n, h, w = imgs.shape
             ptr, fstride, rstride, on_dev = imgs.ctypes.data, h * w, w, 0
-        kps = np.zeros((n, self.max_kp), KP_DTYPE)
-        desc = np.zeros((n, self.max_kp, 32), np.uint8) if want_desc else None
-        cnt = np.zeros(n, np.int32)
+        key = (n, bool(want_desc))
+        if reuse and getattr(self, "_orb_out", {}).get(key) is not None:
+            kps, desc, cnt = self._orb_out[key]
+        else:
+            kps = np.zeros((n, self.max_kp), KP_DTYPE)
+            desc = np.zeros((n, self.max_kp, 32), np.uint8) if want_desc else None
+            cnt = np.zeros(n, np.int32)
+            if reuse:
+                self._orb_out = getattr(self, "_orb_out", {}); self._orb_out[key] = (kps, desc, cnt)
         self._check(self.lib.vido_orb_extract_batch(self.h, C.c_void_p(ptr), on_dev, n, fstride, rstride, w, h, _ptr(kps), self.max_kp,
                                                     _ptr(cnt), _ptr(desc) if want_desc else None))
         return kps, desc, cnt
@@ -208,15 +215,19 @@ class FrameFeatures:
         n = depth.shape[0] if depth.ndim == 3 else 1
         self.ctx._check(self.ctx.lib.vido_frame_upload(self.ctx.h, slot0, n, _ptr(depth), _ptr(flow), _ptr(mask), 0, C.byref(self.p)))
 
-    def features(self, slot0, kps, n_kps):
-        """kps: (n, max_kp) KP_DTYPE, n_kps: (n,) -> dict of per-frame lists."""
+    def features(self, slot0, kps, n_kps, reuse=False):
+        """kps: (n, max_kp) KP_DTYPE, n_kps: (n,) -> dict of per-frame lists (reuse=True: same arrays every call)."""
         kps = np.ascontiguousarray(kps); n_kps = np.ascontiguousarray(n_kps, np.int32)
         n, max_kp = kps.shape
         max_obj = ((self.ctx.cfg.width + 3) // 4) * ((self.ctx.cfg.height + 3) // 4)
-        o = dict(n_stat=np.zeros(n, np.int32), stat_idx=np.zeros((n, max_kp), np.int32), stat_corr=np.zeros((n, max_kp, 2), np.float32),
+        o = getattr(self, "_out", {}).get((n, max_kp)) if reuse else None
+        if o is None:
+          o = dict(n_stat=np.zeros(n, np.int32), stat_idx=np.zeros((n, max_kp), np.int32), stat_corr=np.zeros((n, max_kp, 2), np.float32),
                  stat_flow=np.zeros((n, max_kp, 2), np.float32), stat_depth=np.zeros((n, max_kp), np.float32),
                  n_obj=np.zeros(n, np.int32), obj_keys=np.zeros((n, max_obj, 2), np.float32), obj_corr=np.zeros((n, max_obj, 2), np.float32),
                  obj_depth=np.zeros((n, max_obj), np.float32), obj_label=np.zeros((n, max_obj), np.int32), obj_flow=np.zeros((n, max_obj, 2), np.float32))
+          if reuse:
+            self._out = getattr(self, "_out", {}); self._out[(n, max_kp)] = o
         L = FrameLists(max_kp, max_obj, *[o[k].ctypes.data for k in ("n_stat", "stat_idx", "stat_corr", "stat_flow", "stat_depth",
                                                                       "n_obj", "obj_keys", "obj_corr", "obj_depth", "obj_label", "obj_flow")])
         self.ctx._check(self.ctx.lib.vido_frame_features(self.ctx.h, slot0, n, _ptr(kps), _ptr(n_kps), max_kp, C.byref(self.p), C.byref(L)))
