@@ -44,6 +44,20 @@
 __constant__ int c_umax[HALF_PATCH + 1];
 __constant__ signed char c_pattern[256 * 4];
 
+// XCD-aware (tile, frame) assignment for grids of (tiles, frames): workgroup b lands on XCD b % 8 (observed
+// dispatch order, MI355X_MICROARCH.md), so consecutive tiles of ONE frame would be spread over the 8 private L2s
+// and every halo line would be fetched from the fabric up to 8 times.  With frames % 8 == 0 all tiles of a
+// frame are steered to one XCD instead (pure performance remap, any placement stays correct).
+__device__ __forceinline__ void xcd_tile_frame(int& tile, int& frame)
+{
+    const int nx = gridDim.x, ny = gridDim.y;
+    tile = blockIdx.x; frame = blockIdx.y;
+    if ((ny & 7) == 0) {
+        const int lin = blockIdx.y * nx + blockIdx.x, xcd = lin & 7, j = lin >> 3;
+        frame = xcd + 8 * (j / nx); tile = j % nx;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: bilinear downscale of level l-1 into level l (OpenCV INTER_LINEAR u8 fixed-point semantics:
 // 11-bit coefficients; (b0*(r0>>4))>>16 + (b1*(r1>>4))>>16 + 2 >> 2).  4 output pixels per thread.
@@ -153,7 +167,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     uint16_t* corners = cand + lds_ncand;
     uint32_t* listA = (uint32_t*)(corners + lds_ncand);
     uint32_t* listB = listA + VIDO_CELL_CAP;
-    const int cell = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    int cell, f; xcd_tile_frame(cell, f);
+    const int lane = threadIdx.x;
     const CellDesc c = cells[cell];
     const int pitch = P.pitch[c.level];
     const uint8_t* img = pyr + (size_t)f * slab + P.off[c.level];
@@ -300,10 +315,11 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ pyr, 
 {
     __shared__ uint8_t in[22][72];
     __shared__ uint16_t hb[22][64];
-    const BlurTile t = tiles[blockIdx.x];
+    int ti, fr; xcd_tile_frame(ti, fr);
+    const BlurTile t = tiles[ti];
     const int w = P.w[t.level], h = P.h[t.level], pitch = P.pitch[t.level];
-    const uint8_t* img = pyr + (size_t)blockIdx.y * slab + P.off[t.level];
-    uint8_t* out = blur + (size_t)blockIdx.y * slab + P.off[t.level];
+    const uint8_t* img = pyr + (size_t)fr * slab + P.off[t.level];
+    uint8_t* out = blur + (size_t)fr * slab + P.off[t.level];
     const int tid = threadIdx.x, x0 = t.tx * 64, y0 = t.ty * 16;
     for (int i = tid; i < 22 * 70; i += 256) {
         const int r = i / 70, cx = i - r * 70;
@@ -350,7 +366,10 @@ __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict_
                                                       const uint2* __restrict__ kps, int n_kp, int with_desc,
                                                       float* __restrict__ angle_out, uint8_t* __restrict__ desc_out)
 {
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // XCD-aware: each of the 8 XCDs (block b -> XCD b % 8) walks one contiguous eighth of the keypoint list, i.e.
+    // whole frames, so the patch / pattern gathers of a frame stay in one private L2
+    const int chunk = gridDim.x >> 3, blk = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int k = blk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (k >= n_kp) return;
     const uint2 kp = kps[k];
     const int x = kp.x & 0xfff, y = (kp.x >> 12) & 0xfff, level = kp.x >> 24, f = kp.y;
@@ -796,7 +815,7 @@ static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, si
     const int with_desc = ctx->cfg.compute_descriptors ? 1 : 0;
     if (nk > 0) {
         HIP_TRY(ctx, hipMemcpyAsync(S->d_kp, S->h_kp, nk * sizeof(uint2), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_orient_brief, dim3((unsigned)((nk + 3) / 4)), dim3(256), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_kp, (int)nk,
+        hipLaunchKernelGGL(k_orient_brief, dim3((unsigned)((((nk + 3) / 4) + 7) & ~(size_t)7)), dim3(256), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_kp, (int)nk,
                            with_desc, S->d_angle, S->d_desc);
         HIP_TRY(ctx, hipMemcpyAsync(S->h_angle, S->d_angle, nk * sizeof(float), hipMemcpyDeviceToHost, st));
         if (with_desc) HIP_TRY(ctx, hipMemcpyAsync(S->h_desc, S->d_desc, nk * 32, hipMemcpyDeviceToHost, st));
