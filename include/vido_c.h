@@ -215,6 +215,14 @@ int vido_nms(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, int n,
 int vido_box_decode(vido_ctx* ctx, const float* deltas, const float* boxes, int n, int k, const float weights[4],
                     float* out, int on_device);
 
+/* ---- Initial model: seeded P3P-RANSAC (Tracking::GetInitModelCam / GetInitModelObj, Tracking.cc:1965-1970, 2068-2073:
+ * cv::solvePnPRansac(pre_3d, cur_2d, K, 0, ..., 500, 0.4, 0.98, inliers, SOLVEPNP_P3P)).  pts3d [n*3] f32 (previous frame,
+ * world), pts2d [n*2] f32 (current keypoints); T_out row-major 4x4 world->camera; inlier_mask[n] may be NULL.
+ * All max_iters hypotheses are scored in parallel; OpenCV's adaptive early stop is replayed on the counts. */
+int vido_pnp_ransac(vido_ctx* ctx, const float* pts3d, const float* pts2d, int n, double fx, double fy, double cx, double cy,
+                    int max_iters, double reproj_err, double confidence, uint64_t seed, double T_out[16], uint8_t* inlier_mask,
+                    int32_t* n_inliers);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,176 @@
+/* vido_slam.h — C++ facade with the reference's class surface (namespace VIDO_SLAM) over the C-ABI of vido_c.h.
+ * Class / method names, argument order and meaning follow the reference headers so that the offline driver
+ * (vido_slam/demo/run_vido_slam.cc:67-137) ports by changing includes only:
+ *   System      vido_slam/include/System.h:72-114        Init, TrackRGBD, SaveResultsIJRR2020
+ *   Tracking    vido_slam/include/Tracking.h:63-114       GrabImageRGBD, Track, Initialization, GetInitModelCam/Obj,
+ *                                                         GetSceneFlowObj, DynObjTracking, RenewFrameInfo, UpdateMask,
+ *                                                         GetStaticTrack, GetDynamicTrackNew
+ *   Frame       vido_slam/include/Frame.h                 RGB-D constructor + the public per-frame lists
+ *   Map         vido_slam/include/Map.h:20-104
+ *   Optimizer   vido_slam/include/Optimizer.h:22-38       static PoseOptimization*, Partial/FullBatchOptimization
+ *   ORBextractor vido_slam/include/ORBextractor.h:33-104
+ * Out of scope here: viewer, cvplot, IMU/VIO overloads, GT metrics.  The heavy lifting (ORB, frame
+ * lists, LM optimisers, BA) runs on the GPU through vido_c.h; this layer is host orchestration only and has no
+ * CPU fallback for those stages. */
+#ifndef VIDO_SLAM_FACADE_H
+#define VIDO_SLAM_FACADE_H
+#if defined(__has_include)
+#if __has_include(<opencv2/core.hpp>) && !defined(VIDO_FORCE_CV_COMPAT)
+#include <opencv2/core.hpp>
+#else
+#include "cv_compat.h"
+#endif
+#else
+#include "cv_compat.h"
+#endif
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+#include "../vido_c.h"
+
+namespace VIDO_SLAM {
+
+class System; class Tracking; class Map; class Frame;
+
+class ORBextractor {
+public:
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+    ~ORBextractor();
+    /* image: CV_8UC1; mask is ignored as in the reference (ORBextractor.cc:1034). */
+    void operator()(const cv::Mat& image, const cv::Mat& mask, std::vector<cv::KeyPoint>& keypoints, cv::Mat& descriptors);
+    int GetLevels() const { return nlevels; }
+    float GetScaleFactor() const { return scaleFactor; }
+    std::vector<float> GetScaleFactors() const { return mvScaleFactor; }
+    vido_ctx* context(int width, int height);          /* lazily created for the first image size seen */
+    int nfeatures; float scaleFactor; int nlevels, iniThFAST, minThFAST;
+private:
+    std::vector<float> mvScaleFactor;
+    vido_ctx* ctx_ = nullptr; int w_ = 0, h_ = 0;
+};
+
+class Frame {
+public:
+    Frame() {}
+    /* RGB-D constructor, Frame.cc:36-241 (UseSampleFea == 0). */
+    Frame(const cv::Mat& imGray, const cv::Mat& imDepth, const cv::Mat& imFlow, const cv::Mat& maskSEM, const double& timeStamp,
+          ORBextractor* extractor, cv::Mat& K, cv::Mat& distCoef, const float& bf, const float& thDepth, const float& thDepthObj, const int& UseSampleFea);
+    void SetPose(cv::Mat Tcw);
+    cv::Mat GetRotationInverse() const { return mRwc.clone(); }
+    cv::Mat GetCameraCenter() const { return mOw.clone(); }
+    cv::Mat UnprojectStereoStat(const int& i, const bool& addnoise);      /* Frame.cc:706-737; addnoise is ignored */
+    cv::Mat UnprojectStereoObject(const int& i, const bool& addnoise);    /* Frame.cc:739-771 */
+    cv::Mat ObtainFlowDepthCamera(const int& i, const bool& addnoise);    /* Frame.cc:833-858: (flow_x, flow_y, depth) */
+    cv::Mat ObtainFlowDepthObject(const int& i, const bool& addnoise);    /* Frame.cc:860-886 */
+
+    static long unsigned int nNextId;
+    long unsigned int mnId = 0; double mTimeStamp = 0;
+    float fx = 0, fy = 0, cx = 0, cy = 0, invfx = 0, invfy = 0, mbf = 0, mThDepth = 0, mThDepthObj = 0;
+    cv::Mat mK, mDistCoef, mTcw, mRcw, mtcw, mRwc, mOw, mInitModel;
+    int N = 0, N_s = 0, N_s_tmp = 0;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn; cv::Mat mDescriptors;
+    std::vector<cv::KeyPoint> mvStatKeysTmp, mvCorres, mvStatKeys; std::vector<cv::Point2f> mvFlowNext;
+    std::vector<float> mvStatDepthTmp, mvStatDepth; std::vector<cv::Mat> mvStat3DPointTmp;
+    std::vector<cv::KeyPoint> mvObjKeys, mvObjCorres; std::vector<cv::Point2f> mvObjFlowNext; std::vector<float> mvObjDepth;
+    std::vector<cv::Mat> mvObj3DPoint; std::vector<int> vSemObjLabel, vObjLabel;
+    std::vector<cv::Point3f> vFlow_3d;
+    std::vector<int> nModLabel, nSemPosition, nStaInlierID, nDynInlierID; std::vector<bool> bObjStat;
+    std::vector<cv::Mat> vObjMod, vObjCentre3D; std::vector<cv::Point2f> vSpeed;
+    std::vector<std::vector<int> > vnObjID, vnObjInlierID;
+    Frame *mpPrevFrame = nullptr, *mpNextFrame = nullptr;
+};
+
+class Map {
+public:
+    Map() {}
+    void reset();
+    void AddFrame(Frame* f) { vpFrames.push_back(f); }
+    int GetFramesInMapSize() { return (int)vpFrames.size(); }
+    std::vector<std::vector<cv::KeyPoint> > vpFeatSta, vpFeatDyn;
+    std::vector<std::vector<float> > vfDepSta, vfDepDyn;
+    std::vector<std::vector<cv::Mat> > vp3DPointSta, vp3DPointDyn;
+    std::vector<std::vector<int> > vnAssoSta, vnAssoDyn, vnFeatLabel;
+    std::vector<std::vector<std::pair<int, int> > > TrackletSta, TrackletDyn; std::vector<int> nObjID;
+    std::vector<cv::Mat> vmCameraPose, vmCameraPose_RF, vmCameraPose_GT;
+    std::vector<std::vector<cv::Mat> > vmRigidCentre, vmRigidMotion, vmRigidMotion_RF;
+    std::vector<std::vector<int> > vnRMLabel, vnSMLabel; std::vector<std::vector<bool> > vbObjStat;
+    std::vector<float> fLBA_time; std::vector<std::vector<float> > vfAll_time;
+protected:
+    std::vector<Frame*> vpFrames;
+};
+
+class Optimizer {
+public:
+    static int PoseOptimizationNew(Frame* pCurFrame, Frame* pLastFrame, std::vector<int>& TemperalMatch);
+    static int PoseOptimizationFlow2Cam(Frame* pCurFrame, Frame* pLastFrame, std::vector<int>& TemperalMatch);
+    static cv::Mat PoseOptimizationObjMot(Frame* pCurFrame, Frame* pLastFrame, const std::vector<int>& ObjId, std::vector<int>& InlierID);
+    static cv::Mat PoseOptimizationFlow2(Frame* pCurFrame, Frame* pLastFrame, const std::vector<int>& ObjId, std::vector<int>& InlierID);
+    static void FullBatchOptimization(Map* pMap, const cv::Mat Calib_K);
+    static void PartialBatchOptimization(Map* pMap, const cv::Mat Calib_K, const int WINDOW_SIZE);
+    static cv::Mat Get3DinWorld(const cv::KeyPoint& Feats2d, const float& Dpts, const cv::Mat& Calib_K, const cv::Mat& CameraPose);
+    static cv::Mat Get3DinCamera(const cv::KeyPoint& Feats2d, const float& Dpts, const cv::Mat& Calib_K);
+};
+
+class Converter {
+public:
+    static cv::Mat toInvMatrix(const cv::Mat& T);       /* Converter.cc:155-170: rigid inverse of a 4x4 CV_32F */
+};
+
+class Tracking {
+public:
+    Tracking(System* pSys, Map* pMap, const std::string& strSettingPath, const int sensor);
+    ~Tracking();
+    cv::Mat GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Mat& imFlow, const cv::Mat& maskSEM, const cv::Mat& mTcw_gt,
+                          const std::vector<std::vector<float> >& vObjPose_gt, const double& timestamp, cv::Mat& imTraj, const int& nImage);
+    void Track();
+    void Initialization();
+    void GetSceneFlowObj();
+    std::vector<std::vector<int> > DynObjTracking();
+    cv::Mat GetInitModelCam(const std::vector<int>& MatchId, std::vector<int>& MatchId_sub);
+    cv::Mat GetInitModelObj(const std::vector<int>& ObjId, std::vector<int>& ObjId_sub, const int objid);
+    std::vector<std::vector<std::pair<int, int> > > GetStaticTrack();
+    std::vector<std::vector<std::pair<int, int> > > GetDynamicTrackNew();
+    void RenewFrameInfo(const std::vector<int>& TM_sta);
+    void UpdateMask();
+
+    enum eTrackingState { NO_IMAGES_YET = 0, NOT_INITIALIZED = 1, OK = 2 };
+    enum eDataState { OMD = 1, KITTI = 2, KAIST = 3 };
+    eTrackingState mState; eDataState mTestData; int mSensor;
+    bool bJoint;                      /* never initialised in the reference; explicit here, default true */
+    int f_id, max_id, StopFrame;
+    Frame *mpCurrentFrame = nullptr, *mpLastFrame = nullptr;
+    cv::Mat mImGray, mImGrayLast, mDepthMap, mFlowMap, mFlowMapLast, mSegMap, mSegMapLast, mK, mDistCoef, mVelocity;
+    float mbf, mThDepth, mThDepthObj, mDepthMapFactor, mScale, fSFMgThres, fSFDsThres;
+    int nMaxTrackPointBG, nMaxTrackPointOBJ, nWINDOW_SIZE, nOVERLAP_SIZE, nUseSampleFea; bool mbRGB;
+    std::vector<int> TemperalMatch, TemperalMatch_subset;
+    std::vector<cv::KeyPoint> mvTmpObjKeys, mvTmpObjCorres; std::vector<float> mvTmpObjDepth; std::vector<int> mvTmpSemObjLabel; std::vector<cv::Point2f> mvTmpObjFlowNext;
+    std::vector<float> all_timing;
+    unsigned ransac_seed;             /* solvePnPRansac uses OpenCV's global RNG; seeded explicitly here */
+    ORBextractor* mpORBextractorLeft = nullptr;
+protected:
+    System* mpSystem; Map* mpMap;
+    int slot_cur_ = 0;
+};
+
+class System {
+public:
+    enum eSensor { MONOCULAR = 0, STEREO = 1, RGBD = 2, IMU_RGBD = 3 };
+    System() {}
+    ~System();
+    void Init(const std::string& strSettingsFile, const eSensor sensor);
+    cv::Mat TrackRGBD(const cv::Mat& im, cv::Mat& depthmap, const cv::Mat& flowmap, const cv::Mat& masksem, const cv::Mat& mTcw_gt,
+                      const std::vector<std::vector<float> >& vObjPose_gt, const double& timestamp, cv::Mat& imTraj, const int& nImage);
+    void SaveResultsIJRR2020(const std::string& filename);
+    Map* GetMap() { return mpMap; }
+    Tracking* GetTracker() { return mpTracker; }
+private:
+    eSensor mSensor = RGBD; Map* mpMap = nullptr; Tracking* mpTracker = nullptr;
+};
+
+namespace detail {
+vido_ctx* Context();                                   /* the process-wide ctx of the live System (one System per process, as in the reference) */
+std::map<std::string, std::string> ParseSettings(const std::string& path);    /* OpenCV-YAML 1.0 `key: value` subset */
+}
+
+}  // namespace VIDO_SLAM
+#endif

@@ -310,3 +310,19 @@ def box_decode(deltas, boxes, weights):
     out = np.empty_like(deltas)
     lib().vo_box_decode(_p(deltas), _p(boxes), len(boxes), deltas.shape[1] // 4, _p(w), _p(out))
     return out
+
+
+# ---- P3P-RANSAC (pnp_oracle.c) -----------------------------------------------------------------------
+def pnp_ransac(pts3d, pts2d, K, max_iters=500, thr=0.4, conf=0.98, seed=1):
+    X = np.ascontiguousarray(pts3d, np.float32).reshape(-1, 3); x = np.ascontiguousarray(pts2d, np.float32).reshape(-1, 2)
+    T = np.zeros(16); mask = np.zeros(max(len(X), 1), np.uint8)
+    f = lib().vo_pnp_ransac
+    n = f(_p(X), _p(x), len(X), C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), max_iters, C.c_double(thr), C.c_double(conf),
+          C.c_uint64(seed), _p(T), _p(mask))
+    return T.reshape(4, 4), mask[:len(X)].astype(bool), n
+
+def p3p(P, j):
+    P = np.ascontiguousarray(P, np.float64).reshape(3, 3); j = np.ascontiguousarray(j, np.float64).reshape(3, 3)
+    R = np.zeros((4, 9)); t = np.zeros((4, 3))
+    n = lib().vo_p3p(_p(P), _p(j), _p(R), _p(t))
+    return [(R[k].reshape(3, 3), t[k]) for k in range(n)]

@@ -46,6 +46,7 @@ struct vido_ctx {
     struct HamState* ham = nullptr;
     struct PoseState* pose = nullptr;
     struct NetState* net = nullptr;
+    struct PnpState* pnp = nullptr;
 };
 
 int vido_set_error(vido_ctx* ctx, int code, const char* fmt, ...);
@@ -64,4 +65,5 @@ void ham_state_destroy(vido_ctx* ctx);
 void pose_state_destroy(vido_ctx* ctx);
 void ba_state_destroy(vido_ctx* ctx);
 void net_state_destroy(vido_ctx* ctx);
+void pnp_state_destroy(vido_ctx* ctx);
 void orb_state_destroy(vido_ctx* ctx);

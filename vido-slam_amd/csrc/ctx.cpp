@@ -82,6 +82,7 @@ void vido_destroy(vido_ctx* ctx)
     pose_state_destroy(ctx);
     ba_state_destroy(ctx);
     net_state_destroy(ctx);
+    pnp_state_destroy(ctx);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     delete ctx;

@@ -1,0 +1,226 @@
+// pnp.hip — seeded P3P-RANSAC on gfx950: the initial-model stage of the tracker.
+// Replaces the cv::solvePnPRansac(..., 500, 0.4, 0.98, SOLVEPNP_P3P) calls of Tracking::GetInitModelCam and
+// Tracking::GetInitModelObj (reference vido_slam/src/Tracking.cc:1965-1970, :2068-2073).  OpenCV runs the
+// hypotheses one after the other; here ALL max_iters hypotheses are evaluated at once — one workgroup per
+// hypothesis: lane 0 solves Grunert's P3P quartic for the sampled triple (FP64, Durand-Kerner), the 4th sample picks
+// among the up to four solutions, then the 256 threads count the inliers of the N correspondences with a DPP/LDS
+// reduction — and a single-thread epilogue replays OpenCV's sequential bookkeeping (best-so-far, adaptive
+// niters = log(1-conf)/log(1-(1-eps)^4)) over the per-iteration counts, so the outcome equals the sequential loop
+// run with the same per-iteration samples.  Samples come from a counter-based generator (splitmix64 of seed and
+// iteration index) instead of OpenCV's global RNG; the final EPnP refit is omitted (LM refinement follows).
+#include "common.hpp"
+#include <cfloat>
+
+__host__ __device__ inline uint64_t splitmix64(uint64_t& s)
+{
+    uint64_t z = (s += 0x9E3779B97F4A7C15ULL); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31);
+}
+__device__ void sample4(uint64_t seed, int it, int n, int idx[4])
+{
+    uint64_t s = seed ^ (0xD1B54A32D192ED03ULL * (uint64_t)(it + 1));
+    for (int k = 0; k < 4;) {
+        const int c = (int)(splitmix64(s) % (uint64_t)n); bool dup = false;
+        for (int j = 0; j < k; j++) if (idx[j] == c) dup = true;
+        if (!dup) idx[k++] = c;
+    }
+}
+__device__ int quartic_real_roots(const double* c, double* roots)
+{
+    if (fabs(c[4]) < 1e-300) return 0;
+    const double a3 = c[3] / c[4], a2 = c[2] / c[4], a1 = c[1] / c[4], a0 = c[0] / c[4];
+    double zr[4] = {1.0, 0.4, -0.65, -0.2755}, zi[4] = {0.0, 0.9, 0.72, -0.9602};
+    for (int it = 0; it < 100; it++) {
+        double maxd = 0;
+        for (int k = 0; k < 4; k++) {
+            double pr = 1, pi = 0, tr, ti;
+            tr = pr * zr[k] - pi * zi[k] + a3; ti = pr * zi[k] + pi * zr[k]; pr = tr; pi = ti;
+            tr = pr * zr[k] - pi * zi[k] + a2; ti = pr * zi[k] + pi * zr[k]; pr = tr; pi = ti;
+            tr = pr * zr[k] - pi * zi[k] + a1; ti = pr * zi[k] + pi * zr[k]; pr = tr; pi = ti;
+            tr = pr * zr[k] - pi * zi[k] + a0; ti = pr * zi[k] + pi * zr[k]; pr = tr; pi = ti;
+            double qr = 1, qi = 0;
+            for (int j = 0; j < 4; j++) if (j != k) { const double dr = zr[k] - zr[j], di = zi[k] - zi[j]; tr = qr * dr - qi * di; ti = qr * di + qi * dr; qr = tr; qi = ti; }
+            const double den = qr * qr + qi * qi;
+            if (den < 1e-300) continue;
+            const double dr = (pr * qr + pi * qi) / den, di = (pi * qr - pr * qi) / den;
+            zr[k] -= dr; zi[k] -= di;
+            if (fabs(dr) + fabs(di) > maxd) maxd = fabs(dr) + fabs(di);
+        }
+        if (maxd < 1e-14) break;
+    }
+    int n = 0;
+    for (int k = 0; k < 4; k++) if (fabs(zi[k]) < 1e-7 * (1.0 + fabs(zr[k]))) {
+        double v = zr[k];
+        for (int t = 0; t < 2; t++) {
+            const double p = (((c[4] * v + c[3]) * v + c[2]) * v + c[1]) * v + c[0], dp = ((4 * c[4] * v + 3 * c[3]) * v + 2 * c[2]) * v + c[1];
+            if (fabs(dp) > 1e-300) v -= p / dp;
+        }
+        roots[n++] = v;
+    }
+    return n;
+}
+__device__ inline void cross3(const double* a, const double* b, double* c) { c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0]; }
+__device__ inline double norm3(const double* a) { return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+
+// Grunert P3P: with s2 = u s1, s3 = v s1 the three cosine-law equations give u = N(v)/D(v) and the quartic
+// D^2 + N^2 - 2 cos(gamma) N D - (c^2/b^2) Q D^2 = 0, Q = 1 + v^2 - 2 v cos(beta); poses from triangle alignment.
+__device__ int p3p(const double P[3][3], const double j[3][3], double R[4][9], double t[4][3])
+{
+    double d[3];
+    for (int k = 0; k < 3; k++) d[k] = P[1][k] - P[2][k]; const double a2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    for (int k = 0; k < 3; k++) d[k] = P[0][k] - P[2][k]; const double b2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    for (int k = 0; k < 3; k++) d[k] = P[0][k] - P[1][k]; const double c2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    if (a2 < 1e-20 || b2 < 1e-20 || c2 < 1e-20) return 0;
+    const double ca = j[1][0] * j[2][0] + j[1][1] * j[2][1] + j[1][2] * j[2][2];
+    const double cb = j[0][0] * j[2][0] + j[0][1] * j[2][1] + j[0][2] * j[2][2];
+    const double cg = j[0][0] * j[1][0] + j[0][1] * j[1][1] + j[0][2] * j[1][2];
+    const double K = (a2 - c2) / b2, M = c2 / b2;
+    const double N[3] = {1 + K, -2 * K * cb, K - 1}, D[2] = {2 * cg, -2 * ca}, Q[3] = {1, -2 * cb, 1};
+    const double D2[3] = {D[0] * D[0], 2 * D[0] * D[1], D[1] * D[1]};
+    double c[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; i++) c[i] += D2[i];
+    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) c[i + k] += N[i] * N[k];
+    for (int i = 0; i < 3; i++) for (int k = 0; k < 2; k++) c[i + k] -= 2 * cg * N[i] * D[k];
+    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) c[i + k] -= M * Q[i] * D2[k];
+    double roots[4]; const int nr = quartic_real_roots(c, roots);
+    int ns = 0;
+    for (int r = 0; r < nr; r++) {
+        const double v = roots[r];
+        if (!(v > 0)) continue;
+        const double den = D[0] + D[1] * v;
+        if (fabs(den) < 1e-12) continue;
+        const double u = (N[0] + N[1] * v + N[2] * v * v) / den;
+        if (!(u > 0)) continue;
+        const double q = 1 + v * v - 2 * v * cb;
+        if (!(q > 0)) continue;
+        const double s1 = sqrt(b2 / q), s2 = u * s1, s3 = v * s1;
+        double C[3][3];
+        for (int k = 0; k < 3; k++) { C[0][k] = s1 * j[0][k]; C[1][k] = s2 * j[1][k]; C[2][k] = s3 * j[2][k]; }
+        double p1[3], p2[3], e1[3], e2[3], e3[3], f1[3], f2[3], f3[3], q1[3], q2[3];
+        for (int k = 0; k < 3; k++) { p1[k] = P[1][k] - P[0][k]; p2[k] = P[2][k] - P[0][k]; q1[k] = C[1][k] - C[0][k]; q2[k] = C[2][k] - C[0][k]; }
+        const double n1 = norm3(p1), m1 = norm3(q1);
+        if (n1 < 1e-12 || m1 < 1e-12) continue;
+        for (int k = 0; k < 3; k++) { e1[k] = p1[k] / n1; f1[k] = q1[k] / m1; }
+        cross3(e1, p2, e3); cross3(f1, q2, f3);
+        const double n3 = norm3(e3), m3 = norm3(f3);
+        if (n3 < 1e-12 || m3 < 1e-12) continue;
+        for (int k = 0; k < 3; k++) { e3[k] /= n3; f3[k] /= m3; }
+        cross3(e3, e1, e2); cross3(f3, f1, f2);
+        for (int rr = 0; rr < 3; rr++) for (int cc = 0; cc < 3; cc++) R[ns][rr * 3 + cc] = f1[rr] * e1[cc] + f2[rr] * e2[cc] + f3[rr] * e3[cc];
+        for (int rr = 0; rr < 3; rr++) t[ns][rr] = C[0][rr] - (R[ns][rr * 3] * P[0][0] + R[ns][rr * 3 + 1] * P[0][1] + R[ns][rr * 3 + 2] * P[0][2]);
+        ns++;
+    }
+    return ns;
+}
+__device__ inline double reproj2(const double* R, const double* t, const float* X, const float* x, double fx, double fy, double cx, double cy)
+{
+    const double xc = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0], yc = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1], zc = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+    if (!(zc > 1e-9)) return 1e30;
+    const double du = fx * xc / zc + cx - x[0], dv = fy * yc / zc + cy - x[1];
+    return du * du + dv * dv;
+}
+
+// one workgroup per hypothesis
+__global__ __launch_bounds__(256) void k_pnp_hypotheses(const float* __restrict__ X, const float* __restrict__ x, int n, double fx, double fy, double cx, double cy,
+                                                        uint64_t seed, double thr2, double* __restrict__ models /*[iters][12]*/, int* __restrict__ counts)
+{
+    __shared__ double sR[9], st[3]; __shared__ int has; __shared__ int wcnt[4];
+    const int it = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int idx[4]; sample4(seed, it, n, idx);
+        double P[3][3], j[3][3];
+        for (int k = 0; k < 3; k++) {
+            for (int a = 0; a < 3; a++) P[k][a] = X[3 * idx[k] + a];
+            const double bx = (x[2 * idx[k]] - cx) / fx, by = (x[2 * idx[k] + 1] - cy) / fy, nn = sqrt(bx * bx + by * by + 1);
+            j[k][0] = bx / nn; j[k][1] = by / nn; j[k][2] = 1 / nn;
+        }
+        double Rs[4][9], ts[4][3];
+        const int ns = p3p(P, j, Rs, ts);
+        int best = -1; double be = 1e300;
+        for (int s = 0; s < ns; s++) { const double e = reproj2(Rs[s], ts[s], X + 3 * idx[3], x + 2 * idx[3], fx, fy, cx, cy); if (e < be) { be = e; best = s; } }
+        has = best >= 0;
+        if (best >= 0) { for (int k = 0; k < 9; k++) sR[k] = Rs[best][k]; for (int k = 0; k < 3; k++) st[k] = ts[best][k]; }
+    }
+    __syncthreads();
+    int cnt = 0;
+    if (has) {
+        double R[9], t[3];
+        for (int k = 0; k < 9; k++) R[k] = sR[k];
+        for (int k = 0; k < 3; k++) t[k] = st[k];
+        for (int i = threadIdx.x; i < n; i += 256) cnt += reproj2(R, t, X + 3 * i, x + 2 * i, fx, fy, cx, cy) <= thr2;
+    }
+    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counts[it] = has ? wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3] : 0;
+        for (int k = 0; k < 9; k++) models[12 * it + k] = sR[k];
+        for (int k = 0; k < 3; k++) models[12 * it + 9 + k] = st[k];
+    }
+}
+
+__device__ int ransac_update_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = fmax(fmin(p, 1.), 0.); ep = fmax(fmin(ep, 1.), 0.);
+    double num = fmax(1. - p, DBL_MIN), denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num); denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)llrint(num / denom);
+}
+// sequential bookkeeping of cv::RANSAC over the precomputed hypotheses, then the inlier mask of the winner
+__global__ __launch_bounds__(256) void k_pnp_select(const float* __restrict__ X, const float* __restrict__ x, int n, double fx, double fy, double cx, double cy,
+                                                    int max_iters, double thr2, double conf, const double* __restrict__ models, const int* __restrict__ counts,
+                                                    double* __restrict__ T_out, unsigned char* __restrict__ mask, int* __restrict__ n_inl)
+{
+    __shared__ int sbest;
+    if (threadIdx.x == 0) {
+        int niters = max_iters, best_cnt = 0, best = -1;
+        for (int it = 0; it < niters; it++) {
+            const int cnt = counts[it];
+            if (cnt > max(best_cnt, 3)) { best_cnt = cnt; best = it; niters = ransac_update_iters(conf, (double)(n - cnt) / n, 4, niters); }
+        }
+        sbest = best;
+        for (int k = 0; k < 16; k++) T_out[k] = (k % 5 == 0) ? 1.0 : 0.0;
+        if (best >= 0) { for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T_out[r * 4 + c] = models[12 * best + r * 3 + c]; T_out[r * 4 + 3] = models[12 * best + 9 + r]; } }
+        *n_inl = best >= 0 ? best_cnt : 0;
+    }
+    __syncthreads();
+    const int best = sbest;
+    for (int i = threadIdx.x; i < n; i += 256) mask[i] = best >= 0 ? (unsigned char)(reproj2(models + 12 * best, models + 12 * best + 9, X + 3 * i, x + 2 * i, fx, fy, cx, cy) <= thr2) : 0;
+}
+
+struct PnpState { char* d = nullptr; char* h = nullptr; size_t cap = 0; };
+void pnp_state_destroy(vido_ctx* ctx) { PnpState* S = ctx->pnp; if (!S) return; hipFree(S->d); hipHostFree(S->h); delete S; ctx->pnp = nullptr; }
+
+extern "C" int vido_pnp_ransac(vido_ctx* ctx, const float* pts3d, const float* pts2d, int n, double fx, double fy, double cx, double cy,
+                               int max_iters, double reproj_err, double confidence, uint64_t seed, double T_out[16], uint8_t* inlier_mask, int32_t* n_inliers)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!T_out || !n_inliers || n < 0 || (n && (!pts3d || !pts2d)) || max_iters < 1 || max_iters > 65536) return vido_set_error(ctx, VIDO_E_INVALID, "pnp_ransac: bad arguments");
+    for (int k = 0; k < 16; k++) T_out[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    *n_inliers = 0;
+    if (inlier_mask && n) memset(inlier_mask, 0, n);
+    if (n < 4) return VIDO_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->pnp) ctx->pnp = new PnpState();
+    PnpState* S = ctx->pnp; hipStream_t st = ctx->stream;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_x3 = 0, o_x2 = o_x3 + al((size_t)n * 12), o_mod = o_x2 + al((size_t)n * 8), o_cnt = o_mod + al((size_t)max_iters * 96),
+                 o_T = o_cnt + al((size_t)max_iters * 4), o_mask = o_T + 256, o_n = o_mask + al(n), total = o_n + 256;
+    if (total > S->cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (S->d) { hipFree(S->d); hipHostFree(S->h); S->d = nullptr; S->h = nullptr; }
+        S->cap = total + total / 2; HIP_TRY(ctx, hipMalloc((void**)&S->d, S->cap)); HIP_TRY(ctx, hipHostMalloc((void**)&S->h, S->cap));
+    }
+    memcpy(S->h + o_x3, pts3d, (size_t)n * 12); memcpy(S->h + o_x2, pts2d, (size_t)n * 8);
+    HIP_TRY(ctx, hipMemcpyAsync(S->d, S->h, o_mod, hipMemcpyHostToDevice, st));
+    const float* dX = (const float*)(S->d + o_x3); const float* dx = (const float*)(S->d + o_x2);
+    hipLaunchKernelGGL(k_pnp_hypotheses, dim3(max_iters), dim3(256), 0, st, dX, dx, n, fx, fy, cx, cy, seed, reproj_err * reproj_err, (double*)(S->d + o_mod), (int*)(S->d + o_cnt));
+    hipLaunchKernelGGL(k_pnp_select, dim3(1), dim3(256), 0, st, dX, dx, n, fx, fy, cx, cy, max_iters, reproj_err * reproj_err, confidence,
+                       (const double*)(S->d + o_mod), (const int*)(S->d + o_cnt), (double*)(S->d + o_T), (unsigned char*)(S->d + o_mask), (int*)(S->d + o_n));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(S->h + o_T, S->d + o_T, total - o_T, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    memcpy(T_out, S->h + o_T, 128); *n_inliers = *(int*)(S->h + o_n);
+    if (inlier_mask) memcpy(inlier_mask, S->h + o_mask, n);
+    return VIDO_OK;
+}

@@ -414,6 +414,15 @@ def ba_optimize(ctx, k, rank=0, world=1, shard=None, allreduce=None):
                 ms_solve_loop=r.ms_solve_loop, ms_linearize_kernel=r.ms_linearize_kernel)
 
 
+def pnp_ransac(ctx, pts3d, pts2d, K, max_iters=500, reproj_err=0.4, confidence=0.98, seed=1):
+    """cv::solvePnPRansac(..., SOLVEPNP_P3P) as called by Tracking::GetInitModelCam/Obj (Tracking.cc:1965, 2068)."""
+    X = np.ascontiguousarray(pts3d, np.float32).reshape(-1, 3); x = np.ascontiguousarray(pts2d, np.float32).reshape(-1, 2)
+    T = np.zeros(16); mask = np.zeros(max(len(X), 1), np.uint8); n = C.c_int32()
+    ctx._check(ctx.lib.vido_pnp_ransac(ctx.h, _ptr(X), _ptr(x), len(X), C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]),
+                                       max_iters, C.c_double(reproj_err), C.c_double(confidence), C.c_uint64(seed), _ptr(T), _ptr(mask), C.byref(n)))
+    return T.reshape(4, 4), mask[:len(X)].astype(bool), n.value
+
+
 class NetOps:
     """The reference's native network ops, same names and argument meaning:
     FunctionCorrelation (flow_net/src/correlation/correlation.py:339), layers.ROIAlign / layers.nms
