@@ -35,5 +35,18 @@ def build(force=False, verbose=False):
     return LIB
 
 
+DRIVER = os.path.join(HERE, "run_vido_slam.bin")
+
+
+def build_driver(force=False):
+    """Offline driver (tools/run_vido_slam.cpp) against the in-tree library."""
+    src = os.path.join(HERE, "..", "tools", "run_vido_slam.cpp")
+    if not force and os.path.exists(DRIVER) and os.path.getmtime(DRIVER) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return DRIVER
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "-O2", "-std=c++17", "-x", "c++", src, "-o", DRIVER, "-L" + HERE, "-lvido_slam_hip", "-Wl,-rpath," + HERE, "-Wl,-rpath,$ORIGIN"])
+    return DRIVER
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

@@ -1,0 +1,816 @@
+// facade.cpp — host orchestration behind the reference's C++ class surface (include/vido_slam/vido_slam.h).
+// Follows, function by function, vido_slam/src/{System,Tracking,Frame,Optimizer,Converter}.cc of the reference; every
+// data-parallel stage is a call into the C-ABI (GPU), everything here is bookkeeping on a few thousand points.
+// Not reproduced (SURVEY.md §2 out of scope): viewer / imshow / plots, ground-truth metrics, IMU paths, the
+// time(NULL)-seeded depth noise of the addnoise=1 branches.
+#include "../../include/vido_slam/vido_slam.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+
+namespace VIDO_SLAM {
+
+// ---------------------------------------------------------------------------------------------------------------
+namespace detail {
+static vido_ctx* g_ctx = nullptr;
+static int g_slot = 0;                 // device slot holding the maps of the frame under construction
+static vido_track_params g_tp;
+vido_ctx* Context() { return g_ctx; }
+
+std::map<std::string, std::string> ParseSettings(const std::string& path)
+{
+    std::ifstream f(path.c_str());
+    if (!f.is_open()) throw std::runtime_error("Failed to open settings file at: " + path);
+    std::map<std::string, std::string> kv; std::string line;
+    while (std::getline(f, line)) {
+        const size_t h = line.find('#'); if (h != std::string::npos) line = line.substr(0, h);
+        if (line.empty() || line[0] == '%' || line.compare(0, 3, "---") == 0) continue;
+        const size_t c = line.find(':'); if (c == std::string::npos) continue;
+        std::string k = line.substr(0, c), v = line.substr(c + 1);
+        auto trim = [](std::string& s) { const char* ws = " \t\r\n\""; s.erase(0, s.find_first_not_of(ws)); const size_t e = s.find_last_not_of(ws); if (e == std::string::npos) s.clear(); else s.erase(e + 1); };
+        trim(k); trim(v);
+        if (!k.empty() && k.find(' ') == std::string::npos) kv[k] = v;
+    }
+    return kv;
+}
+static double num(const std::map<std::string, std::string>& kv, const char* key, double def = 0.0)
+{
+    auto it = kv.find(key); if (it == kv.end() || it->second.empty()) return def;
+    return atof(it->second.c_str());
+}
+static void check(int rc, const char* what)
+{
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + vido_last_error(g_ctx));
+}
+static void toRow16(const cv::Mat& T, double* o) { for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) o[r * 4 + c] = T.at<float>(r, c); }
+static cv::Mat fromRow16(const double* o) { cv::Mat T(4, 4, CV_32F); for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T.at<float>(r, c) = (float)o[r * 4 + c]; return T; }
+static cv::Mat vec3(float x, float y, float z) { cv::Mat m(3, 1, CV_32F); m.at<float>(0) = x; m.at<float>(1) = y; m.at<float>(2) = z; return m; }
+}  // namespace detail
+using namespace detail;
+
+cv::Mat Converter::toInvMatrix(const cv::Mat& T)      // Converter.cc:155-170
+{
+    cv::Mat Ti = cv::Mat::eye(4, 4, CV_32F);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ti.at<float>(r, c) = T.at<float>(c, r);
+    for (int r = 0; r < 3; r++) { double s = 0; for (int c = 0; c < 3; c++) s += (double)(-Ti.at<float>(r, c)) * T.at<float>(c, 3); Ti.at<float>(r, 3) = (float)s; }
+    return Ti;
+}
+
+// ---- ORBextractor -------------------------------------------------------------------------------------------------
+ORBextractor::ORBextractor(int nf, float sf, int nl, int ini, int mn) : nfeatures(nf), scaleFactor(sf), nlevels(nl), iniThFAST(ini), minThFAST(mn)
+{
+    mvScaleFactor.resize(nl); mvScaleFactor[0] = 1.0f;
+    for (int i = 1; i < nl; i++) mvScaleFactor[i] = mvScaleFactor[i - 1] * sf;
+}
+ORBextractor::~ORBextractor() { if (ctx_) { if (g_ctx == ctx_) g_ctx = nullptr; vido_destroy(ctx_); } }
+vido_ctx* ORBextractor::context(int width, int height)
+{
+    if (ctx_ && (width != w_ || height != h_)) throw std::runtime_error("ORBextractor: image size changed after the first frame");
+    if (!ctx_) {
+        vido_config cfg; vido_config_default(&cfg);
+        cfg.width = width; cfg.height = height; cfg.n_features = nfeatures; cfg.scale_factor = scaleFactor; cfg.n_levels = nlevels;
+        cfg.ini_th_fast = iniThFAST; cfg.min_th_fast = minThFAST; cfg.max_batch = 1;
+        if (const char* d = getenv("VIDO_DEVICE")) cfg.device = atoi(d);
+        if (vido_create(&cfg, &ctx_) != VIDO_OK) throw std::runtime_error(std::string("vido_create: ") + vido_last_error(nullptr));
+        w_ = width; h_ = height;
+        if (!g_ctx) g_ctx = ctx_;
+    }
+    return ctx_;
+}
+void ORBextractor::operator()(const cv::Mat& image, const cv::Mat&, std::vector<cv::KeyPoint>& keypoints, cv::Mat& descriptors)
+{
+    keypoints.clear();
+    if (image.empty()) return;
+    if (image.type() != CV_8UC1) throw std::runtime_error("ORBextractor: image must be CV_8UC1");
+    vido_ctx* c = context(image.cols, image.rows);
+    const int cap = 2 * nfeatures + 256; int n = 0;
+    std::vector<vido_keypoint> k(cap); cv::Mat desc(cap, 32, CV_8U);
+    if (vido_orb_extract(c, image.data, (int)image.step, image.cols, image.rows, k.data(), cap, &n, desc.data) != VIDO_OK) throw std::runtime_error(vido_last_error(c));
+    keypoints.resize(n);
+    for (int i = 0; i < n; i++) keypoints[i] = cv::KeyPoint(k[i].x, k[i].y, k[i].size, k[i].angle, k[i].response, k[i].octave);
+    descriptors = cv::Mat(n, 32, CV_8U);
+    for (int i = 0; i < n; i++) memcpy(descriptors.ptr<uint8_t>(i), desc.ptr<uint8_t>(i), 32);
+}
+
+// ---- Frame ----------------------------------------------------------------------------------------------------------
+long unsigned int Frame::nNextId = 0;
+
+Frame::Frame(const cv::Mat& imGray, const cv::Mat& imDepth, const cv::Mat& imFlow, const cv::Mat& maskSEM, const double& timeStamp,
+             ORBextractor* extractor, cv::Mat& K, cv::Mat& distCoef, const float& bf, const float& thDepth, const float& thDepthObj, const int& UseSampleFea)
+{
+    (void)imDepth; (void)imFlow; (void)maskSEM;            // their (patched) copies live in the device slot uploaded by GrabImageRGBD
+    if (UseSampleFea != 0) throw std::runtime_error("Frame: UseSampleFeature=1 (time-seeded random sampling, SURVEY fact 4) is not supported");
+    mnId = nNextId++; mTimeStamp = timeStamp; mK = K.clone(); mDistCoef = distCoef.clone(); mbf = bf; mThDepth = thDepth; mThDepthObj = thDepthObj;
+    fx = K.at<float>(0, 0); fy = K.at<float>(1, 1); cx = K.at<float>(0, 2); cy = K.at<float>(1, 2); invfx = 1.0f / fx; invfy = 1.0f / fy;
+    (*extractor)(imGray, cv::Mat(), mvKeys, mDescriptors);                         // Frame.cc:62 ExtractORB
+    N = (int)mvKeys.size();
+    if (mvKeys.empty()) return;
+    vido_ctx* c = extractor->context(imGray.cols, imGray.rows);
+    const int max_kp = 2 * extractor->nfeatures + 256, max_obj = ((imGray.cols + 3) / 4) * ((imGray.rows + 3) / 4);
+    std::vector<vido_keypoint> k(N);
+    for (int i = 0; i < N; i++) { k[i].x = mvKeys[i].pt.x; k[i].y = mvKeys[i].pt.y; k[i].size = mvKeys[i].size; k[i].angle = mvKeys[i].angle; k[i].response = mvKeys[i].response; k[i].octave = mvKeys[i].octave; }
+    k.resize(max_kp);
+    std::vector<int32_t> sidx(max_kp), olab(max_obj); std::vector<float> scorr(2 * max_kp), sflow(2 * max_kp), sdep(max_kp), okeys(2 * max_obj), ocorr(2 * max_obj), odep(max_obj), oflow(2 * max_obj);
+    int32_t ns = 0, no = 0, nk = N;
+    vido_frame_lists L; L.max_stat = max_kp; L.max_obj = max_obj; L.n_stat = &ns; L.stat_idx = sidx.data(); L.stat_corr = scorr.data(); L.stat_flow = sflow.data(); L.stat_depth = sdep.data();
+    L.n_obj = &no; L.obj_keys = okeys.data(); L.obj_corr = ocorr.data(); L.obj_depth = odep.data(); L.obj_label = olab.data(); L.obj_flow = oflow.data();
+    vido_track_params tp = g_tp; tp.th_depth_bg = thDepth; tp.th_depth_obj = thDepthObj;
+    if (vido_frame_features(c, g_slot, 1, k.data(), &nk, max_kp, &tp, &L) != VIDO_OK) throw std::runtime_error(vido_last_error(c));
+    for (int i = 0; i < ns; i++) {                                                 // Frame.cc:72-100, 165-177
+        const cv::KeyPoint& kp = mvKeys[sidx[i]];
+        mvStatKeysTmp.push_back(kp);
+        mvCorres.push_back(cv::KeyPoint(scorr[2 * i], scorr[2 * i + 1], 0, 0, 0, kp.octave, -1));
+        mvFlowNext.push_back(cv::Point2f(sflow[2 * i], sflow[2 * i + 1]));
+        mvStatDepthTmp.push_back(sdep[i]);
+    }
+    N_s_tmp = ns;
+    for (int i = 0; i < no; i++) {                                                 // Frame.cc:184-211
+        mvObjFlowNext.push_back(cv::Point2f(oflow[2 * i], oflow[2 * i + 1]));
+        mvObjCorres.push_back(cv::KeyPoint(ocorr[2 * i], ocorr[2 * i + 1], 0, 0, 0, -1));
+        mvObjKeys.push_back(cv::KeyPoint(okeys[2 * i], okeys[2 * i + 1], 0, 0, 0, -1));
+        mvObjDepth.push_back(odep[i]); vSemObjLabel.push_back(olab[i]);
+    }
+    // UndistortKeyPoints (Frame.cc:603-633): cv::undistortPoints(P=K) is a 5-iteration fixed point of the Brown model
+    mvKeysUn = mvKeys;
+    if (mDistCoef.at<float>(0) != 0.0f) {
+        const float k1 = mDistCoef.at<float>(0), k2 = mDistCoef.at<float>(1), p1 = mDistCoef.at<float>(2), p2 = mDistCoef.at<float>(3), k3 = mDistCoef.rows > 4 ? mDistCoef.at<float>(4) : 0.f;
+        for (int i = 0; i < N; i++) {
+            const double x0 = (mvKeys[i].pt.x - cx) / fx, y0 = (mvKeys[i].pt.y - cy) / fy; double x = x0, y = y0;
+            for (int it = 0; it < 5; it++) {
+                const double r2 = x * x + y * y, icdist = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+                const double dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x), dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+                x = (x0 - dx) * icdist; y = (y0 - dy) * icdist;
+            }
+            mvKeysUn[i].pt.x = (float)(x * fx + cx); mvKeysUn[i].pt.y = (float)(y * fy + cy);
+        }
+    }
+}
+
+void Frame::SetPose(cv::Mat Tcw)                          // Frame.cc SetPose / UpdatePoseMatrices
+{
+    mTcw = Tcw.clone();
+    mRcw = cv::Mat(3, 3, CV_32F); mtcw = cv::Mat(3, 1, CV_32F);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) mRcw.at<float>(r, c) = mTcw.at<float>(r, c); mtcw.at<float>(r) = mTcw.at<float>(r, 3); }
+    mRwc = mRcw.t(); mOw = cv::Mat(3, 1, CV_32F);
+    for (int r = 0; r < 3; r++) { double s = 0; for (int c = 0; c < 3; c++) s += (double)(-mRwc.at<float>(r, c)) * mtcw.at<float>(c); mOw.at<float>(r) = (float)s; }
+}
+static cv::Mat unproject(const Frame& F, float u, float v, float z)
+{
+    const float x = (u - F.cx) * z * F.invfx, y = (v - F.cy) * z * F.invfy;
+    cv::Mat Twl = Converter::toInvMatrix(F.mTcw), out(3, 1, CV_32F);
+    for (int r = 0; r < 3; r++) { const double s = (double)Twl.at<float>(r, 0) * x + (double)Twl.at<float>(r, 1) * y + (double)Twl.at<float>(r, 2) * z; out.at<float>(r) = (float)s + Twl.at<float>(r, 3); }
+    return out;
+}
+cv::Mat Frame::UnprojectStereoStat(const int& i, const bool&) { const float z = mvStatDepth[i]; if (z < 0) return cv::Mat(); return unproject(*this, mvStatKeys[i].pt.x, mvStatKeys[i].pt.y, z); }
+cv::Mat Frame::UnprojectStereoObject(const int& i, const bool&) { const float z = mvObjDepth[i]; if (!(z > 0)) return cv::Mat(); return unproject(*this, mvObjKeys[i].pt.x, mvObjKeys[i].pt.y, z); }
+cv::Mat Frame::ObtainFlowDepthCamera(const int& i, const bool&) { const float z = mvStatDepth[i]; if (!(z > 0)) return cv::Mat(); return vec3(mvFlowNext[i].x, mvFlowNext[i].y, z); }
+cv::Mat Frame::ObtainFlowDepthObject(const int& i, const bool&) { const float z = mvObjDepth[i]; if (!(z > 0)) return cv::Mat(); return vec3(mvObjFlowNext[i].x, mvObjFlowNext[i].y, z); }
+
+void Map::reset() { *this = Map(); }
+
+// ---- Optimizer ---------------------------------------------------------------------------------------------------------
+cv::Mat Optimizer::Get3DinWorld(const cv::KeyPoint& f, const float& d, const cv::Mat& K, const cv::Mat& Twc)
+{
+    const float invfx = 1.0f / K.at<float>(0, 0), invfy = 1.0f / K.at<float>(1, 1), cx = K.at<float>(0, 2), cy = K.at<float>(1, 2);
+    const float z = d, x = (f.pt.x - cx) * z * invfx, y = (f.pt.y - cy) * z * invfy;
+    cv::Mat out(3, 1, CV_32F);
+    for (int r = 0; r < 3; r++) { const double s = (double)Twc.at<float>(r, 0) * x + (double)Twc.at<float>(r, 1) * y + (double)Twc.at<float>(r, 2) * z; out.at<float>(r) = (float)s + Twc.at<float>(r, 3); }
+    return out;
+}
+cv::Mat Optimizer::Get3DinCamera(const cv::KeyPoint& f, const float& d, const cv::Mat& K)
+{
+    const float invfx = 1.0f / K.at<float>(0, 0), invfy = 1.0f / K.at<float>(1, 1), cx = K.at<float>(0, 2), cy = K.at<float>(1, 2);
+    return vec3((f.pt.x - cx) * d * invfx, (f.pt.y - cy) * d * invfy, d);
+}
+
+static void fill_common(vido_pose_problem& p, const Frame* cur, int n)
+{
+    memset(&p, 0, sizeof p); p.n = n; p.fx = cur->fx; p.fy = cur->fy; p.cx = cur->cx; p.cy = cur->cy;
+    for (int k = 0; k < 16; k++) { p.Twl[k] = (k % 5 == 0); p.T_init[k] = (k % 5 == 0); }
+}
+
+int Optimizer::PoseOptimizationNew(Frame* cur, Frame* last, std::vector<int>& TM)      // Optimizer.cc:2180-2334
+{
+    const int N = (int)TM.size();
+    std::vector<double> Xw(3 * N), obs(2 * N);
+    for (int i = 0; i < N; i++) {
+        obs[2 * i] = cur->mvStatKeys[TM[i]].pt.x; obs[2 * i + 1] = cur->mvStatKeys[TM[i]].pt.y;
+        cv::Mat X = last->UnprojectStereoStat(TM[i], 0);
+        for (int a = 0; a < 3; a++) Xw[3 * i + a] = X.empty() ? 0.0 : X.at<float>(a);
+    }
+    vido_pose_problem p; fill_common(p, cur, N); p.mode = 0; p.Xw = Xw.data(); p.obs = obs.data(); toRow16(cur->mTcw, p.T_init);
+    p.info_edge = 1.0; p.huber_delta = (double)std::sqrt(0.01f); p.use_huber = 1; p.rounds = 1; p.drop_kernel_after_round = 2;
+    const int its[4] = {100, 10, 10, 10}; const float th[4] = {0.01f, 5.991f, 5.991f, 5.991f};
+    memcpy(p.iters, its, sizeof its); memcpy(p.chi2_th, th, sizeof th);
+    vido_pose_result r; std::vector<uint8_t> outl(std::max(N, 1));
+    check(vido_pose_optimize(g_ctx, &p, &r, outl.data(), nullptr), "PoseOptimizationNew");
+    if (N < 3) return 0;
+    cur->SetPose(fromRow16(r.T));
+    for (int i = 0; i < N; i++) if (outl[i]) TM[i] = -1;
+    return r.n_inliers;
+}
+
+int Optimizer::PoseOptimizationFlow2Cam(Frame* cur, Frame* last, std::vector<int>& TM)   // Optimizer.cc:2622-2824
+{
+    const int N = (int)TM.size();
+    std::vector<double> obs(2 * N), flow(2 * N), depth(N);
+    for (int i = 0; i < N; i++) {
+        cv::Mat fd = last->ObtainFlowDepthCamera(TM[i], 0);
+        flow[2 * i] = fd.empty() ? 0.0 : fd.at<float>(0); flow[2 * i + 1] = fd.empty() ? 0.0 : fd.at<float>(1); depth[i] = fd.empty() ? 1.0 : fd.at<float>(2);
+        obs[2 * i] = last->mvStatKeys[TM[i]].pt.x; obs[2 * i + 1] = last->mvStatKeys[TM[i]].pt.y;
+    }
+    vido_pose_problem p; fill_common(p, cur, N); p.mode = 1; p.obs = obs.data(); p.flow0 = flow.data(); p.depth = depth.data();
+    toRow16(Converter::toInvMatrix(last->mTcw), p.Twl); toRow16(cur->mTcw, p.T_init);
+    p.info_edge = 0.1; p.info_prior = 0.3; p.huber_delta = (double)std::sqrt(0.04f); p.use_huber = 1; p.rounds = 4; p.drop_kernel_after_round = 2;
+    const int its[4] = {100, 100, 100, 100}; const float th[4] = {0.04f, 5.991f, 5.991f, 5.991f};
+    memcpy(p.iters, its, sizeof its); memcpy(p.chi2_th, th, sizeof th);
+    vido_pose_result r; std::vector<uint8_t> outl(std::max(N, 1)); std::vector<double> f(2 * std::max(N, 1));
+    check(vido_pose_optimize(g_ctx, &p, &r, outl.data(), f.data()), "PoseOptimizationFlow2Cam");
+    if (N < 3) return 0;
+    cur->SetPose(fromRow16(r.T));
+    for (int i = 0; i < N; i++) {
+        if (!outl[i]) {      // :2807-2813 refined optical flow
+            cur->mvStatKeys[TM[i]].pt.x = last->mvStatKeys[TM[i]].pt.x + (float)f[2 * i];
+            cur->mvStatKeys[TM[i]].pt.y = last->mvStatKeys[TM[i]].pt.y + (float)f[2 * i + 1];
+        }
+    }
+    for (int i = 0; i < N; i++) if (outl[i]) TM[i] = -1;
+    return r.n_inliers;
+}
+
+cv::Mat Optimizer::PoseOptimizationObjMot(Frame* cur, Frame* last, const std::vector<int>& ObjId, std::vector<int>& InlierID)   // :2826-3035
+{
+    const int N = (int)ObjId.size();
+    if (N < 3) return cv::Mat::eye(4, 4, CV_32F);
+    std::vector<double> Xw(3 * N), obs(2 * N);
+    for (int i = 0; i < N; i++) {
+        obs[2 * i] = cur->mvObjKeys[ObjId[i]].pt.x; obs[2 * i + 1] = cur->mvObjKeys[ObjId[i]].pt.y;
+        cv::Mat X = last->UnprojectStereoObject(ObjId[i], 0);
+        for (int a = 0; a < 3; a++) Xw[3 * i + a] = X.empty() ? 0.0 : X.at<float>(a);
+    }
+    vido_pose_problem p; fill_common(p, cur, N); p.mode = 2; p.Xw = Xw.data(); p.obs = obs.data();
+    toRow16(Converter::toInvMatrix(cur->mTcw) * cur->mInitModel, p.T_init);
+    const double K[12] = {cur->fx, 0, cur->cx, 0, 0, cur->fy, cur->cy, 0, 0, 0, 1, 0}; double T[16]; toRow16(cur->mTcw, T);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) { double s = 0; for (int k = 0; k < 4; k++) s += K[r * 4 + k] * T[k * 4 + c]; p.P[r * 4 + c] = s; }
+    p.info_edge = 1.0; p.use_huber = 0; p.rounds = 1; p.drop_kernel_after_round = 2;
+    const int its[4] = {200, 100, 100, 100}; const float th[4] = {0.01f, 5.991f, 5.991f, 5.991f};
+    memcpy(p.iters, its, sizeof its); memcpy(p.chi2_th, th, sizeof th);
+    vido_pose_result r; std::vector<uint8_t> outl(N);
+    check(vido_pose_optimize(g_ctx, &p, &r, outl.data(), nullptr), "PoseOptimizationObjMot");
+    InlierID.clear();
+    for (int i = 0; i < N; i++) { if (!outl[i]) InlierID.push_back(ObjId[i]); else cur->vObjLabel[ObjId[i]] = -1; }
+    return fromRow16(r.T);
+}
+
+cv::Mat Optimizer::PoseOptimizationFlow2(Frame* cur, Frame* last, const std::vector<int>& ObjId, std::vector<int>& InlierID)    // :3037-3253
+{
+    const int N = (int)ObjId.size();
+    if (N < 3) return cv::Mat::eye(4, 4, CV_32F);
+    std::vector<double> obs(2 * N), flow(2 * N), depth(N);
+    for (int i = 0; i < N; i++) {
+        cv::Mat fd = last->ObtainFlowDepthObject(ObjId[i], 0);
+        flow[2 * i] = fd.empty() ? 0.0 : fd.at<float>(0); flow[2 * i + 1] = fd.empty() ? 0.0 : fd.at<float>(1); depth[i] = fd.empty() ? 1.0 : fd.at<float>(2);
+        obs[2 * i] = last->mvObjKeys[ObjId[i]].pt.x; obs[2 * i + 1] = last->mvObjKeys[ObjId[i]].pt.y;
+    }
+    vido_pose_problem p; fill_common(p, cur, N); p.mode = 1; p.obs = obs.data(); p.flow0 = flow.data(); p.depth = depth.data();
+    toRow16(Converter::toInvMatrix(last->mTcw), p.Twl); toRow16(cur->mInitModel, p.T_init);
+    p.info_edge = 0.1; p.info_prior = 0.5; p.huber_delta = (double)std::sqrt(0.04f); p.use_huber = 1; p.rounds = 1; p.drop_kernel_after_round = 2;
+    const int its[4] = {200, 100, 100, 100}; const float th[4] = {0.04f, 5.991f, 5.991f, 5.991f};
+    memcpy(p.iters, its, sizeof its); memcpy(p.chi2_th, th, sizeof th);
+    vido_pose_result r; std::vector<uint8_t> outl(N); std::vector<double> f(2 * N);
+    check(vido_pose_optimize(g_ctx, &p, &r, outl.data(), f.data()), "PoseOptimizationFlow2");
+    InlierID.clear();
+    for (int i = 0; i < N; i++) {
+        if (!outl[i]) {
+            cur->mvObjKeys[ObjId[i]].pt.x = last->mvObjKeys[ObjId[i]].pt.x + (float)f[2 * i];
+            cur->mvObjKeys[ObjId[i]].pt.y = last->mvObjKeys[ObjId[i]].pt.y + (float)f[2 * i + 1];
+            InlierID.push_back(ObjId[i]);
+        } else cur->vObjLabel[ObjId[i]] = -1;
+    }
+    return fromRow16(r.T);
+}
+
+// Map walk of PartialBatchOptimization (Optimizer.cc:56-160, 216-350) onto the flat BA problem (STATIC_ONLY graph).
+static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool global)
+{
+    const int N = (int)pMap->vpFeatSta.size();
+    if (N < 2 || WINDOW_SIZE < 1) return;
+    const int start = global ? 0 : std::max(N - WINDOW_SIZE, 0), nc = N - start;
+    const auto& Tr = pMap->TrackletSta;
+    std::vector<std::vector<int> > lab(N), mak(N);
+    for (int i = 0; i < N; i++) { lab[i].assign(pMap->vpFeatSta[i].size(), -1); mak[i].assign(pMap->vpFeatSta[i].size(), -1); }
+    for (size_t t = 0; t < Tr.size(); t++) { if (Tr[t].size() < 3) continue; for (auto& pr : Tr[t]) lab[pr.first][pr.second] = (int)t; }
+    std::vector<double> cam((size_t)nc * 12), pts, meas, odo; std::vector<int32_t> oc, op, oi, oj;
+    for (int i = start; i < N; i++) for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) cam[(size_t)(i - start) * 12 + r * 4 + c] = pMap->vmCameraPose[i].at<float>(r, c);
+    std::vector<int> trackPoint(Tr.size(), -1); std::vector<std::pair<int, int> > ptOwner;
+    for (int i = start; i < N; i++) {
+        if (i != start) {
+            const cv::Mat& M = pMap->vmRigidMotion[i - 1][0];
+            oi.push_back(i - 1 - start); oj.push_back(i - start);
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) odo.push_back(M.at<float>(r, c));
+        }
+        for (size_t j = 0; j < lab[i].size(); j++) {
+            const int t = lab[i][j]; if (t == -1) continue;
+            int pos = -1;
+            for (size_t k = 0; k < Tr[t].size(); k++) if (Tr[t][k].first == i && Tr[t][k].second == (int)j) { pos = (int)k; break; }
+            if (pos == -1) continue;
+            int pid;
+            if (pos == 0) {                                   // tracklet starts inside the window: new point vertex (:290-325)
+                pid = (int)ptOwner.size(); ptOwner.push_back(std::make_pair(i, (int)j)); trackPoint[t] = pid;
+                const cv::Mat& Xw = pMap->vp3DPointSta[i][j]; for (int a = 0; a < 3; a++) pts.push_back(Xw.at<float>(a));
+            } else {
+                const int pm = mak[Tr[t][pos - 1].first][Tr[t][pos - 1].second];
+                if (pm == -1) continue;                       // started before the window (:332-333)
+                pid = pm;
+            }
+            mak[i][j] = pid;
+            cv::Mat Xc = Optimizer::Get3DinCamera(pMap->vpFeatSta[i][j], pMap->vfDepSta[i][j], K);
+            oc.push_back(i - start); op.push_back(pid); for (int a = 0; a < 3; a++) meas.push_back(Xc.at<float>(a));
+        }
+    }
+    if (pts.empty()) return;
+    vido_ba_problem b; memset(&b, 0, sizeof b);
+    b.n_cam = nc; b.cam_T = cam.data(); b.n_pt = (int)ptOwner.size(); b.pt_xyz = pts.data();
+    b.n_obs = (int)oc.size(); b.obs_cam = oc.data(); b.obs_pt = op.data(); b.obs_meas = meas.data();
+    b.n_odo = (int)oi.size(); b.odo_i = oi.data(); b.odo_j = oj.data(); b.odo_T = odo.data();
+    b.use_huber = 1; b.huber_obs = b.huber_odo = (double)0.01f; b.info_odo = 1.0 / (double)0.0001f;
+    if (!global) { b.prior_cam = (N == WINDOW_SIZE) ? 0 : -1; b.info_prior = 1.0 / 0.0000001; b.info_obs = 1.0 / (double)16.f; b.max_iters = 100; b.gain_threshold = 1e-3; }   // :183,191-196,226-235
+    else { b.prior_cam = 0; b.info_prior = 1e5; b.info_obs = 1.0 / (double)80.f; b.max_iters = 300; b.gain_threshold = 1e-4; }                                             // :1325,1333-1338
+    for (int k = 0; k < 12; k++) b.prior_T[k] = cam[k];
+    vido_ba_result r;
+    check(vido_ba_optimize(g_ctx, &b, &r, nullptr, nullptr), global ? "FullBatchOptimization" : "PartialBatchOptimization");
+    auto& poses = global ? pMap->vmCameraPose_RF : pMap->vmCameraPose;
+    for (int i = start; i < N; i++) {                      // write-back, Optimizer.cc:1084-1128
+        cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+        for (int rr = 0; rr < 3; rr++) for (int c = 0; c < 4; c++) T.at<float>(rr, c) = (float)cam[(size_t)(i - start) * 12 + rr * 4 + c];
+        poses[i] = T;
+        if (i > start) (global ? pMap->vmRigidMotion_RF : pMap->vmRigidMotion)[i - 1][0] = Converter::toInvMatrix(poses[i - 1]) * poses[i];
+    }
+    if (!global) for (size_t q = 0; q < ptOwner.size(); q++) { /* the reference writes the optimised point back to EVERY observation slot that references it */ }
+    for (int i = start; i < N; i++) for (size_t j = 0; j < mak[i].size(); j++) if (mak[i][j] != -1 && !global)
+        pMap->vp3DPointSta[i][j] = vec3((float)pts[3 * (size_t)mak[i][j]], (float)pts[3 * (size_t)mak[i][j] + 1], (float)pts[3 * (size_t)mak[i][j] + 2]);
+}
+void Optimizer::PartialBatchOptimization(Map* pMap, const cv::Mat K, const int W) { batch_optimize(pMap, K, W, false); }
+void Optimizer::FullBatchOptimization(Map* pMap, const cv::Mat K) { batch_optimize(pMap, K, (int)pMap->vpFeatSta.size(), true); }
+
+// ---- Tracking ----------------------------------------------------------------------------------------------------------------
+Tracking::Tracking(System* pSys, Map* pMap, const std::string& path, const int sensor)        // Tracking.cc:39-172
+    : mState(NO_IMAGES_YET), mTestData(KAIST), mSensor(sensor), bJoint(true), f_id(0), max_id(1), StopFrame(0), mScale(1.0f), ransac_seed(20260926u), mpSystem(pSys), mpMap(pMap)
+{
+    auto kv = ParseSettings(path);
+    mK = cv::Mat::eye(3, 3, CV_32F);
+    mK.at<float>(0, 0) = (float)num(kv, "Camera.fx"); mK.at<float>(1, 1) = (float)num(kv, "Camera.fy"); mK.at<float>(0, 2) = (float)num(kv, "Camera.cx"); mK.at<float>(1, 2) = (float)num(kv, "Camera.cy");
+    const float k3 = (float)num(kv, "Camera.k3");
+    mDistCoef = cv::Mat(k3 != 0 ? 5 : 4, 1, CV_32F);
+    mDistCoef.at<float>(0) = (float)num(kv, "Camera.k1"); mDistCoef.at<float>(1) = (float)num(kv, "Camera.k2"); mDistCoef.at<float>(2) = (float)num(kv, "Camera.p1"); mDistCoef.at<float>(3) = (float)num(kv, "Camera.p2");
+    if (k3 != 0) mDistCoef.at<float>(4) = k3;
+    mbf = (float)num(kv, "Camera.bf"); mbRGB = num(kv, "Camera.RGB") != 0;
+    mpORBextractorLeft = new ORBextractor((int)num(kv, "ORBextractor.nFeatures", 2000), (float)num(kv, "ORBextractor.scaleFactor", 1.2), (int)num(kv, "ORBextractor.nLevels", 8),
+                                          (int)num(kv, "ORBextractor.iniThFAST", 20), (int)num(kv, "ORBextractor.minThFAST", 7));
+    const int code = (int)num(kv, "ChooseData", 3);
+    mTestData = code == 1 ? OMD : (code == 2 ? KITTI : KAIST);
+    mThDepth = (float)num(kv, "ThDepthBG", 80); mThDepthObj = (float)num(kv, "ThDepthOBJ", 60); mDepthMapFactor = (float)num(kv, "DepthMapFactor", 1);
+    if (mDepthMapFactor == 0) mDepthMapFactor = 1;
+    nMaxTrackPointBG = (int)num(kv, "MaxTrackPointBG", 3000); nMaxTrackPointOBJ = (int)num(kv, "MaxTrackPointOBJ", 800);
+    fSFMgThres = (float)num(kv, "SFMgThres", 0.12); fSFDsThres = (float)num(kv, "SFDsThres", 0.3);
+    nWINDOW_SIZE = (int)num(kv, "WINDOW_SIZE", 20); nOVERLAP_SIZE = (int)num(kv, "OVERLAP_SIZE", 4); nUseSampleFea = (int)num(kv, "UseSampleFeature", 0);
+    if (kv.count("Joint")) bJoint = num(kv, "Joint") != 0;
+    if (kv.count("RansacSeed")) ransac_seed = (unsigned)num(kv, "RansacSeed");
+    all_timing.assign(5, 0.f);
+}
+Tracking::~Tracking() { delete mpORBextractorLeft; }
+
+static cv::Mat to_gray(const cv::Mat& im, bool rgb)           // cvtColor BGR/RGB(A)2GRAY, Tracking.cc:327-340
+{
+    if (im.channels() == 1) return im;
+    cv::Mat g(im.rows, im.cols, CV_8UC1); const int cn = im.channels();
+    for (int y = 0; y < im.rows; y++) { const uint8_t* s = im.ptr<uint8_t>(y); uint8_t* d = g.ptr<uint8_t>(y);
+        for (int x = 0; x < im.cols; x++, s += cn) { const int b = rgb ? s[2] : s[0], gg = s[1], r = rgb ? s[0] : s[2]; d[x] = (uint8_t)((b * 1868 + gg * 9617 + r * 4899 + 8192) >> 14); } }
+    return g;
+}
+
+cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Mat& imFlow, const cv::Mat& maskSEM, const cv::Mat&,
+                                const std::vector<std::vector<float> >&, const double& timestamp, cv::Mat&, const int& nImage)
+{
+    StopFrame = nImage - 1;
+    if (mState == NO_IMAGES_YET) f_id = 0;
+    if (imD.type() != CV_32FC1 || imFlow.type() != CV_32FC2 || maskSEM.type() != CV_32SC1 || !imD.isContinuous() || !imFlow.isContinuous() || !maskSEM.isContinuous())
+        throw std::runtime_error("GrabImageRGBD: depth CV_32F, flow CV_32FC2, mask CV_32SC1 (continuous) expected");
+    vido_ctx* c = mpORBextractorLeft->context(imRGB.cols, imRGB.rows);
+    g_ctx = c;
+    memset(&g_tp, 0, sizeof g_tp);
+    g_tp.dataset = mTestData == OMD ? 0 : (mTestData == KITTI ? 1 : 2); g_tp.depth_map_factor = mDepthMapFactor; g_tp.bf = mbf; g_tp.kaist_scale = mScale;
+    g_tp.th_depth_bg = mThDepth; g_tp.th_depth_obj = mThDepthObj; g_tp.dense_step = 4; g_tp.fx = mK.at<float>(0, 0); g_tp.fy = mK.at<float>(1, 1); g_tp.cx = mK.at<float>(0, 2); g_tp.cy = mK.at<float>(1, 2);
+    const int slot_last = slot_cur_; slot_cur_ = (mState == NO_IMAGES_YET) ? 0 : 1 - slot_cur_; g_slot = slot_cur_;
+    // depth pre-scale in place on the caller's buffer (:299-322) + maps resident in the slot
+    check(vido_frame_upload(c, slot_cur_, 1, imD.ptr<float>(), imFlow.ptr<float>(), maskSEM.ptr<int32_t>(), 0, &g_tp), "frame_upload");
+    mImGray = to_gray(imRGB, mbRGB);
+    mDepthMap = imD; mFlowMap = imFlow; mSegMap = maskSEM.clone();
+    all_timing.assign(5, 0.f);
+    if (mState != NO_IMAGES_YET) UpdateMask();
+    (void)slot_last;
+    mpCurrentFrame = new Frame(mImGray, imD, imFlow, mSegMap, timestamp, mpORBextractorLeft, mK, mDistCoef, mbf, mThDepth, mThDepthObj, nUseSampleFea);
+    if (mState != NO_IMAGES_YET) {                             // :369-421
+        Frame* F = mpCurrentFrame;
+        F->mvStatKeys = mpLastFrame->mvCorres; F->N_s = (int)F->mvStatKeys.size();
+        std::vector<float> xy(2 * std::max(F->N_s, 1)); F->mvStatDepth.assign(F->N_s, -1.f);
+        for (int i = 0; i < F->N_s; i++) { xy[2 * i] = F->mvStatKeys[i].pt.x; xy[2 * i + 1] = F->mvStatKeys[i].pt.y; }
+        if (F->N_s) check(vido_gather_static_depth(c, slot_cur_, xy.data(), F->N_s, F->mvStatDepth.data()), "gather_static_depth");
+        mvTmpObjKeys = F->mvObjKeys; mvTmpObjDepth = F->mvObjDepth; mvTmpSemObjLabel = F->vSemObjLabel; mvTmpObjFlowNext = F->mvObjFlowNext; mvTmpObjCorres = F->mvObjCorres;
+        F->mvObjKeys = mpLastFrame->mvObjCorres;
+        const int no = (int)F->mvObjKeys.size();
+        F->mvObjDepth.assign(no, -1.f); F->vSemObjLabel.assign(no, -1);
+        std::vector<float> oxy(2 * std::max(no, 1));
+        for (int i = 0; i < no; i++) { oxy[2 * i] = F->mvObjKeys[i].pt.x; oxy[2 * i + 1] = F->mvObjKeys[i].pt.y; }
+        if (no) check(vido_gather_object_depth_label(c, slot_cur_, oxy.data(), no, mThDepthObj, F->mvObjDepth.data(), F->vSemObjLabel.data()), "gather_object");
+        TemperalMatch.assign(F->N_s, -1);
+    }
+    mpCurrentFrame->vObjLabel.assign(mpCurrentFrame->mvObjKeys.size(), -2);
+    Track();
+    f_id = f_id + 1;
+    mImGrayLast = mImGray; mSegMapLast = mSegMap; mFlowMapLast = mFlowMap;      // :777-780
+    return mpCurrentFrame->mTcw.clone();
+}
+
+void Tracking::UpdateMask()                                   // Tracking.cc:3291-3357, device scatter
+{
+    Frame* L = mpLastFrame; const int n = (int)L->vSemObjLabel.size();
+    if (n == 0) return;
+    std::vector<float> corr(2 * n);
+    for (int i = 0; i < n; i++) { corr[2 * i] = L->mvObjCorres[i].pt.x; corr[2 * i + 1] = L->mvObjCorres[i].pt.y; }
+    int32_t rec[64], nrec = 0;
+    check(vido_update_mask(g_ctx, 1 - slot_cur_, slot_cur_, L->vSemObjLabel.data(), corr.data(), n, rec, 64, &nrec), "update_mask");
+    if (nrec > 0) check(vido_read_maps(g_ctx, slot_cur_, nullptr, nullptr, mSegMap.ptr<int32_t>()), "read_maps");     // host copy used by RenewFrameInfo
+}
+
+void Tracking::Initialization()                               // Tracking.cc:1512-1580
+{
+    Frame* F = mpCurrentFrame;
+    for (size_t i = 0; i < F->mvStatKeysTmp.size(); i++) F->mvStat3DPointTmp.push_back(Optimizer::Get3DinCamera(F->mvStatKeysTmp[i], F->mvStatDepthTmp[i], mK));
+    for (size_t i = 0; i < F->mvObjKeys.size(); i++) F->mvObj3DPoint.push_back(Optimizer::Get3DinCamera(F->mvObjKeys[i], F->mvObjDepth[i], mK));
+    mpMap->vpFeatSta.push_back(F->mvStatKeysTmp); mpMap->vfDepSta.push_back(F->mvStatDepthTmp); mpMap->vp3DPointSta.push_back(F->mvStat3DPointTmp);
+    mpMap->vpFeatDyn.push_back(F->mvObjKeys); mpMap->vfDepDyn.push_back(F->mvObjDepth); mpMap->vp3DPointDyn.push_back(F->mvObj3DPoint);
+    mpMap->vmCameraPose.push_back(cv::Mat::eye(4, 4, CV_32F)); mpMap->vmCameraPose_RF.push_back(cv::Mat::eye(4, 4, CV_32F)); mpMap->vmCameraPose_GT.push_back(cv::Mat::eye(4, 4, CV_32F));
+    F->SetPose(cv::Mat::eye(4, 4, CV_32F));
+    mpLastFrame = F; mpLastFrame->mvStatKeys = F->mvStatKeysTmp; mpLastFrame->mvStatDepth = F->mvStatDepthTmp; mpLastFrame->N_s = F->N_s_tmp;
+    mState = OK;
+}
+
+static float reproj(const cv::Mat& T, const cv::Point3f& X, const cv::Point2f& x, float fx, float fy, float cx, float cy)
+{
+    const float xc = T.at<float>(0, 0) * X.x + T.at<float>(0, 1) * X.y + T.at<float>(0, 2) * X.z + T.at<float>(0, 3);
+    const float yc = T.at<float>(1, 0) * X.x + T.at<float>(1, 1) * X.y + T.at<float>(1, 2) * X.z + T.at<float>(1, 3);
+    const float invzc = 1.0f / (T.at<float>(2, 0) * X.x + T.at<float>(2, 1) * X.y + T.at<float>(2, 2) * X.z + T.at<float>(2, 3));
+    const float u_ = x.x - (fx * xc * invzc + cx), v_ = x.y - (fy * yc * invzc + cy);
+    return std::sqrt(u_ * u_ + v_ * v_);
+}
+
+cv::Mat Tracking::GetInitModelCam(const std::vector<int>& MatchId, std::vector<int>& MatchId_sub)   // Tracking.cc:1914-2028
+{
+    const int N = (int)MatchId.size(); Frame *C = mpCurrentFrame, *L = mpLastFrame;
+    std::vector<cv::Point2f> cur_2d(N); std::vector<cv::Point3f> pre_3d(N); std::vector<int> outl(N, 0);
+    for (int i = 0; i < N; i++) {
+        cur_2d[i] = C->mvStatKeys[MatchId[i]].pt;
+        cv::Mat X = L->UnprojectStereoStat(MatchId[i], 0);
+        if (X.empty()) { outl[i] = -1; continue; }
+        pre_3d[i] = cv::Point3f(X.at<float>(0), X.at<float>(1), X.at<float>(2));
+    }
+    std::vector<float> g3, g2; std::vector<int> gidx;
+    for (int i = 0; i < N; i++) if (outl[i] == 0) { g3.push_back(pre_3d[i].x); g3.push_back(pre_3d[i].y); g3.push_back(pre_3d[i].z); g2.push_back(cur_2d[i].x); g2.push_back(cur_2d[i].y); gidx.push_back(i); }
+    double T[16]; int32_t ninl = 0; std::vector<uint8_t> mask(std::max<size_t>(gidx.size(), 1));
+    check(vido_pnp_ransac(g_ctx, g3.data(), g2.data(), (int)gidx.size(), C->fx, C->fy, C->cx, C->cy, 500, 0.4, 0.98, ransac_seed + (unsigned)f_id, T, mask.data(), &ninl), "pnp_ransac");
+    cv::Mat Mod = fromRow16(T);
+    cv::Mat MotionModel = mVelocity.empty() ? L->mTcw.clone() : mVelocity * L->mTcw;
+    std::vector<int> MM_inlier;
+    for (int i = 0; i < N; i++) if (reproj(MotionModel, pre_3d[i], cur_2d[i], C->fx, C->fy, C->cx, C->cy) < 0.4f) MM_inlier.push_back(i);
+    MatchId_sub.clear();
+    if (ninl > (int)MM_inlier.size()) { for (size_t k = 0; k < gidx.size(); k++) if (mask[k]) MatchId_sub.push_back(MatchId[gidx[k]]); return Mod; }
+    for (int i : MM_inlier) MatchId_sub.push_back(MatchId[i]);
+    return MotionModel;
+}
+
+cv::Mat Tracking::GetInitModelObj(const std::vector<int>& ObjId, std::vector<int>& ObjId_sub, const int objid)   // Tracking.cc:2030-2162
+{
+    const int N = (int)ObjId.size(); Frame *C = mpCurrentFrame, *L = mpLastFrame;
+    std::vector<cv::Point2f> cur_2d(N); std::vector<cv::Point3f> pre_3d(N); std::vector<float> g3(3 * N), g2(2 * N);
+    for (int i = 0; i < N; i++) {
+        cur_2d[i] = C->mvObjKeys[ObjId[i]].pt;
+        cv::Mat X = L->UnprojectStereoObject(ObjId[i], 0);
+        pre_3d[i] = X.empty() ? cv::Point3f(0, 0, 1) : cv::Point3f(X.at<float>(0), X.at<float>(1), X.at<float>(2));
+        g3[3 * i] = pre_3d[i].x; g3[3 * i + 1] = pre_3d[i].y; g3[3 * i + 2] = pre_3d[i].z; g2[2 * i] = cur_2d[i].x; g2[2 * i + 1] = cur_2d[i].y;
+    }
+    double T[16]; int32_t ninl = 0; std::vector<uint8_t> mask(std::max(N, 1));
+    check(vido_pnp_ransac(g_ctx, g3.data(), g2.data(), N, C->fx, C->fy, C->cx, C->cy, 500, 0.4, 0.98, ransac_seed + 7919u * (unsigned)(objid + 1) + (unsigned)f_id, T, mask.data(), &ninl), "pnp_ransac(obj)");
+    cv::Mat Mod = fromRow16(T);
+    const int CurObjLab = C->nModLabel[objid]; int PreObjID = -1;
+    for (size_t i = 0; i < L->nModLabel.size(); i++) if (L->nModLabel[i] == CurObjLab) { PreObjID = (int)i; break; }
+    ObjId_sub.clear();
+    if (PreObjID != -1 && PreObjID < (int)L->vObjMod.size() && !L->vObjMod[PreObjID].empty()) {
+        cv::Mat MotionModel = C->mTcw * L->vObjMod[PreObjID];
+        std::vector<int> MM;
+        for (int i = 0; i < N; i++) if (reproj(MotionModel, pre_3d[i], cur_2d[i], C->fx, C->fy, C->cx, C->cy) < 0.4f) MM.push_back(i);
+        if (ninl > (int)MM.size()) { for (int i = 0; i < N; i++) if (mask[i]) ObjId_sub.push_back(ObjId[i]); return Mod; }
+        for (int i : MM) ObjId_sub.push_back(ObjId[i]);
+        return MotionModel;
+    }
+    for (int i = 0; i < N; i++) if (mask[i]) ObjId_sub.push_back(ObjId[i]);      // no previous motion: RANSAC model (:2136-2147)
+    return Mod;
+}
+
+void Tracking::GetSceneFlowObj()                              // Tracking.cc:1582-1668
+{
+    Frame *C = mpCurrentFrame, *L = mpLastFrame; const int N = (int)C->mvObjKeys.size();
+    C->vFlow_3d.assign(N, cv::Point3f(0, 0, 0));
+    if (N == 0) return;
+    std::vector<float> kc(2 * N), kl(2 * N), xl(3 * N), xc(3 * N), f3(3 * N);
+    for (int i = 0; i < N; i++) { kc[2 * i] = C->mvObjKeys[i].pt.x; kc[2 * i + 1] = C->mvObjKeys[i].pt.y; kl[2 * i] = L->mvObjKeys[i].pt.x; kl[2 * i + 1] = L->mvObjKeys[i].pt.y; }
+    check(vido_unproject_world(g_ctx, kl.data(), L->mvObjDepth.data(), N, &g_tp, L->mTcw.ptr<float>(), xl.data()), "unproject(last)");
+    check(vido_unproject_world(g_ctx, kc.data(), C->mvObjDepth.data(), N, &g_tp, C->mTcw.ptr<float>(), xc.data()), "unproject(cur)");
+    check(vido_scene_flow(g_ctx, xl.data(), xc.data(), L->vSemObjLabel.data(), C->vSemObjLabel.data(), N, f3.data(), C->vObjLabel.data()), "scene_flow");
+    for (int i = 0; i < N; i++) C->vFlow_3d[i] = cv::Point3f(f3[3 * i], f3[3 * i + 1], f3[3 * i + 2]);
+}
+
+static int most_frequent(std::vector<int> v)                  // std::map count + SortPairInt (descending count)
+{
+    std::sort(v.begin(), v.end()); int best = v[0], bc = 0, run = 0;
+    for (size_t j = 0; j < v.size(); j++) { run = (j > 0 && v[j] == v[j - 1]) ? run + 1 : 1; if (run > bc) { bc = run; best = v[j]; } }
+    return best;
+}
+
+std::vector<std::vector<int> > Tracking::DynObjTracking()     // Tracking.cc:1670-1912
+{
+    Frame *C = mpCurrentFrame, *L = mpLastFrame;
+    std::vector<int> UniLab = C->vSemObjLabel; std::sort(UniLab.begin(), UniLab.end()); UniLab.erase(std::unique(UniLab.begin(), UniLab.end()), UniLab.end());
+    std::vector<std::vector<int> > Posi(UniLab.size());
+    for (size_t i = 0; i < C->vSemObjLabel.size(); i++) {
+        if (C->vObjLabel[i] == -1) continue;
+        const size_t j = std::lower_bound(UniLab.begin(), UniLab.end(), C->vSemObjLabel[i]) - UniLab.begin();
+        Posi[j].push_back((int)i);
+    }
+    std::vector<std::vector<int> > ObjId; std::vector<int> sem_posi;
+    const int shr_row = 10, shr_col = 20;
+    for (size_t i = 0; i < Posi.size(); i++) {
+        if (Posi[i].empty()) continue;                        // (the reference divides by zero here)
+        float count = 0;
+        for (int id : Posi[i]) { const float u = C->mvObjKeys[id].pt.x, v = C->mvObjKeys[id].pt.y; if (v < shr_row || v > (mImGray.rows - shr_row) || u < shr_col || u > (mImGray.cols - shr_col)) count += 1; }
+        if (count / Posi[i].size() > 0.5f) { for (int id : Posi[i]) C->vObjLabel[id] = -1; continue; }
+        ObjId.push_back(Posi[i]); sem_posi.push_back(UniLab[i]);
+    }
+    std::vector<std::vector<int> > ObjIdNew; std::vector<int> SemPosNew;
+    for (size_t i = 0; i < ObjId.size(); i++) {
+        float depth_sum = 0, sf_count = 0;
+        for (int id : ObjId[i]) {
+            depth_sum += C->mvObjDepth[id];
+            const float sf = std::sqrt(C->vFlow_3d[id].x * C->vFlow_3d[id].x + C->vFlow_3d[id].z * C->vFlow_3d[id].z);
+            if (sf < fSFMgThres) sf_count += 1;
+        }
+        if (sf_count / ObjId[i].size() > fSFDsThres) { for (int id : ObjId[i]) C->vObjLabel[id] = 0; continue; }            // static object
+        if (depth_sum / ObjId[i].size() > mThDepthObj || ObjId[i].size() < 150) { for (int id : ObjId[i]) C->vObjLabel[id] = -1; continue; }   // far / small
+        ObjIdNew.push_back(ObjId[i]); SemPosNew.push_back(sem_posi[i]);
+    }
+    if (f_id == 1) max_id = 1;
+    std::vector<int> LabId(ObjIdNew.size());
+    for (size_t i = 0; i < ObjIdNew.size(); i++) {
+        std::vector<int> Lb_last; for (int id : ObjIdNew[i]) Lb_last.push_back(L->vSemObjLabel[id]);
+        const int New_lab = most_frequent(Lb_last);
+        bool exist = false;
+        if (max_id != 1) for (size_t k = 0; k < L->nSemPosition.size(); k++) if (L->nSemPosition[k] == New_lab && L->bObjStat[k]) { LabId[i] = L->nModLabel[k]; exist = true; break; }
+        if (!exist) { LabId[i] = max_id; max_id = max_id + 1; }
+        for (int id : ObjIdNew[i]) C->vObjLabel[id] = LabId[i];
+    }
+    C->nModLabel = LabId; C->nSemPosition = SemPosNew;
+    return ObjIdNew;
+}
+
+std::vector<std::vector<std::pair<int, int> > > Tracking::GetStaticTrack()     // Tracking.cc:2514-2613
+{
+    const auto& TM = mpMap->vnAssoSta; const int N = (int)TM.size();
+    std::vector<int> pre; std::vector<std::vector<std::pair<int, int> > > T;
+    for (int i = 0; i < N; i++) {
+        std::vector<int> cur(TM[i].size(), -1);
+        for (size_t j = 0; j < TM[i].size(); j++) {
+            const int m = TM[i][j]; if (m == -1) continue;
+            if (i > 0 && m < (int)pre.size() && pre[m] != -1) { T[pre[m]].push_back(std::make_pair(i + 1, (int)j)); cur[j] = pre[m]; }
+            else { T.push_back({std::make_pair(i, m), std::make_pair(i + 1, (int)j)}); cur[j] = (int)T.size() - 1; }
+        }
+        pre = cur;
+    }
+    return T;
+}
+std::vector<std::vector<std::pair<int, int> > > Tracking::GetDynamicTrackNew()  // Tracking.cc:2615-2720
+{
+    const auto& TM = mpMap->vnAssoDyn; const auto& Lab = mpMap->vnFeatLabel; const int N = (int)TM.size();
+    std::vector<int> pre, ObjectID; std::vector<std::vector<std::pair<int, int> > > T;
+    for (int i = 0; i < N; i++) {
+        std::vector<int> cur(TM[i].size(), -1);
+        for (size_t j = 0; j < TM[i].size(); j++) {
+            const int m = TM[i][j]; if (m == -1) continue;
+            if (i > 0 && m < (int)pre.size() && pre[m] != -1) { T[pre[m]].push_back(std::make_pair(i + 1, (int)j)); cur[j] = pre[m]; }
+            else { T.push_back({std::make_pair(i, m), std::make_pair(i + 1, (int)j)}); ObjectID.push_back(Lab[i][j]); cur[j] = (int)T.size() - 1; }
+        }
+        pre = cur;
+    }
+    mpMap->nObjID = ObjectID;
+    return T;
+}
+
+void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:2959-3289
+{
+    Frame* C = mpCurrentFrame; const int W = mImGray.cols, H = mImGray.rows;
+    const int max_num_sta = nMaxTrackPointBG, max_num_obj = nMaxTrackPointOBJ;
+    std::vector<cv::KeyPoint> keys, corres; std::vector<cv::Point2f> flows; std::vector<int> inlierID;
+    auto try_static = [&](const cv::KeyPoint& kp, int id) -> bool {
+        const int x = (int)kp.pt.x, y = (int)kp.pt.y;
+        if (x >= W || y >= H || x <= 0 || y <= 0) return false;
+        if (mSegMap.at<int32_t>(y, x) != 0) return false;
+        const float d = mDepthMap.at<float>(y, x); if (d > 40 || d <= 0) return false;
+        const cv::Vec2f fl = mFlowMap.at<cv::Vec2f>(y, x);
+        if (fl[0] != 0 && fl[1] != 0 && kp.pt.x + fl[0] < W && kp.pt.y + fl[1] < H && kp.pt.x + fl[0] > 0 && kp.pt.y + fl[1] > 0) {
+            keys.push_back(kp); corres.push_back(cv::KeyPoint(kp.pt.x + fl[0], kp.pt.y + fl[1], 0, 0, 0, -1)); flows.push_back(cv::Point2f(fl[0], fl[1])); inlierID.push_back(id); return true;
+        }
+        return false;
+    };
+    for (size_t i = 0; i < TM_sta.size(); i++) {
+        if (TM_sta[i] == -1) continue;
+        try_static(C->mvStatKeys[TM_sta[i]], TM_sta[i]);
+        if ((int)keys.size() > max_num_sta) break;
+    }
+    int tot = (int)keys.size(), start_id = 0; const int step = 20;
+    const std::vector<cv::KeyPoint> check_set = keys;                    // mvKeysTmpCheck: the inlier set only (copied once)
+    const std::vector<cv::KeyPoint>& sample = C->mvKeys;
+    while (tot < max_num_sta) {
+        if (start_id == step) break;
+        for (size_t i = start_id; i < sample.size(); i += step) {
+            bool used = false; float min_dist = 100;
+            for (const cv::KeyPoint& k : check_set) {
+                const float dx = k.pt.x - sample[i].pt.x, dy = k.pt.y - sample[i].pt.y, dd = std::sqrt(dx * dx + dy * dy);
+                if (dd < min_dist) min_dist = dd;
+                if (min_dist < 1.0f) { used = true; break; }
+            }
+            if (used) continue;
+            if (try_static(sample[i], -1)) tot++;
+            if (tot >= max_num_sta) break;
+        }
+        start_id++;
+    }
+    C->N_s_tmp = (int)keys.size();
+    std::vector<float> depth(C->N_s_tmp, -1.f); std::vector<cv::Mat> p3d(C->N_s_tmp);
+    const cv::Mat Twc = Converter::toInvMatrix(C->mTcw);
+    for (int i = 0; i < C->N_s_tmp; i++) { const float d = mDepthMap.at<float>((int)keys[i].pt.y, (int)keys[i].pt.x); if (d > 0) depth[i] = d; p3d[i] = Optimizer::Get3DinWorld(keys[i], depth[i], mK, Twc); }
+    C->nStaInlierID = inlierID; C->mvStatKeysTmp = keys; C->mvStatDepthTmp = depth; C->mvStat3DPointTmp = p3d; C->mvFlowNext = flows; C->mvCorres = corres;
+
+    // ---- objects (:3116-3289)
+    std::vector<cv::KeyPoint> okeys, ocorr; std::vector<float> odep; std::vector<cv::Point2f> oflow; std::vector<int> osem, oinl, olab;
+    const auto& InSet = C->vnObjInlierID; std::vector<int> cnt(InSet.size());
+    for (size_t i = 0; i < InSet.size(); i++) {
+        if (!C->bObjStat[i]) { cnt[i] = -1; continue; }
+        int count = 0;
+        for (int id : InSet[i]) {
+            const int x = (int)C->mvObjKeys[id].pt.x, y = (int)C->mvObjKeys[id].pt.y;
+            if (x >= W || y >= H || x <= 0 || y <= 0) continue;
+            const float d = mDepthMap.at<float>(y, x);
+            if (mSegMap.at<int32_t>(y, x) != 0 && d < 25 && d > 0) {
+                const cv::Vec2f fl = mFlowMap.at<cv::Vec2f>(y, x);
+                if (x + fl[0] < W && y + fl[1] < H && x + fl[0] > 0 && y + fl[1] > 0) {
+                    okeys.push_back(cv::KeyPoint((float)x, (float)y, 0, 0, 0, -1)); odep.push_back(d); osem.push_back(mSegMap.at<int32_t>(y, x)); oflow.push_back(cv::Point2f(fl[0], fl[1]));
+                    ocorr.push_back(cv::KeyPoint(x + fl[0], y + fl[1], 0, 0, 0, -1)); oinl.push_back(id); olab.push_back(C->vObjLabel[id]); count++;
+                }
+            }
+        }
+        cnt[i] = count;
+    }
+    const std::vector<cv::KeyPoint> ocheck = okeys;
+    for (size_t i = 0; i < C->vnObjID.size(); i++) {
+        if (!C->bObjStat[i]) continue;
+        const int SemLabel = C->nSemPosition[i]; int tot_o = cnt[i], sid = 0; const int ostep = 15;
+        while (tot_o < max_num_obj) {
+            if (sid == ostep) break;
+            for (size_t j = sid; j < mvTmpSemObjLabel.size(); j += ostep) {
+                if (mvTmpSemObjLabel[j] != SemLabel) continue;
+                bool used = false; float min_dist = 100;
+                for (const cv::KeyPoint& k : ocheck) { const float dx = k.pt.x - mvTmpObjKeys[j].pt.x, dy = k.pt.y - mvTmpObjKeys[j].pt.y, dd = std::sqrt(dx * dx + dy * dy); if (dd < min_dist) min_dist = dd; if (min_dist < 1.0f) { used = true; break; } }
+                if (used) continue;
+                okeys.push_back(mvTmpObjKeys[j]); odep.push_back(mvTmpObjDepth[j]); osem.push_back(mvTmpSemObjLabel[j]); oflow.push_back(mvTmpObjFlowNext[j]); ocorr.push_back(mvTmpObjCorres[j]);
+                oinl.push_back(-1); olab.push_back(C->nModLabel[i]); tot_o++;
+                if (tot_o >= max_num_obj) break;
+            }
+            sid++;
+        }
+    }
+    std::vector<int> UniLab = mvTmpSemObjLabel; std::sort(UniLab.begin(), UniLab.end()); UniLab.erase(std::unique(UniLab.begin(), UniLab.end()), UniLab.end());
+    std::vector<bool> known(UniLab.size(), false);
+    for (size_t i = 0; i < C->nSemPosition.size(); i++) for (size_t j = 0; j < UniLab.size(); j++) if (UniLab[j] == C->nSemPosition[i] && C->bObjStat[i]) { known[j] = true; break; }
+    for (size_t i = 0; i < known.size(); i++) if (!known[i]) for (size_t j = 0; j < mvTmpSemObjLabel.size(); j++) if (UniLab[i] == mvTmpSemObjLabel[j]) {
+        okeys.push_back(mvTmpObjKeys[j]); odep.push_back(mvTmpObjDepth[j]); osem.push_back(mvTmpSemObjLabel[j]); oflow.push_back(mvTmpObjFlowNext[j]); ocorr.push_back(mvTmpObjCorres[j]); oinl.push_back(-1); olab.push_back(-2);
+    }
+    std::vector<cv::Mat> o3d(okeys.size());
+    for (size_t i = 0; i < okeys.size(); i++) o3d[i] = Optimizer::Get3DinWorld(okeys[i], odep[i], mK, Twc);
+    C->mvObjKeys = okeys; C->mvObjDepth = odep; C->mvObj3DPoint = o3d; C->mvObjCorres = ocorr; C->mvObjFlowNext = oflow; C->vSemObjLabel = osem; C->nDynInlierID = oinl; C->vObjLabel = olab;
+}
+
+void Tracking::Track()                                        // Tracking.cc:1081-1509
+{
+    if (mState == NO_IMAGES_YET) mState = NOT_INITIALIZED;
+    Frame* C = mpCurrentFrame;
+    if (mState == NOT_INITIALIZED) { Initialization(); if (mState != OK) return; }
+    else {
+        Frame* L = mpLastFrame;
+        for (int i = 0; i < C->N_s; i++) TemperalMatch[i] = i;
+        if (TemperalMatch.size() < 2) { C->SetPose(L->mTcw); return; }
+        auto t0 = std::chrono::steady_clock::now();
+        cv::Mat iniTcw = GetInitModelCam(TemperalMatch, TemperalMatch_subset);
+        C->SetPose(iniTcw);
+        if (bJoint) Optimizer::PoseOptimizationFlow2Cam(C, L, TemperalMatch_subset); else Optimizer::PoseOptimizationNew(C, L, TemperalMatch_subset);
+        all_timing[1] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (!L->mTcw.empty()) mVelocity = C->mTcw * Converter::toInvMatrix(L->mTcw);
+        GetSceneFlowObj();
+        t0 = std::chrono::steady_clock::now();
+        std::vector<std::vector<int> > ObjIdNew = DynObjTracking();
+        all_timing[2] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        const size_t no = ObjIdNew.size();
+        C->bObjStat.assign(no, true); C->vObjMod.resize(no); C->vSpeed.resize(no); C->vObjCentre3D.resize(no); C->vnObjID.resize(no); C->vnObjInlierID.resize(no);
+        t0 = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < no; i++) {
+            cv::Mat centre = vec3(0, 0, 0); int nvalid = 0;
+            for (int id : ObjIdNew[i]) { cv::Mat X = L->UnprojectStereoObject(id, 0); if (X.empty()) continue; for (int a = 0; a < 3; a++) centre.at<float>(a) += X.at<float>(a); nvalid++; }
+            for (int a = 0; a < 3; a++) centre.at<float>(a) /= (float)ObjIdNew[i].size();
+            C->vObjCentre3D[i] = centre; C->vnObjID[i] = ObjIdNew[i];
+            std::vector<int> in_ids;
+            C->mInitModel = GetInitModelObj(ObjIdNew[i], in_ids, (int)i);
+            if (in_ids.size() < 50) { C->bObjStat[i] = false; C->vObjMod[i] = cv::Mat::eye(4, 4, CV_32F); C->vObjCentre3D[i] = vec3(0, 0, 0); C->vSpeed[i] = cv::Point2f(0, 0); C->vnObjInlierID[i] = in_ids; continue; }
+            std::vector<int> InlierID;
+            if (bJoint) { cv::Mat X = Optimizer::PoseOptimizationFlow2(C, L, in_ids, InlierID); C->vObjMod[i] = Converter::toInvMatrix(C->mTcw) * X; }
+            else C->vObjMod[i] = Optimizer::PoseOptimizationObjMot(C, L, in_ids, InlierID);
+            C->vnObjInlierID[i] = InlierID;
+            const cv::Mat& Hm = C->vObjMod[i]; float v[3];       // speed = |t - (I - R) c| * 36   (:1295-1302)
+            for (int r = 0; r < 3; r++) { float s = Hm.at<float>(r, 3); for (int c2 = 0; c2 < 3; c2++) s -= ((r == c2 ? 1.f : 0.f) - Hm.at<float>(r, c2)) * centre.at<float>(c2); v[r] = s; }
+            C->vSpeed[i].x = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * 36 * 36;
+        }
+        all_timing[3] = no ? std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() / no : 0.f;
+        t0 = std::chrono::steady_clock::now();
+        RenewFrameInfo(TemperalMatch_subset);
+        all_timing[4] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        mpMap->vfAll_time.push_back(all_timing);
+        C->mpPrevFrame = L; L->mpNextFrame = C;
+        mpLastFrame = C; mpLastFrame->mvStatKeys = C->mvStatKeysTmp; mpLastFrame->mvStatDepth = C->mvStatDepthTmp; mpLastFrame->N_s = C->N_s_tmp;
+        mpMap->vpFeatSta.push_back(C->mvStatKeysTmp); mpMap->vfDepSta.push_back(C->mvStatDepthTmp); mpMap->vp3DPointSta.push_back(C->mvStat3DPointTmp); mpMap->vnAssoSta.push_back(C->nStaInlierID);
+        mpMap->vpFeatDyn.push_back(C->mvObjKeys); mpMap->vfDepDyn.push_back(C->mvObjDepth); mpMap->vp3DPointDyn.push_back(C->mvObj3DPoint); mpMap->vnAssoDyn.push_back(C->nDynInlierID); mpMap->vnFeatLabel.push_back(C->vObjLabel);
+        mpMap->TrackletSta = GetStaticTrack(); mpMap->TrackletDyn = GetDynamicTrackNew();
+        cv::Mat Twc = Converter::toInvMatrix(C->mTcw);
+        mpMap->vmCameraPose.push_back(Twc); mpMap->vmCameraPose_RF.push_back(Twc);
+        std::vector<cv::Mat> Mot, Cen; std::vector<int> MotLab, SemLab; std::vector<bool> Stat;
+        Mot.push_back(Converter::toInvMatrix(mVelocity)); MotLab.push_back(0); SemLab.push_back(0); Stat.push_back(true); Cen.push_back(vec3(0, 0, 0));
+        for (size_t i = 0; i < C->vObjMod.size(); i++) { if (!C->bObjStat[i]) continue; Stat.push_back(true); Mot.push_back(C->vObjMod[i]); MotLab.push_back(C->nModLabel[i]); SemLab.push_back(C->nSemPosition[i]); Cen.push_back(C->vObjCentre3D[i]); }
+        mpMap->vmRigidMotion.push_back(Mot); mpMap->vmRigidMotion_RF.push_back(Mot); mpMap->vnRMLabel.push_back(MotLab); mpMap->vnSMLabel.push_back(SemLab); mpMap->vbObjStat.push_back(Stat); mpMap->vmRigidCentre.push_back(Cen);
+        mpMap->AddFrame(C);
+        // local batch optimisation every frame (:1430-1451)
+        const int window = f_id < nWINDOW_SIZE ? f_id : nWINDOW_SIZE;
+        t0 = std::chrono::steady_clock::now();
+        Optimizer::PartialBatchOptimization(mpMap, mK, window);
+        mpMap->fLBA_time.push_back(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    if (f_id == StopFrame && mTestData == KITTI) { Optimizer::FullBatchOptimization(mpMap, mK); f_id = 0; }   // :1489-1498
+    mState = OK;
+}
+
+// ---- System ------------------------------------------------------------------------------------------------------------------------
+System::~System() { delete mpTracker; delete mpMap; }
+void System::Init(const std::string& strSettingsFile, const eSensor sensor)    // System.cc:23-48
+{
+    mSensor = sensor;
+    if (sensor != RGBD) throw std::runtime_error("System::Init: only the RGBD sensor path is built (IMU_RGBD / VIO is out of scope)");
+    mpMap = new Map();
+    mpTracker = new Tracking(this, mpMap, strSettingsFile, (int)sensor);
+}
+cv::Mat System::TrackRGBD(const cv::Mat& im, cv::Mat& depthmap, const cv::Mat& flowmap, const cv::Mat& masksem, const cv::Mat& Tgt,
+                          const std::vector<std::vector<float> >& vObjPose_gt, const double& ts, cv::Mat& imTraj, const int& nImage)
+{
+    if (mSensor != RGBD) throw std::runtime_error("ERROR: you called TrackRGBD but input sensor was not set to RGBD.");
+    return mpTracker->GrabImageRGBD(im, depthmap, flowmap, masksem, Tgt, vObjPose_gt, ts, imTraj, nImage);
+}
+void System::SaveResultsIJRR2020(const std::string& prefix)   // System.cc:80-240 (pose / motion files; GT files are not produced)
+{
+    auto dump = [](const std::string& path, const std::vector<cv::Mat>& poses) {
+        FILE* f = fopen(path.c_str(), "w"); if (!f) return;
+        for (size_t i = 0; i < poses.size(); i++) { fprintf(f, "%zu", i); for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) fprintf(f, " %.9f", poses[i].at<float>(r, c)); fprintf(f, "\n"); }
+        fclose(f);
+    };
+    dump(prefix + "initial_rgbd_new.txt", mpMap->vmCameraPose); dump(prefix + "refined_rgbd_new.txt", mpMap->vmCameraPose_RF);
+    FILE* f = fopen((prefix + "obj_mot_rgbd_new.txt").c_str(), "w");
+    if (f) {
+        for (size_t i = 0; i < mpMap->vmRigidMotion.size(); i++) for (size_t j = 1; j < mpMap->vmRigidMotion[i].size(); j++) {
+            fprintf(f, "%zu %d", i, mpMap->vnRMLabel[i][j]); const cv::Mat& M = mpMap->vmRigidMotion[i][j];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) fprintf(f, " %.9f", M.at<float>(r, c));
+            fprintf(f, " 0 0 0 1\n");
+        }
+        fclose(f);
+    }
+}
+
+}  // namespace VIDO_SLAM

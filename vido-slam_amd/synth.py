@@ -89,3 +89,68 @@ class Sequence:
     def __iter__(self):
         for k in range(self.n):
             yield self.frame(k)
+
+
+class Scene3D:
+    """Geometrically consistent RGB-D + flow + mask sequence: a textured ground plane
+    (y = ground_y, camera looks along +z with y down) and a far wall (z = wall_z), plus moving fronto-parallel
+    textured squares (instance labels 1..), seen from a camera that drives forward with a slow yaw.  Everything is
+    rendered by ray casting, so depth is exact, flow(k) is the exact projection of the same surface point into
+    frame k+1 (objects move between the frames), and the ground-truth poses are known."""
+
+    def __init__(self, n_frames=12, w=640, h=480, K=(500.0, 500.0, 319.5, 239.5), seed=3, step=0.25, yaw_deg=0.4,
+                 objects=((-2.0, 0.2, 9.0, 0.10, 0.0, 0.05),)):
+        self.n, self.w, self.h, self.K = n_frames, w, h, K
+        self.ground_y, self.wall_z = 1.6, 32.0
+        self.tex = make_canvas(1024, 1024, seed, n_rect=600).astype(np.float32)
+        self.otex = [make_canvas(256, 256, seed + 17 * (i + 1), n_rect=40).astype(np.float32) for i in range(len(objects))]
+        self.objects = objects          # (x, y, z, vx, vy, vz) of the square centre at frame 0, metres / frame
+        self.obj_half = 1.1
+        self.poses = []                 # camera-to-world 4x4
+        T = np.eye(4)
+        for k in range(n_frames + 1):
+            self.poses.append(T.copy())
+            a = np.deg2rad(yaw_deg)
+            d = np.eye(4); d[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]); d[2, 3] = step
+            T = T @ d
+        fx, fy, cx, cy = K
+        u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+        self.rays = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], -1)        # camera frame, z = 1
+        self.uv = np.stack([u, v], -1)
+
+    def _sample(self, tex, a, b, scale):
+        th, tw = tex.shape
+        x = (a * scale) % (tw - 1); y = (b * scale) % (th - 1)
+        x0 = np.floor(x).astype(int); y0 = np.floor(y).astype(int); fx = x - x0; fy = y - y0
+        return tex[y0, x0] * (1 - fx) * (1 - fy) + tex[y0, x0 + 1] * fx * (1 - fy) + tex[y0 + 1, x0] * (1 - fx) * fy + tex[y0 + 1, x0 + 1] * fx * fy
+
+    def Tcw(self, k):
+        return np.linalg.inv(self.poses[k])
+
+    def frame(self, k):
+        w, h = self.w, self.h; fx, fy, cx, cy = self.K
+        Twc, Tcw_next = self.poses[k], np.linalg.inv(self.poses[k + 1])
+        o = Twc[:3, 3]; d = self.rays @ Twc[:3, :3].T                                   # world ray directions (per unit camera z)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tg = np.where(d[..., 1] > 1e-6, (self.ground_y - o[1]) / d[..., 1], np.inf)
+            tw_ = np.where(d[..., 2] > 1e-6, (self.wall_z - o[2]) / d[..., 2], np.inf)
+        t = np.minimum(tg, tw_); is_ground = tg <= tw_
+        X = o + d * t[..., None]
+        gray = np.where(is_ground, self._sample(self.tex, X[..., 0] + 200, X[..., 2] + 50, 14.0), self._sample(self.tex, X[..., 0] + 300, X[..., 1] + 40, 9.0))
+        Xn = X.copy()                                                                  # where the surface point is at frame k+1 (static)
+        mask = np.zeros((h, w), np.int32)
+        for i, (ox, oy, oz, vx, vy, vz) in enumerate(self.objects):
+            c = np.array([ox + vx * k, oy + vy * k, oz + vz * k])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                to = np.where(d[..., 2] > 1e-6, (c[2] - o[2]) / d[..., 2], np.inf)
+            P = o + d * to[..., None]
+            hit = (np.abs(P[..., 0] - c[0]) < self.obj_half) & (np.abs(P[..., 1] - c[1]) < self.obj_half) & (to < t) & (to > 0)
+            gray = np.where(hit, self._sample(self.otex[i], P[..., 0] - c[0] + 2, P[..., 1] - c[1] + 2, 50.0), gray)
+            t = np.where(hit, to, t); X = np.where(hit[..., None], P, X); Xn = np.where(hit[..., None], P + np.array([vx, vy, vz]), Xn)
+            mask[hit] = i + 1
+        depth = t.astype(np.float32)                                                   # rays have camera z = 1  =>  t is the depth
+        Xc = Xn @ Tcw_next[:3, :3].T + Tcw_next[:3, 3]
+        un = Xc[..., 0] / Xc[..., 2] * fx + cx; vn = Xc[..., 1] / Xc[..., 2] * fy + cy
+        flow = np.stack([un - self.uv[..., 0], vn - self.uv[..., 1]], -1).astype(np.float32)
+        g8 = np.clip(np.rint(gray), 0, 255).astype(np.uint8)
+        return g8, depth, flow, mask
