@@ -38,7 +38,7 @@ def test_offline_clip_recovers_ground_truth_poses(tmp_path, vido):
     import build
     driver = build.build_driver()
     n = 10
-    scene = vido.synth.Scene3D(n_frames=n, seed=3)
+    scene = vido.synth.Scene3D(n_frames=n, seed=3, objects=((-2.0, 0.2, 9.0, 0.25, 0.0, 0.05),))   # scene flow 0.255 m/frame > SFMgThres
     cfg = write_clip(str(tmp_path), scene, n)
     out = os.path.join(str(tmp_path), "poses.txt")
     r = subprocess.run([driver, cfg, out, os.path.join(str(tmp_path), "res_")], capture_output=True, text=True, timeout=300)
@@ -56,4 +56,9 @@ def test_offline_clip_recovers_ground_truth_poses(tmp_path, vido):
     ref = np.loadtxt(os.path.join(str(tmp_path), "res_refined_rgbd_new.txt"))
     assert ref.shape == (n, 17)
     mot = np.loadtxt(os.path.join(str(tmp_path), "res_obj_mot_rgbd_new.txt"), ndmin=2)
-    assert mot.shape[1] == 18
+    assert mot.shape[1] == 18 and len(mot) >= n - 3
+    # the square translates by (0.25, 0, 0.05) m per frame in the world: the estimated object motions must say so
+    for row in mot:
+        H = row[2:14].reshape(3, 4)
+        assert np.abs(H[:, :3] - np.eye(3)).max() < 0.02 and np.abs(H[:, 3] - np.array([0.25, 0.0, 0.05])).max() < 0.05, row
+    assert set(mot[:, 1].astype(int)) == {1}                                # one consistently tracked object id
