@@ -188,10 +188,11 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BaDev P)
     }
 }
 
-// odometry edges (k < n_odo) and the prior (k == n_odo)
-__global__ void k_ba_camfactors(BaDev P, int with_jac, const double* cam, double* chi_out)
+// odometry edges (k < n_odo) and the prior (k == n_odo): one wave per factor, lane a*6+b owns entry (a,b) of the
+// 6x6 blocks (the residual and Jacobians are cheap and recomputed by every lane)
+__global__ __launch_bounds__(64) void k_ba_camfactors(BaDev P, int with_jac, const double* cam, double* chi_out)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.x, lane = threadIdx.x;
     const int n = P.n_odo + (P.prior_cam >= 0 ? 1 : 0);
     if (k >= n) return;
     const bool is_prior = k == P.n_odo;
@@ -202,20 +203,19 @@ __global__ void k_ba_camfactors(BaDev P, int with_jac, const double* cam, double
     const double info = is_prior ? P.info_prior : P.info_odo;
     double r0 = info * s2, w = 1;
     if (!is_prior) huber_w(info * s2, P.huber_odo, P.use_huber, r0, w);
-    atomicAdd(chi_out, r0);
-    if (!with_jac) return;
+    if (lane == 0) atomicAdd(chi_out, r0);
+    if (!with_jac || lane >= 36) return;
     const double wo = w * info;
-    for (int a = 0; a < 6; a++) {
-        double sj = 0, si = 0;
-        for (int r = 0; r < 6; r++) { sj += Jj[r * 6 + a] * e[r]; if (!is_prior) si += Ji[r * 6 + a] * e[r]; }
-        atomicAdd(P.bc + 6 * j + a, -wo * sj); if (!is_prior) atomicAdd(P.bc + 6 * i + a, -wo * si);
-        for (int b = 0; b < 6; b++) {
-            double hjj = 0, hii = 0, hij = 0;
-            for (int r = 0; r < 6; r++) { hjj += Jj[r * 6 + a] * Jj[r * 6 + b]; if (!is_prior) { hii += Ji[r * 6 + a] * Ji[r * 6 + b]; hij += Ji[r * 6 + a] * Jj[r * 6 + b]; } }
-            atomicAdd(P.Hcd + 36 * j + a * 6 + b, wo * hjj);
-            if (!is_prior) { atomicAdd(P.Hcd + 36 * i + a * 6 + b, wo * hii); P.Hodo[36 * k + a * 6 + b] = wo * hij; }
-        }
+    const int a = lane / 6, b = lane - a * 6;
+    double hjj = 0, hii = 0, hij = 0, sj = 0, si = 0;
+    for (int r = 0; r < 6; r++) {
+        hjj += Jj[r * 6 + a] * Jj[r * 6 + b];
+        if (!is_prior) { hii += Ji[r * 6 + a] * Ji[r * 6 + b]; hij += Ji[r * 6 + a] * Jj[r * 6 + b]; }
+        if (b == 0) { sj += Jj[r * 6 + a] * e[r]; if (!is_prior) si += Ji[r * 6 + a] * e[r]; }
     }
+    atomicAdd(P.Hcd + 36 * j + a * 6 + b, wo * hjj);
+    if (!is_prior) { atomicAdd(P.Hcd + 36 * i + a * 6 + b, wo * hii); P.Hodo[36 * k + a * 6 + b] = wo * hij; }
+    if (b == 0) { atomicAdd(P.bc + 6 * j + a, -wo * sj); if (!is_prior) atomicAdd(P.bc + 6 * i + a, -wo * si); }
 }
 
 // max |diag| over camera blocks and landmark blocks (computeLambdaInit)
@@ -257,50 +257,82 @@ __global__ void k_ba_add_odo(BaDev P)
 
 // ---- Schur complement: one wave per landmark ------------------------------------------------------------
 // LDS_S: the whole reduced system lives in LDS (n6 <= BA_LDS_MAX_N6) and is flushed once per workgroup.
-template <bool LDS_S>
-__global__ __launch_bounds__(256) void k_ba_schur(BaDev P, int n_ptl, double lambda, int kcap, double* S_part /*[grid][n6*n6 + n6] when LDS_S*/)
+// Only the LOWER triangle of S is produced (the Cholesky kernels read nothing else): slots of a landmark are in
+// ascending camera order, so slot pairs (i >= j) are exactly the blocks (ci >= cj).
+// MODE 0: the whole reduced system lives in LDS (n6 <= BA_LDS_MAX_N6, the local-BA window), flushed once per workgroup.
+// MODE 1: FP64 atomics straight into the dense S in HBM.
+// MODE 2: workgroups walk chunks of BA_CHUNK consecutive landmarks; landmark ids are contiguous in time for a SLAM
+//         map, so a chunk touches a short run of cameras: a BA_WC-camera window of S is accumulated in LDS and flushed
+//         once per chunk (blocks that fall outside the window go to HBM atomics directly).
+#define BA_WC 16
+#define BA_CHUNK 64
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ba_schur(BaDev P, int n_ptl, double lambda, int kcap, double* S_part /*[grid][n6*n6 + n6], MODE 0*/,
+                                                  const int* __restrict__ chunk_cmin /*MODE 2*/)
 {
     extern __shared__ double lds[];
     const int n6 = P.n6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    double* Sl = lds;                                        // [n6*n6 + n6] when LDS_S
-    double* stage = lds + (LDS_S ? (size_t)n6 * n6 + n6 : 0) + (size_t)wave * (2 * kcap * 18);   // W, WD of up to kcap obs per wave
-    if (LDS_S) { for (int t = threadIdx.x; t < n6 * n6 + n6; t += blockDim.x) Sl[t] = 0; __syncthreads(); }
-    for (int l = blockIdx.x * nw + wave; l < n_ptl; l += gridDim.x * nw) {
-        const int beg = P.pt_start[l], k = min(P.pt_start[l + 1] - beg, kcap);
-        double Di[9]; inv3sym(P.Hpp + 6 * (size_t)l, lambda, Di);
-        const double b0 = P.bp[3 * (size_t)l], b1 = P.bp[3 * (size_t)l + 1], b2 = P.bp[3 * (size_t)l + 2];
-        double* Wl = stage; double* WDl = stage + kcap * 18;
-        for (int t = lane; t < k * 18; t += 64) Wl[t] = P.W[18 * (size_t)beg + t];
-        __builtin_amdgcn_wave_barrier();
-        for (int t = lane; t < k * 6; t += 64) {              // WD = W * Di, row t of the stacked (6k x 3)
-            const double w0 = Wl[t * 3], w1 = Wl[t * 3 + 1], w2 = Wl[t * 3 + 2];
-            const double d0 = w0 * Di[0] + w1 * Di[3] + w2 * Di[6], d1 = w0 * Di[1] + w1 * Di[4] + w2 * Di[7], d2 = w0 * Di[2] + w1 * Di[5] + w2 * Di[8];
-            WDl[t * 3] = d0; WDl[t * 3 + 1] = d1; WDl[t * 3 + 2] = d2;
-            const int c = P.slot_cam[beg + t / 6];
-            const double rv = -(d0 * b0 + d1 * b1 + d2 * b2);
-            if (LDS_S) atomicAdd(Sl + (size_t)n6 * n6 + 6 * c + t % 6, rv); else atomicAdd(P.r + 6 * c + t % 6, rv);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // all ordered pairs (i, j): block (ci, cj) -= WD_i W_j^T ; one 6x6 block per lane-iteration
-        for (int pq = lane; pq < k * k; pq += 64) {
-            const int i = pq / k, j = pq - i * k;
-            const int ci = P.slot_cam[beg + i], cj = P.slot_cam[beg + j];
-            const double* A = WDl + i * 18; const double* Bm = Wl + j * 18;
+    const int wn = MODE == 0 ? n6 : BA_WC * 6;                 // side of the LDS-resident (window of) S
+    double* Sl = lds;                                        // [wn*wn + wn] for MODE 0 / 2
+    double* stage = lds + (MODE == 1 ? 0 : (size_t)wn * wn + wn) + (size_t)wave * (2 * kcap * 18);   // W, WD of up to kcap obs per wave
+    const int n_units = MODE == 2 ? (n_ptl + BA_CHUNK - 1) / BA_CHUNK : 1;
+    for (int unit = MODE == 2 ? blockIdx.x : 0; unit < n_units; unit += MODE == 2 ? gridDim.x : 1) {
+        int cbase = 0, l_beg, l_end, l_step;
+        if (MODE == 2) { cbase = chunk_cmin[unit]; l_beg = unit * BA_CHUNK + wave; l_end = min(n_ptl, (unit + 1) * BA_CHUNK); l_step = nw; }
+        else { l_beg = blockIdx.x * nw + wave; l_end = n_ptl; l_step = gridDim.x * nw; }
+        if (MODE != 1) { for (int t = threadIdx.x; t < wn * wn + wn; t += blockDim.x) Sl[t] = 0; __syncthreads(); }
+        for (int l = l_beg; l < l_end; l += l_step) {
+            const int beg = P.pt_start[l], k = min(P.pt_start[l + 1] - beg, kcap);
+            double Di[9]; inv3sym(P.Hpp + 6 * (size_t)l, lambda, Di);
+            const double b0 = P.bp[3 * (size_t)l], b1 = P.bp[3 * (size_t)l + 1], b2 = P.bp[3 * (size_t)l + 2];
+            double* Wl = stage; double* WDl = stage + kcap * 18;
+            for (int t = lane; t < k * 18; t += 64) Wl[t] = P.W[18 * (size_t)beg + t];
+            __builtin_amdgcn_wave_barrier();
+            for (int t = lane; t < k * 6; t += 64) {              // WD = W * Di, row t of the stacked (6k x 3)
+                const double w0 = Wl[t * 3], w1 = Wl[t * 3 + 1], w2 = Wl[t * 3 + 2];
+                const double d0 = w0 * Di[0] + w1 * Di[3] + w2 * Di[6], d1 = w0 * Di[1] + w1 * Di[4] + w2 * Di[7], d2 = w0 * Di[2] + w1 * Di[5] + w2 * Di[8];
+                WDl[t * 3] = d0; WDl[t * 3 + 1] = d1; WDl[t * 3 + 2] = d2;
+                const int c = P.slot_cam[beg + t / 6] - cbase;
+                const double rv = -(d0 * b0 + d1 * b1 + d2 * b2);
+                if (MODE == 1 || (MODE == 2 && (c < 0 || c >= BA_WC))) atomicAdd(P.r + 6 * (c + cbase) + t % 6, rv);
+                else atomicAdd(Sl + (size_t)wn * wn + 6 * c + t % 6, rv);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // slot pairs (i >= j): block (ci, cj) -= WD_i W_j^T ; one 6x6 block per lane-iteration
+            const int npair = k * (k + 1) / 2;
+            for (int pq = lane; pq < npair; pq += 64) {
+                int i = (int)((sqrtf(8.f * (float)pq + 1.f) - 1.f) * 0.5f);
+                while (i * (i + 1) / 2 > pq) i--;
+                while ((i + 1) * (i + 2) / 2 <= pq) i++;
+                const int j = pq - i * (i + 1) / 2;
+                const int ci = P.slot_cam[beg + i] - cbase, cj = P.slot_cam[beg + j] - cbase;
+                const double* A = WDl + i * 18; const double* Bm = Wl + j * 18;
+                const bool to_hbm = MODE == 1 || (MODE == 2 && (cj < 0 || ci >= BA_WC));       // ci >= cj
 #pragma unroll
-            for (int a = 0; a < 6; a++)
+                for (int a = 0; a < 6; a++)
 #pragma unroll
-                for (int b = 0; b < 6; b++) {
-                    const double v = -(A[a * 3] * Bm[b * 3] + A[a * 3 + 1] * Bm[b * 3 + 1] + A[a * 3 + 2] * Bm[b * 3 + 2]);
-                    if (LDS_S) atomicAdd(Sl + (size_t)(6 * ci + a) * n6 + 6 * cj + b, v);
-                    else atomicAdd(P.S + (size_t)(6 * ci + a) * n6 + 6 * cj + b, v);
-                }
+                    for (int b = 0; b < 6; b++) {
+                        const double v = -(A[a * 3] * Bm[b * 3] + A[a * 3 + 1] * Bm[b * 3 + 1] + A[a * 3 + 2] * Bm[b * 3 + 2]);
+                        if (to_hbm) atomicAdd(P.S + (size_t)(6 * (ci + cbase) + a) * n6 + 6 * (cj + cbase) + b, v);
+                        else atomicAdd(Sl + (size_t)(6 * ci + a) * wn + 6 * cj + b, v);
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (LDS_S) {
-        __syncthreads();
-        double* out = S_part + (size_t)blockIdx.x * ((size_t)n6 * n6 + n6);
-        for (int t = threadIdx.x; t < n6 * n6 + n6; t += blockDim.x) out[t] = Sl[t];
+        if (MODE == 0) {
+            __syncthreads();
+            double* out = S_part + (size_t)blockIdx.x * ((size_t)n6 * n6 + n6);
+            for (int t = threadIdx.x; t < n6 * n6 + n6; t += blockDim.x) out[t] = Sl[t];
+        }
+        if (MODE == 2) {                                          // flush the window: one HBM atomic per touched entry
+            __syncthreads();
+            for (int t = threadIdx.x; t < wn * wn; t += blockDim.x) {
+                const double v = Sl[t];
+                if (v != 0.0) { const int r = t / wn, c = t - r * wn; const int gr = 6 * cbase + r, gc = 6 * cbase + c; if (gr < n6 && gc < n6) atomicAdd(P.S + (size_t)gr * n6 + gc, v); }
+            }
+            for (int t = threadIdx.x; t < wn; t += blockDim.x) { const double v = Sl[(size_t)wn * wn + t]; if (v != 0.0 && 6 * cbase + t < n6) atomicAdd(P.r + 6 * cbase + t, v); }
+            __syncthreads();
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_ba_fold_parts(BaDev P, const double* S_part, int nparts)
@@ -343,10 +375,10 @@ __global__ __launch_bounds__(1024) void k_ba_chol_small(BaDev P)
         for (int i = j + 1 + tid; i <= n; i += nt) { const double v = A[i * ld + j] * inv; A[i * ld + j] = v; col[i] = v; }
         __syncthreads();
         if (tid == 0) A[j * ld + j] = sqrt(d);      // after every thread has read the pivot; not touched by the update below
-        const int m = n - j;             // rows j+1 .. n (row n = rhs), columns j+1 .. n-1
-        for (int t = tid; t < m * (m - 1); t += nt) {
-            const int i = j + 1 + t / (m - 1), c = j + 1 + t % (m - 1);
-            if (c <= i) A[i * ld + c] -= col[i] * col[c];
+        // rank-1 update of rows j+1 .. n (row n = rhs), columns j+1 .. min(i, n-1); 32x32 thread tile, no divisions
+        for (int i = j + 1 + (tid >> 5); i <= n; i += 32) {
+            const double ci = col[i]; const int cmax = min(i, n - 1);
+            for (int c = j + 1 + (tid & 31); c <= cmax; c += 32) A[i * ld + c] -= ci * col[c];
         }
         __syncthreads();
     }
@@ -367,7 +399,10 @@ __global__ __launch_bounds__(1024) void k_ba_chol_small(BaDev P)
     if (tid == 0) P.scal[4] = (double)ok;
 }
 
-// blocked right-looking Cholesky in HBM, lower triangle of row-major A (n x n, n any), tile NB = 32.
+// blocked right-looking Cholesky in HBM, lower triangle of the row-major n x n matrix A, tile NB = 32.  The buffer
+// holds one extra row (row n = right-hand side, [S | r] is contiguous): carried through the panel / update kernels it
+// comes out as z = L^-1 r, so the forward substitution is free; the backward substitution L^T x = z walks the block
+// columns from the last to the first with two small launches per block (rows-below dot products, 32x32 solve).
 #define NB 32
 __global__ __launch_bounds__(256) void k_chol_diag(double* A, int n, int k0, double* okflag)
 {
@@ -385,11 +420,11 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* A, int n, int k0, dou
     }
     for (int t = tid; t < nb * nb; t += 256) if (t % nb <= t / nb) A[(size_t)(k0 + t / nb) * n + k0 + t % nb] = T[t / nb][t % nb];
 }
-// panel: rows below the diagonal tile: X L11^T = A21  (each workgroup: NB rows)
-__global__ __launch_bounds__(256) void k_chol_panel(double* A, int n, int k0)
+// panel: rows below the diagonal tile (including the rhs row n): X L11^T = A21  (each workgroup: NB rows)
+__global__ __launch_bounds__(256) void k_chol_panel(double* A, int n, int nrows, int k0)
 {
     __shared__ double L[NB][NB + 1], X[NB][NB + 1];
-    const int nb = min(NB, n - k0), r0 = k0 + nb + blockIdx.x * NB, nr = min(NB, n - r0), tid = threadIdx.x;
+    const int nb = min(NB, n - k0), r0 = k0 + nb + blockIdx.x * NB, nr = min(NB, nrows - r0), tid = threadIdx.x;
     if (nr <= 0) return;
     for (int t = tid; t < nb * nb; t += 256) L[t / nb][t % nb] = A[(size_t)(k0 + t / nb) * n + k0 + t % nb];
     for (int t = tid; t < nr * nb; t += 256) X[t / nb][t % nb] = A[(size_t)(r0 + t / nb) * n + k0 + t % nb];
@@ -400,14 +435,14 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* A, int n, int k0)
     __syncthreads();
     for (int t = tid; t < nr * nb; t += 256) A[(size_t)(r0 + t / nb) * n + k0 + t % nb] = X[t / nb][t % nb];
 }
-// trailing update: A22 -= L21 L21^T on the lower triangle, one NBxNB tile per workgroup
-__global__ __launch_bounds__(256) void k_chol_update(double* A, int n, int k0)
+// trailing update: A22 -= L21 L21^T on the lower triangle (+ the rhs row), one NBxNB tile per workgroup
+__global__ __launch_bounds__(256) void k_chol_update(double* A, int n, int nrows, int k0)
 {
     __shared__ double Pa[NB][NB + 1], Pb[NB][NB + 1];
     const int nb = min(NB, n - k0), base = k0 + nb;
     const int ti = blockIdx.y, tj = blockIdx.x;
     if (tj > ti) return;
-    const int r0 = base + ti * NB, c0 = base + tj * NB, nr = min(NB, n - r0), nc = min(NB, n - c0), tid = threadIdx.x;
+    const int r0 = base + ti * NB, c0 = base + tj * NB, nr = min(NB, nrows - r0), nc = min(NB, n - c0), tid = threadIdx.x;
     if (nr <= 0 || nc <= 0) return;
     for (int t = tid; t < nr * nb; t += 256) Pa[t / nb][t % nb] = A[(size_t)(r0 + t / nb) * n + k0 + t % nb];
     for (int t = tid; t < nc * nb; t += 256) Pb[t / nb][t % nb] = A[(size_t)(c0 + t / nb) * n + k0 + t % nb];
@@ -420,51 +455,34 @@ __global__ __launch_bounds__(256) void k_chol_update(double* A, int n, int k0)
         A[(size_t)(r0 + i) * n + c0 + c] -= s;
     }
 }
-// triangular solves with the factor in HBM: single workgroup of 1024 threads, blocked by NB so that every
-// global access is a contiguous NB-double row segment (x in place in y, y in LDS).
-__global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ A, int n, const double* __restrict__ b, double* __restrict__ x)
+// backward substitution, block column k0: tmp[c] += sum over the rows i below the block of L[i][k0+c] * x[i]
+__global__ __launch_bounds__(256) void k_chol_back_rows(const double* __restrict__ A, int n, int k0, const double* __restrict__ x, double* __restrict__ tmp)
 {
-    extern __shared__ double y[];                         // [n] + [NB*NB] diagonal tile + [16*NB] partials
-    double* T = y + n; double* part = T + NB * NB;
-    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-    for (int t = tid; t < n; t += nt) y[t] = b[t];
+    __shared__ double part[4][NB];
+    const int nb = min(NB, n - k0), i = k0 + nb + blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double acc[NB];
+    const bool act = i < n;
+    const double xi = act ? x[i] : 0.0; const double* row = A + (size_t)(act ? i : 0) * n + k0;
+#pragma unroll
+    for (int c = 0; c < NB; c++) acc[c] = (act && c < nb) ? row[c] * xi : 0.0;
+#pragma unroll
+    for (int c = 0; c < NB; c++) { double v = acc[c];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) part[wave][c] = v; }
     __syncthreads();
-    for (int k0 = 0; k0 < n; k0 += NB) {                  // forward: L z = b
-        const int nb = min(NB, n - k0);
-        for (int t = tid; t < nb * nb; t += nt) T[t] = A[(size_t)(k0 + t / nb) * n + k0 + t % nb];
-        __syncthreads();
-        if (tid == 0) for (int j = 0; j < nb; j++) { double s = y[k0 + j]; for (int c = 0; c < j; c++) s -= T[j * nb + c] * y[k0 + c]; y[k0 + j] = s / T[j * nb + j]; }
-        __syncthreads();
-        for (int i = k0 + nb + tid; i < n; i += nt) {     // rows below: y[i] -= L[i][k0..k0+nb) . z_blk
-            const double* row = A + (size_t)i * n + k0; double s = 0;
-            for (int c = 0; c < nb; c++) s += row[c] * y[k0 + c];
-            y[i] -= s;
-        }
-        __syncthreads();
-    }
-    for (int k0 = ((n - 1) / NB) * NB; k0 >= 0; k0 -= NB) {   // backward: L^T x = z
-        const int nb = min(NB, n - k0);
-        double acc[NB];
-#pragma unroll
-        for (int c = 0; c < NB; c++) acc[c] = 0;
-        for (int i = k0 + nb + tid; i < n; i += nt) {     // s[c] = sum_{i below} L[i][k0+c] * x[i]
-            const double* row = A + (size_t)i * n + k0; const double xi = y[i];
-#pragma unroll
-            for (int c = 0; c < NB; c++) if (c < nb) acc[c] += row[c] * xi;
-        }
-#pragma unroll
-        for (int c = 0; c < NB; c++) { double v = acc[c];
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0) part[wave * NB + c] = v; }
-        for (int t = tid; t < nb * nb; t += nt) T[t] = A[(size_t)(k0 + t / nb) * n + k0 + t % nb];
-        __syncthreads();
-        if (tid < nb) { double s = 0; for (int w = 0; w < nw; w++) s += part[w * NB + tid]; y[k0 + tid] -= s; }
-        __syncthreads();
-        if (tid == 0) for (int j = nb - 1; j >= 0; j--) { double s = y[k0 + j]; for (int c = j + 1; c < nb; c++) s -= T[c * nb + j] * y[k0 + c]; y[k0 + j] = s / T[j * nb + j]; }
-        __syncthreads();
-    }
-    for (int t = tid; t < n; t += nt) x[t] = y[t];
+    if (threadIdx.x < nb) atomicAdd(tmp + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(64) void k_chol_back_diag(const double* __restrict__ A, int n, int k0, double* __restrict__ x, double* __restrict__ tmp)
+{
+    __shared__ double T[NB][NB + 1], y[NB];
+    const int nb = min(NB, n - k0), tid = threadIdx.x;
+    for (int t = tid; t < nb * nb; t += 64) T[t / nb][t % nb] = A[(size_t)(k0 + t / nb) * n + k0 + t % nb];
+    if (tid < nb) { y[tid] = x[k0 + tid] - tmp[tid]; tmp[tid] = 0.0; }
+    __syncthreads();
+    if (tid == 0) for (int j = nb - 1; j >= 0; j--) { double s = y[j]; for (int c = j + 1; c < nb; c++) s -= T[c][j] * y[c]; y[j] = s / T[j][j]; }
+    __syncthreads();
+    if (tid < nb) x[k0 + tid] = y[tid];
 }
 
 // ---- trial state ------------------------------------------------------------------------------------------
@@ -560,18 +578,27 @@ struct Arena {                       // bump allocator over the ctx's persistent
 };
 }
 
-static int chol_large(vido_ctx* ctx, double* A, int n, const double* b, double* x, double* okflag, hipStream_t st)
+// A = [S | r] (n+1 rows of n doubles); on return x = S^-1 r.  tmp: NB doubles of zeroed device scratch.
+static int chol_large(vido_ctx* ctx, double* A, int n, double* x, double* okflag, double* tmp, hipStream_t st)
 {
+    const int nrows = n + 1;
     for (int k0 = 0; k0 < n; k0 += NB) {
         hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, A, n, k0, okflag);
-        const int rem = n - k0 - std::min(NB, n - k0);
-        if (rem > 0) {
-            const int nt = (rem + NB - 1) / NB;
-            hipLaunchKernelGGL(k_chol_panel, dim3(nt), dim3(256), 0, st, A, n, k0);
-            hipLaunchKernelGGL(k_chol_update, dim3(nt, nt), dim3(256), 0, st, A, n, k0);
+        const int nbk = std::min(NB, n - k0), rem_r = nrows - k0 - nbk, rem_c = n - k0 - nbk;
+        if (rem_r > 0) {
+            const int ntr = (rem_r + NB - 1) / NB, ntc = (rem_c + NB - 1) / NB;
+            hipLaunchKernelGGL(k_chol_panel, dim3(ntr), dim3(256), 0, st, A, n, nrows, k0);
+            if (ntc > 0) hipLaunchKernelGGL(k_chol_update, dim3(ntc, ntr), dim3(256), 0, st, A, n, nrows, k0);
         }
     }
-    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), ((size_t)n + NB * NB + 16 * NB) * sizeof(double), st, A, n, b, x);
+    double* z = A + (size_t)n * n;                        // the rhs row now holds z = L^-1 r; solved in place
+    HIP_TRY(ctx, hipMemsetAsync(tmp, 0, NB * sizeof(double), st));
+    for (int k0 = ((n - 1) / NB) * NB; k0 >= 0; k0 -= NB) {
+        const int below = n - k0 - std::min(NB, n - k0);
+        if (below > 0) hipLaunchKernelGGL(k_chol_back_rows, dim3((below + 255) / 256), dim3(256), 0, st, A, n, k0, z, tmp);
+        hipLaunchKernelGGL(k_chol_back_diag, dim3(1), dim3(64), 0, st, A, n, k0, z, tmp);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(x, z, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }
@@ -613,7 +640,7 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
     // ---- device buffers
     {   // size the persistent pool (device + pinned mirror for the uploads) for this problem
         const size_t nd = (size_t)p.n_cam * (24 + 36 + 36) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + 18) + (size_t)p.n_odo * (12 + 36) + (size_t)n6 * n6 + 5 * (size_t)n6 + 64;
-        const size_t ni32 = 4 * (size_t)no + (size_t)n_ptl + 2 * (size_t)p.n_odo + 64;
+        const size_t ni32 = 4 * (size_t)no + (size_t)n_ptl + (size_t)n_ptl / 32 + 2 * (size_t)p.n_odo + 256;
         const size_t need = nd * 8 + ni32 * 4 + 64 * 256;
         if (need > BS->pool_cap) {
             HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -637,6 +664,7 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
     D.Hcd = A.get<double>((size_t)p.n_cam * 36); D.bc = A.get<double>(n6); D.Hodo = A.get<double>((size_t)p.n_odo * 36);
     // S and r are contiguous so that one all-reduce covers both
     double* Sr = A.get<double>((size_t)n6 * n6 + n6); D.S = Sr; D.r = Sr + (size_t)n6 * n6; D.x = A.get<double>(n6);
+    double* chol_tmp = A.get<double>(64);
     double* red = A.get<double>((size_t)p.n_cam * 36 + n6 + 8);      // [Hcd | bc | scal] contiguous for the linearisation all-reduce
     D.Hcd = red; D.bc = red + (size_t)p.n_cam * 36; D.scal = D.bc + n6;
     if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device allocation failed (n6=%d, n_obs=%d)", n6, no);
@@ -649,12 +677,20 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
     }
     const int kcap = std::max(maxk, 1);
     const size_t lds_chol = ((size_t)(n6 + 1) * ((n6 + 1) | 1) + n6 + 2) * sizeof(double);
-    const size_t lds_schur = ((lds_path ? sz_sr : 0) + (size_t)4 * (2 * kcap * 18)) * sizeof(double);
+    const size_t win_sz = (size_t)(BA_WC * 6) * (BA_WC * 6) + BA_WC * 6;
+    const size_t lds_schur = ((lds_path ? sz_sr : win_sz) + (size_t)4 * (2 * kcap * 18)) * sizeof(double);
+    // camera window base of every landmark chunk (the first slot of a landmark is its lowest camera)
+    int* d_chunk_cmin = nullptr; int n_chunks = (n_ptl + BA_CHUNK - 1) / BA_CHUNK;
+    if (!lds_path && n_ptl) {
+        std::vector<int> cmin(n_chunks, 0);
+        for (int c = 0; c < n_chunks; c++) { int m = p.n_cam; for (int l = c * BA_CHUNK; l < std::min(n_ptl, (c + 1) * BA_CHUNK); l++) if (pstart[l + 1] > pstart[l]) m = std::min(m, slotcam[pstart[l]]); cmin[c] = m == p.n_cam ? 0 : m; }
+        d_chunk_cmin = A.put(cmin.data(), n_chunks, st);
+        if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device pool exhausted");
+    }
     if (lds_schur > 160 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "ba: LDS budget exceeded (n6=%d, max track %d)", n6, maxk);
-    if (lds_path) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
+    if (lds_path) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
                     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol)); }
-    else { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur)); }
-    if (!lds_path) HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((n6 + NB * NB + 16 * NB) * sizeof(double))));
+    else { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur)); }
 
     auto AR = [&](double* dptr, size_t cnt, int op) -> int {
         if (!allreduce) return VIDO_OK;
@@ -668,7 +704,7 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
         HIP_TRY(ctx, hipMemsetAsync(D.scal + slot, 0, sizeof(double), st));
         if (no) hipLaunchKernelGGL(k_ba_chi2, dim3((no + 255) / 256), dim3(256), 0, st, D, cam, pt, D.scal + slot);
         const int ncf = D.n_odo + (D.prior_cam >= 0 ? 1 : 0);
-        if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3((ncf + 63) / 64), dim3(64), 0, st, D, 0, cam, D.scal + slot);
+        if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3(ncf), dim3(64), 0, st, D, 0, cam, D.scal + slot);
         int rc = AR(D.scal + slot, 1, 0); if (rc) return rc;
         rc = read_scal(); if (rc) return rc;
         *out = BS->h_scal[slot];
@@ -691,7 +727,7 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
         HIP_TRY(ctx, hipEventRecord(BS->ev1, st));
         n_lin++;
         const int ncf = D.n_odo + (D.prior_cam >= 0 ? 1 : 0);
-        if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3((ncf + 63) / 64), dim3(64), 0, st, D, 1, D.cam, D.scal + 0);
+        if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3(ncf), dim3(64), 0, st, D, 1, D.cam, D.scal + 0);
         if (it == 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3(64), dim3(256), 0, st, D, n_ptl);
         HIP_TRY(ctx, hipGetLastError());
         if (allreduce) {     // camera diagonal blocks, bc, chi2 (sum) — then the max-diagonal (max) on its own
@@ -716,22 +752,22 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
             if (add_cam && D.n_odo) hipLaunchKernelGGL(k_ba_add_odo, dim3((D.n_odo * 36 + 255) / 256), dim3(256), 0, st, D);
             if (n_ptl) {
                 if (lds_path) {
-                    hipLaunchKernelGGL(k_ba_schur<true>, dim3(schur_grid), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, BS->d_parts);
+                    hipLaunchKernelGGL(k_ba_schur<0>, dim3(schur_grid), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, BS->d_parts, (const int*)nullptr);
                     hipLaunchKernelGGL(k_ba_fold_parts, dim3(std::min(256, (int)((sz_sr + 255) / 256))), dim3(256), 0, st, D, BS->d_parts, schur_grid);
-                } else hipLaunchKernelGGL(k_ba_schur<false>, dim3(schur_grid), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, nullptr);
+                } else hipLaunchKernelGGL(k_ba_schur<2>, dim3(std::min(n_chunks, 1024)), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, (double*)nullptr, (const int*)d_chunk_cmin);
             }
             HIP_TRY(ctx, hipGetLastError());
             if ((rc = AR(Sr, sz_sr, 0))) return rc;
             // ---- replicated reduced solve
             HIP_TRY(ctx, hipMemsetAsync(D.scal + 2, 0, 2 * sizeof(double), st));
             if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
-            else { const double one = 1.0; HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4, &one, 8, hipMemcpyHostToDevice, st)); if ((rc = chol_large(ctx, D.S, n6, D.r, D.x, D.scal + 4, st))) return rc; }
+            else { const double one = 1.0; HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4, &one, 8, hipMemcpyHostToDevice, st)); if ((rc = chol_large(ctx, D.S, n6, D.x, D.scal + 4, chol_tmp, st))) return rc; }
             // ---- trial state + its chi2
             hipLaunchKernelGGL(k_ba_update_cams, dim3((p.n_cam + 63) / 64), dim3(64), 0, st, D, (allreduce && p.rank != 0) ? 0.0 : lambda);
             if (allreduce && p.rank != 0) HIP_TRY(ctx, hipMemsetAsync(D.scal + 3, 0, sizeof(double), st));      // camera part of computeScale counted once (rank 0)
             if (n_ptl) hipLaunchKernelGGL(k_ba_backsub, dim3((n_ptl + 255) / 256), dim3(256), 0, st, D, n_ptl, lambda);
             if (no) hipLaunchKernelGGL(k_ba_chi2, dim3((no + 255) / 256), dim3(256), 0, st, D, D.cam_new, D.pt_new, D.scal + 2);
-            if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3((ncf + 63) / 64), dim3(64), 0, st, D, 0, D.cam_new, D.scal + 2);
+            if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3(ncf), dim3(64), 0, st, D, 0, D.cam_new, D.scal + 2);
             HIP_TRY(ctx, hipGetLastError());
             if ((rc = AR(D.scal + 2, 2, 0))) return rc;
             if ((rc = read_scal())) return rc;

@@ -124,7 +124,7 @@ def synth_ba_problem(n_cam=20, n_pt=2000, seed=7, kind="local", track_len=None, 
     if track_len is None:
         pts = np.stack([rng.uniform(-20, 20, n_pt), rng.uniform(-5, 5, n_pt), rng.uniform(5, length + 45, n_pt)], 1)
     else:
-        zc = rng.uniform(0, length, n_pt)
+        zc = np.sort(rng.uniform(0, length, n_pt))        # landmark ids in creation (= temporal) order, as in a SLAM map
         pts = np.stack([rng.uniform(-15, 15, n_pt), rng.uniform(-4, 4, n_pt), zc + rng.uniform(8, 25, n_pt)], 1)
     obs_cam, obs_pt, obs_meas = [], [], []
     inv = np.linalg.inv(cams)
