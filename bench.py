@@ -206,8 +206,25 @@ def main():
                                 "ms_setup": round(r["ms_setup"], 2), "lm_iters_per_s": round(r["iterations"] / (r["ms_solve_loop"] * 1e-3), 2),
                                 "chi2": [round(r["chi2_initial"], 3), round(r["chi2_final"], 3)], "wall_ms": round(d * 1e3, 1),
                                 "collective": "RCCL all-reduce (sum) of S (6n x 6n f64) + r per LM trial" if world > 1 else "none"}
+          # rows N1/N2: network nodes (fp32 like the reference, random-init weights), KITTI-sized frames, rank 0 only
+          if rank == 0:
+              from vido_slam_amd import nets
+              lfn = nets.fill_deterministic(nets.LiteFlowNet(nets.HipOps(ctx).correlation), 1).eval().cuda()
+              md = nets.fill_deterministic(nets.MonoDepth2(), 2).eval().cuda()
+              rgb = (np.random.RandomState(0).rand(375, 1242, 3) * 255).astype(np.uint8)
+              def timed(fn, reps=5):
+                  fn(); fn(); torch.cuda.synchronize()
+                  t = time.perf_counter()
+                  for _ in range(reps):
+                      fn()
+                  torch.cuda.synchronize()
+                  return (time.perf_counter() - t) / reps * 1e3
+              extra["nets_fp32_1242x375"] = {"liteflownet_ms": round(timed(lambda: nets.analyse_flow(lfn, rgb, rgb)), 3),
+                                             "monodepth2_ms": round(timed(lambda: nets.analyse_depth(md, rgb)), 3),
+                                             "note": "includes the u8 host->device upload and pre/post resizes (run_flow_net.py / run_mono_depth.py wrappers)"}
+              del lfn, md
           out["extra"] = extra
-      except Exception as e:      # side measurements must never take the headline line down
+      except Exception as e:     # side measurements must never take the headline line down
         import traceback
         out["extra_error"] = "%s: %s" % (type(e).__name__, e)
         traceback.print_exc(file=sys.stderr)

@@ -54,6 +54,9 @@ const char* vido_last_error(const vido_ctx* ctx);            /* valid until the 
 int         vido_device_name(const vido_ctx* ctx, char* buf, int buflen);
 void*       vido_stream(vido_ctx* ctx);                      /* the ctx's hipStream_t (for callers that enqueue device work) */
 int         vido_synchronize(vido_ctx* ctx);
+/* Network ops called with on_device != 0 enqueue on `hip_stream` (a caller-owned hipStream_t, e.g. torch's current
+ * stream; NULL = the legacy default stream) while enable != 0; enable == 0 restores the ctx stream. */
+int         vido_set_stream(vido_ctx* ctx, void* hip_stream, int enable);
 
 /* ---- ORB ---------------------------------------------------------------------------------------
  * Single frame, host buffers (what ORBextractor::operator() is handed): gray CV_8UC1 `stride` bytes/row.

@@ -1,0 +1,65 @@
+"""Rows N1/N2 on the MI355X: the torch modules with the HIP cost-volume kernel (through the C-ABI, on torch's
+stream) against the golden outputs of the reference modules."""
+import os
+import numpy as np
+import pytest
+import torch
+from vido_slam_amd import nets
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "nets_kats.npz"))
+TOL = 2e-4            # relative to the output's max magnitude (fp32 MIOpen convolutions vs the CPU reference run)
+
+
+@pytest.fixture(scope="module")
+def ctx(vido):
+    c = vido.Context()
+    yield c
+    c.close()
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+def test_liteflownet_hip_correlation_matches_reference(ctx):
+    ops = nets.HipOps(ctx)
+    net = nets.fill_deterministic(nets.LiteFlowNet(ops.correlation), int(G["lfn_seed"])).eval().cuda()
+    a = torch.from_numpy(G["lfn_first"].astype(np.float32) / 255.0)[None].cuda(); b = torch.from_numpy(G["lfn_second"].astype(np.float32) / 255.0)[None].cuda()
+    flow = net(a, b).cpu().numpy()
+    assert rel_err(flow, G["lfn_flow"]) < TOL
+    # non-default torch stream: the library must enqueue on it (no sync between the torch convs and the HIP op)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        flow2 = net(a, b)
+    s.synchronize()
+    assert rel_err(flow2.cpu().numpy(), G["lfn_flow"]) < TOL
+
+
+def test_hip_correlation_matches_torch_reference(ctx):
+    ops = nets.HipOps(ctx)
+    g = torch.Generator().manual_seed(5)
+    for stride, shape in ((1, (2, 96, 24, 78)), (2, (1, 64, 96, 312)), (2, (1, 32, 95, 311))):
+        f1 = torch.randn(shape, generator=g); f2 = torch.randn(shape, generator=g)
+        ref = nets.correlation_torch_reference(f1, f2, stride)
+        got = ops.correlation(f1.cuda(), f2.cuda(), stride).cpu()
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-5
+
+
+def test_monodepth2_decoder_matches_reference(ctx):
+    dec = nets.fill_deterministic(nets.DepthDecoder(), int(G["md_seed"])).eval().cuda()
+    rng = np.random.RandomState(int(G["md_feat_seed"]))
+    shapes = [(1, 64, 32, 64), (1, 64, 16, 32), (1, 128, 8, 16), (1, 256, 4, 8), (1, 512, 2, 4)]
+    feats = [torch.from_numpy(rng.uniform(0, 1.5, s).astype(np.float32)).cuda() for s in shapes]
+    with torch.no_grad():
+        out = dec(feats)
+    for s in range(4):
+        assert rel_err(out[("disp", s)].cpu().numpy(), G["md_disp%d" % s]) < TOL
+
+
+def test_monodepth2_gpu_matches_cpu_run(ctx):
+    net = nets.fill_deterministic(nets.MonoDepth2(), 9).eval()
+    x = torch.rand(1, 3, 192, 640, generator=torch.Generator().manual_seed(1))
+    ref = net(x)
+    got = net.cuda()(x.cuda()).cpu()
+    assert float((got - ref).abs().max()) < 2e-4

@@ -38,6 +38,8 @@ struct vido_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;
+    hipStream_t ext_stream = nullptr;  // vido_set_stream: caller-owned stream for the on_device network ops
+    bool has_ext_stream = false;
     std::string err;
     char dev_name[256] = {0};
     OrbState* orb = nullptr;

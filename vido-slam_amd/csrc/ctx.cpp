@@ -97,6 +97,13 @@ int vido_device_name(const vido_ctx* ctx, char* buf, int buflen)
 
 void* vido_stream(vido_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+int vido_set_stream(vido_ctx* ctx, void* hip_stream, int enable)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    ctx->ext_stream = (hipStream_t)hip_stream; ctx->has_ext_stream = enable != 0;
+    return VIDO_OK;
+}
+
 int vido_synchronize(vido_ctx* ctx)
 {
     if (!ctx) return VIDO_E_INVALID;

@@ -193,7 +193,7 @@ int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int
     if (!ctx) return VIDO_E_INVALID;
     if (!first || !second || !out || B < 1 || C < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2)) return vido_set_error(ctx, VIDO_E_INVALID, "correlation: bad arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = (on_device && ctx->has_ext_stream) ? ctx->ext_stream : ctx->stream;
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
     const size_t nin = (size_t)B * C * H * W * 4, nout = (size_t)B * 49 * Ho * Wo * 4;
     const float *d1 = first, *d2 = second; float* dout = out;
@@ -221,7 +221,7 @@ int vido_roi_align(vido_ctx* ctx, const float* feat, int B, int C, int H, int W,
     if (!feat || (n_rois && (!rois || !out)) || B < 1 || C < 1 || H < 1 || W < 1 || n_rois < 0 || pooled_h < 1 || pooled_w < 1) return vido_set_error(ctx, VIDO_E_INVALID, "roi_align: bad arguments");
     if (n_rois == 0) return VIDO_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = (on_device && ctx->has_ext_stream) ? ctx->ext_stream : ctx->stream;
     const size_t nf = (size_t)B * C * H * W * 4, nr = (size_t)n_rois * 5 * 4, nout = (size_t)n_rois * C * pooled_h * pooled_w * 4;
     const float *df = feat, *dr = rois; float* dout = out; NetState* S = nullptr;
     if (!on_device) {
@@ -251,7 +251,7 @@ int vido_nms(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, int n,
     if (n < 0 || !n_keep || (n && (!boxes_xyxy || !keep_out)) || (!on_device && n && !scores)) return vido_set_error(ctx, VIDO_E_INVALID, "nms: bad arguments");
     if (n > 65536) return vido_set_error(ctx, VIDO_E_CAPACITY, "nms: %d boxes > 65536", n);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = (on_device && ctx->has_ext_stream) ? ctx->ext_stream : ctx->stream;
     if (n == 0) { if (on_device) HIP_TRY(ctx, hipMemsetAsync(n_keep, 0, 4, st)); else *n_keep = 0; return VIDO_OK; }
     const int cb = (n + 63) / 64;
     const size_t nb = (size_t)n * 16, nm = (size_t)n * cb * 8, nk = (size_t)n * 4 + 256;
@@ -288,7 +288,7 @@ int vido_box_decode(vido_ctx* ctx, const float* deltas, const float* boxes, int 
     if (n < 0 || k < 1 || !weights || (n && (!deltas || !boxes || !out))) return vido_set_error(ctx, VIDO_E_INVALID, "box_decode: bad arguments");
     if (n == 0) return VIDO_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = (on_device && ctx->has_ext_stream) ? ctx->ext_stream : ctx->stream;
     const size_t nd = (size_t)n * k * 16, nb = (size_t)n * 16;
     const float *dd = deltas, *db = boxes; float* dout = out; NetState* S = nullptr;
     if (!on_device) {

@@ -1,0 +1,157 @@
+"""LiteFlowNet forward pass (reference src/thirdparty/flow_net/src/layers.py:39-315 + run_flow_net.py:66-110),
+written table-first: every stage is described by a row of LEVELS and built by small factories.  Parameter names
+match the reference module tree (netFeatures.netOne.0.weight, netMatching.0.netMain.6.bias, ...)."""
+import math
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+LEAK = 0.1
+#            level: (feature channels, backwarp scale, last-conv kernel, subpixel in-ch, regular. in-ch, dist channels)
+LEVELS = {2: (32, 10.0, 7, 130, 131, 49), 3: (64, 5.0, 5, 130, 131, 25), 4: (96, 2.5, 5, 194, 131, 25), 5: (128, 1.25, 3, 258, 131, 9), 6: (192, 0.625, 3, 386, 195, 9)}
+MEAN_FIRST = (0.411618, 0.434631, 0.454253)
+MEAN_SECOND = (0.410782, 0.433645, 0.452793)
+
+
+def _chain(specs):
+    """specs: [(cin, cout, kernel, stride, act)] -> Sequential with the reference's index layout (conv, lrelu, conv, ...)."""
+    mods = []
+    for cin, cout, k, s, act in specs:
+        pad = (k[0] // 2, k[1] // 2) if isinstance(k, tuple) else k // 2
+        mods.append(nn.Conv2d(cin, cout, k, s, pad))
+        if act:
+            mods.append(nn.LeakyReLU(LEAK, inplace=False))
+    return nn.Sequential(*mods)
+
+
+def _flow_head(cin, k):
+    return _chain([(cin, 128, 3, 1, True), (128, 64, 3, 1, True), (64, 32, 3, 1, True), (32, 2, k, 1, False)])
+
+
+def backwarp(x, flow):
+    """Bilinear warp of x by flow (pixels), zero padding, align_corners=False grid (layers.py:25-37)."""
+    B, _, H, W = flow.shape
+    hor = torch.linspace(-1.0 + 1.0 / W, 1.0 - 1.0 / W, W, device=flow.device, dtype=flow.dtype).view(1, 1, 1, W).expand(B, 1, H, W)
+    ver = torch.linspace(-1.0 + 1.0 / H, 1.0 - 1.0 / H, H, device=flow.device, dtype=flow.dtype).view(1, 1, H, 1).expand(B, 1, H, W)
+    g = torch.cat([hor + flow[:, 0:1] / ((x.shape[3] - 1.0) / 2.0), ver + flow[:, 1:2] / ((x.shape[2] - 1.0) / 2.0)], 1)
+    return F.grid_sample(x, g.permute(0, 2, 3, 1), mode="bilinear", padding_mode="zeros", align_corners=False)
+
+
+class _Features(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.netOne = _chain([(3, 32, 7, 1, True)])
+        self.netTwo = _chain([(32, 32, 3, 2, True), (32, 32, 3, 1, True), (32, 32, 3, 1, True)])
+        self.netThr = _chain([(32, 64, 3, 2, True), (64, 64, 3, 1, True)])
+        self.netFou = _chain([(64, 96, 3, 2, True), (96, 96, 3, 1, True)])
+        self.netFiv = _chain([(96, 128, 3, 2, True)])
+        self.netSix = _chain([(128, 192, 3, 2, True)])
+
+    def forward(self, x):
+        out = []
+        for stage in (self.netOne, self.netTwo, self.netThr, self.netFou, self.netFiv, self.netSix):
+            x = stage(x); out.append(x)
+        return out
+
+
+class _Matching(nn.Module):
+    def __init__(self, level, corr):
+        super().__init__()
+        ch, self.scale, k, _, _, _ = LEVELS[level]
+        self.corr, self.stride = corr, (2 if level < 4 else 1)
+        self.netFeat = _chain([(32, 64, 1, 1, True)]) if level == 2 else nn.Sequential()
+        self.netUpflow = None if level == 6 else nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=False, groups=2)
+        self.netUpcorr = nn.ConvTranspose2d(49, 49, 4, 2, 1, bias=False, groups=49) if level < 4 else None
+        self.netMain = _flow_head(49, k)
+
+    def forward(self, im1, im2, f1, f2, flow):
+        f1, f2 = self.netFeat(f1), self.netFeat(f2)
+        if flow is not None:
+            flow = self.netUpflow(flow)
+            f2 = backwarp(f2, flow * self.scale)
+        c = F.leaky_relu(self.corr(f1, f2, self.stride), LEAK)
+        if self.netUpcorr is not None:
+            c = self.netUpcorr(c)
+        return (flow if flow is not None else 0.0) + self.netMain(c)
+
+
+class _Subpixel(nn.Module):
+    def __init__(self, level):
+        super().__init__()
+        _, self.scale, k, cin, _, _ = LEVELS[level]
+        self.netFeat = _chain([(32, 64, 1, 1, True)]) if level == 2 else nn.Sequential()
+        self.netMain = _flow_head(cin, k)
+
+    def forward(self, im1, im2, f1, f2, flow):
+        f1, f2 = self.netFeat(f1), self.netFeat(f2)
+        f2 = backwarp(f2, flow * self.scale)
+        return flow + self.netMain(torch.cat([f1, f2, flow], 1))
+
+
+class _Regularization(nn.Module):
+    def __init__(self, level):
+        super().__init__()
+        ch, self.scale, k, _, cin, nd = LEVELS[level]
+        self.k = k
+        self.netFeat = _chain([(ch, 128, 1, 1, True)]) if level < 5 else nn.Sequential()
+        self.netMain = _chain([(cin, 128, 3, 1, True), (128, 128, 3, 1, True), (128, 64, 3, 1, True), (64, 64, 3, 1, True), (64, 32, 3, 1, True), (32, 32, 3, 1, True)])
+        self.netDist = _chain([(32, nd, k, 1, False)]) if level >= 5 else _chain([(32, nd, (k, 1), 1, False), (nd, nd, (1, k), 1, False)])
+        self.netScaleX = nn.Conv2d(nd, 1, 1); self.netScaleY = nn.Conv2d(nd, 1, 1)
+
+    def forward(self, im1, im2, f1, f2, flow):
+        diff = (im1 - backwarp(im2, flow * self.scale)).pow(2.0).sum(1, True).sqrt()
+        centred = flow - flow.flatten(2).mean(2, True).unsqueeze(-1)
+        d = self.netDist(self.netMain(torch.cat([diff, centred, self.netFeat(f1)], 1))).pow(2.0).neg()
+        d = (d - d.max(1, True)[0]).exp()
+        div = d.sum(1, True).reciprocal()
+        pad = (self.k - 1) // 2
+        sx = self.netScaleX(d * F.unfold(flow[:, 0:1], self.k, 1, pad).view_as(d)) * div
+        sy = self.netScaleY(d * F.unfold(flow[:, 1:2], self.k, 1, pad).view_as(d)) * div
+        return torch.cat([sx, sy], 1)
+
+
+class LiteFlowNet(nn.Module):
+    """`correlation`: callable (first, second, stride) -> cost volume.  On the GPU pass HipOps(ctx).correlation (the HIP
+    kernel); the CPU tests pass correlation_torch_reference."""
+
+    def __init__(self, correlation):
+        super().__init__()
+        self.netFeatures = _Features()
+        self.netMatching = nn.ModuleList([_Matching(l, correlation) for l in (2, 3, 4, 5, 6)])
+        self.netSubpixel = nn.ModuleList([_Subpixel(l) for l in (2, 3, 4, 5, 6)])
+        self.netRegularization = nn.ModuleList([_Regularization(l) for l in (2, 3, 4, 5, 6)])
+
+    @torch.no_grad()
+    def forward(self, first, second):
+        first = first - first.new_tensor(MEAN_FIRST).view(1, 3, 1, 1)
+        second = second - second.new_tensor(MEAN_SECOND).view(1, 3, 1, 1)
+        f1, f2 = self.netFeatures(first), self.netFeatures(second)
+        p1, p2 = [first], [second]
+        for l in range(1, 6):
+            size = f1[l].shape[2:]
+            p1.append(F.interpolate(p1[-1], size=size, mode="bilinear", align_corners=False))
+            p2.append(F.interpolate(p2[-1], size=size, mode="bilinear", align_corners=False))
+        flow = None
+        for l in (-1, -2, -3, -4, -5):          # level 6 -> 2
+            flow = self.netMatching[l](p1[l], p2[l], f1[l], f2[l], flow)
+            flow = self.netSubpixel[l](p1[l], p2[l], f1[l], f2[l], flow)
+            flow = self.netRegularization[l](p1[l], p2[l], f1[l], f2[l], flow)
+        return flow * 20.0
+
+
+@torch.no_grad()
+def analyse_flow(net, previous_bgr, current_bgr):
+    """run_flow_net.py:66-110: HxWx3 u8 BGR pair -> HxWx2 f32 flow (BGR->RGB, /255, bilinear resize to x32, forward,
+    bilinear resize back, rescale u by W/W', v by H/H')."""
+    dev = next(net.parameters()).device
+    def prep(img):
+        t = torch.as_tensor(img[:, :, ::-1].copy(), device=dev).permute(2, 0, 1).float().div(255.0).unsqueeze(0)
+        return t
+    a, b = prep(previous_bgr), prep(current_bgr)
+    H, W = a.shape[2], a.shape[3]
+    Hp, Wp = int(math.floor(math.ceil(H / 32.0) * 32.0)), int(math.floor(math.ceil(W / 32.0) * 32.0))
+    a = F.interpolate(a, size=(Hp, Wp), mode="bilinear", align_corners=False)
+    b = F.interpolate(b, size=(Hp, Wp), mode="bilinear", align_corners=False)
+    flow = F.interpolate(net(a, b), size=(H, W), mode="bilinear", align_corners=False)
+    flow[:, 0] *= float(W) / float(Wp); flow[:, 1] *= float(H) / float(Hp)
+    return flow[0].permute(1, 2, 0).contiguous()

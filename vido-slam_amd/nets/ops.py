@@ -1,0 +1,55 @@
+"""torch <-> C-ABI glue for the network ops.  Device tensors are handed to the library as raw pointers
+(on_device=1); the ctx adopts torch's current stream (vido_set_stream) so launches are ordered with the
+surrounding torch kernels without any synchronisation."""
+import ctypes as C
+import torch
+
+
+def correlation_torch_reference(first, second, stride):
+    """Plain-PyTorch fp32 reference of the 7x7 cost volume (used by the CPU tests only; the product path is the HIP
+    kernel): out[b,(p+3)*7+(o+3),y,x] = mean_c f1[b,c,y*s,x*s] * f2[b,c,(y+p)*s,(x+o)*s]."""
+    a, b = first[:, :, ::stride, ::stride], second[:, :, ::stride, ::stride]
+    pad = torch.nn.functional.pad(b, (3, 3, 3, 3))
+    H, W = a.shape[2], a.shape[3]
+    return torch.stack([(a * pad[:, :, p:p + H, o:o + W]).mean(1) for p in range(7) for o in range(7)], 1)
+
+
+class HipOps:
+    """FunctionCorrelation / ROIAlign / nms / box decode on device tensors through libvido_slam_hip.so."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def _adopt_stream(self):
+        st = torch.cuda.current_stream().cuda_stream
+        self.ctx._check(self.ctx.lib.vido_set_stream(self.ctx.h, C.c_void_p(st), 1))
+
+    def correlation(self, first, second, stride):
+        if not first.is_cuda:
+            raise RuntimeError("HipOps.correlation needs CUDA(HIP) tensors; there is no CPU fallback")
+        first = first.contiguous().float(); second = second.contiguous().float()
+        B, Cc, H, W = first.shape
+        out = torch.empty((B, 49, (H + stride - 1) // stride, (W + stride - 1) // stride), device=first.device, dtype=torch.float32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_correlation(self.ctx.h, C.c_void_p(first.data_ptr()), C.c_void_p(second.data_ptr()), B, Cc, H, W, stride,
+                                                      C.c_void_p(out.data_ptr()), 1))
+        return out
+
+    def roi_align(self, feat, rois, output_size, spatial_scale, sampling_ratio):
+        feat = feat.contiguous().float(); rois = rois.contiguous().float()
+        B, Cc, H, W = feat.shape; ph, pw = output_size
+        out = torch.empty((rois.shape[0], Cc, ph, pw), device=feat.device, dtype=torch.float32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_roi_align(self.ctx.h, C.c_void_p(feat.data_ptr()), B, Cc, H, W, C.c_void_p(rois.data_ptr()), rois.shape[0],
+                                                    C.c_float(spatial_scale), ph, pw, sampling_ratio, C.c_void_p(out.data_ptr()), 1))
+        return out
+
+    def nms(self, boxes, scores, thresh):
+        """maskrcnn_benchmark.layers.nms: kept original indices, ascending (sort on the device with torch, sweep in HIP)."""
+        order = torch.sort(scores, descending=True, stable=True)[1]
+        sb = boxes[order].contiguous().float(); n = sb.shape[0]
+        keep = torch.empty(max(n, 1), device=boxes.device, dtype=torch.int32); cnt = torch.zeros(1, device=boxes.device, dtype=torch.int32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_nms(self.ctx.h, C.c_void_p(sb.data_ptr()), None, n, C.c_float(thresh), C.c_void_p(keep.data_ptr()), C.c_void_p(cnt.data_ptr()), 1))
+        m = int(cnt.item())
+        return torch.sort(order[keep[:m].long()])[0]
