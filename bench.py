@@ -133,6 +133,15 @@ def main():
     roofline = {"kernel": "k_fast_cells", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "algorithmic_bytes_per_launch": int(fast_bytes), "avg_launch_ms": round(stage["fast_ms"], 4)}
+    # HBM traffic per launch from the committed PMC passes of this same command (tools/profile_round.sh; a bench run cannot
+    # collect counters on itself).  FETCH_SIZE is doubled per MI355X_MICROARCH.md (128-B requests tallied at 64 B; checked
+    # here on k_depth_prescale: 39.3 MB counted for 78.6 MB read), WRITE_SIZE is taken as is; both are KB.
+    pmc_path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")
+    if os.path.exists(pmc_path) and B == 64 and (W, H) == (640, 480):
+        k = json.load(open(pmc_path))["kernels"].get("k_fast_cells")
+        if k:
+            roofline["traffic"] = int((2.0 * k["FETCH_SIZE_KB_mean_per_launch"] + k["WRITE_SIZE_KB_mean_per_launch"]) * 1024)
+            roofline["traffic_source"] = "profiles/r1/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes; FETCH x2 gfx950 correction)"
 
     out = {
         "metric": "frames/sec end-to-end (flow+depth+track+local-BA) at 640x480; BA iters/sec",
