@@ -198,6 +198,25 @@ typedef int (*vido_allreduce_fn)(void* user, void* dev_ptr, size_t count, int op
 
 int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_result* result, vido_allreduce_fn allreduce, void* user);
 
+/* Object part of Optimizer::FullBatchOptimization (Optimizer.cc:1235-2178 with STATIC_ONLY = false): per (object, frame)
+ * motion vertices H (VertexSE3, the reference initialises them to identity, :1592), one dynamic point vertex per
+ * observation with its EdgeSE3PointXYZ to camera dyn_cam[k] (:1560-1582, :1683-1726), LandmarkMotionTernaryEdge
+ * (tern_prev, tern_cur, tern_H), e = p_prev - H^-1 p_cur (:1728-1745, types/types_dyn_slam3d.cpp:53-85) and EdgeSE3
+ * smoothness edges with identity measurement between motion vertices sm_i -> sm_j (:1604-1636).  The ternary edges
+ * must link the dynamic points into chains (every point has at most one predecessor and one successor), which is what
+ * the reference's tracklets produce.  H_T / dyn_xyz are updated in place.  With an all-reduce hook rank 0 owns this part. */
+typedef struct vido_ba_dynamic {
+    int32_t n_H, n_dyn, n_tern, n_smooth;
+    double* H_T;                 /* [n_H*12] row-major 3x4 */
+    double* dyn_xyz;             /* [n_dyn*3] world */
+    const int32_t* dyn_cam; const double* dyn_meas;                            /* [n_dyn], [n_dyn*3] (point in the camera frame) */
+    const int32_t* tern_prev; const int32_t* tern_cur; const int32_t* tern_H;  /* [n_tern] */
+    const int32_t* sm_i; const int32_t* sm_j;                                  /* [n_smooth] indices into H */
+    double info_dyn, info_tern, info_smooth, huber_dyn, huber_tern, huber_smooth;
+} vido_ba_dynamic;
+int vido_ba_optimize_dynamic(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dyn, vido_ba_result* result,
+                             vido_allreduce_fn allreduce, void* user);
+
 /* ---- Native ops of the three network nodes (the nets' conv/GEMM layers run on PyTorch-ROCm) -----------------
  * All tensors f32, NCHW contiguous.  on_device != 0: every pointer is a device pointer and the call only
  * enqueues on the ctx stream (this is how the torch modules call them); otherwise host pointers, synchronous. */

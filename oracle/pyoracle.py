@@ -255,6 +255,47 @@ def ba_chi2(k):
     p, a = ba_struct(k); f = lib().vo_ba_chi2; f.restype = C.c_double
     return f(C.byref(p))
 
+class BaDynamic(C.Structure):
+    _fields_ = [("n_H", C.c_int32), ("n_dyn", C.c_int32), ("n_tern", C.c_int32), ("n_smooth", C.c_int32),
+                ("H_T", C.c_void_p), ("dyn_xyz", C.c_void_p), ("dyn_cam", C.c_void_p), ("dyn_meas", C.c_void_p),
+                ("tern_prev", C.c_void_p), ("tern_cur", C.c_void_p), ("tern_H", C.c_void_p), ("sm_i", C.c_void_p), ("sm_j", C.c_void_p),
+                ("info_dyn", C.c_double), ("info_tern", C.c_double), ("info_smooth", C.c_double),
+                ("huber_dyn", C.c_double), ("huber_tern", C.c_double), ("huber_smooth", C.c_double)]
+
+def badyn_struct(d, cls=BaDynamic):
+    """dict from vido_slam_amd.problems.synth_ba_dynamic -> (struct, keepalive arrays); H_T / dyn_xyz are COPIES the solver updates."""
+    a = dict(H_T=np.array(d["H_T"], np.float64).reshape(-1, 12).copy(), dyn_xyz=np.array(d["dyn_xyz"], np.float64).reshape(-1, 3).copy(),
+             dyn_cam=np.ascontiguousarray(d["dyn_cam"], np.int32), dyn_meas=np.ascontiguousarray(d["dyn_meas"], np.float64).reshape(-1, 3))
+    for name in ("tern_prev", "tern_cur", "tern_H", "sm_i", "sm_j"):
+        a[name] = np.ascontiguousarray(d[name], np.int32)
+    s = cls()
+    s.n_H, s.n_dyn, s.n_tern, s.n_smooth = len(a["H_T"]), len(a["dyn_cam"]), len(a["tern_prev"]), len(a["sm_i"])
+    for name in a:
+        setattr(s, name, a[name].ctypes.data)
+    for name in ("info_dyn", "info_tern", "info_smooth", "huber_dyn", "huber_tern", "huber_smooth"):
+        setattr(s, name, float(d[name]))
+    return s, a
+
+def badyn_optimize(k, d):
+    p, a = ba_struct(k); s, b = badyn_struct(d); r = BaResult()
+    lib().vo_badyn_optimize(C.byref(p), C.byref(s), C.byref(r))
+    return dict(cam_T=a["cam_T"].reshape(-1, 3, 4), pt_xyz=a["pt_xyz"], H_T=b["H_T"].reshape(-1, 3, 4), dyn_xyz=b["dyn_xyz"], iterations=r.iterations,
+                lm_trials=r.lm_trials, chi2_initial=r.chi2_initial, chi2_final=r.chi2_final, lambda_final=r.lambda_final)
+
+def badyn_system(k, d):
+    """dense (H, b, chi2) of the whole graph; unknown order = cams, Hs, static points, dynamic points."""
+    p, a = ba_struct(k); s, b = badyn_struct(d)
+    N = 6 * (p.n_cam + s.n_H) + 3 * (p.n_pt + s.n_dyn)
+    Hm = np.zeros((N, N)); g = np.zeros(N); f = lib().vo_badyn_system; f.restype = C.c_double
+    chi = f(C.byref(p), C.byref(s), _p(Hm), _p(g))
+    return Hm, g, chi
+
+def edge_tern(H, pp, pc):
+    H = np.ascontiguousarray(H, np.float64).reshape(12); pp = np.ascontiguousarray(pp, np.float64); pc = np.ascontiguousarray(pc, np.float64)
+    e = np.zeros(3); Jc = np.zeros((3, 3)); JH = np.zeros((3, 6))
+    lib().vo_edge_tern(_p(H), _p(pp), _p(pc), _p(e), _p(Jc), _p(JH))
+    return e, Jc, JH
+
 def ba_reduced_system(k, lam, pt_lo=0, pt_hi=None, with_cam_factors=True):
     """(S, r, chi2) of the landmark shard [pt_lo, pt_hi) at the problem's current estimate."""
     p, a = ba_struct(k); n6 = 6 * p.n_cam; pt_hi = p.n_pt if pt_hi is None else pt_hi

@@ -44,6 +44,15 @@ struct BaDev {
     double *Hcd, *bc, *Hodo;                                // [n_cam*36], [n6], [n_odo*36]
     double *S, *r, *x;                                      // [n6*n6], [n6], [n6]
     double *scal;                                           // [8]: 0 chi2 1 maxdiag 2 tempChi 3 scale 4 ok
+    const double *odo_info, *odo_delta;                     // per camera-camera factor (odometry | object-motion smoothness)
+    // ---- object part (FullBatchOptimization, STATIC_ONLY = false).  n_cam above counts ALL pose vertices: cameras first,
+    // then the object motions H.  Dynamic points are stored chain-major (a chain = one dynamic tracklet).
+    int n_dyn, n_chain;
+    double info_dyn, info_tern, huber_dyn, huber_tern;
+    double *dyn, *dyn_new;                                  // [n_dyn*3]
+    const int *dyn_cam, *dyn_hin;                           // camera; pose index of the H of the ternary edge (k-1, k, H), -1 = chain head
+    const double* dyn_meas; const int* chain_start;         // [n_dyn*3], [n_chain+1]
+    double *Vd, *bd, *U, *Wc, *Wi, *Wo, *fac, *yb;          // [6],[3],[9],[18],[18],[18],[18: Dinv|G],[3] per dynamic point
 };
 
 // ---- small math ------------------------------------------------------------------------------------
@@ -200,9 +209,9 @@ __global__ __launch_bounds__(64) void k_ba_camfactors(BaDev P, int with_jac, con
     double e[6], Ji[36], Jj[36];
     edge_se3(is_prior ? P.prior_T : P.odo_T + 12 * k, is_prior ? nullptr : cam + 12 * i, cam + 12 * j, e, is_prior ? nullptr : Ji, Jj, with_jac != 0);
     double s2 = 0; for (int a = 0; a < 6; a++) s2 += e[a] * e[a];
-    const double info = is_prior ? P.info_prior : P.info_odo;
+    const double info = is_prior ? P.info_prior : P.odo_info[k];
     double r0 = info * s2, w = 1;
-    if (!is_prior) huber_w(info * s2, P.huber_odo, P.use_huber, r0, w);
+    if (!is_prior) huber_w(info * s2, P.odo_delta[k], P.use_huber, r0, w);
     if (lane == 0) atomicAdd(chi_out, r0);
     if (!with_jac || lane >= 36) return;
     const double wo = w * info;
@@ -225,6 +234,7 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev P, int n_ptl)
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
     for (int a = tid; a < P.n6; a += nt) m = fmax(m, fabs(P.Hcd[36 * (a / 6) + 7 * (a % 6)]));
     for (int l = tid; l < n_ptl; l += nt) m = fmax(m, fmax(fabs(P.Hpp[6 * (size_t)l]), fmax(fabs(P.Hpp[6 * (size_t)l + 3]), fabs(P.Hpp[6 * (size_t)l + 5]))));
+    if (n_ptl >= 0) for (int l = tid; l < P.n_dyn; l += nt) m = fmax(m, fmax(fabs(P.Vd[6 * (size_t)l]), fmax(fabs(P.Vd[6 * (size_t)l + 3]), fabs(P.Vd[6 * (size_t)l + 5]))));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) {      // non-negative doubles order like their bit patterns
@@ -548,19 +558,283 @@ __global__ __launch_bounds__(256) void k_ba_chi2(BaDev P, const double* cam, con
     if ((threadIdx.x & 63) == 0) atomicAdd(out, v);
 }
 
+// ---- object part: dynamic-point chains -------------------------------------------------------------------------
+// A dynamic tracklet contributes one VertexPointXYZ per frame, tied to its camera by an EdgeSE3PointXYZ and to its
+// predecessor by LandmarkMotionTernaryEdge(p_prev, p_cur, H): e = p_prev - H^-1 p_cur, de/dp_prev = I,
+// de/dp_cur = -R_H^T, de/dH = [I | -[H^-1 p_cur]x] (types/types_dyn_slam3d.cpp:53-85).  The point-point Hessian of a
+// tracklet is therefore block tridiagonal; the chain is eliminated with a block LDL^T (3x3 blocks) instead of the
+// 3x3 inverse used for static landmarks, which is the same LM step g2o takes on the un-eliminated system.
+__device__ __forceinline__ void tern_eval(const double* H, const double* pp, const double* pc, double* e, double* v)
+{
+    const double d0 = pc[0] - H[3], d1 = pc[1] - H[7], d2 = pc[2] - H[11];
+    v[0] = H[0] * d0 + H[4] * d1 + H[8] * d2; v[1] = H[1] * d0 + H[5] * d1 + H[9] * d2; v[2] = H[2] * d0 + H[6] * d1 + H[10] * d2;
+    e[0] = pp[0] - v[0]; e[1] = pp[1] - v[1]; e[2] = pp[2] - v[2];
+}
+__device__ __forceinline__ void tern_JH(const double* v, double* J /*3x6 row-major*/)
+{
+#pragma unroll
+    for (int a = 0; a < 18; a++) J[a] = 0;
+    J[0] = J[7] = J[14] = 1;
+    J[4] = v[2]; J[5] = -v[1]; J[6 + 3] = -v[2]; J[6 + 5] = v[0]; J[12 + 3] = v[1]; J[12 + 4] = -v[0];
+}
+__device__ __forceinline__ void pose_accum(const BaDev& P, int c, double wo, const double* J /*3x6*/, const double* e)
+{
+    for (int a = 0; a < 6; a++) {
+        atomicAdd(P.bc + 6 * c + a, -wo * (J[a] * e[0] + J[6 + a] * e[1] + J[12 + a] * e[2]));
+        for (int b = a; b < 6; b++) {
+            const double h = wo * (J[a] * J[b] + J[6 + a] * J[6 + b] + J[12 + a] * J[12 + b]);
+            if (h != 0.0) { atomicAdd(P.Hcd + 36 * c + a * 6 + b, h); if (b != a) atomicAdd(P.Hcd + 36 * c + b * 6 + a, h); }
+        }
+    }
+}
+// one thread per dynamic point: its camera edge, the ternary edge it closes (as p_cur) and the one it opens (as p_prev)
+__global__ __launch_bounds__(256) void k_badyn_linearize(BaDev P)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    double chi = 0;
+    if (k < P.n_dyn) {
+        double V[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+        const double* p = P.dyn + 3 * (size_t)k;
+        {   // EdgeSE3PointXYZ to the camera
+            const int c = P.dyn_cam[k];
+            const double* X = P.cam + 12 * c; const double* m = P.dyn_meas + 3 * (size_t)k;
+            const double d0 = p[0] - X[3], d1 = p[1] - X[7], d2 = p[2] - X[11];
+            const double Z0 = X[0] * d0 + X[4] * d1 + X[8] * d2, Z1 = X[1] * d0 + X[5] * d1 + X[9] * d2, Z2 = X[2] * d0 + X[6] * d1 + X[10] * d2;
+            const double e[3] = {Z0 - m[0], Z1 - m[1], Z2 - m[2]};
+            double r0, w; huber_w(P.info_dyn * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), P.huber_dyn, P.use_huber, r0, w);
+            chi += r0;
+            const double wo = w * P.info_dyn;
+            const double Jc[18] = {-1, 0, 0, 0, -2 * Z2, 2 * Z1,   0, -1, 0, 2 * Z2, 0, -2 * Z0,   0, 0, -1, -2 * Z1, 2 * Z0, 0};
+            const double Jp[9] = {X[0], X[4], X[8], X[1], X[5], X[9], X[2], X[6], X[10]};
+            int q = 0;
+            for (int a = 0; a < 3; a++) {
+                b[a] -= wo * (Jp[a] * e[0] + Jp[3 + a] * e[1] + Jp[6 + a] * e[2]);
+                for (int bb = a; bb < 3; bb++) V[q++] += wo * (Jp[a] * Jp[bb] + Jp[3 + a] * Jp[3 + bb] + Jp[6 + a] * Jp[6 + bb]);
+            }
+            double* Wk = P.Wc + 18 * (size_t)k;
+            for (int a = 0; a < 6; a++) for (int bb = 0; bb < 3; bb++) Wk[a * 3 + bb] = wo * (Jc[a] * Jp[bb] + Jc[6 + a] * Jp[3 + bb] + Jc[12 + a] * Jp[6 + bb]);
+            pose_accum(P, c, wo, Jc, e);
+        }
+        const int hin = P.dyn_hin[k];
+        double* Uk = P.U + 9 * (size_t)k; double* Wik = P.Wi + 18 * (size_t)k; double* Wok = P.Wo + 18 * (size_t)k;
+        if (hin >= 0) {   // ternary edge (k-1, k, H): this point is p_cur
+            const double* H = P.cam + 12 * hin;
+            double e[3], v[3], JH[18]; tern_eval(H, p - 3, p, e, v); tern_JH(v, JH);
+            double r0, w; huber_w(P.info_tern * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), P.huber_tern, P.use_huber, r0, w);
+            chi += r0;
+            const double wt = w * P.info_tern;
+            const double Jc[9] = {-H[0], -H[4], -H[8], -H[1], -H[5], -H[9], -H[2], -H[6], -H[10]};      // -R^T
+            int q = 0;
+            for (int a = 0; a < 3; a++) {
+                b[a] -= wt * (Jc[a] * e[0] + Jc[3 + a] * e[1] + Jc[6 + a] * e[2]);
+                for (int bb = a; bb < 3; bb++) V[q++] += wt * (Jc[a] * Jc[bb] + Jc[3 + a] * Jc[3 + bb] + Jc[6 + a] * Jc[6 + bb]);
+            }
+            for (int a = 0; a < 9; a++) Uk[a] = wt * Jc[a];                                               // J_prev^T Omega J_cur, J_prev = I
+            for (int a = 0; a < 6; a++) for (int bb = 0; bb < 3; bb++) Wik[a * 3 + bb] = wt * (JH[a] * Jc[bb] + JH[6 + a] * Jc[3 + bb] + JH[12 + a] * Jc[6 + bb]);
+            pose_accum(P, hin, wt, JH, e);
+        } else {
+            for (int a = 0; a < 9; a++) Uk[a] = 0;
+            for (int a = 0; a < 18; a++) Wik[a] = 0;
+        }
+        const int hout = (k + 1 < P.n_dyn) ? P.dyn_hin[k + 1] : -1;
+        if (hout >= 0) {  // ternary edge (k, k+1, H'): this point is p_prev (J = I)
+            const double* H = P.cam + 12 * hout;
+            double e[3], v[3], JH[18]; tern_eval(H, p, p + 3, e, v); tern_JH(v, JH);
+            double r0, w; huber_w(P.info_tern * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), P.huber_tern, P.use_huber, r0, w);
+            const double wt = w * P.info_tern;
+            V[0] += wt; V[3] += wt; V[5] += wt;
+            for (int a = 0; a < 3; a++) b[a] -= wt * e[a];
+            for (int a = 0; a < 6; a++) for (int bb = 0; bb < 3; bb++) Wok[a * 3 + bb] = wt * JH[bb * 6 + a];
+        } else {
+            for (int a = 0; a < 18; a++) Wok[a] = 0;
+        }
+        for (int a = 0; a < 6; a++) P.Vd[6 * (size_t)k + a] = V[a];
+        for (int a = 0; a < 3; a++) P.bd[3 * (size_t)k + a] = b[a];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) chi += __shfl_xor(chi, o, 64);
+    if ((threadIdx.x & 63) == 0 && chi != 0) atomicAdd(P.scal + 0, chi);
+}
+
+__device__ __forceinline__ void mat3_mul(const double* A, const double* B, double* C, bool transA)
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            C[r * 3 + c] = transA ? (A[r] * B[c] + A[3 + r] * B[3 + c] + A[6 + r] * B[6 + c]) : (A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c]);
+}
+__device__ __forceinline__ void inv3full(const double* A, double* I)
+{
+    const double c0 = A[4] * A[8] - A[5] * A[7], c1 = A[5] * A[6] - A[3] * A[8], c2 = A[3] * A[7] - A[4] * A[6];
+    const double d = 1.0 / (A[0] * c0 + A[1] * c1 + A[2] * c2);
+    I[0] = c0 * d; I[1] = (A[2] * A[7] - A[1] * A[8]) * d; I[2] = (A[1] * A[5] - A[2] * A[4]) * d;
+    I[3] = c1 * d; I[4] = (A[0] * A[8] - A[2] * A[6]) * d; I[5] = (A[2] * A[3] - A[0] * A[5]) * d;
+    I[6] = c2 * d; I[7] = (A[1] * A[6] - A[0] * A[7]) * d; I[8] = (A[0] * A[4] - A[1] * A[3]) * d;
+}
+// block LDL^T of one chain per thread: D_0 = A_0, G_k = D_{k-1}^-1 U_k, D_k = A_k - U_k^T G_k (A = Vd + lambda I);
+// stores D_k^-1 | G_k and yb = V^-1 bd (the chain's part of the reduced right-hand side)
+__global__ __launch_bounds__(64) void k_badyn_factor(BaDev P, double lambda)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.n_chain) return;
+    const int k0 = P.chain_start[c], k1 = P.chain_start[c + 1];
+    double Dinv[9], z[3] = {0, 0, 0};
+    for (int k = k0; k < k1; k++) {
+        const double* V = P.Vd + 6 * (size_t)k; const double* U = P.U + 9 * (size_t)k; double* F = P.fac + 18 * (size_t)k;
+        double D[9] = {V[0] + lambda, V[1], V[2], V[1], V[3] + lambda, V[4], V[2], V[4], V[5] + lambda};
+        double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double w[3] = {P.bd[3 * (size_t)k], P.bd[3 * (size_t)k + 1], P.bd[3 * (size_t)k + 2]};
+        if (k > k0) {
+            mat3_mul(Dinv, U, G, false);
+            double T[9]; mat3_mul(U, G, T, true);
+            for (int a = 0; a < 9; a++) D[a] -= T[a];
+            for (int a = 0; a < 3; a++) w[a] -= G[a] * z[0] + G[3 + a] * z[1] + G[6 + a] * z[2];       // z_k = w_k - G_k^T z_{k-1}
+        }
+        inv3full(D, Dinv);
+        for (int a = 0; a < 9; a++) { F[a] = Dinv[a]; F[9 + a] = G[a]; }
+        for (int a = 0; a < 3; a++) { z[a] = w[a]; P.yb[3 * (size_t)k + a] = w[a]; }
+    }
+    double y[3] = {0, 0, 0};
+    for (int k = k1 - 1; k >= k0; k--) {
+        const double* F = P.fac + 18 * (size_t)k; double* yk = P.yb + 3 * (size_t)k;
+        double u[3];
+        for (int a = 0; a < 3; a++) u[a] = F[a * 3] * yk[0] + F[a * 3 + 1] * yk[1] + F[a * 3 + 2] * yk[2];
+        if (k + 1 < k1) { const double* Gn = P.fac + 18 * (size_t)(k + 1) + 9; for (int a = 0; a < 3; a++) u[a] -= Gn[a * 3] * y[0] + Gn[a * 3 + 1] * y[1] + Gn[a * 3 + 2] * y[2]; }
+        for (int a = 0; a < 3; a++) { y[a] = u[a]; yk[a] = u[a]; }
+    }
+}
+// Reduced-system contribution of the chains: one wave per chain, one lane per column of the chain's coupling block
+// W_c^T (6 columns for each camera of the chain and each H of the chain, + one column for the right-hand side): the lane
+// solves V y = w with the stored factor (y kept in this wave's scratch slice, [3L][64] so that lanes coalesce) and
+// subtracts W y from the lower triangle of S (r for the last column).
+__global__ __launch_bounds__(64) void k_badyn_schur(BaDev P, double* __restrict__ scratch, int lmax)
+{
+    const int lane = threadIdx.x;
+    double* zs = scratch + (size_t)blockIdx.x * 64 * 3 * lmax + lane;
+    const int n6 = P.n6;
+    for (int c = blockIdx.x; c < P.n_chain; c += gridDim.x) {
+        const int k0 = P.chain_start[c], L = P.chain_start[c + 1] - k0;
+        const int nslot = 2 * L - 1, ncol = 6 * nslot + 1;
+        for (int col = lane; col < ncol; col += 64) {
+            const bool rhs = col == ncol - 1;
+            const int slot = col / 6, q = col - slot * 6;
+            // support of the column: point j (and j-1 for an H column)
+            const int j = rhs ? 0 : (slot < L ? slot : slot - L + 1);
+            const bool isH = !rhs && slot >= L;
+            const int first = rhs ? 0 : (isH ? j - 1 : j);
+            const int pose_b = rhs ? -1 : (isH ? P.dyn_hin[k0 + j] : P.dyn_cam[k0 + j]);
+            if (!rhs) {
+                double z[3] = {0, 0, 0};
+                for (int k = first; k < L; k++) {
+                    double w[3] = {0, 0, 0};
+                    if (isH) { if (k == j) { const double* W = P.Wi + 18 * (size_t)(k0 + k) + q * 3; w[0] = W[0]; w[1] = W[1]; w[2] = W[2]; }
+                               else if (k == j - 1) { const double* W = P.Wo + 18 * (size_t)(k0 + k) + q * 3; w[0] = W[0]; w[1] = W[1]; w[2] = W[2]; } }
+                    else if (k == j) { const double* W = P.Wc + 18 * (size_t)(k0 + k) + q * 3; w[0] = W[0]; w[1] = W[1]; w[2] = W[2]; }
+                    if (k > first) { const double* G = P.fac + 18 * (size_t)(k0 + k) + 9; for (int a = 0; a < 3; a++) w[a] -= G[a] * z[0] + G[3 + a] * z[1] + G[6 + a] * z[2]; }
+                    for (int a = 0; a < 3; a++) { z[a] = w[a]; zs[(size_t)(3 * k + a) * 64] = w[a]; }
+                }
+                double y[3] = {0, 0, 0};
+                for (int k = L - 1; k >= 0; k--) {
+                    double u[3] = {0, 0, 0};
+                    if (k >= first) { const double* F = P.fac + 18 * (size_t)(k0 + k); const double z0 = zs[(size_t)(3 * k) * 64], z1 = zs[(size_t)(3 * k + 1) * 64], z2 = zs[(size_t)(3 * k + 2) * 64];
+                                      for (int a = 0; a < 3; a++) u[a] = F[a * 3] * z0 + F[a * 3 + 1] * z1 + F[a * 3 + 2] * z2; }
+                    if (k + 1 < L) { const double* Gn = P.fac + 18 * (size_t)(k0 + k + 1) + 9; for (int a = 0; a < 3; a++) u[a] -= Gn[a * 3] * y[0] + Gn[a * 3 + 1] * y[1] + Gn[a * 3 + 2] * y[2]; }
+                    for (int a = 0; a < 3; a++) { y[a] = u[a]; zs[(size_t)(3 * k + a) * 64] = u[a]; }
+                }
+            }
+            // S[(pose_a, p), (pose_b, q)] -= sum_pts W_{a,pt}[p,:] . y[pt]    (pose_a >= pose_b only)
+            for (int k = 0; k < L; k++) {
+                double y[3];
+                if (rhs) { y[0] = P.yb[3 * (size_t)(k0 + k)]; y[1] = P.yb[3 * (size_t)(k0 + k) + 1]; y[2] = P.yb[3 * (size_t)(k0 + k) + 2]; }
+                else { y[0] = zs[(size_t)(3 * k) * 64]; y[1] = zs[(size_t)(3 * k + 1) * 64]; y[2] = zs[(size_t)(3 * k + 2) * 64]; }
+                const int hk = P.dyn_hin[k0 + k], hn = (k + 1 < L) ? P.dyn_hin[k0 + k + 1] : -1;
+                const int poses[3] = {P.dyn_cam[k0 + k], hk, hn};
+                const double* Ws[3] = {P.Wc + 18 * (size_t)(k0 + k), P.Wi + 18 * (size_t)(k0 + k), P.Wo + 18 * (size_t)(k0 + k)};
+                for (int t = 0; t < 3; t++) {
+                    const int pa = poses[t];
+                    if (pa < 0 || (!rhs && pa < pose_b)) continue;
+                    const double* W = Ws[t];
+                    for (int pp = 0; pp < 6; pp++) {
+                        const double v = W[pp * 3] * y[0] + W[pp * 3 + 1] * y[1] + W[pp * 3 + 2] * y[2];
+                        if (v == 0.0) continue;
+                        if (rhs) atomicAdd(P.r + 6 * pa + pp, -v);
+                        else atomicAdd(P.S + (size_t)(6 * pa + pp) * n6 + 6 * pose_b + q, -v);
+                    }
+                }
+            }
+        }
+    }
+}
+// back-substitution of one chain per thread: V dx = bd - W^T x_pose, p_new = p + dx, and the chain's part of computeScale
+__global__ __launch_bounds__(64) void k_badyn_backsub(BaDev P, double lambda)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    double sc = 0;
+    if (c < P.n_chain) {
+        const int k0 = P.chain_start[c], k1 = P.chain_start[c + 1];
+        double z[3] = {0, 0, 0};
+        for (int k = k0; k < k1; k++) {
+            double w[3] = {P.bd[3 * (size_t)k], P.bd[3 * (size_t)k + 1], P.bd[3 * (size_t)k + 2]};
+            const int hk = P.dyn_hin[k], hn = (k + 1 < k1) ? P.dyn_hin[k + 1] : -1;
+            const int poses[3] = {P.dyn_cam[k], hk, hn};
+            const double* Ws[3] = {P.Wc + 18 * (size_t)k, P.Wi + 18 * (size_t)k, P.Wo + 18 * (size_t)k};
+            for (int t = 0; t < 3; t++) {
+                if (poses[t] < 0) continue;
+                const double* x = P.x + 6 * poses[t]; const double* W = Ws[t];
+                for (int a = 0; a < 6; a++) { w[0] -= W[a * 3] * x[a]; w[1] -= W[a * 3 + 1] * x[a]; w[2] -= W[a * 3 + 2] * x[a]; }
+            }
+            if (k > k0) { const double* G = P.fac + 18 * (size_t)k + 9; for (int a = 0; a < 3; a++) w[a] -= G[a] * z[0] + G[3 + a] * z[1] + G[6 + a] * z[2]; }
+            for (int a = 0; a < 3; a++) { z[a] = w[a]; P.dyn_new[3 * (size_t)k + a] = w[a]; }
+        }
+        double y[3] = {0, 0, 0};
+        for (int k = k1 - 1; k >= k0; k--) {
+            const double* F = P.fac + 18 * (size_t)k; double* zk = P.dyn_new + 3 * (size_t)k;
+            double u[3];
+            for (int a = 0; a < 3; a++) u[a] = F[a * 3] * zk[0] + F[a * 3 + 1] * zk[1] + F[a * 3 + 2] * zk[2];
+            if (k + 1 < k1) { const double* Gn = P.fac + 18 * (size_t)(k + 1) + 9; for (int a = 0; a < 3; a++) u[a] -= Gn[a * 3] * y[0] + Gn[a * 3 + 1] * y[1] + Gn[a * 3 + 2] * y[2]; }
+            for (int a = 0; a < 3; a++) { y[a] = u[a]; sc += u[a] * (lambda * u[a] + P.bd[3 * (size_t)k + a]); zk[a] = P.dyn[3 * (size_t)k + a] + u[a]; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o, 64);
+    if ((threadIdx.x & 63) == 0 && sc != 0) atomicAdd(P.scal + 3, sc);
+}
+__global__ __launch_bounds__(256) void k_badyn_chi2(BaDev P, const double* cam, const double* dyn, double* out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    double v = 0;
+    if (k < P.n_dyn) {
+        const double* X = cam + 12 * P.dyn_cam[k]; const double* p = dyn + 3 * (size_t)k; const double* m = P.dyn_meas + 3 * (size_t)k;
+        const double d0 = p[0] - X[3], d1 = p[1] - X[7], d2 = p[2] - X[11];
+        const double e0 = X[0] * d0 + X[4] * d1 + X[8] * d2 - m[0], e1 = X[1] * d0 + X[5] * d1 + X[9] * d2 - m[1], e2 = X[2] * d0 + X[6] * d1 + X[10] * d2 - m[2];
+        double w; huber_w(P.info_dyn * (e0 * e0 + e1 * e1 + e2 * e2), P.huber_dyn, P.use_huber, v, w);
+        const int hin = P.dyn_hin[k];
+        if (hin >= 0) {
+            double e[3], vv[3], r0; tern_eval(cam + 12 * hin, p - 3, p, e, vv);
+            huber_w(P.info_tern * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), P.huber_tern, P.use_huber, r0, w);
+            v += r0;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(out, v);
+}
+
 // ---- host driver ---------------------------------------------------------------------------------------------
 struct BaState {
     std::vector<void*> allocs;
     double* h_scal = nullptr;      // pinned [8]
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double* d_parts = nullptr; size_t parts_cap = 0;
+    double* d_scratch = nullptr; size_t scratch_cap = 0;
     char* pool = nullptr; char* h_pool = nullptr; size_t pool_cap = 0;
 };
 void ba_state_destroy(vido_ctx* ctx)
 {
     BaState* S = ctx->ba; if (!S) return;
     for (void* p : S->allocs) hipFree(p);
-    hipFree(S->d_parts); hipHostFree(S->h_scal); hipFree(S->pool); hipHostFree(S->h_pool);
+    hipFree(S->d_parts); hipFree(S->d_scratch); hipHostFree(S->h_scal); hipFree(S->pool); hipHostFree(S->h_pool);
     if (S->ev0) hipEventDestroy(S->ev0);
     if (S->ev1) hipEventDestroy(S->ev1);
     delete S; ctx->ba = nullptr;
@@ -603,11 +877,28 @@ static int chol_large(vido_ctx* ctx, double* A, int n, double* x, double* okflag
     return VIDO_OK;
 }
 
+static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, vido_ba_result* res, vido_allreduce_fn allreduce, void* user);
 extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_result* res, vido_allreduce_fn allreduce, void* user)
+{
+    return ba_run(ctx, prob, nullptr, res, allreduce, user);
+}
+extern "C" int vido_ba_optimize_dynamic(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dyn, vido_ba_result* res, vido_allreduce_fn allreduce, void* user)
+{
+    return ba_run(ctx, prob, dyn, res, allreduce, user);
+}
+
+static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, vido_ba_result* res, vido_allreduce_fn allreduce, void* user)
 {
     if (!ctx) return VIDO_E_INVALID;
     if (!prob || !res) return vido_set_error(ctx, VIDO_E_INVALID, "ba: null problem/result");
     const vido_ba_problem& p = *prob;
+    static const vido_ba_dynamic no_dyn{};
+    const vido_ba_dynamic& dy = (dynp && p.rank == 0) ? *dynp : no_dyn;      // rank 0 owns the object part (like the camera-camera factors)
+    if (dy.n_H < 0 || dy.n_dyn < 0 || dy.n_tern < 0 || dy.n_smooth < 0 || (dy.n_H && !dy.H_T) || (dy.n_dyn && (!dy.dyn_xyz || !dy.dyn_cam || !dy.dyn_meas)) ||
+        (dy.n_tern && (!dy.tern_prev || !dy.tern_cur || !dy.tern_H)) || (dy.n_smooth && (!dy.sm_i || !dy.sm_j)))
+        return vido_set_error(ctx, VIDO_E_INVALID, "ba: malformed dynamic part");
+    const int n_H = dynp ? dynp->n_H : 0;                                    // every rank carries the H vertices (replicated reduced solve)
+    const int n_pose = p.n_cam + n_H;
     if (p.n_cam < 1 || p.n_pt < 0 || p.n_obs < 0 || p.n_odo < 0 || !p.cam_T || (p.n_pt && !p.pt_xyz) ||
         (p.n_obs && (!p.obs_cam || !p.obs_pt || !p.obs_meas)) || (p.n_odo && (!p.odo_i || !p.odo_j || !p.odo_T)) || p.prior_cam >= p.n_cam)
         return vido_set_error(ctx, VIDO_E_INVALID, "ba: malformed problem");
@@ -620,7 +911,56 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
                     HIP_TRY(ctx, hipEventCreate(&ctx->ba->ev0)); HIP_TRY(ctx, hipEventCreate(&ctx->ba->ev1)); }
     BaState* BS = ctx->ba;
     hipStream_t st = ctx->stream;
-    const int n6 = 6 * p.n_cam, n_ptl = pt_hi - pt_lo;
+    const int n6 = 6 * n_pose, n_ptl = pt_hi - pt_lo;
+    // ---- object part: order the dynamic points chain-major (a chain = points linked by ternary edges)
+    const int nd = dy.n_dyn;
+    std::vector<int> d_order, d_new(nd, -1), d_cam(nd), d_hin(nd, -1), chain_start;
+    std::vector<double> d_xyz((size_t)nd * 3), d_meas((size_t)nd * 3);
+    int lmax = 0;
+    if (nd) {
+        std::vector<int> tin(nd, -1), tout(nd, -1);
+        for (int k = 0; k < dy.n_tern; k++) {
+            const int a = dy.tern_prev[k], c = dy.tern_cur[k], h = dy.tern_H[k];
+            if (a < 0 || a >= nd || c < 0 || c >= nd || a == c || h < 0 || h >= n_H) return vido_set_error(ctx, VIDO_E_INVALID, "ba: ternary edge %d has a bad index", k);
+            if (tin[c] >= 0 || tout[a] >= 0) return vido_set_error(ctx, VIDO_E_INVALID, "ba: ternary edge %d: dynamic points must form chains (one predecessor, one successor)", k);
+            tin[c] = k; tout[a] = k;
+        }
+        d_order.reserve(nd);
+        for (int s = 0; s < nd; s++) {
+            if (tin[s] >= 0) continue;
+            chain_start.push_back((int)d_order.size());
+            for (int k = s; ; k = dy.tern_cur[tout[k]]) {
+                d_new[k] = (int)d_order.size(); d_order.push_back(k);
+                if (tout[k] < 0) break;
+                if ((int)d_order.size() > nd) break;
+            }
+            lmax = std::max(lmax, (int)d_order.size() - chain_start.back());
+        }
+        if ((int)d_order.size() != nd) return vido_set_error(ctx, VIDO_E_INVALID, "ba: ternary edges form a cycle");
+        chain_start.push_back(nd);
+        for (int t = 0; t < nd; t++) {
+            const int k = d_order[t];
+            if (dy.dyn_cam[k] < 0 || dy.dyn_cam[k] >= p.n_cam) return vido_set_error(ctx, VIDO_E_INVALID, "ba: dynamic point %d has a bad camera", k);
+            d_cam[t] = dy.dyn_cam[k]; d_hin[t] = tin[k] >= 0 ? p.n_cam + dy.tern_H[tin[k]] : -1;
+            for (int a = 0; a < 3; a++) { d_xyz[3 * (size_t)t + a] = dy.dyn_xyz[3 * (size_t)k + a]; d_meas[3 * (size_t)t + a] = dy.dyn_meas[3 * (size_t)k + a]; }
+        }
+    }
+    const int n_chain = nd ? (int)chain_start.size() - 1 : 0;
+    // camera-camera factor list: odometry edges, then the object-motion smoothness edges (EdgeSE3 between H vertices, Z = I)
+    const int n_cc = p.n_odo + dy.n_smooth;
+    std::vector<int> cc_i(n_cc), cc_j(n_cc); std::vector<double> cc_T((size_t)n_cc * 12), cc_info(n_cc), cc_delta(n_cc);
+    for (int k = 0; k < p.n_odo; k++) {
+        if (p.odo_i[k] < 0 || p.odo_i[k] >= p.n_cam || p.odo_j[k] < 0 || p.odo_j[k] >= p.n_cam) return vido_set_error(ctx, VIDO_E_INVALID, "ba: odometry edge %d has a bad index", k);
+        cc_i[k] = p.odo_i[k]; cc_j[k] = p.odo_j[k]; memcpy(&cc_T[12 * (size_t)k], p.odo_T + 12 * (size_t)k, 12 * sizeof(double)); cc_info[k] = p.info_odo; cc_delta[k] = p.huber_odo;
+    }
+    for (int k = 0; k < dy.n_smooth; k++) {
+        if (dy.sm_i[k] < 0 || dy.sm_i[k] >= n_H || dy.sm_j[k] < 0 || dy.sm_j[k] >= n_H) return vido_set_error(ctx, VIDO_E_INVALID, "ba: smoothness edge %d has a bad index", k);
+        const int t = p.n_odo + k; static const double I12[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        cc_i[t] = p.n_cam + dy.sm_i[k]; cc_j[t] = p.n_cam + dy.sm_j[k]; memcpy(&cc_T[12 * (size_t)t], I12, sizeof I12); cc_info[t] = dy.info_smooth; cc_delta[t] = dy.huber_smooth;
+    }
+    std::vector<double> poses((size_t)n_pose * 12);
+    memcpy(poses.data(), p.cam_T, (size_t)p.n_cam * 12 * sizeof(double));
+    if (n_H) memcpy(poses.data() + (size_t)p.n_cam * 12, dynp->H_T, (size_t)n_H * 12 * sizeof(double));
     // ---- host preprocessing: keep this shard's observations, sort by camera, build the landmark-major slots
     std::vector<int> keep; keep.reserve(p.n_obs);
     for (int k = 0; k < p.n_obs; k++) {
@@ -636,12 +976,12 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
     for (int l = 0; l < n_ptl; l++) { maxk = std::max(maxk, pstart[l + 1]); pstart[l + 1] += pstart[l]; }
     if (maxk > 64) return vido_set_error(ctx, VIDO_E_CAPACITY, "ba: a landmark has %d observations; this build handles tracks up to 64", maxk);
     { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (int t = 0; t < no; t++) { opos[t] = fill[opt[t]]++; slotcam[opos[t]] = ocam[t]; } }
-    for (int k = 0; k < p.n_odo; k++) if (p.odo_i[k] < 0 || p.odo_i[k] >= p.n_cam || p.odo_j[k] < 0 || p.odo_j[k] >= p.n_cam) return vido_set_error(ctx, VIDO_E_INVALID, "ba: odometry edge %d has a bad index", k);
     // ---- device buffers
     {   // size the persistent pool (device + pinned mirror for the uploads) for this problem
-        const size_t nd = (size_t)p.n_cam * (24 + 36 + 36) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + 18) + (size_t)p.n_odo * (12 + 36) + (size_t)n6 * n6 + 5 * (size_t)n6 + 64;
-        const size_t ni32 = 4 * (size_t)no + (size_t)n_ptl + (size_t)n_ptl / 32 + 2 * (size_t)p.n_odo + 256;
-        const size_t need = nd * 8 + ni32 * 4 + 64 * 256;
+        const size_t ndb = (size_t)n_pose * (24 + 36 + 36) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + 18) + (size_t)n_cc * (12 + 36 + 2) + (size_t)n6 * n6 + 5 * (size_t)n6 + 64 +
+                           (size_t)nd * (3 + 3 + 3 + 6 + 3 + 9 + 18 * 4 + 3);
+        const size_t ni32 = 4 * (size_t)no + (size_t)n_ptl + (size_t)n_ptl / 32 + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 256;
+        const size_t need = ndb * 8 + ni32 * 4 + 96 * 256;
         if (need > BS->pool_cap) {
             HIP_TRY(ctx, hipStreamSynchronize(st));
             if (BS->pool) { hipFree(BS->pool); hipHostFree(BS->h_pool); BS->pool = nullptr; BS->h_pool = nullptr; }
@@ -651,22 +991,37 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
     }
     Arena A{BS->pool, BS->pool_cap, 0, false, BS->h_pool};
     BaDev D{};
-    D.n_cam = p.n_cam; D.n_pt = p.n_pt; D.n_obs = no; D.n_odo = owns_cam_factors ? p.n_odo : 0; D.prior_cam = owns_cam_factors ? p.prior_cam : -1;
+    D.n_cam = n_pose; D.n_pt = p.n_pt; D.n_obs = no; D.n_odo = owns_cam_factors ? n_cc : 0; D.prior_cam = owns_cam_factors ? p.prior_cam : -1;
     D.use_huber = p.use_huber; D.n6 = n6; D.pt_lo = pt_lo;
     D.info_obs = p.info_obs; D.info_odo = p.info_odo; D.info_prior = p.info_prior; D.huber_obs = p.huber_obs; D.huber_odo = p.huber_odo;
     memcpy(D.prior_T, p.prior_T, sizeof D.prior_T);
-    D.cam = A.put(p.cam_T, (size_t)p.n_cam * 12, st); D.cam_new = A.get<double>((size_t)p.n_cam * 12);
+    D.cam = A.put(poses.data(), (size_t)n_pose * 12, st); D.cam_new = A.get<double>((size_t)n_pose * 12);
     D.pt = A.put(p.pt_xyz + 3 * (size_t)pt_lo, (size_t)n_ptl * 3, st); D.pt_new = A.get<double>((size_t)n_ptl * 3);
     D.obs_cam = A.put(ocam.data(), no, st); D.obs_pt = A.put(opt.data(), no, st); D.obs_pos = A.put(opos.data(), no, st);
     D.obs_meas = A.put(omeas.data(), (size_t)no * 3, st); D.pt_start = A.put(pstart.data(), n_ptl + 1, st); D.slot_cam = A.put(slotcam.data(), no, st);
-    D.odo_i = A.put(p.odo_i, p.n_odo, st); D.odo_j = A.put(p.odo_j, p.n_odo, st); D.odo_T = A.put(p.odo_T, (size_t)p.n_odo * 12, st);
+    D.odo_i = A.put(cc_i.data(), n_cc, st); D.odo_j = A.put(cc_j.data(), n_cc, st); D.odo_T = A.put(cc_T.data(), (size_t)n_cc * 12, st);
+    D.odo_info = A.put(cc_info.data(), n_cc, st); D.odo_delta = A.put(cc_delta.data(), n_cc, st);
     D.W = A.get<double>((size_t)no * 18); D.Hpp = A.get<double>((size_t)n_ptl * 6); D.bp = A.get<double>((size_t)n_ptl * 3);
-    D.Hcd = A.get<double>((size_t)p.n_cam * 36); D.bc = A.get<double>(n6); D.Hodo = A.get<double>((size_t)p.n_odo * 36);
+    D.Hodo = A.get<double>((size_t)n_cc * 36);
+    // object part
+    D.n_dyn = nd; D.n_chain = n_chain; D.info_dyn = dy.info_dyn; D.info_tern = dy.info_tern; D.huber_dyn = dy.huber_dyn; D.huber_tern = dy.huber_tern;
+    if (nd) {
+        D.dyn = A.put(d_xyz.data(), (size_t)nd * 3, st); D.dyn_new = A.get<double>((size_t)nd * 3); D.dyn_meas = A.put(d_meas.data(), (size_t)nd * 3, st);
+        D.dyn_cam = A.put(d_cam.data(), nd, st); D.dyn_hin = A.put(d_hin.data(), nd, st); D.chain_start = A.put(chain_start.data(), n_chain + 1, st);
+        D.Vd = A.get<double>((size_t)nd * 6); D.bd = A.get<double>((size_t)nd * 3); D.U = A.get<double>((size_t)nd * 9);
+        D.Wc = A.get<double>((size_t)nd * 18); D.Wi = A.get<double>((size_t)nd * 18); D.Wo = A.get<double>((size_t)nd * 18); D.fac = A.get<double>((size_t)nd * 18);
+        D.yb = A.get<double>((size_t)nd * 3);
+    }
+    const int dyn_grid = std::min(n_chain, 512);
+    if (nd && (size_t)dyn_grid * 64 * 3 * lmax > BS->scratch_cap) {      // per-wave column scratch of k_badyn_schur (device only, not mirrored)
+        HIP_TRY(ctx, hipStreamSynchronize(st)); if (BS->d_scratch) hipFree(BS->d_scratch);
+        BS->scratch_cap = (size_t)512 * 64 * 3 * lmax; HIP_TRY(ctx, hipMalloc((void**)&BS->d_scratch, BS->scratch_cap * sizeof(double)));
+    }
     // S and r are contiguous so that one all-reduce covers both
     double* Sr = A.get<double>((size_t)n6 * n6 + n6); D.S = Sr; D.r = Sr + (size_t)n6 * n6; D.x = A.get<double>(n6);
     double* chol_tmp = A.get<double>(64);
-    double* red = A.get<double>((size_t)p.n_cam * 36 + n6 + 8);      // [Hcd | bc | scal] contiguous for the linearisation all-reduce
-    D.Hcd = red; D.bc = red + (size_t)p.n_cam * 36; D.scal = D.bc + n6;
+    double* red = A.get<double>((size_t)n_pose * 36 + n6 + 8);      // [Hcd | bc | scal] contiguous for the linearisation all-reduce
+    D.Hcd = red; D.bc = red + (size_t)n_pose * 36; D.scal = D.bc + n6;
     if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device allocation failed (n6=%d, n_obs=%d)", n6, no);
     const bool lds_path = n6 <= BA_LDS_MAX_N6;
     const int schur_grid = lds_path ? std::min(256, std::max(1, (n_ptl + 3) / 4)) : std::min(4096, std::max(1, (n_ptl + 3) / 4));
@@ -703,6 +1058,7 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
     auto chi2_at = [&](const double* cam, const double* pt, int slot, double* out) -> int {
         HIP_TRY(ctx, hipMemsetAsync(D.scal + slot, 0, sizeof(double), st));
         if (no) hipLaunchKernelGGL(k_ba_chi2, dim3((no + 255) / 256), dim3(256), 0, st, D, cam, pt, D.scal + slot);
+        if (nd) hipLaunchKernelGGL(k_badyn_chi2, dim3((nd + 255) / 256), dim3(256), 0, st, D, cam, (const double*)D.dyn, D.scal + slot);
         const int ncf = D.n_odo + (D.prior_cam >= 0 ? 1 : 0);
         if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3(ncf), dim3(64), 0, st, D, 0, cam, D.scal + slot);
         int rc = AR(D.scal + slot, 1, 0); if (rc) return rc;
@@ -719,12 +1075,13 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
     res->chi2_final = res->chi2_initial;
     for (it = 0; it < p.max_iters; it++) {
         // ---- linearise
-        HIP_TRY(ctx, hipMemsetAsync(red, 0, ((size_t)p.n_cam * 36 + n6 + 8) * sizeof(double), st));
+        HIP_TRY(ctx, hipMemsetAsync(red, 0, ((size_t)n_pose * 36 + n6 + 8) * sizeof(double), st));
         HIP_TRY(ctx, hipMemsetAsync(D.Hpp, 0, (size_t)n_ptl * 6 * sizeof(double), st));
         HIP_TRY(ctx, hipMemsetAsync(D.bp, 0, (size_t)n_ptl * 3 * sizeof(double), st));
         HIP_TRY(ctx, hipEventRecord(BS->ev0, st));
         if (no) hipLaunchKernelGGL(k_ba_linearize, dim3((no + 255) / 256), dim3(256), 0, st, D);
         HIP_TRY(ctx, hipEventRecord(BS->ev1, st));
+        if (nd) hipLaunchKernelGGL(k_badyn_linearize, dim3((nd + 255) / 256), dim3(256), 0, st, D);
         n_lin++;
         const int ncf = D.n_odo + (D.prior_cam >= 0 ? 1 : 0);
         if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3(ncf), dim3(64), 0, st, D, 1, D.cam, D.scal + 0);
@@ -732,11 +1089,11 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
         HIP_TRY(ctx, hipGetLastError());
         if (allreduce) {     // camera diagonal blocks, bc, chi2 (sum) — then the max-diagonal (max) on its own
             if (it == 0) { HIP_TRY(ctx, hipStreamSynchronize(st)); double md; HIP_TRY(ctx, hipMemcpy(&md, D.scal + 1, 8, hipMemcpyDeviceToHost)); HIP_TRY(ctx, hipMemsetAsync(D.scal + 1, 0, 8, st));
-                           if ((rc = AR(red, (size_t)p.n_cam * 36 + n6 + 1, 0))) return rc;
+                           if ((rc = AR(red, (size_t)n_pose * 36 + n6 + 1, 0))) return rc;
                            HIP_TRY(ctx, hipMemcpy(D.scal + 1, &md, 8, hipMemcpyHostToDevice)); if ((rc = AR(D.scal + 1, 1, 1))) return rc;
                            // the camera part of the max must see the SUMMED camera diagonals
                            hipLaunchKernelGGL(k_ba_maxdiag, dim3(64), dim3(256), 0, st, D, 0); if ((rc = AR(D.scal + 1, 1, 1))) return rc; }
-            else if ((rc = AR(red, (size_t)p.n_cam * 36 + n6 + 1, 0))) return rc;
+            else if ((rc = AR(red, (size_t)n_pose * 36 + n6 + 1, 0))) return rc;
         }
         if ((rc = read_scal())) return rc;
         { float ms = 0; if (hipEventElapsedTime(&ms, BS->ev0, BS->ev1) == hipSuccess) ms_lin += ms; }
@@ -756,6 +1113,10 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
                     hipLaunchKernelGGL(k_ba_fold_parts, dim3(std::min(256, (int)((sz_sr + 255) / 256))), dim3(256), 0, st, D, BS->d_parts, schur_grid);
                 } else hipLaunchKernelGGL(k_ba_schur<2>, dim3(std::min(n_chunks, 1024)), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, (double*)nullptr, (const int*)d_chunk_cmin);
             }
+            if (nd) {
+                hipLaunchKernelGGL(k_badyn_factor, dim3((n_chain + 63) / 64), dim3(64), 0, st, D, lambda);
+                hipLaunchKernelGGL(k_badyn_schur, dim3(dyn_grid), dim3(64), 0, st, D, BS->d_scratch, lmax);
+            }
             HIP_TRY(ctx, hipGetLastError());
             if ((rc = AR(Sr, sz_sr, 0))) return rc;
             // ---- replicated reduced solve
@@ -763,10 +1124,12 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
             if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
             else { const double one = 1.0; HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4, &one, 8, hipMemcpyHostToDevice, st)); if ((rc = chol_large(ctx, D.S, n6, D.x, D.scal + 4, chol_tmp, st))) return rc; }
             // ---- trial state + its chi2
-            hipLaunchKernelGGL(k_ba_update_cams, dim3((p.n_cam + 63) / 64), dim3(64), 0, st, D, (allreduce && p.rank != 0) ? 0.0 : lambda);
+            hipLaunchKernelGGL(k_ba_update_cams, dim3((n_pose + 63) / 64), dim3(64), 0, st, D, (allreduce && p.rank != 0) ? 0.0 : lambda);
             if (allreduce && p.rank != 0) HIP_TRY(ctx, hipMemsetAsync(D.scal + 3, 0, sizeof(double), st));      // camera part of computeScale counted once (rank 0)
             if (n_ptl) hipLaunchKernelGGL(k_ba_backsub, dim3((n_ptl + 255) / 256), dim3(256), 0, st, D, n_ptl, lambda);
             if (no) hipLaunchKernelGGL(k_ba_chi2, dim3((no + 255) / 256), dim3(256), 0, st, D, D.cam_new, D.pt_new, D.scal + 2);
+            if (nd) { hipLaunchKernelGGL(k_badyn_backsub, dim3((n_chain + 63) / 64), dim3(64), 0, st, D, lambda);
+                      hipLaunchKernelGGL(k_badyn_chi2, dim3((nd + 255) / 256), dim3(256), 0, st, D, (const double*)D.cam_new, (const double*)D.dyn_new, D.scal + 2); }
             if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3(ncf), dim3(64), 0, st, D, 0, D.cam_new, D.scal + 2);
             HIP_TRY(ctx, hipGetLastError());
             if ((rc = AR(D.scal + 2, 2, 0))) return rc;
@@ -777,7 +1140,7 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
             if (rho > 0 && std::isfinite(tempChi)) {
                 double alpha = 1. - pow((2 * rho - 1), 3); alpha = std::min(alpha, 2. / 3.);
                 lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;
-                std::swap(D.cam, D.cam_new); std::swap(D.pt, D.pt_new);
+                std::swap(D.cam, D.cam_new); std::swap(D.pt, D.pt_new); std::swap(D.dyn, D.dyn_new);
             } else { lambda *= ni; ni *= 2; }
             qmax++; trials++;
         } while (rho < 0 && qmax < 10);
@@ -796,6 +1159,9 @@ extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_re
     res->ms_solve_loop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
     HIP_TRY(ctx, hipMemcpyAsync(prob->cam_T, D.cam, (size_t)p.n_cam * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (n_ptl) HIP_TRY(ctx, hipMemcpyAsync(prob->pt_xyz + 3 * (size_t)pt_lo, D.pt, (size_t)n_ptl * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (n_H) HIP_TRY(ctx, hipMemcpyAsync(dynp->H_T, D.cam + (size_t)p.n_cam * 12, (size_t)n_H * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (nd) HIP_TRY(ctx, hipMemcpyAsync(d_xyz.data(), D.dyn, (size_t)nd * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int t = 0; t < nd; t++) for (int a = 0; a < 3; a++) dynp->dyn_xyz[3 * (size_t)d_order[t] + a] = d_xyz[3 * (size_t)t + a];
     return VIDO_OK;
 }

@@ -388,7 +388,29 @@ def landmark_shards(obs_pt, n_pt, world):
     return [(int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
 
 
-def ba_optimize(ctx, k, rank=0, world=1, shard=None, allreduce=None):
+class BaDynamic(C.Structure):
+    _fields_ = [("n_H", C.c_int32), ("n_dyn", C.c_int32), ("n_tern", C.c_int32), ("n_smooth", C.c_int32),
+                ("H_T", C.c_void_p), ("dyn_xyz", C.c_void_p), ("dyn_cam", C.c_void_p), ("dyn_meas", C.c_void_p),
+                ("tern_prev", C.c_void_p), ("tern_cur", C.c_void_p), ("tern_H", C.c_void_p), ("sm_i", C.c_void_p), ("sm_j", C.c_void_p),
+                ("info_dyn", C.c_double), ("info_tern", C.c_double), ("info_smooth", C.c_double),
+                ("huber_dyn", C.c_double), ("huber_tern", C.c_double), ("huber_smooth", C.c_double)]
+
+
+def _ba_dynamic_struct(d):
+    b = dict(H_T=np.array(d["H_T"], np.float64).reshape(-1, 12).copy(), dyn_xyz=np.array(d["dyn_xyz"], np.float64).reshape(-1, 3).copy(),
+             dyn_cam=np.ascontiguousarray(d["dyn_cam"], np.int32), dyn_meas=np.ascontiguousarray(d["dyn_meas"], np.float64).reshape(-1, 3))
+    for name in ("tern_prev", "tern_cur", "tern_H", "sm_i", "sm_j"):
+        b[name] = np.ascontiguousarray(d[name], np.int32)
+    s = BaDynamic()
+    s.n_H, s.n_dyn, s.n_tern, s.n_smooth = len(b["H_T"]), len(b["dyn_cam"]), len(b["tern_prev"]), len(b["sm_i"])
+    for name in b:
+        setattr(s, name, b[name].ctypes.data)
+    for name in ("info_dyn", "info_tern", "info_smooth", "huber_dyn", "huber_tern", "huber_smooth"):
+        setattr(s, name, float(d[name]))
+    return s, b
+
+
+def ba_optimize(ctx, k, rank=0, world=1, shard=None, allreduce=None, dynamic=None):
     """Mirror of Optimizer::PartialBatchOptimization / FullBatchOptimization (Optimizer.h:30-31) on the flat problem
     dict built by vido_slam_amd.problems.synth_ba_problem (or by the C++ facade from Map).  Returns the updated
     poses/points and LM statistics.  With world > 1 every rank calls this with its (rank, shard) and the hook."""
@@ -408,10 +430,16 @@ def ba_optimize(ctx, k, rank=0, world=1, shard=None, allreduce=None):
     p.pt_lo, p.pt_hi, p.rank, p.world = lo, hi, rank, world
     r = BaResult()
     fn = allreduce if allreduce is not None else C.cast(None, ALLREDUCE_FN)
-    ctx._check(ctx.lib.vido_ba_optimize(ctx.h, C.byref(p), C.byref(r), fn, None))
+    extra = {}
+    if dynamic is not None:          # object part of FullBatchOptimization (problems.synth_ba_dynamic)
+        s, b = _ba_dynamic_struct(dynamic)
+        ctx._check(ctx.lib.vido_ba_optimize_dynamic(ctx.h, C.byref(p), C.byref(s), C.byref(r), fn, None))
+        extra = dict(H_T=b["H_T"].reshape(-1, 3, 4), dyn_xyz=b["dyn_xyz"])
+    else:
+        ctx._check(ctx.lib.vido_ba_optimize(ctx.h, C.byref(p), C.byref(r), fn, None))
     return dict(cam_T=a["cam_T"].reshape(-1, 3, 4), pt_xyz=a["pt_xyz"], iterations=r.iterations, lm_trials=r.lm_trials,
                 chi2_initial=r.chi2_initial, chi2_final=r.chi2_final, lambda_final=r.lambda_final, ms_setup=r.ms_setup,
-                ms_solve_loop=r.ms_solve_loop, ms_linearize_kernel=r.ms_linearize_kernel)
+                ms_solve_loop=r.ms_solve_loop, ms_linearize_kernel=r.ms_linearize_kernel, **extra)
 
 
 def pnp_ransac(ctx, pts3d, pts2d, K, max_iters=500, reproj_err=0.4, confidence=0.98, seed=1):

@@ -154,3 +154,57 @@ def synth_ba_problem(n_cam=20, n_pt=2000, seed=7, kind="local", track_len=None, 
              cam_true=np.stack([_iso(c) for c in cams]), pt_true=pts)
     d.update(ba_constants(kind))
     return d
+
+
+def dyn_constants():
+    """Optimizer.cc:1333-1338,1358: sigma2_3d_dyn 80, sigma2_obj 100, sigma2_obj_smo 1e-3, Huber deltas 0.01."""
+    return dict(info_dyn=1.0 / float(F32(80)), info_tern=1.0 / float(F32(100)), info_smooth=1.0 / float(F32(0.001)),
+                huber_dyn=float(F32(0.01)), huber_tern=float(F32(0.01)), huber_smooth=float(F32(0.01)))
+
+
+def synth_ba_dynamic(base, n_obj=2, pts_per_obj=30, seed=21, obs_noise=0.02, min_len=3):
+    """Object part of the FullBatchOptimization graph on top of a static problem `base` (synth_ba_problem, kind="global"):
+    rigid objects moving with a constant world-frame motion H (p_{k+1} = H p_k), each point tracked over a contiguous
+    run of frames.  Mirrors Optimizer.cc:1560-1745: one dynamic vertex per observation (initialised at the noisy
+    back-projection through the INITIAL camera pose), its camera edge, a ternary edge to the previous vertex of the
+    tracklet and the (object, frame) motion vertex (initialised to identity), smoothness edges between consecutive motion
+    vertices of one object from frame 3 on.  Returns the dict of the vido_ba_dynamic fields (+ H_true)."""
+    rng = np.random.RandomState(seed)
+    n_cam = base["n_cam"]; cams = np.stack([np.vstack([c, [0, 0, 0, 1]]) for c in base["cam_true"]])
+    cam0 = np.stack([np.vstack([c, [0, 0, 0, 1]]) for c in base["cam_T"]])
+    H_idx = {}; H_true = []; H_T = []
+    dyn_xyz, dyn_cam, dyn_meas, t_prev, t_cur, t_H, sm_i, sm_j = [], [], [], [], [], [], [], []
+    for o in range(n_obj):
+        yaw = np.deg2rad(rng.uniform(-3, 3))
+        H = np.eye(4); H[:3, :3] = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+        H[:3, 3] = [rng.uniform(-0.2, 0.2), 0.0, rng.uniform(0.6, 1.2)]
+        f0 = int(rng.randint(0, max(1, n_cam // 3))); f1 = int(min(n_cam - 1, f0 + rng.randint(max(min_len, n_cam // 2), n_cam)))
+        centre = cams[f0] @ np.array([rng.uniform(-4, 4), rng.uniform(-0.5, 0.5), rng.uniform(8, 14), 1.0])
+        P = centre[:3] + rng.uniform(-1, 1, (pts_per_obj, 3))
+        for f in range(max(f0, 1), f1 + 1):
+            H_idx[(o, f)] = len(H_true); H_true.append(_iso(H)); H_T.append(_iso(np.eye(4)))
+            if f > 2 and (o, f - 1) in H_idx:
+                sm_i.append(H_idx[(o, f - 1)]); sm_j.append(H_idx[(o, f)])
+        for q in range(pts_per_obj):
+            a = int(rng.randint(f0, max(f0 + 1, f1 - min_len + 1))); b = int(min(f1, a + rng.randint(min_len - 1, f1 - f0 + 1)))
+            p = np.append(P[q], 1.0)
+            for f in range(f0, a):
+                p = H @ p
+            prev = -1
+            for f in range(a, b + 1):
+                if f > a:
+                    p = H @ p
+                Xc = (np.linalg.inv(cams[f]) @ p)[:3]
+                m = Xc + rng.normal(0, 1, 3) * obs_noise * Xc[2]
+                idx = len(dyn_cam)
+                dyn_cam.append(f); dyn_meas.append(m); dyn_xyz.append((cam0[f] @ np.append(m, 1.0))[:3])
+                if prev >= 0:
+                    t_prev.append(prev); t_cur.append(idx); t_H.append(H_idx[(o, f)])
+                prev = idx
+    i32 = lambda v: np.asarray(v, np.int32)
+    d = dict(n_H=len(H_T), n_dyn=len(dyn_cam), n_tern=len(t_prev), n_smooth=len(sm_i),
+             H_T=np.ascontiguousarray(np.stack(H_T)) if H_T else np.zeros((0, 3, 4)), dyn_xyz=np.ascontiguousarray(np.stack(dyn_xyz)),
+             dyn_cam=i32(dyn_cam), dyn_meas=np.ascontiguousarray(np.stack(dyn_meas)), tern_prev=i32(t_prev), tern_cur=i32(t_cur), tern_H=i32(t_H),
+             sm_i=i32(sm_i), sm_j=i32(sm_j), H_true=np.stack(H_true) if H_true else np.zeros((0, 3, 4)))
+    d.update(dyn_constants())
+    return d
