@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def write_clip(tmp, scene, n):
+def write_clip(tmp, scene, n, dataset=1, factor=1.0, bf=387.57):
     for sub in ("image_0", "flow_image", "depth_image", "mask_image"):
         os.makedirs(os.path.join(tmp, sub), exist_ok=True)
     for k in range(n):
@@ -20,6 +20,8 @@ def write_clip(tmp, scene, n):
         g.tofile(os.path.join(tmp, "image_0", "%06d.gray" % k))
         with open(os.path.join(tmp, "flow_image", "%06d.flo" % k), "wb") as fh:
             np.array([202021.25], np.float32).tofile(fh); np.array([scene.w, scene.h], np.int32).tofile(fh); f.astype(np.float32).tofile(fh)
+        if dataset == 2:                  # KITTI convention: the file holds a scaled disparity, depth = bf / (value / factor)  (Tracking.cc:305-309)
+            d = (bf * factor / d.astype(np.float64))
         d.astype(np.float32).tofile(os.path.join(tmp, "depth_image", "%06d.depth" % k))
         m.astype(np.int32).tofile(os.path.join(tmp, "mask_image", "%06d.mask" % k))
     fx, fy, cx, cy = scene.K
@@ -27,7 +29,7 @@ def write_clip(tmp, scene, n):
     with open(cfg, "w") as fh:
         fh.write("%%YAML:1.0\nimage_path: %s\nn_frames: %d\nCamera.width: %d\nCamera.height: %d\n" % (os.path.join(tmp, "image_0"), n, scene.w, scene.h))
         fh.write("Camera.fx: %r\nCamera.fy: %r\nCamera.cx: %r\nCamera.cy: %r\nCamera.k1: 0.0\nCamera.k2: 0.0\nCamera.p1: 0.0\nCamera.p2: 0.0\nCamera.k3: 0.0\n" % (fx, fy, cx, cy))
-        fh.write("Camera.bf: 387.57\nCamera.fps: 10.0\nCamera.RGB: 0\nChooseData: 1\nDepthMapFactor: 1.0\nThDepthBG: 40.0\nThDepthOBJ: 25.0\n")
+        fh.write("Camera.bf: %r\nCamera.fps: 10.0\nCamera.RGB: 0\nChooseData: %d\nDepthMapFactor: %r\nThDepthBG: 40.0\nThDepthOBJ: 25.0\n" % (bf, dataset, factor))
         fh.write("MaxTrackPointBG: 3000\nMaxTrackPointOBJ: 800\nSFMgThres: 0.12\nSFDsThres: 0.3\nWINDOW_SIZE: 20\nOVERLAP_SIZE: 4\nUseSampleFeature: 0\n")
         fh.write("ORBextractor.nFeatures: 2000\nORBextractor.scaleFactor: 1.2\nORBextractor.nLevels: 8\nORBextractor.iniThFAST: 20\nORBextractor.minThFAST: 7\n")
     return cfg
@@ -62,3 +64,27 @@ def test_offline_clip_recovers_ground_truth_poses(tmp_path, vido):
         H = row[2:14].reshape(3, 4)
         assert np.abs(H[:, :3] - np.eye(3)).max() < 0.02 and np.abs(H[:, 3] - np.array([0.25, 0.0, 0.05])).max() < 0.05, row
     assert set(mot[:, 1].astype(int)) == {1}                                # one consistently tracked object id
+
+
+def test_kitti_mode_runs_the_full_batch_with_object_factors(tmp_path, vido):
+    """ChooseData = KITTI: at the last frame Tracking::Track calls Optimizer::FullBatchOptimization (Tracking.cc:1489-1498) —
+    static landmarks + object motion vertices + dynamic point chains — and the refined results land in *_RF."""
+    sys.path.insert(0, os.path.join(ROOT, "vido-slam_amd"))
+    import build
+    driver = build.build_driver()
+    n = 10
+    scene = vido.synth.Scene3D(n_frames=n, seed=3, objects=((-2.0, 0.2, 9.0, 0.25, 0.0, 0.05),))
+    cfg = write_clip(str(tmp_path), scene, n, dataset=2, factor=256.0)
+    out = os.path.join(str(tmp_path), "poses.txt")
+    r = subprocess.run([driver, cfg, out, os.path.join(str(tmp_path), "res_")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    ref = np.loadtxt(os.path.join(str(tmp_path), "res_refined_rgbd_new.txt"))
+    assert ref.shape == (n, 17)
+    for k in range(1, n):
+        T = np.linalg.inv(ref[k, 1:].reshape(4, 4)); G = scene.Tcw(k)             # vmCameraPose_RF holds camera-to-world poses
+        E = T @ np.linalg.inv(G)
+        assert np.linalg.norm(E[:3, 3]) < 0.06, (k, E)
+    mot = np.loadtxt(os.path.join(str(tmp_path), "res_obj_mot_refined.txt"), ndmin=2)
+    assert len(mot) >= n - 3
+    moved = [np.abs(row[2:14].reshape(3, 4) - np.eye(3, 4)).max() for row in mot]
+    assert max(moved) > 1e-3                                                     # the motion vertices start at identity and were optimised

@@ -296,7 +296,8 @@ cv::Mat Optimizer::PoseOptimizationFlow2(Frame* cur, Frame* last, const std::vec
     return fromRow16(r.T);
 }
 
-// Map walk of PartialBatchOptimization (Optimizer.cc:56-160, 216-350) onto the flat BA problem (STATIC_ONLY graph).
+// Map walk of PartialBatchOptimization (Optimizer.cc:56-160, 216-350; STATIC_ONLY graph) and FullBatchOptimization (:1235-2178;
+// static + object factors) onto the flat BA problem.
 static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool global)
 {
     const int N = (int)pMap->vpFeatSta.size();
@@ -344,17 +345,78 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
     else { b.prior_cam = 0; b.info_prior = 1e5; b.info_obs = 1.0 / (double)80.f; b.max_iters = 300; b.gain_threshold = 1e-4; }                                             // :1325,1333-1338
     for (int k = 0; k < 12; k++) b.prior_T[k] = cam[k];
     vido_ba_result r;
-    check(vido_ba_optimize(g_ctx, &b, &r, nullptr, nullptr), global ? "FullBatchOptimization" : "PartialBatchOptimization");
+    // ---- object part of FullBatchOptimization (STATIC_ONLY = false, Optimizer.cc:1540-1750)
+    std::vector<double> Hs, dxyz, dmeas; std::vector<int32_t> dcam, tp, tc, th, smi, smj;
+    std::vector<std::vector<int> > labD(N), makD(N), Hid(std::max(N - 1, 0));
+    if (global) {
+        const auto& TrD = pMap->TrackletDyn;
+        for (int i = 0; i < N; i++) { labD[i].assign(pMap->vpFeatDyn[i].size(), -1); makD[i].assign(pMap->vpFeatDyn[i].size(), -1); }
+        for (size_t t = 0; t < TrD.size(); t++) { if (TrD[t].size() < 3) continue; for (auto& pr : TrD[t]) labD[pr.first][pr.second] = (int)t; }
+        for (int i = 0; i < N - 1; i++) Hid[i].assign(pMap->vnRMLabel[i].size(), -1);
+        auto add_dyn = [&](int i, int j) -> int {          // VertexPointXYZ + EdgeSE3PointXYZ of one dynamic observation (:1560-1582)
+            const int id = (int)dcam.size();
+            const cv::Mat& Xw = pMap->vp3DPointDyn[i][j]; for (int a = 0; a < 3; a++) dxyz.push_back(Xw.at<float>(a));
+            cv::Mat Xc = Optimizer::Get3DinCamera(pMap->vpFeatDyn[i][j], pMap->vfDepDyn[i][j], K);
+            for (int a = 0; a < 3; a++) dmeas.push_back(Xc.at<float>(a));
+            dcam.push_back(i); makD[i][j] = id;
+            return id;
+        };
+        for (int i = 0; i < N; i++) {
+            if (i == 0) { for (size_t j = 0; j < labD[0].size(); j++) if (labD[0][j] != -1) add_dyn(0, (int)j); continue; }
+            // one motion vertex per object of frame i, initialised to identity (:1583-1592), smoothness edge to the same object's
+            // vertex of the previous frame when i > 2 (:1604-1636)
+            for (size_t j = 1; j < pMap->vmRigidMotion[i - 1].size(); j++) {
+                const int hid = (int)(Hs.size() / 12);
+                static const double I12[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+                Hs.insert(Hs.end(), I12, I12 + 12);
+                if (i > 2) {
+                    int trace = -1;
+                    for (size_t k = 0; k < pMap->vnRMLabel[i - 2].size(); k++) if (pMap->vnRMLabel[i - 2][k] == pMap->vnRMLabel[i - 1][j]) { trace = (int)k; break; }
+                    if (trace > 0 && Hid[i - 2][trace] >= 0) { smi.push_back(Hid[i - 2][trace]); smj.push_back(hid); }
+                }
+                Hid[i - 1][j] = hid;
+            }
+            for (size_t j = 0; j < labD[i].size(); j++) {
+                const int t = labD[i][j]; if (t == -1) continue;
+                int pos = -1;
+                for (size_t k = 0; k < TrD[t].size(); k++) if (TrD[t][k].first == i && TrD[t][k].second == (int)j) { pos = (int)k; break; }
+                if (pos == -1) continue;
+                int hobj = -1;
+                for (size_t k = 1; k < pMap->vnRMLabel[i - 1].size(); k++) if (pMap->vnRMLabel[i - 1][k] == pMap->nObjID[t]) { hobj = Hid[i - 1][k]; break; }
+                if (hobj == -1 && pos != 0) continue;                         // no motion vertex for this object in this frame (:1668-1671)
+                if (pos == 0) { add_dyn(i, (int)j); continue; }
+                const int prev = makD[TrD[t][pos - 1].first][TrD[t][pos - 1].second];
+                const int id = add_dyn(i, (int)j);
+                if (prev >= 0) { tp.push_back(prev); tc.push_back(id); th.push_back(hobj); }    // LandmarkMotionTernaryEdge (:1728-1745)
+            }
+        }
+    }
+    vido_ba_dynamic d; memset(&d, 0, sizeof d);
+    d.n_H = (int)(Hs.size() / 12); d.H_T = Hs.data(); d.n_dyn = (int)dcam.size(); d.dyn_xyz = dxyz.data(); d.dyn_cam = dcam.data(); d.dyn_meas = dmeas.data();
+    d.n_tern = (int)tp.size(); d.tern_prev = tp.data(); d.tern_cur = tc.data(); d.tern_H = th.data(); d.n_smooth = (int)smi.size(); d.sm_i = smi.data(); d.sm_j = smj.data();
+    d.info_dyn = 1.0 / (double)80.f; d.info_tern = 1.0 / (double)100.f; d.info_smooth = 1.0 / (double)0.001f;                     // :1333-1338
+    d.huber_dyn = d.huber_tern = d.huber_smooth = (double)0.01f;                                                              // :1358
+    if (global && (d.n_H || d.n_dyn)) check(vido_ba_optimize_dynamic(g_ctx, &b, &d, &r, nullptr, nullptr), "FullBatchOptimization");
+    else check(vido_ba_optimize(g_ctx, &b, &r, nullptr, nullptr), global ? "FullBatchOptimization" : "PartialBatchOptimization");
     auto& poses = global ? pMap->vmCameraPose_RF : pMap->vmCameraPose;
-    for (int i = start; i < N; i++) {                      // write-back, Optimizer.cc:1084-1128
+    for (int i = start; i < N; i++) {                      // write-back, Optimizer.cc:1084-1128 / :2098-2137
+        if (global && i == 0) continue;                    // the full batch writes vmCameraPose_RF[i+1] only
         cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
         for (int rr = 0; rr < 3; rr++) for (int c = 0; c < 4; c++) T.at<float>(rr, c) = (float)cam[(size_t)(i - start) * 12 + rr * 4 + c];
         poses[i] = T;
-        if (i > start) (global ? pMap->vmRigidMotion_RF : pMap->vmRigidMotion)[i - 1][0] = Converter::toInvMatrix(poses[i - 1]) * poses[i];
+        if (i > start && !global) pMap->vmRigidMotion[i - 1][0] = Converter::toInvMatrix(poses[i - 1]) * poses[i];
     }
-    if (!global) for (size_t q = 0; q < ptOwner.size(); q++) { /* the reference writes the optimised point back to EVERY observation slot that references it */ }
-    for (int i = start; i < N; i++) for (size_t j = 0; j < mak[i].size(); j++) if (mak[i][j] != -1 && !global)
+    for (int i = start; i < N; i++) for (size_t j = 0; j < mak[i].size(); j++) if (mak[i][j] != -1)      // every observation slot of the landmark (:1130-1160, :2140-2154)
         pMap->vp3DPointSta[i][j] = vec3((float)pts[3 * (size_t)mak[i][j]], (float)pts[3 * (size_t)mak[i][j] + 1], (float)pts[3 * (size_t)mak[i][j] + 2]);
+    if (global) {
+        for (int i = 0; i < N - 1; i++) for (size_t j = 1; j < Hid[i].size(); j++) if (Hid[i][j] >= 0) {   // :2119-2134
+            cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+            for (int rr = 0; rr < 3; rr++) for (int c = 0; c < 4; c++) T.at<float>(rr, c) = (float)Hs[(size_t)Hid[i][j] * 12 + rr * 4 + c];
+            pMap->vmRigidMotion_RF[i][j] = T;
+        }
+        for (int i = 0; i < N; i++) for (size_t j = 0; j < makD[i].size(); j++) if (makD[i][j] != -1)       // :2155-2172
+            pMap->vp3DPointDyn[i][j] = vec3((float)dxyz[3 * (size_t)makD[i][j]], (float)dxyz[3 * (size_t)makD[i][j] + 1], (float)dxyz[3 * (size_t)makD[i][j] + 2]);
+    }
 }
 void Optimizer::PartialBatchOptimization(Map* pMap, const cv::Mat K, const int W) { batch_optimize(pMap, K, W, false); }
 void Optimizer::FullBatchOptimization(Map* pMap, const cv::Mat K) { batch_optimize(pMap, K, (int)pMap->vpFeatSta.size(), true); }
@@ -806,6 +868,16 @@ void System::SaveResultsIJRR2020(const std::string& prefix)   // System.cc:80-24
     if (f) {
         for (size_t i = 0; i < mpMap->vmRigidMotion.size(); i++) for (size_t j = 1; j < mpMap->vmRigidMotion[i].size(); j++) {
             fprintf(f, "%zu %d", i, mpMap->vnRMLabel[i][j]); const cv::Mat& M = mpMap->vmRigidMotion[i][j];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) fprintf(f, " %.9f", M.at<float>(r, c));
+            fprintf(f, " 0 0 0 1\n");
+        }
+        fclose(f);
+    }
+    // extension (not written by the reference): the object motions refined by FullBatchOptimization (vmRigidMotion_RF)
+    f = fopen((prefix + "obj_mot_refined.txt").c_str(), "w");
+    if (f) {
+        for (size_t i = 0; i < mpMap->vmRigidMotion_RF.size(); i++) for (size_t j = 1; j < mpMap->vmRigidMotion_RF[i].size(); j++) {
+            fprintf(f, "%zu %d", i, mpMap->vnRMLabel[i][j]); const cv::Mat& M = mpMap->vmRigidMotion_RF[i][j];
             for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) fprintf(f, " %.9f", M.at<float>(r, c));
             fprintf(f, " 0 0 0 1\n");
         }
