@@ -231,7 +231,9 @@ def main():
               extra["nets_fp32_1242x375"] = {"liteflownet_ms": round(timed(lambda: nets.analyse_flow(lfn, rgb, rgb)), 3),
                                              "monodepth2_ms": round(timed(lambda: nets.analyse_depth(md, rgb)), 3),
                                              "note": "includes the u8 host->device upload and pre/post resizes (run_flow_net.py / run_mono_depth.py wrappers)"}
-              del lfn, md
+              mr = nets.fill_maskrcnn(nets.MaskRCNN(nets.HipOps(ctx)), 3).eval().cuda()
+              extra["nets_fp32_1242x375"]["maskrcnn_x101_fpn_ms"] = round(timed(lambda: nets.analyse_image(mr, rgb), reps=3), 3)
+              del lfn, md, mr
           out["extra"] = extra
       except Exception as e:     # side measurements must never take the headline line down
         import traceback

@@ -1,0 +1,395 @@
+"""Mask R-CNN inference graph (reference src/thirdparty/mask_rcnn: maskrcnn_benchmark/modeling/** as configured by
+src/configs/caffe2/e2e_mask_rcnn_X_101_32x8d_FPN_1x_caffe2.yaml + config/defaults.py, driven by src/predictor.py:215-262 and
+src/run_mask_rcnn.py:76-127).  Forward only, tensors instead of BoxList objects, one image per call (the node processes one
+frame at a time).  Module/parameter names equal the reference's (backbone.body.layer3.22.conv2.weight,
+rpn.anchor_generator.cell_anchors.0, roi_heads.mask.predictor.conv5_mask.bias ...), so its checkpoints load unchanged.
+ROI-Align, NMS and box decoding go through `ops` (HipOps: the HIP kernels of libvido_slam_hip.so); there is no CPU path
+in the product — the CPU tests inject oracle-backed ops."""
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+@dataclass
+class MaskRCNNConfig:
+    # backbone (modeling/backbone/resnet.py:64-130, fpn.py)
+    blocks: tuple = (3, 4, 23, 3)            # R-101-FPN
+    groups: int = 32
+    width_per_group: int = 8
+    stride_in_1x1: bool = False
+    stem_out: int = 64
+    res2_out: int = 256
+    fpn_out: int = 256
+    # RPN (config/defaults.py:128-175, rpn/*.py)
+    anchor_sizes: tuple = (32, 64, 128, 256, 512)
+    aspect_ratios: tuple = (0.5, 1.0, 2.0)
+    anchor_strides: tuple = (4, 8, 16, 32, 64)
+    pre_nms_top_n: int = 1000
+    post_nms_top_n: int = 1000
+    fpn_post_nms_top_n: int = 1000
+    rpn_nms: float = 0.7
+    rpn_min_size: int = 0
+    # box head (defaults.py:198-232)
+    pool_scales: tuple = (0.25, 0.125, 0.0625, 0.03125)
+    box_resolution: int = 7
+    sampling_ratio: int = 2
+    mlp_dim: int = 1024
+    num_classes: int = 81
+    score_thresh: float = 0.05
+    nms: float = 0.5
+    detections_per_img: int = 100
+    bbox_reg_weights: tuple = (10.0, 10.0, 5.0, 5.0)
+    # mask head (defaults.py:234-256)
+    mask_resolution: int = 14
+    mask_layers: tuple = (256, 256, 256, 256)
+
+
+class FrozenBatchNorm2d(nn.Module):        # layers/batch_norm.py:6-31
+    def __init__(self, n):
+        super().__init__()
+        for name, v in (("weight", torch.ones(n)), ("bias", torch.zeros(n)), ("running_mean", torch.zeros(n)), ("running_var", torch.ones(n))):
+            self.register_buffer(name, v)
+
+    def forward(self, x):
+        scale = self.weight * self.running_var.rsqrt()
+        bias = self.bias - self.running_mean * scale
+        return x * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
+
+
+class _Bottleneck(nn.Module):              # resnet.py:277-372 (BottleneckWithFixedBatchNorm)
+    def __init__(self, cin, mid, cout, groups, stride_in_1x1, stride):
+        super().__init__()
+        self.downsample = None
+        if cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), FrozenBatchNorm2d(cout))
+        s1, s3 = (stride, 1) if stride_in_1x1 else (1, stride)
+        self.conv1 = nn.Conv2d(cin, mid, 1, s1, bias=False); self.bn1 = FrozenBatchNorm2d(mid)
+        self.conv2 = nn.Conv2d(mid, mid, 3, s3, 1, bias=False, groups=groups); self.bn2 = FrozenBatchNorm2d(mid)
+        self.conv3 = nn.Conv2d(mid, cout, 1, bias=False); self.bn3 = FrozenBatchNorm2d(cout)
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = F.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return F.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+class _Stem(nn.Module):                    # resnet.py:375-395
+    def __init__(self, cout):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, cout, 7, 2, 3, bias=False); self.bn1 = FrozenBatchNorm2d(cout)
+
+    def forward(self, x):
+        return F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, 2, 1)
+
+
+class _Body(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.stem = _Stem(c.stem_out)
+        cin = c.stem_out
+        for i, n in enumerate(c.blocks, 1):
+            f = 2 ** (i - 1)
+            mid, cout = c.groups * c.width_per_group * f, c.res2_out * f
+            blocks = []
+            for b in range(n):
+                blocks.append(_Bottleneck(cin, mid, cout, c.groups, c.stride_in_1x1, (2 if i > 1 else 1) if b == 0 else 1))
+                cin = cout
+            setattr(self, "layer%d" % i, nn.Sequential(*blocks))
+        self.n_stages = len(c.blocks)
+
+    def forward(self, x):
+        x = self.stem(x); out = []
+        for i in range(1, self.n_stages + 1):
+            x = getattr(self, "layer%d" % i)(x); out.append(x)
+        return out
+
+
+class _FPN(nn.Module):                     # fpn.py:7-82 with LastLevelMaxPool
+    def __init__(self, c):
+        super().__init__()
+        self.n = len(c.blocks)
+        for i in range(1, self.n + 1):
+            setattr(self, "fpn_inner%d" % i, nn.Conv2d(c.res2_out * 2 ** (i - 1), c.fpn_out, 1))
+            setattr(self, "fpn_layer%d" % i, nn.Conv2d(c.fpn_out, c.fpn_out, 3, 1, 1))
+
+    def forward(self, feats):
+        inner = getattr(self, "fpn_inner%d" % self.n)(feats[-1])
+        out = [getattr(self, "fpn_layer%d" % self.n)(inner)]
+        for i in range(self.n - 1, 0, -1):
+            inner = getattr(self, "fpn_inner%d" % i)(feats[i - 1]) + F.interpolate(inner, scale_factor=2, mode="nearest")
+            out.insert(0, getattr(self, "fpn_layer%d" % i)(inner))
+        out.append(F.max_pool2d(out[-1], 1, 2, 0))
+        return out
+
+
+def cell_anchors(stride, size, ratios):
+    """rpn/anchor_generator.py:219-292 (Detectron's generate_anchors): one scale per FPN level, float64 then .float()."""
+    base = np.array([0.0, 0.0, stride - 1.0, stride - 1.0])
+    w, h = base[2] - base[0] + 1, base[3] - base[1] + 1
+    xc, yc = base[0] + 0.5 * (w - 1), base[1] + 0.5 * (h - 1)
+    ws = np.round(np.sqrt(w * h / np.asarray(ratios, np.float64))); hs = np.round(ws * np.asarray(ratios, np.float64))
+    s = float(size) / stride
+    rows = [[xc - 0.5 * (a * s - 1), yc - 0.5 * (b * s - 1), xc + 0.5 * (a * s - 1), yc + 0.5 * (b * s - 1)] for a, b in zip(ws, hs)]
+    return torch.from_numpy(np.asarray(rows, np.float64)).float()
+
+
+class _Buffers(nn.Module):
+    def __init__(self, tensors):
+        super().__init__()
+        for i, t in enumerate(tensors):
+            self.register_buffer(str(i), t)
+
+    def __iter__(self):
+        return iter(self._buffers.values())
+
+
+class _AnchorGenerator(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.strides = c.anchor_strides
+        self.cell_anchors = _Buffers([cell_anchors(st, sz, c.aspect_ratios) for st, sz in zip(c.anchor_strides, c.anchor_sizes)])
+
+    def forward(self, grid_sizes):          # anchor_generator.py:77-101; order (y, x, anchor)
+        out = []
+        for (gh, gw), stride, base in zip(grid_sizes, self.strides, self.cell_anchors):
+            sx = torch.arange(0, gw * stride, step=stride, dtype=torch.float32, device=base.device)
+            sy = torch.arange(0, gh * stride, step=stride, dtype=torch.float32, device=base.device)
+            yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+            shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), 1)
+            out.append((shifts.view(-1, 1, 4) + base.view(1, -1, 4)).reshape(-1, 4))
+        return out
+
+
+class _RPNHead(nn.Module):                 # rpn/rpn.py:74-107
+    def __init__(self, ch, na):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, 1, 1); self.cls_logits = nn.Conv2d(ch, na, 1); self.bbox_pred = nn.Conv2d(ch, na * 4, 1)
+
+    def forward(self, feats):
+        t = [F.relu(self.conv(f)) for f in feats]
+        return [self.cls_logits(x) for x in t], [self.bbox_pred(x) for x in t]
+
+
+def clip_boxes(b, w, h):                    # structures/bounding_box.py:214-224 (TO_REMOVE = 1)
+    b = b.clone()
+    b[:, 0::2] = b[:, 0::2].clamp(min=0, max=w - 1); b[:, 1::2] = b[:, 1::2].clamp(min=0, max=h - 1)
+    return b
+
+
+def _topk_stable(v, k):
+    """topk(sorted=True) with ties broken by the lower index — torch.topk leaves the tie order to the backend (CPU and
+    GPU differ), and saturated objectness (sigmoid == 1.0) makes ties common."""
+    s, idx = torch.sort(v, descending=True, stable=True)
+    return s[:k], idx[:k]
+
+
+class _RPN(nn.Module):
+    def __init__(self, c, ops):
+        super().__init__()
+        self.c, self.ops = c, ops
+        self.anchor_generator = _AnchorGenerator(c)
+        self.head = _RPNHead(c.fpn_out, len(c.aspect_ratios))
+
+    def forward(self, feats, image_wh):     # rpn/inference.py:73-159 (test path, one image)
+        c = self.c; W, H = image_wh
+        logits, deltas = self.head(feats)
+        anchors = self.anchor_generator([f.shape[-2:] for f in feats])
+        boxes, scores = [], []
+        for a, lo, de in zip(anchors, logits, deltas):
+            A, h, w = lo.shape[1:]
+            obj = lo[0].permute(1, 2, 0).reshape(-1).sigmoid()                       # (y, x, anchor)
+            reg = de[0].view(A, 4, h, w).permute(2, 3, 0, 1).reshape(-1, 4)
+            k = min(c.pre_nms_top_n, obj.numel())
+            obj, idx = _topk_stable(obj, k)
+            prop = clip_boxes(self.ops.box_decode(reg[idx], a[idx], (1.0, 1.0, 1.0, 1.0)), W, H)
+            keep = ((prop[:, 2] - prop[:, 0] + 1 >= c.rpn_min_size) & (prop[:, 3] - prop[:, 1] + 1 >= c.rpn_min_size)).nonzero().squeeze(1)
+            prop, obj = prop[keep], obj[keep]
+            keep = self.ops.nms(prop, obj, c.rpn_nms)[: c.post_nms_top_n]
+            boxes.append(prop[keep]); scores.append(obj[keep])
+        boxes, scores = torch.cat(boxes), torch.cat(scores)
+        k = min(c.fpn_post_nms_top_n, scores.numel())                                 # select_over_all_levels, test branch
+        _, idx = _topk_stable(scores, k)
+        return boxes[idx], scores[idx]
+
+
+class _Pooler(nn.Module):                  # modeling/poolers.py:11-121
+    def __init__(self, resolution, scales, sampling_ratio, ops):
+        super().__init__()
+        self.res, self.scales, self.sr, self.ops = resolution, scales, sampling_ratio, ops
+        self.k_min = -math.log2(scales[0]); self.k_max = -math.log2(scales[-1])
+
+    def forward(self, feats, boxes):
+        area = (boxes[:, 2] - boxes[:, 0] + 1) * (boxes[:, 3] - boxes[:, 1] + 1)
+        lvl = torch.floor(4 + torch.log2(torch.sqrt(area) / 224 + 1e-6)).clamp(min=self.k_min, max=self.k_max).to(torch.int64) - int(self.k_min)
+        rois = torch.cat([boxes.new_zeros((len(boxes), 1)), boxes], 1)
+        out = feats[0].new_zeros((len(boxes), feats[0].shape[1], self.res, self.res))
+        for l, (f, s) in enumerate(zip(feats, self.scales)):
+            idx = torch.nonzero(lvl == l).squeeze(1)
+            if idx.numel():
+                out[idx] = self.ops.roi_align(f, rois[idx], (self.res, self.res), s, self.sr)
+        return out
+
+
+class _BoxFeatures(nn.Module):             # roi_box_feature_extractors.py:50-81
+    def __init__(self, c, ops):
+        super().__init__()
+        self.pooler = _Pooler(c.box_resolution, c.pool_scales, c.sampling_ratio, ops)
+        self.fc6 = nn.Linear(c.fpn_out * c.box_resolution ** 2, c.mlp_dim); self.fc7 = nn.Linear(c.mlp_dim, c.mlp_dim)
+
+    def forward(self, feats, boxes):
+        x = self.pooler(feats, boxes).flatten(1)
+        return F.relu(self.fc7(F.relu(self.fc6(x))))
+
+
+class _BoxPredictor(nn.Module):            # roi_box_predictors.py:35-57
+    def __init__(self, c):
+        super().__init__()
+        self.cls_score = nn.Linear(c.mlp_dim, c.num_classes); self.bbox_pred = nn.Linear(c.mlp_dim, c.num_classes * 4)
+
+    def forward(self, x):
+        return self.cls_score(x), self.bbox_pred(x)
+
+
+class _BoxHead(nn.Module):
+    def __init__(self, c, ops):
+        super().__init__()
+        self.c, self.ops = c, ops
+        self.feature_extractor = _BoxFeatures(c, ops); self.predictor = _BoxPredictor(c)
+
+    def forward(self, feats, proposals, image_wh):
+        logits, deltas = self.predictor(self.feature_extractor(feats, proposals))
+        return self.postprocess(logits, deltas, proposals, image_wh)
+
+    def postprocess(self, logits, deltas, proposals, image_wh):      # box_head/inference.py:47-137
+        c = self.c; W, H = image_wh; nc = logits.shape[1]
+        prob = F.softmax(logits, -1)
+        boxes = clip_boxes(self.ops.box_decode(deltas, proposals, c.bbox_reg_weights).reshape(-1, 4), W, H).reshape(-1, nc * 4)
+        rb, rs, rl = [], [], []
+        for j in range(1, nc):
+            idx = (prob[:, j] > c.score_thresh).nonzero().squeeze(1)
+            if not idx.numel():
+                continue
+            bj, sj = boxes[idx, 4 * j:4 * j + 4], prob[idx, j]
+            keep = self.ops.nms(bj, sj, c.nms)
+            rb.append(bj[keep]); rs.append(sj[keep]); rl.append(torch.full((len(keep),), j, dtype=torch.int64, device=logits.device))
+        if not rb:
+            return proposals.new_zeros((0, 4)), proposals.new_zeros((0,)), torch.zeros((0,), dtype=torch.int64, device=logits.device)
+        rb, rs, rl = torch.cat(rb), torch.cat(rs), torch.cat(rl)
+        if len(rs) > c.detections_per_img > 0:
+            thresh, _ = torch.kthvalue(rs.cpu(), len(rs) - c.detections_per_img + 1)
+            keep = torch.nonzero(rs >= thresh.item()).squeeze(1)
+            rb, rs, rl = rb[keep], rs[keep], rl[keep]
+        return rb, rs, rl
+
+
+class _MaskFeatures(nn.Module):            # roi_mask_feature_extractors.py:17-65
+    def __init__(self, c, ops):
+        super().__init__()
+        self.pooler = _Pooler(c.mask_resolution, c.pool_scales, c.sampling_ratio, ops)
+        cin = c.fpn_out; self.names = []
+        for i, ch in enumerate(c.mask_layers, 1):
+            setattr(self, "mask_fcn%d" % i, nn.Conv2d(cin, ch, 3, 1, 1)); self.names.append("mask_fcn%d" % i); cin = ch
+
+    def forward(self, feats, boxes):
+        x = self.pooler(feats, boxes)
+        for n in self.names:
+            x = F.relu(getattr(self, n)(x))
+        return x
+
+
+class _MaskPredictor(nn.Module):           # roi_mask_predictors.py:11-31
+    def __init__(self, c):
+        super().__init__()
+        self.conv5_mask = nn.ConvTranspose2d(c.mask_layers[-1], c.mask_layers[-1], 2, 2, 0)
+        self.mask_fcn_logits = nn.Conv2d(c.mask_layers[-1], c.num_classes, 1)
+
+    def forward(self, x):
+        return self.mask_fcn_logits(F.relu(self.conv5_mask(x)))
+
+
+class _MaskHead(nn.Module):
+    def __init__(self, c, ops):
+        super().__init__()
+        self.feature_extractor = _MaskFeatures(c, ops); self.predictor = _MaskPredictor(c)
+
+    def forward(self, feats, boxes, labels):                         # mask_head/inference.py:29-47: per-detection class channel
+        if not len(boxes):
+            return feats[0].new_zeros((0, 1, 2 * self.feature_extractor.pooler.res, 2 * self.feature_extractor.pooler.res))
+        logits = self.predictor(self.feature_extractor(feats, boxes))
+        return logits.sigmoid()[torch.arange(len(boxes), device=labels.device), labels][:, None]
+
+
+class _RoiHeads(nn.Module):
+    def __init__(self, c, ops):
+        super().__init__()
+        self.box = _BoxHead(c, ops); self.mask = _MaskHead(c, ops)
+
+
+def paste_masks(masks, boxes, im_h, im_w, thresh=0.5, padding=1):
+    """Masker / paste_mask_in_image (mask_head/inference.py:87-160): masks [n,1,M,M] probabilities, boxes [n,4] in the target
+    image -> bool [n, im_h, im_w].  Per detection: pad the mask by 1 px, scale the box by (M+2)/M, truncate to int,
+    bilinear-resize to the box size, threshold, crop to the image."""
+    n, M = masks.shape[0], masks.shape[-1]
+    out = torch.zeros((n, im_h, im_w), dtype=torch.bool, device=masks.device)
+    if n == 0:
+        return out
+    scale = float(M + 2 * padding) / M
+    padded = F.pad(masks.float(), (padding,) * 4)
+    b = boxes.float()
+    wh, hh = (b[:, 2] - b[:, 0]) * 0.5 * scale, (b[:, 3] - b[:, 1]) * 0.5 * scale
+    xc, yc = (b[:, 2] + b[:, 0]) * 0.5, (b[:, 3] + b[:, 1]) * 0.5
+    ib = torch.stack([xc - wh, yc - hh, xc + wh, yc + hh], 1).to(torch.int32).cpu().tolist()
+    for i, (x0, y0, x1, y1) in enumerate(ib):
+        w, h = max(x1 - x0 + 1, 1), max(y1 - y0 + 1, 1)
+        m = F.interpolate(padded[i:i + 1], size=(h, w), mode="bilinear", align_corners=False)[0, 0] > thresh
+        xa, xb, ya, yb = max(x0, 0), min(x1 + 1, im_w), max(y0, 0), min(y1 + 1, im_h)
+        if xb > xa and yb > ya:
+            out[i, ya:yb, xa:xb] = m[ya - y0:yb - y0, xa - x0:xb - x0]
+    return out
+
+
+class MaskRCNN(nn.Module):
+    """GeneralizedRCNN (modeling/detector/generalized_rcnn.py:33-65), eval mode, MASK_ON."""
+
+    def __init__(self, ops, config=None):
+        super().__init__()
+        self.config = c = config or MaskRCNNConfig()
+        self.backbone = nn.Sequential(OrderedDict([("body", _Body(c)), ("fpn", _FPN(c))]))
+        self.rpn = _RPN(c, ops)
+        self.roi_heads = _RoiHeads(c, ops)
+
+    @torch.no_grad()
+    def forward(self, image):
+        """image: [1,3,H,W] float (0..255, the reference feeds unnormalised RGB).  Returns dict(boxes, scores, labels, masks[n,1,28,28])."""
+        H, W = image.shape[-2:]
+        feats = self.backbone(image)
+        proposals, objectness = self.rpn(feats, (W, H))
+        boxes, scores, labels = self.roi_heads.box(feats[:len(self.config.pool_scales)], proposals, (W, H))
+        masks = self.roi_heads.mask(feats[:len(self.config.pool_scales)], boxes, labels)
+        return dict(boxes=boxes, scores=scores, labels=labels, masks=masks, proposals=proposals, objectness=objectness)
+
+
+@torch.no_grad()
+def analyse_image(net, bgr, feed=(1088, 800), confidence=0.8):
+    """predictor.py:compute_prediction + select_top_predictions (:215-283) and run_mask_rcnn.py:create_pixel_masks (:83-123):
+    HxWx3 u8 BGR -> (label image HxW u8 = sum of mask * class index, label indices).  The frame is area-resized to 800x1088
+    (W x H, cv2.INTER_AREA; third-party, restated with torch's area interpolation), flipped to RGB, NOT normalised."""
+    dev = next(net.parameters()).device
+    t = torch.as_tensor(bgr[:, :, ::-1].copy(), device=dev).permute(2, 0, 1).float().unsqueeze(0)
+    H, W = t.shape[-2:]
+    out = net(F.interpolate(t, size=feed, mode="area"))
+    rw, rh = float(W) / feed[1], float(H) / feed[0]
+    boxes = out["boxes"] * out["boxes"].new_tensor([rw, rh, rw, rh]) if rw != rh else out["boxes"] * rw
+    pasted = paste_masks(out["masks"], boxes, H, W)
+    keep = torch.nonzero(out["scores"] > confidence).squeeze(1)
+    keep = keep[out["scores"][keep].sort(0, descending=True)[1]]
+    labels = out["labels"][keep]
+    img = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+    for m, l in zip(pasted[keep], labels):
+        img += m.to(torch.uint8) * int(l)                            # u8 accumulation (wraps on overlap, like the reference)
+    return img, labels

@@ -36,6 +36,8 @@ class HipOps:
         return out
 
     def roi_align(self, feat, rois, output_size, spatial_scale, sampling_ratio):
+        if not feat.is_cuda:
+            raise RuntimeError("HipOps.roi_align needs CUDA(HIP) tensors; there is no CPU fallback")
         feat = feat.contiguous().float(); rois = rois.contiguous().float()
         B, Cc, H, W = feat.shape; ph, pw = output_size
         out = torch.empty((rois.shape[0], Cc, ph, pw), device=feat.device, dtype=torch.float32)
@@ -44,8 +46,23 @@ class HipOps:
                                                     C.c_float(spatial_scale), ph, pw, sampling_ratio, C.c_void_p(out.data_ptr()), 1))
         return out
 
+    def box_decode(self, deltas, boxes, weights):
+        """BoxCoder(weights).decode(deltas [n,4k], boxes [n,4]) -> [n,4k]."""
+        deltas = deltas.contiguous().float(); boxes = boxes.contiguous().float(); n = deltas.shape[0]
+        out = torch.empty_like(deltas)
+        if n:
+            w = (C.c_float * 4)(*[float(x) for x in weights])
+            self._adopt_stream()
+            self.ctx._check(self.ctx.lib.vido_box_decode(self.ctx.h, C.c_void_p(deltas.data_ptr()), C.c_void_p(boxes.data_ptr()), n, deltas.shape[1] // 4, w,
+                                                         C.c_void_p(out.data_ptr()), 1))
+        return out
+
     def nms(self, boxes, scores, thresh):
         """maskrcnn_benchmark.layers.nms: kept original indices, ascending (sort on the device with torch, sweep in HIP)."""
+        if not boxes.is_cuda:
+            raise RuntimeError("HipOps.nms needs CUDA(HIP) tensors; there is no CPU fallback")
+        if boxes.shape[0] == 0:
+            return torch.zeros((0,), dtype=torch.int64, device=boxes.device)
         order = torch.sort(scores, descending=True, stable=True)[1]
         sb = boxes[order].contiguous().float(); n = sb.shape[0]
         keep = torch.empty(max(n, 1), device=boxes.device, dtype=torch.int32); cnt = torch.zeros(1, device=boxes.device, dtype=torch.int32)
