@@ -44,7 +44,7 @@ typedef struct vido_config {
     /* ORBextractor ctor arguments (ORBextractor.h:39-40); YAML keys ORBextractor.* (Tracking.cc:137-141) */
     int32_t n_features; float scale_factor; int32_t n_levels; int32_t ini_th_fast; int32_t min_th_fast;
     int32_t compute_descriptors;   /* 1: blur + rBRIEF (north_star); 0: reference behaviour (call commented out) */
-    int32_t host_threads;      /* threads for the serial per-(frame,level) quadtree stage; 0 = auto */
+    int32_t host_threads;      /* unused since the quadtree stage moved to the device (kept for ABI stability) */
 } vido_config;
 
 void        vido_config_default(vido_config* cfg);           /* 640x480, batch 1, KAIST ORB params */
@@ -80,7 +80,7 @@ int vido_orb_read_level(vido_ctx* ctx, int frame, int level, int blurred, uint8_
  * (level coordinates).  Returns count (or <0). */
 int vido_orb_read_candidates(vido_ctx* ctx, int frame, int level, uint32_t* out, int cap);
 /* per-stage time of the last batch call (HIP events on the ctx stream), ms: [0] pyramid (level-0 copy + resize
- * launches) [1] k_fast_cells alone [2] host quadtree [3] blur [4] keypoint upload + orient/rBRIEF + download
+ * launches) [1] k_fast_cells alone [2] device quadtree + keypoint list [3] blur [4] orient/rBRIEF
  * [5] total wall [6] scan+gather [7] number of FAST candidates in the batch */
 int vido_orb_last_timing(const vido_ctx* ctx, float ms[8]);
 

@@ -14,8 +14,9 @@
 //     (th=20, else th=7 if the cell came back empty) + per-sub-image 3x3 NMS run on the LDS score tile;
 //     survivors are emitted in row-major order with wave ballots, so the candidate list comes out in
 //     exactly the order the reference's nested loops produce;
-//   * the serial quadtree (DistributeOctTree) stays on the host, one task per (frame, level), run on a
-//     small thread pool while the GPU blurs the pyramids;
+//   * DistributeOctTree runs on the device too (k_quadtree, one workgroup per (frame, level)): the std::list walk
+//     is restated as ordered-array passes built from LDS vote histograms, block scans and a bitonic sort, so the
+//     candidates never leave HBM and the whole extractor is one stream of launches with a single sync at the end;
 //   * orientation + rBRIEF: one wave per keypoint, wave-shuffle reductions for the moments and
 //     shuffles to assemble the 256 descriptor bits.
 // Compiled with -ffp-contract=off: the float formulas (fastAtan2 polynomial, pattern rotation) must
@@ -303,6 +304,240 @@ __global__ __launch_bounds__(64) void k_gather_cands(const uint32_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3b: DistributeOctTree (ORBextractor.cc:529-753) on the device, one workgroup per (frame, level).
+// The reference walks a std::list of nodes; what the result depends on is (a) which nodes get divided in which pass,
+// (b) the list order (children are pushed to the FRONT in n1..n4 order while the pass iterates, undivided nodes keep
+// their place), (c) the (size, creation order) sort of the last passes and its early stop at N nodes, (d) the
+// best-response keypoint of every final node.  All of that is data-parallel once nodes are held as an ordered array:
+//   pass:   candidates vote into their node's four quadrants (LDS atomics) -> per-node child counts;
+//           processing order = list order (bulk passes) or (count, creation id) descending (final passes, bitonic sort),
+//           cut at the first k whose running list size reaches N;
+//           new list = [children of the k-th processed node, reversed] ... [children of the 1st, reversed] ++ [undivided
+//           nodes in their old order]   — exactly what the push_front / erase sequence produces; positions and creation
+//           ids come from block-wide exclusive scans;  candidates then move to their child slot.
+//   finish: best candidate per node = max (response, lowest input index) by 64-bit LDS atomicMax; output in list order.
+// Keypoints never leave the GPU: the former D2H of all candidates and the host threads are gone.
+struct QtNode { short x0, y0, x1, y1; int cnt; int cid; };
+
+__device__ int qt_block_scan(int* a, int n, int* wsum)          // exclusive scan in place (LDS), returns the total; 256 threads
+{
+    const int t = threadIdx.x, per = (n + 255) >> 8, b = t * per;
+    int s = 0;
+    for (int i = 0; i < per; i++) if (b + i < n) s += a[b + i];
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if ((t & 63) >= o) inc += v; }
+    if ((t & 63) == 63) wsum[t >> 6] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (t >> 6); w++) base += wsum[w];
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int run = base + inc - s;
+    for (int i = 0; i < per; i++) if (b + i < n) { const int v = a[b + i]; a[b + i] = run; run += v; }
+    __syncthreads();
+    return total;
+}
+__device__ __forceinline__ int qt_quadrant(const QtNode& nd, int x, int y)
+{
+    const int hx = (nd.x1 - nd.x0 + 1) >> 1, hy = (nd.y1 - nd.y0 + 1) >> 1;      // ceil(./2) of a non-negative int
+    return (x < nd.x0 + hx ? 0 : 1) + (y < nd.y0 + hy ? 0 : 2);
+}
+
+__global__ __launch_bounds__(256) void k_quadtree(const uint32_t* __restrict__ cand, const int* __restrict__ lvloff, PyrDev P, int L,
+                                                  const int* __restrict__ budget, int qcap, uint16_t* __restrict__ slot_scratch,
+                                                  int* __restrict__ sel, int* __restrict__ selcnt, int* __restrict__ overflow, int cand_cap)
+{
+    extern __shared__ unsigned char qt_lds[];
+    QtNode* cur = (QtNode*)qt_lds;                       // [qcap]
+    QtNode* nxt = cur + qcap;                            // [qcap]
+    int* childcnt = (int*)(nxt + qcap);                  // [4*qcap]  (aliased by the 64-bit `best` keys at the end)
+    int* childslot = childcnt + 4 * qcap;                // [4*qcap]
+    int* nch = childslot + 4 * qcap;                     // [qcap]
+    int* keep = nch + qcap;                              // [qcap]
+    int* proc = keep + qcap;                             // [qcap]
+    int* pre = proc + qcap;                              // [qcap]
+    int* newslot = pre + qcap;                           // [qcap]
+    unsigned long long* keys = (unsigned long long*)(newslot + qcap);   // [qcap]
+    __shared__ int wsum[8];
+    __shared__ int sh_nexp, sh_fail;
+    const int task = blockIdx.x, l = task % L, tid = threadIdx.x;
+    const int beg = lvloff[task], n = lvloff[task + 1] - beg, N = budget[l];
+    // a FAST cell or the candidate buffer overflowed: the host reports VIDO_E_CAPACITY; nothing downstream may touch the lists
+    if (n <= 0 || *overflow != 0 || lvloff[gridDim.x] > cand_cap) { if (tid == 0) selcnt[task] = 0; return; }
+    const int minB = EDGE_THRESHOLD - 3, width = P.w[l] - 2 * minB, height = P.h[l] - 2 * minB;
+    const uint32_t* cd = cand + beg; uint16_t* slot = slot_scratch + beg;
+    // ---- initial column nodes (ORBextractor.cc:534-560)
+    int nIni = (int)roundf((float)width / (float)height); if (nIni < 1) nIni = 1;
+    const float hX = (float)width / (float)nIni;
+    if (nIni > qcap) { if (tid == 0) { atomicExch(overflow, 2); selcnt[task] = 0; } return; }
+    for (int b = tid; b < nIni; b += 256) { childcnt[b] = 0; }
+    if (tid == 0) sh_fail = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int x = (int)(cd[i] & 0xfff) - minB;
+        int b = (int)((float)x / hX); if (b >= nIni) b = nIni - 1;
+        slot[i] = (uint16_t)b; atomicAdd(&childcnt[b], 1);
+    }
+    __syncthreads();
+    for (int b = tid; b < nIni; b += 256) keep[b] = childcnt[b] > 0 ? 1 : 0;
+    __syncthreads();
+    int Lc = qt_block_scan(keep, nIni, wsum);
+    for (int b = tid; b < nIni; b += 256) {
+        newslot[b] = keep[b];
+        if (childcnt[b] > 0) { QtNode q; q.x0 = (short)(int)(hX * (float)b); q.y0 = 0; q.x1 = (short)(int)(hX * (float)(b + 1)); q.y1 = (short)height; q.cnt = childcnt[b]; q.cid = b; cur[keep[b]] = q; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) slot[i] = (uint16_t)newslot[slot[i]];
+    int counter = nIni;
+    bool final_mode = false, finish = false;
+    __syncthreads();
+    while (!finish) {
+        // ---- votes
+        for (int s = tid; s < 4 * Lc; s += 256) childcnt[s] = 0;
+        if (tid == 0) sh_nexp = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const int s = slot[i]; const QtNode nd = cur[s];
+            if (nd.cnt > 1) { const uint32_t p = cd[i]; atomicAdd(&childcnt[4 * s + qt_quadrant(nd, (int)(p & 0xfff) - minB, (int)((p >> 12) & 0xfff) - minB)], 1); }
+        }
+        __syncthreads();
+        for (int s = tid; s < Lc; s += 256) {
+            const bool ex = cur[s].cnt > 1;
+            nch[s] = ex ? (childcnt[4 * s] > 0) + (childcnt[4 * s + 1] > 0) + (childcnt[4 * s + 2] > 0) + (childcnt[4 * s + 3] > 0) : 0;
+            keep[s] = ex ? 1 : 0;                        // reused: expandable flag -> rank
+        }
+        __syncthreads();
+        // ---- processing order proc[0..k)
+        int k;
+        if (!final_mode) {
+            k = qt_block_scan(keep, Lc, wsum);
+            for (int s = tid; s < Lc; s += 256) if (cur[s].cnt > 1) proc[keep[s]] = s;
+            __syncthreads();
+        } else {
+            const int E = qt_block_scan(keep, Lc, wsum);
+            int M = 1; while (M < E) M <<= 1;
+            for (int j = tid; j < M; j += 256) keys[j] = 0ull;
+            __syncthreads();
+            for (int s = tid; s < Lc; s += 256) if (cur[s].cnt > 1)
+                keys[keep[s]] = ((unsigned long long)cur[s].cnt << 42) | ((unsigned long long)(unsigned)cur[s].cid << 10) | (unsigned long long)s;
+            __syncthreads();
+            for (int kk = 2; kk <= M; kk <<= 1)
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < M; i += 256) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const unsigned long long a = keys[i], b = keys[ixj];
+                            const bool desc = (i & kk) == 0;
+                            if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int j = tid; j < E; j += 256) { proc[j] = (int)(keys[j] & 1023ull); pre[j] = nch[proc[j]] - 1; }
+            __syncthreads();
+            qt_block_scan(pre, E, wsum);                 // list growth before processing the j-th node
+            if (tid == 0) sh_nexp = 0;
+            __syncthreads();
+            int mine = 0;
+            for (int j = tid; j < E; j += 256) if (Lc + pre[j] < N) mine++;
+            if (mine) atomicAdd(&sh_nexp, mine);
+            __syncthreads();
+            k = sh_nexp;
+            __syncthreads();
+            if (tid == 0) sh_nexp = 0;
+        }
+        // ---- positions
+        for (int j = tid; j < k; j += 256) pre[j] = nch[proc[j]];
+        for (int s = tid; s < Lc; s += 256) keep[s] = 1;
+        __syncthreads();
+        for (int j = tid; j < k; j += 256) keep[proc[j]] = 0;
+        __syncthreads();
+        const int C = qt_block_scan(pre, k, wsum);
+        const int nkeep = qt_block_scan(keep, Lc, wsum);
+        const int Lnew = C + nkeep;
+        if (Lnew > qcap) { if (tid == 0) { atomicExch(overflow, 2); selcnt[task] = 0; } return; }
+        // keep[] now holds exclusive ranks for EVERY slot; a divided slot is recognised through childslot >= 0 below
+        for (int s = tid; s < 4 * Lc; s += 256) childslot[s] = -1;
+        __syncthreads();
+        int nexp_local = 0;
+        for (int j = tid; j < k; j += 256) {
+            const int s = proc[j]; const QtNode nd = cur[s];
+            const int hx = (nd.x1 - nd.x0 + 1) >> 1, hy = (nd.y1 - nd.y0 + 1) >> 1;
+            const int c0 = childcnt[4 * s], c1 = childcnt[4 * s + 1], c2 = childcnt[4 * s + 2], c3 = childcnt[4 * s + 3];
+            const int cc[4] = {c0, c1, c2, c3};
+            const int base = C - pre[j] - nch[s];
+            int before = 0;
+            for (int q = 0; q < 4; q++) {
+                if (cc[q] <= 0) continue;
+                int after = 0; for (int r = q + 1; r < 4; r++) after += cc[r] > 0;
+                const int pos = base + after;
+                QtNode ch;
+                ch.x0 = (short)((q & 1) ? nd.x0 + hx : nd.x0); ch.x1 = (short)((q & 1) ? nd.x1 : nd.x0 + hx);
+                ch.y0 = (short)((q & 2) ? nd.y0 + hy : nd.y0); ch.y1 = (short)((q & 2) ? nd.y1 : nd.y0 + hy);
+                ch.cnt = cc[q]; ch.cid = counter + pre[j] + before;
+                nxt[pos] = ch; childslot[4 * s + q] = pos;
+                if (cc[q] > 1) nexp_local++;
+                before++;
+            }
+        }
+        if (nexp_local) atomicAdd(&sh_nexp, nexp_local);
+        __syncthreads();
+        for (int s = tid; s < Lc; s += 256) {
+            const bool divided = cur[s].cnt > 1 && (childslot[4 * s] >= 0 || childslot[4 * s + 1] >= 0 || childslot[4 * s + 2] >= 0 || childslot[4 * s + 3] >= 0);
+            if (!divided) { nxt[C + keep[s]] = cur[s]; newslot[s] = C + keep[s]; } else newslot[s] = -1;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const int s = slot[i];
+            if (newslot[s] >= 0) slot[i] = (uint16_t)newslot[s];
+            else { const QtNode nd = cur[s]; const uint32_t p = cd[i]; slot[i] = (uint16_t)childslot[4 * s + qt_quadrant(nd, (int)(p & 0xfff) - minB, (int)((p >> 12) & 0xfff) - minB)]; }
+        }
+        const int nToExpand = sh_nexp;
+        __syncthreads();
+        { QtNode* t = cur; cur = nxt; nxt = t; }
+        counter += C;
+        if (Lnew >= N || Lnew == Lc) finish = true;
+        else if (!final_mode && Lnew + 3 * nToExpand > N) final_mode = true;
+        Lc = Lnew;
+    }
+    // ---- best keypoint per node, list order
+    // key = response << 16 | (65535 - input index): n <= VIDO_MAX_CAND_PER_FRAME < 65536 (the slot map is u16 for the same reason)
+    unsigned* best = (unsigned*)childcnt;
+    for (int s = tid; s < Lc; s += 256) best[s] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) atomicMax(&best[slot[i]], ((cd[i] >> 24) << 16) | (unsigned)(65535 - i));
+    __syncthreads();
+    for (int s = tid; s < Lc; s += 256) sel[(size_t)task * qcap + s] = 65535 - (int)(best[s] & 0xffffu);
+    if (tid == 0) selcnt[task] = Lc;
+}
+
+// keypoint list: frame-major, level-major, list order (== ORBextractor::operator() output order)
+__global__ __launch_bounds__(1024) void k_kp_offsets(const int* __restrict__ selcnt, int n_tasks, int L, int* __restrict__ kpoff, int* __restrict__ frame_beg, int nf)
+{
+    __shared__ int part[1024];
+    const int t = threadIdx.x, per = (n_tasks + 1023) / 1024, b = t * per;
+    int s = 0;
+    for (int i = 0; i < per; i++) if (b + i < n_tasks) s += selcnt[b + i];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { const int v = t >= o ? part[t - o] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
+    int run = part[t] - s;
+    for (int i = 0; i < per; i++) if (b + i < n_tasks) { kpoff[b + i] = run; if ((b + i) % L == 0) frame_beg[(b + i) / L] = run; run += selcnt[b + i]; }
+    if (t == 1023) { kpoff[n_tasks] = part[1023]; frame_beg[nf] = part[1023]; }
+}
+__global__ __launch_bounds__(256) void k_kp_write(const uint32_t* __restrict__ cand, const int* __restrict__ lvloff, const int* __restrict__ sel, const int* __restrict__ selcnt,
+                                                 const int* __restrict__ kpoff, int qcap, int L, uint2* __restrict__ kps, float* __restrict__ resp, int kp_cap)
+{
+    const int task = blockIdx.x, f = task / L, l = task - f * L, beg = lvloff[task], m = selcnt[task], off = kpoff[task];
+    for (int i = threadIdx.x; i < m; i += 256) {
+        if (off + i >= kp_cap) break;
+        const uint32_t p = cand[beg + sel[(size_t)task * qcap + i]];
+        kps[off + i] = make_uint2((p & 0xffffffu) | ((uint32_t)l << 24), (uint32_t)f);
+        resp[off + i] = (float)(p >> 24);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K4: 7x7 sigma=2 Gaussian, reflect-101, Q0.8 taps {18,34,49,54,49,34,18}; 64x16 output tile per WG.
 __device__ __forceinline__ int reflect101(int i, int n)
 {
@@ -363,12 +598,16 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)      // cv::fa
 }
 
 __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t slab, PyrDev P,
-                                                      const uint2* __restrict__ kps, int n_kp, int with_desc,
+                                                      const uint2* __restrict__ kps, const int* __restrict__ n_kp_ptr, int with_desc,
                                                       float* __restrict__ angle_out, uint8_t* __restrict__ desc_out)
 {
     // XCD-aware: each of the 8 XCDs (block b -> XCD b % 8) walks one contiguous eighth of the keypoint list, i.e.
     // whole frames, so the patch / pattern gathers of a frame stay in one private L2
-    const int chunk = gridDim.x >> 3, blk = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    // (the grid is an upper bound; the real list length lives on the device)
+    const int n_kp = *n_kp_ptr;
+    const int chunk = (((n_kp + 3) >> 2) + 7) >> 3;
+    if ((int)(blockIdx.x >> 3) >= chunk) return;
+    const int blk = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     const int k = blk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (k >= n_kp) return;
     const uint2 kp = kps[k];
@@ -407,32 +646,6 @@ __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict_
 
 // ================================================================================================
 // host side
-// Persistent worker pool for the host quadtree stage (thread creation per call would cost more than the work).
-struct WorkerPool {
-    std::vector<std::thread> th; std::mutex mu; std::condition_variable cv_go, cv_done;
-    std::function<void(int)> fn; std::atomic<int> next{0}; int n = 0, active = 0; uint64_t gen = 0; bool stop = false;
-    explicit WorkerPool(int nthreads)
-    {
-        for (int t = 0; t < nthreads; t++) th.emplace_back([this] {
-            uint64_t seen = 0;
-            for (;;) {
-                { std::unique_lock<std::mutex> lk(mu); cv_go.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
-                for (int i; (i = next.fetch_add(1)) < n;) fn(i);
-                { std::lock_guard<std::mutex> lk(mu); if (--active == 0) cv_done.notify_all(); }
-            }
-        });
-    }
-    ~WorkerPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv_go.notify_all(); for (auto& t : th) t.join(); }
-    void run(int count, std::function<void(int)> f)
-    {
-        if (th.empty() || count < 4) { for (int i = 0; i < count; i++) f(i); return; }
-        { std::lock_guard<std::mutex> lk(mu); fn = std::move(f); n = count; next = 0; active = (int)th.size(); gen++; }
-        cv_go.notify_all();
-        for (int i; (i = next.fetch_add(1)) < n;) fn(i);          // the caller works too
-        std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return active == 0; });
-    }
-};
-
 struct OrbState {
     int L = 0, W = 0, H = 0, B = 0;
     LevelInfo lv[VIDO_MAX_LEVELS];
@@ -453,9 +666,11 @@ struct OrbState {
     hipEvent_t ev[8] = {};
     float timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int last_frames = 0;
-    int n_threads = 1;
-    struct WorkerPool* pool = nullptr;
     int fast_rows = 0, fast_ncand = 0; size_t fast_lds = 0;
+    // device quadtree / keypoint assembly
+    uint16_t* d_qt_slot = nullptr; int *d_sel = nullptr, *d_selcnt = nullptr, *d_kpoff = nullptr, *d_frame_beg = nullptr, *d_budget = nullptr;
+    float* d_resp = nullptr; int* h_frame_beg = nullptr; float* h_resp = nullptr;
+    int qcap = 0; size_t qt_lds = 0;
 };
 
 static inline int cv_round_f(float v) { return (int)lrintf(v); }
@@ -604,10 +819,24 @@ int orb_state_create(vido_ctx* ctx)
     HIP_TRY(ctx, hipHostMalloc(&S->h_angle, S->kp_cap * sizeof(float)));
     HIP_TRY(ctx, hipHostMalloc(&S->h_desc, S->kp_cap * 32));
     for (auto& e : S->ev) HIP_TRY(ctx, hipEventCreate(&e));
-    int nt = ctx->cfg.host_threads;
-    if (nt <= 0) { nt = (int)std::thread::hardware_concurrency(); nt = std::max(1, std::min(nt, 32)); }
-    S->n_threads = nt;
-    S->pool = new WorkerPool(nt > 1 ? nt - 1 : 0);
+    {   // device quadtree: the node list never exceeds budget + 3 entries (a pass stops at >= budget nodes)
+        int maxN = 0; std::vector<int> bud(S->L);
+        for (int l = 0; l < S->L; l++) { bud[l] = S->lv[l].n_budget; maxN = std::max(maxN, bud[l]); }
+        S->qcap = (maxN + 8 + 63) & ~63;
+        if (S->qcap > 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "orb: per-level feature budget %d exceeds the quadtree kernel's 1016", maxN);
+        { int m2 = 1; while (m2 < S->qcap) m2 <<= 1; S->qt_lds = (size_t)S->qcap * 84 + (size_t)m2 * 8; }      // the bitonic sort pads its keys to a power of two
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->qt_lds));
+        HIP_TRY(ctx, hipMalloc(&S->d_qt_slot, S->cand_cap * sizeof(uint16_t)));
+        HIP_TRY(ctx, hipMalloc(&S->d_sel, B * S->L * (size_t)S->qcap * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&S->d_selcnt, B * S->L * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&S->d_kpoff, (B * S->L + 1) * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&S->d_frame_beg, (B + 1) * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&S->d_budget, S->L * sizeof(int)));
+        HIP_TRY(ctx, hipMemcpy(S->d_budget, bud.data(), S->L * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMalloc(&S->d_resp, S->kp_cap * sizeof(float)));
+        HIP_TRY(ctx, hipHostMalloc(&S->h_frame_beg, (B + 1) * sizeof(int)));
+        HIP_TRY(ctx, hipHostMalloc(&S->h_resp, S->kp_cap * sizeof(float)));
+    }
     return VIDO_OK;
 }
 
@@ -620,112 +849,9 @@ void orb_state_destroy(vido_ctx* ctx)
     hipFree(S->d_cand); hipFree(S->d_kp); hipFree(S->d_angle); hipFree(S->d_desc);
     hipHostFree(S->h_lvloff); hipHostFree(S->h_overflow); hipHostFree(S->h_cand); hipHostFree(S->h_kp); hipHostFree(S->h_angle); hipHostFree(S->h_desc);
     for (auto& e : S->ev) if (e) hipEventDestroy(e);
-    delete S->pool;
+    hipFree(S->d_qt_slot); hipFree(S->d_sel); hipFree(S->d_selcnt); hipFree(S->d_kpoff); hipFree(S->d_frame_beg); hipFree(S->d_budget); hipFree(S->d_resp);
+    hipHostFree(S->h_frame_beg); hipHostFree(S->h_resp);
     delete S; ctx->orb = nullptr;
-}
-
-// ---- quadtree distribution (DistributeOctTree, ORBextractor.cc:529-753) -------------------------
-// Host, serial per (frame, level).  Nodes are rectangles over an index array that is stably
-// partitioned in place (the reference copies KeyPoint vectors); the std::list is an index-linked
-// list over the node pool.  Size ties in the reference's sort of (size, node*) pairs fall back to
-// node creation order here (the reference's pointer order is allocation-dependent).
-namespace {
-struct QNode { int x0, y0, x1, y1; int beg, cnt; int prev, next; bool no_more; };
-struct QTree {
-    std::vector<QNode> pool; std::vector<int> idx, tmp; int head = -1, tail = -1, size = 0;
-    const float *cx, *cy;
-    int add(int x0, int y0, int x1, int y1, int beg, int cnt) { pool.push_back(QNode{x0, y0, x1, y1, beg, cnt, -1, -1, cnt == 1}); return (int)pool.size() - 1; }
-    void push_front(int i) { pool[i].prev = -1; pool[i].next = head; if (head >= 0) pool[head].prev = i; else tail = i; head = i; size++; }
-    void push_back(int i) { pool[i].next = -1; pool[i].prev = tail; if (tail >= 0) pool[tail].next = i; else head = i; tail = i; size++; }
-    int erase(int i) { int p = pool[i].prev, n = pool[i].next; if (p >= 0) pool[p].next = n; else head = n; if (n >= 0) pool[n].prev = p; else tail = p; size--; return n; }
-    // split node i into up to four children; returns their pool indices in n1..n4 order (-1 = empty)
-    void divide(int i, int ch[4])
-    {
-        const QNode nd = pool[i];
-        const int hx = (int)ceilf((float)(nd.x1 - nd.x0) / 2), hy = (int)ceilf((float)(nd.y1 - nd.y0) / 2);
-        const float mx = (float)(nd.x0 + hx), my = (float)(nd.y0 + hy);
-        int cnt[4] = {0, 0, 0, 0};
-        for (int k = nd.beg; k < nd.beg + nd.cnt; k++) {
-            const int id = idx[k];
-            const int q = cx[id] < mx ? (cy[id] < my ? 0 : 2) : (cy[id] < my ? 1 : 3);
-            tmp[k] = q; cnt[q]++;
-        }
-        int start[4] = {nd.beg, nd.beg + cnt[0], nd.beg + cnt[0] + cnt[1], nd.beg + cnt[0] + cnt[1] + cnt[2]};
-        int fill[4] = {start[0], start[1], start[2], start[3]};
-        scratch.resize(nd.cnt);
-        for (int k = 0; k < nd.cnt; k++) scratch[k] = idx[nd.beg + k];
-        for (int k = 0; k < nd.cnt; k++) idx[fill[tmp[nd.beg + k]]++] = scratch[k];
-        const int rx0[4] = {nd.x0, nd.x0 + hx, nd.x0, nd.x0 + hx}, ry0[4] = {nd.y0, nd.y0, nd.y0 + hy, nd.y0 + hy};
-        const int rx1[4] = {nd.x0 + hx, nd.x1, nd.x0 + hx, nd.x1}, ry1[4] = {nd.y0 + hy, nd.y0 + hy, nd.y1, nd.y1};
-        for (int q = 0; q < 4; q++) ch[q] = cnt[q] > 0 ? add(rx0[q], ry0[q], rx1[q], ry1[q], start[q], cnt[q]) : -1;
-    }
-    std::vector<int> scratch;
-};
-}  // namespace
-
-static int quadtree_select(const float* cx, const float* cy, const float* resp, int n,
-                           int minX, int maxX, int minY, int maxY, int N, std::vector<int>& out)
-{
-    out.clear();
-    if (n <= 0) return 0;
-    QTree T; T.cx = cx; T.cy = cy;
-    T.pool.reserve(4 * (size_t)std::max(n, N) + 16); T.idx.resize(n); T.tmp.resize(n);
-    int nIni = (int)roundf((float)(maxX - minX) / (maxY - minY));
-    if (nIni < 1) nIni = 1;
-    const float hX = (float)(maxX - minX) / nIni;
-    {   // bucket keys into the initial column nodes, keeping input order inside each
-        std::vector<int> bucket(n), cnt(nIni, 0), start(nIni, 0);
-        for (int i = 0; i < n; i++) { int b = (int)(cx[i] / hX); if (b >= nIni) b = nIni - 1; bucket[i] = b; cnt[b]++; }
-        for (int b = 1; b < nIni; b++) start[b] = start[b - 1] + cnt[b - 1];
-        std::vector<int> fill = start;
-        for (int i = 0; i < n; i++) T.idx[fill[bucket[i]]++] = i;
-        for (int b = 0; b < nIni; b++) {
-            int q = T.add((int)(hX * (float)b), 0, (int)(hX * (float)(b + 1)), maxY - minY, start[b], cnt[b]);
-            if (cnt[b] > 0) T.push_back(q);
-        }
-    }
-    struct SP { int size, node; };
-    std::vector<SP> vs, vprev;
-    bool finish = false;
-    while (!finish) {
-        const int prevSize = T.size;
-        int nToExpand = 0;
-        vs.clear();
-        for (int it = T.head; it >= 0;) {
-            if (T.pool[it].no_more) { it = T.pool[it].next; continue; }
-            int ch[4]; T.divide(it, ch);
-            for (int q = 0; q < 4; q++) if (ch[q] >= 0) {
-                T.push_front(ch[q]);
-                if (T.pool[ch[q]].cnt > 1) { nToExpand++; vs.push_back(SP{T.pool[ch[q]].cnt, ch[q]}); }
-            }
-            it = T.erase(it);
-        }
-        if (T.size >= N || T.size == prevSize) finish = true;
-        else if (T.size + nToExpand * 3 > N) {
-            while (!finish) {
-                const int prev2 = T.size;
-                vprev = vs; vs.clear();
-                std::sort(vprev.begin(), vprev.end(), [](const SP& a, const SP& b) { return a.size != b.size ? a.size < b.size : a.node < b.node; });
-                for (int j = (int)vprev.size() - 1; j >= 0; j--) {
-                    int ch[4]; T.divide(vprev[j].node, ch);
-                    for (int q = 0; q < 4; q++) if (ch[q] >= 0) {
-                        T.push_front(ch[q]);
-                        if (T.pool[ch[q]].cnt > 1) vs.push_back(SP{T.pool[ch[q]].cnt, ch[q]});
-                    }
-                    T.erase(vprev[j].node);
-                    if (T.size >= N) break;
-                }
-                if (T.size >= N || T.size == prev2) finish = true;
-            }
-        }
-    }
-    for (int it = T.head; it >= 0; it = T.pool[it].next) {
-        const QNode& q = T.pool[it];
-        int best = T.idx[q.beg]; float mr = resp[best];
-        for (int k = 1; k < q.cnt; k++) { const int id = T.idx[q.beg + k]; if (resp[id] > mr) { best = id; mr = resp[id]; } }
-        out.push_back(best);
-    }
-    return (int)out.size();
 }
 
 static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_t frame_stride, int stride, int width, int height,
@@ -760,69 +886,53 @@ static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, si
                        S->d_first_cell, S->d_lvloff, S->d_overflow);
     hipLaunchKernelGGL(k_gather_cands, dim3(S->n_cells, nf), dim3(64), 0, st, S->d_slots, S->d_counts, S->d_offsets, S->n_cells, S->d_cand, (int)S->cand_cap);
     HIP_TRY(ctx, hipEventRecord(S->ev[2], st));
+    // ---- DistributeOctTree per (frame, level) + keypoint list, all on the device
+    const int n_tasks = nf * L;
+    static const bool dbg = getenv("VIDO_DEBUG_SYNC") != nullptr;
+#define DBG_SYNC(name) do { if (dbg) { fprintf(stderr, "[vido] %s...\n", name); hipStreamSynchronize(st); fprintf(stderr, "[vido] %s ok\n", name); } } while (0)
+    DBG_SYNC("fast+gather");
+    hipLaunchKernelGGL(k_quadtree, dim3(n_tasks), dim3(256), S->qt_lds, st, S->d_cand, S->d_lvloff, S->P, L, S->d_budget, S->qcap, S->d_qt_slot, S->d_sel, S->d_selcnt, S->d_overflow, (int)S->cand_cap);
+    DBG_SYNC("k_quadtree");
+    hipLaunchKernelGGL(k_kp_offsets, dim3(1), dim3(1024), 0, st, S->d_selcnt, n_tasks, L, S->d_kpoff, S->d_frame_beg, nf);
+    DBG_SYNC("k_kp_offsets");
+    hipLaunchKernelGGL(k_kp_write, dim3(n_tasks), dim3(256), 0, st, S->d_cand, S->d_lvloff, S->d_sel, S->d_selcnt, S->d_kpoff, S->qcap, L, S->d_kp, S->d_resp, (int)S->kp_cap);
+    DBG_SYNC("k_kp_write");
+    HIP_TRY(ctx, hipEventRecord(S->ev[3], st));
+    const int with_desc = ctx->cfg.compute_descriptors ? 1 : 0;
+    if (with_desc)
+        hipLaunchKernelGGL(k_blur7, dim3(S->n_blur_tiles, nf), dim3(256), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_btiles);
+    HIP_TRY(ctx, hipEventRecord(S->ev[4], st));
+    HIP_TRY(ctx, hipEventRecord(S->ev[5], st));
+    {   // launch bound: every (frame, level) list holds at most budget + 3 nodes; the kernel reads the real count from d_frame_beg[nf]
+        size_t bound = 0; for (int l = 0; l < L; l++) bound += (size_t)S->lv[l].n_budget + 3;
+        bound = std::min(bound * nf, S->kp_cap);
+        hipLaunchKernelGGL(k_orient_brief, dim3((unsigned)((((bound + 3) / 4) + 7) & ~(size_t)7)), dim3(256), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_kp,
+                           (const int*)(S->d_frame_beg + nf), with_desc, S->d_angle, S->d_desc);
+    }
+    DBG_SYNC("k_orient_brief");
+    HIP_TRY(ctx, hipEventRecord(S->ev[6], st));
+    HIP_TRY(ctx, hipMemcpyAsync(S->h_frame_beg, S->d_frame_beg, ((size_t)nf + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(S->h_lvloff, S->d_lvloff, ((size_t)nf * L + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(S->h_overflow, S->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (*S->h_overflow) { hipMemsetAsync(S->d_overflow, 0, sizeof(int), st); return vido_set_error(ctx, VIDO_E_CAPACITY, "orb: a FAST cell produced more than %d corners", VIDO_CELL_CAP); }
+    HIP_TRY(ctx, hipGetLastError());
+    if (*S->h_overflow) {
+        const int code = *S->h_overflow; hipMemsetAsync(S->d_overflow, 0, sizeof(int), st);
+        return code == 2 ? vido_set_error(ctx, VIDO_E_CAPACITY, "orb: quadtree node list exceeded %d entries", S->qcap)
+                         : vido_set_error(ctx, VIDO_E_CAPACITY, "orb: a FAST cell produced more than %d corners", VIDO_CELL_CAP);
+    }
     const int total = S->h_lvloff[nf * L];
     if ((size_t)total > S->cand_cap) return vido_set_error(ctx, VIDO_E_CAPACITY, "orb: %d FAST candidates exceed the %zu-entry buffer", total, S->cand_cap);
-    if (total > 0) HIP_TRY(ctx, hipMemcpyAsync(S->h_cand, S->d_cand, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipEventRecord(S->ev[3], st));
-    // blur runs on the GPU while the host distributes keypoints
-    if (ctx->cfg.compute_descriptors)
-        hipLaunchKernelGGL(k_blur7, dim3(S->n_blur_tiles, nf), dim3(256), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_btiles);
-    HIP_TRY(ctx, hipEventRecord(S->ev[4], st));
-    HIP_TRY(ctx, hipEventSynchronize(S->ev[3]));
-    auto t_q0 = std::chrono::steady_clock::now();
-    // ---- host quadtree per (frame, level)
-    std::vector<std::vector<int>> sel((size_t)nf * L);
-    std::vector<std::vector<float>> fx((size_t)nf * L), fy((size_t)nf * L), fr((size_t)nf * L);
-    S->pool->run(nf * L, [&](int task) {
-        const int l = task % L;
-        const int beg = S->h_lvloff[task], end = S->h_lvloff[task + 1];
-        const int n = end - beg;
-        const LevelInfo& v = S->lv[l];
-        const int minBX = EDGE_THRESHOLD - 3, minBY = minBX, maxBX = v.w - EDGE_THRESHOLD + 3, maxBY = v.h - EDGE_THRESHOLD + 3;
-        auto &X = fx[task], &Y = fy[task], &R = fr[task];
-        X.resize(n); Y.resize(n); R.resize(n);
-        for (int i = 0; i < n; i++) {
-            const uint32_t p = S->h_cand[beg + i];
-            X[i] = (float)((int)(p & 0xfff) - minBX); Y[i] = (float)((int)((p >> 12) & 0xfff) - minBY); R[i] = (float)(p >> 24);
-        }
-        quadtree_select(X.data(), Y.data(), R.data(), n, minBX, maxBX, minBY, maxBY, v.n_budget, sel[task]);
-    });
-    // flatten the selection: frame-major, level-major, list order (== ORBextractor::operator() output order)
-    std::vector<int> frame_beg(nf + 1, 0);
-    size_t nk = 0;
-    for (int f = 0; f < nf; f++) {
-        frame_beg[f] = (int)nk;
-        for (int l = 0; l < L; l++) {
-            const int task = f * L + l;
-            for (int id : sel[task]) {
-                if (nk >= S->kp_cap) return vido_set_error(ctx, VIDO_E_CAPACITY, "orb: keypoint buffer overflow");
-                const uint32_t p = S->h_cand[S->h_lvloff[task] + id];
-                S->h_kp[nk] = make_uint2((p & 0xffffff) | ((uint32_t)l << 24), (uint32_t)f);
-                S->h_angle[nk] = (float)(p >> 24);      // stash response; replaced by the angle after the kernel
-                nk++;
-            }
-        }
-    }
-    frame_beg[nf] = (int)nk;
-    std::vector<float> response(nk);
-    for (size_t i = 0; i < nk; i++) response[i] = S->h_angle[i];
-    auto t_q1 = std::chrono::steady_clock::now();
-    HIP_TRY(ctx, hipEventRecord(S->ev[5], st));
-    const int with_desc = ctx->cfg.compute_descriptors ? 1 : 0;
+    const size_t nk = (size_t)S->h_frame_beg[nf];
+    if (nk > S->kp_cap) return vido_set_error(ctx, VIDO_E_CAPACITY, "orb: keypoint buffer overflow");
     if (nk > 0) {
-        HIP_TRY(ctx, hipMemcpyAsync(S->d_kp, S->h_kp, nk * sizeof(uint2), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_orient_brief, dim3((unsigned)((((nk + 3) / 4) + 7) & ~(size_t)7)), dim3(256), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_kp, (int)nk,
-                           with_desc, S->d_angle, S->d_desc);
+        HIP_TRY(ctx, hipMemcpyAsync(S->h_kp, S->d_kp, nk * sizeof(uint2), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(S->h_resp, S->d_resp, nk * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipMemcpyAsync(S->h_angle, S->d_angle, nk * sizeof(float), hipMemcpyDeviceToHost, st));
         if (with_desc) HIP_TRY(ctx, hipMemcpyAsync(S->h_desc, S->d_desc, nk * 32, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
     }
-    HIP_TRY(ctx, hipEventRecord(S->ev[6], st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    HIP_TRY(ctx, hipGetLastError());
+    const int* frame_beg = S->h_frame_beg; const float* response = S->h_resp;
     // assemble cv::KeyPoint-equivalent output (ORBextractor.cc:827-836, 1094-1103)
     for (int f = 0; f < nf; f++) {
         const int n = frame_beg[f + 1] - frame_beg[f];
@@ -848,7 +958,7 @@ static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, si
     hipEventElapsedTime(&ms, S->ev[1], S->ev[7]); S->timing[1] = ms;
     hipEventElapsedTime(&ms, S->ev[7], S->ev[2]); S->timing[6] = ms;
     S->timing[7] = (float)S->h_lvloff[nf * L];
-    S->timing[2] = std::chrono::duration<float, std::milli>(t_q1 - t_q0).count();
+    hipEventElapsedTime(&ms, S->ev[2], S->ev[3]); S->timing[2] = ms;
     hipEventElapsedTime(&ms, S->ev[3], S->ev[4]); S->timing[3] = ms;
     hipEventElapsedTime(&ms, S->ev[5], S->ev[6]); S->timing[4] = ms;
     S->timing[5] = std::chrono::duration<float, std::milli>(t_end - t_start).count();
@@ -899,7 +1009,12 @@ int vido_orb_read_candidates(vido_ctx* ctx, int frame, int level, uint32_t* out,
     if (level < 0 || level >= S->L || frame < 0 || frame >= S->last_frames) return vido_set_error(ctx, VIDO_E_INVALID, "read_candidates: bad frame/level");
     const int task = frame * S->L + level;
     const int beg = S->h_lvloff[task], n = S->h_lvloff[task + 1] - beg;
-    if (out) for (int i = 0; i < std::min(n, cap); i++) out[i] = S->h_cand[beg + i];
+    if (out && n > 0 && cap > 0) {       // candidates stay on the device in the normal path; this debug read copies one level back
+        const int m = std::min(n, cap);
+        HIP_TRY(ctx, hipMemcpyAsync(S->h_cand, S->d_cand + beg, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(out, S->h_cand, (size_t)m * sizeof(uint32_t));
+    }
     return n;
 }
 

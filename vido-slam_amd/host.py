@@ -169,7 +169,7 @@ class Context:
     def orb_timing(self):
         t = np.zeros(8, np.float32)
         self._check(self.lib.vido_orb_last_timing(self.h, _ptr(t)))
-        return dict(zip(["pyramid_ms", "fast_ms", "quadtree_host_ms", "blur_ms", "orient_brief_ms", "wall_ms", "compact_ms", "n_candidates"], t.tolist()))
+        return dict(zip(["pyramid_ms", "fast_ms", "quadtree_ms", "blur_ms", "orient_brief_ms", "wall_ms", "compact_ms", "n_candidates"], t.tolist()))
 
     # ---- Hamming ---------------------------------------------------------------------------------
     def hamming_match(self, a, b):
