@@ -19,6 +19,7 @@ struct LevelInfo {
     int xtab_off, ytab_off;        // offsets (elements) into the resize tables
     int n_budget;                  // mnFeaturesPerLevel
     float scale;                   // mvScaleFactor
+    int rs_rows, rs_ndw;           // resize staging tile: max source rows / dwords per row of a 128x8 output tile
 };
 
 struct PyrDev {                    // passed by value to kernels

@@ -61,18 +61,48 @@ __device__ __forceinline__ void xcd_tile_frame(int& tile, int& frame)
 
 // ------------------------------------------------------------------------------------------------
 // K1: bilinear downscale of level l-1 into level l (OpenCV INTER_LINEAR u8 fixed-point semantics:
-// 11-bit coefficients; (b0*(r0>>4))>>16 + (b1*(r1>>4))>>16 + 2 >> 2).  4 output pixels per thread.
+// 11-bit coefficients; (b0*(r0>>4))>>16 + (b1*(r1>>4))>>16 + 2 >> 2).
+// One workgroup = a 128 x 8 output tile: the source rows/columns it touches (~156 x 12 bytes at scale 1.2) are staged
+// into LDS with aligned dword loads (each source byte leaves HBM/L2 once, 4 B per lane instead of 1-byte gathers),
+// every thread then produces 4 adjacent pixels of one row from LDS and stores one dword.
+// K0: level 0 <- caller's frames (device-resident batch): one launch instead of one 2-D copy per frame
+__global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ imgs, size_t frame_stride, int stride, int width, int height,
+                                                uint8_t* __restrict__ pyr, size_t slab, int off, int pitch)
+{
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= height || x4 >= pitch) return;
+    const uint8_t* s = imgs + (size_t)blockIdx.z * frame_stride + (size_t)y * stride + x4;
+    uint32_t v = 0;
+    if (x4 + 3 < width && (((uintptr_t)s) & 3) == 0) v = *(const uint32_t*)s;
+    else { for (int k = 0; k < 4; k++) if (x4 + k < width) v |= (uint32_t)s[k] << (8 * k); }
+    *(uint32_t*)(pyr + (size_t)blockIdx.z * slab + off + (size_t)y * pitch + x4) = v;
+}
+
+#define RS_TW 128
+#define RS_TH 8
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_t slab, int sw, int sh, int spitch, int soff,
                                                 int dw, int dh, int dpitch, int doff,
-                                                const int2* __restrict__ xtab, const int4* __restrict__ ytab)
+                                                const int2* __restrict__ xtab, const int4* __restrict__ ytab, int lds_ndw)
 {
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (y >= dh || x4 >= dpitch) return;
+    extern __shared__ uint32_t rs_lds[];
     uint8_t* base = pyr + (size_t)blockIdx.z * slab;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * RS_TW, y0 = blockIdx.y * RS_TH;
+    const int xl = min(x0 + RS_TW, dw) - 1, yl = min(y0 + RS_TH, dh) - 1;
+    const int rs0 = ytab[y0].x, rs1 = ytab[yl].y;                          // source rows are monotone in y
+    const int c0 = (xtab[x0].x & 0xffff) & ~3;
+    const int c1 = min((xtab[xl].x & 0xffff) + 1, sw - 1);
+    const int ndw = ((c1 - c0) >> 2) + 1, nrows = rs1 - rs0 + 1;
+    const uint8_t* src = base + soff + (size_t)rs0 * spitch + c0;
+    for (int rr = tid >> 6; rr < nrows; rr += 4)
+        for (int dd = tid & 63; dd < ndw; dd += 64)
+            rs_lds[rr * lds_ndw + dd] = *(const uint32_t*)(src + (size_t)rr * spitch + 4 * dd);
+    __syncthreads();
+    const int y = y0 + (tid >> 5), x4 = x0 + (tid & 31) * 4;
+    if (y >= dh || x4 >= dpitch) return;
     const int4 yt = ytab[y];
-    const uint8_t* S0 = base + soff + (size_t)yt.x * spitch;
-    const uint8_t* S1 = base + soff + (size_t)yt.y * spitch;
+    const uint8_t* L0 = (const uint8_t*)rs_lds + (yt.x - rs0) * lds_ndw * 4 - c0;
+    const uint8_t* L1 = (const uint8_t*)rs_lds + (yt.y - rs0) * lds_ndw * 4 - c0;
     uint32_t out = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -81,8 +111,8 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
             const int2 xt = xtab[x];
             const int sx = xt.x & 0xffff, a0 = xt.x >> 16, a1 = xt.y;
             const int sx1 = sx + 1 < sw ? sx + 1 : sx;
-            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+            const int r0 = L0[sx] * a0 + L0[sx1] * a1;
+            const int r1 = L1[sx] * a0 + L1[sx1] * a1;
             int v = (((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2;
             v = v < 0 ? 0 : (v > 255 ? 255 : v);
             out |= (uint32_t)v << (8 * k);
@@ -545,38 +575,62 @@ __device__ __forceinline__ int reflect101(int i, int n)
     while (i < 0 || i >= n) { i = i < 0 ? -i : 2 * n - 2 - i; }
     return i;
 }
+// 128 x 32 output tile per workgroup, everything in dword units: the (32+6) x (128+8)-byte input window is staged with aligned
+// dword loads (only dwords that touch the image border take the per-byte reflect path), the horizontal pass turns three
+// LDS dwords into four u16 sums, the vertical pass reads seven 8-byte LDS words per four outputs and stores one dword.
+#define BL_TW 128
+#define BL_TH 32
+#define BL_IN_STRIDE 35            // dwords per staged row (34 used; odd stride spreads rows over the LDS banks)
+__device__ __forceinline__ uint32_t blur_load4(const uint8_t* __restrict__ row, int c, int w)
+{
+    if (c >= 0 && c + 3 < w) return *(const uint32_t*)(row + c);
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v |= (uint32_t)row[reflect101(c + k, w)] << (8 * k);
+    return v;
+}
 __global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, size_t slab, PyrDev P,
                                                const BlurTile* __restrict__ tiles)
 {
-    __shared__ uint8_t in[22][72];
-    __shared__ uint16_t hb[22][64];
+    __shared__ uint32_t in[(BL_TH + 6) * BL_IN_STRIDE];
+    __shared__ uint2 hb[(BL_TH + 6) * (BL_TW / 4)];
     int ti, fr; xcd_tile_frame(ti, fr);
     const BlurTile t = tiles[ti];
     const int w = P.w[t.level], h = P.h[t.level], pitch = P.pitch[t.level];
     const uint8_t* img = pyr + (size_t)fr * slab + P.off[t.level];
     uint8_t* out = blur + (size_t)fr * slab + P.off[t.level];
-    const int tid = threadIdx.x, x0 = t.tx * 64, y0 = t.ty * 16;
-    for (int i = tid; i < 22 * 70; i += 256) {
-        const int r = i / 70, cx = i - r * 70;
-        in[r][cx] = img[(size_t)reflect101(y0 + r - 3, h) * pitch + reflect101(x0 + cx - 3, w)];
+    const int tid = threadIdx.x, x0 = t.tx * BL_TW, y0 = t.ty * BL_TH;
+    for (int r = tid >> 6; r < BL_TH + 6; r += 4) {
+        const int d = tid & 63;
+        if (d < 34) in[r * BL_IN_STRIDE + d] = blur_load4(img + (size_t)reflect101(y0 + r - 3, h) * pitch, x0 - 4 + 4 * d, w);
     }
     __syncthreads();
-    for (int i = tid; i < 22 * 64; i += 256) {
-        const int r = i >> 6, x = i & 63;
-        const int acc = 18 * (in[r][x] + in[r][x + 6]) + 34 * (in[r][x + 1] + in[r][x + 5]) + 49 * (in[r][x + 2] + in[r][x + 4]) + 54 * in[r][x + 3];
-        hb[r][x] = (uint16_t)acc;
+    for (int i = tid; i < (BL_TH + 6) * (BL_TW / 4); i += 256) {
+        const int r = i >> 5, d = i & 31;
+        const uint32_t* q = in + r * BL_IN_STRIDE + d;
+        const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+        // bytes 1..10 of the 12-byte window: output k uses bytes k+1 .. k+7
+        const int b1 = (w0 >> 8) & 255, b2 = (w0 >> 16) & 255, b3 = w0 >> 24, b4 = w1 & 255, b5 = (w1 >> 8) & 255, b6 = (w1 >> 16) & 255, b7 = w1 >> 24,
+                  b8 = w2 & 255, b9 = (w2 >> 8) & 255, b10 = (w2 >> 16) & 255;
+        const uint32_t s0 = 18 * (b1 + b7) + 34 * (b2 + b6) + 49 * (b3 + b5) + 54 * b4;
+        const uint32_t s1 = 18 * (b2 + b8) + 34 * (b3 + b7) + 49 * (b4 + b6) + 54 * b5;
+        const uint32_t s2 = 18 * (b3 + b9) + 34 * (b4 + b8) + 49 * (b5 + b7) + 54 * b6;
+        const uint32_t s3 = 18 * (b4 + b10) + 34 * (b5 + b9) + 49 * (b6 + b8) + 54 * b7;
+        hb[i] = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
     }
     __syncthreads();
-    const int row = tid >> 4, x4 = (tid & 15) * 4;
-    if (y0 + row < h && x0 + x4 < pitch) {
-        uint32_t o = 0;
+    for (int i = tid; i < BL_TH * (BL_TW / 4); i += 256) {
+        const int y = i >> 5, d = i & 31;
+        if (y0 + y >= h || x0 + 4 * d >= pitch) continue;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        const int taps[7] = {18, 34, 49, 54, 49, 34, 18};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = x4 + k;
-            const int acc = 18 * (hb[row][x] + hb[row + 6][x]) + 34 * (hb[row + 1][x] + hb[row + 5][x]) + 49 * (hb[row + 2][x] + hb[row + 4][x]) + 54 * hb[row + 3][x];
-            o |= (uint32_t)((acc + 32768) >> 16) << (8 * k);
+        for (int k = 0; k < 7; k++) {
+            const uint2 v = hb[(y + k) * (BL_TW / 4) + d];
+            a0 += taps[k] * (v.x & 0xffff); a1 += taps[k] * (v.x >> 16); a2 += taps[k] * (v.y & 0xffff); a3 += taps[k] * (v.y >> 16);
         }
-        *(uint32_t*)(out + (size_t)(y0 + row) * pitch + x0 + x4) = o;
+        *(uint32_t*)(out + (size_t)(y0 + y) * pitch + x0 + 4 * d) =
+            ((a0 + 32768) >> 16) | (((a1 + 32768) >> 16) << 8) | (((a2 + 32768) >> 16) << 16) | (((a3 + 32768) >> 16) << 24);
     }
 }
 
@@ -732,6 +786,18 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
             ytab.push_back(make_int4(y0, y1, b0, b1));
         }
     }
+    for (int l = 1; l < L; l++) {                           // LDS staging extent of the resize tiles
+        const LevelInfo& s = S->lv[l - 1]; LevelInfo& d = S->lv[l];
+        const int2* xt = xtab.data() + d.xtab_off; const int4* yt = ytab.data() + d.ytab_off;
+        int mr = 1, mw = 1;
+        for (int y0 = 0; y0 < d.h; y0 += RS_TH) mr = std::max(mr, yt[std::min(y0 + RS_TH, d.h) - 1].y - yt[y0].x + 1);
+        for (int x0 = 0; x0 < d.w; x0 += RS_TW) {
+            const int c0 = (xt[x0].x & 0xffff) & ~3, c1 = std::min((xt[std::min(x0 + RS_TW, d.w) - 1].x & 0xffff) + 1, s.w - 1);
+            mw = std::max(mw, ((c1 - c0) >> 2) + 1);
+        }
+        d.rs_rows = mr; d.rs_ndw = mw | 1;                  // odd dword stride: the two source rows of a pixel fall into different banks
+        if ((size_t)d.rs_rows * d.rs_ndw * 4 > 64 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "pyramid scale factor too large for the resize tile");
+    }
     // FAST cell table in the reference's loop order (ORBextractor.cc:759-796)
     std::vector<CellDesc> cells; std::vector<BlurTile> btiles;
     S->first_cell.assign(L, 0);
@@ -761,8 +827,8 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
             }
         }
         v.n_cells = (int)cells.size() - v.first_cell;
-        for (int ty = 0; ty < (v.h + 15) / 16; ty++)
-            for (int tx = 0; tx < (v.w + 63) / 64; tx++) btiles.push_back(BlurTile{l, tx, ty, 0});
+        for (int ty = 0; ty < (v.h + BL_TH - 1) / BL_TH; ty++)
+            for (int tx = 0; tx < (v.w + BL_TW - 1) / BL_TW; tx++) btiles.push_back(BlurTile{l, tx, ty, 0});
     }
     S->n_cells = (int)cells.size(); S->n_blur_tiles = (int)btiles.size();
     {   // dynamic LDS of k_fast_cells: sized for the largest cell of this pyramid
@@ -869,14 +935,17 @@ static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, si
     auto t_start = std::chrono::steady_clock::now();
     HIP_TRY(ctx, hipEventRecord(S->ev[0], st));
     // level 0 <- input
-    for (int f = 0; f < nf; f++)
+    if (on_device)
+        hipLaunchKernelGGL(k_ingest, dim3((S->lv[0].pitch / 4 + 63) / 64, (height + 3) / 4, nf), dim3(256), 0, st, imgs, frame_stride, stride, width, height,
+                           S->d_pyr, S->slab, S->lv[0].off, S->lv[0].pitch);
+    else for (int f = 0; f < nf; f++)
         HIP_TRY(ctx, hipMemcpy2DAsync(S->d_pyr + (size_t)f * S->slab + S->lv[0].off, S->lv[0].pitch, imgs + (size_t)f * frame_stride, stride,
-                                      width, height, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+                                      width, height, hipMemcpyHostToDevice, st));
     for (int l = 1; l < L; l++) {
         const LevelInfo &s = S->lv[l - 1], &d = S->lv[l];
-        dim3 grid((d.pitch / 4 + 63) / 64, (d.h + 3) / 4, nf), block(64, 4);
-        hipLaunchKernelGGL(k_resize, grid, block, 0, st, S->d_pyr, S->slab, s.w, s.h, s.pitch, s.off, d.w, d.h, d.pitch, d.off,
-                           S->d_xtab + d.xtab_off, S->d_ytab + d.ytab_off);
+        dim3 grid((d.pitch + RS_TW - 1) / RS_TW, (d.h + RS_TH - 1) / RS_TH, nf), block(256);
+        hipLaunchKernelGGL(k_resize, grid, block, (size_t)d.rs_rows * d.rs_ndw * 4, st, S->d_pyr, S->slab, s.w, s.h, s.pitch, s.off, d.w, d.h, d.pitch, d.off,
+                           S->d_xtab + d.xtab_off, S->d_ytab + d.ytab_off, d.rs_ndw);
     }
     HIP_TRY(ctx, hipEventRecord(S->ev[1], st));
     hipLaunchKernelGGL(k_fast_cells, dim3(S->n_cells, nf), dim3(64), S->fast_lds, st, S->d_pyr, S->slab, S->P, S->d_cells, S->n_cells,
