@@ -88,12 +88,10 @@ def main():
     dev_arg = (gray_d.data_ptr(), B, H, W, H * W, W)
 
     def step():
-        kps, desc, cnt = ctx.orb_extract_batch(dev_arg, want_desc=True, reuse=True)
         depth_work.copy_(depth_d)                          # the pre-scale mutates its input in place
-        ctx._check(ctx.lib.vido_frame_upload(ctx.h, 0, B, C.c_void_p(depth_work.data_ptr()), C.c_void_p(flow_d.data_ptr()),
-                                             C.c_void_p(mask_d.data_ptr()), 1, C.byref(tp)))
-        lists = ff.features(0, kps, cnt, reuse=True)
-        return kps, cnt, lists
+        torch.cuda.current_stream().synchronize()          # torch's stream -> the ctx stream hand-over of the scratch copy
+        o = ff.frontend_batch(0, dev_arg, depth_work.data_ptr(), flow_d.data_ptr(), mask_d.data_ptr())   # fused ORB + pre-scale + lists
+        return o["kps"], o["n_kp"], o
 
     def sync_all():
         torch.cuda.synchronize()

@@ -119,6 +119,20 @@ int vido_frame_upload(vido_ctx* ctx, int slot0, int n_frames, float* depth, cons
  * ORB keypoints kps[n_frames][max_kp] (host). */
 int vido_frame_features(vido_ctx* ctx, int slot0, int n_frames, const vido_keypoint* kps, const int32_t* n_kps, int max_kp,
                         const vido_track_params* p, vido_frame_lists* out);
+/* Fused batch front end (what Tracking::GrabImageRGBD does per frame before Track(): ORBextractor::operator() +
+ * depth pre-scale + the Frame::Frame lists), one stream of launches, keypoints handed over on the device.  Results are
+ * returned as a VIEW into ctx-owned pinned host memory, valid until the next call on ctx: kps/desc rows are
+ * [frame][kp_pitch], list rows [frame][stat_pitch] / [frame][obj_pitch]; frame f has frame_beg[f+1]-frame_beg[f]
+ * keypoints.  `depth` is rescaled in place like the reference does. */
+typedef struct vido_frontend_view {
+    int32_t n_frames, kp_pitch, stat_pitch, obj_pitch;
+    const vido_keypoint* kps; const uint8_t* desc; const int32_t* frame_beg;
+    const int32_t* n_stat; const int32_t* stat_idx; const float* stat_corr; const float* stat_flow; const float* stat_depth;
+    const int32_t* n_obj; const float* obj_keys; const float* obj_corr; const float* obj_depth; const int32_t* obj_label; const float* obj_flow;
+} vido_frontend_view;
+int vido_frontend_batch(vido_ctx* ctx, const uint8_t* imgs, int imgs_on_device, int n_frames, size_t frame_stride, int stride, int width, int height,
+                        float* depth, const float* flow, const int32_t* mask, int maps_on_device, int slot0, const vido_track_params* p,
+                        vido_frontend_view* view);
 /* Tracking.cc:369-391 / 398-421: depth (and label) of the current frame at last frame's correspondences. */
 int vido_gather_static_depth(vido_ctx* ctx, int slot, const float* keys_xy, int n, float* depth_out);
 int vido_gather_object_depth_label(vido_ctx* ctx, int slot, const float* keys_xy, int n, float th_depth_obj,

@@ -1,5 +1,9 @@
 import os, sys
 import pytest
+try:                      # torch bundles its own HIP runtime: it must be the one the process initialises first,
+    import torch          # before libvido_slam_hip.so creates a context (otherwise torch.cuda later finds no GPU)
+except ImportError:       # noqa
+    torch = None
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -2,6 +2,7 @@
 restating Tracking.cc:299-322, 369-421, 1582-1668, 3291-3357 and Frame.cc:72-211, 706-771). Bit-exact."""
 import numpy as np
 import pytest
+import torch   # before the first Context: torch bundles its own HIP runtime and must be the one the process initialises
 
 pytestmark = pytest.mark.gpu
 
@@ -78,3 +79,33 @@ def test_gathers_update_mask_unproject_sceneflow(vido, oracle, setup):
     f3, ol = ff.scene_flow(xw, xw2, lab, sem_cur, np.full(len(lab), -2, np.int32))
     r3, rl = oracle.scene_flow(xw, xw2, lab, sem_cur, np.full(len(lab), -2, np.int32))
     assert np.array_equal(f3, r3) and np.array_equal(ol, rl)
+
+
+def test_fused_frontend_equals_separate_calls(vido, setup):
+    """vido_frontend_batch (ORB + pre-scale + lists in one stream, keypoints handed over on the device, results as a view
+    of pinned memory) must reproduce the three separate entry points bit for bit — host inputs and device inputs."""
+    ctx, frames = setup
+    p = vido.track_params(dataset=0, depth_map_factor=1.0, th_depth_bg=40.0, th_depth_obj=25.0)
+    ff = vido.FrameFeatures(ctx, p)
+    gray = np.stack([f[0] for f in frames]); flow = np.stack([f[3] for f in frames]); mask = np.stack([f[4] for f in frames])
+    depth0 = np.stack([f[2] for f in frames]).astype(np.float32)
+    d1 = depth0.copy(); ff.upload(0, d1, flow, mask)
+    kps, desc, cnt = ctx.orb_extract_batch(gray, want_desc=True)
+    ref = {k: v.copy() for k, v in ff.features(0, kps, cnt).items()}
+    def check(out, depth_after):
+        assert np.array_equal(depth_after, d1)
+        assert np.array_equal(out["n_kp"], cnt) and np.array_equal(out["n_stat"], ref["n_stat"]) and np.array_equal(out["n_obj"], ref["n_obj"])
+        for f in range(3):
+            n = cnt[f]
+            assert np.array_equal(out["kps"][f, :n], kps[f, :n]) and np.array_equal(out["desc"][f, :n], desc[f, :n])
+            ns, no = ref["n_stat"][f], ref["n_obj"][f]
+            for k in ("stat_idx", "stat_corr", "stat_flow", "stat_depth"):
+                assert np.array_equal(out[k][f, :ns], ref[k][f, :ns]), k
+            for k in ("obj_keys", "obj_corr", "obj_depth", "obj_label", "obj_flow"):
+                assert np.array_equal(out[k][f, :no], ref[k][f, :no]), k
+    d2 = depth0.copy()
+    check(ff.frontend_batch(0, gray, d2, flow, mask), d2)
+    g = torch.from_numpy(gray).cuda(); dd = torch.from_numpy(depth0.copy()).cuda(); fl = torch.from_numpy(flow).cuda(); mk = torch.from_numpy(mask).cuda()
+    out = ff.frontend_batch(0, (g.data_ptr(), 3, 480, 640, 480 * 640, 640), dd.data_ptr(), fl.data_ptr(), mk.data_ptr())
+    torch.cuda.synchronize()
+    check(out, dd.cpu().numpy())

@@ -555,15 +555,26 @@ __global__ __launch_bounds__(1024) void k_kp_offsets(const int* __restrict__ sel
     for (int i = 0; i < per; i++) if (b + i < n_tasks) { kpoff[b + i] = run; if ((b + i) % L == 0) frame_beg[(b + i) / L] = run; run += selcnt[b + i]; }
     if (t == 1023) { kpoff[n_tasks] = part[1023]; frame_beg[nf] = part[1023]; }
 }
+struct KpLevels { float scale[VIDO_MAX_LEVELS]; float size[VIDO_MAX_LEVELS]; };
+// packed (x | y<<12 | level<<24, frame) records for k_orient_brief + the final cv::KeyPoint-equivalent rows
+// (ORBextractor.cc:827-836, 1094-1103) in [frame][row_cap] layout; the angle is filled in by k_orient_brief
 __global__ __launch_bounds__(256) void k_kp_write(const uint32_t* __restrict__ cand, const int* __restrict__ lvloff, const int* __restrict__ sel, const int* __restrict__ selcnt,
-                                                 const int* __restrict__ kpoff, int qcap, int L, uint2* __restrict__ kps, float* __restrict__ resp, int kp_cap)
+                                                 const int* __restrict__ kpoff, int qcap, int L, uint2* __restrict__ kps, int kp_cap,
+                                                 vido_keypoint* __restrict__ kpf, int row_cap, int* __restrict__ nkp, KpLevels lv)
 {
-    const int task = blockIdx.x, f = task / L, l = task - f * L, beg = lvloff[task], m = selcnt[task], off = kpoff[task];
+    const int task = blockIdx.x, f = task / L, l = task - f * L, beg = lvloff[task], m = selcnt[task], off = kpoff[task], fbeg = kpoff[f * L];
+    if (l == 0 && threadIdx.x == 0) nkp[f] = kpoff[(f + 1) * L] - fbeg;
     for (int i = threadIdx.x; i < m; i += 256) {
         if (off + i >= kp_cap) break;
         const uint32_t p = cand[beg + sel[(size_t)task * qcap + i]];
         kps[off + i] = make_uint2((p & 0xffffffu) | ((uint32_t)l << 24), (uint32_t)f);
-        resp[off + i] = (float)(p >> 24);
+        const int row = off + i - fbeg;
+        if (row < row_cap) {
+            float x = (float)(p & 0xfff), y = (float)((p >> 12) & 0xfff);
+            if (l != 0) { x *= lv.scale[l]; y *= lv.scale[l]; }
+            vido_keypoint k; k.x = x; k.y = y; k.size = lv.size[l]; k.angle = -1.f; k.response = (float)(p >> 24); k.octave = l;
+            kpf[(size_t)f * row_cap + row] = k;
+        }
     }
 }
 
@@ -652,13 +663,13 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)      // cv::fa
 }
 
 __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t slab, PyrDev P,
-                                                      const uint2* __restrict__ kps, const int* __restrict__ n_kp_ptr, int with_desc,
-                                                      float* __restrict__ angle_out, uint8_t* __restrict__ desc_out)
+                                                      const uint2* __restrict__ kps, const int* __restrict__ frame_beg, int nf, int with_desc,
+                                                      vido_keypoint* __restrict__ kpf, uint8_t* __restrict__ descf, int row_cap)
 {
     // XCD-aware: each of the 8 XCDs (block b -> XCD b % 8) walks one contiguous eighth of the keypoint list, i.e.
     // whole frames, so the patch / pattern gathers of a frame stay in one private L2
     // (the grid is an upper bound; the real list length lives on the device)
-    const int n_kp = *n_kp_ptr;
+    const int n_kp = frame_beg[nf];
     const int chunk = (((n_kp + 3) >> 2) + 7) >> 3;
     if ((int)(blockIdx.x >> 3) >= chunk) return;
     const int blk = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
@@ -676,7 +687,10 @@ __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict_
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
     const float ang = fast_atan2_deg((float)m01, (float)m10);
-    if (lane == 0) angle_out[k] = ang;
+    const int row = k - frame_beg[f];
+    if (row >= row_cap) return;
+    const size_t o = (size_t)f * row_cap + row;
+    if (lane == 0) kpf[o].angle = ang;
     if (!with_desc) return;
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ar = ang * factorPI;
@@ -695,7 +709,7 @@ __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict_
     uint32_t w = nib | (__shfl_down(nib, 1, 64) << 4);
     w |= __shfl_down(w, 2, 64) << 8;
     w |= __shfl_down(w, 4, 64) << 16;
-    if ((lane & 7) == 0) ((uint32_t*)(desc_out + (size_t)k * 32))[lane >> 3] = w;
+    if ((lane & 7) == 0) ((uint32_t*)(descf + o * 32))[lane >> 3] = w;
 }
 
 // ================================================================================================
@@ -714,17 +728,21 @@ struct OrbState {
     int2* d_xtab = nullptr; int4* d_ytab = nullptr;
     uint32_t* d_slots = nullptr; int *d_counts = nullptr, *d_offsets = nullptr, *d_first_cell = nullptr, *d_lvloff = nullptr, *d_overflow = nullptr;
     uint32_t* d_cand = nullptr; size_t cand_cap = 0;
-    uint2* d_kp = nullptr; float* d_angle = nullptr; uint8_t* d_desc = nullptr; size_t kp_cap = 0;
+    uint2* d_kp = nullptr; size_t kp_cap = 0;
     // pinned host
-    int* h_lvloff = nullptr; int* h_overflow = nullptr; uint32_t* h_cand = nullptr; uint2* h_kp = nullptr; float* h_angle = nullptr; uint8_t* h_desc = nullptr;
+    int* h_lvloff = nullptr; int* h_overflow = nullptr; uint32_t* h_cand = nullptr;
     hipEvent_t ev[8] = {};
     float timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::chrono::steady_clock::time_point t_start;
     int last_frames = 0;
     int fast_rows = 0, fast_ncand = 0; size_t fast_lds = 0;
     // device quadtree / keypoint assembly
     uint16_t* d_qt_slot = nullptr; int *d_sel = nullptr, *d_selcnt = nullptr, *d_kpoff = nullptr, *d_frame_beg = nullptr, *d_budget = nullptr;
-    float* d_resp = nullptr; int* h_frame_beg = nullptr; float* h_resp = nullptr;
+    int* h_frame_beg = nullptr;
     int qcap = 0; size_t qt_lds = 0;
+    // final results, [frame][row_cap] rows: device + pinned host mirror (the "result view")
+    int row_cap = 0; vido_keypoint *d_kpf = nullptr, *h_kpf = nullptr; uint8_t *d_descf = nullptr, *h_descf = nullptr; int *d_nkp = nullptr;
+    KpLevels kpl{};
 };
 
 static inline int cv_round_f(float v) { return (int)lrintf(v); }
@@ -876,14 +894,9 @@ int orb_state_create(vido_ctx* ctx)
     HIP_TRY(ctx, hipMemset(S->d_overflow, 0, sizeof(int)));
     HIP_TRY(ctx, hipMalloc(&S->d_cand, S->cand_cap * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&S->d_kp, S->kp_cap * sizeof(uint2)));
-    HIP_TRY(ctx, hipMalloc(&S->d_angle, S->kp_cap * sizeof(float)));
-    HIP_TRY(ctx, hipMalloc(&S->d_desc, S->kp_cap * 32));
     HIP_TRY(ctx, hipHostMalloc(&S->h_lvloff, (B * S->L + 1) * sizeof(int)));
     HIP_TRY(ctx, hipHostMalloc(&S->h_overflow, sizeof(int)));
     HIP_TRY(ctx, hipHostMalloc(&S->h_cand, S->cand_cap * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipHostMalloc(&S->h_kp, S->kp_cap * sizeof(uint2)));
-    HIP_TRY(ctx, hipHostMalloc(&S->h_angle, S->kp_cap * sizeof(float)));
-    HIP_TRY(ctx, hipHostMalloc(&S->h_desc, S->kp_cap * 32));
     for (auto& e : S->ev) HIP_TRY(ctx, hipEventCreate(&e));
     {   // device quadtree: the node list never exceeds budget + 3 entries (a pass stops at >= budget nodes)
         int maxN = 0; std::vector<int> bud(S->L);
@@ -899,9 +912,14 @@ int orb_state_create(vido_ctx* ctx)
         HIP_TRY(ctx, hipMalloc(&S->d_frame_beg, (B + 1) * sizeof(int)));
         HIP_TRY(ctx, hipMalloc(&S->d_budget, S->L * sizeof(int)));
         HIP_TRY(ctx, hipMemcpy(S->d_budget, bud.data(), S->L * sizeof(int), hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMalloc(&S->d_resp, S->kp_cap * sizeof(float)));
         HIP_TRY(ctx, hipHostMalloc(&S->h_frame_beg, (B + 1) * sizeof(int)));
-        HIP_TRY(ctx, hipHostMalloc(&S->h_resp, S->kp_cap * sizeof(float)));
+        int rows = 0; for (int l = 0; l < S->L; l++) { rows += bud[l] + 3; S->kpl.scale[l] = S->lv[l].scale; S->kpl.size[l] = (float)(int)(31 * S->lv[l].scale); }
+        S->row_cap = (rows + 63) & ~63;                    // a level's list never exceeds budget + 3 nodes
+        HIP_TRY(ctx, hipMalloc(&S->d_kpf, B * S->row_cap * sizeof(vido_keypoint)));
+        HIP_TRY(ctx, hipMalloc(&S->d_descf, B * (size_t)S->row_cap * 32));
+        HIP_TRY(ctx, hipMalloc(&S->d_nkp, B * sizeof(int)));
+        HIP_TRY(ctx, hipHostMalloc(&S->h_kpf, B * S->row_cap * sizeof(vido_keypoint)));
+        HIP_TRY(ctx, hipHostMalloc(&S->h_descf, B * (size_t)S->row_cap * 32));
     }
     return VIDO_OK;
 }
@@ -912,27 +930,28 @@ void orb_state_destroy(vido_ctx* ctx)
     if (!S) return;
     hipFree(S->d_pyr); hipFree(S->d_blur); hipFree(S->d_cells); hipFree(S->d_btiles); hipFree(S->d_xtab); hipFree(S->d_ytab);
     hipFree(S->d_slots); hipFree(S->d_counts); hipFree(S->d_offsets); hipFree(S->d_first_cell); hipFree(S->d_lvloff); hipFree(S->d_overflow);
-    hipFree(S->d_cand); hipFree(S->d_kp); hipFree(S->d_angle); hipFree(S->d_desc);
-    hipHostFree(S->h_lvloff); hipHostFree(S->h_overflow); hipHostFree(S->h_cand); hipHostFree(S->h_kp); hipHostFree(S->h_angle); hipHostFree(S->h_desc);
+    hipFree(S->d_cand); hipFree(S->d_kp);
+    hipHostFree(S->h_lvloff); hipHostFree(S->h_overflow); hipHostFree(S->h_cand);
     for (auto& e : S->ev) if (e) hipEventDestroy(e);
-    hipFree(S->d_qt_slot); hipFree(S->d_sel); hipFree(S->d_selcnt); hipFree(S->d_kpoff); hipFree(S->d_frame_beg); hipFree(S->d_budget); hipFree(S->d_resp);
-    hipHostFree(S->h_frame_beg); hipHostFree(S->h_resp);
+    hipFree(S->d_qt_slot); hipFree(S->d_sel); hipFree(S->d_selcnt); hipFree(S->d_kpoff); hipFree(S->d_frame_beg); hipFree(S->d_budget); hipFree(S->d_kpf); hipFree(S->d_descf); hipFree(S->d_nkp);
+    hipHostFree(S->h_frame_beg); hipHostFree(S->h_kpf); hipHostFree(S->h_descf);
     delete S; ctx->orb = nullptr;
 }
 
-static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_t frame_stride, int stride, int width, int height,
-                   vido_keypoint* kp_out, int max_kp, int* n_out, uint8_t* desc_out)
+// Enqueues the whole extractor for nf frames on the ctx stream; nothing is synchronised.  Results land in the device
+// rows d_kpf / d_descf / d_nkp ([frame][row_cap]).
+int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_t frame_stride, int stride, int width, int height)
 {
     OrbState* S = ctx->orb;
     if (!S) return vido_set_error(ctx, VIDO_E_INVALID, "orb: context has no ORB state");
-    if (!imgs || !kp_out || !n_out || max_kp <= 0) return vido_set_error(ctx, VIDO_E_INVALID, "orb: null output/input");
+    if (!imgs) return vido_set_error(ctx, VIDO_E_INVALID, "orb: null input");
     if (width != S->W || height != S->H) return vido_set_error(ctx, VIDO_E_INVALID, "orb: frame %dx%d but ctx was created for %dx%d", width, height, S->W, S->H);
     if (nf < 1 || nf > S->B) return vido_set_error(ctx, VIDO_E_INVALID, "orb: n_frames=%d outside [1,%d]", nf, S->B);
     if (stride < width) return vido_set_error(ctx, VIDO_E_INVALID, "orb: stride < width");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int L = S->L;
-    auto t_start = std::chrono::steady_clock::now();
+    S->t_start = std::chrono::steady_clock::now();
     HIP_TRY(ctx, hipEventRecord(S->ev[0], st));
     // level 0 <- input
     if (on_device)
@@ -964,7 +983,8 @@ static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, si
     DBG_SYNC("k_quadtree");
     hipLaunchKernelGGL(k_kp_offsets, dim3(1), dim3(1024), 0, st, S->d_selcnt, n_tasks, L, S->d_kpoff, S->d_frame_beg, nf);
     DBG_SYNC("k_kp_offsets");
-    hipLaunchKernelGGL(k_kp_write, dim3(n_tasks), dim3(256), 0, st, S->d_cand, S->d_lvloff, S->d_sel, S->d_selcnt, S->d_kpoff, S->qcap, L, S->d_kp, S->d_resp, (int)S->kp_cap);
+    hipLaunchKernelGGL(k_kp_write, dim3(n_tasks), dim3(256), 0, st, S->d_cand, S->d_lvloff, S->d_sel, S->d_selcnt, S->d_kpoff, S->qcap, L, S->d_kp, (int)S->kp_cap,
+                       S->d_kpf, S->row_cap, S->d_nkp, S->kpl);
     DBG_SYNC("k_kp_write");
     HIP_TRY(ctx, hipEventRecord(S->ev[3], st));
     const int with_desc = ctx->cfg.compute_descriptors ? 1 : 0;
@@ -973,13 +993,20 @@ static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, si
     HIP_TRY(ctx, hipEventRecord(S->ev[4], st));
     HIP_TRY(ctx, hipEventRecord(S->ev[5], st));
     {   // launch bound: every (frame, level) list holds at most budget + 3 nodes; the kernel reads the real count from d_frame_beg[nf]
-        size_t bound = 0; for (int l = 0; l < L; l++) bound += (size_t)S->lv[l].n_budget + 3;
-        bound = std::min(bound * nf, S->kp_cap);
+        const size_t bound = std::min((size_t)S->row_cap * nf, S->kp_cap);
         hipLaunchKernelGGL(k_orient_brief, dim3((unsigned)((((bound + 3) / 4) + 7) & ~(size_t)7)), dim3(256), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_kp,
-                           (const int*)(S->d_frame_beg + nf), with_desc, S->d_angle, S->d_desc);
+                           (const int*)S->d_frame_beg, nf, with_desc, S->d_kpf, S->d_descf, S->row_cap);
     }
     DBG_SYNC("k_orient_brief");
     HIP_TRY(ctx, hipEventRecord(S->ev[6], st));
+    S->last_frames = nf;
+    return VIDO_OK;
+}
+
+// Waits for the extractor, checks the capacity flags and (copy != 0) brings the result rows into the pinned mirror.
+int orb_collect(vido_ctx* ctx, int nf, int copy)
+{
+    OrbState* S = ctx->orb; hipStream_t st = ctx->stream; const int L = S->L;
     HIP_TRY(ctx, hipMemcpyAsync(S->h_frame_beg, S->d_frame_beg, ((size_t)nf + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(S->h_lvloff, S->d_lvloff, ((size_t)nf * L + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(S->h_overflow, S->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -992,36 +1019,19 @@ static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, si
     }
     const int total = S->h_lvloff[nf * L];
     if ((size_t)total > S->cand_cap) return vido_set_error(ctx, VIDO_E_CAPACITY, "orb: %d FAST candidates exceed the %zu-entry buffer", total, S->cand_cap);
-    const size_t nk = (size_t)S->h_frame_beg[nf];
-    if (nk > S->kp_cap) return vido_set_error(ctx, VIDO_E_CAPACITY, "orb: keypoint buffer overflow");
-    if (nk > 0) {
-        HIP_TRY(ctx, hipMemcpyAsync(S->h_kp, S->d_kp, nk * sizeof(uint2), hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(S->h_resp, S->d_resp, nk * sizeof(float), hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(S->h_angle, S->d_angle, nk * sizeof(float), hipMemcpyDeviceToHost, st));
-        if (with_desc) HIP_TRY(ctx, hipMemcpyAsync(S->h_desc, S->d_desc, nk * 32, hipMemcpyDeviceToHost, st));
+    if ((size_t)S->h_frame_beg[nf] > S->kp_cap) return vido_set_error(ctx, VIDO_E_CAPACITY, "orb: keypoint buffer overflow");
+    int maxn = 0;
+    for (int f = 0; f < nf; f++) {
+        const int n = S->h_frame_beg[f + 1] - S->h_frame_beg[f];
+        if (n > S->row_cap) return vido_set_error(ctx, VIDO_E_CAPACITY, "orb: frame %d has %d keypoints > row capacity %d", f, n, S->row_cap);
+        maxn = std::max(maxn, n);
+    }
+    if (copy && maxn > 0) {
+        const size_t kp_pitch = (size_t)S->row_cap * sizeof(vido_keypoint), de_pitch = (size_t)S->row_cap * 32;
+        HIP_TRY(ctx, hipMemcpy2DAsync(S->h_kpf, kp_pitch, S->d_kpf, kp_pitch, (size_t)maxn * sizeof(vido_keypoint), nf, hipMemcpyDeviceToHost, st));
+        if (ctx->cfg.compute_descriptors) HIP_TRY(ctx, hipMemcpy2DAsync(S->h_descf, de_pitch, S->d_descf, de_pitch, (size_t)maxn * 32, nf, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
     }
-    const int* frame_beg = S->h_frame_beg; const float* response = S->h_resp;
-    // assemble cv::KeyPoint-equivalent output (ORBextractor.cc:827-836, 1094-1103)
-    for (int f = 0; f < nf; f++) {
-        const int n = frame_beg[f + 1] - frame_beg[f];
-        n_out[f] = n;
-        const int m = std::min(n, max_kp);
-        for (int i = 0; i < m; i++) {
-            const size_t g = (size_t)frame_beg[f] + i;
-            const uint32_t p = S->h_kp[g].x;
-            const int l = p >> 24;
-            vido_keypoint& k = kp_out[(size_t)f * max_kp + i];
-            float x = (float)(p & 0xfff), y = (float)((p >> 12) & 0xfff);
-            if (l != 0) { x *= S->lv[l].scale; y *= S->lv[l].scale; }
-            k.x = x; k.y = y; k.size = (float)(int)(31 * S->lv[l].scale); k.angle = S->h_angle[g]; k.response = response[g]; k.octave = l;
-        }
-        if (desc_out) {
-            if (with_desc) memcpy(desc_out + (size_t)f * max_kp * 32, S->h_desc + (size_t)frame_beg[f] * 32, (size_t)m * 32);
-            else memset(desc_out + (size_t)f * max_kp * 32, 0, (size_t)m * 32);
-        }
-    }
-    auto t_end = std::chrono::steady_clock::now();
     float ms;
     hipEventElapsedTime(&ms, S->ev[0], S->ev[1]); S->timing[0] = ms;
     hipEventElapsedTime(&ms, S->ev[1], S->ev[7]); S->timing[1] = ms;
@@ -1030,8 +1040,34 @@ static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, si
     hipEventElapsedTime(&ms, S->ev[2], S->ev[3]); S->timing[2] = ms;
     hipEventElapsedTime(&ms, S->ev[3], S->ev[4]); S->timing[3] = ms;
     hipEventElapsedTime(&ms, S->ev[5], S->ev[6]); S->timing[4] = ms;
-    S->timing[5] = std::chrono::duration<float, std::milli>(t_end - t_start).count();
-    S->last_frames = nf;
+    S->timing[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S->t_start).count();
+    return VIDO_OK;
+}
+
+OrbView orb_view(vido_ctx* ctx)
+{
+    OrbState* S = ctx->orb;
+    return OrbView{S->d_kpf, S->d_nkp, S->row_cap, S->h_kpf, S->h_descf, S->h_frame_beg};
+}
+
+static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_t frame_stride, int stride, int width, int height,
+                   vido_keypoint* kp_out, int max_kp, int* n_out, uint8_t* desc_out)
+{
+    if (!kp_out || !n_out || max_kp <= 0) return vido_set_error(ctx, VIDO_E_INVALID, "orb: null output");
+    int rc = orb_enqueue(ctx, imgs, on_device, nf, frame_stride, stride, width, height); if (rc) return rc;
+    if ((rc = orb_collect(ctx, nf, 1))) return rc;
+    OrbState* S = ctx->orb;
+    const int with_desc = ctx->cfg.compute_descriptors ? 1 : 0;
+    for (int f = 0; f < nf; f++) {
+        const int n = S->h_frame_beg[f + 1] - S->h_frame_beg[f];
+        n_out[f] = n;
+        const int m = std::min(n, max_kp);
+        memcpy(kp_out + (size_t)f * max_kp, S->h_kpf + (size_t)f * S->row_cap, (size_t)m * sizeof(vido_keypoint));
+        if (desc_out) {
+            if (with_desc) memcpy(desc_out + (size_t)f * max_kp * 32, S->h_descf + (size_t)f * S->row_cap * 32, (size_t)m * 32);
+            else memset(desc_out + (size_t)f * max_kp * 32, 0, (size_t)m * 32);
+        }
+    }
     for (int f = 0; f < nf; f++) if (n_out[f] > max_kp) return vido_set_error(ctx, VIDO_E_CAPACITY, "orb: frame %d has %d keypoints, max_kp=%d", f, n_out[f], max_kp);
     return VIDO_OK;
 }

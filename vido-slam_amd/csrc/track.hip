@@ -19,6 +19,7 @@ struct TrackState {
     float* d_tmpf = nullptr; int32_t* d_tmpi = nullptr; size_t tmp_cap = 0;       // scratch for gathers
     int32_t* h_cnt = nullptr;
     char* h_stage = nullptr; size_t stage_cap = 0;
+    char* h_view = nullptr; size_t view_cap = 0;         // pinned lists of the fused front end (vido_frontend_batch)
 };
 
 // ---- kernels -------------------------------------------------------------------------------------
@@ -58,7 +59,7 @@ __device__ __forceinline__ int block_ordered_slot(bool flag, int& base, int* wsu
 }
 
 // Frame.cc:72-100 + :165-177.  One workgroup per frame.
-__global__ __launch_bounds__(1024) void k_static_filter(const vido_keypoint* __restrict__ kps, const int32_t* __restrict__ n_kps, int max_kp,
+__global__ __launch_bounds__(1024) void k_static_filter(const vido_keypoint* __restrict__ kps, const int32_t* __restrict__ n_kps, int kp_pitch, int max_kp,
                                                         const float* __restrict__ depth, const float* __restrict__ flow, const int32_t* __restrict__ mask,
                                                         int w, int h, float th_depth,
                                                         int32_t* __restrict__ out_idx, float* __restrict__ out_corr, float* __restrict__ out_flow,
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(1024) void k_static_filter(const vido_keypoint* __r
     __shared__ int wsum[17];
     const int f = blockIdx.x;
     const size_t px = (size_t)w * h;
-    const vido_keypoint* K = kps + (size_t)f * max_kp;
+    const vido_keypoint* K = kps + (size_t)f * kp_pitch;
     const float* D = depth + f * px; const float* F = flow + f * px * 2; const int32_t* M = mask + f * px;
     const int n = n_kps[f];
     int base = 0;
@@ -225,7 +226,7 @@ void track_state_destroy(vido_ctx* ctx)
     if (!T) return;
     hipFree(T->d_depth); hipFree(T->d_flow); hipFree(T->d_mask); hipFree(T->d_kps); hipFree(T->d_sidx); hipFree(T->d_scorr); hipFree(T->d_sflow);
     hipFree(T->d_sdepth); hipFree(T->d_nstat); hipFree(T->d_nobj); hipFree(T->d_okeys); hipFree(T->d_ocorr); hipFree(T->d_odepth); hipFree(T->d_olabel);
-    hipFree(T->d_oflow); hipFree(T->d_tmpf); hipFree(T->d_tmpi); hipHostFree(T->h_cnt); hipHostFree(T->h_stage);
+    hipFree(T->d_oflow); hipFree(T->d_tmpf); hipFree(T->d_tmpi); hipHostFree(T->h_cnt); hipHostFree(T->h_stage); hipHostFree(T->h_view);
     delete T; ctx->trk = nullptr;
 }
 
@@ -281,7 +282,7 @@ int vido_frame_features(vido_ctx* ctx, int slot0, int n_frames, const vido_keypo
                                   (size_t)max_kp * sizeof(vido_keypoint), n_frames, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(T->d_nstat, n_kps, n_frames * 4, hipMemcpyHostToDevice, st));     // reused as the input count, overwritten by the kernel
     HIP_TRY(ctx, hipMemcpyAsync(T->d_nobj, n_kps, n_frames * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_static_filter, dim3(n_frames), dim3(1024), 0, st, T->d_kps, T->d_nobj, T->max_kp,
+    hipLaunchKernelGGL(k_static_filter, dim3(n_frames), dim3(1024), 0, st, T->d_kps, T->d_nobj, T->max_kp, T->max_kp,
                        T->d_depth + slot0 * px, T->d_flow + slot0 * px * 2, T->d_mask + slot0 * px, T->W, T->H, p->th_depth_bg,
                        T->d_sidx, T->d_scorr, T->d_sflow, T->d_sdepth, T->d_nstat);
     const int step = p->dense_step > 0 ? p->dense_step : 4;
@@ -330,6 +331,64 @@ int vido_frame_features(vido_ctx* ctx, int slot0, int n_frames, const vido_keypo
             const int cnt = (g.dst == out->stat_idx || g.dst == out->stat_corr || g.dst == out->stat_flow || g.dst == out->stat_depth) ? out->n_stat[f] : out->n_obj[f];
             memcpy((char*)g.dst + (size_t)f * g.dpitch, g.stage + (size_t)f * g.width * g.el, (size_t)cnt * g.el);
         }
+    return VIDO_OK;
+}
+
+/* Fused per-frame front end for a batch: ORB extraction + depth pre-scale + Frame::Frame lists in ONE stream of launches with
+ * the keypoints handed from the extractor to the static filter on the device (no H2D of keypoints, no intermediate sync),
+ * results mirrored into ctx-owned pinned host memory and returned as a view (no copies into caller arrays). */
+int vido_frontend_batch(vido_ctx* ctx, const uint8_t* imgs, int imgs_on_device, int n_frames, size_t frame_stride, int stride, int width, int height,
+                        float* depth, const float* flow, const int32_t* mask, int maps_on_device, int slot0, const vido_track_params* p,
+                        vido_frontend_view* view)
+{
+    if (!ctx || !p || !view) return VIDO_E_INVALID;
+    TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
+    if (slot0 < 0 || n_frames < 1 || slot0 + n_frames > T->B || !depth || !flow || !mask)
+        return vido_set_error(ctx, VIDO_E_INVALID, "frontend_batch: slots [%d,%d) outside [0,%d) or null map", slot0, slot0 + n_frames, T->B);
+    if ((rc = orb_enqueue(ctx, imgs, imgs_on_device, n_frames, frame_stride, stride, width, height))) return rc;
+    hipStream_t st = ctx->stream;
+    const size_t px = (size_t)T->W * T->H, n = px * n_frames;
+    if ((n & 3) != 0) return vido_set_error(ctx, VIDO_E_INVALID, "frontend_batch: width*height must be a multiple of 4");
+    float* dd = T->d_depth + slot0 * px;
+    HIP_TRY(ctx, hipMemcpyAsync(dd, depth, n * 4, in_kind(maps_on_device), st));
+    HIP_TRY(ctx, hipMemcpyAsync(T->d_flow + slot0 * px * 2, flow, n * 8, in_kind(maps_on_device), st));
+    HIP_TRY(ctx, hipMemcpyAsync(T->d_mask + slot0 * px, mask, n * 4, in_kind(maps_on_device), st));
+    hipLaunchKernelGGL(k_depth_prescale, dim3((int)std::min<size_t>((n / 4 + 255) / 256, 2048)), dim3(256), 0, st, dd, n / 4, p->dataset, p->depth_map_factor, p->bf, p->kaist_scale);
+    HIP_TRY(ctx, hipMemcpyAsync(depth, dd, n * 4, maps_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));     // in-place semantics of Tracking.cc:299-322
+    const OrbView ov = orb_view(ctx);
+    if (ov.row_cap > T->max_kp) return vido_set_error(ctx, VIDO_E_INVALID, "frontend_batch: extractor rows (%d) exceed the list capacity (%d)", ov.row_cap, T->max_kp);
+    hipLaunchKernelGGL(k_static_filter, dim3(n_frames), dim3(1024), 0, st, ov.d_kpf, ov.d_nkp, ov.row_cap, T->max_kp,
+                       T->d_depth + slot0 * px, T->d_flow + slot0 * px * 2, T->d_mask + slot0 * px, T->W, T->H, p->th_depth_bg,
+                       T->d_sidx, T->d_scorr, T->d_sflow, T->d_sdepth, T->d_nstat);
+    const int step = p->dense_step > 0 ? p->dense_step : 4;
+    const int lattice = ((T->W + step - 1) / step) * ((T->H + step - 1) / step);
+    if (lattice > T->max_obj) return vido_set_error(ctx, VIDO_E_INVALID, "frontend_batch: dense_step %d gives %d probes > %d", step, lattice, T->max_obj);
+    hipLaunchKernelGGL(k_dense_sample, dim3(n_frames), dim3(1024), 0, st, T->d_depth + slot0 * px, T->d_flow + slot0 * px * 2, T->d_mask + slot0 * px,
+                       T->W, T->H, p->th_depth_obj, step, T->max_obj, T->d_okeys, T->d_ocorr, T->d_odepth, T->d_olabel, T->d_oflow, T->d_nobj);
+    HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt, T->d_nstat, n_frames * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt + T->B, T->d_nobj, n_frames * 4, hipMemcpyDeviceToHost, st));
+    if ((rc = orb_collect(ctx, n_frames, 1))) return rc;           // waits for everything enqueued above; mirrors keypoints + descriptors
+    // pinned list rows: [frame][max_kp] (static) and [frame][max_obj] (object samples)
+    const size_t B = T->B, need = B * ((size_t)T->max_kp * 24 + (size_t)T->max_obj * 32);
+    if (need > T->view_cap) { if (T->h_view) HIP_TRY(ctx, hipHostFree(T->h_view)); T->view_cap = need; HIP_TRY(ctx, hipHostMalloc((void**)&T->h_view, T->view_cap)); }
+    int max_ns = 0, max_no = 0;
+    for (int f = 0; f < n_frames; f++) { max_ns = std::max(max_ns, T->h_cnt[f]); max_no = std::max(max_no, T->h_cnt[T->B + f]); }
+    char* cur = T->h_view;
+    auto rows = [&](const void* src, size_t pitch_el, size_t el, int width_el) -> char* {
+        char* dst = cur; cur += B * pitch_el * el;
+        if (width_el > 0) hipMemcpy2DAsync(dst, pitch_el * el, src, pitch_el * el, (size_t)width_el * el, n_frames, hipMemcpyDeviceToHost, st);
+        return dst;
+    };
+    view->n_frames = n_frames; view->kp_pitch = ov.row_cap; view->stat_pitch = T->max_kp; view->obj_pitch = T->max_obj;
+    view->kps = ov.h_kpf; view->desc = ov.h_descf; view->frame_beg = ov.h_frame_beg;
+    view->n_stat = T->h_cnt; view->n_obj = T->h_cnt + T->B;
+    view->stat_idx = (const int32_t*)rows(T->d_sidx, T->max_kp, 4, max_ns); view->stat_corr = (const float*)rows(T->d_scorr, T->max_kp, 8, max_ns);
+    view->stat_flow = (const float*)rows(T->d_sflow, T->max_kp, 8, max_ns); view->stat_depth = (const float*)rows(T->d_sdepth, T->max_kp, 4, max_ns);
+    view->obj_keys = (const float*)rows(T->d_okeys, T->max_obj, 8, max_no); view->obj_corr = (const float*)rows(T->d_ocorr, T->max_obj, 8, max_no);
+    view->obj_depth = (const float*)rows(T->d_odepth, T->max_obj, 4, max_no); view->obj_label = (const int32_t*)rows(T->d_olabel, T->max_obj, 4, max_no);
+    view->obj_flow = (const float*)rows(T->d_oflow, T->max_obj, 8, max_no);
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }
 

@@ -201,6 +201,13 @@ def track_params(dataset=0, depth_map_factor=1.0, bf=387.57, kaist_scale=1.0, th
     return TrackParams(dataset, depth_map_factor, bf, kaist_scale, th_depth_bg, th_depth_obj, dense_step, fx, fy, cx, cy)
 
 
+class FrontendView(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("kp_pitch", C.c_int32), ("stat_pitch", C.c_int32), ("obj_pitch", C.c_int32),
+                ("kps", C.c_void_p), ("desc", C.c_void_p), ("frame_beg", C.c_void_p),
+                ("n_stat", C.c_void_p), ("stat_idx", C.c_void_p), ("stat_corr", C.c_void_p), ("stat_flow", C.c_void_p), ("stat_depth", C.c_void_p),
+                ("n_obj", C.c_void_p), ("obj_keys", C.c_void_p), ("obj_corr", C.c_void_p), ("obj_depth", C.c_void_p), ("obj_label", C.c_void_p), ("obj_flow", C.c_void_p)]
+
+
 class FrameFeatures:
     """Device-side Frame::Frame RGB-D ctor stages (Frame.cc:36-241) bound to a Context."""
 
@@ -232,6 +239,38 @@ class FrameFeatures:
                                                                       "n_obj", "obj_keys", "obj_corr", "obj_depth", "obj_label", "obj_flow")])
         self.ctx._check(self.ctx.lib.vido_frame_features(self.ctx.h, slot0, n, _ptr(kps), _ptr(n_kps), max_kp, C.byref(self.p), C.byref(L)))
         return o
+
+    def frontend_batch(self, slot0, imgs, depth, flow, mask):
+        """Fused ORB + depth pre-scale + Frame::Frame lists for a batch (vido_frontend_batch).  Every argument is either a
+        host numpy array or a (device_ptr, ...) description: imgs like Context.orb_extract_batch, depth/flow/mask either all
+        numpy (n,h,w[,2]) or all raw device pointers (ints).  Returns zero-copy numpy VIEWS of the ctx's pinned result
+        buffers — valid until the next call on this context."""
+        ctx = self.ctx
+        if isinstance(imgs, tuple):
+            ptr, n, h, w, fstride, rstride = imgs; img_dev = 1
+        else:
+            imgs = np.ascontiguousarray(imgs, np.uint8); n, h, w = imgs.shape
+            ptr, fstride, rstride, img_dev = imgs.ctypes.data, h * w, w, 0
+        if isinstance(depth, np.ndarray):
+            assert depth.dtype == np.float32 and depth.flags.c_contiguous
+            flow = np.ascontiguousarray(flow, np.float32); mask = np.ascontiguousarray(mask, np.int32)
+            dp, fp, mp, maps_dev = depth.ctypes.data, flow.ctypes.data, mask.ctypes.data, 0
+        else:
+            dp, fp, mp, maps_dev = int(depth), int(flow), int(mask), 1
+        v = FrontendView()
+        ctx._check(ctx.lib.vido_frontend_batch(ctx.h, C.c_void_p(ptr), img_dev, n, C.c_size_t(fstride), rstride, w, h, C.c_void_p(dp), C.c_void_p(fp), C.c_void_p(mp),
+                                               maps_dev, slot0, C.byref(self.p), C.byref(v)))
+        def arr(p, shape, dtype):
+            count = int(np.prod(shape))
+            return np.frombuffer((C.c_char * (count * np.dtype(dtype).itemsize)).from_address(p), dtype=dtype, count=count).reshape(shape) if count else np.zeros(shape, dtype)
+        B = ctx.cfg.max_batch if ctx.cfg.max_batch > 1 else 2
+        fb = arr(v.frame_beg, (n + 1,), np.int32)
+        return dict(kps=arr(v.kps, (n, v.kp_pitch), KP_DTYPE), desc=arr(v.desc, (n, v.kp_pitch, 32), np.uint8), n_kp=np.diff(fb),
+                    n_stat=arr(v.n_stat, (n,), np.int32), stat_idx=arr(v.stat_idx, (n, v.stat_pitch), np.int32), stat_corr=arr(v.stat_corr, (n, v.stat_pitch, 2), np.float32),
+                    stat_flow=arr(v.stat_flow, (n, v.stat_pitch, 2), np.float32), stat_depth=arr(v.stat_depth, (n, v.stat_pitch), np.float32),
+                    n_obj=arr(v.n_obj, (n,), np.int32), obj_keys=arr(v.obj_keys, (n, v.obj_pitch, 2), np.float32), obj_corr=arr(v.obj_corr, (n, v.obj_pitch, 2), np.float32),
+                    obj_depth=arr(v.obj_depth, (n, v.obj_pitch), np.float32), obj_label=arr(v.obj_label, (n, v.obj_pitch), np.int32),
+                    obj_flow=arr(v.obj_flow, (n, v.obj_pitch, 2), np.float32))
 
     def gather_static_depth(self, slot, keys):
         keys = np.ascontiguousarray(keys, np.float32).reshape(-1, 2); out = np.empty(len(keys), np.float32)
