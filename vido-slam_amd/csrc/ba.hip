@@ -45,6 +45,7 @@ struct BaDev {
     double *S, *r, *x;                                      // [n6*n6], [n6], [n6]
     double *scal;                                           // [8]: 0 chi2 1 maxdiag 2 tempChi 3 scale 4 ok
     const double *odo_info, *odo_delta;                     // per camera-camera factor (odometry | object-motion smoothness)
+    int bw, ldb;                                            // bw >= 0: S is stored as a lower BAND, entry (r, c) at S[r*ldb + c - r + bw]; bw < 0: dense n6 x n6
     // ---- object part (FullBatchOptimization, STATIC_ONLY = false).  n_cam above counts ALL pose vertices: cameras first,
     // then the object motions H.  Dynamic points are stored chain-major (a chain = one dynamic tracklet).
     int n_dyn, n_chain;
@@ -60,6 +61,13 @@ __device__ __forceinline__ void huber_w(double e2, double delta, int use, double
 {
     if (!use || e2 <= delta * delta) { r0 = e2; r1 = 1.0; return; }
     const double s = sqrt(e2); r0 = 2 * s * delta - delta * delta; r1 = delta / s;
+}
+// address of entry (row, col) of the reduced system, or nullptr when the band layout does not store it (upper triangle)
+__device__ __forceinline__ double* s_entry(const BaDev& P, int row, int col)
+{
+    if (P.bw < 0) return P.S + (size_t)row * P.n6 + col;
+    if (col > row || row - col > P.bw) return nullptr;
+    return P.S + (size_t)row * P.ldb + (col - row + P.bw);
 }
 __device__ __forceinline__ void iso_inv_mul(const double* A, const double* B, double* C)
 {
@@ -245,12 +253,12 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev P, int n_ptl)
 // S <- camera-camera part (+ lambda on the diagonal when add_lambda), r <- bc   (upper AND lower filled)
 __global__ __launch_bounds__(256) void k_ba_init_S(BaDev P, double lambda, int add_cam_part)
 {
-    const int n6 = P.n6;
-    const size_t tot = (size_t)n6 * n6;
+    const int n6 = P.n6, ld = P.bw < 0 ? n6 : P.ldb;
+    const size_t tot = (size_t)n6 * ld;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
-        const int row = (int)(t / n6), col = (int)(t % n6);
+        const int row = (int)(t / ld), col = P.bw < 0 ? (int)(t % ld) : row - P.bw + (int)(t % ld);
         double v = 0;
-        if (add_cam_part && row / 6 == col / 6) { v = P.Hcd[36 * (row / 6) + (row % 6) * 6 + col % 6]; if (row == col) v += lambda; }
+        if (add_cam_part && col >= 0 && col < n6 && row / 6 == col / 6) { v = P.Hcd[36 * (row / 6) + (row % 6) * 6 + col % 6]; if (row == col) v += lambda; }
         P.S[t] = v;
     }
     for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < n6; a += gridDim.x * blockDim.x) P.r[a] = P.bc[a];
@@ -261,8 +269,8 @@ __global__ void k_ba_add_odo(BaDev P)
     if (t >= P.n_odo * 36) return;
     const int k = t / 36, a = (t % 36) / 6, b = t % 6, i = P.odo_i[k], j = P.odo_j[k];
     const double v = P.Hodo[t];
-    atomicAdd(P.S + (size_t)(6 * i + a) * P.n6 + 6 * j + b, v);
-    atomicAdd(P.S + (size_t)(6 * j + b) * P.n6 + 6 * i + a, v);
+    double* e0 = s_entry(P, 6 * i + a, 6 * j + b); if (e0) atomicAdd(e0, v);
+    double* e1 = s_entry(P, 6 * j + b, 6 * i + a); if (e1) atomicAdd(e1, v);
 }
 
 // ---- Schur complement: one wave per landmark ------------------------------------------------------------
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev P, int n_ptl, double lam
 #pragma unroll
                     for (int b = 0; b < 6; b++) {
                         const double v = -(A[a * 3] * Bm[b * 3] + A[a * 3 + 1] * Bm[b * 3 + 1] + A[a * 3 + 2] * Bm[b * 3 + 2]);
-                        if (to_hbm) atomicAdd(P.S + (size_t)(6 * (ci + cbase) + a) * n6 + 6 * (cj + cbase) + b, v);
+                        if (to_hbm) { double* e = s_entry(P, 6 * (ci + cbase) + a, 6 * (cj + cbase) + b); if (e) atomicAdd(e, v); }
                         else atomicAdd(Sl + (size_t)(6 * ci + a) * wn + 6 * cj + b, v);
                     }
             }
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev P, int n_ptl, double lam
             __syncthreads();
             for (int t = threadIdx.x; t < wn * wn; t += blockDim.x) {
                 const double v = Sl[t];
-                if (v != 0.0) { const int r = t / wn, c = t - r * wn; const int gr = 6 * cbase + r, gc = 6 * cbase + c; if (gr < n6 && gc < n6) atomicAdd(P.S + (size_t)gr * n6 + gc, v); }
+                if (v != 0.0) { const int r = t / wn, c = t - r * wn; const int gr = 6 * cbase + r, gc = 6 * cbase + c; if (gr < n6 && gc < n6) { double* e = s_entry(P, gr, gc); if (e) atomicAdd(e, v); } }
             }
             for (int t = threadIdx.x; t < wn; t += blockDim.x) { const double v = Sl[(size_t)wn * wn + t]; if (v != 0.0 && 6 * cbase + t < n6) atomicAdd(P.r + 6 * cbase + t, v); }
             __syncthreads();
@@ -493,6 +501,305 @@ __global__ __launch_bounds__(64) void k_chol_back_diag(const double* __restrict_
     if (tid == 0) for (int j = nb - 1; j >= 0; j--) { double s = y[j]; for (int c = j + 1; c < nb; c++) s -= T[c][j] * y[c]; y[j] = s / T[j][j]; }
     __syncthreads();
     if (tid < nb) x[k0 + tid] = y[tid];
+}
+
+// ---- banded reduced solve ------------------------------------------------------------------------------------
+// A SLAM map without loop closures couples a camera only to its temporal neighbours (track length, odometry), so the
+// reduced camera system is block-banded: it is stored, all-reduced and factored as a band (n6 x (bw+1) doubles instead of
+// n6^2 — 3 MB instead of 72 MB for 500 keyframes).  One persistent workgroup walks the diagonal in NB-column steps:
+// diagonal block factored in LDS by one wave, panel rows solved one thread per row, trailing (bw x bw) window updated by
+// all 1024 threads, the right-hand side carried along (forward substitution for free), then the backward sweep.
+#define CB_NB 16
+#define CB_MAXROWS 256                     // panel rows of one step = bw <= 255
+__global__ __launch_bounds__(1024) void k_chol_band(BaDev P)
+{
+    __shared__ double Ld[CB_NB + 1][CB_NB + 1];            // row CB_NB carries the right-hand side of the block (forward substitution for free)
+    __shared__ double Pn[CB_MAXROWS][CB_NB + 1];
+    __shared__ double zk[CB_NB];
+    __shared__ int ok;
+    const int n = P.n6, bw = P.bw, ldb = P.ldb, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double* Sg = P.S; double* r = P.r; double* x = P.x;
+#define AB(i, j) Sg[(size_t)(i) * ldb + ((j) - (i) + bw)]
+    if (tid == 0) ok = 1;
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += CB_NB) {
+        const int nb = min(CB_NB, n - k0), i0 = k0 + nb, i1 = min(n, k0 + nb + bw), m = i1 - i0;      // panel rows [i0, i1)
+        // the block is always handled as CB_NB x CB_NB (+ the rhs row): a short last block is padded with an identity tail
+        if (tid < CB_NB * CB_NB) { const int a = tid >> 4, b = tid & 15; Ld[a][b] = (a < nb && b <= a) ? AB(k0 + a, k0 + b) : (a == b ? 1.0 : 0.0); }
+        if (tid >= 512 && tid < 512 + CB_NB) Ld[CB_NB][tid - 512] = tid - 512 < nb ? r[k0 + tid - 512] : 0.0;
+        // panel rows are prefetched into registers while wave 0 factors the diagonal block
+        double v[CB_NB];
+        const bool prow = tid >= 64 && tid < 64 + m;
+        const int pi = i0 + tid - 64;
+        double rpi = 0;
+        if (prow) {
+#pragma unroll
+            for (int c = 0; c < CB_NB; c++) v[c] = (c < nb && pi - (k0 + c) <= bw) ? AB(pi, k0 + c) : 0.0;
+            rpi = r[pi];
+        }
+        __syncthreads();
+        if (tid < 64) {                                   // unblocked Cholesky of the (CB_NB+1) x CB_NB block (rhs row included), all in LDS
+#pragma unroll 1
+            for (int c = 0; c < CB_NB; c++) {
+                const double d = Ld[c][c];
+                if (!(d > 0.0) || !isfinite(d)) { if (tid == 0) ok = 0; break; }
+                const double sd = sqrt(d), inv = 1.0 / sd;
+                __builtin_amdgcn_wave_barrier();
+                if (tid > c && tid <= CB_NB) Ld[tid][c] *= inv;
+                if (tid == c) Ld[c][c] = sd;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < 5; q++) {             // (CB_NB + 1) * CB_NB = 272 entries = 4.25 x 64 lanes
+                    const int t = tid + 64 * q, a = t >> 4, b2 = t & 15;
+                    if (t < (CB_NB + 1) * CB_NB && b2 > c && a >= b2) Ld[a][b2] -= Ld[a][c] * Ld[b2][c];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        if (!ok) break;
+        if (tid < nb * nb) { const int a = tid / nb, b = tid - a * nb; if (b <= a) AB(k0 + a, k0 + b) = Ld[a][b]; }
+        if (tid >= 512 && tid < 512 + nb) r[k0 + tid - 512] = Ld[CB_NB][tid - 512];
+        if (prow) {                                       // row pi of L against the block; entries outside the band are structurally zero
+            double rr = 0;
+#pragma unroll
+            for (int c = 0; c < CB_NB; c++) {
+                if (c < nb) {
+                    double a = v[c];
+#pragma unroll
+                    for (int e = 0; e < c; e++) a -= v[e] * Ld[c][e];
+                    a /= Ld[c][c];
+                    v[c] = a; rr += a * Ld[CB_NB][c];
+                    if (pi - (k0 + c) <= bw) AB(pi, k0 + c) = a;
+                }
+                Pn[tid - 64][c] = c < nb ? v[c] : 0.0;
+            }
+            r[pi] = rpi - rr;
+        }
+        __syncthreads();
+        // trailing window: A(i, j) -= L(i, k) . L(j, k) for i0 <= j <= i < i1 (i - j <= bw holds: m <= bw); a wave per row, lanes along the
+        // contiguous band storage of that row; all loads of a wave's rows are issued before the first store
+        {
+            double cur[4][4]; int na = 0;
+            for (int a = wave; a < m && na < 4; a += 16, na++) {
+                const double* rowp = &AB(i0 + a, i0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const int b = lane + 64 * q; cur[na][q] = b <= a ? rowp[b] : 0.0; }
+            }
+            na = 0;
+            for (int a = wave; a < m; a += 16, na++) {
+                double pa[CB_NB];
+#pragma unroll
+                for (int c = 0; c < CB_NB; c++) pa[c] = Pn[a][c];
+                double* rowp = &AB(i0 + a, i0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int b = lane + 64 * q;
+                    if (b <= a) {
+                        double sum = 0;
+#pragma unroll
+                        for (int c = 0; c < CB_NB; c++) sum += pa[c] * Pn[b][c];
+                        rowp[b] = (na < 4 ? cur[na < 4 ? na : 0][q] : rowp[b]) - sum;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (ok) {                                               // backward sweep: x = L^-T z (z sits in r)
+        for (int k0 = ((n - 1) / CB_NB) * CB_NB; k0 >= 0; k0 -= CB_NB) {
+            const int nb = min(CB_NB, n - k0), i0 = k0 + nb, i1 = min(n, k0 + nb + bw);
+            if (tid >= 512 && tid < 512 + nb * nb) { const int t = tid - 512, a = t / nb, b = t - a * nb; Ld[a][b] = b <= a ? AB(k0 + a, k0 + b) : 0.0; }
+            if (wave < nb) {                                // wave c: z_c - sum_{i in panel} L(i, k0+c) x_i
+                const int col = k0 + wave; double sacc = 0;
+                for (int i = i0 + lane; i < i1; i += 64) if (i - col <= bw) sacc += AB(i, col) * x[i];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+                if (lane == 0) zk[wave] = r[col] - sacc;
+            }
+            __syncthreads();
+            if (tid < 64) {                                 // column-oriented triangular solve: one LDS round trip per unknown
+                for (int c = nb - 1; c >= 0; c--) {
+                    const double xc = zk[c] / Ld[c][c];
+                    __builtin_amdgcn_wave_barrier();
+                    if (tid < c) zk[tid] -= Ld[c][tid] * xc;
+                    if (tid == c) { zk[c] = xc; x[k0 + c] = xc; }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) P.scal[4] = ok ? 1.0 : 0.0;
+#undef AB
+}
+
+// Pose-block variant for short bands (the usual case: a landmark is seen from <= ~20 consecutive keyframes): pivots are the 6x6
+// camera blocks, not scalars.  Every thread factors the 6x6 pivot block redundantly in registers (no broadcast, no barrier),
+// panel rows are one thread each, the trailing update is one thread per (row, column block), and the (bwc+1)-block window of
+// the trailing matrix lives in LDS with circular block indexing: each block row of S is read from HBM once when it enters
+// the window and the factor is written once.  Two workgroup barriers per camera instead of ~10 per 16 scalar pivots.
+// The backward sweep is row oriented (contiguous band rows, next row prefetched while the current one is consumed).
+// Workgroup barrier that orders LDS traffic only: the factor rows streamed out to HBM inside the loop are not read again
+// before the full __syncthreads() that precedes the backward sweep, so the barrier must not wait for those stores to retire
+// (a plain __syncthreads() drains vmcnt: ~5 us per step, 10x the arithmetic of a step).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ bool chol6(const double* A /*21: row-major lower*/, double* L /*21*/, double* inv /*6: 1/L_cc*/)
+{
+    bool good = true;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        double d = A[c * (c + 1) / 2 + c];
+#pragma unroll
+        for (int e = 0; e < c; e++) d -= L[c * (c + 1) / 2 + e] * L[c * (c + 1) / 2 + e];
+        good = good && (d > 0.0) && isfinite(d);
+        double iv = __builtin_amdgcn_rsq(d);
+        iv = iv * (1.5 - 0.5 * d * iv * iv); iv = iv * (1.5 - 0.5 * d * iv * iv);
+        inv[c] = iv; L[c * (c + 1) / 2 + c] = d * iv;
+#pragma unroll
+        for (int a = c + 1; a < 6; a++) {
+            double v = A[a * (a + 1) / 2 + c];
+#pragma unroll
+            for (int e = 0; e < c; e++) v -= L[a * (a + 1) / 2 + e] * L[c * (c + 1) / 2 + e];
+            L[a * (a + 1) / 2 + c] = v * iv;
+        }
+    }
+    return good;
+}
+__global__ __launch_bounds__(1024) void k_chol_band6(BaDev P, int bwc /* block half-bandwidth: bw = 6*bwc + 5 */)
+{
+    extern __shared__ double cb6[];
+    const int Wb = bwc + 1, Wr = 6 * Wb, ldw = Wr + 1;
+    double* W = cb6;                                        // [Wr][ldw]  block (ib, jb) at physical blocks (pb(ib), pb(jb))
+    double* rW = W + (size_t)Wr * ldw;                       // [Wr]  rhs of the window rows
+    double* Pn = rW + Wr;                                    // [6*bwc][7]  panel rows of L of the current step (window-relative row)
+    double* xs = Pn + (size_t)6 * bwc * 7;                   // [Wr]  backward sweep: x of the blocks below (circular)
+    double* acc = xs + Wr;                                   // [Wr]  backward sweep: sum_i L_ik^T x_i accumulators (circular)
+    __shared__ int ok;
+    const int n = P.n6, nblk = n / 6, bw = P.bw, ldb = P.ldb, tid = threadIdx.x;
+    double* Sg = P.S; double* r = P.r; double* x = P.x;
+#define AB(i, j) Sg[(size_t)(i) * ldb + ((j) - (i) + bw)]
+#define PB(ib) (((ib) - kb + boff) >= Wb ? ((ib) - kb + boff - Wb) : ((ib) - kb + boff))
+    if (tid == 0) ok = 1;
+    int boff = 0;
+    {   // block rows [0, min(nblk, Wb)) enter
+        const int kb = 0;
+        for (int t = tid; t < min(nblk, Wb) * 6 * Wr; t += 1024) {
+            const int i = t / Wr, jj = t - i * Wr, ib = i / 6, j = 6 * (ib - bwc) + jj;          // jj-th in-band column slot of row i (by block)
+            if (j >= 0 && j <= i) W[(6 * PB(ib) + i % 6) * ldw + 6 * PB(j / 6) + j % 6] = AB(i, j);
+        }
+        for (int i = tid; i < min(nblk, Wb) * 6; i += 1024) rW[6 * PB(i / 6) + i % 6] = r[i];
+    }
+    // per-thread trailing item(s): (panel row ri in [0, 6*bwc), column block jc in [0, bwc)), active when jc <= ri / 6
+    const int n_items = 6 * bwc * bwc;
+    __syncthreads();
+    for (int kb = 0; kb < nblk; kb++, boff = (boff + 1 >= Wb ? 0 : boff + 1)) {
+        const int pk = 6 * boff;                             // physical row/col of block kb
+        const int nbelow = min(bwc, nblk - 1 - kb);           // panel block rows
+        // ---- A: 6x6 pivot block, every thread redundantly
+        double Akk[21], Lk[21], inv[6], zk[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = W[(pk + a) * ldw + pk + b];
+        const bool good = chol6(Akk, Lk, inv);
+        if (!good) { if (tid == 0) ok = 0; }
+#pragma unroll
+        for (int c = 0; c < 6; c++) { double v = rW[pk + c]; 
+#pragma unroll
+            for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
+        if (!good) break;                                    // uniform: every thread factored the same block
+        // ---- B1: panel rows, final factor + z of block kb out to HBM
+        if (tid < 6 * nbelow) {
+            const int ibr = tid / 6 + 1, a = tid - (ibr - 1) * 6, ib = kb + ibr, prow = 6 * PB(ib) + a, i = 6 * ib + a;
+            double l[6], rr = 0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double v = W[prow * ldw + pk + c];
+#pragma unroll
+                for (int e = 0; e < c; e++) v -= l[e] * Lk[c * (c + 1) / 2 + e];
+                v *= inv[c]; l[c] = v; rr += v * zk[c];
+                Pn[tid * 7 + c] = v; AB(i, 6 * kb + c) = v;
+            }
+            rW[prow] -= rr;
+        } else if (tid >= 512 && tid < 512 + 21) {           // compile-time register indices only: a dynamic Lk[t] would push the arrays to scratch
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = 0; b <= a; b++) if (tid - 512 == a * (a + 1) / 2 + b) AB(6 * kb + a, 6 * kb + b) = Lk[a * (a + 1) / 2 + b];
+        } else if (tid >= 576 && tid < 582) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) if (tid - 576 == c) r[6 * kb + c] = zk[c];
+        }
+        lds_barrier();
+        // ---- B2: trailing window (LDS only) — item = (panel row ri, column block jc <= block of ri): 6 entries
+        for (int it = tid; it < n_items; it += 1024) {
+            const int ri = it / bwc, jc = it - ri * bwc, ibr = ri / 6;
+            if (ibr >= nbelow || jc > ibr) continue;
+            const int a = ri - 6 * ibr, prow = 6 * PB(kb + 1 + ibr) + a, pcol = 6 * PB(kb + 1 + jc);
+            double li[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) li[c] = Pn[ri * 7 + c];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                if (jc == ibr && b > a) break;
+                const double* lj = Pn + (6 * jc + b) * 7;
+                W[prow * ldw + pcol + b] -= li[0] * lj[0] + li[1] * lj[1] + li[2] * lj[2] + li[3] * lj[3] + li[4] * lj[4] + li[5] * lj[5];
+            }
+        }
+        // ---- D: block row kb + Wb enters (it reuses the storage of block row kb, which nothing above touches any more)
+        {
+            const int ib = kb + Wb;
+            if (ib < nblk) {
+                for (int t = tid; t < 6 * Wr; t += 1024) {
+                    const int a = t / Wr, jj = t - a * Wr, i = 6 * ib + a, j = 6 * (ib - bwc) + jj;
+                    if (j <= i) { const int jb = j / 6; W[(pk + a) * ldw + 6 * (jb == ib ? boff : PB(jb)) + j % 6] = AB(i, j); }
+                }
+                if (tid < 6) rW[pk + tid] = r[6 * ib + tid];
+            }
+        }
+        lds_barrier();
+    }
+    __syncthreads();
+    if (ok) {   // ---- backward sweep, row oriented: x_k = L_kk^-T (z_k - acc_k); then acc_j += L_kj^T x_k for the blocks j < k of row k
+        for (int t = tid; t < Wr; t += 1024) acc[t] = 0.0;
+        __syncthreads();
+        int boff2 = 0;                                       // physical slot of block kb in the circular acc / xs arrays
+        for (int kb = nblk - 1; kb >= 0; kb--, boff2 = (boff2 + 1 >= Wb ? 0 : boff2 + 1)) {
+            // wave 0: x_k from the diagonal block of row-block kb (read from HBM: 21 + 6 values)
+            if (tid < 64) {
+                double Lk[21], t6[6];
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int b = 0; b <= a; b++) Lk[a * (a + 1) / 2 + b] = AB(6 * kb + a, 6 * kb + b);
+#pragma unroll
+                for (int c = 0; c < 6; c++) t6[c] = r[6 * kb + c] - acc[6 * boff2 + c];
+#pragma unroll
+                for (int c = 5; c >= 0; c--) { double v = t6[c];
+#pragma unroll
+                    for (int e = c + 1; e < 6; e++) v -= Lk[e * (e + 1) / 2 + c] * t6[e]; t6[c] = v / Lk[c * (c + 1) / 2 + c]; }
+#pragma unroll
+                for (int c = 0; c < 6; c++) if (tid == c) { x[6 * kb + c] = t6[c]; xs[c] = t6[c]; }
+            }
+            __syncthreads();
+            // acc_j += L(kb-row a, col) * x_kb[a] for the in-band columns left of the diagonal block; slot of block j = boff2 + (kb - j)
+            const int ncols = 6 * min(bwc, kb);
+            for (int t = tid; t < ncols; t += 1024) {
+                const int j = 6 * kb - ncols + t, jb = j / 6;
+                double sum = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) sum += AB(6 * kb + a, j) * xs[a];
+                int slot = boff2 + (kb - jb); if (slot >= Wb) slot -= Wb;
+                acc[6 * slot + j % 6] += sum;
+            }
+            if (tid >= 512 && tid < 518) acc[6 * boff2 + tid - 512] = 0.0;     // this slot becomes block kb - Wb
+            __syncthreads();
+        }
+    }
+    if (tid == 0) P.scal[4] = ok ? 1.0 : 0.0;
+#undef AB
+#undef PB
 }
 
 // ---- trial state ------------------------------------------------------------------------------------------
@@ -1018,14 +1325,28 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         BS->scratch_cap = (size_t)512 * 64 * 3 * lmax; HIP_TRY(ctx, hipMalloc((void**)&BS->d_scratch, BS->scratch_cap * sizeof(double)));
     }
     // S and r are contiguous so that one all-reduce covers both
-    double* Sr = A.get<double>((size_t)n6 * n6 + n6); D.S = Sr; D.r = Sr + (size_t)n6 * n6; D.x = A.get<double>(n6);
+    // band layout of the reduced system when the map is sequential (every landmark / odometry edge spans few keyframes)
+    const bool lds_path = n6 <= BA_LDS_MAX_N6;
+    D.bw = -1; D.ldb = n6;
+    if (!lds_path && n_H == 0) {
+        std::vector<int> cmin(p.n_pt, p.n_cam), cmax(p.n_pt, -1);
+        for (int k = 0; k < p.n_obs; k++) { const int l = p.obs_pt[k], c = p.obs_cam[k]; cmin[l] = std::min(cmin[l], c); cmax[l] = std::max(cmax[l], c); }   // ALL shards: every rank must pick the same layout
+        int bwc = 0;
+        for (int l = 0; l < p.n_pt; l++) if (cmax[l] >= 0) bwc = std::max(bwc, cmax[l] - cmin[l]);
+        for (int k = 0; k < p.n_odo; k++) bwc = std::max(bwc, std::abs(p.odo_i[k] - p.odo_j[k]));
+        if (6 * bwc + 5 <= 255 && 6 * bwc + 6 < n6 / 2) { D.bw = 6 * bwc + 5; D.ldb = (D.bw + 2) & ~1; }
+    }
+    const size_t sz_S = D.bw >= 0 ? (size_t)n6 * D.ldb : (size_t)n6 * n6;
+    size_t band6_lds = 0;                                   // pose-block LDS-window factorisation when the window fits
+    if (D.bw >= 0) { const size_t bwc = (D.bw - 5) / 6, wr = 6 * (bwc + 1), need = (wr * (wr + 1) + 3 * wr + 6 * bwc * 7 + 8) * sizeof(double);
+                     if (bwc >= 1 && need <= 150 * 1024) { band6_lds = need; HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol_band6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)); } }
+    double* Sr = A.get<double>(sz_S + n6); D.S = Sr; D.r = Sr + sz_S; D.x = A.get<double>(n6);
     double* chol_tmp = A.get<double>(64);
     double* red = A.get<double>((size_t)n_pose * 36 + n6 + 8);      // [Hcd | bc | scal] contiguous for the linearisation all-reduce
     D.Hcd = red; D.bc = red + (size_t)n_pose * 36; D.scal = D.bc + n6;
     if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device allocation failed (n6=%d, n_obs=%d)", n6, no);
-    const bool lds_path = n6 <= BA_LDS_MAX_N6;
     const int schur_grid = lds_path ? std::min(256, std::max(1, (n_ptl + 3) / 4)) : std::min(4096, std::max(1, (n_ptl + 3) / 4));
-    const size_t sz_sr = (size_t)n6 * n6 + n6;
+    const size_t sz_sr = sz_S + n6;
     if (lds_path && (size_t)schur_grid * sz_sr > BS->parts_cap) {
         HIP_TRY(ctx, hipStreamSynchronize(st)); if (BS->d_parts) hipFree(BS->d_parts);
         BS->parts_cap = (size_t)256 * sz_sr; HIP_TRY(ctx, hipMalloc((void**)&BS->d_parts, BS->parts_cap * sizeof(double)));
@@ -1122,6 +1443,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             // ---- replicated reduced solve
             HIP_TRY(ctx, hipMemsetAsync(D.scal + 2, 0, 2 * sizeof(double), st));
             if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
+            else if (D.bw >= 0 && band6_lds) hipLaunchKernelGGL(k_chol_band6, dim3(1), dim3(1024), band6_lds, st, D, (D.bw - 5) / 6);
+            else if (D.bw >= 0) hipLaunchKernelGGL(k_chol_band, dim3(1), dim3(1024), 0, st, D);
             else { const double one = 1.0; HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4, &one, 8, hipMemcpyHostToDevice, st)); if ((rc = chol_large(ctx, D.S, n6, D.x, D.scal + 4, chol_tmp, st))) return rc; }
             // ---- trial state + its chi2
             hipLaunchKernelGGL(k_ba_update_cams, dim3((n_pose + 63) / 64), dim3(64), 0, st, D, (allreduce && p.rank != 0) ? 0.0 : lambda);
