@@ -128,7 +128,10 @@ __device__ void block_allreduce(double* v, int first_max, double* lds /* [16][NV
         v[k] = x;
     }
     __syncthreads();
-    if (lane == 0) for (int k = 0; k < NV; k++) lds[wave * NV + k] = v[k];
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) lds[wave * NV + k] = v[k];      // unrolled: a dynamic v[k] would push the accumulators to scratch
+    }
     __syncthreads();
     if (threadIdx.x < NV) {
         const int k = threadIdx.x;
@@ -199,7 +202,9 @@ __global__ __launch_bounds__(256) void k_pose_opt(const PoseProbDev* __restrict_
         for (int round = 0; round < p.rounds; round++) {
             T = Tinit;
             double lambda = -1, ni = 2, chi2_check = 0; int nBad = 0;
-            for (int it = 0; it < p.iters[round]; it++) {
+            const int round_iters = probs[blockIdx.x].iters[round];        // dynamic index: read through the pointer so that the local copy `p` stays in registers
+            const float round_chi2_th = probs[blockIdx.x].chi2_th[round];
+            for (int it = 0; it < round_iters; it++) {
                 // ---- computeActiveErrors + buildSystem in one pass
                 double acc[NRED];
 #pragma unroll
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(const PoseProbDev* __restrict_
                 double e0 = p.err[2 * i], e1 = p.err[2 * i + 1];
                 if (p.outlier[i]) { double e[2]; edge_eval<false>(p, T, i, flowm ? p.f[2 * i] : 0.0, flowm ? p.f[2 * i + 1] : 0.0, e, nullptr); e0 = e[0]; e1 = e[1]; p.err[2 * i] = e0; p.err[2 * i + 1] = e1; }
                 const float chi2 = (float)(p.info_edge * (e0 * e0 + e1 * e1));
-                if (chi2 > p.chi2_th[round]) { p.outlier[i] = 1; nb[0] += 1; } else p.outlier[i] = 0;
+                if (chi2 > round_chi2_th) { p.outlier[i] = 1; nb[0] += 1; } else p.outlier[i] = 0;
                 if (round == p.drop_kernel_after_round) p.has_kernel[i] = 0;
             }
             block_allreduce<1>(nb, 1, lds);
