@@ -802,6 +802,108 @@ __global__ __launch_bounds__(1024) void k_chol_band6(BaDev P, int bwc /* block h
 #undef PB
 }
 
+// Local-BA reduced solve (n6 <= 120, dense): the same pose-block scheme as k_chol_band6 on the whole matrix in LDS —
+// 20 block pivots with three LDS barriers each instead of 120 scalar pivots.  (Factoring the pivot block on every wave
+// redundantly is faster than one wave + publish: the dependent FP64 chain is latency-bound and the copies interleave.)
+__global__ __launch_bounds__(1024) void k_ba_chol_small6(BaDev P)
+{
+    extern __shared__ double cs6[];
+    const int n = P.n6, nblk = n / 6, ldw = n + 1, tid = threadIdx.x;
+    double* W = cs6;                                        // [n][ldw] lower triangle
+    double* rW = W + (size_t)n * ldw;                        // [n] rhs -> z -> x
+    double* Pn = rW + n;                                     // [n][7] panel rows of the current step
+    __shared__ int ok;
+    for (int t = tid; t < n * n; t += 1024) { const int i = t / n, j = t - i * n; if (j <= i) W[i * ldw + j] = P.S[t]; }
+    for (int t = tid; t < n; t += 1024) rW[t] = P.r[t];
+    if (tid == 0) ok = 1;
+    __syncthreads();
+    for (int kb = 0; kb < nblk; kb++) {
+        const int pk = 6 * kb, nbelow = nblk - 1 - kb;
+        double Akk[21], Lk[21], inv[6], zk[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = W[(pk + a) * ldw + pk + b];
+        const bool good = chol6(Akk, Lk, inv);
+#pragma unroll
+        for (int c = 0; c < 6; c++) { double v = rW[pk + c];
+#pragma unroll
+            for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
+        if (!good) { if (tid == 0) ok = 0; break; }
+        lds_barrier();                                       // everybody has read block kb and its rhs
+        if (tid < 6 * nbelow) {
+            const int prow = pk + 6 + tid;
+            double l[6], rr = 0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double v = W[prow * ldw + pk + c];
+#pragma unroll
+                for (int e = 0; e < c; e++) v -= l[e] * Lk[c * (c + 1) / 2 + e];
+                v *= inv[c]; l[c] = v; rr += v * zk[c];
+                Pn[tid * 7 + c] = v; W[prow * ldw + pk + c] = v;
+            }
+            rW[prow] -= rr;
+        } else if (tid >= 512 && tid < 512 + 21) {
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = 0; b <= a; b++) if (tid - 512 == a * (a + 1) / 2 + b) W[(pk + a) * ldw + pk + b] = Lk[a * (a + 1) / 2 + b];
+        } else if (tid >= 576 && tid < 582) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) if (tid - 576 == c) rW[pk + c] = zk[c];
+        }
+        lds_barrier();
+        const int n_items = 6 * nbelow * nbelow;             // (panel row ri, column block jc <= block of ri)
+        for (int it = tid; it < n_items; it += 1024) {
+            const int ri = it / nbelow, jc = it - ri * nbelow, ibr = ri / 6;
+            if (jc > ibr) continue;
+            const int a = ri - 6 * ibr, prow = pk + 6 + ri, pcol = pk + 6 + 6 * jc;
+            double li[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) li[c] = Pn[ri * 7 + c];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                if (jc == ibr && b > a) break;
+                const double* lj = Pn + (6 * jc + b) * 7;
+                W[prow * ldw + pcol + b] -= li[0] * lj[0] + li[1] * lj[1] + li[2] * lj[2] + li[3] * lj[3] + li[4] * lj[4] + li[5] * lj[5];
+            }
+        }
+        lds_barrier();
+    }
+    __syncthreads();
+    if (ok) {                                                // backward sweep in LDS, row oriented: x_k = L_kk^-T (z_k - acc_k), acc_j += L_kj^T x_k
+        for (int kb = nblk - 1; kb >= 0; kb--) {
+            const int pk = 6 * kb;
+            if (tid < 64) {
+                double Lk[21], t6[6];
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int b = 0; b <= a; b++) Lk[a * (a + 1) / 2 + b] = W[(pk + a) * ldw + pk + b];
+#pragma unroll
+                for (int c = 0; c < 6; c++) t6[c] = rW[pk + c];
+#pragma unroll
+                for (int c = 5; c >= 0; c--) { double v = t6[c];
+#pragma unroll
+                    for (int e = c + 1; e < 6; e++) v -= Lk[e * (e + 1) / 2 + c] * t6[e]; t6[c] = v / Lk[c * (c + 1) / 2 + c]; }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int c = 0; c < 6; c++) if (tid == c) rW[pk + c] = t6[c];
+            }
+            lds_barrier();
+            for (int j = tid; j < pk; j += 1024) {
+                double sum = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) sum += W[(pk + a) * ldw + j] * rW[pk + a];
+                rW[j] -= sum;
+            }
+            lds_barrier();
+        }
+        for (int t = tid; t < n; t += 1024) P.x[t] = rW[t];
+    }
+    if (tid == 0) P.scal[4] = ok ? 1.0 : 0.0;
+}
+
 // ---- trial state ------------------------------------------------------------------------------------------
 __global__ void k_ba_update_cams(BaDev P, double lambda)
 {
@@ -1353,6 +1455,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     }
     const int kcap = std::max(maxk, 1);
     const size_t lds_chol = ((size_t)(n6 + 1) * ((n6 + 1) | 1) + n6 + 2) * sizeof(double);
+    const size_t lds_chol6 = ((size_t)n6 * (n6 + 1) + n6 + (size_t)n6 * 7 + 8) * sizeof(double);
     const size_t win_sz = (size_t)(BA_WC * 6) * (BA_WC * 6) + BA_WC * 6;
     const size_t lds_schur = ((lds_path ? sz_sr : win_sz) + (size_t)4 * (2 * kcap * 18)) * sizeof(double);
     // camera window base of every landmark chunk (the first slot of a landmark is its lowest camera)
@@ -1365,7 +1468,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     }
     if (lds_schur > 160 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "ba: LDS budget exceeded (n6=%d, max track %d)", n6, maxk);
     if (lds_path) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
-                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol)); }
+                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol));
+                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol6)); }
     else { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur)); }
 
     auto AR = [&](double* dptr, size_t cnt, int op) -> int {
@@ -1442,7 +1546,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if ((rc = AR(Sr, sz_sr, 0))) return rc;
             // ---- replicated reduced solve
             HIP_TRY(ctx, hipMemsetAsync(D.scal + 2, 0, 2 * sizeof(double), st));
-            if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
+            if (lds_path && n6 % 6 == 0 && n6 >= 12) hipLaunchKernelGGL(k_ba_chol_small6, dim3(1), dim3(1024), lds_chol6, st, D);
+            else if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
             else if (D.bw >= 0 && band6_lds) hipLaunchKernelGGL(k_chol_band6, dim3(1), dim3(1024), band6_lds, st, D, (D.bw - 5) / 6);
             else if (D.bw >= 0) hipLaunchKernelGGL(k_chol_band, dim3(1), dim3(1024), 0, st, D);
             else { const double one = 1.0; HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4, &one, 8, hipMemcpyHostToDevice, st)); if ((rc = chol_large(ctx, D.S, n6, D.x, D.scal + 4, chol_tmp, st))) return rc; }
