@@ -66,6 +66,7 @@ int orb_state_create(vido_ctx* ctx);
 // extractor split used by the fused front end (track.hip): enqueue everything, then wait + check (+ mirror the rows)
 int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_t frame_stride, int stride, int width, int height);
 int orb_collect(vido_ctx* ctx, int nf, int copy);
+int orb_mirror_async(vido_ctx* ctx, int nf);
 struct OrbView { const vido_keypoint* d_kpf; const int* d_nkp; int row_cap; const vido_keypoint* h_kpf; const uint8_t* h_descf; const int* h_frame_beg; };
 OrbView orb_view(vido_ctx* ctx);
 void track_state_destroy(vido_ctx* ctx);

@@ -299,30 +299,41 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ co
                                                       const int* __restrict__ first_cell, int* __restrict__ lvloff,
                                                       int* __restrict__ overflow)
 {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x;
-    const int chunk = (n + 1023) / 1024;
-    const int beg = tid * chunk, end = min(beg + chunk, n);
+    // every wave owns a contiguous segment and walks it 64 entries at a time (coalesced loads, shuffle scan); the 16 segment
+    // totals are combined through LDS
+    __shared__ int wtot[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int seg = (((n + 15) / 16) + 63) & ~63;
+    const int beg = wave * seg, end = min(beg + seg, n);
     int s = 0, ovf = 0;
-    for (int i = beg; i < end; i++) { int c = counts[i]; if (c > VIDO_CELL_CAP) { ovf = 1; c = VIDO_CELL_CAP; } s += c; }
-    part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        int v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int run = part[tid] - s;
-    for (int i = beg; i < end; i++) { offsets[i] = run; run += min(counts[i], VIDO_CELL_CAP); }
-    if (tid == 1023) offsets[n] = part[1023];
+#pragma unroll 4
+    for (int i = beg + lane; i < end; i += 64) { int c = counts[i]; if (c > VIDO_CELL_CAP) { ovf = 1; c = VIDO_CELL_CAP; } s += c; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) wtot[wave] = s;
     if (ovf) *overflow = 1;
     __syncthreads();
+    int run = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { if (w < wave) run += wtot[w]; total += wtot[w]; }
+#pragma unroll 4
+    for (int i0 = beg; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        const int c = i < end ? min(counts[i], VIDO_CELL_CAP) : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+        if (i < end) offsets[i] = run + inc - c;
+        run += __shfl(inc, 63, 64);
+    }
+    if (tid == 0) offsets[n] = total;
+    __syncthreads();
+    __threadfence_block();
     for (int i = tid; i < n_frames * n_levels; i += 1024) {
         const int f = i / n_levels, l = i - f * n_levels;
         lvloff[i] = offsets[f * n_cells + first_cell[l]];
     }
-    if (tid == 0) lvloff[n_frames * n_levels] = part[1023];
+    if (tid == 0) lvloff[n_frames * n_levels] = total;
 }
 
 __global__ __launch_bounds__(64) void k_gather_cands(const uint32_t* __restrict__ slots, const int* __restrict__ counts,
@@ -731,7 +742,7 @@ struct OrbState {
     uint2* d_kp = nullptr; size_t kp_cap = 0;
     // pinned host
     int* h_lvloff = nullptr; int* h_overflow = nullptr; uint32_t* h_cand = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[8] = {}; hipEvent_t ev_done = nullptr;
     float timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::chrono::steady_clock::time_point t_start;
     int last_frames = 0;
@@ -898,6 +909,7 @@ int orb_state_create(vido_ctx* ctx)
     HIP_TRY(ctx, hipHostMalloc(&S->h_overflow, sizeof(int)));
     HIP_TRY(ctx, hipHostMalloc(&S->h_cand, S->cand_cap * sizeof(uint32_t)));
     for (auto& e : S->ev) HIP_TRY(ctx, hipEventCreate(&e));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_done, hipEventDisableTiming));
     {   // device quadtree: the node list never exceeds budget + 3 entries (a pass stops at >= budget nodes)
         int maxN = 0; std::vector<int> bud(S->L);
         for (int l = 0; l < S->L; l++) { bud[l] = S->lv[l].n_budget; maxN = std::max(maxN, bud[l]); }
@@ -933,6 +945,7 @@ void orb_state_destroy(vido_ctx* ctx)
     hipFree(S->d_cand); hipFree(S->d_kp);
     hipHostFree(S->h_lvloff); hipHostFree(S->h_overflow); hipHostFree(S->h_cand);
     for (auto& e : S->ev) if (e) hipEventDestroy(e);
+    if (S->ev_done) hipEventDestroy(S->ev_done);
     hipFree(S->d_qt_slot); hipFree(S->d_sel); hipFree(S->d_selcnt); hipFree(S->d_kpoff); hipFree(S->d_frame_beg); hipFree(S->d_budget); hipFree(S->d_kpf); hipFree(S->d_descf); hipFree(S->d_nkp);
     hipHostFree(S->h_frame_beg); hipHostFree(S->h_kpf); hipHostFree(S->h_descf);
     delete S; ctx->orb = nullptr;
@@ -1041,6 +1054,19 @@ int orb_collect(vido_ctx* ctx, int nf, int copy)
     hipEventElapsedTime(&ms, S->ev[3], S->ev[4]); S->timing[3] = ms;
     hipEventElapsedTime(&ms, S->ev[5], S->ev[6]); S->timing[4] = ms;
     S->timing[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S->t_start).count();
+    return VIDO_OK;
+}
+
+// Starts mirroring the (full-width) result rows into the pinned buffers on the ctx's second stream as soon as the extractor has
+// finished, so that the copy overlaps whatever the caller enqueues next on the main stream.  Pair with orb_collect(copy = 0) and a
+// hipStreamSynchronize(ctx->stream2).
+int orb_mirror_async(vido_ctx* ctx, int nf)
+{
+    OrbState* S = ctx->orb;
+    HIP_TRY(ctx, hipEventRecord(S->ev_done, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, S->ev_done, 0));
+    HIP_TRY(ctx, hipMemcpyAsync(S->h_kpf, S->d_kpf, (size_t)nf * S->row_cap * sizeof(vido_keypoint), hipMemcpyDeviceToHost, ctx->stream2));
+    if (ctx->cfg.compute_descriptors) HIP_TRY(ctx, hipMemcpyAsync(S->h_descf, S->d_descf, (size_t)nf * S->row_cap * 32, hipMemcpyDeviceToHost, ctx->stream2));
     return VIDO_OK;
 }
 

@@ -346,6 +346,7 @@ int vido_frontend_batch(vido_ctx* ctx, const uint8_t* imgs, int imgs_on_device, 
     if (slot0 < 0 || n_frames < 1 || slot0 + n_frames > T->B || !depth || !flow || !mask)
         return vido_set_error(ctx, VIDO_E_INVALID, "frontend_batch: slots [%d,%d) outside [0,%d) or null map", slot0, slot0 + n_frames, T->B);
     if ((rc = orb_enqueue(ctx, imgs, imgs_on_device, n_frames, frame_stride, stride, width, height))) return rc;
+    if ((rc = orb_mirror_async(ctx, n_frames))) return rc;       // keypoint / descriptor rows stream to the host while the tracking kernels run
     hipStream_t st = ctx->stream;
     const size_t px = (size_t)T->W * T->H, n = px * n_frames;
     if ((n & 3) != 0) return vido_set_error(ctx, VIDO_E_INVALID, "frontend_batch: width*height must be a multiple of 4");
@@ -367,7 +368,7 @@ int vido_frontend_batch(vido_ctx* ctx, const uint8_t* imgs, int imgs_on_device, 
                        T->W, T->H, p->th_depth_obj, step, T->max_obj, T->d_okeys, T->d_ocorr, T->d_odepth, T->d_olabel, T->d_oflow, T->d_nobj);
     HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt, T->d_nstat, n_frames * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt + T->B, T->d_nobj, n_frames * 4, hipMemcpyDeviceToHost, st));
-    if ((rc = orb_collect(ctx, n_frames, 1))) return rc;           // waits for everything enqueued above; mirrors keypoints + descriptors
+    if ((rc = orb_collect(ctx, n_frames, 0))) return rc;           // waits for everything enqueued above on the main stream
     // pinned list rows: [frame][max_kp] (static) and [frame][max_obj] (object samples)
     const size_t B = T->B, need = B * ((size_t)T->max_kp * 24 + (size_t)T->max_obj * 32);
     if (need > T->view_cap) { if (T->h_view) HIP_TRY(ctx, hipHostFree(T->h_view)); T->view_cap = need; HIP_TRY(ctx, hipHostMalloc((void**)&T->h_view, T->view_cap)); }
@@ -388,6 +389,7 @@ int vido_frontend_batch(vido_ctx* ctx, const uint8_t* imgs, int imgs_on_device, 
     view->obj_depth = (const float*)rows(T->d_odepth, T->max_obj, 4, max_no); view->obj_label = (const int32_t*)rows(T->d_olabel, T->max_obj, 4, max_no);
     view->obj_flow = (const float*)rows(T->d_oflow, T->max_obj, 8, max_no);
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }
