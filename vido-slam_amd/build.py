@@ -5,7 +5,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvido_slam_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-pthread"]
+         "-fno-fast-math", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-pthread"]
 
 
 def sources():

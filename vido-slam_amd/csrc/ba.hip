@@ -286,20 +286,22 @@ __global__ void k_ba_add_odo(BaDev P)
 #define BA_CHUNK 64
 template <int MODE>
 __global__ __launch_bounds__(256) void k_ba_schur(BaDev P, int n_ptl, double lambda, int kcap, double* S_part /*[grid][n6*n6 + n6], MODE 0*/,
-                                                  const int* __restrict__ chunk_cmin /*MODE 2*/)
+                                                  const int* __restrict__ chunk_cmin /*MODE 2*/, const int* __restrict__ lorder /*MODE 2: landmarks by first camera*/)
 {
     extern __shared__ double lds[];
     const int n6 = P.n6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int wn = MODE == 0 ? n6 : BA_WC * 6;                 // side of the LDS-resident (window of) S
-    double* Sl = lds;                                        // [wn*wn + wn] for MODE 0 / 2
-    double* stage = lds + (MODE == 1 ? 0 : (size_t)wn * wn + wn) + (size_t)wave * (2 * kcap * 18);   // W, WD of up to kcap obs per wave
+    const int ldw = wn + 1;                                  // odd row pitch: a 6x6 block's rows (and the rows of different lanes) fall into different LDS banks
+    double* Sl = lds;                                        // [wn*ldw + wn] for MODE 0 / 2
+    double* stage = lds + (MODE == 1 ? 0 : (size_t)wn * ldw + wn) + (size_t)wave * (2 * kcap * 18);   // W, WD of up to kcap obs per wave
     const int n_units = MODE == 2 ? (n_ptl + BA_CHUNK - 1) / BA_CHUNK : 1;
     for (int unit = MODE == 2 ? blockIdx.x : 0; unit < n_units; unit += MODE == 2 ? gridDim.x : 1) {
         int cbase = 0, l_beg, l_end, l_step;
         if (MODE == 2) { cbase = chunk_cmin[unit]; l_beg = unit * BA_CHUNK + wave; l_end = min(n_ptl, (unit + 1) * BA_CHUNK); l_step = nw; }
         else { l_beg = blockIdx.x * nw + wave; l_end = n_ptl; l_step = gridDim.x * nw; }
-        if (MODE != 1) { for (int t = threadIdx.x; t < wn * wn + wn; t += blockDim.x) Sl[t] = 0; __syncthreads(); }
-        for (int l = l_beg; l < l_end; l += l_step) {
+        if (MODE != 1) { for (int t = threadIdx.x; t < wn * ldw + wn; t += blockDim.x) Sl[t] = 0; __syncthreads(); }
+        for (int lp = l_beg; lp < l_end; lp += l_step) {
+            const int l = MODE == 2 ? lorder[lp] : lp;
             const int beg = P.pt_start[l], k = min(P.pt_start[l + 1] - beg, kcap);
             double Di[9]; inv3sym(P.Hpp + 6 * (size_t)l, lambda, Di);
             const double b0 = P.bp[3 * (size_t)l], b1 = P.bp[3 * (size_t)l + 1], b2 = P.bp[3 * (size_t)l + 2];
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev P, int n_ptl, double lam
                 const int c = P.slot_cam[beg + t / 6] - cbase;
                 const double rv = -(d0 * b0 + d1 * b1 + d2 * b2);
                 if (MODE == 1 || (MODE == 2 && (c < 0 || c >= BA_WC))) atomicAdd(P.r + 6 * (c + cbase) + t % 6, rv);
-                else atomicAdd(Sl + (size_t)wn * wn + 6 * c + t % 6, rv);
+                else atomicAdd(Sl + (size_t)wn * ldw + 6 * c + t % 6, rv);
             }
             __builtin_amdgcn_wave_barrier();
             // slot pairs (i >= j): block (ci, cj) -= WD_i W_j^T ; one 6x6 block per lane-iteration
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev P, int n_ptl, double lam
                     for (int b = 0; b < 6; b++) {
                         const double v = -(A[a * 3] * Bm[b * 3] + A[a * 3 + 1] * Bm[b * 3 + 1] + A[a * 3 + 2] * Bm[b * 3 + 2]);
                         if (to_hbm) { double* e = s_entry(P, 6 * (ci + cbase) + a, 6 * (cj + cbase) + b); if (e) atomicAdd(e, v); }
-                        else atomicAdd(Sl + (size_t)(6 * ci + a) * wn + 6 * cj + b, v);
+                        else atomicAdd(Sl + (size_t)(6 * ci + a) * ldw + 6 * cj + b, v);
                     }
             }
             __builtin_amdgcn_wave_barrier();
@@ -340,15 +342,17 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev P, int n_ptl, double lam
         if (MODE == 0) {
             __syncthreads();
             double* out = S_part + (size_t)blockIdx.x * ((size_t)n6 * n6 + n6);
-            for (int t = threadIdx.x; t < n6 * n6 + n6; t += blockDim.x) out[t] = Sl[t];
+            for (int t = threadIdx.x; t < n6 * n6; t += blockDim.x) { const int r = t / n6, c = t - r * n6; out[t] = Sl[r * ldw + c]; }
+            for (int t = threadIdx.x; t < n6; t += blockDim.x) out[(size_t)n6 * n6 + t] = Sl[(size_t)wn * ldw + t];
         }
         if (MODE == 2) {                                          // flush the window: one HBM atomic per touched entry
             __syncthreads();
             for (int t = threadIdx.x; t < wn * wn; t += blockDim.x) {
-                const double v = Sl[t];
-                if (v != 0.0) { const int r = t / wn, c = t - r * wn; const int gr = 6 * cbase + r, gc = 6 * cbase + c; if (gr < n6 && gc < n6) { double* e = s_entry(P, gr, gc); if (e) atomicAdd(e, v); } }
+                const int r = t / wn, c = t - r * wn;
+                const double v = Sl[r * ldw + c];
+                if (v != 0.0) { const int gr = 6 * cbase + r, gc = 6 * cbase + c; if (gr < n6 && gc < n6) { double* e = s_entry(P, gr, gc); if (e) atomicAdd(e, v); } }
             }
-            for (int t = threadIdx.x; t < wn; t += blockDim.x) { const double v = Sl[(size_t)wn * wn + t]; if (v != 0.0 && 6 * cbase + t < n6) atomicAdd(P.r + 6 * cbase + t, v); }
+            for (int t = threadIdx.x; t < wn; t += blockDim.x) { const double v = Sl[(size_t)wn * ldw + t]; if (v != 0.0 && 6 * cbase + t < n6) atomicAdd(P.r + 6 * cbase + t, v); }
             __syncthreads();
         }
     }
@@ -1377,7 +1381,13 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         if (p.obs_pt[k] >= pt_lo && p.obs_pt[k] < pt_hi) keep.push_back(k);
     }
     const int no = (int)keep.size();
-    std::stable_sort(keep.begin(), keep.end(), [&](int a, int b) { return p.obs_cam[a] < p.obs_cam[b]; });
+    {   // stable counting sort by camera (O(n); a comparison sort of 1M observations costs more than the whole LM loop)
+        std::vector<int> cstart(p.n_cam + 1, 0), sorted(no);
+        for (int t = 0; t < no; t++) cstart[p.obs_cam[keep[t]] + 1]++;
+        for (int c = 0; c < p.n_cam; c++) cstart[c + 1] += cstart[c];
+        for (int t = 0; t < no; t++) sorted[cstart[p.obs_cam[keep[t]]]++] = keep[t];
+        keep.swap(sorted);
+    }
     std::vector<int> ocam(no), opt(no), opos(no), pstart(n_ptl + 1, 0), slotcam(no);
     std::vector<double> omeas((size_t)no * 3);
     for (int t = 0; t < no; t++) { const int k = keep[t]; ocam[t] = p.obs_cam[k]; opt[t] = p.obs_pt[k] - pt_lo; for (int a = 0; a < 3; a++) omeas[3 * (size_t)t + a] = p.obs_meas[3 * (size_t)k + a]; pstart[opt[t] + 1]++; }
@@ -1389,7 +1399,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     {   // size the persistent pool (device + pinned mirror for the uploads) for this problem
         const size_t ndb = (size_t)n_pose * (24 + 36 + 36) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + 18) + (size_t)n_cc * (12 + 36 + 2) + (size_t)n6 * n6 + 5 * (size_t)n6 + 64 +
                            (size_t)nd * (3 + 3 + 3 + 6 + 3 + 9 + 18 * 4 + 3);
-        const size_t ni32 = 4 * (size_t)no + (size_t)n_ptl + (size_t)n_ptl / 32 + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 256;
+        const size_t ni32 = 4 * (size_t)no + 2 * (size_t)n_ptl + (size_t)n_ptl / 32 + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 256;
         const size_t need = ndb * 8 + ni32 * 4 + 96 * 256;
         if (need > BS->pool_cap) {
             HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -1456,14 +1466,23 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     const int kcap = std::max(maxk, 1);
     const size_t lds_chol = ((size_t)(n6 + 1) * ((n6 + 1) | 1) + n6 + 2) * sizeof(double);
     const size_t lds_chol6 = ((size_t)n6 * (n6 + 1) + n6 + (size_t)n6 * 7 + 8) * sizeof(double);
-    const size_t win_sz = (size_t)(BA_WC * 6) * (BA_WC * 6) + BA_WC * 6;
-    const size_t lds_schur = ((lds_path ? sz_sr : win_sz) + (size_t)4 * (2 * kcap * 18)) * sizeof(double);
-    // camera window base of every landmark chunk (the first slot of a landmark is its lowest camera)
-    int* d_chunk_cmin = nullptr; int n_chunks = (n_ptl + BA_CHUNK - 1) / BA_CHUNK;
+    const size_t win_sz = (size_t)(BA_WC * 6) * (BA_WC * 6 + 1) + BA_WC * 6;
+    const size_t lds_schur = ((lds_path ? sz_sr + n6 : win_sz) + (size_t)4 * (2 * kcap * 18)) * sizeof(double);
+    // MODE 2 walks the landmarks ordered by their first camera, so that a chunk of BA_CHUNK of them touches a short run of cameras
+    // (the BA_WC-camera window of S held in LDS); window base of a chunk = lowest first camera in it
+    int* d_chunk_cmin = nullptr; int* d_lorder = nullptr; int n_chunks = (n_ptl + BA_CHUNK - 1) / BA_CHUNK;
     if (!lds_path && n_ptl) {
+        std::vector<int> lorder(n_ptl);
+        auto first_cam = [&](int l) { return pstart[l + 1] > pstart[l] ? slotcam[pstart[l]] : p.n_cam; };
+        {   // stable counting sort by first camera
+            std::vector<int> cs(p.n_cam + 2, 0);
+            for (int l = 0; l < n_ptl; l++) cs[first_cam(l) + 1]++;
+            for (int c = 0; c <= p.n_cam; c++) cs[c + 1] += cs[c];
+            for (int l = 0; l < n_ptl; l++) lorder[cs[first_cam(l)]++] = l;
+        }
         std::vector<int> cmin(n_chunks, 0);
-        for (int c = 0; c < n_chunks; c++) { int m = p.n_cam; for (int l = c * BA_CHUNK; l < std::min(n_ptl, (c + 1) * BA_CHUNK); l++) if (pstart[l + 1] > pstart[l]) m = std::min(m, slotcam[pstart[l]]); cmin[c] = m == p.n_cam ? 0 : m; }
-        d_chunk_cmin = A.put(cmin.data(), n_chunks, st);
+        for (int c = 0; c < n_chunks; c++) { const int m = first_cam(lorder[c * BA_CHUNK]); cmin[c] = m == p.n_cam ? 0 : m; }
+        d_chunk_cmin = A.put(cmin.data(), n_chunks, st); d_lorder = A.put(lorder.data(), n_ptl, st);
         if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device pool exhausted");
     }
     if (lds_schur > 160 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "ba: LDS budget exceeded (n6=%d, max track %d)", n6, maxk);
@@ -1534,9 +1553,9 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if (add_cam && D.n_odo) hipLaunchKernelGGL(k_ba_add_odo, dim3((D.n_odo * 36 + 255) / 256), dim3(256), 0, st, D);
             if (n_ptl) {
                 if (lds_path) {
-                    hipLaunchKernelGGL(k_ba_schur<0>, dim3(schur_grid), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, BS->d_parts, (const int*)nullptr);
+                    hipLaunchKernelGGL(k_ba_schur<0>, dim3(schur_grid), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, BS->d_parts, (const int*)nullptr, (const int*)nullptr);
                     hipLaunchKernelGGL(k_ba_fold_parts, dim3(std::min(256, (int)((sz_sr + 255) / 256))), dim3(256), 0, st, D, BS->d_parts, schur_grid);
-                } else hipLaunchKernelGGL(k_ba_schur<2>, dim3(std::min(n_chunks, 1024)), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, (double*)nullptr, (const int*)d_chunk_cmin);
+                } else hipLaunchKernelGGL(k_ba_schur<2>, dim3(std::min(n_chunks, 1024)), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, (double*)nullptr, (const int*)d_chunk_cmin, (const int*)d_lorder);
             }
             if (nd) {
                 hipLaunchKernelGGL(k_badyn_factor, dim3((n_chain + 63) / 64), dim3(64), 0, st, D, lambda);
