@@ -2,8 +2,9 @@
 """bench.py — driver contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.
 
 Workload (BASELINE.json configs[1]): "ORB pyramid + flow-guided tracking only, synthetic 640x480 stream,
-1 MI355X".  A step = one pass of the per-frame hot path over one batch of `--batch` synthetic frames whose
-gray/depth/flow/mask maps are already resident in HBM when the timed region starts:
+1 MI355X".  A step = one pass of the per-frame hot path (one call of the fused C-ABI entry vido_frontend_batch) over one
+batch of `--batch` synthetic frames whose gray/depth/flow/mask maps are already resident in HBM when the timed region
+starts; results (keypoints, descriptors, lists) are on the host, in pinned memory, when the step returns:
     ORB extraction (pyramid, per-cell FAST, quadtree, IC angle, 7x7 blur, rBRIEF)      A2-A8
     depth pre-scale, static-candidate filter + depth gather, dense object sampling    A1, A9, A10
 The per-frame path does not shard (frame k depends on frame k-1): with --gpus N every rank runs an
