@@ -247,6 +247,10 @@ int vido_roi_align(vido_ctx* ctx, const float* feat, int B, int C, int H, int W,
  * sorted by descending score, keep_out/n_keep are device pointers receiving kept positions (ascending). */
 int vido_nms(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, int n, float thresh, int32_t* keep_out,
              int32_t* n_keep, int on_device);
+/* The per-class NMS loop of the box head (modeling/roi_heads/box_head/inference.py:96-118: layers.nms once per class) in one
+ * pass: boxes with different `groups` never suppress each other.  Conventions as vido_nms. */
+int vido_nms_grouped(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, const int32_t* groups, int n, float thresh,
+                     int32_t* keep_out, int32_t* n_keep, int on_device);
 /* BoxCoder(weights).decode(deltas [n,4k], boxes [n,4]) — modeling/box_coder.py:52-95. */
 int vido_box_decode(vido_ctx* ctx, const float* deltas, const float* boxes, int n, int k, const float weights[4],
                     float* out, int on_device);

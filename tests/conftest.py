@@ -46,6 +46,15 @@ class OracleNetOps:
             return torch.zeros((0,), dtype=torch.int64)
         return torch.from_numpy(self.o.nms(boxes.numpy(), scores.numpy(), float(thresh)).astype(np.int64))
 
+    def nms_grouped(self, boxes, scores, groups, thresh):
+        import numpy as np, torch
+        keep = []
+        g = groups.numpy()
+        for c in np.unique(g):
+            idx = np.nonzero(g == c)[0]
+            keep.append(idx[self.o.nms(boxes.numpy()[idx], scores.numpy()[idx], float(thresh))])
+        return torch.from_numpy(np.sort(np.concatenate(keep)).astype(np.int64)) if keep else torch.zeros((0,), dtype=torch.int64)
+
     def roi_align(self, feat, rois, output_size, spatial_scale, sampling_ratio):
         import torch
         return torch.from_numpy(self.o.roi_align(feat.numpy(), rois.numpy(), float(spatial_scale), output_size[0], output_size[1], sampling_ratio))

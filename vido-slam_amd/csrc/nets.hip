@@ -105,19 +105,22 @@ __device__ __forceinline__ float dev_iou(const float* a, const float* b)
     return inter / (Sa + Sb - inter);
 }
 // mask[i][cb] bit j: box (cb*64+j) overlaps box i by more than thresh (only j > i inside the diagonal tile)
-__global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, int n, float thresh, unsigned long long* __restrict__ mask, int col_blocks)
+__global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ group /* may be null */, int n, float thresh,
+                                                unsigned long long* __restrict__ mask, int col_blocks)
 {
     const int row_start = blockIdx.y, col_start = blockIdx.x;
     const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
-    __shared__ float bb[64 * 4];
-    if ((int)threadIdx.x < col_size) { for (int k = 0; k < 4; k++) bb[threadIdx.x * 4 + k] = boxes[(size_t)(col_start * 64 + threadIdx.x) * 4 + k]; }
+    __shared__ float bb[64 * 4]; __shared__ int gg[64];
+    if ((int)threadIdx.x < col_size) { for (int k = 0; k < 4; k++) bb[threadIdx.x * 4 + k] = boxes[(size_t)(col_start * 64 + threadIdx.x) * 4 + k];
+                                        gg[threadIdx.x] = group ? group[col_start * 64 + threadIdx.x] : 0; }
     __syncthreads();
     if ((int)threadIdx.x < row_size) {
         const int cur = row_start * 64 + threadIdx.x;
         const float* cb = boxes + (size_t)cur * 4;
         unsigned long long t = 0;
         const int start = row_start == col_start ? threadIdx.x + 1 : 0;
-        for (int i = start; i < col_size; i++) if (dev_iou(cb, bb + i * 4) > thresh) t |= 1ULL << i;
+        const int g = group ? group[cur] : 0;                      // boxes of different groups (classes) never suppress each other
+        for (int i = start; i < col_size; i++) if (gg[i] == g && dev_iou(cb, bb + i * 4) > thresh) t |= 1ULL << i;
         mask[(size_t)cur * col_blocks + col_start] = t;
     }
 }
@@ -245,7 +248,7 @@ int vido_roi_align(vido_ctx* ctx, const float* feat, int B, int C, int H, int W,
 /* maskrcnn_benchmark.layers.nms(boxes, scores, thresh): kept ORIGINAL indices, ascending.
  * on_device: boxes_xyxy must already be sorted by descending score (scores ignored), keep_out/n_keep are device
  * pointers receiving the kept POSITIONS in that order (ascending); only enqueues on the ctx stream. */
-int vido_nms(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, int n, float thresh, int32_t* keep_out, int32_t* n_keep, int on_device)
+static int nms_impl(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, const int32_t* groups, int n, float thresh, int32_t* keep_out, int32_t* n_keep, int on_device)
 {
     if (!ctx) return VIDO_E_INVALID;
     if (n < 0 || !n_keep || (n && (!boxes_xyxy || !keep_out)) || (!on_device && n && !scores)) return vido_set_error(ctx, VIDO_E_INVALID, "nms: bad arguments");
@@ -254,9 +257,10 @@ int vido_nms(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, int n,
     hipStream_t st = (on_device && ctx->has_ext_stream) ? ctx->ext_stream : ctx->stream;
     if (n == 0) { if (on_device) HIP_TRY(ctx, hipMemsetAsync(n_keep, 0, 4, st)); else *n_keep = 0; return VIDO_OK; }
     const int cb = (n + 63) / 64;
-    const size_t nb = (size_t)n * 16, nm = (size_t)n * cb * 8, nk = (size_t)n * 4 + 256;
+    const size_t nb = (size_t)n * 16, nm = (size_t)n * cb * 8, nk = (size_t)n * 4 + 256, ng = (size_t)n * 4;
     NetState* S = nullptr;
-    int rc = net_scratch(ctx, al256(nb) + al256(nm) + al256(nk), &S); if (rc) return rc;
+    int rc = net_scratch(ctx, al256(nb) + al256(nm) + al256(nk) + al256(ng), &S); if (rc) return rc;
+    const int* dgroups = groups;
     const float* dboxes = boxes_xyxy; unsigned long long* dmask = (unsigned long long*)(S->d + al256(nb));
     int* dkeep = keep_out; int* dn = n_keep;
     std::vector<int> order;
@@ -267,8 +271,13 @@ int vido_nms(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, int n,
         for (int i = 0; i < n; i++) memcpy(hb + 4 * (size_t)i, boxes_xyxy + 4 * (size_t)order[i], 16);
         HIP_TRY(ctx, hipMemcpyAsync(S->d, S->h, nb, hipMemcpyHostToDevice, st));
         dboxes = (float*)S->d; dkeep = (int*)(S->d + al256(nb) + al256(nm)); dn = dkeep + n;
+        if (groups) {
+            int* hg = (int*)(S->h + al256(nb)); for (int i = 0; i < n; i++) hg[i] = groups[order[i]];
+            int* dg = (int*)(S->d + al256(nb) + al256(nm) + al256(nk));
+            HIP_TRY(ctx, hipMemcpyAsync(dg, hg, ng, hipMemcpyHostToDevice, st)); dgroups = dg;
+        }
     }
-    hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb), dim3(64), 0, st, dboxes, n, thresh, dmask, cb);
+    hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb), dim3(64), 0, st, dboxes, dgroups, n, thresh, dmask, cb);
     hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, st, dmask, n, cb, dkeep, dn);
     HIP_TRY(ctx, hipGetLastError());
     if (!on_device) {
@@ -280,6 +289,19 @@ int vido_nms(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, int n,
         *n_keep = m;
     }
     return VIDO_OK;
+}
+
+int vido_nms(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, int n, float thresh, int32_t* keep_out, int32_t* n_keep, int on_device)
+{
+    return nms_impl(ctx, boxes_xyxy, scores, nullptr, n, thresh, keep_out, n_keep, on_device);
+}
+/* Per-class NMS in one pass (box_head/inference.py:96-118 runs layers.nms once per class): boxes of different `groups` never
+ * suppress each other.  Same conventions as vido_nms; on_device: boxes AND groups sorted by descending score. */
+int vido_nms_grouped(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, const int32_t* groups, int n, float thresh,
+                     int32_t* keep_out, int32_t* n_keep, int on_device)
+{
+    if (n > 0 && !groups) return ctx ? vido_set_error(ctx, VIDO_E_INVALID, "nms_grouped: null groups") : VIDO_E_INVALID;
+    return nms_impl(ctx, boxes_xyxy, scores, groups, n, thresh, keep_out, n_keep, on_device);
 }
 
 int vido_box_decode(vido_ctx* ctx, const float* deltas, const float* boxes, int n, int k, const float weights[4], float* out, int on_device)

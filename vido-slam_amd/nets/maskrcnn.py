@@ -269,17 +269,16 @@ class _BoxHead(nn.Module):
         c = self.c; W, H = image_wh; nc = logits.shape[1]
         prob = F.softmax(logits, -1)
         boxes = clip_boxes(self.ops.box_decode(deltas, proposals, c.bbox_reg_weights).reshape(-1, 4), W, H).reshape(-1, nc * 4)
-        rb, rs, rl = [], [], []
-        for j in range(1, nc):
-            idx = (prob[:, j] > c.score_thresh).nonzero().squeeze(1)
-            if not idx.numel():
-                continue
-            bj, sj = boxes[idx, 4 * j:4 * j + 4], prob[idx, j]
-            keep = self.ops.nms(bj, sj, c.nms)
-            rb.append(bj[keep]); rs.append(sj[keep]); rl.append(torch.full((len(keep),), j, dtype=torch.int64, device=logits.device))
-        if not rb:
+        # the reference loops over the classes (one nonzero + one NMS each); here: one nonzero over (proposal, class), one grouped NMS, and the
+        # result put back into the reference's order (class ascending, then proposal index)
+        ij = (prob[:, 1:] > c.score_thresh).nonzero()
+        if not ij.shape[0]:
             return proposals.new_zeros((0, 4)), proposals.new_zeros((0,)), torch.zeros((0,), dtype=torch.int64, device=logits.device)
-        rb, rs, rl = torch.cat(rb), torch.cat(rs), torch.cat(rl)
+        i, j = ij[:, 0], ij[:, 1] + 1
+        sc = prob[i, j]; bx = boxes.view(-1, nc, 4)[i, j]
+        keep = self.ops.nms_grouped(bx, sc, j, c.nms)
+        keep = keep[torch.sort(j[keep] * prob.shape[0] + i[keep], stable=True)[1]]
+        rb, rs, rl = bx[keep], sc[keep], j[keep]
         if len(rs) > c.detections_per_img > 0:
             thresh, _ = torch.kthvalue(rs.cpu(), len(rs) - c.detections_per_img + 1)
             keep = torch.nonzero(rs >= thresh.item()).squeeze(1)

@@ -57,6 +57,22 @@ class HipOps:
                                                          C.c_void_p(out.data_ptr()), 1))
         return out
 
+    def nms_grouped(self, boxes, scores, groups, thresh):
+        """layers.nms applied independently per group (the box head's per-class loop in one launch pair): kept original
+        indices, ascending."""
+        if not boxes.is_cuda:
+            raise RuntimeError("HipOps.nms_grouped needs CUDA(HIP) tensors; there is no CPU fallback")
+        if boxes.shape[0] == 0:
+            return torch.zeros((0,), dtype=torch.int64, device=boxes.device)
+        order = torch.sort(scores, descending=True, stable=True)[1]
+        sb = boxes[order].contiguous().float(); sg = groups[order].to(torch.int32).contiguous(); n = sb.shape[0]
+        keep = torch.empty(n, device=boxes.device, dtype=torch.int32); cnt = torch.zeros(1, device=boxes.device, dtype=torch.int32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_nms_grouped(self.ctx.h, C.c_void_p(sb.data_ptr()), None, C.c_void_p(sg.data_ptr()), n, C.c_float(thresh),
+                                                      C.c_void_p(keep.data_ptr()), C.c_void_p(cnt.data_ptr()), 1))
+        m = int(cnt.item())
+        return torch.sort(order[keep[:m].long()])[0]
+
     def nms(self, boxes, scores, thresh):
         """maskrcnn_benchmark.layers.nms: kept original indices, ascending (sort on the device with torch, sweep in HIP)."""
         if not boxes.is_cuda:
