@@ -675,7 +675,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)      // cv::fa
 
 __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t slab, PyrDev P,
                                                       const uint2* __restrict__ kps, const int* __restrict__ frame_beg, int nf, int with_desc,
-                                                      vido_keypoint* __restrict__ kpf, uint8_t* __restrict__ descf, int row_cap)
+                                                      vido_keypoint* __restrict__ kpf, uint8_t* __restrict__ descf, int row_cap, unsigned long long umax_packed)
 {
     // XCD-aware: each of the 8 XCDs (block b -> XCD b % 8) walks one contiguous eighth of the keypoint list, i.e.
     // whole frames, so the patch / pattern gathers of a frame stay in one private L2
@@ -690,10 +690,25 @@ __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict_
     const int x = kp.x & 0xfff, y = (kp.x >> 12) & 0xfff, level = kp.x >> 24, f = kp.y;
     const int pitch = P.pitch[level];
     const uint8_t* c = pyr + (size_t)f * slab + P.off[level] + (size_t)y * pitch + x;
+    // IC moments over the radius-15 disc: 31 rows x 9 aligned dwords (the 31-byte row span + alignment slack) = 279 dword loads spread
+    // over the lanes; the disc half-widths umax[|v|] travel as 16 nibbles in a kernel argument (no table fetch)
     int m10 = 0, m01 = 0;
-    for (int q = lane; q < 31 * 31; q += 64) {
-        const int vy = q / 31, v = vy - 15, u = q - vy * 31 - 15;
-        if (abs(u) <= c_umax[abs(v)]) { const int val = c[v * pitch + u]; m10 += u * val; m01 += v * val; }
+    const unsigned x_al = (unsigned)(x - 15) & ~3u;                        // rows are 64-byte aligned, so aligning x aligns the address
+    const uint8_t* rows = pyr + (size_t)f * slab + P.off[level] + (size_t)y * pitch + x_al;
+    const int u0 = (int)x_al - x;                                         // u of byte 0 of dword 0
+#pragma unroll
+    for (int it = 0; it < 5; it++) {
+        const int q = lane + 64 * it;
+        if (q < 31 * 9) {
+            const int vy = q / 9, d = q - vy * 9, v = vy - 15;
+            const int um = (int)((umax_packed >> (4 * abs(v))) & 15ull);
+            const uint32_t w = *(const uint32_t*)(rows + v * pitch + 4 * d);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int u = u0 + 4 * d + k;
+                if (abs(u) <= um) { const int val = (int)((w >> (8 * k)) & 255u); m10 += u * val; m01 += v * val; }
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
@@ -731,7 +746,7 @@ struct OrbState {
     PyrDev P{};
     size_t slab = 0;
     int n_cells = 0, n_blur_tiles = 0;
-    int umax[HALF_PATCH + 1];
+    int umax[HALF_PATCH + 1]; unsigned long long umax_packed = 0;
     std::vector<int> first_cell;
     // device
     uint8_t *d_pyr = nullptr, *d_blur = nullptr;
@@ -879,6 +894,7 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
     HIP_TRY(ctx, hipMalloc(&S->d_first_cell, L * sizeof(int)));
     HIP_TRY(ctx, hipMemcpy(S->d_first_cell, S->first_cell.data(), L * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_umax), S->umax, sizeof S->umax));
+    S->umax_packed = 0; for (int v = 0; v <= HALF_PATCH; v++) S->umax_packed |= (unsigned long long)(S->umax[v] & 15) << (4 * v);
     HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), VIDO_ORB_PATTERN, 1024));
     return VIDO_OK;
 }
@@ -1008,7 +1024,7 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     {   // launch bound: every (frame, level) list holds at most budget + 3 nodes; the kernel reads the real count from d_frame_beg[nf]
         const size_t bound = std::min((size_t)S->row_cap * nf, S->kp_cap);
         hipLaunchKernelGGL(k_orient_brief, dim3((unsigned)((((bound + 3) / 4) + 7) & ~(size_t)7)), dim3(256), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_kp,
-                           (const int*)S->d_frame_beg, nf, with_desc, S->d_kpf, S->d_descf, S->row_cap);
+                           (const int*)S->d_frame_beg, nf, with_desc, S->d_kpf, S->d_descf, S->row_cap, S->umax_packed);
     }
     DBG_SYNC("k_orient_brief");
     HIP_TRY(ctx, hipEventRecord(S->ev[6], st));
