@@ -185,7 +185,7 @@ __device__ __forceinline__ int fast_score(const uint8_t* t, int th)
     return best - 1;
 }
 
-// dynamic LDS layout (bytes): [16 pad][tile rows*FT_PITCH][score (rows-4)*FS_PITCH][cand u16 x ncand][corner u16 x ncand][listA][listB]
+// dynamic LDS layout (bytes): [16 pad][tile rows*FT_PITCH][score (rows-4)*FS_PITCH][cand/corner u16 x ncand][list u32 x CELL_CAP]  (~10 KB -> 16 cells per CU)
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t slab, PyrDev P,
                                                    const CellDesc* __restrict__ cells, int n_cells,
                                                    int ini_th, int min_th, int lds_rows, int lds_ncand,
@@ -195,9 +195,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
     uint8_t* tile = lds_raw + 16;                                    // quads at column 0 peek one dword to the left
     uint8_t* sc = tile + lds_rows * FT_PITCH;
     uint16_t* cand = (uint16_t*)(sc + (lds_rows - 4) * FS_PITCH);
-    uint16_t* corners = cand + lds_ncand;
-    uint32_t* listA = (uint32_t*)(corners + lds_ncand);
-    uint32_t* listB = listA + VIDO_CELL_CAP;
+    uint16_t* corners = cand;                                        // in-place ordered compaction: a corner is written at or before the slot it was read from
+    uint32_t* listA = (uint32_t*)(cand + lds_ncand);
     int cell, f; xcd_tile_frame(cell, f);
     const int lane = threadIdx.x;
     const CellDesc c = cells[cell];
@@ -879,7 +878,7 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
         int max_sh = 8, max_px = 64;
         for (const CellDesc& cd : cells) { max_sh = std::max(max_sh, cd.sh); max_px = std::max(max_px, (cd.sw - 6) * (cd.sh - 6)); }
         S->fast_rows = max_sh; S->fast_ncand = (max_px + 63) & ~63;
-        S->fast_lds = 16 + (size_t)max_sh * FT_PITCH + (size_t)(max_sh - 4) * FS_PITCH + 2 * sizeof(uint16_t) * S->fast_ncand + 2 * sizeof(uint32_t) * VIDO_CELL_CAP + 16;
+        S->fast_lds = 16 + (size_t)max_sh * FT_PITCH + (size_t)(max_sh - 4) * FS_PITCH + sizeof(uint16_t) * S->fast_ncand + sizeof(uint32_t) * VIDO_CELL_CAP + 16;
     }
     HIP_TRY(ctx, hipMalloc(&S->d_cells, cells.size() * sizeof(CellDesc)));
     HIP_TRY(ctx, hipMemcpy(S->d_cells, cells.data(), cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
