@@ -183,11 +183,13 @@ __device__ bool ldlt6(const double* A, const double* b, double* x)
 
 #define NRED 29      // 21 H + 6 b + chi + maxdiag
 
-__global__ __launch_bounds__(256) void k_pose_opt(const PoseProbDev* __restrict__ probs)
+__global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict__ probs)
 {
     __shared__ double lds[17 * NRED];
     const PoseProbDev p = probs[blockIdx.x];
-    const int n = p.n, tid = threadIdx.x, nt = blockDim.x;
+    // the edge->thread mapping depends on the problem alone (not on the batch it is launched with), so results are bit-identical
+    // however problems are grouped: nt = ~4 edges per thread, threads beyond it only take part in the reductions
+    const int n = p.n, nt = min((int)blockDim.x, max(64, (((n + 3) >> 2) + 63) & ~63)), tid = (int)threadIdx.x < nt ? (int)threadIdx.x : n;
     const bool flowm = p.mode == 1;
     Se3 T, Tinit;
 #pragma unroll
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(const PoseProbDev* __restrict_
             n_inl = n - (int)nb[0];
         }
     }
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         vido_pose_result* r = p.res;
         for (int rr = 0; rr < 3; rr++) { for (int c = 0; c < 3; c++) r->T[rr * 4 + c] = T.R[rr * 3 + c]; r->T[rr * 4 + 3] = T.t[rr]; }
         r->T[12] = r->T[13] = r->T[14] = 0; r->T[15] = 1;
@@ -478,7 +480,7 @@ extern "C" int vido_pose_optimize_batch(vido_ctx* ctx, const vido_pose_problem* 
     }
     if (so) HIP_TRY(ctx, hipMemcpyAsync(S->d_arena, S->h_stage, so * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(S->d_probs, S->h_probs, n_prob * sizeof(PoseProbDev), hipMemcpyHostToDevice, st));
-    const int threads = std::min(256, std::max(64, (nmax + 63) & ~63));
+    const int threads = std::min(512, std::max(64, ((nmax + 3) / 4 + 63) & ~63));      // ~4 edges per thread, up to 8 waves (2 per SIMD keeps the 256-VGPR budget)
     hipLaunchKernelGGL(k_pose_opt, dim3(n_prob), dim3(threads), 0, st, S->d_probs);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(S->h_res, S->d_res, n_prob * sizeof(vido_pose_result), hipMemcpyDeviceToHost, st));
