@@ -1539,10 +1539,14 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
                            hipLaunchKernelGGL(k_ba_maxdiag, dim3(64), dim3(256), 0, st, D, 0); if ((rc = AR(D.scal + 1, 1, 1))) return rc; }
             else if ((rc = AR(red, (size_t)n_pose * 36 + n6 + 1, 0))) return rc;
         }
-        if ((rc = read_scal())) return rc;
-        { float ms = 0; if (hipEventElapsedTime(&ms, BS->ev0, BS->ev1) == hipSuccess) ms_lin += ms; }
-        double currentChi = BS->h_scal[0]; const double iniChi = currentChi;
-        if (it == 0) { lambda = 1e-5 * BS->h_scal[1]; ni = 2; nBad = 0; }
+        // chi2 at the linearisation point (scal[0]) is only needed once the first trial of this iteration has been evaluated, so after the
+        // first iteration (whose lambda needs the max diagonal) it is read together with the trial's scalars: one host sync per trial
+        bool have_chi = false; double currentChi = 0, iniChi = 0;
+        if (it == 0 || allreduce) {
+            if ((rc = read_scal())) return rc;
+            currentChi = iniChi = BS->h_scal[0]; have_chi = true;
+            if (it == 0) { lambda = 1e-5 * BS->h_scal[1]; ni = 2; nBad = 0; }
+        }
         double rho = 0; int qmax = 0;
         do {
             // ---- reduced system of this shard.  With an all-reduce every rank contributes Hcd/bc ALREADY summed,
@@ -1581,6 +1585,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             HIP_TRY(ctx, hipGetLastError());
             if ((rc = AR(D.scal + 2, 2, 0))) return rc;
             if ((rc = read_scal())) return rc;
+            if (!have_chi) { currentChi = iniChi = BS->h_scal[0]; have_chi = true; }
+            if (qmax == 0) { float ms = 0; if (hipEventElapsedTime(&ms, BS->ev0, BS->ev1) == hipSuccess) ms_lin += ms; }
             const bool ok2 = BS->h_scal[4] > 0.5;
             const double tempChi = ok2 ? BS->h_scal[2] : DBL_MAX, scale = ok2 ? BS->h_scal[3] : 0.0;
             rho = (currentChi - tempChi) / (scale + 1e-3);
