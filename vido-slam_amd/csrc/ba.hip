@@ -700,20 +700,21 @@ __global__ __launch_bounds__(1024) void k_chol_band6(BaDev P, int bwc /* block h
     for (int kb = 0; kb < nblk; kb++, boff = (boff + 1 >= Wb ? 0 : boff + 1)) {
         const int pk = 6 * boff;                             // physical row/col of block kb
         const int nbelow = min(bwc, nblk - 1 - kb);           // panel block rows
-        // ---- A: 6x6 pivot block, every thread redundantly
+        // ---- A: 6x6 pivot block, redundantly on the three waves that use it (panel rows tid < 126, writers tid 128..165)
         double Akk[21], Lk[21], inv[6], zk[6];
+        if (tid < 192) {
 #pragma unroll
-        for (int a = 0; a < 6; a++)
+            for (int a = 0; a < 6; a++)
 #pragma unroll
-            for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = W[(pk + a) * ldw + pk + b];
-        const bool good = chol6(Akk, Lk, inv);
-        if (!good) { if (tid == 0) ok = 0; }
+                for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = W[(pk + a) * ldw + pk + b];
+            const bool good = chol6(Akk, Lk, inv);
+            if (!good && tid == 0) ok = 0;
 #pragma unroll
-        for (int c = 0; c < 6; c++) { double v = rW[pk + c]; 
+            for (int c = 0; c < 6; c++) { double v = rW[pk + c];
 #pragma unroll
-            for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
-        if (!good) break;                                    // uniform: every thread factored the same block
-        // ---- B1: panel rows, final factor + z of block kb out to HBM
+                for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
+        }
+        // ---- B1: panel rows, final factor + z of block kb out to HBM (no barrier needed: B1 touches neither the pivot block nor its rhs in LDS)
         if (tid < 6 * nbelow) {
             const int ibr = tid / 6 + 1, a = tid - (ibr - 1) * 6, ib = kb + ibr, prow = 6 * PB(ib) + a, i = 6 * ib + a;
             double l[6], rr = 0;
@@ -726,16 +727,17 @@ __global__ __launch_bounds__(1024) void k_chol_band6(BaDev P, int bwc /* block h
                 Pn[tid * 7 + c] = v; AB(i, 6 * kb + c) = v;
             }
             rW[prow] -= rr;
-        } else if (tid >= 512 && tid < 512 + 21) {           // compile-time register indices only: a dynamic Lk[t] would push the arrays to scratch
+        } else if (tid >= 128 && tid < 128 + 21) {           // compile-time register indices only: a dynamic Lk[t] would push the arrays to scratch
 #pragma unroll
             for (int a = 0; a < 6; a++)
 #pragma unroll
-                for (int b = 0; b <= a; b++) if (tid - 512 == a * (a + 1) / 2 + b) AB(6 * kb + a, 6 * kb + b) = Lk[a * (a + 1) / 2 + b];
-        } else if (tid >= 576 && tid < 582) {
+                for (int b = 0; b <= a; b++) if (tid - 128 == a * (a + 1) / 2 + b) AB(6 * kb + a, 6 * kb + b) = Lk[a * (a + 1) / 2 + b];
+        } else if (tid >= 160 && tid < 166) {
 #pragma unroll
-            for (int c = 0; c < 6; c++) if (tid - 576 == c) r[6 * kb + c] = zk[c];
+            for (int c = 0; c < 6; c++) if (tid - 160 == c) r[6 * kb + c] = zk[c];
         }
         lds_barrier();
+        if (!ok) break;
         // ---- B2: trailing window (LDS only) — item = (panel row ri, column block jc <= block of ri): 6 entries
         for (int it = tid; it < n_items; it += 1024) {
             const int ri = it / bwc, jc = it - ri * bwc, ibr = ri / 6;
@@ -823,18 +825,24 @@ __global__ __launch_bounds__(1024) void k_ba_chol_small6(BaDev P)
     __syncthreads();
     for (int kb = 0; kb < nblk; kb++) {
         const int pk = 6 * kb, nbelow = nblk - 1 - kb;
+        // only the three waves that use the factor compute it (panel rows: tid < 114, writers: tid 128..165); sixteen redundant copies
+        // would queue four deep on every SIMD
         double Akk[21], Lk[21], inv[6], zk[6];
+        bool good = true;
+        if (tid < 192) {
 #pragma unroll
-        for (int a = 0; a < 6; a++)
+            for (int a = 0; a < 6; a++)
 #pragma unroll
-            for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = W[(pk + a) * ldw + pk + b];
-        const bool good = chol6(Akk, Lk, inv);
+                for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = W[(pk + a) * ldw + pk + b];
+            good = chol6(Akk, Lk, inv);
 #pragma unroll
-        for (int c = 0; c < 6; c++) { double v = rW[pk + c];
+            for (int c = 0; c < 6; c++) { double v = rW[pk + c];
 #pragma unroll
-            for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
-        if (!good) { if (tid == 0) ok = 0; break; }
-        lds_barrier();                                       // everybody has read block kb and its rhs
+                for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
+            if (!good && tid == 0) ok = 0;
+        }
+        lds_barrier();                                       // the factoring waves have read block kb and its rhs
+        if (!ok) break;
         if (tid < 6 * nbelow) {
             const int prow = pk + 6 + tid;
             double l[6], rr = 0;
@@ -847,14 +855,14 @@ __global__ __launch_bounds__(1024) void k_ba_chol_small6(BaDev P)
                 Pn[tid * 7 + c] = v; W[prow * ldw + pk + c] = v;
             }
             rW[prow] -= rr;
-        } else if (tid >= 512 && tid < 512 + 21) {
+        } else if (tid >= 128 && tid < 128 + 21) {
 #pragma unroll
             for (int a = 0; a < 6; a++)
 #pragma unroll
-                for (int b = 0; b <= a; b++) if (tid - 512 == a * (a + 1) / 2 + b) W[(pk + a) * ldw + pk + b] = Lk[a * (a + 1) / 2 + b];
-        } else if (tid >= 576 && tid < 582) {
+                for (int b = 0; b <= a; b++) if (tid - 128 == a * (a + 1) / 2 + b) W[(pk + a) * ldw + pk + b] = Lk[a * (a + 1) / 2 + b];
+        } else if (tid >= 160 && tid < 166) {
 #pragma unroll
-            for (int c = 0; c < 6; c++) if (tid - 576 == c) rW[pk + c] = zk[c];
+            for (int c = 0; c < 6; c++) if (tid - 160 == c) rW[pk + c] = zk[c];
         }
         lds_barrier();
         const int n_items = 6 * nbelow * nbelow;             // (panel row ri, column block jc <= block of ri)
