@@ -384,11 +384,14 @@ def analyse_image(net, bgr, feed=(1088, 800), confidence=0.8):
     out = net(F.interpolate(t, size=feed, mode="area"))
     rw, rh = float(W) / feed[1], float(H) / feed[0]
     boxes = out["boxes"] * out["boxes"].new_tensor([rw, rh, rw, rh]) if rw != rh else out["boxes"] * rw
-    pasted = paste_masks(out["masks"], boxes, H, W)
     keep = torch.nonzero(out["scores"] > confidence).squeeze(1)
     keep = keep[out["scores"][keep].sort(0, descending=True)[1]]
     labels = out["labels"][keep]
-    img = torch.zeros((H, W), dtype=torch.uint8, device=dev)
-    for m, l in zip(pasted[keep], labels):
-        img += m.to(torch.uint8) * int(l)                            # u8 accumulation (wraps on overlap, like the reference)
+    pasted_kept = paste_masks(out["masks"][keep], boxes[keep], H, W)      # the reference pastes every detection and then selects; only the selected ones reach the output
+    # label image = sum over detections of mask * class index, accumulated in u8 (wraps on overlap, like the reference's numpy loop);
+    # one reduction on the device instead of a host-synchronising loop over the detections
+    if len(keep):
+        img = (pasted_kept.to(torch.int32) * labels.view(-1, 1, 1).to(torch.int32)).sum(0).remainder(256).to(torch.uint8)
+    else:
+        img = torch.zeros((H, W), dtype=torch.uint8, device=dev)
     return img, labels
