@@ -15,19 +15,22 @@
 // 16x16 output tile per workgroup; per channel chunk the (16+6)^2 neighbourhood of f2 is staged in LDS and every
 // thread keeps its 49 displacement sums in registers.
 #define CORR_CH 8
+// Small pyramid levels have only a handful of 16x16 tiles: the channel range is then split over `nsplit` workgroups per tile (grid.z =
+// batch x nsplit) that write unscaled partial sums, reduced in a fixed order by k_correlation_reduce (deterministic, no float atomics).
 __global__ __launch_bounds__(256) void k_correlation(const float* __restrict__ f1, const float* __restrict__ f2, int C, int H, int W, int s,
-                                                     int Ho, int Wo, float* __restrict__ out)
+                                                     int Ho, int Wo, float* __restrict__ out, int nsplit, int cper)
 {
     __shared__ float t2[CORR_CH][22][23];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, b = blockIdx.z;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, b = blockIdx.z / nsplit, split = blockIdx.z - b * nsplit;
+    const int c_lo = split * cper, c_hi = min(C, c_lo + cper);
     const int x = blockIdx.x * 16 + tx, y = blockIdx.y * 16 + ty;
     const bool valid = x < Wo && y < Ho;
     float acc[49];
 #pragma unroll
     for (int k = 0; k < 49; k++) acc[k] = 0.f;
     const size_t plane = (size_t)H * W;
-    for (int c0 = 0; c0 < C; c0 += CORR_CH) {
-        const int nc = min(CORR_CH, C - c0);
+    for (int c0 = c_lo; c0 < c_hi; c0 += CORR_CH) {
+        const int nc = min(CORR_CH, c_hi - c0);
         for (int i = threadIdx.x; i < nc * 22 * 22; i += 256) {
             const int cc = i / (22 * 22), r = (i / 22) % 22, q = i % 22;
             const int yy = (blockIdx.y * 16 + r - 3), xx = (blockIdx.x * 16 + q - 3);
@@ -51,9 +54,18 @@ __global__ __launch_bounds__(256) void k_correlation(const float* __restrict__ f
         __syncthreads();
     }
     if (valid) {
+        float* o = out + (size_t)split * (gridDim.z / nsplit) * 49 * Ho * Wo;      // partial plane of this split (nsplit == 1: the output itself)
 #pragma unroll
-        for (int k = 0; k < 49; k++) out[(((size_t)b * 49 + k) * Ho + y) * Wo + x] = acc[k] / (float)C;
+        for (int k = 0; k < 49; k++) o[(((size_t)b * 49 + k) * Ho + y) * Wo + x] = nsplit == 1 ? acc[k] / (float)C : acc[k];
     }
+}
+__global__ __launch_bounds__(256) void k_correlation_reduce(const float* __restrict__ part, int nsplit, size_t n, float inv_c_dummy, int C, float* __restrict__ out)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float sum = 0.f;
+    for (int k = 0; k < nsplit; k++) sum += part[(size_t)k * n + i];
+    out[i] = sum / (float)C;
 }
 
 // ---- ROI-Align ---------------------------------------------------------------------------------------------
@@ -200,14 +212,23 @@ int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
     const size_t nin = (size_t)B * C * H * W * 4, nout = (size_t)B * 49 * Ho * Wo * 4;
     const float *d1 = first, *d2 = second; float* dout = out;
+    const int tiles = ((Wo + 15) / 16) * ((Ho + 15) / 16) * B, nchunk = (C + CORR_CH - 1) / CORR_CH;
+    int nsplit = std::max(1, std::min(nchunk, 512 / std::max(tiles, 1)));
+    const int cper = ((nchunk + nsplit - 1) / nsplit) * CORR_CH; nsplit = (C + cper - 1) / cper;
+    const size_t nel = (size_t)B * 49 * Ho * Wo, io_bytes = on_device ? 0 : 2 * al256(nin) + al256(nout), pbytes = nsplit > 1 ? al256(nel * 4 * nsplit) : 0;
     NetState* S = nullptr;
+    if (io_bytes + pbytes) { int rc = net_scratch(ctx, io_bytes + pbytes, &S); if (rc) return rc; }
     if (!on_device) {
-        int rc = net_scratch(ctx, 2 * al256(nin) + al256(nout), &S); if (rc) return rc;
         memcpy(S->h, first, nin); memcpy(S->h + al256(nin), second, nin);
         HIP_TRY(ctx, hipMemcpyAsync(S->d, S->h, 2 * al256(nin), hipMemcpyHostToDevice, st));
         d1 = (float*)S->d; d2 = (float*)(S->d + al256(nin)); dout = (float*)(S->d + 2 * al256(nin));
     }
-    hipLaunchKernelGGL(k_correlation, dim3((Wo + 15) / 16, (Ho + 15) / 16, B), dim3(256), 0, st, d1, d2, C, H, W, stride, Ho, Wo, dout);
+    if (nsplit == 1) hipLaunchKernelGGL(k_correlation, dim3((Wo + 15) / 16, (Ho + 15) / 16, B), dim3(256), 0, st, d1, d2, C, H, W, stride, Ho, Wo, dout, 1, C);
+    else {
+        float* part = (float*)(S->d + io_bytes);
+        hipLaunchKernelGGL(k_correlation, dim3((Wo + 15) / 16, (Ho + 15) / 16, B * nsplit), dim3(256), 0, st, d1, d2, C, H, W, stride, Ho, Wo, part, nsplit, cper);
+        hipLaunchKernelGGL(k_correlation_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, (const float*)part, nsplit, nel, 0.f, C, dout);
+    }
     HIP_TRY(ctx, hipGetLastError());
     if (!on_device) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
