@@ -217,7 +217,8 @@ def main():
           # rows N1/N2: network nodes (fp32 like the reference, random-init weights), KITTI-sized frames, rank 0 only
           if rank == 0:
               from vido_slam_amd import nets
-              lfn = nets.fill_deterministic(nets.LiteFlowNet(nets.HipOps(ctx).correlation), 1).eval().cuda()
+              hops = nets.HipOps(ctx)
+              lfn = nets.fill_deterministic(nets.LiteFlowNet(hops.correlation, epilogue=hops.bias_act_), 1).eval().cuda()
               md = nets.fill_deterministic(nets.MonoDepth2(), 2).eval().cuda()
               rgb = (np.random.RandomState(0).rand(375, 1242, 3) * 255).astype(np.uint8)
               def timed(fn, reps=5):

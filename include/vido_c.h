@@ -238,6 +238,9 @@ int vido_ba_optimize_dynamic(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynam
  * out: [B, 49, ceil(H/stride), ceil(W/stride)]. */
 int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int B, int C, int H, int W, int stride,
                      float* out, int on_device);
+/* Conv epilogue on a DEVICE tensor x[N,C,H,W] (f32, contiguous), in place: x = leaky_relu(x + bias[c], slope) — the bias add and the
+ * LeakyReLU(0.1) that follow every convolution of flow_net/src/layers.py fused into one pass (slope = 1: plain bias add). */
+int vido_bias_act(vido_ctx* ctx, float* x, const float* bias, int N, int C, int H, int W, float slope);
 /* layers.ROIAlign forward — mask_rcnn/maskrcnn_benchmark/csrc/cuda/ROIAlign_cuda.cu:257-299.  rois [n,5] =
  * (batch index, x1, y1, x2, y2); out [n, C, pooled_h, pooled_w]. */
 int vido_roi_align(vido_ctx* ctx, const float* feat, int B, int C, int H, int W, const float* rois, int n_rois,

@@ -28,6 +28,9 @@ def test_liteflownet_hip_correlation_matches_reference(ctx):
     a = torch.from_numpy(G["lfn_first"].astype(np.float32) / 255.0)[None].cuda(); b = torch.from_numpy(G["lfn_second"].astype(np.float32) / 255.0)[None].cuda()
     flow = net(a, b).cpu().numpy()
     assert rel_err(flow, G["lfn_flow"]) < TOL
+    # fused conv epilogue (bias + LeakyReLU as one HIP pass) gives the same flow
+    net_f = nets.fill_deterministic(nets.LiteFlowNet(ops.correlation, epilogue=ops.bias_act_), int(G["lfn_seed"])).eval().cuda()
+    assert rel_err(net_f(a, b).cpu().numpy(), G["lfn_flow"]) < TOL
     # non-default torch stream: the library must enqueue on it (no sync between the torch convs and the HIP op)
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):

@@ -68,6 +68,24 @@ __global__ __launch_bounds__(256) void k_correlation_reduce(const float* __restr
     out[i] = sum / (float)C;
 }
 
+// ---- bias + LeakyReLU epilogue -------------------------------------------------------------------------------
+// y[n,c,:,:] = leaky(x[n,c,:,:] + bias[c]) in place: the convolution library runs without its bias so that bias add and activation are
+// one pass over the tensor instead of two extra kernels (float4 when the plane size allows it).
+__global__ __launch_bounds__(256) void k_bias_act(float* __restrict__ x, const float* __restrict__ bias, int C, size_t hw, size_t total, float slope)
+{
+    const size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4;
+    if (i >= total) return;
+    if ((hw & 3) == 0) {
+        const float b = bias[(i / hw) % C];
+        float4 v = *(float4*)(x + i);
+        v.x += b; v.y += b; v.z += b; v.w += b;
+        v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope; v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+        *(float4*)(x + i) = v;
+    } else {
+        for (size_t k = i; k < min(i + 4, total); k++) { float v = x[k] + bias[(k / hw) % C]; x[k] = v > 0.f ? v : v * slope; }
+    }
+}
+
 // ---- ROI-Align ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bilinear(const float* __restrict__ d, int h, int w, float y, float x)
 {
@@ -235,6 +253,19 @@ int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int
         HIP_TRY(ctx, hipMemcpyAsync(S->h, dout, nout, hipMemcpyDeviceToHost, st)); HIP_TRY(ctx, hipStreamSynchronize(st));
         memcpy(out, S->h, nout);
     }
+    return VIDO_OK;
+}
+
+/* In-place conv epilogue on a DEVICE tensor x[N,C,H,W] (f32, contiguous): x = leaky_relu(x + bias[c], slope); slope = 1 is a plain bias add. */
+int vido_bias_act(vido_ctx* ctx, float* x, const float* bias, int N, int C, int H, int W, float slope)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!x || !bias || N < 1 || C < 1 || H < 1 || W < 1) return vido_set_error(ctx, VIDO_E_INVALID, "bias_act: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    const size_t hw = (size_t)H * W, total = (size_t)N * C * hw;
+    hipLaunchKernelGGL(k_bias_act, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, st, x, bias, C, hw, total, slope);
+    HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }
 

@@ -13,15 +13,35 @@ MEAN_FIRST = (0.411618, 0.434631, 0.454253)
 MEAN_SECOND = (0.410782, 0.433645, 0.452793)
 
 
+class _Chain(nn.Sequential):
+    """nn.Sequential with the reference's index layout (conv, lrelu, conv, ...).  With `epilogue` set (HipOps.bias_act_, GPU only) every
+    Conv2d runs without its bias and the bias add + the following LeakyReLU become one in-place HIP pass."""
+    epilogue = None
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if self.epilogue is not None and isinstance(m, nn.Conv2d) and x.is_cuda and m.bias is not None:
+                x = F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
+                act = i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU)
+                x = self.epilogue(x.contiguous(), m.bias, LEAK if act else 1.0)
+                i += 2 if act else 1
+            else:
+                x = m(x); i += 1
+        return x
+
+
 def _chain(specs):
-    """specs: [(cin, cout, kernel, stride, act)] -> Sequential with the reference's index layout (conv, lrelu, conv, ...)."""
+    """specs: [(cin, cout, kernel, stride, act)] -> _Chain with the reference's index layout (conv, lrelu, conv, ...)."""
     mods = []
     for cin, cout, k, s, act in specs:
         pad = (k[0] // 2, k[1] // 2) if isinstance(k, tuple) else k // 2
         mods.append(nn.Conv2d(cin, cout, k, s, pad))
         if act:
             mods.append(nn.LeakyReLU(LEAK, inplace=False))
-    return nn.Sequential(*mods)
+    return _Chain(*mods)
 
 
 def _flow_head(cin, k):
@@ -114,12 +134,16 @@ class LiteFlowNet(nn.Module):
     """`correlation`: callable (first, second, stride) -> cost volume.  On the GPU pass HipOps(ctx).correlation (the HIP
     kernel); the CPU tests pass correlation_torch_reference."""
 
-    def __init__(self, correlation):
+    def __init__(self, correlation, epilogue=None):
         super().__init__()
         self.netFeatures = _Features()
         self.netMatching = nn.ModuleList([_Matching(l, correlation) for l in (2, 3, 4, 5, 6)])
         self.netSubpixel = nn.ModuleList([_Subpixel(l) for l in (2, 3, 4, 5, 6)])
         self.netRegularization = nn.ModuleList([_Regularization(l) for l in (2, 3, 4, 5, 6)])
+        if epilogue is not None:
+            for m in self.modules():
+                if isinstance(m, _Chain):
+                    m.epilogue = epilogue
 
     @torch.no_grad()
     def forward(self, first, second):

@@ -35,6 +35,14 @@ class HipOps:
                                                       C.c_void_p(out.data_ptr()), 1))
         return out
 
+    def bias_act_(self, x, bias, slope):
+        """in place: x = leaky_relu(x + bias[None, :, None, None], slope)"""
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
+        N, Cc, H, W = x.shape
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), N, Cc, H, W, C.c_float(slope)))
+        return x
+
     def roi_align(self, feat, rois, output_size, spatial_scale, sampling_ratio):
         if not feat.is_cuda:
             raise RuntimeError("HipOps.roi_align needs CUDA(HIP) tensors; there is no CPU fallback")
