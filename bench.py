@@ -183,6 +183,17 @@ def main():
               rs = opt.pose_optimize_batch(objs)
           d = (time.perf_counter() - t1) / 5
           extra["PoseOptimizationFlow2_5objects_x800"] = {"ms_per_frame": round(d * 1e3, 3), "lm_iterations": [r["lm_iterations"] for r in rs]}
+          # brute-force Hamming matcher (north_star), descriptors resident on the device: 2000 x 2000 and a 64-frame batch worth of queries
+          for na, nb in ((2000, 2000), (128000, 2000)):
+              da = torch.randint(0, 256, (na, 32), dtype=torch.uint8, device="cuda"); db = torch.randint(0, 256, (nb, 32), dtype=torch.uint8, device="cuda")
+              mi = torch.empty(na, dtype=torch.int32, device="cuda"); md = torch.empty(na, dtype=torch.int32, device="cuda")
+              torch.cuda.synchronize()
+              run = lambda: (ctx.hamming_match_device(da.data_ptr(), na, db.data_ptr(), nb, mi.data_ptr(), md.data_ptr()), ctx.synchronize())
+              run(); t1 = time.perf_counter(); reps = 10
+              for _ in range(reps):
+                  run()
+              d = (time.perf_counter() - t1) / reps
+              extra["hamming_%dx%d" % (na, nb)] = {"ms_per_call": round(d * 1e3, 4), "pairs_per_s": round(na * nb / d, 0), "descriptor_GB_per_s": round(32.0 * (na + nb) / d / 1e9, 2)}
           # configs[3] (static graph): 20 KF x 2k landmarks
           pr = P.synth_ba_problem(n_cam=20, n_pt=2000, kind="local", seed=7)
           V.ba_optimize(ctx, pr)
