@@ -225,6 +225,15 @@ def main():
                                 "ms_setup": round(r["ms_setup"], 2), "lm_iters_per_s": round(r["iterations"] / (r["ms_solve_loop"] * 1e-3), 2),
                                 "chi2": [round(r["chi2_initial"], 3), round(r["chi2_final"], 3)], "wall_ms": round(d * 1e3, 1),
                                 "collective": "RCCL all-reduce (sum) of S (6n x 6n f64) + r per LM trial" if world > 1 else "none"}
+          # configs[4]/[5] with the object factors (FullBatchOptimization, STATIC_ONLY = false): frame-interleaved pose order + band layout
+          if rank == 0:
+              dpr = P.synth_ba_problem(n_cam=200, n_pt=20000, kind="global", track_len=10, seed=13); dpr["max_iters"] = 5
+              ddy = P.synth_ba_dynamic(dpr, n_obj=3, pts_per_obj=300, seed=14, max_len=8)
+              t1 = time.perf_counter(); r = V.ba_optimize(ctx, dpr, dynamic=ddy); d = time.perf_counter() - t1
+              extra["global_ba_dynamic"] = {"n_cam": 200, "n_H": int(ddy["n_H"]), "n_landmarks": int(dpr["n_pt"]), "n_obs": int(len(dpr["obs_cam"])), "n_dyn_points": int(ddy["n_dyn"]),
+                                            "n_ternary": int(ddy["n_tern"]), "lm_iterations": r["iterations"], "ms_lm_loop": round(r["ms_solve_loop"], 2), "ms_setup": round(r["ms_setup"], 2),
+                                            "lm_iters_per_s": round(r["iterations"] / (r["ms_solve_loop"] * 1e-3), 2), "chi2": [round(r["chi2_initial"], 3), round(r["chi2_final"], 3)],
+                                            "wall_ms": round(d * 1e3, 1)}
           # rows N1/N2: network nodes (fp32 like the reference, random-init weights), KITTI-sized frames, rank 0 only
           if rank == 0:
               from vido_slam_amd import nets

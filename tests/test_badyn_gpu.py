@@ -34,6 +34,22 @@ def test_dynamic_ba_matches_oracle(vido, oracle, ctx, n_cam, n_pt, n_obj, ppo, s
         assert rel(got[key], ref[key]) < TOL, key
 
 
+@pytest.mark.parametrize("n_cam,max_len,seed", [(40, 5, 3), (48, 12, 6)])
+def test_dynamic_ba_band_layout_matches_oracle(vido, oracle, ctx, n_cam, max_len, seed):
+    """longer sequences with bounded tracklets: poses are interleaved by frame and the reduced system is banded (pose-block LDS-window
+    Cholesky for the short band, scalar banded Cholesky in HBM for the wide one); the oracle still solves the dense full system"""
+    P = vido.problems
+    base = P.synth_ba_problem(n_cam=n_cam, n_pt=60, kind="global", track_len=4, seed=seed)
+    dyn = P.synth_ba_dynamic(base, n_obj=2, pts_per_obj=5, seed=seed + 1, max_len=max_len)
+    base["max_iters"] = 6
+    ref = oracle.badyn_optimize(base, dyn)
+    got = vido.ba_optimize(ctx, base, dynamic=dyn)
+    assert (got["iterations"], got["lm_trials"]) == (ref["iterations"], ref["lm_trials"])
+    assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-6 * ref["chi2_final"]
+    for key in ("cam_T", "pt_xyz", "H_T", "dyn_xyz"):
+        assert rel(got[key], ref[key]) < TOL, key
+
+
 def test_dynamic_ba_first_step_exact(vido, oracle, ctx):
     """one LM iteration: identical step => the elimination scheme is the same linear solve as the dense oracle"""
     P = vido.problems

@@ -514,11 +514,12 @@ __global__ __launch_bounds__(64) void k_chol_back_diag(const double* __restrict_
 // diagonal block factored in LDS by one wave, panel rows solved one thread per row, trailing (bw x bw) window updated by
 // all 1024 threads, the right-hand side carried along (forward substitution for free), then the backward sweep.
 #define CB_NB 16
-#define CB_MAXROWS 256                     // panel rows of one step = bw <= 255
+#define CB_MAXROWS 960                     // panel rows of one step = bw; one thread per panel row on threads 64..1023
+#define CB_MAXBW 959
 __global__ __launch_bounds__(1024) void k_chol_band(BaDev P)
 {
     __shared__ double Ld[CB_NB + 1][CB_NB + 1];            // row CB_NB carries the right-hand side of the block (forward substitution for free)
-    __shared__ double Pn[CB_MAXROWS][CB_NB + 1];
+    extern __shared__ double Pn[];                         // [bw][CB_NB + 1] panel rows (dynamic: up to 130 KB)
     __shared__ double zk[CB_NB];
     __shared__ int ok;
     const int n = P.n6, bw = P.bw, ldb = P.ldb, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -576,36 +577,23 @@ __global__ __launch_bounds__(1024) void k_chol_band(BaDev P)
                     v[c] = a; rr += a * Ld[CB_NB][c];
                     if (pi - (k0 + c) <= bw) AB(pi, k0 + c) = a;
                 }
-                Pn[tid - 64][c] = c < nb ? v[c] : 0.0;
+                Pn[(tid - 64) * (CB_NB + 1) + c] = c < nb ? v[c] : 0.0;
             }
             r[pi] = rpi - rr;
         }
         __syncthreads();
         // trailing window: A(i, j) -= L(i, k) . L(j, k) for i0 <= j <= i < i1 (i - j <= bw holds: m <= bw); a wave per row, lanes along the
         // contiguous band storage of that row; all loads of a wave's rows are issued before the first store
-        {
-            double cur[4][4]; int na = 0;
-            for (int a = wave; a < m && na < 4; a += 16, na++) {
-                const double* rowp = &AB(i0 + a, i0);
+        for (int a = wave; a < m; a += 16) {
+            double pa[CB_NB];
 #pragma unroll
-                for (int q = 0; q < 4; q++) { const int b = lane + 64 * q; cur[na][q] = b <= a ? rowp[b] : 0.0; }
-            }
-            na = 0;
-            for (int a = wave; a < m; a += 16, na++) {
-                double pa[CB_NB];
+            for (int c = 0; c < CB_NB; c++) pa[c] = Pn[a * (CB_NB + 1) + c];
+            double* rowp = &AB(i0 + a, i0);
+            for (int b = lane; b <= a; b += 64) {
+                double sum = 0;
 #pragma unroll
-                for (int c = 0; c < CB_NB; c++) pa[c] = Pn[a][c];
-                double* rowp = &AB(i0 + a, i0);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int b = lane + 64 * q;
-                    if (b <= a) {
-                        double sum = 0;
-#pragma unroll
-                        for (int c = 0; c < CB_NB; c++) sum += pa[c] * Pn[b][c];
-                        rowp[b] = (na < 4 ? cur[na < 4 ? na : 0][q] : rowp[b]) - sum;
-                    }
-                }
+                for (int c = 0; c < CB_NB; c++) sum += pa[c] * Pn[b * (CB_NB + 1) + c];
+                rowp[b] -= sum;
             }
         }
         __syncthreads();
@@ -1180,7 +1168,7 @@ __global__ __launch_bounds__(64) void k_badyn_schur(BaDev P, double* __restrict_
                         const double v = W[pp * 3] * y[0] + W[pp * 3 + 1] * y[1] + W[pp * 3 + 2] * y[2];
                         if (v == 0.0) continue;
                         if (rhs) atomicAdd(P.r + 6 * pa + pp, -v);
-                        else atomicAdd(P.S + (size_t)(6 * pa + pp) * n6 + 6 * pose_b + q, -v);
+                        else { double* e = s_entry(P, 6 * pa + pp, 6 * pose_b + q); if (e) atomicAdd(e, -v); }
                     }
                 }
             }
@@ -1379,9 +1367,40 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         const int t = p.n_odo + k; static const double I12[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
         cc_i[t] = p.n_cam + dy.sm_i[k]; cc_j[t] = p.n_cam + dy.sm_j[k]; memcpy(&cc_T[12 * (size_t)t], I12, sizeof I12); cc_info[t] = dy.info_smooth; cc_delta[t] = dy.huber_smooth;
     }
+    // Pose order inside the solver.  Without object vertices: the cameras as given.  With them: interleaved by frame (camera f, then the object
+    // motions of frame f) so that every factor couples poses that are close in the order and the reduced system stays banded.  The frame of an
+    // object motion is the camera of the dynamic point it moves INTO (LandmarkMotionTernaryEdge(p_prev, p_cur, H)); unused H go last.
+    std::vector<int> perm(n_pose);
+    for (int i = 0; i < n_pose; i++) perm[i] = i;
+    if (n_H) {
+        std::vector<int> hframe(n_H, p.n_cam);
+        for (int k = 0; k < dynp->n_tern; k++) {
+            const int h = dynp->tern_H[k], c = dynp->tern_cur[k];
+            if (h >= 0 && h < n_H && c >= 0 && c < dynp->n_dyn) { const int f = dynp->dyn_cam[c]; if (f >= 0 && f < p.n_cam) hframe[h] = std::min(hframe[h], f); }
+        }
+        // motions that no ternary edge uses (the object was tracked but none of its points survived into a tracklet) get their frame from the
+        // smoothness edges (consecutive frames of one object); anything still unknown goes last
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (int k = 0; k < dynp->n_smooth; k++) {
+                const int a = dynp->sm_i[k], b = dynp->sm_j[k];
+                if (a < 0 || a >= n_H || b < 0 || b >= n_H) continue;
+                if (hframe[a] == p.n_cam && hframe[b] != p.n_cam) { hframe[a] = std::max(hframe[b] - 1, 0); changed = true; }
+                else if (hframe[b] == p.n_cam && hframe[a] != p.n_cam) { hframe[b] = std::min(hframe[a] + 1, p.n_cam - 1); changed = true; }
+            }
+        }
+        std::vector<int> cnt(p.n_cam + 2, 0);                              // counting sort on the frame: camera f first, then its H in input order
+        for (int h = 0; h < n_H; h++) cnt[hframe[h] + 1]++;
+        for (int f = 0; f <= p.n_cam; f++) cnt[f + 1] += cnt[f];            // cnt[f] = number of H with frame < f
+        std::vector<int> fillh(cnt.begin(), cnt.end() - 1);
+        for (int f = 0; f < p.n_cam; f++) perm[f] = f + cnt[f];
+        for (int h = 0; h < n_H; h++) { const int f = hframe[h]; perm[p.n_cam + h] = std::min(f + 1, p.n_cam) + fillh[f]++; }
+    }
+    for (int k = 0; k < n_cc; k++) { cc_i[k] = perm[cc_i[k]]; cc_j[k] = perm[cc_j[k]]; }
+    for (int t = 0; t < nd; t++) { d_cam[t] = perm[d_cam[t]]; if (d_hin[t] >= 0) d_hin[t] = perm[d_hin[t]]; }
     std::vector<double> poses((size_t)n_pose * 12);
-    memcpy(poses.data(), p.cam_T, (size_t)p.n_cam * 12 * sizeof(double));
-    if (n_H) memcpy(poses.data() + (size_t)p.n_cam * 12, dynp->H_T, (size_t)n_H * 12 * sizeof(double));
+    for (int i = 0; i < p.n_cam; i++) memcpy(poses.data() + (size_t)perm[i] * 12, p.cam_T + (size_t)i * 12, 12 * sizeof(double));
+    for (int h = 0; h < n_H; h++) memcpy(poses.data() + (size_t)perm[p.n_cam + h] * 12, dynp->H_T + (size_t)h * 12, 12 * sizeof(double));
     // ---- host preprocessing: keep this shard's observations, sort by camera, build the landmark-major slots
     std::vector<int> keep; keep.reserve(p.n_obs);
     for (int k = 0; k < p.n_obs; k++) {
@@ -1390,15 +1409,15 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     }
     const int no = (int)keep.size();
     {   // stable counting sort by camera (O(n); a comparison sort of 1M observations costs more than the whole LM loop)
-        std::vector<int> cstart(p.n_cam + 1, 0), sorted(no);
-        for (int t = 0; t < no; t++) cstart[p.obs_cam[keep[t]] + 1]++;
-        for (int c = 0; c < p.n_cam; c++) cstart[c + 1] += cstart[c];
-        for (int t = 0; t < no; t++) sorted[cstart[p.obs_cam[keep[t]]]++] = keep[t];
+        std::vector<int> cstart(n_pose + 1, 0), sorted(no);
+        for (int t = 0; t < no; t++) cstart[perm[p.obs_cam[keep[t]]] + 1]++;
+        for (int c = 0; c < n_pose; c++) cstart[c + 1] += cstart[c];
+        for (int t = 0; t < no; t++) sorted[cstart[perm[p.obs_cam[keep[t]]]]++] = keep[t];
         keep.swap(sorted);
     }
     std::vector<int> ocam(no), opt(no), opos(no), pstart(n_ptl + 1, 0), slotcam(no);
     std::vector<double> omeas((size_t)no * 3);
-    for (int t = 0; t < no; t++) { const int k = keep[t]; ocam[t] = p.obs_cam[k]; opt[t] = p.obs_pt[k] - pt_lo; for (int a = 0; a < 3; a++) omeas[3 * (size_t)t + a] = p.obs_meas[3 * (size_t)k + a]; pstart[opt[t] + 1]++; }
+    for (int t = 0; t < no; t++) { const int k = keep[t]; ocam[t] = perm[p.obs_cam[k]]; opt[t] = p.obs_pt[k] - pt_lo; for (int a = 0; a < 3; a++) omeas[3 * (size_t)t + a] = p.obs_meas[3 * (size_t)k + a]; pstart[opt[t] + 1]++; }
     int maxk = 0;
     for (int l = 0; l < n_ptl; l++) { maxk = std::max(maxk, pstart[l + 1]); pstart[l + 1] += pstart[l]; }
     if (maxk > 64) return vido_set_error(ctx, VIDO_E_CAPACITY, "ba: a landmark has %d observations; this build handles tracks up to 64", maxk);
@@ -1418,7 +1437,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     }
     Arena A{BS->pool, BS->pool_cap, 0, false, BS->h_pool};
     BaDev D{};
-    D.n_cam = n_pose; D.n_pt = p.n_pt; D.n_obs = no; D.n_odo = owns_cam_factors ? n_cc : 0; D.prior_cam = owns_cam_factors ? p.prior_cam : -1;
+    D.n_cam = n_pose; D.n_pt = p.n_pt; D.n_obs = no; D.n_odo = owns_cam_factors ? n_cc : 0; D.prior_cam = (owns_cam_factors && p.prior_cam >= 0) ? perm[p.prior_cam] : -1;
     D.use_huber = p.use_huber; D.n6 = n6; D.pt_lo = pt_lo;
     D.info_obs = p.info_obs; D.info_odo = p.info_odo; D.info_prior = p.info_prior; D.huber_obs = p.huber_obs; D.huber_odo = p.huber_odo;
     memcpy(D.prior_T, p.prior_T, sizeof D.prior_T);
@@ -1448,15 +1467,26 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     // band layout of the reduced system when the map is sequential (every landmark / odometry edge spans few keyframes)
     const bool lds_path = n6 <= BA_LDS_MAX_N6;
     D.bw = -1; D.ldb = n6;
-    if (!lds_path && n_H == 0) {
-        std::vector<int> cmin(p.n_pt, p.n_cam), cmax(p.n_pt, -1);
-        for (int k = 0; k < p.n_obs; k++) { const int l = p.obs_pt[k], c = p.obs_cam[k]; cmin[l] = std::min(cmin[l], c); cmax[l] = std::max(cmax[l], c); }   // ALL shards: every rank must pick the same layout
+    if (!lds_path) {
+        std::vector<int> cmin(p.n_pt, n_pose), cmax(p.n_pt, -1);
+        for (int k = 0; k < p.n_obs; k++) { const int l = p.obs_pt[k], c = perm[p.obs_cam[k]]; cmin[l] = std::min(cmin[l], c); cmax[l] = std::max(cmax[l], c); }   // ALL shards: every rank must pick the same layout
         int bwc = 0;
         for (int l = 0; l < p.n_pt; l++) if (cmax[l] >= 0) bwc = std::max(bwc, cmax[l] - cmin[l]);
-        for (int k = 0; k < p.n_odo; k++) bwc = std::max(bwc, std::abs(p.odo_i[k] - p.odo_j[k]));
-        if (6 * bwc + 5 <= 255 && 6 * bwc + 6 < n6 / 2) { D.bw = 6 * bwc + 5; D.ldb = (D.bw + 2) & ~1; }
+        for (int k = 0; k < p.n_odo; k++) bwc = std::max(bwc, std::abs(perm[p.odo_i[k]] - perm[p.odo_j[k]]));
+        if (dynp) {   // a dynamic tracklet couples every pose it touches with every other one (its point block is eliminated as a whole)
+            for (int k = 0; k < dynp->n_smooth; k++) bwc = std::max(bwc, std::abs(perm[p.n_cam + dynp->sm_i[k]] - perm[p.n_cam + dynp->sm_j[k]]));
+            std::vector<int> root(dynp->n_dyn), lo(dynp->n_dyn, n_pose), hi(dynp->n_dyn, -1);
+            for (int k = 0; k < dynp->n_dyn; k++) root[k] = k;
+            auto find = [&](int a) { while (root[a] != a) { root[a] = root[root[a]]; a = root[a]; } return a; };
+            for (int k = 0; k < dynp->n_tern; k++) { const int a = find(dynp->tern_prev[k]), c = find(dynp->tern_cur[k]); if (a != c) root[a] = c; }
+            for (int k = 0; k < dynp->n_dyn; k++) { const int r0 = find(k), c = perm[dynp->dyn_cam[k]]; lo[r0] = std::min(lo[r0], c); hi[r0] = std::max(hi[r0], c); }
+            for (int k = 0; k < dynp->n_tern; k++) { const int r0 = find(dynp->tern_cur[k]), h = perm[p.n_cam + dynp->tern_H[k]]; lo[r0] = std::min(lo[r0], h); hi[r0] = std::max(hi[r0], h); }
+            for (int k = 0; k < dynp->n_dyn; k++) if (hi[k] >= 0) bwc = std::max(bwc, hi[k] - lo[k]);
+        }
+        if (6 * bwc + 5 <= CB_MAXBW && 6 * bwc + 6 < n6 / 2) { D.bw = 6 * bwc + 5; D.ldb = (D.bw + 2) & ~1; }
     }
     const size_t sz_S = D.bw >= 0 ? (size_t)n6 * D.ldb : (size_t)n6 * n6;
+    if (D.bw >= 0) HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)D.bw * (CB_NB + 1) * sizeof(double))));
     size_t band6_lds = 0;                                   // pose-block LDS-window factorisation when the window fits
     if (D.bw >= 0) { const size_t bwc = (D.bw - 5) / 6, wr = 6 * (bwc + 1), need = (wr * (wr + 1) + 3 * wr + 6 * bwc * 7 + 8) * sizeof(double);
                      if (bwc >= 1 && need <= 150 * 1024) { band6_lds = need; HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol_band6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)); } }
@@ -1481,15 +1511,15 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     int* d_chunk_cmin = nullptr; int* d_lorder = nullptr; int n_chunks = (n_ptl + BA_CHUNK - 1) / BA_CHUNK;
     if (!lds_path && n_ptl) {
         std::vector<int> lorder(n_ptl);
-        auto first_cam = [&](int l) { return pstart[l + 1] > pstart[l] ? slotcam[pstart[l]] : p.n_cam; };
+        auto first_cam = [&](int l) { return pstart[l + 1] > pstart[l] ? slotcam[pstart[l]] : n_pose; };
         {   // stable counting sort by first camera
-            std::vector<int> cs(p.n_cam + 2, 0);
+            std::vector<int> cs(n_pose + 2, 0);
             for (int l = 0; l < n_ptl; l++) cs[first_cam(l) + 1]++;
-            for (int c = 0; c <= p.n_cam; c++) cs[c + 1] += cs[c];
+            for (int c = 0; c <= n_pose; c++) cs[c + 1] += cs[c];
             for (int l = 0; l < n_ptl; l++) lorder[cs[first_cam(l)]++] = l;
         }
         std::vector<int> cmin(n_chunks, 0);
-        for (int c = 0; c < n_chunks; c++) { const int m = first_cam(lorder[c * BA_CHUNK]); cmin[c] = m == p.n_cam ? 0 : m; }
+        for (int c = 0; c < n_chunks; c++) { const int m = first_cam(lorder[c * BA_CHUNK]); cmin[c] = m == n_pose ? 0 : m; }
         d_chunk_cmin = A.put(cmin.data(), n_chunks, st); d_lorder = A.put(lorder.data(), n_ptl, st);
         if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device pool exhausted");
     }
@@ -1580,7 +1610,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if (lds_path && n6 % 6 == 0 && n6 >= 12) hipLaunchKernelGGL(k_ba_chol_small6, dim3(1), dim3(1024), lds_chol6, st, D);
             else if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
             else if (D.bw >= 0 && band6_lds) hipLaunchKernelGGL(k_chol_band6, dim3(1), dim3(1024), band6_lds, st, D, (D.bw - 5) / 6);
-            else if (D.bw >= 0) hipLaunchKernelGGL(k_chol_band, dim3(1), dim3(1024), 0, st, D);
+            else if (D.bw >= 0) hipLaunchKernelGGL(k_chol_band, dim3(1), dim3(1024), (size_t)D.bw * (CB_NB + 1) * sizeof(double), st, D);
             else { const double one = 1.0; HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4, &one, 8, hipMemcpyHostToDevice, st)); if ((rc = chol_large(ctx, D.S, n6, D.x, D.scal + 4, chol_tmp, st))) return rc; }
             // ---- trial state + its chi2
             hipLaunchKernelGGL(k_ba_update_cams, dim3((n_pose + 63) / 64), dim3(64), 0, st, D, (allreduce && p.rank != 0) ? 0.0 : lambda);
@@ -1618,11 +1648,12 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     res->iterations = it; res->lm_trials = trials; res->lambda_final = lambda;
     res->ms_linearize_kernel = n_lin ? ms_lin / n_lin : 0.0;
     res->ms_solve_loop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
-    HIP_TRY(ctx, hipMemcpyAsync(prob->cam_T, D.cam, (size_t)p.n_cam * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(poses.data(), D.cam, (size_t)n_pose * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (n_ptl) HIP_TRY(ctx, hipMemcpyAsync(prob->pt_xyz + 3 * (size_t)pt_lo, D.pt, (size_t)n_ptl * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (n_H) HIP_TRY(ctx, hipMemcpyAsync(dynp->H_T, D.cam + (size_t)p.n_cam * 12, (size_t)n_H * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (nd) HIP_TRY(ctx, hipMemcpyAsync(d_xyz.data(), D.dyn, (size_t)nd * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int i = 0; i < p.n_cam; i++) memcpy(prob->cam_T + (size_t)i * 12, poses.data() + (size_t)perm[i] * 12, 12 * sizeof(double));
+    for (int h = 0; h < n_H; h++) memcpy(dynp->H_T + (size_t)h * 12, poses.data() + (size_t)perm[p.n_cam + h] * 12, 12 * sizeof(double));
     for (int t = 0; t < nd; t++) for (int a = 0; a < 3; a++) dynp->dyn_xyz[3 * (size_t)d_order[t] + a] = d_xyz[3 * (size_t)t + a];
     return VIDO_OK;
 }

@@ -162,7 +162,7 @@ def dyn_constants():
                 huber_dyn=float(F32(0.01)), huber_tern=float(F32(0.01)), huber_smooth=float(F32(0.01)))
 
 
-def synth_ba_dynamic(base, n_obj=2, pts_per_obj=30, seed=21, obs_noise=0.02, min_len=3):
+def synth_ba_dynamic(base, n_obj=2, pts_per_obj=30, seed=21, obs_noise=0.02, min_len=3, max_len=None):
     """Object part of the FullBatchOptimization graph on top of a static problem `base` (synth_ba_problem, kind="global"):
     rigid objects moving with a constant world-frame motion H (p_{k+1} = H p_k), each point tracked over a contiguous
     run of frames.  Mirrors Optimizer.cc:1560-1745: one dynamic vertex per observation (initialised at the noisy
@@ -187,6 +187,8 @@ def synth_ba_dynamic(base, n_obj=2, pts_per_obj=30, seed=21, obs_noise=0.02, min
                 sm_i.append(H_idx[(o, f - 1)]); sm_j.append(H_idx[(o, f)])
         for q in range(pts_per_obj):
             a = int(rng.randint(f0, max(f0 + 1, f1 - min_len + 1))); b = int(min(f1, a + rng.randint(min_len - 1, f1 - f0 + 1)))
+            if max_len is not None:
+                b = min(b, a + max_len - 1)          # bounded tracklet length (the usual case: dynamic points are re-sampled every few frames)
             p = np.append(P[q], 1.0)
             for f in range(f0, a):
                 p = H @ p
