@@ -101,3 +101,26 @@ def test_hamming_matches_oracle(ctx, oracle):
         assert np.array_equal(idx, ri) and np.array_equal(dist, rd), (na, nb)
     idx, dist = ctx.hamming_match(np.zeros((5, 32), np.uint8), np.zeros((0, 32), np.uint8))
     assert (idx == -1).all() and (dist == -1).all()
+
+
+@pytest.mark.parametrize("nf,scale,levels,ini,mn", [(300, 1.2, 8, 20, 7), (1000, 1.2, 8, 20, 7), (2500, 1.2, 8, 20, 7), (1500, 1.5, 4, 20, 7),
+                                                    (800, 1.2, 5, 30, 10), (4000, 1.1, 8, 12, 5)])
+def test_extractor_parameter_sweep(vido, oracle, nf, scale, levels, ini, mn):
+    """The device quadtree (node-list passes, final sorted passes with the early stop, best-response selection) and the rest of the
+    extractor across feature budgets / pyramids / thresholds, on textured, low-texture and duplicate-heavy images: every keypoint field
+    and every descriptor bit must equal the oracle's."""
+    from vido_slam_amd import synth
+    w, h = 640, 480
+    imgs = [synth.make_frame(w, h, seed=11), synth.make_canvas(h, w, seed=12, n_rect=15),
+            np.kron(synth.make_canvas(h // 4, w // 4, seed=13, n_rect=40), np.ones((4, 4), np.uint8))]       # 4x4 replicated blocks: many equal responses
+    c = vido.Context(width=w, height=h, max_batch=len(imgs), n_features=nf, scale_factor=scale, n_levels=levels, ini_th_fast=ini, min_th_fast=mn)
+    kps, desc, cnt = c.orb_extract_batch(np.stack(imgs))
+    p = oracle.orb_params(n_features=nf, scale_factor=scale, n_levels=levels, ini_th=ini, min_th=mn)
+    for f, g in enumerate(imgs):
+        rk, rd, _ = oracle.orb_extract(p, g)
+        assert cnt[f] == len(rk), (f, cnt[f], len(rk))
+        k = kps[f, :cnt[f]]
+        for name in ("x", "y", "size", "angle", "response", "octave"):
+            assert np.array_equal(k[name], rk[name]), (f, name)
+        assert np.array_equal(desc[f, :cnt[f]], rd)
+    c.close()
