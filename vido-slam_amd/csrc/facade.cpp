@@ -682,6 +682,25 @@ std::vector<std::vector<std::pair<int, int> > > Tracking::GetDynamicTrackNew()  
     return T;
 }
 
+// "is some point of a fixed set closer than 1 px to q" — the reference scans the whole set for every sample (Tracking.cc:3030-3040, 3198-3208: O(N*M));
+// a 1-px cell grid restricts the scan to the 3x3 neighbourhood and evaluates the same float expression, so the answer is identical.
+struct NearSet {
+    int W, H; std::vector<int> head, next; const std::vector<cv::KeyPoint>* pts;
+    NearSet(const std::vector<cv::KeyPoint>& p, int w, int h) : W(w + 2), H(h + 2), head((size_t)(w + 2) * (h + 2), -1), next(p.size(), -1), pts(&p) {
+        for (size_t i = 0; i < p.size(); i++) { const int c = cell(p[i].pt.x, p[i].pt.y); next[i] = head[c]; head[c] = (int)i; }
+    }
+    int cell(float x, float y) const { const int cx = std::min(std::max((int)std::floor(x) + 1, 0), W - 1), cy = std::min(std::max((int)std::floor(y) + 1, 0), H - 1); return cy * W + cx; }
+    bool near(const cv::Point2f& q) const {
+        const int cx = std::min(std::max((int)std::floor(q.x) + 1, 0), W - 1), cy = std::min(std::max((int)std::floor(q.y) + 1, 0), H - 1);
+        for (int yy = std::max(cy - 1, 0); yy <= std::min(cy + 1, H - 1); yy++) for (int xx = std::max(cx - 1, 0); xx <= std::min(cx + 1, W - 1); xx++)
+            for (int i = head[yy * W + xx]; i >= 0; i = next[i]) {
+                const float dx = (*pts)[i].pt.x - q.x, dy = (*pts)[i].pt.y - q.y;
+                if (std::sqrt(dx * dx + dy * dy) < 1.0f) return true;
+            }
+        return false;
+    }
+};
+
 void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:2959-3289
 {
     Frame* C = mpCurrentFrame; const int W = mImGray.cols, H = mImGray.rows;
@@ -706,16 +725,11 @@ void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:29
     int tot = (int)keys.size(), start_id = 0; const int step = 20;
     const std::vector<cv::KeyPoint> check_set = keys;                    // mvKeysTmpCheck: the inlier set only (copied once)
     const std::vector<cv::KeyPoint>& sample = C->mvKeys;
+    const NearSet near_static(check_set, W, H);
     while (tot < max_num_sta) {
         if (start_id == step) break;
         for (size_t i = start_id; i < sample.size(); i += step) {
-            bool used = false; float min_dist = 100;
-            for (const cv::KeyPoint& k : check_set) {
-                const float dx = k.pt.x - sample[i].pt.x, dy = k.pt.y - sample[i].pt.y, dd = std::sqrt(dx * dx + dy * dy);
-                if (dd < min_dist) min_dist = dd;
-                if (min_dist < 1.0f) { used = true; break; }
-            }
-            if (used) continue;
+            if (near_static.near(sample[i].pt)) continue;
             if (try_static(sample[i], -1)) tot++;
             if (tot >= max_num_sta) break;
         }
@@ -748,6 +762,7 @@ void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:29
         cnt[i] = count;
     }
     const std::vector<cv::KeyPoint> ocheck = okeys;
+    const NearSet near_obj(ocheck, W, H);
     for (size_t i = 0; i < C->vnObjID.size(); i++) {
         if (!C->bObjStat[i]) continue;
         const int SemLabel = C->nSemPosition[i]; int tot_o = cnt[i], sid = 0; const int ostep = 15;
@@ -755,9 +770,7 @@ void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:29
             if (sid == ostep) break;
             for (size_t j = sid; j < mvTmpSemObjLabel.size(); j += ostep) {
                 if (mvTmpSemObjLabel[j] != SemLabel) continue;
-                bool used = false; float min_dist = 100;
-                for (const cv::KeyPoint& k : ocheck) { const float dx = k.pt.x - mvTmpObjKeys[j].pt.x, dy = k.pt.y - mvTmpObjKeys[j].pt.y, dd = std::sqrt(dx * dx + dy * dy); if (dd < min_dist) min_dist = dd; if (min_dist < 1.0f) { used = true; break; } }
-                if (used) continue;
+                if (near_obj.near(mvTmpObjKeys[j].pt)) continue;
                 okeys.push_back(mvTmpObjKeys[j]); odep.push_back(mvTmpObjDepth[j]); osem.push_back(mvTmpSemObjLabel[j]); oflow.push_back(mvTmpObjFlowNext[j]); ocorr.push_back(mvTmpObjCorres[j]);
                 oinl.push_back(-1); olab.push_back(C->nModLabel[i]); tot_o++;
                 if (tot_o >= max_num_obj) break;
