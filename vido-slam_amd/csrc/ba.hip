@@ -138,71 +138,92 @@ __device__ __forceinline__ void inv3sym(const double* H6 /*00 01 02 11 12 22*/, 
 }
 
 // ---- linearisation -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ba_linearize(BaDev P)
+// Every wave walks E consecutive groups of 64 observations (sorted by camera, so a wave normally sees one camera) and keeps the 28 camera-side
+// sums in registers across the groups: the 28-value wave reduction (336 cross-lane FP64 shuffles — two thirds of this kernel's time when it
+// was done per group) and the atomics onto the few camera blocks happen once per camera change instead of once per 64 observations.
+__device__ __forceinline__ void ba_flush_cam(const BaDev& P, int c, double* acc, int lane)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool act = k < P.n_obs;
-    int c = -1, l = 0;
-    double acc[28];
 #pragma unroll
-    for (int a = 0; a < 28; a++) acc[a] = 0;
-    if (act) {
-        c = P.obs_cam[k]; l = P.obs_pt[k];
-        const double* X = P.cam + 12 * c; const double* p = P.pt + 3 * l; const double* m = P.obs_meas + 3 * (size_t)k;
-        const double R00 = X[0], R01 = X[1], R02 = X[2], R10 = X[4], R11 = X[5], R12 = X[6], R20 = X[8], R21 = X[9], R22 = X[10];
-        const double d0 = p[0] - X[3], d1 = p[1] - X[7], d2 = p[2] - X[11];
-        const double Z0 = R00 * d0 + R10 * d1 + R20 * d2, Z1 = R01 * d0 + R11 * d1 + R21 * d2, Z2 = R02 * d0 + R12 * d1 + R22 * d2;
-        const double e0 = Z0 - m[0], e1 = Z1 - m[1], e2 = Z2 - m[2];
-        double r0, w; huber_w(P.info_obs * (e0 * e0 + e1 * e1 + e2 * e2), P.huber_obs, P.use_huber, r0, w);
-        const double wo = w * P.info_obs;
-        // Jc = [-I | 2[Zc]x] (3x6), Jp = R^T
-        const double Jc[18] = {-1, 0, 0, 0, -2 * Z2, 2 * Z1,   0, -1, 0, 2 * Z2, 0, -2 * Z0,   0, 0, -1, -2 * Z1, 2 * Z0, 0};
-        const double Jp[9] = {R00, R10, R20, R01, R11, R21, R02, R12, R22};
-        const double e[3] = {e0, e1, e2};
-        int q = 0;
+    for (int a = 0; a < 28; a++) {
+        double v = acc[a];
 #pragma unroll
-        for (int a = 0; a < 6; a++) {
-            acc[21 + a] = -wo * (Jc[a] * e[0] + Jc[6 + a] * e[1] + Jc[12 + a] * e[2]);
-#pragma unroll
-            for (int b = a; b < 6; b++) acc[q++] = wo * (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b] + Jc[12 + a] * Jc[12 + b]);
-        }
-        acc[27] = r0;
-        double* Wk = P.W + 18 * (size_t)P.obs_pos[k];
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) Wk[a * 3 + b] = wo * (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b]);
-        double* Hp = P.Hpp + 6 * (size_t)l; double* bpp = P.bp + 3 * (size_t)l;
-        q = 0;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            atomicAdd(bpp + a, -wo * (Jp[a] * e[0] + Jp[3 + a] * e[1] + Jp[6 + a] * e[2]));
-#pragma unroll
-            for (int b = a; b < 3; b++) atomicAdd(Hp + q++, wo * (Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b] + Jp[6 + a] * Jp[6 + b]));
-        }
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        acc[a] = v;
     }
-    // camera-side sums: observations are sorted by camera, so a wave normally holds one camera
-    const int c0 = __shfl(c, 0, 64);
-    const bool uniform = __all(c == c0 || !act) && c0 >= 0;
-    if (uniform) {
-#pragma unroll
-        for (int a = 0; a < 28; a++) {
-            double v = acc[a];
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-            acc[a] = v;
-        }
-        if (lane == 0) {
-            int q = 0;
-            for (int a = 0; a < 6; a++) { atomicAdd(P.bc + 6 * c0 + a, acc[21 + a]); for (int b = a; b < 6; b++) { atomicAdd(P.Hcd + 36 * c0 + a * 6 + b, acc[q]); if (b != a) atomicAdd(P.Hcd + 36 * c0 + b * 6 + a, acc[q]); q++; } }
-            atomicAdd(P.scal + 0, acc[27]);
-        }
-    } else if (act) {
+    if (lane == 0) {
         int q = 0;
         for (int a = 0; a < 6; a++) { atomicAdd(P.bc + 6 * c + a, acc[21 + a]); for (int b = a; b < 6; b++) { atomicAdd(P.Hcd + 36 * c + a * 6 + b, acc[q]); if (b != a) atomicAdd(P.Hcd + 36 * c + b * 6 + a, acc[q]); q++; } }
         atomicAdd(P.scal + 0, acc[27]);
     }
+#pragma unroll
+    for (int a = 0; a < 28; a++) acc[a] = 0;
+}
+__global__ __launch_bounds__(256) void k_ba_linearize(BaDev P, int E)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wave_g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    double acc[28];
+#pragma unroll
+    for (int a = 0; a < 28; a++) acc[a] = 0;
+    int acc_cam = -1;                                            // camera the register sums belong to (wave-uniform)
+    for (int j = 0; j < E; j++) {
+        const size_t k = (wave_g * E + j) * 64 + lane;
+        const bool act = k < (size_t)P.n_obs;
+        int c = -1, l = 0;
+        double con[28];
+#pragma unroll
+        for (int a = 0; a < 28; a++) con[a] = 0;
+        if (act) {
+            c = P.obs_cam[k]; l = P.obs_pt[k];
+            const double* X = P.cam + 12 * c; const double* p = P.pt + 3 * l; const double* m = P.obs_meas + 3 * (size_t)k;
+            const double R00 = X[0], R01 = X[1], R02 = X[2], R10 = X[4], R11 = X[5], R12 = X[6], R20 = X[8], R21 = X[9], R22 = X[10];
+            const double d0 = p[0] - X[3], d1 = p[1] - X[7], d2 = p[2] - X[11];
+            const double Z0 = R00 * d0 + R10 * d1 + R20 * d2, Z1 = R01 * d0 + R11 * d1 + R21 * d2, Z2 = R02 * d0 + R12 * d1 + R22 * d2;
+            const double e0 = Z0 - m[0], e1 = Z1 - m[1], e2 = Z2 - m[2];
+            double r0, w; huber_w(P.info_obs * (e0 * e0 + e1 * e1 + e2 * e2), P.huber_obs, P.use_huber, r0, w);
+            const double wo = w * P.info_obs;
+            // Jc = [-I | 2[Zc]x] (3x6), Jp = R^T
+            const double Jc[18] = {-1, 0, 0, 0, -2 * Z2, 2 * Z1,   0, -1, 0, 2 * Z2, 0, -2 * Z0,   0, 0, -1, -2 * Z1, 2 * Z0, 0};
+            const double Jp[9] = {R00, R10, R20, R01, R11, R21, R02, R12, R22};
+            const double e[3] = {e0, e1, e2};
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                con[21 + a] = -wo * (Jc[a] * e[0] + Jc[6 + a] * e[1] + Jc[12 + a] * e[2]);
+#pragma unroll
+                for (int b = a; b < 6; b++) con[q++] = wo * (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b] + Jc[12 + a] * Jc[12 + b]);
+            }
+            con[27] = r0;
+            double* Wk = P.W + 18 * (size_t)P.obs_pos[k];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) Wk[a * 3 + b] = wo * (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b]);
+            double* Hp = P.Hpp + 6 * (size_t)l; double* bpp = P.bp + 3 * (size_t)l;
+            q = 0;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                atomicAdd(bpp + a, -wo * (Jp[a] * e[0] + Jp[3 + a] * e[1] + Jp[6 + a] * e[2]));
+#pragma unroll
+                for (int b = a; b < 3; b++) atomicAdd(Hp + q++, wo * (Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b] + Jp[6 + a] * Jp[6 + b]));
+            }
+        }
+        // camera of this group: uniform over the active lanes?
+        const int c0 = __shfl(c, 0, 64);
+        const bool any = __any(act);
+        const bool uniform = any && c0 >= 0 && __all(c == c0 || !act);
+        if (uniform) {
+            if (acc_cam >= 0 && acc_cam != c0) ba_flush_cam(P, acc_cam, acc, lane);
+            acc_cam = c0;
+#pragma unroll
+            for (int a = 0; a < 28; a++) acc[a] += con[a];
+        } else if (act) {                                         // a group that straddles two cameras: per-observation atomics
+            int q = 0;
+            for (int a = 0; a < 6; a++) { atomicAdd(P.bc + 6 * c + a, con[21 + a]); for (int b = a; b < 6; b++) { atomicAdd(P.Hcd + 36 * c + a * 6 + b, con[q]); if (b != a) atomicAdd(P.Hcd + 36 * c + b * 6 + a, con[q]); q++; } }
+            atomicAdd(P.scal + 0, con[27]);
+        }
+    }
+    if (acc_cam >= 0) ba_flush_cam(P, acc_cam, acc, lane);
 }
 
 // odometry edges (k < n_odo) and the prior (k == n_odo): one wave per factor, lane a*6+b owns entry (a,b) of the
@@ -1529,6 +1550,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
                     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol6)); }
     else { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur)); }
 
+    const int lin_E = no >= 400000 ? 8 : (no >= 16384 ? 4 : 1);     // groups of 64 observations per wave in k_ba_linearize
     auto AR = [&](double* dptr, size_t cnt, int op) -> int {
         if (!allreduce) return VIDO_OK;
         HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -1561,7 +1583,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         HIP_TRY(ctx, hipMemsetAsync(D.Hpp, 0, (size_t)n_ptl * 6 * sizeof(double), st));
         HIP_TRY(ctx, hipMemsetAsync(D.bp, 0, (size_t)n_ptl * 3 * sizeof(double), st));
         HIP_TRY(ctx, hipEventRecord(BS->ev0, st));
-        if (no) hipLaunchKernelGGL(k_ba_linearize, dim3((no + 255) / 256), dim3(256), 0, st, D);
+        if (no) hipLaunchKernelGGL(k_ba_linearize, dim3((no + 256 * lin_E - 1) / (256 * lin_E)), dim3(256), 0, st, D, lin_E);
         HIP_TRY(ctx, hipEventRecord(BS->ev1, st));
         if (nd) hipLaunchKernelGGL(k_badyn_linearize, dim3((nd + 255) / 256), dim3(256), 0, st, D);
         n_lin++;
