@@ -91,7 +91,7 @@ def main():
     def step():
         depth_work.copy_(depth_d)                          # the pre-scale mutates its input in place
         torch.cuda.current_stream().synchronize()          # torch's stream -> the ctx stream hand-over of the scratch copy
-        o = ff.frontend_batch(0, dev_arg, depth_work.data_ptr(), flow_d.data_ptr(), mask_d.data_ptr())   # fused ORB + pre-scale + lists
+        o = ff.frontend_batch(0, dev_arg, depth_work.data_ptr(), flow_d.data_ptr(), mask_d.data_ptr(), alias=True)   # fused ORB + pre-scale + lists, maps zero-copy
         return o["kps"], o["n_kp"], o
 
     def sync_all():

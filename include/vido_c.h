@@ -123,7 +123,9 @@ int vido_frame_features(vido_ctx* ctx, int slot0, int n_frames, const vido_keypo
  * depth pre-scale + the Frame::Frame lists), one stream of launches, keypoints handed over on the device.  Results are
  * returned as a VIEW into ctx-owned pinned host memory, valid until the next call on ctx: kps/desc rows are
  * [frame][kp_pitch], list rows [frame][stat_pitch] / [frame][obj_pitch]; frame f has frame_beg[f+1]-frame_beg[f]
- * keypoints.  `depth` is rescaled in place like the reference does. */
+ * keypoints.  `depth` is rescaled in place like the reference does.  maps_on_device: 0 host buffers, 1 device buffers copied into the
+ * ctx's slots, 2 device buffers used ZERO-COPY: the slots refer to them until they are overwritten (the reference keeps shallow
+ * references to the caller's Mats the same way, Tracking.cc:343-345), so the caller must keep them alive and unmodified. */
 typedef struct vido_frontend_view {
     int32_t n_frames, kp_pitch, stat_pitch, obj_pitch;
     const vido_keypoint* kps; const uint8_t* desc; const int32_t* frame_beg;

@@ -109,3 +109,11 @@ def test_fused_frontend_equals_separate_calls(vido, setup):
     out = ff.frontend_batch(0, (g.data_ptr(), 3, 480, 640, 480 * 640, 640), dd.data_ptr(), fl.data_ptr(), mk.data_ptr())
     torch.cuda.synchronize()
     check(out, dd.cpu().numpy())
+    # zero-copy: the slots refer to the caller's device buffers; later slot readers (gathers) see them
+    dd2 = torch.from_numpy(depth0.copy()).cuda()
+    out = ff.frontend_batch(0, (g.data_ptr(), 3, 480, 640, 480 * 640, 640), dd2.data_ptr(), fl.data_ptr(), mk.data_ptr(), alias=True)
+    torch.cuda.synchronize()
+    check(out, dd2.cpu().numpy())
+    assert np.array_equal(ff.read_maps(1)[0], d1[1])
+    keys = np.array([[10.5, 20.5], [300.0, 200.0]], np.float32)
+    assert np.array_equal(ff.gather_static_depth(2, keys), np.array([d1[2][20, 10], d1[2][200, 300]], np.float32))

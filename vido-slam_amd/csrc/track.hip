@@ -20,6 +20,8 @@ struct TrackState {
     int32_t* h_cnt = nullptr;
     char* h_stage = nullptr; size_t stage_cap = 0;
     char* h_view = nullptr; size_t view_cap = 0;         // pinned lists of the fused front end (vido_frontend_batch)
+    // where the maps of each slot live: the ctx's own buffers, or (zero-copy batches) the caller's device memory
+    std::vector<float*> sdepth, sflow; std::vector<int32_t*> smask;
 };
 
 // ---- kernels -------------------------------------------------------------------------------------
@@ -216,6 +218,8 @@ static int track_state(vido_ctx* ctx, TrackState** out)
     T->tmp_cap = (size_t)std::max(T->max_obj, T->max_kp) * 8;
     HIP_TRY(ctx, hipMalloc(&T->d_tmpf, T->tmp_cap * 4)); HIP_TRY(ctx, hipMalloc(&T->d_tmpi, T->tmp_cap * 4));
     HIP_TRY(ctx, hipHostMalloc(&T->h_cnt, 2 * B * 4));
+    T->sdepth.resize(B); T->sflow.resize(B); T->smask.resize(B);
+    for (size_t b = 0; b < B; b++) { T->sdepth[b] = T->d_depth + b * px; T->sflow[b] = T->d_flow + b * px * 2; T->smask[b] = T->d_mask + b * px; }
     *out = T;
     return VIDO_OK;
 }
@@ -252,6 +256,7 @@ int vido_frame_upload(vido_ctx* ctx, int slot0, int n_frames, float* depth, cons
     hipStream_t st = ctx->stream;
     const size_t px = (size_t)T->W * T->H, n = px * n_frames;
     float* dd = T->d_depth + slot0 * px;
+    for (int f = 0; f < n_frames; f++) { T->sdepth[slot0 + f] = T->d_depth + (slot0 + f) * px; T->sflow[slot0 + f] = T->d_flow + (slot0 + f) * px * 2; T->smask[slot0 + f] = T->d_mask + (slot0 + f) * px; }
     HIP_TRY(ctx, hipMemcpyAsync(dd, depth, n * 4, in_kind(on_device), st));
     HIP_TRY(ctx, hipMemcpyAsync(T->d_flow + slot0 * px * 2, flow, n * 8, in_kind(on_device), st));
     HIP_TRY(ctx, hipMemcpyAsync(T->d_mask + slot0 * px, mask, n * 4, in_kind(on_device), st));
@@ -282,13 +287,14 @@ int vido_frame_features(vido_ctx* ctx, int slot0, int n_frames, const vido_keypo
                                   (size_t)max_kp * sizeof(vido_keypoint), n_frames, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(T->d_nstat, n_kps, n_frames * 4, hipMemcpyHostToDevice, st));     // reused as the input count, overwritten by the kernel
     HIP_TRY(ctx, hipMemcpyAsync(T->d_nobj, n_kps, n_frames * 4, hipMemcpyHostToDevice, st));
+    for (int f = 1; f < n_frames; f++) if (T->sdepth[slot0 + f] != T->sdepth[slot0] + f * px) return vido_set_error(ctx, VIDO_E_INVALID, "frame_features: slots [%d,%d) do not hold one contiguous batch", slot0, slot0 + n_frames);
     hipLaunchKernelGGL(k_static_filter, dim3(n_frames), dim3(1024), 0, st, T->d_kps, T->d_nobj, T->max_kp, T->max_kp,
-                       T->d_depth + slot0 * px, T->d_flow + slot0 * px * 2, T->d_mask + slot0 * px, T->W, T->H, p->th_depth_bg,
+                       T->sdepth[slot0], T->sflow[slot0], T->smask[slot0], T->W, T->H, p->th_depth_bg,
                        T->d_sidx, T->d_scorr, T->d_sflow, T->d_sdepth, T->d_nstat);
     const int step = p->dense_step > 0 ? p->dense_step : 4;
     const int lattice = ((T->W + step - 1) / step) * ((T->H + step - 1) / step);
     if (lattice > T->max_obj) return vido_set_error(ctx, VIDO_E_INVALID, "frame_features: dense_step %d gives %d probes > %d", step, lattice, T->max_obj);
-    hipLaunchKernelGGL(k_dense_sample, dim3(n_frames), dim3(1024), 0, st, T->d_depth + slot0 * px, T->d_flow + slot0 * px * 2, T->d_mask + slot0 * px,
+    hipLaunchKernelGGL(k_dense_sample, dim3(n_frames), dim3(1024), 0, st, T->sdepth[slot0], T->sflow[slot0], T->smask[slot0],
                        T->W, T->H, p->th_depth_obj, step, T->max_obj, T->d_okeys, T->d_ocorr, T->d_odepth, T->d_olabel, T->d_oflow, T->d_nobj);
     HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt, T->d_nstat, n_frames * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt + T->B, T->d_nobj, n_frames * 4, hipMemcpyDeviceToHost, st));
@@ -350,21 +356,28 @@ int vido_frontend_batch(vido_ctx* ctx, const uint8_t* imgs, int imgs_on_device, 
     hipStream_t st = ctx->stream;
     const size_t px = (size_t)T->W * T->H, n = px * n_frames;
     if ((n & 3) != 0) return vido_set_error(ctx, VIDO_E_INVALID, "frontend_batch: width*height must be a multiple of 4");
-    float* dd = T->d_depth + slot0 * px;
-    HIP_TRY(ctx, hipMemcpyAsync(dd, depth, n * 4, in_kind(maps_on_device), st));
-    HIP_TRY(ctx, hipMemcpyAsync(T->d_flow + slot0 * px * 2, flow, n * 8, in_kind(maps_on_device), st));
-    HIP_TRY(ctx, hipMemcpyAsync(T->d_mask + slot0 * px, mask, n * 4, in_kind(maps_on_device), st));
+    // maps_on_device == 2: zero-copy — the slots REFER to the caller's device buffers (the reference keeps shallow references to the caller's
+    // depth/flow/mask Mats until the next frame, Tracking.cc:343-345, and rescales the depth in the caller's buffer); 0/1: copied into the ctx
+    const bool alias = maps_on_device == 2;
+    float* dd = alias ? depth : T->d_depth + slot0 * px;
+    const float* fl = alias ? flow : T->d_flow + slot0 * px * 2; const int32_t* mk = alias ? mask : T->d_mask + slot0 * px;
+    for (int f = 0; f < n_frames; f++) { T->sdepth[slot0 + f] = dd + (size_t)f * px; T->sflow[slot0 + f] = (float*)fl + (size_t)f * px * 2; T->smask[slot0 + f] = (int32_t*)mk + (size_t)f * px; }
+    if (!alias) {
+        HIP_TRY(ctx, hipMemcpyAsync(dd, depth, n * 4, in_kind(maps_on_device), st));
+        HIP_TRY(ctx, hipMemcpyAsync(T->d_flow + slot0 * px * 2, flow, n * 8, in_kind(maps_on_device), st));
+        HIP_TRY(ctx, hipMemcpyAsync(T->d_mask + slot0 * px, mask, n * 4, in_kind(maps_on_device), st));
+    }
     hipLaunchKernelGGL(k_depth_prescale, dim3((int)std::min<size_t>((n / 4 + 255) / 256, 2048)), dim3(256), 0, st, dd, n / 4, p->dataset, p->depth_map_factor, p->bf, p->kaist_scale);
-    HIP_TRY(ctx, hipMemcpyAsync(depth, dd, n * 4, maps_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));     // in-place semantics of Tracking.cc:299-322
+    if (!alias) HIP_TRY(ctx, hipMemcpyAsync(depth, dd, n * 4, maps_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));     // in-place semantics of Tracking.cc:299-322
     const OrbView ov = orb_view(ctx);
     if (ov.row_cap > T->max_kp) return vido_set_error(ctx, VIDO_E_INVALID, "frontend_batch: extractor rows (%d) exceed the list capacity (%d)", ov.row_cap, T->max_kp);
     hipLaunchKernelGGL(k_static_filter, dim3(n_frames), dim3(1024), 0, st, ov.d_kpf, ov.d_nkp, ov.row_cap, T->max_kp,
-                       T->d_depth + slot0 * px, T->d_flow + slot0 * px * 2, T->d_mask + slot0 * px, T->W, T->H, p->th_depth_bg,
+                       (const float*)dd, fl, mk, T->W, T->H, p->th_depth_bg,
                        T->d_sidx, T->d_scorr, T->d_sflow, T->d_sdepth, T->d_nstat);
     const int step = p->dense_step > 0 ? p->dense_step : 4;
     const int lattice = ((T->W + step - 1) / step) * ((T->H + step - 1) / step);
     if (lattice > T->max_obj) return vido_set_error(ctx, VIDO_E_INVALID, "frontend_batch: dense_step %d gives %d probes > %d", step, lattice, T->max_obj);
-    hipLaunchKernelGGL(k_dense_sample, dim3(n_frames), dim3(1024), 0, st, T->d_depth + slot0 * px, T->d_flow + slot0 * px * 2, T->d_mask + slot0 * px,
+    hipLaunchKernelGGL(k_dense_sample, dim3(n_frames), dim3(1024), 0, st, (const float*)dd, fl, mk,
                        T->W, T->H, p->th_depth_obj, step, T->max_obj, T->d_okeys, T->d_ocorr, T->d_odepth, T->d_olabel, T->d_oflow, T->d_nobj);
     HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt, T->d_nstat, n_frames * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt + T->B, T->d_nobj, n_frames * 4, hipMemcpyDeviceToHost, st));
@@ -402,7 +415,7 @@ int vido_gather_static_depth(vido_ctx* ctx, int slot, const float* keys_xy, int 
     if (n == 0) return VIDO_OK;
     hipStream_t st = ctx->stream; const size_t px = (size_t)T->W * T->H;
     HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, keys_xy, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_gather_static, dim3((n + 255) / 256), dim3(256), 0, st, T->d_tmpf, n, T->d_depth + slot * px, T->W, T->H, T->d_tmpf + 2 * (size_t)n);
+    hipLaunchKernelGGL(k_gather_static, dim3((n + 255) / 256), dim3(256), 0, st, T->d_tmpf, n, T->sdepth[slot], T->W, T->H, T->d_tmpf + 2 * (size_t)n);
     HIP_TRY(ctx, hipMemcpyAsync(depth_out, T->d_tmpf + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return VIDO_OK;
@@ -416,7 +429,7 @@ int vido_gather_object_depth_label(vido_ctx* ctx, int slot, const float* keys_xy
     if (n == 0) return VIDO_OK;
     hipStream_t st = ctx->stream; const size_t px = (size_t)T->W * T->H;
     HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, keys_xy, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_gather_object, dim3((n + 255) / 256), dim3(256), 0, st, T->d_tmpf, n, T->d_depth + slot * px, T->d_mask + slot * px,
+    hipLaunchKernelGGL(k_gather_object, dim3((n + 255) / 256), dim3(256), 0, st, T->d_tmpf, n, T->sdepth[slot], T->smask[slot],
                        T->W, T->H, th_depth_obj, T->d_tmpf + 2 * (size_t)n, T->d_tmpi);
     HIP_TRY(ctx, hipMemcpyAsync(depth_out, T->d_tmpf + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(label_out, T->d_tmpi, (size_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -443,7 +456,7 @@ int vido_update_mask(vido_ctx* ctx, int slot_last, int slot_cur, const int32_t* 
         const int m = (int)corr.size() / 2;
         if (m < 100) continue;                                   // fewer than 100 in-image samples is impossible to reach with < 100 points
         HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, corr.data(), (size_t)m * 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_mask_at, dim3((m + 255) / 256), dim3(256), 0, st, T->d_tmpf, m, T->d_mask + slot_cur * px, T->W, T->H, T->d_tmpi);
+        hipLaunchKernelGGL(k_mask_at, dim3((m + 255) / 256), dim3(256), 0, st, T->d_tmpf, m, T->smask[slot_cur], T->W, T->H, T->d_tmpi);
         labs.resize(m);
         HIP_TRY(ctx, hipMemcpyAsync(labs.data(), T->d_tmpi, (size_t)m * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -453,8 +466,8 @@ int vido_update_mask(vido_ctx* ctx, int slot_last, int slot_cur, const int32_t* 
         int best = labs[0], bc = 0, run = 0;
         for (size_t j = 0; j < labs.size(); j++) { run = (j > 0 && labs[j] == labs[j - 1]) ? run + 1 : 1; if (run > bc) { bc = run; best = labs[j]; } }
         if (best != 0) continue;
-        hipLaunchKernelGGL(k_mask_scatter, dim3(1024), dim3(256), 0, st, T->d_mask + slot_last * px, T->d_flow + slot_last * px * 2,
-                           T->d_mask + slot_cur * px, T->W, T->H, lab);
+        hipLaunchKernelGGL(k_mask_scatter, dim3(1024), dim3(256), 0, st, T->smask[slot_last], T->sflow[slot_last],
+                           T->smask[slot_cur], T->W, T->H, lab);
         if (*n_recovered < cap && recovered_out) recovered_out[*n_recovered] = lab;
         (*n_recovered)++;
     }
@@ -469,9 +482,9 @@ int vido_read_maps(vido_ctx* ctx, int slot, float* depth_out, float* flow_out, i
     TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
     if (slot < 0 || slot >= T->B) return vido_set_error(ctx, VIDO_E_INVALID, "read_maps: bad slot");
     const size_t px = (size_t)T->W * T->H;
-    if (depth_out) HIP_TRY(ctx, hipMemcpyAsync(depth_out, T->d_depth + slot * px, px * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (flow_out) HIP_TRY(ctx, hipMemcpyAsync(flow_out, T->d_flow + slot * px * 2, px * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (mask_out) HIP_TRY(ctx, hipMemcpyAsync(mask_out, T->d_mask + slot * px, px * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (depth_out) HIP_TRY(ctx, hipMemcpyAsync(depth_out, T->sdepth[slot], px * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (flow_out) HIP_TRY(ctx, hipMemcpyAsync(flow_out, T->sflow[slot], px * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask_out) HIP_TRY(ctx, hipMemcpyAsync(mask_out, T->smask[slot], px * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return VIDO_OK;
 }

@@ -240,11 +240,12 @@ class FrameFeatures:
         self.ctx._check(self.ctx.lib.vido_frame_features(self.ctx.h, slot0, n, _ptr(kps), _ptr(n_kps), max_kp, C.byref(self.p), C.byref(L)))
         return o
 
-    def frontend_batch(self, slot0, imgs, depth, flow, mask):
+    def frontend_batch(self, slot0, imgs, depth, flow, mask, alias=False):
         """Fused ORB + depth pre-scale + Frame::Frame lists for a batch (vido_frontend_batch).  Every argument is either a
         host numpy array or a (device_ptr, ...) description: imgs like Context.orb_extract_batch, depth/flow/mask either all
         numpy (n,h,w[,2]) or all raw device pointers (ints).  Returns zero-copy numpy VIEWS of the ctx's pinned result
-        buffers — valid until the next call on this context."""
+        buffers — valid until the next call on this context.  alias=True (device maps only): no copies into the ctx, the caller keeps the
+        three device buffers alive until the slots are overwritten (the reference's own ownership rule)."""
         ctx = self.ctx
         if isinstance(imgs, tuple):
             ptr, n, h, w, fstride, rstride = imgs; img_dev = 1
@@ -256,7 +257,7 @@ class FrameFeatures:
             flow = np.ascontiguousarray(flow, np.float32); mask = np.ascontiguousarray(mask, np.int32)
             dp, fp, mp, maps_dev = depth.ctypes.data, flow.ctypes.data, mask.ctypes.data, 0
         else:
-            dp, fp, mp, maps_dev = int(depth), int(flow), int(mask), 1
+            dp, fp, mp, maps_dev = int(depth), int(flow), int(mask), (2 if alias else 1)     # 2: zero-copy, the slots refer to the caller's device buffers
         v = FrontendView()
         ctx._check(ctx.lib.vido_frontend_batch(ctx.h, C.c_void_p(ptr), img_dev, n, C.c_size_t(fstride), rstride, w, h, C.c_void_p(dp), C.c_void_p(fp), C.c_void_p(mp),
                                                maps_dev, slot0, C.byref(self.p), C.byref(v)))
