@@ -756,7 +756,7 @@ struct OrbState {
     uint2* d_kp = nullptr; size_t kp_cap = 0;
     // pinned host
     int* h_lvloff = nullptr; int* h_overflow = nullptr; uint32_t* h_cand = nullptr;
-    hipEvent_t ev[8] = {}; hipEvent_t ev_done = nullptr;
+    hipEvent_t ev[8] = {}; hipEvent_t ev_done = nullptr, ev_pyr = nullptr, ev_qt = nullptr;
     float timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::chrono::steady_clock::time_point t_start;
     int last_frames = 0;
@@ -925,6 +925,7 @@ int orb_state_create(vido_ctx* ctx)
     HIP_TRY(ctx, hipHostMalloc(&S->h_cand, S->cand_cap * sizeof(uint32_t)));
     for (auto& e : S->ev) HIP_TRY(ctx, hipEventCreate(&e));
     HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_done, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_pyr, hipEventDisableTiming)); HIP_TRY(ctx, hipEventCreate(&S->ev_qt));
     {   // device quadtree: the node list never exceeds budget + 3 entries (a pass stops at >= budget nodes)
         int maxN = 0; std::vector<int> bud(S->L);
         for (int l = 0; l < S->L; l++) { bud[l] = S->lv[l].n_budget; maxN = std::max(maxN, bud[l]); }
@@ -961,6 +962,8 @@ void orb_state_destroy(vido_ctx* ctx)
     hipHostFree(S->h_lvloff); hipHostFree(S->h_overflow); hipHostFree(S->h_cand);
     for (auto& e : S->ev) if (e) hipEventDestroy(e);
     if (S->ev_done) hipEventDestroy(S->ev_done);
+    if (S->ev_pyr) hipEventDestroy(S->ev_pyr);
+    if (S->ev_qt) hipEventDestroy(S->ev_qt);
     hipFree(S->d_qt_slot); hipFree(S->d_sel); hipFree(S->d_selcnt); hipFree(S->d_kpoff); hipFree(S->d_frame_beg); hipFree(S->d_budget); hipFree(S->d_kpf); hipFree(S->d_descf); hipFree(S->d_nkp);
     hipHostFree(S->h_frame_beg); hipHostFree(S->h_kpf); hipHostFree(S->h_descf);
     delete S; ctx->orb = nullptr;
@@ -995,6 +998,7 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
                            S->d_xtab + d.xtab_off, S->d_ytab + d.ytab_off, d.rs_ndw);
     }
     HIP_TRY(ctx, hipEventRecord(S->ev[1], st));
+    const int with_desc = ctx->cfg.compute_descriptors ? 1 : 0;
     hipLaunchKernelGGL(k_fast_cells, dim3(S->n_cells, nf), dim3(64), S->fast_lds, st, S->d_pyr, S->slab, S->P, S->d_cells, S->n_cells,
                        ctx->cfg.ini_th_fast, ctx->cfg.min_th_fast, S->fast_rows, S->fast_ncand, S->d_slots, S->d_counts);
     HIP_TRY(ctx, hipEventRecord(S->ev[7], st));
@@ -1002,6 +1006,15 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
                        S->d_first_cell, S->d_lvloff, S->d_overflow);
     hipLaunchKernelGGL(k_gather_cands, dim3(S->n_cells, nf), dim3(64), 0, st, S->d_slots, S->d_counts, S->d_offsets, S->n_cells, S->d_cand, (int)S->cand_cap);
     HIP_TRY(ctx, hipEventRecord(S->ev[2], st));
+    // the blur only needs the pyramid: it runs on the second stream, concurrently with the quadtree and the keypoint list kernels (512 latency-bound
+    // workgroups that leave most CUs idle; forking before FAST just makes the two full-GPU kernels contend), and joins before orientation + rBRIEF
+    if (with_desc) {
+        HIP_TRY(ctx, hipEventRecord(S->ev_pyr, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, S->ev_pyr, 0));
+        HIP_TRY(ctx, hipEventRecord(S->ev[3], ctx->stream2));
+        hipLaunchKernelGGL(k_blur7, dim3(S->n_blur_tiles, nf), dim3(256), 0, ctx->stream2, S->d_pyr, S->d_blur, S->slab, S->P, S->d_btiles);
+        HIP_TRY(ctx, hipEventRecord(S->ev[4], ctx->stream2));
+    }
     // ---- DistributeOctTree per (frame, level) + keypoint list, all on the device
     const int n_tasks = nf * L;
     static const bool dbg = getenv("VIDO_DEBUG_SYNC") != nullptr;
@@ -1014,11 +1027,8 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     hipLaunchKernelGGL(k_kp_write, dim3(n_tasks), dim3(256), 0, st, S->d_cand, S->d_lvloff, S->d_sel, S->d_selcnt, S->d_kpoff, S->qcap, L, S->d_kp, (int)S->kp_cap,
                        S->d_kpf, S->row_cap, S->d_nkp, S->kpl);
     DBG_SYNC("k_kp_write");
-    HIP_TRY(ctx, hipEventRecord(S->ev[3], st));
-    const int with_desc = ctx->cfg.compute_descriptors ? 1 : 0;
-    if (with_desc)
-        hipLaunchKernelGGL(k_blur7, dim3(S->n_blur_tiles, nf), dim3(256), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_btiles);
-    HIP_TRY(ctx, hipEventRecord(S->ev[4], st));
+    HIP_TRY(ctx, hipEventRecord(S->ev_qt, st));
+    if (with_desc) HIP_TRY(ctx, hipStreamWaitEvent(st, S->ev[4], 0));
     HIP_TRY(ctx, hipEventRecord(S->ev[5], st));
     {   // launch bound: every (frame, level) list holds at most budget + 3 nodes; the kernel reads the real count from d_frame_beg[nf]
         const size_t bound = std::min((size_t)S->row_cap * nf, S->kp_cap);
@@ -1065,8 +1075,8 @@ int orb_collect(vido_ctx* ctx, int nf, int copy)
     hipEventElapsedTime(&ms, S->ev[1], S->ev[7]); S->timing[1] = ms;
     hipEventElapsedTime(&ms, S->ev[7], S->ev[2]); S->timing[6] = ms;
     S->timing[7] = (float)S->h_lvloff[nf * L];
-    hipEventElapsedTime(&ms, S->ev[2], S->ev[3]); S->timing[2] = ms;
-    hipEventElapsedTime(&ms, S->ev[3], S->ev[4]); S->timing[3] = ms;
+    hipEventElapsedTime(&ms, S->ev[2], S->ev_qt); S->timing[2] = ms;
+    S->timing[3] = 0; if (ctx->cfg.compute_descriptors && hipEventElapsedTime(&ms, S->ev[3], S->ev[4]) == hipSuccess) S->timing[3] = ms;      // ran concurrently on stream2
     hipEventElapsedTime(&ms, S->ev[5], S->ev[6]); S->timing[4] = ms;
     S->timing[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S->t_start).count();
     return VIDO_OK;
