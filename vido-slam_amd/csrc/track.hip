@@ -22,6 +22,7 @@ struct TrackState {
     char* h_view = nullptr; size_t view_cap = 0;         // pinned lists of the fused front end (vido_frontend_batch)
     // where the maps of each slot live: the ctx's own buffers, or (zero-copy batches) the caller's device memory
     std::vector<float*> sdepth, sflow; std::vector<int32_t*> smask;
+    hipEvent_t ev_maps = nullptr, ev_cnt = nullptr;
 };
 
 // ---- kernels -------------------------------------------------------------------------------------
@@ -231,6 +232,8 @@ void track_state_destroy(vido_ctx* ctx)
     hipFree(T->d_depth); hipFree(T->d_flow); hipFree(T->d_mask); hipFree(T->d_kps); hipFree(T->d_sidx); hipFree(T->d_scorr); hipFree(T->d_sflow);
     hipFree(T->d_sdepth); hipFree(T->d_nstat); hipFree(T->d_nobj); hipFree(T->d_okeys); hipFree(T->d_ocorr); hipFree(T->d_odepth); hipFree(T->d_olabel);
     hipFree(T->d_oflow); hipFree(T->d_tmpf); hipFree(T->d_tmpi); hipHostFree(T->h_cnt); hipHostFree(T->h_stage); hipHostFree(T->h_view);
+    if (T->ev_maps) hipEventDestroy(T->ev_maps);
+    if (T->ev_cnt) hipEventDestroy(T->ev_cnt);
     delete T; ctx->trk = nullptr;
 }
 
@@ -351,56 +354,66 @@ int vido_frontend_batch(vido_ctx* ctx, const uint8_t* imgs, int imgs_on_device, 
     TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
     if (slot0 < 0 || n_frames < 1 || slot0 + n_frames > T->B || !depth || !flow || !mask)
         return vido_set_error(ctx, VIDO_E_INVALID, "frontend_batch: slots [%d,%d) outside [0,%d) or null map", slot0, slot0 + n_frames, T->B);
-    if ((rc = orb_enqueue(ctx, imgs, imgs_on_device, n_frames, frame_stride, stride, width, height))) return rc;
-    if ((rc = orb_mirror_async(ctx, n_frames))) return rc;       // keypoint / descriptor rows stream to the host while the tracking kernels run
-    hipStream_t st = ctx->stream;
+    hipStream_t st = ctx->stream, st2 = ctx->stream2;
     const size_t px = (size_t)T->W * T->H, n = px * n_frames;
     if ((n & 3) != 0) return vido_set_error(ctx, VIDO_E_INVALID, "frontend_batch: width*height must be a multiple of 4");
+    const int step = p->dense_step > 0 ? p->dense_step : 4;
+    const int lattice = ((T->W + step - 1) / step) * ((T->H + step - 1) / step);
+    if (lattice > T->max_obj) return vido_set_error(ctx, VIDO_E_INVALID, "frontend_batch: dense_step %d gives %d probes > %d", step, lattice, T->max_obj);
+    if (!T->ev_maps) { HIP_TRY(ctx, hipEventCreateWithFlags(&T->ev_maps, hipEventDisableTiming)); HIP_TRY(ctx, hipEventCreateWithFlags(&T->ev_cnt, hipEventDisableTiming)); }
     // maps_on_device == 2: zero-copy — the slots REFER to the caller's device buffers (the reference keeps shallow references to the caller's
     // depth/flow/mask Mats until the next frame, Tracking.cc:343-345, and rescales the depth in the caller's buffer); 0/1: copied into the ctx
     const bool alias = maps_on_device == 2;
     float* dd = alias ? depth : T->d_depth + slot0 * px;
     const float* fl = alias ? flow : T->d_flow + slot0 * px * 2; const int32_t* mk = alias ? mask : T->d_mask + slot0 * px;
     for (int f = 0; f < n_frames; f++) { T->sdepth[slot0 + f] = dd + (size_t)f * px; T->sflow[slot0 + f] = (float*)fl + (size_t)f * px * 2; T->smask[slot0 + f] = (int32_t*)mk + (size_t)f * px; }
+    // ---- second stream: everything that only needs the maps (pre-scale, dense object sampling) runs next to the extractor
+    HIP_TRY(ctx, hipEventRecord(T->ev_maps, st)); HIP_TRY(ctx, hipStreamWaitEvent(st2, T->ev_maps, 0));      // order behind earlier work on the main stream
     if (!alias) {
-        HIP_TRY(ctx, hipMemcpyAsync(dd, depth, n * 4, in_kind(maps_on_device), st));
-        HIP_TRY(ctx, hipMemcpyAsync(T->d_flow + slot0 * px * 2, flow, n * 8, in_kind(maps_on_device), st));
-        HIP_TRY(ctx, hipMemcpyAsync(T->d_mask + slot0 * px, mask, n * 4, in_kind(maps_on_device), st));
+        HIP_TRY(ctx, hipMemcpyAsync(dd, depth, n * 4, in_kind(maps_on_device), st2));
+        HIP_TRY(ctx, hipMemcpyAsync(T->d_flow + slot0 * px * 2, flow, n * 8, in_kind(maps_on_device), st2));
+        HIP_TRY(ctx, hipMemcpyAsync(T->d_mask + slot0 * px, mask, n * 4, in_kind(maps_on_device), st2));
     }
-    hipLaunchKernelGGL(k_depth_prescale, dim3((int)std::min<size_t>((n / 4 + 255) / 256, 2048)), dim3(256), 0, st, dd, n / 4, p->dataset, p->depth_map_factor, p->bf, p->kaist_scale);
-    if (!alias) HIP_TRY(ctx, hipMemcpyAsync(depth, dd, n * 4, maps_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));     // in-place semantics of Tracking.cc:299-322
+    hipLaunchKernelGGL(k_depth_prescale, dim3((int)std::min<size_t>((n / 4 + 255) / 256, 2048)), dim3(256), 0, st2, dd, n / 4, p->dataset, p->depth_map_factor, p->bf, p->kaist_scale);
+    if (!alias) HIP_TRY(ctx, hipMemcpyAsync(depth, dd, n * 4, maps_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st2));     // in-place semantics of Tracking.cc:299-322
+    hipLaunchKernelGGL(k_dense_sample, dim3(n_frames), dim3(1024), 0, st2, (const float*)dd, fl, mk,
+                       T->W, T->H, p->th_depth_obj, step, T->max_obj, T->d_okeys, T->d_ocorr, T->d_odepth, T->d_olabel, T->d_oflow, T->d_nobj);
+    HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt + T->B, T->d_nobj, n_frames * 4, hipMemcpyDeviceToHost, st2));
+    HIP_TRY(ctx, hipEventRecord(T->ev_maps, st2));                 // maps rescaled, object samples done
+    HIP_TRY(ctx, hipEventRecord(T->ev_cnt, st2));
+    // ---- main stream: extractor, then the static filter (needs the keypoints AND the rescaled depth)
+    if ((rc = orb_enqueue(ctx, imgs, imgs_on_device, n_frames, frame_stride, stride, width, height))) return rc;
+    // object-sample rows go to the host on the second stream while the extractor is still running (their counts are known early)
+    HIP_TRY(ctx, hipEventSynchronize(T->ev_cnt));
+    const size_t Bv = T->B, need = Bv * ((size_t)T->max_kp * 24 + (size_t)T->max_obj * 32);
+    if (need > T->view_cap) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipStreamSynchronize(st2)); if (T->h_view) HIP_TRY(ctx, hipHostFree(T->h_view)); T->view_cap = need; HIP_TRY(ctx, hipHostMalloc((void**)&T->h_view, T->view_cap)); }
+    int max_no = 0;
+    for (int f = 0; f < n_frames; f++) max_no = std::max(max_no, T->h_cnt[T->B + f]);
+    char* cur = T->h_view;
+    auto rows = [&](hipStream_t s_, const void* src, size_t pitch_el, size_t el, int width_el) -> char* {
+        char* dst = cur; cur += Bv * pitch_el * el;
+        if (width_el > 0) hipMemcpy2DAsync(dst, pitch_el * el, src, pitch_el * el, (size_t)width_el * el, n_frames, hipMemcpyDeviceToHost, s_);
+        return dst;
+    };
+    view->obj_keys = (const float*)rows(st2, T->d_okeys, T->max_obj, 8, max_no); view->obj_corr = (const float*)rows(st2, T->d_ocorr, T->max_obj, 8, max_no);
+    view->obj_depth = (const float*)rows(st2, T->d_odepth, T->max_obj, 4, max_no); view->obj_label = (const int32_t*)rows(st2, T->d_olabel, T->max_obj, 4, max_no);
+    view->obj_flow = (const float*)rows(st2, T->d_oflow, T->max_obj, 8, max_no);
+    if ((rc = orb_mirror_async(ctx, n_frames))) return rc;       // keypoint / descriptor rows stream to the host while the static filter runs
     const OrbView ov = orb_view(ctx);
     if (ov.row_cap > T->max_kp) return vido_set_error(ctx, VIDO_E_INVALID, "frontend_batch: extractor rows (%d) exceed the list capacity (%d)", ov.row_cap, T->max_kp);
+    HIP_TRY(ctx, hipStreamWaitEvent(st, T->ev_maps, 0));
     hipLaunchKernelGGL(k_static_filter, dim3(n_frames), dim3(1024), 0, st, ov.d_kpf, ov.d_nkp, ov.row_cap, T->max_kp,
                        (const float*)dd, fl, mk, T->W, T->H, p->th_depth_bg,
                        T->d_sidx, T->d_scorr, T->d_sflow, T->d_sdepth, T->d_nstat);
-    const int step = p->dense_step > 0 ? p->dense_step : 4;
-    const int lattice = ((T->W + step - 1) / step) * ((T->H + step - 1) / step);
-    if (lattice > T->max_obj) return vido_set_error(ctx, VIDO_E_INVALID, "frontend_batch: dense_step %d gives %d probes > %d", step, lattice, T->max_obj);
-    hipLaunchKernelGGL(k_dense_sample, dim3(n_frames), dim3(1024), 0, st, (const float*)dd, fl, mk,
-                       T->W, T->H, p->th_depth_obj, step, T->max_obj, T->d_okeys, T->d_ocorr, T->d_odepth, T->d_olabel, T->d_oflow, T->d_nobj);
     HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt, T->d_nstat, n_frames * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt + T->B, T->d_nobj, n_frames * 4, hipMemcpyDeviceToHost, st));
     if ((rc = orb_collect(ctx, n_frames, 0))) return rc;           // waits for everything enqueued above on the main stream
-    // pinned list rows: [frame][max_kp] (static) and [frame][max_obj] (object samples)
-    const size_t B = T->B, need = B * ((size_t)T->max_kp * 24 + (size_t)T->max_obj * 32);
-    if (need > T->view_cap) { if (T->h_view) HIP_TRY(ctx, hipHostFree(T->h_view)); T->view_cap = need; HIP_TRY(ctx, hipHostMalloc((void**)&T->h_view, T->view_cap)); }
-    int max_ns = 0, max_no = 0;
-    for (int f = 0; f < n_frames; f++) { max_ns = std::max(max_ns, T->h_cnt[f]); max_no = std::max(max_no, T->h_cnt[T->B + f]); }
-    char* cur = T->h_view;
-    auto rows = [&](const void* src, size_t pitch_el, size_t el, int width_el) -> char* {
-        char* dst = cur; cur += B * pitch_el * el;
-        if (width_el > 0) hipMemcpy2DAsync(dst, pitch_el * el, src, pitch_el * el, (size_t)width_el * el, n_frames, hipMemcpyDeviceToHost, st);
-        return dst;
-    };
+    int max_ns = 0;
+    for (int f = 0; f < n_frames; f++) max_ns = std::max(max_ns, T->h_cnt[f]);
     view->n_frames = n_frames; view->kp_pitch = ov.row_cap; view->stat_pitch = T->max_kp; view->obj_pitch = T->max_obj;
     view->kps = ov.h_kpf; view->desc = ov.h_descf; view->frame_beg = ov.h_frame_beg;
     view->n_stat = T->h_cnt; view->n_obj = T->h_cnt + T->B;
-    view->stat_idx = (const int32_t*)rows(T->d_sidx, T->max_kp, 4, max_ns); view->stat_corr = (const float*)rows(T->d_scorr, T->max_kp, 8, max_ns);
-    view->stat_flow = (const float*)rows(T->d_sflow, T->max_kp, 8, max_ns); view->stat_depth = (const float*)rows(T->d_sdepth, T->max_kp, 4, max_ns);
-    view->obj_keys = (const float*)rows(T->d_okeys, T->max_obj, 8, max_no); view->obj_corr = (const float*)rows(T->d_ocorr, T->max_obj, 8, max_no);
-    view->obj_depth = (const float*)rows(T->d_odepth, T->max_obj, 4, max_no); view->obj_label = (const int32_t*)rows(T->d_olabel, T->max_obj, 4, max_no);
-    view->obj_flow = (const float*)rows(T->d_oflow, T->max_obj, 8, max_no);
+    view->stat_idx = (const int32_t*)rows(st, T->d_sidx, T->max_kp, 4, max_ns); view->stat_corr = (const float*)rows(st, T->d_scorr, T->max_kp, 8, max_ns);
+    view->stat_flow = (const float*)rows(st, T->d_sflow, T->max_kp, 8, max_ns); view->stat_depth = (const float*)rows(st, T->d_sdepth, T->max_kp, 4, max_ns);
     HIP_TRY(ctx, hipStreamSynchronize(st));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     HIP_TRY(ctx, hipGetLastError());
