@@ -673,18 +673,20 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)      // cv::fa
 }
 
 __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t slab, PyrDev P,
-                                                      const uint2* __restrict__ kps, const int* __restrict__ frame_beg, int nf, int with_desc,
+                                                      const uint2* __restrict__ kps, const int* __restrict__ frame_beg, int f0, int f1, int with_desc,
                                                       vido_keypoint* __restrict__ kpf, uint8_t* __restrict__ descf, int row_cap, unsigned long long umax_packed)
 {
     // XCD-aware: each of the 8 XCDs (block b -> XCD b % 8) walks one contiguous eighth of the keypoint list, i.e.
     // whole frames, so the patch / pattern gathers of a frame stay in one private L2
     // (the grid is an upper bound; the real list length lives on the device)
-    const int n_kp = frame_beg[nf];
+    // this launch covers the keypoints of frames [f0, f1)
+    const int k_lo = frame_beg[f0], n_kp = frame_beg[f1] - k_lo;
     const int chunk = (((n_kp + 3) >> 2) + 7) >> 3;
     if ((int)(blockIdx.x >> 3) >= chunk) return;
     const int blk = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    const int k = blk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (k >= n_kp) return;
+    const int kk = blk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (kk >= n_kp) return;
+    const int k = k_lo + kk;
     const uint2 kp = kps[k];
     const int x = kp.x & 0xfff, y = (kp.x >> 12) & 0xfff, level = kp.x >> 24, f = kp.y;
     const int pitch = P.pitch[level];
@@ -756,7 +758,7 @@ struct OrbState {
     uint2* d_kp = nullptr; size_t kp_cap = 0;
     // pinned host
     int* h_lvloff = nullptr; int* h_overflow = nullptr; uint32_t* h_cand = nullptr;
-    hipEvent_t ev[8] = {}; hipEvent_t ev_done = nullptr, ev_pyr = nullptr, ev_qt = nullptr;
+    hipEvent_t ev[8] = {}; hipEvent_t ev_done = nullptr, ev_pyr = nullptr, ev_qt = nullptr, ev_half = nullptr; int half_frames = 0;
     float timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::chrono::steady_clock::time_point t_start;
     int last_frames = 0;
@@ -926,6 +928,7 @@ int orb_state_create(vido_ctx* ctx)
     for (auto& e : S->ev) HIP_TRY(ctx, hipEventCreate(&e));
     HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_done, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_pyr, hipEventDisableTiming)); HIP_TRY(ctx, hipEventCreate(&S->ev_qt));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_half, hipEventDisableTiming));
     {   // device quadtree: the node list never exceeds budget + 3 entries (a pass stops at >= budget nodes)
         int maxN = 0; std::vector<int> bud(S->L);
         for (int l = 0; l < S->L; l++) { bud[l] = S->lv[l].n_budget; maxN = std::max(maxN, bud[l]); }
@@ -964,6 +967,7 @@ void orb_state_destroy(vido_ctx* ctx)
     if (S->ev_done) hipEventDestroy(S->ev_done);
     if (S->ev_pyr) hipEventDestroy(S->ev_pyr);
     if (S->ev_qt) hipEventDestroy(S->ev_qt);
+    if (S->ev_half) hipEventDestroy(S->ev_half);
     hipFree(S->d_qt_slot); hipFree(S->d_sel); hipFree(S->d_selcnt); hipFree(S->d_kpoff); hipFree(S->d_frame_beg); hipFree(S->d_budget); hipFree(S->d_kpf); hipFree(S->d_descf); hipFree(S->d_nkp);
     hipHostFree(S->h_frame_beg); hipHostFree(S->h_kpf); hipHostFree(S->h_descf);
     delete S; ctx->orb = nullptr;
@@ -1030,10 +1034,18 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     HIP_TRY(ctx, hipEventRecord(S->ev_qt, st));
     if (with_desc) HIP_TRY(ctx, hipStreamWaitEvent(st, S->ev[4], 0));
     HIP_TRY(ctx, hipEventRecord(S->ev[5], st));
-    {   // launch bound: every (frame, level) list holds at most budget + 3 nodes; the kernel reads the real count from d_frame_beg[nf]
-        const size_t bound = std::min((size_t)S->row_cap * nf, S->kp_cap);
-        hipLaunchKernelGGL(k_orient_brief, dim3((unsigned)((((bound + 3) / 4) + 7) & ~(size_t)7)), dim3(256), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_kp,
-                           (const int*)S->d_frame_beg, nf, with_desc, S->d_kpf, S->d_descf, S->row_cap, S->umax_packed);
+    {   // launch bound: every (frame, level) list holds at most budget + 3 nodes; the kernel reads the real counts from d_frame_beg.
+        // Two launches (first / second half of the frames): the rows of the first half are already on their way to the host (second stream)
+        // while the second half is being computed.
+        const int fh = nf >= 8 ? nf / 2 : nf;
+        for (int part = 0; part < (fh < nf ? 2 : 1); part++) {
+            const int f0 = part ? fh : 0, f1 = part ? nf : fh;
+            const size_t bound = std::min((size_t)S->row_cap * (f1 - f0), S->kp_cap);
+            hipLaunchKernelGGL(k_orient_brief, dim3((unsigned)((((bound + 3) / 4) + 7) & ~(size_t)7)), dim3(256), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_kp,
+                               (const int*)S->d_frame_beg, f0, f1, with_desc, S->d_kpf, S->d_descf, S->row_cap, S->umax_packed);
+            if (part == 0 && fh < nf) HIP_TRY(ctx, hipEventRecord(S->ev_half, st));
+        }
+        S->half_frames = fh < nf ? fh : 0;
     }
     DBG_SYNC("k_orient_brief");
     HIP_TRY(ctx, hipEventRecord(S->ev[6], st));
@@ -1087,11 +1099,18 @@ int orb_collect(vido_ctx* ctx, int nf, int copy)
 // hipStreamSynchronize(ctx->stream2).
 int orb_mirror_async(vido_ctx* ctx, int nf)
 {
-    OrbState* S = ctx->orb;
+    OrbState* S = ctx->orb; hipStream_t s2 = ctx->stream2;
     HIP_TRY(ctx, hipEventRecord(S->ev_done, ctx->stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, S->ev_done, 0));
-    HIP_TRY(ctx, hipMemcpyAsync(S->h_kpf, S->d_kpf, (size_t)nf * S->row_cap * sizeof(vido_keypoint), hipMemcpyDeviceToHost, ctx->stream2));
-    if (ctx->cfg.compute_descriptors) HIP_TRY(ctx, hipMemcpyAsync(S->h_descf, S->d_descf, (size_t)nf * S->row_cap * 32, hipMemcpyDeviceToHost, ctx->stream2));
+    const bool desc = ctx->cfg.compute_descriptors != 0;
+    const int fh = S->half_frames;
+    if (fh > 0) {
+        HIP_TRY(ctx, hipStreamWaitEvent(s2, S->ev_half, 0));
+        HIP_TRY(ctx, hipMemcpyAsync(S->h_kpf, S->d_kpf, (size_t)fh * S->row_cap * sizeof(vido_keypoint), hipMemcpyDeviceToHost, s2));
+        if (desc) HIP_TRY(ctx, hipMemcpyAsync(S->h_descf, S->d_descf, (size_t)fh * S->row_cap * 32, hipMemcpyDeviceToHost, s2));
+    }
+    HIP_TRY(ctx, hipStreamWaitEvent(s2, S->ev_done, 0));
+    HIP_TRY(ctx, hipMemcpyAsync(S->h_kpf + (size_t)fh * S->row_cap, S->d_kpf + (size_t)fh * S->row_cap, (size_t)(nf - fh) * S->row_cap * sizeof(vido_keypoint), hipMemcpyDeviceToHost, s2));
+    if (desc) HIP_TRY(ctx, hipMemcpyAsync(S->h_descf + (size_t)fh * S->row_cap * 32, S->d_descf + (size_t)fh * S->row_cap * 32, (size_t)(nf - fh) * S->row_cap * 32, hipMemcpyDeviceToHost, s2));
     return VIDO_OK;
 }
 
