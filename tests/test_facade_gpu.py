@@ -76,8 +76,18 @@ def test_kitti_mode_runs_the_full_batch_with_object_factors(tmp_path, vido):
     scene = vido.synth.Scene3D(n_frames=n, seed=3, objects=((-2.0, 0.2, 9.0, 0.25, 0.0, 0.05),))
     cfg = write_clip(str(tmp_path), scene, n, dataset=2, factor=256.0)
     out = os.path.join(str(tmp_path), "poses.txt")
-    r = subprocess.run([driver, cfg, out, os.path.join(str(tmp_path), "res_")], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([driver, cfg, out, os.path.join(str(tmp_path), "res_")], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, VIDO_DUMP_G2O=str(tmp_path)))
     assert r.returncode == 0, r.stderr + r.stdout
+    # the graph dumps the reference writes (Optimizer.cc:1937-1939), in the vendored g2o's text format
+    for name in ("dynamic_slam_graph_before_opt.g2o", "dynamic_slam_graph_after_opt.g2o"):
+        lines = open(os.path.join(str(tmp_path), name)).read().splitlines()
+        tags = [l.split()[0] for l in lines]
+        assert tags[0] == "PARAMS_SE3OFFSET" and tags.count("EDGE_SE3_PRIOR") == 1
+        assert tags.count("VERTEX_SE3:QUAT") >= n and tags.count("VERTEX_TRACKXYZ") > 100 and tags.count("EDGE_SE3_TRACKXYZ") > 300
+        assert tags.count("EDGE_SE3_MOTION") > 10 and tags.count("EDGE_SE3:QUAT") >= n - 1
+        ids = [int(l.split()[1]) for l in lines if l.startswith("VERTEX")]
+        assert ids == list(range(1, len(ids) + 1))                                   # one running id in creation order
     ref = np.loadtxt(os.path.join(str(tmp_path), "res_refined_rgbd_new.txt"))
     assert ref.shape == (n, 17)
     for k in range(1, n):

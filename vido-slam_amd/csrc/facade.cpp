@@ -296,6 +296,54 @@ cv::Mat Optimizer::PoseOptimizationFlow2(Frame* cur, Frame* last, const std::vec
     return fromRow16(r.T);
 }
 
+// g2o text dump of the full-batch graph (the reference saves dynamic_slam_graph_{before,after}_opt.g2o, Optimizer.cc:1937-1939) with the
+// vendored g2o's tags and field order (types_slam3d.cpp:37-45; VertexSE3 / EdgeSE3 / EdgeSE3Prior / EdgeSE3PointXYZ / VertexPointXYZ ::write,
+// LandmarkMotionTernaryEdge::write types_dyn_slam3d.cpp:44-51) and its vertex numbering (one running id in creation order: per frame the
+// camera, the static points first seen there, the object motions, the dynamic points).  Written only when VIDO_DUMP_G2O names a directory.
+static void rot2quat(const double* T /*3x4*/, double* q /*x y z w*/)
+{
+    const double m00 = T[0], m01 = T[1], m02 = T[2], m10 = T[4], m11 = T[5], m12 = T[6], m20 = T[8], m21 = T[9], m22 = T[10];
+    const double tr = m00 + m11 + m22;
+    if (tr > 0) { const double s = std::sqrt(tr + 1.0) * 2; q[3] = 0.25 * s; q[0] = (m21 - m12) / s; q[1] = (m02 - m20) / s; q[2] = (m10 - m01) / s; }
+    else if (m00 > m11 && m00 > m22) { const double s = std::sqrt(1.0 + m00 - m11 - m22) * 2; q[3] = (m21 - m12) / s; q[0] = 0.25 * s; q[1] = (m01 + m10) / s; q[2] = (m02 + m20) / s; }
+    else if (m11 > m22) { const double s = std::sqrt(1.0 + m11 - m00 - m22) * 2; q[3] = (m02 - m20) / s; q[0] = (m01 + m10) / s; q[1] = 0.25 * s; q[2] = (m12 + m21) / s; }
+    else { const double s = std::sqrt(1.0 + m22 - m00 - m11) * 2; q[3] = (m10 - m01) / s; q[0] = (m02 + m20) / s; q[1] = (m12 + m21) / s; q[2] = 0.25 * s; }
+}
+static void dump_g2o(const std::string& path, const vido_ba_problem& b, const vido_ba_dynamic& d, const std::vector<std::pair<int, int> >& ptOwner, const std::vector<int>& Hfr)
+{
+    FILE* f = fopen(path.c_str(), "w"); if (!f) return;
+    std::vector<int> cu(b.n_cam), pu(b.n_pt), hu(d.n_H), du(d.n_dyn);
+    { int uid = 1; size_t ip = 0, ih = 0, id = 0;
+      for (int i = 0; i < b.n_cam; i++) {
+          cu[i] = uid++;
+          while (ip < ptOwner.size() && ptOwner[ip].first == i) pu[ip++] = uid++;
+          while (ih < Hfr.size() && Hfr[ih] == i) hu[ih++] = uid++;
+          while ((int)id < d.n_dyn && d.dyn_cam[id] == i) du[id++] = uid++;
+      } }
+    auto se3 = [&](const double* T) { double q[4]; rot2quat(T, q); fprintf(f, "%.9g %.9g %.9g %.9g %.9g %.9g %.9g ", T[3], T[7], T[11], q[0], q[1], q[2], q[3]); };
+    auto info = [&](int n, double v) { for (int i = 0; i < n; i++) for (int j = i; j < n; j++) fprintf(f, "%.9g ", i == j ? v : 0.0); };
+    fprintf(f, "PARAMS_SE3OFFSET 0 0 0 0 0 0 0 1 \n");
+    struct V { int uid, kind, idx; }; std::vector<V> vs;
+    for (int i = 0; i < b.n_cam; i++) vs.push_back(V{cu[i], 0, i});
+    for (int i = 0; i < b.n_pt; i++) vs.push_back(V{pu[i], 1, i});
+    for (int i = 0; i < d.n_H; i++) vs.push_back(V{hu[i], 2, i});
+    for (int i = 0; i < d.n_dyn; i++) vs.push_back(V{du[i], 3, i});
+    std::sort(vs.begin(), vs.end(), [](const V& a, const V& c) { return a.uid < c.uid; });
+    for (const V& v : vs) {
+        if (v.kind == 0 || v.kind == 2) { fprintf(f, "VERTEX_SE3:QUAT %d ", v.uid); se3(v.kind == 0 ? b.cam_T + 12 * (size_t)v.idx : d.H_T + 12 * (size_t)v.idx); }
+        else { const double* x = v.kind == 1 ? b.pt_xyz + 3 * (size_t)v.idx : d.dyn_xyz + 3 * (size_t)v.idx; fprintf(f, "VERTEX_TRACKXYZ %d %.9g %.9g %.9g ", v.uid, x[0], x[1], x[2]); }
+        fprintf(f, "\n");
+    }
+    if (b.prior_cam >= 0) { fprintf(f, "EDGE_SE3_PRIOR %d 0 ", cu[b.prior_cam]); se3(b.prior_T); info(6, b.info_prior); fprintf(f, "\n"); }
+    for (int k = 0; k < b.n_odo; k++) { fprintf(f, "EDGE_SE3:QUAT %d %d ", cu[b.odo_i[k]], cu[b.odo_j[k]]); se3(b.odo_T + 12 * (size_t)k); info(6, b.info_odo); fprintf(f, "\n"); }
+    for (int k = 0; k < b.n_obs; k++) { fprintf(f, "EDGE_SE3_TRACKXYZ %d %d 0 %.9g %.9g %.9g ", cu[b.obs_cam[k]], pu[b.obs_pt[k]], b.obs_meas[3 * (size_t)k], b.obs_meas[3 * (size_t)k + 1], b.obs_meas[3 * (size_t)k + 2]); info(3, b.info_obs); fprintf(f, "\n"); }
+    static const double I12[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (int k = 0; k < d.n_smooth; k++) { fprintf(f, "EDGE_SE3:QUAT %d %d ", hu[d.sm_i[k]], hu[d.sm_j[k]]); se3(I12); info(6, d.info_smooth); fprintf(f, "\n"); }
+    for (int k = 0; k < d.n_dyn; k++) { fprintf(f, "EDGE_SE3_TRACKXYZ %d %d 0 %.9g %.9g %.9g ", cu[d.dyn_cam[k]], du[k], d.dyn_meas[3 * (size_t)k], d.dyn_meas[3 * (size_t)k + 1], d.dyn_meas[3 * (size_t)k + 2]); info(3, d.info_dyn); fprintf(f, "\n"); }
+    for (int k = 0; k < d.n_tern; k++) { fprintf(f, "EDGE_SE3_MOTION %d %d %d 0 0 0 ", du[d.tern_prev[k]], du[d.tern_cur[k]], hu[d.tern_H[k]]); info(3, d.info_tern); fprintf(f, "\n"); }
+    fclose(f);
+}
+
 // Map walk of PartialBatchOptimization (Optimizer.cc:56-160, 216-350; STATIC_ONLY graph) and FullBatchOptimization (:1235-2178;
 // static + object factors) onto the flat BA problem.
 static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool global)
@@ -346,7 +394,7 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
     for (int k = 0; k < 12; k++) b.prior_T[k] = cam[k];
     vido_ba_result r;
     // ---- object part of FullBatchOptimization (STATIC_ONLY = false, Optimizer.cc:1540-1750)
-    std::vector<double> Hs, dxyz, dmeas; std::vector<int32_t> dcam, tp, tc, th, smi, smj;
+    std::vector<double> Hs, dxyz, dmeas; std::vector<int32_t> dcam, tp, tc, th, smi, smj; std::vector<int> Hfr;
     std::vector<std::vector<int> > labD(N), makD(N), Hid(std::max(N - 1, 0));
     if (global) {
         const auto& TrD = pMap->TrackletDyn;
@@ -368,7 +416,7 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
             for (size_t j = 1; j < pMap->vmRigidMotion[i - 1].size(); j++) {
                 const int hid = (int)(Hs.size() / 12);
                 static const double I12[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-                Hs.insert(Hs.end(), I12, I12 + 12);
+                Hs.insert(Hs.end(), I12, I12 + 12); Hfr.push_back(i);
                 if (i > 2) {
                     int trace = -1;
                     for (size_t k = 0; k < pMap->vnRMLabel[i - 2].size(); k++) if (pMap->vnRMLabel[i - 2][k] == pMap->vnRMLabel[i - 1][j]) { trace = (int)k; break; }
@@ -396,8 +444,11 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
     d.n_tern = (int)tp.size(); d.tern_prev = tp.data(); d.tern_cur = tc.data(); d.tern_H = th.data(); d.n_smooth = (int)smi.size(); d.sm_i = smi.data(); d.sm_j = smj.data();
     d.info_dyn = 1.0 / (double)80.f; d.info_tern = 1.0 / (double)100.f; d.info_smooth = 1.0 / (double)0.001f;                     // :1333-1338
     d.huber_dyn = d.huber_tern = d.huber_smooth = (double)0.01f;                                                              // :1358
+    const char* dump_dir = global ? getenv("VIDO_DUMP_G2O") : nullptr;
+    if (dump_dir) dump_g2o(std::string(dump_dir) + "/dynamic_slam_graph_before_opt.g2o", b, d, ptOwner, Hfr);
     if (global && (d.n_H || d.n_dyn)) check(vido_ba_optimize_dynamic(g_ctx, &b, &d, &r, nullptr, nullptr), "FullBatchOptimization");
     else check(vido_ba_optimize(g_ctx, &b, &r, nullptr, nullptr), global ? "FullBatchOptimization" : "PartialBatchOptimization");
+    if (dump_dir) dump_g2o(std::string(dump_dir) + "/dynamic_slam_graph_after_opt.g2o", b, d, ptOwner, Hfr);
     auto& poses = global ? pMap->vmCameraPose_RF : pMap->vmCameraPose;
     for (int i = start; i < N; i++) {                      // write-back, Optimizer.cc:1084-1128 / :2098-2137
         if (global && i == 0) continue;                    // the full batch writes vmCameraPose_RF[i+1] only
