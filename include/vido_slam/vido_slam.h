@@ -91,6 +91,12 @@ public:
     std::vector<std::vector<cv::Mat> > vp3DPointSta, vp3DPointDyn;
     std::vector<std::vector<int> > vnAssoSta, vnAssoDyn, vnFeatLabel;
     std::vector<std::vector<std::pair<int, int> > > TrackletSta, TrackletDyn; std::vector<int> nObjID;
+    /* Incremental tracklet store (extension).  UpdateTracklets() consumes the rows of vnAssoSta / vnAssoDyn added since the last
+       call and appends to TrackletSta / TrackletDyn / nObjID in place - same content as the reference's per-frame full rebuild (Tracking.cc:2514-2720).
+       vnTrkSta[f][k] / vnPosSta[f][k]: tracklet (of length >= 3) that owns feature k of frame f and its position in it, -1 if none; same for Dyn. */
+    void UpdateTracklets();
+    std::vector<std::vector<int> > vnTrkSta, vnPosSta, vnTrkDyn, vnPosDyn;
+    std::vector<int> trkPreSta, trkPreDyn; size_t trkRowsSta = 0, trkRowsDyn = 0;
     std::vector<cv::Mat> vmCameraPose, vmCameraPose_RF, vmCameraPose_GT;
     std::vector<std::vector<cv::Mat> > vmRigidCentre, vmRigidMotion, vmRigidMotion_RF;
     std::vector<std::vector<int> > vnRMLabel, vnSMLabel; std::vector<std::vector<bool> > vbObjStat;

@@ -45,6 +45,7 @@ def test_offline_clip_recovers_ground_truth_poses(tmp_path, vido):
     out = os.path.join(str(tmp_path), "poses.txt")
     r = subprocess.run([driver, cfg, out, os.path.join(str(tmp_path), "res_")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr + r.stdout
+    assert "incremental_equals_rebuild 1" in r.stdout, r.stdout              # Map::UpdateTracklets == GetStaticTrack / GetDynamicTrackNew rebuilds
     P = np.loadtxt(out)
     assert P.shape == (n, 17)
     assert np.allclose(P[0, 1:].reshape(4, 4), np.eye(4))                     # first frame = identity (Initialization)

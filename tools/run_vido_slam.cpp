@@ -57,6 +57,11 @@ int main(int argc, char** argv)
         SLAM.SaveResultsIJRR2020(argc > 3 ? argv[3] : "");
         Map* M = SLAM.GetMap(); double lba = 0; for (float t : M->fLBA_time) lba += t;
         std::cout << "frames " << n - start << " local-BA mean ms " << (M->fLBA_time.empty() ? 0.0 : lba / M->fLBA_time.size()) << std::endl;
+        {   // the incremental tracklet store against the reference-style full rebuild from the association tables
+            const std::vector<int> ids = M->nObjID;
+            const bool ok = SLAM.GetTracker()->GetStaticTrack() == M->TrackletSta && SLAM.GetTracker()->GetDynamicTrackNew() == M->TrackletDyn && ids == M->nObjID;
+            std::cout << "tracklets static " << M->TrackletSta.size() << " dynamic " << M->TrackletDyn.size() << " incremental_equals_rebuild " << (ok ? 1 : 0) << std::endl;
+        }
         if (!M->vfAll_time.empty()) {   // Tracking::Track stage means (the reference's all_timing layout: [0] feature, [1] camera pose, [2] scene flow/object tracking, [3] per-object motion, [4] renew + map)
             std::vector<double> acc(5, 0.0); int cnt = 0;
             for (size_t i = 2; i < M->vfAll_time.size(); i++) { for (int k = 0; k < 5 && k < (int)M->vfAll_time[i].size(); k++) acc[k] += M->vfAll_time[i][k]; cnt++; }

@@ -174,6 +174,36 @@ cv::Mat Frame::ObtainFlowDepthObject(const int& i, const bool&) { const float z 
 
 void Map::reset() { *this = Map(); }
 
+// One association table -> tracklets, incrementally.  Row i of TM maps feature j of frame i+1 to feature TM[i][j] of frame i (Tracking.cc:2530-2600).
+// The owner tables reproduce what the optimiser's label pass derives from the full list (Optimizer.cc:120-140): a feature is owned by the
+// highest-numbered tracklet of length >= 3 that contains it (only a tracklet's first element can be shared).
+static void grow_tracklets(const std::vector<std::vector<int> >& TM, const std::vector<std::vector<cv::KeyPoint> >& feat, const std::vector<std::vector<int> >* Lab,
+                           std::vector<std::vector<std::pair<int, int> > >& T, std::vector<int>* objid, std::vector<std::vector<int> >& trk, std::vector<std::vector<int> >& pos,
+                           std::vector<int>& pre, size_t& rows)
+{
+    while (trk.size() < feat.size()) { trk.emplace_back(feat[trk.size()].size(), -1); pos.emplace_back(feat[pos.size()].size(), -1); }
+    auto own = [&](int t, int k) { const std::pair<int, int>& e = T[t][k]; if (trk[e.first][e.second] <= t) { trk[e.first][e.second] = t; pos[e.first][e.second] = k; } };
+    for (; rows < TM.size(); rows++) {
+        const int i = (int)rows;
+        std::vector<int> cur(TM[i].size(), -1);
+        for (size_t j = 0; j < TM[i].size(); j++) {
+            const int m = TM[i][j]; if (m == -1) continue;
+            int t;
+            if (i > 0 && m < (int)pre.size() && pre[m] != -1) { t = pre[m]; T[t].push_back(std::make_pair(i + 1, (int)j)); }
+            else { t = (int)T.size(); T.push_back({std::make_pair(i, m), std::make_pair(i + 1, (int)j)}); if (objid) objid->push_back((*Lab)[i][j]); }
+            cur[j] = t;
+            const int len = (int)T[t].size();
+            if (len == 3) { own(t, 0); own(t, 1); own(t, 2); } else if (len > 3) own(t, len - 1);
+        }
+        pre.swap(cur);
+    }
+}
+void Map::UpdateTracklets()
+{
+    grow_tracklets(vnAssoSta, vpFeatSta, nullptr, TrackletSta, nullptr, vnTrkSta, vnPosSta, trkPreSta, trkRowsSta);
+    grow_tracklets(vnAssoDyn, vpFeatDyn, &vnFeatLabel, TrackletDyn, &nObjID, vnTrkDyn, vnPosDyn, trkPreDyn, trkRowsDyn);
+}
+
 // ---- Optimizer ---------------------------------------------------------------------------------------------------------
 cv::Mat Optimizer::Get3DinWorld(const cv::KeyPoint& f, const float& d, const cv::Mat& K, const cv::Mat& Twc)
 {
@@ -351,10 +381,10 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
     const int N = (int)pMap->vpFeatSta.size();
     if (N < 2 || WINDOW_SIZE < 1) return;
     const int start = global ? 0 : std::max(N - WINDOW_SIZE, 0), nc = N - start;
-    const auto& Tr = pMap->TrackletSta;
-    std::vector<std::vector<int> > lab(N), mak(N);
-    for (int i = 0; i < N; i++) { lab[i].assign(pMap->vpFeatSta[i].size(), -1); mak[i].assign(pMap->vpFeatSta[i].size(), -1); }
-    for (size_t t = 0; t < Tr.size(); t++) { if (Tr[t].size() < 3) continue; for (auto& pr : Tr[t]) lab[pr.first][pr.second] = (int)t; }
+    pMap->UpdateTracklets();                                  // no-op when Tracking::Track already did it for this frame
+    const auto& Tr = pMap->TrackletSta; const auto& lab = pMap->vnTrkSta;
+    std::vector<std::vector<int> > mak(N);                     // only the window's frames are touched
+    for (int i = start; i < N; i++) mak[i].assign(pMap->vpFeatSta[i].size(), -1);
     std::vector<double> cam((size_t)nc * 12), pts, meas, odo; std::vector<int32_t> oc, op, oi, oj;
     for (int i = start; i < N; i++) for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) cam[(size_t)(i - start) * 12 + r * 4 + c] = pMap->vmCameraPose[i].at<float>(r, c);
     std::vector<int> trackPoint(Tr.size(), -1); std::vector<std::pair<int, int> > ptOwner;
@@ -366,15 +396,14 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
         }
         for (size_t j = 0; j < lab[i].size(); j++) {
             const int t = lab[i][j]; if (t == -1) continue;
-            int pos = -1;
-            for (size_t k = 0; k < Tr[t].size(); k++) if (Tr[t][k].first == i && Tr[t][k].second == (int)j) { pos = (int)k; break; }
-            if (pos == -1) continue;
+            const int pos = pMap->vnPosSta[i][j];
             int pid;
             if (pos == 0) {                                   // tracklet starts inside the window: new point vertex (:290-325)
                 pid = (int)ptOwner.size(); ptOwner.push_back(std::make_pair(i, (int)j)); trackPoint[t] = pid;
                 const cv::Mat& Xw = pMap->vp3DPointSta[i][j]; for (int a = 0; a < 3; a++) pts.push_back(Xw.at<float>(a));
             } else {
-                const int pm = mak[Tr[t][pos - 1].first][Tr[t][pos - 1].second];
+                const int pf = Tr[t][pos - 1].first;
+                const int pm = pf < start ? -1 : mak[pf][Tr[t][pos - 1].second];
                 if (pm == -1) continue;                       // started before the window (:332-333)
                 pid = pm;
             }
@@ -395,11 +424,10 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
     vido_ba_result r;
     // ---- object part of FullBatchOptimization (STATIC_ONLY = false, Optimizer.cc:1540-1750)
     std::vector<double> Hs, dxyz, dmeas; std::vector<int32_t> dcam, tp, tc, th, smi, smj; std::vector<int> Hfr;
-    std::vector<std::vector<int> > labD(N), makD(N), Hid(std::max(N - 1, 0));
+    std::vector<std::vector<int> > makD(N), Hid(std::max(N - 1, 0));
     if (global) {
-        const auto& TrD = pMap->TrackletDyn;
-        for (int i = 0; i < N; i++) { labD[i].assign(pMap->vpFeatDyn[i].size(), -1); makD[i].assign(pMap->vpFeatDyn[i].size(), -1); }
-        for (size_t t = 0; t < TrD.size(); t++) { if (TrD[t].size() < 3) continue; for (auto& pr : TrD[t]) labD[pr.first][pr.second] = (int)t; }
+        const auto& TrD = pMap->TrackletDyn; const auto& labD = pMap->vnTrkDyn;
+        for (int i = 0; i < N; i++) makD[i].assign(pMap->vpFeatDyn[i].size(), -1);
         for (int i = 0; i < N - 1; i++) Hid[i].assign(pMap->vnRMLabel[i].size(), -1);
         auto add_dyn = [&](int i, int j) -> int {          // VertexPointXYZ + EdgeSE3PointXYZ of one dynamic observation (:1560-1582)
             const int id = (int)dcam.size();
@@ -426,9 +454,7 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
             }
             for (size_t j = 0; j < labD[i].size(); j++) {
                 const int t = labD[i][j]; if (t == -1) continue;
-                int pos = -1;
-                for (size_t k = 0; k < TrD[t].size(); k++) if (TrD[t][k].first == i && TrD[t][k].second == (int)j) { pos = (int)k; break; }
-                if (pos == -1) continue;
+                const int pos = pMap->vnPosDyn[i][j];
                 int hobj = -1;
                 for (size_t k = 1; k < pMap->vnRMLabel[i - 1].size(); k++) if (pMap->vnRMLabel[i - 1][k] == pMap->nObjID[t]) { hobj = Hid[i - 1][k]; break; }
                 if (hobj == -1 && pos != 0) continue;                         // no motion vertex for this object in this frame (:1668-1671)
@@ -729,7 +755,7 @@ std::vector<std::vector<std::pair<int, int> > > Tracking::GetDynamicTrackNew()  
         }
         pre = cur;
     }
-    mpMap->nObjID = ObjectID;
+    mpMap->nObjID = ObjectID;          // the same list UpdateTracklets() maintains
     return T;
 }
 
@@ -887,7 +913,7 @@ void Tracking::Track()                                        // Tracking.cc:108
         mpLastFrame = C; mpLastFrame->mvStatKeys = C->mvStatKeysTmp; mpLastFrame->mvStatDepth = C->mvStatDepthTmp; mpLastFrame->N_s = C->N_s_tmp;
         mpMap->vpFeatSta.push_back(C->mvStatKeysTmp); mpMap->vfDepSta.push_back(C->mvStatDepthTmp); mpMap->vp3DPointSta.push_back(C->mvStat3DPointTmp); mpMap->vnAssoSta.push_back(C->nStaInlierID);
         mpMap->vpFeatDyn.push_back(C->mvObjKeys); mpMap->vfDepDyn.push_back(C->mvObjDepth); mpMap->vp3DPointDyn.push_back(C->mvObj3DPoint); mpMap->vnAssoDyn.push_back(C->nDynInlierID); mpMap->vnFeatLabel.push_back(C->vObjLabel);
-        mpMap->TrackletSta = GetStaticTrack(); mpMap->TrackletDyn = GetDynamicTrackNew();
+        mpMap->UpdateTracklets();                      // incremental form of GetStaticTrack() / GetDynamicTrackNew() (Tracking.cc:1395-1400)
         cv::Mat Twc = Converter::toInvMatrix(C->mTcw);
         mpMap->vmCameraPose.push_back(Twc); mpMap->vmCameraPose_RF.push_back(Twc);
         std::vector<cv::Mat> Mot, Cen; std::vector<int> MotLab, SemLab; std::vector<bool> Stat;
