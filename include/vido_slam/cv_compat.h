@@ -8,7 +8,10 @@
 #include <cstdint>
 #include <cstring>
 #include <cstddef>
+#include <atomic>
+#include <cstdlib>
 #include <memory>
+#include <new>
 #include <vector>
 #include <stdexcept>
 
@@ -52,13 +55,22 @@ struct KeyPoint {
 class Mat {
 public:
     int rows, cols; uchar* data; size_t step;
-    Mat() : rows(0), cols(0), data(nullptr), step(0), type_(0) {}
-    Mat(int r, int c, int type) : rows(0), cols(0), data(nullptr), step(0), type_(0) { create(r, c, type); }
-    Mat(int r, int c, int type, void* ext, size_t step_ = 0) : rows(r), cols(c), data((uchar*)ext), step(step_ ? step_ : (size_t)c * esz(type)), type_(type) {}
+    Mat() : rows(0), cols(0), data(nullptr), step(0), type_(0), buf_(nullptr) {}
+    Mat(int r, int c, int type) : rows(0), cols(0), data(nullptr), step(0), type_(0), buf_(nullptr) { create(r, c, type); }
+    Mat(int r, int c, int type, void* ext, size_t step_ = 0) : rows(r), cols(c), data((uchar*)ext), step(step_ ? step_ : (size_t)c * esz(type)), type_(type), buf_(nullptr) {}
+    Mat(const Mat& o) : rows(o.rows), cols(o.cols), data(o.data), step(o.step), type_(o.type_), buf_(o.buf_) { if (buf_) buf_->fetch_add(1, std::memory_order_relaxed); }
+    Mat(Mat&& o) noexcept : rows(o.rows), cols(o.cols), data(o.data), step(o.step), type_(o.type_), buf_(o.buf_) { o.buf_ = nullptr; o.data = nullptr; o.rows = o.cols = 0; }
+    Mat& operator=(const Mat& o) { if (this != &o) { if (o.buf_) o.buf_->fetch_add(1, std::memory_order_relaxed); release(); rows = o.rows; cols = o.cols; data = o.data; step = o.step; type_ = o.type_; buf_ = o.buf_; } return *this; }
+    Mat& operator=(Mat&& o) noexcept { if (this != &o) { release(); rows = o.rows; cols = o.cols; data = o.data; step = o.step; type_ = o.type_; buf_ = o.buf_; o.buf_ = nullptr; o.data = nullptr; o.rows = o.cols = 0; } return *this; }
+    ~Mat() { release(); }
+    /* header = shared view, like cv::Mat: one malloc holds the reference count and the zero-filled pixels */
     void create(int r, int c, int type)
     {
+        release();
         rows = r; cols = c; type_ = type; step = (size_t)c * esz(type);
-        buf_.reset(new std::vector<uchar>((size_t)r * step + 16, 0)); data = buf_->data();
+        void* blk = calloc(1, kHdr + (size_t)r * step + 16);
+        if (!blk) throw std::bad_alloc();
+        buf_ = new (blk) std::atomic<int>(1); data = (uchar*)blk + kHdr;
     }
     static Mat zeros(int r, int c, int type) { return Mat(r, c, type); }
     static Mat eye(int r, int c, int type)
@@ -112,8 +124,10 @@ public:
     static size_t esz(int type) { static const size_t d[8] = {1, 1, 2, 2, 4, 4, 8, 2}; return d[type & 7] * ((type >> CV_CN_SHIFT) + 1); }
     static int depth_of(int type) { return type & 7; }
 private:
+    static constexpr size_t kHdr = 16;
+    void release() { if (buf_ && buf_->fetch_sub(1, std::memory_order_acq_rel) == 1) free((void*)buf_); buf_ = nullptr; }
     int type_;
-    std::shared_ptr<std::vector<uchar> > buf_;
+    std::atomic<int>* buf_;
 };
 
 /* CV_32F / CV_64F matrix product; like cv::gemm, float products accumulate in double */

@@ -381,13 +381,15 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
     const int N = (int)pMap->vpFeatSta.size();
     if (N < 2 || WINDOW_SIZE < 1) return;
     const int start = global ? 0 : std::max(N - WINDOW_SIZE, 0), nc = N - start;
+    const float invfx = 1.0f / K.at<float>(0, 0), invfy = 1.0f / K.at<float>(1, 1), kcx = K.at<float>(0, 2), kcy = K.at<float>(1, 2);
     pMap->UpdateTracklets();                                  // no-op when Tracking::Track already did it for this frame
     const auto& Tr = pMap->TrackletSta; const auto& lab = pMap->vnTrkSta;
     std::vector<std::vector<int> > mak(N);                     // only the window's frames are touched
     for (int i = start; i < N; i++) mak[i].assign(pMap->vpFeatSta[i].size(), -1);
     std::vector<double> cam((size_t)nc * 12), pts, meas, odo; std::vector<int32_t> oc, op, oi, oj;
     for (int i = start; i < N; i++) for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) cam[(size_t)(i - start) * 12 + r * 4 + c] = pMap->vmCameraPose[i].at<float>(r, c);
-    std::vector<int> trackPoint(Tr.size(), -1); std::vector<std::pair<int, int> > ptOwner;
+    std::vector<std::pair<int, int> > ptOwner;
+    { size_t cap = 0; for (int i = start; i < N; i++) cap += lab[i].size(); oc.reserve(cap); op.reserve(cap); meas.reserve(3 * cap); }
     for (int i = start; i < N; i++) {
         if (i != start) {
             const cv::Mat& M = pMap->vmRigidMotion[i - 1][0];
@@ -399,7 +401,7 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
             const int pos = pMap->vnPosSta[i][j];
             int pid;
             if (pos == 0) {                                   // tracklet starts inside the window: new point vertex (:290-325)
-                pid = (int)ptOwner.size(); ptOwner.push_back(std::make_pair(i, (int)j)); trackPoint[t] = pid;
+                pid = (int)ptOwner.size(); ptOwner.push_back(std::make_pair(i, (int)j));
                 const cv::Mat& Xw = pMap->vp3DPointSta[i][j]; for (int a = 0; a < 3; a++) pts.push_back(Xw.at<float>(a));
             } else {
                 const int pf = Tr[t][pos - 1].first;
@@ -408,8 +410,8 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
                 pid = pm;
             }
             mak[i][j] = pid;
-            cv::Mat Xc = Optimizer::Get3DinCamera(pMap->vpFeatSta[i][j], pMap->vfDepSta[i][j], K);
-            oc.push_back(i - start); op.push_back(pid); for (int a = 0; a < 3; a++) meas.push_back(Xc.at<float>(a));
+            const cv::KeyPoint& f = pMap->vpFeatSta[i][j]; const float z = pMap->vfDepSta[i][j];                  // Optimizer::Get3DinCamera, inlined
+            oc.push_back(i - start); op.push_back(pid); meas.push_back((f.pt.x - kcx) * z * invfx); meas.push_back((f.pt.y - kcy) * z * invfy); meas.push_back(z);
         }
     }
     if (pts.empty()) return;
@@ -432,8 +434,8 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
         auto add_dyn = [&](int i, int j) -> int {          // VertexPointXYZ + EdgeSE3PointXYZ of one dynamic observation (:1560-1582)
             const int id = (int)dcam.size();
             const cv::Mat& Xw = pMap->vp3DPointDyn[i][j]; for (int a = 0; a < 3; a++) dxyz.push_back(Xw.at<float>(a));
-            cv::Mat Xc = Optimizer::Get3DinCamera(pMap->vpFeatDyn[i][j], pMap->vfDepDyn[i][j], K);
-            for (int a = 0; a < 3; a++) dmeas.push_back(Xc.at<float>(a));
+            const cv::KeyPoint& f = pMap->vpFeatDyn[i][j]; const float z = pMap->vfDepDyn[i][j];
+            dmeas.push_back((f.pt.x - kcx) * z * invfx); dmeas.push_back((f.pt.y - kcy) * z * invfy); dmeas.push_back(z);
             dcam.push_back(i); makD[i][j] = id;
             return id;
         };
@@ -474,6 +476,9 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
     if (dump_dir) dump_g2o(std::string(dump_dir) + "/dynamic_slam_graph_before_opt.g2o", b, d, ptOwner, Hfr);
     if (global && (d.n_H || d.n_dyn)) check(vido_ba_optimize_dynamic(g_ctx, &b, &d, &r, nullptr, nullptr), "FullBatchOptimization");
     else check(vido_ba_optimize(g_ctx, &b, &r, nullptr, nullptr), global ? "FullBatchOptimization" : "PartialBatchOptimization");
+    if (getenv("VIDO_BA_VERBOSE"))
+        fprintf(stderr, "[batch %s] cams %d pts %d obs %d | H %d dyn %d tern %d smooth %d | iters %d trials %d chi2 %.6g -> %.6g | setup %.2f ms loop %.2f ms\n", global ? "full" : "partial",
+                b.n_cam, b.n_pt, b.n_obs, d.n_H, d.n_dyn, d.n_tern, d.n_smooth, r.iterations, r.lm_trials, r.chi2_initial, r.chi2_final, r.ms_setup, r.ms_solve_loop);
     if (dump_dir) dump_g2o(std::string(dump_dir) + "/dynamic_slam_graph_after_opt.g2o", b, d, ptOwner, Hfr);
     auto& poses = global ? pMap->vmCameraPose_RF : pMap->vmCameraPose;
     for (int i = start; i < N; i++) {                      // write-back, Optimizer.cc:1084-1128 / :2098-2137
