@@ -40,7 +40,8 @@ struct BaDev {
     const int *slot_cam;                                    // [n_obs] camera of each landmark-major slot
     const int *odo_i, *odo_j; const double* odo_T; double prior_T[12];
     double *W;                                              // [n_obs*18] landmark-major
-    double *Hpp, *bp;                                       // [n_ptl*6], [n_ptl*3]
+    double *Hpp, *bp;                                       // [n_ptl*6], [n_ptl*3]: summed from Cp by k_ba_schur (no atomics)
+    double *Cp;                                             // [n_obs*9] landmark-major: point-side terms of one observation (Hpp 6 | bp 3)
     double *Hcd, *bc, *Hodo;                                // [n_cam*36], [n6], [n_odo*36]
     double *S, *r, *x;                                      // [n6*n6], [n6], [n6]
     double *scal;                                           // [8]: 0 chi2 1 maxdiag 2 tempChi 3 scale 4 ok
@@ -138,43 +139,71 @@ __device__ __forceinline__ void inv3sym(const double* H6 /*00 01 02 11 12 22*/, 
 }
 
 // ---- linearisation -----------------------------------------------------------------------------------
-// Every wave walks E consecutive groups of 64 observations (sorted by camera, so a wave normally sees one camera) and keeps the 28 camera-side
-// sums in registers across the groups: the 28-value wave reduction (336 cross-lane FP64 shuffles — two thirds of this kernel's time when it
-// was done per group) and the atomics onto the few camera blocks happen once per camera change instead of once per 64 observations.
-__device__ __forceinline__ void ba_flush_cam(const BaDev& P, int c, double* acc, int lane)
+// FP64 atomics that land on one cache line serialise in L2 (~45 ns each), so the kernel is built to issue almost none of them:
+//  * point side: the 9 terms of an observation go to its landmark-major slot (Cp, next to W) with plain stores; k_ba_schur, which walks a
+//    landmark's slots anyway, sums them (a 17-observation track was 17 atomics per address before).
+//  * camera side: observations are sorted by camera.  Every wave walks E consecutive groups of 64 observations and keeps the 28 sums in
+//    registers across them; a group that straddles two cameras is folded camera by camera with lane masks (64 lanes issuing atomics onto the
+//    same 43 addresses made one such wave the 30 us long pole of a 35k-edge launch).  On a camera change the wave sum goes to one of
+//    LIN_SLOTS LDS accumulators of the workgroup (8 waves = 512 observations rarely see more than two cameras); the workgroup issues one
+//    set of 43 atomics per camera it saw.
+#define LIN_SLOTS 4
+#define LIN_THREADS 512
+// Transposing wave reduction: N per-lane values -> every lane ends up holding the wave sum of ONE of them.  Each step halves the number of
+// values a lane carries by trading the half it does not keep with lane ^ O: 29 double shuffles for 28 values instead of 168 for 28 butterflies
+// (ds_bpermute goes through the CU's LDS pipe, which the 8 waves of the workgroup share — the butterflies were 40 % of the kernel).
+template <int N, int O>
+__device__ __forceinline__ void wave_halve(double* v, int lane)
 {
+    constexpr int H = (N + 1) / 2;
+    const bool up = (lane & O) != 0;
 #pragma unroll
-    for (int a = 0; a < 28; a++) {
-        double v = acc[a];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-        acc[a] = v;
+    for (int a = 0; a < H; a++) {
+        const double lo = v[a], hi = (a + H < N) ? v[a + H] : 0.0;
+        const double send = up ? lo : hi, keep = up ? hi : lo;
+        v[a] = keep + __shfl_xor(send, O, 64);
     }
-    if (lane == 0) {
-        int q = 0;
-        for (int a = 0; a < 6; a++) { atomicAdd(P.bc + 6 * c + a, acc[21 + a]); for (int b = a; b < 6; b++) { atomicAdd(P.Hcd + 36 * c + a * 6 + b, acc[q]); if (b != a) atomicAdd(P.Hcd + 36 * c + b * 6 + a, acc[q]); q++; } }
-        atomicAdd(P.scal + 0, acc[27]);
+}
+// camera-side sums of a wave -> LDS accumulator of the workgroup (or HBM atomics when the camera is outside the workgroup's slots)
+__device__ __forceinline__ void ba_flush_cam(const BaDev& P, int c, int cam0, double* lsum, int* lused, double* acc, int lane)
+{
+    wave_halve<28, 32>(acc, lane); wave_halve<14, 16>(acc, lane); wave_halve<7, 8>(acc, lane); wave_halve<4, 4>(acc, lane); wave_halve<2, 2>(acc, lane);
+    const double sum = acc[0] + __shfl_xor(acc[0], 1, 64);
+    const int sub = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    const int v = ((lane >> 5) & 1) * 14 + ((lane >> 4) & 1) * 7 + sub;          // which of the 28 sums this lane holds
+    if (!(lane & 1) && sub < 7) {
+        const int slot = c - cam0;
+        if (slot >= 0 && slot < LIN_SLOTS) { if (v == 0) lused[slot] = 1; atomicAdd(lsum + slot * 28 + v, sum); }       // ds_add_f64
+        else if (v < 21) { int a = 0, t = v; while (t >= 6 - a) { t -= 6 - a; a++; } const int b = a + t; atomicAdd(P.Hcd + 36 * c + a * 6 + b, sum); if (b != a) atomicAdd(P.Hcd + 36 * c + b * 6 + a, sum); }
+        else if (v < 27) atomicAdd(P.bc + 6 * c + (v - 21), sum);
+        else atomicAdd(P.scal + 0, sum);
     }
 #pragma unroll
     for (int a = 0; a < 28; a++) acc[a] = 0;
 }
-__global__ __launch_bounds__(256) void k_ba_linearize(BaDev P, int E)
+__global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
 {
+    __shared__ double lsum[LIN_SLOTS * 28];
+    __shared__ int lused[LIN_SLOTS];
     const int lane = threadIdx.x & 63;
-    const size_t wave_g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t wave_g = (size_t)blockIdx.x * (LIN_THREADS / 64) + (threadIdx.x >> 6);
+    if (threadIdx.x < LIN_SLOTS * 28) lsum[threadIdx.x] = 0;
+    if (threadIdx.x < LIN_SLOTS) lused[threadIdx.x] = 0;
+    const int cam0 = P.obs_cam[min((size_t)blockIdx.x * (LIN_THREADS / 64) * E * 64, (size_t)P.n_obs - 1)];     // first camera of the workgroup
+    __syncthreads();
     double acc[28];
 #pragma unroll
     for (int a = 0; a < 28; a++) acc[a] = 0;
     int acc_cam = -1;                                            // camera the register sums belong to (wave-uniform)
-    for (int j = 0; j < E; j++) {
+    for (int j = 0; j <= E; j++) {                               // j == E: sentinel pass that flushes the last camera
         const size_t k = (wave_g * E + j) * 64 + lane;
-        const bool act = k < (size_t)P.n_obs;
-        int c = -1, l = 0;
+        const bool act = j < E && k < (size_t)P.n_obs;
+        int c = -1;
         double con[28];
 #pragma unroll
         for (int a = 0; a < 28; a++) con[a] = 0;
         if (act) {
-            c = P.obs_cam[k]; l = P.obs_pt[k];
+            c = P.obs_cam[k]; const int l = P.obs_pt[k];
             const double* X = P.cam + 12 * c; const double* p = P.pt + 3 * l; const double* m = P.obs_meas + 3 * (size_t)k;
             const double R00 = X[0], R01 = X[1], R02 = X[2], R10 = X[4], R11 = X[5], R12 = X[6], R20 = X[8], R21 = X[9], R22 = X[10];
             const double d0 = p[0] - X[3], d1 = p[1] - X[7], d2 = p[2] - X[11];
@@ -194,36 +223,42 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BaDev P, int E)
                 for (int b = a; b < 6; b++) con[q++] = wo * (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b] + Jc[12 + a] * Jc[12 + b]);
             }
             con[27] = r0;
-            double* Wk = P.W + 18 * (size_t)P.obs_pos[k];
+            const size_t slot = (size_t)P.obs_pos[k];
+            double* Wk = P.W + 18 * slot;
 #pragma unroll
             for (int a = 0; a < 6; a++)
 #pragma unroll
                 for (int b = 0; b < 3; b++) Wk[a * 3 + b] = wo * (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b]);
-            double* Hp = P.Hpp + 6 * (size_t)l; double* bpp = P.bp + 3 * (size_t)l;
+            double* Ck = P.Cp + 9 * slot;
             q = 0;
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-                atomicAdd(bpp + a, -wo * (Jp[a] * e[0] + Jp[3 + a] * e[1] + Jp[6 + a] * e[2]));
+                Ck[6 + a] = -wo * (Jp[a] * e[0] + Jp[3 + a] * e[1] + Jp[6 + a] * e[2]);
 #pragma unroll
-                for (int b = a; b < 3; b++) atomicAdd(Hp + q++, wo * (Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b] + Jp[6 + a] * Jp[6 + b]));
+                for (int b = a; b < 3; b++) Ck[q++] = wo * (Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b] + Jp[6 + a] * Jp[6 + b]);
             }
         }
-        // camera of this group: uniform over the active lanes?
-        const int c0 = __shfl(c, 0, 64);
-        const bool any = __any(act);
-        const bool uniform = any && c0 >= 0 && __all(c == c0 || !act);
-        if (uniform) {
-            if (acc_cam >= 0 && acc_cam != c0) ba_flush_cam(P, acc_cam, acc, lane);
-            acc_cam = c0;
+        // fold the group into the register sums, one camera at a time (cameras are non-decreasing along the lanes)
+        unsigned long long rem = j < E ? __ballot(act) : 1ull;
+        while (rem) {
+            const int cc = j < E ? __shfl(c, __ffsll((long long)rem) - 1, 64) : -1;
+            if (acc_cam != cc) { if (acc_cam >= 0) ba_flush_cam(P, acc_cam, cam0, lsum, lused, acc, lane); acc_cam = cc; }
+            if (j == E) break;
+            const bool sel = act && c == cc;
 #pragma unroll
-            for (int a = 0; a < 28; a++) acc[a] += con[a];
-        } else if (act) {                                         // a group that straddles two cameras: per-observation atomics
-            int q = 0;
-            for (int a = 0; a < 6; a++) { atomicAdd(P.bc + 6 * c + a, con[21 + a]); for (int b = a; b < 6; b++) { atomicAdd(P.Hcd + 36 * c + a * 6 + b, con[q]); if (b != a) atomicAdd(P.Hcd + 36 * c + b * 6 + a, con[q]); q++; } }
-            atomicAdd(P.scal + 0, con[27]);
+            for (int a = 0; a < 28; a++) acc[a] += sel ? con[a] : 0.0;
+            rem &= ~__ballot(sel);
         }
     }
-    if (acc_cam >= 0) ba_flush_cam(P, acc_cam, acc, lane);
+    __syncthreads();
+    // one thread per (slot, entry of the 6x6 block | bc | chi2): 43 atomics per camera the workgroup saw
+    for (int t = threadIdx.x; t < LIN_SLOTS * 43; t += LIN_THREADS) {
+        const int slot = t / 43, e = t - slot * 43, c = cam0 + slot;
+        if (!lused[slot]) continue;
+        if (e < 36) { const int a = e / 6, b = e - a * 6, lo = min(a, b), hi = max(a, b); atomicAdd(P.Hcd + 36 * c + e, lsum[slot * 28 + lo * 6 - lo * (lo - 1) / 2 + (hi - lo)]); }
+        else if (e < 42) atomicAdd(P.bc + 6 * c + (e - 36), lsum[slot * 28 + 21 + (e - 36)]);
+        else atomicAdd(P.scal + 0, lsum[slot * 28 + 27]);
+    }
 }
 
 // odometry edges (k < n_odo) and the prior (k == n_odo): one wave per factor, lane a*6+b owns entry (a,b) of the
@@ -262,7 +297,11 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev P, int n_ptl)
     double m = 0;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
     for (int a = tid; a < P.n6; a += nt) m = fmax(m, fabs(P.Hcd[36 * (a / 6) + 7 * (a % 6)]));
-    for (int l = tid; l < n_ptl; l += nt) m = fmax(m, fmax(fabs(P.Hpp[6 * (size_t)l]), fmax(fabs(P.Hpp[6 * (size_t)l + 3]), fabs(P.Hpp[6 * (size_t)l + 5]))));
+    for (int l = tid; l < n_ptl; l += nt) {          // runs before k_ba_schur has summed Hpp: diagonal of the landmark block from its slots
+        double h0 = 0, h3 = 0, h5 = 0;
+        for (int i = P.pt_start[l]; i < P.pt_start[l + 1]; i++) { h0 += P.Cp[9 * (size_t)i]; h3 += P.Cp[9 * (size_t)i + 3]; h5 += P.Cp[9 * (size_t)i + 5]; }
+        m = fmax(m, fmax(fabs(h0), fmax(fabs(h3), fabs(h5))));
+    }
     if (n_ptl >= 0) for (int l = tid; l < P.n_dyn; l += nt) m = fmax(m, fmax(fabs(P.Vd[6 * (size_t)l]), fmax(fabs(P.Vd[6 * (size_t)l + 3]), fabs(P.Vd[6 * (size_t)l + 5]))));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
@@ -324,8 +363,25 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev P, int n_ptl, double lam
         for (int lp = l_beg; lp < l_end; lp += l_step) {
             const int l = MODE == 2 ? lorder[lp] : lp;
             const int beg = P.pt_start[l], k = min(P.pt_start[l + 1] - beg, kcap);
-            double Di[9]; inv3sym(P.Hpp + 6 * (size_t)l, lambda, Di);
-            const double b0 = P.bp[3 * (size_t)l], b1 = P.bp[3 * (size_t)l + 1], b2 = P.bp[3 * (size_t)l + 2];
+            // point-side block of the landmark = sum of its slots' terms (lane i holds slot i, tracks have <= 64 observations); kept for the
+            // back-substitution
+            double H6[9];
+            { const int cnt = P.pt_start[l + 1] - beg;
+#pragma unroll
+              for (int a = 0; a < 9; a++) H6[a] = lane < cnt ? P.Cp[9 * (size_t)(beg + lane) + a] : 0.0;
+#pragma unroll
+              for (int a = 0; a < 9; a++) {
+#pragma unroll
+                  for (int o = 32; o >= 1; o >>= 1) H6[a] += __shfl_xor(H6[a], o, 64);
+              }
+              if (lane == 0) {
+#pragma unroll
+                  for (int a = 0; a < 6; a++) P.Hpp[6 * (size_t)l + a] = H6[a];
+#pragma unroll
+                  for (int a = 0; a < 3; a++) P.bp[3 * (size_t)l + a] = H6[6 + a];
+              } }
+            const double b0 = H6[6], b1 = H6[7], b2 = H6[8];
+            double Di[9]; inv3sym(H6, lambda, Di);
             double* Wl = stage; double* WDl = stage + kcap * 18;
             for (int t = lane; t < k * 18; t += 64) Wl[t] = P.W[18 * (size_t)beg + t];
             __builtin_amdgcn_wave_barrier();
@@ -952,26 +1008,37 @@ __global__ void k_ba_update_cams(BaDev P, double lambda)
     if ((threadIdx.x & 63) == 0 && sc != 0) atomicAdd(P.scal + 3, sc);
 }
 // x_l = D^-1 (b_l - sum_i W_i^T x_ci), p_new = p + x_l; landmark part of computeScale
+// 8 lanes per landmark: lane `sub` walks slots beg+sub, beg+sub+8, ... (a 17-observation track is 3 trips of the dependent slot_cam -> x
+// load chain instead of 17), the three partial sums meet through xor 1|2|4 shuffles.
 __global__ __launch_bounds__(256) void k_ba_backsub(BaDev P, int n_ptl, double lambda)
 {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x, l = g >> 3, sub = g & 7;
     double sc = 0;
-    if (l < n_ptl) {
-        double t0 = P.bp[3 * (size_t)l], t1 = P.bp[3 * (size_t)l + 1], t2 = P.bp[3 * (size_t)l + 2];
-        const double b0 = t0, b1 = t1, b2 = t2;
-        for (int s = P.pt_start[l]; s < P.pt_start[l + 1]; s++) {
+    const bool on = l < n_ptl;
+    double t0 = 0, t1 = 0, t2 = 0;
+    if (on) {
+        for (int s = P.pt_start[l] + sub; s < P.pt_start[l + 1]; s += 8) {
             const double* W = P.W + 18 * (size_t)s; const double* xc = P.x + 6 * P.slot_cam[s];
 #pragma unroll
             for (int a = 0; a < 6; a++) { t0 -= W[a * 3] * xc[a]; t1 -= W[a * 3 + 1] * xc[a]; t2 -= W[a * 3 + 2] * xc[a]; }
         }
+    }
+#pragma unroll
+    for (int o = 4; o >= 1; o >>= 1) { t0 += __shfl_xor(t0, o, 64); t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+    if (on && sub == 0) {
+        const double b0 = P.bp[3 * (size_t)l], b1 = P.bp[3 * (size_t)l + 1], b2 = P.bp[3 * (size_t)l + 2];
+        t0 += b0; t1 += b1; t2 += b2;
         double Di[9]; inv3sym(P.Hpp + 6 * (size_t)l, lambda, Di);
         const double x0 = Di[0] * t0 + Di[1] * t1 + Di[2] * t2, x1 = Di[3] * t0 + Di[4] * t1 + Di[5] * t2, x2 = Di[6] * t0 + Di[7] * t1 + Di[8] * t2;
         P.pt_new[3 * (size_t)l] = P.pt[3 * (size_t)l] + x0; P.pt_new[3 * (size_t)l + 1] = P.pt[3 * (size_t)l + 1] + x1; P.pt_new[3 * (size_t)l + 2] = P.pt[3 * (size_t)l + 2] + x2;
         sc = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
     }
+    __shared__ double wsum[4];               // one atomic per workgroup: same-address FP64 atomics serialise in L2
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(P.scal + 3, sc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(P.scal + 3, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
 }
 __global__ __launch_bounds__(256) void k_ba_chi2(BaDev P, const double* cam, const double* pt, double* out)
 {
@@ -1445,7 +1512,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (int t = 0; t < no; t++) { opos[t] = fill[opt[t]]++; slotcam[opos[t]] = ocam[t]; } }
     // ---- device buffers
     {   // size the persistent pool (device + pinned mirror for the uploads) for this problem
-        const size_t ndb = (size_t)n_pose * (24 + 36 + 36) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + 18) + (size_t)n_cc * (12 + 36 + 2) + (size_t)n6 * n6 + 5 * (size_t)n6 + 64 +
+        const size_t ndb = (size_t)n_pose * (24 + 36 + 36) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + 18 + 9) + (size_t)n_cc * (12 + 36 + 2) + (size_t)n6 * n6 + 5 * (size_t)n6 + 64 +
                            (size_t)nd * (3 + 3 + 3 + 6 + 3 + 9 + 18 * 4 + 3);
         const size_t ni32 = 4 * (size_t)no + 2 * (size_t)n_ptl + (size_t)n_ptl / 32 + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 256;
         const size_t need = ndb * 8 + ni32 * 4 + 96 * 256;
@@ -1468,7 +1535,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     D.obs_meas = A.put(omeas.data(), (size_t)no * 3, st); D.pt_start = A.put(pstart.data(), n_ptl + 1, st); D.slot_cam = A.put(slotcam.data(), no, st);
     D.odo_i = A.put(cc_i.data(), n_cc, st); D.odo_j = A.put(cc_j.data(), n_cc, st); D.odo_T = A.put(cc_T.data(), (size_t)n_cc * 12, st);
     D.odo_info = A.put(cc_info.data(), n_cc, st); D.odo_delta = A.put(cc_delta.data(), n_cc, st);
-    D.W = A.get<double>((size_t)no * 18); D.Hpp = A.get<double>((size_t)n_ptl * 6); D.bp = A.get<double>((size_t)n_ptl * 3);
+    D.W = A.get<double>((size_t)no * 18); D.Cp = A.get<double>((size_t)no * 9); D.Hpp = A.get<double>((size_t)n_ptl * 6); D.bp = A.get<double>((size_t)n_ptl * 3);
     D.Hodo = A.get<double>((size_t)n_cc * 36);
     // object part
     D.n_dyn = nd; D.n_chain = n_chain; D.info_dyn = dy.info_dyn; D.info_tern = dy.info_tern; D.huber_dyn = dy.huber_dyn; D.huber_tern = dy.huber_tern;
@@ -1580,10 +1647,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     for (it = 0; it < p.max_iters; it++) {
         // ---- linearise
         HIP_TRY(ctx, hipMemsetAsync(red, 0, ((size_t)n_pose * 36 + n6 + 8) * sizeof(double), st));
-        HIP_TRY(ctx, hipMemsetAsync(D.Hpp, 0, (size_t)n_ptl * 6 * sizeof(double), st));
-        HIP_TRY(ctx, hipMemsetAsync(D.bp, 0, (size_t)n_ptl * 3 * sizeof(double), st));
         HIP_TRY(ctx, hipEventRecord(BS->ev0, st));
-        if (no) hipLaunchKernelGGL(k_ba_linearize, dim3((no + 256 * lin_E - 1) / (256 * lin_E)), dim3(256), 0, st, D, lin_E);
+        if (no) hipLaunchKernelGGL(k_ba_linearize, dim3((no + LIN_THREADS * lin_E - 1) / (LIN_THREADS * lin_E)), dim3(LIN_THREADS), 0, st, D, lin_E);
         HIP_TRY(ctx, hipEventRecord(BS->ev1, st));
         if (nd) hipLaunchKernelGGL(k_badyn_linearize, dim3((nd + 255) / 256), dim3(256), 0, st, D);
         n_lin++;
@@ -1637,7 +1702,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             // ---- trial state + its chi2
             hipLaunchKernelGGL(k_ba_update_cams, dim3((n_pose + 63) / 64), dim3(64), 0, st, D, (allreduce && p.rank != 0) ? 0.0 : lambda);
             if (allreduce && p.rank != 0) HIP_TRY(ctx, hipMemsetAsync(D.scal + 3, 0, sizeof(double), st));      // camera part of computeScale counted once (rank 0)
-            if (n_ptl) hipLaunchKernelGGL(k_ba_backsub, dim3((n_ptl + 255) / 256), dim3(256), 0, st, D, n_ptl, lambda);
+            if (n_ptl) hipLaunchKernelGGL(k_ba_backsub, dim3((n_ptl + 31) / 32), dim3(256), 0, st, D, n_ptl, lambda);
             if (no) hipLaunchKernelGGL(k_ba_chi2, dim3((no + 255) / 256), dim3(256), 0, st, D, D.cam_new, D.pt_new, D.scal + 2);
             if (nd) { hipLaunchKernelGGL(k_badyn_backsub, dim3((n_chain + 63) / 64), dim3(64), 0, st, D, lambda);
                       hipLaunchKernelGGL(k_badyn_chi2, dim3((nd + 255) / 256), dim3(256), 0, st, D, (const double*)D.cam_new, (const double*)D.dyn_new, D.scal + 2); }
