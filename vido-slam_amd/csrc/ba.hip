@@ -735,7 +735,35 @@ __device__ __forceinline__ bool chol6(const double* A /*21: row-major lower*/, d
     }
     return good;
 }
-__global__ __launch_bounds__(1024) void k_chol_band6(BaDev P, int bwc /* block half-bandwidth: bw = 6*bwc + 5 */)
+// 12 waves: 168 VGPRs per lane (the pivot block, its factor and a 3x6 tile with its operands do not fit the 128 of a 1024-thread group)
+#define CH_NT 768
+// lane t of a writer wave picks entry t of (Lk[21] | zk[6]) with a select chain: compile-time register indices (a dynamic Lk[t] would push the
+// arrays to scratch) and no branches (27 predicated blocks cost the writer wave ~1300 cycles of taken-branch bubbles per pivot)
+__device__ __forceinline__ double pick27(const double* Lk, const double* zk, int t)
+{
+    double val = zk[5];
+#pragma unroll
+    for (int i = 0; i < 21; i++) val = (t == i) ? Lk[i] : val;
+#pragma unroll
+    for (int c = 0; c < 5; c++) val = (t == 21 + c) ? zk[c] : val;
+    return val;
+}
+// 3x6 half tile of the trailing update: out[a][b] = sum_c Li[a][c] * Lj[b][c] from the panel rows in LDS (pitch 7): 54 LDS reads per 108 FMAs
+// (one thread per (row, column block) re-read the 36 values of Lj for every row: the update ran at the LDS bandwidth limit)
+__device__ __forceinline__ void tile36(const double* Li, const double* Lj, double (*o)[6])
+{
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 6; b++) o[a][b] = 0.0;
+#pragma unroll 2
+    for (int c = 0; c < 6; c++) {
+        const double l0 = Li[c], l1 = Li[7 + c], l2 = Li[14 + c];
+#pragma unroll
+        for (int b = 0; b < 6; b++) { const double lj = Lj[b * 7 + c]; o[0][b] += l0 * lj; o[1][b] += l1 * lj; o[2][b] += l2 * lj; }
+    }
+}
+__global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block half-bandwidth: bw = 6*bwc + 5 */)
 {
     extern __shared__ double cb6[];
     const int Wb = bwc + 1, Wr = 6 * Wb, ldw = Wr + 1;
@@ -753,18 +781,26 @@ __global__ __launch_bounds__(1024) void k_chol_band6(BaDev P, int bwc /* block h
     int boff = 0;
     {   // block rows [0, min(nblk, Wb)) enter
         const int kb = 0;
-        for (int t = tid; t < min(nblk, Wb) * 6 * Wr; t += 1024) {
+        for (int t = tid; t < min(nblk, Wb) * 6 * Wr; t += CH_NT) {
             const int i = t / Wr, jj = t - i * Wr, ib = i / 6, j = 6 * (ib - bwc) + jj;          // jj-th in-band column slot of row i (by block)
             if (j >= 0 && j <= i) W[(6 * PB(ib) + i % 6) * ldw + 6 * PB(j / 6) + j % 6] = AB(i, j);
         }
-        for (int i = tid; i < min(nblk, Wb) * 6; i += 1024) rW[6 * PB(i / 6) + i % 6] = r[i];
+        for (int i = tid; i < min(nblk, Wb) * 6; i += CH_NT) rW[6 * PB(i / 6) + i % 6] = r[i];
     }
-    // per-thread trailing item(s): (panel row ri in [0, 6*bwc), column block jc in [0, bwc)), active when jc <= ri / 6
-    const int n_items = 6 * bwc * bwc;
+    // per-thread trailing item: (row block ibr, column block jc <= ibr, 3-row half); 2*bwc^2 <= CH_NT up to bwc = 19, a second trip above
+    // per-thread entry of the block row that enters the window: row a, in-band column slot jj (6*Wr <= CH_NT up to bwc = 20)
+    const int e_a = tid / Wr, e_jj = tid - e_a * Wr;
+    const bool e_two = 6 * Wr > CH_NT; const int e_a2 = (tid + CH_NT) / Wr, e_jj2 = tid + CH_NT - e_a2 * Wr;
     __syncthreads();
     for (int kb = 0; kb < nblk; kb++, boff = (boff + 1 >= Wb ? 0 : boff + 1)) {
         const int pk = 6 * boff;                             // physical row/col of block kb
         const int nbelow = min(bwc, nblk - 1 - kb);           // panel block rows
+        // ---- D0: the loads of block row kb + Wb are issued now and land in LDS at the end of the step (HBM latency off the critical path)
+        double e_val = 0, e_val2 = 0, e_r = 0; const int e_ib = kb + Wb, e_i = 6 * e_ib + e_a, e_j = 6 * (e_ib - bwc) + e_jj, e_i2 = 6 * e_ib + e_a2, e_j2 = 6 * (e_ib - bwc) + e_jj2;
+        const bool e_on = e_ib < nblk && e_a < 6 && e_j <= e_i, e_on2 = e_two && e_ib < nblk && e_a2 < 6 && e_j2 <= e_i2;
+        if (e_on) e_val = AB(e_i, e_j);
+        if (e_on2) e_val2 = AB(e_i2, e_j2);
+        if (e_ib < nblk && tid < 6) e_r = r[6 * e_ib + tid];
         // ---- A: 6x6 pivot block, redundantly on the three waves that use it (panel rows tid < 126, writers tid 128..165)
         double Akk[21], Lk[21], inv[6], zk[6];
         if (tid < 192) {
@@ -792,80 +828,87 @@ __global__ __launch_bounds__(1024) void k_chol_band6(BaDev P, int bwc /* block h
                 Pn[tid * 7 + c] = v; AB(i, 6 * kb + c) = v;
             }
             rW[prow] -= rr;
-        } else if (tid >= 128 && tid < 128 + 21) {           // compile-time register indices only: a dynamic Lk[t] would push the arrays to scratch
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-                for (int b = 0; b <= a; b++) if (tid - 128 == a * (a + 1) / 2 + b) AB(6 * kb + a, 6 * kb + b) = Lk[a * (a + 1) / 2 + b];
-        } else if (tid >= 160 && tid < 166) {
-#pragma unroll
-            for (int c = 0; c < 6; c++) if (tid - 160 == c) r[6 * kb + c] = zk[c];
+        } else if (tid >= 128 && tid < 128 + 27) {           // factor of the pivot block and its z out to HBM
+            const int t = tid - 128, a = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15), b = t - a * (a + 1) / 2;
+            double* dst = t < 21 ? &AB(6 * kb + a, 6 * kb + b) : r + 6 * kb + (t - 21);
+            *dst = pick27(Lk, zk, t);
         }
         lds_barrier();
         if (!ok) break;
-        // ---- B2: trailing window (LDS only) — item = (panel row ri, column block jc <= block of ri): 6 entries
-        for (int it = tid; it < n_items; it += 1024) {
-            const int ri = it / bwc, jc = it - ri * bwc, ibr = ri / 6;
-            if (ibr >= nbelow || jc > ibr) continue;
-            const int a = ri - 6 * ibr, prow = 6 * PB(kb + 1 + ibr) + a, pcol = 6 * PB(kb + 1 + jc);
-            double li[6];
+        // ---- B2: trailing window (LDS only)
+        for (int it = tid; it < 2 * bwc * bwc; it += CH_NT) {
+            const int t_q = it >> 1, t_ibr = (int)(((float)t_q + 0.5f) / (float)bwc), t_jc = t_q - t_ibr * bwc, t_h3 = 3 * (it & 1);
+            if (t_ibr >= nbelow || t_jc > t_ibr) continue;
+            double o[3][6];
+            tile36(Pn + (6 * t_ibr + t_h3) * 7, Pn + 6 * t_jc * 7, o);
+            double* Wt = W + (size_t)(6 * PB(kb + 1 + t_ibr) + t_h3) * ldw + 6 * PB(kb + 1 + t_jc);
 #pragma unroll
-            for (int c = 0; c < 6; c++) li[c] = Pn[ri * 7 + c];
+            for (int a = 0; a < 3; a++)
 #pragma unroll
-            for (int b = 0; b < 6; b++) {
-                if (jc == ibr && b > a) break;
-                const double* lj = Pn + (6 * jc + b) * 7;
-                W[prow * ldw + pcol + b] -= li[0] * lj[0] + li[1] * lj[1] + li[2] * lj[2] + li[3] * lj[3] + li[4] * lj[4] + li[5] * lj[5];
-            }
+                for (int b = 0; b < 6; b++) if (!(t_jc == t_ibr && b > t_h3 + a)) Wt[a * ldw + b] -= o[a][b];
         }
         // ---- D: block row kb + Wb enters (it reuses the storage of block row kb, which nothing above touches any more)
-        {
-            const int ib = kb + Wb;
-            if (ib < nblk) {
-                for (int t = tid; t < 6 * Wr; t += 1024) {
-                    const int a = t / Wr, jj = t - a * Wr, i = 6 * ib + a, j = 6 * (ib - bwc) + jj;
-                    if (j <= i) { const int jb = j / 6; W[(pk + a) * ldw + 6 * (jb == ib ? boff : PB(jb)) + j % 6] = AB(i, j); }
-                }
-                if (tid < 6) rW[pk + tid] = r[6 * ib + tid];
-            }
-        }
+        if (e_on) { const int jb = e_j / 6; W[(pk + e_a) * ldw + 6 * (jb == e_ib ? boff : PB(jb)) + e_j % 6] = e_val; }
+        if (e_on2) { const int jb = e_j2 / 6; W[(pk + e_a2) * ldw + 6 * (jb == e_ib ? boff : PB(jb)) + e_j2 % 6] = e_val2; }
+        if (e_ib < nblk && tid < 6) rW[pk + tid] = e_r;
         lds_barrier();
     }
     __syncthreads();
-    if (ok) {   // ---- backward sweep, row oriented: x_k = L_kk^-T (z_k - acc_k); then acc_j += L_kj^T x_k for the blocks j < k of row k
-        for (int t = tid; t < Wr; t += 1024) acc[t] = 0.0;
-        __syncthreads();
-        int boff2 = 0;                                       // physical slot of block kb in the circular acc / xs arrays
-        for (int kb = nblk - 1; kb >= 0; kb--, boff2 = (boff2 + 1 >= Wb ? 0 : boff2 + 1)) {
-            // wave 0: x_k from the diagonal block of row-block kb (read from HBM: 21 + 6 values)
+    if (ok) {   // ---- backward sweep, row oriented: x_k = L_kk^-T (z_k - acc_k); then acc_j += L_kj^T x_k for the blocks j < k of row k.
+        // Everything a step reads from HBM (diagonal block, z, the band row) was requested one step earlier.
+        for (int t = tid; t < Wr; t += CH_NT) acc[t] = 0.0;
+        double Lk[21], z6[6], row[6], nLk[21], nz6[6], nrow[6];
+        auto fetch = [&](int kb, double* fL, double* fz, double* frow) {
             if (tid < 64) {
-                double Lk[21], t6[6];
 #pragma unroll
                 for (int a = 0; a < 6; a++)
 #pragma unroll
-                    for (int b = 0; b <= a; b++) Lk[a * (a + 1) / 2 + b] = AB(6 * kb + a, 6 * kb + b);
+                    for (int b = 0; b <= a; b++) fL[a * (a + 1) / 2 + b] = AB(6 * kb + a, 6 * kb + b);
 #pragma unroll
-                for (int c = 0; c < 6; c++) t6[c] = r[6 * kb + c] - acc[6 * boff2 + c];
+                for (int c = 0; c < 6; c++) fz[c] = r[6 * kb + c];
+            }
+            const int ncols = 6 * min(bwc, kb);
+            if (tid < ncols) {
+                const int j = 6 * kb - ncols + tid;
+#pragma unroll
+                for (int a = 0; a < 6; a++) frow[a] = AB(6 * kb + a, j);
+            }
+        };
+        fetch(nblk - 1, Lk, z6, row);
+        __syncthreads();
+        int boff2 = 0;                                       // physical slot of block kb in the circular acc / xs arrays
+        for (int kb = nblk - 1; kb >= 0; kb--, boff2 = (boff2 + 1 >= Wb ? 0 : boff2 + 1)) {
+            if (kb > 0) fetch(kb - 1, nLk, nz6, nrow);
+            if (tid < 64) {                                  // wave 0: x_k from the diagonal block of row-block kb
+                double t6[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) t6[c] = z6[c] - acc[6 * boff2 + c];
 #pragma unroll
                 for (int c = 5; c >= 0; c--) { double v = t6[c];
 #pragma unroll
                     for (int e = c + 1; e < 6; e++) v -= Lk[e * (e + 1) / 2 + c] * t6[e]; t6[c] = v / Lk[c * (c + 1) / 2 + c]; }
+                if (tid < 6) { double v = t6[5];
 #pragma unroll
-                for (int c = 0; c < 6; c++) if (tid == c) { x[6 * kb + c] = t6[c]; xs[c] = t6[c]; }
+                    for (int c = 0; c < 5; c++) v = (tid == c) ? t6[c] : v;
+                    x[6 * kb + tid] = v; xs[tid] = v; }
             }
-            __syncthreads();
+            lds_barrier();
             // acc_j += L(kb-row a, col) * x_kb[a] for the in-band columns left of the diagonal block; slot of block j = boff2 + (kb - j)
             const int ncols = 6 * min(bwc, kb);
-            for (int t = tid; t < ncols; t += 1024) {
-                const int j = 6 * kb - ncols + t, jb = j / 6;
+            if (tid < ncols) {
+                const int j = 6 * kb - ncols + tid, jb = j / 6;
                 double sum = 0;
 #pragma unroll
-                for (int a = 0; a < 6; a++) sum += AB(6 * kb + a, j) * xs[a];
+                for (int a = 0; a < 6; a++) sum += row[a] * xs[a];
                 int slot = boff2 + (kb - jb); if (slot >= Wb) slot -= Wb;
                 acc[6 * slot + j % 6] += sum;
             }
             if (tid >= 512 && tid < 518) acc[6 * boff2 + tid - 512] = 0.0;     // this slot becomes block kb - Wb
-            __syncthreads();
+            lds_barrier();
+#pragma unroll
+            for (int i = 0; i < 21; i++) Lk[i] = nLk[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { z6[i] = nz6[i]; row[i] = nrow[i]; }
         }
     }
     if (tid == 0) P.scal[4] = ok ? 1.0 : 0.0;
@@ -876,7 +919,7 @@ __global__ __launch_bounds__(1024) void k_chol_band6(BaDev P, int bwc /* block h
 // Local-BA reduced solve (n6 <= 120, dense): the same pose-block scheme as k_chol_band6 on the whole matrix in LDS —
 // 20 block pivots with three LDS barriers each instead of 120 scalar pivots.  (Factoring the pivot block on every wave
 // redundantly is faster than one wave + publish: the dependent FP64 chain is latency-bound and the copies interleave.)
-__global__ __launch_bounds__(1024) void k_ba_chol_small6(BaDev P)
+__global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
 {
     extern __shared__ double cs6[];
     const int n = P.n6, nblk = n / 6, ldw = n + 1, tid = threadIdx.x;
@@ -884,8 +927,8 @@ __global__ __launch_bounds__(1024) void k_ba_chol_small6(BaDev P)
     double* rW = W + (size_t)n * ldw;                        // [n] rhs -> z -> x
     double* Pn = rW + n;                                     // [n][7] panel rows of the current step
     __shared__ int ok;
-    for (int t = tid; t < n * n; t += 1024) { const int i = t / n, j = t - i * n; if (j <= i) W[i * ldw + j] = P.S[t]; }
-    for (int t = tid; t < n; t += 1024) rW[t] = P.r[t];
+    for (int t = tid; t < n * n; t += CH_NT) { const int i = t / n, j = t - i * n; if (j <= i) W[i * ldw + j] = P.S[t]; }
+    for (int t = tid; t < n; t += CH_NT) rW[t] = P.r[t];
     if (tid == 0) ok = 1;
     __syncthreads();
     for (int kb = 0; kb < nblk; kb++) {
@@ -920,29 +963,21 @@ __global__ __launch_bounds__(1024) void k_ba_chol_small6(BaDev P)
                 Pn[tid * 7 + c] = v; W[prow * ldw + pk + c] = v;
             }
             rW[prow] -= rr;
-        } else if (tid >= 128 && tid < 128 + 21) {
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-                for (int b = 0; b <= a; b++) if (tid - 128 == a * (a + 1) / 2 + b) W[(pk + a) * ldw + pk + b] = Lk[a * (a + 1) / 2 + b];
-        } else if (tid >= 160 && tid < 166) {
-#pragma unroll
-            for (int c = 0; c < 6; c++) if (tid - 160 == c) rW[pk + c] = zk[c];
+        } else if (tid >= 128 && tid < 128 + 27) {
+            const int t = tid - 128, a = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15), b = t - a * (a + 1) / 2;
+            cs6[t < 21 ? (pk + a) * ldw + pk + b : n * ldw + pk + (t - 21)] = pick27(Lk, zk, t);          // rW follows W
         }
         lds_barrier();
-        const int n_items = 6 * nbelow * nbelow;             // (panel row ri, column block jc <= block of ri)
-        for (int it = tid; it < n_items; it += 1024) {
-            const int ri = it / nbelow, jc = it - ri * nbelow, ibr = ri / 6;
-            if (jc > ibr) continue;
-            const int a = ri - 6 * ibr, prow = pk + 6 + ri, pcol = pk + 6 + 6 * jc;
-            double li[6];
+        {   // trailing update: (row block ibr, column block jc <= ibr, 3-row half), 2 * 19^2 <= CH_NT threads
+            const int q = tid >> 1, ibr = (int)(((float)q + 0.5f) / (float)max(nbelow, 1)), jc = q - ibr * nbelow, h3 = 3 * (tid & 1);
+            if (ibr < nbelow && jc <= ibr) {
+                double o[3][6];
+                tile36(Pn + (6 * ibr + h3) * 7, Pn + 6 * jc * 7, o);
+                double* Wt = W + (size_t)(pk + 6 + 6 * ibr + h3) * ldw + pk + 6 + 6 * jc;
 #pragma unroll
-            for (int c = 0; c < 6; c++) li[c] = Pn[ri * 7 + c];
+                for (int a = 0; a < 3; a++)
 #pragma unroll
-            for (int b = 0; b < 6; b++) {
-                if (jc == ibr && b > a) break;
-                const double* lj = Pn + (6 * jc + b) * 7;
-                W[prow * ldw + pcol + b] -= li[0] * lj[0] + li[1] * lj[1] + li[2] * lj[2] + li[3] * lj[3] + li[4] * lj[4] + li[5] * lj[5];
+                    for (int b = 0; b < 6; b++) if (!(jc == ibr && b > h3 + a)) Wt[a * ldw + b] -= o[a][b];
             }
         }
         lds_barrier();
@@ -968,7 +1003,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol_small6(BaDev P)
                 for (int c = 0; c < 6; c++) if (tid == c) rW[pk + c] = t6[c];
             }
             lds_barrier();
-            for (int j = tid; j < pk; j += 1024) {
+            for (int j = tid; j < pk; j += CH_NT) {
                 double sum = 0;
 #pragma unroll
                 for (int a = 0; a < 6; a++) sum += W[(pk + a) * ldw + j] * rW[pk + a];
@@ -976,7 +1011,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol_small6(BaDev P)
             }
             lds_barrier();
         }
-        for (int t = tid; t < n; t += 1024) P.x[t] = rW[t];
+        for (int t = tid; t < n; t += CH_NT) P.x[t] = rW[t];
     }
     if (tid == 0) P.scal[4] = ok ? 1.0 : 0.0;
 }
@@ -1694,9 +1729,9 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if ((rc = AR(Sr, sz_sr, 0))) return rc;
             // ---- replicated reduced solve
             HIP_TRY(ctx, hipMemsetAsync(D.scal + 2, 0, 2 * sizeof(double), st));
-            if (lds_path && n6 % 6 == 0 && n6 >= 12) hipLaunchKernelGGL(k_ba_chol_small6, dim3(1), dim3(1024), lds_chol6, st, D);
+            if (lds_path && n6 % 6 == 0 && n6 >= 12) hipLaunchKernelGGL(k_ba_chol_small6, dim3(1), dim3(CH_NT), lds_chol6, st, D);
             else if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
-            else if (D.bw >= 0 && band6_lds) hipLaunchKernelGGL(k_chol_band6, dim3(1), dim3(1024), band6_lds, st, D, (D.bw - 5) / 6);
+            else if (D.bw >= 0 && band6_lds) hipLaunchKernelGGL(k_chol_band6, dim3(1), dim3(CH_NT), band6_lds, st, D, (D.bw - 5) / 6);
             else if (D.bw >= 0) hipLaunchKernelGGL(k_chol_band, dim3(1), dim3(1024), (size_t)D.bw * (CB_NB + 1) * sizeof(double), st, D);
             else { const double one = 1.0; HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4, &one, 8, hipMemcpyHostToDevice, st)); if ((rc = chol_large(ctx, D.S, n6, D.x, D.scal + 4, chol_tmp, st))) return rc; }
             // ---- trial state + its chi2
