@@ -787,12 +787,27 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
         }
         for (int i = tid; i < min(nblk, Wb) * 6; i += CH_NT) rW[6 * PB(i / 6) + i % 6] = r[i];
     }
-    // per-thread trailing item: (row block ibr, column block jc <= ibr, 3-row half); 2*bwc^2 <= CH_NT up to bwc = 19, a second trip above
     // per-thread entry of the block row that enters the window: row a, in-band column slot jj (6*Wr <= CH_NT up to bwc = 20)
     const int e_a = tid / Wr, e_jj = tid - e_a * Wr;
     const bool e_two = 6 * Wr > CH_NT; const int e_a2 = (tid + CH_NT) / Wr, e_jj2 = tid + CH_NT - e_a2 * Wr;
     __syncthreads();
-    for (int kb = 0; kb < nblk; kb++, boff = (boff + 1 >= Wb ? 0 : boff + 1)) {
+    // Look-ahead schedule (see k_ba_chol_small6): waves 0..2 factor pivot block kb+1 while waves 3.. run the trailing update of step kb.
+    double Lk[21], inv[6], zk[6];
+    if (tid < 192) {                                         // pivot block 0 (physical block 0)
+        double Akk[21];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = W[a * ldw + b];
+        const bool good = chol6(Akk, Lk, inv);
+        if (!good && tid == 0) ok = 0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) { double v = rW[c];
+#pragma unroll
+            for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
+    }
+    lds_barrier();
+    for (int kb = 0; kb < nblk && ok; kb++, boff = (boff + 1 >= Wb ? 0 : boff + 1)) {
         const int pk = 6 * boff;                             // physical row/col of block kb
         const int nbelow = min(bwc, nblk - 1 - kb);           // panel block rows
         // ---- D0: the loads of block row kb + Wb are issued now and land in LDS at the end of the step (HBM latency off the critical path)
@@ -801,21 +816,7 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
         if (e_on) e_val = AB(e_i, e_j);
         if (e_on2) e_val2 = AB(e_i2, e_j2);
         if (e_ib < nblk && tid < 6) e_r = r[6 * e_ib + tid];
-        // ---- A: 6x6 pivot block, redundantly on the three waves that use it (panel rows tid < 126, writers tid 128..165)
-        double Akk[21], Lk[21], inv[6], zk[6];
-        if (tid < 192) {
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-                for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = W[(pk + a) * ldw + pk + b];
-            const bool good = chol6(Akk, Lk, inv);
-            if (!good && tid == 0) ok = 0;
-#pragma unroll
-            for (int c = 0; c < 6; c++) { double v = rW[pk + c];
-#pragma unroll
-                for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
-        }
-        // ---- B1: panel rows, final factor + z of block kb out to HBM (no barrier needed: B1 touches neither the pivot block nor its rhs in LDS)
+        // ---- B1: panel rows, final factor + z of block kb out to HBM
         if (tid < 6 * nbelow) {
             const int ibr = tid / 6 + 1, a = tid - (ibr - 1) * 6, ib = kb + ibr, prow = 6 * PB(ib) + a, i = 6 * ib + a;
             double l[6], rr = 0;
@@ -834,18 +835,43 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
             *dst = pick27(Lk, zk, t);
         }
         lds_barrier();
-        if (!ok) break;
-        // ---- B2: trailing window (LDS only)
-        for (int it = tid; it < 2 * bwc * bwc; it += CH_NT) {
-            const int t_q = it >> 1, t_ibr = (int)(((float)t_q + 0.5f) / (float)bwc), t_jc = t_q - t_ibr * bwc, t_h3 = 3 * (it & 1);
-            if (t_ibr >= nbelow || t_jc > t_ibr) continue;
-            double o[3][6];
-            tile36(Pn + (6 * t_ibr + t_h3) * 7, Pn + 6 * t_jc * 7, o);
-            double* Wt = W + (size_t)(6 * PB(kb + 1 + t_ibr) + t_h3) * ldw + 6 * PB(kb + 1 + t_jc);
+        if (tid < 192) {
+            // ---- A: pivot block kb+1 = W block - P0 P0^T (P0 = panel rows 0..5 of this step), its factor and z
+            if (nbelow > 0) {
+                const int p1 = 6 * PB(kb + 1);
+                double Akk[21];
 #pragma unroll
-            for (int a = 0; a < 3; a++)
+                for (int a = 0; a < 6; a++)
 #pragma unroll
-                for (int b = 0; b < 6; b++) if (!(t_jc == t_ibr && b > t_h3 + a)) Wt[a * ldw + b] -= o[a][b];
+                    for (int b = 0; b <= a; b++) {
+                        double sum = 0;
+#pragma unroll
+                        for (int c = 0; c < 6; c++) sum += Pn[a * 7 + c] * Pn[b * 7 + c];
+                        Akk[a * (a + 1) / 2 + b] = W[(p1 + a) * ldw + p1 + b] - sum;
+                    }
+                const bool good = chol6(Akk, Lk, inv);
+                if (!good && tid == 0) ok = 0;
+#pragma unroll
+                for (int c = 0; c < 6; c++) { double v = rW[p1 + c];
+#pragma unroll
+                    for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
+            }
+        } else {
+            // ---- B2: trailing window (LDS only) on waves 3..: tiles (row block ibr >= column block jc) except (0, 0), two 3-row halves, packed densely
+            for (int it = tid - 192; it < bwc * (bwc + 1) - 2; it += CH_NT - 192) {
+                const int tl = (it >> 1) + 1, h3 = 3 * (it & 1);
+                int ibr = (int)((sqrtf(8.f * (float)tl + 1.f) - 1.f) * 0.5f);
+                ibr -= (ibr * (ibr + 1) / 2 > tl); ibr += ((ibr + 1) * (ibr + 2) / 2 <= tl);
+                const int jc = tl - ibr * (ibr + 1) / 2;
+                if (ibr >= nbelow) continue;
+                double o[3][6];
+                tile36(Pn + (6 * ibr + h3) * 7, Pn + 6 * jc * 7, o);
+                double* Wt = W + (size_t)(6 * PB(kb + 1 + ibr) + h3) * ldw + 6 * PB(kb + 1 + jc);
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 6; b++) if (!(jc == ibr && b > h3 + a)) Wt[a * ldw + b] -= o[a][b];
+            }
         }
         // ---- D: block row kb + Wb enters (it reuses the storage of block row kb, which nothing above touches any more)
         if (e_on) { const int jb = e_j / 6; W[(pk + e_a) * ldw + 6 * (jb == e_ib ? boff : PB(jb)) + e_j % 6] = e_val; }
@@ -855,18 +881,14 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
     }
     __syncthreads();
     if (ok) {   // ---- backward sweep, row oriented: x_k = L_kk^-T (z_k - acc_k); then acc_j += L_kj^T x_k for the blocks j < k of row k.
-        // Everything a step reads from HBM (diagonal block, z, the band row) was requested one step earlier.
+        // Everything a step reads from HBM was requested one step earlier: the band row of a thread's column stays in registers, the diagonal
+        // block and z (27 values, one per lane of wave 0) are parked in LDS.
+        __shared__ double dz[27];
         for (int t = tid; t < Wr; t += CH_NT) acc[t] = 0.0;
-        double Lk[21], z6[6], row[6], nLk[21], nz6[6], nrow[6];
-        auto fetch = [&](int kb, double* fL, double* fz, double* frow) {
-            if (tid < 64) {
-#pragma unroll
-                for (int a = 0; a < 6; a++)
-#pragma unroll
-                    for (int b = 0; b <= a; b++) fL[a * (a + 1) / 2 + b] = AB(6 * kb + a, 6 * kb + b);
-#pragma unroll
-                for (int c = 0; c < 6; c++) fz[c] = r[6 * kb + c];
-            }
+        double row[6], nrow[6], nval = 0;
+        const int dz_a = (tid >= 1) + (tid >= 3) + (tid >= 6) + (tid >= 10) + (tid >= 15), dz_b = tid - dz_a * (dz_a + 1) / 2;
+        auto fetch = [&](int kb, double* frow, double& fval) {
+            if (tid < 27) fval = tid < 21 ? AB(6 * kb + dz_a, 6 * kb + dz_b) : r[6 * kb + tid - 21];
             const int ncols = 6 * min(bwc, kb);
             if (tid < ncols) {
                 const int j = 6 * kb - ncols + tid;
@@ -874,15 +896,18 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
                 for (int a = 0; a < 6; a++) frow[a] = AB(6 * kb + a, j);
             }
         };
-        fetch(nblk - 1, Lk, z6, row);
+        fetch(nblk - 1, row, nval);
+        if (tid < 27) dz[tid] = nval;
         __syncthreads();
         int boff2 = 0;                                       // physical slot of block kb in the circular acc / xs arrays
         for (int kb = nblk - 1; kb >= 0; kb--, boff2 = (boff2 + 1 >= Wb ? 0 : boff2 + 1)) {
-            if (kb > 0) fetch(kb - 1, nLk, nz6, nrow);
+            if (kb > 0) fetch(kb - 1, nrow, nval);
             if (tid < 64) {                                  // wave 0: x_k from the diagonal block of row-block kb
-                double t6[6];
+                double Lk[21], t6[6];
 #pragma unroll
-                for (int c = 0; c < 6; c++) t6[c] = z6[c] - acc[6 * boff2 + c];
+                for (int i = 0; i < 21; i++) Lk[i] = dz[i];
+#pragma unroll
+                for (int c = 0; c < 6; c++) t6[c] = dz[21 + c] - acc[6 * boff2 + c];
 #pragma unroll
                 for (int c = 5; c >= 0; c--) { double v = t6[c];
 #pragma unroll
@@ -891,6 +916,7 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
 #pragma unroll
                     for (int c = 0; c < 5; c++) v = (tid == c) ? t6[c] : v;
                     x[6 * kb + tid] = v; xs[tid] = v; }
+                if (tid < 27) dz[tid] = nval;                // block kb-1 for the next step (every lane of this wave has read dz above)
             }
             lds_barrier();
             // acc_j += L(kb-row a, col) * x_kb[a] for the in-band columns left of the diagonal block; slot of block j = boff2 + (kb - j)
@@ -906,9 +932,7 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
             if (tid >= 512 && tid < 518) acc[6 * boff2 + tid - 512] = 0.0;     // this slot becomes block kb - Wb
             lds_barrier();
 #pragma unroll
-            for (int i = 0; i < 21; i++) Lk[i] = nLk[i];
-#pragma unroll
-            for (int i = 0; i < 6; i++) { z6[i] = nz6[i]; row[i] = nrow[i]; }
+            for (int i = 0; i < 6; i++) row[i] = nrow[i];
         }
     }
     if (tid == 0) P.scal[4] = ok ? 1.0 : 0.0;
@@ -917,8 +941,8 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
 }
 
 // Local-BA reduced solve (n6 <= 120, dense): the same pose-block scheme as k_chol_band6 on the whole matrix in LDS —
-// 20 block pivots with three LDS barriers each instead of 120 scalar pivots.  (Factoring the pivot block on every wave
-// redundantly is faster than one wave + publish: the dependent FP64 chain is latency-bound and the copies interleave.)
+// 20 block pivots instead of 120 scalar pivots.  (Factoring the pivot block redundantly on the three waves that use it is
+// faster than one wave + publish: the dependent FP64 chain is latency-bound and the copies run on different SIMDs.)
 __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
 {
     extern __shared__ double cs6[];
@@ -931,26 +955,28 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
     for (int t = tid; t < n; t += CH_NT) rW[t] = P.r[t];
     if (tid == 0) ok = 1;
     __syncthreads();
-    for (int kb = 0; kb < nblk; kb++) {
+    // Look-ahead schedule, two LDS barriers per pivot: while waves 3.. run the trailing update of step kb, waves 0..2 (panel rows tid < 114,
+    // writer lanes 128..154) already factor pivot block kb+1 — its entries are the block in W minus the first panel row block times itself,
+    // which is all the trailing update would have done to it.  The latency-bound 6x6 factorisation (dependent FP64 chain, ~1500 cycles)
+    // disappears behind the tile work instead of preceding it.
+    double Lk[21], inv[6], zk[6];
+    if (tid < 192) {                                         // pivot block 0 straight from W
+        double Akk[21];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = W[a * ldw + b];
+        const bool good = chol6(Akk, Lk, inv);
+#pragma unroll
+        for (int c = 0; c < 6; c++) { double v = rW[c];
+#pragma unroll
+            for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
+        if (!good && tid == 0) ok = 0;
+    }
+    lds_barrier();
+    for (int kb = 0; kb < nblk && ok; kb++) {
         const int pk = 6 * kb, nbelow = nblk - 1 - kb;
-        // only the three waves that use the factor compute it (panel rows: tid < 114, writers: tid 128..165); sixteen redundant copies
-        // would queue four deep on every SIMD
-        double Akk[21], Lk[21], inv[6], zk[6];
-        bool good = true;
-        if (tid < 192) {
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-                for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = W[(pk + a) * ldw + pk + b];
-            good = chol6(Akk, Lk, inv);
-#pragma unroll
-            for (int c = 0; c < 6; c++) { double v = rW[pk + c];
-#pragma unroll
-                for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
-            if (!good && tid == 0) ok = 0;
-        }
-        lds_barrier();                                       // the factoring waves have read block kb and its rhs
-        if (!ok) break;
+        // ---- B1: panel rows of step kb; factor of the pivot block and its z into W / rW
         if (tid < 6 * nbelow) {
             const int prow = pk + 6 + tid;
             double l[6], rr = 0;
@@ -968,9 +994,33 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
             cs6[t < 21 ? (pk + a) * ldw + pk + b : n * ldw + pk + (t - 21)] = pick27(Lk, zk, t);          // rW follows W
         }
         lds_barrier();
-        {   // trailing update: (row block ibr, column block jc <= ibr, 3-row half), 2 * 19^2 <= CH_NT threads
-            const int q = tid >> 1, ibr = (int)(((float)q + 0.5f) / (float)max(nbelow, 1)), jc = q - ibr * nbelow, h3 = 3 * (tid & 1);
-            if (ibr < nbelow && jc <= ibr) {
+        if (tid < 192) {
+            // ---- A: pivot block kb+1 = W block - P0 P0^T (P0 = panel rows 0..5 of this step), then its factor and z
+            if (nbelow > 0) {
+                double Akk[21];
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int b = 0; b <= a; b++) {
+                        double sum = 0;
+#pragma unroll
+                        for (int c = 0; c < 6; c++) sum += Pn[a * 7 + c] * Pn[b * 7 + c];
+                        Akk[a * (a + 1) / 2 + b] = W[(pk + 6 + a) * ldw + pk + 6 + b] - sum;
+                    }
+                const bool good = chol6(Akk, Lk, inv);
+#pragma unroll
+                for (int c = 0; c < 6; c++) { double v = rW[pk + 6 + c];
+#pragma unroll
+                    for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
+                if (!good && tid == 0) ok = 0;
+            }
+        } else {
+            // ---- B2: trailing update on waves 3..: tiles (row block ibr >= column block jc) except (0, 0), two 3-row halves each, packed densely
+            const int it = tid - 192, tl = (it >> 1) + 1, h3 = 3 * (it & 1);
+            int ibr = (int)((sqrtf(8.f * (float)tl + 1.f) - 1.f) * 0.5f);
+            ibr -= (ibr * (ibr + 1) / 2 > tl); ibr += ((ibr + 1) * (ibr + 2) / 2 <= tl);
+            const int jc = tl - ibr * (ibr + 1) / 2;
+            if (ibr < nbelow) {
                 double o[3][6];
                 tile36(Pn + (6 * ibr + h3) * 7, Pn + 6 * jc * 7, o);
                 double* Wt = W + (size_t)(pk + 6 + 6 * ibr + h3) * ldw + pk + 6 + 6 * jc;
