@@ -735,6 +735,10 @@ __device__ __forceinline__ bool chol6(const double* A /*21: row-major lower*/, d
     }
     return good;
 }
+__device__ __forceinline__ double readlane_f64(double v, int src /* wave-uniform */)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
 // 12 waves: 168 VGPRs per lane (the pivot block, its factor and a 3x6 tile with its operands do not fit the 128 of a 1024-thread group)
 #define CH_NT 768
 // lane t of a writer wave picks entry t of (Lk[21] | zk[6]) with a select chain: compile-time register indices (a dynamic Lk[t] would push the
@@ -839,16 +843,15 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
             // ---- A: pivot block kb+1 = W block - P0 P0^T (P0 = panel rows 0..5 of this step), its factor and z
             if (nbelow > 0) {
                 const int p1 = 6 * PB(kb + 1);
-                double Akk[21];
+                // lane t < 21 of each wave forms entry t of the updated block, v_readlane hands all 21 to every lane
+                double Akk[21], mine;
+                { const int t = min(tid & 63, 20), a = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15), b = t - a * (a + 1) / 2;
+                  double sum = 0;
 #pragma unroll
-                for (int a = 0; a < 6; a++)
+                  for (int c = 0; c < 6; c++) sum += Pn[a * 7 + c] * Pn[b * 7 + c];
+                  mine = W[(p1 + a) * ldw + p1 + b] - sum; }
 #pragma unroll
-                    for (int b = 0; b <= a; b++) {
-                        double sum = 0;
-#pragma unroll
-                        for (int c = 0; c < 6; c++) sum += Pn[a * 7 + c] * Pn[b * 7 + c];
-                        Akk[a * (a + 1) / 2 + b] = W[(p1 + a) * ldw + p1 + b] - sum;
-                    }
+                for (int i = 0; i < 21; i++) Akk[i] = readlane_f64(mine, i);
                 const bool good = chol6(Akk, Lk, inv);
                 if (!good && tid == 0) ok = 0;
 #pragma unroll
@@ -870,7 +873,7 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
 #pragma unroll
                 for (int a = 0; a < 3; a++)
 #pragma unroll
-                    for (int b = 0; b < 6; b++) if (!(jc == ibr && b > h3 + a)) Wt[a * ldw + b] -= o[a][b];
+                    for (int b = 0; b < 6; b++) { const double w = Wt[a * ldw + b]; Wt[a * ldw + b] = (jc == ibr && b > h3 + a) ? w : w - o[a][b]; }     // select, not a branch
             }
         }
         // ---- D: block row kb + Wb enters (it reuses the storage of block row kb, which nothing above touches any more)
@@ -997,16 +1000,15 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
         if (tid < 192) {
             // ---- A: pivot block kb+1 = W block - P0 P0^T (P0 = panel rows 0..5 of this step), then its factor and z
             if (nbelow > 0) {
-                double Akk[21];
+                // lane t < 21 of each wave forms entry t of the updated block, v_readlane hands all 21 to every lane
+                double Akk[21], mine;
+                { const int t = min(tid & 63, 20), a = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15), b = t - a * (a + 1) / 2;
+                  double sum = 0;
 #pragma unroll
-                for (int a = 0; a < 6; a++)
+                  for (int c = 0; c < 6; c++) sum += Pn[a * 7 + c] * Pn[b * 7 + c];
+                  mine = W[(pk + 6 + a) * ldw + pk + 6 + b] - sum; }
 #pragma unroll
-                    for (int b = 0; b <= a; b++) {
-                        double sum = 0;
-#pragma unroll
-                        for (int c = 0; c < 6; c++) sum += Pn[a * 7 + c] * Pn[b * 7 + c];
-                        Akk[a * (a + 1) / 2 + b] = W[(pk + 6 + a) * ldw + pk + 6 + b] - sum;
-                    }
+                for (int i = 0; i < 21; i++) Akk[i] = readlane_f64(mine, i);
                 const bool good = chol6(Akk, Lk, inv);
 #pragma unroll
                 for (int c = 0; c < 6; c++) { double v = rW[pk + 6 + c];
@@ -1027,7 +1029,7 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
 #pragma unroll
                 for (int a = 0; a < 3; a++)
 #pragma unroll
-                    for (int b = 0; b < 6; b++) if (!(jc == ibr && b > h3 + a)) Wt[a * ldw + b] -= o[a][b];
+                    for (int b = 0; b < 6; b++) { const double w = Wt[a * ldw + b]; Wt[a * ldw + b] = (jc == ibr && b > h3 + a) ? w : w - o[a][b]; }     // select, not a branch
             }
         }
         lds_barrier();
