@@ -760,7 +760,7 @@ __device__ __forceinline__ void tile36(const double* Li, const double* Lj, doubl
     for (int a = 0; a < 3; a++)
 #pragma unroll
         for (int b = 0; b < 6; b++) o[a][b] = 0.0;
-#pragma unroll 2
+#pragma unroll
     for (int c = 0; c < 6; c++) {
         const double l0 = Li[c], l1 = Li[7 + c], l2 = Li[14 + c];
 #pragma unroll
@@ -795,51 +795,62 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
     const int e_a = tid / Wr, e_jj = tid - e_a * Wr;
     const bool e_two = 6 * Wr > CH_NT; const int e_a2 = (tid + CH_NT) / Wr, e_jj2 = tid + CH_NT - e_a2 * Wr;
     __syncthreads();
-    // Look-ahead schedule (see k_ba_chol_small6): waves 0..2 factor pivot block kb+1 while waves 3.. run the trailing update of step kb.
-    double Lk[21], inv[6], zk[6];
-    if (tid < 192) {                                         // pivot block 0 (physical block 0)
-        double Akk[21];
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = W[a * ldw + b];
-        const bool good = chol6(Akk, Lk, inv);
-        if (!good && tid == 0) ok = 0;
-#pragma unroll
-        for (int c = 0; c < 6; c++) { double v = rW[c];
-#pragma unroll
-            for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
-    }
-    lds_barrier();
-    for (int kb = 0; kb < nblk && ok; kb++, boff = (boff + 1 >= Wb ? 0 : boff + 1)) {
-        const int pk = 6 * boff;                             // physical row/col of block kb
-        const int nbelow = min(bwc, nblk - 1 - kb);           // panel block rows
-        // ---- D0: the loads of block row kb + Wb are issued now and land in LDS at the end of the step (HBM latency off the critical path)
-        double e_val = 0, e_val2 = 0, e_r = 0; const int e_ib = kb + Wb, e_i = 6 * e_ib + e_a, e_j = 6 * (e_ib - bwc) + e_jj, e_i2 = 6 * e_ib + e_a2, e_j2 = 6 * (e_ib - bwc) + e_jj2;
-        const bool e_on = e_ib < nblk && e_a < 6 && e_j <= e_i, e_on2 = e_two && e_ib < nblk && e_a2 < 6 && e_j2 <= e_i2;
-        if (e_on) e_val = AB(e_i, e_j);
-        if (e_on2) e_val2 = AB(e_i2, e_j2);
+    // Look-ahead schedule with role-specialised waves (see k_ba_chol_small6): waves 0..2 (role F) own the pivot blocks, the panel rows and
+    // the factor write-out; waves 3.. (role T) own the trailing tiles.  The roles run SEPARATE loops that meet at the same two LDS barriers
+    // per pivot, so the 33 doubles of pivot state are live only in role F and role T keeps its tile operands in registers.  (In one shared
+    // loop the allocator spilled; a spill reload waits on vmcnt(0), i.e. on the window-row prefetch and the factor stores still in flight —
+    // 3000 cycles of HBM latency back on the critical path of every pivot.)
+#define BAND6_STEP_BEGIN \
+        const int pk = 6 * boff, nbelow = min(bwc, nblk - 1 - kb); \
+        double e_val = 0, e_val2 = 0, e_r = 0; const int e_ib = kb + Wb, e_i = 6 * e_ib + e_a, e_j = 6 * (e_ib - bwc) + e_jj, e_i2 = 6 * e_ib + e_a2, e_j2 = 6 * (e_ib - bwc) + e_jj2; \
+        const bool e_on = e_ib < nblk && e_a < 6 && e_j <= e_i, e_on2 = e_two && e_ib < nblk && e_a2 < 6 && e_j2 <= e_i2; \
+        if (e_on) e_val = AB(e_i, e_j); \
+        if (e_on2) e_val2 = AB(e_i2, e_j2); \
         if (e_ib < nblk && tid < 6) e_r = r[6 * e_ib + tid];
-        // ---- B1: panel rows, final factor + z of block kb out to HBM
-        if (tid < 6 * nbelow) {
-            const int ibr = tid / 6 + 1, a = tid - (ibr - 1) * 6, ib = kb + ibr, prow = 6 * PB(ib) + a, i = 6 * ib + a;
-            double l[6], rr = 0;
+    // D0 above: the loads of block row kb + Wb are issued at the top of the step and land in LDS at its end (HBM latency off the critical path).
+    // D below: the row reuses the storage of block row kb, which nothing in the step touches any more.
+#define BAND6_STEP_END \
+        if (e_on) { const int jb = e_j / 6; W[(pk + e_a) * ldw + 6 * (jb == e_ib ? boff : PB(jb)) + e_j % 6] = e_val; } \
+        if (e_on2) { const int jb = e_j2 / 6; W[(pk + e_a2) * ldw + 6 * (jb == e_ib ? boff : PB(jb)) + e_j2 % 6] = e_val2; } \
+        if (e_ib < nblk && tid < 6) rW[pk + tid] = e_r; \
+        lds_barrier();
+    if (tid < 192) {
+        double Lk[21], inv[6], zk[6];
+        {   // pivot block 0 (physical block 0)
+            double Akk[21];
 #pragma unroll
-            for (int c = 0; c < 6; c++) {
-                double v = W[prow * ldw + pk + c];
+            for (int a = 0; a < 6; a++)
 #pragma unroll
-                for (int e = 0; e < c; e++) v -= l[e] * Lk[c * (c + 1) / 2 + e];
-                v *= inv[c]; l[c] = v; rr += v * zk[c];
-                Pn[tid * 7 + c] = v; AB(i, 6 * kb + c) = v;
-            }
-            rW[prow] -= rr;
-        } else if (tid >= 128 && tid < 128 + 27) {           // factor of the pivot block and its z out to HBM
-            const int t = tid - 128, a = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15), b = t - a * (a + 1) / 2;
-            double* dst = t < 21 ? &AB(6 * kb + a, 6 * kb + b) : r + 6 * kb + (t - 21);
-            *dst = pick27(Lk, zk, t);
+                for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = W[a * ldw + b];
+            const bool good = chol6(Akk, Lk, inv);
+            if (!good && tid == 0) ok = 0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) { double v = rW[c];
+#pragma unroll
+                for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
         }
         lds_barrier();
-        if (tid < 192) {
+        for (int kb = 0; kb < nblk && ok; kb++, boff = (boff + 1 >= Wb ? 0 : boff + 1)) {
+            BAND6_STEP_BEGIN
+            // ---- B1: panel rows, final factor + z of block kb out to HBM
+            if (tid < 6 * nbelow) {
+                const int ibr = tid / 6 + 1, a = tid - (ibr - 1) * 6, ib = kb + ibr, prow = 6 * PB(ib) + a, i = 6 * ib + a;
+                double l[6], rr = 0;
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double v = W[prow * ldw + pk + c];
+#pragma unroll
+                    for (int e = 0; e < c; e++) v -= l[e] * Lk[c * (c + 1) / 2 + e];
+                    v *= inv[c]; l[c] = v; rr += v * zk[c];
+                    Pn[tid * 7 + c] = v; AB(i, 6 * kb + c) = v;
+                }
+                rW[prow] -= rr;
+            } else if (tid >= 128 && tid < 128 + 27) {           // factor of the pivot block and its z out to HBM
+                const int t = tid - 128, a = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15), b = t - a * (a + 1) / 2;
+                double* dst = t < 21 ? &AB(6 * kb + a, 6 * kb + b) : r + 6 * kb + (t - 21);
+                *dst = pick27(Lk, zk, t);
+            }
+            lds_barrier();
             // ---- A: pivot block kb+1 = W block - P0 P0^T (P0 = panel rows 0..5 of this step), its factor and z
             if (nbelow > 0) {
                 const int p1 = 6 * PB(kb + 1);
@@ -859,8 +870,14 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
 #pragma unroll
                     for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
             }
-        } else {
-            // ---- B2: trailing window (LDS only) on waves 3..: tiles (row block ibr >= column block jc) except (0, 0), two 3-row halves, packed densely
+            BAND6_STEP_END
+        }
+    } else {
+        lds_barrier();
+        for (int kb = 0; kb < nblk && ok; kb++, boff = (boff + 1 >= Wb ? 0 : boff + 1)) {
+            BAND6_STEP_BEGIN
+            lds_barrier();
+            // ---- B2: trailing window (LDS only): tiles (row block ibr >= column block jc) except (0, 0), two 3-row halves, packed densely
             for (int it = tid - 192; it < bwc * (bwc + 1) - 2; it += CH_NT - 192) {
                 const int tl = (it >> 1) + 1, h3 = 3 * (it & 1);
                 int ibr = (int)((sqrtf(8.f * (float)tl + 1.f) - 1.f) * 0.5f);
@@ -875,13 +892,11 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
 #pragma unroll
                     for (int b = 0; b < 6; b++) { const double w = Wt[a * ldw + b]; Wt[a * ldw + b] = (jc == ibr && b > h3 + a) ? w : w - o[a][b]; }     // select, not a branch
             }
+            BAND6_STEP_END
         }
-        // ---- D: block row kb + Wb enters (it reuses the storage of block row kb, which nothing above touches any more)
-        if (e_on) { const int jb = e_j / 6; W[(pk + e_a) * ldw + 6 * (jb == e_ib ? boff : PB(jb)) + e_j % 6] = e_val; }
-        if (e_on2) { const int jb = e_j2 / 6; W[(pk + e_a2) * ldw + 6 * (jb == e_ib ? boff : PB(jb)) + e_j2 % 6] = e_val2; }
-        if (e_ib < nblk && tid < 6) rW[pk + tid] = e_r;
-        lds_barrier();
     }
+#undef BAND6_STEP_BEGIN
+#undef BAND6_STEP_END
     __syncthreads();
     if (ok) {   // ---- backward sweep, row oriented: x_k = L_kk^-T (z_k - acc_k); then acc_j += L_kj^T x_k for the blocks j < k of row k.
         // Everything a step reads from HBM was requested one step earlier: the band row of a thread's column stays in registers, the diagonal
@@ -958,46 +973,47 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
     for (int t = tid; t < n; t += CH_NT) rW[t] = P.r[t];
     if (tid == 0) ok = 1;
     __syncthreads();
-    // Look-ahead schedule, two LDS barriers per pivot: while waves 3.. run the trailing update of step kb, waves 0..2 (panel rows tid < 114,
-    // writer lanes 128..154) already factor pivot block kb+1 — its entries are the block in W minus the first panel row block times itself,
-    // which is all the trailing update would have done to it.  The latency-bound 6x6 factorisation (dependent FP64 chain, ~1500 cycles)
-    // disappears behind the tile work instead of preceding it.
-    double Lk[21], inv[6], zk[6];
-    if (tid < 192) {                                         // pivot block 0 straight from W
-        double Akk[21];
+    // Look-ahead schedule, two LDS barriers per pivot: while waves 3.. (role T) run the trailing update of step kb, waves 0..2 (role F: panel
+    // rows tid < 114, writer lanes 128..154) already factor pivot block kb+1 — its entries are the block in W minus the first panel row block
+    // times itself, which is all the trailing update would have done to it.  The latency-bound 6x6 factorisation (dependent FP64 chain,
+    // ~1500 cycles) runs beside the tile work instead of before it.  The roles run separate loops that meet at the same barriers, so the pivot
+    // state is live only in role F and the tile operands of role T stay in registers.
+    if (tid < 192) {
+        double Lk[21], inv[6], zk[6];
+        {   // pivot block 0 straight from W
+            double Akk[21];
 #pragma unroll
-        for (int a = 0; a < 6; a++)
+            for (int a = 0; a < 6; a++)
 #pragma unroll
-            for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = W[a * ldw + b];
-        const bool good = chol6(Akk, Lk, inv);
+                for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = W[a * ldw + b];
+            const bool good = chol6(Akk, Lk, inv);
 #pragma unroll
-        for (int c = 0; c < 6; c++) { double v = rW[c];
+            for (int c = 0; c < 6; c++) { double v = rW[c];
 #pragma unroll
-            for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
-        if (!good && tid == 0) ok = 0;
-    }
-    lds_barrier();
-    for (int kb = 0; kb < nblk && ok; kb++) {
-        const int pk = 6 * kb, nbelow = nblk - 1 - kb;
-        // ---- B1: panel rows of step kb; factor of the pivot block and its z into W / rW
-        if (tid < 6 * nbelow) {
-            const int prow = pk + 6 + tid;
-            double l[6], rr = 0;
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                double v = W[prow * ldw + pk + c];
-#pragma unroll
-                for (int e = 0; e < c; e++) v -= l[e] * Lk[c * (c + 1) / 2 + e];
-                v *= inv[c]; l[c] = v; rr += v * zk[c];
-                Pn[tid * 7 + c] = v; W[prow * ldw + pk + c] = v;
-            }
-            rW[prow] -= rr;
-        } else if (tid >= 128 && tid < 128 + 27) {
-            const int t = tid - 128, a = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15), b = t - a * (a + 1) / 2;
-            cs6[t < 21 ? (pk + a) * ldw + pk + b : n * ldw + pk + (t - 21)] = pick27(Lk, zk, t);          // rW follows W
+                for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
+            if (!good && tid == 0) ok = 0;
         }
         lds_barrier();
-        if (tid < 192) {
+        for (int kb = 0; kb < nblk && ok; kb++) {
+            const int pk = 6 * kb, nbelow = nblk - 1 - kb;
+            // ---- B1: panel rows of step kb; factor of the pivot block and its z into W / rW
+            if (tid < 6 * nbelow) {
+                const int prow = pk + 6 + tid;
+                double l[6], rr = 0;
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double v = W[prow * ldw + pk + c];
+#pragma unroll
+                    for (int e = 0; e < c; e++) v -= l[e] * Lk[c * (c + 1) / 2 + e];
+                    v *= inv[c]; l[c] = v; rr += v * zk[c];
+                    Pn[tid * 7 + c] = v; W[prow * ldw + pk + c] = v;
+                }
+                rW[prow] -= rr;
+            } else if (tid >= 128 && tid < 128 + 27) {
+                const int t = tid - 128, a = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15), b = t - a * (a + 1) / 2;
+                cs6[t < 21 ? (pk + a) * ldw + pk + b : n * ldw + pk + (t - 21)] = pick27(Lk, zk, t);          // rW follows W
+            }
+            lds_barrier();
             // ---- A: pivot block kb+1 = W block - P0 P0^T (P0 = panel rows 0..5 of this step), then its factor and z
             if (nbelow > 0) {
                 // lane t < 21 of each wave forms entry t of the updated block, v_readlane hands all 21 to every lane
@@ -1016,8 +1032,14 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
                     for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
                 if (!good && tid == 0) ok = 0;
             }
-        } else {
-            // ---- B2: trailing update on waves 3..: tiles (row block ibr >= column block jc) except (0, 0), two 3-row halves each, packed densely
+            lds_barrier();
+        }
+    } else {
+        lds_barrier();
+        for (int kb = 0; kb < nblk && ok; kb++) {
+            const int pk = 6 * kb, nbelow = nblk - 1 - kb;
+            lds_barrier();
+            // ---- B2: trailing update: tiles (row block ibr >= column block jc) except (0, 0), two 3-row halves each, packed densely
             const int it = tid - 192, tl = (it >> 1) + 1, h3 = 3 * (it & 1);
             int ibr = (int)((sqrtf(8.f * (float)tl + 1.f) - 1.f) * 0.5f);
             ibr -= (ibr * (ibr + 1) / 2 > tl); ibr += ((ibr + 1) * (ibr + 2) / 2 <= tl);
@@ -1031,8 +1053,8 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
 #pragma unroll
                     for (int b = 0; b < 6; b++) { const double w = Wt[a * ldw + b]; Wt[a * ldw + b] = (jc == ibr && b > h3 + a) ? w : w - o[a][b]; }     // select, not a branch
             }
+            lds_barrier();
         }
-        lds_barrier();
     }
     __syncthreads();
     if (ok) {                                                // backward sweep in LDS, row oriented: x_k = L_kk^-T (z_k - acc_k), acc_j += L_kj^T x_k
