@@ -4,7 +4,8 @@ import os, subprocess, glob, hashlib
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvido_slam_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+import shlex as _shlex
+FLAGS = _shlex.split(os.environ.get("VIDO_EXTRA_FLAGS", "")) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-pthread"]
 
 

@@ -739,19 +739,18 @@ __device__ __forceinline__ double readlane_f64(double v, int src /* wave-uniform
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
+// -DVIDO_CHOL_PROF: per-phase shader-clock totals of the two pose-block Cholesky kernels, printed by one lane of role F and one of role T
+#ifdef VIDO_CHOL_PROF
+#define CH_PROF_DECL long long ch_tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ch_t0 = clock64();
+#define CH_TICK(i) { const long long ch_t1 = clock64(); ch_tp[i] += ch_t1 - ch_t0; ch_t0 = ch_t1; }
+#define CH_PROF_PRINT(name) if (tid == 0 || tid == 130 || tid == 200) printf(name " tid %d: %lld %lld %lld %lld %lld %lld %lld %lld\n", tid, ch_tp[0], ch_tp[1], ch_tp[2], ch_tp[3], ch_tp[4], ch_tp[5], ch_tp[6], ch_tp[7]);
+#else
+#define CH_PROF_DECL
+#define CH_TICK(i)
+#define CH_PROF_PRINT(name)
+#endif
 // 12 waves: 168 VGPRs per lane (the pivot block, its factor and a 3x6 tile with its operands do not fit the 128 of a 1024-thread group)
 #define CH_NT 768
-// lane t of a writer wave picks entry t of (Lk[21] | zk[6]) with a select chain: compile-time register indices (a dynamic Lk[t] would push the
-// arrays to scratch) and no branches (27 predicated blocks cost the writer wave ~1300 cycles of taken-branch bubbles per pivot)
-__device__ __forceinline__ double pick27(const double* Lk, const double* zk, int t)
-{
-    double val = zk[5];
-#pragma unroll
-    for (int i = 0; i < 21; i++) val = (t == i) ? Lk[i] : val;
-#pragma unroll
-    for (int c = 0; c < 5; c++) val = (t == 21 + c) ? zk[c] : val;
-    return val;
-}
 // 3x6 half tile of the trailing update: out[a][b] = sum_c Li[a][c] * Lj[b][c] from the panel rows in LDS (pitch 7): 54 LDS reads per 108 FMAs
 // (one thread per (row, column block) re-read the 36 values of Lj for every row: the update ran at the LDS bandwidth limit)
 __device__ __forceinline__ void tile36(const double* Li, const double* Lj, double (*o)[6])
@@ -777,11 +776,13 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
     double* xs = Pn + (size_t)6 * bwc * 7;                   // [Wr]  backward sweep: x of the blocks below (circular)
     double* acc = xs + Wr;                                   // [Wr]  backward sweep: sum_i L_ik^T x_i accumulators (circular)
     __shared__ int ok;
+    __shared__ double stg[27];                              // factor of the current pivot block | its z, on the way to HBM
     const int n = P.n6, nblk = n / 6, bw = P.bw, ldb = P.ldb, tid = threadIdx.x;
     double* Sg = P.S; double* r = P.r; double* x = P.x;
 #define AB(i, j) Sg[(size_t)(i) * ldb + ((j) - (i) + bw)]
 #define PB(ib) (((ib) - kb + boff) >= Wb ? ((ib) - kb + boff - Wb) : ((ib) - kb + boff))
     if (tid == 0) ok = 1;
+    CH_PROF_DECL
     int boff = 0;
     {   // block rows [0, min(nblk, Wb)) enter
         const int kb = 0;
@@ -831,26 +832,35 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
         }
         lds_barrier();
         for (int kb = 0; kb < nblk && ok; kb++, boff = (boff + 1 >= Wb ? 0 : boff + 1)) {
+            CH_TICK(0)
             BAND6_STEP_BEGIN
+            CH_TICK(1)
             // ---- B1: panel rows, final factor + z of block kb out to HBM
             if (tid < 6 * nbelow) {
                 const int ibr = tid / 6 + 1, a = tid - (ibr - 1) * 6, ib = kb + ibr, prow = 6 * PB(ib) + a, i = 6 * ib + a;
-                double l[6], rr = 0;
+                double l[6], rr = 0, w6[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) w6[c] = W[prow * ldw + pk + c];
+                const double r0 = rW[prow];
 #pragma unroll
                 for (int c = 0; c < 6; c++) {
-                    double v = W[prow * ldw + pk + c];
+                    double v = w6[c];
 #pragma unroll
                     for (int e = 0; e < c; e++) v -= l[e] * Lk[c * (c + 1) / 2 + e];
                     v *= inv[c]; l[c] = v; rr += v * zk[c];
-                    Pn[tid * 7 + c] = v; AB(i, 6 * kb + c) = v;
                 }
-                rW[prow] -= rr;
-            } else if (tid >= 128 && tid < 128 + 27) {           // factor of the pivot block and its z out to HBM
-                const int t = tid - 128, a = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15), b = t - a * (a + 1) / 2;
-                double* dst = t < 21 ? &AB(6 * kb + a, 6 * kb + b) : r + 6 * kb + (t - 21);
-                *dst = pick27(Lk, zk, t);
+#pragma unroll
+                for (int c = 0; c < 6; c++) { Pn[tid * 7 + c] = l[c]; AB(i, 6 * kb + c) = l[c]; }
+                rW[prow] = r0 - rr;
+            } else if (tid == 128) {                             // factor of the pivot block and its z: one lane parks the 27 values in LDS with
+#pragma unroll                                               // compile-time register indices, lanes 704..730 of role T stream them to HBM
+                for (int i = 0; i < 21; i++) stg[i] = Lk[i];
+#pragma unroll
+                for (int c = 0; c < 6; c++) stg[21 + c] = zk[c];
             }
+            CH_TICK(2)
             lds_barrier();
+            CH_TICK(3)
             // ---- A: pivot block kb+1 = W block - P0 P0^T (P0 = panel rows 0..5 of this step), its factor and z
             if (nbelow > 0) {
                 const int p1 = 6 * PB(kb + 1);
@@ -870,13 +880,23 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
 #pragma unroll
                     for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
             }
+            CH_TICK(4)
             BAND6_STEP_END
         }
     } else {
         lds_barrier();
         for (int kb = 0; kb < nblk && ok; kb++, boff = (boff + 1 >= Wb ? 0 : boff + 1)) {
+            CH_TICK(0)
             BAND6_STEP_BEGIN
+            CH_TICK(1)
+            CH_TICK(2)
             lds_barrier();
+            CH_TICK(3)
+            if (tid >= 704 && tid < 704 + 27) {
+                const int t = tid - 704, a = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15), b = t - a * (a + 1) / 2;
+                double* dst = t < 21 ? &AB(6 * kb + a, 6 * kb + b) : r + 6 * kb + (t - 21);
+                *dst = stg[t];
+            }
             // ---- B2: trailing window (LDS only): tiles (row block ibr >= column block jc) except (0, 0), two 3-row halves, packed densely
             for (int it = tid - 192; it < bwc * (bwc + 1) - 2; it += CH_NT - 192) {
                 const int tl = (it >> 1) + 1, h3 = 3 * (it & 1);
@@ -887,16 +907,23 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
                 double o[3][6];
                 tile36(Pn + (6 * ibr + h3) * 7, Pn + 6 * jc * 7, o);
                 double* Wt = W + (size_t)(6 * PB(kb + 1 + ibr) + h3) * ldw + 6 * PB(kb + 1 + jc);
+                double w[3][6];                  // all 18 loads first: a load issued after a store waits a full LDS round trip for that store's operand
 #pragma unroll
                 for (int a = 0; a < 3; a++)
 #pragma unroll
-                    for (int b = 0; b < 6; b++) { const double w = Wt[a * ldw + b]; Wt[a * ldw + b] = (jc == ibr && b > h3 + a) ? w : w - o[a][b]; }     // select, not a branch
+                    for (int b = 0; b < 6; b++) w[a][b] = Wt[a * ldw + b];
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 6; b++) Wt[a * ldw + b] = (jc == ibr && b > h3 + a) ? w[a][b] : w[a][b] - o[a][b];     // select, not a branch
             }
+            CH_TICK(4)
             BAND6_STEP_END
         }
     }
 #undef BAND6_STEP_BEGIN
 #undef BAND6_STEP_END
+    CH_TICK(5)
     __syncthreads();
     if (ok) {   // ---- backward sweep, row oriented: x_k = L_kk^-T (z_k - acc_k); then acc_j += L_kj^T x_k for the blocks j < k of row k.
         // Everything a step reads from HBM was requested one step earlier: the band row of a thread's column stays in registers, the diagonal
@@ -953,6 +980,8 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
             for (int i = 0; i < 6; i++) row[i] = nrow[i];
         }
     }
+    CH_TICK(6)
+    CH_PROF_PRINT("band6 [0 D+bar | 1 D0 | 2 B1 | 3 bar | 4 A or B2 | 6 back]")
     if (tid == 0) P.scal[4] = ok ? 1.0 : 0.0;
 #undef AB
 #undef PB
@@ -972,6 +1001,7 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
     for (int t = tid; t < n * n; t += CH_NT) { const int i = t / n, j = t - i * n; if (j <= i) W[i * ldw + j] = P.S[t]; }
     for (int t = tid; t < n; t += CH_NT) rW[t] = P.r[t];
     if (tid == 0) ok = 1;
+    CH_PROF_DECL
     __syncthreads();
     // Look-ahead schedule, two LDS barriers per pivot: while waves 3.. (role T) run the trailing update of step kb, waves 0..2 (role F: panel
     // rows tid < 114, writer lanes 128..154) already factor pivot block kb+1 — its entries are the block in W minus the first panel row block
@@ -996,24 +1026,35 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
         lds_barrier();
         for (int kb = 0; kb < nblk && ok; kb++) {
             const int pk = 6 * kb, nbelow = nblk - 1 - kb;
+            CH_TICK(0)
             // ---- B1: panel rows of step kb; factor of the pivot block and its z into W / rW
             if (tid < 6 * nbelow) {
                 const int prow = pk + 6 + tid;
-                double l[6], rr = 0;
+                double l[6], rr = 0, w6[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) w6[c] = W[prow * ldw + pk + c];
+                const double r0 = rW[prow];
 #pragma unroll
                 for (int c = 0; c < 6; c++) {
-                    double v = W[prow * ldw + pk + c];
+                    double v = w6[c];
 #pragma unroll
                     for (int e = 0; e < c; e++) v -= l[e] * Lk[c * (c + 1) / 2 + e];
                     v *= inv[c]; l[c] = v; rr += v * zk[c];
-                    Pn[tid * 7 + c] = v; W[prow * ldw + pk + c] = v;
                 }
-                rW[prow] -= rr;
-            } else if (tid >= 128 && tid < 128 + 27) {
-                const int t = tid - 128, a = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15), b = t - a * (a + 1) / 2;
-                cs6[t < 21 ? (pk + a) * ldw + pk + b : n * ldw + pk + (t - 21)] = pick27(Lk, zk, t);          // rW follows W
+#pragma unroll
+                for (int c = 0; c < 6; c++) { Pn[tid * 7 + c] = l[c]; W[prow * ldw + pk + c] = l[c]; }
+                rW[prow] = r0 - rr;
+            } else if (tid == 128) {                             // one lane, 27 stores with compile-time register indices (a 27-way select chain
+#pragma unroll                                               // per lane cost the writer wave ~1000 cycles: it was the long pole of this phase)
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                    for (int b = 0; b <= a; b++) W[(pk + a) * ldw + pk + b] = Lk[a * (a + 1) / 2 + b];
+                    rW[pk + a] = zk[a];
+                }
             }
+            CH_TICK(2)
             lds_barrier();
+            CH_TICK(3)
             // ---- A: pivot block kb+1 = W block - P0 P0^T (P0 = panel rows 0..5 of this step), then its factor and z
             if (nbelow > 0) {
                 // lane t < 21 of each wave forms entry t of the updated block, v_readlane hands all 21 to every lane
@@ -1032,13 +1073,17 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
                     for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
                 if (!good && tid == 0) ok = 0;
             }
+            CH_TICK(4)
             lds_barrier();
         }
     } else {
         lds_barrier();
         for (int kb = 0; kb < nblk && ok; kb++) {
             const int pk = 6 * kb, nbelow = nblk - 1 - kb;
+            CH_TICK(0)
+            CH_TICK(2)
             lds_barrier();
+            CH_TICK(3)
             // ---- B2: trailing update: tiles (row block ibr >= column block jc) except (0, 0), two 3-row halves each, packed densely
             const int it = tid - 192, tl = (it >> 1) + 1, h3 = 3 * (it & 1);
             int ibr = (int)((sqrtf(8.f * (float)tl + 1.f) - 1.f) * 0.5f);
@@ -1048,14 +1093,21 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
                 double o[3][6];
                 tile36(Pn + (6 * ibr + h3) * 7, Pn + 6 * jc * 7, o);
                 double* Wt = W + (size_t)(pk + 6 + 6 * ibr + h3) * ldw + pk + 6 + 6 * jc;
+                double w[3][6];                  // all 18 loads first: a load issued after a store waits a full LDS round trip for that store's operand
 #pragma unroll
                 for (int a = 0; a < 3; a++)
 #pragma unroll
-                    for (int b = 0; b < 6; b++) { const double w = Wt[a * ldw + b]; Wt[a * ldw + b] = (jc == ibr && b > h3 + a) ? w : w - o[a][b]; }     // select, not a branch
+                    for (int b = 0; b < 6; b++) w[a][b] = Wt[a * ldw + b];
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 6; b++) Wt[a * ldw + b] = (jc == ibr && b > h3 + a) ? w[a][b] : w[a][b] - o[a][b];     // select, not a branch
             }
+            CH_TICK(4)
             lds_barrier();
         }
     }
+    CH_TICK(5)
     __syncthreads();
     if (ok) {                                                // backward sweep in LDS, row oriented: x_k = L_kk^-T (z_k - acc_k), acc_j += L_kj^T x_k
         for (int kb = nblk - 1; kb >= 0; kb--) {
@@ -1087,6 +1139,8 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
         }
         for (int t = tid; t < n; t += CH_NT) P.x[t] = rW[t];
     }
+    CH_TICK(6)
+    CH_PROF_PRINT("small6 [0 bar | 2 B1 | 3 bar | 4 A or B2 | 6 back]")
     if (tid == 0) P.scal[4] = ok ? 1.0 : 0.0;
 }
 
