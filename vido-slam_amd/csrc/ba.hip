@@ -856,6 +856,8 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
 #pragma unroll                                               // compile-time register indices, lanes 704..730 of role T stream them to HBM
                 for (int i = 0; i < 21; i++) stg[i] = Lk[i];
 #pragma unroll
+                for (int c = 0; c < 6; c++) stg[c * (c + 1) / 2 + c] = inv[c];                 // diagonal: 1 / L_cc for the back sweep (no FP64 division in its chain)
+#pragma unroll
                 for (int c = 0; c < 6; c++) stg[21 + c] = zk[c];
             }
             CH_TICK(2)
@@ -956,7 +958,7 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
 #pragma unroll
                 for (int c = 5; c >= 0; c--) { double v = t6[c];
 #pragma unroll
-                    for (int e = c + 1; e < 6; e++) v -= Lk[e * (e + 1) / 2 + c] * t6[e]; t6[c] = v / Lk[c * (c + 1) / 2 + c]; }
+                    for (int e = c + 1; e < 6; e++) v -= Lk[e * (e + 1) / 2 + c] * t6[e]; t6[c] = v * Lk[c * (c + 1) / 2 + c]; }
                 if (tid < 6) { double v = t6[5];
 #pragma unroll
                     for (int c = 0; c < 5; c++) v = (tid == c) ? t6[c] : v;
@@ -1048,7 +1050,7 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
 #pragma unroll                                               // per lane cost the writer wave ~1000 cycles: it was the long pole of this phase)
                 for (int a = 0; a < 6; a++) {
 #pragma unroll
-                    for (int b = 0; b <= a; b++) W[(pk + a) * ldw + pk + b] = Lk[a * (a + 1) / 2 + b];
+                    for (int b = 0; b <= a; b++) W[(pk + a) * ldw + pk + b] = b == a ? inv[a] : Lk[a * (a + 1) / 2 + b];      // diagonal: 1 / L_aa for the back sweep
                     rW[pk + a] = zk[a];
                 }
             }
@@ -1123,7 +1125,7 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
 #pragma unroll
                 for (int c = 5; c >= 0; c--) { double v = t6[c];
 #pragma unroll
-                    for (int e = c + 1; e < 6; e++) v -= Lk[e * (e + 1) / 2 + c] * t6[e]; t6[c] = v / Lk[c * (c + 1) / 2 + c]; }
+                    for (int e = c + 1; e < 6; e++) v -= Lk[e * (e + 1) / 2 + c] * t6[e]; t6[c] = v * Lk[c * (c + 1) / 2 + c]; }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int c = 0; c < 6; c++) if (tid == c) rW[pk + c] = t6[c];
