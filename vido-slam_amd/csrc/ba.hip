@@ -63,6 +63,17 @@ __device__ __forceinline__ void huber_w(double e2, double delta, int use, double
     if (!use || e2 <= delta * delta) { r0 = e2; r1 = 1.0; return; }
     const double s = sqrt(e2); r0 = 2 * s * delta - delta * delta; r1 = delta / s;
 }
+// sum over a workgroup, ONE atomic per workgroup: FP64 atomics onto one address retire at ~45 ns each whatever the grid looks like
+// (a million-edge chi2 with one atomic per wave spent 175 of its 190 us queueing on them)
+__device__ __forceinline__ void block_atomic_add(double* out, double v)
+{
+    __shared__ double wsum[16];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += wsum[w]; atomicAdd(out, t); }
+}
 // address of entry (row, col) of the reduced system, or nullptr when the band layout does not store it (upper triangle)
 __device__ __forceinline__ double* s_entry(const BaDev& P, int row, int col)
 {
@@ -1177,47 +1188,43 @@ __global__ void k_ba_update_cams(BaDev P, double lambda)
 // load chain instead of 17), the three partial sums meet through xor 1|2|4 shuffles.
 __global__ __launch_bounds__(256) void k_ba_backsub(BaDev P, int n_ptl, double lambda)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x, l = g >> 3, sub = g & 7;
+    const int sub = threadIdx.x & 7;
     double sc = 0;
-    const bool on = l < n_ptl;
-    double t0 = 0, t1 = 0, t2 = 0;
-    if (on) {
-        for (int s = P.pt_start[l] + sub; s < P.pt_start[l + 1]; s += 8) {
-            const double* W = P.W + 18 * (size_t)s; const double* xc = P.x + 6 * P.slot_cam[s];
+    for (int l0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; l0 - (int)(threadIdx.x >> 3) < n_ptl; l0 += (gridDim.x * blockDim.x) >> 3) {   // uniform trip count per workgroup
+        const int l = l0;
+        const bool on = l < n_ptl;
+        double t0 = 0, t1 = 0, t2 = 0;
+        if (on) {
+            for (int s = P.pt_start[l] + sub; s < P.pt_start[l + 1]; s += 8) {
+                const double* W = P.W + 18 * (size_t)s; const double* xc = P.x + 6 * P.slot_cam[s];
 #pragma unroll
-            for (int a = 0; a < 6; a++) { t0 -= W[a * 3] * xc[a]; t1 -= W[a * 3 + 1] * xc[a]; t2 -= W[a * 3 + 2] * xc[a]; }
+                for (int a = 0; a < 6; a++) { t0 -= W[a * 3] * xc[a]; t1 -= W[a * 3 + 1] * xc[a]; t2 -= W[a * 3 + 2] * xc[a]; }
+            }
+        }
+#pragma unroll
+        for (int o = 4; o >= 1; o >>= 1) { t0 += __shfl_xor(t0, o, 64); t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+        if (on && sub == 0) {
+            const double b0 = P.bp[3 * (size_t)l], b1 = P.bp[3 * (size_t)l + 1], b2 = P.bp[3 * (size_t)l + 2];
+            t0 += b0; t1 += b1; t2 += b2;
+            double Di[9]; inv3sym(P.Hpp + 6 * (size_t)l, lambda, Di);
+            const double x0 = Di[0] * t0 + Di[1] * t1 + Di[2] * t2, x1 = Di[3] * t0 + Di[4] * t1 + Di[5] * t2, x2 = Di[6] * t0 + Di[7] * t1 + Di[8] * t2;
+            P.pt_new[3 * (size_t)l] = P.pt[3 * (size_t)l] + x0; P.pt_new[3 * (size_t)l + 1] = P.pt[3 * (size_t)l + 1] + x1; P.pt_new[3 * (size_t)l + 2] = P.pt[3 * (size_t)l + 2] + x2;
+            sc += x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
         }
     }
-#pragma unroll
-    for (int o = 4; o >= 1; o >>= 1) { t0 += __shfl_xor(t0, o, 64); t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
-    if (on && sub == 0) {
-        const double b0 = P.bp[3 * (size_t)l], b1 = P.bp[3 * (size_t)l + 1], b2 = P.bp[3 * (size_t)l + 2];
-        t0 += b0; t1 += b1; t2 += b2;
-        double Di[9]; inv3sym(P.Hpp + 6 * (size_t)l, lambda, Di);
-        const double x0 = Di[0] * t0 + Di[1] * t1 + Di[2] * t2, x1 = Di[3] * t0 + Di[4] * t1 + Di[5] * t2, x2 = Di[6] * t0 + Di[7] * t1 + Di[8] * t2;
-        P.pt_new[3 * (size_t)l] = P.pt[3 * (size_t)l] + x0; P.pt_new[3 * (size_t)l + 1] = P.pt[3 * (size_t)l + 1] + x1; P.pt_new[3 * (size_t)l + 2] = P.pt[3 * (size_t)l + 2] + x2;
-        sc = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
-    }
-    __shared__ double wsum[4];               // one atomic per workgroup: same-address FP64 atomics serialise in L2
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sc;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(P.scal + 3, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+    block_atomic_add(P.scal + 3, sc);
 }
 __global__ __launch_bounds__(256) void k_ba_chi2(BaDev P, const double* cam, const double* pt, double* out)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    double v = 0;
-    if (k < P.n_obs) {
+    double acc = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < P.n_obs; k += gridDim.x * blockDim.x) {      // grid-stride: <= 512 workgroups
         const double* X = cam + 12 * P.obs_cam[k]; const double* p = pt + 3 * (size_t)P.obs_pt[k]; const double* m = P.obs_meas + 3 * (size_t)k;
         const double d0 = p[0] - X[3], d1 = p[1] - X[7], d2 = p[2] - X[11];
         const double e0 = X[0] * d0 + X[4] * d1 + X[8] * d2 - m[0], e1 = X[1] * d0 + X[5] * d1 + X[9] * d2 - m[1], e2 = X[2] * d0 + X[6] * d1 + X[10] * d2 - m[2];
-        double w; huber_w(P.info_obs * (e0 * e0 + e1 * e1 + e2 * e2), P.huber_obs, P.use_huber, v, w);
+        double v, w; huber_w(P.info_obs * (e0 * e0 + e1 * e1 + e2 * e2), P.huber_obs, P.use_huber, v, w);
+        acc += v;
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, v);
+    block_atomic_add(out, acc);
 }
 
 // ---- object part: dynamic-point chains -------------------------------------------------------------------------
@@ -1793,7 +1800,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     // robust chi2 of the whole graph at (cam, pt): shard part on the device, summed over ranks
     auto chi2_at = [&](const double* cam, const double* pt, int slot, double* out) -> int {
         HIP_TRY(ctx, hipMemsetAsync(D.scal + slot, 0, sizeof(double), st));
-        if (no) hipLaunchKernelGGL(k_ba_chi2, dim3((no + 255) / 256), dim3(256), 0, st, D, cam, pt, D.scal + slot);
+        if (no) hipLaunchKernelGGL(k_ba_chi2, dim3(std::min((no + 255) / 256, 512)), dim3(256), 0, st, D, cam, pt, D.scal + slot);
         if (nd) hipLaunchKernelGGL(k_badyn_chi2, dim3((nd + 255) / 256), dim3(256), 0, st, D, cam, (const double*)D.dyn, D.scal + slot);
         const int ncf = D.n_odo + (D.prior_cam >= 0 ? 1 : 0);
         if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3(ncf), dim3(64), 0, st, D, 0, cam, D.scal + slot);
@@ -1867,7 +1874,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             // ---- trial state + its chi2
             hipLaunchKernelGGL(k_ba_update_cams, dim3((n_pose + 63) / 64), dim3(64), 0, st, D, (allreduce && p.rank != 0) ? 0.0 : lambda);
             if (allreduce && p.rank != 0) HIP_TRY(ctx, hipMemsetAsync(D.scal + 3, 0, sizeof(double), st));      // camera part of computeScale counted once (rank 0)
-            if (n_ptl) hipLaunchKernelGGL(k_ba_backsub, dim3((n_ptl + 31) / 32), dim3(256), 0, st, D, n_ptl, lambda);
+            if (n_ptl) hipLaunchKernelGGL(k_ba_backsub, dim3(std::min((n_ptl + 31) / 32, 1024)), dim3(256), 0, st, D, n_ptl, lambda);
             if (no) hipLaunchKernelGGL(k_ba_chi2, dim3((no + 255) / 256), dim3(256), 0, st, D, D.cam_new, D.pt_new, D.scal + 2);
             if (nd) { hipLaunchKernelGGL(k_badyn_backsub, dim3((n_chain + 63) / 64), dim3(64), 0, st, D, lambda);
                       hipLaunchKernelGGL(k_badyn_chi2, dim3((nd + 255) / 256), dim3(256), 0, st, D, (const double*)D.cam_new, (const double*)D.dyn_new, D.scal + 2); }
