@@ -949,6 +949,10 @@ cv::Mat System::TrackRGBD(const cv::Mat& im, cv::Mat& depthmap, const cv::Mat& f
                           const std::vector<std::vector<float> >& vObjPose_gt, const double& ts, cv::Mat& imTraj, const int& nImage)
 {
     if (mSensor != RGBD) throw std::runtime_error("ERROR: you called TrackRGBD but input sensor was not set to RGBD.");
+    // the realtime demo hands over the services' wire types (run_vido.cc:57-110: depth MONO16, mask MONO8); the offline one converts first
+    // (run_vido_slam.cc:96-118).  Both are accepted: 16U depth -> 32F (converted copy becomes the caller's Mat, like convertTo in place), 8U mask -> 32S.
+    if (depthmap.type() == CV_16UC1) { cv::Mat d32; depthmap.convertTo(d32, CV_32F); depthmap = d32; }
+    if (masksem.type() == CV_8UC1) { cv::Mat m32; masksem.convertTo(m32, CV_32SC1); return mpTracker->GrabImageRGBD(im, depthmap, flowmap, m32, Tgt, vObjPose_gt, ts, imTraj, nImage); }
     return mpTracker->GrabImageRGBD(im, depthmap, flowmap, masksem, Tgt, vObjPose_gt, ts, imTraj, nImage);
 }
 void System::SaveResultsIJRR2020(const std::string& prefix)   // System.cc:80-240 (pose / motion files; GT files are not produced)

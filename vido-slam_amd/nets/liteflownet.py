@@ -169,7 +169,7 @@ def analyse_flow(net, previous_bgr, current_bgr):
     bilinear resize back, rescale u by W/W', v by H/H')."""
     dev = next(net.parameters()).device
     def prep(img):
-        t = torch.as_tensor(img[:, :, ::-1].copy(), device=dev).permute(2, 0, 1).float().div(255.0).unsqueeze(0)
+        t = (img.to(dev).flip(-1) if torch.is_tensor(img) else torch.as_tensor(img[:, :, ::-1].copy(), device=dev)).permute(2, 0, 1).float().div(255.0).unsqueeze(0)   # a device tensor stays on the device
         return t
     a, b = prep(previous_bgr), prep(current_bgr)
     H, W = a.shape[2], a.shape[3]

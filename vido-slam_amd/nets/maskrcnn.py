@@ -379,7 +379,7 @@ def analyse_image(net, bgr, feed=(1088, 800), confidence=0.8):
     HxWx3 u8 BGR -> (label image HxW u8 = sum of mask * class index, label indices).  The frame is area-resized to 800x1088
     (W x H, cv2.INTER_AREA; third-party, restated with torch's area interpolation), flipped to RGB, NOT normalised."""
     dev = next(net.parameters()).device
-    t = torch.as_tensor(bgr[:, :, ::-1].copy(), device=dev).permute(2, 0, 1).float().unsqueeze(0)
+    t = (bgr.to(dev).flip(-1) if torch.is_tensor(bgr) else torch.as_tensor(bgr[:, :, ::-1].copy(), device=dev)).permute(2, 0, 1).float().unsqueeze(0)
     H, W = t.shape[-2:]
     out = net(F.interpolate(t, size=feed, mode="area"))
     rw, rh = float(W) / feed[1], float(H) / feed[0]

@@ -112,7 +112,7 @@ def analyse_depth(net, bgr, feed=(192, 640)):
     """run_mono_depth.py:101-156: HxWx3 u8 BGR -> HxW u16 (area-resize to 640x192, BGR->RGB, /255, forward, bilinear resize of
     disp_0 back, min-max normalise to [0, 65536])."""
     dev = next(net.parameters()).device
-    t = torch.as_tensor(bgr[:, :, ::-1].copy(), device=dev).permute(2, 0, 1).float().unsqueeze(0)
+    t = (bgr.to(dev).flip(-1) if torch.is_tensor(bgr) else torch.as_tensor(bgr[:, :, ::-1].copy(), device=dev)).permute(2, 0, 1).float().unsqueeze(0)
     H, W = t.shape[2], t.shape[3]
     x = F.interpolate(t, size=feed, mode="area").div(255.0)             # cv2.INTER_AREA
     disp = F.interpolate(net(x), size=(H, W), mode="bilinear", align_corners=False)[0, 0]

@@ -3,4 +3,4 @@ Python identifier), so `import vido_slam_amd` resolves its sub-modules from ther
 import os as _os
 __path__ = [_os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "vido-slam_amd")]
 from .host import *  # noqa: F401,F403,E402
-from . import problems, synth  # noqa: F401,E402
+from . import problems, synth, g2o_io  # noqa: F401,E402
