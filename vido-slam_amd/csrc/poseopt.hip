@@ -114,69 +114,107 @@ __device__ __forceinline__ void huber(double e2, double delta, double& rho0, dou
     else { const double s = sqrt(e2); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
 }
 
-// workgroup all-reduce of NV doubles (sum, or max for entries >= first_max): wave shuffle tree, then a
+// Transposing wave reduction (see ba.hip): N per-lane values -> one wave total per lane.  Each step halves the number of values a lane carries by
+// trading the half it does not keep with lane ^ O; once one value is left the remaining steps are a plain butterfly.  28 sums cost 29 double
+// shuffles instead of 168 — ds_bpermute goes through the CU's LDS pipe, which the 8 waves of the workgroup share, and the butterflies were a
+// quarter of an LM iteration.  idx = which of the N values the lane ends up with, valid = the lane is the one writer of that value.
+template <int N, int O>
+struct WaveTranspose {
+    static __device__ __forceinline__ void run(double* v, int lane, int& idx, bool& valid)
+    {
+        if constexpr (O == 0) { idx = 0; valid = true; }
+        else if constexpr (N > 1) {
+            constexpr int H = (N + 1) / 2;
+            const bool up = (lane & O) != 0;
+#pragma unroll
+            for (int a = 0; a < H; a++) {
+                const double lo = v[a], hi = (a + H < N) ? v[a + H] : 0.0;
+                const double send = up ? lo : hi, keep = up ? hi : lo;
+                v[a] = keep + __shfl_xor(send, O, 64);
+            }
+            int sub; bool sv;
+            WaveTranspose<H, O / 2>::run(v, lane, sub, sv);
+            idx = sub + (up ? H : 0); valid = sv && idx < N;
+        } else {
+            v[0] += __shfl_xor(v[0], O, 64);
+            WaveTranspose<1, O / 2>::run(v, lane, idx, valid);
+            valid = valid && !(lane & O);
+        }
+    }
+};
+// Workgroup barrier that orders LDS traffic only.  Every per-edge array in global memory is written and read by the SAME thread in every pass
+// (edge i belongs to thread i mod nt throughout), so nothing has to be visible across threads through global memory — but __syncthreads()
+// also waits for the stores in flight (vmcnt(0)): 12 barriers per LM iteration x ~1.5 us of store latency was the whole n-independent part
+// of an iteration (19 of 67 us at N = 3000).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// workgroup all-reduce of NV doubles: entries [0, NSUM) are summed, entries [NSUM, NV) max-reduced.  Wave stage as above, then a
 // fixed-order pass over the per-wave partials in LDS.  Every thread returns the same totals.
-template <int NV>
-__device__ void block_allreduce(double* v, int first_max, double* lds /* [16][NV] + [NV] */)
+template <int NV, int NSUM>
+__device__ void block_allreduce(double* v, double* lds /* [16][NV] + [NV] */)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
+    for (int k = NSUM; k < NV; k++) {
         double x = v[k];
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { const double y = __shfl_xor(x, o, 64); x = k >= first_max ? fmax(x, y) : x + y; }
+        for (int o = 32; o >= 1; o >>= 1) x = fmax(x, __shfl_xor(x, o, 64));
         v[k] = x;
     }
-    __syncthreads();
+    int idx; bool valid;
+    WaveTranspose<NSUM, 32>::run(v, lane, idx, valid);
+    lds_barrier();
+    if (valid) lds[wave * NV + idx] = v[0];
     if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < NV; k++) lds[wave * NV + k] = v[k];      // unrolled: a dynamic v[k] would push the accumulators to scratch
+        for (int k = NSUM; k < NV; k++) lds[wave * NV + k] = v[k];
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < NV) {
         const int k = threadIdx.x;
         double x = lds[k];
-        for (int w = 1; w < nw; w++) x = k >= first_max ? fmax(x, lds[w * NV + k]) : x + lds[w * NV + k];
+        for (int w = 1; w < nw; w++) x = k >= NSUM ? fmax(x, lds[w * NV + k]) : x + lds[w * NV + k];
         lds[16 * NV + k] = x;
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < NV; k++) v[k] = lds[16 * NV + k];
 }
 
-// 6x6 LDL^T solve in registers; A = upper-triangle-expanded symmetric matrix (row-major 36)
-__device__ bool ldlt6(const double* A, const double* b, double* x)
+// 6x6 LDL^T solve in registers on the packed upper triangle (row-major: 00 01 .. 05 11 12 .. 55): the normal equations are wave-uniform
+// values held in vector registers, and a full 6x6 copy of H plus one of S cost 144 of them (the kernel spilled, and a spill reload inside the
+// edge loops waits for every outstanding global load).  Same operation order as the dense form.
+#define PQ(a, c) ((a) * 6 - (a) * ((a) - 1) / 2 + ((c) - (a)))      /* c >= a */
+#define LL(i, j) L[(i) * ((i) - 1) / 2 + (j)]                        /* i > j  */
+__device__ bool ldlt6p(const double* A, const double* b, double* x)
 {
-    double L[36], D[6];
-#pragma unroll
-    for (int i = 0; i < 36; i++) L[i] = A[i];
+    double L[15], D[6];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-        double d = L[j * 6 + j];
+        double d = A[PQ(j, j)];
 #pragma unroll
-        for (int k = 0; k < 6; k++) if (k < j) d -= L[j * 6 + k] * L[j * 6 + k] * D[k];
+        for (int k = 0; k < 6; k++) if (k < j) d -= LL(j, k) * LL(j, k) * D[k];
         if (!(d > 0) || !isfinite(d)) { ok = false; d = 1.0; }
         D[j] = d;
 #pragma unroll
         for (int i = 0; i < 6; i++) if (i > j) {
-            double s = L[i * 6 + j];
+            double s = A[PQ(j, i)];
 #pragma unroll
-            for (int k = 0; k < 6; k++) if (k < j) s -= L[i * 6 + k] * L[j * 6 + k] * D[k];
-            L[i * 6 + j] = s / d;
+            for (int k = 0; k < 6; k++) if (k < j) s -= LL(i, k) * LL(j, k) * D[k];
+            LL(i, j) = s / d;
         }
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) { double s = b[i];
 #pragma unroll
-        for (int k = 0; k < 6; k++) if (k < i) s -= L[i * 6 + k] * x[k];
+        for (int k = 0; k < 6; k++) if (k < i) s -= LL(i, k) * x[k];
         x[i] = s; }
 #pragma unroll
     for (int i = 0; i < 6; i++) x[i] /= D[i];
 #pragma unroll
     for (int i = 5; i >= 0; i--) { double s = x[i];
 #pragma unroll
-        for (int k = 0; k < 6; k++) if (k > i) s -= L[k * 6 + i] * x[k];
+        for (int k = 0; k < 6; k++) if (k > i) s -= LL(k, i) * x[k];
         x[i] = s; }
     return ok;
 }
@@ -244,30 +282,27 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
                         acc[28] = fmax(acc[28], fabs(hll));
                     }
                 }
-                block_allreduce<NRED>(acc, 28, lds);
-                double H[36], b6[6];
-                { int q = 0;
+                block_allreduce<NRED, 28>(acc, lds);
+                double H[21], b6[6];                           // packed upper triangle, PQ(a, c)
 #pragma unroll
-                  for (int a = 0; a < 6; a++)
-#pragma unroll
-                      for (int c = a; c < 6; c++) { H[a * 6 + c] = acc[q]; H[c * 6 + a] = acc[q]; q++; } }
+                for (int q = 0; q < 21; q++) H[q] = acc[q];
 #pragma unroll
                 for (int a = 0; a < 6; a++) b6[a] = acc[21 + a];
                 double currentChi = acc[27]; const double iniChi = acc[27];
                 if (it == 0) {
                     double md = acc[28];
 #pragma unroll
-                    for (int a = 0; a < 6; a++) md = fmax(md, fabs(H[a * 6 + a]));
+                    for (int a = 0; a < 6; a++) md = fmax(md, fabs(H[PQ(a, a)]));
                     lambda = 1e-5 * md; ni = 2; nBad = 0;
                 }
                 double rho = 0; int qmax = 0;
                 do {
                     const Se3 Tsave = T;
-                    double S[36], bs[6], xp[6];
+                    double S[21], bs[6], xp[6];
 #pragma unroll
-                    for (int k = 0; k < 36; k++) S[k] = H[k];
+                    for (int k = 0; k < 21; k++) S[k] = H[k];
 #pragma unroll
-                    for (int a = 0; a < 6; a++) { bs[a] = b6[a]; S[a * 6 + a] += lambda; }
+                    for (int a = 0; a < 6; a++) { bs[a] = b6[a]; S[PQ(a, a)] += lambda; }
                     if (flowm) {
                         double sa[27];
 #pragma unroll
@@ -287,16 +322,13 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
                                 for (int c = a; c < 6; c++) sa[q++] += dinv * (Bv[2 * a] * Bv[2 * c] + Bv[2 * a + 1] * Bv[2 * c + 1]);
                             }
                         }
-                        block_allreduce<27>(sa, 27, lds);
-                        int q = 0;
+                        block_allreduce<27, 27>(sa, lds);
 #pragma unroll
-                        for (int a = 0; a < 6; a++) {
-                            bs[a] -= sa[21 + a];
+                        for (int a = 0; a < 6; a++) bs[a] -= sa[21 + a];
 #pragma unroll
-                            for (int c = a; c < 6; c++) { S[a * 6 + c] -= sa[q]; if (c != a) S[c * 6 + a] -= sa[q]; q++; }
-                        }
+                        for (int q = 0; q < 21; q++) S[q] -= sa[q];
                     }
-                    const bool ok2 = ldlt6(S, bs, xp);
+                    const bool ok2 = ldlt6p(S, bs, xp);
                     double part[2] = {0, 0};          // [0] tempChi, [1] landmark part of computeScale
                     if (ok2) se3_oplus_left(T, xp);
                     for (int i = tid; i < n; i += nt) {
@@ -323,7 +355,7 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
                             part[0] += r0;
                         }
                     }
-                    block_allreduce<2>(part, 2, lds);
+                    block_allreduce<2, 2>(part, lds);
                     double tempChi = part[0], scale = part[1];
                     if (ok2) {
 #pragma unroll
@@ -331,7 +363,7 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
                     } else tempChi = DBL_MAX;
                     rho = (currentChi - tempChi) / (scale + 1e-3);
                     if (rho > 0 && isfinite(tempChi)) {
-                        double alpha = 1. - pow((2 * rho - 1), 3);
+                        const double tr = 2 * rho - 1; double alpha = 1. - tr * tr * tr;      // pow(x, 3) of the reference; the libm call is ~500 instructions on every lane
                         alpha = fmin(alpha, 2. / 3.);
                         lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
                     } else {
@@ -353,7 +385,7 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
                     }
                     if (flowm) { const double a = p.f[2 * i] - p.flow0[2 * i], b = p.f[2 * i + 1] - p.flow0[2 * i + 1]; last[0] += p.info_prior * (a * a + b * b); }
                 }
-                block_allreduce<1>(last, 1, lds);
+                block_allreduce<1, 1>(last, lds);
                 if (chi2_check < last[0] && it > 0) terminate = true;
                 chi2_check = last[0];
                 chi2_final = currentChi;
@@ -368,7 +400,7 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
                 if (chi2 > round_chi2_th) { p.outlier[i] = 1; nb[0] += 1; } else p.outlier[i] = 0;
                 if (round == p.drop_kernel_after_round) p.has_kernel[i] = 0;
             }
-            block_allreduce<1>(nb, 1, lds);
+            block_allreduce<1, 1>(nb, lds);
             n_inl = n - (int)nb[0];
         }
     }
