@@ -224,15 +224,19 @@ __device__ bool ldlt6p(const double* A, const double* b, double* x)
 __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict__ probs)
 {
     __shared__ double lds[17 * NRED];
-    const PoseProbDev p = probs[blockIdx.x];
+    __shared__ double tsave[12];                              // pose before the trial step (restored when the step is rejected)
+    // a reference, not a copy: the ~130 dwords of the problem descriptor are wave-uniform and are re-read with scalar loads where they are used;
+    // held in registers for the whole kernel they pushed the allocator into scratch (and a scratch reload waits on every store in flight)
+    const PoseProbDev& p = probs[blockIdx.x];
     // the edge->thread mapping depends on the problem alone (not on the batch it is launched with), so results are bit-identical
     // however problems are grouped: nt = ~4 edges per thread, threads beyond it only take part in the reductions
     const int n = p.n, nt = min((int)blockDim.x, max(64, (((n + 3) >> 2) + 63) & ~63)), tid = (int)threadIdx.x < nt ? (int)threadIdx.x : n;
     const bool flowm = p.mode == 1;
-    Se3 T, Tinit;
+    Se3 T;
+    auto reset_pose = [&]() {
 #pragma unroll
-    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Tinit.R[r * 3 + c] = p.T_init[r * 4 + c]; Tinit.t[r] = p.T_init[r * 4 + 3]; }
-    T = Tinit;
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T.R[r * 3 + c] = p.T_init[r * 4 + c]; T.t[r] = p.T_init[r * 4 + 3]; } };
+    reset_pose();
     for (int i = tid; i < n; i += nt) {
         p.outlier[i] = 0; p.has_kernel[i] = p.use_huber ? 1 : 0;
         if (flowm) { p.f[2 * i] = p.flow0[2 * i]; p.f[2 * i + 1] = p.flow0[2 * i + 1]; }
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
     int total_iters = 0, n_inl = 0; double chi2_final = 0;
     if (n >= 3) {
         for (int round = 0; round < p.rounds; round++) {
-            T = Tinit;
+            reset_pose();
             double lambda = -1, ni = 2, chi2_check = 0; int nBad = 0;
             const int round_iters = probs[blockIdx.x].iters[round];        // dynamic index: read through the pointer so that the local copy `p` stays in registers
             const float round_chi2_th = probs[blockIdx.x].chi2_th[round];
@@ -297,7 +301,12 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
                 }
                 double rho = 0; int qmax = 0;
                 do {
-                    const Se3 Tsave = T;
+                    if (threadIdx.x == 0) {                      // one lane, compile-time register indices
+#pragma unroll
+                        for (int k = 0; k < 9; k++) tsave[k] = T.R[k];
+#pragma unroll
+                        for (int k = 0; k < 3; k++) tsave[9 + k] = T.t[k];
+                    }
                     double S[21], bs[6], xp[6];
 #pragma unroll
                     for (int k = 0; k < 21; k++) S[k] = H[k];
@@ -367,7 +376,11 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
                         alpha = fmin(alpha, 2. / 3.);
                         lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
                     } else {
-                        lambda *= ni; ni *= 2; T = Tsave;
+                        lambda *= ni; ni *= 2;
+#pragma unroll
+                        for (int k = 0; k < 9; k++) T.R[k] = tsave[k];       // written before the barriers of this trial's reductions; a re-write by the next trial stores the same values
+#pragma unroll
+                        for (int k = 0; k < 3; k++) T.t[k] = tsave[9 + k];
                         if (flowm) for (int i = tid; i < n; i += nt) { p.f[2 * i] = p.fsave[2 * i]; p.f[2 * i + 1] = p.fsave[2 * i + 1]; }
                     }
                     qmax++;
