@@ -354,23 +354,28 @@ __global__ void k_ba_add_odo(BaDev P)
 //         map, so a chunk touches a short run of cameras: a BA_WC-camera window of S is accumulated in LDS and flushed
 //         once per chunk (blocks that fall outside the window go to HBM atomics directly).
 #define BA_WC 16
-#define BA_CHUNK 64
+#define SB_PITCH 37       // doubles per 6x6 block of the LDS-resident S (odd: consecutive blocks start in different bank pairs)
+#define BA_CHUNK 256      // landmarks per window flush: every flush is a set of HBM atomics, and atomics onto one cache line serialise (~45 ns each)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_ba_schur(BaDev P, int n_ptl, double lambda, int kcap, double* S_part /*[grid][n6*n6 + n6], MODE 0*/,
+__global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void k_ba_schur(BaDev P, int n_ptl, double lambda, int kcap, double* S_part /*[grid][n6*n6 + n6], MODE 0*/,
                                                   const int* __restrict__ chunk_cmin /*MODE 2*/, const int* __restrict__ lorder /*MODE 2: landmarks by first camera*/)
 {
     extern __shared__ double lds[];
     const int n6 = P.n6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int wn = MODE == 0 ? n6 : BA_WC * 6;                 // side of the LDS-resident (window of) S
-    const int ldw = wn + 1;                                  // odd row pitch: a 6x6 block's rows (and the rows of different lanes) fall into different LDS banks
-    double* Sl = lds;                                        // [wn*ldw + wn] for MODE 0 / 2
-    double* stage = lds + (MODE == 1 ? 0 : (size_t)wn * ldw + wn) + (size_t)wave * (2 * kcap * 18);   // W, WD of up to kcap obs per wave
+    // LDS layout of (the window of) S: the lower-triangle 6x6 blocks, block (ci >= cj) at [(ci(ci+1)/2 + cj) * SB_PITCH + 6a + b], then the rhs.
+    // Lanes accumulate the SAME element (a, b) of DIFFERENT blocks at a time: with rows of the dense matrix as the layout every such address
+    // differs by a multiple of 6 doubles and only 16 of the 32 bank pairs are ever hit (>= 4-way conflicts on every ds_add_f64); with one
+    // block per 37 doubles the block index walks all of them.
+    const int wc = wn / 6, nblk_l = wc * (wc + 1) / 2, rhs_off = nblk_l * SB_PITCH;
+    double* Sl = lds;                                        // [nblk_l * SB_PITCH + wn] for MODE 0 / 2
+    double* stage = lds + (MODE == 1 ? 0 : (size_t)rhs_off + wn) + (size_t)wave * (2 * kcap * 18);   // W, WD of up to kcap obs per wave
     const int n_units = MODE == 2 ? (n_ptl + BA_CHUNK - 1) / BA_CHUNK : 1;
     for (int unit = MODE == 2 ? blockIdx.x : 0; unit < n_units; unit += MODE == 2 ? gridDim.x : 1) {
         int cbase = 0, l_beg, l_end, l_step;
         if (MODE == 2) { cbase = chunk_cmin[unit]; l_beg = unit * BA_CHUNK + wave; l_end = min(n_ptl, (unit + 1) * BA_CHUNK); l_step = nw; }
         else { l_beg = blockIdx.x * nw + wave; l_end = n_ptl; l_step = gridDim.x * nw; }
-        if (MODE != 1) { for (int t = threadIdx.x; t < wn * ldw + wn; t += blockDim.x) Sl[t] = 0; __syncthreads(); }
+        if (MODE != 1) { for (int t = threadIdx.x; t < rhs_off + wn; t += blockDim.x) Sl[t] = 0; __syncthreads(); }
         for (int lp = l_beg; lp < l_end; lp += l_step) {
             const int l = MODE == 2 ? lorder[lp] : lp;
             const int beg = P.pt_start[l], k = min(P.pt_start[l + 1] - beg, kcap);
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev P, int n_ptl, double lam
                 const int c = P.slot_cam[beg + t / 6] - cbase;
                 const double rv = -(d0 * b0 + d1 * b1 + d2 * b2);
                 if (MODE == 1 || (MODE == 2 && (c < 0 || c >= BA_WC))) atomicAdd(P.r + 6 * (c + cbase) + t % 6, rv);
-                else atomicAdd(Sl + (size_t)wn * ldw + 6 * c + t % 6, rv);
+                else atomicAdd(Sl + rhs_off + 6 * c + t % 6, rv);
             }
             __builtin_amdgcn_wave_barrier();
             // slot pairs (i >= j): block (ci, cj) -= WD_i W_j^T ; one 6x6 block per lane-iteration
@@ -422,42 +427,59 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev P, int n_ptl, double lam
                     for (int b = 0; b < 6; b++) {
                         const double v = -(A[a * 3] * Bm[b * 3] + A[a * 3 + 1] * Bm[b * 3 + 1] + A[a * 3 + 2] * Bm[b * 3 + 2]);
                         if (to_hbm) { double* e = s_entry(P, 6 * (ci + cbase) + a, 6 * (cj + cbase) + b); if (e) atomicAdd(e, v); }
-                        else atomicAdd(Sl + (size_t)(6 * ci + a) * ldw + 6 * cj + b, v);
+                        else atomicAdd(Sl + (size_t)(ci * (ci + 1) / 2 + cj) * SB_PITCH + a * 6 + b, v);
                     }
             }
             __builtin_amdgcn_wave_barrier();
         }
         if (MODE == 0) {
             __syncthreads();
-            double* out = S_part + (size_t)blockIdx.x * ((size_t)n6 * n6 + n6);
-            for (int t = threadIdx.x; t < n6 * n6; t += blockDim.x) { const int r = t / n6, c = t - r * n6; out[t] = Sl[r * ldw + c]; }
-            for (int t = threadIdx.x; t < n6; t += blockDim.x) out[(size_t)n6 * n6 + t] = Sl[(size_t)wn * ldw + t];
+            double* out = S_part + (size_t)blockIdx.x * (rhs_off + n6);      // same block-major layout, k_ba_fold_parts maps it onto S
+            for (int t = threadIdx.x; t < rhs_off + n6; t += blockDim.x) out[t] = Sl[t];
         }
         if (MODE == 2) {                                          // flush the window: one HBM atomic per touched entry
             __syncthreads();
-            for (int t = threadIdx.x; t < wn * wn; t += blockDim.x) {
-                const int r = t / wn, c = t - r * wn;
-                const double v = Sl[r * ldw + c];
-                if (v != 0.0) { const int gr = 6 * cbase + r, gc = 6 * cbase + c; if (gr < n6 && gc < n6) { double* e = s_entry(P, gr, gc); if (e) atomicAdd(e, v); } }
+            for (int t = threadIdx.x; t < nblk_l * 36; t += blockDim.x) {
+                const int bid = t / 36, el = t - bid * 36;
+                const double v = Sl[bid * SB_PITCH + el];
+                if (v != 0.0) {
+                    int ci = (int)((sqrtf(8.f * (float)bid + 1.f) - 1.f) * 0.5f);
+                    ci -= (ci * (ci + 1) / 2 > bid); ci += ((ci + 1) * (ci + 2) / 2 <= bid);
+                    const int cj = bid - ci * (ci + 1) / 2, gr = 6 * (cbase + ci) + el / 6, gc = 6 * (cbase + cj) + el % 6;
+                    if (gr < n6 && gc < n6) { double* e = s_entry(P, gr, gc); if (e) atomicAdd(e, v); }
+                }
             }
-            for (int t = threadIdx.x; t < wn; t += blockDim.x) { const double v = Sl[(size_t)wn * ldw + t]; if (v != 0.0 && 6 * cbase + t < n6) atomicAdd(P.r + 6 * cbase + t, v); }
+            for (int t = threadIdx.x; t < wn; t += blockDim.x) { const double v = Sl[rhs_off + t]; if (v != 0.0 && 6 * cbase + t < n6) atomicAdd(P.r + 6 * cbase + t, v); }
             __syncthreads();
         }
     }
 }
 __global__ __launch_bounds__(256) void k_ba_fold_parts(BaDev P, const double* S_part, int nparts)
 {
-    const size_t sz = (size_t)P.n6 * P.n6 + P.n6;
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < sz; t += (size_t)gridDim.x * blockDim.x) {
+    // parts are block-major (k_ba_schur<0>): lower-triangle 6x6 blocks at [bid * SB_PITCH + 6a + b], then the rhs; S itself is dense row-major
+    const int nc = P.n6 / 6, nblk_l = nc * (nc + 1) / 2, rhs_off = nblk_l * SB_PITCH;
+    const size_t sz = (size_t)rhs_off + P.n6;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nblk_l * 36 + P.n6; t += gridDim.x * blockDim.x) {
+        const bool is_rhs = t >= nblk_l * 36;
+        const int bid = t / 36, el = t - bid * 36;
+        const size_t src = is_rhs ? (size_t)rhs_off + (t - nblk_l * 36) : (size_t)bid * SB_PITCH + el;
+        // blockIdx.y takes every gridDim.y-th part: a thread that walks all 256 parts serially is 64 dependent-latency steps (22 us for 60 KB);
+        // the gridDim.y partial sums of an entry meet through atomics (8 per address, spread over all of S)
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        int p = 0;
-        for (; p + 4 <= nparts; p += 4) {      // four independent load streams in flight
-            s0 += S_part[(size_t)p * sz + t]; s1 += S_part[(size_t)(p + 1) * sz + t];
-            s2 += S_part[(size_t)(p + 2) * sz + t]; s3 += S_part[(size_t)(p + 3) * sz + t];
+        int p = blockIdx.y; const int ps = gridDim.y;
+        for (; p + 3 * ps < nparts; p += 4 * ps) {      // four independent load streams in flight
+            s0 += S_part[(size_t)p * sz + src]; s1 += S_part[(size_t)(p + ps) * sz + src];
+            s2 += S_part[(size_t)(p + 2 * ps) * sz + src]; s3 += S_part[(size_t)(p + 3 * ps) * sz + src];
         }
-        for (; p < nparts; p++) s0 += S_part[(size_t)p * sz + t];
-        const double s = (s0 + s1) + (s2 + s3);
-        if (t < (size_t)P.n6 * P.n6) P.S[t] += s; else P.r[t - (size_t)P.n6 * P.n6] += s;
+        for (; p < nparts; p += ps) s0 += S_part[(size_t)p * sz + src];
+        const double sum = (s0 + s1) + (s2 + s3);
+        if (is_rhs) atomicAdd(P.r + (t - nblk_l * 36), sum);
+        else {
+            int ci = (int)((sqrtf(8.f * (float)bid + 1.f) - 1.f) * 0.5f);
+            ci -= (ci * (ci + 1) / 2 > bid); ci += ((ci + 1) * (ci + 2) / 2 <= bid);
+            const int cj = bid - ci * (ci + 1) / 2;
+            atomicAdd(P.S + (size_t)(6 * ci + el / 6) * P.n6 + 6 * cj + el % 6, sum);
+        }
     }
 }
 
@@ -1764,8 +1786,11 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     const int kcap = std::max(maxk, 1);
     const size_t lds_chol = ((size_t)(n6 + 1) * ((n6 + 1) | 1) + n6 + 2) * sizeof(double);
     const size_t lds_chol6 = ((size_t)n6 * (n6 + 1) + n6 + (size_t)n6 * 7 + 8) * sizeof(double);
-    const size_t win_sz = (size_t)(BA_WC * 6) * (BA_WC * 6 + 1) + BA_WC * 6;
-    const size_t lds_schur = ((lds_path ? sz_sr + n6 : win_sz) + (size_t)4 * (2 * kcap * 18)) * sizeof(double);
+    const size_t win_sz = (size_t)(BA_WC * (BA_WC + 1) / 2) * SB_PITCH + BA_WC * 6;
+    const size_t loc_sz = (size_t)(n_pose * (n_pose + 1) / 2) * SB_PITCH + n6;          // MODE 0: every lower block of S + rhs
+    // MODE 2 runs up to 16 waves per workgroup (one landmark per wave at a time, BA_CHUNK landmarks per window flush); as many as the per-wave staging leaves room for
+    int schur2_waves = 16; while (schur2_waves > 4 && (win_sz + (size_t)schur2_waves * (2 * kcap * 18)) * sizeof(double) > 150 * 1024) schur2_waves >>= 1;
+    const size_t lds_schur = ((lds_path ? loc_sz : win_sz) + (size_t)(lds_path ? 4 : schur2_waves) * (2 * kcap * 18)) * sizeof(double);
     // MODE 2 walks the landmarks ordered by their first camera, so that a chunk of BA_CHUNK of them touches a short run of cameras
     // (the BA_WC-camera window of S held in LDS); window base of a chunk = lowest first camera in it
     int* d_chunk_cmin = nullptr; int* d_lorder = nullptr; int n_chunks = (n_ptl + BA_CHUNK - 1) / BA_CHUNK;
@@ -1855,8 +1880,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if (n_ptl) {
                 if (lds_path) {
                     hipLaunchKernelGGL(k_ba_schur<0>, dim3(schur_grid), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, BS->d_parts, (const int*)nullptr, (const int*)nullptr);
-                    hipLaunchKernelGGL(k_ba_fold_parts, dim3(std::min(256, (int)((sz_sr + 255) / 256))), dim3(256), 0, st, D, BS->d_parts, schur_grid);
-                } else hipLaunchKernelGGL(k_ba_schur<2>, dim3(std::min(n_chunks, 1024)), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, (double*)nullptr, (const int*)d_chunk_cmin, (const int*)d_lorder);
+                    hipLaunchKernelGGL(k_ba_fold_parts, dim3(std::min(256, (int)((loc_sz + 255) / 256)), std::min(8, schur_grid)), dim3(256), 0, st, D, BS->d_parts, schur_grid);
+                } else hipLaunchKernelGGL(k_ba_schur<2>, dim3(std::min(n_chunks, 1024)), dim3(64 * schur2_waves), lds_schur, st, D, n_ptl, lambda, kcap, (double*)nullptr, (const int*)d_chunk_cmin, (const int*)d_lorder);
             }
             if (nd) {
                 hipLaunchKernelGGL(k_badyn_factor, dim3((n_chain + 63) / 64), dim3(64), 0, st, D, lambda);
