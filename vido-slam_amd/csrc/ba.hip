@@ -46,6 +46,7 @@ struct BaDev {
     double *S, *r, *x;                                      // [n6*n6], [n6], [n6]
     double *scal;                                           // [8]: 0 chi2 1 maxdiag 2 tempChi 3 scale 4 ok
     const double *odo_info, *odo_delta;                     // per camera-camera factor (odometry | object-motion smoothness)
+    int n_cam_ord; const int *pose_ord, *ord_pose;                         // camera ordinal of a pose index (-1: object motion) and back: the Schur window counts CAMERAS, not poses
     int bw, ldb;                                            // bw >= 0: S is stored as a lower BAND, entry (r, c) at S[r*ldb + c - r + bw]; bw < 0: dense n6 x n6
     // ---- object part (FullBatchOptimization, STATIC_ONLY = false).  n_cam above counts ALL pose vertices: cameras first,
     // then the object motions H.  Dynamic points are stored chain-major (a chain = one dynamic tracklet).
@@ -405,9 +406,9 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void k_ba_schur(BaDev P, in
                 const double w0 = Wl[t * 3], w1 = Wl[t * 3 + 1], w2 = Wl[t * 3 + 2];
                 const double d0 = w0 * Di[0] + w1 * Di[3] + w2 * Di[6], d1 = w0 * Di[1] + w1 * Di[4] + w2 * Di[7], d2 = w0 * Di[2] + w1 * Di[5] + w2 * Di[8];
                 WDl[t * 3] = d0; WDl[t * 3 + 1] = d1; WDl[t * 3 + 2] = d2;
-                const int c = P.slot_cam[beg + t / 6] - cbase;
+                const int cpose = P.slot_cam[beg + t / 6], c = (MODE == 2 ? P.pose_ord[cpose] : cpose) - cbase;      // MODE 2: cbase and the window count cameras
                 const double rv = -(d0 * b0 + d1 * b1 + d2 * b2);
-                if (MODE == 1 || (MODE == 2 && (c < 0 || c >= BA_WC))) atomicAdd(P.r + 6 * (c + cbase) + t % 6, rv);
+                if (MODE == 1 || (MODE == 2 && (c < 0 || c >= BA_WC))) atomicAdd(P.r + 6 * cpose + t % 6, rv);
                 else atomicAdd(Sl + rhs_off + 6 * c + t % 6, rv);
             }
             __builtin_amdgcn_wave_barrier();
@@ -418,7 +419,8 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void k_ba_schur(BaDev P, in
                 while (i * (i + 1) / 2 > pq) i--;
                 while ((i + 1) * (i + 2) / 2 <= pq) i++;
                 const int j = pq - i * (i + 1) / 2;
-                const int ci = P.slot_cam[beg + i] - cbase, cj = P.slot_cam[beg + j] - cbase;
+                const int pi = P.slot_cam[beg + i], pj = P.slot_cam[beg + j];
+                const int ci = (MODE == 2 ? P.pose_ord[pi] : pi) - cbase, cj = (MODE == 2 ? P.pose_ord[pj] : pj) - cbase;
                 const double* A = WDl + i * 18; const double* Bm = Wl + j * 18;
                 const bool to_hbm = MODE == 1 || (MODE == 2 && (cj < 0 || ci >= BA_WC));       // ci >= cj
 #pragma unroll
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void k_ba_schur(BaDev P, in
 #pragma unroll
                     for (int b = 0; b < 6; b++) {
                         const double v = -(A[a * 3] * Bm[b * 3] + A[a * 3 + 1] * Bm[b * 3 + 1] + A[a * 3 + 2] * Bm[b * 3 + 2]);
-                        if (to_hbm) { double* e = s_entry(P, 6 * (ci + cbase) + a, 6 * (cj + cbase) + b); if (e) atomicAdd(e, v); }
+                        if (to_hbm) { double* e = s_entry(P, 6 * pi + a, 6 * pj + b); if (e) atomicAdd(e, v); }
                         else atomicAdd(Sl + (size_t)(ci * (ci + 1) / 2 + cj) * SB_PITCH + a * 6 + b, v);
                     }
             }
@@ -445,11 +447,11 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void k_ba_schur(BaDev P, in
                 if (v != 0.0) {
                     int ci = (int)((sqrtf(8.f * (float)bid + 1.f) - 1.f) * 0.5f);
                     ci -= (ci * (ci + 1) / 2 > bid); ci += ((ci + 1) * (ci + 2) / 2 <= bid);
-                    const int cj = bid - ci * (ci + 1) / 2, gr = 6 * (cbase + ci) + el / 6, gc = 6 * (cbase + cj) + el % 6;
-                    if (gr < n6 && gc < n6) { double* e = s_entry(P, gr, gc); if (e) atomicAdd(e, v); }
+                    const int cj = bid - ci * (ci + 1) / 2;
+                    if (cbase + ci < P.n_cam_ord) { const int gr = 6 * P.ord_pose[cbase + ci] + el / 6, gc = 6 * P.ord_pose[cbase + cj] + el % 6; double* e = s_entry(P, gr, gc); if (e) atomicAdd(e, v); }
                 }
             }
-            for (int t = threadIdx.x; t < wn; t += blockDim.x) { const double v = Sl[rhs_off + t]; if (v != 0.0 && 6 * cbase + t < n6) atomicAdd(P.r + 6 * cbase + t, v); }
+            for (int t = threadIdx.x; t < wn; t += blockDim.x) { const double v = Sl[rhs_off + t]; if (v != 0.0 && cbase + t / 6 < P.n_cam_ord) atomicAdd(P.r + 6 * P.ord_pose[cbase + t / 6] + t % 6, v); }
             __syncthreads();
         }
     }
@@ -1889,7 +1891,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     {   // size the persistent pool (device + pinned mirror for the uploads) for this problem
         const size_t ndb = (size_t)n_pose * (24 + 36 + 36) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + 18 + 9) + (size_t)n_cc * (12 + 36 + 2) + (size_t)n6 * n6 + 5 * (size_t)n6 + 64 +
                            (size_t)nd * (3 + 3 + 3 + 6 + 3 + 9 + 18 * 4 + 3);
-        const size_t ni32 = 4 * (size_t)no + 2 * (size_t)n_ptl + (size_t)n_ptl / 32 + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 256;
+        const size_t ni32 = 2 * (size_t)n_pose + 4 * (size_t)no + 2 * (size_t)n_ptl + (size_t)n_ptl / 32 + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 256;
         const size_t need = ndb * 8 + ni32 * 4 + 96 * 256;
         if (need > BS->pool_cap) {
             HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -1979,6 +1981,12 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     const size_t lds_schur = ((lds_path ? loc_sz : win_sz) + (size_t)(lds_path ? 4 : schur2_waves) * (2 * kcap * 18)) * sizeof(double);
     // MODE 2 walks the landmarks ordered by their first camera, so that a chunk of BA_CHUNK of them touches a short run of cameras
     // (the BA_WC-camera window of S held in LDS); window base of a chunk = lowest first camera in it
+    // camera ordinals: static landmarks are seen by cameras only, and with the frame-interleaved pose order a 10-frame track spans ~27 POSE
+    // indices but still 10 cameras — the LDS window of k_ba_schur<2> is indexed by camera ordinal so that it keeps catching them
+    std::vector<int> pose_ord_h(n_pose, -1), ord_pose_h(p.n_cam);
+    { std::vector<int> inv(n_pose, -1); for (int i = 0; i < p.n_cam; i++) inv[perm[i]] = i;
+      int o = 0; for (int q = 0; q < n_pose; q++) if (inv[q] >= 0) { pose_ord_h[q] = o; ord_pose_h[o] = q; o++; } }
+    D.n_cam_ord = p.n_cam; D.pose_ord = A.put(pose_ord_h.data(), n_pose, st); D.ord_pose = A.put(ord_pose_h.data(), p.n_cam, st);
     int* d_chunk_cmin = nullptr; int* d_lorder = nullptr; int n_chunks = (n_ptl + BA_CHUNK - 1) / BA_CHUNK;
     if (!lds_path && n_ptl) {
         std::vector<int> lorder(n_ptl);
@@ -1990,7 +1998,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             for (int l = 0; l < n_ptl; l++) lorder[cs[first_cam(l)]++] = l;
         }
         std::vector<int> cmin(n_chunks, 0);
-        for (int c = 0; c < n_chunks; c++) { const int m = first_cam(lorder[c * BA_CHUNK]); cmin[c] = m == n_pose ? 0 : m; }
+        for (int c = 0; c < n_chunks; c++) { const int m = first_cam(lorder[c * BA_CHUNK]); cmin[c] = m == n_pose ? 0 : pose_ord_h[m]; }
         d_chunk_cmin = A.put(cmin.data(), n_chunks, st); d_lorder = A.put(lorder.data(), n_ptl, st);
         if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device pool exhausted");
     }
