@@ -24,6 +24,7 @@ def ctx(vido):
     dict(n_cam=5, n_pt=120, kind="local", seed=9),
     dict(n_cam=60, n_pt=3000, kind="global", track_len=10, seed=11),       # HBM-atomics path + blocked Cholesky
     dict(n_cam=23, n_pt=900, kind="global", track_len=7, seed=12),         # n6 = 138: just above the LDS limit
+    dict(n_cam=90, n_pt=1500, kind="global", track_len=30, seed=13),       # 30-frame tracks: band too wide for the LDS window -> supernodal k_chol_band6s
 ])
 def test_ba_matches_oracle(vido, oracle, ctx, kw):
     pr = vido.problems.synth_ba_problem(**kw)

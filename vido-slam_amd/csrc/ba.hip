@@ -1033,6 +1033,7 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
 // HBM round trip per pivot, the price of the global window.  Replaces the scalar k_chol_band (16-column blocks) for bwc <= 96: 8.0 -> ~1.5 ms
 // at 546 poses.
 #define CG_NT 768
+#define BAND6S_NB 4         // pivot blocks per supernode of k_chol_band6s
 __global__ __launch_bounds__(CG_NT) void k_chol_band6g(BaDev P, int bwc /* block half-bandwidth: bw = 6*bwc + 5 */)
 {
     extern __shared__ double cg6[];
@@ -1203,6 +1204,219 @@ __global__ __launch_bounds__(CG_NT) void k_chol_band6g(BaDev P, int bwc /* block
     if (tid == 0) P.scal[4] = ok ? 1.0 : 0.0;
 #undef AB
 #undef PB
+}
+
+// Supernodal form of the in-place band factorisation: SNB pivot blocks at a time.  The 6*SNB panel columns (rows down to the end of the last
+// pivot's band) are staged in LDS, factored there with the look-ahead scheme of k_ba_chol_small6 (LDS barriers only), written back once, and
+// the trailing window in HBM gets ONE rank-6*SNB update per supernode: the window's loads, stores and the store drain — which are what a
+// pivot of k_chol_band6g costs (its 3x6 tiles are uncoalesced: ~26k cycles of TA line requests per pivot) — are paid once per SNB pivots.
+template <int SNB>
+__global__ __launch_bounds__(CG_NT) void k_chol_band6s(BaDev P, int bwc /* block half-bandwidth: bw = 6*bwc + 5 */)
+{
+    extern __shared__ double cs6s[];
+    constexpr int PC = 6 * SNB + 1;                           // panel pitch (odd)
+    const int Wb = bwc + 1, Wr = 6 * Wb, R = 6 * (bwc + SNB);
+    double* Pp = cs6s;                                       // [R][PC]  panel: row i0 + row, column 6*k0 + col
+    double* rWs = Pp + (size_t)R * PC;                       // [R]      rhs of the panel rows
+    double* xs = rWs + R;                                    // [Wr]     backward sweep
+    double* acc = xs + Wr;                                   // [Wr]
+    __shared__ int ok;
+    const int n = P.n6, nblk = n / 6, bw = P.bw, ldb = P.ldb, tid = threadIdx.x;
+    double* Sg = P.S; double* r = P.r; double* x = P.x;
+#define AB(i, j) Sg[(size_t)(i) * ldb + ((j) - (i) + bw)]
+    if (tid == 0) ok = 1;
+    const int f_nt = (6 * bwc + 63) & ~63;                   // threads of role F (whole waves): one per panel row of a pivot
+    __syncthreads();
+    for (int k0 = 0; k0 < nblk && ok; k0 += SNB) {
+        const int nb = min(SNB, nblk - k0), i0 = 6 * k0, nrb = min(nblk, k0 + nb + bwc) - k0, m = 6 * nrb, nc = 6 * nb;   // nrb row blocks, nc panel columns
+        // ---- (1) panel and its rhs: HBM -> LDS (everything an earlier supernode did to them reached L2 before the barrier that ended it)
+        for (int t = tid; t < m * nc; t += CG_NT) {
+            const int row = t / nc, col = t - row * nc, i = i0 + row, j = i0 + col;
+            Pp[row * PC + col] = (j <= i && i - j <= bw) ? AB(i, j) : 0.0;
+        }
+        for (int t = tid; t < m; t += CG_NT) rWs[t] = r[i0 + t];
+        __syncthreads();
+        // ---- (2) the nb pivots of the supernode, in LDS
+        if (tid < f_nt) {
+            double Lk[21], inv[6], zk[6];
+            {   // first pivot block of the supernode straight from the panel
+                double Akk[21];
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = Pp[a * PC + b];
+                const bool good = chol6(Akk, Lk, inv);
+                if (!good && tid == 0) ok = 0;
+#pragma unroll
+                for (int c = 0; c < 6; c++) { double v = rWs[c];
+#pragma unroll
+                    for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
+            }
+            for (int p = 0; p < nb; p++) {
+                const int nbelow = min(bwc, nrb - 1 - p), cp = 6 * p;
+                if (tid < 6 * nbelow) {                      // B1: panel rows of pivot p
+                    const int row = cp + 6 + tid;
+                    double l[6], rr = 0, w6[6];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) w6[c] = Pp[row * PC + cp + c];
+                    const double r0 = rWs[row];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double v = w6[c];
+#pragma unroll
+                        for (int e = 0; e < c; e++) v -= l[e] * Lk[c * (c + 1) / 2 + e];
+                        v *= inv[c]; l[c] = v; rr += v * zk[c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 6; c++) Pp[row * PC + cp + c] = l[c];
+                    rWs[row] = r0 - rr;
+                }
+                if (tid == f_nt - 1) {                       // factor of the pivot block (diagonal: 1 / L_cc for the back sweep) and its z; a lane that owns no panel row
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+#pragma unroll
+                        for (int b = 0; b <= a; b++) Pp[(cp + a) * PC + cp + b] = b == a ? inv[a] : Lk[a * (a + 1) / 2 + b];
+                        rWs[cp + a] = zk[a];
+                    }
+                }
+                lds_barrier();
+                if (p + 1 < nb) {                            // A: pivot block p+1 = its panel entries - P0 P0^T
+                    const int c1 = cp + 6;
+                    double Akk[21], mine;
+                    { const int t = min(tid & 63, 20), a = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15), b = t - a * (a + 1) / 2;
+                      double sum = 0;
+#pragma unroll
+                      for (int c = 0; c < 6; c++) sum += Pp[(c1 + a) * PC + cp + c] * Pp[(c1 + b) * PC + cp + c];
+                      mine = Pp[(c1 + a) * PC + c1 + b] - sum; }
+#pragma unroll
+                    for (int i = 0; i < 21; i++) Akk[i] = readlane_f64(mine, i);
+                    const bool good = chol6(Akk, Lk, inv);
+                    if (!good && tid == 0) ok = 0;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) { double v = rWs[c1 + c];
+#pragma unroll
+                        for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
+                }
+                lds_barrier();
+            }
+        } else {
+            for (int p = 0; p < nb; p++) {
+                const int nbelow = min(bwc, nrb - 1 - p), cp = 6 * p, nq = nb - 1 - p;
+                lds_barrier();
+                // trailing update inside the panel: column blocks q = p+1 .. nb-1, row blocks ib = q .. p+nbelow, two 3-row halves; not (p+1, p+1)
+                const float inv_rows = 1.0f / (float)max(2 * nbelow, 1);
+                for (int it = tid - f_nt; it < nq * 2 * nbelow; it += CG_NT - f_nt) {
+                    const int qi = (int)(((float)it + 0.5f) * inv_rows), rem = it - qi * 2 * nbelow, ib = p + 1 + (rem >> 1), h3 = 3 * (rem & 1), q = p + 1 + qi;
+                    if (ib < q || (ib == p + 1 && q == p + 1)) continue;
+                    const double* Li = Pp + (6 * ib + h3) * PC + cp; const double* Lj = Pp + 6 * q * PC + cp;
+                    double o[3][6], w[3][6];
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int b = 0; b < 6; b++) { o[a][b] = 0.0; w[a][b] = Pp[(6 * ib + h3 + a) * PC + 6 * q + b]; }
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        const double l0 = Li[c], l1 = Li[PC + c], l2 = Li[2 * PC + c];
+#pragma unroll
+                        for (int b = 0; b < 6; b++) { const double lj = Lj[b * PC + c]; o[0][b] += l0 * lj; o[1][b] += l1 * lj; o[2][b] += l2 * lj; }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int b = 0; b < 6; b++) Pp[(6 * ib + h3 + a) * PC + 6 * q + b] = (q == ib && b > h3 + a) ? w[a][b] : w[a][b] - o[a][b];
+                }
+                lds_barrier();
+            }
+        }
+        if (!ok) break;
+        // ---- (3) the factored panel and the rhs back to HBM
+        for (int t = tid; t < m * nc; t += CG_NT) {
+            const int row = t / nc, col = t - row * nc, i = i0 + row, j = i0 + col;
+            if (j <= i && i - j <= bw) AB(i, j) = Pp[row * PC + col];
+        }
+        for (int t = tid; t < m; t += CG_NT) r[i0 + t] = rWs[t];
+        // ---- (4) rank-6*nb update of the window beyond the panel columns, in place in HBM: tiles (row block ibr >= column block jc), both >= nb
+        {
+            const int nt_rows = nrb - nb, n_half = nt_rows * (nt_rows + 1);
+            for (int it = tid; it < n_half; it += CG_NT) {
+                const int tl = it >> 1, h3 = 3 * (it & 1);
+                int ibr = (int)((sqrtf(8.f * (float)tl + 1.f) - 1.f) * 0.5f);
+                ibr -= (ibr * (ibr + 1) / 2 > tl); ibr += ((ibr + 1) * (ibr + 2) / 2 <= tl);
+                const int jc = tl - ibr * (ibr + 1) / 2;
+                const int ri = 6 * (nb + ibr) + h3, rj = 6 * (nb + jc), gi = i0 + ri, gj = i0 + rj;
+                double w[3][6], o[3][6];
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 6; b++) { o[a][b] = 0.0; w[a][b] = (jc == ibr && b > h3 + a) ? 0.0 : AB(gi + a, gj + b); }
+                for (int c = 0; c < nc; c++) {
+                    const double l0 = Pp[ri * PC + c], l1 = Pp[(ri + 1) * PC + c], l2 = Pp[(ri + 2) * PC + c];
+#pragma unroll
+                    for (int b = 0; b < 6; b++) { const double lj = Pp[(rj + b) * PC + c]; o[0][b] += l0 * lj; o[1][b] += l1 * lj; o[2][b] += l2 * lj; }
+                }
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 6; b++) if (!(jc == ibr && b > h3 + a)) AB(gi + a, gj + b) = w[a][b] - o[a][b];
+            }
+        }
+        __syncthreads();                                      // drains the window stores: the next supernode loads its panel from them
+    }
+    __syncthreads();
+    if (ok) {   // ---- backward sweep (as in k_chol_band6)
+        __shared__ double dz[27];
+        for (int t = tid; t < Wr; t += CG_NT) acc[t] = 0.0;
+        double row[6], nrow[6], nval = 0;
+        const int dz_a = (tid >= 1) + (tid >= 3) + (tid >= 6) + (tid >= 10) + (tid >= 15), dz_b = tid - dz_a * (dz_a + 1) / 2;
+        auto fetch = [&](int kb, double* frow, double& fval) {
+            if (tid < 27) fval = tid < 21 ? AB(6 * kb + dz_a, 6 * kb + dz_b) : r[6 * kb + tid - 21];
+            const int ncols = 6 * min(bwc, kb);
+            if (tid < ncols) {
+                const int j = 6 * kb - ncols + tid;
+#pragma unroll
+                for (int a = 0; a < 6; a++) frow[a] = AB(6 * kb + a, j);
+            }
+        };
+        fetch(nblk - 1, row, nval);
+        if (tid < 27) dz[tid] = nval;
+        __syncthreads();
+        int boff2 = 0;
+        for (int kb = nblk - 1; kb >= 0; kb--, boff2 = (boff2 + 1 >= Wb ? 0 : boff2 + 1)) {
+            if (kb > 0) fetch(kb - 1, nrow, nval);
+            if (tid < 64) {
+                double Lk[21], t6[6];
+#pragma unroll
+                for (int i = 0; i < 21; i++) Lk[i] = dz[i];
+#pragma unroll
+                for (int c = 0; c < 6; c++) t6[c] = dz[21 + c] - acc[6 * boff2 + c];
+#pragma unroll
+                for (int c = 5; c >= 0; c--) { double v = t6[c];
+#pragma unroll
+                    for (int e = c + 1; e < 6; e++) v -= Lk[e * (e + 1) / 2 + c] * t6[e]; t6[c] = v * Lk[c * (c + 1) / 2 + c]; }
+                if (tid < 6) { double v = t6[5];
+#pragma unroll
+                    for (int c = 0; c < 5; c++) v = (tid == c) ? t6[c] : v;
+                    x[6 * kb + tid] = v; xs[tid] = v; }
+                if (tid < 27) dz[tid] = nval;
+            }
+            lds_barrier();
+            const int ncols = 6 * min(bwc, kb);
+            if (tid < ncols) {
+                const int j = 6 * kb - ncols + tid, jb = j / 6;
+                double sum = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) sum += row[a] * xs[a];
+                int slot = boff2 + (kb - jb); if (slot >= Wb) slot -= Wb;
+                acc[6 * slot + j % 6] += sum;
+            }
+            if (tid >= 704 && tid < 710) acc[6 * boff2 + tid - 704] = 0.0;       // this slot becomes block kb - Wb
+            lds_barrier();
+#pragma unroll
+            for (int i = 0; i < 6; i++) row[i] = nrow[i];
+        }
+    }
+    if (tid == 0) P.scal[4] = ok ? 1.0 : 0.0;
+#undef AB
 }
 
 // Local-BA reduced solve (n6 <= 120, dense): the same pose-block scheme as k_chol_band6 on the whole matrix in LDS —
@@ -1956,8 +2170,9 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     if (D.bw >= 0) { const size_t bwc = (D.bw - 5) / 6, wr = 6 * (bwc + 1), need = (wr * (wr + 1) + 3 * wr + 6 * bwc * 7 + 8) * sizeof(double);
                      if (bwc >= 1 && need <= 150 * 1024) { band6_lds = need; HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol_band6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)); } }
     size_t band6g_lds = 0;                                  // pose-block factorisation in place on the band (window in L2) when the LDS window does not fit
-    if (D.bw >= 0 && !band6_lds) { const size_t bwc = (D.bw - 5) / 6, wr = 6 * (bwc + 1); if (bwc >= 1 && bwc <= 96) { band6g_lds = (3 * wr + 6 * bwc * 7 + 8) * sizeof(double);
-                     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol_band6g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band6g_lds)); } }
+    if (D.bw >= 0 && !band6_lds) { const size_t bwc = (D.bw - 5) / 6, wr = 6 * (bwc + 1), rr = 6 * (bwc + BAND6S_NB);
+                     if (bwc >= 1 && bwc <= 96) { band6g_lds = (rr * (6 * BAND6S_NB + 1) + rr + 2 * wr + 8) * sizeof(double);
+                     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol_band6s<BAND6S_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band6g_lds)); } }
     double* Sr = A.get<double>(sz_S + n6); D.S = Sr; D.r = Sr + sz_S; D.x = A.get<double>(n6);
     if (getenv("VIDO_BA_VERBOSE")) fprintf(stderr, "[ba] poses %d (cams %d + H %d) landmarks %d obs %d dyn %d | bw %d (block half-width %d) %s\n", n_pose, p.n_cam, n_H, n_ptl, no, nd, D.bw, D.bw >= 0 ? (D.bw - 5) / 6 : -1,
                                              lds_path ? "LDS-resident system" : (D.bw < 0 ? "dense" : (band6_lds ? "pose-block band, LDS window" : (band6g_lds ? "pose-block band, window in L2" : "scalar band"))));
@@ -2088,7 +2303,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if (lds_path && n6 % 6 == 0 && n6 >= 12) hipLaunchKernelGGL(k_ba_chol_small6, dim3(1), dim3(CH_NT), lds_chol6, st, D);
             else if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
             else if (D.bw >= 0 && band6_lds) hipLaunchKernelGGL(k_chol_band6, dim3(1), dim3(CH_NT), band6_lds, st, D, (D.bw - 5) / 6);
-            else if (D.bw >= 0 && band6g_lds) hipLaunchKernelGGL(k_chol_band6g, dim3(1), dim3(CG_NT), band6g_lds, st, D, (D.bw - 5) / 6);
+            else if (D.bw >= 0 && band6g_lds) hipLaunchKernelGGL(k_chol_band6s<BAND6S_NB>, dim3(1), dim3(CG_NT), band6g_lds, st, D, (D.bw - 5) / 6);
             else if (D.bw >= 0) hipLaunchKernelGGL(k_chol_band, dim3(1), dim3(1024), (size_t)D.bw * (CB_NB + 1) * sizeof(double), st, D);
             else { const double one = 1.0; HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4, &one, 8, hipMemcpyHostToDevice, st)); if ((rc = chol_large(ctx, D.S, n6, D.x, D.scal + 4, chol_tmp, st))) return rc; }
             // ---- trial state + its chi2
