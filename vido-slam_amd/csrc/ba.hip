@@ -1335,29 +1335,32 @@ __global__ __launch_bounds__(CG_NT) void k_chol_band6s(BaDev P, int bwc /* block
             if (j <= i && i - j <= bw) AB(i, j) = Pp[row * PC + col];
         }
         for (int t = tid; t < m; t += CG_NT) r[i0 + t] = rWs[t];
-        // ---- (4) rank-6*nb update of the window beyond the panel columns, in place in HBM: tiles (row block ibr >= column block jc), both >= nb
+        // ---- (4) rank-6*nb update of the window beyond the panel columns, in place in HBM, on the FP64 matrix cores: C -= A A^T over 16x16 tiles
+        // of the lower triangle (v_mfma_f64_16x16x4: lane l feeds A[l & 15][l >> 4] and B[l >> 4][l & 15], holds C[(l >> 4) + 4 v][l & 15],
+        // v = 0..3).  The C layout is what matters here: a register of a wave is 4 rows x 16 consecutive doubles of the band — 3x6 register
+        // tiles on the vector ALUs touched one cache line per lane per load (the TA line-request rate, not arithmetic, set their pace) and
+        // read each panel value from LDS once per 2 FMAs instead of once per 8.
         {
-            const int nt_rows = nrb - nb, n_half = nt_rows * (nt_rows + 1);
-            for (int it = tid; it < n_half; it += CG_NT) {
-                const int tl = it >> 1, h3 = 3 * (it & 1);
-                int ibr = (int)((sqrtf(8.f * (float)tl + 1.f) - 1.f) * 0.5f);
-                ibr -= (ibr * (ibr + 1) / 2 > tl); ibr += ((ibr + 1) * (ibr + 2) / 2 <= tl);
-                const int jc = tl - ibr * (ibr + 1) / 2;
-                const int ri = 6 * (nb + ibr) + h3, rj = 6 * (nb + jc), gi = i0 + ri, gj = i0 + rj;
-                double w[3][6], o[3][6];
+            typedef double d4 __attribute__((ext_vector_type(4)));
+            const int D0 = nc, Dn = m - D0, nT = (Dn + 15) >> 4, ntile = nT * (nT + 1) / 2;
+            const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+            for (int tl = wave; tl < ntile; tl += CG_NT / 64) {
+                int I = (int)((sqrtf(8.f * (float)tl + 1.f) - 1.f) * 0.5f);
+                I -= (I * (I + 1) / 2 > tl); I += ((I + 1) * (I + 2) / 2 <= tl);
+                const int J = tl - I * (I + 1) / 2, rI = D0 + 16 * I, rJ = D0 + 16 * J;
+                const int col = rJ + lr;
+                d4 c;
 #pragma unroll
-                for (int a = 0; a < 3; a++)
-#pragma unroll
-                    for (int b = 0; b < 6; b++) { o[a][b] = 0.0; w[a][b] = (jc == ibr && b > h3 + a) ? 0.0 : AB(gi + a, gj + b); }
-                for (int c = 0; c < nc; c++) {
-                    const double l0 = Pp[ri * PC + c], l1 = Pp[(ri + 1) * PC + c], l2 = Pp[(ri + 2) * PC + c];
-#pragma unroll
-                    for (int b = 0; b < 6; b++) { const double lj = Pp[(rj + b) * PC + c]; o[0][b] += l0 * lj; o[1][b] += l1 * lj; o[2][b] += l2 * lj; }
+                for (int v = 0; v < 4; v++) { const int row = rI + lk + 4 * v; c[v] = (row < m && col <= row) ? AB(i0 + row, i0 + col) : 0.0; }
+                const double* pa = Pp + (size_t)min(rI + lr, m - 1) * PC + lk;       // rows / columns past the window are masked below; clamp keeps the reads inside the panel
+                const double* pb = Pp + (size_t)min(rJ + lr, m - 1) * PC + lk;
+                for (int ks = 0; ks < nc; ks += 4) {
+                    const bool kin = ks + lk < nc;                                   // nc = 6, 12, 18 in the last supernode: not a multiple of 4
+                    const double av = kin ? -pa[ks] : 0.0, bv = kin ? pb[ks] : 0.0;
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
                 }
 #pragma unroll
-                for (int a = 0; a < 3; a++)
-#pragma unroll
-                    for (int b = 0; b < 6; b++) if (!(jc == ibr && b > h3 + a)) AB(gi + a, gj + b) = w[a][b] - o[a][b];
+                for (int v = 0; v < 4; v++) { const int row = rI + lk + 4 * v; if (row < m && col <= row) AB(i0 + row, i0 + col) = c[v]; }
             }
         }
         __syncthreads();                                      // drains the window stores: the next supernode loads its panel from them
