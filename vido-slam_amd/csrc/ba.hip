@@ -1342,25 +1342,41 @@ __global__ __launch_bounds__(CG_NT) void k_chol_band6s(BaDev P, int bwc /* block
         // read each panel value from LDS once per 2 FMAs instead of once per 8.
         {
             typedef double d4 __attribute__((ext_vector_type(4)));
-            const int D0 = nc, Dn = m - D0, nT = (Dn + 15) >> 4, ntile = nT * (nT + 1) / 2;
+            const int D0 = nc, Dn = m - D0, nT = (Dn + 15) >> 4;
             const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-            for (int tl = wave; tl < ntile; tl += CG_NT / 64) {
-                int I = (int)((sqrtf(8.f * (float)tl + 1.f) - 1.f) * 0.5f);
-                I -= (I * (I + 1) / 2 > tl); I += ((I + 1) * (I + 2) / 2 <= tl);
-                const int J = tl - I * (I + 1) / 2, rI = D0 + 16 * I, rJ = D0 + 16 * J;
-                const int col = rJ + lr;
-                d4 c;
+            // a wave takes units of up to 4 tiles of one tile row (same A operand, 4 independent accumulators: the C loads of a unit are one
+            // HBM round trip, the MFMAs of a k step do not wait for each other); unit u -> (tile row I, tiles 4g .. 4g+3 of it)
+            int n_units = 0; for (int I = 0; I < nT; I++) n_units += (I + 4) >> 2;
+            for (int u = wave; u < n_units; u += CG_NT / 64) {
+                int I = 0, first = 0;
+                while (u >= first + ((I + 4) >> 2)) { first += (I + 4) >> 2; I++; }
+                const int J0 = 4 * (u - first), ntl = min(4, I + 1 - J0), rI = D0 + 16 * I;
+                d4 c[4];
 #pragma unroll
-                for (int v = 0; v < 4; v++) { const int row = rI + lk + 4 * v; c[v] = (row < m && col <= row) ? AB(i0 + row, i0 + col) : 0.0; }
-                const double* pa = Pp + (size_t)min(rI + lr, m - 1) * PC + lk;       // rows / columns past the window are masked below; clamp keeps the reads inside the panel
-                const double* pb = Pp + (size_t)min(rJ + lr, m - 1) * PC + lk;
+                for (int t = 0; t < 4; t++) {
+                    const int col = D0 + 16 * (J0 + t) + lr;
+#pragma unroll
+                    for (int v = 0; v < 4; v++) { const int row = rI + lk + 4 * v; c[t][v] = (t < ntl && row < m && col <= row) ? AB(i0 + row, i0 + col) : 0.0; }
+                }
+                const double* pa = Pp + (size_t)min(rI + lr, m - 1) * PC + lk;       // rows / columns past the window are masked on the way out; the clamp keeps the reads inside the panel
+                const double* pb[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) pb[t] = Pp + (size_t)min(D0 + 16 * (J0 + t) + lr, m - 1) * PC + lk;
                 for (int ks = 0; ks < nc; ks += 4) {
                     const bool kin = ks + lk < nc;                                   // nc = 6, 12, 18 in the last supernode: not a multiple of 4
-                    const double av = kin ? -pa[ks] : 0.0, bv = kin ? pb[ks] : 0.0;
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
+                    const double av = kin ? -pa[ks] : 0.0;
+                    double bv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) bv[t] = kin ? pb[t][ks] : 0.0;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) c[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[t], c[t], 0, 0, 0);
                 }
 #pragma unroll
-                for (int v = 0; v < 4; v++) { const int row = rI + lk + 4 * v; if (row < m && col <= row) AB(i0 + row, i0 + col) = c[v]; }
+                for (int t = 0; t < 4; t++) {
+                    const int col = D0 + 16 * (J0 + t) + lr;
+#pragma unroll
+                    for (int v = 0; v < 4; v++) { const int row = rI + lk + 4 * v; if (t < ntl && row < m && col <= row) AB(i0 + row, i0 + col) = c[t][v]; }
+                }
             }
         }
         __syncthreads();                                      // drains the window stores: the next supernode loads its panel from them
