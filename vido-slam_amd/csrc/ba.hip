@@ -1935,7 +1935,7 @@ struct BaState {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double* d_parts = nullptr; size_t parts_cap = 0;
     double* d_scratch = nullptr; size_t scratch_cap = 0;
-    char* pool = nullptr; char* h_pool = nullptr; size_t pool_cap = 0;
+    char* pool = nullptr; char* h_pool = nullptr; size_t pool_cap = 0, hpool_cap = 0;
 };
 void ba_state_destroy(vido_ctx* ctx)
 {
@@ -1949,12 +1949,14 @@ void ba_state_destroy(vido_ctx* ctx)
 
 namespace {
 struct Arena {                       // bump allocator over the ctx's persistent BA pool (no hipMalloc per call);
-    char* base; size_t cap; size_t off = 0; bool failed = false;   // host inputs go through the pinned stage of the same size
-    char* hbase;
+    char* base; size_t cap; size_t off = 0; bool failed = false;   // host inputs go through a pinned stage that only has to hold what is uploaded
+    char* hbase; size_t hcap = 0, hoff = 0;
     template <class T> T* get(size_t n) { const size_t b = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255; if (off + b > cap) { failed = true; return nullptr; } T* p = (T*)(base + off); off += b; return p; }
     template <class T> T* put(const T* src, size_t n, hipStream_t st) {
-        const size_t o = off; T* d = get<T>(n);
-        if (d && n) { memcpy(hbase + o, src, n * sizeof(T)); if (hipMemcpyAsync(d, hbase + o, n * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) failed = true; }
+        T* d = get<T>(n);
+        const size_t b = (n * sizeof(T) + 255) & ~(size_t)255;
+        if (d && n) { if (hoff + b > hcap) { failed = true; return nullptr; }
+                      memcpy(hbase + hoff, src, n * sizeof(T)); if (hipMemcpyAsync(d, hbase + hoff, n * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) failed = true; hoff += b; }
         return d; }
 };
 }
@@ -2128,12 +2130,22 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         const size_t need = ndb * 8 + ni32 * 4 + 96 * 256;
         if (need > BS->pool_cap) {
             HIP_TRY(ctx, hipStreamSynchronize(st));
-            if (BS->pool) { hipFree(BS->pool); hipHostFree(BS->h_pool); BS->pool = nullptr; BS->h_pool = nullptr; }
+            if (BS->pool) { hipFree(BS->pool); BS->pool = nullptr; }
             BS->pool_cap = need + need / 4;
-            HIP_TRY(ctx, hipMalloc((void**)&BS->pool, BS->pool_cap)); HIP_TRY(ctx, hipHostMalloc((void**)&BS->h_pool, BS->pool_cap));
+            HIP_TRY(ctx, hipMalloc((void**)&BS->pool, BS->pool_cap));
+        }
+        // pinned stage: only the arrays that are uploaded (poses, points, observation lists, factors, index tables) — a quarter of the pool;
+        // pinning memory is the slow part of a cold call (~0.1 ms per MB)
+        const size_t up = ((size_t)n_pose * 12 + (size_t)n_ptl * 3 + (size_t)no * 3 + (size_t)n_cc * 14 + (size_t)nd * 6) * 8 +
+                          ((size_t)2 * n_pose + 4 * (size_t)no + 3 * (size_t)n_ptl + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 64) * 4 + 64 * 256;
+        if (up > BS->hpool_cap) {
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (BS->h_pool) { hipHostFree(BS->h_pool); BS->h_pool = nullptr; }
+            BS->hpool_cap = up + up / 4;
+            HIP_TRY(ctx, hipHostMalloc((void**)&BS->h_pool, BS->hpool_cap));
         }
     }
-    Arena A{BS->pool, BS->pool_cap, 0, false, BS->h_pool};
+    Arena A{BS->pool, BS->pool_cap, 0, false, BS->h_pool, BS->hpool_cap, 0};
     BaDev D{};
     D.n_cam = n_pose; D.n_pt = p.n_pt; D.n_obs = no; D.n_odo = owns_cam_factors ? n_cc : 0; D.prior_cam = (owns_cam_factors && p.prior_cam >= 0) ? perm[p.prior_cam] : -1;
     D.use_huber = p.use_huber; D.n6 = n6; D.pt_lo = pt_lo;
