@@ -1815,10 +1815,14 @@ __global__ __launch_bounds__(64) void k_badyn_factor(BaDev P, double lambda)
 // W_c^T (6 columns for each camera of the chain and each H of the chain, + one column for the right-hand side): the lane
 // solves V y = w with the stored factor (y kept in this wave's scratch slice, [3L][64] so that lanes coalesce) and
 // subtracts W y from the lower triangle of S (r for the last column).
-__global__ __launch_bounds__(64) void k_badyn_schur(BaDev P, double* __restrict__ scratch, int lmax)
+// zs = per-lane column scratch (3 doubles per chain point): in LDS when 64 * 3 * lmax doubles fit (use_lds), else in HBM.  Every step of the two
+// substitution sweeps reads what the previous step wrote: through HBM that is a memory round trip per chain point (the whole kernel was that
+// latency: 3.3 ms for 4000 chains of up to 40 points).
+__global__ __launch_bounds__(64) void k_badyn_schur(BaDev P, double* __restrict__ scratch, int lmax, int use_lds)
 {
+    extern __shared__ double zs_lds[];
     const int lane = threadIdx.x;
-    double* zs = scratch + (size_t)blockIdx.x * 64 * 3 * lmax + lane;
+    double* zs = (use_lds ? zs_lds : scratch + (size_t)blockIdx.x * 64 * 3 * lmax) + lane;
     const int n6 = P.n6;
     for (int c = blockIdx.x; c < P.n_chain; c += gridDim.x) {
         const int k0 = P.chain_start[c], L = P.chain_start[c + 1] - k0;
@@ -2168,10 +2172,12 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         D.Wc = A.get<double>((size_t)nd * 18); D.Wi = A.get<double>((size_t)nd * 18); D.Wo = A.get<double>((size_t)nd * 18); D.fac = A.get<double>((size_t)nd * 18);
         D.yb = A.get<double>((size_t)nd * 3);
     }
-    const int dyn_grid = std::min(n_chain, 512);
+    const int dyn_grid = std::min(n_chain, 1024);
+    const size_t dyn_lds = (size_t)64 * 3 * lmax * sizeof(double) <= 150 * 1024 ? (size_t)64 * 3 * std::max(lmax, 1) * sizeof(double) : 0;
+    if (nd && dyn_lds) HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_badyn_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
     if (nd && (size_t)dyn_grid * 64 * 3 * lmax > BS->scratch_cap) {      // per-wave column scratch of k_badyn_schur (device only, not mirrored)
         HIP_TRY(ctx, hipStreamSynchronize(st)); if (BS->d_scratch) hipFree(BS->d_scratch);
-        BS->scratch_cap = (size_t)512 * 64 * 3 * lmax; HIP_TRY(ctx, hipMalloc((void**)&BS->d_scratch, BS->scratch_cap * sizeof(double)));
+        BS->scratch_cap = (size_t)1024 * 64 * 3 * lmax; HIP_TRY(ctx, hipMalloc((void**)&BS->d_scratch, BS->scratch_cap * sizeof(double)));
     }
     // S and r are contiguous so that one all-reduce covers both
     // band layout of the reduced system when the map is sequential (every landmark / odometry edge spans few keyframes)
@@ -2325,7 +2331,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             }
             if (nd) {
                 hipLaunchKernelGGL(k_badyn_factor, dim3((n_chain + 63) / 64), dim3(64), 0, st, D, lambda);
-                hipLaunchKernelGGL(k_badyn_schur, dim3(dyn_grid), dim3(64), 0, st, D, BS->d_scratch, lmax);
+                hipLaunchKernelGGL(k_badyn_schur, dim3(dyn_grid), dim3(64), dyn_lds, st, D, BS->d_scratch, lmax, dyn_lds ? 1 : 0);
             }
             HIP_TRY(ctx, hipGetLastError());
             if ((rc = AR(Sr, sz_sr, 0))) return rc;
