@@ -400,7 +400,9 @@ __global__ __launch_bounds__(256) void k_quadtree(const uint32_t* __restrict__ c
     unsigned long long* keys = (unsigned long long*)(newslot + qcap);   // [qcap]
     __shared__ int wsum[8];
     __shared__ int sh_nexp, sh_fail;
-    const int task = blockIdx.x, l = task % L, tid = threadIdx.x;
+    // workgroups are issued level-major, level 0 first: a (frame, level) task owns a CU's whole LDS, so a launch is two waves of workgroups on 256
+    // CUs; in frame-major order both waves contain level-0 tasks (2 x the longest task), in this order the light levels fill in behind the heavy ones
+    const int nfr = gridDim.x / L, l = blockIdx.x / nfr, task = (blockIdx.x - l * nfr) * L + l, tid = threadIdx.x;
     const int beg = lvloff[task], n = lvloff[task + 1] - beg, N = budget[l];
     // a FAST cell or the candidate buffer overflowed: the host reports VIDO_E_CAPACITY; nothing downstream may touch the lists
     if (n <= 0 || *overflow != 0 || lvloff[gridDim.x] > cand_cap) { if (tid == 0) selcnt[task] = 0; return; }
