@@ -1033,7 +1033,6 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
 // HBM round trip per pivot, the price of the global window.  Replaces the scalar k_chol_band (16-column blocks) for bwc <= 96: 8.0 -> ~1.5 ms
 // at 546 poses.
 #define CG_NT 768
-#define BAND6S_NB 4         // pivot blocks per supernode of k_chol_band6s
 __global__ __launch_bounds__(CG_NT) void k_chol_band6g(BaDev P, int bwc /* block half-bandwidth: bw = 6*bwc + 5 */)
 {
     extern __shared__ double cg6[];
@@ -2207,9 +2206,11 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     if (D.bw >= 0) { const size_t bwc = (D.bw - 5) / 6, wr = 6 * (bwc + 1), need = (wr * (wr + 1) + 3 * wr + 6 * bwc * 7 + 8) * sizeof(double);
                      if (bwc >= 1 && need <= 150 * 1024) { band6_lds = need; HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol_band6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)); } }
     size_t band6g_lds = 0;                                  // pose-block factorisation in place on the band (window in L2) when the LDS window does not fit
-    if (D.bw >= 0 && !band6_lds) { const size_t bwc = (D.bw - 5) / 6, wr = 6 * (bwc + 1), rr = 6 * (bwc + BAND6S_NB);
-                     if (bwc >= 1 && bwc <= 96) { band6g_lds = (rr * (6 * BAND6S_NB + 1) + rr + 2 * wr + 8) * sizeof(double);
-                     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol_band6s<BAND6S_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band6g_lds)); } }
+    int band6s_nb = 0;                                      // pivot blocks per supernode: 8 when the panel fits LDS, else 4
+    if (D.bw >= 0 && !band6_lds) { const size_t bwc = (D.bw - 5) / 6, wr = 6 * (bwc + 1);
+                     auto need = [&](size_t nb) { const size_t rr = 6 * (bwc + nb); return (rr * (6 * nb + 1) + rr + 2 * wr + 8) * sizeof(double); };
+                     if (bwc >= 1 && bwc <= 96) { band6s_nb = need(8) <= 150 * 1024 ? 8 : 4; band6g_lds = need(band6s_nb);
+                     HIP_TRY(ctx, hipFuncSetAttribute(band6s_nb == 8 ? (const void*)k_chol_band6s<8> : (const void*)k_chol_band6s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band6g_lds)); } }
     double* Sr = A.get<double>(sz_S + n6); D.S = Sr; D.r = Sr + sz_S; D.x = A.get<double>(n6);
     if (getenv("VIDO_BA_VERBOSE")) fprintf(stderr, "[ba] poses %d (cams %d + H %d) landmarks %d obs %d dyn %d | bw %d (block half-width %d) %s\n", n_pose, p.n_cam, n_H, n_ptl, no, nd, D.bw, D.bw >= 0 ? (D.bw - 5) / 6 : -1,
                                              lds_path ? "LDS-resident system" : (D.bw < 0 ? "dense" : (band6_lds ? "pose-block band, LDS window" : (band6g_lds ? "pose-block band, window in L2" : "scalar band"))));
@@ -2340,7 +2341,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if (lds_path && n6 % 6 == 0 && n6 >= 12) hipLaunchKernelGGL(k_ba_chol_small6, dim3(1), dim3(CH_NT), lds_chol6, st, D);
             else if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
             else if (D.bw >= 0 && band6_lds) hipLaunchKernelGGL(k_chol_band6, dim3(1), dim3(CH_NT), band6_lds, st, D, (D.bw - 5) / 6);
-            else if (D.bw >= 0 && band6g_lds) hipLaunchKernelGGL(k_chol_band6s<BAND6S_NB>, dim3(1), dim3(CG_NT), band6g_lds, st, D, (D.bw - 5) / 6);
+            else if (D.bw >= 0 && band6g_lds && band6s_nb == 8) hipLaunchKernelGGL(k_chol_band6s<8>, dim3(1), dim3(CG_NT), band6g_lds, st, D, (D.bw - 5) / 6);
+            else if (D.bw >= 0 && band6g_lds) hipLaunchKernelGGL(k_chol_band6s<4>, dim3(1), dim3(CG_NT), band6g_lds, st, D, (D.bw - 5) / 6);
             else if (D.bw >= 0) hipLaunchKernelGGL(k_chol_band, dim3(1), dim3(1024), (size_t)D.bw * (CB_NB + 1) * sizeof(double), st, D);
             else { const double one = 1.0; HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4, &one, 8, hipMemcpyHostToDevice, st)); if ((rc = chol_large(ctx, D.S, n6, D.x, D.scal + 4, chol_tmp, st))) return rc; }
             // ---- trial state + its chi2
