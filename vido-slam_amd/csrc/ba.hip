@@ -968,7 +968,7 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
         // block and z (27 values, one per lane of wave 0) are parked in LDS.
         __shared__ double dz[27];
         for (int t = tid; t < Wr; t += CH_NT) acc[t] = 0.0;
-        double row[6], nrow[6], nval = 0;
+        double row[6], nrow[6], nrow2[6], nval = 0, nval2 = 0;      // two steps of prefetch in flight: one step (~1000 cycles) is shorter than an L2 round trip under load
         const int dz_a = (tid >= 1) + (tid >= 3) + (tid >= 6) + (tid >= 10) + (tid >= 15), dz_b = tid - dz_a * (dz_a + 1) / 2;
         auto fetch = [&](int kb, double* frow, double& fval) {
             if (tid < 27) fval = tid < 21 ? AB(6 * kb + dz_a, 6 * kb + dz_b) : r[6 * kb + tid - 21];
@@ -981,10 +981,11 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
         };
         fetch(nblk - 1, row, nval);
         if (tid < 27) dz[tid] = nval;
+        if (nblk > 1) fetch(nblk - 2, nrow, nval);
         __syncthreads();
         int boff2 = 0;                                       // physical slot of block kb in the circular acc / xs arrays
         for (int kb = nblk - 1; kb >= 0; kb--, boff2 = (boff2 + 1 >= Wb ? 0 : boff2 + 1)) {
-            if (kb > 0) fetch(kb - 1, nrow, nval);
+            if (kb > 1) fetch(kb - 2, nrow2, nval2);
             if (tid < 64) {                                  // wave 0: x_k from the diagonal block of row-block kb
                 double Lk[21], t6[6];
 #pragma unroll
@@ -1015,7 +1016,8 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
             if (tid >= 512 && tid < 518) acc[6 * boff2 + tid - 512] = 0.0;     // this slot becomes block kb - Wb
             lds_barrier();
 #pragma unroll
-            for (int i = 0; i < 6; i++) row[i] = nrow[i];
+            for (int i = 0; i < 6; i++) { row[i] = nrow[i]; nrow[i] = nrow2[i]; }
+            nval = nval2;
         }
     }
     CH_TICK(6)
@@ -1025,190 +1027,11 @@ __global__ __launch_bounds__(CH_NT) void k_chol_band6(BaDev P, int bwc /* block 
 #undef PB
 }
 
-// Wide bands (several objects: camera f and the motions of frame f interleave, a 10-frame track then spans ~36 poses): the trailing window
-// no longer fits LDS, so the same pose-block / look-ahead algorithm runs IN PLACE on the band in HBM (the working set of a pivot, ~(bwc+1)^2
-// blocks, stays in the XCD's L2).  Role F = the waves that own the 6*bwc panel rows (they also factor the next pivot block), role T = the
-// rest, trailing tiles.  Only the rhs window and the panel rows live in LDS.  The barrier after the panel is LDS-only (the factor values
-// streamed to HBM there are not read again before the back sweep); the barrier after the trailing update must drain the tile stores — one
-// HBM round trip per pivot, the price of the global window.  Replaces the scalar k_chol_band (16-column blocks) for bwc <= 96: 8.0 -> ~1.5 ms
-// at 546 poses.
 #define CG_NT 768
-__global__ __launch_bounds__(CG_NT) void k_chol_band6g(BaDev P, int bwc /* block half-bandwidth: bw = 6*bwc + 5 */)
-{
-    extern __shared__ double cg6[];
-    const int Wb = bwc + 1, Wr = 6 * Wb;
-    double* rW = cg6;                                        // [Wr]  rhs of the window rows (circular by block)
-    double* Pn = rW + Wr;                                    // [6*bwc][7]  panel rows of L of the current step
-    double* xs = Pn + (size_t)6 * bwc * 7;                   // [Wr]  backward sweep
-    double* acc = xs + Wr;                                   // [Wr]
-    __shared__ int ok;
-    const int n = P.n6, nblk = n / 6, bw = P.bw, ldb = P.ldb, tid = threadIdx.x;
-    double* Sg = P.S; double* r = P.r; double* x = P.x;
-#define AB(i, j) Sg[(size_t)(i) * ldb + ((j) - (i) + bw)]
-#define PB(ib) (((ib) - kb + boff) >= Wb ? ((ib) - kb + boff - Wb) : ((ib) - kb + boff))
-    if (tid == 0) ok = 1;
-    int boff = 0;
-    { const int kb = 0; for (int i = tid; i < min(nblk, Wb) * 6; i += CG_NT) rW[6 * PB(i / 6) + i % 6] = r[i]; }
-    const int f_nt = (6 * bwc + 63) & ~63;                   // threads of role F (whole waves)
-    __syncthreads();
-    if (tid < f_nt) {
-        double Lk[21], inv[6], zk[6];
-        {   // pivot block 0
-            double Akk[21];
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-                for (int b = 0; b <= a; b++) Akk[a * (a + 1) / 2 + b] = AB(a, b);
-            const bool good = chol6(Akk, Lk, inv);
-            if (!good && tid == 0) ok = 0;
-#pragma unroll
-            for (int c = 0; c < 6; c++) { double v = rW[c];
-#pragma unroll
-                for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
-        }
-        lds_barrier();
-        for (int kb = 0; kb < nblk && ok; kb++, boff = (boff + 1 >= Wb ? 0 : boff + 1)) {
-            const int nbelow = min(bwc, nblk - 1 - kb);
-            const int e_ib = kb + Wb;                          // block row whose rhs enters the window at the end of the step
-            double e_r = 0; if (e_ib < nblk && tid < 6) e_r = r[6 * e_ib + tid];
-            // ---- B1: panel rows (final values of column block kb) to HBM and to Pn
-            if (tid < 6 * nbelow) {
-                const int ibr = tid / 6 + 1, a = tid - (ibr - 1) * 6, ib = kb + ibr, i = 6 * ib + a, pr = 6 * PB(ib) + a;
-                double l[6], rr = 0, w6[6];
-#pragma unroll
-                for (int c = 0; c < 6; c++) w6[c] = AB(i, 6 * kb + c);
-                const double r0 = rW[pr];
-#pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    double v = w6[c];
-#pragma unroll
-                    for (int e = 0; e < c; e++) v -= l[e] * Lk[c * (c + 1) / 2 + e];
-                    v *= inv[c]; l[c] = v; rr += v * zk[c];
-                }
-#pragma unroll
-                for (int c = 0; c < 6; c++) { Pn[tid * 7 + c] = l[c]; AB(i, 6 * kb + c) = l[c]; }
-                rW[pr] = r0 - rr;
-            }
-            if (tid == 0) {                                    // factor of the pivot block (diagonal: 1 / L_cc for the back sweep) and its z, compile-time register indices
-#pragma unroll
-                for (int a = 0; a < 6; a++) {
-#pragma unroll
-                    for (int b = 0; b <= a; b++) AB(6 * kb + a, 6 * kb + b) = b == a ? inv[a] : Lk[a * (a + 1) / 2 + b];
-                    r[6 * kb + a] = zk[a];
-                }
-            }
-            lds_barrier();
-            // ---- A: pivot block kb+1 = its entries in the band (updated by every earlier step) - P0 P0^T, its factor and z
-            if (nbelow > 0) {
-                const int p1 = 6 * PB(kb + 1), g1 = 6 * (kb + 1);
-                double Akk[21], mine;
-                { const int t = min(tid & 63, 20), a = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15), b = t - a * (a + 1) / 2;
-                  double sum = 0;
-#pragma unroll
-                  for (int c = 0; c < 6; c++) sum += Pn[a * 7 + c] * Pn[b * 7 + c];
-                  mine = AB(g1 + a, g1 + b) - sum; }
-#pragma unroll
-                for (int i = 0; i < 21; i++) Akk[i] = readlane_f64(mine, i);
-                const bool good = chol6(Akk, Lk, inv);
-                if (!good && tid == 0) ok = 0;
-#pragma unroll
-                for (int c = 0; c < 6; c++) { double v = rW[p1 + c];
-#pragma unroll
-                    for (int e = 0; e < c; e++) v -= Lk[c * (c + 1) / 2 + e] * zk[e]; zk[c] = v * inv[c]; }
-            }
-            if (e_ib < nblk && tid < 6) rW[6 * boff + tid] = e_r;      // the slot of block kb now belongs to block kb + Wb
-            __syncthreads();                                  // tile stores of role T must have reached L2 before the next panel reads them
-        }
-    } else {
-        lds_barrier();
-        for (int kb = 0; kb < nblk && ok; kb++, boff = (boff + 1 >= Wb ? 0 : boff + 1)) {
-            const int nbelow = min(bwc, nblk - 1 - kb);
-            lds_barrier();
-            // ---- B2: trailing update in place: tiles (row block ibr >= column block jc) except (0, 0), two 3-row halves each
-            const int n_half = nbelow * (nbelow + 1) - 2;
-            for (int it = tid - f_nt; it < n_half; it += CG_NT - f_nt) {
-                const int tl = (it >> 1) + 1, h3 = 3 * (it & 1);
-                int ibr = (int)((sqrtf(8.f * (float)tl + 1.f) - 1.f) * 0.5f);
-                ibr -= (ibr * (ibr + 1) / 2 > tl); ibr += ((ibr + 1) * (ibr + 2) / 2 <= tl);
-                const int jc = tl - ibr * (ibr + 1) / 2;
-                const int gi = 6 * (kb + 1 + ibr) + h3, gj = 6 * (kb + 1 + jc);
-                double w[3][6];
-#pragma unroll
-                for (int a = 0; a < 3; a++)
-#pragma unroll
-                    for (int b = 0; b < 6; b++) w[a][b] = (jc == ibr && b > h3 + a) ? 0.0 : AB(gi + a, gj + b);      // the band stores nothing right of the diagonal
-                double o[3][6];
-                tile36<2>(Pn + (6 * ibr + h3) * 7, Pn + 6 * jc * 7, o);
-#pragma unroll
-                for (int a = 0; a < 3; a++)
-#pragma unroll
-                    for (int b = 0; b < 6; b++) if (!(jc == ibr && b > h3 + a)) AB(gi + a, gj + b) = w[a][b] - o[a][b];
-            }
-            __syncthreads();
-        }
-    }
-    __syncthreads();
-    if (ok) {   // ---- backward sweep (as in k_chol_band6): x_k = L_kk^-T (z_k - acc_k); acc_j += L_kj^T x_k for the blocks j < k of row k
-        __shared__ double dz[27];
-        for (int t = tid; t < Wr; t += CG_NT) acc[t] = 0.0;
-        double row[6], nrow[6], nval = 0;
-        const int dz_a = (tid >= 1) + (tid >= 3) + (tid >= 6) + (tid >= 10) + (tid >= 15), dz_b = tid - dz_a * (dz_a + 1) / 2;
-        auto fetch = [&](int kb, double* frow, double& fval) {
-            if (tid < 27) fval = tid < 21 ? AB(6 * kb + dz_a, 6 * kb + dz_b) : r[6 * kb + tid - 21];
-            const int ncols = 6 * min(bwc, kb);
-            if (tid < ncols) {
-                const int j = 6 * kb - ncols + tid;
-#pragma unroll
-                for (int a = 0; a < 6; a++) frow[a] = AB(6 * kb + a, j);
-            }
-        };
-        fetch(nblk - 1, row, nval);
-        if (tid < 27) dz[tid] = nval;
-        __syncthreads();
-        int boff2 = 0;
-        for (int kb = nblk - 1; kb >= 0; kb--, boff2 = (boff2 + 1 >= Wb ? 0 : boff2 + 1)) {
-            if (kb > 0) fetch(kb - 1, nrow, nval);
-            if (tid < 64) {
-                double Lk[21], t6[6];
-#pragma unroll
-                for (int i = 0; i < 21; i++) Lk[i] = dz[i];
-#pragma unroll
-                for (int c = 0; c < 6; c++) t6[c] = dz[21 + c] - acc[6 * boff2 + c];
-#pragma unroll
-                for (int c = 5; c >= 0; c--) { double v = t6[c];
-#pragma unroll
-                    for (int e = c + 1; e < 6; e++) v -= Lk[e * (e + 1) / 2 + c] * t6[e]; t6[c] = v * Lk[c * (c + 1) / 2 + c]; }
-                if (tid < 6) { double v = t6[5];
-#pragma unroll
-                    for (int c = 0; c < 5; c++) v = (tid == c) ? t6[c] : v;
-                    x[6 * kb + tid] = v; xs[tid] = v; }
-                if (tid < 27) dz[tid] = nval;
-            }
-            lds_barrier();
-            const int ncols = 6 * min(bwc, kb);
-            if (tid < ncols) {
-                const int j = 6 * kb - ncols + tid, jb = j / 6;
-                double sum = 0;
-#pragma unroll
-                for (int a = 0; a < 6; a++) sum += row[a] * xs[a];
-                int slot = boff2 + (kb - jb); if (slot >= Wb) slot -= Wb;
-                acc[6 * slot + j % 6] += sum;
-            }
-            if (tid >= 704 && tid < 710) acc[6 * boff2 + tid - 704] = 0.0;       // this slot becomes block kb - Wb
-            lds_barrier();
-#pragma unroll
-            for (int i = 0; i < 6; i++) row[i] = nrow[i];
-        }
-    }
-    if (tid == 0) P.scal[4] = ok ? 1.0 : 0.0;
-#undef AB
-#undef PB
-}
-
 // Supernodal form of the in-place band factorisation: SNB pivot blocks at a time.  The 6*SNB panel columns (rows down to the end of the last
 // pivot's band) are staged in LDS, factored there with the look-ahead scheme of k_ba_chol_small6 (LDS barriers only), written back once, and
-// the trailing window in HBM gets ONE rank-6*SNB update per supernode: the window's loads, stores and the store drain — which are what a
-// pivot of k_chol_band6g costs (its 3x6 tiles are uncoalesced: ~26k cycles of TA line requests per pivot) — are paid once per SNB pivots.
+// the trailing window in HBM gets ONE rank-6*SNB update per supernode: the window's loads, stores and the store drain (one HBM
+// round trip each; a per-pivot version of this kernel spent 26k cycles per pivot on them) are paid once per SNB pivots.
 template <int SNB>
 __global__ __launch_bounds__(CG_NT) void k_chol_band6s(BaDev P, int bwc /* block half-bandwidth: bw = 6*bwc + 5 */)
 {
@@ -1384,7 +1207,7 @@ __global__ __launch_bounds__(CG_NT) void k_chol_band6s(BaDev P, int bwc /* block
     if (ok) {   // ---- backward sweep (as in k_chol_band6)
         __shared__ double dz[27];
         for (int t = tid; t < Wr; t += CG_NT) acc[t] = 0.0;
-        double row[6], nrow[6], nval = 0;
+        double row[6], nrow[6], nrow2[6], nval = 0, nval2 = 0;      // two steps of prefetch in flight
         const int dz_a = (tid >= 1) + (tid >= 3) + (tid >= 6) + (tid >= 10) + (tid >= 15), dz_b = tid - dz_a * (dz_a + 1) / 2;
         auto fetch = [&](int kb, double* frow, double& fval) {
             if (tid < 27) fval = tid < 21 ? AB(6 * kb + dz_a, 6 * kb + dz_b) : r[6 * kb + tid - 21];
@@ -1397,10 +1220,11 @@ __global__ __launch_bounds__(CG_NT) void k_chol_band6s(BaDev P, int bwc /* block
         };
         fetch(nblk - 1, row, nval);
         if (tid < 27) dz[tid] = nval;
+        if (nblk > 1) fetch(nblk - 2, nrow, nval);
         __syncthreads();
         int boff2 = 0;
         for (int kb = nblk - 1; kb >= 0; kb--, boff2 = (boff2 + 1 >= Wb ? 0 : boff2 + 1)) {
-            if (kb > 0) fetch(kb - 1, nrow, nval);
+            if (kb > 1) fetch(kb - 2, nrow2, nval2);
             if (tid < 64) {
                 double Lk[21], t6[6];
 #pragma unroll
@@ -1430,7 +1254,8 @@ __global__ __launch_bounds__(CG_NT) void k_chol_band6s(BaDev P, int bwc /* block
             if (tid >= 704 && tid < 710) acc[6 * boff2 + tid - 704] = 0.0;       // this slot becomes block kb - Wb
             lds_barrier();
 #pragma unroll
-            for (int i = 0; i < 6; i++) row[i] = nrow[i];
+            for (int i = 0; i < 6; i++) { row[i] = nrow[i]; nrow[i] = nrow2[i]; }
+            nval = nval2;
         }
     }
     if (tid == 0) P.scal[4] = ok ? 1.0 : 0.0;
@@ -2205,15 +2030,15 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     size_t band6_lds = 0;                                   // pose-block LDS-window factorisation when the window fits
     if (D.bw >= 0) { const size_t bwc = (D.bw - 5) / 6, wr = 6 * (bwc + 1), need = (wr * (wr + 1) + 3 * wr + 6 * bwc * 7 + 8) * sizeof(double);
                      if (bwc >= 1 && need <= 150 * 1024) { band6_lds = need; HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol_band6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)); } }
-    size_t band6g_lds = 0;                                  // pose-block factorisation in place on the band (window in L2) when the LDS window does not fit
+    size_t band6s_lds = 0;                                  // pose-block factorisation in place on the band (window in L2) when the LDS window does not fit
     int band6s_nb = 0;                                      // pivot blocks per supernode: 8 when the panel fits LDS, else 4
     if (D.bw >= 0 && !band6_lds) { const size_t bwc = (D.bw - 5) / 6, wr = 6 * (bwc + 1);
                      auto need = [&](size_t nb) { const size_t rr = 6 * (bwc + nb); return (rr * (6 * nb + 1) + rr + 2 * wr + 8) * sizeof(double); };
-                     if (bwc >= 1 && bwc <= 96) { band6s_nb = need(8) <= 150 * 1024 ? 8 : 4; band6g_lds = need(band6s_nb);
-                     HIP_TRY(ctx, hipFuncSetAttribute(band6s_nb == 8 ? (const void*)k_chol_band6s<8> : (const void*)k_chol_band6s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band6g_lds)); } }
+                     if (bwc >= 1 && bwc <= 96) { band6s_nb = need(8) <= 150 * 1024 ? 8 : 4; band6s_lds = need(band6s_nb);
+                     HIP_TRY(ctx, hipFuncSetAttribute(band6s_nb == 8 ? (const void*)k_chol_band6s<8> : (const void*)k_chol_band6s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band6s_lds)); } }
     double* Sr = A.get<double>(sz_S + n6); D.S = Sr; D.r = Sr + sz_S; D.x = A.get<double>(n6);
     if (getenv("VIDO_BA_VERBOSE")) fprintf(stderr, "[ba] poses %d (cams %d + H %d) landmarks %d obs %d dyn %d | bw %d (block half-width %d) %s\n", n_pose, p.n_cam, n_H, n_ptl, no, nd, D.bw, D.bw >= 0 ? (D.bw - 5) / 6 : -1,
-                                             lds_path ? "LDS-resident system" : (D.bw < 0 ? "dense" : (band6_lds ? "pose-block band, LDS window" : (band6g_lds ? "pose-block band, window in L2" : "scalar band"))));
+                                             lds_path ? "LDS-resident system" : (D.bw < 0 ? "dense" : (band6_lds ? "pose-block band, LDS window" : (band6s_lds ? "pose-block band, window in L2" : "scalar band"))));
     double* chol_tmp = A.get<double>(64);
     double* red = A.get<double>((size_t)n_pose * 36 + n6 + 8);      // [Hcd | bc | scal] contiguous for the linearisation all-reduce
     D.Hcd = red; D.bc = red + (size_t)n_pose * 36; D.scal = D.bc + n6;
@@ -2341,8 +2166,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if (lds_path && n6 % 6 == 0 && n6 >= 12) hipLaunchKernelGGL(k_ba_chol_small6, dim3(1), dim3(CH_NT), lds_chol6, st, D);
             else if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
             else if (D.bw >= 0 && band6_lds) hipLaunchKernelGGL(k_chol_band6, dim3(1), dim3(CH_NT), band6_lds, st, D, (D.bw - 5) / 6);
-            else if (D.bw >= 0 && band6g_lds && band6s_nb == 8) hipLaunchKernelGGL(k_chol_band6s<8>, dim3(1), dim3(CG_NT), band6g_lds, st, D, (D.bw - 5) / 6);
-            else if (D.bw >= 0 && band6g_lds) hipLaunchKernelGGL(k_chol_band6s<4>, dim3(1), dim3(CG_NT), band6g_lds, st, D, (D.bw - 5) / 6);
+            else if (D.bw >= 0 && band6s_lds && band6s_nb == 8) hipLaunchKernelGGL(k_chol_band6s<8>, dim3(1), dim3(CG_NT), band6s_lds, st, D, (D.bw - 5) / 6);
+            else if (D.bw >= 0 && band6s_lds) hipLaunchKernelGGL(k_chol_band6s<4>, dim3(1), dim3(CG_NT), band6s_lds, st, D, (D.bw - 5) / 6);
             else if (D.bw >= 0) hipLaunchKernelGGL(k_chol_band, dim3(1), dim3(1024), (size_t)D.bw * (CB_NB + 1) * sizeof(double), st, D);
             else { const double one = 1.0; HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4, &one, 8, hipMemcpyHostToDevice, st)); if ((rc = chol_large(ctx, D.S, n6, D.x, D.scal + 4, chol_tmp, st))) return rc; }
             // ---- trial state + its chi2
