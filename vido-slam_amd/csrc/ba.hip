@@ -46,7 +46,7 @@ struct BaDev {
     double *S, *r, *x;                                      // [n6*n6], [n6], [n6]
     double *scal;                                           // [8]: 0 chi2 1 maxdiag 2 tempChi 3 scale 4 ok
     const double *odo_info, *odo_delta;                     // per camera-camera factor (odometry | object-motion smoothness)
-    int n_cam_ord; const int *pose_ord, *ord_pose;                         // camera ordinal of a pose index (-1: object motion) and back: the Schur window counts CAMERAS, not poses
+    int n_cam_ord; const int *pose_ord, *ord_pose, *slot_ord;   // slot_ord: camera ordinal of every landmark-major slot                         // camera ordinal of a pose index (-1: object motion) and back: the Schur window counts CAMERAS, not poses
     int bw, ldb;                                            // bw >= 0: S is stored as a lower BAND, entry (r, c) at S[r*ldb + c - r + bw]; bw < 0: dense n6 x n6
     // ---- object part (FullBatchOptimization, STATIC_ONLY = false).  n_cam above counts ALL pose vertices: cameras first,
     // then the object motions H.  Dynamic points are stored chain-major (a chain = one dynamic tracklet).
@@ -359,7 +359,8 @@ __global__ void k_ba_add_odo(BaDev P)
 #define BA_CHUNK 256      // landmarks per window flush: every flush is a set of HBM atomics, and atomics onto one cache line serialise (~45 ns each)
 template <int MODE>
 __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void k_ba_schur(BaDev P, int n_ptl, double lambda, int kcap, double* S_part /*[grid][n6*n6 + n6], MODE 0*/,
-                                                  const int* __restrict__ chunk_cmin /*MODE 2*/, const int* __restrict__ lorder /*MODE 2: landmarks by first camera*/)
+                                                  const int* __restrict__ chunk_cmin /*MODE 2*/, const int* __restrict__ lorder /*MODE 2: landmarks by first camera*/,
+                                                  const int2* __restrict__ lbc /*MODE 2: (first slot, slot count) of lorder[lp]*/)
 {
     extern __shared__ double lds[];
     const int n6 = P.n6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
@@ -370,20 +371,31 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void k_ba_schur(BaDev P, in
     // block per 37 doubles the block index walks all of them.
     const int wc = wn / 6, nblk_l = wc * (wc + 1) / 2, rhs_off = nblk_l * SB_PITCH;
     double* Sl = lds;                                        // [nblk_l * SB_PITCH + wn] for MODE 0 / 2
-    double* stage = lds + (MODE == 1 ? 0 : (size_t)rhs_off + wn) + (size_t)wave * (2 * kcap * 18);   // W, WD of up to kcap obs per wave
+    double* stage = lds + (MODE == 1 ? 0 : (size_t)rhs_off + wn) + (size_t)wave * (2 * kcap * 18 + kcap);   // W, WD, (pose, camera ordinal) of up to kcap obs per wave
     const int n_units = MODE == 2 ? (n_ptl + BA_CHUNK - 1) / BA_CHUNK : 1;
     for (int unit = MODE == 2 ? blockIdx.x : 0; unit < n_units; unit += MODE == 2 ? gridDim.x : 1) {
         int cbase = 0, l_beg, l_end, l_step;
         if (MODE == 2) { cbase = chunk_cmin[unit]; l_beg = unit * BA_CHUNK + wave; l_end = min(n_ptl, (unit + 1) * BA_CHUNK); l_step = nw; }
         else { l_beg = blockIdx.x * nw + wave; l_end = n_ptl; l_step = gridDim.x * nw; }
         if (MODE != 1) { for (int t = threadIdx.x; t < rhs_off + wn; t += blockDim.x) Sl[t] = 0; __syncthreads(); }
+        // A landmark is a chain of dependent HBM round trips (its slot range -> its slot data -> the cameras of the slots); with ~30 landmarks
+        // per wave that latency IS the kernel.  The slot range of the NEXT landmark is requested one iteration ahead (MODE 2 reads it from a
+        // table in walk order, no lorder -> pt_start hop), and everything that depends on the range — Cp, W, the slots' poses and camera
+        // ordinals — is requested together and parked in LDS.
+        int l = 0, beg = 0, cnt = 0;
+        if (l_beg < l_end) { if (MODE == 2) { l = lorder[l_beg]; const int2 bc = lbc[l_beg]; beg = bc.x; cnt = bc.y; } else { l = l_beg; beg = P.pt_start[l]; cnt = P.pt_start[l + 1] - beg; } }
         for (int lp = l_beg; lp < l_end; lp += l_step) {
-            const int l = MODE == 2 ? lorder[lp] : lp;
-            const int beg = P.pt_start[l], k = min(P.pt_start[l + 1] - beg, kcap);
+            int nl = 0, nbeg = 0, ncnt = 0;
+            { const int nlp = lp + l_step;
+              if (nlp < l_end) { if (MODE == 2) { nl = lorder[nlp]; const int2 bc = lbc[nlp]; nbeg = bc.x; ncnt = bc.y; } else { nl = nlp; nbeg = P.pt_start[nl]; ncnt = P.pt_start[nl + 1] - nbeg; } } }
+            const int k = min(cnt, kcap);
+            double* Wl = stage; double* WDl = stage + kcap * 18; int* scam = (int*)(stage + 2 * kcap * 18); int* sord = scam + kcap;
+            if (lane < k) { const int cp = P.slot_cam[beg + lane]; scam[lane] = cp; sord[lane] = MODE == 2 ? P.slot_ord[beg + lane] : cp; }
+            for (int t = lane; t < k * 18; t += 64) Wl[t] = P.W[18 * (size_t)beg + t];
             // point-side block of the landmark = sum of its slots' terms (lane i holds slot i, tracks have <= 64 observations); kept for the
             // back-substitution
             double H6[9];
-            { const int cnt = P.pt_start[l + 1] - beg;
+            {
 #pragma unroll
               for (int a = 0; a < 9; a++) H6[a] = lane < cnt ? P.Cp[9 * (size_t)(beg + lane) + a] : 0.0;
 #pragma unroll
@@ -399,14 +411,12 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void k_ba_schur(BaDev P, in
               } }
             const double b0 = H6[6], b1 = H6[7], b2 = H6[8];
             double Di[9]; inv3sym(H6, lambda, Di);
-            double* Wl = stage; double* WDl = stage + kcap * 18;
-            for (int t = lane; t < k * 18; t += 64) Wl[t] = P.W[18 * (size_t)beg + t];
             __builtin_amdgcn_wave_barrier();
             for (int t = lane; t < k * 6; t += 64) {              // WD = W * Di, row t of the stacked (6k x 3)
                 const double w0 = Wl[t * 3], w1 = Wl[t * 3 + 1], w2 = Wl[t * 3 + 2];
                 const double d0 = w0 * Di[0] + w1 * Di[3] + w2 * Di[6], d1 = w0 * Di[1] + w1 * Di[4] + w2 * Di[7], d2 = w0 * Di[2] + w1 * Di[5] + w2 * Di[8];
                 WDl[t * 3] = d0; WDl[t * 3 + 1] = d1; WDl[t * 3 + 2] = d2;
-                const int cpose = P.slot_cam[beg + t / 6], c = (MODE == 2 ? P.pose_ord[cpose] : cpose) - cbase;      // MODE 2: cbase and the window count cameras
+                const int cpose = scam[t / 6], c = sord[t / 6] - cbase;      // MODE 2: cbase and the window count cameras
                 const double rv = -(d0 * b0 + d1 * b1 + d2 * b2);
                 if (MODE == 1 || (MODE == 2 && (c < 0 || c >= BA_WC))) atomicAdd(P.r + 6 * cpose + t % 6, rv);
                 else atomicAdd(Sl + rhs_off + 6 * c + t % 6, rv);
@@ -419,8 +429,7 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void k_ba_schur(BaDev P, in
                 while (i * (i + 1) / 2 > pq) i--;
                 while ((i + 1) * (i + 2) / 2 <= pq) i++;
                 const int j = pq - i * (i + 1) / 2;
-                const int pi = P.slot_cam[beg + i], pj = P.slot_cam[beg + j];
-                const int ci = (MODE == 2 ? P.pose_ord[pi] : pi) - cbase, cj = (MODE == 2 ? P.pose_ord[pj] : pj) - cbase;
+                const int pi = scam[i], pj = scam[j], ci = sord[i] - cbase, cj = sord[j] - cbase;
                 const double* A = WDl + i * 18; const double* Bm = Wl + j * 18;
                 const bool to_hbm = MODE == 1 || (MODE == 2 && (cj < 0 || ci >= BA_WC));       // ci >= cj
 #pragma unroll
@@ -433,6 +442,7 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void k_ba_schur(BaDev P, in
                     }
             }
             __builtin_amdgcn_wave_barrier();
+            l = nl; beg = nbeg; cnt = ncnt;
         }
         if (MODE == 0) {
             __syncthreads();
@@ -1954,7 +1964,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     {   // size the persistent pool (device + pinned mirror for the uploads) for this problem
         const size_t ndb = (size_t)n_pose * (24 + 36 + 36) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + 18 + 9) + (size_t)n_cc * (12 + 36 + 2) + (size_t)n6 * n6 + 5 * (size_t)n6 + 64 +
                            (size_t)nd * (3 + 3 + 3 + 6 + 3 + 9 + 18 * 4 + 3);
-        const size_t ni32 = 2 * (size_t)n_pose + 4 * (size_t)no + 2 * (size_t)n_ptl + (size_t)n_ptl / 32 + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 256;
+        const size_t ni32 = 2 * (size_t)n_pose + 5 * (size_t)no + 4 * (size_t)n_ptl + (size_t)n_ptl / 32 + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 256;
         const size_t need = ndb * 8 + ni32 * 4 + 96 * 256;
         if (need > BS->pool_cap) {
             HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -1965,7 +1975,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         // pinned stage: only the arrays that are uploaded (poses, points, observation lists, factors, index tables) — a quarter of the pool;
         // pinning memory is the slow part of a cold call (~0.1 ms per MB)
         const size_t up = ((size_t)n_pose * 12 + (size_t)n_ptl * 3 + (size_t)no * 3 + (size_t)n_cc * 14 + (size_t)nd * 6) * 8 +
-                          ((size_t)2 * n_pose + 4 * (size_t)no + 3 * (size_t)n_ptl + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 64) * 4 + 64 * 256;
+                          ((size_t)2 * n_pose + 5 * (size_t)no + 5 * (size_t)n_ptl + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 64) * 4 + 64 * 256;
         if (up > BS->hpool_cap) {
             HIP_TRY(ctx, hipStreamSynchronize(st));
             if (BS->h_pool) { hipHostFree(BS->h_pool); BS->h_pool = nullptr; }
@@ -2055,8 +2065,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     const size_t win_sz = (size_t)(BA_WC * (BA_WC + 1) / 2) * SB_PITCH + BA_WC * 6;
     const size_t loc_sz = (size_t)(n_pose * (n_pose + 1) / 2) * SB_PITCH + n6;          // MODE 0: every lower block of S + rhs
     // MODE 2 runs up to 16 waves per workgroup (one landmark per wave at a time, BA_CHUNK landmarks per window flush); as many as the per-wave staging leaves room for
-    int schur2_waves = 16; while (schur2_waves > 4 && (win_sz + (size_t)schur2_waves * (2 * kcap * 18)) * sizeof(double) > 150 * 1024) schur2_waves >>= 1;
-    const size_t lds_schur = ((lds_path ? loc_sz : win_sz) + (size_t)(lds_path ? 4 : schur2_waves) * (2 * kcap * 18)) * sizeof(double);
+    int schur2_waves = 16; while (schur2_waves > 4 && (win_sz + (size_t)schur2_waves * (2 * kcap * 18 + kcap)) * sizeof(double) > 150 * 1024) schur2_waves >>= 1;
+    const size_t lds_schur = ((lds_path ? loc_sz : win_sz) + (size_t)(lds_path ? 4 : schur2_waves) * (2 * kcap * 18 + kcap)) * sizeof(double);
     // MODE 2 walks the landmarks ordered by their first camera, so that a chunk of BA_CHUNK of them touches a short run of cameras
     // (the BA_WC-camera window of S held in LDS); window base of a chunk = lowest first camera in it
     // camera ordinals: static landmarks are seen by cameras only, and with the frame-interleaved pose order a 10-frame track spans ~27 POSE
@@ -2065,7 +2075,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     { std::vector<int> inv(n_pose, -1); for (int i = 0; i < p.n_cam; i++) inv[perm[i]] = i;
       int o = 0; for (int q = 0; q < n_pose; q++) if (inv[q] >= 0) { pose_ord_h[q] = o; ord_pose_h[o] = q; o++; } }
     D.n_cam_ord = p.n_cam; D.pose_ord = A.put(pose_ord_h.data(), n_pose, st); D.ord_pose = A.put(ord_pose_h.data(), p.n_cam, st);
-    int* d_chunk_cmin = nullptr; int* d_lorder = nullptr; int n_chunks = (n_ptl + BA_CHUNK - 1) / BA_CHUNK;
+    { std::vector<int> so(no); for (int t = 0; t < no; t++) so[t] = pose_ord_h[slotcam[t]]; D.slot_ord = A.put(so.data(), no, st); }
+    int* d_chunk_cmin = nullptr; int* d_lorder = nullptr; int2* d_lbc = nullptr; int n_chunks = (n_ptl + BA_CHUNK - 1) / BA_CHUNK;
     if (!lds_path && n_ptl) {
         std::vector<int> lorder(n_ptl);
         auto first_cam = [&](int l) { return pstart[l + 1] > pstart[l] ? slotcam[pstart[l]] : n_pose; };
@@ -2078,6 +2089,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         std::vector<int> cmin(n_chunks, 0);
         for (int c = 0; c < n_chunks; c++) { const int m = first_cam(lorder[c * BA_CHUNK]); cmin[c] = m == n_pose ? 0 : pose_ord_h[m]; }
         d_chunk_cmin = A.put(cmin.data(), n_chunks, st); d_lorder = A.put(lorder.data(), n_ptl, st);
+        { std::vector<int> bc(2 * (size_t)n_ptl); for (int q = 0; q < n_ptl; q++) { const int l = lorder[q]; bc[2 * (size_t)q] = pstart[l]; bc[2 * (size_t)q + 1] = pstart[l + 1] - pstart[l]; }
+          d_lbc = (int2*)A.put(bc.data(), 2 * (size_t)n_ptl, st); }
         if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device pool exhausted");
     }
     if (lds_schur > 160 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "ba: LDS budget exceeded (n6=%d, max track %d)", n6, maxk);
@@ -2151,9 +2164,9 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if (add_cam && D.n_odo) hipLaunchKernelGGL(k_ba_add_odo, dim3((D.n_odo * 36 + 255) / 256), dim3(256), 0, st, D);
             if (n_ptl) {
                 if (lds_path) {
-                    hipLaunchKernelGGL(k_ba_schur<0>, dim3(schur_grid), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, BS->d_parts, (const int*)nullptr, (const int*)nullptr);
+                    hipLaunchKernelGGL(k_ba_schur<0>, dim3(schur_grid), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, BS->d_parts, (const int*)nullptr, (const int*)nullptr, (const int2*)nullptr);
                     hipLaunchKernelGGL(k_ba_fold_parts, dim3(std::min(256, (int)((loc_sz + 255) / 256)), std::min(8, schur_grid)), dim3(256), 0, st, D, BS->d_parts, schur_grid);
-                } else hipLaunchKernelGGL(k_ba_schur<2>, dim3(std::min(n_chunks, 1024)), dim3(64 * schur2_waves), lds_schur, st, D, n_ptl, lambda, kcap, (double*)nullptr, (const int*)d_chunk_cmin, (const int*)d_lorder);
+                } else hipLaunchKernelGGL(k_ba_schur<2>, dim3(std::min(n_chunks, 1024)), dim3(64 * schur2_waves), lds_schur, st, D, n_ptl, lambda, kcap, (double*)nullptr, (const int*)d_chunk_cmin, (const int*)d_lorder, (const int2*)d_lbc);
             }
             if (nd) {
                 hipLaunchKernelGGL(k_badyn_factor, dim3((n_chain + 63) / 64), dim3(64), 0, st, D, lambda);
