@@ -261,9 +261,16 @@ class FrameFeatures:
         v = FrontendView()
         ctx._check(ctx.lib.vido_frontend_batch(ctx.h, C.c_void_p(ptr), img_dev, n, C.c_size_t(fstride), rstride, w, h, C.c_void_p(dp), C.c_void_p(fp), C.c_void_p(mp),
                                                maps_dev, slot0, C.byref(self.p), C.byref(v)))
+        cache = self.__dict__.setdefault("_views", {})          # the result buffers are ctx-owned and stable between calls: build each numpy view once
         def arr(p, shape, dtype):
-            count = int(np.prod(shape))
-            return np.frombuffer((C.c_char * (count * np.dtype(dtype).itemsize)).from_address(p), dtype=dtype, count=count).reshape(shape) if count else np.zeros(shape, dtype)
+            key = (p, shape, np.dtype(dtype).str)
+            a = cache.get(key)
+            if a is None:
+                count = int(np.prod(shape))
+                a = np.frombuffer((C.c_char * (count * np.dtype(dtype).itemsize)).from_address(p), dtype=dtype, count=count).reshape(shape) if count else np.zeros(shape, dtype)
+                if len(cache) > 256: cache.clear()
+                cache[key] = a
+            return a
         B = ctx.cfg.max_batch if ctx.cfg.max_batch > 1 else 2
         fb = arr(v.frame_beg, (n + 1,), np.int32)
         return dict(kps=arr(v.kps, (n, v.kp_pitch), KP_DTYPE), desc=arr(v.desc, (n, v.kp_pitch, 32), np.uint8), n_kp=np.diff(fb),
