@@ -63,18 +63,26 @@ __device__ void se3_oplus_left(Se3& T, const double* u)
 }
 
 // residual (and 2x6 Jacobian when J != nullptr) of edge i
+// the inputs of edge i, fetched together (and before any branch on the outlier flag: one memory round trip per edge instead of two)
+struct EdgeIn { double o0, o1, a0, a1, a2; };          // observation; depth (mode 1: a0) or the 3-D point (a0, a1, a2)
+__device__ __forceinline__ EdgeIn edge_load(const PoseProbDev& p, int i)
+{
+    EdgeIn in; in.o0 = p.obs[2 * i]; in.o1 = p.obs[2 * i + 1]; in.a1 = in.a2 = 0;
+    if (p.mode == 1) in.a0 = p.depth[i]; else { in.a0 = p.Xw[3 * i]; in.a1 = p.Xw[3 * i + 1]; in.a2 = p.Xw[3 * i + 2]; }
+    return in;
+}
 template <bool WITH_J>
-__device__ __forceinline__ void edge_eval(const PoseProbDev& p, const Se3& T, int i, double f0, double f1, double* e, double* J)
+__device__ __forceinline__ void edge_eval(const PoseProbDev& p, const Se3& T, const EdgeIn& in, double f0, double f1, double* e, double* J)
 {
     double X0, X1, X2;
-    const double o0 = p.obs[2 * i], o1 = p.obs[2 * i + 1];
+    const double o0 = in.o0, o1 = in.o1;
     if (p.mode == 1) {
-        const double d = p.depth[i];
+        const double d = in.a0;
         const double c0 = (o0 - p.cx) * d / p.fx, c1 = (o1 - p.cy) * d / p.fy;
         X0 = p.Twl[0] * c0 + p.Twl[1] * c1 + p.Twl[2] * d + p.Twl[3];
         X1 = p.Twl[4] * c0 + p.Twl[5] * c1 + p.Twl[6] * d + p.Twl[7];
         X2 = p.Twl[8] * c0 + p.Twl[9] * c1 + p.Twl[10] * d + p.Twl[11];
-    } else { X0 = p.Xw[3 * i]; X1 = p.Xw[3 * i + 1]; X2 = p.Xw[3 * i + 2]; }
+    } else { X0 = in.a0; X1 = in.a1; X2 = in.a2; }
     const double x = T.R[0] * X0 + T.R[1] * X1 + T.R[2] * X2 + T.t[0];
     const double y = T.R[3] * X0 + T.R[4] * X1 + T.R[5] * X2 + T.t[1];
     const double z = T.R[6] * X0 + T.R[7] * X1 + T.R[8] * X2 + T.t[2];
@@ -262,12 +270,13 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
                         hll = p.info_prior; bl0 = -p.info_prior * a; bl1 = -p.info_prior * b;
                     }
                     double wo = 0, e[2] = {0, 0}, J[12];
-                    const bool act = !p.outlier[i];
+                    const EdgeIn in = edge_load(p, i);
+                    const bool act = !p.outlier[i], hk = p.has_kernel[i] != 0;
                     if (act) {
-                        edge_eval<true>(p, T, i, f0, f1, e, J);
+                        edge_eval<true>(p, T, in, f0, f1, e, J);
                         p.err[2 * i] = e[0]; p.err[2 * i + 1] = e[1];
                         const double c2 = p.info_edge * (e[0] * e[0] + e[1] * e[1]);
-                        double r0 = c2, w = 1; if (p.has_kernel[i]) huber(c2, p.huber_delta, r0, w);
+                        double r0 = c2, w = 1; if (hk) huber(c2, p.huber_delta, r0, w);
                         acc[27] += r0;
                         wo = w * p.info_edge;
                         int q = 0;
@@ -342,6 +351,8 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
                     if (ok2) se3_oplus_left(T, xp);
                     for (int i = tid; i < n; i += nt) {
                         double f0 = 0, f1 = 0;
+                        const EdgeIn in = edge_load(p, i);
+                        const bool out_i = p.outlier[i] != 0, hk = p.has_kernel[i] != 0;
                         if (flowm) {
                             f0 = p.f[2 * i]; f1 = p.f[2 * i + 1];
                             if (ok2) {
@@ -356,11 +367,11 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
                             const double a = f0 - p.flow0[2 * i], b = f1 - p.flow0[2 * i + 1];
                             part[0] += p.info_prior * (a * a + b * b);
                         }
-                        if (!p.outlier[i]) {
-                            double e[2]; edge_eval<false>(p, T, i, f0, f1, e, nullptr);
+                        if (!out_i) {
+                            double e[2]; edge_eval<false>(p, T, in, f0, f1, e, nullptr);
                             p.err[2 * i] = e[0]; p.err[2 * i + 1] = e[1];
                             const double c2 = p.info_edge * (e[0] * e[0] + e[1] * e[1]);
-                            double r0 = c2, w = 1; if (p.has_kernel[i]) huber(c2, p.huber_delta, r0, w);
+                            double r0 = c2, w = 1; if (hk) huber(c2, p.huber_delta, r0, w);
                             part[0] += r0;
                         }
                     }
@@ -408,7 +419,7 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
             double nb[1] = {0};
             for (int i = tid; i < n; i += nt) {
                 double e0 = p.err[2 * i], e1 = p.err[2 * i + 1];
-                if (p.outlier[i]) { double e[2]; edge_eval<false>(p, T, i, flowm ? p.f[2 * i] : 0.0, flowm ? p.f[2 * i + 1] : 0.0, e, nullptr); e0 = e[0]; e1 = e[1]; p.err[2 * i] = e0; p.err[2 * i + 1] = e1; }
+                if (p.outlier[i]) { double e[2]; edge_eval<false>(p, T, edge_load(p, i), flowm ? p.f[2 * i] : 0.0, flowm ? p.f[2 * i + 1] : 0.0, e, nullptr); e0 = e[0]; e1 = e[1]; p.err[2 * i] = e0; p.err[2 * i + 1] = e1; }
                 const float chi2 = (float)(p.info_edge * (e0 * e0 + e1 * e1));
                 if (chi2 > round_chi2_th) { p.outlier[i] = 1; nb[0] += 1; } else p.outlier[i] = 0;
                 if (round == p.drop_kernel_after_round) p.has_kernel[i] = 0;
