@@ -2099,7 +2099,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
                     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol6)); }
     else { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur)); }
 
-    const int lin_E = no >= 400000 ? 8 : (no >= 16384 ? 4 : 1);     // groups of 64 observations per wave in k_ba_linearize
+    const int lin_E = 1;     // groups of 64 observations per wave in k_ba_linearize: with the LDS camera accumulators one group is fastest at every size measured (35 k .. 1 M edges)
     auto AR = [&](double* dptr, size_t cnt, int op) -> int {
         if (!allreduce) return VIDO_OK;
         HIP_TRY(ctx, hipStreamSynchronize(st));
