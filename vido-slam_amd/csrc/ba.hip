@@ -358,7 +358,7 @@ __global__ void k_ba_add_odo(BaDev P)
 #define SB_PITCH 37       // doubles per 6x6 block of the LDS-resident S (odd: consecutive blocks start in different bank pairs)
 #define BA_CHUNK 256      // landmarks per window flush: every flush is a set of HBM atomics, and atomics onto one cache line serialise (~45 ns each)
 template <int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void k_ba_schur(BaDev P, int n_ptl, double lambda, int kcap, double* S_part /*[grid][n6*n6 + n6], MODE 0*/,
+__global__ __launch_bounds__(MODE == 2 ? 1024 : 512) void k_ba_schur(BaDev P, int n_ptl, double lambda, int kcap, double* S_part /*[grid][n6*n6 + n6], MODE 0*/,
                                                   const int* __restrict__ chunk_cmin /*MODE 2*/, const int* __restrict__ lorder /*MODE 2: landmarks by first camera*/,
                                                   const int2* __restrict__ lbc /*MODE 2: (first slot, slot count) of lorder[lp]*/)
 {
@@ -2066,7 +2066,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     const size_t loc_sz = (size_t)(n_pose * (n_pose + 1) / 2) * SB_PITCH + n6;          // MODE 0: every lower block of S + rhs
     // MODE 2 runs up to 16 waves per workgroup (one landmark per wave at a time, BA_CHUNK landmarks per window flush); as many as the per-wave staging leaves room for
     int schur2_waves = 16; while (schur2_waves > 4 && (win_sz + (size_t)schur2_waves * (2 * kcap * 18 + kcap)) * sizeof(double) > 150 * 1024) schur2_waves >>= 1;
-    const size_t lds_schur = ((lds_path ? loc_sz : win_sz) + (size_t)(lds_path ? 4 : schur2_waves) * (2 * kcap * 18 + kcap)) * sizeof(double);
+    int schur0_waves = 8; while (schur0_waves > 2 && (loc_sz + (size_t)schur0_waves * (2 * kcap * 18 + kcap)) * sizeof(double) > 150 * 1024) schur0_waves >>= 1;     // MODE 0: 8 waves measured best (2.03 -> 1.91 ms per local solve)
+    const size_t lds_schur = ((lds_path ? loc_sz : win_sz) + (size_t)(lds_path ? schur0_waves : schur2_waves) * (2 * kcap * 18 + kcap)) * sizeof(double);
     // MODE 2 walks the landmarks ordered by their first camera, so that a chunk of BA_CHUNK of them touches a short run of cameras
     // (the BA_WC-camera window of S held in LDS); window base of a chunk = lowest first camera in it
     // camera ordinals: static landmarks are seen by cameras only, and with the frame-interleaved pose order a 10-frame track spans ~27 POSE
@@ -2164,7 +2165,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if (add_cam && D.n_odo) hipLaunchKernelGGL(k_ba_add_odo, dim3((D.n_odo * 36 + 255) / 256), dim3(256), 0, st, D);
             if (n_ptl) {
                 if (lds_path) {
-                    hipLaunchKernelGGL(k_ba_schur<0>, dim3(schur_grid), dim3(256), lds_schur, st, D, n_ptl, lambda, kcap, BS->d_parts, (const int*)nullptr, (const int*)nullptr, (const int2*)nullptr);
+                    hipLaunchKernelGGL(k_ba_schur<0>, dim3(schur_grid), dim3(64 * schur0_waves), lds_schur, st, D, n_ptl, lambda, kcap, BS->d_parts, (const int*)nullptr, (const int*)nullptr, (const int2*)nullptr);
                     hipLaunchKernelGGL(k_ba_fold_parts, dim3(std::min(256, (int)((loc_sz + 255) / 256)), std::min(8, schur_grid)), dim3(256), 0, st, D, BS->d_parts, schur_grid);
                 } else hipLaunchKernelGGL(k_ba_schur<2>, dim3(std::min(n_chunks, 1024)), dim3(64 * schur2_waves), lds_schur, st, D, n_ptl, lambda, kcap, (double*)nullptr, (const int*)d_chunk_cmin, (const int*)d_lorder, (const int2*)d_lbc);
             }
