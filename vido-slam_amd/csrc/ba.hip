@@ -356,7 +356,9 @@ __global__ void k_ba_add_odo(BaDev P)
 //         once per chunk (blocks that fall outside the window go to HBM atomics directly).
 #define BA_WC 16
 #define SB_PITCH 37       // doubles per 6x6 block of the LDS-resident S (odd: consecutive blocks start in different bank pairs)
+#ifndef BA_CHUNK
 #define BA_CHUNK 256      // landmarks per window flush: every flush is a set of HBM atomics, and atomics onto one cache line serialise (~45 ns each)
+#endif
 template <int MODE>
 __global__ __launch_bounds__(MODE == 2 ? 1024 : 512) void k_ba_schur(BaDev P, int n_ptl, double lambda, int kcap, double* S_part /*[grid][n6*n6 + n6], MODE 0*/,
                                                   const int* __restrict__ chunk_cmin /*MODE 2*/, const int* __restrict__ lorder /*MODE 2: landmarks by first camera*/,
