@@ -138,19 +138,32 @@ __device__ __forceinline__ bool has9(uint32_t m)           // 9 contiguous set b
 
 // Phase 1a: compass pre-test.  Every arc of 9 contiguous ring pixels contains at least two of the four compass
 // pixels (ring 0, 4, 8, 12), so a corner at threshold th has >= 2 compass pixels brighter than v+th or >= 2
-// darker than v-th.  Sign bits are gathered with v_alignbit, 2 ops per compass pixel and polarity.
-template <int O>
-__device__ __forceinline__ bool fast_compass(const uint32_t* up /*w1 of row -3*/, const uint32_t* mid /*w0..w2 of row 0*/, const uint32_t* dn, int th)
+// darker than v-th.
+// Done for the four pixels of an aligned quad at once, on packed 16-bit lanes (v_pk_add/sub_i16, two pixels per register): the
+// four compass dwords are N = the quad's dword three rows up, S = three rows down, E / W = the quad shifted by +-3 bytes (v_alignbyte across
+// the neighbouring dwords); v_perm widens bytes to u16 pairs, hi - r and r - lo leave their sign in bits 15 / 31, and "at least two of
+// four" is (s0 & s1) | (s2 & s3) | ((s0 | s1) & (s2 | s3)).  ~55 instructions per quad instead of ~4 x 28.
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t fast_compass_quad(uint32_t up, const uint32_t* mid /*w0..w2 of row 0*/, uint32_t dn, int th)
 {
-    const int v = WIN_BYTE(mid, O), lo = v - th, hi = v + th;
-    const int r0 = (int)((dn[0] >> (8 * (O - 4))) & 0xffu), r8 = (int)((up[0] >> (8 * (O - 4))) & 0xffu);
-    const int r4 = WIN_BYTE(mid, O + 3), r12 = WIN_BYTE(mid, O - 3);
-    uint32_t dk = 0, br = 0;
-    dk = __builtin_amdgcn_alignbit(dk, (uint32_t)(r0 - lo), 31); br = __builtin_amdgcn_alignbit(br, (uint32_t)(hi - r0), 31);
-    dk = __builtin_amdgcn_alignbit(dk, (uint32_t)(r4 - lo), 31); br = __builtin_amdgcn_alignbit(br, (uint32_t)(hi - r4), 31);
-    dk = __builtin_amdgcn_alignbit(dk, (uint32_t)(r8 - lo), 31); br = __builtin_amdgcn_alignbit(br, (uint32_t)(hi - r8), 31);
-    dk = __builtin_amdgcn_alignbit(dk, (uint32_t)(r12 - lo), 31); br = __builtin_amdgcn_alignbit(br, (uint32_t)(hi - r12), 31);
-    return (__popc(dk) >= 2) | (__popc(br) >= 2);
+    const uint32_t C = mid[1];
+    const uint32_t E = __builtin_amdgcn_alignbyte(mid[2], mid[1], 3), W = __builtin_amdgcn_alignbyte(mid[1], mid[0], 1);
+    const v2s T = {(short)th, (short)th};
+    uint32_t m4 = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t sel = h == 0 ? 0x0c010c00u : 0x0c030c02u;               // bytes (2h, 2h+1) -> two u16
+        const v2s v = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, C, sel));
+        const v2s hi = v + T, lo = v - T;
+        const v2s r0 = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, dn, sel)), r4 = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, E, sel));
+        const v2s r8 = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, up, sel)), r12 = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, W, sel));
+        const uint32_t b0 = __builtin_bit_cast(uint32_t, hi - r0), b1 = __builtin_bit_cast(uint32_t, hi - r4), b2 = __builtin_bit_cast(uint32_t, hi - r8), b3 = __builtin_bit_cast(uint32_t, hi - r12);
+        const uint32_t d0 = __builtin_bit_cast(uint32_t, r0 - lo), d1 = __builtin_bit_cast(uint32_t, r4 - lo), d2 = __builtin_bit_cast(uint32_t, r8 - lo), d3 = __builtin_bit_cast(uint32_t, r12 - lo);
+        const uint32_t br = (b0 & b1) | (b2 & b3) | ((b0 | b1) & (b2 | b3)), dk = (d0 & d1) | (d2 & d3) | ((d0 | d1) & (d2 | d3));
+        const uint32_t c = (br | dk) & 0x80008000u;                             // bit 15: pixel 2h, bit 31: pixel 2h+1
+        m4 |= (((c >> 15) & 1u) | ((c >> 30) & 2u)) << (2 * h);
+    }
+    return m4;
 }
 
 // Phase 1b: full 9/16 segment test + threshold-free corner score for one candidate pixel at LDS tile position t.
@@ -234,10 +247,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ p
                 const uint32_t* q = (const uint32_t*)(base + 3 * FT_PITCH - 4);
                 const uint32_t mid[3] = {q[0], q[1], q[2]};
                 const int ixq = txq - tx0;                               // interior x of the quad's first pixel (may be < 0)
-                if (ixq + 0 >= 0 && ixq + 0 < iw) m4 |= (uint32_t)fast_compass<4>(&up, mid, &dn, th) << 0;
-                if (ixq + 1 >= 0 && ixq + 1 < iw) m4 |= (uint32_t)fast_compass<5>(&up, mid, &dn, th) << 1;
-                if (ixq + 2 >= 0 && ixq + 2 < iw) m4 |= (uint32_t)fast_compass<6>(&up, mid, &dn, th) << 2;
-                if (ixq + 3 >= 0 && ixq + 3 < iw) m4 |= (uint32_t)fast_compass<7>(&up, mid, &dn, th) << 3;
+                const int plo = max(0, -ixq), phi = min(4, iw - ixq);    // pixels plo .. phi-1 of the quad are interior
+                const uint32_t valid = phi > plo ? ((1u << phi) - 1u) & ~((1u << plo) - 1u) : 0u;
+                m4 = fast_compass_quad(up, mid, dn, th) & valid;
             }
             const unsigned long long b0 = __ballot(m4 & 1), b1 = __ballot(m4 & 2), b2 = __ballot(m4 & 4), b3 = __ballot(m4 & 8);
             int pos = ncand + __popcll(b0 & ltmask) + __popcll(b1 & ltmask) + __popcll(b2 & ltmask) + __popcll(b3 & ltmask);
