@@ -133,9 +133,6 @@ __device__ __forceinline__ bool has9(uint32_t m)           // 9 contiguous set b
     return (x & 0xffffu) != 0;
 }
 
-// Byte `off` (0..11) of a 12-byte window held in three aligned dwords.
-#define WIN_BYTE(W, off) ((int)(((off) < 4 ? (W)[0] >> (8 * (off)) : (off) < 8 ? (W)[1] >> (8 * ((off) - 4)) : (W)[2] >> (8 * ((off) - 8))) & 0xffu))
-
 // Phase 1a: compass pre-test.  Every arc of 9 contiguous ring pixels contains at least two of the four compass
 // pixels (ring 0, 4, 8, 12), so a corner at threshold th has >= 2 compass pixels brighter than v+th or >= 2
 // darker than v-th.
@@ -371,9 +368,10 @@ __global__ __launch_bounds__(64) void k_gather_cands(const uint32_t* __restrict_
 // Keypoints never leave the GPU: the former D2H of all candidates and the host threads are gone.
 struct QtNode { short x0, y0, x1, y1; int cnt; int cid; };
 
-__device__ int qt_block_scan(int* a, int n, int* wsum)          // exclusive scan in place (LDS), returns the total; 256 threads
+#define QT_NT 256          // threads of a quadtree workgroup (the passes are short dependent loops over <= ~5000 candidates / ~2000 nodes)
+__device__ int qt_block_scan(int* a, int n, int* wsum)          // exclusive scan in place (LDS), returns the total; QT_NT threads
 {
-    const int t = threadIdx.x, per = (n + 255) >> 8, b = t * per;
+    const int t = threadIdx.x, per = (n + QT_NT - 1) / QT_NT, b = t * per;
     int s = 0;
     for (int i = 0; i < per; i++) if (b + i < n) s += a[b + i];
     int inc = s;
@@ -381,9 +379,9 @@ __device__ int qt_block_scan(int* a, int n, int* wsum)          // exclusive sca
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if ((t & 63) >= o) inc += v; }
     if ((t & 63) == 63) wsum[t >> 6] = inc;
     __syncthreads();
-    int base = 0;
-    for (int w = 0; w < (t >> 6); w++) base += wsum[w];
-    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < QT_NT / 64; w++) { if (w < (t >> 6)) base += wsum[w]; total += wsum[w]; }
     int run = base + inc - s;
     for (int i = 0; i < per; i++) if (b + i < n) { const int v = a[b + i]; a[b + i] = run; run += v; }
     __syncthreads();
@@ -395,7 +393,7 @@ __device__ __forceinline__ int qt_quadrant(const QtNode& nd, int x, int y)
     return (x < nd.x0 + hx ? 0 : 1) + (y < nd.y0 + hy ? 0 : 2);
 }
 
-__global__ __launch_bounds__(256) void k_quadtree(const uint32_t* __restrict__ cand, const int* __restrict__ lvloff, PyrDev P, int L,
+__global__ __launch_bounds__(QT_NT) void k_quadtree(const uint32_t* __restrict__ cand, const int* __restrict__ lvloff, PyrDev P, int L,
                                                   const int* __restrict__ budget, int qcap, uint16_t* __restrict__ slot_scratch,
                                                   int* __restrict__ sel, int* __restrict__ selcnt, int* __restrict__ overflow, int cand_cap)
 {
@@ -410,7 +408,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const uint32_t* __restrict__ c
     int* pre = proc + qcap;                              // [qcap]
     int* newslot = pre + qcap;                           // [qcap]
     unsigned long long* keys = (unsigned long long*)(newslot + qcap);   // [qcap]
-    __shared__ int wsum[8];
+    __shared__ int wsum[QT_NT / 64];
     __shared__ int sh_nexp, sh_fail;
     // workgroups are issued level-major, level 0 first: a (frame, level) task owns a CU's whole LDS, so a launch is two waves of workgroups on 256
     // CUs; in frame-major order both waves contain level-0 tasks (2 x the longest task), in this order the light levels fill in behind the heavy ones
@@ -424,38 +422,38 @@ __global__ __launch_bounds__(256) void k_quadtree(const uint32_t* __restrict__ c
     int nIni = (int)roundf((float)width / (float)height); if (nIni < 1) nIni = 1;
     const float hX = (float)width / (float)nIni;
     if (nIni > qcap) { if (tid == 0) { atomicExch(overflow, 2); selcnt[task] = 0; } return; }
-    for (int b = tid; b < nIni; b += 256) { childcnt[b] = 0; }
+    for (int b = tid; b < nIni; b += QT_NT) { childcnt[b] = 0; }
     if (tid == 0) sh_fail = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += QT_NT) {
         const int x = (int)(cd[i] & 0xfff) - minB;
         int b = (int)((float)x / hX); if (b >= nIni) b = nIni - 1;
         slot[i] = (uint16_t)b; atomicAdd(&childcnt[b], 1);
     }
     __syncthreads();
-    for (int b = tid; b < nIni; b += 256) keep[b] = childcnt[b] > 0 ? 1 : 0;
+    for (int b = tid; b < nIni; b += QT_NT) keep[b] = childcnt[b] > 0 ? 1 : 0;
     __syncthreads();
     int Lc = qt_block_scan(keep, nIni, wsum);
-    for (int b = tid; b < nIni; b += 256) {
+    for (int b = tid; b < nIni; b += QT_NT) {
         newslot[b] = keep[b];
         if (childcnt[b] > 0) { QtNode q; q.x0 = (short)(int)(hX * (float)b); q.y0 = 0; q.x1 = (short)(int)(hX * (float)(b + 1)); q.y1 = (short)height; q.cnt = childcnt[b]; q.cid = b; cur[keep[b]] = q; }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) slot[i] = (uint16_t)newslot[slot[i]];
+    for (int i = tid; i < n; i += QT_NT) slot[i] = (uint16_t)newslot[slot[i]];
     int counter = nIni;
     bool final_mode = false, finish = false;
     __syncthreads();
     while (!finish) {
         // ---- votes
-        for (int s = tid; s < 4 * Lc; s += 256) childcnt[s] = 0;
+        for (int s = tid; s < 4 * Lc; s += QT_NT) childcnt[s] = 0;
         if (tid == 0) sh_nexp = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += 256) {
+        for (int i = tid; i < n; i += QT_NT) {
             const int s = slot[i]; const QtNode nd = cur[s];
             if (nd.cnt > 1) { const uint32_t p = cd[i]; atomicAdd(&childcnt[4 * s + qt_quadrant(nd, (int)(p & 0xfff) - minB, (int)((p >> 12) & 0xfff) - minB)], 1); }
         }
         __syncthreads();
-        for (int s = tid; s < Lc; s += 256) {
+        for (int s = tid; s < Lc; s += QT_NT) {
             const bool ex = cur[s].cnt > 1;
             nch[s] = ex ? (childcnt[4 * s] > 0) + (childcnt[4 * s + 1] > 0) + (childcnt[4 * s + 2] > 0) + (childcnt[4 * s + 3] > 0) : 0;
             keep[s] = ex ? 1 : 0;                        // reused: expandable flag -> rank
@@ -465,19 +463,19 @@ __global__ __launch_bounds__(256) void k_quadtree(const uint32_t* __restrict__ c
         int k;
         if (!final_mode) {
             k = qt_block_scan(keep, Lc, wsum);
-            for (int s = tid; s < Lc; s += 256) if (cur[s].cnt > 1) proc[keep[s]] = s;
+            for (int s = tid; s < Lc; s += QT_NT) if (cur[s].cnt > 1) proc[keep[s]] = s;
             __syncthreads();
         } else {
             const int E = qt_block_scan(keep, Lc, wsum);
             int M = 1; while (M < E) M <<= 1;
-            for (int j = tid; j < M; j += 256) keys[j] = 0ull;
+            for (int j = tid; j < M; j += QT_NT) keys[j] = 0ull;
             __syncthreads();
-            for (int s = tid; s < Lc; s += 256) if (cur[s].cnt > 1)
+            for (int s = tid; s < Lc; s += QT_NT) if (cur[s].cnt > 1)
                 keys[keep[s]] = ((unsigned long long)cur[s].cnt << 42) | ((unsigned long long)(unsigned)cur[s].cid << 10) | (unsigned long long)s;
             __syncthreads();
             for (int kk = 2; kk <= M; kk <<= 1)
                 for (int j = kk >> 1; j > 0; j >>= 1) {
-                    for (int i = tid; i < M; i += 256) {
+                    for (int i = tid; i < M; i += QT_NT) {
                         const int ixj = i ^ j;
                         if (ixj > i) {
                             const unsigned long long a = keys[i], b = keys[ixj];
@@ -487,13 +485,13 @@ __global__ __launch_bounds__(256) void k_quadtree(const uint32_t* __restrict__ c
                     }
                     __syncthreads();
                 }
-            for (int j = tid; j < E; j += 256) { proc[j] = (int)(keys[j] & 1023ull); pre[j] = nch[proc[j]] - 1; }
+            for (int j = tid; j < E; j += QT_NT) { proc[j] = (int)(keys[j] & 1023ull); pre[j] = nch[proc[j]] - 1; }
             __syncthreads();
             qt_block_scan(pre, E, wsum);                 // list growth before processing the j-th node
             if (tid == 0) sh_nexp = 0;
             __syncthreads();
             int mine = 0;
-            for (int j = tid; j < E; j += 256) if (Lc + pre[j] < N) mine++;
+            for (int j = tid; j < E; j += QT_NT) if (Lc + pre[j] < N) mine++;
             if (mine) atomicAdd(&sh_nexp, mine);
             __syncthreads();
             k = sh_nexp;
@@ -501,20 +499,20 @@ __global__ __launch_bounds__(256) void k_quadtree(const uint32_t* __restrict__ c
             if (tid == 0) sh_nexp = 0;
         }
         // ---- positions
-        for (int j = tid; j < k; j += 256) pre[j] = nch[proc[j]];
-        for (int s = tid; s < Lc; s += 256) keep[s] = 1;
+        for (int j = tid; j < k; j += QT_NT) pre[j] = nch[proc[j]];
+        for (int s = tid; s < Lc; s += QT_NT) keep[s] = 1;
         __syncthreads();
-        for (int j = tid; j < k; j += 256) keep[proc[j]] = 0;
+        for (int j = tid; j < k; j += QT_NT) keep[proc[j]] = 0;
         __syncthreads();
         const int C = qt_block_scan(pre, k, wsum);
         const int nkeep = qt_block_scan(keep, Lc, wsum);
         const int Lnew = C + nkeep;
         if (Lnew > qcap) { if (tid == 0) { atomicExch(overflow, 2); selcnt[task] = 0; } return; }
         // keep[] now holds exclusive ranks for EVERY slot; a divided slot is recognised through childslot >= 0 below
-        for (int s = tid; s < 4 * Lc; s += 256) childslot[s] = -1;
+        for (int s = tid; s < 4 * Lc; s += QT_NT) childslot[s] = -1;
         __syncthreads();
         int nexp_local = 0;
-        for (int j = tid; j < k; j += 256) {
+        for (int j = tid; j < k; j += QT_NT) {
             const int s = proc[j]; const QtNode nd = cur[s];
             const int hx = (nd.x1 - nd.x0 + 1) >> 1, hy = (nd.y1 - nd.y0 + 1) >> 1;
             const int c0 = childcnt[4 * s], c1 = childcnt[4 * s + 1], c2 = childcnt[4 * s + 2], c3 = childcnt[4 * s + 3];
@@ -536,12 +534,12 @@ __global__ __launch_bounds__(256) void k_quadtree(const uint32_t* __restrict__ c
         }
         if (nexp_local) atomicAdd(&sh_nexp, nexp_local);
         __syncthreads();
-        for (int s = tid; s < Lc; s += 256) {
+        for (int s = tid; s < Lc; s += QT_NT) {
             const bool divided = cur[s].cnt > 1 && (childslot[4 * s] >= 0 || childslot[4 * s + 1] >= 0 || childslot[4 * s + 2] >= 0 || childslot[4 * s + 3] >= 0);
             if (!divided) { nxt[C + keep[s]] = cur[s]; newslot[s] = C + keep[s]; } else newslot[s] = -1;
         }
         __syncthreads();
-        for (int i = tid; i < n; i += 256) {
+        for (int i = tid; i < n; i += QT_NT) {
             const int s = slot[i];
             if (newslot[s] >= 0) slot[i] = (uint16_t)newslot[s];
             else { const QtNode nd = cur[s]; const uint32_t p = cd[i]; slot[i] = (uint16_t)childslot[4 * s + qt_quadrant(nd, (int)(p & 0xfff) - minB, (int)((p >> 12) & 0xfff) - minB)]; }
@@ -557,11 +555,11 @@ __global__ __launch_bounds__(256) void k_quadtree(const uint32_t* __restrict__ c
     // ---- best keypoint per node, list order
     // key = response << 16 | (65535 - input index): n <= VIDO_MAX_CAND_PER_FRAME < 65536 (the slot map is u16 for the same reason)
     unsigned* best = (unsigned*)childcnt;
-    for (int s = tid; s < Lc; s += 256) best[s] = 0u;
+    for (int s = tid; s < Lc; s += QT_NT) best[s] = 0u;
     __syncthreads();
-    for (int i = tid; i < n; i += 256) atomicMax(&best[slot[i]], ((cd[i] >> 24) << 16) | (unsigned)(65535 - i));
+    for (int i = tid; i < n; i += QT_NT) atomicMax(&best[slot[i]], ((cd[i] >> 24) << 16) | (unsigned)(65535 - i));
     __syncthreads();
-    for (int s = tid; s < Lc; s += 256) sel[(size_t)task * qcap + s] = 65535 - (int)(best[s] & 0xffffu);
+    for (int s = tid; s < Lc; s += QT_NT) sel[(size_t)task * qcap + s] = 65535 - (int)(best[s] & 0xffffu);
     if (tid == 0) selcnt[task] = Lc;
 }
 
@@ -1038,7 +1036,7 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     static const bool dbg = getenv("VIDO_DEBUG_SYNC") != nullptr;
 #define DBG_SYNC(name) do { if (dbg) { fprintf(stderr, "[vido] %s...\n", name); hipStreamSynchronize(st); fprintf(stderr, "[vido] %s ok\n", name); } } while (0)
     DBG_SYNC("fast+gather");
-    hipLaunchKernelGGL(k_quadtree, dim3(n_tasks), dim3(256), S->qt_lds, st, S->d_cand, S->d_lvloff, S->P, L, S->d_budget, S->qcap, S->d_qt_slot, S->d_sel, S->d_selcnt, S->d_overflow, (int)S->cand_cap);
+    hipLaunchKernelGGL(k_quadtree, dim3(n_tasks), dim3(QT_NT), S->qt_lds, st, S->d_cand, S->d_lvloff, S->P, L, S->d_budget, S->qcap, S->d_qt_slot, S->d_sel, S->d_selcnt, S->d_overflow, (int)S->cand_cap);
     DBG_SYNC("k_quadtree");
     hipLaunchKernelGGL(k_kp_offsets, dim3(1), dim3(1024), 0, st, S->d_selcnt, n_tasks, L, S->d_kpoff, S->d_frame_beg, nf);
     DBG_SYNC("k_kp_offsets");
