@@ -368,6 +368,10 @@ __global__ __launch_bounds__(64) void k_gather_cands(const uint32_t* __restrict_
 // Keypoints never leave the GPU: the former D2H of all candidates and the host threads are gone.
 struct QtNode { short x0, y0, x1, y1; int cnt; int cid; };
 
+// Workgroup barrier that orders LDS traffic only.  The one global array the quadtree passes rewrite (slot[i], the node of candidate i) is read and
+// written by the thread that owns i in every pass, so nothing crosses threads through HBM — and __syncthreads() would also wait for those
+// stores to retire (~1.5 us each time, ~100 barriers per task).
+__device__ __forceinline__ void qt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #define QT_NT 256          // threads of a quadtree workgroup (the passes are short dependent loops over <= ~5000 candidates / ~2000 nodes)
 __device__ int qt_block_scan(int* a, int n, int* wsum)          // exclusive scan in place (LDS), returns the total; QT_NT threads
 {
@@ -378,13 +382,13 @@ __device__ int qt_block_scan(int* a, int n, int* wsum)          // exclusive sca
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if ((t & 63) >= o) inc += v; }
     if ((t & 63) == 63) wsum[t >> 6] = inc;
-    __syncthreads();
+    qt_barrier();
     int base = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < QT_NT / 64; w++) { if (w < (t >> 6)) base += wsum[w]; total += wsum[w]; }
     int run = base + inc - s;
     for (int i = 0; i < per; i++) if (b + i < n) { const int v = a[b + i]; a[b + i] = run; run += v; }
-    __syncthreads();
+    qt_barrier();
     return total;
 }
 __device__ __forceinline__ int qt_quadrant(const QtNode& nd, int x, int y)
@@ -424,55 +428,55 @@ __global__ __launch_bounds__(QT_NT) void k_quadtree(const uint32_t* __restrict__
     if (nIni > qcap) { if (tid == 0) { atomicExch(overflow, 2); selcnt[task] = 0; } return; }
     for (int b = tid; b < nIni; b += QT_NT) { childcnt[b] = 0; }
     if (tid == 0) sh_fail = 0;
-    __syncthreads();
+    qt_barrier();
     for (int i = tid; i < n; i += QT_NT) {
         const int x = (int)(cd[i] & 0xfff) - minB;
         int b = (int)((float)x / hX); if (b >= nIni) b = nIni - 1;
         slot[i] = (uint16_t)b; atomicAdd(&childcnt[b], 1);
     }
-    __syncthreads();
+    qt_barrier();
     for (int b = tid; b < nIni; b += QT_NT) keep[b] = childcnt[b] > 0 ? 1 : 0;
-    __syncthreads();
+    qt_barrier();
     int Lc = qt_block_scan(keep, nIni, wsum);
     for (int b = tid; b < nIni; b += QT_NT) {
         newslot[b] = keep[b];
         if (childcnt[b] > 0) { QtNode q; q.x0 = (short)(int)(hX * (float)b); q.y0 = 0; q.x1 = (short)(int)(hX * (float)(b + 1)); q.y1 = (short)height; q.cnt = childcnt[b]; q.cid = b; cur[keep[b]] = q; }
     }
-    __syncthreads();
+    qt_barrier();
     for (int i = tid; i < n; i += QT_NT) slot[i] = (uint16_t)newslot[slot[i]];
     int counter = nIni;
     bool final_mode = false, finish = false;
-    __syncthreads();
+    qt_barrier();
     while (!finish) {
         // ---- votes
         for (int s = tid; s < 4 * Lc; s += QT_NT) childcnt[s] = 0;
         if (tid == 0) sh_nexp = 0;
-        __syncthreads();
+        qt_barrier();
         for (int i = tid; i < n; i += QT_NT) {
             const int s = slot[i]; const QtNode nd = cur[s];
             if (nd.cnt > 1) { const uint32_t p = cd[i]; atomicAdd(&childcnt[4 * s + qt_quadrant(nd, (int)(p & 0xfff) - minB, (int)((p >> 12) & 0xfff) - minB)], 1); }
         }
-        __syncthreads();
+        qt_barrier();
         for (int s = tid; s < Lc; s += QT_NT) {
             const bool ex = cur[s].cnt > 1;
             nch[s] = ex ? (childcnt[4 * s] > 0) + (childcnt[4 * s + 1] > 0) + (childcnt[4 * s + 2] > 0) + (childcnt[4 * s + 3] > 0) : 0;
             keep[s] = ex ? 1 : 0;                        // reused: expandable flag -> rank
         }
-        __syncthreads();
+        qt_barrier();
         // ---- processing order proc[0..k)
         int k;
         if (!final_mode) {
             k = qt_block_scan(keep, Lc, wsum);
             for (int s = tid; s < Lc; s += QT_NT) if (cur[s].cnt > 1) proc[keep[s]] = s;
-            __syncthreads();
+            qt_barrier();
         } else {
             const int E = qt_block_scan(keep, Lc, wsum);
             int M = 1; while (M < E) M <<= 1;
             for (int j = tid; j < M; j += QT_NT) keys[j] = 0ull;
-            __syncthreads();
+            qt_barrier();
             for (int s = tid; s < Lc; s += QT_NT) if (cur[s].cnt > 1)
                 keys[keep[s]] = ((unsigned long long)cur[s].cnt << 42) | ((unsigned long long)(unsigned)cur[s].cid << 10) | (unsigned long long)s;
-            __syncthreads();
+            qt_barrier();
             for (int kk = 2; kk <= M; kk <<= 1)
                 for (int j = kk >> 1; j > 0; j >>= 1) {
                     for (int i = tid; i < M; i += QT_NT) {
@@ -483,34 +487,34 @@ __global__ __launch_bounds__(QT_NT) void k_quadtree(const uint32_t* __restrict__
                             if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
                         }
                     }
-                    __syncthreads();
+                    qt_barrier();
                 }
             for (int j = tid; j < E; j += QT_NT) { proc[j] = (int)(keys[j] & 1023ull); pre[j] = nch[proc[j]] - 1; }
-            __syncthreads();
+            qt_barrier();
             qt_block_scan(pre, E, wsum);                 // list growth before processing the j-th node
             if (tid == 0) sh_nexp = 0;
-            __syncthreads();
+            qt_barrier();
             int mine = 0;
             for (int j = tid; j < E; j += QT_NT) if (Lc + pre[j] < N) mine++;
             if (mine) atomicAdd(&sh_nexp, mine);
-            __syncthreads();
+            qt_barrier();
             k = sh_nexp;
-            __syncthreads();
+            qt_barrier();
             if (tid == 0) sh_nexp = 0;
         }
         // ---- positions
         for (int j = tid; j < k; j += QT_NT) pre[j] = nch[proc[j]];
         for (int s = tid; s < Lc; s += QT_NT) keep[s] = 1;
-        __syncthreads();
+        qt_barrier();
         for (int j = tid; j < k; j += QT_NT) keep[proc[j]] = 0;
-        __syncthreads();
+        qt_barrier();
         const int C = qt_block_scan(pre, k, wsum);
         const int nkeep = qt_block_scan(keep, Lc, wsum);
         const int Lnew = C + nkeep;
         if (Lnew > qcap) { if (tid == 0) { atomicExch(overflow, 2); selcnt[task] = 0; } return; }
         // keep[] now holds exclusive ranks for EVERY slot; a divided slot is recognised through childslot >= 0 below
         for (int s = tid; s < 4 * Lc; s += QT_NT) childslot[s] = -1;
-        __syncthreads();
+        qt_barrier();
         int nexp_local = 0;
         for (int j = tid; j < k; j += QT_NT) {
             const int s = proc[j]; const QtNode nd = cur[s];
@@ -533,19 +537,19 @@ __global__ __launch_bounds__(QT_NT) void k_quadtree(const uint32_t* __restrict__
             }
         }
         if (nexp_local) atomicAdd(&sh_nexp, nexp_local);
-        __syncthreads();
+        qt_barrier();
         for (int s = tid; s < Lc; s += QT_NT) {
             const bool divided = cur[s].cnt > 1 && (childslot[4 * s] >= 0 || childslot[4 * s + 1] >= 0 || childslot[4 * s + 2] >= 0 || childslot[4 * s + 3] >= 0);
             if (!divided) { nxt[C + keep[s]] = cur[s]; newslot[s] = C + keep[s]; } else newslot[s] = -1;
         }
-        __syncthreads();
+        qt_barrier();
         for (int i = tid; i < n; i += QT_NT) {
             const int s = slot[i];
             if (newslot[s] >= 0) slot[i] = (uint16_t)newslot[s];
             else { const QtNode nd = cur[s]; const uint32_t p = cd[i]; slot[i] = (uint16_t)childslot[4 * s + qt_quadrant(nd, (int)(p & 0xfff) - minB, (int)((p >> 12) & 0xfff) - minB)]; }
         }
         const int nToExpand = sh_nexp;
-        __syncthreads();
+        qt_barrier();
         { QtNode* t = cur; cur = nxt; nxt = t; }
         counter += C;
         if (Lnew >= N || Lnew == Lc) finish = true;
@@ -556,9 +560,9 @@ __global__ __launch_bounds__(QT_NT) void k_quadtree(const uint32_t* __restrict__
     // key = response << 16 | (65535 - input index): n <= VIDO_MAX_CAND_PER_FRAME < 65536 (the slot map is u16 for the same reason)
     unsigned* best = (unsigned*)childcnt;
     for (int s = tid; s < Lc; s += QT_NT) best[s] = 0u;
-    __syncthreads();
+    qt_barrier();
     for (int i = tid; i < n; i += QT_NT) atomicMax(&best[slot[i]], ((cd[i] >> 24) << 16) | (unsigned)(65535 - i));
-    __syncthreads();
+    qt_barrier();
     for (int s = tid; s < Lc; s += QT_NT) sel[(size_t)task * qcap + s] = 65535 - (int)(best[s] & 0xffffu);
     if (tid == 0) selcnt[task] = Lc;
 }
