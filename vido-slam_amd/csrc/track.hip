@@ -19,6 +19,7 @@ struct TrackState {
     float* d_tmpf = nullptr; int32_t* d_tmpi = nullptr; size_t tmp_cap = 0;       // scratch for gathers
     int32_t* h_cnt = nullptr;
     char* h_stage = nullptr; size_t stage_cap = 0;
+    char* h_maps = nullptr; size_t maps_cap = 0;          // pinned stage of host-resident depth / flow / mask (vido_frontend_batch, maps_on_device = 0)
     char* h_view = nullptr; size_t view_cap = 0;         // pinned lists of the fused front end (vido_frontend_batch)
     // where the maps of each slot live: the ctx's own buffers, or (zero-copy batches) the caller's device memory
     std::vector<float*> sdepth, sflow; std::vector<int32_t*> smask;
@@ -231,7 +232,7 @@ void track_state_destroy(vido_ctx* ctx)
     if (!T) return;
     hipFree(T->d_depth); hipFree(T->d_flow); hipFree(T->d_mask); hipFree(T->d_kps); hipFree(T->d_sidx); hipFree(T->d_scorr); hipFree(T->d_sflow);
     hipFree(T->d_sdepth); hipFree(T->d_nstat); hipFree(T->d_nobj); hipFree(T->d_okeys); hipFree(T->d_ocorr); hipFree(T->d_odepth); hipFree(T->d_olabel);
-    hipFree(T->d_oflow); hipFree(T->d_tmpf); hipFree(T->d_tmpi); hipHostFree(T->h_cnt); hipHostFree(T->h_stage); hipHostFree(T->h_view);
+    hipFree(T->d_oflow); hipFree(T->d_tmpf); hipFree(T->d_tmpi); hipHostFree(T->h_cnt); hipHostFree(T->h_stage); hipHostFree(T->h_view); hipHostFree(T->h_maps);
     if (T->ev_maps) hipEventDestroy(T->ev_maps);
     if (T->ev_cnt) hipEventDestroy(T->ev_cnt);
     delete T; ctx->trk = nullptr;
@@ -369,20 +370,34 @@ int vido_frontend_batch(vido_ctx* ctx, const uint8_t* imgs, int imgs_on_device, 
     for (int f = 0; f < n_frames; f++) { T->sdepth[slot0 + f] = dd + (size_t)f * px; T->sflow[slot0 + f] = (float*)fl + (size_t)f * px * 2; T->smask[slot0 + f] = (int32_t*)mk + (size_t)f * px; }
     // ---- second stream: everything that only needs the maps (pre-scale, dense object sampling) runs next to the extractor
     HIP_TRY(ctx, hipEventRecord(T->ev_maps, st)); HIP_TRY(ctx, hipStreamWaitEvent(st2, T->ev_maps, 0));      // order behind earlier work on the main stream
-    if (!alias) {
-        HIP_TRY(ctx, hipMemcpyAsync(dd, depth, n * 4, in_kind(maps_on_device), st2));
-        HIP_TRY(ctx, hipMemcpyAsync(T->d_flow + slot0 * px * 2, flow, n * 8, in_kind(maps_on_device), st2));
-        HIP_TRY(ctx, hipMemcpyAsync(T->d_mask + slot0 * px, mask, n * 4, in_kind(maps_on_device), st2));
+    // Host-resident maps (the facade's per-frame call): a copy from pageable memory blocks the calling thread for its whole duration, so the
+    // extractor is enqueued FIRST and the maps are staged through pinned memory while the GPU is already busy with it; the rescaled depth comes
+    // back into the same pinned stage and reaches the caller's buffer after the final synchronisation.
+    const bool host_maps = maps_on_device == 0;
+    float* hm_depth = nullptr;
+    if (host_maps) {
+        if ((rc = orb_enqueue(ctx, imgs, imgs_on_device, n_frames, frame_stride, stride, width, height))) return rc;
+        if (n * 16 > T->maps_cap) { HIP_TRY(ctx, hipStreamSynchronize(st2)); if (T->h_maps) HIP_TRY(ctx, hipHostFree(T->h_maps)); T->maps_cap = n * 16; HIP_TRY(ctx, hipHostMalloc((void**)&T->h_maps, T->maps_cap)); }
+        hm_depth = (float*)T->h_maps; float* hm_flow = hm_depth + n; int32_t* hm_mask = (int32_t*)(hm_flow + 2 * n);
+        memcpy(hm_depth, depth, n * 4); memcpy(hm_flow, flow, n * 8); memcpy(hm_mask, mask, n * 4);
+        HIP_TRY(ctx, hipMemcpyAsync(dd, hm_depth, n * 4, hipMemcpyHostToDevice, st2));
+        HIP_TRY(ctx, hipMemcpyAsync(T->d_flow + slot0 * px * 2, hm_flow, n * 8, hipMemcpyHostToDevice, st2));
+        HIP_TRY(ctx, hipMemcpyAsync(T->d_mask + slot0 * px, hm_mask, n * 4, hipMemcpyHostToDevice, st2));
+    } else if (!alias) {
+        HIP_TRY(ctx, hipMemcpyAsync(dd, depth, n * 4, hipMemcpyDeviceToDevice, st2));
+        HIP_TRY(ctx, hipMemcpyAsync(T->d_flow + slot0 * px * 2, flow, n * 8, hipMemcpyDeviceToDevice, st2));
+        HIP_TRY(ctx, hipMemcpyAsync(T->d_mask + slot0 * px, mask, n * 4, hipMemcpyDeviceToDevice, st2));
     }
     hipLaunchKernelGGL(k_depth_prescale, dim3((int)std::min<size_t>((n / 4 + 255) / 256, 2048)), dim3(256), 0, st2, dd, n / 4, p->dataset, p->depth_map_factor, p->bf, p->kaist_scale);
-    if (!alias) HIP_TRY(ctx, hipMemcpyAsync(depth, dd, n * 4, maps_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st2));     // in-place semantics of Tracking.cc:299-322
+    if (host_maps) HIP_TRY(ctx, hipMemcpyAsync(hm_depth, dd, n * 4, hipMemcpyDeviceToHost, st2));                       // in-place semantics of Tracking.cc:299-322 ...
+    else if (!alias) HIP_TRY(ctx, hipMemcpyAsync(depth, dd, n * 4, hipMemcpyDeviceToDevice, st2));
     hipLaunchKernelGGL(k_dense_sample, dim3(n_frames), dim3(1024), 0, st2, (const float*)dd, fl, mk,
                        T->W, T->H, p->th_depth_obj, step, T->max_obj, T->d_okeys, T->d_ocorr, T->d_odepth, T->d_olabel, T->d_oflow, T->d_nobj);
     HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt + T->B, T->d_nobj, n_frames * 4, hipMemcpyDeviceToHost, st2));
     HIP_TRY(ctx, hipEventRecord(T->ev_maps, st2));                 // maps rescaled, object samples done
     HIP_TRY(ctx, hipEventRecord(T->ev_cnt, st2));
     // ---- main stream: extractor, then the static filter (needs the keypoints AND the rescaled depth)
-    if ((rc = orb_enqueue(ctx, imgs, imgs_on_device, n_frames, frame_stride, stride, width, height))) return rc;
+    if (!host_maps && (rc = orb_enqueue(ctx, imgs, imgs_on_device, n_frames, frame_stride, stride, width, height))) return rc;
     // object-sample rows go to the host on the second stream while the extractor is still running (their counts are known early)
     HIP_TRY(ctx, hipEventSynchronize(T->ev_cnt));
     const size_t Bv = T->B, need = Bv * ((size_t)T->max_kp * 24 + (size_t)T->max_obj * 32);
@@ -417,6 +432,7 @@ int vido_frontend_batch(vido_ctx* ctx, const uint8_t* imgs, int imgs_on_device, 
     HIP_TRY(ctx, hipStreamSynchronize(st));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     HIP_TRY(ctx, hipGetLastError());
+    if (host_maps) memcpy(depth, hm_depth, n * 4);                 // ... the caller's depth buffer now holds the rescaled values
     return VIDO_OK;
 }
 
