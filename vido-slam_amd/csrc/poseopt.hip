@@ -541,7 +541,8 @@ extern "C" int vido_pose_optimize_batch(vido_ctx* ctx, const vido_pose_problem* 
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(S->h_res, S->d_res, n_prob * sizeof(vido_pose_result), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(S->h_bytes, S->d_bytes, bo, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));           // inputs consumed: the stage can now carry the refined flows back
+    // the refined flows come back through the same pinned stage: the uploads that read it precede these copies in stream order, so no host
+    // synchronisation is needed in between
     size_t fo = 0;
     std::vector<size_t> fstage(n_prob);
     for (int k = 0; k < n_prob; k++) {
