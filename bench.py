@@ -214,8 +214,14 @@ def main():
           if r.get("ms_linearize_kernel", 0.0) > 0:
               nb = 288.0 * len(pr["obs_cam"])
               ach = nb / (r["ms_linearize_kernel"] * 1e-3) / 1e9
+              ba_traffic = None
+              try:
+                  with open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic_ba.json")) as fjs:
+                      ba_traffic = json.load(fjs)["kernels"]["k_ba_linearize"]["traffic_bytes_fetch_x2"]      # tools/profile_ba_pmc.sh, same problem
+              except Exception:
+                  pass
               out["roofline_ba"] = {"kernel": "k_ba_linearize", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(nb),
+                                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": ba_traffic, "algorithmic_bytes_per_launch": int(nb),
                                     "avg_launch_ms": round(r["ms_linearize_kernel"], 5), "workload": "configs[3] static graph, 20 KF x 2k landmarks"}
           # configs[4]: global BA, landmarks sharded over the ranks, RCCL all-reduce of the reduced camera system
           gpr = P.synth_ba_problem(n_cam=args.gba_cams, n_pt=args.gba_points, kind="global", track_len=10, seed=11)
