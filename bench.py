@@ -1,33 +1,57 @@
 #!/usr/bin/env python3
 """bench.py — driver contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.
 
-Workload (BASELINE.json configs[1]): "ORB pyramid + flow-guided tracking only, synthetic 640x480 stream,
-1 MI355X".  A step = one pass of the per-frame hot path (one call of the fused C-ABI entry vido_frontend_batch) over one
-batch of `--batch` synthetic frames whose gray/depth/flow/mask maps are already resident in HBM when the timed region
-starts; results (keypoints, descriptors, lists) are on the host, in pinned memory, when the step returns:
-    ORB extraction (pyramid, per-cell FAST, quadtree, IC angle, 7x7 blur, rBRIEF)      A2-A8
-    depth pre-scale, static-candidate filter + depth gather, dense object sampling    A1, A9, A10
-The per-frame path does not shard (frame k depends on frame k-1): with --gpus N every rank runs an
-independent replica on its own GPU ("replicas only"), no data-path collective; value = frames of all ranks /
-max-over-ranks time.
+HEADLINE (BASELINE.json metric "frames/sec end-to-end (flow+depth+track+local-BA) at 640x480"): BASELINE configs[1]+[2]+[3] CHAINED on
+one GPU, the reference's realtime chain src/realtime_demo/src/run_vido.cc:142-157 (RunNet: FlowNet, MaskRcnn, MonoDepth service calls) ->
+:229-235 (System::TrackRGBD).  A step = ONE 640x480 frame through
+    LiteFlowNet + MonoDepth2 (fed 640x192) + Mask R-CNN X-101-32x8d-FPN (fed 800x1088), fp32, batch 1        configs[2]
+    -> hand-over of flow / depth / mask to the tracker's host interface (one D2H copy per map)
+    -> System::TrackRGBD: cvtColor + ORB pyramid/FAST/quadtree/IC-angle/blur/rBRIEF, depth pre-scale, static filter, dense object
+       sampling, mask propagation, P3P-RANSAC, PoseOptimizationFlow2Cam, scene flow, object tracking, per-object PoseOptimizationFlow2,
+       re-seeding, tracklets                                                                                  configs[1]
+    -> PartialBatchOptimization over the 20-frame window (the reference runs it every frame)                  configs[3]
+with the two halves PIPELINED like two ROS nodes would be: the networks of frame k+1 run (three HIP streams) while frame k is tracked on
+the tracker's own stream.  The BGR frames are resident in pinned host memory when the timed region starts (the camera's hand-over);
+`value` = frames / wall time of the whole chain, max over ranks.  Before the W warm-up steps an untimed prologue of --prologue frames fills
+the local-BA window, so every timed frame optimises a full 20-keyframe window.
+Synthetic data: a ray-cast 640x480 scene (ground plane, far wall, 5 moving objects, forward-driving camera); the networks have random-init
+weights (no checkpoints ship with the reference, no network here), so their outputs carry no geometry: they run at full cost and their
+outputs are copied to the host exactly as the chain requires, and frame k is tracked only after that has completed, but the tracker is handed
+the renderer's exact flow / depth / mask of the same frame (--feed given; --feed nets hands it the networks' outputs instead).
+The per-frame path does not shard (frame k depends on frame k-1): --gpus N runs N independent replicas, no data-path collective.
 
 Extra objects on the same JSON line:
-  roofline      dominant ORB kernel (k_fast_cells): algorithmic bytes / live HIP-event time vs the 8 TB/s HBM peak
-  roofline_ba   BA linearisation kernel (k_ba_linearize): 288 B per edge / live HIP-event time
-  cpu_baseline  the CPU oracle (scalar C restatement, 1 core) on a bounded sample of the same frames (rank 0, N=1)
-  extra         per-frame optimisers (configs[3] prerequisites), local BA (configs[3]) and, with --gpus N > 1, the
-                landmark-sharded global BA (configs[4], scaled by --gba-cams/--gba-points) over RCCL
+  stage_ms       per-frame breakdown of the chain (networks alone, tracker stages, local BA)
+  roofline       dominant hand-written kernel of the tracker front end (FAST): algorithmic bytes / live HIP-event time vs the 8 TB/s HBM peak,
+                 measured on BASELINE configs[1] batched (64 frames in flight, the only regime where an HBM roofline of a <1 MB/frame stage means anything)
+  roofline_ba    k_ba_linearize at configs[3] (local window) and configs[4] (1 M edges) size: 288 B per edge
+  roofline_nets  fp32 FLOP/s of each network node vs the 157.3 TFLOP/s fp32 matrix/vector peak
+  cpu_baseline   the same chain on the host cores: the three nets on torch-CPU + the CPU oracle for ORB / lists / pose optimisers / local BA
+  extra          configs[1] batched throughput, per-frame optimisers, Hamming matcher, local / global / dynamic BA, sharded global BA with --gpus N
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector = fp32 matrix peak
+
+
+def write_settings(path, K, w, h):
+    """Settings file in the reference's OpenCV-YAML schema (src/config/kitti_config.yaml keys, Tracking.cc:45-171); OMD depth convention (d / factor)."""
+    fx, fy, cx, cy = K
+    with open(path, "w") as fh:
+        fh.write("%%YAML:1.0\nCamera.width: %d\nCamera.height: %d\n" % (w, h))
+        fh.write("Camera.fx: %r\nCamera.fy: %r\nCamera.cx: %r\nCamera.cy: %r\nCamera.k1: 0.0\nCamera.k2: 0.0\nCamera.p1: 0.0\nCamera.p2: 0.0\nCamera.k3: 0.0\n" % (fx, fy, cx, cy))
+        fh.write("Camera.bf: 387.57\nCamera.fps: 30.0\nCamera.RGB: 0\nChooseData: 1\nDepthMapFactor: 1.0\nThDepthBG: 40.0\nThDepthOBJ: 25.0\n")
+        fh.write("MaxTrackPointBG: 3000\nMaxTrackPointOBJ: 800\nSFMgThres: 0.12\nSFDsThres: 0.3\nWINDOW_SIZE: 20\nOVERLAP_SIZE: 4\nUseSampleFeature: 0\n")
+        fh.write("ORBextractor.nFeatures: 2000\nORBextractor.scaleFactor: 1.2\nORBextractor.nLevels: 8\nORBextractor.iniThFAST: 20\nORBextractor.minThFAST: 7\n")
 
 
 def main():
@@ -35,11 +59,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step (in flight on one GPU)")
-    ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--prologue", type=int, default=20, help="untimed frames before the warm-up that fill the local-BA window (WINDOW_SIZE)")
+    ap.add_argument("--feed", choices=("given", "nets"), default="given", help="maps the tracker consumes: the renderer's (default) or the networks' outputs")
+    ap.add_argument("--no-pipeline", action="store_true", help="serial chain: networks of frame k, then tracking of frame k")
+    ap.add_argument("--no-graphs", action="store_true"); ap.add_argument("--no-fold", action="store_true"); ap.add_argument("--no-streams", action="store_true")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen measures its solvers once per layer shape)")
+    ap.add_argument("--batch", type=int, default=64, help="frames in flight of the configs[1] batched leg")
+    ap.add_argument("--cpu-baseline", type=int, default=2, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--no-extra", action="store_true", help="skip the optimiser / BA side measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (optimisers / BA / matcher)")
     ap.add_argument("--gba-cams", type=int, default=500)
     ap.add_argument("--gba-points", type=int, default=100000)
     args = ap.parse_args()
@@ -56,6 +85,7 @@ def main():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
     torch.cuda.set_device(local_rank)
+    os.environ["VIDO_DEVICE"] = str(local_rank)            # the System's tracker context (facade) follows the rank's GPU
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -68,38 +98,10 @@ def main():
         dist.barrier()
     import ctypes as C
     import vido_slam_amd as V
-    from vido_slam_amd import synth
+    from vido_slam_amd import synth, pipeline
+    from vido_slam_amd.system import System
 
-    B, W, H = args.batch, args.width, args.height
-    ctx = V.Context(device=local_rank, width=W, height=H, max_batch=B)
-    tp = V.track_params(dataset=0, depth_map_factor=1.0, th_depth_bg=40.0, th_depth_obj=25.0)
-    ff = V.FrameFeatures(ctx, tp)
-    # a synthetic stream (rank-dependent seed: independent replicas); B frames of it are resident in HBM
-    n_distinct = min(B, 16)
-    seq = synth.Sequence(n_frames=n_distinct, w=W, h=H, seed=1 + 100 * rank)
-    fr = [seq.frame(k) for k in range(n_distinct)]
-    sel = np.arange(B) % n_distinct
-    gray_h = np.ascontiguousarray(np.stack([fr[i][0] for i in sel]))
-    depth_h = np.ascontiguousarray(np.stack([fr[i][2] for i in sel]).astype(np.float32))
-    flow_h = np.ascontiguousarray(np.stack([fr[i][3] for i in sel]))
-    mask_h = np.ascontiguousarray(np.stack([fr[i][4] for i in sel]))
-    gray_d = torch.from_numpy(gray_h).cuda(); depth_d = torch.from_numpy(depth_h).cuda()
-    flow_d = torch.from_numpy(flow_h).cuda(); mask_d = torch.from_numpy(mask_h).cuda()
-    # The depth pre-scale rewrites its input in place (Tracking.cc:299-322 does it to the caller's Mat), so every step needs a fresh raw depth batch.
-    # They are all resident in HBM before the timed region starts (one 79 MB batch per step; a real pipeline gets a new one from the depth network),
-    # instead of being re-created by a device copy inside it.
-    n_fresh = min(args.steps + args.warmup, 48)
-    depth_pool = [depth_d.clone() for _ in range(n_fresh)]
-    torch.cuda.synchronize()                               # torch's stream made the copies; the tracker runs on the ctx's stream
-    dev_arg = (gray_d.data_ptr(), B, H, W, H * W, W)
-    step_no = [0]
-
-    def step():
-        k = step_no[0]; step_no[0] += 1
-        if k >= n_fresh:                                   # very long runs: refresh one buffer (outside the common K/W settings)
-            depth_pool[k % n_fresh].copy_(depth_d); torch.cuda.current_stream().synchronize()
-        o = ff.frontend_batch(0, dev_arg, depth_pool[k % n_fresh].data_ptr(), flow_d.data_ptr(), mask_d.data_ptr(), alias=True)   # fused ORB + pre-scale + lists, maps zero-copy
-        return o["kps"], o["n_kp"], o
+    W, H = args.width, args.height
 
     def sync_all():
         torch.cuda.synchronize()
@@ -107,67 +109,177 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    stage = {}
+    # =============================================================================================================================
+    # HEADLINE: the chained, pipelined end-to-end frame rate
+    n_total = args.prologue + args.warmup + args.steps
+    scene = synth.convoy_scene(n_total + 1, w=W, h=H, seed=5 + 100 * rank)
+    frames = []
+    for k in range(n_total):
+        g, d, f, m = scene.frame(k)
+        frames.append((synth.gray_to_bgr(g), np.ascontiguousarray(d, np.float32), np.ascontiguousarray(f, np.float32), np.ascontiguousarray(m, np.int32)))
+    tmp = tempfile.mkdtemp(prefix="vido_bench_")
+    cfg_path = os.path.join(tmp, "settings.yaml")
+    write_settings(cfg_path, scene.K, W, H)
+    net_ctx = V.Context(device=local_rank, width=W, height=H, max_batch=1)             # owns the HIP ops of the network nodes (correlation, ROI-Align, NMS ...)
+    t_setup = time.perf_counter()
+    nodes = pipeline.NetNodes(net_ctx, H, W, optimize=not args.no_fold, graphs=not args.no_graphs, streams=not args.no_streams, miopen_find=args.miopen_find)
+    t_setup = time.perf_counter() - t_setup
+    slam = System(); slam.Init(cfg_path, System.RGBD)
+    e2e = pipeline.EndToEnd(nodes, slam, n_image=10 ** 6, feed=args.feed)
+
+    def run(lo, hi):
+        for k in range(lo, hi):
+            bgr, d, f, m = frames[k]
+            e2e.push(bgr, (d, f, m))
+            if args.no_pipeline:
+                e2e.finish()
+        e2e.finish()
+
+    run(0, args.prologue)                                    # fills the local-BA window (untimed set-up)
+    run(args.prologue, args.prologue + args.warmup)          # W warm-up steps
+    n0 = len(e2e.stats)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        kps, cnt, lists = step()
-        for k, v in ctx.orb_timing().items():
-            stage[k] = stage.get(k, 0.0) + v
+    run(args.prologue + args.warmup, n_total)
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    stage = {k: v / max(args.steps, 1) for k, v in stage.items()}
-    frames_total = B * args.steps * world
-    fps = frames_total / dt
+    fps = args.steps * world / dt
+    st = e2e.stats[n0:]
+    mean = lambda key: float(np.mean([s[key] for s in st])) if st else 0.0
+    # pose accuracy of the timed frames against the renderer's ground truth: the chain did real work
+    t_err = []
+    for i, T in enumerate(e2e.poses):
+        E = T.astype(np.float64) @ np.linalg.inv(scene.Tcw(i))
+        t_err.append(float(np.linalg.norm(E[:3, 3])))
+    stage = {"track_total_ms": mean("ms_total"), "update_mask_ms": mean("ms_update_mask"), "frame_orb_lists_ms": mean("ms_frame"), "cam_pose_ms": mean("ms_cam_pose"),
+             "obj_tracking_ms": mean("ms_obj_tracking"), "obj_motion_ms": mean("ms_obj_motion"), "renew_ms": mean("ms_renew"), "local_ba_ms": mean("ms_local_ba"),
+             "net_enqueue_host_ms": float(np.mean(e2e.t_net[n0:])), "tracker_wait_for_nets_ms": float(np.mean(e2e.t_wait[n0:])), "tracker_thread_ms": float(np.mean(e2e.t_track[n0:]))}
+    counts = {"keypoints": mean("n_keypoints"), "static_points": mean("n_static"), "static_inliers": mean("n_static_inliers"), "dynamic_objects": mean("n_objects"),
+              "object_points": mean("n_object_points"), "ba_window": mean("ba_window")}
+    e2e.close()
 
-    # ---- roofline of the dominant ORB kernel: every pyramid pixel read once (950 532 B per 640x480
-    # frame) + 4 B per emitted candidate, per launch of B frames
-    p_px = 0
-    for l in range(ctx.cfg.n_levels):
-        a, b = C.c_int(), C.c_int()
-        ctx.lib.vido_orb_level_size(ctx.h, l, C.byref(a), C.byref(b))
-        p_px += a.value * b.value
-    fast_bytes = p_px * B + 4.0 * stage.get("n_candidates", 0.0)
-    fast_s = stage["fast_ms"] * 1e-3
-    achieved = fast_bytes / fast_s / 1e9 if fast_s > 0 else 0.0
-    roofline = {"kernel": "k_fast_cells", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "algorithmic_bytes_per_launch": int(fast_bytes), "avg_launch_ms": round(stage["fast_ms"], 4)}
-    # HBM traffic per launch from the committed PMC passes of this same command (tools/profile_round.sh; a bench run cannot
-    # collect counters on itself).  FETCH_SIZE is doubled per MI355X_MICROARCH.md (128-B requests tallied at 64 B; checked
-    # here on k_depth_prescale: 39.3 MB counted for 78.6 MB read), WRITE_SIZE is taken as is; both are KB.
-    pmc_path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")
-    if os.path.exists(pmc_path) and B == 64 and (W, H) == (640, 480):
-        k = json.load(open(pmc_path))["kernels"].get("k_fast_cells")
-        if k:
-            roofline["traffic"] = int((2.0 * k["FETCH_SIZE_KB_mean_per_launch"] + k["WRITE_SIZE_KB_mean_per_launch"]) * 1024)
-            roofline["traffic_source"] = "profiles/r1/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes; FETCH x2 gfx950 correction)"
+    # ---- the three networks alone (sequential, one stream each in turn): ms per forward and fp32 FLOP/s against the 157.3 TFLOP/s peak
+    roofline_nets = {}
+    try:
+        ex = torch.as_tensor(frames[-1][0], device="cuda"); ex0 = torch.as_tensor(frames[-2][0], device="cuda")
+        def timed(fn, reps=5):
+            fn(); torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps
+        from torch.utils.flop_counter import FlopCounterMode
+        def flops(fn):
+            with FlopCounterMode(display=False) as fc:
+                fn()
+            return float(fc.get_total_flops())
+        legs = {"liteflownet": (lambda: (nodes.g_flow or nodes._flow_fn)(ex0, ex), lambda: nodes._flow_fn(ex0, ex)),
+                "monodepth2": (lambda: (nodes.g_depth or nodes._depth_fn)(ex), lambda: nodes._depth_fn(ex)),
+                "maskrcnn_x101_fpn": (lambda: V.nets.analyse_image(nodes.mask_net, ex, feed=nodes.mask_feed, confidence=nodes.confidence, trunk=nodes.g_trunk),
+                                      lambda: V.nets.analyse_image(nodes.mask_net, ex, feed=nodes.mask_feed, confidence=nodes.confidence))}
+        for name, (fast, eager) in legs.items():
+            ms = timed(fast); fl = flops(eager)
+            stage[name + "_ms"] = round(ms, 3)
+            roofline_nets[name] = {"bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "gflop_per_frame": round(fl / 1e9, 1), "ms": round(ms, 3), "dtype": "fp32"}
+        stage["nets_sum_ms"] = round(sum(stage[k + "_ms"] for k in legs), 3)
+    except Exception as e:
+        roofline_nets["error"] = "%s: %s" % (type(e).__name__, e)
 
     out = {
         "metric": "frames/sec end-to-end (flow+depth+track+local-BA) at 640x480; BA iters/sec",
-        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "configs[1]: ORB pyramid (8 levels x1.2, 2000 features, FAST 20/7, quadtree, IC angle, 7x7 blur, rBRIEF) + "
-                               "flow-guided tracking front-end (depth pre-scale, static filter, dense object sampling) on a synthetic "
-                               "%dx%d stream; nets / local BA are measured separately under 'extra'" % (W, H),
-                   "frames_per_step": B, "parallelism": "replicas x%d (per-frame path does not shard)" % world,
-                   "inputs": "gray u8 + depth f32 + flow f32x2 + mask i32 resident in HBM"},
-        "stage_ms_per_step": {k: round(v, 4) for k, v in stage.items() if k != "n_candidates"},
-        "keypoints_per_frame": float(cnt.mean()), "static_candidates_per_frame": float(lists["n_stat"].mean()),
-        "object_samples_per_frame": float(lists["n_obj"].mean()),
-        "roofline": roofline,
+        "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]+[2]+[3] chained: per %dx%d frame LiteFlowNet + MonoDepth2 (640x192 feed) + Mask R-CNN X-101-32x8d-FPN (800x1088 feed), fp32 batch 1, random-init weights "
+                               "-> host hand-over -> System::TrackRGBD (cvtColor, ORB 2000 features, lists, mask propagation, P3P-RANSAC, Flow2Cam, scene flow, object tracking, "
+                               "per-object Flow2, re-seeding) -> PartialBatchOptimization over a full 20-frame window; networks of frame k+1 overlap tracking of frame k" % (W, H),
+                   "frames_per_step": 1, "pipelined": not args.no_pipeline, "tracker_feed": args.feed,
+                   "tracker_feed_note": "networks run at full cost and their outputs are copied to the host; with random-init weights those maps carry no geometry, so the tracker is "
+                                        "handed the renderer's exact flow/depth/mask of the same frame (feed=given) after the network hand-over of that frame has completed",
+                   "prologue_frames": args.prologue, "parallelism": "replicas x%d (per-frame path does not shard)" % world,
+                   "net_optimisations": {"frozen_bn_folded_pairs": nodes.folded, "hip_graphs": nodes.g_flow is not None, "graph_error": nodes.graph_error,
+                                         "three_streams": nodes.streams is not None, "miopen_find": bool(args.miopen_find)},
+                   "inputs": "BGR u8 frames in pinned host memory; flow f32x2 / depth f32 / mask i32 handed to TrackRGBD as host buffers"},
+        "stage_ms": {k: round(v, 3) for k, v in stage.items()},
+        "per_frame_counts": {k: round(v, 1) for k, v in counts.items()},
+        "pose_translation_error_m": {"mean": round(float(np.mean(t_err[1:])), 4), "max": round(float(np.max(t_err[1:])), 4), "path_length_m": round(0.25 * (len(t_err) - 1), 2)},
+        "net_setup_s": round(t_setup, 1),
+        "roofline_nets": roofline_nets,
     }
+    del e2e, slam
+
+    # =============================================================================================================================
+    # roofline of the dominant hand-written front-end kernel, on configs[1] batched (64 frames in flight)
+    B = args.batch
+    extra = {}
+    try:
+        ctx = V.Context(device=local_rank, width=W, height=H, max_batch=B)
+        tp = V.track_params(dataset=0, depth_map_factor=1.0, th_depth_bg=40.0, th_depth_obj=25.0)
+        ff = V.FrameFeatures(ctx, tp)
+        n_distinct = min(B, 16)
+        seq = synth.Sequence(n_frames=n_distinct, w=W, h=H, seed=1 + 100 * rank)
+        fr = [seq.frame(k) for k in range(n_distinct)]
+        sel = np.arange(B) % n_distinct
+        gray_h = np.ascontiguousarray(np.stack([fr[i][0] for i in sel]))
+        depth_h = np.ascontiguousarray(np.stack([fr[i][2] for i in sel]).astype(np.float32))
+        flow_h = np.ascontiguousarray(np.stack([fr[i][3] for i in sel]))
+        mask_h = np.ascontiguousarray(np.stack([fr[i][4] for i in sel]))
+        gray_d = torch.from_numpy(gray_h).cuda(); depth_d = torch.from_numpy(depth_h).cuda()
+        flow_d = torch.from_numpy(flow_h).cuda(); mask_d = torch.from_numpy(mask_h).cuda()
+        bsteps, bwarm = 20, 3
+        depth_pool = [depth_d.clone() for _ in range(bsteps + bwarm)]      # the pre-scale rewrites its input in place: a fresh raw batch per step, resident before timing
+        torch.cuda.synchronize()
+        dev_arg = (gray_d.data_ptr(), B, H, W, H * W, W)
+        stage_b = {}
+        for i in range(bwarm):
+            ff.frontend_batch(0, dev_arg, depth_pool[i].data_ptr(), flow_d.data_ptr(), mask_d.data_ptr(), alias=True)
+        torch.cuda.synchronize(); tb = time.perf_counter()
+        for i in range(bsteps):
+            o = ff.frontend_batch(0, dev_arg, depth_pool[bwarm + i].data_ptr(), flow_d.data_ptr(), mask_d.data_ptr(), alias=True)
+            for k, v in ctx.orb_timing().items():
+                stage_b[k] = stage_b.get(k, 0.0) + v / bsteps
+        torch.cuda.synchronize(); tb = time.perf_counter() - tb
+        p_px = 0
+        for l in range(ctx.cfg.n_levels):
+            a, b = C.c_int(), C.c_int()
+            ctx.lib.vido_orb_level_size(ctx.h, l, C.byref(a), C.byref(b))
+            p_px += a.value * b.value
+        fast_bytes = p_px * B + 4.0 * stage_b.get("n_candidates", 0.0)     # every pyramid pixel read once (950 532 B per 640x480 frame) + 4 B per candidate
+        fast_s = stage_b["fast_ms"] * 1e-3
+        ach = fast_bytes / fast_s / 1e9 if fast_s > 0 else 0.0
+        roofline = {"kernel": "FAST stage (score map + per-cell selection)", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(fast_bytes), "avg_launch_ms": round(stage_b["fast_ms"], 4),
+                    "workload": "configs[1] batched: %d frames of %dx%d in flight" % (B, W, H)}
+        for rnd in ("r2", "r1"):
+            pmc_path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+            if os.path.exists(pmc_path) and B == 64 and (W, H) == (640, 480):
+                ks = json.load(open(pmc_path))["kernels"]
+                tot = 0.0; names = []
+                for name, k in ks.items():
+                    if name.startswith("k_fast"):
+                        tot += (2.0 * k["FETCH_SIZE_KB_mean_per_launch"] + k["WRITE_SIZE_KB_mean_per_launch"]) * 1024; names.append(name)
+                if names:
+                    roofline["traffic"] = int(tot)
+                    roofline["traffic_source"] = "profiles/%s/pmc_traffic.json %s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes; FETCH x2 gfx950 correction)" % (rnd, "+".join(names))
+                    break
+        out["roofline"] = roofline
+        extra["configs1_frontend_batched"] = {"frames_per_s": round(B * bsteps / tb, 1), "ms_per_%d_frames" % B: round(tb / bsteps * 1e3, 4),
+                                              "stage_ms": {k: round(v, 4) for k, v in stage_b.items() if k != "n_candidates"},
+                                              "keypoints_per_frame": float(o["n_kp"].mean()), "note": "round-1 headline workload: ORB + depth pre-scale + frame lists, 64 frames in flight"}
+    except Exception as e:
+        import traceback
+        out["roofline_error"] = "%s: %s" % (type(e).__name__, e); traceback.print_exc(file=sys.stderr)
+        ctx = V.Context(device=local_rank, width=W, height=H, max_batch=1)
 
     if not args.no_extra:
       try:
-          extra = {}
           P = V.problems
           opt = V.Optimizer(ctx)
           s = P.synth_pose_scene(3000, seed=2)
@@ -190,15 +302,14 @@ def main():
               rs = opt.pose_optimize_batch(objs)
           d = (time.perf_counter() - t1) / 5
           extra["PoseOptimizationFlow2_5objects_x800"] = {"ms_per_frame": round(d * 1e3, 3), "lm_iterations": [r["lm_iterations"] for r in rs]}
-          # brute-force Hamming matcher (north_star), descriptors resident on the device: 2000 x 2000 and a 64-frame batch worth of queries
           for na, nb in ((2000, 2000), (128000, 2000)):
               da = torch.randint(0, 256, (na, 32), dtype=torch.uint8, device="cuda"); db = torch.randint(0, 256, (nb, 32), dtype=torch.uint8, device="cuda")
               mi = torch.empty(na, dtype=torch.int32, device="cuda"); md = torch.empty(na, dtype=torch.int32, device="cuda")
               torch.cuda.synchronize()
-              run = lambda: (ctx.hamming_match_device(da.data_ptr(), na, db.data_ptr(), nb, mi.data_ptr(), md.data_ptr()), ctx.synchronize())
-              run(); t1 = time.perf_counter(); reps = 10
+              runh = lambda: (ctx.hamming_match_device(da.data_ptr(), na, db.data_ptr(), nb, mi.data_ptr(), md.data_ptr()), ctx.synchronize())
+              runh(); t1 = time.perf_counter(); reps = 10
               for _ in range(reps):
-                  run()
+                  runh()
               d = (time.perf_counter() - t1) / reps
               extra["hamming_%dx%d" % (na, nb)] = {"ms_per_call": round(d * 1e3, 4), "pairs_per_s": round(na * nb / d, 0), "descriptor_GB_per_s": round(32.0 * (na + nb) / d / 1e9, 2)}
           # configs[3] (static graph): 20 KF x 2k landmarks
@@ -211,18 +322,25 @@ def main():
           extra["local_ba_20kf_2k"] = {"ms_per_solve": round(d * 1e3, 3), "ms_lm_loop": round(r["ms_solve_loop"], 3), "ms_setup": round(r["ms_setup"], 3),
                                        "lm_iterations": r["iterations"], "lm_iters_per_s": round(r["iterations"] / (r["ms_solve_loop"] * 1e-3), 1),
                                        "n_obs": int(len(pr["obs_cam"])), "ms_linearize_kernel": round(r.get("ms_linearize_kernel", 0.0), 5)}
-          if r.get("ms_linearize_kernel", 0.0) > 0:
-              nb = 288.0 * len(pr["obs_cam"])
+
+          def ba_roofline(r, n_obs, workload, pmc_file):
+              if not r.get("ms_linearize_kernel", 0.0) > 0:
+                  return None
+              nb = 288.0 * n_obs
               ach = nb / (r["ms_linearize_kernel"] * 1e-3) / 1e9
-              ba_traffic = None
-              try:
-                  with open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic_ba.json")) as fjs:
-                      ba_traffic = json.load(fjs)["kernels"]["k_ba_linearize"]["traffic_bytes_fetch_x2"]      # tools/profile_ba_pmc.sh, same problem
-              except Exception:
-                  pass
-              out["roofline_ba"] = {"kernel": "k_ba_linearize", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": ba_traffic, "algorithmic_bytes_per_launch": int(nb),
-                                    "avg_launch_ms": round(r["ms_linearize_kernel"], 5), "workload": "configs[3] static graph, 20 KF x 2k landmarks"}
+              traffic = None
+              for rnd in ("r2", "r1"):
+                  try:
+                      with open(os.path.join(ROOT, "profiles", rnd, pmc_file)) as fjs:
+                          traffic = json.load(fjs)["kernels"]["k_ba_linearize"]["traffic_bytes_fetch_x2"]
+                      break
+                  except Exception:
+                      pass
+              return {"kernel": "k_ba_linearize", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                      "traffic": traffic, "algorithmic_bytes_per_launch": int(nb), "avg_launch_ms": round(r["ms_linearize_kernel"], 5), "workload": workload}
+          rb = ba_roofline(r, len(pr["obs_cam"]), "configs[3] static graph, 20 KF x 2k landmarks", "pmc_traffic_ba.json")
+          if rb:
+              out["roofline_ba"] = rb
           # configs[4]: global BA, landmarks sharded over the ranks, RCCL all-reduce of the reduced camera system
           gpr = P.synth_ba_problem(n_cam=args.gba_cams, n_pt=args.gba_points, kind="global", track_len=10, seed=11)
           gpr["max_iters"] = 5
@@ -232,7 +350,7 @@ def main():
           t1 = time.perf_counter()
           r = V.ba_optimize(ctx, gpr, rank=rank, world=world, shard=shards[rank] if world > 1 else None, allreduce=hook)
           sync_all()
-          d_cold = time.perf_counter() - t1            # first call on this context: includes growing the persistent device pool and pinning its upload stage
+          d_cold = time.perf_counter() - t1
           t1 = time.perf_counter()
           r = V.ba_optimize(ctx, gpr, rank=rank, world=world, shard=shards[rank] if world > 1 else None, allreduce=hook)
           sync_all()
@@ -241,8 +359,14 @@ def main():
                                 "lm_iterations": r["iterations"], "lm_trials": r["lm_trials"], "ms_lm_loop": round(r["ms_solve_loop"], 2),
                                 "ms_setup": round(r["ms_setup"], 2), "lm_iters_per_s": round(r["iterations"] / (r["ms_solve_loop"] * 1e-3), 2),
                                 "chi2": [round(r["chi2_initial"], 3), round(r["chi2_final"], 3)], "wall_ms": round(d * 1e3, 1), "wall_ms_first_call": round(d_cold * 1e3, 1),
-                                "collective": "RCCL all-reduce (sum) of S (6n x 6n f64) + r per LM trial" if world > 1 else "none"}
-          # configs[4]/[5] with the object factors (FullBatchOptimization, STATIC_ONLY = false): frame-interleaved pose order + band layout
+                                "collective": "RCCL all-reduce (sum) of the reduced camera system per LM trial" if world > 1 else "none",
+                                "scaling_curve": "no 8-GPU scaling curve measured by the builder (single-GPU boxes); the driver's SCALE record is the measurement"}
+          if "ms_phases" in r:
+              extra["global_ba"]["ms_phases_per_trial"] = r["ms_phases"]
+          if world == 1:
+              rb = ba_roofline(r, len(gpr["obs_cam"]), "configs[4] size on one GPU: %d KF x %d landmarks, %d edges" % (args.gba_cams, int(gpr["n_pt"]), len(gpr["obs_cam"])), "pmc_traffic_ba_global.json")
+              if rb:
+                  out["roofline_ba_global"] = rb
           if rank == 0:
               dpr = P.synth_ba_problem(n_cam=200, n_pt=20000, kind="global", track_len=10, seed=13); dpr["max_iters"] = 5
               ddy = P.synth_ba_dynamic(dpr, n_obj=3, pts_per_obj=300, seed=14, max_len=8)
@@ -251,65 +375,65 @@ def main():
                                             "n_ternary": int(ddy["n_tern"]), "lm_iterations": r["iterations"], "ms_lm_loop": round(r["ms_solve_loop"], 2), "ms_setup": round(r["ms_setup"], 2),
                                             "lm_iters_per_s": round(r["iterations"] / (r["ms_solve_loop"] * 1e-3), 2), "chi2": [round(r["chi2_initial"], 3), round(r["chi2_final"], 3)],
                                             "wall_ms": round(d * 1e3, 1)}
-          # rows N1/N2: network nodes (fp32 like the reference, random-init weights), KITTI-sized frames, rank 0 only
-          if rank == 0:
-              from vido_slam_amd import nets
-              hops = nets.HipOps(ctx)
-              lfn = nets.fill_deterministic(nets.LiteFlowNet(hops.correlation, epilogue=hops.bias_act_), 1).eval().cuda()
-              md = nets.fill_deterministic(nets.MonoDepth2(), 2).eval().cuda()
-              rgb = (np.random.RandomState(0).rand(375, 1242, 3) * 255).astype(np.uint8)
-              def timed(fn, reps=5):
-                  fn(); fn(); torch.cuda.synchronize()
-                  t = time.perf_counter()
-                  for _ in range(reps):
-                      fn()
-                  torch.cuda.synchronize()
-                  return (time.perf_counter() - t) / reps * 1e3
-              extra["nets_fp32_1242x375"] = {"liteflownet_ms": round(timed(lambda: nets.analyse_flow(lfn, rgb, rgb)), 3),
-                                             "monodepth2_ms": round(timed(lambda: nets.analyse_depth(md, rgb)), 3),
-                                             "note": "includes the u8 host->device upload and pre/post resizes (run_flow_net.py / run_mono_depth.py wrappers)"}
-              mr = nets.fill_maskrcnn(nets.MaskRCNN(nets.HipOps(ctx)), 3).eval().cuda()
-              extra["nets_fp32_1242x375"]["maskrcnn_x101_fpn_ms"] = round(timed(lambda: nets.analyse_image(mr, rgb), reps=3), 3)
-              del lfn, md, mr
-          # per-frame tracking end to end through the drop-in C++ facade (System::TrackRGBD: host buffers in, pose out; ORB + lists + P3P-RANSAC +
-          # pose / object optimisers + scene flow + object tracking + windowed local BA), on a geometrically consistent synthetic clip; rank 0
-          if rank == 0:
-              import subprocess, tempfile
-              sys.path.insert(0, os.path.join(ROOT, "vido-slam_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
-              import build as vbuild
-              from test_facade_gpu import write_clip
-              nfr = 16
-              scene = synth.Scene3D(n_frames=nfr, seed=3, objects=((-2.0, 0.2, 9.0, 0.25, 0.0, 0.05),))
-              with tempfile.TemporaryDirectory() as tmp:
-                  cfg = write_clip(tmp, scene, nfr)
-                  r = subprocess.run([vbuild.build_driver(), cfg, os.path.join(tmp, "poses.txt"), os.path.join(tmp, "res_")], capture_output=True, text=True, timeout=300)
-              line = [l for l in r.stdout.splitlines() if l.startswith("track_ms")]
-              if r.returncode == 0 and line:
-                  v = line[0].split()
-                  extra["tracking_end_to_end_640x480"] = {"ms_per_frame_mean": round(float(v[2]), 3), "ms_per_frame_median": round(float(v[4]), 3),
-                                                          "frames_per_s": round(1e3 / float(v[2]), 1), "frames": nfr,
-                                                          "note": "VIDO_SLAM::System::TrackRGBD per call, single stream, network outputs (flow/depth/mask) given"}
           out["extra"] = extra
       except Exception as e:     # side measurements must never take the headline line down
         import traceback
+        out["extra"] = extra
         out["extra_error"] = "%s: %s" % (type(e).__name__, e)
         traceback.print_exc(file=sys.stderr)
+    else:
+        out["extra"] = extra
 
-    if rank == 0 and world == 1 and args.cpu_frames > 0:
-        from oracle import pyoracle as O
-        p = O.orb_params(n_features=ctx.cfg.n_features, scale_factor=ctx.cfg.scale_factor, n_levels=ctx.cfg.n_levels,
-                         ini_th=ctx.cfg.ini_th_fast, min_th=ctx.cfg.min_th_fast)
-        t1 = time.perf_counter()
-        for i in range(args.cpu_frames):
-            g = gray_h[i % B]
-            k, _, _ = O.orb_extract(p, g)
-            dpt = O.depth_prescale(depth_h[i % B], 0, 1.0, tp.bf, 1.0)
-            O.static_candidates(k, dpt, flow_h[i % B], mask_h[i % B], tp.th_depth_bg)
-            O.dense_object_samples(dpt, flow_h[i % B], mask_h[i % B], tp.th_depth_obj)
-        cdt = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": round(args.cpu_frames / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-                               "sample": "%d of the same 640x480 frames through the CPU oracle (oracle/orb_oracle.c + track_oracle.c: scalar C "
-                                         "restatement of ORBextractor::operator() with descriptors + Frame ctor lists), %.1f s" % (args.cpu_frames, cdt)}
+    # =============================================================================================================================
+    # CPU baseline of the same chain (rank 0, N = 1): networks on torch-CPU (the reference's Python modules are torch too) with the oracle's
+    # correlation / ROI-Align / NMS / box decode, then the C oracle for ORB + lists + pose optimisers + local BA of one frame
+    if rank == 0 and world == 1 and args.cpu_baseline > 0:
+        try:
+            from oracle import pyoracle as O
+            nthreads = torch.get_num_threads()
+            cops = O.OracleNetOps(O)
+            corr = lambda a, b, s_: torch.from_numpy(O.correlation(a.numpy(), b.numpy(), s_))
+            lfn = V.nets.fill_deterministic(V.nets.LiteFlowNet(corr), 1).eval()
+            md = V.nets.fill_deterministic(V.nets.MonoDepth2(), 2).eval()
+            mr = V.nets.fill_maskrcnn(V.nets.MaskRCNN(cops), 3).eval()
+            P = V.problems
+            op = O.orb_params(n_features=2000, scale_factor=1.2, n_levels=8, ini_th=20, min_th=7)
+            n_cam_pts = int(counts["static_inliers"]) or 1500
+            sc = P.synth_pose_scene(n_cam_pts, seed=2)
+            cam_pr = P.pose_problem_flow2cam(sc["uv_last"], sc["flow"], sc["depth"], sc["Twl"], sc["K"], sc["T_init"])
+            obj_pr = []
+            for k in range(5):
+                so = P.synth_pose_scene(400, seed=30 + k)
+                obj_pr.append(P.pose_problem_flow2(so["uv_last"], so["flow"], so["depth"], so["Twl"], so["K"], so["T_init"]))
+            ba_pr = P.synth_ba_problem(n_cam=20, n_pt=2000, kind="local", seed=7)
+            parts = {}
+            t_cpu = time.perf_counter()
+            for i in range(args.cpu_baseline):
+                bgr, d, f, m = frames[-1 - i]; prev = frames[-2 - i][0]
+                t1 = time.perf_counter()
+                V.nets.analyse_flow(lfn, prev, bgr); parts["liteflownet_s"] = parts.get("liteflownet_s", 0) + time.perf_counter() - t1; t1 = time.perf_counter()
+                V.nets.analyse_depth(md, bgr); parts["monodepth2_s"] = parts.get("monodepth2_s", 0) + time.perf_counter() - t1; t1 = time.perf_counter()
+                V.nets.analyse_image(mr, bgr); parts["maskrcnn_s"] = parts.get("maskrcnn_s", 0) + time.perf_counter() - t1; t1 = time.perf_counter()
+                g = O.bgr2gray(bgr)
+                kps, _, _ = O.orb_extract(op, g)
+                dpt = O.depth_prescale(d.copy(), 0, 1.0, 387.57, 1.0)
+                O.static_candidates(kps, dpt, f, m, 40.0); O.dense_object_samples(dpt, f, m, 25.0)
+                parts["orb_lists_s"] = parts.get("orb_lists_s", 0) + time.perf_counter() - t1; t1 = time.perf_counter()
+                O.pose_optimize(cam_pr)
+                for pr_ in obj_pr:
+                    O.pose_optimize(pr_)
+                parts["pose_optimisers_s"] = parts.get("pose_optimisers_s", 0) + time.perf_counter() - t1; t1 = time.perf_counter()
+                O.ba_optimize(dict(ba_pr))
+                parts["local_ba_s"] = parts.get("local_ba_s", 0) + time.perf_counter() - t1
+            t_cpu = time.perf_counter() - t_cpu
+            out["cpu_baseline"] = {"value": round(args.cpu_baseline / t_cpu, 4), "unit": "frames/s", "cores": nthreads, "kind": "port",
+                                   "sample": "%d frame(s) of the same chain, %.1f s: the three networks on torch-CPU fp32 (%d threads; correlation / ROI-Align / NMS / box decode = "
+                                             "oracle C), then the scalar C oracle (1 thread) for cvtColor + ORB + frame lists, Flow2Cam on %d points, Flow2 on 5 x 400 object points, "
+                                             "local BA 20 KF x 2k landmarks; serial, not pipelined (the reference library is single-threaded)" % (args.cpu_baseline, t_cpu, nthreads, n_cam_pts),
+                                   "parts_s": {k: round(v / args.cpu_baseline, 3) for k, v in parts.items()}}
+        except Exception as e:
+            import traceback
+            out["cpu_baseline_error"] = "%s: %s" % (type(e).__name__, e); traceback.print_exc(file=sys.stderr)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

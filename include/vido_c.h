@@ -72,6 +72,16 @@ int vido_orb_extract_batch(vido_ctx* ctx, const uint8_t* imgs, int on_device, in
                            size_t frame_stride, int stride, int width, int height,
                            vido_keypoint* kp_out, int max_kp, int* n_out, uint8_t* desc_out);
 
+/* cvtColor(BGR|RGB|BGRA|RGBA -> GRAY) + ORBextractor::operator() in one stream of launches: what Tracking::GrabImageRGBD does with the
+ * caller's colour image before the Frame is built (Tracking.cc:327-340: cvtColor(mImGray, mImGray, CV_RGB2GRAY / CV_BGR2GRAY / ...A2GRAY),
+ * then Frame.cc:62 ExtractORB).  img: n_frames interleaved u8 images, `channels` (3 or 4) bytes per pixel, rows `stride` bytes apart;
+ * rgb_order != 0: the first channel is red (Camera.RGB: 1).  gray_out (may be NULL): tight width*height bytes per frame, in the same memory
+ * space as img (host pointer when on_device == 0, device pointer otherwise) — the mImGray the reference keeps.  Other arguments as
+ * vido_orb_extract_batch.  The converted image is written straight into level 0 of the pyramid (no host pass over the pixels). */
+int vido_orb_extract_color(vido_ctx* ctx, const uint8_t* img, int channels, int rgb_order, int on_device, int n_frames,
+                           size_t frame_stride, int stride, int width, int height, uint8_t* gray_out,
+                           vido_keypoint* kp_out, int max_kp, int* n_out, uint8_t* desc_out);
+
 /* Diagnostics for the parity tests: copy pyramid level `level` (tight lw*lh bytes) of frame `frame` of the
  * last extract call back to the host; blurred!=0 selects the 7x7-blurred copy. */
 int vido_orb_level_size(const vido_ctx* ctx, int level, int* lw, int* lh);
@@ -243,6 +253,10 @@ int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int
 /* Conv epilogue on a DEVICE tensor x[N,C,H,W] (f32, contiguous), in place: x = leaky_relu(x + bias[c], slope) — the bias add and the
  * LeakyReLU(0.1) that follow every convolution of flow_net/src/layers.py fused into one pass (slope = 1: plain bias add). */
 int vido_bias_act(vido_ctx* ctx, float* x, const float* bias, int N, int C, int H, int W, float slope);
+/* x = act(x + bias[c] + res), res a DEVICE tensor shaped like x (NULL: vido_bias_act): closes a ResNe(X)t bottleneck whose FrozenBatchNorm2d
+ * (maskrcnn_benchmark/layers/batch_norm.py:19-31) has been folded into the convolution weights and this bias
+ * (modeling/backbone/resnet.py:352-372: out = bn3(conv3(.)); out += identity; relu). */
+int vido_bias_res_act(vido_ctx* ctx, float* x, const float* bias, const float* res, int N, int C, int H, int W, float slope);
 /* layers.ROIAlign forward — mask_rcnn/maskrcnn_benchmark/csrc/cuda/ROIAlign_cuda.cu:257-299.  rois [n,5] =
  * (batch index, x1, y1, x2, y2); out [n, C, pooled_h, pooled_w]. */
 int vido_roi_align(vido_ctx* ctx, const float* feat, int B, int C, int H, int W, const float* rois, int n_rois,
@@ -267,6 +281,33 @@ int vido_box_decode(vido_ctx* ctx, const float* deltas, const float* boxes, int 
 int vido_pnp_ransac(vido_ctx* ctx, const float* pts3d, const float* pts2d, int n, double fx, double fy, double cx, double cy,
                     int max_iters, double reproj_err, double confidence, uint64_t seed, double T_out[16], uint8_t* inlier_mask,
                     int32_t* n_inliers);
+
+/* ---- The whole per-frame pipeline behind one C handle ---------------------------------------------------------------------------
+ * VIDO_SLAM::System (System.h:72-114) for hosts that bind C instead of C++ (ctypes / cgo / JNI): System::System() + Init(yaml, RGBD)
+ * (System.cc:23-48), TrackRGBD (System.cc:51-63 -> Tracking::GrabImageRGBD, Tracking.cc:283-782 -> Track(), :1081-1509) and
+ * SaveResultsIJRR2020 (System.cc:80-240).  Errors that the C++ facade throws come back as VIDO_E_* + vido_system_last_error.
+ * One live system per process, like the reference (Frame's statics, Frame.cc:26-30). */
+typedef struct vido_system vido_system;
+typedef struct vido_system_stats {          /* of the last vido_system_track_rgbd call */
+    int32_t frame_id, n_keypoints, n_static, n_static_inliers, n_objects, n_object_points, ba_window, pad;
+    float ms_total;                          /* TrackRGBD wall time */
+    float ms_update_mask, ms_frame;          /* Tracking::UpdateMask; Frame::Frame (cvtColor + ORB + lists) + hand-over gathers */
+    float ms_cam_pose, ms_obj_tracking, ms_obj_motion, ms_renew;   /* the reference's all_timing[1..4] (Tracking.cc:1120-1324); obj_motion = sum over objects */
+    float ms_local_ba;                       /* Map::fLBA_time (Tracking.cc:1436-1451) */
+} vido_system_stats;
+int         vido_system_create(const char* settings_yaml, vido_system** out);
+void        vido_system_destroy(vido_system* sys);
+const char* vido_system_last_error(const vido_system* sys);      /* NULL sys: error of the last failed vido_system_create */
+/* im: u8 interleaved, `channels` 1 (gray), 3 or 4 (BGR[A], or RGB[A] when the settings say Camera.RGB: 1), tight rows; depth f32 (raw sensor
+ * units; REWRITTEN IN PLACE with the pre-scaled depth like the reference does to the caller's Mat, Tracking.cc:299-322); flow f32 x2; mask i32;
+ * all width*height, host memory, alive until the NEXT call returns (the reference keeps shallow references, Tracking.cc:343-345, 777-780).
+ * n_image: StopFrame = n_image - 1.  Tcw_out: row-major 4x4 world->camera pose of this frame (identity for the first). */
+int         vido_system_track_rgbd(vido_system* sys, const uint8_t* im, int channels, int width, int height, float* depth, const float* flow,
+                                   const int32_t* mask, double timestamp, int n_image, float Tcw_out[16]);
+int         vido_system_get_stats(const vido_system* sys, vido_system_stats* out);
+int         vido_system_save_results(vido_system* sys, const char* prefix);
+/* the vido_ctx the system's tracker runs on (NULL before the first frame): lets a caller share the device / query timings */
+vido_ctx*   vido_system_context(vido_system* sys);
 
 #ifdef __cplusplus
 }

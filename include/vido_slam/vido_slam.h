@@ -43,10 +43,15 @@ public:
     float GetScaleFactor() const { return scaleFactor; }
     std::vector<float> GetScaleFactors() const { return mvScaleFactor; }
     vido_ctx* context(int width, int height);          /* lazily created for the first image size seen */
+    /* Tracking::GrabImageRGBD's cvtColor (Tracking.cc:327-340) fused into the extractor: the next operator() call whose `image` is `gray`
+       converts `color` (CV_8UC3 / CV_8UC4) on the device straight into pyramid level 0 and fills `gray` with the result, instead of
+       converting on the host and uploading the gray image. */
+    void SetColorSource(const cv::Mat& color, bool rgb_order, const cv::Mat& gray) { color_ = &color; rgb_ = rgb_order; gray_ = gray.data; }
     int nfeatures; float scaleFactor; int nlevels, iniThFAST, minThFAST;
 private:
     std::vector<float> mvScaleFactor;
     vido_ctx* ctx_ = nullptr; int w_ = 0, h_ = 0;
+    const cv::Mat* color_ = nullptr; bool rgb_ = false; const unsigned char* gray_ = nullptr;
 };
 
 class Frame {
@@ -151,6 +156,7 @@ public:
     std::vector<int> TemperalMatch, TemperalMatch_subset;
     std::vector<cv::KeyPoint> mvTmpObjKeys, mvTmpObjCorres; std::vector<float> mvTmpObjDepth; std::vector<int> mvTmpSemObjLabel; std::vector<cv::Point2f> mvTmpObjFlowNext;
     std::vector<float> all_timing;
+    float ms_total = 0, ms_update_mask = 0, ms_frame = 0, ms_obj_motion_sum = 0;     /* wall-clock stage times of the last GrabImageRGBD */
     unsigned ransac_seed;             /* solvePnPRansac uses OpenCV's global RNG; seeded explicitly here */
     ORBextractor* mpORBextractorLeft = nullptr;
 protected:

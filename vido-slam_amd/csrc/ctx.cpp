@@ -60,8 +60,12 @@ int vido_create(const vido_config* cfg, vido_ctx** out)
         int rc = vido_set_error(nullptr, VIDO_E_NO_DEVICE, "vido_create: device %d is %s; kernels are built for gfx950 only", ctx->device, prop.gcnArchName);
         delete ctx; return rc;
     }
-    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess) {
+    // highest stream priority: the tracker's kernels are short and latency-bound; when the network nodes share the GPU (pipeline.py: the networks of
+    // frame k+1 overlap the tracking of frame k) their long convolution kernels must not queue in front of them
+    int prio_least = 0, prio_greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_greatest = 0;
+    if ((e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess ||
+        (e = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_greatest)) != hipSuccess) {
         int rc = vido_set_error(nullptr, VIDO_E_HIP, "vido_create: hipStreamCreate: %s", hipGetErrorString(e));
         delete ctx; return rc;
     }

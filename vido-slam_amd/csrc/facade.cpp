@@ -91,7 +91,12 @@ void ORBextractor::operator()(const cv::Mat& image, const cv::Mat&, std::vector<
     vido_ctx* c = context(image.cols, image.rows);
     const int cap = 2 * nfeatures + 256; int n = 0;
     std::vector<vido_keypoint> k(cap); cv::Mat desc(cap, 32, CV_8U);
-    if (vido_orb_extract(c, image.data, (int)image.step, image.cols, image.rows, k.data(), cap, &n, desc.data) != VIDO_OK) throw std::runtime_error(vido_last_error(c));
+    int rc;
+    if (color_ && gray_ == image.data && color_->cols == image.cols && color_->rows == image.rows && image.isContinuous())      // cvtColor on the device (SetColorSource)
+        rc = vido_orb_extract_color(c, color_->data, color_->channels(), rgb_ ? 1 : 0, 0, 1, 0, (int)color_->step, image.cols, image.rows, image.data, k.data(), cap, &n, desc.data);
+    else rc = vido_orb_extract(c, image.data, (int)image.step, image.cols, image.rows, k.data(), cap, &n, desc.data);
+    color_ = nullptr; gray_ = nullptr;
+    if (rc != VIDO_OK) throw std::runtime_error(vido_last_error(c));
     keypoints.resize(n);
     for (int i = 0; i < n; i++) keypoints[i] = cv::KeyPoint(k[i].x, k[i].y, k[i].size, k[i].angle, k[i].response, k[i].octave);
     descriptors = cv::Mat(n, 32, CV_8U);
@@ -530,18 +535,12 @@ Tracking::Tracking(System* pSys, Map* pMap, const std::string& path, const int s
 }
 Tracking::~Tracking() { delete mpORBextractorLeft; }
 
-static cv::Mat to_gray(const cv::Mat& im, bool rgb)           // cvtColor BGR/RGB(A)2GRAY, Tracking.cc:327-340
-{
-    if (im.channels() == 1) return im;
-    cv::Mat g(im.rows, im.cols, CV_8UC1); const int cn = im.channels();
-    for (int y = 0; y < im.rows; y++) { const uint8_t* s = im.ptr<uint8_t>(y); uint8_t* d = g.ptr<uint8_t>(y);
-        for (int x = 0; x < im.cols; x++, s += cn) { const int b = rgb ? s[2] : s[0], gg = s[1], r = rgb ? s[0] : s[2]; d[x] = (uint8_t)((b * 1868 + gg * 9617 + r * 4899 + 8192) >> 14); } }
-    return g;
-}
 
 cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Mat& imFlow, const cv::Mat& maskSEM, const cv::Mat&,
                                 const std::vector<std::vector<float> >&, const double& timestamp, cv::Mat&, const int& nImage)
 {
+    const auto t_grab = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     StopFrame = nImage - 1;
     if (mState == NO_IMAGES_YET) f_id = 0;
     if (imD.type() != CV_32FC1 || imFlow.type() != CV_32FC2 || maskSEM.type() != CV_32SC1 || !imD.isContinuous() || !imFlow.isContinuous() || !maskSEM.isContinuous())
@@ -554,10 +553,17 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
     const int slot_last = slot_cur_; slot_cur_ = (mState == NO_IMAGES_YET) ? 0 : 1 - slot_cur_; g_slot = slot_cur_;
     // depth pre-scale in place on the caller's buffer (:299-322) + maps resident in the slot
     check(vido_frame_upload(c, slot_cur_, 1, imD.ptr<float>(), imFlow.ptr<float>(), maskSEM.ptr<int32_t>(), 0, &g_tp), "frame_upload");
-    mImGray = to_gray(imRGB, mbRGB);
+    if (imRGB.channels() == 1) mImGray = imRGB;
+    else {                                                     // :327-340 cvtColor: done on the device by the extractor's ingest, which fills mImGray
+        if (imRGB.type() != CV_8UC3 && imRGB.type() != CV_8UC4) throw std::runtime_error("GrabImageRGBD: image must be CV_8UC1 / CV_8UC3 / CV_8UC4");
+        mImGray = cv::Mat(imRGB.rows, imRGB.cols, CV_8UC1);
+        mpORBextractorLeft->SetColorSource(imRGB, mbRGB, mImGray);
+    }
     mDepthMap = imD; mFlowMap = imFlow; mSegMap = maskSEM.clone();
     all_timing.assign(5, 0.f);
+    auto t_st = std::chrono::steady_clock::now();
     if (mState != NO_IMAGES_YET) UpdateMask();
+    ms_update_mask = ms_since(t_st); t_st = std::chrono::steady_clock::now();
     (void)slot_last;
     mpCurrentFrame = new Frame(mImGray, imD, imFlow, mSegMap, timestamp, mpORBextractorLeft, mK, mDistCoef, mbf, mThDepth, mThDepthObj, nUseSampleFea);
     if (mState != NO_IMAGES_YET) {                             // :369-421
@@ -576,9 +582,11 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
         TemperalMatch.assign(F->N_s, -1);
     }
     mpCurrentFrame->vObjLabel.assign(mpCurrentFrame->mvObjKeys.size(), -2);
+    ms_frame = ms_since(t_st);
     Track();
     f_id = f_id + 1;
     mImGrayLast = mImGray; mSegMapLast = mSegMap; mFlowMapLast = mFlowMap;      // :777-780
+    ms_total = ms_since(t_grab);
     return mpCurrentFrame->mTcw.clone();
 }
 
@@ -909,7 +917,8 @@ void Tracking::Track()                                        // Tracking.cc:108
             for (int r = 0; r < 3; r++) { float s = Hm.at<float>(r, 3); for (int c2 = 0; c2 < 3; c2++) s -= ((r == c2 ? 1.f : 0.f) - Hm.at<float>(r, c2)) * centre.at<float>(c2); v[r] = s; }
             C->vSpeed[i].x = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * 36 * 36;
         }
-        all_timing[3] = no ? std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() / no : 0.f;
+        ms_obj_motion_sum = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        all_timing[3] = no ? ms_obj_motion_sum / no : 0.f;
         t0 = std::chrono::steady_clock::now();
         RenewFrameInfo(TemperalMatch_subset);
         all_timing[4] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -985,3 +994,75 @@ void System::SaveResultsIJRR2020(const std::string& prefix)   // System.cc:80-24
 }
 
 }  // namespace VIDO_SLAM
+
+// ---- C handle over System (include/vido_c.h "The whole per-frame pipeline behind one C handle") -----------------------------------------
+struct vido_system {
+    VIDO_SLAM::System sys; std::string err; bool inited = false;
+    cv::Mat im, depth, flow, mask, traj;                      // headers over the caller's buffers of the current call (kept: the tracker holds shallow references)
+};
+static std::string g_sys_create_error;
+
+extern "C" {
+
+int vido_system_create(const char* yaml, vido_system** out)
+{
+    if (!yaml || !out) { g_sys_create_error = "vido_system_create: null argument"; return VIDO_E_INVALID; }
+    *out = nullptr;
+    vido_system* s = new vido_system();
+    try { s->sys.Init(yaml, VIDO_SLAM::System::RGBD); s->inited = true; }
+    catch (const std::exception& e) { g_sys_create_error = e.what(); delete s; return VIDO_E_INVALID; }
+    *out = s;
+    return VIDO_OK;
+}
+void vido_system_destroy(vido_system* s) { delete s; }
+const char* vido_system_last_error(const vido_system* s) { return s ? s->err.c_str() : g_sys_create_error.c_str(); }
+
+int vido_system_track_rgbd(vido_system* s, const uint8_t* im, int channels, int width, int height, float* depth, const float* flow, const int32_t* mask,
+                           double timestamp, int n_image, float Tcw_out[16])
+{
+    if (!s || !s->inited) return VIDO_E_INVALID;
+    if (!im || !depth || !flow || !mask || !Tcw_out || width <= 0 || height <= 0 || (channels != 1 && channels != 3 && channels != 4)) { s->err = "vido_system_track_rgbd: bad argument"; return VIDO_E_INVALID; }
+    try {
+        s->im = cv::Mat(height, width, CV_MAKETYPE(CV_8U, channels), (void*)im);
+        s->depth = cv::Mat(height, width, CV_32FC1, (void*)depth);
+        s->flow = cv::Mat(height, width, CV_32FC2, (void*)flow);
+        s->mask = cv::Mat(height, width, CV_32SC1, (void*)mask);
+        if (s->traj.empty()) s->traj = cv::Mat::zeros(600, 800, CV_8UC3);
+        const cv::Mat id = cv::Mat::eye(4, 4, CV_32F); const std::vector<std::vector<float> > gt;
+        cv::Mat T = s->sys.TrackRGBD(s->im, s->depth, s->flow, s->mask, id, gt, timestamp, s->traj, n_image);
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) Tcw_out[r * 4 + c] = T.at<float>(r, c);
+    } catch (const std::exception& e) {
+        s->err = e.what();
+        return s->err.find("exceed") != std::string::npos || s->err.find("capacity") != std::string::npos ? VIDO_E_CAPACITY : VIDO_E_HIP;
+    }
+    return VIDO_OK;
+}
+
+int vido_system_get_stats(const vido_system* s, vido_system_stats* o)
+{
+    if (!s || !o || !s->inited) return VIDO_E_INVALID;
+    memset(o, 0, sizeof *o);
+    VIDO_SLAM::Tracking* T = const_cast<vido_system*>(s)->sys.GetTracker(); VIDO_SLAM::Map* M = const_cast<vido_system*>(s)->sys.GetMap();
+    if (!T || !T->mpCurrentFrame) return VIDO_OK;
+    const VIDO_SLAM::Frame* F = T->mpCurrentFrame;
+    o->frame_id = T->f_id - 1; o->n_keypoints = F->N; o->n_static = (int)F->mvStatKeysTmp.size(); o->n_static_inliers = 0;
+    for (int id : F->nStaInlierID) if (id >= 0) o->n_static_inliers++;
+    int no = 0; for (size_t i = 0; i < F->bObjStat.size(); i++) if (F->bObjStat[i]) no++;
+    o->n_objects = no; o->n_object_points = (int)F->mvObjKeys.size(); o->ba_window = std::min(std::max(T->f_id - 1, 0), T->nWINDOW_SIZE);
+    o->ms_total = T->ms_total; o->ms_update_mask = T->ms_update_mask; o->ms_frame = T->ms_frame;
+    if (T->all_timing.size() >= 5) { o->ms_cam_pose = T->all_timing[1]; o->ms_obj_tracking = T->all_timing[2]; o->ms_renew = T->all_timing[4]; }
+    o->ms_obj_motion = T->ms_obj_motion_sum;
+    o->ms_local_ba = M && !M->fLBA_time.empty() && T->f_id > 1 ? M->fLBA_time.back() : 0.f;
+    return VIDO_OK;
+}
+
+int vido_system_save_results(vido_system* s, const char* prefix)
+{
+    if (!s || !s->inited) return VIDO_E_INVALID;
+    try { s->sys.SaveResultsIJRR2020(prefix ? prefix : ""); } catch (const std::exception& e) { s->err = e.what(); return VIDO_E_INVALID; }
+    return VIDO_OK;
+}
+
+vido_ctx* vido_system_context(vido_system* s) { return s && s->inited ? VIDO_SLAM::detail::Context() : nullptr; }
+
+}  // extern "C"

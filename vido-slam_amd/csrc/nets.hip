@@ -86,6 +86,23 @@ __global__ __launch_bounds__(256) void k_bias_act(float* __restrict__ x, const f
     }
 }
 
+// x = act(x + bias[c] + res): the FrozenBatchNorm shift (folded into a bias), the shortcut add and the ReLU that close a bottleneck
+// (maskrcnn_benchmark/modeling/backbone/resnet.py:352-372), one pass over the tensor instead of four
+__global__ __launch_bounds__(256) void k_bias_res_act(float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ res, int C, size_t hw, size_t total, float slope)
+{
+    const size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4;
+    if (i >= total) return;
+    if ((hw & 3) == 0) {
+        const float b = bias[(i / hw) % C];
+        float4 v = *(float4*)(x + i); const float4 r = *(const float4*)(res + i);
+        v.x += b + r.x; v.y += b + r.y; v.z += b + r.z; v.w += b + r.w;
+        v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope; v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+        *(float4*)(x + i) = v;
+    } else {
+        for (size_t k = i; k < min(i + 4, total); k++) { float v = x[k] + bias[(k / hw) % C] + res[k]; x[k] = v > 0.f ? v : v * slope; }
+    }
+}
+
 // ---- ROI-Align ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bilinear(const float* __restrict__ d, int h, int w, float y, float x)
 {
@@ -265,6 +282,19 @@ int vido_bias_act(vido_ctx* ctx, float* x, const float* bias, int N, int C, int 
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
     const size_t hw = (size_t)H * W, total = (size_t)N * C * hw;
     hipLaunchKernelGGL(k_bias_act, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, st, x, bias, C, hw, total, slope);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+int vido_bias_res_act(vido_ctx* ctx, float* x, const float* bias, const float* res, int N, int C, int H, int W, float slope)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!res) return vido_bias_act(ctx, x, bias, N, C, H, W, slope);
+    if (!x || !bias || N < 1 || C < 1 || H < 1 || W < 1) return vido_set_error(ctx, VIDO_E_INVALID, "bias_res_act: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    const size_t hw = (size_t)H * W, total = (size_t)N * C * hw;
+    hipLaunchKernelGGL(k_bias_res_act, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, st, x, bias, res, C, hw, total, slope);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }

@@ -78,6 +78,41 @@ __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ imgs
     *(uint32_t*)(pyr + (size_t)blockIdx.z * slab + off + (size_t)y * pitch + x4) = v;
 }
 
+// K0c: cvtColor(BGR/RGB[A] -> GRAY) fused into the ingest (Tracking.cc:327-340 hands ORBextractor::operator() the converted image): interleaved u8
+// pixels in, level 0 of the pyramid out — OpenCV's 14-bit fixed point Y = (B*1868 + G*9617 + R*4899 + 8192) >> 14.  One thread
+// converts 4 adjacent pixels: 3 (or 4) aligned dword loads when the row allows, one dword store; optional tight gray copy for the caller.
+template <int CN>
+__global__ __launch_bounds__(256) void k_ingest_color(const uint8_t* __restrict__ imgs, size_t frame_stride, int stride, int width, int height, int rgb,
+                                                      uint8_t* __restrict__ pyr, size_t slab, int off, int pitch, uint8_t* __restrict__ gray_out)
+{
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= height || x4 >= pitch) return;
+    const uint8_t* s = imgs + (size_t)blockIdx.z * frame_stride + (size_t)y * stride + (size_t)x4 * CN;
+    uint8_t px[4 * CN];
+    if (x4 + 3 < width && (((uintptr_t)s) & 3) == 0) {
+        const uint32_t* q = (const uint32_t*)s;
+#pragma unroll
+        for (int k = 0; k < CN; k++) { const uint32_t v = q[k]; px[4 * k] = (uint8_t)v; px[4 * k + 1] = (uint8_t)(v >> 8); px[4 * k + 2] = (uint8_t)(v >> 16); px[4 * k + 3] = (uint8_t)(v >> 24); }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4 * CN; k++) px[k] = (x4 + k / CN < width) ? s[k] : 0;
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int c0 = px[k * CN], c1 = px[k * CN + 1], c2 = px[k * CN + 2];
+        const int b = rgb ? c2 : c0, r = rgb ? c0 : c2;
+        const uint32_t g = (uint32_t)(b * 1868 + c1 * 9617 + r * 4899 + 8192) >> 14;
+        if (x4 + k < width) out |= g << (8 * k);
+    }
+    *(uint32_t*)(pyr + (size_t)blockIdx.z * slab + off + (size_t)y * pitch + x4) = out;
+    if (gray_out) {
+        uint8_t* g = gray_out + ((size_t)blockIdx.z * height + y) * width + x4;
+        if (x4 + 3 < width && (width & 3) == 0) *(uint32_t*)g = out;
+        else for (int k = 0; k < 4; k++) if (x4 + k < width) g[k] = (uint8_t)(out >> (8 * k));
+    }
+}
+
 #define RS_TW 128
 #define RS_TH 8
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_t slab, int sw, int sh, int spitch, int soff,
@@ -786,6 +821,8 @@ struct OrbState {
     // final results, [frame][row_cap] rows: device + pinned host mirror (the "result view")
     int row_cap = 0; vido_keypoint *d_kpf = nullptr, *h_kpf = nullptr; uint8_t *d_descf = nullptr, *h_descf = nullptr; int *d_nkp = nullptr;
     KpLevels kpl{};
+    // cvtColor fused ingest: staging for host colour frames / the gray copy handed back
+    uint8_t *d_color = nullptr, *d_gray_out = nullptr; size_t color_cap = 0; int in_channels = 1, in_rgb = 0; uint8_t* gray_out = nullptr; int gray_out_on_device = 0;
 };
 
 static inline int cv_round_f(float v) { return (int)lrintf(v); }
@@ -986,6 +1023,7 @@ void orb_state_destroy(vido_ctx* ctx)
     if (S->ev_half) hipEventDestroy(S->ev_half);
     hipFree(S->d_qt_slot); hipFree(S->d_sel); hipFree(S->d_selcnt); hipFree(S->d_kpoff); hipFree(S->d_frame_beg); hipFree(S->d_budget); hipFree(S->d_kpf); hipFree(S->d_descf); hipFree(S->d_nkp);
     hipHostFree(S->h_frame_beg); hipHostFree(S->h_kpf); hipHostFree(S->h_descf);
+    hipFree(S->d_color); hipFree(S->d_gray_out);
     delete S; ctx->orb = nullptr;
 }
 
@@ -1005,7 +1043,29 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     S->t_start = std::chrono::steady_clock::now();
     HIP_TRY(ctx, hipEventRecord(S->ev[0], st));
     // level 0 <- input
-    if (on_device)
+    if (S->in_channels != 1) {                          // colour frames: cvtColor fused into the ingest (set by vido_orb_extract_color for this one call)
+        const int cn = S->in_channels; const uint8_t* src = imgs; size_t fs = frame_stride; int sst = stride;
+        if (stride < width * cn) return vido_set_error(ctx, VIDO_E_INVALID, "orb: stride < width * channels");
+        if (!on_device) {
+            const size_t need = (size_t)S->B * S->W * S->H * 4;
+            if (!S->d_color) { HIP_TRY(ctx, hipMalloc(&S->d_color, need)); S->color_cap = need; }
+            sst = width * cn; fs = (size_t)sst * height;
+            for (int f = 0; f < nf; f++)
+                HIP_TRY(ctx, hipMemcpy2DAsync(S->d_color + (size_t)f * fs, sst, imgs + (size_t)f * frame_stride, stride, (size_t)width * cn, height, hipMemcpyHostToDevice, st));
+            src = S->d_color;
+        }
+        uint8_t* gdev = nullptr;
+        if (S->gray_out) {
+            if (S->gray_out_on_device) gdev = S->gray_out;
+            else { if (!S->d_gray_out) HIP_TRY(ctx, hipMalloc(&S->d_gray_out, (size_t)S->B * S->W * S->H)); gdev = S->d_gray_out; }
+        }
+        const dim3 grid((S->lv[0].pitch / 4 + 63) / 64, (height + 3) / 4, nf);
+        if (cn == 3) hipLaunchKernelGGL(k_ingest_color<3>, grid, dim3(256), 0, st, src, fs, sst, width, height, S->in_rgb, S->d_pyr, S->slab, S->lv[0].off, S->lv[0].pitch, gdev);
+        else         hipLaunchKernelGGL(k_ingest_color<4>, grid, dim3(256), 0, st, src, fs, sst, width, height, S->in_rgb, S->d_pyr, S->slab, S->lv[0].off, S->lv[0].pitch, gdev);
+        if (S->gray_out && !S->gray_out_on_device)
+            HIP_TRY(ctx, hipMemcpyAsync(S->gray_out, gdev, (size_t)nf * width * height, hipMemcpyDeviceToHost, st));
+    }
+    else if (on_device)
         hipLaunchKernelGGL(k_ingest, dim3((S->lv[0].pitch / 4 + 63) / 64, (height + 3) / 4, nf), dim3(256), 0, st, imgs, frame_stride, stride, width, height,
                            S->d_pyr, S->slab, S->lv[0].off, S->lv[0].pitch);
     else for (int f = 0; f < nf; f++)
@@ -1172,6 +1232,18 @@ int vido_orb_extract_batch(vido_ctx* ctx, const uint8_t* imgs, int on_device, in
 {
     if (!ctx) return VIDO_E_INVALID;
     return orb_run(ctx, imgs, on_device, n_frames, frame_stride, stride, width, height, kp_out, max_kp, n_out, desc_out);
+}
+
+int vido_orb_extract_color(vido_ctx* ctx, const uint8_t* img, int channels, int rgb_order, int on_device, int n_frames, size_t frame_stride, int stride,
+                           int width, int height, uint8_t* gray_out, vido_keypoint* kp_out, int max_kp, int* n_out, uint8_t* desc_out)
+{
+    if (!ctx || !ctx->orb) return VIDO_E_INVALID;
+    if (channels != 3 && channels != 4) return vido_set_error(ctx, VIDO_E_INVALID, "orb_extract_color: channels must be 3 or 4 (got %d)", channels);
+    OrbState* S = ctx->orb;
+    S->in_channels = channels; S->in_rgb = rgb_order != 0; S->gray_out = gray_out; S->gray_out_on_device = on_device;
+    const int rc = orb_run(ctx, img, on_device, n_frames, frame_stride, stride, width, height, kp_out, max_kp, n_out, desc_out);
+    S->in_channels = 1; S->in_rgb = 0; S->gray_out = nullptr;
+    return rc;
 }
 
 int vido_orb_level_size(const vido_ctx* ctx, int level, int* lw, int* lh)

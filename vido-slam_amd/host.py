@@ -54,6 +54,8 @@ def load_library():
     lib.vido_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.vido_orb_extract_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.vido_orb_extract_color.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.vido_orb_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.vido_orb_read_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.vido_orb_read_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -128,6 +130,16 @@ class Context:
         kps = np.zeros(self.max_kp, KP_DTYPE); desc = np.zeros((self.max_kp, 32), np.uint8); n = C.c_int()
         self._check(self.lib.vido_orb_extract(self.h, _ptr(gray), w, w, h, _ptr(kps), self.max_kp, C.byref(n), _ptr(desc)))
         return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def orb_extract_color(self, img, rgb_order=False):
+        """cvtColor + ORBextractor::operator() (vido_orb_extract_color): img (h,w,3|4) u8 -> (gray (h,w) u8, keypoints, descriptors)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w, cn = img.shape
+        gray = np.empty((h, w), np.uint8)
+        kps = np.zeros(self.max_kp, KP_DTYPE); desc = np.zeros((self.max_kp, 32), np.uint8); n = C.c_int()
+        self._check(self.lib.vido_orb_extract_color(self.h, _ptr(img), cn, int(bool(rgb_order)), 0, 1, C.c_size_t(0), w * cn, w, h, _ptr(gray),
+                                                    _ptr(kps), self.max_kp, C.byref(n), _ptr(desc)))
+        return gray, kps[:n.value].copy(), desc[:n.value].copy()
 
     def orb_extract_batch(self, imgs, want_desc=True, reuse=False):
         """imgs: (n,h,w) u8 numpy array (host) or a (device_ptr, n, h, w, frame_stride, row_stride) tuple.

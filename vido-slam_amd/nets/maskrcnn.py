@@ -71,7 +71,15 @@ class _Bottleneck(nn.Module):              # resnet.py:277-372 (BottleneckWithFi
         self.conv2 = nn.Conv2d(mid, mid, 3, s3, 1, bias=False, groups=groups); self.bn2 = FrozenBatchNorm2d(mid)
         self.conv3 = nn.Conv2d(mid, cout, 1, bias=False); self.bn3 = FrozenBatchNorm2d(cout)
 
+    _ep = None                             # nets/fuse.py::fold_batchnorm installs the folded tensors + the fused HIP epilogue
+
     def forward(self, x):
+        if self._ep is not None and x.is_cuda:
+            ep = self._ep; c1, c2 = self.conv1, self.conv2
+            y = ep(F.conv2d(x, self._w1, None, c1.stride), self._b1, None, 0.0)
+            y = ep(F.conv2d(y, self._w2, None, c2.stride, c2.padding, c2.dilation, c2.groups), self._b2, None, 0.0)
+            sc = x if self.downsample is None else ep(F.conv2d(x, self._wd, None, self.downsample[0].stride), self._bd, None, 1.0)
+            return ep(F.conv2d(y, self._w3), self._b3, sc.contiguous(), 0.0)
         y = F.relu(self.bn1(self.conv1(x)))
         y = F.relu(self.bn2(self.conv2(y)))
         y = self.bn3(self.conv3(y))
@@ -83,7 +91,11 @@ class _Stem(nn.Module):                    # resnet.py:375-395
         super().__init__()
         self.conv1 = nn.Conv2d(3, cout, 7, 2, 3, bias=False); self.bn1 = FrozenBatchNorm2d(cout)
 
+    _ep = None
+
     def forward(self, x):
+        if self._ep is not None and x.is_cuda:
+            return F.max_pool2d(self._ep(F.conv2d(x, self._w1, None, 2, 3), self._b1, None, 0.0), 3, 2, 1)
         return F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, 2, 1)
 
 
@@ -196,8 +208,11 @@ class _RPN(nn.Module):
         self.head = _RPNHead(c.fpn_out, len(c.aspect_ratios))
 
     def forward(self, feats, image_wh):     # rpn/inference.py:73-159 (test path, one image)
-        c = self.c; W, H = image_wh
         logits, deltas = self.head(feats)
+        return self.proposals(feats, logits, deltas, image_wh)
+
+    def proposals(self, feats, logits, deltas, image_wh):
+        c = self.c; W, H = image_wh
         anchors = self.anchor_generator([f.shape[-2:] for f in feats])
         boxes, scores = [], []
         for a, lo, de in zip(anchors, logits, deltas):
@@ -365,23 +380,44 @@ class MaskRCNN(nn.Module):
     @torch.no_grad()
     def forward(self, image):
         """image: [1,3,H,W] float (0..255, the reference feeds unnormalised RGB).  Returns dict(boxes, scores, labels, masks[n,1,28,28])."""
-        H, W = image.shape[-2:]
+        feats, logits, deltas = self.trunk(image)
+        return self.heads(feats, logits, deltas, image.shape[-2:])
+
+    @torch.no_grad()
+    def trunk(self, image):
+        """The static-shape part (backbone + FPN + RPN head convolutions): everything before the first data-dependent shape.  nets/fuse.py::Graphed
+        captures it into one hipGraph."""
         feats = self.backbone(image)
-        proposals, objectness = self.rpn(feats, (W, H))
+        logits, deltas = self.rpn.head(feats)
+        return feats, logits, deltas
+
+    @torch.no_grad()
+    def heads(self, feats, logits, deltas, image_hw):
+        H, W = image_hw
+        proposals, objectness = self.rpn.proposals(feats, logits, deltas, (W, H))
         boxes, scores, labels = self.roi_heads.box(feats[:len(self.config.pool_scales)], proposals, (W, H))
         masks = self.roi_heads.mask(feats[:len(self.config.pool_scales)], boxes, labels)
         return dict(boxes=boxes, scores=scores, labels=labels, masks=masks, proposals=proposals, objectness=objectness)
 
 
+def image_to_feed(bgr, dev, feed=(1088, 800)):
+    """predictor.py:267-283: HxWx3 u8 BGR -> [1,3,feed_h,feed_w] float RGB, area-resized, not normalised."""
+    t = (bgr.to(dev).flip(-1) if torch.is_tensor(bgr) else torch.as_tensor(bgr[:, :, ::-1].copy(), device=dev)).permute(2, 0, 1).float().unsqueeze(0)
+    return F.interpolate(t, size=feed, mode="area")
+
+
 @torch.no_grad()
-def analyse_image(net, bgr, feed=(1088, 800), confidence=0.8):
+def analyse_image(net, bgr, feed=(1088, 800), confidence=0.8, trunk=None):
     """predictor.py:compute_prediction + select_top_predictions (:215-283) and run_mask_rcnn.py:create_pixel_masks (:83-123):
     HxWx3 u8 BGR -> (label image HxW u8 = sum of mask * class index, label indices).  The frame is area-resized to 800x1088
     (W x H, cv2.INTER_AREA; third-party, restated with torch's area interpolation), flipped to RGB, NOT normalised."""
     dev = next(net.parameters()).device
-    t = (bgr.to(dev).flip(-1) if torch.is_tensor(bgr) else torch.as_tensor(bgr[:, :, ::-1].copy(), device=dev)).permute(2, 0, 1).float().unsqueeze(0)
-    H, W = t.shape[-2:]
-    out = net(F.interpolate(t, size=feed, mode="area"))
+    H, W = bgr.shape[:2]
+    if trunk is not None:                                    # hipGraph-captured static part (pipeline.NetNodes): u8 HxWx3 BGR in -> (feats, logits, deltas)
+        feats, logits, deltas = trunk(bgr)
+        out = net.heads(feats, logits, deltas, feed)
+    else:
+        out = net(image_to_feed(bgr, dev, feed))
     rw, rh = float(W) / feed[1], float(H) / feed[0]
     boxes = out["boxes"] * out["boxes"].new_tensor([rw, rh, rw, rh]) if rw != rh else out["boxes"] * rw
     keep = torch.nonzero(out["scores"] > confidence).squeeze(1)

@@ -16,7 +16,14 @@ class _Basic(nn.Module):
         if stride != 1 or cin != cout:
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
+    _ep = None                             # nets/fuse.py::fold_batchnorm
+
     def forward(self, x):
+        if self._ep is not None and x.is_cuda:
+            ep = self._ep
+            y = ep(F.conv2d(x, self._w1, None, self.conv1.stride, 1), self._b1, None, 0.0)
+            sc = x if self.downsample is None else ep(F.conv2d(x, self._wd, None, self.downsample[0].stride), self._bd, None, 1.0)
+            return ep(F.conv2d(y, self._w2, None, 1, 1), self._b2, sc.contiguous(), 0.0)
         y = F.relu(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
         return F.relu(y + (x if self.downsample is None else self.downsample(x)))
@@ -40,9 +47,14 @@ class ResnetEncoder18(nn.Module):
         super().__init__()
         self.encoder = _ResNet18Trunk()
 
+    _ep = None
+
     def forward(self, image):                     # resnet_encoder.py:87-98
         e = self.encoder
-        x = F.relu(e.bn1(e.conv1((image - 0.45) / 0.225)))
+        if self._ep is not None and image.is_cuda:
+            x = self._ep(F.conv2d((image - 0.45) / 0.225, self._w1, None, 2, 3), self._b1, None, 0.0)
+        else:
+            x = F.relu(e.bn1(e.conv1((image - 0.45) / 0.225)))
         feats = [x]
         x = e.layer1(F.max_pool2d(x, 3, 2, 1)); feats.append(x)
         for layer in (e.layer2, e.layer3, e.layer4):

@@ -43,6 +43,17 @@ class HipOps:
         self.ctx._check(self.ctx.lib.vido_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), N, Cc, H, W, C.c_float(slope)))
         return x
 
+    def bias_res_act_(self, x, bias, res, slope):
+        """in place: x = leaky_relu(x + bias[None, :, None, None] + res, slope); res None -> bias_act_ (slope 0 = ReLU, 1 = none)"""
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
+        N, Cc, H, W = x.shape
+        if res is not None:
+            assert res.shape == x.shape and res.is_contiguous() and res.dtype == torch.float32
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_bias_res_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()),
+                                                       C.c_void_p(res.data_ptr()) if res is not None else None, N, Cc, H, W, C.c_float(slope)))
+        return x
+
     def roi_align(self, feat, rois, output_size, spatial_scale, sampling_ratio):
         if not feat.is_cuda:
             raise RuntimeError("HipOps.roi_align needs CUDA(HIP) tensors; there is no CPU fallback")

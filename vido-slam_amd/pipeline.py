@@ -66,3 +66,164 @@ class NetFrontEnd:
         self.prev = cur
         out = dict(out); out["labels"] = labels; out["slot"] = slot
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# The whole realtime chain of the reference (src/realtime_demo/src/run_vido.cc): RunNet (:131-171, three service calls per frame) feeding
+# RunVidoSlam (:229-235, System::TrackRGBD), with the two stages overlapped: the networks of frame k+1 run while frame k is tracked.
+import queue as _queue
+import threading as _threading
+import time as _time
+
+
+class NetNodes:
+    """The three network nodes (flow_net / mono_depth2 / mask_rcnn ROS services, run_vido.cc:142-157) resident on one device, fp32 like
+    the reference.  infer(prev_bgr, cur_bgr) enqueues the three forwards on three HIP streams (they overlap on the GPU: at batch 1 most
+    layers leave CUs idle) and returns device tensors in the tracker's input types (run_vido.cc:28-37: depth MONO16 -> CV_32F,
+    mask MONO8 -> CV_32SC1, flow 32FC2).  optimize: frozen batch norms folded into the convolutions + fused HIP epilogues
+    (nets/fuse.py); graphs: the static-shape parts (all of LiteFlowNet and MonoDepth2 incl. their resize wrappers, Mask R-CNN's backbone +
+    FPN + RPN head) are captured into hipGraphs."""
+
+    def __init__(self, ctx, height=480, width=640, optimize=True, graphs=True, streams=True, miopen_find=False, seed=1,
+                 mask_feed=(1088, 800), depth_feed=(192, 640), confidence=0.8):
+        self.ctx, self.h, self.w = ctx, height, width
+        self.mask_feed, self.depth_feed, self.confidence = mask_feed, depth_feed, confidence
+        if miopen_find:
+            torch.backends.cudnn.benchmark = True                      # MIOpen find: measure the applicable solvers once per layer shape
+        dev = torch.device("cuda", ctx.cfg.device)
+        self.dev = dev
+        self.ops = ops = _nets.HipOps(ctx)
+        self.flow_net = _nets.fill_deterministic(_nets.LiteFlowNet(ops.correlation, epilogue=ops.bias_act_), seed).eval().to(dev)
+        self.depth_net = _nets.fill_deterministic(_nets.MonoDepth2(), seed + 1).eval().to(dev)
+        self.mask_net = _nets.fill_maskrcnn(_nets.MaskRCNN(ops), seed + 2).eval().to(dev)
+        self.folded = 0
+        if optimize:
+            self.folded = _nets.fold_batchnorm(self.depth_net, ops) + _nets.fold_batchnorm(self.mask_net, ops)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(3)] if streams else None
+        self.g_flow = self.g_depth = self.g_trunk = None
+        self.graph_error = None
+        ex = torch.zeros((height, width, 3), dtype=torch.uint8, device=dev)
+        self._flow_fn = lambda a, b: _nets.analyse_flow(self.flow_net, a, b)
+        self._depth_fn = lambda a: _nets.analyse_depth(self.depth_net, a, feed=self.depth_feed).to(torch.float32)
+        self._trunk_fn = lambda a: self.mask_net.trunk(_nets.maskrcnn.image_to_feed(a, dev, self.mask_feed))
+        with torch.no_grad():
+            for _ in range(2):                                          # first calls: MIOpen compiles / finds its kernels
+                self._flow_fn(ex, ex); self._depth_fn(ex); self._trunk_fn(ex)
+            torch.cuda.synchronize()
+            if graphs:
+                try:
+                    self.g_flow = _nets.Graphed(self._flow_fn, [ex, ex])
+                    self.g_depth = _nets.Graphed(self._depth_fn, [ex])
+                    self.g_trunk = _nets.Graphed(self._trunk_fn, [ex])
+                except Exception as e:                                  # capture is an optimisation: report, run eagerly
+                    self.graph_error = "%s: %s" % (type(e).__name__, e)
+                    self.g_flow = self.g_depth = self.g_trunk = None
+                    torch.cuda.synchronize()
+
+    @torch.no_grad()
+    def infer(self, prev_bgr, cur_bgr):
+        """prev_bgr / cur_bgr: u8 HxWx3 device tensors.  Returns (flow HxWx2 f32, depth HxW f32, mask HxW i32, labels, events): the outputs are
+        complete once the three events have fired (event.synchronize(), or stream.wait_event from a consumer stream)."""
+        cur = torch.cuda.current_stream()
+        ss = self.streams or [cur, cur, cur]
+        for s in ss:
+            if s is not cur:
+                s.wait_stream(cur)
+        with torch.cuda.stream(ss[0]):
+            flow = (self.g_flow or self._flow_fn)(prev_bgr, cur_bgr)
+            e0 = torch.cuda.Event(); e0.record()
+        with torch.cuda.stream(ss[1]):
+            depth = (self.g_depth or self._depth_fn)(cur_bgr)
+            e1 = torch.cuda.Event(); e1.record()
+        with torch.cuda.stream(ss[2]):                                  # last: its data-dependent tail synchronises the host while the other two run
+            mask_u8, labels = _nets.analyse_image(self.mask_net, cur_bgr, feed=self.mask_feed, confidence=self.confidence, trunk=self.g_trunk)
+            mask = mask_u8.to(torch.int32)
+            e2 = torch.cuda.Event(); e2.record()
+        return flow, depth, mask, labels, (e0, e1, e2)
+
+
+class EndToEnd:
+    """RunNet || RunVidoSlam on one GPU: the caller pushes BGR frames; the networks of frame k+1 are enqueued on the network streams while a
+    worker thread tracks frame k through System.TrackRGBD (the C++ facade: ORB, lists, P3P-RANSAC, the four optimisers, scene flow, object
+    tracking, re-seeding, local BA) on the tracker's own stream.  The hand-over is what TrackRGBD's interface asks for: host buffers
+    (pinned), one D2H copy per map.
+
+    feed = "nets": the tracker consumes the networks' outputs.  feed = "given": the networks run and their outputs are copied to the host
+    all the same (full cost, same dependency: frame k is tracked only after its three forwards and copies have completed), but the tracker
+    is handed caller-supplied flow / depth / mask maps for the frame — for synthetic benchmarks, where random-weight networks produce maps
+    without any geometry for the tracker to work on."""
+
+    RING = 4                                  # host buffer sets: the tracker keeps shallow references to the maps of the previous frame
+
+    def __init__(self, nodes, system, n_image=10000, feed="nets"):
+        self.nodes, self.system, self.n_image, self.feed = nodes, system, n_image, feed
+        h, w = nodes.h, nodes.w
+        pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
+        self.host = [dict(bgr=pin((h, w, 3), torch.uint8), flow=pin((h, w, 2), torch.float32), depth=pin((h, w), torch.float32), mask=pin((h, w), torch.int32),
+                          g_flow=pin((h, w, 2), torch.float32), g_depth=pin((h, w), torch.float32), g_mask=pin((h, w), torch.int32)) for _ in range(self.RING)]
+        self.copy_stream = torch.cuda.Stream(device=nodes.dev)
+        self.q = _queue.Queue(maxsize=1)      # the networks run at most one frame ahead of the tracker (+ the one in flight)
+        self.poses, self.stats, self.err = [], [], None
+        self.t_net, self.t_track, self.t_wait = [], [], []
+        self.prev = None; self.k = 0
+        self.worker = _threading.Thread(target=self._track_loop, daemon=True); self.worker.start()
+
+    def _track_loop(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            k, slot, ev = item
+            try:
+                t0 = _time.perf_counter()
+                ev.synchronize()                                         # networks + hand-over copies of frame k are complete
+                t1 = _time.perf_counter()
+                hb = self.host[slot]
+                if self.feed == "nets":
+                    d, f, m = hb["depth"], hb["flow"], hb["mask"]
+                else:
+                    d, f, m = hb["g_depth"], hb["g_flow"], hb["g_mask"]
+                T = self.system.TrackRGBD(hb["bgr"].numpy(), d.numpy(), f.numpy(), m.numpy(), None, None, float(k), None, self.n_image)
+                t2 = _time.perf_counter()
+                self.poses.append(T); self.stats.append(self.system.stats())
+                self.t_wait.append((t1 - t0) * 1e3); self.t_track.append((t2 - t1) * 1e3)
+            except Exception as e:                                       # surfaced by push() / finish()
+                self.err = e
+            finally:
+                self.q.task_done()
+
+    @torch.no_grad()
+    def push(self, bgr, given=None):
+        """bgr: HxWx3 u8 numpy.  given = (depth f32 HxW raw sensor units, flow f32 HxWx2, mask i32 HxW) for feed == "given"."""
+        if self.err is not None:
+            raise self.err
+        t0 = _time.perf_counter()
+        slot = self.k % self.RING
+        hb = self.host[slot]
+        hb["bgr"].numpy()[...] = bgr
+        if given is not None:
+            hb["g_depth"].numpy()[...] = given[0]; hb["g_flow"].numpy()[...] = given[1]; hb["g_mask"].numpy()[...] = given[2]
+        cur = hb["bgr"].to(self.nodes.dev, non_blocking=True)            # the only upload of the frame on the network side
+        prev = cur if self.prev is None else self.prev                   # first frame: RunNet has no previous image yet; the tracker ignores the flow of frame 0's predecessor
+        flow, depth, mask, labels, evs = self.nodes.infer(prev, cur)
+        cs = self.copy_stream
+        for e in evs:
+            cs.wait_event(e)
+        with torch.cuda.stream(cs):
+            hb["flow"].copy_(flow, non_blocking=True); hb["depth"].copy_(depth, non_blocking=True); hb["mask"].copy_(mask, non_blocking=True)
+            done = torch.cuda.Event(); done.record()
+        self._alive = (flow, depth, mask, cur, prev)                     # until the copies have run (static graph outputs are reused next frame: q maxsize 1 + the wait below)
+        self.prev = cur
+        self.t_net.append((_time.perf_counter() - t0) * 1e3)
+        self.q.put((self.k, slot, done))                                 # blocks while the tracker is still two frames behind
+        done.synchronize() if self.nodes.g_flow is not None else None    # graph outputs are static buffers: the next replay must not overwrite them before the copy ran
+        self.k += 1
+
+    def finish(self):
+        self.q.join()
+        if self.err is not None:
+            raise self.err
+
+    def close(self):
+        self.q.put(None)
+        self.worker.join(timeout=10)

@@ -99,13 +99,13 @@ class Scene3D:
     frame k+1 (objects move between the frames), and the ground-truth poses are known."""
 
     def __init__(self, n_frames=12, w=640, h=480, K=(500.0, 500.0, 319.5, 239.5), seed=3, step=0.25, yaw_deg=0.4,
-                 objects=((-2.0, 0.2, 9.0, 0.10, 0.0, 0.05),)):
+                 objects=((-2.0, 0.2, 9.0, 0.10, 0.0, 0.05),), obj_half=1.1, wall_z=32.0):
         self.n, self.w, self.h, self.K = n_frames, w, h, K
-        self.ground_y, self.wall_z = 1.6, 32.0
+        self.ground_y, self.wall_z = 1.6, wall_z
         self.tex = make_canvas(1024, 1024, seed, n_rect=600).astype(np.float32)
         self.otex = [make_canvas(256, 256, seed + 17 * (i + 1), n_rect=40).astype(np.float32) for i in range(len(objects))]
         self.objects = objects          # (x, y, z, vx, vy, vz) of the square centre at frame 0, metres / frame
-        self.obj_half = 1.1
+        self.obj_half = obj_half
         self.poses = []                 # camera-to-world 4x4
         T = np.eye(4)
         for k in range(n_frames + 1):
@@ -154,3 +154,18 @@ class Scene3D:
         flow = np.stack([un - self.uv[..., 0], vn - self.uv[..., 1]], -1).astype(np.float32)
         g8 = np.clip(np.rint(gray), 0, 255).astype(np.uint8)
         return g8, depth, flow, mask
+
+
+def convoy_scene(n_frames, w=640, h=480, seed=5, step=0.25):
+    """BASELINE configs[1]-[3] chained: a 640x480 Scene3D with FIVE dynamic objects that drive ahead of the camera at roughly its own
+    speed (so they stay in view for the whole clip) with distinct lateral / forward velocities — scene flow 0.26-0.34 m per frame, above SFMgThres —
+    each about 110 px wide (>= 150 dense samples, depth < ThDepthOBJ)."""
+    objs = ((-4.4, 0.55, 8.0, -0.004, 0.0, step + 0.010), (-2.2, 0.55, 9.5, -0.006, 0.0, step + 0.020), (0.0, 0.55, 11.0, 0.004, 0.0, step + 0.000),
+            (2.2, 0.55, 9.5, 0.006, 0.0, step + 0.015), (4.4, 0.55, 8.0, 0.004, 0.0, step + 0.005))
+    return Scene3D(n_frames=n_frames, w=w, h=h, seed=seed, step=step, yaw_deg=0.05, objects=objs, obj_half=0.9, wall_z=48.0)
+
+
+def gray_to_bgr(gray):
+    """HxW u8 -> HxWx3 u8 with B = G = R: cvtColor(BGR2GRAY) of it is the gray image again ((1868 + 9617 + 4899) g + 8192) >> 14 == g."""
+    import numpy as _np
+    return _np.ascontiguousarray(_np.repeat(gray[:, :, None], 3, axis=2))
