@@ -270,6 +270,20 @@ int vido_nms(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, int n,
  * pass: boxes with different `groups` never suppress each other.  Conventions as vido_nms. */
 int vido_nms_grouped(vido_ctx* ctx, const float* boxes_xyxy, const float* scores, const int32_t* groups, int n, float thresh,
                      int32_t* keep_out, int32_t* n_keep, int on_device);
+/* Device-only batched NMS (layers.nms semantics per segment): the five per-level NMS calls of the RPN (modeling/rpn/inference.py:106-113), or the per-class
+ * loop of the box head with `groups`, as ONE pair of launches without a host round trip.  boxes [total,4] DEVICE, segments back to back, each sorted by descending
+ * score; seg_off / seg_n DEVICE int32 [n_seg]; max_n >= every segment length.  keep_out [n_seg, max_n]: kept positions relative to the segment start, ascending,
+ * padded with -1; n_keep [n_seg].  Enqueues on the adopted stream (vido_set_stream), synchronises nothing. */
+int vido_nms_segments(vido_ctx* ctx, const float* boxes_xyxy, const int32_t* groups, const int32_t* seg_off, const int32_t* seg_n, int n_seg, int max_n, int total,
+                      float thresh, int32_t* keep_out, int32_t* n_keep);
+/* Pooler.forward (modeling/poolers.py:97-121: LevelMapper, one ROIAlign per FPN level, scatter back by index) in one launch: feat[l] DEVICE [1,C,H[l],W[l]] f32,
+ * boxes [n,4] x1 y1 x2 y2, level [n] in 0..3 (the LevelMapper's result, computed by the caller), out [n,C,pooled_h,pooled_w]. */
+int vido_roi_align_fpn(vido_ctx* ctx, const float* const feat[4], const int H[4], const int W[4], const float scale[4], int C, const float* boxes, const int32_t* level,
+                       int n, int pooled_h, int pooled_w, int sampling_ratio, float* out);
+/* Masker(threshold 0.5, padding 1).forward (modeling/roi_heads/mask_head/inference.py:87-160, per detection on the host in the reference) fused with the node's
+ * label image (src/run_mask_rcnn.py:112-118: blank_mask += mask * class_index): masks [n,1,M,M] f32, boxes [n,4] f32 in the output image, labels [n] i64,
+ * all DEVICE, detections in the order the node adds them; out [H,W] u8 = (sum over detections of pasted mask * class index) mod 256. */
+int vido_mask_label_image(vido_ctx* ctx, const float* masks, const float* boxes, const int64_t* labels, int n, int M, int padding, float thresh, int H, int W, uint8_t* out);
 /* BoxCoder(weights).decode(deltas [n,4k], boxes [n,4]) — modeling/box_coder.py:52-95. */
 int vido_box_decode(vido_ctx* ctx, const float* deltas, const float* boxes, int n, int k, const float weights[4],
                     float* out, int on_device);
@@ -281,6 +295,12 @@ int vido_box_decode(vido_ctx* ctx, const float* deltas, const float* boxes, int 
 int vido_pnp_ransac(vido_ctx* ctx, const float* pts3d, const float* pts2d, int n, double fx, double fy, double cx, double cy,
                     int max_iters, double reproj_err, double confidence, uint64_t seed, double T_out[16], uint8_t* inlier_mask,
                     int32_t* n_inliers);
+
+/* All dynamic objects of a frame in one pair of launches and ONE synchronisation (Tracking::Track loops GetInitModelObj over the objects, Tracking.cc:1192-1228):
+ * problem p has n[p] points pts3d[p] / pts2d[p], seed seeds[p]; T_out [n_prob][16], inlier_mask[p] (may be NULL) [n[p]], n_inliers [n_prob].  Results are identical to
+ * n_prob calls of vido_pnp_ransac. */
+int vido_pnp_ransac_batch(vido_ctx* ctx, int n_prob, const float* const* pts3d, const float* const* pts2d, const int32_t* n, double fx, double fy, double cx, double cy,
+                          int max_iters, double reproj_err, double confidence, const uint64_t* seeds, double* T_out, uint8_t* const* inlier_mask, int32_t* n_inliers);
 
 /* ---- The whole per-frame pipeline behind one C handle ---------------------------------------------------------------------------
  * VIDO_SLAM::System (System.h:72-114) for hosts that bind C instead of C++ (ctypes / cgo / JNI): System::System() + Init(yaml, RGBD)

@@ -116,6 +116,9 @@ public:
     static int PoseOptimizationFlow2Cam(Frame* pCurFrame, Frame* pLastFrame, std::vector<int>& TemperalMatch);
     static cv::Mat PoseOptimizationObjMot(Frame* pCurFrame, Frame* pLastFrame, const std::vector<int>& ObjId, std::vector<int>& InlierID);
     static cv::Mat PoseOptimizationFlow2(Frame* pCurFrame, Frame* pLastFrame, const std::vector<int>& ObjId, std::vector<int>& InlierID);
+    /* extension: PoseOptimizationFlow2 (joint) / PoseOptimizationObjMot for all dynamic objects of the frame in one launch; same results as the per-object calls */
+    static std::vector<cv::Mat> PoseOptimizationObjectsBatch(Frame* pCurFrame, Frame* pLastFrame, const std::vector<std::vector<int> >& ObjIds, const std::vector<cv::Mat>& InitModels,
+                                                             std::vector<std::vector<int> >& InlierIDs, bool joint);
     static void FullBatchOptimization(Map* pMap, const cv::Mat Calib_K);
     static void PartialBatchOptimization(Map* pMap, const cv::Mat Calib_K, const int WINDOW_SIZE);
     static cv::Mat Get3DinWorld(const cv::KeyPoint& Feats2d, const float& Dpts, const cv::Mat& Calib_K, const cv::Mat& CameraPose);
@@ -139,6 +142,8 @@ public:
     std::vector<std::vector<int> > DynObjTracking();
     cv::Mat GetInitModelCam(const std::vector<int>& MatchId, std::vector<int>& MatchId_sub);
     cv::Mat GetInitModelObj(const std::vector<int>& ObjId, std::vector<int>& ObjId_sub, const int objid);
+    /* extension: GetInitModelObj for all objects of the frame with one batched RANSAC launch (same seeds and results) */
+    std::vector<cv::Mat> GetInitModelObjBatch(const std::vector<std::vector<int> >& ObjIds, std::vector<std::vector<int> >& ObjIds_sub);
     std::vector<std::vector<std::pair<int, int> > > GetStaticTrack();
     std::vector<std::vector<std::pair<int, int> > > GetDynamicTrackNew();
     void RenewFrameInfo(const std::vector<int>& TM_sta);

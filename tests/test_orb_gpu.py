@@ -78,14 +78,28 @@ def test_flat_and_noise_images(vido, oracle):
     assert len(k) == 0
     rng = np.random.RandomState(0)
     noise = rng.randint(0, 256, size=(480, 640)).astype(np.uint8)     # worst case: corners everywhere
+    # cv::FAST has no capacity limit (ORBextractor.cc:771-816 grows vToDistributeKeys without bound): neither has the build — every cell has as many
+    # output slots as a 3x3 NMS can leave survivors, the strip kernel re-chunks its lists, the candidate buffers hold a full level
     p = oracle.orb_params()
-    try:
-        k, d = c.orb_extract(noise)
-    except vido.VidoError as e:
-        assert e.code == -4      # documented capacity limit, reported loudly
-    else:
-        rk, rd, _ = oracle.orb_extract(p, noise)
-        assert len(k) == len(rk) and np.array_equal(d, rd)
+    k, d = c.orb_extract(noise)
+    rk, rd, ncand = oracle.orb_extract(p, noise)
+    assert sum(ncand) > 60000                                         # far beyond round 1's 128-per-cell / 49152-per-frame limits
+    assert len(k) == len(rk)
+    for name in ("x", "y", "size", "angle", "response", "octave"):
+        assert np.array_equal(k[name], rk[name]), name
+    assert np.array_equal(d, rd)
+    for l in range(8):                                                # candidate lists (order included) per level
+        x, y, s = c.orb_candidates(0, l)
+        assert len(x) == ncand[l], (l, len(x), ncand[l])
+    # 2x2-pixel checkerboard blocks + salt noise: equal-score plateaus (NMS ties) and cells whose 20-threshold pass comes back empty next to busy ones
+    img = (np.kron(rng.randint(0, 2, size=(120, 160)) * 40 + 100, np.ones((4, 4))) + rng.randint(0, 6, size=(480, 640))).astype(np.uint8)
+    img[200:, :] = 90; img[200:, :] += (rng.rand(280, 640) < 0.002).astype(np.uint8) * 15      # nearly flat lower part: the 7-threshold fallback decides there
+    k, d = c.orb_extract(img)
+    rk, rd, ncand = oracle.orb_extract(p, img)
+    assert len(k) == len(rk)
+    for name in ("x", "y", "size", "angle", "response", "octave"):
+        assert np.array_equal(k[name], rk[name]), name
+    assert np.array_equal(d, rd)
     c.close()
 
 

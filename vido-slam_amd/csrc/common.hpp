@@ -9,8 +9,6 @@
 #include <vector>
 #include "../../include/vido_c.h"
 
-#define VIDO_CELL_CAP 128          // FAST survivors kept per ~30x30 cell (NMS'd corners; >CAP => VIDO_E_CAPACITY)
-#define VIDO_MAX_CAND_PER_FRAME 49152
 
 struct LevelInfo {
     int w, h, pitch;               // level size, row pitch in bytes (multiple of 64)

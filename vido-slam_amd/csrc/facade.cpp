@@ -279,56 +279,93 @@ int Optimizer::PoseOptimizationFlow2Cam(Frame* cur, Frame* last, std::vector<int
     return r.n_inliers;
 }
 
-cv::Mat Optimizer::PoseOptimizationObjMot(Frame* cur, Frame* last, const std::vector<int>& ObjId, std::vector<int>& InlierID)   // :2826-3035
+// One object's problem for the two per-object optimisers (built once, solved alone or in a batch of all objects of the frame)
+namespace {
+struct ObjProblem { vido_pose_problem p; std::vector<double> Xw, obs, flow, depth; std::vector<uint8_t> outl; std::vector<double> f; vido_pose_result r; bool joint = false; int N = 0; };
+void build_objmot(ObjProblem& o, Frame* cur, Frame* last, const std::vector<int>& ObjId, const cv::Mat& InitModel)       // Optimizer.cc:2826-2935
 {
-    const int N = (int)ObjId.size();
-    if (N < 3) return cv::Mat::eye(4, 4, CV_32F);
-    std::vector<double> Xw(3 * N), obs(2 * N);
+    const int N = (int)ObjId.size(); o.N = N; o.joint = false;
+    o.Xw.resize(3 * N); o.obs.resize(2 * N);
     for (int i = 0; i < N; i++) {
-        obs[2 * i] = cur->mvObjKeys[ObjId[i]].pt.x; obs[2 * i + 1] = cur->mvObjKeys[ObjId[i]].pt.y;
+        o.obs[2 * i] = cur->mvObjKeys[ObjId[i]].pt.x; o.obs[2 * i + 1] = cur->mvObjKeys[ObjId[i]].pt.y;
         cv::Mat X = last->UnprojectStereoObject(ObjId[i], 0);
-        for (int a = 0; a < 3; a++) Xw[3 * i + a] = X.empty() ? 0.0 : X.at<float>(a);
+        for (int a = 0; a < 3; a++) o.Xw[3 * i + a] = X.empty() ? 0.0 : X.at<float>(a);
     }
-    vido_pose_problem p; fill_common(p, cur, N); p.mode = 2; p.Xw = Xw.data(); p.obs = obs.data();
-    toRow16(Converter::toInvMatrix(cur->mTcw) * cur->mInitModel, p.T_init);
+    vido_pose_problem& p = o.p; fill_common(p, cur, N); p.mode = 2; p.Xw = o.Xw.data(); p.obs = o.obs.data();
+    toRow16(Converter::toInvMatrix(cur->mTcw) * InitModel, p.T_init);
     const double K[12] = {cur->fx, 0, cur->cx, 0, 0, cur->fy, cur->cy, 0, 0, 0, 1, 0}; double T[16]; toRow16(cur->mTcw, T);
     for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) { double s = 0; for (int k = 0; k < 4; k++) s += K[r * 4 + k] * T[k * 4 + c]; p.P[r * 4 + c] = s; }
     p.info_edge = 1.0; p.use_huber = 0; p.rounds = 1; p.drop_kernel_after_round = 2;
     const int its[4] = {200, 100, 100, 100}; const float th[4] = {0.01f, 5.991f, 5.991f, 5.991f};
     memcpy(p.iters, its, sizeof its); memcpy(p.chi2_th, th, sizeof th);
-    vido_pose_result r; std::vector<uint8_t> outl(N);
-    check(vido_pose_optimize(g_ctx, &p, &r, outl.data(), nullptr), "PoseOptimizationObjMot");
+    o.outl.assign(std::max(N, 1), 0); o.f.clear();
+}
+void build_flow2(ObjProblem& o, Frame* cur, Frame* last, const std::vector<int>& ObjId, const cv::Mat& InitModel)        // Optimizer.cc:3037-3160
+{
+    const int N = (int)ObjId.size(); o.N = N; o.joint = true;
+    o.obs.resize(2 * N); o.flow.resize(2 * N); o.depth.resize(N);
+    for (int i = 0; i < N; i++) {
+        cv::Mat fd = last->ObtainFlowDepthObject(ObjId[i], 0);
+        o.flow[2 * i] = fd.empty() ? 0.0 : fd.at<float>(0); o.flow[2 * i + 1] = fd.empty() ? 0.0 : fd.at<float>(1); o.depth[i] = fd.empty() ? 1.0 : fd.at<float>(2);
+        o.obs[2 * i] = last->mvObjKeys[ObjId[i]].pt.x; o.obs[2 * i + 1] = last->mvObjKeys[ObjId[i]].pt.y;
+    }
+    vido_pose_problem& p = o.p; fill_common(p, cur, N); p.mode = 1; p.obs = o.obs.data(); p.flow0 = o.flow.data(); p.depth = o.depth.data();
+    toRow16(Converter::toInvMatrix(last->mTcw), p.Twl); toRow16(InitModel, p.T_init);
+    p.info_edge = 0.1; p.info_prior = 0.5; p.huber_delta = (double)std::sqrt(0.04f); p.use_huber = 1; p.rounds = 1; p.drop_kernel_after_round = 2;
+    const int its[4] = {200, 100, 100, 100}; const float th[4] = {0.04f, 5.991f, 5.991f, 5.991f};
+    memcpy(p.iters, its, sizeof its); memcpy(p.chi2_th, th, sizeof th);
+    o.outl.assign(std::max(N, 1), 0); o.f.assign(2 * std::max(N, 1), 0.0);
+}
+cv::Mat finish_obj(ObjProblem& o, Frame* cur, Frame* last, const std::vector<int>& ObjId, std::vector<int>& InlierID)     // :2990-3035 / :3215-3253
+{
     InlierID.clear();
-    for (int i = 0; i < N; i++) { if (!outl[i]) InlierID.push_back(ObjId[i]); else cur->vObjLabel[ObjId[i]] = -1; }
-    return fromRow16(r.T);
+    for (int i = 0; i < o.N; i++) {
+        if (!o.outl[i]) {
+            if (o.joint) {      // refined optical flow
+                cur->mvObjKeys[ObjId[i]].pt.x = last->mvObjKeys[ObjId[i]].pt.x + (float)o.f[2 * i];
+                cur->mvObjKeys[ObjId[i]].pt.y = last->mvObjKeys[ObjId[i]].pt.y + (float)o.f[2 * i + 1];
+            }
+            InlierID.push_back(ObjId[i]);
+        } else cur->vObjLabel[ObjId[i]] = -1;
+    }
+    return fromRow16(o.r.T);
+}
+}  // namespace
+
+cv::Mat Optimizer::PoseOptimizationObjMot(Frame* cur, Frame* last, const std::vector<int>& ObjId, std::vector<int>& InlierID)   // :2826-3035
+{
+    if ((int)ObjId.size() < 3) return cv::Mat::eye(4, 4, CV_32F);
+    ObjProblem o; build_objmot(o, cur, last, ObjId, cur->mInitModel);
+    check(vido_pose_optimize(g_ctx, &o.p, &o.r, o.outl.data(), nullptr), "PoseOptimizationObjMot");
+    return finish_obj(o, cur, last, ObjId, InlierID);
 }
 
 cv::Mat Optimizer::PoseOptimizationFlow2(Frame* cur, Frame* last, const std::vector<int>& ObjId, std::vector<int>& InlierID)    // :3037-3253
 {
-    const int N = (int)ObjId.size();
-    if (N < 3) return cv::Mat::eye(4, 4, CV_32F);
-    std::vector<double> obs(2 * N), flow(2 * N), depth(N);
-    for (int i = 0; i < N; i++) {
-        cv::Mat fd = last->ObtainFlowDepthObject(ObjId[i], 0);
-        flow[2 * i] = fd.empty() ? 0.0 : fd.at<float>(0); flow[2 * i + 1] = fd.empty() ? 0.0 : fd.at<float>(1); depth[i] = fd.empty() ? 1.0 : fd.at<float>(2);
-        obs[2 * i] = last->mvObjKeys[ObjId[i]].pt.x; obs[2 * i + 1] = last->mvObjKeys[ObjId[i]].pt.y;
+    if ((int)ObjId.size() < 3) return cv::Mat::eye(4, 4, CV_32F);
+    ObjProblem o; build_flow2(o, cur, last, ObjId, cur->mInitModel);
+    check(vido_pose_optimize(g_ctx, &o.p, &o.r, o.outl.data(), o.f.data()), "PoseOptimizationFlow2");
+    return finish_obj(o, cur, last, ObjId, InlierID);
+}
+
+// All dynamic objects of the frame in one launch (extension: the reference calls PoseOptimizationFlow2 / ObjMot once per object inside Tracking::Track's loop,
+// Tracking.cc:1268-1274; the objects' point sets are disjoint, so the results equal the per-object calls).
+std::vector<cv::Mat> Optimizer::PoseOptimizationObjectsBatch(Frame* cur, Frame* last, const std::vector<std::vector<int> >& ObjIds, const std::vector<cv::Mat>& InitModels,
+                                                              std::vector<std::vector<int> >& InlierIDs, bool joint)
+{
+    const size_t n = ObjIds.size();
+    std::vector<cv::Mat> out(n); InlierIDs.assign(n, std::vector<int>());
+    std::vector<ObjProblem> O(n); std::vector<vido_pose_problem> P; std::vector<vido_pose_result> R; std::vector<uint8_t*> om; std::vector<double*> fo; std::vector<size_t> which;
+    for (size_t i = 0; i < n; i++) {
+        if (ObjIds[i].size() < 3) { out[i] = cv::Mat::eye(4, 4, CV_32F); continue; }
+        if (joint) build_flow2(O[i], cur, last, ObjIds[i], InitModels[i]); else build_objmot(O[i], cur, last, ObjIds[i], InitModels[i]);
+        which.push_back(i);
     }
-    vido_pose_problem p; fill_common(p, cur, N); p.mode = 1; p.obs = obs.data(); p.flow0 = flow.data(); p.depth = depth.data();
-    toRow16(Converter::toInvMatrix(last->mTcw), p.Twl); toRow16(cur->mInitModel, p.T_init);
-    p.info_edge = 0.1; p.info_prior = 0.5; p.huber_delta = (double)std::sqrt(0.04f); p.use_huber = 1; p.rounds = 1; p.drop_kernel_after_round = 2;
-    const int its[4] = {200, 100, 100, 100}; const float th[4] = {0.04f, 5.991f, 5.991f, 5.991f};
-    memcpy(p.iters, its, sizeof its); memcpy(p.chi2_th, th, sizeof th);
-    vido_pose_result r; std::vector<uint8_t> outl(N); std::vector<double> f(2 * N);
-    check(vido_pose_optimize(g_ctx, &p, &r, outl.data(), f.data()), "PoseOptimizationFlow2");
-    InlierID.clear();
-    for (int i = 0; i < N; i++) {
-        if (!outl[i]) {
-            cur->mvObjKeys[ObjId[i]].pt.x = last->mvObjKeys[ObjId[i]].pt.x + (float)f[2 * i];
-            cur->mvObjKeys[ObjId[i]].pt.y = last->mvObjKeys[ObjId[i]].pt.y + (float)f[2 * i + 1];
-            InlierID.push_back(ObjId[i]);
-        } else cur->vObjLabel[ObjId[i]] = -1;
-    }
-    return fromRow16(r.T);
+    for (size_t i : which) { P.push_back(O[i].p); om.push_back(O[i].outl.data()); fo.push_back(joint ? O[i].f.data() : nullptr); }
+    R.resize(P.size());
+    if (!P.empty()) check(vido_pose_optimize_batch(g_ctx, P.data(), (int)P.size(), R.data(), om.data(), fo.data()), "PoseOptimizationObjectsBatch");
+    for (size_t k = 0; k < which.size(); k++) { const size_t i = which[k]; O[i].r = R[k]; out[i] = finish_obj(O[i], cur, last, ObjIds[i], InlierIDs[i]); }
+    return out;
 }
 
 // g2o text dump of the full-batch graph (the reference saves dynamic_slam_graph_{before,after}_opt.g2o, Optimizer.cc:1937-1939) with the
@@ -647,32 +684,66 @@ cv::Mat Tracking::GetInitModelCam(const std::vector<int>& MatchId, std::vector<i
     return MotionModel;
 }
 
-cv::Mat Tracking::GetInitModelObj(const std::vector<int>& ObjId, std::vector<int>& ObjId_sub, const int objid)   // Tracking.cc:2030-2162
+// GetInitModelObj in two halves so that the RANSAC of all objects of a frame can run as one batch: inputs, then the comparison with the previous motion
+namespace {
+struct ObjInit { std::vector<cv::Point2f> cur_2d; std::vector<cv::Point3f> pre_3d; std::vector<float> g3, g2; std::vector<uint8_t> mask; double T[16]; int32_t ninl = 0; };
+void init_obj_inputs(ObjInit& o, Frame* C, Frame* L, const std::vector<int>& ObjId)
 {
-    const int N = (int)ObjId.size(); Frame *C = mpCurrentFrame, *L = mpLastFrame;
-    std::vector<cv::Point2f> cur_2d(N); std::vector<cv::Point3f> pre_3d(N); std::vector<float> g3(3 * N), g2(2 * N);
+    const int N = (int)ObjId.size();
+    o.cur_2d.resize(N); o.pre_3d.resize(N); o.g3.resize(3 * N); o.g2.resize(2 * N); o.mask.assign(std::max(N, 1), 0);
     for (int i = 0; i < N; i++) {
-        cur_2d[i] = C->mvObjKeys[ObjId[i]].pt;
+        o.cur_2d[i] = C->mvObjKeys[ObjId[i]].pt;
         cv::Mat X = L->UnprojectStereoObject(ObjId[i], 0);
-        pre_3d[i] = X.empty() ? cv::Point3f(0, 0, 1) : cv::Point3f(X.at<float>(0), X.at<float>(1), X.at<float>(2));
-        g3[3 * i] = pre_3d[i].x; g3[3 * i + 1] = pre_3d[i].y; g3[3 * i + 2] = pre_3d[i].z; g2[2 * i] = cur_2d[i].x; g2[2 * i + 1] = cur_2d[i].y;
+        o.pre_3d[i] = X.empty() ? cv::Point3f(0, 0, 1) : cv::Point3f(X.at<float>(0), X.at<float>(1), X.at<float>(2));
+        o.g3[3 * i] = o.pre_3d[i].x; o.g3[3 * i + 1] = o.pre_3d[i].y; o.g3[3 * i + 2] = o.pre_3d[i].z; o.g2[2 * i] = o.cur_2d[i].x; o.g2[2 * i + 1] = o.cur_2d[i].y;
     }
-    double T[16]; int32_t ninl = 0; std::vector<uint8_t> mask(std::max(N, 1));
-    check(vido_pnp_ransac(g_ctx, g3.data(), g2.data(), N, C->fx, C->fy, C->cx, C->cy, 500, 0.4, 0.98, ransac_seed + 7919u * (unsigned)(objid + 1) + (unsigned)f_id, T, mask.data(), &ninl), "pnp_ransac(obj)");
-    cv::Mat Mod = fromRow16(T);
+}
+cv::Mat init_obj_decide(const ObjInit& o, Frame* C, Frame* L, const std::vector<int>& ObjId, std::vector<int>& ObjId_sub, int objid)    // Tracking.cc:2076-2162
+{
+    const int N = (int)ObjId.size();
+    cv::Mat Mod = fromRow16(o.T);
     const int CurObjLab = C->nModLabel[objid]; int PreObjID = -1;
     for (size_t i = 0; i < L->nModLabel.size(); i++) if (L->nModLabel[i] == CurObjLab) { PreObjID = (int)i; break; }
     ObjId_sub.clear();
     if (PreObjID != -1 && PreObjID < (int)L->vObjMod.size() && !L->vObjMod[PreObjID].empty()) {
         cv::Mat MotionModel = C->mTcw * L->vObjMod[PreObjID];
         std::vector<int> MM;
-        for (int i = 0; i < N; i++) if (reproj(MotionModel, pre_3d[i], cur_2d[i], C->fx, C->fy, C->cx, C->cy) < 0.4f) MM.push_back(i);
-        if (ninl > (int)MM.size()) { for (int i = 0; i < N; i++) if (mask[i]) ObjId_sub.push_back(ObjId[i]); return Mod; }
+        for (int i = 0; i < N; i++) if (reproj(MotionModel, o.pre_3d[i], o.cur_2d[i], C->fx, C->fy, C->cx, C->cy) < 0.4f) MM.push_back(i);
+        if (o.ninl > (int)MM.size()) { for (int i = 0; i < N; i++) if (o.mask[i]) ObjId_sub.push_back(ObjId[i]); return Mod; }
         for (int i : MM) ObjId_sub.push_back(ObjId[i]);
         return MotionModel;
     }
-    for (int i = 0; i < N; i++) if (mask[i]) ObjId_sub.push_back(ObjId[i]);      // no previous motion: RANSAC model (:2136-2147)
+    for (int i = 0; i < N; i++) if (o.mask[i]) ObjId_sub.push_back(ObjId[i]);      // no previous motion: RANSAC model (:2136-2147)
     return Mod;
+}
+}  // namespace
+
+cv::Mat Tracking::GetInitModelObj(const std::vector<int>& ObjId, std::vector<int>& ObjId_sub, const int objid)   // Tracking.cc:2030-2162
+{
+    Frame *C = mpCurrentFrame, *L = mpLastFrame;
+    ObjInit o; init_obj_inputs(o, C, L, ObjId);
+    check(vido_pnp_ransac(g_ctx, o.g3.data(), o.g2.data(), (int)ObjId.size(), C->fx, C->fy, C->cx, C->cy, 500, 0.4, 0.98, ransac_seed + 7919u * (unsigned)(objid + 1) + (unsigned)f_id, o.T, o.mask.data(), &o.ninl), "pnp_ransac(obj)");
+    return init_obj_decide(o, C, L, ObjId, ObjId_sub, objid);
+}
+
+// GetInitModelObj for every object of the frame: one batched RANSAC launch, one synchronisation; same seeds, same results as the per-object calls
+std::vector<cv::Mat> Tracking::GetInitModelObjBatch(const std::vector<std::vector<int> >& ObjIds, std::vector<std::vector<int> >& ObjIds_sub)
+{
+    Frame *C = mpCurrentFrame, *L = mpLastFrame; const size_t n = ObjIds.size();
+    std::vector<ObjInit> O(n); std::vector<const float*> p3(n), p2(n); std::vector<uint8_t*> mk(n); std::vector<int32_t> nn(n), ninl(n); std::vector<uint64_t> seeds(n); std::vector<double> T(16 * std::max<size_t>(n, 1));
+    for (size_t i = 0; i < n; i++) {
+        init_obj_inputs(O[i], C, L, ObjIds[i]);
+        p3[i] = O[i].g3.data(); p2[i] = O[i].g2.data(); mk[i] = O[i].mask.data(); nn[i] = (int32_t)ObjIds[i].size();
+        seeds[i] = ransac_seed + 7919u * (unsigned)(i + 1) + (unsigned)f_id;
+    }
+    if (n) check(vido_pnp_ransac_batch(g_ctx, (int)n, p3.data(), p2.data(), nn.data(), C->fx, C->fy, C->cx, C->cy, 500, 0.4, 0.98, seeds.data(), T.data(), mk.data(), ninl.data()), "pnp_ransac_batch");
+    std::vector<cv::Mat> out(n); ObjIds_sub.assign(n, std::vector<int>());
+    for (size_t i = 0; i < n; i++) {
+        memcpy(O[i].T, &T[16 * i], sizeof O[i].T); O[i].ninl = ninl[i];
+        if (nn[i] < 4) { for (int k = 0; k < 16; k++) O[i].T[k] = (k % 5 == 0); O[i].ninl = 0; }
+        out[i] = init_obj_decide(O[i], C, L, ObjIds[i], ObjIds_sub[i], (int)i);
+    }
+    return out;
 }
 
 void Tracking::GetSceneFlowObj()                              // Tracking.cc:1582-1668
@@ -901,18 +972,29 @@ void Tracking::Track()                                        // Tracking.cc:108
         const size_t no = ObjIdNew.size();
         C->bObjStat.assign(no, true); C->vObjMod.resize(no); C->vSpeed.resize(no); C->vObjCentre3D.resize(no); C->vnObjID.resize(no); C->vnObjInlierID.resize(no);
         t0 = std::chrono::steady_clock::now();
+        // the reference's per-object loop (:1192-1305) as three batched stages: initial models of all objects (one RANSAC launch), motion
+        // optimisation of all objects that kept >= 50 inliers (one LM launch), then the per-object bookkeeping
+        std::vector<cv::Mat> centres(no);
         for (size_t i = 0; i < no; i++) {
-            cv::Mat centre = vec3(0, 0, 0); int nvalid = 0;
-            for (int id : ObjIdNew[i]) { cv::Mat X = L->UnprojectStereoObject(id, 0); if (X.empty()) continue; for (int a = 0; a < 3; a++) centre.at<float>(a) += X.at<float>(a); nvalid++; }
+            cv::Mat centre = vec3(0, 0, 0);
+            for (int id : ObjIdNew[i]) { cv::Mat X = L->UnprojectStereoObject(id, 0); if (X.empty()) continue; for (int a = 0; a < 3; a++) centre.at<float>(a) += X.at<float>(a); }
             for (int a = 0; a < 3; a++) centre.at<float>(a) /= (float)ObjIdNew[i].size();
-            C->vObjCentre3D[i] = centre; C->vnObjID[i] = ObjIdNew[i];
-            std::vector<int> in_ids;
-            C->mInitModel = GetInitModelObj(ObjIdNew[i], in_ids, (int)i);
-            if (in_ids.size() < 50) { C->bObjStat[i] = false; C->vObjMod[i] = cv::Mat::eye(4, 4, CV_32F); C->vObjCentre3D[i] = vec3(0, 0, 0); C->vSpeed[i] = cv::Point2f(0, 0); C->vnObjInlierID[i] = in_ids; continue; }
-            std::vector<int> InlierID;
-            if (bJoint) { cv::Mat X = Optimizer::PoseOptimizationFlow2(C, L, in_ids, InlierID); C->vObjMod[i] = Converter::toInvMatrix(C->mTcw) * X; }
-            else C->vObjMod[i] = Optimizer::PoseOptimizationObjMot(C, L, in_ids, InlierID);
-            C->vnObjInlierID[i] = InlierID;
+            centres[i] = centre; C->vObjCentre3D[i] = centre; C->vnObjID[i] = ObjIdNew[i];
+        }
+        std::vector<std::vector<int> > in_ids_all;
+        std::vector<cv::Mat> init_models = GetInitModelObjBatch(ObjIdNew, in_ids_all);
+        std::vector<std::vector<int> > opt_ids; std::vector<cv::Mat> opt_init; std::vector<size_t> opt_obj;
+        for (size_t i = 0; i < no; i++) {
+            if (in_ids_all[i].size() < 50) { C->bObjStat[i] = false; C->vObjMod[i] = cv::Mat::eye(4, 4, CV_32F); C->vObjCentre3D[i] = vec3(0, 0, 0); C->vSpeed[i] = cv::Point2f(0, 0); C->vnObjInlierID[i] = in_ids_all[i]; continue; }
+            opt_ids.push_back(in_ids_all[i]); opt_init.push_back(init_models[i]); opt_obj.push_back(i);
+        }
+        std::vector<std::vector<int> > inl_all;
+        std::vector<cv::Mat> mods = Optimizer::PoseOptimizationObjectsBatch(C, L, opt_ids, opt_init, inl_all, bJoint);
+        if (!init_models.empty()) C->mInitModel = init_models.back();
+        for (size_t k = 0; k < opt_obj.size(); k++) {
+            const size_t i = opt_obj[k]; const cv::Mat& centre = centres[i];
+            C->vObjMod[i] = bJoint ? Converter::toInvMatrix(C->mTcw) * mods[k] : mods[k];
+            C->vnObjInlierID[i] = inl_all[k];
             const cv::Mat& Hm = C->vObjMod[i]; float v[3];       // speed = |t - (I - R) c| * 36   (:1295-1302)
             for (int r = 0; r < 3; r++) { float s = Hm.at<float>(r, 3); for (int c2 = 0; c2 < 3; c2++) s -= ((r == c2 ? 1.f : 0.f) - Hm.at<float>(r, c2)) * centre.at<float>(c2); v[r] = s; }
             C->vSpeed[i].x = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * 36 * 36;

@@ -198,6 +198,155 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long* __re
     if (lane == 0) *n_keep = cnt;
 }
 
+// Block-wise sweep, one wave per segment (a segment = one independent NMS problem: an RPN level, or the whole grouped box-head problem).  The sequential
+// dependency of greedy NMS is only INSIDE a block of 64 boxes: that part runs on scalar registers over the block's 64x64 diagonal bit matrix (v_readlane);
+// the suppression rows of the kept boxes are then OR-ed into the lanes' `remv` words with independent loads.  ~40 us for five 1000-box levels in ONE launch
+// instead of five dependent single-wave loops of ~215 us each.  Row stride of `mask` is col_blocks words; segment g covers rows [seg_off[g], seg_off[g]+seg_n[g]),
+// whose bit columns are relative to the segment start (the mask kernel is launched per segment with the same layout).
+__global__ __launch_bounds__(64) void k_nms_sweep_seg(const unsigned long long* __restrict__ mask, const int* __restrict__ seg_off, const int* __restrict__ seg_n, int col_blocks,
+                                                      int* __restrict__ keep, int* __restrict__ n_keep, int keep_stride)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int n = seg_n[g];
+    const unsigned long long* M = mask + (size_t)seg_off[g] * col_blocks;
+    int* kp = keep + (size_t)g * keep_stride;
+    const int cb = (n + 63) >> 6;
+    unsigned long long remv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) remv[k] = 0;
+    const int wpl = (cb + 63) >> 6;
+    int cnt = 0;
+    for (int blk = 0; blk < cb; blk++) {
+        const int owner = blk & 63, slot = blk >> 6, rows = min(n - blk * 64, 64);
+        unsigned long long word = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) if (k == slot) word = remv[k];
+        word = __shfl(word, owner, 64);
+        const unsigned long long diag = lane < rows ? M[(size_t)(blk * 64 + lane) * col_blocks + blk] : 0ull;
+        const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
+        unsigned long long alive = ~word;
+        if (rows < 64) alive &= (1ull << rows) - 1ull;
+        unsigned long long keepmask = 0;
+        while (alive) {                                                          // wave-uniform scalar loop over the surviving boxes of the block
+            const int j = __builtin_ctzll(alive);
+            keepmask |= 1ull << j;
+            const unsigned long long dj = (unsigned long long)__builtin_amdgcn_readlane(dlo, j) | ((unsigned long long)__builtin_amdgcn_readlane(dhi, j) << 32);
+            alive &= ~dj; alive &= ~(1ull << j);
+        }
+        if ((keepmask >> lane) & 1ull) kp[cnt + __popcll(keepmask & ((1ull << lane) - 1ull))] = blk * 64 + lane;
+        cnt += __popcll(keepmask);
+        unsigned long long km = keepmask;
+        while (km) {                                                             // OR the kept rows into the words of the later blocks (independent loads)
+            const int j = __builtin_ctzll(km); km &= km - 1;
+            const unsigned long long* prow = M + (size_t)(blk * 64 + j) * col_blocks;
+#pragma unroll
+            for (int k = 0; k < 16; k++) if (k < wpl) { const int w = k * 64 + lane; if (w > blk && w < cb) remv[k] |= prow[w]; }
+        }
+    }
+    for (int i = cnt + lane; i < keep_stride; i += 64) kp[i] = -1;
+    if (lane == 0) n_keep[g] = cnt;
+}
+// mask kernel for segments: grid (col block, row block, segment); tiles below the diagonal are never read by the sweep
+__global__ __launch_bounds__(64) void k_nms_mask_seg(const float* __restrict__ boxes, const int* __restrict__ group, const int* __restrict__ seg_off, const int* __restrict__ seg_n,
+                                                     float thresh, unsigned long long* __restrict__ mask, int col_blocks)
+{
+    const int g = blockIdx.z, n = seg_n[g], off = seg_off[g];
+    const int row_start = blockIdx.y, col_start = blockIdx.x;
+    if (col_start < row_start || row_start * 64 >= n || col_start * 64 >= n) return;
+    const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
+    __shared__ float bb[64 * 4]; __shared__ int gg[64];
+    if ((int)threadIdx.x < col_size) { for (int k = 0; k < 4; k++) bb[threadIdx.x * 4 + k] = boxes[(size_t)(off + col_start * 64 + threadIdx.x) * 4 + k];
+                                        gg[threadIdx.x] = group ? group[off + col_start * 64 + threadIdx.x] : 0; }
+    __syncthreads();
+    if ((int)threadIdx.x < row_size) {
+        const int cur = row_start * 64 + threadIdx.x;
+        const float* cbx = boxes + (size_t)(off + cur) * 4;
+        unsigned long long t = 0;
+        const int start = row_start == col_start ? threadIdx.x + 1 : 0;
+        const int gme = group ? group[off + cur] : 0;
+        for (int i = start; i < col_size; i++) if (gg[i] == gme && dev_iou(cbx, bb + i * 4) > thresh) t |= 1ULL << i;
+        mask[(size_t)(off + cur) * col_blocks + col_start] = t;
+    }
+}
+
+// ---- ROI-Align over the FPN levels in one launch (modeling/poolers.py:97-121: LevelMapper + one ROIAlign per level + scatter back by index) -----------------
+struct FpnLevels { const float* feat[4]; int H[4], W[4]; float scale[4]; };
+__global__ __launch_bounds__(256) void k_roi_align_fpn(FpnLevels L, int C, const float* __restrict__ boxes /*[n,4]*/, const int* __restrict__ level, int n,
+                                                       int PH, int PW, int sampling, float* __restrict__ out)
+{
+    const size_t total = (size_t)n * C * PH * PW;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int pw = (int)(idx % PW), ph = (int)((idx / PW) % PH), c = (int)((idx / PW / PH) % C), i = (int)(idx / PW / PH / C);
+        const float* r = boxes + 4 * (size_t)i;
+        const int l = level[i];
+        const float scale = L.scale[l]; const int H = L.H[l], W = L.W[l];
+        const float sw = r[0] * scale, sh = r[1] * scale, ew = r[2] * scale, eh = r[3] * scale;
+        const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);
+        const float bh = rh / (float)PH, bw = rw / (float)PW;
+        const int gh = sampling > 0 ? sampling : (int)ceilf(rh / PH), gw = sampling > 0 ? sampling : (int)ceilf(rw / PW);
+        const float count = (float)(gh * gw);
+        const float* d = L.feat[l] + (size_t)c * H * W;
+        float acc = 0.f;
+        for (int iy = 0; iy < gh; iy++) {
+            const float y = sh + ph * bh + (iy + .5f) * bh / (float)gh;
+            for (int ix = 0; ix < gw; ix++) {
+                const float x = sw + pw * bw + (ix + .5f) * bw / (float)gw;
+                acc += bilinear(d, H, W, y, x);
+            }
+        }
+        out[idx] = acc / count;
+    }
+}
+
+// ---- Masker + label image in one pass (mask_head/inference.py:87-160 paste_mask_in_image per detection on the host, then run_mask_rcnn.py:112-118
+// blank_mask += mask * class_index per detection): every output pixel walks the kept detections in order, samples the 1-px padded MxM mask probability with
+// the bilinear rule of F.interpolate(align_corners=False) at the detection's truncated box, thresholds, and accumulates class indices in u8 (wraps on overlap
+// like the reference's numpy loop).
+struct PasteDet { int x0, y0, w, h, label; float rw, rh; };
+__global__ __launch_bounds__(256) void k_paste_prepare(const float* __restrict__ boxes, const int64_t* __restrict__ labels, int n, int M, int padding, PasteDet* __restrict__ det)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float scale = (float)((double)(M + 2 * padding) / (double)M);
+    const float* b = boxes + 4 * (size_t)i;
+    const float wh = (b[2] - b[0]) * 0.5f * scale, hh = (b[3] - b[1]) * 0.5f * scale;
+    const float xc = (b[2] + b[0]) * 0.5f, yc = (b[3] + b[1]) * 0.5f;
+    const int x0 = (int)(xc - wh), y0 = (int)(yc - hh), x1 = (int)(xc + wh), y1 = (int)(yc + hh);      // .to(torch.int32): truncation toward zero
+    PasteDet d; d.x0 = x0; d.y0 = y0; d.w = max(x1 - x0 + 1, 1); d.h = max(y1 - y0 + 1, 1); d.label = (int)labels[i];
+    const int Mp = M + 2 * padding;
+    d.rw = (float)Mp / (float)d.w; d.rh = (float)Mp / (float)d.h;                                      // area_pixel_compute_scale, align_corners = false
+    det[i] = d;
+}
+__global__ __launch_bounds__(256) void k_paste_label(const float* __restrict__ masks /*[n,1,M,M]*/, const PasteDet* __restrict__ det, int n, int M, int padding, float thresh,
+                                                     int H, int W, uint8_t* __restrict__ out)
+{
+    __shared__ PasteDet sd[128];
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const int Mp = M + 2 * padding;
+    unsigned acc = 0;
+    for (int d0 = 0; d0 < n; d0 += 128) {
+        __syncthreads();
+        if ((int)threadIdx.x < min(128, n - d0)) sd[threadIdx.x] = det[d0 + threadIdx.x];
+        __syncthreads();
+        if (x < W && y < H) {
+            for (int k = 0; k < min(128, n - d0); k++) {
+                const PasteDet d = sd[k];
+                const int u = x - d.x0, v = y - d.y0;
+                if (u < 0 || v < 0 || u >= d.w || v >= d.h) continue;
+                float sy = d.rh * ((float)v + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+                float sx = d.rw * ((float)u + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+                const int iy = (int)sy, ix = (int)sx; const int iyp = iy < Mp - 1 ? 1 : 0, ixp = ix < Mp - 1 ? 1 : 0;
+                const float ly = sy - (float)iy, lx = sx - (float)ix, hy = 1.f - ly, hx = 1.f - lx;
+                const float* m = masks + (size_t)(d0 + k) * M * M;
+                auto at = [&](int yy, int xx) -> float { yy -= padding; xx -= padding; return (yy < 0 || xx < 0 || yy >= M || xx >= M) ? 0.f : m[yy * M + xx]; };
+                const float val = hy * (hx * at(iy, ix) + lx * at(iy, ix + ixp)) + ly * (hx * at(iy + iyp, ix) + lx * at(iy + iyp, ix + ixp));
+                if (val > thresh) acc += (unsigned)d.label;
+            }
+        }
+    }
+    if (x < W && y < H) out[(size_t)y * W + x] = (uint8_t)acc;
+}
+
 // ---- box decode ------------------------------------------------------------------------------------------------
 __global__ void k_box_decode(const float* __restrict__ deltas, const float* __restrict__ boxes, int n, int k, float wx, float wy, float ww, float wh, float* __restrict__ out)
 {
@@ -384,6 +533,64 @@ int vido_nms_grouped(vido_ctx* ctx, const float* boxes_xyxy, const float* scores
 {
     if (n > 0 && !groups) return ctx ? vido_set_error(ctx, VIDO_E_INVALID, "nms_grouped: null groups") : VIDO_E_INVALID;
     return nms_impl(ctx, boxes_xyxy, scores, groups, n, thresh, keep_out, n_keep, on_device);
+}
+
+/* Device-only batched NMS: n_seg independent problems laid out back to back in `boxes` (each segment sorted by descending score); seg_off / seg_n are DEVICE
+ * int arrays, max_n >= every segment length (host-known bound), total = rows of `boxes`.  keep_out [n_seg, max_n] receives the kept positions relative to the
+ * segment start, ascending, padded with -1; n_keep [n_seg].  Nothing is synchronised. */
+int vido_nms_segments(vido_ctx* ctx, const float* boxes_xyxy, const int32_t* groups, const int32_t* seg_off, const int32_t* seg_n, int n_seg, int max_n, int total,
+                      float thresh, int32_t* keep_out, int32_t* n_keep)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!boxes_xyxy || !seg_off || !seg_n || !keep_out || !n_keep || n_seg < 1 || max_n < 1 || total < 1) return vido_set_error(ctx, VIDO_E_INVALID, "nms_segments: bad arguments");
+    if (max_n > 65536) return vido_set_error(ctx, VIDO_E_CAPACITY, "nms_segments: %d boxes per segment > 65536", max_n);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    const int cb = (max_n + 63) / 64;
+    NetState* S = nullptr;
+    int rc = net_scratch(ctx, al256((size_t)total * cb * 8), &S); if (rc) return rc;
+    unsigned long long* dmask = (unsigned long long*)S->d;
+    hipLaunchKernelGGL(k_nms_mask_seg, dim3(cb, cb, n_seg), dim3(64), 0, st, boxes_xyxy, groups, seg_off, seg_n, thresh, dmask, cb);
+    hipLaunchKernelGGL(k_nms_sweep_seg, dim3(n_seg), dim3(64), 0, st, dmask, seg_off, seg_n, cb, keep_out, n_keep, max_n);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+/* Pooler.forward (modeling/poolers.py:97-121) in one launch: feat[l] DEVICE tensors [1, C, H[l], W[l]] f32 of the 4 FPN levels, boxes [n,4] (x1,y1,x2,y2),
+ * level [n] in 0..3 (the LevelMapper's result), out [n, C, pooled, pooled].  Device pointers only; enqueues on the adopted stream. */
+int vido_roi_align_fpn(vido_ctx* ctx, const float* const feat[4], const int H[4], const int W[4], const float scale[4], int C, const float* boxes, const int32_t* level,
+                       int n, int pooled_h, int pooled_w, int sampling_ratio, float* out)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!feat || !H || !W || !scale || C < 1 || n < 0 || pooled_h < 1 || pooled_w < 1 || (n && (!boxes || !level || !out))) return vido_set_error(ctx, VIDO_E_INVALID, "roi_align_fpn: bad arguments");
+    if (n == 0) return VIDO_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    FpnLevels L;
+    for (int l = 0; l < 4; l++) { L.feat[l] = feat[l]; L.H[l] = H[l]; L.W[l] = W[l]; L.scale[l] = scale[l]; }
+    const size_t total = (size_t)n * C * pooled_h * pooled_w;
+    hipLaunchKernelGGL(k_roi_align_fpn, dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, st, L, C, boxes, level, n, pooled_h, pooled_w, sampling_ratio, out);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+/* Masker(threshold, padding).forward + the node's label image (mask_head/inference.py:87-160, run_mask_rcnn.py:112-118): masks [n,1,M,M] f32 probabilities,
+ * boxes [n,4] f32 in the output image, labels [n] i64 (DEVICE pointers, detections in the order the node adds them) -> out [H,W] u8 = sum over detections of
+ * (pasted mask) * class index, modulo 256.  n may be 0 (out is cleared). */
+int vido_mask_label_image(vido_ctx* ctx, const float* masks, const float* boxes, const int64_t* labels, int n, int M, int padding, float thresh, int H, int W, uint8_t* out)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!out || H < 1 || W < 1 || n < 0 || M < 1 || padding < 0 || (n && (!masks || !boxes || !labels))) return vido_set_error(ctx, VIDO_E_INVALID, "mask_label_image: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    if (n == 0) { HIP_TRY(ctx, hipMemsetAsync(out, 0, (size_t)H * W, st)); return VIDO_OK; }
+    NetState* S = nullptr;
+    int rc = net_scratch(ctx, al256((size_t)n * sizeof(PasteDet)), &S); if (rc) return rc;
+    PasteDet* det = (PasteDet*)S->d;
+    hipLaunchKernelGGL(k_paste_prepare, dim3((n + 255) / 256), dim3(256), 0, st, boxes, labels, n, M, padding, det);
+    hipLaunchKernelGGL(k_paste_label, dim3((W + 31) / 32, (H + 7) / 8), dim3(256), 0, st, masks, det, n, M, padding, thresh, H, W, out);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
 }
 
 int vido_box_decode(vido_ctx* ctx, const float* deltas, const float* boxes, int n, int k, const float weights[4], float* out, int on_device)

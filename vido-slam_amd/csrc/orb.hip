@@ -35,10 +35,6 @@
 
 #define EDGE_THRESHOLD 19
 #define HALF_PATCH 15
-#define FT_PITCH 80          // LDS pitch of a cell sub-image tile (bytes)
-#define FT_ROWS 72
-#define FS_PITCH 72          // LDS pitch of the score tile
-#define FS_ROWS 68
 
 // ------------------------------------------------------------------------------------------------
 // device tables
@@ -157,190 +153,260 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: FAST 9/16 per reference cell.
-__device__ __forceinline__ bool has9(uint32_t m)           // 9 contiguous set bits in a circular 16-bit mask
-{
-    uint32_t w = m | (m << 16);
-    uint32_t x = w & (w >> 1);
-    x &= x >> 2;
-    x &= x >> 4;            // 8 consecutive
-    x &= w >> 8;            // 9 consecutive
-    return (x & 0xffffu) != 0;
-}
-
-// Phase 1a: compass pre-test.  Every arc of 9 contiguous ring pixels contains at least two of the four compass
-// pixels (ring 0, 4, 8, 12), so a corner at threshold th has >= 2 compass pixels brighter than v+th or >= 2
-// darker than v-th.
-// Done for the four pixels of an aligned quad at once, on packed 16-bit lanes (v_pk_add/sub_i16, two pixels per register): the
-// four compass dwords are N = the quad's dword three rows up, S = three rows down, E / W = the quad shifted by +-3 bytes (v_alignbyte across
-// the neighbouring dwords); v_perm widens bytes to u16 pairs, hi - r and r - lo leave their sign in bits 15 / 31, and "at least two of
-// four" is (s0 & s1) | (s2 & s3) | ((s0 | s1) & (s2 | s3)).  ~55 instructions per quad instead of ~4 x 28.
 typedef short v2s __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t fast_compass_quad(uint32_t up, const uint32_t* mid /*w0..w2 of row 0*/, uint32_t dn, int th)
+
+// ------------------------------------------------------------------------------------------------
+// K2s: FAST 9/16 per STRIP of up to 4 horizontally adjacent reference cells, one wave64 per strip (round 2).
+// Reference semantics (per-cell cv::FAST sub-images, 20-then-7 rule per cell, per-sub-image 3x3 NMS, row-major emission per
+// cell: ORBextractor.cc:779-819), restructured for lane occupancy and instruction count:
+//   * a wave owns the strip end to end — image tile, score tile and lists are wave-private LDS, so there is NO workgroup barrier anywhere;
+//   * phase a (compass pre-test) runs over all quads of the strip (~1000 tasks: 15 full wave iterations; round 1 ran one wave per cell: 4 full + 1 ragged iteration each);
+//     "at least two of the four compass pixels brighter than v+t" is "the second largest of them > v+t": a 4-element min/max network on packed
+//     16-bit lanes (v_pk_min/max_u16), 36 VALU per quad instead of 58;
+//   * surviving quads go to a quad list with ONE ballot per iteration; they are expanded to per-pixel candidates 64 quads at a time, so the
+//     per-pixel ordered compaction (4 ballots + 4 conditional stores) runs once per 64 ACTIVE quads;
+//   * phase b (segment test + score) takes 64 candidates of the whole strip per iteration (~99 % lane fill instead of ~60 %), knows from the pre-test
+//     which family (bright / dark arcs) can fire and evaluates only that one, with the 9-wide sliding minima on packed 16-bit lanes
+//     (v_pk_min_i16: 49 instead of 80 instructions), no separate has9 bit test: corner at t <=> max over arcs of the arc minimum > t;
+//   * scores are laid out in the score tile with one zero gutter column between cells, so the per-sub-image NMS needs no boundary tests;
+//   * nothing has a capacity that an image can exceed: the lists are sized for a chunk of rows, a chunk that overflows them is redone with half the
+//     rows (4 rows always fit), the NMS of a chunk runs one chunk behind (it needs the first score row of the next one), and every cell has
+//     ceil(w/2) * ceil(h/2) output slots — the most 3x3-NMS survivors a w x h sub-image can have.  cv::FAST has no limit either
+//     (ORBextractor.cc:771-816 grows vToDistributeKeys without bound).
+#define FS_MAXC 4
+#define FS_PITCH 148           // image tile pitch (bytes): <= 136 interior + 6 frame + 3 alignment shift; 37 dwords (odd) -> conflict-free column walks
+#define FS_SPITCH 144          // score tile pitch: 136 interior + 4 gutters + border
+#define FS_MAXIW 136
+#define FS_AQ_CAP 384
+#define FS_CAND_CAP 768
+#define FS_RMIN 4
+struct FastStrip { int level, x0, y0, sw, sh, ncell, cell0, pad; int bx[FS_MAXC + 1]; int pad2[3]; };
+
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2u as_v2u(uint32_t x) { return __builtin_bit_cast(v2u, x); }
+__device__ __forceinline__ v2s as_v2s(uint32_t x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ uint32_t as_u32(v2u x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_cast(uint32_t, x); }
+
+// Compass pre-test of the four pixels of an aligned quad.  Returns R with, for pixel p, the pair (bright, dark) at bits (15,14) p=0, (31,30) p=1,
+// (13,12) p=2, (29,28) p=3: "bright" = at least two of ring 0/4/8/12 are > v + th, "dark" = at least two are < v - th.
+__device__ __forceinline__ uint32_t fast_compass_quad2(uint32_t up, uint32_t m0, uint32_t m1, uint32_t m2, uint32_t dn, uint32_t T2)
 {
-    const uint32_t C = mid[1];
-    const uint32_t E = __builtin_amdgcn_alignbyte(mid[2], mid[1], 3), W = __builtin_amdgcn_alignbyte(mid[1], mid[0], 1);
-    const v2s T = {(short)th, (short)th};
-    uint32_t m4 = 0;
+    const uint32_t E = __builtin_amdgcn_alignbyte(m2, m1, 3), W = __builtin_amdgcn_alignbyte(m1, m0, 1);
+    uint32_t R = 0;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const uint32_t sel = h == 0 ? 0x0c010c00u : 0x0c030c02u;               // bytes (2h, 2h+1) -> two u16
-        const v2s v = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, C, sel));
-        const v2s hi = v + T, lo = v - T;
-        const v2s r0 = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, dn, sel)), r4 = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, E, sel));
-        const v2s r8 = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, up, sel)), r12 = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, W, sel));
-        const uint32_t b0 = __builtin_bit_cast(uint32_t, hi - r0), b1 = __builtin_bit_cast(uint32_t, hi - r4), b2 = __builtin_bit_cast(uint32_t, hi - r8), b3 = __builtin_bit_cast(uint32_t, hi - r12);
-        const uint32_t d0 = __builtin_bit_cast(uint32_t, r0 - lo), d1 = __builtin_bit_cast(uint32_t, r4 - lo), d2 = __builtin_bit_cast(uint32_t, r8 - lo), d3 = __builtin_bit_cast(uint32_t, r12 - lo);
-        const uint32_t br = (b0 & b1) | (b2 & b3) | ((b0 | b1) & (b2 | b3)), dk = (d0 & d1) | (d2 & d3) | ((d0 | d1) & (d2 | d3));
-        const uint32_t c = (br | dk) & 0x80008000u;                             // bit 15: pixel 2h, bit 31: pixel 2h+1
-        m4 |= (((c >> 15) & 1u) | ((c >> 30) & 2u)) << (2 * h);
+        const v2u v = as_v2u(__builtin_amdgcn_perm(0u, m1, sel)), T = as_v2u(T2);
+        const v2u r0 = as_v2u(__builtin_amdgcn_perm(0u, dn, sel)), r4 = as_v2u(__builtin_amdgcn_perm(0u, E, sel));
+        const v2u r8 = as_v2u(__builtin_amdgcn_perm(0u, up, sel)), r12 = as_v2u(__builtin_amdgcn_perm(0u, W, sel));
+        const v2u a = __builtin_elementwise_max(r0, r4), b = __builtin_elementwise_min(r0, r4), c = __builtin_elementwise_max(r8, r12), d = __builtin_elementwise_min(r8, r12);
+        const v2u x = __builtin_elementwise_min(a, c), y = __builtin_elementwise_max(b, d);
+        const v2u sl = __builtin_elementwise_max(x, y), ss = __builtin_elementwise_min(x, y);      // second largest / second smallest of the four
+        const uint32_t br = as_u32((v2u)(v + T - sl)), dk = as_u32((v2u)(ss - (v - T)));             // 16-bit wrap-around: sign bit <=> sl > v + th, ss < v - th (|values| < 2^15)
+        const uint32_t bits = (br & 0x80008000u) | ((dk & 0x80008000u) >> 1);
+        R |= h == 0 ? bits : (bits >> 2);
     }
-    return m4;
+    return R;
 }
 
-// Phase 1b: full 9/16 segment test + threshold-free corner score for one candidate pixel at LDS tile position t.
-// S = (max over the 16 arcs of 9 of the arc's min one-signed |centre - ring|) - 1; 0 unless p is a corner at `th`
-// (then S >= th): "corner at threshold t" <=> S >= t, so one score map serves both reference thresholds.
-__device__ __forceinline__ int fast_score(const uint8_t* t, int th)
+// max over the 16 arcs of 9 contiguous ring pixels of the arc's minimum of X (8 registers of two i16: X[j] = (x[2j], x[2j+1]))
+__device__ __forceinline__ int fast_arc_minmax(const uint32_t X[8])
 {
-    const int v = t[0], lo = v - th, hi = v + th;
-    int r[16];
-    r[0] = t[3 * FT_PITCH]; r[1] = t[3 * FT_PITCH + 1]; r[2] = t[2 * FT_PITCH + 2]; r[3] = t[FT_PITCH + 3];
-    r[4] = t[3]; r[5] = t[-FT_PITCH + 3]; r[6] = t[-2 * FT_PITCH + 2]; r[7] = t[-3 * FT_PITCH + 1];
-    r[8] = t[-3 * FT_PITCH]; r[9] = t[-3 * FT_PITCH - 1]; r[10] = t[-2 * FT_PITCH - 2]; r[11] = t[-FT_PITCH - 3];
-    r[12] = t[-3]; r[13] = t[FT_PITCH - 3]; r[14] = t[2 * FT_PITCH - 2]; r[15] = t[3 * FT_PITCH - 1];
-    uint32_t dark = 0, bright = 0;
+    uint32_t A[8], B[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { dark = __builtin_amdgcn_alignbit(dark, (uint32_t)(r[k] - lo), 31); bright = __builtin_amdgcn_alignbit(bright, (uint32_t)(hi - r[k]), 31); }
-    const bool isd = has9(dark), isb = has9(bright);       // bit order reversed w.r.t. k: irrelevant for a circular run
-    if (!(isd | isb)) return 0;
-    int d[16];
+    for (int j = 0; j < 8; j++) A[j] = as_u32(__builtin_elementwise_min(as_v2s(X[j]), as_v2s(__builtin_amdgcn_alignbit(X[(j + 1) & 7], X[j], 16))));     // a2[k] = min(x[k], x[k+1])
 #pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = isd ? v - r[k] : r[k] - v;     // one-signed difference of the arc family
-    int a2[16], a4[16], a8[16];                                        // sliding min over 9 circular neighbours: 2,4,8,+1
+    for (int j = 0; j < 8; j++) B[j] = as_u32(__builtin_elementwise_min(as_v2s(A[j]), as_v2s(A[(j + 1) & 7])));                                          // a4[k] = min(a2[k], a2[k+2])
 #pragma unroll
-    for (int k = 0; k < 16; k++) a2[k] = min(d[k], d[(k + 1) & 15]);
+    for (int j = 0; j < 8; j++) A[j] = as_u32(__builtin_elementwise_min(as_v2s(B[j]), as_v2s(B[(j + 2) & 7])));                                          // a8[k] = min(a4[k], a4[k+4])
 #pragma unroll
-    for (int k = 0; k < 16; k++) a4[k] = min(a2[k], a2[(k + 2) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) a8[k] = min(a4[k], a4[(k + 4) & 15]);
-    int best = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) best = max(best, min(a8[k], d[(k + 8) & 15]));
-    return best - 1;
+    for (int j = 0; j < 8; j++) B[j] = as_u32(__builtin_elementwise_min(as_v2s(A[j]), as_v2s(X[(j + 4) & 7])));                                          // a9[k] = min(a8[k], x[k+8])
+    v2s m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_max(as_v2s(B[0]), as_v2s(B[1])), __builtin_elementwise_max(as_v2s(B[2]), as_v2s(B[3]))),
+                                      __builtin_elementwise_max(__builtin_elementwise_max(as_v2s(B[4]), as_v2s(B[5])), __builtin_elementwise_max(as_v2s(B[6]), as_v2s(B[7]))));
+    return max((int)m.x, (int)m.y);
 }
 
-// dynamic LDS layout (bytes): [16 pad][tile rows*FT_PITCH][score (rows-4)*FS_PITCH][cand/corner u16 x ncand][list u32 x CELL_CAP]  (~10 KB -> 16 cells per CU)
-__global__ __launch_bounds__(64) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t slab, PyrDev P,
-                                                   const CellDesc* __restrict__ cells, int n_cells,
-                                                   int ini_th, int min_th, int lds_rows, int lds_ncand,
-                                                   uint32_t* __restrict__ slots, int* __restrict__ counts)
+// Threshold-free score of the pixel at LDS tile position t for the arc families the pre-test left possible (fl bit 1: bright, bit 0: dark):
+// S = (max over arcs of the arc's min one-signed difference) - 1 if that maximum exceeds th (corner at th: cv::FAST's score, the largest threshold at which
+// the pixel is still a corner), else 0.
+__device__ __forceinline__ int fast_score_pk(const uint8_t* t, int th, int fl)
+{
+    const uint32_t v = t[0];
+    uint32_t P[8];
+    P[0] = t[3 * FS_PITCH] | ((uint32_t)t[3 * FS_PITCH + 1] << 16);  P[1] = t[2 * FS_PITCH + 2] | ((uint32_t)t[FS_PITCH + 3] << 16);
+    P[2] = t[3] | ((uint32_t)t[-FS_PITCH + 3] << 16);                P[3] = t[-2 * FS_PITCH + 2] | ((uint32_t)t[-3 * FS_PITCH + 1] << 16);
+    P[4] = t[-3 * FS_PITCH] | ((uint32_t)t[-3 * FS_PITCH - 1] << 16); P[5] = t[-2 * FS_PITCH - 2] | ((uint32_t)t[-FS_PITCH - 3] << 16);
+    P[6] = t[-3] | ((uint32_t)t[FS_PITCH - 3] << 16);                P[7] = t[2 * FS_PITCH - 2] | ((uint32_t)t[3 * FS_PITCH - 1] << 16);
+    const v2s V = as_v2s(v | (v << 16));
+    uint32_t X[8];
+    const bool dark_first = (fl & 2) == 0;                 // only the dark family can fire
+    const uint32_t M = dark_first ? 0xffffffffu : 0u;      // x -> -x per 16-bit lane: (x ^ M) - M
+#pragma unroll
+    for (int j = 0; j < 8; j++) X[j] = as_u32((v2s)(as_v2s(as_u32((v2s)(as_v2s(P[j]) - V)) ^ M) - as_v2s(M)));
+    int m = fast_arc_minmax(X);
+    if (__builtin_amdgcn_ballot_w64(fl == 3) != 0) {      // both families passed the pre-test for some lane (rare): evaluate the dark one as well there
+        if (fl == 3) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) X[j] = as_u32((v2s)(V - as_v2s(P[j])));
+            m = max(m, fast_arc_minmax(X));
+        }
+    }
+    return m > th ? m - 1 : 0;
+}
+
+// dynamic LDS per wave (bytes): [16 pad][tile sh x FS_PITCH][score (ih + 2) x FS_SPITCH][aq u32 x FS_AQ_CAP][cand u16 x FS_CAND_CAP][corner u16 x 2 x FS_CAND_CAP]
+__global__ __launch_bounds__(64) void k_fast_strips(const uint8_t* __restrict__ pyr, size_t slab, PyrDev P,
+                                                    const FastStrip* __restrict__ strips, int n_cells, const int* __restrict__ slot_off, int slot_total,
+                                                    int ini_th, int min_th, int lds_rows, uint32_t* __restrict__ slots, int* __restrict__ counts)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    uint8_t* tile = lds_raw + 16;                                    // quads at column 0 peek one dword to the left
-    uint8_t* sc = tile + lds_rows * FT_PITCH;
-    uint16_t* cand = (uint16_t*)(sc + (lds_rows - 4) * FS_PITCH);
-    uint16_t* corners = cand;                                        // in-place ordered compaction: a corner is written at or before the slot it was read from
-    uint32_t* listA = (uint32_t*)(cand + lds_ncand);
-    int cell, f; xcd_tile_frame(cell, f);
+    uint8_t* tile = lds_raw + 16;
+    uint8_t* sc = tile + lds_rows * FS_PITCH;
+    uint32_t* aq = (uint32_t*)(sc + (lds_rows - 4) * FS_SPITCH);
+    uint16_t* cand = (uint16_t*)(aq + FS_AQ_CAP);
+    uint16_t* corn = cand + FS_CAND_CAP;                            // two buffers of FS_CAND_CAP
+    int sidx, f; xcd_tile_frame(sidx, f);
     const int lane = threadIdx.x;
-    const CellDesc c = cells[cell];
-    const int pitch = P.pitch[c.level];
-    const uint8_t* img = pyr + (size_t)f * slab + P.off[c.level];
-    const int xa = c.x0 & ~3, shift = c.x0 - xa;
-    const int nd = ((c.x0 + c.sw + 3) >> 2) - (xa >> 2);            // dwords per tile row
-    for (int i = lane; i < nd * c.sh; i += 64) {
+    const FastStrip S = strips[sidx];
+    const int pitch = P.pitch[S.level];
+    const uint8_t* img = pyr + (size_t)f * slab + P.off[S.level];
+    const int xa = S.x0 & ~3, shift = S.x0 - xa;
+    const int nd = ((S.x0 + S.sw + 3) >> 2) - (xa >> 2);          // dwords per tile row
+    for (int i = lane; i < nd * S.sh; i += 64) {
         const int row = i / nd, col = i - row * nd;
-        *(uint32_t*)(tile + row * FT_PITCH + 4 * col) = *(const uint32_t*)(img + (size_t)(c.y0 + row) * pitch + xa + 4 * col);
+        *(uint32_t*)(tile + row * FS_PITCH + 4 * col) = *(const uint32_t*)(img + (size_t)(S.y0 + row) * pitch + xa + 4 * col);
     }
-    const int iw = c.sw - 6, ih = c.sh - 6;
-    for (int i = lane; i < (ih + 2) * (FS_PITCH / 4); i += 64) ((uint32_t*)sc)[i] = 0;
-    __syncthreads();
-    // The reference runs cv::FAST at iniThFAST and only re-runs the cell at minThFAST when that came back empty
-    // (ORBextractor.cc:799-806).  Same control flow here (wave-uniform): pass 0 works on the far smaller
-    // candidate set of the high threshold; the score map is threshold-free, so pass 1 only adds entries.
-    const int tx0 = shift + 3;                                       // tile column of interior x = 0
-    const int qc0 = tx0 >> 2, nq = ((tx0 + iw - 1) >> 2) - qc0 + 1, ntask = ih * nq;
+    const int iw = S.sw - 6, ih = S.sh - 6;
+    for (int i = lane; i < (ih + 2) * (FS_SPITCH / 4); i += 64) ((uint32_t*)sc)[i] = 0;
+    __builtin_amdgcn_s_waitcnt(0);                                  // single wave: LDS is coherent within it once the accesses have completed
+    __builtin_amdgcn_wave_barrier();
+    const int tx0 = shift + 3;                                      // tile column of interior x = 0
     const unsigned long long ltmask = (1ull << lane) - 1ull;
-    bool overflow = false;
-    int n = 0;
-    for (int pass = 0; pass < 2 && n == 0; pass++) {
-        const int th = pass == 0 ? ini_th : min_th;
-        // ---- phase a: compass pre-test, 4 horizontally adjacent pixels per lane (aligned quad), ordered compaction
-        int ncand = 0;
-        for (int t0 = 0; t0 < ntask; t0 += 64) {
-            const int t = t0 + lane;
-            uint32_t m4 = 0; int iy = 0, txq = 0;
-            if (t < ntask) {
-                iy = t / nq; const int qc = qc0 + (t - iy * nq);
-                txq = 4 * qc;
-                const uint8_t* base = tile + iy * FT_PITCH + txq;        // row iy = centre row - 3
-                const uint32_t up = *(const uint32_t*)base, dn = *(const uint32_t*)(base + 6 * FT_PITCH);
-                const uint32_t* q = (const uint32_t*)(base + 3 * FT_PITCH - 4);
-                const uint32_t mid[3] = {q[0], q[1], q[2]};
-                const int ixq = txq - tx0;                               // interior x of the quad's first pixel (may be < 0)
-                const int plo = max(0, -ixq), phi = min(4, iw - ixq);    // pixels plo .. phi-1 of the quad are interior
-                const uint32_t valid = phi > plo ? ((1u << phi) - 1u) & ~((1u << plo) - 1u) : 0u;
-                m4 = fast_compass_quad(up, mid, dn, th) & valid;
-            }
-            const unsigned long long b0 = __ballot(m4 & 1), b1 = __ballot(m4 & 2), b2 = __ballot(m4 & 4), b3 = __ballot(m4 & 8);
-            int pos = ncand + __popcll(b0 & ltmask) + __popcll(b1 & ltmask) + __popcll(b2 & ltmask) + __popcll(b3 & ltmask);
+    const int bx1 = S.ncell > 1 ? S.bx[1] : 0x7fff, bx2 = S.ncell > 2 ? S.bx[2] : 0x7fff, bx3 = S.ncell > 3 ? S.bx[3] : 0x7fff;
+    int ncnt[FS_MAXC] = {0, 0, 0, 0};
+    uint32_t* out = slots + (size_t)f * slot_total;
+    int so[FS_MAXC];
 #pragma unroll
-            for (int p = 0; p < 4; p++) if (m4 & (1u << p)) { if (pos < lds_ncand) cand[pos] = (uint16_t)(iy * 128 + (txq - tx0 + p)); pos++; }
-            ncand += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
-        }
-        overflow |= ncand > lds_ncand;                               // reported through the count (> VIDO_CELL_CAP => VIDO_E_CAPACITY)
-        ncand = min(ncand, lds_ncand);
-        __syncthreads();
-        // ---- phase b: full segment test + score, one candidate per lane; corners keep the row-major order
-        int ncorn = 0;
-        for (int q0 = 0; q0 < ncand; q0 += 64) {
+    for (int c = 0; c < FS_MAXC; c++) so[c] = c < S.ncell ? slot_off[S.cell0 + c] : 0;
+
+    // per-sub-image NMS + ordered emission of the corners in list cl[0..n): strictly greater than the 8 neighbours (gutters / never-written entries are 0)
+    auto nms_emit = [&](const uint16_t* cl, int n) {
+        for (int q0 = 0; q0 < n; q0 += 64) {
             const int q = q0 + lane;
-            int S = 0; uint16_t code = 0;
-            if (q < ncand) {
-                code = cand[q];
-                const int iy = code >> 7, ix = code & 127;
-                S = fast_score(tile + (iy + 3) * FT_PITCH + tx0 + ix, th);
-                if (S > 0) sc[(iy + 1) * FS_PITCH + ix + 1] = (uint8_t)S;
-            }
-            const unsigned long long bc = __ballot(S > 0);
-            if (S > 0) corners[ncorn + __popcll(bc & ltmask)] = code;
-            ncorn += __popcll(bc);
-        }
-        __syncthreads();
-        // ---- phase c: per-sub-image 3x3 NMS (strictly greater than the 8 neighbours' scores at this threshold;
-        // the score tile only holds scores >= th), emission in row-major order
-        for (int q0 = 0; q0 < ncorn; q0 += 64) {
-            const int q = q0 + lane;
-            bool keep = false; uint32_t packed = 0;
-            if (q < ncorn) {
-                const int iy = corners[q] >> 7, ix = corners[q] & 127;
-                const uint8_t* s = sc + (iy + 1) * FS_PITCH + ix + 1;
-                const int S = s[0];
-                const int n0 = s[-FS_PITCH - 1], n1 = s[-FS_PITCH], n2 = s[-FS_PITCH + 1], n3 = s[-1],
-                          n4 = s[1], n5 = s[FS_PITCH - 1], n6 = s[FS_PITCH], n7 = s[FS_PITCH + 1];
+            bool keep = false; uint32_t packed = 0; int c = 0;
+            if (q < n) {
+                const int code = cl[q]; const int iy = code >> 10, ix = (code >> 2) & 255; c = code & 3;
+                const uint8_t* s = sc + (iy + 1) * FS_SPITCH + ix + c + 1;
+                const int Sv = s[0];
+                const int n0 = s[-FS_SPITCH - 1], n1 = s[-FS_SPITCH], n2 = s[-FS_SPITCH + 1], n3 = s[-1], n4 = s[1], n5 = s[FS_SPITCH - 1], n6 = s[FS_SPITCH], n7 = s[FS_SPITCH + 1];
                 const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-                keep = S > mx;
-                packed = (uint32_t)(c.x0 + 3 + ix) | ((uint32_t)(c.y0 + 3 + iy) << 12) | ((uint32_t)S << 24);
+                keep = Sv > mx;
+                packed = (uint32_t)(S.x0 + 3 + ix) | ((uint32_t)(S.y0 + 3 + iy) << 12) | ((uint32_t)Sv << 24);
             }
-            const unsigned long long bk = __ballot(keep);
-            if (keep) { const int pos = n + __popcll(bk & ltmask); if (pos < VIDO_CELL_CAP) listA[pos] = packed; }
-            n += __popcll(bk);
+#pragma unroll
+            for (int cc = 0; cc < FS_MAXC; cc++) {
+                const unsigned long long b = __ballot(keep && c == cc);
+                if (keep && c == cc) out[so[cc] + ncnt[cc] + __popcll(b & ltmask)] = packed;
+                ncnt[cc] += __popcll(b);
+            }
         }
-        __syncthreads();
+    };
+
+    // one pass over interior columns [xlo, xhi) at threshold th
+    auto process = [&](int xlo, int xhi, int th) {
+        const int qc0 = (tx0 + xlo) >> 2, nq = ((tx0 + xhi - 1) >> 2) - qc0 + 1;
+        const uint32_t T2 = (uint32_t)th | ((uint32_t)th << 16);
+        int R = ih, r0 = 0, prev_n = 0, kb = 0;
+        while (r0 < ih) {
+            const int r1 = min(r0 + R, ih), ntask = (r1 - r0) * nq;
+            // ---- phase a: compass pre-test, one aligned quad per lane, surviving quads -> aq (ordered)
+            int naq = 0;
+            int row = r0 + lane / nq, qq = lane - (lane / nq) * nq;
+            const int dq = 64 % nq, dr = 64 / nq;
+            for (int t0 = 0; t0 < ntask; t0 += 64) {
+                uint32_t Rb = 0; int ixq = 0;
+                if (t0 + lane < ntask) {
+                    const int txq = 4 * (qc0 + qq);
+                    const uint8_t* base = tile + row * FS_PITCH + txq;             // row `row` = centre row - 3 in tile rows
+                    const uint32_t up = *(const uint32_t*)base, dn = *(const uint32_t*)(base + 6 * FS_PITCH);
+                    const uint32_t* q = (const uint32_t*)(base + 3 * FS_PITCH - 4);
+                    ixq = txq - tx0;                                               // interior x of the quad's first pixel (may be < xlo)
+                    const int plo = max(0, xlo - ixq), phi = min(4, xhi - ixq);    // pixels plo .. phi-1 of the quad are inside [xlo, xhi)
+                    uint32_t valid = 0;                                            // (bright, dark) bit pairs of the valid pixels, in R's layout
+                    if (plo <= 0 && phi > 0) valid |= 0x0000c000u;
+                    if (plo <= 1 && phi > 1) valid |= 0xc0000000u;
+                    if (plo <= 2 && phi > 2) valid |= 0x00003000u;
+                    if (plo <= 3 && phi > 3) valid |= 0x30000000u;
+                    Rb = fast_compass_quad2(up, q[0], q[1], q[2], dn, T2) & valid;
+                }
+                const unsigned long long b = __ballot(Rb != 0);
+                if (Rb != 0) { const int pos = naq + __popcll(b & ltmask); if (pos < FS_AQ_CAP) aq[pos] = ((uint32_t)row << 16) | ((uint32_t)(ixq + 4) << 8) | (((Rb & 0xf000f000u) >> 12 | (Rb & 0xf000f000u) >> 24) & 0xffu); }
+                naq += __popcll(b);
+                qq += dq; row += dr; if (qq >= nq) { qq -= nq; row++; }
+            }
+            if (naq > FS_AQ_CAP) { R = max((R + 1) >> 1, FS_RMIN); continue; }        // wave-uniform: redo this chunk with half the rows (FS_RMIN rows always fit)
+            __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+            // ---- expansion: quads -> per-pixel candidates (row-major order kept): flags byte = [3:2] px0, [7:6] px1, [1:0] px2, [5:4] px3
+            int ncand = 0;
+            for (int a0 = 0; a0 < naq; a0 += 64) {
+                const uint32_t e = a0 + lane < naq ? aq[a0 + lane] : 0u;
+                const uint32_t f0 = (e >> 2) & 3, f1 = (e >> 6) & 3, f2 = e & 3, f3 = (e >> 4) & 3;
+                const unsigned long long b0 = __ballot(f0 != 0), b1 = __ballot(f1 != 0), b2 = __ballot(f2 != 0), b3 = __ballot(f3 != 0);
+                int pos = ncand + __popcll(b0 & ltmask) + __popcll(b1 & ltmask) + __popcll(b2 & ltmask) + __popcll(b3 & ltmask);
+                const int codeq = (int)((e >> 16) << 10) + (((int)((e >> 8) & 0xff) - 4) * 4);      // (row << 10) + (ix << 2) of pixel 0; its ix may be -3..-1 (that pixel is then invalid): sums, not ORs
+                if (f0) { if (pos < FS_CAND_CAP) cand[pos] = (uint16_t)(codeq | f0); pos++; }
+                if (f1) { if (pos < FS_CAND_CAP) cand[pos] = (uint16_t)((codeq + 4) | f1); pos++; }
+                if (f2) { if (pos < FS_CAND_CAP) cand[pos] = (uint16_t)((codeq + 8) | f2); pos++; }
+                if (f3) { if (pos < FS_CAND_CAP) cand[pos] = (uint16_t)((codeq + 12) | f3); pos++; }
+                ncand += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+            }
+            if (ncand > FS_CAND_CAP) { R = max((R + 1) >> 1, FS_RMIN); continue; }
+            __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+            // ---- phase b: segment test + score, 64 candidates per iteration; corners -> score tile + corner list (ordered)
+            uint16_t* cl = corn + kb * FS_CAND_CAP;
+            int ncorn = 0;
+            for (int q0 = 0; q0 < ncand; q0 += 64) {
+                const int q = q0 + lane;
+                int Sv = 0, code = 0, c = 0;
+                if (q < ncand) {
+                    code = cand[q];
+                    const int iy = code >> 10, ix = (code >> 2) & 255;
+                    Sv = fast_score_pk(tile + (iy + 3) * FS_PITCH + tx0 + ix, th, code & 3);
+                    c = (ix >= bx1) + (ix >= bx2) + (ix >= bx3);
+                    if (Sv > 0) sc[(iy + 1) * FS_SPITCH + ix + c + 1] = (uint8_t)Sv;
+                }
+                const unsigned long long bc = __ballot(Sv > 0);
+                if (Sv > 0) cl[ncorn + __popcll(bc & ltmask)] = (uint16_t)((code & ~3) | c);
+                ncorn += __popcll(bc);
+            }
+            __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+            // ---- phase c, one chunk behind: the corners of the previous chunk now have their row + 1 scores
+            nms_emit(corn + (kb ^ 1) * FS_CAND_CAP, prev_n);
+            prev_n = ncorn; kb ^= 1; r0 = r1;
+        }
+        nms_emit(corn + (kb ^ 1) * FS_CAND_CAP, prev_n);
+    };
+
+    // The reference runs cv::FAST at iniThFAST and re-runs a cell at minThFAST only when that came back empty (ORBextractor.cc:799-806)
+    process(0, iw, ini_th);
+#pragma unroll 1
+    for (int c = 0; c < S.ncell; c++) {                              // (not unrolled: one more copy of the pass instead of four)
+        const int nc = c == 0 ? ncnt[0] : (c == 1 ? ncnt[1] : (c == 2 ? ncnt[2] : ncnt[3]));
+        const int lo = c == 0 ? 0 : (c == 1 ? bx1 : (c == 2 ? bx2 : bx3)), hi = c + 1 == S.ncell ? iw : (c == 0 ? bx1 : (c == 1 ? bx2 : bx3));
+        if (nc == 0) process(lo, hi, min_th);
     }
-    const uint32_t* list = listA;
-    const size_t ci = (size_t)f * n_cells + cell;
-    if (lane == 0) counts[ci] = overflow ? VIDO_CELL_CAP + 1 : n;
-    for (int i = lane; i < min(n, VIDO_CELL_CAP); i += 64) slots[ci * VIDO_CELL_CAP + i] = list[i];
+    if (lane < S.ncell) {
+        const int v = lane == 0 ? ncnt[0] : (lane == 1 ? ncnt[1] : (lane == 2 ? ncnt[2] : ncnt[3]));
+        counts[(size_t)f * n_cells + S.cell0 + lane] = v;
+    }
 }
 
 // K3: exclusive scan of the per-cell counts (frame-major, reference cell order) -> dense offsets;
 // also the per-(frame, level) start offsets the host needs.  One workgroup of 1024 threads.
 __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ counts, int n, int* __restrict__ offsets,
                                                       int n_cells, int n_frames, int n_levels,
-                                                      const int* __restrict__ first_cell, int* __restrict__ lvloff,
-                                                      int* __restrict__ overflow)
+                                                      const int* __restrict__ first_cell, int* __restrict__ lvloff)
 {
     // every wave owns a contiguous segment and walks it 64 entries at a time (coalesced loads, shuffle scan); the 16 segment
     // totals are combined through LDS
@@ -348,13 +414,12 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ co
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int seg = (((n + 15) / 16) + 63) & ~63;
     const int beg = wave * seg, end = min(beg + seg, n);
-    int s = 0, ovf = 0;
+    int s = 0;
 #pragma unroll 4
-    for (int i = beg + lane; i < end; i += 64) { int c = counts[i]; if (c > VIDO_CELL_CAP) { ovf = 1; c = VIDO_CELL_CAP; } s += c; }
+    for (int i = beg + lane; i < end; i += 64) s += counts[i];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
     if (lane == 0) wtot[wave] = s;
-    if (ovf) *overflow = 1;
     __syncthreads();
     int run = 0, total = 0;
 #pragma unroll
@@ -362,7 +427,7 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ co
 #pragma unroll 4
     for (int i0 = beg; i0 < end; i0 += 64) {
         const int i = i0 + lane;
-        const int c = i < end ? min(counts[i], VIDO_CELL_CAP) : 0;
+        const int c = i < end ? counts[i] : 0;
         int inc = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
@@ -379,12 +444,13 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ co
     if (tid == 0) lvloff[n_frames * n_levels] = total;
 }
 
-__global__ __launch_bounds__(64) void k_gather_cands(const uint32_t* __restrict__ slots, const int* __restrict__ counts,
-                                                     const int* __restrict__ offsets, int n_cells, uint32_t* __restrict__ dense, int cap)
+__global__ __launch_bounds__(64) void k_gather_cands(const uint32_t* __restrict__ slots, const int* __restrict__ counts, const int* __restrict__ offsets,
+                                                     const int* __restrict__ slot_off, int slot_total, int n_cells, uint32_t* __restrict__ dense, int cap)
 {
     const size_t ci = (size_t)blockIdx.y * n_cells + blockIdx.x;
-    const int n = min(counts[ci], VIDO_CELL_CAP), off = offsets[ci];
-    for (int i = threadIdx.x; i < n; i += 64) if (off + i < cap) dense[off + i] = slots[ci * VIDO_CELL_CAP + i];
+    const int n = counts[ci], off = offsets[ci];
+    const uint32_t* src = slots + (size_t)blockIdx.y * slot_total + slot_off[blockIdx.x];
+    for (int i = threadIdx.x; i < n; i += 64) if (off + i < cap) dense[off + i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -454,7 +520,7 @@ __global__ __launch_bounds__(QT_NT) void k_quadtree(const uint32_t* __restrict__
     const int nfr = gridDim.x / L, l = blockIdx.x / nfr, task = (blockIdx.x - l * nfr) * L + l, tid = threadIdx.x;
     const int beg = lvloff[task], n = lvloff[task + 1] - beg, N = budget[l];
     // a FAST cell or the candidate buffer overflowed: the host reports VIDO_E_CAPACITY; nothing downstream may touch the lists
-    if (n <= 0 || *overflow != 0 || lvloff[gridDim.x] > cand_cap) { if (tid == 0) selcnt[task] = 0; return; }
+    if (n <= 0 || *overflow != 0 || lvloff[gridDim.x] > cand_cap) { if (tid == 0) selcnt[task] = 0; return; }     // (the candidate buffer is sized for the worst case; defensive)
     const int minB = EDGE_THRESHOLD - 3, width = P.w[l] - 2 * minB, height = P.h[l] - 2 * minB;
     const uint32_t* cd = cand + beg; uint16_t* slot = slot_scratch + beg;
     // ---- initial column nodes (ORBextractor.cc:534-560)
@@ -592,13 +658,13 @@ __global__ __launch_bounds__(QT_NT) void k_quadtree(const uint32_t* __restrict__
         Lc = Lnew;
     }
     // ---- best keypoint per node, list order
-    // key = response << 16 | (65535 - input index): n <= VIDO_MAX_CAND_PER_FRAME < 65536 (the slot map is u16 for the same reason)
-    unsigned* best = (unsigned*)childcnt;
-    for (int s = tid; s < Lc; s += QT_NT) best[s] = 0u;
+    // key = response << 32 | ~input index (64-bit LDS max: a level can hold more than 65535 candidates — a noise image yields one per 2x2 pixels)
+    unsigned long long* best = (unsigned long long*)childcnt;        // childcnt..childslot: 8 * qcap ints
+    for (int s = tid; s < Lc; s += QT_NT) best[s] = 0ull;
     qt_barrier();
-    for (int i = tid; i < n; i += QT_NT) atomicMax(&best[slot[i]], ((cd[i] >> 24) << 16) | (unsigned)(65535 - i));
+    for (int i = tid; i < n; i += QT_NT) atomicMax(&best[slot[i]], ((unsigned long long)(cd[i] >> 24) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i));
     qt_barrier();
-    for (int s = tid; s < Lc; s += QT_NT) sel[(size_t)task * qcap + s] = 65535 - (int)(best[s] & 0xffffu);
+    for (int s = tid; s < Lc; s += QT_NT) sel[(size_t)task * qcap + s] = (int)(0xffffffffu - (unsigned)(best[s] & 0xffffffffull));
     if (tid == 0) selcnt[task] = Lc;
 }
 
@@ -813,7 +879,8 @@ struct OrbState {
     float timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::chrono::steady_clock::time_point t_start;
     int last_frames = 0;
-    int fast_rows = 0, fast_ncand = 0; size_t fast_lds = 0;
+    int fast_rows = 0; size_t fast_lds = 0;
+    FastStrip* d_strips = nullptr; int n_strips = 0; int* d_slot_off = nullptr; int slot_total = 0;      // FAST strips (<= 4 cells each), per-cell output slot offsets, slots per frame
     // device quadtree / keypoint assembly
     uint16_t* d_qt_slot = nullptr; int *d_sel = nullptr, *d_selcnt = nullptr, *d_kpoff = nullptr, *d_frame_beg = nullptr, *d_budget = nullptr;
     int* h_frame_beg = nullptr;
@@ -918,8 +985,6 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
                 if (iniX >= maxBX - 6) continue;
                 if (maxX > maxBX) maxX = (float)maxBX;
                 CellDesc cd{}; cd.level = l; cd.x0 = (int)iniX; cd.y0 = (int)iniY; cd.sw = (int)maxX - (int)iniX; cd.sh = (int)maxY - (int)iniY;
-                if (cd.sw + 3 > FT_PITCH - 4 || cd.sh > FT_ROWS || cd.sw - 6 + 2 > FS_PITCH || cd.sh - 6 + 2 > FS_ROWS)
-                    return vido_set_error(ctx, VIDO_E_INVALID, "FAST cell %dx%d at level %d exceeds the LDS tile (%dx%d)", cd.sw, cd.sh, l, FT_PITCH - 8, FT_ROWS);
                 if (cd.sw < 7 || cd.sh < 7) continue;     // cv::FAST finds nothing in a sub-image thinner than its ring
                 cells.push_back(cd);
             }
@@ -929,12 +994,51 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
             for (int tx = 0; tx < (v.w + BL_TW - 1) / BL_TW; tx++) btiles.push_back(BlurTile{l, tx, ty, 0});
     }
     S->n_cells = (int)cells.size(); S->n_blur_tiles = (int)btiles.size();
-    {   // dynamic LDS of k_fast_cells: sized for the largest cell of this pyramid
-        int max_sh = 8, max_px = 64;
-        for (const CellDesc& cd : cells) { max_sh = std::max(max_sh, cd.sh); max_px = std::max(max_px, (cd.sw - 6) * (cd.sh - 6)); }
-        S->fast_rows = max_sh; S->fast_ncand = (max_px + 63) & ~63;
-        S->fast_lds = 16 + (size_t)max_sh * FT_PITCH + (size_t)(max_sh - 4) * FS_PITCH + sizeof(uint16_t) * S->fast_ncand + sizeof(uint32_t) * VIDO_CELL_CAP + 16;
+    // FAST strips: runs of up to FS_MAXC horizontally adjacent cells of one cell row (consecutive in the reference order), split evenly; per-cell output slots
+    std::vector<FastStrip> strips; std::vector<int> slot_off(cells.size() + 1, 0);
+    {
+        int max_sh = 8;
+        for (size_t c = 0; c < cells.size(); c++) {
+            const CellDesc& cd = cells[c];
+            slot_off[c + 1] = slot_off[c] + ((cd.sw - 6 + 1) / 2) * ((cd.sh - 6 + 1) / 2);      // most 3x3-NMS survivors of a (sw-6) x (sh-6) interior
+            max_sh = std::max(max_sh, cd.sh);
+            if (cd.sw - 6 > FS_MAXIW || cd.sh - 6 > 63)
+                return vido_set_error(ctx, VIDO_E_INVALID, "FAST cell %dx%d at level %d exceeds the strip tile (%dx63 interior)", cd.sw, cd.sh, cd.level, FS_MAXIW);
+        }
+        size_t c0 = 0;
+        while (c0 < cells.size()) {
+            size_t c1 = c0 + 1;                                       // [c0, c1): the cells of one cell row (same level and y0, x adjacent)
+            while (c1 < cells.size() && cells[c1].level == cells[c0].level && cells[c1].y0 == cells[c0].y0 && cells[c1].sh == cells[c0].sh &&
+                   cells[c1].x0 + 3 == cells[c1 - 1].x0 + cells[c1 - 1].sw - 3) c1++;
+            const int ncols = (int)(c1 - c0);
+            int per = FS_MAXC;
+            for (;;) {                                                // widest allowed run that keeps every strip's interior <= FS_MAXIW
+                bool ok = true;
+                const int ns = (ncols + per - 1) / per;
+                for (int k = 0, b = 0; k < ns && ok; k++) { const int len = ncols / ns + (k < ncols % ns ? 1 : 0); int w = 0; for (int j = 0; j < len; j++) w += cells[c0 + b + j].sw - 6; ok = w <= FS_MAXIW; b += len; }
+                if (ok || per == 1) break;
+                per--;
+            }
+            const int ns = (ncols + per - 1) / per;
+            for (int k = 0, b = 0; k < ns; k++) {
+                const int len = ncols / ns + (k < ncols % ns ? 1 : 0);
+                FastStrip st{}; const CellDesc& first = cells[c0 + b]; const CellDesc& last = cells[c0 + b + len - 1];
+                st.level = first.level; st.x0 = first.x0; st.y0 = first.y0; st.sw = last.x0 + last.sw - first.x0; st.sh = first.sh; st.ncell = len; st.cell0 = (int)(c0 + b);
+                for (int j = 0; j <= FS_MAXC; j++) st.bx[j] = st.sw - 6;
+                for (int j = 0; j < len; j++) st.bx[j] = cells[c0 + b + j].x0 - first.x0;
+                st.bx[len] = st.sw - 6;
+                strips.push_back(st); b += len;
+            }
+            c0 = c1;
+        }
+        S->n_strips = (int)strips.size(); S->slot_total = slot_off[cells.size()];
+        S->fast_rows = max_sh;
+        S->fast_lds = 16 + (size_t)max_sh * FS_PITCH + (size_t)(max_sh - 4) * FS_SPITCH + sizeof(uint32_t) * FS_AQ_CAP + sizeof(uint16_t) * 3 * FS_CAND_CAP + 16;
     }
+    HIP_TRY(ctx, hipMalloc(&S->d_strips, strips.size() * sizeof(FastStrip)));
+    HIP_TRY(ctx, hipMemcpy(S->d_strips, strips.data(), strips.size() * sizeof(FastStrip), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMalloc(&S->d_slot_off, slot_off.size() * sizeof(int)));
+    HIP_TRY(ctx, hipMemcpy(S->d_slot_off, slot_off.data(), slot_off.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMalloc(&S->d_cells, cells.size() * sizeof(CellDesc)));
     HIP_TRY(ctx, hipMemcpy(S->d_cells, cells.data(), cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMalloc(&S->d_btiles, btiles.size() * sizeof(BlurTile)));
@@ -961,13 +1065,14 @@ int orb_state_create(vido_ctx* ctx)
     if (rc != VIDO_OK) return rc;
     const size_t B = S->B;
     const size_t ncell = (size_t)S->n_cells * B;
-    S->cand_cap = (size_t)VIDO_MAX_CAND_PER_FRAME * B;
+    S->cand_cap = (size_t)S->slot_total * B;          // every output slot of every cell filled: nothing an image contains can overflow the candidate buffers
     S->kp_cap = (size_t)(ctx->cfg.n_features * 2 + 256) * B;
     HIP_TRY(ctx, hipMalloc(&S->d_pyr, S->slab * B));
     HIP_TRY(ctx, hipMalloc(&S->d_blur, S->slab * B));
     HIP_TRY(ctx, hipMemset(S->d_pyr, 0, S->slab * B));
     HIP_TRY(ctx, hipMemset(S->d_blur, 0, S->slab * B));
-    HIP_TRY(ctx, hipMalloc(&S->d_slots, ncell * VIDO_CELL_CAP * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&S->d_slots, (size_t)S->slot_total * B * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_fast_strips, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->fast_lds));
     HIP_TRY(ctx, hipMalloc(&S->d_counts, ncell * sizeof(int)));
     HIP_TRY(ctx, hipMalloc(&S->d_offsets, (ncell + 1) * sizeof(int)));
     HIP_TRY(ctx, hipMalloc(&S->d_lvloff, (B * S->L + 1) * sizeof(int)));
@@ -977,7 +1082,7 @@ int orb_state_create(vido_ctx* ctx)
     HIP_TRY(ctx, hipMalloc(&S->d_kp, S->kp_cap * sizeof(uint2)));
     HIP_TRY(ctx, hipHostMalloc(&S->h_lvloff, (B * S->L + 1) * sizeof(int)));
     HIP_TRY(ctx, hipHostMalloc(&S->h_overflow, sizeof(int)));
-    HIP_TRY(ctx, hipHostMalloc(&S->h_cand, S->cand_cap * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipHostMalloc(&S->h_cand, (size_t)S->slot_total * sizeof(uint32_t)));          // debug read-back buffer: one (frame, level) list at most
     for (auto& e : S->ev) HIP_TRY(ctx, hipEventCreate(&e));
     HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_done, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&S->ev_pyr, hipEventDisableTiming)); HIP_TRY(ctx, hipEventCreate(&S->ev_qt));
@@ -1014,7 +1119,7 @@ void orb_state_destroy(vido_ctx* ctx)
     if (!S) return;
     hipFree(S->d_pyr); hipFree(S->d_blur); hipFree(S->d_cells); hipFree(S->d_btiles); hipFree(S->d_xtab); hipFree(S->d_ytab);
     hipFree(S->d_slots); hipFree(S->d_counts); hipFree(S->d_offsets); hipFree(S->d_first_cell); hipFree(S->d_lvloff); hipFree(S->d_overflow);
-    hipFree(S->d_cand); hipFree(S->d_kp);
+    hipFree(S->d_cand); hipFree(S->d_kp); hipFree(S->d_strips); hipFree(S->d_slot_off);
     hipHostFree(S->h_lvloff); hipHostFree(S->h_overflow); hipHostFree(S->h_cand);
     for (auto& e : S->ev) if (e) hipEventDestroy(e);
     if (S->ev_done) hipEventDestroy(S->ev_done);
@@ -1079,12 +1184,11 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     }
     HIP_TRY(ctx, hipEventRecord(S->ev[1], st));
     const int with_desc = ctx->cfg.compute_descriptors ? 1 : 0;
-    hipLaunchKernelGGL(k_fast_cells, dim3(S->n_cells, nf), dim3(64), S->fast_lds, st, S->d_pyr, S->slab, S->P, S->d_cells, S->n_cells,
-                       ctx->cfg.ini_th_fast, ctx->cfg.min_th_fast, S->fast_rows, S->fast_ncand, S->d_slots, S->d_counts);
+    hipLaunchKernelGGL(k_fast_strips, dim3(S->n_strips, nf), dim3(64), S->fast_lds, st, S->d_pyr, S->slab, S->P, S->d_strips, S->n_cells, S->d_slot_off, S->slot_total,
+                       ctx->cfg.ini_th_fast, ctx->cfg.min_th_fast, S->fast_rows, S->d_slots, S->d_counts);
     HIP_TRY(ctx, hipEventRecord(S->ev[7], st));
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, S->d_counts, S->n_cells * nf, S->d_offsets, S->n_cells, nf, L,
-                       S->d_first_cell, S->d_lvloff, S->d_overflow);
-    hipLaunchKernelGGL(k_gather_cands, dim3(S->n_cells, nf), dim3(64), 0, st, S->d_slots, S->d_counts, S->d_offsets, S->n_cells, S->d_cand, (int)S->cand_cap);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, S->d_counts, S->n_cells * nf, S->d_offsets, S->n_cells, nf, L, S->d_first_cell, S->d_lvloff);
+    hipLaunchKernelGGL(k_gather_cands, dim3(S->n_cells, nf), dim3(64), 0, st, S->d_slots, S->d_counts, S->d_offsets, S->d_slot_off, S->slot_total, S->n_cells, S->d_cand, (int)S->cand_cap);
     HIP_TRY(ctx, hipEventRecord(S->ev[2], st));
     // the blur only needs the pyramid: it runs on the second stream, concurrently with the quadtree and the keypoint list kernels (512 latency-bound
     // workgroups that leave most CUs idle; forking before FAST just makes the two full-GPU kernels contend), and joins before orientation + rBRIEF
@@ -1140,8 +1244,7 @@ int orb_collect(vido_ctx* ctx, int nf, int copy)
     HIP_TRY(ctx, hipGetLastError());
     if (*S->h_overflow) {
         const int code = *S->h_overflow; hipMemsetAsync(S->d_overflow, 0, sizeof(int), st);
-        return code == 2 ? vido_set_error(ctx, VIDO_E_CAPACITY, "orb: quadtree node list exceeded %d entries", S->qcap)
-                         : vido_set_error(ctx, VIDO_E_CAPACITY, "orb: a FAST cell produced more than %d corners", VIDO_CELL_CAP);
+        return vido_set_error(ctx, VIDO_E_CAPACITY, code == 2 ? "orb: quadtree node list exceeded %d entries" : "orb: internal overflow flag %d", code == 2 ? S->qcap : code);
     }
     const int total = S->h_lvloff[nf * L];
     if ((size_t)total > S->cand_cap) return vido_set_error(ctx, VIDO_E_CAPACITY, "orb: %d FAST candidates exceed the %zu-entry buffer", total, S->cand_cap);
@@ -1273,7 +1376,7 @@ int vido_orb_read_candidates(vido_ctx* ctx, int frame, int level, uint32_t* out,
     const int task = frame * S->L + level;
     const int beg = S->h_lvloff[task], n = S->h_lvloff[task + 1] - beg;
     if (out && n > 0 && cap > 0) {       // candidates stay on the device in the normal path; this debug read copies one level back
-        const int m = std::min(n, cap);
+        const int m = std::min(std::min(n, cap), S->slot_total);
         HIP_TRY(ctx, hipMemcpyAsync(S->h_cand, S->d_cand + beg, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         memcpy(out, S->h_cand, (size_t)m * sizeof(uint32_t));

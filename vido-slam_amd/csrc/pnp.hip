@@ -119,12 +119,18 @@ __device__ inline double reproj2(const double* R, const double* t, const float* 
     return du * du + dv * dv;
 }
 
-// one workgroup per hypothesis
-__global__ __launch_bounds__(256) void k_pnp_hypotheses(const float* __restrict__ X, const float* __restrict__ x, int n, double fx, double fy, double cx, double cy,
-                                                        uint64_t seed, double thr2, double* __restrict__ models /*[iters][12]*/, int* __restrict__ counts)
+// one workgroup per (hypothesis, problem); problem p owns points [off, off + n) of the concatenated arrays
+struct PnpProb { int off, n; unsigned long long seed; };
+__global__ __launch_bounds__(256) void k_pnp_hypotheses(const float* __restrict__ Xall, const float* __restrict__ xall, const PnpProb* __restrict__ prob, int max_iters,
+                                                        double fx, double fy, double cx, double cy, double thr2, double* __restrict__ models_all /*[prob][iters][12]*/,
+                                                        int* __restrict__ counts_all)
 {
     __shared__ double sR[9], st[3]; __shared__ int has; __shared__ int wcnt[4];
-    const int it = blockIdx.x;
+    const int it = blockIdx.x; const PnpProb pr = prob[blockIdx.y];
+    const int n = pr.n; const uint64_t seed = pr.seed;
+    const float* X = Xall + 3 * (size_t)pr.off; const float* x = xall + 2 * (size_t)pr.off;
+    double* models = models_all + (size_t)blockIdx.y * max_iters * 12; int* counts = counts_all + (size_t)blockIdx.y * max_iters;
+    if (n < 4) { if (threadIdx.x == 0) counts[it] = 0; return; }
     if (threadIdx.x == 0) {
         int idx[4]; sample4(seed, it, n, idx);
         double P[3][3], j[3][3];
@@ -166,14 +172,18 @@ __device__ int ransac_update_iters(double p, double ep, int model_points, int ma
     num = log(num); denom = log(denom);
     return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)llrint(num / denom);
 }
-// sequential bookkeeping of cv::RANSAC over the precomputed hypotheses, then the inlier mask of the winner
-__global__ __launch_bounds__(256) void k_pnp_select(const float* __restrict__ X, const float* __restrict__ x, int n, double fx, double fy, double cx, double cy,
-                                                    int max_iters, double thr2, double conf, const double* __restrict__ models, const int* __restrict__ counts,
-                                                    double* __restrict__ T_out, unsigned char* __restrict__ mask, int* __restrict__ n_inl)
+// sequential bookkeeping of cv::RANSAC over the precomputed hypotheses, then the inlier mask of the winner; one workgroup per problem
+__global__ __launch_bounds__(256) void k_pnp_select(const float* __restrict__ Xall, const float* __restrict__ xall, const PnpProb* __restrict__ prob, double fx, double fy, double cx, double cy,
+                                                    int max_iters, double thr2, double conf, const double* __restrict__ models_all, const int* __restrict__ counts_all,
+                                                    double* __restrict__ T_all /*[prob][16]*/, unsigned char* __restrict__ mask_all, int* __restrict__ n_inl_all)
 {
     __shared__ int sbest;
+    const PnpProb pr = prob[blockIdx.x]; const int n = pr.n;
+    const float* X = Xall + 3 * (size_t)pr.off; const float* x = xall + 2 * (size_t)pr.off;
+    const double* models = models_all + (size_t)blockIdx.x * max_iters * 12; const int* counts = counts_all + (size_t)blockIdx.x * max_iters;
+    double* T_out = T_all + 16 * (size_t)blockIdx.x; unsigned char* mask = mask_all + pr.off; int* n_inl = n_inl_all + blockIdx.x;
     if (threadIdx.x == 0) {
-        int niters = max_iters, best_cnt = 0, best = -1;
+        int niters = n >= 4 ? max_iters : 0, best_cnt = 0, best = -1;
         for (int it = 0; it < niters; it++) {
             const int cnt = counts[it];
             if (cnt > max(best_cnt, 3)) { best_cnt = cnt; best = it; niters = ransac_update_iters(conf, (double)(n - cnt) / n, 4, niters); }
@@ -191,6 +201,48 @@ __global__ __launch_bounds__(256) void k_pnp_select(const float* __restrict__ X,
 struct PnpState { char* d = nullptr; char* h = nullptr; size_t cap = 0; };
 void pnp_state_destroy(vido_ctx* ctx) { PnpState* S = ctx->pnp; if (!S) return; hipFree(S->d); hipHostFree(S->h); delete S; ctx->pnp = nullptr; }
 
+extern "C" int vido_pnp_ransac_batch(vido_ctx* ctx, int n_prob, const float* const* pts3d, const float* const* pts2d, const int32_t* n, double fx, double fy, double cx, double cy,
+                                     int max_iters, double reproj_err, double confidence, const uint64_t* seeds, double* T_out /*[n_prob][16]*/, uint8_t* const* inlier_mask,
+                                     int32_t* n_inliers)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (n_prob < 0 || (n_prob && (!pts3d || !pts2d || !n || !seeds || !T_out || !n_inliers)) || max_iters < 1 || max_iters > 65536) return vido_set_error(ctx, VIDO_E_INVALID, "pnp_ransac_batch: bad arguments");
+    if (n_prob == 0) return VIDO_OK;
+    size_t tot = 0;
+    for (int p = 0; p < n_prob; p++) { if (n[p] < 0 || (n[p] && (!pts3d[p] || !pts2d[p]))) return vido_set_error(ctx, VIDO_E_INVALID, "pnp_ransac_batch: problem %d: bad arguments", p); tot += (size_t)n[p]; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->pnp) ctx->pnp = new PnpState();
+    PnpState* S = ctx->pnp; hipStream_t st = ctx->stream;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_x3 = 0, o_x2 = o_x3 + al(tot * 12), o_pr = o_x2 + al(tot * 8), o_mod = o_pr + al((size_t)n_prob * sizeof(PnpProb)),
+                 o_cnt = o_mod + al((size_t)n_prob * max_iters * 96), o_T = o_cnt + al((size_t)n_prob * max_iters * 4), o_n = o_T + al((size_t)n_prob * 128),
+                 o_mask = o_n + al((size_t)n_prob * 4), total = o_mask + al(tot) + 256;
+    if (total > S->cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (S->d) { hipFree(S->d); hipHostFree(S->h); S->d = nullptr; S->h = nullptr; }
+        S->cap = total + total / 2; HIP_TRY(ctx, hipMalloc((void**)&S->d, S->cap)); HIP_TRY(ctx, hipHostMalloc((void**)&S->h, S->cap));
+    }
+    PnpProb* hp = (PnpProb*)(S->h + o_pr); size_t off = 0;
+    for (int p = 0; p < n_prob; p++) {
+        if (n[p]) { memcpy(S->h + o_x3 + off * 12, pts3d[p], (size_t)n[p] * 12); memcpy(S->h + o_x2 + off * 8, pts2d[p], (size_t)n[p] * 8); }
+        hp[p].off = (int)off; hp[p].n = n[p]; hp[p].seed = seeds[p]; off += (size_t)n[p];
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(S->d, S->h, o_mod, hipMemcpyHostToDevice, st));
+    const float* dX = (const float*)(S->d + o_x3); const float* dx = (const float*)(S->d + o_x2); const PnpProb* dp = (const PnpProb*)(S->d + o_pr);
+    hipLaunchKernelGGL(k_pnp_hypotheses, dim3(max_iters, n_prob), dim3(256), 0, st, dX, dx, dp, max_iters, fx, fy, cx, cy, reproj_err * reproj_err, (double*)(S->d + o_mod), (int*)(S->d + o_cnt));
+    hipLaunchKernelGGL(k_pnp_select, dim3(n_prob), dim3(256), 0, st, dX, dx, dp, fx, fy, cx, cy, max_iters, reproj_err * reproj_err, confidence,
+                       (const double*)(S->d + o_mod), (const int*)(S->d + o_cnt), (double*)(S->d + o_T), (unsigned char*)(S->d + o_mask), (int*)(S->d + o_n));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(S->h + o_T, S->d + o_T, total - 256 - o_T, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    memcpy(T_out, S->h + o_T, (size_t)n_prob * 128);
+    for (int p = 0; p < n_prob; p++) {
+        n_inliers[p] = ((const int*)(S->h + o_n))[p];
+        if (inlier_mask && inlier_mask[p] && n[p]) memcpy(inlier_mask[p], S->h + o_mask + hp[p].off, (size_t)n[p]);
+    }
+    return VIDO_OK;
+}
+
 extern "C" int vido_pnp_ransac(vido_ctx* ctx, const float* pts3d, const float* pts2d, int n, double fx, double fy, double cx, double cy,
                                int max_iters, double reproj_err, double confidence, uint64_t seed, double T_out[16], uint8_t* inlier_mask, int32_t* n_inliers)
 {
@@ -200,27 +252,6 @@ extern "C" int vido_pnp_ransac(vido_ctx* ctx, const float* pts3d, const float* p
     *n_inliers = 0;
     if (inlier_mask && n) memset(inlier_mask, 0, n);
     if (n < 4) return VIDO_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!ctx->pnp) ctx->pnp = new PnpState();
-    PnpState* S = ctx->pnp; hipStream_t st = ctx->stream;
-    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t o_x3 = 0, o_x2 = o_x3 + al((size_t)n * 12), o_mod = o_x2 + al((size_t)n * 8), o_cnt = o_mod + al((size_t)max_iters * 96),
-                 o_T = o_cnt + al((size_t)max_iters * 4), o_mask = o_T + 256, o_n = o_mask + al(n), total = o_n + 256;
-    if (total > S->cap) {
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (S->d) { hipFree(S->d); hipHostFree(S->h); S->d = nullptr; S->h = nullptr; }
-        S->cap = total + total / 2; HIP_TRY(ctx, hipMalloc((void**)&S->d, S->cap)); HIP_TRY(ctx, hipHostMalloc((void**)&S->h, S->cap));
-    }
-    memcpy(S->h + o_x3, pts3d, (size_t)n * 12); memcpy(S->h + o_x2, pts2d, (size_t)n * 8);
-    HIP_TRY(ctx, hipMemcpyAsync(S->d, S->h, o_mod, hipMemcpyHostToDevice, st));
-    const float* dX = (const float*)(S->d + o_x3); const float* dx = (const float*)(S->d + o_x2);
-    hipLaunchKernelGGL(k_pnp_hypotheses, dim3(max_iters), dim3(256), 0, st, dX, dx, n, fx, fy, cx, cy, seed, reproj_err * reproj_err, (double*)(S->d + o_mod), (int*)(S->d + o_cnt));
-    hipLaunchKernelGGL(k_pnp_select, dim3(1), dim3(256), 0, st, dX, dx, n, fx, fy, cx, cy, max_iters, reproj_err * reproj_err, confidence,
-                       (const double*)(S->d + o_mod), (const int*)(S->d + o_cnt), (double*)(S->d + o_T), (unsigned char*)(S->d + o_mask), (int*)(S->d + o_n));
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(S->h + o_T, S->d + o_T, total - o_T, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    memcpy(T_out, S->h + o_T, 128); *n_inliers = *(int*)(S->h + o_n);
-    if (inlier_mask) memcpy(inlier_mask, S->h + o_mask, n);
-    return VIDO_OK;
+    const float* p3[1] = {pts3d}; const float* p2[1] = {pts2d}; uint8_t* mk[1] = {inlier_mask}; const int32_t nn[1] = {n}; const uint64_t sd[1] = {seed};
+    return vido_pnp_ransac_batch(ctx, 1, p3, p2, nn, fx, fy, cx, cy, max_iters, reproj_err, confidence, sd, T_out, mk, n_inliers);
 }

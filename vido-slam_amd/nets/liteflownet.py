@@ -144,11 +144,15 @@ class LiteFlowNet(nn.Module):
             for m in self.modules():
                 if isinstance(m, _Chain):
                     m.epilogue = epilogue
+        # per-channel means as (non-persistent) buffers: the reference builds them with new_tensor inside forward (layers.py:286-287), a host-to-device
+        # copy per call that a hipGraph capture cannot contain; not part of the state dict, so the reference's checkpoints still load unchanged
+        self.register_buffer("_mean_first", torch.tensor(MEAN_FIRST).view(1, 3, 1, 1), persistent=False)
+        self.register_buffer("_mean_second", torch.tensor(MEAN_SECOND).view(1, 3, 1, 1), persistent=False)
 
     @torch.no_grad()
     def forward(self, first, second):
-        first = first - first.new_tensor(MEAN_FIRST).view(1, 3, 1, 1)
-        second = second - second.new_tensor(MEAN_SECOND).view(1, 3, 1, 1)
+        first = first - self._mean_first
+        second = second - self._mean_second
         f1, f2 = self.netFeatures(first), self.netFeatures(second)
         p1, p2 = [first], [second]
         for l in range(1, 6):

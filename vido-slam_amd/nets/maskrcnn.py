@@ -212,6 +212,8 @@ class _RPN(nn.Module):
         return self.proposals(feats, logits, deltas, image_wh)
 
     def proposals(self, feats, logits, deltas, image_wh):
+        if hasattr(self.ops, "nms_segments") and logits[0].is_cuda and self.c.rpn_min_size <= 0:
+            return self.proposals_device(feats, logits, deltas, image_wh)
         c = self.c; W, H = image_wh
         anchors = self.anchor_generator([f.shape[-2:] for f in feats])
         boxes, scores = [], []
@@ -232,6 +234,50 @@ class _RPN(nn.Module):
         return boxes[idx], scores[idx]
 
 
+def _rpn_proposals_device(self, feats, logits, deltas, image_wh):
+    """proposals() without a host round trip: the five levels are decoded into one [levels * k] batch, ONE segmented NMS replaces the five layers.nms
+    calls (each of which ended in a device-to-host count), suppressed entries are carried with objectness -1 instead of being compacted, and the final
+    top-k over all levels sorts them to the end.  Same proposals in the same order as the reference's loop (rpn/inference.py:73-159) whenever at least
+    fpn_post_nms_top_n boxes survive in total (the count is returned on the device; fewer survivors leave trailing zero-area boxes with objectness -1,
+    which the box head masks out)."""
+    c = self.c; W, H = image_wh
+    anchors = self.anchor_generator([f.shape[-2:] for f in feats])
+    K = c.pre_nms_top_n
+    props, objs, ns = [], [], []
+    for a, lo, de in zip(anchors, logits, deltas):
+        A, h, w = lo.shape[1:]
+        obj = lo[0].permute(1, 2, 0).reshape(-1).sigmoid()
+        reg = de[0].view(A, 4, h, w).permute(2, 3, 0, 1).reshape(-1, 4)
+        k = min(K, obj.numel())
+        obj, idx = _topk_stable(obj, k)
+        prop = clip_boxes(self.ops.box_decode(reg[idx], a[idx], (1.0, 1.0, 1.0, 1.0)), W, H)
+        if k < K:                                                        # coarse levels have fewer anchors than pre_nms_top_n: pad the segment (never read by the NMS)
+            prop = torch.cat([prop, prop.new_zeros((K - k, 4))]); obj = torch.cat([obj, obj.new_full((K - k,), -1.0)])
+        props.append(prop); objs.append(obj); ns.append(k)
+    L = len(props)
+    boxes = torch.cat(props); scores = torch.cat(objs)
+    dev = boxes.device
+    key = (L, K, tuple(ns), str(dev))
+    if getattr(self, "_seg_key", None) != key:
+        self._seg_off = torch.arange(L, device=dev, dtype=torch.int32) * K; self._seg_n = torch.tensor(ns, device=dev, dtype=torch.int32); self._seg_key = key
+        self._pos = torch.arange(K, device=dev, dtype=torch.int32).unsqueeze(0).expand(L, K)
+    keep, cnt = self.ops.nms_segments(boxes, self._seg_off, self._seg_n, K, c.rpn_nms)
+    # kept[l, p] <=> position p of level l survived: keep rows are ascending positions padded with -1
+    kept = torch.zeros((L, K + 1), dtype=torch.bool, device=dev)
+    kept.scatter_(1, torch.where(keep >= 0, keep, torch.full_like(keep, K)).long(), True)
+    kept = kept[:, :K]
+    if c.post_nms_top_n < K:                                             # [:post_nms_top_n] of every level's kept list
+        kept &= (kept.cumsum(1) <= c.post_nms_top_n)
+    scores = torch.where(kept.reshape(-1), scores, scores.new_full((), -1.0))
+    k = min(c.fpn_post_nms_top_n, scores.numel())
+    top, idx = _topk_stable(scores, k)
+    valid = top >= 0
+    return torch.where(valid.unsqueeze(1), boxes[idx], boxes.new_zeros(())), top
+
+
+_RPN.proposals_device = _rpn_proposals_device
+
+
 class _Pooler(nn.Module):                  # modeling/poolers.py:11-121
     def __init__(self, resolution, scales, sampling_ratio, ops):
         super().__init__()
@@ -241,6 +287,8 @@ class _Pooler(nn.Module):                  # modeling/poolers.py:11-121
     def forward(self, feats, boxes):
         area = (boxes[:, 2] - boxes[:, 0] + 1) * (boxes[:, 3] - boxes[:, 1] + 1)
         lvl = torch.floor(4 + torch.log2(torch.sqrt(area) / 224 + 1e-6)).clamp(min=self.k_min, max=self.k_max).to(torch.int64) - int(self.k_min)
+        if hasattr(self.ops, "roi_align_fpn") and boxes.is_cuda and len(feats) == 4:       # one launch, no per-level nonzero / gather / scatter
+            return self.ops.roi_align_fpn(feats, boxes, lvl, (self.res, self.res), self.scales, self.sr)
         rois = torch.cat([boxes.new_zeros((len(boxes), 1)), boxes], 1)
         out = feats[0].new_zeros((len(boxes), feats[0].shape[1], self.res, self.res))
         for l, (f, s) in enumerate(zip(feats, self.scales)):
@@ -276,13 +324,15 @@ class _BoxHead(nn.Module):
         self.c, self.ops = c, ops
         self.feature_extractor = _BoxFeatures(c, ops); self.predictor = _BoxPredictor(c)
 
-    def forward(self, feats, proposals, image_wh):
+    def forward(self, feats, proposals, image_wh, objectness=None):
         logits, deltas = self.predictor(self.feature_extractor(feats, proposals))
-        return self.postprocess(logits, deltas, proposals, image_wh)
+        return self.postprocess(logits, deltas, proposals, image_wh, objectness)
 
-    def postprocess(self, logits, deltas, proposals, image_wh):      # box_head/inference.py:47-137
+    def postprocess(self, logits, deltas, proposals, image_wh, objectness=None):      # box_head/inference.py:47-137
         c = self.c; W, H = image_wh; nc = logits.shape[1]
         prob = F.softmax(logits, -1)
+        if objectness is not None and objectness.is_cuda:            # padding rows of the device-side RPN path (objectness -1): no detections from them
+            prob = prob * (objectness >= 0).unsqueeze(1)
         boxes = clip_boxes(self.ops.box_decode(deltas, proposals, c.bbox_reg_weights).reshape(-1, 4), W, H).reshape(-1, nc * 4)
         # the reference loops over the classes (one nonzero + one NMS each); here: one nonzero over (proposal, class), one grouped NMS, and the
         # result put back into the reference's order (class ascending, then proposal index)
@@ -327,6 +377,8 @@ class _MaskPredictor(nn.Module):           # roi_mask_predictors.py:11-31
 
 
 class _MaskHead(nn.Module):
+    buckets = (4, 8, 16, 32, 64, 100)
+
     def __init__(self, c, ops):
         super().__init__()
         self.feature_extractor = _MaskFeatures(c, ops); self.predictor = _MaskPredictor(c)
@@ -334,8 +386,15 @@ class _MaskHead(nn.Module):
     def forward(self, feats, boxes, labels):                         # mask_head/inference.py:29-47: per-detection class channel
         if not len(boxes):
             return feats[0].new_zeros((0, 1, 2 * self.feature_extractor.pooler.res, 2 * self.feature_extractor.pooler.res))
+        n = len(boxes)
+        if boxes.is_cuda and self.buckets:
+            # MIOpen compiles / selects its kernels per problem shape, and the detection count is the batch dimension of the mask head's six convolutions:
+            # round it up to a few fixed sizes (zero-area padding boxes, their rows dropped again) so that a new count never means new kernels
+            m = next((b for b in self.buckets if b >= n), n)
+            if m > n:
+                boxes = torch.cat([boxes, boxes.new_zeros((m - n, 4))]); labels = torch.cat([labels, labels.new_zeros((m - n,))])
         logits = self.predictor(self.feature_extractor(feats, boxes))
-        return logits.sigmoid()[torch.arange(len(boxes), device=labels.device), labels][:, None]
+        return logits.sigmoid()[torch.arange(len(boxes), device=labels.device), labels][:n, None]
 
 
 class _RoiHeads(nn.Module):
@@ -395,9 +454,10 @@ class MaskRCNN(nn.Module):
     def heads(self, feats, logits, deltas, image_hw):
         H, W = image_hw
         proposals, objectness = self.rpn.proposals(feats, logits, deltas, (W, H))
-        boxes, scores, labels = self.roi_heads.box(feats[:len(self.config.pool_scales)], proposals, (W, H))
+        boxes, scores, labels = self.roi_heads.box(feats[:len(self.config.pool_scales)], proposals, (W, H), objectness)
         masks = self.roi_heads.mask(feats[:len(self.config.pool_scales)], boxes, labels)
-        return dict(boxes=boxes, scores=scores, labels=labels, masks=masks, proposals=proposals, objectness=objectness)
+        # proposals / objectness: the device-side RPN path returns fixed-size lists whose trailing rows (objectness -1) are padding; n_proposals counts the real ones
+        return dict(boxes=boxes, scores=scores, labels=labels, masks=masks, proposals=proposals, objectness=objectness, n_proposals=(objectness >= 0).sum())
 
 
 def image_to_feed(bgr, dev, feed=(1088, 800)):
@@ -423,6 +483,9 @@ def analyse_image(net, bgr, feed=(1088, 800), confidence=0.8, trunk=None):
     keep = torch.nonzero(out["scores"] > confidence).squeeze(1)
     keep = keep[out["scores"][keep].sort(0, descending=True)[1]]
     labels = out["labels"][keep]
+    ops = getattr(net.rpn, "ops", None)
+    if hasattr(ops, "mask_label_image") and out["masks"].is_cuda:         # Masker + label image in one HIP pass (no per-detection host loop)
+        return ops.mask_label_image(out["masks"][keep], boxes[keep], labels, H, W), labels
     pasted_kept = paste_masks(out["masks"][keep], boxes[keep], H, W)      # the reference pastes every detection and then selects; only the selected ones reach the output
     # label image = sum over detections of mask * class index, accumulated in u8 (wraps on overlap, like the reference's numpy loop);
     # one reduction on the device instead of a host-synchronising loop over the detections

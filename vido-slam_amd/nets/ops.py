@@ -105,3 +105,40 @@ class HipOps:
         self.ctx._check(self.ctx.lib.vido_nms(self.ctx.h, C.c_void_p(sb.data_ptr()), None, n, C.c_float(thresh), C.c_void_p(keep.data_ptr()), C.c_void_p(cnt.data_ptr()), 1))
         m = int(cnt.item())
         return torch.sort(order[keep[:m].long()])[0]
+
+    # ---- device-only variants used by the no-host-round-trip inference path (nets/maskrcnn.py fast path) ------------------------------------
+    def nms_segments(self, boxes, seg_off, seg_n, max_n, thresh, groups=None):
+        """layers.nms on len(seg_n) independent segments of `boxes` (each sorted by descending score): (keep [n_seg, max_n] positions relative to the
+        segment start, ascending, -1 padded; n_keep [n_seg]) — device tensors, no synchronisation."""
+        boxes = boxes.contiguous().float(); n_seg = seg_n.shape[0]
+        keep = torch.empty((n_seg, max_n), device=boxes.device, dtype=torch.int32); cnt = torch.empty(n_seg, device=boxes.device, dtype=torch.int32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_nms_segments(self.ctx.h, C.c_void_p(boxes.data_ptr()), C.c_void_p(groups.data_ptr()) if groups is not None else None,
+                                                       C.c_void_p(seg_off.data_ptr()), C.c_void_p(seg_n.data_ptr()), n_seg, int(max_n), boxes.shape[0], C.c_float(thresh),
+                                                       C.c_void_p(keep.data_ptr()), C.c_void_p(cnt.data_ptr())))
+        return keep, cnt
+
+    def roi_align_fpn(self, feats, boxes, level, output_size, scales, sampling_ratio):
+        """Pooler.forward in one launch: feats = the 4 FPN maps [1,C,H,W], boxes [n,4], level [n] int32 in 0..3."""
+        n = boxes.shape[0]; ph, pw = output_size; Cc = feats[0].shape[1]
+        out = torch.empty((n, Cc, ph, pw), device=boxes.device, dtype=torch.float32)
+        if n == 0:
+            return out
+        feats = [f.contiguous().float() for f in feats]; boxes = boxes.contiguous().float(); level = level.to(torch.int32).contiguous()
+        fp = (C.c_void_p * 4)(*[f.data_ptr() for f in feats]); Hs = (C.c_int * 4)(*[f.shape[2] for f in feats]); Ws = (C.c_int * 4)(*[f.shape[3] for f in feats])
+        sc = (C.c_float * 4)(*[float(x) for x in scales])
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_roi_align_fpn(self.ctx.h, fp, Hs, Ws, sc, Cc, C.c_void_p(boxes.data_ptr()), C.c_void_p(level.data_ptr()), n, ph, pw, sampling_ratio,
+                                                        C.c_void_p(out.data_ptr())))
+        return out
+
+    def mask_label_image(self, masks, boxes, labels, H, W, thresh=0.5, padding=1):
+        """Masker + label image: masks [n,1,M,M], boxes [n,4] (output image), labels [n] int64 -> [H,W] u8."""
+        out = torch.empty((H, W), device=masks.device, dtype=torch.uint8)
+        n = masks.shape[0]
+        masks = masks.contiguous().float(); boxes = boxes.contiguous().float(); labels = labels.contiguous().to(torch.int64)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_mask_label_image(self.ctx.h, C.c_void_p(masks.data_ptr()) if n else None, C.c_void_p(boxes.data_ptr()) if n else None,
+                                                           C.c_void_p(labels.data_ptr()) if n else None, n, masks.shape[-1] if n else 28, padding, C.c_float(thresh), H, W,
+                                                           C.c_void_p(out.data_ptr())))
+        return out
