@@ -302,6 +302,42 @@ int vido_pnp_ransac(vido_ctx* ctx, const float* pts3d, const float* pts2d, int n
 int vido_pnp_ransac_batch(vido_ctx* ctx, int n_prob, const float* const* pts3d, const float* const* pts2d, const int32_t* n, double fx, double fy, double cx, double cy,
                           int max_iters, double reproj_err, double confidence, const uint64_t* seeds, double* T_out, uint8_t* const* inlier_mask, int32_t* n_inliers);
 
+/* ---- Host-side bookkeeping stages of the tracker on flat arrays (no device work, no ctx; vido-slam_amd/csrc/trackhost.cpp) ---------------------------------
+ * What the C++ facade's Tracking / Frame methods of the same names run; exported so that hosts in other languages and the parity tests can call them. */
+typedef struct vido_host_maps { const int32_t* mask; const float* depth; const float* flow; int32_t width, height; } vido_host_maps;   /* mSegMap / mDepthMap / mFlowMap */
+/* Frame::UndistortKeyPoints (Frame.cc:603-633): cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) — five fixed-point iterations of the Brown model;
+ * K = (fx, fy, cx, cy), dist = (k1, k2, p1, p2, k3); k1 == 0: copy (Frame.cc:605-609). */
+int vido_undistort_points(const float* xy, int n, const float K[4], const float dist[5], float* xy_out);
+/* Tracking::RenewFrameInfo, static part (Tracking.cc:2973-3075): the inliers TM_sta (indices into stat_xy = mvStatKeys, -1 = rejected) that still pass the mask /
+ * depth <= 40 / flow tests, then top-up from sample_xy (= mvKeys) in stride-20 passes, skipping samples closer than 1 px to a kept inlier, until max_num.
+ * Element k of the result: src_out[k] = index into stat_xy (inlier_out[k] >= 0) or into sample_xy (inlier_out[k] == -1), inlier_out[k] (nStaInlierID),
+ * flow_out[2k..] (mvFlowNext).  *n_out = count (VIDO_E_CAPACITY if > cap). */
+int vido_renew_static(const vido_host_maps* maps, const float* stat_xy, int n_stat, const int32_t* TM_sta, int n_tm, const float* sample_xy, int n_sample,
+                      int max_num, int32_t* src_out, int32_t* inlier_out, float* flow_out, int cap, int32_t* n_out);
+/* Tracking::RenewFrameInfo, object part (Tracking.cc:3116-3270).  obj_xy / obj_label: mvObjKeys / vObjLabel of the current frame (n_obj_pts); per tracked object i:
+ * inlier ids inl_ids[inl_off[i] .. inl_off[i+1]) (vnObjInlierID), obj_stat (bObjStat), sem_position (nSemPosition), mod_label (nModLabel); tmp_*: the dense samples
+ * of this frame set aside by GrabImageRGBD (mvTmpObjKeys / Depth / SemObjLabel / FlowNext / Corres).  Outputs = the new mvObjKeys, mvObjDepth, vSemObjLabel,
+ * mvObjFlowNext, mvObjCorres, nDynInlierID, vObjLabel. */
+int vido_renew_objects(const vido_host_maps* maps, const float* obj_xy, const int32_t* obj_label, int n_obj_pts,
+                       int n_objects, const int32_t* inl_off, const int32_t* inl_ids, const uint8_t* obj_stat, const int32_t* sem_position, const int32_t* mod_label,
+                       const float* tmp_xy, const float* tmp_depth, const int32_t* tmp_sem, const float* tmp_flow, const float* tmp_corr, int n_tmp, int max_num_obj,
+                       float* keys_out, float* depth_out, int32_t* sem_out, float* flow_out, float* corr_out, int32_t* inlier_out, int32_t* label_out, int cap, int32_t* n_out);
+/* Tracking::DynObjTracking (Tracking.cc:1670-1912): groups the n object points by semantic label, drops objects mostly on the image border / static (scene flow) /
+ * far / smaller than 150 points (obj_label is updated in place: -1 outlier, 0 static, else the track id), and assigns track ids from the last frame's objects
+ * (last_sem_position / last_obj_stat / last_mod_label, n_last) or from *max_id.  Result: n_objects objects, points of object i = obj_ids[obj_off[i] .. obj_off[i+1]),
+ * mod_label_out (nModLabel), sem_position_out (nSemPosition). */
+int vido_dyn_obj_tracking(const int32_t* sem_label, int32_t* obj_label, const float* obj_xy, const float* obj_depth, const float* flow3d, const int32_t* last_sem_label, int n,
+                          const int32_t* last_sem_position, const uint8_t* last_obj_stat, const int32_t* last_mod_label, int n_last, int rows, int cols,
+                          float sf_mg_thres, float sf_ds_thres, float th_depth_obj, int f_id, int32_t* max_id,
+                          int32_t* obj_off, int32_t* obj_ids, int32_t* mod_label_out, int32_t* sem_position_out, int max_objects, int32_t* n_objects);
+
+/* Tracking::GetStaticTrack / GetDynamicTrackNew (Tracking.cc:2514-2720) through the facade's INCREMENTAL store (Map::UpdateTracklets, one association row per call like
+ * Tracking::Track): row i belongs to frame i+1, TM[row_off[i] + j] = feature of frame i matched by its feature j (-1: none), labels (dynamic store; NULL = static store)
+ * the per-feature object labels.  Tracklet t = (frame, feature) pairs pairs[2*trk_off[t] .. 2*trk_off[t+1]); obj_id[t] (dynamic).  owner_trk / owner_pos (may be NULL):
+ * for every feature of every frame (concatenated), the tracklet of length >= 3 that owns it and its position in it, -1 if none. */
+int vido_tracklets_incremental(int n_rows, const int32_t* row_off, const int32_t* row_n, const int32_t* TM, const int32_t* labels, int n_feat0,
+                               int32_t* trk_off, int32_t* pairs, int32_t* obj_id, int32_t* owner_trk, int32_t* owner_pos, int cap_trk, int cap_pairs, int32_t* n_trk);
+
 /* ---- The whole per-frame pipeline behind one C handle ---------------------------------------------------------------------------
  * VIDO_SLAM::System (System.h:72-114) for hosts that bind C instead of C++ (ctypes / cgo / JNI): System::System() + Init(yaml, RGBD)
  * (System.cc:23-48), TrackRGBD (System.cc:51-63 -> Tracking::GrabImageRGBD, Tracking.cc:283-782 -> Track(), :1081-1509) and

@@ -400,3 +400,72 @@ class OracleNetOps:
     def roi_align(self, feat, rois, output_size, spatial_scale, sampling_ratio):
         import torch
         return torch.from_numpy(self.o.roi_align(feat.numpy(), rois.numpy(), float(spatial_scale), output_size[0], output_size[1], sampling_ratio))
+
+
+# ---- host-side tracking bookkeeping (trackhost_oracle.c): literal restatements of Tracking::RenewFrameInfo / DynObjTracking / GetStaticTrack / GetDynamicTrackNew,
+# Frame::UndistortKeyPoints
+class HostMaps(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("depth", C.c_void_p), ("flow", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+def _maps(mask, depth, flow):
+    mask = np.ascontiguousarray(mask, np.int32); depth = np.ascontiguousarray(depth, np.float32); flow = np.ascontiguousarray(flow, np.float32)
+    h, w = mask.shape
+    return HostMaps(mask.ctypes.data, depth.ctypes.data, flow.ctypes.data, w, h), (mask, depth, flow)
+
+
+def undistort_points(xy, K, dist):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2); out = np.empty_like(xy)
+    K = np.ascontiguousarray(K, np.float32); d = np.zeros(5, np.float32); d[:len(dist)] = dist
+    lib().vo_undistort_points(_p(xy), len(xy), _p(K), _p(d), _p(out))
+    return out
+
+
+def renew_static(mask, depth, flow, stat_xy, TM_sta, sample_xy, max_num):
+    m, keep = _maps(mask, depth, flow)
+    stat_xy = np.ascontiguousarray(stat_xy, np.float32).reshape(-1, 2); TM = np.ascontiguousarray(TM_sta, np.int32); sample_xy = np.ascontiguousarray(sample_xy, np.float32).reshape(-1, 2)
+    cap = len(TM) + len(sample_xy) + 8
+    src = np.zeros(cap, np.int32); inl = np.zeros(cap, np.int32); fl = np.zeros((cap, 2), np.float32)
+    n = lib().vo_renew_static(C.byref(m), _p(stat_xy), _p(TM), len(TM), _p(sample_xy), len(sample_xy), int(max_num), _p(src), _p(inl), _p(fl), cap)
+    assert n <= cap
+    return src[:n], inl[:n], fl[:n]
+
+
+def renew_objects(mask, depth, flow, obj_xy, obj_label, inlier_sets, obj_stat, sem_position, mod_label, tmp_xy, tmp_depth, tmp_sem, tmp_flow, tmp_corr, max_num_obj):
+    m, keep = _maps(mask, depth, flow)
+    obj_xy = np.ascontiguousarray(obj_xy, np.float32).reshape(-1, 2); obj_label = np.ascontiguousarray(obj_label, np.int32)
+    off = np.zeros(len(inlier_sets) + 1, np.int32); off[1:] = np.cumsum([len(s) for s in inlier_sets]) if len(inlier_sets) else 0
+    ids = np.ascontiguousarray(np.concatenate([np.asarray(s, np.int32) for s in inlier_sets]) if len(inlier_sets) and off[-1] else np.zeros(0, np.int32), np.int32)
+    st = np.ascontiguousarray(obj_stat, np.uint8); sp = np.ascontiguousarray(sem_position, np.int32); ml = np.ascontiguousarray(mod_label, np.int32)
+    txy = np.ascontiguousarray(tmp_xy, np.float32).reshape(-1, 2); td = np.ascontiguousarray(tmp_depth, np.float32); ts = np.ascontiguousarray(tmp_sem, np.int32)
+    tf = np.ascontiguousarray(tmp_flow, np.float32).reshape(-1, 2); tc = np.ascontiguousarray(tmp_corr, np.float32).reshape(-1, 2)
+    cap = len(ids) + (len(st) + 1) * len(ts) + 8
+    o = dict(keys=np.zeros((cap, 2), np.float32), depth=np.zeros(cap, np.float32), sem=np.zeros(cap, np.int32), flow=np.zeros((cap, 2), np.float32), corr=np.zeros((cap, 2), np.float32),
+             inlier=np.zeros(cap, np.int32), label=np.zeros(cap, np.int32))
+    n = lib().vo_renew_objects(C.byref(m), _p(obj_xy), _p(obj_label), len(st), _p(off), _p(ids), _p(st), _p(sp), _p(ml), _p(txy), _p(td), _p(ts), _p(tf), _p(tc), len(ts), int(max_num_obj),
+                               _p(o["keys"]), _p(o["depth"]), _p(o["sem"]), _p(o["flow"]), _p(o["corr"]), _p(o["inlier"]), _p(o["label"]), cap)
+    assert n <= cap
+    return {k: v[:n] for k, v in o.items()}
+
+
+def dyn_obj_tracking(sem_label, obj_label, obj_xy, obj_depth, flow3d, last_sem_label, last_sem_position, last_obj_stat, last_mod_label, rows, cols, sf_mg, sf_ds, th_depth_obj, f_id, max_id):
+    sem = np.ascontiguousarray(sem_label, np.int32); lab = np.array(obj_label, np.int32, copy=True); n = len(sem)
+    xy = np.ascontiguousarray(obj_xy, np.float32).reshape(-1, 2); dep = np.ascontiguousarray(obj_depth, np.float32); f3 = np.ascontiguousarray(flow3d, np.float32).reshape(-1, 3)
+    lsem = np.ascontiguousarray(last_sem_label, np.int32); lsp = np.ascontiguousarray(last_sem_position, np.int32); lst = np.ascontiguousarray(last_obj_stat, np.uint8)
+    lml = np.ascontiguousarray(last_mod_label, np.int32); mid = C.c_int32(max_id)
+    off = np.zeros(n + 2, np.int32); ids = np.zeros(n + 1, np.int32); ml = np.zeros(n + 1, np.int32); sp = np.zeros(n + 1, np.int32)
+    f = lib().vo_dyn_obj_tracking
+    k = f(_p(sem), _p(lab), _p(xy), _p(dep), _p(f3), _p(lsem), n, _p(lsp), _p(lst), _p(lml), len(lsp), int(rows), int(cols), C.c_float(sf_mg), C.c_float(sf_ds), C.c_float(th_depth_obj),
+          int(f_id), C.byref(mid), _p(off), _p(ids), _p(ml), _p(sp))
+    return dict(obj_label=lab, objects=[ids[off[i]:off[i + 1]].copy() for i in range(k)], mod_label=ml[:k].copy(), sem_position=sp[:k].copy(), max_id=mid.value)
+
+
+def tracklets(rows, labels=None):
+    """rows[i][j] = matched feature of frame i for feature j of frame i+1 (or -1).  Returns (list of [(frame, feature)...], obj_ids or None)."""
+    n_rows = len(rows); row_n = np.array([len(r) for r in rows], np.int32); row_off = np.zeros(n_rows + 1, np.int32); row_off[1:] = np.cumsum(row_n)
+    TM = np.ascontiguousarray(np.concatenate([np.asarray(r, np.int32) for r in rows]) if row_off[-1] else np.zeros(0, np.int32), np.int32)
+    lab = np.ascontiguousarray(np.concatenate([np.asarray(r, np.int32) for r in labels]), np.int32) if labels is not None and row_off[-1] else None
+    cap_t = int((TM >= 0).sum()) + 1; cap_p = 2 * cap_t + 2
+    off = np.zeros(cap_t + 1, np.int32); pairs = np.zeros((cap_p, 2), np.int32); oid = np.zeros(cap_t, np.int32)
+    nt = lib().vo_tracklets(n_rows, _p(row_off), _p(row_n), _p(TM), _p(lab) if lab is not None else None, _p(off), _p(pairs), _p(oid) if lab is not None else None, cap_t, cap_p)
+    return [[tuple(int(v) for v in pr) for pr in pairs[off[t]:off[t + 1]]] for t in range(nt)], (oid[:nt].copy() if lab is not None else None)

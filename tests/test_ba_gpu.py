@@ -57,8 +57,105 @@ def test_sharded_single_process_equals_unsharded(vido, ctx, oracle):
     assert np.array_equal(a["cam_T"], b["cam_T"]) or rel(a["cam_T"], b["cam_T"]) < 1e-9
 
 
+def _two_rank_hooks(vido):
+    """An in-place 'all-reduce' between two vido_ba_optimize calls running in two threads on ONE GPU (two contexts = two streams): every rank brings its
+    device buffer to the host, the ranks meet at a barrier, each writes the sum / max back.  What the RCCL hook does over xGMI, without a second GPU."""
+    import threading
+    import torch
+    from vido_slam_amd.host import ALLREDUCE_FN, _DevBuf
+    barrier = threading.Barrier(2, timeout=120); bufs = [None, None]; calls = [[], []]
+
+    def make(rank):
+        def hook(user, ptr, count, op):
+            try:
+                t = torch.as_tensor(_DevBuf(ptr, count), device="cuda")
+                bufs[rank] = t.cpu().numpy().copy()
+                barrier.wait()
+                s = bufs[0] + bufs[1] if op == 0 else np.maximum(bufs[0], bufs[1])
+                barrier.wait()
+                t.copy_(torch.from_numpy(s)); torch.cuda.synchronize()
+                calls[rank].append((int(count), int(op)))
+                return 0
+            except Exception as e:           # a broken barrier etc.: fail the call instead of hanging the other rank
+                print("hook rank %d: %r" % (rank, e)); barrier.abort(); return 1
+        return ALLREDUCE_FN(hook)
+    return make, calls
+
+
+@pytest.mark.parametrize("kw,dyn", [
+    (dict(n_cam=60, n_pt=3000, kind="global", track_len=10, seed=11), False),     # band layout, pose-block Cholesky
+    (dict(n_cam=23, n_pt=900, kind="global", track_len=7, seed=12), False),
+    (dict(n_cam=20, n_pt=2000, kind="local", seed=7), False),                     # LDS-resident reduced system, sharded all the same
+    (dict(n_cam=48, n_pt=1500, kind="global", track_len=8, seed=15), True),       # + object factors (rank 0 owns them)
+])
+def test_two_shards_on_one_gpu_equal_unsharded_and_oracle(vido, oracle, kw, dyn):
+    """The product's sharded path — rank 1 (no camera-camera factors, add_cam = 0), the three all-reduces per LM trial, landmark ranges — executed for real:
+    vido_ba_optimize as rank 0 and rank 1 of world 2, concurrently, each on its own context, exchanging through the hook above."""
+    import threading
+    pr = vido.problems.synth_ba_problem(**kw); pr["max_iters"] = 8
+    dy = vido.problems.synth_ba_dynamic(pr, n_obj=2, pts_per_obj=40, seed=16, max_len=6) if dyn else None
+    ctxs = [vido.Context(width=640, height=480, max_batch=1) for _ in range(3)]
+    ref = vido.ba_optimize(ctxs[2], pr, dynamic=dy)
+    shards = vido.landmark_shards(pr["obs_pt"], pr["n_pt"], 2)
+    assert shards[0][1] == shards[1][0] and 0 < shards[0][1] < pr["n_pt"]
+    make, calls = _two_rank_hooks(vido)
+    out = [None, None]; err = [None, None]
+
+    def run(rank):
+        try:
+            out[rank] = vido.ba_optimize(ctxs[rank], pr, rank=rank, world=2, shard=shards[rank], allreduce=make(rank), dynamic=dy)
+        except Exception as e:
+            err[rank] = e
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    [t.start() for t in th]; [t.join(timeout=300) for t in th]
+    assert err == [None, None], err
+    a, b = out
+    assert len(calls[0]) == len(calls[1]) and len(calls[0]) >= 3 * a["lm_trials"]       # the collectives really ran, the same sequence on both ranks
+    assert np.array_equal(a["cam_T"], b["cam_T"])                                          # replicated reduced solve: bit-identical poses on both ranks
+    assert a["iterations"] == b["iterations"] == ref["iterations"] and a["lm_trials"] == b["lm_trials"] == ref["lm_trials"]
+    assert rel(a["cam_T"], ref["cam_T"]) < 1e-8 and abs(a["chi2_final"] - ref["chi2_final"]) <= 1e-8 * ref["chi2_final"]
+    lo, hi = shards[0]
+    assert rel(a["pt_xyz"][lo:hi], ref["pt_xyz"][lo:hi]) < 1e-8 and rel(b["pt_xyz"][hi:], ref["pt_xyz"][hi:]) < 1e-8    # every rank refines (and returns) its own landmarks
+    if dyn:
+        assert rel(a["H_T"], ref["H_T"]) < 1e-8 and rel(a["dyn_xyz"], ref["dyn_xyz"]) < 1e-8
+    else:
+        o = oracle.ba_optimize(pr)
+        assert a["iterations"] == o["iterations"] and rel(a["cam_T"], o["cam_T"]) < RTOL
+    for c in ctxs:
+        c.close()
+
+
 def test_malformed_problem_is_rejected(vido, ctx):
     pr = vido.problems.synth_ba_problem(n_cam=4, n_pt=50, seed=1)
     pr["obs_cam"] = pr["obs_cam"].copy(); pr["obs_cam"][0] = 99
     with pytest.raises(vido.VidoError):
         vido.ba_optimize(ctx, pr)
+
+
+def test_tracks_longer_than_64_frames_and_duplicate_observations(vido, oracle, ctx):
+    """FullBatchOptimization has no track-length limit (Optimizer.cc:1235ff): landmarks seen from 65..120 cameras go through k_ba_schur_long and must give the
+    oracle's result; a landmark observed twice from one camera is rejected (the pair kernels assume distinct cameras per landmark)."""
+    pr = vido.problems.synth_ba_problem(n_cam=120, n_pt=400, kind="global", track_len=10, seed=31, step=0.05)
+    # make 12 landmarks visible from every camera (a long static track) by adding synthetic observations consistent with the true geometry
+    rng = np.random.RandomState(3)
+    cams = np.stack([np.vstack([c, [0, 0, 0, 1]]) for c in pr["cam_true"]]); inv = np.linalg.inv(cams)
+    oc, op, om = [pr["obs_cam"]], [pr["obs_pt"]], [pr["obs_meas"]]
+    for l in range(12):
+        seen = set(pr["obs_cam"][pr["obs_pt"] == l].tolist())
+        for c in range(pr["n_cam"] if l < 6 else 80):
+            if c in seen:
+                continue
+            Xc = inv[c][:3, :3] @ pr["pt_true"][l] + inv[c][:3, 3]
+            oc.append(np.array([c], np.int32)); op.append(np.array([l], np.int32)); om.append((Xc + rng.normal(0, 0.01, 3))[None])
+    pr["obs_cam"] = np.concatenate(oc); pr["obs_pt"] = np.concatenate(op); pr["obs_meas"] = np.concatenate(om)
+    assert np.bincount(pr["obs_pt"]).max() == 120
+    pr["max_iters"] = 6
+    ref = oracle.ba_optimize(pr)
+    got = vido.ba_optimize(ctx, pr)
+    assert got["iterations"] == ref["iterations"] and got["lm_trials"] == ref["lm_trials"]
+    assert rel(got["cam_T"], ref["cam_T"]) < RTOL and rel(got["pt_xyz"], ref["pt_xyz"]) < RTOL
+    assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-6 * ref["chi2_final"]
+    dup = dict(pr); dup["obs_cam"] = np.concatenate([pr["obs_cam"], pr["obs_cam"][:1]]); dup["obs_pt"] = np.concatenate([pr["obs_pt"], pr["obs_pt"][:1]])
+    dup["obs_meas"] = np.concatenate([pr["obs_meas"], pr["obs_meas"][:1]])
+    with pytest.raises(vido.VidoError):
+        vido.ba_optimize(ctx, dup)

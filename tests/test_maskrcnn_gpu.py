@@ -81,8 +81,9 @@ def test_device_side_head_ops_match_the_host_forms(ctx, oracle):
     K = 1344
     boxes = np.zeros((len(ns) * K, 4), np.float32); ref = []
     for g, n in enumerate(ns):
-        xy = rng.uniform(0, 300, (n, 2)); wh = rng.uniform(5, 120, (n, 2))
-        b = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        # clustered boxes (40 centres, small jitter): heavy mutual suppression inside and across the 64-box blocks of the sweep, like RPN proposals
+        cen = rng.uniform(20, 300, (40, 2)); c = cen[rng.randint(0, 40, n)] + rng.normal(0, 4, (n, 2)); wh = rng.uniform(30, 60, (n, 2))
+        b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
         boxes[g * K:g * K + n] = b
         ref.append(np.sort(oracle.nms(b, np.arange(n, 0, -1).astype(np.float32), 0.7)) if n else np.zeros(0, np.int64))
     keep, cnt = ops.nms_segments(torch.from_numpy(boxes).cuda(), (torch.arange(len(ns), dtype=torch.int32) * K).cuda(), torch.tensor(ns, dtype=torch.int32).cuda(), K, 0.7)

@@ -390,6 +390,7 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 512) void k_ba_schur(BaDev P, in
             int nl = 0, nbeg = 0, ncnt = 0;
             { const int nlp = lp + l_step;
               if (nlp < l_end) { if (MODE == 2) { nl = lorder[nlp]; const int2 bc = lbc[nlp]; nbeg = bc.x; ncnt = bc.y; } else { nl = nlp; nbeg = P.pt_start[nl]; ncnt = P.pt_start[nl + 1] - nbeg; } } }
+            if (cnt > 64) { l = nl; beg = nbeg; cnt = ncnt; continue; }     // wave-uniform: long tracks go through k_ba_schur_long
             const int k = min(cnt, kcap);
             double* Wl = stage; double* WDl = stage + kcap * 18; int* scam = (int*)(stage + 2 * kcap * 18); int* sord = scam + kcap;
             if (lane < k) { const int cp = P.slot_cam[beg + lane]; scam[lane] = cp; sord[lane] = MODE == 2 ? P.slot_ord[beg + lane] : cp; }
@@ -465,6 +466,60 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 512) void k_ba_schur(BaDev P, in
             }
             for (int t = threadIdx.x; t < wn; t += blockDim.x) { const double v = Sl[rhs_off + t]; if (v != 0.0 && cbase + t / 6 < P.n_cam_ord) atomicAdd(P.r + 6 * P.ord_pose[cbase + t / 6] + t % 6, v); }
             __syncthreads();
+        }
+    }
+}
+// Landmarks with more than 64 observations (a static point watched for more than 64 keyframes: a vehicle waiting at a junction; FullBatchOptimization has no
+// track-length limit, Optimizer.cc:1235ff): one 256-thread workgroup per landmark, slots streamed from HBM instead of being parked in a wave's LDS stage, every
+// contribution an FP64 atomic on S / r.  O(k^2) blocks per landmark like the fast path; rare, so simple.  k_ba_schur skips these landmarks.
+__global__ __launch_bounds__(256) void k_ba_schur_long(BaDev P, double lambda, const int* __restrict__ long_list)
+{
+    __shared__ double red[4][9]; __shared__ double sH[9], sDi[9];
+    const int l = long_list[blockIdx.x], beg = P.pt_start[l], k = P.pt_start[l + 1] - beg, tid = threadIdx.x;
+    double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < k; i += 256) {
+#pragma unroll
+        for (int a = 0; a < 9; a++) h[a] += P.Cp[9 * (size_t)(beg + i) + a];
+    }
+#pragma unroll
+    for (int a = 0; a < 9; a++) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) h[a] += __shfl_xor(h[a], o, 64);
+    }
+    if ((tid & 63) == 0) { for (int a = 0; a < 9; a++) red[tid >> 6][a] = h[a]; }
+    __syncthreads();
+    if (tid == 0) {
+        double H6[9]; for (int a = 0; a < 9; a++) H6[a] = red[0][a] + red[1][a] + red[2][a] + red[3][a];
+        for (int a = 0; a < 6; a++) P.Hpp[6 * (size_t)l + a] = H6[a];
+        for (int a = 0; a < 3; a++) P.bp[3 * (size_t)l + a] = H6[6 + a];
+        double Di[9]; inv3sym(H6, lambda, Di);
+        for (int a = 0; a < 9; a++) { sH[a] = H6[a]; sDi[a] = Di[a]; }
+    }
+    __syncthreads();
+    double Di[9]; for (int a = 0; a < 9; a++) Di[a] = sDi[a];
+    const double b0 = sH[6], b1 = sH[7], b2 = sH[8];
+    for (int t = tid; t < k * 6; t += 256) {                 // rhs: r_c -= (W_i Di) b
+        const double* w = P.W + 18 * (size_t)(beg + t / 6) + 3 * (t % 6);
+        const double d0 = w[0] * Di[0] + w[1] * Di[3] + w[2] * Di[6], d1 = w[0] * Di[1] + w[1] * Di[4] + w[2] * Di[7], d2 = w[0] * Di[2] + w[1] * Di[5] + w[2] * Di[8];
+        atomicAdd(P.r + 6 * P.slot_cam[beg + t / 6] + t % 6, -(d0 * b0 + d1 * b1 + d2 * b2));
+    }
+    const long long npair = (long long)k * (k + 1) / 2;
+    for (long long pq = tid; pq < npair; pq += 256) {        // slot pairs i >= j (slots are in camera order): block (c_i, c_j) -= (W_i Di) W_j^T
+        long long i = (long long)((sqrt(8.0 * (double)pq + 1.0) - 1.0) * 0.5);
+        while (i * (i + 1) / 2 > pq) i--;
+        while ((i + 1) * (i + 2) / 2 <= pq) i++;
+        const int j = (int)(pq - i * (i + 1) / 2);
+        const double* Wi = P.W + 18 * (size_t)(beg + i); const double* Wj = P.W + 18 * (size_t)(beg + j);
+        const int pi = P.slot_cam[beg + i], pj = P.slot_cam[beg + j];
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            const double w0 = Wi[a * 3], w1 = Wi[a * 3 + 1], w2 = Wi[a * 3 + 2];
+            const double d0 = w0 * Di[0] + w1 * Di[3] + w2 * Di[6], d1 = w0 * Di[1] + w1 * Di[4] + w2 * Di[7], d2 = w0 * Di[2] + w1 * Di[5] + w2 * Di[8];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const double v = -(d0 * Wj[b * 3] + d1 * Wj[b * 3 + 1] + d2 * Wj[b * 3 + 2]);
+                double* e = s_entry(P, 6 * pi + a, 6 * pj + b); if (e) atomicAdd(e, v);
+            }
         }
     }
 }
@@ -1431,6 +1486,184 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
     if (tid == 0) P.scal[4] = ok ? 1.0 : 0.0;
 }
 
+// ---- reduced solve by block cyclic reduction (round 2) ---------------------------------------------------------------------------------------
+// The banded reduced camera system of a sequential map (n6 = 3000, half-bandwidth 65 at 500 keyframes with 10-frame tracks) is tiny in FLOPs (~11 MFLOP
+// to factor) but a band Cholesky is a chain of n6/6 = 500 dependent pivot steps: k_chol_band6 spends 1.55 ms on ONE workgroup, replicated on every rank of
+// a sharded solve (64 % of a global-BA iteration).  Grouping the unknowns into superblocks of m = 6 (bwc + 1) >= bw + 1 scalars makes the matrix block
+// TRIDIAGONAL (nb = ceil(n6 / m) superblocks: 46 of 66), and cyclic reduction eliminates every other superblock of the current chain in parallel:
+//   level s (stride): blocks p = s mod 2s are eliminated — D_p = C C^T factored in LDS, GL_p = D_p^-1 L_p, GR_p = D_p^-1 L_{p+s}^T, y_p = D_p^-1 b_p
+//   (k_bcr_eliminate, one workgroup per column slice of a block); the survivors a = 0 mod 2s take the Schur complements
+//   D_a -= L_a GR_{a-s} + L_{a+s}^T GL_{a+s},  b_a -= L_a y_{a-s} + L_{a+s}^T y_{a+s},  L_a' = -L_a GL_{a-s}   (k_bcr_update),
+// log2(nb) levels of two launches instead of 500 dependent steps; the back-substitution x_p = y_p - GL_p x_{p-s} - GR_p x_{p+s} walks the levels back.
+// Schur complements of an SPD matrix are SPD, so no pivoting is needed (block cyclic reduction is backward stable for SPD systems).  L_k is the block
+// (k, left neighbour of k in the current chain); symmetric storage is not exploited (the work is latency, not FLOPs).
+struct BcrDev { int m, nb, n6, bw, ldb; double *D, *L0, *L1, *GL, *GR, *b, *y; const double* S; const double* r; double* x; double* ok; };
+#define BCR_NT 256
+__global__ __launch_bounds__(256) void k_bcr_pack(BcrDev B)
+{
+    const int m = B.m, k = blockIdx.x, tid = threadIdx.x;
+    double* Dk = B.D + (size_t)k * m * m; double* Lk = B.L0 + (size_t)k * m * m;
+    for (int t = tid; t < m * m; t += 256) {
+        const int i = t / m, j = t - i * m; const int gr = k * m + i, gc = k * m + j;
+        double d = 0.0;
+        if (gr < B.n6 && gc < B.n6) { const int hi = max(gr, gc), lo = min(gr, gc); if (hi - lo <= B.bw) d = B.S[(size_t)hi * B.ldb + (lo - hi + B.bw)]; }
+        else if (gr == gc) d = 1.0;                                  // padding rows of the last superblock: identity
+        Dk[t] = d;
+        double l = 0.0;
+        if (k > 0) { const int lc = (k - 1) * m + j; if (gr < B.n6 && gr - lc <= B.bw) l = B.S[(size_t)gr * B.ldb + (lc - gr + B.bw)]; }
+        Lk[t] = l;
+    }
+    for (int t = tid; t < m; t += 256) B.b[(size_t)k * m + t] = k * m + t < B.n6 ? B.r[k * m + t] : 0.0;
+    if (k == 0 && tid == 0) *B.ok = 1.0;
+}
+// in-LDS Cholesky of the m x m matrix A (pitch ld odd, lower triangle; the strictly lower part becomes C, the diagonal is left alone and 1 / C_jj goes to dinv),
+// 256 threads as a 16 x 16 grid over the trailing block, two barriers per column; returns false on a non-positive pivot
+__device__ bool bcr_chol(double* A, double* dinv, int m, int ld)
+{
+    bool good = true;
+    const int tid = threadIdx.x, ti = tid & 15, tk = tid >> 4;
+    for (int j = 0; j < m; j++) {
+        __syncthreads();
+        double d = A[j * ld + j];
+        if (!(d > 0) || !isfinite(d)) { good = false; d = 1.0; }
+        const double inv = 1.0 / sqrt(d);
+        for (int i = j + 1 + tid; i < m; i += BCR_NT) A[i * ld + j] *= inv;
+        if (tid == 0) dinv[j] = inv;
+        __syncthreads();
+        for (int i = j + 1 + ti; i < m; i += 16) {
+            const double aij = A[i * ld + j];
+            for (int k = j + 1 + tk; k <= i; k += 16) A[i * ld + k] -= aij * A[k * ld + j];
+        }
+    }
+    __syncthreads();
+    return good;
+}
+// (C C^T)^-1 v for right-hand sides distributed over groups of 8 lanes: lane sub of a group holds rows sub, sub + 8, ... of ITS column in registers (m <= 96);
+// every step broadcasts one solved entry inside the group with a shuffle and updates the rows still to come — 8 x the parallelism of a thread per column,
+// everything in registers (indexed at compile time: the loops over the register slots are unrolled)
+#define BCR_SLOTS 12
+__device__ __forceinline__ void bcr_solve8(const double* A, const double* dinv, int m, int ld, double (&v)[BCR_SLOTS])
+{
+    const int lane = threadIdx.x & 63, sub = lane & 7, gbase = lane & ~7;
+#pragma unroll
+    for (int t = 0; t < BCR_SLOTS; t++) {                    // forward: C y = v
+        for (int sk = 0; sk < 8; sk++) {
+            const int k = 8 * t + sk;
+            if (k >= m) break;                               // wave-uniform
+            const double vk = __shfl(v[t], gbase | sk, 64) * dinv[k];
+            if (sub == sk) v[t] = vk;
+#pragma unroll
+            for (int tt = t; tt < BCR_SLOTS; tt++) { const int i = sub + 8 * tt; if (i > k && i < m) v[tt] -= A[i * ld + k] * vk; }
+        }
+    }
+#pragma unroll
+    for (int t = BCR_SLOTS - 1; t >= 0; t--) {               // backward: C^T x = y
+        for (int sk = 7; sk >= 0; sk--) {
+            const int k = 8 * t + sk;
+            if (k >= m) continue;                            // wave-uniform
+            const double xk = __shfl(v[t], gbase | sk, 64) * dinv[k];
+            if (sub == sk) v[t] = xk;
+#pragma unroll
+            for (int tt = 0; tt <= t; tt++) { const int i = sub + 8 * tt; if (i < k) v[tt] -= A[k * ld + i] * xk; }
+        }
+    }
+}
+// eliminated block p = s + 2 s blockIdx.x; blockIdx.y selects a slice of 32 of the 2m + 1 right-hand sides [L_p | L_{p+s}^T | b_p] (every slice refactors D_p:
+// the factorisation is a few us of latency, the slices run on different CUs)
+__global__ __launch_bounds__(BCR_NT) void k_bcr_eliminate(BcrDev B, int s, const double* __restrict__ Lcur)
+{
+    extern __shared__ double lds[];
+    const int m = B.m, ld = m | 1, tid = threadIdx.x;
+    const int p = s + 2 * s * blockIdx.x;
+    double* A = lds;                      // [m][ld]
+    double* dinv = lds + (size_t)m * ld;  // [m]
+    const double* Dp = B.D + (size_t)p * m * m;
+    for (int t = tid; t < m * m; t += BCR_NT) { const int i = t / m, j = t - i * m; if (j <= i) A[i * ld + j] = Dp[t]; }
+    const bool good = bcr_chol(A, dinv, m, ld);
+    if (!good && tid == 0) *B.ok = 0.0;
+    const int c = blockIdx.y * (BCR_NT / 8) + (tid >> 3), sub = tid & 7;       // this 8-lane group's right-hand side
+    const bool has_r = p + s < B.nb, live = c < 2 * m + 1;
+    const double* Lp = Lcur + (size_t)p * m * m; const double* Lq = Lcur + (size_t)(p + s) * m * m;
+    double v[BCR_SLOTS];
+#pragma unroll
+    for (int t = 0; t < BCR_SLOTS; t++) {
+        const int i = sub + 8 * t; double x = 0.0;
+        if (live && i < m) {
+            if (c < m) x = Lp[(size_t)i * m + c];                                  // column c of L_p = block (p, p - s)
+            else if (c < 2 * m) x = has_r ? Lq[(size_t)(c - m) * m + i] : 0.0;     // column of L_{p+s}^T = row of L_{p+s}
+            else x = B.b[(size_t)p * m + i];
+        }
+        v[t] = x;
+    }
+    bcr_solve8(A, dinv, m, ld, v);
+#pragma unroll
+    for (int t = 0; t < BCR_SLOTS; t++) {
+        const int i = sub + 8 * t;
+        if (live && i < m) {
+            if (c < m) B.GL[(size_t)p * m * m + (size_t)i * m + c] = v[t];
+            else if (c < 2 * m) B.GR[(size_t)p * m * m + (size_t)i * m + (c - m)] = v[t];
+            else B.y[(size_t)p * m + i] = v[t];
+        }
+    }
+}
+// surviving block a = 2 s blockIdx.x; blockIdx.y takes a slice of the m x m outputs
+__global__ __launch_bounds__(256) void k_bcr_update(BcrDev B, int s, const double* __restrict__ Lcur, double* __restrict__ Lnext)
+{
+    const int m = B.m, a = 2 * s * blockIdx.x, p = a - s, q = a + s;
+    const bool has_p = p >= 0, has_q = q < B.nb;
+    const double* La = Lcur + (size_t)a * m * m; const double* Lq = Lcur + (size_t)q * m * m;
+    const double* GRp = B.GR + (size_t)p * m * m; const double* GLp = B.GL + (size_t)p * m * m; const double* GLq = B.GL + (size_t)q * m * m;
+    double* Da = B.D + (size_t)a * m * m;
+    const int per = (m * m + gridDim.y - 1) / gridDim.y, t0 = blockIdx.y * per, t1 = min(m * m, t0 + per);
+    for (int t = t0 + threadIdx.x; t < t1; t += 256) {
+        const int i = t / m, j = t - i * m;
+        double d = 0.0, ln = 0.0;
+        if (has_p) for (int k = 0; k < m; k++) { const double l = La[(size_t)i * m + k]; d += l * GRp[(size_t)k * m + j]; ln -= l * GLp[(size_t)k * m + j]; }
+        if (has_q) for (int k = 0; k < m; k++) d += Lq[(size_t)k * m + i] * GLq[(size_t)k * m + j];
+        Da[t] -= d;
+        Lnext[(size_t)a * m * m + t] = ln;           // block (a, a - 2s)
+    }
+    if (blockIdx.y == 0) for (int i = threadIdx.x; i < m; i += 256) {
+        double d = 0.0;
+        if (has_p) for (int k = 0; k < m; k++) d += La[(size_t)i * m + k] * B.y[(size_t)p * m + k];
+        if (has_q) for (int k = 0; k < m; k++) d += Lq[(size_t)k * m + i] * B.y[(size_t)q * m + k];
+        B.b[(size_t)a * m + i] -= d;
+    }
+}
+// last block of the chain: D_0 x_0 = b_0
+__global__ __launch_bounds__(BCR_NT) void k_bcr_final(BcrDev B)
+{
+    extern __shared__ double lds[];
+    const int m = B.m, ld = m | 1, tid = threadIdx.x;
+    double* A = lds; double* dinv = lds + (size_t)m * ld;
+    for (int t = tid; t < m * m; t += BCR_NT) { const int i = t / m, j = t - i * m; if (j <= i) A[i * ld + j] = B.D[t]; }
+    const bool good = bcr_chol(A, dinv, m, ld);
+    if (!good && tid == 0) *B.ok = 0.0;
+    if (tid < 64) {                                            // first wave: its first 8-lane group solves the single right-hand side
+        const int sub = tid & 7;
+        double v[BCR_SLOTS];
+#pragma unroll
+        for (int t = 0; t < BCR_SLOTS; t++) { const int i = sub + 8 * t; v[t] = (tid < 8 && i < m) ? B.b[i] : 0.0; }
+        bcr_solve8(A, dinv, m, ld, v);
+#pragma unroll
+        for (int t = 0; t < BCR_SLOTS; t++) { const int i = sub + 8 * t; if (tid < 8 && i < m && i < B.n6) B.x[i] = v[t]; }
+    }
+}
+// x_p = y_p - GL_p x_{p-s} - GR_p x_{p+s} for the blocks eliminated at level s
+__global__ __launch_bounds__(128) void k_bcr_back(BcrDev B, int s)
+{
+    const int m = B.m, p = s + 2 * s * blockIdx.x, i = threadIdx.x;
+    if (i >= m) return;
+    const int gi = p * m + i;
+    if (gi >= B.n6) return;
+    double v = B.y[(size_t)p * m + i];
+    const double* gl = B.GL + (size_t)p * m * m + (size_t)i * m; const double* gr = B.GR + (size_t)p * m * m + (size_t)i * m;
+    const int l0 = (p - s) * m, r0 = (p + s) * m;
+    for (int k = 0; k < m; k++) { if (l0 + k < B.n6) v -= gl[k] * B.x[l0 + k]; }
+    if (p + s < B.nb) for (int k = 0; k < m; k++) { if (r0 + k < B.n6) v -= gr[k] * B.x[r0 + k]; }
+    B.x[gi] = v;
+}
+
 // ---- trial state ------------------------------------------------------------------------------------------
 __global__ void k_ba_update_cams(BaDev P, double lambda)
 {
@@ -1776,12 +2009,14 @@ struct BaState {
     double* d_parts = nullptr; size_t parts_cap = 0;
     double* d_scratch = nullptr; size_t scratch_cap = 0;
     char* pool = nullptr; char* h_pool = nullptr; size_t pool_cap = 0, hpool_cap = 0;
+    int* d_long = nullptr; size_t long_cap = 0;      // landmarks with > 64 observations
+    double* d_bcr = nullptr; size_t bcr_cap = 0;     // block-cyclic-reduction workspace (superblocks D, L x2, GL, GR, b, y)
 };
 void ba_state_destroy(vido_ctx* ctx)
 {
     BaState* S = ctx->ba; if (!S) return;
     for (void* p : S->allocs) hipFree(p);
-    hipFree(S->d_parts); hipFree(S->d_scratch); hipHostFree(S->h_scal); hipFree(S->pool); hipHostFree(S->h_pool);
+    hipFree(S->d_parts); hipFree(S->d_scratch); hipHostFree(S->h_scal); hipFree(S->pool); hipHostFree(S->h_pool); hipFree(S->d_long); hipFree(S->d_bcr);
     if (S->ev0) hipEventDestroy(S->ev0);
     if (S->ev1) hipEventDestroy(S->ev1);
     delete S; ctx->ba = nullptr;
@@ -1960,8 +2195,14 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     for (int t = 0; t < no; t++) { const int k = keep[t]; ocam[t] = perm[p.obs_cam[k]]; opt[t] = p.obs_pt[k] - pt_lo; for (int a = 0; a < 3; a++) omeas[3 * (size_t)t + a] = p.obs_meas[3 * (size_t)k + a]; pstart[opt[t] + 1]++; }
     int maxk = 0;
     for (int l = 0; l < n_ptl; l++) { maxk = std::max(maxk, pstart[l + 1]); pstart[l + 1] += pstart[l]; }
-    if (maxk > 64) return vido_set_error(ctx, VIDO_E_CAPACITY, "ba: a landmark has %d observations; this build handles tracks up to 64", maxk);
     { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (int t = 0; t < no; t++) { opos[t] = fill[opt[t]]++; slotcam[opos[t]] = ocam[t]; } }
+    // the Schur kernels add WD_i W_j^T for slot pairs i >= j into the LOWER triangle and assume the slots of a landmark belong to distinct cameras (for two
+    // slots of one camera the transposed term would be missing); the observations are sorted by camera, so duplicates are adjacent slots
+    for (int l = 0; l < n_ptl; l++) for (int q = pstart[l] + 1; q < pstart[l + 1]; q++)
+        if (slotcam[q] == slotcam[q - 1]) return vido_set_error(ctx, VIDO_E_INVALID, "ba: landmark %d is observed twice from camera %d (merge duplicate observations first)", l + pt_lo, slotcam[q]);
+    std::vector<int> long_list;                             // landmarks with more than 64 observations: k_ba_schur_long
+    for (int l = 0; l < n_ptl; l++) if (pstart[l + 1] - pstart[l] > 64) long_list.push_back(l);
+    maxk = std::min(maxk, 64);
     // ---- device buffers
     {   // size the persistent pool (device + pinned mirror for the uploads) for this problem
         const size_t ndb = (size_t)n_pose * (24 + 36 + 36) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + 18 + 9) + (size_t)n_cc * (12 + 36 + 2) + (size_t)n6 * n6 + 5 * (size_t)n6 + 64 +
@@ -2049,11 +2290,27 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
                      if (bwc >= 1 && bwc <= 96) { band6s_nb = need(8) <= 150 * 1024 ? 8 : 4; band6s_lds = need(band6s_nb);
                      HIP_TRY(ctx, hipFuncSetAttribute(band6s_nb == 8 ? (const void*)k_chol_band6s<8> : (const void*)k_chol_band6s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band6s_lds)); } }
     double* Sr = A.get<double>(sz_S + n6); D.S = Sr; D.r = Sr + sz_S; D.x = A.get<double>(n6);
+    // block cyclic reduction of the band system when it is long enough to pay (>= 6 superblocks) and a superblock fits the 8-lane register solve
+    BcrDev Bc{}; size_t bcr_lds = 0;
+    if (D.bw >= 0 && !getenv("VIDO_BA_NO_BCR")) {
+        const int bwc = (D.bw - 5) / 6, m = 6 * (bwc + 1), nb = (n6 + m - 1) / m;
+        if (m <= 8 * BCR_SLOTS && nb >= 6) {
+            const size_t mm = (size_t)nb * m * m, need = 5 * mm + 2 * (size_t)nb * m;
+            if (need > BS->bcr_cap) { HIP_TRY(ctx, hipStreamSynchronize(st)); if (BS->d_bcr) hipFree(BS->d_bcr); BS->bcr_cap = need + need / 4; HIP_TRY(ctx, hipMalloc((void**)&BS->d_bcr, BS->bcr_cap * sizeof(double))); }
+            Bc.m = m; Bc.nb = nb; Bc.n6 = n6; Bc.bw = D.bw; Bc.ldb = D.ldb;
+            Bc.D = BS->d_bcr; Bc.L0 = Bc.D + mm; Bc.L1 = Bc.L0 + mm; Bc.GL = Bc.L1 + mm; Bc.GR = Bc.GL + mm; Bc.b = Bc.GR + mm; Bc.y = Bc.b + (size_t)nb * m;
+            Bc.S = D.S; Bc.r = D.r; Bc.x = D.x;
+            bcr_lds = ((size_t)m * (m | 1) + m) * sizeof(double);
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_bcr_eliminate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bcr_lds));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_bcr_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bcr_lds));
+        }
+    }
     if (getenv("VIDO_BA_VERBOSE")) fprintf(stderr, "[ba] poses %d (cams %d + H %d) landmarks %d obs %d dyn %d | bw %d (block half-width %d) %s\n", n_pose, p.n_cam, n_H, n_ptl, no, nd, D.bw, D.bw >= 0 ? (D.bw - 5) / 6 : -1,
                                              lds_path ? "LDS-resident system" : (D.bw < 0 ? "dense" : (band6_lds ? "pose-block band, LDS window" : (band6s_lds ? "pose-block band, window in L2" : "scalar band"))));
     double* chol_tmp = A.get<double>(64);
     double* red = A.get<double>((size_t)n_pose * 36 + n6 + 8);      // [Hcd | bc | scal] contiguous for the linearisation all-reduce
     D.Hcd = red; D.bc = red + (size_t)n_pose * 36; D.scal = D.bc + n6;
+    Bc.ok = D.scal + 4;
     if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device allocation failed (n6=%d, n_obs=%d)", n6, no);
     const int schur_grid = lds_path ? std::min(256, std::max(1, (n_ptl + 3) / 4)) : std::min(4096, std::max(1, (n_ptl + 3) / 4));
     const size_t sz_sr = sz_S + n6;
@@ -2095,6 +2352,13 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         { std::vector<int> bc(2 * (size_t)n_ptl); for (int q = 0; q < n_ptl; q++) { const int l = lorder[q]; bc[2 * (size_t)q] = pstart[l]; bc[2 * (size_t)q + 1] = pstart[l + 1] - pstart[l]; }
           d_lbc = (int2*)A.put(bc.data(), 2 * (size_t)n_ptl, st); }
         if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device pool exhausted");
+    }
+    const int n_long = (int)long_list.size();
+    int* d_long = nullptr;
+    if (n_long) {      // rare: its own small allocation instead of a slice of the arena (whose size estimate does not count it)
+        if ((size_t)n_long > BS->long_cap) { HIP_TRY(ctx, hipStreamSynchronize(st)); if (BS->d_long) hipFree(BS->d_long); BS->long_cap = (size_t)n_long * 2; HIP_TRY(ctx, hipMalloc((void**)&BS->d_long, BS->long_cap * sizeof(int))); }
+        d_long = BS->d_long;
+        HIP_TRY(ctx, hipMemcpyAsync(d_long, long_list.data(), (size_t)n_long * sizeof(int), hipMemcpyHostToDevice, st)); HIP_TRY(ctx, hipStreamSynchronize(st));
     }
     if (lds_schur > 160 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "ba: LDS budget exceeded (n6=%d, max track %d)", n6, maxk);
     if (lds_path) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
@@ -2171,6 +2435,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
                     hipLaunchKernelGGL(k_ba_fold_parts, dim3(std::min(256, (int)((loc_sz + 255) / 256)), std::min(8, schur_grid)), dim3(256), 0, st, D, BS->d_parts, schur_grid);
                 } else hipLaunchKernelGGL(k_ba_schur<2>, dim3(std::min(n_chunks, 1024)), dim3(64 * schur2_waves), lds_schur, st, D, n_ptl, lambda, kcap, (double*)nullptr, (const int*)d_chunk_cmin, (const int*)d_lorder, (const int2*)d_lbc);
             }
+            if (n_long) hipLaunchKernelGGL(k_ba_schur_long, dim3(n_long), dim3(256), 0, st, D, lambda, (const int*)d_long);
             if (nd) {
                 hipLaunchKernelGGL(k_badyn_factor, dim3((n_chain + 63) / 64), dim3(64), 0, st, D, lambda);
                 hipLaunchKernelGGL(k_badyn_schur, dim3(dyn_grid), dim3(64), dyn_lds, st, D, BS->d_scratch, lmax, dyn_lds ? 1 : 0);
@@ -2181,6 +2446,19 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             HIP_TRY(ctx, hipMemsetAsync(D.scal + 2, 0, 2 * sizeof(double), st));
             if (lds_path && n6 % 6 == 0 && n6 >= 12) hipLaunchKernelGGL(k_ba_chol_small6, dim3(1), dim3(CH_NT), lds_chol6, st, D);
             else if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
+            else if (Bc.m) {                                   // block cyclic reduction: 2 launches per level, log2(nb) levels, then the levels back
+                const int m = Bc.m, nb = Bc.nb; const int nslice = (2 * m + 1 + BCR_NT / 8 - 1) / (BCR_NT / 8);
+                hipLaunchKernelGGL(k_bcr_pack, dim3(nb), dim3(256), 0, st, Bc);
+                double *Lc = Bc.L0, *Ln = Bc.L1; int smax = 0;
+                for (int sft = 1; sft < nb; sft *= 2) {
+                    const int n_el = (nb - sft + 2 * sft - 1) / (2 * sft), n_sv = (nb + 2 * sft - 1) / (2 * sft);
+                    hipLaunchKernelGGL(k_bcr_eliminate, dim3(n_el, nslice), dim3(BCR_NT), bcr_lds, st, Bc, sft, (const double*)Lc);
+                    hipLaunchKernelGGL(k_bcr_update, dim3(n_sv, 8), dim3(256), 0, st, Bc, sft, (const double*)Lc, Ln);
+                    std::swap(Lc, Ln); smax = sft;
+                }
+                hipLaunchKernelGGL(k_bcr_final, dim3(1), dim3(BCR_NT), bcr_lds, st, Bc);
+                for (int sft = smax; sft >= 1; sft /= 2) hipLaunchKernelGGL(k_bcr_back, dim3((nb - sft + 2 * sft - 1) / (2 * sft)), dim3(128), 0, st, Bc, sft);
+            }
             else if (D.bw >= 0 && band6_lds) hipLaunchKernelGGL(k_chol_band6, dim3(1), dim3(CH_NT), band6_lds, st, D, (D.bw - 5) / 6);
             else if (D.bw >= 0 && band6s_lds && band6s_nb == 8) hipLaunchKernelGGL(k_chol_band6s<8>, dim3(1), dim3(CG_NT), band6s_lds, st, D, (D.bw - 5) / 6);
             else if (D.bw >= 0 && band6s_lds) hipLaunchKernelGGL(k_chol_band6s<4>, dim3(1), dim3(CG_NT), band6s_lds, st, D, (D.bw - 5) / 6);

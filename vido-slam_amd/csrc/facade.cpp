@@ -141,19 +141,15 @@ Frame::Frame(const cv::Mat& imGray, const cv::Mat& imDepth, const cv::Mat& imFlo
         mvObjKeys.push_back(cv::KeyPoint(okeys[2 * i], okeys[2 * i + 1], 0, 0, 0, -1));
         mvObjDepth.push_back(odep[i]); vSemObjLabel.push_back(olab[i]);
     }
-    // UndistortKeyPoints (Frame.cc:603-633): cv::undistortPoints(P=K) is a 5-iteration fixed point of the Brown model
+    // UndistortKeyPoints (Frame.cc:603-633): cv::undistortPoints(P = K), on the flat host function the parity tests pin (trackhost.cpp)
     mvKeysUn = mvKeys;
-    if (mDistCoef.at<float>(0) != 0.0f) {
-        const float k1 = mDistCoef.at<float>(0), k2 = mDistCoef.at<float>(1), p1 = mDistCoef.at<float>(2), p2 = mDistCoef.at<float>(3), k3 = mDistCoef.rows > 4 ? mDistCoef.at<float>(4) : 0.f;
-        for (int i = 0; i < N; i++) {
-            const double x0 = (mvKeys[i].pt.x - cx) / fx, y0 = (mvKeys[i].pt.y - cy) / fy; double x = x0, y = y0;
-            for (int it = 0; it < 5; it++) {
-                const double r2 = x * x + y * y, icdist = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
-                const double dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x), dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
-                x = (x0 - dx) * icdist; y = (y0 - dy) * icdist;
-            }
-            mvKeysUn[i].pt.x = (float)(x * fx + cx); mvKeysUn[i].pt.y = (float)(y * fy + cy);
-        }
+    if (mDistCoef.at<float>(0) != 0.0f && N > 0) {
+        const float Kf[4] = {fx, fy, cx, cy};
+        const float dist[5] = {mDistCoef.at<float>(0), mDistCoef.at<float>(1), mDistCoef.at<float>(2), mDistCoef.at<float>(3), mDistCoef.rows > 4 ? mDistCoef.at<float>(4) : 0.f};
+        std::vector<float> in(2 * N), out(2 * N);
+        for (int i = 0; i < N; i++) { in[2 * i] = mvKeys[i].pt.x; in[2 * i + 1] = mvKeys[i].pt.y; }
+        if (vido_undistort_points(in.data(), N, Kf, dist, out.data()) != VIDO_OK) throw std::runtime_error("UndistortKeyPoints failed");
+        for (int i = 0; i < N; i++) { mvKeysUn[i].pt.x = out[2 * i]; mvKeysUn[i].pt.y = out[2 * i + 1]; }
     }
 }
 
@@ -759,55 +755,22 @@ void Tracking::GetSceneFlowObj()                              // Tracking.cc:158
     for (int i = 0; i < N; i++) C->vFlow_3d[i] = cv::Point3f(f3[3 * i], f3[3 * i + 1], f3[3 * i + 2]);
 }
 
-static int most_frequent(std::vector<int> v)                  // std::map count + SortPairInt (descending count)
+std::vector<std::vector<int> > Tracking::DynObjTracking()     // Tracking.cc:1670-1912: vido_dyn_obj_tracking (trackhost.cpp) on the frame's flat lists
 {
-    std::sort(v.begin(), v.end()); int best = v[0], bc = 0, run = 0;
-    for (size_t j = 0; j < v.size(); j++) { run = (j > 0 && v[j] == v[j - 1]) ? run + 1 : 1; if (run > bc) { bc = run; best = v[j]; } }
-    return best;
-}
-
-std::vector<std::vector<int> > Tracking::DynObjTracking()     // Tracking.cc:1670-1912
-{
-    Frame *C = mpCurrentFrame, *L = mpLastFrame;
-    std::vector<int> UniLab = C->vSemObjLabel; std::sort(UniLab.begin(), UniLab.end()); UniLab.erase(std::unique(UniLab.begin(), UniLab.end()), UniLab.end());
-    std::vector<std::vector<int> > Posi(UniLab.size());
-    for (size_t i = 0; i < C->vSemObjLabel.size(); i++) {
-        if (C->vObjLabel[i] == -1) continue;
-        const size_t j = std::lower_bound(UniLab.begin(), UniLab.end(), C->vSemObjLabel[i]) - UniLab.begin();
-        Posi[j].push_back((int)i);
-    }
-    std::vector<std::vector<int> > ObjId; std::vector<int> sem_posi;
-    const int shr_row = 10, shr_col = 20;
-    for (size_t i = 0; i < Posi.size(); i++) {
-        if (Posi[i].empty()) continue;                        // (the reference divides by zero here)
-        float count = 0;
-        for (int id : Posi[i]) { const float u = C->mvObjKeys[id].pt.x, v = C->mvObjKeys[id].pt.y; if (v < shr_row || v > (mImGray.rows - shr_row) || u < shr_col || u > (mImGray.cols - shr_col)) count += 1; }
-        if (count / Posi[i].size() > 0.5f) { for (int id : Posi[i]) C->vObjLabel[id] = -1; continue; }
-        ObjId.push_back(Posi[i]); sem_posi.push_back(UniLab[i]);
-    }
-    std::vector<std::vector<int> > ObjIdNew; std::vector<int> SemPosNew;
-    for (size_t i = 0; i < ObjId.size(); i++) {
-        float depth_sum = 0, sf_count = 0;
-        for (int id : ObjId[i]) {
-            depth_sum += C->mvObjDepth[id];
-            const float sf = std::sqrt(C->vFlow_3d[id].x * C->vFlow_3d[id].x + C->vFlow_3d[id].z * C->vFlow_3d[id].z);
-            if (sf < fSFMgThres) sf_count += 1;
-        }
-        if (sf_count / ObjId[i].size() > fSFDsThres) { for (int id : ObjId[i]) C->vObjLabel[id] = 0; continue; }            // static object
-        if (depth_sum / ObjId[i].size() > mThDepthObj || ObjId[i].size() < 150) { for (int id : ObjId[i]) C->vObjLabel[id] = -1; continue; }   // far / small
-        ObjIdNew.push_back(ObjId[i]); SemPosNew.push_back(sem_posi[i]);
-    }
-    if (f_id == 1) max_id = 1;
-    std::vector<int> LabId(ObjIdNew.size());
-    for (size_t i = 0; i < ObjIdNew.size(); i++) {
-        std::vector<int> Lb_last; for (int id : ObjIdNew[i]) Lb_last.push_back(L->vSemObjLabel[id]);
-        const int New_lab = most_frequent(Lb_last);
-        bool exist = false;
-        if (max_id != 1) for (size_t k = 0; k < L->nSemPosition.size(); k++) if (L->nSemPosition[k] == New_lab && L->bObjStat[k]) { LabId[i] = L->nModLabel[k]; exist = true; break; }
-        if (!exist) { LabId[i] = max_id; max_id = max_id + 1; }
-        for (int id : ObjIdNew[i]) C->vObjLabel[id] = LabId[i];
-    }
-    C->nModLabel = LabId; C->nSemPosition = SemPosNew;
+    Frame *C = mpCurrentFrame, *L = mpLastFrame; const int n = (int)C->vSemObjLabel.size();
+    std::vector<float> xy(2 * std::max(n, 1)), f3(3 * std::max(n, 1));
+    for (int i = 0; i < n; i++) { xy[2 * i] = C->mvObjKeys[i].pt.x; xy[2 * i + 1] = C->mvObjKeys[i].pt.y; f3[3 * i] = C->vFlow_3d[i].x; f3[3 * i + 1] = C->vFlow_3d[i].y; f3[3 * i + 2] = C->vFlow_3d[i].z; }
+    const int nl = (int)L->nSemPosition.size();
+    std::vector<uint8_t> lstat(std::max(nl, 1)); for (int k = 0; k < nl; k++) lstat[k] = k < (int)L->bObjStat.size() && L->bObjStat[k] ? 1 : 0;
+    std::vector<int32_t> off(n + 2), ids(n + 1), ml(n + 1), sp(n + 1); int32_t nobj = 0, mid = max_id;
+    const int rc = vido_dyn_obj_tracking(C->vSemObjLabel.data(), C->vObjLabel.data(), xy.data(), C->mvObjDepth.data(), f3.data(), L->vSemObjLabel.data(), n,
+                                         L->nSemPosition.data(), lstat.data(), L->nModLabel.data(), nl, mImGray.rows, mImGray.cols, fSFMgThres, fSFDsThres, mThDepthObj, f_id, &mid,
+                                         off.data(), ids.data(), ml.data(), sp.data(), n + 1, &nobj);
+    if (rc != VIDO_OK) throw std::runtime_error("DynObjTracking failed");
+    max_id = mid;
+    std::vector<std::vector<int> > ObjIdNew(nobj);
+    for (int i = 0; i < nobj; i++) ObjIdNew[i].assign(ids.begin() + off[i], ids.begin() + off[i + 1]);
+    C->nModLabel.assign(ml.begin(), ml.begin() + nobj); C->nSemPosition.assign(sp.begin(), sp.begin() + nobj);
     return ObjIdNew;
 }
 
@@ -843,111 +806,54 @@ std::vector<std::vector<std::pair<int, int> > > Tracking::GetDynamicTrackNew()  
     return T;
 }
 
-// "is some point of a fixed set closer than 1 px to q" — the reference scans the whole set for every sample (Tracking.cc:3030-3040, 3198-3208: O(N*M));
-// a 1-px cell grid restricts the scan to the 3x3 neighbourhood and evaluates the same float expression, so the answer is identical.
-struct NearSet {
-    int W, H; std::vector<int> head, next; const std::vector<cv::KeyPoint>* pts;
-    NearSet(const std::vector<cv::KeyPoint>& p, int w, int h) : W(w + 2), H(h + 2), head((size_t)(w + 2) * (h + 2), -1), next(p.size(), -1), pts(&p) {
-        for (size_t i = 0; i < p.size(); i++) { const int c = cell(p[i].pt.x, p[i].pt.y); next[i] = head[c]; head[c] = (int)i; }
-    }
-    int cell(float x, float y) const { const int cx = std::min(std::max((int)std::floor(x) + 1, 0), W - 1), cy = std::min(std::max((int)std::floor(y) + 1, 0), H - 1); return cy * W + cx; }
-    bool near(const cv::Point2f& q) const {
-        const int cx = std::min(std::max((int)std::floor(q.x) + 1, 0), W - 1), cy = std::min(std::max((int)std::floor(q.y) + 1, 0), H - 1);
-        for (int yy = std::max(cy - 1, 0); yy <= std::min(cy + 1, H - 1); yy++) for (int xx = std::max(cx - 1, 0); xx <= std::min(cx + 1, W - 1); xx++)
-            for (int i = head[yy * W + xx]; i >= 0; i = next[i]) {
-                const float dx = (*pts)[i].pt.x - q.x, dy = (*pts)[i].pt.y - q.y;
-                if (std::sqrt(dx * dx + dy * dy) < 1.0f) return true;
-            }
-        return false;
-    }
-};
-
-void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:2959-3289
+void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:2959-3289: vido_renew_static / vido_renew_objects (trackhost.cpp) + depth / 3-D point assembly
 {
     Frame* C = mpCurrentFrame; const int W = mImGray.cols, H = mImGray.rows;
-    const int max_num_sta = nMaxTrackPointBG, max_num_obj = nMaxTrackPointOBJ;
-    std::vector<cv::KeyPoint> keys, corres; std::vector<cv::Point2f> flows; std::vector<int> inlierID;
-    auto try_static = [&](const cv::KeyPoint& kp, int id) -> bool {
-        const int x = (int)kp.pt.x, y = (int)kp.pt.y;
-        if (x >= W || y >= H || x <= 0 || y <= 0) return false;
-        if (mSegMap.at<int32_t>(y, x) != 0) return false;
-        const float d = mDepthMap.at<float>(y, x); if (d > 40 || d <= 0) return false;
-        const cv::Vec2f fl = mFlowMap.at<cv::Vec2f>(y, x);
-        if (fl[0] != 0 && fl[1] != 0 && kp.pt.x + fl[0] < W && kp.pt.y + fl[1] < H && kp.pt.x + fl[0] > 0 && kp.pt.y + fl[1] > 0) {
-            keys.push_back(kp); corres.push_back(cv::KeyPoint(kp.pt.x + fl[0], kp.pt.y + fl[1], 0, 0, 0, -1)); flows.push_back(cv::Point2f(fl[0], fl[1])); inlierID.push_back(id); return true;
-        }
-        return false;
-    };
-    for (size_t i = 0; i < TM_sta.size(); i++) {
-        if (TM_sta[i] == -1) continue;
-        try_static(C->mvStatKeys[TM_sta[i]], TM_sta[i]);
-        if ((int)keys.size() > max_num_sta) break;
+    vido_host_maps maps; maps.mask = mSegMap.ptr<int32_t>(); maps.depth = mDepthMap.ptr<float>(); maps.flow = mFlowMap.ptr<float>(); maps.width = W; maps.height = H;
+    // ---- static features (:2973-3105)
+    const int ns = (int)C->mvStatKeys.size(), nk = (int)C->mvKeys.size();
+    std::vector<float> sxy(2 * std::max(ns, 1)), kxy(2 * std::max(nk, 1));
+    for (int i = 0; i < ns; i++) { sxy[2 * i] = C->mvStatKeys[i].pt.x; sxy[2 * i + 1] = C->mvStatKeys[i].pt.y; }
+    for (int i = 0; i < nk; i++) { kxy[2 * i] = C->mvKeys[i].pt.x; kxy[2 * i + 1] = C->mvKeys[i].pt.y; }
+    const int cap = (int)TM_sta.size() + nk + 8;
+    std::vector<int32_t> src(cap), inl(cap); std::vector<float> fl(2 * (size_t)cap); int32_t n = 0;
+    if (vido_renew_static(&maps, sxy.data(), ns, TM_sta.data(), (int)TM_sta.size(), kxy.data(), nk, nMaxTrackPointBG, src.data(), inl.data(), fl.data(), cap, &n) != VIDO_OK)
+        throw std::runtime_error("RenewFrameInfo: vido_renew_static failed");
+    std::vector<cv::KeyPoint> keys(n), corres(n); std::vector<cv::Point2f> flows(n); std::vector<int> inlierID(n);
+    for (int k = 0; k < n; k++) {
+        keys[k] = inl[k] >= 0 ? C->mvStatKeys[src[k]] : C->mvKeys[src[k]];
+        flows[k] = cv::Point2f(fl[2 * k], fl[2 * k + 1]); inlierID[k] = inl[k];
+        corres[k] = cv::KeyPoint(keys[k].pt.x + fl[2 * k], keys[k].pt.y + fl[2 * k + 1], 0, 0, 0, -1);
     }
-    int tot = (int)keys.size(), start_id = 0; const int step = 20;
-    const std::vector<cv::KeyPoint> check_set = keys;                    // mvKeysTmpCheck: the inlier set only (copied once)
-    const std::vector<cv::KeyPoint>& sample = C->mvKeys;
-    const NearSet near_static(check_set, W, H);
-    while (tot < max_num_sta) {
-        if (start_id == step) break;
-        for (size_t i = start_id; i < sample.size(); i += step) {
-            if (near_static.near(sample[i].pt)) continue;
-            if (try_static(sample[i], -1)) tot++;
-            if (tot >= max_num_sta) break;
-        }
-        start_id++;
-    }
-    C->N_s_tmp = (int)keys.size();
-    std::vector<float> depth(C->N_s_tmp, -1.f); std::vector<cv::Mat> p3d(C->N_s_tmp);
+    C->N_s_tmp = n;
+    std::vector<float> depth(n, -1.f); std::vector<cv::Mat> p3d(n);
     const cv::Mat Twc = Converter::toInvMatrix(C->mTcw);
-    for (int i = 0; i < C->N_s_tmp; i++) { const float d = mDepthMap.at<float>((int)keys[i].pt.y, (int)keys[i].pt.x); if (d > 0) depth[i] = d; p3d[i] = Optimizer::Get3DinWorld(keys[i], depth[i], mK, Twc); }
+    for (int i = 0; i < n; i++) { const float d = mDepthMap.at<float>((int)keys[i].pt.y, (int)keys[i].pt.x); if (d > 0) depth[i] = d; p3d[i] = Optimizer::Get3DinWorld(keys[i], depth[i], mK, Twc); }
     C->nStaInlierID = inlierID; C->mvStatKeysTmp = keys; C->mvStatDepthTmp = depth; C->mvStat3DPointTmp = p3d; C->mvFlowNext = flows; C->mvCorres = corres;
 
     // ---- objects (:3116-3289)
-    std::vector<cv::KeyPoint> okeys, ocorr; std::vector<float> odep; std::vector<cv::Point2f> oflow; std::vector<int> osem, oinl, olab;
-    const auto& InSet = C->vnObjInlierID; std::vector<int> cnt(InSet.size());
-    for (size_t i = 0; i < InSet.size(); i++) {
-        if (!C->bObjStat[i]) { cnt[i] = -1; continue; }
-        int count = 0;
-        for (int id : InSet[i]) {
-            const int x = (int)C->mvObjKeys[id].pt.x, y = (int)C->mvObjKeys[id].pt.y;
-            if (x >= W || y >= H || x <= 0 || y <= 0) continue;
-            const float d = mDepthMap.at<float>(y, x);
-            if (mSegMap.at<int32_t>(y, x) != 0 && d < 25 && d > 0) {
-                const cv::Vec2f fl = mFlowMap.at<cv::Vec2f>(y, x);
-                if (x + fl[0] < W && y + fl[1] < H && x + fl[0] > 0 && y + fl[1] > 0) {
-                    okeys.push_back(cv::KeyPoint((float)x, (float)y, 0, 0, 0, -1)); odep.push_back(d); osem.push_back(mSegMap.at<int32_t>(y, x)); oflow.push_back(cv::Point2f(fl[0], fl[1]));
-                    ocorr.push_back(cv::KeyPoint(x + fl[0], y + fl[1], 0, 0, 0, -1)); oinl.push_back(id); olab.push_back(C->vObjLabel[id]); count++;
-                }
-            }
-        }
-        cnt[i] = count;
+    const int no = (int)C->mvObjKeys.size(), nobj = (int)C->vnObjInlierID.size(), nt = (int)mvTmpSemObjLabel.size();
+    std::vector<float> oxy(2 * std::max(no, 1)), txy(2 * std::max(nt, 1)), tfl(2 * std::max(nt, 1)), tco(2 * std::max(nt, 1));
+    for (int i = 0; i < no; i++) { oxy[2 * i] = C->mvObjKeys[i].pt.x; oxy[2 * i + 1] = C->mvObjKeys[i].pt.y; }
+    for (int j = 0; j < nt; j++) { txy[2 * j] = mvTmpObjKeys[j].pt.x; txy[2 * j + 1] = mvTmpObjKeys[j].pt.y; tfl[2 * j] = mvTmpObjFlowNext[j].x; tfl[2 * j + 1] = mvTmpObjFlowNext[j].y;
+                                   tco[2 * j] = mvTmpObjCorres[j].pt.x; tco[2 * j + 1] = mvTmpObjCorres[j].pt.y; }
+    std::vector<int32_t> ioff(nobj + 1, 0), iids; std::vector<uint8_t> ostat(std::max(nobj, 1));
+    for (int i = 0; i < nobj; i++) { ioff[i + 1] = ioff[i] + (int)C->vnObjInlierID[i].size(); iids.insert(iids.end(), C->vnObjInlierID[i].begin(), C->vnObjInlierID[i].end()); ostat[i] = C->bObjStat[i] ? 1 : 0; }
+    if (iids.empty()) iids.push_back(0);
+    const int ocap = (int)iids.size() + (nobj + 1) * nt + 8;
+    std::vector<float> okx(2 * (size_t)ocap), odep(ocap), ofl(2 * (size_t)ocap), oco(2 * (size_t)ocap); std::vector<int32_t> osem(ocap), oinl(ocap), olab(ocap); int32_t on = 0;
+    if (vido_renew_objects(&maps, oxy.data(), C->vObjLabel.data(), no, nobj, ioff.data(), iids.data(), ostat.data(), C->nSemPosition.data(), C->nModLabel.data(),
+                           txy.data(), mvTmpObjDepth.data(), mvTmpSemObjLabel.data(), tfl.data(), tco.data(), nt, nMaxTrackPointOBJ,
+                           okx.data(), odep.data(), osem.data(), ofl.data(), oco.data(), oinl.data(), olab.data(), ocap, &on) != VIDO_OK)
+        throw std::runtime_error("RenewFrameInfo: vido_renew_objects failed");
+    std::vector<cv::KeyPoint> okeys(on), ocorr(on); std::vector<float> odepth(odep.begin(), odep.begin() + on); std::vector<cv::Point2f> oflow(on);
+    std::vector<cv::Mat> o3d(on);
+    for (int i = 0; i < on; i++) {
+        okeys[i] = cv::KeyPoint(okx[2 * i], okx[2 * i + 1], 0, 0, 0, -1); ocorr[i] = cv::KeyPoint(oco[2 * i], oco[2 * i + 1], 0, 0, 0, -1); oflow[i] = cv::Point2f(ofl[2 * i], ofl[2 * i + 1]);
+        o3d[i] = Optimizer::Get3DinWorld(okeys[i], odepth[i], mK, Twc);
     }
-    const std::vector<cv::KeyPoint> ocheck = okeys;
-    const NearSet near_obj(ocheck, W, H);
-    for (size_t i = 0; i < C->vnObjID.size(); i++) {
-        if (!C->bObjStat[i]) continue;
-        const int SemLabel = C->nSemPosition[i]; int tot_o = cnt[i], sid = 0; const int ostep = 15;
-        while (tot_o < max_num_obj) {
-            if (sid == ostep) break;
-            for (size_t j = sid; j < mvTmpSemObjLabel.size(); j += ostep) {
-                if (mvTmpSemObjLabel[j] != SemLabel) continue;
-                if (near_obj.near(mvTmpObjKeys[j].pt)) continue;
-                okeys.push_back(mvTmpObjKeys[j]); odep.push_back(mvTmpObjDepth[j]); osem.push_back(mvTmpSemObjLabel[j]); oflow.push_back(mvTmpObjFlowNext[j]); ocorr.push_back(mvTmpObjCorres[j]);
-                oinl.push_back(-1); olab.push_back(C->nModLabel[i]); tot_o++;
-                if (tot_o >= max_num_obj) break;
-            }
-            sid++;
-        }
-    }
-    std::vector<int> UniLab = mvTmpSemObjLabel; std::sort(UniLab.begin(), UniLab.end()); UniLab.erase(std::unique(UniLab.begin(), UniLab.end()), UniLab.end());
-    std::vector<bool> known(UniLab.size(), false);
-    for (size_t i = 0; i < C->nSemPosition.size(); i++) for (size_t j = 0; j < UniLab.size(); j++) if (UniLab[j] == C->nSemPosition[i] && C->bObjStat[i]) { known[j] = true; break; }
-    for (size_t i = 0; i < known.size(); i++) if (!known[i]) for (size_t j = 0; j < mvTmpSemObjLabel.size(); j++) if (UniLab[i] == mvTmpSemObjLabel[j]) {
-        okeys.push_back(mvTmpObjKeys[j]); odep.push_back(mvTmpObjDepth[j]); osem.push_back(mvTmpSemObjLabel[j]); oflow.push_back(mvTmpObjFlowNext[j]); ocorr.push_back(mvTmpObjCorres[j]); oinl.push_back(-1); olab.push_back(-2);
-    }
-    std::vector<cv::Mat> o3d(okeys.size());
-    for (size_t i = 0; i < okeys.size(); i++) o3d[i] = Optimizer::Get3DinWorld(okeys[i], odep[i], mK, Twc);
-    C->mvObjKeys = okeys; C->mvObjDepth = odep; C->mvObj3DPoint = o3d; C->mvObjCorres = ocorr; C->mvObjFlowNext = oflow; C->vSemObjLabel = osem; C->nDynInlierID = oinl; C->vObjLabel = olab;
+    C->mvObjKeys = okeys; C->mvObjDepth = odepth; C->mvObj3DPoint = o3d; C->mvObjCorres = ocorr; C->mvObjFlowNext = oflow;
+    C->vSemObjLabel.assign(osem.begin(), osem.begin() + on); C->nDynInlierID.assign(oinl.begin(), oinl.begin() + on); C->vObjLabel.assign(olab.begin(), olab.begin() + on);
 }
 
 void Tracking::Track()                                        // Tracking.cc:1081-1509
@@ -1148,3 +1054,37 @@ int vido_system_save_results(vido_system* s, const char* prefix)
 vido_ctx* vido_system_context(vido_system* s) { return s && s->inited ? VIDO_SLAM::detail::Context() : nullptr; }
 
 }  // extern "C"
+
+// The incremental tracklet store (Map::UpdateTracklets) fed one association row at a time, as Tracking::Track does once per frame, flattened for the parity test against
+// the reference's full rebuild (Tracking::GetStaticTrack / GetDynamicTrackNew, Tracking.cc:2514-2720).  n_feat0: feature count of frame 0.
+extern "C" int vido_tracklets_incremental(int n_rows, const int32_t* row_off, const int32_t* row_n, const int32_t* TM, const int32_t* labels, int n_feat0,
+                                          int32_t* trk_off, int32_t* pairs, int32_t* obj_id, int32_t* owner_trk, int32_t* owner_pos, int cap_trk, int cap_pairs, int32_t* n_trk)
+{
+    if (n_rows < 0 || !n_trk || !trk_off || (n_rows && (!row_off || !row_n || !TM))) return VIDO_E_INVALID;
+    try {
+        VIDO_SLAM::Map M;
+        M.vpFeatSta.push_back(std::vector<cv::KeyPoint>((size_t)std::max(n_feat0, 0)));
+        for (int i = 0; i < n_rows; i++) {                    // one "frame" per row: features of the new frame, its association row, then the incremental update
+            M.vpFeatSta.push_back(std::vector<cv::KeyPoint>((size_t)row_n[i]));
+            M.vnAssoSta.push_back(std::vector<int>(TM + row_off[i], TM + row_off[i] + row_n[i]));
+            if (labels) { M.vpFeatDyn = M.vpFeatSta; M.vnAssoDyn = M.vnAssoSta; M.vnFeatLabel.push_back(std::vector<int>(labels + row_off[i], labels + row_off[i] + row_n[i])); }
+            M.UpdateTracklets();
+        }
+        const auto& T = labels ? M.TrackletDyn : M.TrackletSta;
+        const auto& trk = labels ? M.vnTrkDyn : M.vnTrkSta; const auto& pos = labels ? M.vnPosDyn : M.vnPosSta;
+        *n_trk = (int32_t)T.size();
+        if ((int)T.size() > cap_trk) return VIDO_E_CAPACITY;
+        int o = 0;
+        for (size_t t = 0; t < T.size(); t++) {
+            trk_off[t] = o;
+            for (const auto& e : T[t]) { if (o >= cap_pairs) return VIDO_E_CAPACITY; pairs[2 * o] = e.first; pairs[2 * o + 1] = e.second; o++; }
+            if (labels && obj_id) obj_id[t] = M.nObjID[t];
+        }
+        trk_off[T.size()] = o;
+        if (owner_trk && owner_pos) {                         // per-feature owner tables, frames concatenated (frame 0, then each row's frame)
+            int q = 0;
+            for (size_t f = 0; f < trk.size(); f++) for (size_t k = 0; k < trk[f].size(); k++) { owner_trk[q] = trk[f][k]; owner_pos[q] = pos[f][k]; q++; }
+        }
+    } catch (const std::exception&) { return VIDO_E_INVALID; }
+    return VIDO_OK;
+}

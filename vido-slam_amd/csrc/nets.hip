@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64) void k_nms_sweep_seg(const unsigned long long* 
         while (alive) {                                                          // wave-uniform scalar loop over the surviving boxes of the block
             const int j = __builtin_ctzll(alive);
             keepmask |= 1ull << j;
-            const unsigned long long dj = (unsigned long long)__builtin_amdgcn_readlane(dlo, j) | ((unsigned long long)__builtin_amdgcn_readlane(dhi, j) << 32);
+            const unsigned long long dj = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)dlo, j) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)dhi, j) << 32);   // (the builtin returns a signed int: no sign extension into the high word)
             alive &= ~dj; alive &= ~(1ull << j);
         }
         if ((keepmask >> lane) & 1ull) kp[cnt + __popcll(keepmask & ((1ull << lane) - 1ull))] = blk * 64 + lane;

@@ -173,12 +173,13 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 //     rows (4 rows always fit), the NMS of a chunk runs one chunk behind (it needs the first score row of the next one), and every cell has
 //     ceil(w/2) * ceil(h/2) output slots — the most 3x3-NMS survivors a w x h sub-image can have.  cv::FAST has no limit either
 //     (ORBextractor.cc:771-816 grows vToDistributeKeys without bound).
-#define FS_MAXC 4
-#define FS_PITCH 148           // image tile pitch (bytes): <= 136 interior + 6 frame + 3 alignment shift; 37 dwords (odd) -> conflict-free column walks
-#define FS_SPITCH 144          // score tile pitch: 136 interior + 4 gutters + border
-#define FS_MAXIW 136
-#define FS_AQ_CAP 384
-#define FS_CAND_CAP 768
+#define FS_MAXC 4              // most cells a strip may have (the tables below bound it further: the strip's interior must fit FS_MAXIW)
+#define FS_PITCH 84            // image tile pitch (bytes): <= 74 interior + 6 frame + 3 alignment shift; 21 dwords (odd) -> conflict-free column walks
+#define FS_SPITCH 80           // score tile pitch: 74 interior + gutters + border
+#define FS_MAXIW 74            // two ~31..37-px cells per strip: ~9 KB of LDS per wave, 17 waves per CU (four cells per strip left 9 waves per CU and the
+                               // SIMDs 63 % busy: the kernel is VALU-bound, so occupancy to cover the dependent LDS chains is worth more than longer lists)
+#define FS_AQ_CAP 192
+#define FS_CAND_CAP 384
 #define FS_RMIN 4
 struct FastStrip { int level, x0, y0, sw, sh, ncell, cell0, pad; int bx[FS_MAXC + 1]; int pad2[3]; };
 
@@ -241,9 +242,9 @@ __device__ __forceinline__ int fast_score_pk(const uint8_t* t, int th, int fl)
     const v2s V = as_v2s(v | (v << 16));
     uint32_t X[8];
     const bool dark_first = (fl & 2) == 0;                 // only the dark family can fire
-    const uint32_t M = dark_first ? 0xffffffffu : 0u;      // x -> -x per 16-bit lane: (x ^ M) - M
+    const v2s Sg = as_v2s(dark_first ? 0xffffffffu : 0x00010001u);      // +-1 per 16-bit lane: x -> -x with one v_pk_mul_lo_u16
 #pragma unroll
-    for (int j = 0; j < 8; j++) X[j] = as_u32((v2s)(as_v2s(as_u32((v2s)(as_v2s(P[j]) - V)) ^ M) - as_v2s(M)));
+    for (int j = 0; j < 8; j++) X[j] = as_u32((v2s)((as_v2s(P[j]) - V) * Sg));
     int m = fast_arc_minmax(X);
     if (__builtin_amdgcn_ballot_w64(fl == 3) != 0) {      // both families passed the pre-test for some lane (rare): evaluate the dark one as well there
         if (fl == 3) {
@@ -273,9 +274,17 @@ __global__ __launch_bounds__(64) void k_fast_strips(const uint8_t* __restrict__ 
     const uint8_t* img = pyr + (size_t)f * slab + P.off[S.level];
     const int xa = S.x0 & ~3, shift = S.x0 - xa;
     const int nd = ((S.x0 + S.sw + 3) >> 2) - (xa >> 2);          // dwords per tile row
-    for (int i = lane; i < nd * S.sh; i += 64) {
-        const int row = i / nd, col = i - row * nd;
-        *(uint32_t*)(tile + row * FS_PITCH + 4 * col) = *(const uint32_t*)(img + (size_t)(S.y0 + row) * pitch + xa + 4 * col);
+    {   // lanes 0-31 take the even rows of a batch, lanes 32-63 the odd ones, lane & 31 = dword column (nd <= 21): no division, and the five loads of a batch
+        // are in flight together (one dependent HBM/L2 round trip per 10 rows instead of one per 64 dwords)
+        const int col = lane & 31, rp = lane >> 5;
+        const uint8_t* src = img + (size_t)S.y0 * pitch + xa + 4 * col;
+        for (int r0 = 0; r0 < S.sh; r0 += 10) {
+            uint32_t v[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) { const int row = r0 + 2 * k + rp; v[k] = (col < nd && row < S.sh) ? *(const uint32_t*)(src + (size_t)row * pitch) : 0u; }
+#pragma unroll
+            for (int k = 0; k < 5; k++) { const int row = r0 + 2 * k + rp; if (col < nd && row < S.sh) *(uint32_t*)(tile + row * FS_PITCH + 4 * col) = v[k]; }
+        }
     }
     const int iw = S.sw - 6, ih = S.sh - 6;
     for (int i = lane; i < (ih + 2) * (FS_SPITCH / 4); i += 64) ((uint32_t*)sc)[i] = 0;
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(QT_NT) void k_quadtree(const uint32_t* __restrict__
                                                   const int* __restrict__ budget, int qcap, uint16_t* __restrict__ slot_scratch,
                                                   int* __restrict__ sel, int* __restrict__ selcnt, int* __restrict__ overflow, int cand_cap)
 {
-    extern __shared__ unsigned char qt_lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char qt_lds[];     // 8-byte LDS atomics on the `best` keys need the dynamic segment aligned (the static part is 20 bytes)
     QtNode* cur = (QtNode*)qt_lds;                       // [qcap]
     QtNode* nxt = cur + qcap;                            // [qcap]
     int* childcnt = (int*)(nxt + qcap);                  // [4*qcap]  (aliased by the 64-bit `best` keys at the end)
@@ -1187,6 +1196,16 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     hipLaunchKernelGGL(k_fast_strips, dim3(S->n_strips, nf), dim3(64), S->fast_lds, st, S->d_pyr, S->slab, S->P, S->d_strips, S->n_cells, S->d_slot_off, S->slot_total,
                        ctx->cfg.ini_th_fast, ctx->cfg.min_th_fast, S->fast_rows, S->d_slots, S->d_counts);
     HIP_TRY(ctx, hipEventRecord(S->ev[7], st));
+    if (getenv("VIDO_DEBUG_SYNC")) {       // debugging aid: the FAST stage alone, then its per-cell counts against the slot capacities
+        fprintf(stderr, "[vido] k_fast_strips (%d strips x %d frames, lds %zu)...\n", S->n_strips, nf, S->fast_lds);
+        hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[vido] k_fast_strips: %s\n", hipGetErrorString(e));
+        std::vector<int> hc((size_t)S->n_cells * nf), so(S->n_cells + 1);
+        hipMemcpy(hc.data(), S->d_counts, hc.size() * sizeof(int), hipMemcpyDeviceToHost); hipMemcpy(so.data(), S->d_slot_off, so.size() * sizeof(int), hipMemcpyDeviceToHost);
+        long long tot = 0; int bad = 0;
+        for (size_t i = 0; i < hc.size(); i++) { const int c = (int)(i % S->n_cells), capc = so[c + 1] - so[c]; tot += hc[i];
+            if (hc[i] < 0 || hc[i] > capc) { if (bad++ < 8) fprintf(stderr, "[vido]   cell %d (frame %zu): count %d, capacity %d\n", c, i / S->n_cells, hc[i], capc); } }
+        fprintf(stderr, "[vido] counts: total %lld, %d out of range\n", tot, bad);
+    }
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, S->d_counts, S->n_cells * nf, S->d_offsets, S->n_cells, nf, L, S->d_first_cell, S->d_lvloff);
     hipLaunchKernelGGL(k_gather_cands, dim3(S->n_cells, nf), dim3(64), 0, st, S->d_slots, S->d_counts, S->d_offsets, S->d_slot_off, S->slot_total, S->n_cells, S->d_cand, (int)S->cand_cap);
     HIP_TRY(ctx, hipEventRecord(S->ev[2], st));

@@ -556,3 +556,73 @@ class ORBextractor:
 
     def __call__(self, image, mask=None):
         return self.ctx.orb_extract(image)
+
+
+# ---- host-side bookkeeping stages of the tracker on flat arrays (include/vido_c.h "Host-side bookkeeping stages"; csrc/trackhost.cpp).  No device work: these
+# run without a GPU (the C++ facade's Tracking::RenewFrameInfo / DynObjTracking / Frame::UndistortKeyPoints call the same functions).
+class HostMaps(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("depth", C.c_void_p), ("flow", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+def _host_maps(mask, depth, flow):
+    mask = np.ascontiguousarray(mask, np.int32); depth = np.ascontiguousarray(depth, np.float32); flow = np.ascontiguousarray(flow, np.float32)
+    h, w = mask.shape
+    return HostMaps(mask.ctypes.data, depth.ctypes.data, flow.ctypes.data, w, h), (mask, depth, flow)
+
+
+def _rc(rc, what):
+    if rc < 0:
+        raise VidoError(rc, what)
+
+
+def undistort_points(xy, K, dist):
+    """Frame::UndistortKeyPoints (Frame.cc:603-633): xy (n,2) f32, K = (fx, fy, cx, cy), dist = (k1, k2, p1, p2[, k3])."""
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2); out = np.empty_like(xy)
+    Kf = np.ascontiguousarray(K, np.float32); d = np.zeros(5, np.float32); d[:len(dist)] = dist
+    _rc(load_library().vido_undistort_points(_ptr(xy), len(xy), _ptr(Kf), _ptr(d), _ptr(out)), "undistort_points")
+    return out
+
+
+def renew_static(mask, depth, flow, stat_xy, TM_sta, sample_xy, max_num):
+    """Tracking::RenewFrameInfo, static part (Tracking.cc:2973-3075) -> (src index, inlier id, flow) per kept feature."""
+    m, keep = _host_maps(mask, depth, flow)
+    stat_xy = np.ascontiguousarray(stat_xy, np.float32).reshape(-1, 2); TM = np.ascontiguousarray(TM_sta, np.int32); sample_xy = np.ascontiguousarray(sample_xy, np.float32).reshape(-1, 2)
+    cap = len(TM) + len(sample_xy) + 8
+    src = np.zeros(cap, np.int32); inl = np.zeros(cap, np.int32); fl = np.zeros((cap, 2), np.float32); n = C.c_int32()
+    _rc(load_library().vido_renew_static(C.byref(m), _ptr(stat_xy), len(stat_xy), _ptr(TM), len(TM), _ptr(sample_xy), len(sample_xy), int(max_num), _ptr(src), _ptr(inl), _ptr(fl), cap,
+                                         C.byref(n)), "renew_static")
+    return src[:n.value], inl[:n.value], fl[:n.value]
+
+
+def renew_objects(mask, depth, flow, obj_xy, obj_label, inlier_sets, obj_stat, sem_position, mod_label, tmp_xy, tmp_depth, tmp_sem, tmp_flow, tmp_corr, max_num_obj):
+    """Tracking::RenewFrameInfo, object part (Tracking.cc:3116-3270)."""
+    m, keep = _host_maps(mask, depth, flow)
+    obj_xy = np.ascontiguousarray(obj_xy, np.float32).reshape(-1, 2); obj_label = np.ascontiguousarray(obj_label, np.int32)
+    off = np.zeros(len(inlier_sets) + 1, np.int32)
+    if len(inlier_sets):
+        off[1:] = np.cumsum([len(s_) for s_ in inlier_sets])
+    ids = np.ascontiguousarray(np.concatenate([np.asarray(s_, np.int32) for s_ in inlier_sets]) if off[-1] else np.zeros(0, np.int32), np.int32)
+    st = np.ascontiguousarray(obj_stat, np.uint8); sp = np.ascontiguousarray(sem_position, np.int32); ml = np.ascontiguousarray(mod_label, np.int32)
+    txy = np.ascontiguousarray(tmp_xy, np.float32).reshape(-1, 2); td = np.ascontiguousarray(tmp_depth, np.float32); ts = np.ascontiguousarray(tmp_sem, np.int32)
+    tf = np.ascontiguousarray(tmp_flow, np.float32).reshape(-1, 2); tc = np.ascontiguousarray(tmp_corr, np.float32).reshape(-1, 2)
+    cap = len(ids) + (len(st) + 1) * len(ts) + 8
+    o = dict(keys=np.zeros((cap, 2), np.float32), depth=np.zeros(cap, np.float32), sem=np.zeros(cap, np.int32), flow=np.zeros((cap, 2), np.float32), corr=np.zeros((cap, 2), np.float32),
+             inlier=np.zeros(cap, np.int32), label=np.zeros(cap, np.int32)); n = C.c_int32()
+    _rc(load_library().vido_renew_objects(C.byref(m), _ptr(obj_xy), _ptr(obj_label), len(obj_xy), len(st), _ptr(off), _ptr(ids), _ptr(st), _ptr(sp), _ptr(ml), _ptr(txy), _ptr(td), _ptr(ts),
+                                          _ptr(tf), _ptr(tc), len(ts), int(max_num_obj), _ptr(o["keys"]), _ptr(o["depth"]), _ptr(o["sem"]), _ptr(o["flow"]), _ptr(o["corr"]),
+                                          _ptr(o["inlier"]), _ptr(o["label"]), cap, C.byref(n)), "renew_objects")
+    return {k: v[:n.value] for k, v in o.items()}
+
+
+def dyn_obj_tracking(sem_label, obj_label, obj_xy, obj_depth, flow3d, last_sem_label, last_sem_position, last_obj_stat, last_mod_label, rows, cols, sf_mg, sf_ds, th_depth_obj, f_id, max_id):
+    """Tracking::DynObjTracking (Tracking.cc:1670-1912)."""
+    sem = np.ascontiguousarray(sem_label, np.int32); lab = np.array(obj_label, np.int32, copy=True); n = len(sem)
+    xy = np.ascontiguousarray(obj_xy, np.float32).reshape(-1, 2); dep = np.ascontiguousarray(obj_depth, np.float32); f3 = np.ascontiguousarray(flow3d, np.float32).reshape(-1, 3)
+    lsem = np.ascontiguousarray(last_sem_label, np.int32); lsp = np.ascontiguousarray(last_sem_position, np.int32); lst = np.ascontiguousarray(last_obj_stat, np.uint8)
+    lml = np.ascontiguousarray(last_mod_label, np.int32); mid = C.c_int32(max_id); k = C.c_int32()
+    off = np.zeros(n + 2, np.int32); ids = np.zeros(n + 1, np.int32); ml = np.zeros(n + 1, np.int32); sp = np.zeros(n + 1, np.int32)
+    _rc(load_library().vido_dyn_obj_tracking(_ptr(sem), _ptr(lab), _ptr(xy), _ptr(dep), _ptr(f3), _ptr(lsem), n, _ptr(lsp), _ptr(lst), _ptr(lml), len(lsp), int(rows), int(cols),
+                                             C.c_float(sf_mg), C.c_float(sf_ds), C.c_float(th_depth_obj), int(f_id), C.byref(mid), _ptr(off), _ptr(ids), _ptr(ml), _ptr(sp), n + 1, C.byref(k)),
+        "dyn_obj_tracking")
+    k = k.value
+    return dict(obj_label=lab, objects=[ids[off[i]:off[i + 1]].copy() for i in range(k)], mod_label=ml[:k].copy(), sem_position=sp[:k].copy(), max_id=mid.value)

@@ -387,14 +387,21 @@ class _MaskHead(nn.Module):
         if not len(boxes):
             return feats[0].new_zeros((0, 1, 2 * self.feature_extractor.pooler.res, 2 * self.feature_extractor.pooler.res))
         n = len(boxes)
-        if boxes.is_cuda and self.buckets:
-            # MIOpen compiles / selects its kernels per problem shape, and the detection count is the batch dimension of the mask head's six convolutions:
-            # round it up to a few fixed sizes (zero-area padding boxes, their rows dropped again) so that a new count never means new kernels
-            m = next((b for b in self.buckets if b >= n), n)
-            if m > n:
-                boxes = torch.cat([boxes, boxes.new_zeros((m - n, 4))]); labels = torch.cat([labels, labels.new_zeros((m - n,))])
-        logits = self.predictor(self.feature_extractor(feats, boxes))
-        return logits.sigmoid()[torch.arange(len(boxes), device=labels.device), labels][:n, None]
+        idx = torch.arange(n, device=labels.device)
+        if not (boxes.is_cuda and self.buckets):
+            return self.predictor(self.feature_extractor(feats, boxes)).sigmoid()[idx, labels][:, None]
+        # MIOpen compiles / selects its kernels per problem shape, and the detection count is the batch dimension of the mask head's six convolutions: run it in
+        # chunks of at most buckets[-1] detections, each rounded up to one of a few fixed sizes (zero-area padding boxes, their rows dropped again), so that no
+        # detection count ever means new kernels (score ties at the kthvalue cut can push the count past detections_per_img, box_head/inference.py:131-137)
+        out = []; big = self.buckets[-1]
+        for a in range(0, n, big):
+            bx, lb = boxes[a:a + big], labels[a:a + big]; k = len(bx)
+            m = next(b for b in self.buckets if b >= k)
+            if m > k:
+                bx = torch.cat([bx, bx.new_zeros((m - k, 4))]); lb = torch.cat([lb, lb.new_zeros((m - k,))])
+            logits = self.predictor(self.feature_extractor(feats, bx))
+            out.append(logits.sigmoid()[torch.arange(m, device=lb.device), lb][:k, None])
+        return torch.cat(out)
 
 
 class _RoiHeads(nn.Module):
