@@ -99,3 +99,58 @@ def test_kitti_mode_runs_the_full_batch_with_object_factors(tmp_path, vido):
     assert len(mot) >= n - 3
     moved = [np.abs(row[2:14].reshape(3, 4) - np.eye(3, 4)).max() for row in mot]
     assert max(moved) > 1e-3                                                     # the motion vertices start at identity and were optimised
+
+
+def write_kaist_clip(tmp, scene, n, bf=387.57, factor=100.0):
+    """The reference's on-disk layout (vido_slam/demo/run_vido_slam.cc:47-65, 113-122): vTimestampsImage.txt (header + integer nanoseconds),
+    <image_path>/<first 19 chars of to_string(stamp)>.png Bayer-RG u8, ../flow_image/*.flo, ../depth_image/*.png u16 (KAIST: depth = bf / (value / DepthMapFactor)),
+    ../mask_image/*.png u8."""
+    from PIL import Image
+    for sub in ("image_0", "flow_image", "depth_image", "mask_image"):
+        os.makedirs(os.path.join(tmp, sub), exist_ok=True)
+    stamps = [1544590798700000000 + 100000000 * k for k in range(n)]
+    with open(os.path.join(tmp, "vTimestampsImage.txt"), "w") as fh:
+        fh.write("#timestamp [ns]\n" + "".join("%d\n" % s for s in stamps))
+    for k, s in enumerate(stamps):
+        name = ("%d" % s)[:19]
+        g, d, f, m = scene.frame(k)
+        Image.fromarray(g, mode="L").save(os.path.join(tmp, "image_0", name + ".png"))          # a gray scene: its Bayer mosaic is the gray image itself
+        with open(os.path.join(tmp, "flow_image", name + ".flo"), "wb") as fh:
+            np.array([202021.25], np.float32).tofile(fh); np.array([scene.w, scene.h], np.int32).tofile(fh); f.astype(np.float32).tofile(fh)
+        raw = np.clip(np.rint(bf * factor / d.astype(np.float64)), 1, 65535).astype(np.uint16)
+        Image.fromarray(raw, mode="I;16").save(os.path.join(tmp, "depth_image", name + ".png"))
+        Image.fromarray(m.astype(np.uint8), mode="L").save(os.path.join(tmp, "mask_image", name + ".png"))
+    fx, fy, cx, cy = scene.K
+    cfg = os.path.join(tmp, "config.yaml")
+    with open(cfg, "w") as fh:
+        fh.write("%%YAML:1.0\nimage_path: %s\nstart_index: 0\nslam_mode: 0\nCamera.width: %d\nCamera.height: %d\n" % (os.path.join(tmp, "image_0"), scene.w, scene.h))
+        fh.write("Camera.fx: %r\nCamera.fy: %r\nCamera.cx: %r\nCamera.cy: %r\nCamera.k1: 0.0\nCamera.k2: 0.0\nCamera.p1: 0.0\nCamera.p2: 0.0\nCamera.k3: 0.0\n" % (fx, fy, cx, cy))
+        fh.write("Camera.bf: %r\nCamera.fps: 10.0\nCamera.RGB: 0\nChooseData: 3\nDepthMapFactor: %r\nThDepthBG: 40.0\nThDepthOBJ: 25.0\n" % (bf, factor))
+        fh.write("MaxTrackPointBG: 3000\nMaxTrackPointOBJ: 800\nSFMgThres: 0.12\nSFDsThres: 0.3\nWINDOW_SIZE: 20\nOVERLAP_SIZE: 4\nUseSampleFeature: 0\n")
+        fh.write("ORBextractor.nFeatures: 2000\nORBextractor.scaleFactor: 1.2\nORBextractor.nLevels: 8\nORBextractor.iniThFAST: 20\nORBextractor.minThFAST: 7\n")
+    return cfg
+
+
+def test_reference_disk_layout_50_frame_clip(tmp_path, vido):
+    """BASELINE configs[0]: a 50-frame clip in the REFERENCE's on-disk layout (time-stamp file, Bayer-RG / 16-bit / 8-bit PNGs, .flo) through the offline driver:
+    PNG decoding (zlib inflate + scan-line filters), Bayer demosaic, the KAIST depth convention, the cvtColor ingest on the device, 50 x TrackRGBD with a full 20-frame
+    local-BA window for the last 30 frames.  Poses follow the renderer's ground truth (depth is quantised to 16 bits like the dataset's)."""
+    sys.path.insert(0, os.path.join(ROOT, "vido-slam_amd"))
+    import build
+    driver = build.build_driver()
+    n = 50
+    scene = vido.synth.Scene3D(n_frames=n, seed=3, step=0.2, yaw_deg=0.1, objects=((-2.0, 0.4, 9.0, 0.02, 0.0, 0.22),), wall_z=48.0)
+    cfg = write_kaist_clip(str(tmp_path), scene, n)
+    out = os.path.join(str(tmp_path), "poses.txt")
+    r = subprocess.run([driver, cfg, out, os.path.join(str(tmp_path), "res_")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "frames 50" in r.stdout and "incremental_equals_rebuild 1" in r.stdout, r.stdout
+    P = np.loadtxt(out)
+    assert P.shape == (n, 17)
+    err = []
+    for k in range(1, n):
+        E = P[k, 1:].reshape(4, 4) @ np.linalg.inv(scene.Tcw(k))
+        err.append(np.linalg.norm(E[:3, 3]))
+    assert max(err) < 0.15 and np.mean(err) < 0.06, (max(err), np.mean(err))            # 9.8 m path, u16 disparity depth
+    ref = np.loadtxt(os.path.join(str(tmp_path), "res_refined_rgbd_new.txt"))
+    assert ref.shape == (n, 17)

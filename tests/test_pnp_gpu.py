@@ -14,8 +14,34 @@ def test_pnp_ransac_matches_oracle(vido, oracle, n, outl, seed):
     T, mask, cnt = vido.pnp_ransac(ctx, s["Xw"], s["uv_cur"], s["K"], seed=seed)
     Tr, maskr, cntr = oracle.pnp_ransac(s["Xw"], s["uv_cur"], s["K"], seed=seed)
     assert np.abs(T - Tr).max() < 1e-6
-    assert abs(cnt - cntr) <= 2 and (mask != maskr).sum() <= 2
+    # inlier masks: EXACT, except for points whose squared reprojection error under the oracle's pose lies within EPS of the 0.4 px threshold (the two poses
+    # differ by FP64 rounding of the quartic's roots, so only such points can fall on different sides)
+    EPS = 1e-6
+    fx, fy, cx, cy = s["K"]
+    Xc = s["Xw"] @ Tr[:3, :3].T + Tr[:3, 3]
+    e2 = (fx * Xc[:, 0] / Xc[:, 2] + cx - s["uv_cur"][:, 0]) ** 2 + (fy * Xc[:, 1] / Xc[:, 2] + cy - s["uv_cur"][:, 1]) ** 2
+    band = np.abs(e2 - 0.4 ** 2) <= EPS
+    assert np.array_equal(mask[~band], maskr[~band])
+    assert abs(cnt - cntr) <= int(band.sum())
     assert np.abs(T - s["T_cur"]).max() < 0.05 and cnt > 0.3 * n * (1 - outl)
+
+
+def test_pnp_batch_equals_single_calls(vido):
+    """vido_pnp_ransac_batch (all objects of a frame in one launch pair, one synchronisation) == one vido_pnp_ransac per problem, bit for bit."""
+    import ctypes as C
+    ctx = vido.Context()
+    probs = [vido.problems.synth_pose_scene(n, seed=10 + i, noise_px=0.05, outlier_frac=0.2) for i, n in enumerate((800, 3, 450, 0, 1200))]
+    K = probs[0]["K"]
+    X = [np.ascontiguousarray(p["Xw"], np.float32) for p in probs]; x = [np.ascontiguousarray(p["uv_cur"], np.float32) for p in probs]
+    ns = np.array([len(a) for a in X], np.int32); seeds = np.arange(5, dtype=np.uint64) + 77
+    T = np.zeros((5, 16)); masks = [np.zeros(max(n, 1), np.uint8) for n in ns]; cnt = np.zeros(5, np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    p3 = (C.c_void_p * 5)(*[a.ctypes.data if len(a) else None for a in X]); p2 = (C.c_void_p * 5)(*[a.ctypes.data if len(a) else None for a in x]); pm = (C.c_void_p * 5)(*[m.ctypes.data for m in masks])
+    ctx._check(ctx.lib.vido_pnp_ransac_batch(ctx.h, 5, p3, p2, vp(ns), C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), 500, C.c_double(0.4), C.c_double(0.98),
+                                             vp(seeds), vp(T), pm, vp(cnt)))
+    for i, p in enumerate(probs):
+        Ti, mi, ci = vido.pnp_ransac(ctx, p["Xw"], p["uv_cur"], K, seed=int(seeds[i]))
+        assert np.array_equal(T[i].reshape(4, 4), Ti) and ci == cnt[i] and np.array_equal(masks[i][:ns[i]].astype(bool), mi), i
 
 
 def test_pnp_degenerate(vido):

@@ -45,7 +45,7 @@ def build_driver(force=False):
     if not force and os.path.exists(DRIVER) and os.path.getmtime(DRIVER) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
         return DRIVER
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.check_call([hipcc, "-O2", "-std=c++17", "-x", "c++", src, "-o", DRIVER, "-L" + HERE, "-lvido_slam_hip", "-Wl,-rpath," + HERE, "-Wl,-rpath,$ORIGIN"])
+    subprocess.check_call([hipcc, "-O2", "-std=c++17", "-x", "c++", src, "-o", DRIVER, "-L" + HERE, "-lvido_slam_hip", "-lz", "-Wl,-rpath," + HERE, "-Wl,-rpath,$ORIGIN"])
     return DRIVER
 
 

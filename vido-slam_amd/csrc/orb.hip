@@ -173,13 +173,16 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 //     rows (4 rows always fit), the NMS of a chunk runs one chunk behind (it needs the first score row of the next one), and every cell has
 //     ceil(w/2) * ceil(h/2) output slots — the most 3x3-NMS survivors a w x h sub-image can have.  cv::FAST has no limit either
 //     (ORBextractor.cc:771-816 grows vToDistributeKeys without bound).
-#define FS_MAXC 4              // most cells a strip may have (the tables below bound it further: the strip's interior must fit FS_MAXIW)
-#define FS_PITCH 84            // image tile pitch (bytes): <= 74 interior + 6 frame + 3 alignment shift; 21 dwords (odd) -> conflict-free column walks
-#define FS_SPITCH 80           // score tile pitch: 74 interior + gutters + border
-#define FS_MAXIW 74            // two ~31..37-px cells per strip: ~9 KB of LDS per wave, 17 waves per CU (four cells per strip left 9 waves per CU and the
-                               // SIMDs 63 % busy: the kernel is VALU-bound, so occupancy to cover the dependent LDS chains is worth more than longer lists)
-#define FS_AQ_CAP 192
-#define FS_CAND_CAP 384
+#define FS_MAXC 4              // most cells a strip may have (the strip's interior must also fit FS_MAXIW)
+#ifndef FS_MAXIW
+#define FS_MAXIW 74            // strip interior width: two ~31..37-px cells -> ~9 KB of LDS per wave, 17 waves per CU.  The kernel is VALU-bound (rocprofv3: 63 % of
+                               // the SIMD cycles issue VALU with four cells per strip / 9 waves per CU, 82 % with two / 17), so occupancy to cover the dependent
+                               // LDS chains is worth more than longer candidate lists; measured 0.264 ms (four cells), 0.220 ms (two) per 64 frames
+#endif
+#define FS_PITCH (4 * (((FS_MAXIW + 12) / 4) | 1))     // image tile pitch (bytes): interior + 6 frame + 3 alignment shift, an ODD number of dwords (conflict-free column walks)
+#define FS_SPITCH (4 * ((FS_MAXIW + FS_MAXC + 5) / 4)) // score tile pitch: interior + one gutter per cell + border
+#define FS_AQ_CAP (2 * FS_MAXIW + 44)                  // >= FS_RMIN rows of quads
+#define FS_CAND_CAP (5 * FS_MAXIW + 14)                // >= FS_RMIN rows of pixels
 #define FS_RMIN 4
 struct FastStrip { int level, x0, y0, sw, sh, ncell, cell0, pad; int bx[FS_MAXC + 1]; int pad2[3]; };
 

@@ -256,15 +256,16 @@ int vido_frame_upload(vido_ctx* ctx, int slot0, int n_frames, float* depth, cons
     TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
     if (slot0 < 0 || n_frames < 1 || slot0 + n_frames > T->B || !depth || !flow || !mask)
         return vido_set_error(ctx, VIDO_E_INVALID, "frame_upload: slots [%d,%d) outside [0,%d) or null map", slot0, slot0 + n_frames, T->B);
+    const size_t px = (size_t)T->W * T->H, n = px * n_frames;
+    if ((n & 3) != 0) return vido_set_error(ctx, VIDO_E_INVALID, "frame_upload: width*height must be a multiple of 4");      // every argument is validated before any state changes
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const size_t px = (size_t)T->W * T->H, n = px * n_frames;
     float* dd = T->d_depth + slot0 * px;
-    for (int f = 0; f < n_frames; f++) { T->sdepth[slot0 + f] = T->d_depth + (slot0 + f) * px; T->sflow[slot0 + f] = T->d_flow + (slot0 + f) * px * 2; T->smask[slot0 + f] = T->d_mask + (slot0 + f) * px; }
     HIP_TRY(ctx, hipMemcpyAsync(dd, depth, n * 4, in_kind(on_device), st));
     HIP_TRY(ctx, hipMemcpyAsync(T->d_flow + slot0 * px * 2, flow, n * 8, in_kind(on_device), st));
     HIP_TRY(ctx, hipMemcpyAsync(T->d_mask + slot0 * px, mask, n * 4, in_kind(on_device), st));
-    if ((n & 3) != 0) return vido_set_error(ctx, VIDO_E_INVALID, "frame_upload: width*height must be a multiple of 4");
+    // the slot tables are repointed only once the copies have been accepted (a failed enqueue leaves the previous frame's slots referenced)
+    for (int f = 0; f < n_frames; f++) { T->sdepth[slot0 + f] = T->d_depth + (slot0 + f) * px; T->sflow[slot0 + f] = T->d_flow + (slot0 + f) * px * 2; T->smask[slot0 + f] = T->d_mask + (slot0 + f) * px; }
     const int grid = (int)std::min<size_t>((n / 4 + 255) / 256, 2048);
     hipLaunchKernelGGL(k_depth_prescale, dim3(grid), dim3(256), 0, st, dd, n / 4, p->dataset, p->depth_map_factor, p->bf, p->kaist_scale);
     // the reference mutates the caller's depth buffer in place (Tracking.cc:299-322): hand the scaled map back

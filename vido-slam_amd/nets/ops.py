@@ -85,6 +85,10 @@ class HipOps:
             return torch.zeros((0,), dtype=torch.int64, device=boxes.device)
         order = torch.sort(scores, descending=True, stable=True)[1]
         sb = boxes[order].contiguous().float(); sg = groups[order].to(torch.int32).contiguous(); n = sb.shape[0]
+        if n <= 65536:                                   # one segment through the block-wise sweep (k_nms_sweep_seg): ~10x the single-wave sequential sweep at a few thousand boxes
+            keep, cnt = self.nms_segments(sb, torch.zeros(1, device=boxes.device, dtype=torch.int32), torch.full((1,), n, device=boxes.device, dtype=torch.int32), n, thresh, groups=sg)
+            m = int(cnt.item())
+            return torch.sort(order[keep[0, :m].long()])[0]
         keep = torch.empty(n, device=boxes.device, dtype=torch.int32); cnt = torch.zeros(1, device=boxes.device, dtype=torch.int32)
         self._adopt_stream()
         self.ctx._check(self.ctx.lib.vido_nms_grouped(self.ctx.h, C.c_void_p(sb.data_ptr()), None, C.c_void_p(sg.data_ptr()), n, C.c_float(thresh),
