@@ -21,19 +21,52 @@ def _stamp():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
-    stamp_file = LIB + ".stamp"
-    stamp = _stamp()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
-        return LIB
+def _obj_stamp(src):
+    h = hashlib.sha1()
+    h.update(open(src, "rb").read())
+    for p in sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(glob.glob(os.path.join(HERE, "..", "include", "*.h"))) + sorted(glob.glob(os.path.join(HERE, "..", "include", "vido_slam", "*.h"))):
+        h.update(open(p, "rb").read())
+    h.update(" ".join(FLAGS + _file_flags(src)).encode())
+    return h.hexdigest()
+
+
+def _file_flags(src):
+    """VIDO_FLAGS_<stem> (e.g. VIDO_FLAGS_orb="-DFS_MAXIW=37"): experiment flags for one source only, so that a variant build recompiles one object"""
+    return _shlex.split(os.environ.get("VIDO_FLAGS_" + os.path.basename(src).split(".")[0], ""))
+
+
+def build(force=False, verbose=False, lib=None):
+    """One object per source (compiled in parallel, cached by content hash under build/), one link."""
+    lib = lib or LIB
+    stamp_file = lib + ".stamp"
+    stamp = _stamp() + "".join(" ".join(_file_flags(x)) for x in sources())
+    if not force and os.path.exists(lib) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    srcs = sources()
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + sum((["-x", "hip", s] for s in srcs), [])
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"]
+    jobs, objs = [], []
+    for s in sources():
+        o = os.path.join(objdir, os.path.basename(s) + "." + _obj_stamp(s)[:16] + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o):
+            jobs.append([hipcc] + cflags + _file_flags(s) + ["-c", "-x", "hip", s, "-o", o])
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", lib] + objs)
+    live = set(objs)
+    for o in glob.glob(os.path.join(objdir, "*.o")):            # drop the objects of older source versions
+        if o not in live and lib == LIB:
+            os.remove(o)
     open(stamp_file, "w").write(stamp)
-    return LIB
+    return lib
 
 
 DRIVER = os.path.join(HERE, "run_vido_slam.bin")

@@ -174,16 +174,22 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 //     ceil(w/2) * ceil(h/2) output slots — the most 3x3-NMS survivors a w x h sub-image can have.  cv::FAST has no limit either
 //     (ORBextractor.cc:771-816 grows vToDistributeKeys without bound).
 #define FS_MAXC 4              // most cells a strip may have (the strip's interior must also fit FS_MAXIW)
-#ifndef FS_MAXIW
-#define FS_MAXIW 74            // strip interior width: two ~31..37-px cells -> ~9 KB of LDS per wave, 17 waves per CU.  The kernel is VALU-bound (rocprofv3: 63 % of
-                               // the SIMD cycles issue VALU with four cells per strip / 9 waves per CU, 82 % with two / 17), so occupancy to cover the dependent
-                               // LDS chains is worth more than longer candidate lists; measured 0.264 ms (four cells), 0.220 ms (two) per 64 frames
+// Strip geometry for a strip interior of at most IW pixels.  Two instantiations: IW = 37 (one ~31..37-px cell per strip: ~5 KB of LDS per wave) when every cell of the
+// configuration fits, else IW = 74 (cells are < 60 px wide by construction, ORBextractor.cc:781-787).  The kernel is VALU-bound (rocprofv3: 83 % of the SIMD cycles issue
+// VALU), so short strips (more waves, less ragged list tails per chunk) beat longer candidate lists; per 64 frames of 640x480, r2 final form: 0.176 ms (37), 0.20 ms (74);
+// the first strip kernel: 0.264 ms (148), 0.220 ms (74), 0.213 ms (37); round 1's one-workgroup-per-cell kernel: 0.197 ms.
+template <int IW> struct FsGeom {
+    static constexpr int PITCH = 4 * (((IW + 12) / 4) | 1);       // image tile pitch (bytes): interior + 6 frame + 3 alignment shift, an ODD number of dwords (conflict-free column walks)
+    static constexpr int SPITCH = 4 * ((IW + FS_MAXC + 5) / 4);   // score tile pitch: interior + one gutter per cell + border
+    static constexpr int AQ_CAP = 3 * IW + 34;                    // quad list: a chunk is sized to fit it even if every quad survives (>= FS_RMIN rows of quads)
+    static constexpr int CAND_CAP = 6 * IW + 68;                  // candidate list: denser chunks are redone with half the rows (>= FS_RMIN rows x 2 entries per pixel fit)
+    static size_t lds_bytes(int max_sh) { return 16 + (size_t)max_sh * PITCH + (size_t)(max_sh - 4) * SPITCH + sizeof(uint32_t) * AQ_CAP + sizeof(uint16_t) * 3 * CAND_CAP + 16; }
+};
+#ifndef FS_NARROW
+#define FS_NARROW 37
 #endif
-#define FS_PITCH (4 * (((FS_MAXIW + 12) / 4) | 1))     // image tile pitch (bytes): interior + 6 frame + 3 alignment shift, an ODD number of dwords (conflict-free column walks)
-#define FS_SPITCH (4 * ((FS_MAXIW + FS_MAXC + 5) / 4)) // score tile pitch: interior + one gutter per cell + border
-#define FS_AQ_CAP (2 * FS_MAXIW + 44)                  // >= FS_RMIN rows of quads
-#define FS_CAND_CAP (5 * FS_MAXIW + 14)                // >= FS_RMIN rows of pixels
-#define FS_RMIN 4
+#define FS_WIDE 74
+#define FS_RMIN 2              // rows of the smallest chunk: its quads and its candidate entries (two per pixel at most) always fit the lists
 struct FastStrip { int level, x0, y0, sw, sh, ncell, cell0, pad; int bx[FS_MAXC + 1]; int pad2[3]; };
 
 typedef unsigned short v2u __attribute__((ext_vector_type(2)));
@@ -191,6 +197,18 @@ __device__ __forceinline__ v2u as_v2u(uint32_t x) { return __builtin_bit_cast(v2
 __device__ __forceinline__ v2s as_v2s(uint32_t x) { return __builtin_bit_cast(v2s, x); }
 __device__ __forceinline__ uint32_t as_u32(v2u x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_cast(uint32_t, x); }
+
+// inclusive prefix sum over the 64 lanes of a wave (all lanes active): four row_shr steps inside the rows of 16, then row_bcast:15 / row_bcast:31
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);          // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);          // row_bcast:31 into rows 2 and 3
+    return v;
+}
 
 // Compass pre-test of the four pixels of an aligned quad.  Returns R with, for pixel p, the pair (bright, dark) at bits (15,14) p=0, (31,30) p=1,
 // (13,12) p=2, (29,28) p=3: "bright" = at least two of ring 0/4/8/12 are > v + th, "dark" = at least two are < v - th.
@@ -214,62 +232,70 @@ __device__ __forceinline__ uint32_t fast_compass_quad2(uint32_t up, uint32_t m0,
     return R;
 }
 
-// max over the 16 arcs of 9 contiguous ring pixels of the arc's minimum of X (8 registers of two i16: X[j] = (x[2j], x[2j+1]))
+// max over the 16 arcs of 9 contiguous ring pixels of the arc's minimum of X (8 registers of two u16: X[j] = (x[2j], x[2j+1]), values 0..255)
 __device__ __forceinline__ int fast_arc_minmax(const uint32_t X[8])
 {
     uint32_t A[8], B[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) A[j] = as_u32(__builtin_elementwise_min(as_v2s(X[j]), as_v2s(__builtin_amdgcn_alignbit(X[(j + 1) & 7], X[j], 16))));     // a2[k] = min(x[k], x[k+1])
+    for (int j = 0; j < 8; j++) A[j] = as_u32(__builtin_elementwise_min(as_v2u(X[j]), as_v2u(__builtin_amdgcn_alignbit(X[(j + 1) & 7], X[j], 16))));     // a2[k] = min(x[k], x[k+1])
 #pragma unroll
-    for (int j = 0; j < 8; j++) B[j] = as_u32(__builtin_elementwise_min(as_v2s(A[j]), as_v2s(A[(j + 1) & 7])));                                          // a4[k] = min(a2[k], a2[k+2])
+    for (int j = 0; j < 8; j++) B[j] = as_u32(__builtin_elementwise_min(as_v2u(A[j]), as_v2u(A[(j + 1) & 7])));                                          // a4[k] = min(a2[k], a2[k+2])
 #pragma unroll
-    for (int j = 0; j < 8; j++) A[j] = as_u32(__builtin_elementwise_min(as_v2s(B[j]), as_v2s(B[(j + 2) & 7])));                                          // a8[k] = min(a4[k], a4[k+4])
+    for (int j = 0; j < 8; j++) A[j] = as_u32(__builtin_elementwise_min(as_v2u(B[j]), as_v2u(B[(j + 2) & 7])));                                          // a8[k] = min(a4[k], a4[k+4])
 #pragma unroll
-    for (int j = 0; j < 8; j++) B[j] = as_u32(__builtin_elementwise_min(as_v2s(A[j]), as_v2s(X[(j + 4) & 7])));                                          // a9[k] = min(a8[k], x[k+8])
-    v2s m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_max(as_v2s(B[0]), as_v2s(B[1])), __builtin_elementwise_max(as_v2s(B[2]), as_v2s(B[3]))),
-                                      __builtin_elementwise_max(__builtin_elementwise_max(as_v2s(B[4]), as_v2s(B[5])), __builtin_elementwise_max(as_v2s(B[6]), as_v2s(B[7]))));
+    for (int j = 0; j < 8; j++) B[j] = as_u32(__builtin_elementwise_min(as_v2u(A[j]), as_v2u(X[(j + 4) & 7])));                                          // a9[k] = min(a8[k], x[k+8])
+    v2u m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_max(as_v2u(B[0]), as_v2u(B[1])), __builtin_elementwise_max(as_v2u(B[2]), as_v2u(B[3]))),
+                                      __builtin_elementwise_max(__builtin_elementwise_max(as_v2u(B[4]), as_v2u(B[5])), __builtin_elementwise_max(as_v2u(B[6]), as_v2u(B[7]))));
     return max((int)m.x, (int)m.y);
 }
 
-// Threshold-free score of the pixel at LDS tile position t for the arc families the pre-test left possible (fl bit 1: bright, bit 0: dark):
-// S = (max over arcs of the arc's min one-signed difference) - 1 if that maximum exceeds th (corner at th: cv::FAST's score, the largest threshold at which
-// the pixel is still a corner), else 0.
-__device__ __forceinline__ int fast_score_pk(const uint8_t* t, int th, int fl)
+// One-signed arc strength of the pixel at LDS tile position t for ONE arc family (dark != 0: the darker arcs): max over the 16 arcs of the arc's minimum one-signed
+// difference to the centre; the pixel is a corner at threshold th iff the larger of its two families' strengths exceeds th, and cv::FAST's score (the largest
+// threshold at which it is still a corner) is that maximum - 1.
+// The differences are never formed: bright: max_arcs(min_arc p) - v; dark: v - min_arcs(max_arc p) = max_arcs(min_arc (255 - p)) - (255 - v), i.e. the same
+// tree on p ^ 255 (one v_xor per register pair with a per-lane mask).  Sixteen byte reads at immediate offsets from one address (the compiler pairs horizontally
+// adjacent ones into u16 reads) — measured faster than 7 unaligned b32 / b64 LDS reads + perms (unaligned LDS reads are slow) and than aligned dword pairs + v_alignbyte.
+template <int FS_PITCH> __device__ __forceinline__ int fast_strength_pk(const uint8_t* t, bool dark)
 {
-    const uint32_t v = t[0];
     uint32_t P[8];
-    P[0] = t[3 * FS_PITCH] | ((uint32_t)t[3 * FS_PITCH + 1] << 16);  P[1] = t[2 * FS_PITCH + 2] | ((uint32_t)t[FS_PITCH + 3] << 16);
-    P[2] = t[3] | ((uint32_t)t[-FS_PITCH + 3] << 16);                P[3] = t[-2 * FS_PITCH + 2] | ((uint32_t)t[-3 * FS_PITCH + 1] << 16);
-    P[4] = t[-3 * FS_PITCH] | ((uint32_t)t[-3 * FS_PITCH - 1] << 16); P[5] = t[-2 * FS_PITCH - 2] | ((uint32_t)t[-FS_PITCH - 3] << 16);
-    P[6] = t[-3] | ((uint32_t)t[FS_PITCH - 3] << 16);                P[7] = t[2 * FS_PITCH - 2] | ((uint32_t)t[3 * FS_PITCH - 1] << 16);
-    const v2s V = as_v2s(v | (v << 16));
+    auto pr = [&](int o0, int o1) { v2u p; p.x = t[o0]; p.y = t[o1]; return as_u32(p); };
+    P[0] = pr(3 * FS_PITCH, 3 * FS_PITCH + 1);        P[1] = pr(2 * FS_PITCH + 2, FS_PITCH + 3);
+    P[2] = pr(3, -FS_PITCH + 3);                      P[3] = pr(-2 * FS_PITCH + 2, -3 * FS_PITCH + 1);
+    P[4] = pr(-3 * FS_PITCH, -3 * FS_PITCH - 1);      P[5] = pr(-2 * FS_PITCH - 2, -FS_PITCH - 3);
+    P[6] = pr(-3, FS_PITCH - 3);                      P[7] = pr(2 * FS_PITCH - 2, 3 * FS_PITCH - 1);
+    const uint32_t v = t[0];
+    const uint32_t M = dark ? 0x00ff00ffu : 0u;
     uint32_t X[8];
-    const bool dark_first = (fl & 2) == 0;                 // only the dark family can fire
-    const v2s Sg = as_v2s(dark_first ? 0xffffffffu : 0x00010001u);      // +-1 per 16-bit lane: x -> -x with one v_pk_mul_lo_u16
 #pragma unroll
-    for (int j = 0; j < 8; j++) X[j] = as_u32((v2s)((as_v2s(P[j]) - V) * Sg));
-    int m = fast_arc_minmax(X);
-    if (__builtin_amdgcn_ballot_w64(fl == 3) != 0) {      // both families passed the pre-test for some lane (rare): evaluate the dark one as well there
-        if (fl == 3) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) X[j] = as_u32((v2s)(V - as_v2s(P[j])));
-            m = max(m, fast_arc_minmax(X));
-        }
-    }
-    return m > th ? m - 1 : 0;
+    for (int j = 0; j < 8; j++) X[j] = P[j] ^ M;
+    return fast_arc_minmax(X) - (int)(v ^ (M & 0xffu));
 }
 
+#ifdef FS_PROF
+// debug build only (VIDO_EXTRA_FLAGS=-DFS_PROF): loop-trip counters of k_fast_strips, read by tools/dbg_fast_batch.py
+__device__ unsigned long long fs_prof[16];
+#define FS_CNT(i, v) do { if (lane == 0) atomicAdd(&fs_prof[i], (unsigned long long)(v)); } while (0)
+extern "C" int vido_debug_fs_prof(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fs_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(fs_prof), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define FS_CNT(i, v) do { } while (0)
+#endif
 // dynamic LDS per wave (bytes): [16 pad][tile sh x FS_PITCH][score (ih + 2) x FS_SPITCH][aq u32 x FS_AQ_CAP][cand u16 x FS_CAND_CAP][corner u16 x 2 x FS_CAND_CAP]
-__global__ __launch_bounds__(64) void k_fast_strips(const uint8_t* __restrict__ pyr, size_t slab, PyrDev P,
+template <int IW> __global__ __launch_bounds__(64) void k_fast_strips(const uint8_t* __restrict__ pyr, size_t slab, PyrDev P,
                                                     const FastStrip* __restrict__ strips, int n_cells, const int* __restrict__ slot_off, int slot_total,
                                                     int ini_th, int min_th, int lds_rows, uint32_t* __restrict__ slots, int* __restrict__ counts)
 {
+    constexpr int FS_PITCH = FsGeom<IW>::PITCH, FS_SPITCH = FsGeom<IW>::SPITCH, FS_AQ_CAP = FsGeom<IW>::AQ_CAP, FS_CAND_CAP = FsGeom<IW>::CAND_CAP;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint8_t* tile = lds_raw + 16;
     uint8_t* sc = tile + lds_rows * FS_PITCH;
     uint32_t* aq = (uint32_t*)(sc + (lds_rows - 4) * FS_SPITCH);
     uint16_t* cand = (uint16_t*)(aq + FS_AQ_CAP);
-    uint16_t* corn = cand + FS_CAND_CAP;                            // two buffers of FS_CAND_CAP
+    uint16_t* corn = cand + FS_CAND_CAP + 2;                        // (cand[FS_CAND_CAP] is the expansion's dump slot) two buffers of FS_CAND_CAP
     int sidx, f; xcd_tile_frame(sidx, f);
     const int lane = threadIdx.x;
     const FastStrip S = strips[sidx];
@@ -290,6 +316,7 @@ __global__ __launch_bounds__(64) void k_fast_strips(const uint8_t* __restrict__ 
         }
     }
     const int iw = S.sw - 6, ih = S.sh - 6;
+    FS_CNT(11, 1); FS_CNT(14, iw * ih);
     for (int i = lane; i < (ih + 2) * (FS_SPITCH / 4); i += 64) ((uint32_t*)sc)[i] = 0;
     __builtin_amdgcn_s_waitcnt(0);                                  // single wave: LDS is coherent within it once the accesses have completed
     __builtin_amdgcn_wave_barrier();
@@ -305,6 +332,7 @@ __global__ __launch_bounds__(64) void k_fast_strips(const uint8_t* __restrict__ 
     // per-sub-image NMS + ordered emission of the corners in list cl[0..n): strictly greater than the 8 neighbours (gutters / never-written entries are 0)
     auto nms_emit = [&](const uint16_t* cl, int n) {
         for (int q0 = 0; q0 < n; q0 += 64) {
+            FS_CNT(6, 1); FS_CNT(7, min(64, n - q0));
             const int q = q0 + lane;
             bool keep = false; uint32_t packed = 0; int c = 0;
             if (q < n) {
@@ -329,14 +357,21 @@ __global__ __launch_bounds__(64) void k_fast_strips(const uint8_t* __restrict__ 
     auto process = [&](int xlo, int xhi, int th) {
         const int qc0 = (tx0 + xlo) >> 2, nq = ((tx0 + xhi - 1) >> 2) - qc0 + 1;
         const uint32_t T2 = (uint32_t)th | ((uint32_t)th << 16);
+#ifdef FS_OLD_CHUNK
         int R = ih, r0 = 0, prev_n = 0, kb = 0;
+#else
+        int R = min(ih, max(FS_RMIN, FS_AQ_CAP / nq)), r0 = 0, prev_n = 0, kb = 0;
+#endif      // a chunk's quads always fit the quad list (a first try with all rows failed for 9 strips in 10)
+        FS_CNT(12, 1); FS_CNT(13, (xhi - xlo) * ih);
         while (r0 < ih) {
             const int r1 = min(r0 + R, ih), ntask = (r1 - r0) * nq;
+            FS_CNT(8, 1);
             // ---- phase a: compass pre-test, one aligned quad per lane, surviving quads -> aq (ordered)
             int naq = 0;
             int row = r0 + lane / nq, qq = lane - (lane / nq) * nq;
             const int dq = 64 % nq, dr = 64 / nq;
             for (int t0 = 0; t0 < ntask; t0 += 64) {
+                FS_CNT(0, 1); FS_CNT(1, min(64, ntask - t0));
                 uint32_t Rb = 0; int ixq = 0;
                 if (t0 + lane < ntask) {
                     const int txq = 4 * (qc0 + qq);
@@ -357,36 +392,52 @@ __global__ __launch_bounds__(64) void k_fast_strips(const uint8_t* __restrict__ 
                 naq += __popcll(b);
                 qq += dq; row += dr; if (qq >= nq) { qq -= nq; row++; }
             }
-            if (naq > FS_AQ_CAP) { R = max((R + 1) >> 1, FS_RMIN); continue; }        // wave-uniform: redo this chunk with half the rows (FS_RMIN rows always fit)
+            if (naq > FS_AQ_CAP) { FS_CNT(9, 1); R = max((R + 1) >> 1, FS_RMIN); continue; }        // wave-uniform: redo this chunk with half the rows (FS_RMIN rows always fit)
             __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
-            // ---- expansion: quads -> per-pixel candidates (row-major order kept): flags byte = [3:2] px0, [7:6] px1, [1:0] px2, [5:4] px3
+            // ---- expansion: quads -> one candidate entry per (pixel, arc family the pre-test left possible), row-major order kept, a pixel's bright entry first.
+            // Entry = (row << 10) | (ix << 2) | twin << 1 | dark; twin: the pixel has both entries (adjacent in the list).  Single-family entries keep phase b free of
+            // the divergent "both families" block, which some lane of nearly every wave iteration used to need.
             int ncand = 0;
             for (int a0 = 0; a0 < naq; a0 += 64) {
+                FS_CNT(2, 1); FS_CNT(3, min(64, naq - a0));
                 const uint32_t e = a0 + lane < naq ? aq[a0 + lane] : 0u;
-                const uint32_t f0 = (e >> 2) & 3, f1 = (e >> 6) & 3, f2 = e & 3, f3 = (e >> 4) & 3;
-                const unsigned long long b0 = __ballot(f0 != 0), b1 = __ballot(f1 != 0), b2 = __ballot(f2 != 0), b3 = __ballot(f3 != 0);
-                int pos = ncand + __popcll(b0 & ltmask) + __popcll(b1 & ltmask) + __popcll(b2 & ltmask) + __popcll(b3 & ltmask);
+                const uint32_t fpx[4] = {(e >> 2) & 3, (e >> 6) & 3, e & 3, (e >> 4) & 3};       // flags byte = [3:2] px0, [7:6] px1, [1:0] px2, [5:4] px3; 2 = bright, 1 = dark
+                const int n = __popc(e & 0xffu), incl = wave_incl_scan(n), tot = __builtin_amdgcn_readlane(incl, 63);
+                if (ncand + tot > FS_CAND_CAP) { ncand += tot; break; }                            // wave-uniform: the chunk is redone with half the rows, nothing was stored
+                int pos = ncand + incl - n;
                 const int codeq = (int)((e >> 16) << 10) + (((int)((e >> 8) & 0xff) - 4) * 4);      // (row << 10) + (ix << 2) of pixel 0; its ix may be -3..-1 (that pixel is then invalid): sums, not ORs
-                if (f0) { if (pos < FS_CAND_CAP) cand[pos] = (uint16_t)(codeq | f0); pos++; }
-                if (f1) { if (pos < FS_CAND_CAP) cand[pos] = (uint16_t)((codeq + 4) | f1); pos++; }
-                if (f2) { if (pos < FS_CAND_CAP) cand[pos] = (uint16_t)((codeq + 8) | f2); pos++; }
-                if (f3) { if (pos < FS_CAND_CAP) cand[pos] = (uint16_t)((codeq + 12) | f3); pos++; }
-                ncand += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {                                                      // branch-free: an absent entry goes to the dump slot behind the list
+                    const int code = (codeq + 4 * k) | (fpx[k] == 3 ? 2 : 0);
+                    const int hb = (fpx[k] >> 1) & 1, hd = fpx[k] & 1;
+                    cand[hb ? pos : FS_CAND_CAP] = (uint16_t)code;       pos += hb;
+                    cand[hd ? pos : FS_CAND_CAP] = (uint16_t)(code | 1); pos += hd;
+                }
+                ncand += tot;
             }
-            if (ncand > FS_CAND_CAP) { R = max((R + 1) >> 1, FS_RMIN); continue; }
+            if (ncand > FS_CAND_CAP) { FS_CNT(10, 1); R = max((R + 1) >> 1, FS_RMIN); continue; }
             __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
-            // ---- phase b: segment test + score, 64 candidates per iteration; corners -> score tile + corner list (ordered)
+            // ---- phase b: segment test + score, 64 entries per iteration; corners -> score tile + corner list (ordered).  The second entry of a twin pair takes the
+            // maximum with its left neighbour's strength (DPP wave shift; across an iteration boundary through a scalar carry) and speaks for the pixel.
             uint16_t* cl = corn + kb * FS_CAND_CAP;
-            int ncorn = 0;
+            int ncorn = 0, carry = 0;
             for (int q0 = 0; q0 < ncand; q0 += 64) {
+                FS_CNT(4, 1); FS_CNT(5, min(64, ncand - q0));
                 const int q = q0 + lane;
-                int Sv = 0, code = 0, c = 0;
+                int m = 0, code = 0, c = 0, ix = 0, iy = 0;
                 if (q < ncand) {
                     code = cand[q];
-                    const int iy = code >> 10, ix = (code >> 2) & 255;
-                    Sv = fast_score_pk(tile + (iy + 3) * FS_PITCH + tx0 + ix, th, code & 3);
+                    iy = code >> 10; ix = (code >> 2) & 255;
+                    m = fast_strength_pk<FS_PITCH>(tile + (iy + 3) * FS_PITCH + tx0 + ix, (code & 1) != 0);
+                }
+                const int mprev = __builtin_amdgcn_update_dpp(carry, m, 0x138, 0xf, 0xf, false);          // wave_shr:1 — lane l gets lane l-1, lane 0 keeps the carry
+                carry = __builtin_amdgcn_readlane(m, 63);
+                if ((code & 3) == 3) m = max(m, mprev);
+                const bool speaks = q < ncand && (code & 3) != 2;                                         // not the first entry of a twin pair
+                const int Sv = speaks && m > th ? m - 1 : 0;
+                if (Sv > 0) {
                     c = (ix >= bx1) + (ix >= bx2) + (ix >= bx3);
-                    if (Sv > 0) sc[(iy + 1) * FS_SPITCH + ix + c + 1] = (uint8_t)Sv;
+                    sc[(iy + 1) * FS_SPITCH + ix + c + 1] = (uint8_t)Sv;
                 }
                 const unsigned long long bc = __ballot(Sv > 0);
                 if (Sv > 0) cl[ncorn + __popcll(bc & ltmask)] = (uint16_t)((code & ~3) | c);
@@ -891,7 +942,7 @@ struct OrbState {
     float timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::chrono::steady_clock::time_point t_start;
     int last_frames = 0;
-    int fast_rows = 0; size_t fast_lds = 0;
+    int fast_rows = 0, fast_iw = FS_NARROW; size_t fast_lds = 0;
     FastStrip* d_strips = nullptr; int n_strips = 0; int* d_slot_off = nullptr; int slot_total = 0;      // FAST strips (<= 4 cells each), per-cell output slot offsets, slots per frame
     // device quadtree / keypoint assembly
     uint16_t* d_qt_slot = nullptr; int *d_sel = nullptr, *d_selcnt = nullptr, *d_kpoff = nullptr, *d_frame_beg = nullptr, *d_budget = nullptr;
@@ -1009,14 +1060,16 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
     // FAST strips: runs of up to FS_MAXC horizontally adjacent cells of one cell row (consecutive in the reference order), split evenly; per-cell output slots
     std::vector<FastStrip> strips; std::vector<int> slot_off(cells.size() + 1, 0);
     {
-        int max_sh = 8;
+        int max_sh = 8, max_iw = 0;
         for (size_t c = 0; c < cells.size(); c++) {
             const CellDesc& cd = cells[c];
             slot_off[c + 1] = slot_off[c] + ((cd.sw - 6 + 1) / 2) * ((cd.sh - 6 + 1) / 2);      // most 3x3-NMS survivors of a (sw-6) x (sh-6) interior
-            max_sh = std::max(max_sh, cd.sh);
-            if (cd.sw - 6 > FS_MAXIW || cd.sh - 6 > 63)
-                return vido_set_error(ctx, VIDO_E_INVALID, "FAST cell %dx%d at level %d exceeds the strip tile (%dx63 interior)", cd.sw, cd.sh, cd.level, FS_MAXIW);
+            max_sh = std::max(max_sh, cd.sh); max_iw = std::max(max_iw, cd.sw - 6);
+            if (cd.sw - 6 > FS_WIDE || cd.sh - 6 > 63)
+                return vido_set_error(ctx, VIDO_E_INVALID, "FAST cell %dx%d at level %d exceeds the strip tile (%dx63 interior)", cd.sw, cd.sh, cd.level, FS_WIDE);
         }
+        const int FS_MAXIW = max_iw <= FS_NARROW ? FS_NARROW : FS_WIDE;      // which instantiation of k_fast_strips this configuration runs
+        S->fast_iw = FS_MAXIW;
         size_t c0 = 0;
         while (c0 < cells.size()) {
             size_t c1 = c0 + 1;                                       // [c0, c1): the cells of one cell row (same level and y0, x adjacent)
@@ -1045,7 +1098,7 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
         }
         S->n_strips = (int)strips.size(); S->slot_total = slot_off[cells.size()];
         S->fast_rows = max_sh;
-        S->fast_lds = 16 + (size_t)max_sh * FS_PITCH + (size_t)(max_sh - 4) * FS_SPITCH + sizeof(uint32_t) * FS_AQ_CAP + sizeof(uint16_t) * 3 * FS_CAND_CAP + 16;
+        S->fast_lds = FS_MAXIW == FS_NARROW ? FsGeom<FS_NARROW>::lds_bytes(max_sh) : FsGeom<FS_WIDE>::lds_bytes(max_sh);
     }
     HIP_TRY(ctx, hipMalloc(&S->d_strips, strips.size() * sizeof(FastStrip)));
     HIP_TRY(ctx, hipMemcpy(S->d_strips, strips.data(), strips.size() * sizeof(FastStrip), hipMemcpyHostToDevice));
@@ -1084,7 +1137,7 @@ int orb_state_create(vido_ctx* ctx)
     HIP_TRY(ctx, hipMemset(S->d_pyr, 0, S->slab * B));
     HIP_TRY(ctx, hipMemset(S->d_blur, 0, S->slab * B));
     HIP_TRY(ctx, hipMalloc(&S->d_slots, (size_t)S->slot_total * B * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_fast_strips, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->fast_lds));
+    HIP_TRY(ctx, hipFuncSetAttribute(S->fast_iw == FS_NARROW ? (const void*)k_fast_strips<FS_NARROW> : (const void*)k_fast_strips<FS_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->fast_lds));
     HIP_TRY(ctx, hipMalloc(&S->d_counts, ncell * sizeof(int)));
     HIP_TRY(ctx, hipMalloc(&S->d_offsets, (ncell + 1) * sizeof(int)));
     HIP_TRY(ctx, hipMalloc(&S->d_lvloff, (B * S->L + 1) * sizeof(int)));
@@ -1196,8 +1249,12 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     }
     HIP_TRY(ctx, hipEventRecord(S->ev[1], st));
     const int with_desc = ctx->cfg.compute_descriptors ? 1 : 0;
-    hipLaunchKernelGGL(k_fast_strips, dim3(S->n_strips, nf), dim3(64), S->fast_lds, st, S->d_pyr, S->slab, S->P, S->d_strips, S->n_cells, S->d_slot_off, S->slot_total,
-                       ctx->cfg.ini_th_fast, ctx->cfg.min_th_fast, S->fast_rows, S->d_slots, S->d_counts);
+    if (S->fast_iw == FS_NARROW)
+        hipLaunchKernelGGL(k_fast_strips<FS_NARROW>, dim3(S->n_strips, nf), dim3(64), S->fast_lds, st, S->d_pyr, S->slab, S->P, S->d_strips, S->n_cells, S->d_slot_off, S->slot_total,
+                           ctx->cfg.ini_th_fast, ctx->cfg.min_th_fast, S->fast_rows, S->d_slots, S->d_counts);
+    else
+        hipLaunchKernelGGL(k_fast_strips<FS_WIDE>, dim3(S->n_strips, nf), dim3(64), S->fast_lds, st, S->d_pyr, S->slab, S->P, S->d_strips, S->n_cells, S->d_slot_off, S->slot_total,
+                           ctx->cfg.ini_th_fast, ctx->cfg.min_th_fast, S->fast_rows, S->d_slots, S->d_counts);
     HIP_TRY(ctx, hipEventRecord(S->ev[7], st));
     if (getenv("VIDO_DEBUG_SYNC")) {       // debugging aid: the FAST stage alone, then its per-cell counts against the slot capacities
         fprintf(stderr, "[vido] k_fast_strips (%d strips x %d frames, lds %zu)...\n", S->n_strips, nf, S->fast_lds);
