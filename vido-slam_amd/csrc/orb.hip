@@ -181,9 +181,14 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 template <int IW> struct FsGeom {
     static constexpr int PITCH = 4 * (((IW + 12) / 4) | 1);       // image tile pitch (bytes): interior + 6 frame + 3 alignment shift, an ODD number of dwords (conflict-free column walks)
     static constexpr int SPITCH = 4 * ((IW + FS_MAXC + 5) / 4);   // score tile pitch: interior + one gutter per cell + border
-    static constexpr int AQ_CAP = 3 * IW + 34;                    // quad list: a chunk is sized to fit it even if every quad survives (>= FS_RMIN rows of quads)
-    static constexpr int CAND_CAP = 6 * IW + 68;                  // candidate list: denser chunks are redone with half the rows (>= FS_RMIN rows x 2 entries per pixel fit)
-    static size_t lds_bytes(int max_sh) { return 16 + (size_t)max_sh * PITCH + (size_t)(max_sh - 4) * SPITCH + sizeof(uint32_t) * AQ_CAP + sizeof(uint16_t) * 3 * CAND_CAP + 16; }
+    static constexpr int AQ_CAP = 10 * IW + 32;                   // quad list: holds all quads of a ~35-row strip, so a strip is normally ONE chunk (full wave iterations: 0.73 -> 0.9 lane fill)
+    static constexpr int CAND_CAP = 16 * IW + 64;                 // candidate list (~half of a strip's pixels): denser chunks are redone with half the rows (>= FS_RMIN rows x 2 entries per pixel fit).
+                                                                  // LDS per wave decides the occupancy: 7.5 KB (21 waves per CU) runs as fast as 6 KB, +4 KB costs 20 % of the kernel
+    static constexpr int CORN_CAP = CAND_CAP / 2;                 // corner lists (two: the NMS runs one chunk behind); a chunk with more corners is redone with half the rows
+#ifndef FS_LDS_PAD
+#define FS_LDS_PAD 0
+#endif
+    static size_t lds_bytes(int max_sh) { return 16 + (size_t)max_sh * PITCH + (size_t)(max_sh - 4) * SPITCH + sizeof(uint32_t) * AQ_CAP + sizeof(uint16_t) * (CAND_CAP + 2 + 2 * CORN_CAP) + 16 + FS_LDS_PAD; }
 };
 #ifndef FS_NARROW
 #define FS_NARROW 37
@@ -211,7 +216,7 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 }
 
 // Compass pre-test of the four pixels of an aligned quad.  Returns R with, for pixel p, the pair (bright, dark) at bits (15,14) p=0, (31,30) p=1,
-// (13,12) p=2, (29,28) p=3: "bright" = at least two of ring 0/4/8/12 are > v + th, "dark" = at least two are < v - th.
+// (13,12) p=2, (29,28) p=3: "bright" = two adjacent ones of ring 0/4/8/12 are > v + th, "dark" = two adjacent ones are < v - th (necessary for a 9-arc).
 __device__ __forceinline__ uint32_t fast_compass_quad2(uint32_t up, uint32_t m0, uint32_t m1, uint32_t m2, uint32_t dn, uint32_t T2)
 {
     const uint32_t E = __builtin_amdgcn_alignbyte(m2, m1, 3), W = __builtin_amdgcn_alignbyte(m1, m0, 1);
@@ -222,9 +227,17 @@ __device__ __forceinline__ uint32_t fast_compass_quad2(uint32_t up, uint32_t m0,
         const v2u v = as_v2u(__builtin_amdgcn_perm(0u, m1, sel)), T = as_v2u(T2);
         const v2u r0 = as_v2u(__builtin_amdgcn_perm(0u, dn, sel)), r4 = as_v2u(__builtin_amdgcn_perm(0u, E, sel));
         const v2u r8 = as_v2u(__builtin_amdgcn_perm(0u, up, sel)), r12 = as_v2u(__builtin_amdgcn_perm(0u, W, sel));
+#ifdef FS_COMPASS_ANY2
         const v2u a = __builtin_elementwise_max(r0, r4), b = __builtin_elementwise_min(r0, r4), c = __builtin_elementwise_max(r8, r12), d = __builtin_elementwise_min(r8, r12);
         const v2u x = __builtin_elementwise_min(a, c), y = __builtin_elementwise_max(b, d);
         const v2u sl = __builtin_elementwise_max(x, y), ss = __builtin_elementwise_min(x, y);      // second largest / second smallest of the four
+#else
+        // a 9-arc contains two ADJACENT compass points (90 degrees apart): sl = the largest over the four adjacent pairs of the pair's minimum, ss = the mirror image
+        const v2u n04 = __builtin_elementwise_min(r0, r4), n48 = __builtin_elementwise_min(r4, r8), n8c = __builtin_elementwise_min(r8, r12), nc0 = __builtin_elementwise_min(r12, r0);
+        const v2u x04 = __builtin_elementwise_max(r0, r4), x48 = __builtin_elementwise_max(r4, r8), x8c = __builtin_elementwise_max(r8, r12), xc0 = __builtin_elementwise_max(r12, r0);
+        const v2u sl = __builtin_elementwise_max(__builtin_elementwise_max(n04, n48), __builtin_elementwise_max(n8c, nc0));
+        const v2u ss = __builtin_elementwise_min(__builtin_elementwise_min(x04, x48), __builtin_elementwise_min(x8c, xc0));
+#endif
         const uint32_t br = as_u32((v2u)(v + T - sl)), dk = as_u32((v2u)(ss - (v - T)));             // 16-bit wrap-around: sign bit <=> sl > v + th, ss < v - th (|values| < 2^15)
         const uint32_t bits = (br & 0x80008000u) | ((dk & 0x80008000u) >> 1);
         R |= h == 0 ? bits : (bits >> 2);
@@ -258,7 +271,11 @@ __device__ __forceinline__ int fast_arc_minmax(const uint32_t X[8])
 template <int FS_PITCH> __device__ __forceinline__ int fast_strength_pk(const uint8_t* t, bool dark)
 {
     uint32_t P[8];
-    auto pr = [&](int o0, int o1) { v2u p; p.x = t[o0]; p.y = t[o1]; return as_u32(p); };
+    // (volatile: keeps the compiler from fusing two horizontally adjacent bytes into one u16 read — at an odd address that read is split and stalls the LDS pipe:
+    //  SQ_LDS_UNALIGNED_STALL went from 0 to 2.4e7 cycles per launch when it did)
+    typedef const volatile __attribute__((address_space(3))) uint8_t* lds_vbyte_ptr;
+    lds_vbyte_ptr tv = (lds_vbyte_ptr)t;
+    auto pr = [&](int o0, int o1) { v2u p; p.x = tv[o0]; p.y = tv[o1]; return as_u32(p); };
     P[0] = pr(3 * FS_PITCH, 3 * FS_PITCH + 1);        P[1] = pr(2 * FS_PITCH + 2, FS_PITCH + 3);
     P[2] = pr(3, -FS_PITCH + 3);                      P[3] = pr(-2 * FS_PITCH + 2, -3 * FS_PITCH + 1);
     P[4] = pr(-3 * FS_PITCH, -3 * FS_PITCH - 1);      P[5] = pr(-2 * FS_PITCH - 2, -FS_PITCH - 3);
@@ -289,13 +306,13 @@ template <int IW> __global__ __launch_bounds__(64) void k_fast_strips(const uint
                                                     const FastStrip* __restrict__ strips, int n_cells, const int* __restrict__ slot_off, int slot_total,
                                                     int ini_th, int min_th, int lds_rows, uint32_t* __restrict__ slots, int* __restrict__ counts)
 {
-    constexpr int FS_PITCH = FsGeom<IW>::PITCH, FS_SPITCH = FsGeom<IW>::SPITCH, FS_AQ_CAP = FsGeom<IW>::AQ_CAP, FS_CAND_CAP = FsGeom<IW>::CAND_CAP;
+    constexpr int FS_PITCH = FsGeom<IW>::PITCH, FS_SPITCH = FsGeom<IW>::SPITCH, FS_AQ_CAP = FsGeom<IW>::AQ_CAP, FS_CAND_CAP = FsGeom<IW>::CAND_CAP, FS_CORN_CAP = FsGeom<IW>::CORN_CAP;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint8_t* tile = lds_raw + 16;
     uint8_t* sc = tile + lds_rows * FS_PITCH;
     uint32_t* aq = (uint32_t*)(sc + (lds_rows - 4) * FS_SPITCH);
     uint16_t* cand = (uint16_t*)(aq + FS_AQ_CAP);
-    uint16_t* corn = cand + FS_CAND_CAP + 2;                        // (cand[FS_CAND_CAP] is the expansion's dump slot) two buffers of FS_CAND_CAP
+    uint16_t* corn = cand + FS_CAND_CAP + 2;                        // (cand[FS_CAND_CAP] is the expansion's dump slot) two buffers of FS_CORN_CAP
     int sidx, f; xcd_tile_frame(sidx, f);
     const int lane = threadIdx.x;
     const FastStrip S = strips[sidx];
@@ -357,11 +374,8 @@ template <int IW> __global__ __launch_bounds__(64) void k_fast_strips(const uint
     auto process = [&](int xlo, int xhi, int th) {
         const int qc0 = (tx0 + xlo) >> 2, nq = ((tx0 + xhi - 1) >> 2) - qc0 + 1;
         const uint32_t T2 = (uint32_t)th | ((uint32_t)th << 16);
-#ifdef FS_OLD_CHUNK
-        int R = ih, r0 = 0, prev_n = 0, kb = 0;
-#else
-        int R = min(ih, max(FS_RMIN, FS_AQ_CAP / nq)), r0 = 0, prev_n = 0, kb = 0;
-#endif      // a chunk's quads always fit the quad list (a first try with all rows failed for 9 strips in 10)
+        int R = min(ih, max(FS_RMIN, FS_AQ_CAP / nq)), r0 = 0, prev_n = 0, kb = 0;      // a chunk's quads always fit the quad list
+        if (R < ih) { const int nch = (ih + R - 1) / R; R = (ih + nch - 1) / nch; }        // equal chunks, not a ragged last one      // a chunk's quads always fit the quad list (a first try with all rows failed for 9 strips in 10)
         FS_CNT(12, 1); FS_CNT(13, (xhi - xlo) * ih);
         while (r0 < ih) {
             const int r1 = min(r0 + R, ih), ntask = (r1 - r0) * nq;
@@ -419,7 +433,7 @@ template <int IW> __global__ __launch_bounds__(64) void k_fast_strips(const uint
             __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
             // ---- phase b: segment test + score, 64 entries per iteration; corners -> score tile + corner list (ordered).  The second entry of a twin pair takes the
             // maximum with its left neighbour's strength (DPP wave shift; across an iteration boundary through a scalar carry) and speaks for the pixel.
-            uint16_t* cl = corn + kb * FS_CAND_CAP;
+            uint16_t* cl = corn + kb * FS_CORN_CAP;
             int ncorn = 0, carry = 0;
             for (int q0 = 0; q0 < ncand; q0 += 64) {
                 FS_CNT(4, 1); FS_CNT(5, min(64, ncand - q0));
@@ -440,15 +454,16 @@ template <int IW> __global__ __launch_bounds__(64) void k_fast_strips(const uint
                     sc[(iy + 1) * FS_SPITCH + ix + c + 1] = (uint8_t)Sv;
                 }
                 const unsigned long long bc = __ballot(Sv > 0);
-                if (Sv > 0) cl[ncorn + __popcll(bc & ltmask)] = (uint16_t)((code & ~3) | c);
+                if (Sv > 0) { const int cp = ncorn + __popcll(bc & ltmask); if (cp < FS_CORN_CAP) cl[cp] = (uint16_t)((code & ~3) | c); }
                 ncorn += __popcll(bc);
             }
+            if (ncorn > FS_CORN_CAP) { FS_CNT(10, 1); R = max((R + 1) >> 1, FS_RMIN); continue; }      // (the scores already written are the ones the redo writes again)
             __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
             // ---- phase c, one chunk behind: the corners of the previous chunk now have their row + 1 scores
-            nms_emit(corn + (kb ^ 1) * FS_CAND_CAP, prev_n);
+            nms_emit(corn + (kb ^ 1) * FS_CORN_CAP, prev_n);
             prev_n = ncorn; kb ^= 1; r0 = r1;
         }
-        nms_emit(corn + (kb ^ 1) * FS_CAND_CAP, prev_n);
+        nms_emit(corn + (kb ^ 1) * FS_CORN_CAP, prev_n);
     };
 
     // The reference runs cv::FAST at iniThFAST and re-runs a cell at minThFAST only when that came back empty (ORBextractor.cc:799-806)
