@@ -320,16 +320,21 @@ template <int IW> __global__ __launch_bounds__(64) void k_fast_strips(const uint
     const uint8_t* img = pyr + (size_t)f * slab + P.off[S.level];
     const int xa = S.x0 & ~3, shift = S.x0 - xa;
     const int nd = ((S.x0 + S.sw + 3) >> 2) - (xa >> 2);          // dwords per tile row
-    {   // lanes 0-31 take the even rows of a batch, lanes 32-63 the odd ones, lane & 31 = dword column (nd <= 21): no division, and the five loads of a batch
-        // are in flight together (one dependent HBM/L2 round trip per 10 rows instead of one per 64 dwords)
-        const int col = lane & 31, rp = lane >> 5;
-        const uint8_t* src = img + (size_t)S.y0 * pitch + xa + 4 * col;
-        for (int r0 = 0; r0 < S.sh; r0 += 10) {
-            uint32_t v[5];
+    {   // lane = (row in group, dword column): 16 columns x 4 rows per load instruction for the narrow tile (nd <= 13), 32 x 2 for the wide one; no division, the five
+        // loads of a batch are in flight together (one dependent HBM / L2 round trip per 20 / 10 rows).  Rows past the strip are clamped to its last row (the lanes
+        // re-store that row's own data), so only the column test remains, hoisted out of the loop.
+        constexpr int CB = FS_PITCH / 4 <= 16 ? 4 : 5, RPI = 64 >> CB;
+        const int col = lane & ((1 << CB) - 1), rp = lane >> CB;
+        if (col < nd) {
+            const uint8_t* src = img + (size_t)S.y0 * pitch + xa + 4 * col;
+            uint8_t* dst = tile + 4 * col;
+            for (int r0 = 0; r0 < S.sh; r0 += 5 * RPI) {
+                uint32_t v[5];
 #pragma unroll
-            for (int k = 0; k < 5; k++) { const int row = r0 + 2 * k + rp; v[k] = (col < nd && row < S.sh) ? *(const uint32_t*)(src + (size_t)row * pitch) : 0u; }
+                for (int k = 0; k < 5; k++) { const int row = min(r0 + RPI * k + rp, S.sh - 1); v[k] = *(const uint32_t*)(src + (size_t)(uint32_t)(row * pitch)); }
 #pragma unroll
-            for (int k = 0; k < 5; k++) { const int row = r0 + 2 * k + rp; if (col < nd && row < S.sh) *(uint32_t*)(tile + row * FS_PITCH + 4 * col) = v[k]; }
+                for (int k = 0; k < 5; k++) { const int row = min(r0 + RPI * k + rp, S.sh - 1); *(uint32_t*)(dst + row * FS_PITCH) = v[k]; }
+            }
         }
     }
     const int iw = S.sw - 6, ih = S.sh - 6;
@@ -374,37 +379,42 @@ template <int IW> __global__ __launch_bounds__(64) void k_fast_strips(const uint
     auto process = [&](int xlo, int xhi, int th) {
         const int qc0 = (tx0 + xlo) >> 2, nq = ((tx0 + xhi - 1) >> 2) - qc0 + 1;
         const uint32_t T2 = (uint32_t)th | ((uint32_t)th << 16);
+        // phase-a lane layout of this pass: lane = a_lrow * nq + a_q for a_lrow < a_rpi
+        const int a_rpi = 64 / nq, a_lrow = lane / nq, a_q = lane - a_lrow * nq;
+        const bool a_on = a_lrow < a_rpi;
+        const int a_ixq = 4 * (qc0 + a_q) - tx0;                                    // interior x of the quad's first pixel (may be < xlo)
+        uint32_t a_valid = 0;                                                       // (bright, dark) bit pairs of the quad's pixels inside [xlo, xhi), in the pre-test's layout
+        {
+            const int plo = max(0, xlo - a_ixq), phi = min(4, xhi - a_ixq);
+            if (plo <= 0 && phi > 0) a_valid |= 0x0000c000u;
+            if (plo <= 1 && phi > 1) a_valid |= 0xc0000000u;
+            if (plo <= 2 && phi > 2) a_valid |= 0x00003000u;
+            if (plo <= 3 && phi > 3) a_valid |= 0x30000000u;
+        }
+        const uint32_t a_code = ((uint32_t)a_lrow << 16) | ((uint32_t)(a_ixq + 4) << 8);
+        const uint32_t* a_base = (const uint32_t*)tile + a_lrow * (FS_PITCH / 4) + qc0 + a_q;
         int R = min(ih, max(FS_RMIN, FS_AQ_CAP / nq)), r0 = 0, prev_n = 0, kb = 0;      // a chunk's quads always fit the quad list
         if (R < ih) { const int nch = (ih + R - 1) / R; R = (ih + nch - 1) / nch; }        // equal chunks, not a ragged last one      // a chunk's quads always fit the quad list (a first try with all rows failed for 9 strips in 10)
         FS_CNT(12, 1); FS_CNT(13, (xhi - xlo) * ih);
         while (r0 < ih) {
-            const int r1 = min(r0 + R, ih), ntask = (r1 - r0) * nq;
+            const int r1 = min(r0 + R, ih);
             FS_CNT(8, 1);
-            // ---- phase a: compass pre-test, one aligned quad per lane, surviving quads -> aq (ordered)
+            // ---- phase a: compass pre-test, one aligned quad per lane, surviving quads -> aq (ordered).  A lane keeps its quad column and steps down the rows
+            // (rpi = 64 / nq rows per wave iteration): its valid-pixel mask, list code and tile address are loop invariants / one add per iteration.
             int naq = 0;
-            int row = r0 + lane / nq, qq = lane - (lane / nq) * nq;
-            const int dq = 64 % nq, dr = 64 / nq;
-            for (int t0 = 0; t0 < ntask; t0 += 64) {
-                FS_CNT(0, 1); FS_CNT(1, min(64, ntask - t0));
-                uint32_t Rb = 0; int ixq = 0;
-                if (t0 + lane < ntask) {
-                    const int txq = 4 * (qc0 + qq);
-                    const uint8_t* base = tile + row * FS_PITCH + txq;             // row `row` = centre row - 3 in tile rows
-                    const uint32_t up = *(const uint32_t*)base, dn = *(const uint32_t*)(base + 6 * FS_PITCH);
-                    const uint32_t* q = (const uint32_t*)(base + 3 * FS_PITCH - 4);
-                    ixq = txq - tx0;                                               // interior x of the quad's first pixel (may be < xlo)
-                    const int plo = max(0, xlo - ixq), phi = min(4, xhi - ixq);    // pixels plo .. phi-1 of the quad are inside [xlo, xhi)
-                    uint32_t valid = 0;                                            // (bright, dark) bit pairs of the valid pixels, in R's layout
-                    if (plo <= 0 && phi > 0) valid |= 0x0000c000u;
-                    if (plo <= 1 && phi > 1) valid |= 0xc0000000u;
-                    if (plo <= 2 && phi > 2) valid |= 0x00003000u;
-                    if (plo <= 3 && phi > 3) valid |= 0x30000000u;
-                    Rb = fast_compass_quad2(up, q[0], q[1], q[2], dn, T2) & valid;
+            {
+                const uint32_t* bp = a_base + r0 * (FS_PITCH / 4);                 // tile row r0 = centre row r0 - 3
+                uint32_t codea = a_code + ((uint32_t)r0 << 16);
+                for (int r = r0; r < r1; r += a_rpi) {
+                    FS_CNT(0, 1); FS_CNT(1, min(a_rpi, r1 - r) * nq);
+                    uint32_t Rb = 0;
+                    if (a_on && r + a_lrow < r1)
+                        Rb = fast_compass_quad2(bp[0], bp[3 * (FS_PITCH / 4) - 1], bp[3 * (FS_PITCH / 4)], bp[3 * (FS_PITCH / 4) + 1], bp[6 * (FS_PITCH / 4)], T2) & a_valid;
+                    const unsigned long long b = __ballot(Rb != 0);
+                    if (Rb != 0) { const int pos = naq + __popcll(b & ltmask); if (pos < FS_AQ_CAP) aq[pos] = codea | (((Rb & 0xf000f000u) >> 12 | (Rb & 0xf000f000u) >> 24) & 0xffu); }
+                    naq += __popcll(b);
+                    bp += a_rpi * (FS_PITCH / 4); codea += (uint32_t)a_rpi << 16;
                 }
-                const unsigned long long b = __ballot(Rb != 0);
-                if (Rb != 0) { const int pos = naq + __popcll(b & ltmask); if (pos < FS_AQ_CAP) aq[pos] = ((uint32_t)row << 16) | ((uint32_t)(ixq + 4) << 8) | (((Rb & 0xf000f000u) >> 12 | (Rb & 0xf000f000u) >> 24) & 0xffu); }
-                naq += __popcll(b);
-                qq += dq; row += dr; if (qq >= nq) { qq -= nq; row++; }
             }
             if (naq > FS_AQ_CAP) { FS_CNT(9, 1); R = max((R + 1) >> 1, FS_RMIN); continue; }        // wave-uniform: redo this chunk with half the rows (FS_RMIN rows always fit)
             __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
