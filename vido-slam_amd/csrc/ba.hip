@@ -1492,13 +1492,12 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
 // a sharded solve (64 % of a global-BA iteration).  Grouping the unknowns into superblocks of m = 6 (bwc + 1) >= bw + 1 scalars makes the matrix block
 // TRIDIAGONAL (nb = ceil(n6 / m) superblocks: 46 of 66), and cyclic reduction eliminates every other superblock of the current chain in parallel:
 //   level s (stride): blocks p = s mod 2s are eliminated — D_p = C C^T factored in LDS, GL_p = D_p^-1 L_p, GR_p = D_p^-1 L_{p+s}^T, y_p = D_p^-1 b_p
-//   (k_bcr_eliminate, one workgroup per column slice of a block); the survivors a = 0 mod 2s take the Schur complements
+//   (k_bcr_elim, one workgroup per eliminated block); the survivors a = 0 mod 2s take the Schur complements
 //   D_a -= L_a GR_{a-s} + L_{a+s}^T GL_{a+s},  b_a -= L_a y_{a-s} + L_{a+s}^T y_{a+s},  L_a' = -L_a GL_{a-s}   (k_bcr_update),
 // log2(nb) levels of two launches instead of 500 dependent steps; the back-substitution x_p = y_p - GL_p x_{p-s} - GR_p x_{p+s} walks the levels back.
 // Schur complements of an SPD matrix are SPD, so no pivoting is needed (block cyclic reduction is backward stable for SPD systems).  L_k is the block
 // (k, left neighbour of k in the current chain); symmetric storage is not exploited (the work is latency, not FLOPs).
 struct BcrDev { int m, nb, n6, bw, ldb; double *D, *L0, *L1, *GL, *GR, *b, *y; const double* S; const double* r; double* x; double* ok; };
-#define BCR_NT 256
 __global__ __launch_bounds__(256) void k_bcr_pack(BcrDev B)
 {
     const int m = B.m, k = blockIdx.x, tid = threadIdx.x;
@@ -1516,152 +1515,164 @@ __global__ __launch_bounds__(256) void k_bcr_pack(BcrDev B)
     for (int t = tid; t < m; t += 256) B.b[(size_t)k * m + t] = k * m + t < B.n6 ? B.r[k * m + t] : 0.0;
     if (k == 0 && tid == 0) *B.ok = 1.0;
 }
-// in-LDS Cholesky of the m x m matrix A (pitch ld odd, lower triangle; the strictly lower part becomes C, the diagonal is left alone and 1 / C_jj goes to dinv),
-// 256 threads as a 16 x 16 grid over the trailing block, two barriers per column; returns false on a non-positive pivot
-__device__ bool bcr_chol(double* A, double* dinv, int m, int ld)
+// One elimination of block cyclic reduction: X = D_p^-1 [L_p | L_{p+s}^T | b_p] (mode 0: GL_p, GR_p, y_p) or x_0 = D_0^-1 b_0 (mode 1, the last block of the chain).
+// The first version (in-LDS Cholesky, then triangular solves on 8-lane groups) spent 92 us per level on ~200 dependent steps of ~0.45 us.  This one is Gaussian
+// elimination by COLUMNS IN REGISTERS: thread c owns column c of [D | L | L'^T | b] (M doubles, every loop fully unrolled so that the register indices are compile-time
+// constants); step k: the threads of D publish their row-k element U_kc (c >= k) in row k of an LDS array — by the symmetry of the trailing Schur complement that row IS
+// the multiplier column — one barrier, every thread takes col[i] -= U_ki (col[k] / U_kk) for i > k with broadcast b128 LDS reads.  The rows of U stay in LDS, and the back
+// substitution x_k = (y_k - sum_{j>k} U_kj x_j) / U_kk needs no barrier at all (every right-hand side is a thread).  M steps of ~0.1 us instead of 3M of 0.45 us.
+// D is SPD (Schur complements of an SPD matrix), so elimination without pivoting is backward stable, like the Cholesky it replaces.
+template <int M> struct BcrGeom { static constexpr int NT = ((3 * M + 1 + 63) / 64) * 64; static constexpr size_t LDS = ((size_t)M * M + M + NT) * sizeof(double); };
+// compile-time loops: the step index must be a constant in every register index of col[] (a run-time index would send the array to scratch memory)
+template <typename F, int... Ks> __device__ __forceinline__ void bcr_static_for_impl(F& f, std::integer_sequence<int, Ks...>) { (f(std::integral_constant<int, Ks>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void bcr_static_for(F&& f) { bcr_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+// col[2 jp], col[2 jp + 1] (jp0 <= jp < M / 2, entries with index <= K skipped) op= row pair * scalar, eight b128 LDS reads in flight at a time: the scheduling barrier
+// keeps the machine scheduler from hoisting all 33 reads of a step above the FMAs (132 more live registers: spills)
+typedef double bcr_d2 __attribute__((ext_vector_type(2)));
+typedef const volatile __attribute__((address_space(3))) bcr_d2* bcr_lds_row;      // volatile: the reads stay where they are written (in chunks of eight, next to their FMAs)
+template <int M, int K, int J0, typename OP> __device__ __forceinline__ void bcr_row_chunk(bcr_lds_row row, OP&& op)
 {
-    bool good = true;
-    const int tid = threadIdx.x, ti = tid & 15, tk = tid >> 4;
-    for (int j = 0; j < m; j++) {
+    if constexpr (J0 < M / 2) {
+        constexpr int NE = (M / 2 - J0) < 8 ? (M / 2 - J0) : 8;
+        bcr_d2 u[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) u[e] = row[J0 + e];
+        __builtin_amdgcn_sched_barrier(0);
+        bcr_static_for<NE>([&](auto ec) { constexpr int e = decltype(ec)::value; op(std::integral_constant<int, J0 + e>{}, u[e]); });
+        __builtin_amdgcn_sched_barrier(0);
+        bcr_row_chunk<M, K, J0 + 8>(row, op);
+    }
+}
+template <int M> __global__ __launch_bounds__(BcrGeom<M>::NT) void k_bcr_elim(BcrDev B, int s, const double* __restrict__ Lcur, int mode)
+{
+    extern __shared__ __attribute__((aligned(16))) double bcr_lds[];
+    double* U = bcr_lds;                  // [M][M] row k = (U_k0 .. ) only entries c >= k are written / read
+    double* dinv = bcr_lds + M * M;       // [M]
+    const int c = threadIdx.x;
+    const int p = mode ? 0 : s + 2 * s * blockIdx.x;
+    const int ncol = mode ? M + 1 : 3 * M + 1;
+    const bool has_r = !mode && p + s < B.nb, live = c < ncol;
+    const double* Dp = B.D + (size_t)p * M * M;
+    const double* Lp = Lcur + (size_t)p * M * M; const double* Lq = Lcur + (size_t)(p + s) * M * M;
+    const bool is_d = c < M, is_b = mode ? c == M : c == 3 * M;
+    double col[M];
+    {
+        const double* src = Dp + c; size_t stride = M;                             // D column c / L_p column c - M: coalesced over the lanes
+        bool ld = live;
+        if (!mode && c >= M && c < 2 * M) src = Lp + (c - M);
+        else if (!mode && c >= 2 * M && c < 3 * M) { src = Lq + (size_t)(c - 2 * M) * M; stride = 1; ld = has_r; }      // column of L_{p+s}^T = row of L_{p+s}
+        else if (is_b) { src = B.b + (size_t)p * M; stride = 1; }
+        bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; col[i] = ld ? src[(size_t)i * stride] : 0.0; });
+    }
+    int bad = 0;
+    bcr_static_for<M>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        // (branch-free steps: with predicated stores every step is several basic blocks, and the compiler sinks the FMAs of row i into the block of step i — keeping every
+        //  multiplier row it has read alive in scratch memory; stores that must not happen go to a per-thread dump slot instead)
+        U[(is_d && c >= k) ? k * M + c : M * M + M + c] = col[k];
         __syncthreads();
-        double d = A[j * ld + j];
-        if (!(d > 0) || !isfinite(d)) { good = false; d = 1.0; }
-        const double inv = 1.0 / sqrt(d);
-        for (int i = j + 1 + tid; i < m; i += BCR_NT) A[i * ld + j] *= inv;
-        if (tid == 0) dinv[j] = inv;
-        __syncthreads();
-        for (int i = j + 1 + ti; i < m; i += 16) {
-            const double aij = A[i * ld + j];
-            for (int k = j + 1 + tk; k <= i; k += 16) A[i * ld + k] -= aij * A[k * ld + j];
-        }
+        const double piv = U[k * M + k];
+        bad |= !(piv > 0.0 && piv < 1.0e300);
+        double inv = __builtin_amdgcn_rcp(piv);
+        inv = inv * (2.0 - piv * inv); inv = inv * (2.0 - piv * inv);
+        U[c == k ? M * M + k : M * M + M + c] = inv;                               // dinv[k]
+        const double nt = -(col[k] * inv);
+        bcr_row_chunk<M, k, (k + 1) / 2>((bcr_lds_row)(U + k * M), [&](auto jc, const bcr_d2& u) {      // M even: rows are 16-byte aligned
+            constexpr int jp = decltype(jc)::value;
+            if constexpr (2 * jp > k) col[2 * jp] = __builtin_fma(u.x, nt, col[2 * jp]);
+            col[2 * jp + 1] = __builtin_fma(u.y, nt, col[2 * jp + 1]);
+        });
+    });
+    if (bad && c == 0) *B.ok = 0.0;
+    if (is_d || !live) return;                                                     // (no barrier below)
+    // back substitution of this thread's right-hand side; dinv[] was written before the last barrier except dinv[M-1] (own copy below)
+    {
+        const double pl = U[(M - 1) * M + (M - 1)];
+        double il = __builtin_amdgcn_rcp(pl); il = il * (2.0 - pl * il); il = il * (2.0 - pl * il);
+        col[M - 1] *= il;
     }
-    __syncthreads();
-    return good;
-}
-// (C C^T)^-1 v for right-hand sides distributed over groups of 8 lanes: lane sub of a group holds rows sub, sub + 8, ... of ITS column in registers (m <= 96);
-// every step broadcasts one solved entry inside the group with a shuffle and updates the rows still to come — 8 x the parallelism of a thread per column,
-// everything in registers (indexed at compile time: the loops over the register slots are unrolled)
-#define BCR_SLOTS 12
-__device__ __forceinline__ void bcr_solve8(const double* A, const double* dinv, int m, int ld, double (&v)[BCR_SLOTS])
-{
-    const int lane = threadIdx.x & 63, sub = lane & 7, gbase = lane & ~7;
-#pragma unroll
-    for (int t = 0; t < BCR_SLOTS; t++) {                    // forward: C y = v
-        for (int sk = 0; sk < 8; sk++) {
-            const int k = 8 * t + sk;
-            if (k >= m) break;                               // wave-uniform
-            const double vk = __shfl(v[t], gbase | sk, 64) * dinv[k];
-            if (sub == sk) v[t] = vk;
-#pragma unroll
-            for (int tt = t; tt < BCR_SLOTS; tt++) { const int i = sub + 8 * tt; if (i > k && i < m) v[tt] -= A[i * ld + k] * vk; }
-        }
-    }
-#pragma unroll
-    for (int t = BCR_SLOTS - 1; t >= 0; t--) {               // backward: C^T x = y
-        for (int sk = 7; sk >= 0; sk--) {
-            const int k = 8 * t + sk;
-            if (k >= m) continue;                            // wave-uniform
-            const double xk = __shfl(v[t], gbase | sk, 64) * dinv[k];
-            if (sub == sk) v[t] = xk;
-#pragma unroll
-            for (int tt = 0; tt <= t; tt++) { const int i = sub + 8 * tt; if (i < k) v[tt] -= A[k * ld + i] * xk; }
-        }
+    bcr_static_for<M - 1>([&](auto rc) {
+        constexpr int k = M - 2 - decltype(rc)::value;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        bcr_row_chunk<M, k, (k + 1) / 2>((bcr_lds_row)(U + k * M), [&](auto jc, const bcr_d2& u) {
+            constexpr int jp = decltype(jc)::value;
+            if constexpr (jp & 1) { if constexpr (2 * jp > k) a2 = __builtin_fma(u.x, col[2 * jp], a2); a3 = __builtin_fma(u.y, col[2 * jp + 1], a3); }
+            else                  { if constexpr (2 * jp > k) a0 = __builtin_fma(u.x, col[2 * jp], a0); a1 = __builtin_fma(u.y, col[2 * jp + 1], a1); }
+        });
+        col[k] = (col[k] - ((a0 + a1) + (a2 + a3))) * dinv[k];
+    });
+    if (mode) {
+        bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; if (i < B.n6) B.x[i] = col[i]; });
+    } else if (is_b) {
+        bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; B.y[(size_t)p * M + i] = col[i]; });
+    } else {
+        double* dst = (c < 2 * M ? B.GL + (c - M) : B.GR + (c - 2 * M)) + (size_t)p * M * M;
+        bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; dst[(size_t)i * M] = col[i]; });
     }
 }
-// eliminated block p = s + 2 s blockIdx.x; blockIdx.y selects a slice of 32 of the 2m + 1 right-hand sides [L_p | L_{p+s}^T | b_p] (every slice refactors D_p:
-// the factorisation is a few us of latency, the slices run on different CUs)
-__global__ __launch_bounds__(BCR_NT) void k_bcr_eliminate(BcrDev B, int s, const double* __restrict__ Lcur)
+// surviving block a = 2 s blockIdx.x takes D_a -= L_a GR_{a-s} + L_{a+s}^T GL_{a+s}, L_a' = -L_a GL_{a-s}, b_a -= L_a y_{a-s} + L_{a+s}^T y_{a+s}.
+// blockIdx.y = a slice of BCR_RB rows: the slice's rows of L_a and columns of L_{a+s} are staged in LDS (broadcast operands), thread j owns output column j of the
+// slice (BCR_RB + BCR_RB accumulators) and streams the rows of GR / GL with coalesced loads.
+#define BCR_RB 6
+__global__ __launch_bounds__(128) void k_bcr_update(BcrDev B, int s, const double* __restrict__ Lcur, double* __restrict__ Lnext)
 {
-    extern __shared__ double lds[];
-    const int m = B.m, ld = m | 1, tid = threadIdx.x;
-    const int p = s + 2 * s * blockIdx.x;
-    double* A = lds;                      // [m][ld]
-    double* dinv = lds + (size_t)m * ld;  // [m]
-    const double* Dp = B.D + (size_t)p * m * m;
-    for (int t = tid; t < m * m; t += BCR_NT) { const int i = t / m, j = t - i * m; if (j <= i) A[i * ld + j] = Dp[t]; }
-    const bool good = bcr_chol(A, dinv, m, ld);
-    if (!good && tid == 0) *B.ok = 0.0;
-    const int c = blockIdx.y * (BCR_NT / 8) + (tid >> 3), sub = tid & 7;       // this 8-lane group's right-hand side
-    const bool has_r = p + s < B.nb, live = c < 2 * m + 1;
-    const double* Lp = Lcur + (size_t)p * m * m; const double* Lq = Lcur + (size_t)(p + s) * m * m;
-    double v[BCR_SLOTS];
-#pragma unroll
-    for (int t = 0; t < BCR_SLOTS; t++) {
-        const int i = sub + 8 * t; double x = 0.0;
-        if (live && i < m) {
-            if (c < m) x = Lp[(size_t)i * m + c];                                  // column c of L_p = block (p, p - s)
-            else if (c < 2 * m) x = has_r ? Lq[(size_t)(c - m) * m + i] : 0.0;     // column of L_{p+s}^T = row of L_{p+s}
-            else x = B.b[(size_t)p * m + i];
-        }
-        v[t] = x;
-    }
-    bcr_solve8(A, dinv, m, ld, v);
-#pragma unroll
-    for (int t = 0; t < BCR_SLOTS; t++) {
-        const int i = sub + 8 * t;
-        if (live && i < m) {
-            if (c < m) B.GL[(size_t)p * m * m + (size_t)i * m + c] = v[t];
-            else if (c < 2 * m) B.GR[(size_t)p * m * m + (size_t)i * m + (c - m)] = v[t];
-            else B.y[(size_t)p * m + i] = v[t];
-        }
-    }
-}
-// surviving block a = 2 s blockIdx.x; blockIdx.y takes a slice of the m x m outputs
-__global__ __launch_bounds__(256) void k_bcr_update(BcrDev B, int s, const double* __restrict__ Lcur, double* __restrict__ Lnext)
-{
-    const int m = B.m, a = 2 * s * blockIdx.x, p = a - s, q = a + s;
+    __shared__ double la[BCR_RB * 96], lq[BCR_RB * 96];
+    const int m = B.m, a = 2 * s * blockIdx.x, p = a - s, q = a + s, i0 = blockIdx.y * BCR_RB, j = threadIdx.x;
     const bool has_p = p >= 0, has_q = q < B.nb;
     const double* La = Lcur + (size_t)a * m * m; const double* Lq = Lcur + (size_t)q * m * m;
-    const double* GRp = B.GR + (size_t)p * m * m; const double* GLp = B.GL + (size_t)p * m * m; const double* GLq = B.GL + (size_t)q * m * m;
-    double* Da = B.D + (size_t)a * m * m;
-    const int per = (m * m + gridDim.y - 1) / gridDim.y, t0 = blockIdx.y * per, t1 = min(m * m, t0 + per);
-    for (int t = t0 + threadIdx.x; t < t1; t += 256) {
-        const int i = t / m, j = t - i * m;
-        double d = 0.0, ln = 0.0;
-        if (has_p) for (int k = 0; k < m; k++) { const double l = La[(size_t)i * m + k]; d += l * GRp[(size_t)k * m + j]; ln -= l * GLp[(size_t)k * m + j]; }
-        if (has_q) for (int k = 0; k < m; k++) d += Lq[(size_t)k * m + i] * GLq[(size_t)k * m + j];
-        Da[t] -= d;
-        Lnext[(size_t)a * m * m + t] = ln;           // block (a, a - 2s)
+    for (int t = j; t < BCR_RB * m; t += 128) {
+        const int r = t / m, k = t - r * m;
+        la[r * 96 + k] = has_p ? La[(size_t)(i0 + r) * m + k] : 0.0;          // L_a[i0 + r][k]
+        lq[r * 96 + k] = has_q ? Lq[(size_t)k * m + i0 + r] : 0.0;            // L_{a+s}^T[i0 + r][k]
     }
-    if (blockIdx.y == 0) for (int i = threadIdx.x; i < m; i += 256) {
-        double d = 0.0;
-        if (has_p) for (int k = 0; k < m; k++) d += La[(size_t)i * m + k] * B.y[(size_t)p * m + k];
-        if (has_q) for (int k = 0; k < m; k++) d += Lq[(size_t)k * m + i] * B.y[(size_t)q * m + k];
-        B.b[(size_t)a * m + i] -= d;
+    __syncthreads();
+    if (j < m) {
+        const double* GRp = B.GR + (size_t)p * m * m + j; const double* GLp = B.GL + (size_t)p * m * m + j; const double* GLq = B.GL + (size_t)q * m * m + j;
+        double d[BCR_RB], ln[BCR_RB];
+#pragma unroll
+        for (int r = 0; r < BCR_RB; r++) { d[r] = 0.0; ln[r] = 0.0; }
+        if (has_p) {
+#pragma unroll 6
+            for (int k = 0; k < m; k++) {
+                const double gr = GRp[(size_t)k * m], gl = -GLp[(size_t)k * m];
+#pragma unroll
+                for (int r = 0; r < BCR_RB; r++) { const double l = la[r * 96 + k]; d[r] = __builtin_fma(l, gr, d[r]); ln[r] = __builtin_fma(l, gl, ln[r]); }
+            }
+        }
+        if (has_q) {
+#pragma unroll 6
+            for (int k = 0; k < m; k++) {
+                const double gl = GLq[(size_t)k * m];
+#pragma unroll
+                for (int r = 0; r < BCR_RB; r++) d[r] = __builtin_fma(lq[r * 96 + k], gl, d[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < BCR_RB; r++) {
+            B.D[(size_t)a * m * m + (size_t)(i0 + r) * m + j] -= d[r];
+            Lnext[(size_t)a * m * m + (size_t)(i0 + r) * m + j] = ln[r];        // block (a, a - 2s)
+        }
+    } else if (j >= 96 && j < 96 + BCR_RB) {
+        const int r = j - 96; double dv = 0.0;
+        if (has_p) for (int k = 0; k < m; k++) dv += la[r * 96 + k] * B.y[(size_t)p * m + k];
+        if (has_q) for (int k = 0; k < m; k++) dv += lq[r * 96 + k] * B.y[(size_t)q * m + k];
+        B.b[(size_t)a * m + i0 + r] -= dv;
     }
 }
-// last block of the chain: D_0 x_0 = b_0
-__global__ __launch_bounds__(BCR_NT) void k_bcr_final(BcrDev B)
+// x_p = y_p - GL_p x_{p-s} - GR_p x_{p+s} for the blocks eliminated at level s; four lanes per row, each a quarter of the two dot products
+__global__ __launch_bounds__(384) void k_bcr_back(BcrDev B, int s)
 {
-    extern __shared__ double lds[];
-    const int m = B.m, ld = m | 1, tid = threadIdx.x;
-    double* A = lds; double* dinv = lds + (size_t)m * ld;
-    for (int t = tid; t < m * m; t += BCR_NT) { const int i = t / m, j = t - i * m; if (j <= i) A[i * ld + j] = B.D[t]; }
-    const bool good = bcr_chol(A, dinv, m, ld);
-    if (!good && tid == 0) *B.ok = 0.0;
-    if (tid < 64) {                                            // first wave: its first 8-lane group solves the single right-hand side
-        const int sub = tid & 7;
-        double v[BCR_SLOTS];
-#pragma unroll
-        for (int t = 0; t < BCR_SLOTS; t++) { const int i = sub + 8 * t; v[t] = (tid < 8 && i < m) ? B.b[i] : 0.0; }
-        bcr_solve8(A, dinv, m, ld, v);
-#pragma unroll
-        for (int t = 0; t < BCR_SLOTS; t++) { const int i = sub + 8 * t; if (tid < 8 && i < m && i < B.n6) B.x[i] = v[t]; }
-    }
-}
-// x_p = y_p - GL_p x_{p-s} - GR_p x_{p+s} for the blocks eliminated at level s
-__global__ __launch_bounds__(128) void k_bcr_back(BcrDev B, int s)
-{
-    const int m = B.m, p = s + 2 * s * blockIdx.x, i = threadIdx.x;
-    if (i >= m) return;
+    const int m = B.m, p = s + 2 * s * blockIdx.x, i = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    double v = 0.0;
     const int gi = p * m + i;
-    if (gi >= B.n6) return;
-    double v = B.y[(size_t)p * m + i];
-    const double* gl = B.GL + (size_t)p * m * m + (size_t)i * m; const double* gr = B.GR + (size_t)p * m * m + (size_t)i * m;
-    const int l0 = (p - s) * m, r0 = (p + s) * m;
-    for (int k = 0; k < m; k++) { if (l0 + k < B.n6) v -= gl[k] * B.x[l0 + k]; }
-    if (p + s < B.nb) for (int k = 0; k < m; k++) { if (r0 + k < B.n6) v -= gr[k] * B.x[r0 + k]; }
-    B.x[gi] = v;
+    if (i < m) {
+        const double* gl = B.GL + (size_t)p * m * m + (size_t)i * m; const double* gr = B.GR + (size_t)p * m * m + (size_t)i * m;
+        const int l0 = (p - s) * m, r0 = (p + s) * m;
+        for (int k = sub; k < m; k += 4) { if (l0 + k < B.n6) v += gl[k] * B.x[l0 + k]; }
+        if (p + s < B.nb) for (int k = sub; k < m; k += 4) { if (r0 + k < B.n6) v += gr[k] * B.x[r0 + k]; }
+    }
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
+    if (i < m && sub == 0 && gi < B.n6) B.x[gi] = B.y[(size_t)p * m + i] - v;
 }
 
 // ---- trial state ------------------------------------------------------------------------------------------
@@ -2290,19 +2301,19 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
                      if (bwc >= 1 && bwc <= 96) { band6s_nb = need(8) <= 150 * 1024 ? 8 : 4; band6s_lds = need(band6s_nb);
                      HIP_TRY(ctx, hipFuncSetAttribute(band6s_nb == 8 ? (const void*)k_chol_band6s<8> : (const void*)k_chol_band6s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band6s_lds)); } }
     double* Sr = A.get<double>(sz_S + n6); D.S = Sr; D.r = Sr + sz_S; D.x = A.get<double>(n6);
-    // block cyclic reduction of the band system when it is long enough to pay (>= 6 superblocks) and a superblock fits the 8-lane register solve
-    BcrDev Bc{}; size_t bcr_lds = 0;
-    if (D.bw >= 0 && !getenv("VIDO_BA_NO_BCR")) {
-        const int bwc = (D.bw - 5) / 6, m = 6 * (bwc + 1), nb = (n6 + m - 1) / m;
-        if (m <= 8 * BCR_SLOTS && nb >= 6) {
+    // block cyclic reduction of the band system when it is long enough to pay (>= 4 superblocks); the superblock is 66 or 96 unknowns (>= half-bandwidth + 1), the two
+    // sizes the register-resident elimination kernel is instantiated for
+    BcrDev Bc{};
+    if (D.bw >= 0 && D.bw + 1 <= 96 && !getenv("VIDO_BA_NO_BCR")) {
+        const int m = D.bw + 1 <= 66 ? 66 : 96, nb = (n6 + m - 1) / m;
+        if (nb >= 4) {
             const size_t mm = (size_t)nb * m * m, need = 5 * mm + 2 * (size_t)nb * m;
             if (need > BS->bcr_cap) { HIP_TRY(ctx, hipStreamSynchronize(st)); if (BS->d_bcr) hipFree(BS->d_bcr); BS->bcr_cap = need + need / 4; HIP_TRY(ctx, hipMalloc((void**)&BS->d_bcr, BS->bcr_cap * sizeof(double))); }
             Bc.m = m; Bc.nb = nb; Bc.n6 = n6; Bc.bw = D.bw; Bc.ldb = D.ldb;
             Bc.D = BS->d_bcr; Bc.L0 = Bc.D + mm; Bc.L1 = Bc.L0 + mm; Bc.GL = Bc.L1 + mm; Bc.GR = Bc.GL + mm; Bc.b = Bc.GR + mm; Bc.y = Bc.b + (size_t)nb * m;
             Bc.S = D.S; Bc.r = D.r; Bc.x = D.x;
-            bcr_lds = ((size_t)m * (m | 1) + m) * sizeof(double);
-            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_bcr_eliminate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bcr_lds));
-            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_bcr_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bcr_lds));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_bcr_elim<66>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrGeom<66>::LDS));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_bcr_elim<96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrGeom<96>::LDS));
         }
     }
     if (getenv("VIDO_BA_VERBOSE")) fprintf(stderr, "[ba] poses %d (cams %d + H %d) landmarks %d obs %d dyn %d | bw %d (block half-width %d) %s\n", n_pose, p.n_cam, n_H, n_ptl, no, nd, D.bw, D.bw >= 0 ? (D.bw - 5) / 6 : -1,
@@ -2447,17 +2458,21 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if (lds_path && n6 % 6 == 0 && n6 >= 12) hipLaunchKernelGGL(k_ba_chol_small6, dim3(1), dim3(CH_NT), lds_chol6, st, D);
             else if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
             else if (Bc.m) {                                   // block cyclic reduction: 2 launches per level, log2(nb) levels, then the levels back
-                const int m = Bc.m, nb = Bc.nb; const int nslice = (2 * m + 1 + BCR_NT / 8 - 1) / (BCR_NT / 8);
+                const int m = Bc.m, nb = Bc.nb;
+                auto elim = [&](int n_blocks, int sft, const double* Lc, int mode) {
+                    if (m == 66) hipLaunchKernelGGL(k_bcr_elim<66>, dim3(n_blocks), dim3(BcrGeom<66>::NT), BcrGeom<66>::LDS, st, Bc, sft, Lc, mode);
+                    else         hipLaunchKernelGGL(k_bcr_elim<96>, dim3(n_blocks), dim3(BcrGeom<96>::NT), BcrGeom<96>::LDS, st, Bc, sft, Lc, mode);
+                };
                 hipLaunchKernelGGL(k_bcr_pack, dim3(nb), dim3(256), 0, st, Bc);
                 double *Lc = Bc.L0, *Ln = Bc.L1; int smax = 0;
                 for (int sft = 1; sft < nb; sft *= 2) {
                     const int n_el = (nb - sft + 2 * sft - 1) / (2 * sft), n_sv = (nb + 2 * sft - 1) / (2 * sft);
-                    hipLaunchKernelGGL(k_bcr_eliminate, dim3(n_el, nslice), dim3(BCR_NT), bcr_lds, st, Bc, sft, (const double*)Lc);
-                    hipLaunchKernelGGL(k_bcr_update, dim3(n_sv, 8), dim3(256), 0, st, Bc, sft, (const double*)Lc, Ln);
+                    elim(n_el, sft, Lc, 0);
+                    hipLaunchKernelGGL(k_bcr_update, dim3(n_sv, m / BCR_RB), dim3(128), 0, st, Bc, sft, (const double*)Lc, Ln);
                     std::swap(Lc, Ln); smax = sft;
                 }
-                hipLaunchKernelGGL(k_bcr_final, dim3(1), dim3(BCR_NT), bcr_lds, st, Bc);
-                for (int sft = smax; sft >= 1; sft /= 2) hipLaunchKernelGGL(k_bcr_back, dim3((nb - sft + 2 * sft - 1) / (2 * sft)), dim3(128), 0, st, Bc, sft);
+                elim(1, 0, Lc, 1);
+                for (int sft = smax; sft >= 1; sft /= 2) hipLaunchKernelGGL(k_bcr_back, dim3((nb - sft + 2 * sft - 1) / (2 * sft)), dim3(384), 0, st, Bc, sft);
             }
             else if (D.bw >= 0 && band6_lds) hipLaunchKernelGGL(k_chol_band6, dim3(1), dim3(CH_NT), band6_lds, st, D, (D.bw - 5) / 6);
             else if (D.bw >= 0 && band6s_lds && band6s_nb == 8) hipLaunchKernelGGL(k_chol_band6s<8>, dim3(1), dim3(CG_NT), band6s_lds, st, D, (D.bw - 5) / 6);
