@@ -257,6 +257,12 @@ int vido_bias_act(vido_ctx* ctx, float* x, const float* bias, int N, int C, int 
  * (maskrcnn_benchmark/layers/batch_norm.py:19-31) has been folded into the convolution weights and this bias
  * (modeling/backbone/resnet.py:352-372: out = bn3(conv3(.)); out += identity; relu). */
 int vido_bias_res_act(vido_ctx* ctx, float* x, const float* bias, const float* res, int N, int C, int H, int W, float slope);
+/* Node pre-processing in one pass: u8 H x W x 3 interleaved BGR (DEVICE) -> f32 [3][OH][OW] planar RGB, resized with the area rule of the nodes' cv2.resize(..., INTER_AREA) /
+ * torch interpolate(mode="area") (mask_rcnn/src/predictor.py:267-283, mono_depth2/src/run_mono_depth.py:113-118), divided by `div` (255 for the depth node, 1 for the detector). */
+int vido_area_feed(vido_ctx* ctx, const uint8_t* bgr, int H, int W, float* out, int OH, int OW, float div);
+/* flow_net/src/layers.py:25-37 `Backward`: bilinear warp of x[B,C,H,W] by flow[B,2,H,W] (pixels; grid_sample with zero padding, align_corners False on the grid
+ * -1 + (2i+1)/n + flow / ((n-1)/2)); DEVICE tensors, f32, contiguous. */
+int vido_backwarp(vido_ctx* ctx, const float* x, const float* flow, int B, int C, int H, int W, float* out);
 /* layers.ROIAlign forward — mask_rcnn/maskrcnn_benchmark/csrc/cuda/ROIAlign_cuda.cu:257-299.  rois [n,5] =
  * (batch index, x1, y1, x2, y2); out [n, C, pooled_h, pooled_w]. */
 int vido_roi_align(vido_ctx* ctx, const float* feat, int B, int C, int H, int W, const float* rois, int n_rois,

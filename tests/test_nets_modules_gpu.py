@@ -66,3 +66,23 @@ def test_monodepth2_gpu_matches_cpu_run(ctx):
     ref = net(x)
     got = net.cuda()(x.cuda()).cpu()
     assert float((got - ref).abs().max()) < 2e-4
+
+
+def test_area_feed_and_backwarp_equal_the_torch_forms(ctx):
+    """vido_area_feed == flip + permute + float + interpolate(mode="area") [+ / 255] (bit for bit: same window rule, same summation order);
+    vido_backwarp == layers.py Backward built from linspace + grid_sample (to rounding: the grid is evaluated in one expression)."""
+    import torch.nn.functional as F
+    from vido_slam_amd.nets import liteflownet as L
+    ops = nets.HipOps(ctx)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for (H, W), feed, div in (((480, 640), (1088, 800), 1.0), ((480, 640), (192, 640), 255.0), ((375, 1242), (1088, 800), 1.0), ((37, 53), (16, 90), 255.0)):
+        bgr = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8).cuda()
+        ref = F.interpolate(bgr.flip(-1).permute(2, 0, 1).float().unsqueeze(0), size=feed, mode="area")
+        if div != 1.0:
+            ref = ref.div(div)
+        assert torch.equal(ops.area_feed(bgr, feed, div), ref), (H, W, feed)
+    for B, Cc, H, W in ((1, 32, 60, 80), (2, 3, 30, 40), (1, 96, 15, 20), (1, 64, 120, 160)):
+        x = torch.randn(B, Cc, H, W, generator=g).cuda()
+        flow = (torch.randn(B, 2, H, W, generator=g) * 6.0).cuda()                 # many samples land outside the image
+        ref = L.backwarp(x, flow); got = ops.backwarp(x, flow)
+        assert float((got - ref).abs().max()) < 2e-4 * float(ref.abs().max())

@@ -385,6 +385,59 @@ static int net_scratch(vido_ctx* ctx, size_t bytes, NetState** out)
 }
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// ---- node pre-processing and LiteFlowNet's warp as single passes ------------------------------------------------------------------------------
+// u8 HxWx3 interleaved (BGR) -> f32 [3][OH][OW] planar in REVERSED channel order (RGB), resized like torch's interpolate(mode="area") (= adaptive average pooling,
+// aten/src/ATen/native/cuda/AdaptiveAveragePooling.cu: window [floor(o*I/O), ceil((o+1)*I/O)) evaluated in float, row-major float sum, sum / kH / kW), then divided by
+// `div` when div != 1.  Replaces flip + permute + float + interpolate(area) + div: five launches, one of them 0.37 ms (the pooling kernel walks one output row per thread).
+__global__ __launch_bounds__(256) void k_area_feed(const uint8_t* __restrict__ src, int H, int W, float* __restrict__ dst, int OH, int OW, float div)
+{
+    const int ow = blockIdx.x * 64 + (threadIdx.x & 63), oh = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ow >= OW || oh >= OH) return;
+    const int h0 = (int)floorf((float)(oh * H) / OH), h1 = (int)ceilf((float)((oh + 1) * H) / OH);
+    const int w0 = (int)floorf((float)(ow * W) / OW), w1 = (int)ceilf((float)((ow + 1) * W) / OW);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int ih = h0; ih < h1; ih++) {
+        const uint8_t* row = src + ((size_t)ih * W + w0) * 3;
+        for (int iw = w0; iw < w1; iw++, row += 3) { s0 += (float)row[2]; s1 += (float)row[1]; s2 += (float)row[0]; }
+    }
+    const float kh = (float)(h1 - h0), kw = (float)(w1 - w0);
+    float o0 = s0 / kh / kw, o1 = s1 / kh / kw, o2 = s2 / kh / kw;
+    if (div != 1.0f) { const float inv = 1.0f / div; o0 *= inv; o1 *= inv; o2 *= inv; }      // torch's div-by-scalar on the device multiplies by the reciprocal: same values as the torch form
+    const size_t plane = (size_t)OH * OW, o = (size_t)oh * OW + ow;
+    dst[o] = o0; dst[plane + o] = o1; dst[2 * plane + o] = o2;
+}
+// flow_net/src/layers.py:25-37 (Backward): out[b,c,h,w] = bilinear sample of x[b,c] at the grid point g = (-1 + (2w+1)/W + u / ((W-1)/2), -1 + (2h+1)/H + v / ((H-1)/2)),
+// grid_sample(mode bilinear, padding zeros, align_corners False): pixel coordinate ((g + 1) * size - 1) / 2.  One thread per (b, h, w), the channels in a loop
+// (the four taps and weights are shared by all channels).  Replaces 2 linspace + expand + 2 div + 2 add + cat + permute + grid_sample.
+__global__ __launch_bounds__(256) void k_backwarp(const float* __restrict__ x, const float* __restrict__ flow, int B, int C, int H, int W, float* __restrict__ out)
+{
+    const int w = blockIdx.x * 64 + (threadIdx.x & 63), h = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (w >= W || h >= H) return;
+    const size_t hw = (size_t)H * W, o = (size_t)h * W + w;
+    const float u = flow[(size_t)b * 2 * hw + o], v = flow[(size_t)b * 2 * hw + hw + o];
+    const float stepx = ((1.0f - 1.0f / W) - (-1.0f + 1.0f / W)) / (float)(W - 1), stepy = ((1.0f - 1.0f / H) - (-1.0f + 1.0f / H)) / (float)(H - 1);
+    const float gx = ((-1.0f + 1.0f / W) + stepx * (float)w) + u / (((float)W - 1.0f) / 2.0f);
+    const float gy = ((-1.0f + 1.0f / H) + stepy * (float)h) + v / (((float)H - 1.0f) / 2.0f);
+    const float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float ax = ix - fx, ay = iy - fy;
+    const float wnw = (1.0f - ax) * (1.0f - ay), wne = ax * (1.0f - ay), wsw = (1.0f - ax) * ay, wse = ax * ay;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const float* xb = x + (size_t)b * C * hw; float* ob = out + (size_t)b * C * hw + o;
+    const size_t inw = (size_t)(vy0 ? y0 : 0) * W + (vx0 ? x0 : 0), ine = (size_t)(vy0 ? y0 : 0) * W + (vx1 ? x1 : 0);
+    const size_t isw = (size_t)(vy1 ? y1 : 0) * W + (vx0 ? x0 : 0), ise = (size_t)(vy1 ? y1 : 0) * W + (vx1 ? x1 : 0);
+    const float mnw = (vy0 && vx0) ? wnw : 0.f, mne = (vy0 && vx1) ? wne : 0.f, msw = (vy1 && vx0) ? wsw : 0.f, mse = (vy1 && vx1) ? wse : 0.f;
+#pragma unroll 4
+    for (int c = 0; c < C; c++) {
+        const float* xc = xb + (size_t)c * hw;
+        // grid_sampler_2d_kernel accumulates nw, ne, sw, se in this order, skipping taps outside the image
+        float acc = 0.f;
+        acc += xc[inw] * mnw; acc += xc[ine] * mne; acc += xc[isw] * msw; acc += xc[ise] * mse;
+        ob[(size_t)c * hw] = acc;
+    }
+}
+
 extern "C" {
 
 int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int B, int C, int H, int W, int stride, float* out, int on_device)
@@ -431,6 +484,28 @@ int vido_bias_act(vido_ctx* ctx, float* x, const float* bias, int N, int C, int 
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
     const size_t hw = (size_t)H * W, total = (size_t)N * C * hw;
     hipLaunchKernelGGL(k_bias_act, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, st, x, bias, C, hw, total, slope);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+int vido_area_feed(vido_ctx* ctx, const uint8_t* bgr, int H, int W, float* out, int OH, int OW, float div)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!bgr || !out || H < 1 || W < 1 || OH < 1 || OW < 1 || !(div > 0)) return vido_set_error(ctx, VIDO_E_INVALID, "area_feed: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    hipLaunchKernelGGL(k_area_feed, dim3((OW + 63) / 64, (OH + 3) / 4), dim3(256), 0, st, bgr, H, W, out, OH, OW, div);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+int vido_backwarp(vido_ctx* ctx, const float* x, const float* flow, int B, int C, int H, int W, float* out)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!x || !flow || !out || B < 1 || C < 1 || H < 2 || W < 2 || B > 65535) return vido_set_error(ctx, VIDO_E_INVALID, "backwarp: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    hipLaunchKernelGGL(k_backwarp, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(256), 0, st, x, flow, B, C, H, W, out);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }

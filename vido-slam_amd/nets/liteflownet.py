@@ -75,6 +75,7 @@ class _Features(nn.Module):
 
 
 class _Matching(nn.Module):
+    warp = staticmethod(backwarp)          # LiteFlowNet(warp=HipOps.backwarp) installs the one-pass HIP warp
     def __init__(self, level, corr):
         super().__init__()
         ch, self.scale, k, _, _, _ = LEVELS[level]
@@ -88,7 +89,7 @@ class _Matching(nn.Module):
         f1, f2 = self.netFeat(f1), self.netFeat(f2)
         if flow is not None:
             flow = self.netUpflow(flow)
-            f2 = backwarp(f2, flow * self.scale)
+            f2 = self.warp(f2, flow * self.scale)
         c = F.leaky_relu(self.corr(f1, f2, self.stride), LEAK)
         if self.netUpcorr is not None:
             c = self.netUpcorr(c)
@@ -96,6 +97,7 @@ class _Matching(nn.Module):
 
 
 class _Subpixel(nn.Module):
+    warp = staticmethod(backwarp)          # LiteFlowNet(warp=HipOps.backwarp) installs the one-pass HIP warp
     def __init__(self, level):
         super().__init__()
         _, self.scale, k, cin, _, _ = LEVELS[level]
@@ -104,11 +106,12 @@ class _Subpixel(nn.Module):
 
     def forward(self, im1, im2, f1, f2, flow):
         f1, f2 = self.netFeat(f1), self.netFeat(f2)
-        f2 = backwarp(f2, flow * self.scale)
+        f2 = self.warp(f2, flow * self.scale)
         return flow + self.netMain(torch.cat([f1, f2, flow], 1))
 
 
 class _Regularization(nn.Module):
+    warp = staticmethod(backwarp)          # LiteFlowNet(warp=HipOps.backwarp) installs the one-pass HIP warp
     def __init__(self, level):
         super().__init__()
         ch, self.scale, k, _, cin, nd = LEVELS[level]
@@ -119,7 +122,7 @@ class _Regularization(nn.Module):
         self.netScaleX = nn.Conv2d(nd, 1, 1); self.netScaleY = nn.Conv2d(nd, 1, 1)
 
     def forward(self, im1, im2, f1, f2, flow):
-        diff = (im1 - backwarp(im2, flow * self.scale)).pow(2.0).sum(1, True).sqrt()
+        diff = (im1 - self.warp(im2, flow * self.scale)).pow(2.0).sum(1, True).sqrt()
         centred = flow - flow.flatten(2).mean(2, True).unsqueeze(-1)
         d = self.netDist(self.netMain(torch.cat([diff, centred, self.netFeat(f1)], 1))).pow(2.0).neg()
         d = (d - d.max(1, True)[0]).exp()
@@ -134,7 +137,7 @@ class LiteFlowNet(nn.Module):
     """`correlation`: callable (first, second, stride) -> cost volume.  On the GPU pass HipOps(ctx).correlation (the HIP
     kernel); the CPU tests pass correlation_torch_reference."""
 
-    def __init__(self, correlation, epilogue=None):
+    def __init__(self, correlation, epilogue=None, warp=None):
         super().__init__()
         self.netFeatures = _Features()
         self.netMatching = nn.ModuleList([_Matching(l, correlation) for l in (2, 3, 4, 5, 6)])
@@ -144,6 +147,10 @@ class LiteFlowNet(nn.Module):
             for m in self.modules():
                 if isinstance(m, _Chain):
                     m.epilogue = epilogue
+        if warp is not None:
+            for m in self.modules():
+                if isinstance(m, (_Matching, _Subpixel, _Regularization)):
+                    m.warp = warp
         # per-channel means as (non-persistent) buffers: the reference builds them with new_tensor inside forward (layers.py:286-287), a host-to-device
         # copy per call that a hipGraph capture cannot contain; not part of the state dict, so the reference's checkpoints still load unchanged
         self.register_buffer("_mean_first", torch.tensor(MEAN_FIRST).view(1, 3, 1, 1), persistent=False)

@@ -467,8 +467,10 @@ class MaskRCNN(nn.Module):
         return dict(boxes=boxes, scores=scores, labels=labels, masks=masks, proposals=proposals, objectness=objectness, n_proposals=(objectness >= 0).sum())
 
 
-def image_to_feed(bgr, dev, feed=(1088, 800)):
+def image_to_feed(bgr, dev, feed=(1088, 800), ops=None):
     """predictor.py:267-283: HxWx3 u8 BGR -> [1,3,feed_h,feed_w] float RGB, area-resized, not normalised."""
+    if ops is not None and torch.is_tensor(bgr) and bgr.is_cuda and bgr.dtype == torch.uint8:
+        return ops.area_feed(bgr.contiguous(), feed)                 # one HIP pass (vido_area_feed), identical values
     t = (bgr.to(dev).flip(-1) if torch.is_tensor(bgr) else torch.as_tensor(bgr[:, :, ::-1].copy(), device=dev)).permute(2, 0, 1).float().unsqueeze(0)
     return F.interpolate(t, size=feed, mode="area")
 

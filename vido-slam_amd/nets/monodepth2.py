@@ -120,13 +120,17 @@ class MonoDepth2(nn.Module):
 
 
 @torch.no_grad()
-def analyse_depth(net, bgr, feed=(192, 640)):
+def analyse_depth(net, bgr, feed=(192, 640), ops=None):
     """run_mono_depth.py:101-156: HxWx3 u8 BGR -> HxW u16 (area-resize to 640x192, BGR->RGB, /255, forward, bilinear resize of
     disp_0 back, min-max normalise to [0, 65536])."""
     dev = next(net.parameters()).device
-    t = (bgr.to(dev).flip(-1) if torch.is_tensor(bgr) else torch.as_tensor(bgr[:, :, ::-1].copy(), device=dev)).permute(2, 0, 1).float().unsqueeze(0)
-    H, W = t.shape[2], t.shape[3]
-    x = F.interpolate(t, size=feed, mode="area").div(255.0)             # cv2.INTER_AREA
+    if ops is not None and torch.is_tensor(bgr) and bgr.is_cuda and bgr.dtype == torch.uint8:
+        H, W = bgr.shape[0], bgr.shape[1]
+        x = ops.area_feed(bgr.contiguous(), feed, 255.0)             # flip + float + area resize + / 255 in one HIP pass (vido_area_feed), identical values
+    else:
+        t = (bgr.to(dev).flip(-1) if torch.is_tensor(bgr) else torch.as_tensor(bgr[:, :, ::-1].copy(), device=dev)).permute(2, 0, 1).float().unsqueeze(0)
+        H, W = t.shape[2], t.shape[3]
+        x = F.interpolate(t, size=feed, mode="area").div(255.0)         # cv2.INTER_AREA
     disp = F.interpolate(net(x), size=(H, W), mode="bilinear", align_corners=False)[0, 0]
     lo, hi = disp.min(), disp.max()
     return ((disp - lo) / (hi - lo + 1e-12) * 65536.0).clamp(0, 65535).to(torch.int32)

@@ -54,6 +54,23 @@ class HipOps:
                                                        C.c_void_p(res.data_ptr()) if res is not None else None, N, Cc, H, W, C.c_float(slope)))
         return x
 
+    def area_feed(self, bgr, feed, div=1.0):
+        """u8 HxWx3 BGR device tensor -> f32 [1,3,feed_h,feed_w] RGB, area-resized, / div (flip + permute + float + interpolate(area) + div in one pass)"""
+        assert bgr.is_cuda and bgr.dtype == torch.uint8 and bgr.is_contiguous() and bgr.dim() == 3 and bgr.shape[2] == 3
+        out = torch.empty((1, 3, int(feed[0]), int(feed[1])), device=bgr.device, dtype=torch.float32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_area_feed(self.ctx.h, C.c_void_p(bgr.data_ptr()), bgr.shape[0], bgr.shape[1], C.c_void_p(out.data_ptr()), int(feed[0]), int(feed[1]), C.c_float(div)))
+        return out
+
+    def backwarp(self, x, flow):
+        """layers.py Backward: bilinear warp of x by flow (pixels), zero padding"""
+        assert x.is_cuda and x.dtype == torch.float32 and flow.dtype == torch.float32 and x.shape[0] == flow.shape[0] and x.shape[2:] == flow.shape[2:] and flow.shape[1] == 2
+        x = x.contiguous(); flow = flow.contiguous()
+        out = torch.empty_like(x)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_backwarp(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(flow.data_ptr()), x.shape[0], x.shape[1], x.shape[2], x.shape[3], C.c_void_p(out.data_ptr())))
+        return out
+
     def roi_align(self, feat, rois, output_size, spatial_scale, sampling_ratio):
         if not feat.is_cuda:
             raise RuntimeError("HipOps.roi_align needs CUDA(HIP) tensors; there is no CPU fallback")

@@ -98,7 +98,7 @@ class NetNodes:
         self.ctx2 = _Context(device=ctx.cfg.device, width=ctx.cfg.width, height=ctx.cfg.height, max_batch=1)
         self.ops = ops = _nets.HipOps(ctx)                # Mask R-CNN (ROI-Align, NMS, box decode, paste) + MonoDepth2 epilogues
         self.ops_flow = _nets.HipOps(self.ctx2)           # LiteFlowNet (cost volume, epilogues)
-        self.flow_net = _nets.fill_deterministic(_nets.LiteFlowNet(self.ops_flow.correlation, epilogue=self.ops_flow.bias_act_), seed).eval().to(dev)
+        self.flow_net = _nets.fill_deterministic(_nets.LiteFlowNet(self.ops_flow.correlation, epilogue=self.ops_flow.bias_act_, warp=self.ops_flow.backwarp), seed).eval().to(dev)
         self.depth_net = _nets.fill_deterministic(_nets.MonoDepth2(), seed + 1).eval().to(dev)
         self.mask_net = _nets.fill_maskrcnn(_nets.MaskRCNN(ops), seed + 2).eval().to(dev)
         self.folded = 0
@@ -109,14 +109,14 @@ class NetNodes:
         self.graph_error = None
         ex = torch.zeros((height, width, 3), dtype=torch.uint8, device=dev)
         self._flow_fn = lambda a, b: _nets.analyse_flow(self.flow_net, a, b)
-        self._depth_fn = lambda a: _nets.analyse_depth(self.depth_net, a, feed=self.depth_feed).to(torch.float32)
-        self._trunk_fn = lambda a: self.mask_net.trunk(_nets.maskrcnn.image_to_feed(a, dev, self.mask_feed))
+        self._depth_fn = lambda a: _nets.analyse_depth(self.depth_net, a, feed=self.depth_feed, ops=ops).to(torch.float32)
+        self._trunk_fn = lambda a: self.mask_net.trunk(_nets.maskrcnn.image_to_feed(a, dev, self.mask_feed, ops=ops))
         with torch.no_grad():
             for _ in range(2):                                          # first calls: MIOpen compiles / finds its kernels
                 self._flow_fn(ex, ex); self._depth_fn(ex); self._trunk_fn(ex)
             # the mask head's detection-count buckets: every batch size its convolutions will ever see is compiled now, not in the middle of a sequence
             mh = self.mask_net.roi_heads.mask
-            feats = self.mask_net.trunk(_nets.maskrcnn.image_to_feed(ex, dev, self.mask_feed))[0][:4]
+            feats = self.mask_net.trunk(_nets.maskrcnn.image_to_feed(ex, dev, self.mask_feed, ops=ops))[0][:4]
             for b in mh.buckets:
                 mh(feats, torch.tensor([[10.0, 10.0, 200.0, 300.0]], device=dev).repeat(b, 1), torch.ones(b, dtype=torch.int64, device=dev))
             torch.cuda.synchronize()
