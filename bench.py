@@ -62,7 +62,8 @@ def main():
     ap.add_argument("--prologue", type=int, default=20, help="untimed frames before the warm-up that fill the local-BA window (WINDOW_SIZE)")
     ap.add_argument("--feed", choices=("given", "nets"), default="given", help="maps the tracker consumes: the renderer's (default) or the networks' outputs")
     ap.add_argument("--no-pipeline", action="store_true", help="serial chain: networks of frame k, then tracking of frame k")
-    ap.add_argument("--no-graphs", action="store_true"); ap.add_argument("--no-fold", action="store_true"); ap.add_argument("--no-streams", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true"); ap.add_argument("--no-fold", action="store_true"); ap.add_argument("--no-streams", action="store_true", help="(default) the three networks share one stream")
+    ap.add_argument("--streams", action="store_true", help="one stream per network: measured SLOWER (23.6 vs 21.2 ms per frame for the three networks: their kernels each fill the GPU and evict each other's L2)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen measures its solvers once per layer shape)")
     ap.add_argument("--batch", type=int, default=64, help="frames in flight of the configs[1] batched leg")
     ap.add_argument("--cpu-baseline", type=int, default=2, help="frames of the CPU-baseline sample (0 = skip)")
@@ -122,7 +123,7 @@ def main():
     write_settings(cfg_path, scene.K, W, H)
     net_ctx = V.Context(device=local_rank, width=W, height=H, max_batch=1)             # owns the HIP ops of the network nodes (correlation, ROI-Align, NMS ...)
     t_setup = time.perf_counter()
-    nodes = pipeline.NetNodes(net_ctx, H, W, optimize=not args.no_fold, graphs=not args.no_graphs, streams=not args.no_streams, miopen_find=args.miopen_find)
+    nodes = pipeline.NetNodes(net_ctx, H, W, optimize=not args.no_fold, graphs=not args.no_graphs, streams=args.streams, miopen_find=args.miopen_find)
     t_setup = time.perf_counter() - t_setup
     slam = System(); slam.Init(cfg_path, System.RGBD)
     e2e = pipeline.EndToEnd(nodes, slam, n_image=10 ** 6, feed=args.feed)
@@ -205,7 +206,7 @@ def main():
                                         "handed the renderer's exact flow/depth/mask of the same frame (feed=given) after the network hand-over of that frame has completed",
                    "prologue_frames": args.prologue, "parallelism": "replicas x%d (per-frame path does not shard)" % world,
                    "net_optimisations": {"frozen_bn_folded_pairs": nodes.folded, "hip_graphs": nodes.g_flow is not None, "graph_error": nodes.graph_error,
-                                         "three_streams": nodes.streams is not None, "miopen_find": bool(args.miopen_find)},
+                                         "network_streams": 3 if nodes.streams is not None else 1, "miopen_find": bool(args.miopen_find)},
                    "inputs": "BGR u8 frames in pinned host memory; flow f32x2 / depth f32 / mask i32 handed to TrackRGBD as host buffers"},
         "stage_ms": {k: round(v, 3) for k, v in stage.items()},
         "per_frame_counts": {k: round(v, 1) for k, v in counts.items()},

@@ -78,13 +78,14 @@ import time as _time
 
 class NetNodes:
     """The three network nodes (flow_net / mono_depth2 / mask_rcnn ROS services, run_vido.cc:142-157) resident on one device, fp32 like
-    the reference.  infer(prev_bgr, cur_bgr) enqueues the three forwards on three HIP streams (they overlap on the GPU: at batch 1 most
-    layers leave CUs idle) and returns device tensors in the tracker's input types (run_vido.cc:28-37: depth MONO16 -> CV_32F,
+    the reference.  infer(prev_bgr, cur_bgr) enqueues the three forwards — on ONE stream by default: their convolutions each fill the GPU, and run on three
+    streams (streams=True) they evict each other's L2 working sets (measured 23.6 ms per frame for the three nodes against 21.2 ms back to back); what overlaps
+    with the networks is the tracker of the previous frame (EndToEnd) — and returns device tensors in the tracker's input types (run_vido.cc:28-37: depth MONO16 -> CV_32F,
     mask MONO8 -> CV_32SC1, flow 32FC2).  optimize: frozen batch norms folded into the convolutions + fused HIP epilogues
     (nets/fuse.py); graphs: the static-shape parts (all of LiteFlowNet and MonoDepth2 incl. their resize wrappers, Mask R-CNN's backbone +
     FPN + RPN head) are captured into hipGraphs."""
 
-    def __init__(self, ctx, height=480, width=640, optimize=True, graphs=True, streams=True, miopen_find=False, seed=1,
+    def __init__(self, ctx, height=480, width=640, optimize=True, graphs=True, streams=False, miopen_find=False, seed=1,
                  mask_feed=(1088, 800), depth_feed=(192, 640), confidence=0.8):
         self.ctx, self.h, self.w = ctx, height, width
         self.mask_feed, self.depth_feed, self.confidence = mask_feed, depth_feed, confidence
