@@ -297,7 +297,10 @@ int vido_box_decode(vido_ctx* ctx, const float* deltas, const float* boxes, int 
 /* ---- Initial model: seeded P3P-RANSAC (Tracking::GetInitModelCam / GetInitModelObj, Tracking.cc:1965-1970, 2068-2073:
  * cv::solvePnPRansac(pre_3d, cur_2d, K, 0, ..., 500, 0.4, 0.98, inliers, SOLVEPNP_P3P)).  pts3d [n*3] f32 (previous frame,
  * world), pts2d [n*2] f32 (current keypoints); T_out row-major 4x4 world->camera; inlier_mask[n] may be NULL.
- * All max_iters hypotheses are scored in parallel; OpenCV's adaptive early stop is replayed on the counts. */
+ * All max_iters hypotheses are scored in parallel; OpenCV's adaptive early stop is replayed on the counts.
+ * DEVIATION from cv::solvePnPRansac: OpenCV refits the winning model on its inlier set before returning (solvepnp.cpp, the final solvePnP over the inliers); this entry
+ * returns the winning minimal-sample P3P pose itself.  Both reference call sites hand the pose straight to PoseOptimizationFlow2Cam / PoseOptimizationFlow2, which
+ * re-optimise it over the same inliers, so only the optimiser's starting point differs; the sampling sequence (counter-based RNG) also differs from cv::RNG by design. */
 int vido_pnp_ransac(vido_ctx* ctx, const float* pts3d, const float* pts2d, int n, double fx, double fy, double cx, double cy,
                     int max_iters, double reproj_err, double confidence, uint64_t seed, double T_out[16], uint8_t* inlier_mask,
                     int32_t* n_inliers);

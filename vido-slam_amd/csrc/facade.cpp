@@ -48,6 +48,14 @@ static void check(int rc, const char* what)
 {
     if (rc < 0) throw std::runtime_error(std::string(what) + ": " + vido_last_error(g_ctx));
 }
+// The static Optimizer:: methods and the Frame constructor of the reference's interface carry no context argument, so the facade keeps ONE process-wide context (set by
+// the tracker's extractor / GrabImageRGBD).  One live System per process, like the reference (Frame's static members, Frame.cc:26-30); calls before the first frame or
+// after the System is gone fail with an exception instead of dereferencing a stale pointer.
+static vido_ctx* live_ctx(const char* what)
+{
+    if (!g_ctx) throw std::runtime_error(std::string(what) + ": no live VIDO_SLAM::System (the facade supports one System per process; create it and grab a frame first)");
+    return g_ctx;
+}
 static void toRow16(const cv::Mat& T, double* o) { for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) o[r * 4 + c] = T.at<float>(r, c); }
 static cv::Mat fromRow16(const double* o) { cv::Mat T(4, 4, CV_32F); for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T.at<float>(r, c) = (float)o[r * 4 + c]; return T; }
 static cv::Mat vec3(float x, float y, float z) { cv::Mat m(3, 1, CV_32F); m.at<float>(0) = x; m.at<float>(1) = y; m.at<float>(2) = z; return m; }
@@ -240,7 +248,7 @@ int Optimizer::PoseOptimizationNew(Frame* cur, Frame* last, std::vector<int>& TM
     const int its[4] = {100, 10, 10, 10}; const float th[4] = {0.01f, 5.991f, 5.991f, 5.991f};
     memcpy(p.iters, its, sizeof its); memcpy(p.chi2_th, th, sizeof th);
     vido_pose_result r; std::vector<uint8_t> outl(std::max(N, 1));
-    check(vido_pose_optimize(g_ctx, &p, &r, outl.data(), nullptr), "PoseOptimizationNew");
+    check(vido_pose_optimize(live_ctx("PoseOptimizationNew"), &p, &r, outl.data(), nullptr), "PoseOptimizationNew");
     if (N < 3) return 0;
     cur->SetPose(fromRow16(r.T));
     for (int i = 0; i < N; i++) if (outl[i]) TM[i] = -1;
@@ -262,7 +270,7 @@ int Optimizer::PoseOptimizationFlow2Cam(Frame* cur, Frame* last, std::vector<int
     const int its[4] = {100, 100, 100, 100}; const float th[4] = {0.04f, 5.991f, 5.991f, 5.991f};
     memcpy(p.iters, its, sizeof its); memcpy(p.chi2_th, th, sizeof th);
     vido_pose_result r; std::vector<uint8_t> outl(std::max(N, 1)); std::vector<double> f(2 * std::max(N, 1));
-    check(vido_pose_optimize(g_ctx, &p, &r, outl.data(), f.data()), "PoseOptimizationFlow2Cam");
+    check(vido_pose_optimize(live_ctx("PoseOptimizationFlow2Cam"), &p, &r, outl.data(), f.data()), "PoseOptimizationFlow2Cam");
     if (N < 3) return 0;
     cur->SetPose(fromRow16(r.T));
     for (int i = 0; i < N; i++) {
@@ -332,7 +340,7 @@ cv::Mat Optimizer::PoseOptimizationObjMot(Frame* cur, Frame* last, const std::ve
 {
     if ((int)ObjId.size() < 3) return cv::Mat::eye(4, 4, CV_32F);
     ObjProblem o; build_objmot(o, cur, last, ObjId, cur->mInitModel);
-    check(vido_pose_optimize(g_ctx, &o.p, &o.r, o.outl.data(), nullptr), "PoseOptimizationObjMot");
+    check(vido_pose_optimize(live_ctx("PoseOptimizationObjMot"), &o.p, &o.r, o.outl.data(), nullptr), "PoseOptimizationObjMot");
     return finish_obj(o, cur, last, ObjId, InlierID);
 }
 
@@ -340,7 +348,7 @@ cv::Mat Optimizer::PoseOptimizationFlow2(Frame* cur, Frame* last, const std::vec
 {
     if ((int)ObjId.size() < 3) return cv::Mat::eye(4, 4, CV_32F);
     ObjProblem o; build_flow2(o, cur, last, ObjId, cur->mInitModel);
-    check(vido_pose_optimize(g_ctx, &o.p, &o.r, o.outl.data(), o.f.data()), "PoseOptimizationFlow2");
+    check(vido_pose_optimize(live_ctx("PoseOptimizationFlow2"), &o.p, &o.r, o.outl.data(), o.f.data()), "PoseOptimizationFlow2");
     return finish_obj(o, cur, last, ObjId, InlierID);
 }
 
@@ -359,7 +367,7 @@ std::vector<cv::Mat> Optimizer::PoseOptimizationObjectsBatch(Frame* cur, Frame* 
     }
     for (size_t i : which) { P.push_back(O[i].p); om.push_back(O[i].outl.data()); fo.push_back(joint ? O[i].f.data() : nullptr); }
     R.resize(P.size());
-    if (!P.empty()) check(vido_pose_optimize_batch(g_ctx, P.data(), (int)P.size(), R.data(), om.data(), fo.data()), "PoseOptimizationObjectsBatch");
+    if (!P.empty()) check(vido_pose_optimize_batch(live_ctx("PoseOptimizationObjectsBatch"), P.data(), (int)P.size(), R.data(), om.data(), fo.data()), "PoseOptimizationObjectsBatch");
     for (size_t k = 0; k < which.size(); k++) { const size_t i = which[k]; O[i].r = R[k]; out[i] = finish_obj(O[i], cur, last, ObjIds[i], InlierIDs[i]); }
     return out;
 }
@@ -512,8 +520,8 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
     d.huber_dyn = d.huber_tern = d.huber_smooth = (double)0.01f;                                                              // :1358
     const char* dump_dir = global ? getenv("VIDO_DUMP_G2O") : nullptr;
     if (dump_dir) dump_g2o(std::string(dump_dir) + "/dynamic_slam_graph_before_opt.g2o", b, d, ptOwner, Hfr);
-    if (global && (d.n_H || d.n_dyn)) check(vido_ba_optimize_dynamic(g_ctx, &b, &d, &r, nullptr, nullptr), "FullBatchOptimization");
-    else check(vido_ba_optimize(g_ctx, &b, &r, nullptr, nullptr), global ? "FullBatchOptimization" : "PartialBatchOptimization");
+    if (global && (d.n_H || d.n_dyn)) check(vido_ba_optimize_dynamic(live_ctx("FullBatchOptimization"), &b, &d, &r, nullptr, nullptr), "FullBatchOptimization");
+    else check(vido_ba_optimize(live_ctx("BatchOptimization"), &b, &r, nullptr, nullptr), global ? "FullBatchOptimization" : "PartialBatchOptimization");
     if (getenv("VIDO_BA_VERBOSE"))
         fprintf(stderr, "[batch %s] cams %d pts %d obs %d | H %d dyn %d tern %d smooth %d | iters %d trials %d chi2 %.6g -> %.6g | setup %.2f ms loop %.2f ms\n", global ? "full" : "partial",
                 b.n_cam, b.n_pt, b.n_obs, d.n_H, d.n_dyn, d.n_tern, d.n_smooth, r.iterations, r.lm_trials, r.chi2_initial, r.chi2_final, r.ms_setup, r.ms_solve_loop);
