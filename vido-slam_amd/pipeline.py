@@ -74,6 +74,7 @@ class NetFrontEnd:
 import queue as _queue
 import threading as _threading
 import time as _time
+import os as _os
 
 
 class NetNodes:
@@ -171,12 +172,12 @@ class EndToEnd:
         h, w = nodes.h, nodes.w
         pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
         self.host = [dict(bgr=pin((h, w, 3), torch.uint8), flow=pin((h, w, 2), torch.float32), depth=pin((h, w), torch.float32), mask=pin((h, w), torch.int32),
-                          g_flow=pin((h, w, 2), torch.float32), g_depth=pin((h, w), torch.float32), g_mask=pin((h, w), torch.int32)) for _ in range(self.RING)]
+                          given=None) for _ in range(self.RING)]
         self.copy_stream = torch.cuda.Stream(device=nodes.dev)
         self.q = _queue.Queue(maxsize=1)      # the networks run at most one frame ahead of the tracker (+ the one in flight)
         self.poses, self.stats, self.err = [], [], None
         self.t_net, self.t_track, self.t_wait = [], [], []
-        self.prev = None; self.k = 0
+        self.prev = None; self.k = 0; self._pending = None
         self.worker = _threading.Thread(target=self._track_loop, daemon=True); self.worker.start()
 
     def _track_loop(self):
@@ -191,12 +192,15 @@ class EndToEnd:
                 t1 = _time.perf_counter()
                 hb = self.host[slot]
                 if self.feed == "nets":
-                    d, f, m = hb["depth"], hb["flow"], hb["mask"]
+                    d, f, m = hb["depth"].numpy(), hb["flow"].numpy(), hb["mask"].numpy()
                 else:
-                    d, f, m = hb["g_depth"], hb["g_flow"], hb["g_mask"]
-                T = self.system.TrackRGBD(hb["bgr"].numpy(), d.numpy(), f.numpy(), m.numpy(), None, None, float(k), None, self.n_image)
+                    d, f, m = hb["given"]                                # the caller's arrays, by reference (kept alive in the ring like the tracker's shallow references need)
+                if _os.environ.get("VIDO_E2E_SKIP_TRACK"):               # diagnosis only: networks + hand-over without the tracker
+                    T = None
+                else:
+                    T = self.system.TrackRGBD(hb["bgr"].numpy(), d, f, m, None, None, float(k), None, self.n_image)
                 t2 = _time.perf_counter()
-                self.poses.append(T); self.stats.append(self.system.stats())
+                self.poses.append(T); self.stats.append(self.system.stats() if T is not None else {})
                 self.t_wait.append((t1 - t0) * 1e3); self.t_track.append((t2 - t1) * 1e3)
             except Exception as e:                                       # surfaced by push() / finish()
                 self.err = e
@@ -213,9 +217,12 @@ class EndToEnd:
         hb = self.host[slot]
         hb["bgr"].numpy()[...] = bgr
         if given is not None:
-            hb["g_depth"].numpy()[...] = given[0]; hb["g_flow"].numpy()[...] = given[1]; hb["g_mask"].numpy()[...] = given[2]
+            import numpy as _np
+            hb["given"] = (_np.ascontiguousarray(given[0], dtype=_np.float32), _np.ascontiguousarray(given[1], dtype=_np.float32), _np.ascontiguousarray(given[2], dtype=_np.int32))
         cur = hb["bgr"].to(self.nodes.dev, non_blocking=True)            # the only upload of the frame on the network side
         prev = cur if self.prev is None else self.prev                   # first frame: RunNet has no previous image yet; the tracker ignores the flow of frame 0's predecessor
+        if self._pending is not None:                                    # graph outputs are static buffers: the replay below must not overwrite them before the previous frame's
+            self._pending.synchronize(); self._pending = None            # hand-over copies ran — waited for HERE, after this frame's host-side preparation, not at the end of push
         flow, depth, mask, labels, evs = self.nodes.infer(prev, cur)
         cs = self.copy_stream
         for e in evs:
@@ -227,7 +234,7 @@ class EndToEnd:
         self.prev = cur
         self.t_net.append((_time.perf_counter() - t0) * 1e3)
         self.q.put((self.k, slot, done))                                 # blocks while the tracker is still two frames behind
-        done.synchronize() if self.nodes.g_flow is not None else None    # graph outputs are static buffers: the next replay must not overwrite them before the copy ran
+        self._pending = done if self.nodes.g_flow is not None else None
         self.k += 1
 
     def finish(self):
