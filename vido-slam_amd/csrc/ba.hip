@@ -1632,7 +1632,7 @@ __global__ __launch_bounds__(128) void k_bcr_update(BcrDev B, int s, const doubl
 #pragma unroll
         for (int r = 0; r < BCR_RB; r++) { d[r] = 0.0; ln[r] = 0.0; }
         if (has_p) {
-#pragma unroll 6
+#pragma unroll 22
             for (int k = 0; k < m; k++) {
                 const double gr = GRp[(size_t)k * m], gl = -GLp[(size_t)k * m];
 #pragma unroll
@@ -1640,7 +1640,7 @@ __global__ __launch_bounds__(128) void k_bcr_update(BcrDev B, int s, const doubl
             }
         }
         if (has_q) {
-#pragma unroll 6
+#pragma unroll 22
             for (int k = 0; k < m; k++) {
                 const double gl = GLq[(size_t)k * m];
 #pragma unroll
