@@ -150,10 +150,12 @@ def main():
         dt = float(t.item())
     fps = args.steps * world / dt
     st = e2e.stats[n0:]
-    mean = lambda key: float(np.mean([s[key] for s in st])) if st else 0.0
+    mean = lambda key: float(np.mean([s.get(key, 0.0) for s in st])) if st else 0.0
     # pose accuracy of the timed frames against the renderer's ground truth: the chain did real work
     t_err = []
     for i, T in enumerate(e2e.poses):
+        if T is None:                                        # VIDO_E2E_SKIP_TRACK=1 (diagnosis: the chain without the tracker)
+            t_err.append(0.0); continue
         E = T.astype(np.float64) @ np.linalg.inv(scene.Tcw(i))
         t_err.append(float(np.linalg.norm(E[:3, 3])))
     stage = {"track_total_ms": mean("ms_total"), "update_mask_ms": mean("ms_update_mask"), "frame_orb_lists_ms": mean("ms_frame"), "cam_pose_ms": mean("ms_cam_pose"),
