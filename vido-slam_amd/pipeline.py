@@ -76,6 +76,13 @@ import threading as _threading
 import time as _time
 import os as _os
 
+# MIOpen user find-db recorded once on an MI355X with `bench.py --miopen-find` (MIOPEN_USER_DB_PATH pointing here): the measured best solver per convolution shape of the
+# three nodes at their feed sizes.  With it the default immediate-mode path picks those solvers without searching (the search costs ~3.5 minutes of start-up; the
+# heuristic pick without the db is 0.7 ms per frame slower).  Read by MIOpen when its handle is created, i.e. at the first convolution; an explicit setting wins.
+_MIOPEN_DB = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
+if _os.path.isdir(_MIOPEN_DB) and "MIOPEN_USER_DB_PATH" not in _os.environ:
+    _os.environ["MIOPEN_USER_DB_PATH"] = _MIOPEN_DB
+
 
 class NetNodes:
     """The three network nodes (flow_net / mono_depth2 / mask_rcnn ROS services, run_vido.cc:142-157) resident on one device, fp32 like
