@@ -180,11 +180,13 @@ class EndToEnd:
         pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
         self.host = [dict(bgr=pin((h, w, 3), torch.uint8), flow=pin((h, w, 2), torch.float32), depth=pin((h, w), torch.float32), mask=pin((h, w), torch.int32),
                           given=None) for _ in range(self.RING)]
+        self.dev = [dict(flow=torch.empty((h, w, 2), dtype=torch.float32, device=nodes.dev), depth=torch.empty((h, w), dtype=torch.float32, device=nodes.dev),
+                         mask=torch.empty((h, w), dtype=torch.int32, device=nodes.dev)) for _ in range(self.RING)]
         self.copy_stream = torch.cuda.Stream(device=nodes.dev)
         self.q = _queue.Queue(maxsize=1)      # the networks run at most one frame ahead of the tracker (+ the one in flight)
         self.poses, self.stats, self.err = [], [], None
         self.t_net, self.t_track, self.t_wait = [], [], []
-        self.prev = None; self.k = 0; self._pending = None
+        self.prev = None; self.k = 0
         self.worker = _threading.Thread(target=self._track_loop, daemon=True); self.worker.start()
 
     def _track_loop(self):
@@ -228,20 +230,24 @@ class EndToEnd:
             hb["given"] = (_np.ascontiguousarray(given[0], dtype=_np.float32), _np.ascontiguousarray(given[1], dtype=_np.float32), _np.ascontiguousarray(given[2], dtype=_np.int32))
         cur = hb["bgr"].to(self.nodes.dev, non_blocking=True)            # the only upload of the frame on the network side
         prev = cur if self.prev is None else self.prev                   # first frame: RunNet has no previous image yet; the tracker ignores the flow of frame 0's predecessor
-        if self._pending is not None:                                    # graph outputs are static buffers: the replay below must not overwrite them before the previous frame's
-            self._pending.synchronize(); self._pending = None            # hand-over copies ran — waited for HERE, after this frame's host-side preparation, not at the end of push
         flow, depth, mask, labels, evs = self.nodes.infer(prev, cur)
+        # graph outputs are static buffers that the next replay overwrites: park them in this slot's device buffers (three device-to-device copies of 4.8 MB in stream
+        # order, microseconds) and let the copy stream take its time over PCIe — the next frame's graphs need no host-side wait for the hand-over
+        db = self.dev[slot]
+        if self.nodes.streams is not None:
+            for e in evs:
+                torch.cuda.current_stream().wait_event(e)
+        db["flow"].copy_(flow, non_blocking=True); db["depth"].copy_(depth, non_blocking=True); db["mask"].copy_(mask, non_blocking=True)
+        parked = torch.cuda.Event(); parked.record()
         cs = self.copy_stream
-        for e in evs:
-            cs.wait_event(e)
+        cs.wait_event(parked)
         with torch.cuda.stream(cs):
-            hb["flow"].copy_(flow, non_blocking=True); hb["depth"].copy_(depth, non_blocking=True); hb["mask"].copy_(mask, non_blocking=True)
+            hb["flow"].copy_(db["flow"], non_blocking=True); hb["depth"].copy_(db["depth"], non_blocking=True); hb["mask"].copy_(db["mask"], non_blocking=True)
             done = torch.cuda.Event(); done.record()
-        self._alive = (flow, depth, mask, cur, prev)                     # until the copies have run (static graph outputs are reused next frame: q maxsize 1 + the wait below)
+        self._alive = (flow, depth, mask, cur, prev)
         self.prev = cur
         self.t_net.append((_time.perf_counter() - t0) * 1e3)
         self.q.put((self.k, slot, done))                                 # blocks while the tracker is still two frames behind
-        self._pending = done if self.nodes.g_flow is not None else None
         self.k += 1
 
     def finish(self):
