@@ -25,6 +25,7 @@ def ctx(vido):
     dict(n_cam=60, n_pt=3000, kind="global", track_len=10, seed=11),       # HBM-atomics path + blocked Cholesky
     dict(n_cam=23, n_pt=900, kind="global", track_len=7, seed=12),         # n6 = 138: just above the LDS limit
     dict(n_cam=90, n_pt=1500, kind="global", track_len=30, seed=13),       # 30-frame tracks: band too wide for the LDS window -> supernodal k_chol_band6s
+    dict(n_cam=80, n_pt=2500, kind="global", track_len=14, seed=14),       # half-bandwidth 89: block cyclic reduction with 96-unknown superblocks (k_bcr_elim<96>); the 60-camera case runs k_bcr_elim<66>
 ])
 def test_ba_matches_oracle(vido, oracle, ctx, kw):
     pr = vido.problems.synth_ba_problem(**kw)
@@ -159,3 +160,14 @@ def test_tracks_longer_than_64_frames_and_duplicate_observations(vido, oracle, c
     dup["obs_meas"] = np.concatenate([pr["obs_meas"], pr["obs_meas"][:1]])
     with pytest.raises(vido.VidoError):
         vido.ba_optimize(ctx, dup)
+
+
+def test_block_cyclic_reduction_equals_the_band_cholesky(vido, ctx, monkeypatch):
+    """the same problem through k_bcr_* and (VIDO_BA_NO_BCR) through k_chol_band6: same LM path, same result to rounding"""
+    pr = vido.problems.synth_ba_problem(n_cam=150, n_pt=9000, kind="global", track_len=10, seed=21); pr["max_iters"] = 6
+    a = vido.ba_optimize(ctx, pr)
+    monkeypatch.setenv("VIDO_BA_NO_BCR", "1")
+    b = vido.ba_optimize(ctx, pr)
+    assert a["iterations"] == b["iterations"] and a["lm_trials"] == b["lm_trials"]
+    assert abs(a["chi2_final"] - b["chi2_final"]) <= 1e-9 * b["chi2_final"]
+    assert rel(a["cam_T"], b["cam_T"]) < 1e-9 and rel(a["pt_xyz"], b["pt_xyz"]) < 1e-9
