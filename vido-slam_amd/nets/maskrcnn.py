@@ -399,9 +399,24 @@ class _MaskHead(nn.Module):
             m = next(b for b in self.buckets if b >= k)
             if m > k:
                 bx = torch.cat([bx, bx.new_zeros((m - k, 4))]); lb = torch.cat([lb, lb.new_zeros((m - k,))])
-            logits = self.predictor(self.feature_extractor(feats, bx))
+            g = self.graphed.get(m) if self.graphed and feats[0].data_ptr() == self._graph_feat_ptr else None
+            logits = g(bx) if g is not None else self.chunk_logits(feats, bx)          # hipGraph per bucket (pipeline.NetNodes): ~40 launches -> one replay
             out.append(logits.sigmoid()[torch.arange(m, device=lb.device), lb][:k, None])
         return torch.cat(out)
+
+    graphed = None; _graph_feat_ptr = 0
+
+    def chunk_logits(self, feats, bx):
+        return self.predictor(self.feature_extractor(feats, bx))
+
+    def capture_buckets(self, feats, graphed_cls):
+        """One captured graph per bucket size over the STATIC feature maps `feats` (the outputs of the captured trunk: same addresses every frame)."""
+        feats = list(feats)
+        self.graphed = {}
+        for b in self.buckets:
+            ex = torch.tensor([[10.0, 10.0, 200.0, 300.0]], device=feats[0].device).repeat(b, 1)
+            self.graphed[b] = graphed_cls(lambda bx, _f=feats: self.chunk_logits(_f, bx), [ex])
+        self._graph_feat_ptr = feats[0].data_ptr()
 
 
 class _RoiHeads(nn.Module):

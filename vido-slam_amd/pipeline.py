@@ -134,6 +134,8 @@ class NetNodes:
                     self.g_flow = _nets.Graphed(self._flow_fn, [ex, ex])
                     self.g_depth = _nets.Graphed(self._depth_fn, [ex])
                     self.g_trunk = _nets.Graphed(self._trunk_fn, [ex])
+                    if not _os.environ.get("VIDO_NO_MASK_GRAPHS"):
+                        mh.capture_buckets(self.g_trunk.static_out[0][:4], _nets.Graphed)      # the mask head per detection-count bucket, over the trunk's static feature maps
                 except Exception as e:                                  # capture is an optimisation: report, run eagerly
                     self.graph_error = "%s: %s" % (type(e).__name__, e)
                     self.g_flow = self.g_depth = self.g_trunk = None
