@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (optimisers / BA / matcher)")
+    ap.add_argument("--rccl-direct", action="store_true", help="global BA at N > 1: the library's own ncclAllReduce on its stream (csrc/rccl.cpp) instead of the torch.distributed hook; tested at world 1 only by the builder")
     ap.add_argument("--gba-cams", type=int, default=500)
     ap.add_argument("--gba-points", type=int, default=100000)
     args = ap.parse_args()
@@ -348,7 +349,7 @@ def main():
           gpr = P.synth_ba_problem(n_cam=args.gba_cams, n_pt=args.gba_points, kind="global", track_len=10, seed=11)
           gpr["max_iters"] = 5
           shards = V.landmark_shards(gpr["obs_pt"], gpr["n_pt"], world)
-          hook = V.torch_allreduce_hook() if world > 1 else None
+          hook = (V.rccl_direct_init(ctx, rank, world) if args.rccl_direct else V.torch_allreduce_hook()) if world > 1 else None
           sync_all()
           t1 = time.perf_counter()
           r = V.ba_optimize(ctx, gpr, rank=rank, world=world, shard=shards[rank] if world > 1 else None, allreduce=hook)
@@ -362,7 +363,7 @@ def main():
                                 "lm_iterations": r["iterations"], "lm_trials": r["lm_trials"], "ms_lm_loop": round(r["ms_solve_loop"], 2),
                                 "ms_setup": round(r["ms_setup"], 2), "lm_iters_per_s": round(r["iterations"] / (r["ms_solve_loop"] * 1e-3), 2),
                                 "chi2": [round(r["chi2_initial"], 3), round(r["chi2_final"], 3)], "wall_ms": round(d * 1e3, 1), "wall_ms_first_call": round(d_cold * 1e3, 1),
-                                "collective": "RCCL all-reduce (sum) of the reduced camera system per LM trial" if world > 1 else "none",
+                                "collective": ("RCCL all-reduce (sum) of the reduced camera system per LM trial, " + ("issued by the library on its stream" if args.rccl_direct else "through the torch.distributed hook")) if world > 1 else "none",
                                 "scaling_curve": "no 8-GPU scaling curve measured by the builder (single-GPU boxes); the driver's SCALE record is the measurement"}
           if "ms_phases" in r:
               extra["global_ba"]["ms_phases_per_trial"] = r["ms_phases"]

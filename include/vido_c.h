@@ -223,6 +223,14 @@ typedef struct vido_ba_result { int32_t iterations, lm_trials; double chi2_initi
 typedef int (*vido_allreduce_fn)(void* user, void* dev_ptr, size_t count, int op);
 
 int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_result* result, vido_allreduce_fn allreduce, void* user);
+/* The all-reduce issued by the library itself: RCCL (over xGMI) on the context's stream, in place, no host synchronisation — the role the reference gives nothing to
+ * (it is single-process).  One process per GPU: rank 0 calls vido_rccl_unique_id and distributes the 128 bytes by any means (bench.py: a
+ * torch.distributed broadcast), every rank calls vido_rccl_init on its context, then passes `vido_rccl_allreduce` as `allreduce` and the context as `user`.
+ * librccl is resolved at run time (dlopen); a process that never calls these does not load it. */
+int vido_rccl_unique_id(uint8_t id_out[128]);
+int vido_rccl_init(vido_ctx* ctx, const uint8_t id[128], int rank, int world);
+int vido_rccl_allreduce(void* user_ctx, void* dev_ptr, size_t count, int op);
+int vido_rccl_destroy(vido_ctx* ctx);
 
 /* Object part of Optimizer::FullBatchOptimization (Optimizer.cc:1235-2178 with STATIC_ONLY = false): per (object, frame)
  * motion vertices H (VertexSE3, the reference initialises them to identity, :1592), one dynamic point vertex per

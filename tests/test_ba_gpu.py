@@ -171,3 +171,19 @@ def test_block_cyclic_reduction_equals_the_band_cholesky(vido, ctx, monkeypatch)
     assert a["iterations"] == b["iterations"] and a["lm_trials"] == b["lm_trials"]
     assert abs(a["chi2_final"] - b["chi2_final"]) <= 1e-9 * b["chi2_final"]
     assert rel(a["cam_T"], b["cam_T"]) < 1e-9 and rel(a["pt_xyz"], b["pt_xyz"]) < 1e-9
+
+
+def test_library_side_rccl_allreduce_world_1(vido):
+    """vido_rccl_* (csrc/rccl.cpp): communicator on the context's device, ncclAllReduce enqueued on the context's stream by the sharded code path.  One GPU here,
+    so world = 1 (the reduction is the identity): what this pins is the plumbing — librccl resolved at run time, the init sequence, the stream-ordered call without
+    host synchronisation, the sharded solve (rank 0 of 1) equal to the plain one.  world > 1 needs one GPU per rank and is the driver's multi-GPU run."""
+    c = vido.Context(width=640, height=480, max_batch=1)
+    try:
+        pr = vido.problems.synth_ba_problem(n_cam=60, n_pt=3000, kind="global", track_len=10, seed=11)
+        plain = vido.ba_optimize(c, pr)
+        mode = vido.rccl_direct_init(c, 0, 1)
+        got = vido.ba_optimize(c, pr, rank=0, world=1, shard=(0, int(pr["n_pt"])), allreduce=mode)
+        assert got["iterations"] == plain["iterations"] and got["lm_trials"] == plain["lm_trials"]
+        assert rel(got["cam_T"], plain["cam_T"]) < 1e-9 and rel(got["pt_xyz"], plain["pt_xyz"]) < 1e-9
+    finally:
+        c.close()

@@ -2380,7 +2380,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     const int lin_E = 1;     // groups of 64 observations per wave in k_ba_linearize: with the LDS camera accumulators one group is fastest at every size measured (35 k .. 1 M edges)
     auto AR = [&](double* dptr, size_t cnt, int op) -> int {
         if (!allreduce) return VIDO_OK;
-        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (allreduce != vido_rccl_allreduce) HIP_TRY(ctx, hipStreamSynchronize(st));      // a host-side hook reads the buffer; the built-in RCCL path is ordered by the stream
         if (allreduce(user, dptr, cnt, op) != 0) return vido_set_error(ctx, VIDO_E_INVALID, "ba: all-reduce hook failed");
         return VIDO_OK;
     };

@@ -48,6 +48,8 @@ struct vido_ctx {
     struct PoseState* pose = nullptr;
     struct NetState* net = nullptr;
     struct PnpState* pnp = nullptr;
+    void* rccl_comm = nullptr;         // ncclComm_t of vido_rccl_init (rccl.cpp): the sharded BA's all-reduce on this context's stream
+    int rccl_rank = 0, rccl_world = 1;
 };
 
 int vido_set_error(vido_ctx* ctx, int code, const char* fmt, ...);

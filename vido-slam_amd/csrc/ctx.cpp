@@ -80,6 +80,7 @@ void vido_destroy(vido_ctx* ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    vido_rccl_destroy(ctx);
     orb_state_destroy(ctx);
     track_state_destroy(ctx);
     ham_state_destroy(ctx);

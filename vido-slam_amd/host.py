@@ -434,6 +434,25 @@ def torch_allreduce_hook(group=None):
     return ALLREDUCE_FN(hook)
 
 
+def rccl_direct_init(ctx, rank=0, world=1):
+    """Prepare `ctx` for the library's own RCCL all-reduce (vido_rccl_*, csrc/rccl.cpp): rank 0 draws the unique id, torch.distributed broadcasts its 128 bytes
+    (any transport would do), every rank initialises its communicator.  Afterwards pass allreduce="rccl" to ba_optimize."""
+    lib = ctx.lib
+    lib.vido_rccl_unique_id.argtypes = [C.c_void_p]; lib.vido_rccl_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    buf = (C.c_uint8 * 128)()
+    if rank == 0:
+        ctx._check(lib.vido_rccl_unique_id(buf))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor(list(buf), dtype=torch.uint8, device="cuda")
+        dist.broadcast(t, src=0)
+        for i, v in enumerate(t.cpu().tolist()):
+            buf[i] = v
+    ctx._check(lib.vido_rccl_init(ctx.h, buf, rank, world))
+    return "rccl"
+
+
 def landmark_shards(obs_pt, n_pt, world):
     """Contiguous landmark id ranges balanced by observation count."""
     cnt = np.bincount(np.asarray(obs_pt), minlength=n_pt).astype(np.int64)
@@ -488,14 +507,18 @@ def ba_optimize(ctx, k, rank=0, world=1, shard=None, allreduce=None, dynamic=Non
     lo, hi = shard if shard is not None else (0, 0)
     p.pt_lo, p.pt_hi, p.rank, p.world = lo, hi, rank, world
     r = BaResult()
-    fn = allreduce if allreduce is not None else C.cast(None, ALLREDUCE_FN)
+    user = None
+    if isinstance(allreduce, str) and allreduce == "rccl":            # the library's own RCCL all-reduce on the ctx stream (rccl_direct_init first)
+        fn = C.cast(ctx.lib.vido_rccl_allreduce, ALLREDUCE_FN); user = ctx.h
+    else:
+        fn = allreduce if allreduce is not None else C.cast(None, ALLREDUCE_FN)
     extra = {}
     if dynamic is not None:          # object part of FullBatchOptimization (problems.synth_ba_dynamic)
         s, b = _ba_dynamic_struct(dynamic)
-        ctx._check(ctx.lib.vido_ba_optimize_dynamic(ctx.h, C.byref(p), C.byref(s), C.byref(r), fn, None))
+        ctx._check(ctx.lib.vido_ba_optimize_dynamic(ctx.h, C.byref(p), C.byref(s), C.byref(r), fn, user))
         extra = dict(H_T=b["H_T"].reshape(-1, 3, 4), dyn_xyz=b["dyn_xyz"])
     else:
-        ctx._check(ctx.lib.vido_ba_optimize(ctx.h, C.byref(p), C.byref(r), fn, None))
+        ctx._check(ctx.lib.vido_ba_optimize(ctx.h, C.byref(p), C.byref(r), fn, user))
     return dict(cam_T=a["cam_T"].reshape(-1, 3, 4), pt_xyz=a["pt_xyz"], iterations=r.iterations, lm_trials=r.lm_trials,
                 chi2_initial=r.chi2_initial, chi2_final=r.chi2_final, lambda_final=r.lambda_final, ms_setup=r.ms_setup,
                 ms_solve_loop=r.ms_solve_loop, ms_linearize_kernel=r.ms_linearize_kernel, **extra)
