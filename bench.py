@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (optimisers / BA / matcher)")
     ap.add_argument("--rccl-direct", action="store_true", help="global BA at N > 1: the library's own ncclAllReduce on its stream (csrc/rccl.cpp) instead of the torch.distributed hook; tested at world 1 only by the builder")
+    ap.add_argument("--saturated-detector", action="store_true", help="keep the plain random fill of the detector: every class score saturates to 1.0, the ties defeat the detections_per_img cap and the mask head sees 200-300 detections per frame")
     ap.add_argument("--gba-cams", type=int, default=500)
     ap.add_argument("--gba-points", type=int, default=100000)
     args = ap.parse_args()
@@ -124,7 +125,7 @@ def main():
     write_settings(cfg_path, scene.K, W, H)
     net_ctx = V.Context(device=local_rank, width=W, height=H, max_batch=1)             # owns the HIP ops of the network nodes (correlation, ROI-Align, NMS ...)
     t_setup = time.perf_counter()
-    nodes = pipeline.NetNodes(net_ctx, H, W, optimize=not args.no_fold, graphs=not args.no_graphs, streams=args.streams, miopen_find=args.miopen_find)
+    nodes = pipeline.NetNodes(net_ctx, H, W, optimize=not args.no_fold, graphs=not args.no_graphs, streams=args.streams, miopen_find=args.miopen_find, calibrate_scores=not args.saturated_detector)
     t_setup = time.perf_counter() - t_setup
     slam = System(); slam.Init(cfg_path, System.RGBD)
     e2e = pipeline.EndToEnd(nodes, slam, n_image=10 ** 6, feed=args.feed)
@@ -164,6 +165,7 @@ def main():
              "net_enqueue_host_ms": float(np.mean(e2e.t_net[n0:])), "tracker_wait_for_nets_ms": float(np.mean(e2e.t_wait[n0:])), "tracker_thread_ms": float(np.mean(e2e.t_track[n0:]))}
     counts = {"keypoints": mean("n_keypoints"), "static_points": mean("n_static"), "static_inliers": mean("n_static_inliers"), "dynamic_objects": mean("n_objects"),
               "object_points": mean("n_object_points"), "ba_window": mean("ba_window")}
+    counts["detector_detections"] = float(np.mean(e2e.n_det[n0:])) if len(e2e.n_det) > n0 else 0.0      # what the mask head ran on (reference cap: detections_per_img = 100)
     e2e.close()
 
     # ---- the three networks alone (sequential, one stream each in turn): ms per forward and fp32 FLOP/s against the 157.3 TFLOP/s peak
@@ -209,7 +211,7 @@ def main():
                                         "handed the renderer's exact flow/depth/mask of the same frame (feed=given) after the network hand-over of that frame has completed",
                    "prologue_frames": args.prologue, "parallelism": "replicas x%d (per-frame path does not shard)" % world,
                    "net_optimisations": {"frozen_bn_folded_pairs": nodes.folded, "hip_graphs": nodes.g_flow is not None, "graph_error": nodes.graph_error,
-                                         "network_streams": 3 if nodes.streams is not None else 1, "miopen_find": bool(args.miopen_find)},
+                                         "network_streams": 3 if nodes.streams is not None else 1, "detector_score_calibration": round(nodes.score_scale, 6), "miopen_find": bool(args.miopen_find)},
                    "inputs": "BGR u8 frames in pinned host memory; flow f32x2 / depth f32 / mask i32 handed to TrackRGBD as host buffers"},
         "stage_ms": {k: round(v, 3) for k, v in stage.items()},
         "per_frame_counts": {k: round(v, 1) for k, v in counts.items()},

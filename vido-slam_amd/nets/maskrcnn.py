@@ -386,7 +386,7 @@ class _MaskHead(nn.Module):
     def forward(self, feats, boxes, labels):                         # mask_head/inference.py:29-47: per-detection class channel
         if not len(boxes):
             return feats[0].new_zeros((0, 1, 2 * self.feature_extractor.pooler.res, 2 * self.feature_extractor.pooler.res))
-        n = len(boxes)
+        n = len(boxes); self.last_n = n                              # detections the mask head ran on (bench: per_frame_counts)
         idx = torch.arange(n, device=labels.device)
         if not (boxes.is_cuda and self.buckets):
             return self.predictor(self.feature_extractor(feats, boxes)).sigmoid()[idx, labels][:, None]
@@ -404,7 +404,7 @@ class _MaskHead(nn.Module):
             out.append(logits.sigmoid()[torch.arange(m, device=lb.device), lb][:k, None])
         return torch.cat(out)
 
-    graphed = None; _graph_feat_ptr = 0
+    graphed = None; _graph_feat_ptr = 0; last_n = 0
 
     def chunk_logits(self, feats, bx):
         return self.predictor(self.feature_extractor(feats, bx))

@@ -45,3 +45,22 @@ def fill_maskrcnn(module, seed=0, reg_scale=0.05):
             elif k.endswith("bn3.weight"):
                 v.mul_(0.25)                # damped residual branches: activations stay O(1) through 16..33 bottlenecks
     return module
+
+
+@torch.no_grad()
+def calibrate_detector_scores(net, image, target_std=2.0):
+    """Rescale the box head's class-logit layer so that the logits of `image`'s proposals have standard deviation `target_std`.
+    With the plain deterministic fill the activations grow through the un-normalised FPN / two-FC head and every class score saturates to exactly 1.0 in fp32; all
+    detections then TIE at the kthvalue cut of box_head/inference.py:131-137 and the detections_per_img = 100 cap does not bind (200-300 detections per frame, a workload
+    trained weights cannot produce).  With distinct scores the cap binds: the mask head sees at most 100 detections per image, as in the reference.  Only cls_score is
+    touched (one scalar); the state-dict layout is unchanged.  Returns the factor applied."""
+    feats, logits, deltas = net.trunk(image)
+    H, W = image.shape[-2:]
+    proposals, objectness = net.rpn.proposals(feats, logits, deltas, (W, H))
+    box = net.roi_heads.box
+    cls_logits, _ = box.predictor(box.feature_extractor(feats[:len(net.config.pool_scales)], proposals))
+    valid = objectness >= 0 if objectness is not None else torch.ones(len(proposals), dtype=torch.bool, device=cls_logits.device)
+    std = float(cls_logits[valid].std())
+    k = target_std / std if std > 0 else 1.0
+    box.predictor.cls_score.weight.mul_(k); box.predictor.cls_score.bias.mul_(k)
+    return k

@@ -94,7 +94,7 @@ class NetNodes:
     FPN + RPN head) are captured into hipGraphs."""
 
     def __init__(self, ctx, height=480, width=640, optimize=True, graphs=True, streams=False, miopen_find=False, seed=1,
-                 mask_feed=(1088, 800), depth_feed=(192, 640), confidence=0.8):
+                 mask_feed=(1088, 800), depth_feed=(192, 640), confidence=0.8, calibrate_scores=True):
         self.ctx, self.h, self.w = ctx, height, width
         self.mask_feed, self.depth_feed, self.confidence = mask_feed, depth_feed, confidence
         if miopen_find:
@@ -110,6 +110,13 @@ class NetNodes:
         self.flow_net = _nets.fill_deterministic(_nets.LiteFlowNet(self.ops_flow.correlation, epilogue=self.ops_flow.bias_act_, warp=self.ops_flow.backwarp), seed).eval().to(dev)
         self.depth_net = _nets.fill_deterministic(_nets.MonoDepth2(), seed + 1).eval().to(dev)
         self.mask_net = _nets.fill_maskrcnn(_nets.MaskRCNN(ops), seed + 2).eval().to(dev)
+        # random-init detector: un-saturate the class scores so that the reference's detections_per_img cap binds (see nets/weights.py); a synthetic textured frame
+        self.score_scale = 1.0
+        if calibrate_scores:
+            g = torch.Generator(device="cpu").manual_seed(seed + 3)
+            cal = torch.randint(0, 256, (height // 8, width // 8, 3), generator=g, dtype=torch.uint8).repeat_interleave(8, 0).repeat_interleave(8, 1).to(dev)
+            with torch.no_grad():
+                self.score_scale = _nets.calibrate_detector_scores(self.mask_net, _nets.maskrcnn.image_to_feed(cal, dev, mask_feed, ops=ops))
         self.folded = 0
         if optimize:
             self.folded = _nets.fold_batchnorm(self.depth_net, ops) + _nets.fold_batchnorm(self.mask_net, ops)
@@ -187,7 +194,7 @@ class EndToEnd:
         self.copy_stream = torch.cuda.Stream(device=nodes.dev)
         self.q = _queue.Queue(maxsize=1)      # the networks run at most one frame ahead of the tracker (+ the one in flight)
         self.poses, self.stats, self.err = [], [], None
-        self.t_net, self.t_track, self.t_wait = [], [], []
+        self.t_net, self.t_track, self.t_wait, self.n_det = [], [], [], []
         self.prev = None; self.k = 0
         self.worker = _threading.Thread(target=self._track_loop, daemon=True); self.worker.start()
 
@@ -246,6 +253,7 @@ class EndToEnd:
         with torch.cuda.stream(cs):
             hb["flow"].copy_(db["flow"], non_blocking=True); hb["depth"].copy_(db["depth"], non_blocking=True); hb["mask"].copy_(db["mask"], non_blocking=True)
             done = torch.cuda.Event(); done.record()
+        self.n_det.append(int(getattr(self.nodes.mask_net.roi_heads.mask, "last_n", 0)))
         self._alive = (flow, depth, mask, cur, prev)
         self.prev = cur
         self.t_net.append((_time.perf_counter() - t0) * 1e3)
