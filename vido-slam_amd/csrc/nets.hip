@@ -409,9 +409,12 @@ __global__ __launch_bounds__(256) void k_area_feed(const uint8_t* __restrict__ s
 // flow_net/src/layers.py:25-37 (Backward): out[b,c,h,w] = bilinear sample of x[b,c] at the grid point g = (-1 + (2w+1)/W + u / ((W-1)/2), -1 + (2h+1)/H + v / ((H-1)/2)),
 // grid_sample(mode bilinear, padding zeros, align_corners False): pixel coordinate ((g + 1) * size - 1) / 2.  One thread per (b, h, w), the channels in a loop
 // (the four taps and weights are shared by all channels).  Replaces 2 linspace + expand + 2 div + 2 add + cat + permute + grid_sample.
+#define BW_CG 8
 __global__ __launch_bounds__(256) void k_backwarp(const float* __restrict__ x, const float* __restrict__ flow, int B, int C, int H, int W, float* __restrict__ out)
 {
-    const int w = blockIdx.x * 64 + (threadIdx.x & 63), h = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    // blockIdx.z = (image, group of BW_CG channels): the maps are small (<= 120 x 160 at 640 x 480), one thread per pixel alone leaves most CUs idle
+    const int w = blockIdx.x * 64 + (threadIdx.x & 63), h = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int ncg = (C + BW_CG - 1) / BW_CG, b = blockIdx.z / ncg, c0 = (blockIdx.z - b * ncg) * BW_CG, c1 = min(C, c0 + BW_CG);
     if (w >= W || h >= H) return;
     const size_t hw = (size_t)H * W, o = (size_t)h * W + w;
     const float u = flow[(size_t)b * 2 * hw + o], v = flow[(size_t)b * 2 * hw + hw + o];
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(256) void k_backwarp(const float* __restrict__ x, c
     const size_t isw = (size_t)(vy1 ? y1 : 0) * W + (vx0 ? x0 : 0), ise = (size_t)(vy1 ? y1 : 0) * W + (vx1 ? x1 : 0);
     const float mnw = (vy0 && vx0) ? wnw : 0.f, mne = (vy0 && vx1) ? wne : 0.f, msw = (vy1 && vx0) ? wsw : 0.f, mse = (vy1 && vx1) ? wse : 0.f;
 #pragma unroll 4
-    for (int c = 0; c < C; c++) {
+    for (int c = c0; c < c1; c++) {
         const float* xc = xb + (size_t)c * hw;
         // grid_sampler_2d_kernel accumulates nw, ne, sw, se in this order, skipping taps outside the image
         float acc = 0.f;
@@ -502,10 +505,10 @@ int vido_area_feed(vido_ctx* ctx, const uint8_t* bgr, int H, int W, float* out, 
 int vido_backwarp(vido_ctx* ctx, const float* x, const float* flow, int B, int C, int H, int W, float* out)
 {
     if (!ctx) return VIDO_E_INVALID;
-    if (!x || !flow || !out || B < 1 || C < 1 || H < 2 || W < 2 || B > 65535) return vido_set_error(ctx, VIDO_E_INVALID, "backwarp: bad arguments");
+    if (!x || !flow || !out || B < 1 || C < 1 || H < 2 || W < 2 || (long long)B * ((C + 7) / 8) > 65535) return vido_set_error(ctx, VIDO_E_INVALID, "backwarp: bad arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
-    hipLaunchKernelGGL(k_backwarp, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(256), 0, st, x, flow, B, C, H, W, out);
+    hipLaunchKernelGGL(k_backwarp, dim3((W + 63) / 64, (H + 3) / 4, B * ((C + BW_CG - 1) / BW_CG)), dim3(256), 0, st, x, flow, B, C, H, W, out);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }
