@@ -57,10 +57,13 @@ private:
 class Frame {
 public:
     Frame() {}
-    /* RGB-D constructor, Frame.cc:36-241 (UseSampleFea == 0). */
+    /* RGB-D constructor, Frame.cc:36-241.  UseSampleFea == 1 (Option II, Frame.cc:101-150): the static candidates come from SampleKeyPoints instead of the ORB keypoints. */
     Frame(const cv::Mat& imGray, const cv::Mat& imDepth, const cv::Mat& imFlow, const cv::Mat& maskSEM, const double& timeStamp,
           ORBextractor* extractor, cv::Mat& K, cv::Mat& distCoef, const float& bf, const float& thDepth, const float& thDepthObj, const int& UseSampleFea);
     void SetPose(cv::Mat Tcw);
+    /* Frame.cc:888-956: 3000 points, one per cell of a 20 x 20 grid per round, integer coordinates, listed cell by cell.  The reference seeds cv::RNG with time(NULL)
+     * (not reproducible); this build draws from a counter-based generator seeded with the frame id, so a run can be repeated. */
+    std::vector<cv::KeyPoint> SampleKeyPoints(const int& rows, const int& cols);
     cv::Mat GetRotationInverse() const { return mRwc.clone(); }
     cv::Mat GetCameraCenter() const { return mOw.clone(); }
     cv::Mat UnprojectStereoStat(const int& i, const bool& addnoise);      /* Frame.cc:706-737; addnoise is ignored */

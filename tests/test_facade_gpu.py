@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def write_clip(tmp, scene, n, dataset=1, factor=1.0, bf=387.57):
+def write_clip(tmp, scene, n, dataset=1, factor=1.0, bf=387.57, sample_features=0):
     for sub in ("image_0", "flow_image", "depth_image", "mask_image"):
         os.makedirs(os.path.join(tmp, sub), exist_ok=True)
     for k in range(n):
@@ -30,7 +30,7 @@ def write_clip(tmp, scene, n, dataset=1, factor=1.0, bf=387.57):
         fh.write("%%YAML:1.0\nimage_path: %s\nn_frames: %d\nCamera.width: %d\nCamera.height: %d\n" % (os.path.join(tmp, "image_0"), n, scene.w, scene.h))
         fh.write("Camera.fx: %r\nCamera.fy: %r\nCamera.cx: %r\nCamera.cy: %r\nCamera.k1: 0.0\nCamera.k2: 0.0\nCamera.p1: 0.0\nCamera.p2: 0.0\nCamera.k3: 0.0\n" % (fx, fy, cx, cy))
         fh.write("Camera.bf: %r\nCamera.fps: 10.0\nCamera.RGB: 0\nChooseData: %d\nDepthMapFactor: %r\nThDepthBG: 40.0\nThDepthOBJ: 25.0\n" % (bf, dataset, factor))
-        fh.write("MaxTrackPointBG: 3000\nMaxTrackPointOBJ: 800\nSFMgThres: 0.12\nSFDsThres: 0.3\nWINDOW_SIZE: 20\nOVERLAP_SIZE: 4\nUseSampleFeature: 0\n")
+        fh.write("MaxTrackPointBG: 3000\nMaxTrackPointOBJ: 800\nSFMgThres: 0.12\nSFDsThres: 0.3\nWINDOW_SIZE: 20\nOVERLAP_SIZE: 4\nUseSampleFeature: %d\n" % sample_features)
         fh.write("ORBextractor.nFeatures: 2000\nORBextractor.scaleFactor: 1.2\nORBextractor.nLevels: 8\nORBextractor.iniThFAST: 20\nORBextractor.minThFAST: 7\n")
     return cfg
 
@@ -158,3 +158,25 @@ def test_reference_disk_layout_50_frame_clip(tmp_path, vido):
     assert max(rpe) < 0.03 and max(err) < 0.3, (max(rpe), max(err), np.mean(err))
     ref = np.loadtxt(os.path.join(str(tmp_path), "res_refined_rgbd_new.txt"))
     assert ref.shape == (n, 17)
+
+
+def test_use_sample_feature_option(tmp_path, vido):
+    """UseSampleFeature: 1 (Frame.cc:101-150, Tracking.cc:3013-3018): the static candidates are 3000 random grid samples instead of the ORB keypoints; same filter, same
+    downstream pipeline.  (The reference seeds its generator with time(NULL); this build seeds a counter generator with the frame id, so the run is repeatable.)"""
+    sys.path.insert(0, os.path.join(ROOT, "vido-slam_amd"))
+    import build
+    driver = build.build_driver()
+    n = 8
+    scene = vido.synth.Scene3D(n_frames=n, seed=3, objects=((-2.0, 0.2, 9.0, 0.25, 0.0, 0.05),))
+    cfg = write_clip(str(tmp_path), scene, n, sample_features=1)
+    outs = []
+    for run in range(2):
+        out = os.path.join(str(tmp_path), "poses%d.txt" % run)
+        r = subprocess.run([driver, cfg, out, os.path.join(str(tmp_path), "res%d_" % run)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        outs.append(np.loadtxt(out))
+    assert np.array_equal(outs[0], outs[1])                                       # repeatable
+    P = outs[0]
+    for k in range(1, n):
+        E = P[k, 1:].reshape(4, 4) @ np.linalg.inv(scene.Tcw(k))
+        assert np.linalg.norm(E[:3, 3]) < 0.05, (k, E)

@@ -118,31 +118,36 @@ Frame::Frame(const cv::Mat& imGray, const cv::Mat& imDepth, const cv::Mat& imFlo
              ORBextractor* extractor, cv::Mat& K, cv::Mat& distCoef, const float& bf, const float& thDepth, const float& thDepthObj, const int& UseSampleFea)
 {
     (void)imDepth; (void)imFlow; (void)maskSEM;            // their (patched) copies live in the device slot uploaded by GrabImageRGBD
-    if (UseSampleFea != 0) throw std::runtime_error("Frame: UseSampleFeature=1 (time-seeded random sampling, SURVEY fact 4) is not supported");
     mnId = nNextId++; mTimeStamp = timeStamp; mK = K.clone(); mDistCoef = distCoef.clone(); mbf = bf; mThDepth = thDepth; mThDepthObj = thDepthObj;
     fx = K.at<float>(0, 0); fy = K.at<float>(1, 1); cx = K.at<float>(0, 2); cy = K.at<float>(1, 2); invfx = 1.0f / fx; invfy = 1.0f / fy;
     (*extractor)(imGray, cv::Mat(), mvKeys, mDescriptors);                         // Frame.cc:62 ExtractORB
     N = (int)mvKeys.size();
     if (mvKeys.empty()) return;
     vido_ctx* c = extractor->context(imGray.cols, imGray.rows);
-    const int max_kp = 2 * extractor->nfeatures + 256, max_obj = ((imGray.cols + 3) / 4) * ((imGray.rows + 3) / 4);
-    std::vector<vido_keypoint> k(N);
-    for (int i = 0; i < N; i++) { k[i].x = mvKeys[i].pt.x; k[i].y = mvKeys[i].pt.y; k[i].size = mvKeys[i].size; k[i].angle = mvKeys[i].angle; k[i].response = mvKeys[i].response; k[i].octave = mvKeys[i].octave; }
+    // candidates of the static list: the ORB keypoints (Option I, Frame.cc:72-100) or random grid samples (Option II, UseSampleFeature = 1, Frame.cc:101-150) — the same
+    // mask / depth / flow filter runs on either (k_static_filter); Option II additionally wants the correspondence inside the image on the low side (:142)
+    const std::vector<cv::KeyPoint> sampled = UseSampleFea != 0 ? SampleKeyPoints(imGray.rows, imGray.cols) : std::vector<cv::KeyPoint>();
+    const std::vector<cv::KeyPoint>& cand = UseSampleFea != 0 ? sampled : mvKeys;
+    const int NC = (int)cand.size();
+    const int max_kp = std::max(2 * extractor->nfeatures + 256, NC + 256), max_obj = ((imGray.cols + 3) / 4) * ((imGray.rows + 3) / 4);
+    std::vector<vido_keypoint> k(NC);
+    for (int i = 0; i < NC; i++) { k[i].x = cand[i].pt.x; k[i].y = cand[i].pt.y; k[i].size = cand[i].size; k[i].angle = cand[i].angle; k[i].response = cand[i].response; k[i].octave = cand[i].octave; }
     k.resize(max_kp);
     std::vector<int32_t> sidx(max_kp), olab(max_obj); std::vector<float> scorr(2 * max_kp), sflow(2 * max_kp), sdep(max_kp), okeys(2 * max_obj), ocorr(2 * max_obj), odep(max_obj), oflow(2 * max_obj);
-    int32_t ns = 0, no = 0, nk = N;
+    int32_t ns = 0, no = 0, nk = NC;
     vido_frame_lists L; L.max_stat = max_kp; L.max_obj = max_obj; L.n_stat = &ns; L.stat_idx = sidx.data(); L.stat_corr = scorr.data(); L.stat_flow = sflow.data(); L.stat_depth = sdep.data();
     L.n_obj = &no; L.obj_keys = okeys.data(); L.obj_corr = ocorr.data(); L.obj_depth = odep.data(); L.obj_label = olab.data(); L.obj_flow = oflow.data();
     vido_track_params tp = g_tp; tp.th_depth_bg = thDepth; tp.th_depth_obj = thDepthObj;
     if (vido_frame_features(c, g_slot, 1, k.data(), &nk, max_kp, &tp, &L) != VIDO_OK) throw std::runtime_error(vido_last_error(c));
     for (int i = 0; i < ns; i++) {                                                 // Frame.cc:72-100, 165-177
-        const cv::KeyPoint& kp = mvKeys[sidx[i]];
+        const cv::KeyPoint& kp = cand[sidx[i]];
+        if (UseSampleFea != 0 && !(scorr[2 * i] > 0 && scorr[2 * i + 1] > 0)) continue;
         mvStatKeysTmp.push_back(kp);
         mvCorres.push_back(cv::KeyPoint(scorr[2 * i], scorr[2 * i + 1], 0, 0, 0, kp.octave, -1));
         mvFlowNext.push_back(cv::Point2f(sflow[2 * i], sflow[2 * i + 1]));
         mvStatDepthTmp.push_back(sdep[i]);
     }
-    N_s_tmp = ns;
+    N_s_tmp = (int)mvStatKeysTmp.size();
     for (int i = 0; i < no; i++) {                                                 // Frame.cc:184-211
         mvObjFlowNext.push_back(cv::Point2f(oflow[2 * i], oflow[2 * i + 1]));
         mvObjCorres.push_back(cv::KeyPoint(ocorr[2 * i], ocorr[2 * i + 1], 0, 0, 0, -1));
@@ -159,6 +164,33 @@ Frame::Frame(const cv::Mat& imGray, const cv::Mat& imDepth, const cv::Mat& imFlo
         if (vido_undistort_points(in.data(), N, Kf, dist, out.data()) != VIDO_OK) throw std::runtime_error("UndistortKeyPoints failed");
         for (int i = 0; i < N; i++) { mvKeysUn[i].pt.x = out[2 * i]; mvKeysUn[i].pt.y = out[2 * i + 1]; }
     }
+}
+
+std::vector<cv::KeyPoint> Frame::SampleKeyPoints(const int& rows, const int& cols)      // Frame.cc:888-956
+{
+    const int N_samp = 3000, n_div = 20, x_step = cols / n_div, y_step = rows / n_div;
+    std::vector<std::vector<cv::KeyPoint>> grid((size_t)n_div * n_div);
+    uint64_t ctr = 0;
+    auto next = [&]() {                                      // splitmix64 of (frame id, counter): the reference's generator is cv::RNG(time(NULL))
+        uint64_t z = ((uint64_t)mnId << 32) + 0x9e3779b97f4a7c15ull * (++ctr);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); };
+    auto uniform = [&](int a, int b) { return b > a ? a + (int)(next() % (uint64_t)(b - a)) : a; };      // cv::RNG::uniform(int, int): an integer in [a, b)
+    int key_num = 0;
+    if (x_step < 1 || y_step < 1) return {};
+    while (key_num < N_samp) {
+        const int before = key_num;
+        for (int i = 0; i < n_div && key_num < N_samp; ++i)
+            for (int j = 0; j < n_div && key_num < N_samp; ++j) {
+                const float x = (float)uniform(i * x_step, (i + 1) * x_step), y = (float)uniform(j * y_step, (j + 1) * y_step);
+                if (x >= cols || y >= rows || x <= 0 || y <= 0) continue;
+                grid[(size_t)i * n_div + j].push_back(cv::KeyPoint(x, y, 0, 0, 0, -1));
+                key_num++;
+            }
+        if (key_num == before) break;                        // (degenerate image sizes: nothing can be sampled)
+    }
+    std::vector<cv::KeyPoint> out; out.reserve(key_num);
+    for (const auto& cell : grid) out.insert(out.end(), cell.begin(), cell.end());
+    return out;
 }
 
 void Frame::SetPose(cv::Mat Tcw)                          // Frame.cc SetPose / UpdatePoseMatrices
@@ -819,17 +851,18 @@ void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:29
     Frame* C = mpCurrentFrame; const int W = mImGray.cols, H = mImGray.rows;
     vido_host_maps maps; maps.mask = mSegMap.ptr<int32_t>(); maps.depth = mDepthMap.ptr<float>(); maps.flow = mFlowMap.ptr<float>(); maps.width = W; maps.height = H;
     // ---- static features (:2973-3105)
-    const int ns = (int)C->mvStatKeys.size(), nk = (int)C->mvKeys.size();
+    const std::vector<cv::KeyPoint> sample_src = nUseSampleFea == 1 ? C->mvStatKeysTmp : C->mvKeys;      // Tracking.cc:3013-3018 (a copy: mvStatKeysTmp is rewritten below)
+    const int ns = (int)C->mvStatKeys.size(), nk = (int)sample_src.size();
     std::vector<float> sxy(2 * std::max(ns, 1)), kxy(2 * std::max(nk, 1));
     for (int i = 0; i < ns; i++) { sxy[2 * i] = C->mvStatKeys[i].pt.x; sxy[2 * i + 1] = C->mvStatKeys[i].pt.y; }
-    for (int i = 0; i < nk; i++) { kxy[2 * i] = C->mvKeys[i].pt.x; kxy[2 * i + 1] = C->mvKeys[i].pt.y; }
+    for (int i = 0; i < nk; i++) { kxy[2 * i] = sample_src[i].pt.x; kxy[2 * i + 1] = sample_src[i].pt.y; }
     const int cap = (int)TM_sta.size() + nk + 8;
     std::vector<int32_t> src(cap), inl(cap); std::vector<float> fl(2 * (size_t)cap); int32_t n = 0;
     if (vido_renew_static(&maps, sxy.data(), ns, TM_sta.data(), (int)TM_sta.size(), kxy.data(), nk, nMaxTrackPointBG, src.data(), inl.data(), fl.data(), cap, &n) != VIDO_OK)
         throw std::runtime_error("RenewFrameInfo: vido_renew_static failed");
     std::vector<cv::KeyPoint> keys(n), corres(n); std::vector<cv::Point2f> flows(n); std::vector<int> inlierID(n);
     for (int k = 0; k < n; k++) {
-        keys[k] = inl[k] >= 0 ? C->mvStatKeys[src[k]] : C->mvKeys[src[k]];
+        keys[k] = inl[k] >= 0 ? C->mvStatKeys[src[k]] : sample_src[src[k]];
         flows[k] = cv::Point2f(fl[2 * k], fl[2 * k + 1]); inlierID[k] = inl[k];
         corres[k] = cv::KeyPoint(keys[k].pt.x + fl[2 * k], keys[k].pt.y + fl[2 * k + 1], 0, 0, 0, -1);
     }
