@@ -236,19 +236,31 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
             }
             con[27] = r0;
             const size_t slot = (size_t)P.obs_pos[k];
-            double* Wk = P.W + 18 * slot;
+            // 18 doubles = 144 B per slot, 16-byte aligned: nine 16-byte stores instead of eighteen 8-byte ones (the kernel is bound by the request rate of its
+            // scattered stores — 64 different cache lines per store instruction — not by bytes)
+            double wv[18];
 #pragma unroll
             for (int a = 0; a < 6; a++)
 #pragma unroll
-                for (int b = 0; b < 3; b++) Wk[a * 3 + b] = wo * (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b]);
-            double* Ck = P.Cp + 9 * slot;
+                for (int b = 0; b < 3; b++) wv[a * 3 + b] = wo * (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b]);
+            double2* Wk2 = (double2*)(P.W + 18 * slot);
+#pragma unroll
+            for (int a = 0; a < 9; a++) Wk2[a] = make_double2(wv[2 * a], wv[2 * a + 1]);
+            double cv[9];
             q = 0;
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-                Ck[6 + a] = -wo * (Jp[a] * e[0] + Jp[3 + a] * e[1] + Jp[6 + a] * e[2]);
+                cv[6 + a] = -wo * (Jp[a] * e[0] + Jp[3 + a] * e[1] + Jp[6 + a] * e[2]);
 #pragma unroll
-                for (int b = a; b < 3; b++) Ck[q++] = wo * (Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b] + Jp[6 + a] * Jp[6 + b]);
+                for (int b = a; b < 3; b++) cv[q++] = wo * (Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b] + Jp[6 + a] * Jp[6 + b]);
             }
+            // 9 doubles = 72 B per slot: 16-byte aligned for even slots, 8 off for odd ones — four 16-byte stores from the aligned address + one 8-byte store
+            double* Ck = P.Cp + 9 * slot;
+            const bool odd = (slot & 1) != 0;
+            double2* Ck2 = (double2*)(Ck + (odd ? 1 : 0));
+#pragma unroll
+            for (int a = 0; a < 4; a++) Ck2[a] = make_double2(odd ? cv[2 * a + 1] : cv[2 * a], odd ? cv[2 * a + 2] : cv[2 * a + 1]);
+            Ck[odd ? 0 : 8] = odd ? cv[0] : cv[8];
         }
         // fold the group into the register sums, one camera at a time (cameras are non-decreasing along the lanes)
         unsigned long long rem = j < E ? __ballot(act) : 1ull;
