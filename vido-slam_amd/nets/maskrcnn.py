@@ -345,8 +345,8 @@ class _BoxHead(nn.Module):
         keep = keep[torch.sort(j[keep] * prob.shape[0] + i[keep], stable=True)[1]]
         rb, rs, rl = bx[keep], sc[keep], j[keep]
         if len(rs) > c.detections_per_img > 0:
-            thresh, _ = torch.kthvalue(rs.cpu(), len(rs) - c.detections_per_img + 1)
-            keep = torch.nonzero(rs >= thresh.item()).squeeze(1)
+            thresh, _ = torch.kthvalue(rs if rs.is_cuda else rs.cpu(), len(rs) - c.detections_per_img + 1)      # on the device: no D2H copy + .item() round trips before the nonzero
+            keep = torch.nonzero(rs >= thresh.to(rs.device)).squeeze(1)
             rb, rs, rl = rb[keep], rs[keep], rl[keep]
         return rb, rs, rl
 
