@@ -481,6 +481,154 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 512) void k_ba_schur(BaDev P, in
         }
     }
 }
+// MODE 2 on the FP64 matrix cores (round 2).  The wave-per-landmark kernel above spends ~800 VALU instructions per landmark on pair index arithmetic, 36 address
+// computations and 36 LDS atomics per camera pair (0.5 ms per 100 k landmarks: 39 % of a global LM iteration).  Here a landmark contributes three ROWS of a
+// matrix M instead: with Hpp + lambda I = R^T R (3x3 Cholesky) the rows are A_l = [W_s R^-1 for the landmark's slots s, placed in the columns of camera s | R^-T b], and
+//     S_window -= M^T M   (camera columns),   r_window -= M^T M[:, rhs column]
+// i.e. sum_l (W_i Di W_j^T) = sum_l (W_i R^-1)(W_j R^-1)^T — a dense rank-3L update of the BA_WC-camera window: v_mfma_f64_16x16x4 over 16x16 tiles of the lower
+// triangle (+ one tile row for the rhs), SM_L landmarks (96 rows of M in LDS) per pass, the tiles accumulated in registers across the BA_CHUNK landmarks that share a
+// window and flushed once with FP64 atomics like before.  Landmarks that do not fit their chunk's window (or have more than 64 observations) are listed by the host for
+// k_ba_schur_long and skipped here (their slot count is stored negated).
+#ifndef SM_L
+#define SM_L 32             // landmarks per pass: 96 rows of M = 76.8 KB of LDS, two workgroups per CU
+#endif
+#define SM_NL (SM_L / 16)   // landmarks per wave and pass
+// M is stored in the matrix cores' operand order: element (row, col) of the 3 SM_L x 96 matrix lives at [(row / 4) * 6 + col / 16][row % 4][col % 16], so the 64 lanes of
+// a wave read ONE contiguous 512-byte run per operand (a row-major M with the 4 k-rows of an operand 98 doubles apart ran into 4-way bank conflicts on every read:
+// 17 of the ~35 us of a pass).  The rhs column is kept apart (G): its tile row needs only row 0 of the A operand.
+#define SM_IDX(row, col) (((((row) >> 2) * 6 + ((col) >> 4)) << 6) + (((row) & 3) << 4) + ((col) & 15))
+#define SM_M_DOUBLES (3 * SM_L * 96)
+#define SM_LDS_BYTES ((SM_M_DOUBLES + 3 * SM_L + 9 * SM_L + 96) * sizeof(double))
+__global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, double lambda, const int* __restrict__ chunk_cmin, const int* __restrict__ lorder, const int2* __restrict__ lbc)
+{
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    extern __shared__ double M[];                               // [3 SM_L / 4][6][4][16] | G [3 SM_L] | Hs [SM_L][9]
+    double* G = M + SM_M_DOUBLES; double* Hs = G + 3 * SM_L; double* Rs = Hs + 9 * SM_L;      // Rs [96]: the window's rhs, summed over the thread parts at the flush
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int n_units = (n_ptl + BA_CHUNK - 1) / BA_CHUNK;
+    // tiles of this wave: the 21 lower-triangle tiles of the 6 x 6 camera tile grid (the rhs M^T G is a matrix-vector product: vector ALUs, thread = (column, row part))
+    const int rcol = threadIdx.x % 96, rpart = threadIdx.x / 96;      // 10 row parts (threads 960..1023 idle in that step)
+    int tI[2], tJ[2]; bool tv[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int t = wave + 16 * u; tv[u] = t < 21;
+        int I = 0; while ((I + 1) * (I + 2) / 2 <= t && I < 5) I++;
+        tI[u] = t < 21 ? I : 6; tJ[u] = t < 21 ? t - I * (I + 1) / 2 : t - 21;
+    }
+    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const int cbase = chunk_cmin[unit];
+        d4 acc[2]; double racc = 0.0;
+#pragma unroll
+        for (int u = 0; u < 2; u++) acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int sub = 0; sub < BA_CHUNK / SM_L; sub++) {
+            const int q0 = unit * BA_CHUNK + sub * SM_L;
+            if (q0 >= n_ptl) break;
+            // a landmark is a chain of dependent HBM round trips (slot range -> slot data): the wave's SM_NL landmarks of this pass go through each stage TOGETHER, and
+            // everything that depends on the slot range (Cp, the W rows, the slots' camera ordinals) is requested in one round trip
+            int lm[SM_NL], beg[SM_NL], cnt[SM_NL], wcol[SM_NL]; double cp[SM_NL][9], wv[SM_NL][3];
+#pragma unroll
+            for (int n = 0; n < SM_NL; n++) {
+                const int q = q0 + wave + 16 * n;
+                lm[n] = q < n_ptl ? lorder[q] : 0; const int2 bc = q < n_ptl ? lbc[q] : make_int2(0, -1);
+                beg[n] = bc.x; cnt[n] = bc.y;                    // cnt < 0: out of window / long track (k_ba_schur_long) or past the end
+            }
+#pragma unroll
+            for (int n = 0; n < SM_NL; n++) {
+#pragma unroll
+                for (int a = 0; a < 9; a++) cp[n][a] = lane < cnt[n] ? P.Cp[9 * (size_t)(beg[n] + lane) + a] : 0.0;
+                // the W rows of the first 64 (slot, component) pairs — all of them for tracks of up to 10 observations
+                const bool on = lane < cnt[n] * 6; const int sl = lane / 6, a = lane - sl * 6;
+                wcol[n] = on ? 6 * (P.slot_ord[beg[n] + sl] - cbase) + a : 0;
+                const double* w = P.W + 18 * (size_t)(beg[n] + (on ? sl : 0)) + 3 * a;
+                wv[n][0] = on ? w[0] : 0.0; wv[n][1] = on ? w[1] : 0.0; wv[n][2] = on ? w[2] : 0.0;
+            }
+            for (int t = threadIdx.x; t < SM_M_DOUBLES + 3 * SM_L + 9 * SM_L + 96; t += 1024) M[t] = 0.0;
+            __syncthreads();
+            // the landmarks' point-side sums, reduced with LDS atomics (a shuffle tree is 108 ds_bpermute per landmark: that alone saturated the CU's LDS pipe)
+#pragma unroll
+            for (int n = 0; n < SM_NL; n++) {
+                if (lane < cnt[n]) {
+#pragma unroll
+                    for (int a = 0; a < 9; a++) atomicAdd(Hs + 9 * (wave + 16 * n) + a, cp[n][a]);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();      // the wave reads back only its own landmarks' sums
+#pragma unroll
+            for (int n = 0; n < SM_NL; n++) {
+                if (cnt[n] < 0) continue;                       // wave-uniform
+                double H6[9];
+#pragma unroll
+                for (int a = 0; a < 9; a++) H6[a] = Hs[9 * (wave + 16 * n) + a];
+                if (lane == 0) {
+#pragma unroll
+                    for (int a = 0; a < 6; a++) P.Hpp[6 * (size_t)lm[n] + a] = H6[a];
+#pragma unroll
+                    for (int a = 0; a < 3; a++) P.bp[3 * (size_t)lm[n] + a] = H6[6 + a];
+                }
+                // Hpp + lambda I = R^T R, R upper triangular; X = R^-1 (reciprocal square roots: v_rsq_f64 + two Newton steps instead of the sqrt and division expansions)
+                auto rsq = [](double x) { double y = __builtin_amdgcn_rsq(x); y = y * (1.5 - 0.5 * x * y * y); return y * (1.5 - 0.5 * x * y * y); };
+                const double a00 = H6[0] + lambda, a01 = H6[1], a02 = H6[2], a11 = H6[3] + lambda, a12 = H6[4], a22 = H6[5] + lambda;
+                const double i00 = rsq(a00), r01 = a01 * i00, r02 = a02 * i00;
+                const double i11 = rsq(a11 - r01 * r01), r12 = (a12 - r01 * r02) * i11;
+                const double i22 = rsq(a22 - r02 * r02 - r12 * r12);
+                const double x01 = -r01 * i11 * i00, x12 = -r12 * i22 * i11, x02 = -(r01 * x12 + r02 * i22) * i00;
+                const int row0 = 3 * (wave + 16 * n);
+                if (lane < cnt[n] * 6) {
+                    const double w0 = wv[n][0], w1 = wv[n][1], w2 = wv[n][2]; const int col = wcol[n];
+                    M[SM_IDX(row0, col)] = w0 * i00; M[SM_IDX(row0 + 1, col)] = w0 * x01 + w1 * i11; M[SM_IDX(row0 + 2, col)] = w0 * x02 + w1 * x12 + w2 * i22;
+                }
+                for (int t = lane + 64; t < cnt[n] * 6; t += 64) {          // tracks longer than 10 observations
+                    const int sl = t / 6, a = t - sl * 6, col = 6 * (P.slot_ord[beg[n] + sl] - cbase) + a;
+                    const double* w = P.W + 18 * (size_t)(beg[n] + sl) + 3 * a;
+                    const double w0 = w[0], w1 = w[1], w2 = w[2];
+                    M[SM_IDX(row0, col)] = w0 * i00; M[SM_IDX(row0 + 1, col)] = w0 * x01 + w1 * i11; M[SM_IDX(row0 + 2, col)] = w0 * x02 + w1 * x12 + w2 * i22;
+                }
+                if (lane == 0) { const double b0 = H6[6], b1 = H6[7], b2 = H6[8]; G[row0] = i00 * b0; G[row0 + 1] = x01 * b0 + i11 * b1; G[row0 + 2] = x02 * b0 + x12 * b1 + i22 * b2; }
+                __builtin_amdgcn_sched_barrier(0);             // one landmark's arithmetic at a time: interleaved, the two exceed the 128-VGPR budget of a 1024-thread workgroup (101 spills)
+            }
+            __syncthreads();
+#ifndef SM_NOMFMA
+#pragma unroll
+            for (int u = 0; u < 2; u++) if (tv[u]) {
+                const double* pb = M + 64 * tJ[u] + lane;
+                const double* pa = M + 64 * tI[u] + lane;
+#pragma unroll 8
+                for (int ks = 0; ks < 3 * SM_L / 4; ks++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[384 * ks], pb[384 * ks], acc[u], 0, 0, 0);
+            }
+            if (rpart < 10) {
+#pragma unroll 4
+                for (int k = rpart; k < 3 * SM_L; k += 10) racc = __builtin_fma(G[k], M[SM_IDX(k, rcol)], racc);
+            }
+#endif
+            __syncthreads();
+        }
+        // flush the window: S -= C on the lower block triangle (diagonal camera blocks in full), r -= C[rhs row]
+#pragma unroll
+        for (int u = 0; u < 2; u++) if (tv[u]) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int row = 16 * tI[u] + lk + 4 * v, col = 16 * tJ[u] + lr;
+                const double val = -acc[u][v];
+#ifdef SM_NOFLUSH
+                if (val != 123.456) continue;
+#endif
+                if (val == 0.0 || col >= 96) continue;
+                const int cj = col / 6;
+                if (cbase + cj >= P.n_cam_ord) continue;
+                const int ci = row / 6;
+                if (row >= 96 || ci < cj || cbase + ci >= P.n_cam_ord) continue;
+                const int gr = 6 * P.ord_pose[cbase + ci] + row % 6, gc = 6 * P.ord_pose[cbase + cj] + col % 6;
+                double* e = s_entry(P, gr, gc); if (e) atomicAdd(e, val);
+                if (ci == cj && tI[u] != tJ[u]) { double* e2 = s_entry(P, gc, gr); if (e2) atomicAdd(e2, val); }      // a diagonal camera block that straddles two tiles: its upper part lives in the tile that is not computed
+            }
+        }
+        if (rpart < 10 && racc != 0.0) atomicAdd(Rs + rcol, racc);      // (Rs was zeroed with M by the last pass; nothing touched it since)
+        __syncthreads();
+        if (threadIdx.x < 96) { const double v = -Rs[threadIdx.x]; const int cj = threadIdx.x / 6; if (v != 0.0 && cbase + cj < P.n_cam_ord) atomicAdd(P.r + 6 * P.ord_pose[cbase + cj] + threadIdx.x % 6, v); }
+        __syncthreads();
+    }
+}
+
 // Landmarks with more than 64 observations (a static point watched for more than 64 keyframes: a vehicle waiting at a junction; FullBatchOptimization has no
 // track-length limit, Optimizer.cc:1235ff): one 256-thread workgroup per landmark, slots streamed from HBM instead of being parked in a wave's LDS stage, every
 // contribution an FP64 atomic on S / r.  O(k^2) blocks per landmark like the fast path; rare, so simple.  k_ba_schur skips these landmarks.
@@ -2359,7 +2507,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
       int o = 0; for (int q = 0; q < n_pose; q++) if (inv[q] >= 0) { pose_ord_h[q] = o; ord_pose_h[o] = q; o++; } }
     D.n_cam_ord = p.n_cam; D.pose_ord = A.put(pose_ord_h.data(), n_pose, st); D.ord_pose = A.put(ord_pose_h.data(), p.n_cam, st);
     { std::vector<int> so(no); for (int t = 0; t < no; t++) so[t] = pose_ord_h[slotcam[t]]; D.slot_ord = A.put(so.data(), no, st); }
-    int* d_chunk_cmin = nullptr; int* d_lorder = nullptr; int2* d_lbc = nullptr; int n_chunks = (n_ptl + BA_CHUNK - 1) / BA_CHUNK;
+    int* d_chunk_cmin = nullptr; int* d_lorder = nullptr; int2* d_lbc = nullptr; int n_chunks = (n_ptl + BA_CHUNK - 1) / BA_CHUNK; bool use_mfma_schur = false;
     if (!lds_path && n_ptl) {
         std::vector<int> lorder(n_ptl);
         auto first_cam = [&](int l) { return pstart[l + 1] > pstart[l] ? slotcam[pstart[l]] : n_pose; };
@@ -2372,7 +2520,18 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         std::vector<int> cmin(n_chunks, 0);
         for (int c = 0; c < n_chunks; c++) { const int m = first_cam(lorder[c * BA_CHUNK]); cmin[c] = m == n_pose ? 0 : pose_ord_h[m]; }
         d_chunk_cmin = A.put(cmin.data(), n_chunks, st); d_lorder = A.put(lorder.data(), n_ptl, st);
+        use_mfma_schur = nd == 0 && !getenv("VIDO_BA_SCHUR_OLD");      // (the dynamic-object graphs keep the wave-per-landmark kernel: their pose order interleaves object motions)
         { std::vector<int> bc(2 * (size_t)n_ptl); for (int q = 0; q < n_ptl; q++) { const int l = lorder[q]; bc[2 * (size_t)q] = pstart[l]; bc[2 * (size_t)q + 1] = pstart[l + 1] - pstart[l]; }
+          if (use_mfma_schur) {      // k_ba_schur_mfma takes the landmarks whose cameras all fall inside their chunk's window; the others (and tracks > 64) go to k_ba_schur_long
+              std::vector<char> is_long(n_ptl, 0); for (int l : long_list) is_long[l] = 1;
+              for (int q = 0; q < n_ptl; q++) {
+                  const int l = lorder[q], cnt = pstart[l + 1] - pstart[l]; if (!cnt) continue;
+                  const int cb = cmin[q / BA_CHUNK], lo = pose_ord_h[slotcam[pstart[l]]], hi = pose_ord_h[slotcam[pstart[l + 1] - 1]];
+                  bool out = cnt > 64 || lo < cb || hi >= cb + BA_WC || lo < 0 || hi < 0;
+                  for (int t2 = pstart[l]; t2 < pstart[l + 1] && !out; t2++) { const int o = pose_ord_h[slotcam[t2]]; out = o < cb || o >= cb + BA_WC; }
+                  if (out) { bc[2 * (size_t)q + 1] = -cnt; if (!is_long[l]) { long_list.push_back(l); is_long[l] = 1; } }
+              }
+          }
           d_lbc = (int2*)A.put(bc.data(), 2 * (size_t)n_ptl, st); }
         if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device pool exhausted");
     }
@@ -2387,7 +2546,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     if (lds_path) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
                     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol));
                     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol6)); }
-    else { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur)); }
+    else { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
+           HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM_LDS_BYTES)); }
 
     const int lin_E = 1;     // groups of 64 observations per wave in k_ba_linearize: with the LDS camera accumulators one group is fastest at every size measured (35 k .. 1 M edges)
     auto AR = [&](double* dptr, size_t cnt, int op) -> int {
@@ -2456,7 +2616,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
                 if (lds_path) {
                     hipLaunchKernelGGL(k_ba_schur<0>, dim3(schur_grid), dim3(64 * schur0_waves), lds_schur, st, D, n_ptl, lambda, kcap, BS->d_parts, (const int*)nullptr, (const int*)nullptr, (const int2*)nullptr);
                     hipLaunchKernelGGL(k_ba_fold_parts, dim3(std::min(256, (int)((loc_sz + 255) / 256)), std::min(8, schur_grid)), dim3(256), 0, st, D, BS->d_parts, schur_grid);
-                } else hipLaunchKernelGGL(k_ba_schur<2>, dim3(std::min(n_chunks, 1024)), dim3(64 * schur2_waves), lds_schur, st, D, n_ptl, lambda, kcap, (double*)nullptr, (const int*)d_chunk_cmin, (const int*)d_lorder, (const int2*)d_lbc);
+                } else if (use_mfma_schur) hipLaunchKernelGGL(k_ba_schur_mfma, dim3(std::min(n_chunks, 1024)), dim3(1024), SM_LDS_BYTES, st, D, n_ptl, lambda, (const int*)d_chunk_cmin, (const int*)d_lorder, (const int2*)d_lbc);
+                else hipLaunchKernelGGL(k_ba_schur<2>, dim3(std::min(n_chunks, 1024)), dim3(64 * schur2_waves), lds_schur, st, D, n_ptl, lambda, kcap, (double*)nullptr, (const int*)d_chunk_cmin, (const int*)d_lorder, (const int2*)d_lbc);
             }
             if (n_long) hipLaunchKernelGGL(k_ba_schur_long, dim3(n_long), dim3(256), 0, st, D, lambda, (const int*)d_long);
             if (nd) {
