@@ -2483,11 +2483,14 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     D.Hcd = red; D.bc = red + (size_t)n_pose * 36; D.scal = D.bc + n6;
     Bc.ok = D.scal + 4;
     if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device allocation failed (n6=%d, n_obs=%d)", n6, no);
-    const int schur_grid = lds_path ? std::min(256, std::max(1, (n_ptl + 3) / 4)) : std::min(4096, std::max(1, (n_ptl + 3) / 4));
+#ifndef BA_SCHUR0_GRID
+#define BA_SCHUR0_GRID 256
+#endif
+    const int schur_grid = lds_path ? std::min(BA_SCHUR0_GRID, std::max(1, (n_ptl + 3) / 4)) : std::min(4096, std::max(1, (n_ptl + 3) / 4));
     const size_t sz_sr = sz_S + n6;
     if (lds_path && (size_t)schur_grid * sz_sr > BS->parts_cap) {
         HIP_TRY(ctx, hipStreamSynchronize(st)); if (BS->d_parts) hipFree(BS->d_parts);
-        BS->parts_cap = (size_t)256 * sz_sr; HIP_TRY(ctx, hipMalloc((void**)&BS->d_parts, BS->parts_cap * sizeof(double)));
+        BS->parts_cap = (size_t)BA_SCHUR0_GRID * sz_sr; HIP_TRY(ctx, hipMalloc((void**)&BS->d_parts, BS->parts_cap * sizeof(double)));
     }
     const int kcap = std::max(maxk, 1);
     const size_t lds_chol = ((size_t)(n6 + 1) * ((n6 + 1) | 1) + n6 + 2) * sizeof(double);
