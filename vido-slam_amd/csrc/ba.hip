@@ -1682,7 +1682,14 @@ __global__ __launch_bounds__(256) void k_bcr_pack(BcrDev B)
 // the multiplier column — one barrier, every thread takes col[i] -= U_ki (col[k] / U_kk) for i > k with broadcast b128 LDS reads.  The rows of U stay in LDS, and the back
 // substitution x_k = (y_k - sum_{j>k} U_kj x_j) / U_kk needs no barrier at all (every right-hand side is a thread).  M steps of ~0.1 us instead of 3M of 0.45 us.
 // D is SPD (Schur complements of an SPD matrix), so elimination without pivoting is backward stable, like the Cholesky it replaces.
-template <int M> struct BcrGeom { static constexpr int NT = ((3 * M + 1 + 63) / 64) * 64; static constexpr size_t LDS = ((size_t)M * M + M + NT) * sizeof(double); };
+// The 3M + 1 columns of an elimination are split over TWO workgroups (blockIdx.y): the first takes D and as many right-hand sides as fill whole waves (M = 66: 192 of the
+// 199 columns), the second D again and the rest (7).  One workgroup of four waves spent a quarter of its LDS broadcast reads — what bounds the kernel — on a wave with 7 live lanes.
+template <int M> struct BcrGeom {
+    static constexpr int R0 = ((3 * M + 1) / 64) * 64 - M;                          // right-hand sides (of the 2M + 1: GL columns, GR columns, b) of workgroup 0
+    static constexpr int NT = M + R0;                                               // a multiple of 64; workgroup 1 has M + (2M + 1 - R0) <= NT live threads
+    static constexpr size_t LDS = ((size_t)M * M + M + NT) * sizeof(double);
+    static_assert(R0 > 0 && 2 * M + 1 - R0 <= R0, "column split");
+};
 // compile-time loops: the step index must be a constant in every register index of col[] (a run-time index would send the array to scratch memory)
 template <typename F, int... Ks> __device__ __forceinline__ void bcr_static_for_impl(F& f, std::integer_sequence<int, Ks...>) { (f(std::integral_constant<int, Ks>{}), ...); }
 template <int N, typename F> __device__ __forceinline__ void bcr_static_for(F&& f) { bcr_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
@@ -1710,17 +1717,18 @@ template <int M> __global__ __launch_bounds__(BcrGeom<M>::NT) void k_bcr_elim(Bc
     double* dinv = bcr_lds + M * M;       // [M]
     const int c = threadIdx.x;
     const int p = mode ? 0 : s + 2 * s * blockIdx.x;
-    const int ncol = mode ? M + 1 : 3 * M + 1;
-    const bool has_r = !mode && p + s < B.nb, live = c < ncol;
+    // right-hand side index ri of this thread in [GL columns 0..M-1 | GR columns M..2M-1 | b = 2M]: workgroup (blockIdx.y) 0 takes [0, R0), workgroup 1 the rest; mode 1: b only
+    const int r_lo = mode ? 2 * M : (blockIdx.y ? BcrGeom<M>::R0 : 0), r_hi = mode ? 2 * M + 1 : (blockIdx.y ? 2 * M + 1 : BcrGeom<M>::R0);
+    const int ri = r_lo + (c - M);
+    const bool has_r = !mode && p + s < B.nb, is_d = c < M, live = is_d || ri < r_hi, is_b = !is_d && ri == 2 * M;
     const double* Dp = B.D + (size_t)p * M * M;
     const double* Lp = Lcur + (size_t)p * M * M; const double* Lq = Lcur + (size_t)(p + s) * M * M;
-    const bool is_d = c < M, is_b = mode ? c == M : c == 3 * M;
     double col[M];
     {
-        const double* src = Dp + c; size_t stride = M;                             // D column c / L_p column c - M: coalesced over the lanes
+        const double* src = Dp + c; size_t stride = M;                             // D column c / L_p column: coalesced over the lanes
         bool ld = live;
-        if (!mode && c >= M && c < 2 * M) src = Lp + (c - M);
-        else if (!mode && c >= 2 * M && c < 3 * M) { src = Lq + (size_t)(c - 2 * M) * M; stride = 1; ld = has_r; }      // column of L_{p+s}^T = row of L_{p+s}
+        if (!is_d && ri < M) src = Lp + ri;
+        else if (!is_d && ri < 2 * M) { src = Lq + (size_t)(ri - M) * M; stride = 1; ld = live && has_r; }      // column of L_{p+s}^T = row of L_{p+s}
         else if (is_b) { src = B.b + (size_t)p * M; stride = 1; }
         bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; col[i] = ld ? src[(size_t)i * stride] : 0.0; });
     }
@@ -1766,7 +1774,7 @@ template <int M> __global__ __launch_bounds__(BcrGeom<M>::NT) void k_bcr_elim(Bc
     } else if (is_b) {
         bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; B.y[(size_t)p * M + i] = col[i]; });
     } else {
-        double* dst = (c < 2 * M ? B.GL + (c - M) : B.GR + (c - 2 * M)) + (size_t)p * M * M;
+        double* dst = (ri < M ? B.GL + ri : B.GR + (ri - M)) + (size_t)p * M * M;
         bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; dst[(size_t)i * M] = col[i]; });
     }
 }
@@ -2636,8 +2644,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             else if (Bc.m) {                                   // block cyclic reduction: 2 launches per level, log2(nb) levels, then the levels back
                 const int m = Bc.m, nb = Bc.nb;
                 auto elim = [&](int n_blocks, int sft, const double* Lc, int mode) {
-                    if (m == 66) hipLaunchKernelGGL(k_bcr_elim<66>, dim3(n_blocks), dim3(BcrGeom<66>::NT), BcrGeom<66>::LDS, st, Bc, sft, Lc, mode);
-                    else         hipLaunchKernelGGL(k_bcr_elim<96>, dim3(n_blocks), dim3(BcrGeom<96>::NT), BcrGeom<96>::LDS, st, Bc, sft, Lc, mode);
+                    if (m == 66) hipLaunchKernelGGL(k_bcr_elim<66>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom<66>::NT), BcrGeom<66>::LDS, st, Bc, sft, Lc, mode);
+                    else         hipLaunchKernelGGL(k_bcr_elim<96>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom<96>::NT), BcrGeom<96>::LDS, st, Bc, sft, Lc, mode);
                 };
                 hipLaunchKernelGGL(k_bcr_pack, dim3(nb), dim3(256), 0, st, Bc);
                 double *Lc = Bc.L0, *Ln = Bc.L1; int smax = 0;
