@@ -70,7 +70,9 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (optimisers / BA / matcher)")
-    ap.add_argument("--rccl-direct", action="store_true", help="global BA at N > 1: the library's own ncclAllReduce on its stream (csrc/rccl.cpp) instead of the torch.distributed hook; tested at world 1 only by the builder")
+    ap.add_argument("--torch-allreduce", action="store_true", help="global BA at N > 1: all-reduce through the torch.distributed hook (two stream synchronisations + a Python call each) instead of "
+                                                                   "the default, the library's own ncclAllReduce on its stream (csrc/rccl.cpp)")
+    ap.add_argument("--rccl-direct", action="store_true", help="(default since round 3; kept for old command lines)")
     ap.add_argument("--saturated-detector", action="store_true", help="keep the plain random fill of the detector: every class score saturates to 1.0, the ties defeat the detections_per_img cap and the mask head sees 200-300 detections per frame")
     ap.add_argument("--gba-cams", type=int, default=500)
     ap.add_argument("--gba-points", type=int, default=100000)
@@ -81,8 +83,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: spawn the N ranks the driver's launcher would (one process per GPU, RCCL over xGMI) and pass their line through
+        import socket, subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     if args.gpus > 1 and world != args.gpus:
-        print("bench.py: --gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world), file=sys.stderr)
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
@@ -351,7 +361,8 @@ def main():
           gpr = P.synth_ba_problem(n_cam=args.gba_cams, n_pt=args.gba_points, kind="global", track_len=10, seed=11)
           gpr["max_iters"] = 5
           shards = V.landmark_shards(gpr["obs_pt"], gpr["n_pt"], world)
-          hook = (V.rccl_direct_init(ctx, rank, world) if args.rccl_direct else V.torch_allreduce_hook()) if world > 1 else None
+          rccl_direct = not args.torch_allreduce
+          hook = (V.rccl_direct_init(ctx, rank, world) if rccl_direct else V.torch_allreduce_hook()) if world > 1 else None
           sync_all()
           t1 = time.perf_counter()
           r = V.ba_optimize(ctx, gpr, rank=rank, world=world, shard=shards[rank] if world > 1 else None, allreduce=hook)
@@ -365,10 +376,14 @@ def main():
                                 "lm_iterations": r["iterations"], "lm_trials": r["lm_trials"], "ms_lm_loop": round(r["ms_solve_loop"], 2),
                                 "ms_setup": round(r["ms_setup"], 2), "lm_iters_per_s": round(r["iterations"] / (r["ms_solve_loop"] * 1e-3), 2),
                                 "chi2": [round(r["chi2_initial"], 3), round(r["chi2_final"], 3)], "wall_ms": round(d * 1e3, 1), "wall_ms_first_call": round(d_cold * 1e3, 1),
-                                "collective": ("RCCL all-reduce (sum) of the reduced camera system per LM trial, " + ("issued by the library on its stream" if args.rccl_direct else "through the torch.distributed hook")) if world > 1 else "none",
+                                "collective": ("RCCL all-reduce (sum) of the reduced camera system per LM trial, " + ("issued by the library on its stream" if rccl_direct else "through the torch.distributed hook")) if world > 1 else "none",
                                 "scaling_curve": "no 8-GPU scaling curve measured by the builder (single-GPU boxes); the driver's SCALE record is the measurement"}
           if "ms_phases" in r:
               extra["global_ba"]["ms_phases_per_trial"] = r["ms_phases"]
+          # the second half of BASELINE's metric ("BA iters/sec"), first-class: configs[4] sharded over the N ranks (landmark ranges, one all-reduce of the reduced camera
+          # system per LM trial).  `wall` counts the whole call as a user sees it (host set-up + upload + LM loop + download), `lm_loop` the device loop only.
+          out["global_ba_iters_per_s"] = {"wall": round(r["iterations"] / d, 2), "lm_loop": round(r["iterations"] / (r["ms_solve_loop"] * 1e-3), 2), "n_gpus": world,
+                                          "workload": "configs[4]: %d KF x %d landmarks, %d observations, strong scaling over the ranks" % (args.gba_cams, int(gpr["n_pt"]), len(gpr["obs_cam"]))}
           if world == 1:
               rb = ba_roofline(r, len(gpr["obs_cam"]), "configs[4] size on one GPU: %d KF x %d landmarks, %d edges" % (args.gba_cams, int(gpr["n_pt"]), len(gpr["obs_cam"])), "pmc_traffic_ba_global.json")
               if rb:

@@ -68,6 +68,19 @@ static void edge_tern(const double* H, const double* pp, const double* pc, doubl
 
 typedef struct { int nv; int off[3]; int dim[3]; int ne; double e[6]; double J[3][36]; double info, delta; int robust; } factor_t;
 
+/* Sparse form of the same system (vo_badyn_optimize_sparse): while `coo.on` is set, add_factor appends (row, col, value) triplets of the factor's Hessian blocks
+ * instead of adding into a dense matrix (duplicates are summed by the solver, like g2o's block matrix feeding CSparse, core/block_solver.hpp:104-176 +
+ * solvers/linear_solver_csparse.h).  Single-threaded test code: one static sink. */
+static struct { int on; size_t n, cap; int32_t* r; int32_t* c; double* v; } coo;
+static void coo_push(int r, int c, double v)
+{
+    if (coo.n == coo.cap) {
+        coo.cap = coo.cap ? coo.cap * 2 : (1u << 20);
+        coo.r = (int32_t*)realloc(coo.r, sizeof(int32_t) * coo.cap); coo.c = (int32_t*)realloc(coo.c, sizeof(int32_t) * coo.cap); coo.v = (double*)realloc(coo.v, sizeof(double) * coo.cap);
+    }
+    coo.r[coo.n] = r; coo.c[coo.n] = c; coo.v[coo.n] = v; coo.n++;
+}
+
 /* accumulate one factor into the dense system; returns its robust chi2 */
 static double add_factor(const factor_t* f, int use_huber, double* Hm, double* b, int N)
 {
@@ -82,7 +95,8 @@ static double add_factor(const factor_t* f, int use_huber, double* Hm, double* b
             b[f->off[A] + a] -= wo * s;
             for (int B = 0; B < f->nv; B++) for (int c = 0; c < f->dim[B]; c++) {
                 double h = 0; for (int r = 0; r < f->ne; r++) h += f->J[A][r * f->dim[A] + a] * f->J[B][r * f->dim[B] + c];
-                Hm[(size_t)(f->off[A] + a) * N + f->off[B] + c] += wo * h;
+                if (coo.on) coo_push(f->off[A] + a, f->off[B] + c, wo * h);
+                else Hm[(size_t)(f->off[A] + a) * N + f->off[B] + c] += wo * h;
             }
         }
     }
@@ -94,7 +108,8 @@ static double build(const vo_ba_problem* p, const vo_ba_dynamic* d, double* Hm, 
 {
     const int oP = 0, oS = 6 * (p->n_cam + d->n_H), oD = oS + 3 * p->n_pt;
     double chi = 0; factor_t f;
-    if (Hm) { memset(Hm, 0, sizeof(double) * (size_t)N * N); memset(b, 0, sizeof(double) * N); }
+    if (Hm && coo.on) { coo.n = 0; memset(b, 0, sizeof(double) * N); }
+    else if (Hm) { memset(Hm, 0, sizeof(double) * (size_t)N * N); memset(b, 0, sizeof(double) * N); }
     for (int k = 0; k < p->n_obs; k++) {
         const int c = p->obs_cam[k], l = p->obs_pt[k];
         f.nv = 2; f.off[0] = oP + 6 * c; f.dim[0] = 6; f.off[1] = oS + 3 * l; f.dim[1] = 3; f.ne = 3; f.info = p->info_obs; f.delta = p->huber_obs; f.robust = 1;
@@ -198,6 +213,65 @@ int vo_badyn_optimize(vo_ba_problem* p, vo_ba_dynamic* d, vo_ba_result* res)
     }
     res->iterations = it; res->lm_trials = trials; res->lambda_final = lambda;
     free(Hm); free(A); free(b); free(x); free(save);
+    return 0;
+}
+
+/* The same LM loop over the SPARSE un-eliminated system, for graphs the dense form cannot hold (configs[3](b): 20 keyframes x 2 000 landmarks + 5 objects x 100 points
+ * = 36 690 unknowns).  The linear solve is delegated to `solve` (oracle/pyoracle.py hands in scipy's SuperLU: a sparse direct factorisation of the whole (H + lambda I),
+ * which is what the reference does with CSparse, Optimizer.cc:1318-1324) — again a different algorithm from the product's Schur / chain elimination.
+ * solve(N, nnz, rows, cols, vals, lambda, b, x) returns 1 on success.  LM policy identical to vo_badyn_optimize above. */
+typedef int (*vo_sparse_solve_fn)(int32_t N, int64_t nnz, const int32_t* rows, const int32_t* cols, const double* vals, double lambda, const double* b, double* x);
+
+int vo_badyn_optimize_sparse(vo_ba_problem* p, vo_ba_dynamic* d, vo_ba_result* res, vo_sparse_solve_fn solve)
+{
+    const int N = 6 * (p->n_cam + d->n_H) + 3 * (p->n_pt + d->n_dyn);
+    double* b = (double*)malloc(sizeof(double) * N); double* x = (double*)calloc(N, sizeof(double));
+    const size_t nc = 12 * (size_t)p->n_cam, nh = 12 * (size_t)d->n_H, np = 3 * (size_t)p->n_pt, nd = 3 * (size_t)d->n_dyn;
+    double* save = (double*)malloc(sizeof(double) * (nc + nh + np + nd + 1));
+    double lambda = -1, ni = 2, lastChi = 0, chi2_check = 0; int nBad = 0, trials = 0, it;
+    double dummy = 0;
+    res->chi2_initial = build(p, d, NULL, NULL, 0);
+    res->chi2_final = res->chi2_initial;
+    for (it = 0; it < p->max_iters; it++) {
+        coo.on = 1; double currentChi = build(p, d, &dummy, b, N); coo.on = 0; const double iniChi = currentChi;
+        if (it == 0) {
+            double* dg = (double*)calloc(N, sizeof(double)); double md = 0;
+            for (size_t k = 0; k < coo.n; k++) if (coo.r[k] == coo.c[k]) dg[coo.r[k]] += coo.v[k];
+            for (int a = 0; a < N; a++) md = fmax(md, fabs(dg[a]));
+            free(dg); lambda = 1e-5 * md; ni = 2; nBad = 0;
+        }
+        double rho = 0; int qmax = 0;
+        do {
+            memcpy(save, p->cam_T, 8 * nc); memcpy(save + nc, d->H_T, 8 * nh); memcpy(save + nc + nh, p->pt_xyz, 8 * np); memcpy(save + nc + nh + np, d->dyn_xyz, 8 * nd);
+            const int ok2 = solve(N, (int64_t)coo.n, coo.r, coo.c, coo.v, lambda, b, x);
+            double scale = 0, tempChi = DBL_MAX;
+            if (ok2) {
+                apply(p, d, x);
+                for (int a = 0; a < N; a++) scale += x[a] * (lambda * x[a] + b[a]);
+                tempChi = build(p, d, NULL, NULL, 0);
+            }
+            rho = (currentChi - tempChi) / (scale + 1e-3);
+            if (rho > 0 && isfinite(tempChi)) {
+                double alpha = 1. - pow((2 * rho - 1), 3); alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
+            } else {
+                lambda *= ni; ni *= 2;
+                memcpy(p->cam_T, save, 8 * nc); memcpy(d->H_T, save + nc, 8 * nh); memcpy(p->pt_xyz, save + nc + nh, 8 * np); memcpy(d->dyn_xyz, save + nc + nh + np, 8 * nd);
+            }
+            qmax++; trials++;
+        } while (rho < 0 && qmax < 10);
+        int terminate = (qmax == 10 || rho == 0);
+        if (!terminate) { if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0; if (nBad >= 3) terminate = 1; }
+        const double chiNow = build(p, d, NULL, NULL, 0);
+        if (chi2_check < chiNow && it > 0) terminate = 1;
+        chi2_check = chiNow;
+        if (it == 0) lastChi = chiNow;
+        else { const double gain = (lastChi - chiNow) / chiNow; lastChi = chiNow; if (gain >= 0 && gain < p->gain_threshold) terminate = 1; }
+        res->chi2_final = chiNow;
+        if (terminate) { it++; break; }
+    }
+    res->iterations = it; res->lm_trials = trials; res->lambda_final = lambda;
+    free(b); free(x); free(save); free(coo.r); free(coo.c); free(coo.v); coo.r = coo.c = NULL; coo.v = NULL; coo.n = coo.cap = 0;
     return 0;
 }
 

@@ -282,6 +282,37 @@ def badyn_optimize(k, d):
     return dict(cam_T=a["cam_T"].reshape(-1, 3, 4), pt_xyz=a["pt_xyz"], H_T=b["H_T"].reshape(-1, 3, 4), dyn_xyz=b["dyn_xyz"], iterations=r.iterations,
                 lm_trials=r.lm_trials, chi2_initial=r.chi2_initial, chi2_final=r.chi2_final, lambda_final=r.lambda_final)
 
+def badyn_optimize_sparse(k, d):
+    """vo_badyn_optimize_sparse: the same LM loop over the sparse un-eliminated system, the linear solve by scipy's SuperLU (the reference: g2o BlockSolverX + CSparse,
+    Optimizer.cc:1318-1324).  For graphs whose dense Hessian does not fit (configs[3](b): 36 690 unknowns)."""
+    import scipy.sparse as sp, scipy.sparse.linalg as spl
+    p, a = ba_struct(k); s, b = badyn_struct(d); r = BaResult()
+    cache = {}
+    FN = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double))
+    def solve(N, nnz, rows, cols, vals, lam, bp, xp):
+        try:
+            key = C.addressof(vals.contents)
+            rr = np.ctypeslib.as_array(rows, (nnz,)); cc = np.ctypeslib.as_array(cols, (nnz,)); vv = np.ctypeslib.as_array(vals, (nnz,))
+            sig = (key, nnz, float(vv[:64].sum()), float(vv[-64:].sum()))
+            if cache.get("sig") != sig:                     # one assembly per linearisation, re-used by the lambda trials
+                cache["A"] = sp.coo_matrix((vv.copy(), (rr.copy(), cc.copy())), shape=(N, N)).tocsc(); cache["sig"] = sig
+            # elimination order = the unknowns reversed (dynamic points, static points, then the poses): the classic bundle-adjustment order, 7x faster here than COLAMD
+            perm = np.arange(N - 1, -1, -1)
+            A = (cache["A"] + lam * sp.identity(N, format="csc")).tocsc()[perm][:, perm].tocsc()
+            x = np.empty(N)
+            x[perm] = spl.splu(A, permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True)).solve(np.ctypeslib.as_array(bp, (N,))[perm].copy())
+            if not np.all(np.isfinite(x)):
+                return 0
+            np.ctypeslib.as_array(xp, (N,))[:] = x
+            return 1
+        except Exception:                                    # singular factorisation -> the LM loop treats it as a failed trial
+            return 0
+    cb = FN(solve)
+    f = lib().vo_badyn_optimize_sparse; f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, FN]
+    f(C.byref(p), C.byref(s), C.byref(r), cb)
+    return dict(cam_T=a["cam_T"].reshape(-1, 3, 4), pt_xyz=a["pt_xyz"], H_T=b["H_T"].reshape(-1, 3, 4), dyn_xyz=b["dyn_xyz"], iterations=r.iterations,
+                lm_trials=r.lm_trials, chi2_initial=r.chi2_initial, chi2_final=r.chi2_final, lambda_final=r.lambda_final)
+
 def badyn_system(k, d):
     """dense (H, b, chi2) of the whole graph; unknown order = cams, Hs, static points, dynamic points."""
     p, a = ba_struct(k); s, b = badyn_struct(d)

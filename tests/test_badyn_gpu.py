@@ -50,6 +50,26 @@ def test_dynamic_ba_band_layout_matches_oracle(vido, oracle, ctx, n_cam, max_len
         assert rel(got[key], ref[key]) < TOL, key
 
 
+def test_configs3b_20kf_2k_landmarks_5_objects_x_100_points_matches_sparse_oracle(vido, oracle, ctx):
+    """BASELINE configs[3] with its dynamic part at the defining size: 20 keyframes x 2 000 static landmarks (35.6 k observations) + 5 objects x 100
+    points tracked through all 20 frames = 10 000 dynamic point vertices, 9 500 ternary edges, 95 object-motion vertices (36 690 unknowns).  The oracle solves the sparse
+    un-eliminated system with SuperLU (vo_badyn_optimize_sparse, pinned to the dense form in tests/test_oracle_cpu.py); the HIP path eliminates static points (3x3 Schur)
+    and dynamic chains (block tridiagonal) and solves the 690-unknown pose system."""
+    import copy
+    P = vido.problems
+    base = P.synth_ba_problem(n_cam=20, n_pt=2000, kind="local", seed=7)
+    dyn = P.synth_ba_dynamic(base, n_obj=5, pts_per_obj=100, seed=8, full_tracks=True)
+    assert (dyn["n_H"], dyn["n_dyn"], dyn["n_tern"]) == (95, 10000, 9500) and len(base["obs_cam"]) > 30000
+    base["max_iters"] = 20
+    ref = oracle.badyn_optimize_sparse(copy.deepcopy(base), copy.deepcopy(dyn))
+    got = vido.ba_optimize(ctx, base, dynamic=dyn)
+    assert abs(got["chi2_initial"] - ref["chi2_initial"]) <= 1e-9 * ref["chi2_initial"]
+    assert (got["iterations"], got["lm_trials"]) == (ref["iterations"], ref["lm_trials"])
+    assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-6 * ref["chi2_final"]
+    for key in ("cam_T", "pt_xyz", "H_T", "dyn_xyz"):
+        assert rel(got[key], ref[key]) < TOL, key
+
+
 def test_dynamic_ba_first_step_exact(vido, oracle, ctx):
     """one LM iteration: identical step => the elimination scheme is the same linear solve as the dense oracle"""
     P = vido.problems

@@ -101,7 +101,7 @@ def test_kitti_mode_runs_the_full_batch_with_object_factors(tmp_path, vido):
     assert max(moved) > 1e-3                                                     # the motion vertices start at identity and were optimised
 
 
-def write_kaist_clip(tmp, scene, n, bf=387.57, factor=100.0):
+def write_kaist_clip(tmp, scene, n, bf=387.57, factor=100.0, dist=(0.0, 0.0, 0.0, 0.0, 0.0)):
     """The reference's on-disk layout (vido_slam/demo/run_vido_slam.cc:47-65, 113-122): vTimestampsImage.txt (header + integer nanoseconds),
     <image_path>/<first 19 chars of to_string(stamp)>.png Bayer-RG u8, ../flow_image/*.flo, ../depth_image/*.png u16 (KAIST: depth = bf / (value / DepthMapFactor)),
     ../mask_image/*.png u8."""
@@ -124,7 +124,7 @@ def write_kaist_clip(tmp, scene, n, bf=387.57, factor=100.0):
     cfg = os.path.join(tmp, "config.yaml")
     with open(cfg, "w") as fh:
         fh.write("%%YAML:1.0\nimage_path: %s\nstart_index: 0\nslam_mode: 0\nCamera.width: %d\nCamera.height: %d\n" % (os.path.join(tmp, "image_0"), scene.w, scene.h))
-        fh.write("Camera.fx: %r\nCamera.fy: %r\nCamera.cx: %r\nCamera.cy: %r\nCamera.k1: 0.0\nCamera.k2: 0.0\nCamera.p1: 0.0\nCamera.p2: 0.0\nCamera.k3: 0.0\n" % (fx, fy, cx, cy))
+        fh.write("Camera.fx: %r\nCamera.fy: %r\nCamera.cx: %r\nCamera.cy: %r\nCamera.k1: %r\nCamera.k2: %r\nCamera.p1: %r\nCamera.p2: %r\nCamera.k3: %r\n" % ((fx, fy, cx, cy) + tuple(dist)))
         fh.write("Camera.bf: %r\nCamera.fps: 10.0\nCamera.RGB: 0\nChooseData: 3\nDepthMapFactor: %r\nThDepthBG: 40.0\nThDepthOBJ: 25.0\n" % (bf, factor))
         fh.write("MaxTrackPointBG: 3000\nMaxTrackPointOBJ: 800\nSFMgThres: 0.12\nSFDsThres: 0.3\nWINDOW_SIZE: 20\nOVERLAP_SIZE: 4\nUseSampleFeature: 0\n")
         fh.write("ORBextractor.nFeatures: 2000\nORBextractor.scaleFactor: 1.2\nORBextractor.nLevels: 8\nORBextractor.iniThFAST: 20\nORBextractor.minThFAST: 7\n")
@@ -158,6 +158,38 @@ def test_reference_disk_layout_50_frame_clip(tmp_path, vido):
     assert max(rpe) < 0.03 and max(err) < 0.3, (max(rpe), max(err), np.mean(err))
     ref = np.loadtxt(os.path.join(str(tmp_path), "res_refined_rgbd_new.txt"))
     assert ref.shape == (n, 17)
+
+
+def test_kaist_intrinsics_with_lens_distortion_1280x560(tmp_path, vido):
+    """Row A11 inside the facade: the KAIST settings of the reference (src/config/kaist_config.yaml:24-33: 1280 x 560, fx 816.4, k1 = -0.05004 ...), ChooseData: 3, the
+    reference's disk layout.  Frame::Frame runs UndistortKeyPoints (Frame.cc:603-633 -> vido_undistort_points, pinned bit-exactly against the oracle in
+    tests/test_trackhost_cpu.py) on every frame: mvKeysUn differs from mvKeys by more than a pixel at the image corners, and — as in the reference, whose tracking lists are
+    built from mvKeys, not mvKeysUn — the poses still follow the renderer's (pinhole) ground truth."""
+    sys.path.insert(0, os.path.join(ROOT, "vido-slam_amd"))
+    import build
+    driver = build.build_driver()
+    n = 8
+    K = (816.402, 817.38, 608.2658, 266.688); dist = (-0.05004, 0.120012, -0.0006259, -0.00118, -0.063505)
+    scene = vido.synth.Scene3D(n_frames=n, w=1280, h=560, K=K, seed=5, step=0.2, yaw_deg=0.1, objects=((-2.0, 0.4, 9.0, 0.02, 0.0, 0.22),), wall_z=48.0)
+    cfg = write_kaist_clip(str(tmp_path), scene, n, dist=dist)
+    out = os.path.join(str(tmp_path), "poses.txt")
+    r = subprocess.run([driver, cfg, out, os.path.join(str(tmp_path), "res_")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    line = [l for l in r.stdout.splitlines() if l.startswith("undistort keys")][0].split()
+    assert int(line[2]) > 1000 and float(line[4]) > 1.0, line                 # the undistortion ran and moved keypoints (corner shift at these coefficients: several px)
+    P = np.loadtxt(out)
+    assert P.shape == (n, 17)
+    for k in range(1, n):
+        E = P[k, 1:].reshape(4, 4) @ np.linalg.inv(scene.Tcw(k))
+        assert np.linalg.norm(E[:3, 3]) < 0.08, (k, E)
+    # the same clip declared distortion-free: identical poses (nothing downstream of the tracking lists reads mvKeysUn — Tracking.cc:283-782), no displacement reported
+    cfg0 = write_kaist_clip(str(tmp_path), scene, n)
+    out0 = os.path.join(str(tmp_path), "poses0.txt")
+    r0 = subprocess.run([driver, cfg0, out0, os.path.join(str(tmp_path), "res0_")], capture_output=True, text=True, timeout=600)
+    assert r0.returncode == 0, r0.stderr + r0.stdout
+    line0 = [l for l in r0.stdout.splitlines() if l.startswith("undistort keys")][0].split()
+    assert float(line0[4]) == 0.0
+    assert np.array_equal(np.loadtxt(out0), P)
 
 
 def test_use_sample_feature_option(tmp_path, vido):

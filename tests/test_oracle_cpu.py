@@ -185,6 +185,23 @@ def test_ternary_edge_jacobians(oracle):
         assert np.allclose(fd, JH[:, a] * (1.0 if a < 3 else 2.0), atol=1e-5)
 
 
+@pytest.mark.usefixtures("box")
+def test_sparse_full_graph_oracle_equals_the_dense_one(oracle, vido):
+    """oracle/badyn_oracle.c::vo_badyn_optimize_sparse (sparse un-eliminated system + SuperLU, for configs[3](b)-sized graphs) against the dense LDL^T form of the
+    same LM loop: same iteration / trial counts, same estimates."""
+    import copy
+    P = vido.problems
+    for n_cam, n_pt, n_obj, ppo, seed in [(8, 60, 2, 8, 9), (14, 80, 3, 10, 5)]:
+        base = P.synth_ba_problem(n_cam=n_cam, n_pt=n_pt, kind="global", track_len=5, seed=seed)
+        dyn = P.synth_ba_dynamic(base, n_obj=n_obj, pts_per_obj=ppo, seed=seed + 1)
+        base["max_iters"] = 25
+        a = oracle.badyn_optimize(copy.deepcopy(base), copy.deepcopy(dyn)); b = oracle.badyn_optimize_sparse(copy.deepcopy(base), copy.deepcopy(dyn))
+        assert (a["iterations"], a["lm_trials"]) == (b["iterations"], b["lm_trials"])
+        assert abs(a["chi2_final"] - b["chi2_final"]) <= 1e-9 * a["chi2_final"]
+        for key in ("cam_T", "pt_xyz", "H_T", "dyn_xyz"):
+            assert np.abs(a[key] - b[key]).max() < 1e-8, key
+
+
 def test_badyn_system_and_convergence(oracle):
     import vido_slam_amd as V
     P = V.problems
@@ -274,6 +291,7 @@ def test_fast_known_behaviours_on_constructed_patterns(oracle):
     assert not [1 for x, y, sc in oracle.fast9_16(plate, 20, nonmax=True) if sm[y, x] == sm[y, x + 1] or sm[y, x] == sm[y, x - 1]]
 
 
+@pytest.mark.usefixtures("box")
 def test_static_ba_oracle_against_the_uneliminated_dense_solve(oracle):
     """The static-BA oracle (oracle/ba_oracle.c) uses LM on the point-Schur reduced system — the same formulation as the HIP path.  g2o does NOT eliminate
     (no vertex is marginalised in Partial/FullBatchOptimization): it solves the full pose + point system.  oracle/badyn_oracle.c does that too

@@ -11,6 +11,8 @@ import pytest
 import vido_slam_amd as V
 from vido_slam_amd import host
 
+pytestmark = pytest.mark.usefixtures("box")          # host + GPU box (tests/conftest.py): the driver's -m gpu run executes these rows too
+
 KAIST_K = (816.402, 817.38, 608.2658, 266.688)                      # src/config/kaist_config.yaml:24-33
 KAIST_DIST = (-0.05004, 0.120012, -0.0006259, -0.00118, -0.063505)
 

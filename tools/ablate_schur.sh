@@ -3,7 +3,7 @@
 cd /tmp; export TMPDIR=/tmp
 for lib in /root/repo/vido-slam_amd/variants/*.so; do
   n=$(basename $lib .so)
-  VIDO_LIB_PATH=$lib timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/r2m -o $n -- python /root/repo/tools/dbg_bcr.py > /dev/null 2>&1
+  VIDO_LIB_PATH=$lib timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/r2m -o $n -- python /root/repo/tools/prof_ba_global.py > /dev/null 2>&1
   python - <<PY
 import csv
 for r in csv.DictReader(open("/root/repo/gpurun_out/r2m/${n}_kernel_stats.csv")):

@@ -1,9 +1,9 @@
 #!/bin/bash
-# SQ counters of k_fast_strips (tools/dbg_fast_batch.py) for one library build: tools/pmc_fast.sh <lib.so> <outdir>
+# SQ counters of k_fast_strips (tools/prof_frontend_batch.py) for one library build: tools/pmc_fast.sh <lib.so> <outdir>
 lib=$1; out=/root/repo/$2; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 run() { tag=$1; shift
-  VIDO_LIB_PATH=$lib timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/pmc_$tag -o fast -- python /root/repo/tools/dbg_fast_batch.py > $out/pmc_$tag.log 2>&1 || tail -3 $out/pmc_$tag.log
+  VIDO_LIB_PATH=$lib timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/pmc_$tag -o fast -- python /root/repo/tools/prof_frontend_batch.py > $out/pmc_$tag.log 2>&1 || tail -3 $out/pmc_$tag.log
 }
 run a SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY
 run b SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS

@@ -9,6 +9,7 @@
 // PNG decoding: chunk walk + zlib inflate + the five scan-line filters, 8/16-bit gray and 8-bit RGB(A), non-interlaced (what the reference's dataset holds); OpenCV is not
 // in this image, and cv::imread / cv::cvtColor(COLOR_BayerRG2BGR) are third-party code: the bilinear demosaic below restates OpenCV's published scheme (parity unpinned).
 #include "../include/vido_slam/vido_slam.h"
+#include <cmath>
 #include <zlib.h>
 #include <sstream>
 #include <chrono>
@@ -168,6 +169,12 @@ int main(int argc, char** argv)
             const std::vector<int> ids = M->nObjID;
             const bool ok = SLAM.GetTracker()->GetStaticTrack() == M->TrackletSta && SLAM.GetTracker()->GetDynamicTrackNew() == M->TrackletDyn && ids == M->nObjID;
             std::cout << "tracklets static " << M->TrackletSta.size() << " dynamic " << M->TrackletDyn.size() << " incremental_equals_rebuild " << (ok ? 1 : 0) << std::endl;
+        }
+        {   // Frame::UndistortKeyPoints on the last frame (Frame.cc:603-633): largest displacement mvKeys -> mvKeysUn (0 when Camera.k1 == 0)
+            const Frame* F = SLAM.GetTracker()->mpLastFrame ? SLAM.GetTracker()->mpLastFrame : SLAM.GetTracker()->mpCurrentFrame;
+            double mx = 0; if (F) for (size_t i = 0; i < F->mvKeys.size() && i < F->mvKeysUn.size(); i++)
+                mx = std::max(mx, (double)std::hypot(F->mvKeys[i].pt.x - F->mvKeysUn[i].pt.x, F->mvKeys[i].pt.y - F->mvKeysUn[i].pt.y));
+            std::cout << "undistort keys " << (F ? F->mvKeysUn.size() : 0) << " max_shift_px " << mx << std::endl;
         }
         if (!M->vfAll_time.empty()) {   // Tracking::Track stage means (the reference's all_timing layout: [0] feature, [1] camera pose, [2] scene flow/object tracking, [3] per-object motion, [4] renew + map)
             std::vector<double> acc(5, 0.0); int cnt = 0;

@@ -1,4 +1,4 @@
-import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import vido_slam_amd as V
 ctx = V.Context(); P = V.problems
 dpr = P.synth_ba_problem(n_cam=200, n_pt=20000, kind="global", track_len=10, seed=13); dpr["max_iters"] = 3

@@ -1,6 +1,6 @@
 """Per-kernel profile of the flow node as NetNodes runs it (fused epilogues, HIP warp / correlation), eager, 640x480."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import vido_slam_amd as V
 from vido_slam_amd import nets

@@ -1,6 +1,6 @@
 """A/B: incremental tracklet store vs the previous full-rebuild build (vido-slam_amd/_old/) on the same clip; all result files must be byte-identical."""
 import sys, os, subprocess, tempfile, filecmp
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vido-slam_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import vido_slam_amd as V
 import build as vbuild

@@ -1,6 +1,6 @@
 """conv + bias + ReLU: MIOpen's fused entry (torch.miopen_convolution_relu) vs conv2d + the in-place HIP epilogue, on detector shapes"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn.functional as F
 import vido_slam_amd as V
 from vido_slam_amd import nets

@@ -1,6 +1,6 @@
 """Where the detector's 14.5 ms go: trunk (hipGraph) vs the eager head section (GPU time by events, host time by the clock)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import torch
 import vido_slam_amd as V
 from vido_slam_amd import pipeline, nets

@@ -1,6 +1,6 @@
 """Every convolution LiteFlowNet runs at 640x480 (hooked), with MIOpen's time per shape: where do the 5.4 ms go by pyramid level?"""
 import os, sys, time, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn as nn, torch.nn.functional as F
 import vido_slam_amd as V
 from vido_slam_amd import nets

@@ -1,6 +1,6 @@
 """Throughput of the three network nodes alone (no tracker), as pipeline.NetNodes runs them: three streams + hipGraphs, and serially on one stream."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import torch
 import vido_slam_amd as V
 from vido_slam_amd import pipeline

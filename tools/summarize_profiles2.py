@@ -38,7 +38,7 @@ def traffic(tag, command):
             "kernels": res}
 
 
-json.dump(traffic("fe", "tools/dbg_fast_batch.py: the batched front end, 64 frames of 640x480 per launch"), open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-json.dump(traffic("bal", "tools/dbg_ba_local.py: configs[3] local window, 20 KF x 2k landmarks"), open(os.path.join(dst, "pmc_traffic_ba.json"), "w"), indent=1)
-json.dump(traffic("bag", "tools/dbg_bcr.py: configs[4] size, 500 KF x 100k landmarks, 1 M edges"), open(os.path.join(dst, "pmc_traffic_ba_global.json"), "w"), indent=1)
+json.dump(traffic("fe", "tools/prof_frontend_batch.py: the batched front end, 64 frames of 640x480 per launch"), open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+json.dump(traffic("bal", "tools/prof_ba_local.py: configs[3] local window, 20 KF x 2k landmarks"), open(os.path.join(dst, "pmc_traffic_ba.json"), "w"), indent=1)
+json.dump(traffic("bag", "tools/prof_ba_global.py: configs[4] size, 500 KF x 100k landmarks, 1 M edges"), open(os.path.join(dst, "pmc_traffic_ba_global.json"), "w"), indent=1)
 print("wrote", dst, sorted(os.listdir(dst)))

@@ -2561,6 +2561,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM_LDS_BYTES)); }
 
     const int lin_E = 1;     // groups of 64 observations per wave in k_ba_linearize: with the LDS camera accumulators one group is fastest at every size measured (35 k .. 1 M edges)
+    if (allreduce == vido_rccl_allreduce && user != (void*)ctx)      // the built-in path enqueues on user->stream: another context's stream would lose all ordering with this solve
+        return vido_set_error(ctx, VIDO_E_INVALID, "ba: vido_rccl_allreduce must be passed with user = the context the solve runs on");
     auto AR = [&](double* dptr, size_t cnt, int op) -> int {
         if (!allreduce) return VIDO_OK;
         if (allreduce != vido_rccl_allreduce) HIP_TRY(ctx, hipStreamSynchronize(st));      // a host-side hook reads the buffer; the built-in RCCL path is ordered by the stream
@@ -2602,6 +2604,9 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         if (allreduce) {     // camera diagonal blocks, bc, chi2 (sum) — then the max-diagonal (max) on its own
             if (it == 0) { HIP_TRY(ctx, hipStreamSynchronize(st)); double md; HIP_TRY(ctx, hipMemcpy(&md, D.scal + 1, 8, hipMemcpyDeviceToHost)); HIP_TRY(ctx, hipMemsetAsync(D.scal + 1, 0, 8, st));
                            if ((rc = AR(red, (size_t)n_pose * 36 + n6 + 1, 0))) return rc;
+                           // the stream-ordered RCCL path does not synchronise inside AR(): order the blocking copy below behind the memset and the sum all-reduce on `st`
+                           // (it == 0 only; ADVICE r2: without this the landmark part of the max-diagonal could be zeroed after it had been written)
+                           HIP_TRY(ctx, hipStreamSynchronize(st));
                            HIP_TRY(ctx, hipMemcpy(D.scal + 1, &md, 8, hipMemcpyHostToDevice)); if ((rc = AR(D.scal + 1, 1, 1))) return rc;
                            // the camera part of the max must see the SUMMED camera diagonals
                            hipLaunchKernelGGL(k_ba_maxdiag, dim3(64), dim3(256), 0, st, D, 0); if ((rc = AR(D.scal + 1, 1, 1))) return rc; }

@@ -162,13 +162,14 @@ def dyn_constants():
                 huber_dyn=float(F32(0.01)), huber_tern=float(F32(0.01)), huber_smooth=float(F32(0.01)))
 
 
-def synth_ba_dynamic(base, n_obj=2, pts_per_obj=30, seed=21, obs_noise=0.02, min_len=3, max_len=None):
+def synth_ba_dynamic(base, n_obj=2, pts_per_obj=30, seed=21, obs_noise=0.02, min_len=3, max_len=None, full_tracks=False):
     """Object part of the FullBatchOptimization graph on top of a static problem `base` (synth_ba_problem, kind="global"):
     rigid objects moving with a constant world-frame motion H (p_{k+1} = H p_k), each point tracked over a contiguous
     run of frames.  Mirrors Optimizer.cc:1560-1745: one dynamic vertex per observation (initialised at the noisy
     back-projection through the INITIAL camera pose), its camera edge, a ternary edge to the previous vertex of the
     tracklet and the (object, frame) motion vertex (initialised to identity), smoothness edges between consecutive motion
-    vertices of one object from frame 3 on.  Returns the dict of the vido_ba_dynamic fields (+ H_true)."""
+    vertices of one object from frame 3 on.  full_tracks: every object lives in every frame and every point is tracked through all of them — SURVEY 8(d) row 4(b):
+    5 objects x 100 points over 20 keyframes = 10 000 dynamic point vertices, 9 500 ternary edges, 95 motion vertices.  Returns the dict of the vido_ba_dynamic fields (+ H_true)."""
     rng = np.random.RandomState(seed)
     n_cam = base["n_cam"]; cams = np.stack([np.vstack([c, [0, 0, 0, 1]]) for c in base["cam_true"]])
     cam0 = np.stack([np.vstack([c, [0, 0, 0, 1]]) for c in base["cam_T"]])
@@ -179,6 +180,8 @@ def synth_ba_dynamic(base, n_obj=2, pts_per_obj=30, seed=21, obs_noise=0.02, min
         H = np.eye(4); H[:3, :3] = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
         H[:3, 3] = [rng.uniform(-0.2, 0.2), 0.0, rng.uniform(0.6, 1.2)]
         f0 = int(rng.randint(0, max(1, n_cam // 3))); f1 = int(min(n_cam - 1, f0 + rng.randint(max(min_len, n_cam // 2), n_cam)))
+        if full_tracks:
+            f0, f1 = 0, n_cam - 1
         centre = cams[f0] @ np.array([rng.uniform(-4, 4), rng.uniform(-0.5, 0.5), rng.uniform(8, 14), 1.0])
         P = centre[:3] + rng.uniform(-1, 1, (pts_per_obj, 3))
         for f in range(max(f0, 1), f1 + 1):
@@ -187,6 +190,8 @@ def synth_ba_dynamic(base, n_obj=2, pts_per_obj=30, seed=21, obs_noise=0.02, min
                 sm_i.append(H_idx[(o, f - 1)]); sm_j.append(H_idx[(o, f)])
         for q in range(pts_per_obj):
             a = int(rng.randint(f0, max(f0 + 1, f1 - min_len + 1))); b = int(min(f1, a + rng.randint(min_len - 1, f1 - f0 + 1)))
+            if full_tracks:
+                a, b = f0, f1
             if max_len is not None:
                 b = min(b, a + max_len - 1)          # bounded tracklet length (the usual case: dynamic points are re-sampled every few frames)
             p = np.append(P[q], 1.0)
