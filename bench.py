@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--prologue", type=int, default=20, help="untimed frames before the warm-up that fill the local-BA window (WINDOW_SIZE)")
     ap.add_argument("--feed", choices=("given", "nets"), default="given", help="maps the tracker consumes: the renderer's (default) or the networks' outputs")
+    ap.add_argument("--handover", choices=("device", "host"), default="device", help="network -> tracker hand-over: device-resident (default: one BGR upload per frame, no map crosses PCIe) or round 2's pinned-host round trip")
     ap.add_argument("--no-pipeline", action="store_true", help="serial chain: networks of frame k, then tracking of frame k")
     ap.add_argument("--no-graphs", action="store_true"); ap.add_argument("--no-fold", action="store_true"); ap.add_argument("--no-streams", action="store_true", help="(default) the three networks share one stream")
     ap.add_argument("--streams", action="store_true", help="one stream per network: measured SLOWER (23.6 vs 21.2 ms per frame for the three networks: their kernels each fill the GPU and evict each other's L2)")
@@ -135,10 +136,11 @@ def main():
     write_settings(cfg_path, scene.K, W, H)
     net_ctx = V.Context(device=local_rank, width=W, height=H, max_batch=1)             # owns the HIP ops of the network nodes (correlation, ROI-Align, NMS ...)
     t_setup = time.perf_counter()
-    nodes = pipeline.NetNodes(net_ctx, H, W, optimize=not args.no_fold, graphs=not args.no_graphs, streams=args.streams, miopen_find=args.miopen_find, calibrate_scores=not args.saturated_detector)
+    nodes = pipeline.NetNodes(net_ctx, H, W, optimize=not args.no_fold, graphs=not args.no_graphs, streams=args.streams, miopen_find=args.miopen_find, calibrate_scores=not args.saturated_detector,
+                              static_detector=not args.saturated_detector)      # saturated scores tie at the detections_per_img cut on every frame: the fixed-slot head would fall back every time
     t_setup = time.perf_counter() - t_setup
     slam = System(); slam.Init(cfg_path, System.RGBD)
-    e2e = pipeline.EndToEnd(nodes, slam, n_image=10 ** 6, feed=args.feed)
+    e2e = pipeline.EndToEnd(nodes, slam, n_image=10 ** 6, feed=args.feed, handover=args.handover)
 
     def run(lo, hi):
         for k in range(lo, hi):
@@ -197,7 +199,8 @@ def main():
             return float(fc.get_total_flops())
         legs = {"liteflownet": (lambda: (nodes.g_flow or nodes._flow_fn)(ex0, ex), lambda: nodes._flow_fn(ex0, ex)),
                 "monodepth2": (lambda: (nodes.g_depth or nodes._depth_fn)(ex), lambda: nodes._depth_fn(ex)),
-                "maskrcnn_x101_fpn": (lambda: V.nets.analyse_image(nodes.mask_net, ex, feed=nodes.mask_feed, confidence=nodes.confidence, trunk=nodes.g_trunk),
+                "maskrcnn_x101_fpn": ((lambda: nodes.g_det(ex)) if nodes.g_det is not None else
+                                      (lambda: V.nets.analyse_image(nodes.mask_net, ex, feed=nodes.mask_feed, confidence=nodes.confidence, trunk=nodes.g_trunk)),
                                       lambda: V.nets.analyse_image(nodes.mask_net, ex, feed=nodes.mask_feed, confidence=nodes.confidence))}
         for name, (fast, eager) in legs.items():
             ms = timed(fast); fl = flops(eager)
@@ -214,15 +217,17 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[1]+[2]+[3] chained: per %dx%d frame LiteFlowNet + MonoDepth2 (640x192 feed) + Mask R-CNN X-101-32x8d-FPN (800x1088 feed), fp32 batch 1, random-init weights "
-                               "-> host hand-over -> System::TrackRGBD (cvtColor, ORB 2000 features, lists, mask propagation, P3P-RANSAC, Flow2Cam, scene flow, object tracking, "
-                               "per-object Flow2, re-seeding) -> PartialBatchOptimization over a full 20-frame window; networks of frame k+1 overlap tracking of frame k" % (W, H),
+                               "-> %s hand-over -> System::TrackRGBD (cvtColor, ORB 2000 features, lists, mask propagation, P3P-RANSAC, Flow2Cam, scene flow, object tracking, "
+                               "per-object Flow2, re-seeding) -> PartialBatchOptimization over a full 20-frame window; networks of frame k+1 overlap tracking of frame k" % (W, H, "device-resident" if args.handover == "device" else "pinned-host"),
                    "frames_per_step": 1, "pipelined": not args.no_pipeline, "tracker_feed": args.feed,
-                   "tracker_feed_note": "networks run at full cost and their outputs are copied to the host; with random-init weights those maps carry no geometry, so the tracker is "
-                                        "handed the renderer's exact flow/depth/mask of the same frame (feed=given) after the network hand-over of that frame has completed",
+                   "handover": args.handover,
+                   "tracker_feed_note": "networks run at full cost and their outputs are parked in the hand-over ring; with random-init weights those maps carry no geometry, so the tracker is "
+                                        "handed the renderer's exact flow/depth/mask of the same frame (feed=given; uploaded next to the BGR frame) once the networks of that frame have completed",
                    "prologue_frames": args.prologue, "parallelism": "replicas x%d (per-frame path does not shard)" % world,
                    "net_optimisations": {"frozen_bn_folded_pairs": nodes.folded, "hip_graphs": nodes.g_flow is not None, "graph_error": nodes.graph_error,
-                                         "network_streams": 3 if nodes.streams is not None else 1, "detector_score_calibration": round(nodes.score_scale, 6), "miopen_find": bool(args.miopen_find)},
-                   "inputs": "BGR u8 frames in pinned host memory; flow f32x2 / depth f32 / mask i32 handed to TrackRGBD as host buffers"},
+                                         "network_streams": 3 if nodes.streams is not None else 1, "detector_one_graph": nodes.g_det is not None, "detector_overflow_frames": nodes.det_overflows, "detector_score_calibration": round(nodes.score_scale, 6), "miopen_find": bool(args.miopen_find)},
+                   "inputs": "BGR u8 frames in pinned host memory, one upload per frame; " + ("flow f32x2 / depth f32 / mask i32 handed to System::TrackRGBDDevice as device pointers (no map crosses PCIe)"
+                                                                                                if args.handover == "device" else "flow f32x2 / depth f32 / mask i32 copied to pinned host buffers and handed to TrackRGBD")},
         "stage_ms": {k: round(v, 3) for k, v in stage.items()},
         "per_frame_counts": {k: round(v, 1) for k, v in counts.items()},
         "pose_translation_error_m": {"mean": round(float(np.mean(t_err[1:])), 4), "max": round(float(np.max(t_err[1:])), 4), "path_length_m": round(0.25 * (len(t_err) - 1), 2)},

@@ -57,6 +57,9 @@ int         vido_synchronize(vido_ctx* ctx);
 /* Network ops called with on_device != 0 enqueue on `hip_stream` (a caller-owned hipStream_t, e.g. torch's current
  * stream; NULL = the legacy default stream) while enable != 0; enable == 0 restores the ctx stream. */
 int         vido_set_stream(vido_ctx* ctx, void* hip_stream, int enable);
+/* The ctx's own stream waits (on the device) for `hip_event` (a hipEvent_t the producer recorded on its stream): how device buffers written by another stream — the
+ * network nodes' — are handed to the tracker without a host-side wait. */
+int         vido_stream_wait_event(vido_ctx* ctx, void* hip_event);
 
 /* ---- ORB ---------------------------------------------------------------------------------------
  * Single frame, host buffers (what ORBextractor::operator() is handed): gray CV_8UC1 `stride` bytes/row.
@@ -153,6 +156,9 @@ int vido_gather_object_depth_label(vido_ctx* ctx, int slot, const float* keys_xy
 int vido_update_mask(vido_ctx* ctx, int slot_last, int slot_cur, const int32_t* last_label, const float* last_corr_xy, int n,
                      int32_t* recovered_out, int cap, int32_t* n_recovered);
 int vido_read_maps(vido_ctx* ctx, int slot, float* depth_out, float* flow_out, int32_t* mask_out);   /* any pointer may be NULL */
+/* mask / depth / flow of slot `slot` at ((int)x, (int)y) of n points (host xy in, host values out; points outside the image give 0): the only map data the host-side
+ * renew stages need (vido_renew_*_sampled) — a few thousand points instead of three whole maps. */
+int vido_gather_point_samples(vido_ctx* ctx, int slot, const float* xy, int n, int32_t* mask_out, float* depth_out, float* flow_out);
 /* Frame::UnprojectStereoStat/Object, addnoise=0 (Frame.cc:706-771): Tcw row-major 4x4 f32. */
 int vido_unproject_world(vido_ctx* ctx, const float* keys_xy, const float* z, int n, const vido_track_params* p,
                          const float* Tcw, float* xyz_out);
@@ -294,6 +300,12 @@ int vido_nms_segments(vido_ctx* ctx, const float* boxes_xyxy, const int32_t* gro
  * boxes [n,4] x1 y1 x2 y2, level [n] in 0..3 (the LevelMapper's result, computed by the caller), out [n,C,pooled_h,pooled_w]. */
 int vido_roi_align_fpn(vido_ctx* ctx, const float* const feat[4], const int H[4], const int W[4], const float scale[4], int C, const float* boxes, const int32_t* level,
                        int n, int pooled_h, int pooled_w, int sampling_ratio, float* out);
+/* The layout the ROI-Align kernel reads: [B][C][H][W] -> [B][H][W][C] (DEVICE, f32).  ROIAlign_cuda.cu:15-122 gives every thread one output element and four scattered
+ * 4-byte gathers per sample from channel-planar maps; this build reads channels-last (lanes across channels: one coalesced 256-byte load per tap and 64 channels). */
+int vido_nchw_to_nhwc(vido_ctx* ctx, const float* src, int B, int C, int H, int W, float* dst);
+/* vido_roi_align_fpn with CHANNELS-LAST maps feat[l] = [H[l]][W[l]][C] (vido_nchw_to_nhwc once per frame; the box and the mask pooler share the copies). */
+int vido_roi_align_fpn_nhwc(vido_ctx* ctx, const float* const feat[4], const int H[4], const int W[4], const float scale[4], int C, const float* boxes, const int32_t* level,
+                            int n, int pooled_h, int pooled_w, int sampling_ratio, float* out);
 /* Masker(threshold 0.5, padding 1).forward (modeling/roi_heads/mask_head/inference.py:87-160, per detection on the host in the reference) fused with the node's
  * label image (src/run_mask_rcnn.py:112-118: blank_mask += mask * class_index): masks [n,1,M,M] f32, boxes [n,4] f32 in the output image, labels [n] i64,
  * all DEVICE, detections in the order the node adds them; out [H,W] u8 = (sum over detections of pasted mask * class index) mod 256. */
@@ -339,6 +351,17 @@ int vido_renew_objects(const vido_host_maps* maps, const float* obj_xy, const in
                        int n_objects, const int32_t* inl_off, const int32_t* inl_ids, const uint8_t* obj_stat, const int32_t* sem_position, const int32_t* mod_label,
                        const float* tmp_xy, const float* tmp_depth, const int32_t* tmp_sem, const float* tmp_flow, const float* tmp_corr, int n_tmp, int max_num_obj,
                        float* keys_out, float* depth_out, int32_t* sem_out, float* flow_out, float* corr_out, int32_t* inlier_out, int32_t* label_out, int cap, int32_t* n_out);
+/* The same two stages for maps that live on the DEVICE (the in-process network -> tracker hand-over): instead of whole host maps they take the map
+ * values AT the candidate points — mask / depth / flow at ((int)x, (int)y) of every point of the list, gathered on the device (vido_gather_point_samples).  Entries of
+ * points outside the image are never read.  vido_renew_static / vido_renew_objects sample their host maps and call these. */
+typedef struct vido_point_samples { const int32_t* mask; const float* depth; const float* flow; } vido_point_samples;   /* [n], [n], [2n] */
+int vido_renew_static_sampled(int width, int height, const float* stat_xy, int n_stat, const vido_point_samples* stat_samples, const int32_t* TM_sta, int n_tm,
+                              const float* sample_xy, int n_sample, const vido_point_samples* sample_samples, int max_num,
+                              int32_t* src_out, int32_t* inlier_out, float* flow_out, int cap, int32_t* n_out);
+int vido_renew_objects_sampled(int width, int height, const float* obj_xy, const int32_t* obj_label, int n_obj_pts, const vido_point_samples* obj_samples,
+                               int n_objects, const int32_t* inl_off, const int32_t* inl_ids, const uint8_t* obj_stat, const int32_t* sem_position, const int32_t* mod_label,
+                               const float* tmp_xy, const float* tmp_depth, const int32_t* tmp_sem, const float* tmp_flow, const float* tmp_corr, int n_tmp, int max_num_obj,
+                               float* keys_out, float* depth_out, int32_t* sem_out, float* flow_out, float* corr_out, int32_t* inlier_out, int32_t* label_out, int cap, int32_t* n_out);
 /* Tracking::DynObjTracking (Tracking.cc:1670-1912): groups the n object points by semantic label, drops objects mostly on the image border / static (scene flow) /
  * far / smaller than 150 points (obj_label is updated in place: -1 outlier, 0 static, else the track id), and assigns track ids from the last frame's objects
  * (last_sem_position / last_obj_stat / last_mod_label, n_last) or from *max_id.  Result: n_objects objects, points of object i = obj_ids[obj_off[i] .. obj_off[i+1]),
@@ -377,6 +400,11 @@ const char* vido_system_last_error(const vido_system* sys);      /* NULL sys: er
  * n_image: StopFrame = n_image - 1.  Tcw_out: row-major 4x4 world->camera pose of this frame (identity for the first). */
 int         vido_system_track_rgbd(vido_system* sys, const uint8_t* im, int channels, int width, int height, float* depth, const float* flow,
                                    const int32_t* mask, double timestamp, int n_image, float Tcw_out[16]);
+/* The same with the image (u8, 1 / 3 / 4 interleaved channels) and the three maps already RESIDENT ON THE DEVICE (plain device pointers; depth is rescaled in place on the
+ * device): the in-process replacement of the reference's three service round trips (src/realtime_demo/src/run_vido.cc:57-171 -> :229-235).  Nothing is uploaded, no map is
+ * downloaded; ready_event (hipEvent_t, may be NULL) orders the tracker's stream behind the producer of the buffers. */
+int         vido_system_track_rgbd_device(vido_system* sys, const void* im_dev, int channels, int width, int height, float* depth_dev, const float* flow_dev,
+                                          const int32_t* mask_dev, void* ready_event, double timestamp, int n_image, float Tcw_out[16]);
 int         vido_system_get_stats(const vido_system* sys, vido_system_stats* out);
 int         vido_system_save_results(vido_system* sys, const char* prefix);
 /* the vido_ctx the system's tracker runs on (NULL before the first frame): lets a caller share the device / query timings */

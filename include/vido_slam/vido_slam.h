@@ -47,11 +47,15 @@ public:
        converts `color` (CV_8UC3 / CV_8UC4) on the device straight into pyramid level 0 and fills `gray` with the result, instead of
        converting on the host and uploading the gray image. */
     void SetColorSource(const cv::Mat& color, bool rgb_order, const cv::Mat& gray) { color_ = &color; rgb_ = rgb_order; gray_ = gray.data; }
+    /* extension: the next operator() call reads a DEVICE-resident image (u8, `channels` = 1 / 3 / 4 interleaved, rows contiguous) instead of `image`'s host pixels —
+       the in-process network -> tracker hand-over (Tracking::GrabImageRGBDDevice); `image` then only carries the size. */
+    void SetDeviceSource(const void* dev_pixels, int channels, bool rgb_order) { dev_src_ = dev_pixels; dev_ch_ = channels; rgb_ = rgb_order; }
     int nfeatures; float scaleFactor; int nlevels, iniThFAST, minThFAST;
 private:
     std::vector<float> mvScaleFactor;
     vido_ctx* ctx_ = nullptr; int w_ = 0, h_ = 0;
     const cv::Mat* color_ = nullptr; bool rgb_ = false; const unsigned char* gray_ = nullptr;
+    const void* dev_src_ = nullptr; int dev_ch_ = 0;
 };
 
 class Frame {
@@ -139,6 +143,12 @@ public:
     ~Tracking();
     cv::Mat GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Mat& imFlow, const cv::Mat& maskSEM, const cv::Mat& mTcw_gt,
                           const std::vector<std::vector<float> >& vObjPose_gt, const double& timestamp, cv::Mat& imTraj, const int& nImage);
+    /* extension (replaces the three service round trips of src/realtime_demo/src/run_vido.cc:57-171): the same call with the image and the three
+       maps RESIDENT ON THE DEVICE — u8 image (1 / 3 / 4 channels), depth CV_32F (raw sensor units, rescaled in place like the host form), flow CV_32FC2, mask CV_32SC1 as
+       plain device pointers of a width x height frame.  Nothing is uploaded and no map is downloaded: the host-side stages read the map values at their few thousand
+       candidate points through device gathers.  ready_event: a hipEvent_t the producer recorded after writing the buffers (the tracker's stream waits for it; may be null). */
+    cv::Mat GrabImageRGBDDevice(const void* im_dev, int channels, int width, int height, float* depth_dev, const float* flow_dev, const int* mask_dev, void* ready_event,
+                                const double& timestamp, const int& nImage);
     void Track();
     void Initialization();
     void GetSceneFlowObj();
@@ -170,6 +180,7 @@ public:
 protected:
     System* mpSystem; Map* mpMap;
     int slot_cur_ = 0;
+    cv::Mat GrabCommon(const double& timestamp, const int& nImage, void* t_grab);      /* everything after the maps are in the slot and mImGray is set */
 };
 
 class System {
@@ -180,6 +191,9 @@ public:
     void Init(const std::string& strSettingsFile, const eSensor sensor);
     cv::Mat TrackRGBD(const cv::Mat& im, cv::Mat& depthmap, const cv::Mat& flowmap, const cv::Mat& masksem, const cv::Mat& mTcw_gt,
                       const std::vector<std::vector<float> >& vObjPose_gt, const double& timestamp, cv::Mat& imTraj, const int& nImage);
+    /* extension: TrackRGBD on device-resident inputs (Tracking::GrabImageRGBDDevice) */
+    cv::Mat TrackRGBDDevice(const void* im_dev, int channels, int width, int height, float* depth_dev, const float* flow_dev, const int* mask_dev, void* ready_event,
+                            const double& timestamp, const int& nImage);
     void SaveResultsIJRR2020(const std::string& filename);
     Map* GetMap() { return mpMap; }
     Tracking* GetTracker() { return mpTracker; }

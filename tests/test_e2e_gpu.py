@@ -75,7 +75,99 @@ def test_pipelined_chain_tracks_and_hands_over(tmp_path, vido):
         E = T.astype(np.float64) @ np.linalg.inv(scene.Tcw(k))
         assert np.linalg.norm(E[:3, 3]) < 0.05, (k, E)
     assert e2e.stats[-1]["n_objects"] >= 4                          # the five convoy objects are tracked as dynamic
-    # the network hand-over buffers were filled (flow of the last frame: finite numbers, mask u8 range, depth MONO16 range)
-    hb = e2e.host[(n - 1) % e2e.RING]
-    assert np.isfinite(hb["flow"].numpy()).all() and hb["depth"].numpy().max() <= 65535 and hb["mask"].numpy().min() >= 0
+    # the network hand-over ring was filled on the device (flow of the last frame: finite numbers, mask u8 range, depth MONO16 range), the detector ran as one graph
+    db = e2e.dev[(n - 1) % e2e.RING]
+    assert bool(torch.isfinite(db["flow"]).all()) and float(db["depth"].max()) <= 65535 and int(db["mask"].min()) >= 0
+    assert nodes.g_det is not None and nodes.det_overflows == 0 and 0 < e2e.n_det[-1] <= 100
+    poses_dev = [T.copy() for T in e2e.poses]
     e2e.close(); slam.close()
+    # the same clip through round 2's hand-over (maps to pinned host buffers, TrackRGBD uploads them again): the device-resident hand-over changes where the maps live,
+    # not what the tracker computes
+    slam = System(); slam.Init(_settings(tmp_path, scene), System.RGBD)
+    e2e = pipeline.EndToEnd(nodes, slam, n_image=10 ** 6, feed="given", handover="host")
+    for k in range(n):
+        g, d, f, m = scene.frame(k)
+        e2e.push(synth.gray_to_bgr(g), (np.ascontiguousarray(d, np.float32), np.ascontiguousarray(f, np.float32), np.ascontiguousarray(m, np.int32)))
+    e2e.finish()
+    for a, b in zip(poses_dev, e2e.poses):
+        assert np.array_equal(a, b)
+    e2e.close(); slam.close()
+
+
+def test_static_detector_head_equals_the_dynamic_one(vido):
+    """nets/maskrcnn.py::heads_static / analyse_image_static (fixed shapes, no host synchronisation, one hipGraph with the trunk) against heads() / analyse_image (the
+    reference's data-dependent flow, validated stage by stage against the reference fixture in test_maskrcnn_gpu.py) on the SAME trunk outputs of the full-size detector:
+    same detections in the same order, same masks, same label image."""
+    from vido_slam_amd import pipeline, synth, nets
+    net_ctx = vido.Context(width=640, height=480, max_batch=1)
+    nodes = pipeline.NetNodes(net_ctx, 480, 640)
+    net = nodes.mask_net
+    scene = synth.convoy_scene(3)
+    for k in range(2):
+        bgr = torch.as_tensor(synth.gray_to_bgr(scene.frame(k)[0]), device="cuda")
+        with torch.no_grad():
+            feats, logits, deltas = nodes.g_trunk(bgr)
+            dyn = net.heads(feats, logits, deltas, nodes.mask_feed)
+            sta = net.heads_static(feats, logits, deltas, nodes.mask_feed)
+            n = int(sta["n_det"])
+            assert n == len(dyn["boxes"]) and 0 < n <= 100
+            assert torch.equal(sta["labels"][:n], dyn["labels"]) and torch.equal(sta["scores"][:n], dyn["scores"]) and torch.equal(sta["boxes"][:n], dyn["boxes"])
+            assert float((sta["masks"][:n] - dyn["masks"]).abs().max()) < 1e-4                     # the mask head sees batch 100 instead of a bucket: other MIOpen kernels
+            assert bool((sta["labels"][n:] == 0).all()) and bool((sta["boxes"][n:] == 0).all())
+            img_s, lab_s, n_lab, n_det = nets.analyse_image_static(net, feats, logits, deltas, (480, 640), feed=nodes.mask_feed, confidence=nodes.confidence)
+            img_d, lab_d = nets.analyse_image(net, bgr, feed=nodes.mask_feed, confidence=nodes.confidence, trunk=nodes.g_trunk)
+            assert int(n_det) == n and int(n_lab) == len(lab_d)
+            assert sorted(lab_s[:int(n_lab)].tolist()) == sorted(lab_d.tolist()) and bool((lab_s[int(n_lab):] == 0).all())
+            assert float((img_s != img_d).float().mean()) < 1e-3                                    # isolated pixels at the 0.5 threshold of the pasted masks
+            # and the captured graph returns the same as the eager static head
+            mask_g, lab_g, n_lab_g, n_det_g = nodes.g_det(bgr)
+            assert int(n_det_g) == n and float((mask_g.to(torch.uint8) != img_s).float().mean()) < 1e-3
+
+
+def test_feed_nets_hand_over_contract_at_full_size(vido, oracle):
+    """BASELINE configs[2] -> configs[1] with the networks' OWN outputs (bench.py --feed nets), 10 frames, deterministic weights, full-size nodes (LiteFlowNet at 640x480 with
+    its half-resolution flow upsampled, MonoDepth2's MONO16 disparity image, Mask R-CNN's u8 label image): the tracker's front end on the device-resident maps
+    (vido_frontend_batch through NetNodes' graphs) against the oracle fed the same maps — keypoints, descriptors, static candidates and dense object samples bit-exact."""
+    from vido_slam_amd import pipeline, synth
+    W, H = 640, 480
+    net_ctx = vido.Context(width=W, height=H, max_batch=1)
+    nodes = pipeline.NetNodes(net_ctx, H, W)
+    ctx = vido.Context(width=W, height=H, max_batch=1)
+    p = vido.track_params(dataset=2, depth_map_factor=256.0, bf=387.57, kaist_scale=1.2, th_depth_bg=80.0, th_depth_obj=60.0)      # MONO16 disparity -> metres like the KAIST settings
+    ff = vido.FrameFeatures(ctx, p)
+    op = oracle.orb_params(n_features=2000, scale_factor=1.2, n_levels=8, ini_th=20, min_th=7)
+    scene = synth.convoy_scene(12)
+    prev = None; seen_obj = 0
+    for k in range(11):
+        bgr_h = synth.gray_to_bgr(scene.frame(k)[0])
+        cur = torch.as_tensor(bgr_h, device="cuda")
+        if prev is None:
+            prev = cur; continue
+        flow, depth, mask, labels, evs = nodes.infer(prev, cur)
+        flow, depth, mask = flow.clone(), depth.clone(), mask.clone()
+        torch.cuda.synchronize()
+        assert flow.shape == (H, W, 2) and depth.dtype == torch.float32 and float(depth.max()) <= 65535 and mask.dtype == torch.int32 and int(mask.max()) <= 255
+        fh, dh, mh = flow.cpu().numpy(), depth.cpu().numpy(), mask.cpu().numpy()
+        gray = pipeline.bgr_to_gray(cur)
+        torch.cuda.synchronize()                                     # the front end runs on its context's own stream
+        out = ff.frontend_batch(k & 1, (gray.data_ptr(), 1, H, W, H * W, W), depth.data_ptr(), flow.data_ptr(), mask.data_ptr(), alias=True)
+        n_kp, n_stat, n_obj = int(out["n_kp"][0]), int(out["n_stat"][0]), int(out["n_obj"][0])
+        g = oracle.bgr2gray(bgr_h)
+        assert np.array_equal(g, gray.cpu().numpy())
+        rk, rd, _ = oracle.orb_extract(op, g)
+        assert n_kp == len(rk) and n_kp > 500
+        kp = np.array(out["kps"][0])[:n_kp]
+        for f in ("x", "y", "size", "angle", "response", "octave"):
+            assert np.array_equal(kp[f], rk[f]), (k, f)
+        assert np.array_equal(np.array(out["desc"][0])[:n_kp], rd)
+        dref = oracle.depth_prescale(dh.copy(), 2, p.depth_map_factor, p.bf, p.kaist_scale)
+        i, c, fl, dd = oracle.static_candidates(rk, dref, fh, mh, p.th_depth_bg)
+        assert n_stat == len(i)
+        assert np.array_equal(np.array(out["stat_idx"][0])[:n_stat], i) and np.array_equal(np.array(out["stat_corr"][0])[:n_stat], c)
+        assert np.array_equal(np.array(out["stat_flow"][0])[:n_stat], fl) and np.array_equal(np.array(out["stat_depth"][0])[:n_stat], dd)
+        kk, cc, od, lab, ofl = oracle.dense_object_samples(dref, fh, mh, p.th_depth_obj)
+        assert n_obj == len(kk)
+        assert np.array_equal(np.array(out["obj_keys"][0])[:n_obj], kk) and np.array_equal(np.array(out["obj_label"][0])[:n_obj], lab)
+        assert np.array_equal(np.array(out["obj_depth"][0])[:n_obj], od) and np.array_equal(np.array(out["obj_flow"][0])[:n_obj], ofl)
+        seen_obj += n_obj
+        prev = cur

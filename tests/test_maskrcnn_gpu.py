@@ -102,6 +102,23 @@ def test_device_side_head_ops_match_the_host_forms(ctx, oracle):
     for l in range(4):
         idx = torch.nonzero(lvl == l).squeeze(1)
         assert torch.equal(got[idx], ops.roi_align(feats[l], rois[idx], (7, 7), scales[l], 2)), l
+    # the channels-last form (what the detector calls: one transpose per level and frame) against the oracle, C = 256 and a C that is not a multiple of the 64-channel
+    # groups; sampling_ratio 2 (the node's) and 0 (adaptive grid); boxes partly outside the maps
+    for Cc, res, sr in ((256, 7, 2), (256, 14, 2), (100, 7, 0)):
+        feats = [torch.randn(1, Cc, 64 >> l, 80 >> l, device="cuda") for l in range(4)]
+        nh = [ops.to_nhwc(f) for f in feats]
+        for f, t in zip(feats, nh):
+            assert torch.equal(t, f.permute(0, 2, 3, 1).contiguous())
+        xy = rng.uniform(-30, 300, (n, 2)); wh = rng.uniform(1, 160, (n, 2))
+        b = torch.from_numpy(np.concatenate([xy, xy + wh], 1).astype(np.float32)).cuda()
+        got = ops.roi_align_fpn_nhwc(nh, b, lvl, (res, res), scales, sr).cpu().numpy()
+        assert np.array_equal(got, ops.roi_align_fpn(feats, b, lvl, (res, res), scales, sr).cpu().numpy())
+        rois = np.concatenate([np.zeros((n, 1), np.float32), b.cpu().numpy()], 1)
+        lv = lvl.cpu().numpy()
+        for l in range(4):
+            idx = np.nonzero(lv == l)[0]
+            ref = oracle.roi_align(feats[l].cpu().numpy(), rois[idx], scales[l], res, res, sr)
+            assert np.array_equal(got[idx], ref), (Cc, res, sr, l)
     # Masker + label image
     nd, Hh, Ww = 37, 120, 200
     masks = torch.rand(nd, 1, 28, 28, device="cuda")

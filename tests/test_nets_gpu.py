@@ -35,6 +35,12 @@ def test_nms_random_vs_oracle(ops, oracle):
         boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32); scores = rng.uniform(0, 1, n).astype(np.float32)
         assert np.array_equal(ops.nms(boxes, scores, th), oracle.nms(boxes, scores, th).astype(np.int64)), (n, th)
     assert len(ops.nms(np.zeros((0, 4), np.float32), np.zeros(0, np.float32), 0.5)) == 0
+    # clustered boxes: long suppression chains across the 64-box tiles of the bit matrix (upper-triangle tiles only are computed), exact duplicates (IoU = 1), ties in score
+    cen = rng.uniform(50, 400, (30, 2)); c = cen[rng.randint(0, 30, 3000)] + rng.normal(0, 3, (3000, 2)); wh = rng.uniform(40, 80, (3000, 2))
+    boxes = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32); boxes[100:140] = boxes[60:100]
+    scores = np.round(rng.uniform(0, 1, 3000), 2).astype(np.float32)
+    for th in (0.3, 0.5, 0.7):
+        assert np.array_equal(ops.nms(boxes, scores, th), oracle.nms(boxes, scores, th).astype(np.int64)), th
 
 
 def test_roi_align_vs_oracle_bit_exact(ops, oracle):

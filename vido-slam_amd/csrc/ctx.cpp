@@ -109,6 +109,13 @@ int vido_set_stream(vido_ctx* ctx, void* hip_stream, int enable)
     return VIDO_OK;
 }
 
+int vido_stream_wait_event(vido_ctx* ctx, void* hip_event)
+{
+    if (!ctx || !hip_event) return VIDO_E_INVALID;
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)hip_event, 0));
+    return VIDO_OK;
+}
+
 int vido_synchronize(vido_ctx* ctx)
 {
     if (!ctx) return VIDO_E_INVALID;

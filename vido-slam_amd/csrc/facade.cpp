@@ -100,7 +100,12 @@ void ORBextractor::operator()(const cv::Mat& image, const cv::Mat&, std::vector<
     const int cap = 2 * nfeatures + 256; int n = 0;
     std::vector<vido_keypoint> k(cap); cv::Mat desc(cap, 32, CV_8U);
     int rc;
-    if (color_ && gray_ == image.data && color_->cols == image.cols && color_->rows == image.rows && image.isContinuous())      // cvtColor on the device (SetColorSource)
+    if (dev_src_) {                                            // device-resident image (SetDeviceSource): colour -> fused cvtColor ingest, gray -> plain ingest; no host pixels involved
+        if (dev_ch_ == 1) rc = vido_orb_extract_batch(c, (const uint8_t*)dev_src_, 1, 1, (size_t)image.cols * image.rows, image.cols, image.cols, image.rows, k.data(), cap, &n, desc.data);
+        else rc = vido_orb_extract_color(c, (const uint8_t*)dev_src_, dev_ch_, rgb_ ? 1 : 0, 1, 1, 0, image.cols * dev_ch_, image.cols, image.rows, nullptr, k.data(), cap, &n, desc.data);
+        dev_src_ = nullptr;
+    }
+    else if (color_ && gray_ == image.data && color_->cols == image.cols && color_->rows == image.rows && image.isContinuous())      // cvtColor on the device (SetColorSource)
         rc = vido_orb_extract_color(c, color_->data, color_->channels(), rgb_ ? 1 : 0, 0, 1, 0, (int)color_->step, image.cols, image.rows, image.data, k.data(), cap, &n, desc.data);
     else rc = vido_orb_extract(c, image.data, (int)image.step, image.cols, image.rows, k.data(), cap, &n, desc.data);
     color_ = nullptr; gray_ = nullptr;
@@ -623,7 +628,7 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
     memset(&g_tp, 0, sizeof g_tp);
     g_tp.dataset = mTestData == OMD ? 0 : (mTestData == KITTI ? 1 : 2); g_tp.depth_map_factor = mDepthMapFactor; g_tp.bf = mbf; g_tp.kaist_scale = mScale;
     g_tp.th_depth_bg = mThDepth; g_tp.th_depth_obj = mThDepthObj; g_tp.dense_step = 4; g_tp.fx = mK.at<float>(0, 0); g_tp.fy = mK.at<float>(1, 1); g_tp.cx = mK.at<float>(0, 2); g_tp.cy = mK.at<float>(1, 2);
-    const int slot_last = slot_cur_; slot_cur_ = (mState == NO_IMAGES_YET) ? 0 : 1 - slot_cur_; g_slot = slot_cur_;
+    slot_cur_ = (mState == NO_IMAGES_YET) ? 0 : 1 - slot_cur_; g_slot = slot_cur_;
     // depth pre-scale in place on the caller's buffer (:299-322) + maps resident in the slot
     check(vido_frame_upload(c, slot_cur_, 1, imD.ptr<float>(), imFlow.ptr<float>(), maskSEM.ptr<int32_t>(), 0, &g_tp), "frame_upload");
     if (imRGB.channels() == 1) mImGray = imRGB;
@@ -632,12 +637,43 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
         mImGray = cv::Mat(imRGB.rows, imRGB.cols, CV_8UC1);
         mpORBextractorLeft->SetColorSource(imRGB, mbRGB, mImGray);
     }
-    mDepthMap = imD; mFlowMap = imFlow; mSegMap = maskSEM.clone();
+    mDepthMap = imD; mFlowMap = imFlow; mSegMap = maskSEM;      // shallow references like the reference keeps (Tracking.cc:343-345); the host-side stages read the device slot
+    return GrabCommon(timestamp, nImage, (void*)&t_grab);
+}
+
+cv::Mat Tracking::GrabImageRGBDDevice(const void* im_dev, int channels, int width, int height, float* depth_dev, const float* flow_dev, const int* mask_dev, void* ready_event,
+                                      const double& timestamp, const int& nImage)
+{
+    const auto t_grab = std::chrono::steady_clock::now();
+    StopFrame = nImage - 1;
+    if (mState == NO_IMAGES_YET) f_id = 0;
+    if (!im_dev || !depth_dev || !flow_dev || !mask_dev || width < 1 || height < 1 || (channels != 1 && channels != 3 && channels != 4))
+        throw std::runtime_error("GrabImageRGBDDevice: device image (1 / 3 / 4 channels), depth, flow and mask pointers expected");
+    vido_ctx* c = mpORBextractorLeft->context(width, height);
+    g_ctx = c;
+    if (ready_event) check(vido_stream_wait_event(c, ready_event), "stream_wait_event");      // ordered behind the producer (the network stream) without a host wait
+    memset(&g_tp, 0, sizeof g_tp);
+    g_tp.dataset = mTestData == OMD ? 0 : (mTestData == KITTI ? 1 : 2); g_tp.depth_map_factor = mDepthMapFactor; g_tp.bf = mbf; g_tp.kaist_scale = mScale;
+    g_tp.th_depth_bg = mThDepth; g_tp.th_depth_obj = mThDepthObj; g_tp.dense_step = 4; g_tp.fx = mK.at<float>(0, 0); g_tp.fy = mK.at<float>(1, 1); g_tp.cx = mK.at<float>(0, 2); g_tp.cy = mK.at<float>(1, 2);
+    slot_cur_ = (mState == NO_IMAGES_YET) ? 0 : 1 - slot_cur_; g_slot = slot_cur_;
+    check(vido_frame_upload(c, slot_cur_, 1, depth_dev, flow_dev, (const int32_t*)mask_dev, 1, &g_tp), "frame_upload");      // device -> slot (no PCIe), depth pre-scale in place
+    mImGray = cv::Mat(height, width, CV_8UC1);                  // size carrier: the pixels stay on the device (ORBextractor::SetDeviceSource)
+    mpORBextractorLeft->SetDeviceSource(im_dev, channels, mbRGB);
+    mDepthMap = cv::Mat(); mFlowMap = cv::Mat(); mSegMap = cv::Mat();
+    return GrabCommon(timestamp, nImage, (void*)&t_grab);
+}
+
+cv::Mat Tracking::GrabCommon(const double& timestamp, const int& nImage, void* t_grab_p)
+{
+    (void)nImage;
+    const auto t_grab = *(const std::chrono::steady_clock::time_point*)t_grab_p;
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    vido_ctx* c = g_ctx;
+    cv::Mat imD, imFlow;                                        // Frame's map arguments are unused (the slot holds the maps)
     all_timing.assign(5, 0.f);
     auto t_st = std::chrono::steady_clock::now();
     if (mState != NO_IMAGES_YET) UpdateMask();
     ms_update_mask = ms_since(t_st); t_st = std::chrono::steady_clock::now();
-    (void)slot_last;
     mpCurrentFrame = new Frame(mImGray, imD, imFlow, mSegMap, timestamp, mpORBextractorLeft, mK, mDistCoef, mbf, mThDepth, mThDepthObj, nUseSampleFea);
     if (mState != NO_IMAGES_YET) {                             // :369-421
         Frame* F = mpCurrentFrame;
@@ -671,7 +707,7 @@ void Tracking::UpdateMask()                                   // Tracking.cc:329
     for (int i = 0; i < n; i++) { corr[2 * i] = L->mvObjCorres[i].pt.x; corr[2 * i + 1] = L->mvObjCorres[i].pt.y; }
     int32_t rec[64], nrec = 0;
     check(vido_update_mask(g_ctx, 1 - slot_cur_, slot_cur_, L->vSemObjLabel.data(), corr.data(), n, rec, 64, &nrec), "update_mask");
-    if (nrec > 0) check(vido_read_maps(g_ctx, slot_cur_, nullptr, nullptr, mSegMap.ptr<int32_t>()), "read_maps");     // host copy used by RenewFrameInfo
+    (void)nrec;                                                 // the recovered labels live in the device slot's mask; RenewFrameInfo samples it there
 }
 
 void Tracking::Initialization()                               // Tracking.cc:1512-1580
@@ -849,16 +885,24 @@ std::vector<std::vector<std::pair<int, int> > > Tracking::GetDynamicTrackNew()  
 void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:2959-3289: vido_renew_static / vido_renew_objects (trackhost.cpp) + depth / 3-D point assembly
 {
     Frame* C = mpCurrentFrame; const int W = mImGray.cols, H = mImGray.rows;
-    vido_host_maps maps; maps.mask = mSegMap.ptr<int32_t>(); maps.depth = mDepthMap.ptr<float>(); maps.flow = mFlowMap.ptr<float>(); maps.width = W; maps.height = H;
     // ---- static features (:2973-3105)
     const std::vector<cv::KeyPoint> sample_src = nUseSampleFea == 1 ? C->mvStatKeysTmp : C->mvKeys;      // Tracking.cc:3013-3018 (a copy: mvStatKeysTmp is rewritten below)
     const int ns = (int)C->mvStatKeys.size(), nk = (int)sample_src.size();
     std::vector<float> sxy(2 * std::max(ns, 1)), kxy(2 * std::max(nk, 1));
     for (int i = 0; i < ns; i++) { sxy[2 * i] = C->mvStatKeys[i].pt.x; sxy[2 * i + 1] = C->mvStatKeys[i].pt.y; }
     for (int i = 0; i < nk; i++) { kxy[2 * i] = sample_src[i].pt.x; kxy[2 * i + 1] = sample_src[i].pt.y; }
+    // the values of mSegMap / mDepthMap / mFlowMap at the candidate points of both parts, from the device slot in ONE gather: [static list | sample source | object points]
+    // (the maps themselves never come to the host; the slot's mask carries UpdateMask's recovered labels, its depth is the pre-scaled one)
+    const int no_pts = (int)C->mvObjKeys.size(), n_all = ns + nk + no_pts;
+    std::vector<float> axy(2 * (size_t)std::max(n_all, 1)), sdep(std::max(n_all, 1)), sflo(2 * (size_t)std::max(n_all, 1)); std::vector<int32_t> smsk(std::max(n_all, 1));
+    memcpy(axy.data(), sxy.data(), sizeof(float) * 2 * ns); memcpy(axy.data() + 2 * (size_t)ns, kxy.data(), sizeof(float) * 2 * nk);
+    for (int i = 0; i < no_pts; i++) { axy[2 * (size_t)(ns + nk + i)] = C->mvObjKeys[i].pt.x; axy[2 * (size_t)(ns + nk + i) + 1] = C->mvObjKeys[i].pt.y; }
+    check(vido_gather_point_samples(g_ctx, slot_cur_, axy.data(), n_all, smsk.data(), sdep.data(), sflo.data()), "gather_point_samples");
+    const vido_point_samples ss = {smsk.data(), sdep.data(), sflo.data()}, ks = {smsk.data() + ns, sdep.data() + ns, sflo.data() + 2 * (size_t)ns},
+                             os = {smsk.data() + ns + nk, sdep.data() + ns + nk, sflo.data() + 2 * (size_t)(ns + nk)};
     const int cap = (int)TM_sta.size() + nk + 8;
     std::vector<int32_t> src(cap), inl(cap); std::vector<float> fl(2 * (size_t)cap); int32_t n = 0;
-    if (vido_renew_static(&maps, sxy.data(), ns, TM_sta.data(), (int)TM_sta.size(), kxy.data(), nk, nMaxTrackPointBG, src.data(), inl.data(), fl.data(), cap, &n) != VIDO_OK)
+    if (vido_renew_static_sampled(W, H, sxy.data(), ns, &ss, TM_sta.data(), (int)TM_sta.size(), kxy.data(), nk, &ks, nMaxTrackPointBG, src.data(), inl.data(), fl.data(), cap, &n) != VIDO_OK)
         throw std::runtime_error("RenewFrameInfo: vido_renew_static failed");
     std::vector<cv::KeyPoint> keys(n), corres(n); std::vector<cv::Point2f> flows(n); std::vector<int> inlierID(n);
     for (int k = 0; k < n; k++) {
@@ -869,7 +913,7 @@ void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:29
     C->N_s_tmp = n;
     std::vector<float> depth(n, -1.f); std::vector<cv::Mat> p3d(n);
     const cv::Mat Twc = Converter::toInvMatrix(C->mTcw);
-    for (int i = 0; i < n; i++) { const float d = mDepthMap.at<float>((int)keys[i].pt.y, (int)keys[i].pt.x); if (d > 0) depth[i] = d; p3d[i] = Optimizer::Get3DinWorld(keys[i], depth[i], mK, Twc); }
+    for (int i = 0; i < n; i++) { const float d = inl[i] >= 0 ? ss.depth[src[i]] : ks.depth[src[i]]; if (d > 0) depth[i] = d; p3d[i] = Optimizer::Get3DinWorld(keys[i], depth[i], mK, Twc); }      // mDepthMap.at(key)
     C->nStaInlierID = inlierID; C->mvStatKeysTmp = keys; C->mvStatDepthTmp = depth; C->mvStat3DPointTmp = p3d; C->mvFlowNext = flows; C->mvCorres = corres;
 
     // ---- objects (:3116-3289)
@@ -883,7 +927,7 @@ void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:29
     if (iids.empty()) iids.push_back(0);
     const int ocap = (int)iids.size() + (nobj + 1) * nt + 8;
     std::vector<float> okx(2 * (size_t)ocap), odep(ocap), ofl(2 * (size_t)ocap), oco(2 * (size_t)ocap); std::vector<int32_t> osem(ocap), oinl(ocap), olab(ocap); int32_t on = 0;
-    if (vido_renew_objects(&maps, oxy.data(), C->vObjLabel.data(), no, nobj, ioff.data(), iids.data(), ostat.data(), C->nSemPosition.data(), C->nModLabel.data(),
+    if (vido_renew_objects_sampled(W, H, oxy.data(), C->vObjLabel.data(), no, &os, nobj, ioff.data(), iids.data(), ostat.data(), C->nSemPosition.data(), C->nModLabel.data(),
                            txy.data(), mvTmpObjDepth.data(), mvTmpSemObjLabel.data(), tfl.data(), tco.data(), nt, nMaxTrackPointOBJ,
                            okx.data(), odep.data(), osem.data(), ofl.data(), oco.data(), oinl.data(), olab.data(), ocap, &on) != VIDO_OK)
         throw std::runtime_error("RenewFrameInfo: vido_renew_objects failed");
@@ -993,6 +1037,12 @@ cv::Mat System::TrackRGBD(const cv::Mat& im, cv::Mat& depthmap, const cv::Mat& f
     if (masksem.type() == CV_8UC1) { cv::Mat m32; masksem.convertTo(m32, CV_32SC1); return mpTracker->GrabImageRGBD(im, depthmap, flowmap, m32, Tgt, vObjPose_gt, ts, imTraj, nImage); }
     return mpTracker->GrabImageRGBD(im, depthmap, flowmap, masksem, Tgt, vObjPose_gt, ts, imTraj, nImage);
 }
+cv::Mat System::TrackRGBDDevice(const void* im_dev, int channels, int width, int height, float* depth_dev, const float* flow_dev, const int* mask_dev, void* ready_event,
+                                const double& ts, const int& nImage)
+{
+    if (mSensor != RGBD) throw std::runtime_error("ERROR: you called TrackRGBDDevice but input sensor was not set to RGBD.");
+    return mpTracker->GrabImageRGBDDevice(im_dev, channels, width, height, depth_dev, flow_dev, mask_dev, ready_event, ts, nImage);
+}
 void System::SaveResultsIJRR2020(const std::string& prefix)   // System.cc:80-240 (pose / motion files; GT files are not produced)
 {
     auto dump = [](const std::string& path, const std::vector<cv::Mat>& poses) {
@@ -1059,6 +1109,21 @@ int vido_system_track_rgbd(vido_system* s, const uint8_t* im, int channels, int 
         if (s->traj.empty()) s->traj = cv::Mat::zeros(600, 800, CV_8UC3);
         const cv::Mat id = cv::Mat::eye(4, 4, CV_32F); const std::vector<std::vector<float> > gt;
         cv::Mat T = s->sys.TrackRGBD(s->im, s->depth, s->flow, s->mask, id, gt, timestamp, s->traj, n_image);
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) Tcw_out[r * 4 + c] = T.at<float>(r, c);
+    } catch (const std::exception& e) {
+        s->err = e.what();
+        return s->err.find("exceed") != std::string::npos || s->err.find("capacity") != std::string::npos ? VIDO_E_CAPACITY : VIDO_E_HIP;
+    }
+    return VIDO_OK;
+}
+
+int vido_system_track_rgbd_device(vido_system* s, const void* im_dev, int channels, int width, int height, float* depth_dev, const float* flow_dev, const int32_t* mask_dev,
+                                  void* ready_event, double timestamp, int n_image, float Tcw_out[16])
+{
+    if (!s || !s->inited) return VIDO_E_INVALID;
+    if (!im_dev || !depth_dev || !flow_dev || !mask_dev || !Tcw_out || width <= 0 || height <= 0 || (channels != 1 && channels != 3 && channels != 4)) { s->err = "vido_system_track_rgbd_device: bad argument"; return VIDO_E_INVALID; }
+    try {
+        cv::Mat T = s->sys.TrackRGBDDevice(im_dev, channels, width, height, depth_dev, flow_dev, (const int*)mask_dev, ready_event, timestamp, n_image);
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) Tcw_out[r * 4 + c] = T.at<float>(r, c);
     } catch (const std::exception& e) {
         s->err = e.what();

@@ -104,72 +104,112 @@ __global__ __launch_bounds__(256) void k_bias_res_act(float* __restrict__ x, con
 }
 
 // ---- ROI-Align ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bilinear(const float* __restrict__ d, int h, int w, float y, float x)
+// MI355X form of ROIAlign_forward (maskrcnn_benchmark/csrc/cuda/ROIAlign_cuda.cu:15-122 defines the VALUES; the mapping below is this build's own):
+//  * the feature maps are read CHANNELS-LAST ([B][H][W][C]; k_nchw_to_nhwc makes that copy once per frame, shared by the box and the mask pooler): a bilinear tap of 64
+//    channels is ONE coalesced 256-byte wave load, where the channel-planar layout gave every lane its own cache line;
+//  * a workgroup owns (roi, 64 channels); its 4 waves split the PH x PW bins, lane = channel.  Sample coordinates, tap indices and the four weights depend on
+//    (roi, bin, sample) only, i.e. they are wave-uniform: computed once per sample for all 64 channels (no per-output-element index arithmetic);
+//  * per channel the arithmetic order is the reference's — w1*v1 + w2*v2 + w3*v3 + w4*v4 per sample, samples accumulated row-major, one division by the sample count —
+//    so the result is bit-identical to the oracle's restatement;
+//  * results go to an LDS tile [64 channels][bins] (odd pitch) and leave as ONE contiguous run of out[roi][c0 .. c0+63][PH][PW]: full-line stores although lanes run over channels.
+struct RoiLevels { const float* feat[4]; int H[4], W[4]; float scale[4]; };     // channels-last maps
+__global__ __launch_bounds__(256) void k_roi_align_nhwc(RoiLevels L, int C, const float* __restrict__ rois, int roi_stride /* 5: (batch, x1, y1, x2, y2); 4: (x1, y1, x2, y2) */,
+                                                        const int* __restrict__ level /* null: level 0 */, int PH, int PW, int sampling, float* __restrict__ out)
 {
-    if (y < -1.0 || y > h || x < -1.0 || x > w) return 0;
-    if (y <= 0) y = 0;
-    if (x <= 0) x = 0;
-    int yl = (int)y, xl = (int)x, yh, xh;
-    if (yl >= h - 1) { yh = yl = h - 1; y = (float)yl; } else yh = yl + 1;
-    if (xl >= w - 1) { xh = xl = w - 1; x = (float)xl; } else xh = xl + 1;
-    const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
-    const float v1 = d[yl * w + xl], v2 = d[yl * w + xh], v3 = d[yh * w + xl], v4 = d[yh * w + xh];
-    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-    return (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
-}
-__global__ __launch_bounds__(256) void k_roi_align(const float* __restrict__ feat, int C, int H, int W, const float* __restrict__ rois, int n,
-                                                   float scale, int PH, int PW, int sampling, float* __restrict__ out)
-{
-    const size_t total = (size_t)n * C * PH * PW;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int pw = (int)(idx % PW), ph = (int)((idx / PW) % PH), c = (int)((idx / PW / PH) % C), i = (int)(idx / PW / PH / C);
-        const float* r = rois + 5 * i;
-        const int bi = (int)r[0];
-        const float sw = r[1] * scale, sh = r[2] * scale, ew = r[3] * scale, eh = r[4] * scale;
-        const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);
-        const float bh = rh / (float)PH, bw = rw / (float)PW;
-        const int gh = sampling > 0 ? sampling : (int)ceilf(rh / PH), gw = sampling > 0 ? sampling : (int)ceilf(rw / PW);
-        const float count = (float)(gh * gw);
-        const float* d = feat + ((size_t)bi * C + c) * H * W;
-        float acc = 0;
+    extern __shared__ __attribute__((aligned(16))) float rl_tile[];
+    const int i = blockIdx.x, c0 = blockIdx.y * 64, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nbin = PH * PW, pitch = nbin | 1;
+    const float* r = rois + (size_t)roi_stride * i;
+    const int l = level ? level[i] : 0, bi = roi_stride == 5 ? (int)r[0] : 0;
+    const float* box = r + (roi_stride == 5 ? 1 : 0);
+    const float scale = L.scale[l]; const int H = L.H[l], W = L.W[l];
+    const float sw = box[0] * scale, sh = box[1] * scale, ew = box[2] * scale, eh = box[3] * scale;
+    const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);
+    const float bh = rh / (float)PH, bw = rw / (float)PW;
+    const int gh = sampling > 0 ? sampling : (int)ceilf(rh / PH), gw = sampling > 0 ? sampling : (int)ceilf(rw / PW);
+    const float count = (float)(gh * gw);
+    const int c = min(c0 + lane, C - 1);                                      // lanes past C repeat the last channel (their column of the tile is never written out)
+    const float* d = L.feat[l] + (size_t)bi * H * W * C + c;
+    for (int bin = wave; bin < nbin; bin += 4) {
+        const int ph = bin / PW, pw = bin - ph * PW;
+        float acc = 0.f;
         for (int iy = 0; iy < gh; iy++) {
-            const float y = sh + ph * bh + (float)(iy + .5f) * bh / (float)gh;
+            const float y0 = sh + ph * bh + (float)(iy + .5f) * bh / (float)gh;
             for (int ix = 0; ix < gw; ix++) {
-                const float x = sw + pw * bw + (float)(ix + .5f) * bw / (float)gw;
-                acc += bilinear(d, H, W, y, x);
+                float x = sw + pw * bw + (float)(ix + .5f) * bw / (float)gw, y = y0;
+                if (y < -1.0 || y > H || x < -1.0 || x > W) { acc += 0.f; continue; }      // bilinear_interpolate: outside the map by more than a pixel -> 0
+                if (y <= 0) y = 0;
+                if (x <= 0) x = 0;
+                int yl = (int)y, xl = (int)x, yh, xh;
+                if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+                if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
+                const float v1 = d[(size_t)(yl * W + xl) * C], v2 = d[(size_t)(yl * W + xh) * C], v3 = d[(size_t)(yh * W + xl) * C], v4 = d[(size_t)(yh * W + xh) * C];
+                const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                acc += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
             }
         }
-        out[idx] = acc / count;
+        rl_tile[lane * pitch + bin] = acc / count;
     }
+    __syncthreads();
+    const int nc = min(64, C - c0), total = nc * nbin;
+    float* o = out + ((size_t)i * C + c0) * nbin;
+    for (int e = threadIdx.x; e < total; e += 256) { const int cc = e / nbin; o[e] = rl_tile[cc * pitch + (e - cc * nbin)]; }
+}
+// [B][C][H][W] -> [B][H][W][C] through a 64 x 64 LDS tile: coalesced 256-byte runs on both sides
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ src, int C, int HW, float* __restrict__ dst)
+{
+    __shared__ float t[64][65];
+    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const float* s = src + (size_t)b * C * HW; float* d = dst + (size_t)b * HW * C;
+    for (int k = q; k < 64; k += 4) if (c0 + k < C && p0 + lane < HW) t[k][lane] = s[(size_t)(c0 + k) * HW + p0 + lane];
+    __syncthreads();
+    for (int k = q; k < 64; k += 4) if (p0 + k < HW && c0 + lane < C) d[(size_t)(p0 + k) * C + c0 + lane] = t[lane][k];
 }
 
 // ---- NMS (boxes sorted by descending score) ----------------------------------------------------------------------
-__device__ __forceinline__ float dev_iou(const float* a, const float* b)
+// Suppression bit matrix (the VALUES are nms.cu:13-67's: bit j of mask[i][cb] <=> IoU(box i, box cb*64+j) > thresh, "+1" box convention, j > i on the diagonal tile).
+// MI355X form: one WAVE per 64 x 64 tile, upper-triangle tiles only (the sweeps never read below the diagonal: a box is only suppressed by a better-scored one);
+// lane j keeps COLUMN box j and its area in registers for the whole tile, the 64 row boxes come in one at a time through wave-uniform (scalar) loads, and the
+// row's 64-bit word is the wave's BALLOT of "IoU > thresh" — one v_cmp per row instead of a 64-step per-lane loop over an LDS copy of the column boxes.
+__device__ __forceinline__ void tile_of(int t, int nb, int& rb, int& cb)
 {
-    const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]), top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
-    const float w = fmaxf(right - left + 1, 0.f), h = fmaxf(bottom - top + 1, 0.f), inter = w * h;
-    const float Sa = (a[2] - a[0] + 1) * (a[3] - a[1] + 1), Sb = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
-    return inter / (Sa + Sb - inter);
+    // linear index t over the upper triangle (row-major: row rb holds nb - rb tiles) -> (rb, cb)
+    int r = (int)((2.0f * nb + 1.0f - sqrtf((2.0f * nb + 1.0f) * (2.0f * nb + 1.0f) - 8.0f * (float)t)) * 0.5f);
+    r = max(0, min(r, nb - 1));
+    while (r > 0 && r * nb - r * (r - 1) / 2 > t) r--;
+    while ((r + 1) * nb - (r + 1) * r / 2 <= t) r++;
+    rb = r; cb = r + (t - (r * nb - r * (r - 1) / 2));
 }
-// mask[i][cb] bit j: box (cb*64+j) overlaps box i by more than thresh (only j > i inside the diagonal tile)
-__global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ group /* may be null */, int n, float thresh,
-                                                unsigned long long* __restrict__ mask, int col_blocks)
+__device__ __forceinline__ void nms_tile(const float* __restrict__ boxes, const int* __restrict__ group, int n, float thresh, unsigned long long* __restrict__ mask, int col_blocks, int rb, int cb, int lane)
 {
-    const int row_start = blockIdx.y, col_start = blockIdx.x;
-    const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
-    __shared__ float bb[64 * 4]; __shared__ int gg[64];
-    if ((int)threadIdx.x < col_size) { for (int k = 0; k < 4; k++) bb[threadIdx.x * 4 + k] = boxes[(size_t)(col_start * 64 + threadIdx.x) * 4 + k];
-                                        gg[threadIdx.x] = group ? group[col_start * 64 + threadIdx.x] : 0; }
-    __syncthreads();
-    if ((int)threadIdx.x < row_size) {
-        const int cur = row_start * 64 + threadIdx.x;
-        const float* cb = boxes + (size_t)cur * 4;
-        unsigned long long t = 0;
-        const int start = row_start == col_start ? threadIdx.x + 1 : 0;
-        const int g = group ? group[cur] : 0;                      // boxes of different groups (classes) never suppress each other
-        for (int i = start; i < col_size; i++) if (gg[i] == g && dev_iou(cb, bb + i * 4) > thresh) t |= 1ULL << i;
-        mask[(size_t)cur * col_blocks + col_start] = t;
+    const int col = cb * 64 + lane; const bool cv = col < n;
+    const float4 b = cv ? *(const float4*)(boxes + 4 * (size_t)col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float Sb = (b.z - b.x + 1) * (b.w - b.y + 1);
+    const int gb = (group && cv) ? group[col] : 0;
+    const int rows = min(n - rb * 64, 64);
+    unsigned long long mine = 0;
+    for (int i = 0; i < rows; i++) {
+        const float* a = boxes + 4 * (size_t)(rb * 64 + i);                      // wave-uniform address: scalar loads
+        const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+        const int ga = group ? group[rb * 64 + i] : 0;                           // boxes of different groups (classes) never suppress each other
+        const float left = fmaxf(a0, b.x), right = fminf(a2, b.z), top = fmaxf(a1, b.y), bottom = fminf(a3, b.w);
+        const float w = fmaxf(right - left + 1, 0.f), h = fmaxf(bottom - top + 1, 0.f), inter = w * h;
+        const float Sa = (a2 - a0 + 1) * (a3 - a1 + 1);
+        const bool hit = cv && ga == gb && inter / (Sa + Sb - inter) > thresh;
+        unsigned long long word = __ballot(hit);
+        if (rb == cb) word &= i >= 63 ? 0ull : ~((2ull << i) - 1ull);           // diagonal tile: only the boxes after i
+        if (lane == i) mine = word;
     }
+    if (lane < rows) mask[(size_t)(rb * 64 + lane) * col_blocks + cb] = mine;
+}
+__global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ group /* may be null */, int n, float thresh,
+                                                 unsigned long long* __restrict__ mask, int col_blocks)
+{
+    const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nb = col_blocks;      // wave-uniform: the row-box loads below become scalar loads
+    if (t >= nb * (nb + 1) / 2) return;
+    int rb, cb; tile_of(t, nb, rb, cb);
+    nms_tile(boxes, group, n, thresh, mask, col_blocks, rb, cb, threadIdx.x & 63);
 }
 // the reference does this sweep on the host after a D2H copy; here one wave owns the `remv` words (lane w <-> word w)
 __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long* __restrict__ mask, int n, int col_blocks, int* __restrict__ keep, int* __restrict__ n_keep)
@@ -246,56 +286,15 @@ __global__ __launch_bounds__(64) void k_nms_sweep_seg(const unsigned long long* 
     for (int i = cnt + lane; i < keep_stride; i += 64) kp[i] = -1;
     if (lane == 0) n_keep[g] = cnt;
 }
-// mask kernel for segments: grid (col block, row block, segment); tiles below the diagonal are never read by the sweep
-__global__ __launch_bounds__(64) void k_nms_mask_seg(const float* __restrict__ boxes, const int* __restrict__ group, const int* __restrict__ seg_off, const int* __restrict__ seg_n,
+// the same for independent segments (RPN levels, box-head classes): grid (tile quads, segment); a segment's rows start at seg_off[g], its bit columns are relative to that
+__global__ __launch_bounds__(256) void k_nms_mask_seg(const float* __restrict__ boxes, const int* __restrict__ group, const int* __restrict__ seg_off, const int* __restrict__ seg_n,
                                                      float thresh, unsigned long long* __restrict__ mask, int col_blocks)
 {
-    const int g = blockIdx.z, n = seg_n[g], off = seg_off[g];
-    const int row_start = blockIdx.y, col_start = blockIdx.x;
-    if (col_start < row_start || row_start * 64 >= n || col_start * 64 >= n) return;
-    const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
-    __shared__ float bb[64 * 4]; __shared__ int gg[64];
-    if ((int)threadIdx.x < col_size) { for (int k = 0; k < 4; k++) bb[threadIdx.x * 4 + k] = boxes[(size_t)(off + col_start * 64 + threadIdx.x) * 4 + k];
-                                        gg[threadIdx.x] = group ? group[off + col_start * 64 + threadIdx.x] : 0; }
-    __syncthreads();
-    if ((int)threadIdx.x < row_size) {
-        const int cur = row_start * 64 + threadIdx.x;
-        const float* cbx = boxes + (size_t)(off + cur) * 4;
-        unsigned long long t = 0;
-        const int start = row_start == col_start ? threadIdx.x + 1 : 0;
-        const int gme = group ? group[off + cur] : 0;
-        for (int i = start; i < col_size; i++) if (gg[i] == gme && dev_iou(cbx, bb + i * 4) > thresh) t |= 1ULL << i;
-        mask[(size_t)(off + cur) * col_blocks + col_start] = t;
-    }
-}
-
-// ---- ROI-Align over the FPN levels in one launch (modeling/poolers.py:97-121: LevelMapper + one ROIAlign per level + scatter back by index) -----------------
-struct FpnLevels { const float* feat[4]; int H[4], W[4]; float scale[4]; };
-__global__ __launch_bounds__(256) void k_roi_align_fpn(FpnLevels L, int C, const float* __restrict__ boxes /*[n,4]*/, const int* __restrict__ level, int n,
-                                                       int PH, int PW, int sampling, float* __restrict__ out)
-{
-    const size_t total = (size_t)n * C * PH * PW;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int pw = (int)(idx % PW), ph = (int)((idx / PW) % PH), c = (int)((idx / PW / PH) % C), i = (int)(idx / PW / PH / C);
-        const float* r = boxes + 4 * (size_t)i;
-        const int l = level[i];
-        const float scale = L.scale[l]; const int H = L.H[l], W = L.W[l];
-        const float sw = r[0] * scale, sh = r[1] * scale, ew = r[2] * scale, eh = r[3] * scale;
-        const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);
-        const float bh = rh / (float)PH, bw = rw / (float)PW;
-        const int gh = sampling > 0 ? sampling : (int)ceilf(rh / PH), gw = sampling > 0 ? sampling : (int)ceilf(rw / PW);
-        const float count = (float)(gh * gw);
-        const float* d = L.feat[l] + (size_t)c * H * W;
-        float acc = 0.f;
-        for (int iy = 0; iy < gh; iy++) {
-            const float y = sh + ph * bh + (iy + .5f) * bh / (float)gh;
-            for (int ix = 0; ix < gw; ix++) {
-                const float x = sw + pw * bw + (ix + .5f) * bw / (float)gw;
-                acc += bilinear(d, H, W, y, x);
-            }
-        }
-        out[idx] = acc / count;
-    }
+    const int g = blockIdx.y, n = seg_n[g], off = seg_off[g];
+    const int nb = (n + 63) >> 6, t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (t >= nb * (nb + 1) / 2) return;
+    int rb, cb; tile_of(t, nb, rb, cb);
+    nms_tile(boxes + 4 * (size_t)off, group ? group + off : nullptr, n, thresh, mask + (size_t)off * col_blocks, col_blocks, rb, cb, threadIdx.x & 63);
 }
 
 // ---- Masker + label image in one pass (mask_head/inference.py:87-160 paste_mask_in_image per detection on the host, then run_mask_rcnn.py:112-118
@@ -441,6 +440,17 @@ __global__ __launch_bounds__(256) void k_backwarp(const float* __restrict__ x, c
     }
 }
 
+// dynamic-LDS limit of k_roi_align_nhwc: raised only when a call needs more than any earlier one (the attribute call is kept out of hipGraph captures, whose
+// replays run with the limit the warm-up calls have set)
+static int roi_lds_limit(vido_ctx* ctx, size_t lds)
+{
+    static size_t have = 48 * 1024;
+    if (lds <= have) return VIDO_OK;
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_roi_align_nhwc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    have = lds;
+    return VIDO_OK;
+}
+
 extern "C" {
 
 int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int B, int C, int H, int W, int stride, float* out, int on_device)
@@ -526,6 +536,18 @@ int vido_bias_res_act(vido_ctx* ctx, float* x, const float* bias, const float* r
     return VIDO_OK;
 }
 
+/* [B][C][H][W] -> [B][H][W][C] on DEVICE tensors (f32): the layout the ROI-Align kernel reads (lanes across channels). */
+int vido_nchw_to_nhwc(vido_ctx* ctx, const float* src, int B, int C, int H, int W, float* dst)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!src || !dst || B < 1 || C < 1 || H < 1 || W < 1 || B > 65535) return vido_set_error(ctx, VIDO_E_INVALID, "nchw_to_nhwc: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((H * W + 63) / 64, (C + 63) / 64, B), dim3(256), 0, st, src, C, H * W, dst);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
 int vido_roi_align(vido_ctx* ctx, const float* feat, int B, int C, int H, int W, const float* rois, int n_rois, float spatial_scale,
                    int pooled_h, int pooled_w, int sampling_ratio, float* out, int on_device)
 {
@@ -536,15 +558,22 @@ int vido_roi_align(vido_ctx* ctx, const float* feat, int B, int C, int H, int W,
     hipStream_t st = (on_device && ctx->has_ext_stream) ? ctx->ext_stream : ctx->stream;
     const size_t nf = (size_t)B * C * H * W * 4, nr = (size_t)n_rois * 5 * 4, nout = (size_t)n_rois * C * pooled_h * pooled_w * 4;
     const float *df = feat, *dr = rois; float* dout = out; NetState* S = nullptr;
+    // scratch: [host staging of map | rois | out]  (host callers only)  +  the channels-last copy of the map
+    const size_t base = on_device ? 0 : al256(nf) + al256(nr) + al256(nout);
+    { int rc = net_scratch(ctx, base + al256(nf), &S); if (rc) return rc; }
     if (!on_device) {
         for (int i = 0; i < n_rois; i++) if (!(rois[5 * i] >= 0 && rois[5 * i] < B)) return vido_set_error(ctx, VIDO_E_INVALID, "roi_align: roi %d has batch index %g", i, rois[5 * i]);
-        int rc = net_scratch(ctx, al256(nf) + al256(nr) + al256(nout), &S); if (rc) return rc;
         memcpy(S->h, feat, nf); memcpy(S->h + al256(nf), rois, nr);
         HIP_TRY(ctx, hipMemcpyAsync(S->d, S->h, al256(nf) + al256(nr), hipMemcpyHostToDevice, st));
         df = (float*)S->d; dr = (float*)(S->d + al256(nf)); dout = (float*)(S->d + al256(nf) + al256(nr));
     }
-    const size_t total = (size_t)n_rois * C * pooled_h * pooled_w;
-    hipLaunchKernelGGL(k_roi_align, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, st, df, C, H, W, dr, n_rois, spatial_scale, pooled_h, pooled_w, sampling_ratio, dout);
+    float* nhwc = (float*)(S->d + base);
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((H * W + 63) / 64, (C + 63) / 64, B), dim3(256), 0, st, df, C, H * W, nhwc);
+    RoiLevels L{}; L.feat[0] = nhwc; L.H[0] = H; L.W[0] = W; L.scale[0] = spatial_scale;
+    const size_t lds = (size_t)64 * ((pooled_h * pooled_w) | 1) * sizeof(float);
+    if (lds > 150 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "roi_align: pooled size %d x %d too large", pooled_h, pooled_w);
+    { int rc = roi_lds_limit(ctx, lds); if (rc) return rc; }
+    hipLaunchKernelGGL(k_roi_align_nhwc, dim3(n_rois, (C + 63) / 64), dim3(256), lds, st, L, C, dr, 5, (const int*)nullptr, pooled_h, pooled_w, sampling_ratio, dout);
     HIP_TRY(ctx, hipGetLastError());
     if (!on_device) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -586,7 +615,7 @@ static int nms_impl(vido_ctx* ctx, const float* boxes_xyxy, const float* scores,
             HIP_TRY(ctx, hipMemcpyAsync(dg, hg, ng, hipMemcpyHostToDevice, st)); dgroups = dg;
         }
     }
-    hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb), dim3(64), 0, st, dboxes, dgroups, n, thresh, dmask, cb);
+    hipLaunchKernelGGL(k_nms_mask, dim3((cb * (cb + 1) / 2 + 3) / 4), dim3(256), 0, st, dboxes, dgroups, n, thresh, dmask, cb);
     hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, st, dmask, n, cb, dkeep, dn);
     HIP_TRY(ctx, hipGetLastError());
     if (!on_device) {
@@ -628,7 +657,7 @@ int vido_nms_segments(vido_ctx* ctx, const float* boxes_xyxy, const int32_t* gro
     NetState* S = nullptr;
     int rc = net_scratch(ctx, al256((size_t)total * cb * 8), &S); if (rc) return rc;
     unsigned long long* dmask = (unsigned long long*)S->d;
-    hipLaunchKernelGGL(k_nms_mask_seg, dim3(cb, cb, n_seg), dim3(64), 0, st, boxes_xyxy, groups, seg_off, seg_n, thresh, dmask, cb);
+    hipLaunchKernelGGL(k_nms_mask_seg, dim3((cb * (cb + 1) / 2 + 3) / 4, n_seg), dim3(256), 0, st, boxes_xyxy, groups, seg_off, seg_n, thresh, dmask, cb);
     hipLaunchKernelGGL(k_nms_sweep_seg, dim3(n_seg), dim3(64), 0, st, dmask, seg_off, seg_n, cb, keep_out, n_keep, max_n);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
@@ -644,10 +673,34 @@ int vido_roi_align_fpn(vido_ctx* ctx, const float* const feat[4], const int H[4]
     if (n == 0) return VIDO_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
-    FpnLevels L;
+    // channel-planar maps: channels-last copies in the scratch first (callers that pool twice from the same maps use vido_nchw_to_nhwc + vido_roi_align_fpn_nhwc)
+    size_t off[5] = {0, 0, 0, 0, 0};
+    for (int l = 0; l < 4; l++) off[l + 1] = off[l] + al256((size_t)C * H[l] * W[l] * 4);
+    NetState* S = nullptr;
+    { int rc = net_scratch(ctx, off[4], &S); if (rc) return rc; }
+    const float* nh[4];
+    for (int l = 0; l < 4; l++) {
+        hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((H[l] * W[l] + 63) / 64, (C + 63) / 64, 1), dim3(256), 0, st, feat[l], C, H[l] * W[l], (float*)(S->d + off[l]));
+        nh[l] = (const float*)(S->d + off[l]);
+    }
+    return vido_roi_align_fpn_nhwc(ctx, nh, H, W, scale, C, boxes, level, n, pooled_h, pooled_w, sampling_ratio, out);
+}
+
+/* The same with CHANNELS-LAST maps feat[l] = [H[l]][W[l]][C] (vido_nchw_to_nhwc): what the detector calls — one copy per frame serves the box and the mask pooler. */
+int vido_roi_align_fpn_nhwc(vido_ctx* ctx, const float* const feat[4], const int H[4], const int W[4], const float scale[4], int C, const float* boxes, const int32_t* level,
+                            int n, int pooled_h, int pooled_w, int sampling_ratio, float* out)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!feat || !H || !W || !scale || C < 1 || n < 0 || pooled_h < 1 || pooled_w < 1 || (n && (!boxes || !level || !out))) return vido_set_error(ctx, VIDO_E_INVALID, "roi_align_fpn_nhwc: bad arguments");
+    if (n == 0) return VIDO_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    RoiLevels L;
     for (int l = 0; l < 4; l++) { L.feat[l] = feat[l]; L.H[l] = H[l]; L.W[l] = W[l]; L.scale[l] = scale[l]; }
-    const size_t total = (size_t)n * C * pooled_h * pooled_w;
-    hipLaunchKernelGGL(k_roi_align_fpn, dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, st, L, C, boxes, level, n, pooled_h, pooled_w, sampling_ratio, out);
+    const size_t lds = (size_t)64 * ((pooled_h * pooled_w) | 1) * sizeof(float);
+    if (lds > 150 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "roi_align_fpn: pooled size %d x %d too large", pooled_h, pooled_w);
+    { int rc = roi_lds_limit(ctx, lds); if (rc) return rc; }
+    hipLaunchKernelGGL(k_roi_align_nhwc, dim3(n, (C + 63) / 64), dim3(256), lds, st, L, C, boxes, 4, level, pooled_h, pooled_w, sampling_ratio, out);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }

@@ -155,6 +155,17 @@ __global__ void k_gather_object(const float* __restrict__ keys, int n, const flo
     }
     out_d[i] = d; out_l[i] = l;
 }
+// mask / depth / flow at ((int)x, (int)y) of a point list: what the host-side renew stages (trackhost.cpp: vido_renew_*_sampled) read from the maps
+__global__ void k_gather_samples(const float* __restrict__ keys, int n, const float* __restrict__ depth, const float* __restrict__ flow, const int32_t* __restrict__ mask,
+                                 int w, int h, float* __restrict__ out_d, float* __restrict__ out_f, int32_t* __restrict__ out_m)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int u = (int)keys[2 * i], v = (int)keys[2 * i + 1];
+    float d = 0.f, fx = 0.f, fy = 0.f; int m = 0;
+    if (u < w && u >= 0 && v < h && v >= 0) { const size_t o = (size_t)v * w + u; d = depth[o]; m = mask[o]; fx = flow[2 * o]; fy = flow[2 * o + 1]; }
+    out_d[i] = d; out_f[2 * i] = fx; out_f[2 * i + 1] = fy; out_m[i] = m;
+}
 // UpdateMask helpers: labels of the current mask at the propagated points; scatter of one lost label
 __global__ void k_mask_at(const float* __restrict__ corr, int n, const int32_t* __restrict__ mask, int w, int h, int32_t* __restrict__ out)
 {
@@ -463,6 +474,23 @@ int vido_gather_object_depth_label(vido_ctx* ctx, int slot, const float* keys_xy
                        T->W, T->H, th_depth_obj, T->d_tmpf + 2 * (size_t)n, T->d_tmpi);
     HIP_TRY(ctx, hipMemcpyAsync(depth_out, T->d_tmpf + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(label_out, T->d_tmpi, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return VIDO_OK;
+}
+
+int vido_gather_point_samples(vido_ctx* ctx, int slot, const float* xy, int n, int32_t* mask_out, float* depth_out, float* flow_out)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
+    if (slot < 0 || slot >= T->B || n < 0 || (size_t)n * 5 > T->tmp_cap || (n && (!xy || !mask_out || !depth_out || !flow_out))) return vido_set_error(ctx, VIDO_E_INVALID, "gather_point_samples: bad slot/n");
+    if (n == 0) return VIDO_OK;
+    hipStream_t st = ctx->stream;
+    float* dk = T->d_tmpf; float* dd = dk + 2 * (size_t)n; float* df = dd + n;
+    HIP_TRY(ctx, hipMemcpyAsync(dk, xy, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gather_samples, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, T->sdepth[slot], T->sflow[slot], T->smask[slot], T->W, T->H, dd, df, T->d_tmpi);
+    HIP_TRY(ctx, hipMemcpyAsync(depth_out, dd, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(flow_out, df, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(mask_out, T->d_tmpi, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return VIDO_OK;
 }

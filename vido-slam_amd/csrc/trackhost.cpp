@@ -63,20 +63,32 @@ int vido_undistort_points(const float* xy, int n, const float K[4], const float 
     return VIDO_OK;
 }
 
-int vido_renew_static(const vido_host_maps* m, const float* stat_xy, int n_stat, const int32_t* TM_sta, int n_tm, const float* sample_xy, int n_sample,
-                      int max_num, int32_t* src_out, int32_t* inlier_out, float* flow_out, int cap, int32_t* n_out)
+// values of the three maps at ((int)x, (int)y) of every point of a list: what the renew stages read from mSegMap / mDepthMap / mFlowMap.  Points outside the image
+// are never looked at by the stages (their bounds test comes first), so their entries may hold anything.
+static void sample_maps(const vido_host_maps* m, const float* xy, int n, std::vector<int32_t>& mask, std::vector<float>& depth, std::vector<float>& flow)
 {
-    if (!m || !m->mask || !m->depth || !m->flow || !n_out || n_tm < 0 || n_sample < 0 || cap < 0 || (n_tm && (!TM_sta || !stat_xy)) || (n_sample && !sample_xy) ||
-        (cap && (!src_out || !inlier_out || !flow_out))) return VIDO_E_INVALID;
-    const int W = m->width, H = m->height;
+    mask.assign((size_t)std::max(n, 1), 0); depth.assign((size_t)std::max(n, 1), 0.f); flow.assign(2 * (size_t)std::max(n, 1), 0.f);
+    for (int i = 0; i < n; i++) {
+        const int x = (int)xy[2 * i], y = (int)xy[2 * i + 1];
+        if (x >= m->width || y >= m->height || x < 0 || y < 0) continue;
+        const size_t o = (size_t)y * m->width + x;
+        mask[i] = m->mask[o]; depth[i] = m->depth[o]; flow[2 * i] = m->flow[2 * o]; flow[2 * i + 1] = m->flow[2 * o + 1];
+    }
+}
+
+int vido_renew_static_sampled(int W, int H, const float* stat_xy, int n_stat, const vido_point_samples* ss, const int32_t* TM_sta, int n_tm,
+                              const float* sample_xy, int n_sample, const vido_point_samples* ks, int max_num, int32_t* src_out, int32_t* inlier_out, float* flow_out, int cap, int32_t* n_out)
+{
+    if (W < 1 || H < 1 || !n_out || n_tm < 0 || n_sample < 0 || cap < 0 || (n_tm && (!TM_sta || !stat_xy || !ss || !ss->mask || !ss->depth || !ss->flow)) ||
+        (n_sample && (!sample_xy || !ks || !ks->mask || !ks->depth || !ks->flow)) || (cap && (!src_out || !inlier_out || !flow_out))) return VIDO_E_INVALID;
     int n = 0; bool overflow = false;
     std::vector<float> kept;                                  // positions of the kept points (the inlier part is the "already used" check set)
-    auto try_add = [&](float px, float py, int src, int inl) -> bool {
+    auto try_add = [&](float px, float py, int src, int inl, const vido_point_samples* v) -> bool {
         const int x = (int)px, y = (int)py;
         if (x >= W || y >= H || x <= 0 || y <= 0) return false;
-        if (m->mask[(size_t)y * W + x] != 0) return false;
-        const float d = m->depth[(size_t)y * W + x]; if (d > 40 || d <= 0) return false;
-        const float fxe = m->flow[2 * ((size_t)y * W + x)], fye = m->flow[2 * ((size_t)y * W + x) + 1];
+        if (v->mask[src] != 0) return false;
+        const float d = v->depth[src]; if (d > 40 || d <= 0) return false;
+        const float fxe = v->flow[2 * (size_t)src], fye = v->flow[2 * (size_t)src + 1];
         if (fxe != 0 && fye != 0 && px + fxe < W && py + fye < H && px + fxe > 0 && py + fye > 0) {
             if (n < cap) { src_out[n] = src; inlier_out[n] = inl; flow_out[2 * n] = fxe; flow_out[2 * n + 1] = fye; } else overflow = true;
             kept.push_back(px); kept.push_back(py); n++;
@@ -87,7 +99,7 @@ int vido_renew_static(const vido_host_maps* m, const float* stat_xy, int n_stat,
     for (int i = 0; i < n_tm; i++) {                          // (1) the inliers of the last frame (:2977-3012)
         if (TM_sta[i] == -1) continue;
         if (TM_sta[i] < 0 || TM_sta[i] >= n_stat) return VIDO_E_INVALID;
-        try_add(stat_xy[2 * TM_sta[i]], stat_xy[2 * TM_sta[i] + 1], TM_sta[i], TM_sta[i]);
+        try_add(stat_xy[2 * TM_sta[i]], stat_xy[2 * TM_sta[i] + 1], TM_sta[i], TM_sta[i], ss);
         if (n > max_num) break;
     }
     int tot = n, start_id = 0; const int step = 20;         // (2) top-up from the detected keypoints in stride-20 passes (:3014-3075)
@@ -97,7 +109,7 @@ int vido_renew_static(const vido_host_maps* m, const float* stat_xy, int n_stat,
         if (start_id == step) break;
         for (int i = start_id; i < n_sample; i += step) {
             if (near_set.near(sample_xy[2 * i], sample_xy[2 * i + 1])) continue;
-            if (try_add(sample_xy[2 * i], sample_xy[2 * i + 1], i, -1)) tot++;
+            if (try_add(sample_xy[2 * i], sample_xy[2 * i + 1], i, -1, ks)) tot++;
             if (tot >= max_num) break;
         }
         start_id++;
@@ -106,15 +118,38 @@ int vido_renew_static(const vido_host_maps* m, const float* stat_xy, int n_stat,
     return overflow ? VIDO_E_CAPACITY : VIDO_OK;
 }
 
+int vido_renew_static(const vido_host_maps* m, const float* stat_xy, int n_stat, const int32_t* TM_sta, int n_tm, const float* sample_xy, int n_sample,
+                      int max_num, int32_t* src_out, int32_t* inlier_out, float* flow_out, int cap, int32_t* n_out)
+{
+    if (!m || !m->mask || !m->depth || !m->flow || n_stat < 0 || n_sample < 0 || (n_stat && !stat_xy) || (n_sample && !sample_xy)) return VIDO_E_INVALID;
+    std::vector<int32_t> m1, m2; std::vector<float> d1, d2, f1, f2;
+    sample_maps(m, stat_xy, n_stat, m1, d1, f1); sample_maps(m, sample_xy, n_sample, m2, d2, f2);
+    const vido_point_samples ss = {m1.data(), d1.data(), f1.data()}, ks = {m2.data(), d2.data(), f2.data()};
+    return vido_renew_static_sampled(m->width, m->height, stat_xy, n_stat, &ss, TM_sta, n_tm, sample_xy, n_sample, &ks, max_num, src_out, inlier_out, flow_out, cap, n_out);
+}
+
 int vido_renew_objects(const vido_host_maps* m, const float* obj_xy, const int32_t* obj_label, int n_obj_pts,
                        int n_objects, const int32_t* inl_off, const int32_t* inl_ids, const uint8_t* obj_stat, const int32_t* sem_position, const int32_t* mod_label,
                        const float* tmp_xy, const float* tmp_depth, const int32_t* tmp_sem, const float* tmp_flow, const float* tmp_corr, int n_tmp, int max_num_obj,
                        float* keys_out, float* depth_out, int32_t* sem_out, float* flow_out, float* corr_out, int32_t* inlier_out, int32_t* label_out, int cap, int32_t* n_out)
 {
-    if (!m || !m->mask || !m->depth || !m->flow || !n_out || n_objects < 0 || n_tmp < 0 || cap < 0 || (n_objects && (!inl_off || !obj_stat || !sem_position || !mod_label)) ||
+    if (!m || !m->mask || !m->depth || !m->flow || n_obj_pts < 0 || (n_obj_pts && !obj_xy)) return VIDO_E_INVALID;
+    std::vector<int32_t> m1; std::vector<float> d1, f1;
+    sample_maps(m, obj_xy, n_obj_pts, m1, d1, f1);
+    const vido_point_samples os = {m1.data(), d1.data(), f1.data()};
+    return vido_renew_objects_sampled(m->width, m->height, obj_xy, obj_label, n_obj_pts, &os, n_objects, inl_off, inl_ids, obj_stat, sem_position, mod_label,
+                                      tmp_xy, tmp_depth, tmp_sem, tmp_flow, tmp_corr, n_tmp, max_num_obj, keys_out, depth_out, sem_out, flow_out, corr_out, inlier_out, label_out, cap, n_out);
+}
+
+int vido_renew_objects_sampled(int W, int H, const float* obj_xy, const int32_t* obj_label, int n_obj_pts, const vido_point_samples* os,
+                               int n_objects, const int32_t* inl_off, const int32_t* inl_ids, const uint8_t* obj_stat, const int32_t* sem_position, const int32_t* mod_label,
+                               const float* tmp_xy, const float* tmp_depth, const int32_t* tmp_sem, const float* tmp_flow, const float* tmp_corr, int n_tmp, int max_num_obj,
+                               float* keys_out, float* depth_out, int32_t* sem_out, float* flow_out, float* corr_out, int32_t* inlier_out, int32_t* label_out, int cap, int32_t* n_out)
+{
+    if (W < 1 || H < 1 || !n_out || n_objects < 0 || n_tmp < 0 || cap < 0 || (n_objects && (!inl_off || !obj_stat || !sem_position || !mod_label)) ||
+        (n_obj_pts && (!os || !os->mask || !os->depth || !os->flow)) ||
         (n_tmp && (!tmp_xy || !tmp_depth || !tmp_sem || !tmp_flow || !tmp_corr)) || (cap && (!keys_out || !depth_out || !sem_out || !flow_out || !corr_out || !inlier_out || !label_out)))
         return VIDO_E_INVALID;
-    const int W = m->width, H = m->height;
     int n = 0; bool overflow = false;
     std::vector<float> kept;
     auto push = [&](float kx, float ky, float d, int sem, float fx_, float fy_, float cx_, float cy_, int inl, int lab) {
@@ -131,9 +166,9 @@ int vido_renew_objects(const vido_host_maps* m, const float* obj_xy, const int32
             if (id < 0 || id >= n_obj_pts) return VIDO_E_INVALID;
             const int x = (int)obj_xy[2 * id], y = (int)obj_xy[2 * id + 1];
             if (x >= W || y >= H || x <= 0 || y <= 0) continue;
-            const float d = m->depth[(size_t)y * W + x]; const int sem = m->mask[(size_t)y * W + x];
+            const float d = os->depth[id]; const int sem = os->mask[id];
             if (sem != 0 && d < 25 && d > 0) {
-                const float fl0 = m->flow[2 * ((size_t)y * W + x)], fl1 = m->flow[2 * ((size_t)y * W + x) + 1];
+                const float fl0 = os->flow[2 * (size_t)id], fl1 = os->flow[2 * (size_t)id + 1];
                 if (x + fl0 < W && y + fl1 < H && x + fl0 > 0 && y + fl1 > 0) {
                     push((float)x, (float)y, d, sem, fl0, fl1, x + fl0, y + fl1, id, obj_label[id]);
                     kept.push_back((float)x); kept.push_back((float)y); count++;

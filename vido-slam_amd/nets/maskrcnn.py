@@ -278,6 +278,11 @@ def _rpn_proposals_device(self, feats, logits, deltas, image_wh):
 _RPN.proposals_device = _rpn_proposals_device
 
 
+class FpnMaps(tuple):
+    """The four pooled FPN maps [1,C,H,W] plus their channels-last copies (.nhwc: [1,H,W,C], HipOps.to_nhwc) — what the ROI-Align kernel reads."""
+    nhwc = ()
+
+
 class _Pooler(nn.Module):                  # modeling/poolers.py:11-121
     def __init__(self, resolution, scales, sampling_ratio, ops):
         super().__init__()
@@ -287,6 +292,8 @@ class _Pooler(nn.Module):                  # modeling/poolers.py:11-121
     def forward(self, feats, boxes):
         area = (boxes[:, 2] - boxes[:, 0] + 1) * (boxes[:, 3] - boxes[:, 1] + 1)
         lvl = torch.floor(4 + torch.log2(torch.sqrt(area) / 224 + 1e-6)).clamp(min=self.k_min, max=self.k_max).to(torch.int64) - int(self.k_min)
+        if isinstance(feats, FpnMaps):                                                      # channels-last copies made once per frame (MaskRCNN.fpn_maps): lanes across channels
+            return self.ops.roi_align_fpn_nhwc(feats.nhwc, boxes, lvl, (self.res, self.res), self.scales, self.sr)
         if hasattr(self.ops, "roi_align_fpn") and boxes.is_cuda and len(feats) == 4:       # one launch, no per-level nonzero / gather / scatter
             return self.ops.roi_align_fpn(feats, boxes, lvl, (self.res, self.res), self.scales, self.sr)
         rois = torch.cat([boxes.new_zeros((len(boxes), 1)), boxes], 1)
@@ -349,6 +356,56 @@ class _BoxHead(nn.Module):
             keep = torch.nonzero(rs >= thresh.to(rs.device)).squeeze(1)
             rb, rs, rl = rb[keep], rs[keep], rl[keep]
         return rb, rs, rl
+
+
+def _postprocess_static(self, logits, deltas, proposals, image_wh, objectness, cap):
+    """postprocess() with STATIC shapes (no nonzero / .item(): capturable in a hipGraph, no host round trip): the same detections in the same order
+    (class ascending, then proposal index — box_head/inference.py:96-137), written into `cap` fixed slots.  Returns (boxes [cap,4], scores [cap], labels [cap] i64,
+    n_det) where n_det (device scalar) counts the detections the reference would return; when score ties at the kthvalue cut push it past `cap`, only the first
+    `cap` are stored and the caller falls back to postprocess() for that image (n_det > cap).
+      * candidates: class-major score matrix S[j, i] (80 x 1000), one stable descending sort per class row, below-threshold entries pushed behind (score -1);
+      * NMS: one segment per class through the segmented HIP kernels (fixed 1000-slot segments, the live length per class is a device array);
+      * the detections_per_img rule (kthvalue on the CPU in the reference): threshold = the cap-th largest kept score, keep >= threshold;
+      * compaction: a cumulative count over the (class, proposal) grid scatters the survivors into their slots."""
+    c = self.c; W, H = image_wh; nc = logits.shape[1]; N = logits.shape[0]; dev = logits.device
+    prob = F.softmax(logits, -1)
+    if objectness is not None:
+        prob = prob * (objectness >= 0).unsqueeze(1)
+    boxes = clip_boxes(self.ops.box_decode(deltas, proposals, c.bbox_reg_weights).reshape(-1, 4), W, H).reshape(N, nc, 4)
+    S = prob[:, 1:].t().contiguous()                                       # [nc-1, N]
+    valid = S > c.score_thresh
+    key = torch.where(valid, S, S.new_full((), -1.0))
+    _, order = torch.sort(key, dim=1, descending=True, stable=True)        # per class: score descending, ties by proposal index
+    bx_cls = boxes[:, 1:].permute(1, 0, 2).contiguous()                    # [nc-1, N, 4]
+    bx_sorted = torch.gather(bx_cls, 1, order.unsqueeze(-1).expand(-1, -1, 4)).reshape(-1, 4)
+    st = getattr(self, "_static_tabs", None)
+    if st is None or st[0] != (nc, N, str(dev)):
+        st = ((nc, N, str(dev)), torch.arange(nc - 1, device=dev, dtype=torch.int32) * N,
+              (torch.arange(1, nc, device=dev, dtype=torch.int64).unsqueeze(1).expand(nc - 1, N)).reshape(-1).contiguous())
+        self._static_tabs = st
+    seg_off, lab_grid = st[1], st[2]
+    seg_n = valid.sum(1).to(torch.int32)
+    keep, _ = self.ops.nms_segments(bx_sorted, seg_off, seg_n, N, c.nms)   # [nc-1, N] kept sorted positions, -1 padded
+    kept_sorted = torch.zeros((nc - 1, N + 1), dtype=torch.bool, device=dev)
+    kept_sorted.scatter_(1, torch.where(keep >= 0, keep, torch.full_like(keep, N)).long(), True)
+    Fk = torch.zeros((nc - 1, N), dtype=torch.bool, device=dev).scatter_(1, order, kept_sorted[:, :N])      # back to (class, proposal)
+    Sc = torch.where(Fk, S, S.new_full((), -1.0)).reshape(-1)
+    n_keep = Fk.sum()
+    if c.detections_per_img > 0:
+        top = torch.sort(Sc, descending=True)[0]
+        th = torch.where(n_keep > c.detections_per_img, top[c.detections_per_img - 1], top.new_full((), -0.5))
+        Fk = Fk & (Sc.reshape(nc - 1, N) >= th)
+    flat = Fk.reshape(-1)
+    pos = torch.cumsum(flat, 0) - 1
+    n_det = flat.sum()
+    dst = torch.where(flat & (pos < cap), pos, torch.full_like(pos, cap))
+    ob = boxes.new_zeros((cap + 1, 4)).index_copy_(0, dst, bx_cls.reshape(-1, 4))
+    osc = boxes.new_zeros((cap + 1,)).index_copy_(0, dst, S.reshape(-1))
+    olb = torch.zeros((cap + 1,), dtype=torch.int64, device=dev).index_copy_(0, dst, lab_grid)
+    return ob[:cap], osc[:cap], olb[:cap], n_det
+
+
+_BoxHead.postprocess_static = _postprocess_static
 
 
 class _MaskFeatures(nn.Module):            # roi_mask_feature_extractors.py:17-65
@@ -476,10 +533,56 @@ class MaskRCNN(nn.Module):
     def heads(self, feats, logits, deltas, image_hw):
         H, W = image_hw
         proposals, objectness = self.rpn.proposals(feats, logits, deltas, (W, H))
-        boxes, scores, labels = self.roi_heads.box(feats[:len(self.config.pool_scales)], proposals, (W, H), objectness)
-        masks = self.roi_heads.mask(feats[:len(self.config.pool_scales)], boxes, labels)
+        maps = self.fpn_maps(feats)
+        boxes, scores, labels = self.roi_heads.box(maps, proposals, (W, H), objectness)
+        masks = self.roi_heads.mask(maps, boxes, labels)
         # proposals / objectness: the device-side RPN path returns fixed-size lists whose trailing rows (objectness -1) are padding; n_proposals counts the real ones
         return dict(boxes=boxes, scores=scores, labels=labels, masks=masks, proposals=proposals, objectness=objectness, n_proposals=(objectness >= 0).sum())
+
+
+def _fpn_maps(self, feats):
+    """The pooled levels + their channels-last copies (one HIP transpose per level and frame, shared by the box and the mask pooler)."""
+    ops = self.rpn.ops; lv = tuple(feats[:len(self.config.pool_scales)])
+    if not (hasattr(ops, "to_nhwc") and lv[0].is_cuda and len(lv) == 4):
+        return lv
+    m = FpnMaps(lv); m.nhwc = tuple(ops.to_nhwc(f) for f in lv)
+    return m
+
+
+@torch.no_grad()
+def _heads_static(self, feats, logits, deltas, image_hw, cap=None):
+    """heads() with static shapes end to end (device-side RPN selection, fixed 1000 proposals, postprocess_static, the mask head on `cap` padded slots): no host
+    synchronisation anywhere, so trunk + heads + label image replay as ONE hipGraph.  Slots >= n_det hold zero boxes / label 0."""
+    H, W = image_hw; c = self.config; cap = cap or c.detections_per_img
+    proposals, objectness = self.rpn.proposals_device(feats, logits, deltas, (W, H))
+    maps = self.fpn_maps(feats)
+    bh = self.roi_heads.box
+    lg, dl = bh.predictor(bh.feature_extractor(maps, proposals))
+    boxes, scores, labels, n_det = bh.postprocess_static(lg, dl, proposals, (W, H), objectness, cap)
+    mh = self.roi_heads.mask
+    masks = mh.chunk_logits(maps, boxes).sigmoid()[torch.arange(cap, device=labels.device), labels][:, None]
+    return dict(boxes=boxes, scores=scores, labels=labels, masks=masks, n_det=n_det, proposals=proposals, objectness=objectness, n_proposals=(objectness >= 0).sum())
+
+
+MaskRCNN.fpn_maps = _fpn_maps
+MaskRCNN.heads_static = _heads_static
+
+
+@torch.no_grad()
+def analyse_image_static(net, feats, logits, deltas, out_hw, feed=(1088, 800), confidence=0.8, cap=None):
+    """analyse_image's tail on the static head: (label image [H,W] u8, labels [cap] i64 in descending score order with 0 for unused slots, n_labels, n_det) — all device
+    tensors, nothing synchronised.  Detections that fail the confidence test (and the padding slots) keep their slot with class index 0: they add nothing to the label image
+    (run_mask_rcnn.py:112-118 sums mask * class_index), which is what selecting them away does in the reference.  n_det > cap: the caller must redo the image with analyse_image()."""
+    H, W = out_hw
+    out = net.heads_static(feats, logits, deltas, feed, cap)
+    cap = out["boxes"].shape[0]
+    rw, rh = float(W) / feed[1], float(H) / feed[0]
+    boxes = out["boxes"] * out["boxes"].new_tensor([rw, rh, rw, rh]) if rw != rh else out["boxes"] * rw
+    live = (out["scores"] > confidence) & (torch.arange(cap, device=boxes.device) < out["n_det"])
+    order = torch.sort(torch.where(live, out["scores"], out["scores"].new_full((), -1.0)), descending=True, stable=True)[1]
+    labels = torch.where(live, out["labels"], torch.zeros_like(out["labels"]))[order]
+    img = net.rpn.ops.mask_label_image(out["masks"][order], boxes[order], labels, H, W)
+    return img, labels, live.sum(), out["n_det"]
 
 
 def image_to_feed(bgr, dev, feed=(1088, 800), ops=None):

@@ -161,6 +161,29 @@ class HipOps:
                                                         C.c_void_p(out.data_ptr())))
         return out
 
+    def to_nhwc(self, x):
+        """[B,C,H,W] f32 -> channels-last copy [B,H,W,C] (vido_nchw_to_nhwc): the layout roi_align_fpn_nhwc reads."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+        x = x.contiguous(); B, Cc, H, W = x.shape
+        out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_nchw_to_nhwc(self.ctx.h, C.c_void_p(x.data_ptr()), B, Cc, H, W, C.c_void_p(out.data_ptr())))
+        return out
+
+    def roi_align_fpn_nhwc(self, feats_nhwc, boxes, level, output_size, scales, sampling_ratio):
+        """Pooler.forward over channels-last maps [1,H,W,C] (to_nhwc of the 4 FPN maps, made once per frame)."""
+        n = boxes.shape[0]; ph, pw = output_size; Cc = feats_nhwc[0].shape[3]
+        out = torch.empty((n, Cc, ph, pw), device=boxes.device, dtype=torch.float32)
+        if n == 0:
+            return out
+        boxes = boxes.contiguous().float(); level = level.to(torch.int32).contiguous()
+        fp = (C.c_void_p * 4)(*[f.data_ptr() for f in feats_nhwc]); Hs = (C.c_int * 4)(*[f.shape[1] for f in feats_nhwc]); Ws = (C.c_int * 4)(*[f.shape[2] for f in feats_nhwc])
+        sc = (C.c_float * 4)(*[float(x) for x in scales])
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_roi_align_fpn_nhwc(self.ctx.h, fp, Hs, Ws, sc, Cc, C.c_void_p(boxes.data_ptr()), C.c_void_p(level.data_ptr()), n, ph, pw, sampling_ratio,
+                                                             C.c_void_p(out.data_ptr())))
+        return out
+
     def mask_label_image(self, masks, boxes, labels, H, W, thresh=0.5, padding=1):
         """Masker + label image: masks [n,1,M,M], boxes [n,4] (output image), labels [n] int64 -> [H,W] u8."""
         out = torch.empty((H, W), device=masks.device, dtype=torch.uint8)

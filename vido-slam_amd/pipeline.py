@@ -94,7 +94,7 @@ class NetNodes:
     FPN + RPN head) are captured into hipGraphs."""
 
     def __init__(self, ctx, height=480, width=640, optimize=True, graphs=True, streams=False, miopen_find=False, seed=1,
-                 mask_feed=(1088, 800), depth_feed=(192, 640), confidence=0.8, calibrate_scores=True):
+                 mask_feed=(1088, 800), depth_feed=(192, 640), confidence=0.8, calibrate_scores=True, static_detector=True):
         self.ctx, self.h, self.w = ctx, height, width
         self.mask_feed, self.depth_feed, self.confidence = mask_feed, depth_feed, confidence
         if miopen_find:
@@ -121,12 +121,21 @@ class NetNodes:
         if optimize:
             self.folded = _nets.fold_batchnorm(self.depth_net, ops) + _nets.fold_batchnorm(self.mask_net, ops)
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(3)] if streams else None
-        self.g_flow = self.g_depth = self.g_trunk = None
+        self.g_flow = self.g_depth = self.g_trunk = self.g_det = None
         self.graph_error = None
+        self.last_counts = None
+        self.det_overflows = 0                                        # frames whose detection count exceeded the static head's slots (redone through the dynamic head)
         ex = torch.zeros((height, width, 3), dtype=torch.uint8, device=dev)
         self._flow_fn = lambda a, b: _nets.analyse_flow(self.flow_net, a, b)
         self._depth_fn = lambda a: _nets.analyse_depth(self.depth_net, a, feed=self.depth_feed, ops=ops).to(torch.float32)
         self._trunk_fn = lambda a: self.mask_net.trunk(_nets.maskrcnn.image_to_feed(a, dev, self.mask_feed, ops=ops))
+        # the whole detector with static shapes (nets/maskrcnn.py: heads_static / analyse_image_static): trunk + device-side RPN selection + box head + fixed-slot
+        # post-processing + mask head + label image, no host synchronisation -> ONE hipGraph; returns (mask i32 HxW, labels [cap], n_labels, n_det)
+        def _det_fn(a):
+            feats, logits, deltas = self._trunk_fn(a)
+            img, labels, n_lab, n_det = _nets.analyse_image_static(self.mask_net, feats, logits, deltas, (height, width), feed=self.mask_feed, confidence=self.confidence)
+            return img.to(torch.int32), labels, n_lab.to(torch.int32), n_det.to(torch.int32)
+        self._det_fn = _det_fn
         with torch.no_grad():
             for _ in range(2):                                          # first calls: MIOpen compiles / finds its kernels
                 self._flow_fn(ex, ex); self._depth_fn(ex); self._trunk_fn(ex)
@@ -143,6 +152,10 @@ class NetNodes:
                     self.g_trunk = _nets.Graphed(self._trunk_fn, [ex])
                     if not _os.environ.get("VIDO_NO_MASK_GRAPHS"):
                         mh.capture_buckets(self.g_trunk.static_out[0][:4], _nets.Graphed)      # the mask head per detection-count bucket, over the trunk's static feature maps
+                    if static_detector and not _os.environ.get("VIDO_NO_DET_GRAPH"):
+                        self._det_fn(ex); torch.cuda.synchronize()
+                        self.g_det = _nets.Graphed(self._det_fn, [ex])
+                        self._det_pin = torch.zeros(2, dtype=torch.int32).pin_memory()
                 except Exception as e:                                  # capture is an optimisation: report, run eagerly
                     self.graph_error = "%s: %s" % (type(e).__name__, e)
                     self.g_flow = self.g_depth = self.g_trunk = None
@@ -163,35 +176,56 @@ class NetNodes:
         with torch.cuda.stream(ss[1]):
             depth = (self.g_depth or self._depth_fn)(cur_bgr)
             e1 = torch.cuda.Event(); e1.record()
-        with torch.cuda.stream(ss[2]):                                  # last: its data-dependent tail synchronises the host while the other two run
-            mask_u8, labels = _nets.analyse_image(self.mask_net, cur_bgr, feed=self.mask_feed, confidence=self.confidence, trunk=self.g_trunk)
-            mask = mask_u8.to(torch.int32)
+        with torch.cuda.stream(ss[2]):
+            if self.g_det is not None:                                  # one graph replay, nothing synchronised: labels [cap] (0 = unused slot), counts stay on the device
+                mask, labels, n_lab, n_det = self.g_det(cur_bgr)
+                self.last_counts = (n_lab, n_det)
+            else:                                                       # dynamic head: its data-dependent tail synchronises the host while the other two networks run
+                mask_u8, labels = _nets.analyse_image(self.mask_net, cur_bgr, feed=self.mask_feed, confidence=self.confidence, trunk=self.g_trunk)
+                mask = mask_u8.to(torch.int32); self.last_counts = None
             e2 = torch.cuda.Event(); e2.record()
         return flow, depth, mask, labels, (e0, e1, e2)
 
+    @torch.no_grad()
+    def redo_detector_if_overflowed(self, cur_bgr, n_det_host):
+        """The static head stores detections_per_img slots; score ties at the reference's kthvalue cut (box_head/inference.py:131-137) can leave more.  The caller reads
+        n_det with the frame's hand-over and, in that (rare) case, recomputes the label image through the dynamic head."""
+        cap = self.mask_net.config.detections_per_img
+        if n_det_host <= cap:
+            return None
+        self.det_overflows += 1
+        mask_u8, labels = _nets.analyse_image(self.mask_net, cur_bgr, feed=self.mask_feed, confidence=self.confidence, trunk=self.g_trunk)
+        return mask_u8.to(torch.int32), labels
+
 
 class EndToEnd:
-    """RunNet || RunVidoSlam on one GPU: the caller pushes BGR frames; the networks of frame k+1 are enqueued on the network streams while a
-    worker thread tracks frame k through System.TrackRGBD (the C++ facade: ORB, lists, P3P-RANSAC, the four optimisers, scene flow, object
-    tracking, re-seeding, local BA) on the tracker's own stream.  The hand-over is what TrackRGBD's interface asks for: host buffers
-    (pinned), one D2H copy per map.
+    """RunNet || RunVidoSlam on one GPU: the caller pushes BGR frames; the networks of frame k+1 are enqueued (three hipGraph replays) on the network stream while a
+    worker thread tracks frame k through the System (the C++ facade: ORB, lists, P3P-RANSAC, the four optimisers, scene flow, object tracking, re-seeding, local BA)
+    on the tracker's own stream.
 
-    feed = "nets": the tracker consumes the networks' outputs.  feed = "given": the networks run and their outputs are copied to the host
-    all the same (full cost, same dependency: frame k is tracked only after its three forwards and copies have completed), but the tracker
-    is handed caller-supplied flow / depth / mask maps for the frame — for synthetic benchmarks, where random-weight networks produce maps
-    without any geometry for the tracker to work on."""
+    handover = "device" (default): the frame is uploaded ONCE (BGR, 0.9 MB), the three networks write device tensors, those are parked in a device
+    ring (three device-to-device copies in stream order, because the next graph replay overwrites the graphs' static outputs) and System.TrackRGBDDevice takes the
+    ring's pointers: the tracker's stream waits for the producer's event ON THE DEVICE, no map crosses PCIe in either direction and the host never waits for the
+    networks before it starts enqueuing the tracker (the reference's chain being replaced: src/realtime_demo/src/run_vido.cc:57-171, three service calls with the
+    image going out and a map coming back each, then TrackRGBD uploading the three maps again).
+    handover = "host": round 2's form — one D2H copy per map into pinned buffers, TrackRGBD(host arrays) uploads them again (kept for A/B measurements).
 
-    RING = 4                                  # host buffer sets: the tracker keeps shallow references to the maps of the previous frame
+    feed = "nets": the tracker consumes the networks' outputs.  feed = "given": the networks run at full cost and their outputs are parked exactly as above, but the
+    tracker is handed caller-supplied depth / flow / mask maps of the frame (uploaded next to the BGR frame) — for synthetic benchmarks, where random-weight networks
+    produce maps without any geometry for the tracker to work on.  Frame k is still tracked only after its three forwards have completed (same event)."""
 
-    def __init__(self, nodes, system, n_image=10000, feed="nets"):
-        self.nodes, self.system, self.n_image, self.feed = nodes, system, n_image, feed
-        h, w = nodes.h, nodes.w
+    RING = 4                                  # buffer sets: the tracker keeps the maps of the previous frame in use (mask / flow of frame k-1 during frame k)
+
+    def __init__(self, nodes, system, n_image=10000, feed="nets", handover="device"):
+        self.nodes, self.system, self.n_image, self.feed, self.handover = nodes, system, n_image, feed, handover
+        h, w = nodes.h, nodes.w; dev = nodes.dev
         pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
         self.host = [dict(bgr=pin((h, w, 3), torch.uint8), flow=pin((h, w, 2), torch.float32), depth=pin((h, w), torch.float32), mask=pin((h, w), torch.int32),
-                          given=None) for _ in range(self.RING)]
-        self.dev = [dict(flow=torch.empty((h, w, 2), dtype=torch.float32, device=nodes.dev), depth=torch.empty((h, w), dtype=torch.float32, device=nodes.dev),
-                         mask=torch.empty((h, w), dtype=torch.int32, device=nodes.dev)) for _ in range(self.RING)]
-        self.copy_stream = torch.cuda.Stream(device=nodes.dev)
+                          counts=pin((2,), torch.int32)) for _ in range(self.RING)]
+        mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        self.dev = [dict(bgr=mk((h, w, 3), torch.uint8), flow=mk((h, w, 2), torch.float32), depth=mk((h, w), torch.float32), mask=mk((h, w), torch.int32),
+                         gflow=mk((h, w, 2), torch.float32), gdepth=mk((h, w), torch.float32), gmask=mk((h, w), torch.int32)) for _ in range(self.RING)]
+        self.copy_stream = torch.cuda.Stream(device=dev)
         self.q = _queue.Queue(maxsize=1)      # the networks run at most one frame ahead of the tracker (+ the one in flight)
         self.poses, self.stats, self.err = [], [], None
         self.t_net, self.t_track, self.t_wait, self.n_det = [], [], [], []
@@ -205,56 +239,90 @@ class EndToEnd:
                 return
             k, slot, ev = item
             try:
+                if self.err is not None:                                 # a failed frame stops the sequence: later frames are drained, not tracked on a broken System
+                    continue
                 t0 = _time.perf_counter()
-                ev.synchronize()                                         # networks + hand-over copies of frame k are complete
-                t1 = _time.perf_counter()
-                hb = self.host[slot]
-                if self.feed == "nets":
-                    d, f, m = hb["depth"].numpy(), hb["flow"].numpy(), hb["mask"].numpy()
+                hb, db = self.host[slot], self.dev[slot]
+                T = None
+                if self.handover == "device":
+                    if self.nodes.g_det is not None:                     # the static head's overflow flag (rare): needs the frame's counts, i.e. a host wait for this one event
+                        ev.synchronize()
+                        self._redo_if_overflowed(slot)
+                    t1 = _time.perf_counter()
+                    if not _os.environ.get("VIDO_E2E_SKIP_TRACK"):
+                        d, f, m = (db["depth"], db["flow"], db["mask"]) if self.feed == "nets" else (db["gdepth"], db["gflow"], db["gmask"])
+                        T = self.system.TrackRGBDDevice(db["bgr"].data_ptr(), 3, self.nodes.w, self.nodes.h, d.data_ptr(), f.data_ptr(), m.data_ptr(), ev.cuda_event,
+                                                        float(k), self.n_image)
                 else:
-                    d, f, m = hb["given"]                                # the caller's arrays, by reference (kept alive in the ring like the tracker's shallow references need)
-                if _os.environ.get("VIDO_E2E_SKIP_TRACK"):               # diagnosis only: networks + hand-over without the tracker
-                    T = None
-                else:
-                    T = self.system.TrackRGBD(hb["bgr"].numpy(), d, f, m, None, None, float(k), None, self.n_image)
+                    ev.synchronize()                                     # networks + hand-over copies of frame k are complete
+                    t1 = _time.perf_counter()
+                    if self.feed == "nets":
+                        d, f, m = hb["depth"].numpy(), hb["flow"].numpy(), hb["mask"].numpy()
+                    else:
+                        d, f, m = hb["given"]
+                    if not _os.environ.get("VIDO_E2E_SKIP_TRACK"):       # diagnosis only: networks + hand-over without the tracker
+                        T = self.system.TrackRGBD(hb["bgr"].numpy(), d, f, m, None, None, float(k), None, self.n_image)
                 t2 = _time.perf_counter()
                 self.poses.append(T); self.stats.append(self.system.stats() if T is not None else {})
                 self.t_wait.append((t1 - t0) * 1e3); self.t_track.append((t2 - t1) * 1e3)
+                self.n_det.append(int(hb["counts"][1]) if self.nodes.g_det is not None else int(getattr(self.nodes.mask_net.roi_heads.mask, "last_n", 0)))
             except Exception as e:                                       # surfaced by push() / finish()
                 self.err = e
             finally:
                 self.q.task_done()
 
     @torch.no_grad()
+    def _redo_if_overflowed(self, slot):
+        n_det = int(self.host[slot]["counts"][1])
+        if n_det <= self.nodes.mask_net.config.detections_per_img:
+            return
+        with torch.cuda.stream(self.net_stream):                         # on the NETWORK stream: the detector's HIP ops share one device scratch, which only stream order protects
+            r = self.nodes.redo_detector_if_overflowed(self.dev[slot]["bgr"], n_det)
+            if r is not None:
+                self.dev[slot]["mask"].copy_(r[0])
+            self.net_stream.synchronize()
+
+    @torch.no_grad()
     def push(self, bgr, given=None):
-        """bgr: HxWx3 u8 numpy.  given = (depth f32 HxW raw sensor units, flow f32 HxWx2, mask i32 HxW) for feed == "given"."""
+        """bgr: HxWx3 u8 numpy.  given = (depth f32 HxW raw sensor units, flow f32 HxWx2, mask i32 HxW) for feed == "given" (copied: the caller's arrays are not modified,
+        although the tracker rescales the depth map it is handed in place)."""
         if self.err is not None:
             raise self.err
         t0 = _time.perf_counter()
+        self.net_stream = torch.cuda.current_stream()
         slot = self.k % self.RING
-        hb = self.host[slot]
+        hb, db = self.host[slot], self.dev[slot]
         hb["bgr"].numpy()[...] = bgr
+        cur = db["bgr"]
+        cur.copy_(hb["bgr"], non_blocking=True)                          # the only upload of the frame on the network side
         if given is not None:
-            import numpy as _np
-            hb["given"] = (_np.ascontiguousarray(given[0], dtype=_np.float32), _np.ascontiguousarray(given[1], dtype=_np.float32), _np.ascontiguousarray(given[2], dtype=_np.int32))
-        cur = hb["bgr"].to(self.nodes.dev, non_blocking=True)            # the only upload of the frame on the network side
+            hb["depth"].numpy()[...] = given[0]; hb["flow"].numpy()[...] = given[1]; hb["mask"].numpy()[...] = given[2]
+            if self.handover == "device":                                # the stand-in maps go up next to the frame (feed == "nets" uploads nothing but the frame)
+                db["gdepth"].copy_(hb["depth"], non_blocking=True); db["gflow"].copy_(hb["flow"], non_blocking=True); db["gmask"].copy_(hb["mask"], non_blocking=True)
+            else:
+                hb["given"] = (hb["depth"].numpy().copy(), hb["flow"].numpy().copy(), hb["mask"].numpy().copy())
         prev = cur if self.prev is None else self.prev                   # first frame: RunNet has no previous image yet; the tracker ignores the flow of frame 0's predecessor
         flow, depth, mask, labels, evs = self.nodes.infer(prev, cur)
-        # graph outputs are static buffers that the next replay overwrites: park them in this slot's device buffers (three device-to-device copies of 4.8 MB in stream
-        # order, microseconds) and let the copy stream take its time over PCIe — the next frame's graphs need no host-side wait for the hand-over
-        db = self.dev[slot]
+        # graph outputs are static buffers that the next replay overwrites: park them in this slot's device buffers (three device-to-device copies of 4.8 MB in stream order)
         if self.nodes.streams is not None:
             for e in evs:
                 torch.cuda.current_stream().wait_event(e)
         db["flow"].copy_(flow, non_blocking=True); db["depth"].copy_(depth, non_blocking=True); db["mask"].copy_(mask, non_blocking=True)
+        if self.nodes.last_counts is not None:
+            hb["counts"][0:1].copy_(self.nodes.last_counts[0].reshape(1), non_blocking=True); hb["counts"][1:2].copy_(self.nodes.last_counts[1].reshape(1), non_blocking=True)
         parked = torch.cuda.Event(); parked.record()
-        cs = self.copy_stream
-        cs.wait_event(parked)
-        with torch.cuda.stream(cs):
-            hb["flow"].copy_(db["flow"], non_blocking=True); hb["depth"].copy_(db["depth"], non_blocking=True); hb["mask"].copy_(db["mask"], non_blocking=True)
-            done = torch.cuda.Event(); done.record()
-        self.n_det.append(int(getattr(self.nodes.mask_net.roi_heads.mask, "last_n", 0)))
-        self._alive = (flow, depth, mask, cur, prev)
+        done = parked
+        if self.handover != "device":                                    # round 2's hand-over: the maps go to pinned host buffers on the copy stream
+            cs = self.copy_stream
+            cs.wait_event(parked)
+            with torch.cuda.stream(cs):
+                if self.feed == "nets":
+                    hb["flow"].copy_(db["flow"], non_blocking=True); hb["depth"].copy_(db["depth"], non_blocking=True); hb["mask"].copy_(db["mask"], non_blocking=True)
+                else:                                                    # same traffic, into a scratch set (hb[...] holds the given maps)
+                    self._sink = getattr(self, "_sink", None) or [torch.empty_like(hb["flow"]).pin_memory(), torch.empty_like(hb["depth"]).pin_memory(), torch.empty_like(hb["mask"]).pin_memory()]
+                    self._sink[0].copy_(db["flow"], non_blocking=True); self._sink[1].copy_(db["depth"], non_blocking=True); self._sink[2].copy_(db["mask"], non_blocking=True)
+                done = torch.cuda.Event(); done.record()
+        self._alive = (flow, depth, mask, labels)
         self.prev = cur
         self.t_net.append((_time.perf_counter() - t0) * 1e3)
         self.q.put((self.k, slot, done))                                 # blocks while the tracker is still two frames behind

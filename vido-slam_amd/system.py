@@ -35,6 +35,7 @@ def _bind(lib):
     lib.vido_system_last_error.restype = C.c_char_p
     lib.vido_system_last_error.argtypes = [C.c_void_p]
     lib.vido_system_track_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
+    lib.vido_system_track_rgbd_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
     lib.vido_system_get_stats.argtypes = [C.c_void_p, C.POINTER(SystemStats)]
     lib.vido_system_save_results.argtypes = [C.c_void_p, C.c_char_p]
     lib.vido_system_context.restype = C.c_void_p
@@ -81,6 +82,19 @@ class System:
         rc = self.lib.vido_system_track_rgbd(self.h, im.ctypes.data, cn, w, h, depthmap.ctypes.data, flowmap.ctypes.data, masksem.ctypes.data,
                                              float(timestamp), int(nImage), T.ctypes.data)
         self._keep = keep
+        if rc != VIDO_OK:
+            raise VidoError(rc, self.lib.vido_system_last_error(self.h).decode())
+        return T
+
+    def TrackRGBDDevice(self, im_dev, channels, width, height, depth_dev, flow_dev, mask_dev, ready_event=None, timestamp=0.0, nImage=10000):
+        """System::TrackRGBDDevice (extension, SURVEY.md 8f row 4): the same call on DEVICE-resident buffers given as raw pointers (e.g. tensor.data_ptr()): u8 image with
+        `channels` interleaved channels, depth f32 (rescaled in place on the device), flow f32 x2, mask i32 of a width x height frame; ready_event: raw hipEvent_t
+        (torch.cuda.Event.cuda_event) recorded by the producer of the buffers, or None.  The caller keeps the buffers alive for two frames.  Returns Tcw (4,4) f32."""
+        if self.h is None:
+            raise VidoError(-1, "System.TrackRGBDDevice before Init")
+        T = np.empty((4, 4), np.float32)
+        rc = self.lib.vido_system_track_rgbd_device(self.h, C.c_void_p(int(im_dev)), int(channels), int(width), int(height), C.c_void_p(int(depth_dev)), C.c_void_p(int(flow_dev)),
+                                                    C.c_void_p(int(mask_dev)), C.c_void_p(int(ready_event)) if ready_event else None, float(timestamp), int(nImage), T.ctypes.data)
         if rc != VIDO_OK:
             raise VidoError(rc, self.lib.vido_system_last_error(self.h).decode())
         return T
