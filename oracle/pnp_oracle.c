@@ -159,10 +159,12 @@ static int ransac_update_iters(double p, double ep, int model_points, int max_it
 }
 
 /* sequential RANSAC over the per-iteration hypotheses; returns inlier count, T (row-major 4x4), mask */
-int vo_pnp_ransac(const float* pts3d, const float* pts2d, int n, double fx, double fy, double cx, double cy, int max_iters, double thr, double conf,
-                  uint64_t seed, double* T, uint8_t* mask)
+/* T: the pose cv::solvePnPRansac returns (refitted on the inliers); T_ransac (may be NULL): the winning minimal-sample model the inlier mask belongs to */
+int vo_pnp_ransac_full(const float* pts3d, const float* pts2d, int n, double fx, double fy, double cx, double cy, int max_iters, double thr, double conf,
+                       uint64_t seed, double* T, uint8_t* mask, double* T_ransac)
 {
     for (int k = 0; k < 16; k++) T[k] = (k % 5 == 0);
+    if (T_ransac) for (int k = 0; k < 16; k++) T_ransac[k] = (k % 5 == 0);
     if (mask) memset(mask, 0, n);
     if (n < 4) return 0;
     int niters = max_iters, best_cnt = 0; double bR[9], bt[3];
@@ -177,6 +179,58 @@ int vo_pnp_ransac(const float* pts3d, const float* pts2d, int n, double fx, doub
     if (best_cnt == 0) return 0;
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T[r * 4 + c] = bR[r * 3 + c]; T[r * 4 + 3] = bt[r]; }
     int cnt = 0;
-    for (int i = 0; i < n; i++) { const int in = reproj2(bR, bt, pts3d + 3 * i, pts2d + 2 * i, fx, fy, cx, cy) <= thr * thr; if (mask) mask[i] = (uint8_t)in; cnt += in; }
+    uint8_t* in_mask = (uint8_t*)malloc((size_t)n);
+    for (int i = 0; i < n; i++) { const int in = reproj2(bR, bt, pts3d + 3 * i, pts2d + 2 * i, fx, fy, cx, cy) <= thr * thr; in_mask[i] = (uint8_t)in; if (mask) mask[i] = (uint8_t)in; cnt += in; }
+    if (T_ransac) memcpy(T_ransac, T, sizeof(double) * 16);
+    /* cv::solvePnPRansac (OpenCV 3.4 calib3d/src/solvepnp.cpp): after RANSAC the pose is re-estimated from the inliers of the winning model with solvePnP (P3P -> EPNP, which ends
+     * in Gauss-Newton on the reprojection error) and THAT pose is returned; the reported inliers stay those of the RANSAC model.  Restated as 8 Gauss-Newton steps on
+     * sum |proj(R X + t) - x|^2 over the inliers from the winning model, update R <- exp(w) R, t <- exp(w) t + v; a failed solve keeps the RANSAC model. */
+    {
+        double R[9], t[3]; memcpy(R, bR, sizeof R); memcpy(t, bt, sizeof t); int ok = 1;
+        for (int iter = 0; iter < 8 && ok; iter++) {
+            double H[6][6], g[6]; memset(H, 0, sizeof H); memset(g, 0, sizeof g);
+            for (int i = 0; i < n; i++) if (in_mask[i]) {
+                const float* X = pts3d + 3 * i; const float* x = pts2d + 2 * i;
+                const double xc = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0], yc = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1], zc = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+                const double iz = 1.0 / zc, ru = fx * xc * iz + cx - x[0], rv = fy * yc * iz + cy - x[1];
+                const double au[3] = {fx * iz, 0.0, -fx * xc * iz * iz}, av[3] = {0.0, fy * iz, -fy * yc * iz * iz};
+                const double ju[6] = {yc * au[2] - zc * au[1], zc * au[0] - xc * au[2], xc * au[1] - yc * au[0], au[0], au[1], au[2]};
+                const double jv[6] = {yc * av[2] - zc * av[1], zc * av[0] - xc * av[2], xc * av[1] - yc * av[0], av[0], av[1], av[2]};
+                for (int p = 0; p < 6; p++) { for (int c = 0; c < 6; c++) H[p][c] += ju[p] * ju[c] + jv[p] * jv[c]; g[p] += ju[p] * ru + jv[p] * rv; }
+            }
+            double L[6][6]; memcpy(L, H, sizeof L);
+            for (int j = 0; j < 6 && ok; j++) {
+                double s = L[j][j]; for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+                if (!(s > 1e-300)) { ok = 0; break; }
+                const double dj = sqrt(s); L[j][j] = dj;
+                for (int i = j + 1; i < 6; i++) { double v = L[i][j]; for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k]; L[i][j] = v / dj; }
+            }
+            if (!ok) break;
+            double y[6], d[6];
+            for (int i = 0; i < 6; i++) { double v = -g[i]; for (int k = 0; k < i; k++) v -= L[i][k] * y[k]; y[i] = v / L[i][i]; }
+            for (int i = 5; i >= 0; i--) { double v = y[i]; for (int k = i + 1; k < 6; k++) v -= L[k][i] * d[k]; d[i] = v / L[i][i]; }
+            const double th = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            if (th > 1e-12) {
+                const double kx = d[0] / th, ky = d[1] / th, kz = d[2] / th, c = cos(th), s = sin(th), v = 1 - c;
+                E[0] = c + kx * kx * v; E[1] = kx * ky * v - kz * s; E[2] = kx * kz * v + ky * s;
+                E[3] = ky * kx * v + kz * s; E[4] = c + ky * ky * v; E[5] = ky * kz * v - kx * s;
+                E[6] = kz * kx * v - ky * s; E[7] = kz * ky * v + kx * s; E[8] = c + kz * kz * v;
+            }
+            double Rn[9], tn[3];
+            for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rn[r * 3 + c] = E[r * 3] * R[c] + E[r * 3 + 1] * R[3 + c] + E[r * 3 + 2] * R[6 + c];
+                                          tn[r] = E[r * 3] * t[0] + E[r * 3 + 1] * t[1] + E[r * 3 + 2] * t[2] + d[3 + r]; }
+            memcpy(R, Rn, sizeof R); memcpy(t, tn, sizeof t);
+        }
+        int fin = ok; for (int k = 0; k < 9; k++) fin = fin && isfinite(R[k]); for (int k = 0; k < 3; k++) fin = fin && isfinite(t[k]);
+        if (fin) for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T[r * 4 + c] = R[r * 3 + c]; T[r * 4 + 3] = t[r]; }
+    }
+    free(in_mask);
     return cnt;
+}
+
+int vo_pnp_ransac(const float* pts3d, const float* pts2d, int n, double fx, double fy, double cx, double cy, int max_iters, double thr, double conf,
+                  uint64_t seed, double* T, uint8_t* mask)
+{
+    return vo_pnp_ransac_full(pts3d, pts2d, n, fx, fy, cx, cy, max_iters, thr, conf, seed, T, mask, NULL);
 }

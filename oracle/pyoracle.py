@@ -385,12 +385,15 @@ def box_decode(deltas, boxes, weights):
 
 
 # ---- P3P-RANSAC (pnp_oracle.c) -----------------------------------------------------------------------
-def pnp_ransac(pts3d, pts2d, K, max_iters=500, thr=0.4, conf=0.98, seed=1):
+def pnp_ransac(pts3d, pts2d, K, max_iters=500, thr=0.4, conf=0.98, seed=1, with_ransac_model=False):
+    """(T, mask, n): T = the pose cv::solvePnPRansac returns (refit on the inliers), mask / n = the inliers of the winning RANSAC model; with_ransac_model appends that model."""
     X = np.ascontiguousarray(pts3d, np.float32).reshape(-1, 3); x = np.ascontiguousarray(pts2d, np.float32).reshape(-1, 2)
-    T = np.zeros(16); mask = np.zeros(max(len(X), 1), np.uint8)
-    f = lib().vo_pnp_ransac
+    T = np.zeros(16); Tr = np.zeros(16); mask = np.zeros(max(len(X), 1), np.uint8)
+    f = lib().vo_pnp_ransac_full
     n = f(_p(X), _p(x), len(X), C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), max_iters, C.c_double(thr), C.c_double(conf),
-          C.c_uint64(seed), _p(T), _p(mask))
+          C.c_uint64(seed), _p(T), _p(mask), _p(Tr))
+    if with_ransac_model:
+        return T.reshape(4, 4), mask[:len(X)].astype(bool), n, Tr.reshape(4, 4)
     return T.reshape(4, 4), mask[:len(X)].astype(bool), n
 
 def p3p(P, j):

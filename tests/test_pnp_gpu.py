@@ -12,8 +12,17 @@ def test_pnp_ransac_matches_oracle(vido, oracle, n, outl, seed):
     ctx = vido.Context()
     s = vido.problems.synth_pose_scene(n, seed=seed, noise_px=0.05, outlier_frac=outl)
     T, mask, cnt = vido.pnp_ransac(ctx, s["Xw"], s["uv_cur"], s["K"], seed=seed)
-    Tr, maskr, cntr = oracle.pnp_ransac(s["Xw"], s["uv_cur"], s["K"], seed=seed)
+    Tr, maskr, cntr, Tm = oracle.pnp_ransac(s["Xw"], s["uv_cur"], s["K"], seed=seed, with_ransac_model=True)
     assert np.abs(T - Tr).max() < 1e-6
+    # the returned pose is the all-inlier refit (cv::solvePnPRansac re-estimates on the inliers, Tracking.cc:1967-1970 gets that pose): a least-squares pose over hundreds of
+    # points, closer to the truth than the 3-point model it started from, with a smaller reprojection RMS over the inliers
+    def rms(Tx):
+        Xc = s["Xw"][maskr] @ Tx[:3, :3].T + Tx[:3, 3]; fx, fy, cx, cy = s["K"]
+        return np.sqrt(np.mean((fx * Xc[:, 0] / Xc[:, 2] + cx - s["uv_cur"][maskr, 0]) ** 2 + (fy * Xc[:, 1] / Xc[:, 2] + cy - s["uv_cur"][maskr, 1]) ** 2))
+    assert rms(T) <= rms(Tm) + 1e-12
+    if n >= 200:
+        assert np.abs(T - s["T_cur"]).max() <= np.abs(Tm - s["T_cur"]).max()
+    Tr = Tm                                                           # the inlier mask belongs to the RANSAC model (OpenCV does not re-evaluate it after the refit)
     # inlier masks: EXACT, except for points whose squared reprojection error under the oracle's pose lies within EPS of the 0.4 px threshold (the two poses
     # differ by FP64 rounding of the quartic's roots, so only such points can fall on different sides)
     EPS = 1e-6

@@ -7,7 +7,7 @@
 // reduction — and a single-thread epilogue replays OpenCV's sequential bookkeeping (best-so-far, adaptive
 // niters = log(1-conf)/log(1-(1-eps)^4)) over the per-iteration counts, so the outcome equals the sequential loop
 // run with the same per-iteration samples.  Samples come from a counter-based generator (splitmix64 of seed and
-// iteration index) instead of OpenCV's global RNG; the final EPnP refit is omitted (LM refinement follows).
+// iteration index) instead of OpenCV's global RNG; OpenCV's final solvePnP over the inliers is the Gauss-Newton refit at the end of k_pnp_select.
 #include "common.hpp"
 #include <cfloat>
 
@@ -172,7 +172,56 @@ __device__ int ransac_update_iters(double p, double ep, int model_points, int ma
     num = log(num); denom = log(denom);
     return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)llrint(num / denom);
 }
-// sequential bookkeeping of cv::RANSAC over the precomputed hypotheses, then the inlier mask of the winner; one workgroup per problem
+// ---- all-inlier refit.  cv::solvePnPRansac does not return the winning minimal-sample model: after RANSAC it calls solvePnP on the inliers of that model
+// (calib3d/src/solvepnp.cpp, OpenCV 3.4: compressElems(...mask...) + solvePnP(opoints_inliers, ipoints_inliers, ..., SOLVEPNP_P3P -> SOLVEPNP_EPNP)), returns THAT pose,
+// and reports the inliers of the RANSAC model (the mask is not re-evaluated under the refitted pose).  EPnP ends in Gauss-Newton on the reprojection error; here the
+// refit is REFIT_ITERS Gauss-Newton steps on the same least-squares problem (sum over the inliers of |proj(R X + t) - x|^2) started at the winning model, pose update
+// R <- exp(w) R, t <- exp(w) t + v.  A failed 6x6 solve or a non-finite result keeps the RANSAC model (OpenCV keeps it when solvePnP fails).
+#define REFIT_ITERS 8
+__device__ inline void refit_rows(const double* R, const double* t, const float* X, const float* x, double fx, double fy, double cx, double cy, double ju[6], double jv[6], double& ru, double& rv)
+{
+    const double xc = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0], yc = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1], zc = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+    const double iz = 1.0 / zc;
+    ru = fx * xc * iz + cx - x[0]; rv = fy * yc * iz + cy - x[1];
+    const double au[3] = {fx * iz, 0.0, -fx * xc * iz * iz}, av[3] = {0.0, fy * iz, -fy * yc * iz * iz};      // d(u, v) / d(Xc)
+    // Xc moves by w x Xc + v: d/dw = (Xc x a)^T, d/dv = a^T
+    ju[0] = yc * au[2] - zc * au[1]; ju[1] = zc * au[0] - xc * au[2]; ju[2] = xc * au[1] - yc * au[0]; ju[3] = au[0]; ju[4] = au[1]; ju[5] = au[2];
+    jv[0] = yc * av[2] - zc * av[1]; jv[1] = zc * av[0] - xc * av[2]; jv[2] = xc * av[1] - yc * av[0]; jv[3] = av[0]; jv[4] = av[1]; jv[5] = av[2];
+}
+// solves the symmetric 6x6 system H d = -g (H upper triangle packed row-major: 21 entries) by Cholesky; false if not positive definite
+__device__ inline bool refit_solve(const double* Hp, const double* g, double d[6])
+{
+    double L[6][6];
+    for (int i = 0, q = 0; i < 6; i++) for (int j = i; j < 6; j++, q++) { L[i][j] = Hp[q]; L[j][i] = Hp[q]; }
+    for (int j = 0; j < 6; j++) {
+        double s = L[j][j]; for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+        if (!(s > 1e-300)) return false;
+        const double dj = sqrt(s); L[j][j] = dj;
+        for (int i = j + 1; i < 6; i++) { double v = L[i][j]; for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k]; L[i][j] = v / dj; }
+    }
+    double y[6];
+    for (int i = 0; i < 6; i++) { double v = -g[i]; for (int k = 0; k < i; k++) v -= L[i][k] * y[k]; y[i] = v / L[i][i]; }
+    for (int i = 5; i >= 0; i--) { double v = y[i]; for (int k = i + 1; k < 6; k++) v -= L[k][i] * d[k]; d[i] = v / L[i][i]; }
+    return true;
+}
+__device__ inline void refit_apply(double* R, double* t, const double* d)
+{
+    const double th = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (th > 1e-12) {                                        // Rodrigues
+        const double kx = d[0] / th, ky = d[1] / th, kz = d[2] / th, c = cos(th), s = sin(th), v = 1 - c;
+        E[0] = c + kx * kx * v; E[1] = kx * ky * v - kz * s; E[2] = kx * kz * v + ky * s;
+        E[3] = ky * kx * v + kz * s; E[4] = c + ky * ky * v; E[5] = ky * kz * v - kx * s;
+        E[6] = kz * kx * v - ky * s; E[7] = kz * ky * v + kx * s; E[8] = c + kz * kz * v;
+    }
+    double Rn[9], tn[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rn[r * 3 + c] = E[r * 3] * R[c] + E[r * 3 + 1] * R[3 + c] + E[r * 3 + 2] * R[6 + c];
+                                  tn[r] = E[r * 3] * t[0] + E[r * 3 + 1] * t[1] + E[r * 3 + 2] * t[2] + d[3 + r]; }
+    for (int k = 0; k < 9; k++) R[k] = Rn[k];
+    for (int k = 0; k < 3; k++) t[k] = tn[k];
+}
+
+// sequential bookkeeping of cv::RANSAC over the precomputed hypotheses, the inlier mask of the winner, then the refit on those inliers; one workgroup per problem
 __global__ __launch_bounds__(256) void k_pnp_select(const float* __restrict__ Xall, const float* __restrict__ xall, const PnpProb* __restrict__ prob, double fx, double fy, double cx, double cy,
                                                     int max_iters, double thr2, double conf, const double* __restrict__ models_all, const int* __restrict__ counts_all,
                                                     double* __restrict__ T_all /*[prob][16]*/, unsigned char* __restrict__ mask_all, int* __restrict__ n_inl_all)
@@ -196,6 +245,39 @@ __global__ __launch_bounds__(256) void k_pnp_select(const float* __restrict__ Xa
     __syncthreads();
     const int best = sbest;
     for (int i = threadIdx.x; i < n; i += 256) mask[i] = best >= 0 ? (unsigned char)(reproj2(models + 12 * best, models + 12 * best + 9, X + 3 * i, x + 2 * i, fx, fy, cx, cy) <= thr2) : 0;
+    if (best < 0) return;
+    // ---- refit on the inliers (mask[] entries are re-read by the thread that wrote them: same i -> threadIdx mapping)
+    __shared__ double sacc[4][27]; __shared__ double sRt[12]; __shared__ int sok;
+    if (threadIdx.x < 12) sRt[threadIdx.x] = models[12 * best + threadIdx.x];
+    if (threadIdx.x == 0) sok = 1;
+    __syncthreads();
+    for (int iter = 0; iter < REFIT_ITERS; iter++) {
+        double R[9], t[3], a[27];
+        for (int k = 0; k < 9; k++) R[k] = sRt[k];
+        for (int k = 0; k < 3; k++) t[k] = sRt[9 + k];
+        for (int k = 0; k < 27; k++) a[k] = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) if (mask[i]) {
+            double ju[6], jv[6], ru, rv; refit_rows(R, t, X + 3 * i, x + 2 * i, fx, fy, cx, cy, ju, jv, ru, rv);
+            for (int p = 0, q = 0; p < 6; p++) { for (int c = p; c < 6; c++, q++) a[q] += ju[p] * ju[c] + jv[p] * jv[c]; a[21 + p] += ju[p] * ru + jv[p] * rv; }
+        }
+        for (int k = 0; k < 27; k++) { double v = a[k]; for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64); a[k] = v; }
+        __syncthreads();                                      // (sRt has been read by everyone; sacc of the previous iteration consumed)
+        if ((threadIdx.x & 63) == 0) for (int k = 0; k < 27; k++) sacc[threadIdx.x >> 6][k] = a[k];
+        __syncthreads();
+        if (threadIdx.x == 0 && sok) {
+            double Hp[21], g[6], d[6];
+            for (int k = 0; k < 21; k++) Hp[k] = sacc[0][k] + sacc[1][k] + sacc[2][k] + sacc[3][k];
+            for (int k = 0; k < 6; k++) g[k] = sacc[0][21 + k] + sacc[1][21 + k] + sacc[2][21 + k] + sacc[3][21 + k];
+            if (refit_solve(Hp, g, d)) { double Rn[9], tn[3]; for (int k = 0; k < 9; k++) Rn[k] = sRt[k]; for (int k = 0; k < 3; k++) tn[k] = sRt[9 + k];
+                                         refit_apply(Rn, tn, d); for (int k = 0; k < 9; k++) sRt[k] = Rn[k]; for (int k = 0; k < 3; k++) sRt[9 + k] = tn[k]; }
+            else sok = 0;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && sok) {
+        bool fin = true; for (int k = 0; k < 12; k++) fin = fin && isfinite(sRt[k]);
+        if (fin) for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T_out[r * 4 + c] = sRt[r * 3 + c]; T_out[r * 4 + 3] = sRt[9 + r]; }
+    }
 }
 
 struct PnpState { char* d = nullptr; char* h = nullptr; size_t cap = 0; };

@@ -577,7 +577,11 @@ def analyse_image_static(net, feats, logits, deltas, out_hw, feed=(1088, 800), c
     out = net.heads_static(feats, logits, deltas, feed, cap)
     cap = out["boxes"].shape[0]
     rw, rh = float(W) / feed[1], float(H) / feed[0]
-    boxes = out["boxes"] * out["boxes"].new_tensor([rw, rh, rw, rh]) if rw != rh else out["boxes"] * rw
+    cache = net.__dict__.setdefault("_const_cache", {})            # constants are made once, outside any capture: tensor-from-list is a synchronous host-to-device copy, which a hipGraph capture forbids
+    key = ("box_scale", rw, rh, str(out["boxes"].device))
+    if key not in cache:
+        cache[key] = out["boxes"].new_tensor([rw, rh, rw, rh])
+    boxes = out["boxes"] * cache[key]
     live = (out["scores"] > confidence) & (torch.arange(cap, device=boxes.device) < out["n_det"])
     order = torch.sort(torch.where(live, out["scores"], out["scores"].new_full((), -1.0)), descending=True, stable=True)[1]
     labels = torch.where(live, out["labels"], torch.zeros_like(out["labels"]))[order]

@@ -152,14 +152,18 @@ class NetNodes:
                     self.g_trunk = _nets.Graphed(self._trunk_fn, [ex])
                     if not _os.environ.get("VIDO_NO_MASK_GRAPHS"):
                         mh.capture_buckets(self.g_trunk.static_out[0][:4], _nets.Graphed)      # the mask head per detection-count bucket, over the trunk's static feature maps
-                    if static_detector and not _os.environ.get("VIDO_NO_DET_GRAPH"):
-                        self._det_fn(ex); torch.cuda.synchronize()
-                        self.g_det = _nets.Graphed(self._det_fn, [ex])
-                        self._det_pin = torch.zeros(2, dtype=torch.int32).pin_memory()
                 except Exception as e:                                  # capture is an optimisation: report, run eagerly
                     self.graph_error = "%s: %s" % (type(e).__name__, e)
                     self.g_flow = self.g_depth = self.g_trunk = None
                     torch.cuda.synchronize()
+                if self.g_trunk is not None and static_detector and not _os.environ.get("VIDO_NO_DET_GRAPH"):
+                    try:                                                # on its own: a failure here leaves the three graphs above in place (dynamic head after the trunk graph)
+                        self._det_fn(ex); torch.cuda.synchronize()
+                        self.g_det = _nets.Graphed(self._det_fn, [ex])
+                    except Exception as e:
+                        self.graph_error = "detector graph: %s: %s" % (type(e).__name__, e)
+                        self.g_det = None
+                        torch.cuda.synchronize()
 
     @torch.no_grad()
     def infer(self, prev_bgr, cur_bgr):
