@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void k_bias_res_act(float* __restrict__ x, con
 //    so the result is bit-identical to the oracle's restatement;
 //  * results go to an LDS tile [64 channels][bins] (odd pitch) and leave as ONE contiguous run of out[roi][c0 .. c0+63][PH][PW]: full-line stores although lanes run over channels.
 struct RoiLevels { const float* feat[4]; int H[4], W[4]; float scale[4]; };     // channels-last maps
+template <int SR /* sampling ratio known at compile time (2: the node's setting; the 4 x 4 taps of a bin are then 16 independent loads in flight), 0: run-time / adaptive */>
 __global__ __launch_bounds__(256) void k_roi_align_nhwc(RoiLevels L, int C, const float* __restrict__ rois, int roi_stride /* 5: (batch, x1, y1, x2, y2); 4: (x1, y1, x2, y2) */,
                                                         const int* __restrict__ level /* null: level 0 */, int PH, int PW, int sampling, float* __restrict__ out)
 {
@@ -126,27 +127,50 @@ __global__ __launch_bounds__(256) void k_roi_align_nhwc(RoiLevels L, int C, cons
     const float sw = box[0] * scale, sh = box[1] * scale, ew = box[2] * scale, eh = box[3] * scale;
     const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);
     const float bh = rh / (float)PH, bw = rw / (float)PW;
-    const int gh = sampling > 0 ? sampling : (int)ceilf(rh / PH), gw = sampling > 0 ? sampling : (int)ceilf(rw / PW);
+    const int gh = SR > 0 ? SR : (sampling > 0 ? sampling : (int)ceilf(rh / PH)), gw = SR > 0 ? SR : (sampling > 0 ? sampling : (int)ceilf(rw / PW));
     const float count = (float)(gh * gw);
     const int c = min(c0 + lane, C - 1);                                      // lanes past C repeat the last channel (their column of the tile is never written out)
     const float* d = L.feat[l] + (size_t)bi * H * W * C + c;
+    // one sample: tap offsets (in pixels) and weights; outside the map by more than a pixel -> weights 0 (bilinear_interpolate returns 0: adding +0.f leaves the sum unchanged)
+    auto taps = [&](float y, float x, int& o1, int& o2, int& o3, int& o4, float& w1, float& w2, float& w3, float& w4) {
+        const bool out = y < -1.0 || y > H || x < -1.0 || x > W;
+        if (y <= 0) y = 0;
+        if (x <= 0) x = 0;
+        int yl = out ? 0 : (int)y, xl = out ? 0 : (int)x, yh, xh;
+        if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+        if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+        const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
+        o1 = yl * W + xl; o2 = yl * W + xh; o3 = yh * W + xl; o4 = yh * W + xh;
+        w1 = hy * hx; w2 = hy * lx; w3 = ly * hx; w4 = ly * lx;
+        return out;
+    };
     for (int bin = wave; bin < nbin; bin += 4) {
         const int ph = bin / PW, pw = bin - ph * PW;
         float acc = 0.f;
-        for (int iy = 0; iy < gh; iy++) {
-            const float y0 = sh + ph * bh + (float)(iy + .5f) * bh / (float)gh;
-            for (int ix = 0; ix < gw; ix++) {
-                float x = sw + pw * bw + (float)(ix + .5f) * bw / (float)gw, y = y0;
-                if (y < -1.0 || y > H || x < -1.0 || x > W) { acc += 0.f; continue; }      // bilinear_interpolate: outside the map by more than a pixel -> 0
-                if (y <= 0) y = 0;
-                if (x <= 0) x = 0;
-                int yl = (int)y, xl = (int)x, yh, xh;
-                if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
-                if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
-                const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
-                const float v1 = d[(size_t)(yl * W + xl) * C], v2 = d[(size_t)(yl * W + xh) * C], v3 = d[(size_t)(yh * W + xl) * C], v4 = d[(size_t)(yh * W + xh) * C];
-                const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-                acc += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+        if (SR == 2) {
+            int o[4][4]; float w[4][4], v[4][4]; bool out[4];
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++) {
+                const int iy = s2 >> 1, ix = s2 & 1;
+                const float y = sh + ph * bh + (float)(iy + .5f) * bh / (float)gh, x = sw + pw * bw + (float)(ix + .5f) * bw / (float)gw;
+                out[s2] = taps(y, x, o[s2][0], o[s2][1], o[s2][2], o[s2][3], w[s2][0], w[s2][1], w[s2][2], w[s2][3]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[s2][t] = d[(size_t)o[s2][t] * C];               // 16 coalesced 256-byte wave loads in flight
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++) acc += out[s2] ? 0.f : (w[s2][0] * v[s2][0] + w[s2][1] * v[s2][1] + w[s2][2] * v[s2][2] + w[s2][3] * v[s2][3]);
+        } else {
+            for (int iy = 0; iy < gh; iy++) {
+                const float y = sh + ph * bh + (float)(iy + .5f) * bh / (float)gh;
+                for (int ix = 0; ix < gw; ix++) {
+                    const float x = sw + pw * bw + (float)(ix + .5f) * bw / (float)gw;
+                    int o1, o2, o3, o4; float w1, w2, w3, w4;
+                    if (taps(y, x, o1, o2, o3, o4, w1, w2, w3, w4)) { acc += 0.f; continue; }
+                    const float v1 = d[(size_t)o1 * C], v2 = d[(size_t)o2 * C], v3 = d[(size_t)o3 * C], v4 = d[(size_t)o4 * C];
+                    acc += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+                }
             }
         }
         rl_tile[lane * pitch + bin] = acc / count;
@@ -446,7 +470,8 @@ static int roi_lds_limit(vido_ctx* ctx, size_t lds)
 {
     static size_t have = 48 * 1024;
     if (lds <= have) return VIDO_OK;
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_roi_align_nhwc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_roi_align_nhwc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_roi_align_nhwc<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     have = lds;
     return VIDO_OK;
 }
@@ -573,7 +598,8 @@ int vido_roi_align(vido_ctx* ctx, const float* feat, int B, int C, int H, int W,
     const size_t lds = (size_t)64 * ((pooled_h * pooled_w) | 1) * sizeof(float);
     if (lds > 150 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "roi_align: pooled size %d x %d too large", pooled_h, pooled_w);
     { int rc = roi_lds_limit(ctx, lds); if (rc) return rc; }
-    hipLaunchKernelGGL(k_roi_align_nhwc, dim3(n_rois, (C + 63) / 64), dim3(256), lds, st, L, C, dr, 5, (const int*)nullptr, pooled_h, pooled_w, sampling_ratio, dout);
+    if (sampling_ratio == 2) hipLaunchKernelGGL(k_roi_align_nhwc<2>, dim3(n_rois, (C + 63) / 64), dim3(256), lds, st, L, C, dr, 5, (const int*)nullptr, pooled_h, pooled_w, sampling_ratio, dout);
+    else hipLaunchKernelGGL(k_roi_align_nhwc<0>, dim3(n_rois, (C + 63) / 64), dim3(256), lds, st, L, C, dr, 5, (const int*)nullptr, pooled_h, pooled_w, sampling_ratio, dout);
     HIP_TRY(ctx, hipGetLastError());
     if (!on_device) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -700,7 +726,8 @@ int vido_roi_align_fpn_nhwc(vido_ctx* ctx, const float* const feat[4], const int
     const size_t lds = (size_t)64 * ((pooled_h * pooled_w) | 1) * sizeof(float);
     if (lds > 150 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "roi_align_fpn: pooled size %d x %d too large", pooled_h, pooled_w);
     { int rc = roi_lds_limit(ctx, lds); if (rc) return rc; }
-    hipLaunchKernelGGL(k_roi_align_nhwc, dim3(n, (C + 63) / 64), dim3(256), lds, st, L, C, boxes, 4, level, pooled_h, pooled_w, sampling_ratio, out);
+    if (sampling_ratio == 2) hipLaunchKernelGGL(k_roi_align_nhwc<2>, dim3(n, (C + 63) / 64), dim3(256), lds, st, L, C, boxes, 4, level, pooled_h, pooled_w, sampling_ratio, out);
+    else hipLaunchKernelGGL(k_roi_align_nhwc<0>, dim3(n, (C + 63) / 64), dim3(256), lds, st, L, C, boxes, 4, level, pooled_h, pooled_w, sampling_ratio, out);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }
