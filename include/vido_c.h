@@ -277,6 +277,13 @@ int vido_area_feed(vido_ctx* ctx, const uint8_t* bgr, int H, int W, float* out, 
 /* flow_net/src/layers.py:25-37 `Backward`: bilinear warp of x[B,C,H,W] by flow[B,2,H,W] (pixels; grid_sample with zero padding, align_corners False on the grid
  * -1 + (2i+1)/n + flow / ((n-1)/2)); DEVICE tensors, f32, contiguous. */
 int vido_backwarp(vido_ctx* ctx, const float* x, const float* flow, int B, int C, int H, int W, float* out);
+/* LiteFlowNet's regularisation stage (flow_net/src/layers.py:213-262, Regularization.forward) outside its convolutions, as two passes over DEVICE tensors (f32, NCHW):
+ * front: out[:, 0] = sqrt(sum_c (im1 - Backward(im2, flow * scale))^2), out[:, 1:3] = flow - mean (mean [B,2] = the spatial mean of flow, a device tensor); out has
+ *        out_channels >= 3 channels, the caller copies netFeat's features behind the first three (the stage's torch.cat);
+ * tail:  dist [B, K*K, H, W] = netDist's output -> out [B, 2, H, W] = (netScaleX(d * unfold(flow_x, K)), netScaleY(d * unfold(flow_y, K))) / sum_c d with
+ *        d = exp(-dist^2 - max_c(-dist^2)); wx / wy [K*K] and bx / by [1] are the two 1x1 convolutions' parameters; K in {3, 5, 7}. */
+int vido_lfn_reg_front(vido_ctx* ctx, const float* im1, const float* im2, const float* flow, const float* mean, float scale, int B, int C, int H, int W, float* out, int out_channels);
+int vido_lfn_reg_tail(vido_ctx* ctx, const float* dist, const float* flow, const float* wx, const float* bx, const float* wy, const float* by, int B, int K, int H, int W, float* out);
 /* layers.ROIAlign forward — mask_rcnn/maskrcnn_benchmark/csrc/cuda/ROIAlign_cuda.cu:257-299.  rois [n,5] =
  * (batch index, x1, y1, x2, y2); out [n, C, pooled_h, pooled_w]. */
 int vido_roi_align(vido_ctx* ctx, const float* feat, int B, int C, int H, int W, const float* rois, int n_rois,

@@ -39,6 +39,35 @@ def test_liteflownet_hip_correlation_matches_reference(ctx):
     assert rel_err(flow2.cpu().numpy(), G["lfn_flow"]) < TOL
 
 
+def test_liteflownet_fused_regularisation_passes(ctx):
+    """vido_lfn_reg_front / vido_lfn_reg_tail (everything of Regularization.forward outside its convolutions, layers.py:213-262, as two HIP passes) against the torch
+    expressions they replace, at the five levels' kernel sizes, and the whole network with them against the reference fixture."""
+    import torch.nn.functional as F
+    from vido_slam_amd.nets.liteflownet import backwarp
+    ops = nets.HipOps(ctx)
+    g = torch.Generator().manual_seed(11)
+    for k, (H, W) in ((3, (8, 10)), (3, (15, 20)), (5, (30, 40)), (5, (60, 80)), (7, (97, 131))):
+        nd = k * k
+        dist = torch.randn((2, nd, H, W), generator=g).cuda(); flow = (torch.randn((2, 2, H, W), generator=g) * 3).cuda()
+        sx = torch.nn.Conv2d(nd, 1, 1).cuda(); sy = torch.nn.Conv2d(nd, 1, 1).cuda()
+        with torch.no_grad():
+            d = dist.pow(2.0).neg(); d = (d - d.max(1, True)[0]).exp(); div = d.sum(1, True).reciprocal(); pad = (k - 1) // 2
+            ref = torch.cat([sx(d * F.unfold(flow[:, 0:1], k, 1, pad).view_as(d)) * div, sy(d * F.unfold(flow[:, 1:2], k, 1, pad).view_as(d)) * div], 1)
+            got = ops.lfn_reg_tail(dist, flow, sx, sy, k)
+        assert float((got - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max())), k
+        im1 = torch.rand((2, 3, H, W), generator=g).cuda(); im2 = torch.rand((2, 3, H, W), generator=g).cuda(); feat = torch.randn((2, 5, H, W), generator=g).cuda()
+        with torch.no_grad():
+            diff = (im1 - backwarp(im2, flow * 2.5)).pow(2.0).sum(1, True).sqrt()
+            ref = torch.cat([diff, flow - flow.flatten(2).mean(2, True).unsqueeze(-1), feat], 1)
+            got = ops.lfn_reg_front(im1, im2, flow, 2.5, feat)
+        assert float((got - ref).abs().max()) < 2e-5, k
+    net = nets.fill_deterministic(nets.LiteFlowNet(ops.correlation, epilogue=ops.bias_act_, warp=ops.backwarp, fused=ops), int(G["lfn_seed"])).eval().cuda()
+    a = torch.from_numpy(G["lfn_first"].astype(np.float32) / 255.0)[None].cuda(); b = torch.from_numpy(G["lfn_second"].astype(np.float32) / 255.0)[None].cuda()
+    assert rel_err(net(a, b).cpu().numpy(), G["lfn_flow"]) < TOL
+    net_p = nets.fill_deterministic(nets.LiteFlowNet(ops.correlation, epilogue=ops.bias_act_, warp=ops.backwarp, fused=ops, pair_batch=True), int(G["lfn_seed"])).eval().cuda()
+    assert rel_err(net_p(a, b).cpu().numpy(), G["lfn_flow"]) < TOL
+
+
 def test_hip_correlation_matches_torch_reference(ctx):
     ops = nets.HipOps(ctx)
     g = torch.Generator().manual_seed(5)

@@ -193,17 +193,14 @@ __device__ __forceinline__ void ba_flush_cam(const BaDev& P, int c, int cam0, do
 #pragma unroll
     for (int a = 0; a < 28; a++) acc[a] = 0;
 }
-__global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E, int xcd_order)
+__global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
 {
     __shared__ double lsum[LIN_SLOTS * 28];
     __shared__ int lused[LIN_SLOTS];
     const int lane = threadIdx.x & 63;
-    // XCD-aware order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), and the 8 XCDs' L2s are not coherent with each other.  The observations are sorted by camera and
-    // a landmark's slots (W / Cp, landmark-major) are written by the workgroups of its ~10 consecutive cameras: with the plain order those sit on all 8 XCDs, every 128-byte
-    // line of W is assembled from partial writes of several L2s and leaves each of them partially written (WRITE_SIZE 254 MB for 216 MB of stores, round 2).  Here XCD x owns
-    // the CONTIGUOUS eighth [x * per, (x + 1) * per) of the camera-sorted list, so the partial writes of a line meet in one L2 and leave it as a full line.
-    const int per = gridDim.x >> 3;                                 // the grid is a multiple of 8 workgroups
-    const int vb = xcd_order ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;      // (0: the plain order, kept for the A/B measurement — VIDO_BA_LIN_PLAIN=1)
+    // (round 3: giving every XCD one CONTIGUOUS eighth of the camera-sorted list — so that the partial-line writes of a landmark's W / Cp slots meet in one L2 — was
+    // measured and changed nothing: 109-112 us per 1 M edges either way, profiles/r3/README.md; the plain order stays)
+    const int vb = blockIdx.x;
     const size_t wave_g = (size_t)vb * (LIN_THREADS / 64) + (threadIdx.x >> 6);
     if ((size_t)vb * (LIN_THREADS / 64) * E * 64 >= (size_t)P.n_obs) return;      // (whole workgroup: the rounded-up tail)
     if (threadIdx.x < LIN_SLOTS * 28) lsum[threadIdx.x] = 0;
@@ -2567,7 +2564,6 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     else { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM_LDS_BYTES)); }
 
-    const int lin_xcd = getenv("VIDO_BA_LIN_PLAIN") ? 0 : 1;
     const int lin_E = 1;     // groups of 64 observations per wave in k_ba_linearize: with the LDS camera accumulators one group is fastest at every size measured (35 k .. 1 M edges)
     if (allreduce == vido_rccl_allreduce && user != (void*)ctx)      // the built-in path enqueues on user->stream: another context's stream would lose all ordering with this solve
         return vido_set_error(ctx, VIDO_E_INVALID, "ba: vido_rccl_allreduce must be passed with user = the context the solve runs on");
@@ -2601,7 +2597,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         // ---- linearise
         HIP_TRY(ctx, hipMemsetAsync(red, 0, ((size_t)n_pose * 36 + n6 + 8) * sizeof(double), st));
         HIP_TRY(ctx, hipEventRecord(BS->ev0, st));
-        if (no) hipLaunchKernelGGL(k_ba_linearize, dim3((((no + LIN_THREADS * lin_E - 1) / (LIN_THREADS * lin_E)) + 7) & ~7), dim3(LIN_THREADS), 0, st, D, lin_E, lin_xcd);      // multiple of 8: one contiguous eighth of the edges per XCD
+        if (no) hipLaunchKernelGGL(k_ba_linearize, dim3((no + LIN_THREADS * lin_E - 1) / (LIN_THREADS * lin_E)), dim3(LIN_THREADS), 0, st, D, lin_E);
         HIP_TRY(ctx, hipEventRecord(BS->ev1, st));
         if (nd) hipLaunchKernelGGL(k_badyn_linearize, dim3((nd + 255) / 256), dim3(256), 0, st, D);
         n_lin++;

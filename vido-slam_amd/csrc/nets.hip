@@ -464,6 +464,73 @@ __global__ __launch_bounds__(256) void k_backwarp(const float* __restrict__ x, c
     }
 }
 
+// ---- LiteFlowNet's regularisation stage as two passes (flow_net/src/layers.py:213-262, Regularization.forward) -----------------------------------------------------
+// front: diff = sqrt(sum_c (first - Backward(second, flow * scale))^2), centred = flow - mean(flow) -> channels 0..2 of the stage's input tensor (the netFeat features
+// are copied behind them); replaces mul + Backward + sub + pow + sum + sqrt + sub + cat (the spatial mean comes in as a device scalar pair).
+__global__ __launch_bounds__(256) void k_lfn_reg_front(const float* __restrict__ im1, const float* __restrict__ im2, const float* __restrict__ flow, const float* __restrict__ mean /*[B,2]*/,
+                                                       float scale, int B, int C, int H, int W, float* __restrict__ out, int out_ch)
+{
+    const int w = blockIdx.x * 64 + (threadIdx.x & 63), h = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (w >= W || h >= H) return;
+    const size_t hw = (size_t)H * W, o = (size_t)h * W + w;
+    const float fu = flow[(size_t)b * 2 * hw + o], fv = flow[(size_t)b * 2 * hw + hw + o];
+    const float u = fu * scale, v = fv * scale;
+    // the sampling grid of k_backwarp (layers.py:25-37), same expression order
+    const float stepx = ((1.0f - 1.0f / W) - (-1.0f + 1.0f / W)) / (float)(W - 1), stepy = ((1.0f - 1.0f / H) - (-1.0f + 1.0f / H)) / (float)(H - 1);
+    const float gx = ((-1.0f + 1.0f / W) + stepx * (float)w) + u / (((float)W - 1.0f) / 2.0f);
+    const float gy = ((-1.0f + 1.0f / H) + stepy * (float)h) + v / (((float)H - 1.0f) / 2.0f);
+    const float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float ax = ix - fx, ay = iy - fy;
+    const float wnw = (1.0f - ax) * (1.0f - ay), wne = ax * (1.0f - ay), wsw = (1.0f - ax) * ay, wse = ax * ay;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const size_t inw = (size_t)(vy0 ? y0 : 0) * W + (vx0 ? x0 : 0), ine = (size_t)(vy0 ? y0 : 0) * W + (vx1 ? x1 : 0);
+    const size_t isw = (size_t)(vy1 ? y1 : 0) * W + (vx0 ? x0 : 0), ise = (size_t)(vy1 ? y1 : 0) * W + (vx1 ? x1 : 0);
+    const float mnw = (vy0 && vx0) ? wnw : 0.f, mne = (vy0 && vx1) ? wne : 0.f, msw = (vy1 && vx0) ? wsw : 0.f, mse = (vy1 && vx1) ? wse : 0.f;
+    float acc2 = 0.f;
+    for (int c = 0; c < C; c++) {
+        const float* xc = im2 + ((size_t)b * C + c) * hw;
+        float wv = 0.f;
+        wv += xc[inw] * mnw; wv += xc[ine] * mne; wv += xc[isw] * msw; wv += xc[ise] * mse;
+        const float dlt = im1[((size_t)b * C + c) * hw + o] - wv;
+        acc2 += dlt * dlt;
+    }
+    float* ob = out + (size_t)b * out_ch * hw + o;
+    ob[0] = sqrtf(acc2); ob[hw] = fu - mean[2 * b]; ob[2 * hw] = fv - mean[2 * b + 1];
+}
+// tail: dist = netDist(...) [B, K*K, H, W] -> d = exp(-dist^2 - max_c(-dist^2)), div = 1 / sum_c d, out_x = (netScaleX(d * unfold(flow_x)) ) * div, out_y likewise, where
+// unfold is the K x K neighbourhood (zero padded) and netScaleX/Y are 1x1 convolutions K*K -> 1 (weights wx / wy, biases bx / by).  One thread per pixel; replaces
+// pow + neg + max + sub + exp + sum + reciprocal + 2 unfold + 2 mul + 2 (im2col + GEMM + bias) + 2 mul + cat.
+template <int K>
+__global__ __launch_bounds__(256) void k_lfn_reg_tail(const float* __restrict__ dist, const float* __restrict__ flow, const float* __restrict__ wx, const float* __restrict__ bx,
+                                                      const float* __restrict__ wy, const float* __restrict__ by, int B, int H, int W, float* __restrict__ out)
+{
+    constexpr int ND = K * K, PAD = (K - 1) / 2;
+    const int w = blockIdx.x * 64 + (threadIdx.x & 63), h = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (w >= W || h >= H) return;
+    const size_t hw = (size_t)H * W, o = (size_t)h * W + w;
+    const float* dp = dist + (size_t)b * ND * hw + o;
+    float e[ND]; float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < ND; c++) { const float v = dp[(size_t)c * hw]; e[c] = -(v * v); m = fmaxf(m, e[c]); }
+    const float* fxp = flow + (size_t)b * 2 * hw; const float* fyp = fxp + hw;
+    float s = 0.f, ax = 0.f, ay = 0.f;
+#pragma unroll
+    for (int c = 0; c < ND; c++) {
+        const float p = expf(e[c] - m);
+        s += p;
+        const int yy = h + c / K - PAD, xx = w + c % K - PAD;
+        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const size_t q = in ? (size_t)yy * W + xx : 0;
+        const float ux = in ? fxp[q] : 0.f, uy = in ? fyp[q] : 0.f;
+        ax += wx[c] * (p * ux); ay += wy[c] * (p * uy);
+    }
+    const float div = 1.0f / s;
+    out[(size_t)b * 2 * hw + o] = (ax + bx[0]) * div;
+    out[(size_t)b * 2 * hw + hw + o] = (ay + by[0]) * div;
+}
+
 // dynamic-LDS limit of k_roi_align_nhwc: raised only when a call needs more than any earlier one (the attribute call is kept out of hipGraph captures, whose
 // replays run with the limit the warm-up calls have set)
 static int roi_lds_limit(vido_ctx* ctx, size_t lds)
@@ -544,6 +611,31 @@ int vido_backwarp(vido_ctx* ctx, const float* x, const float* flow, int B, int C
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
     hipLaunchKernelGGL(k_backwarp, dim3((W + 63) / 64, (H + 3) / 4, B * ((C + BW_CG - 1) / BW_CG)), dim3(256), 0, st, x, flow, B, C, H, W, out);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+int vido_lfn_reg_front(vido_ctx* ctx, const float* im1, const float* im2, const float* flow, const float* mean, float scale, int B, int C, int H, int W, float* out, int out_channels)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!im1 || !im2 || !flow || !mean || !out || B < 1 || B > 65535 || C < 1 || H < 2 || W < 2 || out_channels < 3) return vido_set_error(ctx, VIDO_E_INVALID, "lfn_reg_front: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    hipLaunchKernelGGL(k_lfn_reg_front, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(256), 0, st, im1, im2, flow, mean, scale, B, C, H, W, out, out_channels);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+int vido_lfn_reg_tail(vido_ctx* ctx, const float* dist, const float* flow, const float* wx, const float* bx, const float* wy, const float* by, int B, int K, int H, int W, float* out)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!dist || !flow || !wx || !bx || !wy || !by || !out || B < 1 || B > 65535 || H < 1 || W < 1 || (K != 3 && K != 5 && K != 7)) return vido_set_error(ctx, VIDO_E_INVALID, "lfn_reg_tail: bad arguments (K must be 3, 5 or 7)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    const dim3 grid((W + 63) / 64, (H + 3) / 4, B);
+    if (K == 3) hipLaunchKernelGGL(k_lfn_reg_tail<3>, grid, dim3(256), 0, st, dist, flow, wx, bx, wy, by, B, H, W, out);
+    else if (K == 5) hipLaunchKernelGGL(k_lfn_reg_tail<5>, grid, dim3(256), 0, st, dist, flow, wx, bx, wy, by, B, H, W, out);
+    else hipLaunchKernelGGL(k_lfn_reg_tail<7>, grid, dim3(256), 0, st, dist, flow, wx, bx, wy, by, B, H, W, out);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }

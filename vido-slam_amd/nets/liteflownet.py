@@ -121,7 +121,12 @@ class _Regularization(nn.Module):
         self.netDist = _chain([(32, nd, k, 1, False)]) if level >= 5 else _chain([(32, nd, (k, 1), 1, False), (nd, nd, (1, k), 1, False)])
         self.netScaleX = nn.Conv2d(nd, 1, 1); self.netScaleY = nn.Conv2d(nd, 1, 1)
 
+    fused = None                           # LiteFlowNet(fused=HipOps) installs the two-pass HIP form of everything outside the convolutions (lfn_reg_front / lfn_reg_tail)
+
     def forward(self, im1, im2, f1, f2, flow):
+        if self.fused is not None and flow.is_cuda:
+            x = self.fused.lfn_reg_front(im1, im2, flow, self.scale, self.netFeat(f1))
+            return self.fused.lfn_reg_tail(self.netDist(self.netMain(x)), flow, self.netScaleX, self.netScaleY, self.k)
         diff = (im1 - self.warp(im2, flow * self.scale)).pow(2.0).sum(1, True).sqrt()
         centred = flow - flow.flatten(2).mean(2, True).unsqueeze(-1)
         d = self.netDist(self.netMain(torch.cat([diff, centred, self.netFeat(f1)], 1))).pow(2.0).neg()
@@ -137,8 +142,9 @@ class LiteFlowNet(nn.Module):
     """`correlation`: callable (first, second, stride) -> cost volume.  On the GPU pass HipOps(ctx).correlation (the HIP
     kernel); the CPU tests pass correlation_torch_reference."""
 
-    def __init__(self, correlation, epilogue=None, warp=None):
+    def __init__(self, correlation, epilogue=None, warp=None, fused=None, pair_batch=False):
         super().__init__()
+        self.pair_batch = pair_batch
         self.netFeatures = _Features()
         self.netMatching = nn.ModuleList([_Matching(l, correlation) for l in (2, 3, 4, 5, 6)])
         self.netSubpixel = nn.ModuleList([_Subpixel(l) for l in (2, 3, 4, 5, 6)])
@@ -151,6 +157,10 @@ class LiteFlowNet(nn.Module):
             for m in self.modules():
                 if isinstance(m, (_Matching, _Subpixel, _Regularization)):
                     m.warp = warp
+        if fused is not None:
+            for m in self.modules():
+                if isinstance(m, _Regularization):
+                    m.fused = fused
         # per-channel means as (non-persistent) buffers: the reference builds them with new_tensor inside forward (layers.py:286-287), a host-to-device
         # copy per call that a hipGraph capture cannot contain; not part of the state dict, so the reference's checkpoints still load unchanged
         self.register_buffer("_mean_first", torch.tensor(MEAN_FIRST).view(1, 3, 1, 1), persistent=False)
@@ -160,12 +170,21 @@ class LiteFlowNet(nn.Module):
     def forward(self, first, second):
         first = first - self._mean_first
         second = second - self._mean_second
-        f1, f2 = self.netFeatures(first), self.netFeatures(second)
-        p1, p2 = [first], [second]
-        for l in range(1, 6):
-            size = f1[l].shape[2:]
-            p1.append(F.interpolate(p1[-1], size=size, mode="bilinear", align_corners=False))
-            p2.append(F.interpolate(p2[-1], size=size, mode="bilinear", align_corners=False))
+        if self.pair_batch and first.is_cuda:
+            # the two images as one batch of 2 through the shared-weight feature pyramid and the image pyramid (same arithmetic per image; half the launches)
+            fb = self.netFeatures(torch.cat([first, second], 0)); B = first.shape[0]
+            f1, f2 = [t[:B] for t in fb], [t[B:] for t in fb]
+            pb = [torch.cat([first, second], 0)]
+            for l in range(1, 6):
+                pb.append(F.interpolate(pb[-1], size=fb[l].shape[2:], mode="bilinear", align_corners=False))
+            p1, p2 = [t[:B] for t in pb], [t[B:] for t in pb]
+        else:
+            f1, f2 = self.netFeatures(first), self.netFeatures(second)
+            p1, p2 = [first], [second]
+            for l in range(1, 6):
+                size = f1[l].shape[2:]
+                p1.append(F.interpolate(p1[-1], size=size, mode="bilinear", align_corners=False))
+                p2.append(F.interpolate(p2[-1], size=size, mode="bilinear", align_corners=False))
         flow = None
         for l in (-1, -2, -3, -4, -5):          # level 6 -> 2
             flow = self.netMatching[l](p1[l], p2[l], f1[l], f2[l], flow)

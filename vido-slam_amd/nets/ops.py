@@ -71,6 +71,30 @@ class HipOps:
         self.ctx._check(self.ctx.lib.vido_backwarp(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(flow.data_ptr()), x.shape[0], x.shape[1], x.shape[2], x.shape[3], C.c_void_p(out.data_ptr())))
         return out
 
+    def lfn_reg_front(self, im1, im2, flow, scale, feat):
+        """Regularization.forward up to netMain's input (layers.py:236-243): torch.cat([sqrt(sum((im1 - Backward(im2, flow * scale))^2)), flow - mean(flow), feat], 1) with the
+        first three channels from one HIP pass."""
+        im1 = im1.contiguous(); im2 = im2.contiguous(); flow = flow.contiguous()
+        B, Cc, H, W = im1.shape
+        out = torch.empty((B, 3 + feat.shape[1], H, W), device=im1.device, dtype=torch.float32)
+        mean = flow.flatten(2).mean(2).contiguous()
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_lfn_reg_front(self.ctx.h, C.c_void_p(im1.data_ptr()), C.c_void_p(im2.data_ptr()), C.c_void_p(flow.data_ptr()), C.c_void_p(mean.data_ptr()),
+                                                        C.c_float(scale), B, Cc, H, W, C.c_void_p(out.data_ptr()), out.shape[1]))
+        out[:, 3:] = feat
+        return out
+
+    def lfn_reg_tail(self, dist, flow, scale_x, scale_y, k):
+        """Regularization.forward after netDist (layers.py:245-262); scale_x / scale_y: the netScaleX / netScaleY modules (Conv2d(k*k, 1, 1))."""
+        dist = dist.contiguous(); flow = flow.contiguous()
+        B, nd, H, W = dist.shape
+        assert nd == k * k
+        out = torch.empty((B, 2, H, W), device=dist.device, dtype=torch.float32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_lfn_reg_tail(self.ctx.h, C.c_void_p(dist.data_ptr()), C.c_void_p(flow.data_ptr()), C.c_void_p(scale_x.weight.data_ptr()), C.c_void_p(scale_x.bias.data_ptr()),
+                                                       C.c_void_p(scale_y.weight.data_ptr()), C.c_void_p(scale_y.bias.data_ptr()), B, int(k), H, W, C.c_void_p(out.data_ptr())))
+        return out
+
     def roi_align(self, feat, rois, output_size, spatial_scale, sampling_ratio):
         if not feat.is_cuda:
             raise RuntimeError("HipOps.roi_align needs CUDA(HIP) tensors; there is no CPU fallback")
