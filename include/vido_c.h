@@ -282,6 +282,9 @@ int vido_backwarp(vido_ctx* ctx, const float* x, const float* flow, int B, int C
  *        out_channels >= 3 channels, the caller copies netFeat's features behind the first three (the stage's torch.cat);
  * tail:  dist [B, K*K, H, W] = netDist's output -> out [B, 2, H, W] = (netScaleX(d * unfold(flow_x, K)), netScaleY(d * unfold(flow_y, K))) / sum_c d with
  *        d = exp(-dist^2 - max_c(-dist^2)); wx / wy [K*K] and bx / by [1] are the two 1x1 convolutions' parameters; K in {3, 5, 7}. */
+/* Depthwise ConvTranspose2d(C, C, 4, stride 2, padding 1, groups = C, bias = False) on DEVICE tensors: x [B,C,H,W] -> out [B,C,2H,2W], weight [C,1,4,4]; the input passes
+ * through LeakyReLU(input_slope) first (1 = none).  LiteFlowNet's netUpflow / netUpcorr (flow_net/src/layers.py:105-108, 130-135). */
+int vido_deconv4s2_depthwise(vido_ctx* ctx, const float* x, const float* weight, int B, int C, int H, int W, float input_slope, float* out);
 int vido_lfn_reg_front(vido_ctx* ctx, const float* im1, const float* im2, const float* flow, const float* mean, float scale, int B, int C, int H, int W, float* out, int out_channels);
 int vido_lfn_reg_tail(vido_ctx* ctx, const float* dist, const float* flow, const float* wx, const float* bx, const float* wy, const float* by, int B, int K, int H, int W, float* out);
 /* layers.ROIAlign forward — mask_rcnn/maskrcnn_benchmark/csrc/cuda/ROIAlign_cuda.cu:257-299.  rois [n,5] =

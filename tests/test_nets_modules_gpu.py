@@ -61,6 +61,12 @@ def test_liteflownet_fused_regularisation_passes(ctx):
             ref = torch.cat([diff, flow - flow.flatten(2).mean(2, True).unsqueeze(-1), feat], 1)
             got = ops.lfn_reg_front(im1, im2, flow, 2.5, feat)
         assert float((got - ref).abs().max()) < 2e-5, k
+    for Cc, (H, W) in ((2, (15, 20)), (49, (31, 41)), (49, (120, 160))):
+        x = torch.randn((2, Cc, H, W), generator=g).cuda()
+        dc = torch.nn.ConvTranspose2d(Cc, Cc, 4, 2, 1, bias=False, groups=Cc).cuda()
+        with torch.no_grad():
+            assert float((ops.deconv4s2_depthwise(x, dc.weight) - dc(x)).abs().max()) < 1e-5
+            assert float((ops.deconv4s2_depthwise(x, dc.weight, 0.1) - dc(F.leaky_relu(x, 0.1))).abs().max()) < 1e-5
     net = nets.fill_deterministic(nets.LiteFlowNet(ops.correlation, epilogue=ops.bias_act_, warp=ops.backwarp, fused=ops), int(G["lfn_seed"])).eval().cuda()
     a = torch.from_numpy(G["lfn_first"].astype(np.float32) / 255.0)[None].cuda(); b = torch.from_numpy(G["lfn_second"].astype(np.float32) / 255.0)[None].cuda()
     assert rel_err(net(a, b).cpu().numpy(), G["lfn_flow"]) < TOL

@@ -31,6 +31,10 @@
 
 #define BA_LDS_MAX_N6 120          // reduced systems up to 20 cameras (the reference WINDOW_SIZE) accumulate / factor in LDS
 
+// One slot record per observation, landmark-major: W (18 doubles) and Cp (9) side by side in 32 doubles = 256 bytes = two whole cache lines.  Round 2 kept two dense arrays
+// (144- and 72-byte records): a record then shared its first and last line with its neighbours — other landmarks, written by other waves at other times — so lines left
+// the L2 partially written (WRITE_SIZE 254 MB for 216 MB of stores) and the memory side had to merge them.  With line-aligned records every line is written by ONE lane.
+#define BA_REC 32
 struct BaDev {
     int n_cam, n_pt, n_obs, n_odo, prior_cam, use_huber, n6, pt_lo;
     double info_obs, info_odo, info_prior, huber_obs, huber_odo;
@@ -39,9 +43,9 @@ struct BaDev {
     const int *pt_start;                                    // [n_ptl+1] CSR over landmark-major slots
     const int *slot_cam;                                    // [n_obs] camera of each landmark-major slot
     const int *odo_i, *odo_j; const double* odo_T; double prior_T[12];
-    double *W;                                              // [n_obs*18] landmark-major
+    double *W;                                              // [n_obs*BA_REC] landmark-major slot RECORDS of BA_REC doubles (256 bytes, line-aligned): [0,18) W (6x3), [18,27) Cp = point-side terms (Hpp 6 | bp 3), rest padding
     double *Hpp, *bp;                                       // [n_ptl*6], [n_ptl*3]: summed from Cp by k_ba_schur (no atomics)
-    double *Cp;                                             // [n_obs*9] landmark-major: point-side terms of one observation (Hpp 6 | bp 3)
+    double *Cp;                                             // = W + 18: the Cp part of slot s is Cp[BA_REC * s + a] (kept as a member for readability)
     double *Hcd, *bc, *Hodo;                                // [n_cam*36], [n6], [n_odo*36]
     double *S, *r, *x;                                      // [n6*n6], [n6], [n6]
     double *scal;                                           // [8]: 0 chi2 1 maxdiag 2 tempChi 3 scale 4 ok
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
             for (int a = 0; a < 6; a++)
 #pragma unroll
                 for (int b = 0; b < 3; b++) wv[a * 3 + b] = wo * (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b]);
-            double2* Wk2 = (double2*)(P.W + 18 * slot);
+            double2* Wk2 = (double2*)(P.W + BA_REC * slot);
 #pragma unroll
             for (int a = 0; a < 9; a++) Wk2[a] = make_double2(wv[2 * a], wv[2 * a + 1]);
             double cv[9];
@@ -258,13 +262,11 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
 #pragma unroll
                 for (int b = a; b < 3; b++) cv[q++] = wo * (Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b] + Jp[6 + a] * Jp[6 + b]);
             }
-            // 9 doubles = 72 B per slot: 16-byte aligned for even slots, 8 off for odd ones — four 16-byte stores from the aligned address + one 8-byte store
-            double* Ck = P.Cp + 9 * slot;
-            const bool odd = (slot & 1) != 0;
-            double2* Ck2 = (double2*)(Ck + (odd ? 1 : 0));
+            // Cp: 9 doubles behind W in the same record (16-byte aligned: four 16-byte stores + one 8-byte store)
+            double2* Ck2 = (double2*)(P.W + BA_REC * slot + 18);
 #pragma unroll
-            for (int a = 0; a < 4; a++) Ck2[a] = make_double2(odd ? cv[2 * a + 1] : cv[2 * a], odd ? cv[2 * a + 2] : cv[2 * a + 1]);
-            Ck[odd ? 0 : 8] = odd ? cv[0] : cv[8];
+            for (int a = 0; a < 4; a++) Ck2[a] = make_double2(cv[2 * a], cv[2 * a + 1]);
+            P.W[BA_REC * slot + 26] = cv[8];
         }
         // fold the group into the register sums, one camera at a time (cameras are non-decreasing along the lanes)
         unsigned long long rem = j < E ? __ballot(act) : 1ull;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev P, int n_ptl)
     for (int a = tid; a < P.n6; a += nt) m = fmax(m, fabs(P.Hcd[36 * (a / 6) + 7 * (a % 6)]));
     for (int l = tid; l < n_ptl; l += nt) {          // runs before k_ba_schur has summed Hpp: diagonal of the landmark block from its slots
         double h0 = 0, h3 = 0, h5 = 0;
-        for (int i = P.pt_start[l]; i < P.pt_start[l + 1]; i++) { h0 += P.Cp[9 * (size_t)i]; h3 += P.Cp[9 * (size_t)i + 3]; h5 += P.Cp[9 * (size_t)i + 5]; }
+        for (int i = P.pt_start[l]; i < P.pt_start[l + 1]; i++) { h0 += P.Cp[BA_REC * (size_t)i]; h3 += P.Cp[BA_REC * (size_t)i + 3]; h5 += P.Cp[BA_REC * (size_t)i + 5]; }
         m = fmax(m, fmax(fabs(h0), fmax(fabs(h3), fabs(h5))));
     }
     if (n_ptl >= 0) for (int l = tid; l < P.n_dyn; l += nt) m = fmax(m, fmax(fabs(P.Vd[6 * (size_t)l]), fmax(fabs(P.Vd[6 * (size_t)l + 3]), fabs(P.Vd[6 * (size_t)l + 5]))));
@@ -410,13 +412,13 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 512) void k_ba_schur(BaDev P, in
             const int k = min(cnt, kcap);
             double* Wl = stage; double* WDl = stage + kcap * 18; int* scam = (int*)(stage + 2 * kcap * 18); int* sord = scam + kcap;
             if (lane < k) { const int cp = P.slot_cam[beg + lane]; scam[lane] = cp; sord[lane] = MODE == 2 ? P.slot_ord[beg + lane] : cp; }
-            for (int t = lane; t < k * 18; t += 64) Wl[t] = P.W[18 * (size_t)beg + t];
+            for (int t = lane; t < k * 18; t += 64) { const int sl = t / 18; Wl[t] = P.W[BA_REC * (size_t)(beg + sl) + (t - sl * 18)]; }
             // point-side block of the landmark = sum of its slots' terms (lane i holds slot i, tracks have <= 64 observations); kept for the
             // back-substitution
             double H6[9];
             {
 #pragma unroll
-              for (int a = 0; a < 9; a++) H6[a] = lane < cnt ? P.Cp[9 * (size_t)(beg + lane) + a] : 0.0;
+              for (int a = 0; a < 9; a++) H6[a] = lane < cnt ? P.Cp[BA_REC * (size_t)(beg + lane) + a] : 0.0;
 #pragma unroll
               for (int a = 0; a < 9; a++) {
 #pragma unroll
@@ -539,11 +541,11 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
 #pragma unroll
             for (int n = 0; n < SM_NL; n++) {
 #pragma unroll
-                for (int a = 0; a < 9; a++) cp[n][a] = lane < cnt[n] ? P.Cp[9 * (size_t)(beg[n] + lane) + a] : 0.0;
+                for (int a = 0; a < 9; a++) cp[n][a] = lane < cnt[n] ? P.Cp[BA_REC * (size_t)(beg[n] + lane) + a] : 0.0;
                 // the W rows of the first 64 (slot, component) pairs — all of them for tracks of up to 10 observations
                 const bool on = lane < cnt[n] * 6; const int sl = lane / 6, a = lane - sl * 6;
                 wcol[n] = on ? 6 * (P.slot_ord[beg[n] + sl] - cbase) + a : 0;
-                const double* w = P.W + 18 * (size_t)(beg[n] + (on ? sl : 0)) + 3 * a;
+                const double* w = P.W + BA_REC * (size_t)(beg[n] + (on ? sl : 0)) + 3 * a;
                 wv[n][0] = on ? w[0] : 0.0; wv[n][1] = on ? w[1] : 0.0; wv[n][2] = on ? w[2] : 0.0;
             }
             for (int t = threadIdx.x; t < SM_M_DOUBLES + 3 * SM_L + 9 * SM_L + 96; t += 1024) M[t] = 0.0;
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
                 }
                 for (int t = lane + 64; t < cnt[n] * 6; t += 64) {          // tracks longer than 10 observations
                     const int sl = t / 6, a = t - sl * 6, col = 6 * (P.slot_ord[beg[n] + sl] - cbase) + a;
-                    const double* w = P.W + 18 * (size_t)(beg[n] + sl) + 3 * a;
+                    const double* w = P.W + BA_REC * (size_t)(beg[n] + sl) + 3 * a;
                     const double w0 = w[0], w1 = w[1], w2 = w[2];
                     M[SM_IDX(row0, col)] = w0 * i00; M[SM_IDX(row0 + 1, col)] = w0 * x01 + w1 * i11; M[SM_IDX(row0 + 2, col)] = w0 * x02 + w1 * x12 + w2 * i22;
                 }
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_long(BaDev P, double lambda, c
     double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = tid; i < k; i += 256) {
 #pragma unroll
-        for (int a = 0; a < 9; a++) h[a] += P.Cp[9 * (size_t)(beg + i) + a];
+        for (int a = 0; a < 9; a++) h[a] += P.Cp[BA_REC * (size_t)(beg + i) + a];
     }
 #pragma unroll
     for (int a = 0; a < 9; a++) {
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_long(BaDev P, double lambda, c
     double Di[9]; for (int a = 0; a < 9; a++) Di[a] = sDi[a];
     const double b0 = sH[6], b1 = sH[7], b2 = sH[8];
     for (int t = tid; t < k * 6; t += 256) {                 // rhs: r_c -= (W_i Di) b
-        const double* w = P.W + 18 * (size_t)(beg + t / 6) + 3 * (t % 6);
+        const double* w = P.W + BA_REC * (size_t)(beg + t / 6) + 3 * (t % 6);
         const double d0 = w[0] * Di[0] + w[1] * Di[3] + w[2] * Di[6], d1 = w[0] * Di[1] + w[1] * Di[4] + w[2] * Di[7], d2 = w[0] * Di[2] + w[1] * Di[5] + w[2] * Di[8];
         atomicAdd(P.r + 6 * P.slot_cam[beg + t / 6] + t % 6, -(d0 * b0 + d1 * b1 + d2 * b2));
     }
@@ -673,7 +675,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_long(BaDev P, double lambda, c
         while (i * (i + 1) / 2 > pq) i--;
         while ((i + 1) * (i + 2) / 2 <= pq) i++;
         const int j = (int)(pq - i * (i + 1) / 2);
-        const double* Wi = P.W + 18 * (size_t)(beg + i); const double* Wj = P.W + 18 * (size_t)(beg + j);
+        const double* Wi = P.W + BA_REC * (size_t)(beg + i); const double* Wj = P.W + BA_REC * (size_t)(beg + j);
         const int pi = P.slot_cam[beg + i], pj = P.slot_cam[beg + j];
 #pragma unroll
         for (int a = 0; a < 6; a++) {
@@ -1886,7 +1888,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev P, int n_ptl, double l
         double t0 = 0, t1 = 0, t2 = 0;
         if (on) {
             for (int s = P.pt_start[l] + sub; s < P.pt_start[l + 1]; s += 8) {
-                const double* W = P.W + 18 * (size_t)s; const double* xc = P.x + 6 * P.slot_cam[s];
+                const double* W = P.W + BA_REC * (size_t)s; const double* xc = P.x + 6 * P.slot_cam[s];
 #pragma unroll
                 for (int a = 0; a < 6; a++) { t0 -= W[a * 3] * xc[a]; t1 -= W[a * 3 + 1] * xc[a]; t2 -= W[a * 3 + 2] * xc[a]; }
             }
@@ -2388,7 +2390,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     maxk = std::min(maxk, 64);
     // ---- device buffers
     {   // size the persistent pool (device + pinned mirror for the uploads) for this problem
-        const size_t ndb = (size_t)n_pose * (24 + 36 + 36) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + 18 + 9) + (size_t)n_cc * (12 + 36 + 2) + (size_t)n6 * n6 + 5 * (size_t)n6 + 64 +
+        const size_t ndb = (size_t)n_pose * (24 + 36 + 36) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + BA_REC) + (size_t)n_cc * (12 + 36 + 2) + (size_t)n6 * n6 + 5 * (size_t)n6 + 64 +
                            (size_t)nd * (3 + 3 + 3 + 6 + 3 + 9 + 18 * 4 + 3);
         const size_t ni32 = 2 * (size_t)n_pose + 5 * (size_t)no + 4 * (size_t)n_ptl + (size_t)n_ptl / 32 + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 256;
         const size_t need = ndb * 8 + ni32 * 4 + 96 * 256;
@@ -2421,7 +2423,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     D.obs_meas = A.put(omeas.data(), (size_t)no * 3, st); D.pt_start = A.put(pstart.data(), n_ptl + 1, st); D.slot_cam = A.put(slotcam.data(), no, st);
     D.odo_i = A.put(cc_i.data(), n_cc, st); D.odo_j = A.put(cc_j.data(), n_cc, st); D.odo_T = A.put(cc_T.data(), (size_t)n_cc * 12, st);
     D.odo_info = A.put(cc_info.data(), n_cc, st); D.odo_delta = A.put(cc_delta.data(), n_cc, st);
-    D.W = A.get<double>((size_t)no * 18); D.Cp = A.get<double>((size_t)no * 9); D.Hpp = A.get<double>((size_t)n_ptl * 6); D.bp = A.get<double>((size_t)n_ptl * 3);
+    D.W = A.get<double>((size_t)no * BA_REC); D.Cp = D.W + 18;      /* the arena hands out 256-byte aligned blocks: records are line-aligned */
+    D.Hpp = A.get<double>((size_t)n_ptl * 6); D.bp = A.get<double>((size_t)n_ptl * 3);
     D.Hodo = A.get<double>((size_t)n_cc * 36);
     // object part
     D.n_dyn = nd; D.n_chain = n_chain; D.info_dyn = dy.info_dyn; D.info_tern = dy.info_tern; D.huber_dyn = dy.huber_dyn; D.huber_tern = dy.huber_tern;

@@ -531,6 +531,30 @@ __global__ __launch_bounds__(256) void k_lfn_reg_tail(const float* __restrict__ 
     out[(size_t)b * 2 * hw + hw + o] = (ay + by[0]) * div;
 }
 
+// Depthwise ConvTranspose2d(C, C, kernel 4, stride 2, padding 1, groups = C, no bias): LiteFlowNet's netUpflow (2 channels) and netUpcorr (49 channels)
+// (flow_net/src/layers.py:105-108).  out[c][oy][ox] = sum over the (at most) 2 x 2 input pixels iy = (oy + 1 - ky) / 2, ix = (ox + 1 - kx) / 2 with ky = (oy + 1) % 2 + {0, 2},
+// kx likewise, of act(in[c][iy][ix]) * w[c][ky][kx]; act = LeakyReLU(slope) of the INPUT (slope 1: none) — the matching stage applies it to the cost volume just before
+// netUpcorr, so that pass is folded in.  One thread per output pixel, memory-bound (MIOpen runs this as a grouped backward-data convolution: 70 us for 49 x 120 x 160).
+__global__ __launch_bounds__(256) void k_deconv4s2_dw(const float* __restrict__ in, const float* __restrict__ wgt /*[C][4][4]*/, int C, int H, int W, float slope, float* __restrict__ out)
+{
+    const int OW = 2 * W, OH = 2 * H;
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6), bc = blockIdx.z, c = bc % C;
+    if (ox >= OW || oy >= OH) return;
+    const float* ip = in + (size_t)bc * H * W; const float* wp = wgt + 16 * c;
+    const int ky0 = (oy + 1) & 1, kx0 = (ox + 1) & 1, iy0 = (oy + 1 - ky0) >> 1, ix0 = (ox + 1 - kx0) >> 1;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const int iy = iy0 - a, ky = ky0 + 2 * a;
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int ix = ix0 - b, kx = kx0 + 2 * b;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) { float v = ip[(size_t)iy * W + ix]; v = v > 0.f ? v : v * slope; acc += v * wp[ky * 4 + kx]; }
+        }
+    }
+    out[((size_t)bc * OH + oy) * OW + ox] = acc;
+}
+
 // dynamic-LDS limit of k_roi_align_nhwc: raised only when a call needs more than any earlier one (the attribute call is kept out of hipGraph captures, whose
 // replays run with the limit the warm-up calls have set)
 static int roi_lds_limit(vido_ctx* ctx, size_t lds)
@@ -611,6 +635,17 @@ int vido_backwarp(vido_ctx* ctx, const float* x, const float* flow, int B, int C
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
     hipLaunchKernelGGL(k_backwarp, dim3((W + 63) / 64, (H + 3) / 4, B * ((C + BW_CG - 1) / BW_CG)), dim3(256), 0, st, x, flow, B, C, H, W, out);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+int vido_deconv4s2_depthwise(vido_ctx* ctx, const float* x, const float* weight, int B, int C, int H, int W, float input_slope, float* out)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!x || !weight || !out || B < 1 || C < 1 || H < 1 || W < 1 || (long long)B * C > 65535) return vido_set_error(ctx, VIDO_E_INVALID, "deconv4s2_depthwise: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    hipLaunchKernelGGL(k_deconv4s2_dw, dim3((2 * W + 63) / 64, (2 * H + 3) / 4, B * C), dim3(256), 0, st, x, weight, C, H, W, input_slope, out);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }

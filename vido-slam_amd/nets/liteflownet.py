@@ -17,8 +17,9 @@ class _Chain(nn.Sequential):
     """nn.Sequential with the reference's index layout (conv, lrelu, conv, ...).  With `epilogue` set (HipOps.bias_act_, GPU only) every
     Conv2d runs without its bias and the bias add + the following LeakyReLU become one in-place HIP pass."""
     epilogue = None
+    epilogue_res = None                    # HipOps.bias_res_act_: the chain's last bias add fused with the residual the caller adds (flow + netMain(...), layers.py:160, 199)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         mods = list(self)
         i = 0
         while i < len(mods):
@@ -26,11 +27,15 @@ class _Chain(nn.Sequential):
             if self.epilogue is not None and isinstance(m, nn.Conv2d) and x.is_cuda and m.bias is not None:
                 x = F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
                 act = i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU)
-                x = self.epilogue(x.contiguous(), m.bias, LEAK if act else 1.0)
+                last = i + (2 if act else 1) >= len(mods)
+                if last and residual is not None and self.epilogue_res is not None and not act:
+                    x = self.epilogue_res(x.contiguous(), m.bias, residual.contiguous(), 1.0); residual = None
+                else:
+                    x = self.epilogue(x.contiguous(), m.bias, LEAK if act else 1.0)
                 i += 2 if act else 1
             else:
                 x = m(x); i += 1
-        return x
+        return x if residual is None else residual + x
 
 
 def _chain(specs):
@@ -85,15 +90,20 @@ class _Matching(nn.Module):
         self.netUpcorr = nn.ConvTranspose2d(49, 49, 4, 2, 1, bias=False, groups=49) if level < 4 else None
         self.netMain = _flow_head(49, k)
 
+    fused = None                           # LiteFlowNet(fused=HipOps): the two depthwise transposed convolutions as one-pass HIP kernels (LeakyReLU of the cost volume folded in)
+
     def forward(self, im1, im2, f1, f2, flow):
         f1, f2 = self.netFeat(f1), self.netFeat(f2)
+        fz = self.fused if f1.is_cuda else None
         if flow is not None:
-            flow = self.netUpflow(flow)
+            flow = fz.deconv4s2_depthwise(flow, self.netUpflow.weight) if fz is not None else self.netUpflow(flow)
             f2 = self.warp(f2, flow * self.scale)
-        c = F.leaky_relu(self.corr(f1, f2, self.stride), LEAK)
+        c = self.corr(f1, f2, self.stride)
         if self.netUpcorr is not None:
-            c = self.netUpcorr(c)
-        return (flow if flow is not None else 0.0) + self.netMain(c)
+            c = fz.deconv4s2_depthwise(c, self.netUpcorr.weight, LEAK) if fz is not None else self.netUpcorr(F.leaky_relu(c, LEAK))
+        else:
+            c = F.leaky_relu(c, LEAK)
+        return self.netMain(c, residual=flow) if flow is not None else self.netMain(c)
 
 
 class _Subpixel(nn.Module):
@@ -107,7 +117,7 @@ class _Subpixel(nn.Module):
     def forward(self, im1, im2, f1, f2, flow):
         f1, f2 = self.netFeat(f1), self.netFeat(f2)
         f2 = self.warp(f2, flow * self.scale)
-        return flow + self.netMain(torch.cat([f1, f2, flow], 1))
+        return self.netMain(torch.cat([f1, f2, flow], 1), residual=flow)
 
 
 class _Regularization(nn.Module):
@@ -142,7 +152,7 @@ class LiteFlowNet(nn.Module):
     """`correlation`: callable (first, second, stride) -> cost volume.  On the GPU pass HipOps(ctx).correlation (the HIP
     kernel); the CPU tests pass correlation_torch_reference."""
 
-    def __init__(self, correlation, epilogue=None, warp=None, fused=None, pair_batch=False):
+    def __init__(self, correlation, epilogue=None, warp=None, fused=None, pair_batch=True):
         super().__init__()
         self.pair_batch = pair_batch
         self.netFeatures = _Features()
@@ -150,16 +160,17 @@ class LiteFlowNet(nn.Module):
         self.netSubpixel = nn.ModuleList([_Subpixel(l) for l in (2, 3, 4, 5, 6)])
         self.netRegularization = nn.ModuleList([_Regularization(l) for l in (2, 3, 4, 5, 6)])
         if epilogue is not None:
+            res = getattr(getattr(epilogue, "__self__", None), "bias_res_act_", None)      # the residual form of the same HipOps object
             for m in self.modules():
                 if isinstance(m, _Chain):
-                    m.epilogue = epilogue
+                    m.epilogue = epilogue; m.epilogue_res = res
         if warp is not None:
             for m in self.modules():
                 if isinstance(m, (_Matching, _Subpixel, _Regularization)):
                     m.warp = warp
         if fused is not None:
             for m in self.modules():
-                if isinstance(m, _Regularization):
+                if isinstance(m, (_Regularization, _Matching)):
                     m.fused = fused
         # per-channel means as (non-persistent) buffers: the reference builds them with new_tensor inside forward (layers.py:286-287), a host-to-device
         # copy per call that a hipGraph capture cannot contain; not part of the state dict, so the reference's checkpoints still load unchanged

@@ -71,6 +71,15 @@ class HipOps:
         self.ctx._check(self.ctx.lib.vido_backwarp(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(flow.data_ptr()), x.shape[0], x.shape[1], x.shape[2], x.shape[3], C.c_void_p(out.data_ptr())))
         return out
 
+    def deconv4s2_depthwise(self, x, weight, input_slope=1.0):
+        """ConvTranspose2d(C, C, 4, 2, 1, groups=C, bias=False)(leaky_relu(x, input_slope)) in one HIP pass."""
+        x = x.contiguous(); B, Cc, H, W = x.shape
+        assert weight.shape == (Cc, 1, 4, 4) and weight.is_contiguous()
+        out = torch.empty((B, Cc, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_deconv4s2_depthwise(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(weight.data_ptr()), B, Cc, H, W, C.c_float(input_slope), C.c_void_p(out.data_ptr())))
+        return out
+
     def lfn_reg_front(self, im1, im2, flow, scale, feat):
         """Regularization.forward up to netMain's input (layers.py:236-243): torch.cat([sqrt(sum((im1 - Backward(im2, flow * scale))^2)), flow - mean(flow), feat], 1) with the
         first three channels from one HIP pass."""

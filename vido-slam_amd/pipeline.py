@@ -109,7 +109,7 @@ class NetNodes:
         self.ops_flow = _nets.HipOps(self.ctx2)           # LiteFlowNet (cost volume, epilogues)
         self.flow_net = _nets.fill_deterministic(_nets.LiteFlowNet(self.ops_flow.correlation, epilogue=self.ops_flow.bias_act_, warp=self.ops_flow.backwarp,
                                                                        fused=None if _os.environ.get("VIDO_LFN_NO_FUSED") else self.ops_flow,
-                                                                       pair_batch=bool(_os.environ.get("VIDO_LFN_PAIR_BATCH"))), seed).eval().to(dev)
+                                                                       pair_batch=not _os.environ.get("VIDO_LFN_NO_PAIR_BATCH")), seed).eval().to(dev)
         self.depth_net = _nets.fill_deterministic(_nets.MonoDepth2(), seed + 1).eval().to(dev)
         self.mask_net = _nets.fill_maskrcnn(_nets.MaskRCNN(ops), seed + 2).eval().to(dev)
         # random-init detector: un-saturate the class scores so that the reference's detections_per_img cap binds (see nets/weights.py); a synthetic textured frame
