@@ -49,9 +49,9 @@ def test_graph_replay_equals_eager(vido):
     g = nets.Graphed(fn, [a, b])
     out = g(a, b)
     torch.cuda.synchronize()
-    assert rel_err(out, ref) < 1e-6
+    assert rel_err(out, ref) < 2e-5                                # (MIOpen's split-K convolutions are not bit-reproducible from call to call)
     out2 = g(b, a).clone(); torch.cuda.synchronize()
-    assert rel_err(out2, fn(b, a)) < 1e-6                          # new inputs flow through the static buffers
+    assert rel_err(out2, fn(b, a)) < 2e-5                          # new inputs flow through the static buffers
 
 
 def test_pipelined_chain_tracks_and_hands_over(tmp_path, vido):

@@ -165,6 +165,7 @@ __device__ __forceinline__ void inv3sym(const double* H6 /*00 01 02 11 12 22*/, 
 //    set of 43 atomics per camera it saw.
 #define LIN_SLOTS 4
 #define LIN_THREADS 512
+#define LIN_RECP 30         // doubles per staged record in LDS (27 used; 240 bytes keeps every 16-byte piece aligned)
 // Transposing wave reduction: N per-lane values -> every lane ends up holding the wave sum of ONE of them.  Each step halves the number of
 // values a lane carries by trading the half it does not keep with lane ^ O: 29 double shuffles for 28 values instead of 168 for 28 butterflies
 // (ds_bpermute goes through the CU's LDS pipe, which the 8 waves of the workgroup share — the butterflies were 40 % of the kernel).
@@ -201,6 +202,8 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
 {
     __shared__ double lsum[LIN_SLOTS * 28];
     __shared__ int lused[LIN_SLOTS];
+    __shared__ __attribute__((aligned(16))) double lin_stage[LIN_THREADS / 64][32 * LIN_RECP];
+    __shared__ int lin_sslot[LIN_THREADS / 64][32];
     const int lane = threadIdx.x & 63;
     // (round 3: giving every XCD one CONTIGUOUS eighth of the camera-sorted list — so that the partial-line writes of a landmark's W / Cp slots meet in one L2 — was
     // measured and changed nothing: 109-112 us per 1 M edges either way, profiles/r3/README.md; the plain order stays)
@@ -218,10 +221,10 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
     for (int j = 0; j <= E; j++) {                               // j == E: sentinel pass that flushes the last camera
         const size_t k = (wave_g * E + j) * 64 + lane;
         const bool act = j < E && k < (size_t)P.n_obs;
-        int c = -1;
-        double con[28];
+        int c = -1, slot_k = -1;
+        double con[28], rec[28];
 #pragma unroll
-        for (int a = 0; a < 28; a++) con[a] = 0;
+        for (int a = 0; a < 28; a++) { con[a] = 0; rec[a] = 0; }
         if (act) {
             c = P.obs_cam[k]; const int l = P.obs_pt[k];
             const double* X = P.cam + 12 * c; const double* p = P.pt + 3 * l; const double* m = P.obs_meas + 3 * (size_t)k;
@@ -243,30 +246,42 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
                 for (int b = a; b < 6; b++) con[q++] = wo * (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b] + Jc[12 + a] * Jc[12 + b]);
             }
             con[27] = r0;
-            const size_t slot = (size_t)P.obs_pos[k];
-            // 18 doubles = 144 B per slot, 16-byte aligned: nine 16-byte stores instead of eighteen 8-byte ones (the kernel is bound by the request rate of its
-            // scattered stores — 64 different cache lines per store instruction — not by bytes)
-            double wv[18];
+            slot_k = P.obs_pos[k];
 #pragma unroll
             for (int a = 0; a < 6; a++)
 #pragma unroll
-                for (int b = 0; b < 3; b++) wv[a * 3 + b] = wo * (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b]);
-            double2* Wk2 = (double2*)(P.W + BA_REC * slot);
-#pragma unroll
-            for (int a = 0; a < 9; a++) Wk2[a] = make_double2(wv[2 * a], wv[2 * a + 1]);
-            double cv[9];
-            q = 0;
+                for (int b = 0; b < 3; b++) rec[a * 3 + b] = wo * (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b] + Jc[12 + a] * Jp[6 + b]);
+            q = 18;
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-                cv[6 + a] = -wo * (Jp[a] * e[0] + Jp[3 + a] * e[1] + Jp[6 + a] * e[2]);
+                rec[24 + a] = -wo * (Jp[a] * e[0] + Jp[3 + a] * e[1] + Jp[6 + a] * e[2]);
 #pragma unroll
-                for (int b = a; b < 3; b++) cv[q++] = wo * (Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b] + Jp[6 + a] * Jp[6 + b]);
+                for (int b = a; b < 3; b++) rec[q++] = wo * (Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b] + Jp[6 + a] * Jp[6 + b]);
             }
-            // Cp: 9 doubles behind W in the same record (16-byte aligned: four 16-byte stores + one 8-byte store)
-            double2* Ck2 = (double2*)(P.W + BA_REC * slot + 18);
+        }
+        // ---- the slot records leave through LDS: a lane owns ONE record (W 18 | Cp 9 doubles) that goes to a scattered, line-aligned 256-byte slot.  Stored from the lane's
+        // own registers that is 14 instructions of 64 sixteen-byte writes to 64 different lines — 14 M partial-line transactions per million edges, and the transaction rate
+        // (not the bytes) was what bounded the kernel.  Staged, 16 consecutive lanes write the 14 sixteen-byte pieces of ONE record: every instruction covers four records
+        // with 224 contiguous bytes each, 2 M full-line writes in all.  Half a wave at a time (32 records of 30 doubles: 61 KB of LDS for the 8 waves).
+        if (j < E) {
+            double* stg = lin_stage[threadIdx.x >> 6]; int* ssl = lin_sslot[threadIdx.x >> 6];
 #pragma unroll
-            for (int a = 0; a < 4; a++) Ck2[a] = make_double2(cv[2 * a], cv[2 * a + 1]);
-            P.W[BA_REC * slot + 26] = cv[8];
+            for (int half = 0; half < 2; half++) {
+                if ((lane >> 5) == half) {
+                    ssl[lane & 31] = act ? slot_k : -1;
+                    if (act) {
+#pragma unroll
+                        for (int a = 0; a < 14; a++) *(double2*)(stg + (lane & 31) * LIN_RECP + 2 * a) = make_double2(rec[2 * a], rec[2 * a + 1]);
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();      // lgkmcnt(0): the LDS writes of this wave have landed
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const int r = it * 4 + (lane >> 4), pc = lane & 15, sl = ssl[r];
+                    if (sl >= 0 && pc < 14) *(double2*)(P.W + BA_REC * (size_t)sl + 2 * pc) = *(const double2*)(stg + r * LIN_RECP + 2 * pc);
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
+            }
         }
         // fold the group into the register sums, one camera at a time (cameras are non-decreasing along the lanes)
         unsigned long long rem = j < E ? __ballot(act) : 1ull;
