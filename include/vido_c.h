@@ -316,6 +316,23 @@ int vido_nchw_to_nhwc(vido_ctx* ctx, const float* src, int B, int C, int H, int 
 /* vido_roi_align_fpn with CHANNELS-LAST maps feat[l] = [H[l]][W[l]][C] (vido_nchw_to_nhwc once per frame; the box and the mask pooler share the copies). */
 int vido_roi_align_fpn_nhwc(vido_ctx* ctx, const float* const feat[4], const int H[4], const int W[4], const float scale[4], int C, const float* boxes, const int32_t* level,
                             int n, int pooled_h, int pooled_w, int sampling_ratio, float* out);
+/* ---- The detector's selection logic between its convolutions, device-side with fixed shapes (vido-slam_amd/csrc/detpost.hip).  Keys are (score bits << 32) | ~index, so a
+ * descending key order is the reference's stable descending sort (ties -> lower index).
+ * vido_rpn_select: RPNPostProcessor.forward_for_single_feature_map without the NMS (modeling/rpn/inference.py:73-105) for all FPN levels in one launch: sigmoid(objectness),
+ *   the K = pre_nms_top_n best anchors of every level (anchors counted (y, x, a)), BoxCoder(1,1,1,1).decode + clip_to_image.  logits[l] [A,h,w], deltas[l] [4A,h,w] DEVICE;
+ *   cell_anchors [n_levels][A][4] HOST; boxes_out [n_levels*K, 4], scores_out [n_levels*K] (-1 = padding row), n_out [n_levels] DEVICE.
+ * vido_rpn_merge: select_over_all_levels (test branch, :125-159) after vido_nms_segments: the n_final best kept boxes over all levels.
+ * vido_det_class_sort / vido_det_select: PostProcessor.filter_results (modeling/roi_heads/box_head/inference.py:96-137) around the per-class NMS: score threshold + descending
+ *   order per class with decoded, clipped boxes; then the detections_per_img rule (threshold = k-th largest kept score, the reference's kthvalue) and the detections in
+ *   (class, proposal) order in `cap` fixed slots; n_det (DEVICE) = the count the reference returns.  scratch: DEVICE, >= (nc + 1) int32. */
+int vido_rpn_select(vido_ctx* ctx, int n_levels, const float* const* logits, const float* const* deltas, const int* h, const int* w, const int* stride, const float* cell_anchors,
+                    int A, int K, int img_w, int img_h, float* boxes_out, float* scores_out, int32_t* n_out);
+int vido_rpn_merge(vido_ctx* ctx, const float* boxes, const float* scores, const int32_t* keep, const int32_t* cnt, int n_levels, int K, int post_nms_top_n, int n_final,
+                   float* out_boxes, float* out_scores, int32_t* n_valid);
+int vido_det_class_sort(vido_ctx* ctx, const float* prob, const float* deltas, const float* proposals, const float* objectness, int N, int nc, float thresh, const float weights[4],
+                        int img_w, int img_h, float* seg_boxes, int32_t* order, int32_t* seg_n);
+int vido_det_select(vido_ctx* ctx, const float* prob, const float* seg_boxes, const int32_t* order, const int32_t* keep, const int32_t* cnt, int N, int nc, int detections_per_img, int cap,
+                    int32_t* scratch, float* out_boxes, float* out_scores, int64_t* out_labels, int32_t* n_det);
 /* Masker(threshold 0.5, padding 1).forward (modeling/roi_heads/mask_head/inference.py:87-160, per detection on the host in the reference) fused with the node's
  * label image (src/run_mask_rcnn.py:112-118: blank_mask += mask * class_index): masks [n,1,M,M] f32, boxes [n,4] f32 in the output image, labels [n] i64,
  * all DEVICE, detections in the order the node adds them; out [H,W] u8 = (sum over detections of pasted mask * class index) mod 256. */

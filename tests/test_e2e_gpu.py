@@ -119,6 +119,12 @@ def test_static_detector_head_equals_the_dynamic_one(vido):
             assert int(n_det) == n and int(n_lab) == len(lab_d)
             assert sorted(lab_s[:int(n_lab)].tolist()) == sorted(lab_d.tolist()) and bool((lab_s[int(n_lab):] == 0).all())
             assert float((img_s != img_d).float().mean()) < 1e-3                                    # isolated pixels at the 0.5 threshold of the pasted masks
+            # the torch-op form of the static head (round 3's first version; the default runs the selection logic in csrc/detpost.hip): identical slots
+            net.fused_post = False
+            st2 = net.heads_static(feats, logits, deltas, nodes.mask_feed)
+            net.fused_post = True
+            assert int(st2["n_det"]) == n and torch.equal(st2["labels"], sta["labels"]) and torch.equal(st2["scores"], sta["scores"]) and torch.equal(st2["boxes"], sta["boxes"])
+            assert torch.equal(st2["proposals"], sta["proposals"]) and torch.equal(st2["objectness"], sta["objectness"])
             # and the captured graph returns the same as the eager static head
             mask_g, lab_g, n_lab_g, n_det_g = nodes.g_det(bgr)
             assert int(n_det_g) == n and float((mask_g.to(torch.uint8) != img_s).float().mean()) < 1e-3

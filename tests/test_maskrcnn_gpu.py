@@ -130,3 +130,48 @@ def test_device_side_head_ops_match_the_host_forms(ctx, oracle):
     ref_img = (pasted.to(torch.int32) * labels.view(-1, 1, 1).to(torch.int32)).sum(0).remainder(256).to(torch.uint8)
     assert (img != ref_img).float().mean().item() < 1e-4           # bilinear resize at the 0.5 threshold: isolated pixels may fall on the other side
     assert torch.equal(ops.mask_label_image(masks[:0], bx[:0], labels[:0], Hh, Ww), torch.zeros((Hh, Ww), dtype=torch.uint8, device="cuda"))
+
+
+def test_fused_selection_kernels_equal_the_torch_forms(ctx):
+    """csrc/detpost.hip (vido_rpn_select / vido_rpn_merge / vido_det_class_sort / vido_det_select) against the torch-op forms they replace (proposals_device /
+    postprocess_static, themselves checked against the reference's data-dependent flow), on inputs full of TIES: quantised objectness logits (thousands of equal sigmoids,
+    many saturated to exactly 1.0, a tie group straddling the top-k cut), a level with fewer anchors than pre_nms_top_n, duplicate class-score rows, and more than
+    detections_per_img equal top scores (n_det > cap: the overflow the caller must detect)."""
+    ops = nets.HipOps(ctx)
+    net = nets.fill_maskrcnn(nets.MaskRCNN(ops, nets.MaskRCNNConfig(num_classes=9, detections_per_img=30)), 7).eval().cuda()
+    g = torch.Generator().manual_seed(3)
+    sizes = [(100, 136), (50, 68), (25, 34), (13, 17), (7, 9)]                      # 40 800 ... 189 anchors: the last two levels have fewer than 1000
+    for trial, quant in enumerate((0.25, 2.0, 0.0)):
+        logits = [torch.randn((1, 3, h, w), generator=g) * (6.0 if trial == 1 else 3.0) for h, w in sizes]
+        if quant:
+            logits = [torch.round(t / quant) * quant for t in logits]
+        logits = [t.cuda() for t in logits]
+        deltas = [(torch.randn((1, 12, h, w), generator=g) * 0.5).cuda() for h, w in sizes]
+        feats = [torch.zeros((1, 1, h, w), device="cuda") for h, w in sizes]
+        with torch.no_grad():
+            a_b, a_s = net.rpn.proposals_device(feats, logits, deltas, (800, 1088))
+            f_b, f_s = net.rpn.proposals_fused(feats, logits, deltas, (800, 1088))
+        assert torch.equal(a_s, f_s), trial
+        assert torch.equal(a_b, f_b), trial
+    N, nc = 1000, 9
+    for trial in range(3):
+        lg = torch.randn((N, nc), generator=g) * 2.0
+        if trial >= 1:
+            lg = torch.round(lg)                                                    # equal logit rows -> equal probabilities: ties inside the classes
+        if trial == 2:
+            lg[:60] = torch.tensor([0.0, 9.0, 0, 0, 0, 0, 0, 0, 0])                  # 60 proposals with the same (top) score of class 1 ...
+        dl = torch.randn((N, nc * 4), generator=g) * 0.3
+        xy = torch.rand((N, 2), generator=g) * 600; wh = torch.rand((N, 2), generator=g) * 200 + 8
+        if trial == 2:
+            xy[:60] = torch.arange(60).float().view(-1, 1) * 13.0 % 700; wh[:60] = 10.0; dl[:60] = 0.0          # ... on small disjoint boxes: none of them suppresses another
+        pr = torch.cat([xy, xy + wh], 1)
+        obj = torch.rand((N,), generator=g); obj[900:] = -1.0; pr[900:] = 0.0      # padding rows of the device-side RPN path
+        lg, dl, pr, obj = lg.cuda(), dl.cuda(), pr.cuda(), obj.cuda()
+        with torch.no_grad():
+            a = net.roi_heads.box.postprocess_static(lg, dl, pr, (800, 1088), obj, 30)
+            f = net.roi_heads.box.postprocess_fused(lg, dl, pr, (800, 1088), obj, 30)
+        assert int(a[3]) == int(f[3]) and int(a[3]) > 0, trial
+        if trial == 2:
+            assert int(f[3]) > 30                                                  # ties at the detections_per_img cut: the reference keeps them all
+        for k in range(3):
+            assert torch.equal(a[k], f[k]), (trial, k)

@@ -278,6 +278,21 @@ def _rpn_proposals_device(self, feats, logits, deltas, image_wh):
 _RPN.proposals_device = _rpn_proposals_device
 
 
+def _rpn_proposals_fused(self, feats, logits, deltas, image_wh):
+    """proposals_device() with the selection logic in three ordered device kernels (csrc/detpost.hip) instead of ~80 torch launches: vido_rpn_select (sigmoid + top-k +
+    decode + clip of all levels), the segmented NMS, vido_rpn_merge (the best fpn_post_nms_top_n over the levels).  Same rows as proposals_device()."""
+    c = self.c; W, H = image_wh; K = c.pre_nms_top_n; L = len(logits); dev = logits[0].device
+    boxes, scores, n = self.ops.rpn_select(logits, deltas, list(self.anchor_generator.cell_anchors), self.anchor_generator.strides, K, (W, H))
+    if getattr(self, "_fseg_key", None) != (L, K, str(dev)):
+        self._fseg_off = torch.arange(L, device=dev, dtype=torch.int32) * K; self._fseg_key = (L, K, str(dev))
+    keep, cnt = self.ops.nms_segments(boxes, self._fseg_off, n, K, c.rpn_nms)
+    props, obj, _ = self.ops.rpn_merge(boxes, scores, keep, cnt, K, c.post_nms_top_n, min(c.fpn_post_nms_top_n, L * K))
+    return props, obj
+
+
+_RPN.proposals_fused = _rpn_proposals_fused
+
+
 class FpnMaps(tuple):
     """The four pooled FPN maps [1,C,H,W] plus their channels-last copies (.nhwc: [1,H,W,C], HipOps.to_nhwc) — what the ROI-Align kernel reads."""
     nhwc = ()
@@ -406,6 +421,22 @@ def _postprocess_static(self, logits, deltas, proposals, image_wh, objectness, c
 
 
 _BoxHead.postprocess_static = _postprocess_static
+
+
+def _postprocess_fused(self, logits, deltas, proposals, image_wh, objectness, cap):
+    """postprocess_static() with the selection logic in ordered device kernels (csrc/detpost.hip): softmax (torch) -> vido_det_class_sort (threshold + per-class descending
+    order + decode + clip) -> segmented NMS -> vido_det_select (detections_per_img rule + the result lists in (class, proposal) order).  ~8 launches instead of ~45."""
+    c = self.c; W, H = image_wh; nc = logits.shape[1]; N = logits.shape[0]; dev = logits.device
+    prob = F.softmax(logits, -1)
+    seg, order, seg_n = self.ops.det_class_sort(prob, deltas, proposals, objectness, c.score_thresh, c.bbox_reg_weights, (W, H))
+    if getattr(self, "_fseg_key", None) != (nc, N, str(dev)):
+        self._fseg_off = torch.arange(nc - 1, device=dev, dtype=torch.int32) * N; self._fseg_key = (nc, N, str(dev))
+    keep, cnt = self.ops.nms_segments(seg, self._fseg_off, seg_n, N, c.nms)
+    ob, osc, ol, nd = self.ops.det_select(prob, seg, order, keep, cnt, c.detections_per_img, cap)
+    return ob, osc, ol, nd[0]
+
+
+_BoxHead.postprocess_fused = _postprocess_fused
 
 
 class _MaskFeatures(nn.Module):            # roi_mask_feature_extractors.py:17-65
@@ -554,16 +585,18 @@ def _heads_static(self, feats, logits, deltas, image_hw, cap=None):
     """heads() with static shapes end to end (device-side RPN selection, fixed 1000 proposals, postprocess_static, the mask head on `cap` padded slots): no host
     synchronisation anywhere, so trunk + heads + label image replay as ONE hipGraph.  Slots >= n_det hold zero boxes / label 0."""
     H, W = image_hw; c = self.config; cap = cap or c.detections_per_img
-    proposals, objectness = self.rpn.proposals_device(feats, logits, deltas, (W, H))
+    fused = self.fused_post and hasattr(self.rpn.ops, "det_select") and c.pre_nms_top_n <= 1024 and c.rpn_min_size <= 0       # csrc/detpost.hip (False: the torch-op form of round 3's first static head)
+    proposals, objectness = (self.rpn.proposals_fused if fused else self.rpn.proposals_device)(feats, logits, deltas, (W, H))
     maps = self.fpn_maps(feats)
     bh = self.roi_heads.box
     lg, dl = bh.predictor(bh.feature_extractor(maps, proposals))
-    boxes, scores, labels, n_det = bh.postprocess_static(lg, dl, proposals, (W, H), objectness, cap)
+    boxes, scores, labels, n_det = (bh.postprocess_fused if fused else bh.postprocess_static)(lg, dl, proposals, (W, H), objectness, cap)
     mh = self.roi_heads.mask
     masks = mh.chunk_logits(maps, boxes).sigmoid()[torch.arange(cap, device=labels.device), labels][:, None]
     return dict(boxes=boxes, scores=scores, labels=labels, masks=masks, n_det=n_det, proposals=proposals, objectness=objectness, n_proposals=(objectness >= 0).sum())
 
 
+MaskRCNN.fused_post = True
 MaskRCNN.fpn_maps = _fpn_maps
 MaskRCNN.heads_static = _heads_static
 

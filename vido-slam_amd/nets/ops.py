@@ -194,6 +194,51 @@ class HipOps:
                                                         C.c_void_p(out.data_ptr())))
         return out
 
+    # ---- detpost.hip: the detector's selection logic as ordered device kernels -----------------------------------------------------------------------------
+    def rpn_select(self, logits, deltas, cell_anchors, strides, K, image_wh):
+        """rpn/inference.py:73-105 for all levels in one launch: (boxes [L*K,4], scores [L*K] (-1 = padding), n [L])."""
+        L = len(logits); A = logits[0].shape[1]; dev = logits[0].device
+        logits = [t.contiguous() for t in logits]; deltas = [t.contiguous() for t in deltas]
+        boxes = torch.empty((L * K, 4), device=dev, dtype=torch.float32); scores = torch.empty((L * K,), device=dev, dtype=torch.float32); n = torch.empty((L,), device=dev, dtype=torch.int32)
+        lp = (C.c_void_p * L)(*[t.data_ptr() for t in logits]); dp = (C.c_void_p * L)(*[t.data_ptr() for t in deltas])
+        hs = (C.c_int * L)(*[t.shape[2] for t in logits]); ws = (C.c_int * L)(*[t.shape[3] for t in logits]); st = (C.c_int * L)(*[int(s) for s in strides])
+        key = ("anch", L, A)
+        if getattr(self, "_anch_key", None) != key:                 # host copy of the cell anchors (module buffers): made once, outside any capture
+            self._anch = (C.c_float * (L * A * 4))(*[float(v) for a in cell_anchors for v in a.detach().cpu().reshape(-1).tolist()]); self._anch_key = key
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_rpn_select(self.ctx.h, L, lp, dp, hs, ws, st, self._anch, A, int(K), int(image_wh[0]), int(image_wh[1]),
+                                                     C.c_void_p(boxes.data_ptr()), C.c_void_p(scores.data_ptr()), C.c_void_p(n.data_ptr())))
+        return boxes, scores, n
+
+    def rpn_merge(self, boxes, scores, keep, cnt, K, post_nms_top_n, n_final):
+        L = cnt.shape[0]; dev = boxes.device
+        ob = torch.empty((n_final, 4), device=dev, dtype=torch.float32); osc = torch.empty((n_final,), device=dev, dtype=torch.float32); nv = torch.empty((1,), device=dev, dtype=torch.int32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_rpn_merge(self.ctx.h, C.c_void_p(boxes.data_ptr()), C.c_void_p(scores.data_ptr()), C.c_void_p(keep.data_ptr()), C.c_void_p(cnt.data_ptr()),
+                                                    L, int(K), int(post_nms_top_n), int(n_final), C.c_void_p(ob.data_ptr()), C.c_void_p(osc.data_ptr()), C.c_void_p(nv.data_ptr())))
+        return ob, osc, nv
+
+    def det_class_sort(self, prob, deltas, proposals, objectness, thresh, weights, image_wh):
+        prob = prob.contiguous(); deltas = deltas.contiguous(); proposals = proposals.contiguous()
+        N, nc = prob.shape; dev = prob.device
+        seg = torch.empty(((nc - 1) * N, 4), device=dev, dtype=torch.float32); order = torch.empty((nc - 1, N), device=dev, dtype=torch.int32); seg_n = torch.empty((nc - 1,), device=dev, dtype=torch.int32)
+        wv = (C.c_float * 4)(*[float(x) for x in weights])
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_det_class_sort(self.ctx.h, C.c_void_p(prob.data_ptr()), C.c_void_p(deltas.data_ptr()), C.c_void_p(proposals.data_ptr()),
+                                                         C.c_void_p(objectness.data_ptr()) if objectness is not None else None, N, nc, C.c_float(thresh), wv, int(image_wh[0]), int(image_wh[1]),
+                                                         C.c_void_p(seg.data_ptr()), C.c_void_p(order.data_ptr()), C.c_void_p(seg_n.data_ptr())))
+        return seg, order, seg_n
+
+    def det_select(self, prob, seg_boxes, order, keep, cnt, detections_per_img, cap):
+        N, nc = prob.shape; dev = prob.device
+        ob = torch.empty((cap, 4), device=dev, dtype=torch.float32); osc = torch.empty((cap,), device=dev, dtype=torch.float32); ol = torch.empty((cap,), device=dev, dtype=torch.int64)
+        nd = torch.empty((1,), device=dev, dtype=torch.int32); scratch = torch.empty((nc + 3,), device=dev, dtype=torch.int32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_det_select(self.ctx.h, C.c_void_p(prob.data_ptr()), C.c_void_p(seg_boxes.data_ptr()), C.c_void_p(order.data_ptr()), C.c_void_p(keep.data_ptr()),
+                                                     C.c_void_p(cnt.data_ptr()), N, nc, int(detections_per_img), int(cap), C.c_void_p(scratch.data_ptr()),
+                                                     C.c_void_p(ob.data_ptr()), C.c_void_p(osc.data_ptr()), C.c_void_p(ol.data_ptr()), C.c_void_p(nd.data_ptr())))
+        return ob, osc, ol, nd
+
     def to_nhwc(self, x):
         """[B,C,H,W] f32 -> channels-last copy [B,H,W,C] (vido_nchw_to_nhwc): the layout roi_align_fpn_nhwc reads."""
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
