@@ -57,8 +57,8 @@ def write_settings(path, K, w, h):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100, help="timed frames (100 frames = ~2 s: the round-2 review asked for more than 20)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--prologue", type=int, default=20, help="untimed frames before the warm-up that fill the local-BA window (WINDOW_SIZE)")
     ap.add_argument("--feed", choices=("given", "nets"), default="given", help="maps the tracker consumes: the renderer's (default) or the networks' outputs")
     ap.add_argument("--handover", choices=("device", "host"), default="device", help="network -> tracker hand-over: device-resident (default: one BGR upload per frame, no map crosses PCIe) or round 2's pinned-host round trip")
@@ -278,7 +278,7 @@ def main():
         roofline = {"kernel": "FAST stage (score map + per-cell selection)", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(fast_bytes), "avg_launch_ms": round(stage_b["fast_ms"], 4),
                     "workload": "configs[1] batched: %d frames of %dx%d in flight" % (B, W, H)}
-        for rnd in ("r2", "r1"):
+        for rnd in ("r3", "r2", "r1"):
             pmc_path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
             if os.path.exists(pmc_path) and B == 64 and (W, H) == (640, 480):
                 ks = json.load(open(pmc_path))["kernels"]
@@ -350,7 +350,7 @@ def main():
               nb = 288.0 * n_obs
               ach = nb / (r["ms_linearize_kernel"] * 1e-3) / 1e9
               traffic = None
-              for rnd in ("r2", "r1"):
+              for rnd in ("r3", "r2", "r1"):
                   try:
                       with open(os.path.join(ROOT, "profiles", rnd, pmc_file)) as fjs:
                           traffic = json.load(fjs)["kernels"]["k_ba_linearize"]["traffic_bytes_fetch_x2"]

@@ -123,8 +123,11 @@ def test_static_detector_head_equals_the_dynamic_one(vido):
             net.fused_post = False
             st2 = net.heads_static(feats, logits, deltas, nodes.mask_feed)
             net.fused_post = True
-            assert int(st2["n_det"]) == n and torch.equal(st2["labels"], sta["labels"]) and torch.equal(st2["scores"], sta["scores"]) and torch.equal(st2["boxes"], sta["boxes"])
+            # (the selection kernels themselves are compared bit for bit on synthetic, tie-heavy inputs in test_maskrcnn_gpu.py; here the two heads each run the box head's
+            #  GEMMs, which are not bit-reproducible from call to call)
             assert torch.equal(st2["proposals"], sta["proposals"]) and torch.equal(st2["objectness"], sta["objectness"])
+            assert int(st2["n_det"]) == n and torch.equal(st2["labels"], sta["labels"])
+            assert float((st2["scores"] - sta["scores"]).abs().max()) < 1e-5 and float((st2["boxes"] - sta["boxes"]).abs().max()) < 1e-2
             # and the captured graph returns the same as the eager static head
             mask_g, lab_g, n_lab_g, n_det_g = nodes.g_det(bgr)
             assert int(n_det_g) == n and float((mask_g.to(torch.uint8) != img_s).float().mean()) < 1e-3

@@ -48,7 +48,7 @@ struct vido_ctx {
     struct PoseState* pose = nullptr;
     struct NetState* net = nullptr;
     struct PnpState* pnp = nullptr;
-    void* detpost_buf = nullptr; size_t detpost_cap = 0;   // detpost.hip: score-bit scratch of the RPN selection
+    void* detpost_buf = nullptr; size_t detpost_cap = 0; unsigned long long detpost_sig = 0;   // detpost.hip: scratch of the RPN selection (keys, histograms, state)
     void* rccl_comm = nullptr;         // ncclComm_t of vido_rccl_init (rccl.cpp): the sharded BA's all-reduce on this context's stream
     int rccl_rank = 0, rccl_world = 1;
 };

@@ -79,60 +79,129 @@ __device__ inline void decode_clip(const float* b, float d0, float d1, float d2,
 
 struct RpnLevels { const float* logits[8]; const float* deltas[8]; int h[8], w[8]; float stride[8]; float anchors[8][4][4]; };
 
-// ---- RPN, one workgroup per FPN level: the pre_nms_top_n best anchors by sigmoid(objectness) in descending order (ties: lower anchor index, anchors counted (y, x, a)),
-// decoded and clipped.  out rows [level * K, level * K + n): boxes + scores; the rest of the level's K rows: zero box, score -1 (never read by the NMS).
-__global__ __launch_bounds__(1024) void k_rpn_level_topk(RpnLevels L, int A, int K, float img_w, float img_h, unsigned* __restrict__ ubuf, int ubuf_stride,
-                                                         float* __restrict__ boxes, float* __restrict__ scores, int* __restrict__ n_out)
+// ---- RPN: the pre_nms_top_n best anchors of every FPN level by sigmoid(objectness), descending (ties: lower anchor index, anchors counted (y, x, a)), decoded and clipped.
+// A level has up to 163 200 anchors (P2 at 800 x 1088): one workgroup walking them several times is a chain of ~1 300 dependent memory round trips (0.9 ms, measured), so the
+// selection is a short sequence of wide launches over chunks of SEL_CHUNK anchors:
+//   k_rpn_keys      score bits -> ubuf, histogram of bits 31..20                      (chunks x levels)
+//   k_sel_resolve   digit that holds the K-th largest -> prefix, remaining k          (1 x levels)          x 3, interleaved with
+//   k_sel_hist      histogram of the next digit among the keys matching the prefix    (chunks x levels)      x 2; the last one also counts, per chunk, the keys of every
+//                   low-byte value (a tie group at the cut is cut in INDEX order: the chunks' counts give every chunk the rank of its first equal key)
+//   k_sel_collect   keys above the cut + the first need_eq keys equal to it -> the level's list (unordered)
+//   k_rpn_emit      bitonic sort of the <= 1024 selected composite keys, decode + clip, padding rows
+#define SEL_CHUNK 2048
+#define SEL_BINS 4096
+struct SelState { unsigned prefix, mask, kk, T, need_eq, done, n_sel, pad; };      // per level
+
+__global__ __launch_bounds__(1024) void k_rpn_keys(RpnLevels L, int A, unsigned* __restrict__ ubuf, int ubuf_stride, unsigned* __restrict__ hist /*[levels][SEL_BINS]*/)
 {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned s_prefix, s_kk, s_cnt;
+    __shared__ unsigned lh[SEL_BINS];
+    const int lv = blockIdx.y, tid = threadIdx.x;
+    const int hw = L.h[lv] * L.w[lv], N = A * hw, i0 = blockIdx.x * SEL_CHUNK;
+    if (i0 >= N) return;
+    for (int t = tid; t < SEL_BINS; t += 1024) lh[t] = 0;
+    __syncthreads();
+    const float* lg = L.logits[lv]; unsigned* ub = ubuf + (size_t)lv * ubuf_stride;
+    // score keys in (y, x, a) order: rpn/inference.py:88-92 permutes the [A, h, w] map to (h, w, A) before flattening; sigmoid like torch's kernel: 1 / (1 + exp(-x))
+#pragma unroll
+    for (int r = 0; r < SEL_CHUNK / 1024; r++) {
+        const int i = i0 + r * 1024 + tid;
+        if (i < N) { const int pix = i / A, a = i - pix * A; const float x = lg[(size_t)a * hw + pix]; const unsigned u = __float_as_uint(1.0f / (1.0f + expf(-x))); ub[i] = u; atomicAdd(&lh[u >> 20], 1u); }
+    }
+    __syncthreads();
+    for (int t = tid; t < SEL_BINS; t += 1024) if (lh[t]) atomicAdd(&hist[(size_t)lv * SEL_BINS + t], lh[t]);
+}
+// one workgroup per level: the bin (counted from the TOP) that holds the kk-th largest key; step 0 / 1 / 2 = bits 31..20 / 19..8 / 7..0.  After step 2: T, need_eq and — from
+// the chunks' low-byte counts — the rank of every chunk's first key equal to T (chunk_eq[chunk][256] -> eq_off[chunk]).
+__global__ __launch_bounds__(1024) void k_sel_resolve(const int* __restrict__ n_of /*[levels]*/, int K, int step, unsigned* __restrict__ hist, SelState* __restrict__ state,
+                                                      const unsigned* __restrict__ chunk_eq, unsigned* __restrict__ eq_off, int max_chunks)
+{
+    __shared__ int wsum[17];
+    __shared__ unsigned s_digit, s_kk;
+    const int lv = blockIdx.x, tid = threadIdx.x, N = n_of[lv];
+    SelState st = state[lv];
+    if (step == 0) { st.prefix = 0; st.mask = 0; st.kk = (unsigned)K; st.done = N <= K ? 1u : 0u; st.T = 0; st.need_eq = 0; st.n_sel = 0; }
+    unsigned* h = hist + (size_t)lv * SEL_BINS;
+    if (!st.done) {
+        // thread t owns bins [4t, 4t+4) counted from the top: bin index SEL_BINS - 1 - (4t + q)
+        unsigned c[4]; int mine = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { c[q] = h[SEL_BINS - 1 - (4 * tid + q)]; mine += (int)c[q]; }
+        int total; const int before = block_excl_scan(mine, wsum, &total);
+        if ((unsigned)before < st.kk && st.kk <= (unsigned)(before + mine)) {          // exactly one thread
+            unsigned kk = st.kk - (unsigned)before;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { if (kk <= c[q]) { s_digit = (unsigned)(SEL_BINS - 1 - (4 * tid + q)); s_kk = kk; break; } kk -= c[q]; }
+        }
+        __syncthreads();
+        const int shift = step == 0 ? 20 : (step == 1 ? 8 : 0);
+        st.prefix |= s_digit << shift; st.mask |= (step == 2 ? 0xffu : 0xfffu) << shift; st.kk = s_kk;
+        if (step == 2) { st.T = st.prefix; st.need_eq = st.kk; }
+    }
+    __syncthreads();
+    for (int t = tid; t < SEL_BINS; t += 1024) h[t] = 0;                              // ready for the next histogram pass (and for the next frame)
+    if (step == 2 && !st.done) {                                                      // exclusive scan over the chunks of their counts of keys equal to T
+        const unsigned low = st.T & 0xffu; const int nch = (N + SEL_CHUNK - 1) / SEL_CHUNK;
+        unsigned run = 0;
+        for (int c0 = 0; c0 < nch; c0 += 1024) {
+            const int ch = c0 + tid; const int v = ch < nch ? (int)chunk_eq[((size_t)lv * max_chunks + ch) * 256 + low] : 0;
+            int tot; const int ex = block_excl_scan(v, wsum, &tot);
+            if (ch < nch) eq_off[(size_t)lv * max_chunks + ch] = run + (unsigned)ex;
+            run += (unsigned)tot;
+        }
+    }
+    if (tid == 0) state[lv] = st;
+}
+__global__ __launch_bounds__(1024) void k_sel_hist(const int* __restrict__ n_of, const unsigned* __restrict__ ubuf, int ubuf_stride, int step /*1: bits 19..8, 2: bits 7..0*/,
+                                                   const SelState* __restrict__ state, unsigned* __restrict__ hist, unsigned* __restrict__ chunk_eq, int max_chunks)
+{
+    __shared__ unsigned lh[SEL_BINS];
+    const int lv = blockIdx.y, tid = threadIdx.x, N = n_of[lv], i0 = blockIdx.x * SEL_CHUNK;
+    const SelState st = state[lv];
+    if (i0 >= N || st.done) return;
+    const int nb = step == 1 ? SEL_BINS : 256, shift = step == 1 ? 8 : 0;
+    for (int t = tid; t < nb; t += 1024) lh[t] = 0;
+    __syncthreads();
+    const unsigned* ub = ubuf + (size_t)lv * ubuf_stride;
+#pragma unroll
+    for (int r = 0; r < SEL_CHUNK / 1024; r++) {
+        const int i = i0 + r * 1024 + tid;
+        if (i < N) { const unsigned u = ub[i]; if ((u & st.mask) == st.prefix) atomicAdd(&lh[(u >> shift) & (unsigned)(nb - 1)], 1u); }
+    }
+    __syncthreads();
+    for (int t = tid; t < nb; t += 1024) { const unsigned v = lh[t]; if (v) atomicAdd(&hist[(size_t)lv * SEL_BINS + t], v); if (step == 2) chunk_eq[((size_t)lv * max_chunks + blockIdx.x) * 256 + t] = v; }
+}
+__global__ __launch_bounds__(1024) void k_sel_collect(const int* __restrict__ n_of, const unsigned* __restrict__ ubuf, int ubuf_stride, SelState* __restrict__ state,
+                                                      const unsigned* __restrict__ eq_off, int max_chunks, int K, u64* __restrict__ sel /*[levels][1024]*/)
+{
+    __shared__ int wsum[17];
+    const int lv = blockIdx.y, tid = threadIdx.x, N = n_of[lv], i0 = blockIdx.x * SEL_CHUNK;
+    if (i0 >= N) return;
+    const SelState st = state[lv];
+    const unsigned* ub = ubuf + (size_t)lv * ubuf_stride;
+    unsigned eq_run = st.done ? 0u : eq_off[(size_t)lv * max_chunks + blockIdx.x];
+    for (int r = 0; r < SEL_CHUNK / 1024; r++) {                                     // (uniform trip count: the block scan below has barriers)
+        const int i = i0 + r * 1024 + tid;
+        const unsigned u = i < N ? ub[i] : 0u;
+        const bool gt = i < N && (st.done || u > st.T), eq = i < N && !st.done && u == st.T;
+        int tot; const int ex = block_excl_scan(eq ? 1 : 0, wsum, &tot);
+        if (gt || (eq && eq_run + (unsigned)ex < st.need_eq)) {
+            const unsigned pos = atomicAdd(&state[lv].n_sel, 1u);
+            if (pos < 1024u) sel[(size_t)lv * 1024 + pos] = ((u64)u << 32) | (u64)(0xffffffffu - (unsigned)i);
+        }
+        eq_run += (unsigned)tot;
+    }
+}
+__global__ __launch_bounds__(1024) void k_rpn_emit(RpnLevels L, int A, int K, float img_w, float img_h, const u64* __restrict__ sel, SelState* __restrict__ state,
+                                                   float* __restrict__ boxes, float* __restrict__ scores, int* __restrict__ n_out)
+{
     __shared__ u64 keys[1024];
     const int lv = blockIdx.x, tid = threadIdx.x;
-    const int h = L.h[lv], w = L.w[lv], hw = h * w, N = A * hw;
-    const float* lg = L.logits[lv]; const float* dl = L.deltas[lv];
-    unsigned* ub = ubuf + (size_t)lv * ubuf_stride;
-    // score keys in (y, x, a) order: rpn/inference.py:88-92 permutes the [A, h, w] map to (h, w, A) before flattening; sigmoid like torch's kernel: 1 / (1 + exp(-x))
-    for (int i = tid; i < N; i += 1024) { const int pix = i / A, a = i - pix * A; const float x = lg[(size_t)a * hw + pix]; ub[i] = __float_as_uint(1.0f / (1.0f + expf(-x))); }
-    __syncthreads();
-    unsigned T = 0, istar = 0xffffffffu; int n = min(N, K);
-    if (N > K) {
-        unsigned prefix = 0, mask = 0;
-        if (tid == 0) s_kk = (unsigned)K;
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            for (int i = tid; i < N; i += 1024) { const unsigned u = ub[i]; if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u); }
-            __syncthreads();
-            if (tid == 0) { unsigned kk = s_kk, d; pick_digit_desc(hist, kk, d); s_kk = kk; s_prefix = prefix | (d << shift); }
-            __syncthreads();
-            prefix = s_prefix; mask |= 0xffu << shift;
-        }
-        T = prefix;
-        const unsigned need_eq = s_kk;                       // how many of the elements equal to T belong to the top K (>= 1): the ones with the lowest indices
-        // among the elements equal to T: the need_eq-th smallest index (radix select on the index, ascending)
-        unsigned ip = 0, im = 0;
-        __syncthreads();
-        if (tid == 0) s_kk = need_eq;
-        for (int shift = 16; shift >= 0; shift -= 8) {
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            for (int i = tid; i < N; i += 1024) if (ub[i] == T && ((unsigned)i & im) == ip) atomicAdd(&hist[((unsigned)i >> shift) & 255u], 1u);
-            __syncthreads();
-            if (tid == 0) { unsigned kk = s_kk, d; pick_digit_asc(hist, kk, d); s_kk = kk; s_prefix = ip | (d << shift); }
-            __syncthreads();
-            ip = s_prefix; im |= 0xffu << shift;
-        }
-        istar = ip;
-    }
-    keys[tid] = 0;
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    for (int i = tid; i < N; i += 1024) {
-        const unsigned u = ub[i];
-        if (N <= K || u > T || (u == T && (unsigned)i <= istar)) { const unsigned pos = atomicAdd(&s_cnt, 1u); if (pos < 1024u) keys[pos] = ((u64)u << 32) | (u64)(0xffffffffu - (unsigned)i); }
-    }
+    const int h = L.h[lv], w = L.w[lv], hw = h * w, N = A * hw, n = min(N, K);
+    const int ns = (int)min(state[lv].n_sel, 1024u);
+    keys[tid] = tid < ns ? sel[(size_t)lv * 1024 + tid] : 0;
     __syncthreads();
     block_sort_desc(keys, 1024);
+    const float* dl = L.deltas[lv];
     float* ob = boxes + (size_t)lv * K * 4; float* os = scores + (size_t)lv * K;
     for (int r = tid; r < K; r += 1024) {
         if (r < n) {
@@ -145,39 +214,47 @@ __global__ __launch_bounds__(1024) void k_rpn_level_topk(RpnLevels L, int A, int
             os[r] = __uint_as_float(u);
         } else { ob[4 * r] = ob[4 * r + 1] = ob[4 * r + 2] = ob[4 * r + 3] = 0.f; os[r] = -1.f; }
     }
-    if (tid == 0) n_out[lv] = n;
+    __syncthreads();
+    if (tid == 0) { n_out[lv] = n; state[lv].n_sel = 0; }
 }
 
 // ---- RPN, after the per-level NMS: the n_final best kept boxes over all levels (select_over_all_levels, test branch), descending objectness, ties by (level, position).
-// keep [L, K]: kept positions per level ascending, cnt [L]; post: per-level cap (post_nms_top_n).  One workgroup, up to 8192 candidates.
+// keep [L, K]: kept positions per level ascending — i.e. every level's kept list is already in descending key order: the output position of an entry is its RANK in the
+// union, the number of entries of the other lists with a larger key (binary searches in LDS) plus its position in its own list.  One workgroup; no sort.
 __global__ __launch_bounds__(1024) void k_rpn_merge(const float* __restrict__ boxes, const float* __restrict__ scores, const int* __restrict__ keep, const int* __restrict__ cnt,
                                                     int Lv, int K, int post, int n_final, float* __restrict__ out_boxes, float* __restrict__ out_scores, int* __restrict__ n_valid)
 {
-    extern __shared__ __attribute__((aligned(16))) u64 mkeys[];
-    const int tid = threadIdx.x, cap = Lv * K;
-    int P2 = 1; while (P2 < cap) P2 <<= 1;
-    for (int t = tid; t < P2; t += 1024) {
-        u64 key = 0;
-        if (t < cap) { const int l = t / K, q = t - l * K; if (q < min(cnt[l], post)) { const int flat = l * K + keep[(size_t)l * K + q]; key = ((u64)__float_as_uint(scores[flat]) << 32) | (u64)(0xffffffffu - (unsigned)flat); } }
-        mkeys[t] = key;
+    extern __shared__ __attribute__((aligned(16))) u64 mkeys[];      // [Lv][K]
+    __shared__ int s_cnt[8];
+    const int tid = threadIdx.x;
+    if (tid < Lv) s_cnt[tid] = min(cnt[tid], post);
+    __syncthreads();
+    int total = 0;
+    for (int l = 0; l < Lv; l++) total += s_cnt[l];
+    for (int t = tid; t < Lv * K; t += 1024) {
+        const int l = t / K, q = t - l * K;
+        if (q < s_cnt[l]) { const int flat = l * K + keep[(size_t)l * K + q]; mkeys[t] = ((u64)__float_as_uint(scores[flat]) << 32) | (u64)(0xffffffffu - (unsigned)flat); }
     }
+    for (int r = total + tid; r < n_final; r += 1024) { for (int c = 0; c < 4; c++) out_boxes[4 * r + c] = 0.f; out_scores[r] = -1.f; }
     __syncthreads();
-    block_sort_desc(mkeys, P2);
-    int nv = 0;
-    for (int r = tid; r < n_final; r += 1024) {
-        const u64 key = r < P2 ? mkeys[r] : 0;
-        if (key != 0) { const int flat = (int)(0xffffffffu - (unsigned)key);
-                        for (int c = 0; c < 4; c++) out_boxes[4 * r + c] = boxes[4 * (size_t)flat + c];
-                        out_scores[r] = __uint_as_float((unsigned)(key >> 32)); nv++; }
-        else { for (int c = 0; c < 4; c++) out_boxes[4 * r + c] = 0.f; out_scores[r] = -1.f; }
+    for (int t = tid; t < Lv * K; t += 1024) {
+        const int l = t / K, q = t - l * K;
+        if (q >= s_cnt[l]) continue;
+        const u64 key = mkeys[t];
+        int rank = q;
+        for (int m = 0; m < Lv; m++) {
+            if (m == l) continue;
+            const u64* lst = mkeys + (size_t)m * K; int lo = 0, hi = s_cnt[m];           // number of keys of list m larger than `key` (lists are descending, keys are unique)
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (lst[mid] > key) lo = mid + 1; else hi = mid; }
+            rank += lo;
+        }
+        if (rank < n_final) {
+            const int flat = (int)(0xffffffffu - (unsigned)key);
+            for (int c = 0; c < 4; c++) out_boxes[4 * rank + c] = boxes[4 * (size_t)flat + c];
+            out_scores[rank] = __uint_as_float((unsigned)(key >> 32));
+        }
     }
-    // number of real proposals: keys are sorted, so it is the position of the first zero key
-    __shared__ int s_nv;
-    if (tid == 0) s_nv = 0;
-    __syncthreads();
-    if (nv) atomicAdd(&s_nv, nv);
-    __syncthreads();
-    if (tid == 0) *n_valid = s_nv;
+    if (tid == 0) *n_valid = min(total, n_final);
 }
 
 // ---- box head, one workgroup per foreground class j: the proposals whose class score exceeds the threshold, by descending score (ties: lower proposal index), their
@@ -215,32 +292,34 @@ __global__ __launch_bounds__(1024) void k_det_class_sort(const float* __restrict
 }
 
 // ---- box head, the detections_per_img rule: threshold = the k-th largest score among all kept (class, proposal) pairs when there are more than k of them (0 otherwise).
-// keep [(nc-1), N] kept positions (into the class's sorted segment) ascending, cnt [(nc-1)].  One workgroup.  thr_out[0] = threshold score bits, thr_out[1] = total kept.
+// keep [(nc-1), N] kept positions (into the class's sorted segment) ascending, cnt [(nc-1)].  One workgroup; its 16 waves take the classes round-robin (lanes over a class's
+// kept list), the kept scores are staged in LDS once (up to DT_STAGE of them; beyond that the radix passes re-read them from memory).  thr_out[0] = threshold bits, [1] = total.
+#define DT_STAGE 8192
 __global__ __launch_bounds__(1024) void k_det_thresh(const float* __restrict__ prob, const int* __restrict__ order, const int* __restrict__ keep, const int* __restrict__ cnt,
                                                      int N, int nc, int kth, unsigned* __restrict__ thr_out)
 {
     __shared__ unsigned hist[256];
-    __shared__ unsigned s_prefix, s_kk, s_total;
-    const int tid = threadIdx.x, ncls = nc - 1;
-    if (tid == 0) s_total = 0;
+    __shared__ unsigned stage[DT_STAGE];
+    __shared__ int coff[1025];
+    __shared__ unsigned s_prefix, s_kk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ncls = nc - 1;
+    if (tid == 0) { int run = 0; for (int j = 0; j < ncls && j < 1024; j++) { coff[j] = run; run += cnt[j]; } coff[min(ncls, 1024)] = run; }
     __syncthreads();
-    { unsigned t = 0; for (int j = tid; j < ncls; j += 1024) t += (unsigned)cnt[j]; if (t) atomicAdd(&s_total, t); }
-    __syncthreads();
-    const unsigned total = s_total;
-    if (kth <= 0 || total <= (unsigned)kth) { if (tid == 0) { thr_out[0] = 0u; thr_out[1] = total; } return; }
+    const unsigned total = (unsigned)coff[min(ncls, 1024)];
+    if (kth <= 0 || total <= (unsigned)kth || ncls > 1024) { if (tid == 0) { thr_out[0] = 0u; thr_out[1] = total; } return; }
+    const bool staged = total <= DT_STAGE;
+    auto score_bits = [&](int j, int q) { const int i = order[(size_t)j * N + keep[(size_t)j * N + q]]; return __float_as_uint(prob[(size_t)i * nc + j + 1]); };
+    if (staged) {
+        for (int j = wave; j < ncls; j += 16) { const int c = coff[j + 1] - coff[j]; for (int q = lane; q < c; q += 64) stage[coff[j] + q] = score_bits(j, q); }
+        __syncthreads();
+    }
     unsigned prefix = 0, mask = 0;
     if (tid == 0) s_kk = (unsigned)kth;
     for (int shift = 24; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        for (int j = 0; j < ncls; j++) {
-            const int c = cnt[j];
-            for (int q = tid; q < c; q += 1024) {
-                const int i = order[(size_t)j * N + keep[(size_t)j * N + q]];
-                const unsigned u = __float_as_uint(prob[(size_t)i * nc + j + 1]);
-                if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
-            }
-        }
+        if (staged) { for (unsigned t = tid; t < total; t += 1024) { const unsigned u = stage[t]; if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u); } }
+        else for (int j = wave; j < ncls; j += 16) { const int c = coff[j + 1] - coff[j]; for (int q = lane; q < c; q += 64) { const unsigned u = score_bits(j, q); if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u); } }
         __syncthreads();
         if (tid == 0) { unsigned kk = s_kk, d; pick_digit_desc(hist, kk, d); s_kk = kk; s_prefix = prefix | (d << shift); }
         __syncthreads();
@@ -299,18 +378,41 @@ int vido_rpn_select(vido_ctx* ctx, int n_levels, const float* const* logits, con
         return vido_set_error(ctx, VIDO_E_INVALID, "rpn_select: bad arguments (<= 8 levels, <= 4 anchors per cell, K <= 1024)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
-    RpnLevels L; memset(&L, 0, sizeof L); int maxn = 0;
+    RpnLevels L; memset(&L, 0, sizeof L); int maxn = 0; int n_of[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int l = 0; l < n_levels; l++) {
         if (!logits[l] || !deltas[l] || h[l] < 1 || w[l] < 1 || (long long)A * h[l] * w[l] > (1 << 24)) return vido_set_error(ctx, VIDO_E_INVALID, "rpn_select: level %d: bad map", l);
-        L.logits[l] = logits[l]; L.deltas[l] = deltas[l]; L.h[l] = h[l]; L.w[l] = w[l]; L.stride[l] = (float)stride[l]; maxn = std::max(maxn, A * h[l] * w[l]);
+        L.logits[l] = logits[l]; L.deltas[l] = deltas[l]; L.h[l] = h[l]; L.w[l] = w[l]; L.stride[l] = (float)stride[l]; n_of[l] = A * h[l] * w[l]; maxn = std::max(maxn, n_of[l]);
         for (int a = 0; a < A; a++) for (int c = 0; c < 4; c++) L.anchors[l][a][c] = cell_anchors[((size_t)l * A + a) * 4 + c];
     }
-    if (!ctx->detpost_buf || ctx->detpost_cap < (size_t)n_levels * maxn * 4) {      // score-bit scratch; sized once (the warm-up calls happen outside any graph capture)
+    const int max_chunks = (maxn + SEL_CHUNK - 1) / SEL_CHUNK;
+    // scratch: [ubuf levels x maxn u32][hist levels x SEL_BINS][state levels][n_of 8 ints][chunk_eq levels x chunks x 256][eq_off levels x chunks][sel levels x 1024 u64]
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_ub = 0, o_hist = o_ub + al((size_t)n_levels * maxn * 4), o_state = o_hist + al((size_t)n_levels * SEL_BINS * 4), o_n = o_state + al((size_t)n_levels * sizeof(SelState)),
+                 o_ceq = o_n + al(8 * 4), o_eoff = o_ceq + al((size_t)n_levels * max_chunks * 256 * 4), o_sel = o_eoff + al((size_t)n_levels * max_chunks * 4), total = o_sel + al((size_t)n_levels * 1024 * 8);
+    unsigned long long sig = 1469598103934665603ull;                                  // FNV-1a over the geometry: a change re-initialises the scratch
+    for (int l = 0; l < 8; l++) { sig ^= (unsigned long long)(unsigned)n_of[l]; sig *= 1099511628211ull; }
+    sig ^= (unsigned long long)n_levels; sig *= 1099511628211ull; if (!sig) sig = 1;
+    if (!ctx->detpost_buf || ctx->detpost_cap < total || ctx->detpost_sig != sig) {
+        // sized and initialised once per geometry, by the warm-up calls outside any graph capture: the histograms are left zero by every call, n_of never changes
         HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (ctx->detpost_buf) hipFree(ctx->detpost_buf);
-        ctx->detpost_cap = (size_t)n_levels * maxn * 4 + 4096; HIP_TRY(ctx, hipMalloc(&ctx->detpost_buf, ctx->detpost_cap));
+        if (ctx->detpost_cap < total) { if (ctx->detpost_buf) hipFree(ctx->detpost_buf); ctx->detpost_cap = total + 4096; HIP_TRY(ctx, hipMalloc(&ctx->detpost_buf, ctx->detpost_cap)); }
+        HIP_TRY(ctx, hipMemsetAsync(ctx->detpost_buf, 0, ctx->detpost_cap, st));
+        HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->detpost_buf + o_n, n_of, sizeof n_of, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        ctx->detpost_sig = sig;
     }
-    hipLaunchKernelGGL(k_rpn_level_topk, dim3(n_levels), dim3(1024), 0, st, L, A, K, (float)img_w, (float)img_h, (unsigned*)ctx->detpost_buf, maxn, boxes_out, scores_out, n_out);
+    char* base = (char*)ctx->detpost_buf;
+    unsigned* ub = (unsigned*)(base + o_ub); unsigned* hist = (unsigned*)(base + o_hist); SelState* state = (SelState*)(base + o_state); const int* dn = (const int*)(base + o_n);
+    unsigned* ceq = (unsigned*)(base + o_ceq); unsigned* eoff = (unsigned*)(base + o_eoff); u64* sel = (u64*)(base + o_sel);
+    const dim3 wide(max_chunks, n_levels);
+    hipLaunchKernelGGL(k_rpn_keys, wide, dim3(1024), 0, st, L, A, ub, maxn, hist);
+    hipLaunchKernelGGL(k_sel_resolve, dim3(n_levels), dim3(1024), 0, st, dn, K, 0, hist, state, (const unsigned*)ceq, eoff, max_chunks);
+    hipLaunchKernelGGL(k_sel_hist, wide, dim3(1024), 0, st, dn, (const unsigned*)ub, maxn, 1, (const SelState*)state, hist, ceq, max_chunks);
+    hipLaunchKernelGGL(k_sel_resolve, dim3(n_levels), dim3(1024), 0, st, dn, K, 1, hist, state, (const unsigned*)ceq, eoff, max_chunks);
+    hipLaunchKernelGGL(k_sel_hist, wide, dim3(1024), 0, st, dn, (const unsigned*)ub, maxn, 2, (const SelState*)state, hist, ceq, max_chunks);
+    hipLaunchKernelGGL(k_sel_resolve, dim3(n_levels), dim3(1024), 0, st, dn, K, 2, hist, state, (const unsigned*)ceq, eoff, max_chunks);
+    hipLaunchKernelGGL(k_sel_collect, wide, dim3(1024), 0, st, dn, (const unsigned*)ub, maxn, state, (const unsigned*)eoff, max_chunks, K, sel);
+    hipLaunchKernelGGL(k_rpn_emit, dim3(n_levels), dim3(1024), 0, st, L, A, K, (float)img_w, (float)img_h, (const u64*)sel, state, boxes_out, scores_out, n_out);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }
@@ -321,14 +423,13 @@ int vido_rpn_merge(vido_ctx* ctx, const float* boxes, const float* scores, const
                    float* out_boxes, float* out_scores, int32_t* n_valid)
 {
     if (!ctx) return VIDO_E_INVALID;
-    if (!boxes || !scores || !keep || !cnt || !out_boxes || !out_scores || !n_valid || n_levels < 1 || K < 1 || n_final < 1 || (long long)n_levels * K > 8192 || n_final > n_levels * K)
+    if (!boxes || !scores || !keep || !cnt || !out_boxes || !out_scores || !n_valid || n_levels < 1 || K < 1 || n_final < 1 || (long long)n_levels * K > 8192 || n_levels > 8 || n_final > n_levels * K)
         return vido_set_error(ctx, VIDO_E_INVALID, "rpn_merge: bad arguments (n_levels * K <= 8192)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
-    int P2 = 1; while (P2 < n_levels * K) P2 <<= 1;
     static bool attr = false;
     if (!attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_rpn_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8)); attr = true; }
-    hipLaunchKernelGGL(k_rpn_merge, dim3(1), dim3(1024), (size_t)P2 * 8, st, boxes, scores, keep, cnt, n_levels, K, post_nms_top_n, n_final, out_boxes, out_scores, n_valid);
+    hipLaunchKernelGGL(k_rpn_merge, dim3(1), dim3(1024), (size_t)n_levels * K * 8, st, boxes, scores, keep, cnt, n_levels, K, post_nms_top_n, n_final, out_boxes, out_scores, n_valid);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }
