@@ -316,6 +316,18 @@ int vido_nchw_to_nhwc(vido_ctx* ctx, const float* src, int B, int C, int H, int 
 /* vido_roi_align_fpn with CHANNELS-LAST maps feat[l] = [H[l]][W[l]][C] (vido_nchw_to_nhwc once per frame; the box and the mask pooler share the copies). */
 int vido_roi_align_fpn_nhwc(vido_ctx* ctx, const float* const feat[4], const int H[4], const int W[4], const float scale[4], int C, const float* boxes, const int32_t* level,
                             int n, int pooled_h, int pooled_w, int sampling_ratio, float* out);
+/* ---- The local-BA window resident on the device between frames (vido-slam_amd/csrc/bawin.hip).  The reference re-assembles the graph of
+ * Optimizer::PartialBatchOptimization from the Map on every call (Optimizer.cc:56-94, 276-350).  Here a ring of the last frames' static features stays on the device:
+ * vido_bawin_push_frame sends one frame's rows (Get3DinCamera measurement, world point, index of the previous frame's feature it continues: Map::vpFeatSta / vfDepSta /
+ * vp3DPointSta / vnAssoSta), vido_bawin_set_labels the tracklet-label changes ((frame, feature, tracklet, position) quads: Map::vnTrkSta / vnPosSta), vido_bawin_solve assembles
+ * the window's graph on the device exactly like the Map walk does (observations in (frame, feature) order, landmark ids in order of first appearance, chains that start before
+ * the window dropped), solves it in place and writes the refined landmarks back into the ring.  prob: cameras (n_cam = N - start), odometry factors, prior, weights and LM
+ * parameters as for vido_ba_optimize; its observation / point fields are ignored.  vido_bawin_read_points: one stored frame's world points (f32 [n][3]). */
+int vido_bawin_create(vido_ctx* ctx, int cap_frames, int cap_features);
+int vido_bawin_push_frame(vido_ctx* ctx, int frame, int n, const double* meas, const float* xyz, const int32_t* asso);
+int vido_bawin_set_labels(vido_ctx* ctx, int n, const int32_t* quads);
+int vido_bawin_solve(vido_ctx* ctx, int start, int N, vido_ba_problem* prob, vido_ba_result* res, int32_t* n_obs_out, int32_t* n_pt_out);
+int vido_bawin_read_points(vido_ctx* ctx, int frame, int n, float* xyz_out);
 /* ---- The detector's selection logic between its convolutions, device-side with fixed shapes (vido-slam_amd/csrc/detpost.hip).  Keys are (score bits << 32) | ~index, so a
  * descending key order is the reference's stable descending sort (ties -> lower index).
  * vido_rpn_select: RPNPostProcessor.forward_for_single_feature_map without the NMS (modeling/rpn/inference.py:73-105) for all FPN levels in one launch: sigmoid(objectness),

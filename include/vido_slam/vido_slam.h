@@ -109,6 +109,12 @@ public:
     void UpdateTracklets();
     std::vector<std::vector<int> > vnTrkSta, vnPosSta, vnTrkDyn, vnPosDyn;
     std::vector<int> trkPreSta, trkPreDyn; size_t trkRowsSta = 0, trkRowsDyn = 0;
+    /* Device-resident local-BA window (extension; SURVEY.md 8f row 2, csrc/bawin.hip): the static features of the last frames live on the device, PartialBatchOptimization
+       sends only the new frame and the label changes below.  vp3DPointSta rows of the frames still in the device ring may be stale on the host until SyncPointsFromDevice()
+       (called before anything on the host reads them: FullBatchOptimization, the host-walk check). */
+    std::vector<int> trkChangesSta;           /* (frame, feature, tracklet, position) quads written by UpdateTracklets since the last PartialBatchOptimization */
+    int devFramesPushed = 0; bool devWindow = false;
+    void SyncPointsFromDevice();
     std::vector<cv::Mat> vmCameraPose, vmCameraPose_RF, vmCameraPose_GT;
     std::vector<std::vector<cv::Mat> > vmRigidCentre, vmRigidMotion, vmRigidMotion_RF;
     std::vector<std::vector<int> > vnRMLabel, vnSMLabel; std::vector<std::vector<bool> > vbObjStat;
@@ -202,6 +208,7 @@ private:
 };
 
 namespace detail {
+void ResidentCheckStats(int* checks, int* mismatches);  /* VIDO_BA_RESIDENT_CHECK=1: windows solved both ways (device-resident window / Map walk) and how many disagreed */
 vido_ctx* Context();                                   /* the process-wide ctx of the live System (one System per process, as in the reference) */
 std::map<std::string, std::string> ParseSettings(const std::string& path);    /* OpenCV-YAML 1.0 `key: value` subset */
 }

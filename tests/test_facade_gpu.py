@@ -160,6 +160,31 @@ def test_reference_disk_layout_50_frame_clip(tmp_path, vido):
     assert ref.shape == (n, 17)
 
 
+def test_device_resident_ba_window_equals_the_map_walk(tmp_path, vido):
+    """SURVEY 8(f) row 2, second half: PartialBatchOptimization on the device-resident window (csrc/bawin.hip: per frame only the new frame's feature rows and the tracklet
+    label changes go up; the graph is assembled on the device) against the Map walk of rounds 1-2 (facade.cpp batch_optimize: Optimizer.cc:56-94, 276-350) on a 50-frame
+    clip — the window slides for 30 frames and the ring (24 slots) wraps twice.  VIDO_BA_RESIDENT_CHECK=1 solves EVERY window both ways from the same Map state and counts
+    disagreements (graph size, poses to 1e-7); separately the whole clip is run with the walk only and the trajectories compared."""
+    sys.path.insert(0, os.path.join(ROOT, "vido-slam_amd"))
+    import build
+    driver = build.build_driver()
+    n = 50
+    scene = vido.synth.Scene3D(n_frames=n, seed=3, step=0.2, yaw_deg=0.1, objects=((-2.0, 0.4, 9.0, 0.02, 0.0, 0.22),), wall_z=48.0)
+    cfg = write_kaist_clip(str(tmp_path), scene, n)
+    runs = {}
+    for tag, env in (("check", {"VIDO_BA_RESIDENT_CHECK": "1"}), ("walk", {"VIDO_BA_HOST_WALK": "1"}), ("resident", {})):
+        out = os.path.join(str(tmp_path), "poses_%s.txt" % tag)
+        r = subprocess.run([driver, cfg, out, os.path.join(str(tmp_path), "res_%s_" % tag)], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr + r.stdout
+        line = [l for l in r.stdout.splitlines() if l.startswith("resident_window")][0].split()
+        runs[tag] = (np.loadtxt(out), np.loadtxt(os.path.join(str(tmp_path), "res_%s_initial_rgbd_new.txt" % tag)), int(line[2]), int(line[4]), r.stderr)
+    assert runs["check"][2] >= n - 3 and runs["check"][3] == 0, runs["check"][4][-2000:]        # every window of the clip was cross-checked, none disagreed
+    assert runs["walk"][2] == 0 and runs["resident"][2] == 0
+    # same trajectory (TrackRGBD's return values) and same refined window poses (vmCameraPose -> initial_rgbd_new.txt) whichever way the windows were assembled
+    for tag in ("check", "resident"):
+        assert np.abs(runs[tag][0] - runs["walk"][0]).max() < 1e-4 and np.abs(runs[tag][1] - runs["walk"][1]).max() < 1e-4, tag
+
+
 def test_kaist_intrinsics_with_lens_distortion_1280x560(tmp_path, vido):
     """Row A11 inside the facade: the KAIST settings of the reference (src/config/kaist_config.yaml:24-33: 1280 x 560, fx 816.4, k1 = -0.05004 ...), ChooseData: 3, the
     reference's disk layout.  Frame::Frame runs UndistortKeyPoints (Frame.cc:603-633 -> vido_undistort_points, pinned bit-exactly against the oracle in

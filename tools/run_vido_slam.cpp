@@ -170,6 +170,8 @@ int main(int argc, char** argv)
             const bool ok = SLAM.GetTracker()->GetStaticTrack() == M->TrackletSta && SLAM.GetTracker()->GetDynamicTrackNew() == M->TrackletDyn && ids == M->nObjID;
             std::cout << "tracklets static " << M->TrackletSta.size() << " dynamic " << M->TrackletDyn.size() << " incremental_equals_rebuild " << (ok ? 1 : 0) << std::endl;
         }
+        { int ck = 0, mm = 0; detail::ResidentCheckStats(&ck, &mm);      // VIDO_BA_RESIDENT_CHECK=1: every local window solved on the device-resident window AND through the Map walk
+          std::cout << "resident_window checks " << ck << " mismatches " << mm << std::endl; }
         {   // Frame::UndistortKeyPoints on the last frame (Frame.cc:603-633): largest displacement mvKeys -> mvKeysUn (0 when Camera.k1 == 0)
             const Frame* F = SLAM.GetTracker()->mpLastFrame ? SLAM.GetTracker()->mpLastFrame : SLAM.GetTracker()->mpCurrentFrame;
             double mx = 0; if (F) for (size_t i = 0; i < F->mvKeys.size() && i < F->mvKeysUn.size(); i++)

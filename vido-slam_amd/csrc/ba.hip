@@ -2261,7 +2261,10 @@ static int chol_large(vido_ctx* ctx, double* A, int n, double* x, double* okflag
     return VIDO_OK;
 }
 
-static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, vido_ba_result* res, vido_allreduce_fn allreduce, void* user);
+static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, vido_ba_result* res, vido_allreduce_fn allreduce, void* user, const BaDevInputs* DI = nullptr);
+// the local-window solve on observation / landmark arrays that already live on the device (csrc/bawin.hip): prob carries the cameras, the camera-camera factors and the
+// parameters; its observation and point fields are ignored
+int ba_run_device_inputs(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_result* res, const BaDevInputs* DI) { return ba_run(ctx, prob, nullptr, res, nullptr, nullptr, DI); }
 extern "C" int vido_ba_optimize(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_result* res, vido_allreduce_fn allreduce, void* user)
 {
     return ba_run(ctx, prob, nullptr, res, allreduce, user);
@@ -2271,11 +2274,14 @@ extern "C" int vido_ba_optimize_dynamic(vido_ctx* ctx, vido_ba_problem* prob, vi
     return ba_run(ctx, prob, dyn, res, allreduce, user);
 }
 
-static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, vido_ba_result* res, vido_allreduce_fn allreduce, void* user)
+static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, vido_ba_result* res, vido_allreduce_fn allreduce, void* user, const BaDevInputs* DI)
 {
     if (!ctx) return VIDO_E_INVALID;
     if (!prob || !res) return vido_set_error(ctx, VIDO_E_INVALID, "ba: null problem/result");
-    const vido_ba_problem& p = *prob;
+    vido_ba_problem pcopy = *prob;
+    if (DI) { pcopy.n_pt = DI->n_ptl; pcopy.n_obs = 0; pcopy.pt_lo = pcopy.pt_hi = 0; pcopy.rank = 0; pcopy.world = 1;
+              if (dynp || allreduce || 6 * pcopy.n_cam > BA_LDS_MAX_N6) return vido_set_error(ctx, VIDO_E_INVALID, "ba: device-resident inputs are for the static local window (<= %d cameras)", BA_LDS_MAX_N6 / 6); }
+    const vido_ba_problem& p = pcopy;
     static const vido_ba_dynamic no_dyn{};
     const vido_ba_dynamic& dy = (dynp && p.rank == 0) ? *dynp : no_dyn;      // rank 0 owns the object part (like the camera-camera factors)
     if (dy.n_H < 0 || dy.n_dyn < 0 || dy.n_tern < 0 || dy.n_smooth < 0 || (dy.n_H && !dy.H_T) || (dy.n_dyn && (!dy.dyn_xyz || !dy.dyn_cam || !dy.dyn_meas)) ||
@@ -2283,7 +2289,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         return vido_set_error(ctx, VIDO_E_INVALID, "ba: malformed dynamic part");
     const int n_H = dynp ? dynp->n_H : 0;                                    // every rank carries the H vertices (replicated reduced solve)
     const int n_pose = p.n_cam + n_H;
-    if (p.n_cam < 1 || p.n_pt < 0 || p.n_obs < 0 || p.n_odo < 0 || !p.cam_T || (p.n_pt && !p.pt_xyz) ||
+    if (p.n_cam < 1 || p.n_pt < 0 || p.n_obs < 0 || p.n_odo < 0 || !p.cam_T || (p.n_pt && !p.pt_xyz && !DI) ||
         (p.n_obs && (!p.obs_cam || !p.obs_pt || !p.obs_meas)) || (p.n_odo && (!p.odo_i || !p.odo_j || !p.odo_T)) || p.prior_cam >= p.n_cam)
         return vido_set_error(ctx, VIDO_E_INVALID, "ba: malformed problem");
     const int pt_lo = p.pt_hi > p.pt_lo ? p.pt_lo : 0, pt_hi = p.pt_hi > p.pt_lo ? p.pt_hi : p.n_pt;
@@ -2382,26 +2388,28 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         if (p.obs_cam[k] < 0 || p.obs_cam[k] >= p.n_cam || p.obs_pt[k] < 0 || p.obs_pt[k] >= p.n_pt) return vido_set_error(ctx, VIDO_E_INVALID, "ba: observation %d has a bad index", k);
         if (p.obs_pt[k] >= pt_lo && p.obs_pt[k] < pt_hi) keep.push_back(k);
     }
-    const int no = (int)keep.size();
-    {   // stable counting sort by camera (O(n); a comparison sort of 1M observations costs more than the whole LM loop)
+    const int no = DI ? DI->no : (int)keep.size();
+    if (!DI) {   // stable counting sort by camera (O(n); a comparison sort of 1M observations costs more than the whole LM loop)
         std::vector<int> cstart(n_pose + 1, 0), sorted(no);
         for (int t = 0; t < no; t++) cstart[perm[p.obs_cam[keep[t]]] + 1]++;
         for (int c = 0; c < n_pose; c++) cstart[c + 1] += cstart[c];
         for (int t = 0; t < no; t++) sorted[cstart[perm[p.obs_cam[keep[t]]]]++] = keep[t];
         keep.swap(sorted);
     }
-    std::vector<int> ocam(no), opt(no), opos(no), pstart(n_ptl + 1, 0), slotcam(no);
-    std::vector<double> omeas((size_t)no * 3);
-    for (int t = 0; t < no; t++) { const int k = keep[t]; ocam[t] = perm[p.obs_cam[k]]; opt[t] = p.obs_pt[k] - pt_lo; for (int a = 0; a < 3; a++) omeas[3 * (size_t)t + a] = p.obs_meas[3 * (size_t)k + a]; pstart[opt[t] + 1]++; }
+    const int nh = DI ? 0 : no;                              // host-side observation arrays (none when the inputs are device-resident)
+    std::vector<int> ocam(nh), opt(nh), opos(nh), pstart(n_ptl + 1, 0), slotcam(nh);
+    std::vector<double> omeas((size_t)nh * 3);
+    for (int t = 0; t < nh; t++) { const int k = keep[t]; ocam[t] = perm[p.obs_cam[k]]; opt[t] = p.obs_pt[k] - pt_lo; for (int a = 0; a < 3; a++) omeas[3 * (size_t)t + a] = p.obs_meas[3 * (size_t)k + a]; pstart[opt[t] + 1]++; }
     int maxk = 0;
     for (int l = 0; l < n_ptl; l++) { maxk = std::max(maxk, pstart[l + 1]); pstart[l + 1] += pstart[l]; }
-    { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (int t = 0; t < no; t++) { opos[t] = fill[opt[t]]++; slotcam[opos[t]] = ocam[t]; } }
+    { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (int t = 0; t < nh; t++) { opos[t] = fill[opt[t]]++; slotcam[opos[t]] = ocam[t]; } }
+    if (DI) maxk = DI->kcap;                                 // (a landmark of the window has at most one observation per keyframe)
     // the Schur kernels add WD_i W_j^T for slot pairs i >= j into the LOWER triangle and assume the slots of a landmark belong to distinct cameras (for two
     // slots of one camera the transposed term would be missing); the observations are sorted by camera, so duplicates are adjacent slots
-    for (int l = 0; l < n_ptl; l++) for (int q = pstart[l] + 1; q < pstart[l + 1]; q++)
+    if (!DI) for (int l = 0; l < n_ptl; l++) for (int q = pstart[l] + 1; q < pstart[l + 1]; q++)
         if (slotcam[q] == slotcam[q - 1]) return vido_set_error(ctx, VIDO_E_INVALID, "ba: landmark %d is observed twice from camera %d (merge duplicate observations first)", l + pt_lo, slotcam[q]);
     std::vector<int> long_list;                             // landmarks with more than 64 observations: k_ba_schur_long
-    for (int l = 0; l < n_ptl; l++) if (pstart[l + 1] - pstart[l] > 64) long_list.push_back(l);
+    if (!DI) for (int l = 0; l < n_ptl; l++) if (pstart[l + 1] - pstart[l] > 64) long_list.push_back(l);
     maxk = std::min(maxk, 64);
     // ---- device buffers
     {   // size the persistent pool (device + pinned mirror for the uploads) for this problem
@@ -2433,9 +2441,14 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     D.info_obs = p.info_obs; D.info_odo = p.info_odo; D.info_prior = p.info_prior; D.huber_obs = p.huber_obs; D.huber_odo = p.huber_odo;
     memcpy(D.prior_T, p.prior_T, sizeof D.prior_T);
     D.cam = A.put(poses.data(), (size_t)n_pose * 12, st); D.cam_new = A.get<double>((size_t)n_pose * 12);
+    if (DI) {                                                // observations, landmarks and their index tables are already on the device
+        D.pt = DI->pt; D.pt_new = A.get<double>((size_t)n_ptl * 3);
+        D.obs_cam = DI->obs_cam; D.obs_pt = DI->obs_pt; D.obs_pos = DI->obs_pos; D.obs_meas = DI->obs_meas; D.pt_start = DI->pt_start; D.slot_cam = DI->slot_cam;
+    } else {
     D.pt = A.put(p.pt_xyz + 3 * (size_t)pt_lo, (size_t)n_ptl * 3, st); D.pt_new = A.get<double>((size_t)n_ptl * 3);
     D.obs_cam = A.put(ocam.data(), no, st); D.obs_pt = A.put(opt.data(), no, st); D.obs_pos = A.put(opos.data(), no, st);
     D.obs_meas = A.put(omeas.data(), (size_t)no * 3, st); D.pt_start = A.put(pstart.data(), n_ptl + 1, st); D.slot_cam = A.put(slotcam.data(), no, st);
+    }
     D.odo_i = A.put(cc_i.data(), n_cc, st); D.odo_j = A.put(cc_j.data(), n_cc, st); D.odo_T = A.put(cc_T.data(), (size_t)n_cc * 12, st);
     D.odo_info = A.put(cc_info.data(), n_cc, st); D.odo_delta = A.put(cc_delta.data(), n_cc, st);
     D.W = A.get<double>((size_t)no * BA_REC); D.Cp = D.W + 18;      /* the arena hands out 256-byte aligned blocks: records are line-aligned */
@@ -2727,7 +2740,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     res->ms_linearize_kernel = n_lin ? ms_lin / n_lin : 0.0;
     res->ms_solve_loop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
     HIP_TRY(ctx, hipMemcpyAsync(poses.data(), D.cam, (size_t)n_pose * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (n_ptl) HIP_TRY(ctx, hipMemcpyAsync(prob->pt_xyz + 3 * (size_t)pt_lo, D.pt, (size_t)n_ptl * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (n_ptl && !DI) HIP_TRY(ctx, hipMemcpyAsync(prob->pt_xyz + 3 * (size_t)pt_lo, D.pt, (size_t)n_ptl * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (n_ptl && DI && D.pt != DI->pt) HIP_TRY(ctx, hipMemcpyAsync(DI->pt, D.pt, (size_t)n_ptl * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));      // the accepted state may sit in the other buffer
     if (nd) HIP_TRY(ctx, hipMemcpyAsync(d_xyz.data(), D.dyn, (size_t)nd * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     for (int i = 0; i < p.n_cam; i++) memcpy(prob->cam_T + (size_t)i * 12, poses.data() + (size_t)perm[i] * 12, 12 * sizeof(double));

@@ -48,6 +48,7 @@ struct vido_ctx {
     struct PoseState* pose = nullptr;
     struct NetState* net = nullptr;
     struct PnpState* pnp = nullptr;
+    struct BaWin* bawin = nullptr;     // bawin.hip: the device-resident local-BA window
     void* detpost_buf = nullptr; size_t detpost_cap = 0; unsigned long long detpost_sig = 0;   // detpost.hip: scratch of the RPN selection (keys, histograms, state)
     void* rccl_comm = nullptr;         // ncclComm_t of vido_rccl_init (rccl.cpp): the sharded BA's all-reduce on this context's stream
     int rccl_rank = 0, rccl_world = 1;
@@ -74,6 +75,10 @@ void track_state_destroy(vido_ctx* ctx);
 void ham_state_destroy(vido_ctx* ctx);
 void pose_state_destroy(vido_ctx* ctx);
 void ba_state_destroy(vido_ctx* ctx);
+// device-resident inputs of the local-window solve (bawin.hip assembles them, ba.hip solves): observations sorted by camera, landmark-major slot tables, points (in / out)
+struct BaDevInputs { int no, n_ptl, kcap; const int *obs_cam, *obs_pt, *obs_pos, *pt_start, *slot_cam; const double* obs_meas; double* pt; };
+int ba_run_device_inputs(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_result* res, const BaDevInputs* DI);
+void bawin_state_destroy(vido_ctx* ctx);
 void net_state_destroy(vido_ctx* ctx);
 void pnp_state_destroy(vido_ctx* ctx);
 void orb_state_destroy(vido_ctx* ctx);

@@ -88,6 +88,7 @@ void vido_destroy(vido_ctx* ctx)
     ba_state_destroy(ctx);
     net_state_destroy(ctx);
     pnp_state_destroy(ctx);
+    bawin_state_destroy(ctx);
     if (ctx->detpost_buf) { hipFree(ctx->detpost_buf); ctx->detpost_buf = nullptr; }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);

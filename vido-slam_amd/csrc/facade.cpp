@@ -225,10 +225,11 @@ void Map::reset() { *this = Map(); }
 // highest-numbered tracklet of length >= 3 that contains it (only a tracklet's first element can be shared).
 static void grow_tracklets(const std::vector<std::vector<int> >& TM, const std::vector<std::vector<cv::KeyPoint> >& feat, const std::vector<std::vector<int> >* Lab,
                            std::vector<std::vector<std::pair<int, int> > >& T, std::vector<int>* objid, std::vector<std::vector<int> >& trk, std::vector<std::vector<int> >& pos,
-                           std::vector<int>& pre, size_t& rows)
+                           std::vector<int>& pre, size_t& rows, std::vector<int>* changes = nullptr)
 {
     while (trk.size() < feat.size()) { trk.emplace_back(feat[trk.size()].size(), -1); pos.emplace_back(feat[pos.size()].size(), -1); }
-    auto own = [&](int t, int k) { const std::pair<int, int>& e = T[t][k]; if (trk[e.first][e.second] <= t) { trk[e.first][e.second] = t; pos[e.first][e.second] = k; } };
+    auto own = [&](int t, int k) { const std::pair<int, int>& e = T[t][k]; if (trk[e.first][e.second] <= t) { trk[e.first][e.second] = t; pos[e.first][e.second] = k;
+                                   if (changes) { changes->push_back(e.first); changes->push_back(e.second); changes->push_back(t); changes->push_back(k); } } };
     for (; rows < TM.size(); rows++) {
         const int i = (int)rows;
         std::vector<int> cur(TM[i].size(), -1);
@@ -246,8 +247,22 @@ static void grow_tracklets(const std::vector<std::vector<int> >& TM, const std::
 }
 void Map::UpdateTracklets()
 {
-    grow_tracklets(vnAssoSta, vpFeatSta, nullptr, TrackletSta, nullptr, vnTrkSta, vnPosSta, trkPreSta, trkRowsSta);
+    grow_tracklets(vnAssoSta, vpFeatSta, nullptr, TrackletSta, nullptr, vnTrkSta, vnPosSta, trkPreSta, trkRowsSta, &trkChangesSta);
     grow_tracklets(vnAssoDyn, vpFeatDyn, &vnFeatLabel, TrackletDyn, &nObjID, vnTrkDyn, vnPosDyn, trkPreDyn, trkRowsDyn);
+}
+
+void Map::SyncPointsFromDevice()
+{
+    if (!devWindow || !g_ctx) return;
+    const int N = (int)vp3DPointSta.size();
+    std::vector<float> buf;
+    for (int f = std::max(0, N - 64); f < devFramesPushed && f < N; f++) {
+        const int n = (int)vp3DPointSta[f].size();
+        if (!n) continue;
+        buf.resize(3 * (size_t)n);
+        if (vido_bawin_read_points(g_ctx, f, n, buf.data()) != VIDO_OK) continue;      // (frames that have left the ring were synchronised when they left)
+        for (int j = 0; j < n; j++) vp3DPointSta[f][j] = vec3(buf[3 * (size_t)j], buf[3 * (size_t)j + 1], buf[3 * (size_t)j + 2]);
+    }
 }
 
 // ---- Optimizer ---------------------------------------------------------------------------------------------------------
@@ -459,6 +474,80 @@ static void dump_g2o(const std::string& path, const vido_ba_problem& b, const vi
 
 // Map walk of PartialBatchOptimization (Optimizer.cc:56-160, 216-350; STATIC_ONLY graph) and FullBatchOptimization (:1235-2178;
 // static + object factors) onto the flat BA problem.
+static int g_res_checks = 0, g_res_mismatch = 0;
+namespace detail { void ResidentCheckStats(int* checks, int* mismatches) { if (checks) *checks = g_res_checks; if (mismatches) *mismatches = g_res_mismatch; } }
+
+// Commits a local-window result to the Map (Optimizer.cc:1084-1128): refined camera poses, the odometry factors re-derived from them
+static void commit_window_poses(Map* pMap, int start, int N, const std::vector<double>& cam)
+{
+    for (int i = start; i < N; i++) {
+        cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+        for (int rr = 0; rr < 3; rr++) for (int c = 0; c < 4; c++) T.at<float>(rr, c) = (float)cam[(size_t)(i - start) * 12 + rr * 4 + c];
+        pMap->vmCameraPose[i] = T;
+        if (i > start) pMap->vmRigidMotion[i - 1][0] = Converter::toInvMatrix(pMap->vmCameraPose[i - 1]) * pMap->vmCameraPose[i];
+    }
+}
+
+// PartialBatchOptimization on the device-resident window (csrc/bawin.hip): only the new frames' feature rows and the tracklet-label changes go up, the graph is assembled
+// and solved on the device, the refined landmarks stay there (Map::SyncPointsFromDevice brings them home when the host needs them).  false: the window cannot take this
+// sequence (more features per frame than the ring holds) -> the caller walks the Map like rounds 1-2 did.
+static bool batch_optimize_resident(Map* pMap, const cv::Mat& K, int start, int N, int WINDOW_SIZE, const std::vector<double>* check_cam, int check_nobs, int check_npt)
+{
+    static bool disabled = false;
+    if (disabled) return false;
+    vido_ctx* c = live_ctx("PartialBatchOptimization");
+    const int cap_f = std::max(WINDOW_SIZE, 20) + 4, cap_n = 8192, nc = N - start;
+    const float invfx = 1.0f / K.at<float>(0, 0), invfy = 1.0f / K.at<float>(1, 1), kcx = K.at<float>(0, 2), kcy = K.at<float>(1, 2);
+    if (!pMap->devWindow) { check(vido_bawin_create(c, cap_f, cap_n), "bawin_create"); pMap->devWindow = true; pMap->devFramesPushed = 0; }
+    std::vector<double> meas; std::vector<float> xyz;
+    for (int f = std::max(pMap->devFramesPushed, N - (cap_f - 1)); f < N; f++) {
+        const int n = (int)pMap->vpFeatSta[f].size(), fo = f - cap_f;
+        if (n > cap_n || (f > 0 && (int)pMap->vnAssoSta[f - 1].size() != n)) { disabled = true; pMap->SyncPointsFromDevice(); pMap->devWindow = false; return false; }
+        if (fo >= 0 && !pMap->vp3DPointSta[fo].empty()) {      // the frame this one replaces in the ring: its points go home first
+            std::vector<float> buf(3 * pMap->vp3DPointSta[fo].size());
+            if (vido_bawin_read_points(c, fo, (int)pMap->vp3DPointSta[fo].size(), buf.data()) == VIDO_OK)
+                for (size_t j = 0; j < pMap->vp3DPointSta[fo].size(); j++) pMap->vp3DPointSta[fo][j] = vec3(buf[3 * j], buf[3 * j + 1], buf[3 * j + 2]);
+        }
+        meas.resize(3 * (size_t)n); xyz.resize(3 * (size_t)n);
+        for (int j = 0; j < n; j++) {
+            const cv::KeyPoint& kp = pMap->vpFeatSta[f][j]; const float z = pMap->vfDepSta[f][j];                   // Optimizer::Get3DinCamera, as the walk inlines it
+            meas[3 * (size_t)j] = (kp.pt.x - kcx) * z * invfx; meas[3 * (size_t)j + 1] = (kp.pt.y - kcy) * z * invfy; meas[3 * (size_t)j + 2] = z;
+            const cv::Mat& Xw = pMap->vp3DPointSta[f][j]; for (int a = 0; a < 3; a++) xyz[3 * (size_t)j + a] = Xw.at<float>(a);
+        }
+        check(vido_bawin_push_frame(c, f, n, meas.data(), xyz.data(), f > 0 ? pMap->vnAssoSta[f - 1].data() : nullptr), "bawin_push_frame");
+    }
+    pMap->devFramesPushed = N;
+    if (!pMap->trkChangesSta.empty()) { check(vido_bawin_set_labels(c, (int)(pMap->trkChangesSta.size() / 4), pMap->trkChangesSta.data()), "bawin_set_labels"); pMap->trkChangesSta.clear(); }
+    std::vector<double> cam((size_t)nc * 12), odo; std::vector<int32_t> oi, oj;
+    for (int i = start; i < N; i++) for (int r = 0; r < 3; r++) for (int cc = 0; cc < 4; cc++) cam[(size_t)(i - start) * 12 + r * 4 + cc] = pMap->vmCameraPose[i].at<float>(r, cc);
+    for (int i = start + 1; i < N; i++) {
+        const cv::Mat& M = pMap->vmRigidMotion[i - 1][0];
+        oi.push_back(i - 1 - start); oj.push_back(i - start);
+        for (int r = 0; r < 3; r++) for (int cc = 0; cc < 4; cc++) odo.push_back(M.at<float>(r, cc));
+    }
+    vido_ba_problem b; memset(&b, 0, sizeof b);
+    b.n_cam = nc; b.cam_T = cam.data();
+    b.n_odo = (int)oi.size(); b.odo_i = oi.data(); b.odo_j = oj.data(); b.odo_T = odo.data();
+    b.use_huber = 1; b.huber_obs = b.huber_odo = (double)0.01f; b.info_odo = 1.0 / (double)0.0001f;
+    b.prior_cam = (N == WINDOW_SIZE) ? 0 : -1; b.info_prior = 1.0 / 0.0000001; b.info_obs = 1.0 / (double)16.f; b.max_iters = 100; b.gain_threshold = 1e-3;      // Optimizer.cc:183,191-196,226-235
+    for (int k = 0; k < 12; k++) b.prior_T[k] = cam[k];
+    vido_ba_result r; int32_t no = 0, np = 0;
+    check(vido_bawin_solve(c, start, N, &b, &r, &no, &np), "PartialBatchOptimization (resident window)");
+    if (getenv("VIDO_BA_VERBOSE"))
+        fprintf(stderr, "[batch partial, resident] cams %d pts %d obs %d | iters %d trials %d chi2 %.6g -> %.6g | setup %.2f ms loop %.2f ms\n", nc, np, no, r.iterations, r.lm_trials, r.chi2_initial, r.chi2_final, r.ms_setup, r.ms_solve_loop);
+    if (check_cam) {                                           // VIDO_BA_RESIDENT_CHECK: the Map walk solved the same window on the host-assembled arrays
+        g_res_checks++;
+        double worst = 0; for (size_t k = 0; k < cam.size() && k < check_cam->size(); k++) worst = std::max(worst, std::fabs(cam[k] - (*check_cam)[k]));
+        if (no != check_nobs || np != check_npt || !(worst < 1e-7) || (np && r.iterations == 0)) {
+            g_res_mismatch++;
+            fprintf(stderr, "[resident check] window [%d,%d): obs %d vs %d, landmarks %d vs %d, max pose difference %.3g\n", start, N, no, check_nobs, np, check_npt, worst);
+        }
+    }
+    if (np == 0) return true;
+    commit_window_poses(pMap, start, N, cam);
+    return true;
+}
+
 static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool global)
 {
     const int N = (int)pMap->vpFeatSta.size();
@@ -466,6 +555,10 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
     const int start = global ? 0 : std::max(N - WINDOW_SIZE, 0), nc = N - start;
     const float invfx = 1.0f / K.at<float>(0, 0), invfy = 1.0f / K.at<float>(1, 1), kcx = K.at<float>(0, 2), kcy = K.at<float>(1, 2);
     pMap->UpdateTracklets();                                  // no-op when Tracking::Track already did it for this frame
+    static const bool host_walk = getenv("VIDO_BA_HOST_WALK") != nullptr, check_walk = getenv("VIDO_BA_RESIDENT_CHECK") != nullptr;
+    const bool resident = !global && !host_walk && 6 * nc <= 120;
+    if (resident && !check_walk && batch_optimize_resident(pMap, K, start, N, WINDOW_SIZE, nullptr, 0, 0)) return;
+    pMap->SyncPointsFromDevice();                             // the walk below reads vp3DPointSta
     const auto& Tr = pMap->TrackletSta; const auto& lab = pMap->vnTrkSta;
     std::vector<std::vector<int> > mak(N);                     // only the window's frames are touched
     for (int i = start; i < N; i++) mak[i].assign(pMap->vpFeatSta[i].size(), -1);
@@ -563,6 +656,7 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
         fprintf(stderr, "[batch %s] cams %d pts %d obs %d | H %d dyn %d tern %d smooth %d | iters %d trials %d chi2 %.6g -> %.6g | setup %.2f ms loop %.2f ms\n", global ? "full" : "partial",
                 b.n_cam, b.n_pt, b.n_obs, d.n_H, d.n_dyn, d.n_tern, d.n_smooth, r.iterations, r.lm_trials, r.chi2_initial, r.chi2_final, r.ms_setup, r.ms_solve_loop);
     if (dump_dir) dump_g2o(std::string(dump_dir) + "/dynamic_slam_graph_after_opt.g2o", b, d, ptOwner, Hfr);
+    if (resident && check_walk && batch_optimize_resident(pMap, K, start, N, WINDOW_SIZE, &cam, b.n_obs, b.n_pt)) return;      // the resident solve commits; this walk was the check
     auto& poses = global ? pMap->vmCameraPose_RF : pMap->vmCameraPose;
     for (int i = start; i < N; i++) {                      // write-back, Optimizer.cc:1084-1128 / :2098-2137
         if (global && i == 0) continue;                    // the full batch writes vmCameraPose_RF[i+1] only

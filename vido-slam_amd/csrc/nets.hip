@@ -299,12 +299,27 @@ __global__ __launch_bounds__(64) void k_nms_sweep_seg(const unsigned long long* 
         }
         if ((keepmask >> lane) & 1ull) kp[cnt + __popcll(keepmask & ((1ull << lane) - 1ull))] = blk * 64 + lane;
         cnt += __popcll(keepmask);
-        unsigned long long km = keepmask;
-        while (km) {                                                             // OR the kept rows into the words of the later blocks (independent loads)
-            const int j = __builtin_ctzll(km); km &= km - 1;
-            const unsigned long long* prow = M + (size_t)(blk * 64 + j) * col_blocks;
+        // OR the kept rows into the words of the later blocks.  Round 2 walked the kept rows one after the other (a dependent chain of up to 64 memory round trips per block);
+        // here lane j loads ITS row's word of column block w (all 64 loads of a column block in flight together, the column blocks unrolled four at a time) and the wave
+        // OR-reduces them: one round trip per four column blocks.
+        const bool mine = (keepmask >> lane) & 1ull;
+        const unsigned long long* prow = M + (size_t)(blk * 64 + lane) * col_blocks;
+        for (int w0 = blk + 1; w0 < cb; w0 += 4) {
+            unsigned long long v[4];
 #pragma unroll
-            for (int k = 0; k < 16; k++) if (k < wpl) { const int w = k * 64 + lane; if (w > blk && w < cb) remv[k] |= prow[w]; }
+            for (int u = 0; u < 4; u++) v[u] = (mine && w0 + u < cb) ? prow[w0 + u] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t lo = (uint32_t)v[u], hi = (uint32_t)(v[u] >> 32);
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) { lo |= (uint32_t)__shfl_xor((int)lo, o, 64); hi |= (uint32_t)__shfl_xor((int)hi, o, 64); }
+                const int w = w0 + u;
+                if (w < cb && lane == (w & 63)) {
+                    const unsigned long long r = (unsigned long long)lo | ((unsigned long long)hi << 32);
+#pragma unroll
+                    for (int k = 0; k < 16; k++) if (k == (w >> 6)) remv[k] |= r;
+                }
+            }
         }
     }
     for (int i = cnt + lane; i < keep_stride; i += 64) kp[i] = -1;
