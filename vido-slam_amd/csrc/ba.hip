@@ -2552,7 +2552,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     { std::vector<int> inv(n_pose, -1); for (int i = 0; i < p.n_cam; i++) inv[perm[i]] = i;
       int o = 0; for (int q = 0; q < n_pose; q++) if (inv[q] >= 0) { pose_ord_h[q] = o; ord_pose_h[o] = q; o++; } }
     D.n_cam_ord = p.n_cam; D.pose_ord = A.put(pose_ord_h.data(), n_pose, st); D.ord_pose = A.put(ord_pose_h.data(), p.n_cam, st);
-    { std::vector<int> so(no); for (int t = 0; t < no; t++) so[t] = pose_ord_h[slotcam[t]]; D.slot_ord = A.put(so.data(), no, st); }
+    if (DI) D.slot_ord = DI->slot_cam;                      // (no object motions in the local window: the camera ordinal IS the pose index)
+    else { std::vector<int> so(no); for (int t = 0; t < no; t++) so[t] = pose_ord_h[slotcam[t]]; D.slot_ord = A.put(so.data(), no, st); }
     int* d_chunk_cmin = nullptr; int* d_lorder = nullptr; int2* d_lbc = nullptr; int n_chunks = (n_ptl + BA_CHUNK - 1) / BA_CHUNK; bool use_mfma_schur = false;
     if (!lds_path && n_ptl) {
         std::vector<int> lorder(n_ptl);

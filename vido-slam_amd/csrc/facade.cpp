@@ -496,9 +496,10 @@ static bool batch_optimize_resident(Map* pMap, const cv::Mat& K, int start, int 
     static bool disabled = false;
     if (disabled) return false;
     vido_ctx* c = live_ctx("PartialBatchOptimization");
-    const int cap_f = std::max(WINDOW_SIZE, 20) + 4, cap_n = 8192, nc = N - start;
+    const int cap_f = 24, cap_n = 8192, nc = N - start;      // (the caller sends windows of <= 20 cameras here)
     const float invfx = 1.0f / K.at<float>(0, 0), invfy = 1.0f / K.at<float>(1, 1), kcx = K.at<float>(0, 2), kcy = K.at<float>(1, 2);
-    if (!pMap->devWindow) { check(vido_bawin_create(c, cap_f, cap_n), "bawin_create"); pMap->devWindow = true; pMap->devFramesPushed = 0; }
+    const bool fresh = !pMap->devWindow;
+    if (fresh) { check(vido_bawin_create(c, cap_f, cap_n), "bawin_create"); pMap->devWindow = true; pMap->devFramesPushed = 0; }
     std::vector<double> meas; std::vector<float> xyz;
     for (int f = std::max(pMap->devFramesPushed, N - (cap_f - 1)); f < N; f++) {
         const int n = (int)pMap->vpFeatSta[f].size(), fo = f - cap_f;
@@ -517,6 +518,11 @@ static bool batch_optimize_resident(Map* pMap, const cv::Mat& K, int start, int 
         check(vido_bawin_push_frame(c, f, n, meas.data(), xyz.data(), f > 0 ? pMap->vnAssoSta[f - 1].data() : nullptr), "bawin_push_frame");
     }
     pMap->devFramesPushed = N;
+    if (fresh) {                                               // a ring that starts late takes the labels of its frames from the Map's tables, not from the change list
+        pMap->trkChangesSta.clear();
+        for (int f = std::max(0, N - (cap_f - 1)); f < N; f++) for (size_t j = 0; j < pMap->vnTrkSta[f].size(); j++) if (pMap->vnTrkSta[f][j] != -1) {
+            pMap->trkChangesSta.push_back(f); pMap->trkChangesSta.push_back((int)j); pMap->trkChangesSta.push_back(pMap->vnTrkSta[f][j]); pMap->trkChangesSta.push_back(pMap->vnPosSta[f][j]); }
+    }
     if (!pMap->trkChangesSta.empty()) { check(vido_bawin_set_labels(c, (int)(pMap->trkChangesSta.size() / 4), pMap->trkChangesSta.data()), "bawin_set_labels"); pMap->trkChangesSta.clear(); }
     std::vector<double> cam((size_t)nc * 12), odo; std::vector<int32_t> oi, oj;
     for (int i = start; i < N; i++) for (int r = 0; r < 3; r++) for (int cc = 0; cc < 4; cc++) cam[(size_t)(i - start) * 12 + r * 4 + cc] = pMap->vmCameraPose[i].at<float>(r, cc);
@@ -559,6 +565,7 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
     const bool resident = !global && !host_walk && 6 * nc <= 120;
     if (resident && !check_walk && batch_optimize_resident(pMap, K, start, N, WINDOW_SIZE, nullptr, 0, 0)) return;
     pMap->SyncPointsFromDevice();                             // the walk below reads vp3DPointSta
+    if (!(resident && check_walk)) pMap->devWindow = false;   // ... and writes it: the ring's copy is stale from here on (a later resident window starts afresh)
     const auto& Tr = pMap->TrackletSta; const auto& lab = pMap->vnTrkSta;
     std::vector<std::vector<int> > mak(N);                     // only the window's frames are touched
     for (int i = start; i < N; i++) mak[i].assign(pMap->vpFeatSta[i].size(), -1);

@@ -119,49 +119,61 @@ __device__ inline double reproj2(const double* R, const double* t, const float* 
     return du * du + dv * dv;
 }
 
-// one workgroup per (hypothesis, problem); problem p owns points [off, off + n) of the concatenated arrays
+// problem p owns points [off, off + n) of the concatenated arrays
 struct PnpProb { int off, n; unsigned long long seed; };
-__global__ __launch_bounds__(256) void k_pnp_hypotheses(const float* __restrict__ Xall, const float* __restrict__ xall, const PnpProb* __restrict__ prob, int max_iters,
-                                                        double fx, double fy, double cx, double cy, double thr2, double* __restrict__ models_all /*[prob][iters][12]*/,
-                                                        int* __restrict__ counts_all)
+// Phase 1 (round 3: split off the scoring): ONE THREAD per (hypothesis, problem) samples its four points, solves Grunert's quartic and picks the solution the 4th point agrees
+// with.  Round 2 ran this on lane 0 of a 256-thread workgroup per hypothesis — 3 000 workgroups per frame (camera + 5 objects x 500 hypotheses) whose other 255 lanes waited
+// ~15 us for the FP64 root finder before they could score anything.
+__global__ __launch_bounds__(64) void k_pnp_solve(const float* __restrict__ Xall, const float* __restrict__ xall, const PnpProb* __restrict__ prob, int max_iters,
+                                                  double fx, double fy, double cx, double cy, double* __restrict__ models_all /*[prob][iters][12]*/, int* __restrict__ has_all)
 {
-    __shared__ double sR[9], st[3]; __shared__ int has; __shared__ int wcnt[4];
-    const int it = blockIdx.x; const PnpProb pr = prob[blockIdx.y];
-    const int n = pr.n; const uint64_t seed = pr.seed;
+    const int it = blockIdx.x * 64 + threadIdx.x; const PnpProb pr = prob[blockIdx.y];
+    if (it >= max_iters) return;
+    const int n = pr.n;
+    double* m = models_all + ((size_t)blockIdx.y * max_iters + it) * 12; int* has = has_all + (size_t)blockIdx.y * max_iters + it;
+    if (n < 4) { *has = 0; return; }
     const float* X = Xall + 3 * (size_t)pr.off; const float* x = xall + 2 * (size_t)pr.off;
-    double* models = models_all + (size_t)blockIdx.y * max_iters * 12; int* counts = counts_all + (size_t)blockIdx.y * max_iters;
-    if (n < 4) { if (threadIdx.x == 0) counts[it] = 0; return; }
-    if (threadIdx.x == 0) {
-        int idx[4]; sample4(seed, it, n, idx);
-        double P[3][3], j[3][3];
-        for (int k = 0; k < 3; k++) {
-            for (int a = 0; a < 3; a++) P[k][a] = X[3 * idx[k] + a];
-            const double bx = (x[2 * idx[k]] - cx) / fx, by = (x[2 * idx[k] + 1] - cy) / fy, nn = sqrt(bx * bx + by * by + 1);
-            j[k][0] = bx / nn; j[k][1] = by / nn; j[k][2] = 1 / nn;
-        }
-        double Rs[4][9], ts[4][3];
-        const int ns = p3p(P, j, Rs, ts);
-        int best = -1; double be = 1e300;
-        for (int s = 0; s < ns; s++) { const double e = reproj2(Rs[s], ts[s], X + 3 * idx[3], x + 2 * idx[3], fx, fy, cx, cy); if (e < be) { be = e; best = s; } }
-        has = best >= 0;
-        if (best >= 0) { for (int k = 0; k < 9; k++) sR[k] = Rs[best][k]; for (int k = 0; k < 3; k++) st[k] = ts[best][k]; }
+    int idx[4]; sample4(pr.seed, it, n, idx);
+    double P[3][3], j[3][3];
+    for (int k = 0; k < 3; k++) {
+        for (int a = 0; a < 3; a++) P[k][a] = X[3 * idx[k] + a];
+        const double bx = (x[2 * idx[k]] - cx) / fx, by = (x[2 * idx[k] + 1] - cy) / fy, nn = sqrt(bx * bx + by * by + 1);
+        j[k][0] = bx / nn; j[k][1] = by / nn; j[k][2] = 1 / nn;
     }
+    double Rs[4][9], ts[4][3];
+    const int ns = p3p(P, j, Rs, ts);
+    int best = -1; double be = 1e300;
+    for (int s2 = 0; s2 < ns; s2++) { const double e = reproj2(Rs[s2], ts[s2], X + 3 * idx[3], x + 2 * idx[3], fx, fy, cx, cy); if (e < be) { be = e; best = s2; } }
+    *has = best >= 0;
+    for (int k = 0; k < 9; k++) m[k] = best >= 0 ? Rs[best][k] : 0.0;
+    for (int k = 0; k < 3; k++) m[9 + k] = best >= 0 ? ts[best][k] : 0.0;
+}
+// Phase 2: inlier counts.  A workgroup scores PNP_H hypotheses of one problem: every thread loads its points once and evaluates them against all PNP_H models (LDS).
+#define PNP_H 4
+__global__ __launch_bounds__(256) void k_pnp_score(const float* __restrict__ Xall, const float* __restrict__ xall, const PnpProb* __restrict__ prob, int max_iters,
+                                                   double fx, double fy, double cx, double cy, double thr2, const double* __restrict__ models_all, const int* __restrict__ has_all,
+                                                   int* __restrict__ counts_all)
+{
+    __shared__ double sm[PNP_H][12]; __shared__ int shas[PNP_H]; __shared__ int wcnt[4][PNP_H];
+    const int it0 = blockIdx.x * PNP_H; const PnpProb pr = prob[blockIdx.y];
+    const int n = pr.n;
+    const float* X = Xall + 3 * (size_t)pr.off; const float* x = xall + 2 * (size_t)pr.off;
+    int* counts = counts_all + (size_t)blockIdx.y * max_iters;
+    if (threadIdx.x < PNP_H * 12) { const int h = threadIdx.x / 12, k = threadIdx.x - h * 12; sm[h][k] = it0 + h < max_iters ? models_all[((size_t)blockIdx.y * max_iters + it0 + h) * 12 + k] : 0.0; }
+    if (threadIdx.x < PNP_H) shas[threadIdx.x] = it0 + threadIdx.x < max_iters ? has_all[(size_t)blockIdx.y * max_iters + it0 + threadIdx.x] : 0;
     __syncthreads();
-    int cnt = 0;
-    if (has) {
-        double R[9], t[3];
-        for (int k = 0; k < 9; k++) R[k] = sR[k];
-        for (int k = 0; k < 3; k++) t[k] = st[k];
-        for (int i = threadIdx.x; i < n; i += 256) cnt += reproj2(R, t, X + 3 * i, x + 2 * i, fx, fy, cx, cy) <= thr2;
+    int cnt[PNP_H];
+#pragma unroll
+    for (int h = 0; h < PNP_H; h++) cnt[h] = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float Xp[3] = {X[3 * i], X[3 * i + 1], X[3 * i + 2]}, xp[2] = {x[2 * i], x[2 * i + 1]};
+#pragma unroll
+        for (int h = 0; h < PNP_H; h++) if (shas[h]) cnt[h] += reproj2(sm[h], sm[h] + 9, Xp, xp, fx, fy, cx, cy) <= thr2;
     }
-    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = cnt;
+#pragma unroll
+    for (int h = 0; h < PNP_H; h++) { int c = cnt[h]; for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64); if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6][h] = c; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        counts[it] = has ? wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3] : 0;
-        for (int k = 0; k < 9; k++) models[12 * it + k] = sR[k];
-        for (int k = 0; k < 3; k++) models[12 * it + 9 + k] = st[k];
-    }
+    if (threadIdx.x < PNP_H && it0 + threadIdx.x < max_iters) counts[it0 + threadIdx.x] = shas[threadIdx.x] ? wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x] : 0;
 }
 
 __device__ int ransac_update_iters(double p, double ep, int model_points, int max_iters)
@@ -298,7 +310,7 @@ extern "C" int vido_pnp_ransac_batch(vido_ctx* ctx, int n_prob, const float* con
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_x3 = 0, o_x2 = o_x3 + al(tot * 12), o_pr = o_x2 + al(tot * 8), o_mod = o_pr + al((size_t)n_prob * sizeof(PnpProb)),
                  o_cnt = o_mod + al((size_t)n_prob * max_iters * 96), o_T = o_cnt + al((size_t)n_prob * max_iters * 4), o_n = o_T + al((size_t)n_prob * 128),
-                 o_mask = o_n + al((size_t)n_prob * 4), total = o_mask + al(tot) + 256;
+                 o_mask = o_n + al((size_t)n_prob * 4), o_has = o_mask + al(tot) + 256, total = o_has + al((size_t)n_prob * max_iters * 4) + 256;
     if (total > S->cap) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
         if (S->d) { hipFree(S->d); hipHostFree(S->h); S->d = nullptr; S->h = nullptr; }
@@ -311,11 +323,13 @@ extern "C" int vido_pnp_ransac_batch(vido_ctx* ctx, int n_prob, const float* con
     }
     HIP_TRY(ctx, hipMemcpyAsync(S->d, S->h, o_mod, hipMemcpyHostToDevice, st));
     const float* dX = (const float*)(S->d + o_x3); const float* dx = (const float*)(S->d + o_x2); const PnpProb* dp = (const PnpProb*)(S->d + o_pr);
-    hipLaunchKernelGGL(k_pnp_hypotheses, dim3(max_iters, n_prob), dim3(256), 0, st, dX, dx, dp, max_iters, fx, fy, cx, cy, reproj_err * reproj_err, (double*)(S->d + o_mod), (int*)(S->d + o_cnt));
+    hipLaunchKernelGGL(k_pnp_solve, dim3((max_iters + 63) / 64, n_prob), dim3(64), 0, st, dX, dx, dp, max_iters, fx, fy, cx, cy, (double*)(S->d + o_mod), (int*)(S->d + o_has));
+    hipLaunchKernelGGL(k_pnp_score, dim3((max_iters + PNP_H - 1) / PNP_H, n_prob), dim3(256), 0, st, dX, dx, dp, max_iters, fx, fy, cx, cy, reproj_err * reproj_err,
+                       (const double*)(S->d + o_mod), (const int*)(S->d + o_has), (int*)(S->d + o_cnt));
     hipLaunchKernelGGL(k_pnp_select, dim3(n_prob), dim3(256), 0, st, dX, dx, dp, fx, fy, cx, cy, max_iters, reproj_err * reproj_err, confidence,
                        (const double*)(S->d + o_mod), (const int*)(S->d + o_cnt), (double*)(S->d + o_T), (unsigned char*)(S->d + o_mask), (int*)(S->d + o_n));
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(S->h + o_T, S->d + o_T, total - 256 - o_T, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(S->h + o_T, S->d + o_T, o_has - 256 - o_T, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     memcpy(T_out, S->h + o_T, (size_t)n_prob * 128);
     for (int p = 0; p < n_prob; p++) {
