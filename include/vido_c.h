@@ -285,6 +285,18 @@ int vido_backwarp(vido_ctx* ctx, const float* x, const float* flow, int B, int C
 /* Depthwise ConvTranspose2d(C, C, 4, stride 2, padding 1, groups = C, bias = False) on DEVICE tensors: x [B,C,H,W] -> out [B,C,2H,2W], weight [C,1,4,4]; the input passes
  * through LeakyReLU(input_slope) first (1 = none).  LiteFlowNet's netUpflow / netUpcorr (flow_net/src/layers.py:105-108, 130-135). */
 int vido_deconv4s2_depthwise(vido_ctx* ctx, const float* x, const float* weight, int B, int C, int H, int W, float input_slope, float* out);
+
+/* Grouped 3x3 convolution + bias + ReLU on the fp32 matrix cores (csrc/gconv.hip): `conv2` of BottleneckWithFixedBatchNorm with the frozen batch norm folded in
+ * (maskrcnn_benchmark/modeling/backbone/resnet.py:300-372, layers/batch_norm.py:19-31) — Conv2d(width, width, 3, 1, 1, groups) + FrozenBatchNorm2d + relu_ as ONE launch.
+ * x [groups * cpg_in][H][W], y [groups * cpg_out][H][W] f32 DEVICE tensors of one image (x != y), bias [groups * cpg_out]; w_packed: the folded weight rearranged into
+ * matrix-core operand order (vido_gconv3x3_packed_size floats; layout in csrc/gconv.hip, built by vido_slam_amd/nets/ops.py::pack_gconv3x3).  slope: 0 = ReLU, 1 = none.
+ * in_bias (NULL or [groups * cpg_in]): the convolution reads relu(x + in_bias[channel]) instead of x — conv1's folded batch norm + relu_ of the same bottleneck applied on
+ * the way in, so that the 1x1 convolution in front needs no pass of its own over its output.
+ * vido_gconv3x3_supported: 1 when a kernel exists for the shape (8, 16 or a multiple of 32 channels per group and a row band that fits LDS); otherwise the call returns
+ * VIDO_E_INVALID and the caller keeps the library convolution. */
+int vido_gconv3x3_supported(int H, int W, int cpg_in, int cpg_out);
+int64_t vido_gconv3x3_packed_size(int groups, int cpg_in, int cpg_out);
+int vido_gconv3x3_bias_act(vido_ctx* ctx, const float* x, const float* in_bias, const float* w_packed, const float* bias, float* y, int groups, int cpg_in, int cpg_out, int H, int W, float slope);
 int vido_lfn_reg_front(vido_ctx* ctx, const float* im1, const float* im2, const float* flow, const float* mean, float scale, int B, int C, int H, int W, float* out, int out_channels);
 int vido_lfn_reg_tail(vido_ctx* ctx, const float* dist, const float* flow, const float* wx, const float* bx, const float* wy, const float* by, int B, int K, int H, int W, float* out);
 /* layers.ROIAlign forward — mask_rcnn/maskrcnn_benchmark/csrc/cuda/ROIAlign_cuda.cu:257-299.  rois [n,5] =

@@ -175,3 +175,47 @@ def test_fused_selection_kernels_equal_the_torch_forms(ctx):
             assert int(f[3]) > 30                                                  # ties at the detections_per_img cut: the reference keeps them all
         for k in range(3):
             assert torch.equal(a[k], f[k]), (trial, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cpg,H,W", [(32, 50, 68), (64, 25, 34), (16, 100, 136), (8, 200, 272), (32, 7, 9), (16, 9, 300), (8, 3, 5), (32, 1, 1), (16, 33, 61), (8, 6, 302), (16, 2, 4)])
+def test_grouped_conv_matrix_core_kernel_equals_conv2d(vido, ctx, cpg, H, W):
+    """csrc/gconv.hip against conv2d in float64: the detector's four bottleneck shapes (8 / 16 / 32 / 64 channels per group at their FPN-stage sizes) and ragged small ones
+    (tiles that run across row ends, bands cut by the image border, a single pixel)."""
+    from vido_slam_amd.nets.ops import HipOps, pack_gconv3x3
+    ops = HipOps(ctx); groups = 32 if H * W > 2000 else 3
+    g = torch.Generator().manual_seed(cpg * 1000 + H)
+    x = torch.randn(1, groups * cpg, H, W, generator=g); w = torch.randn(groups * cpg, cpg, 3, 3, generator=g) * (1.0 / (3 * cpg ** 0.5)); b = torch.randn(groups * cpg, generator=g)
+    assert ops.gconv3x3_supported(H, W, cpg, cpg)
+    wp = pack_gconv3x3(w, groups).cuda()
+    for slope in (0.0, 1.0):
+        y = ops.gconv3x3_bias_act(x.cuda(), wp, b.cuda(), groups, slope).cpu()
+        ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, 1, 1, groups), slope)
+        err = float((y.double() - ref).abs().max())
+        assert err < 2e-5 * max(1.0, float(ref.abs().max())), (cpg, H, W, slope, err)
+    ib = torch.randn(groups * cpg, generator=g)             # with the producer's bias + ReLU folded into the operand reads
+    y = ops.gconv3x3_bias_act(x.cuda(), wp, b.cuda(), groups, 0.0, in_bias=ib.cuda()).cpu()
+    ref = torch.relu(torch.nn.functional.conv2d(torch.relu(x.double() + ib.double()[None, :, None, None]), w.double(), b.double(), 1, 1, 1, groups))
+    assert float((y.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), (cpg, H, W, "in_bias")
+    # shapes outside the plan are refused, not mangled
+    assert not ops.gconv3x3_supported(50, 100, 32, 32) and not ops.gconv3x3_supported(50, 68, 12, 12)
+    with pytest.raises(vido.VidoError):
+        ops.gconv3x3_bias_act(torch.zeros(1, 64, 50, 100, device="cuda"), torch.zeros(64 * 32 * 9, device="cuda"), torch.zeros(64, device="cuda"), 2, 0.0)
+
+
+@pytest.mark.gpu
+def test_bottleneck_with_matrix_core_conv2_equals_library_path(vido, ctx):
+    """_Bottleneck.forward with conv2 on csrc/gconv.hip against the same block on the library convolution + bias pass."""
+    from vido_slam_amd.nets import maskrcnn as M
+    from vido_slam_amd.nets.fuse import fold_batchnorm
+    from vido_slam_amd.nets.ops import HipOps
+    from vido_slam_amd.nets.weights import fill_maskrcnn
+    blk = M._Bottleneck(256, 256, 256, 32, False, 1)
+    fill_maskrcnn(blk); blk = blk.cuda().eval()
+    x = torch.randn(1, 256, 40, 52, generator=torch.Generator().manual_seed(4)).cuda()
+    with torch.no_grad():
+        assert fold_batchnorm(blk, HipOps(ctx)) == 3 and blk._w2p is not None
+        y_fast = blk(x).clone()
+        blk._w2p = None
+        y_lib = blk(x)
+    assert float((y_fast - y_lib).abs().max()) < 1e-4 * max(1.0, float(y_lib.abs().max()))

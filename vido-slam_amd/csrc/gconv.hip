@@ -1,0 +1,297 @@
+// Grouped 3x3 convolution + bias + ReLU of the detector's ResNeXt bottlenecks on the fp32 matrix cores (gfx950).
+//
+// What it replaces: `conv2` of BottleneckWithFixedBatchNorm (maskrcnn_benchmark/modeling/backbone/resnet.py:300-372: Conv2d(width, width, 3, stride, 1, groups=32)
+// + FrozenBatchNorm2d + relu_) at batch 1 — 33 convolutions per frame of X-101-32x8d, 2.0 GFLOP each, which the library runs as Winograd kernels at 107 / 50 / 30 / 29 us
+// per call (8 / 16 / 32 / 64 channels per group) followed by a separate bias+ReLU pass over the output.
+//
+// Formulation.  With the input rows zero-padded to Wp = W + 2 columns and FLATTENED (q = y * Wp + x), the nine taps of output position q are the inputs at q + dy * Wp + dx:
+// constant offsets.  A tile is therefore 32 (or 16) CONSECUTIVE flattened positions — it may run across a row end; the two pad positions per row are computed and thrown
+// away (3 % at W = 68) — and one group is a GEMM  Out[co][q] = sum_k Wt[co][k] In[k][q + off(k)],  k = (input channel, tap):
+//   * channels per group >= 32: v_mfma_f32_32x32x2 (A = 32 output channels x 2 input channels of one tap, B = the same 2 channels x 32 positions),
+//   * 16 or 8 channels per group: v_mfma_f32_16x16x4 (8: the upper 8 rows of A are zero).
+// A workgroup stages a band of input rows of 8 input channels at a time in LDS (each element is read by 9 taps x all output channels of the group from there) together with
+// that chunk's weights in operand order; B operands are plain ds_read_b32 of consecutive addresses, A operands one ds_read_b32 at lane * 4.  The accumulators start at the
+// folded batch-norm bias and leave through the ReLU: no epilogue pass over the output.
+#include "common.hpp"
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GcArgs { const float* x; const float* w; const float* bias; const float* in_bias; float* y; int H, W, cpg_in, cpg_out, R, PS; float slope; int gx, total; };
+
+// Workgroup -> work item.  The hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2; neighbouring position chunks of a group share
+// two halo rows and the group's weights, so the 1-D grid (8 * ceil(total / 8) workgroups) is folded such that every XCD walks a CONTIGUOUS range of (group, chunk) items:
+// with the plain (chunk, group) grid each band of rows was fetched from HBM by two XCDs and the weights of a group by all eight.
+__device__ __forceinline__ int gc_item(int total) { const int per = gridDim.x >> 3, L = (blockIdx.x & 7) * per + (blockIdx.x >> 3); return L < total ? L : -1; }
+
+#define GC_KC 8          // input channels per K chunk
+#define GC32_PS 512      // floats per input-channel plane in LDS (k_gconv3x3_m32)
+
+// ---- >= 32 channels per group.  Workgroup = 4 waves = 8 tiles of 32 positions (2 per wave) x 32 output channels; work items = (position chunk, output-channel block, group), see gc_item.
+// Weights packed [group][co block][chunk][tap][8 ci][32 co].  The next chunk's input rows and weights are requested into registers before the matrix phase of the current one.
+__global__ __launch_bounds__(256) void k_gconv3x3_m32(GcArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float gc_lds[];
+    float* Wl = gc_lds;                         // [9][8][32]
+    float* In = gc_lds + 9 * GC_KC * 32;        // [8][GC32_PS]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int H = A.H, W = A.W, Wpd = W + 2, npos = H * Wpd, RW = A.R * Wpd;
+    const int nchunk = A.cpg_in / GC_KC, ncob = A.cpg_out / 32;
+    const int item = gc_item(A.total); if (item < 0) return;
+    const int chunk = item % A.gx, cob = (item / A.gx) % ncob, g = item / (A.gx * ncob), q0 = chunk * 256, r0 = q0 / Wpd;
+    const size_t HW = (size_t)H * W;
+    const float* xg = A.x + (size_t)g * A.cpg_in * HW;
+    const float* wg = A.w + ((size_t)(g * ncob + cob) * nchunk) * (9 * GC_KC * 32);
+    int poff[8];                                // this lane's 8 elements of a channel plane of the band (offset inside the channel image, -1: zero padding)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int p = lane + 64 * j, rr = p / Wpd, xp = p - rr * Wpd, row = r0 - 1 + rr;
+        poff[j] = (p < RW && row >= 0 && row < H && xp >= 1 && xp <= W) ? row * W + xp - 1 : -1;
+    }
+    float pin0[8], pin1[8], pw[9], pib0 = 0.f, pib1 = 0.f;
+#define GC32_PREFETCH(c) { \
+        if (A.in_bias) { pib0 = A.in_bias[(size_t)g * A.cpg_in + (c) * GC_KC + 2 * wv]; pib1 = A.in_bias[(size_t)g * A.cpg_in + (c) * GC_KC + 2 * wv + 1]; } \
+        const float* xc0 = xg + (size_t)((c) * GC_KC + 2 * wv) * HW; const float* xc1 = xc0 + HW; \
+        _Pragma("unroll") for (int j = 0; j < 8; j++) { pin0[j] = poff[j] >= 0 ? xc0[poff[j]] : 0.f; pin1[j] = poff[j] >= 0 ? xc1[poff[j]] : 0.f; } \
+        const float* wc = wg + (size_t)(c) * (9 * GC_KC * 32); \
+        _Pragma("unroll") for (int i = 0; i < 9; i++) pw[i] = wc[tid + 256 * i]; }
+    const int co_base = g * A.cpg_out + cob * 32;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const float b = A.bias[co_base + 8 * (r / 4) + 4 * (lane >> 5) + (r & 3)]; acc0[r] = b; acc1[r] = b; }
+    const int bbase = (lane >> 5) * GC32_PS + (q0 + 64 * wv - r0 * Wpd) + (lane & 31);      // B operand of tile 2 wv (tile 2 wv + 1: + 32), tap (0, 0), channel pair 0
+    GC32_PREFETCH(0)
+    for (int c = 0; c < nchunk; c++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float v0 = pin0[j], v1 = pin1[j];
+            if (A.in_bias) { v0 = poff[j] >= 0 ? fmaxf(v0 + pib0, 0.f) : 0.f; v1 = poff[j] >= 0 ? fmaxf(v1 + pib1, 0.f) : 0.f; }      // the 1x1 convolution's bias + ReLU, applied on the way in
+            In[(2 * wv) * GC32_PS + lane + 64 * j] = v0; In[(2 * wv + 1) * GC32_PS + lane + 64 * j] = v1;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) Wl[tid + 256 * i] = pw[i];
+        __syncthreads();
+        if (c + 1 < nchunk) GC32_PREFETCH(c + 1)
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int toff = (tap / 3) * Wpd + (tap % 3);
+#pragma unroll
+            for (int kp = 0; kp < 4; kp++) {
+                const float a = Wl[(tap * 8 + 2 * kp) * 32 + lane];
+                const float b0 = In[bbase + 2 * kp * GC32_PS + toff], b1 = In[bbase + 32 + 2 * kp * GC32_PS + toff];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#undef GC32_PREFETCH
+    // D[i][j]: lane = 32 * ((i / 4) & 1) + j, register = 4 * (i / 8) + (i & 3)  ->  a register holds one output channel of 32 consecutive positions per half wave
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int q = q0 + 64 * wv + 32 * t + (lane & 31), yy = q / Wpd, xx = q - yy * Wpd;
+        if (q < npos && xx < W) {
+            float* yo = A.y + (size_t)co_base * HW + (size_t)yy * W + xx;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = 8 * (r / 4) + 4 * (lane >> 5) + (r & 3);
+                float v = t ? acc1[r] : acc0[r]; v = v > 0.f ? v : v * A.slope;
+                yo[(size_t)co * HW] = v;
+            }
+        }
+    }
+}
+
+// asynchronous global -> LDS copy of one dword per lane: the LDS address is the wave-uniform `l` + lane * 4, lanes switched off by the caller's branch write nothing
+__device__ __forceinline__ void glds4(const float* g, float* l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
+
+__device__ __forceinline__ void glds16(const float* g, float* l)      // four dwords per lane: LDS address = l + lane * 16 (both sides 16-byte aligned)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// ---- 16 (or 8) channels per group.  Workgroup = 4 waves x NTW tiles of 16 positions x 16 output channels; work items = (position chunk, group).  Weights packed
+// [group][chunk][tap][8 ci][16 co] (co >= cpg_out: zeros).  The band goes global -> LDS with the asynchronous copy: no staging registers, every copy of a chunk in flight
+// at once (the first version copied through registers in a loop the compiler could not batch and spent 100 of its 155 us waiting on one load at a time).  A copy
+// instruction costs the same ~60 issue cycles whatever it moves, so when W is a multiple of 4 the rows are laid out with FOUR pad positions on the left (row pitch W + 4:
+// the four pads double as the right pad of the row above) and move as 16-byte pieces — 1 KiB per instruction instead of 256 B (V4).  The padding is written once per
+// workgroup: the copies only touch positions inside the image.  With an input bias (IB) the operand is max(x + in_bias[ci], 0) — the bias + ReLU pass of the 1x1
+// convolution in front, applied where the value is read — and the padding holds -3e38, which that expression turns into the zero the convolution pads with.
+// Several workgroups share a CU (<= 67 KB of LDS each), one copies while another multiplies.
+template <int NTW, bool IB, bool V4>
+__global__ __launch_bounds__(256) void k_gconv3x3_m16(GcArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float gc_lds[];
+    float* Wl = gc_lds;                         // [9][8][16]
+    float* In = gc_lds + 9 * GC_KC * 16;        // [8][PS]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int L = V4 ? 4 : 1;
+    const int H = A.H, W = A.W, Wpd = V4 ? W + 4 : W + 2, npos = H * Wpd, PS = A.PS, R = A.R;
+    constexpr int P = NTW * 64;
+    const int item = gc_item(A.total); if (item < 0) return;
+    const int g = item / A.gx, q0 = (item - g * A.gx) * P, r0 = q0 / Wpd;
+    const int nchunk = A.cpg_in / GC_KC;
+    const size_t HW = (size_t)H * W;
+    const float* xg = A.x + (size_t)g * A.cpg_in * HW;
+    const float* wg = A.w + (size_t)g * nchunk * (9 * GC_KC * 16);
+    const int co_base = g * A.cpg_out;
+    f32x4 acc[NTW];
+    {
+        float b4[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int co = 4 * (lane >> 4) + r; b4[r] = co < A.cpg_out ? A.bias[co_base + co] : 0.f; }
+#pragma unroll
+        for (int t = 0; t < NTW; t++) { acc[t][0] = b4[0]; acc[t][1] = b4[1]; acc[t][2] = b4[2]; acc[t][3] = b4[3]; }
+    }
+    const int bbase = (lane >> 4) * PS + (q0 + 16 * NTW * wv - r0 * Wpd) + (lane & 15) + (L - 1);
+    {   // padding: the pad columns of every row of the band, whole rows outside the image, the pad after the last row
+        const float padv = IB ? -3.0e38f : 0.f;
+        for (int s2 = wv; s2 < GC_KC * R; s2 += 4) {
+            const int ci = s2 / R, rr = s2 - ci * R, row = r0 - 1 + rr; float* dst = In + ci * PS + rr * Wpd;
+            if (row < 0 || row >= H) { for (int xp = lane; xp < Wpd; xp += 64) dst[xp] = padv; }
+            else if (lane < L) dst[lane] = padv;
+            else if (lane < Wpd - W) dst[W + lane] = padv;
+        }
+        if (tid < GC_KC * 4) In[(tid >> 2) * PS + R * Wpd + (tid & 3)] = padv;
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunk; c++) {
+#pragma unroll
+        for (int ci = 0; ci < GC_KC; ci++) {
+            const float* xc = xg + (size_t)(c * GC_KC + ci) * HW;
+            for (int rr = wv; rr < R; rr += 4) {
+                const int row = r0 - 1 + rr;
+                if (row < 0 || row >= H) continue;
+                const float* xr = xc + (size_t)row * W; float* dst = In + ci * PS + rr * Wpd + L;
+                if (V4) { for (int x0 = 0; x0 < W; x0 += 256) { const int x = x0 + 4 * lane; if (x < W) glds16(xr + x, dst + x0); } }
+                else { for (int x0 = 0; x0 < W; x0 += 64) { const int x = x0 + lane; if (x < W) glds4(xr + x, dst + x0); } }
+            }
+        }
+        { const float* wc = wg + (size_t)c * (9 * GC_KC * 16); for (int i0 = wv * 64; i0 < 9 * GC_KC * 16; i0 += 256) glds4(wc + i0 + lane, Wl + i0); }
+        float ib0 = 0.f, ib1 = 0.f;
+        if (IB) { const float* ibp = A.in_bias + (size_t)g * A.cpg_in + c * GC_KC + (lane >> 4); ib0 = ibp[0]; ib1 = ibp[4]; }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int toff = (tap / 3) * Wpd + (tap % 3);
+#pragma unroll
+            for (int k4 = 0; k4 < 2; k4++) {
+                const float a = Wl[(tap * 8 + 4 * k4) * 16 + lane];
+                const float* bp = In + bbase + 4 * k4 * PS + toff;
+#pragma unroll
+                for (int t = 0; t < NTW; t++) {
+                    float bv = bp[16 * t];
+                    if (IB) bv = fmaxf(bv + (k4 ? ib1 : ib0), 0.f);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // D[i][j]: lane = 16 * (i / 4) + j, register = i & 3
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        const int q = q0 + 16 * (NTW * wv + t) + (lane & 15), yy = q / Wpd, xx = q - yy * Wpd;
+        if (q < npos && xx < W) {
+            float* yo = A.y + (size_t)co_base * HW + (size_t)yy * W + xx;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int co = 4 * (lane >> 4) + r;
+                float v = acc[t][r]; v = v > 0.f ? v : v * A.slope;
+                if (co < A.cpg_out) yo[(size_t)co * HW] = v;
+            }
+        }
+    }
+}
+
+// geometry of a call: which kernel, rows of the band, plane pitch, LDS bytes; 0 = not supported
+struct GcPlan { int kind; int R, PS; size_t lds; int gx; bool v4; };
+static GcPlan gc_plan(int H, int W, int cpg_in, int cpg_out, bool aligned16 = true)
+{
+    GcPlan p{};
+    if (H < 1 || W < 1 || cpg_in < GC_KC || cpg_in % GC_KC) return p;
+    if (cpg_out % 32 == 0) {
+        const int Wpd = W + 2; const long npos = (long)H * Wpd;
+        const int R = 4 + 254 / Wpd;
+        if (R * Wpd > GC32_PS || 3 * Wpd + 257 > GC32_PS) return p;
+        p.kind = 32; p.R = R; p.PS = GC32_PS; p.lds = (size_t)(9 * GC_KC * 32 + GC_KC * GC32_PS) * 4; p.gx = (int)((npos + 255) / 256);
+        return p;
+    }
+    if (cpg_out != 16 && cpg_out != 8) return p;
+    const bool v4 = W % 4 == 0 && aligned16; const int L = v4 ? 4 : 1, Wpd = v4 ? W + 4 : W + 2; const long npos = (long)H * Wpd;
+    for (int ntw : {8, 16}) {                                   // 512 positions per workgroup when the band then covers >= 3 output rows of 7, else 1024
+        const int P = ntw * 64, R = 4 + (P - 2) / Wpd;
+        int PS = std::max(R * Wpd + 4, 3 * Wpd + P + 2 + L) + 16; PS = ((PS + 31) & ~31) + 16;      // = 16 (mod 32): the four 16-float runs of a B operand fall in distinct banks
+        const size_t lds = (size_t)(9 * GC_KC * 16 + GC_KC * PS) * 4;
+        if (lds > 78 * 1024) continue;                                                      // two workgroups per CU
+        if (ntw == 8 && P < 3 * Wpd && npos > 4 * 1024) continue;                           // wide rows: the halo would triple the reads
+        p.kind = ntw; p.R = R; p.PS = PS; p.lds = lds; p.gx = (int)((npos + P - 1) / P); p.v4 = v4;
+        return p;
+    }
+    return p;
+}
+template <int NTW> static int gc_m16_limits(vido_ctx* ctx)
+{
+    for (const void* f : {(const void*)k_gconv3x3_m16<NTW, false, false>, (const void*)k_gconv3x3_m16<NTW, false, true>, (const void*)k_gconv3x3_m16<NTW, true, false>, (const void*)k_gconv3x3_m16<NTW, true, true>})
+        HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    return VIDO_OK;
+}
+static int gc_lds_limit(vido_ctx* ctx)
+{
+    static bool done = false;
+    if (done) return VIDO_OK;
+    { int rc = gc_m16_limits<8>(ctx); if (rc) return rc; }
+    { int rc = gc_m16_limits<16>(ctx); if (rc) return rc; }
+    done = true;
+    return VIDO_OK;
+}
+template <int NTW> static void gc_m16_launch(const GcPlan& p, int groups, hipStream_t st, const GcArgs& A)
+{
+    const dim3 grid(8 * ((A.total + 7) / 8)), blk(256);
+    if (A.in_bias) { if (p.v4) hipLaunchKernelGGL((k_gconv3x3_m16<NTW, true, true>), grid, blk, p.lds, st, A); else hipLaunchKernelGGL((k_gconv3x3_m16<NTW, true, false>), grid, blk, p.lds, st, A); }
+    else { if (p.v4) hipLaunchKernelGGL((k_gconv3x3_m16<NTW, false, true>), grid, blk, p.lds, st, A); else hipLaunchKernelGGL((k_gconv3x3_m16<NTW, false, false>), grid, blk, p.lds, st, A); }
+}
+}  // namespace
+
+extern "C" {
+
+/* 1 when vido_gconv3x3_bias_act has a kernel for this shape (channels per group 8, 16 or a multiple of 32; the row band must fit the LDS plan). */
+int vido_gconv3x3_supported(int H, int W, int cpg_in, int cpg_out)
+{
+    return gc_plan(H, W, cpg_in, cpg_out).kind != 0;
+}
+
+/* Floats of the packed weight tensor (per group: output channels padded to the matrix-core tile). */
+int64_t vido_gconv3x3_packed_size(int groups, int cpg_in, int cpg_out)
+{
+    const int co_pad = cpg_out % 32 == 0 ? cpg_out : 16;
+    return (int64_t)groups * co_pad * cpg_in * 9;
+}
+
+/* y = leaky_relu(conv2d(x', w, stride 1, padding 1, groups) + bias, slope) for one image, x' = x, or relu(x + in_bias[channel]) when in_bias is given (the epilogue of the
+ * convolution that produced x, folded into this one's operand reads): x [groups * cpg_in][H][W], y [groups * cpg_out][H][W] f32 DEVICE tensors (x != y),
+ * bias [groups * cpg_out], w_packed: the convolution weight [groups * cpg_out][cpg_in][3][3] rearranged per (group, 32-channel output block, 8-channel input chunk) as
+ * [tap][ci][co] (16 / 8 channels per group: [group][chunk][tap][ci][16 co], missing output channels zero) — vido_slam_amd/nets/ops.py::pack_gconv3x3 builds it once per
+ * layer.  slope 0 = ReLU, 1 = none.  Enqueues on the adopted stream; capturable. */
+int vido_gconv3x3_bias_act(vido_ctx* ctx, const float* x, const float* in_bias, const float* w_packed, const float* bias, float* y, int groups, int cpg_in, int cpg_out, int H, int W, float slope)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!x || !w_packed || !bias || !y || x == y || groups < 1 || groups > 65535) return vido_set_error(ctx, VIDO_E_INVALID, "gconv3x3: bad arguments");
+    const GcPlan p = gc_plan(H, W, cpg_in, cpg_out, ((uintptr_t)x & 15) == 0);      // (the 16-byte copies need an aligned image; torch allocations are)
+    if (!p.kind) return vido_set_error(ctx, VIDO_E_INVALID, "gconv3x3: no kernel for %d -> %d channels per group at %d x %d", cpg_in, cpg_out, H, W);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc = gc_lds_limit(ctx); if (rc) return rc; }
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    GcArgs A{x, w_packed, bias, in_bias, y, H, W, cpg_in, cpg_out, p.R, p.PS, slope, p.gx, p.gx * groups * (p.kind == 32 ? cpg_out / 32 : 1)};
+    if (p.kind == 32) hipLaunchKernelGGL(k_gconv3x3_m32, dim3(8 * ((A.total + 7) / 8)), dim3(256), p.lds, st, A);
+    else if (p.kind == 8) gc_m16_launch<8>(p, groups, st, A);
+    else gc_m16_launch<16>(p, groups, st, A);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+}  // extern "C"

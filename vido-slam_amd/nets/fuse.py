@@ -9,6 +9,7 @@
 * Graphed: a static-shape forward captured once into a hipGraph (torch.cuda.CUDAGraph) and replayed per frame: one launch per network
   instead of several hundred (the nodes run at batch 1, where the host launch rate — not the GPU — paces the small layers).
 """
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -40,6 +41,11 @@ def fold_batchnorm(net, ops):
             if m.downsample is not None:
                 m._wd, m._bd = _fold(m.downsample[0], m.downsample[1], _eps(m.downsample[1])); n += 1
             m._ep = ops.bias_res_act_
+            # the grouped 3x3 convolution + its bias + ReLU as one matrix-core kernel (csrc/gconv.hip) where it has a form for the layer
+            c2 = m.conv2; m._w2p = None; m._ops = ops
+            if c2.groups > 1 and tuple(c2.stride) == (1, 1) and tuple(c2.padding) == (1, 1) and tuple(c2.dilation) == (1, 1) and not os.environ.get("VIDO_NO_GCONV"):
+                from .ops import pack_gconv3x3
+                m._w2p = pack_gconv3x3(m._w2, c2.groups)
         elif isinstance(m, _Stem):
             m._w1, m._b1 = _fold(m.conv1, m.bn1, _eps(m.bn1)); m._ep = ops.bias_res_act_; n += 1
         elif isinstance(m, _Basic):

@@ -72,12 +72,17 @@ class _Bottleneck(nn.Module):              # resnet.py:277-372 (BottleneckWithFi
         self.conv3 = nn.Conv2d(mid, cout, 1, bias=False); self.bn3 = FrozenBatchNorm2d(cout)
 
     _ep = None                             # nets/fuse.py::fold_batchnorm installs the folded tensors + the fused HIP epilogue
+    _w2p = None                            # ... and conv2's weight in the operand order of csrc/gconv.hip where that kernel takes the layer
 
     def forward(self, x):
         if self._ep is not None and x.is_cuda:
             ep = self._ep; c1, c2 = self.conv1, self.conv2
-            y = ep(F.conv2d(x, self._w1, None, c1.stride), self._b1, None, 0.0)
-            y = ep(F.conv2d(y, self._w2, None, c2.stride, c2.padding, c2.dilation, c2.groups), self._b2, None, 0.0)
+            y = F.conv2d(x, self._w1, None, c1.stride)
+            if self._w2p is not None and y.shape[0] == 1 and self._ops.gconv3x3_supported(y.shape[2], y.shape[3], c2.in_channels // c2.groups, c2.out_channels // c2.groups):
+                # conv1's bias + ReLU ride on conv2's operand reads, conv2's own leave through its accumulators: two passes over the activations less per block
+                y = self._ops.gconv3x3_bias_act(y, self._w2p, self._b2, c2.groups, 0.0, in_bias=self._b1)
+            else:
+                y = ep(F.conv2d(ep(y, self._b1, None, 0.0), self._w2, None, c2.stride, c2.padding, c2.dilation, c2.groups), self._b2, None, 0.0)
             sc = x if self.downsample is None else ep(F.conv2d(x, self._wd, None, self.downsample[0].stride), self._bd, None, 1.0)
             return ep(F.conv2d(y, self._w3), self._b3, sc.contiguous(), 0.0)
         y = F.relu(self.bn1(self.conv1(x)))

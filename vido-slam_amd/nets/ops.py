@@ -80,6 +80,22 @@ class HipOps:
         self.ctx._check(self.ctx.lib.vido_deconv4s2_depthwise(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(weight.data_ptr()), B, Cc, H, W, C.c_float(input_slope), C.c_void_p(out.data_ptr())))
         return out
 
+    def gconv3x3_supported(self, H, W, cpg_in, cpg_out):
+        return bool(self.ctx.lib.vido_gconv3x3_supported(int(H), int(W), int(cpg_in), int(cpg_out)))
+
+    def gconv3x3_bias_act(self, x, w_packed, bias, groups, slope=0.0, in_bias=None):
+        """leaky_relu(conv2d(x', w, None, 1, 1, 1, groups) + bias, slope) for one image as one matrix-core launch; w_packed = pack_gconv3x3(w, groups);
+        x' = x, or relu(x + in_bias[None, :, None, None]) when in_bias is given."""
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and x.shape[0] == 1
+        _, Cin, H, W = x.shape
+        cpg_in = Cin // groups; cpg_out = bias.numel() // groups
+        out = torch.empty((1, bias.numel(), H, W), device=x.device, dtype=torch.float32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_gconv3x3_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(in_bias.data_ptr()) if in_bias is not None else None,
+                                                            C.c_void_p(w_packed.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                            int(groups), cpg_in, cpg_out, H, W, C.c_float(slope)))
+        return out
+
     def lfn_reg_front(self, im1, im2, flow, scale, feat):
         """Regularization.forward up to netMain's input (layers.py:236-243): torch.cat([sqrt(sum((im1 - Backward(im2, flow * scale))^2)), flow - mean(flow), feat], 1) with the
         first three channels from one HIP pass."""
@@ -272,3 +288,17 @@ class HipOps:
                                                            C.c_void_p(labels.data_ptr()) if n else None, n, masks.shape[-1] if n else 28, padding, C.c_float(thresh), H, W,
                                                            C.c_void_p(out.data_ptr())))
         return out
+
+
+def pack_gconv3x3(w, groups):
+    """Convolution weight [groups * cpg_out, cpg_in, 3, 3] -> the operand order of csrc/gconv.hip: per (group, 32-channel output block, 8-channel input chunk) [tap][ci][co];
+    with 16 or 8 output channels per group: [group][chunk][tap][ci][16 co] (missing output channels zero).  None when the kernels do not take the shape."""
+    cout, cpg_in = int(w.shape[0]), int(w.shape[1])
+    cpg_out = cout // groups
+    if tuple(w.shape[2:]) != (3, 3) or cpg_in % 8 or not (cpg_out % 32 == 0 or cpg_out in (8, 16)):
+        return None
+    w9 = w.detach().reshape(groups, cpg_out, cpg_in // 8, 8, 9)
+    if cpg_out % 32 == 0:
+        return w9.reshape(groups, cpg_out // 32, 32, cpg_in // 8, 8, 9).permute(0, 1, 3, 5, 4, 2).contiguous()
+    pad = w9.new_zeros((groups, 16, cpg_in // 8, 8, 9)); pad[:, :cpg_out] = w9
+    return pad.permute(0, 2, 4, 3, 1).contiguous()
