@@ -26,6 +26,7 @@ Extra objects on the same JSON line:
                  measured on BASELINE configs[1] batched (64 frames in flight, the only regime where an HBM roofline of a <1 MB/frame stage means anything)
   roofline_ba    k_ba_linearize at configs[3] (local window) and configs[4] (1 M edges) size: 288 B per edge
   roofline_nets  fp32 FLOP/s of each network node vs the 157.3 TFLOP/s fp32 matrix/vector peak
+  roofline_gconv the detector's grouped 3x3 convolution kernel (csrc/gconv.hip) vs the same peak
   cpu_baseline   the same chain on the host cores: the three nets on torch-CPU + the CPU oracle for ORB / lists / pose optimisers / local BA
   extra          configs[1] batched throughput, per-frame optimisers, Hamming matcher, local / global / dynamic BA, sharded global BA with --gpus N
 """
@@ -194,9 +195,10 @@ def main():
             return a.elapsed_time(b) / reps
         from torch.utils.flop_counter import FlopCounterMode
         def flops(fn):
+            nodes.ops.gconv_flops = 0.0                                   # convolutions run by csrc/gconv.hip are not torch ops: counted by the wrapper
             with FlopCounterMode(display=False) as fc:
                 fn()
-            return float(fc.get_total_flops())
+            return float(fc.get_total_flops()) + float(getattr(nodes.ops, "gconv_flops", 0.0))
         legs = {"liteflownet": (lambda: (nodes.g_flow or nodes._flow_fn)(ex0, ex), lambda: nodes._flow_fn(ex0, ex)),
                 "monodepth2": (lambda: (nodes.g_depth or nodes._depth_fn)(ex), lambda: nodes._depth_fn(ex)),
                 "maskrcnn_x101_fpn": ((lambda: nodes.g_det(ex)) if nodes.g_det is not None else
@@ -333,6 +335,30 @@ def main():
                   runh()
               d = (time.perf_counter() - t1) / reps
               extra["hamming_%dx%d" % (na, nb)] = {"ms_per_call": round(d * 1e3, 4), "pairs_per_s": round(na * nb / d, 0), "descriptor_GB_per_s": round(32.0 * (na + nb) / d / 1e9, 2)}
+          # the detector's grouped 3x3 convolution on the matrix cores (csrc/gconv.hip): the hand-written kernel with the most GPU time per frame in the headline
+          # (22 launches of the 32-channels-per-group shape); fp32 FLOPs of the convolution / HIP-event time on the stream it is launched on
+          try:
+              from vido_slam_amd.nets.ops import HipOps, pack_gconv3x3
+              gops = HipOps(ctx); rg = {}
+              for cpg, gh, gw, per_frame in ((32, 50, 68, 22), (16, 100, 136, 3), (8, 200, 272, 3), (64, 25, 34, 2)):
+                  gx = torch.randn(1, 32 * cpg, gh, gw, device="cuda"); gwt = torch.randn(32 * cpg, cpg, 3, 3, device="cuda") * 0.05; gb = torch.randn(32 * cpg, device="cuda")
+                  gp = pack_gconv3x3(gwt, 32)
+                  for _ in range(5):
+                      gops.gconv3x3_bias_act(gx, gp, gb, 32, 0.0, in_bias=gb)
+                  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); reps = 100
+                  e0.record()
+                  for _ in range(reps):
+                      gops.gconv3x3_bias_act(gx, gp, gb, 32, 0.0, in_bias=gb)
+                  e1.record(); torch.cuda.synchronize()
+                  us = e0.elapsed_time(e1) * 1e3 / reps; fl = 2.0 * 32 * cpg * cpg * 9 * gh * gw
+                  rg["%d_channels_per_group_%dx%d" % (cpg, gh, gw)] = {"us_per_launch": round(us, 2), "achieved": round(fl / us / 1e6, 2), "launches_per_frame": per_frame}
+              main = rg["32_channels_per_group_50x68"]
+              out["roofline_gconv"] = {"kernel": "k_gconv3x3_m32 (grouped 3x3 convolution + both folded batch norms + ReLUs, fp32 matrix cores)", "bound": "mfma", "achieved": main["achieved"],
+                                       "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(main["achieved"] / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                                       "flops_per_launch": 2.0 * 1024 * 32 * 9 * 50 * 68, "shapes": rg,
+                                       "note": "algorithmic FLOPs of the convolution (pad positions and the zero half of the 8-channel form not counted) / HIP-event time of 100 back-to-back launches"}
+          except Exception as e:
+              out["roofline_gconv_error"] = "%s: %s" % (type(e).__name__, e)
           # configs[3] (static graph): 20 KF x 2k landmarks
           pr = P.synth_ba_problem(n_cam=20, n_pt=2000, kind="local", seed=7)
           V.ba_optimize(ctx, pr)

@@ -106,7 +106,8 @@ def test_static_detector_head_equals_the_dynamic_one(vido):
     for k in range(2):
         bgr = torch.as_tensor(synth.gray_to_bgr(scene.frame(k)[0]), device="cuda")
         with torch.no_grad():
-            feats, logits, deltas = nodes.g_trunk(bgr)
+            feats, logits, deltas = [[t.clone() for t in ts] for ts in nodes.g_trunk(bgr)]      # (copies: analyse_image below replays the trunk graph into the same static tensors,
+            #                                                                                     and the library GEMMs are not bit-reproducible from replay to replay)
             dyn = net.heads(feats, logits, deltas, nodes.mask_feed)
             sta = net.heads_static(feats, logits, deltas, nodes.mask_feed)
             n = int(sta["n_det"])

@@ -7,10 +7,10 @@ import csv, glob, json, os, shutil, sys
 out = sys.argv[1]
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "profiles_r3")
 os.makedirs(dst, exist_ok=True)
-for tag, name in (("e2e", "e2e_kernel_stats.csv"), ("fe", "frontend_kernel_stats.csv")):
+for tag, name in (("e2e", "e2e_kernel_stats.csv"), ("fe", "frontend_kernel_stats.csv"), ("gc", "gconv_kernel_stats.csv")):
     for f in glob.glob(os.path.join(out, tag, "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(dst, name))
-for f in ("bench_under_rocprof.json", "fast_sq_counters.txt", "bench_e2e.json", "bench_e2e_200.json", "pytest_gpu.txt", "nets_mfma.json", "det_timeline_summary.txt", "nets_timeline_summary.txt"):
+for f in ("bench_under_rocprof.json", "fast_sq_counters.txt", "bench_e2e.json", "bench_e2e_200.json", "pytest_gpu.txt", "nets_mfma.json", "det_timeline_summary.txt", "nets_timeline_summary.txt", "gconv_microbench.txt"):
     if os.path.exists(os.path.join(out, f)):
         shutil.copy(os.path.join(out, f), os.path.join(dst, f))
 

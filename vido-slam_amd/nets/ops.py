@@ -90,6 +90,7 @@ class HipOps:
         _, Cin, H, W = x.shape
         cpg_in = Cin // groups; cpg_out = bias.numel() // groups
         out = torch.empty((1, bias.numel(), H, W), device=x.device, dtype=torch.float32)
+        self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * bias.numel() * cpg_in * 9 * H * W      # (torch's FlopCounterMode does not see this launch; bench.py adds it)
         self._adopt_stream()
         self.ctx._check(self.ctx.lib.vido_gconv3x3_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(in_bias.data_ptr()) if in_bias is not None else None,
                                                             C.c_void_p(w_packed.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()),
