@@ -257,3 +257,33 @@ def test_library_side_rccl_allreduce_world_1(vido):
         assert rel(got["cam_T"], plain["cam_T"]) < 1e-9 and rel(got["pt_xyz"], plain["pt_xyz"]) < 1e-9
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("share", [0.002, 0.10])
+def test_revisited_landmarks_leave_the_camera_window(vido, oracle, ctx, share, capfd, monkeypatch):
+    """A map with revisits (loop closures): `share` of the landmarks get two extra observations from cameras 60-70 frames after their track — outside the 16-camera
+    window of the matrix-core Schur kernel.  0.2 %: those landmarks go to k_ba_schur_long; 10 %: the wave-per-landmark kernel takes the whole graph (csrc/ba.hip, the 3 % rule).
+    Either way the solve equals the oracle's (same LM iteration and trial counts, poses / landmarks to the suite's tolerance)."""
+    pr = vido.problems.synth_ba_problem(n_cam=100, n_pt=4000, kind="global", track_len=10, seed=41)
+    rng = np.random.RandomState(5); n_pt = pr["n_pt"]
+    last = np.zeros(n_pt, np.int64); np.maximum.at(last, pr["obs_pt"], pr["obs_cam"])
+    cand = np.nonzero(last + 72 < pr["n_cam"])[0]; pick = rng.choice(cand, int(share * n_pt), replace=False)
+    cams = np.stack([np.vstack([c, [0, 0, 0, 1]]) for c in pr["cam_true"]])
+    oc, op, om = [pr["obs_cam"]], [pr["obs_pt"]], [pr["obs_meas"]]
+    for l in pick:
+        for gap in (60, 70):
+            c = int(last[l]) + gap; inv = np.linalg.inv(cams[c]); Xc = inv[:3, :3] @ pr["pt_true"][l] + inv[:3, 3]
+            oc.append(np.array([c], np.int32)); op.append(np.array([l], np.int32)); om.append((Xc + rng.normal(0, 0.02, 3))[None])
+    pr["obs_cam"] = np.concatenate(oc).astype(np.int32); pr["obs_pt"] = np.concatenate(op).astype(np.int32); pr["obs_meas"] = np.concatenate(om)
+    pr["max_iters"] = 6
+    monkeypatch.setenv("VIDO_BA_VERBOSE", "1")
+    ref = oracle.ba_optimize(dict(pr))
+    got = vido.ba_optimize(ctx, dict(pr))
+    err = capfd.readouterr().err
+    import re
+    m = re.search(r"outside their chunk's camera window: (\d+) of (\d+) \(([0-9.]+) %\)", err)
+    assert m and int(m.group(1)) >= len(pick) and (float(m.group(3)) > 3.0) == (share > 0.05)      # (a few ordinary tracks straddle a window edge as well: ~2 % here)
+    assert got["iterations"] == ref["iterations"] and got["lm_trials"] == ref["lm_trials"]
+    assert rel(got["cam_T"], ref["cam_T"]) < RTOL and rel(got["pt_xyz"], ref["pt_xyz"]) < RTOL
+    assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-6 * ref["chi2_final"]

@@ -2571,13 +2571,20 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         { std::vector<int> bc(2 * (size_t)n_ptl); for (int q = 0; q < n_ptl; q++) { const int l = lorder[q]; bc[2 * (size_t)q] = pstart[l]; bc[2 * (size_t)q + 1] = pstart[l + 1] - pstart[l]; }
           if (use_mfma_schur) {      // k_ba_schur_mfma takes the landmarks whose cameras all fall inside their chunk's window; the others (and tracks > 64) go to k_ba_schur_long
               std::vector<char> is_long(n_ptl, 0); for (int l : long_list) is_long[l] = 1;
+              std::vector<int> outside;                                  // positions q whose landmark leaves its chunk's window (loop closures, revisits, long gaps)
               for (int q = 0; q < n_ptl; q++) {
                   const int l = lorder[q], cnt = pstart[l + 1] - pstart[l]; if (!cnt) continue;
                   const int cb = cmin[q / BA_CHUNK], lo = pose_ord_h[slotcam[pstart[l]]], hi = pose_ord_h[slotcam[pstart[l + 1] - 1]];
                   bool out = cnt > 64 || lo < cb || hi >= cb + BA_WC || lo < 0 || hi < 0;
                   for (int t2 = pstart[l]; t2 < pstart[l + 1] && !out; t2++) { const int o = pose_ord_h[slotcam[t2]]; out = o < cb || o >= cb + BA_WC; }
-                  if (out) { bc[2 * (size_t)q + 1] = -cnt; if (!is_long[l]) { long_list.push_back(l); is_long[l] = 1; } }
+                  if (out) outside.push_back(q);
               }
+              // k_ba_schur_long is one workgroup and O(36 k^2) HBM atomics per landmark: right for the rare track of > 64 keyframes, a cliff when a map with many revisits
+              // sends a sizeable share of its landmarks there.  Above 3 % the wave-per-landmark kernel takes the whole graph instead (it spills out-of-window pairs itself).
+              const size_t n_out_short = outside.size() - std::min(outside.size(), long_list.size());
+              if (getenv("VIDO_BA_VERBOSE")) fprintf(stderr, "[ba] landmarks outside their chunk's camera window: %zu of %d (%.2f %%), tracks > 64: %zu\n", outside.size(), n_ptl, 100.0 * outside.size() / std::max(n_ptl, 1), long_list.size());
+              if (n_out_short * 100 > (size_t)n_ptl * 3) use_mfma_schur = false;
+              else for (int q : outside) { const int l = lorder[q]; bc[2 * (size_t)q + 1] = -(pstart[l + 1] - pstart[l]); if (!is_long[l]) { long_list.push_back(l); is_long[l] = 1; } }
           }
           d_lbc = (int2*)A.put(bc.data(), 2 * (size_t)n_ptl, st); }
         if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device pool exhausted");

@@ -66,34 +66,51 @@ __global__ __launch_bounds__(1024) void k_bawin_assemble(BaWinDev W, int start, 
 {
     __shared__ int wsum[17];
     const int tid = threadIdx.x;
-    for (int t = tid; t < W.cap_pt; t += 1024) W.cnt[t] = 0;
-    __syncthreads();
+    // (W.cnt is cleared by the caller with a memset on the stream: one workgroup clearing cap_pt counters took 60 of this kernel's 258 us)
     int n_pt = 0, n_obs = 0, overflow = 0;
     for (int f = start; f < N; f++) {
         const int s = f % W.cap_f, sp = (f + W.cap_f - 1) % W.cap_f, n = W.nfeat[s], np = f > start ? W.nfeat[sp] : 0;
-        for (int j0 = 0; j0 < n; j0 += 1024) {                   // (uniform trip count: the scan has barriers)
-            const int j = j0 + tid; const bool in = j < n;
-            const size_t o = (size_t)s * W.cap_n + j;
-            const int lab = in ? W.trk[o] : -1, ps = in ? W.pos[o] : 0;
-            const bool is_new = lab != -1 && ps == 0;
-            int pm = -1;
-            if (lab != -1 && ps > 0 && f > start) { const int a = W.asso[o]; if (a >= 0 && a < np) pm = W.pid[(size_t)sp * W.cap_n + a]; }
-            const bool has = is_new || pm != -1;
-            int tot; const int ex = bw_excl_scan((is_new ? 1 : 0) | (has ? 1 << 16 : 0), wsum, &tot);
-            const int p = is_new ? n_pt + (ex & 0xffff) : pm;
-            if (in) W.pid[o] = has ? p : -1;
-            if (has) {
-                const int k = n_obs + (ex >> 16);
-                if (k < W.cap_obs && p < W.cap_pt) {
-                    W.obs_cam[k] = f - start; W.obs_pt[k] = p; W.obs_src[k] = (int)o;
-                    W.obs_meas[3 * (size_t)k] = W.meas[3 * o]; W.obs_meas[3 * (size_t)k + 1] = W.meas[3 * o + 1]; W.obs_meas[3 * (size_t)k + 2] = W.meas[3 * o + 2];
-                    atomicAdd(&W.cnt[p], 1);
-                    if (is_new) { W.first[p] = f - start; W.pt[3 * (size_t)p] = (double)W.xyz[3 * o]; W.pt[3 * (size_t)p + 1] = (double)W.xyz[3 * o + 1]; W.pt[3 * (size_t)p + 2] = (double)W.xyz[3 * o + 2]; }
-                } else overflow = 1;
+        // a thread takes ipt CONSECUTIVE features, so that one scan over the per-thread sums gives ids and observation positions in feature order (three scans of 1024
+        // features each per frame, as the first version did, are 9 barriers per frame on a chain of 20 frames)
+        const int ipt = (n + 1023) >> 10;                         // <= 8 (cap_features <= 8192)
+        int pm[8]; unsigned char fl[8];                            // predecessor's landmark, flags: 1 = starts a landmark, 2 = has a landmark
+        int mine_new = 0, mine_has = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            pm[i] = -1; fl[i] = 0;
+            const int j = tid * ipt + i;
+            if (i < ipt && j < n) {
+                const size_t o = (size_t)s * W.cap_n + j;
+                const int lab = W.trk[o], ps = W.pos[o];
+                const bool is_new = lab != -1 && ps == 0;
+                if (lab != -1 && ps > 0 && f > start) { const int a = W.asso[o]; if (a >= 0 && a < np) pm[i] = W.pid[(size_t)sp * W.cap_n + a]; }
+                fl[i] = (unsigned char)((is_new ? 1 : 0) | ((is_new || pm[i] != -1) ? 2 : 0));
+                mine_new += fl[i] & 1; mine_has += (fl[i] >> 1) & 1;
             }
-            n_pt += tot & 0xffff; n_obs += tot >> 16;
         }
-        __syncthreads();                                         // this frame's ids are the next frame's predecessors
+        int tot; const int ex = bw_excl_scan(mine_new | (mine_has << 16), wsum, &tot);
+        int pnew = n_pt + (ex & 0xffff), k = n_obs + (ex >> 16);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int j = tid * ipt + i;
+            if (i < ipt && j < n) {
+                const size_t o = (size_t)s * W.cap_n + j;
+                const bool is_new = fl[i] & 1, has = fl[i] & 2;
+                const int p = is_new ? pnew : pm[i];
+                W.pid[o] = has ? p : -1;
+                if (has) {
+                    if (k < W.cap_obs && p < W.cap_pt) {
+                        W.obs_cam[k] = f - start; W.obs_pt[k] = p; W.obs_src[k] = (int)o;
+                        W.obs_meas[3 * (size_t)k] = W.meas[3 * o]; W.obs_meas[3 * (size_t)k + 1] = W.meas[3 * o + 1]; W.obs_meas[3 * (size_t)k + 2] = W.meas[3 * o + 2];
+                        atomicAdd(&W.cnt[p], 1);
+                        if (is_new) { W.first[p] = f - start; W.pt[3 * (size_t)p] = (double)W.xyz[3 * o]; W.pt[3 * (size_t)p + 1] = (double)W.xyz[3 * o + 1]; W.pt[3 * (size_t)p + 2] = (double)W.xyz[3 * o + 2]; }
+                    } else overflow = 1;
+                    k++; pnew += is_new ? 1 : 0;
+                }
+            }
+        }
+        n_pt += tot & 0xffff; n_obs += tot >> 16;
+        __threadfence_block(); __syncthreads();                  // this frame's ids are the next frame's predecessors
     }
     n_pt = min(n_pt, W.cap_pt); n_obs = min(n_obs, W.cap_obs);
     __threadfence(); __syncthreads();
@@ -230,6 +247,8 @@ int vido_bawin_solve(vido_ctx* ctx, int start, int N, vido_ba_problem* prob, vid
     BaWinDev W{B->cap_f, B->cap_n, B->cap_obs, B->cap_pt, B->d_meas, B->d_xyz, B->d_asso, B->d_trk, B->d_pos, B->d_pid, B->d_nfeat,
                B->d_obs_cam, B->d_obs_pt, B->d_obs_pos, B->d_obs_src, B->d_pt_start, B->d_slot_cam, B->d_cnt, B->d_first, B->d_obs_meas, B->d_pt};
     HIP_TRY(ctx, hipMemsetAsync(B->d_counts, 0, 16, st));
+    { size_t tot = 0; for (int f = start; f < N; f++) tot += (size_t)B->nfeat[f % B->cap_f];      // an upper bound of the landmark count: every feature of the window
+      HIP_TRY(ctx, hipMemsetAsync(B->d_cnt, 0, std::min(tot, (size_t)B->cap_pt) * sizeof(int), st)); }
     hipLaunchKernelGGL(k_bawin_assemble, dim3(1), dim3(1024), 0, st, W, start, N, B->d_counts);
     HIP_TRY(ctx, hipMemcpyAsync(B->h_counts, B->d_counts, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));

@@ -44,9 +44,22 @@ static double num(const std::map<std::string, std::string>& kv, const char* key,
     auto it = kv.find(key); if (it == kv.end() || it->second.empty()) return def;
     return atof(it->second.c_str());
 }
+// A failed C-ABI call surfaces as an exception that still carries the VIDO_E_* code, so that the C handle (vido_system_*) can hand the same code back to its caller
+// instead of guessing it from the message text.
+struct VidoFailure : std::runtime_error {
+    int code;
+    VidoFailure(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
 static void check(int rc, const char* what)
 {
-    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + vido_last_error(g_ctx));
+    if (rc < 0) throw VidoFailure(rc, std::string(what) + ": " + vido_last_error(g_ctx));
+}
+int failure_code(const std::exception& e)
+{
+    if (const VidoFailure* v = dynamic_cast<const VidoFailure*>(&e)) return v->code;
+    if (dynamic_cast<const std::invalid_argument*>(&e)) return VIDO_E_INVALID;
+    if (dynamic_cast<const std::bad_alloc*>(&e)) return VIDO_E_NOMEM;
+    return VIDO_E_INVALID;                                    // the facade's own throws are argument / state errors (wrong sensor, wrong image type, no live System)
 }
 // The static Optimizer:: methods and the Frame constructor of the reference's interface carry no context argument, so the facade keeps ONE process-wide context (set by
 // the tracker's extractor / GrabImageRGBD).  One live System per process, like the reference (Frame's static members, Frame.cc:26-30); calls before the first frame or
@@ -846,7 +859,7 @@ cv::Mat Tracking::GetInitModelCam(const std::vector<int>& MatchId, std::vector<i
     std::vector<float> g3, g2; std::vector<int> gidx;
     for (int i = 0; i < N; i++) if (outl[i] == 0) { g3.push_back(pre_3d[i].x); g3.push_back(pre_3d[i].y); g3.push_back(pre_3d[i].z); g2.push_back(cur_2d[i].x); g2.push_back(cur_2d[i].y); gidx.push_back(i); }
     double T[16]; int32_t ninl = 0; std::vector<uint8_t> mask(std::max<size_t>(gidx.size(), 1));
-    check(vido_pnp_ransac(g_ctx, g3.data(), g2.data(), (int)gidx.size(), C->fx, C->fy, C->cx, C->cy, 500, 0.4, 0.98, ransac_seed + (unsigned)f_id, T, mask.data(), &ninl), "pnp_ransac");
+    check(vido_pnp_ransac(live_ctx("GetInitModelCam"), g3.data(), g2.data(), (int)gidx.size(), C->fx, C->fy, C->cx, C->cy, 500, 0.4, 0.98, ransac_seed + (unsigned)f_id, T, mask.data(), &ninl), "pnp_ransac");
     cv::Mat Mod = fromRow16(T);
     cv::Mat MotionModel = mVelocity.empty() ? L->mTcw.clone() : mVelocity * L->mTcw;
     std::vector<int> MM_inlier;
@@ -895,7 +908,7 @@ cv::Mat Tracking::GetInitModelObj(const std::vector<int>& ObjId, std::vector<int
 {
     Frame *C = mpCurrentFrame, *L = mpLastFrame;
     ObjInit o; init_obj_inputs(o, C, L, ObjId);
-    check(vido_pnp_ransac(g_ctx, o.g3.data(), o.g2.data(), (int)ObjId.size(), C->fx, C->fy, C->cx, C->cy, 500, 0.4, 0.98, ransac_seed + 7919u * (unsigned)(objid + 1) + (unsigned)f_id, o.T, o.mask.data(), &o.ninl), "pnp_ransac(obj)");
+    check(vido_pnp_ransac(live_ctx("GetInitModelObj"), o.g3.data(), o.g2.data(), (int)ObjId.size(), C->fx, C->fy, C->cx, C->cy, 500, 0.4, 0.98, ransac_seed + 7919u * (unsigned)(objid + 1) + (unsigned)f_id, o.T, o.mask.data(), &o.ninl), "pnp_ransac(obj)");
     return init_obj_decide(o, C, L, ObjId, ObjId_sub, objid);
 }
 
@@ -909,7 +922,7 @@ std::vector<cv::Mat> Tracking::GetInitModelObjBatch(const std::vector<std::vecto
         p3[i] = O[i].g3.data(); p2[i] = O[i].g2.data(); mk[i] = O[i].mask.data(); nn[i] = (int32_t)ObjIds[i].size();
         seeds[i] = ransac_seed + 7919u * (unsigned)(i + 1) + (unsigned)f_id;
     }
-    if (n) check(vido_pnp_ransac_batch(g_ctx, (int)n, p3.data(), p2.data(), nn.data(), C->fx, C->fy, C->cx, C->cy, 500, 0.4, 0.98, seeds.data(), T.data(), mk.data(), ninl.data()), "pnp_ransac_batch");
+    if (n) check(vido_pnp_ransac_batch(live_ctx("GetInitModelObjBatch"), (int)n, p3.data(), p2.data(), nn.data(), C->fx, C->fy, C->cx, C->cy, 500, 0.4, 0.98, seeds.data(), T.data(), mk.data(), ninl.data()), "pnp_ransac_batch");
     std::vector<cv::Mat> out(n); ObjIds_sub.assign(n, std::vector<int>());
     for (size_t i = 0; i < n; i++) {
         memcpy(O[i].T, &T[16 * i], sizeof O[i].T); O[i].ninl = ninl[i];
@@ -1213,7 +1226,7 @@ int vido_system_track_rgbd(vido_system* s, const uint8_t* im, int channels, int 
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) Tcw_out[r * 4 + c] = T.at<float>(r, c);
     } catch (const std::exception& e) {
         s->err = e.what();
-        return s->err.find("exceed") != std::string::npos || s->err.find("capacity") != std::string::npos ? VIDO_E_CAPACITY : VIDO_E_HIP;
+        return VIDO_SLAM::failure_code(e);
     }
     return VIDO_OK;
 }
@@ -1228,7 +1241,7 @@ int vido_system_track_rgbd_device(vido_system* s, const void* im_dev, int channe
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) Tcw_out[r * 4 + c] = T.at<float>(r, c);
     } catch (const std::exception& e) {
         s->err = e.what();
-        return s->err.find("exceed") != std::string::npos || s->err.find("capacity") != std::string::npos ? VIDO_E_CAPACITY : VIDO_E_HIP;
+        return VIDO_SLAM::failure_code(e);
     }
     return VIDO_OK;
 }

@@ -187,9 +187,22 @@ class _RPNHead(nn.Module):                 # rpn/rpn.py:74-107
         super().__init__()
         self.conv = nn.Conv2d(ch, ch, 3, 1, 1); self.cls_logits = nn.Conv2d(ch, na, 1); self.bbox_pred = nn.Conv2d(ch, na * 4, 1)
 
+    _ops = None                            # MaskRCNN.__init__: HipOps, for the one-pass bias + ReLU
+
     def forward(self, feats):
-        t = [F.relu(self.conv(f)) for f in feats]
+        t = [_conv_bias_relu(self.conv, f, self._ops) for f in feats]
         return [self.cls_logits(x) for x in t], [self.bbox_pred(x) for x in t]
+
+
+def _conv_bias_relu(conv, x, ops):
+    """relu(conv(x)); on the device the library convolution runs without its bias and the bias + ReLU are ONE in-place pass (vido_bias_act) instead of an add and a clamp."""
+    if ops is None or not x.is_cuda or conv.bias is None:
+        return F.relu(conv(x))
+    if isinstance(conv, nn.ConvTranspose2d):
+        y = F.conv_transpose2d(x, conv.weight, None, conv.stride, conv.padding, conv.output_padding, conv.groups, conv.dilation)
+    else:
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return ops.bias_act_(y.contiguous(), conv.bias, 0.0)
 
 
 def clip_boxes(b, w, h):                    # structures/bounding_box.py:214-224 (TO_REMOVE = 1)
@@ -455,7 +468,7 @@ class _MaskFeatures(nn.Module):            # roi_mask_feature_extractors.py:17-6
     def forward(self, feats, boxes):
         x = self.pooler(feats, boxes)
         for n in self.names:
-            x = F.relu(getattr(self, n)(x))
+            x = _conv_bias_relu(getattr(self, n), x, self.pooler.ops if hasattr(self.pooler.ops, "bias_act_") else None)
         return x
 
 
@@ -465,8 +478,10 @@ class _MaskPredictor(nn.Module):           # roi_mask_predictors.py:11-31
         self.conv5_mask = nn.ConvTranspose2d(c.mask_layers[-1], c.mask_layers[-1], 2, 2, 0)
         self.mask_fcn_logits = nn.Conv2d(c.mask_layers[-1], c.num_classes, 1)
 
+    _ops = None
+
     def forward(self, x):
-        return self.mask_fcn_logits(F.relu(self.conv5_mask(x)))
+        return self.mask_fcn_logits(_conv_bias_relu(self.conv5_mask, x, self._ops))
 
 
 class _MaskHead(nn.Module):
@@ -550,6 +565,9 @@ class MaskRCNN(nn.Module):
         self.backbone = nn.Sequential(OrderedDict([("body", _Body(c)), ("fpn", _FPN(c))]))
         self.rpn = _RPN(c, ops)
         self.roi_heads = _RoiHeads(c, ops)
+        for m in self.modules():
+            if isinstance(m, (_RPNHead, _MaskPredictor)):
+                m._ops = ops if hasattr(ops, "bias_act_") else None
 
     @torch.no_grad()
     def forward(self, image):

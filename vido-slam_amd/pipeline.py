@@ -79,9 +79,36 @@ import os as _os
 # MIOpen user find-db recorded once on an MI355X with `bench.py --miopen-find` (MIOPEN_USER_DB_PATH pointing here): the measured best solver per convolution shape of the
 # three nodes at their feed sizes.  With it the default immediate-mode path picks those solvers without searching (the search costs ~3.5 minutes of start-up; the
 # heuristic pick without the db is 0.7 ms per frame slower).  Read by MIOpen when its handle is created, i.e. at the first convolution; an explicit setting wins.
+# The db is keyed to one MIOpen build (file name gfx950100.HIP.<major>_<minor>_<patch>_...): it is offered only when this process' MIOpen has that version, MIOpen
+# writes new entries into the directory it is given, so a read-only installation gets a private copy under the temp directory; VIDO_NO_MIOPEN_DB=1 opts out.
 _MIOPEN_DB = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
-if _os.path.isdir(_MIOPEN_DB) and "MIOPEN_USER_DB_PATH" not in _os.environ:
-    _os.environ["MIOPEN_USER_DB_PATH"] = _MIOPEN_DB
+
+
+def _offer_miopen_db():
+    if "MIOPEN_USER_DB_PATH" in _os.environ or _os.environ.get("VIDO_NO_MIOPEN_DB") or not _os.path.isdir(_MIOPEN_DB):
+        return None
+    try:
+        import torch as _t
+        v = int(_t.backends.cudnn.version() or 0)                # MIOpen's version on ROCm builds: major * 1e6 + minor * 1e3 + patch
+    except Exception:
+        return None
+    tag = "HIP.%d_%d_%d_" % (v // 1000000, (v // 1000) % 1000, v % 1000)
+    files = [f for f in _os.listdir(_MIOPEN_DB) if tag in f]
+    if not files:
+        return None
+    path = _MIOPEN_DB
+    if not _os.access(path, _os.W_OK):
+        import shutil, tempfile
+        path = _os.path.join(tempfile.gettempdir(), "vido_slam_miopen_db_%d" % _os.getuid())
+        _os.makedirs(path, exist_ok=True)
+        for f in files:
+            if not _os.path.exists(_os.path.join(path, f)):
+                shutil.copy(_os.path.join(_MIOPEN_DB, f), path)
+    _os.environ["MIOPEN_USER_DB_PATH"] = path
+    return path
+
+
+_offer_miopen_db()
 
 
 class NetNodes:
