@@ -121,3 +121,33 @@ def test_area_feed_and_backwarp_equal_the_torch_forms(ctx):
         flow = (torch.randn(B, 2, H, W, generator=g) * 6.0).cuda()                 # many samples land outside the image
         ref = L.backwarp(x, flow); got = ops.backwarp(x, flow)
         assert float((got - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+
+
+def test_monodepth2_decoder_glue_kernels_and_fused_path(ctx):
+    """vido_upcat_reflect / vido_bias_unary / vido_minmax_norm_u16 against their torch forms, and the decoder's fused forward (disp 0 only) against the module-by-module one
+    and the reference fixture."""
+    import torch.nn.functional as F
+    from vido_slam_amd.nets.fuse import fold_batchnorm
+    ops = nets.HipOps(ctx); g = torch.Generator().manual_seed(11)
+    for C1, C2, h, w in ((16, 0, 5, 7), (32, 64, 3, 4), (256, 256, 6, 20), (1, 1, 1, 1), (16, 64, 96, 320)):
+        x = torch.randn(1, C1, h, w, generator=g).cuda(); skip = torch.randn(1, C2, 2 * h, 2 * w, generator=g).cuda() if C2 else None
+        up = F.interpolate(x, scale_factor=2, mode="nearest")
+        ref = F.pad(torch.cat([up, skip], 1) if C2 else up, (1, 1, 1, 1), mode="reflect") if min(h, w) > 0 and 2 * min(h, w) > 1 else None
+        assert torch.equal(ops.upcat_reflect(x, skip), ref), (C1, C2, h, w)
+    for shape in ((1, 16, 9, 13), (1, 256, 12, 40), (2, 3, 5, 5)):
+        x = (torch.randn(shape, generator=g) * 3).cuda(); b = torch.randn(shape[1], generator=g).cuda()
+        assert float((ops.bias_unary_(x.clone(), b, "elu") - F.elu(x + b[None, :, None, None])).abs().max()) < 1e-6
+        assert float((ops.bias_unary_(x.clone(), b, "sigmoid") - torch.sigmoid(x + b[None, :, None, None])).abs().max()) < 1e-6
+    d = torch.rand(480, 640, generator=g).cuda() * 0.7 + 0.01
+    lo, hi = d.min(), d.max()
+    assert torch.equal(ops.minmax_norm_u16(d), ((d - lo) / (hi - lo + 1e-12) * 65536.0).clamp(0, 65535).to(torch.int32))
+    dec = nets.fill_deterministic(nets.DepthDecoder(), int(G["md_seed"])).eval().cuda()
+    rng = np.random.RandomState(int(G["md_feat_seed"]))
+    shapes = [(1, 64, 32, 64), (1, 64, 16, 32), (1, 128, 8, 16), (1, 256, 4, 8), (1, 512, 2, 4)]
+    feats = [torch.from_numpy(rng.uniform(0, 1.5, s).astype(np.float32)).cuda() for s in shapes]
+    with torch.no_grad():
+        plain = dec(feats)[("disp", 0)]
+        fold_batchnorm(dec, ops); assert dec._ops is not None
+        fused = dec(feats)
+    assert list(fused.keys()) == [("disp", 0)] and float((fused[("disp", 0)] - plain).abs().max()) < 1e-6
+    assert rel_err(fused[("disp", 0)].cpu().numpy(), G["md_disp0"]) < TOL

@@ -86,6 +86,41 @@ __global__ __launch_bounds__(256) void k_bias_act(float* __restrict__ x, const f
     }
 }
 
+// y = f(x + bias[c]) in place, f = ELU (alpha 1) or the logistic function: the decoder blocks of MonoDepth2 (mono_depth2/src/networks/depth_decoder.py:33-63, layers.py ConvBlock /
+// Conv3x3) — the library convolution runs without its bias, bias add and activation are one pass
+template <int KIND>
+__global__ __launch_bounds__(256) void k_bias_unary(float* __restrict__ x, const float* __restrict__ bias, int C, size_t hw, size_t total)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float v = x[i] + bias[(i / hw) % C];
+    x[i] = KIND == 1 ? (v > 0.f ? v : expf(v) - 1.f) : 1.f / (1.f + expf(-v));
+}
+
+// torch.cat([interpolate(x, scale_factor=2, mode="nearest"), skip], 1) followed by ReflectionPad2d(1) (depth_decoder.py:52-57 + Conv3x3's pad) as ONE pass:
+// x [C1][h][w], skip [C2][2h][2w] (C2 may be 0) -> out [C1 + C2][2h + 2][2w + 2]
+__global__ __launch_bounds__(256) void k_upcat_reflect(const float* __restrict__ x, const float* __restrict__ skip, int C1, int C2, int h, int w, float* __restrict__ out)
+{
+    const int H2 = 2 * h, W2 = 2 * w, OW = W2 + 2, OH = H2 + 2;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, total = (size_t)(C1 + C2) * OH * OW;
+    if (i >= total) return;
+    const int X = (int)(i % OW), Y = (int)((i / OW) % OH), c = (int)(i / ((size_t)OW * OH));
+    int yy = Y - 1, xx = X - 1;
+    yy = yy < 0 ? -yy : (yy >= H2 ? 2 * H2 - 2 - yy : yy); xx = xx < 0 ? -xx : (xx >= W2 ? 2 * W2 - 2 - xx : xx);
+    out[i] = c < C1 ? x[((size_t)c * h + (yy >> 1)) * w + (xx >> 1)] : skip[((size_t)(c - C1) * H2 + yy) * W2 + xx];
+}
+
+// run_mono_depth.py:150-156: (disp - min) / (max - min + 1e-12) * 65536, clamped to the MONO16 range, as int32; mm = {min, max} on the device
+__global__ __launch_bounds__(256) void k_minmax_norm_u16(const float* __restrict__ d, const float* __restrict__ mm, size_t n, int* __restrict__ out)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float lo = mm[0], hi = mm[1];
+    float v = (d[i] - lo) / (hi - lo + 1e-12f) * 65536.0f;
+    v = fminf(fmaxf(v, 0.f), 65535.f);
+    out[i] = (int)v;
+}
+
 // x = act(x + bias[c] + res): the FrozenBatchNorm shift (folded into a bias), the shortcut add and the ReLU that close a bottleneck
 // (maskrcnn_benchmark/modeling/backbone/resnet.py:352-372), one pass over the tensor instead of four
 __global__ __launch_bounds__(256) void k_bias_res_act(float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ res, int C, size_t hw, size_t total, float slope)
@@ -628,6 +663,45 @@ int vido_bias_act(vido_ctx* ctx, float* x, const float* bias, int N, int C, int 
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
     const size_t hw = (size_t)H * W, total = (size_t)N * C * hw;
     hipLaunchKernelGGL(k_bias_act, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, st, x, bias, C, hw, total, slope);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+/* x = f(x + bias[c]) in place on a DEVICE tensor x[N,C,H,W]; kind 1: ELU (alpha = 1), 2: logistic function. */
+int vido_bias_unary(vido_ctx* ctx, float* x, const float* bias, int N, int C, int H, int W, int kind)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!x || !bias || N < 1 || C < 1 || H < 1 || W < 1 || (kind != 1 && kind != 2)) return vido_set_error(ctx, VIDO_E_INVALID, "bias_unary: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    const size_t hw = (size_t)H * W, total = (size_t)N * C * hw;
+    if (kind == 1) hipLaunchKernelGGL(k_bias_unary<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, bias, C, hw, total);
+    else hipLaunchKernelGGL(k_bias_unary<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, bias, C, hw, total);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+/* ReflectionPad2d(1)(cat([nearest-upsample x2 of x [C1][h][w], skip [C2][2h][2w]], channel axis)) -> out [C1 + C2][2h + 2][2w + 2]; DEVICE tensors, skip may be NULL (C2 = 0). */
+int vido_upcat_reflect(vido_ctx* ctx, const float* x, const float* skip, int C1, int C2, int h, int w, float* out)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!x || !out || C1 < 1 || C2 < 0 || (C2 && !skip) || h < 1 || w < 1) return vido_set_error(ctx, VIDO_E_INVALID, "upcat_reflect: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    const size_t total = (size_t)(C1 + C2) * (2 * h + 2) * (2 * w + 2);
+    hipLaunchKernelGGL(k_upcat_reflect, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, skip, C1, C2, h, w, out);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+/* out[i] = (int) clamp((d[i] - mm[0]) / (mm[1] - mm[0] + 1e-12) * 65536, 0, 65535): the MONO16 normalisation of the depth node; d [n] f32, mm [2] f32 = {min, max}, out [n] i32, DEVICE. */
+int vido_minmax_norm_u16(vido_ctx* ctx, const float* d, const float* mm, int64_t n, int32_t* out)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!d || !mm || !out || n < 1) return vido_set_error(ctx, VIDO_E_INVALID, "minmax_norm_u16: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    hipLaunchKernelGGL(k_minmax_norm_u16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, mm, (size_t)n, (int*)out);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }

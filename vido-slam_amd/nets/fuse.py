@@ -33,7 +33,7 @@ def fold_batchnorm(net, ops):
     """Installs the folded fast path on every block that has one (`fused_forward`); returns the number of folded pairs.  `ops` is a HipOps
     (bias_res_act_): there is no CPU flavour of this path."""
     from .maskrcnn import _Bottleneck, _Stem
-    from .monodepth2 import _Basic, ResnetEncoder18
+    from .monodepth2 import _Basic, ResnetEncoder18, DepthDecoder
     n = 0
     for m in net.modules():
         if isinstance(m, _Bottleneck):
@@ -53,6 +53,8 @@ def fold_batchnorm(net, ops):
             if m.downsample is not None:
                 m._wd, m._bd = _fold(m.downsample[0], m.downsample[1], m.downsample[1].eps); n += 1
             m._ep = ops.bias_res_act_
+        elif isinstance(m, DepthDecoder):
+            m._ops = ops if hasattr(ops, "upcat_reflect") and not os.environ.get("VIDO_NO_DEPTH_FUSED") else None
         elif isinstance(m, ResnetEncoder18):
             e = m.encoder
             w, b = _fold(e.conv1, e.bn1, e.bn1.eps)

@@ -96,7 +96,23 @@ class DepthDecoder(nn.Module):
             self.index[("dispconv", s)] = len(mods); mods.append(_Conv3x3(self.num_ch_dec[s], 1))
         self.decoder = nn.ModuleList(mods)
 
+    _ops = None                            # nets/fuse.py::fold_batchnorm: HipOps for the one-pass decoder glue
+
+    def forward_fused(self, feats):
+        """("disp", 0) only (the node uses nothing else, run_mono_depth.py:139), with the glue of every level as single passes: bias + ELU (vido_bias_unary), upsample + cat +
+        the next block's reflection pad (vido_upcat_reflect), bias + sigmoid; the convolutions stay the library's."""
+        ops = self._ops; x = feats[-1]
+        for i in range(4, -1, -1):
+            b0 = self.decoder[self.index[("upconv", i, 0)]].conv; b1 = self.decoder[self.index[("upconv", i, 1)]].conv
+            x = ops.bias_unary_(F.conv2d(b0.pad(x), b0.conv.weight, None), b0.conv.bias, "elu")
+            x = ops.upcat_reflect(x, feats[i - 1].contiguous() if i > 0 else None)
+            x = ops.bias_unary_(F.conv2d(x, b1.conv.weight, None), b1.conv.bias, "elu")
+        d0 = self.decoder[self.index[("dispconv", 0)]]
+        return {("disp", 0): ops.bias_unary_(F.conv2d(d0.pad(x), d0.conv.weight, None), d0.conv.bias, "sigmoid")}
+
     def forward(self, feats):
+        if self._ops is not None and feats[-1].is_cuda and feats[-1].shape[0] == 1:
+            return self.forward_fused(feats)
         out = {}; x = feats[-1]
         for i in range(4, -1, -1):
             x = self.decoder[self.index[("upconv", i, 0)]](x)
@@ -132,5 +148,7 @@ def analyse_depth(net, bgr, feed=(192, 640), ops=None):
         H, W = t.shape[2], t.shape[3]
         x = F.interpolate(t, size=feed, mode="area").div(255.0)         # cv2.INTER_AREA
     disp = F.interpolate(net(x), size=(H, W), mode="bilinear", align_corners=False)[0, 0]
+    if ops is not None and disp.is_cuda and hasattr(ops, "minmax_norm_u16"):
+        return ops.minmax_norm_u16(disp)
     lo, hi = disp.min(), disp.max()
     return ((disp - lo) / (hi - lo + 1e-12) * 65536.0).clamp(0, 65535).to(torch.int32)

@@ -54,6 +54,36 @@ class HipOps:
                                                        C.c_void_p(res.data_ptr()) if res is not None else None, N, Cc, H, W, C.c_float(slope)))
         return x
 
+    def bias_unary_(self, x, bias, kind):
+        """in place: x = f(x + bias[None, :, None, None]); kind "elu" | "sigmoid" """
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
+        N, Cc, H, W = x.shape
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_bias_unary(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), N, Cc, H, W, 1 if kind == "elu" else 2))
+        return x
+
+    def upcat_reflect(self, x, skip=None):
+        """ReflectionPad2d(1)(cat([interpolate(x, scale_factor=2, mode="nearest"), skip], 1)) for one image, one pass."""
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and x.shape[0] == 1
+        _, C1, h, w = x.shape
+        C2 = 0
+        if skip is not None:
+            assert skip.is_contiguous() and skip.shape[0] == 1 and tuple(skip.shape[2:]) == (2 * h, 2 * w)
+            C2 = skip.shape[1]
+        out = torch.empty((1, C1 + C2, 2 * h + 2, 2 * w + 2), device=x.device, dtype=torch.float32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_upcat_reflect(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(skip.data_ptr()) if skip is not None else None, C1, C2, h, w, C.c_void_p(out.data_ptr())))
+        return out
+
+    def minmax_norm_u16(self, d):
+        """((d - d.min()) / (d.max() - d.min() + 1e-12) * 65536).clamp(0, 65535).to(int32) with one reduction and one pass."""
+        d = d.contiguous()
+        mm = torch.stack(torch.aminmax(d))
+        out = torch.empty(d.shape, device=d.device, dtype=torch.int32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_minmax_norm_u16(self.ctx.h, C.c_void_p(d.data_ptr()), C.c_void_p(mm.data_ptr()), C.c_int64(d.numel()), C.c_void_p(out.data_ptr())))
+        return out
+
     def area_feed(self, bgr, feed, div=1.0):
         """u8 HxWx3 BGR device tensor -> f32 [1,3,feed_h,feed_w] RGB, area-resized, / div (flip + permute + float + interpolate(area) + div in one pass)"""
         assert bgr.is_cuda and bgr.dtype == torch.uint8 and bgr.is_contiguous() and bgr.dim() == 3 and bgr.shape[2] == 3
