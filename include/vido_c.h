@@ -267,7 +267,7 @@ int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int
 /* Conv epilogue on a DEVICE tensor x[N,C,H,W] (f32, contiguous), in place: x = leaky_relu(x + bias[c], slope) — the bias add and the
  * LeakyReLU(0.1) that follow every convolution of flow_net/src/layers.py fused into one pass (slope = 1: plain bias add). */
 int vido_bias_act(vido_ctx* ctx, float* x, const float* bias, int N, int C, int H, int W, float slope);
-/* MonoDepth2's decoder glue as single passes (mono_depth2/src/networks/depth_decoder.py:45-63, layers.py ConvBlock / Conv3x3 / upsample; run_mono_depth.py:150-156), DEVICE tensors:
+/* MonoDepth2's decoder glue as single passes (mono_depth2/src/networks/depth_decoder.py:51-66, layers.py ConvBlock / Conv3x3 / upsample; run_mono_depth.py:137-145), DEVICE tensors:
  * vido_bias_unary: x = f(x + bias[c]) in place, kind 1 = ELU (ConvBlock), 2 = logistic function (the disparity head);
  * vido_upcat_reflect: ReflectionPad2d(1)(cat([upsample(x, 2, nearest), skip], 1)) — upsample + cat + the next Conv3x3's pad; x [C1][h][w], skip [C2][2h][2w] or NULL, out [C1+C2][2h+2][2w+2];
  * vido_minmax_norm_u16: the node's min-max normalisation to MONO16, out = (int) clamp((d - min) / (max - min + 1e-12) * 65536, 0, 65535), mm = {min, max} on the device. */

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_bias_act(float* __restrict__ x, const f
     }
 }
 
-// y = f(x + bias[c]) in place, f = ELU (alpha 1) or the logistic function: the decoder blocks of MonoDepth2 (mono_depth2/src/networks/depth_decoder.py:33-63, layers.py ConvBlock /
+// y = f(x + bias[c]) in place, f = ELU (alpha 1) or the logistic function: the decoder blocks of MonoDepth2 (mono_depth2/src/networks/depth_decoder.py:51-66, layers.py ConvBlock /
 // Conv3x3) — the library convolution runs without its bias, bias add and activation are one pass
 template <int KIND>
 __global__ __launch_bounds__(256) void k_bias_unary(float* __restrict__ x, const float* __restrict__ bias, int C, size_t hw, size_t total)
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_bias_unary(float* __restrict__ x, const
     x[i] = KIND == 1 ? (v > 0.f ? v : expf(v) - 1.f) : 1.f / (1.f + expf(-v));
 }
 
-// torch.cat([interpolate(x, scale_factor=2, mode="nearest"), skip], 1) followed by ReflectionPad2d(1) (depth_decoder.py:52-57 + Conv3x3's pad) as ONE pass:
+// torch.cat([interpolate(x, scale_factor=2, mode="nearest"), skip], 1) followed by ReflectionPad2d(1) (depth_decoder.py:58-61 + Conv3x3's pad) as ONE pass:
 // x [C1][h][w], skip [C2][2h][2w] (C2 may be 0) -> out [C1 + C2][2h + 2][2w + 2]
 __global__ __launch_bounds__(256) void k_upcat_reflect(const float* __restrict__ x, const float* __restrict__ skip, int C1, int C2, int h, int w, float* __restrict__ out)
 {
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_upcat_reflect(const float* __restrict__
     out[i] = c < C1 ? x[((size_t)c * h + (yy >> 1)) * w + (xx >> 1)] : skip[((size_t)(c - C1) * H2 + yy) * W2 + xx];
 }
 
-// run_mono_depth.py:150-156: (disp - min) / (max - min + 1e-12) * 65536, clamped to the MONO16 range, as int32; mm = {min, max} on the device
+// run_mono_depth.py:137-145: (disp - min) / (max - min + 1e-12) * 65536, clamped to the MONO16 range, as int32; mm = {min, max} on the device
 __global__ __launch_bounds__(256) void k_minmax_norm_u16(const float* __restrict__ d, const float* __restrict__ mm, size_t n, int* __restrict__ out)
 {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;

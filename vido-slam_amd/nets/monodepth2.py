@@ -99,7 +99,7 @@ class DepthDecoder(nn.Module):
     _ops = None                            # nets/fuse.py::fold_batchnorm: HipOps for the one-pass decoder glue
 
     def forward_fused(self, feats):
-        """("disp", 0) only (the node uses nothing else, run_mono_depth.py:139), with the glue of every level as single passes: bias + ELU (vido_bias_unary), upsample + cat +
+        """("disp", 0) only (the node uses nothing else, run_mono_depth.py:137), with the glue of every level as single passes: bias + ELU (vido_bias_unary), upsample + cat +
         the next block's reflection pad (vido_upcat_reflect), bias + sigmoid; the convolutions stay the library's."""
         ops = self._ops; x = feats[-1]
         for i in range(4, -1, -1):
