@@ -25,6 +25,10 @@
 // partial reduced system (S, r) and the LM scalars are summed through the caller's all-reduce hook (RCCL via
 // torch.distributed in bench.py), the reduced solve is replicated, back-substitution is local.
 #include "common.hpp"
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -2223,6 +2227,59 @@ void ba_state_destroy(vido_ctx* ctx)
 }
 
 namespace {
+// Worker threads for the host set-up of LARGE graphs (>= 200 k observations: the global BA; the per-frame window stays on the calling thread).  The set-up is a dozen
+// passes over the observation list (validate, stable sort by camera, gather, slot tables, window tables: 12 ms for 1 M edges on one core — more than the LM loop it
+// prepares); each pass is split into contiguous chunks, one per thread, and the two sorts are stable counting sorts with per-thread histograms.  Threads are created once
+// per process (a spawn per pass would cost what the pass saves).
+class HostPool {
+public:
+    static HostPool& get() { static HostPool p; return p; }
+    int size() const { return n_; }
+    // f(tid) on n_ threads (the caller is thread 0); returns when all are done
+    void run(const std::function<void(int)>& f) {
+        if (n_ == 1) { f(0); return; }
+        std::lock_guard<std::mutex> one(run_m_);                 // (several contexts may set up at once — the sharded solve in threads: their passes take turns)
+        { std::lock_guard<std::mutex> g(m_); job_ = &f; gen_++; pending_ = n_ - 1; }
+        cv_.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> g(m_); done_.wait(g, [&] { return pending_ == 0; }); job_ = nullptr;
+    }
+    // chunks of [0, n): f(lo, hi, tid)
+    template <class F> void chunks(size_t n, F f) { const int T = n_; run([&](int t) { const size_t lo = n * t / T, hi = n * (t + 1) / T; if (hi > lo) f(lo, hi, t); }); }
+private:
+    HostPool() {
+        const char* e = getenv("VIDO_BA_HOST_THREADS"); int want = e ? atoi(e) : 8;
+        n_ = std::max(1, std::min(want, (int)std::thread::hardware_concurrency()));
+        for (int t = 1; t < n_; t++) th_.emplace_back([this, t] { int seen = 0; for (;;) { const std::function<void(int)>* j;
+            { std::unique_lock<std::mutex> g(m_); cv_.wait(g, [&] { return stop_ || gen_ != seen; }); if (stop_) return; seen = gen_; j = job_; }
+            (*j)(t);
+            { std::lock_guard<std::mutex> g(m_); if (--pending_ == 0) done_.notify_one(); } } });
+    }
+    ~HostPool() { { std::lock_guard<std::mutex> g(m_); stop_ = true; } cv_.notify_all(); for (auto& t : th_) t.join(); }
+    int n_ = 1, gen_ = 0, pending_ = 0; bool stop_ = false; const std::function<void(int)>* job_ = nullptr;
+    std::mutex m_, run_m_; std::condition_variable cv_, done_; std::vector<std::thread> th_;
+};
+// stable counting sort on the pool: pos[i] = rank of element i among the n elements ordered by (key, i); bin_start[b] = first rank of bin b (nbins + 1 entries)
+template <class KeyFn> static void par_counting_rank(HostPool& P, size_t n, int nbins, KeyFn key, int* pos, std::vector<int>& bin_start)
+{
+    const int T = P.size();
+    std::vector<int> hist((size_t)T * nbins, 0);
+    P.chunks(n, [&](size_t lo, size_t hi, int t) { int* h = hist.data() + (size_t)t * nbins; for (size_t i = lo; i < hi; i++) h[key(i)]++; });
+    bin_start.assign(nbins + 1, 0);
+    std::vector<long> part(T + 1, 0);                          // bins split over the threads: totals per range, then the offsets inside
+    P.chunks((size_t)nbins, [&](size_t lo, size_t hi, int t) { long s2 = 0; for (size_t b = lo; b < hi; b++) for (int u = 0; u < T; u++) s2 += hist[(size_t)u * nbins + b]; part[t + 1] = s2; });
+    for (int t = 0; t < T; t++) part[t + 1] += part[t];
+    P.chunks((size_t)nbins, [&](size_t lo, size_t hi, int t) { long run = part[t]; for (size_t b = lo; b < hi; b++) { bin_start[b] = (int)run; for (int u = 0; u < T; u++) { const int c = hist[(size_t)u * nbins + b]; hist[(size_t)u * nbins + b] = (int)run; run += c; } } });
+    bin_start[nbins] = (int)n;
+    P.chunks(n, [&](size_t lo, size_t hi, int t) { int* h = hist.data() + (size_t)t * nbins; for (size_t i = lo; i < hi; i++) pos[i] = h[key(i)]++; });
+}
+static void par_memcpy(HostPool& P, void* dst, const void* src, size_t bytes)
+{
+    if (bytes < (1u << 20) || P.size() == 1) { memcpy(dst, src, bytes); return; }
+    P.chunks(bytes >> 6, [&](size_t lo, size_t hi, int) { memcpy((char*)dst + (lo << 6), (const char*)src + (lo << 6), (hi - lo) << 6); });
+    if (bytes & 63) memcpy((char*)dst + (bytes & ~(size_t)63), (const char*)src + (bytes & ~(size_t)63), bytes & 63);
+}
+
 struct Arena {                       // bump allocator over the ctx's persistent BA pool (no hipMalloc per call);
     char* base; size_t cap; size_t off = 0; bool failed = false;   // host inputs go through a pinned stage that only has to hold what is uploaded
     char* hbase; size_t hcap = 0, hoff = 0;
@@ -2231,7 +2288,7 @@ struct Arena {                       // bump allocator over the ctx's persistent
         T* d = get<T>(n);
         const size_t b = (n * sizeof(T) + 255) & ~(size_t)255;
         if (d && n) { if (hoff + b > hcap) { failed = true; return nullptr; }
-                      memcpy(hbase + hoff, src, n * sizeof(T)); if (hipMemcpyAsync(d, hbase + hoff, n * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) failed = true; hoff += b; }
+                      par_memcpy(HostPool::get(), hbase + hoff, src, n * sizeof(T)); if (hipMemcpyAsync(d, hbase + hoff, n * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) failed = true; hoff += b; }
         return d; }
 };
 }
@@ -2296,6 +2353,10 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     if (pt_lo < 0 || pt_hi > p.n_pt) return vido_set_error(ctx, VIDO_E_INVALID, "ba: landmark shard [%d,%d) outside [0,%d)", pt_lo, pt_hi, p.n_pt);
     const bool owns_cam_factors = (p.rank == 0);
     const auto t_begin = std::chrono::steady_clock::now();
+    static const bool setup_verbose = getenv("VIDO_BA_VERBOSE") != nullptr;
+    auto t_mark = t_begin;
+    auto phase = [&](const char* what) { if (!setup_verbose) return; const auto t = std::chrono::steady_clock::now();
+                                         fprintf(stderr, "[ba setup] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_mark).count()); t_mark = t; };
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->ba) { ctx->ba = new BaState(); HIP_TRY(ctx, hipHostMalloc((void**)&ctx->ba->h_scal, 8 * sizeof(double)));
                     HIP_TRY(ctx, hipEventCreate(&ctx->ba->ev0)); HIP_TRY(ctx, hipEventCreate(&ctx->ba->ev1)); }
@@ -2382,35 +2443,76 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     std::vector<double> poses((size_t)n_pose * 12);
     for (int i = 0; i < p.n_cam; i++) memcpy(poses.data() + (size_t)perm[i] * 12, p.cam_T + (size_t)i * 12, 12 * sizeof(double));
     for (int h = 0; h < n_H; h++) memcpy(poses.data() + (size_t)perm[p.n_cam + h] * 12, dynp->H_T + (size_t)h * 12, 12 * sizeof(double));
+    phase("factors, pose order");
     // ---- host preprocessing: keep this shard's observations, sort by camera, build the landmark-major slots
-    std::vector<int> keep; keep.reserve(p.n_obs);
-    for (int k = 0; k < p.n_obs; k++) {
-        if (p.obs_cam[k] < 0 || p.obs_cam[k] >= p.n_cam || p.obs_pt[k] < 0 || p.obs_pt[k] >= p.n_pt) return vido_set_error(ctx, VIDO_E_INVALID, "ba: observation %d has a bad index", k);
-        if (p.obs_pt[k] >= pt_lo && p.obs_pt[k] < pt_hi) keep.push_back(k);
+    HostPool& HP = HostPool::get();
+    const bool par = !DI && p.n_obs >= 200000 && HP.size() > 1;      // the same tables either way; see HostPool
+    std::vector<int> keep;
+    if (par) {
+        std::vector<int> bad(HP.size(), -1), cntk(HP.size() + 1, 0);
+        HP.chunks((size_t)p.n_obs, [&](size_t lo, size_t hi, int t) { int c = 0; for (size_t k = lo; k < hi; k++) {
+            if (p.obs_cam[k] < 0 || p.obs_cam[k] >= p.n_cam || p.obs_pt[k] < 0 || p.obs_pt[k] >= p.n_pt) { if (bad[t] < 0) bad[t] = (int)k; continue; }
+            if (p.obs_pt[k] >= pt_lo && p.obs_pt[k] < pt_hi) c++; } cntk[t + 1] = c; });
+        for (int t = 0; t < HP.size(); t++) { if (bad[t] >= 0) return vido_set_error(ctx, VIDO_E_INVALID, "ba: observation %d has a bad index", bad[t]); cntk[t + 1] += cntk[t]; }
+        keep.resize(cntk[HP.size()]);
+        HP.chunks((size_t)p.n_obs, [&](size_t lo, size_t hi, int t) { int w = cntk[t]; for (size_t k = lo; k < hi; k++) if (p.obs_pt[k] >= pt_lo && p.obs_pt[k] < pt_hi) keep[w++] = (int)k; });
+    } else {
+        keep.reserve(p.n_obs);
+        for (int k = 0; k < p.n_obs; k++) {
+            if (p.obs_cam[k] < 0 || p.obs_cam[k] >= p.n_cam || p.obs_pt[k] < 0 || p.obs_pt[k] >= p.n_pt) return vido_set_error(ctx, VIDO_E_INVALID, "ba: observation %d has a bad index", k);
+            if (p.obs_pt[k] >= pt_lo && p.obs_pt[k] < pt_hi) keep.push_back(k);
+        }
     }
     const int no = DI ? DI->no : (int)keep.size();
     if (!DI) {   // stable counting sort by camera (O(n); a comparison sort of 1M observations costs more than the whole LM loop)
-        std::vector<int> cstart(n_pose + 1, 0), sorted(no);
-        for (int t = 0; t < no; t++) cstart[perm[p.obs_cam[keep[t]]] + 1]++;
-        for (int c = 0; c < n_pose; c++) cstart[c + 1] += cstart[c];
-        for (int t = 0; t < no; t++) sorted[cstart[perm[p.obs_cam[keep[t]]]]++] = keep[t];
+        std::vector<int> sorted(no);
+        if (par) {
+            std::vector<int> rank(no), bs;
+            par_counting_rank(HP, (size_t)no, n_pose, [&](size_t t) { return perm[p.obs_cam[keep[t]]]; }, rank.data(), bs);
+            HP.chunks((size_t)no, [&](size_t lo, size_t hi, int) { for (size_t t = lo; t < hi; t++) sorted[rank[t]] = keep[t]; });
+        } else {
+            std::vector<int> cstart(n_pose + 1, 0);
+            for (int t = 0; t < no; t++) cstart[perm[p.obs_cam[keep[t]]] + 1]++;
+            for (int c = 0; c < n_pose; c++) cstart[c + 1] += cstart[c];
+            for (int t = 0; t < no; t++) sorted[cstart[perm[p.obs_cam[keep[t]]]]++] = keep[t];
+        }
         keep.swap(sorted);
     }
+    phase("filter + sort by camera");
     const int nh = DI ? 0 : no;                              // host-side observation arrays (none when the inputs are device-resident)
     std::vector<int> ocam(nh), opt(nh), opos(nh), pstart(n_ptl + 1, 0), slotcam(nh);
     std::vector<double> omeas((size_t)nh * 3);
-    for (int t = 0; t < nh; t++) { const int k = keep[t]; ocam[t] = perm[p.obs_cam[k]]; opt[t] = p.obs_pt[k] - pt_lo; for (int a = 0; a < 3; a++) omeas[3 * (size_t)t + a] = p.obs_meas[3 * (size_t)k + a]; pstart[opt[t] + 1]++; }
     int maxk = 0;
-    for (int l = 0; l < n_ptl; l++) { maxk = std::max(maxk, pstart[l + 1]); pstart[l + 1] += pstart[l]; }
-    { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (int t = 0; t < nh; t++) { opos[t] = fill[opt[t]]++; slotcam[opos[t]] = ocam[t]; } }
+    if (par) {
+        HP.chunks((size_t)nh, [&](size_t lo, size_t hi, int) { for (size_t t = lo; t < hi; t++) { const int k = keep[t]; ocam[t] = perm[p.obs_cam[k]]; opt[t] = p.obs_pt[k] - pt_lo;
+                                                                 for (int a = 0; a < 3; a++) omeas[3 * t + a] = p.obs_meas[3 * (size_t)k + a]; } });
+        // the slots of a landmark in ascending camera order = the stable order of the camera-sorted list by landmark
+        par_counting_rank(HP, (size_t)nh, n_ptl, [&](size_t t) { return opt[t]; }, opos.data(), pstart);
+        HP.chunks((size_t)nh, [&](size_t lo, size_t hi, int) { for (size_t t = lo; t < hi; t++) slotcam[opos[t]] = ocam[t]; });
+        std::vector<int> mk(HP.size(), 0);
+        HP.chunks((size_t)n_ptl, [&](size_t lo, size_t hi, int t) { int m = 0; for (size_t l = lo; l < hi; l++) m = std::max(m, pstart[l + 1] - pstart[l]); mk[t] = m; });
+        for (int m : mk) maxk = std::max(maxk, m);
+    } else {
+        for (int t = 0; t < nh; t++) { const int k = keep[t]; ocam[t] = perm[p.obs_cam[k]]; opt[t] = p.obs_pt[k] - pt_lo; for (int a = 0; a < 3; a++) omeas[3 * (size_t)t + a] = p.obs_meas[3 * (size_t)k + a]; pstart[opt[t] + 1]++; }
+        for (int l = 0; l < n_ptl; l++) { maxk = std::max(maxk, pstart[l + 1]); pstart[l + 1] += pstart[l]; }
+        { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (int t = 0; t < nh; t++) { opos[t] = fill[opt[t]]++; slotcam[opos[t]] = ocam[t]; } }
+    }
     if (DI) maxk = DI->kcap;                                 // (a landmark of the window has at most one observation per keyframe)
     // the Schur kernels add WD_i W_j^T for slot pairs i >= j into the LOWER triangle and assume the slots of a landmark belong to distinct cameras (for two
     // slots of one camera the transposed term would be missing); the observations are sorted by camera, so duplicates are adjacent slots
-    if (!DI) for (int l = 0; l < n_ptl; l++) for (int q = pstart[l] + 1; q < pstart[l + 1]; q++)
-        if (slotcam[q] == slotcam[q - 1]) return vido_set_error(ctx, VIDO_E_INVALID, "ba: landmark %d is observed twice from camera %d (merge duplicate observations first)", l + pt_lo, slotcam[q]);
     std::vector<int> long_list;                             // landmarks with more than 64 observations: k_ba_schur_long
-    if (!DI) for (int l = 0; l < n_ptl; l++) if (pstart[l + 1] - pstart[l] > 64) long_list.push_back(l);
+    if (!DI) {
+        std::vector<int> dup(HP.size(), -1); std::vector<std::vector<int> > longs(HP.size());
+        auto scan = [&](size_t lo, size_t hi, int t) { for (size_t l = lo; l < hi; l++) {
+            for (int q = pstart[l] + 1; q < pstart[l + 1]; q++) if (slotcam[q] == slotcam[q - 1] && dup[t] < 0) dup[t] = (int)l;
+            if (pstart[l + 1] - pstart[l] > 64) longs[t].push_back((int)l); } };
+        if (par) HP.chunks((size_t)n_ptl, scan); else scan(0, (size_t)n_ptl, 0);
+        for (int t = 0; t < HP.size(); t++) if (dup[t] >= 0) { const int l = dup[t]; int q = pstart[l] + 1; while (slotcam[q] != slotcam[q - 1]) q++;
+            return vido_set_error(ctx, VIDO_E_INVALID, "ba: landmark %d is observed twice from camera %d (merge duplicate observations first)", l + pt_lo, slotcam[q]); }
+        for (auto& v : longs) long_list.insert(long_list.end(), v.begin(), v.end());
+    }
     maxk = std::min(maxk, 64);
+    phase("slot tables, checks");
     // ---- device buffers
     {   // size the persistent pool (device + pinned mirror for the uploads) for this problem
         const size_t ndb = (size_t)n_pose * (24 + 36 + 36) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + BA_REC) + (size_t)n_cc * (12 + 36 + 2) + (size_t)n6 * n6 + 5 * (size_t)n6 + 64 +
@@ -2434,6 +2536,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             HIP_TRY(ctx, hipHostMalloc((void**)&BS->h_pool, BS->hpool_cap));
         }
     }
+    phase("pool sizing");
     Arena A{BS->pool, BS->pool_cap, 0, false, BS->h_pool, BS->hpool_cap, 0};
     BaDev D{};
     D.n_cam = n_pose; D.n_pt = p.n_pt; D.n_obs = no; D.n_odo = owns_cam_factors ? n_cc : 0; D.prior_cam = (owns_cam_factors && p.prior_cam >= 0) ? perm[p.prior_cam] : -1;
@@ -2449,6 +2552,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     D.obs_cam = A.put(ocam.data(), no, st); D.obs_pt = A.put(opt.data(), no, st); D.obs_pos = A.put(opos.data(), no, st);
     D.obs_meas = A.put(omeas.data(), (size_t)no * 3, st); D.pt_start = A.put(pstart.data(), n_ptl + 1, st); D.slot_cam = A.put(slotcam.data(), no, st);
     }
+    phase("staging copies (obs, points)");
     D.odo_i = A.put(cc_i.data(), n_cc, st); D.odo_j = A.put(cc_j.data(), n_cc, st); D.odo_T = A.put(cc_T.data(), (size_t)n_cc * 12, st);
     D.odo_info = A.put(cc_info.data(), n_cc, st); D.odo_delta = A.put(cc_delta.data(), n_cc, st);
     D.W = A.get<double>((size_t)no * BA_REC); D.Cp = D.W + 18;      /* the arena hands out 256-byte aligned blocks: records are line-aligned */
@@ -2475,10 +2579,24 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     const bool lds_path = n6 <= BA_LDS_MAX_N6;
     D.bw = -1; D.ldb = n6;
     if (!lds_path) {
-        std::vector<int> cmin(p.n_pt, n_pose), cmax(p.n_pt, -1);
-        for (int k = 0; k < p.n_obs; k++) { const int l = p.obs_pt[k], c = perm[p.obs_cam[k]]; cmin[l] = std::min(cmin[l], c); cmax[l] = std::max(cmax[l], c); }   // ALL shards: every rank must pick the same layout
         int bwc = 0;
-        for (int l = 0; l < p.n_pt; l++) if (cmax[l] >= 0) bwc = std::max(bwc, cmax[l] - cmin[l]);
+        if (par && pt_lo == 0 && pt_hi == p.n_pt) {                // unsharded: the slot tables already hold every landmark's cameras in ascending order
+            std::vector<int> bw_t(HP.size(), 0);
+            HP.chunks((size_t)n_ptl, [&](size_t lo, size_t hi, int t) { int m = 0; for (size_t l = lo; l < hi; l++) if (pstart[l + 1] > pstart[l]) m = std::max(m, slotcam[pstart[l + 1] - 1] - slotcam[pstart[l]]); bw_t[t] = m; });
+            for (int m : bw_t) bwc = std::max(bwc, m);
+        } else if (par) {                                          // a shard: the layout must be the one every rank picks, so all observations count (per-thread tables, merged)
+            const int T = HP.size(); std::vector<int> cmn((size_t)T * p.n_pt, n_pose), cmx((size_t)T * p.n_pt, -1);
+            HP.chunks((size_t)p.n_obs, [&](size_t lo, size_t hi, int t) { int* a = cmn.data() + (size_t)t * p.n_pt; int* b2 = cmx.data() + (size_t)t * p.n_pt;
+                for (size_t k = lo; k < hi; k++) { const int l = p.obs_pt[k], c = perm[p.obs_cam[k]]; a[l] = std::min(a[l], c); b2[l] = std::max(b2[l], c); } });
+            std::vector<int> bw_t(T, 0);
+            HP.chunks((size_t)p.n_pt, [&](size_t lo, size_t hi, int t) { int m = 0; for (size_t l = lo; l < hi; l++) { int a = n_pose, b2 = -1;
+                for (int u = 0; u < T; u++) { a = std::min(a, cmn[(size_t)u * p.n_pt + l]); b2 = std::max(b2, cmx[(size_t)u * p.n_pt + l]); } if (b2 >= 0) m = std::max(m, b2 - a); } bw_t[t] = m; });
+            for (int m : bw_t) bwc = std::max(bwc, m);
+        } else {
+            std::vector<int> cmin(p.n_pt, n_pose), cmax(p.n_pt, -1);
+            for (int k = 0; k < p.n_obs; k++) { const int l = p.obs_pt[k], c = perm[p.obs_cam[k]]; cmin[l] = std::min(cmin[l], c); cmax[l] = std::max(cmax[l], c); }   // ALL shards: every rank must pick the same layout
+            for (int l = 0; l < p.n_pt; l++) if (cmax[l] >= 0) bwc = std::max(bwc, cmax[l] - cmin[l]);
+        }
         for (int k = 0; k < p.n_odo; k++) bwc = std::max(bwc, std::abs(perm[p.odo_i[k]] - perm[p.odo_j[k]]));
         if (dynp) {   // a dynamic tracklet couples every pose it touches with every other one (its point block is eliminated as a whole)
             for (int k = 0; k < dynp->n_smooth; k++) bwc = std::max(bwc, std::abs(perm[p.n_cam + dynp->sm_i[k]] - perm[p.n_cam + dynp->sm_j[k]]));
@@ -2553,7 +2671,9 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
       int o = 0; for (int q = 0; q < n_pose; q++) if (inv[q] >= 0) { pose_ord_h[q] = o; ord_pose_h[o] = q; o++; } }
     D.n_cam_ord = p.n_cam; D.pose_ord = A.put(pose_ord_h.data(), n_pose, st); D.ord_pose = A.put(ord_pose_h.data(), p.n_cam, st);
     if (DI) D.slot_ord = DI->slot_cam;                      // (no object motions in the local window: the camera ordinal IS the pose index)
-    else { std::vector<int> so(no); for (int t = 0; t < no; t++) so[t] = pose_ord_h[slotcam[t]]; D.slot_ord = A.put(so.data(), no, st); }
+    else { std::vector<int> so(no);
+           if (par) HP.chunks((size_t)no, [&](size_t lo, size_t hi, int) { for (size_t t = lo; t < hi; t++) so[t] = pose_ord_h[slotcam[t]]; }); else for (int t = 0; t < no; t++) so[t] = pose_ord_h[slotcam[t]];
+           D.slot_ord = A.put(so.data(), no, st); }
     int* d_chunk_cmin = nullptr; int* d_lorder = nullptr; int2* d_lbc = nullptr; int n_chunks = (n_ptl + BA_CHUNK - 1) / BA_CHUNK; bool use_mfma_schur = false;
     if (!lds_path && n_ptl) {
         std::vector<int> lorder(n_ptl);
@@ -2572,13 +2692,15 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
           if (use_mfma_schur) {      // k_ba_schur_mfma takes the landmarks whose cameras all fall inside their chunk's window; the others (and tracks > 64) go to k_ba_schur_long
               std::vector<char> is_long(n_ptl, 0); for (int l : long_list) is_long[l] = 1;
               std::vector<int> outside;                                  // positions q whose landmark leaves its chunk's window (loop closures, revisits, long gaps)
-              for (int q = 0; q < n_ptl; q++) {
+              { std::vector<std::vector<int> > outs(HP.size());
+                auto scan_q = [&](size_t qlo, size_t qhi, int t) { for (size_t q = qlo; q < qhi; q++) {
                   const int l = lorder[q], cnt = pstart[l + 1] - pstart[l]; if (!cnt) continue;
                   const int cb = cmin[q / BA_CHUNK], lo = pose_ord_h[slotcam[pstart[l]]], hi = pose_ord_h[slotcam[pstart[l + 1] - 1]];
                   bool out = cnt > 64 || lo < cb || hi >= cb + BA_WC || lo < 0 || hi < 0;
                   for (int t2 = pstart[l]; t2 < pstart[l + 1] && !out; t2++) { const int o = pose_ord_h[slotcam[t2]]; out = o < cb || o >= cb + BA_WC; }
-                  if (out) outside.push_back(q);
-              }
+                  if (out) outs[t].push_back((int)q); } };
+                if (par) HP.chunks((size_t)n_ptl, scan_q); else scan_q(0, (size_t)n_ptl, 0);
+                for (auto& v : outs) outside.insert(outside.end(), v.begin(), v.end()); }
               // k_ba_schur_long is one workgroup and O(36 k^2) HBM atomics per landmark: right for the rare track of > 64 keyframes, a cliff when a map with many revisits
               // sends a sizeable share of its landmarks there.  Above 3 % the wave-per-landmark kernel takes the whole graph instead (it spills out-of-window pairs itself).
               const size_t n_out_short = outside.size() - std::min(outside.size(), long_list.size());
@@ -2589,6 +2711,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
           d_lbc = (int2*)A.put(bc.data(), 2 * (size_t)n_ptl, st); }
         if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device pool exhausted");
     }
+    phase("chunk order, window tables");
     const int n_long = (int)long_list.size();
     int* d_long = nullptr;
     if (n_long) {      // rare: its own small allocation instead of a slice of the arena (whose size estimate does not count it)
@@ -2627,6 +2750,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     };
     int rc;
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    phase("attributes, launch set-up");
     res->ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     const auto t_loop = std::chrono::steady_clock::now();
     double lambda = -1, ni = 2, lastChi = 0, chi2_check = 0, ms_lin = 0; int nBad = 0, trials = 0, it = 0, n_lin = 0;
