@@ -162,7 +162,9 @@ def convoy_scene(n_frames, w=640, h=480, seed=5, step=0.25):
     each about 110 px wide (>= 150 dense samples, depth < ThDepthOBJ)."""
     objs = ((-4.4, 0.55, 8.0, -0.004, 0.0, step + 0.010), (-2.2, 0.55, 9.5, -0.006, 0.0, step + 0.020), (0.0, 0.55, 11.0, 0.004, 0.0, step + 0.000),
             (2.2, 0.55, 9.5, 0.006, 0.0, step + 0.015), (4.4, 0.55, 8.0, 0.004, 0.0, step + 0.005))
-    return Scene3D(n_frames=n_frames, w=w, h=h, seed=seed, step=step, yaw_deg=0.05, objects=objs, obj_half=0.9, wall_z=48.0)
+    # the far wall stays ahead of the camera for the whole clip (48 m for clips of up to 128 frames — the default bench — and 16 m beyond the end of longer ones: a 200-step run used
+    # to drive through it at frame 192 and finish on a scene without structure)
+    return Scene3D(n_frames=n_frames, w=w, h=h, seed=seed, step=step, yaw_deg=0.05, objects=objs, obj_half=0.9, wall_z=max(48.0, n_frames * step + 16.0))
 
 
 def gray_to_bgr(gray):
