@@ -125,12 +125,20 @@ __global__ __launch_bounds__(1024) void k_bawin_assemble(BaWinDev W, int start, 
         run += tot;
     }
     if (tid == 0) W.pt_start[n_pt] = run;
-    __syncthreads();
-    for (int k = tid; k < n_obs; k += 1024) { const int p = W.obs_pt[k], sl = W.pt_start[p] + (W.obs_cam[k] - W.first[p]); W.obs_pos[k] = sl; W.slot_cam[sl] = W.obs_cam[k]; }
+    // (obs_pos / slot_cam: k_bawin_slots, all CUs — 35 dependent three-load trips per thread of this one workgroup were 60 of its 160 us)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { maxk = max(maxk, __shfl_xor(maxk, o, 64)); overflow |= __shfl_xor(overflow, o, 64); }
     if ((tid & 63) == 0) { atomicMax(&counts[3], maxk); if (overflow) counts[2] = 1; }
     if (tid == 0) { counts[0] = n_obs; counts[1] = n_pt; if (run != n_obs) counts[2] = 1; }
+}
+
+// slot of an observation = pt_start[landmark] + (camera - first camera of the landmark); counts[0] = number of observations (written by k_bawin_assemble)
+__global__ __launch_bounds__(256) void k_bawin_slots(BaWinDev W, const int* __restrict__ counts)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= counts[0]) return;
+    const int p = W.obs_pt[k], c = W.obs_cam[k], sl = W.pt_start[p] + (c - W.first[p]);
+    W.obs_pos[k] = sl; W.slot_cam[sl] = c;
 }
 
 // Optimizer.cc:1130-1160: the refined landmark goes into every observation slot of the window (float, like the Map's cv::Mat 3x1 CV_32F)
@@ -247,9 +255,10 @@ int vido_bawin_solve(vido_ctx* ctx, int start, int N, vido_ba_problem* prob, vid
     BaWinDev W{B->cap_f, B->cap_n, B->cap_obs, B->cap_pt, B->d_meas, B->d_xyz, B->d_asso, B->d_trk, B->d_pos, B->d_pid, B->d_nfeat,
                B->d_obs_cam, B->d_obs_pt, B->d_obs_pos, B->d_obs_src, B->d_pt_start, B->d_slot_cam, B->d_cnt, B->d_first, B->d_obs_meas, B->d_pt};
     HIP_TRY(ctx, hipMemsetAsync(B->d_counts, 0, 16, st));
-    { size_t tot = 0; for (int f = start; f < N; f++) tot += (size_t)B->nfeat[f % B->cap_f];      // an upper bound of the landmark count: every feature of the window
-      HIP_TRY(ctx, hipMemsetAsync(B->d_cnt, 0, std::min(tot, (size_t)B->cap_pt) * sizeof(int), st)); }
+    size_t n_feat_window = 0; for (int f = start; f < N; f++) n_feat_window += (size_t)B->nfeat[f % B->cap_f];      // an upper bound of the landmark / observation counts
+    HIP_TRY(ctx, hipMemsetAsync(B->d_cnt, 0, std::min(n_feat_window, (size_t)B->cap_pt) * sizeof(int), st));
     hipLaunchKernelGGL(k_bawin_assemble, dim3(1), dim3(1024), 0, st, W, start, N, B->d_counts);
+    hipLaunchKernelGGL(k_bawin_slots, dim3((unsigned)std::max<size_t>(1, (std::min(n_feat_window, (size_t)B->cap_obs) + 255) / 256)), dim3(256), 0, st, W, (const int*)B->d_counts);
     HIP_TRY(ctx, hipMemcpyAsync(B->h_counts, B->d_counts, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     const int no = B->h_counts[0], np = B->h_counts[1];

@@ -24,6 +24,9 @@ __device__ void sample4(uint64_t seed, int it, int n, int idx[4])
         if (!dup) idx[k++] = c;
     }
 }
+// Real roots of c[4] z^4 + ... + c[0] by Durand-Kerner (Gauss-Seidel order) + two Newton steps; root k is valid when bit k of the returned mask is set (the roots keep
+// their positions: every index below is a compile-time constant, so zr / zi / roots live in registers — with a compacting `roots[n++]` and rolled loops the arrays went to
+// scratch memory and every access of the 100-iteration loop was a memory operation: 139 us per launch of k_pnp_solve)
 __device__ int quartic_real_roots(const double* c, double* roots)
 {
     if (fabs(c[4]) < 1e-300) return 0;
@@ -31,6 +34,7 @@ __device__ int quartic_real_roots(const double* c, double* roots)
     double zr[4] = {1.0, 0.4, -0.65, -0.2755}, zi[4] = {0.0, 0.9, 0.72, -0.9602};
     for (int it = 0; it < 100; it++) {
         double maxd = 0;
+#pragma unroll
         for (int k = 0; k < 4; k++) {
             double pr = 1, pi = 0, tr, ti;
             tr = pr * zr[k] - pi * zi[k] + a3; ti = pr * zi[k] + pi * zr[k]; pr = tr; pi = ti;
@@ -38,79 +42,36 @@ __device__ int quartic_real_roots(const double* c, double* roots)
             tr = pr * zr[k] - pi * zi[k] + a1; ti = pr * zi[k] + pi * zr[k]; pr = tr; pi = ti;
             tr = pr * zr[k] - pi * zi[k] + a0; ti = pr * zi[k] + pi * zr[k]; pr = tr; pi = ti;
             double qr = 1, qi = 0;
+#pragma unroll
             for (int j = 0; j < 4; j++) if (j != k) { const double dr = zr[k] - zr[j], di = zi[k] - zi[j]; tr = qr * dr - qi * di; ti = qr * di + qi * dr; qr = tr; qi = ti; }
             const double den = qr * qr + qi * qi;
-            if (den < 1e-300) continue;
-            const double dr = (pr * qr + pi * qi) / den, di = (pi * qr - pr * qi) / den;
-            zr[k] -= dr; zi[k] -= di;
-            if (fabs(dr) + fabs(di) > maxd) maxd = fabs(dr) + fabs(di);
+            if (!(den < 1e-300)) {
+                const double dr = (pr * qr + pi * qi) / den, di = (pi * qr - pr * qi) / den;
+                zr[k] -= dr; zi[k] -= di;
+                if (fabs(dr) + fabs(di) > maxd) maxd = fabs(dr) + fabs(di);
+            }
         }
         if (maxd < 1e-14) break;
     }
-    int n = 0;
-    for (int k = 0; k < 4; k++) if (fabs(zi[k]) < 1e-7 * (1.0 + fabs(zr[k]))) {
+    int mask = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
         double v = zr[k];
+#pragma unroll
         for (int t = 0; t < 2; t++) {
             const double p = (((c[4] * v + c[3]) * v + c[2]) * v + c[1]) * v + c[0], dp = ((4 * c[4] * v + 3 * c[3]) * v + 2 * c[2]) * v + c[1];
             if (fabs(dp) > 1e-300) v -= p / dp;
         }
-        roots[n++] = v;
+        roots[k] = v;
+        if (fabs(zi[k]) < 1e-7 * (1.0 + fabs(zr[k]))) mask |= 1 << k;
     }
-    return n;
+    return mask;
 }
 __device__ inline void cross3(const double* a, const double* b, double* c) { c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0]; }
 __device__ inline double norm3(const double* a) { return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
 
 // Grunert P3P: with s2 = u s1, s3 = v s1 the three cosine-law equations give u = N(v)/D(v) and the quartic
 // D^2 + N^2 - 2 cos(gamma) N D - (c^2/b^2) Q D^2 = 0, Q = 1 + v^2 - 2 v cos(beta); poses from triangle alignment.
-__device__ int p3p(const double P[3][3], const double j[3][3], double R[4][9], double t[4][3])
-{
-    double d[3];
-    for (int k = 0; k < 3; k++) d[k] = P[1][k] - P[2][k]; const double a2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    for (int k = 0; k < 3; k++) d[k] = P[0][k] - P[2][k]; const double b2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    for (int k = 0; k < 3; k++) d[k] = P[0][k] - P[1][k]; const double c2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    if (a2 < 1e-20 || b2 < 1e-20 || c2 < 1e-20) return 0;
-    const double ca = j[1][0] * j[2][0] + j[1][1] * j[2][1] + j[1][2] * j[2][2];
-    const double cb = j[0][0] * j[2][0] + j[0][1] * j[2][1] + j[0][2] * j[2][2];
-    const double cg = j[0][0] * j[1][0] + j[0][1] * j[1][1] + j[0][2] * j[1][2];
-    const double K = (a2 - c2) / b2, M = c2 / b2;
-    const double N[3] = {1 + K, -2 * K * cb, K - 1}, D[2] = {2 * cg, -2 * ca}, Q[3] = {1, -2 * cb, 1};
-    const double D2[3] = {D[0] * D[0], 2 * D[0] * D[1], D[1] * D[1]};
-    double c[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < 3; i++) c[i] += D2[i];
-    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) c[i + k] += N[i] * N[k];
-    for (int i = 0; i < 3; i++) for (int k = 0; k < 2; k++) c[i + k] -= 2 * cg * N[i] * D[k];
-    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) c[i + k] -= M * Q[i] * D2[k];
-    double roots[4]; const int nr = quartic_real_roots(c, roots);
-    int ns = 0;
-    for (int r = 0; r < nr; r++) {
-        const double v = roots[r];
-        if (!(v > 0)) continue;
-        const double den = D[0] + D[1] * v;
-        if (fabs(den) < 1e-12) continue;
-        const double u = (N[0] + N[1] * v + N[2] * v * v) / den;
-        if (!(u > 0)) continue;
-        const double q = 1 + v * v - 2 * v * cb;
-        if (!(q > 0)) continue;
-        const double s1 = sqrt(b2 / q), s2 = u * s1, s3 = v * s1;
-        double C[3][3];
-        for (int k = 0; k < 3; k++) { C[0][k] = s1 * j[0][k]; C[1][k] = s2 * j[1][k]; C[2][k] = s3 * j[2][k]; }
-        double p1[3], p2[3], e1[3], e2[3], e3[3], f1[3], f2[3], f3[3], q1[3], q2[3];
-        for (int k = 0; k < 3; k++) { p1[k] = P[1][k] - P[0][k]; p2[k] = P[2][k] - P[0][k]; q1[k] = C[1][k] - C[0][k]; q2[k] = C[2][k] - C[0][k]; }
-        const double n1 = norm3(p1), m1 = norm3(q1);
-        if (n1 < 1e-12 || m1 < 1e-12) continue;
-        for (int k = 0; k < 3; k++) { e1[k] = p1[k] / n1; f1[k] = q1[k] / m1; }
-        cross3(e1, p2, e3); cross3(f1, q2, f3);
-        const double n3 = norm3(e3), m3 = norm3(f3);
-        if (n3 < 1e-12 || m3 < 1e-12) continue;
-        for (int k = 0; k < 3; k++) { e3[k] /= n3; f3[k] /= m3; }
-        cross3(e3, e1, e2); cross3(f3, f1, f2);
-        for (int rr = 0; rr < 3; rr++) for (int cc = 0; cc < 3; cc++) R[ns][rr * 3 + cc] = f1[rr] * e1[cc] + f2[rr] * e2[cc] + f3[rr] * e3[cc];
-        for (int rr = 0; rr < 3; rr++) t[ns][rr] = C[0][rr] - (R[ns][rr * 3] * P[0][0] + R[ns][rr * 3 + 1] * P[0][1] + R[ns][rr * 3 + 2] * P[0][2]);
-        ns++;
-    }
-    return ns;
-}
 __device__ inline double reproj2(const double* R, const double* t, const float* X, const float* x, double fx, double fy, double cx, double cy)
 {
     const double xc = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0], yc = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1], zc = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
@@ -119,6 +80,82 @@ __device__ inline double reproj2(const double* R, const double* t, const float* 
     return du * du + dv * dv;
 }
 
+// Grunert P3P + the choice among its solutions by a fourth correspondence (X4, x4): true and (R, t) = the solution with the smallest reprojection error of the fourth point
+// (the first one on ties, in root order), false when the triple has no admissible solution.  One solution is alive at a time, everything has compile-time indices.
+__device__ bool p3p_best(const double P[3][3], const double j[3][3], const float* X4, const float* x4, double fx, double fy, double cx, double cy, double Rb[9], double tb[3])
+{
+    double d[3];
+    for (int k = 0; k < 3; k++) d[k] = P[1][k] - P[2][k]; const double a2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    for (int k = 0; k < 3; k++) d[k] = P[0][k] - P[2][k]; const double b2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    for (int k = 0; k < 3; k++) d[k] = P[0][k] - P[1][k]; const double c2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    if (a2 < 1e-20 || b2 < 1e-20 || c2 < 1e-20) return false;
+    const double ca = j[1][0] * j[2][0] + j[1][1] * j[2][1] + j[1][2] * j[2][2];
+    const double cb = j[0][0] * j[2][0] + j[0][1] * j[2][1] + j[0][2] * j[2][2];
+    const double cg = j[0][0] * j[1][0] + j[0][1] * j[1][1] + j[0][2] * j[1][2];
+    const double K = (a2 - c2) / b2, M = c2 / b2;
+    const double N[3] = {1 + K, -2 * K * cb, K - 1}, D[2] = {2 * cg, -2 * ca}, Q[3] = {1, -2 * cb, 1};
+    const double D2[3] = {D[0] * D[0], 2 * D[0] * D[1], D[1] * D[1]};
+    double c[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 3; i++) c[i] += D2[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) c[i + k] += N[i] * N[k];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) c[i + k] -= 2 * cg * N[i] * D[k];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) c[i + k] -= M * Q[i] * D2[k];
+    double roots[4]; const int mask = quartic_real_roots(c, roots);
+    bool found = false; double be = 1e300;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        bool ok = (mask >> r) & 1;
+        const double v = roots[r];
+        ok = ok && v > 0;
+        const double den = D[0] + D[1] * v;
+        ok = ok && !(fabs(den) < 1e-12);
+        const double u = (N[0] + N[1] * v + N[2] * v * v) / den;
+        ok = ok && u > 0;
+        const double q = 1 + v * v - 2 * v * cb;
+        ok = ok && q > 0;
+        if (!ok) continue;
+        const double s1 = sqrt(b2 / q), s2 = u * s1, s3 = v * s1;
+        double C0[3], p1[3], p2[3], e1[3], e2[3], e3[3], f1[3], f2[3], f3[3], q1[3], q2[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { C0[k] = s1 * j[0][k]; const double C1 = s2 * j[1][k], C2 = s3 * j[2][k]; p1[k] = P[1][k] - P[0][k]; p2[k] = P[2][k] - P[0][k]; q1[k] = C1 - C0[k]; q2[k] = C2 - C0[k]; }
+        const double n1 = norm3(p1), m1 = norm3(q1);
+        if (n1 < 1e-12 || m1 < 1e-12) continue;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { e1[k] = p1[k] / n1; f1[k] = q1[k] / m1; }
+        cross3(e1, p2, e3); cross3(f1, q2, f3);
+        const double n3 = norm3(e3), m3 = norm3(f3);
+        if (n3 < 1e-12 || m3 < 1e-12) continue;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { e3[k] /= n3; f3[k] /= m3; }
+        cross3(e3, e1, e2); cross3(f3, f1, f2);
+        double Rk[9], tk[3];
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) Rk[rr * 3 + cc] = f1[rr] * e1[cc] + f2[rr] * e2[cc] + f3[rr] * e3[cc];
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) tk[rr] = C0[rr] - (Rk[rr * 3] * P[0][0] + Rk[rr * 3 + 1] * P[0][1] + Rk[rr * 3 + 2] * P[0][2]);
+        const double e = reproj2(Rk, tk, X4, x4, fx, fy, cx, cy);
+        if (e < be) {
+            be = e; found = true;
+#pragma unroll
+            for (int k = 0; k < 9; k++) Rb[k] = Rk[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) tb[k] = tk[k];
+        }
+    }
+    return found;
+}
 // problem p owns points [off, off + n) of the concatenated arrays
 struct PnpProb { int off, n; unsigned long long seed; };
 // Phase 1 (round 3: split off the scoring): ONE THREAD per (hypothesis, problem) samples its four points, solves Grunert's quartic and picks the solution the 4th point agrees
@@ -140,13 +177,13 @@ __global__ __launch_bounds__(64) void k_pnp_solve(const float* __restrict__ Xall
         const double bx = (x[2 * idx[k]] - cx) / fx, by = (x[2 * idx[k] + 1] - cy) / fy, nn = sqrt(bx * bx + by * by + 1);
         j[k][0] = bx / nn; j[k][1] = by / nn; j[k][2] = 1 / nn;
     }
-    double Rs[4][9], ts[4][3];
-    const int ns = p3p(P, j, Rs, ts);
-    int best = -1; double be = 1e300;
-    for (int s2 = 0; s2 < ns; s2++) { const double e = reproj2(Rs[s2], ts[s2], X + 3 * idx[3], x + 2 * idx[3], fx, fy, cx, cy); if (e < be) { be = e; best = s2; } }
-    *has = best >= 0;
-    for (int k = 0; k < 9; k++) m[k] = best >= 0 ? Rs[best][k] : 0.0;
-    for (int k = 0; k < 3; k++) m[9 + k] = best >= 0 ? ts[best][k] : 0.0;
+    double Rb[9], tb[3];
+    const bool ok = p3p_best(P, j, X + 3 * idx[3], x + 2 * idx[3], fx, fy, cx, cy, Rb, tb);
+    *has = ok;
+#pragma unroll
+    for (int k = 0; k < 9; k++) m[k] = ok ? Rb[k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) m[9 + k] = ok ? tb[k] : 0.0;
 }
 // Phase 2: inlier counts.  A workgroup scores PNP_H hypotheses of one problem: every thread loads its points once and evaluates them against all PNP_H models (LDS).
 #define PNP_H 4
