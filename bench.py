@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="serial chain: networks of frame k, then tracking of frame k")
     ap.add_argument("--no-graphs", action="store_true"); ap.add_argument("--no-fold", action="store_true"); ap.add_argument("--no-streams", action="store_true", help="(default) the three networks share one stream")
     ap.add_argument("--streams", action="store_true", help="one stream per network: measured SLOWER (23.6 vs 21.2 ms per frame for the three networks: their kernels each fill the GPU and evict each other's L2)")
+    ap.add_argument("--depth-stream", action="store_true", help="MonoDepth2 alone on a side stream next to LiteFlowNet / the detector (experiment)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen measures its solvers once per layer shape)")
     ap.add_argument("--batch", type=int, default=64, help="frames in flight of the configs[1] batched leg")
     ap.add_argument("--cpu-baseline", type=int, default=2, help="frames of the CPU-baseline sample (0 = skip)")
@@ -137,7 +138,7 @@ def main():
     write_settings(cfg_path, scene.K, W, H)
     net_ctx = V.Context(device=local_rank, width=W, height=H, max_batch=1)             # owns the HIP ops of the network nodes (correlation, ROI-Align, NMS ...)
     t_setup = time.perf_counter()
-    nodes = pipeline.NetNodes(net_ctx, H, W, optimize=not args.no_fold, graphs=not args.no_graphs, streams=args.streams, miopen_find=args.miopen_find, calibrate_scores=not args.saturated_detector,
+    nodes = pipeline.NetNodes(net_ctx, H, W, optimize=not args.no_fold, graphs=not args.no_graphs, streams=("depth" if args.depth_stream else args.streams), miopen_find=args.miopen_find, calibrate_scores=not args.saturated_detector,
                               static_detector=not args.saturated_detector)      # saturated scores tie at the detections_per_img cut on every frame: the fixed-slot head would fall back every time
     t_setup = time.perf_counter() - t_setup
     slam = System(); slam.Init(cfg_path, System.RGBD)
@@ -227,7 +228,7 @@ def main():
                                         "handed the renderer's exact flow/depth/mask of the same frame (feed=given; uploaded next to the BGR frame) once the networks of that frame have completed",
                    "prologue_frames": args.prologue, "parallelism": "replicas x%d (per-frame path does not shard)" % world,
                    "net_optimisations": {"frozen_bn_folded_pairs": nodes.folded, "hip_graphs": nodes.g_flow is not None, "graph_error": nodes.graph_error,
-                                         "network_streams": 3 if nodes.streams is not None else 1, "detector_one_graph": nodes.g_det is not None, "detector_overflow_frames": nodes.det_overflows, "detector_score_calibration": round(nodes.score_scale, 6), "miopen_find": bool(args.miopen_find)},
+                                         "network_streams": (1 if nodes.streams is None else len({id(x) for x in nodes.streams if x is not None}) + (1 if any(x is None for x in nodes.streams) else 0)), "detector_one_graph": nodes.g_det is not None, "detector_overflow_frames": nodes.det_overflows, "detector_score_calibration": round(nodes.score_scale, 6), "miopen_find": bool(args.miopen_find)},
                    "inputs": "BGR u8 frames in pinned host memory, one upload per frame; " + ("flow f32x2 / depth f32 / mask i32 handed to System::TrackRGBDDevice as device pointers (no map crosses PCIe)"
                                                                                                 if args.handover == "device" else "flow f32x2 / depth f32 / mask i32 copied to pinned host buffers and handed to TrackRGBD")},
         "stage_ms": {k: round(v, 3) for k, v in stage.items()},

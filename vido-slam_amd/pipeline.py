@@ -149,7 +149,9 @@ class NetNodes:
         self.folded = 0
         if optimize:
             self.folded = _nets.fold_batchnorm(self.depth_net, ops) + _nets.fold_batchnorm(self.mask_net, ops)
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(3)] if streams else None
+        # streams: False = the three networks back to back on the caller's stream; True = one stream each; "depth" = MonoDepth2 alone on a side stream (its ~120 launches of a
+        # few microseconds leave most CUs idle: next to the detector's convolutions they cost next to nothing, while three full networks side by side evict each other's L2 sets)
+        self.streams = ([None, torch.cuda.Stream(device=dev), None] if streams == "depth" else [torch.cuda.Stream(device=dev) for _ in range(3)]) if streams else None
         self.g_flow = self.g_depth = self.g_trunk = self.g_det = None
         self.graph_error = None
         self.last_counts = None
@@ -199,7 +201,7 @@ class NetNodes:
         """prev_bgr / cur_bgr: u8 HxWx3 device tensors.  Returns (flow HxWx2 f32, depth HxW f32, mask HxW i32, labels, events): the outputs are
         complete once the three events have fired (event.synchronize(), or stream.wait_event from a consumer stream)."""
         cur = torch.cuda.current_stream()
-        ss = self.streams or [cur, cur, cur]
+        ss = [s or cur for s in self.streams] if self.streams else [cur, cur, cur]
         for s in ss:
             if s is not cur:
                 s.wait_stream(cur)
