@@ -65,8 +65,8 @@ def main():
     ap.add_argument("--handover", choices=("device", "host"), default="device", help="network -> tracker hand-over: device-resident (default: one BGR upload per frame, no map crosses PCIe) or round 2's pinned-host round trip")
     ap.add_argument("--no-pipeline", action="store_true", help="serial chain: networks of frame k, then tracking of frame k")
     ap.add_argument("--no-graphs", action="store_true"); ap.add_argument("--no-fold", action="store_true"); ap.add_argument("--no-streams", action="store_true", help="(default) the three networks share one stream")
-    ap.add_argument("--streams", action="store_true", help="one stream per network: measured SLOWER (23.6 vs 21.2 ms per frame for the three networks: their kernels each fill the GPU and evict each other's L2)")
-    ap.add_argument("--depth-stream", action="store_true", help="MonoDepth2 alone on a side stream next to LiteFlowNet / the detector (experiment)")
+    ap.add_argument("--streams", action="store_true", help="one stream per network (round 3: 69.5 frames/s; round 2 measured this slower than back to back, when the detector head still synchronised the host)")
+    ap.add_argument("--net-streams", default="flow+depth", help="which networks leave the main stream: \"flow+depth\" (default: LiteFlowNet and MonoDepth2 share ONE side stream next to the detector: measured 72.5 frames/s against 59.6 with everything back to back), \"none\", \"depth\", \"flow\", \"det\", \"flow,depth\" (one side stream each: 52.7)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen measures its solvers once per layer shape)")
     ap.add_argument("--batch", type=int, default=64, help="frames in flight of the configs[1] batched leg")
     ap.add_argument("--cpu-baseline", type=int, default=2, help="frames of the CPU-baseline sample (0 = skip)")
@@ -138,7 +138,7 @@ def main():
     write_settings(cfg_path, scene.K, W, H)
     net_ctx = V.Context(device=local_rank, width=W, height=H, max_batch=1)             # owns the HIP ops of the network nodes (correlation, ROI-Align, NMS ...)
     t_setup = time.perf_counter()
-    nodes = pipeline.NetNodes(net_ctx, H, W, optimize=not args.no_fold, graphs=not args.no_graphs, streams=("depth" if args.depth_stream else args.streams), miopen_find=args.miopen_find, calibrate_scores=not args.saturated_detector,
+    nodes = pipeline.NetNodes(net_ctx, H, W, optimize=not args.no_fold, graphs=not args.no_graphs, streams=(True if args.streams else (False if args.net_streams in ("none", "") else args.net_streams)), miopen_find=args.miopen_find, calibrate_scores=not args.saturated_detector,
                               static_detector=not args.saturated_detector)      # saturated scores tie at the detections_per_img cut on every frame: the fixed-slot head would fall back every time
     t_setup = time.perf_counter() - t_setup
     slam = System(); slam.Init(cfg_path, System.RGBD)

@@ -113,14 +113,15 @@ _offer_miopen_db()
 
 class NetNodes:
     """The three network nodes (flow_net / mono_depth2 / mask_rcnn ROS services, run_vido.cc:142-157) resident on one device, fp32 like
-    the reference.  infer(prev_bgr, cur_bgr) enqueues the three forwards — on ONE stream by default: their convolutions each fill the GPU, and run on three
-    streams (streams=True) they evict each other's L2 working sets (measured 23.6 ms per frame for the three nodes against 21.2 ms back to back); what overlaps
-    with the networks is the tracker of the previous frame (EndToEnd) — and returns device tensors in the tracker's input types (run_vido.cc:28-37: depth MONO16 -> CV_32F,
+    the reference.  infer(prev_bgr, cur_bgr) enqueues the three forwards — the detector on the caller's stream, LiteFlowNet and MonoDepth2 back to back on ONE side stream
+    (streams="flow+depth", the default since round 3: with every network a graph and no host synchronisation left in the detector, the two chains fill each other's
+    small-kernel phases: 13.8 ms per frame against 16.8 ms with everything on one stream; a stream per network gives 14.4, LiteFlowNet and MonoDepth2 on a stream EACH 19.0;
+    round 2 had measured any overlap slower because its detector head still ran eagerly); the tracker of the previous frame overlaps with all of it (EndToEnd) — and returns device tensors in the tracker's input types (run_vido.cc:28-37: depth MONO16 -> CV_32F,
     mask MONO8 -> CV_32SC1, flow 32FC2).  optimize: frozen batch norms folded into the convolutions + fused HIP epilogues
     (nets/fuse.py); graphs: the static-shape parts (all of LiteFlowNet and MonoDepth2 incl. their resize wrappers, Mask R-CNN's backbone +
     FPN + RPN head) are captured into hipGraphs."""
 
-    def __init__(self, ctx, height=480, width=640, optimize=True, graphs=True, streams=False, miopen_find=False, seed=1,
+    def __init__(self, ctx, height=480, width=640, optimize=True, graphs=True, streams="flow+depth", miopen_find=False, seed=1,
                  mask_feed=(1088, 800), depth_feed=(192, 640), confidence=0.8, calibrate_scores=True, static_detector=True):
         self.ctx, self.h, self.w = ctx, height, width
         self.mask_feed, self.depth_feed, self.confidence = mask_feed, depth_feed, confidence
@@ -151,7 +152,14 @@ class NetNodes:
             self.folded = _nets.fold_batchnorm(self.depth_net, ops) + _nets.fold_batchnorm(self.mask_net, ops)
         # streams: False = the three networks back to back on the caller's stream; True = one stream each; "depth" = MonoDepth2 alone on a side stream (its ~120 launches of a
         # few microseconds leave most CUs idle: next to the detector's convolutions they cost next to nothing, while three full networks side by side evict each other's L2 sets)
-        self.streams = ([None, torch.cuda.Stream(device=dev), None] if streams == "depth" else [torch.cuda.Stream(device=dev) for _ in range(3)]) if streams else None
+        if isinstance(streams, str):                              # e.g. "depth", "flow", "flow+depth" (those networks share ONE side stream), "flow,depth" (a side stream each)
+            side = {}; self.streams = [None, None, None]
+            for grp in streams.split(","):
+                st_ = torch.cuda.Stream(device=dev)
+                for name in grp.split("+"):
+                    self.streams[{"flow": 0, "depth": 1, "det": 2}[name.strip()]] = st_
+        else:
+            self.streams = [torch.cuda.Stream(device=dev) for _ in range(3)] if streams else None
         self.g_flow = self.g_depth = self.g_trunk = self.g_det = None
         self.graph_error = None
         self.last_counts = None
