@@ -154,8 +154,9 @@ class NetNodes:
         # few microseconds leave most CUs idle: next to the detector's convolutions they cost next to nothing, while three full networks side by side evict each other's L2 sets)
         if isinstance(streams, str):                              # e.g. "depth", "flow", "flow+depth" (those networks share ONE side stream), "flow,depth" (a side stream each)
             side = {}; self.streams = [None, None, None]
-            for grp in streams.split(","):
-                st_ = torch.cuda.Stream(device=dev)
+            for grp in streams.split(","):                          # a trailing "!" puts the group's stream at high priority
+                hi = grp.endswith("!"); grp = grp.rstrip("!")
+                st_ = torch.cuda.Stream(device=dev, priority=-1 if hi else 0)
                 for name in grp.split("+"):
                     self.streams[{"flow": 0, "depth": 1, "det": 2}[name.strip()]] = st_
         else:
