@@ -6,4 +6,4 @@ ctx = V.Context(width=640, height=480, max_batch=1)
 gpr = V.problems.synth_ba_problem(n_cam=500, n_pt=100000, kind="global", track_len=10, seed=11); gpr["max_iters"] = 5
 V.ba_optimize(ctx, gpr)
 r = V.ba_optimize(ctx, gpr)
-print("iters", r["iterations"], "loop ms %.2f" % r["ms_solve_loop"])
+print("iters", r["iterations"], "loop ms %.2f" % r["ms_solve_loop"], "linearize us %.1f" % (1e3 * r.get("ms_linearize_kernel", 0.0)))
