@@ -181,3 +181,25 @@ def test_feed_nets_hand_over_contract_at_full_size(vido, oracle):
         assert np.array_equal(np.array(out["obj_depth"][0])[:n_obj], od) and np.array_equal(np.array(out["obj_flow"][0])[:n_obj], ofl)
         seen_obj += n_obj
         prev = cur
+
+
+def test_two_chain_schedule_returns_the_same_maps(vido):
+    """NetNodes(streams="flow+depth") — LiteFlowNet + MonoDepth2 on a side stream next to the detector, the default — against everything on the caller's stream: same flow,
+    depth and label image once the returned events have fired (the graphs are the same; only the queues differ)."""
+    from vido_slam_amd import pipeline, synth
+    scene = synth.convoy_scene(4)
+    fr = [torch.as_tensor(synth.gray_to_bgr(scene.frame(k)[0]), device="cuda") for k in range(3)]
+    outs = []
+    for mode in ("flow+depth", False):
+        nodes = pipeline.NetNodes(vido.Context(width=640, height=480, max_batch=1), 480, 640, streams=mode)
+        assert (nodes.streams is not None) == bool(mode)
+        res = []
+        for k in (1, 2):
+            flow, depth, mask, labels, evs = nodes.infer(fr[k - 1], fr[k])
+            for e in evs:
+                torch.cuda.current_stream().wait_event(e)
+            res.append((flow.clone(), depth.clone(), mask.clone()))
+        torch.cuda.synchronize(); outs.append(res)
+    for (fa, da, ma), (fb, db, mb) in zip(*outs):
+        assert float((fa - fb).abs().max()) < 1e-3 and float((da.float() - db.float()).abs().max()) <= 2.0      # (library GEMMs are not bit-reproducible; depth is a 16-bit integer scale)
+        assert float((ma != mb).float().mean()) < 1e-3
