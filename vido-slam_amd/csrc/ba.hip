@@ -360,14 +360,26 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev P, int n_ptl)
 }
 
 // S <- camera-camera part (+ lambda on the diagonal when add_lambda), r <- bc   (upper AND lower filled)
-__global__ __launch_bounds__(256) void k_ba_init_S(BaDev P, double lambda, int add_cam_part)
+// inline_odo (the dense LDS-path system of the local window, <= 64 camera-camera factors): the off-diagonal blocks of the factors are written here instead of by
+// k_ba_add_odo, and the trial's two scalar accumulators are cleared here instead of by a memset — two stream operations less per LM trial, each of which queues behind the
+// networks' workgroups when the tracker shares the GPU.  (An entry gets 0 + its factor's value either way: the same bits as the atomic add onto the initialised zero.)
+__global__ __launch_bounds__(256) void k_ba_init_S(BaDev P, double lambda, int add_cam_part, int inline_odo)
 {
     const int n6 = P.n6, ld = P.bw < 0 ? n6 : P.ldb;
     const size_t tot = (size_t)n6 * ld;
+    if (inline_odo && blockIdx.x == 0 && threadIdx.x < 2) P.scal[2 + threadIdx.x] = 0.0;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(t / ld), col = P.bw < 0 ? (int)(t % ld) : row - P.bw + (int)(t % ld);
         double v = 0;
         if (add_cam_part && col >= 0 && col < n6 && row / 6 == col / 6) { v = P.Hcd[36 * (row / 6) + (row % 6) * 6 + col % 6]; if (row == col) v += lambda; }
+        if (inline_odo && add_cam_part && row / 6 != col / 6) {
+            const int bi = row / 6, bj = col / 6, a = row % 6, b = col % 6;
+            for (int k = 0; k < P.n_odo; k++) {
+                const int i = P.odo_i[k], j = P.odo_j[k];
+                if (i == bi && j == bj) v += P.Hodo[36 * k + a * 6 + b];
+                if (j == bi && i == bj) v += P.Hodo[36 * k + b * 6 + a];
+            }
+        }
         P.S[t] = v;
     }
     for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < n6; a += gridDim.x * blockDim.x) P.r[a] = P.bc[a];
@@ -2792,9 +2804,10 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             // ---- reduced system of this shard.  With an all-reduce every rank contributes Hcd/bc ALREADY summed,
             // so only rank 0 adds the camera-camera part (+lambda) to S; the others start from zero.
             const int add_cam = (!allreduce || p.rank == 0) ? 1 : 0;
-            hipLaunchKernelGGL(k_ba_init_S, dim3(std::min(2048, (int)((sz_sr + 255) / 256))), dim3(256), 0, st, D, lambda, add_cam);
+            const int inline_odo = (lds_path && !allreduce && D.bw < 0 && D.n_odo <= 64) ? 1 : 0;
+            hipLaunchKernelGGL(k_ba_init_S, dim3(std::min(2048, (int)((sz_sr + 255) / 256))), dim3(256), 0, st, D, lambda, add_cam, inline_odo);
             if (!add_cam) HIP_TRY(ctx, hipMemsetAsync(D.r, 0, n6 * sizeof(double), st));
-            if (add_cam && D.n_odo) hipLaunchKernelGGL(k_ba_add_odo, dim3((D.n_odo * 36 + 255) / 256), dim3(256), 0, st, D);
+            if (add_cam && D.n_odo && !inline_odo) hipLaunchKernelGGL(k_ba_add_odo, dim3((D.n_odo * 36 + 255) / 256), dim3(256), 0, st, D);
             if (n_ptl) {
                 if (lds_path) {
                     hipLaunchKernelGGL(k_ba_schur<0>, dim3(schur_grid), dim3(64 * schur0_waves), lds_schur, st, D, n_ptl, lambda, kcap, BS->d_parts, (const int*)nullptr, (const int*)nullptr, (const int2*)nullptr);
@@ -2810,7 +2823,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             HIP_TRY(ctx, hipGetLastError());
             if ((rc = AR(Sr, sz_sr, 0))) return rc;
             // ---- replicated reduced solve
-            HIP_TRY(ctx, hipMemsetAsync(D.scal + 2, 0, 2 * sizeof(double), st));
+            if (!inline_odo) HIP_TRY(ctx, hipMemsetAsync(D.scal + 2, 0, 2 * sizeof(double), st));
             if (lds_path && n6 % 6 == 0 && n6 >= 12) hipLaunchKernelGGL(k_ba_chol_small6, dim3(1), dim3(CH_NT), lds_chol6, st, D);
             else if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
             else if (Bc.m) {                                   // block cyclic reduction: 2 launches per level, log2(nb) levels, then the levels back
