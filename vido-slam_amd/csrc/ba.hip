@@ -1529,7 +1529,29 @@ __global__ __launch_bounds__(CG_NT) void k_chol_band6s(BaDev P, int bwc /* block
 // Local-BA reduced solve (n6 <= 120, dense): the same pose-block scheme as k_chol_band6 on the whole matrix in LDS —
 // 20 block pivots instead of 120 scalar pivots.  (Factoring the pivot block redundantly on the three waves that use it is
 // faster than one wave + publish: the dependent FP64 chain is latency-bound and the copies run on different SIMDs.)
-__global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
+// trial pose of camera c: cam_new = cam (+) d (the step's six entries), returns the camera's part of computeScale
+__device__ double ba_update_cam(const BaDev& P, int c, const double* d, double lambda)
+{
+    const double* X = P.cam + 12 * c; double* N = P.cam_new + 12 * c;
+    double w = 1 - (d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (!(w < 0)) {
+        w = sqrt(w);
+        const double x = d[3], y = d[4], z = d[5];
+        R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+        R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+        R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+    }
+    for (int r = 0; r < 3; r++) {
+        for (int q = 0; q < 3; q++) N[r * 4 + q] = X[r * 4] * R[q] + X[r * 4 + 1] * R[3 + q] + X[r * 4 + 2] * R[6 + q];
+        N[r * 4 + 3] = X[r * 4] * d[0] + X[r * 4 + 1] * d[1] + X[r * 4 + 2] * d[2] + X[r * 4 + 3];
+    }
+    double sc = 0;
+    for (int a = 0; a < 6; a++) sc += d[a] * (lambda * d[a] + P.bc[6 * c + a]);
+    return sc;
+}
+
+__global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P, int fuse_update, double lambda)
 {
     extern __shared__ double cs6[];
     const int n = P.n6, nblk = n / 6, ldw = n + 1, tid = threadIdx.x;
@@ -1681,6 +1703,13 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P)
     CH_TICK(6)
     CH_PROF_PRINT("small6 [0 bar | 2 B1 | 3 bar | 4 A or B2 | 6 back]")
     if (tid == 0) P.scal[4] = ok ? 1.0 : 0.0;
+    // the trial poses, straight from the solution in LDS (k_ba_update_cams as the tail of this workgroup: one launch less per LM trial; <= 20 cameras here, one wave)
+    if (fuse_update && tid < 64) {
+        double sc = (ok && tid < P.n_cam) ? ba_update_cam(P, tid, rW + 6 * tid, lambda) : 0.0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o, 64);
+        if (tid == 0 && sc != 0) atomicAdd(P.scal + 3, sc);
+    }
 }
 
 // ---- reduced solve by block cyclic reduction (round 2) ---------------------------------------------------------------------------------------
@@ -1884,24 +1913,7 @@ __global__ __launch_bounds__(384) void k_bcr_back(BcrDev B, int s)
 __global__ void k_ba_update_cams(BaDev P, double lambda)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    double sc = 0;
-    if (c < P.n_cam) {
-        const double* d = P.x + 6 * c; const double* X = P.cam + 12 * c; double* N = P.cam_new + 12 * c;
-        double w = 1 - (d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
-        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        if (!(w < 0)) {
-            w = sqrt(w);
-            const double x = d[3], y = d[4], z = d[5];
-            R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
-            R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
-            R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
-        }
-        for (int r = 0; r < 3; r++) {
-            for (int q = 0; q < 3; q++) N[r * 4 + q] = X[r * 4] * R[q] + X[r * 4 + 1] * R[3 + q] + X[r * 4 + 2] * R[6 + q];
-            N[r * 4 + 3] = X[r * 4] * d[0] + X[r * 4 + 1] * d[1] + X[r * 4 + 2] * d[2] + X[r * 4 + 3];
-        }
-        for (int a = 0; a < 6; a++) sc += d[a] * (lambda * d[a] + P.bc[6 * c + a]);
-    }
+    double sc = c < P.n_cam ? ba_update_cam(P, c, P.x + 6 * c, lambda) : 0.0;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o, 64);
     if ((threadIdx.x & 63) == 0 && sc != 0) atomicAdd(P.scal + 3, sc);
@@ -2824,7 +2836,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if ((rc = AR(Sr, sz_sr, 0))) return rc;
             // ---- replicated reduced solve
             if (!inline_odo) HIP_TRY(ctx, hipMemsetAsync(D.scal + 2, 0, 2 * sizeof(double), st));
-            if (lds_path && n6 % 6 == 0 && n6 >= 12) hipLaunchKernelGGL(k_ba_chol_small6, dim3(1), dim3(CH_NT), lds_chol6, st, D);
+            const int fuse_update = (lds_path && n6 % 6 == 0 && n6 >= 12 && !allreduce && n_pose <= 64) ? 1 : 0;
+            if (lds_path && n6 % 6 == 0 && n6 >= 12) hipLaunchKernelGGL(k_ba_chol_small6, dim3(1), dim3(CH_NT), lds_chol6, st, D, fuse_update, lambda);
             else if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
             else if (Bc.m) {                                   // block cyclic reduction: 2 launches per level, log2(nb) levels, then the levels back
                 const int m = Bc.m, nb = Bc.nb;
@@ -2849,7 +2862,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             else if (D.bw >= 0) hipLaunchKernelGGL(k_chol_band, dim3(1), dim3(1024), (size_t)D.bw * (CB_NB + 1) * sizeof(double), st, D);
             else { const double one = 1.0; HIP_TRY(ctx, hipMemcpyAsync(D.scal + 4, &one, 8, hipMemcpyHostToDevice, st)); if ((rc = chol_large(ctx, D.S, n6, D.x, D.scal + 4, chol_tmp, st))) return rc; }
             // ---- trial state + its chi2
-            hipLaunchKernelGGL(k_ba_update_cams, dim3((n_pose + 63) / 64), dim3(64), 0, st, D, (allreduce && p.rank != 0) ? 0.0 : lambda);
+            if (!fuse_update) hipLaunchKernelGGL(k_ba_update_cams, dim3((n_pose + 63) / 64), dim3(64), 0, st, D, (allreduce && p.rank != 0) ? 0.0 : lambda);
             if (allreduce && p.rank != 0) HIP_TRY(ctx, hipMemsetAsync(D.scal + 3, 0, sizeof(double), st));      // camera part of computeScale counted once (rank 0)
             if (n_ptl) hipLaunchKernelGGL(k_ba_backsub, dim3(std::min((n_ptl + 31) / 32, 1024)), dim3(256), 0, st, D, n_ptl, lambda);
             if (no) hipLaunchKernelGGL(k_ba_chi2, dim3((no + 255) / 256), dim3(256), 0, st, D, D.cam_new, D.pt_new, D.scal + 2);
