@@ -207,8 +207,8 @@ class NetNodes:
 
     @torch.no_grad()
     def infer(self, prev_bgr, cur_bgr):
-        """prev_bgr / cur_bgr: u8 HxWx3 device tensors.  Returns (flow HxWx2 f32, depth HxW f32, mask HxW i32, labels, events): the outputs are
-        complete once the three events have fired (event.synchronize(), or stream.wait_event from a consumer stream)."""
+        """prev_bgr / cur_bgr: u8 HxWx3 device tensors.  Returns (flow HxWx2 f32, depth HxW f32, mask HxW i32, labels, events): work enqueued on the caller's stream after
+        this call sees the complete outputs (the caller's stream waits for the side stream's events); another stream or the host waits for the three events."""
         cur = torch.cuda.current_stream()
         ss = [s or cur for s in self.streams] if self.streams else [cur, cur, cur]
         for s in ss:
@@ -228,6 +228,9 @@ class NetNodes:
                 mask_u8, labels = _nets.analyse_image(self.mask_net, cur_bgr, feed=self.mask_feed, confidence=self.confidence, trunk=self.g_trunk)
                 mask = mask_u8.to(torch.int32); self.last_counts = None
             e2 = torch.cuda.Event(); e2.record()
+        for s, e in zip(ss, (e0, e1, e2)):                          # the outputs are valid in stream order on the CALLER's stream, whatever queue produced them
+            if s is not cur:
+                cur.wait_event(e)
         return flow, depth, mask, labels, (e0, e1, e2)
 
     @torch.no_grad()
