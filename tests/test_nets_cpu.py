@@ -84,3 +84,47 @@ def test_hip_ops_have_no_cpu_fallback():
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("CPU tensors must be refused")
+
+
+def test_pack_gconv3x3_is_the_operand_order_of_the_kernel():
+    """nets/ops.py::pack_gconv3x3 (host side of csrc/gconv.hip): element (group g, output channel co, input channel ci, tap t) of the convolution weight sits where the kernel's
+    A operand reads it — [g][co / 32][ci / 8][t][ci % 8][co % 32] for >= 32 channels per group, [g][ci / 8][t][ci % 8][co (16 slots, zero above cpg)] for 16 / 8."""
+    from vido_slam_amd.nets.ops import pack_gconv3x3
+    g = torch.Generator().manual_seed(3)
+    for groups, cpg in ((2, 64), (3, 32), (4, 16), (5, 8)):
+        w = torch.randn(groups * cpg, cpg, 3, 3, generator=g)
+        p = pack_gconv3x3(w, groups)
+        for _ in range(200):
+            gi, co, ci, t = (int(torch.randint(0, n, (1,), generator=g)) for n in (groups, cpg, cpg, 9))
+            ref = float(w[gi * cpg + co, ci, t // 3, t % 3])
+            got = float(p[gi, co // 32, ci // 8, t, ci % 8, co % 32]) if cpg % 32 == 0 else float(p[gi, ci // 8, t, ci % 8, co])
+            assert got == ref
+        if cpg < 16:
+            assert p.shape[-1] == 16 and float(p[..., cpg:].abs().max()) == 0.0
+    assert pack_gconv3x3(torch.zeros(24, 12, 3, 3), 2) is None and pack_gconv3x3(torch.zeros(64, 32, 1, 1), 2) is None
+
+
+def test_miopen_find_db_is_offered_only_to_its_own_miopen_build(monkeypatch, tmp_path):
+    """pipeline._offer_miopen_db: the shipped find-db (file names carry the MIOpen version it was recorded with) is put into MIOPEN_USER_DB_PATH only when torch reports that
+    version; an explicit setting and VIDO_NO_MIOPEN_DB win; a read-only package directory gets a private copy."""
+    import os
+    from vido_slam_amd import pipeline
+    files = [f for f in os.listdir(pipeline._MIOPEN_DB) if ".HIP." in f]
+    assert files
+    tag = files[0].split(".HIP.")[1].split("_")[:3]
+    ver = int(tag[0]) * 1000000 + int(tag[1]) * 1000 + int(tag[2])
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False); monkeypatch.delenv("VIDO_NO_MIOPEN_DB", raising=False)
+    monkeypatch.setattr(torch.backends.cudnn, "version", lambda: ver)
+    assert pipeline._offer_miopen_db() == pipeline._MIOPEN_DB and os.environ["MIOPEN_USER_DB_PATH"] == pipeline._MIOPEN_DB
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    monkeypatch.setattr(torch.backends.cudnn, "version", lambda: ver + 1000)          # another minor version: not offered
+    assert pipeline._offer_miopen_db() is None and "MIOPEN_USER_DB_PATH" not in os.environ
+    monkeypatch.setattr(torch.backends.cudnn, "version", lambda: ver)
+    monkeypatch.setenv("VIDO_NO_MIOPEN_DB", "1")
+    assert pipeline._offer_miopen_db() is None
+    monkeypatch.delenv("VIDO_NO_MIOPEN_DB"); monkeypatch.setenv("MIOPEN_USER_DB_PATH", str(tmp_path))
+    assert pipeline._offer_miopen_db() is None and os.environ["MIOPEN_USER_DB_PATH"] == str(tmp_path)
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    monkeypatch.setattr(os, "access", lambda p, m: False)                               # read-only installation
+    got = pipeline._offer_miopen_db()
+    assert got is not None and got != pipeline._MIOPEN_DB and sorted(os.listdir(got)) >= sorted(files)
