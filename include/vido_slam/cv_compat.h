@@ -130,6 +130,29 @@ private:
     std::atomic<int>* buf_;
 };
 
+/* cv::InputArray / cv::OutputArray as OpenCV declares them (typedefs of const references to proxy classes), reduced to the Mat case: what
+ * ORBextractor::operator() takes in the reference (vido_slam/include/ORBextractor.h:49), so that the facade's signature is the same in both builds. */
+class _InputArray {
+public:
+    _InputArray() : m_(nullptr) {}
+    _InputArray(const Mat& m) : m_(const_cast<Mat*>(&m)) {}
+    Mat getMat(int = -1) const { return m_ ? *m_ : Mat(); }
+    bool empty() const { return !m_ || m_->empty(); }
+protected:
+    Mat* m_;
+};
+class _OutputArray : public _InputArray {
+public:
+    _OutputArray() {}
+    _OutputArray(Mat& m) : _InputArray(m) {}
+    void create(int rows, int cols, int type) const { if (m_) m_->create(rows, cols, type); }
+    Mat& getMatRef(int = -1) const { return *m_; }
+    bool needed() const { return m_ != nullptr; }
+};
+typedef const _InputArray& InputArray;
+typedef const _OutputArray& OutputArray;
+inline InputArray noArray() { static const _InputArray none; return none; }
+
 /* CV_32F / CV_64F matrix product; like cv::gemm, float products accumulate in double */
 inline Mat operator*(const Mat& a, const Mat& b)
 {

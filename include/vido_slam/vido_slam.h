@@ -32,13 +32,18 @@
 namespace VIDO_SLAM {
 
 class System; class Tracking; class Map; class Frame;
+/* ONE System per process: like the reference, whose Frame keeps the camera intrinsics and grid in static members (Frame.h: fx, fy, cx, cy, mnMinX ..., set by the first
+ * frame), this build keeps the tracker's device context, map slot and frame parameters in process-wide state (csrc/facade.cpp: g_ctx / g_slot / g_tp) because the static
+ * Optimizer:: methods and the Frame constructor of the reference's interface carry no context argument.  Two Systems grabbing frames in one process would share that state:
+ * not supported.  Calls with no live System throw instead of touching a stale context; the C-ABI below the facade (vido_create + the per-stage entry points) has no such limit. */
 
 class ORBextractor {
 public:
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
     ~ORBextractor();
-    /* image: CV_8UC1; mask is ignored as in the reference (ORBextractor.cc:1034). */
-    void operator()(const cv::Mat& image, const cv::Mat& mask, std::vector<cv::KeyPoint>& keypoints, cv::Mat& descriptors);
+    /* image: CV_8UC1; mask is ignored as in the reference (ORBextractor.cc:1034).  Same signature (and, against real OpenCV, the same symbol) as
+       vido_slam/include/ORBextractor.h:49; a cv::Mat converts to both proxy types implicitly. */
+    void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors);
     int GetLevels() const { return nlevels; }
     float GetScaleFactor() const { return scaleFactor; }
     std::vector<float> GetScaleFactors() const { return mvScaleFactor; }
@@ -113,7 +118,7 @@ public:
        sends only the new frame and the label changes below.  vp3DPointSta rows of the frames still in the device ring may be stale on the host until SyncPointsFromDevice()
        (called before anything on the host reads them: FullBatchOptimization, the host-walk check). */
     std::vector<int> trkChangesSta;           /* (frame, feature, tracklet, position) quads written by UpdateTracklets since the last PartialBatchOptimization */
-    int devFramesPushed = 0; bool devWindow = false;
+    int devFramesPushed = 0; bool devWindow = false; bool devWindowDisabled = false;   /* disabled: this map's sequence does not fit the ring (a frame with > 8192 static features) */
     void SyncPointsFromDevice();
     std::vector<cv::Mat> vmCameraPose, vmCameraPose_RF, vmCameraPose_GT;
     std::vector<std::vector<cv::Mat> > vmRigidCentre, vmRigidMotion, vmRigidMotion_RF;

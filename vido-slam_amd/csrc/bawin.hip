@@ -27,6 +27,8 @@ struct BaWin {
     int last_start = -1, last_N = -1, last_nobs = 0;
 };
 
+#define BAWIN_MAX_FEATURES 8192      // per frame: 1024 threads x 8 features, and n < 2^16 for the packed scan of k_bawin_assemble
+
 namespace {
 struct BaWinDev {
     int cap_f, cap_n, cap_obs, cap_pt;
@@ -102,9 +104,13 @@ __global__ __launch_bounds__(1024) void k_bawin_assemble(BaWinDev W, int start, 
                     if (k < W.cap_obs && p < W.cap_pt) {
                         W.obs_cam[k] = f - start; W.obs_pt[k] = p; W.obs_src[k] = (int)o;
                         W.obs_meas[3 * (size_t)k] = W.meas[3 * o]; W.obs_meas[3 * (size_t)k + 1] = W.meas[3 * o + 1]; W.obs_meas[3 * (size_t)k + 2] = W.meas[3 * o + 2];
-                        atomicAdd(&W.cnt[p], 1);
+                        // a landmark is seen once per frame from its first frame on: the observation of frame f must be number (f - start) - first.  Two features of one
+                        // frame that continue the same predecessor (or a gap in the chain) would share / skip a slot and leave another one unwritten -> flagged,
+                        // the host reports VIDO_E_INVALID like ba_run does for host inputs
+                        const int seen = atomicAdd(&W.cnt[p], 1);
+                        if (seen != (is_new ? 0 : (f - start) - W.first[p])) overflow |= 2;
                         if (is_new) { W.first[p] = f - start; W.pt[3 * (size_t)p] = (double)W.xyz[3 * o]; W.pt[3 * (size_t)p + 1] = (double)W.xyz[3 * o + 1]; W.pt[3 * (size_t)p + 2] = (double)W.xyz[3 * o + 2]; }
-                    } else overflow = 1;
+                    } else overflow |= 1;
                     k++; pnew += is_new ? 1 : 0;
                 }
             }
@@ -128,8 +134,8 @@ __global__ __launch_bounds__(1024) void k_bawin_assemble(BaWinDev W, int start, 
     // (obs_pos / slot_cam: k_bawin_slots, all CUs — 35 dependent three-load trips per thread of this one workgroup were 60 of its 160 us)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { maxk = max(maxk, __shfl_xor(maxk, o, 64)); overflow |= __shfl_xor(overflow, o, 64); }
-    if ((tid & 63) == 0) { atomicMax(&counts[3], maxk); if (overflow) counts[2] = 1; }
-    if (tid == 0) { counts[0] = n_obs; counts[1] = n_pt; if (run != n_obs) counts[2] = 1; }
+    if ((tid & 63) == 0) { atomicMax(&counts[3], maxk); if (overflow) atomicOr(&counts[2], overflow); }
+    if (tid == 0) { counts[0] = n_obs; counts[1] = n_pt; if (run != n_obs) atomicOr(&counts[2], 1); }
 }
 
 // slot of an observation = pt_start[landmark] + (camera - first camera of the landmark); counts[0] = number of observations (written by k_bawin_assemble)
@@ -168,7 +174,9 @@ extern "C" {
 int vido_bawin_create(vido_ctx* ctx, int cap_frames, int cap_features)
 {
     if (!ctx) return VIDO_E_INVALID;
-    if (cap_frames < 2 || cap_frames > 64 || cap_features < 1 || cap_features > (1 << 20)) return vido_set_error(ctx, VIDO_E_INVALID, "bawin_create: bad capacities");
+    // k_bawin_assemble walks at most 8 features per thread of its 1024-thread workgroup and packs two counts into the 16-bit halves of one scan word
+    if (cap_frames < 2 || cap_frames > 64 || cap_features < 1 || cap_features > BAWIN_MAX_FEATURES)
+        return vido_set_error(ctx, VIDO_E_INVALID, "bawin_create: bad capacities (2..64 frames, 1..%d features per frame)", BAWIN_MAX_FEATURES);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     bawin_state_destroy(ctx);
     BaWin* B = new BaWin(); ctx->bawin = B;
@@ -262,7 +270,8 @@ int vido_bawin_solve(vido_ctx* ctx, int start, int N, vido_ba_problem* prob, vid
     HIP_TRY(ctx, hipMemcpyAsync(B->h_counts, B->d_counts, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     const int no = B->h_counts[0], np = B->h_counts[1];
-    if (B->h_counts[2]) return vido_set_error(ctx, VIDO_E_CAPACITY, "bawin_solve: window exceeds the ring's capacity or a landmark chain is not contiguous (obs %d, landmarks %d)", no, np);
+    if (B->h_counts[2] & 2) return vido_set_error(ctx, VIDO_E_INVALID, "bawin_solve: a landmark is observed twice from one frame, or its chain skips a frame (obs %d, landmarks %d)", no, np);
+    if (B->h_counts[2]) return vido_set_error(ctx, VIDO_E_CAPACITY, "bawin_solve: window exceeds the ring's capacity (obs %d, landmarks %d)", no, np);
     if (n_obs_out) *n_obs_out = no;
     if (n_pt_out) *n_pt_out = np;
     B->last_start = start; B->last_N = N; B->last_nobs = no;

@@ -423,12 +423,12 @@ int vido_rpn_merge(vido_ctx* ctx, const float* boxes, const float* scores, const
                    float* out_boxes, float* out_scores, int32_t* n_valid)
 {
     if (!ctx) return VIDO_E_INVALID;
-    if (!boxes || !scores || !keep || !cnt || !out_boxes || !out_scores || !n_valid || n_levels < 1 || K < 1 || n_final < 1 || (long long)n_levels * K > 8192 || n_levels > 8 || n_final > n_levels * K)
-        return vido_set_error(ctx, VIDO_E_INVALID, "rpn_merge: bad arguments (n_levels * K <= 8192)");
+    if (!boxes || !scores || !keep || !cnt || !out_boxes || !out_scores || !n_valid || n_levels < 1 || K < 1 || n_final < 1 || (long long)n_levels * K > 8160 || n_levels > 8 || n_final > n_levels * K)
+        return vido_set_error(ctx, VIDO_E_INVALID, "rpn_merge: bad arguments (n_levels * K <= 8160: 8 bytes per box of dynamic LDS + the kernel's static LDS within the 64 KB of a workgroup)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
-    static bool attr = false;
-    if (!attr) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_rpn_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8)); attr = true; }
+    static bool attr[64] = {};      // per device: the attribute belongs to the device's copy of the code object
+    if (!attr[ctx->device & 63]) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_rpn_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 8160 * 8)); attr[ctx->device & 63] = true; }
     hipLaunchKernelGGL(k_rpn_merge, dim3(1), dim3(1024), (size_t)n_levels * K * 8, st, boxes, scores, keep, cnt, n_levels, K, post_nms_top_n, n_final, out_boxes, out_scores, n_valid);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;

@@ -104,10 +104,11 @@ vido_ctx* ORBextractor::context(int width, int height)
     }
     return ctx_;
 }
-void ORBextractor::operator()(const cv::Mat& image, const cv::Mat&, std::vector<cv::KeyPoint>& keypoints, cv::Mat& descriptors)
+void ORBextractor::operator()(cv::InputArray image_, cv::InputArray, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors_)
 {
     keypoints.clear();
-    if (image.empty()) return;
+    if (image_.empty()) return;
+    const cv::Mat image = image_.getMat();                     // (a header: shares the caller's pixels)
     if (image.type() != CV_8UC1) throw std::runtime_error("ORBextractor: image must be CV_8UC1");
     vido_ctx* c = context(image.cols, image.rows);
     const int cap = 2 * nfeatures + 256; int n = 0;
@@ -125,7 +126,8 @@ void ORBextractor::operator()(const cv::Mat& image, const cv::Mat&, std::vector<
     if (rc != VIDO_OK) throw std::runtime_error(vido_last_error(c));
     keypoints.resize(n);
     for (int i = 0; i < n; i++) keypoints[i] = cv::KeyPoint(k[i].x, k[i].y, k[i].size, k[i].angle, k[i].response, k[i].octave);
-    descriptors = cv::Mat(n, 32, CV_8U);
+    descriptors_.create(n, 32, CV_8U);
+    cv::Mat descriptors = descriptors_.getMat();
     for (int i = 0; i < n; i++) memcpy(descriptors.ptr<uint8_t>(i), desc.ptr<uint8_t>(i), 32);
 }
 
@@ -260,7 +262,7 @@ static void grow_tracklets(const std::vector<std::vector<int> >& TM, const std::
 }
 void Map::UpdateTracklets()
 {
-    grow_tracklets(vnAssoSta, vpFeatSta, nullptr, TrackletSta, nullptr, vnTrkSta, vnPosSta, trkPreSta, trkRowsSta, &trkChangesSta);
+    grow_tracklets(vnAssoSta, vpFeatSta, nullptr, TrackletSta, nullptr, vnTrkSta, vnPosSta, trkPreSta, trkRowsSta, devWindow ? &trkChangesSta : nullptr);      // (a window that starts later reads the tables)
     grow_tracklets(vnAssoDyn, vpFeatDyn, &vnFeatLabel, TrackletDyn, &nObjID, vnTrkDyn, vnPosDyn, trkPreDyn, trkRowsDyn);
 }
 
@@ -506,8 +508,7 @@ static void commit_window_poses(Map* pMap, int start, int N, const std::vector<d
 // sequence (more features per frame than the ring holds) -> the caller walks the Map like rounds 1-2 did.
 static bool batch_optimize_resident(Map* pMap, const cv::Mat& K, int start, int N, int WINDOW_SIZE, const std::vector<double>* check_cam, int check_nobs, int check_npt)
 {
-    static bool disabled = false;
-    if (disabled) return false;
+    if (pMap->devWindowDisabled) return false;                 // per Map (a process-wide latch switched the resident path off for every later System)
     vido_ctx* c = live_ctx("PartialBatchOptimization");
     const int cap_f = 24, cap_n = 8192, nc = N - start;      // (the caller sends windows of <= 20 cameras here)
     const float invfx = 1.0f / K.at<float>(0, 0), invfy = 1.0f / K.at<float>(1, 1), kcx = K.at<float>(0, 2), kcy = K.at<float>(1, 2);
@@ -516,7 +517,7 @@ static bool batch_optimize_resident(Map* pMap, const cv::Mat& K, int start, int 
     std::vector<double> meas; std::vector<float> xyz;
     for (int f = std::max(pMap->devFramesPushed, N - (cap_f - 1)); f < N; f++) {
         const int n = (int)pMap->vpFeatSta[f].size(), fo = f - cap_f;
-        if (n > cap_n || (f > 0 && (int)pMap->vnAssoSta[f - 1].size() != n)) { disabled = true; pMap->SyncPointsFromDevice(); pMap->devWindow = false; return false; }
+        if (n > cap_n || (f > 0 && (int)pMap->vnAssoSta[f - 1].size() != n)) { pMap->devWindowDisabled = true; pMap->SyncPointsFromDevice(); pMap->devWindow = false; return false; }
         if (fo >= 0 && !pMap->vp3DPointSta[fo].empty()) {      // the frame this one replaces in the ring: its points go home first
             std::vector<float> buf(3 * pMap->vp3DPointSta[fo].size());
             if (vido_bawin_read_points(c, fo, (int)pMap->vp3DPointSta[fo].size(), buf.data()) == VIDO_OK)
@@ -578,7 +579,7 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
     const bool resident = !global && !host_walk && 6 * nc <= 120;
     if (resident && !check_walk && batch_optimize_resident(pMap, K, start, N, WINDOW_SIZE, nullptr, 0, 0)) return;
     pMap->SyncPointsFromDevice();                             // the walk below reads vp3DPointSta
-    if (!(resident && check_walk)) pMap->devWindow = false;   // ... and writes it: the ring's copy is stale from here on (a later resident window starts afresh)
+    if (!(resident && check_walk)) { pMap->devWindow = false; std::vector<int>().swap(pMap->trkChangesSta); }      // nobody consumes the change list on this path (a later resident window starts from the Map's tables): it must not grow with the sequence   // ... and writes it: the ring's copy is stale from here on (a later resident window starts afresh)
     const auto& Tr = pMap->TrackletSta; const auto& lab = pMap->vnTrkSta;
     std::vector<std::vector<int> > mak(N);                     // only the window's frames are touched
     for (int i = start; i < N; i++) mak[i].assign(pMap->vpFeatSta[i].size(), -1);

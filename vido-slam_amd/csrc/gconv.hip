@@ -242,11 +242,11 @@ template <int NTW> static int gc_m16_limits(vido_ctx* ctx)
 }
 static int gc_lds_limit(vido_ctx* ctx)
 {
-    static bool done = false;
-    if (done) return VIDO_OK;
+    static bool done[64] = {};      // per device
+    if (done[ctx->device & 63]) return VIDO_OK;
     { int rc = gc_m16_limits<8>(ctx); if (rc) return rc; }
     { int rc = gc_m16_limits<16>(ctx); if (rc) return rc; }
-    done = true;
+    done[ctx->device & 63] = true;
     return VIDO_OK;
 }
 template <int NTW> static void gc_m16_launch(const GcPlan& p, int groups, hipStream_t st, const GcArgs& A)

@@ -277,6 +277,7 @@ class EndToEnd:
         self.poses, self.stats, self.err = [], [], None
         self.t_net, self.t_track, self.t_wait, self.n_det = [], [], [], []
         self.prev = None; self.k = 0
+        self.net_lock = _threading.Lock()     # the networks' host-side state (stream adoption, ctx scratch, static trunk buffers) has ONE user at a time: push() or the overflow redo
         self.worker = _threading.Thread(target=self._track_loop, daemon=True); self.worker.start()
 
     def _track_loop(self):
@@ -323,7 +324,9 @@ class EndToEnd:
         n_det = int(self.host[slot]["counts"][1])
         if n_det <= self.nodes.mask_net.config.detections_per_img:
             return
-        with torch.cuda.stream(self.net_stream):                         # on the NETWORK stream: the detector's HIP ops share one device scratch, which only stream order protects
+        # on the NETWORK stream (the detector's HIP ops share one device scratch, which stream order protects) and under the lock push() holds around infer():
+        # the host-side state of the nodes (adopted stream, ctx scratch pointers, static trunk buffers) is not protected by stream order
+        with self.net_lock, torch.cuda.stream(self.net_stream):
             r = self.nodes.redo_detector_if_overflowed(self.dev[slot]["bgr"], n_det)
             if r is not None:
                 self.dev[slot]["mask"].copy_(r[0])
@@ -349,7 +352,8 @@ class EndToEnd:
             else:
                 hb["given"] = (hb["depth"].numpy().copy(), hb["flow"].numpy().copy(), hb["mask"].numpy().copy())
         prev = cur if self.prev is None else self.prev                   # first frame: RunNet has no previous image yet; the tracker ignores the flow of frame 0's predecessor
-        flow, depth, mask, labels, evs = self.nodes.infer(prev, cur)
+        with self.net_lock:
+            flow, depth, mask, labels, evs = self.nodes.infer(prev, cur)
         # graph outputs are static buffers that the next replay overwrites: park them in this slot's device buffers (three device-to-device copies of 4.8 MB in stream order)
         if self.nodes.streams is not None:
             for e in evs:
