@@ -176,7 +176,9 @@ def main():
         t_err.append(float(np.linalg.norm(E[:3, 3])))
     stage = {"track_total_ms": mean("ms_total"), "update_mask_ms": mean("ms_update_mask"), "frame_orb_lists_ms": mean("ms_frame"), "cam_pose_ms": mean("ms_cam_pose"),
              "obj_tracking_ms": mean("ms_obj_tracking"), "obj_motion_ms": mean("ms_obj_motion"), "renew_ms": mean("ms_renew"), "local_ba_ms": mean("ms_local_ba"),
-             "net_enqueue_host_ms": float(np.mean(e2e.t_net[n0:])), "tracker_wait_for_nets_ms": float(np.mean(e2e.t_wait[n0:])), "tracker_thread_ms": float(np.mean(e2e.t_track[n0:]))}
+             "net_enqueue_host_ms": float(np.mean(e2e.t_net[n0:])), "tracker_wait_for_nets_ms": float(np.mean(e2e.t_wait[n0:])), "tracker_thread_ms": float(np.mean(e2e.t_track[n0:])),
+             "tracker_wait_inputs_ms": mean("ms_wait_inputs")}
+    stage["tracker_work_ms"] = stage["tracker_thread_ms"] - stage["tracker_wait_inputs_ms"]      # the thread's time minus its wait for the frame's networks (an event the tracker's stream is ordered behind)
     counts = {"keypoints": mean("n_keypoints"), "static_points": mean("n_static"), "static_inliers": mean("n_static_inliers"), "dynamic_objects": mean("n_objects"),
               "object_points": mean("n_object_points"), "ba_window": mean("ba_window")}
     counts["detector_detections"] = float(np.mean(e2e.n_det[n0:])) if len(e2e.n_det) > n0 else 0.0      # what the mask head ran on (reference cap: detections_per_img = 100)

@@ -448,6 +448,8 @@ typedef struct vido_system_stats {          /* of the last vido_system_track_rgb
     float ms_update_mask, ms_frame;          /* Tracking::UpdateMask; Frame::Frame (cvtColor + ORB + lists) + hand-over gathers */
     float ms_cam_pose, ms_obj_tracking, ms_obj_motion, ms_renew;   /* the reference's all_timing[1..4] (Tracking.cc:1120-1324); obj_motion = sum over objects */
     float ms_local_ba;                       /* Map::fLBA_time (Tracking.cc:1436-1451) */
+    float ms_wait_inputs;                    /* vido_system_track_rgbd_device only: host time spent waiting for the producer's ready event (the networks of this frame) — inside ms_total,
+                                                outside every stage time above */
 } vido_system_stats;
 int         vido_system_create(const char* settings_yaml, vido_system** out);
 void        vido_system_destroy(vido_system* sys);

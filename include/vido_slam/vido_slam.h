@@ -185,7 +185,7 @@ public:
     std::vector<int> TemperalMatch, TemperalMatch_subset;
     std::vector<cv::KeyPoint> mvTmpObjKeys, mvTmpObjCorres; std::vector<float> mvTmpObjDepth; std::vector<int> mvTmpSemObjLabel; std::vector<cv::Point2f> mvTmpObjFlowNext;
     std::vector<float> all_timing;
-    float ms_total = 0, ms_update_mask = 0, ms_frame = 0, ms_obj_motion_sum = 0;     /* wall-clock stage times of the last GrabImageRGBD */
+    float ms_total = 0, ms_update_mask = 0, ms_frame = 0, ms_obj_motion_sum = 0, ms_wait_inputs = 0;     /* wall-clock stage times of the last GrabImageRGBD */
     unsigned ransac_seed;             /* solvePnPRansac uses OpenCV's global RNG; seeded explicitly here */
     ORBextractor* mpORBextractorLeft = nullptr;
 protected:

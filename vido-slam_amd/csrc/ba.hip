@@ -25,6 +25,7 @@
 // partial reduced system (S, r) and the LM scalars are summed through the caller's all-reduce hook (RCCL via
 // torch.distributed in bench.py), the reduced solve is replicated, back-substitution is local.
 #include "common.hpp"
+#include "xwg.hpp"
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -202,21 +203,26 @@ __device__ __forceinline__ void ba_flush_cam(const BaDev& P, int c, int cam0, do
 #pragma unroll
     for (int a = 0; a < 28; a++) acc[a] = 0;
 }
-__global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
+// Body of the linearisation for virtual block `vb` (NT threads = NT / 64 groups of 64 consecutive observations x E).  k_ba_linearize runs it once per workgroup; the
+// persistent local-window solver (k_ba_local_lm) loops it over the blocks of its grid.  smem: LIN_SMEM_DOUBLES(NT) doubles, 16-byte aligned.  MEAS: the observation's
+// measurement rides along in the slot record's padding ([27, 30)) so that the trial chi2 can be formed landmark-major next to the back-substitution.
+#define LIN_SMEM_DOUBLES(NT) (LIN_SLOTS * 28 + ((NT) / 64) * 32 * LIN_RECP + (LIN_SLOTS + ((NT) / 64) * 32 + 1) / 2 + 2)
+template <int NT, bool MEAS>
+__device__ __forceinline__ void ba_linearize_body(const BaDev& P, int E, int vb, double* smem)
 {
-    __shared__ double lsum[LIN_SLOTS * 28];
-    __shared__ int lused[LIN_SLOTS];
-    __shared__ __attribute__((aligned(16))) double lin_stage[LIN_THREADS / 64][32 * LIN_RECP];
-    __shared__ int lin_sslot[LIN_THREADS / 64][32];
+    double* lsum = smem;                                                                       // [LIN_SLOTS * 28]
+    double (*lin_stage)[32 * LIN_RECP] = (double (*)[32 * LIN_RECP])(smem + LIN_SLOTS * 28);     // [NT / 64][32 * LIN_RECP]   (LIN_SLOTS * 28 doubles = 896 bytes: 16-byte aligned)
+    int* lused = (int*)(smem + LIN_SLOTS * 28 + (NT / 64) * 32 * LIN_RECP);                      // [LIN_SLOTS]
+    int (*lin_sslot)[32] = (int (*)[32])(lused + LIN_SLOTS);                                     // [NT / 64][32]
+    constexpr int NREC = MEAS ? 30 : 28, NPIECE = MEAS ? 15 : 14;
     const int lane = threadIdx.x & 63;
     // (round 3: giving every XCD one CONTIGUOUS eighth of the camera-sorted list — so that the partial-line writes of a landmark's W / Cp slots meet in one L2 — was
     // measured and changed nothing: 109-112 us per 1 M edges either way, profiles/r3/README.md; the plain order stays)
-    const int vb = blockIdx.x;
-    const size_t wave_g = (size_t)vb * (LIN_THREADS / 64) + (threadIdx.x >> 6);
-    if ((size_t)vb * (LIN_THREADS / 64) * E * 64 >= (size_t)P.n_obs) return;      // (whole workgroup: the rounded-up tail)
+    const size_t wave_g = (size_t)vb * (NT / 64) + (threadIdx.x >> 6);
+    if ((size_t)vb * (NT / 64) * E * 64 >= (size_t)P.n_obs) return;      // (whole workgroup: the rounded-up tail)
     if (threadIdx.x < LIN_SLOTS * 28) lsum[threadIdx.x] = 0;
     if (threadIdx.x < LIN_SLOTS) lused[threadIdx.x] = 0;
-    const int cam0 = P.obs_cam[min((size_t)vb * (LIN_THREADS / 64) * E * 64, (size_t)P.n_obs - 1)];     // first camera of the workgroup
+    const int cam0 = P.obs_cam[min((size_t)vb * (NT / 64) * E * 64, (size_t)P.n_obs - 1)];     // first camera of the workgroup
     __syncthreads();
     double acc[28];
 #pragma unroll
@@ -226,9 +232,11 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
         const size_t k = (wave_g * E + j) * 64 + lane;
         const bool act = j < E && k < (size_t)P.n_obs;
         int c = -1, slot_k = -1;
-        double con[28], rec[28];
+        double con[28], rec[NREC];
 #pragma unroll
-        for (int a = 0; a < 28; a++) { con[a] = 0; rec[a] = 0; }
+        for (int a = 0; a < 28; a++) con[a] = 0;
+#pragma unroll
+        for (int a = 0; a < NREC; a++) rec[a] = 0;
         if (act) {
             c = P.obs_cam[k]; const int l = P.obs_pt[k];
             const double* X = P.cam + 12 * c; const double* p = P.pt + 3 * l; const double* m = P.obs_meas + 3 * (size_t)k;
@@ -262,6 +270,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
 #pragma unroll
                 for (int b = a; b < 3; b++) rec[q++] = wo * (Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b] + Jp[6 + a] * Jp[6 + b]);
             }
+            if constexpr (MEAS) { rec[27] = m[0]; rec[28] = m[1]; rec[29] = m[2]; }
         }
         // ---- the slot records leave through LDS: a lane owns ONE record (W 18 | Cp 9 doubles) that goes to a scattered, line-aligned 256-byte slot.  Stored from the lane's
         // own registers that is 14 instructions of 64 sixteen-byte writes to 64 different lines — 14 M partial-line transactions per million edges, and the transaction rate
@@ -275,14 +284,14 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
                     ssl[lane & 31] = act ? slot_k : -1;
                     if (act) {
 #pragma unroll
-                        for (int a = 0; a < 14; a++) *(double2*)(stg + (lane & 31) * LIN_RECP + 2 * a) = make_double2(rec[2 * a], rec[2 * a + 1]);
+                        for (int a = 0; a < NPIECE; a++) *(double2*)(stg + (lane & 31) * LIN_RECP + 2 * a) = make_double2(rec[2 * a], rec[2 * a + 1]);
                     }
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();      // lgkmcnt(0): the LDS writes of this wave have landed
 #pragma unroll
                 for (int it = 0; it < 8; it++) {
                     const int r = it * 4 + (lane >> 4), pc = lane & 15, sl = ssl[r];
-                    if (sl >= 0 && pc < 14) *(double2*)(P.W + BA_REC * (size_t)sl + 2 * pc) = *(const double2*)(stg + r * LIN_RECP + 2 * pc);
+                    if (sl >= 0 && pc < NPIECE) *(double2*)(P.W + BA_REC * (size_t)sl + 2 * pc) = *(const double2*)(stg + r * LIN_RECP + 2 * pc);
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
             }
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
     }
     __syncthreads();
     // one thread per (slot, entry of the 6x6 block | bc | chi2): 43 atomics per camera the workgroup saw
-    for (int t = threadIdx.x; t < LIN_SLOTS * 43; t += LIN_THREADS) {
+    for (int t = threadIdx.x; t < LIN_SLOTS * 43; t += NT) {
         const int slot = t / 43, e = t - slot * 43, c = cam0 + slot;
         if (!lused[slot]) continue;
         if (e < 36) { const int a = e / 6, b = e - a * 6, lo = min(a, b), hi = max(a, b); atomicAdd(P.Hcd + 36 * c + e, lsum[slot * 28 + lo * 6 - lo * (lo - 1) / 2 + (hi - lo)]); }
@@ -309,12 +318,16 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
         else atomicAdd(P.scal + 0, lsum[slot * 28 + 27]);
     }
 }
+__global__ __launch_bounds__(LIN_THREADS) void k_ba_linearize(BaDev P, int E)
+{
+    __shared__ __attribute__((aligned(16))) double lin_smem[LIN_SMEM_DOUBLES(LIN_THREADS)];
+    ba_linearize_body<LIN_THREADS, false>(P, E, blockIdx.x, lin_smem);
+}
 
 // odometry edges (k < n_odo) and the prior (k == n_odo): one wave per factor, lane a*6+b owns entry (a,b) of the
 // 6x6 blocks (the residual and Jacobians are cheap and recomputed by every lane)
-__global__ __launch_bounds__(64) void k_ba_camfactors(BaDev P, int with_jac, const double* cam, double* chi_out)
+__device__ void ba_camfactor_body(const BaDev& P, int with_jac, const double* cam, double* chi_out, int k, int lane)
 {
-    const int k = blockIdx.x, lane = threadIdx.x;
     const int n = P.n_odo + (P.prior_cam >= 0 ? 1 : 0);
     if (k >= n) return;
     const bool is_prior = k == P.n_odo;
@@ -339,12 +352,12 @@ __global__ __launch_bounds__(64) void k_ba_camfactors(BaDev P, int with_jac, con
     if (!is_prior) { atomicAdd(P.Hcd + 36 * i + a * 6 + b, wo * hii); P.Hodo[36 * k + a * 6 + b] = wo * hij; }
     if (b == 0) { atomicAdd(P.bc + 6 * j + a, -wo * sj); if (!is_prior) atomicAdd(P.bc + 6 * i + a, -wo * si); }
 }
+__global__ __launch_bounds__(64) void k_ba_camfactors(BaDev P, int with_jac, const double* cam, double* chi_out) { ba_camfactor_body(P, with_jac, cam, chi_out, blockIdx.x, threadIdx.x); }
 
 // max |diag| over camera blocks and landmark blocks (computeLambdaInit)
-__global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev P, int n_ptl)
+__device__ __forceinline__ void ba_maxdiag_body(const BaDev& P, int n_ptl, int tid, int nt)
 {
     double m = 0;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
     for (int a = tid; a < P.n6; a += nt) m = fmax(m, fabs(P.Hcd[36 * (a / 6) + 7 * (a % 6)]));
     for (int l = tid; l < n_ptl; l += nt) {          // runs before k_ba_schur has summed Hpp: diagonal of the landmark block from its slots
         double h0 = 0, h3 = 0, h5 = 0;
@@ -358,6 +371,7 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev P, int n_ptl)
         atomicMax((unsigned long long*)(P.scal + 1), (unsigned long long)__double_as_longlong(m));
     }
 }
+__global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev P, int n_ptl) { ba_maxdiag_body(P, n_ptl, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x); }
 
 // S <- camera-camera part (+ lambda on the diagonal when add_lambda), r <- bc   (upper AND lower filled)
 // inline_odo (the dense LDS-path system of the local window, <= 64 camera-camera factors): the off-diagonal blocks of the factors are written here instead of by
@@ -408,12 +422,12 @@ __global__ void k_ba_add_odo(BaDev P)
 #ifndef BA_CHUNK
 #define BA_CHUNK 256      // landmarks per window flush: every flush is a set of HBM atomics, and atomics onto one cache line serialise (~45 ns each)
 #endif
+// (bid, nblk) = (blockIdx.x, gridDim.x) for the kernel below; the persistent local-window solver passes its own workgroup index and grid
 template <int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 1024 : 512) void k_ba_schur(BaDev P, int n_ptl, double lambda, int kcap, double* S_part /*[grid][n6*n6 + n6], MODE 0*/,
-                                                  const int* __restrict__ chunk_cmin /*MODE 2*/, const int* __restrict__ lorder /*MODE 2: landmarks by first camera*/,
-                                                  const int2* __restrict__ lbc /*MODE 2: (first slot, slot count) of lorder[lp]*/)
+__device__ __forceinline__ void ba_schur_body(const BaDev& P, int n_ptl, double lambda, int kcap, double* S_part /*[grid][n6*n6 + n6], MODE 0*/,
+                                              const int* __restrict__ chunk_cmin /*MODE 2*/, const int* __restrict__ lorder /*MODE 2: landmarks by first camera*/,
+                                              const int2* __restrict__ lbc /*MODE 2: (first slot, slot count) of lorder[lp]*/, int bid, int nblk, double* lds)
 {
-    extern __shared__ double lds[];
     const int n6 = P.n6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int wn = MODE == 0 ? n6 : BA_WC * 6;                 // side of the LDS-resident (window of) S
     // LDS layout of (the window of) S: the lower-triangle 6x6 blocks, block (ci >= cj) at [(ci(ci+1)/2 + cj) * SB_PITCH + 6a + b], then the rhs.
@@ -424,10 +438,10 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 512) void k_ba_schur(BaDev P, in
     double* Sl = lds;                                        // [nblk_l * SB_PITCH + wn] for MODE 0 / 2
     double* stage = lds + (MODE == 1 ? 0 : (size_t)rhs_off + wn) + (size_t)wave * (2 * kcap * 18 + kcap);   // W, WD, (pose, camera ordinal) of up to kcap obs per wave
     const int n_units = MODE == 2 ? (n_ptl + BA_CHUNK - 1) / BA_CHUNK : 1;
-    for (int unit = MODE == 2 ? blockIdx.x : 0; unit < n_units; unit += MODE == 2 ? gridDim.x : 1) {
+    for (int unit = MODE == 2 ? bid : 0; unit < n_units; unit += MODE == 2 ? nblk : 1) {
         int cbase = 0, l_beg, l_end, l_step;
         if (MODE == 2) { cbase = chunk_cmin[unit]; l_beg = unit * BA_CHUNK + wave; l_end = min(n_ptl, (unit + 1) * BA_CHUNK); l_step = nw; }
-        else { l_beg = blockIdx.x * nw + wave; l_end = n_ptl; l_step = gridDim.x * nw; }
+        else { l_beg = bid * nw + wave; l_end = n_ptl; l_step = nblk * nw; }
         if (MODE != 1) { for (int t = threadIdx.x; t < rhs_off + wn; t += blockDim.x) Sl[t] = 0; __syncthreads(); }
         // A landmark is a chain of dependent HBM round trips (its slot range -> its slot data -> the cameras of the slots); with ~30 landmarks
         // per wave that latency IS the kernel.  The slot range of the NEXT landmark is requested one iteration ahead (MODE 2 reads it from a
@@ -498,7 +512,7 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 512) void k_ba_schur(BaDev P, in
         }
         if (MODE == 0) {
             __syncthreads();
-            double* out = S_part + (size_t)blockIdx.x * (rhs_off + n6);      // same block-major layout, k_ba_fold_parts maps it onto S
+            double* out = S_part + (size_t)bid * (rhs_off + n6);      // same block-major layout, k_ba_fold_parts maps it onto S
             for (int t = threadIdx.x; t < rhs_off + n6; t += blockDim.x) out[t] = Sl[t];
         }
         if (MODE == 2) {                                          // flush the window: one HBM atomic per touched entry
@@ -517,6 +531,13 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 512) void k_ba_schur(BaDev P, in
             __syncthreads();
         }
     }
+}
+template <int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 1024 : 512) void k_ba_schur(BaDev P, int n_ptl, double lambda, int kcap, double* S_part, const int* __restrict__ chunk_cmin, const int* __restrict__ lorder,
+                                                  const int2* __restrict__ lbc)
+{
+    extern __shared__ double lds_schur_dyn[];
+    ba_schur_body<MODE>(P, n_ptl, lambda, kcap, S_part, chunk_cmin, lorder, lbc, blockIdx.x, gridDim.x, lds_schur_dyn);
 }
 // MODE 2 on the FP64 matrix cores (round 2).  The wave-per-landmark kernel above spends ~800 VALU instructions per landmark on pair index arithmetic, 36 address
 // computations and 36 LDS atomics per camera pair (0.5 ms per 100 k landmarks: 39 % of a global LM iteration).  Here a landmark contributes three ROWS of a
@@ -1551,16 +1572,17 @@ __device__ double ba_update_cam(const BaDev& P, int c, const double* d, double l
     return sc;
 }
 
-__global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P, int fuse_update, double lambda)
+// NT threads (>= 256): 768 in k_ba_chol_small6 (every tile of the first trailing update has its own thread), 512 inside the persistent solver (the first two steps take two rounds)
+template <int NT>
+__device__ __forceinline__ void ba_chol_small6_body(const BaDev& P, int fuse_update, double lambda, double* cs6)
 {
-    extern __shared__ double cs6[];
     const int n = P.n6, nblk = n / 6, ldw = n + 1, tid = threadIdx.x;
     double* W = cs6;                                        // [n][ldw] lower triangle
     double* rW = W + (size_t)n * ldw;                        // [n] rhs -> z -> x
     double* Pn = rW + n;                                     // [n][7] panel rows of the current step
     __shared__ int ok;
-    for (int t = tid; t < n * n; t += CH_NT) { const int i = t / n, j = t - i * n; if (j <= i) W[i * ldw + j] = P.S[t]; }
-    for (int t = tid; t < n; t += CH_NT) rW[t] = P.r[t];
+    for (int t = tid; t < n * n; t += NT) { const int i = t / n, j = t - i * n; if (j <= i) W[i * ldw + j] = P.S[t]; }
+    for (int t = tid; t < n; t += NT) rW[t] = P.r[t];
     if (tid == 0) ok = 1;
     CH_PROF_DECL
     __syncthreads();
@@ -1646,7 +1668,8 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P, int fuse_upda
             lds_barrier();
             CH_TICK(3)
             // ---- B2: trailing update: tiles (row block ibr >= column block jc) except (0, 0), two 3-row halves each, packed densely
-            const int it = tid - 192, tl = (it >> 1) + 1, h3 = 3 * (it & 1);
+            for (int it = tid - 192; it < nbelow * (nbelow + 1) - 2; it += NT - 192) {      // 2 half tiles per block of the lower triangle of the trailing matrix, block (0, 0) excepted
+            const int tl = (it >> 1) + 1, h3 = 3 * (it & 1);
             int ibr = (int)((sqrtf(8.f * (float)tl + 1.f) - 1.f) * 0.5f);
             ibr -= (ibr * (ibr + 1) / 2 > tl); ibr += ((ibr + 1) * (ibr + 2) / 2 <= tl);
             const int jc = tl - ibr * (ibr + 1) / 2;
@@ -1663,6 +1686,7 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P, int fuse_upda
                 for (int a = 0; a < 3; a++)
 #pragma unroll
                     for (int b = 0; b < 6; b++) Wt[a * ldw + b] = (jc == ibr && b > h3 + a) ? w[a][b] : w[a][b] - o[a][b];     // select, not a branch
+            }
             }
             CH_TICK(4)
             lds_barrier();
@@ -1690,7 +1714,7 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P, int fuse_upda
                 for (int c = 0; c < 6; c++) if (tid == c) rW[pk + c] = t6[c];
             }
             lds_barrier();
-            for (int j = tid; j < pk; j += CH_NT) {
+            for (int j = tid; j < pk; j += NT) {
                 double sum = 0;
 #pragma unroll
                 for (int a = 0; a < 6; a++) sum += W[(pk + a) * ldw + j] * rW[pk + a];
@@ -1698,7 +1722,7 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P, int fuse_upda
             }
             lds_barrier();
         }
-        for (int t = tid; t < n; t += CH_NT) P.x[t] = rW[t];
+        for (int t = tid; t < n; t += NT) P.x[t] = rW[t];
     }
     CH_TICK(6)
     CH_PROF_PRINT("small6 [0 bar | 2 B1 | 3 bar | 4 A or B2 | 6 back]")
@@ -1710,6 +1734,11 @@ __global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P, int fuse_upda
         for (int o = 32; o >= 1; o >>= 1) sc += __shfl_xor(sc, o, 64);
         if (tid == 0 && sc != 0) atomicAdd(P.scal + 3, sc);
     }
+}
+__global__ __launch_bounds__(CH_NT) void k_ba_chol_small6(BaDev P, int fuse_update, double lambda)
+{
+    extern __shared__ double cs6_dyn[];
+    ba_chol_small6_body<CH_NT>(P, fuse_update, lambda, cs6_dyn);
 }
 
 // ---- reduced solve by block cyclic reduction (round 2) ---------------------------------------------------------------------------------------
@@ -1960,6 +1989,211 @@ __global__ __launch_bounds__(256) void k_ba_chi2(BaDev P, const double* cam, con
         acc += v;
     }
     block_atomic_add(out, acc);
+}
+
+// ---- the local window as ONE persistent launch (round 4) ------------------------------------------------------------------------------------------------------
+// Round 3 drove the window's Levenberg-Marquardt loop from the host: ~10 launches and one read-back per trial, ~9 trials per frame — about 100 dependent stream operations
+// per solve, each of which queues behind the networks' convolution workgroups when the tracker shares the GPU (2.0 ms alone, 4.6 ms inside the pipeline).  Here the whole
+// solve (core/optimization_algorithm_levenberg.cpp:61-189 around block_solver.hpp:354-486) is one launch of a few dozen resident workgroups that walk the phases of an
+// iteration together, separated by grid-wide barriers (xwg.hpp), and take the accept / reject / stop decisions from the same reduced scalars — every thread of every
+// workgroup runs the same control flow, no broadcast, no host:
+//   L   linearise (ba_linearize_body over the grid's share of the observations, the measurement stored next to W) + camera-camera factors
+//   M   first iteration only: max |diagonal| for the initial lambda
+//   S   Schur complement of this workgroup's landmarks into its LDS copy of the reduced system -> one partial per workgroup
+//   F   fold: S = camera part + lambda I + sum of the partials (plain stores: nothing to clear, no atomics), r likewise
+//   C   workgroup 0: pose-block Cholesky + back sweep in LDS, trial cameras, camera part of computeScale; the others wait
+//   B   back-substitution with the trial's chi2 formed per landmark from the slot records (8 lanes per landmark), camera-camera factors at the trial state; the
+//       accumulators of the NEXT linearisation (the other of two copies) are cleared here
+// and then decide.  5 barriers per iteration; the accepted state flips between two buffers and is copied home at the end.
+struct BaLmCtl { unsigned bar_count, abort_word; int status, iterations, trials, n_lin, barriers, pad; double lambda_final, chi2_initial, chi2_final, lin_ticks; };
+struct BaLocalArgs {
+    BaLmCtl* ctl; double *red0, *red1, *S_part, *cam_out, *pt_home;
+    int n_ptl, kcap, max_iters; unsigned bar_base; double gain_threshold;
+};
+#define BAL_NT 512
+
+__device__ __forceinline__ double bal_ld(const double* p) { return __longlong_as_double((long long)xwg_load64((const unsigned long long*)p)); }
+__device__ __forceinline__ void bal_st(double* p, double v) { xwg_store64((unsigned long long*)p, (unsigned long long)__double_as_longlong(v)); }
+
+// F: the reduced system from the camera part and the workgroups' partial Schur sums.  parts are block-major (ba_schur_body<0>): lower-triangle 6x6 blocks at
+// [bid * SB_PITCH + 6a + b], then the rhs; S is dense row-major, only its lower block triangle is written (all the factorisation reads).
+__device__ __forceinline__ void ba_fold_local_body(const BaDev& P, const double* __restrict__ S_part, int nparts, double lambda, int gt, int gnt)
+{
+    const int nc = P.n6 / 6, nblk_l = nc * (nc + 1) / 2, rhs_off = nblk_l * SB_PITCH;
+    const size_t sz = (size_t)rhs_off + P.n6;
+    if (gt < 2) bal_st(P.scal + 2 + gt, 0.0);                  // tempChi / scale of the trial that follows
+    for (int t = gt; t < nblk_l * 36 + P.n6; t += gnt) {
+        const bool is_rhs = t >= nblk_l * 36;
+        const int bid = t / 36, el = t - bid * 36;
+        const size_t src = is_rhs ? (size_t)rhs_off + (t - nblk_l * 36) : (size_t)bid * SB_PITCH + el;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int q = 0;
+        for (; q + 3 < nparts; q += 4) {                        // four independent load streams in flight
+            s0 += S_part[(size_t)q * sz + src]; s1 += S_part[(size_t)(q + 1) * sz + src];
+            s2 += S_part[(size_t)(q + 2) * sz + src]; s3 += S_part[(size_t)(q + 3) * sz + src];
+        }
+        for (; q < nparts; q++) s0 += S_part[(size_t)q * sz + src];
+        double v = (s0 + s1) + (s2 + s3);
+        if (is_rhs) { const int a = t - nblk_l * 36; P.r[a] = P.bc[a] + v; continue; }
+        int ci = (int)((sqrtf(8.f * (float)bid + 1.f) - 1.f) * 0.5f);
+        ci -= (ci * (ci + 1) / 2 > bid); ci += ((ci + 1) * (ci + 2) / 2 <= bid);
+        const int cj = bid - ci * (ci + 1) / 2, a = el / 6, b = el - a * 6;
+        if (ci == cj) { v += P.Hcd[36 * ci + el]; if (a == b) v += lambda; }
+        else for (int k = 0; k < P.n_odo; k++) {                 // camera-camera factors between the two poses (k_ba_init_S, inline_odo)
+            const int i = P.odo_i[k], j = P.odo_j[k];
+            if (i == ci && j == cj) v += P.Hodo[36 * k + a * 6 + b];
+            if (j == ci && i == cj) v += P.Hodo[36 * k + b * 6 + a];
+        }
+        P.S[(size_t)(6 * ci + a) * P.n6 + 6 * cj + b] = v;
+    }
+}
+// B: k_ba_backsub with the robust chi2 of the trial state formed on the way.  8 lanes per landmark; after the xor shuffles all 8 hold the landmark's sums, so every lane has
+// the new point and walks its share of the slots a second time: e = R_new^T (p_new - t_new) - m with the measurement the linearisation left in the slot record.
+__device__ __forceinline__ void ba_backsub_chi2_body(const BaDev& P, int n_ptl, double lambda, int gt, int gnt, double* wsum /*[32] LDS*/)
+{
+    const int sub = threadIdx.x & 7;
+    double sc = 0, chi = 0;
+    for (int l0 = gt >> 3; l0 - (int)(threadIdx.x >> 3) < n_ptl; l0 += gnt >> 3) {   // uniform trip count per workgroup
+        const int l = l0;
+        const bool on = l < n_ptl;
+        double t0 = 0, t1 = 0, t2 = 0;
+        int beg = 0, end = 0;
+        if (on) {
+            beg = P.pt_start[l]; end = P.pt_start[l + 1];
+            for (int s = beg + sub; s < end; s += 8) {
+                const double* W = P.W + BA_REC * (size_t)s; const double* xc = P.x + 6 * P.slot_cam[s];
+#pragma unroll
+                for (int a = 0; a < 6; a++) { t0 -= W[a * 3] * xc[a]; t1 -= W[a * 3 + 1] * xc[a]; t2 -= W[a * 3 + 2] * xc[a]; }
+            }
+        }
+#pragma unroll
+        for (int o = 4; o >= 1; o >>= 1) { t0 += __shfl_xor(t0, o, 64); t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+        if (on) {
+            const double b0 = P.bp[3 * (size_t)l], b1 = P.bp[3 * (size_t)l + 1], b2 = P.bp[3 * (size_t)l + 2];
+            t0 += b0; t1 += b1; t2 += b2;
+            double Di[9]; inv3sym(P.Hpp + 6 * (size_t)l, lambda, Di);
+            const double x0 = Di[0] * t0 + Di[1] * t1 + Di[2] * t2, x1 = Di[3] * t0 + Di[4] * t1 + Di[5] * t2, x2 = Di[6] * t0 + Di[7] * t1 + Di[8] * t2;
+            const double p0 = P.pt[3 * (size_t)l] + x0, p1 = P.pt[3 * (size_t)l + 1] + x1, p2 = P.pt[3 * (size_t)l + 2] + x2;
+            if (sub == 0) {
+                P.pt_new[3 * (size_t)l] = p0; P.pt_new[3 * (size_t)l + 1] = p1; P.pt_new[3 * (size_t)l + 2] = p2;
+                sc += x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+            }
+            for (int s = beg + sub; s < end; s += 8) {
+                const double* X = P.cam_new + 12 * P.slot_cam[s]; const double* m = P.W + BA_REC * (size_t)s + 27;
+                const double d0 = p0 - X[3], d1 = p1 - X[7], d2 = p2 - X[11];
+                const double e0 = X[0] * d0 + X[4] * d1 + X[8] * d2 - m[0], e1 = X[1] * d0 + X[5] * d1 + X[9] * d2 - m[1], e2 = X[2] * d0 + X[6] * d1 + X[10] * d2 - m[2];
+                double v, w; huber_w(P.info_obs * (e0 * e0 + e1 * e1 + e2 * e2), P.huber_obs, P.use_huber, v, w);
+                chi += v;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { sc += __shfl_xor(sc, o, 64); chi += __shfl_xor(chi, o, 64); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = sc; wsum[16 + (threadIdx.x >> 6)] = chi; }
+    __syncthreads();
+    if (threadIdx.x < 2) { double t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += wsum[16 * threadIdx.x + w]; if (t != 0) atomicAdd(P.scal + (threadIdx.x == 0 ? 3 : 2), t); }
+}
+
+// ---- the same bodies as stand-alone launches of the HOST-driven local-window loop (the default: see DESIGN.md section 9 for why the persistent form is opt-in).  Round 3
+// spent 11 stream operations per LM iteration on the window (memset, linearise, camera factors | init S, Schur, fold, memset, Cholesky, back-substitution, chi2, camera
+// factors, read-back); with these it is 6: the camera factors ride in the linearisation / back-substitution launches as extra workgroups, the fold writes S outright (no
+// init, no atomics), the trial chi2 is formed landmark-major inside the back-substitution, the accumulators are double-buffered and cleared by the previous iteration.
+__global__ __launch_bounds__(LIN_THREADS) void k_ba_lin_local(BaDev P, int nvb)
+{
+    __shared__ __attribute__((aligned(16))) double lin_smem[LIN_SMEM_DOUBLES(LIN_THREADS)];
+    if ((int)blockIdx.x < nvb) { ba_linearize_body<LIN_THREADS, true>(P, 1, blockIdx.x, lin_smem); return; }
+    ba_camfactor_body(P, 1, P.cam, P.scal + 0, ((int)blockIdx.x - nvb) * (LIN_THREADS / 64) + (int)(threadIdx.x >> 6), threadIdx.x & 63);      // (a factor index past the list returns)
+}
+__global__ __launch_bounds__(256) void k_ba_fold_local(BaDev P, const double* S_part, int nparts, double lambda) { ba_fold_local_body(P, S_part, nparts, lambda, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256); }
+__global__ __launch_bounds__(256) void k_ba_backsub_chi2_local(BaDev P, int n_ptl, double lambda, int n_bs, double* zero_buf, int zero_len)
+{
+    __shared__ double wsum[32];
+    if ((int)blockIdx.x < n_bs) {
+        ba_backsub_chi2_body(P, n_ptl, lambda, blockIdx.x * 256 + threadIdx.x, n_bs * 256, wsum);
+        if (zero_buf) for (int t = blockIdx.x * 256 + threadIdx.x; t < zero_len; t += n_bs * 256) zero_buf[t] = 0.0;      // the NEXT linearisation's accumulators (the other copy)
+        return;
+    }
+    ba_camfactor_body(P, 0, P.cam_new, P.scal + 2, ((int)blockIdx.x - n_bs) * 4 + (int)(threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// The solver's state flips between two buffers (accepted / trial) and the linearisation's accumulators between two copies: four variants of the problem descriptor, all
+// in the kernel arguments (constant memory, read with scalar loads where a field is used); `sel` picks one.  A descriptor mutated in place would live in registers.
+struct BaDev4 { BaDev v[4]; };      // [accumulator copy (iteration parity)][state flip]
+static_assert(sizeof(BaDev4) + sizeof(BaLocalArgs) <= 4000, "kernel arguments of k_ba_local_lm exceed the 4 KB kernarg segment");
+__global__ __launch_bounds__(BAL_NT) void k_ba_local_lm(BaDev4 V, BaLocalArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) double bal_smem[];
+    __shared__ int bar_flag;
+    __shared__ double bal_wsum[32];
+    const int bid = blockIdx.x, nblk = gridDim.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = BAL_NT / 64, gt = bid * BAL_NT + tid, gnt = nblk * BAL_NT;
+    unsigned phase = 0; bool dead = false;
+    auto barrier = [&]() { if (!dead && !xwg_grid_barrier(&A.ctl->bar_count, &A.ctl->abort_word, (unsigned)nblk, A.bar_base, ++phase, &bar_flag)) dead = true; };
+    const int n6 = V.v[0].n6, n_cam = V.v[0].n_cam, n_obs = V.v[0].n_obs, ncf = V.v[0].n_odo + (V.v[0].prior_cam >= 0 ? 1 : 0);
+    const size_t red_len = (size_t)n_cam * 36 + n6 + 8;
+    for (size_t t = gt; t < red_len; t += gnt) { A.red0[t] = 0.0; A.red1[t] = 0.0; }
+    barrier();
+    double lambda = -1, ni = 2, lastChi = 0, chi2_check = 0, chi_init = 0, chi_final = 0, lin_ticks = 0; int nBad = 0, trials = 0, it = 0, n_lin = 0, flip = 0;
+    for (it = 0; it < A.max_iters && !dead; it++) {
+        double* red_next = (it & 1) ? A.red0 : A.red1;
+        // ---- L
+        const long long tk0 = wall_clock64();
+        { const BaDev& P = V.v[(it & 1) * 2 + flip];
+          const int nvb = (n_obs + BAL_NT - 1) / BAL_NT;
+          for (int vb = bid; vb < nvb; vb += nblk) { ba_linearize_body<BAL_NT, true>(P, 1, vb, bal_smem); __syncthreads(); }
+          for (int f = bid * nw + wave; f < ncf; f += nblk * nw) ba_camfactor_body(P, 1, P.cam, P.scal + 0, f, lane); }
+        barrier();
+        lin_ticks += (double)(wall_clock64() - tk0); n_lin++;
+        if (it == 0) { ba_maxdiag_body(V.v[flip], A.n_ptl, gt, gnt); barrier(); }
+        const double* scal = V.v[(it & 1) * 2].scal;
+        double currentChi = bal_ld(scal + 0); const double iniChi = currentChi;
+        if (it == 0) { lambda = 1e-5 * bal_ld(scal + 1); ni = 2; nBad = 0; chi_init = currentChi; chi_final = currentChi; }
+        double rho = 0; int qmax = 0;
+        do {
+            const BaDev& P = V.v[(it & 1) * 2 + flip];
+            // ---- S
+            ba_schur_body<0>(P, A.n_ptl, lambda, A.kcap, A.S_part, (const int*)nullptr, (const int*)nullptr, (const int2*)nullptr, bid, nblk, bal_smem);
+            barrier();
+            // ---- F
+            ba_fold_local_body(P, A.S_part, nblk, lambda, gt, gnt);
+            barrier();
+            // ---- C
+            if (bid == 0) ba_chol_small6_body<BAL_NT>(P, 1, lambda, bal_smem);
+            barrier();
+            // ---- B
+            ba_backsub_chi2_body(P, A.n_ptl, lambda, gt, gnt, bal_wsum);
+            for (int f = bid * nw + wave; f < ncf; f += nblk * nw) ba_camfactor_body(P, 0, P.cam_new, P.scal + 2, f, lane);
+            if (qmax == 0) for (size_t t = gt; t < red_len; t += gnt) red_next[t] = 0.0;      // (the other copy was last read in the previous iteration)
+            barrier();
+            const bool ok2 = bal_ld(scal + 4) > 0.5;
+            const double tempChi = ok2 ? bal_ld(scal + 2) : DBL_MAX, scale = ok2 ? bal_ld(scal + 3) : 0.0;
+            rho = (currentChi - tempChi) / (scale + 1e-3);
+            if (rho > 0 && isfinite(tempChi)) {
+                const double tr = 2 * rho - 1; double alpha = 1. - tr * tr * tr; alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
+                flip ^= 1;                                   // the trial state becomes the accepted one
+            } else { lambda *= ni; ni *= 2; }
+            qmax++; trials++;
+        } while (rho < 0 && qmax < 10 && !dead);
+        bool terminate = (qmax == 10 || rho == 0);
+        if (!terminate) { if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0; if (nBad >= 3) terminate = true; }
+        const double chiNow = currentChi;
+        if (chi2_check < chiNow && it > 0) terminate = true;
+        chi2_check = chiNow;
+        if (it == 0) lastChi = chiNow;
+        else { const double gain = (lastChi - chiNow) / chiNow; lastChi = chiNow; if (gain >= 0 && gain < A.gain_threshold) terminate = true; }
+        chi_final = chiNow;
+        if (terminate) { it++; break; }
+    }
+    // the accepted state goes home: cameras into cam_out, landmarks into the caller's array when the last accepted trial left them in the other buffer
+    { const BaDev& P = V.v[flip];
+      for (int t = gt; t < n_cam * 12; t += gnt) A.cam_out[t] = P.cam[t];
+      if (P.pt != A.pt_home) for (size_t t = gt; t < (size_t)A.n_ptl * 3; t += gnt) A.pt_home[t] = P.pt[t]; }
+    if (gt == 0) {
+        BaLmCtl* c = A.ctl;
+        c->status = dead ? 1 : 0; c->iterations = it; c->trials = trials; c->n_lin = n_lin; c->barriers = (int)phase;
+        c->lambda_final = lambda; c->chi2_initial = chi_init; c->chi2_final = chi_final; c->lin_ticks = lin_ticks;
+    }
 }
 
 // ---- object part: dynamic-point chains -------------------------------------------------------------------------
@@ -2239,12 +2473,14 @@ struct BaState {
     char* pool = nullptr; char* h_pool = nullptr; size_t pool_cap = 0, hpool_cap = 0;
     int* d_long = nullptr; size_t long_cap = 0;      // landmarks with > 64 observations
     double* d_bcr = nullptr; size_t bcr_cap = 0;     // block-cyclic-reduction workspace (superblocks D, L x2, GL, GR, b, y)
+    struct BaLmCtl* d_ctl = nullptr; struct BaLmCtl* h_ctl = nullptr; unsigned bar_base = 0;   // persistent local-window solver: control block (device + pinned mirror), barrier count so far
 };
 void ba_state_destroy(vido_ctx* ctx)
 {
     BaState* S = ctx->ba; if (!S) return;
     for (void* p : S->allocs) hipFree(p);
     hipFree(S->d_parts); hipFree(S->d_scratch); hipHostFree(S->h_scal); hipFree(S->pool); hipHostFree(S->h_pool); hipFree(S->d_long); hipFree(S->d_bcr);
+    hipFree(S->d_ctl); hipHostFree(S->h_ctl);
     if (S->ev0) hipEventDestroy(S->ev0);
     if (S->ev1) hipEventDestroy(S->ev1);
     delete S; ctx->ba = nullptr;
@@ -2539,7 +2775,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     phase("slot tables, checks");
     // ---- device buffers
     {   // size the persistent pool (device + pinned mirror for the uploads) for this problem
-        const size_t ndb = (size_t)n_pose * (24 + 36 + 36) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + BA_REC) + (size_t)n_cc * (12 + 36 + 2) + (size_t)n6 * n6 + 5 * (size_t)n6 + 64 +
+        const size_t ndb = (size_t)n_pose * (24 + 36 + 36 + 36 + 12) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + BA_REC) + (size_t)n_cc * (12 + 36 + 2) + (size_t)n6 * n6 + 6 * (size_t)n6 + 128 +
                            (size_t)nd * (3 + 3 + 3 + 6 + 3 + 9 + 18 * 4 + 3);
         const size_t ni32 = 2 * (size_t)n_pose + 5 * (size_t)no + 4 * (size_t)n_ptl + (size_t)n_ptl / 32 + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 256;
         const size_t need = ndb * 8 + ni32 * 4 + 96 * 256;
@@ -2667,6 +2903,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     double* red = A.get<double>((size_t)n_pose * 36 + n6 + 8);      // [Hcd | bc | scal] contiguous for the linearisation all-reduce
     D.Hcd = red; D.bc = red + (size_t)n_pose * 36; D.scal = D.bc + n6;
     Bc.ok = D.scal + 4;
+    double* red1 = A.get<double>((size_t)n_pose * 36 + n6 + 8);     // second copy of the linearisation accumulators + the accepted cameras (persistent local-window solver)
+    double* cam_out = A.get<double>((size_t)n_pose * 12);
     if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device allocation failed (n6=%d, n_obs=%d)", n6, no);
 #ifndef BA_SCHUR0_GRID
 #define BA_SCHUR0_GRID 256
@@ -2778,18 +3016,75 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     res->ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     const auto t_loop = std::chrono::steady_clock::now();
     double lambda = -1, ni = 2, lastChi = 0, chi2_check = 0, ms_lin = 0; int nBad = 0, trials = 0, it = 0, n_lin = 0;
-    if ((rc = chi2_at(D.cam, D.pt, 2, &res->chi2_initial))) return rc;
-    res->chi2_final = res->chi2_initial;
+    // ---- the local window as one persistent launch (k_ba_local_lm): static graph, LDS-resident reduced system, one GPU
+    // (opt-in, VIDO_BA_PERSIST=1: measured SLOWER than the host-driven loop below — 3.0 against 2.1 ms per solve alone on the GPU — and its 32 full-CU workgroups never
+    //  all become resident while the networks keep the chip busy; DESIGN.md section 9.  The default local-window path is the fused host-driven loop, `fl`.)
+    static const bool want_persist = getenv("VIDO_BA_PERSIST") != nullptr, no_fused_local = getenv("VIDO_BA_NO_FUSED_LOCAL") != nullptr;
+    const bool local_static = lds_path && !allreduce && nd == 0 && n6 % 6 == 0 && n6 >= 12 && n_pose <= 64 && D.n_odo <= 64 && n_long == 0 && p.max_iters >= 1 && n_ptl > 0 && no > 0;
+    bool persist = local_static && want_persist;
+    const double* cam_final = nullptr;
+    if (persist) {
+        static const int persist_wgs = [] { const char* e = getenv("VIDO_BA_PERSIST_WGS"); const int v = e ? atoi(e) : 32; return std::max(1, std::min(v, 64)); }();
+        const size_t lds_bal = std::max(std::max(lds_chol6, (loc_sz + (size_t)(BAL_NT / 64) * (2 * kcap * 18 + kcap)) * sizeof(double)), (size_t)LIN_SMEM_DOUBLES(BAL_NT) * sizeof(double));
+        if (lds_bal > 159 * 1024) persist = false;
+        else {
+            if (!BS->d_ctl) { HIP_TRY(ctx, hipMalloc((void**)&BS->d_ctl, sizeof(BaLmCtl))); HIP_TRY(ctx, hipMemset(BS->d_ctl, 0, sizeof(BaLmCtl))); HIP_TRY(ctx, hipHostMalloc((void**)&BS->h_ctl, sizeof(BaLmCtl))); BS->bar_base = 0; }
+            if ((size_t)persist_wgs * loc_sz > BS->parts_cap) {
+                HIP_TRY(ctx, hipStreamSynchronize(st)); if (BS->d_parts) hipFree(BS->d_parts);
+                BS->parts_cap = (size_t)BA_SCHUR0_GRID * sz_sr; HIP_TRY(ctx, hipMalloc((void**)&BS->d_parts, BS->parts_cap * sizeof(double)));
+            }
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_local_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bal));
+            BaDev4 V;
+            for (int par = 0; par < 2; par++) for (int flip = 0; flip < 2; flip++) {
+                BaDev& Q = V.v[par * 2 + flip]; Q = D;
+                double* rp = par ? red1 : red; Q.Hcd = rp; Q.bc = rp + (size_t)n_pose * 36; Q.scal = Q.bc + n6;
+                if (flip) { std::swap(Q.cam, Q.cam_new); std::swap(Q.pt, Q.pt_new); }
+            }
+            BaLocalArgs LA{BS->d_ctl, red, red1, BS->d_parts, cam_out, D.pt, n_ptl, kcap, p.max_iters, BS->bar_base, p.gain_threshold};
+            hipLaunchKernelGGL(k_ba_local_lm, dim3(persist_wgs), dim3(BAL_NT), lds_bal, st, V, LA);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemcpyAsync(BS->h_ctl, BS->d_ctl, sizeof(BaLmCtl), hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(poses.data(), cam_out, (size_t)n_pose * 12 * sizeof(double), hipMemcpyDeviceToHost, st));      // (pageable destination: the copy is complete on return)
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            const BaLmCtl& C = *BS->h_ctl;
+            if (C.status != 0) {      // a workgroup never arrived at a barrier (never seen; the spins are bounded so that this is an error, not a hang)
+                HIP_TRY(ctx, hipMemset(BS->d_ctl, 0, sizeof(BaLmCtl))); BS->bar_base = 0;
+                return vido_set_error(ctx, VIDO_E_HIP, "ba: the persistent local-window solver lost a workgroup at a grid barrier (%d barriers in)", C.barriers);
+            }
+            BS->bar_base += (unsigned)C.barriers * (unsigned)persist_wgs;
+            it = C.iterations; trials = C.trials; lambda = C.lambda_final; n_lin = C.n_lin; ms_lin = C.lin_ticks * 1e-5;      // wall_clock64: 100 MHz
+            res->chi2_initial = C.chi2_initial; res->chi2_final = C.chi2_final;
+            cam_final = cam_out;
+        }
+    }
+    // the fused host-driven loop of the local window (k_ba_lin_local / k_ba_fold_local / k_ba_backsub_chi2_local): 6 stream operations per LM iteration instead of 11
+    const bool fl = local_static && !persist && !no_fused_local;
+    static const int fl_schur_grid_env = [] { const char* e = getenv("VIDO_BA_SCHUR0_GRID"); return e ? std::max(1, std::min(atoi(e), BA_SCHUR0_GRID)) : 64; }();
+    const int fl_grid = std::min(fl_schur_grid_env, std::max(1, (n_ptl + 3) / 4));       // partial reduced systems: every one is summed by the fold, 64 measured against 256 (tools/scratch)
+    const size_t red_len = (size_t)n_pose * 36 + n6 + 8;
+    if (!persist) {
+    if (!fl) { if ((rc = chi2_at(D.cam, D.pt, 2, &res->chi2_initial))) return rc; res->chi2_final = res->chi2_initial; }
     for (it = 0; it < p.max_iters; it++) {
         // ---- linearise
+        const int ncf = D.n_odo + (D.prior_cam >= 0 ? 1 : 0);
+        if (fl) {
+            // accumulators double-buffered by iteration parity: this iteration's copy was cleared by the previous iteration's back-substitution launch (both copies — they are
+            // neighbours in the arena — by one memset before the first)
+            if (it == 0) HIP_TRY(ctx, hipMemsetAsync(red, 0, (size_t)((char*)(red1 + red_len) - (char*)red), st));
+            double* rp = (it & 1) ? red1 : red; D.Hcd = rp; D.bc = rp + (size_t)n_pose * 36; D.scal = D.bc + n6;
+            const int nvb = (no + LIN_THREADS - 1) / LIN_THREADS;
+            if (it == 0) HIP_TRY(ctx, hipEventRecord(BS->ev0, st));
+            hipLaunchKernelGGL(k_ba_lin_local, dim3(nvb + (ncf + LIN_THREADS / 64 - 1) / (LIN_THREADS / 64)), dim3(LIN_THREADS), 0, st, D, nvb);
+            if (it == 0) { HIP_TRY(ctx, hipEventRecord(BS->ev1, st)); n_lin++; }
+        } else {
         HIP_TRY(ctx, hipMemsetAsync(red, 0, ((size_t)n_pose * 36 + n6 + 8) * sizeof(double), st));
         HIP_TRY(ctx, hipEventRecord(BS->ev0, st));
         if (no) hipLaunchKernelGGL(k_ba_linearize, dim3((no + LIN_THREADS * lin_E - 1) / (LIN_THREADS * lin_E)), dim3(LIN_THREADS), 0, st, D, lin_E);
         HIP_TRY(ctx, hipEventRecord(BS->ev1, st));
         if (nd) hipLaunchKernelGGL(k_badyn_linearize, dim3((nd + 255) / 256), dim3(256), 0, st, D);
         n_lin++;
-        const int ncf = D.n_odo + (D.prior_cam >= 0 ? 1 : 0);
         if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3(ncf), dim3(64), 0, st, D, 1, D.cam, D.scal + 0);
+        }
         if (it == 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3(64), dim3(256), 0, st, D, n_ptl);
         HIP_TRY(ctx, hipGetLastError());
         if (allreduce) {     // camera diagonal blocks, bc, chi2 (sum) — then the max-diagonal (max) on its own
@@ -2810,9 +3105,19 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if ((rc = read_scal())) return rc;
             currentChi = iniChi = BS->h_scal[0]; have_chi = true;
             if (it == 0) { lambda = 1e-5 * BS->h_scal[1]; ni = 2; nBad = 0; }
+            if (it == 0 && fl) { res->chi2_initial = res->chi2_final = currentChi; float ms = 0; if (hipEventElapsedTime(&ms, BS->ev0, BS->ev1) == hipSuccess) ms_lin += ms; }      // (the linearisation point of the first iteration IS the initial state; the timed launch carries the camera factors too)
         }
         double rho = 0; int qmax = 0;
         do {
+            if (fl) {
+                // ---- S, F, C, B as four launches (bodies shared with k_ba_local_lm)
+                hipLaunchKernelGGL(k_ba_schur<0>, dim3(fl_grid), dim3(64 * schur0_waves), lds_schur, st, D, n_ptl, lambda, kcap, BS->d_parts, (const int*)nullptr, (const int*)nullptr, (const int2*)nullptr);
+                hipLaunchKernelGGL(k_ba_fold_local, dim3(std::min(64, (int)((loc_sz + 255) / 256))), dim3(256), 0, st, D, (const double*)BS->d_parts, fl_grid, lambda);
+                hipLaunchKernelGGL(k_ba_chol_small6, dim3(1), dim3(CH_NT), lds_chol6, st, D, 1, lambda);
+                const int n_bs = std::min((n_ptl + 31) / 32, 1024);
+                hipLaunchKernelGGL(k_ba_backsub_chi2_local, dim3(n_bs + (ncf + 3) / 4), dim3(256), 0, st, D, n_ptl, lambda, n_bs, qmax == 0 ? ((it & 1) ? red : red1) : (double*)nullptr, (int)red_len);
+                HIP_TRY(ctx, hipGetLastError());
+            } else {
             // ---- reduced system of this shard.  With an all-reduce every rank contributes Hcd/bc ALREADY summed,
             // so only rank 0 adds the camera-camera part (+lambda) to S; the others start from zero.
             const int add_cam = (!allreduce || p.rank == 0) ? 1 : 0;
@@ -2871,9 +3176,10 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3(ncf), dim3(64), 0, st, D, 0, D.cam_new, D.scal + 2);
             HIP_TRY(ctx, hipGetLastError());
             if ((rc = AR(D.scal + 2, 2, 0))) return rc;
+            }
             if ((rc = read_scal())) return rc;
             if (!have_chi) { currentChi = iniChi = BS->h_scal[0]; have_chi = true; }
-            if (qmax == 0) { float ms = 0; if (hipEventElapsedTime(&ms, BS->ev0, BS->ev1) == hipSuccess) ms_lin += ms; }
+            if (qmax == 0 && !fl) { float ms = 0; if (hipEventElapsedTime(&ms, BS->ev0, BS->ev1) == hipSuccess) ms_lin += ms; }
             const bool ok2 = BS->h_scal[4] > 0.5;
             const double tempChi = ok2 ? BS->h_scal[2] : DBL_MAX, scale = ok2 ? BS->h_scal[3] : 0.0;
             rho = (currentChi - tempChi) / (scale + 1e-3);
@@ -2894,10 +3200,11 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         res->chi2_final = chiNow;
         if (terminate) { it++; break; }
     }
+    }
     res->iterations = it; res->lm_trials = trials; res->lambda_final = lambda;
-    res->ms_linearize_kernel = n_lin ? ms_lin / n_lin : 0.0;
+    res->ms_linearize_kernel = n_lin ? ms_lin / n_lin : 0.0;      // (persistent solver: the linearisation phase up to its grid barrier, device clock)
     res->ms_solve_loop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
-    HIP_TRY(ctx, hipMemcpyAsync(poses.data(), D.cam, (size_t)n_pose * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (!cam_final) HIP_TRY(ctx, hipMemcpyAsync(poses.data(), D.cam, (size_t)n_pose * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (n_ptl && !DI) HIP_TRY(ctx, hipMemcpyAsync(prob->pt_xyz + 3 * (size_t)pt_lo, D.pt, (size_t)n_ptl * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (n_ptl && DI && D.pt != DI->pt) HIP_TRY(ctx, hipMemcpyAsync(DI->pt, D.pt, (size_t)n_ptl * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));      // the accepted state may sit in the other buffer
     if (nd) HIP_TRY(ctx, hipMemcpyAsync(d_xyz.data(), D.dyn, (size_t)nd * 3 * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -221,13 +221,24 @@ void Frame::SetPose(cv::Mat Tcw)                          // Frame.cc SetPose / 
     mRwc = mRcw.t(); mOw = cv::Mat(3, 1, CV_32F);
     for (int r = 0; r < 3; r++) { double s = 0; for (int c = 0; c < 3; c++) s += (double)(-mRwc.at<float>(r, c)) * mtcw.at<float>(c); mOw.at<float>(r) = (float)s; }
 }
-static cv::Mat unproject(const Frame& F, float u, float v, float z)
+// Raw forms of Frame::UnprojectStereo* / ObtainFlowDepth* for the facade's own loops: the same float / double arithmetic without a cv::Mat per point.  The per-frame loops
+// made ~40 000 of those (a calloc + free each) and inverted the frame's pose once per POINT (Converter::toInvMatrix inside the unprojection): most of the ~2 ms of host time
+// between the tracker's kernels.  Twl = [mRwc | mOw] is what Frame::SetPose keeps (the same expression as Converter::toInvMatrix, entry by entry).
+static bool unproject_raw(const Frame& F, float u, float v, float z, float* out)
 {
     const float x = (u - F.cx) * z * F.invfx, y = (v - F.cy) * z * F.invfy;
-    cv::Mat Twl = Converter::toInvMatrix(F.mTcw), out(3, 1, CV_32F);
-    for (int r = 0; r < 3; r++) { const double s = (double)Twl.at<float>(r, 0) * x + (double)Twl.at<float>(r, 1) * y + (double)Twl.at<float>(r, 2) * z; out.at<float>(r) = (float)s + Twl.at<float>(r, 3); }
-    return out;
+    if (F.mRwc.empty() || F.mOw.empty()) {                    // pose never set through SetPose: the general form
+        const cv::Mat Twl = Converter::toInvMatrix(F.mTcw);
+        for (int r = 0; r < 3; r++) { const double s = (double)Twl.at<float>(r, 0) * x + (double)Twl.at<float>(r, 1) * y + (double)Twl.at<float>(r, 2) * z; out[r] = (float)s + Twl.at<float>(r, 3); }
+        return true;
+    }
+    const float* R = F.mRwc.ptr<float>(); const float* O = F.mOw.ptr<float>();
+    for (int r = 0; r < 3; r++) { const double s = (double)R[r * 3] * x + (double)R[r * 3 + 1] * y + (double)R[r * 3 + 2] * z; out[r] = (float)s + O[r]; }
+    return true;
 }
+static inline bool stat3d_raw(const Frame& F, int i, float* out) { const float z = F.mvStatDepth[i]; if (z < 0) return false; return unproject_raw(F, F.mvStatKeys[i].pt.x, F.mvStatKeys[i].pt.y, z, out); }
+static inline bool obj3d_raw(const Frame& F, int i, float* out) { const float z = F.mvObjDepth[i]; if (!(z > 0)) return false; return unproject_raw(F, F.mvObjKeys[i].pt.x, F.mvObjKeys[i].pt.y, z, out); }
+static cv::Mat unproject(const Frame& F, float u, float v, float z) { float o[3]; unproject_raw(F, u, v, z, o); return vec3(o[0], o[1], o[2]); }
 cv::Mat Frame::UnprojectStereoStat(const int& i, const bool&) { const float z = mvStatDepth[i]; if (z < 0) return cv::Mat(); return unproject(*this, mvStatKeys[i].pt.x, mvStatKeys[i].pt.y, z); }
 cv::Mat Frame::UnprojectStereoObject(const int& i, const bool&) { const float z = mvObjDepth[i]; if (!(z > 0)) return cv::Mat(); return unproject(*this, mvObjKeys[i].pt.x, mvObjKeys[i].pt.y, z); }
 cv::Mat Frame::ObtainFlowDepthCamera(const int& i, const bool&) { const float z = mvStatDepth[i]; if (!(z > 0)) return cv::Mat(); return vec3(mvFlowNext[i].x, mvFlowNext[i].y, z); }
@@ -307,8 +318,8 @@ int Optimizer::PoseOptimizationNew(Frame* cur, Frame* last, std::vector<int>& TM
     std::vector<double> Xw(3 * N), obs(2 * N);
     for (int i = 0; i < N; i++) {
         obs[2 * i] = cur->mvStatKeys[TM[i]].pt.x; obs[2 * i + 1] = cur->mvStatKeys[TM[i]].pt.y;
-        cv::Mat X = last->UnprojectStereoStat(TM[i], 0);
-        for (int a = 0; a < 3; a++) Xw[3 * i + a] = X.empty() ? 0.0 : X.at<float>(a);
+        float X[3]; const bool have = stat3d_raw(*last, TM[i], X);          // Frame::UnprojectStereoStat
+        for (int a = 0; a < 3; a++) Xw[3 * i + a] = have ? X[a] : 0.0;
     }
     vido_pose_problem p; fill_common(p, cur, N); p.mode = 0; p.Xw = Xw.data(); p.obs = obs.data(); toRow16(cur->mTcw, p.T_init);
     p.info_edge = 1.0; p.huber_delta = (double)std::sqrt(0.01f); p.use_huber = 1; p.rounds = 1; p.drop_kernel_after_round = 2;
@@ -327,8 +338,8 @@ int Optimizer::PoseOptimizationFlow2Cam(Frame* cur, Frame* last, std::vector<int
     const int N = (int)TM.size();
     std::vector<double> obs(2 * N), flow(2 * N), depth(N);
     for (int i = 0; i < N; i++) {
-        cv::Mat fd = last->ObtainFlowDepthCamera(TM[i], 0);
-        flow[2 * i] = fd.empty() ? 0.0 : fd.at<float>(0); flow[2 * i + 1] = fd.empty() ? 0.0 : fd.at<float>(1); depth[i] = fd.empty() ? 1.0 : fd.at<float>(2);
+        const float zd = last->mvStatDepth[TM[i]]; const bool have = zd > 0;      // Frame::ObtainFlowDepthCamera
+        flow[2 * i] = have ? last->mvFlowNext[TM[i]].x : 0.0; flow[2 * i + 1] = have ? last->mvFlowNext[TM[i]].y : 0.0; depth[i] = have ? zd : 1.0;
         obs[2 * i] = last->mvStatKeys[TM[i]].pt.x; obs[2 * i + 1] = last->mvStatKeys[TM[i]].pt.y;
     }
     vido_pose_problem p; fill_common(p, cur, N); p.mode = 1; p.obs = obs.data(); p.flow0 = flow.data(); p.depth = depth.data();
@@ -359,8 +370,8 @@ void build_objmot(ObjProblem& o, Frame* cur, Frame* last, const std::vector<int>
     o.Xw.resize(3 * N); o.obs.resize(2 * N);
     for (int i = 0; i < N; i++) {
         o.obs[2 * i] = cur->mvObjKeys[ObjId[i]].pt.x; o.obs[2 * i + 1] = cur->mvObjKeys[ObjId[i]].pt.y;
-        cv::Mat X = last->UnprojectStereoObject(ObjId[i], 0);
-        for (int a = 0; a < 3; a++) o.Xw[3 * i + a] = X.empty() ? 0.0 : X.at<float>(a);
+        float X[3]; const bool have = obj3d_raw(*last, ObjId[i], X);        // Frame::UnprojectStereoObject
+        for (int a = 0; a < 3; a++) o.Xw[3 * i + a] = have ? X[a] : 0.0;
     }
     vido_pose_problem& p = o.p; fill_common(p, cur, N); p.mode = 2; p.Xw = o.Xw.data(); p.obs = o.obs.data();
     toRow16(Converter::toInvMatrix(cur->mTcw) * InitModel, p.T_init);
@@ -376,8 +387,8 @@ void build_flow2(ObjProblem& o, Frame* cur, Frame* last, const std::vector<int>&
     const int N = (int)ObjId.size(); o.N = N; o.joint = true;
     o.obs.resize(2 * N); o.flow.resize(2 * N); o.depth.resize(N);
     for (int i = 0; i < N; i++) {
-        cv::Mat fd = last->ObtainFlowDepthObject(ObjId[i], 0);
-        o.flow[2 * i] = fd.empty() ? 0.0 : fd.at<float>(0); o.flow[2 * i + 1] = fd.empty() ? 0.0 : fd.at<float>(1); o.depth[i] = fd.empty() ? 1.0 : fd.at<float>(2);
+        const float zd = last->mvObjDepth[ObjId[i]]; const bool have = zd > 0;      // Frame::ObtainFlowDepthObject
+        o.flow[2 * i] = have ? last->mvObjFlowNext[ObjId[i]].x : 0.0; o.flow[2 * i + 1] = have ? last->mvObjFlowNext[ObjId[i]].y : 0.0; o.depth[i] = have ? zd : 1.0;
         o.obs[2 * i] = last->mvObjKeys[ObjId[i]].pt.x; o.obs[2 * i + 1] = last->mvObjKeys[ObjId[i]].pt.y;
     }
     vido_pose_problem& p = o.p; fill_common(p, cur, N); p.mode = 1; p.obs = o.obs.data(); p.flow0 = o.flow.data(); p.depth = o.depth.data();
@@ -734,7 +745,7 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
 {
     const auto t_grab = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-    StopFrame = nImage - 1;
+    StopFrame = nImage - 1; ms_wait_inputs = 0;
     if (mState == NO_IMAGES_YET) f_id = 0;
     if (imD.type() != CV_32FC1 || imFlow.type() != CV_32FC2 || maskSEM.type() != CV_32SC1 || !imD.isContinuous() || !imFlow.isContinuous() || !maskSEM.isContinuous())
         throw std::runtime_error("GrabImageRGBD: depth CV_32F, flow CV_32FC2, mask CV_32SC1 (continuous) expected");
@@ -766,7 +777,13 @@ cv::Mat Tracking::GrabImageRGBDDevice(const void* im_dev, int channels, int widt
         throw std::runtime_error("GrabImageRGBDDevice: device image (1 / 3 / 4 channels), depth, flow and mask pointers expected");
     vido_ctx* c = mpORBextractorLeft->context(width, height);
     g_ctx = c;
-    if (ready_event) check(vido_stream_wait_event(c, ready_event), "stream_wait_event");      // ordered behind the producer (the network stream) without a host wait
+    ms_wait_inputs = 0;
+    if (ready_event) {      // ordered behind the producer (the network stream) on the tracker's stream; the host then waits here, so that the wait for the frame's networks is a number
+        check(vido_stream_wait_event(c, ready_event), "stream_wait_event");      // of its own (ms_wait_inputs) instead of sitting inside the first stage that synchronises (round 3: ~5 of the "6.1 ms ORB" were this wait)
+        const auto tw = std::chrono::steady_clock::now();
+        check(vido_synchronize(c), "synchronize");
+        ms_wait_inputs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tw).count();
+    }
     memset(&g_tp, 0, sizeof g_tp);
     g_tp.dataset = mTestData == OMD ? 0 : (mTestData == KITTI ? 1 : 2); g_tp.depth_map_factor = mDepthMapFactor; g_tp.bf = mbf; g_tp.kaist_scale = mScale;
     g_tp.th_depth_bg = mThDepth; g_tp.th_depth_obj = mThDepthObj; g_tp.dense_step = 4; g_tp.fx = mK.at<float>(0, 0); g_tp.fy = mK.at<float>(1, 1); g_tp.cx = mK.at<float>(0, 2); g_tp.cy = mK.at<float>(1, 2);
@@ -853,9 +870,9 @@ cv::Mat Tracking::GetInitModelCam(const std::vector<int>& MatchId, std::vector<i
     std::vector<cv::Point2f> cur_2d(N); std::vector<cv::Point3f> pre_3d(N); std::vector<int> outl(N, 0);
     for (int i = 0; i < N; i++) {
         cur_2d[i] = C->mvStatKeys[MatchId[i]].pt;
-        cv::Mat X = L->UnprojectStereoStat(MatchId[i], 0);
-        if (X.empty()) { outl[i] = -1; continue; }
-        pre_3d[i] = cv::Point3f(X.at<float>(0), X.at<float>(1), X.at<float>(2));
+        float X[3];
+        if (!stat3d_raw(*L, MatchId[i], X)) { outl[i] = -1; continue; }      // Frame::UnprojectStereoStat
+        pre_3d[i] = cv::Point3f(X[0], X[1], X[2]);
     }
     std::vector<float> g3, g2; std::vector<int> gidx;
     for (int i = 0; i < N; i++) if (outl[i] == 0) { g3.push_back(pre_3d[i].x); g3.push_back(pre_3d[i].y); g3.push_back(pre_3d[i].z); g2.push_back(cur_2d[i].x); g2.push_back(cur_2d[i].y); gidx.push_back(i); }
@@ -880,8 +897,8 @@ void init_obj_inputs(ObjInit& o, Frame* C, Frame* L, const std::vector<int>& Obj
     o.cur_2d.resize(N); o.pre_3d.resize(N); o.g3.resize(3 * N); o.g2.resize(2 * N); o.mask.assign(std::max(N, 1), 0);
     for (int i = 0; i < N; i++) {
         o.cur_2d[i] = C->mvObjKeys[ObjId[i]].pt;
-        cv::Mat X = L->UnprojectStereoObject(ObjId[i], 0);
-        o.pre_3d[i] = X.empty() ? cv::Point3f(0, 0, 1) : cv::Point3f(X.at<float>(0), X.at<float>(1), X.at<float>(2));
+        float X[3];
+        o.pre_3d[i] = obj3d_raw(*L, ObjId[i], X) ? cv::Point3f(X[0], X[1], X[2]) : cv::Point3f(0, 0, 1);      // Frame::UnprojectStereoObject
         o.g3[3 * i] = o.pre_3d[i].x; o.g3[3 * i + 1] = o.pre_3d[i].y; o.g3[3 * i + 2] = o.pre_3d[i].z; o.g2[2 * i] = o.cur_2d[i].x; o.g2[2 * i + 1] = o.cur_2d[i].y;
     }
 }
@@ -1083,7 +1100,7 @@ void Tracking::Track()                                        // Tracking.cc:108
         std::vector<cv::Mat> centres(no);
         for (size_t i = 0; i < no; i++) {
             cv::Mat centre = vec3(0, 0, 0);
-            for (int id : ObjIdNew[i]) { cv::Mat X = L->UnprojectStereoObject(id, 0); if (X.empty()) continue; for (int a = 0; a < 3; a++) centre.at<float>(a) += X.at<float>(a); }
+            for (int id : ObjIdNew[i]) { float X[3]; if (!obj3d_raw(*L, id, X)) continue; for (int a = 0; a < 3; a++) centre.at<float>(a) += X[a]; }
             for (int a = 0; a < 3; a++) centre.at<float>(a) /= (float)ObjIdNew[i].size();
             centres[i] = centre; C->vObjCentre3D[i] = centre; C->vnObjID[i] = ObjIdNew[i];
         }
@@ -1258,7 +1275,7 @@ int vido_system_get_stats(const vido_system* s, vido_system_stats* o)
     for (int id : F->nStaInlierID) if (id >= 0) o->n_static_inliers++;
     int no = 0; for (size_t i = 0; i < F->bObjStat.size(); i++) if (F->bObjStat[i]) no++;
     o->n_objects = no; o->n_object_points = (int)F->mvObjKeys.size(); o->ba_window = std::min(std::max(T->f_id - 1, 0), T->nWINDOW_SIZE);
-    o->ms_total = T->ms_total; o->ms_update_mask = T->ms_update_mask; o->ms_frame = T->ms_frame;
+    o->ms_total = T->ms_total; o->ms_update_mask = T->ms_update_mask; o->ms_frame = T->ms_frame; o->ms_wait_inputs = T->ms_wait_inputs;
     if (T->all_timing.size() >= 5) { o->ms_cam_pose = T->all_timing[1]; o->ms_obj_tracking = T->all_timing[2]; o->ms_renew = T->all_timing[4]; }
     o->ms_obj_motion = T->ms_obj_motion_sum;
     o->ms_local_ba = M && !M->fLBA_time.empty() && T->f_id > 1 ? M->fLBA_time.back() : 0.f;

@@ -5,8 +5,9 @@
 // outer loop core/sparse_optimizer.cpp:354-427, Schur core/block_solver.hpp:354-486, Huber
 // core/robust_kernel_impl.cpp:65-91, residuals/Jacobians types/types_six_dof_expmap.{h,cpp}).
 //
-// Mapping: one workgroup (<=1024 threads, 16 waves) per problem, the WHOLE Levenberg-Marquardt run stays
-// on the device (no host round trip per iteration): every thread owns residuals i, i+T, ...; per
+// Mapping: a cluster of 1..8 workgroups (512 threads: one residual per thread from n = 512 on) per problem, the WHOLE
+// Levenberg-Marquardt run stays on the device (no host round trip per iteration); the workgroups of a cluster
+// exchange their partial sums through tagged words in HBM (xwg.hpp) and all run the same control flow; per
 // linearisation the 21+6 entries of J^T W J / J^T W e (+ chi2, + max diagonal) are summed with a
 // wavefront DPP/shuffle tree and one LDS pass across the waves; for the flow-coupled edges each
 // thread keeps its points' 2x2 (scalar*I) landmark block, 6x2 coupling block and rhs in HBM and forms
@@ -14,6 +15,7 @@
 // (LDL^T), so the LM accept/reject logic is wave-uniform without broadcasts.  All FP64.
 // Several problems (e.g. the frame's dynamic objects, or a batch of frames) run as a grid.
 #include "common.hpp"
+#include "xwg.hpp"
 #include <cfloat>
 
 struct PoseProbDev {
@@ -25,6 +27,7 @@ struct PoseProbDev {
     double *f, *err, *fsave, *Hpl, *Hll, *bl, *xl;
     unsigned char *outlier, *has_kernel;
     vido_pose_result* res;
+    unsigned long long* xch; int G;      // exchange area of the problem's workgroup cluster (PO_XCH_WORDS), cluster size
 };
 
 struct Se3 { double R[9], t[3]; };
@@ -151,14 +154,26 @@ struct WaveTranspose {
     }
 };
 // Workgroup barrier that orders LDS traffic only.  Every per-edge array in global memory is written and read by the SAME thread in every pass
-// (edge i belongs to thread i mod nt throughout), so nothing has to be visible across threads through global memory — but __syncthreads()
+// (edge i belongs to the same thread of the same workgroup throughout), so nothing has to be visible across threads through global memory — but __syncthreads()
 // also waits for the stores in flight (vmcnt(0)): 12 barriers per LM iteration x ~1.5 us of store latency was the whole n-independent part
 // of an iteration (19 of 67 us at N = 3000).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// workgroup all-reduce of NV doubles: entries [0, NSUM) are summed, entries [NSUM, NV) max-reduced.  Wave stage as above, then a
-// fixed-order pass over the per-wave partials in LDS.  Every thread returns the same totals.
+
+// ---- all-reduce over the workgroups of a problem (round 4) ---------------------------------------------------------------------------------------------------
+// A problem is solved by a CLUSTER of G workgroups (G = ceil(n / 512) <= 8: one edge per thread) that run the same LM control flow on the same reduced numbers.
+// Stage 1 is the workgroup reduction (wave transpose + one LDS pass); stage 2 exchanges the G workgroup totals through tagged granules (xwg.hpp): every workgroup
+// publishes its totals, reads everybody's and adds them in rank order — the sums are bit-identical in all G workgroups, so every branch of the LM policy stays uniform
+// across the cluster without a broadcast.  Two exchange buffers alternate by epoch parity: a workgroup can only be one exchange ahead of the slowest one (it needs that
+// one's contribution to finish its own), so the buffer it overwrites at epoch e + 2 has been read by everybody.
+#define PO_NMAX 56         // largest exchange: 29 linearisation entries + 27 Schur sums
+#define PO_GMAX 8
+#define PO_XCH_WORDS ((size_t)2 * PO_GMAX * PO_NMAX * 2)      // u64 words of one problem's exchange area
+struct Cluster { unsigned long long* xch; unsigned* abort_word; int G, rank; unsigned epoch; bool dead; };
+struct PoLds { double part[16 * 29]; double tot[PO_NMAX]; double xl[PO_GMAX * PO_NMAX]; double tsave[12]; int flag; };
+
+// workgroup stage: entries [0, NSUM) of v are summed, [NSUM, NV) max-reduced over the workgroup; totals land in tot[0..NV) (visible to all threads on return)
 template <int NV, int NSUM>
-__device__ void block_allreduce(double* v, double* lds /* [16][NV] + [NV] */)
+__device__ void wg_reduce(double* v, double* part /*[16][NV]*/, double* tot)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
@@ -171,21 +186,47 @@ __device__ void block_allreduce(double* v, double* lds /* [16][NV] + [NV] */)
     int idx; bool valid;
     WaveTranspose<NSUM, 32>::run(v, lane, idx, valid);
     lds_barrier();
-    if (valid) lds[wave * NV + idx] = v[0];
+    if (valid) part[wave * NV + idx] = v[0];
     if (lane == 0) {
 #pragma unroll
-        for (int k = NSUM; k < NV; k++) lds[wave * NV + k] = v[k];
+        for (int k = NSUM; k < NV; k++) part[wave * NV + k] = v[k];
     }
     lds_barrier();
     if (threadIdx.x < NV) {
         const int k = threadIdx.x;
-        double x = lds[k];
-        for (int w = 1; w < nw; w++) x = k >= NSUM ? fmax(x, lds[w * NV + k]) : x + lds[w * NV + k];
-        lds[16 * NV + k] = x;
+        double x = part[k];
+        for (int w = 1; w < nw; w++) x = k >= NSUM ? fmax(x, part[w * NV + k]) : x + part[w * NV + k];
+        tot[k] = x;
     }
     lds_barrier();
-#pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = lds[16 * NV + k];
+}
+// cluster stage on tot[0..nv): sum over the G workgroups (entry max_idx: maximum).  No-op for a single workgroup.
+__device__ void cluster_sum(double* tot, int nv, int max_idx, PoLds& L, Cluster& cs)
+{
+    if (cs.G == 1) return;
+    const unsigned ep = ++cs.epoch;
+    unsigned long long* buf = cs.xch + (size_t)(ep & 1u) * PO_GMAX * PO_NMAX * 2;
+    if (cs.dead) return;
+    if ((int)threadIdx.x < nv) xwg_publish_f64(buf + ((size_t)cs.rank * PO_NMAX + threadIdx.x) * 2, ep, tot[threadIdx.x]);
+    if (threadIdx.x == 0) L.flag = 0;
+    lds_barrier();
+    unsigned* xw = (unsigned*)L.xl;                       // [G][2 nv] 32-bit halves = [G][nv] doubles
+    const int nwords = cs.G * nv * 2;
+    for (int w = threadIdx.x; w < nwords; w += blockDim.x) {
+        const int g = w / (2 * nv), j = w - g * 2 * nv;
+        unsigned payload;
+        if (!xwg_wait_word(buf + (size_t)g * PO_NMAX * 2 + j, ep, cs.abort_word, &payload)) L.flag = 1;
+        xw[w] = payload;
+    }
+    lds_barrier();
+    if (L.flag) { cs.dead = true; if (threadIdx.x == 0) xwg_store32(cs.abort_word, 1u); }
+    if ((int)threadIdx.x < nv) {
+        const int k = threadIdx.x;
+        double x = L.xl[k];
+        for (int g = 1; g < cs.G; g++) x = k == max_idx ? fmax(x, L.xl[g * nv + k]) : x + L.xl[g * nv + k];
+        tot[k] = cs.dead ? 0.0 : x;
+    }
+    lds_barrier();
 }
 
 // 6x6 LDL^T solve in registers on the packed upper triangle (row-major: 00 01 .. 05 11 12 .. 55): the normal equations are wave-uniform
@@ -229,39 +270,53 @@ __device__ bool ldlt6p(const double* A, const double* b, double* x)
 
 #define NRED 29      // 21 H + 6 b + chi + maxdiag
 
-__global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict__ probs)
+// One LM iteration costs two exchanges in the steady state (round 3: four workgroup reductions behind four passes over the edges):
+//   pass L  residuals + Jacobians + normal equations; for the flow-coupled problems the Schur sums of the first trial are formed in the same pass from the values just
+//           computed (lambda is known from the previous iteration; the first iteration of a round — lambda comes from this very linearisation — and repeated trials
+//           take the separate pass S);
+//   pass T  trial state: flow update, new residuals, robust chi2 of the trial (edge part and prior part apart), computeScale, and the prior part at the OLD flows — so
+//           that activeRobustChi2() over "the errors left by the last trial" (sparse_optimizer.cpp:393-396), which round 3 evaluated with a fourth pass, is a sum of
+//           numbers this pass already has.
+// The end-of-round classification needs no reduction except the final inlier count.
+__global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict__ probs, const int2* __restrict__ wgmap, unsigned epoch0, unsigned* abort_word)
 {
-    __shared__ double lds[17 * NRED];
-    __shared__ double tsave[12];                              // pose before the trial step (restored when the step is rejected)
+    __shared__ PoLds L;
+    const int2 wm = wgmap[blockIdx.x];
     // a reference, not a copy: the ~130 dwords of the problem descriptor are wave-uniform and are re-read with scalar loads where they are used;
     // held in registers for the whole kernel they pushed the allocator into scratch (and a scratch reload waits on every store in flight)
-    const PoseProbDev& p = probs[blockIdx.x];
+    const PoseProbDev& p = probs[wm.x];
+    Cluster cs{p.xch, abort_word, p.G, wm.y, epoch0, false};
     // the edge->thread mapping depends on the problem alone (not on the batch it is launched with), so results are bit-identical
-    // however problems are grouped: nt = ~4 edges per thread, threads beyond it only take part in the reductions
-    const int n = p.n, nt = min((int)blockDim.x, max(64, (((n + 3) >> 2) + 63) & ~63)), tid = (int)threadIdx.x < nt ? (int)threadIdx.x : n;
+    // however problems are grouped.  One workgroup: nt = ~4 edges per thread (threads beyond it only take part in the reductions); a cluster: 512 threads per workgroup
+    const int n = p.n, G = p.G;
+    const int nt = G > 1 ? (int)blockDim.x : min((int)blockDim.x, max(64, (((n + 3) >> 2) + 63) & ~63));
+    const int tid = (int)threadIdx.x < nt ? wm.y * nt + (int)threadIdx.x : n, stride = G * nt;
     const bool flowm = p.mode == 1;
     Se3 T;
     auto reset_pose = [&]() {
 #pragma unroll
         for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T.R[r * 3 + c] = p.T_init[r * 4 + c]; T.t[r] = p.T_init[r * 4 + 3]; } };
     reset_pose();
-    for (int i = tid; i < n; i += nt) {
+    for (int i = tid; i < n; i += stride) {
         p.outlier[i] = 0; p.has_kernel[i] = p.use_huber ? 1 : 0;
         if (flowm) { p.f[2 * i] = p.flow0[2 * i]; p.f[2 * i + 1] = p.flow0[2 * i + 1]; }
     }
     int total_iters = 0, n_inl = 0; double chi2_final = 0;
     if (n >= 3) {
-        for (int round = 0; round < p.rounds; round++) {
+        for (int round = 0; round < p.rounds && !cs.dead; round++) {
             reset_pose();
             double lambda = -1, ni = 2, chi2_check = 0; int nBad = 0;
-            const int round_iters = probs[blockIdx.x].iters[round];        // dynamic index: read through the pointer so that the local copy `p` stays in registers
-            const float round_chi2_th = probs[blockIdx.x].chi2_th[round];
-            for (int it = 0; it < round_iters; it++) {
-                // ---- computeActiveErrors + buildSystem in one pass
-                double acc[NRED];
+            const int round_iters = probs[wm.x].iters[round];        // dynamic index: read through the pointer so that the local copy `p` stays in registers
+            const float round_chi2_th = probs[wm.x].chi2_th[round];
+            for (int it = 0; it < round_iters && !cs.dead; it++) {
+                // ---- pass L: computeActiveErrors + buildSystem (+ the first trial's Schur sums)
+                const bool fused = flowm && it > 0;
+                double acc[NRED], sa[27];
 #pragma unroll
                 for (int k = 0; k < NRED; k++) acc[k] = 0;
-                for (int i = tid; i < n; i += nt) {
+#pragma unroll
+                for (int k = 0; k < 27; k++) sa[k] = 0;
+                for (int i = tid; i < n; i += stride) {
                     double f0 = 0, f1 = 0, hll = 0, bl0 = 0, bl1 = 0;
                     if (flowm) {
                         f0 = p.f[2 * i]; f1 = p.f[2 * i + 1];
@@ -290,31 +345,42 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
                     if (flowm) {
                         if (act) { hll += wo; bl0 -= wo * e[0]; bl1 -= wo * e[1]; }
                         p.Hll[i] = hll; p.bl[2 * i] = bl0; p.bl[2 * i + 1] = bl1;
+                        double Bv[12];
 #pragma unroll
-                        for (int a = 0; a < 6; a++) { p.Hpl[12 * i + 2 * a] = act ? wo * J[a] : 0.0; p.Hpl[12 * i + 2 * a + 1] = act ? wo * J[6 + a] : 0.0; }
+                        for (int a = 0; a < 6; a++) { Bv[2 * a] = act ? wo * J[a] : 0.0; Bv[2 * a + 1] = act ? wo * J[6 + a] : 0.0; p.Hpl[12 * i + 2 * a] = Bv[2 * a]; p.Hpl[12 * i + 2 * a + 1] = Bv[2 * a + 1]; }
                         acc[28] = fmax(acc[28], fabs(hll));
+                        if (fused) {
+                            const double dinv = 1.0 / (hll + lambda);
+                            int q = 0;
+#pragma unroll
+                            for (int a = 0; a < 6; a++) {
+                                sa[21 + a] += dinv * (Bv[2 * a] * bl0 + Bv[2 * a + 1] * bl1);
+#pragma unroll
+                                for (int c = a; c < 6; c++) sa[q++] += dinv * (Bv[2 * a] * Bv[2 * c] + Bv[2 * a + 1] * Bv[2 * c + 1]);
+                            }
+                        }
                     }
                 }
-                block_allreduce<NRED, 28>(acc, lds);
-                double H[21], b6[6];                           // packed upper triangle, PQ(a, c)
-#pragma unroll
-                for (int q = 0; q < 21; q++) H[q] = acc[q];
-#pragma unroll
-                for (int a = 0; a < 6; a++) b6[a] = acc[21 + a];
-                double currentChi = acc[27]; const double iniChi = acc[27];
+                wg_reduce<NRED, 28>(acc, L.part, L.tot);
+                if (fused) { wg_reduce<27, 27>(sa, L.part, L.tot + NRED); cluster_sum(L.tot, NRED + 27, 28, L, cs); }
+                else cluster_sum(L.tot, NRED, 28, L, cs);
+                // the normal equations (packed upper triangle PQ(a, c) at tot[0..21), rhs at tot[21..27)) stay in LDS for the trials of this iteration: as wave-uniform values in
+                // vector registers they cost 54 VGPRs for the whole trial loop
+                const double* H = L.tot; const double* b6 = L.tot + 21;
+                double currentChi = L.tot[27]; const double iniChi = L.tot[27];
                 if (it == 0) {
-                    double md = acc[28];
+                    double md = L.tot[28];
 #pragma unroll
                     for (int a = 0; a < 6; a++) md = fmax(md, fabs(H[PQ(a, a)]));
                     lambda = 1e-5 * md; ni = 2; nBad = 0;
                 }
-                double rho = 0; int qmax = 0;
+                double rho = 0, last = 0; int qmax = 0;
                 do {
                     if (threadIdx.x == 0) {                      // one lane, compile-time register indices
 #pragma unroll
-                        for (int k = 0; k < 9; k++) tsave[k] = T.R[k];
+                        for (int k = 0; k < 9; k++) L.tsave[k] = T.R[k];
 #pragma unroll
-                        for (int k = 0; k < 3; k++) tsave[9 + k] = T.t[k];
+                        for (int k = 0; k < 3; k++) L.tsave[9 + k] = T.t[k];
                     }
                     double S[21], bs[6], xp[6];
 #pragma unroll
@@ -322,50 +388,54 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
 #pragma unroll
                     for (int a = 0; a < 6; a++) { bs[a] = b6[a]; S[PQ(a, a)] += lambda; }
                     if (flowm) {
-                        double sa[27];
+                        if (!(fused && qmax == 0)) {               // pass S: the Schur sums at this trial's lambda
 #pragma unroll
-                        for (int k = 0; k < 27; k++) sa[k] = 0;
-                        for (int i = tid; i < n; i += nt) {
-                            p.fsave[2 * i] = p.f[2 * i]; p.fsave[2 * i + 1] = p.f[2 * i + 1];
-                            const double dinv = 1.0 / (p.Hll[i] + lambda); const double* B = p.Hpl + 12 * i;
-                            const double g0 = p.bl[2 * i], g1 = p.bl[2 * i + 1];
-                            double Bv[12];
+                            for (int k = 0; k < 27; k++) sa[k] = 0;
+                            for (int i = tid; i < n; i += stride) {
+                                const double dinv = 1.0 / (p.Hll[i] + lambda); const double* B = p.Hpl + 12 * i;
+                                const double g0 = p.bl[2 * i], g1 = p.bl[2 * i + 1];
+                                double Bv[12];
 #pragma unroll
-                            for (int k = 0; k < 12; k++) Bv[k] = B[k];
-                            int q = 0;
+                                for (int k = 0; k < 12; k++) Bv[k] = B[k];
+                                int q = 0;
 #pragma unroll
-                            for (int a = 0; a < 6; a++) {
-                                sa[21 + a] += dinv * (Bv[2 * a] * g0 + Bv[2 * a + 1] * g1);
+                                for (int a = 0; a < 6; a++) {
+                                    sa[21 + a] += dinv * (Bv[2 * a] * g0 + Bv[2 * a + 1] * g1);
 #pragma unroll
-                                for (int c = a; c < 6; c++) sa[q++] += dinv * (Bv[2 * a] * Bv[2 * c] + Bv[2 * a + 1] * Bv[2 * c + 1]);
+                                    for (int c = a; c < 6; c++) sa[q++] += dinv * (Bv[2 * a] * Bv[2 * c] + Bv[2 * a + 1] * Bv[2 * c + 1]);
+                                }
                             }
+                            wg_reduce<27, 27>(sa, L.part, L.tot + NRED);
+                            cluster_sum(L.tot + NRED, 27, -1, L, cs);
                         }
-                        block_allreduce<27, 27>(sa, lds);
 #pragma unroll
-                        for (int a = 0; a < 6; a++) bs[a] -= sa[21 + a];
+                        for (int a = 0; a < 6; a++) bs[a] -= L.tot[NRED + 21 + a];
 #pragma unroll
-                        for (int q = 0; q < 21; q++) S[q] -= sa[q];
+                        for (int q = 0; q < 21; q++) S[q] -= L.tot[NRED + q];
                     }
                     const bool ok2 = ldlt6p(S, bs, xp);
-                    double part[2] = {0, 0};          // [0] tempChi, [1] landmark part of computeScale
+                    // pass T.  part: [0] robust chi2 of the edges at the trial state, [1] flow prior at the trial flows, [2] landmark part of computeScale, [3] flow prior at the flows before the trial
+                    double part[4] = {0, 0, 0, 0};
                     if (ok2) se3_oplus_left(T, xp);
-                    for (int i = tid; i < n; i += nt) {
+                    for (int i = tid; i < n; i += stride) {
                         double f0 = 0, f1 = 0;
                         const EdgeIn in = edge_load(p, i);
                         const bool out_i = p.outlier[i] != 0, hk = p.has_kernel[i] != 0;
                         if (flowm) {
                             f0 = p.f[2 * i]; f1 = p.f[2 * i + 1];
+                            p.fsave[2 * i] = f0; p.fsave[2 * i + 1] = f1;
+                            { const double a = f0 - p.flow0[2 * i], b = f1 - p.flow0[2 * i + 1]; part[3] += p.info_prior * (a * a + b * b); }
                             if (ok2) {
                                 const double dinv = 1.0 / (p.Hll[i] + lambda); const double* B = p.Hpl + 12 * i;
                                 double c0 = p.bl[2 * i], c1 = p.bl[2 * i + 1];
 #pragma unroll
                                 for (int a = 0; a < 6; a++) { c0 -= B[2 * a] * xp[a]; c1 -= B[2 * a + 1] * xp[a]; }
                                 const double x0 = dinv * c0, x1 = dinv * c1;
-                                part[1] += x0 * (lambda * x0 + p.bl[2 * i]) + x1 * (lambda * x1 + p.bl[2 * i + 1]);
+                                part[2] += x0 * (lambda * x0 + p.bl[2 * i]) + x1 * (lambda * x1 + p.bl[2 * i + 1]);
                                 f0 += x0; f1 += x1; p.f[2 * i] = f0; p.f[2 * i + 1] = f1;
                             }
                             const double a = f0 - p.flow0[2 * i], b = f1 - p.flow0[2 * i + 1];
-                            part[0] += p.info_prior * (a * a + b * b);
+                            part[1] += p.info_prior * (a * a + b * b);
                         }
                         if (!out_i) {
                             double e[2]; edge_eval<false>(p, T, in, f0, f1, e, nullptr);
@@ -375,8 +445,10 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
                             part[0] += r0;
                         }
                     }
-                    block_allreduce<2, 2>(part, lds);
-                    double tempChi = part[0], scale = part[1];
+                    wg_reduce<4, 4>(part, L.part, L.tot + NRED + 27 - 27);      // (the Schur totals have been consumed: tot[NRED ..] is free again)
+                    cluster_sum(L.tot + NRED, 4, -1, L, cs);
+                    const double chiE = L.tot[NRED], priN = L.tot[NRED + 1], priO = L.tot[NRED + 3];
+                    double tempChi = chiE + priN, scale = L.tot[NRED + 2];
                     if (ok2) {
 #pragma unroll
                         for (int a = 0; a < 6; a++) scale += xp[a] * (lambda * xp[a] + b6[a]);
@@ -386,53 +458,48 @@ __global__ __launch_bounds__(512) void k_pose_opt(const PoseProbDev* __restrict_
                         const double tr = 2 * rho - 1; double alpha = 1. - tr * tr * tr;      // pow(x, 3) of the reference; the libm call is ~500 instructions on every lane
                         alpha = fmin(alpha, 2. / 3.);
                         lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
+                        last = chiE + priN;                      // activeRobustChi2() after this trial: its errors, the flows it left
                     } else {
                         lambda *= ni; ni *= 2;
 #pragma unroll
-                        for (int k = 0; k < 9; k++) T.R[k] = tsave[k];       // written before the barriers of this trial's reductions; a re-write by the next trial stores the same values
+                        for (int k = 0; k < 9; k++) T.R[k] = L.tsave[k];       // written before the barriers of this trial's reductions; a re-write by the next trial stores the same values
 #pragma unroll
-                        for (int k = 0; k < 3; k++) T.t[k] = tsave[9 + k];
-                        if (flowm) for (int i = tid; i < n; i += nt) { p.f[2 * i] = p.fsave[2 * i]; p.f[2 * i + 1] = p.fsave[2 * i + 1]; }
+                        for (int k = 0; k < 3; k++) T.t[k] = L.tsave[9 + k];
+                        if (flowm) for (int i = tid; i < n; i += stride) { p.f[2 * i] = p.fsave[2 * i]; p.f[2 * i + 1] = p.fsave[2 * i + 1]; }
+                        last = chiE + priO;                      // the trial's edge errors stay (g2o does not recompute them on a rejected step), the flow vertices are popped back
                     }
                     qmax++;
+                    if (cs.dead) break;
                 } while (rho < 0 && qmax < 10);
                 total_iters++;
                 bool terminate = (qmax == 10 || rho == 0);
                 if (!terminate) { if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0; if (nBad >= 3) terminate = true; }
-                // activeRobustChi2() over the errors left by the last trial (sparse_optimizer.cpp:393-396)
-                double last[1] = {0};
-                for (int i = tid; i < n; i += nt) {
-                    if (!p.outlier[i]) {
-                        const double c2 = p.info_edge * (p.err[2 * i] * p.err[2 * i] + p.err[2 * i + 1] * p.err[2 * i + 1]);
-                        double r0 = c2, w; if (p.has_kernel[i]) huber(c2, p.huber_delta, r0, w);
-                        last[0] += r0;
-                    }
-                    if (flowm) { const double a = p.f[2 * i] - p.flow0[2 * i], b = p.f[2 * i + 1] - p.flow0[2 * i + 1]; last[0] += p.info_prior * (a * a + b * b); }
-                }
-                block_allreduce<1, 1>(last, lds);
-                if (chi2_check < last[0] && it > 0) terminate = true;
-                chi2_check = last[0];
+                if (chi2_check < last && it > 0) terminate = true;      // sparse_optimizer.cpp:393-396
+                chi2_check = last;
                 chi2_final = currentChi;
                 if (terminate) break;
             }
             // ---- inlier / outlier classification
             double nb[1] = {0};
-            for (int i = tid; i < n; i += nt) {
+            for (int i = tid; i < n; i += stride) {
                 double e0 = p.err[2 * i], e1 = p.err[2 * i + 1];
                 if (p.outlier[i]) { double e[2]; edge_eval<false>(p, T, edge_load(p, i), flowm ? p.f[2 * i] : 0.0, flowm ? p.f[2 * i + 1] : 0.0, e, nullptr); e0 = e[0]; e1 = e[1]; p.err[2 * i] = e0; p.err[2 * i + 1] = e1; }
                 const float chi2 = (float)(p.info_edge * (e0 * e0 + e1 * e1));
                 if (chi2 > round_chi2_th) { p.outlier[i] = 1; nb[0] += 1; } else p.outlier[i] = 0;
                 if (round == p.drop_kernel_after_round) p.has_kernel[i] = 0;
             }
-            block_allreduce<1, 1>(nb, lds);
-            n_inl = n - (int)nb[0];
+            if (round == p.rounds - 1) {                      // (the count of the earlier rounds is never used)
+                wg_reduce<1, 1>(nb, L.part, L.tot);
+                cluster_sum(L.tot, 1, -1, L, cs);
+                n_inl = n - (int)L.tot[0];
+            }
         }
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && wm.y == 0) {
         vido_pose_result* r = p.res;
         for (int rr = 0; rr < 3; rr++) { for (int c = 0; c < 3; c++) r->T[rr * 4 + c] = T.R[rr * 3 + c]; r->T[rr * 4 + 3] = T.t[rr]; }
         r->T[12] = r->T[13] = r->T[14] = 0; r->T[15] = 1;
-        r->n_inliers = n_inl; r->lm_iterations = total_iters; r->chi2_final = chi2_final;
+        r->n_inliers = cs.dead ? -1 : n_inl; r->lm_iterations = cs.dead ? -1 : total_iters; r->chi2_final = chi2_final;
     }
 }
 
@@ -443,7 +510,12 @@ struct PoseState {
     PoseProbDev* d_probs = nullptr; vido_pose_result* d_res = nullptr; size_t prob_cap = 0;
     double* h_stage = nullptr; size_t stage_cap = 0;       // pinned
     PoseProbDev* h_probs = nullptr; vido_pose_result* h_res = nullptr; unsigned char* h_bytes = nullptr; size_t hbytes_cap = 0;
+    unsigned long long* d_xch = nullptr; int2* d_wgmap = nullptr; int2* h_wgmap = nullptr; unsigned* d_abort = nullptr;   // cluster exchange areas [prob_cap], workgroup -> (problem, rank)
+    unsigned launches = 0;                                  // epoch base of a launch = launches << PO_EPOCH_SHIFT: tags of earlier launches never match
 };
+#define PO_EPOCH_SHIFT 14                                   // > the exchanges of one launch (4 rounds x 100 iterations x (1 + 2 x 10 trials) = 8400)
+#define PO_MAX_WGS 64                                       // workgroups per launch: a quarter of the chip, so that every cluster is resident whatever else runs (xwg.hpp)
+static inline int pose_cluster_size(int n) { return std::min(PO_GMAX, std::max(1, (n + 511) / 512)); }
 
 template <class T>
 static int grow_dev(vido_ctx* ctx, T** p, size_t* cap, size_t need)
@@ -472,8 +544,8 @@ void pose_state_destroy(vido_ctx* ctx)
 {
     PoseState* S = ctx->pose;
     if (!S) return;
-    hipFree(S->d_arena); hipFree(S->d_bytes); hipFree(S->d_probs); hipFree(S->d_res);
-    hipHostFree(S->h_stage); hipHostFree(S->h_probs); hipHostFree(S->h_res); hipHostFree(S->h_bytes);
+    hipFree(S->d_arena); hipFree(S->d_bytes); hipFree(S->d_probs); hipFree(S->d_res); hipFree(S->d_xch); hipFree(S->d_wgmap); hipFree(S->d_abort);
+    hipHostFree(S->h_stage); hipHostFree(S->h_probs); hipHostFree(S->h_res); hipHostFree(S->h_bytes); hipHostFree(S->h_wgmap);
     delete S; ctx->pose = nullptr;
 }
 
@@ -502,10 +574,17 @@ extern "C" int vido_pose_optimize_batch(vido_ctx* ctx, const vido_pose_problem* 
     if ((rc = grow_pinned(ctx, &S->h_bytes, &S->hbytes_cap, nb))) return rc;
     if ((size_t)n_prob > S->prob_cap) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (S->d_probs) { hipFree(S->d_probs); hipFree(S->d_res); hipHostFree(S->h_probs); hipHostFree(S->h_res); }
+        if (S->d_probs) { hipFree(S->d_probs); hipFree(S->d_res); hipHostFree(S->h_probs); hipHostFree(S->h_res); hipFree(S->d_xch); hipFree(S->d_wgmap); hipHostFree(S->h_wgmap); }
         S->prob_cap = (size_t)n_prob * 2 + 8;
         HIP_TRY(ctx, hipMalloc((void**)&S->d_probs, S->prob_cap * sizeof(PoseProbDev))); HIP_TRY(ctx, hipMalloc((void**)&S->d_res, S->prob_cap * sizeof(vido_pose_result)));
         HIP_TRY(ctx, hipHostMalloc((void**)&S->h_probs, S->prob_cap * sizeof(PoseProbDev))); HIP_TRY(ctx, hipHostMalloc((void**)&S->h_res, S->prob_cap * sizeof(vido_pose_result)));
+        HIP_TRY(ctx, hipMalloc((void**)&S->d_xch, S->prob_cap * PO_XCH_WORDS * sizeof(unsigned long long))); HIP_TRY(ctx, hipMemset(S->d_xch, 0, S->prob_cap * PO_XCH_WORDS * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMalloc((void**)&S->d_wgmap, S->prob_cap * PO_GMAX * sizeof(int2))); HIP_TRY(ctx, hipHostMalloc((void**)&S->h_wgmap, S->prob_cap * PO_GMAX * sizeof(int2)));
+        S->launches = 0;                                  // (fresh, zeroed exchange areas)
+    }
+    if (!S->d_abort) { HIP_TRY(ctx, hipMalloc((void**)&S->d_abort, sizeof(unsigned))); HIP_TRY(ctx, hipMemset(S->d_abort, 0, sizeof(unsigned))); }
+    if (S->launches + (unsigned)n_prob + 2 >= (1u << (32 - PO_EPOCH_SHIFT)) - 1) {      // the 32-bit tags are about to wrap: start over on zeroed areas
+        HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipMemset(S->d_xch, 0, S->prob_cap * PO_XCH_WORDS * sizeof(unsigned long long))); S->launches = 0;
     }
     // pack inputs into the pinned stage and lay out the device arena
     size_t so = 0, wo = nd_in, bo = 0;
@@ -533,11 +612,22 @@ extern "C" int vido_pose_optimize_batch(vido_ctx* ctx, const vido_pose_problem* 
         wo += 23 * n + 32;
         d.outlier = S->d_bytes + bo; byte_off[k] = bo; d.has_kernel = S->d_bytes + bo + n; bo += 2 * n + 16;
         d.res = S->d_res + k;
+        d.G = pose_cluster_size(p.n); d.xch = S->d_xch + (size_t)k * PO_XCH_WORDS;
     }
     if (so) HIP_TRY(ctx, hipMemcpyAsync(S->d_arena, S->h_stage, so * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(S->d_probs, S->h_probs, n_prob * sizeof(PoseProbDev), hipMemcpyHostToDevice, st));
-    const int threads = std::min(512, std::max(64, ((nmax + 3) / 4 + 63) & ~63));      // ~4 edges per thread, up to 8 waves (2 per SIMD keeps the 256-VGPR budget)
-    hipLaunchKernelGGL(k_pose_opt, dim3(n_prob), dim3(threads), 0, st, S->d_probs);
+    const int threads = nmax > 512 ? 512 : std::min(512, std::max(64, ((nmax + 3) / 4 + 63) & ~63));      // one workgroup: ~4 edges per thread; a cluster (n > 512): 512 threads, one edge each (2 waves per SIMD keeps the 256-VGPR budget)
+    // workgroup table: the G workgroups of a problem are consecutive; launches of at most PO_MAX_WGS workgroups, whole clusters each (stream order between them)
+    int n_wg = 0;
+    for (int k = 0; k < n_prob; k++) for (int r = 0; r < S->h_probs[k].G; r++) S->h_wgmap[n_wg++] = make_int2(k, r);
+    HIP_TRY(ctx, hipMemcpyAsync(S->d_wgmap, S->h_wgmap, (size_t)n_wg * sizeof(int2), hipMemcpyHostToDevice, st));
+    for (int w0 = 0, k = 0; k < n_prob;) {
+        int w1 = w0, k1 = k;
+        while (k1 < n_prob && (w1 == w0 || w1 - w0 + S->h_probs[k1].G <= PO_MAX_WGS)) { w1 += S->h_probs[k1].G; k1++; }
+        S->launches++;
+        hipLaunchKernelGGL(k_pose_opt, dim3(w1 - w0), dim3(threads), 0, st, S->d_probs, (const int2*)(S->d_wgmap + w0), S->launches << PO_EPOCH_SHIFT, S->d_abort);
+        w0 = w1; k = k1;
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(S->h_res, S->d_res, n_prob * sizeof(vido_pose_result), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(S->h_bytes, S->d_bytes, bo, hipMemcpyDeviceToHost, st));
@@ -551,6 +641,10 @@ extern "C" int vido_pose_optimize_batch(vido_ctx* ctx, const vido_pose_problem* 
         if (flow_out && flow_out[k] && probs[k].mode == 1 && n) { HIP_TRY(ctx, hipMemcpyAsync(S->h_stage + fo, S->d_arena + flow_off[k], 2 * n * sizeof(double), hipMemcpyDeviceToHost, st)); fo += 2 * n; }
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int k = 0; k < n_prob; k++) if (S->h_res[k].lm_iterations < 0) {      // a cluster gave up waiting for one of its workgroups (xwg.hpp): never seen, reported instead of hanging
+        HIP_TRY(ctx, hipMemset(S->d_abort, 0, sizeof(unsigned)));
+        return vido_set_error(ctx, VIDO_E_HIP, "pose_optimize: the workgroups of problem %d lost each other (exchange timed out)", k);
+    }
     for (int k = 0; k < n_prob; k++) {
         const size_t n = (size_t)probs[k].n;
         results[k] = S->h_res[k];

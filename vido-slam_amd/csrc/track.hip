@@ -507,27 +507,40 @@ int vido_update_mask(vido_ctx* ctx, int slot_last, int slot_cur, const int32_t* 
     hipStream_t st = ctx->stream; const size_t px = (size_t)T->W * T->H;
     std::vector<int> uni(last_label, last_label + n);
     std::sort(uni.begin(), uni.end()); uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
-    std::vector<float> corr; std::vector<int32_t> labs;
+    // The labels' samples are read in ONE gather (one upload, one launch, one download, one wait) instead of a round trip per label: five labels were 15 stream operations
+    // and 5 host waits per frame.  A label that IS recovered rewrites the mask, which the labels after it must see (the reference's loop is sequential): after a scatter the
+    // remaining labels are sampled again — rare (an object whose mask the detector lost in this frame).
+    std::vector<float> corr; std::vector<int32_t> labs, vals; std::vector<int> g_lab, g_off;
     for (int lab : uni) {
-        corr.clear();
+        const size_t before = corr.size();
         for (int j = 0; j < n; j++) if (last_label[j] == lab) { corr.push_back(last_corr_xy[2 * j]); corr.push_back(last_corr_xy[2 * j + 1]); }
-        const int m = (int)corr.size() / 2;
-        if (m < 100) continue;                                   // fewer than 100 in-image samples is impossible to reach with < 100 points
-        HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, corr.data(), (size_t)m * 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_mask_at, dim3((m + 255) / 256), dim3(256), 0, st, T->d_tmpf, m, T->smask[slot_cur], T->W, T->H, T->d_tmpi);
-        labs.resize(m);
-        HIP_TRY(ctx, hipMemcpyAsync(labs.data(), T->d_tmpi, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+        if ((corr.size() - before) / 2 < 100) { corr.resize(before); continue; }      // fewer than 100 in-image samples is impossible to reach with < 100 points
+        g_lab.push_back(lab); g_off.push_back((int)(before / 2));
+    }
+    g_off.push_back((int)(corr.size() / 2));
+    for (size_t g0 = 0; g0 < g_lab.size();) {
+        const int p0 = g_off[g0], m_all = g_off.back() - p0;
+        HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, corr.data() + 2 * (size_t)p0, (size_t)m_all * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_mask_at, dim3((m_all + 255) / 256), dim3(256), 0, st, T->d_tmpf, m_all, T->smask[slot_cur], T->W, T->H, T->d_tmpi);
+        vals.resize(m_all);
+        HIP_TRY(ctx, hipMemcpyAsync(vals.data(), T->d_tmpi, (size_t)m_all * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
-        labs.erase(std::remove(labs.begin(), labs.end(), INT32_MIN), labs.end());
-        if (labs.size() < 100) continue;
-        std::sort(labs.begin(), labs.end());
-        int best = labs[0], bc = 0, run = 0;
-        for (size_t j = 0; j < labs.size(); j++) { run = (j > 0 && labs[j] == labs[j - 1]) ? run + 1 : 1; if (run > bc) { bc = run; best = labs[j]; } }
-        if (best != 0) continue;
-        hipLaunchKernelGGL(k_mask_scatter, dim3(1024), dim3(256), 0, st, T->smask[slot_last], T->sflow[slot_last],
-                           T->smask[slot_cur], T->W, T->H, lab);
-        if (*n_recovered < cap && recovered_out) recovered_out[*n_recovered] = lab;
-        (*n_recovered)++;
+        size_t g = g0; bool scattered = false;
+        for (; g < g_lab.size() && !scattered; g++) {
+            labs.assign(vals.begin() + (g_off[g] - p0), vals.begin() + (g_off[g + 1] - p0));
+            labs.erase(std::remove(labs.begin(), labs.end(), INT32_MIN), labs.end());
+            if (labs.size() < 100) continue;
+            std::sort(labs.begin(), labs.end());
+            int best = labs[0], bc = 0, run = 0;
+            for (size_t j = 0; j < labs.size(); j++) { run = (j > 0 && labs[j] == labs[j - 1]) ? run + 1 : 1; if (run > bc) { bc = run; best = labs[j]; } }
+            if (best != 0) continue;
+            hipLaunchKernelGGL(k_mask_scatter, dim3(1024), dim3(256), 0, st, T->smask[slot_last], T->sflow[slot_last],
+                               T->smask[slot_cur], T->W, T->H, g_lab[g]);
+            if (*n_recovered < cap && recovered_out) recovered_out[*n_recovered] = g_lab[g];
+            (*n_recovered)++;
+            scattered = true;                                      // the labels after this one read the rewritten mask
+        }
+        g0 = g;
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));
     HIP_TRY(ctx, hipGetLastError());
