@@ -77,6 +77,9 @@ def main():
                                                                    "the default, the library's own ncclAllReduce on its stream (csrc/rccl.cpp)")
     ap.add_argument("--rccl-direct", action="store_true", help="(default since round 3; kept for old command lines)")
     ap.add_argument("--saturated-detector", action="store_true", help="keep the plain random fill of the detector: every class score saturates to 1.0, the ties defeat the detections_per_img cap and the mask head sees 200-300 detections per frame")
+    ap.add_argument("--oversubscribe", action="store_true", help="N > 1 on a ONE-GPU box: every rank uses GPU 0, the process group is gloo and the sharded BA's all-reduce goes through host memory "
+                                                                 "(host.host_allreduce_hook).  Numbers are meaningless; the point is that the launcher, the N-rank code path and the N > 1 JSON line "
+                                                                 "have executed end to end before an 8-GPU node sees them (tests/test_e2e_gpu.py)")
     ap.add_argument("--gba-cams", type=int, default=500)
     ap.add_argument("--gba-points", type=int, default=100000)
     args = ap.parse_args()
@@ -100,12 +103,17 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    if args.oversubscribe:
+        local_rank = 0                                      # all ranks on the one GPU of the box
     torch.cuda.set_device(local_rank)
     os.environ["VIDO_DEVICE"] = str(local_rank)            # the System's tracker context (facade) follows the rank's GPU
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.oversubscribe:
+            dist.init_process_group("gloo")                # (RCCL refuses two ranks on one device)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -161,7 +169,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if args.oversubscribe else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     fps = args.steps * world / dt
@@ -177,7 +185,7 @@ def main():
     stage = {"track_total_ms": mean("ms_total"), "update_mask_ms": mean("ms_update_mask"), "frame_orb_lists_ms": mean("ms_frame"), "cam_pose_ms": mean("ms_cam_pose"),
              "obj_tracking_ms": mean("ms_obj_tracking"), "obj_motion_ms": mean("ms_obj_motion"), "renew_ms": mean("ms_renew"), "local_ba_ms": mean("ms_local_ba"),
              "net_enqueue_host_ms": float(np.mean(e2e.t_net[n0:])), "tracker_wait_for_nets_ms": float(np.mean(e2e.t_wait[n0:])), "tracker_thread_ms": float(np.mean(e2e.t_track[n0:])),
-             "tracker_wait_inputs_ms": mean("ms_wait_inputs")}
+             "tracker_wait_inputs_ms": mean("ms_wait_inputs"), "orb_ms": mean("ms_orb"), "lists_ms": mean("ms_lists")}
     stage["tracker_work_ms"] = stage["tracker_thread_ms"] - stage["tracker_wait_inputs_ms"]      # the thread's time minus its wait for the frame's networks (an event the tracker's stream is ordered behind)
     counts = {"keypoints": mean("n_keypoints"), "static_points": mean("n_static"), "static_inliers": mean("n_static_inliers"), "dynamic_objects": mean("n_objects"),
               "object_points": mean("n_object_points"), "ba_window": mean("ba_window")}
@@ -318,6 +326,14 @@ def main():
                   r = opt.pose_optimize(pr)
               d = (time.perf_counter() - t1) / reps
               extra[name] = {"ms_per_call": round(d * 1e3, 3), "lm_iterations": r["lm_iterations"], "lm_iters_per_s": round(r["lm_iterations"] / d, 1)}
+          # k_pose_opt, the largest hand-written kernel of the tracker's trace, against what bounds it.  SURVEY section 8d prices an LM iteration at ~56 B per residual
+          # (168 KB at N = 3000): 0.02 us of HBM time — the kernel is a chain of dependent passes and exchanges, so what it is measured against is
+          # the latency floor of that chain: 2 cluster exchanges (~3 us each) + 2 passes of one residual per thread (~2.5 us) per iteration.
+          f2c = extra["PoseOptimizationFlow2Cam_N3000"]
+          us_it = f2c["ms_per_call"] * 1e3 / max(f2c["lm_iterations"], 1)
+          out["roofline_pose_opt"] = {"kernel": "k_pose_opt", "workload": "PoseOptimizationFlow2Cam, N = 3000 (6 workgroups of 512 threads, one residual per thread)", "bound": "latency",
+                                      "lm_iterations_per_s": f2c["lm_iters_per_s"], "us_per_lm_iteration_whole_call": round(us_it, 2), "hbm_floor_us_per_iteration": round(168e3 / (HBM_PEAK_GBS * 1e9) * 1e6, 4),
+                                      "latency_floor_us_per_iteration": 11.0, "frac_of_latency_floor": round(11.0 / us_it, 3)}
           objs = []
           for k in range(5):
               so = P.synth_pose_scene(800, seed=30 + k)
@@ -395,8 +411,8 @@ def main():
           gpr = P.synth_ba_problem(n_cam=args.gba_cams, n_pt=args.gba_points, kind="global", track_len=10, seed=11)
           gpr["max_iters"] = 5
           shards = V.landmark_shards(gpr["obs_pt"], gpr["n_pt"], world)
-          rccl_direct = not args.torch_allreduce
-          hook = (V.rccl_direct_init(ctx, rank, world) if rccl_direct else V.torch_allreduce_hook()) if world > 1 else None
+          rccl_direct = not args.torch_allreduce and not args.oversubscribe
+          hook = (V.host_allreduce_hook() if args.oversubscribe else (V.rccl_direct_init(ctx, rank, world) if rccl_direct else V.torch_allreduce_hook())) if world > 1 else None
           sync_all()
           t1 = time.perf_counter()
           r = V.ba_optimize(ctx, gpr, rank=rank, world=world, shard=shards[rank] if world > 1 else None, allreduce=hook)
@@ -410,7 +426,7 @@ def main():
                                 "lm_iterations": r["iterations"], "lm_trials": r["lm_trials"], "ms_lm_loop": round(r["ms_solve_loop"], 2),
                                 "ms_setup": round(r["ms_setup"], 2), "lm_iters_per_s": round(r["iterations"] / (r["ms_solve_loop"] * 1e-3), 2),
                                 "chi2": [round(r["chi2_initial"], 3), round(r["chi2_final"], 3)], "wall_ms": round(d * 1e3, 1), "wall_ms_first_call": round(d_cold * 1e3, 1),
-                                "collective": ("RCCL all-reduce (sum) of the reduced camera system per LM trial, " + ("issued by the library on its stream" if rccl_direct else "through the torch.distributed hook")) if world > 1 else "none",
+                                "collective": ("gloo all-reduce through host memory (--oversubscribe: all ranks on one GPU)" if args.oversubscribe else "RCCL all-reduce (sum) of the reduced camera system per LM trial, " + ("issued by the library on its stream" if rccl_direct else "through the torch.distributed hook")) if world > 1 else "none",
                                 "scaling_curve": "no 8-GPU scaling curve measured by the builder (single-GPU boxes); the driver's SCALE record is the measurement"}
           if "ms_phases" in r:
               extra["global_ba"]["ms_phases_per_trial"] = r["ms_phases"]

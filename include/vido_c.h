@@ -450,6 +450,7 @@ typedef struct vido_system_stats {          /* of the last vido_system_track_rgb
     float ms_local_ba;                       /* Map::fLBA_time (Tracking.cc:1436-1451) */
     float ms_wait_inputs;                    /* vido_system_track_rgbd_device only: host time spent waiting for the producer's ready event (the networks of this frame) — inside ms_total,
                                                 outside every stage time above */
+    float ms_orb, ms_lists;                  /* inside ms_frame: the extractor call (cvtColor + pyramid + FAST + quadtree + rBRIEF, keypoints on the host) | Frame's static / object lists */
 } vido_system_stats;
 int         vido_system_create(const char* settings_yaml, vido_system** out);
 void        vido_system_destroy(vido_system* sys);

@@ -213,6 +213,7 @@ private:
 };
 
 namespace detail {
+float LastFrameStageMs(int which);                     /* wall time inside the last Frame constructor: 0 = extractor call, 1 = static / object lists */
 void ResidentCheckStats(int* checks, int* mismatches);  /* VIDO_BA_RESIDENT_CHECK=1: windows solved both ways (device-resident window / Map walk) and how many disagreed */
 vido_ctx* Context();                                   /* the process-wide ctx of the live System (one System per process, as in the reference) */
 std::map<std::string, std::string> ParseSettings(const std::string& path);    /* OpenCV-YAML 1.0 `key: value` subset */

@@ -203,3 +203,23 @@ def test_two_chain_schedule_returns_the_same_maps(vido):
     for (fa, da, ma), (fb, db, mb) in zip(*outs):
         assert float((fa - fb).abs().max()) < 1e-3 and float((da.float() - db.float()).abs().max()) <= 2.0      # (library GEMMs are not bit-reproducible; depth is a 16-bit integer scale)
         assert float((ma != mb).float().mean()) < 1e-3
+
+
+def test_bench_two_ranks_on_one_gpu_prints_the_n2_line():
+    """`python bench.py --gpus 2 --oversubscribe`: the self-spawn through torch.distributed.run (the driver's launcher), two ranks (both on GPU 0, gloo), the replicated
+    per-frame chain with barrier + max-over-ranks timing, the landmark-sharded global BA with an all-reduce per LM trial, ONE JSON line from rank 0 with n_gpus = 2.
+    The numbers mean nothing on one GPU; the point is that the N > 1 path has executed end to end before a multi-GPU node runs it (round-3 review, item 3c)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", "3", "--warmup", "1", "--prologue", "3", "--cpu-baseline", "0",
+           "--gba-cams", "80", "--gba-points", "6000"]
+    env = dict(os.environ); env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                        # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    g = d["extra"]["global_ba"]
+    assert g["n_gpus"] == 2 and "gloo" in g["collective"] and g["lm_iterations"] >= 1 and g["chi2"][1] < g["chi2"][0]
+    assert d["global_ba_iters_per_s"]["n_gpus"] == 2

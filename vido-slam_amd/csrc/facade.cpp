@@ -133,6 +133,7 @@ void ORBextractor::operator()(cv::InputArray image_, cv::InputArray, std::vector
 
 // ---- Frame ----------------------------------------------------------------------------------------------------------
 long unsigned int Frame::nNextId = 0;
+static float g_ms_orb = 0, g_ms_lists = 0;      // wall time of the last Frame's extractor call / list stage (vido_system_stats.ms_orb / ms_lists)
 
 Frame::Frame(const cv::Mat& imGray, const cv::Mat& imDepth, const cv::Mat& imFlow, const cv::Mat& maskSEM, const double& timeStamp,
              ORBextractor* extractor, cv::Mat& K, cv::Mat& distCoef, const float& bf, const float& thDepth, const float& thDepthObj, const int& UseSampleFea)
@@ -140,7 +141,9 @@ Frame::Frame(const cv::Mat& imGray, const cv::Mat& imDepth, const cv::Mat& imFlo
     (void)imDepth; (void)imFlow; (void)maskSEM;            // their (patched) copies live in the device slot uploaded by GrabImageRGBD
     mnId = nNextId++; mTimeStamp = timeStamp; mK = K.clone(); mDistCoef = distCoef.clone(); mbf = bf; mThDepth = thDepth; mThDepthObj = thDepthObj;
     fx = K.at<float>(0, 0); fy = K.at<float>(1, 1); cx = K.at<float>(0, 2); cy = K.at<float>(1, 2); invfx = 1.0f / fx; invfy = 1.0f / fy;
+    const auto t_orb = std::chrono::steady_clock::now();
     (*extractor)(imGray, cv::Mat(), mvKeys, mDescriptors);                         // Frame.cc:62 ExtractORB
+    g_ms_orb = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_orb).count(); g_ms_lists = 0;
     N = (int)mvKeys.size();
     if (mvKeys.empty()) return;
     vido_ctx* c = extractor->context(imGray.cols, imGray.rows);
@@ -158,7 +161,9 @@ Frame::Frame(const cv::Mat& imGray, const cv::Mat& imDepth, const cv::Mat& imFlo
     vido_frame_lists L; L.max_stat = max_kp; L.max_obj = max_obj; L.n_stat = &ns; L.stat_idx = sidx.data(); L.stat_corr = scorr.data(); L.stat_flow = sflow.data(); L.stat_depth = sdep.data();
     L.n_obj = &no; L.obj_keys = okeys.data(); L.obj_corr = ocorr.data(); L.obj_depth = odep.data(); L.obj_label = olab.data(); L.obj_flow = oflow.data();
     vido_track_params tp = g_tp; tp.th_depth_bg = thDepth; tp.th_depth_obj = thDepthObj;
+    const auto t_lists = std::chrono::steady_clock::now();
     if (vido_frame_features(c, g_slot, 1, k.data(), &nk, max_kp, &tp, &L) != VIDO_OK) throw std::runtime_error(vido_last_error(c));
+    g_ms_lists = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_lists).count();
     for (int i = 0; i < ns; i++) {                                                 // Frame.cc:72-100, 165-177
         const cv::KeyPoint& kp = cand[sidx[i]];
         if (UseSampleFea != 0 && !(scorr[2 * i] > 0 && scorr[2 * i + 1] > 0)) continue;
@@ -501,7 +506,8 @@ static void dump_g2o(const std::string& path, const vido_ba_problem& b, const vi
 // Map walk of PartialBatchOptimization (Optimizer.cc:56-160, 216-350; STATIC_ONLY graph) and FullBatchOptimization (:1235-2178;
 // static + object factors) onto the flat BA problem.
 static int g_res_checks = 0, g_res_mismatch = 0;
-namespace detail { void ResidentCheckStats(int* checks, int* mismatches) { if (checks) *checks = g_res_checks; if (mismatches) *mismatches = g_res_mismatch; } }
+namespace detail { void ResidentCheckStats(int* checks, int* mismatches) { if (checks) *checks = g_res_checks; if (mismatches) *mismatches = g_res_mismatch; }
+                   float LastFrameStageMs(int which) { return which == 0 ? g_ms_orb : g_ms_lists; } }
 
 // Commits a local-window result to the Map (Optimizer.cc:1084-1128): refined camera poses, the odometry factors re-derived from them
 static void commit_window_poses(Map* pMap, int start, int N, const std::vector<double>& cam)
@@ -1275,7 +1281,7 @@ int vido_system_get_stats(const vido_system* s, vido_system_stats* o)
     for (int id : F->nStaInlierID) if (id >= 0) o->n_static_inliers++;
     int no = 0; for (size_t i = 0; i < F->bObjStat.size(); i++) if (F->bObjStat[i]) no++;
     o->n_objects = no; o->n_object_points = (int)F->mvObjKeys.size(); o->ba_window = std::min(std::max(T->f_id - 1, 0), T->nWINDOW_SIZE);
-    o->ms_total = T->ms_total; o->ms_update_mask = T->ms_update_mask; o->ms_frame = T->ms_frame; o->ms_wait_inputs = T->ms_wait_inputs;
+    o->ms_total = T->ms_total; o->ms_update_mask = T->ms_update_mask; o->ms_frame = T->ms_frame; o->ms_wait_inputs = T->ms_wait_inputs; o->ms_orb = VIDO_SLAM::detail::LastFrameStageMs(0); o->ms_lists = VIDO_SLAM::detail::LastFrameStageMs(1);
     if (T->all_timing.size() >= 5) { o->ms_cam_pose = T->all_timing[1]; o->ms_obj_tracking = T->all_timing[2]; o->ms_renew = T->all_timing[4]; }
     o->ms_obj_motion = T->ms_obj_motion_sum;
     o->ms_local_ba = M && !M->fLBA_time.empty() && T->f_id > 1 ? M->fLBA_time.back() : 0.f;

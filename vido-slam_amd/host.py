@@ -434,6 +434,27 @@ def torch_allreduce_hook(group=None):
     return ALLREDUCE_FN(hook)
 
 
+def host_allreduce_hook(group=None):
+    """All-reduce hook through HOST memory over a CPU process group (gloo): for `bench.py --oversubscribe` and the one-GPU tests of the N-rank path, where every rank
+    shares one device and RCCL cannot be used.  Device -> host copy, gloo all-reduce, host -> device copy."""
+    import torch
+    import torch.distributed as dist
+
+    def hook(user, ptr, count, op):
+        try:
+            t = torch.as_tensor(_DevBuf(ptr, count), device="cuda")
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX, group=group)
+            t.copy_(h)
+            torch.cuda.synchronize()
+            return 0
+        except Exception as e:
+            import sys
+            print("vido all-reduce hook (host): %r" % (e,), file=sys.stderr)
+            return 1
+    return ALLREDUCE_FN(hook)
+
+
 def rccl_direct_init(ctx, rank=0, world=1):
     """Prepare `ctx` for the library's own RCCL all-reduce (vido_rccl_*, csrc/rccl.cpp): rank 0 draws the unique id, torch.distributed broadcasts its 128 bytes
     (any transport would do), every rank initialises its communicator.  Afterwards pass allreduce="rccl" to ba_optimize."""

@@ -21,7 +21,7 @@ class SystemStats(C.Structure):
     _fields_ = [("frame_id", C.c_int32), ("n_keypoints", C.c_int32), ("n_static", C.c_int32), ("n_static_inliers", C.c_int32),
                 ("n_objects", C.c_int32), ("n_object_points", C.c_int32), ("ba_window", C.c_int32), ("pad", C.c_int32),
                 ("ms_total", C.c_float), ("ms_update_mask", C.c_float), ("ms_frame", C.c_float), ("ms_cam_pose", C.c_float),
-                ("ms_obj_tracking", C.c_float), ("ms_obj_motion", C.c_float), ("ms_renew", C.c_float), ("ms_local_ba", C.c_float), ("ms_wait_inputs", C.c_float)]
+                ("ms_obj_tracking", C.c_float), ("ms_obj_motion", C.c_float), ("ms_renew", C.c_float), ("ms_local_ba", C.c_float), ("ms_wait_inputs", C.c_float), ("ms_orb", C.c_float), ("ms_lists", C.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}
