@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -55,6 +56,15 @@ struct vido_ctx {
 };
 
 int vido_set_error(vido_ctx* ctx, int code, const char* fmt, ...);
+// VIDO_CALL_PROF=1: named host-side sections inside the library (ctx.cpp keeps the table, prints it at exit next to the facade's per-call table).  A section that ends with
+// `sync` waits for the stream first, so that the section owns the device time of what it enqueued (diagnosis only: the waits change the overlap they measure).
+bool vido_prof_on();
+void vido_prof_add(const char* name, double ms);
+struct VidoProfScope {
+    const char* name; hipStream_t st; bool sync; std::chrono::steady_clock::time_point t0;
+    VidoProfScope(const char* n, hipStream_t s = nullptr, bool sy = false) : name(n), st(s), sync(sy) { if (vido_prof_on()) t0 = std::chrono::steady_clock::now(); }
+    ~VidoProfScope() { if (!vido_prof_on()) return; if (sync) (void)hipStreamSynchronize(st); vido_prof_add(name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+};
 
 #define HIP_TRY(ctx, expr)                                                                  \
     do {                                                                                    \

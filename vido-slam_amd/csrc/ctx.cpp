@@ -126,3 +126,18 @@ int vido_synchronize(vido_ctx* ctx)
 }
 
 }  // extern "C"
+
+// ---- VIDO_CALL_PROF: named host-side sections (common.hpp) -------------------------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+namespace {
+struct SectionProf {
+    bool on = getenv("VIDO_CALL_PROF") != nullptr; std::mutex m; std::map<std::string, std::pair<double, long> > acc;
+    ~SectionProf() { if (!on) return; std::vector<std::pair<double, std::string> > v; for (auto& kv : acc) v.push_back({kv.second.first, kv.first});
+                     std::sort(v.rbegin(), v.rend());
+                     for (auto& e : v) fprintf(stderr, "[section prof] %-44s %8.3f ms total %7ld calls %8.3f ms each\n", e.second.c_str(), e.first, acc[e.second].second, e.first / std::max(1L, acc[e.second].second)); }
+};
+SectionProf g_sections;
+}
+bool vido_prof_on() { return g_sections.on; }
+void vido_prof_add(const char* name, double ms) { std::lock_guard<std::mutex> g(g_sections.m); auto& a = g_sections.acc[name]; a.first += ms; a.second++; }

@@ -5,6 +5,7 @@
 // time(NULL)-seeded depth noise of the addnoise=1 branches.
 #include "../../include/vido_slam/vido_slam.h"
 #include <algorithm>
+#include <map>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -50,10 +51,29 @@ struct VidoFailure : std::runtime_error {
     int code;
     VidoFailure(int c, const std::string& m) : std::runtime_error(m), code(c) {}
 };
-static void check(int rc, const char* what)
+static void check_rc(int rc, const char* what)
 {
     if (rc < 0) throw VidoFailure(rc, std::string(what) + ": " + vido_last_error(g_ctx));
 }
+// VIDO_CALL_PROF=1: wall time of every C-ABI call the facade makes, by name, printed when the process ends — where a tracked frame's host time goes (inside the pipeline
+// the same calls take several times what they take on an idle GPU, and which ones is the question)
+namespace {
+struct CallProf {
+    bool on = getenv("VIDO_CALL_PROF") != nullptr; std::map<std::string, std::pair<double, long> > acc;
+    ~CallProf() { if (!on) return; std::vector<std::pair<double, std::string> > v; for (auto& kv : acc) v.push_back({kv.second.first, kv.first});
+                  std::sort(v.rbegin(), v.rend());
+                  for (auto& e : v) fprintf(stderr, "[call prof] %-44s %8.3f ms total %7ld calls %8.3f ms each\n", e.second.c_str(), e.first, acc[e.second].second, e.first / std::max(1L, acc[e.second].second)); }
+};
+CallProf g_prof;
+template <class F> inline int timed_call(F&& f, const char* what)
+{
+    if (!g_prof.on) return f();
+    const auto t0 = std::chrono::steady_clock::now(); const int rc = f();
+    auto& a = g_prof.acc[what]; a.first += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); a.second++;
+    return rc;
+}
+}
+#define check(expr, what) check_rc(timed_call([&]() -> int { return (expr); }, (what)), (what))
 int failure_code(const std::exception& e)
 {
     if (const VidoFailure* v = dynamic_cast<const VidoFailure*>(&e)) return v->code;
@@ -116,7 +136,7 @@ void ORBextractor::operator()(cv::InputArray image_, cv::InputArray, std::vector
     int rc;
     if (dev_src_) {                                            // device-resident image (SetDeviceSource): colour -> fused cvtColor ingest, gray -> plain ingest; no host pixels involved
         if (dev_ch_ == 1) rc = vido_orb_extract_batch(c, (const uint8_t*)dev_src_, 1, 1, (size_t)image.cols * image.rows, image.cols, image.cols, image.rows, k.data(), cap, &n, desc.data);
-        else rc = vido_orb_extract_color(c, (const uint8_t*)dev_src_, dev_ch_, rgb_ ? 1 : 0, 1, 1, 0, image.cols * dev_ch_, image.cols, image.rows, nullptr, k.data(), cap, &n, desc.data);
+        else rc = timed_call([&]() -> int { return vido_orb_extract_color(c, (const uint8_t*)dev_src_, dev_ch_, rgb_ ? 1 : 0, 1, 1, 0, image.cols * dev_ch_, image.cols, image.rows, nullptr, k.data(), cap, &n, desc.data); }, "orb_extract_color(device)");
         dev_src_ = nullptr;
     }
     else if (color_ && gray_ == image.data && color_->cols == image.cols && color_->rows == image.rows && image.isContinuous())      // cvtColor on the device (SetColorSource)
@@ -162,7 +182,7 @@ Frame::Frame(const cv::Mat& imGray, const cv::Mat& imDepth, const cv::Mat& imFlo
     L.n_obj = &no; L.obj_keys = okeys.data(); L.obj_corr = ocorr.data(); L.obj_depth = odep.data(); L.obj_label = olab.data(); L.obj_flow = oflow.data();
     vido_track_params tp = g_tp; tp.th_depth_bg = thDepth; tp.th_depth_obj = thDepthObj;
     const auto t_lists = std::chrono::steady_clock::now();
-    if (vido_frame_features(c, g_slot, 1, k.data(), &nk, max_kp, &tp, &L) != VIDO_OK) throw std::runtime_error(vido_last_error(c));
+    if (timed_call([&]() -> int { return vido_frame_features(c, g_slot, 1, k.data(), &nk, max_kp, &tp, &L); }, "frame_features") != VIDO_OK) throw std::runtime_error(vido_last_error(c));
     g_ms_lists = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_lists).count();
     for (int i = 0; i < ns; i++) {                                                 // Frame.cc:72-100, 165-177
         const cv::KeyPoint& kp = cand[sidx[i]];

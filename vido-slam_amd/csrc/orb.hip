@@ -1231,6 +1231,7 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     if (!imgs) return vido_set_error(ctx, VIDO_E_INVALID, "orb: null input");
     if (width != S->W || height != S->H) return vido_set_error(ctx, VIDO_E_INVALID, "orb: frame %dx%d but ctx was created for %dx%d", width, height, S->W, S->H);
     if (nf < 1 || nf > S->B) return vido_set_error(ctx, VIDO_E_INVALID, "orb: n_frames=%d outside [1,%d]", nf, S->B);
+    VidoProfScope ps_e("orb_enqueue: host time of the launches", nullptr, false);
     if (stride < width) return vido_set_error(ctx, VIDO_E_INVALID, "orb: stride < width");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -1341,6 +1342,7 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
 int orb_collect(vido_ctx* ctx, int nf, int copy)
 {
     OrbState* S = ctx->orb; hipStream_t st = ctx->stream; const int L = S->L;
+    VidoProfScope ps_c("orb_collect: wait for the extraction + downloads", st, false);
     HIP_TRY(ctx, hipMemcpyAsync(S->h_frame_beg, S->d_frame_beg, ((size_t)nf + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(S->h_lvloff, S->d_lvloff, ((size_t)nf * L + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(S->h_overflow, S->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));

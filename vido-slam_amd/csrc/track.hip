@@ -17,6 +17,7 @@ struct TrackState {
     float *d_scorr = nullptr, *d_sflow = nullptr, *d_sdepth = nullptr;
     float *d_okeys = nullptr, *d_ocorr = nullptr, *d_odepth = nullptr, *d_oflow = nullptr;
     float* d_tmpf = nullptr; int32_t* d_tmpi = nullptr; size_t tmp_cap = 0;       // scratch for gathers
+    float* h_io = nullptr;                                                        // pinned mirror of d_tmpf, word for word: a call packs its inputs there (ONE copy up) and reads its outputs there (ONE copy down)
     int32_t* h_cnt = nullptr;
     char* h_stage = nullptr; size_t stage_cap = 0;
     char* h_maps = nullptr; size_t maps_cap = 0;          // pinned stage of host-resident depth / flow / mask (vido_frontend_batch, maps_on_device = 0)
@@ -230,6 +231,7 @@ static int track_state(vido_ctx* ctx, TrackState** out)
     HIP_TRY(ctx, hipMalloc(&T->d_oflow, B * T->max_obj * 8));
     T->tmp_cap = (size_t)std::max(T->max_obj, T->max_kp) * 8;
     HIP_TRY(ctx, hipMalloc(&T->d_tmpf, T->tmp_cap * 4)); HIP_TRY(ctx, hipMalloc(&T->d_tmpi, T->tmp_cap * 4));
+    HIP_TRY(ctx, hipHostMalloc((void**)&T->h_io, T->tmp_cap * 4 + (size_t)T->max_kp * sizeof(vido_keypoint) + 256));
     HIP_TRY(ctx, hipHostMalloc(&T->h_cnt, 2 * B * 4));
     T->sdepth.resize(B); T->sflow.resize(B); T->smask.resize(B);
     for (size_t b = 0; b < B; b++) { T->sdepth[b] = T->d_depth + b * px; T->sflow[b] = T->d_flow + b * px * 2; T->smask[b] = T->d_mask + b * px; }
@@ -243,7 +245,7 @@ void track_state_destroy(vido_ctx* ctx)
     if (!T) return;
     hipFree(T->d_depth); hipFree(T->d_flow); hipFree(T->d_mask); hipFree(T->d_kps); hipFree(T->d_sidx); hipFree(T->d_scorr); hipFree(T->d_sflow);
     hipFree(T->d_sdepth); hipFree(T->d_nstat); hipFree(T->d_nobj); hipFree(T->d_okeys); hipFree(T->d_ocorr); hipFree(T->d_odepth); hipFree(T->d_olabel);
-    hipFree(T->d_oflow); hipFree(T->d_tmpf); hipFree(T->d_tmpi); hipHostFree(T->h_cnt); hipHostFree(T->h_stage); hipHostFree(T->h_view); hipHostFree(T->h_maps);
+    hipFree(T->d_oflow); hipFree(T->d_tmpf); hipFree(T->d_tmpi); hipHostFree(T->h_cnt); hipHostFree(T->h_io); hipHostFree(T->h_stage); hipHostFree(T->h_view); hipHostFree(T->h_maps);
     if (T->ev_maps) hipEventDestroy(T->ev_maps);
     if (T->ev_cnt) hipEventDestroy(T->ev_cnt);
     delete T; ctx->trk = nullptr;
@@ -286,6 +288,9 @@ int vido_frame_upload(vido_ctx* ctx, int slot0, int n_frames, float* depth, cons
     return VIDO_OK;
 }
 
+// threads of the one-workgroup-per-frame list kernels.  (VIDO_LISTS_NT: experiment switch)
+static int lists_nt() { static const int v = [] { const char* e = getenv("VIDO_LISTS_NT"); const int t = e ? atoi(e) : 1024; return (t == 64 || t == 128 || t == 256 || t == 512) ? t : 1024; }(); return v; }
+
 int vido_frame_features(vido_ctx* ctx, int slot0, int n_frames, const vido_keypoint* kps, const int32_t* n_kps, int max_kp,
                         const vido_track_params* p, vido_frame_lists* out)
 {
@@ -299,22 +304,37 @@ int vido_frame_features(vido_ctx* ctx, int slot0, int n_frames, const vido_keypo
     const size_t px = (size_t)T->W * T->H;
     for (int f = 0; f < n_frames; f++) if (n_kps[f] < 0 || n_kps[f] > max_kp) return vido_set_error(ctx, VIDO_E_INVALID, "frame_features: n_kps[%d]=%d", f, n_kps[f]);
     // keypoints are packed to the ctx's own pitch
+    // (through the pinned stage: an asynchronous copy FROM PAGEABLE memory of this size — 100 KB of keypoints — took 3 ms inside the pipeline, 0.04 ms on an idle GPU; the runtime
+    //  pins such a range on the fly and that waits on the busy device.  Only the n_kps[f] rows that exist go up.)
+    { VidoProfScope ps("frame_features: uploads (keypoints + counts, pinned stage)", st, true);
+    char* hk = (char*)T->h_io + T->tmp_cap * 4;                                    // [max_kp] keypoints of ONE frame at a time, then the counts
+    if (n_frames == 1) {
+        memcpy(hk, kps, (size_t)n_kps[0] * sizeof(vido_keypoint));
+        int32_t* hc = (int32_t*)(hk + (size_t)T->max_kp * sizeof(vido_keypoint)); hc[0] = n_kps[0];
+        if (n_kps[0]) HIP_TRY(ctx, hipMemcpyAsync(T->d_kps, hk, (size_t)n_kps[0] * sizeof(vido_keypoint), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(T->d_nstat, hc, 4, hipMemcpyHostToDevice, st));     // reused as the input count, overwritten by the kernel
+        HIP_TRY(ctx, hipMemcpyAsync(T->d_nobj, hc, 4, hipMemcpyHostToDevice, st));
+    } else {
     HIP_TRY(ctx, hipMemcpy2DAsync(T->d_kps, (size_t)T->max_kp * sizeof(vido_keypoint), kps, (size_t)max_kp * sizeof(vido_keypoint),
                                   (size_t)max_kp * sizeof(vido_keypoint), n_frames, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(T->d_nstat, n_kps, n_frames * 4, hipMemcpyHostToDevice, st));     // reused as the input count, overwritten by the kernel
     HIP_TRY(ctx, hipMemcpyAsync(T->d_nobj, n_kps, n_frames * 4, hipMemcpyHostToDevice, st));
+    } }
     for (int f = 1; f < n_frames; f++) if (T->sdepth[slot0 + f] != T->sdepth[slot0] + f * px) return vido_set_error(ctx, VIDO_E_INVALID, "frame_features: slots [%d,%d) do not hold one contiguous batch", slot0, slot0 + n_frames);
-    hipLaunchKernelGGL(k_static_filter, dim3(n_frames), dim3(1024), 0, st, T->d_kps, T->d_nobj, T->max_kp, T->max_kp,
+    { VidoProfScope ps("frame_features: k_static_filter", st, true);
+    hipLaunchKernelGGL(k_static_filter, dim3(n_frames), dim3(lists_nt()), 0, st, T->d_kps, T->d_nobj, T->max_kp, T->max_kp,
                        T->sdepth[slot0], T->sflow[slot0], T->smask[slot0], T->W, T->H, p->th_depth_bg,
-                       T->d_sidx, T->d_scorr, T->d_sflow, T->d_sdepth, T->d_nstat);
+                       T->d_sidx, T->d_scorr, T->d_sflow, T->d_sdepth, T->d_nstat); }
     const int step = p->dense_step > 0 ? p->dense_step : 4;
     const int lattice = ((T->W + step - 1) / step) * ((T->H + step - 1) / step);
     if (lattice > T->max_obj) return vido_set_error(ctx, VIDO_E_INVALID, "frame_features: dense_step %d gives %d probes > %d", step, lattice, T->max_obj);
-    hipLaunchKernelGGL(k_dense_sample, dim3(n_frames), dim3(1024), 0, st, T->sdepth[slot0], T->sflow[slot0], T->smask[slot0],
-                       T->W, T->H, p->th_depth_obj, step, T->max_obj, T->d_okeys, T->d_ocorr, T->d_odepth, T->d_olabel, T->d_oflow, T->d_nobj);
+    { VidoProfScope ps("frame_features: k_dense_sample", st, true);
+    hipLaunchKernelGGL(k_dense_sample, dim3(n_frames), dim3(lists_nt()), 0, st, T->sdepth[slot0], T->sflow[slot0], T->smask[slot0],
+                       T->W, T->H, p->th_depth_obj, step, T->max_obj, T->d_okeys, T->d_ocorr, T->d_odepth, T->d_olabel, T->d_oflow, T->d_nobj); }
+    { VidoProfScope ps("frame_features: counts download + wait", st, false);
     HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt, T->d_nstat, n_frames * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(T->h_cnt + T->B, T->d_nobj, n_frames * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipStreamSynchronize(st)); }
     HIP_TRY(ctx, hipGetLastError());
     int max_ns = 0, max_no = 0;
     for (int f = 0; f < n_frames; f++) {
@@ -338,6 +358,7 @@ int vido_frame_features(vido_ctx* ctx, int slot0, int n_frames, const vido_keypo
         segs.push_back(Seg{dst, dpitch_el * el, cur, el, width_el}); cur += (size_t)n_frames * width_el * el;
         return VIDO_OK;
     };
+    VidoProfScope ps_dl("frame_features: 9 list downloads + wait + host copies", st, false);
     if ((rc = copy2d(out->stat_idx, out->max_stat, T->d_sidx, T->max_kp, 4, max_ns))) return rc;
     if ((rc = copy2d(out->stat_corr, out->max_stat, T->d_scorr, T->max_kp, 8, max_ns))) return rc;
     if ((rc = copy2d(out->stat_flow, out->max_stat, T->d_sflow, T->max_kp, 8, max_ns))) return rc;
@@ -448,17 +469,21 @@ int vido_frontend_batch(vido_ctx* ctx, const uint8_t* imgs, int imgs_on_device, 
     return VIDO_OK;
 }
 
+// The small per-point calls below hand caller (pageable) arrays in and out.  Each packs its inputs into the pinned mirror of the device scratch (h_io <-> d_tmpf, same
+// layout), sends them with ONE copy, and fetches all of its outputs with ONE copy: 3 stream operations per call instead of 3..8, none of them on pageable memory.
 int vido_gather_static_depth(vido_ctx* ctx, int slot, const float* keys_xy, int n, float* depth_out)
 {
     if (!ctx) return VIDO_E_INVALID;
     TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
-    if (slot < 0 || slot >= T->B || n < 0 || (size_t)n * 2 > T->tmp_cap) return vido_set_error(ctx, VIDO_E_INVALID, "gather_static_depth: bad slot/n");
+    if (slot < 0 || slot >= T->B || n < 0 || (size_t)n * 3 > T->tmp_cap) return vido_set_error(ctx, VIDO_E_INVALID, "gather_static_depth: bad slot/n");
     if (n == 0) return VIDO_OK;
-    hipStream_t st = ctx->stream; const size_t px = (size_t)T->W * T->H;
-    HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, keys_xy, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    hipStream_t st = ctx->stream;
+    memcpy(T->h_io, keys_xy, (size_t)n * 8);
+    HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, T->h_io, (size_t)n * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_gather_static, dim3((n + 255) / 256), dim3(256), 0, st, T->d_tmpf, n, T->sdepth[slot], T->W, T->H, T->d_tmpf + 2 * (size_t)n);
-    HIP_TRY(ctx, hipMemcpyAsync(depth_out, T->d_tmpf + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 2 * (size_t)n, T->d_tmpf + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    memcpy(depth_out, T->h_io + 2 * (size_t)n, (size_t)n * 4);
     return VIDO_OK;
 }
 
@@ -466,15 +491,16 @@ int vido_gather_object_depth_label(vido_ctx* ctx, int slot, const float* keys_xy
 {
     if (!ctx) return VIDO_E_INVALID;
     TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
-    if (slot < 0 || slot >= T->B || n < 0 || (size_t)n * 3 > T->tmp_cap) return vido_set_error(ctx, VIDO_E_INVALID, "gather_object: bad slot/n");
+    if (slot < 0 || slot >= T->B || n < 0 || (size_t)n * 4 > T->tmp_cap) return vido_set_error(ctx, VIDO_E_INVALID, "gather_object: bad slot/n");
     if (n == 0) return VIDO_OK;
-    hipStream_t st = ctx->stream; const size_t px = (size_t)T->W * T->H;
-    HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, keys_xy, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_gather_object, dim3((n + 255) / 256), dim3(256), 0, st, T->d_tmpf, n, T->sdepth[slot], T->smask[slot],
-                       T->W, T->H, th_depth_obj, T->d_tmpf + 2 * (size_t)n, T->d_tmpi);
-    HIP_TRY(ctx, hipMemcpyAsync(depth_out, T->d_tmpf + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(label_out, T->d_tmpi, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    hipStream_t st = ctx->stream;
+    float* dd = T->d_tmpf + 2 * (size_t)n; int32_t* dl = (int32_t*)(T->d_tmpf + 3 * (size_t)n);      // [keys 2n | depth n | label n]
+    memcpy(T->h_io, keys_xy, (size_t)n * 8);
+    HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, T->h_io, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gather_object, dim3((n + 255) / 256), dim3(256), 0, st, T->d_tmpf, n, T->sdepth[slot], T->smask[slot], T->W, T->H, th_depth_obj, dd, dl);
+    HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 2 * (size_t)n, dd, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    memcpy(depth_out, T->h_io + 2 * (size_t)n, (size_t)n * 4); memcpy(label_out, T->h_io + 3 * (size_t)n, (size_t)n * 4);
     return VIDO_OK;
 }
 
@@ -482,16 +508,16 @@ int vido_gather_point_samples(vido_ctx* ctx, int slot, const float* xy, int n, i
 {
     if (!ctx) return VIDO_E_INVALID;
     TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
-    if (slot < 0 || slot >= T->B || n < 0 || (size_t)n * 5 > T->tmp_cap || (n && (!xy || !mask_out || !depth_out || !flow_out))) return vido_set_error(ctx, VIDO_E_INVALID, "gather_point_samples: bad slot/n");
+    if (slot < 0 || slot >= T->B || n < 0 || (size_t)n * 6 > T->tmp_cap || (n && (!xy || !mask_out || !depth_out || !flow_out))) return vido_set_error(ctx, VIDO_E_INVALID, "gather_point_samples: bad slot/n");
     if (n == 0) return VIDO_OK;
     hipStream_t st = ctx->stream;
-    float* dk = T->d_tmpf; float* dd = dk + 2 * (size_t)n; float* df = dd + n;
-    HIP_TRY(ctx, hipMemcpyAsync(dk, xy, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_gather_samples, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, T->sdepth[slot], T->sflow[slot], T->smask[slot], T->W, T->H, dd, df, T->d_tmpi);
-    HIP_TRY(ctx, hipMemcpyAsync(depth_out, dd, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(flow_out, df, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(mask_out, T->d_tmpi, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    float* dk = T->d_tmpf; float* dd = dk + 2 * (size_t)n; float* df = dd + n; int32_t* dm = (int32_t*)(df + 2 * (size_t)n);      // [xy 2n | depth n | flow 2n | mask n]
+    memcpy(T->h_io, xy, (size_t)n * 8);
+    HIP_TRY(ctx, hipMemcpyAsync(dk, T->h_io, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gather_samples, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, T->sdepth[slot], T->sflow[slot], T->smask[slot], T->W, T->H, dd, df, dm);
+    HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 2 * (size_t)n, dd, (size_t)n * 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    memcpy(depth_out, T->h_io + 2 * (size_t)n, (size_t)n * 4); memcpy(flow_out, T->h_io + 3 * (size_t)n, (size_t)n * 8); memcpy(mask_out, T->h_io + 5 * (size_t)n, (size_t)n * 4);
     return VIDO_OK;
 }
 
@@ -501,7 +527,7 @@ int vido_update_mask(vido_ctx* ctx, int slot_last, int slot_cur, const int32_t* 
     if (!ctx || !n_recovered) return VIDO_E_INVALID;
     TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
     *n_recovered = 0;
-    if (slot_last < 0 || slot_last >= T->B || slot_cur < 0 || slot_cur >= T->B || n < 0 || (size_t)n * 2 > T->tmp_cap)
+    if (slot_last < 0 || slot_last >= T->B || slot_cur < 0 || slot_cur >= T->B || n < 0 || (size_t)n * 3 > T->tmp_cap)
         return vido_set_error(ctx, VIDO_E_INVALID, "update_mask: bad slots/n");
     if (n == 0) return VIDO_OK;
     hipStream_t st = ctx->stream; const size_t px = (size_t)T->W * T->H;
@@ -520,11 +546,12 @@ int vido_update_mask(vido_ctx* ctx, int slot_last, int slot_cur, const int32_t* 
     g_off.push_back((int)(corr.size() / 2));
     for (size_t g0 = 0; g0 < g_lab.size();) {
         const int p0 = g_off[g0], m_all = g_off.back() - p0;
-        HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, corr.data() + 2 * (size_t)p0, (size_t)m_all * 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_mask_at, dim3((m_all + 255) / 256), dim3(256), 0, st, T->d_tmpf, m_all, T->smask[slot_cur], T->W, T->H, T->d_tmpi);
-        vals.resize(m_all);
-        HIP_TRY(ctx, hipMemcpyAsync(vals.data(), T->d_tmpi, (size_t)m_all * 4, hipMemcpyDeviceToHost, st));
+        memcpy(T->h_io, corr.data() + 2 * (size_t)p0, (size_t)m_all * 8);                 // [corr 2m | values m] in the pinned mirror of d_tmpf
+        HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, T->h_io, (size_t)m_all * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_mask_at, dim3((m_all + 255) / 256), dim3(256), 0, st, T->d_tmpf, m_all, T->smask[slot_cur], T->W, T->H, (int32_t*)(T->d_tmpf + 2 * (size_t)m_all));
+        HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 2 * (size_t)m_all, T->d_tmpf + 2 * (size_t)m_all, (size_t)m_all * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
+        vals.assign((const int32_t*)(T->h_io + 2 * (size_t)m_all), (const int32_t*)(T->h_io + 2 * (size_t)m_all) + m_all);
         size_t g = g0; bool scattered = false;
         for (; g < g_lab.size() && !scattered; g++) {
             labs.assign(vals.begin() + (g_off[g] - p0), vals.begin() + (g_off[g + 1] - p0));
@@ -570,13 +597,13 @@ int vido_unproject_world(vido_ctx* ctx, const float* keys_xy, const float* z, in
     float RT[12];
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) RT[r * 3 + c] = Tcw[c * 4 + r];
     for (int r = 0; r < 3; r++) { double s = 0; for (int c = 0; c < 3; c++) s += (double)(-RT[r * 3 + c]) * (double)Tcw[c * 4 + 3]; RT[9 + r] = (float)s; }
-    float* dk = T->d_tmpf; float* dz = dk + 2 * (size_t)n; float* dout = dz + n; float* drt = dout + 3 * (size_t)n;
-    HIP_TRY(ctx, hipMemcpyAsync(dk, keys_xy, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(dz, z, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(drt, RT, sizeof RT, hipMemcpyHostToDevice, st));
+    float* dk = T->d_tmpf; float* dz = dk + 2 * (size_t)n; float* drt = dz + n; float* dout = drt + 16;      // [keys 2n | z n | RT 12 (+4) | xyz 3n]
+    memcpy(T->h_io, keys_xy, (size_t)n * 8); memcpy(T->h_io + 2 * (size_t)n, z, (size_t)n * 4); memcpy(T->h_io + 3 * (size_t)n, RT, sizeof RT);
+    HIP_TRY(ctx, hipMemcpyAsync(dk, T->h_io, ((size_t)n * 3 + 16) * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_unproject_world, dim3((n + 255) / 256), dim3(256), 0, st, dk, dz, n, p->cx, p->cy, 1.0f / p->fx, 1.0f / p->fy, drt, dout);
-    HIP_TRY(ctx, hipMemcpyAsync(xyz_out, dout, (size_t)n * 12, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 3 * (size_t)n + 16, dout, (size_t)n * 12, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    memcpy(xyz_out, T->h_io + 3 * (size_t)n + 16, (size_t)n * 12);
     return VIDO_OK;
 }
 
@@ -585,19 +612,17 @@ int vido_scene_flow(vido_ctx* ctx, const float* xyz_last, const float* xyz_cur, 
 {
     if (!ctx) return VIDO_E_INVALID;
     TrackState* T; int rc = track_state(ctx, &T); if (rc) return rc;
-    if (n < 0 || (size_t)n * 9 > T->tmp_cap || (size_t)n * 3 > T->tmp_cap) return vido_set_error(ctx, VIDO_E_INVALID, "scene_flow: n too large");
+    if (n < 0 || (size_t)n * 12 > T->tmp_cap) return vido_set_error(ctx, VIDO_E_INVALID, "scene_flow: n too large");
     if (n == 0) return VIDO_OK;
     hipStream_t st = ctx->stream;
-    float *a = T->d_tmpf, *b = a + 3 * (size_t)n, *c = b + 3 * (size_t)n; int32_t *sl = T->d_tmpi, *sc = sl + n, *ol = sc + n;
-    HIP_TRY(ctx, hipMemcpyAsync(a, xyz_last, (size_t)n * 12, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(b, xyz_cur, (size_t)n * 12, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(sl, sem_last, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(sc, sem_cur, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(ol, obj_label_inout, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    const size_t N = (size_t)n;
+    float *a = T->d_tmpf, *b = a + 3 * N; int32_t *sl = (int32_t*)(b + 3 * N), *sc = sl + N, *ol = sc + N; float* c = (float*)(ol + N);      // [last 3n | cur 3n | sem last n | sem cur n | label n (in/out) | flow 3n]
+    memcpy(T->h_io, xyz_last, N * 12); memcpy(T->h_io + 3 * N, xyz_cur, N * 12); memcpy(T->h_io + 6 * N, sem_last, N * 4); memcpy(T->h_io + 7 * N, sem_cur, N * 4); memcpy(T->h_io + 8 * N, obj_label_inout, N * 4);
+    HIP_TRY(ctx, hipMemcpyAsync(a, T->h_io, N * 36, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_scene_flow, dim3((n + 255) / 256), dim3(256), 0, st, a, b, sl, sc, n, c, ol);
-    HIP_TRY(ctx, hipMemcpyAsync(flow3d_out, c, (size_t)n * 12, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(obj_label_inout, ol, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 8 * N, ol, N * 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    memcpy(obj_label_inout, T->h_io + 8 * N, N * 4); memcpy(flow3d_out, T->h_io + 9 * N, N * 12);
     return VIDO_OK;
 }
 
