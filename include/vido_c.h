@@ -301,6 +301,12 @@ int vido_deconv4s2_depthwise(vido_ctx* ctx, const float* x, const float* weight,
  * the way in, so that the 1x1 convolution in front needs no pass of its own over its output.
  * vido_gconv3x3_supported: 1 when a kernel exists for the shape (8, 16 or a multiple of 32 channels per group and a row band that fits LDS); otherwise the call returns
  * VIDO_E_INVALID and the caller keeps the library convolution. */
+/* 1x1 convolution (stride 1, batch 1) + bias + residual + leaky-ReLU as one fp32 matrix-core GEMM (csrc/conv1x1.hip): conv1 / conv3 / the stride-1 shortcut of
+ * BottleneckWithFixedBatchNorm with their folded FrozenBatchNorm2d (maskrcnn_benchmark/modeling/backbone/resnet.py:300-372, layers/batch_norm.py:19-31).  x [cin][hw],
+ * y / residual [cout][hw], f32 DEVICE, 16-byte aligned, y != x; bias [cout] or NULL; residual NULL = none; w_packed: [cout][cin] in operand order
+ * (vido_slam_amd/nets/ops.py::pack_conv1x1).  slope: 0 = ReLU, 1 = none.  vido_conv1x1_supported: cout % 128 == 0, cin % 32 == 0, hw % 4 == 0, hw >= 128. */
+int vido_conv1x1_supported(int cin, int cout, int hw);
+int vido_conv1x1_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, int hw, float slope);
 int vido_gconv3x3_supported(int H, int W, int cpg_in, int cpg_out);
 int64_t vido_gconv3x3_packed_size(int groups, int cpg_in, int cpg_out);
 int vido_gconv3x3_bias_act(vido_ctx* ctx, const float* x, const float* in_bias, const float* w_packed, const float* bias, float* y, int groups, int cpg_in, int cpg_out, int H, int W, float slope);

@@ -219,3 +219,52 @@ def test_bottleneck_with_matrix_core_conv2_equals_library_path(vido, ctx):
         blk._w2p = None
         y_lib = blk(x)
     assert float((y_fast - y_lib).abs().max()) < 1e-4 * max(1.0, float(y_lib.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 256, 40, 68), (256, 256, 50, 68), (256, 128, 37, 52), (1024, 1024, 10, 34), (512, 512, 25, 36), (32, 128, 12, 11), (2048, 256, 16, 16)])
+def test_conv1x1_matrix_core_gemm_equals_conv2d(vido, ctx, cin, cout, H, W):
+    """csrc/conv1x1.hip against conv2d in float64: bottleneck shapes of the detector (64 -> 256, 256 -> 256, 1024 -> 1024 ...), position counts that are not a multiple of
+    the 128-wide tile (the last tile's clamped copies), with and without bias / residual, ReLU / leaky / no activation."""
+    from vido_slam_amd.nets.ops import HipOps, pack_conv1x1
+    ops = HipOps(ctx)
+    g = torch.Generator().manual_seed(cin * 7 + H)
+    x = torch.randn(1, cin, H, W, generator=g); w = torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin ** 0.5); b = torch.randn(cout, generator=g); r = torch.randn(1, cout, H, W, generator=g)
+    assert ops.conv1x1_supported(cin, cout, H * W)
+    wp = pack_conv1x1(w).cuda()
+    ref0 = torch.nn.functional.conv2d(x.double(), w.double())
+    for bias, res, slope in ((None, None, 1.0), (b, None, 0.0), (b, r, 0.0), (b, r, 0.1), (None, r, 1.0)):
+        y = ops.conv1x1_bias_act(x.cuda(), wp, bias.cuda() if bias is not None else None, res.cuda() if res is not None else None, slope).cpu()
+        ref = ref0 + (bias.double()[None, :, None, None] if bias is not None else 0.0) + (res.double() if res is not None else 0.0)
+        ref = torch.nn.functional.leaky_relu(ref, slope)
+        err = float((y.double() - ref).abs().max())
+        assert err < 2e-5 * max(1.0, float(ref.abs().max())), (cin, cout, H, W, slope, err)
+    # shapes outside the plan are refused, not mangled
+    assert not ops.conv1x1_supported(48, 128, 1024) and not ops.conv1x1_supported(64, 64, 1024) and not ops.conv1x1_supported(64, 128, 850) and not ops.conv1x1_supported(64, 128, 64)
+    with pytest.raises(vido.VidoError):
+        ops.conv1x1_bias_act(torch.zeros(1, 64, 25, 34, device="cuda"), torch.zeros(4, 2, 64, 16, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_bottleneck_with_matrix_core_1x1_equals_library_path(vido, ctx):
+    """_Bottleneck.forward with conv1 / conv3 / the stride-1 shortcut on csrc/conv1x1.hip (bias, shortcut add and ReLU in the GEMM's epilogue) against the same block on the
+    library convolutions + the bias / residual pass."""
+    from vido_slam_amd.nets import maskrcnn as M
+    from vido_slam_amd.nets.fuse import fold_batchnorm
+    from vido_slam_amd.nets.ops import HipOps
+    from vido_slam_amd.nets.weights import fill_maskrcnn
+    for cin, mid, cout in ((64, 256, 256), (256, 256, 256)):                     # first block of layer1 (with the stride-1 shortcut convolution) and a plain one
+        blk = M._Bottleneck(cin, mid, cout, 32, False, 1)
+        fill_maskrcnn(blk); blk = blk.cuda().eval()
+        x = torch.randn(1, cin, 40, 52, generator=torch.Generator().manual_seed(4)).cuda()
+        with torch.no_grad():
+            os.environ["VIDO_CONV1X1"] = "all"                                       # every 1x1 convolution of the block, whatever the size rule of fuse.py says
+            try:
+                fold_batchnorm(blk, HipOps(ctx))
+            finally:
+                del os.environ["VIDO_CONV1X1"]
+            assert blk._w1p is not None and blk._w3p is not None and (blk.downsample is None or blk._wdp is not None)
+            y_fast = blk(x).clone()
+            blk._w1p = blk._w3p = blk._wdp = None
+            y_lib = blk(x)
+        assert float((y_fast - y_lib).abs().max()) < 1e-4 * max(1.0, float(y_lib.abs().max()))

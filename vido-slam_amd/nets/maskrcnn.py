@@ -73,17 +73,31 @@ class _Bottleneck(nn.Module):              # resnet.py:277-372 (BottleneckWithFi
 
     _ep = None                             # nets/fuse.py::fold_batchnorm installs the folded tensors + the fused HIP epilogue
     _w2p = None                            # ... and conv2's weight in the operand order of csrc/gconv.hip where that kernel takes the layer
+    _w1p = _w3p = _wdp = None; _c1x1_min_tiles = 0      # ... and the 1x1 convolutions' in the operand order of csrc/conv1x1.hip (fuse.py decides which layers take it)
 
     def forward(self, x):
         if self._ep is not None and x.is_cuda:
-            ep = self._ep; c1, c2 = self.conv1, self.conv2
-            y = F.conv2d(x, self._w1, None, c1.stride)
+            ep = self._ep; c1, c2 = self.conv1, self.conv2; ops = self._ops
+            b1x = x.shape[0] == 1
+            hw_in = x.shape[2] * x.shape[3]
+            if self._w1p is not None and b1x and ops.conv1x1_supported(x.shape[1], self._w1.shape[0], hw_in):
+                y = ops.conv1x1_bias_act(x.contiguous(), self._w1p)                      # (its bias + ReLU ride on conv2's operand reads, or run below)
+            else:
+                y = F.conv2d(x, self._w1, None, c1.stride)
             if self._w2p is not None and y.shape[0] == 1 and self._ops.gconv3x3_supported(y.shape[2], y.shape[3], c2.in_channels // c2.groups, c2.out_channels // c2.groups):
                 # conv1's bias + ReLU ride on conv2's operand reads, conv2's own leave through its accumulators: two passes over the activations less per block
                 y = self._ops.gconv3x3_bias_act(y, self._w2p, self._b2, c2.groups, 0.0, in_bias=self._b1)
             else:
                 y = ep(F.conv2d(ep(y, self._b1, None, 0.0), self._w2, None, c2.stride, c2.padding, c2.dilation, c2.groups), self._b2, None, 0.0)
-            sc = x if self.downsample is None else ep(F.conv2d(x, self._wd, None, self.downsample[0].stride), self._bd, None, 1.0)
+            if self.downsample is None:
+                sc = x
+            elif self._wdp is not None and b1x and ops.conv1x1_supported(x.shape[1], self._wd.shape[0], hw_in):
+                sc = ops.conv1x1_bias_act(x.contiguous(), self._wdp, self._bd, None, 1.0)
+            else:
+                sc = ep(F.conv2d(x, self._wd, None, self.downsample[0].stride), self._bd, None, 1.0)
+            if (self._w3p is not None and y.shape[0] == 1 and ops.conv1x1_supported(y.shape[1], self._w3.shape[0], y.shape[2] * y.shape[3])
+                    and (self._w3.shape[0] // 128) * ((y.shape[2] * y.shape[3] + 127) // 128) >= self._c1x1_min_tiles):
+                return ops.conv1x1_bias_act(y.contiguous(), self._w3p, self._b3, sc, 0.0)      # bias + shortcut + ReLU leave through the GEMM's accumulators: no pass over the output
             return ep(F.conv2d(y, self._w3), self._b3, sc.contiguous(), 0.0)
         y = F.relu(self.bn1(self.conv1(x)))
         y = F.relu(self.bn2(self.conv2(y)))

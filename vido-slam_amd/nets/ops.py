@@ -127,6 +127,24 @@ class HipOps:
                                                             int(groups), cpg_in, cpg_out, H, W, C.c_float(slope)))
         return out
 
+    def conv1x1_supported(self, cin, cout, hw):
+        return bool(self.ctx.lib.vido_conv1x1_supported(int(cin), int(cout), int(hw)))
+
+    def conv1x1_bias_act(self, x, w_packed, bias=None, residual=None, slope=1.0):
+        """leaky_relu(conv2d(x, w) + bias + residual, slope) for one image, 1x1 kernel, stride 1, as one matrix-core GEMM launch (csrc/conv1x1.hip); w_packed = pack_conv1x1(w).
+        slope 0 = ReLU, 1 = none."""
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and x.shape[0] == 1
+        _, cin, H, W = x.shape
+        cout = w_packed.shape[0] * 32
+        out = torch.empty((1, cout, H, W), device=x.device, dtype=torch.float32)
+        if residual is not None:
+            residual = residual.contiguous(); assert residual.shape == out.shape
+        self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * cout * cin * H * W      # (torch's FlopCounterMode does not see this launch; bench.py adds it)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_conv1x1_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(w_packed.data_ptr()), C.c_void_p(bias.data_ptr()) if bias is not None else None,
+                                                           C.c_void_p(residual.data_ptr()) if residual is not None else None, C.c_void_p(out.data_ptr()), int(cin), int(cout), int(H * W), C.c_float(slope)))
+        return out
+
     def lfn_reg_front(self, im1, im2, flow, scale, feat):
         """Regularization.forward up to netMain's input (layers.py:236-243): torch.cat([sqrt(sum((im1 - Backward(im2, flow * scale))^2)), flow - mean(flow), feat], 1) with the
         first three channels from one HIP pass."""
@@ -319,6 +337,18 @@ class HipOps:
                                                            C.c_void_p(labels.data_ptr()) if n else None, n, masks.shape[-1] if n else 28, padding, C.c_float(thresh), H, W,
                                                            C.c_void_p(out.data_ptr())))
         return out
+
+
+def pack_conv1x1(w):
+    """1x1 convolution weight [cout, cin, 1, 1] (or [cout, cin]) -> the operand order of csrc/conv1x1.hip: element (co, k) at [co / 32][k / 32][32 * (k & 1) + co % 32][(k % 32) / 2]
+    (a lane's 16 operands of a 32-channel K chunk are consecutive; a wave's chunk is 4 KB contiguous).  None when the kernel does not take the shape."""
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    if w.dim() == 4 and tuple(w.shape[2:]) != (1, 1):
+        return None
+    if cout % 128 or cin % 32:
+        return None
+    w5 = w.detach().reshape(cout // 32, 32, cin // 32, 16, 2)          # [mb][co32][kc][kp][half]
+    return w5.permute(0, 2, 4, 1, 3).contiguous().reshape(cout // 32, cin // 32, 64, 16)
 
 
 def pack_gconv3x3(w, groups):
