@@ -2,6 +2,7 @@
 PartialBatchOptimization / the static part of FullBatchOptimization on g2o's LM).  Tolerance: camera SE(3) and
 landmarks within 1e-4 relative (BASELINE.json north_star); FP64 atomics make the summation order free, so the
 comparison is not bitwise."""
+import os
 import numpy as np
 import pytest
 
@@ -287,3 +288,19 @@ def test_revisited_landmarks_leave_the_camera_window(vido, oracle, ctx, share, c
     assert got["iterations"] == ref["iterations"] and got["lm_trials"] == ref["lm_trials"]
     assert rel(got["cam_T"], ref["cam_T"]) < RTOL and rel(got["pt_xyz"], ref["pt_xyz"]) < RTOL
     assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-6 * ref["chi2_final"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"VIDO_BA_PERSIST": "1"}, {"VIDO_BA_NO_FUSED_LOCAL": "1"}])
+def test_local_window_alternative_drivers_match_the_oracle(env):
+    """The local window has three drivers over the same kernels' bodies: the fused host-driven loop (default), the persistent one-launch solver k_ba_local_lm
+    (VIDO_BA_PERSIST=1: opt-in) and round 3's loop (VIDO_BA_NO_FUSED_LOCAL=1).  The switches are read once per process, so the two alternatives run
+    the local-window oracle cases (same LM iteration AND trial counts, poses / points to 1e-4) and the facade's resident-window cross-check in a child process."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e.update(env)
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_ba_gpu.py"), os.path.join(root, "tests", "test_facade_gpu.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "(test_ba_matches_oracle and kw0 or test_ba_matches_oracle and kw1 or test_ba_matches_oracle and kw2 or zero_noise or device_resident_ba_window) and not alternative_drivers"],
+                       cwd=root, env=e, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout and "5 passed" in p.stdout, p.stdout[-1500:]
