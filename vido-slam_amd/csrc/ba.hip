@@ -2106,15 +2106,24 @@ __global__ __launch_bounds__(LIN_THREADS) void k_ba_lin_local(BaDev P, int nvb)
     ba_camfactor_body(P, 1, P.cam, P.scal + 0, ((int)blockIdx.x - nvb) * (LIN_THREADS / 64) + (int)(threadIdx.x >> 6), threadIdx.x & 63);      // (a factor index past the list returns)
 }
 __global__ __launch_bounds__(256) void k_ba_fold_local(BaDev P, const double* S_part, int nparts, double lambda) { ba_fold_local_body(P, S_part, nparts, lambda, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256); }
-__global__ __launch_bounds__(256) void k_ba_backsub_chi2_local(BaDev P, int n_ptl, double lambda, int n_bs, double* zero_buf, int zero_len)
+// (the LAST workgroup to finish — ticket counter, the classic threadfence reduction — copies the trial's five scalars straight into the host's pinned block: the host waits for
+//  the launch and reads them there, one copy per trial less on the stream)
+__global__ __launch_bounds__(256) void k_ba_backsub_chi2_local(BaDev P, int n_ptl, double lambda, int n_bs, double* zero_buf, int zero_len, int* ticket, double* host_scal)
 {
     __shared__ double wsum[32];
+    __shared__ int is_last;
     if ((int)blockIdx.x < n_bs) {
         ba_backsub_chi2_body(P, n_ptl, lambda, blockIdx.x * 256 + threadIdx.x, n_bs * 256, wsum);
         if (zero_buf) for (int t = blockIdx.x * 256 + threadIdx.x; t < zero_len; t += n_bs * 256) zero_buf[t] = 0.0;      // the NEXT linearisation's accumulators (the other copy)
-        return;
+    } else ba_camfactor_body(P, 0, P.cam_new, P.scal + 2, ((int)blockIdx.x - n_bs) * 4 + (int)(threadIdx.x >> 6), threadIdx.x & 63);
+    __threadfence();                                            // this workgroup's atomics have been performed before its ticket is drawn
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (is_last) {
+        if (threadIdx.x < 5) host_scal[threadIdx.x] = bal_ld(P.scal + threadIdx.x);
+        if (threadIdx.x == 0) *ticket = 0;
     }
-    ba_camfactor_body(P, 0, P.cam_new, P.scal + 2, ((int)blockIdx.x - n_bs) * 4 + (int)(threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 // The solver's state flips between two buffers (accepted / trial) and the linearisation's accumulators between two copies: four variants of the problem descriptor, all
@@ -2473,6 +2482,7 @@ struct BaState {
     char* pool = nullptr; char* h_pool = nullptr; size_t pool_cap = 0, hpool_cap = 0;
     int* d_long = nullptr; size_t long_cap = 0;      // landmarks with > 64 observations
     double* d_bcr = nullptr; size_t bcr_cap = 0;     // block-cyclic-reduction workspace (superblocks D, L x2, GL, GR, b, y)
+    int* d_ticket = nullptr;                        // k_ba_backsub_chi2_local: workgroups finished so far (reset by the last one)
     struct BaLmCtl* d_ctl = nullptr; struct BaLmCtl* h_ctl = nullptr; unsigned bar_base = 0;   // persistent local-window solver: control block (device + pinned mirror), barrier count so far
 };
 void ba_state_destroy(vido_ctx* ctx)
@@ -2480,7 +2490,7 @@ void ba_state_destroy(vido_ctx* ctx)
     BaState* S = ctx->ba; if (!S) return;
     for (void* p : S->allocs) hipFree(p);
     hipFree(S->d_parts); hipFree(S->d_scratch); hipHostFree(S->h_scal); hipFree(S->pool); hipHostFree(S->h_pool); hipFree(S->d_long); hipFree(S->d_bcr);
-    hipFree(S->d_ctl); hipHostFree(S->h_ctl);
+    hipFree(S->d_ctl); hipHostFree(S->h_ctl); hipFree(S->d_ticket);
     if (S->ev0) hipEventDestroy(S->ev0);
     if (S->ev1) hipEventDestroy(S->ev1);
     delete S; ctx->ba = nullptr;
@@ -2540,16 +2550,20 @@ static void par_memcpy(HostPool& P, void* dst, const void* src, size_t bytes)
     if (bytes & 63) memcpy((char*)dst + (bytes & ~(size_t)63), (const char*)src + (bytes & ~(size_t)63), bytes & 63);
 }
 
-struct Arena {                       // bump allocator over the ctx's persistent BA pool (no hipMalloc per call);
-    char* base; size_t cap; size_t off = 0; bool failed = false;   // host inputs go through a pinned stage that only has to hold what is uploaded
-    char* hbase; size_t hcap = 0, hoff = 0;
+struct Arena {                       // bump allocator over the ctx's persistent BA pool (no hipMalloc per call).  The pool's first `up_cap` bytes MIRROR the pinned stage:
+    char* base; size_t cap; size_t off = 0; bool failed = false;   // an uploaded array lives at the same offset on both sides, so the uploads of a call leave as ONE copy (flush) —
+    char* hbase; size_t hcap = 0, hoff = 0;                        // the local window used to enqueue nine 100-byte copies per solve, each a stream operation that queues behind the
+    size_t up_cap = 0, flushed = 0;                                // networks — or, for the multi-megabyte tables of a global solve, as 4 MB pieces while the host fills the next ones
     template <class T> T* get(size_t n) { const size_t b = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255; if (off + b > cap) { failed = true; return nullptr; } T* p = (T*)(base + off); off += b; return p; }
     template <class T> T* put(const T* src, size_t n, hipStream_t st) {
-        T* d = get<T>(n);
-        const size_t b = (n * sizeof(T) + 255) & ~(size_t)255;
-        if (d && n) { if (hoff + b > hcap) { failed = true; return nullptr; }
-                      par_memcpy(HostPool::get(), hbase + hoff, src, n * sizeof(T)); if (hipMemcpyAsync(d, hbase + hoff, n * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) failed = true; hoff += b; }
+        const size_t b = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+        if (hoff + b > up_cap || hoff + b > hcap) { failed = true; return nullptr; }
+        T* d = (T*)(base + hoff);
+        if (n) par_memcpy(HostPool::get(), hbase + hoff, src, n * sizeof(T));
+        hoff += b;
+        if (hoff - flushed >= ((size_t)4 << 20)) flush(st);
         return d; }
+    void flush(hipStream_t st) { if (hoff > flushed) { if (hipMemcpyAsync(base + flushed, hbase + flushed, hoff - flushed, hipMemcpyHostToDevice, st) != hipSuccess) failed = true; flushed = hoff; } }
 };
 }
 
@@ -2774,11 +2788,12 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     maxk = std::min(maxk, 64);
     phase("slot tables, checks");
     // ---- device buffers
+    size_t up_this = 0;                                      // upload bytes of THIS call (estimate with slack): the mirrored region of the arena
     {   // size the persistent pool (device + pinned mirror for the uploads) for this problem
         const size_t ndb = (size_t)n_pose * (24 + 36 + 36 + 36 + 12) + (size_t)n_ptl * (6 + 6 + 3) + (size_t)no * (3 + BA_REC) + (size_t)n_cc * (12 + 36 + 2) + (size_t)n6 * n6 + 6 * (size_t)n6 + 128 +
                            (size_t)nd * (3 + 3 + 3 + 6 + 3 + 9 + 18 * 4 + 3);
         const size_t ni32 = 2 * (size_t)n_pose + 5 * (size_t)no + 4 * (size_t)n_ptl + (size_t)n_ptl / 32 + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 256;
-        const size_t need = ndb * 8 + ni32 * 4 + 96 * 256;
+        const size_t need = ndb * 8 + ni32 * 4 + 96 * 256 + 64 * 256 + 8192;      // (+ the slack of the upload region's estimate below)
         if (need > BS->pool_cap) {
             HIP_TRY(ctx, hipStreamSynchronize(st));
             if (BS->pool) { hipFree(BS->pool); BS->pool = nullptr; }
@@ -2789,6 +2804,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         // pinning memory is the slow part of a cold call (~0.1 ms per MB)
         const size_t up = ((size_t)n_pose * 12 + (size_t)n_ptl * 3 + (size_t)no * 3 + (size_t)n_cc * 14 + (size_t)nd * 6) * 8 +
                           ((size_t)2 * n_pose + 5 * (size_t)no + 5 * (size_t)n_ptl + 2 * (size_t)n_cc + 2 * (size_t)nd + (size_t)n_chain + 64) * 4 + 64 * 256;
+        up_this = (up + 255) & ~(size_t)255;
         if (up > BS->hpool_cap) {
             HIP_TRY(ctx, hipStreamSynchronize(st));
             if (BS->h_pool) { hipHostFree(BS->h_pool); BS->h_pool = nullptr; }
@@ -2797,7 +2813,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         }
     }
     phase("pool sizing");
-    Arena A{BS->pool, BS->pool_cap, 0, false, BS->h_pool, BS->hpool_cap, 0};
+    Arena A; A.base = BS->pool; A.cap = BS->pool_cap; A.hbase = BS->h_pool; A.hcap = BS->hpool_cap;
+    A.up_cap = up_this; A.off = A.up_cap;                      // uploads in [0, up_cap), everything else behind
     BaDev D{};
     D.n_cam = n_pose; D.n_pt = p.n_pt; D.n_obs = no; D.n_odo = owns_cam_factors ? n_cc : 0; D.prior_cam = (owns_cam_factors && p.prior_cam >= 0) ? perm[p.prior_cam] : -1;
     D.use_huber = p.use_huber; D.n6 = n6; D.pt_lo = pt_lo;
@@ -3011,6 +3028,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         return VIDO_OK;
     };
     int rc;
+    A.flush(st);                                                // the uploads of this call (one copy for the local window)
+    if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: upload staging exhausted");
     HIP_TRY(ctx, hipStreamSynchronize(st));
     phase("attributes, launch set-up");
     res->ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -3059,8 +3078,9 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     }
     // the fused host-driven loop of the local window (k_ba_lin_local / k_ba_fold_local / k_ba_backsub_chi2_local): 6 stream operations per LM iteration instead of 11
     const bool fl = local_static && !persist && !no_fused_local;
-    static const int fl_schur_grid_env = [] { const char* e = getenv("VIDO_BA_SCHUR0_GRID"); return e ? std::max(1, std::min(atoi(e), BA_SCHUR0_GRID)) : 64; }();
-    const int fl_grid = std::min(fl_schur_grid_env, std::max(1, (n_ptl + 3) / 4));       // partial reduced systems: every one is summed by the fold, 64 measured against 256 (tools/scratch)
+    if (fl && !BS->d_ticket) { HIP_TRY(ctx, hipMalloc((void**)&BS->d_ticket, sizeof(int))); HIP_TRY(ctx, hipMemset(BS->d_ticket, 0, sizeof(int))); }
+    static const int fl_schur_grid_env = [] { const char* e = getenv("VIDO_BA_SCHUR0_GRID"); return e ? std::max(1, std::min(atoi(e), BA_SCHUR0_GRID)) : 128; }();
+    const int fl_grid = std::min(fl_schur_grid_env, std::max(1, (n_ptl + 3) / 4));       // partial reduced systems: every one is summed by the fold; tracker alone: 32 / 64 / 128 / 256 partials -> 2.49 / 2.13 / 1.95 / 1.95 ms per solve
     const size_t red_len = (size_t)n_pose * 36 + n6 + 8;
     if (!persist) {
     if (!fl) { if ((rc = chi2_at(D.cam, D.pt, 2, &res->chi2_initial))) return rc; res->chi2_final = res->chi2_initial; }
@@ -3115,8 +3135,10 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
                 hipLaunchKernelGGL(k_ba_fold_local, dim3(std::min(64, (int)((loc_sz + 255) / 256))), dim3(256), 0, st, D, (const double*)BS->d_parts, fl_grid, lambda);
                 hipLaunchKernelGGL(k_ba_chol_small6, dim3(1), dim3(CH_NT), lds_chol6, st, D, 1, lambda);
                 const int n_bs = std::min((n_ptl + 31) / 32, 1024);
-                hipLaunchKernelGGL(k_ba_backsub_chi2_local, dim3(n_bs + (ncf + 3) / 4), dim3(256), 0, st, D, n_ptl, lambda, n_bs, qmax == 0 ? ((it & 1) ? red : red1) : (double*)nullptr, (int)red_len);
+                hipLaunchKernelGGL(k_ba_backsub_chi2_local, dim3(n_bs + (ncf + 3) / 4), dim3(256), 0, st, D, n_ptl, lambda, n_bs, qmax == 0 ? ((it & 1) ? red : red1) : (double*)nullptr, (int)red_len,
+                                   BS->d_ticket, BS->h_scal);
                 HIP_TRY(ctx, hipGetLastError());
+                HIP_TRY(ctx, hipStreamSynchronize(st));      // the launch's last workgroup has written the trial's scalars into h_scal
             } else {
             // ---- reduced system of this shard.  With an all-reduce every rank contributes Hcd/bc ALREADY summed,
             // so only rank 0 adds the camera-camera part (+lambda) to S; the others start from zero.
@@ -3176,8 +3198,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             if (ncf) hipLaunchKernelGGL(k_ba_camfactors, dim3(ncf), dim3(64), 0, st, D, 0, D.cam_new, D.scal + 2);
             HIP_TRY(ctx, hipGetLastError());
             if ((rc = AR(D.scal + 2, 2, 0))) return rc;
-            }
             if ((rc = read_scal())) return rc;
+            }
             if (!have_chi) { currentChi = iniChi = BS->h_scal[0]; have_chi = true; }
             if (qmax == 0 && !fl) { float ms = 0; if (hipEventElapsedTime(&ms, BS->ev0, BS->ev1) == hipSuccess) ms_lin += ms; }
             const bool ok2 = BS->h_scal[4] > 0.5;

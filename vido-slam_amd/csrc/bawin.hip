@@ -52,6 +52,21 @@ __device__ int bw_excl_scan(int v, int* wsum /*[17]*/, int* total)
     return wsum[wave] + incl - v;
 }
 
+// One frame's rows from the staging block [meas n x 3 f64 | xyz n x 3 f32 | asso n i32] into ring slot s; the slot's labels start as "no tracklet".  One upload + this
+// launch instead of four copies and two fills per frame (every stream operation of the tracker queues behind the networks' workgroups).
+__global__ __launch_bounds__(256) void k_bawin_ingest(const char* __restrict__ stage, int n, int cap_n, size_t o, double* __restrict__ meas, float* __restrict__ xyz,
+                                                      int* __restrict__ asso, int* __restrict__ trk, int* __restrict__ pos, int* __restrict__ nfeat_s)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *nfeat_s = n;
+    if (i < cap_n) { trk[o + i] = -1; pos[o + i] = 0; }
+    if (i >= n) return;
+    const double* sm = (const double*)stage; const float* sx = (const float*)(stage + (size_t)n * 24); const int* sa = (const int*)(stage + (size_t)n * 36);
+#pragma unroll
+    for (int a = 0; a < 3; a++) { meas[3 * (o + i) + a] = sm[3 * (size_t)i + a]; xyz[3 * (o + i) + a] = sx[3 * (size_t)i + a]; }
+    asso[o + i] = sa[i];
+}
+
 __global__ __launch_bounds__(256) void k_bawin_labels(const int4* __restrict__ upd, int n, int cap_f, int cap_n, int* __restrict__ trk, int* __restrict__ pos)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -68,7 +83,10 @@ __global__ __launch_bounds__(1024) void k_bawin_assemble(BaWinDev W, int start, 
 {
     __shared__ int wsum[17];
     const int tid = threadIdx.x;
-    // (W.cnt is cleared by the caller with a memset on the stream: one workgroup clearing cap_pt counters took 60 of this kernel's 258 us)
+    if (tid == 0) { counts[2] = 0; counts[3] = 0; }            // (the flags / maximum this launch accumulates below; counts[0..1] are plain stores at the end)
+    __syncthreads();
+    // (W.cnt is all zero on entry: cleared at creation and re-cleared after every solve by k_bawin_slots, all CUs — one workgroup clearing cap_pt counters here took 60 of
+    //  this kernel's 258 us, a memset on the stream is one more operation queueing behind the networks)
     int n_pt = 0, n_obs = 0, overflow = 0;
     for (int f = start; f < N; f++) {
         const int s = f % W.cap_f, sp = (f + W.cap_f - 1) % W.cap_f, n = W.nfeat[s], np = f > start ? W.nfeat[sp] : 0;
@@ -139,9 +157,10 @@ __global__ __launch_bounds__(1024) void k_bawin_assemble(BaWinDev W, int start, 
 }
 
 // slot of an observation = pt_start[landmark] + (camera - first camera of the landmark); counts[0] = number of observations (written by k_bawin_assemble)
-__global__ __launch_bounds__(256) void k_bawin_slots(BaWinDev W, const int* __restrict__ counts)
+__global__ __launch_bounds__(256) void k_bawin_slots(BaWinDev W, const int* __restrict__ counts, int clear_n)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < clear_n) W.cnt[k] = 0;                             // the per-landmark counters of this assembly, for the next one (k_bawin_assemble is done with them)
     if (k >= counts[0]) return;
     const int p = W.obs_pt[k], c = W.obs_cam[k], sl = W.pt_start[p] + (c - W.first[p]);
     W.obs_pos[k] = sl; W.slot_cam[sl] = c;
@@ -192,6 +211,7 @@ int vido_bawin_create(vido_ctx* ctx, int cap_frames, int cap_features)
     B->stage_cap = (size_t)cap_features * (24 + 12 + 4) + (size_t)cap_features * 16 * 4 + 4096;      // one frame's rows, or 4 x cap_features label quads
     HIP_TRY(ctx, hipHostMalloc((void**)&B->h_stage, B->stage_cap)); HIP_TRY(ctx, hipMalloc((void**)&B->d_stage, B->stage_cap));
     HIP_TRY(ctx, hipMemset(B->d_trk, 0xff, nf * 4)); HIP_TRY(ctx, hipMemset(B->d_pos, 0, nf * 4)); HIP_TRY(ctx, hipMemset(B->d_nfeat, 0, cap_frames * 4));
+    HIP_TRY(ctx, hipMemset(B->d_cnt, 0, nf * 4)); HIP_TRY(ctx, hipMemset(B->d_counts, 0, 16));
     B->frame_of.assign(cap_frames, -1); B->nfeat.assign(cap_frames, 0);
     return VIDO_OK;
 }
@@ -206,20 +226,15 @@ int vido_bawin_push_frame(vido_ctx* ctx, int frame, int n, const double* meas, c
     if (frame < 0 || n < 0 || n > B->cap_n || (n && (!meas || !xyz))) return vido_set_error(ctx, n > B->cap_n ? VIDO_E_CAPACITY : VIDO_E_INVALID, "bawin_push_frame: %d features (capacity %d)", n, B->cap_n);
     hipStream_t st = ctx->stream; const int s = frame % B->cap_f;
     HIP_TRY(ctx, hipStreamSynchronize(st));                                           // the staging buffer is reused
-    char* h = B->h_stage;
-    memcpy(h, meas, (size_t)n * 24); memcpy(h + (size_t)B->cap_n * 24, xyz, (size_t)n * 12);
-    int* ha = (int*)(h + (size_t)B->cap_n * 36);
+    char* h = B->h_stage;                                                              // [meas n x 24 | xyz n x 12 | asso n x 4], 8-byte aligned pieces (n x 24 and n x 36 are multiples of 4; meas first)
+    memcpy(h, meas, (size_t)n * 24); memcpy(h + (size_t)n * 24, xyz, (size_t)n * 12);
+    int* ha = (int*)(h + (size_t)n * 36);
     for (int i = 0; i < n; i++) ha[i] = asso ? asso[i] : -1;
     const size_t o = (size_t)s * B->cap_n;
-    if (n) {
-        HIP_TRY(ctx, hipMemcpyAsync(B->d_meas + 3 * o, h, (size_t)n * 24, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(B->d_xyz + 3 * o, h + (size_t)B->cap_n * 24, (size_t)n * 12, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(B->d_asso + o, ha, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    }
-    HIP_TRY(ctx, hipMemsetAsync(B->d_trk + o, 0xff, (size_t)B->cap_n * 4, st)); HIP_TRY(ctx, hipMemsetAsync(B->d_pos + o, 0, (size_t)B->cap_n * 4, st));
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(B->d_stage, h, (size_t)n * 40, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_bawin_ingest, dim3((B->cap_n + 255) / 256), dim3(256), 0, st, (const char*)B->d_stage, n, B->cap_n, o, B->d_meas, B->d_xyz, B->d_asso, B->d_trk, B->d_pos, B->d_nfeat + s);
+    HIP_TRY(ctx, hipGetLastError());
     B->frame_of[s] = frame; B->nfeat[s] = n;
-    int* hn = (int*)(h + (size_t)B->cap_n * 40); *hn = n;
-    HIP_TRY(ctx, hipMemcpyAsync(B->d_nfeat + s, hn, 4, hipMemcpyHostToDevice, st));
     return VIDO_OK;
 }
 
@@ -262,11 +277,10 @@ int vido_bawin_solve(vido_ctx* ctx, int start, int N, vido_ba_problem* prob, vid
     hipStream_t st = ctx->stream;
     BaWinDev W{B->cap_f, B->cap_n, B->cap_obs, B->cap_pt, B->d_meas, B->d_xyz, B->d_asso, B->d_trk, B->d_pos, B->d_pid, B->d_nfeat,
                B->d_obs_cam, B->d_obs_pt, B->d_obs_pos, B->d_obs_src, B->d_pt_start, B->d_slot_cam, B->d_cnt, B->d_first, B->d_obs_meas, B->d_pt};
-    HIP_TRY(ctx, hipMemsetAsync(B->d_counts, 0, 16, st));
     size_t n_feat_window = 0; for (int f = start; f < N; f++) n_feat_window += (size_t)B->nfeat[f % B->cap_f];      // an upper bound of the landmark / observation counts
-    HIP_TRY(ctx, hipMemsetAsync(B->d_cnt, 0, std::min(n_feat_window, (size_t)B->cap_pt) * sizeof(int), st));
+    const size_t bound = std::min(n_feat_window, (size_t)B->cap_obs);
     hipLaunchKernelGGL(k_bawin_assemble, dim3(1), dim3(1024), 0, st, W, start, N, B->d_counts);
-    hipLaunchKernelGGL(k_bawin_slots, dim3((unsigned)std::max<size_t>(1, (std::min(n_feat_window, (size_t)B->cap_obs) + 255) / 256)), dim3(256), 0, st, W, (const int*)B->d_counts);
+    hipLaunchKernelGGL(k_bawin_slots, dim3((unsigned)std::max<size_t>(1, (bound + 255) / 256)), dim3(256), 0, st, W, (const int*)B->d_counts, (int)std::min(n_feat_window, (size_t)B->cap_pt));
     HIP_TRY(ctx, hipMemcpyAsync(B->h_counts, B->d_counts, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     const int no = B->h_counts[0], np = B->h_counts[1];

@@ -152,6 +152,60 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
     *(uint32_t*)(base + doff + (size_t)y * dpitch + x4) = out;
 }
 
+// The whole pyramid of a frame in ONE launch (round 4; the tracker's single-frame path).  The seven k_resize launches above are a dependent chain — level l + 1 is resized
+// from level l (ORBextractor.cc:1107-1132) — of ~5 us each; beside the networks every link of that chain queues for a CU again.  Here a workgroup owns a horizontal BAND of
+// the image through all levels: it keeps, per level, the rows it owns plus the few rows the bands of the later levels need from it (PyrBand: computed on the host from the
+// monotone row tables, walking back from the last level) in LDS, computes level l + 1's rows from level l's with the same fixed-point arithmetic, and writes the rows it owns.
+// Rows near a band border are computed by both neighbours (about a third more resize work), there is no exchange between workgroups.
+#define PB_MAXL 8
+struct PyrBand { int need_lo[PB_MAXL], need_n[PB_MAXL], own_lo[PB_MAXL], own_hi[PB_MAXL], lds_off[PB_MAXL]; };      // per level: first needed row / count, owned rows [lo, hi), byte offset of the level's rows in LDS
+struct PyrBandLv { int w[PB_MAXL], h[PB_MAXL], pitch[PB_MAXL], off[PB_MAXL], xoff[PB_MAXL], yoff[PB_MAXL]; int L; };
+__global__ __launch_bounds__(256) void k_pyramid_bands(uint8_t* __restrict__ pyr, size_t slab, PyrBandLv V, const PyrBand* __restrict__ bands,
+                                                       const int2* __restrict__ xtab, const int4* __restrict__ ytab)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t pb_lds[];
+    const PyrBand& B = bands[blockIdx.x];
+    uint8_t* base = pyr + (size_t)blockIdx.y * slab;
+    const int tid = threadIdx.x;
+    {   // level 0: the needed rows of the ingested image, dword copies
+        const int ndw = V.pitch[0] >> 2, n = B.need_n[0] * ndw;
+        const uint32_t* src = (const uint32_t*)(base + V.off[0] + (size_t)B.need_lo[0] * V.pitch[0]);
+        uint32_t* dst = (uint32_t*)(pb_lds + B.lds_off[0]);
+        for (int i = tid; i < n; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    for (int l = 1; l < V.L; l++) {
+        const int sw = V.w[l - 1], spitch = V.pitch[l - 1], dw = V.w[l], dpitch = V.pitch[l], ndw = dpitch >> 2;
+        const int2* xt = xtab + V.xoff[l]; const int4* yt = ytab + V.yoff[l];
+        const uint8_t* S0 = pb_lds + B.lds_off[l - 1] - (size_t)B.need_lo[l - 1] * spitch;      // source row r lives at S0 + r * spitch
+        uint8_t* D0 = pb_lds + B.lds_off[l];
+        const int rows = B.need_n[l], ylo = B.need_lo[l];
+        for (int i = tid; i < rows * ndw; i += 256) {
+            const int rr = i / ndw, x4 = (i - rr * ndw) * 4, y = ylo + rr;
+            const int4 ytv = yt[y];
+            const uint8_t* L0 = S0 + (size_t)ytv.x * spitch; const uint8_t* L1 = S0 + (size_t)ytv.y * spitch;
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = x4 + k;
+                if (x < dw) {
+                    const int2 xv = xt[x];
+                    const int sx = xv.x & 0xffff, a0 = xv.x >> 16, a1 = xv.y;
+                    const int sx1 = sx + 1 < sw ? sx + 1 : sx;
+                    const int r0 = L0[sx] * a0 + L0[sx1] * a1;
+                    const int r1 = L1[sx] * a0 + L1[sx1] * a1;
+                    int v = (((ytv.z * (r0 >> 4)) >> 16) + ((ytv.w * (r1 >> 4)) >> 16) + 2) >> 2;
+                    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                    out |= (uint32_t)v << (8 * k);
+                }
+            }
+            *(uint32_t*)(D0 + (size_t)rr * dpitch + x4) = out;
+            if (y >= B.own_lo[l] && y < B.own_hi[l]) *(uint32_t*)(base + V.off[l] + (size_t)y * dpitch + x4) = out;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 typedef short v2s __attribute__((ext_vector_type(2)));
 
@@ -958,6 +1012,7 @@ struct OrbState {
     uint8_t *d_pyr = nullptr, *d_blur = nullptr;
     CellDesc* d_cells = nullptr; BlurTile* d_btiles = nullptr;
     int2* d_xtab = nullptr; int4* d_ytab = nullptr;
+    PyrBand* d_bands = nullptr; int n_bands = 0; size_t bands_lds = 0; PyrBandLv band_lv{};      // single-launch pyramid (k_pyramid_bands)
     uint32_t* d_slots = nullptr; int *d_counts = nullptr, *d_offsets = nullptr, *d_first_cell = nullptr, *d_lvloff = nullptr, *d_overflow = nullptr;
     uint32_t* d_cand = nullptr; size_t cand_cap = 0;
     uint2* d_kp = nullptr; size_t kp_cap = 0;
@@ -966,7 +1021,7 @@ struct OrbState {
     hipEvent_t ev[8] = {}; hipEvent_t ev_done = nullptr, ev_pyr = nullptr, ev_qt = nullptr, ev_half = nullptr; int half_frames = 0;
     float timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::chrono::steady_clock::time_point t_start;
-    int last_frames = 0;
+    int last_frames = 0; bool lean_last = false;
     int fast_rows = 0, fast_iw = FS_NARROW; size_t fast_lds = 0;
     FastStrip* d_strips = nullptr; int n_strips = 0; int* d_slot_off = nullptr; int slot_total = 0;      // FAST strips (<= 4 cells each), per-cell output slot offsets, slots per frame
     // device quadtree / keypoint assembly
@@ -1050,6 +1105,28 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
         }
         d.rs_rows = mr; d.rs_ndw = mw | 1;                  // odd dword stride: the two source rows of a pixel fall into different banks
         if ((size_t)d.rs_rows * d.rs_ndw * 4 > 64 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "pyramid scale factor too large for the resize tile");
+    }
+    // bands of the single-launch pyramid (k_pyramid_bands): per band and level the owned rows and the rows later levels need, walking back from the last level
+    std::vector<PyrBand> bands; S->n_bands = 0; S->bands_lds = 0;
+    if (L >= 2 && L <= PB_MAXL) {
+        const int NB = std::max(1, std::min(24, S->lv[L - 1].h / 4));
+        PyrBandLv& V = S->band_lv; V.L = L;
+        for (int l = 0; l < L; l++) { V.w[l] = S->lv[l].w; V.h[l] = S->lv[l].h; V.pitch[l] = S->lv[l].pitch; V.off[l] = S->lv[l].off; V.xoff[l] = S->lv[l].xtab_off; V.yoff[l] = S->lv[l].ytab_off; }
+        for (int b = 0; b < NB; b++) {
+            PyrBand pb{}; int lo[PB_MAXL], hi[PB_MAXL];
+            for (int l = 0; l < L; l++) { pb.own_lo[l] = (int)((long long)b * S->lv[l].h / NB); pb.own_hi[l] = (int)((long long)(b + 1) * S->lv[l].h / NB); }
+            lo[L - 1] = pb.own_lo[L - 1]; hi[L - 1] = pb.own_hi[L - 1];                      // needed rows [lo, hi) per level
+            for (int l = L - 2; l >= 0; l--) {
+                lo[l] = pb.own_lo[l]; hi[l] = pb.own_hi[l];
+                if (hi[l + 1] > lo[l + 1]) { const int4* yt = ytab.data() + S->lv[l + 1].ytab_off; lo[l] = std::min(lo[l], yt[lo[l + 1]].x); hi[l] = std::max(hi[l], yt[hi[l + 1] - 1].y + 1); }
+                if (l >= 1 && hi[l] <= lo[l]) { lo[l] = hi[l] = pb.own_lo[l]; }
+            }
+            size_t off = 0;
+            for (int l = 0; l < L; l++) { pb.need_lo[l] = lo[l]; pb.need_n[l] = std::max(hi[l] - lo[l], 0); pb.lds_off[l] = (int)off; off += (size_t)pb.need_n[l] * S->lv[l].pitch; off = (off + 15) & ~(size_t)15; }
+            S->bands_lds = std::max(S->bands_lds, off);
+            bands.push_back(pb);
+        }
+        if (S->bands_lds <= 150 * 1024) S->n_bands = NB;      // (else the per-level kernels stay)
     }
     // FAST cell table in the reference's loop order (ORBextractor.cc:759-796)
     std::vector<CellDesc> cells; std::vector<BlurTile> btiles;
@@ -1139,6 +1216,11 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
         HIP_TRY(ctx, hipMemcpy(S->d_xtab, xtab.data(), xtab.size() * sizeof(int2), hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(S->d_ytab, ytab.data(), ytab.size() * sizeof(int4), hipMemcpyHostToDevice));
     }
+    if (S->n_bands) {
+        HIP_TRY(ctx, hipMalloc(&S->d_bands, bands.size() * sizeof(PyrBand)));
+        HIP_TRY(ctx, hipMemcpy(S->d_bands, bands.data(), bands.size() * sizeof(PyrBand), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_pyramid_bands, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->bands_lds));
+    }
     HIP_TRY(ctx, hipMalloc(&S->d_first_cell, L * sizeof(int)));
     HIP_TRY(ctx, hipMemcpy(S->d_first_cell, S->first_cell.data(), L * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_umax), S->umax, sizeof S->umax));
@@ -1207,7 +1289,7 @@ void orb_state_destroy(vido_ctx* ctx)
 {
     OrbState* S = ctx->orb;
     if (!S) return;
-    hipFree(S->d_pyr); hipFree(S->d_blur); hipFree(S->d_cells); hipFree(S->d_btiles); hipFree(S->d_xtab); hipFree(S->d_ytab);
+    hipFree(S->d_pyr); hipFree(S->d_blur); hipFree(S->d_cells); hipFree(S->d_btiles); hipFree(S->d_xtab); hipFree(S->d_ytab); hipFree(S->d_bands);
     hipFree(S->d_slots); hipFree(S->d_counts); hipFree(S->d_offsets); hipFree(S->d_first_cell); hipFree(S->d_lvloff); hipFree(S->d_overflow);
     hipFree(S->d_cand); hipFree(S->d_kp); hipFree(S->d_strips); hipFree(S->d_slot_off);
     hipHostFree(S->h_lvloff); hipHostFree(S->h_overflow); hipHostFree(S->h_cand);
@@ -1237,7 +1319,13 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     hipStream_t st = ctx->stream;
     const int L = S->L;
     S->t_start = std::chrono::steady_clock::now();
-    HIP_TRY(ctx, hipEventRecord(S->ev[0], st));
+    // The tracker's single-frame path (nf <= 2) runs LEAN: no stage-timing events (vido_orb_last_timing then reports zeros: the stage times are only meaningful batched),
+    // the pyramid as one launch, the blur on the same stream — beside the networks every stream operation of this dependent chain queues for the GPU again (3.9 ms for
+    // the ~30 operations of an extraction that takes 0.35 ms alone).  VIDO_ORB_FULL_TIMING=1 keeps the batched form.
+    static const bool full_timing = getenv("VIDO_ORB_FULL_TIMING") != nullptr;
+    const bool lean = nf <= 2 && !full_timing;
+#define ORB_EV(e, s_) do { if (!lean) HIP_TRY(ctx, hipEventRecord((e), (s_))); } while (0)
+    ORB_EV(S->ev[0], st);
     // level 0 <- input
     if (S->in_channels != 1) {                          // colour frames: cvtColor fused into the ingest (set by vido_orb_extract_color for this one call)
         const int cn = S->in_channels; const uint8_t* src = imgs; size_t fs = frame_stride; int sst = stride;
@@ -1267,13 +1355,15 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     else for (int f = 0; f < nf; f++)
         HIP_TRY(ctx, hipMemcpy2DAsync(S->d_pyr + (size_t)f * S->slab + S->lv[0].off, S->lv[0].pitch, imgs + (size_t)f * frame_stride, stride,
                                       width, height, hipMemcpyHostToDevice, st));
-    for (int l = 1; l < L; l++) {
+    if (lean && S->n_bands)
+        hipLaunchKernelGGL(k_pyramid_bands, dim3(S->n_bands, nf), dim3(256), S->bands_lds, st, S->d_pyr, S->slab, S->band_lv, (const PyrBand*)S->d_bands, (const int2*)S->d_xtab, (const int4*)S->d_ytab);
+    else for (int l = 1; l < L; l++) {
         const LevelInfo &s = S->lv[l - 1], &d = S->lv[l];
         dim3 grid((d.pitch + RS_TW - 1) / RS_TW, (d.h + RS_TH - 1) / RS_TH, nf), block(256);
         hipLaunchKernelGGL(k_resize, grid, block, (size_t)d.rs_rows * d.rs_ndw * 4, st, S->d_pyr, S->slab, s.w, s.h, s.pitch, s.off, d.w, d.h, d.pitch, d.off,
                            S->d_xtab + d.xtab_off, S->d_ytab + d.ytab_off, d.rs_ndw);
     }
-    HIP_TRY(ctx, hipEventRecord(S->ev[1], st));
+    ORB_EV(S->ev[1], st);
     const int with_desc = ctx->cfg.compute_descriptors ? 1 : 0;
     if (S->fast_iw == FS_NARROW)
         hipLaunchKernelGGL(k_fast_strips<FS_NARROW>, dim3(S->n_strips, nf), dim3(64), S->fast_lds, st, S->d_pyr, S->slab, S->P, S->d_strips, S->n_cells, S->d_slot_off, S->slot_total,
@@ -1281,7 +1371,7 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     else
         hipLaunchKernelGGL(k_fast_strips<FS_WIDE>, dim3(S->n_strips, nf), dim3(64), S->fast_lds, st, S->d_pyr, S->slab, S->P, S->d_strips, S->n_cells, S->d_slot_off, S->slot_total,
                            ctx->cfg.ini_th_fast, ctx->cfg.min_th_fast, S->fast_rows, S->d_slots, S->d_counts);
-    HIP_TRY(ctx, hipEventRecord(S->ev[7], st));
+    ORB_EV(S->ev[7], st);
     if (getenv("VIDO_DEBUG_SYNC")) {       // debugging aid: the FAST stage alone, then its per-cell counts against the slot capacities
         fprintf(stderr, "[vido] k_fast_strips (%d strips x %d frames, lds %zu)...\n", S->n_strips, nf, S->fast_lds);
         hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[vido] k_fast_strips: %s\n", hipGetErrorString(e));
@@ -1294,10 +1384,12 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     }
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, S->d_counts, S->n_cells * nf, S->d_offsets, S->n_cells, nf, L, S->d_first_cell, S->d_lvloff);
     hipLaunchKernelGGL(k_gather_cands, dim3(S->n_cells, nf), dim3(64), 0, st, S->d_slots, S->d_counts, S->d_offsets, S->d_slot_off, S->slot_total, S->n_cells, S->d_cand, (int)S->cand_cap);
-    HIP_TRY(ctx, hipEventRecord(S->ev[2], st));
+    ORB_EV(S->ev[2], st);
     // the blur only needs the pyramid: it runs on the second stream, concurrently with the quadtree and the keypoint list kernels (512 latency-bound
     // workgroups that leave most CUs idle; forking before FAST just makes the two full-GPU kernels contend), and joins before orientation + rBRIEF
-    if (with_desc) {
+    if (with_desc && lean)
+        hipLaunchKernelGGL(k_blur7, dim3(S->n_blur_tiles, nf), dim3(256), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_btiles);      // (11 us on the way; a fork / join costs four more stream operations)
+    else if (with_desc) {
         HIP_TRY(ctx, hipEventRecord(S->ev_pyr, st));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, S->ev_pyr, 0));
         HIP_TRY(ctx, hipEventRecord(S->ev[3], ctx->stream2));
@@ -1316,9 +1408,9 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     hipLaunchKernelGGL(k_kp_write, dim3(n_tasks), dim3(256), 0, st, S->d_cand, S->d_lvloff, S->d_sel, S->d_selcnt, S->d_kpoff, S->qcap, L, S->d_kp, (int)S->kp_cap,
                        S->d_kpf, S->row_cap, S->d_nkp, S->kpl);
     DBG_SYNC("k_kp_write");
-    HIP_TRY(ctx, hipEventRecord(S->ev_qt, st));
-    if (with_desc) HIP_TRY(ctx, hipStreamWaitEvent(st, S->ev[4], 0));
-    HIP_TRY(ctx, hipEventRecord(S->ev[5], st));
+    ORB_EV(S->ev_qt, st);
+    if (with_desc && !lean) HIP_TRY(ctx, hipStreamWaitEvent(st, S->ev[4], 0));
+    ORB_EV(S->ev[5], st);
     {   // launch bound: every (frame, level) list holds at most budget + 3 nodes; the kernel reads the real counts from d_frame_beg.
         // Two launches (first / second half of the frames): the rows of the first half are already on their way to the host (second stream)
         // while the second half is being computed.
@@ -1333,7 +1425,8 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
         S->half_frames = fh < nf ? fh : 0;
     }
     DBG_SYNC("k_orient_brief");
-    HIP_TRY(ctx, hipEventRecord(S->ev[6], st));
+    ORB_EV(S->ev[6], st);
+    S->lean_last = lean;
     S->last_frames = nf;
     return VIDO_OK;
 }
@@ -1368,6 +1461,11 @@ int orb_collect(vido_ctx* ctx, int nf, int copy)
         HIP_TRY(ctx, hipStreamSynchronize(st));
     }
     float ms;
+    if (S->lean_last) {      // (no stage events on the lean single-frame path)
+        for (int i = 0; i < 5; i++) S->timing[i] = 0; S->timing[6] = 0; S->timing[7] = (float)S->h_lvloff[nf * L];
+        S->timing[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S->t_start).count();
+        return VIDO_OK;
+    }
     hipEventElapsedTime(&ms, S->ev[0], S->ev[1]); S->timing[0] = ms;
     hipEventElapsedTime(&ms, S->ev[1], S->ev[7]); S->timing[1] = ms;
     hipEventElapsedTime(&ms, S->ev[7], S->ev[2]); S->timing[6] = ms;
