@@ -1355,7 +1355,8 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     else for (int f = 0; f < nf; f++)
         HIP_TRY(ctx, hipMemcpy2DAsync(S->d_pyr + (size_t)f * S->slab + S->lv[0].off, S->lv[0].pitch, imgs + (size_t)f * frame_stride, stride,
                                       width, height, hipMemcpyHostToDevice, st));
-    if (lean && S->n_bands)
+    static const int bands_mode = [] { const char* e = getenv("VIDO_ORB_BANDS"); return e ? atoi(e) : -1; }();      // experiment switch: 1 = the band pyramid for every batch size, 0 = never
+    if (S->n_bands && (bands_mode == 1 || (bands_mode != 0 && lean)))
         hipLaunchKernelGGL(k_pyramid_bands, dim3(S->n_bands, nf), dim3(256), S->bands_lds, st, S->d_pyr, S->slab, S->band_lv, (const PyrBand*)S->d_bands, (const int2*)S->d_xtab, (const int4*)S->d_ytab);
     else for (int l = 1; l < L; l++) {
         const LevelInfo &s = S->lv[l - 1], &d = S->lv[l];
