@@ -307,6 +307,19 @@ int vido_deconv4s2_depthwise(vido_ctx* ctx, const float* x, const float* weight,
  * (vido_slam_amd/nets/ops.py::pack_conv1x1).  slope: 0 = ReLU, 1 = none.  vido_conv1x1_supported: cout % 128 == 0, cin % 32 == 0, hw % 4 == 0, hw >= 128. */
 int vido_conv1x1_supported(int cin, int cout, int hw);
 int vido_conv1x1_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, int hw, float slope);
+
+/* 3x3 stride-1 padding-1 convolution + bias + leaky-ReLU as Winograd F(2x2, 3x3) with its sixteen channel contractions on the fp32 matrix pipe (csrc/wino.hip): the
+ * dense 3x3 convolutions of LiteFlowNet (flow_net/src/layers.py:39-315), the FPN output / RPN head / mask head convolutions of the detector
+ * (maskrcnn_benchmark/modeling/backbone/fpn.py, rpn/rpn.py:74-107, roi_heads/mask_head/roi_mask_feature_extractors.py) — what the library runs as a vector-ALU Winograd
+ * kernel followed by a bias + activation pass.  x [n][cin][h][w], y [n][cout][h][w] f32 DEVICE tensors (y != x), bias [cout] or NULL, slope 0 = ReLU, 1 = none.
+ * u_packed: vido_wino3x3_pack(w) copied to the device (16-byte aligned), vido_wino3x3_packed_floats(cin, cout) floats.  vido_wino3x3_pack runs on the HOST:
+ * w [cout][cin][3][3] -> U = G g G^T in float64, rounded once, in the kernel's operand order.  vido_wino3x3_supported: cin >= 8, cout >= 32, h, w >= 2, tensors < 1 GB.
+ * The result differs from a direct fp32 convolution by rounding only (the class of the library's own Winograd kernels).  Enqueues on the adopted stream; capturable. */
+int vido_wino3x3_supported(int cin, int cout, int h, int w);
+int vido_wino3x3_fills_chip(int n, int cout, int h, int w, int min_wgs);   /* 1 when the launch has >= min_wgs (0: 128) workgroups: below that the library's kernels win */
+long long vido_wino3x3_packed_floats(int cin, int cout);
+int vido_wino3x3_pack(const float* w, int cin, int cout, float* u_packed);
+int vido_wino3x3_bias_act(vido_ctx* ctx, const float* x, const float* u_packed, const float* bias, float* y, int n, int cin, int cout, int h, int w, float slope);
 int vido_gconv3x3_supported(int H, int W, int cpg_in, int cpg_out);
 int64_t vido_gconv3x3_packed_size(int groups, int cpg_in, int cpg_out);
 int vido_gconv3x3_bias_act(vido_ctx* ctx, const float* x, const float* in_bias, const float* w_packed, const float* bias, float* y, int groups, int cpg_in, int cpg_out, int H, int W, float slope);

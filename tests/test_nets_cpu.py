@@ -143,3 +143,35 @@ def test_pack_conv1x1_is_the_operand_order_of_the_kernel():
             co, k = (int(torch.randint(0, n, (1,), generator=g)) for n in (cout, cin))
             assert float(p[co // 32, k // 32, 32 * (k & 1) + co % 32, (k % 32) // 2]) == float(w[co, k, 0, 0])
     assert pack_conv1x1(torch.zeros(64, 32, 1, 1)) is None and pack_conv1x1(torch.zeros(128, 48, 1, 1)) is None and pack_conv1x1(torch.zeros(128, 32, 3, 3)) is None
+
+
+def test_pack_wino3x3_operands_reproduce_the_convolution():
+    """vido_wino3x3_pack (host side of csrc/wino.hip): U = G g G^T in the kernel's operand order.  A numpy walk of the kernel's own data path — V = B^T d B of the zero-padded
+    4x4 windows, M_p[co][tile] = sum_c U_p[co][c] V_p[c][tile] with U_p[co][c] read from [co / 32][c / KC][p][32 * (c & 1) + co % 32][(c % KC) / 2], Y = A^T M A — must be
+    the padded 3x3 cross-correlation (float64 reference), for both chunk sizes (KC = 8: 64-channel workgroups; KC = 4: 32-channel ones), ragged channel counts and odd maps."""
+    import torch.nn.functional as F
+    from vido_slam_amd.nets.ops import pack_wino3x3
+    g = torch.Generator().manual_seed(11)
+    Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+    At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+    for cout, cin, H, W in ((64, 9, 6, 8), (32, 13, 5, 7), (96, 8, 4, 4), (130, 17, 3, 6)):
+        w = torch.randn(cout, cin, 3, 3, generator=g); x = torch.randn(1, cin, H, W, generator=g)
+        up = pack_wino3x3(w)
+        kc = 8 if (((cout + 63) // 64) * 64 - cout) < 32 else 4
+        assert up.shape[1:] == (-(-cin // kc), 16, 64, kc // 2) and up.shape[0] * 32 >= cout and up.is_contiguous()
+        U = np.zeros((16, up.shape[0] * 32, up.shape[1] * kc))
+        for co in range(U.shape[1]):
+            for c in range(U.shape[2]):
+                U[:, co, c] = up[co // 32, c // kc, :, 32 * (c & 1) + co % 32, (c % kc) // 2].numpy()
+        assert np.all(U[:, cout:] == 0) and np.all(U[:, :, cin:] == 0)                      # padded channels carry zero weights
+        Ht, Wt = (H + 1) // 2, (W + 1) // 2
+        xp = np.zeros((U.shape[2], 2 * Ht + 2, 2 * Wt + 2)); xp[:cin, 1:H + 1, 1:W + 1] = x[0].double().numpy()
+        y = np.zeros((cout, 2 * Ht, 2 * Wt))
+        for ty in range(Ht):
+            for tx in range(Wt):
+                d = xp[:, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]
+                V = np.einsum("ij,cjk,lk->cil", Bt, d, Bt).reshape(-1, 16)                   # [c][p]
+                M = np.einsum("poc,cp->op", U, V)[:cout].reshape(cout, 4, 4)
+                y[:, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum("ij,ojk,lk->oil", At, M, At)
+        ref = F.conv2d(x.double(), w.double(), None, 1, 1)[0].numpy()
+        assert np.abs(y[:, :H, :W] - ref).max() < 1e-5 * max(1.0, np.abs(ref).max())

@@ -2,6 +2,7 @@
 written table-first: every stage is described by a row of LEVELS and built by small factories.  Parameter names
 match the reference module tree (netFeatures.netOne.0.weight, netMatching.0.netMain.6.bias, ...)."""
 import math
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -18,6 +19,7 @@ class _Chain(nn.Sequential):
     Conv2d runs without its bias and the bias add + the following LeakyReLU become one in-place HIP pass."""
     epilogue = None
     epilogue_res = None                    # HipOps.bias_res_act_: the chain's last bias add fused with the residual the caller adds (flow + netMain(...), layers.py:160, 199)
+    wino = None                            # HipOps: dense 3x3 stride-1 convolutions + bias + LeakyReLU as ONE Winograd launch on the matrix pipe (csrc/wino.hip)
 
     def forward(self, x, residual=None):
         mods = list(self)
@@ -25,8 +27,13 @@ class _Chain(nn.Sequential):
         while i < len(mods):
             m = mods[i]
             if self.epilogue is not None and isinstance(m, nn.Conv2d) and x.is_cuda and m.bias is not None:
-                x = F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
                 act = i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU)
+                if self.wino is not None and (act or i + 1 >= len(mods)):
+                    y = self.wino.wino3x3_conv(m, x, LEAK if act else 1.0)
+                    if y is not None:
+                        x = y; i += 2 if act else 1
+                        continue
+                x = F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
                 last = i + (2 if act else 1) >= len(mods)
                 if last and residual is not None and self.epilogue_res is not None and not act:
                     x = self.epilogue_res(x.contiguous(), m.bias, residual.contiguous(), 1.0); residual = None
@@ -161,9 +168,11 @@ class LiteFlowNet(nn.Module):
         self.netRegularization = nn.ModuleList([_Regularization(l) for l in (2, 3, 4, 5, 6)])
         if epilogue is not None:
             res = getattr(getattr(epilogue, "__self__", None), "bias_res_act_", None)      # the residual form of the same HipOps object
+            hip = getattr(epilogue, "__self__", None)
+            wino = hip if hasattr(hip, "wino3x3_conv") and not os.environ.get("VIDO_NO_WINO") else None
             for m in self.modules():
                 if isinstance(m, _Chain):
-                    m.epilogue = epilogue; m.epilogue_res = res
+                    m.epilogue = epilogue; m.epilogue_res = res; m.wino = wino
         if warp is not None:
             for m in self.modules():
                 if isinstance(m, (_Matching, _Subpixel, _Regularization)):

@@ -6,6 +6,7 @@ rpn.anchor_generator.cell_anchors.0, roi_heads.mask.predictor.conv5_mask.bias ..
 ROI-Align, NMS and box decoding go through `ops` (HipOps: the HIP kernels of libvido_slam_hip.so); there is no CPU path
 in the product — the CPU tests inject oracle-backed ops."""
 import math
+import os
 from collections import OrderedDict
 from dataclasses import dataclass
 import numpy as np
@@ -148,12 +149,22 @@ class _FPN(nn.Module):                     # fpn.py:7-82 with LastLevelMaxPool
             setattr(self, "fpn_inner%d" % i, nn.Conv2d(c.res2_out * 2 ** (i - 1), c.fpn_out, 1))
             setattr(self, "fpn_layer%d" % i, nn.Conv2d(c.fpn_out, c.fpn_out, 3, 1, 1))
 
+    _ops = None                            # MaskRCNN.__init__: HipOps — the output convolutions as Winograd launches on the matrix pipe (csrc/wino.hip)
+
+    def _layer(self, i, x):
+        conv = getattr(self, "fpn_layer%d" % i)
+        if self._ops is not None and x.is_cuda and hasattr(self._ops, "wino3x3_conv") and not os.environ.get("VIDO_NO_WINO"):
+            y = self._ops.wino3x3_conv(conv, x, 1.0)
+            if y is not None:
+                return y
+        return conv(x)
+
     def forward(self, feats):
         inner = getattr(self, "fpn_inner%d" % self.n)(feats[-1])
-        out = [getattr(self, "fpn_layer%d" % self.n)(inner)]
+        out = [self._layer(self.n, inner)]
         for i in range(self.n - 1, 0, -1):
             inner = getattr(self, "fpn_inner%d" % i)(feats[i - 1]) + F.interpolate(inner, scale_factor=2, mode="nearest")
-            out.insert(0, getattr(self, "fpn_layer%d" % i)(inner))
+            out.insert(0, self._layer(i, inner))
         out.append(F.max_pool2d(out[-1], 1, 2, 0))
         return out
 
@@ -212,6 +223,10 @@ def _conv_bias_relu(conv, x, ops):
     """relu(conv(x)); on the device the library convolution runs without its bias and the bias + ReLU are ONE in-place pass (vido_bias_act) instead of an add and a clamp."""
     if ops is None or not x.is_cuda or conv.bias is None:
         return F.relu(conv(x))
+    if isinstance(conv, nn.Conv2d) and hasattr(ops, "wino3x3_conv") and not os.environ.get("VIDO_NO_WINO"):
+        y = ops.wino3x3_conv(conv, x, 0.0)              # dense 3x3: Winograd on the matrix pipe with bias + ReLU in its epilogue (csrc/wino.hip)
+        if y is not None:
+            return y
     if isinstance(conv, nn.ConvTranspose2d):
         y = F.conv_transpose2d(x, conv.weight, None, conv.stride, conv.padding, conv.output_padding, conv.groups, conv.dilation)
     else:
@@ -580,7 +595,7 @@ class MaskRCNN(nn.Module):
         self.rpn = _RPN(c, ops)
         self.roi_heads = _RoiHeads(c, ops)
         for m in self.modules():
-            if isinstance(m, (_RPNHead, _MaskPredictor)):
+            if isinstance(m, (_RPNHead, _MaskPredictor, _FPN)):
                 m._ops = ops if hasattr(ops, "bias_act_") else None
 
     @torch.no_grad()

@@ -2,7 +2,10 @@
 (on_device=1); the ctx adopts torch's current stream (vido_set_stream) so launches are ordered with the
 surrounding torch kernels without any synchronisation."""
 import ctypes as C
+import os
 import torch
+
+_WINO_MIN_WGS = int(os.environ.get("VIDO_WINO_MIN_WGS", "0"))
 
 
 def correlation_torch_reference(first, second, stride):
@@ -144,6 +147,38 @@ class HipOps:
         self.ctx._check(self.ctx.lib.vido_conv1x1_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(w_packed.data_ptr()), C.c_void_p(bias.data_ptr()) if bias is not None else None,
                                                            C.c_void_p(residual.data_ptr()) if residual is not None else None, C.c_void_p(out.data_ptr()), int(cin), int(cout), int(H * W), C.c_float(slope)))
         return out
+
+    def wino3x3_supported(self, cin, cout, H, W):
+        return bool(self.ctx.lib.vido_wino3x3_supported(int(cin), int(cout), int(H), int(W)))
+
+    def wino3x3_bias_act(self, x, u_packed, bias, cout, slope=1.0):
+        """leaky_relu(conv2d(x, w, None, 1, 1) + bias, slope) for a batch, 3x3 kernel, as one Winograd launch whose channel contractions run on the matrix pipe (csrc/wino.hip);
+        u_packed = pack_wino3x3(w) on x's device.  slope 0 = ReLU, 1 = none."""
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and u_packed.is_cuda
+        N, cin, H, W = x.shape
+        out = torch.empty((N, cout, H, W), device=x.device, dtype=torch.float32)
+        self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * N * cout * cin * 9 * H * W      # direct-convolution count, as FlopCounterMode would give the library call
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_wino3x3_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(u_packed.data_ptr()), C.c_void_p(bias.data_ptr()) if bias is not None else None,
+                                                           C.c_void_p(out.data_ptr()), int(N), int(cin), int(cout), int(H), int(W), C.c_float(slope)))
+        return out
+
+    def wino3x3_conv(self, conv, x, slope, weight=None, bias=None):
+        """The convolution `conv` (nn.Conv2d, or the folded weight / bias given) + bias + activation through wino3x3_bias_act when the layer has that form, else None.  The
+        packed weight is cached on the module and rebuilt when the weight tensor changes (a checkpoint loaded later)."""
+        w = conv.weight if weight is None else weight
+        b = conv.bias if bias is None and weight is None else bias
+        if (tuple(w.shape[2:]) != (3, 3) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (1, 1) or tuple(conv.dilation) != (1, 1) or conv.groups != 1
+                or getattr(conv, "padding_mode", "zeros") != "zeros" or not x.is_cuda or not self.wino3x3_supported(w.shape[1], w.shape[0], x.shape[2], x.shape[3])
+                or 4 * x.numel() >= 1 << 30 or 4 * x.shape[0] * w.shape[0] * x.shape[2] * x.shape[3] >= 1 << 30):
+            return None
+        # a launch of a few dozen workgroups (small maps) runs as long as a chip-filling one: the library's kernels win there (VIDO_WINO_MIN_WGS, default 128 = half the CUs)
+        if not self.ctx.lib.vido_wino3x3_fills_chip(int(x.shape[0]), int(w.shape[0]), int(x.shape[2]), int(x.shape[3]), _WINO_MIN_WGS):
+            return None
+        key = (w.data_ptr(), w._version, str(x.device))
+        if getattr(conv, "_wino_key", None) != key:
+            conv._wino_u = pack_wino3x3(w).to(x.device); conv._wino_key = key
+        return self.wino3x3_bias_act(x.contiguous(), conv._wino_u, b, int(w.shape[0]), slope)
 
     def lfn_reg_front(self, im1, im2, flow, scale, feat):
         """Regularization.forward up to netMain's input (layers.py:236-243): torch.cat([sqrt(sum((im1 - Backward(im2, flow * scale))^2)), flow - mean(flow), feat], 1) with the
@@ -363,3 +398,24 @@ def pack_gconv3x3(w, groups):
         return w9.reshape(groups, cpg_out // 32, 32, cpg_in // 8, 8, 9).permute(0, 1, 3, 5, 4, 2).contiguous()
     pad = w9.new_zeros((groups, 16, cpg_in // 8, 8, 9)); pad[:, :cpg_out] = w9
     return pad.permute(0, 2, 4, 3, 1).contiguous()
+
+
+def pack_wino3x3(w):
+    """3x3 convolution weight [cout, cin, 3, 3] -> U = G g G^T (float64, rounded once) in the operand order of csrc/wino.hip, as a CPU tensor
+    [cout_pad / 32, cin_pad / KC, 16, 64, KC / 2] (the library's vido_wino3x3_pack: ONE implementation of the layout, also what a C caller uses)."""
+    import numpy as np
+    from ..host import load_library
+    lib = load_library()
+    lib.vido_wino3x3_packed_floats.restype = C.c_longlong
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    assert tuple(w.shape[2:]) == (3, 3)
+    wh = np.ascontiguousarray(w.detach().to("cpu", torch.float32).numpy())
+    n = int(lib.vido_wino3x3_packed_floats(cin, cout))
+    out = np.empty(n, np.float32)
+    rc = lib.vido_wino3x3_pack(C.c_void_p(wh.ctypes.data), cin, cout, C.c_void_p(out.ctypes.data))
+    if rc != 0:
+        raise RuntimeError("vido_wino3x3_pack: %d" % rc)
+    kc = 8 if (((cout + 63) // 64) * 64 - cout) < 32 else 4
+    cop = ((cout + 63) // 64) * 64 if kc == 8 else ((cout + 31) // 32) * 32
+    cip = ((cin + kc - 1) // kc) * kc
+    return torch.from_numpy(out).reshape(cop // 32, cip // kc, 16, 64, kc // 2)
