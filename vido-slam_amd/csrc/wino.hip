@@ -30,9 +30,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define WN_OOB 0x40000000u
-struct WnArgs { const float* x; const float* up; const float* bias; float* y; int N, Cin, Cout, H, W, Ht, Wt, T, nchunk, cgroups, total; float slope; int vec2; unsigned xbytes, ubytes; };
+#ifndef WN_ABLATE
+#define WN_ABLATE 0          // timing experiments (tools/ubench/wino_ablate.hip): 1 no transform, 2 no window loads, 4 no U copies, 8 no barrier, 16 no operand reads
+#endif
+struct WnArgs { const float* x; const float* up; const float* bias; float* y; int N, Cin, Cout, H, W, Ht, Wt, T, nchunk, cgroups, total; float slope; int vec2; unsigned xbytes, ubytes; unsigned long long* prof; };
 
-template <int CW, int TW, int KC>
+template <int CW, int TW, int KC, bool ODD>
 __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
 {
     static_assert(CW * TW == 4 && (KC == 8 || KC == 4), "workgroup = 4 waves");
@@ -42,66 +45,84 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
     constexpr int NJ = TW * KS / 4;                   // (channel, tile) pairs a thread transforms per chunk
     constexpr int KSTEP = 4 / TW;
     constexpr int PPB = U_BLK * 4 / 1024;             // 1 KB copy pieces per U block
+    static_assert(NJ == 2, "the slices below are written for two pairs per thread");
     extern __shared__ __attribute__((aligned(16))) float wn_lds[];      // [2][U_BUF] [2][V_BUF]
     float* Ul = wn_lds; float* Vl = wn_lds + 2 * U_BUF;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // Measured on this chip (tools/ubench/mfma_fillers*.hip): beside v_mfma_f32_32x32x2f32 EVERY vector-ALU instruction of the same wave costs ~5.5 cycles of matrix time
+    // (add, move, integer, packed alike — nothing hides), a buffer load with a 32-bit offset ~1.5, a 1 KB global -> LDS copy ~4, LDS reads < 1.  So the loop below keeps
+    // vector instructions to the transform itself (packed: two adds per instruction) and does all addressing with SCALAR registers: the wave index is made scalar here,
+    // per-lane byte offsets are loop invariants, everything that changes with the chunk rides in the loads' scalar offset.
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int per = gridDim.x >> 3, item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (item >= A.total) return;
     const int tb = item / A.cgroups, cg = item - tb * A.cgroups, tile0 = tb * (TW * 32);
     const int hw = A.H * A.W, tpi = A.Ht * A.Wt;
 
     // ---- transform role: tile block tw_t, k-pairs ks0 + j * KSTEP; lane = (tile & 31) + 32 * (channel & 1) = the operand slot it fills.
-    // Input windows are read with BUFFER loads: an element outside the image (zero padding), of a tile past the end or of a channel >= Cin gets a byte offset with bit 30
-    // set, which is past the descriptor's range (the tensor is < 1 GB) — the hardware returns 0, no select.
+    // Input windows are read with BUFFER loads: voff[e] = byte offset of window element e of channel (lane >> 5) of the tile's image; the k-pair's channel base is the
+    // scalar offset.  An element outside the image (zero padding) or of a tile past the end has bit 30 set in voff — past the descriptor's range (the tensor is < 1 GB):
+    // the hardware returns 0, no select.  A k-pair past Cin reads through a descriptor of size 0 (all zeros); the odd channel past an odd Cin (ODD) gets bit 30 per lane.
     const int tw_t = w % TW, ks0 = w / TW;
-    unsigned rowo[4], colo[4];
+    unsigned voff[16];
     {
         const int gt = tile0 + tw_t * 32 + (lane & 31), gtc = min(gt, A.T - 1);
         const int n = gtc / tpi, rem = gtc - n * tpi, ty = rem / A.Wt, tx = rem - ty * A.Wt;
+        unsigned rowo[4], colo[4];
 #pragma unroll
         for (int d = 0; d < 4; d++) {
             const int iy = 2 * ty - 1 + d, ix = 2 * tx - 1 + d;
-            rowo[d] = (gt < A.T && iy >= 0 && iy < A.H) ? 4u * ((unsigned)n * (unsigned)A.Cin * (unsigned)hw + (unsigned)(iy * A.W)) : WN_OOB;
+            rowo[d] = (gt < A.T && iy >= 0 && iy < A.H) ? 4u * (((unsigned)n * (unsigned)A.Cin + (unsigned)(lane >> 5)) * (unsigned)hw + (unsigned)(iy * A.W)) : WN_OOB;
             colo[d] = (ix >= 0 && ix < A.W) ? 4u * (unsigned)ix : WN_OOB;
         }
-    }
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.x, 0, A.xbytes, 0x00020000);
-    float in[NJ][16];
-    // V = B^T d B of pair j in two steps the main loop spreads over its slices: rows (r = B^T d: the window registers are dead afterwards), then output row i -> LDS
-    float r[16];
-    auto xf_rows = [&](int j) {
-        const float* d = in[j];
 #pragma unroll
-        for (int x = 0; x < 4; x++) { r[x] = d[x] - d[8 + x]; r[4 + x] = d[4 + x] + d[8 + x]; r[8 + x] = d[8 + x] - d[4 + x]; r[12 + x] = d[4 + x] - d[12 + x]; }
+        for (int e = 0; e < 16; e++) voff[e] = rowo[e >> 2] + colo[e & 3];
+    }
+    const unsigned par_oob = (lane >> 5) ? WN_OOB : 0u;
+    f32x2 inp[NJ][8];                                                    // window of pair j: inp[j][2 * row + half] = columns (2 half, 2 half + 1)
+    auto load_win = [&](int chunk, int j, int e0, int e1) {              // window elements [e0, e1) of pair j of `chunk`
+        const int cb = chunk * KC + 2 * (ks0 + j * KSTEP);               // (scalar) first channel of the k-pair
+        const bool any = cb < A.Cin;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.x, 0, any ? A.xbytes : 0u, 0x00020000);
+        const unsigned so = any ? 4u * (unsigned)cb * (unsigned)hw : 0u;
+        const unsigned extra = (ODD && cb == A.Cin - 1) ? par_oob : 0u;
+#pragma unroll
+        for (int e = e0; e < e1; e++)
+            inp[j][e >> 1][e & 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ODD ? voff[e] + extra : voff[e], so, 0));
+    };
+    // V = B^T d B of pair j in two steps: rows (R = B^T d, packed over column pairs: the window registers are dead afterwards), then output row i -> LDS.  The column
+    // step mixes the halves of a register pair: (v0, v1) = (r0 - r2, r1 + r2), (v2, v3) = (r2 - r1, r1 - r3) are ONE packed add each through the operand selects /
+    // negations of v_pk_add_f32 (the compiler turns the same expression into moves and xors).
+    f32x2 R[NJ][8];
+    auto xf_rows = [&](int j) {
+        const f32x2* D = inp[j];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {                                    // (asm: left to itself the compiler splits these into single adds)
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(R[j][h]) : "v"(D[h]), "v"(D[4 + h]));
+            asm("v_pk_add_f32 %0, %1, %2" : "=v"(R[j][2 + h]) : "v"(D[2 + h]), "v"(D[4 + h]));
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(R[j][4 + h]) : "v"(D[4 + h]), "v"(D[2 + h]));
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(R[j][6 + h]) : "v"(D[2 + h]), "v"(D[6 + h]));
+        }
     };
     auto xf_out = [&](int j, int i, int buf) {
+        f32x2 v01, v23;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(v01) : "v"(R[j][2 * i]), "v"(R[j][2 * i + 1]));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(v23) : "v"(R[j][2 * i]), "v"(R[j][2 * i + 1]));
         float* dst = Vl + buf * V_BUF + (tw_t * KS + ks0 + j * KSTEP) * 64 + lane;
-        dst[(4 * i + 0) * V_P] = r[4 * i] - r[4 * i + 2];
-        dst[(4 * i + 1) * V_P] = r[4 * i + 1] + r[4 * i + 2];
-        dst[(4 * i + 2) * V_P] = r[4 * i + 2] - r[4 * i + 1];
-        dst[(4 * i + 3) * V_P] = r[4 * i + 1] - r[4 * i + 3];
+        dst[(4 * i + 0) * V_P] = v01.x; dst[(4 * i + 1) * V_P] = v01.y; dst[(4 * i + 2) * V_P] = v23.x; dst[(4 * i + 3) * V_P] = v23.y;
     };
-    auto load_rows = [&](int chunk, int j, int dy0) {                     // window rows dy0, dy0 + 1 of pair j of `chunk`
-        const int c = chunk * KC + 2 * (ks0 + j * KSTEP) + (lane >> 5);
-        const unsigned cb = c < A.Cin ? 4u * (unsigned)c * (unsigned)hw : WN_OOB;
-#pragma unroll
-        for (int dy = dy0; dy < dy0 + 2; dy++) {
-            const unsigned rb = rowo[dy] + cb;
-#pragma unroll
-            for (int dx = 0; dx < 4; dx++) in[j][4 * dy + dx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, rb + colo[dx], 0, 0));
-        }
-    };
-    // U pieces travel global -> LDS as BUFFER loads with the lds bit (16 bytes per lane): unlike the flat-encoded global_load_lds they keep the compiler's vmcnt bookkeeping
-    // in order (a pending flat LDS access makes it fall back to vmcnt(0) / lgkmcnt(0) in front of every later use of any loaded register)
+    // U pieces travel global -> LDS as BUFFER loads with the lds bit (16 bytes per lane; the flat-encoded global_load_lds makes the compiler fall back to vmcnt(0) /
+    // lgkmcnt(0) in front of every later use of any loaded register): per-lane offset 16 * lane, everything else scalar
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)A.up, 0, A.ubytes, 0x00020000);
-    auto issue_u = [&](int chunk, int buf) {                             // wave w moves pieces w, w + 4, ... of the CW blocks of this chunk
+    const unsigned uvo = 16u * (unsigned)lane;
+    auto issue_u = [&](int chunk, int buf, int first, int count) {        // wave w moves pieces w, w + 4, ... of the CW blocks of this chunk: `count` of them from `first`
 #pragma unroll
-        for (int i0 = 0; i0 < CW * PPB; i0 += 4) {
-            const int i = i0 + w, cwi = i / PPB, pi = i - cwi * PPB;
-            const unsigned src = 4u * (unsigned)(((cg * CW + cwi) * A.nchunk + chunk) * U_BLK + pi * 256 + lane * 4);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void*)(Ul + buf * U_BUF + cwi * U_BLK + pi * 256), 16, src, 0, 0, 0);
+        for (int q = first; q < first + count; q++) {
+            const int i = 4 * q + w, cwi = i / PPB, pi = i - cwi * PPB;
+            const unsigned so = 4u * (unsigned)(((cg * CW + cwi) * A.nchunk + chunk) * U_BLK + pi * 256);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void*)(Ul + buf * U_BUF + cwi * U_BLK + pi * 256), 16, uvo, so, 0, 0);
         }
     };
+    constexpr int NPW = CW * PPB / 4;                                    // pieces per wave and chunk
 
     // ---- matrix role: channel block cw, tile block tw
     const int cw = w % CW, tw = w / CW;
@@ -111,21 +132,28 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[p][q] = 0.f;
 
-    static_assert(NJ == 2, "the slices below are written for two pairs per thread");
-    load_rows(0, 0, 0); load_rows(0, 0, 2); load_rows(0, 1, 0); load_rows(0, 1, 2);
-    issue_u(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    load_win(0, 0, 0, 16); load_win(0, 1, 0, 16);
+    issue_u(0, 0, 0, NPW);
+    xf_rows(0); xf_rows(1);
+    load_win(1, 0, 0, 16); load_win(1, 1, 0, 16);
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        xf_rows(j);
+    for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int i = 0; i < 4; i++) xf_out(j, i, 0);
-    }
-    load_rows(1, 0, 0); load_rows(1, 0, 2); load_rows(1, 1, 0); load_rows(1, 1, 2);
     typedef float uvec __attribute__((ext_vector_type(KS)));
+#ifdef WN_PROF
+    unsigned long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // (debug build: shader-clock stamps of the LAST chunk: loop top, after the barrier, after each slice)
+#define WN_STAMP(k) asm volatile("s_memtime %0" : "=s"(ts[k]))
+#else
+#define WN_STAMP(k) do { } while (0)
+#endif
     for (int c = 0; c < A.nchunk; c++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                                 // U(c), V(c) are in buffer c & 1; everybody is done with buffer (c + 1) & 1
+        WN_STAMP(0);
+        if (!(WN_ABLATE & 8)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                             // U(c), V(c) are in buffer c & 1; everybody is done with buffer (c + 1) & 1
+        }
+        WN_STAMP(1);
         const int nb = (c + 1) & 1;
         const float* Ub = Ul + (c & 1) * U_BUF + cw * U_BLK + lane * KS;
         const float* Vb = Vl + (c & 1) * V_BUF + tw * KS * 64 + lane;
@@ -138,23 +166,27 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
                 for (int ks = 0; ks < KS; ks++) vb[g % 3][q][ks] = Vb[(2 * g + q) * V_P + ks * 64];
             }
         };
-        ldops(0); ldops(1);
-        // Eight slices of 2 KS matrix instructions (positions 2 g, 2 g + 1), operands requested two slices ahead; the next chunk's transform and the window loads of the
-        // chunk after it are dealt over the slices by hand and run in the matrix pipe's shadow (left alone the scheduler puts all ~200 vector instructions in front of
-        // 64 back-to-back matrix instructions, and fetches every operand pair right before its use)
+        ldops(0); ldops(1);                                              // (with WN_ABLATE & 16 these stay the only operand reads of the chunk)
+        // Eight slices of 2 KS matrix instructions (positions 2 g, 2 g + 1), operands requested two slices ahead.  The side work of the chunk is dealt over the slices by
+        // hand: slice 0 takes the row step of BOTH pairs (the only reads of window registers: whatever wait the compiler puts in front of them finds loads that are at
+        // least three slices old), slices 1-4 refill the windows (chunk c + 2; past the end they read zeros) EIGHT loads at a time — 32 gathers issued at once by four
+        // waves fill the address unit's queue and the slice that issues them takes 1800 cycles instead of 512 (shader-clock stamps, tools/ubench/wino_ablate.hip) — and
+        // finish the transform of chunk c + 1 into the other V buffer, slices 5-6 send for the next U block (past the last chunk: the last block again, into the
+        // buffer nobody reads any more).
+#define WN_XF(...) do { if (!(WN_ABLATE & 1)) { __VA_ARGS__; } } while (0)
+#define WN_LD(...) do { if (!(WN_ABLATE & 2)) { __VA_ARGS__; } } while (0)
 #pragma unroll
         for (int g = 0; g < 8; g++) {
             __builtin_amdgcn_sched_barrier(0);
-            if (g + 2 < 8) ldops(g + 2);
-            if (g == 0) { xf_rows(0); xf_out(0, 0, nb); }
-            if (g == 1) { xf_out(0, 1, nb); xf_out(0, 2, nb); load_rows(c + 2, 0, 0); }
-            if (g == 2) { xf_out(0, 3, nb); load_rows(c + 2, 0, 2); }
-            // (the copy of the next U block goes out only after the last read of window registers loaded an iteration ago: the wait the compiler puts in front of that
-            //  read is vmcnt(0) and would otherwise wait for the copy as well.  Past the last chunk the copy repeats the last block into the buffer nobody reads again
-            //  and the window loads return zeros: channel >= Cin)
-            if (g == 3) { xf_rows(1); xf_out(1, 0, nb); issue_u(min(c + 1, A.nchunk - 1), nb); }
-            if (g == 4) { xf_out(1, 1, nb); xf_out(1, 2, nb); load_rows(c + 2, 1, 0); }
-            if (g == 5) { xf_out(1, 3, nb); load_rows(c + 2, 1, 2); }
+            if (g + 2 < 8 && !(WN_ABLATE & 16)) ldops(g + 2);
+            if (g == 0) { WN_XF(xf_rows(0); xf_rows(1)); }
+            if (g >= 1 && g <= 4) { WN_LD(load_win(c + 2, (g - 1) >> 1, 8 * ((g - 1) & 1), 8 * ((g - 1) & 1) + 8)); }      // eight window loads per slice: one per matrix instruction
+            if (g == 1) { WN_XF(xf_out(0, 0, nb); xf_out(0, 1, nb)); }
+            if (g == 2) { WN_XF(xf_out(0, 2, nb); xf_out(0, 3, nb)); }
+            if (g == 3) { WN_XF(xf_out(1, 0, nb); xf_out(1, 1, nb)); }
+            if (g == 4) { WN_XF(xf_out(1, 2, nb); xf_out(1, 3, nb)); }
+            if (g == 5 && !(WN_ABLATE & 4)) issue_u(min(c + 1, A.nchunk - 1), nb, 0, NPW / 2);
+            if (g == 6 && !(WN_ABLATE & 4)) issue_u(min(c + 1, A.nchunk - 1), nb, NPW / 2, NPW - NPW / 2);
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 acc[2 * g] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[g % 3][0][ks], vb[g % 3][0][ks], acc[2 * g], 0, 0, 0);
@@ -164,13 +196,19 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
             for (int i = 0; i < 2 * KS; i++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
+            if (g < 7) { __builtin_amdgcn_sched_barrier(0); WN_STAMP(2 + g); }
         }
         __builtin_amdgcn_sched_barrier(0);
+        WN_STAMP(9);
     }
+#ifdef WN_PROF
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (A.prof && lane == 0 && (item == 0 || item == A.total / 2)) for (int k = 0; k < 10; k++) A.prof[((item ? 4 : 0) + w) * 10 + k] = ts[k];
+#endif
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // (the last, unused copy and loads)
     // ---- inverse transform Y = A^T M A, bias, activation, store.  D[i][j]: register r of a lane = output channel 8 (r / 4) + 4 (lane >> 5) + (r & 3), tile lane & 31.
@@ -277,17 +315,18 @@ int vido_wino3x3_bias_act(vido_ctx* ctx, const float* x, const float* u_packed, 
         return vido_set_error(ctx, VIDO_E_INVALID, "wino3x3: a batch of %d images of %d x %d x %d is past the 1 GB the kernel addresses", n, cin, h, w);
     const int tb = kc == 8 ? 64 : 128, cgroups = kc == 8 ? (cout + 63) / 64 : (cout + 31) / 32;
     const int nblk = (int)((T + tb - 1) / tb), total = nblk * cgroups;
-    WnArgs A{x, u_packed, bias, y, n, cin, cout, h, w, ht, wt, (int)T, wn_cin_pad(cin, kc) / kc, cgroups, total, slope, (w % 2 == 0 && ((uintptr_t)y & 7) == 0) ? 1 : 0, (unsigned)(4ll * n * cin * h * w), (unsigned)(4ll * vido_wino3x3_packed_floats(cin, cout))};
+    WnArgs A{x, u_packed, bias, y, n, cin, cout, h, w, ht, wt, (int)T, wn_cin_pad(cin, kc) / kc, cgroups, total, slope, (w % 2 == 0 && ((uintptr_t)y & 7) == 0) ? 1 : 0, (unsigned)(4ll * n * cin * h * w), (unsigned)(4ll * vido_wino3x3_packed_floats(cin, cout)), nullptr};
     const dim3 grid(8 * ((total + 7) / 8)), blk(256);
     constexpr size_t LDS8 = (size_t)2 * (2 * 16 * 64 * 4 + 16 * 2 * 4 * 64) * 4, LDS4 = (size_t)2 * (1 * 16 * 64 * 2 + 16 * 4 * 2 * 64) * 4;
     static bool attr[64] = {};
     if (!attr[ctx->device & 63]) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wino3x3<2, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS8));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wino3x3<1, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS4));
+        for (const void* f : {(const void*)k_wino3x3<2, 2, 8, false>, (const void*)k_wino3x3<2, 2, 8, true>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS8));
+        for (const void* f : {(const void*)k_wino3x3<1, 4, 4, false>, (const void*)k_wino3x3<1, 4, 4, true>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS4));
         attr[ctx->device & 63] = true;
     }
-    if (kc == 8) hipLaunchKernelGGL((k_wino3x3<2, 2, 8>), grid, blk, LDS8, st, A);
-    else hipLaunchKernelGGL((k_wino3x3<1, 4, 4>), grid, blk, LDS4, st, A);
+    const bool odd = cin & 1;                                            // (an odd channel count costs 17 vector instructions per window: its last channel pair is half padding)
+    if (kc == 8) { if (odd) hipLaunchKernelGGL((k_wino3x3<2, 2, 8, true>), grid, blk, LDS8, st, A); else hipLaunchKernelGGL((k_wino3x3<2, 2, 8, false>), grid, blk, LDS8, st, A); }
+    else { if (odd) hipLaunchKernelGGL((k_wino3x3<1, 4, 4, true>), grid, blk, LDS4, st, A); else hipLaunchKernelGGL((k_wino3x3<1, 4, 4, false>), grid, blk, LDS4, st, A); }
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }
