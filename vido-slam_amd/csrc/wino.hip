@@ -35,6 +35,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 struct WnArgs { const float* x; const float* up; const float* bias; float* y; int N, Cin, Cout, H, W, Ht, Wt, T, nchunk, cgroups, total; float slope; int vec2; unsigned xbytes, ubytes; unsigned long long* prof; };
 
+// packed fp32 add / subtract of register pairs (asm: the compiler splits a packed subtract into two single ones, and a vector instruction costs matrix time — see below)
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 template <int CW, int TW, int KC, bool ODD>
 __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
 {
@@ -52,6 +56,10 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
     // (add, move, integer, packed alike — nothing hides), a buffer load with a 32-bit offset ~1.5, a 1 KB global -> LDS copy ~4, LDS reads < 1.  So the loop below keeps
     // vector instructions to the transform itself (packed: two adds per instruction) and does all addressing with SCALAR registers: the wave index is made scalar here,
     // per-lane byte offsets are loop invariants, everything that changes with the chunk rides in the loads' scalar offset.
+#ifdef WN_PROF
+    unsigned long long tk[4] = {0, 0, 0, 0};                             // (debug build: kernel entry, loop entry, loop exit, after the stores)
+    asm volatile("s_memtime %0" : "=s"(tk[0]));
+#endif
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int per = gridDim.x >> 3, item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (item >= A.total) return;
@@ -131,6 +139,10 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
     for (int p = 0; p < 16; p++)
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[p][q] = 0.f;
+    if (A.bias) {                                                        // Y = A^T M A: M[1][1] reaches all four outputs of a tile with weight 1 -> the bias starts there
+#pragma unroll
+        for (int q = 0; q < 16; q++) { const int co = (cg * CW + cw) * 32 + 4 * (lane >> 5) + 8 * (q >> 2) + (q & 3); acc[5][q] = co < A.Cout ? A.bias[co] : 0.f; }
+    }
 
     load_win(0, 0, 0, 16); load_win(0, 1, 0, 16);
     issue_u(0, 0, 0, NPW);
@@ -146,6 +158,9 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
 #define WN_STAMP(k) asm volatile("s_memtime %0" : "=s"(ts[k]))
 #else
 #define WN_STAMP(k) do { } while (0)
+#endif
+#ifdef WN_PROF
+    asm volatile("s_memtime %0" : "=s"(tk[1]));
 #endif
     for (int c = 0; c < A.nchunk; c++) {
         WN_STAMP(0);
@@ -206,6 +221,7 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
         WN_STAMP(9);
     }
 #ifdef WN_PROF
+    asm volatile("s_memtime %0" : "=s"(tk[2]));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (A.prof && lane == 0 && (item == 0 || item == A.total / 2)) for (int k = 0; k < 10; k++) A.prof[((item ? 4 : 0) + w) * 10 + k] = ts[k];
 #endif
@@ -218,28 +234,49 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
     const bool row1 = 2 * ty + 1 < A.H, col1 = 2 * tx + 1 < A.W;
     const int cob = (cg * CW + cw) * 32 + 4 * (lane >> 5);
     float* yb = A.y + ((size_t)n * A.Cout * A.H + 2 * ty) * A.W + 2 * tx;
-    float bv[16];
+    // (the bias is already in the accumulators: position (1, 1) of M contributes 1 to all four outputs of a tile, so acc[5] started from bias[co] instead of 0.)
+    // Output channels two at a time (registers r, r + 1 of every accumulator): packed adds / multiplies; leaky ReLU as max(y, slope * y) (0 <= slope <= 1).
+    const f32x2 sl = {A.slope, A.slope};
+    const bool full = __all((A.vec2 != 0) & row1) && (cg * CW + cw) * 32 + 32 <= A.Cout;       // whole wave: every lane stores both rows of all 32 channels as 8-byte pairs
 #pragma unroll
-    for (int r = 0; r < 16; r++) { const int co = cob + 8 * (r >> 2) + (r & 3); bv[r] = (A.bias && co < A.Cout) ? A.bias[co] : 0.f; }
+    for (int r = 0; r < 16; r += 2) {
+        f32x2 t0[4], t1[4];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int co = cob + 8 * (r >> 2) + (r & 3);
-        float t0[4], t1[4];
+        for (int j = 0; j < 4; j++) {
+            const f32x2 m0 = {acc[j][r], acc[j][r + 1]}, m1 = {acc[4 + j][r], acc[4 + j][r + 1]}, m2 = {acc[8 + j][r], acc[8 + j][r + 1]}, m3 = {acc[12 + j][r], acc[12 + j][r + 1]};
+            t0[j] = pk_add(pk_add(m0, m1), m2); t1[j] = pk_sub(pk_sub(m1, m2), m3);
+        }
+        f32x2 y00 = pk_add(pk_add(t0[0], t0[1]), t0[2]), y01 = pk_sub(pk_sub(t0[1], t0[2]), t0[3]), y10 = pk_add(pk_add(t1[0], t1[1]), t1[2]), y11 = pk_sub(pk_sub(t1[1], t1[2]), t1[3]);
+        const f32x2 s00 = y00 * sl, s01 = y01 * sl, s10 = y10 * sl, s11 = y11 * sl;
+        y00.x = fmaxf(y00.x, s00.x); y00.y = fmaxf(y00.y, s00.y); y01.x = fmaxf(y01.x, s01.x); y01.y = fmaxf(y01.y, s01.y);
+        y10.x = fmaxf(y10.x, s10.x); y10.y = fmaxf(y10.y, s10.y); y11.x = fmaxf(y11.x, s11.x); y11.y = fmaxf(y11.y, s11.y);
+        const int co = cob + 8 * (r >> 2) + (r & 3);                     // channel of register r; r + 1 is the next one
+        float* yp = yb + (size_t)co * hw;
+        if (full) {
+            *(f32x2*)yp = f32x2{y00.x, y01.x}; *(f32x2*)(yp + A.W) = f32x2{y10.x, y11.x};
+            *(f32x2*)(yp + hw) = f32x2{y00.y, y01.y}; *(f32x2*)(yp + hw + A.W) = f32x2{y10.y, y11.y};
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) { t0[j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r]; t1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r]; }
-        float y00 = t0[0] + t0[1] + t0[2] + bv[r], y01 = t0[1] - t0[2] - t0[3] + bv[r], y10 = t1[0] + t1[1] + t1[2] + bv[r], y11 = t1[1] - t1[2] - t1[3] + bv[r];
-        y00 = y00 > 0.f ? y00 : y00 * A.slope; y01 = y01 > 0.f ? y01 : y01 * A.slope; y10 = y10 > 0.f ? y10 : y10 * A.slope; y11 = y11 > 0.f ? y11 : y11 * A.slope;
-        if (co < A.Cout) {
-            float* yp = yb + (size_t)co * hw;
-            if (A.vec2) {                                                // W even and y 8-byte aligned: a tile row is one 8-byte store
-                *(f32x2*)yp = f32x2{y00, y01};
-                if (row1) *(f32x2*)(yp + A.W) = f32x2{y10, y11};
-            } else {
-                yp[0] = y00; if (col1) yp[1] = y01;
-                if (row1) { yp[A.W] = y10; if (col1) yp[A.W + 1] = y11; }
+            for (int h = 0; h < 2; h++) {
+                if (co + h >= A.Cout) continue;
+                float* q = yp + (size_t)h * hw;
+                const float a00 = h ? y00.y : y00.x, a01 = h ? y01.y : y01.x, a10 = h ? y10.y : y10.x, a11 = h ? y11.y : y11.x;
+                if (A.vec2) {                                            // W even and y 8-byte aligned: a tile row is one 8-byte store
+                    *(f32x2*)q = f32x2{a00, a01};
+                    if (row1) *(f32x2*)(q + A.W) = f32x2{a10, a11};
+                } else {
+                    q[0] = a00; if (col1) q[1] = a01;
+                    if (row1) { q[A.W] = a10; if (col1) q[A.W + 1] = a11; }
+                }
             }
         }
     }
+#ifdef WN_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_memtime %0" : "=s"(tk[3]));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (A.prof && lane == 0 && item == 0) for (int k = 0; k < 4; k++) A.prof[80 + w * 4 + k] = tk[k];
+#endif
 }
 
 // KC of the configuration that serves `cout` output channels: 2 x 2 waves (64 channels per workgroup, 8-channel chunks) unless a 64-channel grouping would compute
