@@ -242,7 +242,7 @@ def test_conv1x1_matrix_core_gemm_equals_conv2d(vido, ctx, cin, cout, H, W):
     # shapes outside the plan are refused, not mangled
     assert not ops.conv1x1_supported(48, 128, 1024) and not ops.conv1x1_supported(64, 64, 1024) and not ops.conv1x1_supported(64, 128, 850) and not ops.conv1x1_supported(64, 128, 64)
     with pytest.raises(vido.VidoError):
-        ops.conv1x1_bias_act(torch.zeros(1, 64, 25, 34, device="cuda"), torch.zeros(4, 2, 64, 16, device="cuda"))
+        ops.conv1x1_bias_act(torch.zeros(1, 64, 25, 34, device="cuda"), torch.zeros(4, 8, 64, 4, device="cuda"))
 
 
 @pytest.mark.gpu

@@ -132,16 +132,16 @@ def test_miopen_find_db_is_offered_only_to_its_own_miopen_build(monkeypatch, tmp
 
 def test_pack_conv1x1_is_the_operand_order_of_the_kernel():
     """nets/ops.py::pack_conv1x1 (host side of csrc/conv1x1.hip): element (co, k) of the 1x1 weight sits where lane 32 * (k & 1) + co % 32 of the wave that owns row block
-    co / 32 reads its (k % 32) / 2-th operand of K chunk k / 32 — v_mfma_f32_32x32x2's A operand: lane l supplies A[row l % 32][k l / 32]."""
+    co / 32 reads its (k % 8) / 2-th operand of the group of four k-pairs k / 8 — v_mfma_f32_32x32x2's A operand: lane l supplies A[row l % 32][k l / 32]."""
     from vido_slam_amd.nets.ops import pack_conv1x1
     g = torch.Generator().manual_seed(5)
     for cout, cin in ((128, 32), (256, 64), (384, 96)):
         w = torch.randn(cout, cin, 1, 1, generator=g)
         p = pack_conv1x1(w)
-        assert tuple(p.shape) == (cout // 32, cin // 32, 64, 16) and p.is_contiguous()
+        assert tuple(p.shape) == (cout // 32, cin // 8, 64, 4) and p.is_contiguous()
         for _ in range(300):
             co, k = (int(torch.randint(0, n, (1,), generator=g)) for n in (cout, cin))
-            assert float(p[co // 32, k // 32, 32 * (k & 1) + co % 32, (k % 32) // 2]) == float(w[co, k, 0, 0])
+            assert float(p[co // 32, k // 8, 32 * (k & 1) + co % 32, (k % 8) // 2]) == float(w[co, k, 0, 0])
     assert pack_conv1x1(torch.zeros(64, 32, 1, 1)) is None and pack_conv1x1(torch.zeros(128, 48, 1, 1)) is None and pack_conv1x1(torch.zeros(128, 32, 3, 3)) is None
 
 

@@ -46,11 +46,11 @@ def fold_batchnorm(net, ops):
             if c2.groups > 1 and tuple(c2.stride) == (1, 1) and tuple(c2.padding) == (1, 1) and tuple(c2.dilation) == (1, 1) and not os.environ.get("VIDO_NO_GCONV"):
                 from .ops import pack_gconv3x3
                 m._w2p = pack_gconv3x3(m._w2, c2.groups)
-            # conv3 as our own fp32 matrix-core GEMM with bias + shortcut + ReLU in its epilogue (csrc/conv1x1.hip) WHERE THAT WINS: measured on the detector's shapes
-            # (tools/prof_conv1x1.py, profiles/r4/conv1x1_microbench.txt) the kernel runs at 82-98 TFLOP/s against the library GEMM's 94-108, so a convolution without an
-            # epilogue (conv1: its bias + ReLU ride on conv2's operand reads) stays with the library; with the epilogue it beats library GEMM + pass by ~10 us on the large
-            # maps (>= 400 tiles of 128 x 128: layer1, layer2) and ties on 1024 -> 1024 at 50 x 68 (216 tiles for 256 CUs).  VIDO_CONV1X1=all takes every 1x1 convolution.
-            m._w1p = m._w3p = m._wdp = None; m._c1x1_min_tiles = 400
+            # conv3 as our own fp32 matrix-core GEMM with bias + shortcut + ReLU in its epilogue (csrc/conv1x1.hip).  Measured on the detector's shapes (tools/prof_conv1x1.py,
+            # profiles/r4/conv1x1_microbench_v3.txt) the GEMM alone runs where the library's does (66 us / 107 TFLOP/s at 1024 -> 1024 on 50 x 68 against 66-68), so a
+            # convolution without an epilogue (conv1: its bias + ReLU ride on conv2's operand reads) stays with the library; WITH the epilogue it saves the library's separate
+            # pass over the output (8-13 us per block) on every layer it has a form for.  VIDO_CONV1X1=all takes every 1x1 convolution.
+            m._w1p = m._w3p = m._wdp = None; m._c1x1_min_tiles = 0
             mode = os.environ.get("VIDO_CONV1X1", "")
             if not os.environ.get("VIDO_NO_CONV1X1") and hasattr(ops, "conv1x1_bias_act"):
                 from .ops import pack_conv1x1

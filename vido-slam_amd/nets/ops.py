@@ -139,6 +139,7 @@ class HipOps:
         assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and x.shape[0] == 1
         _, cin, H, W = x.shape
         cout = w_packed.shape[0] * 32
+        assert w_packed.shape[1] * 8 == cin and 0.0 <= slope <= 1.0
         out = torch.empty((1, cout, H, W), device=x.device, dtype=torch.float32)
         if residual is not None:
             residual = residual.contiguous(); assert residual.shape == out.shape
@@ -375,15 +376,15 @@ class HipOps:
 
 
 def pack_conv1x1(w):
-    """1x1 convolution weight [cout, cin, 1, 1] (or [cout, cin]) -> the operand order of csrc/conv1x1.hip: element (co, k) at [co / 32][k / 32][32 * (k & 1) + co % 32][(k % 32) / 2]
-    (a lane's 16 operands of a 32-channel K chunk are consecutive; a wave's chunk is 4 KB contiguous).  None when the kernel does not take the shape."""
+    """1x1 convolution weight [cout, cin, 1, 1] (or [cout, cin]) -> the operand order of csrc/conv1x1.hip: element (co, k) at [co / 32][k / 8][32 * (k & 1) + co % 32][(k % 8) / 2]
+    (a lane's four operands of a group of four k-pairs are one 16-byte read; a (32-channel block, group) is one 1 KB copy piece).  None when the kernel does not take the shape."""
     cout, cin = int(w.shape[0]), int(w.shape[1])
     if w.dim() == 4 and tuple(w.shape[2:]) != (1, 1):
         return None
     if cout % 128 or cin % 32:
         return None
-    w5 = w.detach().reshape(cout // 32, 32, cin // 32, 16, 2)          # [mb][co32][kc][kp][half]
-    return w5.permute(0, 2, 4, 1, 3).contiguous().reshape(cout // 32, cin // 32, 64, 16)
+    w5 = w.detach().reshape(cout // 32, 32, cin // 8, 4, 2)            # [mb][co32][group][kk][half]
+    return w5.permute(0, 2, 4, 1, 3).contiguous().reshape(cout // 32, cin // 8, 64, 4)
 
 
 def pack_gconv3x3(w, groups):
