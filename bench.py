@@ -221,6 +221,18 @@ def main():
             roofline_nets[name] = {"bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": round(fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "gflop_per_frame": round(fl / 1e9, 1), "ms": round(ms, 3), "dtype": "fp32"}
         stage["nets_sum_ms"] = round(sum(stage[k + "_ms"] for k in legs), 3)
+        # the largest hand-written network kernel, alone: csrc/wino.hip on the detector's FPN / RPN convolution at P2 (256 -> 256 on 200 x 272), bias + ReLU included.
+        # `achieved` counts the multiply-adds the kernel ISSUES to the matrix pipe (Winograd domain: 16 per 2x2 output tile and channel pair instead of 36); `direct_equivalent`
+        # is the same launch priced as the direct convolution it replaces (what roofline_nets and the library's kernels are priced as).
+        if hasattr(nodes.ops, "wino3x3_bias_act"):
+            from vido_slam_amd.nets.ops import pack_wino3x3
+            wx = torch.randn(1, 256, 200, 272, device="cuda"); ww = torch.randn(256, 256, 3, 3) / 48.0; wb = torch.randn(256, device="cuda"); wu = pack_wino3x3(ww).cuda()
+            wms = timed(lambda: nodes.ops.wino3x3_bias_act(wx, wu, wb, 256, 0.0), reps=20)
+            direct = 2.0 * 9 * 256 * 256 * 200 * 272
+            roofline_nets["wino3x3_fpn_p2"] = {"kernel": "k_wino3x3<2,2,8>", "bound": "mfma", "achieved": round(direct * 16.0 / 36.0 / (wms * 1e-3) / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": round(direct * 16.0 / 36.0 / (wms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "direct_equivalent_tflops": round(direct / (wms * 1e-3) / 1e12, 1),
+                                               "avg_launch_ms": round(wms, 4), "workgroups": 852, "dtype": "fp32"}
+            del wx, ww, wb, wu
     except Exception as e:
         roofline_nets["error"] = "%s: %s" % (type(e).__name__, e)
 
@@ -303,6 +315,11 @@ def main():
                     roofline["traffic"] = int(tot)
                     roofline["traffic_source"] = "profiles/%s/pmc_traffic.json %s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes; FETCH x2 gfx950 correction)" % (rnd, "+".join(names))
                     break
+        # what actually bounds the kernel (profiles/r3/fast_sq_counters.txt: 6.3e7 vector-ALU wave instructions per 64-frame launch, 4 cycles each on a 16-lane SIMD, 62.8 MB
+        # moved = 0.98 x the algorithmic bytes): the integer vector ALUs, not HBM — reported next to the HBM fraction the contract asks for
+        if fast_s > 0 and B == 64 and (W, H) == (640, 480):
+            roofline["limiter"] = {"bound": "integer VALU issue", "valu_wave_instructions_per_launch": 6.3e7, "cycles_per_instruction": 4, "simds": 1024, "clock_ghz": 2.4,
+                                   "frac_of_valu_issue_peak": round(6.3e7 * 4 / (1024 * 2.4e9 * fast_s), 3), "source": "profiles/r3/fast_sq_counters.txt (rocprofv3 --pmc SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU)"}
         out["roofline"] = roofline
         extra["configs1_frontend_batched"] = {"frames_per_s": round(B * bsteps / tb, 1), "ms_per_%d_frames" % B: round(tb / bsteps * 1e3, 4),
                                               "stage_ms": {k: round(v, 4) for k, v in stage_b.items() if k != "n_candidates"},
