@@ -111,12 +111,17 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
             asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(R[j][6 + h]) : "v"(D[2 + h]), "v"(D[6 + h]));
         }
     };
+    f32x2 Vo[NJ][8];                                                     // transformed window of pair j: Vo[j][2 i] = (v[i][0], v[i][1]), Vo[j][2 i + 1] = (v[i][2], v[i][3])
+    auto xf_cols = [&](int j) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(Vo[j][2 * i]) : "v"(R[j][2 * i]), "v"(R[j][2 * i + 1]));
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(Vo[j][2 * i + 1]) : "v"(R[j][2 * i]), "v"(R[j][2 * i + 1]));
+        }
+    };
     auto xf_out = [&](int j, int i, int buf) {
-        f32x2 v01, v23;
-        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(v01) : "v"(R[j][2 * i]), "v"(R[j][2 * i + 1]));
-        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(v23) : "v"(R[j][2 * i]), "v"(R[j][2 * i + 1]));
         float* dst = Vl + buf * V_BUF + (tw_t * KS + ks0 + j * KSTEP) * 64 + lane;
-        dst[(4 * i + 0) * V_P] = v01.x; dst[(4 * i + 1) * V_P] = v01.y; dst[(4 * i + 2) * V_P] = v23.x; dst[(4 * i + 3) * V_P] = v23.y;
+        dst[(4 * i + 0) * V_P] = Vo[j][2 * i].x; dst[(4 * i + 1) * V_P] = Vo[j][2 * i].y; dst[(4 * i + 2) * V_P] = Vo[j][2 * i + 1].x; dst[(4 * i + 3) * V_P] = Vo[j][2 * i + 1].y;
     };
     // U pieces travel global -> LDS as BUFFER loads with the lds bit (16 bytes per lane; the flat-encoded global_load_lds makes the compiler fall back to vmcnt(0) /
     // lgkmcnt(0) in front of every later use of any loaded register): per-lane offset 16 * lane, everything else scalar
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
     issue_u(0, 0, 0, NPW);
     xf_rows(0); xf_rows(1);
     load_win(1, 0, 0, 16); load_win(1, 1, 0, 16);
+    xf_cols(0); xf_cols(1);
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -182,19 +188,21 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
             }
         };
         ldops(0); ldops(1);                                              // (with WN_ABLATE & 16 these stay the only operand reads of the chunk)
-        // Eight slices of 2 KS matrix instructions (positions 2 g, 2 g + 1), operands requested two slices ahead.  The side work of the chunk is dealt over the slices by
-        // hand: slice 0 takes the row step of BOTH pairs (the only reads of window registers: whatever wait the compiler puts in front of them finds loads that are at
-        // least three slices old), slices 1-4 refill the windows (chunk c + 2; past the end they read zeros) EIGHT loads at a time — 32 gathers issued at once by four
-        // waves fill the address unit's queue and the slice that issues them takes 1800 cycles instead of 512 (shader-clock stamps, tools/ubench/wino_ablate.hip) — and
-        // finish the transform of chunk c + 1 into the other V buffer, slices 5-6 send for the next U block (past the last chunk: the last block again, into the
-        // buffer nobody reads any more).
 #define WN_XF(...) do { if (!(WN_ABLATE & 1)) { __VA_ARGS__; } } while (0)
 #define WN_LD(...) do { if (!(WN_ABLATE & 2)) { __VA_ARGS__; } } while (0)
+        // the transform's 32 packed adds sit HERE, in front of the first matrix instruction: they run while the first operands are on their way from LDS (the matrix pipe
+        // is idle then anyway); anywhere later each of them takes 5.5 cycles away from it.  They are the only reads of the window registers: every wait the compiler puts in
+        // front of them finds loads that are at least three slices old.
+        WN_XF(xf_rows(0); xf_rows(1); xf_cols(0); xf_cols(1));
+        // Eight slices of 2 KS matrix instructions (positions 2 g, 2 g + 1), operands requested two slices ahead.  The side work of the chunk is dealt over the slices by
+        // hand: slices 1-4 refill the windows (chunk c + 2; past the end they read zeros) EIGHT loads at a time — 32 gathers issued at once by four
+        // waves fill the address unit's queue and the slice that issues them takes 1800 cycles instead of 512 (shader-clock stamps, tools/ubench/wino_ablate.hip) — and
+        // write the transform of chunk c + 1 into the other V buffer, slices 5-6 send for the next U block (past the last chunk: the last block again, into the
+        // buffer nobody reads any more).
 #pragma unroll
         for (int g = 0; g < 8; g++) {
             __builtin_amdgcn_sched_barrier(0);
             if (g + 2 < 8 && !(WN_ABLATE & 16)) ldops(g + 2);
-            if (g == 0) { WN_XF(xf_rows(0); xf_rows(1)); }
             if (g >= 1 && g <= 4) { WN_LD(load_win(c + 2, (g - 1) >> 1, 8 * ((g - 1) & 1), 8 * ((g - 1) & 1) + 8)); }      // eight window loads per slice: one per matrix instruction
             if (g == 1) { WN_XF(xf_out(0, 0, nb); xf_out(0, 1, nb)); }
             if (g == 2) { WN_XF(xf_out(0, 2, nb); xf_out(0, 3, nb)); }
