@@ -206,10 +206,12 @@ def main():
             return a.elapsed_time(b) / reps
         from torch.utils.flop_counter import FlopCounterMode
         def flops(fn):
-            nodes.ops.gconv_flops = 0.0                                   # convolutions run by csrc/gconv.hip are not torch ops: counted by the wrapper
-            with FlopCounterMode(display=False) as fc:
+            hops = [o for o in (nodes.ops, getattr(nodes, "ops_flow", None)) if o is not None]
+            for o in hops:
+                o.gconv_flops = 0.0                                       # convolutions run by csrc/gconv.hip / conv1x1.hip / wino.hip are not torch ops: counted by the wrappers
+            with FlopCounterMode(display=False) as fc:                    # (as the direct convolutions they replace)
                 fn()
-            return float(fc.get_total_flops()) + float(getattr(nodes.ops, "gconv_flops", 0.0))
+            return float(fc.get_total_flops()) + sum(float(getattr(o, "gconv_flops", 0.0)) for o in hops)
         legs = {"liteflownet": (lambda: (nodes.g_flow or nodes._flow_fn)(ex0, ex), lambda: nodes._flow_fn(ex0, ex)),
                 "monodepth2": (lambda: (nodes.g_depth or nodes._depth_fn)(ex), lambda: nodes._depth_fn(ex)),
                 "maskrcnn_x101_fpn": ((lambda: nodes.g_det(ex)) if nodes.g_det is not None else

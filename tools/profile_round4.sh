@@ -12,7 +12,7 @@ REPO=$(pwd); OUT=$REPO/gpurun_out/prof_r4; mkdir -p $OUT
 WHAT="${*:-tests bench e2e fe nets wino}"
 has() { case " $WHAT " in *" $1 "*) return 0;; *) return 1;; esac; }
 stats() { f=$(find $1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "$f" > $2; }
-if has tests; then timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_full.txt 2>&1; tail -12 $OUT/pytest_full.txt > $OUT/pytest_gpu.txt; tail -3 $OUT/pytest_gpu.txt; fi
+if has tests; then timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_full.txt 2>&1; grep -E "passed|failed|error" $OUT/pytest_full.txt | tail -5 > $OUT/pytest_gpu.txt; tail -3 $OUT/pytest_gpu.txt; fi
 if has bench; then
   timeout 900 python bench.py > $OUT/bench_e2e.json 2> $OUT/bench_e2e.err; echo "bench rc $?"
   timeout 900 python bench.py --steps 200 --warmup 10 --no-extra --cpu-baseline 0 > $OUT/bench_e2e_200.json 2> $OUT/bench_e2e_200.err; echo "bench200 rc $?"
