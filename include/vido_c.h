@@ -413,6 +413,9 @@ int vido_pnp_ransac_batch(vido_ctx* ctx, int n_prob, const float* const* pts3d, 
 typedef struct vido_host_maps { const int32_t* mask; const float* depth; const float* flow; int32_t width, height; } vido_host_maps;   /* mSegMap / mDepthMap / mFlowMap */
 /* Frame::UndistortKeyPoints (Frame.cc:603-633): cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) — five fixed-point iterations of the Brown model;
  * K = (fx, fy, cx, cy), dist = (k1, k2, p1, p2, k3); k1 == 0: copy (Frame.cc:605-609). */
+/* Frame::UnprojectStereo* / ObtainFlowDepth* with addnoise = 1 (Frame.cc:706-716 ...): the depth with ONE draw of a fresh cv::RNG(seed) added,
+ * z + gaussian(z*z / (725*0.5) * 0.15); seed 0 = time(NULL) as the reference.  Host function (cv::RNG's multiply-with-carry + ziggurat restated; OpenCV side unpinned). */
+float vido_depth_noise(float z, unsigned seed);
 int vido_undistort_points(const float* xy, int n, const float K[4], const float dist[5], float* xy_out);
 /* Tracking::RenewFrameInfo, static part (Tracking.cc:2973-3075): the inliers TM_sta (indices into stat_xy = mvStatKeys, -1 = rejected) that still pass the mask /
  * depth <= 40 / flow tests, then top-up from sample_xy (= mvKeys) in stride-20 passes, skipping samples closer than 1 px to a kept inlier, until max_num.

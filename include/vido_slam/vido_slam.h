@@ -75,7 +75,7 @@ public:
     std::vector<cv::KeyPoint> SampleKeyPoints(const int& rows, const int& cols);
     cv::Mat GetRotationInverse() const { return mRwc.clone(); }
     cv::Mat GetCameraCenter() const { return mOw.clone(); }
-    cv::Mat UnprojectStereoStat(const int& i, const bool& addnoise);      /* Frame.cc:706-737; addnoise is ignored */
+    cv::Mat UnprojectStereoStat(const int& i, const bool& addnoise);      /* Frame.cc:706-737; addnoise = 1: one cv::RNG(time(NULL)) draw on the depth (vido_depth_noise) */
     cv::Mat UnprojectStereoObject(const int& i, const bool& addnoise);    /* Frame.cc:739-771 */
     cv::Mat ObtainFlowDepthCamera(const int& i, const bool& addnoise);    /* Frame.cc:833-858: (flow_x, flow_y, depth) */
     cv::Mat ObtainFlowDepthObject(const int& i, const bool& addnoise);    /* Frame.cc:860-886 */
@@ -213,6 +213,7 @@ private:
 };
 
 namespace detail {
+void SetDepthNoiseSeed(unsigned seed);                 /* addnoise = 1 draws: seed != 0 pins cv::RNG's seed (tests, reproducible runs); 0 = (unsigned)time(NULL) as the reference (Frame.cc:711) */
 float LastFrameStageMs(int which);                     /* wall time inside the last Frame constructor: 0 = extractor call, 1 = static / object lists */
 void ResidentCheckStats(int* checks, int* mismatches);  /* VIDO_BA_RESIDENT_CHECK=1: windows solved both ways (device-resident window / Map walk) and how many disagreed */
 vido_ctx* Context();                                   /* the process-wide ctx of the live System (one System per process, as in the reference) */

@@ -162,3 +162,57 @@ def test_incremental_tracklets_equal_the_full_rebuild(oracle, seed, dyn):
                 if want_t[base[f] + j] <= t:
                     want_t[base[f] + j] = t; want_p[base[f] + j] = k
     assert np.array_equal(ot, want_t) and np.array_equal(op, want_p)
+
+
+def _cv_rng_gaussian_py(seed):
+    """A fresh cv::RNG(seed).gaussian(1.0), written from the published algorithm a second time (numpy float32 where OpenCV computes in float): multiply-with-carry state,
+    128-strip ziggurat (Marsaglia & Tsang) on the state's low word BEFORE the step (modules/core/src/rand.cpp::randn_0_1_32f)."""
+    f32 = np.float32
+    m1 = 2147483648.0; dn = 3.442619855899; tn = dn; vn = 9.91256303526217e-3
+    q = vn / np.exp(-0.5 * dn * dn)
+    kn = [0] * 128; wn = [f32(0)] * 128; fn = [f32(0)] * 128
+    kn[0] = int((dn / q) * m1) & 0xffffffff; kn[1] = 0
+    wn[0] = f32(q / m1); wn[127] = f32(dn / m1); fn[0] = f32(1.0); fn[127] = f32(np.exp(-0.5 * dn * dn))
+    for i in range(126, 0, -1):
+        dn = np.sqrt(-2.0 * np.log(vn / dn + np.exp(-0.5 * dn * dn)))
+        kn[i + 1] = int((dn / tn) * m1) & 0xffffffff; tn = dn
+        fn[i] = f32(np.exp(-0.5 * dn * dn)); wn[i] = f32(dn / m1)
+    st = seed if seed else 0xffffffff
+    def step(s): return ((s & 0xffffffff) * 4164903690 + (s >> 32)) & 0xffffffffffffffff
+    rng_flt = f32(2.3283064365386962890625e-10)
+    while True:
+        lo = st & 0xffffffff; hz = lo - (1 << 32) if lo >= (1 << 31) else lo
+        st = step(st); iz = hz & 127
+        x = f32(f32(hz) * wn[iz])
+        if abs(hz) < kn[iz]:
+            return float(x)
+        if iz == 0:
+            while True:
+                x = f32(f32(st & 0xffffffff) * rng_flt); st = step(st)
+                y = f32(f32(st & 0xffffffff) * rng_flt); st = step(st)
+                x = f32(-np.log(np.float64(x) + np.finfo(np.float32).tiny) * 0.2904764); y = f32(-np.log(np.float64(y) + np.finfo(np.float32).tiny))
+                if not (f32(y + y) < f32(x * x)):
+                    break
+            return float(f32(3.442620) + x) if hz > 0 else float(-f32(3.442620) - x)
+        y = f32(f32(st & 0xffffffff) * rng_flt); st = step(st)
+        if f32(fn[iz] + y * f32(fn[iz - 1] - fn[iz])) < f32(np.exp(-0.5 * np.float64(x) * np.float64(x))):
+            return float(x)
+
+
+def test_depth_noise_is_one_draw_of_a_fresh_rng_per_call():
+    """vido_depth_noise (Frame.cc:711-716: `cv::RNG rng((unsigned)time(NULL)); z = z + rng.gaussian(z*z/(725*0.5)*0.15)`): a deterministic function of (z, seed) — the same
+    standard-normal draw for every point of one second — against a second restatement of cv::RNG + the ziggurat; accepted strips, wedges and the two seeds that land in the
+    base strip (seed & 127 == 0)."""
+    lib = V.load_library()
+    lib.vido_depth_noise.restype = C.c_float; lib.vido_depth_noise.argtypes = [C.c_float, C.c_uint]
+    seeds = [1, 2, 127, 128, 256, 1758900000, 1758900001, 1758900127, 1758900096, 0x7fffffff, 0x80000000, 0xfffffffe, 0x9e3779b9, 4096, 1 << 20]
+    for seed in seeds:
+        g = _cv_rng_gaussian_py(seed)
+        for z in (0.5, 7.25, 31.0, 80.0):
+            zf = np.float32(z)
+            want = np.float32(np.float64(zf) + np.float64(np.float32(g)) * (np.float64(np.float32(zf * zf)) / (725 * 0.5) * 0.15))
+            got = lib.vido_depth_noise(float(zf), seed)
+            assert got == want, (seed, z, got, want, g)
+    # one seed = one offset: the relative perturbation grows with z (sigma = 0.15 z^2 / 362.5), and a second's worth of calls shares it
+    a = [lib.vido_depth_noise(z, 1758900000) - z for z in (5.0, 10.0, 20.0)]
+    assert abs(a[1] / a[0] - 4.0) < 1e-3 and abs(a[2] / a[0] - 16.0) < 1e-3

@@ -1,8 +1,9 @@
 // facade.cpp — host orchestration behind the reference's C++ class surface (include/vido_slam/vido_slam.h).
 // Follows, function by function, vido_slam/src/{System,Tracking,Frame,Optimizer,Converter}.cc of the reference; every
 // data-parallel stage is a call into the C-ABI (GPU), everything here is bookkeeping on a few thousand points.
-// Not reproduced (SURVEY.md §2 out of scope): viewer / imshow / plots, ground-truth metrics, IMU paths, the
-// time(NULL)-seeded depth noise of the addnoise=1 branches.
+// Not reproduced (SURVEY.md §2 out of scope): viewer / imshow / plots, ground-truth metrics, IMU paths.  The addnoise = 1 branches (time(NULL)-seeded cv::RNG draw on the
+// depth) are vido_depth_noise (trackhost.cpp); detail::SetDepthNoiseSeed pins the seed.
+#include <ctime>
 #include "../../include/vido_slam/vido_slam.h"
 #include <algorithm>
 #include <map>
@@ -264,10 +265,14 @@ static bool unproject_raw(const Frame& F, float u, float v, float z, float* out)
 static inline bool stat3d_raw(const Frame& F, int i, float* out) { const float z = F.mvStatDepth[i]; if (z < 0) return false; return unproject_raw(F, F.mvStatKeys[i].pt.x, F.mvStatKeys[i].pt.y, z, out); }
 static inline bool obj3d_raw(const Frame& F, int i, float* out) { const float z = F.mvObjDepth[i]; if (!(z > 0)) return false; return unproject_raw(F, F.mvObjKeys[i].pt.x, F.mvObjKeys[i].pt.y, z, out); }
 static cv::Mat unproject(const Frame& F, float u, float v, float z) { float o[3]; unproject_raw(F, u, v, z, o); return vec3(o[0], o[1], o[2]); }
-cv::Mat Frame::UnprojectStereoStat(const int& i, const bool&) { const float z = mvStatDepth[i]; if (z < 0) return cv::Mat(); return unproject(*this, mvStatKeys[i].pt.x, mvStatKeys[i].pt.y, z); }
-cv::Mat Frame::UnprojectStereoObject(const int& i, const bool&) { const float z = mvObjDepth[i]; if (!(z > 0)) return cv::Mat(); return unproject(*this, mvObjKeys[i].pt.x, mvObjKeys[i].pt.y, z); }
-cv::Mat Frame::ObtainFlowDepthCamera(const int& i, const bool&) { const float z = mvStatDepth[i]; if (!(z > 0)) return cv::Mat(); return vec3(mvFlowNext[i].x, mvFlowNext[i].y, z); }
-cv::Mat Frame::ObtainFlowDepthObject(const int& i, const bool&) { const float z = mvObjDepth[i]; if (!(z > 0)) return cv::Mat(); return vec3(mvObjFlowNext[i].x, mvObjFlowNext[i].y, z); }
+// addnoise = 1 (Frame.cc:711-716, 744-750, 838-845, 865-872): one draw of a fresh cv::RNG((unsigned)time(NULL)) per call, scaled by z*z / (725*0.5) * 0.15 —
+// vido_depth_noise (trackhost.cpp).  detail::SetDepthNoiseSeed(s != 0) pins the seed (tests, reproducible runs); 0 = the reference's time(NULL).
+static unsigned g_noise_seed = 0;
+static inline float noisy(float z, bool addnoise) { return addnoise ? vido_depth_noise(z, g_noise_seed) : z; }
+cv::Mat Frame::UnprojectStereoStat(const int& i, const bool& addnoise) { const float z = noisy(mvStatDepth[i], addnoise); if (z < 0) return cv::Mat(); return unproject(*this, mvStatKeys[i].pt.x, mvStatKeys[i].pt.y, z); }
+cv::Mat Frame::UnprojectStereoObject(const int& i, const bool& addnoise) { const float z = noisy(mvObjDepth[i], addnoise); if (!(z > 0)) return cv::Mat(); return unproject(*this, mvObjKeys[i].pt.x, mvObjKeys[i].pt.y, z); }
+cv::Mat Frame::ObtainFlowDepthCamera(const int& i, const bool& addnoise) { const float z = noisy(mvStatDepth[i], addnoise); if (!(z > 0)) return cv::Mat(); return vec3(mvFlowNext[i].x, mvFlowNext[i].y, z); }
+cv::Mat Frame::ObtainFlowDepthObject(const int& i, const bool& addnoise) { const float z = noisy(mvObjDepth[i], addnoise); if (!(z > 0)) return cv::Mat(); return vec3(mvObjFlowNext[i].x, mvObjFlowNext[i].y, z); }
 
 void Map::reset() { *this = Map(); }
 
@@ -341,9 +346,12 @@ int Optimizer::PoseOptimizationNew(Frame* cur, Frame* last, std::vector<int>& TM
 {
     const int N = (int)TM.size();
     std::vector<double> Xw(3 * N), obs(2 * N);
+    const unsigned noise_seed = g_noise_seed ? g_noise_seed : (unsigned)time(NULL);        // (the reference re-reads the clock per point: within one call the same second)
     for (int i = 0; i < N; i++) {
         obs[2 * i] = cur->mvStatKeys[TM[i]].pt.x; obs[2 * i + 1] = cur->mvStatKeys[TM[i]].pt.y;
-        float X[3]; const bool have = stat3d_raw(*last, TM[i], X);          // Frame::UnprojectStereoStat
+        // Frame::UnprojectStereoStat(TemperalMatch[i], 1) (Optimizer.cc:2250): the depth carries the addnoise draw (one value of the seed = one offset for the whole call)
+        float X[3]; const float z = vido_depth_noise(last->mvStatDepth[TM[i]], noise_seed);
+        const bool have = !(z < 0) && unproject_raw(*last, last->mvStatKeys[TM[i]].pt.x, last->mvStatKeys[TM[i]].pt.y, z, X);
         for (int a = 0; a < 3; a++) Xw[3 * i + a] = have ? X[a] : 0.0;
     }
     vido_pose_problem p; fill_common(p, cur, N); p.mode = 0; p.Xw = Xw.data(); p.obs = obs.data(); toRow16(cur->mTcw, p.T_init);
@@ -526,7 +534,8 @@ static void dump_g2o(const std::string& path, const vido_ba_problem& b, const vi
 // Map walk of PartialBatchOptimization (Optimizer.cc:56-160, 216-350; STATIC_ONLY graph) and FullBatchOptimization (:1235-2178;
 // static + object factors) onto the flat BA problem.
 static int g_res_checks = 0, g_res_mismatch = 0;
-namespace detail { void ResidentCheckStats(int* checks, int* mismatches) { if (checks) *checks = g_res_checks; if (mismatches) *mismatches = g_res_mismatch; }
+namespace detail { void SetDepthNoiseSeed(unsigned seed) { g_noise_seed = seed; }
+                   void ResidentCheckStats(int* checks, int* mismatches) { if (checks) *checks = g_res_checks; if (mismatches) *mismatches = g_res_mismatch; }
                    float LastFrameStageMs(int which) { return which == 0 ? g_ms_orb : g_ms_lists; } }
 
 // Commits a local-window result to the Map (Optimizer.cc:1084-1128): refined camera poses, the odometry factors re-derived from them

@@ -3,6 +3,8 @@
 // (reference vido_slam/src/Tracking.cc:1670-1912, 2959-3289, 2514-2720; Frame.cc:603-633).  The C++ facade (facade.cpp) calls exactly these
 // functions, and the parity tests compare them with literal restatements of the reference's own O(N*M) loops (test infrastructure, not linked here) — the one place where the build's algorithm differs from the reference's is the "already used" test of the re-seeding (a 1-px cell hash
 // instead of a scan over the whole kept set), and that difference is what those tests pin.
+#include <cfloat>
+#include <ctime>
 #include "../../include/vido_c.h"
 #include <algorithm>
 #include <cmath>
@@ -256,4 +258,52 @@ int vido_dyn_obj_tracking(const int32_t* sem_label, int32_t* obj_label, const fl
     return VIDO_OK;
 }
 
+
+/* Frame::UnprojectStereoStat / UnprojectStereoObject / ObtainFlowDepth*, addnoise = 1 (Frame.cc:706-716, 737-750, 773-790, 833-845, 860-872): every call builds a FRESH
+ * cv::RNG seeded with time(NULL) and adds ONE draw  z + rng.gaussian(z*z / (725*0.5) * 0.15)  to the depth — a deterministic function of (z, seed), the same offset for every
+ * point measured within one second.  cv::RNG (OpenCV 3.4, third-party, not in /root/reference: restated from its published source, parity unpinned): the state is the
+ * seed itself (0 -> 0xffffffff), next() is the multiply-with-carry  state = (uint32)state * 4164903690 + (state >> 32); gaussian() is the 128-strip ziggurat of
+ * modules/core/src/rand.cpp::randn_0_1_32f on the state's low word, scaled by sigma in double.  seed 0 here = "now" (time(NULL)), as the reference. */
+float vido_depth_noise(float z, unsigned seed)
+{
+    static unsigned kn[128]; static float wn[128], fn[128]; static bool init = false;
+    if (!init) {
+        const double m1 = 2147483648.0; double dn = 3.442619855899, tn = dn; const double vn = 9.91256303526217e-3;
+        const double q = vn / std::exp(-.5 * dn * dn);
+        kn[0] = (unsigned)((dn / q) * m1); kn[1] = 0;
+        wn[0] = (float)(q / m1); wn[127] = (float)(dn / m1);
+        fn[0] = 1.f; fn[127] = (float)std::exp(-.5 * dn * dn);
+        for (int i = 126; i >= 1; i--) {
+            dn = std::sqrt(-2. * std::log(vn / dn + std::exp(-.5 * dn * dn)));
+            kn[i + 1] = (unsigned)((dn / tn) * m1); tn = dn;
+            fn[i] = (float)std::exp(-.5 * dn * dn); wn[i] = (float)(dn / m1);
+        }
+        init = true;
+    }
+    if (seed == 0) seed = (unsigned)time(NULL);
+    uint64_t st = seed ? (uint64_t)seed : 0xffffffffull;
+    auto next = [&]() { st = (uint64_t)(unsigned)st * 4164903690u + (unsigned)(st >> 32); return (unsigned)st; };
+    const float r = 3.442620f, rng_flt = 2.3283064365386962890625e-10f;
+    float x, y;
+    for (;;) {
+        const int hz = (int)st; next();
+        const int iz = hz & 127;
+        x = hz * wn[iz];
+        if ((unsigned)std::abs(hz) < kn[iz]) break;
+        if (iz == 0) {                                        // the tail
+            do {
+                x = (unsigned)st * rng_flt; next();
+                y = (unsigned)st * rng_flt; next();
+                x = (float)(-std::log(x + FLT_MIN) * 0.2904764);
+                y = (float)-std::log(y + FLT_MIN);
+            } while (y + y < x * x);
+            x = hz > 0 ? r + x : -r - x;
+            break;
+        }
+        y = (unsigned)st * rng_flt; next();                   // a wedge
+        if (fn[iz] + y * (fn[iz - 1] - fn[iz]) < (float)std::exp(-.5 * x * x)) break;
+    }
+    const double sigma = z * z / (725 * 0.5) * 0.15;          // (float * float) / double * double, as written in Frame.cc
+    return (float)(z + (double)x * sigma);
+}
 }  // extern "C"
