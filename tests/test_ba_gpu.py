@@ -291,10 +291,11 @@ def test_revisited_landmarks_leave_the_camera_window(vido, oracle, ctx, share, c
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"VIDO_BA_PERSIST": "1"}, {"VIDO_BA_NO_FUSED_LOCAL": "1"}])
+@pytest.mark.parametrize("env", [{"VIDO_BA_PERSIST": "1"}, {"VIDO_BA_NO_FUSED_LOCAL": "1"}, {"VIDO_BA_NO_SPEC": "1"}])
 def test_local_window_alternative_drivers_match_the_oracle(env):
-    """The local window has three drivers over the same kernels' bodies: the fused host-driven loop (default), the persistent one-launch solver k_ba_local_lm
-    (VIDO_BA_PERSIST=1: opt-in) and round 3's loop (VIDO_BA_NO_FUSED_LOCAL=1).  The switches are read once per process, so the two alternatives run
+    """The local window has four drivers over the same kernels' bodies: the enqueued-ahead solve with the LM state on the device (default), the fused host-driven trial loop
+    (VIDO_BA_NO_SPEC=1), the persistent one-launch solver k_ba_local_lm (VIDO_BA_PERSIST=1: opt-in) and round 3's loop (VIDO_BA_NO_FUSED_LOCAL=1).
+    The switches are read once per process, so the alternatives run
     the local-window oracle cases (same LM iteration AND trial counts, poses / points to 1e-4) and the facade's resident-window cross-check in a child process."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2130,6 +2130,95 @@ __global__ __launch_bounds__(256) void k_ba_backsub_chi2_local(BaDev P, int n_pt
 // in the kernel arguments (constant memory, read with scalar loads where a field is used); `sel` picks one.  A descriptor mutated in place would live in registers.
 struct BaDev4 { BaDev v[4]; };      // [accumulator copy (iteration parity)][state flip]
 static_assert(sizeof(BaDev4) + sizeof(BaLocalArgs) <= 4000, "kernel arguments of k_ba_local_lm exceed the 4 KB kernarg segment");
+// ---- the local window ENQUEUED AHEAD (the default): the phases of the fused host-driven loop as launches that take the LM state from DEVICE memory (BaSpecCtl) and the
+// problem descriptor as the four variants of BaDev4, so the host can put a whole solve's trials on the stream without waiting for any of them.  A trial slot is
+// S, F, C, B (+ the LM policy, run by the last workgroup of B) and L, which only runs when the policy accepted the trial and asked for a new linearisation; every launch
+// returns at once when the policy has stopped the solve.  The policy is g2o's (optimization_algorithm_levenberg.cpp:61-189 + the facade's stop rules), the same
+// arithmetic as the host loop below and k_ba_local_lm: identical LM traces (tests/test_ba_gpu.py).
+struct BaSpecCtl {
+    double lambda, ni, currentChi, iniChi, chi2_check, lastChi, chi_init, chi_final, gain_threshold;
+    int it, qmax, nBad, flip, stop, need_lin, trials, max_iters;
+};
+__device__ __forceinline__ const BaDev& bas_sel(const BaDev4& V, const BaSpecCtl* c) { return V.v[(c->it & 1) * 2 + c->flip]; }
+__global__ __launch_bounds__(LIN_THREADS) void k_bas_lin(BaDev4 V, const BaSpecCtl* c, int nvb)
+{
+    __shared__ __attribute__((aligned(16))) double lin_smem[LIN_SMEM_DOUBLES(LIN_THREADS)];
+    if (c->stop || !c->need_lin) return;
+    const BaDev& P = bas_sel(V, c);
+    if ((int)blockIdx.x < nvb) { ba_linearize_body<LIN_THREADS, true>(P, 1, blockIdx.x, lin_smem); return; }
+    ba_camfactor_body(P, 1, P.cam, P.scal + 0, ((int)blockIdx.x - nvb) * (LIN_THREADS / 64) + (int)(threadIdx.x >> 6), threadIdx.x & 63);
+}
+__global__ void k_bas_init(BaDev4 V, BaSpecCtl* c)       // after the first linearisation + max diagonal: lambda_0 = tau * max diag (tau = 1e-5), chi2 at the initial state
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const double* scal = V.v[0].scal;
+    c->lambda = 1e-5 * bal_ld(scal + 1); c->ni = 2; c->nBad = 0; c->chi_init = c->chi_final = c->currentChi = c->iniChi = bal_ld(scal + 0);
+}
+__global__ __launch_bounds__(512) void k_bas_schur(BaDev4 V, const BaSpecCtl* c, int n_ptl, int kcap, double* S_part)
+{
+    extern __shared__ double lds_schur_dyn[];
+    if (c->stop) return;
+    ba_schur_body<0>(bas_sel(V, c), n_ptl, c->lambda, kcap, S_part, (const int*)nullptr, (const int*)nullptr, (const int2*)nullptr, blockIdx.x, gridDim.x, lds_schur_dyn);
+}
+__global__ __launch_bounds__(256) void k_bas_fold(BaDev4 V, const BaSpecCtl* c, const double* S_part, int nparts)
+{
+    if (c->stop) return;
+    ba_fold_local_body(bas_sel(V, c), S_part, nparts, c->lambda, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+__global__ __launch_bounds__(CH_NT) void k_bas_chol(BaDev4 V, const BaSpecCtl* c)
+{
+    extern __shared__ double cs6_dyn[];
+    if (c->stop) return;
+    ba_chol_small6_body<CH_NT>(bas_sel(V, c), 1, c->lambda, cs6_dyn);
+}
+__global__ __launch_bounds__(256) void k_bas_backsub(BaDev4 V, BaSpecCtl* c, int n_ptl, int n_bs, double* red0, double* red1, int red_len, int* ticket, BaSpecCtl* host_ctl)
+{
+    __shared__ double wsum[32];
+    __shared__ int is_last;
+    if (c->stop) return;
+    const BaDev& P = bas_sel(V, c);
+    const int it = c->it, qmax = c->qmax;
+    if ((int)blockIdx.x < n_bs) {
+        ba_backsub_chi2_body(P, n_ptl, c->lambda, blockIdx.x * 256 + threadIdx.x, n_bs * 256, wsum);
+        if (qmax == 0) { double* zb = (it & 1) ? red0 : red1; for (int t = blockIdx.x * 256 + threadIdx.x; t < red_len; t += n_bs * 256) zb[t] = 0.0; }      // the NEXT linearisation's accumulators (the other copy)
+    } else ba_camfactor_body(P, 0, P.cam_new, P.scal + 2, ((int)blockIdx.x - n_bs) * 4 + (int)(threadIdx.x >> 6), threadIdx.x & 63);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!is_last || threadIdx.x) return;
+    *ticket = 0;
+    // ---- the LM policy (one thread, after every workgroup of the trial has finished)
+    BaSpecCtl s = *c;
+    const double* scal = P.scal;
+    if (s.qmax == 0) s.currentChi = s.iniChi = bal_ld(scal + 0);                 // chi2 at this iteration's linearisation point
+    const bool ok2 = bal_ld(scal + 4) > 0.5;
+    const double tempChi = ok2 ? bal_ld(scal + 2) : DBL_MAX, scale = ok2 ? bal_ld(scal + 3) : 0.0;
+    const double rho = (s.currentChi - tempChi) / (scale + 1e-3);
+    if (rho > 0 && isfinite(tempChi)) {
+        const double tr = 2 * rho - 1; double alpha = 1. - tr * tr * tr; alpha = fmin(alpha, 2. / 3.);
+        s.lambda *= fmax(1. / 3., alpha); s.ni = 2; s.currentChi = tempChi;
+        s.flip ^= 1;                                                             // the trial state becomes the accepted one
+    } else { s.lambda *= s.ni; s.ni *= 2; }
+    s.qmax++; s.trials++;
+    if (rho < 0 && s.qmax < 10) s.need_lin = 0;                                  // another trial at the same linearisation with the larger lambda
+    else {
+        bool terminate = (s.qmax == 10 || rho == 0);
+        if (!terminate) { if ((s.iniChi - s.currentChi) * 1e3 < s.iniChi) s.nBad++; else s.nBad = 0; if (s.nBad >= 3) terminate = true; }
+        const double chiNow = s.currentChi;
+        if (s.chi2_check < chiNow && s.it > 0) terminate = true;
+        s.chi2_check = chiNow;
+        if (s.it == 0) s.lastChi = chiNow;
+        else { const double gain = (s.lastChi - chiNow) / chiNow; s.lastChi = chiNow; if (gain >= 0 && gain < s.gain_threshold) terminate = true; }
+        s.chi_final = chiNow;
+        s.it++;
+        if (terminate || s.it >= s.max_iters) s.stop = 1; else { s.need_lin = 1; s.qmax = 0; }
+    }
+    *c = s;
+    __threadfence_system();
+    *host_ctl = s;                                                               // the host polls / reads the pinned mirror
+}
+
 __global__ __launch_bounds__(BAL_NT) void k_ba_local_lm(BaDev4 V, BaLocalArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double bal_smem[];
@@ -2483,6 +2572,7 @@ struct BaState {
     int* d_long = nullptr; size_t long_cap = 0;      // landmarks with > 64 observations
     double* d_bcr = nullptr; size_t bcr_cap = 0;     // block-cyclic-reduction workspace (superblocks D, L x2, GL, GR, b, y)
     int* d_ticket = nullptr;                        // k_ba_backsub_chi2_local: workgroups finished so far (reset by the last one)
+    struct BaSpecCtl* d_spec = nullptr; struct BaSpecCtl* h_spec = nullptr; int spec_last_trials = 12;      // the enqueued-ahead local solve: LM state on the device, its pinned mirror, the previous solve's trial count
     struct BaLmCtl* d_ctl = nullptr; struct BaLmCtl* h_ctl = nullptr; unsigned bar_base = 0;   // persistent local-window solver: control block (device + pinned mirror), barrier count so far
 };
 void ba_state_destroy(vido_ctx* ctx)
@@ -2490,7 +2580,7 @@ void ba_state_destroy(vido_ctx* ctx)
     BaState* S = ctx->ba; if (!S) return;
     for (void* p : S->allocs) hipFree(p);
     hipFree(S->d_parts); hipFree(S->d_scratch); hipHostFree(S->h_scal); hipFree(S->pool); hipHostFree(S->h_pool); hipFree(S->d_long); hipFree(S->d_bcr);
-    hipFree(S->d_ctl); hipHostFree(S->h_ctl); hipFree(S->d_ticket);
+    hipFree(S->d_ctl); hipHostFree(S->h_ctl); hipFree(S->d_ticket); hipFree(S->d_spec); hipHostFree(S->h_spec);
     if (S->ev0) hipEventDestroy(S->ev0);
     if (S->ev1) hipEventDestroy(S->ev1);
     delete S; ctx->ba = nullptr;
@@ -3001,7 +3091,9 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     if (lds_schur > 160 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "ba: LDS budget exceeded (n6=%d, max track %d)", n6, maxk);
     if (lds_path) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
                     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol));
-                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol6)); }
+                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol6));
+                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_bas_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
+                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_bas_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol6)); }
     else { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM_LDS_BYTES)); }
 
@@ -3082,7 +3174,54 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     static const int fl_schur_grid_env = [] { const char* e = getenv("VIDO_BA_SCHUR0_GRID"); return e ? std::max(1, std::min(atoi(e), BA_SCHUR0_GRID)) : 128; }();
     const int fl_grid = std::min(fl_schur_grid_env, std::max(1, (n_ptl + 3) / 4));       // partial reduced systems: every one is summed by the fold; tracker alone: 32 / 64 / 128 / 256 partials -> 2.49 / 2.13 / 1.95 / 1.95 ms per solve
     const size_t red_len = (size_t)n_pose * 36 + n6 + 8;
-    if (!persist) {
+    // ---- the local window enqueued ahead (default; VIDO_BA_NO_SPEC=1 keeps the host-driven trial loop below): the LM state lives on the device, the host puts
+    // (previous solve's trials + 2) trial slots on the stream in one go and waits ONCE; a solve that needs more gets four more slots at a time.  No host round trip per trial:
+    // inside the pipeline each one cost a stream drain behind the networks' workgroups.
+    static const bool no_spec = getenv("VIDO_BA_NO_SPEC") != nullptr;
+    const bool spec = fl && !no_spec;
+    if (spec) {
+        if (!BS->d_spec) { HIP_TRY(ctx, hipMalloc((void**)&BS->d_spec, sizeof(BaSpecCtl))); HIP_TRY(ctx, hipHostMalloc((void**)&BS->h_spec, sizeof(BaSpecCtl))); }
+        BaDev4 V;
+        for (int par = 0; par < 2; par++) for (int flip = 0; flip < 2; flip++) {
+            BaDev& Q = V.v[par * 2 + flip]; Q = D;
+            double* rp = par ? red1 : red; Q.Hcd = rp; Q.bc = rp + (size_t)n_pose * 36; Q.scal = Q.bc + n6;
+            if (flip) { std::swap(Q.cam, Q.cam_new); std::swap(Q.pt, Q.pt_new); }
+        }
+        BaSpecCtl init; memset(&init, 0, sizeof init); init.max_iters = p.max_iters; init.gain_threshold = p.gain_threshold; init.need_lin = 1;
+        *BS->h_spec = init;
+        HIP_TRY(ctx, hipMemcpyAsync(BS->d_spec, BS->h_spec, sizeof(BaSpecCtl), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemsetAsync(red, 0, (size_t)((char*)(red1 + red_len) - (char*)red), st));
+        const int ncf = D.n_odo + (D.prior_cam >= 0 ? 1 : 0), nvb = (no + LIN_THREADS - 1) / LIN_THREADS, lin_grid = nvb + (ncf + LIN_THREADS / 64 - 1) / (LIN_THREADS / 64);
+        const int n_bs = std::min((n_ptl + 31) / 32, 1024), fold_grid = std::min(64, (int)((loc_sz + 255) / 256));
+        HIP_TRY(ctx, hipEventRecord(BS->ev0, st));
+        hipLaunchKernelGGL(k_bas_lin, dim3(lin_grid), dim3(LIN_THREADS), 0, st, V, (const BaSpecCtl*)BS->d_spec, nvb);
+        HIP_TRY(ctx, hipEventRecord(BS->ev1, st)); n_lin = 1;
+        hipLaunchKernelGGL(k_ba_maxdiag, dim3(64), dim3(256), 0, st, V.v[0], n_ptl);
+        hipLaunchKernelGGL(k_bas_init, dim3(1), dim3(64), 0, st, V, BS->d_spec);
+        int budget = std::max(4, std::min(BS->spec_last_trials + 2, 48)), enq = 0;
+        for (;;) {
+            for (int sl = 0; sl < budget; sl++) {
+                hipLaunchKernelGGL(k_bas_schur, dim3(fl_grid), dim3(64 * schur0_waves), lds_schur, st, V, (const BaSpecCtl*)BS->d_spec, n_ptl, kcap, BS->d_parts);
+                hipLaunchKernelGGL(k_bas_fold, dim3(fold_grid), dim3(256), 0, st, V, (const BaSpecCtl*)BS->d_spec, (const double*)BS->d_parts, fl_grid);
+                hipLaunchKernelGGL(k_bas_chol, dim3(1), dim3(CH_NT), lds_chol6, st, V, (const BaSpecCtl*)BS->d_spec);
+                hipLaunchKernelGGL(k_bas_backsub, dim3(n_bs + (ncf + 3) / 4), dim3(256), 0, st, V, BS->d_spec, n_ptl, n_bs, red, red1, (int)red_len, BS->d_ticket, BS->h_spec);
+                hipLaunchKernelGGL(k_bas_lin, dim3(lin_grid), dim3(LIN_THREADS), 0, st, V, (const BaSpecCtl*)BS->d_spec, nvb);
+            }
+            enq += budget;
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (BS->h_spec->stop || enq > 10 * p.max_iters + 16) break;
+            budget = 4;
+        }
+        const BaSpecCtl hs = *BS->h_spec;
+        if (!hs.stop) return vido_set_error(ctx, VIDO_E_HIP, "ba: the enqueued-ahead local solve did not stop after %d trial slots", enq);
+        BS->spec_last_trials = hs.trials;
+        it = hs.it; trials = hs.trials; lambda = hs.lambda; res->chi2_initial = hs.chi_init; res->chi2_final = hs.chi_final;
+        n_lin = hs.it;
+        { float ms = 0; if (hipEventElapsedTime(&ms, BS->ev0, BS->ev1) == hipSuccess) ms_lin = ms * n_lin; }
+        if (hs.flip) { std::swap(D.cam, D.cam_new); std::swap(D.pt, D.pt_new); }
+    }
+    if (!persist && !spec) {
     if (!fl) { if ((rc = chi2_at(D.cam, D.pt, 2, &res->chi2_initial))) return rc; res->chi2_final = res->chi2_initial; }
     for (it = 0; it < p.max_iters; it++) {
         // ---- linearise
