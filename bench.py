@@ -447,6 +447,14 @@ def main():
                                 "chi2": [round(r["chi2_initial"], 3), round(r["chi2_final"], 3)], "wall_ms": round(d * 1e3, 1), "wall_ms_first_call": round(d_cold * 1e3, 1),
                                 "collective": ("gloo all-reduce through host memory (--oversubscribe: all ranks on one GPU)" if args.oversubscribe else "RCCL all-reduce (sum) of the reduced camera system per LM trial, " + ("issued by the library on its stream" if rccl_direct else "through the torch.distributed hook")) if world > 1 else "none",
                                 "scaling_curve": "no 8-GPU scaling curve measured by the builder (single-GPU boxes); the driver's SCALE record is the measurement"}
+          if r.get("ms_schur_kernel", 0.0) > 0:
+              # the Schur kernel of the global path (k_ba_schur_mfma): per observation it reads the 27-double slot record the linearisation wrote (216 B), per landmark it writes
+              # 3 doubles; the camera-pair blocks stay in LDS and leave once per chunk.  Counted traffic (profiles/r3/pmc_traffic_ba_global.json): 345 MB per launch.
+              nb = 216.0 * len(gpr["obs_cam"]) + 24.0 * gpr["n_pt"]
+              ach = nb / (r["ms_schur_kernel"] * 1e-3) / 1e9
+              out["roofline_ba_schur"] = {"kernel": "k_ba_schur_mfma", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                                          "traffic": 345000000, "traffic_source": "profiles/r3/pmc_traffic_ba_global.json (FETCH x2 + WRITE)", "algorithmic_bytes_per_launch": int(nb),
+                                          "avg_launch_ms": round(r["ms_schur_kernel"], 5), "note": "FP64 matrix-core outer products per landmark chunk; bounded by the dependent chain per chunk, not by HBM"}
           if "ms_phases" in r:
               extra["global_ba"]["ms_phases_per_trial"] = r["ms_phases"]
           # the second half of BASELINE's metric ("BA iters/sec"), first-class: configs[4] sharded over the N ranks (landmark ranges, one all-reduce of the reduced camera

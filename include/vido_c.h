@@ -222,6 +222,7 @@ typedef struct vido_ba_result { int32_t iterations, lm_trials; double chi2_initi
                                 double ms_setup;        /* host preprocessing + upload (wall) */
                                 double ms_solve_loop;   /* the LM loop proper, inputs resident in HBM (wall) */
                                 double ms_linearize_kernel;   /* mean k_ba_linearize duration (HIP events on the ctx stream) */
+                                double ms_schur_kernel;       /* mean k_ba_schur_mfma duration (global path; 0 when another Schur kernel ran) */
 } vido_ba_result;
 
 /* In-place all-reduce of `count` doubles at DEVICE address `dev_ptr` over all ranks (op 0 = sum, 1 = max);

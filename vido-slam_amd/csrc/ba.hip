@@ -2565,7 +2565,7 @@ __global__ __launch_bounds__(256) void k_badyn_chi2(BaDev P, const double* cam, 
 struct BaState {
     std::vector<void*> allocs;
     double* h_scal = nullptr;      // pinned [8]
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;      // around the linearisation launch; around the Schur launch (global path)
     double* d_parts = nullptr; size_t parts_cap = 0;
     double* d_scratch = nullptr; size_t scratch_cap = 0;
     char* pool = nullptr; char* h_pool = nullptr; size_t pool_cap = 0, hpool_cap = 0;
@@ -2583,6 +2583,8 @@ void ba_state_destroy(vido_ctx* ctx)
     hipFree(S->d_ctl); hipHostFree(S->h_ctl); hipFree(S->d_ticket); hipFree(S->d_spec); hipHostFree(S->h_spec);
     if (S->ev0) hipEventDestroy(S->ev0);
     if (S->ev1) hipEventDestroy(S->ev1);
+    if (S->ev2) hipEventDestroy(S->ev2);
+    if (S->ev3) hipEventDestroy(S->ev3);
     delete S; ctx->ba = nullptr;
 }
 
@@ -2723,7 +2725,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
                                          fprintf(stderr, "[ba setup] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_mark).count()); t_mark = t; };
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->ba) { ctx->ba = new BaState(); HIP_TRY(ctx, hipHostMalloc((void**)&ctx->ba->h_scal, 8 * sizeof(double)));
-                    HIP_TRY(ctx, hipEventCreate(&ctx->ba->ev0)); HIP_TRY(ctx, hipEventCreate(&ctx->ba->ev1)); }
+                    HIP_TRY(ctx, hipEventCreate(&ctx->ba->ev0)); HIP_TRY(ctx, hipEventCreate(&ctx->ba->ev1)); HIP_TRY(ctx, hipEventCreate(&ctx->ba->ev2)); HIP_TRY(ctx, hipEventCreate(&ctx->ba->ev3)); }
     BaState* BS = ctx->ba;
     hipStream_t st = ctx->stream;
     const int n6 = 6 * n_pose, n_ptl = pt_hi - pt_lo;
@@ -3126,7 +3128,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     phase("attributes, launch set-up");
     res->ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     const auto t_loop = std::chrono::steady_clock::now();
-    double lambda = -1, ni = 2, lastChi = 0, chi2_check = 0, ms_lin = 0; int nBad = 0, trials = 0, it = 0, n_lin = 0;
+    double lambda = -1, ni = 2, lastChi = 0, chi2_check = 0, ms_lin = 0, ms_schur = 0; int nBad = 0, trials = 0, it = 0, n_lin = 0, n_schur_timed = 0, n_schur_read = 0;
     // ---- the local window as one persistent launch (k_ba_local_lm): static graph, LDS-resident reduced system, one GPU
     // (opt-in, VIDO_BA_PERSIST=1: measured SLOWER than the host-driven loop below — 3.0 against 2.1 ms per solve alone on the GPU — and its 32 full-CU workgroups never
     //  all become resident while the networks keep the chip busy; DESIGN.md section 9.  The default local-window path is the fused host-driven loop, `fl`.)
@@ -3290,7 +3292,11 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
                 if (lds_path) {
                     hipLaunchKernelGGL(k_ba_schur<0>, dim3(schur_grid), dim3(64 * schur0_waves), lds_schur, st, D, n_ptl, lambda, kcap, BS->d_parts, (const int*)nullptr, (const int*)nullptr, (const int2*)nullptr);
                     hipLaunchKernelGGL(k_ba_fold_parts, dim3(std::min(256, (int)((loc_sz + 255) / 256)), std::min(8, schur_grid)), dim3(256), 0, st, D, BS->d_parts, schur_grid);
-                } else if (use_mfma_schur) hipLaunchKernelGGL(k_ba_schur_mfma, dim3(std::min(n_chunks, 1024)), dim3(1024), SM_LDS_BYTES, st, D, n_ptl, lambda, (const int*)d_chunk_cmin, (const int*)d_lorder, (const int2*)d_lbc);
+                } else if (use_mfma_schur) {
+                    HIP_TRY(ctx, hipEventRecord(BS->ev2, st));
+                    hipLaunchKernelGGL(k_ba_schur_mfma, dim3(std::min(n_chunks, 1024)), dim3(1024), SM_LDS_BYTES, st, D, n_ptl, lambda, (const int*)d_chunk_cmin, (const int*)d_lorder, (const int2*)d_lbc);
+                    HIP_TRY(ctx, hipEventRecord(BS->ev3, st)); n_schur_timed++;
+                }
                 else hipLaunchKernelGGL(k_ba_schur<2>, dim3(std::min(n_chunks, 1024)), dim3(64 * schur2_waves), lds_schur, st, D, n_ptl, lambda, kcap, (double*)nullptr, (const int*)d_chunk_cmin, (const int*)d_lorder, (const int2*)d_lbc);
             }
             if (n_long) hipLaunchKernelGGL(k_ba_schur_long, dim3(n_long), dim3(256), 0, st, D, lambda, (const int*)d_long);
@@ -3341,6 +3347,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             }
             if (!have_chi) { currentChi = iniChi = BS->h_scal[0]; have_chi = true; }
             if (qmax == 0 && !fl) { float ms = 0; if (hipEventElapsedTime(&ms, BS->ev0, BS->ev1) == hipSuccess) ms_lin += ms; }
+            if (!fl && n_schur_timed > n_schur_read) { float ms = 0; if (hipEventElapsedTime(&ms, BS->ev2, BS->ev3) == hipSuccess) ms_schur += ms; n_schur_read = n_schur_timed; }
             const bool ok2 = BS->h_scal[4] > 0.5;
             const double tempChi = ok2 ? BS->h_scal[2] : DBL_MAX, scale = ok2 ? BS->h_scal[3] : 0.0;
             rho = (currentChi - tempChi) / (scale + 1e-3);
@@ -3363,6 +3370,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     }
     }
     res->iterations = it; res->lm_trials = trials; res->lambda_final = lambda;
+    res->ms_schur_kernel = n_schur_read ? ms_schur / n_schur_read : 0.0;
     res->ms_linearize_kernel = n_lin ? ms_lin / n_lin : 0.0;      // (persistent solver: the linearisation phase up to its grid barrier, device clock)
     res->ms_solve_loop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
     if (!cam_final) HIP_TRY(ctx, hipMemcpyAsync(poses.data(), D.cam, (size_t)n_pose * 12 * sizeof(double), hipMemcpyDeviceToHost, st));

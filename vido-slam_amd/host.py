@@ -402,7 +402,8 @@ class BaProblem(C.Structure):
 
 class BaResult(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("lm_trials", C.c_int32), ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
-                ("lambda_final", C.c_double), ("ms_setup", C.c_double), ("ms_solve_loop", C.c_double), ("ms_linearize_kernel", C.c_double)]
+                ("lambda_final", C.c_double), ("ms_setup", C.c_double), ("ms_solve_loop", C.c_double), ("ms_linearize_kernel", C.c_double),
+                ("ms_schur_kernel", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
@@ -542,7 +543,7 @@ def ba_optimize(ctx, k, rank=0, world=1, shard=None, allreduce=None, dynamic=Non
         ctx._check(ctx.lib.vido_ba_optimize(ctx.h, C.byref(p), C.byref(r), fn, user))
     return dict(cam_T=a["cam_T"].reshape(-1, 3, 4), pt_xyz=a["pt_xyz"], iterations=r.iterations, lm_trials=r.lm_trials,
                 chi2_initial=r.chi2_initial, chi2_final=r.chi2_final, lambda_final=r.lambda_final, ms_setup=r.ms_setup,
-                ms_solve_loop=r.ms_solve_loop, ms_linearize_kernel=r.ms_linearize_kernel, **extra)
+                ms_solve_loop=r.ms_solve_loop, ms_linearize_kernel=r.ms_linearize_kernel, ms_schur_kernel=r.ms_schur_kernel, **extra)
 
 
 def pnp_ransac(ctx, pts3d, pts2d, K, max_iters=500, reproj_err=0.4, confidence=0.98, seed=1):
