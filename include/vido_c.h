@@ -305,7 +305,7 @@ int vido_deconv4s2_depthwise(vido_ctx* ctx, const float* x, const float* weight,
 /* 1x1 convolution (stride 1, batch 1) + bias + residual + leaky-ReLU as one fp32 matrix-core GEMM (csrc/conv1x1.hip): conv1 / conv3 / the stride-1 shortcut of
  * BottleneckWithFixedBatchNorm with their folded FrozenBatchNorm2d (maskrcnn_benchmark/modeling/backbone/resnet.py:300-372, layers/batch_norm.py:19-31).  x [cin][hw],
  * y / residual [cout][hw], f32 DEVICE, 16-byte aligned, y != x; bias [cout] or NULL; residual NULL = none; w_packed: [cout][cin] in operand order
- * (vido_slam_amd/nets/ops.py::pack_conv1x1).  slope: 0 = ReLU, 1 = none.  vido_conv1x1_supported: cout % 128 == 0, cin % 32 == 0, hw % 4 == 0, hw >= 128. */
+ * (vido_slam_amd/nets/ops.py::pack_conv1x1).  slope: 0 = ReLU, 1 = none.  vido_conv1x1_supported: cout % 128 == 0, cin % 32 == 0, hw >= 128. */
 int vido_conv1x1_supported(int cin, int cout, int hw);
 int vido_conv1x1_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, int hw, float slope);
 

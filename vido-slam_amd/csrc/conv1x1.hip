@@ -47,11 +47,12 @@ __global__ __launch_bounds__(256) void k_conv1x1(C1Args A)
     // ---- copies: both operands global -> LDS with buffer loads carrying the lds bit (16 bytes per lane, 1 KB per instruction); per-lane offsets are loop invariants, the
     // chunk and the piece ride in the scalar offset.  A piece of A = one (32-row block, group of four k-pairs) of the packed weight: 64 lanes x 4 operands, already in the
     // order the matrix instruction wants.  A piece of B = two rows of the [KC][128] activation chunk (lanes 0..31 row r, 32..63 row r + 1, four positions each); positions
-    // past the end of the image are clamped to its last 16 bytes: those columns are computed and never stored.
+    // past the end of a row read into the next row (past the end of the tensor: the descriptor's range check returns 0): those columns are computed and never stored.
+    // The global side of a copy is only 4-byte aligned when H*W is not a multiple of 4 (25 x 34): the 16-byte copy takes that.
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)A.wp, 0, A.wbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.x, 0, A.xbytes, 0x00020000);
     const unsigned avo = 16u * (unsigned)lane;
-    const unsigned bvo = 4u * ((unsigned)(lane >> 5) * (unsigned)A.N + (unsigned)min(n0 + 4 * (lane & 31), A.N - 4));
+    const unsigned bvo = 4u * ((unsigned)(lane >> 5) * (unsigned)A.N + (unsigned)(n0 + 4 * (lane & 31)));      // (columns past the row's end read the next row, past the tensor's end 0)
     const int kg = A.K / 8;                           // groups per row block of the packed weight
     auto issue = [&](int chunk, int buf, int first, int count) {
 #pragma unroll
@@ -150,11 +151,10 @@ __global__ __launch_bounds__(256) void k_conv1x1(C1Args A)
 
 extern "C" {
 
-/* 1 when vido_conv1x1_bias_act takes the shape: output channels a multiple of 128, input channels a multiple of 32, H*W a multiple of 4 and >= 128 (16-byte copies),
- * activations below 4 GB. */
+/* 1 when vido_conv1x1_bias_act takes the shape: output channels a multiple of 128, input channels a multiple of 32, H*W >= 128, activations below 4 GB. */
 int vido_conv1x1_supported(int cin, int cout, int hw)
 {
-    return cin >= 32 && cin % 32 == 0 && cout >= C1_TM && cout % C1_TM == 0 && hw >= C1_TN && hw % 4 == 0 && 4ll * cin * hw < (1ll << 32) && 4ll * cin * cout < (1ll << 32);
+    return cin >= 32 && cin % 32 == 0 && cout >= C1_TM && cout % C1_TM == 0 && hw >= C1_TN && 4ll * cin * hw < (1ll << 32) && 4ll * cin * cout < (1ll << 32);
 }
 
 /* y = leaky_relu(conv2d(x, w) + bias + residual, slope) for one image, 1x1 kernel, stride 1: x [cin][hw], y / residual [cout][hw] f32 DEVICE tensors (16-byte aligned,
@@ -164,7 +164,7 @@ int vido_conv1x1_supported(int cin, int cout, int hw)
 int vido_conv1x1_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, int hw, float slope)
 {
     if (!ctx) return VIDO_E_INVALID;
-    if (!x || !w_packed || !y || x == y || !vido_conv1x1_supported(cin, cout, hw) || slope < 0.f || slope > 1.f || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w_packed | (uintptr_t)residual) & 15))
+    if (!x || !w_packed || !y || x == y || !vido_conv1x1_supported(cin, cout, hw) || slope < 0.f || slope > 1.f || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 3) || ((uintptr_t)w_packed & 15))
         return vido_set_error(ctx, VIDO_E_INVALID, "conv1x1: no kernel for %d -> %d channels at %d positions (or a pointer is not 16-byte aligned, or slope outside [0, 1])", cin, cout, hw);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;

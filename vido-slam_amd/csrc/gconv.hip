@@ -18,7 +18,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct GcArgs { const float* x; const float* w; const float* bias; const float* in_bias; float* y; int H, W, cpg_in, cpg_out, R, PS; float slope; int gx, total; };
+struct GcArgs { const float* x; const float* w; const float* bias; const float* in_bias; float* y; int H, W, cpg_in, cpg_out, R, PS; float slope; int gx, total; unsigned xbytes, wbytes; };
 
 // Workgroup -> work item.  The hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2; neighbouring position chunks of a group share
 // two halo rows and the group's weights, so the 1-D grid (8 * ceil(total / 8) workgroups) is folded such that every XCD walks a CONTIGUOUS range of (group, chunk) items:
@@ -98,6 +98,95 @@ __global__ __launch_bounds__(256) void k_gconv3x3_m32(GcArgs A)
                 const int co = 8 * (r / 4) + 4 * (lane >> 5) + (r & 3);
                 float v = t ? acc1[r] : acc0[r]; v = v > 0.f ? v : v * A.slope;
                 yo[(size_t)co * HW] = v;
+            }
+        }
+    }
+}
+
+// ---- >= 32 channels per group WITHOUT an input bias (the 1x1 convolution in front applied its own bias + ReLU: csrc/conv1x1.hip), round 4.  Same tiles, items and weight
+// packing as k_gconv3x3_m32; what changes is everything around the matrix instructions, because beside an fp32 matrix instruction every vector-ALU instruction costs
+// ~5.5 cycles of matrix time (tools/ubench/mfma_fillers*.hip) and the kernel above spends ~150 of them per 72 matrix instructions (staging through registers with
+// selects for the padding, 64-bit addresses, LDS address adds):
+//   * the band and the weights go global -> LDS by buffer loads with the lds bit — one dword per lane for the band (the LDS side is the padded, flattened row layout: 64
+//     consecutive positions per instruction; a pad position carries an out-of-range offset, for which the copy writes 0), 16 bytes per lane for the weights; per-lane
+//     offsets are loop invariants, the channel rides in the scalar offset: no vector instruction;
+//   * two LDS buffers, ONE barrier per 8-channel chunk, the next chunk's copies issued right behind it;
+//   * operands at immediate offsets from three per-tap-row base registers, requested two steps ahead.
+__global__ __launch_bounds__(256) void k_gconv3x3_m32d(GcArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float gc_lds[];
+    constexpr int WSZ = 9 * GC_KC * 32, BUF = WSZ + GC_KC * GC32_PS;      // floats per buffer: weights [9][8][32], then the band [8][GC32_PS]
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = A.H, W = A.W, Wpd = W + 2, npos = H * Wpd, RW = A.R * Wpd;
+    const int nchunk = A.cpg_in / GC_KC, ncob = A.cpg_out / 32;
+    const int item = gc_item(A.total); if (item < 0) return;
+    const int chunk = item % A.gx, cob = (item / A.gx) % ncob, g = item / (A.gx * ncob), q0 = chunk * 256, r0 = q0 / Wpd;
+    const unsigned HW = (unsigned)H * (unsigned)W;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.x, 0, A.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)A.w, 0, A.wbytes, 0x00020000);
+    unsigned poff[8];                           // byte offset, inside a channel image, of this lane's 8 positions of the band; bit 30: padding / outside the band
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int p = lane + 64 * j, rr = p / Wpd, xp = p - rr * Wpd, row = r0 - 1 + rr;
+        poff[j] = (p < RW && row >= 0 && row < H && xp >= 1 && xp <= W) ? 4u * (unsigned)(row * W + xp - 1) : 0x40000000u;
+    }
+    const unsigned wvo = 16u * (unsigned)lane;
+    const unsigned wbase = 4u * (unsigned)(((g * ncob + cob) * nchunk) * WSZ);
+    const unsigned xbase = 4u * (unsigned)(g * A.cpg_in) * HW;
+    // wave wv copies channels 2 wv, 2 wv + 1 of a chunk (8 instructions each) and pieces wv, wv + 4, wv + 8 of its 9 KB of weights
+    auto issue = [&](int c, int buf) {
+        float* base = gc_lds + buf * BUF;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned so = xbase + 4u * (unsigned)(c * GC_KC + 2 * wv + h) * HW;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(base + WSZ + (2 * wv + h) * GC32_PS + 64 * j), 4, poff[j], so, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int piece = wv + 4 * q;
+            if (piece < 9) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(base + piece * 256), 16, wvo, wbase + 4u * (unsigned)(c * WSZ + piece * 256), 0, 0);
+        }
+    };
+    const int co_base = g * A.cpg_out + cob * 32;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const float b = A.bias[co_base + 8 * (r / 4) + 4 * (lane >> 5) + (r & 3)]; acc0[r] = b; acc1[r] = b; }
+    typedef const volatile __attribute__((address_space(3))) float* lds_f;      // (volatile: keeps the compiler from pairing neighbouring reads into ds_read2_b32, whose 8-bit
+                                                                               //  offsets cost a vector add per read; a ds_read_b32 takes any of these offsets as an immediate)
+    const int bbase = WSZ + (lane >> 5) * GC32_PS + (q0 + 64 * wv - r0 * Wpd) + (lane & 31);      // B operand of tile 2 wv (tile 2 wv + 1: + 32), tap (0, 0), channel pair 0
+    issue(0, 0);
+    for (int c = 0; c < nchunk; c++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                              // chunk c has landed in buffer c & 1; everybody is done with buffer (c + 1) & 1
+        if (c + 1 < nchunk) issue(c + 1, (c + 1) & 1);
+        lds_f Wb = (lds_f)(gc_lds + (c & 1) * BUF) + lane;
+        lds_f B0 = (lds_f)(gc_lds + (c & 1) * BUF) + bbase, B1 = B0 + Wpd, B2 = B1 + Wpd;      // one base per tap row: everything else is an immediate
+        float a[3], b0[3], b1[3];
+        auto ld = [&](int s) {                                        // step s = tap * 4 + kp
+            const int tap = s >> 2, kp = s & 3; lds_f Bt = tap < 3 ? B0 : (tap < 6 ? B1 : B2);
+            a[s % 3] = Wb[(tap * 8 + 2 * kp) * 32]; b0[s % 3] = Bt[2 * kp * GC32_PS + tap % 3]; b1[s % 3] = Bt[2 * kp * GC32_PS + tap % 3 + 32];
+        };
+        ld(0); ld(1);
+#pragma unroll
+        for (int s = 0; s < 36; s++) {
+            if (s + 2 < 36) ld(s + 2);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s % 3], b0[s % 3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s % 3], b1[s % 3], acc1, 0, 0, 0);
+        }
+    }
+    // D[i][j]: lane = 32 * ((i / 4) & 1) + j, register = 4 * (i / 8) + (i & 3)  ->  a register holds one output channel of 32 consecutive positions per half wave
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int q = q0 + 64 * wv + 32 * t + (lane & 31), yy = q / Wpd, xx = q - yy * Wpd;
+        if (q < npos && xx < W) {
+            float* yo = A.y + (size_t)co_base * HW + (size_t)yy * W + xx;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = 8 * (r / 4) + 4 * (lane >> 5) + (r & 3);
+                const float v = t ? acc1[r] : acc0[r];
+                yo[(size_t)co * HW] = fmaxf(v, v * A.slope);
             }
         }
     }
@@ -286,8 +375,15 @@ int vido_gconv3x3_bias_act(vido_ctx* ctx, const float* x, const float* in_bias, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int rc = gc_lds_limit(ctx); if (rc) return rc; }
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
-    GcArgs A{x, w_packed, bias, in_bias, y, H, W, cpg_in, cpg_out, p.R, p.PS, slope, p.gx, p.gx * groups * (p.kind == 32 ? cpg_out / 32 : 1)};
-    if (p.kind == 32) hipLaunchKernelGGL(k_gconv3x3_m32, dim3(8 * ((A.total + 7) / 8)), dim3(256), p.lds, st, A);
+    const long long xb = 4ll * groups * cpg_in * H * W, wb = 4ll * vido_gconv3x3_packed_size(groups, cpg_in, cpg_out);
+    GcArgs A{x, w_packed, bias, in_bias, y, H, W, cpg_in, cpg_out, p.R, p.PS, slope, p.gx, p.gx * groups * (p.kind == 32 ? cpg_out / 32 : 1), (unsigned)xb, (unsigned)wb};
+    static const bool no_dma32 = getenv("VIDO_GCONV_NO_DMA") != nullptr;
+    if (p.kind == 32 && !in_bias && !no_dma32 && xb < (1ll << 30) && wb < (1ll << 32) && slope >= 0.f && slope <= 1.f && ((uintptr_t)w_packed & 15) == 0) {
+        static bool attr[64] = {};
+        if (!attr[ctx->device & 63]) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gconv3x3_m32d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * p.lds))); attr[ctx->device & 63] = true; }
+        hipLaunchKernelGGL(k_gconv3x3_m32d, dim3(8 * ((A.total + 7) / 8)), dim3(256), 2 * p.lds, st, A);
+    }
+    else if (p.kind == 32) hipLaunchKernelGGL(k_gconv3x3_m32, dim3(8 * ((A.total + 7) / 8)), dim3(256), p.lds, st, A);
     else if (p.kind == 8) gc_m16_launch<8>(p, groups, st, A);
     else gc_m16_launch<16>(p, groups, st, A);
     HIP_TRY(ctx, hipGetLastError());

@@ -46,17 +46,17 @@ def fold_batchnorm(net, ops):
             if c2.groups > 1 and tuple(c2.stride) == (1, 1) and tuple(c2.padding) == (1, 1) and tuple(c2.dilation) == (1, 1) and not os.environ.get("VIDO_NO_GCONV"):
                 from .ops import pack_gconv3x3
                 m._w2p = pack_gconv3x3(m._w2, c2.groups)
-            # conv3 as our own fp32 matrix-core GEMM with bias + shortcut + ReLU in its epilogue (csrc/conv1x1.hip).  Measured on the detector's shapes (tools/prof_conv1x1.py,
-            # profiles/r4/conv1x1_microbench_v3.txt) the GEMM alone runs where the library's does (66 us / 107 TFLOP/s at 1024 -> 1024 on 50 x 68 against 66-68), so a
-            # convolution without an epilogue (conv1: its bias + ReLU ride on conv2's operand reads) stays with the library; WITH the epilogue it saves the library's separate
-            # pass over the output (8-13 us per block) on every layer it has a form for.  VIDO_CONV1X1=all takes every 1x1 convolution.
+            # the 1x1 convolutions as our own fp32 matrix-core GEMM with the bias (+ shortcut) + ReLU in its epilogue (csrc/conv1x1.hip).  Measured on the detector's shapes
+            # (tools/prof_conv1x1.py, profiles/r4/conv1x1_microbench_v3.txt) the GEMM alone runs where the library's does (66 us / 107 TFLOP/s at 1024 -> 1024 on 50 x 68 against
+            # 66-68); what it saves is the pass behind the library's: conv3's bias + shortcut + ReLU (8-13 us per block), the stride-1 shortcut's bias, and conv1's bias + ReLU,
+            # which otherwise ride on conv2's operand reads as vector instructions inside ITS matrix loop (detector 9.43 -> 9.29 ms).  VIDO_CONV1X1=conv3 keeps conv1 / the
+            # shortcut with the library, VIDO_NO_CONV1X1=1 everything.
             m._w1p = m._w3p = m._wdp = None; m._c1x1_min_tiles = 0
-            mode = os.environ.get("VIDO_CONV1X1", "")
+            mode = os.environ.get("VIDO_CONV1X1", "all")
             if not os.environ.get("VIDO_NO_CONV1X1") and hasattr(ops, "conv1x1_bias_act"):
                 from .ops import pack_conv1x1
                 m._w3p = pack_conv1x1(m._w3)
                 if mode == "all":
-                    m._c1x1_min_tiles = 0
                     if tuple(m.conv1.stride) == (1, 1): m._w1p = pack_conv1x1(m._w1)
                     if m.downsample is not None and tuple(m.downsample[0].stride) == (1, 1): m._wdp = pack_conv1x1(m._wd)
         elif isinstance(m, _Stem):

@@ -81,15 +81,16 @@ class _Bottleneck(nn.Module):              # resnet.py:277-372 (BottleneckWithFi
             ep = self._ep; c1, c2 = self.conv1, self.conv2; ops = self._ops
             b1x = x.shape[0] == 1
             hw_in = x.shape[2] * x.shape[3]
+            b1_done = False
             if self._w1p is not None and b1x and ops.conv1x1_supported(x.shape[1], self._w1.shape[0], hw_in):
-                y = ops.conv1x1_bias_act(x.contiguous(), self._w1p)                      # (its bias + ReLU ride on conv2's operand reads, or run below)
+                y = ops.conv1x1_bias_act(x.contiguous(), self._w1p, self._b1, None, 0.0); b1_done = True      # our GEMM: its bias + ReLU leave through its accumulators
             else:
-                y = F.conv2d(x, self._w1, None, c1.stride)
+                y = F.conv2d(x, self._w1, None, c1.stride)                                                   # the library's: they ride on conv2's operand reads, or run below
             if self._w2p is not None and y.shape[0] == 1 and self._ops.gconv3x3_supported(y.shape[2], y.shape[3], c2.in_channels // c2.groups, c2.out_channels // c2.groups):
-                # conv1's bias + ReLU ride on conv2's operand reads, conv2's own leave through its accumulators: two passes over the activations less per block
-                y = self._ops.gconv3x3_bias_act(y, self._w2p, self._b2, c2.groups, 0.0, in_bias=self._b1)
+                # conv2's own bias + ReLU leave through its accumulators; after a library conv1 its bias + ReLU are applied where conv2 reads its operands
+                y = self._ops.gconv3x3_bias_act(y, self._w2p, self._b2, c2.groups, 0.0, in_bias=None if b1_done else self._b1)
             else:
-                y = ep(F.conv2d(ep(y, self._b1, None, 0.0), self._w2, None, c2.stride, c2.padding, c2.dilation, c2.groups), self._b2, None, 0.0)
+                y = ep(F.conv2d(y if b1_done else ep(y, self._b1, None, 0.0), self._w2, None, c2.stride, c2.padding, c2.dilation, c2.groups), self._b2, None, 0.0)
             if self.downsample is None:
                 sc = x
             elif self._wdp is not None and b1x and ops.conv1x1_supported(x.shape[1], self._wd.shape[0], hw_in):
