@@ -308,6 +308,8 @@ int vido_deconv4s2_depthwise(vido_ctx* ctx, const float* x, const float* weight,
  * (vido_slam_amd/nets/ops.py::pack_conv1x1).  slope: 0 = ReLU, 1 = none.  vido_conv1x1_supported: cout % 128 == 0, cin % 32 == 0, hw >= 128. */
 int vido_conv1x1_supported(int cin, int cout, int hw);
 int vido_conv1x1_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, int hw, float slope);
+/* ... with the residual at half the resolution [cout][h/2][w/2], added nearest-upsampled: the FPN's lateral convolution + top-down sum (backbone/fpn.py:55-66); h, w even */
+int vido_conv1x1_bias_up2_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual_half, float* y, int cin, int cout, int h, int w, float slope);
 
 /* 3x3 stride-1 padding-1 convolution + bias + leaky-ReLU as Winograd F(2x2, 3x3) with its sixteen channel contractions on the fp32 matrix pipe (csrc/wino.hip): the
  * dense 3x3 convolutions of LiteFlowNet (flow_net/src/layers.py:39-315), the FPN output / RPN head / mask head convolutions of the detector

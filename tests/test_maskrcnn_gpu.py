@@ -269,3 +269,23 @@ def test_bottleneck_with_matrix_core_1x1_equals_library_path(vido, ctx):
             blk._w1p = blk._w3p = blk._wdp = None
             y_lib = blk(x)
         assert float((y_fast - y_lib).abs().max()) < 1e-4 * max(1.0, float(y_lib.abs().max()))
+
+
+@pytest.mark.gpu
+def test_fpn_lateral_with_upsampled_sum_equals_the_reference_form(vido, ctx):
+    """_FPN._inner on csrc/conv1x1.hip (lateral 1x1 convolution + bias + nearest-upsampled coarser level in the GEMM's epilogue, fpn.py:55-66) against conv2d + F.interpolate + add in
+    float64, incl. a map whose size is not a multiple of 4 and the top level (no sum)."""
+    from vido_slam_amd.nets.ops import HipOps
+    ops = HipOps(ctx)
+    g = torch.Generator().manual_seed(17)
+    for cin, cout, H, W in ((512, 256, 24, 36), (256, 256, 26, 34), (1024, 128, 10, 14)):
+        conv = torch.nn.Conv2d(cin, cout, 1).cuda()
+        x = torch.randn(1, cin, H, W, generator=g).cuda(); top = torch.randn(1, cout, H // 2, W // 2, generator=g).cuda()
+        with torch.no_grad():
+            y = ops.conv1x1_conv(conv, x, 1.0, residual_up2=top); y0 = ops.conv1x1_conv(conv, x, 1.0)
+            ref0 = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double())
+            ref = ref0 + torch.nn.functional.interpolate(top.double(), scale_factor=2, mode="nearest")
+        assert y is not None and float((y.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+        assert float((y0.double() - ref0).abs().max()) < 2e-5 * max(1.0, float(ref0.abs().max()))
+    with pytest.raises((vido.VidoError, AssertionError)):                   # odd map: no half-resolution residual for it
+        ops.conv1x1_bias_act(torch.zeros(1, 64, 13, 12, device="cuda"), torch.zeros(4, 8, 64, 4, device="cuda"), None, None, 1.0, residual_up2=torch.zeros(1, 128, 6, 6, device="cuda"))

@@ -28,10 +28,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define C1_TM 128
 #define C1_TN 128
 
-struct C1Args { const float* x; const float* wp; const float* bias; const float* res; float* y; int M, N, K, mt, total, nchunk; float slope; unsigned xbytes, wbytes; };
+struct C1Args { const float* x; const float* wp; const float* bias; const float* res; float* y; int M, N, K, mt, total, nchunk; float slope; unsigned xbytes, wbytes; int W; };
 
-// RES: a residual is added; KC: input channels per chunk and barrier (64: 128 KB of LDS, 128 matrix instructions per wave between barriers; 32 for K % 64 != 0)
-template <bool RES, int KC>
+// RES: 1 a residual [cout][H*W] is added, 2 a residual at HALF the resolution [cout][H/2][W/2] is added nearest-upsampled (the FPN's top-down path: fpn.py
+// `F.interpolate(last_inner, scale_factor=2, mode="nearest") + inner_lateral`); KC: input channels per chunk and barrier (64: 128 KB of LDS, 128 matrix instructions per
+// wave between barriers; 32 for K % 64 != 0)
+template <int RES, int KC>
 __global__ __launch_bounds__(256) void k_conv1x1(C1Args A)
 {
     constexpr int NG = KC / 8;                        // groups of four k-pairs (16 matrix instructions per wave) per chunk
@@ -132,11 +134,13 @@ __global__ __launch_bounds__(256) void k_conv1x1(C1Args A)
             const int co0 = m0 + 64 * wm + 32 * mi + 4 * (lane >> 5), q = n0 + 64 * wn + 32 * ni + (lane & 31);
             if (q < A.N) {
                 float rv[16], bv[16];
+                size_t rq = (size_t)q, rn = (size_t)A.N;                  // residual position and plane size
+                if (RES == 2) { const int yy = q / A.W, xx = q - yy * A.W; rq = (size_t)(yy >> 1) * (A.W >> 1) + (xx >> 1); rn = (size_t)(A.N / A.W >> 1) * (A.W >> 1); }
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int co = co0 + 8 * (r >> 2) + (r & 3);
                     bv[r] = A.bias ? A.bias[co] : 0.f;
-                    rv[r] = RES ? A.res[(size_t)co * A.N + q] : 0.f;
+                    rv[r] = RES ? A.res[(size_t)co * rn + rq] : 0.f;
                 }
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
@@ -161,29 +165,43 @@ int vido_conv1x1_supported(int cin, int cout, int hw)
  * y != x), bias [cout] or NULL, residual NULL when there is none.  w_packed: the weight [cout][cin] in operand order, element (co, k) at
  * [co / 32][k / 8][32 * (k & 1) + co % 32][(k % 8) / 2]  (vido_slam_amd/nets/ops.py::pack_conv1x1).  slope 0 = ReLU, 1 = none (0 <= slope <= 1).  Enqueues on the adopted
  * stream; capturable. */
-int vido_conv1x1_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, int hw, float slope)
+static int c1_launch(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, int res_mode, float* y, int cin, int cout, int hw, int w, float slope)
 {
     if (!ctx) return VIDO_E_INVALID;
     if (!x || !w_packed || !y || x == y || !vido_conv1x1_supported(cin, cout, hw) || slope < 0.f || slope > 1.f || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 3) || ((uintptr_t)w_packed & 15))
-        return vido_set_error(ctx, VIDO_E_INVALID, "conv1x1: no kernel for %d -> %d channels at %d positions (or a pointer is not 16-byte aligned, or slope outside [0, 1])", cin, cout, hw);
+        return vido_set_error(ctx, VIDO_E_INVALID, "conv1x1: no kernel for %d -> %d channels at %d positions (or a pointer is misaligned, or slope outside [0, 1])", cin, cout, hw);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
     const int mt = cout / C1_TM, ntl = (hw + C1_TN - 1) / C1_TN, total = mt * ntl;
     static const int force_kc = [] { const char* e = getenv("VIDO_CONV1X1_KC"); return e ? atoi(e) : 0; }();
     const int kc = (cin % 64 == 0 && force_kc != 32) ? 64 : 32;
-    C1Args A{x, w_packed, bias, residual, y, cout, hw, cin, mt, total, cin / kc, slope, (unsigned)(4ll * cin * hw), (unsigned)(4ll * cin * cout)};
+    C1Args A{x, w_packed, bias, residual, y, cout, hw, cin, mt, total, cin / kc, slope, (unsigned)(4ll * cin * hw), (unsigned)(4ll * cin * cout), w};
     const dim3 grid(8 * ((total + 7) / 8)), blk(256);
     constexpr size_t LDS64 = (size_t)2 * (4 * 8 * 256 + 64 * C1_TN) * 4, LDS32 = (size_t)2 * (4 * 4 * 256 + 32 * C1_TN) * 4;
     static bool attr[64] = {};
     if (!attr[ctx->device & 63]) {
-        for (const void* f : {(const void*)k_conv1x1<true, 64>, (const void*)k_conv1x1<false, 64>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS64));
-        for (const void* f : {(const void*)k_conv1x1<true, 32>, (const void*)k_conv1x1<false, 32>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS32));
+        for (const void* f : {(const void*)k_conv1x1<0, 64>, (const void*)k_conv1x1<1, 64>, (const void*)k_conv1x1<2, 64>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS64));
+        for (const void* f : {(const void*)k_conv1x1<0, 32>, (const void*)k_conv1x1<1, 32>, (const void*)k_conv1x1<2, 32>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS32));
         attr[ctx->device & 63] = true;
     }
-    if (kc == 64) { if (residual) hipLaunchKernelGGL((k_conv1x1<true, 64>), grid, blk, LDS64, st, A); else hipLaunchKernelGGL((k_conv1x1<false, 64>), grid, blk, LDS64, st, A); }
-    else { if (residual) hipLaunchKernelGGL((k_conv1x1<true, 32>), grid, blk, LDS32, st, A); else hipLaunchKernelGGL((k_conv1x1<false, 32>), grid, blk, LDS32, st, A); }
+    const int rm = residual ? res_mode : 0;
+    if (kc == 64) { if (rm == 2) hipLaunchKernelGGL((k_conv1x1<2, 64>), grid, blk, LDS64, st, A); else if (rm) hipLaunchKernelGGL((k_conv1x1<1, 64>), grid, blk, LDS64, st, A); else hipLaunchKernelGGL((k_conv1x1<0, 64>), grid, blk, LDS64, st, A); }
+    else { if (rm == 2) hipLaunchKernelGGL((k_conv1x1<2, 32>), grid, blk, LDS32, st, A); else if (rm) hipLaunchKernelGGL((k_conv1x1<1, 32>), grid, blk, LDS32, st, A); else hipLaunchKernelGGL((k_conv1x1<0, 32>), grid, blk, LDS32, st, A); }
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
+}
+
+int vido_conv1x1_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, int hw, float slope)
+{
+    return c1_launch(ctx, x, w_packed, bias, residual, 1, y, cin, cout, hw, hw, slope);
+}
+
+/* The same with the residual at HALF the resolution, added nearest-upsampled: y[co][yy][xx] = act(conv + bias[co] + residual_half[co][yy / 2][xx / 2]) — the FPN's
+ * lateral convolution + top-down sum (maskrcnn_benchmark/modeling/backbone/fpn.py:55-66) as one launch.  h, w even; residual_half [cout][h / 2][w / 2]. */
+int vido_conv1x1_bias_up2_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual_half, float* y, int cin, int cout, int h, int w, float slope)
+{
+    if (ctx && (h < 2 || w < 2 || (h & 1) || (w & 1) || !residual_half)) return vido_set_error(ctx, VIDO_E_INVALID, "conv1x1 (upsampled residual): %d x %d must be even and the residual given", h, w);
+    return c1_launch(ctx, x, w_packed, bias, residual_half, 2, y, cin, cout, h * w, w, slope);
 }
 
 }  // extern "C"

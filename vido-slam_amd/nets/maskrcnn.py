@@ -160,11 +160,27 @@ class _FPN(nn.Module):                     # fpn.py:7-82 with LastLevelMaxPool
                 return y
         return conv(x)
 
+    def _inner(self, i, x, top=None):
+        """fpn.py:55-66: the lateral 1x1 convolution (+ bias) + the nearest-upsampled coarser level — one GEMM launch with both in its epilogue (csrc/conv1x1.hip) where the
+        maps have that form (even sizes), else the library convolution, the upsampling and the sum."""
+        conv = getattr(self, "fpn_inner%d" % i)
+        if self._ops is not None and x.is_cuda and hasattr(self._ops, "conv1x1_conv") and not os.environ.get("VIDO_NO_CONV1X1"):
+            if top is None:
+                y = self._ops.conv1x1_conv(conv, x, 1.0)
+            elif x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and tuple(top.shape[2:]) == (x.shape[2] // 2, x.shape[3] // 2):
+                y = self._ops.conv1x1_conv(conv, x, 1.0, residual_up2=top)
+            else:
+                y = None
+            if y is not None:
+                return y
+        y = conv(x)
+        return y if top is None else y + F.interpolate(top, scale_factor=2, mode="nearest")
+
     def forward(self, feats):
-        inner = getattr(self, "fpn_inner%d" % self.n)(feats[-1])
+        inner = self._inner(self.n, feats[-1])
         out = [self._layer(self.n, inner)]
         for i in range(self.n - 1, 0, -1):
-            inner = getattr(self, "fpn_inner%d" % i)(feats[i - 1]) + F.interpolate(inner, scale_factor=2, mode="nearest")
+            inner = self._inner(i, feats[i - 1], inner)
             out.insert(0, self._layer(i, inner))
         out.append(F.max_pool2d(out[-1], 1, 2, 0))
         return out

@@ -133,21 +133,39 @@ class HipOps:
     def conv1x1_supported(self, cin, cout, hw):
         return bool(self.ctx.lib.vido_conv1x1_supported(int(cin), int(cout), int(hw)))
 
-    def conv1x1_bias_act(self, x, w_packed, bias=None, residual=None, slope=1.0):
+    def conv1x1_bias_act(self, x, w_packed, bias=None, residual=None, slope=1.0, residual_up2=None):
         """leaky_relu(conv2d(x, w) + bias + residual, slope) for one image, 1x1 kernel, stride 1, as one matrix-core GEMM launch (csrc/conv1x1.hip); w_packed = pack_conv1x1(w).
-        slope 0 = ReLU, 1 = none."""
+        slope 0 = ReLU, 1 = none.  residual_up2: a residual at half the resolution, added nearest-upsampled (the FPN's top-down sum)."""
         assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and x.shape[0] == 1
         _, cin, H, W = x.shape
         cout = w_packed.shape[0] * 32
-        assert w_packed.shape[1] * 8 == cin and 0.0 <= slope <= 1.0
+        assert w_packed.shape[1] * 8 == cin and 0.0 <= slope <= 1.0 and (residual is None or residual_up2 is None)
         out = torch.empty((1, cout, H, W), device=x.device, dtype=torch.float32)
-        if residual is not None:
-            residual = residual.contiguous(); assert residual.shape == out.shape
         self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * cout * cin * H * W      # (torch's FlopCounterMode does not see this launch; bench.py adds it)
         self._adopt_stream()
-        self.ctx._check(self.ctx.lib.vido_conv1x1_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(w_packed.data_ptr()), C.c_void_p(bias.data_ptr()) if bias is not None else None,
+        pb = C.c_void_p(bias.data_ptr()) if bias is not None else None
+        if residual_up2 is not None:
+            residual_up2 = residual_up2.contiguous(); assert tuple(residual_up2.shape) == (1, cout, H // 2, W // 2) and H % 2 == 0 and W % 2 == 0
+            self.ctx._check(self.ctx.lib.vido_conv1x1_bias_up2_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(w_packed.data_ptr()), pb, C.c_void_p(residual_up2.data_ptr()),
+                                                                   C.c_void_p(out.data_ptr()), int(cin), int(cout), int(H), int(W), C.c_float(slope)))
+            return out
+        if residual is not None:
+            residual = residual.contiguous(); assert residual.shape == out.shape
+        self.ctx._check(self.ctx.lib.vido_conv1x1_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(w_packed.data_ptr()), pb,
                                                            C.c_void_p(residual.data_ptr()) if residual is not None else None, C.c_void_p(out.data_ptr()), int(cin), int(cout), int(H * W), C.c_float(slope)))
         return out
+
+    def conv1x1_conv(self, conv, x, slope=1.0, residual=None, residual_up2=None):
+        """The 1x1 convolution `conv` (nn.Conv2d, stride 1) + bias (+ residual) + activation through conv1x1_bias_act when the layer has that form, else None; the packed weight
+        is cached on the module and rebuilt when the weight tensor changes."""
+        w = conv.weight
+        if (tuple(w.shape[2:]) != (1, 1) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (0, 0) or conv.groups != 1 or not x.is_cuda or x.shape[0] != 1
+                or not self.conv1x1_supported(w.shape[1], w.shape[0], x.shape[2] * x.shape[3])):
+            return None
+        key = (w.data_ptr(), w._version, str(x.device))
+        if getattr(conv, "_c1_key", None) != key:
+            conv._c1_w = pack_conv1x1(w).to(x.device); conv._c1_key = key
+        return self.conv1x1_bias_act(x.contiguous(), conv._c1_w, conv.bias, residual, slope, residual_up2)
 
     def wino3x3_supported(self, cin, cout, H, W):
         return bool(self.ctx.lib.vido_wino3x3_supported(int(cin), int(cout), int(H), int(W)))
