@@ -247,13 +247,14 @@ def test_conv1x1_matrix_core_gemm_equals_conv2d(vido, ctx, cin, cout, H, W):
 
 
 @pytest.mark.gpu
-def test_bottleneck_with_matrix_core_1x1_equals_library_path(vido, ctx):
+def test_bottleneck_with_matrix_core_1x1_equals_library_path(vido, ctx, monkeypatch):
     """_Bottleneck.forward with conv1 / conv3 / the stride-1 shortcut on csrc/conv1x1.hip (bias, shortcut add and ReLU in the GEMM's epilogue) against the same block on the
     library convolutions + the bias / residual pass."""
     from vido_slam_amd.nets import maskrcnn as M
     from vido_slam_amd.nets.fuse import fold_batchnorm
     from vido_slam_amd.nets.ops import HipOps
     from vido_slam_amd.nets.weights import fill_maskrcnn
+    monkeypatch.setattr("vido_slam_amd.nets.ops._C1X1_MIN_TILES", 0)          # (test-sized maps: by default a layer of fewer than 160 tiles stays with the library)
     for cin, mid, cout in ((64, 256, 256), (256, 256, 256)):                     # first block of layer1 (with the stride-1 shortcut convolution) and a plain one
         blk = M._Bottleneck(cin, mid, cout, 32, False, 1)
         fill_maskrcnn(blk); blk = blk.cuda().eval()
@@ -272,11 +273,13 @@ def test_bottleneck_with_matrix_core_1x1_equals_library_path(vido, ctx):
 
 
 @pytest.mark.gpu
-def test_fpn_lateral_with_upsampled_sum_equals_the_reference_form(vido, ctx):
+def test_fpn_lateral_with_upsampled_sum_equals_the_reference_form(vido, ctx, monkeypatch):
     """_FPN._inner on csrc/conv1x1.hip (lateral 1x1 convolution + bias + nearest-upsampled coarser level in the GEMM's epilogue, fpn.py:55-66) against conv2d + F.interpolate + add in
     float64, incl. a map whose size is not a multiple of 4 and the top level (no sum)."""
-    from vido_slam_amd.nets.ops import HipOps
+    from vido_slam_amd.nets.ops import HipOps, conv1x1_fills_chip
     ops = HipOps(ctx)
+    assert conv1x1_fills_chip(256, 100 * 136) and not conv1x1_fills_chip(256, 50 * 68) and not conv1x1_fills_chip(2048, 25 * 34)      # FPN P3 yes, P4 and layer4 no
+    monkeypatch.setattr("vido_slam_amd.nets.ops._C1X1_MIN_TILES", 0)
     g = torch.Generator().manual_seed(17)
     for cin, cout, H, W in ((512, 256, 24, 36), (256, 256, 26, 34), (1024, 128, 10, 14)):
         conv = torch.nn.Conv2d(cin, cout, 1).cuda()

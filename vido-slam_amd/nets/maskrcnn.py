@@ -82,7 +82,8 @@ class _Bottleneck(nn.Module):              # resnet.py:277-372 (BottleneckWithFi
             b1x = x.shape[0] == 1
             hw_in = x.shape[2] * x.shape[3]
             b1_done = False
-            if self._w1p is not None and b1x and ops.conv1x1_supported(x.shape[1], self._w1.shape[0], hw_in):
+            from .ops import conv1x1_fills_chip as fills
+            if self._w1p is not None and b1x and ops.conv1x1_supported(x.shape[1], self._w1.shape[0], hw_in) and fills(self._w1.shape[0], hw_in):
                 y = ops.conv1x1_bias_act(x.contiguous(), self._w1p, self._b1, None, 0.0); b1_done = True      # our GEMM: its bias + ReLU leave through its accumulators
             else:
                 y = F.conv2d(x, self._w1, None, c1.stride)                                                   # the library's: they ride on conv2's operand reads, or run below
@@ -93,12 +94,12 @@ class _Bottleneck(nn.Module):              # resnet.py:277-372 (BottleneckWithFi
                 y = ep(F.conv2d(y if b1_done else ep(y, self._b1, None, 0.0), self._w2, None, c2.stride, c2.padding, c2.dilation, c2.groups), self._b2, None, 0.0)
             if self.downsample is None:
                 sc = x
-            elif self._wdp is not None and b1x and ops.conv1x1_supported(x.shape[1], self._wd.shape[0], hw_in):
+            elif self._wdp is not None and b1x and ops.conv1x1_supported(x.shape[1], self._wd.shape[0], hw_in) and fills(self._wd.shape[0], hw_in):
                 sc = ops.conv1x1_bias_act(x.contiguous(), self._wdp, self._bd, None, 1.0)
             else:
                 sc = ep(F.conv2d(x, self._wd, None, self.downsample[0].stride), self._bd, None, 1.0)
             if (self._w3p is not None and y.shape[0] == 1 and ops.conv1x1_supported(y.shape[1], self._w3.shape[0], y.shape[2] * y.shape[3])
-                    and (self._w3.shape[0] // 128) * ((y.shape[2] * y.shape[3] + 127) // 128) >= self._c1x1_min_tiles):
+                    and (fills(self._w3.shape[0], y.shape[2] * y.shape[3]) or self._c1x1_min_tiles < 0)):
                 return ops.conv1x1_bias_act(y.contiguous(), self._w3p, self._b3, sc, 0.0)      # bias + shortcut + ReLU leave through the GEMM's accumulators: no pass over the output
             return ep(F.conv2d(y, self._w3), self._b3, sc.contiguous(), 0.0)
         y = F.relu(self.bn1(self.conv1(x)))

@@ -162,6 +162,8 @@ class HipOps:
         if (tuple(w.shape[2:]) != (1, 1) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (0, 0) or conv.groups != 1 or not x.is_cuda or x.shape[0] != 1
                 or not self.conv1x1_supported(w.shape[1], w.shape[0], x.shape[2] * x.shape[3])):
             return None
+        if not conv1x1_fills_chip(w.shape[0], x.shape[2] * x.shape[3]):
+            return None
         key = (w.data_ptr(), w._version, str(x.device))
         if getattr(conv, "_c1_key", None) != key:
             conv._c1_w = pack_conv1x1(w).to(x.device); conv._c1_key = key
@@ -391,6 +393,16 @@ class HipOps:
                                                            C.c_void_p(labels.data_ptr()) if n else None, n, masks.shape[-1] if n else 28, padding, C.c_float(thresh), H, W,
                                                            C.c_void_p(out.data_ptr())))
         return out
+
+
+_C1X1_MIN_TILES = int(os.environ.get("VIDO_CONV1X1_MIN_TILES", "160"))
+
+
+def conv1x1_fills_chip(cout, hw):
+    """csrc/conv1x1.hip works on 128 x 128 tiles, one per CU, each walking ALL input channels: a layer with few tiles (layer4's 2048 -> 2048 on 25 x 34: 112; the FPN laterals of
+    P4 / P5: 54 / 14) leaves most of the 256 CUs idle for as long as a chip-filling layer takes — measured 119 us against the library's 68 at 112 tiles.  Callers keep the
+    library below VIDO_CONV1X1_MIN_TILES (default 160)."""
+    return (int(cout) // 128) * ((int(hw) + 127) // 128) >= _C1X1_MIN_TILES
 
 
 def pack_conv1x1(w):
