@@ -331,6 +331,9 @@ def main():
         out["roofline_error"] = "%s: %s" % (type(e).__name__, e); traceback.print_exc(file=sys.stderr)
         ctx = V.Context(device=local_rank, width=W, height=H, max_batch=1)
 
+    # the side measurements include host-side C++ set-up that runs on the library's own worker threads: torch's OpenMP pool, still spinning after the pipeline's CPU-side tensor
+    # ops, took their cores away (global BA set-up 4 ms in a fresh process, 12-22 ms behind a torch CPU op; profiles/r4/global_ba_setup_variance.txt)
+    torch_threads = torch.get_num_threads(); torch.set_num_threads(1)
     if not args.no_extra:
       try:
           P = V.problems
@@ -488,7 +491,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_baseline > 0:
         try:
             from oracle import pyoracle as O
-            nthreads = torch.get_num_threads()
+            torch.set_num_threads(torch_threads); nthreads = torch.get_num_threads()
             cops = O.OracleNetOps(O)
             corr = lambda a, b, s_: torch.from_numpy(O.correlation(a.numpy(), b.numpy(), s_))
             lfn = V.nets.fill_deterministic(V.nets.LiteFlowNet(corr), 1).eval()

@@ -2572,6 +2572,8 @@ struct BaState {
     int* d_long = nullptr; size_t long_cap = 0;      // landmarks with > 64 observations
     double* d_bcr = nullptr; size_t bcr_cap = 0;     // block-cyclic-reduction workspace (superblocks D, L x2, GL, GR, b, y)
     int* d_ticket = nullptr;                        // k_ba_backsub_chi2_local: workgroups finished so far (reset by the last one)
+    std::vector<int> hv_i[8]; std::vector<double> hv_d;      // host scratch of the set-up (observation tables of the call): kept across calls — as fresh vectors they were ~40 MB of
+                                                              // mmap + page faults + zero fill per global solve, the largest and most variable part of its host time
     struct BaSpecCtl* d_spec = nullptr; struct BaSpecCtl* h_spec = nullptr; int spec_last_trials = 12;      // the enqueued-ahead local solve: LM state on the device, its pinned mirror, the previous solve's trial count
     struct BaLmCtl* d_ctl = nullptr; struct BaLmCtl* h_ctl = nullptr; unsigned bar_base = 0;   // persistent local-window solver: control block (device + pinned mirror), barrier count so far
 };
@@ -2684,6 +2686,18 @@ static int chol_large(vido_ctx* ctx, double* A, int n, double* x, double* okflag
     return VIDO_OK;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when a kernel needs MORE than it has been given on this device: the local window asks for the same sizes every
+// frame, and the call is not free — it takes the runtime's lock (sporadically 6-13 ms when another thread of the process holds it: measured as the largest and the most
+// variable part of the global solve's host set-up).
+static hipError_t ba_lds_attr(int device, const void* fn, size_t bytes)
+{
+    static std::mutex mu; static std::vector<std::pair<std::pair<int, const void*>, size_t>> have;
+    std::lock_guard<std::mutex> g(mu);
+    for (auto& h : have) if (h.first.first == device && h.first.second == fn) { if (h.second >= bytes) return hipSuccess; const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e == hipSuccess) h.second = bytes; return e; }
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have.push_back({{device, fn}, bytes});
+    return e;
+}
 static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, vido_ba_result* res, vido_allreduce_fn allreduce, void* user, const BaDevInputs* DI = nullptr);
 // the local-window solve on observation / landmark arrays that already live on the device (csrc/bawin.hip): prob carries the cameras, the camera-camera factors and the
 // parameters; its observation and point fields are ignored
@@ -2813,7 +2827,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     // ---- host preprocessing: keep this shard's observations, sort by camera, build the landmark-major slots
     HostPool& HP = HostPool::get();
     const bool par = !DI && p.n_obs >= 200000 && HP.size() > 1;      // the same tables either way; see HostPool
-    std::vector<int> keep;
+    std::vector<int>& keep = BS->hv_i[0]; keep.clear();
     if (par) {
         std::vector<int> bad(HP.size(), -1), cntk(HP.size() + 1, 0);
         HP.chunks((size_t)p.n_obs, [&](size_t lo, size_t hi, int t) { int c = 0; for (size_t k = lo; k < hi; k++) {
@@ -2831,9 +2845,9 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     }
     const int no = DI ? DI->no : (int)keep.size();
     if (!DI) {   // stable counting sort by camera (O(n); a comparison sort of 1M observations costs more than the whole LM loop)
-        std::vector<int> sorted(no);
+        std::vector<int>& sorted = BS->hv_i[1]; sorted.resize(no);
         if (par) {
-            std::vector<int> rank(no), bs;
+            std::vector<int>& rank = BS->hv_i[2]; rank.resize(no); std::vector<int> bs;
             par_counting_rank(HP, (size_t)no, n_pose, [&](size_t t) { return perm[p.obs_cam[keep[t]]]; }, rank.data(), bs);
             HP.chunks((size_t)no, [&](size_t lo, size_t hi, int) { for (size_t t = lo; t < hi; t++) sorted[rank[t]] = keep[t]; });
         } else {
@@ -2846,8 +2860,9 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     }
     phase("filter + sort by camera");
     const int nh = DI ? 0 : no;                              // host-side observation arrays (none when the inputs are device-resident)
-    std::vector<int> ocam(nh), opt(nh), opos(nh), pstart(n_ptl + 1, 0), slotcam(nh);
-    std::vector<double> omeas((size_t)nh * 3);
+    std::vector<int>&ocam = BS->hv_i[3], &opt = BS->hv_i[4], &opos = BS->hv_i[5], &slotcam = BS->hv_i[6]; std::vector<int> pstart(n_ptl + 1, 0);
+    ocam.resize(nh); opt.resize(nh); opos.resize(nh); slotcam.resize(nh);      // (every element is written below)
+    std::vector<double>& omeas = BS->hv_d; omeas.resize((size_t)nh * 3);
     int maxk = 0;
     if (par) {
         HP.chunks((size_t)nh, [&](size_t lo, size_t hi, int) { for (size_t t = lo; t < hi; t++) { const int k = keep[t]; ocam[t] = perm[p.obs_cam[k]]; opt[t] = p.obs_pt[k] - pt_lo;
@@ -2938,7 +2953,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     }
     const int dyn_grid = std::min(n_chain, 1024);
     const size_t dyn_lds = (size_t)64 * 3 * lmax * sizeof(double) <= 150 * 1024 ? (size_t)64 * 3 * std::max(lmax, 1) * sizeof(double) : 0;
-    if (nd && dyn_lds) HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_badyn_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+    if (nd && dyn_lds) HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_badyn_schur, (size_t)(dyn_lds)));
     if (nd && (size_t)dyn_grid * 64 * 3 * lmax > BS->scratch_cap) {      // per-wave column scratch of k_badyn_schur (device only, not mirrored)
         HIP_TRY(ctx, hipStreamSynchronize(st)); if (BS->d_scratch) hipFree(BS->d_scratch);
         BS->scratch_cap = (size_t)1024 * 64 * 3 * lmax; HIP_TRY(ctx, hipMalloc((void**)&BS->d_scratch, BS->scratch_cap * sizeof(double)));
@@ -2980,16 +2995,16 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         if (6 * bwc + 5 <= CB_MAXBW && 6 * bwc + 6 < n6 / 2) { D.bw = 6 * bwc + 5; D.ldb = (D.bw + 2) & ~1; }
     }
     const size_t sz_S = D.bw >= 0 ? (size_t)n6 * D.ldb : (size_t)n6 * n6;
-    if (D.bw >= 0) HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)D.bw * (CB_NB + 1) * sizeof(double))));
+    if (D.bw >= 0) HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_chol_band, (size_t)(((size_t)D.bw * (CB_NB + 1) * sizeof(double)))));
     size_t band6_lds = 0;                                   // pose-block LDS-window factorisation when the window fits
     if (D.bw >= 0) { const size_t bwc = (D.bw - 5) / 6, wr = 6 * (bwc + 1), need = (wr * (wr + 1) + 3 * wr + 6 * bwc * 7 + 8) * sizeof(double);
-                     if (bwc >= 1 && need <= 150 * 1024) { band6_lds = need; HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol_band6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)); } }
+                     if (bwc >= 1 && need <= 150 * 1024) { band6_lds = need; HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_chol_band6, (size_t)(need))); } }
     size_t band6s_lds = 0;                                  // pose-block factorisation in place on the band (window in L2) when the LDS window does not fit
     int band6s_nb = 0;                                      // pivot blocks per supernode: 8 when the panel fits LDS, else 4
     if (D.bw >= 0 && !band6_lds) { const size_t bwc = (D.bw - 5) / 6, wr = 6 * (bwc + 1);
                      auto need = [&](size_t nb) { const size_t rr = 6 * (bwc + nb); return (rr * (6 * nb + 1) + rr + 2 * wr + 8) * sizeof(double); };
                      if (bwc >= 1 && bwc <= 96) { band6s_nb = need(8) <= 150 * 1024 ? 8 : 4; band6s_lds = need(band6s_nb);
-                     HIP_TRY(ctx, hipFuncSetAttribute(band6s_nb == 8 ? (const void*)k_chol_band6s<8> : (const void*)k_chol_band6s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band6s_lds)); } }
+                     HIP_TRY(ctx, ba_lds_attr(ctx->device, band6s_nb == 8 ? (const void*)k_chol_band6s<8> : (const void*)k_chol_band6s<4>, (size_t)(band6s_lds))); } }
     double* Sr = A.get<double>(sz_S + n6); D.S = Sr; D.r = Sr + sz_S; D.x = A.get<double>(n6);
     // block cyclic reduction of the band system when it is long enough to pay (>= 4 superblocks); the superblock is 66 or 96 unknowns (>= half-bandwidth + 1), the two
     // sizes the register-resident elimination kernel is instantiated for
@@ -3002,8 +3017,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             Bc.m = m; Bc.nb = nb; Bc.n6 = n6; Bc.bw = D.bw; Bc.ldb = D.ldb;
             Bc.D = BS->d_bcr; Bc.L0 = Bc.D + mm; Bc.L1 = Bc.L0 + mm; Bc.GL = Bc.L1 + mm; Bc.GR = Bc.GL + mm; Bc.b = Bc.GR + mm; Bc.y = Bc.b + (size_t)nb * m;
             Bc.S = D.S; Bc.r = D.r; Bc.x = D.x;
-            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_bcr_elim<66>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrGeom<66>::LDS));
-            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_bcr_elim<96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BcrGeom<96>::LDS));
+            HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bcr_elim<66>, (size_t)(BcrGeom<66>::LDS)));
+            HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bcr_elim<96>, (size_t)(BcrGeom<96>::LDS)));
         }
     }
     if (getenv("VIDO_BA_VERBOSE")) fprintf(stderr, "[ba] poses %d (cams %d + H %d) landmarks %d obs %d dyn %d | bw %d (block half-width %d) %s\n", n_pose, p.n_cam, n_H, n_ptl, no, nd, D.bw, D.bw >= 0 ? (D.bw - 5) / 6 : -1,
@@ -3042,7 +3057,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
       int o = 0; for (int q = 0; q < n_pose; q++) if (inv[q] >= 0) { pose_ord_h[q] = o; ord_pose_h[o] = q; o++; } }
     D.n_cam_ord = p.n_cam; D.pose_ord = A.put(pose_ord_h.data(), n_pose, st); D.ord_pose = A.put(ord_pose_h.data(), p.n_cam, st);
     if (DI) D.slot_ord = DI->slot_cam;                      // (no object motions in the local window: the camera ordinal IS the pose index)
-    else { std::vector<int> so(no);
+    else { std::vector<int>& so = BS->hv_i[7]; so.resize(no);
            if (par) HP.chunks((size_t)no, [&](size_t lo, size_t hi, int) { for (size_t t = lo; t < hi; t++) so[t] = pose_ord_h[slotcam[t]]; }); else for (int t = 0; t < no; t++) so[t] = pose_ord_h[slotcam[t]];
            D.slot_ord = A.put(so.data(), no, st); }
     int* d_chunk_cmin = nullptr; int* d_lorder = nullptr; int2* d_lbc = nullptr; int n_chunks = (n_ptl + BA_CHUNK - 1) / BA_CHUNK; bool use_mfma_schur = false;
@@ -3091,13 +3106,13 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
         HIP_TRY(ctx, hipMemcpyAsync(d_long, long_list.data(), (size_t)n_long * sizeof(int), hipMemcpyHostToDevice, st)); HIP_TRY(ctx, hipStreamSynchronize(st));
     }
     if (lds_schur > 160 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "ba: LDS budget exceeded (n6=%d, max track %d)", n6, maxk);
-    if (lds_path) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
-                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol));
-                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_chol_small6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol6));
-                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_bas_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
-                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_bas_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol6)); }
-    else { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_schur));
-           HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_schur_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM_LDS_BYTES)); }
+    if (lds_path) { HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_ba_schur<0>, (size_t)(lds_schur)));
+                    HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_ba_chol_small, (size_t)(lds_chol)));
+                    HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_ba_chol_small6, (size_t)(lds_chol6)));
+                    HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bas_schur, (size_t)(lds_schur)));
+                    HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bas_chol, (size_t)(lds_chol6))); }
+    else { HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_ba_schur<2>, (size_t)(lds_schur)));
+           HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_ba_schur_mfma, (size_t)(SM_LDS_BYTES))); }
 
     const int lin_E = 1;     // groups of 64 observations per wave in k_ba_linearize: with the LDS camera accumulators one group is fastest at every size measured (35 k .. 1 M edges)
     if (allreduce == vido_rccl_allreduce && user != (void*)ctx)      // the built-in path enqueues on user->stream: another context's stream would lose all ordering with this solve
@@ -3146,7 +3161,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
                 HIP_TRY(ctx, hipStreamSynchronize(st)); if (BS->d_parts) hipFree(BS->d_parts);
                 BS->parts_cap = (size_t)BA_SCHUR0_GRID * sz_sr; HIP_TRY(ctx, hipMalloc((void**)&BS->d_parts, BS->parts_cap * sizeof(double)));
             }
-            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_ba_local_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bal));
+            HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_ba_local_lm, (size_t)(lds_bal)));
             BaDev4 V;
             for (int par = 0; par < 2; par++) for (int flip = 0; flip < 2; flip++) {
                 BaDev& Q = V.v[par * 2 + flip]; Q = D;
