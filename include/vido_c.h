@@ -311,6 +311,11 @@ int vido_conv1x1_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, 
 /* ... with the residual at half the resolution [cout][h/2][w/2], added nearest-upsampled: the FPN's lateral convolution + top-down sum (backbone/fpn.py:55-66); h, w even */
 int vido_conv1x1_bias_up2_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual_half, float* y, int cin, int cout, int h, int w, float slope);
 
+/* k x k convolution (k = 3, 5, 7; stride 1, padding k / 2) to TWO output channels + bias + residual for one image (csrc/convsmall.hip): the last layer of LiteFlowNet's
+ * matching / sub-pixel heads with the `flow + netMain(...)` behind it (flow_net/src/layers.py:152-160, 191-199).  x [cin][h][w], w [2][cin][k][k], bias [2] or NULL,
+ * residual [2][h][w] or NULL, y [2][h][w]: f32 DEVICE tensors. */
+int vido_conv_kxk_c2(vido_ctx* ctx, const float* x, const float* w, const float* bias, const float* residual, float* y, int cin, int k, int h, int w_);
+
 /* 3x3 stride-1 padding-1 convolution + bias + leaky-ReLU as Winograd F(2x2, 3x3) with its sixteen channel contractions on the fp32 matrix pipe (csrc/wino.hip): the
  * dense 3x3 convolutions of LiteFlowNet (flow_net/src/layers.py:39-315), the FPN output / RPN head / mask head convolutions of the detector
  * (maskrcnn_benchmark/modeling/backbone/fpn.py, rpn/rpn.py:74-107, roi_heads/mask_head/roi_mask_feature_extractors.py) — what the library runs as a vector-ALU Winograd

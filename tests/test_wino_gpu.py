@@ -85,3 +85,18 @@ def test_liteflownet_with_and_without_the_winograd_launches(vido, ctx, monkeypat
         y0 = ref(a, b)
     assert taken >= 40 and sum(1 for m in ref.modules() if getattr(m, "_wino_u", None) is not None) == 0
     assert float((y1 - y0).abs().max()) < 2e-3 * max(1.0, float(y0.abs().max()))
+
+
+@pytest.mark.parametrize("k,cin,H,W", [(7, 32, 60, 80), (5, 32, 33, 47), (3, 32, 15, 20), (7, 19, 17, 16), (5, 8, 1, 3)])
+def test_conv_kxk_to_two_channels_equals_conv2d(vido, ctx, k, cin, H, W):
+    """csrc/convsmall.hip (the last layer of LiteFlowNet's flow heads: k x k, 32 -> 2, + bias + the flow it refines) against conv2d in float64."""
+    from vido_slam_amd.nets.ops import HipOps
+    ops = HipOps(ctx)
+    torch.manual_seed(k * 100 + cin)
+    conv = torch.nn.Conv2d(cin, 2, k, 1, k // 2).cuda(); x = torch.randn(1, cin, H, W, device="cuda"); r = torch.randn(1, 2, H, W, device="cuda")
+    with torch.no_grad():
+        ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), 1, k // 2)
+        y0 = ops.conv_kxk_c2(conv, x); y1 = ops.conv_kxk_c2(conv, x, r)
+    assert float((y0.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+    assert float((y1.double() - (ref + r.double())).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+    assert ops.conv_kxk_c2(torch.nn.Conv2d(cin, 3, k, 1, k // 2).cuda(), x) is None and ops.conv_kxk_c2(torch.nn.Conv2d(cin, 2, k, 2, k // 2).cuda(), x) is None

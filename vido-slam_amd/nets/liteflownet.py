@@ -28,6 +28,10 @@ class _Chain(nn.Sequential):
             m = mods[i]
             if self.epilogue is not None and isinstance(m, nn.Conv2d) and x.is_cuda and m.bias is not None:
                 act = i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU)
+                if self.wino is not None and not act and i + 1 >= len(mods) and m.out_channels == 2 and hasattr(self.wino, "conv_kxk_c2") and not os.environ.get("VIDO_NO_CONVSMALL"):
+                    y = self.wino.conv_kxk_c2(m, x, residual)       # the heads' last layer (32 -> 2, k x k) + bias + `flow +`: one stencil launch (csrc/convsmall.hip)
+                    if y is not None:
+                        return y
                 if self.wino is not None and (act or i + 1 >= len(mods)):
                     y = self.wino.wino3x3_conv(m, x, LEAK if act else 1.0)
                     if y is not None:

@@ -169,6 +169,25 @@ class HipOps:
             conv._c1_w = pack_conv1x1(w).to(x.device); conv._c1_key = key
         return self.conv1x1_bias_act(x.contiguous(), conv._c1_w, conv.bias, residual, slope, residual_up2)
 
+    def conv_kxk_c2(self, conv, x, residual=None):
+        """conv(x) + residual for a k x k (3, 5, 7) stride-1 `same` convolution with TWO output channels on one image — the last layer of LiteFlowNet's flow heads — as one
+        stencil launch (csrc/convsmall.hip) instead of the library's im2col + GEMM + our bias / residual pass; None when the layer is not of that form."""
+        w = conv.weight
+        k = int(w.shape[2])
+        if (w.shape[0] != 2 or w.shape[2] != w.shape[3] or k not in (3, 5, 7) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (k // 2, k // 2) or tuple(conv.dilation) != (1, 1)
+                or conv.groups != 1 or not x.is_cuda or x.shape[0] != 1 or x.dtype != torch.float32):
+            return None
+        x = x.contiguous(); wc = w.contiguous()
+        _, cin, H, W = x.shape
+        out = torch.empty((1, 2, H, W), device=x.device, dtype=torch.float32)
+        if residual is not None:
+            residual = residual.contiguous(); assert residual.shape == out.shape
+        self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * 2 * cin * k * k * H * W
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_conv_kxk_c2(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(wc.data_ptr()), C.c_void_p(conv.bias.data_ptr()) if conv.bias is not None else None,
+                                                      C.c_void_p(residual.data_ptr()) if residual is not None else None, C.c_void_p(out.data_ptr()), int(cin), k, int(H), int(W)))
+        return out
+
     def wino3x3_supported(self, cin, cout, H, W):
         return bool(self.ctx.lib.vido_wino3x3_supported(int(cin), int(cout), int(H), int(W)))
 
