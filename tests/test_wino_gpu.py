@@ -100,3 +100,18 @@ def test_conv_kxk_to_two_channels_equals_conv2d(vido, ctx, k, cin, H, W):
     assert float((y0.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
     assert float((y1.double() - (ref + r.double())).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
     assert ops.conv_kxk_c2(torch.nn.Conv2d(cin, 3, k, 1, k // 2).cuda(), x) is None and ops.conv_kxk_c2(torch.nn.Conv2d(cin, 2, k, 2, k // 2).cuda(), x) is None
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(32, 64, 60, 80), (32, 128, 33, 47), (64, 128, 15, 20), (96, 128, 30, 40), (6, 40, 5, 7), (128, 32, 9, 9)])
+def test_conv1x1_skinny_equals_conv2d(vido, ctx, cin, cout, H, W):
+    """csrc/convsmall.hip::k_conv1x1_skinny (LiteFlowNet's netFeat layers: 1x1, few input channels, bias + LeakyReLU) against conv2d in float64."""
+    from vido_slam_amd.nets.ops import HipOps
+    ops = HipOps(ctx)
+    torch.manual_seed(cin * 7 + cout)
+    conv = torch.nn.Conv2d(cin, cout, 1).cuda(); x = torch.randn(1, cin, H, W, device="cuda")
+    with torch.no_grad():
+        for slope in (0.1, 1.0, 0.0):
+            y = ops.conv1x1_skinny_conv(conv, x, slope)
+            ref = F.leaky_relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double()), slope)
+            assert float((y.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max())), (cin, cout, slope)
+    assert ops.conv1x1_skinny_conv(torch.nn.Conv2d(cin + 1, cout, 1).cuda(), torch.randn(1, cin + 1, H, W, device="cuda")) is None      # odd channel count: the library's

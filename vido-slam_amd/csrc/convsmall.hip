@@ -66,6 +66,55 @@ __global__ __launch_bounds__(256) void k_conv_kxk_c2(const float* __restrict__ x
         y[o] = acc0 + (res ? res[o] : 0.f); y[HW + o] = acc1 + (res ? res[HW + o] : 0.f);
     }
 }
+
+// ---- 1x1 convolution with FEW input channels (<= 128) + bias + leaky ReLU: LiteFlowNet's netFeat layers (layers.py:99, 125, 140: 32 -> 64 on both feature maps of level 2,
+// 32 / 64 / 96 -> 128 in the regularisation).  H*W is large (76 800 at level 2), K is tiny: the library's GEMM + our bias pass take 29-40 + 6 us for 30-50 MB of traffic.
+// No LDS: a wave owns 32 positions and ALL output channels; the B operand of v_mfma_f32_32x32x2f32 (two input channels x 32 positions) IS a coalesced global load in operand
+// order (lane = position & 31 + 32 * channel parity), the weights are packed in operand order [32-channel block][k-pair][64 lanes] and stay in L1 / L2; bias and the
+// activation are applied in the accumulators, a register is a 128-byte line of one output channel.
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+template <int CB>
+__global__ __launch_bounds__(256) void k_conv1x1_skinny(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
+                                                        int Cin, int Cout, long long HW, float slope)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long p0 = ((long long)blockIdx.x * 4 + wv) * 32;
+    if (p0 >= HW) return;
+    const long long p = min(p0 + (lane & 31), HW - 1);                        // (positions past the end repeat the last one: computed, not stored)
+    const int nkp = Cin >> 1;
+    f32x16s acc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const int co = cb * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3); acc[cb][r] = (bias && co < Cout) ? bias[co] : 0.f; }
+    const float* xb = x + (size_t)(lane >> 5) * HW + p;
+    for (int kp0 = 0; kp0 < nkp; kp0 += 8) {                                  // eight k-pairs at a time: their loads are in flight together
+        float b[8], a[8][CB];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int kp = min(kp0 + u, nkp - 1);
+            b[u] = xb[(size_t)(2 * kp) * HW];
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) a[u][cb] = wp[((size_t)cb * nkp + kp) * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (kp0 + u < nkp) {
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][cb], b[u], acc[cb], 0, 0, 0);
+            }
+    }
+    if (p0 + (lane & 31) < HW) {
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = cb * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                const float v = acc[cb][r];
+                if (co < Cout) y[(size_t)co * HW + p] = fmaxf(v, v * slope);
+            }
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -83,6 +132,27 @@ int vido_conv_kxk_c2(vido_ctx* ctx, const float* x, const float* w, const float*
     if (k == 7) hipLaunchKernelGGL(k_conv_kxk_c2<7>, grid, blk, 0, st, x, w, bias, residual, y, cin, h, wd);
     else if (k == 5) hipLaunchKernelGGL(k_conv_kxk_c2<5>, grid, blk, 0, st, x, w, bias, residual, y, cin, h, wd);
     else hipLaunchKernelGGL(k_conv_kxk_c2<3>, grid, blk, 0, st, x, w, bias, residual, y, cin, h, wd);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+/* y = leaky_relu(conv2d(x, w) + bias, slope) for one image, 1x1 kernel, FEW input channels (even, <= 128), cout <= 128: x [cin][hw], y [cout][hw] f32 DEVICE tensors;
+ * w_packed: element (co, k) of the weight at [co / 32][k / 2][32 * (k & 1) + co % 32] (cout padded to a multiple of 32 with zeros; vido_slam_amd/nets/ops.py::pack_conv1x1_skinny).
+ * LiteFlowNet's netFeat layers (flow_net/src/layers.py:99, 125, 140).  slope in [0, 1]: 0 = ReLU, 1 = none. */
+int vido_conv1x1_skinny(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, float* y, int cin, int cout, long long hw, float slope)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!x || !w_packed || !y || x == y || cin < 2 || (cin & 1) || cin > 128 || cout < 1 || cout > 128 || hw < 1 || slope < 0.f || slope > 1.f)
+        return vido_set_error(ctx, VIDO_E_INVALID, "conv1x1_skinny: no kernel for %d -> %d channels", cin, cout);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    const dim3 grid((unsigned)((hw + 127) / 128)), blk(256);
+    switch ((cout + 31) / 32) {
+    case 1: hipLaunchKernelGGL(k_conv1x1_skinny<1>, grid, blk, 0, st, x, w_packed, bias, y, cin, cout, hw, slope); break;
+    case 2: hipLaunchKernelGGL(k_conv1x1_skinny<2>, grid, blk, 0, st, x, w_packed, bias, y, cin, cout, hw, slope); break;
+    case 3: hipLaunchKernelGGL(k_conv1x1_skinny<3>, grid, blk, 0, st, x, w_packed, bias, y, cin, cout, hw, slope); break;
+    default: hipLaunchKernelGGL(k_conv1x1_skinny<4>, grid, blk, 0, st, x, w_packed, bias, y, cin, cout, hw, slope); break;
+    }
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }

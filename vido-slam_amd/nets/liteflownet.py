@@ -32,6 +32,11 @@ class _Chain(nn.Sequential):
                     y = self.wino.conv_kxk_c2(m, x, residual)       # the heads' last layer (32 -> 2, k x k) + bias + `flow +`: one stencil launch (csrc/convsmall.hip)
                     if y is not None:
                         return y
+                if self.wino is not None and tuple(m.kernel_size) == (1, 1) and (act or i + 1 >= len(mods)) and hasattr(self.wino, "conv1x1_skinny_conv") and not os.environ.get("VIDO_NO_CONVSMALL"):
+                    y = self.wino.conv1x1_skinny_conv(m, x, LEAK if act else 1.0)      # netFeat: few input channels, a large map — one launch, no LDS (csrc/convsmall.hip)
+                    if y is not None:
+                        x = y; i += 2 if act else 1
+                        continue
                 if self.wino is not None and (act or i + 1 >= len(mods)):
                     y = self.wino.wino3x3_conv(m, x, LEAK if act else 1.0)
                     if y is not None:

@@ -188,6 +188,25 @@ class HipOps:
                                                       C.c_void_p(residual.data_ptr()) if residual is not None else None, C.c_void_p(out.data_ptr()), int(cin), k, int(H), int(W)))
         return out
 
+    def conv1x1_skinny_conv(self, conv, x, slope=1.0):
+        """leaky_relu(conv(x), slope) for a 1x1 stride-1 convolution with few input channels (even, <= 128) and <= 128 output channels on one image, as one launch without LDS
+        (csrc/convsmall.hip::k_conv1x1_skinny) — LiteFlowNet's netFeat layers; None when the layer is not of that form.  Packed weight cached on the module."""
+        w = conv.weight
+        cout, cin = int(w.shape[0]), int(w.shape[1])
+        if (tuple(w.shape[2:]) != (1, 1) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (0, 0) or conv.groups != 1 or cin % 2 or cin > 128 or cout > 128
+                or not x.is_cuda or x.shape[0] != 1 or x.dtype != torch.float32):
+            return None
+        key = (w.data_ptr(), w._version, str(x.device))
+        if getattr(conv, "_c1s_key", None) != key:
+            conv._c1s_w = pack_conv1x1_skinny(w).to(x.device); conv._c1s_key = key
+        x = x.contiguous(); H, W = int(x.shape[2]), int(x.shape[3])
+        out = torch.empty((1, cout, H, W), device=x.device, dtype=torch.float32)
+        self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * cout * cin * H * W
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_conv1x1_skinny(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(conv._c1s_w.data_ptr()), C.c_void_p(conv.bias.data_ptr()) if conv.bias is not None else None,
+                                                         C.c_void_p(out.data_ptr()), cin, cout, C.c_longlong(H * W), C.c_float(slope)))
+        return out
+
     def wino3x3_supported(self, cin, cout, H, W):
         return bool(self.ctx.lib.vido_wino3x3_supported(int(cin), int(cout), int(H), int(W)))
 
@@ -434,6 +453,15 @@ def pack_conv1x1(w):
         return None
     w5 = w.detach().reshape(cout // 32, 32, cin // 8, 4, 2)            # [mb][co32][group][kk][half]
     return w5.permute(0, 2, 4, 1, 3).contiguous().reshape(cout // 32, cin // 8, 64, 4)
+
+
+def pack_conv1x1_skinny(w):
+    """1x1 convolution weight [cout, cin, 1, 1] (cin even) -> the operand order of csrc/convsmall.hip::k_conv1x1_skinny: element (co, k) at [co / 32][k / 2][32 * (k & 1) + co % 32],
+    output channels padded to a multiple of 32 with zeros."""
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    cop = (cout + 31) // 32 * 32
+    wz = w.detach().reshape(cout, cin).new_zeros((cop, cin)); wz[:cout] = w.detach().reshape(cout, cin)
+    return wz.reshape(cop // 32, 32, cin // 2, 2).permute(0, 2, 3, 1).contiguous().reshape(cop // 32, cin // 2, 64)
 
 
 def pack_gconv3x3(w, groups):
