@@ -315,9 +315,9 @@ int vido_conv1x1_bias_up2_act(vido_ctx* ctx, const float* x, const float* w_pack
  * matching / sub-pixel heads with the `flow + netMain(...)` behind it (flow_net/src/layers.py:152-160, 191-199).  x [cin][h][w], w [2][cin][k][k], bias [2] or NULL,
  * residual [2][h][w] or NULL, y [2][h][w]: f32 DEVICE tensors. */
 int vido_conv_kxk_c2(vido_ctx* ctx, const float* x, const float* w, const float* bias, const float* residual, float* y, int cin, int k, int h, int w_);
-/* 1x1 convolution with FEW input channels (even, <= 128; cout <= 128) + bias + leaky ReLU for one image, no LDS: LiteFlowNet's netFeat layers (layers.py:99, 125, 140).
- * w_packed: element (co, k) at [co / 32][k / 2][32 * (k & 1) + co % 32], cout padded to 32 with zeros. */
-int vido_conv1x1_skinny(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, float* y, int cin, int cout, long long hw, float slope);
+/* 1x1 convolution with FEW input channels (even, <= 256; cout <= 256) + bias + residual + leaky ReLU for one image, no LDS: LiteFlowNet's netFeat layers
+ * (layers.py:99, 125, 140), the detector's layer1.  w_packed: element (co, k) at [co / 32][k / 2][32 * (k & 1) + co % 32], cout padded to 32 with zeros. */
+int vido_conv1x1_skinny(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, long long hw, float slope);
 
 /* 3x3 stride-1 padding-1 convolution + bias + leaky-ReLU as Winograd F(2x2, 3x3) with its sixteen channel contractions on the fp32 matrix pipe (csrc/wino.hip): the
  * dense 3x3 convolutions of LiteFlowNet (flow_net/src/layers.py:39-315), the FPN output / RPN head / mask head convolutions of the detector

@@ -73,11 +73,11 @@ __global__ __launch_bounds__(256) void k_conv_kxk_c2(const float* __restrict__ x
 // order (lane = position & 31 + 32 * channel parity), the weights are packed in operand order [32-channel block][k-pair][64 lanes] and stay in L1 / L2; bias and the
 // activation are applied in the accumulators, a register is a 128-byte line of one output channel.
 typedef float f32x16s __attribute__((ext_vector_type(16)));
-template <int CB>
-__global__ __launch_bounds__(256) void k_conv1x1_skinny(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
-                                                        int Cin, int Cout, long long HW, float slope)
+template <int CB, bool RES>
+__global__ __launch_bounds__(256) void k_conv1x1_skinny(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, const float* __restrict__ res,
+                                                        float* __restrict__ y, int Cin, int Cout, long long HW, float slope, unsigned xbytes, unsigned wbytes)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long p0 = ((long long)blockIdx.x * 4 + wv) * 32;
     if (p0 >= HW) return;
     const long long p = min(p0 + (lane & 31), HW - 1);                        // (positions past the end repeat the last one: computed, not stored)
@@ -86,19 +86,24 @@ __global__ __launch_bounds__(256) void k_conv1x1_skinny(const float* __restrict_
 #pragma unroll
     for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) { const int co = cb * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3); acc[cb][r] = (bias && co < Cout) ? bias[co] : 0.f; }
-    const float* xb = x + (size_t)(lane >> 5) * HW + p;
-    for (int kp0 = 0; kp0 < nkp; kp0 += 8) {                                  // eight k-pairs at a time: their loads are in flight together
-        float b[8], a[8][CB];
+        for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;
+    // all addressing scalar (a vector instruction beside the matrix instructions costs 5.5 cycles of their time): per-lane byte offsets are loop invariants, the k-pair rides
+    // in the buffer loads' scalar offset
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, wbytes, 0x00020000);
+    const unsigned xvo = 4u * (unsigned)((lane >> 5) * HW + p), wvo = 4u * (unsigned)lane;
+    const unsigned hw8 = 8u * (unsigned)HW;
+    for (int kp0 = 0; kp0 < nkp; kp0 += 4) {                                  // four k-pairs at a time: their loads are in flight together
+        float b[4], a[4][CB];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < 4; u++) {
             const int kp = min(kp0 + u, nkp - 1);
-            b[u] = xb[(size_t)(2 * kp) * HW];
+            b[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, xvo, hw8 * (unsigned)kp, 0));
 #pragma unroll
-            for (int cb = 0; cb < CB; cb++) a[u][cb] = wp[((size_t)cb * nkp + kp) * 64 + lane];
+            for (int cb = 0; cb < CB; cb++) a[u][cb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, wvo, 256u * (unsigned)(cb * nkp + kp), 0));
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++)
+        for (int u = 0; u < 4; u++)
             if (kp0 + u < nkp) {
 #pragma unroll
                 for (int cb = 0; cb < CB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][cb], b[u], acc[cb], 0, 0, 0);
@@ -106,13 +111,20 @@ __global__ __launch_bounds__(256) void k_conv1x1_skinny(const float* __restrict_
     }
     if (p0 + (lane & 31) < HW) {
 #pragma unroll
-        for (int cb = 0; cb < CB; cb++)
+        for (int cb = 0; cb < CB; cb++) {
+            float bv[16], rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = min(cb * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), Cout - 1);
+                bv[r] = bias ? bias[co] : 0.f; rv[r] = RES ? res[(size_t)co * HW + p] : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int co = cb * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-                const float v = acc[cb][r];
+                const float v = acc[cb][r] + bv[r] + rv[r];
                 if (co < Cout) y[(size_t)co * HW + p] = fmaxf(v, v * slope);
             }
+        }
     }
 }
 }  // namespace
@@ -136,23 +148,27 @@ int vido_conv_kxk_c2(vido_ctx* ctx, const float* x, const float* w, const float*
     return VIDO_OK;
 }
 
-/* y = leaky_relu(conv2d(x, w) + bias, slope) for one image, 1x1 kernel, FEW input channels (even, <= 128), cout <= 128: x [cin][hw], y [cout][hw] f32 DEVICE tensors;
- * w_packed: element (co, k) of the weight at [co / 32][k / 2][32 * (k & 1) + co % 32] (cout padded to a multiple of 32 with zeros; vido_slam_amd/nets/ops.py::pack_conv1x1_skinny).
- * LiteFlowNet's netFeat layers (flow_net/src/layers.py:99, 125, 140).  slope in [0, 1]: 0 = ReLU, 1 = none. */
-int vido_conv1x1_skinny(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, float* y, int cin, int cout, long long hw, float slope)
+/* y = leaky_relu(conv2d(x, w) + bias + residual, slope) for one image, 1x1 kernel, FEW input channels (even, <= 256), cout <= 256: x [cin][hw], y / residual [cout][hw] f32
+ * DEVICE tensors (residual NULL = none); w_packed: element (co, k) of the weight at [co / 32][k / 2][32 * (k & 1) + co % 32] (cout padded to a multiple of 32 with zeros;
+ * vido_slam_amd/nets/ops.py::pack_conv1x1_skinny).  LiteFlowNet's netFeat layers (flow_net/src/layers.py:99, 125, 140); the detector's layer1 1x1 convolutions
+ * (K = 64 / 256 on 200 x 272).  slope in [0, 1]: 0 = ReLU, 1 = none. */
+int vido_conv1x1_skinny(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, long long hw, float slope)
 {
     if (!ctx) return VIDO_E_INVALID;
-    if (!x || !w_packed || !y || x == y || cin < 2 || (cin & 1) || cin > 128 || cout < 1 || cout > 128 || hw < 1 || slope < 0.f || slope > 1.f)
+    if (!x || !w_packed || !y || x == y || cin < 2 || (cin & 1) || cin > 256 || cout < 1 || cout > 256 || hw < 1 || slope < 0.f || slope > 1.f || 4ll * cin * hw >= (1ll << 32))
         return vido_set_error(ctx, VIDO_E_INVALID, "conv1x1_skinny: no kernel for %d -> %d channels", cin, cout);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
     const dim3 grid((unsigned)((hw + 127) / 128)), blk(256);
-    switch ((cout + 31) / 32) {
-    case 1: hipLaunchKernelGGL(k_conv1x1_skinny<1>, grid, blk, 0, st, x, w_packed, bias, y, cin, cout, hw, slope); break;
-    case 2: hipLaunchKernelGGL(k_conv1x1_skinny<2>, grid, blk, 0, st, x, w_packed, bias, y, cin, cout, hw, slope); break;
-    case 3: hipLaunchKernelGGL(k_conv1x1_skinny<3>, grid, blk, 0, st, x, w_packed, bias, y, cin, cout, hw, slope); break;
-    default: hipLaunchKernelGGL(k_conv1x1_skinny<4>, grid, blk, 0, st, x, w_packed, bias, y, cin, cout, hw, slope); break;
+    const int cbn = (cout + 31) / 32;
+    const unsigned xb = (unsigned)(4ll * cin * hw), wb = (unsigned)(4ll * cbn * 32 * cin);
+#define SK_LAUNCH(CBV) { if (residual) hipLaunchKernelGGL((k_conv1x1_skinny<CBV, true>), grid, blk, 0, st, x, w_packed, bias, residual, y, cin, cout, hw, slope, xb, wb); \
+                         else hipLaunchKernelGGL((k_conv1x1_skinny<CBV, false>), grid, blk, 0, st, x, w_packed, bias, residual, y, cin, cout, hw, slope, xb, wb); }
+    switch (cbn) {
+    case 1: SK_LAUNCH(1) break; case 2: SK_LAUNCH(2) break; case 3: SK_LAUNCH(3) break; case 4: SK_LAUNCH(4) break;
+    case 5: SK_LAUNCH(5) break; case 6: SK_LAUNCH(6) break; case 7: SK_LAUNCH(7) break; default: SK_LAUNCH(8) break;
     }
+#undef SK_LAUNCH
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }

@@ -188,24 +188,31 @@ class HipOps:
                                                       C.c_void_p(residual.data_ptr()) if residual is not None else None, C.c_void_p(out.data_ptr()), int(cin), k, int(H), int(W)))
         return out
 
+    def conv1x1_skinny(self, x, w_packed, bias, cout, slope=1.0, residual=None):
+        """leaky_relu(conv2d(x, w) + bias + residual, slope), 1x1, one image, cin even <= 256, cout <= 256: one launch without LDS (csrc/convsmall.hip::k_conv1x1_skinny);
+        w_packed = pack_conv1x1_skinny(w) on the device."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.shape[0] == 1
+        x = x.contiguous(); cin, H, W = int(x.shape[1]), int(x.shape[2]), int(x.shape[3])
+        out = torch.empty((1, cout, H, W), device=x.device, dtype=torch.float32)
+        if residual is not None:
+            residual = residual.contiguous(); assert residual.shape == out.shape
+        self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * cout * cin * H * W
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_conv1x1_skinny(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(w_packed.data_ptr()), C.c_void_p(bias.data_ptr()) if bias is not None else None,
+                                                         C.c_void_p(residual.data_ptr()) if residual is not None else None, C.c_void_p(out.data_ptr()), cin, int(cout), C.c_longlong(H * W), C.c_float(slope)))
+        return out
+
     def conv1x1_skinny_conv(self, conv, x, slope=1.0):
-        """leaky_relu(conv(x), slope) for a 1x1 stride-1 convolution with few input channels (even, <= 128) and <= 128 output channels on one image, as one launch without LDS
-        (csrc/convsmall.hip::k_conv1x1_skinny) — LiteFlowNet's netFeat layers; None when the layer is not of that form.  Packed weight cached on the module."""
+        """The same for an nn.Conv2d (LiteFlowNet's netFeat layers); None when the layer is not of that form.  Packed weight cached on the module."""
         w = conv.weight
         cout, cin = int(w.shape[0]), int(w.shape[1])
-        if (tuple(w.shape[2:]) != (1, 1) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (0, 0) or conv.groups != 1 or cin % 2 or cin > 128 or cout > 128
+        if (tuple(w.shape[2:]) != (1, 1) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (0, 0) or conv.groups != 1 or cin % 2 or cin > 256 or cout > 256
                 or not x.is_cuda or x.shape[0] != 1 or x.dtype != torch.float32):
             return None
         key = (w.data_ptr(), w._version, str(x.device))
         if getattr(conv, "_c1s_key", None) != key:
             conv._c1s_w = pack_conv1x1_skinny(w).to(x.device); conv._c1s_key = key
-        x = x.contiguous(); H, W = int(x.shape[2]), int(x.shape[3])
-        out = torch.empty((1, cout, H, W), device=x.device, dtype=torch.float32)
-        self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * cout * cin * H * W
-        self._adopt_stream()
-        self.ctx._check(self.ctx.lib.vido_conv1x1_skinny(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(conv._c1s_w.data_ptr()), C.c_void_p(conv.bias.data_ptr()) if conv.bias is not None else None,
-                                                         C.c_void_p(out.data_ptr()), cin, cout, C.c_longlong(H * W), C.c_float(slope)))
-        return out
+        return self.conv1x1_skinny(x, conv._c1s_w, conv.bias, cout, slope)
 
     def wino3x3_supported(self, cin, cout, H, W):
         return bool(self.ctx.lib.vido_wino3x3_supported(int(cin), int(cout), int(H), int(W)))
