@@ -234,6 +234,18 @@ class _RPNHead(nn.Module):                 # rpn/rpn.py:74-107
 
     def forward(self, feats):
         t = [_conv_bias_relu(self.conv, f, self._ops) for f in feats]
+        ops = self._ops
+        if ops is not None and t[0].is_cuda and hasattr(ops, "conv1x1_skinny") and not os.environ.get("VIDO_NO_CONVSMALL") and t[0].shape[0] == 1 and self.conv.out_channels % 2 == 0 and self.conv.out_channels <= 256:
+            # objectness + box deltas (3 + 12 output channels) as ONE few-output-channel 1x1 launch per level that reads the head's feature map once (csrc/convsmall.hip); the two
+            # results are the leading / trailing planes of its output.  The library runs two convolutions of 36 + 46 us at P2 for 56 MB of input.
+            from .ops import pack_conv1x1_skinny
+            key = (self.cls_logits.weight.data_ptr(), self.cls_logits.weight._version, self.bbox_pred.weight.data_ptr(), self.bbox_pred.weight._version, str(t[0].device))
+            if getattr(self, "_head_key", None) != key:
+                self._head_w = pack_conv1x1_skinny(torch.cat([self.cls_logits.weight, self.bbox_pred.weight], 0)).to(t[0].device)
+                self._head_b = torch.cat([self.cls_logits.bias, self.bbox_pred.bias], 0).detach().contiguous(); self._head_key = key
+            na = self.cls_logits.out_channels; nt = na + self.bbox_pred.out_channels
+            ys = [ops.conv1x1_skinny(x, self._head_w, self._head_b, nt, 1.0) for x in t]
+            return [y[:, :na] for y in ys], [y[:, na:] for y in ys]
         return [self.cls_logits(x) for x in t], [self.bbox_pred(x) for x in t]
 
 
