@@ -3146,7 +3146,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     double lambda = -1, ni = 2, lastChi = 0, chi2_check = 0, ms_lin = 0, ms_schur = 0; int nBad = 0, trials = 0, it = 0, n_lin = 0, n_schur_timed = 0, n_schur_read = 0;
     // ---- the local window as one persistent launch (k_ba_local_lm): static graph, LDS-resident reduced system, one GPU
     // (opt-in, VIDO_BA_PERSIST=1: measured SLOWER than the host-driven loop below — 3.0 against 2.1 ms per solve alone on the GPU — and its 32 full-CU workgroups never
-    //  all become resident while the networks keep the chip busy; DESIGN.md section 9.  The default local-window path is the fused host-driven loop, `fl`.)
+    //  all become resident while the networks keep the chip busy; DESIGN.md section 9.  The default local-window path is the enqueued-ahead form of the fused loop below (`spec`); VIDO_BA_NO_SPEC=1 keeps the host-driven trial loop `fl`.)
     static const bool want_persist = getenv("VIDO_BA_PERSIST") != nullptr, no_fused_local = getenv("VIDO_BA_NO_FUSED_LOCAL") != nullptr;
     const bool local_static = lds_path && !allreduce && nd == 0 && n6 % 6 == 0 && n6 >= 12 && n_pose <= 64 && D.n_odo <= 64 && n_long == 0 && p.max_iters >= 1 && n_ptl > 0 && no > 0;
     bool persist = local_static && want_persist;
