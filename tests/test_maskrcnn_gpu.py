@@ -255,8 +255,8 @@ def test_bottleneck_with_matrix_core_1x1_equals_library_path(vido, ctx, monkeypa
     from vido_slam_amd.nets.ops import HipOps
     from vido_slam_amd.nets.weights import fill_maskrcnn
     monkeypatch.setattr("vido_slam_amd.nets.ops._C1X1_MIN_TILES", 0)          # (test-sized maps: by default a layer of fewer than 160 tiles stays with the library)
-    for cin, mid, cout in ((64, 256, 256), (256, 256, 256)):                     # first block of layer1 (with the stride-1 shortcut convolution) and a plain one
-        blk = M._Bottleneck(cin, mid, cout, 32, False, 1)
+    for cin, mid, cout, stride in ((64, 256, 256, 1), (256, 256, 256, 1), (256, 512, 512, 2)):     # first block of layer1 (stride-1 shortcut convolution), a plain one, a stage's first block (stride-2 shortcut)
+        blk = M._Bottleneck(cin, mid, cout, 32, False, stride)
         fill_maskrcnn(blk); blk = blk.cuda().eval()
         x = torch.randn(1, cin, 40, 52, generator=torch.Generator().manual_seed(4)).cuda()
         with torch.no_grad():

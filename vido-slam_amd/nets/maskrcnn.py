@@ -94,8 +94,13 @@ class _Bottleneck(nn.Module):              # resnet.py:277-372 (BottleneckWithFi
                 y = ep(F.conv2d(y if b1_done else ep(y, self._b1, None, 0.0), self._w2, None, c2.stride, c2.padding, c2.dilation, c2.groups), self._b2, None, 0.0)
             if self.downsample is None:
                 sc = x
-            elif self._wdp is not None and b1x and ops.conv1x1_supported(x.shape[1], self._wd.shape[0], hw_in) and fills(self._wd.shape[0], hw_in):
+            elif self._wdp is not None and b1x and tuple(self.downsample[0].stride) == (1, 1) and ops.conv1x1_supported(x.shape[1], self._wd.shape[0], hw_in) and fills(self._wd.shape[0], hw_in):
                 sc = ops.conv1x1_bias_act(x.contiguous(), self._wdp, self._bd, None, 1.0)
+            elif (self._wdp is not None and b1x and tuple(self.downsample[0].stride) == (2, 2) and ops.conv1x1_supported(x.shape[1], self._wd.shape[0], ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2))
+                  and fills(self._wd.shape[0], ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2))):
+                # a 1x1 convolution with stride 2 reads every other row and column: one strided copy (a quarter of the map), then the GEMM with the bias in its epilogue — the
+                # library's strided form runs at 36 TFLOP/s (100 us for 3.6 GFLOP) and needs the bias pass behind it
+                sc = ops.conv1x1_bias_act(x[:, :, ::2, ::2].contiguous(), self._wdp, self._bd, None, 1.0)
             else:
                 sc = ep(F.conv2d(x, self._wd, None, self.downsample[0].stride), self._bd, None, 1.0)
             if (self._w3p is not None and y.shape[0] == 1 and ops.conv1x1_supported(y.shape[1], self._w3.shape[0], y.shape[2] * y.shape[3])
