@@ -18,7 +18,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct GcArgs { const float* x; const float* w; const float* bias; const float* in_bias; float* y; int H, W, cpg_in, cpg_out, R, PS; float slope; int gx, total; unsigned xbytes, wbytes; };
+struct GcArgs { const float* x; const float* w; const float* bias; const float* in_bias; float* y; int H, W, cpg_in, cpg_out, R, PS; float slope; int gx, total; unsigned xbytes, wbytes; int nj, ablate; unsigned m_wq, m_wpd, m_gx; };      // m_*: ceil(2^32 / d) for d = (W + 4) / 4, W + 4, gx (k_gconv3x3_m16d: n / d = umulhi(n, m), exact while n d < 2^32)
 
 // Workgroup -> work item.  The hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2; neighbouring position chunks of a group share
 // two halo rows and the group's weights, so the 1-D grid (8 * ceil(total / 8) workgroups) is folded such that every XCD walks a CONTIGUOUS range of (group, chunk) items:
@@ -297,8 +297,119 @@ __global__ __launch_bounds__(256) void k_gconv3x3_m16(GcArgs A)
     }
 }
 
+
+// ---- 16 (or 8) channels per group WITHOUT an input bias, W a multiple of 4 (round 4).  Same tiles, items, weight packing and LDS row layout (four pad positions on the left
+// of every row) as k_gconv3x3_m16<NTW, false, true>; what changes is how a chunk gets into LDS.  The kernel above walks (channel, row) pairs with 64-bit addresses and a
+// branch per row, writes the padding in a pass of its own and needs a barrier between the two: ~900 vector instructions and two barriers around 288 matrix instructions —
+// at layer1's 200 x 272 (ONE 8-channel chunk per workgroup, nothing inside the workgroup to overlap with) 78 us per call for 26 us of matrix time.  Here a channel plane is a
+// run of 16-byte slots in flattened (row, quad) order and moves as `nj` buffer-load-to-LDS instructions of 64 slots each: a lane's global offset per instruction is a loop
+// invariant computed once (pad quads, rows outside the image and slots past the band carry an out-of-range offset: the copy writes the zeros the convolution pads with),
+// the channel rides in the scalar offset — no vector instruction, no padding pass, one barrier per chunk; operands at immediate offsets from six base registers, requested
+// one step ahead.  A plane's pitch is >= 256 nj floats so that the last instruction's spare slots stay inside the plane.
+#define GC16_MAXJ 10
+#define GC16_WSZ 1280     // floats reserved for a chunk's weights: 1152, copied as five 1 KB pieces (the last one drags 128 floats of the next chunk along)
+template <int NTW>
+__global__ __launch_bounds__(256) void k_gconv3x3_m16d(GcArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float gc_lds[];
+    float* Wl = gc_lds;                         // [9][8][16] (+ 128)
+    float* In = gc_lds + GC16_WSZ;              // [8][PS]
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = A.H, W = A.W, Wpd = W + 4, Wq = Wpd >> 2, npos = H * Wpd, PS = A.PS, R = A.R, nj = A.nj;
+    constexpr int P = NTW * 64;
+    const int item = gc_item(A.total); if (item < 0) return;
+    const int dbg = A.ablate;           // VIDO_GCONV_ABLATE (measurement only): 1 no matrix instructions, 2 no stores, 4 no copies
+    // (divisions by multiplication with host-made reciprocals: beside the matrix instructions of the CU's other workgroup every vector instruction of this one is paid in full)
+    const int g = A.gx == 1 ? item : (int)__umulhi((unsigned)item, A.m_gx), q0 = (item - g * A.gx) * P, r0 = (int)__umulhi((unsigned)q0, A.m_wpd);
+    const int nchunk = A.cpg_in / GC_KC;
+    const unsigned HW = (unsigned)H * (unsigned)W;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.x, 0, A.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)A.w, 0, A.wbytes, 0x00020000);
+    unsigned voff[GC16_MAXJ];                   // byte offset, inside a channel image, of this lane's quad of instruction j; bit 30: padding / outside the image / past the band
+#pragma unroll
+    for (int j = 0; j < GC16_MAXJ; j++) {
+        const int s = lane + 64 * j, rr = (int)__umulhi((unsigned)s, A.m_wq), xq = s - rr * Wq, row = r0 - 1 + rr;
+        voff[j] = (rr < R && xq >= 1 && row >= 0 && row < H) ? 4u * (unsigned)(row * W + 4 * (xq - 1)) : 0x40000000u;
+    }
+    const unsigned wvo = 16u * (unsigned)lane;
+    const unsigned wbase = 4u * (unsigned)(g * nchunk * (9 * GC_KC * 16));
+    const unsigned xbase = 4u * (unsigned)(g * A.cpg_in) * HW;
+    // wave wv copies channels 2 wv, 2 wv + 1 of a chunk (nj instructions each) and piece wv of its weights (wave 0: piece 4 as well)
+    auto issue = [&](int c) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned so = xbase + 4u * (unsigned)(c * GC_KC + 2 * wv + h) * HW;
+            float* plane = In + (2 * wv + h) * PS;
+#pragma unroll
+            for (int j = 0; j < GC16_MAXJ; j++)
+                if (j < nj) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(plane + 256 * j), 16, voff[j], so, 0, 0);
+        }
+        const unsigned wso = wbase + 4u * (unsigned)(c * (9 * GC_KC * 16));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(Wl + 256 * wv), 16, wvo, wso + 1024u * (unsigned)wv, 0, 0);
+        if (wv == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(Wl + 1024), 16, wvo, wso + 4096u, 0, 0);
+    };
+    const int co_base = g * A.cpg_out;
+    f32x4 acc[NTW];
+    {
+        float b4[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int co = 4 * (lane >> 4) + r; b4[r] = co < A.cpg_out ? A.bias[co_base + co] : 0.f; }
+#pragma unroll
+        for (int t = 0; t < NTW; t++) { acc[t][0] = b4[0]; acc[t][1] = b4[1]; acc[t][2] = b4[2]; acc[t][3] = b4[3]; }
+    }
+    typedef const volatile __attribute__((address_space(3))) float* lds_f;      // (volatile: see k_gconv3x3_m32d)
+    const int bbase = (lane >> 4) * PS + (q0 + 16 * NTW * wv - r0 * Wpd) + (lane & 15) + 3;
+    lds_f Wb = (lds_f)Wl + lane;
+    lds_f B00 = (lds_f)In + bbase, B01 = B00 + Wpd, B02 = B01 + Wpd, B10 = B00 + 4 * PS, B11 = B10 + Wpd, B12 = B11 + Wpd;      // [k4][tap row]: everything else is an immediate
+    for (int c = 0; c < nchunk; c++) {
+        if (c) __syncthreads();                                       // everybody is done with the previous chunk
+        if (!(dbg & 4)) issue(c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float a[2], b[2][NTW];
+        // step s = tap * 2 + k4; the operands of step s + 1 are requested in two halves between the two halves of step s's matrix instructions (at most 15 LDS reads can
+        // be outstanding).  Scheduling barriers: left alone, the scheduler sinks every read to just before its matrix instruction and the loop runs at LDS latency.
+        auto ld = [&](int s, int half) {
+            const int tap = s >> 1, k4 = s & 1;
+            lds_f Bt = k4 ? (tap < 3 ? B10 : (tap < 6 ? B11 : B12)) : (tap < 3 ? B00 : (tap < 6 ? B01 : B02));
+            if (half == 0) a[s & 1] = Wb[(tap * 8 + 4 * k4) * 16];
+#pragma unroll
+            for (int t = half * (NTW / 2); t < (half + 1) * (NTW / 2); t++) b[s & 1][t] = Bt[tap % 3 + 16 * t];
+        };
+        if (dbg & 1) continue;
+        ld(0, 0); ld(0, 1);
+#pragma unroll
+        for (int s = 0; s < 18; s++) {
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                if (s + 1 < 18) ld(s + 1, half);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = half * (NTW / 2); t < (half + 1) * (NTW / 2); t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1], b[s & 1][t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // D[i][j]: lane = 16 * (i / 4) + j, register = i & 3.  Buffer stores, no branches: a lane without an output (pad position, past the image, output channel >= cpg_out)
+    // carries an out-of-range offset and its store is dropped; the output channel r of a lane's four rides in the scalar offset.
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)A.y, 0, A.xbytes / (unsigned)A.cpg_in * (unsigned)A.cpg_out, 0x00020000);
+    const int co0 = 4 * (lane >> 4);
+    const unsigned ybase = 4u * ((unsigned)(co_base + co0) * HW);
+    if (dbg & 2) return;
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        const int q = q0 + 16 * (NTW * wv + t) + (lane & 15), yy = (int)__umulhi((unsigned)q, A.m_wpd), xx = q - yy * Wpd;
+        const unsigned vo = (q < npos && xx < W && co0 < A.cpg_out) ? ybase + 4u * (unsigned)(yy * W + xx) : 0x40000000u;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float v = acc[t][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(v, v * A.slope)), yr, vo, 4u * (unsigned)r * HW, 0);
+        }
+    }
+}
+
 // geometry of a call: which kernel, rows of the band, plane pitch, LDS bytes; 0 = not supported
-struct GcPlan { int kind; int R, PS; size_t lds; int gx; bool v4; };
+struct GcPlan { int kind; int R, PS; size_t lds; int gx; bool v4; int nj, PSd; size_t lds_d; };      // nj > 0: k_gconv3x3_m16d has a plan too (plane pitch PSd, lds_d bytes)
 static GcPlan gc_plan(int H, int W, int cpg_in, int cpg_out, bool aligned16 = true)
 {
     GcPlan p{};
@@ -319,6 +430,12 @@ static GcPlan gc_plan(int H, int W, int cpg_in, int cpg_out, bool aligned16 = tr
         if (lds > 78 * 1024) continue;                                                      // two workgroups per CU
         if (ntw == 8 && P < 3 * Wpd && npos > 4 * 1024) continue;                           // wide rows: the halo would triple the reads
         p.kind = ntw; p.R = R; p.PS = PS; p.lds = lds; p.gx = (int)((npos + P - 1) / P); p.v4 = v4;
+        if (v4) {                                                                           // k_gconv3x3_m16d: planes of 16-byte slots, 64 per copy instruction
+            const int nslots = R * (Wpd / 4) + 1, nj = (nslots + 63) / 64;
+            int PSd = std::max(PS, 256 * nj + 16); PSd = ((PSd + 15) & ~31) + 16;
+            const size_t lds_d = (size_t)(GC16_WSZ + GC_KC * PSd) * 4;
+            if (nj <= GC16_MAXJ && lds_d <= 78 * 1024) { p.nj = nj; p.PSd = PSd; p.lds_d = lds_d; }
+        }
         return p;
     }
     return p;
@@ -327,6 +444,7 @@ template <int NTW> static int gc_m16_limits(vido_ctx* ctx)
 {
     for (const void* f : {(const void*)k_gconv3x3_m16<NTW, false, false>, (const void*)k_gconv3x3_m16<NTW, false, true>, (const void*)k_gconv3x3_m16<NTW, true, false>, (const void*)k_gconv3x3_m16<NTW, true, true>})
         HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gconv3x3_m16d<NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     return VIDO_OK;
 }
 static int gc_lds_limit(vido_ctx* ctx)
@@ -376,8 +494,19 @@ int vido_gconv3x3_bias_act(vido_ctx* ctx, const float* x, const float* in_bias, 
     { int rc = gc_lds_limit(ctx); if (rc) return rc; }
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
     const long long xb = 4ll * groups * cpg_in * H * W, wb = 4ll * vido_gconv3x3_packed_size(groups, cpg_in, cpg_out);
-    GcArgs A{x, w_packed, bias, in_bias, y, H, W, cpg_in, cpg_out, p.R, p.PS, slope, p.gx, p.gx * groups * (p.kind == 32 ? cpg_out / 32 : 1), (unsigned)xb, (unsigned)wb};
-    static const bool no_dma32 = getenv("VIDO_GCONV_NO_DMA") != nullptr;
+    GcArgs A{x, w_packed, bias, in_bias, y, H, W, cpg_in, cpg_out, p.R, p.PS, slope, p.gx, p.gx * groups * (p.kind == 32 ? cpg_out / 32 : 1), (unsigned)xb, (unsigned)wb, 0, 0, 0, 0, 0};
+    static const bool no_dma32 = getenv("VIDO_GCONV_NO_DMA") != nullptr, no_dma16 = getenv("VIDO_GCONV_NO_DMA16") != nullptr;
+    const long long yb = 4ll * groups * cpg_out * H * W, npos16 = (long long)H * (W + 4) + 1024;
+    if (p.kind != 32 && p.nj && !in_bias && !no_dma16 && xb < (1ll << 30) && yb < (1ll << 30) && wb < (1ll << 32) && slope >= 0.f && slope <= 1.f && ((uintptr_t)w_packed & 15) == 0
+        && npos16 * (W + 4) < (1ll << 32) && (long long)A.total * p.gx < (1ll << 32)) {      // (the last two: the kernel's reciprocal divisions are exact)
+        A.PS = p.PSd; A.nj = p.nj; { static const int abl = [] { const char* e = getenv("VIDO_GCONV_ABLATE"); return e ? atoi(e) : 0; }(); A.ablate = abl; }
+        auto magic = [](unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); };      // d >= 2
+        A.m_wq = magic((unsigned)(W + 4) / 4); A.m_wpd = magic((unsigned)(W + 4)); A.m_gx = p.gx > 1 ? magic((unsigned)p.gx) : 0;
+        const dim3 grid(8 * ((A.total + 7) / 8)), blk(256);
+        if (p.kind == 8) hipLaunchKernelGGL(k_gconv3x3_m16d<8>, grid, blk, p.lds_d, st, A); else hipLaunchKernelGGL(k_gconv3x3_m16d<16>, grid, blk, p.lds_d, st, A);
+        HIP_TRY(ctx, hipGetLastError());
+        return VIDO_OK;
+    }
     if (p.kind == 32 && !in_bias && !no_dma32 && xb < (1ll << 30) && wb < (1ll << 32) && slope >= 0.f && slope <= 1.f && ((uintptr_t)w_packed & 15) == 0) {
         static bool attr[64] = {};
         if (!attr[ctx->device & 63]) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gconv3x3_m32d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * p.lds))); attr[ctx->device & 63] = true; }
