@@ -1,0 +1,61 @@
+// Do the vector-ALU instructions of ANOTHER wave on the same SIMD hide behind fp32 matrix instructions?  Workgroup of 8 waves = two per SIMD: waves 0-3 run back-to-back
+// v_mfma_f32_32x32x2f32 (or 16x16x4) on 16 independent accumulators, waves 4-7 run independent v_add_f32 (8 chains).  Each role is timed alone and beside the other one.
+// build: hipcc -w --offload-arch=gfx950 -O3 tools/ubench/mfma_two_waves.hip -o tools/ubench/mfma_two_waves.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int KIND> __global__ __launch_bounds__(512) void k(float* out, int it_m, int it_v, unsigned long long* clk)
+{
+    const int wv = threadIdx.x >> 6;
+    float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f, s = 0.f;
+    if (wv < 4) {
+        if (it_m == 0) return;
+        f32x16 acc[8]; f32x4 acc4[16];      // (two waves per SIMD: 256 registers each)
+#pragma unroll
+        for (int i = 0; i < 16; i++) { for (int r = 0; r < 16; r++) acc[i & 7][r] = 0.f; for (int r = 0; r < 4; r++) acc4[i][r] = 0.f; }
+        const unsigned long long c0 = clock64();
+        for (int it = 0; it < it_m; it++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (KIND == 0) acc[i & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i & 7], 0, 0, 0);
+                else acc4[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc4[i], 0, 0, 0);
+            }
+        }
+        const unsigned long long c1 = clock64();
+#pragma unroll
+        for (int i = 0; i < 16; i++) { for (int r = 0; r < 16; r++) s += acc[i & 7][r]; for (int r = 0; r < 4; r++) s += acc4[i][r]; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) clk[0] = c1 - c0;
+    } else {
+        if (it_v == 0) return;
+        float v[8]; for (int i = 0; i < 8; i++) v[i] = a + i;
+        const unsigned long long c0 = clock64();
+        for (int it = 0; it < it_v; it++) {
+#pragma unroll
+            for (int f = 0; f < 64; f++) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[f & 7]) : "v"(b));
+        }
+        const unsigned long long c1 = clock64();
+        for (int i = 0; i < 8; i++) s += v[i];
+        if (blockIdx.x == 0 && threadIdx.x == 256) clk[1] = c1 - c0;
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+template <int KIND> void run(int it_m, int it_v, const char* what)
+{
+    const int wgs = 256;
+    float* out; unsigned long long* clk; (void)hipMalloc(&out, wgs * 512 * 4); (void)hipMalloc(&clk, 16); (void)hipMemset(clk, 0, 16);
+    for (int rep = 0; rep < 2; rep++) { hipLaunchKernelGGL((k<KIND>), dim3(wgs), dim3(512), 0, 0, out, it_m, it_v, clk); (void)hipDeviceSynchronize(); }
+    unsigned long long h[2]; (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+    const double cyc_m = KIND == 0 ? 64.0 : 32.0;
+    printf("%-34s %s: ", what, KIND == 0 ? "32x32x2" : "16x16x4");
+    if (it_m) printf("matrix waves %.1f cycles per instruction (alone: %.0f)  ", (double)h[0] / (16.0 * it_m), cyc_m);
+    if (it_v) printf("vector waves %.2f cycles per v_add_f32", (double)h[1] / (64.0 * it_v));
+    printf("\n");
+    (void)hipFree(out); (void)hipFree(clk);
+}
+int main()
+{
+    run<0>(4000, 0, "matrix alone"); run<0>(0, 16000, "vector alone"); run<0>(4000, 16000, "both (equal work if hidden)"); run<0>(4000, 64000, "both, vector outlasts matrix");
+    run<1>(8000, 0, "matrix alone"); run<1>(8000, 16000, "both"); run<1>(8000, 64000, "both, vector outlasts matrix");
+    return 0;
+}

@@ -408,6 +408,7 @@ __global__ __launch_bounds__(256) void k_gconv3x3_m16d(GcArgs A)
     }
 }
 
+
 // geometry of a call: which kernel, rows of the band, plane pitch, LDS bytes; 0 = not supported
 struct GcPlan { int kind; int R, PS; size_t lds; int gx; bool v4; int nj, PSd; size_t lds_d; };      // nj > 0: k_gconv3x3_m16d has a plan too (plane pitch PSd, lds_d bytes)
 static GcPlan gc_plan(int H, int W, int cpg_in, int cpg_out, bool aligned16 = true)
