@@ -204,6 +204,28 @@ def test_grouped_conv_matrix_core_kernel_equals_conv2d(vido, ctx, cpg, H, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cpg,H,W", [(32, 100, 136), (64, 50, 68), (32, 11, 12), (32, 2, 4), (64, 7, 8), (32, 40, 200)])
+def test_strided_grouped_conv_matrix_core_kernel_equals_conv2d(vido, ctx, cpg, H, W):
+    """csrc/gconv.hip::k_gconv3x3_s2_m32 against conv2d(stride 2, padding 1) in float64: the first bottleneck of layer3 / layer4 at its FPN-stage size, odd heights, bands cut
+    by the image border, a 2 x 4 map, a row wider than a tile."""
+    from vido_slam_amd.nets.ops import HipOps, pack_gconv3x3
+    ops = HipOps(ctx); groups = 32 if H * W > 2000 else 3
+    g = torch.Generator().manual_seed(cpg * 1000 + H)
+    x = torch.randn(1, groups * cpg, H, W, generator=g); w = torch.randn(groups * cpg, cpg, 3, 3, generator=g) * (1.0 / (3 * cpg ** 0.5)); b = torch.randn(groups * cpg, generator=g)
+    assert ops.gconv3x3_s2_supported(H, W, cpg, cpg)
+    wp = pack_gconv3x3(w, groups).cuda()
+    for slope in (0.0, 1.0):
+        y = ops.gconv3x3_s2_bias_act(x.cuda(), wp, b.cuda(), groups, slope).cpu()
+        ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 2, 1, 1, groups), slope)
+        assert y.shape == ref.shape, (y.shape, ref.shape)
+        err = float((y.double() - ref).abs().max())
+        assert err < 2e-5 * max(1.0, float(ref.abs().max())), (cpg, H, W, slope, err)
+    assert not ops.gconv3x3_s2_supported(50, 70, 32, 32) and not ops.gconv3x3_s2_supported(50, 68, 16, 16) and not ops.gconv3x3_s2_supported(40, 300, 32, 32)      # W % 4, < 32 channels per group, a band that does not fit two LDS buffers: the library keeps them
+    with pytest.raises(vido.VidoError):
+        ops.gconv3x3_s2_bias_act(torch.zeros(1, 64, 50, 70, device="cuda"), torch.zeros(64 * 32 * 9, device="cuda"), torch.zeros(64, device="cuda"), 2, 0.0)
+
+
+@pytest.mark.gpu
 def test_bottleneck_with_matrix_core_conv2_equals_library_path(vido, ctx):
     """_Bottleneck.forward with conv2 on csrc/gconv.hip against the same block on the library convolution + bias pass."""
     from vido_slam_amd.nets import maskrcnn as M
@@ -255,7 +277,7 @@ def test_bottleneck_with_matrix_core_1x1_equals_library_path(vido, ctx, monkeypa
     from vido_slam_amd.nets.ops import HipOps
     from vido_slam_amd.nets.weights import fill_maskrcnn
     monkeypatch.setattr("vido_slam_amd.nets.ops._C1X1_MIN_TILES", 0)          # (test-sized maps: by default a layer of fewer than 160 tiles stays with the library)
-    for cin, mid, cout, stride in ((64, 256, 256, 1), (256, 256, 256, 1), (256, 512, 512, 2)):     # first block of layer1 (stride-1 shortcut convolution), a plain one, a stage's first block (stride-2 shortcut)
+    for cin, mid, cout, stride in ((64, 256, 256, 1), (256, 256, 256, 1), (256, 512, 512, 2), (512, 1024, 1024, 2)):     # first block of layer1 (stride-1 shortcut convolution), a plain one, a stage's first block (stride-2 shortcut), layer3's (+ the strided conv2 on csrc/gconv.hip)
         blk = M._Bottleneck(cin, mid, cout, 32, False, stride)
         fill_maskrcnn(blk); blk = blk.cuda().eval()
         x = torch.randn(1, cin, 40, 52, generator=torch.Generator().manual_seed(4)).cuda()

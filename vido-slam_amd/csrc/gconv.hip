@@ -170,10 +170,12 @@ __global__ __launch_bounds__(256) void k_gconv3x3_m32d(GcArgs A)
         };
         ld(0); ld(1);
 #pragma unroll
-        for (int s = 0; s < 36; s++) {
+        for (int s = 0; s < 36; s++) {                                // (scheduling barriers: left alone, the scheduler sinks every read to just before its matrix instruction and a lone wave runs at LDS latency)
             if (s + 2 < 36) ld(s + 2);
+            __builtin_amdgcn_sched_barrier(0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s % 3], b0[s % 3], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s % 3], b1[s % 3], acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // D[i][j]: lane = 32 * ((i / 4) & 1) + j, register = 4 * (i / 8) + (i & 3)  ->  a register holds one output channel of 32 consecutive positions per half wave
@@ -463,6 +465,119 @@ template <int NTW> static void gc_m16_launch(const GcPlan& p, int groups, hipStr
     if (A.in_bias) { if (p.v4) hipLaunchKernelGGL((k_gconv3x3_m16<NTW, true, true>), grid, blk, p.lds, st, A); else hipLaunchKernelGGL((k_gconv3x3_m16<NTW, true, false>), grid, blk, p.lds, st, A); }
     else { if (p.v4) hipLaunchKernelGGL((k_gconv3x3_m16<NTW, false, true>), grid, blk, p.lds, st, A); else hipLaunchKernelGGL((k_gconv3x3_m16<NTW, false, false>), grid, blk, p.lds, st, A); }
 }
+
+// ---- stride 2, >= 32 channels per group (round 4): `conv2` of the first bottleneck of layer3 / layer4 (resnet.py:300-372 with STRIDE_IN_1X1 = False), which the library runs
+// as a strided Winograd kernel on the vector ALUs at 57-58 us per call + our bias pass.  The flattened-position formulation survives the stride if the band's EVEN and ODD
+// input rows live in separate LDS planes of row pitch PL = W + 4 (four pad positions on the left of every row, as in k_gconv3x3_m16d) and the outputs are flattened with
+// pitch PL / 2: output position q = yo * (PL / 2) + xo then reads input (2 yo - 1 + dy, 2 xo - 1 + dx) at  2 q + dx + 3  in the even plane (dy = 1), in the odd plane
+// (dy = 0) or one row further down the odd plane (dy = 2) — constant offsets again, the B operand of a lane is one ds_read_b32 at twice its position.  Everything else is
+// k_gconv3x3_m32d (tiles, items, weight packing, two LDS buffers, one barrier per 8-channel chunk) with the 16-byte slot copies of k_gconv3x3_m16d.
+#define GS2_MAXJ 12
+struct Gs2Args { const float* x; const float* w; const float* bias; float* y; int H, W, Ho, Wo, Wop, PL, NE, PS, cpg_in, cpg_out, gx, total, nj; float slope; unsigned xbytes, wbytes, m_plq; };
+__global__ __launch_bounds__(256) void k_gconv3x3_s2_m32(Gs2Args A)
+{
+    extern __shared__ __attribute__((aligned(16))) float gc_lds[];
+    constexpr int WSZ = 9 * GC_KC * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = A.H, W = A.W, Wo = A.Wo, Wop = A.Wop, PL = A.PL, PLq = PL >> 2, NE = A.NE, PS = A.PS, nj = A.nj, npos = A.Ho * Wop;
+    const int BUF = WSZ + GC_KC * PS;                                 // floats per buffer: weights [9][8][32], then 8 channels of [even rows | odd rows]
+    const int nchunk = A.cpg_in / GC_KC, ncob = A.cpg_out / 32;
+    const int item = gc_item(A.total); if (item < 0) return;
+    const int chunk = item % A.gx, cob = (item / A.gx) % ncob, g = item / (A.gx * ncob), q0 = chunk * 256, r0 = q0 / Wop;
+    const unsigned HW = (unsigned)H * (unsigned)W, HWo = (unsigned)A.Ho * (unsigned)Wo;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.x, 0, A.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)A.w, 0, A.wbytes, 0x00020000);
+    unsigned voff[GS2_MAXJ];                    // byte offset, inside a channel image, of this lane's quad of instruction j; bit 30: padding / outside the image / past the band
+#pragma unroll
+    for (int j = 0; j < GS2_MAXJ; j++) {
+        const int s = lane + 64 * j, rr = (int)__umulhi((unsigned)s, A.m_plq), xq = s - rr * PLq;
+        const int row = rr < NE ? 2 * (r0 + rr) : 2 * (r0 + rr - NE) - 1;      // even plane: output rows r0 .., odd plane: the input rows above them (2 (r0 - 1) + 1 ..)
+        voff[j] = (rr < 2 * NE + 1 && xq >= 1 && row >= 0 && row < H) ? 4u * (unsigned)(row * W + 4 * (xq - 1)) : 0x40000000u;
+    }
+    const unsigned wvo = 16u * (unsigned)lane;
+    const unsigned wbase = 4u * (unsigned)(((g * ncob + cob) * nchunk) * WSZ);
+    const unsigned xbase = 4u * (unsigned)(g * A.cpg_in) * HW;
+    // wave wv copies channels 2 wv, 2 wv + 1 of a chunk (nj instructions each) and pieces wv, wv + 4, wv + 8 of its 9 KB of weights
+    auto issue = [&](int c, int buf) {
+        float* base = gc_lds + buf * BUF;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned so = xbase + 4u * (unsigned)(c * GC_KC + 2 * wv + h) * HW;
+            float* plane = base + WSZ + (2 * wv + h) * PS;
+#pragma unroll
+            for (int j = 0; j < GS2_MAXJ; j++)
+                if (j < nj) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(plane + 256 * j), 16, voff[j], so, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int piece = wv + 4 * q;
+            if (piece < 9) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(base + piece * 256), 16, wvo, wbase + 4u * (unsigned)(c * WSZ + piece * 256), 0, 0);
+        }
+    };
+    const int co_base = g * A.cpg_out + cob * 32;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const float b = A.bias[co_base + 8 * (r / 4) + 4 * (lane >> 5) + (r & 3)]; acc0[r] = b; acc1[r] = b; }
+    typedef const volatile __attribute__((address_space(3))) float* lds_f;      // (volatile: see k_gconv3x3_m32d)
+    const int bbase = WSZ + (lane >> 5) * PS + 2 * (q0 + 64 * wv - r0 * Wop + (lane & 31)) + 3;      // B operand of tile 2 wv (tile 2 wv + 1: + 64), even plane, dx = 0, channel pair 0
+    issue(0, 0);
+    for (int c = 0; c < nchunk; c++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                              // chunk c has landed in buffer c & 1; everybody is done with buffer (c + 1) & 1
+        if (c + 1 < nchunk) issue(c + 1, (c + 1) & 1);
+        lds_f Wb = (lds_f)(gc_lds + (c & 1) * BUF) + lane;
+        lds_f BE = (lds_f)(gc_lds + (c & 1) * BUF) + bbase;
+        lds_f Bk[4][3];                                               // [channel pair][tap row]: odd plane (dy = 0), even plane (dy = 1), odd plane one row down (dy = 2)
+#pragma unroll
+        for (int kp = 0; kp < 4; kp++) { Bk[kp][1] = BE + 2 * kp * PS; Bk[kp][0] = Bk[kp][1] + NE * PL; Bk[kp][2] = Bk[kp][0] + PL; }
+        float a[3], b0[3], b1[3];
+        auto ld = [&](int s) {                                        // step s = tap * 4 + kp
+            const int tap = s >> 2, kp = s & 3; lds_f Bt = Bk[kp][tap / 3];
+            a[s % 3] = Wb[(tap * 8 + 2 * kp) * 32]; b0[s % 3] = Bt[tap % 3]; b1[s % 3] = Bt[tap % 3 + 64];
+        };
+        ld(0); ld(1);
+#pragma unroll
+        for (int s = 0; s < 36; s++) {                                // (scheduling barriers: left alone, the scheduler sinks every read to just before its matrix instruction and a lone wave runs at LDS latency)
+            if (s + 2 < 36) ld(s + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s % 3], b0[s % 3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s % 3], b1[s % 3], acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // D[i][j]: lane = 32 * ((i / 4) & 1) + j, register = 4 * (i / 8) + (i & 3)  ->  a register holds one output channel of 32 consecutive positions per half wave
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int q = q0 + 64 * wv + 32 * t + (lane & 31), yy = q / Wop, xx = q - yy * Wop;
+        if (q < npos && xx < Wo) {
+            float* yo = A.y + (size_t)co_base * HWo + (size_t)yy * Wo + xx;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = 8 * (r / 4) + 4 * (lane >> 5) + (r & 3);
+                const float v = t ? acc1[r] : acc0[r];
+                yo[(size_t)co * HWo] = fmaxf(v, v * A.slope);
+            }
+        }
+    }
+}
+
+// geometry of a stride-2 call; lds == 0: not supported
+struct Gs2Plan { int Ho, Wo, Wop, PL, NE, PS, gx, nj; size_t lds; };
+static Gs2Plan gs2_plan(int H, int W, int cpg_in, int cpg_out)
+{
+    Gs2Plan p{};
+    if (H < 2 || W < 4 || W % 4 || cpg_in < GC_KC || cpg_in % GC_KC || cpg_out % 32) return p;
+    p.Ho = (H + 1) / 2; p.Wo = W / 2; p.PL = W + 4; p.Wop = p.PL / 2;
+    p.NE = 2 + 255 / p.Wop;                                         // output rows 256 consecutive positions can touch; the odd plane holds one row more
+    const int nslots = (2 * p.NE + 1) * (p.PL / 4) + 1;             // (+ the pad quad behind the last row)
+    p.nj = (nslots + 63) / 64;
+    p.PS = std::max((2 * p.NE + 1) * p.PL + 4, 256 * p.nj);
+    p.gx = (p.Ho * p.Wop + 255) / 256;
+    const size_t lds = 2 * (size_t)(9 * GC_KC * 32 + GC_KC * p.PS) * 4;
+    if (p.nj > GS2_MAXJ || lds > 156 * 1024) return p;
+    p.lds = lds;
+    return p;
+}
 }  // namespace
 
 extern "C" {
@@ -516,6 +631,34 @@ int vido_gconv3x3_bias_act(vido_ctx* ctx, const float* x, const float* in_bias, 
     else if (p.kind == 32) hipLaunchKernelGGL(k_gconv3x3_m32, dim3(8 * ((A.total + 7) / 8)), dim3(256), p.lds, st, A);
     else if (p.kind == 8) gc_m16_launch<8>(p, groups, st, A);
     else gc_m16_launch<16>(p, groups, st, A);
+    HIP_TRY(ctx, hipGetLastError());
+    return VIDO_OK;
+}
+
+/* 1 when vido_gconv3x3_s2_bias_act has a kernel for this shape (stride 2, padding 1: output (H + 1) / 2 x W / 2): W a multiple of 4, channels per group a multiple of 32 (out) / 8 (in). */
+int vido_gconv3x3_s2_supported(int H, int W, int cpg_in, int cpg_out)
+{
+    return gs2_plan(H, W, cpg_in, cpg_out).lds != 0;
+}
+
+/* y = leaky_relu(conv2d(x, w, stride 2, padding 1, groups) + bias, slope) for one image: x [groups * cpg_in][H][W], y [groups * cpg_out][(H + 1) / 2][W / 2] f32 DEVICE tensors
+ * (x 16-byte aligned), w_packed as for vido_gconv3x3_bias_act (>= 32 output channels per group).  Replaces the strided `conv2` + `bn2` + `relu_` of the first bottleneck of a
+ * ResNeXt stage (maskrcnn_benchmark/modeling/backbone/resnet.py:300-372, STRIDE_IN_1X1 = False).  Enqueues on the adopted stream; capturable. */
+int vido_gconv3x3_s2_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, float* y, int groups, int cpg_in, int cpg_out, int H, int W, float slope)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!x || !w_packed || !bias || !y || x == y || groups < 1 || groups > 65535 || ((uintptr_t)x & 15) || ((uintptr_t)w_packed & 15) || !(slope >= 0.f && slope <= 1.f))
+        return vido_set_error(ctx, VIDO_E_INVALID, "gconv3x3_s2: bad arguments");
+    const Gs2Plan p = gs2_plan(H, W, cpg_in, cpg_out);
+    const long long xb = 4ll * groups * cpg_in * H * W, wb = 4ll * vido_gconv3x3_packed_size(groups, cpg_in, cpg_out);
+    if (!p.lds || xb >= (1ll << 30) || wb >= (1ll << 32)) return vido_set_error(ctx, VIDO_E_INVALID, "gconv3x3_s2: no kernel for %d -> %d channels per group at %d x %d", cpg_in, cpg_out, H, W);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    static bool attr[64] = {};
+    if (!attr[ctx->device & 63]) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gconv3x3_s2_m32, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); attr[ctx->device & 63] = true; }
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    Gs2Args A{x, w_packed, bias, y, H, W, p.Ho, p.Wo, p.Wop, p.PL, p.NE, p.PS, cpg_in, cpg_out, p.gx, p.gx * groups * (cpg_out / 32), p.nj, slope, (unsigned)xb, (unsigned)wb,
+              (unsigned)((0x100000000ull + (unsigned)(p.PL / 4) - 1) / (unsigned)(p.PL / 4))};
+    hipLaunchKernelGGL(k_gconv3x3_s2_m32, dim3(8 * ((A.total + 7) / 8)), dim3(256), p.lds, st, A);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }

@@ -46,6 +46,10 @@ def fold_batchnorm(net, ops):
             if c2.groups > 1 and tuple(c2.stride) == (1, 1) and tuple(c2.padding) == (1, 1) and tuple(c2.dilation) == (1, 1) and not os.environ.get("VIDO_NO_GCONV"):
                 from .ops import pack_gconv3x3
                 m._w2p = pack_gconv3x3(m._w2, c2.groups)
+            elif (c2.groups > 1 and tuple(c2.stride) == (2, 2) and tuple(c2.padding) == (1, 1) and tuple(c2.dilation) == (1, 1) and (c2.out_channels // c2.groups) % 32 == 0
+                  and not os.environ.get("VIDO_NO_GCONV") and not os.environ.get("VIDO_NO_GCONV_S2")):
+                from .ops import pack_gconv3x3
+                m._w2p = pack_gconv3x3(m._w2, c2.groups)      # the strided conv2 of a stage's first block: csrc/gconv.hip::k_gconv3x3_s2_m32 (same operand order)
             # the 1x1 convolutions as our own fp32 matrix-core GEMM with the bias (+ shortcut) + ReLU in its epilogue (csrc/conv1x1.hip).  Measured on the detector's shapes
             # (tools/prof_conv1x1.py, profiles/r4/conv1x1_microbench_v3.txt) the GEMM alone runs where the library's does (66 us / 107 TFLOP/s at 1024 -> 1024 on 50 x 68 against
             # 66-68); what it saves is the pass behind the library's: conv3's bias + shortcut + ReLU (8-13 us per block), the stride-1 shortcut's bias, and conv1's bias + ReLU,

@@ -87,7 +87,12 @@ class _Bottleneck(nn.Module):              # resnet.py:277-372 (BottleneckWithFi
                 y = ops.conv1x1_bias_act(x.contiguous(), self._w1p, self._b1, None, 0.0); b1_done = True      # our GEMM: its bias + ReLU leave through its accumulators
             else:
                 y = F.conv2d(x, self._w1, None, c1.stride)                                                   # the library's: they ride on conv2's operand reads, or run below
-            if self._w2p is not None and y.shape[0] == 1 and self._ops.gconv3x3_supported(y.shape[2], y.shape[3], c2.in_channels // c2.groups, c2.out_channels // c2.groups):
+            if (self._w2p is not None and tuple(c2.stride) == (2, 2)):
+                if b1_done and y.shape[0] == 1 and self._ops.gconv3x3_s2_supported(y.shape[2], y.shape[3], c2.in_channels // c2.groups, c2.out_channels // c2.groups):
+                    y = self._ops.gconv3x3_s2_bias_act(y, self._w2p, self._b2, c2.groups, 0.0)
+                else:
+                    y = ep(F.conv2d(y if b1_done else ep(y, self._b1, None, 0.0), self._w2, None, c2.stride, c2.padding, c2.dilation, c2.groups), self._b2, None, 0.0)
+            elif self._w2p is not None and y.shape[0] == 1 and self._ops.gconv3x3_supported(y.shape[2], y.shape[3], c2.in_channels // c2.groups, c2.out_channels // c2.groups):
                 # conv2's own bias + ReLU leave through its accumulators; after a library conv1 its bias + ReLU are applied where conv2 reads its operands
                 y = self._ops.gconv3x3_bias_act(y, self._w2p, self._b2, c2.groups, 0.0, in_bias=None if b1_done else self._b1)
             else:

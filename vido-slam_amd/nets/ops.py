@@ -130,6 +130,21 @@ class HipOps:
                                                             int(groups), cpg_in, cpg_out, H, W, C.c_float(slope)))
         return out
 
+    def gconv3x3_s2_supported(self, H, W, cpg_in, cpg_out):
+        return bool(self.ctx.lib.vido_gconv3x3_s2_supported(int(H), int(W), int(cpg_in), int(cpg_out)))
+
+    def gconv3x3_s2_bias_act(self, x, w_packed, bias, groups, slope=0.0):
+        """leaky_relu(conv2d(x, w, None, 2, 1, 1, groups) + bias, slope) for one image as one matrix-core launch (csrc/gconv.hip::k_gconv3x3_s2_m32); w_packed = pack_gconv3x3(w, groups)."""
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and x.shape[0] == 1
+        _, Cin, H, W = x.shape
+        cpg_in = Cin // groups; cpg_out = bias.numel() // groups
+        out = torch.empty((1, bias.numel(), (H + 1) // 2, W // 2), device=x.device, dtype=torch.float32)
+        self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * bias.numel() * cpg_in * 9 * out.shape[2] * out.shape[3]
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_gconv3x3_s2_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(w_packed.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                               int(groups), cpg_in, cpg_out, H, W, C.c_float(slope)))
+        return out
+
     def conv1x1_supported(self, cin, cout, hw):
         return bool(self.ctx.lib.vido_conv1x1_supported(int(cin), int(cout), int(hw)))
 
