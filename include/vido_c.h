@@ -335,7 +335,7 @@ int vido_gconv3x3_supported(int H, int W, int cpg_in, int cpg_out);
 int64_t vido_gconv3x3_packed_size(int groups, int cpg_in, int cpg_out);
 int vido_gconv3x3_bias_act(vido_ctx* ctx, const float* x, const float* in_bias, const float* w_packed, const float* bias, float* y, int groups, int cpg_in, int cpg_out, int H, int W, float slope);
 /* ... with stride 2 (padding 1): the strided `conv2` of the first bottleneck of a ResNeXt stage (resnet.py:300-372 with STRIDE_IN_1X1 = False).  y [groups * cpg_out][(H + 1) / 2][W / 2];
- * W a multiple of 4, >= 32 output channels per group (same w_packed), x 16-byte aligned, no in_bias.  vido_gconv3x3_s2_supported: 1 when the shape has a kernel. */
+ * W a multiple of 4, 8 / 16 / a multiple of 32 output channels per group (same w_packed), x 16-byte aligned, no in_bias.  vido_gconv3x3_s2_supported: 1 when the shape has a kernel. */
 int vido_gconv3x3_s2_supported(int H, int W, int cpg_in, int cpg_out);
 int vido_gconv3x3_s2_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, float* y, int groups, int cpg_in, int cpg_out, int H, int W, float slope);
 int vido_lfn_reg_front(vido_ctx* ctx, const float* im1, const float* im2, const float* flow, const float* mean, float scale, int B, int C, int H, int W, float* out, int out_channels);

@@ -473,7 +473,7 @@ template <int NTW> static void gc_m16_launch(const GcPlan& p, int groups, hipStr
 // (dy = 0) or one row further down the odd plane (dy = 2) — constant offsets again, the B operand of a lane is one ds_read_b32 at twice its position.  Everything else is
 // k_gconv3x3_m32d (tiles, items, weight packing, two LDS buffers, one barrier per 8-channel chunk) with the 16-byte slot copies of k_gconv3x3_m16d.
 #define GS2_MAXJ 12
-struct Gs2Args { const float* x; const float* w; const float* bias; float* y; int H, W, Ho, Wo, Wop, PL, NE, PS, cpg_in, cpg_out, gx, total, nj; float slope; unsigned xbytes, wbytes, m_plq; };
+struct Gs2Args { const float* x; const float* w; const float* bias; float* y; int H, W, Ho, Wo, Wop, PL, NE, PS, cpg_in, cpg_out, gx, total, nj; float slope; unsigned xbytes, wbytes, m_plq, ybytes; };
 __global__ __launch_bounds__(256) void k_gconv3x3_s2_m32(Gs2Args A)
 {
     extern __shared__ __attribute__((aligned(16))) float gc_lds[];
@@ -561,20 +561,120 @@ __global__ __launch_bounds__(256) void k_gconv3x3_s2_m32(Gs2Args A)
     }
 }
 
+
+// ---- stride 2, 16 (or 8) channels per group: `conv2` of layer2's first bottleneck.  k_gconv3x3_m16d's matrix loop (16x16x4 tiles, one 8-channel chunk in ONE LDS buffer, two
+// workgroups per CU) over k_gconv3x3_s2_m32's band (even / odd input rows in separate planes of pitch W + 4, outputs flattened with half that pitch: B operand at twice the
+// lane's position).  NTW tiles of 16 output positions per wave.
+template <int NTW>
+__global__ __launch_bounds__(256) void k_gconv3x3_s2_m16(Gs2Args A)
+{
+    extern __shared__ __attribute__((aligned(16))) float gc_lds[];
+    float* Wl = gc_lds;                         // [9][8][16] (+ 128)
+    float* In = gc_lds + GC16_WSZ;              // [8][PS]: [even rows | odd rows]
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = A.H, W = A.W, Wo = A.Wo, Wop = A.Wop, PL = A.PL, PLq = PL >> 2, NE = A.NE, PS = A.PS, nj = A.nj, npos = A.Ho * Wop;
+    constexpr int P = NTW * 64;
+    const int item = gc_item(A.total); if (item < 0) return;
+    const int g = item / A.gx, q0 = (item - g * A.gx) * P, r0 = q0 / Wop;
+    const int nchunk = A.cpg_in / GC_KC;
+    const unsigned HW = (unsigned)H * (unsigned)W, HWo = (unsigned)A.Ho * (unsigned)Wo;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.x, 0, A.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)A.w, 0, A.wbytes, 0x00020000);
+    unsigned voff[GS2_MAXJ];
+#pragma unroll
+    for (int j = 0; j < GS2_MAXJ; j++) {
+        const int s = lane + 64 * j, rr = (int)__umulhi((unsigned)s, A.m_plq), xq = s - rr * PLq;
+        const int row = rr < NE ? 2 * (r0 + rr) : 2 * (r0 + rr - NE) - 1;
+        voff[j] = (rr < 2 * NE + 1 && xq >= 1 && row >= 0 && row < H) ? 4u * (unsigned)(row * W + 4 * (xq - 1)) : 0x40000000u;
+    }
+    const unsigned wvo = 16u * (unsigned)lane;
+    const unsigned wbase = 4u * (unsigned)(g * nchunk * (9 * GC_KC * 16));
+    const unsigned xbase = 4u * (unsigned)(g * A.cpg_in) * HW;
+    auto issue = [&](int c) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned so = xbase + 4u * (unsigned)(c * GC_KC + 2 * wv + h) * HW;
+            float* plane = In + (2 * wv + h) * PS;
+#pragma unroll
+            for (int j = 0; j < GS2_MAXJ; j++)
+                if (j < nj) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(plane + 256 * j), 16, voff[j], so, 0, 0);
+        }
+        const unsigned wso = wbase + 4u * (unsigned)(c * (9 * GC_KC * 16));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(Wl + 256 * wv), 16, wvo, wso + 1024u * (unsigned)wv, 0, 0);
+        if (wv == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(Wl + 1024), 16, wvo, wso + 4096u, 0, 0);
+    };
+    const int co_base = g * A.cpg_out;
+    f32x4 acc[NTW];
+    {
+        float b4[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int co = 4 * (lane >> 4) + r; b4[r] = co < A.cpg_out ? A.bias[co_base + co] : 0.f; }
+#pragma unroll
+        for (int t = 0; t < NTW; t++) { acc[t][0] = b4[0]; acc[t][1] = b4[1]; acc[t][2] = b4[2]; acc[t][3] = b4[3]; }
+    }
+    typedef const volatile __attribute__((address_space(3))) float* lds_f;
+    const int bbase = (lane >> 4) * PS + 2 * (q0 + 16 * NTW * wv - r0 * Wop + (lane & 15)) + 3;      // even plane, dx = 0, channel quad 0; tile t: + 32 t
+    lds_f Wb = (lds_f)Wl + lane;
+    lds_f B01 = (lds_f)In + bbase, B00 = B01 + NE * PL, B02 = B00 + PL, B11 = B01 + 4 * PS, B10 = B11 + NE * PL, B12 = B10 + PL;      // [k4][tap row]: odd plane, even plane, odd plane one row down
+    for (int c = 0; c < nchunk; c++) {
+        if (c) __syncthreads();
+        issue(c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float a[2], b[2][NTW];
+        auto ld = [&](int s, int half) {
+            const int tap = s >> 1, k4 = s & 1;
+            lds_f Bt = k4 ? (tap < 3 ? B10 : (tap < 6 ? B11 : B12)) : (tap < 3 ? B00 : (tap < 6 ? B01 : B02));
+            if (half == 0) a[s & 1] = Wb[(tap * 8 + 4 * k4) * 16];
+#pragma unroll
+            for (int t = half * (NTW / 2); t < (half + 1) * (NTW / 2); t++) b[s & 1][t] = Bt[tap % 3 + 32 * t];
+        };
+        ld(0, 0); ld(0, 1);
+#pragma unroll
+        for (int s = 0; s < 18; s++) {
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                if (s + 1 < 18) ld(s + 1, half);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = half * (NTW / 2); t < (half + 1) * (NTW / 2); t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1], b[s & 1][t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)A.y, 0, A.ybytes, 0x00020000);
+    const int co0 = 4 * (lane >> 4);
+    const unsigned ybase = 4u * ((unsigned)(co_base + co0) * HWo);
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        const int q = q0 + 16 * (NTW * wv + t) + (lane & 15), yy = q / Wop, xx = q - yy * Wop;
+        const unsigned vo = (q < npos && xx < Wo && co0 < A.cpg_out) ? ybase + 4u * (unsigned)(yy * Wo + xx) : 0x40000000u;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float v = acc[t][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(v, v * A.slope)), yr, vo, 4u * (unsigned)r * HWo, 0);
+        }
+    }
+}
+#define GS2_NTW16 4      // tiles of 16 output positions per wave of k_gconv3x3_s2_m16: 256 positions per workgroup (one LDS buffer <= 78 KB: two workgroups per CU)
+
 // geometry of a stride-2 call; lds == 0: not supported
 struct Gs2Plan { int Ho, Wo, Wop, PL, NE, PS, gx, nj; size_t lds; };
 static Gs2Plan gs2_plan(int H, int W, int cpg_in, int cpg_out)
 {
     Gs2Plan p{};
-    if (H < 2 || W < 4 || W % 4 || cpg_in < GC_KC || cpg_in % GC_KC || cpg_out % 32) return p;
+    const bool m16 = cpg_out == 16 || cpg_out == 8;
+    if (H < 2 || W < 4 || W % 4 || cpg_in < GC_KC || cpg_in % GC_KC || (cpg_out % 32 && !m16)) return p;
+    const int P = m16 ? GS2_NTW16 * 64 : 256;                       // output positions per workgroup
     p.Ho = (H + 1) / 2; p.Wo = W / 2; p.PL = W + 4; p.Wop = p.PL / 2;
-    p.NE = 2 + 255 / p.Wop;                                         // output rows 256 consecutive positions can touch; the odd plane holds one row more
+    p.NE = 2 + (P - 1) / p.Wop;                                     // output rows P consecutive positions can touch; the odd plane holds one row more
     const int nslots = (2 * p.NE + 1) * (p.PL / 4) + 1;             // (+ the pad quad behind the last row)
     p.nj = (nslots + 63) / 64;
     p.PS = std::max((2 * p.NE + 1) * p.PL + 4, 256 * p.nj);
-    p.gx = (p.Ho * p.Wop + 255) / 256;
-    const size_t lds = 2 * (size_t)(9 * GC_KC * 32 + GC_KC * p.PS) * 4;
-    if (p.nj > GS2_MAXJ || lds > 156 * 1024) return p;
+    if (m16) p.PS = ((p.PS + 15) & ~31) + 16;                       // = 16 (mod 32), as in gc_plan
+    p.gx = (p.Ho * p.Wop + P - 1) / P;
+    const size_t lds = m16 ? (size_t)(GC16_WSZ + GC_KC * p.PS) * 4 : 2 * (size_t)(9 * GC_KC * 32 + GC_KC * p.PS) * 4;
+    if (p.nj > GS2_MAXJ || lds > (m16 ? 78 : 156) * (size_t)1024) return p;
     p.lds = lds;
     return p;
 }
@@ -635,7 +735,7 @@ int vido_gconv3x3_bias_act(vido_ctx* ctx, const float* x, const float* in_bias, 
     return VIDO_OK;
 }
 
-/* 1 when vido_gconv3x3_s2_bias_act has a kernel for this shape (stride 2, padding 1: output (H + 1) / 2 x W / 2): W a multiple of 4, channels per group a multiple of 32 (out) / 8 (in). */
+/* 1 when vido_gconv3x3_s2_bias_act has a kernel for this shape (stride 2, padding 1: output (H + 1) / 2 x W / 2): W a multiple of 4, output channels per group 8, 16 or a multiple of 32, input channels per group a multiple of 8. */
 int vido_gconv3x3_s2_supported(int H, int W, int cpg_in, int cpg_out)
 {
     return gs2_plan(H, W, cpg_in, cpg_out).lds != 0;
@@ -654,11 +754,19 @@ int vido_gconv3x3_s2_bias_act(vido_ctx* ctx, const float* x, const float* w_pack
     if (!p.lds || xb >= (1ll << 30) || wb >= (1ll << 32)) return vido_set_error(ctx, VIDO_E_INVALID, "gconv3x3_s2: no kernel for %d -> %d channels per group at %d x %d", cpg_in, cpg_out, H, W);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     static bool attr[64] = {};
-    if (!attr[ctx->device & 63]) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gconv3x3_s2_m32, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); attr[ctx->device & 63] = true; }
+    if (!attr[ctx->device & 63]) {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gconv3x3_s2_m32, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gconv3x3_s2_m16<GS2_NTW16>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr[ctx->device & 63] = true;
+    }
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
-    Gs2Args A{x, w_packed, bias, y, H, W, p.Ho, p.Wo, p.Wop, p.PL, p.NE, p.PS, cpg_in, cpg_out, p.gx, p.gx * groups * (cpg_out / 32), p.nj, slope, (unsigned)xb, (unsigned)wb,
-              (unsigned)((0x100000000ull + (unsigned)(p.PL / 4) - 1) / (unsigned)(p.PL / 4))};
-    hipLaunchKernelGGL(k_gconv3x3_s2_m32, dim3(8 * ((A.total + 7) / 8)), dim3(256), p.lds, st, A);
+    const bool m16 = cpg_out % 32 != 0;
+    const long long yb = 4ll * groups * cpg_out * p.Ho * p.Wo;
+    if (yb >= (1ll << 30)) return vido_set_error(ctx, VIDO_E_INVALID, "gconv3x3_s2: output too large");
+    Gs2Args A{x, w_packed, bias, y, H, W, p.Ho, p.Wo, p.Wop, p.PL, p.NE, p.PS, cpg_in, cpg_out, p.gx, p.gx * groups * (m16 ? 1 : cpg_out / 32), p.nj, slope, (unsigned)xb, (unsigned)wb,
+              (unsigned)((0x100000000ull + (unsigned)(p.PL / 4) - 1) / (unsigned)(p.PL / 4)), (unsigned)yb};
+    if (m16) hipLaunchKernelGGL(k_gconv3x3_s2_m16<GS2_NTW16>, dim3(8 * ((A.total + 7) / 8)), dim3(256), p.lds, st, A);
+    else hipLaunchKernelGGL(k_gconv3x3_s2_m32, dim3(8 * ((A.total + 7) / 8)), dim3(256), p.lds, st, A);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }

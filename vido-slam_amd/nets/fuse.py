@@ -46,7 +46,7 @@ def fold_batchnorm(net, ops):
             if c2.groups > 1 and tuple(c2.stride) == (1, 1) and tuple(c2.padding) == (1, 1) and tuple(c2.dilation) == (1, 1) and not os.environ.get("VIDO_NO_GCONV"):
                 from .ops import pack_gconv3x3
                 m._w2p = pack_gconv3x3(m._w2, c2.groups)
-            elif (c2.groups > 1 and tuple(c2.stride) == (2, 2) and tuple(c2.padding) == (1, 1) and tuple(c2.dilation) == (1, 1) and (c2.out_channels // c2.groups) % 32 == 0
+            elif (c2.groups > 1 and tuple(c2.stride) == (2, 2) and tuple(c2.padding) == (1, 1) and tuple(c2.dilation) == (1, 1) and ((c2.out_channels // c2.groups) % 32 == 0 or (c2.out_channels // c2.groups) in (8, 16))
                   and not os.environ.get("VIDO_NO_GCONV") and not os.environ.get("VIDO_NO_GCONV_S2")):
                 from .ops import pack_gconv3x3
                 m._w2p = pack_gconv3x3(m._w2, c2.groups)      # the strided conv2 of a stage's first block: csrc/gconv.hip::k_gconv3x3_s2_m32 (same operand order)
