@@ -145,6 +145,16 @@ def test_pack_conv1x1_is_the_operand_order_of_the_kernel():
     assert pack_conv1x1(torch.zeros(64, 32, 1, 1)) is None and pack_conv1x1(torch.zeros(128, 48, 1, 1)) is None and pack_conv1x1(torch.zeros(128, 32, 3, 3)) is None
 
 
+def test_strided_grouped_conv_plan_answers_without_a_gpu():
+    """vido_gconv3x3_s2_supported (host side of csrc/gconv.hip::k_gconv3x3_s2_m32 / _m16): the detector's three strided conv2 shapes have a kernel; a width that is not a
+    multiple of 4, 24 channels per group, and a band that does not fit two LDS buffers are refused (the caller keeps the library convolution)."""
+    from vido_slam_amd.host import load_library
+    lib = load_library()
+    ok = lambda H, W, ci, co: bool(lib.vido_gconv3x3_s2_supported(H, W, ci, co))
+    assert ok(200, 272, 16, 16) and ok(100, 136, 32, 32) and ok(50, 68, 64, 64) and ok(2, 4, 32, 32) and ok(31, 40, 8, 8) and ok(100, 136, 32, 64)
+    assert not ok(50, 70, 32, 32) and not ok(50, 68, 24, 24) and not ok(40, 300, 32, 32) and not ok(50, 68, 12, 32) and not ok(1, 8, 32, 32)
+
+
 def test_pack_wino3x3_operands_reproduce_the_convolution():
     """vido_wino3x3_pack (host side of csrc/wino.hip): U = G g G^T in the kernel's operand order.  A numpy walk of the kernel's own data path — V = B^T d B of the zero-padded
     4x4 windows, M_p[co][tile] = sum_c U_p[co][c] V_p[c][tile] with U_p[co][c] read from [co / 32][c / KC][p][32 * (c & 1) + co % 32][(c % KC) / 2], Y = A^T M A — must be
