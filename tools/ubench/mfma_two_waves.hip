@@ -26,6 +26,19 @@ template <int KIND> __global__ __launch_bounds__(512) void k(float* out, int it_
 #pragma unroll
         for (int i = 0; i < 16; i++) { for (int r = 0; r < 16; r++) s += acc[i & 7][r]; for (int r = 0; r < 4; r++) s += acc4[i][r]; }
         if (blockIdx.x == 0 && threadIdx.x == 0) clk[0] = c1 - c0;
+    } else if (it_v < 0) {      // the second wave of the SIMD issues matrix instructions as well
+        f32x16 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+        const unsigned long long c0 = clock64();
+        for (int it = 0; it < -it_v; it++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i & 7], 0, 0, 0);
+        }
+        const unsigned long long c1 = clock64();
+#pragma unroll
+        for (int i = 0; i < 8; i++) for (int r = 0; r < 16; r++) s += acc[i][r];
+        if (blockIdx.x == 0 && threadIdx.x == 256) clk[1] = c1 - c0;
     } else {
         if (it_v == 0) return;
         float v[8]; for (int i = 0; i < 8; i++) v[i] = a + i;
@@ -49,13 +62,15 @@ template <int KIND> void run(int it_m, int it_v, const char* what)
     const double cyc_m = KIND == 0 ? 64.0 : 32.0;
     printf("%-34s %s: ", what, KIND == 0 ? "32x32x2" : "16x16x4");
     if (it_m) printf("matrix waves %.1f cycles per instruction (alone: %.0f)  ", (double)h[0] / (16.0 * it_m), cyc_m);
-    if (it_v) printf("vector waves %.2f cycles per v_add_f32", (double)h[1] / (64.0 * it_v));
+    if (it_v > 0) printf("vector waves %.2f cycles per v_add_f32", (double)h[1] / (64.0 * it_v));
+    if (it_v < 0) printf("second matrix waves %.1f cycles per instruction", (double)h[1] / (16.0 * -it_v));
     printf("\n");
     (void)hipFree(out); (void)hipFree(clk);
 }
 int main()
 {
     run<0>(4000, 0, "matrix alone"); run<0>(0, 16000, "vector alone"); run<0>(4000, 16000, "both (equal work if hidden)"); run<0>(4000, 64000, "both, vector outlasts matrix");
+    run<0>(4000, -4000, "two matrix waves per SIMD");
     run<1>(8000, 0, "matrix alone"); run<1>(8000, 16000, "both"); run<1>(8000, 64000, "both, vector outlasts matrix");
     return 0;
 }

@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
 #endif
 }
 
+
 // KC of the configuration that serves `cout` output channels: 2 x 2 waves (64 channels per workgroup, 8-channel chunks) unless a 64-channel grouping would compute
 // 32 or more padded channels (cout = 32, 96, ...), then 1 x 4 (32 channels per workgroup, 4-channel chunks)
 inline int wn_kc(int cout) { return (((cout + 63) / 64) * 64 - cout) < 32 ? 8 : 4; }
