@@ -155,6 +155,46 @@ def test_strided_grouped_conv_plan_answers_without_a_gpu():
     assert not ok(50, 70, 32, 32) and not ok(50, 68, 24, 24) and not ok(40, 300, 32, 32) and not ok(50, 68, 12, 32) and not ok(1, 8, 32, 32)
 
 
+def test_strided_grouped_conv_band_addressing_reproduces_the_convolution():
+    """csrc/gconv.hip::k_gconv3x3_s2_*: a numpy walk of the kernel's data path with the library's own geometry (vido_debug_gs2_plan).  Per position chunk the band is filled the way
+    the copy instructions fill it — 16-byte slots in flattened (row, quad) order, even input rows first, then the odd ones, a zero quad in front of every row — and output position
+    q = yo * Wop + xo reads tap (dy, dx) at 2 (q - r0 Wop) + dx + 3 in the even plane (dy = 1), the odd plane (dy = 0) or one row further down it (dy = 2).  Must be
+    conv2d(stride 2, padding 1) for even and odd heights, a 2 x 4 map and the detector's widths."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from vido_slam_amd.host import load_library
+    lib = load_library()
+    g = torch.Generator().manual_seed(5)
+    for H, W, cpg in ((10, 12, 32), (7, 8, 32), (2, 4, 32), (9, 136, 32), (6, 272, 16), (5, 20, 8)):
+        out = (C.c_int * 9)()
+        assert lib.vido_debug_gs2_plan(H, W, 8, cpg, out) == 1
+        Ho, Wo, Wop, PL, NE, PS, gx, nj, P = list(out)
+        assert Ho == (H + 1) // 2 and Wo == W // 2 and PL == W + 4 and Wop == PL // 2 and gx == -(-(Ho * Wop) // P) and 256 * nj <= PS and (2 * NE + 1) * PL + 4 <= PS
+        x = torch.randn(1, 1, H, W, generator=g).double(); w = torch.randn(1, 1, 3, 3, generator=g).double()
+        ref = F.conv2d(x, w, None, 2, 1)[0, 0].numpy(); xi = x[0, 0].numpy(); wk = w[0, 0].numpy()
+        got = np.zeros((Ho, Wo))
+        for chunk in range(gx):
+            q0 = chunk * P; r0 = q0 // Wop
+            plane = np.full(PS, np.nan)                                                   # (a read of something the copies did not write would poison the result)
+            for s in range(64 * nj):                                                      # one 16-byte slot per lane and copy instruction
+                rr, xq = divmod(s, PL // 4)
+                row = 2 * (r0 + rr) if rr < NE else 2 * (r0 + rr - NE) - 1
+                ok = rr < 2 * NE + 1 and xq >= 1 and 0 <= row < H
+                plane[4 * s:4 * s + 4] = xi[row, 4 * (xq - 1):4 * (xq - 1) + 4] if ok else 0.0
+            for q in range(q0, min(q0 + P, Ho * Wop)):
+                yo, xo = divmod(q, Wop)
+                if xo >= Wo:
+                    continue
+                base = 2 * (q - r0 * Wop) + 3
+                acc = 0.0
+                for dy in range(3):
+                    off = (NE * PL, 0, NE * PL + PL)[dy]                                   # odd plane, even plane, odd plane one row down
+                    for dx in range(3):
+                        acc += wk[dy, dx] * plane[off + base + dx]
+                got[yo, xo] = acc
+        assert np.allclose(got, ref, rtol=0, atol=1e-12), (H, W, cpg, float(np.abs(got - ref).max()))
+
+
 def test_pack_wino3x3_operands_reproduce_the_convolution():
     """vido_wino3x3_pack (host side of csrc/wino.hip): U = G g G^T in the kernel's operand order.  A numpy walk of the kernel's own data path — V = B^T d B of the zero-padded
     4x4 windows, M_p[co][tile] = sum_c U_p[co][c] V_p[c][tile] with U_p[co][c] read from [co / 32][c / KC][p][32 * (c & 1) + co % 32][(c % KC) / 2], Y = A^T M A — must be

@@ -735,6 +735,16 @@ int vido_gconv3x3_bias_act(vido_ctx* ctx, const float* x, const float* in_bias, 
     return VIDO_OK;
 }
 
+/* test hook (tests/test_nets_cpu.py walks the band addressing on the CPU): the geometry of a stride-2 call as
+ * out[0..8] = Ho, Wo, Wop (flattened output pitch), PL (LDS row pitch), NE (even-plane rows), PS (plane pitch), gx (position chunks), nj (copy instructions), positions per workgroup; 0 = no kernel */
+int vido_debug_gs2_plan(int H, int W, int cpg_in, int cpg_out, int* out)
+{
+    const Gs2Plan p = gs2_plan(H, W, cpg_in, cpg_out);
+    if (!p.lds || !out) return 0;
+    out[0] = p.Ho; out[1] = p.Wo; out[2] = p.Wop; out[3] = p.PL; out[4] = p.NE; out[5] = p.PS; out[6] = p.gx; out[7] = p.nj; out[8] = (cpg_out % 32) ? GS2_NTW16 * 64 : 256;
+    return 1;
+}
+
 /* 1 when vido_gconv3x3_s2_bias_act has a kernel for this shape (stride 2, padding 1: output (H + 1) / 2 x W / 2): W a multiple of 4, output channels per group 8, 16 or a multiple of 32, input channels per group a multiple of 8. */
 int vido_gconv3x3_s2_supported(int H, int W, int cpg_in, int cpg_out)
 {
