@@ -195,6 +195,40 @@ def test_strided_grouped_conv_band_addressing_reproduces_the_convolution():
         assert np.allclose(got, ref, rtol=0, atol=1e-12), (H, W, cpg, float(np.abs(got - ref).max()))
 
 
+def test_grouped_conv_buffer_copy_band_addressing_reproduces_the_convolution():
+    """csrc/gconv.hip::k_gconv3x3_m16d (8 / 16 channels per group, stride 1): the same walk — a channel plane is a run of 16-byte slots in flattened (row, quad) order with a zero
+    quad in front of every row, filled by nj copy instructions of 64 slots; output position q = y * (W + 4) + x reads tap (dy, dx) at (q - r0 (W + 4)) + dy (W + 4) + dx + 3."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from vido_slam_amd.host import load_library
+    lib = load_library()
+    g = torch.Generator().manual_seed(6)
+    for H, W, cpg in ((9, 12, 16), (3, 4, 8), (7, 272, 8), (12, 136, 16), (40, 8, 16)):
+        out = (C.c_int * 6)()
+        assert lib.vido_debug_gc16_plan(H, W, 8, cpg, out) == 1
+        R, PS, nj, gx, P, Wpd = list(out)
+        assert Wpd == W + 4 and gx == -(-(H * Wpd) // P) and 256 * nj <= PS and R * Wpd + 4 <= PS
+        x = torch.randn(1, 1, H, W, generator=g).double(); w = torch.randn(1, 1, 3, 3, generator=g).double()
+        ref = F.conv2d(x, w, None, 1, 1)[0, 0].numpy(); xi = x[0, 0].numpy(); wk = w[0, 0].numpy()
+        got = np.zeros((H, W))
+        for chunk in range(gx):
+            q0 = chunk * P; r0 = q0 // Wpd
+            plane = np.full(PS, np.nan)
+            for s in range(64 * nj):
+                rr, xq = divmod(s, Wpd // 4)
+                row = r0 - 1 + rr
+                ok = rr < R and xq >= 1 and 0 <= row < H
+                plane[4 * s:4 * s + 4] = xi[row, 4 * (xq - 1):4 * (xq - 1) + 4] if ok else 0.0
+            for q in range(q0, min(q0 + P, H * Wpd)):
+                yy, xx = divmod(q, Wpd)
+                if xx >= W:
+                    continue
+                base = (q - r0 * Wpd) + 3
+                got[yy, xx] = sum(wk[dy, dx] * plane[base + dy * Wpd + dx] for dy in range(3) for dx in range(3))
+        assert np.allclose(got, ref, rtol=0, atol=1e-12), (H, W, cpg, float(np.abs(got - ref).max()))
+    assert lib.vido_debug_gc16_plan(9, 13, 8, 16, (C.c_int * 6)()) == 0                  # W not a multiple of 4: the round-3 kernel keeps the shape
+
+
 def test_pack_wino3x3_operands_reproduce_the_convolution():
     """vido_wino3x3_pack (host side of csrc/wino.hip): U = G g G^T in the kernel's operand order.  A numpy walk of the kernel's own data path — V = B^T d B of the zero-padded
     4x4 windows, M_p[co][tile] = sum_c U_p[co][c] V_p[c][tile] with U_p[co][c] read from [co / 32][c / KC][p][32 * (c & 1) + co % 32][(c % KC) / 2], Y = A^T M A — must be

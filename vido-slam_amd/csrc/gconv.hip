@@ -735,6 +735,16 @@ int vido_gconv3x3_bias_act(vido_ctx* ctx, const float* x, const float* in_bias, 
     return VIDO_OK;
 }
 
+/* test hook: the geometry of k_gconv3x3_m16d for a stride-1 call with 8 / 16 channels per group as out[0..5] = R (band rows), PS (plane pitch), nj (copy instructions), gx (position
+ * chunks), positions per workgroup, Wpd (flattened row pitch); 0 = that kernel does not take the shape */
+int vido_debug_gc16_plan(int H, int W, int cpg_in, int cpg_out, int* out)
+{
+    const GcPlan p = gc_plan(H, W, cpg_in, cpg_out);
+    if (!p.kind || p.kind == 32 || !p.nj || !out) return 0;
+    out[0] = p.R; out[1] = p.PSd; out[2] = p.nj; out[3] = p.gx; out[4] = p.kind * 64; out[5] = W + 4;
+    return 1;
+}
+
 /* test hook (tests/test_nets_cpu.py walks the band addressing on the CPU): the geometry of a stride-2 call as
  * out[0..8] = Ho, Wo, Wop (flattened output pitch), PL (LDS row pitch), NE (even-plane rows), PS (plane pitch), gx (position chunks), nj (copy instructions), positions per workgroup; 0 = no kernel */
 int vido_debug_gs2_plan(int H, int W, int cpg_in, int cpg_out, int* out)
