@@ -507,6 +507,9 @@ int         vido_system_get_stats(const vido_system* sys, vido_system_stats* out
 int         vido_system_save_results(vido_system* sys, const char* prefix);
 /* the vido_ctx the system's tracker runs on (NULL before the first frame): lets a caller share the device / query timings */
 vido_ctx*   vido_system_context(vido_system* sys);
+/* The reference's addnoise = 1 depth noise (Frame.cc:711-716) is seeded with time(NULL): PoseOptimizationNew's result then differs from one wall-clock second to the next.
+ * seed != 0 pins cv::RNG's seed for every later draw of this process (tests, reproducible runs); 0 restores the reference behaviour.  (C++ callers: detail::SetDepthNoiseSeed.) */
+int         vido_system_set_depth_noise_seed(vido_system* sys, unsigned seed);
 
 #ifdef __cplusplus
 }

@@ -49,12 +49,14 @@ __global__ __launch_bounds__(256) void k_conv1x1(C1Args A)
     // ---- copies: both operands global -> LDS with buffer loads carrying the lds bit (16 bytes per lane, 1 KB per instruction); per-lane offsets are loop invariants, the
     // chunk and the piece ride in the scalar offset.  A piece of A = one (32-row block, group of four k-pairs) of the packed weight: 64 lanes x 4 operands, already in the
     // order the matrix instruction wants.  A piece of B = two rows of the [KC][128] activation chunk (lanes 0..31 row r, 32..63 row r + 1, four positions each); positions
-    // past the end of a row read into the next row (past the end of the tensor: the descriptor's range check returns 0): those columns are computed and never stored.
+    // past the end of a row read into the next row; past the end of the tensor they must read 0 and touch nothing.  The hardware's range check covers the PER-LANE
+    // offset (+ the instruction offset) only, never the scalar offset, so the row rides in the descriptor instead: every B copy gets base = x + row offset and
+    // num_records = the bytes left behind that row (two scalar adds per copy, no vector instruction) — the last row of the last position tile of a map whose H*W is
+    // not a multiple of 128 (25 x 34, 50 x 68) then reads zeros instead of up to 508 bytes behind the allocation.  Those columns are computed and never stored.
     // The global side of a copy is only 4-byte aligned when H*W is not a multiple of 4 (25 x 34): the 16-byte copy takes that.
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)A.wp, 0, A.wbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.x, 0, A.xbytes, 0x00020000);
     const unsigned avo = 16u * (unsigned)lane;
-    const unsigned bvo = 4u * ((unsigned)(lane >> 5) * (unsigned)A.N + (unsigned)(n0 + 4 * (lane & 31)));      // (columns past the row's end read the next row, past the tensor's end 0)
+    const unsigned bvo = 4u * ((unsigned)(lane >> 5) * (unsigned)A.N + (unsigned)(n0 + 4 * (lane & 31)));      // (checked against the bytes left behind the copy's first row)
     const int kg = A.K / 8;                           // groups per row block of the packed weight
     auto issue = [&](int chunk, int buf, int first, int count) {
 #pragma unroll
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(256) void k_conv1x1(C1Args A)
             } else {
                 const int p = i - 4 * NG;
                 const unsigned so = 4u * (unsigned)(chunk * KC + 2 * p) * (unsigned)A.N;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(Bl + buf * B_BUF + 2 * p * C1_TN), 16, bvo, so, 0, 0);
+                const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)A.x + so), 0, A.xbytes - so, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(Bl + buf * B_BUF + 2 * p * C1_TN), 16, bvo, 0, 0, 0);
             }
         }
     };

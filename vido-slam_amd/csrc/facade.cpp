@@ -1326,6 +1326,13 @@ int vido_system_save_results(vido_system* s, const char* prefix)
 
 vido_ctx* vido_system_context(vido_system* s) { return s && s->inited ? VIDO_SLAM::detail::Context() : nullptr; }
 
+int vido_system_set_depth_noise_seed(vido_system* s, unsigned seed)
+{
+    if (!s) return VIDO_E_INVALID;
+    VIDO_SLAM::detail::SetDepthNoiseSeed(seed);
+    return VIDO_OK;
+}
+
 }  // extern "C"
 
 // The incremental tracklet store (Map::UpdateTracklets) fed one association row at a time, as Tracking::Track does once per frame, flattened for the parity test against

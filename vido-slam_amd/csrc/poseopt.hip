@@ -564,6 +564,13 @@ extern "C" int vido_pose_optimize_batch(vido_ctx* ctx, const vido_pose_problem* 
         if (p.n < 0 || p.mode < 0 || p.mode > 2 || p.rounds < 1 || p.rounds > 4 || (p.n > 0 && !p.obs) || (p.mode != 1 && p.n > 0 && !p.Xw) ||
             (p.mode == 1 && p.n > 0 && (!p.flow0 || !p.depth)))
             return vido_set_error(ctx, VIDO_E_INVALID, "pose_optimize: problem %d is malformed (mode %d, n %d)", k, p.mode, p.n);
+        {   // a clustered problem (n > 512) tags its exchanges with epochs from a window of 1 << PO_EPOCH_SHIFT per launch: at most 1 + 2 x 10 exchanges per LM iteration
+            // (+ 1 per round), so the iteration counts must keep a launch inside its window or the NEXT launch would match this one's stale tags
+            long long it = 0; bool neg = false;
+            for (int q = 0; q < p.rounds; q++) { neg |= p.iters[q] < 0; it += p.iters[q]; }
+            if (neg || 21 * it + p.rounds + 1 >= (1ll << PO_EPOCH_SHIFT))
+                return vido_set_error(ctx, VIDO_E_INVALID, "pose_optimize: problem %d asks for %lld LM iterations over its rounds (allowed: 0 .. %lld)", k, it, ((1ll << PO_EPOCH_SHIFT) - 6) / 21);
+        }
         const size_t n = (size_t)p.n;
         nd_in += 8 * n + 8; nd_work += 23 * n + 32; nb += 2 * n + 16; nmax = std::max(nmax, p.n);
     }

@@ -229,7 +229,7 @@ static int track_state(vido_ctx* ctx, TrackState** out)
     HIP_TRY(ctx, hipMalloc(&T->d_okeys, B * T->max_obj * 8)); HIP_TRY(ctx, hipMalloc(&T->d_ocorr, B * T->max_obj * 8));
     HIP_TRY(ctx, hipMalloc(&T->d_odepth, B * T->max_obj * 4)); HIP_TRY(ctx, hipMalloc(&T->d_olabel, B * T->max_obj * 4));
     HIP_TRY(ctx, hipMalloc(&T->d_oflow, B * T->max_obj * 8));
-    T->tmp_cap = (size_t)std::max(T->max_obj, T->max_kp) * 8;
+    T->tmp_cap = (size_t)std::max(T->max_obj, T->max_kp) * 12 + 16;      // the widest call layout (scene_flow: 12 words per point) for every n up to max_obj / max_kp
     HIP_TRY(ctx, hipMalloc(&T->d_tmpf, T->tmp_cap * 4)); HIP_TRY(ctx, hipMalloc(&T->d_tmpi, T->tmp_cap * 4));
     HIP_TRY(ctx, hipHostMalloc((void**)&T->h_io, T->tmp_cap * 4 + (size_t)T->max_kp * sizeof(vido_keypoint) + 256));
     HIP_TRY(ctx, hipHostMalloc(&T->h_cnt, 2 * B * 4));

@@ -266,20 +266,22 @@ int vido_dyn_obj_tracking(const int32_t* sem_label, int32_t* obj_label, const fl
  * modules/core/src/rand.cpp::randn_0_1_32f on the state's low word, scaled by sigma in double.  seed 0 here = "now" (time(NULL)), as the reference. */
 float vido_depth_noise(float z, unsigned seed)
 {
-    static unsigned kn[128]; static float wn[128], fn[128]; static bool init = false;
-    if (!init) {
+    struct Zig { unsigned kn[128]; float wn[128], fn[128]; };
+    static const Zig Z = [] {                                 // (function-local static: built once, thread-safe — two Systems may draw their first sample at the same time)
+        Zig z{};
         const double m1 = 2147483648.0; double dn = 3.442619855899, tn = dn; const double vn = 9.91256303526217e-3;
         const double q = vn / std::exp(-.5 * dn * dn);
-        kn[0] = (unsigned)((dn / q) * m1); kn[1] = 0;
-        wn[0] = (float)(q / m1); wn[127] = (float)(dn / m1);
-        fn[0] = 1.f; fn[127] = (float)std::exp(-.5 * dn * dn);
+        z.kn[0] = (unsigned)((dn / q) * m1); z.kn[1] = 0;
+        z.wn[0] = (float)(q / m1); z.wn[127] = (float)(dn / m1);
+        z.fn[0] = 1.f; z.fn[127] = (float)std::exp(-.5 * dn * dn);
         for (int i = 126; i >= 1; i--) {
             dn = std::sqrt(-2. * std::log(vn / dn + std::exp(-.5 * dn * dn)));
-            kn[i + 1] = (unsigned)((dn / tn) * m1); tn = dn;
-            fn[i] = (float)std::exp(-.5 * dn * dn); wn[i] = (float)(dn / m1);
+            z.kn[i + 1] = (unsigned)((dn / tn) * m1); tn = dn;
+            z.fn[i] = (float)std::exp(-.5 * dn * dn); z.wn[i] = (float)(dn / m1);
         }
-        init = true;
-    }
+        return z;
+    }();
+    const unsigned* kn = Z.kn; const float *wn = Z.wn, *fn = Z.fn;
     if (seed == 0) seed = (unsigned)time(NULL);
     uint64_t st = seed ? (uint64_t)seed : 0xffffffffull;
     auto next = [&]() { st = (uint64_t)(unsigned)st * 4164903690u + (unsigned)(st >> 32); return (unsigned)st; };

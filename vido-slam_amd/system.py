@@ -40,6 +40,7 @@ def _bind(lib):
     lib.vido_system_save_results.argtypes = [C.c_void_p, C.c_char_p]
     lib.vido_system_context.restype = C.c_void_p
     lib.vido_system_context.argtypes = [C.c_void_p]
+    lib.vido_system_set_depth_noise_seed.argtypes = [C.c_void_p, C.c_uint]
     lib._vido_system_bound = True
     return lib
 
@@ -98,6 +99,12 @@ class System:
         if rc != VIDO_OK:
             raise VidoError(rc, self.lib.vido_system_last_error(self.h).decode())
         return T
+
+    def set_depth_noise_seed(self, seed):
+        """Pins the seed of the reference's time(NULL)-seeded depth noise (Frame.cc:711-716; 0 = the reference behaviour): reproducible PoseOptimizationNew results."""
+        rc = self.lib.vido_system_set_depth_noise_seed(self.h, int(seed) & 0xffffffff)
+        if rc != 0:
+            raise VidoError(rc, "set_depth_noise_seed: no system")
 
     def stats(self):
         s = SystemStats()
