@@ -206,6 +206,79 @@ __global__ __launch_bounds__(256) void k_pyramid_bands(uint8_t* __restrict__ pyr
     }
 }
 
+// The whole pyramid of a BATCH in one launch (round 5): a workgroup owns a 2-D TILE of the image through all levels.  The seven k_resize launches are a dependent chain of
+// latency-bound kernels (three dependent global round trips per workgroup: table corners -> source window -> table rows; 167 us per 64 frames = 7.5 % of the HBM
+// roofline); the band kernel above needs the full image width in LDS (up to 150 KB: one workgroup per CU).  Here
+//   * the host walks back from the last level once (build_tables): per tile and level the OWNED rectangle (a partition of the level, x cuts on multiples of 4) and the
+//     NEEDED rectangle (owned + whatever the next level's needed rectangle samples), ~1.2x recomputed pixels at 128 x 60 level-0 tiles;
+//   * the workgroup stages its level-0 rectangle and its slices of the coefficient tables into LDS in ONE round trip (table entries of columns past the level's width are
+//     staged as zeros: they produce the 0 the pad bytes hold, no per-pixel test), then computes level l + 1 from level l entirely out of LDS — same fixed-point
+//     arithmetic as k_resize, four pixels per item, one dword store into LDS (next level's source) and, for owned pixels, into the slab;
+//   * ~30 KB of LDS per workgroup: five workgroups per CU, 40 tiles x frames workgroups per launch.
+// Right image edge: the table has a1 = 0 where sx = sw - 1 (build_tables), so the unclamped L[sx + 1] read only ever meets weight 0.
+#define PT_MAXL 8
+struct PyrTile {
+    int nx0[PT_MAXL], nw[PT_MAXL], ny0[PT_MAXL], nh[PT_MAXL];          // needed rectangle: first column (multiple of 4), columns (multiple of 4), first row, rows
+    int ox0[PT_MAXL], ox1[PT_MAXL], oy0[PT_MAXL], oy1[PT_MAXL];        // owned rectangle [ox0, ox1) x [oy0, oy1), ox0 / ox1 multiples of 4
+    int lds[PT_MAXL], xt_lds[PT_MAXL], yt_lds[PT_MAXL];                // byte offsets in LDS: the level's pixels [nh][nw], its x / y table slices
+    unsigned magic[PT_MAXL];                                          // ceil(2^32 / (nw / 4)): item -> (row, quad) without a division
+};
+struct PyrTileLv { int w[PT_MAXL], pitch[PT_MAXL], off[PT_MAXL], xoff[PT_MAXL], yoff[PT_MAXL]; int L; };
+__global__ __launch_bounds__(256) void k_pyramid_tiles(uint8_t* __restrict__ pyr, size_t slab, PyrTileLv V, const PyrTile* __restrict__ tiles,
+                                                       const int2* __restrict__ xtab, const int4* __restrict__ ytab)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t pt_lds[];
+    const PyrTile& T = tiles[blockIdx.x];
+    uint8_t* base = pyr + (size_t)blockIdx.y * slab;
+    const int tid = threadIdx.x;
+    {   // one round trip: the level-0 rectangle (dword copies) and the table slices of every level
+        const int nq = T.nw[0] >> 2, n = T.nh[0] * nq;
+        const uint8_t* src = base + V.off[0] + (size_t)T.ny0[0] * V.pitch[0] + T.nx0[0];
+        uint32_t* dst = (uint32_t*)(pt_lds + T.lds[0]);
+        for (int i = tid; i < n; i += 256) {
+            const int rr = (int)__umulhi((unsigned)i, T.magic[0]), q = i - rr * nq;
+            dst[i] = *(const uint32_t*)(src + (size_t)rr * V.pitch[0] + 4 * q);
+        }
+        for (int l = 1; l < V.L; l++) {
+            int2* xs = (int2*)(pt_lds + T.xt_lds[l]); int4* ys = (int4*)(pt_lds + T.yt_lds[l]);
+            const int2* xt = xtab + V.xoff[l]; const int4* yt = ytab + V.yoff[l];
+            const int nx0 = T.nx0[l], nw = T.nw[l], dw = V.w[l];
+            for (int i = tid; i < nw; i += 256) xs[i] = nx0 + i < dw ? xt[nx0 + i] : make_int2(T.nx0[l - 1], 0);      // (a column of the source rectangle, both weights 0)
+            for (int i = tid; i < T.nh[l]; i += 256) ys[i] = yt[T.ny0[l] + i];
+        }
+    }
+    __syncthreads();
+    for (int l = 1; l < V.L; l++) {
+        const int snw = T.nw[l - 1], nw = T.nw[l], nq = nw >> 2, n = T.nh[l] * nq, dpitch = V.pitch[l];
+        const uint8_t* S0 = pt_lds + T.lds[l - 1] - T.ny0[l - 1] * snw - T.nx0[l - 1];       // source pixel (x, y) of level l - 1 lives at S0 + y * snw + x
+        const int2* xs = (const int2*)(pt_lds + T.xt_lds[l]); const int4* ys = (const int4*)(pt_lds + T.yt_lds[l]);
+        uint8_t* D = pt_lds + T.lds[l];
+        uint8_t* G = base + V.off[l];
+        const bool keep = l + 1 < V.L;
+        const int nx0 = T.nx0[l], ny0 = T.ny0[l], ox0 = T.ox0[l], ox1 = T.ox1[l], oy0 = T.oy0[l], oy1 = T.oy1[l];
+        const unsigned magic = T.magic[l];
+        for (int i = tid; i < n; i += 256) {
+            const int rr = (int)__umulhi((unsigned)i, magic), q = i - rr * nq;
+            const int4 yt = ys[rr];
+            const uint8_t* L0 = S0 + yt.x * snw; const uint8_t* L1 = S0 + yt.y * snw;
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int2 xv = xs[4 * q + k];
+                const int sx = xv.x & 0xffff, a0 = xv.x >> 16, a1 = xv.y;
+                const int r0 = L0[sx] * a0 + L0[sx + 1] * a1;
+                const int r1 = L1[sx] * a0 + L1[sx + 1] * a1;
+                const int v = (((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2;      // <= 255: the weights sum to <= 2049 per axis (no clamp needed)
+                out |= (uint32_t)v << (8 * k);
+            }
+            if (keep) *(uint32_t*)(D + rr * nw + 4 * q) = out;
+            const int y = ny0 + rr, x4 = nx0 + 4 * q;
+            if (y >= oy0 && y < oy1 && x4 >= ox0 && x4 < ox1) *(uint32_t*)(G + (size_t)y * dpitch + x4) = out;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 typedef short v2s __attribute__((ext_vector_type(2)));
 
@@ -914,6 +987,111 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ pyr, 
     }
 }
 
+// K4w (round 5): the same blur WITHOUT LDS and without workgroup barriers — one wave per strip of BS_QUADS x 4 output columns, sliding down the rows.
+// k_blur7 above spends ~33 vector instructions per pixel (byte extraction, 32-bit multiply-adds, two LDS round trips, two barriers) and runs at 13 % of the HBM roofline;
+// this form needs ~11:
+//   * lane l owns the aligned quad of columns c = x0 - 4 + 4 l (lanes 0 and 63 are halo only) and keeps the last seven rows of it UNPACKED as two registers of two
+//     u16 (bytes 0,1 | bytes 2,3): a new row costs one dword load and two v_perm;
+//   * vertical pass first, on packed 16-bit lanes: S = sum_k tap[k] * row[k] as v_pk_mul_lo_u16 / v_pk_mad_u16 (the column sums are <= 255 * 256 = 65280: exact in u16);
+//   * horizontal pass on the column sums with v_dot2_u32_u16: the six pairs (s[-4],s[-3]) .. (s[6],s[7]) around the quad are the lane's own two registers and its
+//     neighbours' (wave_shr / wave_shl DPP moves), each output is four dot2 with constant tap pairs, the rounding constant rides in the first accumulator; the result
+//     byte is bits 23:16 of the accumulator (<= 255 * 65536 + 32768), picked out by two v_perm;
+//   * reflect-101 columns (left edge, right edge, a partial last quad) are built ONCE per loaded row from real lanes' dwords: every virtual byte is some real byte of
+//     at most two other lanes of the wave — two ds_bpermute + one v_perm with per-lane constants, only in waves that contain an edge; reflect-101 rows are a scalar row
+//     index.  Integer arithmetic throughout, no intermediate rounding: identical to the horizontal-then-vertical order of the oracle (oracle/orb_oracle.c vo_gaussian_blur7).
+#define BS_QUADS 62                // output quads per wave (lanes 1 .. 62)
+// reflect-101 for an index at most n - 1 outside [0, n): one fold per side, no loop (the host only builds strips for levels where that holds); clamped, so that the rows
+// below the image a last strip still loads (and never stores an output for) stay in bounds
+__device__ __forceinline__ int reflect101_once(int i, int n) { i = i < 0 ? -i : i; i = i >= n ? 2 * n - 2 - i : i; return min(max(i, 0), n - 1); }
+typedef unsigned short bs_v2u __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(64) void k_blur7_strips(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, size_t slab, PyrDev P, const BlurTile* __restrict__ strips)
+{
+    int ti, fr; xcd_tile_frame(ti, fr);
+    const BlurTile t = strips[ti];                                   // {level, first output column (multiple of 4), first output row, batches of 7 input rows}
+    const int w = P.w[t.level], h = P.h[t.level], pitch = P.pitch[t.level];
+    const uint8_t* img = pyr + (size_t)fr * slab + P.off[t.level];
+    uint8_t* out = blur + (size_t)fr * slab + P.off[t.level];
+    const int lane = threadIdx.x, x0 = t.tx, y0 = t.ty, nb = t.pad;
+    const int c = x0 - 4 + 4 * lane;                                 // this lane's quad of (virtual) columns
+    // reflect-101 fix-up constants: source lanes A / B (byte addresses for ds_bpermute) and the v_perm selector that assembles the quad from their dwords
+    int srcA = lane * 4, srcB = lane * 4; uint32_t sel = 0x03020100u; bool fix = false;
+    if (c < w + 4 && (c < 0 || c + 3 >= w)) {
+        int la = -1, lb = -1; sel = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = reflect101_once(c + k, w), ls = (r - x0 + 4) >> 2;
+            if (la < 0 || ls == la) { la = ls; sel |= (uint32_t)(r & 3) << (8 * k); }
+            else { lb = ls; sel |= (uint32_t)(4 + (r & 3)) << (8 * k); }
+        }
+        srcA = la * 4; srcB = (lb < 0 ? la : lb) * 4; fix = true;
+    }
+    const bool any_fix = __ballot(fix) != 0ull;
+    const int cl = min(max(c, 0), pitch - 4);                        // where the lane's raw dword comes from (virtual quads: any in-bounds address)
+    const uint8_t* colp = img + cl;
+    auto load_row = [&](int idx) -> uint32_t {                       // input row idx of the strip = image row y0 - 3 + idx, reflected
+        const int ry = reflect101_once(y0 - 3 + idx, h);
+        return *(const uint32_t*)(colp + (size_t)(uint32_t)(ry * pitch));
+    };
+    uint32_t lo[7], hi[7];                                           // the window, slot j = input row idx with idx % 7 == j
+    uint32_t cur[7], nxt[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) cur[j] = load_row(j);
+    const bool writes = lane >= 1 && lane <= BS_QUADS && c < w;
+    uint8_t* op = out + c;
+    constexpr uint32_t T0 = 18, T1 = 34, T2 = 49, T3 = 54;           // taps {18, 34, 49, 54, 49, 34, 18}
+    const bs_v2u t0 = {T0, T0}, t1 = {T1, T1}, t2 = {T2, T2}, t3 = {T3, T3};
+    for (int b = 0; b < nb; b++) {
+        if (b + 1 < nb) {
+#pragma unroll
+            for (int j = 0; j < 7; j++) nxt[j] = load_row(7 * (b + 1) + j);
+        }
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            uint32_t d = cur[j];
+            if (any_fix) {
+                const uint32_t da = (uint32_t)__builtin_amdgcn_ds_bpermute(srcA, (int)d), db = (uint32_t)__builtin_amdgcn_ds_bpermute(srcB, (int)d);
+                d = __builtin_amdgcn_perm(db, da, sel);
+            }
+            lo[j] = __builtin_amdgcn_perm(0u, d, 0x0c010c00u);        // (byte 0, byte 1) as two u16
+            hi[j] = __builtin_amdgcn_perm(0u, d, 0x0c030c02u);        // (byte 2, byte 3)
+            const int idx = 7 * b + j;
+            if (idx >= 6) {                                           // (wave-uniform) the window holds rows idx - 6 .. idx: output row y = y0 + idx - 6
+                // slot of input row idx - 6 + k is (j + 1 + k) % 7; the taps are symmetric
+                auto vs = [&](const uint32_t* r) -> uint32_t {
+                    bs_v2u a = __builtin_bit_cast(bs_v2u, r[(j + 1) % 7]) * t0;
+                    a = __builtin_bit_cast(bs_v2u, r[(j + 2) % 7]) * t1 + a;
+                    a = __builtin_bit_cast(bs_v2u, r[(j + 3) % 7]) * t2 + a;
+                    a = __builtin_bit_cast(bs_v2u, r[(j + 4) % 7]) * t3 + a;
+                    a = __builtin_bit_cast(bs_v2u, r[(j + 5) % 7]) * t2 + a;
+                    a = __builtin_bit_cast(bs_v2u, r[(j + 6) % 7]) * t1 + a;
+                    a = __builtin_bit_cast(bs_v2u, r[(j + 7) % 7]) * t0 + a;
+                    return __builtin_bit_cast(uint32_t, a);
+                };
+                const uint32_t P2 = vs(lo), P3 = vs(hi);              // (s0, s1), (s2, s3)
+                const uint32_t P0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P2, 0x138, 0xf, 0xf, true);      // wave_shr:1 — the left neighbour's (s[-4], s[-3])
+                const uint32_t P1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P3, 0x138, 0xf, 0xf, true);      //                                   (s[-2], s[-1])
+                const uint32_t P4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P2, 0x130, 0xf, 0xf, true);      // wave_shl:1 — the right neighbour's (s[4], s[5])
+                const uint32_t P5 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P3, 0x130, 0xf, 0xf, true);      //                                    (s[6], s[7])
+                auto dot = [](uint32_t p, uint32_t wlo, uint32_t whi, uint32_t acc) -> uint32_t {
+                    const bs_v2u wv = {(unsigned short)wlo, (unsigned short)whi};
+                    return __builtin_amdgcn_udot2(__builtin_bit_cast(bs_v2u, p), wv, acc, false);
+                };
+                // out k = sum_i tap[i] * s[k - 3 + i]
+                uint32_t a0 = dot(P0, 0, T0, 32768u);  a0 = dot(P1, T1, T2, a0); a0 = dot(P2, T3, T2, a0); a0 = dot(P3, T1, T0, a0);
+                uint32_t a1 = dot(P1, T0, T1, 32768u); a1 = dot(P2, T2, T3, a1); a1 = dot(P3, T2, T1, a1); a1 = dot(P4, T0, 0, a1);
+                uint32_t a2 = dot(P1, 0, T0, 32768u);  a2 = dot(P2, T1, T2, a2); a2 = dot(P3, T3, T2, a2); a2 = dot(P4, T1, T0, a2);
+                uint32_t a3 = dot(P2, T0, T1, 32768u); a3 = dot(P3, T2, T3, a3); a3 = dot(P4, T2, T1, a3); a3 = dot(P5, T0, 0, a3);
+                const uint32_t o01 = __builtin_amdgcn_perm(a1, a0, 0x0c0c0602u);      // byte 2 of a0, byte 2 of a1
+                const uint32_t o23 = __builtin_amdgcn_perm(a3, a2, 0x06020c0cu);      // byte 2 of a2 -> byte 2, byte 2 of a3 -> byte 3
+                const int y = y0 + idx - 6;
+                if (writes && y < h) *(uint32_t*)(op + (size_t)(uint32_t)(y * pitch)) = o01 | o23;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 7; j++) cur[j] = nxt[j];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K5: orientation (IC_Angle) + steered BRIEF, one wave per keypoint.
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)      // cv::fastAtan2 scalar polynomial
@@ -1011,8 +1189,10 @@ struct OrbState {
     // device
     uint8_t *d_pyr = nullptr, *d_blur = nullptr;
     CellDesc* d_cells = nullptr; BlurTile* d_btiles = nullptr;
+    BlurTile* d_bstrips = nullptr; int n_blur_strips = 0;            // k_blur7_strips: {level, first column, first row, batches of 7 input rows} per wave; 0 = the tile kernel stays
     int2* d_xtab = nullptr; int4* d_ytab = nullptr;
     PyrBand* d_bands = nullptr; int n_bands = 0; size_t bands_lds = 0; PyrBandLv band_lv{};      // single-launch pyramid (k_pyramid_bands)
+    PyrTile* d_ptiles = nullptr; int n_ptiles = 0; size_t ptiles_lds = 0; PyrTileLv ptile_lv{};  // single-launch pyramid for any batch (k_pyramid_tiles); 0 tiles = not built
     uint32_t* d_slots = nullptr; int *d_counts = nullptr, *d_offsets = nullptr, *d_first_cell = nullptr, *d_lvloff = nullptr, *d_overflow = nullptr;
     uint32_t* d_cand = nullptr; size_t cand_cap = 0;
     uint2* d_kp = nullptr; size_t kp_cap = 0;
@@ -1128,6 +1308,54 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
         }
         if (S->bands_lds <= 150 * 1024) S->n_bands = NB;      // (else the per-level kernels stay)
     }
+    // tiles of the single-launch batched pyramid (k_pyramid_tiles): owned / needed rectangles per tile and level, walking back from the last level
+    std::vector<PyrTile> ptiles; S->n_ptiles = 0; S->ptiles_lds = 0;
+    if (L >= 2 && L <= PT_MAXL && getenv("VIDO_PYR_LEVELS") == nullptr) {
+        static const int env_nx = [] { const char* e = getenv("VIDO_PYR_NX"); return e ? atoi(e) : 0; }(), env_ny = [] { const char* e = getenv("VIDO_PYR_NY"); return e ? atoi(e) : 0; }();      // (experiments)
+        // ~107 x 48 level-0 tiles (640 x 480: 6 x 10 = 60 workgroups per frame, 35 KB of LDS each; measured 5 x 8 .. 12 x 20: 106 / 95 / 100 / 129 us per 64 frames incl. the ingest)
+        const int NX = std::max(1, std::min(env_nx > 0 ? env_nx : (c.width + 53) / 107, S->lv[L - 1].w / 8)), NY = std::max(1, std::min(env_ny > 0 ? env_ny : (c.height + 24) / 48, S->lv[L - 1].h / 4));
+        PyrTileLv& V = S->ptile_lv; V.L = L;
+        for (int l = 0; l < L; l++) { V.w[l] = S->lv[l].w; V.pitch[l] = S->lv[l].pitch; V.off[l] = S->lv[l].off; V.xoff[l] = S->lv[l].xtab_off; V.yoff[l] = S->lv[l].ytab_off; }
+        bool ok = true;
+        for (int ty = 0; ty < NY && ok; ty++)
+            for (int tx = 0; tx < NX && ok; tx++) {
+                PyrTile t{}; int x0[PT_MAXL], x1[PT_MAXL], y0[PT_MAXL], y1[PT_MAXL];            // computed rectangle [x0, x1) x [y0, y1): the needed columns widened to whole quads
+                int n0[PT_MAXL], n1[PT_MAXL];                                                   // the columns really needed [n0, n1)
+                for (int l = 1; l < L; l++) {
+                    const int w = S->lv[l].w, h = S->lv[l].h, w4 = (w + 3) & ~3;
+                    t.ox0[l] = tx == 0 ? 0 : (int)((long long)tx * w / NX) & ~3; t.ox1[l] = tx + 1 == NX ? w4 : (int)((long long)(tx + 1) * w / NX) & ~3;
+                    t.oy0[l] = (int)((long long)ty * h / NY); t.oy1[l] = (int)((long long)(ty + 1) * h / NY);
+                }
+                x0[L - 1] = t.ox0[L - 1]; x1[L - 1] = t.ox1[L - 1]; y0[L - 1] = t.oy0[L - 1]; y1[L - 1] = t.oy1[L - 1];
+                n0[L - 1] = t.ox0[L - 1]; n1[L - 1] = std::min(t.ox1[L - 1], S->lv[L - 1].w);
+                for (int l = L - 2; l >= 0; l--) {
+                    const int w = S->lv[l].w, w4 = (w + 3) & ~3;
+                    const int2* xt = xtab.data() + S->lv[l + 1].xtab_off; const int4* yt = ytab.data() + S->lv[l + 1].ytab_off;
+                    // what the next level's NEEDED pixels sample: columns sx .. sx + 1 (clamped), rows ytab.x .. ytab.y; + this level's own rectangle (level 0 owns nothing).
+                    // The quad padding of the next level's rectangle is computed too, from whatever lies beside the staged columns (a few bytes of the neighbouring LDS
+                    // row or buffer): nobody needs those pixels, so their sources are not staged — needed rectangles grow by ~2 px per level instead of ~2 + up to 6.
+                    int lo = xt[n0[l + 1]].x & 0xffff, hi = std::min((xt[n1[l + 1] - 1].x & 0xffff) + 1, w - 1) + 1;
+                    int ylo = yt[y0[l + 1]].x, yhi = yt[y1[l + 1] - 1].y + 1;
+                    if (l >= 1) { lo = std::min(lo, t.ox0[l]); hi = std::max(hi, t.ox1[l]); ylo = std::min(ylo, t.oy0[l]); yhi = std::max(yhi, t.oy1[l]); }
+                    n0[l] = lo; n1[l] = std::min(hi, w);
+                    x0[l] = lo & ~3; x1[l] = std::min((hi + 3) & ~3, l == 0 ? S->lv[0].pitch : w4); y0[l] = ylo; y1[l] = yhi;
+                    if (x1[l] <= x0[l] || y1[l] <= y0[l] || n1[l] <= n0[l]) ok = false;
+                }
+                if (x1[L - 1] <= x0[L - 1] || y1[L - 1] <= y0[L - 1]) ok = false;
+                size_t off = 16;                                      // (guard: a padding pixel may sample a few bytes in front of its source rectangle)
+                for (int l = 0; l < L && ok; l++) {
+                    t.nx0[l] = x0[l]; t.nw[l] = x1[l] - x0[l]; t.ny0[l] = y0[l]; t.nh[l] = y1[l] - y0[l];
+                    const unsigned nq = (unsigned)t.nw[l] / 4u; t.magic[l] = (unsigned)((0x100000000ull + nq - 1) / nq);
+                    for (unsigned i = 0; i < nq * (unsigned)t.nh[l]; i++) if ((unsigned)(((unsigned long long)i * t.magic[l]) >> 32) != i / nq) ok = false;      // the reciprocal is exact on the item range
+                    if (l + 1 < L) { t.lds[l] = (int)off; off += (size_t)t.nh[l] * t.nw[l]; off = (off + 15) & ~(size_t)15; }
+                }
+                off += 16;                                            // (the unclamped sx + 1 read of a last row)
+                for (int l = 1; l < L && ok; l++) { t.xt_lds[l] = (int)off; off += (size_t)t.nw[l] * sizeof(int2); t.yt_lds[l] = (int)off; off += (size_t)t.nh[l] * sizeof(int4); }
+                S->ptiles_lds = std::max(S->ptiles_lds, off);
+                ptiles.push_back(t);
+            }
+        if (ok && S->ptiles_lds <= 150 * 1024) S->n_ptiles = (int)ptiles.size();
+    }
     // FAST cell table in the reference's loop order (ORBextractor.cc:759-796)
     std::vector<CellDesc> cells; std::vector<BlurTile> btiles;
     S->first_cell.assign(L, 0);
@@ -1159,6 +1387,21 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
             for (int tx = 0; tx < (v.w + BL_TW - 1) / BL_TW; tx++) btiles.push_back(BlurTile{l, tx, ty, 0});
     }
     S->n_cells = (int)cells.size(); S->n_blur_tiles = (int)btiles.size();
+    std::vector<BlurTile> bstrips;
+    {   // strips of the LDS-free blur: a level's quads split evenly over ceil(quads / BS_QUADS) waves per row band, bands of 7 nb - 6 output rows
+        static const int nb_env = [] { const char* e = getenv("VIDO_BLUR_NB"); return e ? atoi(e) : 0; }();
+        const int nb = nb_env >= 1 && nb_env <= 16 ? nb_env : 3, rows_out = 7 * nb - 6;
+        bool ok = getenv("VIDO_BLUR_TILES") == nullptr;                 // (A/B switch: the round-1 tile kernel)
+        for (int l = 0; l < L && ok; l++) {
+            const LevelInfo& v = S->lv[l];
+            const int nq = (v.w + 3) / 4, nt = (nq + BS_QUADS - 1) / BS_QUADS, qpt = (nq + nt - 1) / nt, x_last = 4 * qpt * (nt - 1);
+            if (v.w < 16 || v.h < 7 * nb + 8 || v.w - 8 - x_last + 4 < 0) { ok = false; break; }      // the reflected columns of the right edge must live in lanes of the last strip
+            for (int y0 = 0; y0 < v.h; y0 += rows_out)
+                for (int tx = 0; tx < nt; tx++) bstrips.push_back(BlurTile{l, 4 * qpt * tx, y0, nb});
+        }
+        if (!ok) bstrips.clear();
+    }
+    S->n_blur_strips = (int)bstrips.size();
     // FAST strips: runs of up to FS_MAXC horizontally adjacent cells of one cell row (consecutive in the reference order), split evenly; per-cell output slots
     std::vector<FastStrip> strips; std::vector<int> slot_off(cells.size() + 1, 0);
     {
@@ -1210,6 +1453,10 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
     HIP_TRY(ctx, hipMemcpy(S->d_cells, cells.data(), cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMalloc(&S->d_btiles, btiles.size() * sizeof(BlurTile)));
     HIP_TRY(ctx, hipMemcpy(S->d_btiles, btiles.data(), btiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
+    if (!bstrips.empty()) {
+        HIP_TRY(ctx, hipMalloc(&S->d_bstrips, bstrips.size() * sizeof(BlurTile)));
+        HIP_TRY(ctx, hipMemcpy(S->d_bstrips, bstrips.data(), bstrips.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
+    }
     HIP_TRY(ctx, hipMalloc(&S->d_xtab, std::max<size_t>(xtab.size(), 1) * sizeof(int2)));
     HIP_TRY(ctx, hipMalloc(&S->d_ytab, std::max<size_t>(ytab.size(), 1) * sizeof(int4)));
     if (!xtab.empty()) {
@@ -1219,7 +1466,14 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
     if (S->n_bands) {
         HIP_TRY(ctx, hipMalloc(&S->d_bands, bands.size() * sizeof(PyrBand)));
         HIP_TRY(ctx, hipMemcpy(S->d_bands, bands.data(), bands.size() * sizeof(PyrBand), hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_pyramid_bands, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->bands_lds));
+        static bool battr[64] = {};                                   // per function and device, not per ctx: a second, smaller ctx must not lower the first one's limit
+        if (!battr[ctx->device & 63]) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_pyramid_bands, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); battr[ctx->device & 63] = true; }
+    }
+    if (S->n_ptiles) {
+        HIP_TRY(ctx, hipMalloc(&S->d_ptiles, ptiles.size() * sizeof(PyrTile)));
+        HIP_TRY(ctx, hipMemcpy(S->d_ptiles, ptiles.data(), ptiles.size() * sizeof(PyrTile), hipMemcpyHostToDevice));
+        static bool attr[64] = {};                                    // (the attribute belongs to the function and the device, not to this ctx: set once, to the ceiling)
+        if (!attr[ctx->device & 63]) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_pyramid_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr[ctx->device & 63] = true; }
     }
     HIP_TRY(ctx, hipMalloc(&S->d_first_cell, L * sizeof(int)));
     HIP_TRY(ctx, hipMemcpy(S->d_first_cell, S->first_cell.data(), L * sizeof(int), hipMemcpyHostToDevice));
@@ -1289,7 +1543,7 @@ void orb_state_destroy(vido_ctx* ctx)
 {
     OrbState* S = ctx->orb;
     if (!S) return;
-    hipFree(S->d_pyr); hipFree(S->d_blur); hipFree(S->d_cells); hipFree(S->d_btiles); hipFree(S->d_xtab); hipFree(S->d_ytab); hipFree(S->d_bands);
+    hipFree(S->d_pyr); hipFree(S->d_blur); hipFree(S->d_cells); hipFree(S->d_btiles); hipFree(S->d_bstrips); hipFree(S->d_xtab); hipFree(S->d_ytab); hipFree(S->d_bands); hipFree(S->d_ptiles);
     hipFree(S->d_slots); hipFree(S->d_counts); hipFree(S->d_offsets); hipFree(S->d_first_cell); hipFree(S->d_lvloff); hipFree(S->d_overflow);
     hipFree(S->d_cand); hipFree(S->d_kp); hipFree(S->d_strips); hipFree(S->d_slot_off);
     hipHostFree(S->h_lvloff); hipHostFree(S->h_overflow); hipHostFree(S->h_cand);
@@ -1302,6 +1556,12 @@ void orb_state_destroy(vido_ctx* ctx)
     hipHostFree(S->h_frame_beg); hipHostFree(S->h_kpf); hipHostFree(S->h_descf);
     hipFree(S->d_color); hipFree(S->d_gray_out);
     delete S; ctx->orb = nullptr;
+}
+
+static inline void orb_launch_blur(OrbState* S, int nf, hipStream_t st)
+{
+    if (S->n_blur_strips) hipLaunchKernelGGL(k_blur7_strips, dim3(S->n_blur_strips, nf), dim3(64), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_bstrips);
+    else hipLaunchKernelGGL(k_blur7, dim3(S->n_blur_tiles, nf), dim3(256), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_btiles);
 }
 
 // Enqueues the whole extractor for nf frames on the ctx stream; nothing is synchronised.  Results land in the device
@@ -1356,7 +1616,10 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
         HIP_TRY(ctx, hipMemcpy2DAsync(S->d_pyr + (size_t)f * S->slab + S->lv[0].off, S->lv[0].pitch, imgs + (size_t)f * frame_stride, stride,
                                       width, height, hipMemcpyHostToDevice, st));
     static const int bands_mode = [] { const char* e = getenv("VIDO_ORB_BANDS"); return e ? atoi(e) : -1; }();      // experiment switch: 1 = the band pyramid for every batch size, 0 = never
-    if (S->n_bands && (bands_mode == 1 || (bands_mode != 0 && lean)))
+    static const int tiles_mode = [] { const char* e = getenv("VIDO_PYR_TILES"); return e ? atoi(e) : 1; }();        // A/B switch: 0 = the round-4 kernels (bands for one frame, per-level launches for a batch)
+    if (S->n_ptiles && tiles_mode)
+        hipLaunchKernelGGL(k_pyramid_tiles, dim3(S->n_ptiles, nf), dim3(256), S->ptiles_lds, st, S->d_pyr, S->slab, S->ptile_lv, (const PyrTile*)S->d_ptiles, (const int2*)S->d_xtab, (const int4*)S->d_ytab);
+    else if (S->n_bands && (bands_mode == 1 || (bands_mode != 0 && lean)))
         hipLaunchKernelGGL(k_pyramid_bands, dim3(S->n_bands, nf), dim3(256), S->bands_lds, st, S->d_pyr, S->slab, S->band_lv, (const PyrBand*)S->d_bands, (const int2*)S->d_xtab, (const int4*)S->d_ytab);
     else for (int l = 1; l < L; l++) {
         const LevelInfo &s = S->lv[l - 1], &d = S->lv[l];
@@ -1389,12 +1652,12 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     // the blur only needs the pyramid: it runs on the second stream, concurrently with the quadtree and the keypoint list kernels (512 latency-bound
     // workgroups that leave most CUs idle; forking before FAST just makes the two full-GPU kernels contend), and joins before orientation + rBRIEF
     if (with_desc && lean)
-        hipLaunchKernelGGL(k_blur7, dim3(S->n_blur_tiles, nf), dim3(256), 0, st, S->d_pyr, S->d_blur, S->slab, S->P, S->d_btiles);      // (11 us on the way; a fork / join costs four more stream operations)
+        orb_launch_blur(S, nf, st);      // (11 us on the way; a fork / join costs four more stream operations)
     else if (with_desc) {
         HIP_TRY(ctx, hipEventRecord(S->ev_pyr, st));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, S->ev_pyr, 0));
         HIP_TRY(ctx, hipEventRecord(S->ev[3], ctx->stream2));
-        hipLaunchKernelGGL(k_blur7, dim3(S->n_blur_tiles, nf), dim3(256), 0, ctx->stream2, S->d_pyr, S->d_blur, S->slab, S->P, S->d_btiles);
+        orb_launch_blur(S, nf, ctx->stream2);
         HIP_TRY(ctx, hipEventRecord(S->ev[4], ctx->stream2));
     }
     // ---- DistributeOctTree per (frame, level) + keypoint list, all on the device
