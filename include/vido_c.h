@@ -307,6 +307,9 @@ int vido_deconv4s2_depthwise(vido_ctx* ctx, const float* x, const float* weight,
  * y / residual [cout][hw], f32 DEVICE, 16-byte aligned, y != x; bias [cout] or NULL; residual NULL = none; w_packed: [cout][cin] in operand order
  * (vido_slam_amd/nets/ops.py::pack_conv1x1).  slope: 0 = ReLU, 1 = none.  vido_conv1x1_supported: cout % 128 == 0, cin % 32 == 0, hw >= 128. */
 int vido_conv1x1_supported(int cin, int cout, int hw);
+/* the weight packing vido_conv1x1_bias_act / _up2_act expect for a shape: 0 = [co / 32][k / 8][32 (k & 1) + co % 32][(k % 8) / 2] (128 x 128 tiles),
+ * 1 = [co / 16][k / 16][16 (k & 3) + co % 16][(k % 16) / 4] (128 x 112 tiles: fewer idle CUs in the last round of workgroups) */
+int vido_conv1x1_layout(int cin, int cout, int hw);
 int vido_conv1x1_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, int hw, float slope);
 /* ... with the residual at half the resolution [cout][h/2][w/2], added nearest-upsampled: the FPN's lateral convolution + top-down sum (backbone/fpn.py:55-66); h, w even */
 int vido_conv1x1_bias_up2_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual_half, float* y, int cin, int cout, int h, int w, float slope);

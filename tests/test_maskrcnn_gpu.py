@@ -243,10 +243,47 @@ def test_bottleneck_with_matrix_core_conv2_equals_library_path(vido, ctx):
     assert float((y_fast - y_lib).abs().max()) < 1e-4 * max(1.0, float(y_lib.abs().max()))
 
 
+_FORCED_C1 = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+import vido_slam_amd as V
+from vido_slam_amd.nets.ops import HipOps, pack_conv1x1
+cin, cout, H, W, layout = (int(a) for a in sys.argv[2:7])
+ctx = V.Context(width=640, height=480, max_batch=1); ops = HipOps(ctx)
+assert ops.conv1x1_layout(cin, cout, H * W) == layout
+g = torch.Generator().manual_seed(cin * 7 + H)
+x = torch.randn(1, cin, H, W, generator=g); w = torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin ** 0.5); b = torch.randn(cout, generator=g); r = torch.randn(1, cout, H, W, generator=g)
+wp = pack_conv1x1(w, layout).cuda()
+ref0 = torch.nn.functional.conv2d(x.double(), w.double())
+for bias, res, slope in ((None, None, 1.0), (b, r, 0.0), (b, r, 0.1)):
+    y = ops.conv1x1_bias_act(x.cuda(), wp, bias.cuda() if bias is not None else None, res.cuda() if res is not None else None, slope).cpu()
+    ref = ref0 + (bias.double()[None, :, None, None] if bias is not None else 0.0) + (res.double() if res is not None else 0.0)
+    ref = torch.nn.functional.leaky_relu(ref, slope)
+    err = float((y.double() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), (cin, cout, H, W, slope, err)
+if H % 2 == 0 and W % 2 == 0:
+    rh = torch.randn(1, cout, H // 2, W // 2, generator=g)
+    y = ops.conv1x1_bias_act(x.cuda(), wp, b.cuda(), None, 1.0, residual_up2=rh.cuda()).cpu()
+    ref = ref0 + b.double()[None, :, None, None] + torch.nn.functional.interpolate(rh.double(), scale_factor=2, mode="nearest")
+    assert float((y.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+print("forced ok")
+"""
+
+
+def _run_forced_conv1x1(cin, cout, H, W, layout):
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VIDO_CONV1X1_TN="112" if layout == 1 else "128")
+    out = subprocess.run([sys.executable, "-c", _FORCED_C1, root, str(cin), str(cout), str(H), str(W), str(layout)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "forced ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", [None, 0, 1])      # None: the tile form the library picks for the shape; 0 / 1: forced 128 x 128 / 128 x 112 tiles (VIDO_CONV1X1_TN)
 @pytest.mark.parametrize("cin,cout,H,W", [(64, 256, 40, 68), (256, 256, 50, 68), (256, 128, 37, 52), (1024, 1024, 10, 34), (512, 512, 25, 36), (32, 128, 12, 11), (2048, 256, 16, 16),
-                                            (2048, 2048, 25, 34), (256, 128, 13, 11), (96, 128, 9, 15)])      # the last three: H*W not a multiple of 4 (layer4: 850 positions)
-def test_conv1x1_matrix_core_gemm_equals_conv2d(vido, ctx, cin, cout, H, W):
+                                            (2048, 2048, 25, 34), (256, 128, 13, 11), (96, 128, 9, 15),      # the last three: H*W not a multiple of 4 (layer4: 850 positions)
+                                            (256, 256, 200, 272), (1024, 1024, 50, 68), (512, 512, 100, 136)])      # the bench's own bottleneck shapes (layer1 / layer3 / layer2)
+def test_conv1x1_matrix_core_gemm_equals_conv2d(vido, ctx, cin, cout, H, W, layout):
     """csrc/conv1x1.hip against conv2d in float64: bottleneck shapes of the detector (64 -> 256, 256 -> 256, 1024 -> 1024 ...), position counts that are not a multiple of
     the 128-wide tile or of 4 (rows then start at 4-byte-aligned addresses only), with and without bias / residual, ReLU / leaky / no activation."""
     from vido_slam_amd.nets.ops import HipOps, pack_conv1x1
@@ -254,7 +291,13 @@ def test_conv1x1_matrix_core_gemm_equals_conv2d(vido, ctx, cin, cout, H, W):
     g = torch.Generator().manual_seed(cin * 7 + H)
     x = torch.randn(1, cin, H, W, generator=g); w = torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin ** 0.5); b = torch.randn(cout, generator=g); r = torch.randn(1, cout, H, W, generator=g)
     assert ops.conv1x1_supported(cin, cout, H * W)
-    wp = pack_conv1x1(w).cuda()
+    if layout is not None:
+        # the form is read once per process from VIDO_CONV1X1_TN: a forced form runs in a child process (below); here only the library's own choice
+        if cin % 64 and layout == 1:
+            pytest.skip("the 112-wide form needs input channels in multiples of 64")
+        _run_forced_conv1x1(cin, cout, H, W, layout); return
+    lay = ops.conv1x1_layout(cin, cout, H * W)
+    wp = pack_conv1x1(w, lay).cuda()
     ref0 = torch.nn.functional.conv2d(x.double(), w.double())
     for bias, res, slope in ((None, None, 1.0), (b, None, 0.0), (b, r, 0.0), (b, r, 0.1), (None, r, 1.0)):
         y = ops.conv1x1_bias_act(x.cuda(), wp, bias.cuda() if bias is not None else None, res.cuda() if res is not None else None, slope).cpu()

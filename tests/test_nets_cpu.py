@@ -143,6 +143,29 @@ def test_pack_conv1x1_is_the_operand_order_of_the_kernel():
             co, k = (int(torch.randint(0, n, (1,), generator=g)) for n in (cout, cin))
             assert float(p[co // 32, k // 8, 32 * (k & 1) + co % 32, (k % 8) // 2]) == float(w[co, k, 0, 0])
     assert pack_conv1x1(torch.zeros(64, 32, 1, 1)) is None and pack_conv1x1(torch.zeros(128, 48, 1, 1)) is None and pack_conv1x1(torch.zeros(128, 32, 3, 3)) is None
+    # layout 1 (128 x 112 tiles on v_mfma_f32_16x16x4: lane l supplies A[row l % 16][k l / 16]): element (co, k) is the (k % 16) / 4-th operand that lane 16 * (k & 3) + co % 16
+    # reads for the group of four k-steps k / 16 of the 16-row fragment co / 16
+    for cout, cin in ((128, 64), (256, 128)):
+        w = torch.randn(cout, cin, 1, 1, generator=g)
+        p = pack_conv1x1(w, 1)
+        assert tuple(p.shape) == (cout // 16, cin // 16, 64, 4) and p.is_contiguous()
+        for _ in range(300):
+            co, k = (int(torch.randint(0, n, (1,), generator=g)) for n in (cout, cin))
+            assert float(p[co // 16, k // 16, 16 * (k & 3) + co % 16, (k % 16) // 4]) == float(w[co, k, 0, 0])
+    assert pack_conv1x1(torch.zeros(128, 96, 1, 1), 1) is None
+
+
+def test_conv1x1_tile_form_is_chosen_by_rounds_of_workgroups():
+    """vido_conv1x1_layout (host side of csrc/conv1x1.hip): 128 x 112 tiles where they need fewer (rounds of 256 CUs) x (tile width) than 128 x 128 — every bottleneck
+    shape of X-101-32x8d at the 800 x 1088 feed (850 tiles of 128 x 128 = 3.3 rounds -> 972 of 128 x 112 = 3.8 rounds, each 7 / 8 of the work); 128 x 128 where the
+    112-wide form would add a round, or when the input channels are not a multiple of 64."""
+    import ctypes as C
+    from vido_slam_amd.host import load_library
+    lib = load_library()
+    for cin, cout, hw in ((256, 256, 200 * 272), (512, 512, 100 * 136), (1024, 1024, 50 * 68)):
+        assert lib.vido_conv1x1_layout(cin, cout, hw) == 1
+    assert lib.vido_conv1x1_layout(96, 128, 4096) == 0                 # input channels not a multiple of 64
+    assert lib.vido_conv1x1_layout(256, 256, 128 * 128 * 2) == 0       # 2 x 256 tiles of 128 x 128 = 2 rounds; 586 of 112 = 3 rounds
 
 
 def test_strided_grouped_conv_plan_answers_without_a_gpu():

@@ -21,8 +21,8 @@ for cin, cout, H, W, name in shapes:
     t_lib = timed(lambda: F.conv2d(x, w)); t_lib_ep = timed(lambda: ops.bias_res_act_(F.conv2d(x, w), b, r, 0.0))
     line = "%-34s %4d -> %4d @ %3dx%3d  %6.2f GF | library %6.1f us (%5.1f TF), + bias/res/relu pass %6.1f us" % (name, cin, cout, H, W, gf, t_lib, gf / t_lib * 1e3, t_lib_ep)
     if ops.conv1x1_supported(cin, cout, H * W):
-        wp = pack_conv1x1(w)
+        lay = ops.conv1x1_layout(cin, cout, H * W); wp = pack_conv1x1(w, lay)
         t0 = timed(lambda: ops.conv1x1_bias_act(x, wp)); t1 = timed(lambda: ops.conv1x1_bias_act(x, wp, b, r, 0.0))
         y = ops.conv1x1_bias_act(x, wp, b, r, 0.0); ref = torch.relu(F.conv2d(x, w, b) + r)
-        line += " | ours %6.1f us (%5.1f TF), with epilogue %6.1f us (%5.1f TF)  max err %.2e" % (t0, gf / t0 * 1e3, t1, gf / t1 * 1e3, float((y - ref).abs().max()))
+        line += " | ours %6.1f us (%5.1f TF), with epilogue %6.1f us (%5.1f TF)  max err %.2e  [layout %d]" % (t0, gf / t0 * 1e3, t1, gf / t1 * 1e3, float((y - ref).abs().max()), lay)
     print(line)

@@ -156,6 +156,118 @@ __global__ __launch_bounds__(256) void k_conv1x1(C1Args A)
             }
         }
 }
+
+// ---- 128 x 112 tiles on the 16 x 16 x 4 matrix instruction (round 5) ------------------------------------------------------------------------------------------------------
+// Every bottleneck shape of X-101-32x8d has M * N = 13.9 M outputs = 850 tiles of 128 x 128 = 3.32 rounds of 256 CUs (layer3: 216 tiles, 0.84 rounds): a sixth of the
+// chip-time is CUs waiting for the last round.  128 x 112 tiles make it 972 tiles = 3.8 rounds (layer3: 248 tiles, one round on 97 % of the CUs), each 7 / 8 of the work.
+// 112 is not a multiple of 32, so the tile runs on v_mfma_f32_16x16x4_f32 (same 64 FLOP / clk / SIMD as 32x32x2): a wave owns 32 output channels x 112 positions =
+// 2 x 7 fragments (56 accumulator registers), a k-step (4 input channels) is 14 matrix instructions on 14 different accumulators (the 40-cycle dependent latency of this
+// instruction never shows).  What carries over from the kernel above: both operands global -> LDS by scalar-addressed 1 KB buffer copies, two LDS buffers and one barrier
+// per chunk, operands read at immediate offsets, no vector-ALU instruction in the loop.  What differs:
+//   * weights packed [co / 16][k / 16][lane][4] (pack_conv1x1 layout 1): a lane's 16-byte read = its A operands of four k-steps of one 16-row fragment;
+//   * a B operand of k-step s is rows 4 s .. 4 s + 3 x 16 positions: a copy piece carries rows (r, r + 2) and the two pieces of a k-step sit 272 floats apart, so that the
+//     four 16-lane groups of a ds_read_b32 fall into disjoint banks (rows at the plain pitch of 128 floats would collide two by two);
+//   * the copy's last four lanes of a row (positions 112 .. 127 of the 128 a piece could carry) carry an out-of-range offset: no fetch.
+#define C2_TN 112
+template <int RES, int KC>
+__global__ __launch_bounds__(256) void k_conv1x1_n112(C1Args A)
+{
+    constexpr int NS = KC / 4, NG = KC / 16;          // k-steps / groups of four k-steps per chunk
+    constexpr int A_BUF = 8 * NG * 256;               // floats: 8 fragments of 16 rows x NG pieces of 1 KB
+    constexpr int B_PIECE = 272, B_BUF = 2 * NS * B_PIECE;
+    constexpr int NPA = 2 * NG, NPB = NS / 2, NPW = NPA + NPB;      // copy pieces per wave and chunk
+    extern __shared__ __attribute__((aligned(16))) float c1_lds[];  // [2][A_BUF] [2][B_BUF]
+    float* Al = c1_lds; float* Bl = c1_lds + 2 * A_BUF;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per = gridDim.x >> 3, item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (item >= A.total) return;
+    const int nt = item / A.mt, mtile = item - nt * A.mt, n0 = nt * C2_TN, m0 = mtile * C1_TM;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)A.wp, 0, A.wbytes, 0x00020000);
+    const unsigned avo = 16u * (unsigned)lane;
+    const unsigned bvo = (lane & 31) < C2_TN / 4 ? 4u * ((unsigned)(lane >> 5) * 2u * (unsigned)A.N + (unsigned)(n0 + 4 * (lane & 31))) : 0xfffffff0u;      // lanes 0..31 row r, 32..63 row r + 2; the last four lanes of a row: out of range, no fetch
+    const int kg = A.K / 16;                          // pieces per 16-row fragment of the packed weight
+    auto issue = [&](int chunk, int buf, int first, int count) {
+#pragma unroll
+        for (int q = first; q < first + count; q++) {
+            if (q >= NPW) break;
+            const int i = 4 * q + w;                                      // (scalar) a wave's pieces of one q are of one kind
+            if (q < NPA) {
+                const int mb = i / NG, g = i - mb * NG;                   // fragment 0..7 of the tile, group
+                const unsigned so = 4u * (unsigned)((((m0 >> 4) + mb) * kg + chunk * NG + g) * 256);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(Al + buf * A_BUF + i * 256), 16, avo, so, 0, 0);
+            } else {
+                const int p = i - 4 * NPA, s = p >> 1, h = p & 1;         // piece h of k-step s: rows 4 s + h and 4 s + h + 2
+                const unsigned so = 4u * (unsigned)(chunk * KC + 4 * s + h) * (unsigned)A.N;
+                const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)A.x + so), 0, A.xbytes - so, 0x00020000);      // (exact range check, see above)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(Bl + buf * B_BUF + p * B_PIECE), 16, bvo, 0, 0, 0);
+            }
+        }
+    };
+    f32x4 acc[2][7];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int j = 0; j < 7; j++) acc[mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    issue(0, 0, 0, NPW);
+    constexpr int PS = (NPW + NS - 3) / (NS - 2);     // pieces a wave sends per k-step: all of them gone two k-steps before the chunk ends
+    typedef const volatile __attribute__((address_space(3))) float* lds_f;      // (volatile: keeps the compiler from pairing the reads into ds_read2_b32, whose 8-bit offsets cost a vector add per pair)
+    for (int c = 0; c < A.nchunk; c++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                              // chunk c has landed in buffer c & 1; everybody is done with buffer (c + 1) & 1
+        const int nb = (c + 1) & 1, cn = min(c + 1, A.nchunk - 1);
+        const float* Ab = Al + (c & 1) * A_BUF + (2 * w * NG) * 256 + lane * 4;       // fragment 2 w + mi, group g: + (mi NG + g) 256
+        lds_f Bb = (lds_f)(Bl + (c & 1) * B_BUF + ((lane >> 4) & 1) * B_PIECE + (lane >> 5) * 128 + (lane & 15));      // k-step s, fragment j: + s 2 B_PIECE + 16 j
+        asm("" : "+v"(Bb));
+        f32x4 a[2][2]; float b[3][7];
+        auto lda = [&](int g) {
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) a[g & 1][mi] = *(const f32x4*)(Ab + (mi * NG + g) * 256);
+        };
+        auto ldb = [&](int s) {
+#pragma unroll
+            for (int j = 0; j < 7; j++) b[s % 3][j] = Bb[s * 2 * B_PIECE + 16 * j];
+        };
+        lda(0); ldb(0); ldb(1);
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < NS) ldb(s + 2);
+            if ((s & 3) == 1 && s / 4 + 1 < NG) lda(s / 4 + 1);
+            issue(cn, nb, s * PS, PS);
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                for (int j = 0; j < 7; j++) acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[(s >> 2) & 1][mi][s & 3], b[s % 3][j], acc[mi][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 14; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the last, unused copies)
+    // D of a 16 x 16 fragment: lane l, register r = output channel 4 (l >> 4) + r, position l & 15
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const int co0 = m0 + 32 * w + 16 * mi + 4 * (lane >> 4), q = n0 + 16 * j + (lane & 15);
+            if (q < A.N) {
+                float rv[4], bv[4];
+                size_t rq = (size_t)q, rn = (size_t)A.N;
+                if (RES == 2) { const int yy = q / A.W, xx = q - yy * A.W; rq = (size_t)(yy >> 1) * (A.W >> 1) + (xx >> 1); rn = (size_t)(A.N / A.W >> 1) * (A.W >> 1); }
+#pragma unroll
+                for (int r = 0; r < 4; r++) { bv[r] = A.bias ? A.bias[co0 + r] : 0.f; rv[r] = RES ? A.res[(size_t)(co0 + r) * rn + rq] : 0.f; }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float v = acc[mi][j][r] + bv[r] + rv[r];
+                    A.y[(size_t)(co0 + r) * A.N + q] = fmaxf(v, v * A.slope);
+                }
+            }
+        }
+}
 }  // namespace
 
 extern "C" {
@@ -166,10 +278,23 @@ int vido_conv1x1_supported(int cin, int cout, int hw)
     return cin >= 32 && cin % 32 == 0 && cout >= C1_TM && cout % C1_TM == 0 && hw >= C1_TN && 4ll * cin * hw < (1ll << 32) && 4ll * cin * cout < (1ll << 32);
 }
 
+/* Which tile form (= which weight packing) the library uses for a shape: 0 = 128 x 128 tiles on 32x32x2 (pack layout 0), 1 = 128 x 112 tiles on 16x16x4 (pack layout 1).
+ * The form with fewer (rounds of 256 CUs) x (tile width) wins; VIDO_CONV1X1_TN = 128 / 112 forces one.  The packer (vido_slam_amd/nets/ops.py::pack_conv1x1) asks this
+ * function, vido_conv1x1_bias_act asks it again with the same shape. */
+int vido_conv1x1_layout(int cin, int cout, int hw)
+{
+    static const int force = [] { const char* e = getenv("VIDO_CONV1X1_TN"); return e ? atoi(e) : 0; }();
+    if (force == 128 || cin % 64 != 0) return 0;
+    if (force == 112) return 1;
+    const long long mt = cout / C1_TM, t128 = mt * ((hw + 127) / 128), t112 = mt * ((hw + C2_TN - 1) / C2_TN);
+    const long long c128 = ((t128 + 255) / 256) * 128, c112 = ((t112 + 255) / 256) * C2_TN;
+    return c112 < c128 ? 1 : 0;
+}
+
 /* y = leaky_relu(conv2d(x, w) + bias + residual, slope) for one image, 1x1 kernel, stride 1: x [cin][hw], y / residual [cout][hw] f32 DEVICE tensors (16-byte aligned,
- * y != x), bias [cout] or NULL, residual NULL when there is none.  w_packed: the weight [cout][cin] in operand order, element (co, k) at
- * [co / 32][k / 8][32 * (k & 1) + co % 32][(k % 8) / 2]  (vido_slam_amd/nets/ops.py::pack_conv1x1).  slope 0 = ReLU, 1 = none (0 <= slope <= 1).  Enqueues on the adopted
- * stream; capturable. */
+ * y != x), bias [cout] or NULL, residual NULL when there is none.  w_packed: the weight [cout][cin] in operand order — layout vido_conv1x1_layout(cin, cout, hw):
+ *   0: element (co, k) at [co / 32][k / 8][32 * (k & 1) + co % 32][(k % 8) / 2];   1: at [co / 16][k / 16][16 * (k & 3) + co % 16][(k % 16) / 4]
+ * (vido_slam_amd/nets/ops.py::pack_conv1x1).  slope 0 = ReLU, 1 = none (0 <= slope <= 1).  Enqueues on the adopted stream; capturable. */
 static int c1_launch(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, int res_mode, float* y, int cin, int cout, int hw, int w, float slope)
 {
     if (!ctx) return VIDO_E_INVALID;
@@ -177,6 +302,21 @@ static int c1_launch(vido_ctx* ctx, const float* x, const float* w_packed, const
         return vido_set_error(ctx, VIDO_E_INVALID, "conv1x1: no kernel for %d -> %d channels at %d positions (or a pointer is misaligned, or slope outside [0, 1])", cin, cout, hw);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    const int rm = residual ? res_mode : 0;
+    if (vido_conv1x1_layout(cin, cout, hw) == 1) {
+        const int mt = cout / C1_TM, ntl = (hw + C2_TN - 1) / C2_TN, total = mt * ntl;
+        C1Args A{x, w_packed, bias, residual, y, cout, hw, cin, mt, total, cin / 64, slope, (unsigned)(4ll * cin * hw), (unsigned)(4ll * cin * cout), w};
+        constexpr size_t LDS112 = (size_t)2 * (8 * 4 * 256 + 2 * 16 * 272) * 4;
+        static bool attr2[64] = {};
+        if (!attr2[ctx->device & 63]) {
+            for (const void* f : {(const void*)k_conv1x1_n112<0, 64>, (const void*)k_conv1x1_n112<1, 64>, (const void*)k_conv1x1_n112<2, 64>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS112));
+            attr2[ctx->device & 63] = true;
+        }
+        const dim3 grid(8 * ((total + 7) / 8)), blk(256);
+        if (rm == 2) hipLaunchKernelGGL((k_conv1x1_n112<2, 64>), grid, blk, LDS112, st, A); else if (rm) hipLaunchKernelGGL((k_conv1x1_n112<1, 64>), grid, blk, LDS112, st, A); else hipLaunchKernelGGL((k_conv1x1_n112<0, 64>), grid, blk, LDS112, st, A);
+        HIP_TRY(ctx, hipGetLastError());
+        return VIDO_OK;
+    }
     const int mt = cout / C1_TM, ntl = (hw + C1_TN - 1) / C1_TN, total = mt * ntl;
     static const int force_kc = [] { const char* e = getenv("VIDO_CONV1X1_KC"); return e ? atoi(e) : 0; }();
     const int kc = (cin % 64 == 0 && force_kc != 32) ? 64 : 32;
@@ -189,7 +329,6 @@ static int c1_launch(vido_ctx* ctx, const float* x, const float* w_packed, const
         for (const void* f : {(const void*)k_conv1x1<0, 32>, (const void*)k_conv1x1<1, 32>, (const void*)k_conv1x1<2, 32>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS32));
         attr[ctx->device & 63] = true;
     }
-    const int rm = residual ? res_mode : 0;
     if (kc == 64) { if (rm == 2) hipLaunchKernelGGL((k_conv1x1<2, 64>), grid, blk, LDS64, st, A); else if (rm) hipLaunchKernelGGL((k_conv1x1<1, 64>), grid, blk, LDS64, st, A); else hipLaunchKernelGGL((k_conv1x1<0, 64>), grid, blk, LDS64, st, A); }
     else { if (rm == 2) hipLaunchKernelGGL((k_conv1x1<2, 32>), grid, blk, LDS32, st, A); else if (rm) hipLaunchKernelGGL((k_conv1x1<1, 32>), grid, blk, LDS32, st, A); else hipLaunchKernelGGL((k_conv1x1<0, 32>), grid, blk, LDS32, st, A); }
     HIP_TRY(ctx, hipGetLastError());

@@ -224,8 +224,11 @@ struct PyrTile {
     unsigned magic[PT_MAXL];                                          // ceil(2^32 / (nw / 4)): item -> (row, quad) without a division
 };
 struct PyrTileLv { int w[PT_MAXL], pitch[PT_MAXL], off[PT_MAXL], xoff[PT_MAXL], yoff[PT_MAXL]; int L; };
+// imgs != nullptr: level 0 comes straight from the caller's (device-resident, 4-byte aligned, width % 4 == 0) gray frames and the tile writes its owned part of it into the slab —
+// the ingest copy (k_ingest: 15 us per 64 frames, a full read + write of level 0) rides on the staging loads.
 __global__ __launch_bounds__(256) void k_pyramid_tiles(uint8_t* __restrict__ pyr, size_t slab, PyrTileLv V, const PyrTile* __restrict__ tiles,
-                                                       const int2* __restrict__ xtab, const int4* __restrict__ ytab)
+                                                       const int2* __restrict__ xtab, const int4* __restrict__ ytab,
+                                                       const uint8_t* __restrict__ imgs, size_t frame_stride, int stride)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t pt_lds[];
     const PyrTile& T = tiles[blockIdx.x];
@@ -233,11 +236,17 @@ __global__ __launch_bounds__(256) void k_pyramid_tiles(uint8_t* __restrict__ pyr
     const int tid = threadIdx.x;
     {   // one round trip: the level-0 rectangle (dword copies) and the table slices of every level
         const int nq = T.nw[0] >> 2, n = T.nh[0] * nq;
-        const uint8_t* src = base + V.off[0] + (size_t)T.ny0[0] * V.pitch[0] + T.nx0[0];
+        const int spitch = imgs ? stride : V.pitch[0];
+        const uint8_t* src = (imgs ? imgs + (size_t)blockIdx.y * frame_stride : base + V.off[0]) + (size_t)T.ny0[0] * spitch + T.nx0[0];
         uint32_t* dst = (uint32_t*)(pt_lds + T.lds[0]);
+        uint8_t* G0 = base + V.off[0];
+        const int w0 = V.w[0], ox0 = T.ox0[0], ox1 = T.ox1[0], oy0 = T.oy0[0], oy1 = T.oy1[0];
         for (int i = tid; i < n; i += 256) {
             const int rr = (int)__umulhi((unsigned)i, T.magic[0]), q = i - rr * nq;
-            dst[i] = *(const uint32_t*)(src + (size_t)rr * V.pitch[0] + 4 * q);
+            const int y = T.ny0[0] + rr, x4 = T.nx0[0] + 4 * q;
+            const uint32_t v = (!imgs || x4 < w0) ? *(const uint32_t*)(src + (size_t)rr * spitch + 4 * q) : 0u;      // (pad columns of the slab hold 0)
+            dst[i] = v;
+            if (imgs && y >= oy0 && y < oy1 && x4 >= ox0 && x4 < ox1) *(uint32_t*)(G0 + (size_t)y * V.pitch[0] + x4) = v;
         }
         for (int l = 1; l < V.L; l++) {
             int2* xs = (int2*)(pt_lds + T.xt_lds[l]); int4* ys = (int4*)(pt_lds + T.yt_lds[l]);
@@ -359,11 +368,11 @@ __device__ __forceinline__ uint32_t fast_compass_quad2(uint32_t up, uint32_t m0,
         const v2u x = __builtin_elementwise_min(a, c), y = __builtin_elementwise_max(b, d);
         const v2u sl = __builtin_elementwise_max(x, y), ss = __builtin_elementwise_min(x, y);      // second largest / second smallest of the four
 #else
-        // a 9-arc contains two ADJACENT compass points (90 degrees apart): sl = the largest over the four adjacent pairs of the pair's minimum, ss = the mirror image
-        const v2u n04 = __builtin_elementwise_min(r0, r4), n48 = __builtin_elementwise_min(r4, r8), n8c = __builtin_elementwise_min(r8, r12), nc0 = __builtin_elementwise_min(r12, r0);
-        const v2u x04 = __builtin_elementwise_max(r0, r4), x48 = __builtin_elementwise_max(r4, r8), x8c = __builtin_elementwise_max(r8, r12), xc0 = __builtin_elementwise_max(r12, r0);
-        const v2u sl = __builtin_elementwise_max(__builtin_elementwise_max(n04, n48), __builtin_elementwise_max(n8c, nc0));
-        const v2u ss = __builtin_elementwise_min(__builtin_elementwise_min(x04, x48), __builtin_elementwise_min(x8c, xc0));
+        // a 9-arc contains two ADJACENT compass points (90 degrees apart): sl = the largest over the four adjacent pairs of the pair's minimum, ss = the mirror image.
+        // On the 4-cycle 0 - 4 - 8 - 12 every adjacent pair is one of {0, 8} with one of {4, 12}, and min / max distribute over each other, so
+        //   max(min(r0,r4), min(r4,r8), min(r8,r12), min(r12,r0)) = min(max(r0,r8), max(r4,r12))     (round 5: 3 + 3 packed instructions instead of 8 + 6, same bits)
+        const v2u sl = __builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12));
+        const v2u ss = __builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12));
 #endif
         const uint32_t br = as_u32((v2u)(v + T - sl)), dk = as_u32((v2u)(ss - (v - T)));             // 16-bit wrap-around: sign bit <=> sl > v + th, ss < v - th (|values| < 2^15)
         const uint32_t bits = (br & 0x80008000u) | ((dk & 0x80008000u) >> 1);
@@ -657,6 +666,50 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ co
         lvloff[i] = offsets[f * n_cells + first_cell[l]];
     }
     if (tid == 0) lvloff[n_frames * n_levels] = total;
+}
+
+// The same scan in two short launches (round 5): k_scan_counts above is ONE workgroup walking frames x cells counts twice (28 us at 64 frames x 870 cells — as long as
+// a fifth of the FAST kernel it follows).  k_scan_frames: one workgroup per frame scans that frame's cells (local offsets, per-level local starts, the frame total);
+// k_scan_apply: every entry adds its frame's base = the sum of the earlier frames' totals (<= max_batch values, summed by one wave).
+__global__ __launch_bounds__(256) void k_scan_frames(const int* __restrict__ counts, int n_cells, int n_levels, const int* __restrict__ first_cell,
+                                                     int* __restrict__ offsets, int* __restrict__ lvloff, int* __restrict__ totals)
+{
+    __shared__ int wtot[4];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n_cells + 255) / 256, beg = min(tid * per, n_cells), end = min(beg + per, n_cells);
+    const int* c = counts + (size_t)f * n_cells; int* o = offsets + (size_t)f * n_cells;
+    int s = 0;
+    for (int i = beg; i < end; i++) s += c[i];
+    int inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int run = inc - s;
+#pragma unroll
+    for (int w = 0; w < 4; w++) if (w < wave) run += wtot[w];
+    for (int i = beg; i < end; i++) { const int v = c[i]; o[i] = run; run += v; }
+    if (tid == 255) totals[f] = run;                                 // (the last thread's running sum ends at the frame total: its segment is the last one, possibly empty)
+    __syncthreads();
+    __threadfence_block();
+    if (tid < n_levels) lvloff[f * n_levels + tid] = o[first_cell[tid]];
+}
+__global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ offsets, int* __restrict__ lvloff, const int* __restrict__ totals, int n_cells, int n_levels, int n_frames)
+{
+    __shared__ int sbase;
+    const int f = blockIdx.y, tid = threadIdx.x;
+    if (tid < 64) {
+        int b = 0;
+        for (int g = tid; g < f; g += 64) b += totals[g];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) b += __shfl_xor(b, d, 64);
+        if (tid == 0) sbase = b;
+    }
+    __syncthreads();
+    const int base = sbase, i = blockIdx.x * 256 + tid;
+    if (i < n_cells) offsets[(size_t)f * n_cells + i] += base;
+    if (blockIdx.x == 0 && tid < n_levels) lvloff[f * n_levels + tid] += base;
+    if (blockIdx.x == 0 && tid == 0 && f == n_frames - 1) { const int total = base + totals[f]; offsets[(size_t)n_frames * n_cells] = total; lvloff[n_frames * n_levels] = total; }
 }
 
 __global__ __launch_bounds__(64) void k_gather_cands(const uint32_t* __restrict__ slots, const int* __restrict__ counts, const int* __restrict__ offsets,
@@ -998,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ pyr, 
 //     byte is bits 23:16 of the accumulator (<= 255 * 65536 + 32768), picked out by two v_perm;
 //   * reflect-101 columns (left edge, right edge, a partial last quad) are built ONCE per loaded row from real lanes' dwords: every virtual byte is some real byte of
 //     at most two other lanes of the wave — two ds_bpermute + one v_perm with per-lane constants, only in waves that contain an edge; reflect-101 rows are a scalar row
-//     index.  Integer arithmetic throughout, no intermediate rounding: identical to the horizontal-then-vertical order of the oracle (oracle/orb_oracle.c vo_gaussian_blur7).
+//     index.  Integer arithmetic throughout, no intermediate rounding: identical to the horizontal-then-vertical order of k_blur7 and of the CPU checker.
 #define BS_QUADS 62                // output quads per wave (lanes 1 .. 62)
 // reflect-101 for an index at most n - 1 outside [0, n): one fold per side, no loop (the host only builds strips for levels where that holds); clamped, so that the rows
 // below the image a last strip still loads (and never stores an output for) stay in bounds
@@ -1109,6 +1162,31 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)      // cv::fa
     return a;
 }
 
+// (float)cos((double)x), (float)sin((double)x) for x in [0, 2 pi] (the steered-BRIEF rotation, ORBextractor.cc:103): the device library's double sin + cos are ~190 fp64
+// instructions per wave (argument reduction for any magnitude, done twice) — 40 % of k_orient_brief.  Here: one Cody-Waite reduction by pi/2 (k <= 4, two fused multiply-adds,
+// exact to < 1 ulp for this range) and fdlibm's __kernel_sin / __kernel_cos minimax polynomials on |r| <= pi/4 (< 1 ulp in double, as the libraries'): ~25 fp64 instructions.
+// The float result differs from a correctly rounded one only when the double lands within ~1e-16 relative of a float rounding boundary (2^-29 of the arguments) — the same
+// caveat the host libm / device library pair always had.
+__device__ __forceinline__ void sincos_0_2pi(double x, float* sn, float* cs)
+{
+    const double k = __builtin_rint(x * 6.36619772367581382433e-01);          // 2 / pi
+    double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);               // pi / 2, high part
+    r = __builtin_fma(-k, 6.12323399573676603587e-17, r);                      //         low part
+    const double z = r * r;
+    // sin r = r + r z (S1 + z (S2 + ... z S6));  cos r = 1 - z / 2 + z z (C1 + z (C2 + ... z C6))
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06); ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03); ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double s = __builtin_fma(r * z, ps, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07); pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03); pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double c = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+    const int q = (int)k & 3;
+    const double so = q == 0 ? s : (q == 1 ? c : (q == 2 ? -s : -c)), co = q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
+    *sn = (float)so; *cs = (float)co;
+}
+
 __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t slab, PyrDev P,
                                                       const uint2* __restrict__ kps, const int* __restrict__ frame_beg, int f0, int f1, int with_desc,
                                                       vido_keypoint* __restrict__ kpf, uint8_t* __restrict__ descf, int row_cap, unsigned long long umax_packed)
@@ -1158,7 +1236,7 @@ __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict_
     if (!with_desc) return;
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ar = ang * factorPI;
-    const float a = (float)cos((double)ar), b = (float)sin((double)ar);
+    float a, b; sincos_0_2pi((double)ar, &b, &a);             // a = (float)cos((double)ar), b = (float)sin((double)ar)
     const uint8_t* cb = blur + (size_t)f * slab + P.off[level] + (size_t)y * pitch + x;
     uint32_t nib = 0;
 #pragma unroll
@@ -1193,6 +1271,7 @@ struct OrbState {
     int2* d_xtab = nullptr; int4* d_ytab = nullptr;
     PyrBand* d_bands = nullptr; int n_bands = 0; size_t bands_lds = 0; PyrBandLv band_lv{};      // single-launch pyramid (k_pyramid_bands)
     PyrTile* d_ptiles = nullptr; int n_ptiles = 0; size_t ptiles_lds = 0; PyrTileLv ptile_lv{};  // single-launch pyramid for any batch (k_pyramid_tiles); 0 tiles = not built
+    int* d_frame_tot = nullptr;                                       // per-frame candidate totals (k_scan_frames -> k_scan_apply)
     uint32_t* d_slots = nullptr; int *d_counts = nullptr, *d_offsets = nullptr, *d_first_cell = nullptr, *d_lvloff = nullptr, *d_overflow = nullptr;
     uint32_t* d_cand = nullptr; size_t cand_cap = 0;
     uint2* d_kp = nullptr; size_t kp_cap = 0;
@@ -1321,8 +1400,8 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
             for (int tx = 0; tx < NX && ok; tx++) {
                 PyrTile t{}; int x0[PT_MAXL], x1[PT_MAXL], y0[PT_MAXL], y1[PT_MAXL];            // computed rectangle [x0, x1) x [y0, y1): the needed columns widened to whole quads
                 int n0[PT_MAXL], n1[PT_MAXL];                                                   // the columns really needed [n0, n1)
-                for (int l = 1; l < L; l++) {
-                    const int w = S->lv[l].w, h = S->lv[l].h, w4 = (w + 3) & ~3;
+                for (int l = 0; l < L; l++) {                       // (level 0's rectangle is only written when the ingest is fused into the launch; it is staged either way)
+                    const int w = S->lv[l].w, h = S->lv[l].h, w4 = l == 0 ? S->lv[0].pitch : (w + 3) & ~3;
                     t.ox0[l] = tx == 0 ? 0 : (int)((long long)tx * w / NX) & ~3; t.ox1[l] = tx + 1 == NX ? w4 : (int)((long long)(tx + 1) * w / NX) & ~3;
                     t.oy0[l] = (int)((long long)ty * h / NY); t.oy1[l] = (int)((long long)(ty + 1) * h / NY);
                 }
@@ -1336,9 +1415,9 @@ static int build_tables(vido_ctx* ctx, OrbState* S)
                     // row or buffer): nobody needs those pixels, so their sources are not staged — needed rectangles grow by ~2 px per level instead of ~2 + up to 6.
                     int lo = xt[n0[l + 1]].x & 0xffff, hi = std::min((xt[n1[l + 1] - 1].x & 0xffff) + 1, w - 1) + 1;
                     int ylo = yt[y0[l + 1]].x, yhi = yt[y1[l + 1] - 1].y + 1;
-                    if (l >= 1) { lo = std::min(lo, t.ox0[l]); hi = std::max(hi, t.ox1[l]); ylo = std::min(ylo, t.oy0[l]); yhi = std::max(yhi, t.oy1[l]); }
+                    lo = std::min(lo, t.ox0[l]); hi = std::max(hi, t.ox1[l]); ylo = std::min(ylo, t.oy0[l]); yhi = std::max(yhi, t.oy1[l]);
                     n0[l] = lo; n1[l] = std::min(hi, w);
-                    x0[l] = lo & ~3; x1[l] = std::min((hi + 3) & ~3, l == 0 ? S->lv[0].pitch : w4); y0[l] = ylo; y1[l] = yhi;
+                    x0[l] = lo & ~3; x1[l] = std::min((hi + 3) & ~3, l == 0 ? S->lv[0].pitch : w4); y0[l] = ylo; y1[l] = std::min(yhi, S->lv[l].h);
                     if (x1[l] <= x0[l] || y1[l] <= y0[l] || n1[l] <= n0[l]) ok = false;
                 }
                 if (x1[L - 1] <= x0[L - 1] || y1[L - 1] <= y0[L - 1]) ok = false;
@@ -1501,6 +1580,7 @@ int orb_state_create(vido_ctx* ctx)
     HIP_TRY(ctx, hipFuncSetAttribute(S->fast_iw == FS_NARROW ? (const void*)k_fast_strips<FS_NARROW> : (const void*)k_fast_strips<FS_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->fast_lds));
     HIP_TRY(ctx, hipMalloc(&S->d_counts, ncell * sizeof(int)));
     HIP_TRY(ctx, hipMalloc(&S->d_offsets, (ncell + 1) * sizeof(int)));
+    HIP_TRY(ctx, hipMalloc(&S->d_frame_tot, (B + 1) * sizeof(int)));
     HIP_TRY(ctx, hipMalloc(&S->d_lvloff, (B * S->L + 1) * sizeof(int)));
     HIP_TRY(ctx, hipMalloc(&S->d_overflow, sizeof(int)));
     HIP_TRY(ctx, hipMemset(S->d_overflow, 0, sizeof(int)));
@@ -1544,7 +1624,7 @@ void orb_state_destroy(vido_ctx* ctx)
     OrbState* S = ctx->orb;
     if (!S) return;
     hipFree(S->d_pyr); hipFree(S->d_blur); hipFree(S->d_cells); hipFree(S->d_btiles); hipFree(S->d_bstrips); hipFree(S->d_xtab); hipFree(S->d_ytab); hipFree(S->d_bands); hipFree(S->d_ptiles);
-    hipFree(S->d_slots); hipFree(S->d_counts); hipFree(S->d_offsets); hipFree(S->d_first_cell); hipFree(S->d_lvloff); hipFree(S->d_overflow);
+    hipFree(S->d_slots); hipFree(S->d_counts); hipFree(S->d_offsets); hipFree(S->d_frame_tot); hipFree(S->d_first_cell); hipFree(S->d_lvloff); hipFree(S->d_overflow);
     hipFree(S->d_cand); hipFree(S->d_kp); hipFree(S->d_strips); hipFree(S->d_slot_off);
     hipHostFree(S->h_lvloff); hipHostFree(S->h_overflow); hipHostFree(S->h_cand);
     for (auto& e : S->ev) if (e) hipEventDestroy(e);
@@ -1586,6 +1666,9 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
     const bool lean = nf <= 2 && !full_timing;
 #define ORB_EV(e, s_) do { if (!lean) HIP_TRY(ctx, hipEventRecord((e), (s_))); } while (0)
     ORB_EV(S->ev[0], st);
+    static const int tiles_mode = [] { const char* e = getenv("VIDO_PYR_TILES"); return e ? atoi(e) : 1; }();        // A/B switch: 0 = the round-4 kernels (bands for one frame, per-level launches for a batch); 2 = tiles, ingest not fused
+    // gray device frames that allow dword loads ride on the tile kernel's staging instead of a copy of their own
+    const bool fuse_ingest = S->n_ptiles && tiles_mode == 1 && S->in_channels == 1 && on_device && L >= 2 && (((uintptr_t)imgs | (uintptr_t)frame_stride | (uintptr_t)stride | (uintptr_t)width) & 3) == 0;
     // level 0 <- input
     if (S->in_channels != 1) {                          // colour frames: cvtColor fused into the ingest (set by vido_orb_extract_color for this one call)
         const int cn = S->in_channels; const uint8_t* src = imgs; size_t fs = frame_stride; int sst = stride;
@@ -1609,6 +1692,7 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
         if (S->gray_out && !S->gray_out_on_device)
             HIP_TRY(ctx, hipMemcpyAsync(S->gray_out, gdev, (size_t)nf * width * height, hipMemcpyDeviceToHost, st));
     }
+    else if (on_device && fuse_ingest) { /* level 0 is written by k_pyramid_tiles below */ }
     else if (on_device)
         hipLaunchKernelGGL(k_ingest, dim3((S->lv[0].pitch / 4 + 63) / 64, (height + 3) / 4, nf), dim3(256), 0, st, imgs, frame_stride, stride, width, height,
                            S->d_pyr, S->slab, S->lv[0].off, S->lv[0].pitch);
@@ -1616,9 +1700,9 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
         HIP_TRY(ctx, hipMemcpy2DAsync(S->d_pyr + (size_t)f * S->slab + S->lv[0].off, S->lv[0].pitch, imgs + (size_t)f * frame_stride, stride,
                                       width, height, hipMemcpyHostToDevice, st));
     static const int bands_mode = [] { const char* e = getenv("VIDO_ORB_BANDS"); return e ? atoi(e) : -1; }();      // experiment switch: 1 = the band pyramid for every batch size, 0 = never
-    static const int tiles_mode = [] { const char* e = getenv("VIDO_PYR_TILES"); return e ? atoi(e) : 1; }();        // A/B switch: 0 = the round-4 kernels (bands for one frame, per-level launches for a batch)
     if (S->n_ptiles && tiles_mode)
-        hipLaunchKernelGGL(k_pyramid_tiles, dim3(S->n_ptiles, nf), dim3(256), S->ptiles_lds, st, S->d_pyr, S->slab, S->ptile_lv, (const PyrTile*)S->d_ptiles, (const int2*)S->d_xtab, (const int4*)S->d_ytab);
+        hipLaunchKernelGGL(k_pyramid_tiles, dim3(S->n_ptiles, nf), dim3(256), S->ptiles_lds, st, S->d_pyr, S->slab, S->ptile_lv, (const PyrTile*)S->d_ptiles, (const int2*)S->d_xtab, (const int4*)S->d_ytab,
+                           fuse_ingest ? imgs : (const uint8_t*)nullptr, frame_stride, stride);
     else if (S->n_bands && (bands_mode == 1 || (bands_mode != 0 && lean)))
         hipLaunchKernelGGL(k_pyramid_bands, dim3(S->n_bands, nf), dim3(256), S->bands_lds, st, S->d_pyr, S->slab, S->band_lv, (const PyrBand*)S->d_bands, (const int2*)S->d_xtab, (const int4*)S->d_ytab);
     else for (int l = 1; l < L; l++) {
@@ -1646,7 +1730,13 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
             if (hc[i] < 0 || hc[i] > capc) { if (bad++ < 8) fprintf(stderr, "[vido]   cell %d (frame %zu): count %d, capacity %d\n", c, i / S->n_cells, hc[i], capc); } }
         fprintf(stderr, "[vido] counts: total %lld, %d out of range\n", tot, bad);
     }
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, S->d_counts, S->n_cells * nf, S->d_offsets, S->n_cells, nf, L, S->d_first_cell, S->d_lvloff);
+    static const bool scan_one = getenv("VIDO_ORB_SCAN1") != nullptr;       // A/B switch: the single-workgroup scan
+    if (scan_one || nf == 1 || L > 64)
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, S->d_counts, S->n_cells * nf, S->d_offsets, S->n_cells, nf, L, S->d_first_cell, S->d_lvloff);
+    else {
+        hipLaunchKernelGGL(k_scan_frames, dim3(nf), dim3(256), 0, st, S->d_counts, S->n_cells, L, S->d_first_cell, S->d_offsets, S->d_lvloff, S->d_frame_tot);
+        hipLaunchKernelGGL(k_scan_apply, dim3((S->n_cells + 255) / 256, nf), dim3(256), 0, st, S->d_offsets, S->d_lvloff, S->d_frame_tot, S->n_cells, L, nf);
+    }
     hipLaunchKernelGGL(k_gather_cands, dim3(S->n_cells, nf), dim3(64), 0, st, S->d_slots, S->d_counts, S->d_offsets, S->d_slot_off, S->slot_total, S->n_cells, S->d_cand, (int)S->cand_cap);
     ORB_EV(S->ev[2], st);
     // the blur only needs the pyramid: it runs on the second stream, concurrently with the quadtree and the keypoint list kernels (512 latency-bound

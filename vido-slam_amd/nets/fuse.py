@@ -58,11 +58,11 @@ def fold_batchnorm(net, ops):
             m._w1p = m._w3p = m._wdp = None; m._c1x1_min_tiles = 0
             mode = os.environ.get("VIDO_CONV1X1", "all")
             if not os.environ.get("VIDO_NO_CONV1X1") and hasattr(ops, "conv1x1_bias_act"):
-                from .ops import pack_conv1x1
-                m._w3p = pack_conv1x1(m._w3)
+                from .ops import PackedConv1x1
+                m._w3p = PackedConv1x1.make(m._w3)
                 if mode == "all":
-                    if tuple(m.conv1.stride) == (1, 1): m._w1p = pack_conv1x1(m._w1)
-                    if m.downsample is not None and tuple(m.downsample[0].stride) in ((1, 1), (2, 2)): m._wdp = pack_conv1x1(m._wd)      # (stride 2: on the subsampled map)
+                    if tuple(m.conv1.stride) == (1, 1): m._w1p = PackedConv1x1.make(m._w1)
+                    if m.downsample is not None and tuple(m.downsample[0].stride) in ((1, 1), (2, 2)): m._wdp = PackedConv1x1.make(m._wd)      # (stride 2: on the subsampled map)
         elif isinstance(m, _Stem):
             m._w1, m._b1 = _fold(m.conv1, m.bn1, _eps(m.bn1)); m._ep = ops.bias_res_act_; n += 1
         elif isinstance(m, _Basic):

@@ -148,13 +148,21 @@ class HipOps:
     def conv1x1_supported(self, cin, cout, hw):
         return bool(self.ctx.lib.vido_conv1x1_supported(int(cin), int(cout), int(hw)))
 
+    def conv1x1_layout(self, cin, cout, hw):
+        return int(self.ctx.lib.vido_conv1x1_layout(int(cin), int(cout), int(hw)))
+
     def conv1x1_bias_act(self, x, w_packed, bias=None, residual=None, slope=1.0, residual_up2=None):
-        """leaky_relu(conv2d(x, w) + bias + residual, slope) for one image, 1x1 kernel, stride 1, as one matrix-core GEMM launch (csrc/conv1x1.hip); w_packed = pack_conv1x1(w).
-        slope 0 = ReLU, 1 = none.  residual_up2: a residual at half the resolution, added nearest-upsampled (the FPN's top-down sum)."""
+        """leaky_relu(conv2d(x, w) + bias + residual, slope) for one image, 1x1 kernel, stride 1, as one matrix-core GEMM launch (csrc/conv1x1.hip);
+        w_packed = pack_conv1x1(w, conv1x1_layout(cin, cout, H * W)).  slope 0 = ReLU, 1 = none.  residual_up2: a residual at half the resolution, added nearest-upsampled
+        (the FPN's top-down sum)."""
         assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and x.shape[0] == 1
         _, cin, H, W = x.shape
-        cout = w_packed.shape[0] * 32
-        assert w_packed.shape[1] * 8 == cin and 0.0 <= slope <= 1.0 and (residual is None or residual_up2 is None)
+        if isinstance(w_packed, PackedConv1x1):                     # packed on first use, in the tile form the library picks for this (cin, cout, H * W)
+            w_packed = w_packed.get(self.conv1x1_layout(cin, w_packed.cout, H * W), x.device)
+        cout = w_packed.numel() // cin
+        layout = self.conv1x1_layout(cin, cout, H * W)
+        assert tuple(w_packed.shape) == ((cout // 16, cin // 16, 64, 4) if layout == 1 else (cout // 32, cin // 8, 64, 4)), "conv1x1: weight packed for the other tile form (pack_conv1x1(w, layout))"
+        assert 0.0 <= slope <= 1.0 and (residual is None or residual_up2 is None)
         out = torch.empty((1, cout, H, W), device=x.device, dtype=torch.float32)
         self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * cout * cin * H * W      # (torch's FlopCounterMode does not see this launch; bench.py adds it)
         self._adopt_stream()
@@ -172,16 +180,17 @@ class HipOps:
 
     def conv1x1_conv(self, conv, x, slope=1.0, residual=None, residual_up2=None):
         """The 1x1 convolution `conv` (nn.Conv2d, stride 1) + bias (+ residual) + activation through conv1x1_bias_act when the layer has that form, else None; the packed weight
-        is cached on the module and rebuilt when the weight tensor changes."""
+        is cached on the module (per tile form) and rebuilt when the weight tensor changes."""
         w = conv.weight
         if (tuple(w.shape[2:]) != (1, 1) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (0, 0) or conv.groups != 1 or not x.is_cuda or x.shape[0] != 1
                 or not self.conv1x1_supported(w.shape[1], w.shape[0], x.shape[2] * x.shape[3])):
             return None
         if not conv1x1_fills_chip(w.shape[0], x.shape[2] * x.shape[3]):
             return None
-        key = (w.data_ptr(), w._version, str(x.device))
+        layout = self.conv1x1_layout(w.shape[1], w.shape[0], x.shape[2] * x.shape[3])
+        key = (w.data_ptr(), w._version, str(x.device), layout)
         if getattr(conv, "_c1_key", None) != key:
-            conv._c1_w = pack_conv1x1(w).to(x.device); conv._c1_key = key
+            conv._c1_w = pack_conv1x1(w, layout).to(x.device); conv._c1_key = key
         return self.conv1x1_bias_act(x.contiguous(), conv._c1_w, conv.bias, residual, slope, residual_up2)
 
     def conv_kxk_c2(self, conv, x, residual=None):
@@ -465,16 +474,42 @@ def conv1x1_fills_chip(cout, hw):
     return (int(cout) // 128) * ((int(hw) + 127) // 128) >= _C1X1_MIN_TILES
 
 
-def pack_conv1x1(w):
-    """1x1 convolution weight [cout, cin, 1, 1] (or [cout, cin]) -> the operand order of csrc/conv1x1.hip: element (co, k) at [co / 32][k / 8][32 * (k & 1) + co % 32][(k % 8) / 2]
-    (a lane's four operands of a group of four k-pairs are one 16-byte read; a (32-channel block, group) is one 1 KB copy piece).  None when the kernel does not take the shape."""
+def pack_conv1x1(w, layout=0):
+    """1x1 convolution weight [cout, cin, 1, 1] (or [cout, cin]) -> the operand order of csrc/conv1x1.hip (layout = HipOps.conv1x1_layout(cin, cout, H * W) = vido_conv1x1_layout):
+    0: element (co, k) at [co / 32][k / 8][32 * (k & 1) + co % 32][(k % 8) / 2] (a lane's four operands of a group of four k-pairs are one 16-byte read; a (32-channel block, group)
+       is one 1 KB copy piece) — the 128 x 128 tiles on the 32 x 32 x 2 matrix instruction;
+    1: at [co / 16][k / 16][16 * (k & 3) + co % 16][(k % 16) / 4] (a lane's 16-byte read = its operands of four k-steps of a 16-row fragment) — the 128 x 112 tiles on 16 x 16 x 4.
+    None when the kernel does not take the shape."""
     cout, cin = int(w.shape[0]), int(w.shape[1])
     if w.dim() == 4 and tuple(w.shape[2:]) != (1, 1):
         return None
-    if cout % 128 or cin % 32:
+    if cout % 128 or cin % 32 or (layout == 1 and cin % 64):
         return None
+    if layout == 1:
+        w5 = w.detach().reshape(cout // 16, 16, cin // 16, 4, 4)         # [fragment][co16][group][e][kk]   with k = 16 group + 4 e + kk
+        return w5.permute(0, 2, 4, 1, 3).contiguous().reshape(cout // 16, cin // 16, 64, 4)
     w5 = w.detach().reshape(cout // 32, 32, cin // 8, 4, 2)            # [mb][co32][group][kk][half]
     return w5.permute(0, 2, 4, 1, 3).contiguous().reshape(cout // 32, cin // 8, 64, 4)
+
+
+class PackedConv1x1:
+    """A 1x1 convolution weight whose operand order depends on the map it meets (pack_conv1x1 layouts 0 / 1): packed lazily per (layout, device), outside any graph capture
+    (the warm-up calls of fuse.Graphed come first).  None-like when no layout takes the shape: use PackedConv1x1.make."""
+
+    def __init__(self, w):
+        self.w = w.detach(); self.cout = int(w.shape[0]); self.cin = int(w.shape[1]); self._p = {}
+
+    @staticmethod
+    def make(w):
+        return PackedConv1x1(w) if pack_conv1x1(w, 0) is not None else None
+
+    def get(self, layout, device):
+        key = (int(layout), str(device))
+        if key not in self._p:
+            p = pack_conv1x1(self.w, layout)
+            assert p is not None, "conv1x1: layout %d does not take %d -> %d channels" % (layout, self.cin, self.cout)
+            self._p[key] = p.to(device)
+        return self._p[key]
 
 
 def pack_conv1x1_skinny(w):
