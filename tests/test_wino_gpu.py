@@ -22,6 +22,7 @@ def ctx(vido):
 SHAPES = [  # (N, cin, cout, H, W): LiteFlowNet heads at the small levels, ragged channel counts, odd maps, the 32-channel form (4-channel chunks), batches, the minimum
     (1, 49, 128, 30, 40), (1, 130, 128, 60, 80), (1, 131, 128, 15, 20), (1, 386, 128, 15, 20), (2, 32, 32, 24, 32), (1, 64, 32, 30, 40), (1, 64, 96, 17, 23),
     (1, 96, 96, 60, 80), (3, 256, 256, 14, 14), (1, 256, 256, 25, 34), (1, 8, 64, 2, 2), (1, 9, 32, 3, 5), (2, 16, 64, 7, 9), (1, 128, 64, 120, 160),
+    (1, 256, 256, 200, 272), (1, 128, 128, 240, 320),      # the two shapes the bench prices: the FPN output convolution of P2 (852 workgroups), LiteFlowNet's level-2 regularisation
 ]
 
 
