@@ -7,6 +7,7 @@ import vido_slam_amd
 from vido_slam_amd import nets
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "nets_kats.npz"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-4            # relative to the output's max magnitude (fp32, different summation orders)
 
 
@@ -156,16 +157,19 @@ def test_pack_conv1x1_is_the_operand_order_of_the_kernel():
 
 
 def test_conv1x1_tile_form_is_chosen_by_rounds_of_workgroups():
-    """vido_conv1x1_layout (host side of csrc/conv1x1.hip): 128 x 112 tiles where they need fewer (rounds of 256 CUs) x (tile width) than 128 x 128 — every bottleneck
-    shape of X-101-32x8d at the 800 x 1088 feed (850 tiles of 128 x 128 = 3.3 rounds -> 972 of 128 x 112 = 3.8 rounds, each 7 / 8 of the work); 128 x 128 where the
-    112-wide form would add a round, or when the input channels are not a multiple of 64."""
-    import ctypes as C
-    from vido_slam_amd.host import load_library
-    lib = load_library()
-    for cin, cout, hw in ((256, 256, 200 * 272), (512, 512, 100 * 136), (1024, 1024, 50 * 68)):
-        assert lib.vido_conv1x1_layout(cin, cout, hw) == 1
-    assert lib.vido_conv1x1_layout(96, 128, 4096) == 0                 # input channels not a multiple of 64
-    assert lib.vido_conv1x1_layout(256, 256, 128 * 128 * 2) == 0       # 2 x 256 tiles of 128 x 128 = 2 rounds; 586 of 112 = 3 rounds
+    """vido_conv1x1_layout (host side of csrc/conv1x1.hip).  Default: 128 x 128 tiles (the form that measured faster on the pipelined headline).  VIDO_CONV1X1_TN=0: 128 x 112
+    tiles where they need fewer (rounds of 256 CUs) x (tile width) — every bottleneck shape of X-101-32x8d at the 800 x 1088 feed (850 tiles of 128 x 128 = 3.3 rounds -> 972
+    of 128 x 112 = 3.8 rounds, each 7 / 8 of the work); 128 x 128 where the 112-wide form would add a round, or when the input channels are not a multiple of 64.  The switch
+    is read once per process: the rule is asked in a child process."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); from vido_slam_amd.host import load_library; lib = load_library(); "
+            "print([lib.vido_conv1x1_layout(*a) for a in ((256, 256, 200 * 272), (512, 512, 100 * 136), (1024, 1024, 50 * 68), (96, 128, 4096), (256, 256, 128 * 128 * 2))])" % ROOT)
+    for tn, want in (("0", [1, 1, 1, 0, 0]), ("128", [0, 0, 0, 0, 0]), ("112", [1, 1, 1, 0, 1]), (None, [0, 0, 0, 0, 0])):
+        env = {k: v for k, v in os.environ.items() if k != "VIDO_CONV1X1_TN"}
+        if tn is not None:
+            env["VIDO_CONV1X1_TN"] = tn
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == str(want), (tn, out.stdout, out.stderr[-500:])
 
 
 def test_strided_grouped_conv_plan_answers_without_a_gpu():

@@ -283,7 +283,11 @@ int vido_conv1x1_supported(int cin, int cout, int hw)
  * function, vido_conv1x1_bias_act asks it again with the same shape. */
 int vido_conv1x1_layout(int cin, int cout, int hw)
 {
-    static const int force = [] { const char* e = getenv("VIDO_CONV1X1_TN"); return e ? atoi(e) : 0; }();
+    // Default 128: measured on the pipelined headline (two A/B pairs of 100 steps, profiles/r5/conv1x1_tile_form_ab.txt) the 112-wide form costs 2.5 % (88.3 -> 86.1 frames/s)
+    // although the detector ALONE gets faster (8.87 -> 8.65 ms): beside two other streams the CUs a 216-tile launch leaves idle are not idle — they run LiteFlowNet and the
+    // tracker — and the 112-wide form needs the same matrix time on 248 CUs plus more LDS reads per matrix instruction.  VIDO_CONV1X1_TN=0 lets the rounds rule below decide
+    // (a detector running alone), 112 / 128 force a form.
+    static const int force = [] { const char* e = getenv("VIDO_CONV1X1_TN"); return e ? atoi(e) : 128; }();
     if (force == 128 || cin % 64 != 0) return 0;
     if (force == 112) return 1;
     const long long mt = cout / C1_TM, t128 = mt * ((hw + 127) / 128), t112 = mt * ((hw + C2_TN - 1) / C2_TN);

@@ -221,7 +221,13 @@ class NetNodes:
             depth = (self.g_depth or self._depth_fn)(cur_bgr)
             e1 = torch.cuda.Event(); e1.record()
         with torch.cuda.stream(ss[2]):
-            if self.g_det is not None:                                  # one graph replay, nothing synchronised: labels [cap] (0 = unused slot), counts stay on the device
+            if getattr(self, "skip_detector", False):                   # the literal "flow+depth+track+local-BA" chain of BASELINE's metric text (bench.py extra.e2e_without_detector)
+                if getattr(self, "_no_det", None) is None:
+                    z = torch.zeros((), dtype=torch.int32, device=self.dev)
+                    self._no_det = (torch.zeros((self.h, self.w), dtype=torch.int32, device=self.dev), torch.zeros((1,), dtype=torch.int64, device=self.dev), z, z.clone())
+                mask, labels, n_lab, n_det = self._no_det
+                self.last_counts = (n_lab, n_det)
+            elif self.g_det is not None:                                # one graph replay, nothing synchronised: labels [cap] (0 = unused slot), counts stay on the device
                 mask, labels, n_lab, n_det = self.g_det(cur_bgr)
                 self.last_counts = (n_lab, n_det)
             else:                                                       # dynamic head: its data-dependent tail synchronises the host while the other two networks run
