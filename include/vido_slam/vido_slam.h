@@ -119,7 +119,8 @@ public:
        (called before anything on the host reads them: FullBatchOptimization, the host-walk check). */
     std::vector<int> trkChangesSta;           /* (frame, feature, tracklet, position) quads written by UpdateTracklets since the last PartialBatchOptimization */
     int devFramesPushed = 0; bool devWindow = false; bool devWindowDisabled = false;   /* disabled: this map's sequence does not fit the ring (a frame with > 8192 static features) */
-    void SyncPointsFromDevice();
+    void SyncPointsFromDevice();              /* waits for a window solve still in flight (Tracking::Track runs it beside the next frame), then copies */
+    void SyncPointsFromDeviceNow();           /* internal: the copy alone (the solve's own thread) */
     std::vector<cv::Mat> vmCameraPose, vmCameraPose_RF, vmCameraPose_GT;
     std::vector<std::vector<cv::Mat> > vmRigidCentre, vmRigidMotion, vmRigidMotion_RF;
     std::vector<std::vector<int> > vnRMLabel, vnSMLabel; std::vector<std::vector<bool> > vbObjStat;

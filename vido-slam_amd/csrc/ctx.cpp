@@ -64,6 +64,11 @@ int vido_create(const vido_config* cfg, vido_ctx** out)
     // frame k+1 overlap the tracking of frame k) their long convolution kernels must not queue in front of them
     int prio_least = 0, prio_greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_greatest = 0;
+    if (const char* pe = getenv("VIDO_CTX_PRIO")) {             // experiments: "normal" / "least" instead of the greatest priority; "skipN": N throw-away streams first (shifts the
+        if (!strcmp(pe, "normal")) prio_greatest = 0;           // runtime's round-robin stream -> hardware-queue assignment)
+        else if (!strcmp(pe, "least")) prio_greatest = prio_least;
+        else if (!strncmp(pe, "skip", 4)) { for (int i = 0; i < atoi(pe + 4); i++) { hipStream_t t; if (hipStreamCreateWithPriority(&t, hipStreamNonBlocking, prio_greatest) != hipSuccess) break; } }
+    }
     if ((e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess ||
         (e = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_greatest)) != hipSuccess) {
         int rc = vido_set_error(nullptr, VIDO_E_HIP, "vido_create: hipStreamCreate: %s", hipGetErrorString(e));

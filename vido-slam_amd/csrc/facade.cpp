@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <future>
+#include <mutex>
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
@@ -24,6 +26,14 @@ static vido_ctx* g_ctx = nullptr;
 static int g_slot = 0;                 // device slot holding the maps of the frame under construction
 static vido_track_params g_tp;
 vido_ctx* Context() { return g_ctx; }
+// The local window (PartialBatchOptimization) has a context of its own — own stream, own resident ring, own scratch — so that the window solve of frame k can run on a helper
+// thread BESIDE the tracking of frame k + 1 (round 5; Tracking::Track): nothing the tracker reads depends on it (the reference's tracker never reads the refined map either:
+// Tracking.cc only appends to vmCameraPose, Optimizer.cc:1084-1128 rewrites it), the next window solve and every reader of the Map wait for it (finish_local_ba).
+static vido_ctx* g_ctx_ba = nullptr;
+static int g_w = 0, g_h = 0;
+struct LocalBaJob { std::future<float> fut; bool pending = false; Map* map = nullptr; };
+static LocalBaJob g_lba;
+static void finish_local_ba();
 
 std::map<std::string, std::string> ParseSettings(const std::string& path)
 {
@@ -66,15 +76,20 @@ struct CallProf {
                   for (auto& e : v) fprintf(stderr, "[call prof] %-44s %8.3f ms total %7ld calls %8.3f ms each\n", e.second.c_str(), e.first, acc[e.second].second, e.first / std::max(1L, acc[e.second].second)); }
 };
 CallProf g_prof;
+std::mutex g_prof_mu;                  // (the local-BA helper thread times its calls too)
 template <class F> inline int timed_call(F&& f, const char* what)
 {
     if (!g_prof.on) return f();
     const auto t0 = std::chrono::steady_clock::now(); const int rc = f();
-    auto& a = g_prof.acc[what]; a.first += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); a.second++;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    auto& a = g_prof.acc[what]; a.first += ms; a.second++;
     return rc;
 }
 }
 #define check(expr, what) check_rc(timed_call([&]() -> int { return (expr); }, (what)), (what))
+static void check_rc_ba(int rc, const char* what) { if (rc < 0) throw VidoFailure(rc, std::string(what) + ": " + vido_last_error(g_ctx_ba)); }
+#define check_ba(expr, what) check_rc_ba(timed_call([&]() -> int { return (expr); }, (what)), (what))
 int failure_code(const std::exception& e)
 {
     if (const VidoFailure* v = dynamic_cast<const VidoFailure*>(&e)) return v->code;
@@ -89,6 +104,22 @@ static vido_ctx* live_ctx(const char* what)
 {
     if (!g_ctx) throw std::runtime_error(std::string(what) + ": no live VIDO_SLAM::System (the facade supports one System per process; create it and grab a frame first)");
     return g_ctx;
+}
+// the local / global BA context (see g_ctx_ba above): created with the tracker's first BA call, on the tracker's device; its extractor state is the smallest the library builds
+static vido_ctx* ba_ctx(const char* what)
+{
+    live_ctx(what);
+    if (!g_ctx_ba) {
+        vido_config cfg; vido_config_default(&cfg);
+        cfg.width = g_w > 0 ? g_w : 640; cfg.height = g_h > 0 ? g_h : 480; cfg.n_levels = 1; cfg.n_features = 64; cfg.max_batch = 1;
+        if (const char* d = getenv("VIDO_DEVICE")) cfg.device = atoi(d);
+        const char* bp = getenv("VIDO_BA_CTX_PRIO");              // (experiment: the BA context's stream priority / queue slot, see ctx.cpp VIDO_CTX_PRIO)
+        if (bp) setenv("VIDO_CTX_PRIO", bp, 1);
+        const int crc = vido_create(&cfg, &g_ctx_ba);
+        if (bp) unsetenv("VIDO_CTX_PRIO");
+        if (crc != VIDO_OK) { g_ctx_ba = nullptr; throw std::runtime_error(std::string(what) + ": vido_create (BA context): " + vido_last_error(nullptr)); }
+    }
+    return g_ctx_ba;
 }
 static void toRow16(const cv::Mat& T, double* o) { for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) o[r * 4 + c] = T.at<float>(r, c); }
 static cv::Mat fromRow16(const double* o) { cv::Mat T(4, 4, CV_32F); for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T.at<float>(r, c) = (float)o[r * 4 + c]; return T; }
@@ -110,7 +141,16 @@ ORBextractor::ORBextractor(int nf, float sf, int nl, int ini, int mn) : nfeature
     mvScaleFactor.resize(nl); mvScaleFactor[0] = 1.0f;
     for (int i = 1; i < nl; i++) mvScaleFactor[i] = mvScaleFactor[i - 1] * sf;
 }
-ORBextractor::~ORBextractor() { if (ctx_) { if (g_ctx == ctx_) g_ctx = nullptr; vido_destroy(ctx_); } }
+ORBextractor::~ORBextractor()
+{
+    if (!ctx_) return;
+    if (g_ctx == ctx_) {
+        try { finish_local_ba(); } catch (...) { }              // (a window solve still in flight belongs to the System that is going away)
+        g_ctx = nullptr;
+        if (g_ctx_ba) { vido_destroy(g_ctx_ba); g_ctx_ba = nullptr; }
+    }
+    vido_destroy(ctx_);
+}
 vido_ctx* ORBextractor::context(int width, int height)
 {
     if (ctx_ && (width != w_ || height != h_)) throw std::runtime_error("ORBextractor: image size changed after the first frame");
@@ -121,7 +161,7 @@ vido_ctx* ORBextractor::context(int width, int height)
         if (const char* d = getenv("VIDO_DEVICE")) cfg.device = atoi(d);
         if (vido_create(&cfg, &ctx_) != VIDO_OK) throw std::runtime_error(std::string("vido_create: ") + vido_last_error(nullptr));
         w_ = width; h_ = height;
-        if (!g_ctx) g_ctx = ctx_;
+        if (!g_ctx) { g_ctx = ctx_; g_w = width; g_h = height; }
     }
     return ctx_;
 }
@@ -307,16 +347,17 @@ void Map::UpdateTracklets()
     grow_tracklets(vnAssoDyn, vpFeatDyn, &vnFeatLabel, TrackletDyn, &nObjID, vnTrkDyn, vnPosDyn, trkPreDyn, trkRowsDyn);
 }
 
-void Map::SyncPointsFromDevice()
+void Map::SyncPointsFromDevice() { finish_local_ba(); SyncPointsFromDeviceNow(); }
+void Map::SyncPointsFromDeviceNow()                        // (without waiting for a window solve in flight: what the solve itself calls)
 {
-    if (!devWindow || !g_ctx) return;
+    if (!devWindow || !g_ctx_ba) return;
     const int N = (int)vp3DPointSta.size();
     std::vector<float> buf;
     for (int f = std::max(0, N - 64); f < devFramesPushed && f < N; f++) {
         const int n = (int)vp3DPointSta[f].size();
         if (!n) continue;
         buf.resize(3 * (size_t)n);
-        if (vido_bawin_read_points(g_ctx, f, n, buf.data()) != VIDO_OK) continue;      // (frames that have left the ring were synchronised when they left)
+        if (vido_bawin_read_points(g_ctx_ba, f, n, buf.data()) != VIDO_OK) continue;      // (frames that have left the ring were synchronised when they left)
         for (int j = 0; j < n; j++) vp3DPointSta[f][j] = vec3(buf[3 * (size_t)j], buf[3 * (size_t)j + 1], buf[3 * (size_t)j + 2]);
     }
 }
@@ -555,15 +596,15 @@ static void commit_window_poses(Map* pMap, int start, int N, const std::vector<d
 static bool batch_optimize_resident(Map* pMap, const cv::Mat& K, int start, int N, int WINDOW_SIZE, const std::vector<double>* check_cam, int check_nobs, int check_npt)
 {
     if (pMap->devWindowDisabled) return false;                 // per Map (a process-wide latch switched the resident path off for every later System)
-    vido_ctx* c = live_ctx("PartialBatchOptimization");
+    vido_ctx* c = ba_ctx("PartialBatchOptimization");
     const int cap_f = 24, cap_n = 8192, nc = N - start;      // (the caller sends windows of <= 20 cameras here)
     const float invfx = 1.0f / K.at<float>(0, 0), invfy = 1.0f / K.at<float>(1, 1), kcx = K.at<float>(0, 2), kcy = K.at<float>(1, 2);
     const bool fresh = !pMap->devWindow;
-    if (fresh) { check(vido_bawin_create(c, cap_f, cap_n), "bawin_create"); pMap->devWindow = true; pMap->devFramesPushed = 0; }
+    if (fresh) { check_ba(vido_bawin_create(c, cap_f, cap_n), "bawin_create"); pMap->devWindow = true; pMap->devFramesPushed = 0; }
     std::vector<double> meas; std::vector<float> xyz;
     for (int f = std::max(pMap->devFramesPushed, N - (cap_f - 1)); f < N; f++) {
         const int n = (int)pMap->vpFeatSta[f].size(), fo = f - cap_f;
-        if (n > cap_n || (f > 0 && (int)pMap->vnAssoSta[f - 1].size() != n)) { pMap->devWindowDisabled = true; pMap->SyncPointsFromDevice(); pMap->devWindow = false; return false; }
+        if (n > cap_n || (f > 0 && (int)pMap->vnAssoSta[f - 1].size() != n)) { pMap->devWindowDisabled = true; pMap->SyncPointsFromDeviceNow(); pMap->devWindow = false; return false; }
         if (fo >= 0 && !pMap->vp3DPointSta[fo].empty()) {      // the frame this one replaces in the ring: its points go home first
             std::vector<float> buf(3 * pMap->vp3DPointSta[fo].size());
             if (vido_bawin_read_points(c, fo, (int)pMap->vp3DPointSta[fo].size(), buf.data()) == VIDO_OK)
@@ -575,7 +616,7 @@ static bool batch_optimize_resident(Map* pMap, const cv::Mat& K, int start, int 
             meas[3 * (size_t)j] = (kp.pt.x - kcx) * z * invfx; meas[3 * (size_t)j + 1] = (kp.pt.y - kcy) * z * invfy; meas[3 * (size_t)j + 2] = z;
             const cv::Mat& Xw = pMap->vp3DPointSta[f][j]; for (int a = 0; a < 3; a++) xyz[3 * (size_t)j + a] = Xw.at<float>(a);
         }
-        check(vido_bawin_push_frame(c, f, n, meas.data(), xyz.data(), f > 0 ? pMap->vnAssoSta[f - 1].data() : nullptr), "bawin_push_frame");
+        check_ba(vido_bawin_push_frame(c, f, n, meas.data(), xyz.data(), f > 0 ? pMap->vnAssoSta[f - 1].data() : nullptr), "bawin_push_frame");
     }
     pMap->devFramesPushed = N;
     if (fresh) {                                               // a ring that starts late takes the labels of its frames from the Map's tables, not from the change list
@@ -583,7 +624,7 @@ static bool batch_optimize_resident(Map* pMap, const cv::Mat& K, int start, int 
         for (int f = std::max(0, N - (cap_f - 1)); f < N; f++) for (size_t j = 0; j < pMap->vnTrkSta[f].size(); j++) if (pMap->vnTrkSta[f][j] != -1) {
             pMap->trkChangesSta.push_back(f); pMap->trkChangesSta.push_back((int)j); pMap->trkChangesSta.push_back(pMap->vnTrkSta[f][j]); pMap->trkChangesSta.push_back(pMap->vnPosSta[f][j]); }
     }
-    if (!pMap->trkChangesSta.empty()) { check(vido_bawin_set_labels(c, (int)(pMap->trkChangesSta.size() / 4), pMap->trkChangesSta.data()), "bawin_set_labels"); pMap->trkChangesSta.clear(); }
+    if (!pMap->trkChangesSta.empty()) { check_ba(vido_bawin_set_labels(c, (int)(pMap->trkChangesSta.size() / 4), pMap->trkChangesSta.data()), "bawin_set_labels"); pMap->trkChangesSta.clear(); }
     std::vector<double> cam((size_t)nc * 12), odo; std::vector<int32_t> oi, oj;
     for (int i = start; i < N; i++) for (int r = 0; r < 3; r++) for (int cc = 0; cc < 4; cc++) cam[(size_t)(i - start) * 12 + r * 4 + cc] = pMap->vmCameraPose[i].at<float>(r, cc);
     for (int i = start + 1; i < N; i++) {
@@ -598,7 +639,7 @@ static bool batch_optimize_resident(Map* pMap, const cv::Mat& K, int start, int 
     b.prior_cam = (N == WINDOW_SIZE) ? 0 : -1; b.info_prior = 1.0 / 0.0000001; b.info_obs = 1.0 / (double)16.f; b.max_iters = 100; b.gain_threshold = 1e-3;      // Optimizer.cc:183,191-196,226-235
     for (int k = 0; k < 12; k++) b.prior_T[k] = cam[k];
     vido_ba_result r; int32_t no = 0, np = 0;
-    check(vido_bawin_solve(c, start, N, &b, &r, &no, &np), "PartialBatchOptimization (resident window)");
+    check_ba(vido_bawin_solve(c, start, N, &b, &r, &no, &np), "PartialBatchOptimization (resident window)");
     if (getenv("VIDO_BA_VERBOSE"))
         fprintf(stderr, "[batch partial, resident] cams %d pts %d obs %d | iters %d trials %d chi2 %.6g -> %.6g | setup %.2f ms loop %.2f ms\n", nc, np, no, r.iterations, r.lm_trials, r.chi2_initial, r.chi2_final, r.ms_setup, r.ms_solve_loop);
     if (check_cam) {                                           // VIDO_BA_RESIDENT_CHECK: the Map walk solved the same window on the host-assembled arrays
@@ -624,7 +665,7 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
     static const bool host_walk = getenv("VIDO_BA_HOST_WALK") != nullptr, check_walk = getenv("VIDO_BA_RESIDENT_CHECK") != nullptr;
     const bool resident = !global && !host_walk && 6 * nc <= 120;
     if (resident && !check_walk && batch_optimize_resident(pMap, K, start, N, WINDOW_SIZE, nullptr, 0, 0)) return;
-    pMap->SyncPointsFromDevice();                             // the walk below reads vp3DPointSta
+    pMap->SyncPointsFromDeviceNow();                          // the walk below reads vp3DPointSta
     if (!(resident && check_walk)) { pMap->devWindow = false; std::vector<int>().swap(pMap->trkChangesSta); }      // nobody consumes the change list on this path (a later resident window starts from the Map's tables): it must not grow with the sequence   // ... and writes it: the ring's copy is stale from here on (a later resident window starts afresh)
     const auto& Tr = pMap->TrackletSta; const auto& lab = pMap->vnTrkSta;
     std::vector<std::vector<int> > mak(N);                     // only the window's frames are touched
@@ -717,8 +758,8 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
     d.huber_dyn = d.huber_tern = d.huber_smooth = (double)0.01f;                                                              // :1358
     const char* dump_dir = global ? getenv("VIDO_DUMP_G2O") : nullptr;
     if (dump_dir) dump_g2o(std::string(dump_dir) + "/dynamic_slam_graph_before_opt.g2o", b, d, ptOwner, Hfr);
-    if (global && (d.n_H || d.n_dyn)) check(vido_ba_optimize_dynamic(live_ctx("FullBatchOptimization"), &b, &d, &r, nullptr, nullptr), "FullBatchOptimization");
-    else check(vido_ba_optimize(live_ctx("BatchOptimization"), &b, &r, nullptr, nullptr), global ? "FullBatchOptimization" : "PartialBatchOptimization");
+    if (global && (d.n_H || d.n_dyn)) check_ba(vido_ba_optimize_dynamic(ba_ctx("FullBatchOptimization"), &b, &d, &r, nullptr, nullptr), "FullBatchOptimization");
+    else check_ba(vido_ba_optimize(ba_ctx("BatchOptimization"), &b, &r, nullptr, nullptr), global ? "FullBatchOptimization" : "PartialBatchOptimization");
     if (getenv("VIDO_BA_VERBOSE"))
         fprintf(stderr, "[batch %s] cams %d pts %d obs %d | H %d dyn %d tern %d smooth %d | iters %d trials %d chi2 %.6g -> %.6g | setup %.2f ms loop %.2f ms\n", global ? "full" : "partial",
                 b.n_cam, b.n_pt, b.n_obs, d.n_H, d.n_dyn, d.n_tern, d.n_smooth, r.iterations, r.lm_trials, r.chi2_initial, r.chi2_final, r.ms_setup, r.ms_solve_loop);
@@ -744,8 +785,37 @@ static void batch_optimize(Map* pMap, const cv::Mat K, int WINDOW_SIZE, bool glo
             pMap->vp3DPointDyn[i][j] = vec3((float)dxyz[3 * (size_t)makD[i][j]], (float)dxyz[3 * (size_t)makD[i][j] + 1], (float)dxyz[3 * (size_t)makD[i][j] + 2]);
     }
 }
-void Optimizer::PartialBatchOptimization(Map* pMap, const cv::Mat K, const int W) { batch_optimize(pMap, K, W, false); }
-void Optimizer::FullBatchOptimization(Map* pMap, const cv::Mat K) { batch_optimize(pMap, K, (int)pMap->vpFeatSta.size(), true); }
+void Optimizer::PartialBatchOptimization(Map* pMap, const cv::Mat K, const int W) { finish_local_ba(); batch_optimize(pMap, K, W, false); }
+void Optimizer::FullBatchOptimization(Map* pMap, const cv::Mat K) { finish_local_ba(); batch_optimize(pMap, K, (int)pMap->vpFeatSta.size(), true); }
+
+// The window solve of Tracking::Track, beside the next frame (round 5).  The reference calls PartialBatchOptimization at the end of Track() and waits (Tracking.cc:1430-1451);
+// nothing the tracker does with the NEXT frame before it appends that frame to the Map reads what the solve writes (refined vmCameraPose / vmRigidMotion[.][0] / landmarks), so
+// the solve runs on a helper thread with the BA context's own stream and is joined (a) before the Map grows again, (b) before the next solve, (c) before any reader of the Map
+// (FullBatchOptimization, SaveResults, SyncPointsFromDevice, the System's destructor).  Same results, in the same order; 2.3 ms of a 5.7 ms tracker frame leave the tracker's
+// critical path.  VIDO_LBA_SYNC=1 (and the two host-walk check modes, whose solves share the Map walk) keep the reference's order.
+namespace detail {
+static void finish_local_ba()
+{
+    if (!g_lba.pending) return;
+    g_lba.pending = false;
+    const float ms = g_lba.fut.get();                          // (rethrows what the solve threw)
+    if (g_lba.map) g_lba.map->fLBA_time.push_back(ms);
+}
+static void start_local_ba(Map* pMap, const cv::Mat& K, int window)
+{
+    static const bool sync_mode = getenv("VIDO_LBA_SYNC") != nullptr || getenv("VIDO_BA_HOST_WALK") != nullptr || getenv("VIDO_BA_RESIDENT_CHECK") != nullptr;
+    finish_local_ba();
+    auto job = [pMap, K, window]() -> float {
+        const auto t0 = std::chrono::steady_clock::now();
+        batch_optimize(pMap, K, window, false);
+        return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    if (sync_mode) { pMap->fLBA_time.push_back(job()); return; }
+    ba_ctx("PartialBatchOptimization");                         // (created on the tracker's thread, before the helper needs it)
+    g_lba.map = pMap; g_lba.pending = true;
+    g_lba.fut = std::async(std::launch::async, job);
+}
+}  // namespace detail
 
 // ---- Tracking ----------------------------------------------------------------------------------------------------------------
 Tracking::Tracking(System* pSys, Map* pMap, const std::string& path, const int sensor)        // Tracking.cc:39-172
@@ -1162,6 +1232,7 @@ void Tracking::Track()                                        // Tracking.cc:108
         t0 = std::chrono::steady_clock::now();
         RenewFrameInfo(TemperalMatch_subset);
         all_timing[4] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        finish_local_ba();                                 // the previous frame's window solve: everything below appends to the Map it read
         mpMap->vfAll_time.push_back(all_timing);
         C->mpPrevFrame = L; L->mpNextFrame = C;
         mpLastFrame = C; mpLastFrame->mvStatKeys = C->mvStatKeysTmp; mpLastFrame->mvStatDepth = C->mvStatDepthTmp; mpLastFrame->N_s = C->N_s_tmp;
@@ -1177,16 +1248,14 @@ void Tracking::Track()                                        // Tracking.cc:108
         mpMap->AddFrame(C);
         // local batch optimisation every frame (:1430-1451)
         const int window = f_id < nWINDOW_SIZE ? f_id : nWINDOW_SIZE;
-        t0 = std::chrono::steady_clock::now();
-        Optimizer::PartialBatchOptimization(mpMap, mK, window);
-        mpMap->fLBA_time.push_back(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        start_local_ba(mpMap, mK, window);                 // (fLBA_time gets this solve's duration when it is joined)
     }
     if (f_id == StopFrame && mTestData == KITTI) { Optimizer::FullBatchOptimization(mpMap, mK); f_id = 0; }   // :1489-1498
     mState = OK;
 }
 
 // ---- System ------------------------------------------------------------------------------------------------------------------------
-System::~System() { delete mpTracker; delete mpMap; }
+System::~System() { try { finish_local_ba(); } catch (...) { } delete mpTracker; delete mpMap; }
 void System::Init(const std::string& strSettingsFile, const eSensor sensor)    // System.cc:23-48
 {
     mSensor = sensor;
@@ -1212,6 +1281,7 @@ cv::Mat System::TrackRGBDDevice(const void* im_dev, int channels, int width, int
 }
 void System::SaveResultsIJRR2020(const std::string& prefix)   // System.cc:80-240 (pose / motion files; GT files are not produced)
 {
+    finish_local_ba();
     auto dump = [](const std::string& path, const std::vector<cv::Mat>& poses) {
         FILE* f = fopen(path.c_str(), "w"); if (!f) return;
         for (size_t i = 0; i < poses.size(); i++) { fprintf(f, "%zu", i); for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) fprintf(f, " %.9f", poses[i].at<float>(r, c)); fprintf(f, "\n"); }
