@@ -142,9 +142,9 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
             const int2 xt = xtab[x];
             const int sx = xt.x & 0xffff, a0 = xt.x >> 16, a1 = xt.y;
             const int sx1 = sx + 1 < sw ? sx + 1 : sx;
-            const int r0 = L0[sx] * a0 + L0[sx1] * a1;
-            const int r1 = L1[sx] * a0 + L1[sx1] * a1;
-            int v = (((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2;
+            const int r0 = (int)(__umul24(L0[sx], (unsigned)a0) + __umul24(L0[sx1], (unsigned)a1));      // (24-bit multiplies: full rate; `*` became the quarter-rate v_mul_lo_u32)
+            const int r1 = (int)(__umul24(L1[sx], (unsigned)a0) + __umul24(L1[sx1], (unsigned)a1));
+            int v = (int)(((__umul24((unsigned)yt.z, (unsigned)(r0 >> 4)) >> 16) + (__umul24((unsigned)yt.w, (unsigned)(r1 >> 4)) >> 16) + 2u) >> 2);
             v = v < 0 ? 0 : (v > 255 ? 255 : v);
             out |= (uint32_t)v << (8 * k);
         }
@@ -192,9 +192,9 @@ __global__ __launch_bounds__(256) void k_pyramid_bands(uint8_t* __restrict__ pyr
                     const int2 xv = xt[x];
                     const int sx = xv.x & 0xffff, a0 = xv.x >> 16, a1 = xv.y;
                     const int sx1 = sx + 1 < sw ? sx + 1 : sx;
-                    const int r0 = L0[sx] * a0 + L0[sx1] * a1;
-                    const int r1 = L1[sx] * a0 + L1[sx1] * a1;
-                    int v = (((ytv.z * (r0 >> 4)) >> 16) + ((ytv.w * (r1 >> 4)) >> 16) + 2) >> 2;
+                    const int r0 = (int)(__umul24(L0[sx], (unsigned)a0) + __umul24(L0[sx1], (unsigned)a1));
+                    const int r1 = (int)(__umul24(L1[sx], (unsigned)a0) + __umul24(L1[sx1], (unsigned)a1));
+                    int v = (int)(((__umul24((unsigned)ytv.z, (unsigned)(r0 >> 4)) >> 16) + (__umul24((unsigned)ytv.w, (unsigned)(r1 >> 4)) >> 16) + 2u) >> 2);
                     v = v < 0 ? 0 : (v > 255 ? 255 : v);
                     out |= (uint32_t)v << (8 * k);
                 }
@@ -269,16 +269,19 @@ __global__ __launch_bounds__(256) void k_pyramid_tiles(uint8_t* __restrict__ pyr
         for (int i = tid; i < n; i += 256) {
             const int rr = (int)__umulhi((unsigned)i, magic), q = i - rr * nq;
             const int4 yt = ys[rr];
-            const uint8_t* L0 = S0 + yt.x * snw; const uint8_t* L1 = S0 + yt.y * snw;
+            // every product below has factors < 2^24 and fits 32 bits (pixels <= 255, weights <= 2048, r >> 4 <= 32 655): v_mul_u32_u24 / v_mad_u32_u24 at full rate —
+            // plain `*` on values the compiler cannot bound became v_mul_lo_u32, a quarter-rate instruction, 18 times per item (half the kernel's issue time)
+            const uint8_t* L0 = S0 + __umul24((unsigned)yt.x, (unsigned)snw); const uint8_t* L1 = S0 + __umul24((unsigned)yt.y, (unsigned)snw);
+            const unsigned b0 = (unsigned)yt.z, b1 = (unsigned)yt.w;
             uint32_t out = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int2 xv = xs[4 * q + k];
-                const int sx = xv.x & 0xffff, a0 = xv.x >> 16, a1 = xv.y;
-                const int r0 = L0[sx] * a0 + L0[sx + 1] * a1;
-                const int r1 = L1[sx] * a0 + L1[sx + 1] * a1;
-                const int v = (((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2;      // <= 255: the weights sum to <= 2049 per axis (no clamp needed)
-                out |= (uint32_t)v << (8 * k);
+                const unsigned sx = (unsigned)xv.x & 0xffffu, a0 = (unsigned)xv.x >> 16, a1 = (unsigned)xv.y;
+                const unsigned r0 = __umul24(L0[sx], a0) + __umul24(L0[sx + 1], a1);
+                const unsigned r1 = __umul24(L1[sx], a0) + __umul24(L1[sx + 1], a1);
+                const unsigned v = ((__umul24(b0, r0 >> 4) >> 16) + (__umul24(b1, r1 >> 4) >> 16) + 2u) >> 2;      // <= 255: the weights sum to <= 2049 per axis (no clamp needed)
+                out |= v << (8 * k);
             }
             if (keep) *(uint32_t*)(D + rr * nw + 4 * q) = out;
             const int y = ny0 + rr, x4 = nx0 + 4 * q;
@@ -467,9 +470,9 @@ template <int IW> __global__ __launch_bounds__(64) void k_fast_strips(const uint
             for (int r0 = 0; r0 < S.sh; r0 += 5 * RPI) {
                 uint32_t v[5];
 #pragma unroll
-                for (int k = 0; k < 5; k++) { const int row = min(r0 + RPI * k + rp, S.sh - 1); v[k] = *(const uint32_t*)(src + (size_t)(uint32_t)(row * pitch)); }
+                for (int k = 0; k < 5; k++) { const int row = min(r0 + RPI * k + rp, S.sh - 1); v[k] = *(const uint32_t*)(src + (size_t)__umul24((unsigned)row, (unsigned)pitch)); }      // (24-bit multiplies: full rate)
 #pragma unroll
-                for (int k = 0; k < 5; k++) { const int row = min(r0 + RPI * k + rp, S.sh - 1); *(uint32_t*)(dst + row * FS_PITCH) = v[k]; }
+                for (int k = 0; k < 5; k++) { const int row = min(r0 + RPI * k + rp, S.sh - 1); *(uint32_t*)(dst + __umul24((unsigned)row, (unsigned)FS_PITCH)) = v[k]; }
             }
         }
     }
@@ -741,7 +744,9 @@ struct QtNode { short x0, y0, x1, y1; int cnt; int cid; };
 // written by the thread that owns i in every pass, so nothing crosses threads through HBM — and __syncthreads() would also wait for those
 // stores to retire (~1.5 us each time, ~100 barriers per task).
 __device__ __forceinline__ void qt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#define QT_NT 256          // threads of a quadtree workgroup (the passes are short dependent loops over <= ~5000 candidates / ~2000 nodes)
+#ifndef QT_NT
+#define QT_NT 512             // (round 5: 128 / 256 / 512 / 1024 threads -> 149 / 111 / 94 / 127 us per 64 frames)
+#endif                     // threads of a quadtree workgroup (the passes are short dependent loops over <= ~5000 candidates / ~2000 nodes)
 __device__ int qt_block_scan(int* a, int n, int* wsum)          // exclusive scan in place (LDS), returns the total; QT_NT threads
 {
     const int t = threadIdx.x, per = (n + QT_NT - 1) / QT_NT, b = t * per;
@@ -1216,9 +1221,9 @@ __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict_
     for (int it = 0; it < 5; it++) {
         const int q = lane + 64 * it;
         if (q < 31 * 9) {
-            const int vy = q / 9, d = q - vy * 9, v = vy - 15;
+            const int vy = (int)(__umul24((unsigned)q, 7282u) >> 16), d = q - vy * 9, v = vy - 15;      // q / 9 for q < 320 (7282 / 65536 = 1 / 9 + 3.4e-6)
             const int um = (int)((umax_packed >> (4 * abs(v))) & 15ull);
-            const uint32_t w = *(const uint32_t*)(rows + v * pitch + 4 * d);
+            const uint32_t w = *(const uint32_t*)(rows + __mul24(v, pitch) + 4 * d);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int u = u0 + 4 * d + k;
@@ -1237,14 +1242,29 @@ __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict_
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ar = ang * factorPI;
     float a, b; sincos_0_2pi((double)ar, &b, &a);             // a = (float)cos((double)ar), b = (float)sin((double)ar)
-    const uint8_t* cb = blur + (size_t)f * slab + P.off[level] + (size_t)y * pitch + x;
+    // The 512 rotated sample points of a keypoint lie within 18 px of it (the pattern's largest radius is 18.38): the wave stages that 37-row window of the BLURRED level
+    // in its own LDS slice with aligned dword loads (370 dwords, six per lane: ~40 contiguous bytes per row) and gathers the test pairs from there.  Eight scattered
+    // global byte loads per lane — 64 different cache lines per instruction — were what bounded this kernel (round 5).
+    constexpr int OB_R = 18, OB_DW = 10, OB_LD = 11;                        // window radius, dwords per staged row, LDS row stride in dwords (odd)
+    __shared__ uint32_t ob_lds[4][(2 * OB_R + 1) * OB_LD];
+    uint32_t* win = ob_lds[threadIdx.x >> 6];
+    const unsigned bx_al = (unsigned)(x - OB_R) & ~3u;                      // x >= 19 (EDGE_THRESHOLD): never negative
+    const uint8_t* brow = blur + (size_t)f * slab + P.off[level] + (size_t)(y - OB_R) * pitch + bx_al;
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+        const int q = lane + 64 * it;
+        if (q < (2 * OB_R + 1) * OB_DW) { const int r = (int)(__umul24((unsigned)q, 6554u) >> 16), d = q - r * OB_DW;      // q / 10 for q < 370
+                                              win[r * OB_LD + d] = *(const uint32_t*)(brow + __umul24((unsigned)r, (unsigned)pitch) + 4 * d); }
+    }
+    __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();          // (a wave's slice is its own: no workgroup barrier)
+    const uint8_t* cb = (const uint8_t*)win + OB_R * (OB_LD * 4) + (x - (int)bx_al);      // the keypoint inside the window
     uint32_t nib = 0;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const signed char* pt = c_pattern + (lane * 4 + t) * 4;
         const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
-        const int t0 = cb[__float2int_rn(x0 * b + y0 * a) * pitch + __float2int_rn(x0 * a - y0 * b)];
-        const int t1 = cb[__float2int_rn(x1 * b + y1 * a) * pitch + __float2int_rn(x1 * a - y1 * b)];
+        const int t0 = cb[__mul24(__float2int_rn(x0 * b + y0 * a), OB_LD * 4) + __float2int_rn(x0 * a - y0 * b)];
+        const int t1 = cb[__mul24(__float2int_rn(x1 * b + y1 * a), OB_LD * 4) + __float2int_rn(x1 * a - y1 * b)];
         nib |= (uint32_t)(t0 < t1) << t;
     }
     // lanes 2i / 2i+1 hold the low / high nibble of descriptor byte i; fold 8 lanes into one dword
