@@ -121,6 +121,18 @@ public:
         for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) memcpy(m.data + (size_t)c * m.step + (size_t)r * esz(type_), data + (size_t)r * step + (size_t)c * esz(type_), esz(type_));
         return m;
     }
+    /* Build extension (not an OpenCV call): n 3 x 1 CV_32F matrices — the per-point world coordinates of Frame / Map (vp3DPointSta ...) — as views into ONE reference-counted
+     * block instead of n allocations; every element behaves like a Mat(3, 1, CV_32F) of its own (the block goes when the last view goes). */
+    static void batch3x1(const float* xyz, int n, std::vector<Mat>& out)
+    {
+        out.clear(); if (n <= 0) return;
+        void* blk = malloc(kHdr + (size_t)n * 12 + 16);
+        if (!blk) throw std::bad_alloc();
+        std::atomic<int>* rc = new (blk) std::atomic<int>(n);
+        memcpy((uchar*)blk + kHdr, xyz, (size_t)n * 12);
+        out.resize((size_t)n);
+        for (int i = 0; i < n; i++) { Mat& m = out[(size_t)i]; m.rows = 3; m.cols = 1; m.step = 4; m.type_ = CV_32F; m.buf_ = rc; m.data = (uchar*)blk + kHdr + (size_t)i * 12; }
+    }
     static size_t esz(int type) { static const size_t d[8] = {1, 1, 2, 2, 4, 4, 8, 2}; return d[type & 7] * ((type >> CV_CN_SHIFT) + 1); }
     static int depth_of(int type) { return type & 7; }
 private:

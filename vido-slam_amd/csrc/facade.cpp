@@ -87,6 +87,12 @@ template <class F> inline int timed_call(F&& f, const char* what)
     return rc;
 }
 }
+struct ProfSection {                  // VIDO_CALL_PROF=1: a named host-side section of the facade in the same table as the C-ABI calls
+    const char* name; std::chrono::steady_clock::time_point t0;
+    explicit ProfSection(const char* n) : name(n) { if (g_prof.on) t0 = std::chrono::steady_clock::now(); }
+    ~ProfSection() { if (!g_prof.on) return; const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                     std::lock_guard<std::mutex> g(g_prof_mu); auto& a = g_prof.acc[name]; a.first += ms; a.second++; }
+};
 #define check(expr, what) check_rc(timed_call([&]() -> int { return (expr); }, (what)), (what))
 static void check_rc_ba(int rc, const char* what) { if (rc < 0) throw VidoFailure(rc, std::string(what) + ": " + vido_last_error(g_ctx_ba)); }
 #define check_ba(expr, what) check_rc_ba(timed_call([&]() -> int { return (expr); }, (what)), (what))
@@ -363,12 +369,16 @@ void Map::SyncPointsFromDeviceNow()                        // (without waiting f
 }
 
 // ---- Optimizer ---------------------------------------------------------------------------------------------------------
-cv::Mat Optimizer::Get3DinWorld(const cv::KeyPoint& f, const float& d, const cv::Mat& K, const cv::Mat& Twc)
+static inline void get3d_world(const cv::KeyPoint& f, float d, const cv::Mat& K, const cv::Mat& Twc, float o[3])
 {
     const float invfx = 1.0f / K.at<float>(0, 0), invfy = 1.0f / K.at<float>(1, 1), cx = K.at<float>(0, 2), cy = K.at<float>(1, 2);
     const float z = d, x = (f.pt.x - cx) * z * invfx, y = (f.pt.y - cy) * z * invfy;
+    for (int r = 0; r < 3; r++) { const double s = (double)Twc.at<float>(r, 0) * x + (double)Twc.at<float>(r, 1) * y + (double)Twc.at<float>(r, 2) * z; o[r] = (float)s + Twc.at<float>(r, 3); }
+}
+cv::Mat Optimizer::Get3DinWorld(const cv::KeyPoint& f, const float& d, const cv::Mat& K, const cv::Mat& Twc)
+{
     cv::Mat out(3, 1, CV_32F);
-    for (int r = 0; r < 3; r++) { const double s = (double)Twc.at<float>(r, 0) * x + (double)Twc.at<float>(r, 1) * y + (double)Twc.at<float>(r, 2) * z; out.at<float>(r) = (float)s + Twc.at<float>(r, 3); }
+    get3d_world(f, d, K, Twc, out.ptr<float>());
     return out;
 }
 cv::Mat Optimizer::Get3DinCamera(const cv::KeyPoint& f, const float& d, const cv::Mat& K)
@@ -1139,8 +1149,10 @@ void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:29
                              os = {smsk.data() + ns + nk, sdep.data() + ns + nk, sflo.data() + 2 * (size_t)(ns + nk)};
     const int cap = (int)TM_sta.size() + nk + 8;
     std::vector<int32_t> src(cap), inl(cap); std::vector<float> fl(2 * (size_t)cap); int32_t n = 0;
+    { ProfSection ps_("renew: vido_renew_static_sampled (host)");
     if (vido_renew_static_sampled(W, H, sxy.data(), ns, &ss, TM_sta.data(), (int)TM_sta.size(), kxy.data(), nk, &ks, nMaxTrackPointBG, src.data(), inl.data(), fl.data(), cap, &n) != VIDO_OK)
-        throw std::runtime_error("RenewFrameInfo: vido_renew_static failed");
+        throw std::runtime_error("RenewFrameInfo: vido_renew_static failed"); }
+    ProfSection* ps_a = new ProfSection("renew: static lists + 3-D points (host)");
     std::vector<cv::KeyPoint> keys(n), corres(n); std::vector<cv::Point2f> flows(n); std::vector<int> inlierID(n);
     for (int k = 0; k < n; k++) {
         keys[k] = inl[k] >= 0 ? C->mvStatKeys[src[k]] : sample_src[src[k]];
@@ -1148,10 +1160,12 @@ void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:29
         corres[k] = cv::KeyPoint(keys[k].pt.x + fl[2 * k], keys[k].pt.y + fl[2 * k + 1], 0, 0, 0, -1);
     }
     C->N_s_tmp = n;
-    std::vector<float> depth(n, -1.f); std::vector<cv::Mat> p3d(n);
+    std::vector<float> depth(n, -1.f); std::vector<cv::Mat> p3d; std::vector<float> xyz3(3 * (size_t)std::max(n, 1));
     const cv::Mat Twc = Converter::toInvMatrix(C->mTcw);
-    for (int i = 0; i < n; i++) { const float d = inl[i] >= 0 ? ss.depth[src[i]] : ks.depth[src[i]]; if (d > 0) depth[i] = d; p3d[i] = Optimizer::Get3DinWorld(keys[i], depth[i], mK, Twc); }      // mDepthMap.at(key)
-    C->nStaInlierID = inlierID; C->mvStatKeysTmp = keys; C->mvStatDepthTmp = depth; C->mvStat3DPointTmp = p3d; C->mvFlowNext = flows; C->mvCorres = corres;
+    for (int i = 0; i < n; i++) { const float d = inl[i] >= 0 ? ss.depth[src[i]] : ks.depth[src[i]]; if (d > 0) depth[i] = d; get3d_world(keys[i], depth[i], mK, Twc, &xyz3[3 * (size_t)i]); }      // mDepthMap.at(key); Get3DinWorld per point
+    cv::Mat::batch3x1(xyz3.data(), n, p3d);                                       // (one block for the frame's points instead of n allocations)
+    C->nStaInlierID = std::move(inlierID); C->mvStatKeysTmp = std::move(keys); C->mvStatDepthTmp = std::move(depth); C->mvStat3DPointTmp = std::move(p3d); C->mvFlowNext = std::move(flows); C->mvCorres = std::move(corres);
+    delete ps_a;
 
     // ---- objects (:3116-3289)
     const int no = (int)C->mvObjKeys.size(), nobj = (int)C->vnObjInlierID.size(), nt = (int)mvTmpSemObjLabel.size();
@@ -1163,18 +1177,25 @@ void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:29
     for (int i = 0; i < nobj; i++) { ioff[i + 1] = ioff[i] + (int)C->vnObjInlierID[i].size(); iids.insert(iids.end(), C->vnObjInlierID[i].begin(), C->vnObjInlierID[i].end()); ostat[i] = C->bObjStat[i] ? 1 : 0; }
     if (iids.empty()) iids.push_back(0);
     const int ocap = (int)iids.size() + (nobj + 1) * nt + 8;
-    std::vector<float> okx(2 * (size_t)ocap), odep(ocap), ofl(2 * (size_t)ocap), oco(2 * (size_t)ocap); std::vector<int32_t> osem(ocap), oinl(ocap), olab(ocap); int32_t on = 0;
+    // output scratch sized for the worst case (every dense sample kept for every object: ~0.5 MB per array) — kept across frames: as fresh vectors each was an mmap + page
+    // faults + a fill per frame (glibc serves blocks > 128 KB from mmap), 0.2 ms of this function (round 5)
+    static thread_local std::vector<float> okx, odep, ofl, oco; static thread_local std::vector<int32_t> osem, oinl, olab; int32_t on = 0;
+    if ((int)odep.size() < ocap) { okx.resize(2 * (size_t)ocap); odep.resize(ocap); ofl.resize(2 * (size_t)ocap); oco.resize(2 * (size_t)ocap); osem.resize(ocap); oinl.resize(ocap); olab.resize(ocap); }
+    ProfSection* ps_b = new ProfSection("renew: vido_renew_objects_sampled (host)");
     if (vido_renew_objects_sampled(W, H, oxy.data(), C->vObjLabel.data(), no, &os, nobj, ioff.data(), iids.data(), ostat.data(), C->nSemPosition.data(), C->nModLabel.data(),
                            txy.data(), mvTmpObjDepth.data(), mvTmpSemObjLabel.data(), tfl.data(), tco.data(), nt, nMaxTrackPointOBJ,
                            okx.data(), odep.data(), osem.data(), ofl.data(), oco.data(), oinl.data(), olab.data(), ocap, &on) != VIDO_OK)
         throw std::runtime_error("RenewFrameInfo: vido_renew_objects failed");
+    delete ps_b;
+    ProfSection ps_c("renew: object lists + 3-D points (host)");
     std::vector<cv::KeyPoint> okeys(on), ocorr(on); std::vector<float> odepth(odep.begin(), odep.begin() + on); std::vector<cv::Point2f> oflow(on);
-    std::vector<cv::Mat> o3d(on);
+    std::vector<cv::Mat> o3d; std::vector<float> oxyz3(3 * (size_t)std::max(on, 1));
     for (int i = 0; i < on; i++) {
         okeys[i] = cv::KeyPoint(okx[2 * i], okx[2 * i + 1], 0, 0, 0, -1); ocorr[i] = cv::KeyPoint(oco[2 * i], oco[2 * i + 1], 0, 0, 0, -1); oflow[i] = cv::Point2f(ofl[2 * i], ofl[2 * i + 1]);
-        o3d[i] = Optimizer::Get3DinWorld(okeys[i], odepth[i], mK, Twc);
+        get3d_world(okeys[i], odepth[i], mK, Twc, &oxyz3[3 * (size_t)i]);
     }
-    C->mvObjKeys = okeys; C->mvObjDepth = odepth; C->mvObj3DPoint = o3d; C->mvObjCorres = ocorr; C->mvObjFlowNext = oflow;
+    cv::Mat::batch3x1(oxyz3.data(), on, o3d);
+    C->mvObjKeys = std::move(okeys); C->mvObjDepth = std::move(odepth); C->mvObj3DPoint = std::move(o3d); C->mvObjCorres = std::move(ocorr); C->mvObjFlowNext = std::move(oflow);
     C->vSemObjLabel.assign(osem.begin(), osem.begin() + on); C->nDynInlierID.assign(oinl.begin(), oinl.begin() + on); C->vObjLabel.assign(olab.begin(), olab.begin() + on);
 }
 

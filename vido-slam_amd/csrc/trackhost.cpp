@@ -17,10 +17,15 @@ namespace {
 // "is some point of a fixed set closer than 1 px to q" — the reference scans the whole set for every sample (Tracking.cc:3030-3040, 3198-3208: O(N*M));
 // a 1-px cell grid restricts the scan to the 3x3 neighbourhood and evaluates the same float expression, so the answer is identical.
 struct NearSet {
-    int W, H; std::vector<int> head, next; const float* xy;
-    NearSet(const float* p, int n, int w, int h) : W(w + 2), H(h + 2), head((size_t)(w + 2) * (h + 2), -1), next((size_t)std::max(n, 1), -1), xy(p) {
+    // The cell heads live in ONE per-thread array that is all -1 between uses: a set touches only the cells of its own points and puts them back in its destructor.
+    // (Round 5: as a fresh (W + 2) x (H + 2) vector per call the grid was 1.2 MB of allocation + fill at 640 x 480, twice per frame — most of RenewFrameInfo's host time.)
+    int W, H; std::vector<int>& head; std::vector<int> next; const float* xy; int n_pts;
+    static std::vector<int>& grid(size_t cells) { static thread_local std::vector<int> g; if (g.size() < cells) g.assign(cells, -1); return g; }
+    NearSet(const float* p, int n, int w, int h) : W(w + 2), H(h + 2), head(grid((size_t)(w + 2) * (h + 2))), next((size_t)std::max(n, 1), -1), xy(p), n_pts(n) {
         for (int i = 0; i < n; i++) { const int c = cell(p[2 * i], p[2 * i + 1]); next[i] = head[c]; head[c] = i; }
     }
+    ~NearSet() { for (int i = 0; i < n_pts; i++) head[cell(xy[2 * i], xy[2 * i + 1])] = -1; }
+    NearSet(const NearSet&) = delete; NearSet& operator=(const NearSet&) = delete;
     int clampx(float x) const { return std::min(std::max((int)std::floor(x) + 1, 0), W - 1); }
     int clampy(float y) const { return std::min(std::max((int)std::floor(y) + 1, 0), H - 1); }
     int cell(float x, float y) const { return clampy(y) * W + clampx(x); }
