@@ -13,6 +13,7 @@
 // slot tables, and ba.hip solves on them in place (ba_run_device_inputs).  Afterwards k_bawin_writeback stores the refined landmark into every observation slot's xyz
 // (Optimizer.cc:1130-1160).  What still crosses PCIe per solve: the window's poses and odometry factors (2 KB each way) and two counters.
 #include "common.hpp"
+#include <chrono>
 #include <vector>
 #include <cstring>
 
@@ -231,8 +232,13 @@ int vido_bawin_push_frame(vido_ctx* ctx, int frame, int n, const double* meas, c
     int* ha = (int*)(h + (size_t)n * 36);
     for (int i = 0; i < n; i++) ha[i] = asso ? asso[i] : -1;
     const size_t o = (size_t)s * B->cap_n;
+    static const bool trace = getenv("VIDO_LBA_TRACE") != nullptr;      // diagnosis: where the first operations of the window's stream wait
+    auto stamp = [&](const char* w) { if (trace) { hipStreamSynchronize(st); fprintf(stderr, "[lba trace] %12.3f   bawin: %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(), w); } };
+    stamp("before the upload");
     if (n) HIP_TRY(ctx, hipMemcpyAsync(B->d_stage, h, (size_t)n * 40, hipMemcpyHostToDevice, st));
+    stamp("upload done");
     hipLaunchKernelGGL(k_bawin_ingest, dim3((B->cap_n + 255) / 256), dim3(256), 0, st, (const char*)B->d_stage, n, B->cap_n, o, B->d_meas, B->d_xyz, B->d_asso, B->d_trk, B->d_pos, B->d_nfeat + s);
+    stamp("ingest kernel done");
     HIP_TRY(ctx, hipGetLastError());
     B->frame_of[s] = frame; B->nfeat[s] = n;
     return VIDO_OK;

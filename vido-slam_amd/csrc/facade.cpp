@@ -94,6 +94,9 @@ struct ProfSection {                  // VIDO_CALL_PROF=1: a named host-side sec
                      std::lock_guard<std::mutex> g(g_prof_mu); auto& a = g_prof.acc[name]; a.first += ms; a.second++; }
 };
 #define check(expr, what) check_rc(timed_call([&]() -> int { return (expr); }, (what)), (what))
+static inline double lba_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static const bool g_lba_trace = getenv("VIDO_LBA_TRACE") != nullptr;      // diagnosis: host timestamps of the window solve's steps and of the tracker's frame boundaries
+#define LBA_TRACE(what) do { if (g_lba_trace) fprintf(stderr, "[lba trace] %12.3f %s\n", lba_now_ms(), (what)); } while (0)
 static void check_rc_ba(int rc, const char* what) { if (rc < 0) throw VidoFailure(rc, std::string(what) + ": " + vido_last_error(g_ctx_ba)); }
 #define check_ba(expr, what) check_rc_ba(timed_call([&]() -> int { return (expr); }, (what)), (what))
 int failure_code(const std::exception& e)
@@ -364,7 +367,7 @@ void Map::SyncPointsFromDeviceNow()                        // (without waiting f
         if (!n) continue;
         buf.resize(3 * (size_t)n);
         if (vido_bawin_read_points(g_ctx_ba, f, n, buf.data()) != VIDO_OK) continue;      // (frames that have left the ring were synchronised when they left)
-        for (int j = 0; j < n; j++) vp3DPointSta[f][j] = vec3(buf[3 * (size_t)j], buf[3 * (size_t)j + 1], buf[3 * (size_t)j + 2]);
+        cv::Mat::batch3x1(buf.data(), n, vp3DPointSta[f]);
     }
 }
 
@@ -618,7 +621,7 @@ static bool batch_optimize_resident(Map* pMap, const cv::Mat& K, int start, int 
         if (fo >= 0 && !pMap->vp3DPointSta[fo].empty()) {      // the frame this one replaces in the ring: its points go home first
             std::vector<float> buf(3 * pMap->vp3DPointSta[fo].size());
             if (vido_bawin_read_points(c, fo, (int)pMap->vp3DPointSta[fo].size(), buf.data()) == VIDO_OK)
-                for (size_t j = 0; j < pMap->vp3DPointSta[fo].size(); j++) pMap->vp3DPointSta[fo][j] = vec3(buf[3 * j], buf[3 * j + 1], buf[3 * j + 2]);
+                cv::Mat::batch3x1(buf.data(), (int)pMap->vp3DPointSta[fo].size(), pMap->vp3DPointSta[fo]);      // (one block for the row, not one allocation per point)
         }
         meas.resize(3 * (size_t)n); xyz.resize(3 * (size_t)n);
         for (int j = 0; j < n; j++) {
@@ -626,7 +629,9 @@ static bool batch_optimize_resident(Map* pMap, const cv::Mat& K, int start, int 
             meas[3 * (size_t)j] = (kp.pt.x - kcx) * z * invfx; meas[3 * (size_t)j + 1] = (kp.pt.y - kcy) * z * invfy; meas[3 * (size_t)j + 2] = z;
             const cv::Mat& Xw = pMap->vp3DPointSta[f][j]; for (int a = 0; a < 3; a++) xyz[3 * (size_t)j + a] = Xw.at<float>(a);
         }
+        LBA_TRACE("ba: push_frame begin");
         check_ba(vido_bawin_push_frame(c, f, n, meas.data(), xyz.data(), f > 0 ? pMap->vnAssoSta[f - 1].data() : nullptr), "bawin_push_frame");
+        LBA_TRACE("ba: push_frame end");
     }
     pMap->devFramesPushed = N;
     if (fresh) {                                               // a ring that starts late takes the labels of its frames from the Map's tables, not from the change list
@@ -634,6 +639,7 @@ static bool batch_optimize_resident(Map* pMap, const cv::Mat& K, int start, int 
         for (int f = std::max(0, N - (cap_f - 1)); f < N; f++) for (size_t j = 0; j < pMap->vnTrkSta[f].size(); j++) if (pMap->vnTrkSta[f][j] != -1) {
             pMap->trkChangesSta.push_back(f); pMap->trkChangesSta.push_back((int)j); pMap->trkChangesSta.push_back(pMap->vnTrkSta[f][j]); pMap->trkChangesSta.push_back(pMap->vnPosSta[f][j]); }
     }
+    LBA_TRACE("ba: set_labels begin");
     if (!pMap->trkChangesSta.empty()) { check_ba(vido_bawin_set_labels(c, (int)(pMap->trkChangesSta.size() / 4), pMap->trkChangesSta.data()), "bawin_set_labels"); pMap->trkChangesSta.clear(); }
     std::vector<double> cam((size_t)nc * 12), odo; std::vector<int32_t> oi, oj;
     for (int i = start; i < N; i++) for (int r = 0; r < 3; r++) for (int cc = 0; cc < 4; cc++) cam[(size_t)(i - start) * 12 + r * 4 + cc] = pMap->vmCameraPose[i].at<float>(r, cc);
@@ -649,7 +655,9 @@ static bool batch_optimize_resident(Map* pMap, const cv::Mat& K, int start, int 
     b.prior_cam = (N == WINDOW_SIZE) ? 0 : -1; b.info_prior = 1.0 / 0.0000001; b.info_obs = 1.0 / (double)16.f; b.max_iters = 100; b.gain_threshold = 1e-3;      // Optimizer.cc:183,191-196,226-235
     for (int k = 0; k < 12; k++) b.prior_T[k] = cam[k];
     vido_ba_result r; int32_t no = 0, np = 0;
+    LBA_TRACE("ba: solve begin");
     check_ba(vido_bawin_solve(c, start, N, &b, &r, &no, &np), "PartialBatchOptimization (resident window)");
+    LBA_TRACE("ba: solve end");
     if (getenv("VIDO_BA_VERBOSE"))
         fprintf(stderr, "[batch partial, resident] cams %d pts %d obs %d | iters %d trials %d chi2 %.6g -> %.6g | setup %.2f ms loop %.2f ms\n", nc, np, no, r.iterations, r.lm_trials, r.chi2_initial, r.chi2_final, r.ms_setup, r.ms_solve_loop);
     if (check_cam) {                                           // VIDO_BA_RESIDENT_CHECK: the Map walk solved the same window on the host-assembled arrays
@@ -808,7 +816,9 @@ static void finish_local_ba()
 {
     if (!g_lba.pending) return;
     g_lba.pending = false;
-    const float ms = g_lba.fut.get();                          // (rethrows what the solve threw)
+    LBA_TRACE("tracker: join begin");
+    const float ms = g_lba.fut.get();
+    LBA_TRACE("tracker: join end");                          // (rethrows what the solve threw)
     if (g_lba.map) g_lba.map->fLBA_time.push_back(ms);
 }
 static void start_local_ba(Map* pMap, const cv::Mat& K, int window)
@@ -1201,6 +1211,7 @@ void Tracking::RenewFrameInfo(const std::vector<int>& TM_sta)  // Tracking.cc:29
 
 void Tracking::Track()                                        // Tracking.cc:1081-1509
 {
+    LBA_TRACE("tracker: Track begin");
     if (mState == NO_IMAGES_YET) mState = NOT_INITIALIZED;
     Frame* C = mpCurrentFrame;
     if (mState == NOT_INITIALIZED) { Initialization(); if (mState != OK) return; }
@@ -1269,6 +1280,7 @@ void Tracking::Track()                                        // Tracking.cc:108
         mpMap->AddFrame(C);
         // local batch optimisation every frame (:1430-1451)
         const int window = f_id < nWINDOW_SIZE ? f_id : nWINDOW_SIZE;
+        LBA_TRACE("tracker: start_local_ba");
         start_local_ba(mpMap, mK, window);                 // (fLBA_time gets this solve's duration when it is joined)
     }
     if (f_id == StopFrame && mTestData == KITTI) { Optimizer::FullBatchOptimization(mpMap, mK); f_id = 0; }   // :1489-1498
