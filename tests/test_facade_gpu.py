@@ -237,3 +237,26 @@ def test_use_sample_feature_option(tmp_path, vido):
     for k in range(1, n):
         E = P[k, 1:].reshape(4, 4) @ np.linalg.inv(scene.Tcw(k))
         assert np.linalg.norm(E[:3, 3]) < 0.05, (k, E)
+
+
+def test_window_solve_beside_the_next_frame_gives_the_same_result_files(tmp_path, vido):
+    """VIDO_LBA_ASYNC=1 (facade.cpp start_local_ba / finish_local_ba): the local window solve of frame k on a helper thread and a context of its own, joined before the Map
+    grows again.  Same clip through the offline driver in both orders: every pose the tracker returns, the refined trajectory and the object-motion files must be IDENTICAL
+    (nothing the tracker reads depends on the solve; the solves see the same Map in the same order)."""
+    sys.path.insert(0, os.path.join(ROOT, "vido-slam_amd"))
+    import build
+    driver = build.build_driver()
+    n = 30                                                                    # past WINDOW_SIZE: full 20-frame windows and ring evictions are covered
+    scene = vido.synth.Scene3D(n_frames=n, seed=5, objects=((-2.0, 0.2, 9.0, 0.25, 0.0, 0.05),))
+    cfg = write_clip(str(tmp_path), scene, n)
+    outs = {}
+    for mode in ("sync", "async"):
+        env = {k: v for k, v in os.environ.items() if k not in ("VIDO_LBA_ASYNC", "VIDO_LBA_SYNC")}
+        if mode == "async":
+            env["VIDO_LBA_ASYNC"] = "1"
+        out = os.path.join(str(tmp_path), "poses_%s.txt" % mode); pre = os.path.join(str(tmp_path), "res_%s_" % mode)
+        r = subprocess.run([driver, cfg, out, pre], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr + r.stdout
+        outs[mode] = (np.loadtxt(out), np.loadtxt(pre + "refined_rgbd_new.txt"), np.loadtxt(pre + "initial_rgbd_new.txt"))
+    for a, b in zip(outs["sync"], outs["async"]):
+        assert a.shape == b.shape and np.array_equal(a, b)

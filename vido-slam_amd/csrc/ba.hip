@@ -2612,7 +2612,7 @@ public:
     template <class F> void chunks(size_t n, F f) { const int T = n_; run([&](int t) { const size_t lo = n * t / T, hi = n * (t + 1) / T; if (hi > lo) f(lo, hi, t); }); }
 private:
     HostPool() {
-        const char* e = getenv("VIDO_BA_HOST_THREADS"); int want = e ? atoi(e) : 8;
+        const char* e = getenv("VIDO_BA_HOST_THREADS"); int want = e ? atoi(e) : 4;      // (round 5: 4 / 8 / 16 / 32 / 64 threads -> 8.7 / 9.3 / 8.8 / 9.9 / 11.2 ms per 1 M-edge call on a 16-CPU container)
         n_ = std::max(1, std::min(want, (int)std::thread::hardware_concurrency()));
         for (int t = 1; t < n_; t++) th_.emplace_back([this, t] { int seen = 0; for (;;) { const std::function<void(int)>* j;
             { std::unique_lock<std::mutex> g(m_); cv_.wait(g, [&] { return stop_ || gen_ != seen; }); if (stop_) return; seen = gen_; j = job_; }

@@ -810,7 +810,7 @@ void Optimizer::FullBatchOptimization(Map* pMap, const cv::Mat K) { finish_local
 // nothing the tracker does with the NEXT frame before it appends that frame to the Map reads what the solve writes (refined vmCameraPose / vmRigidMotion[.][0] / landmarks), so
 // the solve runs on a helper thread with the BA context's own stream and is joined (a) before the Map grows again, (b) before the next solve, (c) before any reader of the Map
 // (FullBatchOptimization, SaveResults, SyncPointsFromDevice, the System's destructor).  Same results, in the same order; 2.3 ms of a 5.7 ms tracker frame leave the tracker's
-// critical path.  VIDO_LBA_SYNC=1 (and the two host-walk check modes, whose solves share the Map walk) keep the reference's order.
+// critical path of the tracker ALONE.  Opt-in (VIDO_LBA_ASYNC=1, see start_local_ba); the two host-walk check modes always keep the reference's order.
 namespace detail {
 static void finish_local_ba()
 {
@@ -823,7 +823,10 @@ static void finish_local_ba()
 }
 static void start_local_ba(Map* pMap, const cv::Mat& K, int window)
 {
-    static const bool sync_mode = getenv("VIDO_LBA_SYNC") != nullptr || getenv("VIDO_BA_HOST_WALK") != nullptr || getenv("VIDO_BA_RESIDENT_CHECK") != nullptr;
+    // Default: the reference's order (solve, then return).  VIDO_LBA_ASYNC=1 runs the solve beside the next frame: measured 5.97 -> 4.61 ms per frame for the tracker alone
+    // (tools/prof_tracker.py), and NO gain beside the networks (174 frames/s either way for the chain without the detector): there the helper's first stream operation waits
+    // 2-5 ms for the GPU while LiteFlowNet's graph runs, the join waits for it, and the solve's reported duration triples — so it stays opt-in.
+    static const bool sync_mode = getenv("VIDO_LBA_ASYNC") == nullptr || getenv("VIDO_LBA_SYNC") != nullptr || getenv("VIDO_BA_HOST_WALK") != nullptr || getenv("VIDO_BA_RESIDENT_CHECK") != nullptr;
     finish_local_ba();
     auto job = [pMap, K, window]() -> float {
         const auto t0 = std::chrono::steady_clock::now();
