@@ -265,10 +265,10 @@ def test_pack_wino3x3_operands_reproduce_the_convolution():
     g = torch.Generator().manual_seed(11)
     Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
     At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
-    for cout, cin, H, W in ((64, 9, 6, 8), (32, 13, 5, 7), (96, 8, 4, 4), (130, 17, 3, 6)):
+    for cout, cin, H, W, form in ((64, 9, 6, 8, 0), (32, 13, 5, 7, 0), (96, 8, 4, 4, 0), (130, 17, 3, 6, 0), (64, 9, 6, 8, 1), (130, 17, 3, 6, 1)):      # form 1 (K-split launches): KC = 4 for every cout
         w = torch.randn(cout, cin, 3, 3, generator=g); x = torch.randn(1, cin, H, W, generator=g)
-        up = pack_wino3x3(w)
-        kc = 8 if (((cout + 63) // 64) * 64 - cout) < 32 else 4
+        up = pack_wino3x3(w, form)
+        kc = 8 if (((cout + 63) // 64) * 64 - cout) < 32 and form == 0 else 4
         assert up.shape[1:] == (-(-cin // kc), 16, 64, kc // 2) and up.shape[0] * 32 >= cout and up.is_contiguous()
         U = np.zeros((16, up.shape[0] * 32, up.shape[1] * kc))
         for co in range(U.shape[1]):

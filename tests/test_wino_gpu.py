@@ -26,20 +26,25 @@ SHAPES = [  # (N, cin, cout, H, W): LiteFlowNet heads at the small levels, ragge
 ]
 
 
+@pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("N,cin,cout,H,W", SHAPES)
-def test_wino3x3_equals_conv2d(vido, ctx, N, cin, cout, H, W):
+def test_wino3x3_equals_conv2d(vido, ctx, N, cin, cout, H, W, form):
+    """both launch forms on every shape: the tile form (a wave walks all input channels) and the K-split form (the four waves of a workgroup share them; what under-filled
+    launches take — vido_wino3x3_form)"""
     from vido_slam_amd.nets.ops import HipOps, pack_wino3x3
     ops = HipOps(ctx)
+    if form == 1 and N * cin * H * W > 40e6:
+        pytest.skip("the K-split form is for small launches")
     g = torch.Generator().manual_seed(cin * 13 + cout + H)
     x = torch.randn(N, cin, H, W, generator=g); w = torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (3.0 * cin ** 0.5)); b = torch.randn(cout, generator=g)
     assert ops.wino3x3_supported(cin, cout, H, W)
-    up = pack_wino3x3(w).cuda()
+    up = pack_wino3x3(w, form).cuda()
     ref0 = F.conv2d(x.double(), w.double(), None, 1, 1)
     for bias, slope in ((None, 1.0), (b, 0.1), (b, 0.0)):
-        y = ops.wino3x3_bias_act(x.cuda(), up, bias.cuda() if bias is not None else None, cout, slope).cpu()
+        y = ops.wino3x3_bias_act(x.cuda(), up, bias.cuda() if bias is not None else None, cout, slope, form).cpu()
         ref = F.leaky_relu(ref0 + (bias.double()[None, :, None, None] if bias is not None else 0.0), slope)
         err = float((y.double() - ref).abs().max())
-        assert tuple(y.shape) == (N, cout, H, W) and err < TOL * max(1.0, float(ref.abs().max())), (N, cin, cout, H, W, slope, err)
+        assert tuple(y.shape) == (N, cout, H, W) and err < TOL * max(1.0, float(ref.abs().max())), (N, cin, cout, H, W, slope, form, err)
 
 
 def test_wino3x3_refuses_what_it_has_no_form_for(vido, ctx):
@@ -50,15 +55,17 @@ def test_wino3x3_refuses_what_it_has_no_form_for(vido, ctx):
         ops.wino3x3_bias_act(torch.zeros(1, 64, 8, 8, device="cuda"), torch.zeros(16, device="cuda"), None, 2, 1.0)
     conv = torch.nn.Conv2d(64, 64, 3, 2, 1).cuda()                         # stride 2: not this kernel's; the caller keeps the library path
     assert ops.wino3x3_conv(conv, torch.zeros(1, 64, 8, 8, device="cuda"), 1.0) is None
-    small = torch.nn.Conv2d(64, 64, 3, 1, 1).cuda()                        # 16 tiles: one workgroup — left to the library unless asked for (VIDO_WINO_MIN_WGS)
-    assert ops.wino3x3_conv(small, torch.zeros(1, 64, 8, 8, device="cuda"), 1.0) is None
+    small = torch.nn.Conv2d(64, 64, 3, 1, 1).cuda()                        # 16 tiles: one workgroup of the tile form -> the K-split form
+    assert ops.wino3x3_form(1, 64, 64, 8, 8) == 1 and ops.wino3x3_form(1, 256, 256, 200, 272) == 0 and ops.wino3x3_form(1, 256, 256, 50, 68) == 1
+    with torch.no_grad():
+        xs = torch.randn(1, 64, 8, 8, device="cuda"); ys = ops.wino3x3_conv(small, xs, 1.0)
+        assert ys is not None and float((ys - small(xs)).abs().max()) < 1e-4
     assert ctx.lib.vido_wino3x3_fills_chip(1, 256, 200, 272, 0) == 1 and ctx.lib.vido_wino3x3_fills_chip(1, 256, 50, 68, 0) == 0 and ctx.lib.vido_wino3x3_fills_chip(1, 256, 50, 68, 40) == 1
 
 
 def test_wino3x3_conv_follows_a_weight_update(vido, ctx, monkeypatch):
     """wino3x3_conv caches the packed transformed weight on the module: loading other weights (load_state_dict copies in place) must rebuild it."""
     from vido_slam_amd.nets.ops import HipOps
-    monkeypatch.setattr("vido_slam_amd.nets.ops._WINO_MIN_WGS", 1)          # (small maps: by default the callers leave launches of < 128 workgroups to the library)
     ops = HipOps(ctx)
     conv = torch.nn.Conv2d(16, 32, 3, 1, 1).cuda(); x = torch.randn(1, 16, 12, 10, device="cuda")
     with torch.no_grad():

@@ -39,13 +39,15 @@ struct WnArgs { const float* x; const float* up; const float* bias; float* y; in
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-template <int CW, int TW, int KC, bool ODD>
+template <int CW, int TW, int KC, bool ODD, bool KSPL = false>
 __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
 {
     static_assert(CW * TW == 4 && (KC == 8 || KC == 4), "workgroup = 4 waves");
+    static_assert(!KSPL || (CW == 1 && TW == 4 && KC == 4), "the K-split form is the 1 x 4 form with the four tile blocks re-read as four channel slices");
     constexpr int KS = KC / 2;                        // matrix instructions (k-pairs) per position and chunk
     constexpr int U_BLK = 16 * 64 * KS;               // floats of one (32-channel block, chunk): [p][lane][KS]
-    constexpr int U_BUF = CW * U_BLK, V_BUF = 16 * TW * KS * 64, V_P = TW * KS * 64;
+    constexpr int UB = KSPL ? 4 : CW;                 // U blocks per chunk in LDS (K-split: one per channel slice)
+    constexpr int U_BUF = UB * U_BLK, V_BUF = 16 * TW * KS * 64, V_P = TW * KS * 64;
     constexpr int NJ = TW * KS / 4;                   // (channel, tile) pairs a thread transforms per chunk
     constexpr int KSTEP = 4 / TW;
     constexpr int PPB = U_BLK * 4 / 1024;             // 1 KB copy pieces per U block
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int per = gridDim.x >> 3, item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (item >= A.total) return;
-    const int tb = item / A.cgroups, cg = item - tb * A.cgroups, tile0 = tb * (TW * 32);
+    const int tb = item / A.cgroups, cg = item - tb * A.cgroups, tile0 = tb * (KSPL ? 32 : TW * 32);
     const int hw = A.H * A.W, tpi = A.Ht * A.Wt;
 
     // ---- transform role: tile block tw_t, k-pairs ks0 + j * KSTEP; lane = (tile & 31) + 32 * (channel & 1) = the operand slot it fills.
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
     const int tw_t = w % TW, ks0 = w / TW;
     unsigned voff[16];
     {
-        const int gt = tile0 + tw_t * 32 + (lane & 31), gtc = min(gt, A.T - 1);
+        const int gt = tile0 + (KSPL ? 0 : tw_t * 32) + (lane & 31), gtc = min(gt, A.T - 1);
         const int n = gtc / tpi, rem = gtc - n * tpi, ty = rem / A.Wt, tx = rem - ty * A.Wt;
         unsigned rowo[4], colo[4];
 #pragma unroll
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
     const unsigned par_oob = (lane >> 5) ? WN_OOB : 0u;
     f32x2 inp[NJ][8];                                                    // window of pair j: inp[j][2 * row + half] = columns (2 half, 2 half + 1)
     auto load_win = [&](int chunk, int j, int e0, int e1) {              // window elements [e0, e1) of pair j of `chunk`
-        const int cb = chunk * KC + 2 * (ks0 + j * KSTEP);               // (scalar) first channel of the k-pair
+        const int cb = (KSPL ? 4 * chunk + w : chunk) * KC + 2 * (ks0 + j * KSTEP);      // (scalar) first channel of the k-pair; K-split: slice w of the 16-channel chunk
         const bool any = cb < A.Cin;
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.x, 0, any ? A.xbytes : 0u, 0x00020000);
         const unsigned so = any ? 4u * (unsigned)cb * (unsigned)hw : 0u;
@@ -131,22 +133,26 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
 #pragma unroll
         for (int q = first; q < first + count; q++) {
             const int i = 4 * q + w, cwi = i / PPB, pi = i - cwi * PPB;
-            const unsigned so = 4u * (unsigned)(((cg * CW + cwi) * A.nchunk + chunk) * U_BLK + pi * 256);
+            // (K-split: block cwi is the slice's 4-channel chunk; a slice past the last chunk re-reads the last one — its V is zero)
+            const unsigned so = KSPL ? 4u * (unsigned)((cg * A.nchunk + min(4 * chunk + cwi, A.nchunk - 1)) * U_BLK + pi * 256)
+                                     : 4u * (unsigned)(((cg * CW + cwi) * A.nchunk + chunk) * U_BLK + pi * 256);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void*)(Ul + buf * U_BUF + cwi * U_BLK + pi * 256), 16, uvo, so, 0, 0);
         }
     };
-    constexpr int NPW = CW * PPB / 4;                                    // pieces per wave and chunk
+    constexpr int NPW = UB * PPB / 4;                                    // pieces per wave and chunk
 
     // ---- matrix role: channel block cw, tile block tw
-    const int cw = w % CW, tw = w / CW;
+    const int cw = KSPL ? w : w % CW, tw = w / CW;                       // operand blocks in LDS (K-split: U block = V block = the wave's channel slice)
+    const int cwo = KSPL ? 0 : cw, two = KSPL ? 0 : tw;                  // output blocks
+    const int nloop = KSPL ? (A.nchunk + 3) >> 2 : A.nchunk;
     f32x16 acc[16];
 #pragma unroll
     for (int p = 0; p < 16; p++)
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[p][q] = 0.f;
-    if (A.bias) {                                                        // Y = A^T M A: M[1][1] reaches all four outputs of a tile with weight 1 -> the bias starts there
+    if (A.bias && !(KSPL && w)) {                                        // Y = A^T M A: M[1][1] reaches all four outputs of a tile with weight 1 -> the bias starts there
 #pragma unroll
-        for (int q = 0; q < 16; q++) { const int co = (cg * CW + cw) * 32 + 4 * (lane >> 5) + 8 * (q >> 2) + (q & 3); acc[5][q] = co < A.Cout ? A.bias[co] : 0.f; }
+        for (int q = 0; q < 16; q++) { const int co = (cg * CW + cwo) * 32 + 4 * (lane >> 5) + 8 * (q >> 2) + (q & 3); acc[5][q] = co < A.Cout ? A.bias[co] : 0.f; }
     }
 
     load_win(0, 0, 0, 16); load_win(0, 1, 0, 16);
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
 #ifdef WN_PROF
     asm volatile("s_memtime %0" : "=s"(tk[1]));
 #endif
-    for (int c = 0; c < A.nchunk; c++) {
+    for (int c = 0; c < nloop; c++) {
         WN_STAMP(0);
         if (!(WN_ABLATE & 8)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -208,8 +214,8 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
             if (g == 2) { WN_XF(xf_out(0, 2, nb); xf_out(0, 3, nb)); }
             if (g == 3) { WN_XF(xf_out(1, 0, nb); xf_out(1, 1, nb)); }
             if (g == 4) { WN_XF(xf_out(1, 2, nb); xf_out(1, 3, nb)); }
-            if (g == 5 && !(WN_ABLATE & 4)) issue_u(min(c + 1, A.nchunk - 1), nb, 0, NPW / 2);
-            if (g == 6 && !(WN_ABLATE & 4)) issue_u(min(c + 1, A.nchunk - 1), nb, NPW / 2, NPW - NPW / 2);
+            if (g == 5 && !(WN_ABLATE & 4)) issue_u(min(c + 1, nloop - 1), nb, 0, NPW / 2);
+            if (g == 6 && !(WN_ABLATE & 4)) issue_u(min(c + 1, nloop - 1), nb, NPW / 2, NPW - NPW / 2);
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 acc[2 * g] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[g % 3][0][ks], vb[g % 3][0][ks], acc[2 * g], 0, 0, 0);
@@ -236,25 +242,49 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // (the last, unused copy and loads)
     // ---- inverse transform Y = A^T M A, bias, activation, store.  D[i][j]: register r of a lane = output channel 8 (r / 4) + 4 (lane >> 5) + (r & 3), tile lane & 31.
-    const int gt = tile0 + tw * 32 + (lane & 31);
-    if (gt >= A.T) return;
-    const int n = gt / tpi, rem = gt - n * tpi, ty = rem / A.Wt, tx = rem - ty * A.Wt;
+    // K-split: the four waves hold partial M of the SAME outputs; the inverse transform is linear, so waves 1-3 leave their transformed partial sums (64 floats a lane)
+    // in LDS and wave 0 adds them in a fixed order (1, 2, 3) before the activation.
+    f32x2* red = (f32x2*)wn_lds;                                         // [3][8][4][64] pairs of floats (48 KB; the operand buffers are dead)
+    if (KSPL) __syncthreads();                                           // everybody has read its last operands
+    const int gt = tile0 + two * 32 + (lane & 31);
+    if (!KSPL && gt >= A.T) return;
+    const int gtc = min(gt, A.T - 1);
+    const int n = gtc / tpi, rem = gtc - n * tpi, ty = rem / A.Wt, tx = rem - ty * A.Wt;
     const bool row1 = 2 * ty + 1 < A.H, col1 = 2 * tx + 1 < A.W;
-    const int cob = (cg * CW + cw) * 32 + 4 * (lane >> 5);
+    const int cob = (cg * CW + cwo) * 32 + 4 * (lane >> 5);
     float* yb = A.y + ((size_t)n * A.Cout * A.H + 2 * ty) * A.W + 2 * tx;
     // (the bias is already in the accumulators: position (1, 1) of M contributes 1 to all four outputs of a tile, so acc[5] started from bias[co] instead of 0.)
     // Output channels two at a time (registers r, r + 1 of every accumulator): packed adds / multiplies; leaky ReLU as max(y, slope * y) (0 <= slope <= 1).
     const f32x2 sl = {A.slope, A.slope};
-    const bool full = __all((A.vec2 != 0) & row1) && (cg * CW + cw) * 32 + 32 <= A.Cout;       // whole wave: every lane stores both rows of all 32 channels as 8-byte pairs
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
+    const bool full = __all((A.vec2 != 0) & row1 & (gt < A.T)) && (cg * CW + cwo) * 32 + 32 <= A.Cout;       // whole wave: every lane stores both rows of all 32 channels as 8-byte pairs
+    auto inverse = [&](int r, f32x2& y00, f32x2& y01, f32x2& y10, f32x2& y11) {
         f32x2 t0[4], t1[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const f32x2 m0 = {acc[j][r], acc[j][r + 1]}, m1 = {acc[4 + j][r], acc[4 + j][r + 1]}, m2 = {acc[8 + j][r], acc[8 + j][r + 1]}, m3 = {acc[12 + j][r], acc[12 + j][r + 1]};
             t0[j] = pk_add(pk_add(m0, m1), m2); t1[j] = pk_sub(pk_sub(m1, m2), m3);
         }
-        f32x2 y00 = pk_add(pk_add(t0[0], t0[1]), t0[2]), y01 = pk_sub(pk_sub(t0[1], t0[2]), t0[3]), y10 = pk_add(pk_add(t1[0], t1[1]), t1[2]), y11 = pk_sub(pk_sub(t1[1], t1[2]), t1[3]);
+        y00 = pk_add(pk_add(t0[0], t0[1]), t0[2]); y01 = pk_sub(pk_sub(t0[1], t0[2]), t0[3]); y10 = pk_add(pk_add(t1[0], t1[1]), t1[2]); y11 = pk_sub(pk_sub(t1[1], t1[2]), t1[3]);
+    };
+    if (KSPL && w) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            f32x2 y00, y01, y10, y11; inverse(r, y00, y01, y10, y11);
+            f32x2* d = red + (((w - 1) * 8 + (r >> 1)) * 4) * 64 + lane;
+            d[0] = y00; d[64] = y01; d[128] = y10; d[192] = y11;
+        }
+    }
+    if (KSPL) { __syncthreads(); if (w || gt >= A.T) return; }
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        f32x2 y00, y01, y10, y11; inverse(r, y00, y01, y10, y11);
+        if (KSPL) {
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                const f32x2* d = red + ((s * 8 + (r >> 1)) * 4) * 64 + lane;
+                y00 = pk_add(y00, d[0]); y01 = pk_add(y01, d[64]); y10 = pk_add(y10, d[128]); y11 = pk_add(y11, d[192]);
+            }
+        }
         const f32x2 s00 = y00 * sl, s01 = y01 * sl, s10 = y10 * sl, s11 = y11 * sl;
         y00.x = fmaxf(y00.x, s00.x); y00.y = fmaxf(y00.y, s00.y); y01.x = fmaxf(y01.x, s01.x); y01.y = fmaxf(y01.y, s01.y);
         y10.x = fmaxf(y10.x, s10.x); y10.y = fmaxf(y10.y, s10.y); y11.x = fmaxf(y11.x, s11.x); y11.y = fmaxf(y11.y, s11.y);
@@ -315,21 +345,35 @@ int vido_wino3x3_fills_chip(int n, int cout, int h, int w, int min_wgs)
     return ((T + tb - 1) / tb) * cg >= (min_wgs > 0 ? min_wgs : 128);
 }
 
-/* floats of the packed transformed weight of a cin -> cout layer */
-long long vido_wino3x3_packed_floats(int cin, int cout)
+/* The form vido_wino3x3_bias_act_form should be given for this launch.  0: the tile form (a workgroup = 64 tiles x 64 channels or 128 x 32, each wave walks ALL input
+ * channels).  1: the K-split form for launches that would leave most of the chip idle (fewer than 128 workgroups of the tile form): a workgroup = 32 tiles x 32 channels,
+ * its four waves each take a quarter of the input channels and the partial sums meet in LDS — four times the waves, a quarter of the chain each.
+ * VIDO_WINO_KSPLIT=0 / 1 forces a form (experiments). */
+int vido_wino3x3_form(int n, int cin, int cout, int h, int w)
+{
+    static const int force = [] { const char* e = getenv("VIDO_WINO_KSPLIT"); return e ? atoi(e) : -1; }();
+    (void)cin;
+    if (force == 0 || force == 1) return force;
+    return vido_wino3x3_fills_chip(n, cout, h, w, 128) ? 0 : 1;
+}
+
+/* floats of the packed transformed weight of a cin -> cout layer (form 0; _form: of the given form) */
+long long vido_wino3x3_packed_floats_form(int cin, int cout, int form)
 {
     if (cin < 1 || cout < 1) return 0;
+    if (form == 1) return 16ll * (((cout + 31) / 32) * 32) * wn_cin_pad(cin, 4);
     return 16ll * wn_cout_pad(cout) * wn_cin_pad(cin, wn_kc(cout));
 }
+long long vido_wino3x3_packed_floats(int cin, int cout) { return vido_wino3x3_packed_floats_form(cin, cout, 0); }
 
 /* HOST: weight [cout][cin][3][3] f32 -> U = G g G^T (float64 arithmetic, rounded once) in the operand order of k_wino3x3:
  * element (position p = 4 i + j, output channel co, input channel c) at [co / 32][c / KC][p][32 * (c & 1) + co % 32][(c % KC) / 2], KC = 8 (4 when
- * cout rounds up to 64 with >= 32 padded channels); padded channels are zero. */
-int vido_wino3x3_pack(const float* w, int cin, int cout, float* up)
+ * cout rounds up to 64 with >= 32 padded channels, and always in form 1); padded channels are zero. */
+int vido_wino3x3_pack_form(const float* w, int cin, int cout, int form, float* up)
 {
-    if (!w || !up || cin < 1 || cout < 1) return VIDO_E_INVALID;
-    const int kc = wn_kc(cout), ks = kc / 2, cop = wn_cout_pad(cout), cip = wn_cin_pad(cin, kc), nchunk = cip / kc;
-    std::memset(up, 0, sizeof(float) * (size_t)vido_wino3x3_packed_floats(cin, cout));
+    if (!w || !up || cin < 1 || cout < 1 || form < 0 || form > 1) return VIDO_E_INVALID;
+    const int kc = form == 1 ? 4 : wn_kc(cout), ks = kc / 2, cip = wn_cin_pad(cin, kc), nchunk = cip / kc;
+    std::memset(up, 0, sizeof(float) * (size_t)vido_wino3x3_packed_floats_form(cin, cout, form));
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     for (int co = 0; co < cout; co++)
         for (int c = 0; c < cin; c++) {
@@ -341,40 +385,50 @@ int vido_wino3x3_pack(const float* w, int cin, int cout, float* up)
             const int slot = 32 * (c & 1) + co % 32, kk = (c % kc) / 2;
             for (int p = 0; p < 16; p++) up[base + ((size_t)p * 64 + slot) * ks + kk] = (float)u[p >> 2][p & 3];
         }
-    (void)cop;
     return VIDO_OK;
 }
+int vido_wino3x3_pack(const float* w, int cin, int cout, float* up) { return vido_wino3x3_pack_form(w, cin, cout, 0, up); }
 
 /* y = leaky_relu(conv2d(x, w, padding 1) + bias, slope) for n images, 3x3 kernel, stride 1: x [n][cin][h][w], y [n][cout][h][w] f32 DEVICE tensors (y != x),
- * bias [cout] or NULL, u_packed = vido_wino3x3_pack(w) on the device (16-byte aligned).  slope 0 = ReLU, 1 = none.  Winograd F(2x2, 3x3) in fp32: the result differs
- * from a direct fp32 convolution by rounding only (~1e-6 of the output scale, the class of the library's own Winograd kernels).  Enqueues on the adopted stream; capturable. */
-int vido_wino3x3_bias_act(vido_ctx* ctx, const float* x, const float* u_packed, const float* bias, float* y, int n, int cin, int cout, int h, int w, float slope)
+ * bias [cout] or NULL, u_packed = vido_wino3x3_pack_form(w, .., form) on the device (16-byte aligned).  slope 0 = ReLU, 1 = none.  Winograd F(2x2, 3x3) in fp32: the result differs
+ * from a direct fp32 convolution by rounding only (~1e-6 of the output scale, the class of the library's own Winograd kernels).  Enqueues on the adopted stream; capturable.
+ * form: 0 or 1 (vido_wino3x3_form picks); the result is the same up to the order of the channel sums. */
+int vido_wino3x3_bias_act_form(vido_ctx* ctx, const float* x, const float* u_packed, const float* bias, float* y, int n, int cin, int cout, int h, int w, float slope, int form)
 {
     if (!ctx) return VIDO_E_INVALID;
-    if (!x || !u_packed || !y || x == y || n < 1 || !vido_wino3x3_supported(cin, cout, h, w) || ((uintptr_t)u_packed & 15) || (((uintptr_t)x | (uintptr_t)y) & 3))
+    if (!x || !u_packed || !y || x == y || n < 1 || form < 0 || form > 1 || !vido_wino3x3_supported(cin, cout, h, w) || ((uintptr_t)u_packed & 15) || (((uintptr_t)x | (uintptr_t)y) & 3))
         return vido_set_error(ctx, VIDO_E_INVALID, "wino3x3: no kernel for %d -> %d channels on %d x %d x %d (or a pointer is misaligned)", cin, cout, n, h, w);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
-    const int kc = wn_kc(cout), ht = (h + 1) / 2, wt = (w + 1) / 2;
+    const int kc = form == 1 ? 4 : wn_kc(cout), ht = (h + 1) / 2, wt = (w + 1) / 2;
     const long long T = (long long)n * ht * wt;
     if (T >= (1ll << 30) || 4ll * n * cin * h * w >= (1ll << 30) || 4ll * n * cout * h * w >= (1ll << 32))
         return vido_set_error(ctx, VIDO_E_INVALID, "wino3x3: a batch of %d images of %d x %d x %d is past the 1 GB the kernel addresses", n, cin, h, w);
-    const int tb = kc == 8 ? 64 : 128, cgroups = kc == 8 ? (cout + 63) / 64 : (cout + 31) / 32;
-    const int nblk = (int)((T + tb - 1) / tb), total = nblk * cgroups;
-    WnArgs A{x, u_packed, bias, y, n, cin, cout, h, w, ht, wt, (int)T, wn_cin_pad(cin, kc) / kc, cgroups, total, slope, (w % 2 == 0 && ((uintptr_t)y & 7) == 0) ? 1 : 0, (unsigned)(4ll * n * cin * h * w), (unsigned)(4ll * vido_wino3x3_packed_floats(cin, cout)), nullptr};
+    const int tb = form == 1 ? 32 : (kc == 8 ? 64 : 128), cgroups = kc == 8 ? (cout + 63) / 64 : (cout + 31) / 32;
+    const long long nblk_ll = (T + tb - 1) / tb;
+    if (nblk_ll * cgroups >= (1ll << 30)) return vido_set_error(ctx, VIDO_E_INVALID, "wino3x3: too many work items");
+    const int nblk = (int)nblk_ll, total = nblk * cgroups;
+    WnArgs A{x, u_packed, bias, y, n, cin, cout, h, w, ht, wt, (int)T, wn_cin_pad(cin, kc) / kc, cgroups, total, slope, (w % 2 == 0 && ((uintptr_t)y & 7) == 0) ? 1 : 0, (unsigned)(4ll * n * cin * h * w), (unsigned)(4ll * vido_wino3x3_packed_floats_form(cin, cout, form)),
+             nullptr};
     const dim3 grid(8 * ((total + 7) / 8)), blk(256);
-    constexpr size_t LDS8 = (size_t)2 * (2 * 16 * 64 * 4 + 16 * 2 * 4 * 64) * 4, LDS4 = (size_t)2 * (1 * 16 * 64 * 2 + 16 * 4 * 2 * 64) * 4;
+    constexpr size_t LDS8 = (size_t)2 * (2 * 16 * 64 * 4 + 16 * 2 * 4 * 64) * 4, LDS4 = (size_t)2 * (1 * 16 * 64 * 2 + 16 * 4 * 2 * 64) * 4, LDSK = (size_t)2 * (4 * 16 * 64 * 2 + 16 * 4 * 2 * 64) * 4;
     static bool attr[64] = {};
     if (!attr[ctx->device & 63]) {
         for (const void* f : {(const void*)k_wino3x3<2, 2, 8, false>, (const void*)k_wino3x3<2, 2, 8, true>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS8));
         for (const void* f : {(const void*)k_wino3x3<1, 4, 4, false>, (const void*)k_wino3x3<1, 4, 4, true>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS4));
+        for (const void* f : {(const void*)k_wino3x3<1, 4, 4, false, true>, (const void*)k_wino3x3<1, 4, 4, true, true>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSK));
         attr[ctx->device & 63] = true;
     }
     const bool odd = cin & 1;                                            // (an odd channel count costs 17 vector instructions per window: its last channel pair is half padding)
-    if (kc == 8) { if (odd) hipLaunchKernelGGL((k_wino3x3<2, 2, 8, true>), grid, blk, LDS8, st, A); else hipLaunchKernelGGL((k_wino3x3<2, 2, 8, false>), grid, blk, LDS8, st, A); }
+    if (form == 1) { if (odd) hipLaunchKernelGGL((k_wino3x3<1, 4, 4, true, true>), grid, blk, LDSK, st, A); else hipLaunchKernelGGL((k_wino3x3<1, 4, 4, false, true>), grid, blk, LDSK, st, A); }
+    else if (kc == 8) { if (odd) hipLaunchKernelGGL((k_wino3x3<2, 2, 8, true>), grid, blk, LDS8, st, A); else hipLaunchKernelGGL((k_wino3x3<2, 2, 8, false>), grid, blk, LDS8, st, A); }
     else { if (odd) hipLaunchKernelGGL((k_wino3x3<1, 4, 4, true>), grid, blk, LDS4, st, A); else hipLaunchKernelGGL((k_wino3x3<1, 4, 4, false>), grid, blk, LDS4, st, A); }
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
+}
+int vido_wino3x3_bias_act(vido_ctx* ctx, const float* x, const float* u_packed, const float* bias, float* y, int n, int cin, int cout, int h, int w, float slope)
+{
+    return vido_wino3x3_bias_act_form(ctx, x, u_packed, bias, y, n, cin, cout, h, w, slope, 0);
 }
 
 }  // extern "C"

@@ -241,16 +241,20 @@ class HipOps:
     def wino3x3_supported(self, cin, cout, H, W):
         return bool(self.ctx.lib.vido_wino3x3_supported(int(cin), int(cout), int(H), int(W)))
 
-    def wino3x3_bias_act(self, x, u_packed, bias, cout, slope=1.0):
+    def wino3x3_form(self, N, cin, cout, H, W):
+        """0: the tile form, 1: the K-split form (launches that would leave most of the chip idle) — the library's own rule, vido_wino3x3_form"""
+        return int(self.ctx.lib.vido_wino3x3_form(int(N), int(cin), int(cout), int(H), int(W)))
+
+    def wino3x3_bias_act(self, x, u_packed, bias, cout, slope=1.0, form=0):
         """leaky_relu(conv2d(x, w, None, 1, 1) + bias, slope) for a batch, 3x3 kernel, as one Winograd launch whose channel contractions run on the matrix pipe (csrc/wino.hip);
-        u_packed = pack_wino3x3(w) on x's device.  slope 0 = ReLU, 1 = none."""
+        u_packed = pack_wino3x3(w, form) on x's device.  slope 0 = ReLU, 1 = none."""
         assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and u_packed.is_cuda
         N, cin, H, W = x.shape
         out = torch.empty((N, cout, H, W), device=x.device, dtype=torch.float32)
         self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * N * cout * cin * 9 * H * W      # direct-convolution count, as FlopCounterMode would give the library call
         self._adopt_stream()
-        self.ctx._check(self.ctx.lib.vido_wino3x3_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(u_packed.data_ptr()), C.c_void_p(bias.data_ptr()) if bias is not None else None,
-                                                           C.c_void_p(out.data_ptr()), int(N), int(cin), int(cout), int(H), int(W), C.c_float(slope)))
+        self.ctx._check(self.ctx.lib.vido_wino3x3_bias_act_form(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(u_packed.data_ptr()), C.c_void_p(bias.data_ptr()) if bias is not None else None,
+                                                                C.c_void_p(out.data_ptr()), int(N), int(cin), int(cout), int(H), int(W), C.c_float(slope), int(form)))
         return out
 
     def wino3x3_conv(self, conv, x, slope, weight=None, bias=None):
@@ -262,13 +266,17 @@ class HipOps:
                 or getattr(conv, "padding_mode", "zeros") != "zeros" or not x.is_cuda or not self.wino3x3_supported(w.shape[1], w.shape[0], x.shape[2], x.shape[3])
                 or 4 * x.numel() >= 1 << 30 or 4 * x.shape[0] * w.shape[0] * x.shape[2] * x.shape[3] >= 1 << 30):
             return None
-        # a launch of a few dozen workgroups (small maps) runs as long as a chip-filling one: the library's kernels win there (VIDO_WINO_MIN_WGS, default 128 = half the CUs)
-        if not self.ctx.lib.vido_wino3x3_fills_chip(int(x.shape[0]), int(w.shape[0]), int(x.shape[2]), int(x.shape[3]), _WINO_MIN_WGS):
+        # a launch of a few dozen workgroups of the tile form (small maps) runs as long as a chip-filling one; those take the K-split form (four waves of a workgroup share
+        # the input channels).  VIDO_WINO_MIN_WGS=128 restores the rule of round 4 (the library's kernels below 128 workgroups).
+        if _WINO_MIN_WGS > 0 and not self.ctx.lib.vido_wino3x3_fills_chip(int(x.shape[0]), int(w.shape[0]), int(x.shape[2]), int(x.shape[3]), _WINO_MIN_WGS):
             return None
+        form = self.wino3x3_form(x.shape[0], w.shape[1], w.shape[0], x.shape[2], x.shape[3])
         key = (w.data_ptr(), w._version, str(x.device))
         if getattr(conv, "_wino_key", None) != key:
-            conv._wino_u = pack_wino3x3(w).to(x.device); conv._wino_key = key
-        return self.wino3x3_bias_act(x.contiguous(), conv._wino_u, b, int(w.shape[0]), slope)
+            conv._wino_u = {}; conv._wino_key = key                          # per form: a layer shared by several map sizes (the RPN head over P2-P6) is launched in both
+        if form not in conv._wino_u:
+            conv._wino_u[form] = pack_wino3x3(w, form).to(x.device)
+        return self.wino3x3_bias_act(x.contiguous(), conv._wino_u[form], b, int(w.shape[0]), slope, form)
 
     def lfn_reg_front(self, im1, im2, flow, scale, feat):
         """Regularization.forward up to netMain's input (layers.py:236-243): torch.cat([sqrt(sum((im1 - Backward(im2, flow * scale))^2)), flow - mean(flow), feat], 1) with the
@@ -535,22 +543,23 @@ def pack_gconv3x3(w, groups):
     return pad.permute(0, 2, 4, 3, 1).contiguous()
 
 
-def pack_wino3x3(w):
+def pack_wino3x3(w, form=0):
     """3x3 convolution weight [cout, cin, 3, 3] -> U = G g G^T (float64, rounded once) in the operand order of csrc/wino.hip, as a CPU tensor
-    [cout_pad / 32, cin_pad / KC, 16, 64, KC / 2] (the library's vido_wino3x3_pack: ONE implementation of the layout, also what a C caller uses)."""
+    [cout_pad / 32, cin_pad / KC, 16, 64, KC / 2] (the library's vido_wino3x3_pack_form: ONE implementation of the layout, also what a C caller uses).
+    form 0: KC by cout (8, or 4 for 32 / 96 .. channels), form 1 (K-split launches): KC = 4."""
     import numpy as np
     from ..host import load_library
     lib = load_library()
-    lib.vido_wino3x3_packed_floats.restype = C.c_longlong
+    lib.vido_wino3x3_packed_floats_form.restype = C.c_longlong
     cout, cin = int(w.shape[0]), int(w.shape[1])
-    assert tuple(w.shape[2:]) == (3, 3)
+    assert tuple(w.shape[2:]) == (3, 3) and form in (0, 1)
     wh = np.ascontiguousarray(w.detach().to("cpu", torch.float32).numpy())
-    n = int(lib.vido_wino3x3_packed_floats(cin, cout))
+    n = int(lib.vido_wino3x3_packed_floats_form(cin, cout, int(form)))
     out = np.empty(n, np.float32)
-    rc = lib.vido_wino3x3_pack(C.c_void_p(wh.ctypes.data), cin, cout, C.c_void_p(out.ctypes.data))
+    rc = lib.vido_wino3x3_pack_form(C.c_void_p(wh.ctypes.data), cin, cout, int(form), C.c_void_p(out.ctypes.data))
     if rc != 0:
-        raise RuntimeError("vido_wino3x3_pack: %d" % rc)
-    kc = 8 if (((cout + 63) // 64) * 64 - cout) < 32 else 4
+        raise RuntimeError("vido_wino3x3_pack_form: %d" % rc)
+    kc = 8 if (((cout + 63) // 64) * 64 - cout) < 32 and form == 0 else 4
     cop = ((cout + 63) // 64) * 64 if kc == 8 else ((cout + 31) // 32) * 32
     cip = ((cin + kc - 1) // kc) * kc
     return torch.from_numpy(out).reshape(cop // 32, cip // kc, 16, 64, kc // 2)
