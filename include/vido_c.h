@@ -322,6 +322,16 @@ int vido_conv_kxk_c2(vido_ctx* ctx, const float* x, const float* w, const float*
  * (layers.py:99, 125, 140), the detector's layer1.  w_packed: element (co, k) at [co / 32][k / 2][32 * (k & 1) + co % 32], cout padded to 32 with zeros. */
 int vido_conv1x1_skinny(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, long long hw, float slope);
 
+/* k x k convolution (7x7, 5x5, 3x3, 7x1, 1x7, 5x1, 1x5, 1x1; strides 1-4; zero padding) + bias + leaky ReLU as a direct implicit GEMM on the fp32 matrix pipe, one launch
+ * (csrc/convdirect.hip): the layers of LiteFlowNet that the library ran as im2col / transposes + GEMM + a bias pass — the 7x7 stem, the stride-2 3x3 convolutions of the
+ * feature pyramid, the separable distance layers of the regularisation (flow_net/src/layers.py:39-73, 217-235).  x [n][cin][h][w], y [n][cout][ho][wo] f32 DEVICE tensors,
+ * w_packed = vido_conv_direct_pack(w [cout][cin][kh][kw]) (host) copied to the device, vido_conv_direct_packed_floats floats; bias [cout] or NULL; slope 0 = ReLU, 1 = none. */
+int vido_conv_direct_supported(int cin, int cout, int h, int w, int kh, int kw, int sh, int sw, int ph, int pw);
+long long vido_conv_direct_packed_floats(int cin, int cout, int kh, int kw);
+int vido_conv_direct_pack(const float* w, int cin, int cout, int kh, int kw, float* w_packed);
+int vido_conv_direct_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, float* y, int n, int cin, int cout, int h, int w,
+                              int kh, int kw, int sh, int sw, int ph, int pw, float slope);
+
 /* 3x3 stride-1 padding-1 convolution + bias + leaky-ReLU as Winograd F(2x2, 3x3) with its sixteen channel contractions on the fp32 matrix pipe (csrc/wino.hip): the
  * dense 3x3 convolutions of LiteFlowNet (flow_net/src/layers.py:39-315), the FPN output / RPN head / mask head convolutions of the detector
  * (maskrcnn_benchmark/modeling/backbone/fpn.py, rpn/rpn.py:74-107, roi_heads/mask_head/roi_mask_feature_extractors.py) — what the library runs as a vector-ALU Winograd

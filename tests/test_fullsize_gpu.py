@@ -1,5 +1,5 @@
 """The networks AT THE SIZE AND IN THE FORM THE BENCH RUNS THEM (pipeline.NetNodes at 640x480: frozen batch norms folded, every own matrix-core kernel on — csrc/conv1x1.hip,
-gconv.hip, wino.hip, convsmall.hip —, hipGraph replay) against the same module graphs with the same weights in plain eager fp32 with every switch off (library convolutions,
+gconv.hip, wino.hip, convsmall.hip, convdirect.hip —, hipGraph replay) against the same module graphs with the same weights in plain eager fp32 with every switch off (library convolutions,
 un-folded batch norms, torch glue): Mask R-CNN X-101-32x8d-FPN at the 800x1088 feed (maskrcnn_benchmark/modeling/detector/generalized_rcnn.py, backbone/resnet.py:300-372,
 backbone/fpn.py), LiteFlowNet at 640x480 (flow_net/src/layers.py:39-315, run_flow_net.py:66-110), MonoDepth2 at the 640x192 feed (mono_depth2/src/networks/*.py).
 The reference fixtures of tests/test_maskrcnn_gpu.py / test_nets_modules_gpu.py are tiny-config graphs (where the own kernels refuse most layers); this file closes the gap
@@ -11,7 +11,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
-OFF = ("VIDO_NO_WINO", "VIDO_NO_CONV1X1", "VIDO_NO_CONVSMALL", "VIDO_NO_GCONV", "VIDO_NO_GCONV_S2", "VIDO_NO_DEPTH_FUSED")
+OFF = ("VIDO_NO_WINO", "VIDO_NO_CONV1X1", "VIDO_NO_CONVSMALL", "VIDO_NO_CONVDIRECT", "VIDO_NO_GCONV", "VIDO_NO_GCONV_S2", "VIDO_NO_DEPTH_FUSED")
 
 
 def rel(a, b):

@@ -30,9 +30,15 @@ def _obj_stamp(src):
     return h.hexdigest()
 
 
+# per-source flags.  convdirect: matrix-instruction accumulators in VGPRs (the kernel needs < 128 registers; in AGPR form the compiler copies the 16-32 accumulators
+# AGPR -> VGPR -> AGPR around every tap's loop: ~130 moves per tap)
+FILE_FLAGS = {"convdirect": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def _file_flags(src):
-    """VIDO_FLAGS_<stem> (e.g. VIDO_FLAGS_orb="-DFS_MAXIW=37"): experiment flags for one source only, so that a variant build recompiles one object"""
-    return _shlex.split(os.environ.get("VIDO_FLAGS_" + os.path.basename(src).split(".")[0], ""))
+    """FILE_FLAGS + VIDO_FLAGS_<stem> (e.g. VIDO_FLAGS_orb="-DFS_MAXIW=37"): experiment flags for one source only, so that a variant build recompiles one object"""
+    stem = os.path.basename(src).split(".")[0]
+    return FILE_FLAGS.get(stem, []) + _shlex.split(os.environ.get("VIDO_FLAGS_" + stem, ""))
 
 
 def build(force=False, verbose=False, lib=None):

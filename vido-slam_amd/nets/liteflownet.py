@@ -42,6 +42,11 @@ class _Chain(nn.Sequential):
                     if y is not None:
                         x = y; i += 2 if act else 1
                         continue
+                if self.wino is not None and hasattr(self.wino, "conv_direct_conv") and not os.environ.get("VIDO_NO_CONVDIRECT") and not (residual is not None and i + 1 >= len(mods)):
+                    y = self.wino.conv_direct_conv(m, x, LEAK if act else 1.0)        # stem, stride-2 and separable layers: one direct implicit-GEMM launch (csrc/convdirect.hip)
+                    if y is not None:
+                        x = y; i += 2 if act else 1
+                        continue
                 x = F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
                 last = i + (2 if act else 1) >= len(mods)
                 if last and residual is not None and self.epilogue_res is not None and not act:

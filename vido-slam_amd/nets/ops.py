@@ -278,6 +278,31 @@ class HipOps:
             conv._wino_u[form] = pack_wino3x3(w, form).to(x.device)
         return self.wino3x3_bias_act(x.contiguous(), conv._wino_u[form], b, int(w.shape[0]), slope, form)
 
+    def conv_direct_conv(self, conv, x, slope):
+        """The convolution `conv` (nn.Conv2d: groups 1, dilation 1, zero padding, a k x k of csrc/convdirect.hip) + bias + activation as ONE direct implicit-GEMM launch on
+        the matrix pipe, else None.  The packed weight is cached on the module and rebuilt when the weight tensor changes."""
+        w = conv.weight
+        kh, kw = int(w.shape[2]), int(w.shape[3]); sh, sw = (int(v) for v in conv.stride); ph, pw = (int(v) for v in conv.padding)
+        if (tuple(conv.dilation) != (1, 1) or conv.groups != 1 or getattr(conv, "padding_mode", "zeros") != "zeros" or not x.is_cuda or x.dtype != torch.float32
+                or not self.ctx.lib.vido_conv_direct_supported(int(w.shape[1]), int(w.shape[0]), int(x.shape[2]), int(x.shape[3]), kh, kw, sh, sw, ph, pw)
+                or 4 * x.numel() >= 1 << 30):
+            return None
+        N, cin, H, W = x.shape; cout = int(w.shape[0])
+        Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+        if 4 * N * cout * Ho * Wo >= 1 << 30:
+            return None
+        key = (w.data_ptr(), w._version, str(x.device))
+        if getattr(conv, "_cd_key", None) != key:
+            conv._cd_w = pack_conv_direct(w).to(x.device); conv._cd_key = key
+        x = x.contiguous()
+        out = torch.empty((N, cout, Ho, Wo), device=x.device, dtype=torch.float32)
+        self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * N * cout * cin * kh * kw * Ho * Wo
+        self._adopt_stream()
+        b = conv.bias
+        self.ctx._check(self.ctx.lib.vido_conv_direct_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(conv._cd_w.data_ptr()), C.c_void_p(b.data_ptr()) if b is not None else None,
+                                                               C.c_void_p(out.data_ptr()), int(N), int(cin), cout, int(H), int(W), kh, kw, sh, sw, ph, pw, C.c_float(slope)))
+        return out
+
     def lfn_reg_front(self, im1, im2, flow, scale, feat):
         """Regularization.forward up to netMain's input (layers.py:236-243): torch.cat([sqrt(sum((im1 - Backward(im2, flow * scale))^2)), flow - mean(flow), feat], 1) with the
         first three channels from one HIP pass."""
@@ -541,6 +566,24 @@ def pack_gconv3x3(w, groups):
         return w9.reshape(groups, cpg_out // 32, 32, cpg_in // 8, 8, 9).permute(0, 1, 3, 5, 4, 2).contiguous()
     pad = w9.new_zeros((groups, 16, cpg_in // 8, 8, 9)); pad[:, :cpg_out] = w9
     return pad.permute(0, 2, 4, 3, 1).contiguous()
+
+
+def pack_conv_direct(w):
+    """convolution weight [cout, cin, kh, kw] -> the operand order of csrc/convdirect.hip (the library's vido_conv_direct_pack), a flat CPU tensor"""
+    import numpy as np
+    from ..host import load_library
+    lib = load_library()
+    lib.vido_conv_direct_packed_floats.restype = C.c_longlong
+    cout, cin, kh, kw = (int(v) for v in w.shape)
+    wh = np.ascontiguousarray(w.detach().to("cpu", torch.float32).numpy())
+    n = int(lib.vido_conv_direct_packed_floats(cin, cout, kh, kw))
+    if n <= 0:
+        raise RuntimeError("vido_conv_direct_pack: no kernel for %d x %d taps" % (kh, kw))
+    out = np.empty(n, np.float32)
+    rc = lib.vido_conv_direct_pack(C.c_void_p(wh.ctypes.data), cin, cout, kh, kw, C.c_void_p(out.ctypes.data))
+    if rc != 0:
+        raise RuntimeError("vido_conv_direct_pack: %d" % rc)
+    return torch.from_numpy(out)
 
 
 def pack_wino3x3(w, form=0):
