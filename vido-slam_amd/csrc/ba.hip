@@ -25,6 +25,8 @@
 // partial reduced system (S, r) and the LM scalars are summed through the caller's all-reduce hook (RCCL via
 // torch.distributed in bench.py), the reduced solve is replicated, back-substitution is local.
 #include "common.hpp"
+#include <atomic>
+#include <sched.h>
 #include "xwg.hpp"
 #include <thread>
 #include <mutex>
@@ -2598,30 +2600,51 @@ namespace {
 class HostPool {
 public:
     static HostPool& get() { static HostPool p; return p; }
+    // processes that share this host's cores: the ranks of the first solve of the process, or what the launcher says (torchrun's LOCAL_WORLD_SIZE) — the pool is created
+    // by the first bundle adjustment of the process, which may be a single-rank local window
+    static int& world_hint() { static int w = [] { const char* e = getenv("LOCAL_WORLD_SIZE"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }(); return w; }
+    static int usable_cpus() {
+        int n = (int)std::thread::hardware_concurrency();
+        cpu_set_t cs; if (sched_getaffinity(0, sizeof cs, &cs) == 0) n = std::min(n, CPU_COUNT(&cs));
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { long long q = 0, per = 0; char buf[64] = {0};
+            if (fscanf(f, "%63s %lld", buf, &per) == 2 && strcmp(buf, "max") != 0 && per > 0) { q = atoll(buf); if (q > 0) n = std::min(n, (int)std::max(1ll, q / per)); } fclose(f); }
+        return std::max(1, n);
+    }
     int size() const { return n_; }
-    // f(tid) on n_ threads (the caller is thread 0); returns when all are done
+    // f(tid) on n_ threads (the caller is thread 0); returns when all are done.  A set-up is ~30 passes of 30-300 us back to back: a worker that went to sleep on the
+    // condition variable after every pass cost a futex wake-up (30-60 us) per pass and thread — more than a third of the set-up.  Workers therefore SPIN for the next pass
+    // for a few hundred microseconds after finishing one (they sleep between calls), and the caller spins for their completion.
     void run(const std::function<void(int)>& f) {
         if (n_ == 1) { f(0); return; }
         std::lock_guard<std::mutex> one(run_m_);                 // (several contexts may set up at once — the sharded solve in threads: their passes take turns)
-        { std::lock_guard<std::mutex> g(m_); job_ = &f; gen_++; pending_ = n_ - 1; }
-        cv_.notify_all();
+        { std::lock_guard<std::mutex> g(m_); job_ = &f; pending_.store(n_ - 1, std::memory_order_relaxed); gen_.fetch_add(1, std::memory_order_release); }
+        if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
         f(0);
-        std::unique_lock<std::mutex> g(m_); done_.wait(g, [&] { return pending_ == 0; }); job_ = nullptr;
+        while (pending_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+        job_ = nullptr;
     }
     // chunks of [0, n): f(lo, hi, tid)
     template <class F> void chunks(size_t n, F f) { const int T = n_; run([&](int t) { const size_t lo = n * t / T, hi = n * (t + 1) / T; if (hi > lo) f(lo, hi, t); }); }
 private:
     HostPool() {
-        const char* e = getenv("VIDO_BA_HOST_THREADS"); int want = e ? atoi(e) : 4;      // (round 5: 4 / 8 / 16 / 32 / 64 threads -> 8.7 / 9.3 / 8.8 / 9.9 / 11.2 ms per 1 M-edge call on a 16-CPU container)
+        // default: the CPUs this process may use (cgroup quota, affinity mask) shared among the ranks of the solve, at most 16.  With workers that spin between passes a
+        // 1 M-edge call takes 9.3 / 8.7 / 8.1 / 7.8 ms on 4 / 8 / 12 / 16 threads of a 16-CPU container (sleeping workers: 8.7 / 9.3 / - / 8.8).
+        const char* e = getenv("VIDO_BA_HOST_THREADS"); int want = e ? atoi(e) : std::max(1, std::min(16, usable_cpus() / std::max(1, world_hint())));
         n_ = std::max(1, std::min(want, (int)std::thread::hardware_concurrency()));
-        for (int t = 1; t < n_; t++) th_.emplace_back([this, t] { int seen = 0; for (;;) { const std::function<void(int)>* j;
-            { std::unique_lock<std::mutex> g(m_); cv_.wait(g, [&] { return stop_ || gen_ != seen; }); if (stop_) return; seen = gen_; j = job_; }
+        for (int t = 1; t < n_; t++) th_.emplace_back([this, t] { int seen = 0; for (;;) {
+            bool got = false;
+            for (int i = 0; i < 20000 && !got; i++) { got = stop_.load(std::memory_order_relaxed) || gen_.load(std::memory_order_acquire) != seen; if (!got) __builtin_ia32_pause(); }
+            if (!got) { std::unique_lock<std::mutex> g(m_); sleepers_.fetch_add(1, std::memory_order_release);
+                        cv_.wait(g, [&] { return stop_.load(std::memory_order_relaxed) || gen_.load(std::memory_order_acquire) != seen; }); sleepers_.fetch_sub(1, std::memory_order_release); }
+            if (stop_.load(std::memory_order_relaxed)) return;
+            seen = gen_.load(std::memory_order_acquire);
+            const std::function<void(int)>* j = job_;
             (*j)(t);
-            { std::lock_guard<std::mutex> g(m_); if (--pending_ == 0) done_.notify_one(); } } });
+            pending_.fetch_sub(1, std::memory_order_release); } });
     }
-    ~HostPool() { { std::lock_guard<std::mutex> g(m_); stop_ = true; } cv_.notify_all(); for (auto& t : th_) t.join(); }
-    int n_ = 1, gen_ = 0, pending_ = 0; bool stop_ = false; const std::function<void(int)>* job_ = nullptr;
-    std::mutex m_, run_m_; std::condition_variable cv_, done_; std::vector<std::thread> th_;
+    ~HostPool() { { std::lock_guard<std::mutex> g(m_); stop_.store(true); } cv_.notify_all(); for (auto& t : th_) t.join(); }
+    int n_ = 1; std::atomic<int> gen_{0}, pending_{0}, sleepers_{0}; std::atomic<bool> stop_{false}; const std::function<void(int)>* volatile job_ = nullptr;
+    std::mutex m_, run_m_; std::condition_variable cv_; std::vector<std::thread> th_;
 };
 // stable counting sort on the pool: pos[i] = rank of element i among the n elements ordered by (key, i); bin_start[b] = first rank of bin b (nbins + 1 entries)
 template <class KeyFn> static void par_counting_rank(HostPool& P, size_t n, int nbins, KeyFn key, int* pos, std::vector<int>& bin_start)
@@ -2636,6 +2659,30 @@ template <class KeyFn> static void par_counting_rank(HostPool& P, size_t n, int 
     P.chunks((size_t)nbins, [&](size_t lo, size_t hi, int t) { long run = part[t]; for (size_t b = lo; b < hi; b++) { bin_start[b] = (int)run; for (int u = 0; u < T; u++) { const int c = hist[(size_t)u * nbins + b]; hist[(size_t)u * nbins + b] = (int)run; run += c; } } });
     bin_start[nbins] = (int)n;
     P.chunks(n, [&](size_t lo, size_t hi, int t) { int* h = hist.data() + (size_t)t * nbins; for (size_t i = lo; i < hi; i++) pos[i] = h[key(i)]++; });
+}
+// the same ranking for MANY bins (landmark ids: 100 k bins — per-thread histograms of all bins would be T x nbins counters to clear and to scan, more than the n elements
+// at 16 threads): two levels.  Level 1 ranks by the high bits (<= 1024 buckets, per-thread histograms) and lists the elements bucket by bucket in their original order;
+// level 2 gives every bucket to one thread, which counts the low bits (<= a few hundred values) of its few thousand elements and hands out the ranks in list order — stable.
+template <class KeyFn> static void par_counting_rank_large(HostPool& P, size_t n, int nbins, KeyFn key, int* pos, std::vector<int>& bin_start, std::vector<int>& scratch)
+{
+    int shift = 0; while (((nbins - 1) >> shift) >= 1024) shift++;
+    const int nb1 = ((nbins - 1) >> shift) + 1, nlow = 1 << shift;
+    if (shift == 0) { par_counting_rank(P, n, nbins, key, pos, bin_start); return; }
+    std::vector<int> b1;
+    par_counting_rank(P, n, nb1, [&](size_t i) { return key(i) >> shift; }, pos, b1);      // pos = level-1 rank for now
+    scratch.resize(n); int* order = scratch.data();
+    P.chunks(n, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; i++) order[pos[i]] = (int)i; });
+    bin_start.assign(nbins + 1, 0);
+    P.chunks((size_t)nb1, [&](size_t blo, size_t bhi, int) {
+        std::vector<int> cnt(nlow + 1);
+        for (size_t b = blo; b < bhi; b++) {
+            const int s0 = b1[b], e0 = b1[b + 1], k0 = (int)b << shift, kn = std::min(nlow, nbins - k0);
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int q = s0; q < e0; q++) cnt[(key((size_t)order[q]) - k0) + 1]++;
+            for (int k = 0; k < kn; k++) { bin_start[k0 + k] = s0 + cnt[k]; cnt[k + 1] += cnt[k]; }
+            for (int q = s0; q < e0; q++) { const int i = order[q]; pos[i] = s0 + cnt[key((size_t)i) - k0]++; }
+        } });
+    bin_start[nbins] = (int)n;
 }
 static void par_memcpy(HostPool& P, void* dst, const void* src, size_t bytes)
 {
@@ -2657,7 +2704,13 @@ struct Arena {                       // bump allocator over the ctx's persistent
         hoff += b;
         if (hoff - flushed >= ((size_t)4 << 20)) flush(st);
         return d; }
-    void flush(hipStream_t st) { if (hoff > flushed) { if (hipMemcpyAsync(base + flushed, hbase + flushed, hoff - flushed, hipMemcpyHostToDevice, st) != hipSuccess) failed = true; flushed = hoff; } }
+    // a region of the stage the caller fills IN PLACE (no copy); nothing is flushed until commit()
+    bool hold = false;
+    template <class T> T* stage(size_t n, const T** dev) { const size_t b = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+        if (hoff + b > up_cap || hoff + b > hcap) { failed = true; *dev = nullptr; return nullptr; }
+        *dev = (const T*)(base + hoff); T* h = (T*)(hbase + hoff); hoff += b; hold = true; return h; }
+    void commit(hipStream_t st) { hold = false; if (hoff - flushed >= ((size_t)4 << 20)) flush(st); }
+    void flush(hipStream_t st) { if (hold) return; if (hoff > flushed) { if (hipMemcpyAsync(base + flushed, hbase + flushed, hoff - flushed, hipMemcpyHostToDevice, st) != hipSuccess) failed = true; flushed = hoff; } }
 };
 }
 
@@ -2825,6 +2878,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     for (int h = 0; h < n_H; h++) memcpy(poses.data() + (size_t)perm[p.n_cam + h] * 12, dynp->H_T + (size_t)h * 12, 12 * sizeof(double));
     phase("factors, pose order");
     // ---- host preprocessing: keep this shard's observations, sort by camera, build the landmark-major slots
+    HostPool::world_hint() = std::max(HostPool::world_hint(), p.world);
     HostPool& HP = HostPool::get();
     const bool par = !DI && p.n_obs >= 200000 && HP.size() > 1;      // the same tables either way; see HostPool
     std::vector<int>& keep = BS->hv_i[0]; keep.clear();
@@ -2860,40 +2914,6 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     }
     phase("filter + sort by camera");
     const int nh = DI ? 0 : no;                              // host-side observation arrays (none when the inputs are device-resident)
-    std::vector<int>&ocam = BS->hv_i[3], &opt = BS->hv_i[4], &opos = BS->hv_i[5], &slotcam = BS->hv_i[6]; std::vector<int> pstart(n_ptl + 1, 0);
-    ocam.resize(nh); opt.resize(nh); opos.resize(nh); slotcam.resize(nh);      // (every element is written below)
-    std::vector<double>& omeas = BS->hv_d; omeas.resize((size_t)nh * 3);
-    int maxk = 0;
-    if (par) {
-        HP.chunks((size_t)nh, [&](size_t lo, size_t hi, int) { for (size_t t = lo; t < hi; t++) { const int k = keep[t]; ocam[t] = perm[p.obs_cam[k]]; opt[t] = p.obs_pt[k] - pt_lo;
-                                                                 for (int a = 0; a < 3; a++) omeas[3 * t + a] = p.obs_meas[3 * (size_t)k + a]; } });
-        // the slots of a landmark in ascending camera order = the stable order of the camera-sorted list by landmark
-        par_counting_rank(HP, (size_t)nh, n_ptl, [&](size_t t) { return opt[t]; }, opos.data(), pstart);
-        HP.chunks((size_t)nh, [&](size_t lo, size_t hi, int) { for (size_t t = lo; t < hi; t++) slotcam[opos[t]] = ocam[t]; });
-        std::vector<int> mk(HP.size(), 0);
-        HP.chunks((size_t)n_ptl, [&](size_t lo, size_t hi, int t) { int m = 0; for (size_t l = lo; l < hi; l++) m = std::max(m, pstart[l + 1] - pstart[l]); mk[t] = m; });
-        for (int m : mk) maxk = std::max(maxk, m);
-    } else {
-        for (int t = 0; t < nh; t++) { const int k = keep[t]; ocam[t] = perm[p.obs_cam[k]]; opt[t] = p.obs_pt[k] - pt_lo; for (int a = 0; a < 3; a++) omeas[3 * (size_t)t + a] = p.obs_meas[3 * (size_t)k + a]; pstart[opt[t] + 1]++; }
-        for (int l = 0; l < n_ptl; l++) { maxk = std::max(maxk, pstart[l + 1]); pstart[l + 1] += pstart[l]; }
-        { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (int t = 0; t < nh; t++) { opos[t] = fill[opt[t]]++; slotcam[opos[t]] = ocam[t]; } }
-    }
-    if (DI) maxk = DI->kcap;                                 // (a landmark of the window has at most one observation per keyframe)
-    // the Schur kernels add WD_i W_j^T for slot pairs i >= j into the LOWER triangle and assume the slots of a landmark belong to distinct cameras (for two
-    // slots of one camera the transposed term would be missing); the observations are sorted by camera, so duplicates are adjacent slots
-    std::vector<int> long_list;                             // landmarks with more than 64 observations: k_ba_schur_long
-    if (!DI) {
-        std::vector<int> dup(HP.size(), -1); std::vector<std::vector<int> > longs(HP.size());
-        auto scan = [&](size_t lo, size_t hi, int t) { for (size_t l = lo; l < hi; l++) {
-            for (int q = pstart[l] + 1; q < pstart[l + 1]; q++) if (slotcam[q] == slotcam[q - 1] && dup[t] < 0) dup[t] = (int)l;
-            if (pstart[l + 1] - pstart[l] > 64) longs[t].push_back((int)l); } };
-        if (par) HP.chunks((size_t)n_ptl, scan); else scan(0, (size_t)n_ptl, 0);
-        for (int t = 0; t < HP.size(); t++) if (dup[t] >= 0) { const int l = dup[t]; int q = pstart[l] + 1; while (slotcam[q] != slotcam[q - 1]) q++;
-            return vido_set_error(ctx, VIDO_E_INVALID, "ba: landmark %d is observed twice from camera %d (merge duplicate observations first)", l + pt_lo, slotcam[q]); }
-        for (auto& v : longs) long_list.insert(long_list.end(), v.begin(), v.end());
-    }
-    maxk = std::min(maxk, 64);
-    phase("slot tables, checks");
     // ---- device buffers
     size_t up_this = 0;                                      // upload bytes of THIS call (estimate with slack): the mirrored region of the arena
     {   // size the persistent pool (device + pinned mirror for the uploads) for this problem
@@ -2928,13 +2948,50 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     D.info_obs = p.info_obs; D.info_odo = p.info_odo; D.info_prior = p.info_prior; D.huber_obs = p.huber_obs; D.huber_odo = p.huber_odo;
     memcpy(D.prior_T, p.prior_T, sizeof D.prior_T);
     D.cam = A.put(poses.data(), (size_t)n_pose * 12, st); D.cam_new = A.get<double>((size_t)n_pose * 12);
+    std::vector<int>&ocam = BS->hv_i[3], &opt = BS->hv_i[4], &opos = BS->hv_i[5], &slotcam = BS->hv_i[6]; std::vector<int> pstart(n_ptl + 1, 0);
+    ocam.resize(nh); opt.resize(nh); opos.resize(nh); slotcam.resize(nh);      // (every element is written below)
+    // the measurements (24 MB at 1 M observations) are gathered straight into the pinned stage: as a vector of their own they were written once and copied once more
+    const double* d_omeas = nullptr; double* omeas = DI ? nullptr : A.stage<double>((size_t)nh * 3, &d_omeas);
+    if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: upload staging exhausted");
+    int maxk = 0;
+    if (par) {
+        HP.chunks((size_t)nh, [&](size_t lo, size_t hi, int) { for (size_t t = lo; t < hi; t++) { const int k = keep[t]; ocam[t] = perm[p.obs_cam[k]]; opt[t] = p.obs_pt[k] - pt_lo;
+                                                                 for (int a = 0; a < 3; a++) omeas[3 * t + a] = p.obs_meas[3 * (size_t)k + a]; } });
+        A.commit(st);                                          // (the measurements leave for the device while the slot tables are built)
+        // the slots of a landmark in ascending camera order = the stable order of the camera-sorted list by landmark
+        par_counting_rank_large(HP, (size_t)nh, n_ptl, [&](size_t t) { return opt[t]; }, opos.data(), pstart, BS->hv_i[2]);      // (hv_i[2]: the camera sort's rank array, free again)
+        HP.chunks((size_t)nh, [&](size_t lo, size_t hi, int) { for (size_t t = lo; t < hi; t++) slotcam[opos[t]] = ocam[t]; });
+        std::vector<int> mk(HP.size(), 0);
+        HP.chunks((size_t)n_ptl, [&](size_t lo, size_t hi, int t) { int m = 0; for (size_t l = lo; l < hi; l++) m = std::max(m, pstart[l + 1] - pstart[l]); mk[t] = m; });
+        for (int m : mk) maxk = std::max(maxk, m);
+    } else {
+        for (int t = 0; t < nh; t++) { const int k = keep[t]; ocam[t] = perm[p.obs_cam[k]]; opt[t] = p.obs_pt[k] - pt_lo; for (int a = 0; a < 3; a++) omeas[3 * (size_t)t + a] = p.obs_meas[3 * (size_t)k + a]; pstart[opt[t] + 1]++; }
+        for (int l = 0; l < n_ptl; l++) { maxk = std::max(maxk, pstart[l + 1]); pstart[l + 1] += pstart[l]; }
+        { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (int t = 0; t < nh; t++) { opos[t] = fill[opt[t]]++; slotcam[opos[t]] = ocam[t]; } }
+    }
+    if (DI) maxk = DI->kcap;                                 // (a landmark of the window has at most one observation per keyframe)
+    // the Schur kernels add WD_i W_j^T for slot pairs i >= j into the LOWER triangle and assume the slots of a landmark belong to distinct cameras (for two
+    // slots of one camera the transposed term would be missing); the observations are sorted by camera, so duplicates are adjacent slots
+    std::vector<int> long_list;                             // landmarks with more than 64 observations: k_ba_schur_long
+    if (!DI) {
+        std::vector<int> dup(HP.size(), -1); std::vector<std::vector<int> > longs(HP.size());
+        auto scan = [&](size_t lo, size_t hi, int t) { for (size_t l = lo; l < hi; l++) {
+            for (int q = pstart[l] + 1; q < pstart[l + 1]; q++) if (slotcam[q] == slotcam[q - 1] && dup[t] < 0) dup[t] = (int)l;
+            if (pstart[l + 1] - pstart[l] > 64) longs[t].push_back((int)l); } };
+        if (par) HP.chunks((size_t)n_ptl, scan); else scan(0, (size_t)n_ptl, 0);
+        for (int t = 0; t < HP.size(); t++) if (dup[t] >= 0) { const int l = dup[t]; int q = pstart[l] + 1; while (slotcam[q] != slotcam[q - 1]) q++;
+            return vido_set_error(ctx, VIDO_E_INVALID, "ba: landmark %d is observed twice from camera %d (merge duplicate observations first)", l + pt_lo, slotcam[q]); }
+        for (auto& v : longs) long_list.insert(long_list.end(), v.begin(), v.end());
+    }
+    maxk = std::min(maxk, 64);
+    phase("slot tables, checks");
     if (DI) {                                                // observations, landmarks and their index tables are already on the device
         D.pt = DI->pt; D.pt_new = A.get<double>((size_t)n_ptl * 3);
         D.obs_cam = DI->obs_cam; D.obs_pt = DI->obs_pt; D.obs_pos = DI->obs_pos; D.obs_meas = DI->obs_meas; D.pt_start = DI->pt_start; D.slot_cam = DI->slot_cam;
     } else {
     D.pt = A.put(p.pt_xyz + 3 * (size_t)pt_lo, (size_t)n_ptl * 3, st); D.pt_new = A.get<double>((size_t)n_ptl * 3);
     D.obs_cam = A.put(ocam.data(), no, st); D.obs_pt = A.put(opt.data(), no, st); D.obs_pos = A.put(opos.data(), no, st);
-    D.obs_meas = A.put(omeas.data(), (size_t)no * 3, st); D.pt_start = A.put(pstart.data(), n_ptl + 1, st); D.slot_cam = A.put(slotcam.data(), no, st);
+    A.commit(st); D.obs_meas = d_omeas; D.pt_start = A.put(pstart.data(), n_ptl + 1, st); D.slot_cam = A.put(slotcam.data(), no, st);
     }
     phase("staging copies (obs, points)");
     D.odo_i = A.put(cc_i.data(), n_cc, st); D.odo_j = A.put(cc_j.data(), n_cc, st); D.odo_T = A.put(cc_T.data(), (size_t)n_cc * 12, st);
