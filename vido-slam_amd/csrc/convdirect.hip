@@ -14,7 +14,8 @@
 //     channel pairs.  Consecutive lanes = consecutive pixels: a load is one or two cache lines (stride 1), the 49 taps of the stem re-read the same lines from L1.
 //   * A (the weights): packed on the host in operand order [channel block][tap][channel pair][64 lanes], one coalesced 256-byte load per matrix instruction, the same
 //     sequence for every wave (L1 / L2 resident).
-// Loads run U channel pairs ahead of the matrix instructions inside a wave; several waves per SIMD (the kernel needs < 128 registers) cover the rest of the latency.
+// Loads run two steps (2 U channel pairs) ahead of the matrix instructions inside a wave (three operand register sets); several waves per SIMD (the kernel needs < 128
+// registers) cover the rest of the latency on the large maps.
 // Bias, activation and the stores (a lane holds 16 channels of its pixel; for one channel 32 lanes store 128 consecutive bytes) are register work.
 #include "common.hpp"
 
@@ -53,17 +54,20 @@ __global__ __launch_bounds__(256) void k_conv_direct(CdArgs A)
         for (int q = 0; q < 16; q++) acc[i][q] = 0.f;
     const int cpr = A.cpr, cpp = A.cpp, nmain = ((A.Cin >> 1) / U) * U;                   // real / padded channel pairs; pairs of the unmasked steps
     const unsigned cstep = 8u * (unsigned)hw;                                             // bytes between channel pairs
-    unsigned wso = 4u * 64u * (unsigned)(cg * CBW * T * cpp);                             // byte offset of (first channel block of the wave, tap 0, pair 0)
-    const unsigned wblk = 4u * 64u * (unsigned)(T * cpp);                                 // channel block stride
-#pragma unroll
-    for (int t = 0; t < T; t++) {
+    const unsigned wblk = 4u * 64u * (unsigned)(T * cpp);                                 // channel block stride of the packed weight
+    // The K loop is a flat sequence of steps (tap-major, U channel pairs each); the operands of a step are loaded TWO steps ahead of its matrix instructions into one of
+    // three register sets, so that a wave alone on its SIMD (the small maps: fewer waves than SIMDs) still has its loads in flight under 2 U CBW matrix instructions.
+    // State of the loader: tap, channel pair, the tap's per-lane offset, the scalar offsets of input and weight.
+    int lt = 0, lcp = 0;
+    unsigned xso = 0u, wsc = 4u * 64u * (unsigned)(cg * CBW * T * cpp);
+    auto tap_off = [&](int t) -> unsigned {
         const int ky = t / KW, kx = t - ky * KW;
         const bool tv = pv && (unsigned)(iy0 + ky) < (unsigned)A.H && (unsigned)(ix0 + kx) < (unsigned)A.W;
-        const unsigned vt = tv ? (unsigned)(vbase + 4 * (ky * A.W + kx)) : CD_OOB;
-        // main steps: U pairs of real channels each — the per-lane offset is the tap's, the scalar offset walks the channels, no vector instruction but the loads
-        unsigned xso = 0u, wsc = wso;
-        for (int cp = 0; cp < nmain; cp += U) {
-            float b[U], a[CBW][U];
+        return tv ? (unsigned)(vbase + 4 * (ky * A.W + kx)) : CD_OOB;
+    };
+    unsigned vt = tap_off(0);
+    auto load_step = [&](float (&b)[U], float (&a)[CBW][U]) {
+        if (lcp < nmain) {                                                                // U pairs of real channels: the per-lane offset is the tap's, everything else scalar
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 b[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vt, xso + (unsigned)u * cstep, 0));
@@ -71,30 +75,42 @@ __global__ __launch_bounds__(256) void k_conv_direct(CdArgs A)
                 for (int i = 0; i < CBW; i++)
                     a[i][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, wl, wsc + (unsigned)i * wblk + 256u * (unsigned)u, 0));
             }
-#pragma unroll
-            for (int u = 0; u < U; u++)
-#pragma unroll
-                for (int i = 0; i < CBW; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[u], acc[i], 0, 0, 0);
-            xso += (unsigned)U * cstep; wsc += 256u * (unsigned)U;
-        }
-        if (nmain < cpp) {                                                                // the last step of a channel count that is not a multiple of 2 U: masked
-            float b[U], a[CBW][U];
+        } else {                                                                          // the last step of a channel count that is not a multiple of 2 U: masked
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int c = nmain + u;                                                  // (scalar)
+                const int c = lcp + u;                                                    // (scalar)
                 // pairs past the real ones (padding of the packed weight) read through voffset = out of range; the last real pair of an odd Cin masks its odd lanes
                 const unsigned vo = c >= cpr ? CD_OOB : (c == cpr - 1 ? (vt | odd_oob) : vt);
                 b[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vo, cstep * (unsigned)min(c, cpr - 1), 0));
 #pragma unroll
                 for (int i = 0; i < CBW; i++)
-                    a[i][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, wl, wso + (unsigned)i * wblk + 256u * (unsigned)c, 0));
+                    a[i][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, wl, wsc + (unsigned)i * wblk + 256u * (unsigned)u, 0));
             }
-#pragma unroll
-            for (int u = 0; u < U; u++)
-#pragma unroll
-                for (int i = 0; i < CBW; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[u], acc[i], 0, 0, 0);
         }
-        wso += 256u * (unsigned)cpp;
+        lcp += U; xso += (unsigned)U * cstep; wsc += 256u * (unsigned)U;                  // (the taps of a channel block follow each other in the packed weight)
+        if (lcp >= cpp) { lcp = 0; xso = 0u; lt++; vt = tap_off(min(lt, T - 1)); }
+    };
+    auto mma = [&](const float (&b)[U], const float (&a)[CBW][U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int i = 0; i < CBW; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[u], acc[i], 0, 0, 0);
+    };
+    const int S = T * (cpp / U);
+    float b0[U], a0[CBW][U], b1[U], a1[CBW][U], b2[U], a2[CBW][U];
+    load_step(b0, a0);
+    if (S > 1) load_step(b1, a1);
+    for (int st = 0; st < S; st += 3) {
+        if (st + 2 < S) load_step(b2, a2);
+        mma(b0, a0);
+        if (st + 1 < S) {
+            if (st + 3 < S) load_step(b0, a0);
+            mma(b1, a1);
+            if (st + 2 < S) {
+                if (st + 4 < S) load_step(b1, a1);
+                mma(b2, a2);
+            }
+        }
     }
     if (!pv) return;
     // D: register q of a lane = output channel 8 (q / 4) + 4 (lane >> 5) + (q & 3) of the block, pixel lane & 31

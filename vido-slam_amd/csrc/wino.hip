@@ -22,6 +22,20 @@
 //     and the mask head's per-detection 14x14 maps are just more tiles.  Input channels are padded to KC with zero weights, output channels to 32.
 // Work items (tile block, channel block) are dealt so that an XCD walks a contiguous range with the channel block fastest (the blocks that share input windows run back to
 // back on one L2).
+//
+// K-split form (KSPL; round 5) for launches whose tile form would leave most of the chip idle (fewer than 128 workgroups: FPN P4-P6, LiteFlowNet's levels 3-6).  A wave of the
+// tile form walks ALL input channels of its 32 x 32 outputs at one wave per SIMD, so a 16-workgroup launch runs as long as a chip-filling one.  Here a workgroup is 32
+// channels x 32 tiles and its four waves take the 4-channel chunks w, w + 4, ... with a full set of sixteen accumulators each (the 1 x 4 form with its four tile blocks
+// re-read as four channel slices, KC = 4 packing for every cout); the inverse transform is linear, so every wave transforms its own partial M, waves 1-3 leave 64 floats a
+// lane in LDS and wave 0 adds them in a fixed order before the activation.  Four times the waves, a quarter of the chain each: FPN P4 73 -> 39 us, flow level 4 57 -> 34 us
+// (library + its bias pass: 53 / 42; profiles/r5/wino_ksplit_microbench.txt).
+// What bounds it: every wave pulls its OWN U block — 8 KB per 32 matrix instructions (0.98 us) per wave, 8.6 TB/s over 1024 waves: the L2's rate, where the tile forms share
+// a U block among 2-4 tile blocks through LDS.  Tried and dropped (same file, round 5): a barrier-free variant (the lane that transforms a window IS the lane that holds that
+// B operand, so V can stay in registers and U be read straight into operand registers: no LDS, no barrier in the loop) — slower on every shape (P4 53 us, level 5 50 vs 46):
+// the barrier was never the bound, the U traffic is, and register loads of U are slower than the asynchronous LDS copies.  Two compiler traps met on the way, kept here for
+// the next kernel: (1) __builtin_amdgcn_raw_buffer_load_b64 / _b128 whose result is bit-cast ELEMENT by element is shrunk to a 4-byte load (bit-cast the whole vector);
+// (2) a vector register written by INLINE-ASSEMBLY v_pk_add_f32 and read as the B operand of the next matrix instruction gets no wait states from the hazard recognizer
+// (it does not look inside inline assembly): wrong sums in one template instance, right in the other — an explicit s_nop 1 in the asm string fixes it.
 #include "common.hpp"
 
 namespace {

@@ -8,6 +8,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 LEAK = 0.1
+_LFN_NO_WINO = bool(os.environ.get("VIDO_LFN_NO_WINO"))      # experiment: the flow network's dense 3x3 layers on the library's vector-ALU Winograd kernels
 #            level: (feature channels, backwarp scale, last-conv kernel, subpixel in-ch, regular. in-ch, dist channels)
 LEVELS = {2: (32, 10.0, 7, 130, 131, 49), 3: (64, 5.0, 5, 130, 131, 25), 4: (96, 2.5, 5, 194, 131, 25), 5: (128, 1.25, 3, 258, 131, 9), 6: (192, 0.625, 3, 386, 195, 9)}
 MEAN_FIRST = (0.411618, 0.434631, 0.454253)
@@ -37,7 +38,7 @@ class _Chain(nn.Sequential):
                     if y is not None:
                         x = y; i += 2 if act else 1
                         continue
-                if self.wino is not None and (act or i + 1 >= len(mods)):
+                if self.wino is not None and (act or i + 1 >= len(mods)) and not _LFN_NO_WINO:
                     y = self.wino.wino3x3_conv(m, x, LEAK if act else 1.0)
                     if y is not None:
                         x = y; i += 2 if act else 1

@@ -6,6 +6,11 @@ import os
 import torch
 
 _WINO_MIN_WGS = int(os.environ.get("VIDO_WINO_MIN_WGS", "0"))
+# which layers conv_direct_conv takes: "all", or "novalu" (default) = not the 7x7 stem / stride-2 3x3 layers, which the library runs as Winograd on the VECTOR ALUs — beside
+# the detector (whose convolutions saturate the MATRIX pipe) those run in its shadow, while the direct kernel competes for the matrix pipe.  Measured (two pairs of 100
+# steps, profiles/r5/convdirect_ab.txt): headline 90.3 frames/s without the direct kernel, 89.4 with it on every layer (LiteFlowNet alone 3.85 -> 3.65 ms), 90.6 with
+# "novalu" (3.76 ms alone).  The same trade does NOT extend to the dense 3x3 layers: LiteFlowNet on the library's vector-ALU Winograd throughout gives 82 frames/s.
+_CONVDIRECT_SET = os.environ.get("VIDO_CONVDIRECT_SET", "novalu")
 
 
 def correlation_torch_reference(first, second, stride):
@@ -283,6 +288,8 @@ class HipOps:
         the matrix pipe, else None.  The packed weight is cached on the module and rebuilt when the weight tensor changes."""
         w = conv.weight
         kh, kw = int(w.shape[2]), int(w.shape[3]); sh, sw = (int(v) for v in conv.stride); ph, pw = (int(v) for v in conv.padding)
+        if _CONVDIRECT_SET == "novalu" and (kh, kw) in ((3, 3), (7, 7)) and int(w.shape[0]) >= 32:
+            return None                                                       # layers the library runs as Winograd on the VECTOR ALUs (see _CONVDIRECT_SET)
         if (tuple(conv.dilation) != (1, 1) or conv.groups != 1 or getattr(conv, "padding_mode", "zeros") != "zeros" or not x.is_cuda or x.dtype != torch.float32
                 or not self.ctx.lib.vido_conv_direct_supported(int(w.shape[1]), int(w.shape[0]), int(x.shape[2]), int(x.shape[3]), kh, kw, sh, sw, ph, pw)
                 or 4 * x.numel() >= 1 << 30):
