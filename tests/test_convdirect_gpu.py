@@ -15,6 +15,12 @@ def ctx(vido):
     c.close()
 
 
+@pytest.fixture(autouse=True)
+def every_layer(monkeypatch):
+    """the kernel on every layer it has an instance for (the callers' default leaves the 7x7 stem and the stride-2 3x3 layers to the library: nets/ops.py _CONVDIRECT_SET)"""
+    monkeypatch.setattr("vido_slam_amd.nets.ops._CONVDIRECT_SET", "all")
+
+
 SHAPES = [  # (N, cin, cout, H, W, (kh, kw), (sh, sw)): the layers of LiteFlowNet at 480 x 640 scaled down where the map is large, ragged sizes, odd channel counts, batches
     (2, 3, 32, 40, 56, (7, 7), (1, 1)), (2, 32, 32, 48, 64, (3, 3), (2, 2)), (1, 32, 64, 30, 40, (3, 3), (2, 2)), (2, 64, 96, 30, 40, (3, 3), (2, 2)), (1, 96, 128, 15, 20, (3, 3), (2, 2)),
     (2, 128, 192, 16, 20, (3, 3), (2, 2)), (1, 32, 49, 24, 32, (7, 1), (1, 1)), (1, 49, 49, 24, 32, (1, 7), (1, 1)), (1, 32, 25, 30, 40, (5, 1), (1, 1)), (1, 25, 25, 30, 40, (1, 5), (1, 1)),
@@ -74,3 +80,14 @@ def test_conv_direct_follows_a_weight_update(vido, ctx):
         conv.weight.mul_(-0.5); conv.bias.add_(1.0)
         y1 = ops.conv_direct_conv(conv, x, 0.1)
         assert float((y1 - F.leaky_relu(conv(x), 0.1)).abs().max()) < 1e-4 and float((y1 - y0).abs().max()) > 1e-2
+
+
+def test_default_set_leaves_the_vector_alu_winograd_layers_to_the_library(vido, ctx, monkeypatch):
+    """beside the detector the stem and the stride-2 3x3 layers run faster on the library's vector-ALU Winograd kernels (profiles/r5/convdirect_ab.txt): the default set"""
+    from vido_slam_amd.nets.ops import HipOps
+    monkeypatch.setattr("vido_slam_amd.nets.ops._CONVDIRECT_SET", "novalu")
+    ops = HipOps(ctx)
+    assert ops.conv_direct_conv(torch.nn.Conv2d(3, 32, 7, 1, 3).cuda(), torch.zeros(1, 3, 16, 16, device="cuda"), 0.1) is None
+    assert ops.conv_direct_conv(torch.nn.Conv2d(32, 64, 3, 2, 1).cuda(), torch.zeros(1, 32, 16, 16, device="cuda"), 0.1) is None
+    assert ops.conv_direct_conv(torch.nn.Conv2d(32, 49, (7, 1), 1, (3, 0)).cuda(), torch.zeros(1, 32, 16, 16, device="cuda"), 1.0) is not None
+    assert ops.conv_direct_conv(torch.nn.Conv2d(32, 9, 3, 1, 1).cuda(), torch.zeros(1, 32, 16, 16, device="cuda"), 1.0) is not None
