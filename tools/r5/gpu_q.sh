@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 5, call q: full-size parity + Winograd parity after the per-form weight cache; headline A/B of the K-split form against the round-4 rule
 set -u
 OUT=gpurun_out/r5q; mkdir -p $OUT
 timeout 900 python -m pytest tests/test_fullsize_gpu.py tests/test_wino_gpu.py -x -q 2>&1 | tail -4 | tee $OUT/pytest.txt
