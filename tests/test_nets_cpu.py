@@ -286,3 +286,35 @@ def test_pack_wino3x3_operands_reproduce_the_convolution():
                 y[:, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum("ij,ojk,lk->oil", At, M, At)
         ref = F.conv2d(x.double(), w.double(), None, 1, 1)[0].numpy()
         assert np.abs(y[:, :H, :W] - ref).max() < 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_pack_conv_direct_operands_reproduce_the_convolution():
+    """vido_conv_direct_pack (host side of csrc/convdirect.hip): element (co, c, tap) at [co / 32][tap][c / 2][32 * (c & 1) + co % 32], channel pairs of a tap padded to the
+    kernel's step (2 pairs for 25 / 49 taps, 4 otherwise), channel blocks to an even count.  A numpy walk of the kernel's data path — per (tap, channel pair) a 32 x 2
+    weight operand times the 2 x pixels patch rows, zero padding outside the image — must be conv2d (float64 reference), for strides, odd channel counts, ragged sizes."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from vido_slam_amd.nets.ops import pack_conv_direct
+    from vido_slam_amd.host import load_library
+    lib = load_library()
+    lib.vido_conv_direct_packed_floats.restype = C.c_longlong
+    g = torch.Generator().manual_seed(5)
+    for cout, cin, H, W, k, s in ((32, 3, 9, 11, (7, 7), (1, 1)), (49, 32, 6, 8, (7, 1), (1, 1)), (70, 7, 7, 9, (3, 3), (2, 2)), (9, 32, 5, 6, (3, 3), (1, 1)), (1, 9, 4, 5, (1, 1), (1, 1)), (25, 25, 5, 7, (1, 5), (1, 1))):
+        kh, kw = k; ph, pw = kh // 2, kw // 2; T = kh * kw
+        w = torch.randn(cout, cin, kh, kw, generator=g); x = torch.randn(1, cin, H, W, generator=g)
+        wp = pack_conv_direct(w).numpy()
+        U = 2 if T >= 25 else 4
+        cpr = (cin + 1) // 2; cpp = -(-cpr // U) * U; cb = -(-cout // 32); cbp = 1 if cb == 1 else -(-cb // 2) * 2
+        assert wp.size == int(lib.vido_conv_direct_packed_floats(cin, cout, kh, kw)) == 64 * cbp * T * cpp
+        wp = wp.reshape(cbp, T, cpp, 2, 32)                                                    # [block][tap][pair][channel parity][co % 32]
+        assert lib.vido_conv_direct_supported(cin, cout, H, W, kh, kw, s[0], s[1], ph, pw) == 1
+        Ho, Wo = (H + 2 * ph - kh) // s[0] + 1, (W + 2 * pw - kw) // s[1] + 1
+        xp = np.zeros((2 * cpp, H + 2 * ph, W + 2 * pw)); xp[:cin, ph:ph + H, pw:pw + W] = x[0].double().numpy()
+        y = np.zeros((cbp * 32, Ho, Wo))
+        for t in range(T):
+            ky, kx = divmod(t, kw)
+            patch = xp[:, ky:ky + s[0] * Ho:s[0], kx:kx + s[1] * Wo:s[1]].reshape(cpp, 2, Ho, Wo)     # [pair][parity][oy][ox]
+            y += np.einsum("bpqo,pqyx->boyx", wp[:, t].astype(np.float64), patch).reshape(cbp * 32, Ho, Wo)
+        ref = F.conv2d(x.double(), w.double(), None, s, (ph, pw))[0].numpy()
+        assert np.all(y[cout:] == 0) and np.abs(y[:cout] - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), (cout, cin, k, s)
+    assert lib.vido_conv_direct_supported(8, 8, 8, 8, 3, 5, 1, 1, 1, 2) == 0 and lib.vido_conv_direct_packed_floats(8, 8, 3, 5) == 0

@@ -216,3 +216,25 @@ def test_depth_noise_is_one_draw_of_a_fresh_rng_per_call():
     # one seed = one offset: the relative perturbation grows with z (sigma = 0.15 z^2 / 362.5), and a second's worth of calls shares it
     a = [lib.vido_depth_noise(z, 1758900000) - z for z in (5.0, 10.0, 20.0)]
     assert abs(a[1] / a[0] - 4.0) < 1e-3 and abs(a[2] / a[0] - 16.0) < 1e-3
+
+
+@pytest.mark.parametrize("n,nbins,seed", [(0, 5, 0), (1, 1, 1), (1000, 7, 2), (50000, 1024, 3), (200000, 1025, 4), (300000, 100000, 5), (4096, 70000, 6)])
+def test_stable_rank_of_the_ba_setup_equals_a_stable_argsort(n, nbins, seed):
+    """vido_debug_stable_rank (csrc/ba.hip: par_counting_rank / par_counting_rank_large on the set-up's host pool): what sorts a global bundle adjustment's observation
+    list by camera (500 bins, one level) and by landmark (100 k bins, two levels).  pos[i] must be the rank of i in a STABLE sort by key, bin_start the first rank of each
+    key — the order of a landmark's slots (ascending camera) depends on the stability."""
+    import ctypes as C
+    from vido_slam_amd.host import load_library
+    lib = load_library()
+    rng = np.random.default_rng(seed)
+    keys = (rng.integers(0, nbins, n) if n else np.zeros(0)).astype(np.int32)
+    if n > 10:
+        keys[: n // 3] = keys[0]                                   # a heavy bin and many empty ones
+    pos = np.full(n, -1, np.int32); bs = np.full(nbins + 1, -1, np.int32)
+    assert lib.vido_debug_stable_rank(C.c_void_p(keys.ctypes.data), n, nbins, C.c_void_p(pos.ctypes.data), C.c_void_p(bs.ctypes.data)) == 0
+    order = np.argsort(keys, kind="stable")
+    ref = np.empty(n, np.int32); ref[order] = np.arange(n, dtype=np.int32)
+    assert np.array_equal(pos, ref)
+    assert np.array_equal(bs, np.concatenate([[0], np.cumsum(np.bincount(keys, minlength=nbins))]).astype(np.int32))
+    bad = np.array([0, nbins], np.int32)
+    assert lib.vido_debug_stable_rank(C.c_void_p(bad.ctypes.data), 2, nbins, C.c_void_p(pos.ctypes.data), C.c_void_p(bs.ctypes.data)) != 0      # a key outside [0, nbins)

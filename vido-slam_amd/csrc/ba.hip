@@ -2691,6 +2691,19 @@ static void par_memcpy(HostPool& P, void* dst, const void* src, size_t bytes)
     if (bytes & 63) memcpy((char*)dst + (bytes & ~(size_t)63), (const char*)src + (bytes & ~(size_t)63), bytes & 63);
 }
 
+}  // namespace
+/* HOST-only test hook (tests/test_trackhost_cpu.py): the stable ranking the BA set-up sorts its observation list with — pos[i] = rank of element i among the n elements
+ * ordered by (key, i), bin_start[b] = first rank of key b (nbins + 1 entries) — on the set-up's own thread pool; two-level when nbins > 1024. */
+extern "C" int vido_debug_stable_rank(const int* keys, int n, int nbins, int* pos, int* bin_start)
+{
+    if (!keys || !pos || !bin_start || n < 0 || nbins < 1) return VIDO_E_INVALID;
+    for (int i = 0; i < n; i++) if (keys[i] < 0 || keys[i] >= nbins) return VIDO_E_INVALID;
+    std::vector<int> bs, scratch;
+    par_counting_rank_large(HostPool::get(), (size_t)n, nbins, [&](size_t i) { return keys[i]; }, pos, bs, scratch);
+    memcpy(bin_start, bs.data(), sizeof(int) * (size_t)(nbins + 1));
+    return VIDO_OK;
+}
+namespace {
 struct Arena {                       // bump allocator over the ctx's persistent BA pool (no hipMalloc per call).  The pool's first `up_cap` bytes MIRROR the pinned stage:
     char* base; size_t cap; size_t off = 0; bool failed = false;   // an uploaded array lives at the same offset on both sides, so the uploads of a call leave as ONE copy (flush) —
     char* hbase; size_t hcap = 0, hoff = 0;                        // the local window used to enqueue nine 100-byte copies per solve, each a stream operation that queues behind the
