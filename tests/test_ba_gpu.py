@@ -197,6 +197,23 @@ def test_configs4_full_size_500_keyframes_100k_landmarks(vido, oracle, ctx):
         assert rel(o["pt_xyz"][lo:hi], got["pt_xyz"][lo:hi]) < 1e-8
 
 
+@pytest.mark.parametrize("n_cam,n_pt", [(60, 3000), (300, 30000)])
+def test_observation_order_does_not_matter(vido, ctx, n_cam, n_pt):
+    """The set-up sorts the observation list by camera — and skips the sort when the list arrives in camera order, as a SLAM map's does (csrc/ba.hip `in_order`).  The same
+    graph with its observations SHUFFLED (the sort runs; above 200 k observations on the host pool) and in landmark-major order must give the same solve; the slot order of a
+    landmark (ascending camera) is what the stable sorts guarantee, so the results agree to rounding of the order-independent sums."""
+    pr = vido.problems.synth_ba_problem(n_cam=n_cam, n_pt=n_pt, kind="global", track_len=10, seed=23); pr["max_iters"] = 4
+    assert np.all(np.diff(pr["obs_cam"]) >= 0)                      # the generator emits camera-major lists: the in-order path
+    ref = vido.ba_optimize(ctx, pr)
+    rng = np.random.default_rng(5)
+    for order in (rng.permutation(len(pr["obs_cam"])), np.lexsort((pr["obs_cam"], pr["obs_pt"]))):
+        q = dict(pr); q["obs_cam"] = np.ascontiguousarray(pr["obs_cam"][order]); q["obs_pt"] = np.ascontiguousarray(pr["obs_pt"][order]); q["obs_meas"] = np.ascontiguousarray(pr["obs_meas"][order])
+        got = vido.ba_optimize(ctx, q)
+        assert (got["iterations"], got["lm_trials"]) == (ref["iterations"], ref["lm_trials"])
+        assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-9 * ref["chi2_final"]
+        assert rel(got["cam_T"], ref["cam_T"]) < 1e-9 and rel(got["pt_xyz"], ref["pt_xyz"]) < 1e-9
+
+
 def test_malformed_problem_is_rejected(vido, ctx):
     pr = vido.problems.synth_ba_problem(n_cam=4, n_pt=50, seed=1)
     pr["obs_cam"] = pr["obs_cam"].copy(); pr["obs_cam"][0] = 99
