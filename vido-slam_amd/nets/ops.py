@@ -9,7 +9,9 @@ _WINO_MIN_WGS = int(os.environ.get("VIDO_WINO_MIN_WGS", "0"))
 # which layers conv_direct_conv takes: "all", or "novalu" (default) = not the 7x7 stem / stride-2 3x3 layers, which the library runs as Winograd on the VECTOR ALUs — beside
 # the detector (whose convolutions saturate the MATRIX pipe) those run in its shadow, while the direct kernel competes for the matrix pipe.  Measured (two pairs of 100
 # steps, profiles/r5/convdirect_ab.txt): headline 90.3 frames/s without the direct kernel, 89.4 with it on every layer (LiteFlowNet alone 3.85 -> 3.65 ms), 90.6 with
-# "novalu" (3.76 ms alone).  The same trade does NOT extend to the dense 3x3 layers: LiteFlowNet on the library's vector-ALU Winograd throughout gives 82 frames/s.
+# "novalu" (3.76 ms alone).  Leaving only the two miopenSp3AsmConv layers (stem, 32 -> 32 stride 2) to the library and taking the other stride-2 layers (implicit GEMM
+# in the library) gives 90.0 against 90.4: the direct kernel's matrix-pipe time costs the frame more than the library's kernels there too.  The trade does NOT extend to
+# the dense 3x3 layers: LiteFlowNet on the library's vector-ALU Winograd throughout gives 82 frames/s.
 _CONVDIRECT_SET = os.environ.get("VIDO_CONVDIRECT_SET", "novalu")
 
 
