@@ -346,7 +346,8 @@ int vido_wino3x3_pack(const float* w, int cin, int cout, float* u_packed);
 int vido_wino3x3_bias_act(vido_ctx* ctx, const float* x, const float* u_packed, const float* bias, float* y, int n, int cin, int cout, int h, int w, float slope);
 /* The two launch forms.  0: the tile form above (a wave walks ALL input channels of its 32 channels x 32 tiles).  1: the K-split form for launches that would leave most of
  * the chip idle (fewer than 128 workgroups of the tile form: FPN P4-P6, the flow network's levels 3-6): a workgroup = 32 channels x 32 tiles, its four waves take a quarter of
- * the input channels each, the partial sums meet in LDS in a fixed order.  vido_wino3x3_form: the form the library recommends for a launch (VIDO_WINO_KSPLIT=0/1 forces one);
+ * the input channels each, the partial sums meet in LDS in a fixed order.  2: two channel slices x two tile blocks per workgroup (same packing as 1).  vido_wino3x3_form: the
+ * form the library recommends for a launch (VIDO_WINO_KSPLIT=0/4/2: never / always 1 / always 2 for under-filled launches);
  * the packed weight must be of the form the launch is given (form 1 packs 4-channel chunks for every cout).  The un-suffixed entries are form 0. */
 int vido_wino3x3_form(int n, int cin, int cout, int h, int w);
 long long vido_wino3x3_packed_floats_form(int cin, int cout, int form);

@@ -26,14 +26,14 @@ SHAPES = [  # (N, cin, cout, H, W): LiteFlowNet heads at the small levels, ragge
 ]
 
 
-@pytest.mark.parametrize("form", [0, 1])
+@pytest.mark.parametrize("form", [0, 1, 2])
 @pytest.mark.parametrize("N,cin,cout,H,W", SHAPES)
 def test_wino3x3_equals_conv2d(vido, ctx, N, cin, cout, H, W, form):
     """both launch forms on every shape: the tile form (a wave walks all input channels) and the K-split form (the four waves of a workgroup share them; what under-filled
     launches take — vido_wino3x3_form)"""
     from vido_slam_amd.nets.ops import HipOps, pack_wino3x3
     ops = HipOps(ctx)
-    if form == 1 and N * cin * H * W > 40e6:
+    if form and N * cin * H * W > 40e6:
         pytest.skip("the K-split form is for small launches")
     g = torch.Generator().manual_seed(cin * 13 + cout + H)
     x = torch.randn(N, cin, H, W, generator=g); w = torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (3.0 * cin ** 0.5)); b = torch.randn(cout, generator=g)
@@ -56,7 +56,7 @@ def test_wino3x3_refuses_what_it_has_no_form_for(vido, ctx):
     conv = torch.nn.Conv2d(64, 64, 3, 2, 1).cuda()                         # stride 2: not this kernel's; the caller keeps the library path
     assert ops.wino3x3_conv(conv, torch.zeros(1, 64, 8, 8, device="cuda"), 1.0) is None
     small = torch.nn.Conv2d(64, 64, 3, 1, 1).cuda()                        # 16 tiles: one workgroup of the tile form -> the K-split form
-    assert ops.wino3x3_form(1, 64, 64, 8, 8) == 1 and ops.wino3x3_form(1, 256, 256, 200, 272) == 0 and ops.wino3x3_form(1, 256, 256, 50, 68) == 1
+    assert ops.wino3x3_form(1, 64, 64, 8, 8) == 1 and ops.wino3x3_form(1, 256, 256, 200, 272) == 0 and ops.wino3x3_form(1, 256, 256, 50, 68) == 1 and ops.wino3x3_form(1, 128, 64, 120, 160) == 2
     with torch.no_grad():
         xs = torch.randn(1, 64, 8, 8, device="cuda"); ys = ops.wino3x3_conv(small, xs, 1.0)
         assert ys is not None and float((ys - small(xs)).abs().max()) < 1e-4

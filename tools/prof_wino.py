@@ -29,8 +29,8 @@ for N, cin, cout, H, W, name in shapes:
     t1 = timed(lambda: ops.wino3x3_bias_act(x, up, b, cout, 0.1))
     line = "%-28s %d x %3d -> %3d @ %3dx%3d %6.2f GF | ours + bias + lrelu %7.1f us (%6.1f TF)" % (name, N, cin, cout, H, W, gf, t1, gf / t1 * 1e3)
     if N * cin * H * W < 40e6:                                 # the K-split form (what vido_wino3x3_form gives launches of < 128 workgroups)
-        upk = pack_wino3x3(w, 1).cuda(); tk = timed(lambda: ops.wino3x3_bias_act(x, upk, b, cout, 0.1, 1))
-        line += " | K-split %7.1f us%s" % (tk, " *" if ops.wino3x3_form(N, cin, cout, H, W) == 1 else "  ")
+        upk = pack_wino3x3(w, 1).cuda(); tk = timed(lambda: ops.wino3x3_bias_act(x, upk, b, cout, 0.1, 1)); tk2 = timed(lambda: ops.wino3x3_bias_act(x, upk, b, cout, 0.1, 2))
+        line += " | K-split x4 %7.1f us, x2 %7.1f us%s" % (tk, tk2, " *" if ops.wino3x3_form(N, cin, cout, H, W) else "  ")
     if not only:
         t_lib = timed(lambda: F.conv2d(x, w, None, 1, 1)); t_lib_ep = timed(lambda: ops.bias_act_(F.conv2d(x, w, None, 1, 1), b, 0.1))
         y = ops.wino3x3_bias_act(x, up, b, cout, 0.1); ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1), 0.1)

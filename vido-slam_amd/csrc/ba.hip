@@ -2454,7 +2454,6 @@ __global__ __launch_bounds__(64) void k_badyn_schur(BaDev P, double* __restrict_
     extern __shared__ double zs_lds[];
     const int lane = threadIdx.x;
     double* zs = (use_lds ? zs_lds : scratch + (size_t)blockIdx.x * 64 * 3 * lmax) + lane;
-    const int n6 = P.n6;
     for (int c = blockIdx.x; c < P.n_chain; c += gridDim.x) {
         const int k0 = P.chain_start[c], L = P.chain_start[c + 1] - k0;
         const int nslot = 2 * L - 1, ncol = 6 * nslot + 1;

@@ -872,7 +872,6 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
                                 const std::vector<std::vector<float> >&, const double& timestamp, cv::Mat&, const int& nImage)
 {
     const auto t_grab = std::chrono::steady_clock::now();
-    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     StopFrame = nImage - 1; ms_wait_inputs = 0;
     if (mState == NO_IMAGES_YET) f_id = 0;
     if (imD.type() != CV_32FC1 || imFlow.type() != CV_32FC2 || maskSEM.type() != CV_32SC1 || !imD.isContinuous() || !imFlow.isContinuous() || !maskSEM.isContinuous())

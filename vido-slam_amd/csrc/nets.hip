@@ -313,7 +313,6 @@ __global__ __launch_bounds__(64) void k_nms_sweep_seg(const unsigned long long* 
     unsigned long long remv[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) remv[k] = 0;
-    const int wpl = (cb + 63) >> 6;
     int cnt = 0;
     for (int blk = 0; blk < cb; blk++) {
         const int owner = blk & 63, slot = blk >> 6, rows = min(n - blk * 64, 64);

@@ -787,7 +787,7 @@ __global__ __launch_bounds__(QT_NT) void k_quadtree(const uint32_t* __restrict__
     int* newslot = pre + qcap;                           // [qcap]
     unsigned long long* keys = (unsigned long long*)(newslot + qcap);   // [qcap]
     __shared__ int wsum[QT_NT / 64];
-    __shared__ int sh_nexp, sh_fail;
+    __shared__ int sh_nexp;
     // workgroups are issued level-major, level 0 first: a (frame, level) task owns a CU's whole LDS, so a launch is two waves of workgroups on 256
     // CUs; in frame-major order both waves contain level-0 tasks (2 x the longest task), in this order the light levels fill in behind the heavy ones
     const int nfr = gridDim.x / L, l = blockIdx.x / nfr, task = (blockIdx.x - l * nfr) * L + l, tid = threadIdx.x;
@@ -801,7 +801,6 @@ __global__ __launch_bounds__(QT_NT) void k_quadtree(const uint32_t* __restrict__
     const float hX = (float)width / (float)nIni;
     if (nIni > qcap) { if (tid == 0) { atomicExch(overflow, 2); selcnt[task] = 0; } return; }
     for (int b = tid; b < nIni; b += QT_NT) { childcnt[b] = 0; }
-    if (tid == 0) sh_fail = 0;
     qt_barrier();
     for (int i = tid; i < n; i += QT_NT) {
         const int x = (int)(cd[i] & 0xfff) - minB;
@@ -1210,7 +1209,6 @@ __global__ __launch_bounds__(256) void k_orient_brief(const uint8_t* __restrict_
     const uint2 kp = kps[k];
     const int x = kp.x & 0xfff, y = (kp.x >> 12) & 0xfff, level = kp.x >> 24, f = kp.y;
     const int pitch = P.pitch[level];
-    const uint8_t* c = pyr + (size_t)f * slab + P.off[level] + (size_t)y * pitch + x;
     // IC moments over the radius-15 disc: 31 rows x 9 aligned dwords (the 31-byte row span + alignment slack) = 279 dword loads spread
     // over the lanes; the disc half-widths umax[|v|] travel as 16 nibbles in a kernel argument (no table fetch)
     int m10 = 0, m01 = 0;

@@ -530,7 +530,7 @@ int vido_update_mask(vido_ctx* ctx, int slot_last, int slot_cur, const int32_t* 
     if (slot_last < 0 || slot_last >= T->B || slot_cur < 0 || slot_cur >= T->B || n < 0 || (size_t)n * 3 > T->tmp_cap)
         return vido_set_error(ctx, VIDO_E_INVALID, "update_mask: bad slots/n");
     if (n == 0) return VIDO_OK;
-    hipStream_t st = ctx->stream; const size_t px = (size_t)T->W * T->H;
+    hipStream_t st = ctx->stream;
     std::vector<int> uni(last_label, last_label + n);
     std::sort(uni.begin(), uni.end()); uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
     // The labels' samples are read in ONE gather (one upload, one launch, one download, one wait) instead of a round trip per label: five labels were 15 stream operations

@@ -53,14 +53,15 @@ struct WnArgs { const float* x; const float* up; const float* bias; float* y; in
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-template <int CW, int TW, int KC, bool ODD, bool KSPL = false>
+template <int CW, int TW, int KC, bool ODD, int KSPL = 0>      // KSPL: 0 = tile form; 4 / 2 = K-split form with that many channel slices (4 / KSPL tile blocks per workgroup)
 __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
 {
     static_assert(CW * TW == 4 && (KC == 8 || KC == 4), "workgroup = 4 waves");
-    static_assert(!KSPL || (CW == 1 && TW == 4 && KC == 4), "the K-split form is the 1 x 4 form with the four tile blocks re-read as four channel slices");
+    static_assert(!KSPL || ((KSPL == 4 || KSPL == 2) && CW == 1 && TW == 4 && KC == 4), "the K-split form is the 1 x 4 form with its four tile blocks re-read as (tile block, channel slice) pairs");
+    constexpr int KSL = KSPL ? KSPL : 1, KTB = KSPL ? 4 / KSPL : 1;      // channel slices, tile blocks of a K-split workgroup: wave w = KSL * (tile block) + slice
     constexpr int KS = KC / 2;                        // matrix instructions (k-pairs) per position and chunk
     constexpr int U_BLK = 16 * 64 * KS;               // floats of one (32-channel block, chunk): [p][lane][KS]
-    constexpr int UB = KSPL ? 4 : CW;                 // U blocks per chunk in LDS (K-split: one per channel slice)
+    constexpr int UB = KSPL ? KSL : CW;               // U blocks per chunk in LDS (K-split: one per channel slice)
     constexpr int U_BUF = UB * U_BLK, V_BUF = 16 * TW * KS * 64, V_P = TW * KS * 64;
     constexpr int NJ = TW * KS / 4;                   // (channel, tile) pairs a thread transforms per chunk
     constexpr int KSTEP = 4 / TW;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int per = gridDim.x >> 3, item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (item >= A.total) return;
-    const int tb = item / A.cgroups, cg = item - tb * A.cgroups, tile0 = tb * (KSPL ? 32 : TW * 32);
+    const int tb = item / A.cgroups, cg = item - tb * A.cgroups, tile0 = tb * (KSPL ? KTB * 32 : TW * 32);
     const int hw = A.H * A.W, tpi = A.Ht * A.Wt;
 
     // ---- transform role: tile block tw_t, k-pairs ks0 + j * KSTEP; lane = (tile & 31) + 32 * (channel & 1) = the operand slot it fills.
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
     const int tw_t = w % TW, ks0 = w / TW;
     unsigned voff[16];
     {
-        const int gt = tile0 + (KSPL ? 0 : tw_t * 32) + (lane & 31), gtc = min(gt, A.T - 1);
+        const int gt = tile0 + (KSPL ? (w / KSL) * 32 : tw_t * 32) + (lane & 31), gtc = min(gt, A.T - 1);
         const int n = gtc / tpi, rem = gtc - n * tpi, ty = rem / A.Wt, tx = rem - ty * A.Wt;
         unsigned rowo[4], colo[4];
 #pragma unroll
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
     const unsigned par_oob = (lane >> 5) ? WN_OOB : 0u;
     f32x2 inp[NJ][8];                                                    // window of pair j: inp[j][2 * row + half] = columns (2 half, 2 half + 1)
     auto load_win = [&](int chunk, int j, int e0, int e1) {              // window elements [e0, e1) of pair j of `chunk`
-        const int cb = (KSPL ? 4 * chunk + w : chunk) * KC + 2 * (ks0 + j * KSTEP);      // (scalar) first channel of the k-pair; K-split: slice w of the 16-channel chunk
+        const int cb = (KSPL ? KSL * chunk + w % KSL : chunk) * KC + 2 * (ks0 + j * KSTEP);      // (scalar) first channel of the k-pair; K-split: the wave's slice of the 4 KSL-channel chunk
         const bool any = cb < A.Cin;
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.x, 0, any ? A.xbytes : 0u, 0x00020000);
         const unsigned so = any ? 4u * (unsigned)cb * (unsigned)hw : 0u;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
         for (int q = first; q < first + count; q++) {
             const int i = 4 * q + w, cwi = i / PPB, pi = i - cwi * PPB;
             // (K-split: block cwi is the slice's 4-channel chunk; a slice past the last chunk re-reads the last one — its V is zero)
-            const unsigned so = KSPL ? 4u * (unsigned)((cg * A.nchunk + min(4 * chunk + cwi, A.nchunk - 1)) * U_BLK + pi * 256)
+            const unsigned so = KSPL ? 4u * (unsigned)((cg * A.nchunk + min(KSL * chunk + cwi, A.nchunk - 1)) * U_BLK + pi * 256)
                                      : 4u * (unsigned)(((cg * CW + cwi) * A.nchunk + chunk) * U_BLK + pi * 256);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void*)(Ul + buf * U_BUF + cwi * U_BLK + pi * 256), 16, uvo, so, 0, 0);
         }
@@ -156,15 +157,16 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
     constexpr int NPW = UB * PPB / 4;                                    // pieces per wave and chunk
 
     // ---- matrix role: channel block cw, tile block tw
-    const int cw = KSPL ? w : w % CW, tw = w / CW;                       // operand blocks in LDS (K-split: U block = V block = the wave's channel slice)
-    const int cwo = KSPL ? 0 : cw, two = KSPL ? 0 : tw;                  // output blocks
-    const int nloop = KSPL ? (A.nchunk + 3) >> 2 : A.nchunk;
+    const int cw = KSPL ? w % KSL : w % CW, tw = w / CW;                 // operand blocks in LDS (K-split: U block = the wave's channel slice, V block = the wave itself)
+    const int cwo = KSPL ? 0 : cw, two = KSPL ? w / KSL : tw;            // output blocks
+    const int ksl = KSPL ? w % KSL : 0;                                  // channel slice of the wave (0: the wave that adds the partial sums and stores)
+    const int nloop = KSPL ? (A.nchunk + KSL - 1) / KSL : A.nchunk;
     f32x16 acc[16];
 #pragma unroll
     for (int p = 0; p < 16; p++)
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[p][q] = 0.f;
-    if (A.bias && !(KSPL && w)) {                                        // Y = A^T M A: M[1][1] reaches all four outputs of a tile with weight 1 -> the bias starts there
+    if (A.bias && !(KSPL && ksl)) {                                        // Y = A^T M A: M[1][1] reaches all four outputs of a tile with weight 1 -> the bias starts there
 #pragma unroll
         for (int q = 0; q < 16; q++) { const int co = (cg * CW + cwo) * 32 + 4 * (lane >> 5) + 8 * (q >> 2) + (q & 3); acc[5][q] = co < A.Cout ? A.bias[co] : 0.f; }
     }
@@ -280,22 +282,22 @@ __global__ __launch_bounds__(256) void k_wino3x3(WnArgs A)
         }
         y00 = pk_add(pk_add(t0[0], t0[1]), t0[2]); y01 = pk_sub(pk_sub(t0[1], t0[2]), t0[3]); y10 = pk_add(pk_add(t1[0], t1[1]), t1[2]); y11 = pk_sub(pk_sub(t1[1], t1[2]), t1[3]);
     };
-    if (KSPL && w) {
+    if (KSPL && ksl) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             f32x2 y00, y01, y10, y11; inverse(r, y00, y01, y10, y11);
-            f32x2* d = red + (((w - 1) * 8 + (r >> 1)) * 4) * 64 + lane;
+            f32x2* d = red + (((two * (KSL - 1) + ksl - 1) * 8 + (r >> 1)) * 4) * 64 + lane;
             d[0] = y00; d[64] = y01; d[128] = y10; d[192] = y11;
         }
     }
-    if (KSPL) { __syncthreads(); if (w || gt >= A.T) return; }
+    if (KSPL) { __syncthreads(); if (ksl || gt >= A.T) return; }
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
         f32x2 y00, y01, y10, y11; inverse(r, y00, y01, y10, y11);
         if (KSPL) {
 #pragma unroll
-            for (int s = 0; s < 3; s++) {
-                const f32x2* d = red + ((s * 8 + (r >> 1)) * 4) * 64 + lane;
+            for (int s = 0; s < KSL - 1; s++) {
+                const f32x2* d = red + (((two * (KSL - 1) + s) * 8 + (r >> 1)) * 4) * 64 + lane;
                 y00 = pk_add(y00, d[0]); y01 = pk_add(y01, d[64]); y10 = pk_add(y10, d[128]); y11 = pk_add(y11, d[192]);
             }
         }
@@ -362,20 +364,26 @@ int vido_wino3x3_fills_chip(int n, int cout, int h, int w, int min_wgs)
 /* The form vido_wino3x3_bias_act_form should be given for this launch.  0: the tile form (a workgroup = 64 tiles x 64 channels or 128 x 32, each wave walks ALL input
  * channels).  1: the K-split form for launches that would leave most of the chip idle (fewer than 128 workgroups of the tile form): a workgroup = 32 tiles x 32 channels,
  * its four waves each take a quarter of the input channels and the partial sums meet in LDS — four times the waves, a quarter of the chain each.
- * VIDO_WINO_KSPLIT=0 / 1 forces a form (experiments). */
+ * 2: the same with TWO channel slices x two tile blocks per workgroup (half the U traffic per matrix instruction, twice the chain).  Under-filled launches get form 2
+ * where that still gives >= 128 workgroups, else form 1; VIDO_WINO_KSPLIT=0 / 4 / 2: never / always form 1 / always form 2 for them. */
 int vido_wino3x3_form(int n, int cin, int cout, int h, int w)
 {
-    static const int force = [] { const char* e = getenv("VIDO_WINO_KSPLIT"); return e ? atoi(e) : -1; }();
+    static const int ks = [] { const char* e = getenv("VIDO_WINO_KSPLIT"); return e ? atoi(e) : -1; }();      // 0: never; 4 / 2: that form for every under-filled launch; default: by size
     (void)cin;
-    if (force == 0 || force == 1) return force;
-    return vido_wino3x3_fills_chip(n, cout, h, w, 128) ? 0 : 1;
+    if (ks == 0 || vido_wino3x3_fills_chip(n, cout, h, w, 128)) return 0;
+    if (ks == 4 || ks == 1) return 1;
+    if (ks == 2) return 2;
+    // two slices x two tile blocks read half the U bytes per matrix instruction but walk twice the chain: they win where they still put >= 128 workgroups on the chip
+    // (LiteFlowNet's level 3: 128 -> 64 at 120 x 160 41 -> 33 us, 64 -> 64 28 -> 21), four slices below that (FPN P4 39 vs 63 us; profiles/r5/wino_ksplit_microbench.txt)
+    const long long T = (long long)n * ((h + 1) / 2) * ((w + 1) / 2);
+    return ((T + 63) / 64) * ((cout + 31) / 32) >= 128 ? 2 : 1;
 }
 
 /* floats of the packed transformed weight of a cin -> cout layer (form 0; _form: of the given form) */
 long long vido_wino3x3_packed_floats_form(int cin, int cout, int form)
 {
     if (cin < 1 || cout < 1) return 0;
-    if (form == 1) return 16ll * (((cout + 31) / 32) * 32) * wn_cin_pad(cin, 4);
+    if (form == 1 || form == 2) return 16ll * (((cout + 31) / 32) * 32) * wn_cin_pad(cin, 4);
     return 16ll * wn_cout_pad(cout) * wn_cin_pad(cin, wn_kc(cout));
 }
 long long vido_wino3x3_packed_floats(int cin, int cout) { return vido_wino3x3_packed_floats_form(cin, cout, 0); }
@@ -385,8 +393,8 @@ long long vido_wino3x3_packed_floats(int cin, int cout) { return vido_wino3x3_pa
  * cout rounds up to 64 with >= 32 padded channels, and always in form 1); padded channels are zero. */
 int vido_wino3x3_pack_form(const float* w, int cin, int cout, int form, float* up)
 {
-    if (!w || !up || cin < 1 || cout < 1 || form < 0 || form > 1) return VIDO_E_INVALID;
-    const int kc = form == 1 ? 4 : wn_kc(cout), ks = kc / 2, cip = wn_cin_pad(cin, kc), nchunk = cip / kc;
+    if (!w || !up || cin < 1 || cout < 1 || form < 0 || form > 2) return VIDO_E_INVALID;
+    const int kc = form ? 4 : wn_kc(cout), ks = kc / 2, cip = wn_cin_pad(cin, kc), nchunk = cip / kc;
     std::memset(up, 0, sizeof(float) * (size_t)vido_wino3x3_packed_floats_form(cin, cout, form));
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     for (int co = 0; co < cout; co++)
@@ -410,31 +418,33 @@ int vido_wino3x3_pack(const float* w, int cin, int cout, float* up) { return vid
 int vido_wino3x3_bias_act_form(vido_ctx* ctx, const float* x, const float* u_packed, const float* bias, float* y, int n, int cin, int cout, int h, int w, float slope, int form)
 {
     if (!ctx) return VIDO_E_INVALID;
-    if (!x || !u_packed || !y || x == y || n < 1 || form < 0 || form > 1 || !vido_wino3x3_supported(cin, cout, h, w) || ((uintptr_t)u_packed & 15) || (((uintptr_t)x | (uintptr_t)y) & 3))
+    if (!x || !u_packed || !y || x == y || n < 1 || form < 0 || form > 2 || !vido_wino3x3_supported(cin, cout, h, w) || ((uintptr_t)u_packed & 15) || (((uintptr_t)x | (uintptr_t)y) & 3))
         return vido_set_error(ctx, VIDO_E_INVALID, "wino3x3: no kernel for %d -> %d channels on %d x %d x %d (or a pointer is misaligned)", cin, cout, n, h, w);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
-    const int kc = form == 1 ? 4 : wn_kc(cout), ht = (h + 1) / 2, wt = (w + 1) / 2;
+    const int kc = form ? 4 : wn_kc(cout), ht = (h + 1) / 2, wt = (w + 1) / 2;
     const long long T = (long long)n * ht * wt;
     if (T >= (1ll << 30) || 4ll * n * cin * h * w >= (1ll << 30) || 4ll * n * cout * h * w >= (1ll << 32))
         return vido_set_error(ctx, VIDO_E_INVALID, "wino3x3: a batch of %d images of %d x %d x %d is past the 1 GB the kernel addresses", n, cin, h, w);
-    const int tb = form == 1 ? 32 : (kc == 8 ? 64 : 128), cgroups = kc == 8 ? (cout + 63) / 64 : (cout + 31) / 32;
+    const int tb = form == 1 ? 32 : form == 2 ? 64 : (kc == 8 ? 64 : 128), cgroups = kc == 8 ? (cout + 63) / 64 : (cout + 31) / 32;
     const long long nblk_ll = (T + tb - 1) / tb;
     if (nblk_ll * cgroups >= (1ll << 30)) return vido_set_error(ctx, VIDO_E_INVALID, "wino3x3: too many work items");
     const int nblk = (int)nblk_ll, total = nblk * cgroups;
     WnArgs A{x, u_packed, bias, y, n, cin, cout, h, w, ht, wt, (int)T, wn_cin_pad(cin, kc) / kc, cgroups, total, slope, (w % 2 == 0 && ((uintptr_t)y & 7) == 0) ? 1 : 0, (unsigned)(4ll * n * cin * h * w), (unsigned)(4ll * vido_wino3x3_packed_floats_form(cin, cout, form)),
              nullptr};
     const dim3 grid(8 * ((total + 7) / 8)), blk(256);
-    constexpr size_t LDS8 = (size_t)2 * (2 * 16 * 64 * 4 + 16 * 2 * 4 * 64) * 4, LDS4 = (size_t)2 * (1 * 16 * 64 * 2 + 16 * 4 * 2 * 64) * 4, LDSK = (size_t)2 * (4 * 16 * 64 * 2 + 16 * 4 * 2 * 64) * 4;
+    constexpr size_t LDS8 = (size_t)2 * (2 * 16 * 64 * 4 + 16 * 2 * 4 * 64) * 4, LDS4 = (size_t)2 * (1 * 16 * 64 * 2 + 16 * 4 * 2 * 64) * 4, LDSK = (size_t)2 * (4 * 16 * 64 * 2 + 16 * 4 * 2 * 64) * 4, LDSK2 = (size_t)2 * (2 * 16 * 64 * 2 + 16 * 4 * 2 * 64) * 4;
     static bool attr[64] = {};
     if (!attr[ctx->device & 63]) {
         for (const void* f : {(const void*)k_wino3x3<2, 2, 8, false>, (const void*)k_wino3x3<2, 2, 8, true>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS8));
         for (const void* f : {(const void*)k_wino3x3<1, 4, 4, false>, (const void*)k_wino3x3<1, 4, 4, true>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS4));
-        for (const void* f : {(const void*)k_wino3x3<1, 4, 4, false, true>, (const void*)k_wino3x3<1, 4, 4, true, true>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSK));
+        for (const void* f : {(const void*)k_wino3x3<1, 4, 4, false, 4>, (const void*)k_wino3x3<1, 4, 4, true, 4>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSK));
+        for (const void* f : {(const void*)k_wino3x3<1, 4, 4, false, 2>, (const void*)k_wino3x3<1, 4, 4, true, 2>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSK2));
         attr[ctx->device & 63] = true;
     }
     const bool odd = cin & 1;                                            // (an odd channel count costs 17 vector instructions per window: its last channel pair is half padding)
-    if (form == 1) { if (odd) hipLaunchKernelGGL((k_wino3x3<1, 4, 4, true, true>), grid, blk, LDSK, st, A); else hipLaunchKernelGGL((k_wino3x3<1, 4, 4, false, true>), grid, blk, LDSK, st, A); }
+    if (form == 1) { if (odd) hipLaunchKernelGGL((k_wino3x3<1, 4, 4, true, 4>), grid, blk, LDSK, st, A); else hipLaunchKernelGGL((k_wino3x3<1, 4, 4, false, 4>), grid, blk, LDSK, st, A); }
+    else if (form == 2) { if (odd) hipLaunchKernelGGL((k_wino3x3<1, 4, 4, true, 2>), grid, blk, LDSK2, st, A); else hipLaunchKernelGGL((k_wino3x3<1, 4, 4, false, 2>), grid, blk, LDSK2, st, A); }
     else if (kc == 8) { if (odd) hipLaunchKernelGGL((k_wino3x3<2, 2, 8, true>), grid, blk, LDS8, st, A); else hipLaunchKernelGGL((k_wino3x3<2, 2, 8, false>), grid, blk, LDS8, st, A); }
     else { if (odd) hipLaunchKernelGGL((k_wino3x3<1, 4, 4, true>), grid, blk, LDS4, st, A); else hipLaunchKernelGGL((k_wino3x3<1, 4, 4, false>), grid, blk, LDS4, st, A); }
     HIP_TRY(ctx, hipGetLastError());

@@ -604,7 +604,7 @@ def pack_wino3x3(w, form=0):
     lib = load_library()
     lib.vido_wino3x3_packed_floats_form.restype = C.c_longlong
     cout, cin = int(w.shape[0]), int(w.shape[1])
-    assert tuple(w.shape[2:]) == (3, 3) and form in (0, 1)
+    assert tuple(w.shape[2:]) == (3, 3) and form in (0, 1, 2)
     wh = np.ascontiguousarray(w.detach().to("cpu", torch.float32).numpy())
     n = int(lib.vido_wino3x3_packed_floats_form(cin, cout, int(form)))
     out = np.empty(n, np.float32)
