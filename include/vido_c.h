@@ -310,6 +310,12 @@ int vido_conv1x1_supported(int cin, int cout, int hw);
 /* the weight packing vido_conv1x1_bias_act / _up2_act expect for a shape: 0 = [co / 32][k / 8][32 (k & 1) + co % 32][(k % 8) / 2] (128 x 128 tiles),
  * 1 = [co / 16][k / 16][16 (k & 3) + co % 16][(k % 16) / 4] (128 x 112 tiles: fewer idle CUs in the last round of workgroups) */
 int vido_conv1x1_layout(int cin, int cout, int hw);
+/* Arithmetic of the 1x1 GEMM (round 6).  0 (default) = split-bf16: every fp32 operand is the exact sum of three bf16 planes, the six plane products with i + j <= 2 run on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulators — fp32-equivalent results (error against float64 not above the fp32 instruction's: tests/test_maskrcnn_gpu.py) at up to
+ * 2.67x the fp32 matrix rate; vido_conv1x1_layout then answers 2 = [co / 32][k / 16][plane 3][32 ((k % 16) / 8) + co % 32][k % 8] bf16 (6 bytes per weight).
+ * 1 = the fp32 matrix instruction (layouts 0 / 1 above); also selected by VIDO_CONV1X1_ARITH=f32 in the environment.  Returns the previous setting; process-wide — set it
+ * before weights are packed (a packed weight carries its layout, a mismatch is refused by the caller's shape check). */
+int vido_conv1x1_set_arith(int f32_instruction);
 int vido_conv1x1_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, int hw, float slope);
 /* ... with the residual at half the resolution [cout][h/2][w/2], added nearest-upsampled: the FPN's lateral convolution + top-down sum (backbone/fpn.py:55-66); h, w even */
 int vido_conv1x1_bias_up2_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual_half, float* y, int cin, int cout, int h, int w, float slope);

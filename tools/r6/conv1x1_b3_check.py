@@ -1,0 +1,38 @@
+"""Round 6: the split-bf16 form of csrc/conv1x1.hip (k_conv1x1_b3) against the fp32-instruction form and float64 conv2d on the detector's bottleneck shapes: max-abs error
+of both against float64 (the bar: split <= 1.5 x fp32-instruction), microseconds per call and fp32-equivalent TFLOP/s."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
+import torch
+import torch.nn.functional as F
+import vido_slam_amd as V
+from vido_slam_amd.nets.ops import HipOps, pack_conv1x1
+ctx = V.Context(width=640, height=480, max_batch=1); ops = HipOps(ctx)
+shapes = [(256, 256, 200, 272, "layer1"), (64, 256, 200, 272, "layer1 first"), (512, 512, 100, 136, "layer2"), (1024, 1024, 50, 68, "layer3"), (2048, 2048, 25, 34, "layer4"),
+          (256, 128, 37, 52, "odd"), (32, 128, 12, 11, "tiny"), (96, 128, 9, 15, "hw % 4 != 0")]
+def timed(fn, reps=50):
+    fn(); fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+worst = 0.0
+for cin, cout, H, W, name in shapes:
+    g = torch.Generator().manual_seed(cin * 7 + H)
+    x = torch.randn(1, cin, H, W, generator=g); w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5; b = torch.randn(cout, generator=g); r = torch.randn(1, cout, H, W, generator=g)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double()) + r.double())
+    xc, bc, rc = x.cuda(), b.cuda(), r.cuda()
+    gf = 2.0 * cin * cout * H * W / 1e9
+    out = {}
+    for arith in (1, 0):
+        ops.conv1x1_set_arith(arith)
+        lay = ops.conv1x1_layout(cin, cout, H * W); wp = pack_conv1x1(w, lay).cuda()
+        y = ops.conv1x1_bias_act(xc, wp, bc, rc, 0.0)
+        err = float((y.cpu().double() - ref).abs().max())
+        t = timed(lambda: ops.conv1x1_bias_act(xc, wp, bc, rc, 0.0))
+        out[arith] = (err, t, lay)
+    ops.conv1x1_set_arith(0)
+    ratio = out[0][0] / max(out[1][0], 1e-30); worst = max(worst, ratio)
+    print("%-14s %4d -> %4d @ %3dx%3d %6.2f GF | fp32 instr [layout %d]: err %.3e  %6.1f us %6.1f TF | split-bf16 [layout %d]: err %.3e  %6.1f us %6.1f TF | err ratio %.2f  speed-up %.2fx"
+          % (name, cin, cout, H, W, gf, out[1][2], out[1][0], out[1][1], gf / out[1][1] * 1e3, out[0][2], out[0][0], out[0][1], gf / out[0][1] * 1e3, ratio, out[1][1] / out[0][1]), flush=True)
+print("worst error ratio split / fp32-instruction: %.2f" % worst)

@@ -19,6 +19,7 @@
 // Work items (position tile, channel tile) are dealt so that an XCD walks a contiguous range with the channel tile fastest: the Cout / 128 workgroups that share a B tile
 // run back to back on one L2.
 #include "common.hpp"
+#include <atomic>
 
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -268,6 +269,192 @@ __global__ __launch_bounds__(256) void k_conv1x1_n112(C1Args A)
             }
         }
 }
+
+// ---- fp32-equivalent arithmetic on the bf16 matrix instruction: 3-plane split, 6 products (round 6) ----------------------------------------------------------------------
+// The fp32 matrix instruction runs at the fp32 VECTOR rate (157 TFLOP/s); v_mfma_f32_32x32x16_bf16 does 16x the multiply-adds per cycle.  Every fp32 number is EXACTLY
+// the sum of three bf16 numbers  x = x0 + x1 + x2  (x0 = rne(x), x1 = rne(x - x0), x2 = x - x0 - x1: 3 x (8 significant bits + sign) cover the 24-bit significand),
+// a product of two bf16 numbers is exact in fp32, and the accumulators are fp32 as before.  Of the nine plane products the six with i + j <= 2 are kept
+// (w0 x0, w0 x1, w1 x0, w0 x2, w1 x1, w2 x0); the dropped three are <= 2^-24 |w x| each, with either sign — two orders below what the fp32 accumulation itself loses over
+// K >= 64 terms (tests/test_maskrcnn_gpu.py measures both kernels against float64).  6 instructions of 16x the rate: 2.67x the fp32 matrix peak.
+//   * weights: split on the host at pack time into [co / 32][k / 16][plane][lane][8] (pack_conv1x1 layout 2): a 1 KB copy piece is one A operand of one plane,
+//     a lane's operand one ds_read_b128.
+//   * activations stay fp32 in HBM and in LDS ([16][128] rows per k-step, by the same scalar-addressed buffer copies as above); a wave owns ALL 128 output channels x 32
+//     positions, so that every activation is split exactly once per workgroup — by the wave that multiplies with it: 8 ds_read_b32 per lane and k-step (rows 8 (lane >> 5) + i,
+//     position lane & 31 = the B operand's own order), 11 vector-ALU instructions per PAIR (3 v_cvt_pk_bf16_f32, 2 shifts, 2 ands, 4 exact subtractions) beside 24 matrix
+//     instructions — the bf16 instruction leaves ~5 issue slots per instruction to the wave (MI355X_MICROARCH.md), the loop needs ~3.
+//   * a ring of B3_R LDS slots of one k-step (16 input channels: 12 KB of weight planes + 8 KB of activations), copies B3_R - 1 steps ahead, ONE barrier per k-step; the
+//     operands of step t + 1 are read (and split) from LDS during step t, so the matrix pipe does not wait behind a barrier.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define B3_SLOT 20480       // bytes per k-step in the ring: 12 pieces of A (4 row blocks x 3 planes), 8 pieces of B (two rows each)
+#define B3_PW 5             // copy pieces per wave and step
+
+__device__ __forceinline__ unsigned b3_cvt_pk(float lo, float hi) { unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; }
+// two fp32 values -> their three bf16 planes, packed (low half = the first value)
+__device__ __forceinline__ void b3_split2(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2)
+{
+    p0 = b3_cvt_pk(x0, x1);
+    const float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+    p1 = b3_cvt_pk(r0, r1);
+    const float s0 = r0 - __uint_as_float(p1 << 16), s1 = r1 - __uint_as_float(p1 & 0xffff0000u);
+    p2 = b3_cvt_pk(s0, s1);
+}
+
+// G wave groups of four waves (256 G threads) on one 128 x 128 tile.  G = 2: the two groups take the even / the odd k-steps with accumulators of their own and meet in LDS at
+// the end — two waves per SIMD: measured with one (profiles/r6/conv1x1_b3_counters.txt) a wave issues 5.2 other instructions per matrix instruction, each 4 cycles of issue,
+// against the 8 slots a 32-cycle matrix instruction leaves: the matrix pipe was 61 % busy over a wave's life.  A partner wave on the same SIMD issues into those gaps.
+// A ring slot holds G k-steps (one per group), RB slots; copies run RB - 1 slots ahead; one workgroup barrier per slot.
+// Three forms (c1_launch picks by shape): <G 2, RB 4> one workgroup of 8 waves per CU (160 KB) for long contractions on launches of about one workgroup per CU;
+// <G 1, RB 4> 80 KB and <= 256 registers, so that TWO workgroups share a CU — the prologue / epilogue of one tile runs beside the other tile's loop (layer1: 16 k-steps of
+// ~0.4 us against ~6 us of fixed cost per tile, 3.3 rounds of tiles); <G 1, RB 6> the first form (one workgroup of 4 waves per CU, 120 KB), kept for comparison.
+template <int RES, int G, int RB>
+__global__ __launch_bounds__(256 * G, (G == 1 && RB == 4) ? 2 : G) void k_conv1x1_b3(C1Args A)
+{
+    constexpr int SLOTB = G * B3_SLOT;
+    extern __shared__ __attribute__((aligned(16))) float c1_lds[];
+    char* L = (char*)c1_lds;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), w = wv & 3, g = wv >> 2;
+    const int per = gridDim.x >> 3, item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (item >= A.total) return;
+    const int nt = item / A.mt, mtile = item - nt * A.mt, n0 = nt * C1_TN, m0 = mtile * C1_TM;
+    const int ns = A.nchunk, nb = ns / G;                                 // k-steps of 16 input channels (even: K % 32 == 0), slots
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)A.wp, 0, A.wbytes, 0x00020000);
+    // copy pieces of one k-step: piece i = 4 q + w of wave w of the group that owns the step, q = 0 .. 4; i < 12: the A operand (row block i / 3, plane i % 3), else rows
+    // 2 p, 2 p + 1 (p = i - 12) of the step's 16 activation rows.  Everything that does not depend on the step is computed here: the A pieces' scalar offsets at step 0, the
+    // B pieces' per-lane offsets (the piece's rows ride in the per-lane offset, the STEP in the descriptor: base = x + 64 N t bytes, num_records = the bytes left behind it —
+    // the exact range check of k_conv1x1 with one descriptor per step).
+    const unsigned avo = 16u * (unsigned)lane;
+    unsigned abase[3], bvo[2];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { const int i = 4 * q + w, rb = i / 3, pl = i - 3 * rb; abase[q] = 1024u * (unsigned)(((m0 >> 5) + rb) * ns * 3 + pl); }
+#pragma unroll
+    for (int q = 0; q < 2; q++) bvo[q] = 4u * ((unsigned)((lane >> 5) + 2 * (4 * q + w)) * (unsigned)A.N + (unsigned)(n0 + 4 * (lane & 31)));
+    const unsigned bstep = 64u * (unsigned)A.N;
+    const int wofs = g * B3_SLOT + w * 1024;
+    auto issue = [&](int T, int slot) {                                   // this wave's five pieces of its group's step of slot T
+        char* S = L + slot * SLOTB + wofs;
+        const int t = G * T + g;
+        const unsigned aoff = 3072u * (unsigned)t, boff = bstep * (unsigned)t;
+#pragma unroll
+        for (int q = 0; q < 3; q++) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(S + q * 4096), 16, avo, abase[q] + aoff, 0, 0);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)A.x + boff), 0, A.xbytes - boff, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 2; q++) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(S + 12288 + q * 4096), 16, bvo[q], 0, 0, 0);
+    };
+    // two accumulator sets: the leading product w0 x0 (one rounding per 16 input channels) and the five corrections (2^-8 of it and below: their roundings do not count)
+    f32x16 acc[4], acl[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[rb][r] = 0.f; acl[rb][r] = 0.f; }
+    for (int T = 0; T < RB - 1; T++) issue(min(T, nb - 1), T);
+    u32x4 a[2][4][3], bp[2][3]; float braw[8];
+    typedef const __attribute__((address_space(3))) char* lds_c;
+    const unsigned a_lane = (unsigned)(g * B3_SLOT) + 16u * (unsigned)lane, b_lane = (unsigned)(g * B3_SLOT) + 12288u + 4u * (unsigned)((lane >> 5) * 8 * C1_TN + 32 * w + (lane & 31));
+    auto lda = [&](int slot, int buf) {
+        lds_c Ab = (lds_c)(L + slot * SLOTB) + a_lane;
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) a[buf][rb][pl] = *(const __attribute__((address_space(3))) u32x4*)(Ab + (rb * 3 + pl) * 1024);
+    };
+    auto ldb = [&](int slot) {
+        const volatile __attribute__((address_space(3))) float* Bb = (const volatile __attribute__((address_space(3))) float*)((lds_c)(L + slot * SLOTB) + b_lane);
+#pragma unroll
+        for (int i = 0; i < 8; i++) braw[i] = Bb[i * C1_TN];
+    };
+    auto split = [&](int buf) {
+#pragma unroll
+#ifdef B3_NOSPLIT
+        for (int pr = 0; pr < 4; pr++) { bp[buf][0][pr] = __float_as_uint(braw[2 * pr]); bp[buf][1][pr] = __float_as_uint(braw[2 * pr + 1]); bp[buf][2][pr] = __float_as_uint(braw[2 * pr]) ^ 1; }
+#else
+        for (int pr = 0; pr < 4; pr++) { unsigned p0, p1, p2; b3_split2(braw[2 * pr], braw[2 * pr + 1], p0, p1, p2); bp[buf][0][pr] = p0; bp[buf][1][pr] = p1; bp[buf][2][pr] = p2; }
+#endif
+    };
+    // The barrier is the bare instruction (no fence): __syncthreads() would drain the copies in flight (vmcnt(0)), which is the ring's whole point.  What it must order is
+    // stated explicitly: this wave's copies of the slot about to be read have landed (vmcnt), its own LDS reads are back (lgkmcnt(0): they were issued a slot ago).
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(B3_PW * (RB - 2)) : "memory");      // slot 0 has landed
+    lda(0, 0); ldb(0); split(0);
+    int slot = 0, ti = min(RB - 2, nb - 1);                               // ring slot of T; the last slot the copies have been issued for
+    for (int T2 = 0; T2 < nb; T2 += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(B3_PW * (RB - 3)) : "memory");      // slot T + 1 has landed; everybody is done reading slot T - 1
+            __builtin_amdgcn_sched_barrier(0);
+            const int sn = slot + 1 == RB ? 0 : slot + 1, sf = slot == 0 ? RB - 1 : slot - 1;      // ring positions of T + 1 and of T + RB - 1 (= the one T - 1 left)
+            ti = min(ti + 1, nb - 1);                                     // (past the last slot the copies repeat it into a position nobody reads again: the count per slot stays 5)
+            ldb(sn); lda(sn, h ^ 1);                                      // (past the last slot: read, never used)
+            issue(ti, sf);
+            // the six products, small ones first; consecutive matrix instructions go to different accumulators
+#pragma unroll
+            for (int term = 0; term < 6; term++) {
+                constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) {
+                    f32x16& d = term == 5 ? acc[rb] : acl[rb];
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[h][rb][PA[term]]), __builtin_bit_cast(bf16x8, bp[h][PB[term]]), d, 0, 0, 0);
+                }
+            }
+            split(h ^ 1);
+            // 24 matrix instructions of 32 cycles each: the 20 LDS reads and the 5 copies go beside the first twelve, the split's 44 vector-ALU instructions beside the rest
+            // (their inputs are back from LDS by then)
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);            // the two LDS base addresses of the next slot
+#pragma unroll
+            for (int i = 0; i < 24; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); else if (i < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (i >= 3 && i < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (i >= 6) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            slot = sn;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           // (the last, unused copies)
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++) acc[rb] += acl[rb];
+    // D[i][j] as above: register r of a lane = output channel 8 (r / 4) + 4 (lane >> 5) + (r & 3) of the row block, position lane & 31
+    auto finish = [&](int rb, const f32x16& v0, const float* other) {
+        const int co0 = m0 + 32 * rb + 4 * (lane >> 5), q = n0 + 32 * w + (lane & 31);
+        float ov[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) ov[r] = other ? other[r * 64] : 0.f;
+        if (q < A.N) {
+            float rv[16], bv[16];
+            size_t rq = (size_t)q, rn = (size_t)A.N;
+            if (RES == 2) { const int yy = q / A.W, xx = q - yy * A.W; rq = (size_t)(yy >> 1) * (A.W >> 1) + (xx >> 1); rn = (size_t)(A.N / A.W >> 1) * (A.W >> 1); }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = co0 + 8 * (r >> 2) + (r & 3);
+                bv[r] = A.bias ? A.bias[co] : 0.f;
+                rv[r] = RES ? A.res[(size_t)co * rn + rq] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = co0 + 8 * (r >> 2) + (r & 3);
+                const float v = (v0[r] + ov[r]) + bv[r] + rv[r];
+                A.y[(size_t)co * A.N + q] = fmaxf(v, v * A.slope);
+            }
+        }
+    };
+    if (G == 1) {
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) finish(rb, acc[rb], nullptr);
+    } else {
+        // the two groups' sums meet in LDS (the ring is free): group 1 hands over its row blocks 0, 1 and finishes 2, 3, group 0 the other way round
+        float* X = (float*)L;                                             // [which 2][w 4][rbl 2][r 16][lane 64]
+        __builtin_amdgcn_s_barrier();                                     // every wave is past its last ring read (lgkmcnt(0) above) and its last copy has landed
+        auto put = [&](int which, const f32x16& v0, const f32x16& v1) {
+            float* Pw = X + (((which * 4 + w) * 2) * 16) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { Pw[r * 64] = v0[r]; Pw[(16 + r) * 64] = v1[r]; }
+        };
+        if (g == 1) put(0, acc[0], acc[1]); else put(1, acc[2], acc[3]);
+        __syncthreads();
+        const float* Pr = X + (((g * 4 + w) * 2) * 16) * 64 + lane;
+        if (g == 0) { finish(0, acc[0], Pr); finish(1, acc[1], Pr + 16 * 64); } else { finish(2, acc[2], Pr); finish(3, acc[3], Pr + 16 * 64); }
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -281,12 +468,23 @@ int vido_conv1x1_supported(int cin, int cout, int hw)
 /* Which tile form (= which weight packing) the library uses for a shape: 0 = 128 x 128 tiles on 32x32x2 (pack layout 0), 1 = 128 x 112 tiles on 16x16x4 (pack layout 1).
  * The form with fewer (rounds of 256 CUs) x (tile width) wins; VIDO_CONV1X1_TN = 128 / 112 forces one.  The packer (vido_slam_amd/nets/ops.py::pack_conv1x1) asks this
  * function, vido_conv1x1_bias_act asks it again with the same shape. */
+static std::atomic<int>& c1_f32_arith()
+{
+    static std::atomic<int> v{[] { const char* e = getenv("VIDO_CONV1X1_ARITH"); return (e && !strcmp(e, "f32")) || getenv("VIDO_CONV1X1_TN") ? 1 : 0; }()};
+    return v;
+}
+
+int vido_conv1x1_set_arith(int f32_instruction) { return c1_f32_arith().exchange(f32_instruction ? 1 : 0); }
+
 int vido_conv1x1_layout(int cin, int cout, int hw)
 {
     // Default 128: measured on the pipelined headline (two A/B pairs of 100 steps, profiles/r5/conv1x1_tile_form_ab.txt) the 112-wide form costs 2.5 % (88.3 -> 86.1 frames/s)
     // although the detector ALONE gets faster (8.87 -> 8.65 ms): beside two other streams the CUs a 216-tile launch leaves idle are not idle — they run LiteFlowNet and the
     // tracker — and the 112-wide form needs the same matrix time on 248 CUs plus more LDS reads per matrix instruction.  VIDO_CONV1X1_TN=0 lets the rounds rule below decide
     // (a detector running alone), 112 / 128 force a form.
+    // round 6: the split-bf16 form (k_conv1x1_b3: fp32-equivalent arithmetic on the bf16 matrix instruction) is the default; VIDO_CONV1X1_ARITH=f32 (or a forced
+    // VIDO_CONV1X1_TN) brings the fp32-instruction forms back.
+    if (!c1_f32_arith().load(std::memory_order_relaxed)) return 2;
     static const int force = [] { const char* e = getenv("VIDO_CONV1X1_TN"); return e ? atoi(e) : 128; }();
     if (force == 128 || cin % 64 != 0) return 0;
     if (force == 112) return 1;
@@ -307,6 +505,28 @@ static int c1_launch(vido_ctx* ctx, const float* x, const float* w_packed, const
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
     const int rm = residual ? res_mode : 0;
+    if (vido_conv1x1_layout(cin, cout, hw) == 2) {
+        const int mt = cout / C1_TM, ntl = (hw + C1_TN - 1) / C1_TN, total = mt * ntl;
+        C1Args A{x, w_packed, bias, residual, y, cout, hw, cin, mt, total, cin / 16, slope, (unsigned)(4ll * cin * hw), (unsigned)(6ll * cin * cout), w};
+        // form: VIDO_CONV1X1_B3_FORM = 0 (default: by shape), 1 = <1, 6>, 2 = <2, 4>, 3 = <1, 4> two workgroups per CU
+        static const int force_form = [] { const char* e = getenv("VIDO_CONV1X1_B3_FORM"); return e ? atoi(e) : 0; }();
+        int form = force_form ? force_form : (cin >= 512 && total <= 320 ? 2 : 3);
+        if (form == 2 && cin % 64) form = 3;                                // (two groups: an even number of slots of two k-steps)
+        constexpr size_t LDS_F1 = (size_t)6 * B3_SLOT, LDS_F2 = (size_t)4 * 2 * B3_SLOT, LDS_F3 = (size_t)4 * B3_SLOT;
+        static bool attr3[64] = {};
+        if (!attr3[ctx->device & 63]) {
+            for (const void* f : {(const void*)k_conv1x1_b3<0, 1, 6>, (const void*)k_conv1x1_b3<1, 1, 6>, (const void*)k_conv1x1_b3<2, 1, 6>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_F1));
+            for (const void* f : {(const void*)k_conv1x1_b3<0, 2, 4>, (const void*)k_conv1x1_b3<1, 2, 4>, (const void*)k_conv1x1_b3<2, 2, 4>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_F2));
+            for (const void* f : {(const void*)k_conv1x1_b3<0, 1, 4>, (const void*)k_conv1x1_b3<1, 1, 4>, (const void*)k_conv1x1_b3<2, 1, 4>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_F3));
+            attr3[ctx->device & 63] = true;
+        }
+        const dim3 grid(8 * ((total + 7) / 8));
+#define B3_LAUNCH(G_, RB_, LDS_) do { const dim3 blk(256 * G_); if (rm == 2) hipLaunchKernelGGL((k_conv1x1_b3<2, G_, RB_>), grid, blk, LDS_, st, A); else if (rm) hipLaunchKernelGGL((k_conv1x1_b3<1, G_, RB_>), grid, blk, LDS_, st, A); else hipLaunchKernelGGL((k_conv1x1_b3<0, G_, RB_>), grid, blk, LDS_, st, A); } while (0)
+        if (form == 2) B3_LAUNCH(2, 4, LDS_F2); else if (form == 1) B3_LAUNCH(1, 6, LDS_F1); else B3_LAUNCH(1, 4, LDS_F3);
+#undef B3_LAUNCH
+        HIP_TRY(ctx, hipGetLastError());
+        return VIDO_OK;
+    }
     if (vido_conv1x1_layout(cin, cout, hw) == 1) {
         const int mt = cout / C1_TM, ntl = (hw + C2_TN - 1) / C2_TN, total = mt * ntl;
         C1Args A{x, w_packed, bias, residual, y, cout, hw, cin, mt, total, cin / 64, slope, (unsigned)(4ll * cin * hw), (unsigned)(4ll * cin * cout), w};

@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvido_slam_hip.so")
+LIB_PATH = os.environ.get("VIDO_LIB_VARIANT") or os.path.join(_HERE, "libvido_slam_hip.so")      # (VIDO_LIB_VARIANT: an experiment build of the same sources, tools/r6/)
 
 VIDO_OK = 0
 KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"), ("octave", "i4")])

@@ -155,6 +155,10 @@ class HipOps:
     def conv1x1_supported(self, cin, cout, hw):
         return bool(self.ctx.lib.vido_conv1x1_supported(int(cin), int(cout), int(hw)))
 
+    def conv1x1_set_arith(self, f32_instruction):
+        """0: split-bf16 (fp32-equivalent, the default), 1: the fp32 matrix instruction; returns the previous setting (vido_conv1x1_set_arith, process-wide)."""
+        return int(self.ctx.lib.vido_conv1x1_set_arith(int(bool(f32_instruction))))
+
     def conv1x1_layout(self, cin, cout, hw):
         return int(self.ctx.lib.vido_conv1x1_layout(int(cin), int(cout), int(hw)))
 
@@ -166,9 +170,10 @@ class HipOps:
         _, cin, H, W = x.shape
         if isinstance(w_packed, PackedConv1x1):                     # packed on first use, in the tile form the library picks for this (cin, cout, H * W)
             w_packed = w_packed.get(self.conv1x1_layout(cin, w_packed.cout, H * W), x.device)
-        cout = w_packed.numel() // cin
+        cout = w_packed.numel() // cin // (3 if w_packed.dtype == torch.int16 else 1)
         layout = self.conv1x1_layout(cin, cout, H * W)
-        assert tuple(w_packed.shape) == ((cout // 16, cin // 16, 64, 4) if layout == 1 else (cout // 32, cin // 8, 64, 4)), "conv1x1: weight packed for the other tile form (pack_conv1x1(w, layout))"
+        assert not self.conv1x1_supported(cin, cout, H * W) or tuple(w_packed.shape) == {0: (cout // 32, cin // 8, 64, 4), 1: (cout // 16, cin // 16, 64, 4), 2: (cout // 32, cin // 16, 3, 64, 8)}[layout], \
+            "conv1x1: weight packed for another form (pack_conv1x1(w, layout))"      # (an unsupported shape is refused by the library call below)
         assert 0.0 <= slope <= 1.0 and (residual is None or residual_up2 is None)
         out = torch.empty((1, cout, H, W), device=x.device, dtype=torch.float32)
         self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * cout * cin * H * W      # (torch's FlopCounterMode does not see this launch; bench.py adds it)
@@ -516,17 +521,33 @@ def conv1x1_fills_chip(cout, hw):
     return (int(cout) // 128) * ((int(hw) + 127) // 128) >= _C1X1_MIN_TILES
 
 
+def split_bf16x3(x):
+    """fp32 tensor -> three bf16 tensors with x0 + x1 + x2 == x EXACTLY (x0 = rne(x), x1 = rne(x - x0), x2 = x - x0 - x1: three 8-bit significands + signs cover the 24 bits
+    of fp32; exponents far above the bf16 subnormal range assumed) — the operand form of csrc/conv1x1.hip::k_conv1x1_b3 and of the Winograd kernel's split-bf16 form."""
+    x = x.float()
+    x0 = x.to(torch.bfloat16); r1 = x - x0.float()
+    x1 = r1.to(torch.bfloat16); r2 = r1 - x1.float()
+    x2 = r2.to(torch.bfloat16)
+    return x0, x1, x2
+
+
 def pack_conv1x1(w, layout=0):
     """1x1 convolution weight [cout, cin, 1, 1] (or [cout, cin]) -> the operand order of csrc/conv1x1.hip (layout = HipOps.conv1x1_layout(cin, cout, H * W) = vido_conv1x1_layout):
     0: element (co, k) at [co / 32][k / 8][32 * (k & 1) + co % 32][(k % 8) / 2] (a lane's four operands of a group of four k-pairs are one 16-byte read; a (32-channel block, group)
        is one 1 KB copy piece) — the 128 x 128 tiles on the 32 x 32 x 2 matrix instruction;
-    1: at [co / 16][k / 16][16 * (k & 3) + co % 16][(k % 16) / 4] (a lane's 16-byte read = its operands of four k-steps of a 16-row fragment) — the 128 x 112 tiles on 16 x 16 x 4.
+    1: at [co / 16][k / 16][16 * (k & 3) + co % 16][(k % 16) / 4] (a lane's 16-byte read = its operands of four k-steps of a 16-row fragment) — the 128 x 112 tiles on 16 x 16 x 4;
+    2: the weight split into three bf16 planes (split_bf16x3), plane p of element (co, k) at [co / 32][k / 16][p][32 * ((k % 16) / 8) + co % 32][k % 8] (int16 tensor: a 1 KB copy
+       piece = the A operand of v_mfma_f32_32x32x16_bf16 for one (32-channel block, 16 input channels, plane)) — the split-bf16 form k_conv1x1_b3.
     None when the kernel does not take the shape."""
     cout, cin = int(w.shape[0]), int(w.shape[1])
     if w.dim() == 4 and tuple(w.shape[2:]) != (1, 1):
         return None
     if cout % 128 or cin % 32 or (layout == 1 and cin % 64):
         return None
+    if layout == 2:
+        p0, p1, p2 = split_bf16x3(w.detach().reshape(cout, cin).float())
+        w6 = torch.stack([p0, p1, p2], 0).view(torch.int16).reshape(3, cout // 32, 32, cin // 16, 2, 8)      # [plane][mb][co32][step][k half][8]
+        return w6.permute(1, 3, 0, 4, 2, 5).contiguous().reshape(cout // 32, cin // 16, 3, 64, 8)
     if layout == 1:
         w5 = w.detach().reshape(cout // 16, 16, cin // 16, 4, 4)         # [fragment][co16][group][e][kk]   with k = 16 group + 4 e + kk
         return w5.permute(0, 2, 4, 1, 3).contiguous().reshape(cout // 16, cin // 16, 64, 4)
