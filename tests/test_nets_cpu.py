@@ -65,6 +65,38 @@ def test_resnet18_encoder_layout():
     assert [tuple(f.shape[1:]) for f in feats] == [(64, 32, 64), (64, 16, 32), (128, 8, 16), (256, 4, 8), (512, 2, 4)]
 
 
+def _seeded_encoder():
+    """the encoder tools/gen_golden_refimpl.py::encoder_case builds (same seed, same order of draws)"""
+    from vido_slam_amd.nets.monodepth2 import ResnetEncoder18
+    torch.manual_seed(5)
+    enc = ResnetEncoder18().eval()
+    with torch.no_grad():
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 2.0); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    img = torch.rand(3, 64, 96)
+    return enc, img
+
+
+def test_resnet18_encoder_matches_the_float64_forward():
+    """ResnetEncoder18 (resnet_encoder.py:87-98 over torchvision's ResNet-18, which this image lacks) against tests/golden/refimpl_kats.npz: the five feature maps of a
+    hand-written float64 numpy ResNet-18 forward (tests/refimpl/resnet18_f64.py: its own convolution, batch norm, max pool and block wiring) on a 64 x 96 image with
+    randomised batch-norm statistics — pins the encoder's ARITHMETIC (strides, paddings, where the ReLUs and the shortcut sit), not only its parameter layout."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "refimpl_kats.npz"))
+    enc, img = _seeded_encoder()
+    assert np.array_equal(img.numpy(), G["enc_image"])                                  # the fixture's own input
+    with torch.no_grad():
+        feats = enc(img[None])
+    assert [tuple(f.shape[1:]) for f in feats] == [(64, 32, 48), (64, 16, 24), (128, 8, 12), (256, 4, 6), (512, 2, 3)]
+    for i, f in enumerate(feats):
+        ref = G["enc_feat%d" % i]
+        assert np.abs(f[0].numpy() - ref).max() <= 5e-6 * np.abs(ref).max(), i          # fp32 module against float64: observed 5e-7
+    # and the float64 forward itself regenerates the fixture (the generator is deterministic)
+    from tests.refimpl.resnet18_f64 import resnet18_encoder_f64
+    again = resnet18_encoder_f64(enc.state_dict(), img.numpy())
+    assert all(np.array_equal(a.astype(np.float32), G["enc_feat%d" % i]) for i, a in enumerate(again))
+
+
 def test_analyse_wrappers_shapes():
     rng = np.random.RandomState(0)
     img = rng.randint(0, 255, (70, 100, 3)).astype(np.uint8)
@@ -154,6 +186,16 @@ def test_pack_conv1x1_is_the_operand_order_of_the_kernel():
             co, k = (int(torch.randint(0, n, (1,), generator=g)) for n in (cout, cin))
             assert float(p[co // 16, k // 16, 16 * (k & 3) + co % 16, (k % 16) // 4]) == float(w[co, k, 0, 0])
     assert pack_conv1x1(torch.zeros(128, 96, 1, 1), 1) is None
+    # layout 2 (the split-bf16 form, v_mfma_f32_32x32x16_bf16: lane l supplies A[row l % 32][k 8 (l / 32) .. + 7]): three bf16 planes whose sum is the weight EXACTLY
+    from vido_slam_amd.nets.ops import split_bf16x3
+    w = torch.randn(256, 64, 1, 1) * torch.logspace(-6, 3, 64)[None, :, None, None]
+    p = pack_conv1x1(w, 2)
+    assert tuple(p.shape) == (8, 4, 3, 64, 8) and p.dtype == torch.int16
+    planes = split_bf16x3(w.reshape(256, 64))
+    assert torch.equal(planes[0].double() + planes[1].double() + planes[2].double(), w.reshape(256, 64).double())
+    for co, k in ((0, 0), (37, 9), (255, 63), (128, 16), (31, 8)):
+        for pl in range(3):
+            assert int(p[co // 32, k // 16, pl, 32 * ((k % 16) // 8) + co % 32, k % 8]) == int(planes[pl].view(torch.int16)[co, k])
 
 
 def test_conv1x1_tile_form_is_chosen_by_rounds_of_workgroups():
@@ -164,9 +206,12 @@ def test_conv1x1_tile_form_is_chosen_by_rounds_of_workgroups():
     import subprocess, sys
     code = ("import sys; sys.path.insert(0, %r); from vido_slam_amd.host import load_library; lib = load_library(); "
             "print([lib.vido_conv1x1_layout(*a) for a in ((256, 256, 200 * 272), (512, 512, 100 * 136), (1024, 1024, 50 * 68), (96, 128, 4096), (256, 256, 128 * 128 * 2))])" % ROOT)
-    for tn, want in (("0", [1, 1, 1, 0, 0]), ("128", [0, 0, 0, 0, 0]), ("112", [1, 1, 1, 0, 1]), (None, [0, 0, 0, 0, 0])):
-        env = {k: v for k, v in os.environ.items() if k != "VIDO_CONV1X1_TN"}
-        if tn is not None:
+    # (round 6: without any switch the split-bf16 form = layout 2 takes every shape; VIDO_CONV1X1_ARITH=f32 or a forced tile width bring the fp32-instruction forms back)
+    for tn, want in (("0", [1, 1, 1, 0, 0]), ("128", [0, 0, 0, 0, 0]), ("112", [1, 1, 1, 0, 1]), (None, [2, 2, 2, 2, 2]), ("f32", [0, 0, 0, 0, 0])):
+        env = {k: v for k, v in os.environ.items() if k not in ("VIDO_CONV1X1_TN", "VIDO_CONV1X1_ARITH")}
+        if tn == "f32":
+            env["VIDO_CONV1X1_ARITH"] = "f32"
+        elif tn is not None:
             env["VIDO_CONV1X1_TN"] = tn
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == str(want), (tn, out.stdout, out.stderr[-500:])

@@ -55,6 +55,30 @@ def test_roi_align_vs_oracle_bit_exact(ops, oracle):
         assert np.array_equal(got, ref), (ph, pw, sr)
 
 
+def test_roi_align_kernels_match_the_independent_float64_implementation(ops, vido):
+    """vido_roi_align (NCHW) and k_roi_align_nhwc (the form the detector runs) against tests/golden/refimpl_kats.npz (float64 numpy ROI-Align written from
+    ROIAlign_cpu.cpp:15-217, tools/gen_golden_refimpl.py) — the kernels are checked against the reference's rule directly, not only against the C oracle."""
+    import os, torch
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refimpl_kats.npz"))
+    feat, rois = G["roi_feat"], G["roi_rois"]
+    for k in range(4):
+        scale, ph, pw, sr = G["roi_cfg%d" % k]; ph, pw, sr = int(ph), int(pw), int(sr)
+        ref = G["roi_out%d" % k]
+        got = ops.roi_align(feat, rois, (ph, pw), float(np.float32(scale)), sr)
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k
+    # the NHWC multi-level form (what the detector runs) with every ROI on level 0
+    from vido_slam_amd.nets.ops import HipOps
+    hops = HipOps(vido.Context(width=640, height=480, max_batch=1))
+    ft = torch.from_numpy(feat).cuda()
+    for img in range(2):
+        sel = rois[:, 0] == img
+        boxes = torch.from_numpy(rois[sel][:, 1:5].copy()).cuda(); lvl = torch.zeros(int(sel.sum()), dtype=torch.int32, device="cuda")
+        nh = [hops.to_nhwc(ft[img:img + 1].contiguous())]
+        got = hops.roi_align_fpn_nhwc(nh, boxes, lvl, (7, 7), (0.25,), 2).cpu().numpy()
+        ref = G["roi_out0"][sel]
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), img
+
+
 def test_correlation_vs_oracle(ops, oracle):
     rng = np.random.RandomState(2)
     # the five LiteFlowNet call shapes scaled down (C, stride as in layers.py:124-159)

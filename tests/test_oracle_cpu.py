@@ -323,3 +323,22 @@ def test_short_sincos_of_the_brief_rotation_equals_libm_on_the_whole_domain():
         assert lib.vo_sincos_0_2pi_mismatches(0, 1) == 0
     for first in (0, 7, 100):
         assert lib.vo_sincos_0_2pi_mismatches(first, 251) == 0
+
+
+def test_roi_align_oracle_matches_the_independent_float64_implementation(oracle):
+    """oracle/nets_oracle.c::vo_roi_align against tests/golden/refimpl_kats.npz — ROI-Align computed by a float64 numpy implementation written from the text of
+    maskrcnn_benchmark/csrc/cpu/ROIAlign_cpu.cpp:15-217 (tests/refimpl/roi_align_f64.py: vectorised over a ROI's sample grid, separable gather — not the oracle's loops).
+    The golden detector fixture was generated with the oracle standing in for _C.roi_align_forward (tools/gen_golden_maskrcnn.py:77-78); this closes that loop.
+    ROIs reaching outside the map, malformed (x2 < x1), far outside, whole-map; sampling ratio 2, 3 and 0 (adaptive)."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refimpl_kats.npz"))
+    feat, rois = G["roi_feat"], G["roi_rois"]
+    from tests.refimpl.roi_align_f64 import roi_align_f64
+    for k in range(4):
+        scale, ph, pw, sr = G["roi_cfg%d" % k]; ph, pw, sr = int(ph), int(pw), int(sr)
+        ref = G["roi_out%d" % k]
+        got = oracle.roi_align(feat, rois, float(np.float32(scale)), ph, pw, sr)
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k          # fp32 arithmetic (the reference's T = float) against float64: observed 7e-6
+        assert np.array_equal(roi_align_f64(feat, rois, np.float32(scale), ph, pw, sr).astype(np.float32), ref)      # the generator reproduces its fixture
+    assert np.all(G["roi_out0"][-1] == 0.0) and np.abs(G["roi_out0"][-2]).max() > 0       # far outside: all samples invalid; whole map: not degenerate

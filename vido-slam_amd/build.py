@@ -35,10 +35,29 @@ def _obj_stamp(src):
 FILE_FLAGS = {"convdirect": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
+_PROBED = {}
+
+
+def _flag_ok(flags):
+    """True when this hipcc accepts `flags` (an LLVM that does not know a `-mllvm` cl::opt aborts with 'Unknown command line argument'): probed once on an empty TU."""
+    key = " ".join(flags)
+    if key not in _PROBED:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "probe.hip"); open(src, "w").write("__global__ void k() {}\n")
+            r = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-c", "-x", "hip", src, "-o", os.path.join(d, "probe.o")] + flags,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _PROBED[key] = r.returncode == 0
+    return _PROBED[key]
+
+
 def _file_flags(src):
     """FILE_FLAGS + VIDO_FLAGS_<stem> (e.g. VIDO_FLAGS_orb="-DFS_MAXIW=37"): experiment flags for one source only, so that a variant build recompiles one object"""
     stem = os.path.basename(src).split(".")[0]
-    return FILE_FLAGS.get(stem, []) + _shlex.split(os.environ.get("VIDO_FLAGS_" + stem, ""))
+    ff = FILE_FLAGS.get(stem, [])
+    if ff and not _flag_ok(ff):
+        ff = []                                                          # (an optimisation flag this compiler does not know: build without it)
+    return ff + _shlex.split(os.environ.get("VIDO_FLAGS_" + stem, ""))
 
 
 def build(force=False, verbose=False, lib=None):

@@ -2610,6 +2610,15 @@ public:
         return std::max(1, n);
     }
     int size() const { return n_; }
+    static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        asm volatile("yield" ::: "memory");
+#else
+        std::this_thread::yield();
+#endif
+    }
     // f(tid) on n_ threads (the caller is thread 0); returns when all are done.  A set-up is ~30 passes of 30-300 us back to back: a worker that went to sleep on the
     // condition variable after every pass cost a futex wake-up (30-60 us) per pass and thread — more than a third of the set-up.  Workers therefore SPIN for the next pass
     // for a few hundred microseconds after finishing one (they sleep between calls), and the caller spins for their completion.
@@ -2619,7 +2628,9 @@ public:
         { std::lock_guard<std::mutex> g(m_); job_ = &f; pending_.store(n_ - 1, std::memory_order_relaxed); gen_.fetch_add(1, std::memory_order_release); }
         if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
         f(0);
-        while (pending_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+        // bounded spin, then yield: with more runnable threads than CPUs (a quota change, several ranks without LOCAL_WORLD_SIZE) a pure spin would hold the very core a
+        // worker needs for a scheduler quantum
+        for (int spin = 0; pending_.load(std::memory_order_acquire) != 0; spin++) { if (spin < 4000) cpu_relax(); else std::this_thread::yield(); }
         job_ = nullptr;
     }
     // chunks of [0, n): f(lo, hi, tid)
@@ -2632,7 +2643,7 @@ private:
         n_ = std::max(1, std::min(want, (int)std::thread::hardware_concurrency()));
         for (int t = 1; t < n_; t++) th_.emplace_back([this, t] { int seen = 0; for (;;) {
             bool got = false;
-            for (int i = 0; i < 20000 && !got; i++) { got = stop_.load(std::memory_order_relaxed) || gen_.load(std::memory_order_acquire) != seen; if (!got) __builtin_ia32_pause(); }
+            for (int i = 0; i < 20000 && !got; i++) { got = stop_.load(std::memory_order_relaxed) || gen_.load(std::memory_order_acquire) != seen; if (!got) cpu_relax(); }
             if (!got) { std::unique_lock<std::mutex> g(m_); sleepers_.fetch_add(1, std::memory_order_release);
                         cv_.wait(g, [&] { return stop_.load(std::memory_order_relaxed) || gen_.load(std::memory_order_acquire) != seen; }); sleepers_.fetch_sub(1, std::memory_order_release); }
             if (stop_.load(std::memory_order_relaxed)) return;

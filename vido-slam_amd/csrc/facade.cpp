@@ -1408,6 +1408,7 @@ int vido_system_get_stats(const vido_system* s, vido_system_stats* o)
 {
     if (!s || !o || !s->inited) return VIDO_E_INVALID;
     memset(o, 0, sizeof *o);
+    try { VIDO_SLAM::finish_local_ba(); } catch (...) { }      // (VIDO_LBA_ASYNC: the helper's window solve writes the Map and the timings read below)
     VIDO_SLAM::Tracking* T = const_cast<vido_system*>(s)->sys.GetTracker(); VIDO_SLAM::Map* M = const_cast<vido_system*>(s)->sys.GetMap();
     if (!T || !T->mpCurrentFrame) return VIDO_OK;
     const VIDO_SLAM::Frame* F = T->mpCurrentFrame;

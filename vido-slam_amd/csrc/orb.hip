@@ -1595,7 +1595,16 @@ int orb_state_create(vido_ctx* ctx)
     HIP_TRY(ctx, hipMemset(S->d_pyr, 0, S->slab * B));
     HIP_TRY(ctx, hipMemset(S->d_blur, 0, S->slab * B));
     HIP_TRY(ctx, hipMalloc(&S->d_slots, (size_t)S->slot_total * B * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipFuncSetAttribute(S->fast_iw == FS_NARROW ? (const void*)k_fast_strips<FS_NARROW> : (const void*)k_fast_strips<FS_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->fast_lds));
+    {   // the attribute is per (function, device), not per ctx: set ONCE to the ceiling, so that a second, smaller ctx (the local-BA helper: 64 features, one level) can never
+        // lower the limit the tracker's launches need (the same rule as k_pyramid_bands / k_pyramid_tiles above)
+        static bool fattr[64] = {};
+        if (S->fast_lds > 64 * 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "orb: a FAST strip of %d rows needs %zu bytes of LDS (limit 65536)", S->fast_rows, S->fast_lds);
+        if (!fattr[ctx->device & 63]) {
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_fast_strips<FS_NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_fast_strips<FS_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            fattr[ctx->device & 63] = true;
+        }
+    }
     HIP_TRY(ctx, hipMalloc(&S->d_counts, ncell * sizeof(int)));
     HIP_TRY(ctx, hipMalloc(&S->d_offsets, (ncell + 1) * sizeof(int)));
     HIP_TRY(ctx, hipMalloc(&S->d_frame_tot, (B + 1) * sizeof(int)));
@@ -1617,7 +1626,10 @@ int orb_state_create(vido_ctx* ctx)
         S->qcap = (maxN + 8 + 63) & ~63;
         if (S->qcap > 1024) return vido_set_error(ctx, VIDO_E_CAPACITY, "orb: per-level feature budget %d exceeds the quadtree kernel's 1016", maxN);
         { int m2 = 1; while (m2 < S->qcap) m2 <<= 1; S->qt_lds = (size_t)S->qcap * 84 + (size_t)m2 * 8; }      // the bitonic sort pads its keys to a power of two
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->qt_lds));
+        {   // once per device, to the ceiling (qcap = 1024: 1024 * 84 + 1024 * 8 bytes): never lowered by a later, smaller ctx
+            static bool qattr[64] = {};
+            if (!qattr[ctx->device & 63]) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 84 + 1024 * 8)); qattr[ctx->device & 63] = true; }
+        }
         HIP_TRY(ctx, hipMalloc(&S->d_qt_slot, S->cand_cap * sizeof(uint16_t)));
         HIP_TRY(ctx, hipMalloc(&S->d_sel, B * S->L * (size_t)S->qcap * sizeof(int)));
         HIP_TRY(ctx, hipMalloc(&S->d_selcnt, B * S->L * sizeof(int)));

@@ -19,12 +19,17 @@ namespace {
 struct NearSet {
     // The cell heads live in ONE per-thread array that is all -1 between uses: a set touches only the cells of its own points and puts them back in its destructor.
     // (Round 5: as a fresh (W + 2) x (H + 2) vector per call the grid was 1.2 MB of allocation + fill at 640 x 480, twice per frame — most of RenewFrameInfo's host time.)
-    int W, H; std::vector<int>& head; std::vector<int> next; const float* xy; int n_pts;
+    // At most ONE set may use the shared grid at a time (two live sets would splice their chains through different next[] arrays): a second set alive on the same thread
+    // gets a private grid instead.  The touched cells are remembered, so the caller's point buffer may change or go away before the set does.
+    int W, H; std::vector<int> own; bool shared; std::vector<int>& head; std::vector<int> next, touched; const float* xy; int n_pts;
+    static bool& in_use() { static thread_local bool u = false; return u; }
     static std::vector<int>& grid(size_t cells) { static thread_local std::vector<int> g; if (g.size() < cells) g.assign(cells, -1); return g; }
-    NearSet(const float* p, int n, int w, int h) : W(w + 2), H(h + 2), head(grid((size_t)(w + 2) * (h + 2))), next((size_t)std::max(n, 1), -1), xy(p), n_pts(n) {
-        for (int i = 0; i < n; i++) { const int c = cell(p[2 * i], p[2 * i + 1]); next[i] = head[c]; head[c] = i; }
+    NearSet(const float* p, int n, int w, int h) : W(w + 2), H(h + 2), own(in_use() ? (size_t)(w + 2) * (h + 2) : 0, -1), shared(!in_use()),
+                                                     head(shared ? grid((size_t)(w + 2) * (h + 2)) : own), next((size_t)std::max(n, 1), -1), touched((size_t)n), xy(p), n_pts(n) {
+        if (shared) in_use() = true;
+        for (int i = 0; i < n; i++) { const int c = cell(p[2 * i], p[2 * i + 1]); touched[i] = c; next[i] = head[c]; head[c] = i; }
     }
-    ~NearSet() { for (int i = 0; i < n_pts; i++) head[cell(xy[2 * i], xy[2 * i + 1])] = -1; }
+    ~NearSet() { if (shared) { for (int c : touched) head[c] = -1; in_use() = false; } }
     NearSet(const NearSet&) = delete; NearSet& operator=(const NearSet&) = delete;
     int clampx(float x) const { return std::min(std::max((int)std::floor(x) + 1, 0), W - 1); }
     int clampy(float y) const { return std::min(std::max((int)std::floor(y) + 1, 0), H - 1); }

@@ -511,13 +511,14 @@ class HipOps:
         return out
 
 
-_C1X1_MIN_TILES = int(os.environ.get("VIDO_CONV1X1_MIN_TILES", "160"))
+_C1X1_MIN_TILES = int(os.environ.get("VIDO_CONV1X1_MIN_TILES", "100"))      # (160 through round 5: the fp32-instruction kernel lost to the library at layer4's 112 tiles; the split-bf16 one wins there)
 
 
 def conv1x1_fills_chip(cout, hw):
     """csrc/conv1x1.hip works on 128 x 128 tiles, one per CU, each walking ALL input channels: a layer with few tiles (layer4's 2048 -> 2048 on 25 x 34: 112; the FPN laterals of
-    P4 / P5: 54 / 14) leaves most of the 256 CUs idle for as long as a chip-filling layer takes — measured 119 us against the library's 68 at 112 tiles.  Callers keep the
-    library below VIDO_CONV1X1_MIN_TILES (default 160)."""
+    P4 / P5: 54 / 14) leaves most of the 256 CUs idle for as long as a chip-filling layer takes — measured 119 us against the library's 68 at 112 tiles with the fp32 matrix
+    instruction, 64 us with the split-bf16 form (round 6; headline 100.8 -> 103.9 frames/s with layer4 on it, profiles/r6/headline_ab.txt).  Callers keep the library below
+    VIDO_CONV1X1_MIN_TILES (default 100)."""
     return (int(cout) // 128) * ((int(hw) + 127) // 128) >= _C1X1_MIN_TILES
 
 
