@@ -1875,6 +1875,128 @@ template <int M> __global__ __launch_bounds__(BcrGeom<M>::NT) void k_bcr_elim(Bc
         bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; dst[(size_t)i * M] = col[i]; });
     }
 }
+// ---- the same elimination with 6 x 6 BLOCK pivots (round 6) -------------------------------------------------------------------------------------
+// k_bcr_elim walks M = 66 scalar pivots: 66 x (publish a row, barrier, reciprocal, 33 broadcast reads + 66 FMAs) = 36 us per level, of which the arithmetic is ~4: the
+// rest is the per-step latency (LDS store -> barrier -> LDS load -> reciprocal chain), paid 66 times.  The unknowns are cameras of 6 parameters, so the natural pivot is a
+// 6 x 6 block: M / 6 = 11 steps.  Step kb: the D threads publish their six pivot-row entries; one barrier; EVERY thread factors the same 6 x 6 pivot block
+// P = L diag(d) L^T in registers (21 broadcast reads; redundant, but no second barrier), solves z = P^-1 col[K] for its own column, and takes
+// col[i] -= sum_j U[K + j][i] z_j for the rows below (the same reads and FMAs as six scalar steps).  The factor (15 + 6 numbers) is kept in LDS for the back substitution
+// x_K = P^-1 (y_K - U[K][rest] x_rest), 11 block steps without a barrier.  Same operation count, a sixth of the barriers and reciprocal chains; elimination without pivoting
+// inside an SPD block is backward stable as before.
+template <int M> struct BcrGeom6 {
+    static_assert(M % 6 == 0, "whole cameras");
+    static constexpr int NBLK = M / 6, R0 = BcrGeom<M>::R0, NT = BcrGeom<M>::NT;
+    static constexpr int F_OFF = M * M, DUMP = M * M + NBLK * 24;
+    static constexpr size_t LDS = ((size_t)M * M + NBLK * 24 + NT) * sizeof(double);
+};
+// P (upper triangle pm[i][j], j >= i) -> unit factor l[k][i] (i > k: L_ik) and reciprocal pivots; returns 0 when a pivot is not positive
+template <typename PM> __device__ __forceinline__ int bcr_ldl6(const PM& pm, double (&l)[6][6], double (&dinv)[6])
+{
+    double u[6][6]; int bad = 0;
+    bcr_static_for<6>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        bcr_static_for<6 - k>([&](auto ic) {
+            constexpr int i = k + decltype(ic)::value;
+            double v = pm[k][i];
+            bcr_static_for<k>([&](auto jc) { constexpr int j = decltype(jc)::value; v = __builtin_fma(-l[j][k], u[j][i], v); });
+            u[k][i] = v;
+        });
+        const double piv = u[k][k];
+        bad |= !(piv > 0.0 && piv < 1.0e300);
+        double inv = __builtin_amdgcn_rcp(piv);
+        inv = inv * (2.0 - piv * inv); inv = inv * (2.0 - piv * inv);
+        dinv[k] = inv;
+        bcr_static_for<5 - k>([&](auto ic) { constexpr int i = k + 1 + decltype(ic)::value; l[k][i] = u[k][i] * inv; });
+    });
+    return bad;
+}
+// z = P^-1 v with P = L diag(1 / dinv) L^T
+__device__ __forceinline__ void bcr_solve6(const double (&l)[6][6], const double (&dinv)[6], double (&v)[6])
+{
+    bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; bcr_static_for<i>([&](auto jc) { constexpr int j = decltype(jc)::value; v[i] = __builtin_fma(-l[j][i], v[j], v[i]); }); });
+    bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; v[i] *= dinv[i]; });
+    bcr_static_for<6>([&](auto rc) { constexpr int i = 5 - decltype(rc)::value; bcr_static_for<5 - i>([&](auto jc) { constexpr int j = i + 1 + decltype(jc)::value; v[i] = __builtin_fma(-l[i][j], v[j], v[i]); }); });
+}
+template <int M> __global__ __launch_bounds__(BcrGeom6<M>::NT) void k_bcr_elim6(BcrDev B, int s, const double* __restrict__ Lcur, int mode)
+{
+    typedef BcrGeom6<M> G;
+    extern __shared__ __attribute__((aligned(16))) double bcr_lds[];
+    double* U = bcr_lds;                  // [M][M]: row K + j = the pivot rows of block step K / 6 (entries c >= K)
+    const int c = threadIdx.x;
+    const int p = mode ? 0 : s + 2 * s * blockIdx.x;
+    const int r_lo = mode ? 2 * M : (blockIdx.y ? G::R0 : 0), r_hi = mode ? 2 * M + 1 : (blockIdx.y ? 2 * M + 1 : G::R0);
+    const int ri = r_lo + (c - M);
+    const bool has_r = !mode && p + s < B.nb, is_d = c < M, live = is_d || ri < r_hi, is_b = !is_d && ri == 2 * M;
+    const double* Dp = B.D + (size_t)p * M * M;
+    const double* Lp = Lcur + (size_t)p * M * M; const double* Lq = Lcur + (size_t)(p + s) * M * M;
+    double col[M];
+    {
+        const double* src = Dp + c; size_t stride = M;
+        bool ld = live;
+        if (!is_d && ri < M) src = Lp + ri;
+        else if (!is_d && ri < 2 * M) { src = Lq + (size_t)(ri - M) * M; stride = 1; ld = live && has_r; }
+        else if (is_b) { src = B.b + (size_t)p * M; stride = 1; }
+        bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; col[i] = ld ? src[(size_t)i * stride] : 0.0; });
+    }
+    int bad = 0;
+    bcr_static_for<G::NBLK>([&](auto kbc) {
+        constexpr int kb = decltype(kbc)::value, K0 = 6 * kb;
+        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; U[(is_d && c >= K0) ? (K0 + j) * M + c : G::DUMP + c] = col[K0 + j]; });
+        __syncthreads();
+        double pm[6][6], l[6][6], dinv[6];
+        bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; bcr_static_for<6 - i>([&](auto jc) { constexpr int j = i + decltype(jc)::value; pm[i][j] = U[(K0 + i) * M + K0 + j]; }); });
+        bad |= bcr_ldl6(pm, l, dinv);
+        {   // the factor of this block for the back substitution (one writer; read after a later barrier)
+            double* F = U + (c == K0 ? G::F_OFF + kb * 24 : G::DUMP + c);
+            int q = 0;
+            bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; bcr_static_for<5 - i>([&](auto jc) { constexpr int j = i + 1 + decltype(jc)::value; if (c == K0) F[q] = l[i][j]; q++; }); });
+            bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; if (c == K0) F[15 + i] = dinv[i]; });
+        }
+        double z[6];
+        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; z[j] = col[K0 + j]; });
+        bcr_solve6(l, dinv, z);
+        bcr_static_for<6>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const double nt = -z[j];
+            bcr_row_chunk<M, K0 + 5, (K0 + 6) / 2>((bcr_lds_row)(U + (K0 + j) * M), [&](auto ipc, const bcr_d2& u) {
+                constexpr int ip = decltype(ipc)::value;
+                col[2 * ip] = __builtin_fma(u.x, nt, col[2 * ip]);
+                col[2 * ip + 1] = __builtin_fma(u.y, nt, col[2 * ip + 1]);
+            });
+        });
+    });
+    if (bad && c == 0) *B.ok = 0.0;
+    __syncthreads();                                                               // the last block's factor is in LDS
+    if (is_d || !live) return;
+    bcr_static_for<G::NBLK>([&](auto rc) {
+        constexpr int kb = G::NBLK - 1 - decltype(rc)::value, K0 = 6 * kb;
+        double t[6];
+        bcr_static_for<6>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            bcr_row_chunk<M, K0 + 5, (K0 + 6) / 2>((bcr_lds_row)(U + (K0 + j) * M), [&](auto ipc, const bcr_d2& u) {
+                constexpr int ip = decltype(ipc)::value;
+                if constexpr (ip & 1) { a2 = __builtin_fma(u.x, col[2 * ip], a2); a3 = __builtin_fma(u.y, col[2 * ip + 1], a3); }
+                else                  { a0 = __builtin_fma(u.x, col[2 * ip], a0); a1 = __builtin_fma(u.y, col[2 * ip + 1], a1); }
+            });
+            t[j] = col[K0 + j] - ((a0 + a1) + (a2 + a3));
+        });
+        double l[6][6], dinv[6];
+        const double* F = U + G::F_OFF + kb * 24;
+        { int q = 0; bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; bcr_static_for<5 - i>([&](auto jc) { constexpr int j = i + 1 + decltype(jc)::value; l[i][j] = F[q]; q++; }); }); }
+        bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; dinv[i] = F[15 + i]; });
+        bcr_solve6(l, dinv, t);
+        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; col[K0 + j] = t[j]; });
+    });
+    if (mode) {
+        bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; if (i < B.n6) B.x[i] = col[i]; });
+    } else if (is_b) {
+        bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; B.y[(size_t)p * M + i] = col[i]; });
+    } else {
+        double* dst = (ri < M ? B.GL + ri : B.GR + (ri - M)) + (size_t)p * M * M;
+        bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; dst[(size_t)i * M] = col[i]; });
+    }
+}
 // surviving block a = 2 s blockIdx.x takes D_a -= L_a GR_{a-s} + L_{a+s}^T GL_{a+s}, L_a' = -L_a GL_{a-s}, b_a -= L_a y_{a-s} + L_{a+s}^T y_{a+s}.
 // blockIdx.y = a slice of BCR_RB rows: the slice's rows of L_a and columns of L_{a+s} are staged in LDS (broadcast operands), thread j owns output column j of the
 // slice (BCR_RB + BCR_RB accumulators) and streams the rows of GR / GL with coalesced loads.
@@ -3113,6 +3235,8 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             Bc.S = D.S; Bc.r = D.r; Bc.x = D.x;
             HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bcr_elim<66>, (size_t)(BcrGeom<66>::LDS)));
             HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bcr_elim<96>, (size_t)(BcrGeom<96>::LDS)));
+            HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bcr_elim6<66>, (size_t)(BcrGeom6<66>::LDS)));
+            HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bcr_elim6<96>, (size_t)(BcrGeom6<96>::LDS)));
         }
     }
     if (getenv("VIDO_BA_VERBOSE")) fprintf(stderr, "[ba] poses %d (cams %d + H %d) landmarks %d obs %d dyn %d | bw %d (block half-width %d) %s\n", n_pose, p.n_cam, n_H, n_ptl, no, nd, D.bw, D.bw >= 0 ? (D.bw - 5) / 6 : -1,
@@ -3428,9 +3552,15 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             else if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
             else if (Bc.m) {                                   // block cyclic reduction: 2 launches per level, log2(nb) levels, then the levels back
                 const int m = Bc.m, nb = Bc.nb;
+                static const bool scalar_piv = getenv("VIDO_BCR_SCALAR") != nullptr;      // (round 5's scalar-pivot elimination, for comparison)
                 auto elim = [&](int n_blocks, int sft, const double* Lc, int mode) {
-                    if (m == 66) hipLaunchKernelGGL(k_bcr_elim<66>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom<66>::NT), BcrGeom<66>::LDS, st, Bc, sft, Lc, mode);
-                    else         hipLaunchKernelGGL(k_bcr_elim<96>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom<96>::NT), BcrGeom<96>::LDS, st, Bc, sft, Lc, mode);
+                    if (scalar_piv) {
+                        if (m == 66) hipLaunchKernelGGL(k_bcr_elim<66>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom<66>::NT), BcrGeom<66>::LDS, st, Bc, sft, Lc, mode);
+                        else         hipLaunchKernelGGL(k_bcr_elim<96>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom<96>::NT), BcrGeom<96>::LDS, st, Bc, sft, Lc, mode);
+                    } else {
+                        if (m == 66) hipLaunchKernelGGL(k_bcr_elim6<66>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom6<66>::NT), BcrGeom6<66>::LDS, st, Bc, sft, Lc, mode);
+                        else         hipLaunchKernelGGL(k_bcr_elim6<96>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom6<96>::NT), BcrGeom6<96>::LDS, st, Bc, sft, Lc, mode);
+                    }
                 };
                 hipLaunchKernelGGL(k_bcr_pack, dim3(nb), dim3(256), 0, st, Bc);
                 double *Lc = Bc.L0, *Ln = Bc.L1; int smax = 0;
