@@ -575,6 +575,12 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
         int I = 0; while ((I + 1) * (I + 2) / 2 <= t && I < 5) I++;
         tI[u] = t < 21 ? I : 6; tJ[u] = t < 21 ? t - I * (I + 1) / 2 : t - 21;
     }
+#ifdef SM_PROF
+    unsigned long long stp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define SM_STAMP(k) do { if (sub == 1) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stp[k]) :: "memory"); } while (0)
+#else
+#define SM_STAMP(k) do { } while (0)
+#endif
     for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
         const int cbase = chunk_cmin[unit];
         d4 acc[2]; double racc = 0.0;
@@ -583,6 +589,7 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
         for (int sub = 0; sub < BA_CHUNK / SM_L; sub++) {
             const int q0 = unit * BA_CHUNK + sub * SM_L;
             if (q0 >= n_ptl) break;
+            SM_STAMP(0);
             // a landmark is a chain of dependent HBM round trips (slot range -> slot data): the wave's SM_NL landmarks of this pass go through each stage TOGETHER, and
             // everything that depends on the slot range (Cp, the W rows, the slots' camera ordinals) is requested in one round trip
             int lm[SM_NL], beg[SM_NL], cnt[SM_NL], wcol[SM_NL]; double cp[SM_NL][9], wv[SM_NL][3];
@@ -602,8 +609,10 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
                 const double* w = P.W + BA_REC * (size_t)(beg[n] + (on ? sl : 0)) + 3 * a;
                 wv[n][0] = on ? w[0] : 0.0; wv[n][1] = on ? w[1] : 0.0; wv[n][2] = on ? w[2] : 0.0;
             }
+            SM_STAMP(1);
             for (int t = threadIdx.x; t < SM_M_DOUBLES + 3 * SM_L + 9 * SM_L + 96; t += 1024) M[t] = 0.0;
             __syncthreads();
+            SM_STAMP(2);
             // the landmarks' point-side sums, reduced with LDS atomics (a shuffle tree is 108 ds_bpermute per landmark: that alone saturated the CU's LDS pipe)
 #pragma unroll
             for (int n = 0; n < SM_NL; n++) {
@@ -613,6 +622,7 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
                 }
             }
             __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();      // the wave reads back only its own landmarks' sums
+            SM_STAMP(3);
 #pragma unroll
             for (int n = 0; n < SM_NL; n++) {
                 if (cnt[n] < 0) continue;                       // wave-uniform
@@ -646,7 +656,9 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
                 if (lane == 0) { const double b0 = H6[6], b1 = H6[7], b2 = H6[8]; G[row0] = i00 * b0; G[row0 + 1] = x01 * b0 + i11 * b1; G[row0 + 2] = x02 * b0 + x12 * b1 + i22 * b2; }
                 __builtin_amdgcn_sched_barrier(0);             // one landmark's arithmetic at a time: interleaved, the two exceed the 128-VGPR budget of a 1024-thread workgroup (101 spills)
             }
+            SM_STAMP(4);
             __syncthreads();
+            SM_STAMP(5);
 #ifndef SM_NOMFMA
 #pragma unroll
             for (int u = 0; u < 2; u++) if (tv[u]) {
@@ -660,8 +672,13 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
                 for (int k = rpart; k < 3 * SM_L; k += 10) racc = __builtin_fma(G[k], M[SM_IDX(k, rcol)], racc);
             }
 #endif
+            SM_STAMP(6);
             __syncthreads();
+            SM_STAMP(7);
         }
+#ifdef SM_PROF
+        { const int sub = 1; SM_STAMP(8); }
+#endif
         // flush the window: S -= C on the lower block triangle (diagonal camera blocks in full), r -= C[rhs row]
 #pragma unroll
         for (int u = 0; u < 2; u++) if (tv[u]) {
@@ -686,6 +703,12 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
         __syncthreads();
         if (threadIdx.x < 96) { const double v = -Rs[threadIdx.x]; const int cj = threadIdx.x / 6; if (v != 0.0 && cbase + cj < P.n_cam_ord) atomicAdd(P.r + 6 * P.ord_pose[cbase + cj] + threadIdx.x % 6, v); }
         __syncthreads();
+#ifdef SM_PROF
+        { const int sub = 1; SM_STAMP(9); }
+        if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && unit == blockIdx.x)
+            printf("[sm_prof wg %d] loads-issued %llu | zero+sync %llu | atomics %llu | fillM %llu | sync %llu | mfma+rhs %llu | sync %llu || flush %llu\n", blockIdx.x,
+                   stp[1] - stp[0], stp[2] - stp[1], stp[3] - stp[2], stp[4] - stp[3], stp[5] - stp[4], stp[6] - stp[5], stp[7] - stp[6], stp[9] - stp[8]);
+#endif
     }
 }
 
@@ -1794,8 +1817,28 @@ template <int N, typename F> __device__ __forceinline__ void bcr_static_for(F&& 
 // keeps the machine scheduler from hoisting all 33 reads of a step above the FMAs (132 more live registers: spills)
 typedef double bcr_d2 __attribute__((ext_vector_type(2)));
 typedef const volatile __attribute__((address_space(3))) bcr_d2* bcr_lds_row;      // volatile: the reads stay where they are written (in chunks of eight, next to their FMAs)
+// (round 6) the chunks are software-pipelined: chunk J + 8 is requested before the FMAs of chunk J — with one wave per SIMD nothing else hides the ~130 cycles an LDS
+// read takes, and a step of four chunks that waited for each of them spent more time waiting than computing.  VIDO-internal switch: -DBCR_NO_PREFETCH restores round 5's form.
+template <int M, int J0, int NE, typename OP> __device__ __forceinline__ void bcr_row_chunk_pf(bcr_lds_row row, OP&& op, const bcr_d2 (&u)[NE])
+{
+    constexpr int J1 = J0 + NE;
+    if constexpr (J1 < M / 2) {
+        constexpr int NN = (M / 2 - J1) < 8 ? (M / 2 - J1) : 8;
+        bcr_d2 un[NN];
+#pragma unroll
+        for (int e = 0; e < NN; e++) un[e] = row[J1 + e];
+        __builtin_amdgcn_sched_barrier(0);
+        bcr_static_for<NE>([&](auto ec) { constexpr int e = decltype(ec)::value; op(std::integral_constant<int, J0 + e>{}, u[e]); });
+        __builtin_amdgcn_sched_barrier(0);
+        bcr_row_chunk_pf<M, J1, NN>(row, op, un);
+    } else {
+        bcr_static_for<NE>([&](auto ec) { constexpr int e = decltype(ec)::value; op(std::integral_constant<int, J0 + e>{}, u[e]); });
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 template <int M, int K, int J0, typename OP> __device__ __forceinline__ void bcr_row_chunk(bcr_lds_row row, OP&& op)
 {
+#ifdef BCR_NO_PREFETCH
     if constexpr (J0 < M / 2) {
         constexpr int NE = (M / 2 - J0) < 8 ? (M / 2 - J0) : 8;
         bcr_d2 u[NE];
@@ -1806,6 +1849,16 @@ template <int M, int K, int J0, typename OP> __device__ __forceinline__ void bcr
         __builtin_amdgcn_sched_barrier(0);
         bcr_row_chunk<M, K, J0 + 8>(row, op);
     }
+#else
+    if constexpr (J0 < M / 2) {
+        constexpr int NE = (M / 2 - J0) < 8 ? (M / 2 - J0) : 8;
+        bcr_d2 u[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) u[e] = row[J0 + e];
+        __builtin_amdgcn_sched_barrier(0);
+        bcr_row_chunk_pf<M, J0, NE>(row, op, u);
+    }
+#endif
 }
 template <int M> __global__ __launch_bounds__(BcrGeom<M>::NT) void k_bcr_elim(BcrDev B, int s, const double* __restrict__ Lcur, int mode)
 {
@@ -1886,8 +1939,9 @@ template <int M> __global__ __launch_bounds__(BcrGeom<M>::NT) void k_bcr_elim(Bc
 template <int M> struct BcrGeom6 {
     static_assert(M % 6 == 0, "whole cameras");
     static constexpr int NBLK = M / 6, R0 = BcrGeom<M>::R0, NT = BcrGeom<M>::NT;
-    static constexpr int F_OFF = M * M, DUMP = M * M + NBLK * 24;
-    static constexpr size_t LDS = ((size_t)M * M + NBLK * 24 + NT) * sizeof(double);
+    static constexpr int MP = 2 * M - 6;                                            // row pitch: a row's entries past column M - 1 are zeros (see k_bcr_elim6)
+    static constexpr int F_OFF = M * MP, DUMP = M * MP + NBLK * 24;
+    static constexpr size_t LDS = ((size_t)M * MP + NBLK * 24 + NT) * sizeof(double);
 };
 // P (upper triangle pm[i][j], j >= i) -> unit factor l[k][i] (i > k: L_ik) and reciprocal pivots; returns 0 when a pivot is not positive
 template <typename PM> __device__ __forceinline__ int bcr_ldl6(const PM& pm, double (&l)[6][6], double (&dinv)[6])
@@ -1917,11 +1971,50 @@ __device__ __forceinline__ void bcr_solve6(const double (&l)[6][6], const double
     bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; v[i] *= dinv[i]; });
     bcr_static_for<6>([&](auto rc) { constexpr int i = 5 - decltype(rc)::value; bcr_static_for<5 - i>([&](auto jc) { constexpr int j = i + 1 + decltype(jc)::value; v[i] = __builtin_fma(-l[i][j], v[j], v[i]); }); });
 }
+// A first version of this kernel unrolled the eleven block steps like k_bcr_elim unrolls its 66 (the register index of a row must be a compile-time constant) and ran in
+// 34 us against 36: both are 65-80 KB of straight-line code executed ONCE — instruction fetch, not arithmetic or barriers, sets their time (~8 cycles per instruction).
+// This version is a LOOP over the block steps with one body: the thread's column lives in the registers as a CYCLIC buffer that is rotated by six after every step
+// (66 register moves), so the pivot rows are always col[0..5] and the rows below always col[6..]; after M / 6 steps the rotation is the identity again.  The rows of U in
+// LDS have a pitch of 2 M - 6 with zeros behind column M - 1: a register position whose row is already eliminated meets a zero there, and whole chunks of them are skipped
+// by a uniform branch.  The back substitution runs the rotation backwards.  ~7 KB of code for the loop bodies.
+template <int M, int J0, int NE, typename OP> __device__ __forceinline__ void bcr_row_chunk_lim_pf(bcr_lds_row row, int npairs, OP&& op, const bcr_d2 (&u)[NE])
+{
+    constexpr int J1 = J0 + NE;
+    if constexpr (J1 < M / 2) {
+        if (J1 < npairs) {                                                          // (uniform) the next chunk is live: request it before this one's FMAs
+            constexpr int NN = (M / 2 - J1) < 8 ? (M / 2 - J1) : 8;
+            bcr_d2 un[NN];
+#pragma unroll
+            for (int e = 0; e < NN; e++) un[e] = row[J1 + e];
+            __builtin_amdgcn_sched_barrier(0);
+            bcr_static_for<NE>([&](auto ec) { constexpr int e = decltype(ec)::value; op(std::integral_constant<int, J0 + e>{}, u[e]); });
+            __builtin_amdgcn_sched_barrier(0);
+            bcr_row_chunk_lim_pf<M, J1, NN>(row, npairs, op, un);
+            return;
+        }
+    }
+    bcr_static_for<NE>([&](auto ec) { constexpr int e = decltype(ec)::value; op(std::integral_constant<int, J0 + e>{}, u[e]); });
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int M, int J0, typename OP> __device__ __forceinline__ void bcr_row_chunk_lim(bcr_lds_row row, int npairs, OP&& op)      // pairs J0 .. M / 2 - 1, chunks of eight, none at or past npairs
+{
+    if constexpr (J0 < M / 2) {
+        if (J0 < npairs) {                                                          // (uniform)
+            constexpr int NE = (M / 2 - J0) < 8 ? (M / 2 - J0) : 8;
+            bcr_d2 u[NE];
+#pragma unroll
+            for (int e = 0; e < NE; e++) u[e] = row[J0 + e];
+            __builtin_amdgcn_sched_barrier(0);
+            bcr_row_chunk_lim_pf<M, J0, NE>(row, npairs, op, u);
+        }
+    }
+}
 template <int M> __global__ __launch_bounds__(BcrGeom6<M>::NT) void k_bcr_elim6(BcrDev B, int s, const double* __restrict__ Lcur, int mode)
 {
     typedef BcrGeom6<M> G;
+    constexpr int MP = G::MP;
     extern __shared__ __attribute__((aligned(16))) double bcr_lds[];
-    double* U = bcr_lds;                  // [M][M]: row K + j = the pivot rows of block step K / 6 (entries c >= K)
+    double* U = bcr_lds;                  // [M][MP]: row K + j = the pivot rows of block step K / 6 (entries K <= c < M), zeros from column M on
     const int c = threadIdx.x;
     const int p = mode ? 0 : s + 2 * s * blockIdx.x;
     const int r_lo = mode ? 2 * M : (blockIdx.y ? G::R0 : 0), r_hi = mode ? 2 * M + 1 : (blockIdx.y ? 2 * M + 1 : G::R0);
@@ -1929,6 +2022,7 @@ template <int M> __global__ __launch_bounds__(BcrGeom6<M>::NT) void k_bcr_elim6(
     const bool has_r = !mode && p + s < B.nb, is_d = c < M, live = is_d || ri < r_hi, is_b = !is_d && ri == 2 * M;
     const double* Dp = B.D + (size_t)p * M * M;
     const double* Lp = Lcur + (size_t)p * M * M; const double* Lq = Lcur + (size_t)(p + s) * M * M;
+    for (int t = c; t < M * (MP - M); t += G::NT) { const int r = t / (MP - M), k = t - r * (MP - M); U[r * MP + M + k] = 0.0; }      // the zero tails (no pivot row is ever published there)
     double col[M];
     {
         const double* src = Dp + c; size_t stride = M;
@@ -1938,56 +2032,77 @@ template <int M> __global__ __launch_bounds__(BcrGeom6<M>::NT) void k_bcr_elim6(
         else if (is_b) { src = B.b + (size_t)p * M; stride = 1; }
         bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; col[i] = ld ? src[(size_t)i * stride] : 0.0; });
     }
+    auto rotate_fwd = [&]() {                                                       // position r <- position r + 6 (cyclic)
+        double t6[6];
+        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; t6[j] = col[j]; });
+        bcr_static_for<M - 6>([&](auto rc) { constexpr int r = decltype(rc)::value; col[r] = col[r + 6]; });
+        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; col[M - 6 + j] = t6[j]; });
+    };
+    auto rotate_back = [&]() {                                                      // position r <- position r - 6 (cyclic)
+        double t6[6];
+        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; t6[j] = col[M - 6 + j]; });
+        bcr_static_for<M - 6>([&](auto rc) { constexpr int r = M - 1 - decltype(rc)::value; col[r] = col[r - 6]; });
+        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; col[j] = t6[j]; });
+    };
     int bad = 0;
-    bcr_static_for<G::NBLK>([&](auto kbc) {
-        constexpr int kb = decltype(kbc)::value, K0 = 6 * kb;
-        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; U[(is_d && c >= K0) ? (K0 + j) * M + c : G::DUMP + c] = col[K0 + j]; });
+#pragma unroll 1
+    for (int kb = 0; kb < G::NBLK; kb++) {
+        const int K0 = 6 * kb;                                                      // col[r] holds row K0 + r (r < M - K0)
+        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; U[(is_d && c >= K0) ? (K0 + j) * MP + c : G::DUMP + c] = col[j]; });
         __syncthreads();
         double pm[6][6], l[6][6], dinv[6];
-        bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; bcr_static_for<6 - i>([&](auto jc) { constexpr int j = i + decltype(jc)::value; pm[i][j] = U[(K0 + i) * M + K0 + j]; }); });
+        const double* Pb = U + K0 * MP + K0;
+        bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; bcr_static_for<6 - i>([&](auto jc) { constexpr int j = i + decltype(jc)::value; pm[i][j] = Pb[i * MP + j]; }); });
         bad |= bcr_ldl6(pm, l, dinv);
         {   // the factor of this block for the back substitution (one writer; read after a later barrier)
             double* F = U + (c == K0 ? G::F_OFF + kb * 24 : G::DUMP + c);
-            int q = 0;
-            bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; bcr_static_for<5 - i>([&](auto jc) { constexpr int j = i + 1 + decltype(jc)::value; if (c == K0) F[q] = l[i][j]; q++; }); });
+            bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; bcr_static_for<5 - i>([&](auto jc) {
+                constexpr int j = i + 1 + decltype(jc)::value; constexpr int q = i * 5 - (i * (i - 1)) / 2 + (j - i - 1); if (c == K0) F[q] = l[i][j]; }); });
             bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; if (c == K0) F[15 + i] = dinv[i]; });
         }
         double z[6];
-        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; z[j] = col[K0 + j]; });
+        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; z[j] = col[j]; });
         bcr_solve6(l, dinv, z);
+        const int npairs = (M - K0) / 2;                                            // live register pairs of this step
         bcr_static_for<6>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             const double nt = -z[j];
-            bcr_row_chunk<M, K0 + 5, (K0 + 6) / 2>((bcr_lds_row)(U + (K0 + j) * M), [&](auto ipc, const bcr_d2& u) {
+            bcr_row_chunk_lim<M, 3>((bcr_lds_row)(Pb + j * MP), npairs, [&](auto ipc, const bcr_d2& u) {
                 constexpr int ip = decltype(ipc)::value;
                 col[2 * ip] = __builtin_fma(u.x, nt, col[2 * ip]);
                 col[2 * ip + 1] = __builtin_fma(u.y, nt, col[2 * ip + 1]);
             });
         });
-    });
+        rotate_fwd();
+    }
     if (bad && c == 0) *B.ok = 0.0;
     __syncthreads();                                                               // the last block's factor is in LDS
     if (is_d || !live) return;
-    bcr_static_for<G::NBLK>([&](auto rc) {
-        constexpr int kb = G::NBLK - 1 - decltype(rc)::value, K0 = 6 * kb;
+#pragma unroll 1
+    for (int kb = G::NBLK - 1; kb >= 0; kb--) {
+        const int K0 = 6 * kb;
+        rotate_back();                                                              // col[r] holds row K0 + r again
+        const double* Pb = U + K0 * MP + K0;
+        const int npairs = (M - K0) / 2;
         double t[6];
         bcr_static_for<6>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            bcr_row_chunk<M, K0 + 5, (K0 + 6) / 2>((bcr_lds_row)(U + (K0 + j) * M), [&](auto ipc, const bcr_d2& u) {
+            bcr_row_chunk_lim<M, 3>((bcr_lds_row)(Pb + j * MP), npairs, [&](auto ipc, const bcr_d2& u) {
                 constexpr int ip = decltype(ipc)::value;
                 if constexpr (ip & 1) { a2 = __builtin_fma(u.x, col[2 * ip], a2); a3 = __builtin_fma(u.y, col[2 * ip + 1], a3); }
                 else                  { a0 = __builtin_fma(u.x, col[2 * ip], a0); a1 = __builtin_fma(u.y, col[2 * ip + 1], a1); }
             });
-            t[j] = col[K0 + j] - ((a0 + a1) + (a2 + a3));
+            t[j] = col[j] - ((a0 + a1) + (a2 + a3));
         });
         double l[6][6], dinv[6];
         const double* F = U + G::F_OFF + kb * 24;
-        { int q = 0; bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; bcr_static_for<5 - i>([&](auto jc) { constexpr int j = i + 1 + decltype(jc)::value; l[i][j] = F[q]; q++; }); }); }
+        bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; bcr_static_for<5 - i>([&](auto jc) {
+            constexpr int j = i + 1 + decltype(jc)::value; constexpr int q = i * 5 - (i * (i - 1)) / 2 + (j - i - 1); l[i][j] = F[q]; }); });
         bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; dinv[i] = F[15 + i]; });
         bcr_solve6(l, dinv, t);
-        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; col[K0 + j] = t[j]; });
-    });
+        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; col[j] = t[j]; });
+    }
     if (mode) {
         bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; if (i < B.n6) B.x[i] = col[i]; });
     } else if (is_b) {
@@ -2060,6 +2175,122 @@ __global__ __launch_bounds__(384) void k_bcr_back(BcrDev B, int s)
     }
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
     if (i < m && sub == 0 && gi < B.n6) B.x[gi] = B.y[(size_t)p * m + i] - v;
+}
+
+// ---- round 6: the Schur update with the contraction split over four lanes, and the whole back substitution as ONE launch ---------------------------------------
+// k_bcr_update walks three 66-term contractions per thread with two dependent-latency-bound global loads per term (23 us per level for 1.7 MFLOP).  Here thread (j, kh)
+// takes the terms k = kh mod 4 of output column j: every load of a thread is in flight at once (17 + 17 + 17), the four partial sums meet in LDS.
+__global__ __launch_bounds__(320) void k_bcr_update4(BcrDev B, int s, const double* __restrict__ Lcur, double* __restrict__ Lnext)
+{
+    __shared__ double la[BCR_RB * 96], lq[BCR_RB * 96], part[3][2 * BCR_RB][96];
+    const int m = B.m, a = 2 * s * blockIdx.x, p = a - s, q = a + s, i0 = blockIdx.y * BCR_RB, tid = threadIdx.x;
+    const bool has_p = p >= 0, has_q = q < B.nb;
+    const double* La = Lcur + (size_t)a * m * m; const double* Lq = Lcur + (size_t)q * m * m;
+    for (int t = tid; t < BCR_RB * m; t += 320) {
+        const int r = t / m, k = t - r * m;
+        la[r * 96 + k] = has_p ? La[(size_t)(i0 + r) * m + k] : 0.0;          // L_a[i0 + r][k]
+        lq[r * 96 + k] = has_q ? Lq[(size_t)k * m + i0 + r] : 0.0;            // L_{a+s}^T[i0 + r][k]
+    }
+    __syncthreads();
+    const int kh = tid / m, j = tid - kh * m;                                 // (m <= 80: four slices of the contraction fit 320 threads; m = 96 takes three and a tail, see below)
+    const int nkh = 320 / m > 4 ? 4 : 320 / m;
+    double d[BCR_RB], ln[BCR_RB];
+#pragma unroll
+    for (int r = 0; r < BCR_RB; r++) { d[r] = 0.0; ln[r] = 0.0; }
+    if (kh < nkh) {
+        const double* GRp = B.GR + (size_t)p * m * m + j; const double* GLp = B.GL + (size_t)p * m * m + j; const double* GLq = B.GL + (size_t)q * m * m + j;
+        if (has_p) {
+#pragma unroll 8
+            for (int k = kh; k < m; k += nkh) {
+                const double gr = GRp[(size_t)k * m], gl = -GLp[(size_t)k * m];
+#pragma unroll
+                for (int r = 0; r < BCR_RB; r++) { const double l = la[r * 96 + k]; d[r] = __builtin_fma(l, gr, d[r]); ln[r] = __builtin_fma(l, gl, ln[r]); }
+            }
+        }
+        if (has_q) {
+#pragma unroll 8
+            for (int k = kh; k < m; k += nkh) {
+                const double gl = GLq[(size_t)k * m];
+#pragma unroll
+                for (int r = 0; r < BCR_RB; r++) d[r] = __builtin_fma(lq[r * 96 + k], gl, d[r]);
+            }
+        }
+        if (kh > 0) {
+#pragma unroll
+            for (int r = 0; r < BCR_RB; r++) { part[kh - 1][r][j] = d[r]; part[kh - 1][BCR_RB + r][j] = ln[r]; }
+        }
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int r = 0; r < BCR_RB; r++) {
+            double dv = d[r], lv = ln[r];
+            for (int h = 1; h < nkh; h++) { dv += part[h - 1][r][j]; lv += part[h - 1][BCR_RB + r][j]; }      // fixed order: slices 0, 1, 2, 3
+            B.D[(size_t)a * m * m + (size_t)(i0 + r) * m + j] -= dv;
+            Lnext[(size_t)a * m * m + (size_t)(i0 + r) * m + j] = lv;           // block (a, a - 2s)
+        }
+    } else if (tid >= 320 - BCR_RB) {                                         // the right-hand side rows of the slice: threads of the last wave that hold no output column
+        const int r = tid - (320 - BCR_RB); double dv = 0.0;
+        if (has_p) for (int k = 0; k < m; k++) dv += la[r * 96 + k] * B.y[(size_t)p * m + k];
+        if (has_q) for (int k = 0; k < m; k++) dv += lq[r * 96 + k] * B.y[(size_t)q * m + k];
+        B.b[(size_t)a * m + i0 + r] -= dv;
+    }
+}
+// The back substitution x_p = y_p - GL_p x_{p-s} - GR_p x_{p+s} walked the levels back with one launch each (6 x 9 us, each a 17-term dependent chain behind two cold
+// loads).  One launch for all levels: one workgroup per eliminated block, ordered by level (the top of the tree first); a workgroup first pulls its rows of GL / GR into
+// registers — they do not depend on x —, then waits for its two neighbours' x, which arrive as tagged granules (xwg.hpp: the data is its own flag) from the workgroups of
+// the levels above, or — the root block 0 — were written by the launch before.  A level costs one granule hop + 17 FMAs instead of a launch.
+// blocks[]: (p, s) per workgroup; xt: [nb][m][2] tagged words; every spin is bounded (xwg_wait_word), a timeout clears *B.ok.
+__global__ __launch_bounds__(384) void k_bcr_back_chain(BcrDev B, const int2* __restrict__ blocks, unsigned long long* xt, unsigned epoch, unsigned* abort_word)
+{
+    __shared__ double xs[2][96]; __shared__ int okf;
+    const int m = B.m, p = blocks[blockIdx.x].x, s = blocks[blockIdx.x].y, i = threadIdx.x >> 2, sub = threadIdx.x & 3, tid = threadIdx.x;
+    const bool has_r = p + s < B.nb;
+    double gl[24], gr[24];                                                    // rows of GL_p / GR_p: terms k = sub mod 4 (m <= 96)
+    const int l0 = (p - s) * m, r0 = (p + s) * m;
+    if (i < m) {
+        const double* glp = B.GL + (size_t)p * m * m + (size_t)i * m; const double* grp = B.GR + (size_t)p * m * m + (size_t)i * m;
+#pragma unroll
+        for (int t = 0; t < 24; t++) { const int k = sub + 4 * t; gl[t] = k < m ? glp[k] : 0.0; gr[t] = (k < m && has_r) ? grp[k] : 0.0; }
+    }
+    if (tid == 0) okf = 1;
+    __syncthreads();
+    // neighbours' x into LDS: threads 0 .. m-1 the left one, 96 .. 96+m-1 the right one
+    {
+        const int side = tid >= 96 ? 1 : 0, k = tid - 96 * side;
+        if (tid < 192 && k < m) {
+            const int nbk = side ? p + s : p - s;
+            double v = 0.0;
+            if (side && !has_r) v = 0.0;
+            else if (nbk == 0) { const int gi = k; v = gi < B.n6 ? B.x[gi] : 0.0; }                 // the root: solved by the launch before this one
+            else {
+                unsigned lo = 0, hi = 0; const unsigned long long* g = xt + ((size_t)nbk * m + k) * 2;
+                const bool ok = xwg_wait_word(g, epoch, abort_word, &lo) && xwg_wait_word(g + 1, epoch, abort_word, &hi);
+                if (!ok) { okf = 0; xwg_store32(abort_word, 1u); }
+                v = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+            }
+            xs[side][k] = v;
+        }
+    }
+    __syncthreads();
+    double v = 0.0;
+    if (i < m) {
+        // (the order of k_bcr_back: the left neighbour's terms, then the right one's, then the four lanes)
+#pragma unroll
+        for (int t = 0; t < 24; t++) { const int k = sub + 4 * t; if (k < m && l0 + k < B.n6) v += gl[t] * xs[0][k]; }
+        if (has_r) {
+#pragma unroll
+            for (int t = 0; t < 24; t++) { const int k = sub + 4 * t; if (k < m && r0 + k < B.n6) v += gr[t] * xs[1][k]; }
+        }
+    }
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
+    const int gi = p * m + i;
+    if (i < m && sub == 0) {
+        const double x = B.y[(size_t)p * m + i] - v;
+        if (gi < B.n6) B.x[gi] = x;
+        xwg_publish_f64(xt + ((size_t)p * m + i) * 2, epoch, x);
+    }
+    if (tid == 0 && !okf) *B.ok = 0.0;
 }
 
 // ---- trial state ------------------------------------------------------------------------------------------
@@ -2694,6 +2925,7 @@ struct BaState {
     char* pool = nullptr; char* h_pool = nullptr; size_t pool_cap = 0, hpool_cap = 0;
     int* d_long = nullptr; size_t long_cap = 0;      // landmarks with > 64 observations
     double* d_bcr = nullptr; size_t bcr_cap = 0;     // block-cyclic-reduction workspace (superblocks D, L x2, GL, GR, b, y)
+    unsigned long long* d_bcr_xt = nullptr; size_t bcr_xt_cap = 0; int2* d_bcr_blocks = nullptr; int bcr_blocks_nb = 0, bcr_blocks_n = 0; unsigned bcr_epoch = 0; unsigned* d_bcr_abort = nullptr;      // k_bcr_back_chain: tagged granules of x, its (block, level) list, the solve counter
     int* d_ticket = nullptr;                        // k_ba_backsub_chi2_local: workgroups finished so far (reset by the last one)
     std::vector<int> hv_i[8]; std::vector<double> hv_d;      // host scratch of the set-up (observation tables of the call): kept across calls — as fresh vectors they were ~40 MB of
                                                               // mmap + page faults + zero fill per global solve, the largest and most variable part of its host time
@@ -2704,7 +2936,7 @@ void ba_state_destroy(vido_ctx* ctx)
 {
     BaState* S = ctx->ba; if (!S) return;
     for (void* p : S->allocs) hipFree(p);
-    hipFree(S->d_parts); hipFree(S->d_scratch); hipHostFree(S->h_scal); hipFree(S->pool); hipHostFree(S->h_pool); hipFree(S->d_long); hipFree(S->d_bcr);
+    hipFree(S->d_parts); hipFree(S->d_scratch); hipHostFree(S->h_scal); hipFree(S->pool); hipHostFree(S->h_pool); hipFree(S->d_long); hipFree(S->d_bcr); hipFree(S->d_bcr_xt); hipFree(S->d_bcr_blocks); hipFree(S->d_bcr_abort);
     hipFree(S->d_ctl); hipHostFree(S->h_ctl); hipFree(S->d_ticket); hipFree(S->d_spec); hipHostFree(S->h_spec);
     if (S->ev0) hipEventDestroy(S->ev0);
     if (S->ev1) hipEventDestroy(S->ev1);
@@ -3237,6 +3469,18 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bcr_elim<96>, (size_t)(BcrGeom<96>::LDS)));
             HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bcr_elim6<66>, (size_t)(BcrGeom6<66>::LDS)));
             HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bcr_elim6<96>, (size_t)(BcrGeom6<96>::LDS)));
+            // the one-launch back substitution: granule buffer (zeroed once: epoch 0 is never used), the (block, level) list with the top of the tree first
+            const size_t xt_need = (size_t)nb * m * 2;
+            if (xt_need > BS->bcr_xt_cap) { HIP_TRY(ctx, hipStreamSynchronize(st)); if (BS->d_bcr_xt) hipFree(BS->d_bcr_xt); BS->bcr_xt_cap = xt_need; HIP_TRY(ctx, hipMalloc((void**)&BS->d_bcr_xt, xt_need * 8)); HIP_TRY(ctx, hipMemset(BS->d_bcr_xt, 0, xt_need * 8)); BS->bcr_epoch = 0; }
+            if (!BS->d_bcr_abort) { HIP_TRY(ctx, hipMalloc((void**)&BS->d_bcr_abort, 4)); HIP_TRY(ctx, hipMemset(BS->d_bcr_abort, 0, 4)); }
+            if (BS->bcr_blocks_nb != nb) {
+                std::vector<int2> bl; int smax = 0;
+                for (int sft = 1; sft < nb; sft *= 2) smax = sft;
+                for (int sft = smax; sft >= 1; sft /= 2) for (int pb = sft; pb < nb; pb += 2 * sft) bl.push_back(make_int2(pb, sft));
+                HIP_TRY(ctx, hipStreamSynchronize(st)); if (BS->d_bcr_blocks) hipFree(BS->d_bcr_blocks);
+                HIP_TRY(ctx, hipMalloc((void**)&BS->d_bcr_blocks, bl.size() * sizeof(int2))); HIP_TRY(ctx, hipMemcpy(BS->d_bcr_blocks, bl.data(), bl.size() * sizeof(int2), hipMemcpyHostToDevice));
+                BS->bcr_blocks_nb = nb; BS->bcr_blocks_n = (int)bl.size();
+            }
         }
     }
     if (getenv("VIDO_BA_VERBOSE")) fprintf(stderr, "[ba] poses %d (cams %d + H %d) landmarks %d obs %d dyn %d | bw %d (block half-width %d) %s\n", n_pose, p.n_cam, n_H, n_ptl, no, nd, D.bw, D.bw >= 0 ? (D.bw - 5) / 6 : -1,
@@ -3552,9 +3796,11 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             else if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
             else if (Bc.m) {                                   // block cyclic reduction: 2 launches per level, log2(nb) levels, then the levels back
                 const int m = Bc.m, nb = Bc.nb;
-                static const bool scalar_piv = getenv("VIDO_BCR_SCALAR") != nullptr;      // (round 5's scalar-pivot elimination, for comparison)
+                // scalar_piv: round 5's whole reduced solve (scalar-pivot elimination, k_bcr_update, one back-substitution launch per level); block6: the 6 x 6 block-pivot
+                // elimination k_bcr_elim6 — measured SLOWER than the scalar one (45 vs 36 us per level: profiles/r6/global_ba_reduced_solve.txt), kept as an experiment
+                static const bool scalar_piv = getenv("VIDO_BCR_SCALAR") != nullptr, block6 = getenv("VIDO_BCR_BLOCK6") != nullptr;
                 auto elim = [&](int n_blocks, int sft, const double* Lc, int mode) {
-                    if (scalar_piv) {
+                    if (!block6) {
                         if (m == 66) hipLaunchKernelGGL(k_bcr_elim<66>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom<66>::NT), BcrGeom<66>::LDS, st, Bc, sft, Lc, mode);
                         else         hipLaunchKernelGGL(k_bcr_elim<96>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom<96>::NT), BcrGeom<96>::LDS, st, Bc, sft, Lc, mode);
                     } else {
@@ -3567,11 +3813,17 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
                 for (int sft = 1; sft < nb; sft *= 2) {
                     const int n_el = (nb - sft + 2 * sft - 1) / (2 * sft), n_sv = (nb + 2 * sft - 1) / (2 * sft);
                     elim(n_el, sft, Lc, 0);
-                    hipLaunchKernelGGL(k_bcr_update, dim3(n_sv, m / BCR_RB), dim3(128), 0, st, Bc, sft, (const double*)Lc, Ln);
+                    if (scalar_piv) hipLaunchKernelGGL(k_bcr_update, dim3(n_sv, m / BCR_RB), dim3(128), 0, st, Bc, sft, (const double*)Lc, Ln);
+                    else            hipLaunchKernelGGL(k_bcr_update4, dim3(n_sv, m / BCR_RB), dim3(320), 0, st, Bc, sft, (const double*)Lc, Ln);
                     std::swap(Lc, Ln); smax = sft;
                 }
                 elim(1, 0, Lc, 1);
-                for (int sft = smax; sft >= 1; sft /= 2) hipLaunchKernelGGL(k_bcr_back, dim3((nb - sft + 2 * sft - 1) / (2 * sft)), dim3(384), 0, st, Bc, sft);
+                static const bool back_levels = getenv("VIDO_BCR_BACK_LEVELS") != nullptr;      // (round 5's launch per level, for comparison)
+                if (scalar_piv || back_levels) { for (int sft = smax; sft >= 1; sft /= 2) hipLaunchKernelGGL(k_bcr_back, dim3((nb - sft + 2 * sft - 1) / (2 * sft)), dim3(384), 0, st, Bc, sft); }
+                else {
+                    if (++BS->bcr_epoch == 0) BS->bcr_epoch = 1;                  // (a tag of 0 is what the zeroed buffer holds)
+                    hipLaunchKernelGGL(k_bcr_back_chain, dim3(BS->bcr_blocks_n), dim3(384), 0, st, Bc, (const int2*)BS->d_bcr_blocks, BS->d_bcr_xt, BS->bcr_epoch, BS->d_bcr_abort);
+                }
             }
             else if (D.bw >= 0 && band6_lds) hipLaunchKernelGGL(k_chol_band6, dim3(1), dim3(CH_NT), band6_lds, st, D, (D.bw - 5) / 6);
             else if (D.bw >= 0 && band6s_lds && band6s_nb == 8) hipLaunchKernelGGL(k_chol_band6s<8>, dim3(1), dim3(CG_NT), band6s_lds, st, D, (D.bw - 5) / 6);
