@@ -311,6 +311,48 @@ def test_conv1x1_matrix_core_gemm_equals_conv2d(vido, ctx, cin, cout, H, W, layo
         ops.conv1x1_bias_act(torch.zeros(1, 48, 25, 36, device="cuda"), torch.zeros(4, 6, 64, 4, device="cuda"))      # 48 input channels: no form for it
 
 
+_C1_SHAPES = [(64, 256, 40, 68), (256, 256, 50, 68), (256, 128, 37, 52), (1024, 1024, 10, 34), (512, 512, 25, 36), (32, 128, 12, 11), (2048, 256, 16, 16), (2048, 2048, 25, 34),
+              (256, 128, 13, 11), (96, 128, 9, 15), (256, 256, 200, 272), (1024, 1024, 50, 68), (512, 512, 100, 136)]      # = the shapes of test_conv1x1_matrix_core_gemm_equals_conv2d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", [0, 1, 2, 3])      # VIDO_CONV1X1_B3_FORM: 0 = the form the library picks by shape; 1 / 2 / 3 = <1, 6> / <2, 4> / <1, 4> forced (a child process)
+def test_split_bf16_conv1x1_is_no_less_accurate_than_the_fp32_instruction(vido, ctx, form):
+    """The admissibility rule of the split-bf16 form: on EVERY shape of the 1x1 tests the max-abs error of k_conv1x1_b3 against float64 conv2d must
+    not exceed 1.5 x the error of the fp32-matrix-instruction kernel on the same inputs — otherwise it would be narrower arithmetic than the reference's fp32 layers.
+    Measured: 0.22 - 0.60 x (two accumulator sets: the leading bf16 product is rounded once per 16 input channels, the fp32 instruction once per channel).  Also: the
+    three planes of a weight sum to it exactly, and both arithmetic settings answer through the same entry point (vido_conv1x1_set_arith)."""
+    if form:
+        import subprocess, sys, os
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        code = ("import sys; sys.path.insert(0, %r); import pytest; sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', "
+                "%r + '::test_split_bf16_conv1x1_is_no_less_accurate_than_the_fp32_instruction[0]']))" % (root, os.path.abspath(__file__)))
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VIDO_CONV1X1_B3_FORM=str(form)), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        return
+    from vido_slam_amd.nets.ops import HipOps, pack_conv1x1
+    ops = HipOps(ctx)
+    worst = 0.0
+    try:
+        for cin, cout, H, W in _C1_SHAPES:
+            g = torch.Generator().manual_seed(cin * 7 + H)
+            x = torch.randn(1, cin, H, W, generator=g); w = torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin ** 0.5); b = torch.randn(cout, generator=g); r = torch.randn(1, cout, H, W, generator=g)
+            ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double()) + r.double())
+            err = {}
+            for arith in (1, 0):
+                ops.conv1x1_set_arith(arith)
+                lay = ops.conv1x1_layout(cin, cout, H * W)
+                assert lay == (2 if arith == 0 else 0)
+                y = ops.conv1x1_bias_act(x.cuda(), pack_conv1x1(w, lay).cuda(), b.cuda(), r.cuda(), 0.0).cpu()
+                err[arith] = float((y.double() - ref).abs().max())
+            assert err[0] <= 1.5 * err[1], (cin, cout, H, W, err)
+            assert err[0] < 2e-5 * max(1.0, float(ref.abs().max()))
+            worst = max(worst, err[0] / err[1])
+    finally:
+        ops.conv1x1_set_arith(0)
+    assert worst <= 1.5
+
+
 @pytest.mark.gpu
 def test_bottleneck_with_matrix_core_1x1_equals_library_path(vido, ctx, monkeypatch):
     """_Bottleneck.forward with conv1 / conv3 / the stride-1 shortcut on csrc/conv1x1.hip (bias, shortcut add and ReLU in the GEMM's epilogue) against the same block on the

@@ -581,34 +581,48 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
 #else
 #define SM_STAMP(k) do { } while (0)
 #endif
-    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    // (round 6) The passes of this workgroup — eight per unit, the units blockIdx.x, blockIdx.x + gridDim.x, ... — are walked as ONE sequence, and the two dependent HBM
+    // round trips of a pass (slot range -> slot data) are taken out of its critical path: the slot data of pass i + 1 is requested right after the barrier in front of pass
+    // i's matrix phase, into the registers pass i has just finished with, and the slot ranges of pass i + 2 behind them.  Shader-clock stamps of the round-5 form
+    // (-DSM_PROF): 8-10 k cycles from the top of a pass to its loads being issued + 7 k in the barrier behind the zero fill (= waiting for those loads), of 39 k per pass.
+    // The point-side terms (6 + 3 doubles per slot) are loaded by the lane that also loads the slot's W row (lane = 6 slot + component: one or two loads) instead of nine
+    // loads by one lane per slot: 5 instead of 12 live registers per landmark across the matrix phase, 2 instead of 9 LDS atomic instructions.
+    constexpr int NSUB = BA_CHUNK / SM_L;
+    auto advance = [&](int& uu, int& ss) { ss++; if (ss == NSUB || uu * BA_CHUNK + ss * SM_L >= n_ptl) { ss = 0; uu += gridDim.x; } };
+    int lm[SM_NL], beg[SM_NL], cnt[SM_NL], wcol[SM_NL]; double cpa[SM_NL], cpb[SM_NL], wv[SM_NL][3];
+    int lm2[SM_NL]; int2 bc2[SM_NL];
+    auto load_idx = [&](int uu, int ss) {
+#pragma unroll
+        for (int n = 0; n < SM_NL; n++) {
+            const int q = uu * BA_CHUNK + ss * SM_L + wave + 16 * n; const bool valid = uu < n_units && q < n_ptl;
+            lm2[n] = valid ? lorder[q] : 0; bc2[n] = valid ? lbc[q] : make_int2(0, -1);      // cnt < 0: out of window / long track (k_ba_schur_long) or past the end
+        }
+    };
+    auto issue_rec = [&](int cb) {
+#pragma unroll
+        for (int n = 0; n < SM_NL; n++) {
+            lm[n] = lm2[n]; beg[n] = bc2[n].x; cnt[n] = bc2[n].y;
+            // (slot, component) pairs of the first 64 lanes — all of them for tracks of up to 10 observations
+            const bool on = lane < cnt[n] * 6; const int sl = lane / 6, a = lane - sl * 6;
+            const size_t rec = BA_REC * (size_t)(beg[n] + (on ? sl : 0));
+            wcol[n] = on ? 6 * (P.slot_ord[beg[n] + sl] - cb) + a : 0;
+            const double* w = P.W + rec + 3 * a;
+            wv[n][0] = on ? w[0] : 0.0; wv[n][1] = on ? w[1] : 0.0; wv[n][2] = on ? w[2] : 0.0;
+            cpa[n] = on ? P.Cp[rec + a] : 0.0; cpb[n] = (on && a < 3) ? P.Cp[rec + 6 + a] : 0.0;
+        }
+    };
+    int unit = blockIdx.x, sub = 0, nu = unit, ns = 0;
+    if (unit < n_units) { load_idx(unit, 0); issue_rec(chunk_cmin[unit]); advance(nu, ns); load_idx(nu, ns); }
+    d4 acc[2]; double racc = 0.0;
+    while (unit < n_units) {
         const int cbase = chunk_cmin[unit];
-        d4 acc[2]; double racc = 0.0;
+        if (sub == 0) {
+            racc = 0.0;
 #pragma unroll
-        for (int u = 0; u < 2; u++) acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int sub = 0; sub < BA_CHUNK / SM_L; sub++) {
-            const int q0 = unit * BA_CHUNK + sub * SM_L;
-            if (q0 >= n_ptl) break;
+            for (int u = 0; u < 2; u++) acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
+        }
+        {
             SM_STAMP(0);
-            // a landmark is a chain of dependent HBM round trips (slot range -> slot data): the wave's SM_NL landmarks of this pass go through each stage TOGETHER, and
-            // everything that depends on the slot range (Cp, the W rows, the slots' camera ordinals) is requested in one round trip
-            int lm[SM_NL], beg[SM_NL], cnt[SM_NL], wcol[SM_NL]; double cp[SM_NL][9], wv[SM_NL][3];
-#pragma unroll
-            for (int n = 0; n < SM_NL; n++) {
-                const int q = q0 + wave + 16 * n;
-                lm[n] = q < n_ptl ? lorder[q] : 0; const int2 bc = q < n_ptl ? lbc[q] : make_int2(0, -1);
-                beg[n] = bc.x; cnt[n] = bc.y;                    // cnt < 0: out of window / long track (k_ba_schur_long) or past the end
-            }
-#pragma unroll
-            for (int n = 0; n < SM_NL; n++) {
-#pragma unroll
-                for (int a = 0; a < 9; a++) cp[n][a] = lane < cnt[n] ? P.Cp[BA_REC * (size_t)(beg[n] + lane) + a] : 0.0;
-                // the W rows of the first 64 (slot, component) pairs — all of them for tracks of up to 10 observations
-                const bool on = lane < cnt[n] * 6; const int sl = lane / 6, a = lane - sl * 6;
-                wcol[n] = on ? 6 * (P.slot_ord[beg[n] + sl] - cbase) + a : 0;
-                const double* w = P.W + BA_REC * (size_t)(beg[n] + (on ? sl : 0)) + 3 * a;
-                wv[n][0] = on ? w[0] : 0.0; wv[n][1] = on ? w[1] : 0.0; wv[n][2] = on ? w[2] : 0.0;
-            }
             SM_STAMP(1);
             for (int t = threadIdx.x; t < SM_M_DOUBLES + 3 * SM_L + 9 * SM_L + 96; t += 1024) M[t] = 0.0;
             __syncthreads();
@@ -616,9 +630,11 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
             // the landmarks' point-side sums, reduced with LDS atomics (a shuffle tree is 108 ds_bpermute per landmark: that alone saturated the CU's LDS pipe)
 #pragma unroll
             for (int n = 0; n < SM_NL; n++) {
-                if (lane < cnt[n]) {
-#pragma unroll
-                    for (int a = 0; a < 9; a++) atomicAdd(Hs + 9 * (wave + 16 * n) + a, cp[n][a]);
+                const int sl = lane / 6, a = lane - sl * 6;
+                if (lane < cnt[n] * 6) { atomicAdd(Hs + 9 * (wave + 16 * n) + a, cpa[n]); if (a < 3) atomicAdd(Hs + 9 * (wave + 16 * n) + 6 + a, cpb[n]); }
+                for (int t = lane + 64; t < cnt[n] * 6; t += 64) {          // tracks longer than 10 observations
+                    const int s2 = t / 6, a2 = t - s2 * 6; const size_t rec = BA_REC * (size_t)(beg[n] + s2);
+                    atomicAdd(Hs + 9 * (wave + 16 * n) + a2, P.Cp[rec + a2]); if (a2 < 3) atomicAdd(Hs + 9 * (wave + 16 * n) + 6 + a2, P.Cp[rec + 6 + a2]);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();      // the wave reads back only its own landmarks' sums
@@ -659,6 +675,9 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
             SM_STAMP(4);
             __syncthreads();
             SM_STAMP(5);
+            // the next pass's slot data (its slot ranges arrived a pass ago) and the slot ranges of the pass after it: in flight beside the matrix phase
+            int fu = nu, fs = ns;
+            if (nu < n_units) { issue_rec(chunk_cmin[nu]); advance(fu, fs); load_idx(fu, fs); }
 #ifndef SM_NOMFMA
 #pragma unroll
             for (int u = 0; u < 2; u++) if (tv[u]) {
@@ -675,6 +694,11 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
             SM_STAMP(6);
             __syncthreads();
             SM_STAMP(7);
+            const bool unit_done = nu != unit;
+            const int cur = unit;
+            unit = nu; sub = ns; nu = fu; ns = fs;
+            if (!unit_done) continue;
+            (void)cur;
         }
 #ifdef SM_PROF
         { const int sub = 1; SM_STAMP(8); }
@@ -705,8 +729,8 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
         __syncthreads();
 #ifdef SM_PROF
         { const int sub = 1; SM_STAMP(9); }
-        if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && unit == blockIdx.x)
-            printf("[sm_prof wg %d] loads-issued %llu | zero+sync %llu | atomics %llu | fillM %llu | sync %llu | mfma+rhs %llu | sync %llu || flush %llu\n", blockIdx.x,
+        if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 200))
+            printf("[sm_prof wg %d] top %llu | zero+sync %llu | atomics %llu | fillM %llu | sync %llu | mfma+rhs %llu | sync %llu || flush %llu\n", blockIdx.x,
                    stp[1] - stp[0], stp[2] - stp[1], stp[3] - stp[2], stp[4] - stp[3], stp[5] - stp[4], stp[6] - stp[5], stp[7] - stp[6], stp[9] - stp[8]);
 #endif
     }
