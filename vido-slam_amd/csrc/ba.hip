@@ -552,26 +552,32 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 512) void k_ba_schur(BaDev P, in
 #ifndef SM_L
 #define SM_L 32             // landmarks per pass: 96 rows of M = 76.8 KB of LDS, two workgroups per CU
 #endif
-#define SM_NL (SM_L / 16)   // landmarks per wave and pass
+#ifndef SM_NW
+#define SM_NW 8             // waves per workgroup.  16 (round 2 - 5) leaves 128 registers per lane: with the next pass's slot data held across the matrix phase the kernel spilled
+#endif                      // 44 of them, and a scratch reload waits (vmcnt is in order) for every prefetched HBM load issued before it — the matrix phase took twice as long.  8 waves: 256.
+#define SM_NT (64 * SM_NW)
+#define SM_NTILE ((21 + SM_NW - 1) / SM_NW)      // tiles of the lower triangle per wave
+#define SM_RP (SM_NT / 96)  // row parts of the rhs matrix-vector product
+#define SM_NL (SM_L / SM_NW)   // landmarks per wave and pass
 // M is stored in the matrix cores' operand order: element (row, col) of the 3 SM_L x 96 matrix lives at [(row / 4) * 6 + col / 16][row % 4][col % 16], so the 64 lanes of
 // a wave read ONE contiguous 512-byte run per operand (a row-major M with the 4 k-rows of an operand 98 doubles apart ran into 4-way bank conflicts on every read:
 // 17 of the ~35 us of a pass).  The rhs column is kept apart (G): its tile row needs only row 0 of the A operand.
 #define SM_IDX(row, col) (((((row) >> 2) * 6 + ((col) >> 4)) << 6) + (((row) & 3) << 4) + ((col) & 15))
 #define SM_M_DOUBLES (3 * SM_L * 96)
 #define SM_LDS_BYTES ((SM_M_DOUBLES + 3 * SM_L + 9 * SM_L + 96) * sizeof(double))
-__global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, double lambda, const int* __restrict__ chunk_cmin, const int* __restrict__ lorder, const int2* __restrict__ lbc)
+__global__ __launch_bounds__(SM_NT) void k_ba_schur_mfma(BaDev P, int n_ptl, double lambda, const int* __restrict__ chunk_cmin, const int* __restrict__ lorder, const int2* __restrict__ lbc, int chunk /* landmarks per unit (window flush): a multiple of SM_L chosen by the host */)
 {
     typedef double d4 __attribute__((ext_vector_type(4)));
     extern __shared__ double M[];                               // [3 SM_L / 4][6][4][16] | G [3 SM_L] | Hs [SM_L][9]
     double* G = M + SM_M_DOUBLES; double* Hs = G + 3 * SM_L; double* Rs = Hs + 9 * SM_L;      // Rs [96]: the window's rhs, summed over the thread parts at the flush
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
-    const int n_units = (n_ptl + BA_CHUNK - 1) / BA_CHUNK;
+    const int n_units = (n_ptl + chunk - 1) / chunk;
     // tiles of this wave: the 21 lower-triangle tiles of the 6 x 6 camera tile grid (the rhs M^T G is a matrix-vector product: vector ALUs, thread = (column, row part))
-    const int rcol = threadIdx.x % 96, rpart = threadIdx.x / 96;      // 10 row parts (threads 960..1023 idle in that step)
-    int tI[2], tJ[2]; bool tv[2];
+    const int rcol = threadIdx.x % 96, rpart = threadIdx.x / 96;      // SM_RP row parts (the threads past 96 SM_RP idle in that step)
+    int tI[SM_NTILE], tJ[SM_NTILE]; bool tv[SM_NTILE];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int t = wave + 16 * u; tv[u] = t < 21;
+    for (int u = 0; u < SM_NTILE; u++) {
+        const int t = wave + SM_NW * u; tv[u] = t < 21;
         int I = 0; while ((I + 1) * (I + 2) / 2 <= t && I < 5) I++;
         tI[u] = t < 21 ? I : 6; tJ[u] = t < 21 ? t - I * (I + 1) / 2 : t - 21;
     }
@@ -587,54 +593,54 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
     // (-DSM_PROF): 8-10 k cycles from the top of a pass to its loads being issued + 7 k in the barrier behind the zero fill (= waiting for those loads), of 39 k per pass.
     // The point-side terms (6 + 3 doubles per slot) are loaded by the lane that also loads the slot's W row (lane = 6 slot + component: one or two loads) instead of nine
     // loads by one lane per slot: 5 instead of 12 live registers per landmark across the matrix phase, 2 instead of 9 LDS atomic instructions.
-    constexpr int NSUB = BA_CHUNK / SM_L;
-    auto advance = [&](int& uu, int& ss) { ss++; if (ss == NSUB || uu * BA_CHUNK + ss * SM_L >= n_ptl) { ss = 0; uu += gridDim.x; } };
+    const int NSUB = chunk / SM_L;
+    auto advance = [&](int& uu, int& ss) { ss++; if (ss == NSUB || uu * chunk + ss * SM_L >= n_ptl) { ss = 0; uu += gridDim.x; } };
     int lm[SM_NL], beg[SM_NL], cnt[SM_NL], wcol[SM_NL]; double cpa[SM_NL], cpb[SM_NL], wv[SM_NL][3];
     int lm2[SM_NL]; int2 bc2[SM_NL];
     auto load_idx = [&](int uu, int ss) {
 #pragma unroll
         for (int n = 0; n < SM_NL; n++) {
-            const int q = uu * BA_CHUNK + ss * SM_L + wave + 16 * n; const bool valid = uu < n_units && q < n_ptl;
+            const int q = uu * chunk + ss * SM_L + wave + SM_NW * n; const bool valid = uu < n_units && q < n_ptl;
             lm2[n] = valid ? lorder[q] : 0; bc2[n] = valid ? lbc[q] : make_int2(0, -1);      // cnt < 0: out of window / long track (k_ba_schur_long) or past the end
         }
     };
-    auto issue_rec = [&](int cb) {
+    auto issue_rec = [&]() {
 #pragma unroll
         for (int n = 0; n < SM_NL; n++) {
             lm[n] = lm2[n]; beg[n] = bc2[n].x; cnt[n] = bc2[n].y;
             // (slot, component) pairs of the first 64 lanes — all of them for tracks of up to 10 observations
             const bool on = lane < cnt[n] * 6; const int sl = lane / 6, a = lane - sl * 6;
             const size_t rec = BA_REC * (size_t)(beg[n] + (on ? sl : 0));
-            wcol[n] = on ? 6 * (P.slot_ord[beg[n] + sl] - cb) + a : 0;
+            wcol[n] = on ? P.slot_ord[beg[n] + sl] : 0;                  // (the slot's camera ordinal as loaded: turning it into a column HERE would wait for the load in front of the matrix phase)
             const double* w = P.W + rec + 3 * a;
             wv[n][0] = on ? w[0] : 0.0; wv[n][1] = on ? w[1] : 0.0; wv[n][2] = on ? w[2] : 0.0;
             cpa[n] = on ? P.Cp[rec + a] : 0.0; cpb[n] = (on && a < 3) ? P.Cp[rec + 6 + a] : 0.0;
         }
     };
     int unit = blockIdx.x, sub = 0, nu = unit, ns = 0;
-    if (unit < n_units) { load_idx(unit, 0); issue_rec(chunk_cmin[unit]); advance(nu, ns); load_idx(nu, ns); }
-    d4 acc[2]; double racc = 0.0;
+    if (unit < n_units) { load_idx(unit, 0); issue_rec(); advance(nu, ns); load_idx(nu, ns); }
+    d4 acc[SM_NTILE]; double racc = 0.0;
     while (unit < n_units) {
         const int cbase = chunk_cmin[unit];
         if (sub == 0) {
             racc = 0.0;
 #pragma unroll
-            for (int u = 0; u < 2; u++) acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
+            for (int u = 0; u < SM_NTILE; u++) acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
         }
         {
             SM_STAMP(0);
             SM_STAMP(1);
-            for (int t = threadIdx.x; t < SM_M_DOUBLES + 3 * SM_L + 9 * SM_L + 96; t += 1024) M[t] = 0.0;
+            for (int t = threadIdx.x; t < SM_M_DOUBLES + 3 * SM_L + 9 * SM_L + 96; t += SM_NT) M[t] = 0.0;
             __syncthreads();
             SM_STAMP(2);
             // the landmarks' point-side sums, reduced with LDS atomics (a shuffle tree is 108 ds_bpermute per landmark: that alone saturated the CU's LDS pipe)
 #pragma unroll
             for (int n = 0; n < SM_NL; n++) {
                 const int sl = lane / 6, a = lane - sl * 6;
-                if (lane < cnt[n] * 6) { atomicAdd(Hs + 9 * (wave + 16 * n) + a, cpa[n]); if (a < 3) atomicAdd(Hs + 9 * (wave + 16 * n) + 6 + a, cpb[n]); }
+                if (lane < cnt[n] * 6) { atomicAdd(Hs + 9 * (wave + SM_NW * n) + a, cpa[n]); if (a < 3) atomicAdd(Hs + 9 * (wave + SM_NW * n) + 6 + a, cpb[n]); }
                 for (int t = lane + 64; t < cnt[n] * 6; t += 64) {          // tracks longer than 10 observations
                     const int s2 = t / 6, a2 = t - s2 * 6; const size_t rec = BA_REC * (size_t)(beg[n] + s2);
-                    atomicAdd(Hs + 9 * (wave + 16 * n) + a2, P.Cp[rec + a2]); if (a2 < 3) atomicAdd(Hs + 9 * (wave + 16 * n) + 6 + a2, P.Cp[rec + 6 + a2]);
+                    atomicAdd(Hs + 9 * (wave + SM_NW * n) + a2, P.Cp[rec + a2]); if (a2 < 3) atomicAdd(Hs + 9 * (wave + SM_NW * n) + 6 + a2, P.Cp[rec + 6 + a2]);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();      // the wave reads back only its own landmarks' sums
@@ -644,7 +650,7 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
                 if (cnt[n] < 0) continue;                       // wave-uniform
                 double H6[9];
 #pragma unroll
-                for (int a = 0; a < 9; a++) H6[a] = Hs[9 * (wave + 16 * n) + a];
+                for (int a = 0; a < 9; a++) H6[a] = Hs[9 * (wave + SM_NW * n) + a];
                 if (lane == 0) {
 #pragma unroll
                     for (int a = 0; a < 6; a++) P.Hpp[6 * (size_t)lm[n] + a] = H6[a];
@@ -658,9 +664,9 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
                 const double i11 = rsq(a11 - r01 * r01), r12 = (a12 - r01 * r02) * i11;
                 const double i22 = rsq(a22 - r02 * r02 - r12 * r12);
                 const double x01 = -r01 * i11 * i00, x12 = -r12 * i22 * i11, x02 = -(r01 * x12 + r02 * i22) * i00;
-                const int row0 = 3 * (wave + 16 * n);
+                const int row0 = 3 * (wave + SM_NW * n);
                 if (lane < cnt[n] * 6) {
-                    const double w0 = wv[n][0], w1 = wv[n][1], w2 = wv[n][2]; const int col = wcol[n];
+                    const double w0 = wv[n][0], w1 = wv[n][1], w2 = wv[n][2]; const int col = 6 * (wcol[n] - cbase) + (lane - 6 * (lane / 6));
                     M[SM_IDX(row0, col)] = w0 * i00; M[SM_IDX(row0 + 1, col)] = w0 * x01 + w1 * i11; M[SM_IDX(row0 + 2, col)] = w0 * x02 + w1 * x12 + w2 * i22;
                 }
                 for (int t = lane + 64; t < cnt[n] * 6; t += 64) {          // tracks longer than 10 observations
@@ -677,18 +683,18 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
             SM_STAMP(5);
             // the next pass's slot data (its slot ranges arrived a pass ago) and the slot ranges of the pass after it: in flight beside the matrix phase
             int fu = nu, fs = ns;
-            if (nu < n_units) { issue_rec(chunk_cmin[nu]); advance(fu, fs); load_idx(fu, fs); }
+            if (nu < n_units) { issue_rec(); advance(fu, fs); load_idx(fu, fs); }
 #ifndef SM_NOMFMA
 #pragma unroll
-            for (int u = 0; u < 2; u++) if (tv[u]) {
+            for (int u = 0; u < SM_NTILE; u++) if (tv[u]) {
                 const double* pb = M + 64 * tJ[u] + lane;
                 const double* pa = M + 64 * tI[u] + lane;
 #pragma unroll 8
                 for (int ks = 0; ks < 3 * SM_L / 4; ks++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[384 * ks], pb[384 * ks], acc[u], 0, 0, 0);
             }
-            if (rpart < 10) {
+            if (rpart < SM_RP) {
 #pragma unroll 4
-                for (int k = rpart; k < 3 * SM_L; k += 10) racc = __builtin_fma(G[k], M[SM_IDX(k, rcol)], racc);
+                for (int k = rpart; k < 3 * SM_L; k += SM_RP) racc = __builtin_fma(G[k], M[SM_IDX(k, rcol)], racc);
             }
 #endif
             SM_STAMP(6);
@@ -705,7 +711,7 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
 #endif
         // flush the window: S -= C on the lower block triangle (diagonal camera blocks in full), r -= C[rhs row]
 #pragma unroll
-        for (int u = 0; u < 2; u++) if (tv[u]) {
+        for (int u = 0; u < SM_NTILE; u++) if (tv[u]) {
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const int row = 16 * tI[u] + lk + 4 * v, col = 16 * tJ[u] + lr;
@@ -723,7 +729,7 @@ __global__ __launch_bounds__(1024) void k_ba_schur_mfma(BaDev P, int n_ptl, doub
                 if (ci == cj && tI[u] != tJ[u]) { double* e2 = s_entry(P, gc, gr); if (e2) atomicAdd(e2, val); }      // a diagonal camera block that straddles two tiles: its upper part lives in the tile that is not computed
             }
         }
-        if (rpart < 10 && racc != 0.0) atomicAdd(Rs + rcol, racc);      // (Rs was zeroed with M by the last pass; nothing touched it since)
+        if (rpart < SM_RP && racc != 0.0) atomicAdd(Rs + rcol, racc);      // (Rs was zeroed with M by the last pass; nothing touched it since)
         __syncthreads();
         if (threadIdx.x < 96) { const double v = -Rs[threadIdx.x]; const int cj = threadIdx.x / 6; if (v != 0.0 && cbase + cj < P.n_cam_ord) atomicAdd(P.r + 6 * P.ord_pose[cbase + cj] + threadIdx.x % 6, v); }
         __syncthreads();
@@ -3546,7 +3552,20 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
     else { std::vector<int>& so = BS->hv_i[7]; so.resize(no);
            if (par) HP.chunks((size_t)no, [&](size_t lo, size_t hi, int) { for (size_t t = lo; t < hi; t++) so[t] = pose_ord_h[slotcam[t]]; }); else for (int t = 0; t < no; t++) so[t] = pose_ord_h[slotcam[t]];
            D.slot_ord = A.put(so.data(), no, st); }
-    int* d_chunk_cmin = nullptr; int* d_lorder = nullptr; int2* d_lbc = nullptr; int n_chunks = (n_ptl + BA_CHUNK - 1) / BA_CHUNK; bool use_mfma_schur = false;
+    // landmarks per unit of the Schur kernels.  k_ba_schur<2> has BA_CHUNK compiled in; k_ba_schur_mfma (round 6) takes it as an argument and the host sizes it so that the
+    // launch is ONE workgroup per CU where the map allows: 100 k landmarks in units of 256 are 391 workgroups on 256 CUs — 135 CUs carry two (which share the CU's matrix
+    // pipes and finish together, late), 121 carry one; units of 416 are 241 workgroups of 13 passes each, every one alone on its CU with its own loads in flight beside
+    // its matrix phase
+    int chunk = BA_CHUNK;
+    const bool mfma_schur_wanted = nd == 0 && !getenv("VIDO_BA_SCHUR_OLD");
+    if (mfma_schur_wanted && !lds_path && n_ptl) {
+        static const int force_chunk = [] { const char* e = getenv("VIDO_BA_SCHUR_CHUNK"); return e ? atoi(e) : 0; }();
+        int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device); if (ncu < 1) ncu = 256;
+        const int per_cu = (n_ptl + ncu - 1) / ncu;
+        chunk = std::max(64, std::min(512, ((per_cu + SM_L - 1) / SM_L) * SM_L));
+        if (force_chunk >= SM_L && force_chunk % SM_L == 0) chunk = force_chunk;
+    }
+    int* d_chunk_cmin = nullptr; int* d_lorder = nullptr; int2* d_lbc = nullptr; int n_chunks = (n_ptl + chunk - 1) / chunk; bool use_mfma_schur = false;
     if (!lds_path && n_ptl) {
         std::vector<int> lorder(n_ptl);
         auto first_cam = [&](int l) { return pstart[l + 1] > pstart[l] ? slotcam[pstart[l]] : n_pose; };
@@ -3561,9 +3580,9 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             for (int l = 0; l < n_ptl; l++) lorder[cs[first_cam(l)]++] = l;
         }
         std::vector<int> cmin(n_chunks, 0);
-        for (int c = 0; c < n_chunks; c++) { const int m = first_cam(lorder[c * BA_CHUNK]); cmin[c] = m == n_pose ? 0 : pose_ord_h[m]; }
-        d_chunk_cmin = A.put(cmin.data(), n_chunks, st); d_lorder = A.put(lorder.data(), n_ptl, st);
-        use_mfma_schur = nd == 0 && !getenv("VIDO_BA_SCHUR_OLD");      // (the dynamic-object graphs keep the wave-per-landmark kernel: their pose order interleaves object motions)
+        for (int c = 0; c < n_chunks; c++) { const int m = first_cam(lorder[c * chunk]); cmin[c] = m == n_pose ? 0 : pose_ord_h[m]; }
+        d_lorder = A.put(lorder.data(), n_ptl, st);
+        use_mfma_schur = mfma_schur_wanted;      // (the dynamic-object graphs keep the wave-per-landmark kernel: their pose order interleaves object motions)
         { std::vector<int>& bc = BS->hv_i[1]; bc.resize(2 * (size_t)n_ptl);      // (hv_i[1]: the camera sort's output list, swapped into `keep` and free since)
           auto fill_bc = [&](size_t qlo, size_t qhi, int) { for (size_t q = qlo; q < qhi; q++) { const int l = lorder[q]; bc[2 * q] = pstart[l]; bc[2 * q + 1] = pstart[l + 1] - pstart[l]; } };
           if (par) HP.chunks((size_t)n_ptl, fill_bc); else fill_bc(0, (size_t)n_ptl, 0);
@@ -3573,7 +3592,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
               { std::vector<std::vector<int> > outs(HP.size());
                 auto scan_q = [&](size_t qlo, size_t qhi, int t) { for (size_t q = qlo; q < qhi; q++) {
                   const int l = lorder[q], cnt = pstart[l + 1] - pstart[l]; if (!cnt) continue;
-                  const int cb = cmin[q / BA_CHUNK], lo = pose_ord_h[slotcam[pstart[l]]], hi = pose_ord_h[slotcam[pstart[l + 1] - 1]];
+                  const int cb = cmin[q / chunk], lo = pose_ord_h[slotcam[pstart[l]]], hi = pose_ord_h[slotcam[pstart[l + 1] - 1]];
                   bool out = cnt > 64 || lo < cb || hi >= cb + BA_WC || lo < 0 || hi < 0;
                   for (int t2 = pstart[l]; t2 < pstart[l + 1] && !out; t2++) { const int o = pose_ord_h[slotcam[t2]]; out = o < cb || o >= cb + BA_WC; }
                   if (out) outs[t].push_back((int)q); } };
@@ -3586,6 +3605,11 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
               if (n_out_short * 100 > (size_t)n_ptl * 3) use_mfma_schur = false;
               else for (int q : outside) { const int l = lorder[q]; bc[2 * (size_t)q + 1] = -(pstart[l + 1] - pstart[l]); if (!is_long[l]) { long_list.push_back(l); is_long[l] = 1; } }
           }
+          if (!use_mfma_schur && chunk != BA_CHUNK) {      // the wave-per-landmark kernel takes over: its unit size is compiled in
+              chunk = BA_CHUNK; n_chunks = (n_ptl + chunk - 1) / chunk; cmin.assign(n_chunks, 0);
+              for (int c = 0; c < n_chunks; c++) { const int m = first_cam(lorder[c * chunk]); cmin[c] = m == n_pose ? 0 : pose_ord_h[m]; }
+          }
+          d_chunk_cmin = A.put(cmin.data(), n_chunks, st);
           d_lbc = (int2*)A.put(bc.data(), 2 * (size_t)n_ptl, st); }
         if (A.failed) return vido_set_error(ctx, VIDO_E_NOMEM, "ba: device pool exhausted");
     }
@@ -3801,7 +3825,7 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
                     hipLaunchKernelGGL(k_ba_fold_parts, dim3(std::min(256, (int)((loc_sz + 255) / 256)), std::min(8, schur_grid)), dim3(256), 0, st, D, BS->d_parts, schur_grid);
                 } else if (use_mfma_schur) {
                     HIP_TRY(ctx, hipEventRecord(BS->ev2, st));
-                    hipLaunchKernelGGL(k_ba_schur_mfma, dim3(std::min(n_chunks, 1024)), dim3(1024), SM_LDS_BYTES, st, D, n_ptl, lambda, (const int*)d_chunk_cmin, (const int*)d_lorder, (const int2*)d_lbc);
+                    hipLaunchKernelGGL(k_ba_schur_mfma, dim3(std::min(n_chunks, 1024)), dim3(SM_NT), SM_LDS_BYTES, st, D, n_ptl, lambda, (const int*)d_chunk_cmin, (const int*)d_lorder, (const int2*)d_lbc, chunk);
                     HIP_TRY(ctx, hipEventRecord(BS->ev3, st)); n_schur_timed++;
                 }
                 else hipLaunchKernelGGL(k_ba_schur<2>, dim3(std::min(n_chunks, 1024)), dim3(64 * schur2_waves), lds_schur, st, D, n_ptl, lambda, kcap, (double*)nullptr, (const int*)d_chunk_cmin, (const int*)d_lorder, (const int2*)d_lbc);
