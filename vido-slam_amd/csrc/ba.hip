@@ -293,7 +293,25 @@ __device__ __forceinline__ void ba_linearize_body(const BaDev& P, int E, int vb,
 #pragma unroll
                 for (int it = 0; it < 8; it++) {
                     const int r = it * 4 + (lane >> 4), pc = lane & 15, sl = ssl[r];
+#if defined(LIN_FULL256) || defined(LIN_NT)
+                    // experiments (round 6): the whole 256-byte record (pad included: no partially written line) and / or non-temporal stores
+#ifdef LIN_FULL256
+                    if (sl >= 0) {
+                        const double2 v = pc < NPIECE ? *(const double2*)(stg + r * LIN_RECP + 2 * pc) : make_double2(0.0, 0.0);
+#else
+                    if (sl >= 0 && pc < NPIECE) {
+                        const double2 v = *(const double2*)(stg + r * LIN_RECP + 2 * pc);
+#endif
+                        double* dst = P.W + BA_REC * (size_t)sl + 2 * pc;
+#ifdef LIN_NT
+                        __builtin_nontemporal_store(v.x, dst); __builtin_nontemporal_store(v.y, dst + 1);
+#else
+                        *(double2*)dst = v;
+#endif
+                    }
+#else
                     if (sl >= 0 && pc < NPIECE) *(double2*)(P.W + BA_REC * (size_t)sl + 2 * pc) = *(const double2*)(stg + r * LIN_RECP + 2 * pc);
+#endif
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier();
             }
@@ -1958,190 +1976,13 @@ template <int M> __global__ __launch_bounds__(BcrGeom<M>::NT) void k_bcr_elim(Bc
         bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; dst[(size_t)i * M] = col[i]; });
     }
 }
-// ---- the same elimination with 6 x 6 BLOCK pivots (round 6) -------------------------------------------------------------------------------------
-// k_bcr_elim walks M = 66 scalar pivots: 66 x (publish a row, barrier, reciprocal, 33 broadcast reads + 66 FMAs) = 36 us per level, of which the arithmetic is ~4: the
-// rest is the per-step latency (LDS store -> barrier -> LDS load -> reciprocal chain), paid 66 times.  The unknowns are cameras of 6 parameters, so the natural pivot is a
-// 6 x 6 block: M / 6 = 11 steps.  Step kb: the D threads publish their six pivot-row entries; one barrier; EVERY thread factors the same 6 x 6 pivot block
-// P = L diag(d) L^T in registers (21 broadcast reads; redundant, but no second barrier), solves z = P^-1 col[K] for its own column, and takes
-// col[i] -= sum_j U[K + j][i] z_j for the rows below (the same reads and FMAs as six scalar steps).  The factor (15 + 6 numbers) is kept in LDS for the back substitution
-// x_K = P^-1 (y_K - U[K][rest] x_rest), 11 block steps without a barrier.  Same operation count, a sixth of the barriers and reciprocal chains; elimination without pivoting
-// inside an SPD block is backward stable as before.
-template <int M> struct BcrGeom6 {
-    static_assert(M % 6 == 0, "whole cameras");
-    static constexpr int NBLK = M / 6, R0 = BcrGeom<M>::R0, NT = BcrGeom<M>::NT;
-    static constexpr int MP = 2 * M - 6;                                            // row pitch: a row's entries past column M - 1 are zeros (see k_bcr_elim6)
-    static constexpr int F_OFF = M * MP, DUMP = M * MP + NBLK * 24;
-    static constexpr size_t LDS = ((size_t)M * MP + NBLK * 24 + NT) * sizeof(double);
-};
-// P (upper triangle pm[i][j], j >= i) -> unit factor l[k][i] (i > k: L_ik) and reciprocal pivots; returns 0 when a pivot is not positive
-template <typename PM> __device__ __forceinline__ int bcr_ldl6(const PM& pm, double (&l)[6][6], double (&dinv)[6])
-{
-    double u[6][6]; int bad = 0;
-    bcr_static_for<6>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        bcr_static_for<6 - k>([&](auto ic) {
-            constexpr int i = k + decltype(ic)::value;
-            double v = pm[k][i];
-            bcr_static_for<k>([&](auto jc) { constexpr int j = decltype(jc)::value; v = __builtin_fma(-l[j][k], u[j][i], v); });
-            u[k][i] = v;
-        });
-        const double piv = u[k][k];
-        bad |= !(piv > 0.0 && piv < 1.0e300);
-        double inv = __builtin_amdgcn_rcp(piv);
-        inv = inv * (2.0 - piv * inv); inv = inv * (2.0 - piv * inv);
-        dinv[k] = inv;
-        bcr_static_for<5 - k>([&](auto ic) { constexpr int i = k + 1 + decltype(ic)::value; l[k][i] = u[k][i] * inv; });
-    });
-    return bad;
-}
-// z = P^-1 v with P = L diag(1 / dinv) L^T
-__device__ __forceinline__ void bcr_solve6(const double (&l)[6][6], const double (&dinv)[6], double (&v)[6])
-{
-    bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; bcr_static_for<i>([&](auto jc) { constexpr int j = decltype(jc)::value; v[i] = __builtin_fma(-l[j][i], v[j], v[i]); }); });
-    bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; v[i] *= dinv[i]; });
-    bcr_static_for<6>([&](auto rc) { constexpr int i = 5 - decltype(rc)::value; bcr_static_for<5 - i>([&](auto jc) { constexpr int j = i + 1 + decltype(jc)::value; v[i] = __builtin_fma(-l[i][j], v[j], v[i]); }); });
-}
-// A first version of this kernel unrolled the eleven block steps like k_bcr_elim unrolls its 66 (the register index of a row must be a compile-time constant) and ran in
-// 34 us against 36: both are 65-80 KB of straight-line code executed ONCE — instruction fetch, not arithmetic or barriers, sets their time (~8 cycles per instruction).
-// This version is a LOOP over the block steps with one body: the thread's column lives in the registers as a CYCLIC buffer that is rotated by six after every step
-// (66 register moves), so the pivot rows are always col[0..5] and the rows below always col[6..]; after M / 6 steps the rotation is the identity again.  The rows of U in
-// LDS have a pitch of 2 M - 6 with zeros behind column M - 1: a register position whose row is already eliminated meets a zero there, and whole chunks of them are skipped
-// by a uniform branch.  The back substitution runs the rotation backwards.  ~7 KB of code for the loop bodies.
-template <int M, int J0, int NE, typename OP> __device__ __forceinline__ void bcr_row_chunk_lim_pf(bcr_lds_row row, int npairs, OP&& op, const bcr_d2 (&u)[NE])
-{
-    constexpr int J1 = J0 + NE;
-    if constexpr (J1 < M / 2) {
-        if (J1 < npairs) {                                                          // (uniform) the next chunk is live: request it before this one's FMAs
-            constexpr int NN = (M / 2 - J1) < 8 ? (M / 2 - J1) : 8;
-            bcr_d2 un[NN];
-#pragma unroll
-            for (int e = 0; e < NN; e++) un[e] = row[J1 + e];
-            __builtin_amdgcn_sched_barrier(0);
-            bcr_static_for<NE>([&](auto ec) { constexpr int e = decltype(ec)::value; op(std::integral_constant<int, J0 + e>{}, u[e]); });
-            __builtin_amdgcn_sched_barrier(0);
-            bcr_row_chunk_lim_pf<M, J1, NN>(row, npairs, op, un);
-            return;
-        }
-    }
-    bcr_static_for<NE>([&](auto ec) { constexpr int e = decltype(ec)::value; op(std::integral_constant<int, J0 + e>{}, u[e]); });
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <int M, int J0, typename OP> __device__ __forceinline__ void bcr_row_chunk_lim(bcr_lds_row row, int npairs, OP&& op)      // pairs J0 .. M / 2 - 1, chunks of eight, none at or past npairs
-{
-    if constexpr (J0 < M / 2) {
-        if (J0 < npairs) {                                                          // (uniform)
-            constexpr int NE = (M / 2 - J0) < 8 ? (M / 2 - J0) : 8;
-            bcr_d2 u[NE];
-#pragma unroll
-            for (int e = 0; e < NE; e++) u[e] = row[J0 + e];
-            __builtin_amdgcn_sched_barrier(0);
-            bcr_row_chunk_lim_pf<M, J0, NE>(row, npairs, op, u);
-        }
-    }
-}
-template <int M> __global__ __launch_bounds__(BcrGeom6<M>::NT) void k_bcr_elim6(BcrDev B, int s, const double* __restrict__ Lcur, int mode)
-{
-    typedef BcrGeom6<M> G;
-    constexpr int MP = G::MP;
-    extern __shared__ __attribute__((aligned(16))) double bcr_lds[];
-    double* U = bcr_lds;                  // [M][MP]: row K + j = the pivot rows of block step K / 6 (entries K <= c < M), zeros from column M on
-    const int c = threadIdx.x;
-    const int p = mode ? 0 : s + 2 * s * blockIdx.x;
-    const int r_lo = mode ? 2 * M : (blockIdx.y ? G::R0 : 0), r_hi = mode ? 2 * M + 1 : (blockIdx.y ? 2 * M + 1 : G::R0);
-    const int ri = r_lo + (c - M);
-    const bool has_r = !mode && p + s < B.nb, is_d = c < M, live = is_d || ri < r_hi, is_b = !is_d && ri == 2 * M;
-    const double* Dp = B.D + (size_t)p * M * M;
-    const double* Lp = Lcur + (size_t)p * M * M; const double* Lq = Lcur + (size_t)(p + s) * M * M;
-    for (int t = c; t < M * (MP - M); t += G::NT) { const int r = t / (MP - M), k = t - r * (MP - M); U[r * MP + M + k] = 0.0; }      // the zero tails (no pivot row is ever published there)
-    double col[M];
-    {
-        const double* src = Dp + c; size_t stride = M;
-        bool ld = live;
-        if (!is_d && ri < M) src = Lp + ri;
-        else if (!is_d && ri < 2 * M) { src = Lq + (size_t)(ri - M) * M; stride = 1; ld = live && has_r; }
-        else if (is_b) { src = B.b + (size_t)p * M; stride = 1; }
-        bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; col[i] = ld ? src[(size_t)i * stride] : 0.0; });
-    }
-    auto rotate_fwd = [&]() {                                                       // position r <- position r + 6 (cyclic)
-        double t6[6];
-        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; t6[j] = col[j]; });
-        bcr_static_for<M - 6>([&](auto rc) { constexpr int r = decltype(rc)::value; col[r] = col[r + 6]; });
-        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; col[M - 6 + j] = t6[j]; });
-    };
-    auto rotate_back = [&]() {                                                      // position r <- position r - 6 (cyclic)
-        double t6[6];
-        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; t6[j] = col[M - 6 + j]; });
-        bcr_static_for<M - 6>([&](auto rc) { constexpr int r = M - 1 - decltype(rc)::value; col[r] = col[r - 6]; });
-        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; col[j] = t6[j]; });
-    };
-    int bad = 0;
-#pragma unroll 1
-    for (int kb = 0; kb < G::NBLK; kb++) {
-        const int K0 = 6 * kb;                                                      // col[r] holds row K0 + r (r < M - K0)
-        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; U[(is_d && c >= K0) ? (K0 + j) * MP + c : G::DUMP + c] = col[j]; });
-        __syncthreads();
-        double pm[6][6], l[6][6], dinv[6];
-        const double* Pb = U + K0 * MP + K0;
-        bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; bcr_static_for<6 - i>([&](auto jc) { constexpr int j = i + decltype(jc)::value; pm[i][j] = Pb[i * MP + j]; }); });
-        bad |= bcr_ldl6(pm, l, dinv);
-        {   // the factor of this block for the back substitution (one writer; read after a later barrier)
-            double* F = U + (c == K0 ? G::F_OFF + kb * 24 : G::DUMP + c);
-            bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; bcr_static_for<5 - i>([&](auto jc) {
-                constexpr int j = i + 1 + decltype(jc)::value; constexpr int q = i * 5 - (i * (i - 1)) / 2 + (j - i - 1); if (c == K0) F[q] = l[i][j]; }); });
-            bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; if (c == K0) F[15 + i] = dinv[i]; });
-        }
-        double z[6];
-        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; z[j] = col[j]; });
-        bcr_solve6(l, dinv, z);
-        const int npairs = (M - K0) / 2;                                            // live register pairs of this step
-        bcr_static_for<6>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const double nt = -z[j];
-            bcr_row_chunk_lim<M, 3>((bcr_lds_row)(Pb + j * MP), npairs, [&](auto ipc, const bcr_d2& u) {
-                constexpr int ip = decltype(ipc)::value;
-                col[2 * ip] = __builtin_fma(u.x, nt, col[2 * ip]);
-                col[2 * ip + 1] = __builtin_fma(u.y, nt, col[2 * ip + 1]);
-            });
-        });
-        rotate_fwd();
-    }
-    if (bad && c == 0) *B.ok = 0.0;
-    __syncthreads();                                                               // the last block's factor is in LDS
-    if (is_d || !live) return;
-#pragma unroll 1
-    for (int kb = G::NBLK - 1; kb >= 0; kb--) {
-        const int K0 = 6 * kb;
-        rotate_back();                                                              // col[r] holds row K0 + r again
-        const double* Pb = U + K0 * MP + K0;
-        const int npairs = (M - K0) / 2;
-        double t[6];
-        bcr_static_for<6>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            bcr_row_chunk_lim<M, 3>((bcr_lds_row)(Pb + j * MP), npairs, [&](auto ipc, const bcr_d2& u) {
-                constexpr int ip = decltype(ipc)::value;
-                if constexpr (ip & 1) { a2 = __builtin_fma(u.x, col[2 * ip], a2); a3 = __builtin_fma(u.y, col[2 * ip + 1], a3); }
-                else                  { a0 = __builtin_fma(u.x, col[2 * ip], a0); a1 = __builtin_fma(u.y, col[2 * ip + 1], a1); }
-            });
-            t[j] = col[j] - ((a0 + a1) + (a2 + a3));
-        });
-        double l[6][6], dinv[6];
-        const double* F = U + G::F_OFF + kb * 24;
-        bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; bcr_static_for<5 - i>([&](auto jc) {
-            constexpr int j = i + 1 + decltype(jc)::value; constexpr int q = i * 5 - (i * (i - 1)) / 2 + (j - i - 1); l[i][j] = F[q]; }); });
-        bcr_static_for<6>([&](auto ic) { constexpr int i = decltype(ic)::value; dinv[i] = F[15 + i]; });
-        bcr_solve6(l, dinv, t);
-        bcr_static_for<6>([&](auto jc) { constexpr int j = decltype(jc)::value; col[j] = t[j]; });
-    }
-    if (mode) {
-        bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; if (i < B.n6) B.x[i] = col[i]; });
-    } else if (is_b) {
-        bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; B.y[(size_t)p * M + i] = col[i]; });
-    } else {
-        double* dst = (ri < M ? B.GL + ri : B.GR + (ri - M)) + (size_t)p * M * M;
-        bcr_static_for<M>([&](auto ic) { constexpr int i = decltype(ic)::value; dst[(size_t)i * M] = col[i]; });
-    }
-}
+// ---- what else was tried for this elimination in round 6 (built, measured on configs[4] size, removed again: profiles/r6/global_ba_reduced_solve.txt) ----------------
+//   * 6 x 6 block pivots, a thread per column, fully unrolled (11 block steps of one barrier instead of 66): 34.0 us per level against 36.1 — the barriers were never the cost;
+//   * the same as a loop over the block steps (the column as a cyclic register buffer rotated by six per step; 20 KB of code instead of 78): 45.4 us — nor is instruction fetch;
+//   * the whole 66 x 199 matrix in LDS, 1024 threads, 3 x 4 register tiles for the trailing update, four lanes per right-hand side in the back substitution: 55.9 us —
+//     shader-clock stamps: the tile update moves 54 LDS reads per 72 FMAs and is bound by LDS bandwidth (2.9 k cycles per block step), the back substitution by LDS latency
+//     (40 - 60 k cycles).  The thread-per-column form feeds 64 lanes x 2 FMAs from ONE broadcast read: that ratio is why it stays.
+//   * what did help: requesting the next chunk of a row before the FMAs of the current one (36.1 -> 34.5 us).
 // surviving block a = 2 s blockIdx.x takes D_a -= L_a GR_{a-s} + L_{a+s}^T GL_{a+s}, L_a' = -L_a GL_{a-s}, b_a -= L_a y_{a-s} + L_{a+s}^T y_{a+s}.
 // blockIdx.y = a slice of BCR_RB rows: the slice's rows of L_a and columns of L_{a+s} are staged in LDS (broadcast operands), thread j owns output column j of the
 // slice (BCR_RB + BCR_RB accumulators) and streams the rows of GR / GL with coalesced loads.
@@ -3497,8 +3338,6 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             Bc.S = D.S; Bc.r = D.r; Bc.x = D.x;
             HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bcr_elim<66>, (size_t)(BcrGeom<66>::LDS)));
             HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bcr_elim<96>, (size_t)(BcrGeom<96>::LDS)));
-            HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bcr_elim6<66>, (size_t)(BcrGeom6<66>::LDS)));
-            HIP_TRY(ctx, ba_lds_attr(ctx->device, (const void*)k_bcr_elim6<96>, (size_t)(BcrGeom6<96>::LDS)));
             // the one-launch back substitution: granule buffer (zeroed once: epoch 0 is never used), the (block, level) list with the top of the tree first
             const size_t xt_need = (size_t)nb * m * 2;
             if (xt_need > BS->bcr_xt_cap) { HIP_TRY(ctx, hipStreamSynchronize(st)); if (BS->d_bcr_xt) hipFree(BS->d_bcr_xt); BS->bcr_xt_cap = xt_need; HIP_TRY(ctx, hipMalloc((void**)&BS->d_bcr_xt, xt_need * 8)); HIP_TRY(ctx, hipMemset(BS->d_bcr_xt, 0, xt_need * 8)); BS->bcr_epoch = 0; }
@@ -3844,17 +3683,11 @@ static int ba_run(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynamic* dynp, v
             else if (lds_path) hipLaunchKernelGGL(k_ba_chol_small, dim3(1), dim3(1024), lds_chol, st, D);
             else if (Bc.m) {                                   // block cyclic reduction: 2 launches per level, log2(nb) levels, then the levels back
                 const int m = Bc.m, nb = Bc.nb;
-                // scalar_piv: round 5's whole reduced solve (scalar-pivot elimination, k_bcr_update, one back-substitution launch per level); block6: the 6 x 6 block-pivot
-                // elimination k_bcr_elim6 — measured SLOWER than the scalar one (45 vs 36 us per level: profiles/r6/global_ba_reduced_solve.txt), kept as an experiment
-                static const bool scalar_piv = getenv("VIDO_BCR_SCALAR") != nullptr, block6 = getenv("VIDO_BCR_BLOCK6") != nullptr;
+                // scalar_piv: round 5's reduced solve around the same elimination kernel (k_bcr_update, one back-substitution launch per level), for comparison
+                static const bool scalar_piv = getenv("VIDO_BCR_SCALAR") != nullptr;
                 auto elim = [&](int n_blocks, int sft, const double* Lc, int mode) {
-                    if (!block6) {
-                        if (m == 66) hipLaunchKernelGGL(k_bcr_elim<66>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom<66>::NT), BcrGeom<66>::LDS, st, Bc, sft, Lc, mode);
-                        else         hipLaunchKernelGGL(k_bcr_elim<96>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom<96>::NT), BcrGeom<96>::LDS, st, Bc, sft, Lc, mode);
-                    } else {
-                        if (m == 66) hipLaunchKernelGGL(k_bcr_elim6<66>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom6<66>::NT), BcrGeom6<66>::LDS, st, Bc, sft, Lc, mode);
-                        else         hipLaunchKernelGGL(k_bcr_elim6<96>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom6<96>::NT), BcrGeom6<96>::LDS, st, Bc, sft, Lc, mode);
-                    }
+                    if (m == 66) hipLaunchKernelGGL(k_bcr_elim<66>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom<66>::NT), BcrGeom<66>::LDS, st, Bc, sft, Lc, mode);
+                    else         hipLaunchKernelGGL(k_bcr_elim<96>, dim3(n_blocks, mode ? 1 : 2), dim3(BcrGeom<96>::NT), BcrGeom<96>::LDS, st, Bc, sft, Lc, mode);
                 };
                 hipLaunchKernelGGL(k_bcr_pack, dim3(nb), dim3(256), 0, st, Bc);
                 double *Lc = Bc.L0, *Ln = Bc.L1; int smax = 0;
