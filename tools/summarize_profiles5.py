@@ -5,14 +5,15 @@ MI355X_MICROARCH.md).  bench.py reads pmc_traffic.json, pmc_traffic_ba_global.js
 import csv, glob, json, os, shutil, sys
 
 out = sys.argv[1]
-dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "profiles_r5")
+rnd = sys.argv[2] if len(sys.argv) > 2 else "5"                      # tools/profile_round6.sh passes 6
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "profiles_r" + rnd)
 os.makedirs(dst, exist_ok=True)
 for tag, name in (("e2e", "e2e_kernel_stats.csv"), ("fe", "frontend_kernel_stats.csv"), ("bag", "global_ba_kernel_stats.csv"), ("nd", "nodet_kernel_stats.csv")):
     for f in glob.glob(os.path.join(out, tag, "**", "*kernel_stats.csv"), recursive=True):
         rows = open(f).read().splitlines()[:60]
         open(os.path.join(dst, name), "w").write("\n".join(rows) + "\n")
 for f in ("bench_under_rocprof.json", "fast_sq_counters.txt", "bench_e2e.json", "bench_e2e_200.json", "pytest_gpu.txt", "nets_mfma.json", "det_timeline_summary.txt", "nets_timeline_summary.txt",
-          "conv1x1_microbench.txt", "nodet_call_profile.txt"):
+          "conv1x1_microbench.txt", "nodet_call_profile.txt", "valu_int_issue.txt"):
     p = os.path.join(out, f)
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(dst, f))
