@@ -7,8 +7,7 @@ s = d["stage_ms"]
 print(sys.argv[1], d["value"], "ms/step", d["ms_per_step"], "det", s["maskrcnn_x101_fpn_ms"], "lfn", s["liteflownet_ms"], "trk", s["tracker_thread_ms"], "lba", s["local_ba_ms"], "wait_nets", s["tracker_wait_for_nets_ms"])
 PY
 }
-run base A=1
-run lba_async VIDO_LBA_ASYNC=1
-run streams3 A=1 
-run base2 A=1
-run lba_async2 VIDO_LBA_ASYNC=1
+run gconv_b3 A=1
+run gconv_f32 VIDO_NO_GCONV_B3=1
+run gconv_b3_2 A=1
+run gconv_f32_2 VIDO_NO_GCONV_B3=1
