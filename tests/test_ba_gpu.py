@@ -322,3 +322,30 @@ def test_local_window_alternative_drivers_match_the_oracle(env):
                        cwd=root, env=e, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert " passed" in p.stdout and "5 passed" in p.stdout, p.stdout[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"VIDO_BCR_SCALAR": "1"}, {"VIDO_BCR_BACK_LEVELS": "1"}, {"VIDO_BA_SCHUR_CHUNK": "64"}, {"VIDO_BA_SCHUR_CHUNK": "512"}, {"VIDO_BA_SCHUR_OLD": "1"}])
+def test_global_solver_forms_of_round_6_agree_with_the_older_ones(env, tmp_path):
+    """Round 6 changed three things inside a global LM trial: the Schur update of the block cyclic reduction (contraction over four lanes), its back substitution (ONE launch,
+    the levels chained by tagged granules: csrc/ba.hip::k_bcr_back_chain) and k_ba_schur_mfma (passes as one prefetching sequence, unit size chosen by the host).  The older
+    forms are still selectable by environment (read once per process): a child process solves the same 300-keyframe graph with each, and the results must agree with this
+    process' default forms — same LM iteration and trial counts, poses and landmarks to 1e-9 relative (they differ only in the order of a few sums)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import vido_slam_amd as V\n"
+            "ctx = V.Context(width=640, height=480, max_batch=1)\n"
+            "pr = V.problems.synth_ba_problem(n_cam=300, n_pt=40000, kind='global', track_len=10, seed=5); pr['max_iters'] = 4\n"
+            "r = V.ba_optimize(ctx, pr)\n"
+            "np.savez(sys.argv[1], cam=r['cam_T'], pt=r['pt_xyz'], it=np.array([r['iterations'], r['lm_trials']]), chi=np.array([r['chi2_initial'], r['chi2_final']]))\n" % root)
+    outs = []
+    for tag, e in (("default", {}), ("alt", env)):
+        f = str(tmp_path / (tag + ".npz"))
+        clean = {k: v for k, v in os.environ.items() if not k.startswith("VIDO_BCR_") and k not in ("VIDO_BA_SCHUR_CHUNK", "VIDO_BA_SCHUR_OLD")}
+        p = subprocess.run([sys.executable, "-c", code, f], env=dict(clean, **e), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        outs.append(np.load(f))
+    a, b = outs
+    assert list(a["it"]) == list(b["it"]) and a["it"][0] >= 2, (a["it"], b["it"])
+    assert rel(a["cam"], b["cam"]) < 1e-9 and rel(a["pt"], b["pt"]) < 1e-9
+    assert abs(a["chi"][1] - b["chi"][1]) <= 1e-9 * b["chi"][1] and a["chi"][1] < 0.5 * a["chi"][0]
