@@ -228,16 +228,23 @@ struct PyrTileLv { int w[PT_MAXL], pitch[PT_MAXL], off[PT_MAXL], xoff[PT_MAXL], 
 // the ingest copy (k_ingest: 15 us per 64 frames, a full read + write of level 0) rides on the staging loads.
 __global__ __launch_bounds__(256) void k_pyramid_tiles(uint8_t* __restrict__ pyr, size_t slab, PyrTileLv V, const PyrTile* __restrict__ tiles,
                                                        const int2* __restrict__ xtab, const int4* __restrict__ ytab,
-                                                       const uint8_t* __restrict__ imgs, size_t frame_stride, int stride)
+                                                       const uint8_t* __restrict__ imgs, size_t frame_stride, int stride, int ntiles, int total, int xcd_deal)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t pt_lds[];
-    const PyrTile& T = tiles[blockIdx.x];
-    uint8_t* base = pyr + (size_t)blockIdx.y * slab;
+    // Work item = (frame, tile), tiles of a frame in row-major order.  Workgroups go to the eight XCDs round-robin by their linear index, so with item = blockIdx two
+    // tiles that meet at a column cut — whose row ends share a cache line of every level, and whose needed rectangles share halo pixels — always sit under DIFFERENT L2s:
+    // the shared line leaves each L2 as a partial write and the halo is fetched from memory twice.  Dealt so that an XCD walks a contiguous range of items, the neighbours
+    // run side by side on one L2 (round 6).
+    const int per = gridDim.x >> 3, item = xcd_deal ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : (int)blockIdx.x;
+    if (item >= total) return;
+    const int frame = item / ntiles, tile = item - frame * ntiles;
+    const PyrTile& T = tiles[tile];
+    uint8_t* base = pyr + (size_t)frame * slab;
     const int tid = threadIdx.x;
     {   // one round trip: the level-0 rectangle (dword copies) and the table slices of every level
         const int nq = T.nw[0] >> 2, n = T.nh[0] * nq;
         const int spitch = imgs ? stride : V.pitch[0];
-        const uint8_t* src = (imgs ? imgs + (size_t)blockIdx.y * frame_stride : base + V.off[0]) + (size_t)T.ny0[0] * spitch + T.nx0[0];
+        const uint8_t* src = (imgs ? imgs + (size_t)frame * frame_stride : base + V.off[0]) + (size_t)T.ny0[0] * spitch + T.nx0[0];
         uint32_t* dst = (uint32_t*)(pt_lds + T.lds[0]);
         uint8_t* G0 = base + V.off[0];
         const int w0 = V.w[0], ox0 = T.ox0[0], ox1 = T.ox1[0], oy0 = T.oy0[0], oy1 = T.oy1[0];
@@ -1730,9 +1737,12 @@ int orb_enqueue(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, size_
         HIP_TRY(ctx, hipMemcpy2DAsync(S->d_pyr + (size_t)f * S->slab + S->lv[0].off, S->lv[0].pitch, imgs + (size_t)f * frame_stride, stride,
                                       width, height, hipMemcpyHostToDevice, st));
     static const int bands_mode = [] { const char* e = getenv("VIDO_ORB_BANDS"); return e ? atoi(e) : -1; }();      // experiment switch: 1 = the band pyramid for every batch size, 0 = never
-    if (S->n_ptiles && tiles_mode)
-        hipLaunchKernelGGL(k_pyramid_tiles, dim3(S->n_ptiles, nf), dim3(256), S->ptiles_lds, st, S->d_pyr, S->slab, S->ptile_lv, (const PyrTile*)S->d_ptiles, (const int2*)S->d_xtab, (const int4*)S->d_ytab,
-                           fuse_ingest ? imgs : (const uint8_t*)nullptr, frame_stride, stride);
+    if (S->n_ptiles && tiles_mode) {
+        static const int xcd_deal = [] { const char* e = getenv("VIDO_PYR_XCD"); return e ? atoi(e) : 1; }();         // (0: item = workgroup index, the round-5 order)
+        const int total = S->n_ptiles * nf;
+        hipLaunchKernelGGL(k_pyramid_tiles, dim3(8 * ((total + 7) / 8)), dim3(256), S->ptiles_lds, st, S->d_pyr, S->slab, S->ptile_lv, (const PyrTile*)S->d_ptiles, (const int2*)S->d_xtab, (const int4*)S->d_ytab,
+                           fuse_ingest ? imgs : (const uint8_t*)nullptr, frame_stride, stride, S->n_ptiles, total, xcd_deal);
+    }
     else if (S->n_bands && (bands_mode == 1 || (bands_mode != 0 && lean)))
         hipLaunchKernelGGL(k_pyramid_bands, dim3(S->n_bands, nf), dim3(256), S->bands_lds, st, S->d_pyr, S->slab, S->band_lv, (const PyrBand*)S->d_bands, (const int2*)S->d_xtab, (const int4*)S->d_ytab);
     else for (int l = 1; l < L; l++) {
