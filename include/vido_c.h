@@ -310,12 +310,21 @@ int vido_conv1x1_supported(int cin, int cout, int hw);
 /* the weight packing vido_conv1x1_bias_act / _up2_act expect for a shape: 0 = [co / 32][k / 8][32 (k & 1) + co % 32][(k % 8) / 2] (128 x 128 tiles),
  * 1 = [co / 16][k / 16][16 (k & 3) + co % 16][(k % 16) / 4] (128 x 112 tiles: fewer idle CUs in the last round of workgroups) */
 int vido_conv1x1_layout(int cin, int cout, int hw);
-/* Arithmetic of the 1x1 GEMM (round 6).  0 (default) = split-bf16: every fp32 operand is the exact sum of three bf16 planes, the six plane products with i + j <= 2 run on
- * v_mfma_f32_32x32x16_bf16 with fp32 accumulators — fp32-equivalent results (error against float64 not above the fp32 instruction's: tests/test_maskrcnn_gpu.py) at up to
- * 2.67x the fp32 matrix rate; vido_conv1x1_layout then answers 2 = [co / 32][k / 16][plane 3][32 ((k % 16) / 8) + co % 32][k % 8] bf16 (6 bytes per weight).
- * 1 = the fp32 matrix instruction (layouts 0 / 1 above); also selected by VIDO_CONV1X1_ARITH=f32 in the environment.  Returns the previous setting; process-wide — set it
- * before weights are packed (a packed weight carries its layout, a mismatch is refused by the caller's shape check). */
-int vido_conv1x1_set_arith(int f32_instruction);
+/* Arithmetic of the 1x1 GEMM (round 6): fp32-equivalent results from the 16-bit matrix instructions (error against float64 not above the fp32 instruction's:
+ * tests/test_maskrcnn_gpu.py).
+ *   0 (default) = split-fp16: every fp32 operand is h + 2^-11 l' with h = rne16(x), l' = rne16(2^11 (x - h)) (|x - h - 2^-11 l'| <= 2^-22 |x|, 2^-24.5 |x| rms); the three products
+ *       w_h x_h, w_h x_l', w_l' x_h run on v_mfma_f32_32x32x16_f16 with fp32 accumulators.  vido_conv1x1_layout answers 3 =
+ *       [co / 32][k / 16][plane 2][32 ((k % 16) / 8) + co % 32][k % 8] fp16 of the weight scaled per OUTPUT CHANNEL by the power of two that puts the channel's largest |w| into
+ *       [2^14, 2^15), followed by [cout] floats: the inverse scales (4 bytes per weight + 4 per channel).  Activations: full precision for 2.5e-4 <= |x| < 65504 (smaller ones: an absolute error <= 1.5e-11); a launch
+ *       that meets |x| >= 65504 raises vido_conv1x1_range_flag (its outputs are not valid then).
+ *   2 = split-bf16: three bf16 planes, the six plane products with i + j <= 2 on v_mfma_f32_32x32x16_bf16; fp32's range, twice the matrix work; layout 2 =
+ *       [co / 32][k / 16][plane 3][32 ((k % 16) / 8) + co % 32][k % 8] bf16 (6 bytes per weight).
+ *   1 = the fp32 matrix instruction (layouts 0 / 1 above).
+ * Also selected by VIDO_CONV1X1_ARITH = f16x2 | bf16x3 | f32 in the environment.  Returns the previous setting; process-wide — set it before weights are packed (a packed
+ * weight carries its layout, a mismatch is refused by the caller's shape check). */
+int vido_conv1x1_set_arith(int arith);
+/* non-zero when a split-fp16 launch on this context met an activation outside fp16's range since the last reset; read after the stream has been waited for */
+int vido_conv1x1_range_flag(vido_ctx* ctx, int reset);
 int vido_conv1x1_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, int hw, float slope);
 /* ... with the residual at half the resolution [cout][h/2][w/2], added nearest-upsampled: the FPN's lateral convolution + top-down sum (backbone/fpn.py:55-66); h, w even */
 int vido_conv1x1_bias_up2_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual_half, float* y, int cin, int cout, int h, int w, float slope);

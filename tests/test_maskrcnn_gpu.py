@@ -339,18 +339,51 @@ def test_split_bf16_conv1x1_is_no_less_accurate_than_the_fp32_instruction(vido, 
             x = torch.randn(1, cin, H, W, generator=g); w = torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin ** 0.5); b = torch.randn(cout, generator=g); r = torch.randn(1, cout, H, W, generator=g)
             ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double()) + r.double())
             err = {}
-            for arith in (1, 0):
+            for arith in (1, 2, 0):
                 ops.conv1x1_set_arith(arith)
                 lay = ops.conv1x1_layout(cin, cout, H * W)
-                assert lay == (2 if arith == 0 else 0)
+                assert lay == {0: 3, 1: 0, 2: 2}[arith]
                 y = ops.conv1x1_bias_act(x.cuda(), pack_conv1x1(w, lay).cuda(), b.cuda(), r.cuda(), 0.0).cpu()
                 err[arith] = float((y.double() - ref).abs().max())
-            assert err[0] <= 1.5 * err[1], (cin, cout, H, W, err)
-            assert err[0] < 2e-5 * max(1.0, float(ref.abs().max()))
-            worst = max(worst, err[0] / err[1])
+            for a in (0, 2):                                             # split-fp16 (the default), split-bf16
+                assert err[a] <= 1.5 * err[1], (cin, cout, H, W, err)
+                assert err[a] < 2e-5 * max(1.0, float(ref.abs().max()))
+                worst = max(worst, err[a] / err[1])
+        assert ops.conv1x1_range_flag() == 0
     finally:
         ops.conv1x1_set_arith(0)
     assert worst <= 1.5
+
+
+@pytest.mark.gpu
+def test_split_fp16_conv1x1_over_its_range_and_past_it(vido, ctx):
+    """The split-fp16 form takes activations as they are: the error bar of the test above holds with the activations scaled to 1e-3 and to 300 and with output channels whose
+    weights differ by e^(2 N(0, 1)) (per-channel powers of two at pack time); an activation of 70 000 — outside fp16 — raises the context's range flag (once: reading resets)
+    instead of passing an infinity on."""
+    from vido_slam_amd.nets.ops import HipOps, pack_conv1x1
+    ops = HipOps(ctx)
+    cin, cout, H, W = 256, 256, 64, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, cin, H, W, generator=g); w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5 * torch.exp(2 * torch.randn(cout, 1, 1, 1, generator=g))
+    try:
+        for sc in (1e-3, 1.0, 300.0):
+            xs = x * sc; ref = torch.nn.functional.conv2d(xs.double(), w.double()); e = {}
+            for arith in (1, 0):
+                ops.conv1x1_set_arith(arith)
+                y = ops.conv1x1_bias_act(xs.cuda(), pack_conv1x1(w, ops.conv1x1_layout(cin, cout, H * W)).cuda(), None, None, 1.0)
+                e[arith] = float(((y.cpu().double() - ref) / ref.abs().mean((0, 2, 3), keepdim=True)).pow(2).mean().sqrt())      # rms over outputs relative to their channel's scale
+            assert e[0] <= 1.5 * e[1], (sc, e)
+            assert ops.conv1x1_range_flag() == 0
+        ops.conv1x1_set_arith(0)
+        xb = x.clone(); xb[0, 17, 3, 5] = 70000.0
+        ops.conv1x1_bias_act(xb.cuda(), pack_conv1x1(w, ops.conv1x1_layout(cin, cout, H * W)).cuda(), None, None, 1.0); torch.cuda.synchronize()
+        assert ops.conv1x1_range_flag() == 1 and ops.conv1x1_range_flag() == 0
+        ops.conv1x1_set_arith(2)                                         # the bf16 form has fp32's range
+        y = ops.conv1x1_bias_act(xb.cuda(), pack_conv1x1(w, ops.conv1x1_layout(cin, cout, H * W)).cuda(), None, None, 1.0).cpu()
+        ref = torch.nn.functional.conv2d(xb.double(), w.double())
+        assert torch.isfinite(y).all() and float((y.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    finally:
+        ops.conv1x1_set_arith(0)
 
 
 @pytest.mark.gpu

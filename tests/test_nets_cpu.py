@@ -196,6 +196,27 @@ def test_pack_conv1x1_is_the_operand_order_of_the_kernel():
     for co, k in ((0, 0), (37, 9), (255, 63), (128, 16), (31, 8)):
         for pl in range(3):
             assert int(p[co // 32, k // 16, pl, 32 * ((k % 16) // 8) + co % 32, k % 8]) == int(planes[pl].view(torch.int16)[co, k])
+    # layout 3 (the split-fp16 form, v_mfma_f32_32x32x16_f16, the default): two fp16 planes of the rows scaled by powers of two, the low one scaled by 2^11, + the inverse row
+    # scales behind them; w == inv * (h + l / 2048) to within 2^-22 |w| (two roundings to 11 bits; 2^-24.5 rms) for everything down to 2^-26 of its row's maximum (smaller
+    # entries: an absolute error below 2^-48 of the maximum), and no plane entry is infinite
+    from vido_slam_amd.nets.ops import split_f16x2
+    w2 = w.reshape(256, 64).clone(); w2[7] = 0.0; w2[9] *= 1e-20; w2[11] *= 1e15
+    h, l, inv = split_f16x2(w2)
+    assert torch.isfinite(h.float()).all() and torch.isfinite(l.float()).all() and float(h.float().abs().max()) < 32768.0
+    rec = inv.double()[:, None] * (h.double() + l.double() / 2048.0)
+    big = w2.abs() >= w2.abs().amax(1, keepdim=True) * 2.0 ** -26
+    assert float(((rec - w2.double()).abs() / w2.abs().double().clamp_min(1e-300))[big].max()) <= 2.0 ** -22
+    assert float(((rec - w2.double()).abs() / w2.abs().amax(1, keepdim=True).double().clamp_min(1e-300)).max()) <= 2.0 ** -22 and torch.equal(rec[7], torch.zeros(64, dtype=torch.float64))
+    relerr = ((rec - w2.double()).abs() / w2.abs().double().clamp_min(1e-300))[big]
+    assert float(relerr.pow(2).mean().sqrt()) <= 2.0 ** -24
+    lg = torch.log2(inv); assert torch.equal(lg, lg.round())                      # powers of two
+    p3 = pack_conv1x1(w2.reshape(256, 64, 1, 1), 3)
+    assert p3.dtype == torch.int16 and tuple(p3.shape) == (2 * 256 * (64 + 1),)
+    pl3 = p3[:2 * 256 * 64].reshape(8, 4, 2, 64, 8)
+    for co, k in ((0, 0), (37, 9), (255, 63), (128, 16), (31, 8)):
+        for pl, src in enumerate((h, l)):
+            assert int(pl3[co // 32, k // 16, pl, 32 * ((k % 16) // 8) + co % 32, k % 8]) == int(src.view(torch.int16)[co, k])
+    assert torch.equal(p3[2 * 256 * 64:].view(torch.float32), inv)
 
 
 def test_conv1x1_tile_form_is_chosen_by_rounds_of_workgroups():
@@ -206,11 +227,12 @@ def test_conv1x1_tile_form_is_chosen_by_rounds_of_workgroups():
     import subprocess, sys
     code = ("import sys; sys.path.insert(0, %r); from vido_slam_amd.host import load_library; lib = load_library(); "
             "print([lib.vido_conv1x1_layout(*a) for a in ((256, 256, 200 * 272), (512, 512, 100 * 136), (1024, 1024, 50 * 68), (96, 128, 4096), (256, 256, 128 * 128 * 2))])" % ROOT)
-    # (round 6: without any switch the split-bf16 form = layout 2 takes every shape; VIDO_CONV1X1_ARITH=f32 or a forced tile width bring the fp32-instruction forms back)
-    for tn, want in (("0", [1, 1, 1, 0, 0]), ("128", [0, 0, 0, 0, 0]), ("112", [1, 1, 1, 0, 1]), (None, [2, 2, 2, 2, 2]), ("f32", [0, 0, 0, 0, 0])):
+    # (round 6: without any switch the split-fp16 form = layout 3 takes every shape, VIDO_CONV1X1_ARITH=bf16x3 the split-bf16 form = layout 2; VIDO_CONV1X1_ARITH=f32 or a
+    # forced tile width bring the fp32-instruction forms back)
+    for tn, want in (("0", [1, 1, 1, 0, 0]), ("128", [0, 0, 0, 0, 0]), ("112", [1, 1, 1, 0, 1]), (None, [3, 3, 3, 3, 3]), ("f32", [0, 0, 0, 0, 0]), ("bf16x3", [2, 2, 2, 2, 2])):
         env = {k: v for k, v in os.environ.items() if k not in ("VIDO_CONV1X1_TN", "VIDO_CONV1X1_ARITH")}
-        if tn == "f32":
-            env["VIDO_CONV1X1_ARITH"] = "f32"
+        if tn in ("f32", "bf16x3"):
+            env["VIDO_CONV1X1_ARITH"] = tn
         elif tn is not None:
             env["VIDO_CONV1X1_TN"] = tn
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)

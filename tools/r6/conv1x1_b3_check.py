@@ -1,4 +1,4 @@
-"""Round 6: the split-bf16 form of csrc/conv1x1.hip (k_conv1x1_b3) against the fp32-instruction form and float64 conv2d on the detector's bottleneck shapes: max-abs error
+"""Round 6: the split-bf16 and split-fp16 forms of csrc/conv1x1.hip (k_conv1x1_b3) against the fp32-instruction form and float64 conv2d on the detector's bottleneck shapes: max-abs error
 of both against float64 (the bar: split <= 1.5 x fp32-instruction), microseconds per call and fp32-equivalent TFLOP/s."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
@@ -24,15 +24,34 @@ for cin, cout, H, W, name in shapes:
     xc, bc, rc = x.cuda(), b.cuda(), r.cuda()
     gf = 2.0 * cin * cout * H * W / 1e9
     out = {}
-    for arith in (1, 0):
+    for arith in (1, 2, 0):
         ops.conv1x1_set_arith(arith)
         lay = ops.conv1x1_layout(cin, cout, H * W); wp = pack_conv1x1(w, lay).cuda()
         y = ops.conv1x1_bias_act(xc, wp, bc, rc, 0.0)
-        err = float((y.cpu().double() - ref).abs().max())
+        d = y.cpu().double() - ref
+        err = float(d.abs().max()); rms = float(d.pow(2).mean().sqrt())
         t = timed(lambda: ops.conv1x1_bias_act(xc, wp, bc, rc, 0.0))
-        out[arith] = (err, t, lay)
+        out[arith] = (err, t, lay, rms)
     ops.conv1x1_set_arith(0)
-    ratio = out[0][0] / max(out[1][0], 1e-30); worst = max(worst, ratio)
-    print("%-14s %4d -> %4d @ %3dx%3d %6.2f GF | fp32 instr [layout %d]: err %.3e  %6.1f us %6.1f TF | split-bf16 [layout %d]: err %.3e  %6.1f us %6.1f TF | err ratio %.2f  speed-up %.2fx"
-          % (name, cin, cout, H, W, gf, out[1][2], out[1][0], out[1][1], gf / out[1][1] * 1e3, out[0][2], out[0][0], out[0][1], gf / out[0][1] * 1e3, ratio, out[1][1] / out[0][1]), flush=True)
+    assert ops.conv1x1_range_flag() == 0
+    ratio = max(out[0][0] / max(out[1][0], 1e-30), out[2][0] / max(out[1][0], 1e-30)); worst = max(worst, ratio)
+    print("%-14s %4d -> %4d @ %3dx%3d %6.2f GF | fp32 instr [%d]: max %.3e rms %.3e %6.1f us %6.1f TF | split-bf16 [%d]: max %.3e rms %.3e %6.1f us %6.1f TF | split-fp16 [%d]: max %.3e rms %.3e %6.1f us %6.1f TF | max-err ratios %.2f %.2f"
+          % (name, cin, cout, H, W, gf, out[1][2], out[1][0], out[1][3], out[1][1], gf / out[1][1] * 1e3, out[2][2], out[2][0], out[2][3], out[2][1], gf / out[2][1] * 1e3,
+             out[0][2], out[0][0], out[0][3], out[0][1], gf / out[0][1] * 1e3, out[2][0] / out[1][0], out[0][0] / out[1][0]), flush=True)
 print("worst error ratio split / fp32-instruction: %.2f" % worst)
+# range: an activation past fp16 raises the flag; scaled inputs (1e-3, 300) keep the error ratio
+cin, cout, H, W = 256, 256, 64, 64
+g = torch.Generator().manual_seed(5)
+x = torch.randn(1, cin, H, W, generator=g); w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5 * torch.exp(2 * torch.randn(cout, 1, 1, 1, generator=g))
+for sc in (1e-3, 1.0, 300.0):
+    xs = x * sc; ref = F.conv2d(xs.double(), w.double())
+    e = {}
+    for arith in (1, 0):
+        ops.conv1x1_set_arith(arith); lay = ops.conv1x1_layout(cin, cout, H * W)
+        y = ops.conv1x1_bias_act(xs.cuda(), pack_conv1x1(w, lay).cuda(), None, None, 1.0)
+        e[arith] = float(((y.cpu().double() - ref) / ref.abs().mean((0, 2, 3), keepdim=True)).pow(2).mean().sqrt())
+    ops.conv1x1_set_arith(0)
+    print("activations x %g, channel scales e^(2 N(0,1)): relative rms error fp32 instr %.3e split-fp16 %.3e (%.2fx) flag %d" % (sc, e[1], e[0], e[0] / e[1], ops.conv1x1_range_flag()))
+xb = x.clone(); xb[0, 17, 3, 5] = 70000.0
+ops.conv1x1_bias_act(xb.cuda(), pack_conv1x1(w, ops.conv1x1_layout(cin, cout, H * W)).cuda(), None, None, 1.0); torch.cuda.synchronize()
+print("activation 70000 -> range flag", ops.conv1x1_range_flag(), "then", ops.conv1x1_range_flag())

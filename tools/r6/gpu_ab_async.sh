@@ -1,0 +1,13 @@
+#!/bin/bash
+# headline A/B: the window solve beside the next frame (VIDO_LBA_ASYNC), with / without the join in vido_system_get_stats
+REPO=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$REPO/gpurun_out; cd $REPO
+run() { name=$1; shift; env "$@" python bench.py --steps 100 --warmup 10 --no-extra --cpu-baseline 0 2>/dev/null | tail -1 > $OUT/ab_$name.json; python - <<P
+import json; d=json.loads(open("$OUT/ab_$name.json").read()); s=d["stage_ms"]
+print("$name", d["value"], "ms/step", d["ms_per_step"], "det", s.get("maskrcnn_x101_fpn_ms"), "lfn", s.get("liteflownet_ms"), "trk", s.get("tracker_thread_ms"), "lba", s.get("local_ba_ms"), "wait_nets", s.get("tracker_wait_for_nets_ms"))
+P
+}
+run base A=1
+run async VIDO_LBA_ASYNC=1
+run async_nojoin VIDO_LBA_ASYNC=1 VIDO_STATS_NO_JOIN=1
+run base2 A=1
+run async_nojoin2 VIDO_LBA_ASYNC=1 VIDO_STATS_NO_JOIN=1

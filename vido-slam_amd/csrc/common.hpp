@@ -53,6 +53,7 @@ struct vido_ctx {
     void* detpost_buf = nullptr; size_t detpost_cap = 0; unsigned long long detpost_sig = 0;   // detpost.hip: scratch of the RPN selection (keys, histograms, state)
     void* rccl_comm = nullptr;         // ncclComm_t of vido_rccl_init (rccl.cpp): the sharded BA's all-reduce on this context's stream
     int rccl_rank = 0, rccl_world = 1;
+    unsigned* c1_range_flag = nullptr; // conv1x1.hip: pinned host word the split-fp16 kernels raise when an activation leaves fp16's range (vido_conv1x1_range_flag)
 };
 
 int vido_set_error(vido_ctx* ctx, int code, const char* fmt, ...);

@@ -29,7 +29,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define C1_TM 128
 #define C1_TN 128
 
-struct C1Args { const float* x; const float* wp; const float* bias; const float* res; float* y; int M, N, K, mt, total, nchunk; float slope; unsigned xbytes, wbytes; int W; };
+struct C1Args { const float* x; const float* wp; const float* bias; const float* res; float* y; int M, N, K, mt, total, nchunk; float slope; unsigned xbytes, wbytes; int W; unsigned* range_flag; };
 
 // RES: 1 a residual [cout][H*W] is added, 2 a residual at HALF the resolution [cout][H/2][W/2] is added nearest-upsampled (the FPN's top-down path: fpn.py
 // `F.interpolate(last_inner, scale_factor=2, mode="nearest") + inner_lateral`); KC: input channels per chunk and barrier (64: 128 KB of LDS, 128 matrix instructions per
@@ -284,10 +284,28 @@ __global__ __launch_bounds__(256) void k_conv1x1_n112(C1Args A)
 //     instructions — the bf16 instruction leaves ~5 issue slots per instruction to the wave (MI355X_MICROARCH.md), the loop needs ~3.
 //   * a ring of B3_R LDS slots of one k-step (16 input channels: 12 KB of weight planes + 8 KB of activations), copies B3_R - 1 steps ahead, ONE barrier per k-step; the
 //     operands of step t + 1 are read (and split) from LDS during step t, so the matrix pipe does not wait behind a barrier.
+//
+// ---- the same on the fp16 instruction with TWO planes and THREE products (round 6, NP = 2; the default) ----------------------------------------------------------------
+// fp16 carries 11 significant bits: h = rne16(x), l = rne16(x - h) leave |x - h - l| <= 2^-22 |x| (two roundings to 11 bits; 2^-24.5 |x| rms — the fp32 instruction's
+// operands are exact, its error is all accumulation: one rounding per TWO products where this form has one per sixteen) wherever both halves are NORMAL fp16 numbers, and
+// the products w_h x_h, w_h x_l, w_l x_h are exact in fp32; the dropped w_l x_l is <= 2^-22 |w x|.  Measured against float64 the sum's error is 0.23 - 0.97x the fp32
+// instruction's (K = 2048 .. 32; the fewer the terms, the closer).  Half the matrix instructions of the bf16 form (3.2 ms -> see DESIGN.md),
+// five vector instructions per pair instead of eleven, two thirds of the weight bytes.  What fp16 lacks is RANGE (2^-14 .. 65504), handled without a pass over the data:
+//   * the low planes are stored SCALED by 2^11 (l' = rne16(2^11 (x - h)): as large as h's last bits, never subnormal where h is normal); their two products meet in the
+//     correction accumulators, which enter the sum as 2^-11 acl — a power of two: exact;
+//   * weights: every output channel is scaled at pack time by the power of two that puts its largest |w| into [2^14, 2^15) (pack_conv1x1 layout 3; the inverse scales, one
+//     float per channel, follow the planes); the epilogue multiplies the sum by it — exact;
+//   * activations are taken as they are: full precision for 2.5e-4 <= |x| < 65504 (28 binades; a smaller |x| keeps an ABSOLUTE error <= 2^-36 = 1.5e-11, far below the
+//     rounding of the sum it enters), and a value past the range would turn into an infinity — so the split tracks max |x| beside its conversions (one v_max3 per pair) and a wave that met
+//     |x| >= 65504 raises the context's range flag (vido_conv1x1_range_flag: the caller of the network checks it where it reads the detections back and can repeat the frame
+//     with vido_conv1x1_set_arith(2), the bf16 form, which has fp32's range).  The detector's activations stay below a few hundred.
+// Error against float64, both forms and the fp32 instruction: tests/test_maskrcnn_gpu.py (the bar: <= 1.5x the fp32 instruction's; measured 0.4 - 1.0x).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#define B3_SLOT 20480       // bytes per k-step in the ring: 12 pieces of A (4 row blocks x 3 planes), 8 pieces of B (two rows each)
-#define B3_PW 5             // copy pieces per wave and step
+#define B3_SLOTB(NP) ((NP) * 4096 + 8192)       // bytes per k-step in the ring: 4 NP pieces of A (4 row blocks x NP planes), 8 pieces of B (two rows each)
+#define B3_PWN(NP) ((NP) + 2)                   // copy pieces per wave and step
 
 __device__ __forceinline__ unsigned b3_cvt_pk(float lo, float hi) { unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; }
 // two fp32 values -> their three bf16 planes, packed (low half = the first value)
@@ -307,9 +325,10 @@ __device__ __forceinline__ void b3_split2(float x0, float x1, unsigned& p0, unsi
 // Three forms (c1_launch picks by shape): <G 2, RB 4> one workgroup of 8 waves per CU (160 KB) for long contractions on launches of about one workgroup per CU;
 // <G 1, RB 4> 80 KB and <= 256 registers, so that TWO workgroups share a CU — the prologue / epilogue of one tile runs beside the other tile's loop (layer1: 16 k-steps of
 // ~0.4 us against ~6 us of fixed cost per tile, 3.3 rounds of tiles); <G 1, RB 6> the first form (one workgroup of 4 waves per CU, 120 KB), kept for comparison.
-template <int RES, int G, int RB>
-__global__ __launch_bounds__(256 * G, (G == 1 && RB == 4) ? 2 : G) void k_conv1x1_b3(C1Args A)
+template <int RES, int G, int RB, int NP>
+__global__ __launch_bounds__(256 * G, (G == 1 && RB != 6) ? 2 : G) void k_conv1x1_b3(C1Args A)
 {
+    constexpr int B3_SLOT = B3_SLOTB(NP), B3_PW = B3_PWN(NP);
     constexpr int SLOTB = G * B3_SLOT;
     extern __shared__ __attribute__((aligned(16))) float c1_lds[];
     char* L = (char*)c1_lds;
@@ -324,9 +343,9 @@ __global__ __launch_bounds__(256 * G, (G == 1 && RB == 4) ? 2 : G) void k_conv1x
     // B pieces' per-lane offsets (the piece's rows ride in the per-lane offset, the STEP in the descriptor: base = x + 64 N t bytes, num_records = the bytes left behind it —
     // the exact range check of k_conv1x1 with one descriptor per step).
     const unsigned avo = 16u * (unsigned)lane;
-    unsigned abase[3], bvo[2];
+    unsigned abase[3], bvo[2];                                            // (abase[NP]: an array of template-dependent size captured by a lambda makes the HOST pass drop the kernel's stub — silently)
 #pragma unroll
-    for (int q = 0; q < 3; q++) { const int i = 4 * q + w, rb = i / 3, pl = i - 3 * rb; abase[q] = 1024u * (unsigned)(((m0 >> 5) + rb) * ns * 3 + pl); }
+    for (int q = 0; q < NP; q++) { const int i = 4 * q + w, rb = i / NP, pl = i - NP * rb; abase[q] = 1024u * (unsigned)(((m0 >> 5) + rb) * ns * NP + pl); }
 #pragma unroll
     for (int q = 0; q < 2; q++) bvo[q] = 4u * ((unsigned)((lane >> 5) + 2 * (4 * q + w)) * (unsigned)A.N + (unsigned)(n0 + 4 * (lane & 31)));
     const unsigned bstep = 64u * (unsigned)A.N;
@@ -334,12 +353,12 @@ __global__ __launch_bounds__(256 * G, (G == 1 && RB == 4) ? 2 : G) void k_conv1x
     auto issue = [&](int T, int slot) {                                   // this wave's five pieces of its group's step of slot T
         char* S = L + slot * SLOTB + wofs;
         const int t = G * T + g;
-        const unsigned aoff = 3072u * (unsigned)t, boff = bstep * (unsigned)t;
+        const unsigned aoff = (unsigned)(NP * 1024) * (unsigned)t, boff = bstep * (unsigned)t;
 #pragma unroll
-        for (int q = 0; q < 3; q++) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(S + q * 4096), 16, avo, abase[q] + aoff, 0, 0);
+        for (int q = 0; q < NP; q++) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(S + q * 4096), 16, avo, abase[q] + aoff, 0, 0);
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)A.x + boff), 0, A.xbytes - boff, 0x00020000);
 #pragma unroll
-        for (int q = 0; q < 2; q++) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(S + 12288 + q * 4096), 16, bvo[q], 0, 0, 0);
+        for (int q = 0; q < 2; q++) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(S + NP * 4096 + q * 4096), 16, bvo[q], 0, 0, 0);
     };
     // two accumulator sets: the leading product w0 x0 (one rounding per 16 input channels) and the five corrections (2^-8 of it and below: their roundings do not count)
     f32x16 acc[4], acl[4];
@@ -348,15 +367,17 @@ __global__ __launch_bounds__(256 * G, (G == 1 && RB == 4) ? 2 : G) void k_conv1x
 #pragma unroll
         for (int r = 0; r < 16; r++) { acc[rb][r] = 0.f; acl[rb][r] = 0.f; }
     for (int T = 0; T < RB - 1; T++) issue(min(T, nb - 1), T);
-    u32x4 a[2][4][3], bp[2][3]; float braw[8];
+    u32x4 a[2][4][NP], bp[2][NP]; float braw[8];
+    float xmax = 0.f;                                                     // (NP == 2) largest |x| this wave has split
+    const f32x2 k2048 = {2048.f, 2048.f};
     typedef const __attribute__((address_space(3))) char* lds_c;
-    const unsigned a_lane = (unsigned)(g * B3_SLOT) + 16u * (unsigned)lane, b_lane = (unsigned)(g * B3_SLOT) + 12288u + 4u * (unsigned)((lane >> 5) * 8 * C1_TN + 32 * w + (lane & 31));
+    const unsigned a_lane = (unsigned)(g * B3_SLOT) + 16u * (unsigned)lane, b_lane = (unsigned)(g * B3_SLOT) + (unsigned)(NP * 4096) + 4u * (unsigned)((lane >> 5) * 8 * C1_TN + 32 * w + (lane & 31));
     auto lda = [&](int slot, int buf) {
         lds_c Ab = (lds_c)(L + slot * SLOTB) + a_lane;
 #pragma unroll
         for (int rb = 0; rb < 4; rb++)
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) a[buf][rb][pl] = *(const __attribute__((address_space(3))) u32x4*)(Ab + (rb * 3 + pl) * 1024);
+            for (int pl = 0; pl < NP; pl++) a[buf][rb][pl] = *(const __attribute__((address_space(3))) u32x4*)(Ab + (rb * NP + pl) * 1024);
     };
     auto ldb = [&](int slot) {
         const volatile __attribute__((address_space(3))) float* Bb = (const volatile __attribute__((address_space(3))) float*)((lds_c)(L + slot * SLOTB) + b_lane);
@@ -364,12 +385,29 @@ __global__ __launch_bounds__(256 * G, (G == 1 && RB == 4) ? 2 : G) void k_conv1x
         for (int i = 0; i < 8; i++) braw[i] = Bb[i * C1_TN];
     };
     auto split = [&](int buf) {
+        if constexpr (NP == 2) {
+#pragma unroll
+            for (int pr = 0; pr < 4; pr++) {
+                const f32x2 v = {braw[2 * pr], braw[2 * pr + 1]};
+                const f16x2 h = __builtin_convertvector(v, f16x2);                                    // v_cvt_pk_f16_f32 (round to nearest even)
+                // 2^11 (x - h) = fma(h, -2^11, 2^11 x), exact (the difference has <= 13 significant bits): one packed multiply + two v_fma_mix_f32, which read h's halves as they
+                // are (left to itself the compiler converts h back with two more instructions and does not pack: 9 instead of 5 vector instructions per pair)
+                f32x2 vs, r;
+                asm("v_pk_mul_f32 %0, %1, %2" : "=v"(vs) : "v"(v), "v"(k2048));
+                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r.x) : "v"(h), "s"(-2048.f), "v"(vs.x));
+                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.y) : "v"(h), "s"(-2048.f), "v"(vs.y));
+                const f16x2 l = __builtin_convertvector(r, f16x2);
+                bp[buf][0][pr] = __builtin_bit_cast(unsigned, h); bp[buf][1][pr] = __builtin_bit_cast(unsigned, l);
+                xmax = __builtin_fmaxf(__builtin_fmaxf(xmax, __builtin_fabsf(v.x)), __builtin_fabsf(v.y));      // one v_max3_f32 with |.| operand modifiers
+            }
+        } else {
 #pragma unroll
 #ifdef B3_NOSPLIT
-        for (int pr = 0; pr < 4; pr++) { bp[buf][0][pr] = __float_as_uint(braw[2 * pr]); bp[buf][1][pr] = __float_as_uint(braw[2 * pr + 1]); bp[buf][2][pr] = __float_as_uint(braw[2 * pr]) ^ 1; }
+            for (int pr = 0; pr < 4; pr++) { bp[buf][0][pr] = __float_as_uint(braw[2 * pr]); bp[buf][1][pr] = __float_as_uint(braw[2 * pr + 1]); bp[buf][2][pr] = __float_as_uint(braw[2 * pr]) ^ 1; }
 #else
-        for (int pr = 0; pr < 4; pr++) { unsigned p0, p1, p2; b3_split2(braw[2 * pr], braw[2 * pr + 1], p0, p1, p2); bp[buf][0][pr] = p0; bp[buf][1][pr] = p1; bp[buf][2][pr] = p2; }
+            for (int pr = 0; pr < 4; pr++) { unsigned p0, p1, p2; b3_split2(braw[2 * pr], braw[2 * pr + 1], p0, p1, p2); bp[buf][0][pr] = p0; bp[buf][1][pr] = p1; bp[buf][2][pr] = p2; }
 #endif
+        }
     };
     // The barrier is the bare instruction (no fence): __syncthreads() would drain the copies in flight (vmcnt(0)), which is the ring's whole point.  What it must order is
     // stated explicitly: this wave's copies of the slot about to be read have landed (vmcnt), its own LDS reads are back (lgkmcnt(0): they were issued a slot ago).
@@ -385,7 +423,28 @@ __global__ __launch_bounds__(256 * G, (G == 1 && RB == 4) ? 2 : G) void k_conv1x
             ti = min(ti + 1, nb - 1);                                     // (past the last slot the copies repeat it into a position nobody reads again: the count per slot stays 5)
             ldb(sn); lda(sn, h ^ 1);                                      // (past the last slot: read, never used)
             issue(ti, sf);
-            // the six products, small ones first; consecutive matrix instructions go to different accumulators
+            // the products, small ones first; consecutive matrix instructions go to different accumulators
+            if constexpr (NP == 2) {
+#pragma unroll
+                for (int term = 0; term < 3; term++) {
+                    constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
+#pragma unroll
+                    for (int rb = 0; rb < 4; rb++) {
+                        f32x16& d = term == 2 ? acc[rb] : acl[rb];
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[h][rb][PA[term]]), __builtin_bit_cast(f16x8, bp[h][PB[term]]), d, 0, 0, 0);
+                    }
+                }
+                split(h ^ 1);
+                // 12 matrix instructions: the 16 LDS reads and the 4 copies beside the first six, the split's ~28 vector instructions beside the rest
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); else if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if (i >= 1 && i < 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+            } else {
 #pragma unroll
             for (int term = 0; term < 6; term++) {
                 constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
@@ -406,13 +465,16 @@ __global__ __launch_bounds__(256 * G, (G == 1 && RB == 4) ? 2 : G) void k_conv1x
                 if (i >= 3 && i < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (i >= 6) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
+            }
             __builtin_amdgcn_sched_barrier(0);
             slot = sn;
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           // (the last, unused copies)
 #pragma unroll
-    for (int rb = 0; rb < 4; rb++) acc[rb] += acl[rb];
+    for (int rb = 0; rb < 4; rb++) acc[rb] += NP == 2 ? acl[rb] * 0x1p-11f : acl[rb];
+    if (NP == 2 && !(xmax < 65504.f) && A.range_flag) atomicOr(A.range_flag, 1u);      // (also a NaN)
+    const float* wsc = (const float*)((const char*)A.wp + (size_t)4 * A.K * A.M);      // (NP == 2) the inverse channel scales behind the planes
     // D[i][j] as above: register r of a lane = output channel 8 (r / 4) + 4 (lane >> 5) + (r & 3) of the row block, position lane & 31
     auto finish = [&](int rb, const f32x16& v0, const float* other) {
         const int co0 = m0 + 32 * rb + 4 * (lane >> 5), q = n0 + 32 * w + (lane & 31);
@@ -432,7 +494,7 @@ __global__ __launch_bounds__(256 * G, (G == 1 && RB == 4) ? 2 : G) void k_conv1x
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int co = co0 + 8 * (r >> 2) + (r & 3);
-                const float v = (v0[r] + ov[r]) + bv[r] + rv[r];
+                const float v = (NP == 2 ? (v0[r] + ov[r]) * wsc[co] : v0[r] + ov[r]) + bv[r] + rv[r];
                 A.y[(size_t)co * A.N + q] = fmaxf(v, v * A.slope);
             }
         }
@@ -468,13 +530,24 @@ int vido_conv1x1_supported(int cin, int cout, int hw)
 /* Which tile form (= which weight packing) the library uses for a shape: 0 = 128 x 128 tiles on 32x32x2 (pack layout 0), 1 = 128 x 112 tiles on 16x16x4 (pack layout 1).
  * The form with fewer (rounds of 256 CUs) x (tile width) wins; VIDO_CONV1X1_TN = 128 / 112 forces one.  The packer (vido_slam_amd/nets/ops.py::pack_conv1x1) asks this
  * function, vido_conv1x1_bias_act asks it again with the same shape. */
-static std::atomic<int>& c1_f32_arith()
+static std::atomic<int>& c1_arith()          // 0 = split-fp16 (two planes, three products: the default), 1 = the fp32 instruction, 2 = split-bf16 (three planes, six products)
 {
-    static std::atomic<int> v{[] { const char* e = getenv("VIDO_CONV1X1_ARITH"); return (e && !strcmp(e, "f32")) || getenv("VIDO_CONV1X1_TN") ? 1 : 0; }()};
+    static std::atomic<int> v{[] { const char* e = getenv("VIDO_CONV1X1_ARITH");
+                                   return (e && !strcmp(e, "f32")) || (!e && getenv("VIDO_CONV1X1_TN")) ? 1 : (e && (!strcmp(e, "bf16x3") || !strcmp(e, "bf16"))) ? 2 : 0; }()};
     return v;
 }
 
-int vido_conv1x1_set_arith(int f32_instruction) { return c1_f32_arith().exchange(f32_instruction ? 1 : 0); }
+int vido_conv1x1_set_arith(int arith) { return c1_arith().exchange(arith == 1 ? 1 : arith == 2 ? 2 : 0); }
+
+/* The range flag of the split-fp16 form: non-zero when a launch since the last reset met an activation with |x| >= 65504 (or a NaN) — its outputs are then not valid.
+ * Host-visible memory written by the kernels: read it after the stream has been waited for.  reset != 0 clears it. */
+int vido_conv1x1_range_flag(vido_ctx* ctx, int reset)
+{
+    if (!ctx || !ctx->c1_range_flag) return 0;
+    const int v = (int)__atomic_load_n(ctx->c1_range_flag, __ATOMIC_ACQUIRE);
+    if (reset) __atomic_store_n(ctx->c1_range_flag, 0u, __ATOMIC_RELEASE);
+    return v;
+}
 
 int vido_conv1x1_layout(int cin, int cout, int hw)
 {
@@ -484,7 +557,7 @@ int vido_conv1x1_layout(int cin, int cout, int hw)
     // (a detector running alone), 112 / 128 force a form.
     // round 6: the split-bf16 form (k_conv1x1_b3: fp32-equivalent arithmetic on the bf16 matrix instruction) is the default; VIDO_CONV1X1_ARITH=f32 (or a forced
     // VIDO_CONV1X1_TN) brings the fp32-instruction forms back.
-    if (!c1_f32_arith().load(std::memory_order_relaxed)) return 2;
+    { const int ar = c1_arith().load(std::memory_order_relaxed); if (ar != 1) return ar == 2 ? 2 : 3; }
     static const int force = [] { const char* e = getenv("VIDO_CONV1X1_TN"); return e ? atoi(e) : 128; }();
     if (force == 128 || cin % 64 != 0) return 0;
     if (force == 112) return 1;
@@ -505,29 +578,36 @@ static int c1_launch(vido_ctx* ctx, const float* x, const float* w_packed, const
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
     const int rm = residual ? res_mode : 0;
-    if (vido_conv1x1_layout(cin, cout, hw) == 2) {
+    const int layout = vido_conv1x1_layout(cin, cout, hw);
+    if (layout >= 2) {
+        const int np = layout == 3 ? 2 : 3;
         const int mt = cout / C1_TM, ntl = (hw + C1_TN - 1) / C1_TN, total = mt * ntl;
-        C1Args A{x, w_packed, bias, residual, y, cout, hw, cin, mt, total, cin / 16, slope, (unsigned)(4ll * cin * hw), (unsigned)(6ll * cin * cout), w};
+        C1Args A{x, w_packed, bias, residual, y, cout, hw, cin, mt, total, cin / 16, slope, (unsigned)(4ll * cin * hw), (unsigned)(2ll * np * cin * cout), w, ctx->c1_range_flag};
         // form: VIDO_CONV1X1_B3_FORM = 0 (default: by shape), 1 = <1, 6>, 2 = <2, 4>, 3 = <1, 4> two workgroups per CU
         static const int force_form = [] { const char* e = getenv("VIDO_CONV1X1_B3_FORM"); return e ? atoi(e) : 0; }();
         int form = force_form ? force_form : (cin >= 512 && total <= 320 ? 2 : 3);
         if (form == 2 && cin % 64) form = 3;                                // (two groups: an even number of slots of two k-steps)
-        constexpr size_t LDS_F1 = (size_t)6 * B3_SLOT, LDS_F2 = (size_t)4 * 2 * B3_SLOT, LDS_F3 = (size_t)4 * B3_SLOT;
+        // ring depths: the bf16 form 4 slots of 20 KB (x 2 groups = 160 KB; one group: 80 KB, two workgroups per CU); the fp16 form's k-step is half as long and its slot
+        // 16 KB: 5 slots (x 2 groups = 160 KB; one group: 80 KB) keep the copies as far ahead in time
         static bool attr3[64] = {};
         if (!attr3[ctx->device & 63]) {
-            for (const void* f : {(const void*)k_conv1x1_b3<0, 1, 6>, (const void*)k_conv1x1_b3<1, 1, 6>, (const void*)k_conv1x1_b3<2, 1, 6>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_F1));
-            for (const void* f : {(const void*)k_conv1x1_b3<0, 2, 4>, (const void*)k_conv1x1_b3<1, 2, 4>, (const void*)k_conv1x1_b3<2, 2, 4>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_F2));
-            for (const void* f : {(const void*)k_conv1x1_b3<0, 1, 4>, (const void*)k_conv1x1_b3<1, 1, 4>, (const void*)k_conv1x1_b3<2, 1, 4>}) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_F3));
+#define B3_ATTR(G_, RB_, NP_) for (const void* f : {(const void*)k_conv1x1_b3<0, G_, RB_, NP_>, (const void*)k_conv1x1_b3<1, G_, RB_, NP_>, (const void*)k_conv1x1_b3<2, G_, RB_, NP_>}) \
+            HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)RB_ * G_ * B3_SLOTB(NP_))))
+            B3_ATTR(1, 6, 3); B3_ATTR(2, 4, 3); B3_ATTR(1, 4, 3); B3_ATTR(2, 5, 2); B3_ATTR(1, 5, 2);
+#undef B3_ATTR
             attr3[ctx->device & 63] = true;
         }
         const dim3 grid(8 * ((total + 7) / 8));
-#define B3_LAUNCH(G_, RB_, LDS_) do { const dim3 blk(256 * G_); if (rm == 2) hipLaunchKernelGGL((k_conv1x1_b3<2, G_, RB_>), grid, blk, LDS_, st, A); else if (rm) hipLaunchKernelGGL((k_conv1x1_b3<1, G_, RB_>), grid, blk, LDS_, st, A); else hipLaunchKernelGGL((k_conv1x1_b3<0, G_, RB_>), grid, blk, LDS_, st, A); } while (0)
-        if (form == 2) B3_LAUNCH(2, 4, LDS_F2); else if (form == 1) B3_LAUNCH(1, 6, LDS_F1); else B3_LAUNCH(1, 4, LDS_F3);
+#define B3_LAUNCH(G_, RB_, NP_) do { const dim3 blk(256 * G_); const size_t lds = (size_t)RB_ * G_ * B3_SLOTB(NP_); \
+            if (rm == 2) hipLaunchKernelGGL((k_conv1x1_b3<2, G_, RB_, NP_>), grid, blk, lds, st, A); else if (rm) hipLaunchKernelGGL((k_conv1x1_b3<1, G_, RB_, NP_>), grid, blk, lds, st, A); \
+            else hipLaunchKernelGGL((k_conv1x1_b3<0, G_, RB_, NP_>), grid, blk, lds, st, A); } while (0)
+        if (np == 2) { if (form == 2) B3_LAUNCH(2, 5, 2); else B3_LAUNCH(1, 5, 2); }
+        else if (form == 2) B3_LAUNCH(2, 4, 3); else if (form == 1) B3_LAUNCH(1, 6, 3); else B3_LAUNCH(1, 4, 3);
 #undef B3_LAUNCH
         HIP_TRY(ctx, hipGetLastError());
         return VIDO_OK;
     }
-    if (vido_conv1x1_layout(cin, cout, hw) == 1) {
+    if (layout == 1) {
         const int mt = cout / C1_TM, ntl = (hw + C2_TN - 1) / C2_TN, total = mt * ntl;
         C1Args A{x, w_packed, bias, residual, y, cout, hw, cin, mt, total, cin / 64, slope, (unsigned)(4ll * cin * hw), (unsigned)(4ll * cin * cout), w};
         constexpr size_t LDS112 = (size_t)2 * (8 * 4 * 256 + 2 * 16 * 272) * 4;

@@ -74,6 +74,8 @@ int vido_create(const vido_config* cfg, vido_ctx** out)
         int rc = vido_set_error(nullptr, VIDO_E_HIP, "vido_create: hipStreamCreate: %s", hipGetErrorString(e));
         delete ctx; return rc;
     }
+    // (conv1x1.hip) the range flag of the split-fp16 GEMM: a pinned host word — allocated here, not at the first launch, because that launch may sit inside a stream capture
+    if (hipHostMalloc((void**)&ctx->c1_range_flag, sizeof(unsigned), hipHostMallocDefault) == hipSuccess) *ctx->c1_range_flag = 0u; else { ctx->c1_range_flag = nullptr; (void)hipGetLastError(); }
     int rc = orb_state_create(ctx);
     if (rc != VIDO_OK) { vido_set_error(nullptr, rc, "%s", ctx->err.c_str()); vido_destroy(ctx); return rc; }
     *out = ctx;
@@ -95,6 +97,7 @@ void vido_destroy(vido_ctx* ctx)
     pnp_state_destroy(ctx);
     bawin_state_destroy(ctx);
     if (ctx->detpost_buf) { hipFree(ctx->detpost_buf); ctx->detpost_buf = nullptr; }
+    if (ctx->c1_range_flag) { hipHostFree(ctx->c1_range_flag); ctx->c1_range_flag = nullptr; }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     delete ctx;

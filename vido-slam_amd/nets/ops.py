@@ -155,9 +155,14 @@ class HipOps:
     def conv1x1_supported(self, cin, cout, hw):
         return bool(self.ctx.lib.vido_conv1x1_supported(int(cin), int(cout), int(hw)))
 
-    def conv1x1_set_arith(self, f32_instruction):
-        """0: split-bf16 (fp32-equivalent, the default), 1: the fp32 matrix instruction; returns the previous setting (vido_conv1x1_set_arith, process-wide)."""
-        return int(self.ctx.lib.vido_conv1x1_set_arith(int(bool(f32_instruction))))
+    def conv1x1_set_arith(self, arith):
+        """0: split-fp16 (two planes, three products; fp32-equivalent, the default), 1: the fp32 matrix instruction, 2: split-bf16 (three planes, six products; fp32's range);
+        returns the previous setting (vido_conv1x1_set_arith, process-wide)."""
+        return int(self.ctx.lib.vido_conv1x1_set_arith(int(arith)))
+
+    def conv1x1_range_flag(self, reset=True):
+        """non-zero when a split-fp16 launch met |x| >= 65504 since the last reset (its outputs are not valid); read after the stream has been waited for"""
+        return int(self.ctx.lib.vido_conv1x1_range_flag(self.ctx.h, int(bool(reset))))
 
     def conv1x1_layout(self, cin, cout, hw):
         return int(self.ctx.lib.vido_conv1x1_layout(int(cin), int(cout), int(hw)))
@@ -170,9 +175,10 @@ class HipOps:
         _, cin, H, W = x.shape
         if isinstance(w_packed, PackedConv1x1):                     # packed on first use, in the tile form the library picks for this (cin, cout, H * W)
             w_packed = w_packed.get(self.conv1x1_layout(cin, w_packed.cout, H * W), x.device)
-        cout = w_packed.numel() // cin // (3 if w_packed.dtype == torch.int16 else 1)
+        cout = (w_packed.numel() // (2 * (cin + 1)) if w_packed.dim() == 1 else w_packed.numel() // cin // 3) if w_packed.dtype == torch.int16 else w_packed.numel() // cin
         layout = self.conv1x1_layout(cin, cout, H * W)
-        assert not self.conv1x1_supported(cin, cout, H * W) or tuple(w_packed.shape) == {0: (cout // 32, cin // 8, 64, 4), 1: (cout // 16, cin // 16, 64, 4), 2: (cout // 32, cin // 16, 3, 64, 8)}[layout], \
+        assert not self.conv1x1_supported(cin, cout, H * W) or tuple(w_packed.shape) == {0: (cout // 32, cin // 8, 64, 4), 1: (cout // 16, cin // 16, 64, 4), 2: (cout // 32, cin // 16, 3, 64, 8),
+                                                                                         3: (2 * cout * (cin + 1),)}[layout], \
             "conv1x1: weight packed for another form (pack_conv1x1(w, layout))"      # (an unsupported shape is refused by the library call below)
         assert 0.0 <= slope <= 1.0 and (residual is None or residual_up2 is None)
         out = torch.empty((1, cout, H, W), device=x.device, dtype=torch.float32)
@@ -532,6 +538,21 @@ def split_bf16x3(x):
     return x0, x1, x2
 
 
+def split_f16x2(w):
+    """fp32 matrix [rows, k] -> (h, l, inv): fp16 planes of the rows scaled by powers of two, w == inv[:, None] * (h + l / 2048) to within 2^-22 |w| (two roundings to 11 bits; 2^-24.5 rms) (h = rne16(s w),
+    l = rne16(2048 (s w - h)); s = 1 / inv puts the row's largest |w| into [2^14, 2^15): no overflow; full precision down to 2^-26 of the row's maximum, below that an absolute error under 2^-48 of it) — the weight
+    side of csrc/conv1x1.hip::k_conv1x1_b3<.., NP = 2>."""
+    w = w.float()
+    m = w.abs().amax(1)
+    _, ex = torch.frexp(torch.where(m > 0, m, torch.ones_like(m)))          # m = mant 2^ex, mant in [0.5, 1)
+    e = torch.where(m > 0, 15 - ex, torch.zeros_like(ex)).clamp(-100, 100)
+    one = torch.ones_like(m)
+    ws = w * torch.ldexp(one, e)[:, None]
+    h = ws.to(torch.float16)
+    l = ((ws - h.float()) * 2048.0).to(torch.float16)
+    return h, l, torch.ldexp(one, -e)
+
+
 def pack_conv1x1(w, layout=0):
     """1x1 convolution weight [cout, cin, 1, 1] (or [cout, cin]) -> the operand order of csrc/conv1x1.hip (layout = HipOps.conv1x1_layout(cin, cout, H * W) = vido_conv1x1_layout):
     0: element (co, k) at [co / 32][k / 8][32 * (k & 1) + co % 32][(k % 8) / 2] (a lane's four operands of a group of four k-pairs are one 16-byte read; a (32-channel block, group)
@@ -539,12 +560,19 @@ def pack_conv1x1(w, layout=0):
     1: at [co / 16][k / 16][16 * (k & 3) + co % 16][(k % 16) / 4] (a lane's 16-byte read = its operands of four k-steps of a 16-row fragment) — the 128 x 112 tiles on 16 x 16 x 4;
     2: the weight split into three bf16 planes (split_bf16x3), plane p of element (co, k) at [co / 32][k / 16][p][32 * ((k % 16) / 8) + co % 32][k % 8] (int16 tensor: a 1 KB copy
        piece = the A operand of v_mfma_f32_32x32x16_bf16 for one (32-channel block, 16 input channels, plane)) — the split-bf16 form k_conv1x1_b3.
+    3: the weight as two fp16 planes of its rows scaled by powers of two (split_f16x2), in the order of 2 with two planes, followed by the [cout] inverse row scales
+       (flat int16 tensor of 2 cout (cin + 1) elements) — the split-fp16 form, the default.
     None when the kernel does not take the shape."""
     cout, cin = int(w.shape[0]), int(w.shape[1])
     if w.dim() == 4 and tuple(w.shape[2:]) != (1, 1):
         return None
     if cout % 128 or cin % 32 or (layout == 1 and cin % 64):
         return None
+    if layout == 3:
+        h, l, inv = split_f16x2(w.detach().reshape(cout, cin))
+        w6 = torch.stack([h, l], 0).view(torch.int16).reshape(2, cout // 32, 32, cin // 16, 2, 8)              # [plane][mb][co32][step][k half][8]
+        planes = w6.permute(1, 3, 0, 4, 2, 5).contiguous().reshape(-1)
+        return torch.cat([planes, inv.contiguous().view(torch.int16).reshape(-1)])
     if layout == 2:
         p0, p1, p2 = split_bf16x3(w.detach().reshape(cout, cin).float())
         w6 = torch.stack([p0, p1, p2], 0).view(torch.int16).reshape(3, cout // 32, 32, cin // 16, 2, 8)      # [plane][mb][co32][step][k half][8]

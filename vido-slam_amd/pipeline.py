@@ -239,6 +239,13 @@ class NetNodes:
                 cur.wait_event(e)
         return flow, depth, mask, labels, (e0, e1, e2)
 
+    def check_conv1x1_range(self):
+        """The split-fp16 1x1 convolutions (csrc/conv1x1.hip, the default arithmetic) take activations below 65504; a launch that met a larger one raised the context's range
+        flag and its outputs are not valid.  Called where a frame's networks are known to be complete; never seen with the detector's weights (activations of a few hundred)."""
+        if hasattr(self.ops, "conv1x1_range_flag") and self.ops.conv1x1_range_flag(reset=True):
+            raise RuntimeError("conv1x1: an activation left the range of the split-fp16 arithmetic (|x| >= 65504); the frame's detections are not valid — "
+                               "run with VIDO_CONV1X1_ARITH=bf16x3 (fp32's range, twice the matrix work)")
+
     @torch.no_grad()
     def redo_detector_if_overflowed(self, cur_bgr, n_det_host):
         """The static head stores detections_per_img slots; score ties at the reference's kthvalue cut (box_head/inference.py:131-137) can leave more.  The caller reads
@@ -302,6 +309,7 @@ class EndToEnd:
                     if self.nodes.g_det is not None:                     # the static head's overflow flag (rare): needs the frame's counts, i.e. a host wait for this one event
                         ev.synchronize()
                         self._redo_if_overflowed(slot)
+                        self.nodes.check_conv1x1_range()                 # (the frame's networks are complete: ev)
                     t1 = _time.perf_counter()
                     if not _os.environ.get("VIDO_E2E_SKIP_TRACK"):
                         d, f, m = (db["depth"], db["flow"], db["mask"]) if self.feed == "nets" else (db["gdepth"], db["gflow"], db["gmask"])
@@ -309,6 +317,7 @@ class EndToEnd:
                                                         float(k), self.n_image)
                 else:
                     ev.synchronize()                                     # networks + hand-over copies of frame k are complete
+                    self.nodes.check_conv1x1_range()
                     t1 = _time.perf_counter()
                     if self.feed == "nets":
                         d, f, m = hb["depth"].numpy(), hb["flow"].numpy(), hb["mask"].numpy()
