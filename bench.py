@@ -18,8 +18,9 @@ Synthetic data: a ray-cast 640x480 scene (ground plane, far wall, 5 moving objec
 weights (no checkpoints ship with the reference, no network here), so their outputs carry no geometry: they run at full cost, their
 outputs are parked in the device ring, and frame k is tracked only after they have completed, but the tracker is handed the renderer's exact
 flow / depth / mask of the same frame (--feed given: uploaded next to the BGR frame; --feed nets hands it the networks' outputs instead — extra.e2e_feed_nets).
-Arithmetic: fp32 results everywhere; since round 6 the detector's 1x1 convolutions compute them as six exact bf16-plane products on the bf16 matrix instruction
-(config.net_arith; csrc/conv1x1.hip), with a measured error against float64 below the fp32 instruction's.
+Arithmetic: fp32 results everywhere; since round 6 the detector's 1x1 convolutions compute them from 16-bit planes of their fp32 operands — two fp16 planes, three exact
+products on the fp16 matrix instruction (the default; VIDO_CONV1X1_ARITH=bf16x3: three bf16 planes, six products) — with fp32 accumulators (config.net_arith;
+csrc/conv1x1.hip), with a measured error against float64 below the fp32 instruction's.
 The per-frame path does not shard (frame k depends on frame k-1): --gpus N runs N independent replicas, no data-path collective.
 
 Extra objects on the same JSON line:
@@ -29,7 +30,7 @@ Extra objects on the same JSON line:
   roofline_ba    k_ba_linearize at configs[3] (local window) and configs[4] (1 M edges) size: 288 B per edge
   roofline_nets  fp32 FLOP/s of each network node vs the 157.3 TFLOP/s fp32 matrix/vector peak
   roofline_gconv the detector's grouped 3x3 convolution kernel (csrc/gconv.hip) vs the same peak
-  roofline_conv1x1 the split-bf16 1x1 GEMM at the detector's layer3 shape: fp32-equivalent TFLOP/s against 2500 / 6 (six bf16 products per multiply-add)
+  roofline_conv1x1 the split 1x1 GEMM at the detector's layer3 shape: fp32-equivalent TFLOP/s against 2500 / 3 (three fp16 products per multiply-add; / 6 for the bf16 form)
   cpu_baseline   BASELINE.md section 3: the SLAM stages (ORB / lists / pose optimisers / local BA, the C oracle) on ONE pinned core, median and p95 over 50 frames = `value`;
                  the three networks on torch-CPU on all cores as a separate part
   parity_pin     which parts of the oracle are pinned by reference outputs and which are not
@@ -336,8 +337,9 @@ def main():
                                "-> %s hand-over -> System::TrackRGBD (cvtColor, ORB 2000 features, lists, mask propagation, P3P-RANSAC, Flow2Cam, scene flow, object tracking, "
                                "per-object Flow2, re-seeding) -> PartialBatchOptimization over a full 20-frame window; networks of frame k+1 overlap tracking of frame k" % (W, H, "device-resident" if args.handover == "device" else "pinned-host"),
                    "frames_per_step": 1, "pipelined": not args.no_pipeline, "tracker_feed": args.feed,
-                   "net_arith": ("bf16x3-split, 6 terms, fp32 accumulate (1x1 convolutions of the detector: csrc/conv1x1.hip::k_conv1x1_b3; every other layer on the fp32 matrix / vector instructions)"
-                                 if not os.environ.get("VIDO_CONV1X1_ARITH") and not os.environ.get("VIDO_CONV1X1_TN") and not os.environ.get("VIDO_NO_CONV1X1") else "fp32 instructions throughout"),
+                   "net_arith": ("fp32 instructions throughout" if os.environ.get("VIDO_CONV1X1_ARITH") == "f32" or os.environ.get("VIDO_NO_CONV1X1") or (os.environ.get("VIDO_CONV1X1_TN") and not os.environ.get("VIDO_CONV1X1_ARITH"))
+                                 else "bf16x3-split, 6 products, fp32 accumulate (1x1 convolutions of the detector: csrc/conv1x1.hip::k_conv1x1_b3<NP 3>; every other layer on the fp32 matrix / vector instructions)" if os.environ.get("VIDO_CONV1X1_ARITH") in ("bf16x3", "bf16")
+                                 else "f16x2-split (per-channel power-of-two weight scales, low planes x 2^11), 3 products, fp32 accumulate (1x1 convolutions of the detector: csrc/conv1x1.hip::k_conv1x1_b3<NP 2>; every other layer on the fp32 matrix / vector instructions)"),
                    "handover": args.handover,
                    "tracker_feed_note": "networks run at full cost and their outputs are parked in the hand-over ring; with random-init weights those maps carry no geometry, so the tracker is "
                                         "handed the renderer's exact flow/depth/mask of the same frame (feed=given; uploaded next to the BGR frame) once the networks of that frame have completed",
@@ -359,7 +361,7 @@ def main():
                       "core cannot be built in this image (no OpenCV / Eigen / CXSparse) and has no tests or fixtures of its own",
         "targets": {"north_star_frames_per_s": 200, "fp32_flop_floor_ms_per_frame": round((888.7 + 200.5 + 16.0) / FP32_PEAK_TFLOPS, 2),
                     "note": "1.105 TFLOP of fp32 convolutions per frame / 157.3 TFLOP/s = 7.0 ms > the 5 ms a 200 frames/s chain has: unreachable on the fp32 matrix instruction alone; "
-                            "the split-bf16 form of the 1x1 layers (round 6) is the first step under that floor"},
+                            "the split-fp16 form of the 1x1 layers (round 6) is the first step under that floor"},
     }
     del e2e, slam
 
@@ -519,8 +521,8 @@ def main():
                                        "note": "algorithmic FLOPs of the convolution (pad positions and the zero half of the 8-channel form not counted) / HIP-event time of 100 back-to-back launches"}
           except Exception as e:
               out["roofline_gconv_error"] = "%s: %s" % (type(e).__name__, e)
-          # the detector's 1x1 convolutions in the split-bf16 form (csrc/conv1x1.hip::k_conv1x1_b3): fp32-equivalent FLOPs / HIP-event time; the peak of this form is the
-          # bf16 matrix peak / 6 (six bf16 products per fp32 multiply-add)
+          # the detector's 1x1 convolutions in the split form (csrc/conv1x1.hip::k_conv1x1_b3): fp32-equivalent FLOPs / HIP-event time; the peak of this form is the
+          # 16-bit matrix peak / the products per fp32 multiply-add (3 for the fp16 form, 6 for the bf16 form)
           try:
               from vido_slam_amd.nets.ops import HipOps, pack_conv1x1
               cops1 = HipOps(ctx); rc = {}
@@ -537,12 +539,17 @@ def main():
                   e1.record(); torch.cuda.synchronize()
                   us = e0.elapsed_time(e1) * 1e3 / reps; fl = 2.0 * cin * cout * ch * cw
                   rc["%s_%d_to_%d_at_%dx%d" % (nm, cin, cout, ch, cw)] = {"us_per_launch": round(us, 2), "fp32_equivalent_tflops": round(fl / us / 1e6, 1), "layout": lay, "launches_per_frame_about": per_frame}
-              mainc = rc["layer3_1024_to_1024_at_50x68"]; split = mainc["layout"] == 2
-              pk = 2500.0 / 6.0 if split else FP32_PEAK_TFLOPS
-              out["roofline_conv1x1"] = {"kernel": "k_conv1x1_b3 (1x1 convolution + bias + residual + ReLU; three bf16 planes per fp32 operand, six products on v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if split else "k_conv1x1 (fp32 matrix instruction)",
+              mainc = rc["layer3_1024_to_1024_at_50x68"]; split = mainc["layout"] >= 2; nprod = {2: 6, 3: 3}.get(mainc["layout"], 1); npl = {2: 3, 3: 2}.get(mainc["layout"], 2)
+              pk = 2500.0 / nprod if split else FP32_PEAK_TFLOPS
+              # operand bytes a launch moves L2 -> LDS: per 128 x 128 tile and input channel 128 weights x 2 bytes x planes + 128 activations x 4 bytes
+              tiles3 = (1024 // 128) * ((50 * 68 + 127) // 128); stream = tiles3 * 1024 * (128 * 2 * npl + 128 * 4)
+              out["roofline_conv1x1"] = {"kernel": ("k_conv1x1_b3<NP 2> (1x1 convolution + bias + residual + ReLU; two fp16 planes per fp32 operand, three products on v_mfma_f32_32x32x16_f16, fp32 accumulate)" if nprod == 3 else
+                                                    "k_conv1x1_b3<NP 3> (1x1 convolution + bias + residual + ReLU; three bf16 planes per fp32 operand, six products on v_mfma_f32_32x32x16_bf16, fp32 accumulate)") if split else "k_conv1x1 (fp32 matrix instruction)",
                                          "bound": "mfma", "achieved": mainc["fp32_equivalent_tflops"], "peak": round(pk, 1), "unit": "TFLOP/s", "frac": round(mainc["fp32_equivalent_tflops"] / pk, 4), "traffic": None,
-                                         "bf16_tflops_issued": round(mainc["fp32_equivalent_tflops"] * 6, 1) if split else None, "shapes": rc,
-                                         "note": "fp32-equivalent FLOPs (2 cin cout H W) / HIP-event time of 100 back-to-back launches with bias + residual + ReLU; peak = 2500 TFLOP/s dense bf16 / 6 products; "
+                                         "tflops_16bit_issued": round(mainc["fp32_equivalent_tflops"] * nprod, 1) if split else None, "shapes": rc,
+                                         "operand_stream": {"bytes_l2_to_lds_per_launch": stream, "tb_per_s": round(stream / mainc["us_per_launch"] / 1e6, 2),
+                                                            "note": "every 128 x 128 tile streams its own weight planes and activations through LDS: what the launch's time follows (DESIGN.md 4d), not the matrix pipe"} if split else None,
+                                         "note": "fp32-equivalent FLOPs (2 cin cout H W) / HIP-event time of 100 back-to-back launches with bias + residual + ReLU; peak = 2500 TFLOP/s dense 16-bit / products per multiply-add; "
                                                  "the fp32 matrix instruction's own peak is 157.3"}
           except Exception as e:
               out["roofline_conv1x1_error"] = "%s: %s" % (type(e).__name__, e)

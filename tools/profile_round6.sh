@@ -11,7 +11,7 @@
 #                                                                                                    -> nets_timeline_summary.txt, det_timeline_summary.txt, nets_mfma.json
 #   ba     rocprofv3 --kernel-trace --stats of tools/prof_ba_global.py (configs[4] size)              -> global_ba_kernel_stats.csv
 #   nodet  the literal chain of the metric text (tools/prof_nodet.py): stage ms + C-ABI call profile  -> nodet_call_profile.txt, nodet_kernel_stats.csv
-#   c1     tools/r6/conv1x1_b3_check.py (split-bf16 vs fp32-instruction 1x1 kernel vs float64) -> conv1x1_microbench.txt; tools/ubench/valu_int_issue -> valu_int_issue.txt
+#   c1     tools/r6/conv1x1_b3_check.py (split-fp16 and split-bf16 vs fp32-instruction 1x1 kernel vs float64) -> conv1x1_microbench.txt; tools/ubench/valu_int_issue -> valu_int_issue.txt
 set -u
 REPO=$(pwd); OUT=$REPO/gpurun_out/prof_r6; mkdir -p $OUT
 WHAT="${*:-tests bench e2e fe pmc sq nets ba nodet c1}"
@@ -21,7 +21,7 @@ if has bench; then
   timeout 900 python bench.py > $OUT/bench_e2e.json 2> $OUT/bench_e2e.err; echo "bench rc $?"
   timeout 900 python bench.py --steps 200 --warmup 10 --no-extra --cpu-baseline 0 > $OUT/bench_e2e_200.json 2> $OUT/bench_e2e_200.err; echo "bench200 rc $?"
 fi
-if has c1; then      # the split-bf16 1x1 kernel against the fp32-instruction one and float64 (error ratio, us, fp32-equivalent TFLOP/s), the form the library picks per shape
+if has c1; then      # the split-fp16 / split-bf16 1x1 kernels against the fp32-instruction one and float64 (error ratio, us, fp32-equivalent TFLOP/s), the form the library picks per shape
   timeout 300 python tools/r6/conv1x1_b3_check.py 2>&1 | grep -v amdgpu.ids > $OUT/conv1x1_microbench.txt
   timeout 120 tools/ubench/valu_int_issue.bin > $OUT/valu_int_issue.txt 2>&1
 fi
