@@ -365,6 +365,14 @@ int vido_wino3x3_bias_act(vido_ctx* ctx, const float* x, const float* u_packed, 
  * form the library recommends for a launch (VIDO_WINO_KSPLIT=0/4/2: never / always 1 / always 2 for under-filled launches);
  * the packed weight must be of the form the launch is given (form 1 packs 4-channel chunks for every cout).  The un-suffixed entries are form 0. */
 int vido_wino3x3_form(int n, int cin, int cout, int h, int w);
+/* Dense 3x3 stride-1 `same` convolution + bias + leaky-ReLU as a DIRECT implicit GEMM in the split-fp16 arithmetic of vido_conv1x1_set_arith(0) (csrc/conv3x3h.hip, round 6):
+ * the detector's chip-filling 256 -> 256 layers (FPN outputs and RPN head on P2 / P3: backbone/fpn.py:55-66, rpn/rpn.py:74-107; the mask head: roi_mask_feature_extractors.py).
+ * x [n][cin][h][w], y [n][cout][h][w] f32 DEVICE; w_packed: two fp16 planes of the output channels scaled by powers of two, plane p of element (co, ci, dy, dx) at
+ * [co / 32][ci / 16][dy][dx][p][32 ((ci % 16) / 8) + co % 32][ci % 8], then [cout] floats: the inverse scales (vido_slam_amd/nets/ops.py::pack_conv3x3_h).
+ * vido_conv3x3_h_supported: cout % 128 == 0, cin % 16 == 0, tensors below 1 GB.  Activations must stay below 65504 in magnitude (vido_conv1x1_range_flag otherwise). */
+int vido_conv3x3_h_supported(int n, int cin, int cout, int h, int w);
+int vido_conv3x3_h_workgroups(int n, int cout, int h, int w);
+int vido_conv3x3_h_bias_act(vido_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* y, int n, int cin, int cout, int h, int w, float slope);
 long long vido_wino3x3_packed_floats_form(int cin, int cout, int form);
 int vido_wino3x3_pack_form(const float* w, int cin, int cout, int form, float* u_packed);
 int vido_wino3x3_bias_act_form(vido_ctx* ctx, const float* x, const float* u_packed, const float* bias, float* y, int n, int cin, int cout, int h, int w, float slope, int form);

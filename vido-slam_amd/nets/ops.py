@@ -6,6 +6,7 @@ import os
 import torch
 
 _WINO_MIN_WGS = int(os.environ.get("VIDO_WINO_MIN_WGS", "0"))
+_CONV3X3_H_MIN_WGS = 0 if os.environ.get("VIDO_CONV3X3_H") == "0" else int(os.environ.get("VIDO_CONV3X3_H_MIN_WGS", "190"))      # direct split-fp16 3x3 (csrc/conv3x3h.hip) from this many workgroups on
 # which layers conv_direct_conv takes: "all", or "novalu" (default) = not the 7x7 stem / stride-2 3x3 layers, which the library runs as Winograd on the VECTOR ALUs — beside
 # the detector (whose convolutions saturate the MATRIX pipe) those run in its shadow, while the direct kernel competes for the matrix pipe.  Measured (two pairs of 100
 # steps, profiles/r5/convdirect_ab.txt): headline 90.3 frames/s without the direct kernel, 89.4 with it on every layer (LiteFlowNet alone 3.85 -> 3.65 ms), 90.6 with
@@ -288,6 +289,15 @@ class HipOps:
         # the input channels).  VIDO_WINO_MIN_WGS=128 restores the rule of round 4 (the library's kernels below 128 workgroups).
         if _WINO_MIN_WGS > 0 and not self.ctx.lib.vido_wino3x3_fills_chip(int(x.shape[0]), int(w.shape[0]), int(x.shape[2]), int(x.shape[3]), _WINO_MIN_WGS):
             return None
+        # (round 6) chip-filling launches of >= 128-channel layers take the DIRECT kernel in split-fp16 arithmetic (csrc/conv3x3h.hip): 256 -> 256 on 200 x 272 in 216 us
+        # against the Winograd kernel's 325, the mask head's 100 x 14 x 14 in 97 against 156; below ~190 workgroups of 128 channels x 16 x 16 positions one workgroup's
+        # K loop is the launch's time and Winograd (its K-split form) stays faster.  VIDO_CONV3X3_H=0 keeps Winograd everywhere; VIDO_CONV3X3_H_MIN_WGS moves the threshold.
+        if (_CONV3X3_H_MIN_WGS > 0 and x.dtype == torch.float32 and self.ctx.lib.vido_conv3x3_h_supported(int(x.shape[0]), int(w.shape[1]), int(w.shape[0]), int(x.shape[2]), int(x.shape[3]))
+                and self.ctx.lib.vido_conv3x3_h_workgroups(int(x.shape[0]), int(w.shape[0]), int(x.shape[2]), int(x.shape[3])) >= _CONV3X3_H_MIN_WGS):
+            key = (w.data_ptr(), w._version, str(x.device))
+            if getattr(conv, "_c3h_key", None) != key:
+                conv._c3h_w = pack_conv3x3_h(w).to(x.device); conv._c3h_key = key
+            return self.conv3x3_h_bias_act(x.contiguous(), conv._c3h_w, b, int(w.shape[0]), slope)
         form = self.wino3x3_form(x.shape[0], w.shape[1], w.shape[0], x.shape[2], x.shape[3])
         key = (w.data_ptr(), w._version, str(x.device))
         if getattr(conv, "_wino_key", None) != key:
@@ -295,6 +305,18 @@ class HipOps:
         if form not in conv._wino_u:
             conv._wino_u[form] = pack_wino3x3(w, form).to(x.device)
         return self.wino3x3_bias_act(x.contiguous(), conv._wino_u[form], b, int(w.shape[0]), slope, form)
+
+    def conv3x3_h_bias_act(self, x, w_packed, bias, cout, slope):
+        """leaky_relu(conv2d(x, w, stride 1, padding 1) + bias, slope) as one direct split-fp16 launch (csrc/conv3x3h.hip); w_packed = pack_conv3x3_h(w)."""
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
+        N, cin, H, W = x.shape
+        assert w_packed.dtype == torch.int16 and w_packed.numel() == 2 * cout * (cin * 9 + 1), "conv3x3_h: weight not packed by pack_conv3x3_h for this layer"
+        out = torch.empty((N, cout, H, W), device=x.device, dtype=torch.float32)
+        self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * N * cout * cin * 9 * H * W
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_conv3x3_h_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(w_packed.data_ptr()), C.c_void_p(bias.data_ptr()) if bias is not None else None,
+                                                             C.c_void_p(out.data_ptr()), int(N), int(cin), int(cout), int(H), int(W), C.c_float(slope)))
+        return out
 
     def conv_direct_conv(self, conv, x, slope):
         """The convolution `conv` (nn.Conv2d: groups 1, dilation 1, zero padding, a k x k of csrc/convdirect.hip) + bias + activation as ONE direct implicit-GEMM launch on
@@ -582,6 +604,19 @@ def pack_conv1x1(w, layout=0):
         return w5.permute(0, 2, 4, 1, 3).contiguous().reshape(cout // 16, cin // 16, 64, 4)
     w5 = w.detach().reshape(cout // 32, 32, cin // 8, 4, 2)            # [mb][co32][group][kk][half]
     return w5.permute(0, 2, 4, 1, 3).contiguous().reshape(cout // 32, cin // 8, 64, 4)
+
+
+def pack_conv3x3_h(w):
+    """3x3 convolution weight [cout, cin, 3, 3] -> the operand order of csrc/conv3x3h.hip (the direct split-fp16 kernel): two fp16 planes of the output channels scaled by
+    powers of two (split_f16x2 over a channel's cin x 9 weights), plane p of element (co, ci, dy, dx) at [co / 32][ci / 16][dy][dx][p][32 * ((ci % 16) / 8) + co % 32][ci % 8],
+    followed by the [cout] inverse scales (flat int16 tensor).  None when the kernel does not take the shape."""
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    if tuple(w.shape[2:]) != (3, 3) or cout % 128 or cin % 16:
+        return None
+    h, l, inv = split_f16x2(w.detach().reshape(cout, cin * 9))
+    planes = torch.stack([h, l], 0).view(torch.int16).reshape(2, cout // 32, 32, cin // 16, 2, 8, 3, 3)        # [plane][mb][co32][chunk][k half][k8][dy][dx]
+    planes = planes.permute(1, 3, 6, 7, 0, 4, 2, 5).contiguous().reshape(-1)                                 # [mb][chunk][dy][dx][plane][k half][co32][k8]
+    return torch.cat([planes, inv.contiguous().view(torch.int16).reshape(-1)])
 
 
 class PackedConv1x1:
