@@ -432,3 +432,44 @@ def test_fpn_lateral_with_upsampled_sum_equals_the_reference_form(vido, ctx, mon
         assert float((y0.double() - ref0).abs().max()) < 2e-5 * max(1.0, float(ref0.abs().max()))
     with pytest.raises((vido.VidoError, AssertionError)):                   # odd map: no half-resolution residual for it
         ops.conv1x1_bias_act(torch.zeros(1, 64, 13, 12, device="cuda"), torch.zeros(4, 8, 64, 4, device="cuda"), None, None, 1.0, residual_up2=torch.zeros(1, 128, 6, 6, device="cuda"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [0, 8, 16])      # VIDO_CONV3X3_H_ROWS: 0 = the block form the library picks by launch size; 8 / 16 forced (a child process)
+def test_direct_split_fp16_conv3x3_against_float64_and_the_winograd_kernel(vido, ctx, rows):
+    """csrc/conv3x3h.hip (direct 3x3 in split-fp16 arithmetic: FPN outputs / RPN head on P2, P3, the mask head) against float64 conv2d on shapes that cover one block, odd
+    sizes with blocks hanging over the edge, a batch, 16 .. 256 input channels, ReLU / leaky / no activation, no bias: error <= 1.5 x the fp32 Winograd kernel's
+    (csrc/wino.hip) on the same input and small against the output's magnitude; the range flag stays down."""
+    if rows:
+        import subprocess, sys, os
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        code = ("import sys; sys.path.insert(0, %r); import pytest; sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', "
+                "%r + '::test_direct_split_fp16_conv3x3_against_float64_and_the_winograd_kernel[0]']))" % (root, os.path.abspath(__file__)))
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VIDO_CONV3X3_H_ROWS=str(rows)), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        return
+    from vido_slam_amd.nets.ops import HipOps, pack_conv3x3_h, pack_wino3x3
+    ops = HipOps(ctx)
+    F = torch.nn.functional
+    for N, cin, cout, H, W, slope, with_bias in ((1, 16, 128, 16, 16, 0.0, True), (2, 32, 128, 13, 21, 0.1, True), (3, 48, 256, 7, 35, 1.0, False), (1, 256, 256, 50, 68, 0.0, True),
+                                                 (5, 256, 256, 14, 14, 0.0, True), (1, 128, 128, 100, 136, 1.0, True), (1, 64, 384, 33, 17, 0.1, True)):
+        assert ops.ctx.lib.vido_conv3x3_h_supported(N, cin, cout, H, W)
+        g = torch.Generator().manual_seed(cin + H)
+        x = torch.randn(N, cin, H, W, generator=g); w = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5) * torch.exp(torch.randn(cout, 1, 1, 1, generator=g)); b = torch.randn(cout, generator=g) if with_bias else None
+        pre = F.conv2d(x.double(), w.double(), b.double() if with_bias else None, padding=1); ref = F.leaky_relu(pre, slope)
+        xc = x.cuda(); bc = b.cuda() if with_bias else None
+        yh = ops.conv3x3_h_bias_act(xc, pack_conv3x3_h(w).cuda(), bc, cout, slope).cpu()
+        assert float((yh.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), (N, cin, cout, H, W)
+        form = ops.wino3x3_form(N, cin, cout, H, W)
+        yw = ops.wino3x3_bias_act(xc, pack_wino3x3(w, form).cuda(), bc if with_bias else torch.zeros(cout, device="cuda"), cout, slope, form).cpu()
+        # the error measure: rms over all outputs, each relative to its channel's mean magnitude (the channels' weights differ by e^N(0,1); a max over 10^5 .. 10^7 outputs of
+        # the largest channel is a tail statistic that moves by 3x between kernels of equal rms error: tools/r6/conv3x3_h_errors.py)
+        scale = pre.abs().mean((0, 2, 3), keepdim=True).clamp_min(1e-30)                 # (before the activation: a ReLU can leave a channel all zeros)
+        eh, ew = (float(((y.double() - ref) / scale).pow(2).mean().sqrt()) for y in (yh, yw))
+        assert eh <= 1.5 * ew and eh < 1e-6, (N, cin, cout, H, W, eh, ew)
+    torch.cuda.synchronize()
+    assert ops.conv1x1_range_flag() == 0
+    assert not ops.ctx.lib.vido_conv3x3_h_supported(1, 24, 128, 16, 16) and not ops.ctx.lib.vido_conv3x3_h_supported(1, 32, 64, 16, 16)
+    xb = torch.randn(1, 16, 16, 16); xb[0, 3, 5, 5] = 1e5
+    ops.conv3x3_h_bias_act(xb.cuda(), pack_conv3x3_h(torch.randn(128, 16, 3, 3)).cuda(), None, 128, 1.0); torch.cuda.synchronize()
+    assert ops.conv1x1_range_flag() == 1

@@ -219,6 +219,28 @@ def test_pack_conv1x1_is_the_operand_order_of_the_kernel():
     assert torch.equal(p3[2 * 256 * 64:].view(torch.float32), inv)
 
 
+def test_pack_conv3x3_h_is_the_operand_order_of_the_direct_kernel():
+    """pack_conv3x3_h (csrc/conv3x3h.hip): plane p of element (co, ci, dy, dx) at [co / 32][ci / 16][dy][dx][p][32 ((ci % 16) / 8) + co % 32][ci % 8], the planes being
+    split_f16x2 of the output channel's cin x 9 weights; the inverse channel scales follow; shapes the kernel does not take give None."""
+    from vido_slam_amd.nets.ops import pack_conv3x3_h, split_f16x2
+    g = torch.Generator().manual_seed(3)
+    cout, cin = 256, 48
+    w = torch.randn(cout, cin, 3, 3, generator=g) * torch.exp(torch.randn(cout, 1, 1, 1, generator=g))
+    p = pack_conv3x3_h(w)
+    assert p.dtype == torch.int16 and tuple(p.shape) == (2 * cout * (cin * 9 + 1),)
+    h, l, inv = split_f16x2(w.reshape(cout, cin * 9))
+    h = h.view(torch.int16).reshape(cout, cin, 3, 3); l = l.view(torch.int16).reshape(cout, cin, 3, 3)
+    pl = p[:2 * cout * cin * 9].reshape(cout // 32, cin // 16, 3, 3, 2, 64, 8)
+    for _ in range(400):
+        co, ci, dy, dx = (int(torch.randint(0, n, (1,), generator=g)) for n in (cout, cin, 3, 3))
+        lane = 32 * ((ci % 16) // 8) + co % 32
+        assert int(pl[co // 32, ci // 16, dy, dx, 0, lane, ci % 8]) == int(h[co, ci, dy, dx]) and int(pl[co // 32, ci // 16, dy, dx, 1, lane, ci % 8]) == int(l[co, ci, dy, dx])
+    assert torch.equal(p[2 * cout * cin * 9:].view(torch.float32), inv)
+    rec = inv.double()[:, None] * (h.view(torch.float16).reshape(cout, -1).double() + l.view(torch.float16).reshape(cout, -1).double() / 2048.0)
+    assert float(((rec - w.reshape(cout, -1).double()).abs() / w.reshape(cout, -1).abs().amax(1, keepdim=True).double()).max()) <= 2.0 ** -22
+    assert pack_conv3x3_h(torch.zeros(64, 32, 3, 3)) is None and pack_conv3x3_h(torch.zeros(128, 24, 3, 3)) is None and pack_conv3x3_h(torch.zeros(128, 32, 1, 1)) is None
+
+
 def test_conv1x1_tile_form_is_chosen_by_rounds_of_workgroups():
     """vido_conv1x1_layout (host side of csrc/conv1x1.hip).  Default: 128 x 128 tiles (the form that measured faster on the pipelined headline).  VIDO_CONV1X1_TN=0: 128 x 112
     tiles where they need fewer (rounds of 256 CUs) x (tile width) — every bottleneck shape of X-101-32x8d at the 800 x 1088 feed (850 tiles of 128 x 128 = 3.3 rounds -> 972

@@ -33,22 +33,29 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define C3_OOB 0x40000000u
 #define C3_WSLOT 24576                   // one step of weights: 4 row blocks x 3 taps x 2 planes x 1 KB
 #define C3_RBW 3                         // ring slots
-#define C3_RAW 22528                     // the fp32 window: 88 pieces of 256 bytes (5184 values + padding to 11 pieces per wave)
-#define C3_PLANE 10368                   // one fp16 plane of the window: 324 pixels x 16 channels x 2 bytes
-#define C3_PBUF (2 * C3_PLANE)
-#define C3_LDS (C3_RBW * C3_WSLOT + C3_RAW + 2 * C3_PBUF)
+// per form (RPW = row blocks of 32 channels a wave owns: 4 = the 16 x 16 position block above; 2 = an 8 x 16 block, wave = 64 channels x two rows — half the K loop's length
+// per workgroup for launches that would not fill the chip with the larger block)
+#define C3_WPIX(RPW) ((4 * (RPW) + 2) * 18)                      // pixels of the window
+#define C3_XP(RPW) ((16 * C3_WPIX(RPW) + 511) / 512)             // window pieces per wave: 11 / 6
+#define C3_RAW(RPW) (C3_XP(RPW) * 8 * 256)                       // the fp32 window, padded to whole pieces per wave
+#define C3_PLANE(RPW) (C3_WPIX(RPW) * 32)                        // one fp16 plane of the window: pixels x 16 channels x 2 bytes
+#define C3_PBUF(RPW) (2 * C3_PLANE(RPW))
+#define C3_LDS(RPW) (C3_RBW * C3_WSLOT + C3_RAW(RPW) + 2 * C3_PBUF(RPW))
 
 struct C3Args { const float* x; const void* wp; const float* bias; float* y; int N, Cin, Cout, H, W, nby, nbx, mt, total, nchunk; float slope; unsigned xbytes, wbytes; unsigned* range_flag; };
 
+template <int RPW>
 __global__ __launch_bounds__(512) void k_conv3x3_h(C3Args A)
 {
+    constexpr int BR = 4 * RPW, WPIX = C3_WPIX(RPW), XP = C3_XP(RPW), RAWB = C3_RAW(RPW), PLANE = C3_PLANE(RPW), PBUF = C3_PBUF(RPW), CK = (WPIX * 8 + 511) / 512, NMM = 9 * RPW, NRD = 2 * RPW + 2;
     extern __shared__ __attribute__((aligned(16))) char c3_lds[];
     char* L = c3_lds;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int per = gridDim.x >> 3, item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // an XCD walks a contiguous range of items, the channel block fastest
     if (item >= A.total) return;
     const int nt = item / A.mt, mtile = item - nt * A.mt, m0 = mtile * 128;
-    const int bpi = A.nby * A.nbx, n = nt / bpi, brem = nt - n * bpi, by = brem / A.nbx, bx = brem - by * A.nbx, Y0 = by * 16, X0 = bx * 16;
+    const int bpi = A.nby * A.nbx, n = nt / bpi, brem = nt - n * bpi, by = brem / A.nbx, bx = brem - by * A.nbx, Y0 = by * BR, X0 = bx * 16;
+    const int rp = RPW == 4 ? w : (w & 3), rb0 = RPW == 4 ? 0 : 2 * (w >> 2);      // the wave's row pair of the block, its first row block of 32 channels
     const int hw = A.H * A.W, nsteps = A.nchunk * 3;
 
     // ---- copies.  Weights: piece i = w + 8 q (q = 0 .. 2) of a step = (row block i / 6, tap-and-plane i % 6); everything but the step rides in abase.
@@ -58,81 +65,81 @@ __global__ __launch_bounds__(512) void k_conv3x3_h(C3Args A)
     unsigned abase[3];
 #pragma unroll
     for (int q = 0; q < 3; q++) { const int i = w + 8 * q, rb = i / 6, rem = i - 6 * rb; abase[q] = 1024u * (unsigned)(((m0 >> 5) + rb) * A.nchunk * 18 + rem); }
-    // Window: piece 8 j + w (j = 0 .. 10) holds elements e = 64 (8 j + w) + lane of [16 channels][18 rows][18 columns]
-    unsigned xvo[11];
+    // Window: piece 8 j + w (j = 0 .. XP - 1) holds elements e = 64 (8 j + w) + lane of [16 channels][BR + 2 rows][18 columns]
+    unsigned xvo[11];                                                      // (fixed bound: see csrc/conv1x1.hip on arrays of template-dependent size captured by lambdas)
 #pragma unroll
-    for (int j = 0; j < 11; j++) {
-        const int e = 64 * (8 * j + w) + lane, ch = e / 324, rem = e - ch * 324, row = rem / 18, col = rem - row * 18, gy = Y0 - 1 + row, gx = X0 - 1 + col;
-        xvo[j] = (e < 5184 && gy >= 0 && gy < A.H && gx >= 0 && gx < A.W) ? 4u * (unsigned)(ch * hw + gy * A.W + gx) : C3_OOB;
+    for (int j = 0; j < XP; j++) {
+        const int e = 64 * (8 * j + w) + lane, ch = e / WPIX, rem = e - ch * WPIX, row = rem / 18, col = rem - row * 18, gy = Y0 - 1 + row, gx = X0 - 1 + col;
+        xvo[j] = (e < 16 * WPIX && gy >= 0 && gy < A.H && gx >= 0 && gx < A.W) ? 4u * (unsigned)(ch * hw + gy * A.W + gx) : C3_OOB;
     }
     const unsigned ximg = 4u * (unsigned)n * (unsigned)A.Cin * (unsigned)hw, xchunk = 64u * (unsigned)hw;
     char* const RAW = L + C3_RBW * C3_WSLOT;
-    char* const PL = RAW + C3_RAW;
+    char* const PL = RAW + RAWB;
     auto issue_w = [&](int s, int slot) {                                  // this wave's three pieces of step s (clamped by the caller)
         char* S = L + slot * C3_WSLOT + w * 1024;
         const unsigned so = 6144u * (unsigned)s;
 #pragma unroll
         for (int q = 0; q < 3; q++) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(S + q * 8192), 16, avo, abase[q] + so, 0, 0);
     };
-    auto issue_x = [&](int c) {                                            // this wave's eleven pieces of chunk c's window
+    auto issue_x = [&](int c) {                                            // this wave's XP pieces of chunk c's window
         const unsigned so = ximg + xchunk * (unsigned)c;
 #pragma unroll
-        for (int j = 0; j < 11; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(RAW + (8 * j + w) * 256), 4, xvo[j], so, 0, 0);
+        for (int j = 0; j < XP; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(RAW + (8 * j + w) * 256), 4, xvo[j], so, 0, 0);
     };
-    // ---- the window's two fp16 planes: item idx = tid + 512 k -> channel pair idx / 324, pixel idx % 324
+    // ---- the window's two fp16 planes: item idx = tid + 512 k -> channel pair idx / WPIX, pixel idx % WPIX
     float xmax = 0.f;
     const f32x2 k2048 = {2048.f, 2048.f};
     auto convert = [&](int buf) {
         const float* R = (const float*)RAW;
-        unsigned* P = (unsigned*)(PL + buf * C3_PBUF);
+        unsigned* P = (unsigned*)(PL + buf * PBUF);
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
+        for (int k = 0; k < CK; k++) {
             const int idx = tid + 512 * k;
-            if (k < 5 || idx < 2592) {
-                const int q = idx / 324, pix = idx - q * 324;
-                const f32x2 v = {R[(2 * q) * 324 + pix], R[(2 * q + 1) * 324 + pix]};
+            if (k < CK - 1 || idx < WPIX * 8) {
+                const int q = idx / WPIX, pix = idx - q * WPIX;
+                const f32x2 v = {R[(2 * q) * WPIX + pix], R[(2 * q + 1) * WPIX + pix]};
                 const f16x2 h = __builtin_convertvector(v, f16x2);
                 f32x2 vs, r;
                 asm("v_pk_mul_f32 %0, %1, %2" : "=v"(vs) : "v"(v), "v"(k2048));
                 asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r.x) : "v"(h), "s"(-2048.f), "v"(vs.x));
                 asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.y) : "v"(h), "s"(-2048.f), "v"(vs.y));
                 const f16x2 l = __builtin_convertvector(r, f16x2);
-                P[pix * 8 + q] = __builtin_bit_cast(unsigned, h); P[2592 + pix * 8 + q] = __builtin_bit_cast(unsigned, l);
+                P[pix * 8 + q] = __builtin_bit_cast(unsigned, h); P[PLANE / 4 + pix * 8 + q] = __builtin_bit_cast(unsigned, l);
                 xmax = __builtin_fmaxf(__builtin_fmaxf(xmax, __builtin_fabsf(v.x)), __builtin_fabsf(v.y));
             }
         }
     };
 
-    f32x16 acc[4], acl[4];
+    f32x16 acc[RPW], acl[RPW];
 #pragma unroll
-    for (int rb = 0; rb < 4; rb++)
+    for (int rb = 0; rb < RPW; rb++)
 #pragma unroll
         for (int r = 0; r < 16; r++) { acc[rb][r] = 0.f; acl[rb][r] = 0.f; }
     typedef const __attribute__((address_space(3))) char* lds_c;
     const unsigned a_lane = 16u * (unsigned)lane;
-    const unsigned b_lane = (unsigned)(C3_RBW * C3_WSLOT + C3_RAW) + 32u * (unsigned)((2 * w + ((lane & 31) >> 4)) * 18 + (lane & 15)) + 16u * (unsigned)(lane >> 5);
+    const unsigned b_lane = (unsigned)(C3_RBW * C3_WSLOT + RAWB) + 32u * (unsigned)((2 * rp + ((lane & 31) >> 4)) * 18 + (lane & 15)) + 16u * (unsigned)(lane >> 5);
 
     // prologue: window of chunk 0 and the first two weight steps; convert chunk 0
     issue_x(0); issue_w(0, 0); issue_w(min(1, nsteps - 1), 1);
-    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the window has landed (everybody's pieces)
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the window has landed (everybody's pieces); the two weight steps may be on their way
     convert(0);
     int slot = 0;
     // step (c, dy): barrier (weights of the step landed, planes visible, everybody done with the slot the next copies overwrite) -> copies two steps ahead
     // (+ the next window on dy = 0) -> 36 matrix instructions (+ the next window's conversion on dy = 2)
     // One step = three taps.  Operands of tap t + 1 are read while tap t multiplies (two register sets); the step's copies are dealt between the matrix instructions by
     // hand — a copy piece costs ~60 cycles of the wave's issue time (csrc/conv1x1.hip), fourteen of them in front of the first matrix instruction would idle the pipe.
-    u32x4 a[2][4][2], b[2][2];
+    u32x4 a[2][RPW][2], b[2][2];
     auto step = [&](auto dy_c, auto nbuf_c, int pbuf, auto&& copies) {
         constexpr int dy = decltype(dy_c)::value, NBUF = decltype(nbuf_c)::value;
         lds_c Ab = (lds_c)(L + slot * C3_WSLOT) + a_lane;
-        lds_c Bb = (lds_c)L + b_lane + pbuf * C3_PBUF + dy * (18 * 32);
+        lds_c Bb = (lds_c)L + b_lane + pbuf * PBUF + dy * (18 * 32);
         auto ld = [&](int dx, int set) {
 #pragma unroll
-            for (int rb = 0; rb < 4; rb++)
+            for (int rb = 0; rb < RPW; rb++)
 #pragma unroll
-                for (int pl = 0; pl < 2; pl++) a[set][rb][pl] = *(const __attribute__((address_space(3))) u32x4*)(Ab + ((rb * 3 + dx) * 2 + pl) * 1024);
+                for (int pl = 0; pl < 2; pl++) a[set][rb][pl] = *(const __attribute__((address_space(3))) u32x4*)(Ab + (((rb0 + rb) * 3 + dx) * 2 + pl) * 1024);
 #pragma unroll
-            for (int pl = 0; pl < 2; pl++) b[set][pl] = *(const __attribute__((address_space(3))) u32x4*)(Bb + dx * 32 + pl * C3_PLANE);
+            for (int pl = 0; pl < 2; pl++) b[set][pl] = *(const __attribute__((address_space(3))) u32x4*)(Bb + dx * 32 + pl * PLANE);
         };
         __builtin_amdgcn_sched_barrier(0);
         ld(0, 0);
@@ -144,17 +151,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_h(C3Args A)
             for (int term = 0; term < 3; term++) {
                 constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
 #pragma unroll
-                for (int rb = 0; rb < 4; rb++) {
+                for (int rb = 0; rb < RPW; rb++) {
                     f32x16& d = term == 2 ? acc[rb] : acl[rb];
                     d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[dx & 1][rb][PA[term]]), __builtin_bit_cast(f16x8, b[dx & 1][PB[term]]), d, 0, 0, 0);
                 }
             }
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);                // operands of the first tap
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);               // operands of the first tap
 #pragma unroll
-        for (int i = 0; i < 36; i++) {
+        for (int i = 0; i < NMM; i++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < 20) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i < 2 * NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if (i >= 1 && i < 1 + NBUF) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -163,10 +170,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_h(C3Args A)
         const int pbuf = c & 1, cn = min(c + 1, A.nchunk - 1);
         // dy = 0.  In flight behind the weights of this step: the next step's three pieces.
         asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        step(std::integral_constant<int, 0>{}, std::integral_constant<int, 14>{}, pbuf, [&] { const int sf = slot == 0 ? C3_RBW - 1 : slot - 1; issue_w(min(3 * c + 2, nsteps - 1), sf); issue_x(cn); });
+        step(std::integral_constant<int, 0>{}, std::integral_constant<int, 3 + XP>{}, pbuf, [&] { const int sf = slot == 0 ? C3_RBW - 1 : slot - 1; issue_w(min(3 * c + 2, nsteps - 1), sf); issue_x(cn); });
         slot = slot + 1 == C3_RBW ? 0 : slot + 1;
         // dy = 1.  Behind this step's weights (issued two steps ago): step (c, 2)'s pieces and the window's eleven.
-        asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(3 + XP) : "memory");
         step(std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{}, pbuf, [&] { const int sf = slot == 0 ? C3_RBW - 1 : slot - 1; issue_w(min(3 * c + 3, nsteps - 1), sf); });
         slot = slot + 1 == C3_RBW ? 0 : slot + 1;
         // dy = 2.  This step's weights AND the window (both older than the three pieces of the step before) have landed.
@@ -177,23 +184,23 @@ __global__ __launch_bounds__(512) void k_conv3x3_h(C3Args A)
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           // (the last, unused copies)
 #pragma unroll
-    for (int rb = 0; rb < 4; rb++) acc[rb] += acl[rb] * 0x1p-11f;
+    for (int rb = 0; rb < RPW; rb++) acc[rb] += acl[rb] * 0x1p-11f;
     if (!(xmax < 65504.f) && A.range_flag) atomicOr(A.range_flag, 1u);     // (also a NaN)
 
     // ---- epilogue: register r of a lane = output channel 8 (r / 4) + 4 (lane >> 5) + (r & 3) of the row block, position lane & 31 of the wave's two rows
     const float* wsc = (const float*)((const char*)A.wp + (size_t)A.nchunk * 16 * 18 * A.Cout * 2);      // the inverse channel scales behind the planes (36 bytes per weight)
-    const int p = lane & 31, Y = Y0 + 2 * w + (p >> 4), X = X0 + (p & 15);
+    const int p = lane & 31, Y = Y0 + 2 * rp + (p >> 4), X = X0 + (p & 15);
     const bool inside = Y < A.H && X < A.W;
     float* yb = A.y + (size_t)n * A.Cout * hw + (size_t)Y * A.W + X;
 #pragma unroll
-    for (int rb = 0; rb < 4; rb++) {
+    for (int rb = 0; rb < RPW; rb++) {
         float bv[16], sv[16];                                              // (loads first: a load issued between stores waits for them)
 #pragma unroll
-        for (int r = 0; r < 16; r++) { const int co = m0 + 32 * rb + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3); bv[r] = A.bias ? A.bias[co] : 0.f; sv[r] = wsc[co]; }
+        for (int r = 0; r < 16; r++) { const int co = m0 + 32 * (rb0 + rb) + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3); bv[r] = A.bias ? A.bias[co] : 0.f; sv[r] = wsc[co]; }
         if (inside) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int co = m0 + 32 * rb + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                const int co = m0 + 32 * (rb0 + rb) + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
                 const float v = acc[rb][r] * sv[r] + bv[r];
                 yb[(size_t)co * hw] = fmaxf(v, v * A.slope);
             }
@@ -211,8 +218,17 @@ int vido_conv3x3_h_supported(int n, int cin, int cout, int h, int w)
            && 36ll * cin * cout < (1ll << 31);
 }
 
+/* The position block a launch uses: 16 rows x 16 columns when that gives at least C3_MIN16 workgroups (128 channels x a block each), else 8 x 16 — half the K loop's length per
+ * workgroup, twice the workgroups.  VIDO_CONV3X3_H_ROWS = 16 / 8 forces one. */
+#define C3_MIN16 190
+static int c3_block_rows(int n, int cout, int h, int w)
+{
+    static const int force = [] { const char* e = getenv("VIDO_CONV3X3_H_ROWS"); return e ? atoi(e) : 0; }();
+    if (force == 16 || force == 8) return force;
+    return n * ((h + 15) / 16) * ((w + 15) / 16) * (cout / 128) >= C3_MIN16 ? 16 : 8;
+}
 /* workgroups of a launch (the caller keeps the Winograd kernel for launches that would leave most of the chip idle) */
-int vido_conv3x3_h_workgroups(int n, int cout, int h, int w) { return n * ((h + 15) / 16) * ((w + 15) / 16) * (cout / 128); }
+int vido_conv3x3_h_workgroups(int n, int cout, int h, int w) { const int br = c3_block_rows(n, cout, h, w); return n * ((h + br - 1) / br) * ((w + 15) / 16) * (cout / 128); }
 
 /* y = leaky_relu(conv2d(x, w, stride 1, padding 1) + bias, slope): x [n][cin][h][w], y [n][cout][h][w] f32 DEVICE tensors (4-byte aligned, y != x), bias [cout] or NULL;
  * w_packed: the weight [cout][cin][3][3] as two fp16 planes of its output channels scaled by powers of two, plane p of element (co, ci, dy, dx) at
@@ -225,11 +241,17 @@ int vido_conv3x3_h_bias_act(vido_ctx* ctx, const float* x, const void* w_packed,
         return vido_set_error(ctx, VIDO_E_INVALID, "conv3x3_h: no kernel for %d x %d -> %d channels at %d x %d (or a pointer is misaligned, or slope outside [0, 1])", n, cin, cout, h, w);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
-    const int nby = (h + 15) / 16, nbx = (w + 15) / 16, mt = cout / 128, total = n * nby * nbx * mt;
+    const int br = c3_block_rows(n, cout, h, w);
+    const int nby = (h + br - 1) / br, nbx = (w + 15) / 16, mt = cout / 128, total = n * nby * nbx * mt;
     C3Args A{x, w_packed, bias, y, n, cin, cout, h, w, nby, nbx, mt, total, cin / 16, slope, (unsigned)(4ll * n * cin * h * w), (unsigned)(36ll * cin * cout), ctx->c1_range_flag};
     static bool attr[64] = {};
-    if (!attr[ctx->device & 63]) { HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_conv3x3_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C3_LDS)); attr[ctx->device & 63] = true; }
-    hipLaunchKernelGGL(k_conv3x3_h, dim3(8 * ((total + 7) / 8)), dim3(512), C3_LDS, st, A);
+    if (!attr[ctx->device & 63]) {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_conv3x3_h<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C3_LDS(4)));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_conv3x3_h<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C3_LDS(2)));
+        attr[ctx->device & 63] = true;
+    }
+    if (br == 16) hipLaunchKernelGGL(k_conv3x3_h<4>, dim3(8 * ((total + 7) / 8)), dim3(512), C3_LDS(4), st, A);
+    else hipLaunchKernelGGL(k_conv3x3_h<2>, dim3(8 * ((total + 7) / 8)), dim3(512), C3_LDS(2), st, A);
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }
