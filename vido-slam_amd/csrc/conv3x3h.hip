@@ -211,11 +211,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_h(C3Args A)
 
 extern "C" {
 
-/* 1 when vido_conv3x3_h_bias_act takes the shape: output channels a multiple of 128, input channels a multiple of 16, tensors below 1 GB. */
+/* 1 when vido_conv3x3_h_bias_act takes the shape: output channels a multiple of 128, tensors below 1 GB.  Input channels are padded to a multiple of 16 with ZERO WEIGHTS
+ * (pack_conv3x3_h): the last chunk's window reads past the image's channels — the next image's (finite) activations times zero, or, past the tensor, the zeros of an
+ * out-of-range copy. */
 int vido_conv3x3_h_supported(int n, int cin, int cout, int h, int w)
 {
-    return n >= 1 && cin >= 16 && cin % 16 == 0 && cout >= 128 && cout % 128 == 0 && h >= 1 && w >= 1 && 4ll * n * cin * h * w < (1ll << 30) && 4ll * n * cout * h * w < (1ll << 30)
-           && 36ll * cin * cout < (1ll << 31);
+    const long long cp = (cin + 15) / 16 * 16;
+    return n >= 1 && cin >= 1 && cout >= 128 && cout % 128 == 0 && h >= 1 && w >= 1 && 4ll * n * cin * h * w < (1ll << 30) && 4ll * n * cout * h * w < (1ll << 30)
+           && 36ll * cp * cout < (1ll << 31);
 }
 
 /* The position block a launch uses: 16 rows x 16 columns when that gives at least C3_MIN16 workgroups (128 channels x a block each), else 8 x 16 — half the K loop's length per
@@ -232,7 +235,8 @@ int vido_conv3x3_h_workgroups(int n, int cout, int h, int w) { const int br = c3
 
 /* y = leaky_relu(conv2d(x, w, stride 1, padding 1) + bias, slope): x [n][cin][h][w], y [n][cout][h][w] f32 DEVICE tensors (4-byte aligned, y != x), bias [cout] or NULL;
  * w_packed: the weight [cout][cin][3][3] as two fp16 planes of its output channels scaled by powers of two, plane p of element (co, ci, dy, dx) at
- * [co / 32][ci / 16][dy][dx][p][32 ((ci % 16) / 8) + co % 32][ci % 8], followed by [cout] floats: the inverse scales (vido_slam_amd/nets/ops.py::pack_conv3x3_h).
+ * [co / 32][ci / 16][dy][dx][p][32 ((ci % 16) / 8) + co % 32][ci % 8] (input channels padded to a multiple of 16 with zeros), followed by [cout] floats: the inverse scales
+ * (vido_slam_amd/nets/ops.py::pack_conv3x3_h).
  * slope: 0 = ReLU, 1 = none (0 <= slope <= 1).  Activations must stay below 65504 in magnitude (else: vido_conv1x1_range_flag).  Enqueues on the adopted stream; capturable. */
 int vido_conv3x3_h_bias_act(vido_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* y, int n, int cin, int cout, int h, int w, float slope)
 {
@@ -243,7 +247,8 @@ int vido_conv3x3_h_bias_act(vido_ctx* ctx, const float* x, const void* w_packed,
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
     const int br = c3_block_rows(n, cout, h, w);
     const int nby = (h + br - 1) / br, nbx = (w + 15) / 16, mt = cout / 128, total = n * nby * nbx * mt;
-    C3Args A{x, w_packed, bias, y, n, cin, cout, h, w, nby, nbx, mt, total, cin / 16, slope, (unsigned)(4ll * n * cin * h * w), (unsigned)(36ll * cin * cout), ctx->c1_range_flag};
+    const int nchunk = (cin + 15) / 16;
+    C3Args A{x, w_packed, bias, y, n, cin, cout, h, w, nby, nbx, mt, total, nchunk, slope, (unsigned)(4ll * n * cin * h * w), (unsigned)(36ll * 16 * nchunk * cout), ctx->c1_range_flag};
     static bool attr[64] = {};
     if (!attr[ctx->device & 63]) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_conv3x3_h<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C3_LDS(4)));

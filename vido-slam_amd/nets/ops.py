@@ -6,7 +6,7 @@ import os
 import torch
 
 _WINO_MIN_WGS = int(os.environ.get("VIDO_WINO_MIN_WGS", "0"))
-_CONV3X3_H_MIN_WGS = 0 if os.environ.get("VIDO_CONV3X3_H") == "0" else int(os.environ.get("VIDO_CONV3X3_H_MIN_WGS", "190"))      # direct split-fp16 3x3 (csrc/conv3x3h.hip) from this many workgroups on
+_CONV3X3_H_MIN_WGS = 0 if os.environ.get("VIDO_CONV3X3_H") == "0" else int(os.environ.get("VIDO_CONV3X3_H_MIN_WGS", "128"))      # direct split-fp16 3x3 (csrc/conv3x3h.hip) from this many workgroups on
 # which layers conv_direct_conv takes: "all", or "novalu" (default) = not the 7x7 stem / stride-2 3x3 layers, which the library runs as Winograd on the VECTOR ALUs — beside
 # the detector (whose convolutions saturate the MATRIX pipe) those run in its shadow, while the direct kernel competes for the matrix pipe.  Measured (two pairs of 100
 # steps, profiles/r5/convdirect_ab.txt): headline 90.3 frames/s without the direct kernel, 89.4 with it on every layer (LiteFlowNet alone 3.85 -> 3.65 ms), 90.6 with
@@ -290,7 +290,7 @@ class HipOps:
         if _WINO_MIN_WGS > 0 and not self.ctx.lib.vido_wino3x3_fills_chip(int(x.shape[0]), int(w.shape[0]), int(x.shape[2]), int(x.shape[3]), _WINO_MIN_WGS):
             return None
         # (round 6) chip-filling launches of >= 128-channel layers take the DIRECT kernel in split-fp16 arithmetic (csrc/conv3x3h.hip): 256 -> 256 on 200 x 272 in 216 us
-        # against the Winograd kernel's 325, the mask head's 100 x 14 x 14 in 97 against 156; below ~190 workgroups of 128 channels x 16 x 16 positions one workgroup's
+        # against the Winograd kernel's 325, the mask head's 100 x 14 x 14 in 97 against 156; below ~128 workgroups one workgroup's
         # K loop is the launch's time and Winograd (its K-split form) stays faster.  VIDO_CONV3X3_H=0 keeps Winograd everywhere; VIDO_CONV3X3_H_MIN_WGS moves the threshold.
         if (_CONV3X3_H_MIN_WGS > 0 and x.dtype == torch.float32 and self.ctx.lib.vido_conv3x3_h_supported(int(x.shape[0]), int(w.shape[1]), int(w.shape[0]), int(x.shape[2]), int(x.shape[3]))
                 and self.ctx.lib.vido_conv3x3_h_workgroups(int(x.shape[0]), int(w.shape[0]), int(x.shape[2]), int(x.shape[3])) >= _CONV3X3_H_MIN_WGS):
@@ -310,7 +310,7 @@ class HipOps:
         """leaky_relu(conv2d(x, w, stride 1, padding 1) + bias, slope) as one direct split-fp16 launch (csrc/conv3x3h.hip); w_packed = pack_conv3x3_h(w)."""
         assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
         N, cin, H, W = x.shape
-        assert w_packed.dtype == torch.int16 and w_packed.numel() == 2 * cout * (cin * 9 + 1), "conv3x3_h: weight not packed by pack_conv3x3_h for this layer"
+        assert w_packed.dtype == torch.int16 and w_packed.numel() == 2 * cout * ((cin + 15) // 16 * 16 * 9 + 1), "conv3x3_h: weight not packed by pack_conv3x3_h for this layer"
         out = torch.empty((N, cout, H, W), device=x.device, dtype=torch.float32)
         self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * N * cout * cin * 9 * H * W
         self._adopt_stream()
@@ -609,10 +609,13 @@ def pack_conv1x1(w, layout=0):
 def pack_conv3x3_h(w):
     """3x3 convolution weight [cout, cin, 3, 3] -> the operand order of csrc/conv3x3h.hip (the direct split-fp16 kernel): two fp16 planes of the output channels scaled by
     powers of two (split_f16x2 over a channel's cin x 9 weights), plane p of element (co, ci, dy, dx) at [co / 32][ci / 16][dy][dx][p][32 * ((ci % 16) / 8) + co % 32][ci % 8],
-    followed by the [cout] inverse scales (flat int16 tensor).  None when the kernel does not take the shape."""
-    cout, cin = int(w.shape[0]), int(w.shape[1])
-    if tuple(w.shape[2:]) != (3, 3) or cout % 128 or cin % 16:
+    followed by the [cout] inverse scales (flat int16 tensor); input channels are padded to a multiple of 16 with zero weights.  None when the kernel does not take the shape."""
+    cout, cin0 = int(w.shape[0]), int(w.shape[1])
+    if tuple(w.shape[2:]) != (3, 3) or cout % 128:
         return None
+    cin = (cin0 + 15) // 16 * 16                                              # input channels padded with zero weights
+    if cin != cin0:
+        w = torch.cat([w.detach(), torch.zeros(cout, cin - cin0, 3, 3, dtype=w.dtype, device=w.device)], 1)
     h, l, inv = split_f16x2(w.detach().reshape(cout, cin * 9))
     planes = torch.stack([h, l], 0).view(torch.int16).reshape(2, cout // 32, 32, cin // 16, 2, 8, 3, 3)        # [plane][mb][co32][chunk][k half][k8][dy][dx]
     planes = planes.permute(1, 3, 6, 7, 0, 4, 2, 5).contiguous().reshape(-1)                                 # [mb][chunk][dy][dx][plane][k half][co32][k8]
