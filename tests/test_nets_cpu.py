@@ -202,7 +202,7 @@ def test_pack_conv1x1_is_the_operand_order_of_the_kernel():
     from vido_slam_amd.nets.ops import split_f16x2
     w2 = w.reshape(256, 64).clone(); w2[7] = 0.0; w2[9] *= 1e-20; w2[11] *= 1e15
     h, l, inv = split_f16x2(w2)
-    assert torch.isfinite(h.float()).all() and torch.isfinite(l.float()).all() and float(h.float().abs().max()) < 32768.0
+    assert torch.isfinite(h.float()).all() and torch.isfinite(l.float()).all() and float(h.float().abs().max()) <= 32768.0      # (a maximum just under 2^15 may round up to it)
     rec = inv.double()[:, None] * (h.double() + l.double() / 2048.0)
     big = w2.abs() >= w2.abs().amax(1, keepdim=True) * 2.0 ** -26
     assert float(((rec - w2.double()).abs() / w2.abs().double().clamp_min(1e-300))[big].max()) <= 2.0 ** -22
