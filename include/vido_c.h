@@ -369,7 +369,7 @@ int vido_wino3x3_form(int n, int cin, int cout, int h, int w);
  * the detector's chip-filling 256 -> 256 layers (FPN outputs and RPN head on P2 / P3: backbone/fpn.py:55-66, rpn/rpn.py:74-107; the mask head: roi_mask_feature_extractors.py).
  * x [n][cin][h][w], y [n][cout][h][w] f32 DEVICE; w_packed: two fp16 planes of the output channels scaled by powers of two, plane p of element (co, ci, dy, dx) at
  * [co / 32][ci / 16][dy][dx][p][32 ((ci % 16) / 8) + co % 32][ci % 8], then [cout] floats: the inverse scales (vido_slam_amd/nets/ops.py::pack_conv3x3_h).
- * vido_conv3x3_h_supported: cout % 128 == 0, cin % 16 == 0, tensors below 1 GB.  Activations must stay below 65504 in magnitude (vido_conv1x1_range_flag otherwise). */
+ * vido_conv3x3_h_supported: cout 32, 64 or a multiple of 128 (input channels are padded to a multiple of 16 with zero weights), tensors below 1 GB.  Activations must stay below 65504 in magnitude (vido_conv1x1_range_flag otherwise). */
 int vido_conv3x3_h_supported(int n, int cin, int cout, int h, int w);
 int vido_conv3x3_h_workgroups(int n, int cout, int h, int w);
 int vido_conv3x3_h_bias_act(vido_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* y, int n, int cin, int cout, int h, int w, float slope);

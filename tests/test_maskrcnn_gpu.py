@@ -452,7 +452,8 @@ def test_direct_split_fp16_conv3x3_against_float64_and_the_winograd_kernel(vido,
     ops = HipOps(ctx)
     F = torch.nn.functional
     for N, cin, cout, H, W, slope, with_bias in ((1, 16, 128, 16, 16, 0.0, True), (2, 32, 128, 13, 21, 0.1, True), (3, 48, 256, 7, 35, 1.0, False), (1, 256, 256, 50, 68, 0.0, True),
-                                                 (5, 256, 256, 14, 14, 0.0, True), (1, 128, 128, 100, 136, 1.0, True), (1, 64, 384, 33, 17, 0.1, True), (2, 49, 128, 30, 40, 0.1, True), (3, 131, 128, 9, 20, 0.1, True)):
+                                                 (5, 256, 256, 14, 14, 0.0, True), (1, 128, 128, 100, 136, 1.0, True), (1, 64, 384, 33, 17, 0.1, True), (2, 49, 128, 30, 40, 0.1, True), (3, 131, 128, 9, 20, 0.1, True),
+                                                 (1, 128, 64, 40, 50, 0.1, True), (2, 64, 64, 17, 33, 0.1, True), (1, 64, 32, 50, 70, 0.1, True), (2, 32, 32, 9, 16, 1.0, False)):
         assert ops.ctx.lib.vido_conv3x3_h_supported(N, cin, cout, H, W)
         g = torch.Generator().manual_seed(cin + H)
         x = torch.randn(N, cin, H, W, generator=g); w = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5) * torch.exp(torch.randn(cout, 1, 1, 1, generator=g)); b = torch.randn(cout, generator=g) if with_bias else None
@@ -469,7 +470,7 @@ def test_direct_split_fp16_conv3x3_against_float64_and_the_winograd_kernel(vido,
         assert eh <= 1.5 * ew and eh < 1e-6, (N, cin, cout, H, W, eh, ew)
     torch.cuda.synchronize()
     assert ops.conv1x1_range_flag() == 0
-    assert ops.ctx.lib.vido_conv3x3_h_supported(1, 24, 128, 16, 16) and not ops.ctx.lib.vido_conv3x3_h_supported(1, 32, 64, 16, 16)
+    assert ops.ctx.lib.vido_conv3x3_h_supported(1, 24, 128, 16, 16) and ops.ctx.lib.vido_conv3x3_h_supported(1, 32, 64, 16, 16) and not ops.ctx.lib.vido_conv3x3_h_supported(1, 32, 96, 16, 16)
     xb = torch.randn(1, 16, 16, 16); xb[0, 3, 5, 5] = 1e5
     ops.conv3x3_h_bias_act(xb.cuda(), pack_conv3x3_h(torch.randn(128, 16, 3, 3)).cuda(), None, 128, 1.0); torch.cuda.synchronize()
     assert ops.conv1x1_range_flag() == 1

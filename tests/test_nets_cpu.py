@@ -238,7 +238,7 @@ def test_pack_conv3x3_h_is_the_operand_order_of_the_direct_kernel():
     assert torch.equal(p[2 * cout * cin * 9:].view(torch.float32), inv)
     rec = inv.double()[:, None] * (h.view(torch.float16).reshape(cout, -1).double() + l.view(torch.float16).reshape(cout, -1).double() / 2048.0)
     assert float(((rec - w.reshape(cout, -1).double()).abs() / w.reshape(cout, -1).abs().amax(1, keepdim=True).double()).max()) <= 2.0 ** -22
-    assert pack_conv3x3_h(torch.zeros(64, 32, 3, 3)) is None and pack_conv3x3_h(torch.zeros(128, 32, 1, 1)) is None
+    assert pack_conv3x3_h(torch.zeros(96, 32, 3, 3)) is None and pack_conv3x3_h(torch.zeros(128, 32, 1, 1)) is None and tuple(pack_conv3x3_h(torch.zeros(64, 32, 3, 3)).shape) == (2 * 64 * (32 * 9 + 1),)
     p24 = pack_conv3x3_h(torch.ones(128, 24, 3, 3))                           # 24 input channels: padded to 32 with zero weights
     assert tuple(p24.shape) == (2 * 128 * (32 * 9 + 1),) and int((p24[:2 * 128 * 32 * 9].reshape(4, 2, 3, 3, 2, 64, 8)[:, 1, :, :, :, 32:, :] != 0).sum()) == 0
 

@@ -6,7 +6,7 @@ import torch.nn.functional as F
 import vido_slam_amd as V
 from vido_slam_amd.nets.ops import HipOps, pack_conv3x3_h, pack_wino3x3
 ctx = V.Context(width=640, height=480, max_batch=1); ops = HipOps(ctx)
-shapes = [(1, 16, 128, 16, 16, "one block"), (2, 32, 128, 13, 21, "small, odd sizes"), (1, 256, 256, 50, 68, "P4"), (100, 256, 256, 14, 14, "mask head"), (1, 256, 256, 100, 136, "P3"), (1, 256, 256, 200, 272, "FPN / RPN at P2")]
+shapes = [(1, 128, 64, 120, 160, "LFN 128->64 level 2"), (1, 64, 64, 120, 160, "LFN 64->64 level 2"), (1, 64, 32, 120, 160, "LFN 64->32 level 2"), (2, 32, 32, 240, 320, "32->32 level 1 x2"), (1, 130, 128, 120, 160, "LFN 130->128 level 2"), (1, 16, 128, 16, 16, "one block"), (2, 32, 128, 13, 21, "small, odd sizes"), (1, 256, 256, 50, 68, "P4"), (100, 256, 256, 14, 14, "mask head"), (1, 256, 256, 100, 136, "P3"), (1, 256, 256, 200, 272, "FPN / RPN at P2")]
 if len(sys.argv) > 1: shapes = shapes[:int(sys.argv[1])]
 def timed(fn, reps=30):
     fn(); fn(); torch.cuda.synchronize()

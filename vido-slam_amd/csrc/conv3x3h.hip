@@ -33,29 +33,32 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define C3_OOB 0x40000000u
 #define C3_WSLOT 24576                   // one step of weights: 4 row blocks x 3 taps x 2 planes x 1 KB
 #define C3_RBW 3                         // ring slots
-// per form (RPW = row blocks of 32 channels a wave owns: 4 = the 16 x 16 position block above; 2 = an 8 x 16 block, wave = 64 channels x two rows — half the K loop's length
-// per workgroup for launches that would not fill the chip with the larger block)
-#define C3_WPIX(RPW) ((4 * (RPW) + 2) * 18)                      // pixels of the window
-#define C3_XP(RPW) ((16 * C3_WPIX(RPW) + 511) / 512)             // window pieces per wave: 11 / 6
-#define C3_RAW(RPW) (C3_XP(RPW) * 8 * 256)                       // the fp32 window, padded to whole pieces per wave
-#define C3_PLANE(RPW) (C3_WPIX(RPW) * 32)                        // one fp16 plane of the window: pixels x 16 channels x 2 bytes
-#define C3_PBUF(RPW) (2 * C3_PLANE(RPW))
-#define C3_LDS(RPW) (C3_RBW * C3_WSLOT + C3_RAW(RPW) + 2 * C3_PBUF(RPW))
+// Forms <RPW, CG>: the eight waves are CG channel groups x 8 / CG row pairs; a wave owns RPW row blocks of 32 channels x two rows of positions.  Channels per workgroup
+// 32 RPW CG, block rows BR = 16 / CG:
+//   <4, 1> 128 channels x 16 x 16 positions (the form above);   <2, 2> 128 channels x 8 x 16: half the K loop's length per workgroup for launches that would not fill the
+//   chip with the larger block;   <2, 1> 64 channels x 16 x 16 and <1, 2> 64 channels x 8 x 16 for 64-channel layers;   <1, 1> 32 channels x 16 x 16 for 32-channel layers.
+// (The weight ring always holds four row blocks per step: the blocks past the layer's channels are out-of-range copies — zeros, no traffic.)
+#define C3_WPIX(BR) (((BR) + 2) * 18)                            // pixels of the window
+#define C3_XP(BR) ((16 * C3_WPIX(BR) + 511) / 512)               // window pieces per wave: 11 / 6
+#define C3_RAW(BR) (C3_XP(BR) * 8 * 256)                         // the fp32 window, padded to whole pieces per wave
+#define C3_PLANE(BR) (C3_WPIX(BR) * 32)                          // one fp16 plane of the window: pixels x 16 channels x 2 bytes
+#define C3_PBUF(BR) (2 * C3_PLANE(BR))
+#define C3_LDS(BR) (C3_RBW * C3_WSLOT + C3_RAW(BR) + 2 * C3_PBUF(BR))
 
 struct C3Args { const float* x; const void* wp; const float* bias; float* y; int N, Cin, Cout, H, W, nby, nbx, mt, total, nchunk; float slope; unsigned xbytes, wbytes; unsigned* range_flag; };
 
-template <int RPW>
+template <int RPW, int CG>
 __global__ __launch_bounds__(512) void k_conv3x3_h(C3Args A)
 {
-    constexpr int BR = 4 * RPW, WPIX = C3_WPIX(RPW), XP = C3_XP(RPW), RAWB = C3_RAW(RPW), PLANE = C3_PLANE(RPW), PBUF = C3_PBUF(RPW), CK = (WPIX * 8 + 511) / 512, NMM = 9 * RPW, NRD = 2 * RPW + 2;
+    constexpr int BR = 16 / CG, MT = 32 * RPW * CG, WPIX = C3_WPIX(BR), XP = C3_XP(BR), RAWB = C3_RAW(BR), PLANE = C3_PLANE(BR), PBUF = C3_PBUF(BR), CK = (WPIX * 8 + 511) / 512, NMM = 9 * RPW, NRD = 2 * RPW + 2;
     extern __shared__ __attribute__((aligned(16))) char c3_lds[];
     char* L = c3_lds;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int per = gridDim.x >> 3, item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // an XCD walks a contiguous range of items, the channel block fastest
     if (item >= A.total) return;
-    const int nt = item / A.mt, mtile = item - nt * A.mt, m0 = mtile * 128;
+    const int nt = item / A.mt, mtile = item - nt * A.mt, m0 = mtile * MT;
     const int bpi = A.nby * A.nbx, n = nt / bpi, brem = nt - n * bpi, by = brem / A.nbx, bx = brem - by * A.nbx, Y0 = by * BR, X0 = bx * 16;
-    const int rp = RPW == 4 ? w : (w & 3), rb0 = RPW == 4 ? 0 : 2 * (w >> 2);      // the wave's row pair of the block, its first row block of 32 channels
+    const int rp = CG == 1 ? w : (w & 3), rb0 = CG == 1 ? 0 : RPW * (w >> 2);      // the wave's row pair of the block, its first row block of 32 channels
     const int hw = A.H * A.W, nsteps = A.nchunk * 3;
 
     // ---- copies.  Weights: piece i = w + 8 q (q = 0 .. 2) of a step = (row block i / 6, tap-and-plane i % 6); everything but the step rides in abase.
@@ -211,27 +214,29 @@ __global__ __launch_bounds__(512) void k_conv3x3_h(C3Args A)
 
 extern "C" {
 
-/* 1 when vido_conv3x3_h_bias_act takes the shape: output channels a multiple of 128, tensors below 1 GB.  Input channels are padded to a multiple of 16 with ZERO WEIGHTS
- * (pack_conv3x3_h): the last chunk's window reads past the image's channels — the next image's (finite) activations times zero, or, past the tensor, the zeros of an
+/* 1 when vido_conv3x3_h_bias_act takes the shape: output channels 32, 64 or a multiple of 128, tensors below 1 GB.  Input channels are padded to a multiple of 16 with ZERO
+ * WEIGHTS (pack_conv3x3_h): the last chunk's window reads past the image's channels — the next image's (finite) activations times zero, or, past the tensor, the zeros of an
  * out-of-range copy. */
 int vido_conv3x3_h_supported(int n, int cin, int cout, int h, int w)
 {
     const long long cp = (cin + 15) / 16 * 16;
-    return n >= 1 && cin >= 1 && cout >= 128 && cout % 128 == 0 && h >= 1 && w >= 1 && 4ll * n * cin * h * w < (1ll << 30) && 4ll * n * cout * h * w < (1ll << 30)
+    return n >= 1 && cin >= 1 && (cout == 32 || cout == 64 || (cout >= 128 && cout % 128 == 0)) && h >= 1 && w >= 1 && 4ll * n * cin * h * w < (1ll << 30) && 4ll * n * cout * h * w < (1ll << 30)
            && 36ll * cp * cout < (1ll << 31);
 }
 
-/* The position block a launch uses: 16 rows x 16 columns when that gives at least C3_MIN16 workgroups (128 channels x a block each), else 8 x 16 — half the K loop's length per
- * workgroup, twice the workgroups.  VIDO_CONV3X3_H_ROWS = 16 / 8 forces one. */
+/* The form a launch uses: channels per workgroup = min(cout, 128); position block 16 rows x 16 columns when that gives at least C3_MIN16 workgroups, else (128- and 64-channel
+ * layers) 8 x 16 — half the K loop's length per workgroup, twice the workgroups.  VIDO_CONV3X3_H_ROWS = 16 / 8 forces one. */
 #define C3_MIN16 190
 static int c3_block_rows(int n, int cout, int h, int w)
 {
     static const int force = [] { const char* e = getenv("VIDO_CONV3X3_H_ROWS"); return e ? atoi(e) : 0; }();
+    if (cout == 32) return 16;
     if (force == 16 || force == 8) return force;
-    return n * ((h + 15) / 16) * ((w + 15) / 16) * (cout / 128) >= C3_MIN16 ? 16 : 8;
+    const int mt = cout >= 128 ? cout / 128 : 1;
+    return n * ((h + 15) / 16) * ((w + 15) / 16) * mt >= C3_MIN16 ? 16 : 8;
 }
 /* workgroups of a launch (the caller keeps the Winograd kernel for launches that would leave most of the chip idle) */
-int vido_conv3x3_h_workgroups(int n, int cout, int h, int w) { const int br = c3_block_rows(n, cout, h, w); return n * ((h + br - 1) / br) * ((w + 15) / 16) * (cout / 128); }
+int vido_conv3x3_h_workgroups(int n, int cout, int h, int w) { const int br = c3_block_rows(n, cout, h, w); return n * ((h + br - 1) / br) * ((w + 15) / 16) * (cout >= 128 ? cout / 128 : 1); }
 
 /* y = leaky_relu(conv2d(x, w, stride 1, padding 1) + bias, slope): x [n][cin][h][w], y [n][cout][h][w] f32 DEVICE tensors (4-byte aligned, y != x), bias [cout] or NULL;
  * w_packed: the weight [cout][cin][3][3] as two fp16 planes of its output channels scaled by powers of two, plane p of element (co, ci, dy, dx) at
@@ -246,17 +251,22 @@ int vido_conv3x3_h_bias_act(vido_ctx* ctx, const float* x, const void* w_packed,
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
     const int br = c3_block_rows(n, cout, h, w);
-    const int nby = (h + br - 1) / br, nbx = (w + 15) / 16, mt = cout / 128, total = n * nby * nbx * mt;
+    const int nby = (h + br - 1) / br, nbx = (w + 15) / 16, mt = cout >= 128 ? cout / 128 : 1, total = n * nby * nbx * mt;
     const int nchunk = (cin + 15) / 16;
     C3Args A{x, w_packed, bias, y, n, cin, cout, h, w, nby, nbx, mt, total, nchunk, slope, (unsigned)(4ll * n * cin * h * w), (unsigned)(36ll * 16 * nchunk * cout), ctx->c1_range_flag};
     static bool attr[64] = {};
     if (!attr[ctx->device & 63]) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_conv3x3_h<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C3_LDS(4)));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_conv3x3_h<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C3_LDS(2)));
+#define C3_ATTR(RPW_, CG_) HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_conv3x3_h<RPW_, CG_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C3_LDS(16 / CG_)))
+        C3_ATTR(4, 1); C3_ATTR(2, 2); C3_ATTR(2, 1); C3_ATTR(1, 2); C3_ATTR(1, 1);
+#undef C3_ATTR
         attr[ctx->device & 63] = true;
     }
-    if (br == 16) hipLaunchKernelGGL(k_conv3x3_h<4>, dim3(8 * ((total + 7) / 8)), dim3(512), C3_LDS(4), st, A);
-    else hipLaunchKernelGGL(k_conv3x3_h<2>, dim3(8 * ((total + 7) / 8)), dim3(512), C3_LDS(2), st, A);
+    const dim3 grid(8 * ((total + 7) / 8));
+#define C3_LAUNCH(RPW_, CG_) hipLaunchKernelGGL((k_conv3x3_h<RPW_, CG_>), grid, dim3(512), C3_LDS(16 / CG_), st, A)
+    if (cout >= 128) { if (br == 16) C3_LAUNCH(4, 1); else C3_LAUNCH(2, 2); }
+    else if (cout == 64) { if (br == 16) C3_LAUNCH(2, 1); else C3_LAUNCH(1, 2); }
+    else C3_LAUNCH(1, 1);
+#undef C3_LAUNCH
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }

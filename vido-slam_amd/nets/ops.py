@@ -611,7 +611,7 @@ def pack_conv3x3_h(w):
     powers of two (split_f16x2 over a channel's cin x 9 weights), plane p of element (co, ci, dy, dx) at [co / 32][ci / 16][dy][dx][p][32 * ((ci % 16) / 8) + co % 32][ci % 8],
     followed by the [cout] inverse scales (flat int16 tensor); input channels are padded to a multiple of 16 with zero weights.  None when the kernel does not take the shape."""
     cout, cin0 = int(w.shape[0]), int(w.shape[1])
-    if tuple(w.shape[2:]) != (3, 3) or cout % 128:
+    if tuple(w.shape[2:]) != (3, 3) or not (cout in (32, 64) or (cout >= 128 and cout % 128 == 0)):
         return None
     cin = (cin0 + 15) // 16 * 16                                              # input channels padded with zero weights
     if cin != cin0:
