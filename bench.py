@@ -30,6 +30,7 @@ Extra objects on the same JSON line:
   roofline_ba    k_ba_linearize at configs[3] (local window) and configs[4] (1 M edges) size: 288 B per edge
   roofline_nets  fp32 FLOP/s of each network node vs the 157.3 TFLOP/s fp32 matrix/vector peak
   roofline_gconv the detector's grouped 3x3 convolution kernel (csrc/gconv.hip) vs the same peak
+  roofline_conv3x3 the direct split-fp16 3x3 kernel at the FPN / RPN P2 shape (and the Winograd kernel's time beside it)
   roofline_conv1x1 the split 1x1 GEMM at the detector's layer3 shape: fp32-equivalent TFLOP/s against 2500 / 3 (three fp16 products per multiply-add; / 6 for the bf16 form)
   cpu_baseline   BASELINE.md section 3: the SLAM stages (ORB / lists / pose optimisers / local BA, the C oracle) on ONE pinned core, median and p95 over 50 frames = `value`;
                  the three networks on torch-CPU on all cores as a separate part
@@ -339,7 +340,7 @@ def main():
                    "frames_per_step": 1, "pipelined": not args.no_pipeline, "tracker_feed": args.feed,
                    "net_arith": ("fp32 instructions throughout" if os.environ.get("VIDO_CONV1X1_ARITH") == "f32" or os.environ.get("VIDO_NO_CONV1X1") or (os.environ.get("VIDO_CONV1X1_TN") and not os.environ.get("VIDO_CONV1X1_ARITH"))
                                  else "bf16x3-split, 6 products, fp32 accumulate (1x1 convolutions of the detector: csrc/conv1x1.hip::k_conv1x1_b3<NP 3>; every other layer on the fp32 matrix / vector instructions)" if os.environ.get("VIDO_CONV1X1_ARITH") in ("bf16x3", "bf16")
-                                 else "f16x2-split (per-channel power-of-two weight scales, low planes x 2^11), 3 products, fp32 accumulate (1x1 convolutions of the detector: csrc/conv1x1.hip::k_conv1x1_b3<NP 2>; every other layer on the fp32 matrix / vector instructions)"),
+                                 else "f16x2-split (per-channel power-of-two weight scales, low planes x 2^11), 3 products, fp32 accumulate (1x1 convolutions of the detector: csrc/conv1x1.hip::k_conv1x1_b3<NP 2>; dense 3x3 layers on launches of >= 128 workgroups: csrc/conv3x3h.hip, the same arithmetic; every other layer on the fp32 matrix / vector instructions)"),
                    "handover": args.handover,
                    "tracker_feed_note": "networks run at full cost and their outputs are parked in the hand-over ring; with random-init weights those maps carry no geometry, so the tracker is "
                                         "handed the renderer's exact flow/depth/mask of the same frame (feed=given; uploaded next to the BGR frame) once the networks of that frame have completed",
@@ -553,6 +554,30 @@ def main():
                                                  "the fp32 matrix instruction's own peak is 157.3"}
           except Exception as e:
               out["roofline_conv1x1_error"] = "%s: %s" % (type(e).__name__, e)
+          # the dense 3x3 layers: the direct split-fp16 kernel (csrc/conv3x3h.hip) and, beside it, the fp32 Winograd kernel it replaced on these launches
+          try:
+              from vido_slam_amd.nets.ops import HipOps, pack_conv3x3_h, pack_wino3x3
+              cops3 = HipOps(ctx); r3 = {}
+              for n3, cin, cout, ch, cw, nm in ((1, 256, 256, 200, 272, "fpn_rpn_p2"), (100, 256, 256, 14, 14, "mask_head"), (1, 256, 256, 100, 136, "fpn_rpn_p3"), (1, 128, 64, 120, 160, "liteflownet_128_to_64_level2")):
+                  cx = torch.randn(n3, cin, ch, cw, device="cuda"); cwt = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5); cb = torch.randn(cout, device="cuda")
+                  wp3 = pack_conv3x3_h(cwt).cuda(); form = cops3.wino3x3_form(n3, cin, cout, ch, cw); u3 = pack_wino3x3(cwt, form).cuda()
+                  def _t(fn, reps=30):
+                      for _ in range(3): fn()
+                      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                      e0.record()
+                      for _ in range(reps): fn()
+                      e1.record(); torch.cuda.synchronize()
+                      return e0.elapsed_time(e1) * 1e3 / reps
+                  us_h = _t(lambda: cops3.conv3x3_h_bias_act(cx, wp3, cb, cout, 0.0)); us_w = _t(lambda: cops3.wino3x3_bias_act(cx, u3, cb, cout, 0.0, form))
+                  fl = 2.0 * n3 * cin * cout * 9 * ch * cw
+                  r3["%s_%dx%d_to_%d_at_%dx%d" % (nm, n3, cin, cout, ch, cw)] = {"us_per_launch": round(us_h, 1), "fp32_equivalent_tflops": round(fl / us_h / 1e6, 1), "winograd_fp32_us": round(us_w, 1),
+                                                                            "workgroups": int(cops3.ctx.lib.vido_conv3x3_h_workgroups(n3, cout, ch, cw))}
+              m3 = r3["fpn_rpn_p2_1x256_to_256_at_200x272"]
+              out["roofline_conv3x3"] = {"kernel": "k_conv3x3_h (direct 3x3 convolution + bias + ReLU; two fp16 planes per fp32 operand, three products on v_mfma_f32_32x32x16_f16, fp32 accumulate)",
+                                         "bound": "mfma", "achieved": m3["fp32_equivalent_tflops"], "peak": round(2500.0 / 3, 1), "unit": "TFLOP/s", "frac": round(m3["fp32_equivalent_tflops"] / (2500.0 / 3), 4), "traffic": None,
+                                         "shapes": r3, "note": "direct-convolution FLOPs (2 x 9 cin cout N H W) / HIP-event time of 30 back-to-back launches; peak = 2500 TFLOP/s dense fp16 / 3 products"}
+          except Exception as e:
+              out["roofline_conv3x3_error"] = "%s: %s" % (type(e).__name__, e)
           # configs[3] (static graph): 20 KF x 2k landmarks
           pr = P.synth_ba_problem(n_cam=20, n_pt=2000, kind="local", seed=7)
           V.ba_optimize(ctx, pr)
