@@ -431,6 +431,9 @@ __global__ __launch_bounds__(256 * G, (G == 1 && RB != 6) ? 2 : G) void k_conv1x
 #pragma unroll
                     for (int rb = 0; rb < 4; rb++) {
                         f32x16& d = term == 2 ? acc[rb] : acl[rb];
+#ifdef B3_NOMFMA                  // (timing experiment: the operand stream and the barriers alone; one matrix instruction per step keeps the operands alive)
+                        if (term != 2 || rb != 0) continue;
+#endif
                         d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[h][rb][PA[term]]), __builtin_bit_cast(f16x8, bp[h][PB[term]]), d, 0, 0, 0);
                     }
                 }
