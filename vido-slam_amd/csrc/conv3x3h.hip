@@ -37,7 +37,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // 32 RPW CG, block rows BR = 16 / CG:
 //   <4, 1> 128 channels x 16 x 16 positions (the form above);   <2, 2> 128 channels x 8 x 16: half the K loop's length per workgroup for launches that would not fill the
 //   chip with the larger block;   <2, 1> 64 channels x 16 x 16 and <1, 2> 64 channels x 8 x 16 for 64-channel layers;   <1, 1> 32 channels x 16 x 16 for 32-channel layers.
-// (The weight ring always holds four row blocks per step: the blocks past the layer's channels are out-of-range copies — zeros, no traffic.)
+// (The weight ring always holds four row blocks per step: the blocks a form does not own are out-of-range copies — zeros, no traffic.)
 #define C3_WPIX(BR) (((BR) + 2) * 18)                            // pixels of the window
 #define C3_XP(BR) ((16 * C3_WPIX(BR) + 511) / 512)               // window pieces per wave: 11 / 6
 #define C3_RAW(BR) (C3_XP(BR) * 8 * 256)                         // the fp32 window, padded to whole pieces per wave
@@ -63,11 +63,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_h(C3Args A)
 
     // ---- copies.  Weights: piece i = w + 8 q (q = 0 .. 2) of a step = (row block i / 6, tap-and-plane i % 6); everything but the step rides in abase.
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)A.wp, 0, A.wbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.x, 0, A.xbytes, 0x00020000);
     const unsigned avo = 16u * (unsigned)lane;
-    unsigned abase[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) { const int i = w + 8 * q, rb = i / 6, rem = i - 6 * rb; abase[q] = 1024u * (unsigned)(((m0 >> 5) + rb) * A.nchunk * 18 + rem); }
+    unsigned abase[3], avq[3];                                             // (a row block the form does not own — 64- / 32-channel layers — is copied from a per-lane offset past the
+#pragma unroll                                                             //  descriptor's range: zeros, no read behind the weight tensor; the range check looks at the per-lane offset only)
+    for (int q = 0; q < 3; q++) { const int i = w + 8 * q, rb = i / 6, rem = i - 6 * rb; abase[q] = 1024u * (unsigned)(((m0 >> 5) + rb) * A.nchunk * 18 + rem); avq[q] = rb < RPW * CG ? avo : 0x80000000u; }
     // Window: piece 8 j + w (j = 0 .. XP - 1) holds elements e = 64 (8 j + w) + lane of [16 channels][BR + 2 rows][18 columns]
     unsigned xvo[11];                                                      // (fixed bound: see csrc/conv1x1.hip on arrays of template-dependent size captured by lambdas)
 #pragma unroll
@@ -82,12 +81,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_h(C3Args A)
         char* S = L + slot * C3_WSLOT + w * 1024;
         const unsigned so = 6144u * (unsigned)s;
 #pragma unroll
-        for (int q = 0; q < 3; q++) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(S + q * 8192), 16, avo, abase[q] + so, 0, 0);
+        for (int q = 0; q < 3; q++) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(S + q * 8192), 16, avq[q], abase[q] + so, 0, 0);
     };
     auto issue_x = [&](int c) {                                            // this wave's XP pieces of chunk c's window
+        // The chunk rides in the DESCRIPTOR (base = first channel of the chunk, num_records = the bytes of the tensor behind it), not in the scalar offset: the hardware's
+        // range check looks at the per-lane offset alone, and the channels a last chunk reads past Cin (their weights are zero) must not leave the tensor behind the last image.
         const unsigned so = ximg + xchunk * (unsigned)c;
+        const __amdgpu_buffer_rsrc_t xc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)A.x + so), 0, A.xbytes - so, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < XP; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(RAW + (8 * j + w) * 256), 4, xvo[j], so, 0, 0);
+        for (int j = 0; j < XP; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(xc, (__attribute__((address_space(3))) void*)(RAW + (8 * j + w) * 256), 4, xvo[j], 0, 0, 0);
     };
     // ---- the window's two fp16 planes: item idx = tid + 512 k -> channel pair idx / WPIX, pixel idx % WPIX
     float xmax = 0.f;
