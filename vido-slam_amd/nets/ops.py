@@ -293,7 +293,8 @@ class HipOps:
         # against the Winograd kernel's 325, the mask head's 100 x 14 x 14 in 97 against 156; below ~128 workgroups one workgroup's
         # K loop is the launch's time and Winograd (its K-split form) stays faster.  VIDO_CONV3X3_H=0 keeps Winograd everywhere; VIDO_CONV3X3_H_MIN_WGS moves the threshold.
         if (_CONV3X3_H_MIN_WGS > 0 and x.dtype == torch.float32 and self.ctx.lib.vido_conv3x3_h_supported(int(x.shape[0]), int(w.shape[1]), int(w.shape[0]), int(x.shape[2]), int(x.shape[3]))
-                and self.ctx.lib.vido_conv3x3_h_workgroups(int(x.shape[0]), int(w.shape[0]), int(x.shape[2]), int(x.shape[3])) >= _CONV3X3_H_MIN_WGS):
+                and self.ctx.lib.vido_conv3x3_h_workgroups(int(x.shape[0]), int(w.shape[0]), int(x.shape[2]), int(x.shape[3])) >= (1 if int(w.shape[0]) == 64 else _CONV3X3_H_MIN_WGS)):
+            # (64-channel layers: the direct kernel wins at every size — 128 -> 64 on 30 x 40: 18 us against the K-split Winograd form's 26; profiles/r6/conv3x3_h_direct.txt)
             key = (w.data_ptr(), w._version, str(x.device))
             if getattr(conv, "_c3h_key", None) != key:
                 conv._c3h_w = pack_conv3x3_h(w).to(x.device); conv._c3h_key = key
