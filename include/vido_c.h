@@ -123,9 +123,12 @@ typedef struct vido_frame_lists {
 } vido_frame_lists;
 
 int vido_track_slots(vido_ctx* ctx);
+/* diagnosis only (VIDO_DIAG_FIRSTOP=n in the facade): n rounds of a trivial stream operation + host wait on the context's stream, timed; means printed at exit */
+int vido_debug_first_op(vido_ctx* ctx, int rounds);
 /* Tracking::GrabImageRGBD depth pre-scale (Tracking.cc:299-322): copies the maps of n_frames frames into
  * slots [slot0, slot0+n_frames), rescales depth on the device and writes the rescaled depth back into the
- * caller's `depth` buffer (the reference mutates it in place).  on_device: the three pointers are device pointers. */
+ * caller's `depth` buffer (the reference mutates it in place).  on_device: 1 = the three pointers are device pointers; 2 = device pointers that the slots ADOPT (zero-copy: no
+ * copy in either direction, depth rescaled in place; the caller keeps a frame's maps alive and untouched while its slot is in use — the current and the previous frame). */
 int vido_frame_upload(vido_ctx* ctx, int slot0, int n_frames, float* depth, const float* flow, const int32_t* mask,
                       int on_device, const vido_track_params* p);
 /* Frame::Frame RGB-D ctor lists (Frame.cc:72-100, 165-177, 184-211) for the frames in the slots, from the
@@ -546,6 +549,9 @@ int         vido_system_track_rgbd(vido_system* sys, const uint8_t* im, int chan
 /* The same with the image (u8, 1 / 3 / 4 interleaved channels) and the three maps already RESIDENT ON THE DEVICE (plain device pointers; depth is rescaled in place on the
  * device): the in-process replacement of the reference's three service round trips (src/realtime_demo/src/run_vido.cc:57-171 -> :229-235).  Nothing is uploaded, no map is
  * downloaded; ready_event (hipEvent_t, may be NULL) orders the tracker's stream behind the producer of the buffers. */
+/* zero_copy != 0: vido_system_track_rgbd_device ADOPTS the three map buffers instead of copying them into the tracker's slots (vido_frame_upload on_device = 2): the caller
+ * keeps the maps of a frame alive and untouched until the call AFTER the next one has returned (a ring of >= 3 frames; pipeline.EndToEnd's has 4).  Default 0. */
+int         vido_system_set_zero_copy_maps(vido_system* sys, int zero_copy);
 int         vido_system_track_rgbd_device(vido_system* sys, const void* im_dev, int channels, int width, int height, float* depth_dev, const float* flow_dev,
                                           const int32_t* mask_dev, void* ready_event, double timestamp, int n_image, float Tcw_out[16]);
 int         vido_system_get_stats(const vido_system* sys, vido_system_stats* out);

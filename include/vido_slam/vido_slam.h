@@ -214,6 +214,7 @@ private:
 };
 
 namespace detail {
+void SetZeroCopyMaps(bool on);                        /* TrackRGBDDevice adopts the caller's map buffers instead of copying them (the caller keeps a frame's maps alive for two more calls) */
 void SetDepthNoiseSeed(unsigned seed);                 /* addnoise = 1 draws: seed != 0 pins cv::RNG's seed (tests, reproducible runs); 0 = (unsigned)time(NULL) as the reference (Frame.cc:711) */
 float LastFrameStageMs(int which);                     /* wall time inside the last Frame constructor: 0 = extractor call, 1 = static / object lists */
 void ResidentCheckStats(int* checks, int* mismatches);  /* VIDO_BA_RESIDENT_CHECK=1: windows solved both ways (device-resident window / Map walk) and how many disagreed */

@@ -24,6 +24,8 @@ namespace VIDO_SLAM {
 namespace detail {
 static vido_ctx* g_ctx = nullptr;
 static int g_slot = 0;                 // device slot holding the maps of the frame under construction
+static bool g_zero_copy_maps = false;  // GrabImageRGBDDevice: the slots adopt the caller's device buffers (vido_system_set_zero_copy_maps)
+void SetZeroCopyMaps(bool on) { g_zero_copy_maps = on; }
 static vido_track_params g_tp;
 vido_ctx* Context() { return g_ctx; }
 // The local window (PartialBatchOptimization) has a context of its own — own stream, own resident ring, own scratch — so that the window solve of frame k can run on a helper
@@ -915,7 +917,7 @@ cv::Mat Tracking::GrabImageRGBDDevice(const void* im_dev, int channels, int widt
     g_tp.dataset = mTestData == OMD ? 0 : (mTestData == KITTI ? 1 : 2); g_tp.depth_map_factor = mDepthMapFactor; g_tp.bf = mbf; g_tp.kaist_scale = mScale;
     g_tp.th_depth_bg = mThDepth; g_tp.th_depth_obj = mThDepthObj; g_tp.dense_step = 4; g_tp.fx = mK.at<float>(0, 0); g_tp.fy = mK.at<float>(1, 1); g_tp.cx = mK.at<float>(0, 2); g_tp.cy = mK.at<float>(1, 2);
     slot_cur_ = (mState == NO_IMAGES_YET) ? 0 : 1 - slot_cur_; g_slot = slot_cur_;
-    check(vido_frame_upload(c, slot_cur_, 1, depth_dev, flow_dev, (const int32_t*)mask_dev, 1, &g_tp), "frame_upload");      // device -> slot (no PCIe), depth pre-scale in place
+    check(vido_frame_upload(c, slot_cur_, 1, depth_dev, flow_dev, (const int32_t*)mask_dev, detail::g_zero_copy_maps ? 2 : 1, &g_tp), "frame_upload");      // device -> slot (no PCIe), or the slot adopts the buffers; depth pre-scale in place
     mImGray = cv::Mat(height, width, CV_8UC1);                  // size carrier: the pixels stay on the device (ORBextractor::SetDeviceSource)
     mpORBextractorLeft->SetDeviceSource(im_dev, channels, mbRGB);
     mDepthMap = cv::Mat(); mFlowMap = cv::Mat(); mSegMap = cv::Mat();
@@ -931,6 +933,10 @@ cv::Mat Tracking::GrabCommon(const double& timestamp, const int& nImage, void* t
     cv::Mat imD, imFlow;                                        // Frame's map arguments are unused (the slot holds the maps)
     all_timing.assign(5, 0.f);
     auto t_st = std::chrono::steady_clock::now();
+    {   // VIDO_DIAG_FIRSTOP=n (diagnosis): n rounds of (trivial stream operation + host wait) in front of the frame's first stage (vido_debug_first_op prints the means at exit)
+        static const int diag = [] { const char* e = getenv("VIDO_DIAG_FIRSTOP"); return e ? atoi(e) : 0; }();
+        if (diag > 0 && mState != NO_IMAGES_YET) { (void)vido_debug_first_op(c, diag); t_st = std::chrono::steady_clock::now(); }
+    }
     if (mState != NO_IMAGES_YET) UpdateMask();
     ms_update_mask = ms_since(t_st); t_st = std::chrono::steady_clock::now();
     mpCurrentFrame = new Frame(mImGray, imD, imFlow, mSegMap, timestamp, mpORBextractorLeft, mK, mDistCoef, mbf, mThDepth, mThDepthObj, nUseSampleFea);
@@ -1431,6 +1437,13 @@ int vido_system_save_results(vido_system* s, const char* prefix)
 }
 
 vido_ctx* vido_system_context(vido_system* s) { return s && s->inited ? VIDO_SLAM::detail::Context() : nullptr; }
+
+int vido_system_set_zero_copy_maps(vido_system* s, int zero_copy)
+{
+    if (!s) return VIDO_E_INVALID;
+    VIDO_SLAM::detail::SetZeroCopyMaps(zero_copy != 0);
+    return VIDO_OK;
+}
 
 int vido_system_set_depth_noise_seed(vido_system* s, unsigned seed)
 {

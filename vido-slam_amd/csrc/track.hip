@@ -17,6 +17,7 @@ struct TrackState {
     float *d_scorr = nullptr, *d_sflow = nullptr, *d_sdepth = nullptr;
     float *d_okeys = nullptr, *d_ocorr = nullptr, *d_odepth = nullptr, *d_oflow = nullptr;
     float* d_tmpf = nullptr; int32_t* d_tmpi = nullptr; size_t tmp_cap = 0;       // scratch for gathers
+    bool zc_io = true;                                                            // the small per-point calls run their kernels on h_io itself (no copies); VIDO_TRACK_IO_COPIES=1: through d_tmpf
     float* h_io = nullptr;                                                        // pinned mirror of d_tmpf, word for word: a call packs its inputs there (ONE copy up) and reads its outputs there (ONE copy down)
     int32_t* h_cnt = nullptr;
     char* h_stage = nullptr; size_t stage_cap = 0;
@@ -232,6 +233,7 @@ static int track_state(vido_ctx* ctx, TrackState** out)
     T->tmp_cap = (size_t)std::max(T->max_obj, T->max_kp) * 12 + 16;      // the widest call layout (scene_flow: 12 words per point) for every n up to max_obj / max_kp
     HIP_TRY(ctx, hipMalloc(&T->d_tmpf, T->tmp_cap * 4)); HIP_TRY(ctx, hipMalloc(&T->d_tmpi, T->tmp_cap * 4));
     HIP_TRY(ctx, hipHostMalloc((void**)&T->h_io, T->tmp_cap * 4 + (size_t)T->max_kp * sizeof(vido_keypoint) + 256));
+    T->zc_io = getenv("VIDO_TRACK_IO_COPIES") == nullptr;
     HIP_TRY(ctx, hipHostMalloc(&T->h_cnt, 2 * B * 4));
     T->sdepth.resize(B); T->sflow.resize(B); T->smask.resize(B);
     for (size_t b = 0; b < B; b++) { T->sdepth[b] = T->d_depth + b * px; T->sflow[b] = T->d_flow + b * px * 2; T->smask[b] = T->d_mask + b * px; }
@@ -253,7 +255,31 @@ void track_state_destroy(vido_ctx* ctx)
 
 static inline hipMemcpyKind in_kind(int on_device) { return on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice; }
 
+__global__ __launch_bounds__(256) void k_diag_lds(int* out) { __shared__ int pad[8192]; pad[threadIdx.x] = threadIdx.x; __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) out[1] = pad[255]; }
 extern "C" {
+
+/* diagnosis (VIDO_DIAG_FIRSTOP): `rounds` x (a 4-byte memset on the context's stream + a host wait), each timed; the means per round are printed when the process exits */
+int vido_debug_first_op(vido_ctx* ctx, int rounds)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    static double acc[8] = {0}; static long cnt = 0; static int* dword = nullptr;
+    struct Printer { ~Printer() { if (cnt) for (int i = 0; i < 8; i++) if (acc[i] > 0) fprintf(stderr, "[diag first-op] round %d: %.3f ms mean over %ld frames\n", i, acc[i] / cnt, cnt); } };
+    static Printer pr;
+    if (!dword) HIP_TRY(ctx, hipMalloc((void**)&dword, 64));
+    for (int i = 0; i < std::min(rounds, 8); i++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        // rounds 0, 1: a 4-byte memset; 2, 3: a 16 KB device -> pinned-host copy; 4, 5: a 16 KB pinned-host -> device copy; 6, 7: a 64-workgroup kernel with 32 KB of LDS each
+        TrackState* T = ctx->trk;
+        if (i < 2 || !T) HIP_TRY(ctx, hipMemsetAsync(dword, 0, 4, ctx->stream));
+        else if (i < 4) HIP_TRY(ctx, hipMemcpyAsync(T->h_io, T->d_tmpf, 16384, hipMemcpyDeviceToHost, ctx->stream));
+        else if (i < 6) HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, T->h_io, 16384, hipMemcpyHostToDevice, ctx->stream));
+        else hipLaunchKernelGGL(k_diag_lds, dim3(64), dim3(256), 0, ctx->stream, dword);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        acc[i] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    cnt++;
+    return VIDO_OK;
+}
 
 int vido_track_slots(vido_ctx* ctx)
 {
@@ -273,6 +299,16 @@ int vido_frame_upload(vido_ctx* ctx, int slot0, int n_frames, float* depth, cons
     if ((n & 3) != 0) return vido_set_error(ctx, VIDO_E_INVALID, "frame_upload: width*height must be a multiple of 4");      // every argument is validated before any state changes
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    if (on_device == 2) {
+        // zero-copy: the slots REFER to the caller's device buffers (the reference keeps shallow references to the caller's Mats, Tracking.cc:343-345, and rescales the depth in
+        // the caller's buffer, :299-322).  No copy in either direction: 6.1 MB of device-to-device copies per 640 x 480 frame, which beside saturating network kernels cost the
+        // tracker's first synchronisation ~1.1 ms (profiles/r6/tracker_zero_copy_maps.txt).  The caller keeps a frame's maps alive and untouched while the slot is in use (the
+        // tracker reads the current and the previous frame).
+        for (int f = 0; f < n_frames; f++) { T->sdepth[slot0 + f] = depth + (size_t)f * px; T->sflow[slot0 + f] = (float*)flow + (size_t)f * px * 2; T->smask[slot0 + f] = (int32_t*)mask + (size_t)f * px; }
+        hipLaunchKernelGGL(k_depth_prescale, dim3((int)std::min<size_t>((n / 4 + 255) / 256, 2048)), dim3(256), 0, st, depth, n / 4, p->dataset, p->depth_map_factor, p->bf, p->kaist_scale);
+        HIP_TRY(ctx, hipGetLastError());
+        return VIDO_OK;
+    }
     float* dd = T->d_depth + slot0 * px;
     HIP_TRY(ctx, hipMemcpyAsync(dd, depth, n * 4, in_kind(on_device), st));
     HIP_TRY(ctx, hipMemcpyAsync(T->d_flow + slot0 * px * 2, flow, n * 8, in_kind(on_device), st));
@@ -471,6 +507,9 @@ int vido_frontend_batch(vido_ctx* ctx, const uint8_t* imgs, int imgs_on_device, 
 
 // The small per-point calls below hand caller (pageable) arrays in and out.  Each packs its inputs into the pinned mirror of the device scratch (h_io <-> d_tmpf, same
 // layout), sends them with ONE copy, and fetches all of its outputs with ONE copy: 3 stream operations per call instead of 3..8, none of them on pageable memory.
+// (round 6) ZERO-COPY by default: the kernels read their inputs from and write their outputs to the pinned buffer itself (device-visible host memory: a few dozen KB per
+// call over the bus) — ONE stream operation per call; beside saturating network kernels a small copy + kernel + copy round trip measured 1.17 ms where the kernel alone
+// takes 0.1 (profiles/r6/tracker_zero_copy_io.txt).  VIDO_TRACK_IO_COPIES=1 restores the copies.
 int vido_gather_static_depth(vido_ctx* ctx, int slot, const float* keys_xy, int n, float* depth_out)
 {
     if (!ctx) return VIDO_E_INVALID;
@@ -478,10 +517,11 @@ int vido_gather_static_depth(vido_ctx* ctx, int slot, const float* keys_xy, int 
     if (slot < 0 || slot >= T->B || n < 0 || (size_t)n * 3 > T->tmp_cap) return vido_set_error(ctx, VIDO_E_INVALID, "gather_static_depth: bad slot/n");
     if (n == 0) return VIDO_OK;
     hipStream_t st = ctx->stream;
+    const bool zc = T->zc_io; float* io = zc ? T->h_io : T->d_tmpf;      // zero-copy: the kernels read and write the pinned buffer itself
     memcpy(T->h_io, keys_xy, (size_t)n * 8);
-    HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, T->h_io, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_gather_static, dim3((n + 255) / 256), dim3(256), 0, st, T->d_tmpf, n, T->sdepth[slot], T->W, T->H, T->d_tmpf + 2 * (size_t)n);
-    HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 2 * (size_t)n, T->d_tmpf + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (!zc) HIP_TRY(ctx, hipMemcpyAsync(io, T->h_io, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gather_static, dim3((n + 255) / 256), dim3(256), 0, st, io, n, T->sdepth[slot], T->W, T->H, io + 2 * (size_t)n);
+    if (!zc) HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 2 * (size_t)n, io + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     memcpy(depth_out, T->h_io + 2 * (size_t)n, (size_t)n * 4);
     return VIDO_OK;
@@ -494,11 +534,12 @@ int vido_gather_object_depth_label(vido_ctx* ctx, int slot, const float* keys_xy
     if (slot < 0 || slot >= T->B || n < 0 || (size_t)n * 4 > T->tmp_cap) return vido_set_error(ctx, VIDO_E_INVALID, "gather_object: bad slot/n");
     if (n == 0) return VIDO_OK;
     hipStream_t st = ctx->stream;
-    float* dd = T->d_tmpf + 2 * (size_t)n; int32_t* dl = (int32_t*)(T->d_tmpf + 3 * (size_t)n);      // [keys 2n | depth n | label n]
+    const bool zc = T->zc_io; float* io = zc ? T->h_io : T->d_tmpf;      // zero-copy: the kernels read and write the pinned buffer itself
+    float* dd = io + 2 * (size_t)n; int32_t* dl = (int32_t*)(io + 3 * (size_t)n);      // [keys 2n | depth n | label n]
     memcpy(T->h_io, keys_xy, (size_t)n * 8);
-    HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, T->h_io, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_gather_object, dim3((n + 255) / 256), dim3(256), 0, st, T->d_tmpf, n, T->sdepth[slot], T->smask[slot], T->W, T->H, th_depth_obj, dd, dl);
-    HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 2 * (size_t)n, dd, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    if (!zc) HIP_TRY(ctx, hipMemcpyAsync(io, T->h_io, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gather_object, dim3((n + 255) / 256), dim3(256), 0, st, io, n, T->sdepth[slot], T->smask[slot], T->W, T->H, th_depth_obj, dd, dl);
+    if (!zc) HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 2 * (size_t)n, dd, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     memcpy(depth_out, T->h_io + 2 * (size_t)n, (size_t)n * 4); memcpy(label_out, T->h_io + 3 * (size_t)n, (size_t)n * 4);
     return VIDO_OK;
@@ -511,11 +552,12 @@ int vido_gather_point_samples(vido_ctx* ctx, int slot, const float* xy, int n, i
     if (slot < 0 || slot >= T->B || n < 0 || (size_t)n * 6 > T->tmp_cap || (n && (!xy || !mask_out || !depth_out || !flow_out))) return vido_set_error(ctx, VIDO_E_INVALID, "gather_point_samples: bad slot/n");
     if (n == 0) return VIDO_OK;
     hipStream_t st = ctx->stream;
-    float* dk = T->d_tmpf; float* dd = dk + 2 * (size_t)n; float* df = dd + n; int32_t* dm = (int32_t*)(df + 2 * (size_t)n);      // [xy 2n | depth n | flow 2n | mask n]
+    const bool zc = T->zc_io; float* io = zc ? T->h_io : T->d_tmpf;      // zero-copy: the kernels read and write the pinned buffer itself
+    float* dk = io; float* dd = dk + 2 * (size_t)n; float* df = dd + n; int32_t* dm = (int32_t*)(df + 2 * (size_t)n);      // [xy 2n | depth n | flow 2n | mask n]
     memcpy(T->h_io, xy, (size_t)n * 8);
-    HIP_TRY(ctx, hipMemcpyAsync(dk, T->h_io, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    if (!zc) HIP_TRY(ctx, hipMemcpyAsync(dk, T->h_io, (size_t)n * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_gather_samples, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, T->sdepth[slot], T->sflow[slot], T->smask[slot], T->W, T->H, dd, df, dm);
-    HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 2 * (size_t)n, dd, (size_t)n * 16, hipMemcpyDeviceToHost, st));
+    if (!zc) HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 2 * (size_t)n, dd, (size_t)n * 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     memcpy(depth_out, T->h_io + 2 * (size_t)n, (size_t)n * 4); memcpy(flow_out, T->h_io + 3 * (size_t)n, (size_t)n * 8); memcpy(mask_out, T->h_io + 5 * (size_t)n, (size_t)n * 4);
     return VIDO_OK;
@@ -531,6 +573,7 @@ int vido_update_mask(vido_ctx* ctx, int slot_last, int slot_cur, const int32_t* 
         return vido_set_error(ctx, VIDO_E_INVALID, "update_mask: bad slots/n");
     if (n == 0) return VIDO_OK;
     hipStream_t st = ctx->stream;
+    const bool zc = T->zc_io; float* io = zc ? T->h_io : T->d_tmpf;      // zero-copy: the kernels read and write the pinned buffer itself
     std::vector<int> uni(last_label, last_label + n);
     std::sort(uni.begin(), uni.end()); uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
     // The labels' samples are read in ONE gather (one upload, one launch, one download, one wait) instead of a round trip per label: five labels were 15 stream operations
@@ -546,10 +589,11 @@ int vido_update_mask(vido_ctx* ctx, int slot_last, int slot_cur, const int32_t* 
     g_off.push_back((int)(corr.size() / 2));
     for (size_t g0 = 0; g0 < g_lab.size();) {
         const int p0 = g_off[g0], m_all = g_off.back() - p0;
+        VidoProfScope prof_round("update_mask: one gather round (upload + k_mask_at + download + wait)");
         memcpy(T->h_io, corr.data() + 2 * (size_t)p0, (size_t)m_all * 8);                 // [corr 2m | values m] in the pinned mirror of d_tmpf
-        HIP_TRY(ctx, hipMemcpyAsync(T->d_tmpf, T->h_io, (size_t)m_all * 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_mask_at, dim3((m_all + 255) / 256), dim3(256), 0, st, T->d_tmpf, m_all, T->smask[slot_cur], T->W, T->H, (int32_t*)(T->d_tmpf + 2 * (size_t)m_all));
-        HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 2 * (size_t)m_all, T->d_tmpf + 2 * (size_t)m_all, (size_t)m_all * 4, hipMemcpyDeviceToHost, st));
+        if (!zc) HIP_TRY(ctx, hipMemcpyAsync(io, T->h_io, (size_t)m_all * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_mask_at, dim3((m_all + 255) / 256), dim3(256), 0, st, io, m_all, T->smask[slot_cur], T->W, T->H, (int32_t*)(io + 2 * (size_t)m_all));
+        if (!zc) HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 2 * (size_t)m_all, io + 2 * (size_t)m_all, (size_t)m_all * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         vals.assign((const int32_t*)(T->h_io + 2 * (size_t)m_all), (const int32_t*)(T->h_io + 2 * (size_t)m_all) + m_all);
         size_t g = g0; bool scattered = false;
@@ -594,14 +638,15 @@ int vido_unproject_world(vido_ctx* ctx, const float* keys_xy, const float* z, in
     if (n < 0 || (size_t)n * 6 + 16 > T->tmp_cap) return vido_set_error(ctx, VIDO_E_INVALID, "unproject_world: n too large");
     if (n == 0) return VIDO_OK;
     hipStream_t st = ctx->stream;
+    const bool zc = T->zc_io; float* io = zc ? T->h_io : T->d_tmpf;      // zero-copy: the kernels read and write the pinned buffer itself
     float RT[12];
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) RT[r * 3 + c] = Tcw[c * 4 + r];
     for (int r = 0; r < 3; r++) { double s = 0; for (int c = 0; c < 3; c++) s += (double)(-RT[r * 3 + c]) * (double)Tcw[c * 4 + 3]; RT[9 + r] = (float)s; }
-    float* dk = T->d_tmpf; float* dz = dk + 2 * (size_t)n; float* drt = dz + n; float* dout = drt + 16;      // [keys 2n | z n | RT 12 (+4) | xyz 3n]
+    float* dk = io; float* dz = dk + 2 * (size_t)n; float* drt = dz + n; float* dout = drt + 16;      // [keys 2n | z n | RT 12 (+4) | xyz 3n]
     memcpy(T->h_io, keys_xy, (size_t)n * 8); memcpy(T->h_io + 2 * (size_t)n, z, (size_t)n * 4); memcpy(T->h_io + 3 * (size_t)n, RT, sizeof RT);
-    HIP_TRY(ctx, hipMemcpyAsync(dk, T->h_io, ((size_t)n * 3 + 16) * 4, hipMemcpyHostToDevice, st));
+    if (!zc) HIP_TRY(ctx, hipMemcpyAsync(dk, T->h_io, ((size_t)n * 3 + 16) * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_unproject_world, dim3((n + 255) / 256), dim3(256), 0, st, dk, dz, n, p->cx, p->cy, 1.0f / p->fx, 1.0f / p->fy, drt, dout);
-    HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 3 * (size_t)n + 16, dout, (size_t)n * 12, hipMemcpyDeviceToHost, st));
+    if (!zc) HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 3 * (size_t)n + 16, dout, (size_t)n * 12, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     memcpy(xyz_out, T->h_io + 3 * (size_t)n + 16, (size_t)n * 12);
     return VIDO_OK;
@@ -615,12 +660,13 @@ int vido_scene_flow(vido_ctx* ctx, const float* xyz_last, const float* xyz_cur, 
     if (n < 0 || (size_t)n * 12 > T->tmp_cap) return vido_set_error(ctx, VIDO_E_INVALID, "scene_flow: n too large");
     if (n == 0) return VIDO_OK;
     hipStream_t st = ctx->stream;
+    const bool zc = T->zc_io; float* io = zc ? T->h_io : T->d_tmpf;      // zero-copy: the kernels read and write the pinned buffer itself
     const size_t N = (size_t)n;
-    float *a = T->d_tmpf, *b = a + 3 * N; int32_t *sl = (int32_t*)(b + 3 * N), *sc = sl + N, *ol = sc + N; float* c = (float*)(ol + N);      // [last 3n | cur 3n | sem last n | sem cur n | label n (in/out) | flow 3n]
+    float *a = io, *b = a + 3 * N; int32_t *sl = (int32_t*)(b + 3 * N), *sc = sl + N, *ol = sc + N; float* c = (float*)(ol + N);      // [last 3n | cur 3n | sem last n | sem cur n | label n (in/out) | flow 3n]
     memcpy(T->h_io, xyz_last, N * 12); memcpy(T->h_io + 3 * N, xyz_cur, N * 12); memcpy(T->h_io + 6 * N, sem_last, N * 4); memcpy(T->h_io + 7 * N, sem_cur, N * 4); memcpy(T->h_io + 8 * N, obj_label_inout, N * 4);
-    HIP_TRY(ctx, hipMemcpyAsync(a, T->h_io, N * 36, hipMemcpyHostToDevice, st));
+    if (!zc) HIP_TRY(ctx, hipMemcpyAsync(a, T->h_io, N * 36, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_scene_flow, dim3((n + 255) / 256), dim3(256), 0, st, a, b, sl, sc, n, c, ol);
-    HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 8 * N, ol, N * 16, hipMemcpyDeviceToHost, st));
+    if (!zc) HIP_TRY(ctx, hipMemcpyAsync(T->h_io + 8 * N, ol, N * 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     memcpy(obj_label_inout, T->h_io + 8 * N, N * 4); memcpy(flow3d_out, T->h_io + 9 * N, N * 12);
     return VIDO_OK;

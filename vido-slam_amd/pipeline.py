@@ -278,6 +278,10 @@ class EndToEnd:
 
     def __init__(self, nodes, system, n_image=10000, feed="nets", handover="device"):
         self.nodes, self.system, self.n_image, self.feed, self.handover = nodes, system, n_image, feed, handover
+        # (round 6) the tracker ADOPTS the ring's map buffers instead of copying them into its own slots: the ring holds RING = 4 frames, the tracker reads frames k and k - 1,
+        # the networks write at most two frames ahead.  VIDO_TRACK_COPY_MAPS=1 keeps the copies (6.1 MB device-to-device per frame).
+        if handover == "device" and hasattr(system, "SetZeroCopyMaps"):
+            system.SetZeroCopyMaps(not _os.environ.get("VIDO_TRACK_COPY_MAPS"))
         h, w = nodes.h, nodes.w; dev = nodes.dev
         pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
         self.host = [dict(bgr=pin((h, w, 3), torch.uint8), flow=pin((h, w, 2), torch.float32), depth=pin((h, w), torch.float32), mask=pin((h, w), torch.int32),

@@ -41,6 +41,7 @@ def _bind(lib):
     lib.vido_system_context.restype = C.c_void_p
     lib.vido_system_context.argtypes = [C.c_void_p]
     lib.vido_system_set_depth_noise_seed.argtypes = [C.c_void_p, C.c_uint]
+    lib.vido_system_set_zero_copy_maps.argtypes = [C.c_void_p, C.c_int]
     lib._vido_system_bound = True
     return lib
 
@@ -86,6 +87,13 @@ class System:
         if rc != VIDO_OK:
             raise VidoError(rc, self.lib.vido_system_last_error(self.h).decode())
         return T
+
+    def SetZeroCopyMaps(self, on=True):
+        """TrackRGBDDevice adopts the three device map buffers instead of copying them into the tracker's slots (6.1 MB of device-to-device copies per 640x480 frame): the
+        caller keeps a frame's maps alive and untouched until the call after the next one has returned (vido_system_set_zero_copy_maps)."""
+        rc = self.lib.vido_system_set_zero_copy_maps(self.h, int(bool(on)))
+        if rc != 0:
+            raise VidoError(rc, "vido_system_set_zero_copy_maps")
 
     def TrackRGBDDevice(self, im_dev, channels, width, height, depth_dev, flow_dev, mask_dev, ready_event=None, timestamp=0.0, nImage=10000):
         """System::TrackRGBDDevice (extension, SURVEY.md 8f row 4): the same call on DEVICE-resident buffers given as raw pointers (e.g. tensor.data_ptr()): u8 image with
