@@ -87,6 +87,8 @@ int vido_orb_extract_color(vido_ctx* ctx, const uint8_t* img, int channels, int 
 
 /* Diagnostics for the parity tests: copy pyramid level `level` (tight lw*lh bytes) of frame `frame` of the
  * last extract call back to the host; blurred!=0 selects the 7x7-blurred copy. */
+/* enqueue the extraction of a device-resident colour frame and return; the next vido_orb_extract_color call for the same pointer and size only collects (csrc/orb.hip) */
+int vido_orb_prefetch_color(vido_ctx* ctx, const uint8_t* img_dev, int channels, int rgb_order, int stride, int width, int height, void* ready_event);
 int vido_orb_level_size(const vido_ctx* ctx, int level, int* lw, int* lh);
 int vido_orb_read_level(vido_ctx* ctx, int frame, int level, int blurred, uint8_t* out);
 /* FAST candidates of the last call for (frame, level) in reference order: packed x | y<<12 | score<<24
@@ -552,6 +554,10 @@ int         vido_system_track_rgbd(vido_system* sys, const uint8_t* im, int chan
 /* zero_copy != 0: vido_system_track_rgbd_device ADOPTS the three map buffers instead of copying them into the tracker's slots (vido_frame_upload on_device = 2): the caller
  * keeps the maps of a frame alive and untouched until the call AFTER the next one has returned (a ring of >= 3 frames; pipeline.EndToEnd's has 4).  Default 0. */
 int         vido_system_set_zero_copy_maps(vido_system* sys, int zero_copy);
+/* The ORB extraction of the NEXT vido_system_track_rgbd_device call's image, put on the tracker's stream now (it needs nothing but the image: a pipeline calls this while it
+ * still waits for the networks of the frame); image_ready_event (hipEvent_t or NULL) orders it behind the image's upload.  The track call for the same pointer and size then
+ * only collects.  Same thread as the track calls; the image stays untouched until that call has returned. */
+int         vido_system_prefetch_image_device(vido_system* sys, const void* im_dev, int channels, int width, int height, void* image_ready_event);
 int         vido_system_track_rgbd_device(vido_system* sys, const void* im_dev, int channels, int width, int height, float* depth_dev, const float* flow_dev,
                                           const int32_t* mask_dev, void* ready_event, double timestamp, int n_image, float Tcw_out[16]);
 int         vido_system_get_stats(const vido_system* sys, vido_system_stats* out);

@@ -55,6 +55,8 @@ public:
     /* extension: the next operator() call reads a DEVICE-resident image (u8, `channels` = 1 / 3 / 4 interleaved, rows contiguous) instead of `image`'s host pixels —
        the in-process network -> tracker hand-over (Tracking::GrabImageRGBDDevice); `image` then only carries the size. */
     void SetDeviceSource(const void* dev_pixels, int channels, bool rgb_order) { dev_src_ = dev_pixels; dev_ch_ = channels; rgb_ = rgb_order; }
+    /* extension: put the extraction of a device-resident colour image on the GPU now (vido_orb_prefetch_color); the operator() call for the same image then only collects */
+    void PrefetchDevice(const void* dev_pixels, int channels, bool rgb_order, int width, int height, void* ready_event);
     int nfeatures; float scaleFactor; int nlevels, iniThFAST, minThFAST;
 private:
     std::vector<float> mvScaleFactor;
@@ -159,6 +161,7 @@ public:
        maps RESIDENT ON THE DEVICE — u8 image (1 / 3 / 4 channels), depth CV_32F (raw sensor units, rescaled in place like the host form), flow CV_32FC2, mask CV_32SC1 as
        plain device pointers of a width x height frame.  Nothing is uploaded and no map is downloaded: the host-side stages read the map values at their few thousand
        candidate points through device gathers.  ready_event: a hipEvent_t the producer recorded after writing the buffers (the tracker's stream waits for it; may be null). */
+    void PrefetchImageDevice(const void* im_dev, int channels, int width, int height, void* image_ready_event);
     cv::Mat GrabImageRGBDDevice(const void* im_dev, int channels, int width, int height, float* depth_dev, const float* flow_dev, const int* mask_dev, void* ready_event,
                                 const double& timestamp, const int& nImage);
     void Track();
@@ -206,6 +209,9 @@ public:
     /* extension: TrackRGBD on device-resident inputs (Tracking::GrabImageRGBDDevice) */
     cv::Mat TrackRGBDDevice(const void* im_dev, int channels, int width, int height, float* depth_dev, const float* flow_dev, const int* mask_dev, void* ready_event,
                             const double& timestamp, const int& nImage);
+    /* extension: the ORB extraction of the NEXT frame's device-resident image, enqueued ahead of TrackRGBDDevice (it needs nothing but the image: a pipeline calls this while it
+       still waits for the frame's depth / flow / mask); image_ready_event (hipEvent_t or NULL) orders it behind the image's producer */
+    void PrefetchImageDevice(const void* im_dev, int channels, int width, int height, void* image_ready_event);
     void SaveResultsIJRR2020(const std::string& filename);
     Map* GetMap() { return mpMap; }
     Tracking* GetTracker() { return mpTracker; }

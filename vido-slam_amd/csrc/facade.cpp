@@ -176,6 +176,13 @@ vido_ctx* ORBextractor::context(int width, int height)
     }
     return ctx_;
 }
+void ORBextractor::PrefetchDevice(const void* dev_pixels, int channels, bool rgb_order, int width, int height, void* ready_event)
+{
+    vido_ctx* c = context(width, height);
+    if (channels != 3 && channels != 4) return;              // (gray device images take the batch entry: no prefetch form)
+    if (vido_orb_prefetch_color(c, (const uint8_t*)dev_pixels, channels, rgb_order ? 1 : 0, width * channels, width, height, ready_event) != VIDO_OK) throw std::runtime_error(vido_last_error(c));
+}
+
 void ORBextractor::operator()(cv::InputArray image_, cv::InputArray, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors_)
 {
     keypoints.clear();
@@ -896,6 +903,12 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
     return GrabCommon(timestamp, nImage, (void*)&t_grab);
 }
 
+void Tracking::PrefetchImageDevice(const void* im_dev, int channels, int width, int height, void* image_ready_event)
+{
+    if (!im_dev || width < 1 || height < 1) throw std::runtime_error("PrefetchImageDevice: device image expected");
+    mpORBextractorLeft->PrefetchDevice(im_dev, channels, mbRGB, width, height, image_ready_event);
+}
+
 cv::Mat Tracking::GrabImageRGBDDevice(const void* im_dev, int channels, int width, int height, float* depth_dev, const float* flow_dev, const int* mask_dev, void* ready_event,
                                       const double& timestamp, const int& nImage)
 {
@@ -1320,6 +1333,11 @@ cv::Mat System::TrackRGBDDevice(const void* im_dev, int channels, int width, int
     if (mSensor != RGBD) throw std::runtime_error("ERROR: you called TrackRGBDDevice but input sensor was not set to RGBD.");
     return mpTracker->GrabImageRGBDDevice(im_dev, channels, width, height, depth_dev, flow_dev, mask_dev, ready_event, ts, nImage);
 }
+void System::PrefetchImageDevice(const void* im_dev, int channels, int width, int height, void* image_ready_event)
+{
+    if (mSensor != RGBD) throw std::runtime_error("ERROR: you called PrefetchImageDevice but input sensor was not set to RGBD.");
+    mpTracker->PrefetchImageDevice(im_dev, channels, width, height, image_ready_event);
+}
 void System::SaveResultsIJRR2020(const std::string& prefix)   // System.cc:80-240 (pose / motion files; GT files are not produced)
 {
     finish_local_ba();
@@ -1437,6 +1455,15 @@ int vido_system_save_results(vido_system* s, const char* prefix)
 }
 
 vido_ctx* vido_system_context(vido_system* s) { return s && s->inited ? VIDO_SLAM::detail::Context() : nullptr; }
+
+int vido_system_prefetch_image_device(vido_system* s, const void* im_dev, int channels, int width, int height, void* image_ready_event)
+{
+    if (!s || !s->inited) return VIDO_E_INVALID;
+    if (!im_dev || width <= 0 || height <= 0 || (channels != 1 && channels != 3 && channels != 4)) { s->err = "vido_system_prefetch_image_device: bad argument"; return VIDO_E_INVALID; }
+    try { s->sys.PrefetchImageDevice(im_dev, channels, width, height, image_ready_event); }
+    catch (const std::exception& e) { s->err = e.what(); return VIDO_SLAM::failure_code(e); }
+    return VIDO_OK;
+}
 
 int vido_system_set_zero_copy_maps(vido_system* s, int zero_copy)
 {

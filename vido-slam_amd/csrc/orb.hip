@@ -1295,6 +1295,7 @@ struct OrbState {
     BlurTile* d_bstrips = nullptr; int n_blur_strips = 0;            // k_blur7_strips: {level, first column, first row, batches of 7 input rows} per wave; 0 = the tile kernel stays
     int2* d_xtab = nullptr; int4* d_ytab = nullptr;
     PyrBand* d_bands = nullptr; int n_bands = 0; size_t bands_lds = 0; PyrBandLv band_lv{};      // single-launch pyramid (k_pyramid_bands)
+    const uint8_t* prefetched_src = nullptr; int prefetched_w = 0, prefetched_h = 0;      // vido_orb_prefetch_color: the device image whose extraction is already on the stream
     PyrTile* d_ptiles = nullptr; int n_ptiles = 0; size_t ptiles_lds = 0; PyrTileLv ptile_lv{};  // single-launch pyramid for any batch (k_pyramid_tiles); 0 tiles = not built
     int* d_frame_tot = nullptr;                                       // per-frame candidate totals (k_scan_frames -> k_scan_apply)
     uint32_t* d_slots = nullptr; int *d_counts = nullptr, *d_offsets = nullptr, *d_first_cell = nullptr, *d_lvloff = nullptr, *d_overflow = nullptr;
@@ -1830,10 +1831,17 @@ int orb_collect(vido_ctx* ctx, int nf, int copy)
 {
     OrbState* S = ctx->orb; hipStream_t st = ctx->stream; const int L = S->L;
     VidoProfScope ps_c("orb_collect: wait for the extraction + downloads", st, false);
+    {
+    VidoProfScope ps_a("orb_collect: (a) plain wait for the stream", st, false);
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    {
+    VidoProfScope ps_b("orb_collect: (b) three count downloads + wait", st, false);
     HIP_TRY(ctx, hipMemcpyAsync(S->h_frame_beg, S->d_frame_beg, ((size_t)nf + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(S->h_lvloff, S->d_lvloff, ((size_t)nf * L + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(S->h_overflow, S->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
     HIP_TRY(ctx, hipGetLastError());
     if (*S->h_overflow) {
         const int code = *S->h_overflow; hipMemsetAsync(S->d_overflow, 0, sizeof(int), st);
@@ -1849,9 +1857,17 @@ int orb_collect(vido_ctx* ctx, int nf, int copy)
         maxn = std::max(maxn, n);
     }
     if (copy && maxn > 0) {
+        VidoProfScope ps_d("orb_collect: (c) keypoint + descriptor rows (2-D copies) + wait", st, false);
         const size_t kp_pitch = (size_t)S->row_cap * sizeof(vido_keypoint), de_pitch = (size_t)S->row_cap * 32;
+        // One frame: plain copies.  A 2-D copy runs as a rectangle kernel of the runtime, which beside saturating network kernels took 1.1 ms for these 112 KB where a plain
+        // copy takes 20 us (profiles/r6/tracker_zero_copy_io.txt) — it was the tracker's "first millisecond" of every frame.
+        if (nf == 1) {
+            HIP_TRY(ctx, hipMemcpyAsync(S->h_kpf, S->d_kpf, (size_t)maxn * sizeof(vido_keypoint), hipMemcpyDeviceToHost, st));
+            if (ctx->cfg.compute_descriptors) HIP_TRY(ctx, hipMemcpyAsync(S->h_descf, S->d_descf, (size_t)maxn * 32, hipMemcpyDeviceToHost, st));
+        } else {
         HIP_TRY(ctx, hipMemcpy2DAsync(S->h_kpf, kp_pitch, S->d_kpf, kp_pitch, (size_t)maxn * sizeof(vido_keypoint), nf, hipMemcpyDeviceToHost, st));
         if (ctx->cfg.compute_descriptors) HIP_TRY(ctx, hipMemcpy2DAsync(S->h_descf, de_pitch, S->d_descf, de_pitch, (size_t)maxn * 32, nf, hipMemcpyDeviceToHost, st));
+        }
         HIP_TRY(ctx, hipStreamSynchronize(st));
     }
     float ms;
@@ -1901,7 +1917,11 @@ static int orb_run(vido_ctx* ctx, const uint8_t* imgs, int on_device, int nf, si
                    vido_keypoint* kp_out, int max_kp, int* n_out, uint8_t* desc_out)
 {
     if (!kp_out || !n_out || max_kp <= 0) return vido_set_error(ctx, VIDO_E_INVALID, "orb: null output");
-    int rc = orb_enqueue(ctx, imgs, on_device, nf, frame_stride, stride, width, height); if (rc) return rc;
+    int rc;
+    // (round 6) an extraction of exactly this device image already on the stream (vido_orb_prefetch_color): only the collection is left
+    const bool prefetched = ctx->orb->prefetched_src && ctx->orb->prefetched_src == imgs && on_device && nf == 1 && ctx->orb->prefetched_w == width && ctx->orb->prefetched_h == height;
+    ctx->orb->prefetched_src = nullptr;
+    if (!prefetched) { rc = orb_enqueue(ctx, imgs, on_device, nf, frame_stride, stride, width, height); if (rc) return rc; }
     if ((rc = orb_collect(ctx, nf, 1))) return rc;
     OrbState* S = ctx->orb;
     const int with_desc = ctx->cfg.compute_descriptors ? 1 : 0;
@@ -1944,6 +1964,24 @@ int vido_orb_extract_color(vido_ctx* ctx, const uint8_t* img, int channels, int 
     S->in_channels = channels; S->in_rgb = rgb_order != 0; S->gray_out = gray_out; S->gray_out_on_device = on_device;
     const int rc = orb_run(ctx, img, on_device, n_frames, frame_stride, stride, width, height, kp_out, max_kp, n_out, desc_out);
     S->in_channels = 1; S->in_rgb = 0; S->gray_out = nullptr;
+    return rc;
+}
+
+/* Enqueue the extraction of a DEVICE-resident colour frame on the context's stream and return at once; the next vido_orb_extract_color call for the same pointer and size only
+ * collects the result.  The extraction needs nothing but the image, so a pipeline can put it on the GPU while it still waits for the frame's other inputs (the networks' maps):
+ * System::PrefetchImageDevice.  ready_event (hipEvent_t or NULL): the stream waits for it first (the image's upload).  One frame in flight; the image must stay untouched
+ * until it has been collected. */
+int vido_orb_prefetch_color(vido_ctx* ctx, const uint8_t* img_dev, int channels, int rgb_order, int stride, int width, int height, void* ready_event)
+{
+    if (!ctx || !ctx->orb || !img_dev) return VIDO_E_INVALID;
+    if (channels != 3 && channels != 4) return vido_set_error(ctx, VIDO_E_INVALID, "orb_prefetch_color: channels must be 3 or 4 (got %d)", channels);
+    OrbState* S = ctx->orb;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ready_event) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)ready_event, 0));
+    S->in_channels = channels; S->in_rgb = rgb_order != 0; S->gray_out = nullptr; S->gray_out_on_device = 1;
+    const int rc = orb_enqueue(ctx, img_dev, 1, 1, 0, stride, width, height);
+    S->in_channels = 1; S->in_rgb = 0; S->gray_out = nullptr;
+    S->prefetched_src = rc == VIDO_OK ? img_dev : nullptr; S->prefetched_w = width; S->prefetched_h = height;
     return rc;
 }
 

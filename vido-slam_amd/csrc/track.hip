@@ -390,7 +390,8 @@ int vido_frame_features(vido_ctx* ctx, int slot0, int n_frames, const vido_keypo
     std::vector<Seg> segs; char* cur = T->h_stage;
     auto copy2d = [&](void* dst, size_t dpitch_el, const void* src, size_t spitch_el, size_t el, int width_el) -> int {
         if (width_el <= 0) return VIDO_OK;
-        HIP_TRY(ctx, hipMemcpy2DAsync(cur, (size_t)width_el * el, src, spitch_el * el, (size_t)width_el * el, n_frames, hipMemcpyDeviceToHost, st));
+        if (n_frames == 1) HIP_TRY(ctx, hipMemcpyAsync(cur, src, (size_t)width_el * el, hipMemcpyDeviceToHost, st));      // (one frame: a plain copy — see orb_collect)
+        else HIP_TRY(ctx, hipMemcpy2DAsync(cur, (size_t)width_el * el, src, spitch_el * el, (size_t)width_el * el, n_frames, hipMemcpyDeviceToHost, st));
         segs.push_back(Seg{dst, dpitch_el * el, cur, el, width_el}); cur += (size_t)n_frames * width_el * el;
         return VIDO_OK;
     };

@@ -282,6 +282,7 @@ class EndToEnd:
         # the networks write at most two frames ahead.  VIDO_TRACK_COPY_MAPS=1 keeps the copies (6.1 MB device-to-device per frame).
         if handover == "device" and hasattr(system, "SetZeroCopyMaps"):
             system.SetZeroCopyMaps(not _os.environ.get("VIDO_TRACK_COPY_MAPS"))
+        self._prefetch = handover == "device" and hasattr(system, "PrefetchImageDevice") and not _os.environ.get("VIDO_TRACK_NO_PREFETCH")
         h, w = nodes.h, nodes.w; dev = nodes.dev
         pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
         self.host = [dict(bgr=pin((h, w, 3), torch.uint8), flow=pin((h, w, 2), torch.float32), depth=pin((h, w), torch.float32), mask=pin((h, w), torch.int32),
@@ -302,7 +303,7 @@ class EndToEnd:
             item = self.q.get()
             if item is None:
                 return
-            k, slot, ev = item
+            k, slot, ev, img_ev = item
             try:
                 if self.err is not None:                                 # a failed frame stops the sequence: later frames are drained, not tracked on a broken System
                     continue
@@ -310,6 +311,10 @@ class EndToEnd:
                 hb, db = self.host[slot], self.dev[slot]
                 T = None
                 if self.handover == "device":
+                    # (round 6) the ORB extraction needs nothing but the image: it goes onto the tracker's stream BEFORE the wait for the frame's networks and runs beside their
+                    # tail, instead of starting — as the frame's first heavy tracker work — against the just-enqueued networks of frame k + 1 (VIDO_TRACK_NO_PREFETCH=1: as before)
+                    if self._prefetch and not _os.environ.get("VIDO_E2E_SKIP_TRACK"):
+                        self.system.PrefetchImageDevice(db["bgr"].data_ptr(), 3, self.nodes.w, self.nodes.h, img_ev.cuda_event)
                     if self.nodes.g_det is not None:                     # the static head's overflow flag (rare): needs the frame's counts, i.e. a host wait for this one event
                         ev.synchronize()
                         self._redo_if_overflowed(slot)
@@ -364,6 +369,7 @@ class EndToEnd:
         hb["bgr"].numpy()[...] = bgr
         cur = db["bgr"]
         cur.copy_(hb["bgr"], non_blocking=True)                          # the only upload of the frame on the network side
+        img_ev = torch.cuda.Event(); img_ev.record()                     # the image is on the device: all the tracker's ORB extraction needs (prefetched in _track_loop)
         if given is not None:
             hb["depth"].numpy()[...] = given[0]; hb["flow"].numpy()[...] = given[1]; hb["mask"].numpy()[...] = given[2]
             if self.handover == "device":                                # the stand-in maps go up next to the frame (feed == "nets" uploads nothing but the frame)
@@ -395,7 +401,7 @@ class EndToEnd:
         self._alive = (flow, depth, mask, labels)
         self.prev = cur
         self.t_net.append((_time.perf_counter() - t0) * 1e3)
-        self.q.put((self.k, slot, done))                                 # blocks while the tracker is still two frames behind
+        self.q.put((self.k, slot, done, img_ev))                         # blocks while the tracker is still two frames behind
         self.k += 1
 
     def finish(self):

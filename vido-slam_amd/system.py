@@ -42,6 +42,7 @@ def _bind(lib):
     lib.vido_system_context.argtypes = [C.c_void_p]
     lib.vido_system_set_depth_noise_seed.argtypes = [C.c_void_p, C.c_uint]
     lib.vido_system_set_zero_copy_maps.argtypes = [C.c_void_p, C.c_int]
+    lib.vido_system_prefetch_image_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib._vido_system_bound = True
     return lib
 
@@ -87,6 +88,13 @@ class System:
         if rc != VIDO_OK:
             raise VidoError(rc, self.lib.vido_system_last_error(self.h).decode())
         return T
+
+    def PrefetchImageDevice(self, im_dev, channels, width, height, image_ready_event=None):
+        """Put the ORB extraction of the next TrackRGBDDevice call's image on the tracker's stream now (it needs nothing but the image): call it, on the thread that tracks,
+        while still waiting for the frame's networks; the track call for the same pointer then only collects (vido_system_prefetch_image_device)."""
+        rc = self.lib.vido_system_prefetch_image_device(self.h, C.c_void_p(im_dev), int(channels), int(width), int(height), C.c_void_p(image_ready_event) if image_ready_event else None)
+        if rc != 0:
+            raise VidoError(rc, self.lib.vido_system_last_error(self.h).decode())
 
     def SetZeroCopyMaps(self, on=True):
         """TrackRGBDDevice adopts the three device map buffers instead of copying them into the tracker's slots (6.1 MB of device-to-device copies per 640x480 frame): the
