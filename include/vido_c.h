@@ -370,6 +370,11 @@ int vido_wino3x3_bias_act(vido_ctx* ctx, const float* x, const float* u_packed, 
  * form the library recommends for a launch (VIDO_WINO_KSPLIT=0/4/2: never / always 1 / always 2 for under-filled launches);
  * the packed weight must be of the form the launch is given (form 1 packs 4-channel chunks for every cout).  The un-suffixed entries are form 0. */
 int vido_wino3x3_form(int n, int cin, int cout, int h, int w);
+/* Fully connected layer y[rows][outs] = leaky_relu(x[rows][k] w[outs][k]^T + bias, slope) in the split-fp16 arithmetic of vido_conv1x1_set_arith(0), split over k (csrc/fch.hip,
+ * round 6): the box head's fc6 (roi_heads/box_head/roi_box_feature_extractors.py:50-81).  w_packed: pack_conv1x1 layout 3 of w viewed as [outs][k][1][1]; part: scratch of
+ * vido_fc_h_splitk(rows, k, outs) x rows x outs floats.  vido_fc_h_splitk: 0 = shape not taken (outs % 128, k % (32 S)). */
+int vido_fc_h_splitk(int rows, int k, int outs);
+int vido_fc_h(vido_ctx* ctx, const float* x, const void* w_packed, const float* bias, float* part, float* y, int rows, int k, int outs, float slope);
 /* Dense 3x3 stride-1 `same` convolution + bias + leaky-ReLU as a DIRECT implicit GEMM in the split-fp16 arithmetic of vido_conv1x1_set_arith(0) (csrc/conv3x3h.hip, round 6):
  * the detector's chip-filling 256 -> 256 layers (FPN outputs and RPN head on P2 / P3: backbone/fpn.py:55-66, rpn/rpn.py:74-107; the mask head: roi_mask_feature_extractors.py).
  * x [n][cin][h][w], y [n][cout][h][w] f32 DEVICE; w_packed: two fp16 planes of the output channels scaled by powers of two, plane p of element (co, ci, dy, dx) at

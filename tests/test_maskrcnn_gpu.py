@@ -474,3 +474,30 @@ def test_direct_split_fp16_conv3x3_against_float64_and_the_winograd_kernel(vido,
     xb = torch.randn(1, 16, 16, 16); xb[0, 3, 5, 5] = 1e5
     ops.conv3x3_h_bias_act(xb.cuda(), pack_conv3x3_h(torch.randn(128, 16, 3, 3)).cuda(), None, 128, 1.0); torch.cuda.synchronize()
     assert ops.conv1x1_range_flag() == 1
+
+
+@pytest.mark.gpu
+def test_split_fp16_fully_connected_layer_against_float64_and_the_library(vido, ctx):
+    """csrc/fch.hip (the box head's fc6 / fc7 as split-fp16 GEMMs split over K) against float64 on the detector's two shapes, a ragged row count, a small layer and per-output
+    weight scales e^N(0,1): rms error (each output relative to its column's mean magnitude before the activation) <= 1.5 x the library's fp32 GEMM on the same input; the K split
+    of the host rule; shapes the kernel does not take answer 0; the range flag."""
+    from vido_slam_amd.nets.ops import HipOps, pack_conv1x1
+    ops = HipOps(ctx); lib = ops.ctx.lib
+    F = torch.nn.functional
+    assert lib.vido_fc_h_splitk(1000, 12544, 1024) == 4 and lib.vido_fc_h_splitk(1000, 1024, 1024) == 4 and lib.vido_fc_h_splitk(100, 12544, 1024) == 8 and lib.vido_fc_h_splitk(37, 64, 128) == 2
+    assert lib.vido_fc_h_splitk(1000, 12544, 1000) == 0 and lib.vido_fc_h_splitk(1000, 48, 128) == 0 and lib.vido_fc_h_splitk(0, 64, 128) == 0
+    for rows, k, outs, slope in ((1000, 12544, 1024, 0.0), (1000, 1024, 1024, 0.0), (333, 2048, 256, 0.1), (37, 64, 128, 1.0)):
+        g = torch.Generator().manual_seed(k + rows)
+        x = torch.relu(torch.randn(rows, k, generator=g)); w = torch.randn(outs, k, generator=g) / k ** 0.5 * torch.exp(torch.randn(outs, 1, generator=g)); b = torch.randn(outs, generator=g)
+        pre = x.double() @ w.double().t() + b.double(); ref = F.leaky_relu(pre, slope); sc = pre.abs().mean(0, keepdim=True)
+        yh = ops.fc_h(x.cuda(), pack_conv1x1(w.reshape(outs, k, 1, 1), 3).cuda(), b.cuda(), outs, slope)
+        yl = F.leaky_relu(F.linear(x.cuda(), w.cuda(), b.cuda()), slope)
+        eh, el = (float(((y.cpu().double() - ref) / sc).pow(2).mean().sqrt()) for y in (yh, yl))
+        assert eh <= 1.5 * el and eh < 1e-6, (rows, k, outs, eh, el)
+        lin = torch.nn.Linear(k, outs); lin.weight.data.copy_(w); lin.bias.data.copy_(b); lin = lin.cuda()
+        assert torch.equal(ops.fc_h_linear(lin, x.cuda(), slope), yh)
+    torch.cuda.synchronize()
+    assert ops.conv1x1_range_flag() == 0
+    xb = torch.randn(130, 64); xb[5, 7] = 1e5
+    ops.fc_h(xb.cuda(), pack_conv1x1(torch.randn(128, 64, 1, 1), 3).cuda(), None, 128, 1.0); torch.cuda.synchronize()
+    assert ops.conv1x1_range_flag() == 1

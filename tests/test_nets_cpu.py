@@ -263,6 +263,16 @@ def test_conv1x1_tile_form_is_chosen_by_rounds_of_workgroups():
         assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == str(want), (tn, out.stdout, out.stderr[-500:])
 
 
+def test_fc_h_split_rule_answers_without_a_gpu():
+    """vido_fc_h_splitk (host side of csrc/fch.hip): the smallest K split of 1, 2, 4, 8 that gives >= 256 workgroups of 128 x 128 outputs — bounded by divisibility (an even number
+    of 16-feature steps per split) — and 0 for shapes the kernel does not take."""
+    from vido_slam_amd.host import load_library
+    lib = load_library()
+    assert lib.vido_fc_h_splitk(1000, 12544, 1024) == 4 and lib.vido_fc_h_splitk(1000, 1024, 1024) == 4 and lib.vido_fc_h_splitk(4000, 1024, 1024) == 1
+    assert lib.vido_fc_h_splitk(100, 12544, 1024) == 8 and lib.vido_fc_h_splitk(1000, 96, 128) == 1 and lib.vido_fc_h_splitk(1000, 64, 128) == 2
+    assert lib.vido_fc_h_splitk(1000, 12544, 1000) == 0 and lib.vido_fc_h_splitk(1000, 40, 128) == 0 and lib.vido_fc_h_splitk(0, 64, 128) == 0 and lib.vido_fc_h_splitk(1000, 64, 64) == 0
+
+
 def test_strided_grouped_conv_plan_answers_without_a_gpu():
     """vido_gconv3x3_s2_supported (host side of csrc/gconv.hip::k_gconv3x3_s2_m32 / _m16): the detector's three strided conv2 shapes have a kernel; a width that is not a
     multiple of 4, 24 channels per group, and a band that does not fit two LDS buffers are refused (the caller keeps the library convolution)."""

@@ -415,7 +415,15 @@ class _BoxFeatures(nn.Module):             # roi_box_feature_extractors.py:50-81
 
     def forward(self, feats, boxes):
         x = self.pooler(feats, boxes).flatten(1)
-        return F.relu(self.fc7(F.relu(self.fc6(x))))
+        ops = self.pooler.ops
+        # fc6 (12544 -> 1024 over the proposals: the largest library launch of the detector, 217 us) and fc7 (1024 -> 1024, 32 us) as split-fp16 GEMMs split over K
+        # (csrc/fch.hip: 96 / 23 us); below 128 rows (the dynamic head on a few detections) the library's launch is as fast
+        use = ops is not None and hasattr(ops, "fc_h_linear") and x.shape[0] >= 128
+        y = ops.fc_h_linear(self.fc6, x, 0.0) if use else None
+        if y is None:
+            y = F.relu(self.fc6(x))
+        z = ops.fc_h_linear(self.fc7, y, 0.0) if use else None
+        return z if z is not None else F.relu(self.fc7(y))
 
 
 class _BoxPredictor(nn.Module):            # roi_box_predictors.py:35-57

@@ -319,6 +319,33 @@ class HipOps:
                                                              C.c_void_p(out.data_ptr()), int(N), int(cin), int(cout), int(H), int(W), C.c_float(slope)))
         return out
 
+    def fc_h(self, x, w_packed, bias, outs, slope=1.0):
+        """leaky_relu(x @ w.T + bias, slope) for x [rows, k] f32 as a split-fp16 matrix-pipe GEMM split over k (csrc/fch.hip); w_packed = pack_conv1x1(w[:, :, None, None], 3).
+        None when the library does not take the shape."""
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 2
+        rows, k = int(x.shape[0]), int(x.shape[1])
+        S = int(self.ctx.lib.vido_fc_h_splitk(rows, k, int(outs)))
+        if S <= 0:
+            return None
+        assert w_packed.dtype == torch.int16 and w_packed.numel() == 2 * outs * (k + 1), "fc_h: weight not packed (pack_conv1x1(w[:, :, None, None], 3))"
+        part = torch.empty((S, rows, outs), device=x.device, dtype=torch.float32); y = torch.empty((rows, outs), device=x.device, dtype=torch.float32)
+        self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * rows * k * outs
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_fc_h(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(w_packed.data_ptr()), C.c_void_p(bias.data_ptr()) if bias is not None else None,
+                                               C.c_void_p(part.data_ptr()), C.c_void_p(y.data_ptr()), rows, k, int(outs), C.c_float(slope)))
+        return y
+
+    def fc_h_linear(self, lin, x, slope=1.0):
+        """nn.Linear `lin` + activation through fc_h when the layer has that form (outputs a multiple of 128, inputs a multiple of 32 S), else None; the packed weight is cached
+        on the module and rebuilt when the weight tensor changes."""
+        w = lin.weight
+        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or os.environ.get("VIDO_NO_FC_H") or int(self.ctx.lib.vido_fc_h_splitk(int(x.shape[0]), int(w.shape[1]), int(w.shape[0]))) <= 0:
+            return None
+        key = (w.data_ptr(), w._version, str(x.device))
+        if getattr(lin, "_fch_key", None) != key:
+            lin._fch_w = pack_conv1x1(w.detach().reshape(int(w.shape[0]), int(w.shape[1]), 1, 1), 3).to(x.device); lin._fch_key = key
+        return self.fc_h(x.contiguous(), lin._fch_w, lin.bias, int(w.shape[0]), slope)
+
     def conv_direct_conv(self, conv, x, slope):
         """The convolution `conv` (nn.Conv2d: groups 1, dilation 1, zero padding, a k x k of csrc/convdirect.hip) + bias + activation as ONE direct implicit-GEMM launch on
         the matrix pipe, else None.  The packed weight is cached on the module and rebuilt when the weight tensor changes."""
@@ -568,12 +595,12 @@ def split_f16x2(w):
     w = w.float()
     m = w.abs().amax(1)
     _, ex = torch.frexp(torch.where(m > 0, m, torch.ones_like(m)))          # m = mant 2^ex, mant in [0.5, 1)
-    e = torch.where(m > 0, 15 - ex, torch.zeros_like(ex)).clamp(-100, 100)
-    one = torch.ones_like(m)
-    ws = w * torch.ldexp(one, e)[:, None]
+    e = torch.where(m > 0, 15 - ex, torch.zeros_like(ex)).clamp(-100, 100).to(torch.int32)
+    pow2 = lambda k: ((k + 127) << 23).view(torch.float32)                  # 2^k from its bit pattern: exact on every device (ldexp goes through pow on some)
+    ws = w * pow2(e)[:, None]
     h = ws.to(torch.float16)
     l = ((ws - h.float()) * 2048.0).to(torch.float16)
-    return h, l, torch.ldexp(one, -e)
+    return h, l, pow2(-e)
 
 
 def pack_conv1x1(w, layout=0):
