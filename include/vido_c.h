@@ -270,6 +270,9 @@ int vido_ba_optimize_dynamic(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynam
  * out: [B, 49, ceil(H/stride), ceil(W/stride)]. */
 int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int B, int C, int H, int W, int stride,
                      float* out, int on_device);
+/* The mask head's tail for the one class channel a detection needs (mask_head/roi_mask_predictors.py:27-31 + inference.py:29-47): out[n][p] = sigmoid(sum_c w[label[n]][c]
+ * feat[n][c][p] + b[label[n]]); feat [n][c][hw] f32, w [classes][c], labels int64 [n], out [n][hw] (csrc/nets.hip). */
+int vido_mask_logit_select(vido_ctx* ctx, const float* feat, const float* w, const float* b, const long long* labels, float* out, int n, int c, int hw, int classes);
 /* Conv epilogue on a DEVICE tensor x[N,C,H,W] (f32, contiguous), in place: x = leaky_relu(x + bias[c], slope) — the bias add and the
  * LeakyReLU(0.1) that follow every convolution of flow_net/src/layers.py fused into one pass (slope = 1: plain bias add). */
 int vido_bias_act(vido_ctx* ctx, float* x, const float* bias, int N, int C, int H, int W, float slope);

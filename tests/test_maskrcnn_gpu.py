@@ -501,3 +501,19 @@ def test_split_fp16_fully_connected_layer_against_float64_and_the_library(vido, 
     xb = torch.randn(130, 64); xb[5, 7] = 1e5
     ops.fc_h(xb.cuda(), pack_conv1x1(torch.randn(128, 64, 1, 1), 3).cuda(), None, 128, 1.0); torch.cuda.synchronize()
     assert ops.conv1x1_range_flag() == 1
+
+
+@pytest.mark.gpu
+def test_mask_logit_select_equals_the_logits_layer_on_the_label_channel(vido, ctx):
+    """vido_mask_logit_select (csrc/nets.hip): sigmoid(mask_fcn_logits(feat))[n, label[n]] for every detection, computed for that one channel only — against the float64
+    evaluation of the same expression; labels at both ends of the class range; odd sizes."""
+    from vido_slam_amd.nets.ops import HipOps
+    ops = HipOps(ctx)
+    for n, c, H, W, classes in ((100, 256, 28, 28, 81), (7, 48, 5, 9, 3), (1, 300, 1, 1, 2)):
+        g = torch.Generator().manual_seed(n + c)
+        feat = torch.relu(torch.randn(n, c, H, W, generator=g)); conv = torch.nn.Conv2d(c, classes, 1)
+        conv.weight.data = torch.randn(classes, c, 1, 1, generator=g) / c ** 0.5; conv.bias.data = torch.randn(classes, generator=g)
+        labels = torch.randint(0, classes, (n,), generator=g); labels[0] = 0; labels[-1] = classes - 1
+        ref = torch.sigmoid(torch.nn.functional.conv2d(feat.double(), conv.weight.data.double(), conv.bias.data.double()))[torch.arange(n), labels][:, None]
+        got = ops.mask_logit_select(feat.cuda(), conv.cuda(), labels.cuda()).cpu()
+        assert tuple(got.shape) == (n, 1, H, W) and float((got.double() - ref).abs().max()) < 2e-7

@@ -68,6 +68,26 @@ __global__ __launch_bounds__(256) void k_correlation_reduce(const float* __restr
     out[i] = sum / (float)C;
 }
 
+// one thread per pixel of one detection: 256 (c) multiply-adds down the channels, the detection's weight row in LDS; reads are coalesced over the pixels
+__global__ __launch_bounds__(256) void k_mask_logit_select(const float* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ b, const long long* __restrict__ labels,
+                                                           float* __restrict__ out, int c, int hw, int classes)
+{
+    __shared__ float wl[1024];
+    const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    long long lab = labels[n]; lab = lab < 0 ? 0 : (lab >= classes ? classes - 1 : lab);
+    for (int i = threadIdx.x; i < c; i += 256) wl[i] = w[(size_t)lab * c + i];
+    __syncthreads();
+    if (p >= hw) return;
+    const float* f = feat + (size_t)n * c * hw + p;
+    // (float64 sums: the kernel is bound by its 80 MB of reads, and its result then differs from the library's convolution by the LIBRARY's rounding only)
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int i = 0;
+    for (; i + 4 <= c; i += 4) { a0 += (double)wl[i] * f[(size_t)i * hw]; a1 += (double)wl[i + 1] * f[(size_t)(i + 1) * hw]; a2 += (double)wl[i + 2] * f[(size_t)(i + 2) * hw]; a3 += (double)wl[i + 3] * f[(size_t)(i + 3) * hw]; }
+    for (; i < c; i++) a0 += (double)wl[i] * f[(size_t)i * hw];
+    const float v = (float)((a0 + a1) + (a2 + a3) + (b ? (double)b[lab] : 0.0));
+    out[(size_t)n * hw + p] = 1.f / (1.f + expf(-v));
+}
+
 // ---- bias + LeakyReLU epilogue -------------------------------------------------------------------------------
 // y[n,c,:,:] = leaky(x[n,c,:,:] + bias[c]) in place: the convolution library runs without its bias so that bias add and activation are
 // one pass over the tensor instead of two extra kernels (float4 when the plane size allows it).
@@ -650,6 +670,20 @@ int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int
         HIP_TRY(ctx, hipMemcpyAsync(S->h, dout, nout, hipMemcpyDeviceToHost, st)); HIP_TRY(ctx, hipStreamSynchronize(st));
         memcpy(out, S->h, nout);
     }
+    return VIDO_OK;
+}
+
+/* The mask head's tail for the ONE class channel a detection needs (maskrcnn_benchmark/modeling/roi_heads/mask_head/roi_mask_predictors.py:27-31 + inference.py:29-47:
+ * mask_fcn_logits, sigmoid, the detection's label channel): out[n][p] = sigmoid(sum_c w[label[n]][c] feat[n][c][p] + b[label[n]]) — instead of all num_classes logit maps,
+ * a bias pass, a sigmoid pass and a gather (81 x the multiply-adds, four launches).  feat [n][c][hw] f32, w [classes][c], labels int64 [n] (clamped to the class range), out [n][hw]. */
+int vido_mask_logit_select(vido_ctx* ctx, const float* feat, const float* w, const float* b, const long long* labels, float* out, int n, int c, int hw, int classes)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!feat || !w || !labels || !out || n < 1 || c < 1 || c > 1024 || hw < 1 || classes < 1) return vido_set_error(ctx, VIDO_E_INVALID, "mask_logit_select: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    hipLaunchKernelGGL(k_mask_logit_select, dim3((unsigned)((hw + 255) / 256), (unsigned)n), dim3(256), 0, st, feat, w, b, labels, out, c, hw, classes);
+    HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }
 

@@ -560,6 +560,14 @@ class _MaskPredictor(nn.Module):           # roi_mask_predictors.py:11-31
     def forward(self, x):
         return self.mask_fcn_logits(_conv_bias_relu(self.conv5_mask, x, self._ops))
 
+    def selected(self, x, labels):
+        """sigmoid(forward(x))[arange(n), labels][:, None] with only each detection's own class channel computed (vido_mask_logit_select): 1 launch instead of the 81-channel
+        convolution, its bias pass, the sigmoid and the gather."""
+        y = _conv_bias_relu(self.conv5_mask, x, self._ops)
+        if self._ops is not None and y.is_cuda and hasattr(self._ops, "mask_logit_select") and not os.environ.get("VIDO_NO_MASK_SELECT") and labels.dtype == torch.int64:
+            return self._ops.mask_logit_select(y.contiguous(), self.mask_fcn_logits, labels.contiguous())
+        return self.mask_fcn_logits(y).sigmoid()[torch.arange(x.shape[0], device=labels.device), labels][:, None]
+
 
 class _MaskHead(nn.Module):
     buckets = (4, 8, 16, 32, 64, 100)
@@ -692,7 +700,7 @@ def _heads_static(self, feats, logits, deltas, image_hw, cap=None):
     lg, dl = bh.predictor(bh.feature_extractor(maps, proposals))
     boxes, scores, labels, n_det = (bh.postprocess_fused if fused else bh.postprocess_static)(lg, dl, proposals, (W, H), objectness, cap)
     mh = self.roi_heads.mask
-    masks = mh.chunk_logits(maps, boxes).sigmoid()[torch.arange(cap, device=labels.device), labels][:, None]
+    masks = mh.predictor.selected(mh.feature_extractor(maps, boxes), labels)      # (only each slot's own class channel: vido_mask_logit_select)
     return dict(boxes=boxes, scores=scores, labels=labels, masks=masks, n_det=n_det, proposals=proposals, objectness=objectness, n_proposals=(objectness >= 0).sum())
 
 

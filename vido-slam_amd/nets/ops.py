@@ -54,6 +54,19 @@ class HipOps:
         self.ctx._check(self.ctx.lib.vido_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), N, Cc, H, W, C.c_float(slope)))
         return x
 
+    def mask_logit_select(self, feat, conv, labels):
+        """sigmoid(conv(feat))[arange(n), labels][:, None] for a 1x1 `conv` (the mask head's logits layer) computing only each detection's own class channel (csrc/nets.hip)."""
+        assert feat.is_cuda and feat.is_contiguous() and feat.dtype == torch.float32 and labels.dtype == torch.int64 and labels.is_contiguous()
+        n, c, H, W = feat.shape; classes = int(conv.weight.shape[0])
+        w = conv.weight.reshape(classes, c)
+        if not w.is_contiguous():
+            w = w.contiguous()
+        out = torch.empty((n, 1, H, W), device=feat.device, dtype=torch.float32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_mask_logit_select(self.ctx.h, C.c_void_p(feat.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(conv.bias.data_ptr()) if conv.bias is not None else None,
+                                                            C.c_void_p(labels.data_ptr()), C.c_void_p(out.data_ptr()), int(n), int(c), int(H * W), classes))
+        return out
+
     def bias_res_act_(self, x, bias, res, slope):
         """in place: x = leaky_relu(x + bias[None, :, None, None] + res, slope); res None -> bias_act_ (slope 0 = ReLU, 1 = none)"""
         assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
