@@ -113,7 +113,10 @@ def test_static_detector_head_equals_the_dynamic_one(vido):
             n = int(sta["n_det"])
             assert n == len(dyn["boxes"]) and 0 < n <= 100
             assert torch.equal(sta["labels"][:n], dyn["labels"]) and torch.equal(sta["scores"][:n], dyn["scores"]) and torch.equal(sta["boxes"][:n], dyn["boxes"])
-            assert float((sta["masks"][:n] - dyn["masks"]).abs().max()) < 1e-4                     # the mask head sees batch 100 instead of a bucket: other MIOpen kernels
+            # the mask head sees batch 100 instead of a bucket: its four 3x3 layers take different kernels (direct split-fp16 with 16-row or 8-row blocks, Winograd below 128
+            # workgroups), the tail computes one class channel with float64 sums instead of 81 with fp32: probabilities equal to 1.5e-4 (measured: 1.0e-4 .. 1.5e-4 box to box;
+            # they are thresholded at 0.5 — the label images below differ in isolated pixels only)
+            assert float((sta["masks"][:n] - dyn["masks"]).abs().max()) < 5e-4
             assert bool((sta["labels"][n:] == 0).all()) and bool((sta["boxes"][n:] == 0).all())
             img_s, lab_s, n_lab, n_det = nets.analyse_image_static(net, feats, logits, deltas, (480, 640), feed=nodes.mask_feed, confidence=nodes.confidence)
             img_d, lab_d = nets.analyse_image(net, bgr, feed=nodes.mask_feed, confidence=nodes.confidence, trunk=nodes.g_trunk)
