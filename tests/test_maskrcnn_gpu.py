@@ -517,3 +517,24 @@ def test_mask_logit_select_equals_the_logits_layer_on_the_label_channel(vido, ct
         ref = torch.sigmoid(torch.nn.functional.conv2d(feat.double(), conv.weight.data.double(), conv.bias.data.double()))[torch.arange(n), labels][:, None]
         got = ops.mask_logit_select(feat.cuda(), conv.cuda(), labels.cuda()).cpu()
         assert tuple(got.shape) == (n, 1, H, W) and float((got.double() - ref).abs().max()) < 2e-7
+
+
+@pytest.mark.gpu
+def test_roi_levels_equals_the_level_mapper_expression(vido, ctx):
+    """vido_roi_levels (one launch) against the torch expression of maskrcnn_benchmark's LevelMapper it replaces, on 200 000 random boxes, boxes at the level boundaries
+    (sides 112 / 224 / 448 / 896 -+ one ulp), degenerate and huge boxes: identical levels."""
+    from vido_slam_amd.nets.ops import HipOps
+    ops = HipOps(ctx)
+    g = torch.Generator().manual_seed(4)
+    xy = torch.rand(200000, 2, generator=g) * 1000; wh = torch.exp(torch.rand(200000, 2, generator=g) * 9 - 1)
+    boxes = torch.cat([xy, xy + wh], 1)
+    edge = []
+    for side in (56.0, 112.0, 224.0, 448.0, 896.0):
+        for d in (-1e-3, -1e-4, 0.0, 1e-4, 1e-3):
+            edge.append([10.0, 20.0, 10.0 + side - 1 + d, 20.0 + side - 1])
+    boxes = torch.cat([boxes, torch.tensor(edge), torch.tensor([[0.0, 0.0, 0.0, 0.0], [5.0, 5.0, 4.0, 4.0], [0.0, 0.0, 1e5, 1e5], [0.0, 0.0, 0.5, 0.5]])]).cuda()
+    for k_min, k_max in ((2.0, 5.0), (3.0, 4.0)):
+        area = (boxes[:, 2] - boxes[:, 0] + 1) * (boxes[:, 3] - boxes[:, 1] + 1)
+        ref = torch.floor(4 + torch.log2(torch.sqrt(area) / 224 + 1e-6)).clamp(min=k_min, max=k_max).to(torch.int64) - int(k_min)
+        got = ops.roi_levels(boxes, k_min, k_max)
+        assert got.dtype == torch.int32 and torch.equal(got.to(torch.int64), ref)

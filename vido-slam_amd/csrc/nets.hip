@@ -68,6 +68,20 @@ __global__ __launch_bounds__(256) void k_correlation_reduce(const float* __restr
     out[i] = sum / (float)C;
 }
 
+// LevelMapper of the FPN pooler (maskrcnn_benchmark/modeling/poolers.py:11-45) for every box in ONE launch — the same fp32 operations in the same order as the torch
+// expression it replaces (floor(4 + log2(sqrt(area) / 224 + 1e-6)) clamped to [k_min, k_max], minus k_min), which was fourteen element-wise launches per pooler call
+__global__ void k_roi_levels(const float* __restrict__ boxes, int n, float k_min, float k_max, int* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x1 = boxes[4 * i], y1 = boxes[4 * i + 1], x2 = boxes[4 * i + 2], y2 = boxes[4 * i + 3];
+    const float area = __fmul_rn(__fadd_rn(__fsub_rn(x2, x1), 1.f), __fadd_rn(__fsub_rn(y2, y1), 1.f));
+    const float t = __fadd_rn(__fdiv_rn(__fsqrt_rn(area), 224.f), 1e-6f);
+    float l = floorf(__fadd_rn(4.f, log2f(t)));
+    l = fminf(fmaxf(l, k_min), k_max);                         // (a NaN area — never produced by the box decoder — maps to k_min like torch's clamp of NaN would not; boxes are finite)
+    out[i] = (int)l - (int)k_min;
+}
+
 // one thread per pixel of one detection: 256 (c) multiply-adds down the channels, the detection's weight row in LDS; reads are coalesced over the pixels
 __global__ __launch_bounds__(256) void k_mask_logit_select(const float* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ b, const long long* __restrict__ labels,
                                                            float* __restrict__ out, int c, int hw, int classes)
@@ -670,6 +684,19 @@ int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int
         HIP_TRY(ctx, hipMemcpyAsync(S->h, dout, nout, hipMemcpyDeviceToHost, st)); HIP_TRY(ctx, hipStreamSynchronize(st));
         memcpy(out, S->h, nout);
     }
+    return VIDO_OK;
+}
+
+/* out[i] = the FPN level (0 .. k_max - k_min) of box i: LevelMapper of modeling/poolers.py:11-45 in one launch; boxes [n][4] f32 (x1, y1, x2, y2), out int32 [n]. */
+int vido_roi_levels(vido_ctx* ctx, const float* boxes, int n, float k_min, float k_max, int* out)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!boxes || !out || n < 0 || !(k_min <= k_max)) return vido_set_error(ctx, VIDO_E_INVALID, "roi_levels: bad arguments");
+    if (n == 0) return VIDO_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    hipLaunchKernelGGL(k_roi_levels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, boxes, n, k_min, k_max, out);
+    HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }
 

@@ -54,6 +54,16 @@ class HipOps:
         self.ctx._check(self.ctx.lib.vido_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), N, Cc, H, W, C.c_float(slope)))
         return x
 
+    def roi_levels(self, boxes, k_min, k_max):
+        """LevelMapper of the FPN pooler for boxes [n, 4] f32 -> int32 [n] in 0 .. k_max - k_min, one launch (csrc/nets.hip::k_roi_levels: the torch expression's fp32 operations
+        in the same order)."""
+        assert boxes.is_cuda and boxes.dtype == torch.float32
+        boxes = boxes.contiguous(); n = int(boxes.shape[0])
+        out = torch.empty((n,), device=boxes.device, dtype=torch.int32)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_roi_levels(self.ctx.h, C.c_void_p(boxes.data_ptr()), n, C.c_float(k_min), C.c_float(k_max), C.c_void_p(out.data_ptr())))
+        return out
+
     def mask_logit_select(self, feat, conv, labels):
         """sigmoid(conv(feat))[arange(n), labels][:, None] for a 1x1 `conv` (the mask head's logits layer) computing only each detection's own class channel (csrc/nets.hip)."""
         assert feat.is_cuda and feat.is_contiguous() and feat.dtype == torch.float32 and labels.dtype == torch.int64 and labels.is_contiguous()
