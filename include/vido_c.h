@@ -270,6 +270,8 @@ int vido_ba_optimize_dynamic(vido_ctx* ctx, vido_ba_problem* prob, vido_ba_dynam
  * out: [B, 49, ceil(H/stride), ceil(W/stride)]. */
 int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int B, int C, int H, int W, int stride,
                      float* out, int on_device);
+/* the static detector head's tail (confidence test, stable descending order by score, labels of the live slots, their count) in one launch: csrc/nets.hip::k_det_order */
+int vido_det_order(vido_ctx* ctx, const float* scores, const long long* labels, const int* n_det, float confidence, int cap, long long* order, long long* labels_out, long long* n_live);
 /* FPN level of every box (LevelMapper, modeling/poolers.py:11-45: floor(4 + log2(sqrt(area) / 224 + 1e-6)) clamped to [k_min, k_max], minus k_min) in one launch */
 int vido_roi_levels(vido_ctx* ctx, const float* boxes, int n, float k_min, float k_max, int* out);
 /* The mask head's tail for the one class channel a detection needs (mask_head/roi_mask_predictors.py:27-31 + inference.py:29-47): out[n][p] = sigmoid(sum_c w[label[n]][c]

@@ -538,3 +538,22 @@ def test_roi_levels_equals_the_level_mapper_expression(vido, ctx):
         ref = torch.floor(4 + torch.log2(torch.sqrt(area) / 224 + 1e-6)).clamp(min=k_min, max=k_max).to(torch.int64) - int(k_min)
         got = ops.roi_levels(boxes, k_min, k_max)
         assert got.dtype == torch.int32 and torch.equal(got.to(torch.int64), ref)
+
+
+
+@pytest.mark.gpu
+def test_det_order_equals_the_torch_tail_of_the_static_head(vido, ctx):
+    """vido_det_order (one launch) against the torch expressions of analyse_image_static it replaces: confidence test, stable descending sort with ties, labels of the live slots,
+    their count — random scores with ties, n_det below / at / above the slot count, cap 100 and 1."""
+    from vido_slam_amd.nets.ops import HipOps
+    ops = HipOps(ctx)
+    g = torch.Generator().manual_seed(8)
+    for cap, nd in ((100, 37), (100, 100), (100, 0), (100, 250), (1, 1), (64, 63)):
+        scores = (torch.randint(0, 40, (cap,), generator=g).float() / 40).cuda()      # many ties
+        labels = torch.randint(1, 81, (cap,), generator=g).cuda(); n_det = torch.tensor([nd], dtype=torch.int32).cuda()
+        for conf in (0.8, 0.0, 2.0):
+            live = (scores > conf) & (torch.arange(cap, device="cuda") < n_det[0])
+            order = torch.sort(torch.where(live, scores, scores.new_full((), -1.0)), descending=True, stable=True)[1]
+            lab = torch.where(live, labels, torch.zeros_like(labels))[order]
+            o2, l2, n2 = ops.det_order(scores, labels, n_det, conf)
+            assert torch.equal(o2, order) and torch.equal(l2, lab) and int(n2) == int(live.sum())

@@ -68,6 +68,30 @@ __global__ __launch_bounds__(256) void k_correlation_reduce(const float* __restr
     out[i] = sum / (float)C;
 }
 
+// The tail of the detector's static head (nets/maskrcnn.py::analyse_image_static; predictor.py:select_top_predictions + run_mask_rcnn.py:create_pixel_masks) in one launch:
+// live[i] = score[i] > confidence and i < n_det; order = stable descending sort of (live ? score : -1); labels_out[r] = live[order[r]] ? label[order[r]] : 0; n_live.
+// cap <= 1024 slots, one workgroup, rank by counting (a stable sort: ties keep their slot order, like torch.sort(stable=True)).
+__global__ __launch_bounds__(1024) void k_det_order(const float* __restrict__ scores, const long long* __restrict__ labels, const int* __restrict__ n_det, float confidence, int cap,
+                                                   long long* __restrict__ order, long long* __restrict__ labels_out, long long* __restrict__ n_live)
+{
+    __shared__ float key[1024];
+    __shared__ int cnt;
+    const int i = threadIdx.x;
+    if (i == 0) cnt = 0;
+    const int nd = *n_det;
+    bool live = false;
+    if (i < cap) { live = scores[i] > confidence && i < nd; key[i] = live ? scores[i] : -1.0f; }
+    __syncthreads();
+    if (i < cap) {
+        const float k = key[i]; int rank = 0;
+        for (int j = 0; j < cap; j++) { const float kj = key[j]; rank += (kj > k) || (kj == k && j < i); }
+        order[rank] = i; labels_out[rank] = live ? labels[i] : 0;
+        if (live) atomicAdd(&cnt, 1);
+    }
+    __syncthreads();
+    if (i == 0) *n_live = cnt;
+}
+
 // LevelMapper of the FPN pooler (maskrcnn_benchmark/modeling/poolers.py:11-45) for every box in ONE launch — the same fp32 operations in the same order as the torch
 // expression it replaces (floor(4 + log2(sqrt(area) / 224 + 1e-6)) clamped to [k_min, k_max], minus k_min), which was fourteen element-wise launches per pooler call
 __global__ void k_roi_levels(const float* __restrict__ boxes, int n, float k_min, float k_max, int* __restrict__ out)
@@ -684,6 +708,19 @@ int vido_correlation(vido_ctx* ctx, const float* first, const float* second, int
         HIP_TRY(ctx, hipMemcpyAsync(S->h, dout, nout, hipMemcpyDeviceToHost, st)); HIP_TRY(ctx, hipStreamSynchronize(st));
         memcpy(out, S->h, nout);
     }
+    return VIDO_OK;
+}
+
+/* The static head's tail in one launch (see k_det_order): scores f32 [cap], labels int64 [cap], n_det int32 [1] -> order int64 [cap] (slots in descending score order, the
+ * slots that fail the confidence test or lie past n_det behind them in slot order), labels_out int64 [cap] (0 for those), n_live int64 [1].  cap <= 1024. */
+int vido_det_order(vido_ctx* ctx, const float* scores, const long long* labels, const int* n_det, float confidence, int cap, long long* order, long long* labels_out, long long* n_live)
+{
+    if (!ctx) return VIDO_E_INVALID;
+    if (!scores || !labels || !n_det || !order || !labels_out || !n_live || cap < 1 || cap > 1024) return vido_set_error(ctx, VIDO_E_INVALID, "det_order: bad arguments (cap 1 .. 1024)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
+    hipLaunchKernelGGL(k_det_order, dim3(1), dim3(1024), 0, st, scores, labels, n_det, confidence, cap, order, labels_out, n_live);
+    HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
 }
 

@@ -726,11 +726,17 @@ def analyse_image_static(net, feats, logits, deltas, out_hw, feed=(1088, 800), c
     if key not in cache:
         cache[key] = out["boxes"].new_tensor([rw, rh, rw, rh])
     boxes = out["boxes"] * cache[key]
-    live = (out["scores"] > confidence) & (torch.arange(cap, device=boxes.device) < out["n_det"])
-    order = torch.sort(torch.where(live, out["scores"], out["scores"].new_full((), -1.0)), descending=True, stable=True)[1]
-    labels = torch.where(live, out["labels"], torch.zeros_like(out["labels"]))[order]
-    img = net.rpn.ops.mask_label_image(out["masks"][order], boxes[order], labels, H, W)
-    return img, labels, live.sum(), out["n_det"]
+    ops = net.rpn.ops
+    nd = out["n_det"]
+    if hasattr(ops, "det_order") and cap <= 1024 and nd.dtype == torch.int32 and out["labels"].dtype == torch.int64 and not os.environ.get("VIDO_NO_DET_ORDER"):
+        order, labels, n_live = ops.det_order(out["scores"].contiguous(), out["labels"].contiguous(), nd.reshape(1), confidence)      # one launch instead of eleven
+    else:
+        live = (out["scores"] > confidence) & (torch.arange(cap, device=boxes.device) < nd)
+        order = torch.sort(torch.where(live, out["scores"], out["scores"].new_full((), -1.0)), descending=True, stable=True)[1]
+        labels = torch.where(live, out["labels"], torch.zeros_like(out["labels"]))[order]
+        n_live = live.sum()
+    img = ops.mask_label_image(out["masks"][order], boxes[order], labels, H, W)
+    return img, labels, n_live, out["n_det"]
 
 
 def image_to_feed(bgr, dev, feed=(1088, 800), ops=None):

@@ -54,6 +54,17 @@ class HipOps:
         self.ctx._check(self.ctx.lib.vido_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), N, Cc, H, W, C.c_float(slope)))
         return x
 
+    def det_order(self, scores, labels, n_det, confidence):
+        """(order int64 [cap], labels in that order with 0 for slots that fail `scores > confidence and slot < n_det`, number of live slots) — analyse_image_static's tail
+        in one launch (csrc/nets.hip::k_det_order); the order is torch.sort(where(live, scores, -1), descending=True, stable=True)."""
+        assert scores.is_cuda and scores.dtype == torch.float32 and labels.dtype == torch.int64 and n_det.dtype == torch.int32 and scores.is_contiguous() and labels.is_contiguous()
+        cap = int(scores.shape[0]); dev = scores.device
+        order = torch.empty((cap,), device=dev, dtype=torch.int64); lab = torch.empty((cap,), device=dev, dtype=torch.int64); n_live = torch.empty((), device=dev, dtype=torch.int64)
+        self._adopt_stream()
+        self.ctx._check(self.ctx.lib.vido_det_order(self.ctx.h, C.c_void_p(scores.data_ptr()), C.c_void_p(labels.data_ptr()), C.c_void_p(n_det.data_ptr()), C.c_float(confidence), cap,
+                                                    C.c_void_p(order.data_ptr()), C.c_void_p(lab.data_ptr()), C.c_void_p(n_live.data_ptr())))
+        return order, lab, n_live
+
     def roi_levels(self, boxes, k_min, k_max):
         """LevelMapper of the FPN pooler for boxes [n, 4] f32 -> int32 [n] in 0 .. k_max - k_min, one launch (csrc/nets.hip::k_roi_levels: the torch expression's fp32 operations
         in the same order)."""
