@@ -338,6 +338,11 @@ int vido_conv1x1_set_arith(int arith);
 /* non-zero when a split-fp16 launch on this context met an activation outside fp16's range since the last reset; read after the stream has been waited for */
 int vido_conv1x1_range_flag(vido_ctx* ctx, int reset);
 int vido_conv1x1_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, int hw, float slope);
+/* 2 x 2 stride-2 transposed convolution + bias + leaky-ReLU of a batch as one split-fp16 GEMM with a scatter epilogue (the mask head's conv5_mask,
+ * roi_heads/mask_head/roi_mask_predictors.py:17-31): x [n][cin][h][w] -> y [n][cout][2 h][2 w]; w_packed: pack_conv1x1 layout 3 of [(2 a + b) cout + co][ci] = w[ci][co][a][b]
+ * (vido_slam_amd/nets/ops.py::pack_deconv2x2).  vido_deconv2x2_supported: cout % 128 == 0, cin % 32 == 0, (h w) % 4 == 0, n h w >= 128, split-fp16 arithmetic selected. */
+int vido_deconv2x2_supported(int n, int cin, int cout, int h, int w);
+int vido_deconv2x2_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, float* y, int n, int cin, int cout, int h, int w, float slope);
 /* ... with the residual at half the resolution [cout][h/2][w/2], added nearest-upsampled: the FPN's lateral convolution + top-down sum (backbone/fpn.py:55-66); h, w even */
 int vido_conv1x1_bias_up2_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual_half, float* y, int cin, int cout, int h, int w, float slope);
 

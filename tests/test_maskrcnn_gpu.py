@@ -557,3 +557,29 @@ def test_det_order_equals_the_torch_tail_of_the_static_head(vido, ctx):
             lab = torch.where(live, labels, torch.zeros_like(labels))[order]
             o2, l2, n2 = ops.det_order(scores, labels, n_det, conf)
             assert torch.equal(o2, order) and torch.equal(l2, lab) and int(n2) == int(live.sum())
+
+
+
+@pytest.mark.gpu
+def test_deconv2x2_as_split_fp16_gemm_against_float64_and_the_library(vido, ctx):
+    """vido_deconv2x2_bias_act (csrc/conv1x1.hip, RES 3: the mask head's transposed convolution as one GEMM with a scatter epilogue) against float64 conv_transpose2d: rms error
+    (per output channel's mean magnitude) <= 1.5 x the library's fp32 on the same input; the detector's shape, a small batch of odd maps, ReLU / none, no bias."""
+    from vido_slam_amd.nets.ops import HipOps
+    ops = HipOps(ctx)
+    F = torch.nn.functional
+    for n, cin, cout, H, W, slope, with_bias in ((100, 256, 256, 14, 14, 0.0, True), (3, 64, 128, 6, 10, 1.0, False), (1, 32, 128, 16, 8, 0.1, True)):
+        g = torch.Generator().manual_seed(n + cin)
+        conv = torch.nn.ConvTranspose2d(cin, cout, 2, 2, 0, bias=with_bias)
+        conv.weight.data = torch.randn(cin, cout, 2, 2, generator=g) / cin ** 0.5 * torch.exp(torch.randn(1, cout, 1, 1, generator=g))
+        if with_bias: conv.bias.data = torch.randn(cout, generator=g)
+        x = torch.relu(torch.randn(n, cin, H, W, generator=g))
+        pre = F.conv_transpose2d(x.double(), conv.weight.data.double(), conv.bias.data.double() if with_bias else None, 2); ref = F.leaky_relu(pre, slope)
+        sc = pre.abs().mean((0, 2, 3), keepdim=True)
+        convc = conv.cuda()
+        got = ops.deconv2x2_conv(convc, x.cuda(), slope)
+        assert got is not None and tuple(got.shape) == (n, cout, 2 * H, 2 * W)
+        lib = F.leaky_relu(convc(x.cuda()), slope)
+        eg, el = (float(((y.cpu().double() - ref) / sc).pow(2).mean().sqrt()) for y in (got, lib))
+        assert eg <= 1.5 * el and eg < 1e-6, (n, cin, cout, H, W, eg, el)
+    assert not ops.ctx.lib.vido_deconv2x2_supported(1, 32, 64, 16, 8) and not ops.ctx.lib.vido_deconv2x2_supported(1, 32, 128, 3, 3)
+    torch.cuda.synchronize(); assert ops.conv1x1_range_flag() == 0

@@ -29,7 +29,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define C1_TM 128
 #define C1_TN 128
 
-struct C1Args { const float* x; const float* wp; const float* bias; const float* res; float* y; int M, N, K, mt, total, nchunk; float slope; unsigned xbytes, wbytes; int W; unsigned* range_flag; };
+struct C1Args { const float* x; const float* wp; const float* bias; const float* res; float* y; int M, N, K, mt, total, nchunk; float slope; unsigned xbytes, wbytes; int W; unsigned* range_flag; int hwimg, c4; };      // hwimg > 0 (k_conv1x1_b3 only): x is a BATCH [img][K][hwimg] and position p = img hwimg + hw; c4: RES 3
 
 // RES: 1 a residual [cout][H*W] is added, 2 a residual at HALF the resolution [cout][H/2][W/2] is added nearest-upsampled (the FPN's top-down path: fpn.py
 // `F.interpolate(last_inner, scale_factor=2, mode="nearest") + inner_lateral`); KC: input channels per chunk and barrier (64: 128 KB of LDS, 128 matrix instructions per
@@ -346,9 +346,13 @@ __global__ __launch_bounds__(256 * G, (G == 1 && RB != 6) ? 2 : G) void k_conv1x
     unsigned abase[3], bvo[2];                                            // (abase[NP]: an array of template-dependent size captured by a lambda makes the HOST pass drop the kernel's stub — silently)
 #pragma unroll
     for (int q = 0; q < NP; q++) { const int i = 4 * q + w, rb = i / NP, pl = i - NP * rb; abase[q] = 1024u * (unsigned)(((m0 >> 5) + rb) * ns * NP + pl); }
+    // (a batch: the four positions of a lane stay inside one image — hwimg % 4 == 0 —, a channel row is hwimg positions long and an image K rows; a position past the last
+    //  image lands past the descriptor's range like one past N does without a batch)
+    unsigned pbase = 4u * (unsigned)(n0 + 4 * (lane & 31)), rowb = 4u * (unsigned)A.N;
+    if (A.hwimg) { const int p = n0 + 4 * (lane & 31), img = p / A.hwimg; pbase = 4u * ((unsigned)img * (unsigned)A.K * (unsigned)A.hwimg + (unsigned)(p - img * A.hwimg)); rowb = 4u * (unsigned)A.hwimg; }
 #pragma unroll
-    for (int q = 0; q < 2; q++) bvo[q] = 4u * ((unsigned)((lane >> 5) + 2 * (4 * q + w)) * (unsigned)A.N + (unsigned)(n0 + 4 * (lane & 31)));
-    const unsigned bstep = 64u * (unsigned)A.N;
+    for (int q = 0; q < 2; q++) bvo[q] = (unsigned)((lane >> 5) + 2 * (4 * q + w)) * rowb + pbase;
+    const unsigned bstep = 16u * rowb;
     const int wofs = g * B3_SLOT + w * 1024;
     auto issue = [&](int T, int slot) {                                   // this wave's five pieces of its group's step of slot T
         char* S = L + slot * SLOTB + wofs;
@@ -486,14 +490,22 @@ __global__ __launch_bounds__(256 * G, (G == 1 && RB != 6) ? 2 : G) void k_conv1x
     const int q_out = n0 + 32 * w + (lane & 31);
     size_t rq = (size_t)q_out, rn = (size_t)A.N;
     if (RES == 2) { const int yy = q_out / A.W, xx = q_out - yy * A.W; rq = (size_t)(yy >> 1) * (A.W >> 1) + (xx >> 1); rn = (size_t)(A.N / A.W >> 1) * (A.W >> 1); }
+    // RES 3: a 2 x 2 stride-2 TRANSPOSED convolution as this GEMM — rows (tap a b, channel co) = 4 c4, positions (image, i, j) —: row tile -> one tap (c4 % 128 == 0), the output
+    // is y[img][co][2 i + a][2 j + b]; bias per co
+    size_t oq = (size_t)q_out, on = (size_t)A.N; int co_sub = 0;
+    if (RES == 3) {
+        const int tap = m0 / A.c4, img = q_out / A.hwimg, rem = q_out - img * A.hwimg, ii = rem / A.W, jj = rem - ii * A.W;
+        co_sub = tap * A.c4; on = (size_t)4 * A.hwimg;
+        oq = (size_t)img * A.c4 * on + (size_t)(2 * ii + (tap >> 1)) * (2 * A.W) + 2 * jj + (tap & 1);
+    }
     auto ep_load = [&](int rb, Ep& E) {
         const int co0 = m0 + 32 * rb + 4 * (lane >> 5);
         if (q_out < A.N) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int co = co0 + 8 * (r >> 2) + (r & 3);
-                E.bv[r] = A.bias ? A.bias[co] : 0.f;
-                E.rv[r] = RES ? A.res[(size_t)co * rn + rq] : 0.f;
+                E.bv[r] = A.bias ? A.bias[co - co_sub] : 0.f;
+                E.rv[r] = (RES == 1 || RES == 2) ? A.res[(size_t)co * rn + rq] : 0.f;
                 E.sv[r] = NP == 2 ? wsc[co] : 1.f;
             }
         }
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(256 * G, (G == 1 && RB != 6) ? 2 : G) void k_conv1x
             for (int r = 0; r < 16; r++) {
                 const int co = co0 + 8 * (r >> 2) + (r & 3);
                 const float v = (NP == 2 ? (v0[r] + ov[r]) * E.sv[r] : v0[r] + ov[r]) + E.bv[r] + E.rv[r];
-                A.y[(size_t)co * A.N + q_out] = fmaxf(v, v * A.slope);
+                A.y[(size_t)(co - co_sub) * on + oq] = fmaxf(v, v * A.slope);
             }
         }
     };
@@ -589,19 +601,21 @@ int vido_conv1x1_layout(int cin, int cout, int hw)
  * y != x), bias [cout] or NULL, residual NULL when there is none.  w_packed: the weight [cout][cin] in operand order — layout vido_conv1x1_layout(cin, cout, hw):
  *   0: element (co, k) at [co / 32][k / 8][32 * (k & 1) + co % 32][(k % 8) / 2];   1: at [co / 16][k / 16][16 * (k & 3) + co % 16][(k % 16) / 4]
  * (vido_slam_amd/nets/ops.py::pack_conv1x1).  slope 0 = ReLU, 1 = none (0 <= slope <= 1).  Enqueues on the adopted stream; capturable. */
-static int c1_launch(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, int res_mode, float* y, int cin, int cout, int hw, int w, float slope)
+static int c1_launch(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, int res_mode, float* y, int cin, int cout, int hw, int w, float slope,
+                     int hwimg = 0, int c4 = 0)
 {
     if (!ctx) return VIDO_E_INVALID;
     if (!x || !w_packed || !y || x == y || !vido_conv1x1_supported(cin, cout, hw) || slope < 0.f || slope > 1.f || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 3) || ((uintptr_t)w_packed & 15))
         return vido_set_error(ctx, VIDO_E_INVALID, "conv1x1: no kernel for %d -> %d channels at %d positions (or a pointer is misaligned, or slope outside [0, 1])", cin, cout, hw);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->has_ext_stream ? ctx->ext_stream : ctx->stream;
-    const int rm = residual ? res_mode : 0;
+    const int rm = res_mode == 3 ? 3 : (residual ? res_mode : 0);
     const int layout = vido_conv1x1_layout(cin, cout, hw);
+    if ((hwimg || rm == 3) && layout != 3) return vido_set_error(ctx, VIDO_E_INVALID, "conv1x1: the batch / transposed-convolution forms exist in the split-fp16 arithmetic only");
     if (layout >= 2) {
         const int np = layout == 3 ? 2 : 3;
         const int mt = cout / C1_TM, ntl = (hw + C1_TN - 1) / C1_TN, total = mt * ntl;
-        C1Args A{x, w_packed, bias, residual, y, cout, hw, cin, mt, total, cin / 16, slope, (unsigned)(4ll * cin * hw), (unsigned)(2ll * np * cin * cout), w, ctx->c1_range_flag};
+        C1Args A{x, w_packed, bias, residual, y, cout, hw, cin, mt, total, cin / 16, slope, (unsigned)(4ll * cin * hw), (unsigned)(2ll * np * cin * cout), w, ctx->c1_range_flag, hwimg, c4};
         // form: VIDO_CONV1X1_B3_FORM = 0 (default: by shape), 1 = <1, 6>, 2 = <2, 4>, 3 = <1, 4> two workgroups per CU
         static const int force_form = [] { const char* e = getenv("VIDO_CONV1X1_B3_FORM"); return e ? atoi(e) : 0; }();
         int form = force_form ? force_form : (cin >= 512 && total <= 320 ? 2 : 3);
@@ -614,6 +628,8 @@ static int c1_launch(vido_ctx* ctx, const float* x, const float* w_packed, const
             HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)RB_ * G_ * B3_SLOTB(NP_))))
             B3_ATTR(1, 6, 3); B3_ATTR(2, 4, 3); B3_ATTR(1, 4, 3); B3_ATTR(2, 5, 2); B3_ATTR(1, 5, 2); B3_ATTR(1, 4, 2); B3_ATTR(1, 3, 2);
 #undef B3_ATTR
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_conv1x1_b3<3, 2, 5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)5 * 2 * B3_SLOTB(2))));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_conv1x1_b3<3, 1, 5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)5 * 1 * B3_SLOTB(2))));
             attr3[ctx->device & 63] = true;
         }
         const dim3 grid(8 * ((total + 7) / 8));
@@ -621,7 +637,11 @@ static int c1_launch(vido_ctx* ctx, const float* x, const float* w_packed, const
             if (rm == 2) hipLaunchKernelGGL((k_conv1x1_b3<2, G_, RB_, NP_>), grid, blk, lds, st, A); else if (rm) hipLaunchKernelGGL((k_conv1x1_b3<1, G_, RB_, NP_>), grid, blk, lds, st, A); \
             else hipLaunchKernelGGL((k_conv1x1_b3<0, G_, RB_, NP_>), grid, blk, lds, st, A); } while (0)
         static const int rb_short = [] { const char* e = getenv("VIDO_CONV1X1_H2_RB"); return e ? atoi(e) : 5; }();      // (experiment: ring depth of the one-group fp16 form)
-        if (np == 2) { if (form == 2) B3_LAUNCH(2, 5, 2); else if (rb_short == 4) B3_LAUNCH(1, 4, 2); else if (rb_short == 3) B3_LAUNCH(1, 3, 2); else B3_LAUNCH(1, 5, 2); }
+        if (rm == 3) {      // (the transposed convolution: the fp16 form's two launch forms)
+            if (form == 2) hipLaunchKernelGGL((k_conv1x1_b3<3, 2, 5, 2>), grid, dim3(512), (size_t)5 * 2 * B3_SLOTB(2), st, A);
+            else hipLaunchKernelGGL((k_conv1x1_b3<3, 1, 5, 2>), grid, dim3(256), (size_t)5 * B3_SLOTB(2), st, A);
+        }
+        else if (np == 2) { if (form == 2) B3_LAUNCH(2, 5, 2); else if (rb_short == 4) B3_LAUNCH(1, 4, 2); else if (rb_short == 3) B3_LAUNCH(1, 3, 2); else B3_LAUNCH(1, 5, 2); }
         else if (form == 2) B3_LAUNCH(2, 4, 3); else if (form == 1) B3_LAUNCH(1, 6, 3); else B3_LAUNCH(1, 4, 3);
 #undef B3_LAUNCH
         HIP_TRY(ctx, hipGetLastError());
@@ -657,6 +677,21 @@ static int c1_launch(vido_ctx* ctx, const float* x, const float* w_packed, const
     else { if (rm == 2) hipLaunchKernelGGL((k_conv1x1<2, 32>), grid, blk, LDS32, st, A); else if (rm) hipLaunchKernelGGL((k_conv1x1<1, 32>), grid, blk, LDS32, st, A); else hipLaunchKernelGGL((k_conv1x1<0, 32>), grid, blk, LDS32, st, A); }
     HIP_TRY(ctx, hipGetLastError());
     return VIDO_OK;
+}
+
+/* 2 x 2 stride-2 transposed convolution + bias + leaky ReLU of a BATCH as one split-fp16 GEMM (round 6): the mask head's conv5_mask over the detections' 14 x 14 maps
+ * (maskrcnn_benchmark/modeling/roi_heads/mask_head/roi_mask_predictors.py:17-31).  y[n][co][2 i + a][2 j + b] = act(sum_ci x[n][ci][i][j] w[ci][co][a][b] + bias[co]):
+ * GEMM rows (tap a b, co) = 4 cout, columns (image, i, j); x [n][cin][h][w], y [n][cout][2 h][2 w] f32 DEVICE.  w_packed: pack_conv1x1 layout 3 of the matrix
+ * [(2 a + b) cout + co][ci] (vido_slam_amd/nets/ops.py::pack_deconv2x2).  Shapes: cout % 128 == 0, cin % 32 == 0, (h w) % 4 == 0, n h w >= 128. */
+int vido_deconv2x2_supported(int n, int cin, int cout, int h, int w)
+{
+    return n >= 1 && h >= 1 && w >= 1 && cout >= 128 && cout % 128 == 0 && (h * w) % 4 == 0 && (long long)n * h * w < (1ll << 28) && vido_conv1x1_supported(cin, 4 * cout, n * h * w)
+           && 16ll * n * cout * h * w < (1ll << 32) && vido_conv1x1_layout(cin, 4 * cout, n * h * w) == 3;
+}
+int vido_deconv2x2_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, float* y, int n, int cin, int cout, int h, int w, float slope)
+{
+    if (ctx && !vido_deconv2x2_supported(n, cin, cout, h, w)) return vido_set_error(ctx, VIDO_E_INVALID, "deconv2x2: no kernel for %d x %d -> %d channels at %d x %d", n, cin, cout, h, w);
+    return c1_launch(ctx, x, w_packed, bias, nullptr, 3, y, cin, 4 * cout, n * h * w, w, slope, h * w, cout);
 }
 
 int vido_conv1x1_bias_act(vido_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* residual, float* y, int cin, int cout, int hw, float slope)

@@ -267,6 +267,10 @@ def _conv_bias_relu(conv, x, ops):
         y = ops.wino3x3_conv(conv, x, 0.0)              # dense 3x3: Winograd on the matrix pipe with bias + ReLU in its epilogue (csrc/wino.hip)
         if y is not None:
             return y
+    if isinstance(conv, nn.ConvTranspose2d) and hasattr(ops, "deconv2x2_conv"):
+        y = ops.deconv2x2_conv(conv, x, 0.0)           # the mask head's 2 x 2 stride-2 transposed convolution: one split-fp16 GEMM with a scatter epilogue (csrc/conv1x1.hip)
+        if y is not None:
+            return y
     if isinstance(conv, nn.ConvTranspose2d):
         y = F.conv_transpose2d(x, conv.weight, None, conv.stride, conv.padding, conv.output_padding, conv.groups, conv.dilation)
     else:

@@ -54,6 +54,27 @@ class HipOps:
         self.ctx._check(self.ctx.lib.vido_bias_act(self.ctx.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), N, Cc, H, W, C.c_float(slope)))
         return x
 
+    def deconv2x2_conv(self, conv, x, slope):
+        """nn.ConvTranspose2d `conv` (2 x 2, stride 2, no padding) + bias + activation of a batch as one split-fp16 GEMM with a scatter epilogue (csrc/conv1x1.hip, RES 3), else
+        None; the packed weight is cached on the module."""
+        w = conv.weight
+        if (tuple(w.shape[2:]) != (2, 2) or tuple(conv.stride) != (2, 2) or tuple(conv.padding) != (0, 0) or tuple(conv.output_padding) != (0, 0) or tuple(conv.dilation) != (1, 1)
+                or conv.groups != 1 or not x.is_cuda or x.dtype != torch.float32 or os.environ.get("VIDO_NO_DECONV_H")):
+            return None
+        n, cin, H, W = (int(v) for v in x.shape); cout = int(w.shape[1])
+        if not self.ctx.lib.vido_deconv2x2_supported(n, cin, cout, H, W):
+            return None
+        key = (w.data_ptr(), w._version, str(x.device))
+        if getattr(conv, "_dc_key", None) != key:
+            conv._dc_w = pack_deconv2x2(w).to(x.device); conv._dc_key = key
+        out = torch.empty((n, cout, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+        self.gconv_flops = getattr(self, "gconv_flops", 0.0) + 2.0 * n * cin * cout * 4 * H * W
+        self._adopt_stream()
+        b = conv.bias
+        self.ctx._check(self.ctx.lib.vido_deconv2x2_bias_act(self.ctx.h, C.c_void_p(x.contiguous().data_ptr()), C.c_void_p(conv._dc_w.data_ptr()), C.c_void_p(b.data_ptr()) if b is not None else None,
+                                                             C.c_void_p(out.data_ptr()), n, cin, cout, H, W, C.c_float(slope)))
+        return out
+
     def det_order(self, scores, labels, n_det, confidence):
         """(order int64 [cap], labels in that order with 0 for slots that fail `scores > confidence and slot < n_det`, number of live slots) — analyse_image_static's tail
         in one launch (csrc/nets.hip::k_det_order); the order is torch.sort(where(live, scores, -1), descending=True, stable=True)."""
@@ -682,6 +703,14 @@ def pack_conv3x3_h(w):
     planes = torch.stack([h, l], 0).view(torch.int16).reshape(2, cout // 32, 32, cin // 16, 2, 8, 3, 3)        # [plane][mb][co32][chunk][k half][k8][dy][dx]
     planes = planes.permute(1, 3, 6, 7, 0, 4, 2, 5).contiguous().reshape(-1)                                 # [mb][chunk][dy][dx][plane][k half][co32][k8]
     return torch.cat([planes, inv.contiguous().view(torch.int16).reshape(-1)])
+
+
+def pack_deconv2x2(w):
+    """nn.ConvTranspose2d weight [cin, cout, 2, 2] -> the split-fp16 packing of the GEMM matrix [(2 a + b) cout + co][ci] = w[ci][co][a][b] (pack_conv1x1 layout 3): the operand of
+    vido_deconv2x2_bias_act."""
+    cin, cout = int(w.shape[0]), int(w.shape[1])
+    wm = w.detach().permute(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1)
+    return pack_conv1x1(wm, 3)
 
 
 class PackedConv1x1:
