@@ -28,7 +28,8 @@ Extra objects on the same JSON line:
   roofline       dominant hand-written kernel of the tracker front end (FAST): algorithmic bytes / live HIP-event time vs the 8 TB/s HBM peak,
                  measured on BASELINE configs[1] batched (64 frames in flight, the only regime where an HBM roofline of a <1 MB/frame stage means anything)
   roofline_ba    k_ba_linearize at configs[3] (local window) and configs[4] (1 M edges) size: 288 B per edge
-  roofline_nets  fp32 FLOP/s of each network node vs the 157.3 TFLOP/s fp32 matrix/vector peak
+  roofline_nets  fp32-EQUIVALENT FLOP/s of each network node vs the 157.3 TFLOP/s fp32 matrix/vector peak (since round 6 the detector's 1x1 / dense 3x3 / FC / transposed layers compute
+                 their fp32 results on the 16-bit matrix instructions: its fraction can pass 1)
   roofline_gconv the detector's grouped 3x3 convolution kernel (csrc/gconv.hip) vs the same peak
   roofline_conv3x3 the direct split-fp16 3x3 kernel at the FPN / RPN P2 shape (and the Winograd kernel's time beside it)
   roofline_conv1x1 the split 1x1 GEMM at the detector's layer3 shape: fp32-equivalent TFLOP/s against 2500 / 3 (three fp16 products per multiply-add; / 6 for the bf16 form)
@@ -312,7 +313,8 @@ def main():
             ms = timed(fast); fl = flops(eager)
             stage[name + "_ms"] = round(ms, 3)
             roofline_nets[name] = {"bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "gflop_per_frame": round(fl / 1e9, 1), "ms": round(ms, 3), "dtype": "fp32"}
+                                   "frac": round(fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "gflop_per_frame": round(fl / 1e9, 1), "ms": round(ms, 3), "dtype": "fp32",
+                                   "note": "fp32-equivalent FLOPs of the node / its graph's replay time against the fp32 matrix instruction's peak; layers that compute their fp32 results on the 16-bit matrix instructions (config.net_arith) can take the fraction past 1"}
         stage["nets_sum_ms"] = round(sum(stage[k + "_ms"] for k in legs), 3)
         # the largest hand-written network kernel, alone: csrc/wino.hip on the detector's FPN / RPN convolution at P2 (256 -> 256 on 200 x 272), bias + ReLU included.
         # `achieved` counts the multiply-adds the kernel ISSUES to the matrix pipe (Winograd domain: 16 per 2x2 output tile and channel pair instead of 36); `direct_equivalent`
