@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256 * G, (G == 1 && RB != 6) ? 2 : G) void k_conv1x
             for (int pl = 0; pl < NP; pl++) a[buf][rb][pl] = *(const __attribute__((address_space(3))) u32x4*)(Ab + (rb * NP + pl) * 1024);
     };
     auto ldb = [&](int slot) {
-        const volatile __attribute__((address_space(3))) float* Bb = (const volatile __attribute__((address_space(3))) float*)((lds_c)(L + slot * SLOTB) + b_lane);
+        const __attribute__((address_space(3))) float* Bb = (const __attribute__((address_space(3))) float*)((lds_c)(L + slot * SLOTB) + b_lane);      // (not volatile: the compiler pairs the eight reads, 512 bytes apart, into four ds_read2st64_b32)
 #pragma unroll
         for (int i = 0; i < 8; i++) braw[i] = Bb[i * C1_TN];
     };
