@@ -384,12 +384,19 @@ __global__ __launch_bounds__(256 * G, (G == 1 && RB != 6) ? 2 : G) void k_conv1x
             for (int pl = 0; pl < NP; pl++) a[buf][rb][pl] = *(const __attribute__((address_space(3))) u32x4*)(Ab + (rb * NP + pl) * 1024);
     };
     auto ldb = [&](int slot) {
+#ifdef H2_PRESPLIT_EMU
+        if (NP == 2) return;
+#endif
         const __attribute__((address_space(3))) float* Bb = (const __attribute__((address_space(3))) float*)((lds_c)(L + slot * SLOTB) + b_lane);      // (not volatile: the compiler pairs the eight reads, 512 bytes apart, into four ds_read2st64_b32)
 #pragma unroll
         for (int i = 0; i < 8; i++) braw[i] = Bb[i * C1_TN];
     };
     auto split = [&](int buf) {
         if constexpr (NP == 2) {
+#ifdef H2_PRESPLIT_EMU      // (timing experiment: what the k-step would cost if the activations arrived already split — two wide LDS reads, no vector instruction; results are garbage)
+            { lds_c Bq = (lds_c)(L + (buf ? SLOTB : 0)) + 16u * (unsigned)lane; bp[buf][0] = *(const __attribute__((address_space(3))) u32x4*)(Bq + 8192); bp[buf][1] = *(const __attribute__((address_space(3))) u32x4*)(Bq + 9216); }
+            return;
+#endif
 #pragma unroll
             for (int pr = 0; pr < 4; pr++) {
                 const f32x2 v = {braw[2 * pr], braw[2 * pr + 1]};
