@@ -86,6 +86,17 @@ def write_settings(path, K, w, h):
         fh.write("ORBextractor.nFeatures: 2000\nORBextractor.scaleFactor: 1.2\nORBextractor.nLevels: 8\nORBextractor.iniThFAST: 20\nORBextractor.minThFAST: 7\n")
 
 
+def _split_pmc(name):
+    """traffic_bytes_fetch_x2 of a split-fp16 kernel from the newest profiles/rN/split_kernels_pmc.json (None when there is none)"""
+    import glob as _glob, json as _json
+    for f in sorted(_glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "split_kernels_pmc.json")), reverse=True):
+        try:
+            return int(_json.load(open(f))["kernels"][name]["traffic_bytes_fetch_x2"])
+        except Exception:
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -548,7 +559,8 @@ def main():
               tiles3 = (1024 // 128) * ((50 * 68 + 127) // 128); stream = tiles3 * 1024 * (128 * 2 * npl + 128 * 4)
               out["roofline_conv1x1"] = {"kernel": ("k_conv1x1_b3<NP 2> (1x1 convolution + bias + residual + ReLU; two fp16 planes per fp32 operand, three products on v_mfma_f32_32x32x16_f16, fp32 accumulate)" if nprod == 3 else
                                                     "k_conv1x1_b3<NP 3> (1x1 convolution + bias + residual + ReLU; three bf16 planes per fp32 operand, six products on v_mfma_f32_32x32x16_bf16, fp32 accumulate)") if split else "k_conv1x1 (fp32 matrix instruction)",
-                                         "bound": "mfma", "achieved": mainc["fp32_equivalent_tflops"], "peak": round(pk, 1), "unit": "TFLOP/s", "frac": round(mainc["fp32_equivalent_tflops"] / pk, 4), "traffic": None,
+                                         "bound": "mfma", "achieved": mainc["fp32_equivalent_tflops"], "peak": round(pk, 1), "unit": "TFLOP/s", "frac": round(mainc["fp32_equivalent_tflops"] / pk, 4),
+                                         "traffic": _split_pmc("k_conv1x1_b3_1024_to_1024_at_50x68") if nprod == 3 else None, "traffic_source": "profiles/rN/split_kernels_pmc.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes; FETCH x2)",
                                          "tflops_16bit_issued": round(mainc["fp32_equivalent_tflops"] * nprod, 1) if split else None, "shapes": rc,
                                          "operand_stream": {"bytes_l2_to_lds_per_launch": stream, "tb_per_s": round(stream / mainc["us_per_launch"] / 1e6, 2),
                                                             "note": "every 128 x 128 tile streams its own weight planes and activations through LDS: what the launch's time follows (DESIGN.md 4d), not the matrix pipe"} if split else None,
@@ -576,7 +588,8 @@ def main():
                                                                             "workgroups": int(cops3.ctx.lib.vido_conv3x3_h_workgroups(n3, cout, ch, cw))}
               m3 = r3["fpn_rpn_p2_1x256_to_256_at_200x272"]
               out["roofline_conv3x3"] = {"kernel": "k_conv3x3_h (direct 3x3 convolution + bias + ReLU; two fp16 planes per fp32 operand, three products on v_mfma_f32_32x32x16_f16, fp32 accumulate)",
-                                         "bound": "mfma", "achieved": m3["fp32_equivalent_tflops"], "peak": round(2500.0 / 3, 1), "unit": "TFLOP/s", "frac": round(m3["fp32_equivalent_tflops"] / (2500.0 / 3), 4), "traffic": None,
+                                         "bound": "mfma", "achieved": m3["fp32_equivalent_tflops"], "peak": round(2500.0 / 3, 1), "unit": "TFLOP/s", "frac": round(m3["fp32_equivalent_tflops"] / (2500.0 / 3), 4),
+                                         "traffic": _split_pmc("k_conv3x3_h_256_to_256_at_200x272"), "traffic_source": "profiles/rN/split_kernels_pmc.json (FETCH x2 + WRITE; the window gathers are an uncalibrated width: raw FETCH + WRITE = 110.8 MB)",
                                          "shapes": r3, "note": "direct-convolution FLOPs (2 x 9 cin cout N H W) / HIP-event time of 30 back-to-back launches; peak = 2500 TFLOP/s dense fp16 / 3 products"}
           except Exception as e:
               out["roofline_conv3x3_error"] = "%s: %s" % (type(e).__name__, e)
