@@ -13,6 +13,7 @@ _CONV3X3_H_MIN_WGS = 0 if os.environ.get("VIDO_CONV3X3_H") == "0" else int(os.en
 # "novalu" (3.76 ms alone).  Leaving only the two miopenSp3AsmConv layers (stem, 32 -> 32 stride 2) to the library and taking the other stride-2 layers (implicit GEMM
 # in the library) gives 90.0 against 90.4: the direct kernel's matrix-pipe time costs the frame more than the library's kernels there too.  The trade does NOT extend to
 # the dense 3x3 layers: LiteFlowNet on the library's vector-ALU Winograd throughout gives 82 frames/s.
+# Round 6 (detector in split fp16, profiles/r6/convdirect_set_ab.txt): 125.0 frames/s with "novalu" against 124.3 / 124.5 with "all" (the chain without the detector: 191.4 against 193.8).
 _CONVDIRECT_SET = os.environ.get("VIDO_CONVDIRECT_SET", "novalu")
 
 
